@@ -1,0 +1,649 @@
+/*
+ * oracle_sim.c -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+ *
+ * Sequential fp32 restatement of this repo's rigid-body step, one env at a time.
+ * It stands where the reference calls gym.simulate (pacer/env/tasks/base_task.py:792-797, engine
+ * parameters pacer/utils/config.py:143-163 and pacer/data/cfg/pacer.yaml:93-104).
+ *
+ * PARITY UNPINNED against the reference: gym.simulate is Isaac Gym 1.0.preview4 / PhysX 5, closed
+ * source and absent from /root/reference.  What is restated here is our own documented scheme:
+ *
+ *   per substep h:
+ *     1. forward kinematics in world axes about O = root origin (all spatial quantities share O, so
+ *        tree recursions need no frame transforms)
+ *     2. bias forces (gravity + velocity products), Newton-Euler in spatial form
+ *     3. articulated-body factorisation of  M^ = M + diag(armature + h kd + h^2 kp)  (implicit PD)
+ *     4. unconstrained velocity  v_free
+ *     5. ground contacts (spheres, capsule ends, box corners vs the plane), deepest ORC_MAXC kept
+ *     6. contact matrix A = J M^^-1 J^T in Gram form from per-row chain propagation, projected
+ *        Gauss-Seidel with friction-cone projection, warm started per contact candidate
+ *     7. velocity update by a second articulated-body solve, semi-implicit Euler integration
+ *
+ * Spatial vectors are [angular(3); linear(3)]; quaternions xyzw.
+ */
+#include <math.h>
+#include <string.h>
+#include "oracle_sim.h"
+
+#define NB ORC_NB
+#define YLEN 30 /* 6 root + 3 per chain level (depth <= 8) */
+
+typedef struct {
+    /* state */
+    float p0[3], q0[4], V0[6];        /* root pose and spatial velocity [w; v] */
+    float qj[NB][4], wj[NB][3];       /* joint rotation / joint-frame angular velocity (index = child body) */
+    /* kinematics */
+    float pw[NB][3], qw[NB][4], R[NB][9], r[NB][3];
+    float S[NB][3][6];
+    float V[NB][6], Aacc[NB][6];
+    float I6[NB][36], f[NB][6];
+    /* drive */
+    float tau[NB][3], dd[NB][3];
+    unsigned char sat[NB][3];
+    /* factorisation */
+    float W[NB][18];  /* 6x3 row-major */
+    float K[NB][6];   /* k00 k10 k11 k20 k21 k22 */
+    float L0[36];     /* Cholesky factor of the root articulated inertia, lower, row-major */
+    int depth[NB];
+} Env;
+
+/* ---------------------------------------------------------------- small helpers */
+static void cross3(const float *a, const float *b, float *o) {
+    float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static float dot6(const float *a, const float *b) {
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+static void qmul(const float *a, const float *b, float *o) { /* Hamilton product, xyzw */
+    float x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    float y = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    float z = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    float w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+static void qnormalize(float *q) {
+    float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    float s = 1.0f / n;
+    q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
+}
+static void q2mat(const float *q, float *R) { /* row-major */
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1.0f - 2.0f * (y * y + z * z); R[1] = 2.0f * (x * y - z * w); R[2] = 2.0f * (x * z + y * w);
+    R[3] = 2.0f * (x * y + z * w); R[4] = 1.0f - 2.0f * (x * x + z * z); R[5] = 2.0f * (y * z - x * w);
+    R[6] = 2.0f * (x * z - y * w); R[7] = 2.0f * (y * z + x * w); R[8] = 1.0f - 2.0f * (x * x + y * y);
+}
+static void matvec3(const float *R, const float *v, float *o) {
+    float x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+    float y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+    float z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+/* rotation vector -> quaternion */
+static void rotvec2quat(const float *e, float *q) {
+    float th2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+    float th = sqrtf(th2);
+    float k, c;
+    if (th < 1e-4f) { k = 0.5f - th2 * (1.0f / 48.0f); c = 1.0f - th2 * 0.125f; }
+    else { k = sinf(0.5f * th) / th; c = cosf(0.5f * th); }
+    q[0] = e[0] * k; q[1] = e[1] * k; q[2] = e[2] * k; q[3] = c;
+}
+/* quaternion -> rotation vector with angle in [0, pi] */
+static void quat2rotvec(const float *qin, float *e) {
+    float q[4] = {qin[0], qin[1], qin[2], qin[3]};
+    if (q[3] < 0.0f) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    float s = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    float k;
+    if (s < 1e-6f) k = 2.0f;
+    else k = 2.0f * atan2f(s, q[3]) / s;
+    e[0] = q[0] * k; e[1] = q[1] * k; e[2] = q[2] * k;
+}
+
+/* ---------------------------------------------------------------- model access */
+typedef struct {
+    const int32_t *parent, *gtype;
+    const float *off, *mass, *com, *inertia, *ga, *gb, *gr, *kp, *kd, *arm, *eff;
+} EnvModel;
+
+static EnvModel env_model(const OrcModel *m, int e) {
+    EnvModel x;
+    x.parent = m->parent; x.gtype = m->geom_type;
+    x.off = m->joint_off + (long)e * NB * 3; x.mass = m->mass + (long)e * NB;
+    x.com = m->com + (long)e * NB * 3; x.inertia = m->inertia + (long)e * NB * 6;
+    x.ga = m->geom_a + (long)e * NB * 3; x.gb = m->geom_b + (long)e * NB * 3; x.gr = m->geom_r + (long)e * NB;
+    x.kp = m->kp + (long)e * ORC_NDOF; x.kd = m->kd + (long)e * ORC_NDOF;
+    x.arm = m->armature + (long)e * ORC_NDOF; x.eff = m->effort + (long)e * ORC_NDOF;
+    return x;
+}
+
+/* ---------------------------------------------------------------- 1. kinematics */
+static void kinematics(Env *s, const EnvModel *m) {
+    memcpy(s->pw[0], s->p0, 12); memcpy(s->qw[0], s->q0, 16);
+    q2mat(s->qw[0], s->R[0]);
+    s->r[0][0] = s->r[0][1] = s->r[0][2] = 0.0f;
+    s->depth[0] = 0;
+    for (int i = 1; i < NB; ++i) {
+        int p = m->parent[i];
+        float o[3];
+        s->depth[i] = s->depth[p] + 1;
+        matvec3(s->R[p], m->off + i * 3, o);
+        for (int k = 0; k < 3; ++k) { s->pw[i][k] = s->pw[p][k] + o[k]; s->r[i][k] = s->pw[i][k] - s->p0[k]; }
+        qmul(s->qw[p], s->qj[i], s->qw[i]);
+        qnormalize(s->qw[i]);
+        q2mat(s->qw[i], s->R[i]);
+        for (int c = 0; c < 3; ++c) { /* motion subspace: joint axes = child-frame axes in world */
+            float ax[3] = {s->R[i][c], s->R[i][3 + c], s->R[i][6 + c]};
+            memcpy(s->S[i][c], ax, 12);
+            cross3(s->r[i], ax, s->S[i][c] + 3);
+        }
+    }
+}
+
+/* spatial velocities from generalized velocities */
+static void velocities(Env *s, const EnvModel *m, float (*V)[6], const float *V0, float (*wj)[3]) {
+    memcpy(V[0], V0, 24);
+    for (int i = 1; i < NB; ++i) {
+        int p = m->parent[i];
+        for (int k = 0; k < 6; ++k)
+            V[i][k] = V[p][k] + (s->S[i][0][k] * wj[i][0] + s->S[i][1][k] * wj[i][1] + s->S[i][2][k] * wj[i][2]);
+    }
+}
+
+/* rigid-body spatial inertia about O in world axes */
+static void body_inertia(const Env *s, const EnvModel *m, int i, float *I6, float *cw_out) {
+    float Rc[9], Ic[9], cw[3], c[3];
+    const float *in = m->inertia + i * 6;
+    const float Ib[9] = {in[0], in[3], in[4], in[3], in[1], in[5], in[4], in[5], in[2]};
+    const float *R = s->R[i];
+    /* Ic = R Ib R^T */
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) Rc[a * 3 + b] = R[a * 3] * Ib[b] + R[a * 3 + 1] * Ib[3 + b] + R[a * 3 + 2] * Ib[6 + b];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) Ic[a * 3 + b] = Rc[a * 3] * R[b * 3] + Rc[a * 3 + 1] * R[b * 3 + 1] + Rc[a * 3 + 2] * R[b * 3 + 2];
+    matvec3(R, m->com + i * 3, cw);
+    for (int k = 0; k < 3; ++k) c[k] = s->r[i][k] + cw[k];
+    if (cw_out) memcpy(cw_out, c, 12);
+    float ms = m->mass[i], cc = dot3(c, c);
+    memset(I6, 0, 36 * sizeof(float));
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            I6[a * 6 + b] = Ic[a * 3 + b] + ms * ((a == b ? cc : 0.0f) - c[a] * c[b]);
+    /* upper-right = m [c]x ; lower-left = transpose */
+    const float cx[9] = {0.0f, -c[2], c[1], c[2], 0.0f, -c[0], -c[1], c[0], 0.0f};
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) { I6[a * 6 + 3 + b] = ms * cx[a * 3 + b]; I6[(3 + b) * 6 + a] = ms * cx[a * 3 + b]; }
+    for (int a = 0; a < 3; ++a) I6[(3 + a) * 6 + 3 + a] = ms;
+}
+
+static void mat6vec(const float *M, const float *v, float *o) {
+    float t[6];
+    for (int a = 0; a < 6; ++a) t[a] = dot6(M + a * 6, v);
+    memcpy(o, t, 24);
+}
+
+/* ---------------------------------------------------------------- 2. bias forces + drive */
+static void bias_and_drive(Env *s, const EnvModel *m, const OrcSimParams *prm, const float *edof,
+                           const float *tgt) {
+    velocities(s, m, s->V, s->V0, s->wj);
+    memset(s->Aacc[0], 0, 24);
+    for (int i = 1; i < NB; ++i) {
+        int p = m->parent[i];
+        float wv[3], vj[3], t[3], c[6];
+        for (int k = 0; k < 3; ++k)
+            wv[k] = s->S[i][0][k] * s->wj[i][0] + s->S[i][1][k] * s->wj[i][1] + s->S[i][2][k] * s->wj[i][2];
+        cross3(s->V[i], s->r[i], t); /* w_i x r_i */
+        for (int k = 0; k < 3; ++k) vj[k] = s->V[i][3 + k] + t[k];
+        cross3(s->V[p], wv, c);      /* w_p x wv */
+        float t1[3], t2[3];
+        cross3(vj, wv, t1);
+        cross3(s->r[i], c, t2);
+        for (int k = 0; k < 3; ++k) c[3 + k] = t1[k] + t2[k];
+        for (int k = 0; k < 6; ++k) s->Aacc[i][k] = s->Aacc[p][k] + c[k];
+    }
+    for (int i = 0; i < NB; ++i) {
+        float c[3], hI[6], IA[6], x1[3], x2[3];
+        body_inertia(s, m, i, s->I6[i], c);
+        mat6vec(s->I6[i], s->V[i], hI);
+        mat6vec(s->I6[i], s->Aacc[i], IA);
+        /* V x* h = [w x h_ang + v x h_lin ; w x h_lin] */
+        cross3(s->V[i], hI, x1); cross3(s->V[i] + 3, hI + 3, x2);
+        for (int k = 0; k < 3; ++k) s->f[i][k] = IA[k] + x1[k] + x2[k];
+        cross3(s->V[i], hI + 3, x1);
+        for (int k = 0; k < 3; ++k) s->f[i][3 + k] = IA[3 + k] + x1[k];
+        /* gravity as an external force at the com: f -= [c x m g ; m g] */
+        float fg[3] = {0.0f, 0.0f, m->mass[i] * prm->gravity_z}, ng[3];
+        cross3(c, fg, ng);
+        for (int k = 0; k < 3; ++k) { s->f[i][k] -= ng[k]; s->f[i][3 + k] -= fg[k]; }
+    }
+    /* implicit PD: tau~ = kp (q* - q) - (kd + h kp) qd ; diagonal d = armature + h kd + h^2 kp.
+     * A drive whose explicit torque exceeds the effort limit acts as a constant torque instead. */
+    float h = prm->h;
+    for (int i = 1; i < NB; ++i)
+        for (int k = 0; k < 3; ++k) {
+            int d = (i - 1) * 3 + k;
+            float e = tgt[d] - edof[d];
+            float te = m->kp[d] * e - m->kd[d] * s->wj[i][k];
+            if (fabsf(te) > m->eff[d]) {
+                s->sat[i][k] = 1;
+                s->tau[i][k] = te > 0.0f ? m->eff[d] : -m->eff[d];
+                s->dd[i][k] = m->arm[d];
+            } else {
+                s->sat[i][k] = 0;
+                s->tau[i][k] = m->kp[d] * e - (m->kd[d] + h * m->kp[d]) * s->wj[i][k];
+                s->dd[i][k] = m->arm[d] + h * m->kd[d] + h * h * m->kp[d];
+            }
+        }
+}
+
+/* ---------------------------------------------------------------- 3. articulated-body factorisation */
+static void factorize(Env *s, const EnvModel *m) {
+    static float IA[NB][36]; /* not re-entrant: the oracle is single threaded per process call */
+    float (*IAp)[36] = IA;
+    memcpy(IAp, s->I6, sizeof(float) * NB * 36);
+    for (int i = NB - 1; i >= 1; --i) {
+        int p = m->parent[i];
+        float U[18], D[9];
+        for (int c = 0; c < 3; ++c) {
+            float u[6];
+            mat6vec(IAp[i], s->S[i][c], u);
+            for (int a = 0; a < 6; ++a) U[a * 3 + c] = u[a];
+        }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                float acc = 0.0f;
+                for (int k = 0; k < 6; ++k) acc += s->S[i][a][k] * U[k * 3 + b];
+                D[a * 3 + b] = acc + (a == b ? s->dd[i][a] : 0.0f);
+            }
+        float l00 = sqrtf(D[0]), l10 = D[3] / l00, l20 = D[6] / l00;
+        float l11 = sqrtf(D[4] - l10 * l10), l21 = (D[7] - l20 * l10) / l11;
+        float l22 = sqrtf(D[8] - l20 * l20 - l21 * l21);
+        float k00 = 1.0f / l00, k11 = 1.0f / l11, k22 = 1.0f / l22;
+        float k10 = -l10 * k00 * k11, k21 = -l21 * k11 * k22, k20 = -(l20 * k00 + l21 * k10) * k22;
+        float *K = s->K[i];
+        K[0] = k00; K[1] = k10; K[2] = k11; K[3] = k20; K[4] = k21; K[5] = k22;
+        float *W = s->W[i];
+        for (int a = 0; a < 6; ++a) {
+            W[a * 3 + 0] = U[a * 3] * k00;
+            W[a * 3 + 1] = U[a * 3] * k10 + U[a * 3 + 1] * k11;
+            W[a * 3 + 2] = U[a * 3] * k20 + U[a * 3 + 1] * k21 + U[a * 3 + 2] * k22;
+        }
+        for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < 6; ++b)
+                IAp[p][a * 6 + b] += IAp[i][a * 6 + b] -
+                                     (W[a * 3] * W[b * 3] + W[a * 3 + 1] * W[b * 3 + 1] + W[a * 3 + 2] * W[b * 3 + 2]);
+    }
+    /* Cholesky of the 6x6 root articulated inertia */
+    float *L = s->L0;
+    memset(L, 0, 36 * sizeof(float));
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b <= a; ++b) {
+            float acc = IAp[0][a * 6 + b];
+            for (int k = 0; k < b; ++k) acc -= L[a * 6 + k] * L[b * 6 + k];
+            L[a * 6 + b] = (a == b) ? sqrtf(acc) : acc / L[b * 6 + b];
+        }
+}
+
+static void root_fwd(const float *L, const float *b, float *y) { /* L y = b */
+    for (int a = 0; a < 6; ++a) {
+        float acc = b[a];
+        for (int k = 0; k < a; ++k) acc -= L[a * 6 + k] * y[k];
+        y[a] = acc / L[a * 6 + a];
+    }
+}
+static void root_bwd(const float *L, const float *y, float *x) { /* L^T x = y */
+    for (int a = 5; a >= 0; --a) {
+        float acc = y[a];
+        for (int k = a + 1; k < 6; ++k) acc -= L[k * 6 + a] * x[k];
+        x[a] = acc / L[a * 6 + a];
+    }
+}
+
+/* solve  M^ x = tau - J^T(body forces pin)  with the factorisation: returns root accel a0 and joint qdd */
+static void aba_solve(const Env *s, const EnvModel *m, float (*pin)[6], float (*tau)[3], float *a0,
+                      float (*qdd)[3]) {
+    float pA[NB][6], uh[NB][3], a[NB][6];
+    memcpy(pA, pin, sizeof(pA));
+    for (int i = NB - 1; i >= 1; --i) {
+        int p = m->parent[i];
+        float u[3];
+        for (int c = 0; c < 3; ++c) u[c] = (tau ? tau[i][c] : 0.0f) - dot6(s->S[i][c], pA[i]);
+        const float *K = s->K[i];
+        uh[i][0] = K[0] * u[0];
+        uh[i][1] = K[1] * u[0] + K[2] * u[1];
+        uh[i][2] = K[3] * u[0] + K[4] * u[1] + K[5] * u[2];
+        const float *W = s->W[i];
+        for (int k = 0; k < 6; ++k)
+            pA[p][k] += pA[i][k] + (W[k * 3] * uh[i][0] + W[k * 3 + 1] * uh[i][1] + W[k * 3 + 2] * uh[i][2]);
+    }
+    float y[6], nb[6];
+    for (int k = 0; k < 6; ++k) nb[k] = -pA[0][k];
+    root_fwd(s->L0, nb, y);
+    root_bwd(s->L0, y, a0);
+    memcpy(a[0], a0, 24);
+    for (int i = 1; i < NB; ++i) {
+        int p = m->parent[i];
+        const float *W = s->W[i], *K = s->K[i];
+        float t[3];
+        for (int c = 0; c < 3; ++c) {
+            float acc = 0.0f;
+            for (int k = 0; k < 6; ++k) acc += W[k * 3 + c] * a[p][k];
+            t[c] = uh[i][c] - acc;
+        }
+        qdd[i][0] = K[0] * t[0] + K[1] * t[1] + K[3] * t[2];
+        qdd[i][1] = K[2] * t[1] + K[4] * t[2];
+        qdd[i][2] = K[5] * t[2];
+        for (int k = 0; k < 6; ++k)
+            a[i][k] = a[p][k] + (s->S[i][0][k] * qdd[i][0] + s->S[i][1][k] * qdd[i][1] + s->S[i][2][k] * qdd[i][2]);
+    }
+}
+
+/* ---------------------------------------------------------------- 5. contact candidates */
+int orc_sim_num_candidates(const int32_t *gtype) {
+    int n = 0;
+    for (int b = 0; b < NB; ++b) n += gtype[b] == ORC_GEOM_SPHERE ? 1 : (gtype[b] == ORC_GEOM_CAPSULE ? 2 : 8);
+    return n;
+}
+
+/* candidate k of body b in the body frame */
+static void cand_local(const EnvModel *m, int b, int k, float *pt) {
+    const float *a = m->ga + b * 3, *bb = m->gb + b * 3;
+    if (m->gtype[b] == ORC_GEOM_SPHERE) { memcpy(pt, a, 12); }
+    else if (m->gtype[b] == ORC_GEOM_CAPSULE) { memcpy(pt, k == 0 ? a : bb, 12); }
+    else {
+        pt[0] = a[0] + ((k & 1) ? bb[0] : -bb[0]);
+        pt[1] = a[1] + ((k & 2) ? bb[1] : -bb[1]);
+        pt[2] = a[2] + ((k & 4) ? bb[2] : -bb[2]);
+    }
+}
+
+typedef struct { int body, cand; float x[3], dist; } Contact;
+
+static int find_contacts(const Env *s, const EnvModel *m, const OrcSimParams *prm, Contact *out) {
+    Contact all[ORC_MAXCAND];
+    int n = 0, cid = 0;
+    for (int b = 0; b < NB; ++b) {
+        int nk = m->gtype[b] == ORC_GEOM_SPHERE ? 1 : (m->gtype[b] == ORC_GEOM_CAPSULE ? 2 : 8);
+        for (int k = 0; k < nk; ++k, ++cid) {
+            float lp[3], wp[3];
+            cand_local(m, b, k, lp);
+            matvec3(s->R[b], lp, wp);
+            float rad = m->gr[b];
+            float z = s->pw[b][2] + wp[2];
+            float dist = (z - prm->ground_z) - rad;
+            if (dist < prm->contact_offset) {
+                Contact c;
+                c.body = b; c.cand = cid; c.dist = dist;
+                c.x[0] = s->r[b][0] + wp[0]; c.x[1] = s->r[b][1] + wp[1]; c.x[2] = (s->r[b][2] + wp[2]) - rad;
+                all[n++] = c;
+            }
+        }
+    }
+    /* keep the ORC_MAXC deepest (drop the largest dist, ties: highest candidate id), keep candidate order */
+    while (n > ORC_MAXC) {
+        int w = 0;
+        for (int i = 1; i < n; ++i)
+            if (all[i].dist >= all[w].dist) w = i;
+        for (int i = w; i < n - 1; ++i) all[i] = all[i + 1];
+        --n;
+    }
+    memcpy(out, all, sizeof(Contact) * n);
+    return n;
+}
+
+/* ---------------------------------------------------------------- substep */
+static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const float *tgt, float *edof,
+                    float *lam_ws, float *cforce, float *dforce, int last) {
+    const float h = prm->h;
+    float a0[6], qdd[NB][3];
+    kinematics(s, m);
+    bias_and_drive(s, m, prm, edof, tgt);
+    factorize(s, m);
+    aba_solve(s, m, s->f, s->tau, a0, qdd);
+
+    /* 4. unconstrained velocities */
+    float V0f[6], wjf[NB][3], Vf[NB][6];
+    for (int k = 0; k < 6; ++k) V0f[k] = s->V0[k] + h * a0[k];
+    for (int i = 1; i < NB; ++i)
+        for (int k = 0; k < 3; ++k) wjf[i][k] = s->wj[i][k] + h * qdd[i][k];
+    velocities(s, m, Vf, V0f, wjf);
+
+    /* 5./6. contacts */
+    Contact con[ORC_MAXC];
+    int nc = find_contacts(s, m, prm, con);
+    int nr = 3 * nc;
+    float J[3 * ORC_MAXC][6], Y[3 * ORC_MAXC][YLEN], rhs[3 * ORC_MAXC], lam[3 * ORC_MAXC];
+    static const float dirs[3][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}};
+    for (int c = 0; c < nc; ++c) {
+        for (int d = 0; d < 3; ++d) {
+            int r = 3 * c + d;
+            cross3(con[c].x, dirs[d], J[r]);
+            memcpy(J[r] + 3, dirs[d], 12);
+            float vel = dot6(J[r], Vf[con[c].body]);
+            float bias = 0.0f;
+            if (d == 0) {
+                float dist = con[c].dist;
+                if (dist > 0.0f) bias = dist / h;
+                else { bias = prm->erp * dist / h; if (bias < -prm->max_depen_vel) bias = -prm->max_depen_vel; }
+            }
+            rhs[r] = vel + bias;
+            /* chain propagation of a unit impulse along this row */
+            float p[6];
+            for (int k = 0; k < 6; ++k) p[k] = -J[r][k];
+            memset(Y[r], 0, sizeof(float) * YLEN);
+            for (int i = con[c].body; i >= 1; i = m->parent[i]) {
+                float u[3], uh[3];
+                for (int a = 0; a < 3; ++a) u[a] = -dot6(s->S[i][a], p);
+                const float *K = s->K[i], *W = s->W[i];
+                uh[0] = K[0] * u[0]; uh[1] = K[1] * u[0] + K[2] * u[1]; uh[2] = K[3] * u[0] + K[4] * u[1] + K[5] * u[2];
+                int slot = 6 + 3 * (s->depth[i] - 1);
+                Y[r][slot] = uh[0]; Y[r][slot + 1] = uh[1]; Y[r][slot + 2] = uh[2];
+                for (int k = 0; k < 6; ++k) p[k] += W[k * 3] * uh[0] + W[k * 3 + 1] * uh[1] + W[k * 3 + 2] * uh[2];
+            }
+            root_fwd(s->L0, p, Y[r]);
+            /* warm start */
+            lam[r] = prm->warm * lam_ws[con[c].cand * 3 + d];
+        }
+    }
+    /* Gram-form contact matrix: common chain = prefix up to the depth of the lowest common ancestor */
+    static float A[3 * ORC_MAXC][3 * ORC_MAXC];
+    for (int c1 = 0; c1 < nc; ++c1)
+        for (int c2 = 0; c2 < nc; ++c2) {
+            int a = con[c1].body, b = con[c2].body;
+            while (s->depth[a] > s->depth[b]) a = m->parent[a];
+            while (s->depth[b] > s->depth[a]) b = m->parent[b];
+            while (a != b) { a = m->parent[a]; b = m->parent[b]; }
+            int len = 6 + 3 * s->depth[a];
+            for (int d1 = 0; d1 < 3; ++d1)
+                for (int d2 = 0; d2 < 3; ++d2) {
+                    float acc = 0.0f;
+                    for (int k = 0; k < len; ++k) acc += Y[3 * c1 + d1][k] * Y[3 * c2 + d2][k];
+                    A[3 * c1 + d1][3 * c2 + d2] = acc;
+                }
+        }
+    /* projected Gauss-Seidel: per contact normal first (>= 0), then the two tangents, cone projection */
+    for (int it = 0; it < prm->n_iter; ++it)
+        for (int c = 0; c < nc; ++c) {
+            for (int d = 0; d < 3; ++d) {
+                int r = 3 * c + d;
+                float res = rhs[r];
+                for (int q = 0; q < nr; ++q) res += A[r][q] * lam[q];
+                float nl = lam[r] - res / (A[r][r] * (1.0f + prm->cfm));
+                if (d == 0 && nl < 0.0f) nl = 0.0f;
+                lam[r] = nl;
+            }
+            float lim = prm->mu * lam[3 * c];
+            float mag = sqrtf(lam[3 * c + 1] * lam[3 * c + 1] + lam[3 * c + 2] * lam[3 * c + 2]);
+            if (mag > lim) {
+                float sc = mag > 0.0f ? lim / mag : 0.0f;
+                lam[3 * c + 1] *= sc; lam[3 * c + 2] *= sc;
+            }
+        }
+
+    /* 7. velocity update from the contact impulses (second solve), integration */
+    float pin[NB][6], da0[6], dq[NB][3];
+    memset(pin, 0, sizeof(pin));
+    memset(lam_ws, 0, sizeof(float) * 3 * ORC_MAXCAND);
+    if (last) memset(cforce, 0, sizeof(float) * NB * 3);
+    for (int c = 0; c < nc; ++c)
+        for (int d = 0; d < 3; ++d) {
+            int r = 3 * c + d;
+            for (int k = 0; k < 6; ++k) pin[con[c].body][k] -= J[r][k] * lam[r];
+            lam_ws[con[c].cand * 3 + d] = lam[r];
+            if (last)
+                for (int k = 0; k < 3; ++k) cforce[con[c].body * 3 + k] += dirs[d][k] * lam[r] / h;
+        }
+    if (nc > 0) aba_solve(s, m, pin, 0, da0, dq);
+    else { memset(da0, 0, sizeof(da0)); memset(dq, 0, sizeof(dq)); }
+
+    float damp = 1.0f / (1.0f + h * prm->ang_damping);
+    for (int k = 0; k < 6; ++k) s->V0[k] = V0f[k] + da0[k];
+    for (int i = 1; i < NB; ++i)
+        for (int k = 0; k < 3; ++k) {
+            int d = (i - 1) * 3 + k;
+            float wn = wjf[i][k] + dq[i][k];
+            if (last) /* drive torque actually applied over this substep */
+                dforce[d] = s->sat[i][k] ? s->tau[i][k]
+                                         : m->kp[d] * (tgt[d] - edof[d] - h * wn) - m->kd[d] * wn;
+            s->wj[i][k] = wn * damp;
+        }
+    for (int k = 0; k < 3; ++k) s->V0[k] *= damp;
+    /* clamp angular speeds */
+    {
+        float n = sqrtf(dot3(s->V0, s->V0));
+        if (n > prm->max_ang_vel) { float sc = prm->max_ang_vel / n; s->V0[0] *= sc; s->V0[1] *= sc; s->V0[2] *= sc; }
+        for (int i = 1; i < NB; ++i) {
+            float nj = sqrtf(dot3(s->wj[i], s->wj[i]));
+            if (nj > prm->max_ang_vel) { float sc = prm->max_ang_vel / nj; s->wj[i][0] *= sc; s->wj[i][1] *= sc; s->wj[i][2] *= sc; }
+        }
+    }
+    /* semi-implicit Euler: positions with the new velocities */
+    float e[3], dqt[4], qn[4];
+    for (int k = 0; k < 3; ++k) { s->p0[k] += h * s->V0[3 + k]; e[k] = h * s->V0[k]; }
+    rotvec2quat(e, dqt);
+    qmul(dqt, s->q0, qn); qnormalize(qn); memcpy(s->q0, qn, 16);   /* world-frame w: left multiply */
+    for (int i = 1; i < NB; ++i) {
+        for (int k = 0; k < 3; ++k) e[k] = h * s->wj[i][k];
+        rotvec2quat(e, dqt);
+        qmul(s->qj[i], dqt, qn); qnormalize(qn); memcpy(s->qj[i], qn, 16); /* joint-frame w: right multiply */
+        quat2rotvec(s->qj[i], edof + (i - 1) * 3);
+    }
+}
+
+static void load_state(Env *s, const float *root, const float *dof) {
+    memcpy(s->p0, root, 12); memcpy(s->q0, root + 3, 16);
+    qnormalize(s->q0);
+    memcpy(s->V0, root + 10, 12); memcpy(s->V0 + 3, root + 7, 12);
+    for (int i = 1; i < NB; ++i) {
+        float e[3] = {dof[((i - 1) * 3) * 2], dof[((i - 1) * 3 + 1) * 2], dof[((i - 1) * 3 + 2) * 2]};
+        rotvec2quat(e, s->qj[i]);
+        for (int k = 0; k < 3; ++k) s->wj[i][k] = dof[((i - 1) * 3 + k) * 2 + 1];
+    }
+}
+
+static void write_bodies(Env *s, const EnvModel *m, float *rb) {
+    kinematics(s, m);
+    velocities(s, m, s->V, s->V0, s->wj);
+    for (int i = 0; i < NB; ++i) {
+        float *o = rb + i * 13, t[3];
+        memcpy(o, s->pw[i], 12); memcpy(o + 3, s->qw[i], 16);
+        cross3(s->V[i], s->r[i], t); /* classical velocity of the body origin */
+        for (int k = 0; k < 3; ++k) { o[7 + k] = s->V[i][3 + k] + t[k]; o[10 + k] = s->V[i][k]; }
+    }
+}
+
+void orc_sim_fk(int n_env, const OrcModel *mdl, const float *root_state, const float *dof_state, float *rb_state) {
+    static Env s;
+    for (int e = 0; e < n_env; ++e) {
+        EnvModel m = env_model(mdl, e);
+        load_state(&s, root_state + (long)e * 13, dof_state + (long)e * ORC_NDOF * 2);
+        write_bodies(&s, &m, rb_state + (long)e * NB * 13);
+    }
+}
+
+void orc_sim_step(int n_env, const OrcSimParams *prm, const OrcModel *mdl, float *root_state, float *dof_state,
+                  const float *pd_target, float *rb_state, float *contact_force, float *dof_force,
+                  float *lambda_ws) {
+    static Env s;
+    for (int e = 0; e < n_env; ++e) {
+        EnvModel m = env_model(mdl, e);
+        float *root = root_state + (long)e * 13, *dof = dof_state + (long)e * ORC_NDOF * 2;
+        float edof[ORC_NDOF];
+        load_state(&s, root, dof);
+        for (int d = 0; d < ORC_NDOF; ++d) edof[d] = dof[d * 2];
+        for (int i = 1; i < NB; ++i) quat2rotvec(s.qj[i], edof + (i - 1) * 3);
+        for (int k = 0; k < prm->n_sub; ++k)
+            substep(&s, &m, prm, pd_target + (long)e * ORC_NDOF, edof, lambda_ws + (long)e * ORC_MAXCAND * 3,
+                    contact_force + (long)e * NB * 3, dof_force + (long)e * ORC_NDOF, k == prm->n_sub - 1);
+        memcpy(root, s.p0, 12); memcpy(root + 3, s.q0, 16);
+        memcpy(root + 7, s.V0 + 3, 12); memcpy(root + 10, s.V0, 12);
+        for (int i = 1; i < NB; ++i)
+            for (int k = 0; k < 3; ++k) {
+                dof[((i - 1) * 3 + k) * 2] = edof[(i - 1) * 3 + k];
+                dof[((i - 1) * 3 + k) * 2 + 1] = s.wj[i][k];
+            }
+        write_bodies(&s, &m, rb_state + (long)e * NB * 13);
+    }
+}
+
+/* ---------------------------------------------------------------- test hooks */
+void orc_sim_free_accel(const OrcSimParams *prm, const OrcModel *mdl, int env, const float *root_state,
+                        const float *dof_state, const float *pd_target, float *qdd75) {
+    static Env s;
+    EnvModel m = env_model(mdl, env);
+    float edof[ORC_NDOF], a0[6], qdd[NB][3];
+    load_state(&s, root_state + (long)env * 13, dof_state + (long)env * ORC_NDOF * 2);
+    for (int i = 1; i < NB; ++i) quat2rotvec(s.qj[i], edof + (i - 1) * 3);
+    kinematics(&s, &m);
+    bias_and_drive(&s, &m, prm, edof, pd_target + (long)env * ORC_NDOF);
+    factorize(&s, &m);
+    aba_solve(&s, &m, s.f, s.tau, a0, qdd);
+    memcpy(qdd75, a0, 24);
+    for (int i = 1; i < NB; ++i)
+        for (int k = 0; k < 3; ++k) qdd75[6 + (i - 1) * 3 + k] = qdd[i][k];
+}
+
+void orc_sim_dense_dynamics(const OrcSimParams *prm, const OrcModel *mdl, int env, const float *root_state,
+                            const float *dof_state, const float *pd_target, double *M, double *rhs) {
+    static Env s;
+    EnvModel m = env_model(mdl, env);
+    float edof[ORC_NDOF];
+    load_state(&s, root_state + (long)env * 13, dof_state + (long)env * ORC_NDOF * 2);
+    for (int i = 1; i < NB; ++i) quat2rotvec(s.qj[i], edof + (i - 1) * 3);
+    kinematics(&s, &m);
+    bias_and_drive(&s, &m, prm, edof, pd_target + (long)env * ORC_NDOF);
+    const int N = 75;
+    memset(M, 0, sizeof(double) * N * N);
+    memset(rhs, 0, sizeof(double) * N);
+    for (int i = 0; i < NB; ++i) {
+        /* body Jacobian (6 x 75): identity for the root dofs, S_j for every joint j on the chain of i */
+        static double Jb[6][75];
+        memset(Jb, 0, sizeof(Jb));
+        for (int k = 0; k < 6; ++k) Jb[k][k] = 1.0;
+        for (int j = i; j >= 1; j = m.parent[j])
+            for (int c = 0; c < 3; ++c)
+                for (int k = 0; k < 6; ++k) Jb[k][6 + (j - 1) * 3 + c] = s.S[j][c][k];
+        for (int a = 0; a < N; ++a) {
+            double IJ[6];
+            for (int k = 0; k < 6; ++k) {
+                double acc = 0.0;
+                for (int l = 0; l < 6; ++l) acc += (double)s.I6[i][k * 6 + l] * Jb[l][a];
+                IJ[k] = acc;
+            }
+            for (int b = 0; b < N; ++b) {
+                double acc = 0.0;
+                for (int k = 0; k < 6; ++k) acc += Jb[k][b] * IJ[k];
+                M[b * N + a] += acc;
+            }
+            double acc = 0.0;
+            for (int k = 0; k < 6; ++k) acc += Jb[k][a] * (double)s.f[i][k];
+            rhs[a] -= acc;
+        }
+    }
+    for (int i = 1; i < NB; ++i)
+        for (int k = 0; k < 3; ++k) {
+            int a = 6 + (i - 1) * 3 + k;
+            M[a * N + a] += s.dd[i][k];
+            rhs[a] += s.tau[i][k];
+        }
+}
