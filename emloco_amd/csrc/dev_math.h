@@ -1,0 +1,171 @@
+// dev_math.h -- device-side vector / quaternion helpers shared by the gfx950 kernels.
+// Quaternions are xyzw.  Two groups:
+//   (1) plain geometry used by the rigid-body step (Hamilton product, rotation matrix, rotation vector);
+//   (2) the reference task code's helpers restated term by term so fp32 observations track it:
+//       /root/reference/pacer/pacer/utils/torch_utils.py (my_quat_rotate :14-24, quat_to_tan_norm :66-79,
+//       exp_map_to_quat :88-111, calc_heading* :137-175) and
+//       /root/reference/isaacgym/python/isaacgym/torch_utils.py (quat_mul :19-41, quat_apply :49-56,
+//       quat_from_angle_axis :96-101).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace emloco {
+
+__device__ __forceinline__ void cross3(const float *a, const float *b, float *o) {
+    float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+__device__ __forceinline__ float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ float dot6(const float *a, const float *b) {
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+__device__ __forceinline__ void qmul(const float *a, const float *b, float *o) {
+    float x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    float y = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    float z = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    float w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+__device__ __forceinline__ void qnormalize(float *q) {
+    float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    float s = 1.0f / n;
+    q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
+}
+__device__ __forceinline__ void q2mat(const float *q, float *R) {
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1.0f - 2.0f * (y * y + z * z); R[1] = 2.0f * (x * y - z * w); R[2] = 2.0f * (x * z + y * w);
+    R[3] = 2.0f * (x * y + z * w); R[4] = 1.0f - 2.0f * (x * x + z * z); R[5] = 2.0f * (y * z - x * w);
+    R[6] = 2.0f * (x * z - y * w); R[7] = 2.0f * (y * z + x * w); R[8] = 1.0f - 2.0f * (x * x + y * y);
+}
+__device__ __forceinline__ void matvec3(const float *R, const float *v, float *o) {
+    float x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+    float y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+    float z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+// Deterministic sin/cos/atan from +,-,*,/ and sqrt only (correctly rounded in IEEE fp32): with
+// -ffp-contract=off the rigid-body step reproduces the CPU oracle bit for bit.
+__device__ __forceinline__ void det_sincos(float x, float *sn, float *cs) {
+    const float inv_pi = 0.318309886f, pi_hi = 3.140625f, pi_lo = 9.67653589793e-4f;
+    const float kf = floorf(x * inv_pi + 0.5f);
+    const float y = (x - kf * pi_hi) - kf * pi_lo;
+    const float y2 = y * y;
+    const float ps = 1.0f + y2 * (-1.0f / 6.0f + y2 * (1.0f / 120.0f + y2 * (-1.0f / 5040.0f + y2 * (1.0f / 362880.0f +
+                     y2 * (-1.0f / 39916800.0f + y2 * (1.0f / 6227020800.0f))))));
+    const float pc = 1.0f + y2 * (-0.5f + y2 * (1.0f / 24.0f + y2 * (-1.0f / 720.0f + y2 * (1.0f / 40320.0f +
+                     y2 * (-1.0f / 3628800.0f + y2 * (1.0f / 479001600.0f + y2 * (-1.0f / 87178291200.0f)))))));
+    const float sgn = (((long)kf) & 1) ? -1.0f : 1.0f;
+    *sn = sgn * (y * ps);
+    *cs = sgn * pc;
+}
+__device__ __forceinline__ float det_atan01(float t) {
+    const float u = t / (1.0f + sqrtf(1.0f + t * t));
+    const float u2 = u * u;
+    const float p = 1.0f + u2 * (-1.0f / 3.0f + u2 * (1.0f / 5.0f + u2 * (-1.0f / 7.0f + u2 * (1.0f / 9.0f + u2 * (-1.0f / 11.0f +
+                    u2 * (1.0f / 13.0f + u2 * (-1.0f / 15.0f + u2 * (1.0f / 17.0f))))))));
+    return 2.0f * (u * p);
+}
+__device__ __forceinline__ float det_atan2_pos(float s, float w) {
+    if (s <= w) return w > 0.0f ? det_atan01(s / w) : 0.0f;
+    return 1.57079637f - det_atan01(w / s);
+}
+__device__ __forceinline__ void rotvec2quat(const float *e, float *q) {
+    float th2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+    float th = sqrtf(th2);
+    float k, c;
+    if (th < 1e-4f) { k = 0.5f - th2 * (1.0f / 48.0f); c = 1.0f - th2 * 0.125f; }
+    else { float sn; det_sincos(0.5f * th, &sn, &c); k = sn / th; }
+    q[0] = e[0] * k; q[1] = e[1] * k; q[2] = e[2] * k; q[3] = c;
+}
+__device__ __forceinline__ void quat2rotvec(const float *qin, float *e) {
+    float q[4] = {qin[0], qin[1], qin[2], qin[3]};
+    if (q[3] < 0.0f) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    float s = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    float k;
+    if (s < 1e-6f) k = 2.0f;
+    else k = 2.0f * det_atan2_pos(s, q[3]) / s;
+    e[0] = q[0] * k; e[1] = q[1] * k; e[2] = q[2] * k;
+}
+
+// ---- reference task-code helpers (group 2) -------------------------------------------------
+__device__ __forceinline__ void ref_quat_rotate(const float *q, const float *v, float *o) {
+    float w = q[3];
+    float s = 2.0f * (w * w) - 1.0f;
+    float cx = q[1] * v[2] - q[2] * v[1];
+    float cy = q[2] * v[0] - q[0] * v[2];
+    float cz = q[0] * v[1] - q[1] * v[0];
+    float d = q[0] * v[0] + q[1] * v[1] + q[2] * v[2];
+    o[0] = (v[0] * s + cx * w * 2.0f) + q[0] * d * 2.0f;
+    o[1] = (v[1] * s + cy * w * 2.0f) + q[1] * d * 2.0f;
+    o[2] = (v[2] * s + cz * w * 2.0f) + q[2] * d * 2.0f;
+}
+__device__ __forceinline__ void ref_quat_mul(const float *a, const float *b, float *o) {
+    float x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3];
+    float x2 = b[0], y2 = b[1], z2 = b[2], w2 = b[3];
+    float ww = (z1 + x1) * (x2 + y2);
+    float yy = (w1 - y1) * (w2 + z2);
+    float zz = (w1 + y1) * (w2 - z2);
+    float xx = ww + yy + zz;
+    float qq = 0.5f * (xx + (z1 - x1) * (x2 - y2));
+    o[3] = qq - ww + (z1 - y1) * (y2 - z2);
+    o[0] = qq - xx + (x1 + w1) * (x2 + w2);
+    o[1] = qq - yy + (w1 - x1) * (y2 + z2);
+    o[2] = qq - zz + (z1 + y1) * (w2 - x2);
+}
+__device__ __forceinline__ void ref_quat_apply(const float *a, const float *b, float *o) {
+    float tx = (a[1] * b[2] - a[2] * b[1]) * 2.0f;
+    float ty = (a[2] * b[0] - a[0] * b[2]) * 2.0f;
+    float tz = (a[0] * b[1] - a[1] * b[0]) * 2.0f;
+    float ux = a[1] * tz - a[2] * ty;
+    float uy = a[2] * tx - a[0] * tz;
+    float uz = a[0] * ty - a[1] * tx;
+    o[0] = (b[0] + a[3] * tx) + ux;
+    o[1] = (b[1] + a[3] * ty) + uy;
+    o[2] = (b[2] + a[3] * tz) + uz;
+}
+// quat_from_angle_axis about +z: normalize(axis) = z, then the quaternion is re-normalised
+__device__ __forceinline__ void ref_quat_about_z(float angle, float *o) {
+    float th = angle / 2.0f;
+    float s = sinf(th), c = cosf(th);
+    float n = sqrtf(s * s + c * c);
+    if (n < 1e-9f) n = 1e-9f;
+    o[0] = 0.0f / n; o[1] = 0.0f / n; o[2] = s / n; o[3] = c / n;
+}
+__device__ __forceinline__ float ref_calc_heading(const float *q) {
+    const float ex[3] = {1.0f, 0.0f, 0.0f};
+    float r[3];
+    ref_quat_rotate(q, ex, r);
+    return atan2f(r[1], r[0]);
+}
+__device__ __forceinline__ void ref_quat_to_tan_norm(const float *q, float *o6) {
+    const float ex[3] = {1.0f, 0.0f, 0.0f}, ez[3] = {0.0f, 0.0f, 1.0f};
+    ref_quat_rotate(q, ex, o6);
+    ref_quat_rotate(q, ez, o6 + 3);
+}
+__device__ __forceinline__ void ref_exp_map_to_quat(const float *e, float *o) {
+    float angle = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    float ax[3] = {e[0] / angle, e[1] / angle, e[2] / angle};
+    angle = atan2f(sinf(angle), cosf(angle));
+    if (!(fabsf(angle) > 1e-5f)) { angle = 0.0f; ax[0] = 0.0f; ax[1] = 0.0f; ax[2] = 1.0f; }
+    float n = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    if (n < 1e-9f) n = 1e-9f;
+    float th = angle / 2.0f;
+    float s = sinf(th);
+    float q[4] = {ax[0] / n * s, ax[1] / n * s, ax[2] / n * s, cosf(th)};
+    float qn = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (qn < 1e-9f) qn = 1e-9f;
+    o[0] = q[0] / qn; o[1] = q[1] / qn; o[2] = q[2] / qn; o[3] = q[3] / qn;
+}
+
+// wave-wide sum by xor butterfly: every lane gets the same value, fixed association order
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __shfl_xor(v, 32);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+}  // namespace emloco

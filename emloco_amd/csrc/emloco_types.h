@@ -1,0 +1,19 @@
+// emloco_types.h -- device-side argument structs shared by the kernels and the C-ABI layer.
+#pragma once
+#include "../../include/emloco_sim.h"
+
+// Device pointers handed to the rollout kernels by value (kernarg segment).
+struct EmlocoSimDev {
+    int n_env, n_cand, max_depth, pad_;
+    // topology (shared by all envs)
+    const int *parent, *depth, *children /* [24][3], descending, -1 padded */, *geom_type;
+    const int *cand_body, *cand_k;            /* [n_cand] */
+    const unsigned char *lca_depth;           /* [24][24] depth of the lowest common ancestor */
+    // per-env model, layout [field][env][body|dof] so one wave reads contiguous segments
+    const float *joint_off, *mass, *com, *inertia, *geom_a, *geom_b, *geom_r;
+    const float *kp, *kd, *armature, *effort;
+    // state
+    float *root_state, *dof_state;
+    const float *pd_target;
+    float *rb_state, *contact_force, *dof_force, *lambda_ws;
+};

@@ -1,0 +1,297 @@
+// sim_capi.hip -- C ABI (include/emloco_sim.h) over the rollout kernels: owns device state, uploads
+// the per-env models, launches the fused step.  Host code is C++; nothing here touches torch.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "sim_kernels.hip"
+#include "topology.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof(buf), "%s", what);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                            \
+    do {                                                                        \
+        hipError_t e_ = (expr);                                                 \
+        if (e_ != hipSuccess) return fail(EMLOCO_E_HIP, #expr, e_);             \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    hipError_t alloc(size_t count) { n = count; return hipMalloc((void **)&p, count * sizeof(T)); }
+    hipError_t upload(const T *src, size_t count) {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+__global__ void copy_rows_kernel(const float *src, float *dst, const int *ids, int n_ids, int row_len) {
+    const int i = blockIdx.x;
+    if (i >= n_ids) return;
+    const long base = (long)ids[i] * row_len;
+    for (int k = threadIdx.x; k < row_len; k += blockDim.x) dst[base + k] = src[base + k];
+}
+
+__global__ void fill_quat_kernel(float *root, int n_env) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_env) root[(long)e * 13 + 6] = 1.0f;
+}
+
+}  // namespace
+
+struct EmlocoSim {
+    int device = 0;
+    EmlocoSimParams prm{};
+    bool have_model = false, prepared = false, timing = false;
+    int n_env = 0;
+    emloco::Topology topo;
+    // host copies of the model until prepare()
+    std::vector<float> h_off, h_mass, h_com, h_inertia, h_ga, h_gb, h_gr, h_kp, h_kd, h_arm, h_eff;
+    // device
+    DevBuf<int> d_parent, d_depth, d_children, d_gtype, d_cand_body, d_cand_k;
+    DevBuf<unsigned char> d_lca;
+    DevBuf<float> d_off, d_mass, d_com, d_inertia, d_ga, d_gb, d_gr, d_kp, d_kd, d_arm, d_eff;
+    DevBuf<float> d_root, d_dof, d_tgt, d_rb, d_cf, d_df, d_lws;
+    EmlocoSimDev dev{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_pending = false;
+    float last_ms = -1.0f;
+};
+
+extern "C" {
+
+const char *emloco_last_error(void) { return g_err.c_str(); }
+
+int emloco_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int emloco_sim_create(const EmlocoSimParams *params, int device, EmlocoSim **out) {
+    if (!params || !out) return fail(EMLOCO_E_ARG, "emloco_sim_create: null argument");
+    if (params->n_sub < 1 || params->h <= 0.0f || params->n_iter < 0)
+        return fail(EMLOCO_E_ARG, "emloco_sim_create: n_sub >= 1, h > 0, n_iter >= 0 required");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(EMLOCO_E_NODEV, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(EMLOCO_E_ARG, "emloco_sim_create: device index out of range");
+    HIPCHK(hipSetDevice(device));
+    EmlocoSim *s = new EmlocoSim();
+    s->device = device;
+    s->prm = *params;
+    *out = s;
+    return EMLOCO_OK;
+}
+
+int emloco_sim_destroy(EmlocoSim *s) {
+    if (!s) return EMLOCO_OK;
+    (void)hipSetDevice(s->device);
+    s->d_parent.release(); s->d_depth.release(); s->d_children.release(); s->d_gtype.release();
+    s->d_cand_body.release(); s->d_cand_k.release(); s->d_lca.release();
+    s->d_off.release(); s->d_mass.release(); s->d_com.release(); s->d_inertia.release();
+    s->d_ga.release(); s->d_gb.release(); s->d_gr.release();
+    s->d_kp.release(); s->d_kd.release(); s->d_arm.release(); s->d_eff.release();
+    s->d_root.release(); s->d_dof.release(); s->d_tgt.release(); s->d_rb.release();
+    s->d_cf.release(); s->d_df.release(); s->d_lws.release();
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+    return EMLOCO_OK;
+}
+
+int emloco_sim_set_models(EmlocoSim *s, const EmlocoModelDesc *m) {
+    if (!s || !m) return fail(EMLOCO_E_ARG, "emloco_sim_set_models: null argument");
+    if (s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_set_models: sim already prepared");
+    if (m->n_env < 1) return fail(EMLOCO_E_ARG, "emloco_sim_set_models: n_env < 1");
+    if (!s->topo.build(m->parent, m->geom_type))
+        return fail(EMLOCO_E_ARG, "emloco_sim_set_models: body tree must be depth-first, depth <= 8, <= 3 children, <= 96 contact candidates");
+    const size_t E = (size_t)m->n_env, NBs = EMLOCO_NB, ND = EMLOCO_NDOF;
+    s->n_env = m->n_env;
+    s->h_off.assign(m->joint_off, m->joint_off + E * NBs * 3);
+    s->h_mass.assign(m->mass, m->mass + E * NBs);
+    s->h_com.assign(m->com, m->com + E * NBs * 3);
+    s->h_inertia.assign(m->inertia, m->inertia + E * NBs * 6);
+    s->h_ga.assign(m->geom_a, m->geom_a + E * NBs * 3);
+    s->h_gb.assign(m->geom_b, m->geom_b + E * NBs * 3);
+    s->h_gr.assign(m->geom_r, m->geom_r + E * NBs);
+    s->h_kp.assign(m->kp, m->kp + E * ND);
+    s->h_kd.assign(m->kd, m->kd + E * ND);
+    s->h_arm.assign(m->armature, m->armature + E * ND);
+    s->h_eff.assign(m->effort, m->effort + E * ND);
+    for (size_t i = 0; i < E * NBs; ++i)
+        if (!(s->h_mass[i] > 0.0f)) return fail(EMLOCO_E_ARG, "emloco_sim_set_models: body masses must be positive");
+    s->have_model = true;
+    return EMLOCO_OK;
+}
+
+int emloco_sim_prepare(EmlocoSim *s) {
+    if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_prepare: null sim");
+    if (!s->have_model) return fail(EMLOCO_E_STATE, "emloco_sim_prepare: no models set");
+    if (s->prepared) return EMLOCO_OK;
+    HIPCHK(hipSetDevice(s->device));
+    const emloco::Topology &t = s->topo;
+    HIPCHK(s->d_parent.upload(t.parent.data(), t.parent.size()));
+    HIPCHK(s->d_depth.upload(t.depth.data(), t.depth.size()));
+    HIPCHK(s->d_children.upload(t.children.data(), t.children.size()));
+    HIPCHK(s->d_gtype.upload(t.geom_type.data(), t.geom_type.size()));
+    HIPCHK(s->d_cand_body.upload(t.cand_body.data(), t.cand_body.size()));
+    HIPCHK(s->d_cand_k.upload(t.cand_k.data(), t.cand_k.size()));
+    HIPCHK(s->d_lca.upload(t.lca_depth.data(), t.lca_depth.size()));
+    HIPCHK(s->d_off.upload(s->h_off.data(), s->h_off.size()));
+    HIPCHK(s->d_mass.upload(s->h_mass.data(), s->h_mass.size()));
+    HIPCHK(s->d_com.upload(s->h_com.data(), s->h_com.size()));
+    HIPCHK(s->d_inertia.upload(s->h_inertia.data(), s->h_inertia.size()));
+    HIPCHK(s->d_ga.upload(s->h_ga.data(), s->h_ga.size()));
+    HIPCHK(s->d_gb.upload(s->h_gb.data(), s->h_gb.size()));
+    HIPCHK(s->d_gr.upload(s->h_gr.data(), s->h_gr.size()));
+    HIPCHK(s->d_kp.upload(s->h_kp.data(), s->h_kp.size()));
+    HIPCHK(s->d_kd.upload(s->h_kd.data(), s->h_kd.size()));
+    HIPCHK(s->d_arm.upload(s->h_arm.data(), s->h_arm.size()));
+    HIPCHK(s->d_eff.upload(s->h_eff.data(), s->h_eff.size()));
+    const size_t E = (size_t)s->n_env;
+    HIPCHK(s->d_root.alloc(E * 13)); HIPCHK(hipMemset(s->d_root.p, 0, E * 13 * 4));
+    HIPCHK(s->d_dof.alloc(E * EMLOCO_NDOF * 2)); HIPCHK(hipMemset(s->d_dof.p, 0, E * EMLOCO_NDOF * 2 * 4));
+    HIPCHK(s->d_tgt.alloc(E * EMLOCO_NDOF)); HIPCHK(hipMemset(s->d_tgt.p, 0, E * EMLOCO_NDOF * 4));
+    HIPCHK(s->d_rb.alloc(E * EMLOCO_NB * 13)); HIPCHK(hipMemset(s->d_rb.p, 0, E * EMLOCO_NB * 13 * 4));
+    HIPCHK(s->d_cf.alloc(E * EMLOCO_NB * 3)); HIPCHK(hipMemset(s->d_cf.p, 0, E * EMLOCO_NB * 3 * 4));
+    HIPCHK(s->d_df.alloc(E * EMLOCO_NDOF)); HIPCHK(hipMemset(s->d_df.p, 0, E * EMLOCO_NDOF * 4));
+    HIPCHK(s->d_lws.alloc(E * EMLOCO_MAXCAND * 3)); HIPCHK(hipMemset(s->d_lws.p, 0, E * EMLOCO_MAXCAND * 3 * 4));
+    hipLaunchKernelGGL(fill_quat_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, 0, s->d_root.p, s->n_env);
+    HIPCHK(hipGetLastError());
+    EmlocoSimDev &d = s->dev;
+    d.n_env = s->n_env; d.n_cand = t.n_cand; d.max_depth = t.max_depth; d.pad_ = 0;
+    d.parent = s->d_parent.p; d.depth = s->d_depth.p; d.children = s->d_children.p; d.geom_type = s->d_gtype.p;
+    d.cand_body = s->d_cand_body.p; d.cand_k = s->d_cand_k.p; d.lca_depth = s->d_lca.p;
+    d.joint_off = s->d_off.p; d.mass = s->d_mass.p; d.com = s->d_com.p; d.inertia = s->d_inertia.p;
+    d.geom_a = s->d_ga.p; d.geom_b = s->d_gb.p; d.geom_r = s->d_gr.p;
+    d.kp = s->d_kp.p; d.kd = s->d_kd.p; d.armature = s->d_arm.p; d.effort = s->d_eff.p;
+    d.root_state = s->d_root.p; d.dof_state = s->d_dof.p; d.pd_target = s->d_tgt.p;
+    d.rb_state = s->d_rb.p; d.contact_force = s->d_cf.p; d.dof_force = s->d_df.p; d.lambda_ws = s->d_lws.p;
+    HIPCHK(hipEventCreate(&s->ev0));
+    HIPCHK(hipEventCreate(&s->ev1));
+    HIPCHK(hipDeviceSynchronize());
+    s->prepared = true;
+    return EMLOCO_OK;
+}
+
+int emloco_sim_get_params(EmlocoSim *s, EmlocoSimParams *out) {
+    if (!s || !out) return fail(EMLOCO_E_ARG, "emloco_sim_get_params: null argument");
+    *out = s->prm;
+    return EMLOCO_OK;
+}
+
+int emloco_sim_set_params(EmlocoSim *s, const EmlocoSimParams *in) {
+    if (!s || !in) return fail(EMLOCO_E_ARG, "emloco_sim_set_params: null argument");
+    if (in->n_sub < 1 || in->h <= 0.0f || in->n_iter < 0) return fail(EMLOCO_E_ARG, "emloco_sim_set_params: invalid parameters");
+    s->prm = *in;
+    return EMLOCO_OK;
+}
+
+int emloco_sim_tensor(EmlocoSim *s, int kind, void **dev_ptr, int64_t shape[2]) {
+    if (!s || !dev_ptr || !shape) return fail(EMLOCO_E_ARG, "emloco_sim_tensor: null argument");
+    if (!s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_tensor: call emloco_sim_prepare first");
+    const int64_t E = s->n_env;
+    switch (kind) {
+        case EMLOCO_T_ROOT_STATE: *dev_ptr = s->d_root.p; shape[0] = E; shape[1] = 13; break;
+        case EMLOCO_T_DOF_STATE: *dev_ptr = s->d_dof.p; shape[0] = E * EMLOCO_NDOF; shape[1] = 2; break;
+        case EMLOCO_T_RIGID_BODY: *dev_ptr = s->d_rb.p; shape[0] = E * EMLOCO_NB; shape[1] = 13; break;
+        case EMLOCO_T_CONTACT_FORCE: *dev_ptr = s->d_cf.p; shape[0] = E * EMLOCO_NB; shape[1] = 3; break;
+        case EMLOCO_T_DOF_FORCE: *dev_ptr = s->d_df.p; shape[0] = E * EMLOCO_NDOF; shape[1] = 1; break;
+        case EMLOCO_T_PD_TARGET: *dev_ptr = s->d_tgt.p; shape[0] = E; shape[1] = EMLOCO_NDOF; break;
+        default: return fail(EMLOCO_E_ARG, "emloco_sim_tensor: unknown tensor kind");
+    }
+    return EMLOCO_OK;
+}
+
+int emloco_sim_set_pd_targets(EmlocoSim *s, const float *dev_targets, void *stream) {
+    if (!s || !dev_targets) return fail(EMLOCO_E_ARG, "emloco_sim_set_pd_targets: null argument");
+    if (!s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_set_pd_targets: sim not prepared");
+    if (dev_targets != s->d_tgt.p)
+        HIPCHK(hipMemcpyAsync(s->d_tgt.p, dev_targets, (size_t)s->n_env * EMLOCO_NDOF * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return EMLOCO_OK;
+}
+
+int emloco_sim_step(EmlocoSim *s, int n_calls, void *stream) {
+    if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_step: null sim");
+    if (!s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_step: sim not prepared");
+    if (n_calls < 1) return fail(EMLOCO_E_ARG, "emloco_sim_step: n_calls < 1");
+    EmlocoSimParams p = s->prm;
+    p.n_sub = s->prm.n_sub * n_calls;
+    hipStream_t st = (hipStream_t)stream;
+    if (s->timing) HIPCHK(hipEventRecord(s->ev0, st));
+    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)s->n_env), dim3(64), 0, st, p, s->dev);
+    HIPCHK(hipGetLastError());
+    if (s->timing) { HIPCHK(hipEventRecord(s->ev1, st)); s->ev_pending = true; }
+    return EMLOCO_OK;
+}
+
+int emloco_sim_sync(EmlocoSim *s, void *stream) {
+    if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_sync: null sim");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return EMLOCO_OK;
+}
+
+static int set_indexed(EmlocoSim *s, const float *dev_full, float *own, int row_len, const int32_t *ids, int n, void *stream) {
+    if (!s || !dev_full || (!ids && n > 0)) return fail(EMLOCO_E_ARG, "set_*_indexed: null argument");
+    if (!s->prepared) return fail(EMLOCO_E_STATE, "set_*_indexed: sim not prepared");
+    if (n < 0 || n > s->n_env) return fail(EMLOCO_E_ARG, "set_*_indexed: bad count");
+    if (n == 0) return EMLOCO_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dev_full != own) {
+        hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)n), dim3(64), 0, st, dev_full, own, (const int *)ids, n, row_len);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(emloco::sim_fk_kernel, dim3((unsigned)n), dim3(64), 0, st, s->dev, (const int *)ids, n);
+    HIPCHK(hipGetLastError());
+    return EMLOCO_OK;
+}
+
+int emloco_sim_set_root_state_indexed(EmlocoSim *s, const float *dev_full, const int32_t *ids, int n, void *stream) {
+    return set_indexed(s, dev_full, s ? s->d_root.p : nullptr, 13, ids, n, stream);
+}
+
+int emloco_sim_set_dof_state_indexed(EmlocoSim *s, const float *dev_full, const int32_t *ids, int n, void *stream) {
+    return set_indexed(s, dev_full, s ? s->d_dof.p : nullptr, EMLOCO_NDOF * 2, ids, n, stream);
+}
+
+int emloco_sim_refresh_bodies(EmlocoSim *s, void *stream) {
+    if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_refresh_bodies: null sim");
+    if (!s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_refresh_bodies: sim not prepared");
+    hipLaunchKernelGGL(emloco::sim_fk_kernel, dim3((unsigned)s->n_env), dim3(64), 0, (hipStream_t)stream, s->dev, (const int *)nullptr, s->n_env);
+    HIPCHK(hipGetLastError());
+    return EMLOCO_OK;
+}
+
+int emloco_sim_num_candidates(EmlocoSim *s) { return s ? s->topo.n_cand : EMLOCO_E_ARG; }
+
+int emloco_sim_enable_timing(EmlocoSim *s, int on) {
+    if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_enable_timing: null sim");
+    s->timing = on != 0;
+    return EMLOCO_OK;
+}
+
+float emloco_sim_last_step_ms(EmlocoSim *s) {
+    if (!s) return -1.0f;
+    if (s->ev_pending) {
+        if (hipEventSynchronize(s->ev1) == hipSuccess) {
+            float ms = -1.0f;
+            if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_ms = ms;
+        }
+        s->ev_pending = false;
+    }
+    return s->last_ms;
+}
+
+}  // extern "C"

@@ -1,0 +1,672 @@
+// sim_kernels.hip -- rigid-body step of the vectorised humanoid rollout for gfx950 (MI355X).
+//
+// Stands where the reference calls gym.simulate (pacer/pacer/env/tasks/base_task.py:792-797; engine
+// parameters pacer/pacer/utils/config.py:143-163, pacer/pacer/data/cfg/pacer.yaml:93-104).  The reference's
+// engine (PhysX 5) is absent; the scheme is this repo's own:
+// articulated-body dynamics with implicit PD drives + maximal-coordinate ground contacts solved by
+// projected Gauss-Seidel on the Gram-form contact matrix.
+//
+// Mapping: ONE 64-lane wave per env (workgroup = 1 wave, so __syncthreads() is free of cross-wave
+// waits); all `n_sub` substeps of an env.step are fused in one launch and the env's state lives in
+// LDS / registers between them.  Lane roles change per phase:
+//   lane = body      (24 active)  kinematics, inertia, bias forces, articulated-body passes (level-synchronous)
+//   lane = candidate (<=128, 2/lane) ground-contact detection, wave ballot + popcount compaction
+//   lane = contact row (<=60)     chain propagation, contact-matrix column, Gauss-Seidel multiplier
+// Gauss-Seidel row products are reduced with a fixed xor butterfly (wave_sum), which is also the order
+// the CPU oracle uses, so multipliers agree to rounding.
+//
+// HBM traffic per env.step is ~9 KB (state in/out + per-env model), the kernel is latency/occupancy
+// bound, not bandwidth bound.
+#include <hip/hip_runtime.h>
+#include "dev_math.h"
+#include "emloco_types.h"
+
+namespace emloco {
+
+#define NB EMLOCO_NB
+#define NDOF EMLOCO_NDOF
+#define MAXC EMLOCO_MAXC
+#define MAXR (3 * EMLOCO_MAXC)
+#define MAXCAND EMLOCO_MAXCAND
+#define YS 32 /* row stride of Y (30 used) */
+#define AS (MAXR + 1) /* row stride of the contact matrix, odd to spread banks */
+
+// index into a packed symmetric 6x6 (upper triangle, row-major): (a<=b)
+__device__ __forceinline__ constexpr int sidx(int a, int b) {
+    return a <= b ? (a * (13 - a)) / 2 + (b - a) : (b * (13 - b)) / 2 + (a - b);
+}
+
+struct BodyConst {   // per-lane (lane = body) constants, loaded once per launch
+    int parent, depth, nchild, child[3];
+    float off[3], mass, com[3], in6[6];
+};
+
+__global__ void __launch_bounds__(64)
+sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
+    const int env = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (env >= d.n_env) return;
+
+    // ---------------------------------------------------------------- LDS
+    __shared__ float sh_pw[NB][3], sh_qw[NB][4], sh_R[NB][9], sh_r[NB][3];
+    __shared__ float sh_V[NB][6], sh_Aacc[NB][6];
+    __shared__ float sh_Ia[NB][21], sh_pa[NB][6];
+    __shared__ float sh_W[NB][18], sh_K[NB][6], sh_L0[36];
+    __shared__ float sh_a[NB][6], sh_Vf[NB][6];
+    __shared__ float sh_root[13];            // p0[3] q0[4] V0[6]
+    __shared__ int sh_par[NB], sh_dep[NB];
+    __shared__ int sh_cbody[MAXC], sh_ccand[MAXC];
+    __shared__ float sh_cx[MAXC][3], sh_cdist[MAXC];
+    __shared__ float sh_Y[MAXR][YS];
+    __shared__ float sh_A[MAXR][AS];
+    __shared__ float sh_lam[MAXR];
+    __shared__ float sh_lws[MAXCAND * 3];
+    __shared__ unsigned char sh_lca[NB * NB];
+    __shared__ float sh_cf[NB][3];
+
+    // ---------------------------------------------------------------- per-lane constants
+    BodyConst bc;
+    const bool is_body = lane < NB;
+    const int b = is_body ? lane : 0;
+    bc.parent = d.parent[b];
+    bc.depth = d.depth[b];
+    bc.nchild = 0;
+    for (int k = 0; k < 3; ++k) { bc.child[k] = d.children[b * 3 + k]; bc.nchild += bc.child[k] >= 0; }
+    {
+        const long mb = (long)env * NB + b;
+        for (int k = 0; k < 3; ++k) { bc.off[k] = d.joint_off[mb * 3 + k]; bc.com[k] = d.com[mb * 3 + k]; }
+        for (int k = 0; k < 6; ++k) bc.in6[k] = d.inertia[mb * 6 + k];
+        bc.mass = d.mass[mb];
+    }
+    float kp[3] = {0, 0, 0}, kd[3] = {0, 0, 0}, arm[3] = {0, 0, 0}, eff[3] = {0, 0, 0}, tgt[3] = {0, 0, 0};
+    if (is_body && lane >= 1)
+        for (int k = 0; k < 3; ++k) {
+            const long di = (long)env * NDOF + (lane - 1) * 3 + k;
+            kp[k] = d.kp[di]; kd[k] = d.kd[di]; arm[k] = d.armature[di]; eff[k] = d.effort[di]; tgt[k] = d.pd_target[di];
+        }
+    // two contact candidates per lane: `lane` and `lane + 64`
+    int cb[2]; float clp[2][3], crad[2];
+    for (int s = 0; s < 2; ++s) {
+        const int c = lane + 64 * s;
+        cb[s] = -1; crad[s] = 0.0f; clp[s][0] = clp[s][1] = clp[s][2] = 0.0f;
+        if (c < d.n_cand) {
+            const int body = d.cand_body[c], k = d.cand_k[c];
+            const long mb = (long)env * NB + body;
+            const float *ga = d.geom_a + mb * 3, *gb = d.geom_b + mb * 3;
+            const int gt = d.geom_type[body];
+            cb[s] = body; crad[s] = d.geom_r[mb];
+            if (gt == EMLOCO_GEOM_SPHERE) { clp[s][0] = ga[0]; clp[s][1] = ga[1]; clp[s][2] = ga[2]; }
+            else if (gt == EMLOCO_GEOM_CAPSULE) {
+                const float *src = k == 0 ? ga : gb;
+                clp[s][0] = src[0]; clp[s][1] = src[1]; clp[s][2] = src[2];
+            } else {
+                clp[s][0] = ga[0] + ((k & 1) ? gb[0] : -gb[0]);
+                clp[s][1] = ga[1] + ((k & 2) ? gb[1] : -gb[1]);
+                clp[s][2] = ga[2] + ((k & 4) ? gb[2] : -gb[2]);
+            }
+        }
+    }
+    if (is_body) { sh_par[lane] = bc.parent; sh_dep[lane] = bc.depth; }
+    for (int i = lane; i < NB * NB; i += 64) sh_lca[i] = d.lca_depth[i];
+    for (int i = lane; i < MAXCAND * 3; i += 64) sh_lws[i] = d.lambda_ws[(long)env * MAXCAND * 3 + i];
+
+    // ---------------------------------------------------------------- state -> registers
+    float qj[4] = {0, 0, 0, 1}, wj[3] = {0, 0, 0}, edof[3] = {0, 0, 0};
+    if (is_body && lane >= 1) {
+        const float *ds = d.dof_state + ((long)env * NDOF + (lane - 1) * 3) * 2;
+        float e[3] = {ds[0], ds[2], ds[4]};
+        rotvec2quat(e, qj);
+        wj[0] = ds[1]; wj[1] = ds[3]; wj[2] = ds[5];
+        quat2rotvec(qj, edof);
+    }
+    if (lane == 0) {
+        const float *rs = d.root_state + (long)env * 13;
+        float q0[4] = {rs[3], rs[4], rs[5], rs[6]};
+        qnormalize(q0);
+        for (int k = 0; k < 3; ++k) { sh_root[k] = rs[k]; sh_root[7 + k] = rs[10 + k]; sh_root[10 + k] = rs[7 + k]; }
+        for (int k = 0; k < 4; ++k) sh_root[3 + k] = q0[k];
+    }
+    __syncthreads();
+
+    const float h = prm.h;
+    // registers that persist across phases (lane = body)
+    float R[9], r[3], Sl[3][3], V[6];
+    float tau[3], dd[3]; bool sat[3];
+    float uh[3], qdd[3];
+
+    for (int sub = 0; sub <= prm.n_sub; ++sub) {
+        const bool final_pass = (sub == prm.n_sub);   // kinematics only, to write the body states
+        const bool last = (sub == prm.n_sub - 1);
+
+        // ============================================================ 1. kinematics + velocities (root -> leaves)
+        if (lane == 0) {
+            float q0[4] = {sh_root[3], sh_root[4], sh_root[5], sh_root[6]};
+            q2mat(q0, R);
+            for (int k = 0; k < 3; ++k) { sh_pw[0][k] = sh_root[k]; sh_r[0][k] = 0.0f; r[k] = 0.0f; }
+            for (int k = 0; k < 4; ++k) sh_qw[0][k] = q0[k];
+            for (int k = 0; k < 9; ++k) sh_R[0][k] = R[k];
+            for (int k = 0; k < 6; ++k) { V[k] = sh_root[7 + k]; sh_V[0][k] = V[k]; sh_Aacc[0][k] = 0.0f; }
+        }
+        __syncthreads();
+        for (int lev = 1; lev <= d.max_depth; ++lev) {
+            if (is_body && bc.depth == lev) {
+                const int p = bc.parent;
+                float Rp[9], o[3], qp[4], qw[4], pw[3];
+                for (int k = 0; k < 9; ++k) Rp[k] = sh_R[p][k];
+                for (int k = 0; k < 4; ++k) qp[k] = sh_qw[p][k];
+                matvec3(Rp, bc.off, o);
+                for (int k = 0; k < 3; ++k) { pw[k] = sh_pw[p][k] + o[k]; r[k] = pw[k] - sh_root[k]; }
+                qmul(qp, qj, qw);
+                qnormalize(qw);
+                q2mat(qw, R);
+                float wv[3], Vp[6];
+                for (int k = 0; k < 6; ++k) Vp[k] = sh_V[p][k];
+                for (int c = 0; c < 3; ++c) {
+                    float ax[3] = {R[c], R[3 + c], R[6 + c]};
+                    cross3(r, ax, Sl[c]);
+                }
+                for (int k = 0; k < 3; ++k) {
+                    wv[k] = R[k * 3] * wj[0] + R[k * 3 + 1] * wj[1] + R[k * 3 + 2] * wj[2];
+                    V[k] = Vp[k] + wv[k];
+                    V[3 + k] = Vp[3 + k] + (Sl[0][k] * wj[0] + Sl[1][k] * wj[1] + Sl[2][k] * wj[2]);
+                }
+                // velocity-product acceleration c = [w_p x wv ; vj x wv + r x (w_p x wv)]
+                float t[3], vj[3], cc[6], t1[3], t2[3];
+                cross3(V, r, t);
+                for (int k = 0; k < 3; ++k) vj[k] = V[3 + k] + t[k];
+                cross3(Vp, wv, cc);
+                cross3(vj, wv, t1);
+                cross3(r, cc, t2);
+                for (int k = 0; k < 3; ++k) cc[3 + k] = t1[k] + t2[k];
+                for (int k = 0; k < 3; ++k) { sh_pw[lane][k] = pw[k]; sh_r[lane][k] = r[k]; }
+                for (int k = 0; k < 4; ++k) sh_qw[lane][k] = qw[k];
+                for (int k = 0; k < 9; ++k) sh_R[lane][k] = R[k];
+                for (int k = 0; k < 6; ++k) { sh_V[lane][k] = V[k]; sh_Aacc[lane][k] = sh_Aacc[p][k] + cc[k]; }
+            }
+            __syncthreads();
+        }
+        if (final_pass) break;
+
+        // ============================================================ 2. inertia about O, bias force, drive
+        float I6[21], f[6];
+        if (is_body) {
+            float Rc[9], Ic[9], cw[3], c[3];
+            const float Ib[9] = {bc.in6[0], bc.in6[3], bc.in6[4], bc.in6[3], bc.in6[1], bc.in6[5], bc.in6[4], bc.in6[5], bc.in6[2]};
+            for (int a = 0; a < 3; ++a)
+                for (int q = 0; q < 3; ++q) Rc[a * 3 + q] = R[a * 3] * Ib[q] + R[a * 3 + 1] * Ib[3 + q] + R[a * 3 + 2] * Ib[6 + q];
+            for (int a = 0; a < 3; ++a)
+                for (int q = a; q < 3; ++q) {
+                    Ic[a * 3 + q] = Rc[a * 3] * R[q * 3] + Rc[a * 3 + 1] * R[q * 3 + 1] + Rc[a * 3 + 2] * R[q * 3 + 2];
+                    Ic[q * 3 + a] = Ic[a * 3 + q];
+                }
+            matvec3(R, bc.com, cw);
+            for (int k = 0; k < 3; ++k) c[k] = r[k] + cw[k];
+            const float ms = bc.mass, cc = dot3(c, c);
+            for (int a = 0; a < 3; ++a)
+                for (int q = a; q < 3; ++q) I6[sidx(a, q)] = Ic[a * 3 + q] + ms * ((a == q ? cc : 0.0f) - c[a] * c[q]);
+            const float cx[9] = {0.0f, -c[2], c[1], c[2], 0.0f, -c[0], -c[1], c[0], 0.0f};
+            for (int a = 0; a < 3; ++a)
+                for (int q = 0; q < 3; ++q) I6[sidx(a, 3 + q)] = ms * cx[a * 3 + q];
+            for (int a = 0; a < 3; ++a)
+                for (int q = a; q < 3; ++q) I6[sidx(3 + a, 3 + q)] = (a == q) ? ms : 0.0f;
+            float Aa[6], hI[6], IAc[6], x1[3], x2[3];
+            for (int k = 0; k < 6; ++k) Aa[k] = sh_Aacc[lane][k];
+            for (int a = 0; a < 6; ++a) {
+                hI[a] = I6[sidx(a, 0)] * V[0] + I6[sidx(a, 1)] * V[1] + I6[sidx(a, 2)] * V[2] + I6[sidx(a, 3)] * V[3] + I6[sidx(a, 4)] * V[4] + I6[sidx(a, 5)] * V[5];
+                IAc[a] = I6[sidx(a, 0)] * Aa[0] + I6[sidx(a, 1)] * Aa[1] + I6[sidx(a, 2)] * Aa[2] + I6[sidx(a, 3)] * Aa[3] + I6[sidx(a, 4)] * Aa[4] + I6[sidx(a, 5)] * Aa[5];
+            }
+            cross3(V, hI, x1); cross3(V + 3, hI + 3, x2);
+            for (int k = 0; k < 3; ++k) f[k] = IAc[k] + x1[k] + x2[k];
+            cross3(V, hI + 3, x1);
+            for (int k = 0; k < 3; ++k) f[3 + k] = IAc[3 + k] + x1[k];
+            float fg[3] = {0.0f, 0.0f, ms * prm.gravity_z}, ng[3];
+            cross3(c, fg, ng);
+            for (int k = 0; k < 3; ++k) { f[k] -= ng[k]; f[3 + k] -= fg[k]; }
+            // implicit PD drive (saturated drives act as a constant torque)
+            for (int k = 0; k < 3; ++k) {
+                const float e = tgt[k] - edof[k];
+                const float te = kp[k] * e - kd[k] * wj[k];
+                if (fabsf(te) > eff[k]) { sat[k] = true; tau[k] = te > 0.0f ? eff[k] : -eff[k]; dd[k] = arm[k]; }
+                else { sat[k] = false; tau[k] = kp[k] * e - (kd[k] + h * kp[k]) * wj[k]; dd[k] = arm[k] + h * kd[k] + h * h * kp[k]; }
+            }
+        }
+
+        // ============================================================ 3. articulated-body factorisation + up pass (leaves -> root)
+        float IA[21], pA[6], Wm[18], Km[6];
+        for (int lev = d.max_depth; lev >= 0; --lev) {
+            if (is_body && bc.depth == lev) {
+                for (int k = 0; k < 21; ++k) IA[k] = I6[k];
+                for (int k = 0; k < 6; ++k) pA[k] = f[k];
+                for (int ci = 0; ci < 3; ++ci) {     // children in descending body index
+                    const int ch = bc.child[ci];
+                    if (ch >= 0) {
+                        for (int k = 0; k < 21; ++k) IA[k] += sh_Ia[ch][k];
+                        for (int k = 0; k < 6; ++k) pA[k] += sh_pa[ch][k];
+                    }
+                }
+                if (lev > 0) {
+                    float U[18], D[9];
+                    for (int c = 0; c < 3; ++c) {
+                        const float Sc[6] = {R[c], R[3 + c], R[6 + c], Sl[c][0], Sl[c][1], Sl[c][2]};
+                        for (int a = 0; a < 6; ++a)
+                            U[a * 3 + c] = IA[sidx(a, 0)] * Sc[0] + IA[sidx(a, 1)] * Sc[1] + IA[sidx(a, 2)] * Sc[2] + IA[sidx(a, 3)] * Sc[3] + IA[sidx(a, 4)] * Sc[4] + IA[sidx(a, 5)] * Sc[5];
+                    }
+                    for (int a = 0; a < 3; ++a) {
+                        const float Sa[6] = {R[a], R[3 + a], R[6 + a], Sl[a][0], Sl[a][1], Sl[a][2]};
+                        for (int q = 0; q < 3; ++q) {
+                            float acc = 0.0f;
+                            for (int k = 0; k < 6; ++k) acc += Sa[k] * U[k * 3 + q];
+                            D[a * 3 + q] = acc + (a == q ? dd[a] : 0.0f);
+                        }
+                    }
+                    const float l00 = sqrtf(D[0]), l10 = D[3] / l00, l20 = D[6] / l00;
+                    const float l11 = sqrtf(D[4] - l10 * l10), l21 = (D[7] - l20 * l10) / l11;
+                    const float l22 = sqrtf(D[8] - l20 * l20 - l21 * l21);
+                    const float k00 = 1.0f / l00, k11 = 1.0f / l11, k22 = 1.0f / l22;
+                    const float k10 = -l10 * k00 * k11, k21 = -l21 * k11 * k22, k20 = -(l20 * k00 + l21 * k10) * k22;
+                    Km[0] = k00; Km[1] = k10; Km[2] = k11; Km[3] = k20; Km[4] = k21; Km[5] = k22;
+                    for (int a = 0; a < 6; ++a) {
+                        Wm[a * 3 + 0] = U[a * 3] * k00;
+                        Wm[a * 3 + 1] = U[a * 3] * k10 + U[a * 3 + 1] * k11;
+                        Wm[a * 3 + 2] = U[a * 3] * k20 + U[a * 3 + 1] * k21 + U[a * 3 + 2] * k22;
+                    }
+                    float u[3];
+                    for (int c = 0; c < 3; ++c) {
+                        const float Sc[6] = {R[c], R[3 + c], R[6 + c], Sl[c][0], Sl[c][1], Sl[c][2]};
+                        u[c] = tau[c] - dot6(Sc, pA);
+                    }
+                    uh[0] = Km[0] * u[0];
+                    uh[1] = Km[1] * u[0] + Km[2] * u[1];
+                    uh[2] = Km[3] * u[0] + Km[4] * u[1] + Km[5] * u[2];
+                    for (int a = 0; a < 6; ++a)
+                        for (int q = a; q < 6; ++q)
+                            sh_Ia[lane][sidx(a, q)] = IA[sidx(a, q)] - (Wm[a * 3] * Wm[q * 3] + Wm[a * 3 + 1] * Wm[q * 3 + 1] + Wm[a * 3 + 2] * Wm[q * 3 + 2]);
+                    for (int k = 0; k < 6; ++k)
+                        sh_pa[lane][k] = pA[k] + (Wm[k * 3] * uh[0] + Wm[k * 3 + 1] * uh[1] + Wm[k * 3 + 2] * uh[2]);
+                    for (int k = 0; k < 18; ++k) sh_W[lane][k] = Wm[k];
+                    for (int k = 0; k < 6; ++k) sh_K[lane][k] = Km[k];
+                } else {
+                    // root: Cholesky of the 6x6 articulated inertia, a0 = -IA0^-1 pA0
+                    float L[36];
+                    for (int a = 0; a < 6; ++a)
+                        for (int q = 0; q <= a; ++q) {
+                            float acc = IA[sidx(a, q)];
+                            for (int k = 0; k < q; ++k) acc -= L[a * 6 + k] * L[q * 6 + k];
+                            L[a * 6 + q] = (a == q) ? sqrtf(acc) : acc / L[q * 6 + q];
+                        }
+                    float y[6], x[6];
+                    for (int a = 0; a < 6; ++a) {
+                        float acc = -pA[a];
+                        for (int k = 0; k < a; ++k) acc -= L[a * 6 + k] * y[k];
+                        y[a] = acc / L[a * 6 + a];
+                    }
+                    for (int a = 5; a >= 0; --a) {
+                        float acc = y[a];
+                        for (int k = a + 1; k < 6; ++k) acc -= L[k * 6 + a] * x[k];
+                        x[a] = acc / L[a * 6 + a];
+                    }
+                    for (int a = 0; a < 6; ++a)
+                        for (int q = 0; q <= a; ++q) sh_L0[a * 6 + q] = L[a * 6 + q];
+                    for (int k = 0; k < 6; ++k) sh_a[0][k] = x[k];
+                }
+            }
+            __syncthreads();
+        }
+
+        // ============================================================ 4. down pass: joint accelerations, v_free
+        for (int lev = 1; lev <= d.max_depth; ++lev) {
+            if (is_body && bc.depth == lev) {
+                float ap[6], t[3], a[6];
+                for (int k = 0; k < 6; ++k) ap[k] = sh_a[bc.parent][k];
+                for (int c = 0; c < 3; ++c) {
+                    float acc = 0.0f;
+                    for (int k = 0; k < 6; ++k) acc += Wm[k * 3 + c] * ap[k];
+                    t[c] = uh[c] - acc;
+                }
+                qdd[0] = Km[0] * t[0] + Km[1] * t[1] + Km[3] * t[2];
+                qdd[1] = Km[2] * t[1] + Km[4] * t[2];
+                qdd[2] = Km[5] * t[2];
+                for (int k = 0; k < 3; ++k) {
+                    a[k] = ap[k] + (R[k * 3] * qdd[0] + R[k * 3 + 1] * qdd[1] + R[k * 3 + 2] * qdd[2]);
+                    a[3 + k] = ap[3 + k] + (Sl[0][k] * qdd[0] + Sl[1][k] * qdd[1] + Sl[2][k] * qdd[2]);
+                }
+                for (int k = 0; k < 6; ++k) sh_a[lane][k] = a[k];
+            }
+            __syncthreads();
+        }
+        float wjf[3] = {0, 0, 0}, V0f[6];
+        if (is_body) {
+            for (int k = 0; k < 6; ++k) sh_Vf[lane][k] = V[k] + h * sh_a[lane][k];
+            if (lane >= 1) for (int k = 0; k < 3; ++k) wjf[k] = wj[k] + h * qdd[k];
+            if (lane == 0) for (int k = 0; k < 6; ++k) V0f[k] = sh_root[7 + k] + h * sh_a[0][k];
+        }
+
+        // ============================================================ 5. ground-contact candidates (lane = candidate)
+        float cdist[2], cxw[2][3]; bool act[2];
+        for (int s = 0; s < 2; ++s) {
+            act[s] = false; cdist[s] = 0.0f;
+            if (cb[s] >= 0) {
+                float Rb[9], wp[3];
+                for (int k = 0; k < 9; ++k) Rb[k] = sh_R[cb[s]][k];
+                matvec3(Rb, clp[s], wp);
+                const float z = sh_pw[cb[s]][2] + wp[2];
+                cdist[s] = (z - prm.ground_z) - crad[s];
+                act[s] = cdist[s] < prm.contact_offset;
+                cxw[s][0] = sh_r[cb[s]][0] + wp[0];
+                cxw[s][1] = sh_r[cb[s]][1] + wp[1];
+                cxw[s][2] = (sh_r[cb[s]][2] + wp[2]) - crad[s];
+            }
+        }
+        unsigned long long m0 = __ballot(act[0]), m1 = __ballot(act[1]);
+        int nc = __popcll(m0) + __popcll(m1);
+        while (nc > MAXC) {   // rare: drop the shallowest candidate (largest dist; ties -> highest candidate id)
+            float best = -3.0e38f; int bid = -1;
+            for (int s = 0; s < 2; ++s)
+                if (act[s] && (cdist[s] > best || (cdist[s] == best && lane + 64 * s > bid))) { best = cdist[s]; bid = lane + 64 * s; }
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bid, off);
+                if (ob > best || (ob == best && oi > bid)) { best = ob; bid = oi; }
+            }
+            if (bid == lane) act[0] = false;
+            if (bid == lane + 64) act[1] = false;
+            m0 = __ballot(act[0]); m1 = __ballot(act[1]);
+            nc = __popcll(m0) + __popcll(m1);
+        }
+        {
+            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            const int i0 = __popcll(m0 & below), i1 = __popcll(m0) + __popcll(m1 & below);
+            for (int s = 0; s < 2; ++s)
+                if (act[s]) {
+                    const int ci = s == 0 ? i0 : i1;
+                    sh_cbody[ci] = cb[s]; sh_ccand[ci] = lane + 64 * s; sh_cdist[ci] = cdist[s];
+                    for (int k = 0; k < 3; ++k) sh_cx[ci][k] = cxw[s][k];
+                }
+        }
+        __syncthreads();
+        const int nr = 3 * nc;
+
+        // ============================================================ 6a. rows: Jacobian, rhs, chain propagation (lane = row)
+        float J[6] = {0, 0, 0, 0, 0, 0}, rhs = 0.0f, lam = 0.0f;
+        const int myc = lane / 3, myd = lane - 3 * myc;
+        int rbody = 0;
+        if (lane < nr) {
+            rbody = sh_cbody[myc];
+            float dir[3] = {myd == 1 ? 1.0f : 0.0f, myd == 2 ? 1.0f : 0.0f, myd == 0 ? 1.0f : 0.0f};
+            float x[3] = {sh_cx[myc][0], sh_cx[myc][1], sh_cx[myc][2]};
+            cross3(x, dir, J);
+            J[3] = dir[0]; J[4] = dir[1]; J[5] = dir[2];
+            float Vb[6];
+            for (int k = 0; k < 6; ++k) Vb[k] = sh_Vf[rbody][k];
+            const float vel = dot6(J, Vb);
+            float bias = 0.0f;
+            if (myd == 0) {
+                const float dist = sh_cdist[myc];
+                if (dist > 0.0f) bias = dist / h;
+                else { bias = prm.erp * dist / h; if (bias < -prm.max_depen_vel) bias = -prm.max_depen_vel; }
+            }
+            rhs = vel + bias;
+            float p[6];
+            for (int k = 0; k < 6; ++k) p[k] = -J[k];
+            for (int k = 0; k < YS; ++k) sh_Y[lane][k] = 0.0f;
+            for (int i = rbody; i >= 1; i = sh_par[i]) {
+                float Ri[9], ri[3], u[3], uhh[3];
+                for (int k = 0; k < 9; ++k) Ri[k] = sh_R[i][k];
+                for (int k = 0; k < 3; ++k) ri[k] = sh_r[i][k];
+                for (int a = 0; a < 3; ++a) {
+                    float ax[3] = {Ri[a], Ri[3 + a], Ri[6 + a]}, sl[3];
+                    cross3(ri, ax, sl);
+                    const float Sa[6] = {ax[0], ax[1], ax[2], sl[0], sl[1], sl[2]};
+                    u[a] = -dot6(Sa, p);
+                }
+                const float *K = sh_K[i], *W = sh_W[i];
+                uhh[0] = K[0] * u[0]; uhh[1] = K[1] * u[0] + K[2] * u[1]; uhh[2] = K[3] * u[0] + K[4] * u[1] + K[5] * u[2];
+                const int slot = 6 + 3 * (sh_dep[i] - 1);
+                sh_Y[lane][slot] = uhh[0]; sh_Y[lane][slot + 1] = uhh[1]; sh_Y[lane][slot + 2] = uhh[2];
+                for (int k = 0; k < 6; ++k) p[k] += W[k * 3] * uhh[0] + W[k * 3 + 1] * uhh[1] + W[k * 3 + 2] * uhh[2];
+            }
+            for (int a = 0; a < 6; ++a) {   // L0 y = p
+                float acc = p[a];
+                for (int k = 0; k < a; ++k) acc -= sh_L0[a * 6 + k] * sh_Y[lane][k];
+                sh_Y[lane][a] = acc / sh_L0[a * 6 + a];
+            }
+            lam = prm.warm * sh_lws[sh_ccand[myc] * 3 + myd];
+        }
+        __syncthreads();
+
+        // ============================================================ 6b. contact-matrix column (lane = column s)
+        if (lane < nr) {
+            float ys[30];
+            for (int k = 0; k < 30; ++k) ys[k] = sh_Y[lane][k];
+            for (int rr = 0; rr < nr; ++rr) {
+                const int len = 6 + 3 * (int)sh_lca[sh_cbody[rr / 3] * NB + rbody];
+                float acc = 0.0f;
+                for (int k = 0; k < 30; ++k)
+                    if (k < len) acc += sh_Y[rr][k] * ys[k];
+                sh_A[rr][lane] = acc;
+            }
+        }
+        __syncthreads();
+
+        // ============================================================ 6c. projected Gauss-Seidel (lane s holds lambda_s)
+        const float adiag = (lane < nr) ? sh_A[lane][lane] * (1.0f + prm.cfm) : 1.0f;
+        for (int it = 0; it < prm.n_iter; ++it)
+            for (int c = 0; c < nc; ++c) {
+                for (int dr = 0; dr < 3; ++dr) {
+                    const int rr = 3 * c + dr;
+                    const float prod = (lane < nr) ? sh_A[rr][lane] * lam : 0.0f;
+                    const float res = __shfl(rhs, rr) + wave_sum(prod);
+                    if (lane == rr) {
+                        float nl = lam - res / adiag;
+                        if (dr == 0 && nl < 0.0f) nl = 0.0f;
+                        lam = nl;
+                    }
+                }
+                const float ln = __shfl(lam, 3 * c), l1 = __shfl(lam, 3 * c + 1), l2 = __shfl(lam, 3 * c + 2);
+                const float lim = prm.mu * ln;
+                const float mag = sqrtf(l1 * l1 + l2 * l2);
+                if (mag > lim && (lane == 3 * c + 1 || lane == 3 * c + 2)) {
+                    const float sc = mag > 0.0f ? lim / mag : 0.0f;
+                    lam *= sc;
+                }
+            }
+        if (lane < MAXR) sh_lam[lane] = (lane < nr) ? lam : 0.0f;
+        for (int i = lane; i < MAXCAND * 3; i += 64) sh_lws[i] = 0.0f;
+        __syncthreads();
+        if (lane < nr) sh_lws[sh_ccand[myc] * 3 + myd] = lam;
+
+        // ============================================================ 7. impulses -> velocity change (second solve)
+        float dq[3] = {0, 0, 0}, da0[6] = {0, 0, 0, 0, 0, 0};
+        if (is_body && last) { sh_cf[lane][0] = 0.0f; sh_cf[lane][1] = 0.0f; sh_cf[lane][2] = 0.0f; }
+        if (nc > 0) {
+            float pin[6] = {0, 0, 0, 0, 0, 0};
+            if (is_body) {
+                float cf[3] = {0, 0, 0};
+                for (int c = 0; c < nc; ++c)
+                    if (sh_cbody[c] == lane)
+                        for (int dr = 0; dr < 3; ++dr) {
+                            const float dir[3] = {dr == 1 ? 1.0f : 0.0f, dr == 2 ? 1.0f : 0.0f, dr == 0 ? 1.0f : 0.0f};
+                            const float x[3] = {sh_cx[c][0], sh_cx[c][1], sh_cx[c][2]};
+                            float Jr[6];
+                            cross3(x, dir, Jr);
+                            Jr[3] = dir[0]; Jr[4] = dir[1]; Jr[5] = dir[2];
+                            const float l = sh_lam[3 * c + dr];
+                            for (int k = 0; k < 6; ++k) pin[k] -= Jr[k] * l;
+                            for (int k = 0; k < 3; ++k) cf[k] += dir[k] * l / h;
+                        }
+                if (last) for (int k = 0; k < 3; ++k) sh_cf[lane][k] = cf[k];
+            }
+            for (int lev = d.max_depth; lev >= 0; --lev) {
+                if (is_body && bc.depth == lev) {
+                    for (int k = 0; k < 6; ++k) pA[k] = pin[k];
+                    for (int ci = 0; ci < 3; ++ci) {
+                        const int ch = bc.child[ci];
+                        if (ch >= 0) for (int k = 0; k < 6; ++k) pA[k] += sh_pa[ch][k];
+                    }
+                    if (lev > 0) {
+                        float u[3];
+                        for (int c = 0; c < 3; ++c) {
+                            const float Sc[6] = {R[c], R[3 + c], R[6 + c], Sl[c][0], Sl[c][1], Sl[c][2]};
+                            u[c] = 0.0f - dot6(Sc, pA);
+                        }
+                        uh[0] = Km[0] * u[0];
+                        uh[1] = Km[1] * u[0] + Km[2] * u[1];
+                        uh[2] = Km[3] * u[0] + Km[4] * u[1] + Km[5] * u[2];
+                        for (int k = 0; k < 6; ++k)
+                            sh_pa[lane][k] = pA[k] + (Wm[k * 3] * uh[0] + Wm[k * 3 + 1] * uh[1] + Wm[k * 3 + 2] * uh[2]);
+                    } else {
+                        float y[6], x[6];
+                        for (int a = 0; a < 6; ++a) {
+                            float acc = -pA[a];
+                            for (int k = 0; k < a; ++k) acc -= sh_L0[a * 6 + k] * y[k];
+                            y[a] = acc / sh_L0[a * 6 + a];
+                        }
+                        for (int a = 5; a >= 0; --a) {
+                            float acc = y[a];
+                            for (int k = a + 1; k < 6; ++k) acc -= sh_L0[k * 6 + a] * x[k];
+                            x[a] = acc / sh_L0[a * 6 + a];
+                        }
+                        for (int k = 0; k < 6; ++k) { sh_a[0][k] = x[k]; da0[k] = x[k]; }
+                    }
+                }
+                __syncthreads();
+            }
+            for (int lev = 1; lev <= d.max_depth; ++lev) {
+                if (is_body && bc.depth == lev) {
+                    float ap[6], t[3], a[6];
+                    for (int k = 0; k < 6; ++k) ap[k] = sh_a[bc.parent][k];
+                    for (int c = 0; c < 3; ++c) {
+                        float acc = 0.0f;
+                        for (int k = 0; k < 6; ++k) acc += Wm[k * 3 + c] * ap[k];
+                        t[c] = uh[c] - acc;
+                    }
+                    dq[0] = Km[0] * t[0] + Km[1] * t[1] + Km[3] * t[2];
+                    dq[1] = Km[2] * t[1] + Km[4] * t[2];
+                    dq[2] = Km[5] * t[2];
+                    for (int k = 0; k < 3; ++k) {
+                        a[k] = ap[k] + (R[k * 3] * dq[0] + R[k * 3 + 1] * dq[1] + R[k * 3 + 2] * dq[2]);
+                        a[3 + k] = ap[3 + k] + (Sl[0][k] * dq[0] + Sl[1][k] * dq[1] + Sl[2][k] * dq[2]);
+                    }
+                    for (int k = 0; k < 6; ++k) sh_a[lane][k] = a[k];
+                }
+                __syncthreads();
+            }
+        }
+
+        // ============================================================ 8. integrate
+        const float damp = 1.0f / (1.0f + h * prm.ang_damping);
+        if (is_body && lane >= 1) {
+            float wn[3];
+            for (int k = 0; k < 3; ++k) {
+                wn[k] = wjf[k] + dq[k];
+                if (last) {
+                    const float tq = sat[k] ? tau[k] : kp[k] * (tgt[k] - edof[k] - h * wn[k]) - kd[k] * wn[k];
+                    d.dof_force[(long)env * NDOF + (lane - 1) * 3 + k] = tq;
+                }
+                wj[k] = wn[k] * damp;
+            }
+            const float nj = sqrtf(dot3(wj, wj));
+            if (nj > prm.max_ang_vel) { const float sc = prm.max_ang_vel / nj; wj[0] *= sc; wj[1] *= sc; wj[2] *= sc; }
+            float e[3] = {h * wj[0], h * wj[1], h * wj[2]}, dqt[4], qn[4];
+            rotvec2quat(e, dqt);
+            qmul(qj, dqt, qn); qnormalize(qn);
+            for (int k = 0; k < 4; ++k) qj[k] = qn[k];
+            quat2rotvec(qj, edof);
+        }
+        if (lane == 0) {
+            float V0[6];
+            for (int k = 0; k < 6; ++k) V0[k] = V0f[k] + da0[k];
+            for (int k = 0; k < 3; ++k) V0[k] *= damp;
+            const float n = sqrtf(dot3(V0, V0));
+            if (n > prm.max_ang_vel) { const float sc = prm.max_ang_vel / n; V0[0] *= sc; V0[1] *= sc; V0[2] *= sc; }
+            float e[3], dqt[4], qn[4], q0[4] = {sh_root[3], sh_root[4], sh_root[5], sh_root[6]};
+            for (int k = 0; k < 3; ++k) { sh_root[k] += h * V0[3 + k]; e[k] = h * V0[k]; }
+            rotvec2quat(e, dqt);
+            qmul(dqt, q0, qn); qnormalize(qn);
+            for (int k = 0; k < 4; ++k) sh_root[3 + k] = qn[k];
+            for (int k = 0; k < 6; ++k) sh_root[7 + k] = V0[k];
+        }
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- write back (state after the final kinematics pass)
+    if (is_body) {
+        float *o = d.rb_state + ((long)env * NB + lane) * 13;
+        float t[3];
+        cross3(V, r, t);
+        for (int k = 0; k < 3; ++k) { o[k] = sh_pw[lane][k]; o[7 + k] = V[3 + k] + t[k]; o[10 + k] = V[k]; }
+        for (int k = 0; k < 4; ++k) o[3 + k] = sh_qw[lane][k];
+        for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = sh_cf[lane][k];
+        if (lane >= 1) {
+            float *ds = d.dof_state + ((long)env * NDOF + (lane - 1) * 3) * 2;
+            for (int k = 0; k < 3; ++k) { ds[2 * k] = edof[k]; ds[2 * k + 1] = wj[k]; }
+        }
+    }
+    if (lane == 0) {
+        float *rs = d.root_state + (long)env * 13;
+        for (int k = 0; k < 3; ++k) { rs[k] = sh_root[k]; rs[7 + k] = sh_root[10 + k]; rs[10 + k] = sh_root[7 + k]; }
+        for (int k = 0; k < 4; ++k) rs[3 + k] = sh_root[3 + k];
+    }
+    for (int i = lane; i < MAXCAND * 3; i += 64) d.lambda_ws[(long)env * MAXCAND * 3 + i] = sh_lws[i];
+}
+
+// Forward kinematics only (used after state writes through the *_indexed setters): fills rb_state of
+// the listed envs from root_state / dof_state.  One wave per env; lanes walk the tree level by level.
+__global__ void __launch_bounds__(64)
+sim_fk_kernel(EmlocoSimDev d, const int *env_ids, int n_ids) {
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= n_ids) return;
+    const int env = env_ids ? env_ids[blockIdx.x] : (int)blockIdx.x;
+    __shared__ float sh_pw[NB][3], sh_qw[NB][4], sh_R[NB][9], sh_V[NB][6];
+    const bool is_body = lane < NB;
+    const int b = is_body ? lane : 0;
+    const int parent = d.parent[b], depth = d.depth[b];
+    float off[3], qj[4] = {0, 0, 0, 1}, wj[3] = {0, 0, 0}, V[6] = {0, 0, 0, 0, 0, 0}, r[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) off[k] = d.joint_off[((long)env * NB + b) * 3 + k];
+    if (is_body && lane >= 1) {
+        const float *ds = d.dof_state + ((long)env * NDOF + (lane - 1) * 3) * 2;
+        float e[3] = {ds[0], ds[2], ds[4]};
+        rotvec2quat(e, qj);
+        wj[0] = ds[1]; wj[1] = ds[3]; wj[2] = ds[5];
+    }
+    const float *rs = d.root_state + (long)env * 13;
+    const float p0[3] = {rs[0], rs[1], rs[2]};
+    if (lane == 0) {
+        float q0[4] = {rs[3], rs[4], rs[5], rs[6]}, R[9];
+        qnormalize(q0);
+        q2mat(q0, R);
+        for (int k = 0; k < 3; ++k) { sh_pw[0][k] = p0[k]; V[k] = rs[10 + k]; V[3 + k] = rs[7 + k]; }
+        for (int k = 0; k < 4; ++k) sh_qw[0][k] = q0[k];
+        for (int k = 0; k < 9; ++k) sh_R[0][k] = R[k];
+        for (int k = 0; k < 6; ++k) sh_V[0][k] = V[k];
+    }
+    __syncthreads();
+    for (int lev = 1; lev <= d.max_depth; ++lev) {
+        if (is_body && depth == lev) {
+            float Rp[9], o[3], qp[4], qw[4], pw[3], R[9];
+            for (int k = 0; k < 9; ++k) Rp[k] = sh_R[parent][k];
+            for (int k = 0; k < 4; ++k) qp[k] = sh_qw[parent][k];
+            matvec3(Rp, off, o);
+            for (int k = 0; k < 3; ++k) { pw[k] = sh_pw[parent][k] + o[k]; r[k] = pw[k] - p0[k]; }
+            qmul(qp, qj, qw); qnormalize(qw); q2mat(qw, R);
+            float Sl[3][3];
+            for (int c = 0; c < 3; ++c) { float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
+            for (int k = 0; k < 3; ++k) {
+                V[k] = sh_V[parent][k] + (R[k * 3] * wj[0] + R[k * 3 + 1] * wj[1] + R[k * 3 + 2] * wj[2]);
+                V[3 + k] = sh_V[parent][3 + k] + (Sl[0][k] * wj[0] + Sl[1][k] * wj[1] + Sl[2][k] * wj[2]);
+            }
+            for (int k = 0; k < 3; ++k) sh_pw[lane][k] = pw[k];
+            for (int k = 0; k < 4; ++k) sh_qw[lane][k] = qw[k];
+            for (int k = 0; k < 9; ++k) sh_R[lane][k] = R[k];
+            for (int k = 0; k < 6; ++k) sh_V[lane][k] = V[k];
+        }
+        __syncthreads();
+    }
+    if (is_body) {
+        float *o = d.rb_state + ((long)env * NB + lane) * 13, t[3];
+        cross3(V, r, t);
+        for (int k = 0; k < 3; ++k) { o[k] = sh_pw[lane][k]; o[7 + k] = V[3 + k] + t[k]; o[10 + k] = V[k]; }
+        for (int k = 0; k < 4; ++k) o[3 + k] = sh_qw[lane][k];
+    }
+}
+
+}  // namespace emloco

@@ -1,0 +1,97 @@
+// task_capi.hip -- C ABI (include/emloco_task.h) over the fused post-physics kernels.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <string>
+#include "task_kernels.hip"
+
+namespace {
+hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+bool g_timing = false, g_pending = false;
+float g_last_ms = -1.0f;
+thread_local std::string g_terr;
+int tfail(int code, const char *what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof(buf), "%s", what);
+    g_terr = buf;
+    fprintf(stderr, "[emloco] %s\n", buf);
+    return code;
+}
+}  // namespace
+
+#define THIPCHK(expr)                                                  \
+    do {                                                               \
+        hipError_t e_ = (expr);                                        \
+        if (e_ != hipSuccess) return tfail(-2, #expr, e_);             \
+    } while (0)
+
+extern "C" {
+
+int emloco_task_enable_timing(int on) {
+    if (on && !g_ev0) {
+        THIPCHK(hipEventCreate(&g_ev0));
+        THIPCHK(hipEventCreate(&g_ev1));
+    }
+    g_timing = on != 0;
+    return 0;
+}
+
+float emloco_task_last_ms(void) {
+    if (g_pending) {
+        if (hipEventSynchronize(g_ev1) == hipSuccess) {
+            float ms = -1.0f;
+            if (hipEventElapsedTime(&ms, g_ev0, g_ev1) == hipSuccess) g_last_ms = ms;
+        }
+        g_pending = false;
+    }
+    return g_last_ms;
+}
+
+int emloco_task_post_physics(const EmlocoTaskBufs *b, int mode, const int32_t *dev_env_ids, int n, void *stream) {
+    if (!b) return tfail(-1, "emloco_task_post_physics: null buffers");
+    if (b->n_env < 1 || b->hf_rows < 2 || b->hf_cols < 2) return tfail(-1, "emloco_task_post_physics: bad sizes");
+    if (!b->rb_state || !b->progress_buf || !b->traj_verts) return tfail(-1, "emloco_task_post_physics: missing tensors");
+    if ((mode & EMLOCO_POST_OBS) && (!b->obs_buf || !b->flip_obs_buf || !b->heightfield || !b->betas || !b->left_to_right))
+        return tfail(-1, "emloco_task_post_physics: observation buffers missing");
+    if ((mode & EMLOCO_POST_REWARD) && (!b->rew_buf || !b->reward_raw || !b->dof_force || !b->dof_state))
+        return tfail(-1, "emloco_task_post_physics: reward buffers missing");
+    if ((mode & EMLOCO_POST_RESET) && (!b->reset_buf || !b->terminate_buf || !b->contact_force || !b->contact_body_mask))
+        return tfail(-1, "emloco_task_post_physics: reset buffers missing");
+    if ((mode & (EMLOCO_POST_AMP_ROW | EMLOCO_POST_AMP_SHIFT)) && (!b->amp_obs_buf || !b->dof_subset || !b->key_bodies || b->n_dof_subset > 64 || b->n_dof_subset % 3))
+        return tfail(-1, "emloco_task_post_physics: AMP buffers missing");
+    const int count = dev_env_ids ? n : b->n_env;
+    if (count < 0 || count > b->n_env) return tfail(-1, "emloco_task_post_physics: bad env count");
+    if (count == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (g_timing) THIPCHK(hipEventRecord(g_ev0, st));
+    hipLaunchKernelGGL(emloco::post_physics_kernel, dim3((unsigned)count), dim3(64), 0, st, *b, mode, dev_env_ids, count);
+    THIPCHK(hipGetLastError());
+    if (g_timing) { THIPCHK(hipEventRecord(g_ev1, st)); g_pending = true; }
+    return 0;
+}
+
+int emloco_task_amp_rows(int n, const float *root_pos, const float *root_rot, const float *root_vel,
+                         const float *root_ang_vel, const float *dof_pos, const float *dof_vel,
+                         const float *key_pos, const float *betas, const int32_t *dof_subset,
+                         int n_dof_subset, float *out, void *stream) {
+    if (n < 0 || !root_pos || !root_rot || !root_vel || !root_ang_vel || !dof_pos || !dof_vel || !key_pos || !betas || !dof_subset || !out)
+        return tfail(-1, "emloco_task_amp_rows: bad argument");
+    if (n_dof_subset > 64 || n_dof_subset % 3) return tfail(-1, "emloco_task_amp_rows: dof subset must be <= 64 and a multiple of 3");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(emloco::amp_rows_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, n, root_pos, root_rot,
+                       root_vel, root_ang_vel, dof_pos, dof_vel, key_pos, betas, dof_subset, n_dof_subset, out);
+    THIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_task_pd_targets(int n_env, const float *actions, const float *offset, const float *scale,
+                           const uint8_t *zero_mask, float *pd_targets, void *stream) {
+    if (n_env < 1 || !actions || !offset || !scale || !zero_mask || !pd_targets) return tfail(-1, "emloco_task_pd_targets: bad argument");
+    const int total = n_env * 69;
+    hipLaunchKernelGGL(emloco::pd_targets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       total, actions, offset, scale, zero_mask, pd_targets);
+    THIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

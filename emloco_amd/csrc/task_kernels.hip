@@ -1,0 +1,286 @@
+// task_kernels.hip -- fused post-physics kernels of the humanoid rollout for gfx950 (MI355X).
+//
+// One wave (64 lanes) per env computes, in one launch, what the reference's post_physics_step does
+// with ~100 small torch kernels (see include/emloco_task.h for the reference lines of each part).
+// The arithmetic of every observation restates the reference's formulas through the ref_* helpers in
+// dev_math.h; integer masks are computed with the same operation order as the CPU oracle so they are
+// bit-exact.  HBM-bound: per env.step it reads ~15 KB (body/dof state, AMP history, trajectory and
+// height-map gathers) and writes ~24 KB (obs, mirrored obs, AMP buffer); all obs stores are coalesced
+// (lane i writes float i of a row segment).
+#include <hip/hip_runtime.h>
+#include "dev_math.h"
+#include "../../include/emloco_task.h"
+
+namespace emloco {
+
+#define TNB 24
+#define TNDOF 69
+
+// np.linspace(lo, hi, n)[i] in fp64, then cast to fp32 (humanoid_pedestrain_terrain.py:650-668)
+__device__ __forceinline__ float linspace_f(double lo, double hi, int n, int i) {
+    if (i == n - 1) return (float)hi;
+    const double step = (hi - lo) / (double)(n - 1);
+    return (float)(lo + (double)i * step);
+}
+
+// traj_generator.py:278-296 calc_pos
+__device__ __forceinline__ void calc_pos(const float *verts, float time, float traj_dur, float *out) {
+    float phase = time / traj_dur;
+    if (phase < 0.0f) phase = 0.0f;
+    if (phase > 1.0f) phase = 1.0f;
+    const float seg_idx = phase * (float)(EMLOCO_TRAJ_VERTS - 1);
+    const long i0 = (long)floorf(seg_idx);
+    const long i1 = (long)ceilf(seg_idx);
+    const float lerp = seg_idx - (float)i0;
+    for (int k = 0; k < 3; ++k) out[k] = (1.0f - lerp) * verts[i0 * 3 + k] + lerp * verts[i1 * 3 + k];
+}
+
+// humanoid_pedestrain_terrain.py:1212-1218,1282-1288
+__device__ __forceinline__ float sample_height(const int16_t *hf, int rows, int cols, float x, float y, float hscale, float vscale) {
+    long px = (long)(x / hscale);
+    long py = (long)(y / hscale);
+    if (px < 0) px = 0;
+    if (px > rows - 2) px = rows - 2;
+    if (py < 0) py = 0;
+    if (py > cols - 2) py = cols - 2;
+    const int16_t h1 = hf[px * cols + py], h2 = hf[(px + 1) * cols + (py + 1)];
+    const int16_t hm = h1 < h2 ? h1 : h2;
+    return (float)hm * vscale;
+}
+
+// one body's share of compute_humanoid_observations_smpl_max (humanoid.py:1625-1687)
+__device__ __forceinline__ void self_obs_body(int b, const float *root_pos, const float *hinv, const float *pos,
+                                              const float *rot, const float *vel, const float *ang, float *obs) {
+    if (b >= 1) {
+        const float dlt[3] = {pos[0] - root_pos[0], pos[1] - root_pos[1], pos[2] - root_pos[2]};
+        ref_quat_rotate(hinv, dlt, obs + (b - 1) * 3);
+    }
+    float lq[4];
+    ref_quat_mul(hinv, rot, lq);
+    ref_quat_to_tan_norm(lq, obs + 69 + b * 6);
+    ref_quat_rotate(hinv, vel, obs + 69 + 144 + b * 3);
+    ref_quat_rotate(hinv, ang, obs + 69 + 144 + 72 + b * 3);
+}
+
+// one AMP row (humanoid_amp.py:917-971); lanes cooperate, `out` points at the row
+__device__ __forceinline__ void amp_row(int lane, const float *root_pos, const float *root_rot, const float *root_vel,
+                                        const float *root_ang, const float *dof_pos, const float *dof_vel,
+                                        int dof_stride /* 2 when both point into dof_state */, const float *key_pos /* [4][3] */,
+                                        const float *betas, const int32_t *subset, int n_sub, float *out) {
+    float hinv[4];
+    ref_quat_about_z(-ref_calc_heading(root_rot), hinv);
+    if (lane == 0) {
+        float lq[4], t6[6], t3[3];
+        ref_quat_mul(hinv, root_rot, lq);
+        ref_quat_to_tan_norm(lq, t6);
+        for (int k = 0; k < 6; ++k) out[k] = t6[k];
+        ref_quat_rotate(hinv, root_vel, t3);
+        for (int k = 0; k < 3; ++k) out[6 + k] = t3[k];
+        ref_quat_rotate(hinv, root_ang, t3);
+        for (int k = 0; k < 3; ++k) out[9 + k] = t3[k];
+    }
+    const int nj = n_sub / 3;
+    if (lane < nj) {
+        float em[3], q[4], t6[6];
+        for (int k = 0; k < 3; ++k) {
+            const int dd = subset[lane * 3 + k];
+            em[k] = dof_pos[dd * dof_stride];
+        }
+        ref_exp_map_to_quat(em, q);
+        ref_quat_to_tan_norm(q, t6);
+        for (int k = 0; k < 6; ++k) out[12 + lane * 6 + k] = t6[k];
+    }
+    if (lane < n_sub) {
+        const int dd = subset[lane];
+        out[12 + nj * 6 + lane] = dof_vel[dd * dof_stride];
+    }
+    if (lane < 4) {
+        float dlt[3], t3[3];
+        for (int k = 0; k < 3; ++k) dlt[k] = key_pos[lane * 3 + k] - root_pos[k];
+        ref_quat_rotate(hinv, dlt, t3);
+        for (int k = 0; k < 3; ++k) out[12 + nj * 6 + n_sub + lane * 3 + k] = t3[k];
+    }
+    if (lane < 11) out[12 + nj * 6 + n_sub + 12 + lane] = betas[lane];
+}
+
+__global__ void __launch_bounds__(64)
+post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_ids) {
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= n_ids) return;
+    const int env = env_ids ? env_ids[blockIdx.x] : (int)blockIdx.x;
+
+    __shared__ float sh_body[TNB][13];
+    __shared__ float sh_samp[EMLOCO_TRAJ_SAMPLES][3];
+    __shared__ float sh_center[9];
+    __shared__ float sh_cf[TNB][3];
+    __shared__ float sh_obs[EMLOCO_SELF_OBS], sh_fobs[EMLOCO_SELF_OBS];
+    __shared__ float sh_key[4][3];
+
+    int64_t prog = t.progress_buf[env];
+    if (mode & EMLOCO_POST_ADVANCE) {
+        prog += 1;
+        if (lane == 0) t.progress_buf[env] = prog;
+    }
+    if (lane < TNB) {
+        const float *src = t.rb_state + ((long)env * TNB + lane) * 13;
+        for (int k = 0; k < 13; ++k) sh_body[lane][k] = src[k];
+        if (mode & EMLOCO_POST_RESET)
+            for (int k = 0; k < 3; ++k) sh_cf[lane][k] = t.contact_force[((long)env * TNB + lane) * 3 + k];
+    }
+    // trajectory samples (lane k < 15): t + k * sample_dt; sample 0 is the reward / reset target
+    if (lane < EMLOCO_TRAJ_SAMPLES) {
+        const float beg = (float)prog * t.dt;
+        float s[3];
+        calc_pos(t.traj_verts + (long)env * EMLOCO_TRAJ_VERTS * 3, beg + (float)lane * t.sample_dt, t.traj_dur, s);
+        for (int k = 0; k < 3; ++k) sh_samp[lane][k] = s[k];
+    }
+    __syncthreads();
+    const float *root = sh_body[0];
+
+    if (mode & EMLOCO_POST_OBS) {
+        float *obs = t.obs_buf + (long)env * EMLOCO_OBS;
+        float *fobs = t.flip_obs_buf + (long)env * EMLOCO_OBS;
+        float hinv[4], hinv_f[4];
+        ref_quat_about_z(-ref_calc_heading(root + 3), hinv);
+        const float froot_rot[4] = {-root[3], root[4], -root[5], root[6]};
+        ref_quat_about_z(-ref_calc_heading(froot_rot), hinv_f);
+        // ---- self obs + mirrored self obs (lane = body); staged in LDS so the row is written coalesced
+        if (lane < TNB) {
+            const float *bd = sh_body[lane];
+            self_obs_body(lane, root, hinv, bd, bd + 3, bd + 7, bd + 10, sh_obs);
+            const float *sb = sh_body[t.left_to_right[lane]];
+            const float fp[3] = {sb[0], -sb[1], sb[2]};
+            const float fr[4] = {-sb[3], sb[4], -sb[5], sb[6]};
+            const float fv[3] = {sb[7], -sb[8], sb[9]};
+            const float fa[3] = {-sb[10], sb[11], -sb[12]};
+            const float froot_pos[3] = {root[0], -root[1], root[2]};
+            self_obs_body(lane, froot_pos, hinv_f, fp, fr, fv, fa, sh_fobs);
+        } else if (lane < TNB + 11) {
+            const float bv = t.betas[(long)env * 17 + (lane - TNB)];
+            sh_obs[357 + lane - TNB] = bv;
+            sh_fobs[357 + lane - TNB] = bv;
+        }
+        // ---- location obs (lane = sample)
+        if (lane < EMLOCO_TRAJ_SAMPLES) {
+            const float dlt[3] = {sh_samp[lane][0] - root[0], sh_samp[lane][1] - root[1], sh_samp[lane][2] - root[2]};
+            float rr[3];
+            ref_quat_rotate(hinv, dlt, rr);
+            obs[EMLOCO_SELF_OBS + 2 * lane] = rr[0];
+            obs[EMLOCO_SELF_OBS + 2 * lane + 1] = rr[1];
+            fobs[EMLOCO_SELF_OBS + 2 * lane] = rr[0];
+            fobs[EMLOCO_SELF_OBS + 2 * lane + 1] = -rr[1];
+        }
+        // ---- centre-height probes (3x3, yaw only) around the root
+        if (lane < 9) {
+            const int i = lane / 3, j = lane - 3 * i;
+            const float pt[3] = {linspace_f(-0.1, 0.1, 3, i), linspace_f(-0.2, 0.2, 3, j), 0.0f};
+            float qy[4] = {0.0f, 0.0f, root[5], root[6]}, rr[3];
+            float nn = sqrtf(qy[2] * qy[2] + qy[3] * qy[3]);
+            if (nn < 1e-9f) nn = 1e-9f;
+            qy[0] = 0.0f / nn; qy[1] = 0.0f / nn; qy[2] = qy[2] / nn; qy[3] = qy[3] / nn;
+            ref_quat_apply(qy, pt, rr);
+            sh_center[lane] = sample_height(t.heightfield, t.hf_rows, t.hf_cols, rr[0] + root[0], rr[1] + root[1], t.hscale, t.vscale);
+        }
+        __syncthreads();
+        for (int i = lane; i < EMLOCO_SELF_OBS; i += 64) { obs[i] = sh_obs[i]; fobs[i] = sh_fobs[i]; }
+        float csum = 0.0f;
+        for (int k = 0; k < 9; ++k) csum += sh_center[k];
+        const float cmean = csum / 9.0f;
+        // ---- 32x32 height grid around the head, rotated by the head's heading (16 points per lane)
+        const float *head = sh_body[t.head_body];
+        float hq[4];
+        ref_quat_about_z(ref_calc_heading(head + 3), hq);
+        float *hobs = obs + EMLOCO_SELF_OBS + 2 * EMLOCO_TRAJ_SAMPLES;
+        float *fhobs = fobs + EMLOCO_SELF_OBS + 2 * EMLOCO_TRAJ_SAMPLES;
+        for (int it = 0; it < EMLOCO_HEIGHT_POINTS / 64; ++it) {
+            const int idx = lane + 64 * it;
+            const int i = idx >> 5, j = idx & 31;
+            const float pt[3] = {linspace_f(-2.0, 2.0, 32, i), linspace_f(-2.0, 2.0, 32, j), 0.0f};
+            float rr[3];
+            ref_quat_apply(hq, pt, rr);
+            const float hh = sample_height(t.heightfield, t.hf_rows, t.hf_cols, rr[0] + head[0], rr[1] + head[1], t.hscale, t.vscale);
+            float v = cmean - hh;
+            if (v < -3.0f) v = -3.0f;
+            if (v > 3.0f) v = 3.0f;
+            v *= 5.0f;
+            hobs[idx] = v;
+            fhobs[i * 32 + (31 - j)] = v;
+        }
+    }
+
+    const float *tar = sh_samp[0];
+    if (mode & EMLOCO_POST_REWARD) {
+        float part = 0.0f;
+        for (int dd = lane; dd < TNDOF; dd += 64)
+            part += fabsf(t.dof_force[(long)env * TNDOF + dd] * t.dof_state[((long)env * TNDOF + dd) * 2 + 1]);
+        const float power = wave_sum(part);
+        if (lane == 0) {
+            const float dx = tar[0] - root[0], dy = tar[1] - root[1];
+            const float err = dx * dx + dy * dy;
+            const float loc = expf(-2.0f * err);
+            const float pw = -t.power_coef * power;
+            t.rew_buf[env] = loc + pw;
+            t.reward_raw[(long)env * 2] = loc;
+            t.reward_raw[(long)env * 2 + 1] = pw;
+        }
+    }
+    if ((mode & EMLOCO_POST_RESET) && lane == 0) {
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (int bb = 0; bb < TNB; ++bb) {
+            const bool masked = t.contact_body_mask[bb] != 0;
+            sx += masked ? 0.0f : sh_cf[bb][0];
+            sy += masked ? 0.0f : sh_cf[bb][1];
+            sz += masked ? 0.0f : sh_cf[bb][2];
+        }
+        const float ax = fabsf(sx), ay = fabsf(sy), az = fabsf(sz);
+        const float mag = sqrtf(ax * ax + ay * ay + az * az);
+        const bool fallen = (mag > 50.0f) && (prog > 1);
+        const float dx = tar[0] - root[0], dy = tar[1] - root[1];
+        const float d2 = dx * dx + dy * dy;
+        const bool far = d2 > t.fail_dist * t.fail_dist;
+        const int64_t term = (fallen || far) ? 1 : 0;
+        t.terminate_buf[env] = term;
+        t.reset_buf[env] = ((float)prog >= t.max_episode_length - 1.0f) ? 1 : term;
+    }
+
+    if (mode & (EMLOCO_POST_AMP_SHIFT | EMLOCO_POST_AMP_ROW)) {
+        float *amp = t.amp_obs_buf + (long)env * EMLOCO_AMP_STEPS * EMLOCO_AMP_ROW;
+        if (mode & EMLOCO_POST_AMP_SHIFT) {
+            // rows 0..13 -> rows 1..14; every lane first loads all of its elements, then stores
+            constexpr int NEL = (EMLOCO_AMP_STEPS - 1) * EMLOCO_AMP_ROW;
+            constexpr int PER = (NEL + 63) / 64;
+            float keep[PER];
+            for (int j = 0; j < PER; ++j) { const int e = lane + 64 * j; keep[j] = e < NEL ? amp[e] : 0.0f; }
+            __syncthreads();
+            for (int j = 0; j < PER; ++j) { const int e = lane + 64 * j; if (e < NEL) amp[EMLOCO_AMP_ROW + e] = keep[j]; }
+        }
+        if (mode & EMLOCO_POST_AMP_ROW) {
+            if (lane < 4) for (int k = 0; k < 3; ++k) sh_key[lane][k] = sh_body[t.key_bodies[lane]][k];
+            __syncthreads();
+            const float *ds = t.dof_state + (long)env * TNDOF * 2;
+            amp_row(lane, root, root + 3, root + 7, root + 10, ds, ds + 1, 2, &sh_key[0][0], t.betas + (long)env * 17, t.dof_subset, t.n_dof_subset, amp);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64)
+amp_rows_kernel(int n, const float *root_pos, const float *root_rot, const float *root_vel, const float *root_ang,
+                const float *dof_pos, const float *dof_vel, const float *key_pos, const float *betas,
+                const int32_t *subset, int n_sub, float *out) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
+    amp_row(lane, root_pos + (long)i * 3, root_rot + (long)i * 4, root_vel + (long)i * 3, root_ang + (long)i * 3,
+            dof_pos + (long)i * TNDOF, dof_vel + (long)i * TNDOF, 1, key_pos + (long)i * 12, betas + (long)i * 17, subset, n_sub,
+            out + (long)i * EMLOCO_AMP_ROW);
+}
+
+// pre_physics_step: pd_tar = offset + scale * a, zero where masked (humanoid.py:1184-1202,1281-1283)
+__global__ void pd_targets_kernel(int total, const float *actions, const float *offset, const float *scale,
+                                  const uint8_t *zero_mask, float *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int dd = i % TNDOF;
+    out[i] = zero_mask[dd] ? 0.0f : offset[dd] + scale[dd] * actions[i];
+}
+
+}  // namespace emloco

@@ -1,0 +1,122 @@
+/*
+ * emloco_sim.h -- C ABI of libemloco_hip.so, part 1: the vectorised humanoid rollout (boundary 1).
+ *
+ * Plain C, plain pointers and sizes, no torch types.  Every entry point returns 0 on success and a
+ * negative EMLOCO_E_* code on failure (the reference's gym API returns bool/None and never throws,
+ * isaacgym/docs/api/python/gym_py.html; the Python shim maps codes back to that convention).
+ * Device pointers belong to the HIP device the sim was created on.  `stream` is a hipStream_t
+ * passed as void* (0 = the default stream); the library never synchronises unless asked to.
+ *
+ * Each entry point names the reference interface it stands behind (file:line under
+ * /root/reference/); the reference-side binding is shown in INTEGRATION.md.
+ */
+#ifndef EMLOCO_SIM_H
+#define EMLOCO_SIM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMLOCO_NB 24        /* rigid bodies per humanoid (humanoid.py:264) */
+#define EMLOCO_NDOF 69      /* 23 joints x 3 (humanoid.py:516-521) */
+#define EMLOCO_MAXC 20      /* contacts kept per env and substep */
+#define EMLOCO_MAXCAND 96   /* contact-candidate slots per env (warm-start storage) */
+
+enum { EMLOCO_GEOM_SPHERE = 0, EMLOCO_GEOM_CAPSULE = 1, EMLOCO_GEOM_BOX = 2 };
+
+enum {
+    EMLOCO_OK = 0,
+    EMLOCO_E_ARG = -1,      /* bad argument */
+    EMLOCO_E_HIP = -2,      /* a HIP runtime call failed (emloco_last_error() has the text) */
+    EMLOCO_E_STATE = -3,    /* call out of order (e.g. step before prepare) */
+    EMLOCO_E_NODEV = -4     /* no usable gfx950 device */
+};
+
+/* gymapi.SimParams subset that reaches the step (pacer/pacer/utils/config.py:141-174,
+ * pacer/pacer/data/cfg/pacer.yaml:93-104). */
+typedef struct {
+    int32_t n_sub;          /* substeps fused per emloco_sim_step call-unit: sim.substeps */
+    int32_t n_iter;         /* physx.num_position_iterations */
+    float h;                /* sim.dt / sim.substeps */
+    float gravity_z;        /* sim.gravity.z */
+    float contact_offset;   /* physx.contact_offset */
+    float erp;              /* penetration fraction corrected per substep */
+    float max_depen_vel;    /* physx.max_depenetration_velocity */
+    float mu;               /* friction: plane/terrain staticFriction (pacer.yaml:70-73,90-92) */
+    float ang_damping;      /* AssetOptions.angular_damping (humanoid.py:685) */
+    float max_ang_vel;      /* AssetOptions.max_angular_velocity (humanoid.py:687) */
+    float ground_z;         /* plane height (gymapi.PlaneParams.distance) */
+    float cfm;              /* relative diagonal regularisation of the contact matrix */
+    float warm;             /* contact warm-start factor */
+} EmlocoSimParams;
+
+/* Host description of the humanoids, one model per env (gym.load_asset + create_actor,
+ * humanoid.py:720,864; per-env shapes: humanoid.py:597-633).  All arrays are host memory, fp32/int32. */
+typedef struct {
+    int32_t n_env;
+    const int32_t *parent;     /* [24] body tree, depth-first order */
+    const int32_t *geom_type;  /* [24] */
+    const float *joint_off;    /* [n_env][24][3] */
+    const float *mass;         /* [n_env][24] */
+    const float *com;          /* [n_env][24][3] */
+    const float *inertia;      /* [n_env][24][6] xx yy zz xy xz yz about com, body frame */
+    const float *geom_a;       /* [n_env][24][3] */
+    const float *geom_b;       /* [n_env][24][3] */
+    const float *geom_r;       /* [n_env][24] */
+    const float *kp, *kd, *armature, *effort; /* [n_env][69] (gym.set_actor_dof_properties, humanoid.py:904-914) */
+} EmlocoModelDesc;
+
+/* state tensors a caller may alias (gym.acquire_*_tensor, humanoid.py:137-148) */
+enum {
+    EMLOCO_T_ROOT_STATE = 0,    /* f32 [n_env][13]      acquire_actor_root_state_tensor */
+    EMLOCO_T_DOF_STATE = 1,     /* f32 [n_env*69][2]    acquire_dof_state_tensor */
+    EMLOCO_T_RIGID_BODY = 2,    /* f32 [n_env*24][13]   acquire_rigid_body_state_tensor */
+    EMLOCO_T_CONTACT_FORCE = 3, /* f32 [n_env*24][3]    acquire_net_contact_force_tensor */
+    EMLOCO_T_DOF_FORCE = 4,     /* f32 [n_env*69]       acquire_dof_force_tensor */
+    EMLOCO_T_PD_TARGET = 5,     /* f32 [n_env][69]      internal copy of the last set_dof_position_target_tensor */
+    EMLOCO_T_COUNT = 6
+};
+
+typedef struct EmlocoSim EmlocoSim;
+
+const char *emloco_last_error(void);
+int emloco_device_count(void);
+
+/* gym.create_sim(compute_device, graphics_device, type, params) -- base_task.py:238 */
+int emloco_sim_create(const EmlocoSimParams *params, int device, EmlocoSim **out);
+/* gym.destroy_sim */
+int emloco_sim_destroy(EmlocoSim *sim);
+/* gym.load_asset + create_env/create_actor + set_actor_dof_properties for all envs -- humanoid.py:720,809,864,914 */
+int emloco_sim_set_models(EmlocoSim *sim, const EmlocoModelDesc *desc);
+/* gym.prepare_sim -- base_task.py:128: allocates the device state, uploads the models */
+int emloco_sim_prepare(EmlocoSim *sim);
+/* gym.get_sim_params / set_sim_params -- base_task.py:151 */
+int emloco_sim_get_params(EmlocoSim *sim, EmlocoSimParams *out);
+int emloco_sim_set_params(EmlocoSim *sim, const EmlocoSimParams *in);
+/* gym.acquire_*_tensor -- humanoid.py:137-148: device pointer + shape of a state tensor the sim owns */
+int emloco_sim_tensor(EmlocoSim *sim, int kind, void **dev_ptr, int64_t shape[2]);
+/* gym.set_dof_position_target_tensor -- humanoid.py:1201-1202 (device pointer, [n_env][69] f32) */
+int emloco_sim_set_pd_targets(EmlocoSim *sim, const float *dev_targets, void *stream);
+/* gym.simulate x n_calls -- base_task.py:792-797 (n_calls = controlFrequencyInv); one fused launch */
+int emloco_sim_step(EmlocoSim *sim, int n_calls, void *stream);
+/* gym.fetch_results(sim, True) -- base_task.py:258: host waits for the stream */
+int emloco_sim_sync(EmlocoSim *sim, void *stream);
+/* gym.set_actor_root_state_tensor_indexed / set_dof_state_tensor_indexed -- humanoid.py:470-475.
+ * `dev_full` is the full tensor (may be the sim's own alias); rows of the listed envs are applied and the
+ * rigid-body state of those envs is recomputed.  `dev_env_ids` int32 device pointer, n entries. */
+int emloco_sim_set_root_state_indexed(EmlocoSim *sim, const float *dev_full, const int32_t *dev_env_ids, int n, void *stream);
+int emloco_sim_set_dof_state_indexed(EmlocoSim *sim, const float *dev_full, const int32_t *dev_env_ids, int n, void *stream);
+/* gym.refresh_rigid_body_state_tensor after host-side state edits: recompute body states of all envs */
+int emloco_sim_refresh_bodies(EmlocoSim *sim, void *stream);
+/* number of ground-contact candidates of the loaded model (68 for the SMPL humanoid) */
+int emloco_sim_num_candidates(EmlocoSim *sim);
+/* wall-clock of the last emloco_sim_step launch measured with HIP events on its stream [ms]; <0 if none */
+float emloco_sim_last_step_ms(EmlocoSim *sim);
+/* enable/disable HIP-event timing of step launches */
+int emloco_sim_enable_timing(EmlocoSim *sim, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

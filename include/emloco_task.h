@@ -1,0 +1,103 @@
+/*
+ * emloco_task.h -- C ABI of libemloco_hip.so, part 2: the fused post-physics task kernels.
+ *
+ * One launch replaces the ~100 small torch kernels of the reference's post_physics_step
+ * (pacer/pacer/env/tasks/humanoid.py:1211-1232, humanoid_amp.py:139-157):
+ *   progress += 1                        humanoid.py:1213
+ *   self observations (368)              humanoid.py:1625-1687 (compute_humanoid_observations_smpl_max)
+ *   mirrored observations                humanoid.py:1066-1108, humanoid_pedestrain_terrain.py:455-491
+ *   trajectory samples + location obs    humanoid_traj.py:208-224, traj_generator.py:278-296,
+ *                                        humanoid_pedestrain_terrain.py:1549-1577
+ *   height-map observations (32x32)      humanoid_pedestrain_terrain.py:394-442,732-815,1212-1288
+ *   reward                               humanoid_pedestrain_terrain.py:907-930,1581-1592
+ *   reset / terminate masks (int64)      humanoid_pedestrain_terrain.py:883-905,1468-1530
+ *   AMP history shift + new AMP row      humanoid_amp.py:585-657,917-971
+ * Buffers are caller-owned device memory (the task object allocates them, base_task.py:96-111).
+ */
+#ifndef EMLOCO_TASK_H
+#define EMLOCO_TASK_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMLOCO_SELF_OBS 368
+#define EMLOCO_TRAJ_SAMPLES 15
+#define EMLOCO_TRAJ_VERTS 101
+#define EMLOCO_HEIGHT_POINTS 1024
+#define EMLOCO_TASK_OBS (2 * EMLOCO_TRAJ_SAMPLES + EMLOCO_HEIGHT_POINTS)
+#define EMLOCO_OBS (EMLOCO_SELF_OBS + EMLOCO_TASK_OBS)
+#define EMLOCO_AMP_ROW 206
+#define EMLOCO_AMP_STEPS 15
+
+/* what one launch computes (bit-or) */
+enum {
+    EMLOCO_POST_ADVANCE = 1,    /* progress_buf += 1 */
+    EMLOCO_POST_OBS = 2,        /* obs_buf and flip_obs_buf */
+    EMLOCO_POST_REWARD = 4,     /* rew_buf, reward_raw */
+    EMLOCO_POST_RESET = 8,      /* reset_buf, terminate_buf */
+    EMLOCO_POST_AMP_SHIFT = 16, /* history shift of amp_obs_buf */
+    EMLOCO_POST_AMP_ROW = 32,   /* newest AMP row */
+    EMLOCO_POST_STEP = 63       /* everything post_physics_step does */
+};
+
+typedef struct {
+    int32_t n_env;
+    int32_t hf_rows, hf_cols;       /* height map shape (first index = x) */
+    int32_t head_body;              /* sensor frame body (terrain_obs_root "head" -> 13) */
+    int32_t n_dof_subset;           /* 57 */
+    float dt;                       /* control dt = controlFrequencyInv * sim.dt */
+    float traj_dur;                 /* num_verts * vertex dt (traj_generator.py:270-273) */
+    float sample_dt;                /* trajSampleTimestep */
+    float hscale, vscale;           /* 0.1, 0.005 */
+    float power_coef;               /* power_coefficient */
+    float fail_dist;                /* 4.0 (humanoid_traj.py:30) */
+    float max_episode_length;       /* episodeLength */
+    /* simulator tensors (device) */
+    const float *rb_state;          /* [E][24][13] */
+    const float *dof_state;         /* [E][69][2] */
+    const float *dof_force;         /* [E][69] */
+    const float *contact_force;     /* [E][24][3] */
+    /* task data (device) */
+    const float *betas;             /* [E][17] humanoid_betas */
+    const float *traj_verts;        /* [E][101][3] */
+    const int16_t *heightfield;     /* [hf_rows][hf_cols] */
+    const int32_t *left_to_right;   /* [24] */
+    const uint8_t *contact_body_mask; /* [24] 1 = foot body excluded from the fall test */
+    const int32_t *key_bodies;      /* [4] */
+    const int32_t *dof_subset;      /* [n_dof_subset] */
+    /* task buffers (device, in/out) */
+    int64_t *progress_buf;          /* [E] */
+    int64_t *reset_buf;             /* [E] */
+    int64_t *terminate_buf;         /* [E] */
+    float *obs_buf;                 /* [E][1422] */
+    float *flip_obs_buf;            /* [E][1422] */
+    float *rew_buf;                 /* [E] */
+    float *reward_raw;              /* [E][2] */
+    float *amp_obs_buf;             /* [E][15][206], index 0 = newest */
+} EmlocoTaskBufs;
+
+/* post_physics_step for all envs (dev_env_ids == NULL) or for the listed envs
+ * (_compute_observations(env_ids) on reset, humanoid.py:459-465). */
+int emloco_task_post_physics(const EmlocoTaskBufs *bufs, int mode, const int32_t *dev_env_ids, int n, void *stream);
+
+/* AMP rows from explicit states (history back-fill from the motion library, humanoid_amp.py:486-535):
+ * n rows; inputs [n][3|4|3|3|69|69|4*3|17]; out [n][206]. */
+int emloco_task_amp_rows(int n, const float *root_pos, const float *root_rot, const float *root_vel,
+                         const float *root_ang_vel, const float *dof_pos, const float *dof_vel,
+                         const float *key_pos, const float *betas, const int32_t *dof_subset,
+                         int n_dof_subset, float *out, void *stream);
+
+/* pre_physics_step: pd_tar = offset + scale * action, zeroed where mask != 0 (humanoid.py:1184-1202,1281-1283) */
+int emloco_task_pd_targets(int n_env, const float *actions, const float *offset, const float *scale,
+                           const uint8_t *zero_mask, float *pd_targets, void *stream);
+
+/* wall-clock of the last emloco_task_post_physics launch measured with HIP events [ms]; <0 if none */
+float emloco_task_last_ms(void);
+int emloco_task_enable_timing(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -80,13 +80,43 @@ static void matvec3(const float *R, const float *v, float *o) {
     float z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
     o[0] = x; o[1] = y; o[2] = z;
 }
+/* Deterministic sin/cos/atan built from +,-,*,/ and sqrt only (all correctly rounded in IEEE fp32), so the
+ * GPU kernel, which uses the same operation sequence, reproduces the oracle bit for bit.  libm / ocml
+ * transcendentals differ in the last ulp, and a falling humanoid amplifies that chaotically. */
+static void det_sincos(float x, float *sn, float *cs) {
+    /* reduce to [-pi/2, pi/2]: x = k*pi + y */
+    const float inv_pi = 0.318309886f, pi_hi = 3.140625f, pi_lo = 9.67653589793e-4f;
+    float kf = floorf(x * inv_pi + 0.5f);
+    float y = (x - kf * pi_hi) - kf * pi_lo;
+    float y2 = y * y;
+    float ps = 1.0f + y2 * (-1.0f / 6.0f + y2 * (1.0f / 120.0f + y2 * (-1.0f / 5040.0f + y2 * (1.0f / 362880.0f +
+               y2 * (-1.0f / 39916800.0f + y2 * (1.0f / 6227020800.0f))))));
+    float pc = 1.0f + y2 * (-0.5f + y2 * (1.0f / 24.0f + y2 * (-1.0f / 720.0f + y2 * (1.0f / 40320.0f +
+               y2 * (-1.0f / 3628800.0f + y2 * (1.0f / 479001600.0f + y2 * (-1.0f / 87178291200.0f)))))));
+    float sgn = (((long)kf) & 1) ? -1.0f : 1.0f;
+    *sn = sgn * (y * ps);
+    *cs = sgn * pc;
+}
+/* atan(t) for t in [0, 1] */
+static float det_atan01(float t) {
+    float u = t / (1.0f + sqrtf(1.0f + t * t)); /* half-angle: atan(t) = 2 atan(u), u <= 0.4143 */
+    float u2 = u * u;
+    float p = 1.0f + u2 * (-1.0f / 3.0f + u2 * (1.0f / 5.0f + u2 * (-1.0f / 7.0f + u2 * (1.0f / 9.0f + u2 * (-1.0f / 11.0f +
+              u2 * (1.0f / 13.0f + u2 * (-1.0f / 15.0f + u2 * (1.0f / 17.0f))))))));
+    return 2.0f * (u * p);
+}
+/* atan2(s, w) for s >= 0, w >= 0 */
+static float det_atan2_pos(float s, float w) {
+    if (s <= w) return w > 0.0f ? det_atan01(s / w) : 0.0f;
+    return 1.57079637f - det_atan01(w / s);
+}
 /* rotation vector -> quaternion */
 static void rotvec2quat(const float *e, float *q) {
     float th2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
     float th = sqrtf(th2);
     float k, c;
     if (th < 1e-4f) { k = 0.5f - th2 * (1.0f / 48.0f); c = 1.0f - th2 * 0.125f; }
-    else { k = sinf(0.5f * th) / th; c = cosf(0.5f * th); }
+    else { float sn; det_sincos(0.5f * th, &sn, &c); k = sn / th; }
     q[0] = e[0] * k; q[1] = e[1] * k; q[2] = e[2] * k; q[3] = c;
 }
 /* quaternion -> rotation vector with angle in [0, pi] */
@@ -96,7 +126,7 @@ static void quat2rotvec(const float *qin, float *e) {
     float s = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
     float k;
     if (s < 1e-6f) k = 2.0f;
-    else k = 2.0f * atan2f(s, q[3]) / s;
+    else k = 2.0f * det_atan2_pos(s, q[3]) / s;
     e[0] = q[0] * k; e[1] = q[1] * k; e[2] = q[2] * k;
 }
 
@@ -160,7 +190,10 @@ static void body_inertia(const Env *s, const EnvModel *m, int i, float *I6, floa
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) Rc[a * 3 + b] = R[a * 3] * Ib[b] + R[a * 3 + 1] * Ib[3 + b] + R[a * 3 + 2] * Ib[6 + b];
     for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) Ic[a * 3 + b] = Rc[a * 3] * R[b * 3] + Rc[a * 3 + 1] * R[b * 3 + 1] + Rc[a * 3 + 2] * R[b * 3 + 2];
+        for (int b = a; b < 3; ++b) { /* upper triangle, mirrored: exactly symmetric */
+            Ic[a * 3 + b] = Rc[a * 3] * R[b * 3] + Rc[a * 3 + 1] * R[b * 3 + 1] + Rc[a * 3 + 2] * R[b * 3 + 2];
+            Ic[b * 3 + a] = Ic[a * 3 + b];
+        }
     matvec3(R, m->com + i * 3, cw);
     for (int k = 0; k < 3; ++k) c[k] = s->r[i][k] + cw[k];
     if (cw_out) memcpy(cw_out, c, 12);
@@ -301,8 +334,8 @@ static void root_bwd(const float *L, const float *y, float *x) { /* L^T x = y */
 
 /* solve  M^ x = tau - J^T(body forces pin)  with the factorisation: returns root accel a0 and joint qdd */
 static void aba_solve(const Env *s, const EnvModel *m, float (*pin)[6], float (*tau)[3], float *a0,
-                      float (*qdd)[3]) {
-    float pA[NB][6], uh[NB][3], a[NB][6];
+                      float (*qdd)[3], float (*a)[6]) {
+    float pA[NB][6], uh[NB][3];
     memcpy(pA, pin, sizeof(pA));
     for (int i = NB - 1; i >= 1; --i) {
         int p = m->parent[i];
@@ -395,18 +428,19 @@ static int find_contacts(const Env *s, const EnvModel *m, const OrcSimParams *pr
 static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const float *tgt, float *edof,
                     float *lam_ws, float *cforce, float *dforce, int last) {
     const float h = prm->h;
-    float a0[6], qdd[NB][3];
+    float a0[6], qdd[NB][3], acc[NB][6];
     kinematics(s, m);
     bias_and_drive(s, m, prm, edof, tgt);
     factorize(s, m);
-    aba_solve(s, m, s->f, s->tau, a0, qdd);
+    aba_solve(s, m, s->f, s->tau, a0, qdd, acc);
 
-    /* 4. unconstrained velocities */
+    /* 4. unconstrained velocities: generalized, and per body V + h a */
     float V0f[6], wjf[NB][3], Vf[NB][6];
     for (int k = 0; k < 6; ++k) V0f[k] = s->V0[k] + h * a0[k];
     for (int i = 1; i < NB; ++i)
         for (int k = 0; k < 3; ++k) wjf[i][k] = s->wj[i][k] + h * qdd[i][k];
-    velocities(s, m, Vf, V0f, wjf);
+    for (int i = 0; i < NB; ++i)
+        for (int k = 0; k < 6; ++k) Vf[i][k] = s->V[i][k] + h * acc[i][k];
 
     /* 5./6. contacts */
     Contact con[ORC_MAXC];
@@ -466,8 +500,15 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
         for (int c = 0; c < nc; ++c) {
             for (int d = 0; d < 3; ++d) {
                 int r = 3 * c + d;
-                float res = rhs[r];
-                for (int q = 0; q < nr; ++q) res += A[r][q] * lam[q];
+                /* row product summed in the order of a 64-lane xor butterfly (offsets 32..1) */
+                float v[64];
+                for (int q = 0; q < 64; ++q) v[q] = q < nr ? A[r][q] * lam[q] : 0.0f;
+                for (int off = 32; off >= 1; off >>= 1) {
+                    float t[64];
+                    for (int q = 0; q < 64; ++q) t[q] = v[q] + v[q ^ off];
+                    memcpy(v, t, sizeof(v));
+                }
+                float res = rhs[r] + v[0];
                 float nl = lam[r] - res / (A[r][r] * (1.0f + prm->cfm));
                 if (d == 0 && nl < 0.0f) nl = 0.0f;
                 lam[r] = nl;
@@ -493,7 +534,7 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
             if (last)
                 for (int k = 0; k < 3; ++k) cforce[con[c].body * 3 + k] += dirs[d][k] * lam[r] / h;
         }
-    if (nc > 0) aba_solve(s, m, pin, 0, da0, dq);
+    if (nc > 0) aba_solve(s, m, pin, 0, da0, dq, acc);
     else { memset(da0, 0, sizeof(da0)); memset(dq, 0, sizeof(dq)); }
 
     float damp = 1.0f / (1.0f + h * prm->ang_damping);
@@ -597,7 +638,8 @@ void orc_sim_free_accel(const OrcSimParams *prm, const OrcModel *mdl, int env, c
     kinematics(&s, &m);
     bias_and_drive(&s, &m, prm, edof, pd_target + (long)env * ORC_NDOF);
     factorize(&s, &m);
-    aba_solve(&s, &m, s.f, s.tau, a0, qdd);
+    float acc[NB][6];
+    aba_solve(&s, &m, s.f, s.tau, a0, qdd, acc);
     memcpy(qdd75, a0, 24);
     for (int i = 1; i < NB; ++i)
         for (int k = 0; k < 3; ++k) qdd75[6 + (i - 1) * 3 + k] = qdd[i][k];

@@ -1,0 +1,58 @@
+// TEST INFRASTRUCTURE ONLY: fiber scheduler behind the CPU emulation of the HIP device language
+// (see hip/hip_runtime.h).
+#include "hip/hip_runtime.h"
+#include <ucontext.h>
+#include <cstdlib>
+
+emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace emu {
+uint64_t g_xbuf[1024];
+
+static ucontext_t g_sched;
+static std::vector<ucontext_t> g_ctx;
+static std::vector<char *> g_stack;
+static std::vector<int> g_alive;
+static const std::function<void()> *g_body = nullptr;
+static int g_cur = 0;
+static const size_t kStack = 1 << 20;
+
+static void trampoline() {
+    (*g_body)();
+    g_alive[g_cur] = 0;
+    swapcontext(&g_ctx[g_cur], &g_sched);
+}
+
+void barrier() { swapcontext(&g_ctx[g_cur], &g_sched); }
+
+void launch_impl(unsigned grid, unsigned block, const std::function<void()> &body) {
+    g_body = &body;
+    if (g_stack.size() < block) {
+        for (size_t i = g_stack.size(); i < block; ++i) g_stack.push_back((char *)std::malloc(kStack));
+    }
+    g_ctx.resize(block);
+    g_alive.assign(block, 1);
+    gridDim.x = grid; blockDim.x = block;
+    for (unsigned b = 0; b < grid; ++b) {
+        blockIdx.x = b;
+        for (unsigned t = 0; t < block; ++t) {
+            getcontext(&g_ctx[t]);
+            g_ctx[t].uc_stack.ss_sp = g_stack[t];
+            g_ctx[t].uc_stack.ss_size = kStack;
+            g_ctx[t].uc_link = &g_sched;
+            makecontext(&g_ctx[t], trampoline, 0);
+            g_alive[t] = 1;
+        }
+        bool any = true;
+        while (any) {
+            any = false;
+            for (unsigned t = 0; t < block; ++t)
+                if (g_alive[t]) {
+                    g_cur = (int)t; threadIdx.x = t;
+                    swapcontext(&g_sched, &g_ctx[t]);
+                    any = any || g_alive[t];
+                }
+        }
+    }
+}
+}  // namespace emu

@@ -1,0 +1,37 @@
+// TEST INFRASTRUCTURE ONLY: runs emloco_amd/csrc/sim_kernels.hip on the CPU through the emulation
+// header in tests/emu/hip/, so the kernel's logic can be compared with the oracle without a GPU.
+#include "hip/hip_runtime.h"
+#include "../../emloco_amd/csrc/sim_kernels.hip"
+#include "../../emloco_amd/csrc/topology.h"
+
+extern "C" int emu_sim_step(const EmlocoSimParams *prm, const EmlocoModelDesc *m, float *root_state,
+                            float *dof_state, const float *pd_target, float *rb_state, float *contact_force,
+                            float *dof_force, float *lambda_ws, int n_calls) {
+    emloco::Topology t;
+    if (!t.build(m->parent, m->geom_type)) return -1;
+    EmlocoSimDev d{};
+    d.n_env = m->n_env; d.n_cand = t.n_cand; d.max_depth = t.max_depth;
+    d.parent = t.parent.data(); d.depth = t.depth.data(); d.children = t.children.data();
+    d.geom_type = t.geom_type.data(); d.cand_body = t.cand_body.data(); d.cand_k = t.cand_k.data();
+    d.lca_depth = t.lca_depth.data();
+    d.joint_off = m->joint_off; d.mass = m->mass; d.com = m->com; d.inertia = m->inertia;
+    d.geom_a = m->geom_a; d.geom_b = m->geom_b; d.geom_r = m->geom_r;
+    d.kp = m->kp; d.kd = m->kd; d.armature = m->armature; d.effort = m->effort;
+    d.root_state = root_state; d.dof_state = dof_state; d.pd_target = pd_target;
+    d.rb_state = rb_state; d.contact_force = contact_force; d.dof_force = dof_force; d.lambda_ws = lambda_ws;
+    EmlocoSimParams p = *prm;
+    p.n_sub = prm->n_sub * n_calls;
+    emu::launch((unsigned)m->n_env, 64, [&] { emloco::sim_step_kernel(p, d); });
+    return 0;
+}
+
+extern "C" int emu_sim_fk(const EmlocoModelDesc *m, float *root_state, float *dof_state, float *rb_state) {
+    emloco::Topology t;
+    if (!t.build(m->parent, m->geom_type)) return -1;
+    EmlocoSimDev d{};
+    d.n_env = m->n_env; d.n_cand = t.n_cand; d.max_depth = t.max_depth;
+    d.parent = t.parent.data(); d.depth = t.depth.data();
+    d.joint_off = m->joint_off; d.root_state = root_state; d.dof_state = dof_state; d.rb_state = rb_state;
+    emu::launch((unsigned)m->n_env, 64, [&] { emloco::sim_fk_kernel(d, nullptr, m->n_env); });
+    return 0;
+}

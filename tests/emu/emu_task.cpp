@@ -1,0 +1,26 @@
+// TEST INFRASTRUCTURE ONLY: runs emloco_amd/csrc/task_kernels.hip on the CPU through tests/emu/hip/.
+#include "hip/hip_runtime.h"
+#include "../../emloco_amd/csrc/task_kernels.hip"
+
+extern "C" int emu_task_post_physics(const EmlocoTaskBufs *b, int mode, const int32_t *env_ids, int n) {
+    const int count = env_ids ? n : b->n_env;
+    EmlocoTaskBufs t = *b;
+    emu::launch((unsigned)count, 64, [&] { emloco::post_physics_kernel(t, mode, env_ids, count); });
+    return 0;
+}
+
+extern "C" int emu_task_amp_rows(int n, const float *root_pos, const float *root_rot, const float *root_vel,
+                                 const float *root_ang, const float *dof_pos, const float *dof_vel, const float *key_pos,
+                                 const float *betas, const int32_t *subset, int n_sub, float *out) {
+    emu::launch((unsigned)n, 64, [&] {
+        emloco::amp_rows_kernel(n, root_pos, root_rot, root_vel, root_ang, dof_pos, dof_vel, key_pos, betas, subset, n_sub, out);
+    });
+    return 0;
+}
+
+extern "C" int emu_task_pd_targets(int n_env, const float *actions, const float *offset, const float *scale,
+                                   const uint8_t *zero_mask, float *out) {
+    const int total = n_env * 69;
+    emu::launch((unsigned)((total + 255) / 256), 256, [&] { emloco::pd_targets_kernel(total, actions, offset, scale, zero_mask, out); });
+    return 0;
+}

@@ -1,0 +1,65 @@
+// tests/emu/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY.
+//
+// A tiny host-side stand-in for the parts of the HIP device language the kernels in
+// emloco_amd/csrc/*_kernels.hip use, so the SAME kernel source can be compiled with g++ and
+// executed on the CPU by the `-m "not gpu"` tests (there is no GPU in the build container).
+// One workgroup = blockDim.x fibers; __syncthreads() yields to a round-robin scheduler; wave shuffles /
+// ballots exchange through a per-block buffer.  Blocks run one after another.  This is NOT a product path:
+// emloco_amd/ never includes it, and the product fails loudly without the gfx950 library.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct emu_dim3 { unsigned x = 1, y = 1, z = 1; };
+extern emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+// One workgroup = blockDim.x fibers (ucontext) run round-robin by a scheduler: a fiber runs until its
+// next barrier, then the next fiber runs; when all have arrived the round starts again.  That is the
+// lock-step-between-barriers semantics the kernels rely on, at ~0.1 us per switch.
+namespace emu {
+void barrier();
+void launch_impl(unsigned grid, unsigned block, const std::function<void()> &body);
+extern uint64_t g_xbuf[1024];
+template <class F> void launch(unsigned grid, unsigned block, F body) { launch_impl(grid, block, std::function<void()>(body)); }
+}  // namespace emu
+
+static inline void __syncthreads() { emu::barrier(); }
+
+template <class T> static inline T emu_exchange(T v, int src) {
+    static_assert(sizeof(T) <= 8, "");
+    uint64_t raw = 0; std::memcpy(&raw, &v, sizeof(T));
+    emu::g_xbuf[threadIdx.x] = raw;
+    emu::barrier();
+    uint64_t got = emu::g_xbuf[(threadIdx.x & ~63u) | (unsigned)(src & 63)];
+    emu::barrier();
+    T out; std::memcpy(&out, &got, sizeof(T));
+    return out;
+}
+template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return emu_exchange(v, (int)(threadIdx.x & 63) ^ mask); }
+template <class T> static inline T __shfl(T v, int src, int = 64) { return emu_exchange(v, src); }
+static inline unsigned long long __ballot(int pred) {
+    emu::g_xbuf[threadIdx.x] = pred ? 1 : 0;
+    emu::barrier();
+    unsigned long long m = 0;
+    unsigned base = threadIdx.x & ~63u;
+    for (int i = 0; i < 64; ++i) if (base + i < blockDim.x && emu::g_xbuf[base + i]) m |= 1ull << i;
+    emu::barrier();
+    return m;
+}
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline float __int_as_float(int x) { float f; std::memcpy(&f, &x, 4); return f; }
+static inline int __float_as_int(float f) { int x; std::memcpy(&x, &f, 4); return x; }
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+using std::fabs; using std::sqrt; using std::floor; using std::ceil;
