@@ -1,0 +1,244 @@
+"""HumanoidPedestrianTerrain: the default EmLoco task (trajectory following over a height-field terrain, with the
+LocoVal inputs captured at reset).
+
+Mirror of pacer/pacer/env/tasks/humanoid_pedestrain_terrain.py (file name spelt as in the reference):
+class HumanoidPedestrianTerrain :34-930, class Terrain :1135-1463.  Everything per step -- 368 self obs,
+30 trajectory obs, 32x32 height obs, mirrored obs, reward, reset masks, AMP -- is one fused HIP launch.
+"""
+import numpy as np
+import torch
+from scipy import ndimage
+
+from ... import _lib as L
+from ...gym import gymapi
+from ...gym import torch_utils as tu
+from ...gym.terrain_utils import convert_heightfield_to_trimesh
+from ...utils.flags import flags
+from . import humanoid_traj
+
+
+class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
+    def __init__(self, cfg, sim_params, physics_engine, device_type, device_id, headless):
+        self.real_mesh = getattr(cfg.get('args', None), "real_mesh", False)
+        if self.real_mesh:
+            raise NotImplementedError("real-mesh city terrain is out of scope")
+        self.device = "cpu"
+        if device_type == "cuda" or device_type == "GPU":
+            self.device = "cuda" + ":" + str(device_id)
+        self.cfg = cfg
+        self.num_envs = cfg["env"]["numEnvs"]
+        self.sensor_extent = cfg["env"].get("sensor_extent", 2)
+        self.sensor_res = cfg["env"].get("sensor_res", 32)
+        self.power_reward = cfg["env"].get("power_reward", False)
+        self.power_coefficient = cfg["env"].get("power_coefficient", 0.0005)
+        self.location_coefficient = cfg["env"].get("location_coefficient", 1)
+        self.terrain_obs_type = cfg['env'].get("terrain_obs_type", "square")
+        self.terrain_obs = cfg['env'].get("terrain_obs", False)
+        self.terrain_obs_root = cfg['env'].get("terrain_obs_root", "pelvis")
+        self.velocity_map = cfg["env"].get("velocity_map", False)
+        if not (self.terrain_obs and self.terrain_obs_type == "square" and self.terrain_obs_root == "head" and
+                self.sensor_res == 32 and self.sensor_extent == 2 and cfg['env'].get("use_center_height", False) and
+                self.power_reward and self.location_coefficient == 1 and not self.velocity_map):
+            raise NotImplementedError("emloco fused kernels cover pacer.yaml's terrain observation / reward settings")
+        self.num_height_points = self.sensor_res * self.sensor_res
+        self.num_center_height_points = 9
+        self.center_height_points = self.init_center_height_points()
+        self.height_meas_scale = 5
+        super().__init__(cfg=cfg, sim_params=sim_params, physics_engine=physics_engine, device_type=device_type,
+                         device_id=device_id, headless=headless)
+        self.reward_raw = torch.zeros((self.num_envs, 2)).to(self.device)
+        self._post_bufs = None
+        n_wp = self._num_traj_samples if not flags.vru else 5
+        self.waypoint_traj = torch.zeros(self.num_envs, n_wp, 3).to(self.device)     # :93-99
+        self.init_pose = torch.zeros(self.num_envs, 24, 3).to(self.device)
+        self.init_vel = torch.zeros(self.num_envs, 2).to(self.device)
+        return
+
+    # ------------------------------------------------------------------ sizes
+    def get_task_obs_size(self):
+        obs_size = 0
+        if (self._enable_task_obs):
+            obs_size = 2 * self._num_traj_samples
+            if self.terrain_obs:
+                obs_size += self.num_height_points
+        return obs_size
+
+    def get_task_obs_size_detail(self):
+        from collections import OrderedDict
+        d = OrderedDict()
+        if (self._enable_task_obs):
+            d['traj'] = 2 * self._num_traj_samples
+        if self.terrain_obs:
+            d['heightmap'] = self.num_height_points
+        return d
+
+    def get_head_pose(self, env_ids=None):
+        head_idx = self._body_names.index("Head")
+        head_pose = torch.cat([self._rigid_body_pos[:, head_idx], self._rigid_body_rot[:, head_idx]], dim=1)
+        return head_pose if env_ids is None else head_pose[env_ids]
+
+    def init_center_height_points(self):                          # :633-648
+        y = torch.tensor(np.linspace(-0.2, 0.2, 3), device=self.device)
+        x = torch.tensor(np.linspace(-0.1, 0.1, 3), device=self.device)
+        grid_x, grid_y = torch.meshgrid(x, y, indexing="ij")
+        points = torch.zeros(self.num_envs, 9, 3, device=self.device)
+        points[:, :, 0] = grid_x.flatten()
+        points[:, :, 1] = grid_y.flatten()
+        return points
+
+    # ------------------------------------------------------------------ terrain (:817-881)
+    def _create_ground_plane(self):
+        self.create_training_ground()
+
+    def create_training_ground(self):
+        if flags.small_terrain:
+            self.cfg["env"]["terrain"]['mapLength'] = 8
+            self.cfg["env"]["terrain"]['mapWidth'] = 8
+        self.terrain = Terrain(self.cfg["env"]["terrain"], num_robots=self.num_envs, device=self.device)
+        tm_params = gymapi.TriangleMeshParams()
+        tm_params.nb_vertices = self.terrain.vertices.shape[0]
+        tm_params.nb_triangles = self.terrain.triangles.shape[0]
+        tm_params.static_friction = self.cfg["env"]["terrain"]["staticFriction"]
+        tm_params.dynamic_friction = self.cfg["env"]["terrain"]["dynamicFriction"]
+        tm_params.restitution = self.cfg["env"]["terrain"]["restitution"]
+        self.gym.add_triangle_mesh(self.sim, self.terrain.vertices.flatten(order='C'),
+                                   self.terrain.triangles.flatten(order='C'), tm_params)
+        self.height_samples = self.terrain.heightsamples.view(self.terrain.tot_rows, self.terrain.tot_cols).to(self.device)
+
+    def get_center_heights(self, root_states, env_ids=None):      # :732-759 (host version, reset path)
+        base_quat = root_states[:, 3:7]
+        if env_ids is None:
+            pts = self.center_height_points
+        else:
+            pts = self.center_height_points[env_ids.to(self.device)]
+        points = tu.quat_apply_yaw(base_quat.repeat(1, self.num_center_height_points), pts) + (root_states[:, :3]).unsqueeze(1)
+        heights = self.terrain.sample_height_points(points.clone(), env_ids=env_ids)
+        return heights.view(root_states.shape[0], -1)
+
+    # ------------------------------------------------------------------ fused step plumbing
+    def _make_post_bufs(self):
+        return self._post.make_bufs(
+            n_env=self.num_envs, heightfield=self.height_samples.contiguous(), dt=self.dt,
+            traj_dur=self._traj_gen.get_traj_duration(), sample_dt=self._traj_sample_timestep,
+            hscale=self.terrain.horizontal_scale, vscale=self.terrain.vertical_scale, power_coef=self.power_coefficient,
+            fail_dist=self._fail_dist, max_episode_length=self.max_episode_length,
+            rb_state=self._rigid_body_state, dof_state=self._dof_state, dof_force=self.dof_force_tensor,
+            contact_force=self._contact_forces, betas=self.humanoid_betas, traj_verts=self._traj_gen._verts,
+            progress_buf=self.progress_buf, reset_buf=self.reset_buf, terminate_buf=self._terminate_buf,
+            obs_buf=self.obs_buf, flip_obs_buf=self._flip_obs_buf, rew_buf=self.rew_buf, reward_raw=self.reward_raw,
+            amp_obs_buf=self._amp_obs_buf)
+
+    # ------------------------------------------------------------------ reset (:493-631)
+    def _reset_task(self, env_ids):
+        if len(env_ids) > 0:
+            root_pos = self._humanoid_root_states[env_ids, 0:3]
+            root_vel = self._humanoid_root_states[env_ids, 7:10]
+            motion_ids = getattr(self, "_reset_ref_motion_ids", None)
+            motion_times = getattr(self, "_reset_ref_motion_times", None)
+            self._traj_gen.reset(env_ids, root_pos, root_vel, motion_ids, motion_times)
+            self.inverted = self._traj_gen.show_inverted()
+            self.waypoint_traj[env_ids] = self._fetch_traj_samples(env_ids)
+            self.init_pose[env_ids] = self._rigid_body_pos[env_ids]
+            self.init_vel[env_ids] = root_vel[:, :2]
+        return
+
+    def _sample_ref_state(self, env_ids, vel_min=1, vel_range=0.5):   # :526-573
+        out = super()._sample_ref_state(env_ids)
+        motion_ids, motion_times, root_pos, root_rot, dof_pos, root_vel, root_ang_vel, dof_vel, key_pos, rb_pos, rb_rot = out
+        num_envs = env_ids.shape[0]
+        if flags.random_heading:
+            yaw = np.pi * (2 * np.random.random([num_envs]) - 1.0)
+            h = torch.from_numpy(np.stack([np.zeros(num_envs), np.zeros(num_envs), np.sin(yaw / 2), np.cos(yaw / 2)], -1)).float().to(self.device)
+            h_rep = h[:, None].repeat(1, 24, 1)
+            root_rot = tu.quat_mul(h, root_rot).clone()
+            rb_pos = tu.quat_apply(h_rep, rb_pos - root_pos[:, None, :]).clone()
+            key_pos = tu.quat_apply(h_rep[:, :4, :], (key_pos - root_pos[:, None, :])).clone()
+            rb_rot = tu.quat_mul(h_rep, rb_rot).clone()
+            root_ang_vel = tu.quat_apply(h, root_ang_vel).clone()
+            curr_heading = tu.calc_heading_quat(root_rot)
+            root_vel[:, 0] = (torch.rand([num_envs]) * vel_range + vel_min).to(self.device)
+            root_vel = tu.quat_apply(curr_heading, root_vel).clone()
+        return motion_ids, motion_times, root_pos, root_rot, dof_pos, root_vel, root_ang_vel, dof_vel, key_pos, rb_pos, rb_rot
+
+    def _reset_ref_state_init(self, env_ids):
+        motion_ids, motion_times, root_pos, root_rot, dof_pos, root_vel, root_ang_vel, dof_vel, key_pos, rb_pos, rb_rot = \
+            self._sample_ref_state(env_ids)
+        new_root_xy = self.terrain.sample_valid_locations(self.num_envs, env_ids)
+        if flags.fixed:
+            new_root_xy[:, 0], new_root_xy[:, 1] = 50, 55          # :588
+        root_pos[:, 0:2] = new_root_xy
+        root_states = torch.cat([root_pos, root_rot], dim=1)
+        center_height = self.get_center_heights(root_states, env_ids=env_ids).mean(dim=-1)
+        self._reset_ground_height = center_height
+        env_ids = env_ids.to(self.device)
+        self._set_env_state(env_ids=env_ids, root_pos=root_pos, root_rot=root_rot, dof_pos=dof_pos, root_vel=root_vel,
+                            root_ang_vel=root_ang_vel, dof_vel=dof_vel, rigid_body_pos=rb_pos, rigid_body_rot=rb_rot)
+        self._reset_ref_env_ids = env_ids
+        self._reset_ref_motion_ids = motion_ids
+        self._reset_ref_motion_times = motion_times
+        self._motion_start_times[env_ids] = motion_times
+        self._sampled_motion_ids[env_ids] = motion_ids
+        return
+
+
+class Terrain:
+    """Height-field terrain (mirror of humanoid_pedestrain_terrain.py:1135-1463): int16 height samples at 0.1 m /
+    0.005 m resolution with a 50 m border, a walkable mask, and sampling helpers.  The shaped sub-terrains
+    (slopes, stairs, stepping stones, poles) are listed under 'next'; the BASELINE configs use the flat one
+    (terrainProportions [0,0,0,0,0,0,0,1], pacer.yaml:84)."""
+
+    def __init__(self, cfg, num_robots, device) -> None:
+        self.type = cfg["terrainType"]
+        self.device = device
+        if self.type in ["none", 'plane']:
+            raise NotImplementedError("terrainType must be trimesh for the terrain observations")
+        self.horizontal_scale = 0.1
+        self.vertical_scale = 0.005
+        self.border_size = 50
+        self.env_length = cfg["mapLength"]
+        self.env_width = cfg["mapWidth"]
+        self.proportions = [np.sum(cfg["terrainProportions"][:i + 1]) for i in range(len(cfg["terrainProportions"]))]
+        if abs(cfg["terrainProportions"][-1] - 1.0) > 1e-9:
+            raise NotImplementedError("emloco round 1: flat terrain only (terrainProportions [...,1])")
+        self.env_rows = cfg["numLevels"]
+        self.env_cols = cfg["numTerrains"]
+        self.num_maps = self.env_rows * self.env_cols
+        self.width_per_env_pixels = int(self.env_width / self.horizontal_scale)
+        self.length_per_env_pixels = int(self.env_length / self.horizontal_scale)
+        self.border = int(self.border_size / self.horizontal_scale)
+        self.tot_cols = int(self.env_cols * self.width_per_env_pixels) + 2 * self.border
+        self.tot_rows = int(self.env_rows * self.length_per_env_pixels) + 2 * self.border
+        self.height_field_raw = np.zeros((self.tot_rows, self.tot_cols), dtype=np.int16)
+        self.walkable_field_raw = np.zeros((self.tot_rows, self.tot_cols), dtype=np.int16)
+        self.walkable_field_raw = ndimage.binary_dilation(self.walkable_field_raw, iterations=3).astype(int)
+        self.heightsamples = torch.from_numpy(self.height_field_raw).to(self.device)
+        self.walkable_field = torch.from_numpy(self.walkable_field_raw).to(self.device)
+        # collision mesh: the flat field is two triangles (a full-resolution mesh of a flat plane adds nothing)
+        ex, ey = (self.tot_rows - 1) * self.horizontal_scale, (self.tot_cols - 1) * self.horizontal_scale
+        self.vertices = np.array([[0, 0, 0], [ex, 0, 0], [0, ey, 0], [ex, ey, 0]], dtype=np.float32)
+        self.triangles = np.array([[0, 3, 1], [0, 2, 3]], dtype=np.uint32)
+        self.sample_extent_x = int((self.tot_rows - self.border * 2) * self.horizontal_scale)
+        self.sample_extent_y = int((self.tot_cols - self.border * 2) * self.horizontal_scale)
+        coord_x, coord_y = torch.where(self.walkable_field == 0)
+        cx, cy = coord_x * self.horizontal_scale, coord_y * self.horizontal_scale
+        b = self.border * self.horizontal_scale
+        sub = torch.logical_and(torch.logical_and(cy < cy.max() - b, cx < cx.max() - b),
+                                torch.logical_and(cy > cy.min() + b, cx > cx.min() + b))
+        self.coord_x_scale = cx[sub]
+        self.coord_y_scale = cy[sub]
+        self.num_samples = self.coord_x_scale.shape[0]
+
+    def sample_valid_locations(self, max_num_envs, env_ids, group_num_people=16, sample_groups=False):   # :1196-1210
+        idxes = np.random.randint(0, self.num_samples, size=env_ids.shape[0])
+        return torch.stack([self.coord_x_scale[idxes], self.coord_y_scale[idxes]], dim=-1)
+
+    def world_points_to_map(self, points):                         # :1212-1218
+        points = (points / self.horizontal_scale).long()
+        px = torch.clip(points[:, :, 0].view(-1), 0, self.heightsamples.shape[0] - 2)
+        py = torch.clip(points[:, :, 1].view(-1), 0, self.heightsamples.shape[1] - 2)
+        return px, py
+
+    def sample_height_points(self, points, root_states=None, root_points=None, env_ids=None, **kw):   # :1282-1288
+        px, py = self.world_points_to_map(points)
+        heights = torch.min(self.heightsamples[px, py], self.heightsamples[px + 1, py + 1])
+        return heights * self.vertical_scale

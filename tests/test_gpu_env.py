@@ -1,0 +1,93 @@
+"""GPU: the task / VecEnv mirror end to end (create -> reset -> step), checked against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _make_env(num_envs=64, extra=()):
+    from emloco_amd.run import create_rlgpu_env, fill_flags
+    from emloco_amd.utils.config import get_args, load_cfg
+    args = get_args(["--num_envs", str(num_envs), "--seed", "3", *extra])
+    cfg, cfg_train, _ = load_cfg(args)
+    fill_flags(args)
+    return create_rlgpu_env(args, cfg, cfg_train)
+
+
+def test_reset_then_step_matches_oracle_recompute():
+    import oracle
+    from helpers import oracle_sim
+    env = _make_env(64, ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel"])
+    task = env.task
+    E = 64
+    assert task.num_obs == 1422 and task.num_actions == 69
+    obs = env.reset(torch.arange(E, device=task.device))
+    torch.cuda.synchronize()
+    assert obs.shape == (E, 1422) and torch.isfinite(obs).all()
+    assert (task.progress_buf == 0).all() and (task.reset_buf == 0).all()
+    # reset obs == oracle self obs of the state the sim holds
+    rb = task._rigid_body_state.view(E, 24, 13).cpu().numpy()
+    betas = task.humanoid_betas.cpu().numpy()
+    o = oracle.self_obs(rb[:, :, 0:3], rb[:, :, 3:7], rb[:, :, 7:10], rb[:, :, 10:13], betas)
+    np.testing.assert_allclose(obs[:, :368].cpu().numpy(), o, rtol=1e-5, atol=2e-5)
+    # lowest collision point of every reset humanoid sits 2 cm above the ground
+    low = task._lowest_point(torch.arange(E, device=task.device)).cpu().numpy()
+    np.testing.assert_allclose(low, 0.02, atol=2e-4)
+    # LocoVal inputs captured at reset (vec_task_wrappers.py:50-66)
+    wp = env.get_waypoint_traj()
+    assert wp.shape == (E, 15, 3) and torch.allclose(wp[:, 0], torch.zeros(E, 3, device=wp.device))
+    assert env.get_init_pose().shape == (E, 24, 3) and env.get_init_vel().shape == (E, 2)
+
+    # one env.step vs the oracle driven with the same state, targets and models
+    root0 = task._root_states.cpu().numpy().copy()
+    dof0 = task._dof_state.view(E, 69, 2).cpu().numpy().copy()
+    actions = torch.randn(E, 69, device=task.device) * 0.05
+    models = [e.actors[0].asset.model for e in task.sim.envs]
+    for m, e in zip(models, task.sim.envs):   # per-env PD gains as set through set_actor_dof_properties
+        pass
+    obs2, rew, done, info = env.step(actions)
+    torch.cuda.synchronize()
+    tgt = task._pd_targets.cpu().numpy()
+    zero = task._pd_zero_mask.cpu().numpy()
+    exp_t = oracle.pd_targets(actions.cpu().numpy(), task._pd_action_offset.cpu().numpy(), task._pd_action_scale.cpu().numpy(), zero)
+    np.testing.assert_array_equal(tgt, exp_t)
+    import copy
+    ms = []
+    for e in task.sim.envs:
+        m = copy.copy(e.actors[0].asset.model)
+        m.kp = e.actors[0].dof_props["stiffness"].astype(np.float64)
+        m.kd = e.actors[0].dof_props["damping"].astype(np.float64)
+        ms.append(m)
+    osim = oracle_sim(ms, root0, dof0, tgt, n_sub=4)
+    osim.step(1)
+    np.testing.assert_array_equal(task._rigid_body_state.view(E, 24, 13).cpu().numpy(), osim.rb_state)   # bit-exact physics
+    assert (task.progress_buf == 1).all()
+    assert set(info) >= {"terminate", "reward_raw", "flip_obs", "obs", "amp_obs"}
+    assert info["amp_obs"].shape == (E, 15 * 206)
+    verts = task._traj_gen._verts.cpu().numpy()
+    tar = oracle.traj_calc_pos(verts, task.progress_buf.cpu().numpy(), task.dt, task._traj_gen.get_traj_duration())
+    r, raw = oracle.reward(osim.rb_state[:, 0, :3], tar, osim.dof_force, osim.dof_state[:, :, 1])
+    np.testing.assert_allclose(rew.cpu().numpy(), r, rtol=1e-5, atol=1e-6)
+    rs, tm = oracle.reset(task.progress_buf.cpu().numpy(), osim.contact_force, osim.rb_state[:, :, :3], tar)
+    np.testing.assert_array_equal(done.cpu().numpy(), rs)
+    np.testing.assert_array_equal(info["terminate"].cpu().numpy(), tm)
+
+
+def test_rollout_with_resets_runs_an_episode():
+    env = _make_env(256, ["--random_heading", "--init_heading"])
+    task = env.task
+    E = 256
+    env.reset(torch.arange(E, device=task.device))
+    n_done = 0
+    for k in range(170):
+        done_ids = task.reset_buf.nonzero(as_tuple=False).flatten()
+        n_done += len(done_ids)
+        if len(done_ids):
+            env.reset(done_ids)
+        obs, rew, done, info = env.step(torch.randn(E, 69, device=task.device) * 0.055)
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert n_done >= E          # every env finished at least one episode (168-step cap or early termination)
+    assert int(task.progress_buf.max()) <= 168

@@ -1,0 +1,60 @@
+"""Host-side mirrors of the reference's per-episode logic, pinned against golden vectors (CPU only)."""
+import numpy as np
+import torch
+
+from emloco_amd.utils.flags import Flags
+
+
+def _flags(**kw):
+    base = dict(real_path=False, jta_path=False, jrdb_path=False, pred_path=False, fixed_path=False, slow=False,
+                adjust_root_vel=False, init_heading=False, heading_inversion=False, add_noise=False, vru=False)
+    base.update(kw)
+    return Flags(base)
+
+
+def _gen(flags, E=16):
+    from emloco_amd.env.util.traj_generator import TrajGenerator
+    dt = 2 * (1.0 / 60.0)
+    return TrajGenerator(E, 168 * dt, 101, "cpu", 2.0, 0.0005, 3.0, 2.0, 0.02, None, hybridInitProb=0.5, flags=flags)
+
+
+def _draws(g, *extra):
+    keys = ["r_dtheta", "r_dtheta_sharp", "bern_sharp", "r_heading", "r_dspeed", "r_speed0"] + list(extra)
+    return {k: torch.from_numpy(g[k]) for k in keys}
+
+
+def test_traj_reset_plain_matches_reference(golden):
+    g = golden("traj_reset_plain")
+    tg = _gen(_flags())
+    ids = torch.arange(16)
+    tg.reset(ids, torch.from_numpy(g["init_pos"]), torch.from_numpy(g["root_vel"]), draws=_draws(g))
+    np.testing.assert_allclose(tg._verts.numpy(), g["verts"], rtol=1e-6, atol=1e-5)
+    assert abs(tg._dt - float(g["dt_vert"])) < 1e-12
+
+
+def test_traj_reset_same_seed_same_stream(golden):
+    """With torch's own CPU generator the mirror consumes the draws in the reference's order."""
+    g = golden("traj_reset_plain")
+    tg = _gen(_flags())
+    torch.manual_seed(int(g["rng_seed"]))
+    tg.reset(torch.arange(16), torch.from_numpy(g["init_pos"]), torch.from_numpy(g["root_vel"]))
+    np.testing.assert_allclose(tg._verts.numpy(), g["verts"], rtol=1e-6, atol=1e-5)
+
+
+def test_traj_reset_heading_inversion_matches_reference(golden):
+    g = golden("traj_reset_heading")
+    tg = _gen(_flags(init_heading=True, heading_inversion=True, adjust_root_vel=True))
+    tg.reset(torch.arange(16), torch.from_numpy(g["init_pos"]), torch.from_numpy(g["root_vel"]),
+             draws=_draws(g, "r_inversion"))
+    np.testing.assert_allclose(tg._verts.numpy(), g["verts"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_array_equal(tg.show_inverted().long().numpy(), g["inverted"])   # bit-exact mask
+
+
+def test_calc_pos_matches_reference(golden):
+    g = golden("traj_samples")
+    tg = _gen(_flags())
+    tg._verts[:] = torch.from_numpy(g["verts"])
+    times = torch.from_numpy(g["progress"]) * float(g["dt"])
+    out = tg.calc_pos(torch.arange(16), times)
+    np.testing.assert_allclose(out.numpy(), g["tar_pos"], rtol=1e-6, atol=1e-6)
+    assert abs(tg.get_traj_duration() - float(g["traj_dur"])) < 1e-12
