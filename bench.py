@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the EmLoco rollout hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one `env.step` of every env of this rank, as AMPValueAgent.play_steps drives it
+(amp_continuous_value.py:46-62): reset the envs that finished, then pre-physics -> 4 fused physics substeps ->
+fused post-physics.  Workload at N=1 = BASELINE.json configs[1]: 4096 SMPL humanoids, random_heading,
+JTA+JRDB-shaped real paths (synthetic: the datasets do not ship), flat terrain.  Policy inference (A19) is
+not part of env.step and is excluded: actions are pre-sampled N(0, e^-2.9) like the frozen policy's noise.
+For N>1 envs are sharded (4096 per rank, weak scaling); the only collective is the LocoVal-gradient-sized
+all-reduce (6 174 floats) once per 32-step horizon, as LocoVal training would issue it.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (sim_step_kernel): algorithmic bytes per
+launch (8 624 B per env) over its HIP-event duration, against the 8 TB/s HBM peak --
+the kernel is latency/occupancy bound, so the fraction is tiny by construction.  `cpu_baseline` times the
+CPU oracle (this repo's sequential C restatement; the reference's own PhysX path does not exist here) on a
+bounded sample of the same workload, single core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SIM_BYTES_PER_ENV = 8624          # state in/out + per-env model + warm-start, per launch
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def synthetic_real_paths(n, seed=0):
+    """JTA/JRDB-shaped paths (load_jta_traj.py:72-114 format): 13 waypoints @0.4 s of a constant-turn-rate
+    walker, natural cubic spline to 101 vertices, z = 0."""
+    from scipy.interpolate import CubicSpline
+    rng = np.random.default_rng(seed)
+    out = {}
+    t = np.arange(13) * 0.4
+    td = np.linspace(0, t[-1], 101)
+    for i in range(n):
+        v, w, h0 = rng.uniform(0.3, 2.0), rng.uniform(-0.35, 0.35), rng.uniform(-np.pi, np.pi)
+        hd = h0 + w * t
+        xy = np.cumsum(np.stack([np.cos(hd), np.sin(hd)], 1) * v * 0.4, 0)
+        xy = np.concatenate([[[0.0, 0.0]], xy[:-1]], 0)
+        cs = CubicSpline(t, xy, bc_type="natural")
+        traj = np.zeros((101, 3), np.float32)
+        traj[:, :2] = cs(td)
+        out[i] = {"traj": traj, "pose": None}
+    return out
+
+
+def make_env(num_envs, rank):
+    from emloco_amd.run import create_rlgpu_env, fill_flags
+    from emloco_amd.utils.config import get_args, load_cfg
+    args = get_args(["--num_envs", str(num_envs), "--seed", "0", "--random_heading", "--init_heading",
+                     "--heading_inversion", "--adjust_root_vel", "--real_path", "JTA+JRDB",
+                     "--sim_device", f"cuda:{rank_local()}", "--rl_device", f"cuda:{rank_local()}"])
+    cfg, cfg_train, _ = load_cfg(args)
+    cfg["env"]["traj_data"] = [synthetic_real_paths(2000, seed=1), synthetic_real_paths(2000, seed=2)]
+    fill_flags(args)
+    return create_rlgpu_env(args, cfg, cfg_train, rank=rank)
+
+
+def rank_local():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def cpu_baseline(sample_envs=512, sample_steps=400):
+    """The CPU oracle on a bounded sample of the same workload (physics + post-physics maths), one core."""
+    import oracle
+    from emloco_amd.model import pack_models
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import varied_models
+    models = varied_models(64, seed=0)
+    models = [models[i % 64] for i in range(sample_envs)]
+    s = oracle.Sim(pack_models(models), oracle.default_params(n_sub=4))
+    s.root_state[:, 2] = 0.93
+    rng = np.random.default_rng(0)
+    betas = rng.normal(size=(sample_envs, 17)).astype(np.float32)
+    verts = np.cumsum(rng.normal(size=(sample_envs, 101, 3)).astype(np.float32) * 0.05, 1)
+    hf = np.zeros((1200, 1200), np.int16)
+    prog = np.zeros(sample_envs, np.int64)
+    subset = np.concatenate([np.arange(3 * j, 3 * j + 3) for j in range(23) if j not in (3, 7, 17, 22)]).astype(np.int32)
+    t0 = time.perf_counter()
+    for k in range(sample_steps):
+        s.pd_target[:] = (rng.normal(size=(sample_envs, 69)) * 0.055 * np.pi).astype(np.float32)
+        s.step(1)
+        prog += 1
+        rb = s.rb_state
+        a = (rb[:, :, 0:3], rb[:, :, 3:7], rb[:, :, 7:10], rb[:, :, 10:13], betas)
+        oracle.self_obs(*a)
+        oracle.self_obs(*a, flip=True)
+        smp = oracle.traj_samples(verts, prog, 1 / 30., 5.656)
+        loc = oracle.location_obs(s.root_state, smp)
+        head = np.concatenate([rb[:, 13, 0:3], rb[:, 13, 3:7]], -1)
+        ho = oracle.height_obs(oracle.get_center_heights(s.root_state, hf), oracle.get_heights(head, hf))
+        oracle.flip_task_obs(np.concatenate([loc, ho], 1))
+        oracle.reward(rb[:, 0, :3], smp[:, 0], s.dof_force, s.dof_state[:, :, 1])
+        oracle.reset(prog, s.contact_force, rb[:, :, :3], smp[:, 0])
+        oracle.amp_obs(rb[:, 0, 0:3], rb[:, 0, 3:7], rb[:, 0, 7:10], rb[:, 0, 10:13], s.dof_state[:, :, 0],
+                       s.dof_state[:, :, 1], rb[:, [7, 3, 22, 17], 0:3], betas, subset)
+        prog[prog >= 167] = 0
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_envs * sample_steps / dt, 1), "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_envs} envs x {sample_steps} steps of the same env.step (oracle/ C restatement, "
+                      f"single thread, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--num_envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from emloco_amd import _lib as L
+    from emloco_amd.dist import init_from_env
+    L.require_device()                                  # fail loudly: no CPU fallback
+    rank, local_rank, world = init_from_env("nccl")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    E = a.num_envs
+    env = make_env(E, rank)
+    task = env.task
+    env.reset(torch.arange(E, device=dev))
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    pool = torch.randn(64, E, 69, device=dev, generator=g) * float(np.exp(-2.9))
+    grad_bucket = torch.zeros(6174, device=dev)          # LocoVal gradient size (value_pose_net.py:36-60)
+    horizon = 32
+
+    def one_step(k):
+        done = task.reset_buf.nonzero(as_tuple=False).flatten()
+        if done.numel():
+            env.reset(done)
+        env.step(pool[k % 64])
+        if world > 1 and (k + 1) % horizon == 0:
+            dist.all_reduce(grad_bucket)
+
+    for k in range(a.warmup):
+        one_step(k)
+    task.sim.native.enable_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    resets = 0
+    for k in range(a.steps):
+        one_step(k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_l, ms_l = task.sim.native.timing_stats()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        kernel_ms = ms_l / max(n_l, 1)
+        achieved = SIM_BYTES_PER_ENV * E / (kernel_ms * 1e-3) / 1e9 if n_l else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_sim_step_hbm_bytes.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/sec (SMPL humanoid, num_envs)", "value": round(E * world * a.steps / elapsed, 1),
+            "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: PACER rollout env.step, 4096 SMPL humanoids per GPU, random_heading, "
+                                   "JTA+JRDB-shaped real_path (synthetic), flat terrain, resets included, policy excluded",
+                       "num_envs_per_gpu": E, "substeps_per_step": 4, "parallelism": f"env-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "sim_step_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l,
+                         "note": "latency/occupancy bound: 8.6 KB of state per env per launch"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

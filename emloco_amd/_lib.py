@@ -72,7 +72,7 @@ SYMBOLS_SIM = [
     "emloco_sim_prepare", "emloco_sim_get_params", "emloco_sim_set_params", "emloco_sim_tensor",
     "emloco_sim_set_pd_targets", "emloco_sim_step", "emloco_sim_sync", "emloco_sim_set_root_state_indexed",
     "emloco_sim_set_dof_state_indexed", "emloco_sim_refresh_bodies", "emloco_sim_num_candidates",
-    "emloco_sim_last_step_ms", "emloco_sim_enable_timing",
+    "emloco_sim_last_step_ms", "emloco_sim_enable_timing", "emloco_sim_timing_stats",
 ]
 SYMBOLS_TASK = [
     "emloco_task_post_physics", "emloco_task_amp_rows", "emloco_task_pd_targets", "emloco_task_last_ms",
@@ -87,6 +87,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own HIP runtime; it must be the one the process binds first, otherwise torch
+    # later fails with "No HIP GPUs are available" (two runtimes with the same soname).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise EmlocoError(f"{LIB_PATH} is missing: run `python -m emloco_amd.build` (hipcc, gfx950). "
                           "There is no CPU fallback.")
@@ -113,6 +116,7 @@ def load():
     lib.emloco_sim_num_candidates.argtypes = [C.c_void_p]
     lib.emloco_sim_last_step_ms.argtypes = [C.c_void_p]
     lib.emloco_sim_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.emloco_sim_timing_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]
     lib.emloco_task_post_physics.argtypes = [C.POINTER(TaskBufs), C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.emloco_task_amp_rows.argtypes = [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.c_void_p]
     lib.emloco_task_pd_targets.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]

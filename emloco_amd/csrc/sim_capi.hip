@@ -65,8 +65,10 @@ struct EmlocoSim {
     DevBuf<float> d_off, d_mass, d_com, d_inertia, d_ga, d_gb, d_gr, d_kp, d_kd, d_arm, d_eff;
     DevBuf<float> d_root, d_dof, d_tgt, d_rb, d_cf, d_df, d_lws;
     EmlocoSimDev dev{};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_pending = false;
+    // HIP-event timing of step launches: a ring of event pairs recorded on the launch stream
+    static constexpr int kRing = 1024;
+    std::vector<hipEvent_t> ev0, ev1;
+    int ev_head = 0, ev_count = 0;
     float last_ms = -1.0f;
 };
 
@@ -105,8 +107,8 @@ int emloco_sim_destroy(EmlocoSim *s) {
     s->d_kp.release(); s->d_kd.release(); s->d_arm.release(); s->d_eff.release();
     s->d_root.release(); s->d_dof.release(); s->d_tgt.release(); s->d_rb.release();
     s->d_cf.release(); s->d_df.release(); s->d_lws.release();
-    if (s->ev0) (void)hipEventDestroy(s->ev0);
-    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (auto e : s->ev0) (void)hipEventDestroy(e);
+    for (auto e : s->ev1) (void)hipEventDestroy(e);
     delete s;
     return EMLOCO_OK;
 }
@@ -179,8 +181,6 @@ int emloco_sim_prepare(EmlocoSim *s) {
     d.kp = s->d_kp.p; d.kd = s->d_kd.p; d.armature = s->d_arm.p; d.effort = s->d_eff.p;
     d.root_state = s->d_root.p; d.dof_state = s->d_dof.p; d.pd_target = s->d_tgt.p;
     d.rb_state = s->d_rb.p; d.contact_force = s->d_cf.p; d.dof_force = s->d_df.p; d.lambda_ws = s->d_lws.p;
-    HIPCHK(hipEventCreate(&s->ev0));
-    HIPCHK(hipEventCreate(&s->ev1));
     HIPCHK(hipDeviceSynchronize());
     s->prepared = true;
     return EMLOCO_OK;
@@ -230,10 +230,15 @@ int emloco_sim_step(EmlocoSim *s, int n_calls, void *stream) {
     EmlocoSimParams p = s->prm;
     p.n_sub = s->prm.n_sub * n_calls;
     hipStream_t st = (hipStream_t)stream;
-    if (s->timing) HIPCHK(hipEventRecord(s->ev0, st));
+    const int slot = s->ev_head;
+    if (s->timing) HIPCHK(hipEventRecord(s->ev0[slot], st));
     hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)s->n_env), dim3(64), 0, st, p, s->dev);
     HIPCHK(hipGetLastError());
-    if (s->timing) { HIPCHK(hipEventRecord(s->ev1, st)); s->ev_pending = true; }
+    if (s->timing) {
+        HIPCHK(hipEventRecord(s->ev1[slot], st));
+        s->ev_head = (slot + 1) % EmlocoSim::kRing;
+        if (s->ev_count < EmlocoSim::kRing) ++s->ev_count;
+    }
     return EMLOCO_OK;
 }
 
@@ -278,18 +283,39 @@ int emloco_sim_num_candidates(EmlocoSim *s) { return s ? s->topo.n_cand : EMLOCO
 
 int emloco_sim_enable_timing(EmlocoSim *s, int on) {
     if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_enable_timing: null sim");
+    if (on && s->ev0.empty()) {
+        HIPCHK(hipSetDevice(s->device));
+        s->ev0.resize(EmlocoSim::kRing); s->ev1.resize(EmlocoSim::kRing);
+        for (int i = 0; i < EmlocoSim::kRing; ++i) { HIPCHK(hipEventCreate(&s->ev0[i])); HIPCHK(hipEventCreate(&s->ev1[i])); }
+    }
     s->timing = on != 0;
+    s->ev_head = 0; s->ev_count = 0;
+    return EMLOCO_OK;
+}
+
+int emloco_sim_timing_stats(EmlocoSim *s, int *n_launches, float *total_ms) {
+    if (!s || !n_launches || !total_ms) return fail(EMLOCO_E_ARG, "emloco_sim_timing_stats: null argument");
+    *n_launches = 0; *total_ms = 0.0f;
+    for (int k = 0; k < s->ev_count; ++k) {
+        const int slot = (s->ev_head - 1 - k + 2 * EmlocoSim::kRing) % EmlocoSim::kRing;
+        HIPCHK(hipEventSynchronize(s->ev1[slot]));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, s->ev0[slot], s->ev1[slot]));
+        if (k == 0) s->last_ms = ms;
+        *total_ms += ms; ++*n_launches;
+    }
+    s->ev_count = 0;
     return EMLOCO_OK;
 }
 
 float emloco_sim_last_step_ms(EmlocoSim *s) {
     if (!s) return -1.0f;
-    if (s->ev_pending) {
-        if (hipEventSynchronize(s->ev1) == hipSuccess) {
+    if (s->ev_count > 0) {
+        const int slot = (s->ev_head - 1 + EmlocoSim::kRing) % EmlocoSim::kRing;
+        if (hipEventSynchronize(s->ev1[slot]) == hipSuccess) {
             float ms = -1.0f;
-            if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_ms = ms;
+            if (hipEventElapsedTime(&ms, s->ev0[slot], s->ev1[slot]) == hipSuccess) s->last_ms = ms;
         }
-        s->ev_pending = false;
     }
     return s->last_ms;
 }

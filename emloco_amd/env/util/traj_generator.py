@@ -121,7 +121,7 @@ class TrajGenerator():
                 init_speed = torch.clamp(torch.norm(traj[:, 1] - traj[:, 0], dim=-1), min=self._speed_min * self._dt)
                 root_speed = torch.norm(root_vel[real_mask, :2].clone(), dim=-1)
                 ratio = root_speed.div(init_speed) * self._dt
-                traj[..., 0:2] = (ratio * traj[..., 0:2].T).T
+                traj[..., 0:2] = ratio.view(-1, 1, 1) * traj[..., 0:2]
             traj[..., 0:2] += init_pos[real_mask, 0:2].unsqueeze(1)
             self._verts[env_ids[real_mask]] = traj
 

@@ -117,6 +117,12 @@ class NativeSim:
     def enable_timing(self, on=True):
         L.check(self.lib.emloco_sim_enable_timing(self._h, int(bool(on))), "emloco_sim_enable_timing")
 
+    def timing_stats(self):
+        """(number of step launches, their summed HIP-event duration in ms) since timing was enabled / last read."""
+        n, ms = C.c_int(), C.c_float()
+        L.check(self.lib.emloco_sim_timing_stats(self._h, C.byref(n), C.byref(ms)), "emloco_sim_timing_stats")
+        return n.value, ms.value
+
     def last_step_ms(self):
         return float(self.lib.emloco_sim_last_step_ms(self._h))
 
