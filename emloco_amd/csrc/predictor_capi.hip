@@ -1,0 +1,159 @@
+// predictor_capi.hip -- C ABI (include/emloco_predictor.h) over the predictor / LocoVal kernels.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "predictor_kernels.hip"
+#include "../../include/emloco_predictor.h"
+
+namespace {
+int pfail(int code, const char *what, hipError_t e = hipSuccess) {
+    if (e != hipSuccess) fprintf(stderr, "[emloco] %s: %s\n", what, hipGetErrorString(e));
+    else fprintf(stderr, "[emloco] %s\n", what);
+    return code;
+}
+constexpr int kRing = 4096;
+std::vector<hipEvent_t> g_e0, g_e1;
+std::vector<double> g_fl;
+int g_head = 0, g_count = 0;
+bool g_timing = false;
+}  // namespace
+
+#define PHIPCHK(expr)                                                  \
+    do {                                                               \
+        hipError_t e_ = (expr);                                        \
+        if (e_ != hipSuccess) return pfail(-2, #expr, e_);             \
+    } while (0)
+
+extern "C" {
+
+int emloco_gemm_enable_timing(int on) {
+    if (on && g_e0.empty()) {
+        g_e0.resize(kRing); g_e1.resize(kRing); g_fl.resize(kRing);
+        for (int i = 0; i < kRing; ++i) { PHIPCHK(hipEventCreate(&g_e0[i])); PHIPCHK(hipEventCreate(&g_e1[i])); }
+    }
+    g_timing = on != 0; g_head = 0; g_count = 0;
+    return 0;
+}
+
+int emloco_gemm_timing_stats(int *n_launches, float *total_ms, double *total_flops) {
+    if (!n_launches || !total_ms || !total_flops) return pfail(-1, "emloco_gemm_timing_stats: null argument");
+    *n_launches = 0; *total_ms = 0.0f; *total_flops = 0.0;
+    for (int k = 0; k < g_count; ++k) {
+        const int slot = (g_head - 1 - k + 2 * kRing) % kRing;
+        PHIPCHK(hipEventSynchronize(g_e1[slot]));
+        float ms = 0.0f;
+        PHIPCHK(hipEventElapsedTime(&ms, g_e0[slot], g_e1[slot]));
+        *total_ms += ms; *total_flops += g_fl[slot]; ++*n_launches;
+    }
+    g_count = 0;
+    return 0;
+}
+
+int emloco_gemm_f32(int batch, int m, int n, int k, float alpha, const float *A, int lda, int64_t stride_a, int trans_a,
+                    const float *B, int ldb, int64_t stride_b, int trans_b, float *C, int ldc, int64_t stride_c,
+                    const float *bias, int flags, int ksplit, float *workspace, void *stream) {
+    if (batch < 1 || m < 1 || n < 1 || k < 1 || !A || !B || !C) return pfail(-1, "emloco_gemm_f32: bad argument");
+    if ((flags & EMLOCO_GEMM_BIAS) && !bias) return pfail(-1, "emloco_gemm_f32: bias flag without bias");
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > 1 && !workspace) return pfail(-1, "emloco_gemm_f32: ksplit > 1 needs a workspace");
+    if ((long)batch * ksplit > 65535) return pfail(-1, "emloco_gemm_f32: batch * ksplit exceeds the grid z limit");
+    emloco::GemmArgs g{batch, m, n, k, alpha, A, lda, (long)stride_a, trans_a, B, ldb, (long)stride_b, trans_b,
+                       C, ldc, (long)stride_c, bias, flags, ksplit, workspace};
+    hipStream_t st = (hipStream_t)stream;
+    const int slot = g_head;
+    if (g_timing) PHIPCHK(hipEventRecord(g_e0[slot], st));
+    dim3 grid((unsigned)((n + GBN - 1) / GBN), (unsigned)((m + GBM - 1) / GBM), (unsigned)(batch * ksplit));
+    hipLaunchKernelGGL(emloco::gemm_f32_kernel, grid, dim3(256), 0, st, g);
+    PHIPCHK(hipGetLastError());
+    if (ksplit > 1) {
+        const long total = (long)batch * m * n;
+        hipLaunchKernelGGL(emloco::gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g);
+        PHIPCHK(hipGetLastError());
+    }
+    if (g_timing) {
+        PHIPCHK(hipEventRecord(g_e1[slot], st));
+        g_fl[slot] = 2.0 * batch * (double)m * n * k;
+        g_head = (slot + 1) % kRing;
+        if (g_count < kRing) ++g_count;
+    }
+    return 0;
+}
+
+int emloco_softmax_fwd(int n_seq, int rows_per_seq, int cols, float scale, const float *S, const float *key_pad, float *P, void *stream) {
+    if (n_seq < 1 || rows_per_seq < 1 || cols < 1 || !S || !P) return pfail(-1, "emloco_softmax_fwd: bad argument");
+    const long rows = (long)n_seq * rows_per_seq;
+    hipLaunchKernelGGL(emloco::softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (int)rows, rows_per_seq, cols, scale, S, key_pad, P);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_softmax_bwd(int rows, int cols, float scale, const float *P, const float *dP, float *dS, void *stream) {
+    if (rows < 1 || cols < 1 || !P || !dP || !dS) return pfail(-1, "emloco_softmax_bwd: bad argument");
+    hipLaunchKernelGGL(emloco::softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rows, cols, scale, P, dP, dS);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_layernorm_fwd(int rows, int d, float eps, const float *x, const float *res, const float *gamma, const float *beta,
+                         float *y, float *mean, float *rstd, void *stream) {
+    if (rows < 1 || d < 1 || d > 1024 || !x || !gamma || !beta || !y || !mean || !rstd) return pfail(-1, "emloco_layernorm_fwd: bad argument");
+    hipLaunchKernelGGL(emloco::layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       rows, d, eps, x, res, gamma, beta, y, mean, rstd);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_layernorm_bwd(int rows, int d, const float *xr, const float *gamma, const float *mean, const float *rstd,
+                         const float *dy, float *dxr, float *dgamma, float *dbeta, float *workspace, void *stream) {
+    if (rows < 1 || d < 1 || d > 1024 || !xr || !gamma || !mean || !rstd || !dy || !dxr || !dgamma || !dbeta || !workspace)
+        return pfail(-1, "emloco_layernorm_bwd: bad argument (workspace = ceil(rows/64)*2*d floats)");
+    const int nblocks = (rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(emloco::layernorm_bwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
+                       rows, d, xr, gamma, mean, rstd, dy, dxr, workspace);
+    PHIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(emloco::layernorm_bwd_reduce_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       nblocks, d, workspace, dgamma, dbeta);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_colsum(int m, int n, const float *X, float *out, float *workspace, void *stream) {
+    if (m < 1 || n < 1 || !X || !out || !workspace) return pfail(-1, "emloco_colsum: bad argument (workspace = ceil(m/256)*n floats)");
+    const int nparts = (m + CS_ROWS - 1) / CS_ROWS;
+    hipLaunchKernelGGL(emloco::colsum_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream, m, n, X, workspace);
+    PHIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(emloco::colsum_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nparts, n, workspace, out);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_locoval_fwd(int B, const float *traj, int traj_stride, const float *pose, const float *vel, const float *w1,
+                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float *value,
+                       float *x100, float *h1, float *h2, float *angle, void *stream) {
+    if (B < 1 || traj_stride < 2 || !traj || !pose || !vel || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !value || !x100 || !h1 || !h2)
+        return pfail(-1, "emloco_locoval_fwd: bad argument");
+    hipLaunchKernelGGL(emloco::locoval_fwd_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, B, traj, traj_stride, pose, vel,
+                       w1, b1, w2, b2, w3, b3, value, x100, h1, h2, angle);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int64_t emloco_locoval_bwd_workspace(int B) { return (int64_t)B * LV_NPARAM * (int64_t)sizeof(float); }
+
+int emloco_locoval_bwd(int B, const float *traj, int traj_stride, const float *pose, const float *vel, const float *w1,
+                       const float *w2, const float *w3, const float *value, const float *x100, const float *h1, const float *h2,
+                       const float *angle, const float *dvalue, float *dparams, float *dtraj, float *workspace, void *stream) {
+    if (B < 1 || traj_stride < 2 || !traj || !pose || !vel || !w1 || !w2 || !w3 || !value || !x100 || !h1 || !h2 || !angle || !dvalue ||
+        !dparams || !dtraj || !workspace)
+        return pfail(-1, "emloco_locoval_bwd: bad argument");
+    hipLaunchKernelGGL(emloco::locoval_bwd_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, B, traj, traj_stride, pose, vel,
+                       w1, w2, w3, value, x100, h1, h2, angle, dvalue, workspace, dtraj);
+    PHIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(emloco::locoval_reduce_kernel, dim3((unsigned)((LV_NPARAM + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, workspace, dparams);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

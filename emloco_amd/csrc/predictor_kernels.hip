@@ -1,0 +1,391 @@
+// predictor_kernels.hip -- Social-Transmotion + LocoVal kernels for gfx950 (MI355X).
+//
+// Reference model: /root/reference/social-transmotion/model_jta.py:130-336 (TransMotionJTA: 6 local + 3 global
+// post-norm encoder layers, d=128, 4 heads, ff=1024) and /root/reference/pacer/pacer/learning/value_pose_net.py
+// (LocoVal MLP 100->49->24->1).  Every dense contraction (QKV / out / FFN projections, Q.K^T, P.V and all their
+// backward products) runs on the matrix cores through ONE batched GEMM kernel built on
+// v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, bit-equal to an fmaf chain, 157 TFLOP/s peak on MI355X
+// (cdna_hip_programming.md section 3).  fp32 keeps the predictor inside the 1e-4 parity bar of the north star;
+// a bf16 operand path (v_mfma_f32_32x32x16_bf16, 16x the rate) is the next step.
+//
+// Tiling: 128x128 output tile per 256-thread workgroup = 4 waves of 64x64 (2x2 MFMA tiles, 64 accumulator
+// registers per lane); K is staged through LDS 16 deep, operands stored k-major so a wave reads its A / B
+// fragments as 32 consecutive floats (conflict-free ds_read_b32).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dev_math.h"
+
+namespace emloco {
+
+typedef float f32x16 __attribute__((vector_size(64)));
+
+#define GBM 128
+#define GBN 128
+#define GBK 16
+#define GLD (GBM + 4)
+
+struct GemmArgs {
+    int batch, m, n, k;
+    float alpha;
+    const float *A; int lda; long sa; int ta;
+    const float *B; int ldb; long sb; int tb;
+    float *C; int ldc; long sc;
+    const float *bias; int flags; int ksplit; float *ws;
+};
+
+__global__ void __launch_bounds__(256)
+gemm_f32_kernel(GemmArgs g) {
+    __shared__ float As[GBK][GLD], Bs[GBK][GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bz = blockIdx.z;
+    const int b = bz / g.ksplit, split = bz - b * g.ksplit;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    int kchunk = (g.k + g.ksplit - 1) / g.ksplit;
+    kchunk = ((kchunk + GBK - 1) / GBK) * GBK;
+    const int kb = split * kchunk;
+    const int ke = (kb + kchunk < g.k) ? kb + kchunk : g.k;
+    const float *A = g.A + (long)b * g.sa;
+    const float *B = g.B + (long)b * g.sb;
+
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    for (int k0 = kb; k0 < ke; k0 += GBK) {
+        for (int e = 0; e < (GBM * GBK) / 256; ++e) {
+            const int idx = tid + 256 * e;
+            int mm, kk;
+            if (!g.ta) { mm = idx / GBK; kk = idx - mm * GBK; } else { kk = idx / GBM; mm = idx - kk * GBM; }
+            float v = 0.0f;
+            if (m0 + mm < g.m && k0 + kk < ke)
+                v = g.ta ? A[(long)(k0 + kk) * g.lda + (m0 + mm)] : A[(long)(m0 + mm) * g.lda + (k0 + kk)];
+            As[kk][mm] = v;
+        }
+        for (int e = 0; e < (GBN * GBK) / 256; ++e) {
+            const int idx = tid + 256 * e;
+            int nn, kk;
+            if (!g.tb) { nn = idx / GBK; kk = idx - nn * GBK; } else { kk = idx / GBN; nn = idx - kk * GBN; }
+            float v = 0.0f;
+            if (n0 + nn < g.n && k0 + kk < ke)
+                v = g.tb ? B[(long)(k0 + kk) * g.ldb + (n0 + nn)] : B[(long)(n0 + nn) * g.ldb + (k0 + kk)];
+            Bs[kk][nn] = v;
+        }
+        __syncthreads();
+        for (int kk = 0; kk < GBK; kk += 2) {
+            const int kr = kk + (lane >> 5);
+            const float a0 = As[kr][wm * 64 + (lane & 31)], a1 = As[kr][wm * 64 + 32 + (lane & 31)];
+            const float b0 = Bs[kr][wn * 64 + (lane & 31)], b1 = Bs[kr][wn * 64 + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D fragment layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+                if (row < g.m && col < g.n) {
+                    float v = g.alpha * acc[i][j][r];
+                    if (g.ksplit > 1) {
+                        g.ws[(((long)split * g.batch + b) * g.m + row) * g.n + col] = v;
+                    } else {
+                        float *c = g.C + (long)b * g.sc + (long)row * g.ldc + col;
+                        if (g.flags & 1) v += g.bias[col];
+                        if (g.flags & 2) v = v > 0.0f ? v : 0.0f;
+                        if (g.flags & 4) v += *c;
+                        *c = v;
+                    }
+                }
+            }
+}
+
+// sum of the ksplit partial products in a fixed order, then the epilogue
+__global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
+    const long total = (long)g.batch * g.m * g.n;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float v = 0.0f;
+    for (int s = 0; s < g.ksplit; ++s) v += g.ws[(long)s * total + i];
+    const int col = (int)(i % g.n);
+    const long rowb = i / g.n;
+    const int row = (int)(rowb % g.m);
+    const int b = (int)(rowb / g.m);
+    float *c = g.C + (long)b * g.sc + (long)row * g.ldc + col;
+    if (g.flags & 1) v += g.bias[col];
+    if (g.flags & 2) v = v > 0.0f ? v : 0.0f;
+    if (g.flags & 4) v += *c;
+    *c = v;
+}
+
+// ------------------------------------------------------------------ softmax (one wave per row)
+__global__ void __launch_bounds__(256)
+softmax_fwd_kernel(int rows, int rows_per_seq, int cols, float scale, const float *S, const float *key_bias, float *P) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *s = S + row * cols;
+    float *p = P + row * cols;
+    const float *kb = key_bias ? key_bias + (row / rows_per_seq) * cols : nullptr;
+    const float NEG = -3.0e38f;
+    float mx = NEG;
+    for (int j = lane; j < cols; j += 64) {
+        const float v = s[j] * scale + (kb ? kb[j] : 0.0f);     // kb = -inf masks the key, a finite value biases it
+        mx = v > mx ? v : mx;
+    }
+    for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+    float sum = 0.0f;
+    for (int j = lane; j < cols; j += 64) {
+        const float v = s[j] * scale + (kb ? kb[j] : 0.0f);
+        const float e = (v > NEG) ? expf(v - mx) : 0.0f;
+        p[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;   // fully masked row -> zeros ("safe softmax")
+    for (int j = lane; j < cols; j += 64) p[j] *= inv;
+}
+
+__global__ void __launch_bounds__(256)
+softmax_bwd_kernel(int rows, int cols, float scale, const float *P, const float *dP, float *dS) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *p = P + row * cols, *dp = dP + row * cols;
+    float *ds = dS + row * cols;
+    float dot = 0.0f;
+    for (int j = lane; j < cols; j += 64) dot += dp[j] * p[j];
+    dot = wave_sum(dot);
+    for (int j = lane; j < cols; j += 64) ds[j] = scale * p[j] * (dp[j] - dot);
+}
+
+// ------------------------------------------------------------------ layer norm (one wave per row, d <= 1024)
+__global__ void __launch_bounds__(256)
+layernorm_fwd_kernel(int rows, int d, float eps, const float *x, const float *res, const float *gamma, const float *beta,
+                     float *y, float *mean, float *rstd) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[16];
+    float s = 0.0f;
+    for (int t = 0; t < 16; ++t) {
+        const int j = lane + 64 * t;
+        v[t] = 0.0f;
+        if (j < d) { v[t] = x[row * d + j] + (res ? res[row * d + j] : 0.0f); s += v[t]; }
+    }
+    const float mu = wave_sum(s) / (float)d;
+    float q = 0.0f;
+    for (int t = 0; t < 16; ++t) { const int j = lane + 64 * t; if (j < d) { const float c = v[t] - mu; q += c * c; } }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+    for (int t = 0; t < 16; ++t) { const int j = lane + 64 * t; if (j < d) y[row * d + j] = (v[t] - mu) * rs * gamma[j] + beta[j]; }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dxr = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ; per-block partial dgamma / dbeta
+#define LN_ROWS_PER_BLOCK 64
+__global__ void __launch_bounds__(256)
+layernorm_bwd_kernel(int rows, int d, const float *xr, const float *gamma, const float *mean, const float *rstd,
+                     const float *dy, float *dxr, float *part /* [nblocks][2][d] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ float sh_g[4][1024], sh_b[4][1024];
+    for (int j = lane; j < d; j += 64) { sh_g[w][j] = 0.0f; sh_b[w][j] = 0.0f; }
+    const long r0 = (long)blockIdx.x * LN_ROWS_PER_BLOCK;
+    for (int rr = w; rr < LN_ROWS_PER_BLOCK; rr += 4) {
+        const long row = r0 + rr;
+        if (row >= rows) break;
+        const float mu = mean[row], rs = rstd[row];
+        float xh[16], gg[16], s1 = 0.0f, s2 = 0.0f;
+        for (int t = 0; t < 16; ++t) {
+            const int j = lane + 64 * t;
+            xh[t] = 0.0f; gg[t] = 0.0f;
+            if (j < d) {
+                const float dyv = dy[row * d + j];
+                xh[t] = (xr[row * d + j] - mu) * rs;
+                gg[t] = dyv * gamma[j];
+                s1 += gg[t]; s2 += gg[t] * xh[t];
+                sh_g[w][j] += dyv * xh[t];
+                sh_b[w][j] += dyv;
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+        for (int t = 0; t < 16; ++t) { const int j = lane + 64 * t; if (j < d) dxr[row * d + j] = rs * (gg[t] - m1 - xh[t] * m2); }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < d; j += 256) {
+        part[((long)blockIdx.x * 2 + 0) * d + j] = (sh_g[0][j] + sh_g[1][j]) + (sh_g[2][j] + sh_g[3][j]);
+        part[((long)blockIdx.x * 2 + 1) * d + j] = (sh_b[0][j] + sh_b[1][j]) + (sh_b[2][j] + sh_b[3][j]);
+    }
+}
+
+__global__ void layernorm_bwd_reduce_kernel(int nblocks, int d, const float *part, float *dgamma, float *dbeta) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d) return;
+    float g = 0.0f, b = 0.0f;
+    for (int k = 0; k < nblocks; ++k) { g += part[((long)k * 2 + 0) * d + j]; b += part[((long)k * 2 + 1) * d + j]; }
+    dgamma[j] = g; dbeta[j] = b;
+}
+
+// column sums in two fixed-order passes
+#define CS_ROWS 256
+__global__ void colsum_partial_kernel(int m, int n, const float *X, float *part) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long r0 = (long)blockIdx.y * CS_ROWS;
+    float s = 0.0f;
+    for (int r = 0; r < CS_ROWS && r0 + r < m; ++r) s += X[(r0 + r) * n + j];
+    part[(long)blockIdx.y * n + j] = s;
+}
+__global__ void colsum_final_kernel(int nparts, int n, const float *part, float *out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.0f;
+    for (int k = 0; k < nparts; ++k) s += part[(long)k * n + j];
+    out[j] = s;
+}
+
+// ------------------------------------------------------------------ LocoVal (one wave per sample)
+#define LV_IN 100
+#define LV_H1 49
+#define LV_H2 24
+
+// value_pose_net.py:73-103 _rotate_normalization + :141-147 forward_full input assembly
+__device__ __forceinline__ void locoval_input(int lane, const float *traj, int ts, const float *pose, const float *vel,
+                                              float *x /* LDS [100] */, float *ang_out) {
+    float xv = traj[ts + 0], yv = traj[ts + 1];
+    if (fabsf(xv) < 1e-10f) xv = 1e-10f;                 // epsilon guard on x (:79-83)
+    const float ang = atan2f(yv, xv);
+    const float c = cosf(ang), s = sinf(ang);
+    if (lane == 0 && ang_out) *ang_out = ang;
+    // bmm(v, R) with R = [[c, -s], [s, c]]:  (x, y) -> (x c + y s, -x s + y c)
+    if (lane < 13) {
+        const float px = traj[lane * ts], py = traj[lane * ts + 1];
+        x[2 * lane] = px * c + py * s;
+        x[2 * lane + 1] = -px * s + py * c;
+    }
+    if (lane < 24) {
+        const bool hidden = lane == 4 || lane == 8 || lane == 9 || lane == 10 || lane == 11;
+        const float px = pose[lane * 3], py = pose[lane * 3 + 1], pz = pose[lane * 3 + 2];
+        x[26 + lane * 3] = hidden ? 0.0f : px * c + py * s;
+        x[26 + lane * 3 + 1] = hidden ? 0.0f : -px * s + py * c;
+        x[26 + lane * 3 + 2] = hidden ? 0.0f : pz;
+    }
+    if (lane == 0) {
+        x[98] = vel[0] * c + vel[1] * s;
+        x[99] = -vel[0] * s + vel[1] * c;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+locoval_fwd_kernel(int B, const float *traj, int ts, const float *pose, const float *vel, const float *w1, const float *b1,
+                   const float *w2, const float *b2, const float *w3, const float *b3, float *value, float *x100,
+                   float *h1o, float *h2o, float *angle) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= B) return;
+    __shared__ float x[LV_IN], h1[LV_H1], h2[LV_H2];
+    locoval_input(lane, traj + (long)i * 13 * ts, ts, pose + (long)i * 72, vel + (long)i * 2, x, angle ? angle + i : nullptr);
+    __syncthreads();
+    for (int k = lane; k < LV_IN; k += 64) x100[(long)i * LV_IN + k] = x[k];
+    if (lane < LV_H1) {
+        float a = b1[lane];
+        for (int k = 0; k < LV_IN; ++k) a += w1[lane * LV_IN + k] * x[k];
+        a = a > 0.0f ? a : 0.0f;
+        h1[lane] = a; h1o[(long)i * LV_H1 + lane] = a;
+    }
+    __syncthreads();
+    if (lane < LV_H2) {
+        float a = b2[lane];
+        for (int k = 0; k < LV_H1; ++k) a += w2[lane * LV_H1 + k] * h1[k];
+        a = a > 0.0f ? a : 0.0f;
+        h2[lane] = a; h2o[(long)i * LV_H2 + lane] = a;
+    }
+    __syncthreads();
+    float p = lane < LV_H2 ? w3[lane] * h2[lane] : 0.0f;
+    p = wave_sum(p);
+    if (lane == 0) value[i] = 1.0f / (1.0f + expf(-(p + b3[0])));
+}
+
+// per-sample backward: writes this sample's parameter-gradient contribution to ws[i][6174] and d traj
+#define LV_NPARAM (LV_H1 * LV_IN + LV_H1 + LV_H2 * LV_H1 + LV_H2 + LV_H2 + 1)
+__global__ void __launch_bounds__(64)
+locoval_bwd_kernel(int B, const float *traj, int ts, const float *pose, const float *vel, const float *w1, const float *w2,
+                   const float *w3, const float *value, const float *x100, const float *h1, const float *h2,
+                   const float *angle, const float *dvalue, float *ws, float *dtraj) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= B) return;
+    __shared__ float x[LV_IN], d1[LV_H1], d2[LV_H2], dx[LV_IN];
+    for (int k = lane; k < LV_IN; k += 64) x[k] = x100[(long)i * LV_IN + k];
+    const float v = value[i];
+    const float dz3 = dvalue[i] * v * (1.0f - v);
+    float *g = ws + (long)i * LV_NPARAM;
+    float *gw1 = g, *gb1 = g + LV_H1 * LV_IN, *gw2 = gb1 + LV_H1, *gb2 = gw2 + LV_H2 * LV_H1, *gw3 = gb2 + LV_H2, *gb3 = gw3 + LV_H2;
+    if (lane < LV_H2) {
+        const float hv = h2[(long)i * LV_H2 + lane];
+        gw3[lane] = dz3 * hv;
+        const float dd = hv > 0.0f ? dz3 * w3[lane] : 0.0f;
+        d2[lane] = dd; gb2[lane] = dd;
+    }
+    if (lane == 0) gb3[0] = dz3;
+    __syncthreads();
+    if (lane < LV_H1) {
+        const float hv = h1[(long)i * LV_H1 + lane];
+        float a = 0.0f;
+        for (int j = 0; j < LV_H2; ++j) a += w2[j * LV_H1 + lane] * d2[j];
+        const float dd = hv > 0.0f ? a : 0.0f;
+        d1[lane] = dd; gb1[lane] = dd;
+        for (int j = 0; j < LV_H2; ++j) gw2[j * LV_H1 + lane] = d2[j] * hv;
+    }
+    __syncthreads();
+    for (int e = lane; e < LV_H1 * LV_IN; e += 64) { const int j = e / LV_IN, k = e - j * LV_IN; gw1[e] = d1[j] * x[k]; }
+    for (int k = lane; k < LV_IN; k += 64) {
+        float a = 0.0f;
+        for (int j = 0; j < LV_H1; ++j) a += w1[j * LV_IN + k] * d1[j];
+        dx[k] = a;
+    }
+    __syncthreads();
+    // back through the yaw normalisation to the trajectory (pose / velocity inputs carry no gradient in the loss)
+    const float *tr = traj + (long)i * 13 * ts, *po = pose + (long)i * 72, *ve = vel + (long)i * 2;
+    float *dt = dtraj + (long)i * 13 * ts;
+    const float ang = angle[i];
+    const float c = cosf(ang), s = sinf(ang);
+    float dth = 0.0f;   // d loss / d angle
+    if (lane < 13) {
+        const float px = tr[lane * ts], py = tr[lane * ts + 1], gx = dx[2 * lane], gy = dx[2 * lane + 1];
+        for (int k = 0; k < ts; ++k) dt[lane * ts + k] = 0.0f;
+        dt[lane * ts] = gx * c - gy * s;
+        dt[lane * ts + 1] = gx * s + gy * c;
+        dth += gx * (-px * s + py * c) + gy * (-px * c - py * s);
+    }
+    if (lane < 24) {
+        const bool hidden = lane == 4 || lane == 8 || lane == 9 || lane == 10 || lane == 11;
+        if (!hidden) {
+            const float px = po[lane * 3], py = po[lane * 3 + 1], gx = dx[26 + lane * 3], gy = dx[26 + lane * 3 + 1];
+            dth += gx * (-px * s + py * c) + gy * (-px * c - py * s);
+        }
+    }
+    if (lane == 0) dth += dx[98] * (-ve[0] * s + ve[1] * c) + dx[99] * (-ve[0] * c - ve[1] * s);
+    dth = wave_sum(dth);
+    __syncthreads();
+    if (lane == 0) {    // angle = atan2(y1, x1'), x1' = guarded x of waypoint 1
+        float xv = tr[ts], yv = tr[ts + 1];
+        const bool guarded = fabsf(xv) < 1e-10f;
+        if (guarded) xv = 1e-10f;
+        const float r2 = xv * xv + yv * yv;
+        if (!guarded) dt[ts] += dth * (-yv / r2);
+        dt[ts + 1] += dth * (xv / r2);
+    }
+}
+
+__global__ void locoval_reduce_kernel(int B, const float *ws, float *dparams) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= LV_NPARAM) return;
+    float s = 0.0f;
+    for (int i = 0; i < B; ++i) s += ws[(long)i * LV_NPARAM + p];
+    dparams[p] = s;
+}
+
+}  // namespace emloco

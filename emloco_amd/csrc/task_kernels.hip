@@ -117,10 +117,7 @@ post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_id
     __shared__ float sh_key[4][3];
 
     int64_t prog = t.progress_buf[env];
-    if (mode & EMLOCO_POST_ADVANCE) {
-        prog += 1;
-        if (lane == 0) t.progress_buf[env] = prog;
-    }
+    if (mode & EMLOCO_POST_ADVANCE) prog += 1;      // stored after the barrier below, once every lane has read it
     if (lane < TNB) {
         const float *src = t.rb_state + ((long)env * TNB + lane) * 13;
         for (int k = 0; k < 13; ++k) sh_body[lane][k] = src[k];
@@ -135,6 +132,7 @@ post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_id
         for (int k = 0; k < 3; ++k) sh_samp[lane][k] = s[k];
     }
     __syncthreads();
+    if ((mode & EMLOCO_POST_ADVANCE) && lane == 0) t.progress_buf[env] = prog;
     const float *root = sh_body[0];
 
     if (mode & EMLOCO_POST_OBS) {

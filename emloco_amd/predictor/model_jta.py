@@ -1,0 +1,191 @@
+"""TransMotionJTA: the Social-Transmotion trajectory predictor on the MI355X kernels.
+
+Mirror of social-transmotion/model_jta.py (live code :130-336): same constructor, same
+`forward(tgt, padding_mask, random_masking=False, limit_obs=0, frame_masking=False)`, same order of torch.rand
+draws for the stochastic masks (:205-264), same parameter names so reference checkpoints load
+(`local_former.layers.{i}.self_attn.in_proj_weight`, `linear1.weight`, `predict_head.{i}.weight`, ...).
+All projections, attention products, softmax and layer norms run through emloco_amd.predictor.ops.
+
+Key padding follows torch's semantics (bool mask = -inf, float mask = additive; a fully -inf row gives zeros as in
+torch >= 2.5 "safe softmax").  The reference passes a float 0/1 mask, so padded persons are biased, not removed.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class _SelfAttnParams(nn.Module):
+    """Parameter container with nn.MultiheadAttention's names."""
+
+    def __init__(self, d, nhead):
+        super().__init__()
+        self.embed_dim, self.num_heads = d, nhead
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = nn.Linear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+
+class EncoderLayer(nn.Module):
+    """Post-norm nn.TransformerEncoderLayer(d, nhead, ff, dropout, relu) (model_jta.py:177-185) on batch-first data."""
+
+    def __init__(self, d, nhead, dim_ff, dropout):
+        super().__init__()
+        self.self_attn = _SelfAttnParams(d, nhead)
+        self.linear1 = nn.Linear(d, dim_ff)
+        self.linear2 = nn.Linear(dim_ff, d)
+        self.norm1 = nn.LayerNorm(d)
+        self.norm2 = nn.LayerNorm(d)
+        self.p = dropout
+
+    def forward(self, x, key_pad):
+        sa = self.self_attn
+        qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
+        att = ops.AttentionFn.apply(qkv, key_pad, sa.num_heads)
+        a = ops.linear(att, sa.out_proj.weight, sa.out_proj.bias)
+        x = ops.layer_norm(F.dropout(a, self.p, self.training), x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        h = ops.linear(x, self.linear1.weight, self.linear1.bias, relu=True)
+        f = ops.linear(F.dropout(h, self.p, self.training), self.linear2.weight, self.linear2.bias)
+        return ops.layer_norm(F.dropout(f, self.p, self.training), x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+
+
+class Encoder(nn.Module):
+    def __init__(self, d, nhead, dim_ff, dropout, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([EncoderLayer(d, nhead, dim_ff, dropout) for _ in range(num_layers)])
+
+    def forward(self, x, key_pad):
+        for layer in self.layers:
+            x = layer(x, key_pad)
+        return x
+
+
+class _Enc(nn.Module):
+    """learned encodings (model_jta.py:61-128): nn.Embedding(max_norm=True) renormalises the looked-up rows in place"""
+
+    def __init__(self, n, d, name="learned_encoding"):
+        super().__init__()
+        setattr(self, name, nn.Embedding(n, d, max_norm=True))
+
+
+class TransMotionJTA(nn.Module):
+    def __init__(self, tok_dim=21, nhid=256, nhead=4, dim_feedfwd=1024, nlayers_local=2, nlayers_global=4, nmode=5, dropout=0.1,
+                 activation='relu', output_scale=1, obs_and_pred=21, num_tokens=47, device='cuda:0', multi_modal=False):
+        super().__init__()
+        assert activation == 'relu'
+        self.seq_len, self.nhid, self.output_scale, self.token_num = tok_dim, nhid, output_scale, num_tokens
+        self.joints_3dpose, self.joints_2dpose, self.obs_and_pred = 24, 22, 21
+        self.device, self.multi_modal, self.nmode = device, multi_modal, nmode
+        self.fc_in_traj = nn.Linear(2, nhid)
+        if multi_modal:
+            self.predict_head = nn.ModuleList([nn.Linear(nhid, 2) for _ in range(nmode)])
+        else:
+            self.fc_out_traj = nn.Linear(nhid, 2)
+        self.double_id_encoder = nn.Module()
+        self.double_id_encoder.learned_encoding = nn.Embedding(21, nhid // 2, max_norm=True)
+        self.double_id_encoder.person_encoding = nn.Embedding(1000, nhid // 2, max_norm=True)
+        self.id_encoder = nn.Module()
+        self.id_encoder.person_encoding = nn.Embedding(1000, nhid, max_norm=True)
+        self.fc_in_3dbb = nn.Linear(4, nhid)
+        self.bb3d_encoder = _Enc(9, nhid)
+        self.fc_in_2dbb = nn.Linear(4, nhid)
+        self.bb2d_encoder = _Enc(9, nhid)
+        self.fc_in_3dpose = nn.Linear(3, nhid)
+        self.pose3d_encoder = _Enc(216, nhid)
+        self.fc_in_2dpose = nn.Linear(2, nhid)
+        self.pose2d_encoder = _Enc(198, nhid)
+        self.local_former = Encoder(nhid, nhead, dim_feedfwd, dropout, nlayers_local)
+        self.global_former = Encoder(nhid, nhead, dim_feedfwd, dropout, nlayers_global)
+        self.dropout_p = dropout
+
+    @staticmethod
+    def _key_bias(padding_mask):
+        """torch's key_padding_mask semantics: bool -> -inf on True; float -> added to the scores as is.  The reference
+        hands over a FLOAT 0/1 mask (dataset_jta.py:86), i.e. a +1 bias on padded persons' keys; kept for parity."""
+        if padding_mask.dtype == torch.bool:
+            return torch.zeros(padding_mask.shape, device=padding_mask.device).masked_fill(padding_mask, float("-inf"))
+        return padding_mask.float()
+
+    def _drop(self, x):
+        return F.dropout(x, self.dropout_p, self.training)
+
+    def forward(self, tgt, padding_mask, random_masking=False, limit_obs=0, frame_masking=False):
+        dev = self.device
+        B, in_F, NJ, K = tgt.shape
+        Fr, J = self.obs_and_pred, self.token_num
+        out_F = Fr - in_F
+        N = NJ // J
+        i_idx = np.append(np.arange(0, in_F), np.repeat([in_F - 1], out_F))
+        tgt = tgt[:, i_idx].reshape(B, Fr, N, J, K).to(dev)
+        mr_traj = 0.2 if random_masking else 0
+        mr_joints = 0.2 if random_masking else 0
+        mr_mod = 0.3 if random_masking else 0
+        mr_frame = 0.2 if frame_masking else 0
+        R = lambda *s: torch.rand(s).float().to(dev)            # CPU draws moved to the device, as the reference does
+        tgt_traj = tgt[:, :, :, 0, :2]
+        tgt_traj = tgt_traj * (R(B, Fr, N) > mr_traj).unsqueeze(3)
+        frame_mask = (R(B, in_F) > mr_frame).unsqueeze(2).unsqueeze(3)
+        tgt_traj = torch.cat([tgt_traj[:, :in_F] * frame_mask, tgt_traj[:, in_F:]], dim=1)
+        sel = [(R(B, 1, N, 1) > mr_mod).unsqueeze(4) for _ in range(4)]
+        tgt_vis = tgt[:, :, :, 1:]
+        tgt_3dbb = tgt_vis[:, :, :, 0, :4] * sel[0][:, :, :, 0]
+        tgt_2dbb = tgt_vis[:, :, :, 1, :4] * sel[1][:, :, :, 0]
+        tgt_3dpose = tgt_vis[:, :, :, 2:26, :3] * sel[2]
+        tgt_2dpose = tgt_vis[:, :, :, 26:, :2] * sel[3]
+        tgt_3dpose = tgt_3dpose * (R(B, Fr, N, self.joints_3dpose) > mr_joints).unsqueeze(4)
+        tgt_2dpose = tgt_2dpose * (R(B, Fr, N, self.joints_2dpose) > mr_joints).unsqueeze(4)
+        if limit_obs != 0:
+            lm = torch.ones((B, Fr, N), device=dev)
+            lm[:, :(9 - limit_obs)] = 0
+            tgt_traj, tgt_3dbb, tgt_2dbb = tgt_traj * lm.unsqueeze(3), tgt_3dbb * lm.unsqueeze(3), tgt_2dbb * lm.unsqueeze(3)
+            tgt_3dpose, tgt_2dpose = tgt_3dpose * lm[..., None, None], tgt_2dpose * lm[..., None, None]
+
+        # input embeddings + learned encodings (model_jta.py:281-297)
+        half = self.nhid // 2
+        t = ops.linear(tgt_traj, self.fc_in_traj.weight, self.fc_in_traj.bias)                     # (B,F,N,d)
+        time_enc = self.double_id_encoder.learned_encoding(torch.arange(Fr, device=dev))             # (F, d/2) even channels
+        pers_enc = self.double_id_encoder.person_encoding(torch.arange(N, device=dev))               # (N, d/2) odd channels
+        enc = torch.zeros(Fr, N, self.nhid, device=dev)
+        enc[:, :, 0:half * 2:2] = time_enc.unsqueeze(1)
+        enc[:, :, 1:half * 2:2] = pers_enc.unsqueeze(0)
+        t = self._drop(t + enc.unsqueeze(0))
+        def emb(x, fc, encmod, n):
+            y = ops.linear(x, fc.weight, fc.bias)
+            return self._drop(y + encmod.learned_encoding(torch.arange(n, device=dev)).unsqueeze(1).unsqueeze(0))
+        bb3 = emb(tgt_3dbb[:, :9], self.fc_in_3dbb, self.bb3d_encoder, 9)                            # (B,9,N,d)
+        bb2 = emb(tgt_2dbb[:, :9], self.fc_in_2dbb, self.bb2d_encoder, 9)
+        p3 = tgt_3dpose[:, :9].transpose(2, 3).reshape(B, -1, N, 3)
+        p3 = emb(p3, self.fc_in_3dpose, self.pose3d_encoder, p3.shape[1])                            # (B,216,N,d)
+        p2 = tgt_2dpose[:, :9].transpose(2, 3).reshape(B, -1, N, 2)
+        p2 = emb(p2, self.fc_in_2dpose, self.pose2d_encoder, p2.shape[1])                            # (B,198,N,d)
+
+        # local former over S = 453 tokens of every person: batch-first (B*N, S, d)
+        seq = torch.cat((t, bb3, bb2, p3, p2), dim=1)                                                # (B,S,N,d)
+        S = seq.shape[1]
+        x = seq.permute(0, 2, 1, 3).reshape(B * N, S, self.nhid).contiguous()
+        pad = self._key_bias(padding_mask.to(dev))                                                   # (B, N) additive
+        pad_local = pad.reshape(-1, 1).expand(-1, S).contiguous()
+        out_local = self.local_former(x, pad_local) * self.output_scale + x
+        # global former over the N*21 trajectory tokens of each scene: (B, N*21, d), person-major like the reference
+        g = out_local[:, :21].reshape(B, N * 21, self.nhid).contiguous()
+        pad_global = pad.repeat_interleave(Fr, dim=1).contiguous()                                   # (B, N*21)
+        out_global = self.global_former(g, pad_global) * self.output_scale + g
+        out_primary = out_global.view(B, N, Fr, self.nhid)[:, 0]                                     # (B,F,d) primary agent
+        if self.multi_modal:
+            outs = [ops.linear(out_primary, h.weight, h.bias) for h in self.predict_head]
+            return torch.stack(outs, dim=2)                                                          # (B,F,M,2)
+        return ops.linear(out_primary, self.fc_out_traj.weight, self.fc_out_traj.bias).reshape(B, Fr, 1, 2)
+
+
+def create_model(config, logger=None):
+    """model_jta.py:548-577."""
+    m = config["MODEL"]
+    return TransMotionJTA(tok_dim=m["seq_len"], nhid=m["dim_hidden"], nhead=m["num_heads"], dim_feedfwd=m["dim_feedforward"],
+                          nlayers_local=m["num_layers_local"], nlayers_global=m["num_layers_global"], nmode=m.get("num_modes", 20),
+                          output_scale=m["output_scale"], obs_and_pred=config["TRAIN"]["input_track_size"] + config["TRAIN"]["output_track_size"],
+                          num_tokens=m["token_num"], device=config["DEVICE"], multi_modal=config.get("MULTI_MODAL", False)
+                          ).to(config["DEVICE"]).float()

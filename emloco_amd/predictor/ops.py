@@ -1,0 +1,248 @@
+"""torch.autograd.Function wrappers over the predictor kernels (include/emloco_predictor.h).
+
+PyTorch carries the autograd graph, device memory and the current stream; every contraction, softmax and
+layer norm below runs in libemloco_hip.so.  There is no fallback: without the library / a GPU these raise.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib as L
+from ..sim import current_stream_handle
+
+GEMM_BIAS, GEMM_RELU, GEMM_ACC = 1, 2, 4
+_bound = False
+
+
+def _lib():
+    global _bound
+    lib = L.require_device()
+    if not _bound:
+        vp, ci, cf, cl = C.c_void_p, C.c_int, C.c_float, C.c_int64
+        lib.emloco_gemm_f32.argtypes = [ci, ci, ci, ci, cf, vp, ci, cl, ci, vp, ci, cl, ci, vp, ci, cl, vp, ci, ci, vp, vp]
+        lib.emloco_softmax_fwd.argtypes = [ci, ci, ci, cf, vp, vp, vp, vp]
+        lib.emloco_softmax_bwd.argtypes = [ci, ci, cf, vp, vp, vp, vp]
+        lib.emloco_layernorm_fwd.argtypes = [ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.emloco_layernorm_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.emloco_colsum.argtypes = [ci, ci, vp, vp, vp, vp]
+        lib.emloco_locoval_fwd.argtypes = [ci, vp, ci] + [vp] * 14
+        lib.emloco_locoval_bwd.argtypes = [ci, vp, ci] + [vp] * 15
+        lib.emloco_locoval_bwd_workspace.argtypes = [ci]
+        lib.emloco_locoval_bwd_workspace.restype = C.c_int64
+        lib.emloco_gemm_enable_timing.argtypes = [ci]
+        lib.emloco_gemm_timing_stats.argtypes = [C.POINTER(ci), C.POINTER(cf), C.POINTER(C.c_double)]
+        _bound = True
+    return lib
+
+
+def _p(t, offset=0):
+    return None if t is None else C.c_void_p(t.data_ptr() + 4 * offset)
+
+
+def _st(t):
+    return current_stream_handle(t.device)
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise L.EmlocoError(f"{what} failed with code {rc}")
+
+
+def gemm(batch, m, n, k, A, lda, sa, ta, B, ldb, sb, tb, Cm, ldc, sc, alpha=1.0, bias=None, flags=0, ksplit=1,
+         a_off=0, b_off=0, c_off=0):
+    """Raw strided batched GEMM: C_b[m][n] (+)= alpha * sum_k A_b(m,k) B_b(n,k) (see the header for the layouts)."""
+    ws = None
+    if ksplit > 1:
+        ws = torch.empty(ksplit * batch * m * n, dtype=torch.float32, device=Cm.device)
+    rc = _lib().emloco_gemm_f32(batch, m, n, k, float(alpha), _p(A, a_off), lda, sa, ta, _p(B, b_off), ldb, sb, tb,
+                                _p(Cm, c_off), ldc, sc, _p(bias), flags, ksplit, _p(ws), _st(Cm))
+    _chk(rc, "emloco_gemm_f32")
+
+
+def _ksplit_for(red, out_elems):
+    """Split a long reduction so the launch has enough workgroups (>= ~512) without a huge workspace."""
+    tiles = max(1, (out_elems + 128 * 128 - 1) // (128 * 128))
+    want = max(1, 512 // tiles)
+    return int(max(1, min(want, red // 256, 64)))
+
+
+def colsum(X2d):
+    m, n = X2d.shape
+    out = torch.empty(n, dtype=torch.float32, device=X2d.device)
+    ws = torch.empty(((m + 255) // 256) * n, dtype=torch.float32, device=X2d.device)
+    _chk(_lib().emloco_colsum(m, n, _p(X2d), _p(out), _p(ws), _st(X2d)), "emloco_colsum")
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b (optionally ReLU); x (..., K), W (N, K)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu):
+        xs = x.shape
+        x2 = x.contiguous().view(-1, xs[-1])
+        M, K = x2.shape
+        N = W.shape[0]
+        Wc = W.contiguous()
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        flags = (GEMM_BIAS if b is not None else 0) | (GEMM_RELU if relu else 0)
+        gemm(1, M, N, K, x2, K, 0, 0, Wc, K, 0, 0, y, N, 0, bias=b.contiguous() if b is not None else None, flags=flags)
+        ctx.save_for_backward(x2, Wc, y if relu else None)
+        ctx.relu, ctx.has_bias, ctx.xs = relu, b is not None, xs
+        return y.view(*xs[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y = ctx.saved_tensors
+        M, K = x2.shape
+        N = W.shape[0]
+        dy2 = dy.contiguous().view(M, N)
+        if ctx.relu:
+            dy2 = dy2 * (y > 0)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+            gemm(1, M, K, N, dy2, N, 0, 0, W, K, 0, 1, dx, K, 0)          # dx = dy W
+            dx = dx.view(ctx.xs)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+            gemm(1, N, K, M, dy2, N, 0, 1, x2, K, 0, 1, dW, K, 0, ksplit=_ksplit_for(M, N * K))   # dW = dy^T x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
+        return dx, dW, db, None
+
+
+def linear(x, W, b=None, relu=False):
+    return LinearFn.apply(x, W, b, relu)
+
+
+class AttentionFn(torch.autograd.Function):
+    """Multi-head self attention core on packed projections.
+
+    qkv (Bn, S, 3*d) as produced by the in-projection (q | k | v), key_pad uint8 (Bn, S) or None -> (Bn, S, d).
+    Per head: scores = q k^T (MFMA GEMM) -> masked softmax -> P v (MFMA GEMM); heads are addressed by pointer
+    offset + leading dimension, so no permute copies are made.  P is kept for the backward (HBM is 288 GB)."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_pad, nhead):
+        Bn, S, d3 = qkv.shape
+        d = d3 // 3
+        dh = d // nhead
+        qkv = qkv.contiguous()
+        P = torch.empty((nhead, Bn, S, S), dtype=torch.float32, device=qkv.device)
+        out = torch.empty((Bn, S, d), dtype=torch.float32, device=qkv.device)
+        scale = 1.0 / float(dh) ** 0.5
+        lib = _lib()
+        for h in range(nhead):
+            Ph = P[h]
+            gemm(Bn, S, S, dh, qkv, d3, S * d3, 0, qkv, d3, S * d3, 0, Ph, S, S * S, a_off=h * dh, b_off=d + h * dh)
+            _chk(lib.emloco_softmax_fwd(Bn, S, S, scale, _p(Ph), _p(key_pad), _p(Ph), _st(qkv)), "emloco_softmax_fwd")
+            gemm(Bn, S, dh, S, Ph, S, S * S, 0, qkv, d3, S * d3, 1, out, d, S * d, b_off=2 * d + h * dh, c_off=h * dh)
+        ctx.save_for_backward(qkv, P)
+        ctx.nhead, ctx.scale = nhead, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, P = ctx.saved_tensors
+        nhead, scale = ctx.nhead, ctx.scale
+        Bn, S, d3 = qkv.shape
+        d = d3 // 3
+        dh = d // nhead
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dP = torch.empty((Bn, S, S), dtype=torch.float32, device=qkv.device)
+        lib = _lib()
+        for h in range(nhead):
+            Ph = P[h]
+            # dP = dO v^T ; dV = P^T dO
+            gemm(Bn, S, S, dh, dout, d, S * d, 0, qkv, d3, S * d3, 0, dP, S, S * S, a_off=h * dh, b_off=2 * d + h * dh)
+            gemm(Bn, S, dh, S, Ph, S, S * S, 1, dout, d, S * d, 1, dqkv, d3, S * d3, b_off=h * dh, c_off=2 * d + h * dh)
+            _chk(lib.emloco_softmax_bwd(Bn * S, S, scale, _p(Ph), _p(dP), _p(dP), _st(qkv)), "emloco_softmax_bwd")
+            # dQ = dS k ; dK = dS^T q
+            gemm(Bn, S, dh, S, dP, S, S * S, 0, qkv, d3, S * d3, 1, dqkv, d3, S * d3, b_off=d + h * dh, c_off=h * dh)
+            gemm(Bn, S, dh, S, dP, S, S * S, 1, qkv, d3, S * d3, 1, dqkv, d3, S * d3, b_off=h * dh, c_off=d + h * dh)
+        return dqkv, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x + res) * gamma + beta (post-norm encoder layer)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        shp = x.shape
+        d = shp[-1]
+        x2 = x.contiguous().view(-1, d)
+        r2 = res.contiguous().view(-1, d) if res is not None else None
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _chk(_lib().emloco_layernorm_fwd(rows, d, float(eps), _p(x2), _p(r2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd),
+                                         _st(x)), "emloco_layernorm_fwd")
+        xr = x2 + r2 if r2 is not None else x2
+        ctx.save_for_backward(xr, gamma, mean, rstd)
+        ctx.has_res, ctx.shp = res is not None, shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, gamma, mean, rstd = ctx.saved_tensors
+        rows, d = xr.shape
+        dy2 = dy.contiguous().view(rows, d)
+        dxr = torch.empty_like(xr)
+        dg = torch.empty(d, dtype=torch.float32, device=dy.device)
+        db = torch.empty(d, dtype=torch.float32, device=dy.device)
+        ws = torch.empty(((rows + 63) // 64) * 2 * d, dtype=torch.float32, device=dy.device)
+        _chk(_lib().emloco_layernorm_bwd(rows, d, _p(xr), _p(gamma), _p(mean), _p(rstd), _p(dy2), _p(dxr), _p(dg), _p(db), _p(ws),
+                                         _st(dy)), "emloco_layernorm_bwd")
+        dxr = dxr.view(ctx.shp)
+        return dxr, (dxr if ctx.has_res else None), dg, db, None
+
+
+def layer_norm(x, res, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, res, gamma, beta, eps)
+
+
+class LocoValFn(torch.autograd.Function):
+    """Fused LocoVal forward/backward; gradients flow to the six parameters and to the trajectory."""
+
+    @staticmethod
+    def forward(ctx, traj, pose, vel, w1, b1, w2, b2, w3, b3):
+        B = traj.shape[0]
+        ts = traj.shape[-1]
+        traj_c, pose_c, vel_c = traj.contiguous().float(), pose.contiguous().float(), vel.contiguous().float()
+        dev = traj.device
+        value = torch.empty(B, device=dev)
+        x100, h1, h2, ang = torch.empty(B, 100, device=dev), torch.empty(B, 49, device=dev), torch.empty(B, 24, device=dev), torch.empty(B, device=dev)
+        ps = [t.contiguous() for t in (w1, b1, w2, b2, w3, b3)]
+        _chk(_lib().emloco_locoval_fwd(B, _p(traj_c), ts, _p(pose_c), _p(vel_c), *[_p(t) for t in ps], _p(value), _p(x100), _p(h1), _p(h2),
+                                       _p(ang), _st(traj)), "emloco_locoval_fwd")
+        ctx.save_for_backward(traj_c, pose_c, vel_c, ps[0], ps[2], ps[4], value, x100, h1, h2, ang)
+        ctx.mark_non_differentiable(x100)
+        return value.view(B, 1), x100
+
+    @staticmethod
+    def backward(ctx, dvalue, _dx100):
+        traj, pose, vel, w1, w2, w3, value, x100, h1, h2, ang = ctx.saved_tensors
+        B, ts = traj.shape[0], traj.shape[-1]
+        dev = traj.device
+        dparams = torch.empty(6174, device=dev)
+        dtraj = torch.empty_like(traj)
+        ws = torch.empty(B * 6174, device=dev)
+        dv = dvalue.contiguous().view(B).float()
+        _chk(_lib().emloco_locoval_bwd(B, _p(traj), ts, _p(pose), _p(vel), _p(w1), _p(w2), _p(w3), _p(value), _p(x100), _p(h1), _p(h2), _p(ang),
+                                       _p(dv), _p(dparams), _p(dtraj), _p(ws), _st(traj)), "emloco_locoval_bwd")
+        o = [0, 4900, 4949, 6125, 6149, 6173, 6174]
+        g = [dparams[o[i]:o[i + 1]] for i in range(6)]
+        return (dtraj, None, None, g[0].view(49, 100), g[1], g[2].view(24, 49), g[3], g[4].view(1, 24), g[5])
+
+
+def gemm_timing(enable=None):
+    lib = _lib()
+    if enable is not None:
+        _chk(lib.emloco_gemm_enable_timing(int(enable)), "emloco_gemm_enable_timing")
+        return None
+    n, ms, fl = C.c_int(), C.c_float(), C.c_double()
+    _chk(lib.emloco_gemm_timing_stats(C.byref(n), C.byref(ms), C.byref(fl)), "emloco_gemm_timing_stats")
+    return n.value, ms.value, fl.value

@@ -1,0 +1,131 @@
+"""One `train_jta.py` iteration: batch normalisation, predictor forward, EmLoco loss, backward, clip, Adam.
+
+Mirror of social-transmotion/train_jta.py (compute_loss :98-127, nan_handler :143-165, train loop body :245-320),
+dataset_jta.py (batch_process_coords :27-86) and utils/metrics.py (MSE_LOSS / MSE_LOSS_MULTI :4-26).  Host control
+flow is the reference's; the arithmetic of the model and of the LocoVal loss runs in the HIP kernels behind
+TransMotionJTA / ValuePoseNet.  For data-parallel training `step` all-reduces one flat gradient bucket (RCCL).
+"""
+import torch
+
+from ..dist import FlatGradBucket
+
+
+def MSE_LOSS(output, target, mask=None):
+    pred_xy = output[:, :, 0, :2]
+    gt_xy = target[:, :, 0, :2]
+    norm = torch.norm(pred_xy - gt_xy, p=2, dim=-1)
+    return torch.mean(torch.mean(norm, dim=-1)) * 100
+
+
+def MSE_LOSS_MULTI(output, target, mask=None):
+    pred_xys = output[:, :, :, :2]
+    gt_xys = target[:, :, 0, :2].unsqueeze(2).repeat(1, 1, pred_xys.size(2), 1)
+    norm = torch.norm(pred_xys - gt_xys, p=2, dim=-1)
+    mean_K = torch.mean(norm, dim=1)
+    return torch.mean(torch.min(mean_K, dim=1)[0]) * 100
+
+
+def batch_process_coords(coords, masks, padding_mask, config, modality_selection='traj+all', training=False, multiperson=True):
+    joints = coords.to(config["DEVICE"]).clone()
+    masks = masks.to(config["DEVICE"])
+    in_F = config["TRAIN"]["input_track_size"]
+    joints[:, :, :, 0] = joints[:, :, :, 0] - joints[:, 0:1, (in_F - 1):in_F, 0]          # primary pelvis at t = in_F-1
+    joints[:, :, :, 1:3] = joints[:, :, :, 1:3] - joints[:, :, (in_F - 1):in_F, 1:3]
+    joints[:, :, :, 3:27] = joints[:, :, :, 3:27] - joints[:, :, (in_F - 1):in_F, 3:27]
+    joints[:, :, :, 27:] = joints[:, :, :, 27:] - joints[:, :, (in_F - 1):in_F, 27:]
+    B, N, F, J, K = joints.shape
+    if not training:
+        sel = {'traj+all': [], 'traj': [slice(1, None)], 'traj+2dbox': [slice(1, 2), slice(3, None)],
+               'traj+3dpose': [slice(1, 3), slice(27, None)], 'traj+2dpose': [slice(1, 27)],
+               'traj+3dpose+3dbox': [slice(2, 3), slice(27, None)], 'traj+2dpose+3dpose': [slice(1, 3)]}
+        if modality_selection not in sel:
+            raise ValueError('modality error')
+        for s in sel[modality_selection]:
+            joints[:, :, :, s] = 0
+    joints = joints.transpose(1, 2).reshape(B, F, N * J, K)
+    masks = masks.transpose(1, 2).reshape(B, F, N * J)
+    out_F = config["TRAIN"]["output_track_size"]
+    return (joints[:, :in_F].float(), masks[:, :in_F].float(), joints[:, in_F:in_F + out_F].float(),
+            masks[:, in_F:in_F + out_F].float(), padding_mask.float())
+
+
+def nan_handler(pred_traj, init_pose, init_vel):
+    if len(pred_traj.shape) == 3:
+        nan_traj = torch.isnan(pred_traj).any(dim=1).any(dim=1)
+    else:
+        nan_traj = torch.isnan(pred_traj).any(dim=1).any(dim=1).any(dim=1)
+    nan_mask = nan_traj | torch.isnan(init_pose).any(dim=1).any(dim=1) | torch.isnan(init_vel).any(dim=1)
+    if nan_mask.any():
+        pred_traj, init_pose, init_vel = pred_traj[~nan_mask], init_pose[~nan_mask], init_vel[~nan_mask]
+    zero = torch.all(init_pose == 0, dim=1).all(dim=1)
+    if zero.any():
+        pred_traj, init_pose, init_vel = pred_traj[~zero], init_pose[~zero], init_vel[~zero]
+    return pred_traj, init_pose, init_vel
+
+
+def compute_loss(model, config, in_joints, out_joints, in_masks, out_masks, padding_mask, mode='val', limit_obs=False):
+    in_F = in_joints.shape[1]
+    random_masking = mode == 'train'
+    if torch.isnan(in_joints).any():
+        in_joints = torch.where(torch.isnan(in_joints), torch.zeros_like(in_joints), in_joints)
+    pred = model(in_joints, padding_mask, random_masking, limit_obs=limit_obs, frame_masking=config.get('USE_FRAME_MASK', False))
+    loss_fn = MSE_LOSS_MULTI if config.get("MULTI_MODAL", False) else MSE_LOSS
+    return loss_fn(pred[:, in_F:], out_joints, out_masks), pred
+
+
+def emloco_loss(config, valuenet, pred_joints, primary_init_pose, primary_init_vel, in_F):
+    """train_jta.py:288-308."""
+    dev = pred_joints.device
+    w = config["TRAIN"].get("valuenet_weight", 1.0)
+    if config.get("MULTI_MODAL", False):
+        pred_trajs = pred_joints[:, in_F:]
+        pred_trajs = torch.cat([torch.zeros(pred_trajs.size(0), 1, pred_trajs.size(2), 2, device=dev), pred_trajs], dim=1)
+        pred_trajs, pose, vel = nan_handler(pred_trajs, primary_init_pose, primary_init_vel)
+        total = 0
+        for i in range(pred_trajs.size(2)):
+            _, vl = valuenet.calc_embodied_motion_loss(pred_trajs[:, :, i].contiguous(), pose, vel)
+            total = total + vl
+        total = total * w
+        return total / pred_trajs.size(2) if pred_trajs.size(2) else 0
+    pred_traj = pred_joints[:, in_F:].squeeze(2)
+    pred_traj = torch.cat([torch.zeros(pred_traj.size(0), 1, 2, device=dev), pred_traj], dim=1)
+    pred_traj, pose, vel = nan_handler(pred_traj, primary_init_pose, primary_init_vel)
+    _, vl = valuenet.calc_embodied_motion_loss(pred_traj, pose, vel)
+    return vl * w
+
+
+class EmLocoTrainer:
+    """Adam(lr) + clip_grad_norm_(max_grad_norm) (train_jta.py:317-318,411) around the loss above."""
+
+    def __init__(self, model, valuenet, config, data_parallel=False):
+        self.model, self.valuenet, self.config = model, valuenet, config
+        if valuenet is not None:
+            valuenet.eval()
+            for p in valuenet.parameters():
+                p.requires_grad_(False)          # the LocoVal weights are frozen while the predictor trains (train_jta.py:197-204)
+        self.optimizer = torch.optim.Adam(model.parameters(), lr=config["TRAIN"]["lr"])
+        self.bucket = FlatGradBucket(model.parameters()) if data_parallel else None
+
+    def step(self, joints, masks, padding_mask, modality_selection='traj+all'):
+        cfg = self.config
+        self.model.train()
+        if self.bucket is not None:
+            self.bucket.zero()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+        in_joints, in_masks, out_joints, out_masks, pm = batch_process_coords(joints, masks, padding_mask, cfg, modality_selection, training=True)
+        pose = joints[:, 0, 8, 3:27, :3].clone().to(cfg["DEVICE"])
+        pose[..., 2] *= -1
+        vel = ((in_joints[:, 8, 0, :2] - in_joints[:, 7, 0, :2]) * 2.5).clone()
+        mse, pred = compute_loss(self.model, cfg, in_joints, out_joints, in_masks, out_masks, pm.to(cfg["DEVICE"]), mode='train')
+        loss = mse.clone()
+        if self.valuenet is not None:
+            vl = emloco_loss(cfg, self.valuenet, pred, pose, vel, in_joints.shape[1])
+            if torch.is_tensor(vl) and not torch.isnan(vl.mean()):
+                loss = loss + vl[~torch.isnan(vl)].mean()
+        loss.backward()
+        if self.bucket is not None:
+            self.bucket.all_reduce(average=True)
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg["TRAIN"]["max_grad_norm"])
+        self.optimizer.step()
+        return loss.detach(), mse.detach()

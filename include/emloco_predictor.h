@@ -1,0 +1,80 @@
+/*
+ * emloco_predictor.h -- C ABI of libemloco_hip.so, part 3: the Social-Transmotion + LocoVal kernels (boundary 2).
+ *
+ * The host side keeps the reference's Python classes (social-transmotion/model_jta.py:130-336 TransMotionJTA,
+ * pacer/pacer/learning/value_pose_net.py:10-159 ValuePoseNet) and calls these entry points from
+ * torch.autograd.Function wrappers; PyTorch only carries the autograd graph and device memory.
+ * All pointers are device memory, fp32, row-major; `stream` is a hipStream_t (0 = default).
+ * Return 0 on success, negative on bad arguments / HIP errors (emloco_last_error()).
+ */
+#ifndef EMLOCO_PREDICTOR_H
+#define EMLOCO_PREDICTOR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { EMLOCO_GEMM_BIAS = 1, EMLOCO_GEMM_RELU = 2, EMLOCO_GEMM_ACCUMULATE = 4 };
+
+/* Batched strided GEMM on the matrix cores, fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: exact fp32):
+ *   C[b][m][n] (+)= alpha * sum_k A_b(m,k) * B_b(n,k)   [+ bias[n]] [relu]
+ *   A_b(m,k) = trans_a ? A[b*sa + k*lda + m] : A[b*sa + m*lda + k]
+ *   B_b(n,k) = trans_b ? B[b*sb + k*ldb + n] : B[b*sb + n*ldb + k]
+ * i.e. with trans_a = trans_b = 0 this is  C = A . B^T  (nn.Linear: y = x W^T, model_jta.py:145-174 and every
+ * nn.TransformerEncoderLayer projection :177-185).  `ksplit` > 1 splits the k range over ksplit partial
+ * products written to `workspace` [ksplit][batch][m][n] and summed in a fixed order (deterministic);
+ * workspace may be NULL when ksplit == 1. */
+int emloco_gemm_f32(int batch, int m, int n, int k, float alpha,
+                    const float *A, int lda, int64_t stride_a, int trans_a,
+                    const float *B, int ldb, int64_t stride_b, int trans_b,
+                    float *C, int ldc, int64_t stride_c,
+                    const float *bias, int flags, int ksplit, float *workspace, void *stream);
+
+/* Row softmax of attention scores with an additive per-key bias (nn.MultiheadAttention's key_padding_mask):
+ *   P[r][j] = softmax_j(scale * S[r][j] + key_bias[seq(r)][j]);  a row whose keys are all -inf gives zeros.
+ * torch semantics: a BOOL padding mask means -inf on padded keys, a FLOAT mask is ADDED to the scores -- and the
+ * reference passes a float 0/1 mask (dataset_jta.py:86 `padding_mask.float()`, model_jta.py:299-300,311,317), so
+ * its "padded" keys are biased by +1, not removed.  rows = n_seq * rows_per_seq; key_bias f32 [n_seq][cols] or NULL.
+ * In place allowed (P == S). */
+int emloco_softmax_fwd(int n_seq, int rows_per_seq, int cols, float scale, const float *S, const float *key_bias,
+                       float *P, void *stream);
+/* dS = scale * P * (dP - sum_j(dP * P)) ; in place allowed (dS == dP) */
+int emloco_softmax_bwd(int rows, int cols, float scale, const float *P, const float *dP, float *dS, void *stream);
+
+/* y = LayerNorm(x + res) * gamma + beta over the last dim (post-norm encoder layer, d <= 1024);
+ * res may be NULL.  Saves mean / rstd [rows] for the backward. */
+int emloco_layernorm_fwd(int rows, int d, float eps, const float *x, const float *res, const float *gamma,
+                         const float *beta, float *y, float *mean, float *rstd, void *stream);
+/* dxr = dL/d(x+res); dgamma/dbeta are reduced over rows in a fixed order.  xr = x + res (the fwd input sum)
+ * is recomputed from y:  xhat = (y - beta) / gamma is avoided -- pass the saved sum `xr`. */
+int emloco_layernorm_bwd(int rows, int d, const float *xr, const float *gamma, const float *mean, const float *rstd,
+                         const float *dy, float *dxr, float *dgamma, float *dbeta, float *workspace, void *stream);
+
+/* column sums: out[n] = sum_m X[m][n]  (bias gradients), fixed reduction order */
+int emloco_colsum(int m, int n, const float *X, float *out, float *workspace, void *stream);
+
+/* LocoVal MLP (value_pose_net.py:36-159), fused: yaw normalisation (:73-103) + hidden joints zeroed (:141-144)
+ * + 100->49->24->1 MLP with ReLU/ReLU/sigmoid.  traj [B][13][traj_stride>=2], pose [B][24][3], vel [B][2].
+ * Outputs value [B]; x100 [B][100] (normalised MLP input) and h1 [B][49], h2 [B][24] are kept for the backward. */
+int emloco_locoval_fwd(int B, const float *traj, int traj_stride, const float *pose, const float *vel,
+                       const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                       float *value, float *x100, float *h1, float *h2, float *angle, void *stream);
+/* Backward: given dvalue [B] -> gradients of the 6 parameter tensors (summed over the batch, fixed order, written
+ * to dparams = [dw1 4900 | db1 49 | dw2 1176 | db2 24 | dw3 24 | db3 1]) and d traj [B][13][traj_stride]
+ * (the gradient that reaches the predicted trajectory in the EmLoco loss, train_jta.py:288-308). */
+int emloco_locoval_bwd(int B, const float *traj, int traj_stride, const float *pose, const float *vel,
+                       const float *w1, const float *w2, const float *w3,
+                       const float *value, const float *x100, const float *h1, const float *h2, const float *angle,
+                       const float *dvalue, float *dparams, float *dtraj, float *workspace, void *stream);
+/* bytes of workspace emloco_locoval_bwd needs for batch B */
+int64_t emloco_locoval_bwd_workspace(int B);
+
+/* HIP-event timing of the GEMM launches (same protocol as emloco_sim_timing_stats) */
+int emloco_gemm_enable_timing(int on);
+int emloco_gemm_timing_stats(int *n_launches, float *total_ms, double *total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

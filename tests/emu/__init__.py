@@ -8,8 +8,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _SO = os.path.join(_HERE, "_build", "libemu.so")
-_SRCS = ["emu_sim.cpp", "emu_task.cpp", "emu_runtime.cpp", "hip/hip_runtime.h"]
-_KERNELS = ["sim_kernels.hip", "task_kernels.hip", "dev_math.h", "emloco_types.h", "topology.h"]
+_SRCS = ["emu_sim.cpp", "emu_task.cpp", "emu_predictor.cpp", "emu_runtime.cpp", "hip/hip_runtime.h"]
+_KERNELS = ["sim_kernels.hip", "task_kernels.hip", "predictor_kernels.hip", "dev_math.h", "emloco_types.h", "topology.h"]
 
 
 def build():
@@ -18,7 +18,7 @@ def build():
     if not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
         cpps = [os.path.join(_HERE, s) for s in _SRCS if s.endswith(".cpp") and os.path.exists(os.path.join(_HERE, s))]
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-ffp-contract=off",
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-ffp-contract=off", "-Wno-psabi",
                                "-I", _HERE, "-o", _SO] + cpps + ["-lpthread"])
     return _SO
 

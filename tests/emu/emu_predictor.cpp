@@ -1,0 +1,58 @@
+// TEST INFRASTRUCTURE ONLY: runs emloco_amd/csrc/predictor_kernels.hip on the CPU through tests/emu/hip/.
+#include "hip/hip_runtime.h"
+#include "../../emloco_amd/csrc/predictor_kernels.hip"
+
+using namespace emloco;
+
+extern "C" int emu_gemm_f32(int batch, int m, int n, int k, float alpha, const float *A, int lda, long sa, int ta,
+                            const float *B, int ldb, long sb, int tb, float *C, int ldc, long sc, const float *bias,
+                            int flags, int ksplit, float *ws) {
+    GemmArgs g{batch, m, n, k, alpha, A, lda, sa, ta, B, ldb, sb, tb, C, ldc, sc, bias, flags, ksplit, ws};
+    const unsigned gx = (n + GBN - 1) / GBN, gy = (m + GBM - 1) / GBM, gz = batch * ksplit;
+    for (unsigned z = 0; z < gz; ++z)
+        for (unsigned y = 0; y < gy; ++y)
+            for (unsigned x = 0; x < gx; ++x) {
+                emu::launch(1, 256, [&] { blockIdx.x = x; blockIdx.y = y; blockIdx.z = z; gemm_f32_kernel(g); });
+            }
+    blockIdx.y = 0; blockIdx.z = 0;
+    if (ksplit > 1) {
+        const long total = (long)batch * m * n;
+        emu::launch((unsigned)((total + 255) / 256), 256, [&] { gemm_splitk_reduce_kernel(g); });
+    }
+    return 0;
+}
+
+extern "C" int emu_softmax_fwd(int n_seq, int rps, int cols, float scale, const float *S, const float *kp, float *P) {
+    const long rows = (long)n_seq * rps;
+    emu::launch((unsigned)((rows + 3) / 4), 256, [&] { softmax_fwd_kernel((int)rows, rps, cols, scale, S, kp, P); });
+    return 0;
+}
+extern "C" int emu_softmax_bwd(int rows, int cols, float scale, const float *P, const float *dP, float *dS) {
+    emu::launch((unsigned)((rows + 3) / 4), 256, [&] { softmax_bwd_kernel(rows, cols, scale, P, dP, dS); });
+    return 0;
+}
+extern "C" int emu_layernorm_fwd(int rows, int d, float eps, const float *x, const float *res, const float *g, const float *b,
+                                 float *y, float *mean, float *rstd) {
+    emu::launch((unsigned)((rows + 3) / 4), 256, [&] { layernorm_fwd_kernel(rows, d, eps, x, res, g, b, y, mean, rstd); });
+    return 0;
+}
+extern "C" int emu_layernorm_bwd(int rows, int d, const float *xr, const float *g, const float *mean, const float *rstd,
+                                 const float *dy, float *dxr, float *dg, float *db, float *ws) {
+    const int nb = (rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
+    emu::launch((unsigned)nb, 256, [&] { layernorm_bwd_kernel(rows, d, xr, g, mean, rstd, dy, dxr, ws); });
+    emu::launch((unsigned)((d + 255) / 256), 256, [&] { layernorm_bwd_reduce_kernel(nb, d, ws, dg, db); });
+    return 0;
+}
+extern "C" int emu_locoval_fwd(int B, const float *traj, int ts, const float *pose, const float *vel, const float *w1,
+                               const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                               float *value, float *x100, float *h1, float *h2, float *angle) {
+    emu::launch((unsigned)B, 64, [&] { locoval_fwd_kernel(B, traj, ts, pose, vel, w1, b1, w2, b2, w3, b3, value, x100, h1, h2, angle); });
+    return 0;
+}
+extern "C" int emu_locoval_bwd(int B, const float *traj, int ts, const float *pose, const float *vel, const float *w1,
+                               const float *w2, const float *w3, const float *value, const float *x100, const float *h1,
+                               const float *h2, const float *angle, const float *dvalue, float *dparams, float *dtraj, float *ws) {
+    emu::launch((unsigned)B, 64, [&] { locoval_bwd_kernel(B, traj, ts, pose, vel, w1, w2, w3, value, x100, h1, h2, angle, dvalue, ws, dtraj); });
+    emu::launch((unsigned)((LV_NPARAM + 255) / 256), 256, [&] { locoval_reduce_kernel(B, ws, dparams); });
+    return 0;
+}

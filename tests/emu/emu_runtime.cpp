@@ -8,6 +8,7 @@ emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 namespace emu {
 uint64_t g_xbuf[1024];
+uint64_t g_ybuf[1024];
 
 static ucontext_t g_sched;
 static std::vector<ucontext_t> g_ctx;

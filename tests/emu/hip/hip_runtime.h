@@ -63,3 +63,30 @@ static inline int __float_as_int(float f) { int x; std::memcpy(&x, &f, 4); retur
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 using std::fabs; using std::sqrt; using std::floor; using std::ceil;
+
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; result fragment
+// col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5); exact fp32 fmaf chain in k order (cdna_hip_programming.md section 3).
+namespace emu { extern uint64_t g_ybuf[1024]; }
+typedef float emu_f32x16 __attribute__((vector_size(64)));
+static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c, int, int, int) {
+    const unsigned tid = threadIdx.x, base = tid & ~63u, lane = tid & 63u;
+    uint64_t ra = 0, rb = 0;
+    std::memcpy(&ra, &a, 4); std::memcpy(&rb, &b, 4);
+    emu::g_xbuf[tid] = ra; emu::g_ybuf[tid] = rb;
+    emu::barrier();
+    emu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (int)(lane >> 5), col = (int)(lane & 31);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            std::memcpy(&av, &emu::g_xbuf[base + row + 32 * k], 4);
+            std::memcpy(&bv, &emu::g_ybuf[base + col + 32 * k], 4);
+            acc = std::fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    emu::barrier();
+    return d;
+}
+using std::exp; using std::cos; using std::sin; using std::atan2;

@@ -1,0 +1,196 @@
+"""CPU execution of the HIP kernel sources (tests/emu) against the oracle, numpy and the reference's golden vectors.
+
+There is no GPU in the build container; the emulator compiles emloco_amd/csrc/*_kernels.hip with g++ and runs one
+workgroup as 64/256 lock-step fibers (wave shuffles, ballots, LDS, barriers and the fp32 MFMA are emulated), so the
+kernels' logic is covered by the `-m "not gpu"` suite.  The same checks run on the real MI355X in tests/test_gpu_*.py.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import emu
+import oracle
+from helpers import oracle_sim, scene_state, varied_models
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def test_sim_step_kernel_is_bit_exact_vs_oracle():
+    E = 3
+    models = varied_models(E, seed=2)
+    root, dof, tgt = scene_state(E, seed=4)
+    a = oracle_sim(models, root, dof, tgt, n_sub=4)
+    b = oracle_sim(models, root, dof, tgt, n_sub=4)
+    for _ in range(2):
+        a.step(1)
+        emu.sim_step(b, 1)
+    for name in ("root_state", "dof_state", "rb_state", "contact_force", "dof_force", "lambda_ws"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert np.abs(a.contact_force).max() > 50
+
+
+def test_sim_fk_kernel_matches_oracle():
+    E = 2
+    models = varied_models(E, seed=5)
+    root, dof, tgt = scene_state(E, seed=6, perturbed_from=0)
+    a = oracle_sim(models, root, dof, tgt)
+    b = oracle_sim(models, root, dof, tgt)
+    a.fk()
+    emu.sim_fk(b)
+    assert np.array_equal(a.rb_state, b.rb_state)
+
+
+def test_post_physics_kernel_matches_reference_golden(golden):
+    from emloco_amd import _lib as L
+    g, gt, gs = golden("self_obs"), golden("terrain_heights"), golden("traj_samples")
+    E = 16
+    th = emu.TaskHost(E, gt["heightfield"])
+    th.rb_state[:] = np.concatenate([g["body_pos"], g["body_rot"], g["body_vel"], g["body_ang_vel"]], -1)
+    th.betas[:] = g["betas"]
+    th.traj_verts[:] = gs["verts"]
+    th.progress[:] = gs["progress"] - 1          # ADVANCE brings it to the fixture's value
+    rng = np.random.default_rng(0)
+    th.dof_state[:] = rng.normal(size=(E, 69, 2))
+    th.dof_force[:] = rng.normal(size=(E, 69)) * 30
+    th.contact_force[:, 11] = rng.normal(size=(E, 3)) * 40
+    th.amp[:] = rng.normal(size=th.amp.shape)
+    amp_before = th.amp.copy()
+    th.post_physics(L.POST_STEP)
+    np.testing.assert_array_equal(th.progress, gs["progress"])
+    np.testing.assert_allclose(th.obs[:, :368], g["obs"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(th.flip_obs[:, :368], g["flip_obs"], rtol=1e-5, atol=2e-5)
+    root_states = np.concatenate([g["body_pos"][:, 0], g["body_rot"][:, 0], g["body_vel"][:, 0], g["body_ang_vel"][:, 0]], -1)
+    np.testing.assert_allclose(th.obs[:, 368:398], oracle.location_obs(root_states, gs["samples"]), rtol=1e-5, atol=2e-5)
+    head = np.concatenate([g["body_pos"][:, 13], g["body_rot"][:, 13]], -1)
+    hf = gt["heightfield"]
+    ho = oracle.height_obs(oracle.get_center_heights(root_states, hf), oracle.get_heights(head, hf))
+    np.testing.assert_allclose(th.obs[:, 398:], ho, rtol=1e-6, atol=1e-5)
+    np.testing.assert_array_equal(th.flip_obs[:, 368:], oracle.flip_task_obs(th.obs[:, 368:]))
+    tar = oracle.traj_calc_pos(gs["verts"], gs["progress"], th.dt, th.traj_dur)
+    rew, raw = oracle.reward(g["body_pos"][:, 0], tar, th.dof_force, th.dof_state[:, :, 1])
+    np.testing.assert_allclose(th.rew, rew, rtol=1e-5, atol=1e-6)
+    rs, tm = oracle.reset(gs["progress"], th.contact_force, g["body_pos"], tar)
+    np.testing.assert_array_equal(th.reset, rs)
+    np.testing.assert_array_equal(th.terminate, tm)
+    amp = oracle.amp_obs(g["body_pos"][:, 0], g["body_rot"][:, 0], g["body_vel"][:, 0], g["body_ang_vel"][:, 0],
+                         th.dof_state[:, :, 0], th.dof_state[:, :, 1], g["body_pos"][:, [7, 3, 22, 17]], g["betas"], th.dof_subset)
+    np.testing.assert_allclose(th.amp[:, 0], amp, rtol=1e-5, atol=2e-5)
+    np.testing.assert_array_equal(th.amp[:, 1:], amp_before[:, :-1])
+
+
+def test_pd_targets_kernel_matches_reference_golden(golden):
+    g = golden("pd_targets")
+    zero = np.zeros(69, np.uint8)
+    for j in (3, 7, 17, 22):
+        zero[3 * j:3 * j + 3] = 1
+    np.testing.assert_allclose(emu.task_pd_targets(g["actions"], g["offset"], g["scale"], zero), g["pd_tar"], rtol=1e-6, atol=1e-6)
+
+
+def _gemm(A, B, ta, tb, m, n, k, batch=1, bias=None, flags=0, ksplit=1, alpha=1.0):
+    lib = emu.lib()
+    out = np.zeros((batch, m, n), np.float32)
+    ws = np.zeros((max(ksplit, 1), batch, m, n), np.float32)
+    lib.emu_gemm_f32.argtypes = [C.c_int] * 4 + [C.c_float, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_int,
+                                                 C.c_long, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.emu_gemm_f32(batch, m, n, k, alpha, P(A), A.shape[-1], A[0].size if batch > 1 else 0, ta, P(B), B.shape[-1],
+                     B[0].size if batch > 1 else 0, tb, P(out), n, m * n, P(bias), flags, ksplit, P(ws))
+    return out
+
+
+def test_mfma_gemm_kernel_all_layouts():
+    rng = np.random.default_rng(0)
+    m, n, k = 150, 70, 37       # ragged: exercises every tile edge
+    A = rng.normal(size=(1, m, k)).astype(np.float32)
+    B = rng.normal(size=(1, n, k)).astype(np.float32)
+    ref = A[0].astype(np.float64) @ B[0].astype(np.float64).T
+    tol = dict(rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(_gemm(A, B, 0, 0, m, n, k)[0], ref, **tol)
+    np.testing.assert_allclose(_gemm(A, B, 0, 0, m, n, k, ksplit=3)[0], ref, **tol)
+    At, Bt = np.ascontiguousarray(A.transpose(0, 2, 1)), np.ascontiguousarray(B.transpose(0, 2, 1))
+    np.testing.assert_allclose(_gemm(At, Bt, 1, 1, m, n, k)[0], ref, **tol)
+    np.testing.assert_allclose(_gemm(At, B, 1, 0, m, n, k, alpha=0.5)[0], 0.5 * ref, **tol)
+    bias = rng.normal(size=n).astype(np.float32)
+    np.testing.assert_allclose(_gemm(A, B, 0, 0, m, n, k, bias=bias, flags=3)[0], np.maximum(ref + bias, 0), **tol)
+    Ab = rng.normal(size=(3, 40, 20)).astype(np.float32)
+    Bb = rng.normal(size=(3, 50, 20)).astype(np.float32)
+    np.testing.assert_allclose(_gemm(Ab, Bb, 0, 0, 40, 50, 20, batch=3), np.einsum("bmk,bnk->bmn", Ab, Bb), **tol)
+
+
+def test_softmax_and_layernorm_kernels():
+    lib = emu.lib()
+    rng = np.random.default_rng(1)
+    n_seq, rps, cols = 3, 5, 77
+    S = rng.normal(size=(n_seq * rps, cols)).astype(np.float32) * 3
+    kp = np.zeros((n_seq, cols), np.float32)
+    kp[0, ::3] = 1.0                  # float mask = additive bias (what the reference actually passes)
+    kp[1, 50:] = -np.inf              # bool-style mask
+    kp[2, :] = -np.inf                # fully padded sequence -> zeros, not NaN
+    Pm = np.zeros_like(S)
+    lib.emu_softmax_fwd(n_seq, rps, cols, C.c_float(0.25), P(S), P(kp), P(Pm))
+    z = S.astype(np.float64) * 0.25 + np.repeat(kp, rps, 0)
+    with np.errstate(invalid="ignore"):
+        e = np.exp(z - np.nanmax(np.where(np.isinf(z), np.nan, z), axis=1, keepdims=True))
+    e[np.isnan(e)] = 0
+    ref = e / np.maximum(e.sum(1, keepdims=True), 1e-300)
+    ref[2 * rps:] = 0
+    np.testing.assert_allclose(Pm, ref, rtol=1e-5, atol=1e-7)
+    dP = rng.normal(size=S.shape).astype(np.float32)
+    dS = np.zeros_like(S)
+    lib.emu_softmax_bwd(n_seq * rps, cols, C.c_float(0.25), P(Pm), P(dP), P(dS))
+    refd = 0.25 * ref * (dP - (dP * ref).sum(1, keepdims=True))
+    np.testing.assert_allclose(dS, refd, rtol=1e-4, atol=1e-6)
+
+    rows, d = 130, 128
+    x = rng.normal(size=(rows, d)).astype(np.float32)
+    res = rng.normal(size=(rows, d)).astype(np.float32)
+    gam = rng.normal(size=d).astype(np.float32)
+    bet = rng.normal(size=d).astype(np.float32)
+    y, mean, rstd = np.zeros_like(x), np.zeros(rows, np.float32), np.zeros(rows, np.float32)
+    lib.emu_layernorm_fwd(rows, d, C.c_float(1e-5), P(x), P(res), P(gam), P(bet), P(y), P(mean), P(rstd))
+    xr = (x + res).astype(np.float64)
+    mu, var = xr.mean(1, keepdims=True), xr.var(1, keepdims=True)
+    xh = (xr - mu) / np.sqrt(var + 1e-5)
+    np.testing.assert_allclose(y, xh * gam + bet, rtol=1e-4, atol=1e-5)
+    dy = rng.normal(size=(rows, d)).astype(np.float32)
+    dxr, dg, db = np.zeros_like(x), np.zeros(d, np.float32), np.zeros(d, np.float32)
+    ws = np.zeros(((rows + 63) // 64) * 2 * d, np.float32)
+    xrf = (x + res).astype(np.float32)
+    lib.emu_layernorm_bwd(rows, d, P(xrf), P(gam), P(mean), P(rstd), P(dy), P(dxr), P(dg), P(db), P(ws))
+    gg = dy * gam
+    ref_dx = (gg - gg.mean(1, keepdims=True) - xh * (gg * xh).mean(1, keepdims=True)) / np.sqrt(var + 1e-5)
+    np.testing.assert_allclose(dxr, ref_dx, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dg, (dy * xh).sum(0), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db, dy.sum(0), rtol=1e-4, atol=1e-4)
+
+
+def test_locoval_kernels_match_reference_golden(golden):
+    """Forward value, EmLoco loss gradient w.r.t. the predicted trajectory and all six parameter gradients."""
+    g = golden("locoval")
+    lib = emu.lib()
+    B = 8
+    traj, pose, vel = g["traj"].copy(), g["pose"].copy(), g["vel"].copy()
+    w1, b1, w2, b2, w3, b3 = (g["_network_fc1_weight"], g["_network_fc1_bias"], g["_network_fc2_weight"],
+                              g["_network_fc2_bias"], g["_network_fc3_weight"], g["_network_fc3_bias"])
+    value, x100 = np.zeros(B, np.float32), np.zeros((B, 100), np.float32)
+    h1, h2, ang = np.zeros((B, 49), np.float32), np.zeros((B, 24), np.float32), np.zeros(B, np.float32)
+    lib.emu_locoval_fwd(B, P(traj), 3, P(pose), P(vel), P(w1), P(b1), P(w2), P(b2), P(w3), P(b3), P(value), P(x100), P(h1), P(h2), P(ang))
+    np.testing.assert_allclose(value, g["value"][:, 0], rtol=1e-5, atol=1e-6)
+    # the reference mutates the caller's pose in place (rotation + hidden joints): our x100 carries that result
+    np.testing.assert_allclose(x100[:, 26:98].reshape(B, 24, 3), g["pose_after_inplace"], rtol=1e-5, atol=1e-6)
+    loss = np.mean((value - 1.0) ** 2)
+    np.testing.assert_allclose(loss, float(g["loss"]), rtol=1e-5)
+    dvalue = (2.0 * (value - 1.0) / B).astype(np.float32)     # d mean((v-1)^2) / dv
+    dparams, dtraj = np.zeros(6174, np.float32), np.zeros_like(traj)
+    ws = np.zeros(B * 6174, np.float32)
+    lib.emu_locoval_bwd(B, P(traj), 3, P(pose), P(vel), P(w1), P(w2), P(w3), P(value), P(x100), P(h1), P(h2), P(ang),
+                        P(dvalue), P(dparams), P(dtraj), P(ws))
+    np.testing.assert_allclose(dtraj, g["grad_traj"], rtol=2e-4, atol=1e-7)
+    o = 0
+    for name, shape in (("fc1_weight", (49, 100)), ("fc1_bias", (49,)), ("fc2_weight", (24, 49)), ("fc2_bias", (24,)),
+                        ("fc3_weight", (1, 24)), ("fc3_bias", (1,))):
+        n = int(np.prod(shape))
+        np.testing.assert_allclose(dparams[o:o + n].reshape(shape), g["grad__network_" + name], rtol=2e-4, atol=1e-7)
+        o += n

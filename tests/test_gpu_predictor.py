@@ -1,0 +1,116 @@
+"""GPU parity of the predictor path: this repo's TransMotionJTA / ValuePoseNet (HIP kernels) against golden vectors
+produced by the reference's own model code (tests/golden/gen_golden_predictor.py).  fp32 MFMA path: 1e-4 rel."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _load_model(g, multi):
+    from emloco_amd.predictor.model_jta import TransMotionJTA
+    m = TransMotionJTA(tok_dim=453, nhid=32, nhead=4, dim_feedfwd=64, nlayers_local=2, nlayers_global=1, nmode=4, output_scale=1,
+                       obs_and_pred=21, num_tokens=49, device="cuda:0", multi_modal=multi).to("cuda:0").float()
+    sd = {k[4:].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("sd__")}
+    missing, unexpected = m.load_state_dict(sd, strict=True), None
+    return m
+
+
+def _vnet(g):
+    from emloco_amd.learning.value_pose_net import ValuePoseNet
+    v = ValuePoseNet(use_pose=True, use_vel=True).to("cuda:0")
+    v.load_state_dict({k[4:].replace("__", "."): torch.from_numpy(val) for k, val in g.items() if k.startswith("vn__")}, strict=True)
+    return v
+
+
+def _close(a, b, rel=1e-4, abs_=1e-5, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.abs(a - b)
+    tol = abs_ + rel * np.abs(b).max()
+    assert err.max() <= tol, f"{what}: max err {err.max():.3e} > {tol:.3e} (scale {np.abs(b).max():.3e})"
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_forward_loss_and_gradients_match_reference(golden, multi):
+    from emloco_amd.predictor.train_jta import MSE_LOSS, MSE_LOSS_MULTI
+    g = golden("predictor_multi" if multi else "predictor_single")
+    model = _load_model(g, multi)
+    vnet = _vnet(g)
+    model.eval()
+    dev = "cuda:0"
+    in_joints, pm, out_joints = (torch.from_numpy(g[k]).to(dev) for k in ("in_joints", "pm", "out_joints"))
+    pred = model(in_joints.clone(), pm.clone())
+    _close(pred.detach().cpu().numpy(), g["pred"], what="logits")
+    mse = (MSE_LOSS_MULTI if multi else MSE_LOSS)(pred[:, 9:], out_joints)
+    _close(mse.item(), g["mse"], what="mse loss")
+    pose, vel = torch.from_numpy(g["pose"]).to(dev), torch.from_numpy(g["vel"]).to(dev)
+    pred_traj = torch.cat([torch.zeros(pred.shape[0], 1, 2, device=dev), pred[:, 9:, 0, :2]], dim=1).contiguous()
+    value, vloss = vnet.calc_embodied_motion_loss(pred_traj, pose.clone(), vel.clone())
+    _close(value.detach().cpu().numpy(), g["value"], what="LocoVal value")
+    loss = mse + 1.0 * vloss
+    _close(loss.item(), g["loss"], what="EmLoco loss")
+    loss.backward()
+    grads = dict(model.named_parameters())
+    for k, v in g.items():
+        if k.startswith("grad__"):
+            name = k[6:].replace("__", ".")
+            _close(grads[name].grad.cpu().numpy(), v, rel=2e-4, abs_=1e-6, what="grad " + name)
+
+
+def test_state_dict_keys_are_the_reference_keys(golden):
+    g = golden("predictor_single")
+    model = _load_model(g, False)
+    ref_keys = {k[4:].replace("__", ".") for k in g if k.startswith("sd__")}
+    assert set(model.state_dict().keys()) == ref_keys
+
+
+def test_batch_process_coords_matches_reference(golden):
+    from emloco_amd.predictor.train_jta import batch_process_coords
+    g = golden("predictor_batch")
+    cfg = {"DEVICE": "cuda:0", "TRAIN": {"input_track_size": 9, "output_track_size": 12}}
+    joints = torch.from_numpy(g["joints"])
+    masks = torch.ones(joints.shape[:-1])
+    i, _, o, _, pm = batch_process_coords(joints, masks, torch.from_numpy(g["padding_mask"]).bool(), cfg, training=True)
+    np.testing.assert_allclose(i.cpu().numpy(), g["in_joints"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(o.cpu().numpy(), g["out_joints"], rtol=1e-6, atol=1e-6)
+
+
+def test_locoval_matches_reference_golden(golden):
+    g = golden("locoval")
+    from emloco_amd.learning.value_pose_net import ValuePoseNet
+    dev = "cuda:0"
+    v = ValuePoseNet(use_pose=True, use_vel=True).to(dev)
+    v.load_state_dict({k: torch.from_numpy(g[k.replace(".", "_")]) for k in v.state_dict().keys()}, strict=True)
+    traj = torch.from_numpy(g["traj"]).to(dev).requires_grad_(True)
+    pose = torch.from_numpy(g["pose"]).to(dev)
+    vel = torch.from_numpy(g["vel"]).to(dev)
+    value, loss = v.calc_embodied_motion_loss(traj, pose, vel)
+    np.testing.assert_allclose(value.detach().cpu().numpy(), g["value"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pose.cpu().numpy(), g["pose_after_inplace"], rtol=1e-5, atol=1e-6)   # in-place side effect kept
+    for p in v.parameters():
+        p.requires_grad_(True)
+    loss.backward()
+    np.testing.assert_allclose(traj.grad.cpu().numpy(), g["grad_traj"], rtol=2e-4, atol=1e-7)
+    for k, p in v.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g["grad_" + k.replace(".", "_")], rtol=2e-4, atol=1e-7)
+
+
+def test_train_step_runs_and_decreases_loss():
+    from emloco_amd.learning.value_pose_net import ValuePoseNet
+    from emloco_amd.predictor.model_jta import TransMotionJTA
+    from emloco_amd.predictor.train_jta import EmLocoTrainer
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    cfg = {"DEVICE": dev, "MULTI_MODAL": False, "TRAIN": {"input_track_size": 9, "output_track_size": 12, "lr": 1e-3,
+                                                          "max_grad_norm": 1.0, "valuenet_weight": 1.0}}
+    model = TransMotionJTA(tok_dim=453, nhid=32, nhead=4, dim_feedfwd=64, nlayers_local=2, nlayers_global=1, output_scale=1,
+                           obs_and_pred=21, num_tokens=49, device=dev, dropout=0.0).to(dev)
+    tr = EmLocoTrainer(model, ValuePoseNet(True, True).to(dev), cfg)
+    B, N = 4, 2
+    joints = torch.randn(B, N, 21, 49, 4) * 0.3
+    joints[:, :, :, 0, :2] = torch.cumsum(torch.full((B, N, 21, 2), 0.2), dim=2)
+    masks = torch.ones(B, N, 21, 49)
+    pad = torch.zeros(B, N, dtype=torch.bool)
+    losses = [tr.step(joints, masks, pad)[0].item() for _ in range(8)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
