@@ -76,6 +76,8 @@ class HumanoidModel:
         m.geom_r *= s
         m.mass *= s ** 3 * ms
         m.inertia *= s ** 5 * ms
+        if m.density is not None:
+            m.density = m.density * ms       # keeps a written MJCF consistent with the scaled masses
         return m
 
 

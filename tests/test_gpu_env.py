@@ -91,3 +91,19 @@ def test_rollout_with_resets_runs_an_episode():
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
     assert n_done >= E          # every env finished at least one episode (168-step cap or early termination)
     assert int(task.progress_buf.max()) <= 168
+
+
+def test_locoval_rollout_fits_value_function():
+    """A17/A18: discounted-return bookkeeping + LocoVal fit through the fused LocoVal kernels."""
+    from emloco_amd.learning.locoval_rollout import LocoValRollout
+    from emloco_amd.run import RLGPUEnv
+    env = RLGPUEnv(_make_env(128, ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel",
+                                   "--input_init_pose", "--input_init_vel"]))
+    agent = LocoValRollout(env, horizon_length=16)
+    w0 = agent.valuenet._network.fc1.weight.detach().clone()
+    for _ in range(6):
+        agent.play_steps()
+    torch.cuda.synchronize()
+    assert agent.vnet_fits > 0 and np.isfinite(agent.vnet_loss)
+    assert not torch.equal(w0, agent.valuenet._network.fc1.weight)      # the optimiser really stepped
+    assert agent.frames == 6 * 16 * 128

@@ -1,0 +1,131 @@
+"""Known-answer tests of the CPU physics oracle (oracle/oracle_sim.c).
+
+The reference's engine (PhysX 5 behind gym.simulate) is absent, so the oracle cannot be pinned to reference
+outputs ("parity unpinned").  These analytic cases pin OUR documented scheme instead; the HIP step
+is then held bit-exact to this oracle (tests/test_gpu_sim.py, tests/test_emu_kernels.py).
+"""
+import numpy as np
+
+import oracle
+from emloco_amd.model import pack_models, smpl_humanoid
+
+
+def _sim(models=None, **p):
+    return oracle.Sim(pack_models(models or [smpl_humanoid()]), oracle.default_params(**p))
+
+
+def test_articulated_body_solve_equals_dense_solve():
+    """ABA factorisation vs an independent dense M^-1 (body Jacobians, float64) at a random state."""
+    s = _sim()
+    rng = np.random.default_rng(0)
+    s.root_state[0, :3] = [0, 0, 5.0]
+    q = rng.normal(size=4)
+    s.root_state[0, 3:7] = q / np.linalg.norm(q)
+    s.root_state[0, 7:13] = rng.normal(size=6)
+    s.dof_state[0, :, 0] = rng.normal(size=69) * 0.3
+    s.dof_state[0, :, 1] = rng.normal(size=69)
+    s.pd_target[0] = rng.normal(size=69) * 0.2
+    M, rhs = s.dense_dynamics()
+    assert np.abs(M - M.T).max() < 1e-6 and np.all(np.linalg.eigvalsh(M) > 0)
+    x = np.linalg.solve(M, rhs)
+    np.testing.assert_allclose(s.free_accel(), x, rtol=2e-5, atol=2e-5 * np.abs(x).max())
+
+
+def test_free_fall_matches_semi_implicit_euler():
+    s = _sim()
+    s.root_state[0, :3] = [0, 0, 100.0]
+    for _ in range(30):
+        s.step()
+    t, h = 30 * 4 / 120.0, 1 / 120.0
+    assert abs(s.root_state[0, 2] - (100 - 0.5 * 9.81 * t * (t + h))) < 2e-3
+    assert abs(s.root_state[0, 9] + 9.81 * t) < 1e-3
+    np.testing.assert_allclose(s.dof_state[0, :, 0], 0, atol=1e-5)      # no internal motion in free fall with targets at rest
+
+
+def test_pd_stand_carries_the_weight_without_penetrating():
+    m = smpl_humanoid()
+    s = _sim([m])
+    s.root_state[0, :3] = [0, 0, 0.95]
+    for _ in range(168):
+        s.step()
+    fz = s.contact_force[0, :, 2].sum()
+    assert abs(fz - m.total_mass() * 9.81) / (m.total_mass() * 9.81) < 0.01
+    assert np.abs(s.contact_force[0][[0, 1, 2, 5, 6, 9, 10, 11, 12, 13]]).max() == 0     # only the feet touch
+    rb = s.rb_state[0]
+    assert rb[:, 2].min() > -0.01 and 0.85 < rb[0, 2] < 0.95      # toe-box origin sits 7 mm below its sole
+    assert np.abs(s.dof_state[0, :, 1]).max() < 1e-2                                    # at rest
+
+
+def test_pd_drive_step_response_is_stable_and_converges():
+    """One joint commanded to 0.5 rad in free fall: the implicit drive converges without overshoot blow-up."""
+    s = _sim()
+    s.root_state[0, :3] = [0, 0, 50.0]
+    j = 3 * 15 + 1                     # L_Elbow y
+    s.pd_target[0, j] = 0.5
+    trace = []
+    for _ in range(60):
+        s.step()
+        trace.append(s.dof_state[0, j, 0])
+    trace = np.array(trace)
+    assert abs(trace[-1] - 0.5) < 0.02 and trace.max() < 0.6 and np.isfinite(trace).all()
+
+
+def test_friction_holds_on_flat_ground_and_tangential_push_decays():
+    s = _sim()
+    s.root_state[0, :3] = [0, 0, 0.92]
+    for _ in range(60):
+        s.step()
+    x0 = s.root_state[0, :2].copy()
+    s.root_state[0, 7] = 0.3            # shove the pelvis forward
+    for _ in range(90):
+        s.step()
+    assert np.linalg.norm(s.root_state[0, 7:9]) < 0.05         # friction (mu = 1) brought it back to rest
+    assert np.linalg.norm(s.root_state[0, :2] - x0) < 0.3
+    lam = s.contact_force[0]
+    assert np.all(np.hypot(lam[:, 0], lam[:, 1]) <= 1.0 * lam[:, 2] + 1e-3)     # net force inside the friction cone
+
+
+def test_left_right_mirror_symmetry():
+    """Mirroring state and targets across the sagittal plane mirrors the trajectory (humanoid.py:334 permutation)."""
+    m = smpl_humanoid()
+    # make the model exactly symmetric first (the SMPL mean shape is not), then compare a motion with its mirror
+    l2r = [0, 5, 6, 7, 8, 1, 2, 3, 4, 9, 10, 11, 12, 13, 19, 20, 21, 22, 23, 14, 15, 16, 17, 18]
+    sym = m.scaled(1.0, 1.0)
+    flip = np.array([1, -1, 1.0])
+    for b in range(24):
+        if l2r[b] > b:
+            o = l2r[b]
+            sym.joint_off[o] = sym.joint_off[b] * flip
+            sym.com[o] = sym.com[b] * flip
+            sym.geom_a[o], sym.geom_b[o] = sym.geom_a[b] * flip, sym.geom_b[b] * (flip if sym.geom_type[b] == 1 else 1)
+            sym.geom_r[o], sym.mass[o] = sym.geom_r[b], sym.mass[b]
+            sym.inertia[o] = sym.inertia[b] * np.array([1, 1, 1, -1, 1, -1])
+        elif l2r[b] == b:
+            sym.joint_off[b][1] = 0
+            sym.com[b][1] = 0
+            sym.geom_a[b][1] = 0
+            sym.geom_b[b][1] = 0 if sym.geom_type[b] == 1 else sym.geom_b[b][1]
+            sym.inertia[b][[3, 5]] = 0
+    rng = np.random.default_rng(3)
+    tgt = rng.normal(size=(23, 3)) * 0.2
+    a, b = _sim([sym]), _sim([sym])
+    for s_ in (a, b):
+        s_.root_state[0, :3] = [0, 0, 0.95]
+    jm = [j - 1 for j in l2r[1:]]
+    a.pd_target[0] = tgt.reshape(-1)
+    b.pd_target[0] = (tgt[jm] * np.array([-1, 1, -1.0])).reshape(-1)      # mirrored rotation vectors
+    for _ in range(40):
+        a.step()
+        b.step()
+    pa, pb = a.rb_state[0, :, :3], b.rb_state[0, l2r, :3] * flip
+    np.testing.assert_allclose(pa, pb, atol=2e-3)
+
+
+def test_same_inputs_same_bytes():
+    a, b = _sim(), _sim()
+    for s_ in (a, b):
+        s_.root_state[0, :3] = [0, 0, 0.93]
+        s_.pd_target[0, ::7] = 0.3
+        for _ in range(25):
+            s_.step()
+    assert a.rb_state.tobytes() == b.rb_state.tobytes()
