@@ -58,6 +58,30 @@ class TaskBufs(C.Structure):
                 ("reward_raw", C.c_void_p), ("amp_obs_buf", C.c_void_p)]
 
 
+class ResetBufs(C.Structure):
+    """EmlocoResetBufs (include/emloco_task.h)."""
+    _fields_ = [("flags", C.c_int32), ("n_motions", C.c_int32), ("n_real", C.c_int32), ("n_valid", C.c_int32),
+                ("n_dof_subset", C.c_int32), ("hf_rows", C.c_int32), ("hf_cols", C.c_int32),
+                ("fixed_x", C.c_float), ("fixed_y", C.c_float), ("dt", C.c_float), ("height_tolerance", C.c_float),
+                ("vert_dt", C.c_float), ("dtheta_max", C.c_float), ("speed_min", C.c_float), ("speed_max", C.c_float),
+                ("accel_max", C.c_float), ("sharp_prob", C.c_float), ("hybrid_prob", C.c_float),
+                ("traj_dur", C.c_float), ("sample_dt", C.c_float), ("hscale", C.c_float), ("vscale", C.c_float),
+                ("gts", C.c_void_p), ("grs", C.c_void_p), ("lrs", C.c_void_p), ("gvs", C.c_void_p), ("gavs", C.c_void_p),
+                ("dvs", C.c_void_p), ("motion_len", C.c_void_p), ("motion_dt", C.c_void_p), ("motion_nframes", C.c_void_p),
+                ("motion_start", C.c_void_p), ("real_traj", C.c_void_p), ("heightfield", C.c_void_p),
+                ("valid_x", C.c_void_p), ("valid_y", C.c_void_p), ("betas", C.c_void_p), ("key_bodies", C.c_void_p),
+                ("dof_subset", C.c_void_p), ("traj_verts", C.c_void_p), ("inverted", C.c_void_p),
+                ("progress_buf", C.c_void_p), ("reset_buf", C.c_void_p), ("terminate_buf", C.c_void_p),
+                ("waypoint_traj", C.c_void_p), ("init_pose", C.c_void_p), ("init_vel", C.c_void_p),
+                ("amp_obs_buf", C.c_void_p), ("motion_ids", C.c_void_p), ("motion_times", C.c_void_p), ("ground_h", C.c_void_p)]
+
+
+RESET_RND = 512
+RESET_RANDOM_HEADING, RESET_INIT_HEADING, RESET_HEADING_INVERSION, RESET_ADJUST_ROOT_VEL, RESET_REAL_PATH, RESET_FIXED_LOCATION = 1, 2, 4, 8, 16, 32
+RND_MOTION, RND_TIME, RND_YAW, RND_SPEED, RND_LOC, RND_REAL, RND_REAL_PICK, RND_INVERSION, RND_HEADING, RND_SPEED0 = range(10)
+RND_DTHETA, RND_SHARP, RND_BERN, RND_DSPEED = 16, 116, 216, 316
+
+
 def default_sim_params(**kw):
     """Engine parameters of pacer.yaml:93-104 / config.py:143-163 mapped onto EmlocoSimParams."""
     p = dict(n_sub=2, n_iter=4, h=(1.0 / 60.0) / 2, gravity_z=-9.81, contact_offset=0.02, erp=0.2,
@@ -76,7 +100,7 @@ SYMBOLS_SIM = [
 ]
 SYMBOLS_TASK = [
     "emloco_task_post_physics", "emloco_task_amp_rows", "emloco_task_pd_targets", "emloco_task_last_ms",
-    "emloco_task_enable_timing",
+    "emloco_task_enable_timing", "emloco_task_reset",
 ]
 
 _lib = None
@@ -121,6 +145,7 @@ def load():
     lib.emloco_task_amp_rows.argtypes = [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.c_void_p]
     lib.emloco_task_pd_targets.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]
     lib.emloco_task_enable_timing.argtypes = [C.c_int]
+    lib.emloco_task_reset.argtypes = [C.c_void_p, C.POINTER(ResetBufs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 

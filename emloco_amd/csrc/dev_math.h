@@ -169,3 +169,31 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 }  // namespace emloco
+
+namespace emloco {
+// pacer/pacer/utils/torch_utils.py:113-135 slerp
+__device__ __forceinline__ void ref_slerp(const float *q0, const float *q1in, float t, float *o) {
+    float q1[4] = {q1in[0], q1in[1], q1in[2], q1in[3]};
+    float c = q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2] + q0[3] * q1[3];
+    if (c < 0.0f) { q1[0] = -q1[0]; q1[1] = -q1[1]; q1[2] = -q1[2]; q1[3] = -q1[3]; }
+    c = fabsf(c);
+    const float half = acosf(c);
+    const float s = sqrtf(1.0f - c * c);
+    const float ra = sinf((1.0f - t) * half) / s, rb = sinf(t * half) / s;
+    for (int i = 0; i < 4; ++i) {
+        float v = ra * q0[i] + rb * q1[i];
+        if (fabsf(s) < 0.001f) v = 0.5f * q0[i] + 0.5f * q1[i];
+        if (fabsf(c) >= 1.0f) v = q0[i];
+        o[i] = v;
+    }
+}
+// pacer/pacer/utils/torch_utils.py:26-64 quat_to_exp_map
+__device__ __forceinline__ void ref_quat_to_exp_map(const float *q, float *o) {
+    const float sin_theta = sqrtf(1.0f - q[3] * q[3]);
+    float angle = 2.0f * acosf(q[3]);
+    angle = atan2f(sinf(angle), cosf(angle));
+    if (fabsf(sin_theta) > 1e-5f) {
+        o[0] = angle * (q[0] / sin_theta); o[1] = angle * (q[1] / sin_theta); o[2] = angle * (q[2] / sin_theta);
+    } else { o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; }
+}
+}  // namespace emloco

@@ -1,0 +1,299 @@
+// reset_kernels.hip -- fused reset of finished envs for gfx950 (see include/emloco_task.h for the reference lines).
+//
+// Three launches per reset call, one wave per reset env:
+//   reset_sample_kernel   motion sample (frame blend, slerp), random heading / forward speed, placement, state write
+//   sim_fk_kernel         forward kinematics of the reset envs on their own skeletons (sim_kernels.hip)
+//   reset_finish_kernel   ground-height fix from the lowest collision point, buffer zeroing, trajectory
+//                         generation (random polyline | real path, heading alignment / inversion), LocoVal input
+//                         capture, AMP history back-fill
+// then emloco_task_post_physics(ids, OBS | AMP_ROW) writes the reset observations.
+#include <hip/hip_runtime.h>
+#include "dev_math.h"
+#include "emloco_types.h"
+#include "../../include/emloco_task.h"
+
+namespace emloco {
+
+#define RNB 24
+#define RNDOF 69
+#define RNV EMLOCO_TRAJ_VERTS
+
+struct FrameBlend { long f0, f1; float blend; };
+
+// motion_lib_smpl.py:596-606 _calc_frame_blend
+__device__ __forceinline__ FrameBlend frame_blend(const EmlocoResetBufs &t, int mid, float time) {
+    const float len = t.motion_len[mid], dt = t.motion_dt[mid];
+    const long nf = t.motion_nframes[mid];
+    float phase = time / len;
+    phase = phase < 0.0f ? 0.0f : (phase > 1.0f ? 1.0f : phase);
+    if (time < 0.0f) time = 0.0f;
+    const long i0 = (long)(phase * (float)(nf - 1));
+    const long i1 = (i0 + 1 < nf - 1) ? i0 + 1 : nf - 1;
+    FrameBlend fb;
+    fb.blend = (time - (float)i0 * dt) / dt;
+    fb.f0 = i0 + t.motion_start[mid];
+    fb.f1 = i1 + t.motion_start[mid];
+    return fb;
+}
+
+__device__ __forceinline__ float lerp1(float a, float b, float w) { return (1.0f - w) * a + w * b; }
+
+__device__ __forceinline__ float sample_h(const EmlocoResetBufs &t, float x, float y) {
+    long px = (long)(x / t.hscale), py = (long)(y / t.hscale);
+    if (px < 0) px = 0;
+    if (px > t.hf_rows - 2) px = t.hf_rows - 2;
+    if (py < 0) py = 0;
+    if (py > t.hf_cols - 2) py = t.hf_cols - 2;
+    const int16_t h1 = t.heightfield[px * t.hf_cols + py], h2 = t.heightfield[(px + 1) * t.hf_cols + (py + 1)];
+    return (float)(h1 < h2 ? h1 : h2) * t.vscale;
+}
+
+__global__ void __launch_bounds__(64)
+reset_sample_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n, const float *rnd) {
+    if ((int)blockIdx.x >= n) return;
+    const int env = ids[blockIdx.x], lane = threadIdx.x;
+    const float *u = rnd + (long)blockIdx.x * EMLOCO_RESET_RND;
+    int mid = (int)(u[EMLOCO_RND_MOTION] * (float)t.n_motions);
+    if (mid > t.n_motions - 1) mid = t.n_motions - 1;
+    const float time = u[EMLOCO_RND_TIME] * t.motion_len[mid];
+    const FrameBlend fb = frame_blend(t, mid, time);
+    if (lane >= 1 && lane < RNB) {          // joint lane-1: local rotation -> rotation vector; dof velocity
+        float q[4], e[3];
+        ref_slerp(t.lrs + (fb.f0 * RNB + lane) * 4, t.lrs + (fb.f1 * RNB + lane) * 4, fb.blend, q);
+        ref_quat_to_exp_map(q, e);
+        float *ds = s.dof_state + ((long)env * RNDOF + (lane - 1) * 3) * 2;
+        for (int k = 0; k < 3; ++k) {
+            ds[2 * k] = e[k];
+            ds[2 * k + 1] = lerp1(t.dvs[fb.f0 * RNDOF + (lane - 1) * 3 + k], t.dvs[fb.f1 * RNDOF + (lane - 1) * 3 + k], fb.blend);
+        }
+    }
+    if (lane == 0) {
+        float pos[3], rot[4], vel[3], ang[3];
+        for (int k = 0; k < 3; ++k) {
+            pos[k] = lerp1(t.gts[(fb.f0 * RNB) * 3 + k], t.gts[(fb.f1 * RNB) * 3 + k], fb.blend);
+            vel[k] = lerp1(t.gvs[(fb.f0 * RNB) * 3 + k], t.gvs[(fb.f1 * RNB) * 3 + k], fb.blend);
+            ang[k] = lerp1(t.gavs[(fb.f0 * RNB) * 3 + k], t.gavs[(fb.f1 * RNB) * 3 + k], fb.blend);
+        }
+        ref_slerp(t.grs + (fb.f0 * RNB) * 4, t.grs + (fb.f1 * RNB) * 4, fb.blend, rot);
+        if (t.flags & EMLOCO_RESET_RANDOM_HEADING) {        // humanoid_pedestrain_terrain.py:556-569
+            const float yaw = 3.14159265358979f * (2.0f * u[EMLOCO_RND_YAW] - 1.0f);
+            const float hq[4] = {0.0f, 0.0f, sinf(0.5f * yaw), cosf(0.5f * yaw)};
+            float r2[4], a2[3], hh[4], v2[3];
+            ref_quat_mul(hq, rot, r2);
+            ref_quat_apply(hq, ang, a2);
+            for (int k = 0; k < 4; ++k) rot[k] = r2[k];
+            for (int k = 0; k < 3; ++k) ang[k] = a2[k];
+            ref_quat_about_z(ref_calc_heading(rot), hh);
+            vel[0] = u[EMLOCO_RND_SPEED] * 0.5f + 1.0f;
+            ref_quat_apply(hh, vel, v2);
+            for (int k = 0; k < 3; ++k) vel[k] = v2[k];
+        }
+        if (t.flags & EMLOCO_RESET_FIXED_LOCATION) { pos[0] = t.fixed_x; pos[1] = t.fixed_y; }
+        else {
+            int li = (int)(u[EMLOCO_RND_LOC] * (float)t.n_valid);
+            if (li > t.n_valid - 1) li = t.n_valid - 1;
+            pos[0] = t.valid_x[li]; pos[1] = t.valid_y[li];
+        }
+        // centre height: 3x3 yaw-only probes (humanoid_pedestrain_terrain.py:607,732-759)
+        float qy[4] = {0.0f, 0.0f, rot[2], rot[3]};
+        float nn = sqrtf(qy[2] * qy[2] + qy[3] * qy[3]);
+        if (nn < 1e-9f) nn = 1e-9f;
+        qy[2] /= nn; qy[3] /= nn;
+        float hsum = 0.0f;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const float pt[3] = {-0.1f + 0.1f * (float)i, -0.2f + 0.2f * (float)j, 0.0f};
+                float rr[3];
+                ref_quat_apply(qy, pt, rr);
+                hsum += sample_h(t, rr[0] + pos[0], rr[1] + pos[1]);
+            }
+        const float gh = hsum / 9.0f;
+        pos[2] += gh;
+        t.ground_h[env] = gh;
+        float *rs = s.root_state + (long)env * 13;
+        for (int k = 0; k < 3; ++k) { rs[k] = pos[k]; rs[7 + k] = vel[k]; rs[10 + k] = ang[k]; }
+        for (int k = 0; k < 4; ++k) rs[3 + k] = rot[k];
+        t.motion_ids[env] = mid;
+        t.motion_times[env] = time;
+    }
+}
+
+// traj_generator.py:278-296 calc_pos at one time
+__device__ __forceinline__ void r_calc_pos(const float *verts, float time, float traj_dur, float *out) {
+    float phase = time / traj_dur;
+    phase = phase < 0.0f ? 0.0f : (phase > 1.0f ? 1.0f : phase);
+    const float seg = phase * (float)(RNV - 1);
+    const long i0 = (long)floorf(seg), i1 = (long)ceilf(seg);
+    const float w = seg - (float)i0;
+    for (int k = 0; k < 3; ++k) out[k] = (1.0f - w) * verts[i0 * 3 + k] + w * verts[i1 * 3 + k];
+}
+
+__global__ void __launch_bounds__(64)
+reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n, const float *rnd) {
+    if ((int)blockIdx.x >= n) return;
+    const int env = ids[blockIdx.x], lane = threadIdx.x;
+    const float *u = rnd + (long)blockIdx.x * EMLOCO_RESET_RND;
+    __shared__ float sh_v[RNV][3];
+    __shared__ float sh_root[13], sh_dp[RNDOF], sh_dv[RNDOF], sh_key[12];
+    __shared__ float sh_misc[4];
+
+    // ---- a. lowest collision point -> vertical shift (replaces the SMPL-mesh height fix, humanoid_amp.py:321-379)
+    float low = 3.0e38f;
+    for (int sl = 0; sl < 2; ++sl) {
+        const int c = lane + 64 * sl;
+        if (c < s.n_cand) {
+            const int body = s.cand_body[c], k = s.cand_k[c];
+            const long mb = (long)env * RNB + body;
+            const float *ga = s.geom_a + mb * 3, *gb = s.geom_b + mb * 3;
+            const int gt = s.geom_type[body];
+            float lp[3];
+            if (gt == EMLOCO_GEOM_SPHERE) { lp[0] = ga[0]; lp[1] = ga[1]; lp[2] = ga[2]; }
+            else if (gt == EMLOCO_GEOM_CAPSULE) { const float *src = k == 0 ? ga : gb; lp[0] = src[0]; lp[1] = src[1]; lp[2] = src[2]; }
+            else {
+                lp[0] = ga[0] + ((k & 1) ? gb[0] : -gb[0]);
+                lp[1] = ga[1] + ((k & 2) ? gb[1] : -gb[1]);
+                lp[2] = ga[2] + ((k & 4) ? gb[2] : -gb[2]);
+            }
+            const float *rb = s.rb_state + mb * 13;
+            float R[9], wp[3];
+            q2mat(rb + 3, R);
+            matvec3(R, lp, wp);
+            const float z = rb[2] + wp[2] - s.geom_r[mb];
+            low = z < low ? z : low;
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(low, off); low = o < low ? o : low; }
+    const float dz = low - t.ground_h[env] - t.height_tolerance;
+    float *rs = s.root_state + (long)env * 13;
+    if (lane < RNB) s.rb_state[((long)env * RNB + lane) * 13 + 2] -= dz;
+    if (lane == 0) rs[2] -= dz;
+    __syncthreads();
+
+    // ---- b. buffers (humanoid.py:477-480) + warm-start impulses
+    if (lane == 0) { t.progress_buf[env] = 0; t.reset_buf[env] = 0; t.terminate_buf[env] = 0; }
+    for (int i = lane; i < RNB * 3; i += 64) s.contact_force[(long)env * RNB * 3 + i] = 0.0f;
+    for (int i = lane; i < EMLOCO_MAXCAND * 3; i += 64) s.lambda_ws[(long)env * EMLOCO_MAXCAND * 3 + i] = 0.0f;
+
+    // ---- c. trajectory (traj_generator.py:60-237)
+    const float ipx = rs[0], ipy = rs[1];
+    const float rvx = rs[7], rvy = rs[8];
+    if (lane == 0) {
+        const float vdt = t.vert_dt;
+        float speed = (t.speed_max - t.speed_min) * u[EMLOCO_RND_SPEED0] + t.speed_min;
+        float ratio = 1.0f;
+        if (t.flags & EMLOCO_RESET_ADJUST_ROOT_VEL) {
+            ratio = sqrtf(rvx * rvx + rvy * rvy) / speed;
+        }
+        float theta = 0.0f, px = 0.0f, py = 0.0f;
+        sh_v[0][0] = ipx; sh_v[0][1] = ipy; sh_v[0][2] = 0.0f;
+        for (int i = 0; i < RNV - 1; ++i) {
+            float dth = (2.0f * u[EMLOCO_RND_DTHETA + i] - 1.0f) * (t.dtheta_max * vdt);
+            if (u[EMLOCO_RND_BERN + i] < t.sharp_prob) dth = 3.14159265358979f * (2.0f * u[EMLOCO_RND_SHARP + i] - 1.0f);
+            if (i == 0) dth = 3.14159265358979f * (2.0f * u[EMLOCO_RND_HEADING] - 1.0f);
+            else {
+                const float ds = (2.0f * u[EMLOCO_RND_DSPEED + i] - 1.0f) * (t.accel_max * vdt);
+                speed = speed + ds;
+                speed = speed < t.speed_min ? t.speed_min : (speed > t.speed_max ? t.speed_max : speed);
+            }
+            float sp = speed;
+            if (t.flags & EMLOCO_RESET_ADJUST_ROOT_VEL) {
+                sp = ratio * speed;
+                sp = sp < t.speed_min ? t.speed_min : (sp > t.speed_max ? t.speed_max : sp);
+            }
+            theta += dth;
+            const float seg = sp * vdt;
+            px += cosf(theta) * seg;
+            py += -sinf(theta) * seg;
+            sh_v[i + 1][0] = px + ipx; sh_v[i + 1][1] = py + ipy; sh_v[i + 1][2] = 0.0f;
+        }
+    }
+    __syncthreads();
+    const bool real = (t.flags & EMLOCO_RESET_REAL_PATH) && t.n_real > 0 && (u[EMLOCO_RND_REAL] > t.hybrid_prob);
+    if (real) {                                     // :121-160
+        int ri = (int)(u[EMLOCO_RND_REAL_PICK] * (float)t.n_real);
+        if (ri > t.n_real - 1) ri = t.n_real - 1;
+        const float *src = t.real_traj + (long)ri * RNV * 3;
+        const float ox = src[0], oy = src[1];
+        float sc = 1.0f;
+        if (t.flags & EMLOCO_RESET_ADJUST_ROOT_VEL) {
+            const float dx = src[3] - src[0], dy = src[4] - src[1], dzz = src[5] - src[2];
+            float is = sqrtf(dx * dx + dy * dy + dzz * dzz);
+            const float mn = t.speed_min * t.vert_dt;
+            is = is < mn ? mn : is;
+            sc = sqrtf(rvx * rvx + rvy * rvy) / is * t.vert_dt;
+        }
+        for (int i = lane; i < RNV; i += 64) {
+            sh_v[i][0] = sc * (src[i * 3] - ox) + ipx;
+            sh_v[i][1] = sc * (src[i * 3 + 1] - oy) + ipy;
+            sh_v[i][2] = src[i * 3 + 2];
+        }
+        __syncthreads();
+    }
+    bool inv = false;
+    if (t.flags & EMLOCO_RESET_INIT_HEADING) {      // :176-235
+        const float ox = sh_v[0][0], oy = sh_v[0][1];
+        const float dx = sh_v[1][0] - ox, dy = sh_v[1][1] - oy;
+        const float rvz = rs[9];
+        const float rmag = sqrtf(rvx * rvx + rvy * rvy + rvz * rvz), dmag = sqrtf(dx * dx + dy * dy);
+        const float root_rot = rmag > 0.0f ? atan2f(rvy, rvx) : 0.0f;
+        const float ih = dmag > 0.0f ? atan2f(dy, dx) : 0.0f;
+        float rd = ih - root_rot;
+        if ((t.flags & EMLOCO_RESET_HEADING_INVERSION) && u[EMLOCO_RND_INVERSION] > 0.5f) { inv = true; rd = ih - root_rot + 3.14159265358979f; }
+        const float c = cosf(rd), sn = sinf(rd);
+        __syncthreads();
+        for (int i = lane; i < RNV; i += 64) {
+            const float x = sh_v[i][0] - ox, y = sh_v[i][1] - oy;
+            sh_v[i][0] = (x * c + y * sn) + ox;
+            sh_v[i][1] = (-x * sn + y * c) + oy;
+        }
+        if (lane == 0 && (t.flags & EMLOCO_RESET_HEADING_INVERSION)) t.inverted[env] = inv ? 1 : 0;
+        __syncthreads();
+    }
+    float *vout = t.traj_verts + (long)env * RNV * 3;
+    for (int i = lane; i < RNV * 3; i += 64) vout[i] = (&sh_v[0][0])[i];
+
+    // ---- d. LocoVal inputs captured at reset (humanoid_pedestrain_terrain.py:511-516)
+    if (lane < EMLOCO_TRAJ_SAMPLES) {
+        float p[3];
+        r_calc_pos(&sh_v[0][0], (float)lane * t.sample_dt, t.traj_dur, p);
+        for (int k = 0; k < 3; ++k) t.waypoint_traj[((long)env * EMLOCO_TRAJ_SAMPLES + lane) * 3 + k] = p[k];
+    }
+    if (lane < RNB)
+        for (int k = 0; k < 3; ++k) t.init_pose[((long)env * RNB + lane) * 3 + k] = s.rb_state[((long)env * RNB + lane) * 13 + k];
+    if (lane == 0) { t.init_vel[(long)env * 2] = rvx; t.init_vel[(long)env * 2 + 1] = rvy; }
+
+    // ---- e. AMP history rows 1..14 from the motion library at t - k dt (humanoid_amp.py:486-535)
+    const int mid = (int)t.motion_ids[env];
+    const float mt = t.motion_times[env];
+    for (int k = 1; k < EMLOCO_AMP_STEPS; ++k) {
+        const FrameBlend fb = frame_blend(t, mid, mt - t.dt * (float)k);
+        if (lane >= 1 && lane < RNB) {
+            float q[4], e[3];
+            ref_slerp(t.lrs + (fb.f0 * RNB + lane) * 4, t.lrs + (fb.f1 * RNB + lane) * 4, fb.blend, q);
+            ref_quat_to_exp_map(q, e);
+            for (int c = 0; c < 3; ++c) {
+                sh_dp[(lane - 1) * 3 + c] = e[c];
+                sh_dv[(lane - 1) * 3 + c] = lerp1(t.dvs[fb.f0 * RNDOF + (lane - 1) * 3 + c], t.dvs[fb.f1 * RNDOF + (lane - 1) * 3 + c], fb.blend);
+            }
+        }
+        if (lane == 0) {
+            for (int c = 0; c < 3; ++c) {
+                sh_root[c] = lerp1(t.gts[(fb.f0 * RNB) * 3 + c], t.gts[(fb.f1 * RNB) * 3 + c], fb.blend);
+                sh_root[7 + c] = lerp1(t.gvs[(fb.f0 * RNB) * 3 + c], t.gvs[(fb.f1 * RNB) * 3 + c], fb.blend);
+                sh_root[10 + c] = lerp1(t.gavs[(fb.f0 * RNB) * 3 + c], t.gavs[(fb.f1 * RNB) * 3 + c], fb.blend);
+            }
+            ref_slerp(t.grs + (fb.f0 * RNB) * 4, t.grs + (fb.f1 * RNB) * 4, fb.blend, sh_root + 3);
+        }
+        if (lane < 4) {
+            const int kb = t.key_bodies[lane];
+            for (int c = 0; c < 3; ++c)
+                sh_key[lane * 3 + c] = lerp1(t.gts[(fb.f0 * RNB + kb) * 3 + c], t.gts[(fb.f1 * RNB + kb) * 3 + c], fb.blend);
+        }
+        __syncthreads();
+        amp_row(lane, sh_root, sh_root + 3, sh_root + 7, sh_root + 10, sh_dp, sh_dv, 1, sh_key, t.betas + (long)env * 17,
+                t.dof_subset, t.n_dof_subset, t.amp_obs_buf + ((long)env * EMLOCO_AMP_STEPS + k) * EMLOCO_AMP_ROW);
+        __syncthreads();
+    }
+}
+
+}  // namespace emloco

@@ -7,6 +7,7 @@
 #include <vector>
 #include "sim_kernels.hip"
 #include "topology.h"
+#include "sim_state.h"
 
 namespace {
 
@@ -26,17 +27,6 @@ int fail(int code, const char *what, hipError_t e = hipSuccess) {
         if (e_ != hipSuccess) return fail(EMLOCO_E_HIP, #expr, e_);             \
     } while (0)
 
-template <class T> struct DevBuf {
-    T *p = nullptr; size_t n = 0;
-    hipError_t alloc(size_t count) { n = count; return hipMalloc((void **)&p, count * sizeof(T)); }
-    hipError_t upload(const T *src, size_t count) {
-        hipError_t e = alloc(count);
-        if (e != hipSuccess) return e;
-        return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-};
-
 __global__ void copy_rows_kernel(const float *src, float *dst, const int *ids, int n_ids, int row_len) {
     const int i = blockIdx.x;
     if (i >= n_ids) return;
@@ -50,27 +40,6 @@ __global__ void fill_quat_kernel(float *root, int n_env) {
 }
 
 }  // namespace
-
-struct EmlocoSim {
-    int device = 0;
-    EmlocoSimParams prm{};
-    bool have_model = false, prepared = false, timing = false;
-    int n_env = 0;
-    emloco::Topology topo;
-    // host copies of the model until prepare()
-    std::vector<float> h_off, h_mass, h_com, h_inertia, h_ga, h_gb, h_gr, h_kp, h_kd, h_arm, h_eff;
-    // device
-    DevBuf<int> d_parent, d_depth, d_children, d_gtype, d_cand_body, d_cand_k;
-    DevBuf<unsigned char> d_lca;
-    DevBuf<float> d_off, d_mass, d_com, d_inertia, d_ga, d_gb, d_gr, d_kp, d_kd, d_arm, d_eff;
-    DevBuf<float> d_root, d_dof, d_tgt, d_rb, d_cf, d_df, d_lws;
-    EmlocoSimDev dev{};
-    // HIP-event timing of step launches: a ring of event pairs recorded on the launch stream
-    static constexpr int kRing = 1024;
-    std::vector<hipEvent_t> ev0, ev1;
-    int ev_head = 0, ev_count = 0;
-    float last_ms = -1.0f;
-};
 
 extern "C" {
 
@@ -275,6 +244,14 @@ int emloco_sim_refresh_bodies(EmlocoSim *s, void *stream) {
     if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_refresh_bodies: null sim");
     if (!s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_refresh_bodies: sim not prepared");
     hipLaunchKernelGGL(emloco::sim_fk_kernel, dim3((unsigned)s->n_env), dim3(64), 0, (hipStream_t)stream, s->dev, (const int *)nullptr, s->n_env);
+    HIPCHK(hipGetLastError());
+    return EMLOCO_OK;
+}
+
+// internal (not in the public header): forward kinematics of the listed envs, used by emloco_task_reset
+int emloco_sim_fk_indexed(EmlocoSim *s, const int32_t *ids, int n, void *stream) {
+    if (!s || !s->prepared || !ids || n < 1) return fail(EMLOCO_E_ARG, "emloco_sim_fk_indexed: bad argument");
+    hipLaunchKernelGGL(emloco::sim_fk_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, s->dev, (const int *)ids, n);
     HIPCHK(hipGetLastError());
     return EMLOCO_OK;
 }

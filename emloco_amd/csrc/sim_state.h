@@ -1,0 +1,40 @@
+// sim_state.h -- internal: the simulator object behind the opaque EmlocoSim handle (shared by the C-ABI units).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "emloco_types.h"
+#include "topology.h"
+
+template <class T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    hipError_t alloc(size_t count) { n = count; return hipMalloc((void **)&p, count * sizeof(T)); }
+    hipError_t upload(const T *src, size_t count) {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+
+struct EmlocoSim {
+    int device = 0;
+    EmlocoSimParams prm{};
+    bool have_model = false, prepared = false, timing = false;
+    int n_env = 0;
+    emloco::Topology topo;
+    // host copies of the model until prepare()
+    std::vector<float> h_off, h_mass, h_com, h_inertia, h_ga, h_gb, h_gr, h_kp, h_kd, h_arm, h_eff;
+    // device
+    DevBuf<int> d_parent, d_depth, d_children, d_gtype, d_cand_body, d_cand_k;
+    DevBuf<unsigned char> d_lca;
+    DevBuf<float> d_off, d_mass, d_com, d_inertia, d_ga, d_gb, d_gr, d_kp, d_kd, d_arm, d_eff;
+    DevBuf<float> d_root, d_dof, d_tgt, d_rb, d_cf, d_df, d_lws;
+    EmlocoSimDev dev{};
+    // HIP-event timing of step launches: a ring of event pairs recorded on the launch stream
+    static constexpr int kRing = 1024;
+    std::vector<hipEvent_t> ev0, ev1;
+    int ev_head = 0, ev_count = 0;
+    float last_ms = -1.0f;
+};
+

@@ -3,6 +3,10 @@
 #include <cstdio>
 #include <string>
 #include "task_kernels.hip"
+#include "reset_kernels.hip"
+#include "sim_state.h"
+
+extern "C" int emloco_sim_fk_indexed(EmlocoSim *s, const int32_t *ids, int n, void *stream);
 
 namespace {
 hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
@@ -80,6 +84,29 @@ int emloco_task_amp_rows(int n, const float *root_pos, const float *root_rot, co
     if (n == 0) return 0;
     hipLaunchKernelGGL(emloco::amp_rows_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, n, root_pos, root_rot,
                        root_vel, root_ang_vel, dof_pos, dof_vel, key_pos, betas, dof_subset, n_dof_subset, out);
+    THIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_task_reset(EmlocoSim *sim, const EmlocoResetBufs *b, const int32_t *dev_env_ids, int n, const float *dev_rnd, void *stream) {
+    if (!sim || !b || !dev_env_ids || !dev_rnd) return tfail(-1, "emloco_task_reset: null argument");
+    if (!sim->prepared) return tfail(-3, "emloco_task_reset: sim not prepared");
+    if (n < 0 || n > sim->n_env) return tfail(-1, "emloco_task_reset: bad env count");
+    if (n == 0) return 0;
+    if (!b->gts || !b->grs || !b->lrs || !b->gvs || !b->gavs || !b->dvs || !b->motion_len || !b->motion_dt || !b->motion_nframes ||
+        !b->motion_start || b->n_motions < 1 || !b->heightfield || !b->betas || !b->key_bodies || !b->dof_subset || !b->traj_verts ||
+        !b->inverted || !b->progress_buf || !b->reset_buf || !b->terminate_buf || !b->waypoint_traj || !b->init_pose || !b->init_vel ||
+        !b->amp_obs_buf || !b->motion_ids || !b->motion_times || !b->ground_h)
+        return tfail(-1, "emloco_task_reset: missing buffers");
+    if (!(b->flags & EMLOCO_RESET_FIXED_LOCATION) && (!b->valid_x || !b->valid_y || b->n_valid < 1))
+        return tfail(-1, "emloco_task_reset: no valid locations");
+    if ((b->flags & EMLOCO_RESET_REAL_PATH) && b->n_real > 0 && !b->real_traj) return tfail(-1, "emloco_task_reset: real_path without data");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(emloco::reset_sample_kernel, dim3((unsigned)n), dim3(64), 0, st, *b, sim->dev, dev_env_ids, n, dev_rnd);
+    THIPCHK(hipGetLastError());
+    const int rc = emloco_sim_fk_indexed(sim, dev_env_ids, n, stream);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(emloco::reset_finish_kernel, dim3((unsigned)n), dim3(64), 0, st, *b, sim->dev, dev_env_ids, n, dev_rnd);
     THIPCHK(hipGetLastError());
     return 0;
 }

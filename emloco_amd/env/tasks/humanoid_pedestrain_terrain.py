@@ -52,6 +52,9 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         self.waypoint_traj = torch.zeros(self.num_envs, n_wp, 3).to(self.device)     # :93-99
         self.init_pose = torch.zeros(self.num_envs, 24, 3).to(self.device)
         self.init_vel = torch.zeros(self.num_envs, 2).to(self.device)
+        self._fused_reset = bool(cfg["env"].get("fused_reset", True)) and self._state_init == self.StateInit.Random \
+            and not flags.vru and not flags.add_noise and not flags.fixed_path and not flags.slow
+        self._reset_bufs = None
         return
 
     # ------------------------------------------------------------------ sizes
@@ -127,6 +130,74 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
             progress_buf=self.progress_buf, reset_buf=self.reset_buf, terminate_buf=self._terminate_buf,
             obs_buf=self.obs_buf, flip_obs_buf=self._flip_obs_buf, rew_buf=self.rew_buf, reward_raw=self.reward_raw,
             amp_obs_buf=self._amp_obs_buf)
+
+    # ------------------------------------------------------------------ fused device reset (include/emloco_task.h)
+    def _make_reset_bufs(self):
+        import ctypes as C
+        ml, tg, dev = self._motion_lib, self._traj_gen, self.device
+        f = 0
+        f |= L.RESET_RANDOM_HEADING if flags.random_heading else 0
+        f |= L.RESET_INIT_HEADING if flags.init_heading else 0
+        f |= L.RESET_HEADING_INVERSION if (flags.init_heading and flags.heading_inversion) else 0
+        f |= L.RESET_ADJUST_ROOT_VEL if flags.adjust_root_vel else 0
+        f |= L.RESET_REAL_PATH if flags.real_path else 0
+        f |= L.RESET_FIXED_LOCATION if flags.fixed else 0
+        real = None
+        if flags.real_path:
+            rows = []
+            for d in tg.traj_data:
+                rows += [np.asarray(v["traj"], np.float32)[:101] for v in (d.values() if isinstance(d, dict) else d)]
+            real = torch.from_numpy(np.stack(rows)).to(dev).contiguous()
+        E = self.num_envs
+        self._reset_motion_ids = torch.zeros(E, dtype=torch.long, device=dev)
+        self._reset_motion_times = torch.zeros(E, device=dev)
+        self._reset_ground_h = torch.zeros(E, device=dev)
+        self._inverted_u8 = torch.zeros(E, dtype=torch.uint8, device=dev)
+        keep = dict(real=real, vx=self.terrain.coord_x_scale.float().contiguous(), vy=self.terrain.coord_y_scale.float().contiguous(),
+                    hf=self.height_samples.contiguous())
+        self._reset_keep = keep
+        p = lambda t: None if t is None else t.data_ptr()
+        return L.ResetBufs(
+            f, ml.num_motions(), 0 if real is None else int(real.shape[0]), int(keep["vx"].numel()), int(self._post.dof_subset.numel()),
+            int(keep["hf"].shape[0]), int(keep["hf"].shape[1]), 50.0, 55.0, float(self.dt), 0.02,
+            float(tg._dt), float(tg._dtheta_max), float(tg._speed_min), float(tg._speed_max), float(tg._accel_max),
+            float(tg._sharp_turn_prob), float(tg._hybrid_init_prob), float(tg.get_traj_duration()), float(self._traj_sample_timestep),
+            float(self.terrain.horizontal_scale), float(self.terrain.vertical_scale),
+            p(ml.gts), p(ml.grs), p(ml.lrs), p(ml.gvs), p(ml.gavs), p(ml.dvs), p(ml._motion_lengths), p(ml._motion_dt),
+            p(ml._motion_num_frames), p(ml.length_starts), p(real), p(keep["hf"]), p(keep["vx"]), p(keep["vy"]),
+            p(self.humanoid_betas), p(self._post.key_bodies), p(self._post.dof_subset), p(tg._verts), p(self._inverted_u8),
+            p(self.progress_buf), p(self.reset_buf), p(self._terminate_buf), p(self.waypoint_traj), p(self.init_pose), p(self.init_vel),
+            p(self._amp_obs_buf), p(self._reset_motion_ids), p(self._reset_motion_times), p(self._reset_ground_h))
+
+    def _fused_reset_envs(self, env_ids, rnd=None):
+        """reset(env_ids) as three kernel launches + the indexed observation launch (replaces ~1 100 torch launches)."""
+        import ctypes as C
+        from ...sim import current_stream_handle
+        if self._reset_bufs is None:
+            self._reset_bufs = self._make_reset_bufs()
+        n = int(env_ids.numel())
+        ids32 = self._humanoid_actor_ids[env_ids.to(self.device)].contiguous()
+        if rnd is None:
+            rnd = torch.rand((n, L.RESET_RND), device=self.device)
+        rc = self._post.lib.emloco_task_reset(self.sim.native._h, C.byref(self._reset_bufs), C.c_void_p(ids32.data_ptr()), n,
+                                              C.c_void_p(rnd.data_ptr()), current_stream_handle(torch.device(self.device)))
+        L.check(rc, "emloco_task_reset")
+        self._post.run(self._post_bufs if self._post_bufs is not None else self._ensure_post_bufs(), L.POST_OBS | L.POST_AMP_ROW, ids32)
+        if flags.init_heading and flags.heading_inversion:
+            self._traj_gen.inverted = self._inverted_u8.bool()
+        self.inverted = self._traj_gen.show_inverted()
+        self._motion_start_times[env_ids] = self._reset_motion_times[env_ids]
+        self._sampled_motion_ids[env_ids] = self._reset_motion_ids[env_ids]
+
+    def _ensure_post_bufs(self):
+        self._post_bufs = self._make_post_bufs()
+        return self._post_bufs
+
+    def _reset_envs(self, env_ids):
+        if getattr(self, "_fused_reset", False) and len(env_ids) > 0 and getattr(self, "_traj_gen", None) is not None:
+            self._fused_reset_envs(env_ids)
+        else:
+            super()._reset_envs(env_ids)
 
     # ------------------------------------------------------------------ reset (:493-631)
     def _reset_task(self, env_ids):

@@ -97,6 +97,66 @@ int emloco_task_pd_targets(int n_env, const float *actions, const float *offset,
 float emloco_task_last_ms(void);
 int emloco_task_enable_timing(int on);
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused reset of finished envs (reference-state init + task reset; per-episode, but with 4096 envs some env
+ * resets almost every step).  Replaces the ~1 100 small torch launches of the host-side path:
+ *   _sample_ref_state / get_motion_state_smpl      humanoid_pedestrain_terrain.py:526-573, motion_lib_smpl.py:485-606
+ *   _reset_ref_state_init, _set_env_state          humanoid_pedestrain_terrain.py:575-631, humanoid_amp.py:537-563
+ *   _reset_env_tensors                             humanoid.py:467-481
+ *   TrajGenerator.reset                            env/util/traj_generator.py:60-237
+ *   _reset_task (LocoVal input capture)            humanoid_pedestrain_terrain.py:493-523
+ *   _init_amp_obs_ref (history back-fill)          humanoid_amp.py:486-535
+ * Random numbers are supplied by the caller (`rnd`, uniform [0,1), EMLOCO_RESET_RND floats per env) so a test can
+ * drive the kernels and the host mirror with the same draws. */
+#define EMLOCO_RESET_RND 512
+enum {
+    EMLOCO_RESET_RANDOM_HEADING = 1, EMLOCO_RESET_INIT_HEADING = 2, EMLOCO_RESET_HEADING_INVERSION = 4,
+    EMLOCO_RESET_ADJUST_ROOT_VEL = 8, EMLOCO_RESET_REAL_PATH = 16, EMLOCO_RESET_FIXED_LOCATION = 32
+};
+/* layout of one env's random row */
+enum {
+    EMLOCO_RND_MOTION = 0, EMLOCO_RND_TIME = 1, EMLOCO_RND_YAW = 2, EMLOCO_RND_SPEED = 3, EMLOCO_RND_LOC = 4,
+    EMLOCO_RND_REAL = 5, EMLOCO_RND_REAL_PICK = 6, EMLOCO_RND_INVERSION = 7, EMLOCO_RND_HEADING = 8, EMLOCO_RND_SPEED0 = 9,
+    EMLOCO_RND_DTHETA = 16, EMLOCO_RND_SHARP = 116, EMLOCO_RND_BERN = 216, EMLOCO_RND_DSPEED = 316
+};
+
+typedef struct {
+    int32_t flags;
+    int32_t n_motions, n_real, n_valid, n_dof_subset;
+    int32_t hf_rows, hf_cols;
+    float fixed_x, fixed_y;
+    float dt;                       /* control dt */
+    float height_tolerance;         /* lowest collision point above ground after reset (0.02) */
+    float vert_dt, dtheta_max, speed_min, speed_max, accel_max, sharp_prob, hybrid_prob;   /* TrajGenerator */
+    float traj_dur, sample_dt, hscale, vscale;
+    /* motion cache (motion_lib_smpl.py:334-341) */
+    const float *gts, *grs, *lrs, *gvs, *gavs, *dvs;
+    const float *motion_len, *motion_dt;
+    const int64_t *motion_nframes, *motion_start;
+    const float *real_traj;         /* [n_real][101][3] or NULL */
+    const int16_t *heightfield;
+    const float *valid_x, *valid_y; /* walkable sample locations [n_valid] */
+    const float *betas;             /* [E][17] */
+    const int32_t *key_bodies, *dof_subset;
+    /* task buffers written */
+    float *traj_verts;              /* [E][101][3] */
+    uint8_t *inverted;              /* [E] (bool) */
+    int64_t *progress_buf, *reset_buf, *terminate_buf;
+    float *waypoint_traj;           /* [E][15][3] */
+    float *init_pose;               /* [E][24][3] */
+    float *init_vel;                /* [E][2] */
+    float *amp_obs_buf;             /* [E][15][206]: rows 1..14 back-filled here, row 0 by emloco_task_post_physics */
+    int64_t *motion_ids;            /* [E] */
+    float *motion_times;            /* [E] */
+    float *ground_h;                /* [E] scratch: ground height under the reset pose */
+} EmlocoResetBufs;
+
+struct EmlocoSim;
+/* resets the listed envs of `sim` (device env ids, n entries, rnd [n][EMLOCO_RESET_RND]) */
+int emloco_task_reset(struct EmlocoSim *sim, const EmlocoResetBufs *bufs, const int32_t *dev_env_ids, int n,
+                      const float *dev_rnd, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

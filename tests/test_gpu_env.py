@@ -107,3 +107,49 @@ def test_locoval_rollout_fits_value_function():
     assert agent.vnet_fits > 0 and np.isfinite(agent.vnet_loss)
     assert not torch.equal(w0, agent.valuenet._network.fc1.weight)      # the optimiser really stepped
     assert agent.frames == 6 * 16 * 128
+
+
+def test_fused_reset_matches_host_mirror():
+    """The three-kernel device reset against the host-side torch mirror of the reference's reset path."""
+    from emloco_amd import _lib as L
+    from emloco_amd.utils.flags import flags
+    env = _make_env(64, ["--init_heading", "--heading_inversion", "--adjust_root_vel"])
+    task = env.task
+    E = 64
+    dev = task.device
+    ids = torch.arange(E, device=dev)
+    torch.manual_seed(0)
+    rnd = torch.rand(E, L.RESET_RND, device=dev)
+    task.progress_buf[:] = 55
+    task._fused_reset_envs(ids, rnd=rnd)
+    torch.cuda.synchronize()
+    assert (task.progress_buf == 0).all() and (task.reset_buf == 0).all() and (task._terminate_buf == 0).all()
+    # motion sample: same (motion id, time) through the host motion library
+    mid, mt = task._reset_motion_ids, task._reset_motion_times
+    ref = task._motion_lib.get_motion_state_smpl(mid, mt)
+    np.testing.assert_allclose(task._dof_pos.cpu().numpy(), ref["dof_pos"].cpu().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(task._dof_vel.cpu().numpy(), ref["dof_vel"].cpu().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(task._humanoid_root_states[:, 3:7].cpu().numpy(), ref["root_rot"].cpu().numpy(), rtol=1e-4, atol=2e-5)
+    assert torch.allclose(task._humanoid_root_states[:, 0], torch.full((E,), 50.0, device=dev))     # flags.fixed placement (:588)
+    low = task._lowest_point(ids).cpu().numpy()
+    np.testing.assert_allclose(low, 0.02, atol=2e-4)
+    # trajectory: host TrajGenerator with the same draws
+    from emloco_amd.env.util.traj_generator import TrajGenerator
+    tg = TrajGenerator(E, task.max_episode_length * task.dt, 101, dev, 2.0, task._speed_min, task._speed_max, task._accel_max,
+                       task._sharp_turn_prob, None, hybridInitProb=task._hybrid_init_prob, flags=flags)
+    draws = dict(r_dtheta=rnd[:, L.RND_DTHETA:L.RND_DTHETA + 100], r_dtheta_sharp=rnd[:, L.RND_SHARP:L.RND_SHARP + 100],
+                 bern_sharp=(rnd[:, L.RND_BERN:L.RND_BERN + 100] < task._sharp_turn_prob).float(), r_heading=rnd[:, L.RND_HEADING],
+                 r_dspeed=rnd[:, L.RND_DSPEED:L.RND_DSPEED + 100], r_speed0=rnd[:, L.RND_SPEED0], r_inversion=rnd[:, L.RND_INVERSION])
+    root = task._humanoid_root_states
+    tg.reset(ids, root[:, 0:3].clone(), root[:, 7:10].clone(), draws={k: v.clone() for k, v in draws.items()})
+    np.testing.assert_allclose(task._traj_gen._verts.cpu().numpy(), tg._verts.cpu().numpy(), rtol=1e-4, atol=2e-3)
+    np.testing.assert_array_equal(task.inverted.cpu().numpy(), tg.inverted.cpu().numpy())            # bit-exact mask
+    # LocoVal inputs and AMP history
+    np.testing.assert_allclose(task.waypoint_traj.cpu().numpy(), task._fetch_traj_samples(ids).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(task.init_pose.cpu().numpy(), task._rigid_body_pos.cpu().numpy(), rtol=0, atol=0)
+    n = 14
+    mids = torch.tile(mid.unsqueeze(-1), [1, n]).view(-1)
+    mts = (mt.unsqueeze(-1) - task.dt * (torch.arange(n, device=dev) + 1)).view(-1)
+    rows = task._amp_rows_from_motion(mids, mts, task.humanoid_betas.unsqueeze(1).expand(-1, n, -1).reshape(-1, 17)).view(E, n, 206)
+    np.testing.assert_allclose(task._amp_obs_buf[:, 1:].cpu().numpy(), rows.cpu().numpy(), rtol=1e-4, atol=2e-5)
+    assert torch.isfinite(task.obs_buf).all()
