@@ -22,7 +22,9 @@ UNITS = [
     ("task_capi.hip", ["-ffp-contract=off"]),
     ("predictor_capi.hip", []),
 ]
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+# EMLOCO_HIPCC_EXTRA="-DFOO=1 ..." appends flags to every unit (A/B experiments)
+EXTRA = os.environ.get("EMLOCO_HIPCC_EXTRA", "").split()
+COMMON = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
 

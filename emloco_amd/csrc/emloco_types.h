@@ -16,4 +16,5 @@ struct EmlocoSimDev {
     float *root_state, *dof_state;
     const float *pd_target;
     float *rb_state, *contact_force, *dof_force, *lambda_ws;
+    long long *prof;   /* optional (built with -DEMLOCO_SIM_PROFILE): per-phase cycle stamps of env 0, else NULL */
 };

@@ -256,6 +256,21 @@ int emloco_sim_fk_indexed(EmlocoSim *s, const int32_t *ids, int n, void *stream)
     return EMLOCO_OK;
 }
 
+// internal profiling hook (kernels built with -DEMLOCO_SIM_PROFILE): cycle stamps of env 0, 16 per substep
+int emloco_sim_profile(EmlocoSim *s, long long *host_out, int n) {
+    if (!s || !host_out || n < 1) return fail(EMLOCO_E_ARG, "emloco_sim_profile: bad argument");
+    if (!s->dev.prof) {
+        long long *p = nullptr;
+        HIPCHK(hipMalloc((void **)&p, 16 * 16 * sizeof(long long)));
+        HIPCHK(hipMemset(p, 0, 16 * 16 * sizeof(long long)));
+        s->dev.prof = p;
+        return EMLOCO_OK;
+    }
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(host_out, s->dev.prof, sizeof(long long) * (n < 256 ? n : 256), hipMemcpyDeviceToHost));
+    return EMLOCO_OK;
+}
+
 int emloco_sim_num_candidates(EmlocoSim *s) { return s ? s->topo.n_cand : EMLOCO_E_ARG; }
 
 int emloco_sim_enable_timing(EmlocoSim *s, int on) {

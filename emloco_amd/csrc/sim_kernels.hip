@@ -12,8 +12,8 @@
 //   lane = body      (24 active)  kinematics, inertia, bias forces, articulated-body passes (level-synchronous)
 //   lane = candidate (<=128, 2/lane) ground-contact detection, wave ballot + popcount compaction
 //   lane = contact row (<=60)     chain propagation, contact-matrix column, Gauss-Seidel multiplier
-// Gauss-Seidel row products are reduced with a fixed xor butterfly (wave_sum), which is also the order
-// the CPU oracle uses, so multipliers agree to rounding.
+// Gauss-Seidel row products are reduced on the DPP crossbar in a fixed association order (wave_sum), which is
+// also the order the CPU oracle uses, so multipliers agree bit for bit.
 //
 // HBM traffic per env.step is ~9 KB (state in/out + per-env model), the kernel is latency/occupancy
 // bound, not bandwidth bound.
@@ -28,20 +28,28 @@ namespace emloco {
 #define MAXC EMLOCO_MAXC
 #define MAXR (3 * EMLOCO_MAXC)
 #define MAXCAND EMLOCO_MAXCAND
-#define YS 32 /* row stride of Y (30 used) */
-#define AS (MAXR + 1) /* row stride of the contact matrix, odd to spread banks */
+#define YLEN 30 /* chain-propagation vector: 6 root + 3 per tree level (depth <= 8) */
 
 // index into a packed symmetric 6x6 (upper triangle, row-major): (a<=b)
 __device__ __forceinline__ constexpr int sidx(int a, int b) {
     return a <= b ? (a * (13 - a)) / 2 + (b - a) : (b * (13 - b)) / 2 + (a - b);
 }
 
+#ifdef EMLOCO_SIM_PROFILE
+#define PSTAMP(i) do { if (d.prof && env == 0 && lane == 0) d.prof[sub * 16 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+
 struct BodyConst {   // per-lane (lane = body) constants, loaded once per launch
     int parent, depth, nchild, child[3];
     float off[3], mass, com[3], in6[6];
 };
 
-__global__ void __launch_bounds__(64)
+#ifndef EMLOCO_SIM_WAVES_PER_SIMD
+#define EMLOCO_SIM_WAVES_PER_SIMD 2   /* register budget 256 per lane: two resident waves per SIMD (8 envs per CU) */
+#endif
+__global__ void __launch_bounds__(64, EMLOCO_SIM_WAVES_PER_SIMD)
 sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     const int env = blockIdx.x;
     const int lane = threadIdx.x;
@@ -57,8 +65,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     __shared__ int sh_par[NB], sh_dep[NB];
     __shared__ int sh_cbody[MAXC], sh_ccand[MAXC];
     __shared__ float sh_cx[MAXC][3], sh_cdist[MAXC];
-    __shared__ float sh_Y[MAXR][YS];
-    __shared__ float sh_A[MAXR][AS];
+    __shared__ float sh_A[MAXR * (MAXR + 1) / 2];   // contact matrix, lower triangle: (r, s<=r) at r(r+1)/2 + s
     __shared__ float sh_lam[MAXR];
     __shared__ float sh_lws[MAXCAND * 3];
     __shared__ unsigned char sh_lca[NB * NB];
@@ -138,6 +145,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         const bool final_pass = (sub == prm.n_sub);   // kinematics only, to write the body states
         const bool last = (sub == prm.n_sub - 1);
 
+        PSTAMP(0);
         // ============================================================ 1. kinematics + velocities (root -> leaves)
         if (lane == 0) {
             float q0[4] = {sh_root[3], sh_root[4], sh_root[5], sh_root[6]};
@@ -187,6 +195,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         }
         if (final_pass) break;
 
+        PSTAMP(1);
         // ============================================================ 2. inertia about O, bias force, drive
         float I6[21], f[6];
         if (is_body) {
@@ -231,6 +240,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             }
         }
 
+        PSTAMP(2);
         // ============================================================ 3. articulated-body factorisation + up pass (leaves -> root)
         float IA[21], pA[6], Wm[18], Km[6];
         for (int lev = d.max_depth; lev >= 0; --lev) {
@@ -313,6 +323,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             __syncthreads();
         }
 
+        PSTAMP(3);
         // ============================================================ 4. down pass: joint accelerations, v_free
         for (int lev = 1; lev <= d.max_depth; ++lev) {
             if (is_body && bc.depth == lev) {
@@ -341,6 +352,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             if (lane == 0) for (int k = 0; k < 6; ++k) V0f[k] = sh_root[7 + k] + h * sh_a[0][k];
         }
 
+        PSTAMP(4);
         // ============================================================ 5. ground-contact candidates (lane = candidate)
         float cdist[2], cxw[2][3]; bool act[2];
         for (int s = 0; s < 2; ++s) {
@@ -385,8 +397,11 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         __syncthreads();
         const int nr = 3 * nc;
 
+        PSTAMP(5);
         // ============================================================ 6a. rows: Jacobian, rhs, chain propagation (lane = row)
         float J[6] = {0, 0, 0, 0, 0, 0}, rhs = 0.0f, lam = 0.0f;
+        float ys[YLEN];                                   // this row's chain-propagation vector, kept in registers
+        for (int k = 0; k < YLEN; ++k) ys[k] = 0.0f;
         const int myc = lane / 3, myd = lane - 3 * myc;
         int rbody = 0;
         if (lane < nr) {
@@ -407,7 +422,6 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             rhs = vel + bias;
             float p[6];
             for (int k = 0; k < 6; ++k) p[k] = -J[k];
-            for (int k = 0; k < YS; ++k) sh_Y[lane][k] = 0.0f;
             for (int i = rbody; i >= 1; i = sh_par[i]) {
                 float Ri[9], ri[3], u[3], uhh[3];
                 for (int k = 0; k < 9; ++k) Ri[k] = sh_R[i][k];
@@ -420,48 +434,51 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 }
                 const float *K = sh_K[i], *W = sh_W[i];
                 uhh[0] = K[0] * u[0]; uhh[1] = K[1] * u[0] + K[2] * u[1]; uhh[2] = K[3] * u[0] + K[4] * u[1] + K[5] * u[2];
-                const int slot = 6 + 3 * (sh_dep[i] - 1);
-                sh_Y[lane][slot] = uhh[0]; sh_Y[lane][slot + 1] = uhh[1]; sh_Y[lane][slot + 2] = uhh[2];
+                const int lev = sh_dep[i] - 1;          // static register indexing: select the level's slot
+                for (int q = 0; q < 8; ++q)
+                    if (q == lev) { ys[6 + 3 * q] = uhh[0]; ys[6 + 3 * q + 1] = uhh[1]; ys[6 + 3 * q + 2] = uhh[2]; }
                 for (int k = 0; k < 6; ++k) p[k] += W[k * 3] * uhh[0] + W[k * 3 + 1] * uhh[1] + W[k * 3 + 2] * uhh[2];
             }
             for (int a = 0; a < 6; ++a) {   // L0 y = p
                 float acc = p[a];
-                for (int k = 0; k < a; ++k) acc -= sh_L0[a * 6 + k] * sh_Y[lane][k];
-                sh_Y[lane][a] = acc / sh_L0[a * 6 + a];
+                for (int k = 0; k < a; ++k) acc -= sh_L0[a * 6 + k] * ys[k];
+                ys[a] = acc / sh_L0[a * 6 + a];
             }
             lam = prm.warm * sh_lws[sh_ccand[myc] * 3 + myd];
         }
         __syncthreads();
 
-        // ============================================================ 6b. contact-matrix column (lane = column s)
-        if (lane < nr) {
-            float ys[30];
-            for (int k = 0; k < 30; ++k) ys[k] = sh_Y[lane][k];
-            for (int rr = 0; rr < nr; ++rr) {
-                const int len = 6 + 3 * (int)sh_lca[sh_cbody[rr / 3] * NB + rbody];
-                float acc = 0.0f;
-                for (int k = 0; k < 30; ++k)
-                    if (k < len) acc += sh_Y[rr][k] * ys[k];
-                sh_A[rr][lane] = acc;
+        PSTAMP(6);
+        // ============================================================ 6b. contact matrix, lower triangle (lane = column s)
+        // A[rr][s] = <y_rr, y_s> over the common-ancestor prefix; y_rr is broadcast from lane rr with v_readlane.
+        for (int rr = 0; rr < nr; ++rr) {
+            const int len = (lane < nr) ? 6 + 3 * (int)sh_lca[sh_cbody[rr / 3] * NB + rbody] : 0;
+            float acc = 0.0f;
+            for (int k = 0; k < YLEN; ++k) {
+                const float yr = lane_bcast(ys[k], rr);
+                if (k < len) acc += yr * ys[k];
             }
+            if (lane <= rr) sh_A[rr * (rr + 1) / 2 + lane] = acc;
         }
         __syncthreads();
 
+        PSTAMP(7);
         // ============================================================ 6c. projected Gauss-Seidel (lane s holds lambda_s)
-        const float adiag = (lane < nr) ? sh_A[lane][lane] * (1.0f + prm.cfm) : 1.0f;
+        const float adiag = (lane < nr) ? sh_A[lane * (lane + 1) / 2 + lane] * (1.0f + prm.cfm) : 1.0f;
         for (int it = 0; it < prm.n_iter; ++it)
             for (int c = 0; c < nc; ++c) {
                 for (int dr = 0; dr < 3; ++dr) {
                     const int rr = 3 * c + dr;
-                    const float prod = (lane < nr) ? sh_A[rr][lane] * lam : 0.0f;
-                    const float res = __shfl(rhs, rr) + wave_sum(prod);
+                    const int ai = lane <= rr ? rr * (rr + 1) / 2 + lane : lane * (lane + 1) / 2 + rr;
+                    const float prod = (lane < nr) ? sh_A[ai] * lam : 0.0f;
+                    const float res = lane_bcast(rhs, rr) + wave_sum(prod);
                     if (lane == rr) {
                         float nl = lam - res / adiag;
                         if (dr == 0 && nl < 0.0f) nl = 0.0f;
                         lam = nl;
                     }
                 }
-                const float ln = __shfl(lam, 3 * c), l1 = __shfl(lam, 3 * c + 1), l2 = __shfl(lam, 3 * c + 2);
+                const float ln = lane_bcast(lam, 3 * c), l1 = lane_bcast(lam, 3 * c + 1), l2 = lane_bcast(lam, 3 * c + 2);
                 const float lim = prm.mu * ln;
                 const float mag = sqrtf(l1 * l1 + l2 * l2);
                 if (mag > lim && (lane == 3 * c + 1 || lane == 3 * c + 2)) {
@@ -474,6 +491,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         __syncthreads();
         if (lane < nr) sh_lws[sh_ccand[myc] * 3 + myd] = lam;
 
+        PSTAMP(8);
         // ============================================================ 7. impulses -> velocity change (second solve)
         float dq[3] = {0, 0, 0}, da0[6] = {0, 0, 0, 0, 0, 0};
         if (is_body && last) { sh_cf[lane][0] = 0.0f; sh_cf[lane][1] = 0.0f; sh_cf[lane][2] = 0.0f; }
@@ -552,6 +570,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             }
         }
 
+        PSTAMP(9);
         // ============================================================ 8. integrate
         const float damp = 1.0f / (1.0f + h * prm.ang_damping);
         if (is_body && lane >= 1) {
@@ -586,6 +605,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             for (int k = 0; k < 6; ++k) sh_root[7 + k] = V0[k];
         }
         __syncthreads();
+        PSTAMP(10);
     }
 
     // ---------------------------------------------------------------- write back (state after the final kinematics pass)

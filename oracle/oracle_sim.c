@@ -424,6 +424,20 @@ static int find_contacts(const Env *s, const EnvModel *m, const OrcSimParams *pr
     return n;
 }
 
+/* Sum of 64 lane values in the order of dev_math.h: wave_sum (DPP row_mirror, row_half_mirror, quad xor 1, quad xor 2
+ * inside each 16-lane row, then ((r0 + r1) + r2) + r3 over the rows). */
+static float wave_sum_order(const float *v) {
+    float z[4];
+    for (int r = 0; r < 4; ++r) {
+        const float *x = v + 16 * r;
+        float w[8], q[4];
+        for (int i = 0; i < 8; ++i) w[i] = x[i] + x[15 - i];
+        for (int i = 0; i < 4; ++i) q[i] = w[i] + w[7 - i];
+        z[r] = (q[0] + q[1]) + (q[2] + q[3]);
+    }
+    return ((z[0] + z[1]) + z[2]) + z[3];
+}
+
 /* ---------------------------------------------------------------- substep */
 static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const float *tgt, float *edof,
                     float *lam_ws, float *cforce, float *dforce, int last) {
@@ -500,15 +514,10 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
         for (int c = 0; c < nc; ++c) {
             for (int d = 0; d < 3; ++d) {
                 int r = 3 * c + d;
-                /* row product summed in the order of a 64-lane xor butterfly (offsets 32..1) */
+                /* row product summed in the association order of the GPU's DPP wave reduction */
                 float v[64];
                 for (int q = 0; q < 64; ++q) v[q] = q < nr ? A[r][q] * lam[q] : 0.0f;
-                for (int off = 32; off >= 1; off >>= 1) {
-                    float t[64];
-                    for (int q = 0; q < 64; ++q) t[q] = v[q] + v[q ^ off];
-                    memcpy(v, t, sizeof(v));
-                }
-                float res = rhs[r] + v[0];
+                float res = rhs[r] + wave_sum_order(v);
                 float nl = lam[r] - res / (A[r][r] * (1.0f + prm->cfm));
                 if (d == 0 && nl < 0.0f) nl = 0.0f;
                 lam[r] = nl;

@@ -90,3 +90,16 @@ static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, 
     return d;
 }
 using std::exp; using std::cos; using std::sin; using std::atan2;
+
+// DPP lane permutations (the gfx9 dpp_ctrl codes the kernels use) and v_readlane
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned from;
+    if (ctrl == 0x140) from = (lane & ~15u) | (15u - (lane & 15u));                 // row_mirror
+    else if (ctrl == 0x141) from = (lane & ~7u) | (7u - (lane & 7u));               // row_half_mirror
+    else if (ctrl >= 0 && ctrl <= 0xFF) from = (lane & ~3u) | ((unsigned)(ctrl >> (2 * (lane & 3u))) & 3u);   // quad_perm
+    else from = lane;
+    return emu_exchange(src, (int)from);
+}
+static inline int __builtin_amdgcn_readlane(int v, int src_lane) { return emu_exchange(v, src_lane); }
