@@ -111,6 +111,90 @@ def cpu_baseline(sample_envs=512, sample_steps=400):
                       f"single thread, {dt:.1f} s)"}
 
 
+def synthetic_jta_batch(B, seed=0, max_people=8):
+    """JTA-shaped batch: joints (B, N, 21, 49, 4), N ~ U{1..8} padded to the batch max, 2.5 fps walker
+    trajectories, 24 SMPL-like 3-D joints around the pelvis, boxes / 2-D pose ~ N(0,1)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    n_people = torch.randint(1, max_people + 1, (B,), generator=g)
+    N = int(n_people.max())
+    joints = torch.randn(B, N, 21, 49, 4, generator=g)
+    speed = torch.rand(B, N, 1, 1, generator=g) * 1.5 + 0.3
+    heading = (torch.rand(B, N, 1, generator=g) * 2 - 1) * 3.14159 + torch.cumsum(torch.randn(B, N, 21, generator=g) * 0.05, dim=2)
+    step = torch.stack([torch.cos(heading), torch.sin(heading)], -1) * speed * 0.4
+    joints[:, :, :, 0, :2] = torch.cumsum(step, dim=2) + torch.randn(B, N, 1, 2, generator=g) * 3
+    joints[:, :, :, 0, 2:] = 0
+    joints[:, :, :, 3:27, :3] = joints[:, :, :, 0:1, :3] + torch.randn(B, N, 21, 24, 3, generator=g) * 0.3
+    pad = torch.arange(N).unsqueeze(0) >= n_people.unsqueeze(1)
+    return joints, torch.ones(B, N, 21, 49), pad
+
+
+def jta_leg(dev, steps=4, warmup=2, B=256):
+    """train_jta.py EmLoco step (configs[3]): fwd + MSE + LocoVal loss + bwd + clip + Adam, batch 256, fp32 MFMA."""
+    import torch
+    from emloco_amd.learning.value_pose_net import ValuePoseNet
+    from emloco_amd.predictor import ops
+    from emloco_amd.predictor.model_jta import TransMotionJTA
+    from emloco_amd.predictor.train_jta import EmLocoTrainer
+    torch.manual_seed(0)
+    cfg = {"DEVICE": str(dev), "MULTI_MODAL": False, "USE_FRAME_MASK": False,
+           "TRAIN": {"input_track_size": 9, "output_track_size": 12, "lr": 1e-4, "max_grad_norm": 1.0, "valuenet_weight": 1.0}}
+    model = TransMotionJTA(tok_dim=453, nhid=128, nhead=4, dim_feedfwd=1024, nlayers_local=6, nlayers_global=3, nmode=20,
+                           output_scale=1, obs_and_pred=21, num_tokens=49, device=str(dev)).to(dev)
+    trainer = EmLocoTrainer(model, ValuePoseNet(True, True).to(dev), cfg)
+    joints, masks, pad = synthetic_jta_batch(B)
+    for _ in range(warmup):
+        trainer.step(joints, masks, pad)
+    ops.gemm_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.step(joints, masks, pad)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n, ms, fl = ops.gemm_timing()
+    ops.gemm_timing(False)
+    tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    out = {"metric": "JTA samples/sec (train_jta EmLoco step)", "value": round(B * steps / dt, 2), "unit": "samples/s",
+           "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "warmup": warmup, "dtype": "f32",
+           "config": {"workload": "configs[3]: Social-Transmotion train_jta.py with EmLoco loss (valueloss_w=1.0), batch 256, "
+                                  "9-in/12-out frames, people/scene U{1..8} padded, d=128 h=4 ff=1024, 6+3 layers",
+                      "batch": B, "people_padded": int(joints.shape[1]), "tokens_per_person": 453},
+           "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": round(tf / 157.3, 4), "traffic": None, "gemm_launches": n, "gemm_ms_per_step": round(ms / steps, 2),
+                        "note": "fp32-in fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32), peak = fp32 matrix peak"}}
+    return out
+
+
+def jta_cpu_baseline(B=4):
+    """The same EmLoco train step on the host cores with the stock-torch restatement (oracle/predictor_torch.py)."""
+    import torch
+    from oracle.predictor_torch import LocoValOracle, TransMotionJTAOracle, emloco_train_step
+    from emloco_amd.predictor.train_jta import batch_process_coords
+    cores = min(os.cpu_count() or 1, 16)      # stock torch oversubscribes badly beyond ~16 threads on these small GEMMs
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = TransMotionJTAOracle(dropout=0.0)
+    vnet = LocoValOracle()
+    for p in vnet.parameters():
+        p.requires_grad_(False)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    joints, masks, pad = synthetic_jta_batch(B, seed=1)
+    cfg = {"DEVICE": "cpu", "TRAIN": {"input_track_size": 9, "output_track_size": 12}}
+    i, _, o, _, pm = batch_process_coords(joints, masks, pad, cfg, training=True)
+    pose = joints[:, 0, 8, 3:27, :3].clone()
+    vel = (i[:, 8, 0, :2] - i[:, 7, 0, :2]) * 2.5
+    emloco_train_step(model, vnet, opt, i, o, pm, pose, vel)            # warm-up
+    iters = 3
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        emloco_train_step(model, vnet, opt, i, o, pm, pose, vel)
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(B / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} timed iterations (after 1 warm-up) of the same train step at batch {B} x {joints.shape[1]} people, "
+                      f"stock torch.nn fp32 restatement on {cores} host threads ({dt:.1f} s / iteration)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +202,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--num_envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_jta", action="store_true", help="skip the train_jta samples/s leg (run on rank 0 at N=1)")
     a = ap.parse_args()
 
     import torch
@@ -193,6 +278,12 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not a.no_jta:
+            del env, task, pool
+            torch.cuda.empty_cache()
+            out["jta"] = jta_leg(dev)
+            if not a.no_cpu_baseline:
+                out["jta"]["cpu_baseline"] = jta_cpu_baseline()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -63,8 +63,13 @@ int emloco_gemm_f32(int batch, int m, int n, int k, float alpha, const float *A,
     hipStream_t st = (hipStream_t)stream;
     const int slot = g_head;
     if (g_timing) PHIPCHK(hipEventRecord(g_e0[slot], st));
-    dim3 grid((unsigned)((n + GBN - 1) / GBN), (unsigned)((m + GBM - 1) / GBM), (unsigned)(batch * ksplit));
-    hipLaunchKernelGGL(emloco::gemm_f32_kernel, grid, dim3(256), 0, st, g);
+    if (n <= 32) {
+        dim3 grid((unsigned)((n + 31) / 32), (unsigned)((m + 127) / 128), (unsigned)(batch * ksplit));
+        hipLaunchKernelGGL((emloco::gemm_f32_kernel<4, 1, 1, 1>), grid, dim3(256), 0, st, g);
+    } else {
+        dim3 grid((unsigned)((n + 127) / 128), (unsigned)((m + 127) / 128), (unsigned)(batch * ksplit));
+        hipLaunchKernelGGL((emloco::gemm_f32_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, g);
+    }
     PHIPCHK(hipGetLastError());
     if (ksplit > 1) {
         const long total = (long)batch * m * n;

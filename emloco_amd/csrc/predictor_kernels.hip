@@ -19,10 +19,7 @@ namespace emloco {
 
 typedef float f32x16 __attribute__((vector_size(64)));
 
-#define GBM 128
-#define GBN 128
 #define GBK 16
-#define GLD (GBM + 4)
 
 struct GemmArgs {
     int batch, m, n, k;
@@ -33,14 +30,19 @@ struct GemmArgs {
     const float *bias; int flags; int ksplit; float *ws;
 };
 
+// Tile shapes: <2,2,2,2> = 128x128 (4 waves as 2x2, each 2x2 MFMA tiles) for the projections / FFN / score products;
+// <4,1,1,1> = 128x32 (4 waves stacked in M, one MFMA tile each) for the products whose N is the head dim (32):
+// P.V, dQ, dK, dV -- a 128-wide tile would waste 3/4 of its MFMAs there.
+template <int WM, int WN, int TI, int TJ>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(GemmArgs g) {
-    __shared__ float As[GBK][GLD], Bs[GBK][GLD];
+    constexpr int BM = WM * TI * 32, BN = WN * TJ * 32;
+    __shared__ float As[GBK][BM + 4], Bs[GBK][BN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave - wm * WN;
     const int bz = blockIdx.z;
     const int b = bz / g.ksplit, split = bz - b * g.ksplit;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     int kchunk = (g.k + g.ksplit - 1) / g.ksplit;
     kchunk = ((kchunk + GBK - 1) / GBK) * GBK;
     const int kb = split * kchunk;
@@ -48,25 +50,25 @@ gemm_f32_kernel(GemmArgs g) {
     const float *A = g.A + (long)b * g.sa;
     const float *B = g.B + (long)b * g.sb;
 
-    f32x16 acc[2][2];
-    for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < 2; ++j)
+    f32x16 acc[TI][TJ];
+    for (int i = 0; i < TI; ++i)
+        for (int j = 0; j < TJ; ++j)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     for (int k0 = kb; k0 < ke; k0 += GBK) {
-        for (int e = 0; e < (GBM * GBK) / 256; ++e) {
+        for (int e = 0; e < (BM * GBK) / 256; ++e) {
             const int idx = tid + 256 * e;
             int mm, kk;
-            if (!g.ta) { mm = idx / GBK; kk = idx - mm * GBK; } else { kk = idx / GBM; mm = idx - kk * GBM; }
+            if (!g.ta) { mm = idx / GBK; kk = idx - mm * GBK; } else { kk = idx / BM; mm = idx - kk * BM; }
             float v = 0.0f;
             if (m0 + mm < g.m && k0 + kk < ke)
                 v = g.ta ? A[(long)(k0 + kk) * g.lda + (m0 + mm)] : A[(long)(m0 + mm) * g.lda + (k0 + kk)];
             As[kk][mm] = v;
         }
-        for (int e = 0; e < (GBN * GBK) / 256; ++e) {
+        for (int e = 0; e < (BN * GBK) / 256; ++e) {
             const int idx = tid + 256 * e;
             int nn, kk;
-            if (!g.tb) { nn = idx / GBK; kk = idx - nn * GBK; } else { kk = idx / GBN; nn = idx - kk * GBN; }
+            if (!g.tb) { nn = idx / GBK; kk = idx - nn * GBK; } else { kk = idx / BN; nn = idx - kk * BN; }
             float v = 0.0f;
             if (n0 + nn < g.n && k0 + kk < ke)
                 v = g.tb ? B[(long)(k0 + kk) * g.ldb + (n0 + nn)] : B[(long)(n0 + nn) * g.ldb + (k0 + kk)];
@@ -75,21 +77,21 @@ gemm_f32_kernel(GemmArgs g) {
         __syncthreads();
         for (int kk = 0; kk < GBK; kk += 2) {
             const int kr = kk + (lane >> 5);
-            const float a0 = As[kr][wm * 64 + (lane & 31)], a1 = As[kr][wm * 64 + 32 + (lane & 31)];
-            const float b0 = Bs[kr][wn * 64 + (lane & 31)], b1 = Bs[kr][wn * 64 + 32 + (lane & 31)];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[TI], bv[TJ];
+            for (int i = 0; i < TI; ++i) av[i] = As[kr][(wm * TI + i) * 32 + (lane & 31)];
+            for (int j = 0; j < TJ; ++j) bv[j] = Bs[kr][(wn * TJ + j) * 32 + (lane & 31)];
+            for (int i = 0; i < TI; ++i)
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
     // epilogue: C/D fragment layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < TI; ++i)
+        for (int j = 0; j < TJ; ++j)
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+                const int row = m0 + (wm * TI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = n0 + (wn * TJ + j) * 32 + (lane & 31);
                 if (row < g.m && col < g.n) {
                     float v = g.alpha * acc[i][j][r];
                     if (g.ksplit > 1) {

@@ -41,9 +41,9 @@ __device__ __forceinline__ constexpr int sidx(int a, int b) {
 #define PSTAMP(i) do { } while (0)
 #endif
 
-struct BodyConst {   // per-lane (lane = body) constants, loaded once per launch
+struct BodyConst {   // per-lane (lane = body) constants kept in registers for the whole launch
     int parent, depth, nchild, child[3];
-    float off[3], mass, com[3], in6[6];
+    float off[3];
 };
 
 #ifndef EMLOCO_SIM_WAVES_PER_SIMD
@@ -70,6 +70,10 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     __shared__ float sh_lws[MAXCAND * 3];
     __shared__ unsigned char sh_lca[NB * NB];
     __shared__ float sh_cf[NB][3];
+    // body inertia / bias force handed from phase 2 to phase 3 through LDS; they alias the contact matrix, which is
+    // only live in phases 6b-6c (barriers separate the phases)
+    float (*sh_I6)[21] = (float (*)[21])sh_A;
+    float (*sh_f)[6] = (float (*)[6])(sh_A + NB * 21);
 
     // ---------------------------------------------------------------- per-lane constants
     BodyConst bc;
@@ -79,40 +83,10 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     bc.depth = d.depth[b];
     bc.nchild = 0;
     for (int k = 0; k < 3; ++k) { bc.child[k] = d.children[b * 3 + k]; bc.nchild += bc.child[k] >= 0; }
-    {
-        const long mb = (long)env * NB + b;
-        for (int k = 0; k < 3; ++k) { bc.off[k] = d.joint_off[mb * 3 + k]; bc.com[k] = d.com[mb * 3 + k]; }
-        for (int k = 0; k < 6; ++k) bc.in6[k] = d.inertia[mb * 6 + k];
-        bc.mass = d.mass[mb];
-    }
-    float kp[3] = {0, 0, 0}, kd[3] = {0, 0, 0}, arm[3] = {0, 0, 0}, eff[3] = {0, 0, 0}, tgt[3] = {0, 0, 0};
-    if (is_body && lane >= 1)
-        for (int k = 0; k < 3; ++k) {
-            const long di = (long)env * NDOF + (lane - 1) * 3 + k;
-            kp[k] = d.kp[di]; kd[k] = d.kd[di]; arm[k] = d.armature[di]; eff[k] = d.effort[di]; tgt[k] = d.pd_target[di];
-        }
-    // two contact candidates per lane: `lane` and `lane + 64`
-    int cb[2]; float clp[2][3], crad[2];
-    for (int s = 0; s < 2; ++s) {
-        const int c = lane + 64 * s;
-        cb[s] = -1; crad[s] = 0.0f; clp[s][0] = clp[s][1] = clp[s][2] = 0.0f;
-        if (c < d.n_cand) {
-            const int body = d.cand_body[c], k = d.cand_k[c];
-            const long mb = (long)env * NB + body;
-            const float *ga = d.geom_a + mb * 3, *gb = d.geom_b + mb * 3;
-            const int gt = d.geom_type[body];
-            cb[s] = body; crad[s] = d.geom_r[mb];
-            if (gt == EMLOCO_GEOM_SPHERE) { clp[s][0] = ga[0]; clp[s][1] = ga[1]; clp[s][2] = ga[2]; }
-            else if (gt == EMLOCO_GEOM_CAPSULE) {
-                const float *src = k == 0 ? ga : gb;
-                clp[s][0] = src[0]; clp[s][1] = src[1]; clp[s][2] = src[2];
-            } else {
-                clp[s][0] = ga[0] + ((k & 1) ? gb[0] : -gb[0]);
-                clp[s][1] = ga[1] + ((k & 2) ? gb[1] : -gb[1]);
-                clp[s][2] = ga[2] + ((k & 4) ? gb[2] : -gb[2]);
-            }
-        }
-    }
+    const long mb0 = (long)env * NB + b;
+    for (int k = 0; k < 3; ++k) bc.off[k] = d.joint_off[mb0 * 3 + k];
+    // drive gains / targets are re-read (L2 hits) where they are used instead of pinning 15 registers for the launch
+    const long dof0 = (long)env * NDOF + (is_body && lane >= 1 ? (lane - 1) * 3 : 0);
     if (is_body) { sh_par[lane] = bc.parent; sh_dep[lane] = bc.depth; }
     for (int i = lane; i < NB * NB; i += 64) sh_lca[i] = d.lca_depth[i];
     for (int i = lane; i < MAXCAND * 3; i += 64) sh_lws[i] = d.lambda_ws[(long)env * MAXCAND * 3 + i];
@@ -137,7 +111,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
 
     const float h = prm.h;
     // registers that persist across phases (lane = body)
-    float R[9], r[3], Sl[3][3], V[6];
+    // (R, r, V of a body live in LDS; the motion-subspace columns S = [R e_c ; r x R e_c] are re-formed where needed)
     float tau[3], dd[3]; bool sat[3];
     float uh[3], qdd[3];
 
@@ -148,18 +122,18 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         PSTAMP(0);
         // ============================================================ 1. kinematics + velocities (root -> leaves)
         if (lane == 0) {
-            float q0[4] = {sh_root[3], sh_root[4], sh_root[5], sh_root[6]};
+            float q0[4] = {sh_root[3], sh_root[4], sh_root[5], sh_root[6]}, R[9];
             q2mat(q0, R);
-            for (int k = 0; k < 3; ++k) { sh_pw[0][k] = sh_root[k]; sh_r[0][k] = 0.0f; r[k] = 0.0f; }
+            for (int k = 0; k < 3; ++k) { sh_pw[0][k] = sh_root[k]; sh_r[0][k] = 0.0f; }
             for (int k = 0; k < 4; ++k) sh_qw[0][k] = q0[k];
             for (int k = 0; k < 9; ++k) sh_R[0][k] = R[k];
-            for (int k = 0; k < 6; ++k) { V[k] = sh_root[7 + k]; sh_V[0][k] = V[k]; sh_Aacc[0][k] = 0.0f; }
+            for (int k = 0; k < 6; ++k) { sh_V[0][k] = sh_root[7 + k]; sh_Aacc[0][k] = 0.0f; }
         }
         __syncthreads();
         for (int lev = 1; lev <= d.max_depth; ++lev) {
             if (is_body && bc.depth == lev) {
                 const int p = bc.parent;
-                float Rp[9], o[3], qp[4], qw[4], pw[3];
+                float Rp[9], o[3], qp[4], qw[4], pw[3], R[9], r[3], Sl[3][3], V[6];
                 for (int k = 0; k < 9; ++k) Rp[k] = sh_R[p][k];
                 for (int k = 0; k < 4; ++k) qp[k] = sh_qw[p][k];
                 matvec3(Rp, bc.off, o);
@@ -197,10 +171,16 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
 
         PSTAMP(1);
         // ============================================================ 2. inertia about O, bias force, drive
-        float I6[21], f[6];
         if (is_body) {
-            float Rc[9], Ic[9], cw[3], c[3];
-            const float Ib[9] = {bc.in6[0], bc.in6[3], bc.in6[4], bc.in6[3], bc.in6[1], bc.in6[5], bc.in6[4], bc.in6[5], bc.in6[2]};
+            float I6[21], f[6], R[9], r[3], V[6];
+            for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
+            for (int k = 0; k < 3; ++k) r[k] = sh_r[lane][k];
+            for (int k = 0; k < 6; ++k) V[k] = sh_V[lane][k];
+            float Rc[9], Ic[9], cw[3], c[3], in6[6], bcom[3];
+            for (int k = 0; k < 6; ++k) in6[k] = d.inertia[mb0 * 6 + k];      // mass properties: re-read per substep (L2 hits)
+            for (int k = 0; k < 3; ++k) bcom[k] = d.com[mb0 * 3 + k];
+            const float bmass = d.mass[mb0];
+            const float Ib[9] = {in6[0], in6[3], in6[4], in6[3], in6[1], in6[5], in6[4], in6[5], in6[2]};
             for (int a = 0; a < 3; ++a)
                 for (int q = 0; q < 3; ++q) Rc[a * 3 + q] = R[a * 3] * Ib[q] + R[a * 3 + 1] * Ib[3 + q] + R[a * 3 + 2] * Ib[6 + q];
             for (int a = 0; a < 3; ++a)
@@ -208,9 +188,9 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     Ic[a * 3 + q] = Rc[a * 3] * R[q * 3] + Rc[a * 3 + 1] * R[q * 3 + 1] + Rc[a * 3 + 2] * R[q * 3 + 2];
                     Ic[q * 3 + a] = Ic[a * 3 + q];
                 }
-            matvec3(R, bc.com, cw);
+            matvec3(R, bcom, cw);
             for (int k = 0; k < 3; ++k) c[k] = r[k] + cw[k];
-            const float ms = bc.mass, cc = dot3(c, c);
+            const float ms = bmass, cc = dot3(c, c);
             for (int a = 0; a < 3; ++a)
                 for (int q = a; q < 3; ++q) I6[sidx(a, q)] = Ic[a * 3 + q] + ms * ((a == q ? cc : 0.0f) - c[a] * c[q]);
             const float cx[9] = {0.0f, -c[2], c[1], c[2], 0.0f, -c[0], -c[1], c[0], 0.0f};
@@ -231,8 +211,14 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             float fg[3] = {0.0f, 0.0f, ms * prm.gravity_z}, ng[3];
             cross3(c, fg, ng);
             for (int k = 0; k < 3; ++k) { f[k] -= ng[k]; f[3 + k] -= fg[k]; }
+            for (int k = 0; k < 21; ++k) sh_I6[lane][k] = I6[k];
+            for (int k = 0; k < 6; ++k) sh_f[lane][k] = f[k];
             // implicit PD drive (saturated drives act as a constant torque)
             for (int k = 0; k < 3; ++k) {
+                float kp[3], kd[3], arm[3], eff[3], tgt[3];
+                kp[k] = lane >= 1 ? d.kp[dof0 + k] : 0.0f; kd[k] = lane >= 1 ? d.kd[dof0 + k] : 0.0f;
+                arm[k] = lane >= 1 ? d.armature[dof0 + k] : 0.0f; eff[k] = lane >= 1 ? d.effort[dof0 + k] : 0.0f;
+                tgt[k] = lane >= 1 ? d.pd_target[dof0 + k] : 0.0f;
                 const float e = tgt[k] - edof[k];
                 const float te = kp[k] * e - kd[k] * wj[k];
                 if (fabsf(te) > eff[k]) { sat[k] = true; tau[k] = te > 0.0f ? eff[k] : -eff[k]; dd[k] = arm[k]; }
@@ -242,11 +228,16 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
 
         PSTAMP(2);
         // ============================================================ 3. articulated-body factorisation + up pass (leaves -> root)
-        float IA[21], pA[6], Wm[18], Km[6];
+        float pA[6];
         for (int lev = d.max_depth; lev >= 0; --lev) {
             if (is_body && bc.depth == lev) {
-                for (int k = 0; k < 21; ++k) IA[k] = I6[k];
-                for (int k = 0; k < 6; ++k) pA[k] = f[k];
+                float IA[21], Wm[18], Km[6];
+                float R[9], r[3], Sl[3][3];
+                for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
+                for (int k = 0; k < 3; ++k) r[k] = sh_r[lane][k];
+                for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
+                for (int k = 0; k < 21; ++k) IA[k] = sh_I6[lane][k];
+                for (int k = 0; k < 6; ++k) pA[k] = sh_f[lane][k];
                 for (int ci = 0; ci < 3; ++ci) {     // children in descending body index
                     const int ch = bc.child[ci];
                     if (ch >= 0) {
@@ -297,26 +288,28 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     for (int k = 0; k < 6; ++k) sh_K[lane][k] = Km[k];
                 } else {
                     // root: Cholesky of the 6x6 articulated inertia, a0 = -IA0^-1 pA0
-                    float L[36];
+                    float L[21];    // lower triangle, (a, q<=a) at a(a+1)/2 + q
+#define LT(a, q) L[(a) * ((a) + 1) / 2 + (q)]
                     for (int a = 0; a < 6; ++a)
                         for (int q = 0; q <= a; ++q) {
                             float acc = IA[sidx(a, q)];
-                            for (int k = 0; k < q; ++k) acc -= L[a * 6 + k] * L[q * 6 + k];
-                            L[a * 6 + q] = (a == q) ? sqrtf(acc) : acc / L[q * 6 + q];
+                            for (int k = 0; k < q; ++k) acc -= LT(a, k) * LT(q, k);
+                            LT(a, q) = (a == q) ? sqrtf(acc) : acc / LT(q, q);
                         }
                     float y[6], x[6];
                     for (int a = 0; a < 6; ++a) {
                         float acc = -pA[a];
-                        for (int k = 0; k < a; ++k) acc -= L[a * 6 + k] * y[k];
-                        y[a] = acc / L[a * 6 + a];
+                        for (int k = 0; k < a; ++k) acc -= LT(a, k) * y[k];
+                        y[a] = acc / LT(a, a);
                     }
                     for (int a = 5; a >= 0; --a) {
                         float acc = y[a];
-                        for (int k = a + 1; k < 6; ++k) acc -= L[k * 6 + a] * x[k];
-                        x[a] = acc / L[a * 6 + a];
+                        for (int k = a + 1; k < 6; ++k) acc -= LT(k, a) * x[k];
+                        x[a] = acc / LT(a, a);
                     }
                     for (int a = 0; a < 6; ++a)
-                        for (int q = 0; q <= a; ++q) sh_L0[a * 6 + q] = L[a * 6 + q];
+                        for (int q = 0; q <= a; ++q) sh_L0[a * 6 + q] = LT(a, q);
+#undef LT
                     for (int k = 0; k < 6; ++k) sh_a[0][k] = x[k];
                 }
             }
@@ -327,7 +320,13 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         // ============================================================ 4. down pass: joint accelerations, v_free
         for (int lev = 1; lev <= d.max_depth; ++lev) {
             if (is_body && bc.depth == lev) {
-                float ap[6], t[3], a[6];
+                float ap[6], t[3], a[6], Wm[18], Km[6];
+                float R[9], r[3], Sl[3][3];
+                for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
+                for (int k = 0; k < 3; ++k) r[k] = sh_r[lane][k];
+                for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
+                for (int k = 0; k < 18; ++k) Wm[k] = sh_W[lane][k];
+                for (int k = 0; k < 6; ++k) Km[k] = sh_K[lane][k];
                 for (int k = 0; k < 6; ++k) ap[k] = sh_a[bc.parent][k];
                 for (int c = 0; c < 3; ++c) {
                     float acc = 0.0f;
@@ -347,13 +346,36 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         }
         float wjf[3] = {0, 0, 0}, V0f[6];
         if (is_body) {
-            for (int k = 0; k < 6; ++k) sh_Vf[lane][k] = V[k] + h * sh_a[lane][k];
+            for (int k = 0; k < 6; ++k) sh_Vf[lane][k] = sh_V[lane][k] + h * sh_a[lane][k];
             if (lane >= 1) for (int k = 0; k < 3; ++k) wjf[k] = wj[k] + h * qdd[k];
             if (lane == 0) for (int k = 0; k < 6; ++k) V0f[k] = sh_root[7 + k] + h * sh_a[0][k];
         }
 
         PSTAMP(4);
         // ============================================================ 5. ground-contact candidates (lane = candidate)
+        // two candidates per lane (`lane`, `lane + 64`); their body-frame points are re-derived from the model each
+        // substep (L2 hits) rather than held in registers across the launch
+        int cb[2]; float clp[2][3], crad[2];
+        for (int s = 0; s < 2; ++s) {
+            const int c = lane + 64 * s;
+            cb[s] = -1; crad[s] = 0.0f; clp[s][0] = clp[s][1] = clp[s][2] = 0.0f;
+            if (c < d.n_cand) {
+                const int body = d.cand_body[c], k = d.cand_k[c];
+                const long mb = (long)env * NB + body;
+                const float *ga = d.geom_a + mb * 3, *gb = d.geom_b + mb * 3;
+                const int gt = d.geom_type[body];
+                cb[s] = body; crad[s] = d.geom_r[mb];
+                if (gt == EMLOCO_GEOM_SPHERE) { clp[s][0] = ga[0]; clp[s][1] = ga[1]; clp[s][2] = ga[2]; }
+                else if (gt == EMLOCO_GEOM_CAPSULE) {
+                    const float *src = k == 0 ? ga : gb;
+                    clp[s][0] = src[0]; clp[s][1] = src[1]; clp[s][2] = src[2];
+                } else {
+                    clp[s][0] = ga[0] + ((k & 1) ? gb[0] : -gb[0]);
+                    clp[s][1] = ga[1] + ((k & 2) ? gb[1] : -gb[1]);
+                    clp[s][2] = ga[2] + ((k & 4) ? gb[2] : -gb[2]);
+                }
+            }
+        }
         float cdist[2], cxw[2][3]; bool act[2];
         for (int s = 0; s < 2; ++s) {
             act[s] = false; cdist[s] = 0.0f;
@@ -521,7 +543,13 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                         if (ch >= 0) for (int k = 0; k < 6; ++k) pA[k] += sh_pa[ch][k];
                     }
                     if (lev > 0) {
-                        float u[3];
+                        float u[3], Wm[18], Km[6];
+                        float R[9], r[3], Sl[3][3];
+                        for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
+                        for (int k = 0; k < 3; ++k) r[k] = sh_r[lane][k];
+                        for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
+                        for (int k = 0; k < 18; ++k) Wm[k] = sh_W[lane][k];
+                        for (int k = 0; k < 6; ++k) Km[k] = sh_K[lane][k];
                         for (int c = 0; c < 3; ++c) {
                             const float Sc[6] = {R[c], R[3 + c], R[6 + c], Sl[c][0], Sl[c][1], Sl[c][2]};
                             u[c] = 0.0f - dot6(Sc, pA);
@@ -550,7 +578,13 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             }
             for (int lev = 1; lev <= d.max_depth; ++lev) {
                 if (is_body && bc.depth == lev) {
-                    float ap[6], t[3], a[6];
+                    float ap[6], t[3], a[6], Wm[18], Km[6];
+                    float R[9], r[3], Sl[3][3];
+                    for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
+                    for (int k = 0; k < 3; ++k) r[k] = sh_r[lane][k];
+                    for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
+                    for (int k = 0; k < 18; ++k) Wm[k] = sh_W[lane][k];
+                    for (int k = 0; k < 6; ++k) Km[k] = sh_K[lane][k];
                     for (int k = 0; k < 6; ++k) ap[k] = sh_a[bc.parent][k];
                     for (int c = 0; c < 3; ++c) {
                         float acc = 0.0f;
@@ -578,7 +612,8 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             for (int k = 0; k < 3; ++k) {
                 wn[k] = wjf[k] + dq[k];
                 if (last) {
-                    const float tq = sat[k] ? tau[k] : kp[k] * (tgt[k] - edof[k] - h * wn[k]) - kd[k] * wn[k];
+                    const float kpk = d.kp[dof0 + k], kdk = d.kd[dof0 + k], tgk = d.pd_target[dof0 + k];
+                    const float tq = sat[k] ? tau[k] : kpk * (tgk - edof[k] - h * wn[k]) - kdk * wn[k];
                     d.dof_force[(long)env * NDOF + (lane - 1) * 3 + k] = tq;
                 }
                 wj[k] = wn[k] * damp;
@@ -611,7 +646,9 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     // ---------------------------------------------------------------- write back (state after the final kinematics pass)
     if (is_body) {
         float *o = d.rb_state + ((long)env * NB + lane) * 13;
-        float t[3];
+        float t[3], V[6], r[3];
+        for (int k = 0; k < 6; ++k) V[k] = sh_V[lane][k];
+        for (int k = 0; k < 3; ++k) r[k] = sh_r[lane][k];
         cross3(V, r, t);
         for (int k = 0; k < 3; ++k) { o[k] = sh_pw[lane][k]; o[7 + k] = V[3 + k] + t[k]; o[10 + k] = V[k]; }
         for (int k = 0; k < 4; ++k) o[3 + k] = sh_qw[lane][k];

@@ -8,11 +8,15 @@ extern "C" int emu_gemm_f32(int batch, int m, int n, int k, float alpha, const f
                             const float *B, int ldb, long sb, int tb, float *C, int ldc, long sc, const float *bias,
                             int flags, int ksplit, float *ws) {
     GemmArgs g{batch, m, n, k, alpha, A, lda, sa, ta, B, ldb, sb, tb, C, ldc, sc, bias, flags, ksplit, ws};
-    const unsigned gx = (n + GBN - 1) / GBN, gy = (m + GBM - 1) / GBM, gz = batch * ksplit;
+    const bool narrow = n <= 32;
+    const unsigned gx = narrow ? (n + 31) / 32 : (n + 127) / 128, gy = (m + 127) / 128, gz = batch * ksplit;
     for (unsigned z = 0; z < gz; ++z)
         for (unsigned y = 0; y < gy; ++y)
             for (unsigned x = 0; x < gx; ++x) {
-                emu::launch(1, 256, [&] { blockIdx.x = x; blockIdx.y = y; blockIdx.z = z; gemm_f32_kernel(g); });
+                emu::launch(1, 256, [&] {
+                    blockIdx.x = x; blockIdx.y = y; blockIdx.z = z;
+                    if (narrow) gemm_f32_kernel<4, 1, 1, 1>(g); else gemm_f32_kernel<2, 2, 2, 2>(g);
+                });
             }
     blockIdx.y = 0; blockIdx.z = 0;
     if (ksplit > 1) {

@@ -114,6 +114,8 @@ def test_mfma_gemm_kernel_all_layouts():
     np.testing.assert_allclose(_gemm(At, B, 1, 0, m, n, k, alpha=0.5)[0], 0.5 * ref, **tol)
     bias = rng.normal(size=n).astype(np.float32)
     np.testing.assert_allclose(_gemm(A, B, 0, 0, m, n, k, bias=bias, flags=3)[0], np.maximum(ref + bias, 0), **tol)
+    Bn = rng.normal(size=(1, 32, k)).astype(np.float32)          # n <= 32 takes the 128x32 tile variant
+    np.testing.assert_allclose(_gemm(A, Bn, 0, 0, m, 32, k)[0], A[0].astype(np.float64) @ Bn[0].astype(np.float64).T, **tol)
     Ab = rng.normal(size=(3, 40, 20)).astype(np.float32)
     Bb = rng.normal(size=(3, 50, 20)).astype(np.float32)
     np.testing.assert_allclose(_gemm(Ab, Bb, 0, 0, 40, 50, 20, batch=3), np.einsum("bmk,bnk->bmn", Ab, Bb), **tol)
