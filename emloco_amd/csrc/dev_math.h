@@ -173,7 +173,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_mov<0x141>(v);   // row_half_mirror
     v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
     v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-    return ((lane_bcast(v, 0) + lane_bcast(v, 16)) + lane_bcast(v, 32)) + lane_bcast(v, 48);
+    return ((lane_bcast(v, 0) + lane_bcast(v, 16)) + lane_bcast(v, 32)) + lane_bcast(v, 48);   // fixed order r0+r1+r2+r3
 }
 
 }  // namespace emloco

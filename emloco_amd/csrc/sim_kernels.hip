@@ -474,11 +474,14 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         // ============================================================ 6b. contact matrix, lower triangle (lane = column s)
         // A[rr][s] = <y_rr, y_s> over the common-ancestor prefix; y_rr is broadcast from lane rr with v_readlane.
         for (int rr = 0; rr < nr; ++rr) {
-            const int len = (lane < nr) ? 6 + 3 * (int)sh_lca[sh_cbody[rr / 3] * NB + rbody] : 0;
+            const int brr = sh_cbody[rr / 3];
+            const int kmax = 6 + 3 * sh_dep[brr];                    // y_rr is zero beyond its own chain (wave-uniform bound)
+            const int len = (lane < nr) ? 6 + 3 * (int)sh_lca[brr * NB + rbody] : 0;
             float acc = 0.0f;
             for (int k = 0; k < YLEN; ++k) {
+                if (k >= kmax) break;
                 const float yr = lane_bcast(ys[k], rr);
-                if (k < len) acc += yr * ys[k];
+                if (k < len) acc = fmaf(yr, ys[k], acc);
             }
             if (lane <= rr) sh_A[rr * (rr + 1) / 2 + lane] = acc;
         }
@@ -486,28 +489,45 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
 
         PSTAMP(7);
         // ============================================================ 6c. projected Gauss-Seidel (lane s holds lambda_s)
-        const float adiag = (lane < nr) ? sh_A[lane * (lane + 1) / 2 + lane] * (1.0f + prm.cfm) : 1.0f;
-        for (int it = 0; it < prm.n_iter; ++it)
+        // Lane s owns row s: its multiplier `lam`, the running residual w_s = rhs_s + sum_r A_sr lam_r and 1/(A_ss (1+cfm)).
+        // A row update happens in lane rr alone; its change is broadcast with one v_readlane and every lane folds it into
+        // w with one fma through column rr of the symmetric matrix -- no wave reduction in the loop.
+        const int ls = lane < nr ? lane : 0;                      // idle lanes shadow lane 0 (their w is never used)
+        const int tri_s = ls * (ls + 1) / 2;
+        const float ainv = (lane < nr) ? 1.0f / (sh_A[tri_s + ls] * (1.0f + prm.cfm)) : 0.0f;
+        float w = rhs;
+        for (int rr = 0; rr < nr; ++rr) {                         // warm start
+            const float lr = lane_bcast(lam, rr);
+            if (lr != 0.0f) w = fmaf(sh_A[ls <= rr ? rr * (rr + 1) / 2 + ls : tri_s + rr], lr, w);
+        }
+        for (int it = 0; it < prm.n_iter; ++it) {
             for (int c = 0; c < nc; ++c) {
+                float acol[3];
                 for (int dr = 0; dr < 3; ++dr) {
                     const int rr = 3 * c + dr;
-                    const int ai = lane <= rr ? rr * (rr + 1) / 2 + lane : lane * (lane + 1) / 2 + rr;
-                    const float prod = (lane < nr) ? sh_A[ai] * lam : 0.0f;
-                    const float res = lane_bcast(rhs, rr) + wave_sum(prod);
+                    acol[dr] = sh_A[ls <= rr ? rr * (rr + 1) / 2 + ls : tri_s + rr];
+                    float delta = 0.0f;
                     if (lane == rr) {
-                        float nl = lam - res / adiag;
+                        float nl = fmaf(-w, ainv, lam);
                         if (dr == 0 && nl < 0.0f) nl = 0.0f;
+                        delta = nl - lam;
                         lam = nl;
                     }
+                    w = fmaf(acol[dr], lane_bcast(delta, rr), w);
                 }
                 const float ln = lane_bcast(lam, 3 * c), l1 = lane_bcast(lam, 3 * c + 1), l2 = lane_bcast(lam, 3 * c + 2);
                 const float lim = prm.mu * ln;
-                const float mag = sqrtf(l1 * l1 + l2 * l2);
-                if (mag > lim && (lane == 3 * c + 1 || lane == 3 * c + 2)) {
-                    const float sc = mag > 0.0f ? lim / mag : 0.0f;
-                    lam *= sc;
+                const float m2 = fmaf(l1, l1, l2 * l2);
+                if (m2 > lim * lim) {                             // wave-uniform: outside the friction cone
+                    const float sc = lim / sqrtf(m2);
+                    const float n1 = l1 * sc, n2 = l2 * sc;
+                    if (lane == 3 * c + 1) lam = n1;
+                    if (lane == 3 * c + 2) lam = n2;
+                    w = fmaf(acol[1], n1 - l1, w);
+                    w = fmaf(acol[2], n2 - l2, w);
                 }
             }
+        }
         if (lane < MAXR) sh_lam[lane] = (lane < nr) ? lam : 0.0f;
         for (int i = lane; i < MAXCAND * 3; i += 64) sh_lws[i] = 0.0f;
         __syncthreads();

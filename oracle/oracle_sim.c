@@ -505,28 +505,38 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
             for (int d1 = 0; d1 < 3; ++d1)
                 for (int d2 = 0; d2 < 3; ++d2) {
                     float acc = 0.0f;
-                    for (int k = 0; k < len; ++k) acc += Y[3 * c1 + d1][k] * Y[3 * c2 + d2][k];
+                    for (int k = 0; k < len; ++k) acc = fmaf(Y[3 * c1 + d1][k], Y[3 * c2 + d2][k], acc);
                     A[3 * c1 + d1][3 * c2 + d2] = acc;
                 }
         }
-    /* projected Gauss-Seidel: per contact normal first (>= 0), then the two tangents, cone projection */
+    /* projected Gauss-Seidel with an incrementally maintained residual w = rhs + A lam: a row update touches w_r only,
+     * then every w_s absorbs the change through column r (one fma per row -- no reduction, so no summation order to
+     * mirror).  Per contact: normal first (>= 0), the two tangents, then the friction-cone projection. */
+    float ainv[3 * ORC_MAXC], w[3 * ORC_MAXC];
+    for (int r = 0; r < nr; ++r) { ainv[r] = 1.0f / (A[r][r] * (1.0f + prm->cfm)); w[r] = rhs[r]; }
+    for (int r = 0; r < nr; ++r) {
+        float lr = lam[r];                                   /* warm start */
+        if (lr != 0.0f)
+            for (int q = 0; q < nr; ++q) w[q] = fmaf(A[q][r], lr, w[q]);
+    }
     for (int it = 0; it < prm->n_iter; ++it)
         for (int c = 0; c < nc; ++c) {
             for (int d = 0; d < 3; ++d) {
                 int r = 3 * c + d;
-                /* row product summed in the association order of the GPU's DPP wave reduction */
-                float v[64];
-                for (int q = 0; q < 64; ++q) v[q] = q < nr ? A[r][q] * lam[q] : 0.0f;
-                float res = rhs[r] + wave_sum_order(v);
-                float nl = lam[r] - res / (A[r][r] * (1.0f + prm->cfm));
+                float nl = fmaf(-w[r], ainv[r], lam[r]);
                 if (d == 0 && nl < 0.0f) nl = 0.0f;
+                float delta = nl - lam[r];
                 lam[r] = nl;
+                for (int q = 0; q < nr; ++q) w[q] = fmaf(A[q][r], delta, w[q]);
             }
+            float l1 = lam[3 * c + 1], l2 = lam[3 * c + 2];
             float lim = prm->mu * lam[3 * c];
-            float mag = sqrtf(lam[3 * c + 1] * lam[3 * c + 1] + lam[3 * c + 2] * lam[3 * c + 2]);
-            if (mag > lim) {
-                float sc = mag > 0.0f ? lim / mag : 0.0f;
-                lam[3 * c + 1] *= sc; lam[3 * c + 2] *= sc;
+            float m2 = fmaf(l1, l1, l2 * l2);
+            if (m2 > lim * lim) {
+                float sc = lim / sqrtf(m2);
+                float n1 = l1 * sc, n2 = l2 * sc, d1 = n1 - l1, d2 = n2 - l2;
+                lam[3 * c + 1] = n1; lam[3 * c + 2] = n2;
+                for (int q = 0; q < nr; ++q) { w[q] = fmaf(A[q][3 * c + 1], d1, w[q]); w[q] = fmaf(A[q][3 * c + 2], d2, w[q]); }
             }
         }
 

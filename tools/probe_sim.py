@@ -1,5 +1,5 @@
 import sys, time, torch, numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 from emloco_amd import _lib as L
 from emloco_amd.sim import NativeSim
 from helpers import varied_models
