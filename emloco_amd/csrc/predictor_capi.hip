@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <string>
+#include <stdlib.h>
 #include <vector>
 #include "predictor_kernels.hip"
 #include "../../include/emloco_predictor.h"
@@ -59,17 +60,19 @@ int emloco_gemm_f32(int batch, int m, int n, int k, float alpha, const float *A,
     if (ksplit > 1 && !workspace) return pfail(-1, "emloco_gemm_f32: ksplit > 1 needs a workspace");
     if ((long)batch * ksplit > 65535) return pfail(-1, "emloco_gemm_f32: batch * ksplit exceeds the grid z limit");
     emloco::GemmArgs g{batch, m, n, k, alpha, A, lda, (long)stride_a, trans_a, B, ldb, (long)stride_b, trans_b,
-                       C, ldc, (long)stride_c, bias, flags, ksplit, workspace};
+                       C, ldc, (long)stride_c, bias, flags, ksplit, workspace, 0, 0};
+    // 16-byte global loads need the base, the leading dimension and the batch stride 16 B aligned
+    g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && (stride_a % 4 == 0);
+    g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (stride_b % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
     const int slot = g_head;
     if (g_timing) PHIPCHK(hipEventRecord(g_e0[slot], st));
-    if (n <= 32) {
-        dim3 grid((unsigned)((n + 31) / 32), (unsigned)((m + 127) / 128), (unsigned)(batch * ksplit));
-        hipLaunchKernelGGL((emloco::gemm_f32_kernel<4, 1, 1, 1>), grid, dim3(256), 0, st, g);
-    } else {
-        dim3 grid((unsigned)((n + 127) / 128), (unsigned)((m + 127) / 128), (unsigned)(batch * ksplit));
-        hipLaunchKernelGGL((emloco::gemm_f32_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, g);
-    }
+    // stage depth: 32 for long reductions (covers the prefetch latency), 16 for short ones (less LDS, more workgroups / CU)
+    static const int force_bk = getenv("EMLOCO_GEMM_BK") ? atoi(getenv("EMLOCO_GEMM_BK")) : 0;
+    const bool deep = force_bk ? force_bk == 32 : (k + ksplit - 1) / ksplit > 256;
+    const unsigned bn = n <= 32 ? 32 : 128;
+    dim3 grid((unsigned)((n + bn - 1) / bn), (unsigned)((m + 127) / 128), (unsigned)(batch * ksplit));
+    hipLaunchKernelGGL(emloco::gemm_pick(g, deep), grid, dim3(256), 0, st, g);
     PHIPCHK(hipGetLastError());
     if (ksplit > 1) {
         const long total = (long)batch * m * n;

@@ -19,7 +19,8 @@ namespace emloco {
 
 typedef float f32x16 __attribute__((vector_size(64)));
 
-#define GBK 16
+// K depth of one LDS stage is a template parameter GBK (16 or 32); LDS rows are [row][GBK + 4] floats: the 80 B / 144 B
+// row stride keeps the ds_read_b128 of 16 consecutive rows on distinct banks.
 
 struct GemmArgs {
     int batch, m, n, k;
@@ -28,16 +29,96 @@ struct GemmArgs {
     const float *B; int ldb; long sb; int tb;
     float *C; int ldc; long sc;
     const float *bias; int flags; int ksplit; float *ws;
+    int vec_a, vec_b;   // operand may be read with 16-byte loads (base, leading dimension and batch stride 16 B aligned)
 };
+
+struct __attribute__((aligned(16))) f32x4 { float x, y, z, w; };
+
+// One operand stage: a ROWS x GBK slab of X (rows = output rows for A, output columns for B) fetched with 16-byte
+// global loads into registers (`gemm_fetch`), later stored to LDS as [row][k] (`gemm_stash`).  Splitting fetch
+// from stash lets the loads of stage t+1 fly while the MFMAs of stage t run (register-prefetch double buffering).
+// The fetch is BRANCH-FREE: out-of-range rows / k are clamped to a valid address and the value is zeroed with a
+// select, so the compiler keeps every load asynchronous (a branchy version made it wait after each load).
+// TRANS: 0 = X[row][k] (k contiguous), 1 = X[k][row] (row contiguous).  VEC: 16-byte loads allowed (base, leading
+// dimension and batch stride 16 B aligned; then a clamped quad never leaves its row: ld % 4 == 0 and rows, k <= ld).
+template <int ROWS, int GBK, int TRANS, int VEC>
+__device__ __forceinline__ void gemm_fetch(f32x4 (&v)[(ROWS * GBK / 4 + 255) / 256], const float *X, int ld,
+                                           int row0, int rows, int k0, int ke, int tid) {
+    constexpr int NQ = ROWS * GBK / 4, QR = GBK / 4;
+    for (int e = 0; e < (NQ + 255) / 256; ++e) {
+        int idx = tid + 256 * e;
+        if (NQ % 256 != 0 && idx >= NQ) idx = NQ - 1;          // surplus threads re-read the last quad (never stashed)
+        f32x4 t;
+        bool ok0, ok1, ok2, ok3;
+        if (!TRANS) {                                          // 4 consecutive k of one row
+            const int r = idx / QR, q = idx - r * QR;
+            const int row = row0 + r, kk = k0 + 4 * q;
+            const int rowc = row < rows ? row : rows - 1;
+            const bool rok = row < rows;
+            ok0 = rok && kk < ke; ok1 = rok && kk + 1 < ke; ok2 = rok && kk + 2 < ke; ok3 = rok && kk + 3 < ke;
+            const float *base = X + (long)rowc * ld;
+            if (VEC) {
+                const int kq = (ke - 1) & ~3;
+                t = *(const f32x4 *)(base + (kk < kq ? kk : kq));
+            } else {
+                const int kl = ke - 1;
+                t.x = base[kk < kl ? kk : kl]; t.y = base[kk + 1 < kl ? kk + 1 : kl];
+                t.z = base[kk + 2 < kl ? kk + 2 : kl]; t.w = base[kk + 3 < kl ? kk + 3 : kl];
+            }
+        } else {                                               // 4 consecutive rows at one k
+            const int kk = idx / (ROWS / 4), rq = idx - kk * (ROWS / 4);
+            const int row = row0 + 4 * rq, kg = k0 + kk;
+            const int kc = kg < ke ? kg : ke - 1;
+            const bool kok = kg < ke;
+            ok0 = kok && row < rows; ok1 = kok && row + 1 < rows; ok2 = kok && row + 2 < rows; ok3 = kok && row + 3 < rows;
+            const float *base = X + (long)kc * ld;
+            if (VEC) {
+                const int rq4 = (rows - 1) & ~3;
+                t = *(const f32x4 *)(base + (row < rq4 ? row : rq4));
+            } else {
+                const int rl = rows - 1;
+                t.x = base[row < rl ? row : rl]; t.y = base[row + 1 < rl ? row + 1 : rl];
+                t.z = base[row + 2 < rl ? row + 2 : rl]; t.w = base[row + 3 < rl ? row + 3 : rl];
+            }
+        }
+        t.x = ok0 ? t.x : 0.0f; t.y = ok1 ? t.y : 0.0f; t.z = ok2 ? t.z : 0.0f; t.w = ok3 ? t.w : 0.0f;
+        v[e] = t;
+    }
+}
+
+template <int ROWS, int GBK, int TRANS>
+__device__ __forceinline__ void gemm_stash(const f32x4 (&v)[(ROWS * GBK / 4 + 255) / 256], float *S, int tid) {
+    constexpr int NQ = ROWS * GBK / 4, QR = GBK / 4, GLDK = GBK + 4;
+    for (int e = 0; e < (NQ + 255) / 256; ++e) {
+        const int idx = tid + 256 * e;
+        if (NQ % 256 == 0 || idx < NQ) {
+            if (!TRANS) {
+                const int r = idx / QR, q = idx - r * QR;
+                *(f32x4 *)&S[r * GLDK + 4 * q] = v[e];
+            } else {
+                const int kk = idx / (ROWS / 4), rq = idx - kk * (ROWS / 4);
+                float *d = &S[(4 * rq) * GLDK + kk];
+                d[0] = v[e].x; d[GLDK] = v[e].y; d[2 * GLDK] = v[e].z; d[3 * GLDK] = v[e].w;
+            }
+        }
+    }
+}
 
 // Tile shapes: <2,2,2,2> = 128x128 (4 waves as 2x2, each 2x2 MFMA tiles) for the projections / FFN / score products;
 // <4,1,1,1> = 128x32 (4 waves stacked in M, one MFMA tile each) for the products whose N is the head dim (32):
 // P.V, dQ, dK, dV -- a 128-wide tile would waste 3/4 of its MFMAs there.
-template <int WM, int WN, int TI, int TJ>
+//
+// v_mfma_f32_32x32x2_f32 wants A[i = lane & 31][k = lane >> 5]: the two lane halves consume different k.  The k order
+// inside a stage is free (both operands agree on it), so half h takes k in [h GBK/2, (h+1) GBK/2): a lane's fragment
+// values per 32-row block are GBK/8 ds_read_b128 of one LDS row, and step j multiplies k = j (low half) with
+// k = GBK/2 + j (high half).  GBK = 32 (one stage = 64 MFMAs per wave, ~4 k cycles) covers the global-load latency
+// of the register prefetch for long reductions; GBK = 16 keeps LDS small (more workgroups per CU) for K <= 256.
+template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(GemmArgs g) {
-    constexpr int BM = WM * TI * 32, BN = WN * TJ * 32;
-    __shared__ float As[GBK][BM + 4], Bs[GBK][BN + 4];
+    constexpr int BM = WM * TI * 32, BN = WN * TJ * 32, GLDK = GBK + 4, NF = GBK / 8;
+    constexpr int QA = (BM * GBK / 4 + 255) / 256, QB = (BN * GBK / 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * GLDK], Bs[2][BN * GLDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int bz = blockIdx.z;
@@ -55,36 +136,39 @@ gemm_f32_kernel(GemmArgs g) {
         for (int j = 0; j < TJ; ++j)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    f32x4 ra[QA], rb[QB];
+    if (kb < ke) {
+        gemm_fetch<BM, GBK, TA, VEC>(ra, A, g.lda, m0, g.m, kb, ke, tid);
+        gemm_fetch<BN, GBK, TB, VEC>(rb, B, g.ldb, n0, g.n, kb, ke, tid);
+        gemm_stash<BM, GBK, TA>(ra, As[0], tid);
+        gemm_stash<BN, GBK, TB>(rb, Bs[0], tid);
+    }
+    __syncthreads();
+    int buf = 0;
+    const int half8 = (GBK / 2) * (lane >> 5), l31 = lane & 31;
     for (int k0 = kb; k0 < ke; k0 += GBK) {
-        for (int e = 0; e < (BM * GBK) / 256; ++e) {
-            const int idx = tid + 256 * e;
-            int mm, kk;
-            if (!g.ta) { mm = idx / GBK; kk = idx - mm * GBK; } else { kk = idx / BM; mm = idx - kk * BM; }
-            float v = 0.0f;
-            if (m0 + mm < g.m && k0 + kk < ke)
-                v = g.ta ? A[(long)(k0 + kk) * g.lda + (m0 + mm)] : A[(long)(m0 + mm) * g.lda + (k0 + kk)];
-            As[kk][mm] = v;
+        // next stage's global loads are in flight during the MFMAs (past the end they fetch zeros: clamped + masked)
+        gemm_fetch<BM, GBK, TA, VEC>(ra, A, g.lda, m0, g.m, k0 + GBK, ke, tid);
+        gemm_fetch<BN, GBK, TB, VEC>(rb, B, g.ldb, n0, g.n, k0 + GBK, ke, tid);
+        f32x4 fa[TI][NF], fb[TJ][NF];
+        for (int i = 0; i < TI; ++i) {
+            const float *src = &As[buf][((wm * TI + i) * 32 + l31) * GLDK + half8];
+            for (int f = 0; f < NF; ++f) fa[i][f] = *(const f32x4 *)(src + 4 * f);
         }
-        for (int e = 0; e < (BN * GBK) / 256; ++e) {
-            const int idx = tid + 256 * e;
-            int nn, kk;
-            if (!g.tb) { nn = idx / GBK; kk = idx - nn * GBK; } else { kk = idx / BN; nn = idx - kk * BN; }
-            float v = 0.0f;
-            if (n0 + nn < g.n && k0 + kk < ke)
-                v = g.tb ? B[(long)(k0 + kk) * g.ldb + (n0 + nn)] : B[(long)(n0 + nn) * g.ldb + (k0 + kk)];
-            Bs[kk][nn] = v;
+        for (int j = 0; j < TJ; ++j) {
+            const float *src = &Bs[buf][((wn * TJ + j) * 32 + l31) * GLDK + half8];
+            for (int f = 0; f < NF; ++f) fb[j][f] = *(const f32x4 *)(src + 4 * f);
         }
+#define GEMM_STEP(H, C)                                                                                          \
+        for (int i = 0; i < TI; ++i)                                                                             \
+            for (int j = 0; j < TJ; ++j)                                                                         \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][H].C, fb[j][H].C, acc[i][j], 0, 0, 0);
+        for (int f = 0; f < NF; ++f) { GEMM_STEP(f, x) GEMM_STEP(f, y) GEMM_STEP(f, z) GEMM_STEP(f, w) }
+#undef GEMM_STEP
+        gemm_stash<BM, GBK, TA>(ra, As[buf ^ 1], tid);
+        gemm_stash<BN, GBK, TB>(rb, Bs[buf ^ 1], tid);
         __syncthreads();
-        for (int kk = 0; kk < GBK; kk += 2) {
-            const int kr = kk + (lane >> 5);
-            float av[TI], bv[TJ];
-            for (int i = 0; i < TI; ++i) av[i] = As[kr][(wm * TI + i) * 32 + (lane & 31)];
-            for (int j = 0; j < TJ; ++j) bv[j] = Bs[kr][(wn * TJ + j) * 32 + (lane & 31)];
-            for (int i = 0; i < TI; ++i)
-                for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
+        buf ^= 1;
     }
     // epilogue: C/D fragment layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     for (int i = 0; i < TI; ++i)
@@ -105,6 +189,27 @@ gemm_f32_kernel(GemmArgs g) {
                     }
                 }
             }
+}
+
+// kernel variant for a problem: tile shape (narrow: n <= 32), stage depth, operand layouts, 16-byte loads
+typedef void (*GemmKernel)(GemmArgs);
+template <int WM, int WN, int TI, int TJ, int GBK>
+inline GemmKernel gemm_pick_layout(int ta, int tb, int vec) {
+    if (vec) {
+        if (!ta && !tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 0, 0, 1>;
+        if (!ta && tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 0, 1, 1>;
+        if (ta && !tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 1, 0, 1>;
+        return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 1, 1, 1>;
+    }
+    if (!ta && !tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 0, 0, 0>;
+    if (!ta && tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 0, 1, 0>;
+    if (ta && !tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 1, 0, 0>;
+    return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 1, 1, 0>;
+}
+inline GemmKernel gemm_pick(const GemmArgs &g, bool deep) {
+    const int vec = g.vec_a && g.vec_b;
+    if (g.n <= 32) return deep ? gemm_pick_layout<4, 1, 1, 1, 32>(g.ta, g.tb, vec) : gemm_pick_layout<4, 1, 1, 1, 16>(g.ta, g.tb, vec);
+    return deep ? gemm_pick_layout<2, 2, 2, 2, 32>(g.ta, g.tb, vec) : gemm_pick_layout<2, 2, 2, 2, 16>(g.ta, g.tb, vec);
 }
 
 // sum of the ksplit partial products in a fixed order, then the epilogue

@@ -1,3 +1,4 @@
+#include <stdint.h>
 // TEST INFRASTRUCTURE ONLY: runs emloco_amd/csrc/predictor_kernels.hip on the CPU through tests/emu/hip/.
 #include "hip/hip_runtime.h"
 #include "../../emloco_amd/csrc/predictor_kernels.hip"
@@ -7,7 +8,9 @@ using namespace emloco;
 extern "C" int emu_gemm_f32(int batch, int m, int n, int k, float alpha, const float *A, int lda, long sa, int ta,
                             const float *B, int ldb, long sb, int tb, float *C, int ldc, long sc, const float *bias,
                             int flags, int ksplit, float *ws) {
-    GemmArgs g{batch, m, n, k, alpha, A, lda, sa, ta, B, ldb, sb, tb, C, ldc, sc, bias, flags, ksplit, ws};
+    GemmArgs g{batch, m, n, k, alpha, A, lda, sa, ta, B, ldb, sb, tb, C, ldc, sc, bias, flags, ksplit, ws, 0, 0};
+    g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && (sa % 4 == 0);     // as emloco_gemm_f32 decides it
+    g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (sb % 4 == 0);
     const bool narrow = n <= 32;
     const unsigned gx = narrow ? (n + 31) / 32 : (n + 127) / 128, gy = (m + 127) / 128, gz = batch * ksplit;
     for (unsigned z = 0; z < gz; ++z)
@@ -15,7 +18,8 @@ extern "C" int emu_gemm_f32(int batch, int m, int n, int k, float alpha, const f
             for (unsigned x = 0; x < gx; ++x) {
                 emu::launch(1, 256, [&] {
                     blockIdx.x = x; blockIdx.y = y; blockIdx.z = z;
-                    if (narrow) gemm_f32_kernel<4, 1, 1, 1>(g); else gemm_f32_kernel<2, 2, 2, 2>(g);
+                    const bool deep = (k + ksplit - 1) / ksplit > 256;     // as emloco_gemm_f32 picks the stage depth
+                    gemm_pick(g, deep)(g);
                 });
             }
     blockIdx.y = 0; blockIdx.z = 0;

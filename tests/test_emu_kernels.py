@@ -116,6 +116,23 @@ def test_mfma_gemm_kernel_all_layouts():
     np.testing.assert_allclose(_gemm(A, B, 0, 0, m, n, k, bias=bias, flags=3)[0], np.maximum(ref + bias, 0), **tol)
     Bn = rng.normal(size=(1, 32, k)).astype(np.float32)          # n <= 32 takes the 128x32 tile variant
     np.testing.assert_allclose(_gemm(A, Bn, 0, 0, m, 32, k)[0], A[0].astype(np.float64) @ Bn[0].astype(np.float64).T, **tol)
+    # 16-byte aligned operands (k, m, n multiples of 4): the vector-load paths, with ragged row / k tails
+    m2, n2, k2 = 148, 136, 44
+    A2 = rng.normal(size=(1, m2, k2)).astype(np.float32)
+    B2 = rng.normal(size=(1, n2, k2)).astype(np.float32)
+    ref2 = A2[0].astype(np.float64) @ B2[0].astype(np.float64).T
+    np.testing.assert_allclose(_gemm(A2, B2, 0, 0, m2, n2, k2)[0], ref2, **tol)
+    A2t, B2t = np.ascontiguousarray(A2.transpose(0, 2, 1)), np.ascontiguousarray(B2.transpose(0, 2, 1))
+    np.testing.assert_allclose(_gemm(A2t, B2t, 1, 1, m2, n2, k2)[0], ref2, **tol)
+    np.testing.assert_allclose(_gemm(A2, B2t, 0, 1, m2, n2, k2, ksplit=2)[0], ref2, **tol)
+    # long reduction (k > 256): the 32-deep stage variant, both tile shapes, aligned and ragged k
+    for k3, n3 in ((300, 40), (290, 24), (521, 133)):
+        A3 = rng.normal(size=(1, 70, k3)).astype(np.float32)
+        B3 = rng.normal(size=(1, n3, k3)).astype(np.float32)
+        ref3 = A3[0].astype(np.float64) @ B3[0].astype(np.float64).T
+        np.testing.assert_allclose(_gemm(A3, B3, 0, 0, 70, n3, k3)[0], ref3, rtol=1e-5, atol=1e-4)
+        B3t = np.ascontiguousarray(B3.transpose(0, 2, 1))
+        np.testing.assert_allclose(_gemm(A3, B3t, 0, 1, 70, n3, k3)[0], ref3, rtol=1e-5, atol=1e-4)
     Ab = rng.normal(size=(3, 40, 20)).astype(np.float32)
     Bb = rng.normal(size=(3, 50, 20)).astype(np.float32)
     np.testing.assert_allclose(_gemm(Ab, Bb, 0, 0, 40, 50, 20, batch=3), np.einsum("bmk,bnk->bmn", Ab, Bb), **tol)
