@@ -113,26 +113,41 @@ int emloco_layernorm_fwd(int rows, int d, float eps, const float *x, const float
     return 0;
 }
 
+namespace {
+struct FoldLaunch {
+    hipStream_t st;
+    void operator()(unsigned gx, unsigned gy, int n, int w, const float *in, float *o0, float *o1, int split) const {
+        hipLaunchKernelGGL(emloco::rows_fold_kernel, dim3(gx, gy), dim3(256), 0, st, n, w, in, o0, o1, split);
+    }
+};
+}  // namespace
+
+int64_t emloco_layernorm_bwd_workspace(int rows, int d) {
+    return emloco::fold_workspace((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK, 2L * d);
+}
+
 int emloco_layernorm_bwd(int rows, int d, const float *xr, const float *gamma, const float *mean, const float *rstd,
                          const float *dy, float *dxr, float *dgamma, float *dbeta, float *workspace, void *stream) {
     if (rows < 1 || d < 1 || d > 1024 || !xr || !gamma || !mean || !rstd || !dy || !dxr || !dgamma || !dbeta || !workspace)
-        return pfail(-1, "emloco_layernorm_bwd: bad argument (workspace = ceil(rows/64)*2*d floats)");
+        return pfail(-1, "emloco_layernorm_bwd: bad argument (workspace = emloco_layernorm_bwd_workspace(rows, d) floats)");
     const int nblocks = (rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
     hipLaunchKernelGGL(emloco::layernorm_bwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
                        rows, d, xr, gamma, mean, rstd, dy, dxr, workspace);
     PHIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(emloco::layernorm_bwd_reduce_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       nblocks, d, workspace, dgamma, dbeta);
+    emloco::fold_rows(FoldLaunch{(hipStream_t)stream}, nblocks, 2 * d, workspace, dgamma, dbeta, d);
     PHIPCHK(hipGetLastError());
     return 0;
 }
 
+int64_t emloco_colsum_workspace(int m, int n) { return emloco::fold_workspace((m + CS_ROWS - 1) / CS_ROWS, n); }
+
 int emloco_colsum(int m, int n, const float *X, float *out, float *workspace, void *stream) {
-    if (m < 1 || n < 1 || !X || !out || !workspace) return pfail(-1, "emloco_colsum: bad argument (workspace = ceil(m/256)*n floats)");
+    if (m < 1 || n < 1 || !X || !out || !workspace)
+        return pfail(-1, "emloco_colsum: bad argument (workspace = emloco_colsum_workspace(m, n) floats)");
     const int nparts = (m + CS_ROWS - 1) / CS_ROWS;
     hipLaunchKernelGGL(emloco::colsum_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream, m, n, X, workspace);
     PHIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(emloco::colsum_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nparts, n, workspace, out);
+    emloco::fold_rows(FoldLaunch{(hipStream_t)stream}, nparts, n, workspace, out, out, n);
     PHIPCHK(hipGetLastError());
     return 0;
 }

@@ -231,6 +231,10 @@ __global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------ softmax (one wave per row)
+// A row of <= 1024 scores lives in 16 registers per lane: one read of S (+ key bias), one write of P -- the row is
+// never re-read from HBM (the three-pass version moved 5 row-lengths; the score matrices are the largest tensors of
+// the step).  Longer rows take the streaming path.
+#define SM_REG 16
 __global__ void __launch_bounds__(256)
 softmax_fwd_kernel(int rows, int rows_per_seq, int cols, float scale, const float *S, const float *key_bias, float *P) {
     const int lane = threadIdx.x & 63;
@@ -240,9 +244,29 @@ softmax_fwd_kernel(int rows, int rows_per_seq, int cols, float scale, const floa
     float *p = P + row * cols;
     const float *kb = key_bias ? key_bias + (row / rows_per_seq) * cols : nullptr;
     const float NEG = -3.0e38f;
+    if (cols <= 64 * SM_REG) {
+        float v[SM_REG];
+        float mx = NEG;
+        for (int t = 0; t < SM_REG; ++t) {
+            const int j = lane + 64 * t;
+            v[t] = NEG;
+            if (j < cols) v[t] = s[j] * scale + (kb ? kb[j] : 0.0f);   // kb = -inf masks the key, a finite value biases it
+            mx = v[t] > mx ? v[t] : mx;
+        }
+        for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+        float sum = 0.0f;
+        for (int t = 0; t < SM_REG; ++t) {
+            v[t] = (v[t] > NEG) ? expf(v[t] - mx) : 0.0f;
+            sum += v[t];
+        }
+        sum = wave_sum(sum);
+        const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;   // fully masked row -> zeros ("safe softmax")
+        for (int t = 0; t < SM_REG; ++t) { const int j = lane + 64 * t; if (j < cols) p[j] = v[t] * inv; }
+        return;
+    }
     float mx = NEG;
     for (int j = lane; j < cols; j += 64) {
-        const float v = s[j] * scale + (kb ? kb[j] : 0.0f);     // kb = -inf masks the key, a finite value biases it
+        const float v = s[j] * scale + (kb ? kb[j] : 0.0f);
         mx = v > mx ? v : mx;
     }
     for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
@@ -254,7 +278,7 @@ softmax_fwd_kernel(int rows, int rows_per_seq, int cols, float scale, const floa
         sum += e;
     }
     sum = wave_sum(sum);
-    const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;   // fully masked row -> zeros ("safe softmax")
+    const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
     for (int j = lane; j < cols; j += 64) p[j] *= inv;
 }
 
@@ -265,6 +289,18 @@ softmax_bwd_kernel(int rows, int cols, float scale, const float *P, const float 
     if (row >= rows) return;
     const float *p = P + row * cols, *dp = dP + row * cols;
     float *ds = dS + row * cols;
+    if (cols <= 64 * SM_REG) {
+        float pv[SM_REG], dv[SM_REG], dot = 0.0f;
+        for (int t = 0; t < SM_REG; ++t) {
+            const int j = lane + 64 * t;
+            pv[t] = 0.0f; dv[t] = 0.0f;
+            if (j < cols) { pv[t] = p[j]; dv[t] = dp[j]; }
+            dot += dv[t] * pv[t];
+        }
+        dot = wave_sum(dot);
+        for (int t = 0; t < SM_REG; ++t) { const int j = lane + 64 * t; if (j < cols) ds[j] = scale * pv[t] * (dv[t] - dot); }
+        return;
+    }
     float dot = 0.0f;
     for (int j = lane; j < cols; j += 64) dot += dp[j] * p[j];
     dot = wave_sum(dot);
@@ -329,15 +365,35 @@ layernorm_bwd_kernel(int rows, int d, const float *xr, const float *gamma, const
     }
 }
 
-__global__ void layernorm_bwd_reduce_kernel(int nblocks, int d, const float *part, float *dgamma, float *dbeta) {
+// Row folding: out[r][j] = sum of rows [32 r, 32 r + 32) of in[n][w] in ascending order.  Applied level by level
+// (n -> n/32 -> ... -> 1) it reduces per-block partials with a fixed association order and full-chip parallelism
+// (the earlier single-pass reduce walked 14 k partial rows with 128 threads: 3.5 ms).  The last level can split its
+// row into two outputs (dgamma | dbeta).
+#define FOLD 32
+__global__ void rows_fold_kernel(int n, int w, const float *in, float *out0, float *out1, int split) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= d) return;
-    float g = 0.0f, b = 0.0f;
-    for (int k = 0; k < nblocks; ++k) { g += part[((long)k * 2 + 0) * d + j]; b += part[((long)k * 2 + 1) * d + j]; }
-    dgamma[j] = g; dbeta[j] = b;
+    if (j >= w) return;
+    const long r = blockIdx.y, i0 = r * FOLD;
+    float s = 0.0f;
+    for (int i = 0; i < FOLD && i0 + i < n; ++i) s += in[(i0 + i) * w + j];
+    if (j < split) out0[r * split + j] = s; else out1[r * (w - split) + (j - split)] = s;
+}
+inline long fold_workspace(long n, long w) { return (n + (n + FOLD - 1) / FOLD) * w; }
+// LAUNCH(grid_x, grid_y, n, w, in, out0, out1, split) runs rows_fold_kernel; buf holds [n][w] and fold_workspace(n, w) floats
+template <class LAUNCH>
+inline void fold_rows(LAUNCH launch, int n, int w, float *buf, float *out0, float *out1, int split) {
+    float *cur = buf, *alt = buf + (long)n * w;
+    for (;;) {
+        const int no = (n + FOLD - 1) / FOLD;
+        const bool fin = no == 1;
+        float *dst = cur == buf ? alt : buf;
+        launch((unsigned)((w + 255) / 256), (unsigned)no, n, w, cur, fin ? out0 : dst, fin ? out1 : dst, fin ? split : w);
+        if (fin) break;
+        cur = dst; n = no;
+    }
 }
 
-// column sums in two fixed-order passes
+// column sums: 256-row partials, then folded
 #define CS_ROWS 256
 __global__ void colsum_partial_kernel(int m, int n, const float *X, float *part) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -346,13 +402,6 @@ __global__ void colsum_partial_kernel(int m, int n, const float *X, float *part)
     float s = 0.0f;
     for (int r = 0; r < CS_ROWS && r0 + r < m; ++r) s += X[(r0 + r) * n + j];
     part[(long)blockIdx.y * n + j] = s;
-}
-__global__ void colsum_final_kernel(int nparts, int n, const float *part, float *out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    float s = 0.0f;
-    for (int k = 0; k < nparts; ++k) s += part[(long)k * n + j];
-    out[j] = s;
 }
 
 // ------------------------------------------------------------------ LocoVal (one wave per sample)

@@ -25,6 +25,10 @@ def _lib():
         lib.emloco_layernorm_fwd.argtypes = [ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_layernorm_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_colsum.argtypes = [ci, ci, vp, vp, vp, vp]
+        lib.emloco_colsum_workspace.argtypes = [ci, ci]
+        lib.emloco_colsum_workspace.restype = C.c_int64
+        lib.emloco_layernorm_bwd_workspace.argtypes = [ci, ci]
+        lib.emloco_layernorm_bwd_workspace.restype = C.c_int64
         lib.emloco_locoval_fwd.argtypes = [ci, vp, ci] + [vp] * 14
         lib.emloco_locoval_bwd.argtypes = [ci, vp, ci] + [vp] * 15
         lib.emloco_locoval_bwd_workspace.argtypes = [ci]
@@ -69,7 +73,7 @@ def _ksplit_for(red, out_elems):
 def colsum(X2d):
     m, n = X2d.shape
     out = torch.empty(n, dtype=torch.float32, device=X2d.device)
-    ws = torch.empty(((m + 255) // 256) * n, dtype=torch.float32, device=X2d.device)
+    ws = torch.empty(_lib().emloco_colsum_workspace(m, n), dtype=torch.float32, device=X2d.device)
     _chk(_lib().emloco_colsum(m, n, _p(X2d), _p(out), _p(ws), _st(X2d)), "emloco_colsum")
     return out
 
@@ -193,7 +197,7 @@ class LayerNormFn(torch.autograd.Function):
         dxr = torch.empty_like(xr)
         dg = torch.empty(d, dtype=torch.float32, device=dy.device)
         db = torch.empty(d, dtype=torch.float32, device=dy.device)
-        ws = torch.empty(((rows + 63) // 64) * 2 * d, dtype=torch.float32, device=dy.device)
+        ws = torch.empty(_lib().emloco_layernorm_bwd_workspace(rows, d), dtype=torch.float32, device=dy.device)
         _chk(_lib().emloco_layernorm_bwd(rows, d, _p(xr), _p(gamma), _p(mean), _p(rstd), _p(dy2), _p(dxr), _p(dg), _p(db), _p(ws),
                                          _st(dy)), "emloco_layernorm_bwd")
         dxr = dxr.view(ctx.shp)

@@ -50,9 +50,12 @@ int emloco_layernorm_fwd(int rows, int d, float eps, const float *x, const float
  * is recomputed from y:  xhat = (y - beta) / gamma is avoided -- pass the saved sum `xr`. */
 int emloco_layernorm_bwd(int rows, int d, const float *xr, const float *gamma, const float *mean, const float *rstd,
                          const float *dy, float *dxr, float *dgamma, float *dbeta, float *workspace, void *stream);
+/* floats of device workspace emloco_layernorm_bwd needs (per-block partials + their fold levels) */
+int64_t emloco_layernorm_bwd_workspace(int rows, int d);
 
 /* column sums: out[n] = sum_m X[m][n]  (bias gradients), fixed reduction order */
 int emloco_colsum(int m, int n, const float *X, float *out, float *workspace, void *stream);
+int64_t emloco_colsum_workspace(int m, int n);   /* floats */
 
 /* LocoVal MLP (value_pose_net.py:36-159), fused: yaw normalisation (:73-103) + hidden joints zeroed (:141-144)
  * + 100->49->24->1 MLP with ReLU/ReLU/sigmoid.  traj [B][13][traj_stride>=2], pose [B][24][3], vel [B][2].

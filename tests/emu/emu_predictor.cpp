@@ -48,9 +48,14 @@ extern "C" int emu_layernorm_bwd(int rows, int d, const float *xr, const float *
                                  const float *dy, float *dxr, float *dg, float *db, float *ws) {
     const int nb = (rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
     emu::launch((unsigned)nb, 256, [&] { layernorm_bwd_kernel(rows, d, xr, g, mean, rstd, dy, dxr, ws); });
-    emu::launch((unsigned)((d + 255) / 256), 256, [&] { layernorm_bwd_reduce_kernel(nb, d, ws, dg, db); });
+    fold_rows([&](unsigned gx, unsigned gy, int n, int w, const float *in, float *o0, float *o1, int split) {
+        for (unsigned y = 0; y < gy; ++y)
+            emu::launch(gx, 256, [&] { blockIdx.y = y; rows_fold_kernel(n, w, in, o0, o1, split); });
+        blockIdx.y = 0;
+    }, nb, 2 * d, ws, dg, db, d);
     return 0;
 }
+extern "C" long emu_layernorm_bwd_workspace(int rows, int d) { return fold_workspace((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK, 2L * d); }
 extern "C" int emu_locoval_fwd(int B, const float *traj, int ts, const float *pose, const float *vel, const float *w1,
                                const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
                                float *value, float *x100, float *h1, float *h2, float *angle) {
