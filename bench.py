@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 SIM_BYTES_PER_ENV = 8624          # state in/out + per-env model + warm-start, per launch
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 
 
 def synthetic_real_paths(n, seed=0):
@@ -195,6 +196,63 @@ def jta_cpu_baseline(B=4):
                       f"stock torch.nn fp32 restatement on {cores} host threads ({dt:.1f} s / iteration)"}
 
 
+def policy_leg(env, E, dev, steps, warmup):
+    """Row A19, reported beside the headline: the frozen PACER policy (random-init weights of the shipped architecture:
+    obs-norm -> task MLP 1054-512-256 -> actor MLP 624-2048-1024-69, sigma = e^-2.9) drives the same rollout."""
+    import torch
+    import yaml
+    from emloco_amd.learning.amp_network_sept_builder import AMPSeptBuilder
+    from emloco_amd.learning.policy_runner import FrozenPolicy
+    from emloco_amd.utils.running_mean_std import RunningMeanStd
+    task = env.task
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "emloco_amd", "data", "cfg", "train", "rlg", "amp_humanoid_smpl_sept_task.yaml")))
+    torch.manual_seed(0)
+    rms = RunningMeanStd((1422,)).to(dev)
+    rms.eval()
+    b = AMPSeptBuilder()
+    b.load(cfg["params"]["network"])
+    net = b.build("amp", actions_num=69, input_shape=(1422,), num_seqs=1, value_size=1, amp_input_shape=(3090,),
+                  self_obs_size=368, task_obs_size=1054, task_obs_size_detail={"traj": 30, "heightmap": 1024}, mean_std=rms).to(dev)
+    pol = FrozenPolicy(net, rms, E, dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def one_step(timed):
+        done = task.reset_buf.nonzero(as_tuple=False).flatten()
+        if done.numel():
+            env.reset(done)
+        if timed:
+            ev0.record()
+        act = pol.act(task.obs_buf, deterministic=False, generator=gen)
+        if timed:
+            ev1.record()
+        env.step(act)
+
+    for _ in range(warmup):
+        one_step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step(False)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pol_ms = []
+    for _ in range(20):
+        one_step(True)
+        torch.cuda.synchronize()
+        pol_ms.append(ev0.elapsed_time(ev1))
+    pm = float(np.median(pol_ms))
+    tf = pol.flops_per_env * E / (pm * 1e-3) / 1e12
+    return {"metric": "env-steps/sec with the frozen policy in the loop", "value": round(E * steps / elapsed, 1), "unit": "env-steps/s",
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "policy_ms": round(pm, 4),
+            "policy_flops_per_env": pol.flops_per_env,
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                         "note": "normalise + 5 GEMM launches (bias/ReLU fused, fp32 MFMA), median of 20 HIP-event timings"},
+            "weights": "random init (no checkpoint ships)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +260,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--num_envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_policy", action="store_true", help="skip the frozen-policy leg (row A19, reported separately)")
     ap.add_argument("--no_jta", action="store_true", help="skip the train_jta samples/s leg (run on rank 0 at N=1)")
     a = ap.parse_args()
 
@@ -276,6 +335,8 @@ def main():
                          "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l,
                          "note": "latency/occupancy bound: 8.6 KB of state per env per launch"},
         }
+        if world == 1 and not a.no_policy:
+            out["policy"] = policy_leg(env, E, dev, a.steps, a.warmup)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if world == 1 and not a.no_jta:

@@ -152,6 +152,17 @@ int emloco_colsum(int m, int n, const float *X, float *out, float *workspace, vo
     return 0;
 }
 
+int emloco_obs_normalize(int rows, int cols, const float *x, int ldx, const float *mean, const float *var, float eps,
+                         float clip, int split, float *out0, int ld0, float *out1, int ld1, void *stream) {
+    if (rows < 1 || cols < 1 || !x || !mean || !var || !out0 || split < 0 || split > cols || (split < cols && !out1) ||
+        ldx < cols || ld0 < split || (split < cols && ld1 < cols - split))
+        return pfail(-1, "emloco_obs_normalize: bad argument");
+    hipLaunchKernelGGL(emloco::obs_normalize_kernel, dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), 0,
+                       (hipStream_t)stream, rows, cols, x, ldx, mean, var, eps, clip, split, out0, ld0, out1 ? out1 : out0, ld1);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
 int emloco_locoval_fwd(int B, const float *traj, int traj_stride, const float *pose, const float *vel, const float *w1,
                        const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float *value,
                        float *x100, float *h1, float *h2, float *angle, void *stream) {

@@ -404,6 +404,23 @@ __global__ void colsum_partial_kernel(int m, int n, const float *X, float *part)
     part[(long)blockIdx.y * n + j] = s;
 }
 
+// ------------------------------------------------------------------ observation normaliser (policy input, A19)
+// RunningMeanStd.forward in eval mode (pacer/pacer/utils/running_mean_std.py:81-83):
+//   y = clamp((x - float(mean)) / sqrt(float(var) + eps), -5, 5)
+// Columns [0, split) go to out0 (leading dimension ld0), columns [split, cols) to out1 (ld1): the policy wants the
+// self observation in the first 368 columns of the actor-MLP input and the task observation as a separate,
+// 16-byte-aligned GEMM operand, so the split costs nothing here and saves a torch.cat and two copies.
+__global__ void __launch_bounds__(256)
+obs_normalize_kernel(int rows, int cols, const float *x, int ldx, const float *mean, const float *var, float eps, float clip,
+                     int split, float *out0, int ld0, float *out1, int ld1) {
+    const long row = blockIdx.y;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < cols; j += gridDim.x * 256) {
+        float y = (x[row * ldx + j] - mean[j]) / sqrtf(var[j] + eps);
+        y = fminf(fmaxf(y, -clip), clip);
+        if (j < split) out0[row * ld0 + j] = y; else out1[row * ld1 + (j - split)] = y;
+    }
+}
+
 // ------------------------------------------------------------------ LocoVal (one wave per sample)
 #define LV_IN 100
 #define LV_H1 49

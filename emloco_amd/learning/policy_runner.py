@@ -1,0 +1,99 @@
+"""Frozen-policy forward for the rollout.
+
+What the reference does per env.step (amp_players.py / common_player.py:166-169 -> rl_games PpoPlayerContinuous
+.get_action): `running_mean_std(obs)` (utils/running_mean_std.py:81-83), `a2c_network.eval_actor`
+(amp_network_sept_builder.py:79-110: task MLP 1054->512->256 on the task part, concat with the 368 self
+observations, actor MLP 624->2048->1024, `mu` head ->69, sigma = const e^-2.9), action = mu (deterministic) or
+mu + sigma * N(0,1), clamped to [-1, 1] (`clip_actions`).
+
+Here: 6 launches on the caller's stream, no torch.cat, no intermediate copies:
+  1. `emloco_obs_normalize`: self part -> columns [0,368) of the actor input, task part -> a zero-padded,
+     16-byte-aligned (E,1056) operand;
+  2-3. task MLP: GEMM+bias+ReLU; the second writes straight into columns [368,624) of the actor input (ldc = 624);
+  4-6. actor MLP and `mu` head on `emloco_gemm_f32` (fp32 MFMA, split-K where the tile grid would not fill 256 CUs).
+Weights are packed once (`_task_mlp.0.weight` padded from K=1054 to 1056 so every operand takes the 16-byte load path).
+"""
+import torch
+
+from ..predictor import ops
+from ..utils.running_mean_std import obs_normalize
+
+_PAD = 4
+
+
+def _ksplit(m, n, k):
+    tiles = ((m + 127) // 128) * ((n + 31) // 32 if n <= 32 else (n + 127) // 128)
+    return int(max(1, min(512 // max(tiles, 1), k // 128, 16)))
+
+
+class FrozenPolicy:
+    def __init__(self, network, mean_std, num_envs, device, clip_actions=1.0):
+        self.E, self.device, self.clip = num_envs, torch.device(device), float(clip_actions)
+        self.self_size, self.task_size = network.self_obs_size, network.task_obs_size
+        sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in network.state_dict().items()}
+
+        def layers(prefix):
+            idx = sorted({int(k.split(".")[1]) for k in sd if k.startswith(prefix + ".") and k.endswith(".weight")})
+            return [(sd[f"{prefix}.{i}.weight"], sd[f"{prefix}.{i}.bias"]) for i in idx]
+
+        self.task_layers, self.actor_layers = layers("_task_mlp"), layers("actor_mlp")
+        self.mu_w, self.mu_b, self.sigma = sd["mu.weight"], sd["mu.bias"], sd["sigma"]
+        # pad the first task layer's K to a multiple of 4 floats (16-byte loads)
+        w0, b0 = self.task_layers[0]
+        self.task_k = (self.task_size + _PAD - 1) // _PAD * _PAD
+        w0p = torch.zeros((w0.shape[0], self.task_k), dtype=torch.float32, device=self.device)
+        w0p[:, :self.task_size] = w0
+        self.task_layers[0] = (w0p, b0)
+        self.mean32 = mean_std.running_mean.to(self.device).float().contiguous()
+        self.var32 = mean_std.running_var.to(self.device).float().contiguous()
+        self.eps = float(mean_std.epsilon)
+        self.actor_in_size = self.self_size + self.task_layers[-1][0].shape[0]
+        assert self.actor_layers[0][0].shape[1] == self.actor_in_size and self.actor_in_size % _PAD == 0
+        E = num_envs
+        f = dict(dtype=torch.float32, device=self.device)
+        self.task_in = torch.zeros((E, self.task_k), **f)          # pad columns stay zero
+        self.actor_in = torch.empty((E, self.actor_in_size), **f)
+        self.task_h = [torch.empty((E, w.shape[0]), **f) for w, _ in self.task_layers[:-1]]
+        self.actor_h = [torch.empty((E, w.shape[0]), **f) for w, _ in self.actor_layers]
+        self.mu = torch.empty((E, self.mu_w.shape[0]), **f)
+        self.flops_per_env = 2 * (sum(w.shape[0] * w.shape[1] for w, _ in self.task_layers + self.actor_layers) + self.mu_w.numel())
+
+    @classmethod
+    def from_checkpoint(cls, path, network, mean_std, num_envs, device, **kw):
+        """rl_games checkpoint: {'model': {'a2c_network.<key>': tensor, ...}, 'running_mean_std': {...}} (common_agent.py:252)."""
+        ck = torch.load(path, map_location="cpu")
+        sd = {k[len("a2c_network."):]: v for k, v in ck["model"].items() if k.startswith("a2c_network.")}
+        network.load_state_dict(sd, strict=False)
+        if "running_mean_std" in ck:
+            mean_std.load_state_dict(ck["running_mean_std"])
+        return cls(network, mean_std, num_envs, device, **kw)
+
+    def _linear(self, x, k, w, b, out, ldc=None, c_off=0, relu=True):
+        m, n = x.shape[0], w.shape[0]
+        ops.gemm(1, m, n, k, x, x.stride(0), 0, 0, w, w.stride(0), 0, 0, out, ldc if ldc is not None else out.stride(0), 0,
+                 bias=b, flags=ops.GEMM_BIAS | (ops.GEMM_RELU if relu else 0), ksplit=_ksplit(m, n, k), c_off=c_off)
+
+    def act_mean(self, obs):
+        """obs (E, self+task) fp32 on the device -> mu (E, actions); the returned tensor is reused by the next call."""
+        assert obs.shape == (self.E, self.self_size + self.task_size)
+        obs_normalize(obs, self.mean32, self.var32, self.eps, 5.0, split=self.self_size, out0=self.actor_in, out1=self.task_in)
+        x, k = self.task_in, self.task_k
+        for i, (w, b) in enumerate(self.task_layers):
+            if i == len(self.task_layers) - 1:          # last task layer lands in the actor input, columns [self_size, ...)
+                self._linear(x, k, w, b, self.actor_in, ldc=self.actor_in_size, c_off=self.self_size)
+            else:
+                self._linear(x, k, w, b, self.task_h[i])
+                x, k = self.task_h[i], w.shape[0]
+        x, k = self.actor_in, self.actor_in_size
+        for i, (w, b) in enumerate(self.actor_layers):
+            self._linear(x, k, w, b, self.actor_h[i])
+            x, k = self.actor_h[i], w.shape[0]
+        self._linear(x, k, self.mu_w, self.mu_b, self.mu, relu=False)
+        return self.mu
+
+    def act(self, obs, deterministic=True, generator=None):
+        mu = self.act_mean(obs)
+        if deterministic:
+            return torch.clamp(mu, -self.clip, self.clip)
+        noise = torch.randn(mu.shape, dtype=mu.dtype, device=mu.device, generator=generator)
+        return torch.clamp(mu + torch.exp(self.sigma) * noise, -self.clip, self.clip)

@@ -57,6 +57,15 @@ int64_t emloco_layernorm_bwd_workspace(int rows, int d);
 int emloco_colsum(int m, int n, const float *X, float *out, float *workspace, void *stream);
 int64_t emloco_colsum_workspace(int m, int n);   /* floats */
 
+/* Policy-input normaliser (frozen policy forward): RunningMeanStd.forward in eval mode,
+ * pacer/pacer/utils/running_mean_std.py:81-83:  y = clamp((x - mean) / sqrt(var + eps), -clip, clip), clip = 5.
+ * x [rows][ldx]; mean / var are the float32 casts of the float64 running buffers.  Columns [0, split) are written to
+ * out0 (leading dimension ld0), columns [split, cols) to out1 (ld1); split == cols writes everything to out0.
+ * The MLPs themselves (amp_network_sept_builder.py:50-110: task MLP 1054->512->256, actor MLP 624->2048->1024->69)
+ * run on emloco_gemm_f32 with the bias + ReLU epilogue. */
+int emloco_obs_normalize(int rows, int cols, const float *x, int ldx, const float *mean, const float *var, float eps,
+                         float clip, int split, float *out0, int ld0, float *out1, int ld1, void *stream);
+
 /* LocoVal MLP (value_pose_net.py:36-159), fused: yaw normalisation (:73-103) + hidden joints zeroed (:141-144)
  * + 100->49->24->1 MLP with ReLU/ReLU/sigmoid.  traj [B][13][traj_stride>=2], pose [B][24][3], vel [B][2].
  * Outputs value [B]; x100 [B][100] (normalised MLP input) and h1 [B][49], h2 [B][24] are kept for the backward. */

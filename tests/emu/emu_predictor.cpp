@@ -30,6 +30,16 @@ extern "C" int emu_gemm_f32(int batch, int m, int n, int k, float alpha, const f
     return 0;
 }
 
+extern "C" int emu_obs_normalize(int rows, int cols, const float *x, int ldx, const float *mean, const float *var, float eps,
+                                 float clip, int split, float *out0, int ld0, float *out1, int ld1) {
+    for (int r = 0; r < rows; ++r)
+        emu::launch((unsigned)((cols + 255) / 256), 256, [&] {
+            blockIdx.y = r; gridDim.x = (cols + 255) / 256;
+            obs_normalize_kernel(rows, cols, x, ldx, mean, var, eps, clip, split, out0, ld0, out1, ld1);
+        });
+    blockIdx.y = 0;
+    return 0;
+}
 extern "C" int emu_softmax_fwd(int n_seq, int rps, int cols, float scale, const float *S, const float *kp, float *P) {
     const long rows = (long)n_seq * rps;
     emu::launch((unsigned)((rows + 3) / 4), 256, [&] { softmax_fwd_kernel((int)rows, rps, cols, scale, S, kp, P); });

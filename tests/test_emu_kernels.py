@@ -224,3 +224,21 @@ def test_locoval_kernels_match_reference_golden(golden):
         n = int(np.prod(shape))
         np.testing.assert_allclose(dparams[o:o + n].reshape(shape), g["grad__network_" + name], rtol=2e-4, atol=1e-7)
         o += n
+
+
+def test_obs_normalize_kernel_matches_reference_golden(golden):
+    """RunningMeanStd eval-mode normalisation with the self | task column split (policy input, row A19)."""
+    g = golden("policy_net")
+    lib = emu.lib()
+    obs = g["obs"].astype(np.float32)
+    rows, cols = obs.shape
+    mean, var = g["running_mean"].astype(np.float32), g["running_var"].astype(np.float32)
+    split, ld1 = 368, 1056
+    out0 = np.zeros((rows, 400), np.float32)
+    out1 = np.zeros((rows, ld1), np.float32)
+    lib.emu_obs_normalize(rows, cols, P(obs), cols, P(mean), P(var), C.c_float(float(g["epsilon"])), C.c_float(5.0), split,
+                          P(out0), 400, P(out1), ld1)
+    ref = g["norm_obs"]
+    np.testing.assert_allclose(out0[:, :split], ref[:, :split], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(out1[:, :cols - split], ref[:, split:], rtol=2e-6, atol=2e-6)
+    assert np.all(out1[:, cols - split:] == 0) and ref.max() == 5.0 and ref.min() == -5.0
