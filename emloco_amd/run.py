@@ -79,12 +79,27 @@ def main(argv=None):
         i = argv.index("--steps")
         steps = int(argv[i + 1])
         del argv[i:i + 2]
+    policy_ckpt, use_policy = None, False
+    if "--policy_checkpoint" in argv:            # rl_games-layout checkpoint of the frozen PACER policy (config 3)
+        i = argv.index("--policy_checkpoint")
+        policy_ckpt, use_policy = argv[i + 1], True
+        del argv[i:i + 2]
+    if "--policy_random_init" in argv:           # same architecture, random weights (no checkpoint ships)
+        use_policy = True
+        argv.remove("--policy_random_init")
     args = get_args(argv)
     cfg, cfg_train, _ = load_cfg(args)
     fill_flags(args)
     env = RLGPUEnv(create_rlgpu_env(args, cfg, cfg_train))
     from .learning.locoval_rollout import LocoValRollout
-    agent = LocoValRollout(env, use_pose=args.input_init_pose, use_vel=args.input_init_vel)
+    kw = {}
+    if use_policy:
+        from .learning.amp_policy import AMPPolicyBundle
+        bundle = AMPPolicyBundle(env.env.task, checkpoint=policy_ckpt)
+        kw = dict(policy=bundle.policy, disc_reward=bundle.disc_reward,
+                  inversion_penalty_scale=float(bundle.config.get("inversion_penalty_scale", 0.3)),
+                  task_reward_w=float(bundle.config.get("task_reward_w", 0.5)), disc_reward_w=float(bundle.config.get("disc_reward_w", 0.5)))
+    agent = LocoValRollout(env, use_pose=args.input_init_pose, use_vel=args.input_init_vel, **kw)
     t0 = time.time()
     n = 0
     while n < steps:

@@ -109,6 +109,39 @@ def test_locoval_rollout_fits_value_function():
     assert agent.frames == 6 * 16 * 128
 
 
+def test_rollout_with_frozen_policy_and_disc_reward(tmp_path):
+    """Config 3: the frozen policy (A19) acts, the AMP discriminator supplies the style reward (A17), LocoVal is fitted (A18);
+    the networks load from an rl_games-layout checkpoint."""
+    from emloco_amd.learning.amp_policy import AMPPolicyBundle
+    from emloco_amd.learning.locoval_rollout import LocoValRollout
+    from emloco_amd.run import RLGPUEnv
+    env = RLGPUEnv(_make_env(128, ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel",
+                                   "--input_init_pose", "--input_init_vel"]))
+    task = env.env.task
+    b0 = AMPPolicyBundle(task, seed=1)
+    with torch.no_grad():                                   # make the checkpoint differ from a fresh initialisation
+        b0.a2c_network.mu.bias.add_(0.05)
+        b0.running_mean_std.running_mean.add_(0.1)
+    ck = {"model": {"a2c_network." + k: v.cpu() for k, v in b0.a2c_network.state_dict().items()},
+          "running_mean_std": b0.running_mean_std.state_dict(), "amp_input_mean_std": b0.amp_input_mean_std.state_dict()}
+    path = str(tmp_path / "Humanoid.pth")
+    torch.save(ck, path)
+    bundle = AMPPolicyBundle(task, checkpoint=path, deterministic=True)
+    obs = task.obs_buf.clone()
+    a = bundle.policy(obs).clone()
+    assert torch.equal(a, AMPPolicyBundle(task, checkpoint=path, deterministic=True).policy(obs))    # checkpoint round trip
+    assert a.shape == (128, 69) and float(a.abs().max()) <= 1.0
+    r = bundle.disc_reward(task._amp_obs_buf)
+    assert r.shape == (128,) and torch.isfinite(r).all() and float(r.min()) >= 0.0
+    assert bundle.eval_critic(obs).shape == (128, 1)
+    agent = LocoValRollout(env, horizon_length=16, policy=bundle.policy, disc_reward=bundle.disc_reward,
+                           inversion_penalty_scale=0.3)
+    for _ in range(4):
+        agent.play_steps()
+    torch.cuda.synchronize()
+    assert agent.frames == 4 * 16 * 128 and np.isfinite(agent.vnet_loss)
+
+
 def test_fused_reset_matches_host_mirror():
     """The three-kernel device reset against the host-side torch mirror of the reference's reset path."""
     from emloco_amd import _lib as L
