@@ -114,3 +114,41 @@ def test_train_step_runs_and_decreases_loss():
     pad = torch.zeros(B, N, dtype=torch.bool)
     losses = [tr.step(joints, masks, pad)[0].item() for _ in range(8)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.52])
+def test_eval_filter_matches_reference_logs(golden, thr):
+    """B10: vectorised multi-modal evaluation + LocoVal filter against the numbers the reference's evaluate_ade_fde
+    logged on the same batches (tests/golden/gen_golden_eval.py); its log prints 5 decimals (values: 3)."""
+    from emloco_amd.predictor.evaluate_jta import evaluate_ade_fde
+    g = golden("eval_filter")
+    gm = golden("predictor_multi")
+    model = _load_model(gm, True)
+    vnet = _vnet(gm)
+    cfg = {"DEVICE": "cuda:0", "TRAIN": {"input_track_size": 9, "output_track_size": 12}, "NOISY_TRAJ": 0,
+           "MODEL": {"value_threshold": thr}}
+    batches = []
+    i = 0
+    while f"batch{i}.joints" in g:
+        batches.append((torch.from_numpy(g[f"batch{i}.joints"]), torch.from_numpy(g[f"batch{i}.masks"]),
+                        torch.from_numpy(g[f"batch{i}.padding_mask"])))
+        i += 1
+
+    class Log:
+        lines = []
+
+        def info(self, m):
+            self.lines.append(str(m))
+
+    res = evaluate_ade_fde(model, vnet, "test", "traj+all", batches, 5, cfg, Log(), "golden", random_ids=torch.from_numpy(g["random_ids"]))
+    tag = f"thr{int(thr * 100)}"
+    assert res["samples"] == int(g[f"{tag}.samples"])
+    for key in ("ade", "fde", "min_ade", "min_fde", "worst_ade", "worst_fde", "iye", "ade_value", "fde_value", "ade_random",
+                "fde_random", "minade_value", "minfde_value", "ade_rejected", "fde_rejected", "chi_velocity", "chi_acceleration",
+                "chi_ang_velocity", "chi_ang_acceleration"):
+        ref = float(g[f"{tag}.{key}"])
+        assert abs(res[key] - ref) <= 2e-4 * max(1.0, abs(ref)), f"{key}: {res[key]:.6f} vs reference log {ref:.5f}"
+    for key in ("value_mean", "value_gt_mean", "value_loss_mean", "value_loss_gt_mean"):
+        assert abs(res[key] - float(g[f"{tag}.{key}"])) <= 6e-4, key
+    np.testing.assert_allclose(res["des"], g[f"{tag}.des"], atol=2e-4)
+    assert any(line.startswith("ADE with Value sampling") for line in Log.lines)
