@@ -20,6 +20,7 @@ import math
 import numpy as np
 import torch
 
+from .dataset_jrdb import batch_process_coords as batch_process_coords_jrdb
 from .train_jta import batch_process_coords
 
 DELTA_T = 0.4      # 2.5 fps (utils/metrics.py:69)
@@ -236,7 +237,8 @@ def evaluate_ade_fde(model, valuenet, split, modality_selection, dataloader, bs,
         joints, masks, padding_mask = batch[0], batch[1], batch[2]
         padding_mask = padding_mask.to(config["DEVICE"])
         primary_init_pose = joints[:, 0, 8, 3:27, :3] if dataset == "jta" else joints[:, 0, 8, 2:, :3]
-        in_joints, in_masks, out_joints, out_masks, padding_mask = batch_process_coords(joints, masks, padding_mask, config, modality_selection)
+        bpc = batch_process_coords if dataset == "jta" else batch_process_coords_jrdb
+        in_joints, in_masks, out_joints, out_masks, padding_mask = bpc(joints, masks, padding_mask, config, modality_selection)
         pred_joints = inference(model, config, in_joints, padding_mask, out_len=out_F, limit_obs=limit_obs)
         B = out_joints.shape[0]
         ids = None if random_ids is None else random_ids[off:off + B]

@@ -145,28 +145,39 @@ class TransMotionJTA(nn.Module):
             tgt_3dpose, tgt_2dpose = tgt_3dpose * lm[..., None, None], tgt_2dpose * lm[..., None, None]
 
         # input embeddings + learned encodings (model_jta.py:281-297)
+        t = self._embed_traj(tgt_traj, Fr, N)                                                        # (B,F,N,d)
+        bb3 = self._embed(tgt_3dbb[:, :9], self.fc_in_3dbb, self.bb3d_encoder, 9)                    # (B,9,N,d)
+        bb2 = self._embed(tgt_2dbb[:, :9], self.fc_in_2dbb, self.bb2d_encoder, 9)
+        p3 = tgt_3dpose[:, :9].transpose(2, 3).reshape(B, -1, N, 3)
+        p3 = self._embed(p3, self.fc_in_3dpose, self.pose3d_encoder, p3.shape[1])                    # (B,216,N,d)
+        p2 = tgt_2dpose[:, :9].transpose(2, 3).reshape(B, -1, N, 2)
+        p2 = self._embed(p2, self.fc_in_2dpose, self.pose2d_encoder, p2.shape[1])                    # (B,198,N,d)
+
+        seq = torch.cat((t, bb3, bb2, p3, p2), dim=1)                                                # (B,S,N,d), S = 453
+        return self._transform(seq, padding_mask, B, N, Fr)
+
+    def _embed_traj(self, tgt_traj, Fr, N):
+        """fc_in_traj + LearnedTrajandIDEncoding (model_jta.py:61-78): time code on even channels, person code on odd."""
+        dev = self.device
         half = self.nhid // 2
-        t = ops.linear(tgt_traj, self.fc_in_traj.weight, self.fc_in_traj.bias)                     # (B,F,N,d)
-        time_enc = self.double_id_encoder.learned_encoding(torch.arange(Fr, device=dev))             # (F, d/2) even channels
-        pers_enc = self.double_id_encoder.person_encoding(torch.arange(N, device=dev))               # (N, d/2) odd channels
+        t = ops.linear(tgt_traj, self.fc_in_traj.weight, self.fc_in_traj.bias)
+        time_enc = self.double_id_encoder.learned_encoding(torch.arange(Fr, device=dev))             # (F, d/2)
+        pers_enc = self.double_id_encoder.person_encoding(torch.arange(N, device=dev))               # (N, d/2)
         enc = torch.zeros(Fr, N, self.nhid, device=dev)
         enc[:, :, 0:half * 2:2] = time_enc.unsqueeze(1)
         enc[:, :, 1:half * 2:2] = pers_enc.unsqueeze(0)
-        t = self._drop(t + enc.unsqueeze(0))
-        def emb(x, fc, encmod, n):
-            y = ops.linear(x, fc.weight, fc.bias)
-            return self._drop(y + encmod.learned_encoding(torch.arange(n, device=dev)).unsqueeze(1).unsqueeze(0))
-        bb3 = emb(tgt_3dbb[:, :9], self.fc_in_3dbb, self.bb3d_encoder, 9)                            # (B,9,N,d)
-        bb2 = emb(tgt_2dbb[:, :9], self.fc_in_2dbb, self.bb2d_encoder, 9)
-        p3 = tgt_3dpose[:, :9].transpose(2, 3).reshape(B, -1, N, 3)
-        p3 = emb(p3, self.fc_in_3dpose, self.pose3d_encoder, p3.shape[1])                            # (B,216,N,d)
-        p2 = tgt_2dpose[:, :9].transpose(2, 3).reshape(B, -1, N, 2)
-        p2 = emb(p2, self.fc_in_2dpose, self.pose2d_encoder, p2.shape[1])                            # (B,198,N,d)
+        return self._drop(t + enc.unsqueeze(0))
 
-        # local former over S = 453 tokens of every person: batch-first (B*N, S, d)
-        seq = torch.cat((t, bb3, bb2, p3, p2), dim=1)                                                # (B,S,N,d)
+    def _embed(self, x, fc, encmod, n):
+        y = ops.linear(x, fc.weight, fc.bias)
+        return self._drop(y + encmod.learned_encoding(torch.arange(n, device=self.device)).unsqueeze(1).unsqueeze(0))
+
+    def _transform(self, seq, padding_mask, B, N, Fr):
+        """local former over every person's S tokens -> global former over the N*21 trajectory tokens -> heads
+        (model_jta.py:299-335; shared with TransMotionJRDB, model_jrdb.py:110-143)."""
+        dev = self.device
         S = seq.shape[1]
-        x = seq.permute(0, 2, 1, 3).reshape(B * N, S, self.nhid).contiguous()
+        x = seq.permute(0, 2, 1, 3).reshape(B * N, S, self.nhid).contiguous()                        # batch-first (B*N, S, d)
         pad = self._key_bias(padding_mask.to(dev))                                                   # (B, N) additive
         pad_local = pad.reshape(-1, 1).expand(-1, S).contiguous()
         out_local = self.local_former(x, pad_local) * self.output_scale + x

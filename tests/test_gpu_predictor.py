@@ -152,3 +152,35 @@ def test_eval_filter_matches_reference_logs(golden, thr):
         assert abs(res[key] - float(g[f"{tag}.{key}"])) <= 6e-4, key
     np.testing.assert_allclose(res["des"], g[f"{tag}.des"], atol=2e-4)
     assert any(line.startswith("ADE with Value sampling") for line in Log.lines)
+
+
+def test_jrdb_model_and_batch_processing_match_reference(golden):
+    """Config 4's model: TransMotionJRDB (26 tokens / person, S = 246) + dataset_jrdb.batch_process_coords."""
+    from emloco_amd.predictor.dataset_jrdb import batch_process_coords
+    from emloco_amd.predictor.model_jrdb import TransMotionJRDB
+    from emloco_amd.predictor.train_jta import MSE_LOSS_MULTI
+    g = golden("predictor_jrdb")
+    cfg = {"DEVICE": "cuda:0", "TRAIN": {"input_track_size": 9, "output_track_size": 12}, "DATA": {"train_datasets": ["jrdb_all_visual_cues"]}}
+    joints = torch.from_numpy(g["joints"])
+    masks = torch.ones(joints.shape[:4])
+    pmask = torch.from_numpy(g["padding_mask"]).bool()
+    for sel in ("traj+all", "traj+2dbox", "traj+3dpose", "traj"):
+        ij, _, oj, _, pm = batch_process_coords(joints, masks, pmask, cfg, modality_selection=sel)
+        np.testing.assert_allclose(ij.cpu().numpy(), g[f"in_joints.{sel}"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(oj.cpu().numpy(), g[f"out_joints.{sel}"], rtol=1e-6, atol=1e-6)
+    assert torch.equal(joints, torch.from_numpy(g["joints"]))          # the caller's batch is left untouched
+    in_joints, _, out_joints, _, pm = batch_process_coords(joints, masks, pmask, cfg)
+    model = TransMotionJRDB(tok_dim=246, nhid=32, nhead=4, dim_feedfwd=64, nlayers_local=2, nlayers_global=1, nmode=4, output_scale=1,
+                            obs_and_pred=21, num_tokens=26, device="cuda:0", multi_modal=True).to("cuda:0").float()
+    model.load_state_dict({k[4:].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("sd__")}, strict=True)
+    model.eval()
+    pred = model(in_joints, pm)
+    _close(pred.detach().cpu(), g["pred"], what="JRDB logits")
+    _close(model(in_joints, pm, limit_obs=3).detach().cpu(), g["pred_limit_obs3"], what="JRDB logits, limit_obs=3")
+    loss = MSE_LOSS_MULTI(pred[:, 9:], out_joints)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * float(g["loss"])
+    loss.backward()
+    params = dict(model.named_parameters())
+    for k, v in g.items():
+        if k.startswith("grad__"):
+            _close(params[k[6:].replace("__", ".")].grad.cpu(), v, rel=2e-4, abs_=1e-6, what=k)
