@@ -167,6 +167,41 @@ def jta_leg(dev, steps=4, warmup=2, B=256):
     return out
 
 
+def eval_leg(dev, B=512, batches=2):
+    """configs[4] at one GPU: multi-modal JRDB predictor (20 heads) + LocoVal filter evaluation, batch 512."""
+    import torch
+    from emloco_amd.learning.value_pose_net import ValuePoseNet
+    from emloco_amd.predictor.evaluate_jta import evaluate_ade_fde
+    from emloco_amd.predictor.model_jrdb import TransMotionJRDB
+    torch.manual_seed(0)
+    cfg = {"DEVICE": str(dev), "MULTI_MODAL": True, "NOISY_TRAJ": 0, "TRAIN": {"input_track_size": 9, "output_track_size": 12},
+           "MODEL": {"value_threshold": 0.8}, "DATA": {"train_datasets": ["jrdb_all_visual_cues"]}}
+    model = TransMotionJRDB(tok_dim=246, nhid=128, nhead=4, dim_feedfwd=1024, nlayers_local=6, nlayers_global=3, nmode=20,
+                            output_scale=1, obs_and_pred=21, num_tokens=26, device=str(dev), multi_modal=True).to(dev)
+    vnet = ValuePoseNet(True, True).to(dev)
+    g = torch.Generator().manual_seed(5)
+    data = []
+    for _ in range(batches):
+        N = 8
+        joints = torch.randn(B, N, 21, 26, 4, generator=g) * 0.3
+        joints[:, :, :, 0, :2] = torch.cumsum(torch.randn(B, N, 21, 2, generator=g) * 0.4, dim=2)
+        n_people = torch.randint(1, N + 1, (B,), generator=g)
+        pad = torch.arange(N)[None, :] >= n_people[:, None]
+        data.append((joints, torch.ones(B, N, 21, 26), pad))
+    evaluate_ade_fde(model, vnet, "test", "traj+all", data[:1], B, cfg, dataset="jrdb")          # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = evaluate_ade_fde(model, vnet, "test", "traj+all", data, B, cfg, dataset="jrdb")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": "JRDB eval samples/sec (multi-modal predictor + LocoVal filter)", "value": round(B * batches / dt, 1),
+            "unit": "samples/s", "ms_per_batch": round(dt / batches * 1e3, 2), "dtype": "f32",
+            "config": {"workload": "configs[4] on one GPU: TransMotionJRDB 20 modes, batch 512, people/scene U{1..8} padded to 8, "
+                                   "246 tokens/person, LocoVal filter threshold 0.8 (host->device copy of the batch included)",
+                       "batch": B, "batches": batches, "locoval_calls_per_batch": B * 40},
+            "ade": round(float(res["ade"]), 4), "ade_value_sampling": round(float(res.get("ade_value", float("nan"))), 4)}
+
+
 def jta_cpu_baseline(B=4):
     """The same EmLoco train step on the host cores with the stock-torch restatement (oracle/predictor_torch.py)."""
     import torch
@@ -343,6 +378,7 @@ def main():
             del env, task, pool
             torch.cuda.empty_cache()
             out["jta"] = jta_leg(dev)
+            out["jta"]["eval"] = eval_leg(dev)
             if not a.no_cpu_baseline:
                 out["jta"]["cpu_baseline"] = jta_cpu_baseline()
         print(json.dumps(out))
