@@ -57,19 +57,40 @@ def motion_primitives(xy):
     return {"velocity": vel, "acceleration": acc, "ang_velocity": ang, "ang_acceleration": ang_acc}
 
 
-def calculate_chi_distance(gt_primitive, pred_primitive, num_bins=20):
-    """utils/metrics.py:112-145 (numpy histograms of the gathered primitive values)."""
+def _chi_from_counts(gt_counts, pred_counts):
+    gt_dens, pred_dens = gt_counts / max(gt_counts.sum(), 1), pred_counts / max(pred_counts.sum(), 1)
+    s = gt_dens + pred_dens
+    nz = s != 0
+    return float((((gt_dens - pred_dens) ** 2)[nz] / s[nz]).sum())
+
+
+def calculate_chi_distance(gt_primitive, pred_primitive, num_bins=20, reduce=None):
+    """utils/metrics.py:112-145: chi-square distance of the 20-bin histograms over the joint value range.
+    `density=True` histograms times the bin width are count fractions, so ranks only need to agree on the range
+    (`reduce("min"/"max", x)`) and add their counts (`reduce("sum", x)`) to get the single-process result."""
     out = {}
     for key in gt_primitive:
         gt_values, pred_values = np.asarray(gt_primitive[key], np.float64), np.asarray(pred_primitive[key], np.float64)
-        bins = np.linspace(min(gt_values.min(), pred_values.min()), max(gt_values.max(), pred_values.max()), num_bins + 1)
-        gt_hist, _ = np.histogram(gt_values, bins=bins, density=True)
-        pred_hist, _ = np.histogram(pred_values, bins=bins, density=True)
-        gt_dens, pred_dens = gt_hist * np.diff(bins), pred_hist * np.diff(bins)
-        s = gt_dens + pred_dens
-        nz = s != 0
-        out[key] = float((((gt_dens - pred_dens) ** 2)[nz] / s[nz]).sum())
+        lo, hi = min(gt_values.min(), pred_values.min()), max(gt_values.max(), pred_values.max())
+        if reduce is not None:
+            lo, hi = float(reduce("min", np.array([lo]))[0]), float(reduce("max", np.array([hi]))[0])
+        bins = np.linspace(lo, hi, num_bins + 1)
+        gt_counts = np.histogram(gt_values, bins=bins)[0].astype(np.float64)
+        pred_counts = np.histogram(pred_values, bins=bins)[0].astype(np.float64)
+        if reduce is not None:
+            gt_counts, pred_counts = reduce("sum", gt_counts), reduce("sum", pred_counts)
+        out[key] = _chi_from_counts(gt_counts, pred_counts)
     return out
+
+
+def _dist_reduce(op, arr):
+    """all-reduce a float64 numpy array over the default process group (RCCL on GPUs, gloo in the CPU tests)."""
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).clone()
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op])
+    return t.cpu().numpy()
 
 
 def _heading(traj):
@@ -197,44 +218,75 @@ class EvalAccumulator:
         self.s["fde_filtered"] += float((fde * rejected).sum() + (fde_best * fallback).sum())
         self.n["filtered"] += int(rejected.sum())
 
-    def summary(self):
-        n = max(self.n["sample"], 1)
-        out = {"samples": self.n["sample"], "ade": self.s["ade"] / n, "fde": self.s["fde"] / n, "min_ade": self.s["ade_min"] / n,
-               "min_fde": self.s["fde_min"] / n, "worst_ade": self.s["ade_max"] / n, "worst_fde": self.s["fde_max"] / n,
-               "iye": self.s["iye"] / n, "des": self.des / n}
+    def summary(self, distributed=None):
+        """The numbers evaluate_ade_fde logs.  With `distributed` (default: a process group with world_size > 1 exists) the
+        running sums, histogram counts and per-bin statistics are all-reduced first, so every rank returns the result of
+        the whole data-parallel evaluation (eval shards by batch, only scalars are exchanged)."""
+        import torch.distributed as dist
+        if distributed is None:
+            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        red = _dist_reduce if distributed else None
+        s, cnt, des, num_mode = dict(self.s), dict(self.n), self.des.copy(), self.num_mode
+        if distributed:
+            keys_s, keys_n = sorted(s), sorted(cnt)
+            flat = _dist_reduce("sum", np.array([s[k] for k in keys_s] + [cnt[k] for k in keys_n] + list(des)))
+            s = dict(zip(keys_s, flat[:len(keys_s)]))
+            cnt = {k: int(round(v)) for k, v in zip(keys_n, flat[len(keys_s):len(keys_s) + len(keys_n)])}
+            des = flat[len(keys_s) + len(keys_n):]
+            num_mode = int(_dist_reduce("max", np.array([float(num_mode)]))[0])
+        n = max(cnt["sample"], 1)
+        out = {"samples": cnt["sample"], "ade": s["ade"] / n, "fde": s["fde"] / n, "min_ade": s["ade_min"] / n,
+               "min_fde": s["fde_min"] / n, "worst_ade": s["ade_max"] / n, "worst_fde": s["fde_max"] / n,
+               "iye": s["iye"] / n, "des": des / n}
         if self.gt_prim["velocity"]:
             gp = {k: torch.cat(v).cpu().numpy() for k, v in self.gt_prim.items()}
             pp = {k: torch.cat(v).cpu().numpy() for k, v in self.pred_prim.items()}
-            out.update({"chi_" + k: v for k, v in calculate_chi_distance(gp, pp).items()})
-        if self.n["values"]:
-            nv = self.n["values"]
-            out.update({"value_mean": self.s["value"] / nv, "value_gt_mean": self.s["value_gt"] / nv,
-                        "value_loss_mean": self.s["value_loss"] / nv, "value_loss_gt_mean": self.s["value_loss_gt"] / nv})
-        if self.num_mode > 1 and self.n["values"]:
+            out.update({"chi_" + k: v for k, v in calculate_chi_distance(gp, pp, reduce=red).items()})
+        if cnt["values"]:
+            nv = cnt["values"]
+            out.update({"value_mean": s["value"] / nv, "value_gt_mean": s["value_gt"] / nv,
+                        "value_loss_mean": s["value_loss"] / nv, "value_loss_gt_mean": s["value_loss_gt"] / nv})
+        if num_mode > 1 and cnt["values"]:
             d = lambda a, b: a / b if b > 0 else 0.0
-            out.update({"threshold": self.thr, "ade_value": d(self.s["ade_value"], self.n["value_sampling"]),
-                        "fde_value": d(self.s["fde_value"], self.n["value_sampling"]),
-                        "ade_random": d(self.s["ade_random"], self.n["sample"]), "fde_random": d(self.s["fde_random"], self.n["sample"]),
-                        "minade_value": d(self.s["minade_value"], self.n["sample"]), "minfde_value": d(self.s["minfde_value"], self.n["sample"]),
-                        "ade_rejected": d(self.s["ade_filtered"], self.n["filtered"]), "fde_rejected": d(self.s["fde_filtered"], self.n["filtered"])})
-            # plausibility-score bins (evaluate_jta.py:432-449): mean ADE / FDE per 0.1-wide value bin
-            v, a, f = torch.cat(self.values).numpy(), torch.cat(self.ades).numpy(), torch.cat(self.fdes).numpy()
+            out.update({"threshold": self.thr, "ade_value": d(s["ade_value"], cnt["value_sampling"]),
+                        "fde_value": d(s["fde_value"], cnt["value_sampling"]),
+                        "ade_random": d(s["ade_random"], cnt["sample"]), "fde_random": d(s["fde_random"], cnt["sample"]),
+                        "minade_value": d(s["minade_value"], cnt["sample"]), "minfde_value": d(s["minfde_value"], cnt["sample"]),
+                        "ade_rejected": d(s["ade_filtered"], cnt["filtered"]), "fde_rejected": d(s["fde_filtered"], cnt["filtered"])})
+            # plausibility-score bins (evaluate_jta.py:432-449): mean ADE / FDE per 0.1-wide value bin, value histogram
+            if self.values:
+                v, a, f = torch.cat(self.values).numpy(), torch.cat(self.ades).numpy(), torch.cat(self.fdes).numpy()
+            else:
+                v = a = f = np.zeros(0)
             idx = np.digitize(v, np.arange(0, 1.05, 0.1))
-            out["ade_per_value_bin"] = np.array([a[idx == i].mean() if np.any(idx == i) else np.nan for i in range(1, 11)])
-            out["fde_per_value_bin"] = np.array([f[idx == i].mean() if np.any(idx == i) else np.nan for i in range(1, 11)])
-            out["value_hist"] = np.histogram(v, bins=10, range=(0, 1))[0]
+            per_bin = np.stack([np.array([x[idx == i].sum() for i in range(1, 11)]) for x in (a, f, np.ones_like(v))])
+            hist = np.histogram(v, bins=10, range=(0, 1))[0].astype(np.float64)
+            if distributed:
+                per_bin, hist = _dist_reduce("sum", per_bin), _dist_reduce("sum", hist)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                out["ade_per_value_bin"] = np.where(per_bin[2] > 0, per_bin[0] / per_bin[2], np.nan)
+                out["fde_per_value_bin"] = np.where(per_bin[2] > 0, per_bin[1] / per_bin[2], np.nan)
+            out["value_hist"] = hist.astype(np.int64)
         return out
 
 
 def evaluate_ade_fde(model, valuenet, split, modality_selection, dataloader, bs, config, logger=None, exp_name="", return_all=False,
-                     visualize=False, limit_obs=False, dataset="jta", random_ids=None, **acc_kw):
-    """Same arguments as the reference; additionally returns the summary dict (the reference only logs it)."""
+                     visualize=False, limit_obs=False, dataset="jta", random_ids=None, shard=None, **acc_kw):
+    """Same arguments as the reference; additionally returns the summary dict (the reference only logs it).
+    Data-parallel (configs[4]): with a process group of W ranks, rank r evaluates batches r, r+W, ... (`shard=(r, W)`,
+    default from torch.distributed) and the summary is all-reduced -- no tensor data crosses ranks."""
+    import torch.distributed as dist
+    if shard is None:
+        shard = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
     out_F = config["TRAIN"]["output_track_size"]
     thr = 0.8 if dataset == "jrdb" else config["MODEL"]["value_threshold"]
     acc = EvalAccumulator(thr, **acc_kw)
     off = 0
-    for batch in dataloader:
+    for bi, batch in enumerate(dataloader):
         joints, masks, padding_mask = batch[0], batch[1], batch[2]
+        if bi % shard[1] != shard[0]:
+            off += joints.shape[0]
+            continue
         padding_mask = padding_mask.to(config["DEVICE"])
         primary_init_pose = joints[:, 0, 8, 3:27, :3] if dataset == "jta" else joints[:, 0, 8, 2:, :3]
         bpc = batch_process_coords if dataset == "jta" else batch_process_coords_jrdb
