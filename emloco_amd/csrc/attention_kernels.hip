@@ -1,0 +1,266 @@
+// attention_kernels.hip -- fused multi-head self-attention for head dim 32 on gfx950 (MI355X), fp32 MFMA.
+//
+// Reference: nn.MultiheadAttention inside nn.TransformerEncoderLayer as used by
+// /root/reference/social-transmotion/model_jta.py:177-178,311-321 (local former: S = 453 tokens per person, d = 128,
+// 4 heads -> head dim 32; global former: S = 21 N).  The score matrix (S x S per head) is never written to HBM: the
+// forward keeps an online softmax per query, the backward recomputes the probabilities from Q, K and the saved
+// log-sum-exp.  The unfused path (GEMM -> softmax -> GEMM, predictor_kernels.hip) moved ~27 GB of scores per layer
+// at batch 256; this one reads Q, K, V once per 128-query block.
+//
+// Mapping (all three kernels): a 256-thread workgroup = 4 waves, a wave owns 32 rows (queries, or keys in the dK/dV
+// kernel) and walks the other sequence in tiles of 32 staged through LDS (double buffered, register prefetch).
+// Everything is computed TRANSPOSED so that the v_mfma_f32_32x32x2_f32 accumulator layout (lane = column) makes the
+// wave's own row index the lane index: a lane then owns one query (key) and
+//   * softmax statistics (running max / sum, log-sum-exp, D = rowsum(dO o O)) are per-lane scalars,
+//   * the probabilities P^T it just computed ARE the B operand of the next MFMA (P.V, dS.K, ...) -- no LDS round trip:
+//     accumulator register s of lane half h holds tile row kappa(s, h) = (s & 3) + 8 (s >> 2) + 4 h, and since the
+//     reduction index order of an MFMA chain is free, step s simply pairs it with row kappa(s, h) of the LDS operand.
+// Reductions over d = 32 use dk(s, h) = 16 h + s, so a lane's 16 operand values are four ds_read_b128 of one LDS row.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dev_math.h"
+
+namespace emloco {
+
+typedef float at_f32x16 __attribute__((vector_size(64)));
+struct __attribute__((aligned(16))) at_f32x4 { float x, y, z, w; };
+
+#define AT_DH 32                 // head dim
+#define AT_T 32                  // tile of the walked sequence
+#define AT_LD 36                 // LDS row stride (floats): 144 B keeps 16 consecutive rows' b128 reads on distinct banks
+#define AT_NEG (-3.0e38f)        // "masked" sentinel: scores at or below it get probability 0
+
+struct AttnArgs {
+    int n_seq, S, nhead, d_model;   // qkv [n_seq][S][3 d_model], d_model = nhead * 32
+    float scale;
+    const float *qkv;
+    const float *key_bias;          // [n_seq][S] additive (-inf masks a key) or NULL
+    float *out;                     // [n_seq][S][d_model]
+    float *lse;                     // [n_seq * nhead][S] log-sum-exp of the scaled, biased scores
+    const float *dout;              // backward: [n_seq][S][d_model]
+    float *dqkv;                    // backward: [n_seq][S][3 d_model]
+    float *dsum;                    // backward: [n_seq * nhead][S]  D = rowsum(dO o O)
+};
+
+__device__ __forceinline__ int at_kappa(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+
+// 16 operand values of row `row` (columns 16 h .. 16 h + 15) of an LDS tile
+__device__ __forceinline__ void at_row16(const float *tile, int row, int h, at_f32x4 (&f)[4]) {
+    const float *src = tile + row * AT_LD + 16 * h;
+    f[0] = *(const at_f32x4 *)src; f[1] = *(const at_f32x4 *)(src + 4);
+    f[2] = *(const at_f32x4 *)(src + 8); f[3] = *(const at_f32x4 *)(src + 12);
+}
+// the same from global memory (a row of Q / K / V / dO / O of one head), zero for rows past the sequence
+__device__ __forceinline__ void at_grow16(const float *base, long ld, int row, int S, int h, at_f32x4 (&f)[4]) {
+    const int rc = row < S ? row : S - 1;
+    const float *src = base + (long)rc * ld + 16 * h;
+    for (int i = 0; i < 4; ++i) {
+        at_f32x4 t = *(const at_f32x4 *)(src + 4 * i);
+        if (row >= S) t = at_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        f[i] = t;
+    }
+}
+// C^T tile (32 x 32) = X_tile (rows from LDS) . Yfrag^T : acc[r] of lane (j, h) = sum_dk X[kappa(r,h)][dk] Y[j][dk]
+__device__ __forceinline__ at_f32x16 at_xyT(const float *tile, int l31, int h, const at_f32x4 (&yf)[4]) {
+    at_f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    at_f32x4 xf[4];
+    at_row16(tile, l31, h, xf);
+    for (int f = 0; f < 4; ++f) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[f].x, yf[f].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[f].y, yf[f].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[f].z, yf[f].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[f].w, yf[f].w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+// acc^T (32 d x 32 own rows) += X_tile^T . p : sum over tile rows kappa(s, h) of X[kappa][d = lane & 31] * p[s]
+__device__ __forceinline__ at_f32x16 at_xTp(const float *tile, int l31, int h, const float (&p)[16], at_f32x16 acc) {
+    for (int s = 0; s < 16; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[at_kappa(s, h) * AT_LD + l31], p[s], acc, 0, 0, 0);
+    return acc;
+}
+// one thread's share of a 32 x 32 tile fetch: rows row0.., 8 float4 per row
+struct AtFetch { at_f32x4 a, b; float c, d; };
+__device__ __forceinline__ at_f32x4 at_fetch4(const float *base, long ld, int row0, int S, int tid) {
+    const int r = tid >> 3, q = tid & 7;
+    const int row = row0 + r, rc = row < S ? row : S - 1;
+    at_f32x4 t = *(const at_f32x4 *)(base + (long)rc * ld + 4 * q);
+    if (row >= S) t = at_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    return t;
+}
+__device__ __forceinline__ void at_stash4(float *tile, int tid, const at_f32x4 &v) {
+    *(at_f32x4 *)&tile[(tid >> 3) * AT_LD + 4 * (tid & 7)] = v;
+}
+// the 16 per-row scalars kappa(r, h), r = 0..15, of a 32-entry LDS vector (4 b128 reads)
+__device__ __forceinline__ void at_vec16(const float *vec, int h, float (&o)[16]) {
+    for (int g = 0; g < 4; ++g) {
+        const at_f32x4 t = *(const at_f32x4 *)&vec[8 * g + 4 * h];
+        o[4 * g] = t.x; o[4 * g + 1] = t.y; o[4 * g + 2] = t.z; o[4 * g + 3] = t.w;
+    }
+}
+// write the transposed accumulator (rows = d, column = own row) as 4 float4 of the row's 32 floats
+__device__ __forceinline__ void at_store_rowT(float *dst, int h, const at_f32x16 &acc, float mul) {
+    for (int g = 0; g < 4; ++g)
+        *(at_f32x4 *)&dst[8 * g + 4 * h] = at_f32x4{acc[4 * g] * mul, acc[4 * g + 1] * mul, acc[4 * g + 2] * mul, acc[4 * g + 3] * mul};
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ void __launch_bounds__(256)
+attn_fwd_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ks[2][AT_T * AT_LD], Vs[2][AT_T * AT_LD], Bs[2][AT_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
+    const long ld = 3L * a.d_model;
+    const float *Q = a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
+    const float *kb = a.key_bias ? a.key_bias + (long)b * a.S : nullptr;
+    const int query = blockIdx.x * 128 + wave * 32 + l31;
+    at_f32x4 qf[4];
+    at_grow16(Q, ld, query, a.S, h, qf);
+    at_f32x16 acc_o;
+    for (int r = 0; r < 16; ++r) acc_o[r] = 0.0f;
+    float m = AT_NEG, lsum = 0.0f;
+    const int ntiles = (a.S + AT_T - 1) / AT_T;
+
+    at_f32x4 rk = at_fetch4(K, ld, 0, a.S, tid), rv = at_fetch4(V, ld, 0, a.S, tid);
+    float rb = 0.0f;
+    if (tid < AT_T) rb = tid < a.S ? (kb ? kb[tid] : 0.0f) : -INFINITY;
+    at_stash4(Ks[0], tid, rk); at_stash4(Vs[0], tid, rv);
+    if (tid < AT_T) Bs[0][tid] = rb;
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, k0n = (t + 1) * AT_T;
+        rk = at_fetch4(K, ld, k0n, a.S, tid); rv = at_fetch4(V, ld, k0n, a.S, tid);      // past the end: zeros, never used
+        if (tid < AT_T) { const int kk = k0n + tid; const int kc = kk < a.S ? kk : a.S - 1; const float v = kb ? kb[kc] : 0.0f; rb = kk < a.S ? v : -INFINITY; }
+        // scores^T tile: keys (rows) x own queries (lanes)
+        at_f32x16 st = at_xyT(Ks[buf], l31, h, qf);
+        float bias[16], p[16];
+        at_vec16(Bs[buf], h, bias);
+        float tmax = AT_NEG;
+        for (int r = 0; r < 16; ++r) { p[r] = st[r] * a.scale + bias[r]; tmax = p[r] > tmax ? p[r] : tmax; }
+        { const float o = __shfl_xor(tmax, 32); tmax = o > tmax ? o : tmax; }
+        const float m_new = tmax > m ? tmax : m;
+        const float alpha = expf(m - m_new);            // m = AT_NEG on the first live tile -> 0 (or 1 while nothing is live)
+        float tsum = 0.0f;
+        for (int r = 0; r < 16; ++r) { p[r] = p[r] > AT_NEG ? expf(p[r] - m_new) : 0.0f; tsum += p[r]; }
+        tsum += __shfl_xor(tsum, 32);
+        lsum = lsum * alpha + tsum;
+        m = m_new;
+        for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
+        acc_o = at_xTp(Vs[buf], l31, h, p, acc_o);     // O^T += V^T P^T
+        at_stash4(Ks[buf ^ 1], tid, rk); at_stash4(Vs[buf ^ 1], tid, rv);
+        if (tid < AT_T) Bs[buf ^ 1][tid] = rb;
+        __syncthreads();
+    }
+    if (query < a.S) {
+        const float inv = lsum > 0.0f ? 1.0f / lsum : 0.0f;            // fully masked row -> zeros ("safe softmax")
+        at_store_rowT(a.out + ((long)b * a.S + query) * a.d_model + hd * AT_DH, h, acc_o, inv);
+        if (h == 0 && a.lse) a.lse[(long)bh * a.S + query] = lsum > 0.0f ? m + logf(lsum) : 3.0e38f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward 1: dQ (and D)
+__global__ void __launch_bounds__(256)
+attn_bwd_dq_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ks[2][AT_T * AT_LD], Vs[2][AT_T * AT_LD], Bs[2][AT_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
+    const long ld = 3L * a.d_model;
+    const float *Q = a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
+    const float *dO = a.dout + (long)b * a.S * a.d_model + hd * AT_DH, *O = a.out + (long)b * a.S * a.d_model + hd * AT_DH;
+    const float *kb = a.key_bias ? a.key_bias + (long)b * a.S : nullptr;
+    const int query = blockIdx.x * 128 + wave * 32 + l31;
+    at_f32x4 qf[4], dof[4], of[4];
+    at_grow16(Q, ld, query, a.S, h, qf);
+    at_grow16(dO, a.d_model, query, a.S, h, dof);
+    at_grow16(O, a.d_model, query, a.S, h, of);
+    float dsum = 0.0f;                                 // D = sum_d dO O (the lane pair holds the two halves of d)
+    for (int f = 0; f < 4; ++f) dsum += (dof[f].x * of[f].x + dof[f].y * of[f].y) + (dof[f].z * of[f].z + dof[f].w * of[f].w);
+    dsum += __shfl_xor(dsum, 32);
+    const float lse = query < a.S ? a.lse[(long)bh * a.S + query] : 3.0e38f;
+    if (query < a.S && h == 0) a.dsum[(long)bh * a.S + query] = dsum;
+    at_f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int ntiles = (a.S + AT_T - 1) / AT_T;
+
+    at_f32x4 rk = at_fetch4(K, ld, 0, a.S, tid), rv = at_fetch4(V, ld, 0, a.S, tid);
+    float rb = 0.0f;
+    if (tid < AT_T) rb = tid < a.S ? (kb ? kb[tid] : 0.0f) : -INFINITY;
+    at_stash4(Ks[0], tid, rk); at_stash4(Vs[0], tid, rv);
+    if (tid < AT_T) Bs[0][tid] = rb;
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, k0n = (t + 1) * AT_T;
+        rk = at_fetch4(K, ld, k0n, a.S, tid); rv = at_fetch4(V, ld, k0n, a.S, tid);
+        if (tid < AT_T) { const int kk = k0n + tid; const int kc = kk < a.S ? kk : a.S - 1; const float v = kb ? kb[kc] : 0.0f; rb = kk < a.S ? v : -INFINITY; }
+        const at_f32x16 st = at_xyT(Ks[buf], l31, h, qf);           // S^T
+        const at_f32x16 dpt = at_xyT(Vs[buf], l31, h, dof);         // dP^T = V dO^T
+        float bias[16], ds[16];
+        at_vec16(Bs[buf], h, bias);
+        for (int r = 0; r < 16; ++r) {
+            const float v = st[r] * a.scale + bias[r];
+            const float p = v > AT_NEG ? expf(v - lse) : 0.0f;
+            ds[r] = a.scale * p * (dpt[r] - dsum);
+        }
+        acc = at_xTp(Ks[buf], l31, h, ds, acc);                     // dQ^T += K^T dS^T
+        at_stash4(Ks[buf ^ 1], tid, rk); at_stash4(Vs[buf ^ 1], tid, rv);
+        if (tid < AT_T) Bs[buf ^ 1][tid] = rb;
+        __syncthreads();
+    }
+    if (query < a.S) at_store_rowT(a.dqkv + ((long)b * a.S + query) * ld + hd * AT_DH, h, acc, 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------ backward 2: dK, dV
+__global__ void __launch_bounds__(256)
+attn_bwd_dkv_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Qs[2][AT_T * AT_LD], Os[2][AT_T * AT_LD], Ls[2][AT_T], Ds[2][AT_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
+    const long ld = 3L * a.d_model;
+    const float *Q = a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
+    const float *dO = a.dout + (long)b * a.S * a.d_model + hd * AT_DH;
+    const float *lse = a.lse + (long)bh * a.S, *dsm = a.dsum + (long)bh * a.S;
+    const int key = blockIdx.x * 128 + wave * 32 + l31;
+    at_f32x4 kf[4], vf[4];
+    at_grow16(K, ld, key, a.S, h, kf);
+    at_grow16(V, ld, key, a.S, h, vf);
+    float bias = -INFINITY;
+    if (key < a.S) bias = a.key_bias ? a.key_bias[(long)b * a.S + key] : 0.0f;
+    at_f32x16 acc_k, acc_v;
+    for (int r = 0; r < 16; ++r) { acc_k[r] = 0.0f; acc_v[r] = 0.0f; }
+    const int ntiles = (a.S + AT_T - 1) / AT_T;
+
+    at_f32x4 rq = at_fetch4(Q, ld, 0, a.S, tid), ro = at_fetch4(dO, a.d_model, 0, a.S, tid);
+    float rl = 3.0e38f, rd = 0.0f;
+    if (tid < AT_T && tid < a.S) { rl = lse[tid]; rd = dsm[tid]; }
+    at_stash4(Qs[0], tid, rq); at_stash4(Os[0], tid, ro);
+    if (tid < AT_T) { Ls[0][tid] = rl; Ds[0][tid] = rd; }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, q0n = (t + 1) * AT_T;
+        rq = at_fetch4(Q, ld, q0n, a.S, tid); ro = at_fetch4(dO, a.d_model, q0n, a.S, tid);
+        if (tid < AT_T) { const int qq = q0n + tid; const int qc = qq < a.S ? qq : a.S - 1; const float l0 = lse[qc], d0 = dsm[qc]; rl = qq < a.S ? l0 : 3.0e38f; rd = qq < a.S ? d0 : 0.0f; }
+        const at_f32x16 s = at_xyT(Qs[buf], l31, h, kf);            // S: queries (rows) x own keys (lanes)
+        const at_f32x16 dp = at_xyT(Os[buf], l31, h, vf);           // dP = dO V^T
+        float lrow[16], drow[16], p[16], ds[16];
+        at_vec16(Ls[buf], h, lrow);
+        at_vec16(Ds[buf], h, drow);
+        for (int r = 0; r < 16; ++r) {
+            const float v = s[r] * a.scale + bias;
+            p[r] = v > AT_NEG ? expf(v - lrow[r]) : 0.0f;           // rows past the sequence carry lse = 3e38 -> 0
+            ds[r] = a.scale * p[r] * (dp[r] - drow[r]);
+        }
+        acc_v = at_xTp(Os[buf], l31, h, p, acc_v);                  // dV^T += dO^T P
+        acc_k = at_xTp(Qs[buf], l31, h, ds, acc_k);                 // dK^T += Q^T dS
+        at_stash4(Qs[buf ^ 1], tid, rq); at_stash4(Os[buf ^ 1], tid, ro);
+        if (tid < AT_T) { Ls[buf ^ 1][tid] = rl; Ds[buf ^ 1][tid] = rd; }
+        __syncthreads();
+    }
+    if (key < a.S) {
+        float *dst = a.dqkv + ((long)b * a.S + key) * ld + hd * AT_DH;
+        at_store_rowT(dst + a.d_model, h, acc_k, 1.0f);
+        at_store_rowT(dst + 2 * a.d_model, h, acc_v, 1.0f);
+    }
+}
+
+}  // namespace emloco

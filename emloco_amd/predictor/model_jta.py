@@ -45,7 +45,7 @@ class EncoderLayer(nn.Module):
     def forward(self, x, key_pad):
         sa = self.self_attn
         qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
-        att = ops.AttentionFn.apply(qkv, key_pad, sa.num_heads)
+        att = ops.attention(qkv, key_pad, sa.num_heads)
         a = ops.linear(att, sa.out_proj.weight, sa.out_proj.bias)
         x = ops.layer_norm(F.dropout(a, self.p, self.training), x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         h = ops.linear(x, self.linear1.weight, self.linear1.bias, relu=True)

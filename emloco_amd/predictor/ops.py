@@ -25,6 +25,8 @@ def _lib():
         lib.emloco_layernorm_fwd.argtypes = [ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_layernorm_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_colsum.argtypes = [ci, ci, vp, vp, vp, vp]
+        lib.emloco_attention_fwd.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp]
+        lib.emloco_attention_bwd.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_colsum_workspace.argtypes = [ci, ci]
         lib.emloco_colsum_workspace.restype = C.c_int64
         lib.emloco_layernorm_bwd_workspace.argtypes = [ci, ci]
@@ -118,6 +120,58 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, W, b=None, relu=False):
     return LinearFn.apply(x, W, b, relu)
+
+
+class FusedAttentionFn(torch.autograd.Function):
+    """Multi-head self-attention with head dim 32 in one kernel per direction (csrc/attention_kernels.hip): online
+    softmax forward, probabilities recomputed from the saved log-sum-exp in the backward; the S x S scores never reach
+    HBM.  qkv (Bn, S, 3 d) from the fused in-projection, key_pad (Bn, S) additive float bias."""
+    MAX_SEQ_HEADS = 65535
+
+    @staticmethod
+    def forward(ctx, qkv, key_pad, nhead):
+        Bn, S, d3 = qkv.shape
+        d = d3 // 3
+        qkv = qkv.contiguous()
+        key_pad = key_pad.contiguous() if key_pad is not None else None
+        out = torch.empty((Bn, S, d), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((Bn * nhead, S), dtype=torch.float32, device=qkv.device)
+        scale = 1.0 / float(d // nhead) ** 0.5
+        lib, st = _lib(), _st(qkv)
+        step = FusedAttentionFn.MAX_SEQ_HEADS // nhead
+        for b0 in range(0, Bn, step):
+            n = min(step, Bn - b0)
+            _chk(lib.emloco_attention_fwd(n, S, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
+                                          _p(out, b0 * S * d), _p(lse, b0 * nhead * S), st), "emloco_attention_fwd")
+        ctx.save_for_backward(qkv, key_pad, out, lse)
+        ctx.nhead, ctx.scale = nhead, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, key_pad, out, lse = ctx.saved_tensors
+        nhead, scale = ctx.nhead, ctx.scale
+        Bn, S, d3 = qkv.shape
+        d = d3 // 3
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dsum = torch.empty_like(lse)
+        lib, st = _lib(), _st(qkv)
+        step = FusedAttentionFn.MAX_SEQ_HEADS // nhead
+        for b0 in range(0, Bn, step):
+            n = min(step, Bn - b0)
+            _chk(lib.emloco_attention_bwd(n, S, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
+                                          _p(out, b0 * S * d), _p(lse, b0 * nhead * S), _p(dout, b0 * S * d), _p(dqkv, b0 * S * d3),
+                                          _p(dsum, b0 * nhead * S), st), "emloco_attention_bwd")
+        return dqkv, None, None
+
+
+def attention(qkv, key_pad, nhead):
+    """softmax(q k^T / sqrt(dh) + key_pad) v per head: the fused kernels for head dim 32 (the shipped d = 128, 4 heads),
+    the GEMM -> softmax -> GEMM composition otherwise."""
+    if qkv.shape[-1] // 3 // nhead == 32:
+        return FusedAttentionFn.apply(qkv, key_pad, nhead)
+    return AttentionFn.apply(qkv, key_pad, nhead)
 
 
 class AttentionFn(torch.autograd.Function):

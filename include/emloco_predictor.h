@@ -42,6 +42,19 @@ int emloco_softmax_fwd(int n_seq, int rows_per_seq, int cols, float scale, const
 /* dS = scale * P * (dP - sum_j(dP * P)) ; in place allowed (dS == dP) */
 int emloco_softmax_bwd(int rows, int cols, float scale, const float *P, const float *dP, float *dS, void *stream);
 
+/* Fused multi-head self-attention, head dim 32 (d_model = nhead * 32): nn.MultiheadAttention's
+ * softmax(q k^T / sqrt(32) + key_bias) v per head (model_jta.py:177-178,311-321), scores never written to memory.
+ * qkv [n_seq][S][3 d_model] = in_proj output (q | k | v, heads contiguous inside each); key_bias [n_seq][S] additive or
+ * NULL; out [n_seq][S][d_model] (heads concatenated = out_proj input); lse [n_seq * nhead][S] is kept for the backward.
+ * n_seq * nhead <= 65535. */
+int emloco_attention_fwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                         float *out, float *lse, void *stream);
+/* Backward: dqkv [n_seq][S][3 d_model] from dout; probabilities are recomputed from q, k and lse.  dsum is a device
+ * scratch of n_seq * nhead * S floats.  Deterministic (no atomics): one kernel owns the query rows (dq), one the key
+ * rows (dk, dv). */
+int emloco_attention_bwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                         const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, void *stream);
+
 /* y = LayerNorm(x + res) * gamma + beta over the last dim (post-norm encoder layer, d <= 1024);
  * res may be NULL.  Saves mean / rstd [rows] for the backward. */
 int emloco_layernorm_fwd(int rows, int d, float eps, const float *x, const float *res, const float *gamma,

@@ -2,6 +2,7 @@
 // TEST INFRASTRUCTURE ONLY: runs emloco_amd/csrc/predictor_kernels.hip on the CPU through tests/emu/hip/.
 #include "hip/hip_runtime.h"
 #include "../../emloco_amd/csrc/predictor_kernels.hip"
+#include "../../emloco_amd/csrc/attention_kernels.hip"
 
 using namespace emloco;
 
@@ -77,5 +78,25 @@ extern "C" int emu_locoval_bwd(int B, const float *traj, int ts, const float *po
                                const float *h2, const float *angle, const float *dvalue, float *dparams, float *dtraj, float *ws) {
     emu::launch((unsigned)B, 64, [&] { locoval_bwd_kernel(B, traj, ts, pose, vel, w1, w2, w3, value, x100, h1, h2, angle, dvalue, ws, dtraj); });
     emu::launch((unsigned)((LV_NPARAM + 255) / 256), 256, [&] { locoval_reduce_kernel(B, ws, dparams); });
+    return 0;
+}
+
+extern "C" int emu_attention_fwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 float *out, float *lse) {
+    AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr};
+    for (int y = 0; y < n_seq * nhead; ++y)
+        for (int x = 0; x < (S + 127) / 128; ++x)
+            emu::launch(1, 256, [&] { blockIdx.x = x; blockIdx.y = y; attn_fwd_kernel(a); });
+    blockIdx.x = 0; blockIdx.y = 0;
+    return 0;
+}
+extern "C" int emu_attention_bwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 float *out, float *lse, const float *dout, float *dqkv, float *dsum) {
+    AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, dout, dqkv, dsum};
+    for (int pass = 0; pass < 2; ++pass)
+        for (int y = 0; y < n_seq * nhead; ++y)
+            for (int x = 0; x < (S + 127) / 128; ++x)
+                emu::launch(1, 256, [&] { blockIdx.x = x; blockIdx.y = y; if (pass == 0) attn_bwd_dq_kernel(a); else attn_bwd_dkv_kernel(a); });
+    blockIdx.x = 0; blockIdx.y = 0;
     return 0;
 }

@@ -242,3 +242,49 @@ def test_obs_normalize_kernel_matches_reference_golden(golden):
     np.testing.assert_allclose(out0[:, :split], ref[:, :split], rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(out1[:, :cols - split], ref[:, split:], rtol=2e-6, atol=2e-6)
     assert np.all(out1[:, cols - split:] == 0) and ref.max() == 5.0 and ref.min() == -5.0
+
+
+def test_fused_attention_kernels_forward_and_backward():
+    """attn_fwd / attn_bwd_dq / attn_bwd_dkv (head dim 32) against a float64 numpy attention, ragged S (two query blocks'
+    worth of tiles would be slow in the emulator: S = 70 covers a partial last tile), additive and -inf key biases."""
+    lib = emu.lib()
+    rng = np.random.default_rng(5)
+    n_seq, S, H = 2, 70, 2
+    d = H * 32
+    qkv = (rng.normal(size=(n_seq, S, 3 * d)) * 0.7).astype(np.float32)
+    kb = np.zeros((n_seq, S), np.float32)
+    kb[0, 5::7] = 1.0                     # the reference's float padding mask: an additive +1
+    kb[1, 50:] = -np.inf                  # bool-style mask
+    scale = 1.0 / np.sqrt(32.0)
+    out = np.zeros((n_seq, S, d), np.float32)
+    lse = np.zeros((n_seq * H, S), np.float32)
+    lib.emu_attention_fwd(n_seq, S, H, d, C.c_float(scale), P(qkv), P(kb), P(out), P(lse))
+    q = qkv[..., :d].reshape(n_seq, S, H, 32).transpose(0, 2, 1, 3).astype(np.float64)
+    k = qkv[..., d:2 * d].reshape(n_seq, S, H, 32).transpose(0, 2, 1, 3).astype(np.float64)
+    v = qkv[..., 2 * d:].reshape(n_seq, S, H, 32).transpose(0, 2, 1, 3).astype(np.float64)
+    s = np.einsum("bhqd,bhkd->bhqk", q, k) * scale + kb[:, None, None, :].astype(np.float64)
+    mx = s.max(-1, keepdims=True)
+    e = np.exp(s - mx)
+    p = e / e.sum(-1, keepdims=True)
+    ref = np.einsum("bhqk,bhkd->bhqd", p, v).transpose(0, 2, 1, 3).reshape(n_seq, S, d)
+    np.testing.assert_allclose(out, ref, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(lse.reshape(n_seq, H, S), (mx[..., 0] + np.log(e.sum(-1))), rtol=1e-5, atol=1e-5)
+    dout = rng.normal(size=out.shape).astype(np.float32)
+    dqkv = np.zeros_like(qkv)
+    dsum = np.zeros((n_seq * H, S), np.float32)
+    lib.emu_attention_bwd(n_seq, S, H, d, C.c_float(scale), P(qkv), P(kb), P(out), P(lse), P(dout), P(dqkv), P(dsum))
+    do = dout.reshape(n_seq, S, H, 32).transpose(0, 2, 1, 3).astype(np.float64)
+    dv = np.einsum("bhqk,bhqd->bhkd", p, do)
+    dp = np.einsum("bhqd,bhkd->bhqk", do, v)
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True)) * scale
+    dq = np.einsum("bhqk,bhkd->bhqd", ds, k)
+    dk = np.einsum("bhqk,bhqd->bhkd", ds, q)
+    back = lambda t: t.transpose(0, 2, 1, 3).reshape(n_seq, S, d)
+    np.testing.assert_allclose(dqkv[..., :d], back(dq), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(dqkv[..., d:2 * d], back(dk), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(dqkv[..., 2 * d:], back(dv), rtol=1e-4, atol=5e-6)
+    # a fully masked sequence gives zeros, not NaN ("safe softmax", torch >= 2.5)
+    kb2 = np.full((1, S), -np.inf, np.float32)
+    out2 = np.ones((1, S, d), np.float32)
+    lib.emu_attention_fwd(1, S, H, d, C.c_float(scale), P(qkv[:1]), P(kb2), P(out2), P(lse[:H]))
+    assert np.all(out2 == 0)

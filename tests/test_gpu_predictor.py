@@ -184,3 +184,29 @@ def test_jrdb_model_and_batch_processing_match_reference(golden):
     for k, v in g.items():
         if k.startswith("grad__"):
             _close(params[k[6:].replace("__", ".")].grad.cpu(), v, rel=2e-4, abs_=1e-6, what=k)
+
+
+def test_fused_attention_matches_composed_path_and_torch():
+    """Head dim 32 (the shipped d = 128 / 4 heads): fused attention kernels vs the GEMM->softmax->GEMM composition and
+    torch's scaled_dot_product_attention math, forward and backward, S = 453 with padded sequences."""
+    from emloco_amd.predictor import ops
+    torch.manual_seed(3)
+    Bn, S, H, d = 6, 453, 4, 128
+    qkv = (torch.randn(Bn, S, 3 * d, device="cuda:0") * 0.6).requires_grad_(True)
+    pad = torch.zeros(Bn, S, device="cuda:0")
+    pad[1] = 1.0                                # the reference's float mask (+1 bias on every key of a padded person)
+    pad[2, 300:] = float("-inf")
+    pad[3] = float("-inf")                      # fully masked sequence -> zeros
+    dout = torch.randn(Bn, S, d, device="cuda:0")
+    o_f = ops.FusedAttentionFn.apply(qkv, pad, H)
+    (g_f,) = torch.autograd.grad(o_f, qkv, dout)
+    o_c = ops.AttentionFn.apply(qkv, pad, H)
+    (g_c,) = torch.autograd.grad(o_c, qkv, dout)
+    _close(o_f.detach().cpu(), o_c.detach().cpu(), rel=2e-5, abs_=1e-6, what="fused vs composed out")
+    _close(g_f.cpu(), g_c.cpu(), rel=1e-4, abs_=1e-6, what="fused vs composed dqkv")
+    live = [0, 1, 2, 4, 5]                      # torch's math on the rows that are not fully masked
+    q, k, v = [t.reshape(Bn, S, H, 32).transpose(1, 2) for t in qkv.detach().double().split(d, dim=-1)]
+    s = q @ k.transpose(-1, -2) / 32 ** 0.5 + pad.double()[:, None, None, :]
+    ref = (torch.softmax(s[live], -1) @ v[live]).transpose(1, 2).reshape(len(live), S, d)
+    _close(o_f.detach()[live].cpu(), ref.cpu(), rel=2e-5, abs_=1e-6, what="fused vs float64 attention")
+    assert float(o_f[3].detach().abs().max()) == 0.0 and torch.isfinite(g_f).all()
