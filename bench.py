@@ -254,9 +254,7 @@ def policy_leg(env, E, dev, steps, warmup):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def one_step(timed):
-        done = task.reset_buf.nonzero(as_tuple=False).flatten()
-        if done.numel():
-            env.reset(done)
+        env.reset_done()
         if timed:
             ev0.record()
         act = pol.act(task.obs_buf, deterministic=False, generator=gen)
@@ -320,9 +318,7 @@ def main():
     horizon = 32
 
     def one_step(k):
-        done = task.reset_buf.nonzero(as_tuple=False).flatten()
-        if done.numel():
-            env.reset(done)
+        env.reset_done()                 # reset(dones.nonzero()) without the host reading the count (device-side compaction)
         env.step(pool[k % 64])
         if world > 1 and (k + 1) % horizon == 0:
             dist.all_reduce(grad_bucket)

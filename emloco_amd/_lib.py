@@ -100,7 +100,7 @@ SYMBOLS_SIM = [
 ]
 SYMBOLS_TASK = [
     "emloco_task_post_physics", "emloco_task_amp_rows", "emloco_task_pd_targets", "emloco_task_last_ms",
-    "emloco_task_enable_timing", "emloco_task_reset",
+    "emloco_task_enable_timing", "emloco_task_reset", "emloco_task_compact_done",
 ]
 
 _lib = None
@@ -146,6 +146,7 @@ def load():
     lib.emloco_task_pd_targets.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]
     lib.emloco_task_enable_timing.argtypes = [C.c_int]
     lib.emloco_task_reset.argtypes = [C.c_void_p, C.POINTER(ResetBufs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.emloco_task_compact_done.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 

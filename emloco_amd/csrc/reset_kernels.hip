@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(64)
 reset_sample_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n, const float *rnd) {
     if ((int)blockIdx.x >= n) return;
     const int env = ids[blockIdx.x], lane = threadIdx.x;
+    if (env < 0) return;                     // padding entry of a device-compacted id list (emloco_task_compact_done)
     const float *u = rnd + (long)blockIdx.x * EMLOCO_RESET_RND;
     int mid = (int)(u[EMLOCO_RND_MOTION] * (float)t.n_motions);
     if (mid > t.n_motions - 1) mid = t.n_motions - 1;
@@ -132,10 +133,9 @@ __global__ void __launch_bounds__(64)
 reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n, const float *rnd) {
     if ((int)blockIdx.x >= n) return;
     const int env = ids[blockIdx.x], lane = threadIdx.x;
+    if (env < 0) return;
     const float *u = rnd + (long)blockIdx.x * EMLOCO_RESET_RND;
     __shared__ float sh_v[RNV][3];
-    __shared__ float sh_root[13], sh_dp[RNDOF], sh_dv[RNDOF], sh_key[12];
-    __shared__ float sh_misc[4];
 
     // ---- a. lowest collision point -> vertical shift (replaces the SMPL-mesh height fix, humanoid_amp.py:321-379)
     float low = 3.0e38f;
@@ -177,6 +177,10 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
     // ---- c. trajectory (traj_generator.py:60-237)
     const float ipx = rs[0], ipy = rs[1];
     const float rvx = rs[7], rvy = rs[8];
+    // The heading / speed recurrences (clamped random walks) are sequential but cheap; the 100 cos / sin evaluations are
+    // the cost, so lane 0 only produces theta_i and the segment length, all lanes evaluate the steps, and lane 0 adds
+    // them up in the original order (same floating-point result as the one-lane loop, ~8x shorter critical path).
+    __shared__ float sh_th[RNV], sh_seg[RNV];
     if (lane == 0) {
         const float vdt = t.vert_dt;
         float speed = (t.speed_max - t.speed_min) * u[EMLOCO_RND_SPEED0] + t.speed_min;
@@ -184,8 +188,7 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
         if (t.flags & EMLOCO_RESET_ADJUST_ROOT_VEL) {
             ratio = sqrtf(rvx * rvx + rvy * rvy) / speed;
         }
-        float theta = 0.0f, px = 0.0f, py = 0.0f;
-        sh_v[0][0] = ipx; sh_v[0][1] = ipy; sh_v[0][2] = 0.0f;
+        float theta = 0.0f;
         for (int i = 0; i < RNV - 1; ++i) {
             float dth = (2.0f * u[EMLOCO_RND_DTHETA + i] - 1.0f) * (t.dtheta_max * vdt);
             if (u[EMLOCO_RND_BERN + i] < t.sharp_prob) dth = 3.14159265358979f * (2.0f * u[EMLOCO_RND_SHARP + i] - 1.0f);
@@ -201,9 +204,23 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
                 sp = sp < t.speed_min ? t.speed_min : (sp > t.speed_max ? t.speed_max : sp);
             }
             theta += dth;
-            const float seg = sp * vdt;
-            px += cosf(theta) * seg;
-            py += -sinf(theta) * seg;
+            sh_th[i] = theta;
+            sh_seg[i] = sp * vdt;
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < RNV - 1; i += 64) {
+        const float th = sh_th[i], seg = sh_seg[i];
+        sh_th[i] = cosf(th) * seg;
+        sh_seg[i] = -sinf(th) * seg;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float px = 0.0f, py = 0.0f;
+        sh_v[0][0] = ipx; sh_v[0][1] = ipy; sh_v[0][2] = 0.0f;
+        for (int i = 0; i < RNV - 1; ++i) {
+            px += sh_th[i];
+            py += sh_seg[i];
             sh_v[i + 1][0] = px + ipx; sh_v[i + 1][1] = py + ipy; sh_v[i + 1][2] = 0.0f;
         }
     }
@@ -262,38 +279,45 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
         for (int k = 0; k < 3; ++k) t.init_pose[((long)env * RNB + lane) * 3 + k] = s.rb_state[((long)env * RNB + lane) * 13 + k];
     if (lane == 0) { t.init_vel[(long)env * 2] = rvx; t.init_vel[(long)env * 2 + 1] = rvy; }
 
-    // ---- e. AMP history rows 1..14 from the motion library at t - k dt (humanoid_amp.py:486-535)
+}
+
+// ---- e. AMP history rows 1..14 from the motion library at t - k dt (humanoid_amp.py:486-535): one workgroup per
+// (finished env, history row) -- the rows are independent, a single wave walking all 14 was the longest serial path of a reset.
+__global__ void __launch_bounds__(64)
+reset_amp_history_kernel(EmlocoResetBufs t, const int32_t *ids, int n) {
+    if ((int)blockIdx.x >= n) return;
+    const int env = ids[blockIdx.x], lane = threadIdx.x;
+    if (env < 0) return;
+    const int k = 1 + (int)blockIdx.y;
+    __shared__ float sh_root[13], sh_dp[RNDOF], sh_dv[RNDOF], sh_key[12];
     const int mid = (int)t.motion_ids[env];
     const float mt = t.motion_times[env];
-    for (int k = 1; k < EMLOCO_AMP_STEPS; ++k) {
-        const FrameBlend fb = frame_blend(t, mid, mt - t.dt * (float)k);
-        if (lane >= 1 && lane < RNB) {
-            float q[4], e[3];
-            ref_slerp(t.lrs + (fb.f0 * RNB + lane) * 4, t.lrs + (fb.f1 * RNB + lane) * 4, fb.blend, q);
-            ref_quat_to_exp_map(q, e);
-            for (int c = 0; c < 3; ++c) {
-                sh_dp[(lane - 1) * 3 + c] = e[c];
-                sh_dv[(lane - 1) * 3 + c] = lerp1(t.dvs[fb.f0 * RNDOF + (lane - 1) * 3 + c], t.dvs[fb.f1 * RNDOF + (lane - 1) * 3 + c], fb.blend);
-            }
+    const FrameBlend fb = frame_blend(t, mid, mt - t.dt * (float)k);
+    if (lane >= 1 && lane < RNB) {
+        float q[4], e[3];
+        ref_slerp(t.lrs + (fb.f0 * RNB + lane) * 4, t.lrs + (fb.f1 * RNB + lane) * 4, fb.blend, q);
+        ref_quat_to_exp_map(q, e);
+        for (int c = 0; c < 3; ++c) {
+            sh_dp[(lane - 1) * 3 + c] = e[c];
+            sh_dv[(lane - 1) * 3 + c] = lerp1(t.dvs[fb.f0 * RNDOF + (lane - 1) * 3 + c], t.dvs[fb.f1 * RNDOF + (lane - 1) * 3 + c], fb.blend);
         }
-        if (lane == 0) {
-            for (int c = 0; c < 3; ++c) {
-                sh_root[c] = lerp1(t.gts[(fb.f0 * RNB) * 3 + c], t.gts[(fb.f1 * RNB) * 3 + c], fb.blend);
-                sh_root[7 + c] = lerp1(t.gvs[(fb.f0 * RNB) * 3 + c], t.gvs[(fb.f1 * RNB) * 3 + c], fb.blend);
-                sh_root[10 + c] = lerp1(t.gavs[(fb.f0 * RNB) * 3 + c], t.gavs[(fb.f1 * RNB) * 3 + c], fb.blend);
-            }
-            ref_slerp(t.grs + (fb.f0 * RNB) * 4, t.grs + (fb.f1 * RNB) * 4, fb.blend, sh_root + 3);
-        }
-        if (lane < 4) {
-            const int kb = t.key_bodies[lane];
-            for (int c = 0; c < 3; ++c)
-                sh_key[lane * 3 + c] = lerp1(t.gts[(fb.f0 * RNB + kb) * 3 + c], t.gts[(fb.f1 * RNB + kb) * 3 + c], fb.blend);
-        }
-        __syncthreads();
-        amp_row(lane, sh_root, sh_root + 3, sh_root + 7, sh_root + 10, sh_dp, sh_dv, 1, sh_key, t.betas + (long)env * 17,
-                t.dof_subset, t.n_dof_subset, t.amp_obs_buf + ((long)env * EMLOCO_AMP_STEPS + k) * EMLOCO_AMP_ROW);
-        __syncthreads();
     }
+    if (lane == 0) {
+        for (int c = 0; c < 3; ++c) {
+            sh_root[c] = lerp1(t.gts[(fb.f0 * RNB) * 3 + c], t.gts[(fb.f1 * RNB) * 3 + c], fb.blend);
+            sh_root[7 + c] = lerp1(t.gvs[(fb.f0 * RNB) * 3 + c], t.gvs[(fb.f1 * RNB) * 3 + c], fb.blend);
+            sh_root[10 + c] = lerp1(t.gavs[(fb.f0 * RNB) * 3 + c], t.gavs[(fb.f1 * RNB) * 3 + c], fb.blend);
+        }
+        ref_slerp(t.grs + (fb.f0 * RNB) * 4, t.grs + (fb.f1 * RNB) * 4, fb.blend, sh_root + 3);
+    }
+    if (lane < 4) {
+        const int kb = t.key_bodies[lane];
+        for (int c = 0; c < 3; ++c)
+            sh_key[lane * 3 + c] = lerp1(t.gts[(fb.f0 * RNB + kb) * 3 + c], t.gts[(fb.f1 * RNB + kb) * 3 + c], fb.blend);
+    }
+    __syncthreads();
+    amp_row(lane, sh_root, sh_root + 3, sh_root + 7, sh_root + 10, sh_dp, sh_dv, 1, sh_key, t.betas + (long)env * 17,
+            t.dof_subset, t.n_dof_subset, t.amp_obs_buf + ((long)env * EMLOCO_AMP_STEPS + k) * EMLOCO_AMP_ROW);
 }
 
 }  // namespace emloco

@@ -693,6 +693,7 @@ sim_fk_kernel(EmlocoSimDev d, const int *env_ids, int n_ids) {
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= n_ids) return;
     const int env = env_ids ? env_ids[blockIdx.x] : (int)blockIdx.x;
+    if (env < 0) return;                     // padding entry of a device-compacted id list
     __shared__ float sh_pw[NB][3], sh_qw[NB][4], sh_R[NB][9], sh_V[NB][6];
     const bool is_body = lane < NB;
     const int b = is_body ? lane : 0;

@@ -108,6 +108,15 @@ int emloco_task_reset(EmlocoSim *sim, const EmlocoResetBufs *b, const int32_t *d
     if (rc != 0) return rc;
     hipLaunchKernelGGL(emloco::reset_finish_kernel, dim3((unsigned)n), dim3(64), 0, st, *b, sim->dev, dev_env_ids, n, dev_rnd);
     THIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(emloco::reset_amp_history_kernel, dim3((unsigned)n, EMLOCO_AMP_STEPS - 1), dim3(64), 0, st, *b, dev_env_ids, n);
+    THIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_task_compact_done(const int64_t *dev_flags, int n, int32_t *dev_ids, void *stream) {
+    if (!dev_flags || !dev_ids || n < 1) return tfail(-1, "emloco_task_compact_done: bad argument (ids holds n + 1 entries)");
+    hipLaunchKernelGGL(emloco::compact_flags_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dev_flags, n, dev_ids);
+    THIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -108,6 +108,7 @@ post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_id
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= n_ids) return;
     const int env = env_ids ? env_ids[blockIdx.x] : (int)blockIdx.x;
+    if (env < 0) return;                     // padding entry of a device-compacted id list
 
     __shared__ float sh_body[TNB][13];
     __shared__ float sh_samp[EMLOCO_TRAJ_SAMPLES][3];
@@ -279,6 +280,35 @@ __global__ void pd_targets_kernel(int total, const float *actions, const float *
     if (i >= total) return;
     const int dd = i % TNDOF;
     out[i] = zero_mask[dd] ? 0.0f : offset[dd] + scale[dd] * actions[i];
+}
+
+// Device-side replacement of `reset_buf.nonzero()` (amp_continuous_value.py:46,74 does it on the host, which stalls the
+// launch queue every step): ids[0..count) = ascending indices of the non-zero flags, ids[count..n) = -1, ids[n] = count.
+// One 1024-thread workgroup; ballot + popcount inside a wave, LDS prefix over the 16 waves, running base over chunks.
+__global__ void __launch_bounds__(1024)
+compact_flags_kernel(const int64_t *flags, int n, int32_t *ids) {
+    __shared__ int sh_wave[16];
+    __shared__ int sh_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) sh_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + tid;
+        const bool on = i < n && flags[i] != 0;
+        const unsigned long long bal = __ballot(on);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) sh_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = sh_base;
+        for (int w = 0; w < wave; ++w) off += sh_wave[w];
+        if (on) ids[off + before] = i;
+        __syncthreads();
+        if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += sh_wave[w]; sh_base += tot; }
+        __syncthreads();
+    }
+    const int count = sh_base;
+    for (int i = count + tid; i < n; i += 1024) ids[i] = -1;
+    if (tid == 0) ids[n] = count;
 }
 
 }  // namespace emloco

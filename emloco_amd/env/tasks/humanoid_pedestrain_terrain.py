@@ -189,6 +189,41 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         self._motion_start_times[env_ids] = self._reset_motion_times[env_ids]
         self._sampled_motion_ids[env_ids] = self._reset_motion_ids[env_ids]
 
+    def reset_done(self, rnd=None):
+        """Reset every env whose reset_buf is set WITHOUT the host reading which ones: the reference's loop does
+        `done_indices = dones.nonzero()` on the host each step (amp_continuous_value.py:46,74), which drains the launch
+        queue; here the id list is compacted on the device (`emloco_task_compact_done`, padding entries -1 are skipped by
+        the kernels) and the per-env bookkeeping uses masks.  Same result as `reset(reset_buf.nonzero())` with the same
+        random rows.  Falls back to that when the fused reset path is not active."""
+        import ctypes as C
+        from ...sim import current_stream_handle
+        if not (getattr(self, "_fused_reset", False) and getattr(self, "_traj_gen", None) is not None):
+            env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
+            if len(env_ids) > 0:
+                self._reset_envs(env_ids)
+            return
+        if self._reset_bufs is None:
+            self._reset_bufs = self._make_reset_bufs()
+        E = self.num_envs
+        if getattr(self, "_done_ids", None) is None:
+            self._done_ids = torch.full((E + 1,), -1, dtype=torch.int32, device=self.device)
+        st = current_stream_handle(torch.device(self.device))
+        done = self.reset_buf != 0                                   # mask snapshot: the reset kernels clear reset_buf
+        lib = self._post.lib
+        L.check(lib.emloco_task_compact_done(C.c_void_p(self.reset_buf.data_ptr()), E, C.c_void_p(self._done_ids.data_ptr()), st),
+                "emloco_task_compact_done")
+        if rnd is None:
+            rnd = torch.rand((E, L.RESET_RND), device=self.device)       # row i serves the i-th finished env (ascending id)
+        L.check(lib.emloco_task_reset(self.sim.native._h, C.byref(self._reset_bufs), C.c_void_p(self._done_ids.data_ptr()), E,
+                                      C.c_void_p(rnd.data_ptr()), st), "emloco_task_reset")
+        self._post.run(self._post_bufs if self._post_bufs is not None else self._ensure_post_bufs(), L.POST_OBS | L.POST_AMP_ROW,
+                       self._done_ids[:E])
+        if flags.init_heading and flags.heading_inversion:
+            self._traj_gen.inverted = self._inverted_u8.bool()
+        self.inverted = self._traj_gen.show_inverted()
+        self._motion_start_times = torch.where(done, self._reset_motion_times, self._motion_start_times)
+        self._sampled_motion_ids = torch.where(done, self._reset_motion_ids, self._sampled_motion_ids)
+
     def _ensure_post_bufs(self):
         self._post_bufs = self._make_post_bufs()
         return self._post_bufs

@@ -52,6 +52,11 @@ class VecTaskPythonWrapper(VecTaskPython):
         self.task.reset(env_ids)
         return self._obs()
 
+    def reset_done(self):
+        """sync-free `reset(dones.nonzero())` (extension; see HumanoidPedestrianTerrain.reset_done)"""
+        self.task.reset_done()
+        return self._obs()
+
     def raw_reward(self):
         return self.task.reward_raw.to(self.rl_device)
 

@@ -157,6 +157,14 @@ struct EmlocoSim;
 int emloco_task_reset(struct EmlocoSim *sim, const EmlocoResetBufs *bufs, const int32_t *dev_env_ids, int n,
                       const float *dev_rnd, void *stream);
 
+/* Device-side `reset_buf.nonzero()`: dev_ids[0..count) = ascending indices of the non-zero flags, the rest of the n
+ * entries = -1, dev_ids[n] = count.  Every *_indexed / env-id-list entry point of this library skips negative ids, so
+ *   emloco_task_compact_done(reset_buf, E, ids, s); emloco_task_reset(sim, bufs, ids, E, rnd, s);
+ *   emloco_task_post_physics(bufs, EMLOCO_POST_OBS | EMLOCO_POST_AMP_ROW, ids, E, s);
+ * resets exactly the finished envs without the host ever reading the count (the reference's loop,
+ * amp_continuous_value.py:46,74, synchronises on `dones.nonzero()` every step). */
+int emloco_task_compact_done(const int64_t *dev_flags, int n, int32_t *dev_ids, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

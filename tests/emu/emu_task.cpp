@@ -24,3 +24,8 @@ extern "C" int emu_task_pd_targets(int n_env, const float *actions, const float 
     emu::launch((unsigned)((total + 255) / 256), 256, [&] { emloco::pd_targets_kernel(total, actions, offset, scale, zero_mask, out); });
     return 0;
 }
+
+extern "C" int emu_compact_flags(const int64_t *flags, int n, int32_t *ids) {
+    emu::launch(1, 1024, [&] { emloco::compact_flags_kernel(flags, n, ids); });
+    return 0;
+}

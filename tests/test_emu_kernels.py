@@ -288,3 +288,16 @@ def test_fused_attention_kernels_forward_and_backward():
     out2 = np.ones((1, S, d), np.float32)
     lib.emu_attention_fwd(1, S, H, d, C.c_float(scale), P(qkv[:1]), P(kb2), P(out2), P(lse[:H]))
     assert np.all(out2 == 0)
+
+
+def test_compact_flags_kernel_is_nonzero():
+    """device-side `reset_buf.nonzero()`: ascending ids, -1 padding, count in the extra slot; ragged sizes around 1024"""
+    lib = emu.lib()
+    rng = np.random.default_rng(2)
+    for n, prob in ((4096, 0.01), (1500, 0.5), (1024, 1.0), (77, 0.0), (2049, 0.3)):
+        flags = (rng.random(n) < prob).astype(np.int64) * rng.integers(1, 5, n)
+        ids = np.full(n + 1, 12345, np.int32)
+        lib.emu_compact_flags(P(flags), n, P(ids))
+        nz = np.nonzero(flags)[0]
+        assert ids[n] == len(nz)
+        assert np.array_equal(ids[:len(nz)], nz) and np.all(ids[len(nz):n] == -1)

@@ -142,6 +142,41 @@ def test_rollout_with_frozen_policy_and_disc_reward(tmp_path):
     assert agent.frames == 4 * 16 * 128 and np.isfinite(agent.vnet_loss)
 
 
+def test_reset_done_equals_reset_of_nonzero():
+    """The sync-free `reset_done()` (device-compacted id list) leaves the same state as `reset(reset_buf.nonzero())` with
+    the same random rows -- two identically seeded envs, one per path, compared bit for bit after several resets."""
+    from emloco_amd import _lib as L
+    args = ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel"]
+    envs = [_make_env(96, args), _make_env(96, args)]
+    dev = envs[0].task.device
+    g = torch.Generator(device=dev)
+    for k in range(40):
+        g.manual_seed(100 + k)
+        act = torch.randn(96, 69, device=dev, generator=g) * 0.3
+        g.manual_seed(500 + k)
+        rnd = torch.rand(96, L.RESET_RND, device=dev, generator=g)
+        ta, tb = envs[0].task, envs[1].task
+        if k == 0:
+            ta.reset_buf[:] = 1
+            tb.reset_buf[:] = 1
+        if k % 7 == 3:
+            ta.reset_buf[5:40:3] = 1                         # force a batch of resets besides the natural terminations
+            tb.reset_buf[5:40:3] = 1
+        done = ta.reset_buf.nonzero(as_tuple=False).flatten()
+        if done.numel():
+            ta._fused_reset_envs(done, rnd=rnd[:done.numel()].contiguous())
+        tb.reset_done(rnd=rnd)
+        envs[0].step(act)
+        envs[1].step(act)
+    torch.cuda.synchronize()
+    ta, tb = envs[0].task, envs[1].task
+    for name in ("_root_states", "_dof_state", "obs_buf", "_amp_obs_buf", "progress_buf", "reset_buf", "rew_buf", "waypoint_traj",
+                 "init_pose", "init_vel", "_motion_start_times", "_sampled_motion_ids"):
+        a, b = getattr(ta, name), getattr(tb, name)
+        assert torch.equal(a, b), name
+    assert torch.equal(ta._traj_gen._traj_verts, tb._traj_gen._traj_verts) if hasattr(ta._traj_gen, "_traj_verts") else True
+
+
 def test_fused_reset_matches_host_mirror():
     """The three-kernel device reset against the host-side torch mirror of the reference's reset path."""
     from emloco_amd import _lib as L
