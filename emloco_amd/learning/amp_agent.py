@@ -1,0 +1,448 @@
+"""AMPAgent -- PPO + adversarial-motion-prior training of the PACER policy (configs[1]) without rl_games.
+
+Mirror of /root/reference/pacer/pacer/learning/amp_continuous.py (AMPAgent: play_steps :98-189, train_epoch :222-321,
+calc_gradients :335-479, losses :515-598, disc reward :675-692) over common_agent.py (GAE :573-587, bound loss :594-603,
+actor / critic losses :657-683, advantages :685-696, prepare_dataset :426-468), amp_datasets.py, replay_buffer.py and
+amp_models.py (model forward incl. the per-joint AMP dropout :62-90).  The pieces that come from rl_games==1.1.4 in the
+reference (A2CBase buffers, ModelA2CContinuousLogStd's neglogp / entropy, policy_kl, Adam set-up) are restated from their
+textbook definitions -- parity with rl_games internals is UNPINNED; the losses are pinned by a
+plain-torch double-backward restatement in tests/test_gpu_policy.py.
+
+Every Linear of actor / critic / discriminator runs on `emloco_gemm_f32` through `predictor.ops.linear` (forward and
+backward).  The discriminator gradient penalty needs d/dtheta of |dD/dx|^2; instead of a double backward through custom
+autograd Functions the input gradient is written out as its own small network (ReLU masks are constants a.e., so the
+result is identical):  dD/dx = W1^T (m1 o (W2^T (m2 o w3)))  -- three more GEMMs whose autograd reaches W1, W2, w3.
+Multi-GPU: one flat gradient bucket all-reduced (averaged) per minibatch over RCCL, KL averaged, as the reference does
+with Horovod (amp_continuous.py:436-444, common_agent.py:179-180).
+"""
+import math
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..dist import FlatGradBucket
+from ..predictor import ops
+from ..utils.running_mean_std import RunningMeanStd
+from .amp_network_sept_builder import AMPSeptBuilder
+
+
+class ReplayBuffer:
+    """replay_buffer.py:3-92."""
+
+    def __init__(self, buffer_size, device):
+        self._head, self._total_count, self._buffer_size, self._device = 0, 0, buffer_size, device
+        self._data_buf = None
+        self._sample_idx = torch.randperm(buffer_size)
+        self._sample_head = 0
+
+    def get_buffer_size(self):
+        return self._buffer_size
+
+    def get_total_count(self):
+        return self._total_count
+
+    def store(self, data_dict):
+        if self._data_buf is None:
+            self._data_buf = {k: torch.zeros((self._buffer_size,) + tuple(v.shape[1:]), dtype=v.dtype, device=self._device)
+                              for k, v in data_dict.items()}
+        n = next(iter(data_dict.values())).shape[0]
+        assert n <= self._buffer_size
+        for key, buf in self._data_buf.items():
+            store_n = min(n, self._buffer_size - self._head)
+            buf[self._head:self._head + store_n] = data_dict[key][:store_n]
+            if n - store_n > 0:
+                buf[0:n - store_n] = data_dict[key][store_n:]
+        self._head = (self._head + n) % self._buffer_size
+        self._total_count += n
+
+    def sample(self, n):
+        idx = torch.arange(self._sample_head, self._sample_head + n) % self._buffer_size
+        rand_idx = self._sample_idx[idx]
+        if self._total_count < self._buffer_size:
+            rand_idx = rand_idx % self._head
+        rand_idx = rand_idx.to(self._device)
+        samples = {k: v[rand_idx] for k, v in self._data_buf.items()}
+        self._sample_head += n
+        if self._sample_head >= self._buffer_size:
+            self._sample_idx[:] = torch.randperm(self._buffer_size)
+            self._sample_head = 0
+        return samples
+
+
+def neglogp(x, mean, std, logstd):
+    """ModelA2CContinuousLogStd.neglogp (rl_games 1.1.4)."""
+    return 0.5 * (((x - mean) / std) ** 2).sum(dim=-1) + 0.5 * math.log(2.0 * math.pi) * x.size()[-1] + logstd.sum(dim=-1)
+
+
+def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma):
+    """torch_ext.policy_kl (rl_games 1.1.4), reduced."""
+    c1 = torch.log(p1_sigma / p0_sigma + 1e-5)
+    c2 = (p0_sigma ** 2 + (p1_mu - p0_mu) ** 2) / (2.0 * (p1_sigma ** 2 + 1e-5))
+    return (c1 + c2 - 0.5).sum(dim=-1).mean()
+
+
+def amp_dropout_mask(B, steps, feat, num_masks=3, dropout_rate=0.3, device="cpu"):
+    """amp_models.py:62-90 for the 206-wide AMP row: whole joints (6 rotation + 3 velocity values) are dropped together."""
+    assert feat == 206
+    dof_off, num_joints = 12, 19
+    vel_off = dof_off + num_joints * 6
+    mask = torch.ones([B, feat, num_masks])
+    for j in range(num_joints):
+        keep = (torch.rand(B, num_masks) > dropout_rate).float()
+        mask[:, dof_off + j * 6:dof_off + j * 6 + 6, :] = keep[:, None]
+        mask[:, vel_off + j * 3:vel_off + j * 3 + 3, :] = keep[:, None]
+    return mask.repeat(1, steps, 1).to(device)
+
+
+def disc_forward_with_grad_penalty(net, amp_obs_demo, input_mask=None):
+    """Discriminator logits on the demo batch and mean |dD/dx|^2 (amp_continuous.py:560-583) with the input gradient
+    written as an explicit network (see module docstring).  `input_mask` is the AMP dropout mask applied to the input."""
+    x = amp_obs_demo if input_mask is None else amp_obs_demo * input_mask
+    lin = [m for m in net._disc_mlp if isinstance(m, nn.Linear)]
+    hs, h = [], x
+    for m in lin:
+        h = ops.linear(h, m.weight, m.bias, relu=True)
+        hs.append(h)
+    logits = ops.linear(h, net._disc_logits.weight, net._disc_logits.bias)
+    g = (hs[-1] > 0).float() * net._disc_logits.weight                       # (B, units[-1])
+    for i in range(len(lin) - 1, 0, -1):
+        g = (hs[i - 1] > 0).float() * ops.linear(g, lin[i].weight.t())
+    gx = ops.linear(g, lin[0].weight.t())
+    if input_mask is not None:
+        gx = gx * input_mask
+    return logits, torch.mean(torch.sum(torch.square(gx), dim=-1))
+
+
+class AMPAgent:
+    def __init__(self, vec_env, cfg_train, seed=0):
+        self.vec_env = vec_env
+        env = vec_env.env if hasattr(vec_env, "env") else vec_env
+        self.env, self.task = env, env.task
+        task = self.task
+        self.device = torch.device(task.device)
+        params = cfg_train["params"]
+        c = self.config = params["config"]
+        self.num_actors = task.num_envs
+        self.horizon_length = int(c["horizon_length"])
+        self.batch_size = self.horizon_length * self.num_actors
+        self.minibatch_size = min(int(c["minibatch_size"]), self.batch_size)
+        assert self.batch_size % self.minibatch_size == 0
+        self.mini_epochs_num = int(c["mini_epochs"])
+        self.gamma, self.tau, self.e_clip = c["gamma"], c["tau"], c["e_clip"]
+        self.critic_coef, self.entropy_coef, self.bounds_loss_coef = c["critic_coef"], c["entropy_coef"], c["bounds_loss_coef"]
+        self.clip_value, self.truncate_grads, self.grad_norm = c["clip_value"], c["truncate_grads"], c["grad_norm"]
+        self.normalize_input, self.normalize_value = c["normalize_input"], c["normalize_value"]
+        self.normalize_advantage = c["normalize_advantage"]
+        self.last_lr = float(c["learning_rate"])
+        self._task_reward_w, self._disc_reward_w = c["task_reward_w"], c["disc_reward_w"]
+        self._amp_batch_size = int(c["amp_batch_size"])
+        self._amp_minibatch_size = min(int(c["amp_minibatch_size"]), self.minibatch_size)
+        self._disc_coef, self._disc_logit_reg = c["disc_coef"], c["disc_logit_reg"]
+        self._disc_grad_penalty, self._disc_weight_decay = c["disc_grad_penalty"], c["disc_weight_decay"]
+        self._disc_reward_scale = c["disc_reward_scale"]
+        self._normalize_amp_input = c.get("normalize_amp_input", True)
+        self._amp_dropout = c.get("amp_dropout", False)
+        self.motion_sym_loss = bool(getattr(task, "motion_sym_loss", False))
+        self.sym_loss_coef = task.cfg["env"].get("sym_loss_coef", 1) if hasattr(task, "cfg") else 1
+        obs_size, self_size, amp_size = task.get_obs_size(), task.get_self_obs_size(), task.get_num_amp_obs()
+        self.actions_num = task.num_actions
+        self.running_mean_std = RunningMeanStd((obs_size,)).to(self.device)
+        self.value_mean_std = RunningMeanStd((1,)).to(self.device)
+        self._amp_input_mean_std = RunningMeanStd((amp_size,)).to(self.device)
+        torch.manual_seed(seed)
+        b = AMPSeptBuilder()
+        b.load(params["network"])
+        self.a2c_network = b.build("amp", actions_num=self.actions_num, input_shape=(obs_size,), num_seqs=self.num_actors, value_size=1,
+                                   amp_input_shape=(amp_size,), self_obs_size=self_size, task_obs_size=obs_size - self_size,
+                                   task_obs_size_detail=task.get_task_obs_size_detail(), mean_std=self.running_mean_std).to(self.device)
+        self.optimizer = torch.optim.Adam(self.a2c_network.parameters(), float(self.last_lr), eps=1e-08, weight_decay=0.0)
+        self.bucket = FlatGradBucket([p for p in self.a2c_network.parameters() if p.requires_grad])
+        self._amp_obs_demo_buffer = ReplayBuffer(int(c["amp_obs_demo_buffer_size"]), self.device)
+        self._amp_replay_buffer = ReplayBuffer(int(c["amp_replay_buffer_size"]), self.device)
+        self._amp_replay_keep_prob = c["amp_replay_keep_prob"]
+        H, E, f = self.horizon_length, self.num_actors, dict(dtype=torch.float32, device=self.device)
+        self.buf = {"obses": torch.zeros((H, E, obs_size), **f), "next_obses": torch.zeros((H, E, obs_size), **f),
+                    "flip_obs": torch.zeros((H, E, obs_size), **f), "rewards": torch.zeros((H, E, 1), **f),
+                    "values": torch.zeros((H, E, 1), **f), "next_values": torch.zeros((H, E, 1), **f),
+                    "neglogpacs": torch.zeros((H, E), **f), "dones": torch.zeros((H, E), dtype=torch.uint8, device=self.device),
+                    "actions": torch.zeros((H, E, self.actions_num), **f), "mus": torch.zeros((H, E, self.actions_num), **f),
+                    "sigmas": torch.zeros((H, E, self.actions_num), **f), "amp_obs": torch.zeros((H, E, amp_size), **f)}
+        self.current_rewards = torch.zeros((E, 1), **f)
+        self.current_lengths = torch.zeros(E, **f)
+        self.done_indices = torch.arange(E, device=self.device)
+        self._idx_buf = torch.randperm(self.batch_size)
+        self.epoch_num, self.frame = 0, 0
+        self.train_result = {}
+        self._init_amp_demo_buf()
+
+    # ------------------------------------------------------------------ helpers
+    def set_eval(self):
+        self.a2c_network.eval(); self.running_mean_std.eval(); self.value_mean_std.eval(); self._amp_input_mean_std.eval()
+
+    def set_train(self):
+        self.a2c_network.train(); self.running_mean_std.train(); self.value_mean_std.train(); self._amp_input_mean_std.train()
+
+    def _preproc_obs(self, obs):
+        return self.running_mean_std(obs) if self.normalize_input else obs
+
+    def _preproc_amp_obs(self, amp_obs):
+        return self._amp_input_mean_std(amp_obs) if self._normalize_amp_input else amp_obs
+
+    def _fetch_amp_obs_demo(self, n):
+        return self.env.fetch_amp_obs_demo(n)
+
+    def _init_amp_demo_buf(self):
+        for _ in range(int(np.ceil(self._amp_obs_demo_buffer.get_buffer_size() / self._amp_batch_size))):
+            self._amp_obs_demo_buffer.store({"amp_obs": self._fetch_amp_obs_demo(self._amp_batch_size)})
+
+    def get_action_values(self, obs):
+        """A2CBase.get_action_values + ModelA2CContinuousLogStd.forward(is_train=False)."""
+        net = self.a2c_network
+        with torch.no_grad():
+            x = self._preproc_obs(obs)
+            mu, logstd = net.eval_actor(x)
+            value = net.eval_critic(x)
+            sigma = torch.exp(logstd)
+            action = mu + sigma * torch.randn_like(mu)
+            res = {"neglogpacs": neglogp(action, mu, sigma, logstd), "values": value, "actions": action, "mus": mu, "sigmas": sigma}
+            if self.normalize_value:
+                res["values"] = self.value_mean_std(res["values"], True)
+        return res
+
+    def _eval_critic(self, obs):
+        with torch.no_grad():
+            value = self.a2c_network.eval_critic(self._preproc_obs(obs))
+            return self.value_mean_std(value, True) if self.normalize_value else value
+
+    def _calc_disc_rewards(self, amp_obs):
+        with torch.no_grad():
+            shp = amp_obs.shape
+            logits = self.a2c_network.eval_disc(self._preproc_amp_obs(amp_obs.reshape(-1, shp[-1]))).reshape(*shp[:-1], 1)
+            prob = 1 / (1 + torch.exp(-logits))
+            return -torch.log(torch.maximum(1 - prob, torch.tensor(0.0001, device=self.device))) * self._disc_reward_scale
+
+    def discount_values(self, mb_fdones, mb_values, mb_rewards, mb_next_values):
+        lastgaelam = 0
+        mb_advs = torch.zeros_like(mb_rewards)
+        for t in reversed(range(self.horizon_length)):
+            not_done = (1.0 - mb_fdones[t]).unsqueeze(1)
+            delta = mb_rewards[t] + self.gamma * mb_next_values[t] - mb_values[t]
+            lastgaelam = delta + self.gamma * self.tau * not_done * lastgaelam
+            mb_advs[t] = lastgaelam
+        return mb_advs
+
+    # ------------------------------------------------------------------ rollout
+    def play_steps(self):
+        self.set_eval()
+        env, task, buf = self.env, self.task, self.buf
+        terminated_flags = torch.zeros(self.num_actors, device=self.device)
+        reward_raw = None
+        with torch.no_grad():
+            for n in range(self.horizon_length):
+                if self.done_indices.numel():
+                    env.reset(self.done_indices)
+                obs = task.obs_buf
+                buf["obses"][n] = obs
+                res = self.get_action_values(obs)
+                for k in ("neglogpacs", "values", "actions", "mus", "sigmas"):
+                    buf[k][n] = res[k]
+                obs, rewards, dones, infos = self.vec_env.step(torch.clamp(res["actions"], -1.0, 1.0))
+                buf["rewards"][n] = rewards.unsqueeze(-1) if rewards.dim() == 1 else rewards
+                buf["next_obses"][n] = obs
+                buf["dones"][n] = dones.to(torch.uint8)
+                buf["amp_obs"][n] = infos["amp_obs"]
+                if self.motion_sym_loss:
+                    buf["flip_obs"][n] = infos["flip_obs"]
+                terminated = infos["terminate"].float()
+                terminated_flags += terminated
+                rr = infos["reward_raw"].mean(dim=0)
+                reward_raw = rr if reward_raw is None else reward_raw + rr
+                next_vals = self._eval_critic(obs) * (1.0 - terminated.unsqueeze(-1))
+                buf["next_values"][n] = next_vals
+                self.current_rewards += buf["rewards"][n]
+                self.current_lengths += 1
+                self.done_indices = dones.nonzero(as_tuple=False).flatten()
+                not_dones = 1.0 - dones.float()
+                self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
+                self.current_lengths = self.current_lengths * not_dones
+            mb_fdones = buf["dones"].float()
+            amp_rewards = self._calc_disc_rewards(buf["amp_obs"])
+            mb_rewards = self._task_reward_w * buf["rewards"] + self._disc_reward_w * amp_rewards
+            mb_advs = self.discount_values(mb_fdones, buf["values"], mb_rewards, buf["next_values"])
+            mb_returns = mb_advs + buf["values"]
+            flat = lambda t: t.transpose(0, 1).reshape(t.shape[0] * t.shape[1], *t.shape[2:])      # swap_and_flatten01
+            batch = {k: flat(v) for k, v in buf.items()}
+            batch["returns"] = flat(mb_returns)
+            batch["disc_rewards"] = flat(amp_rewards)
+            batch["played_frames"] = self.batch_size
+            batch["terminated_flags"] = terminated_flags
+            batch["reward_raw"] = reward_raw / self.horizon_length
+        return batch
+
+    # ------------------------------------------------------------------ losses
+    def _actor_loss(self, old_logp, logp, advantage, e_clip):
+        ratio = torch.exp(old_logp - logp)
+        a_loss = torch.max(-advantage * ratio, -advantage * torch.clamp(ratio, 1.0 - e_clip, 1.0 + e_clip))
+        return {"actor_loss": a_loss, "actor_clipped": (torch.abs(ratio - 1.0) > e_clip).detach()}
+
+    def _critic_loss(self, value_preds, values, e_clip, returns, clip_value):
+        if clip_value:
+            clipped = value_preds + (values - value_preds).clamp(-e_clip, e_clip)
+            return {"critic_loss": torch.max((values - returns) ** 2, (clipped - returns) ** 2)}
+        return {"critic_loss": (returns - values) ** 2}
+
+    def bound_loss(self, mu):
+        if self.bounds_loss_coef is None:
+            return torch.zeros(mu.shape[0], device=mu.device)
+        return (torch.clamp_max(mu + 1.0, 0.0) ** 2 + torch.clamp_min(mu - 1.0, 0.0) ** 2).sum(dim=-1)
+
+    def _sym_loss(self, flip_obs, orig_obs):
+        B = flip_obs.shape[0]
+        idx = self.task.left_to_right_index_action
+        flip_a, _ = self.a2c_network.eval_actor(flip_obs)
+        orig_a, _ = self.a2c_network.eval_actor(orig_obs)
+        orig_a = orig_a.view(B, -1, 3) * torch.tensor([-1.0, 1.0, -1.0], device=orig_a.device)
+        orig_a = orig_a[..., idx, :]
+        return {"sym_loss": (orig_a.reshape(B, -1) - flip_a).pow(2).mean(dim=-1) * 50}
+
+    def _disc_loss(self, disc_agent_logit, disc_demo_logit, grad_penalty):
+        bce = torch.nn.BCEWithLogitsLoss()
+        disc_loss = 0.5 * (bce(disc_agent_logit, torch.zeros_like(disc_agent_logit)) + bce(disc_demo_logit, torch.ones_like(disc_demo_logit)))
+        logit_loss = torch.sum(torch.square(self.a2c_network.get_disc_logit_weights()))
+        disc_loss = disc_loss + self._disc_logit_reg * logit_loss + self._disc_grad_penalty * grad_penalty
+        if self._disc_weight_decay != 0:
+            disc_loss = disc_loss + self._disc_weight_decay * torch.sum(torch.square(torch.cat(self.a2c_network.get_disc_weights(), dim=-1)))
+        return {"disc_loss": disc_loss, "disc_grad_penalty": grad_penalty.detach(), "disc_logit_loss": logit_loss.detach(),
+                "disc_agent_acc": (disc_agent_logit < 0).float().mean().detach(), "disc_demo_acc": (disc_demo_logit > 0).float().mean().detach()}
+
+    def compute_loss(self, d, dropout_masks=None):
+        """The scalar of calc_gradients (amp_continuous.py:335-425) for one minibatch dict `d`."""
+        net = self.a2c_network
+        obs = self._preproc_obs(d["obs"])
+        n_amp = self._amp_minibatch_size
+        amp_obs = self._preproc_amp_obs(d["amp_obs"][0:n_amp])
+        amp_replay = self._preproc_amp_obs(d["amp_obs_replay"][0:n_amp])
+        amp_demo = self._preproc_amp_obs(d["amp_obs_demo"][0:n_amp])
+        mu, logstd = net.eval_actor(obs)
+        values = net.eval_critic(obs)
+        sigma = torch.exp(logstd)
+        action_log_probs = neglogp(d["actions"], mu, sigma, logstd)
+        entropy = (0.5 + 0.5 * math.log(2 * math.pi) + logstd).sum(dim=-1)
+        if self._amp_dropout and dropout_masks is None:
+            steps = self.task._num_amp_obs_steps
+            dropout_masks = amp_dropout_mask(amp_obs.shape[0], steps, amp_obs.shape[1] // steps, device=amp_obs.device)
+        m = (lambda i: dropout_masks[..., i]) if dropout_masks is not None else (lambda i: None)
+        mul = lambda x, k: x if k is None else x * k
+        disc_agent_logit = net.eval_disc(mul(amp_obs, m(0)))
+        disc_replay_logit = net.eval_disc(mul(amp_replay, m(1)))
+        disc_demo_logit, grad_pen = disc_forward_with_grad_penalty(net, amp_demo, m(2))
+        a_info = self._actor_loss(d["old_logp_actions"], action_log_probs, d["advantages"], self.e_clip)
+        c_info = self._critic_loss(d["old_values"], values, self.e_clip, d["returns"], self.clip_value)
+        a_loss, c_loss = torch.mean(a_info["actor_loss"]), torch.mean(c_info["critic_loss"])
+        b_loss, entropy = torch.mean(self.bound_loss(mu)), torch.mean(entropy)
+        disc_info = self._disc_loss(torch.cat([disc_agent_logit, disc_replay_logit], dim=0), disc_demo_logit, grad_pen)
+        loss = a_loss + self.critic_coef * c_loss - self.entropy_coef * entropy + self.bounds_loss_coef * b_loss \
+            + self._disc_coef * disc_info["disc_loss"]
+        info = {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "entropy": entropy.detach(),
+                "actor_clip_frac": a_info["actor_clipped"].float().mean(), **{k: v.detach() for k, v in disc_info.items()}}
+        if self.motion_sym_loss:
+            s_loss = torch.mean(self._sym_loss(self._preproc_obs(d["flip_obs"]), self._preproc_obs(d["next_obses"]))["sym_loss"])
+            loss = loss + s_loss * self.sym_loss_coef
+            info["sym_loss"] = s_loss.detach()
+        return loss, info, mu.detach(), sigma.detach()
+
+    def calc_gradients(self, d):
+        self.set_train()
+        loss, info, mu, sigma = self.compute_loss(d)
+        self.bucket.zero()                                         # the .grad of every parameter aliases the flat bucket
+        loss.backward()
+        self.bucket.all_reduce(average=True)                       # no-op on one rank
+        if self.truncate_grads:
+            nn.utils.clip_grad_norm_(self.a2c_network.parameters(), self.grad_norm)
+        self.optimizer.step()
+        with torch.no_grad():
+            info["kl"] = policy_kl(mu, sigma, d["mu"], d["sigma"])
+        info["loss"] = loss.detach()
+        self.train_result = info
+        return info
+
+    # ------------------------------------------------------------------ epoch
+    def prepare_dataset(self, batch):
+        advantages = torch.sum(batch["returns"] - batch["values"], axis=1)
+        if self.normalize_advantage:
+            advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+        values, returns = batch["values"], batch["returns"]
+        if self.normalize_value:
+            values = self.value_mean_std(values)
+            returns = self.value_mean_std(returns)
+        self.dataset = {"old_values": values, "old_logp_actions": batch["neglogpacs"], "advantages": advantages, "returns": returns,
+                        "actions": batch["actions"], "obs": batch["obses"], "mu": batch["mus"], "sigma": batch["sigmas"],
+                        "amp_obs": batch["amp_obs"], "amp_obs_demo": batch["amp_obs_demo"], "amp_obs_replay": batch["amp_obs_replay"]}
+        if self.motion_sym_loss:
+            self.dataset["flip_obs"], self.dataset["next_obses"] = batch["flip_obs"], batch["next_obses"]
+
+    def _minibatch(self, i):
+        """AMPDataset._get_item (amp_datasets.py:16-33): shuffled index buffer, reshuffled after the last minibatch."""
+        start, end = i * self.minibatch_size, (i + 1) * self.minibatch_size
+        idx = self._idx_buf[start:end].to(self.device)
+        d = {k: v[idx] for k, v in self.dataset.items() if v is not None}
+        if end >= self.batch_size:
+            self._idx_buf[:] = torch.randperm(self.batch_size)
+        return d
+
+    def _store_replay_amp_obs(self, amp_obs):
+        if self._amp_replay_buffer.get_total_count() > self._amp_replay_buffer.get_buffer_size():
+            keep = torch.bernoulli(torch.full((amp_obs.shape[0],), self._amp_replay_keep_prob, device=self.device)) == 1.0
+            amp_obs = amp_obs[keep]
+        if amp_obs.shape[0] > 0:
+            self._amp_replay_buffer.store({"amp_obs": amp_obs[:self._amp_replay_buffer.get_buffer_size()]})
+
+    def train_epoch(self):
+        t0 = time.time()
+        batch = self.play_steps()
+        torch.cuda.synchronize(self.device)
+        t1 = time.time()
+        self._amp_obs_demo_buffer.store({"amp_obs": self._fetch_amp_obs_demo(self._amp_batch_size)})
+        n = batch["amp_obs"].shape[0]
+        batch["amp_obs_demo"] = self._amp_obs_demo_buffer.sample(n)["amp_obs"]
+        batch["amp_obs_replay"] = batch["amp_obs"] if self._amp_replay_buffer.get_total_count() == 0 \
+            else self._amp_replay_buffer.sample(n)["amp_obs"]
+        self.set_train()
+        self.prepare_dataset(batch)
+        infos = []
+        for _ in range(self.mini_epochs_num):
+            for i in range(self.batch_size // self.minibatch_size):
+                infos.append(self.calc_gradients(self._minibatch(i)))
+        self._store_replay_amp_obs(batch["amp_obs"])
+        torch.cuda.synchronize(self.device)
+        t2 = time.time()
+        self.epoch_num += 1
+        self.frame += self.batch_size
+        out = {k: torch.stack([i[k].float() for i in infos]).mean().item() for k in infos[0]}
+        out.update(play_time=t1 - t0, update_time=t2 - t1, total_time=t2 - t0, fps_step=self.batch_size / (t1 - t0),
+                   fps_total=self.batch_size / (t2 - t0), reward_raw=batch["reward_raw"].tolist())
+        return out
+
+    # ------------------------------------------------------------------ checkpoints (common_agent.py:252-264 layout)
+    def get_full_state_weights(self):
+        return {"model": {"a2c_network." + k: v for k, v in self.a2c_network.state_dict().items()},
+                "running_mean_std": self.running_mean_std.state_dict(), "reward_mean_std": self.value_mean_std.state_dict(),
+                "amp_input_mean_std": self._amp_input_mean_std.state_dict(), "optimizer": self.optimizer.state_dict(),
+                "epoch": self.epoch_num, "frame": self.frame}
+
+    def save(self, fn):
+        torch.save(self.get_full_state_weights(), fn if fn.endswith(".pth") else fn + ".pth")
+
+    def restore(self, fn):
+        ck = torch.load(fn, map_location=self.device)
+        self.a2c_network.load_state_dict({k[len("a2c_network."):]: v for k, v in ck["model"].items()})
+        self.running_mean_std.load_state_dict(ck["running_mean_std"])
+        if "reward_mean_std" in ck:
+            self.value_mean_std.load_state_dict(ck["reward_mean_std"])
+        if "amp_input_mean_std" in ck:
+            self._amp_input_mean_std.load_state_dict(ck["amp_input_mean_std"])
+        if "optimizer" in ck:
+            self.optimizer.load_state_dict(ck["optimizer"])
+        self.epoch_num, self.frame = ck.get("epoch", 0), ck.get("frame", 0)

@@ -87,10 +87,27 @@ def main(argv=None):
     if "--policy_random_init" in argv:           # same architecture, random weights (no checkpoint ships)
         use_policy = True
         argv.remove("--policy_random_init")
+    train_policy = "--train_policy" in argv        # configs[1]: PPO + AMP pretraining of the policy (pacer/run.py without --test)
+    if train_policy:
+        argv.remove("--train_policy")
     args = get_args(argv)
     cfg, cfg_train, _ = load_cfg(args)
     fill_flags(args)
     env = RLGPUEnv(create_rlgpu_env(args, cfg, cfg_train))
+    if train_policy:
+        import yaml
+        from .learning.amp_agent import AMPAgent
+        from .learning.amp_policy import DEFAULT_CFG
+        agent = AMPAgent(env, yaml.safe_load(open(DEFAULT_CFG)))
+        if policy_ckpt:
+            agent.restore(policy_ckpt)
+        n = 0
+        while n < steps:
+            info = agent.train_epoch()
+            n += agent.horizon_length
+            print(f"epoch {agent.epoch_num}: fps_step {info['fps_step']:,.0f} fps_total {info['fps_total']:,.0f} "
+                  f"a_loss {info['actor_loss']:.4f} c_loss {info['critic_loss']:.4f} disc_loss {info['disc_loss']:.4f} kl {info['kl']:.5f}")
+        return
     from .learning.locoval_rollout import LocoValRollout
     kw = {}
     if use_policy:

@@ -221,3 +221,27 @@ def test_fused_reset_matches_host_mirror():
     rows = task._amp_rows_from_motion(mids, mts, task.humanoid_betas.unsqueeze(1).expand(-1, n, -1).reshape(-1, 17)).view(E, n, 206)
     np.testing.assert_allclose(task._amp_obs_buf[:, 1:].cpu().numpy(), rows.cpu().numpy(), rtol=1e-4, atol=2e-5)
     assert torch.isfinite(task.obs_buf).all()
+
+
+def test_amp_agent_train_epoch_on_the_rollout():
+    """configs[1] end to end at toy size: PPO + AMP training epoch (rollout with the policy in the loop, GAE, disc reward,
+    minibatch updates on the MFMA GEMMs) runs, changes the policy and keeps everything finite; checkpoint round trip."""
+    import yaml
+    from emloco_amd.learning.amp_agent import AMPAgent
+    from emloco_amd.learning.amp_policy import DEFAULT_CFG
+    from emloco_amd.run import RLGPUEnv
+    env = RLGPUEnv(_make_env(64, ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel"]))
+    cfg = yaml.safe_load(open(DEFAULT_CFG))
+    cfg["params"]["network"]["mlp"]["units"] = [256, 128]
+    cfg["params"]["network"]["disc"]["units"] = [128, 64]
+    cfg["params"]["config"].update(horizon_length=8, minibatch_size=128, amp_minibatch_size=128, amp_batch_size=64,
+                                   amp_obs_demo_buffer_size=512, amp_replay_buffer_size=512, mini_epochs=2)
+    agent = AMPAgent(env, cfg)
+    w0 = agent.a2c_network.mu.weight.detach().clone()
+    d0 = agent.a2c_network._disc_logits.weight.detach().clone()
+    for _ in range(2):
+        info = agent.train_epoch()
+    assert all(np.isfinite(v) for k, v in info.items() if isinstance(v, float)), info
+    assert not torch.equal(w0, agent.a2c_network.mu.weight) and not torch.equal(d0, agent.a2c_network._disc_logits.weight)
+    assert agent.frame == 2 * 8 * 64 and info["fps_step"] > 0
+    assert float(agent.running_mean_std.count) > 1.0            # the observation statistics were updated in train mode
