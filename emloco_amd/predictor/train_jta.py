@@ -129,3 +129,66 @@ class EmLocoTrainer:
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg["TRAIN"]["max_grad_norm"])
         self.optimizer.step()
         return loss.detach(), mse.detach()
+
+
+# ---------------------------------------------------------------------------------------------- training loop pieces
+def adjust_learning_rate(optimizer, epoch, config):
+    """train_jta.py:129-141: lr * decay^epoch, times 0.1 after 80 % of the epochs when TRAIN.lr_drop (applied only then,
+    as in the reference)."""
+    lr = config['TRAIN']['lr'] * (config['TRAIN'].get('lr_decay', 1) ** epoch)
+    if config['TRAIN'].get('lr_drop'):
+        lr = lr * (0.1 ** (epoch // (config['TRAIN']['epochs'] * 4. / 5.)))
+        for param_group in optimizer.param_groups:
+            param_group['lr'] = lr
+    return lr
+
+
+def save_checkpoint(model, optimizer, epoch, config, filename, logger=None):
+    """train_jta.py:166-175 layout: {'model', 'optimizer', 'epoch', 'config'}; keys carry the DataParallel 'module.' prefix
+    the reference's checkpoints have, so either side loads the other's files."""
+    import os
+    sd = model.state_dict()
+    if not any(k.startswith("module.") for k in sd):
+        sd = {"module." + k: v for k, v in sd.items()}
+    path = os.path.join(config['OUTPUT']['ckpt_dir'], filename)
+    if logger is not None:
+        logger.info(f'Saving checkpoint to {path}.')
+    torch.save({'model': sd, 'optimizer': optimizer.state_dict(), 'epoch': epoch, 'config': config}, path)
+    return path
+
+
+def load_checkpoint(model, path, optimizer=None, strict=False):
+    ck = torch.load(path, map_location="cpu")
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ck["model"].items()}
+    model.load_state_dict(sd, strict=strict)
+    if optimizer is not None and "optimizer" in ck:
+        optimizer.load_state_dict(ck["optimizer"])
+    return ck.get("epoch", 0)
+
+
+def evaluate_loss(model, dataloader, config, modality_selection='traj+all', limit_obs=False):
+    """train_jta.py:78-96: mean validation loss (x100 ADE) over a loader."""
+    model.eval()
+    tot, n = 0.0, 0
+    in_F = config['TRAIN']['input_track_size']
+    with torch.no_grad():
+        for joints, masks, padding_mask in dataloader:
+            i, im, o, om, pm = batch_process_coords(joints, masks, padding_mask, config, modality_selection)
+            pred = model(torch.nan_to_num(i), pm, False, limit_obs=limit_obs)
+            loss = (MSE_LOSS_MULTI if config.get("MULTI_MODAL") else MSE_LOSS)(pred[:, in_F:], o, om)
+            tot += loss.item() * len(joints)
+            n += len(joints)
+    return tot / max(n, 1)
+
+
+def train_epoch(trainer, dataloader, epoch, modality_selection='traj+all', max_steps=None):
+    """One epoch of train_jta.py:225-352 over a DataLoader with the EmLoco loss (EmLocoTrainer.step per batch)."""
+    adjust_learning_rate(trainer.optimizer, epoch, trainer.config)
+    tot, n = 0.0, 0
+    for step, (joints, masks, padding_mask) in enumerate(dataloader):
+        loss, _mse = trainer.step(joints, masks, padding_mask, modality_selection)
+        tot += float(loss) * len(joints)
+        n += len(joints)
+        if max_steps is not None and step + 1 >= max_steps:
+            break
+    return tot / max(n, 1)

@@ -210,3 +210,33 @@ def test_fused_attention_matches_composed_path_and_torch():
     ref = (torch.softmax(s[live], -1) @ v[live]).transpose(1, 2).reshape(len(live), S, d)
     _close(o_f.detach()[live].cpu(), ref.cpu(), rel=2e-5, abs_=1e-6, what="fused vs float64 attention")
     assert float(o_f[3].detach().abs().max()) == 0.0 and torch.isfinite(g_f).all()
+
+
+def test_train_loop_over_dataset_files_and_checkpoint_round_trip(tmp_path):
+    """data format -> DataLoader -> EmLoco train steps -> reference-layout checkpoint ('module.'-prefixed) -> reload"""
+    from torch.utils.data import DataLoader
+    from emloco_amd.learning.value_pose_net import ValuePoseNet
+    from emloco_amd.predictor.dataset_jta import collate_batch, create_dataset, write_synthetic_split
+    from emloco_amd.predictor.model_jta import TransMotionJTA
+    from emloco_amd.predictor.train_jta import EmLocoTrainer, evaluate_loss, load_checkpoint, save_checkpoint, train_epoch
+    write_synthetic_split(str(tmp_path), "train", 12, max_people=3, seed=2)
+    ds = create_dataset("jta_all_visual_cues", split="train", preprocessed=True, root=str(tmp_path))
+    dl = DataLoader(ds, batch_size=4, collate_fn=collate_batch, shuffle=False)
+    cfg = {"DEVICE": "cuda:0", "MULTI_MODAL": False, "USE_FRAME_MASK": False, "NOISY_TRAJ": 0, "OUTPUT": {"ckpt_dir": str(tmp_path)},
+           "TRAIN": {"input_track_size": 9, "output_track_size": 12, "lr": 1e-3, "lr_decay": 1, "lr_drop": True, "epochs": 10,
+                     "max_grad_norm": 1.0, "valuenet_weight": 1.0}}
+    torch.manual_seed(0)
+    mk = lambda: TransMotionJTA(tok_dim=453, nhid=128, nhead=4, dim_feedfwd=64, nlayers_local=1, nlayers_global=1, nmode=4, output_scale=1,
+                                obs_and_pred=21, num_tokens=49, device="cuda:0").to("cuda:0")      # head dim 32 -> fused attention path
+    model = mk()
+    trainer = EmLocoTrainer(model, ValuePoseNet(True, True).to("cuda:0"), cfg)
+    l0 = evaluate_loss(model, dl, cfg)
+    for epoch in range(3):
+        train_epoch(trainer, dl, epoch)
+    l1 = evaluate_loss(model, dl, cfg)
+    assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0                    # it learns the synthetic walkers a little
+    path = save_checkpoint(model, trainer.optimizer, 3, cfg, "checkpoint.pth.tar")
+    assert all(k.startswith("module.") for k in torch.load(path, map_location="cpu")["model"])
+    m2 = mk()
+    assert load_checkpoint(m2, path, strict=True) == 3
+    assert abs(evaluate_loss(m2, dl, cfg) - l1) <= 1e-5 * max(1.0, l1)

@@ -1,4 +1,6 @@
 """Host-side mirrors of the reference's per-episode logic, pinned against golden vectors (CPU only)."""
+import os
+import pytest
 import numpy as np
 import torch
 
@@ -58,3 +60,25 @@ def test_calc_pos_matches_reference(golden):
     out = tg.calc_pos(torch.arange(16), times)
     np.testing.assert_allclose(out.numpy(), g["tar_pos"], rtol=1e-6, atol=1e-6)
     assert abs(tg.get_traj_duration() - float(g["traj_dur"])) < 1e-12
+
+
+def test_jta_dataset_pickles_and_collate(tmp_path):
+    """On-disk JTA format (dataset_jta.py:97-103): pickled lists of scenes -> people -> (joints (21,49,4), mask (21,49));
+    collate pads scenes to the largest person count and flags padded persons."""
+    import torch
+    from torch.utils.data import DataLoader
+    from emloco_amd.predictor.dataset_jta import collate_batch, create_dataset, get_datasets, write_synthetic_split
+    write_synthetic_split(str(tmp_path), "train", 23, max_people=5, seed=1, part_size=10)
+    ds = create_dataset("jta_all_visual_cues", split="train", track_size=21, track_cutoff=9, preprocessed=True, root=str(tmp_path))
+    assert len(ds) == 23 and len(os.listdir(tmp_path / "jta_all_visual_cues" / "preprocess_smpl" / "train")) == 3
+    j, m = ds[0]
+    assert j.shape[1:] == (21, 49, 4) and m.shape[1:] == (21, 49)
+    joints, masks, pad = next(iter(DataLoader(ds, batch_size=8, collate_fn=collate_batch, shuffle=False)))
+    n_people = [ds[i][0].shape[0] for i in range(8)]
+    assert joints.shape == (8, max(n_people), 21, 49, 4) and pad.dtype == torch.bool
+    for i, n in enumerate(n_people):
+        assert not pad[i, :n].any() and pad[i, n:].all() and (joints[i, n:] == 0).all()
+    cfg = {"TRAIN": {"input_track_size": 9, "output_track_size": 12}, "DATA": {"preprocessed": True}}
+    assert len(get_datasets(["jta_all_visual_cues"], cfg, root=str(tmp_path))[0]) == 23
+    with pytest.raises(ValueError):
+        create_dataset("nope", split="train", preprocessed=True, root=str(tmp_path))
