@@ -74,12 +74,12 @@ def rank_local():
 def cpu_baseline(sample_envs=512, sample_steps=400):
     """The CPU oracle on a bounded sample of the same workload (physics + post-physics maths), one core."""
     import oracle
-    from emloco_amd.model import pack_models
+    from emloco_amd.model import pack_models, pack_self_collision
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import varied_models
     models = varied_models(64, seed=0)
     models = [models[i % 64] for i in range(sample_envs)]
-    s = oracle.Sim(pack_models(models), oracle.default_params(n_sub=4))
+    s = oracle.Sim(pack_models(models), oracle.default_params(n_sub=4), self_collision=pack_self_collision(models))   # as the GPU run
     s.root_state[:, 2] = 0.93
     rng = np.random.default_rng(0)
     betas = rng.normal(size=(sample_envs, 17)).astype(np.float32)
@@ -359,12 +359,12 @@ def main():
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: PACER rollout env.step, 4096 SMPL humanoids per GPU, random_heading, "
-                                   "JTA+JRDB-shaped real_path (synthetic), flat terrain, resets included, policy excluded",
+                                   "JTA+JRDB-shaped real_path (synthetic), flat terrain, self-collision on, resets included, policy excluded",
                        "num_envs_per_gpu": E, "substeps_per_step": 4, "parallelism": f"env-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "sim_step_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l,
-                         "note": "latency/occupancy bound: 8.6 KB of state per env per launch"},
+                         "note": "VALU-issue bound: ~9 KB of state per env per launch, ~40 k dependent fp32 instructions per substep"},
         }
         if world == 1 and not a.no_policy:
             out["policy"] = policy_leg(env, E, dev, a.steps, a.warmup)

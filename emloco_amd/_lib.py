@@ -41,6 +41,13 @@ class ModelDesc(C.Structure):
                 ("armature", C.POINTER(C.c_float)), ("effort", C.POINTER(C.c_float))]
 
 
+class SelfCollisionDesc(C.Structure):
+    """EmlocoSelfCollisionDesc (include/emloco_sim.h)."""
+    _fields_ = [("n_pairs", C.c_int32), ("pairs", C.POINTER(C.c_uint8)), ("cap_a", C.POINTER(C.c_float)),
+                ("cap_b", C.POINTER(C.c_float)), ("cap_r", C.POINTER(C.c_float)), ("k", C.c_float), ("c", C.c_float),
+                ("max_pen", C.c_float)]
+
+
 class TaskBufs(C.Structure):
     """EmlocoTaskBufs (include/emloco_task.h); pointers are raw device addresses."""
     _fields_ = [("n_env", C.c_int32), ("hf_rows", C.c_int32), ("hf_cols", C.c_int32), ("head_body", C.c_int32),
@@ -93,6 +100,7 @@ def default_sim_params(**kw):
 # every symbol the headers declare; checked at load time
 SYMBOLS_SIM = [
     "emloco_last_error", "emloco_device_count", "emloco_sim_create", "emloco_sim_destroy", "emloco_sim_set_models",
+    "emloco_sim_set_self_collision",
     "emloco_sim_prepare", "emloco_sim_get_params", "emloco_sim_set_params", "emloco_sim_tensor",
     "emloco_sim_set_pd_targets", "emloco_sim_step", "emloco_sim_sync", "emloco_sim_set_root_state_indexed",
     "emloco_sim_set_dof_state_indexed", "emloco_sim_refresh_bodies", "emloco_sim_num_candidates",

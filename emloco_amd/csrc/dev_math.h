@@ -11,6 +11,34 @@
 
 namespace emloco {
 
+// Closest points of two segments P0P1, Q0Q1 (clamped parametrisation, Ericson RTCD 5.1.9).  Plain + - * / and compares in
+// a fixed order (the CPU checker restates the same sequence).
+__device__ __forceinline__ float sc_clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+__device__ __forceinline__ void seg_seg_closest(const float *p0, const float *p1, const float *q0, const float *q1, float *c1, float *c2) {
+    const float EPS = 1e-12f;
+    float d1[3], d2[3], r[3];
+    for (int k = 0; k < 3; ++k) { d1[k] = p1[k] - p0[k]; d2[k] = q1[k] - q0[k]; r[k] = p0[k] - q0[k]; }
+    const float a = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2];
+    const float e = d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2];
+    const float f = d2[0] * r[0] + d2[1] * r[1] + d2[2] * r[2];
+    float s = 0.0f, t = 0.0f;
+    if (a <= EPS && e <= EPS) { s = 0.0f; t = 0.0f; }
+    else if (a <= EPS) { s = 0.0f; t = sc_clamp01(f / e); }
+    else {
+        const float c = d1[0] * r[0] + d1[1] * r[1] + d1[2] * r[2];
+        if (e <= EPS) { t = 0.0f; s = sc_clamp01(-c / a); }
+        else {
+            const float b = d1[0] * d2[0] + d1[1] * d2[1] + d1[2] * d2[2];
+            const float den = a * e - b * b;
+            s = den > EPS ? sc_clamp01((b * f - c * e) / den) : 0.0f;
+            t = (b * s + f) / e;
+            if (t < 0.0f) { t = 0.0f; s = sc_clamp01(-c / a); }
+            else if (t > 1.0f) { t = 1.0f; s = sc_clamp01((b - c) / a); }
+        }
+    }
+    for (int k = 0; k < 3; ++k) { c1[k] = p0[k] + d1[k] * s; c2[k] = q0[k] + d2[k] * t; }
+}
+
 __device__ __forceinline__ void cross3(const float *a, const float *b, float *o) {
     float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
     o[0] = x; o[1] = y; o[2] = z;

@@ -16,5 +16,10 @@ struct EmlocoSimDev {
     float *root_state, *dof_state;
     const float *pd_target;
     float *rb_state, *contact_force, *dof_force, *lambda_ws;
+    // limb-limb penalty contacts (sc_n = 0: off)
+    int sc_n, sc_pad_;
+    const unsigned char *sc_pairs;            /* [sc_n][2] */
+    const float *sc_cap_a, *sc_cap_b, *sc_cap_r;   /* per-env collision capsules [E][24][3|3|1] */
+    float sc_k, sc_c, sc_max_pen, sc_pad2_;
     long long *prof;   /* optional (built with -DEMLOCO_SIM_PROFILE): per-phase cycle stamps of env 0, else NULL */
 };

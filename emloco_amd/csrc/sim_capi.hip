@@ -74,6 +74,7 @@ int emloco_sim_destroy(EmlocoSim *s) {
     s->d_off.release(); s->d_mass.release(); s->d_com.release(); s->d_inertia.release();
     s->d_ga.release(); s->d_gb.release(); s->d_gr.release();
     s->d_kp.release(); s->d_kd.release(); s->d_arm.release(); s->d_eff.release();
+    s->d_sc_pairs.release(); s->d_sc_a.release(); s->d_sc_b.release(); s->d_sc_r.release();
     s->d_root.release(); s->d_dof.release(); s->d_tgt.release(); s->d_rb.release();
     s->d_cf.release(); s->d_df.release(); s->d_lws.release();
     for (auto e : s->ev0) (void)hipEventDestroy(e);
@@ -104,6 +105,27 @@ int emloco_sim_set_models(EmlocoSim *s, const EmlocoModelDesc *m) {
     for (size_t i = 0; i < E * NBs; ++i)
         if (!(s->h_mass[i] > 0.0f)) return fail(EMLOCO_E_ARG, "emloco_sim_set_models: body masses must be positive");
     s->have_model = true;
+    return EMLOCO_OK;
+}
+
+int emloco_sim_set_self_collision(EmlocoSim *s, const EmlocoSelfCollisionDesc *c) {
+    if (!s || !c) return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: null argument");
+    if (!s->have_model) return fail(EMLOCO_E_STATE, "emloco_sim_set_self_collision: set the models first");
+    if (s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_set_self_collision: sim already prepared");
+    if (c->n_pairs < 0 || c->n_pairs > EMLOCO_SC_MAXPAIRS) return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: at most 256 pairs");
+    s->h_sc_pairs.clear();
+    if (c->n_pairs == 0) return EMLOCO_OK;
+    if (!c->pairs || !c->cap_a || !c->cap_b || !c->cap_r || !(c->k > 0.0f) || c->c < 0.0f || !(c->max_pen > 0.0f))
+        return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: missing arrays or non-positive stiffness / penetration cap");
+    for (int i = 0; i < c->n_pairs; ++i)
+        if (c->pairs[2 * i] >= c->pairs[2 * i + 1] || c->pairs[2 * i + 1] >= EMLOCO_NB)
+            return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: pairs must be (i < j < 24)");
+    const size_t E = (size_t)s->n_env, NBs = EMLOCO_NB;
+    s->h_sc_pairs.assign(c->pairs, c->pairs + 2 * (size_t)c->n_pairs);
+    s->h_sc_a.assign(c->cap_a, c->cap_a + E * NBs * 3);
+    s->h_sc_b.assign(c->cap_b, c->cap_b + E * NBs * 3);
+    s->h_sc_r.assign(c->cap_r, c->cap_r + E * NBs);
+    s->sc_k = c->k; s->sc_c = c->c; s->sc_max_pen = c->max_pen;
     return EMLOCO_OK;
 }
 
@@ -150,6 +172,16 @@ int emloco_sim_prepare(EmlocoSim *s) {
     d.kp = s->d_kp.p; d.kd = s->d_kd.p; d.armature = s->d_arm.p; d.effort = s->d_eff.p;
     d.root_state = s->d_root.p; d.dof_state = s->d_dof.p; d.pd_target = s->d_tgt.p;
     d.rb_state = s->d_rb.p; d.contact_force = s->d_cf.p; d.dof_force = s->d_df.p; d.lambda_ws = s->d_lws.p;
+    d.sc_n = 0;
+    if (!s->h_sc_pairs.empty()) {
+        HIPCHK(s->d_sc_pairs.upload(s->h_sc_pairs.data(), s->h_sc_pairs.size()));
+        HIPCHK(s->d_sc_a.upload(s->h_sc_a.data(), s->h_sc_a.size()));
+        HIPCHK(s->d_sc_b.upload(s->h_sc_b.data(), s->h_sc_b.size()));
+        HIPCHK(s->d_sc_r.upload(s->h_sc_r.data(), s->h_sc_r.size()));
+        d.sc_n = (int)(s->h_sc_pairs.size() / 2);
+        d.sc_pairs = s->d_sc_pairs.p; d.sc_cap_a = s->d_sc_a.p; d.sc_cap_b = s->d_sc_b.p; d.sc_cap_r = s->d_sc_r.p;
+        d.sc_k = s->sc_k; d.sc_c = s->sc_c; d.sc_max_pen = s->sc_max_pen;
+    }
     HIPCHK(hipDeviceSynchronize());
     s->prepared = true;
     return EMLOCO_OK;

@@ -70,6 +70,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     __shared__ float sh_lws[MAXCAND * 3];
     __shared__ unsigned char sh_lca[NB * NB];
     __shared__ float sh_cf[NB][3];
+    __shared__ float sh_fext[NB][6];         // limb-limb penalty wrench per body (self-collision), about O
     // body inertia / bias force handed from phase 2 to phase 3 through LDS; they alias the contact matrix, which is
     // only live in phases 6b-6c (barriers separate the phases)
     float (*sh_I6)[21] = (float (*)[21])sh_A;
@@ -169,6 +170,79 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         }
         if (final_pass) break;
 
+        // ============================================================ 1b. limb-limb contacts (self-collision, penalty)
+        // lane = body: world collision capsule -> LDS; lane = pair (4 rounds of 64): closest points, spring-damper force;
+        // hits are compacted in pair order (ballot) and every body adds the wrenches that act on it in that order.
+        if (d.sc_n > 0) {
+            float *sh_seg = sh_A;                                  // [NB][8]   (sh_A is free until the contact phase)
+            float *sh_hitw = sh_A + NB * 8;                        // [MAXHITS][6] wrench on body i about O (body j gets the negative)
+            int *sh_hitb = (int *)(sh_A + NB * 8 + EMLOCO_SC_MAXHITS * 6);   // [MAXHITS][2]
+            if (is_body) {
+                float R[9], r[3], ca[3], cb[3], pa[3], pb[3];
+                for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
+                for (int k = 0; k < 3; ++k) { r[k] = sh_r[lane][k]; ca[k] = d.sc_cap_a[mb0 * 3 + k]; cb[k] = d.sc_cap_b[mb0 * 3 + k]; }
+                matvec3(R, ca, pa); matvec3(R, cb, pb);
+                for (int k = 0; k < 3; ++k) { sh_seg[lane * 8 + k] = r[k] + pa[k]; sh_seg[lane * 8 + 3 + k] = r[k] + pb[k]; }
+                sh_seg[lane * 8 + 6] = d.sc_cap_r[mb0];
+            }
+            __syncthreads();
+            int nh = 0;
+            for (int q0 = 0; q0 < d.sc_n; q0 += 64) {
+                const int q = q0 + lane;
+                bool hit = false;
+                float w6[6] = {0, 0, 0, 0, 0, 0};
+                int bi = 0, bj = 0;
+                if (q < d.sc_n) {
+                    bi = d.sc_pairs[2 * q]; bj = d.sc_pairs[2 * q + 1];
+                    float p0[3], p1[3], g0[3], g1[3], c1[3], c2[3];
+                    for (int k = 0; k < 3; ++k) { p0[k] = sh_seg[bi * 8 + k]; p1[k] = sh_seg[bi * 8 + 3 + k]; g0[k] = sh_seg[bj * 8 + k]; g1[k] = sh_seg[bj * 8 + 3 + k]; }
+                    const float rsum = sh_seg[bi * 8 + 6] + sh_seg[bj * 8 + 6];
+                    seg_seg_closest(p0, p1, g0, g1, c1, c2);
+                    const float dv[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
+                    const float dist2 = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+                    if (dist2 < rsum * rsum && dist2 > 1e-12f) {
+                        const float dist = sqrtf(dist2);
+                        float pen = rsum - dist;
+                        const float n[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist};
+                        const float off = sh_seg[bj * 8 + 6] - 0.5f * pen;     // contact point: middle of the overlap
+                        const float pt[3] = {c2[0] + n[0] * off, c2[1] + n[1] * off, c2[2] + n[2] * off};
+                        float Vi[6], Vj[6], wi[3], wjx[3];
+                        for (int k = 0; k < 6; ++k) { Vi[k] = sh_V[bi][k]; Vj[k] = sh_V[bj][k]; }
+                        cross3(Vi, pt, wi); cross3(Vj, pt, wjx);
+                        const float vn = ((Vi[3] + wi[0]) - (Vj[3] + wjx[0])) * n[0] + ((Vi[4] + wi[1]) - (Vj[4] + wjx[1])) * n[1]
+                                       + ((Vi[5] + wi[2]) - (Vj[5] + wjx[2])) * n[2];
+                        if (pen > d.sc_max_pen) pen = d.sc_max_pen;
+                        float F = d.sc_k * pen - d.sc_c * vn;
+                        if (F > 0.0f) {
+                            const float Fv[3] = {n[0] * F, n[1] * F, n[2] * F};
+                            cross3(pt, Fv, w6);
+                            w6[3] = Fv[0]; w6[4] = Fv[1]; w6[5] = Fv[2];
+                            hit = true;
+                        }
+                    }
+                }
+                const unsigned long long bal = __ballot(hit);
+                const int slot = nh + __popcll(bal & ((1ull << lane) - 1ull));
+                if (hit && slot < EMLOCO_SC_MAXHITS) {
+                    for (int k = 0; k < 6; ++k) sh_hitw[slot * 6 + k] = w6[k];
+                    sh_hitb[slot * 2] = bi; sh_hitb[slot * 2 + 1] = bj;
+                }
+                nh += __popcll(bal);
+            }
+            if (nh > EMLOCO_SC_MAXHITS) nh = EMLOCO_SC_MAXHITS;
+            __syncthreads();
+            if (is_body) {
+                float fe[6] = {0, 0, 0, 0, 0, 0};
+                for (int hh = 0; hh < nh; ++hh) {
+                    const int bi = sh_hitb[hh * 2], bj = sh_hitb[hh * 2 + 1];
+                    if (bi == lane) for (int k = 0; k < 6; ++k) fe[k] += sh_hitw[hh * 6 + k];
+                    else if (bj == lane) for (int k = 0; k < 6; ++k) fe[k] -= sh_hitw[hh * 6 + k];
+                }
+                for (int k = 0; k < 6; ++k) sh_fext[lane][k] = fe[k];
+            }
+            __syncthreads();                                       // the scratch in sh_A is overwritten by phase 2
+        }
+
         PSTAMP(1);
         // ============================================================ 2. inertia about O, bias force, drive
         if (is_body) {
@@ -211,6 +285,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             float fg[3] = {0.0f, 0.0f, ms * prm.gravity_z}, ng[3];
             cross3(c, fg, ng);
             for (int k = 0; k < 3; ++k) { f[k] -= ng[k]; f[3 + k] -= fg[k]; }
+            if (d.sc_n > 0) for (int k = 0; k < 6; ++k) f[k] -= sh_fext[lane][k];     // external wrench: f -= [p x F ; F]
             for (int k = 0; k < 21; ++k) sh_I6[lane][k] = I6[k];
             for (int k = 0; k < 6; ++k) sh_f[lane][k] = f[k];
             // implicit PD drive (saturated drives act as a constant torque)

@@ -25,6 +25,12 @@ struct EmlocoSim {
     emloco::Topology topo;
     // host copies of the model until prepare()
     std::vector<float> h_off, h_mass, h_com, h_inertia, h_ga, h_gb, h_gr, h_kp, h_kd, h_arm, h_eff;
+    // optional self-collision description (host copies until prepare())
+    std::vector<unsigned char> h_sc_pairs;
+    std::vector<float> h_sc_a, h_sc_b, h_sc_r;
+    float sc_k = 0.0f, sc_c = 0.0f, sc_max_pen = 0.0f;
+    DevBuf<unsigned char> d_sc_pairs;
+    DevBuf<float> d_sc_a, d_sc_b, d_sc_r;
     // device
     DevBuf<int> d_parent, d_depth, d_children, d_gtype, d_cand_body, d_cand_k;
     DevBuf<unsigned char> d_lca;

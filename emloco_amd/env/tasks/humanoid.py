@@ -213,6 +213,13 @@ class Humanoid(BaseTask):
         else:
             dof_prop["driveMode"] = gymapi.DOF_MODE_EFFORT
         self.gym.set_actor_dof_properties(env_ptr, humanoid_handle, dof_prop)
+        if self._has_self_collision:                               # humanoid.py:917-944: per-shape collision filter bitmasks
+            from ...model import SMPL_SHAPE_FILTERS
+            props = self.gym.get_actor_rigid_shape_properties(env_ptr, humanoid_handle)
+            assert len(SMPL_SHAPE_FILTERS) == len(props)
+            for p_idx in range(len(props)):
+                props[p_idx].filter = SMPL_SHAPE_FILTERS[p_idx]
+            self.gym.set_actor_rigid_shape_properties(env_ptr, humanoid_handle, props)
         self.humanoid_handles.append(humanoid_handle)
         return
 

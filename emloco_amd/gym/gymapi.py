@@ -307,8 +307,17 @@ class Gym:
                 m.kd = a.dof_props["damping"].astype(np.float64)
             m.effort = a.dof_props["effort"].astype(np.float64)
             models.append(m)
+        # self-collision: create_actor(..., filter=0) enables it (humanoid.py:838-841,864), the per-shape bitmasks written by
+        # set_actor_rigid_shape_properties select the pairs (humanoid.py:917-944)
+        self_collision = None
+        if all(e.actors[0].filter == 0 for e in sim.envs):
+            from ..model import pack_self_collision
+            filters = [int(getattr(sp, "filter", 0)) for sp in sim.envs[0].actors[0].shape_props]
+            self_collision = pack_self_collision(models, filters=filters)
+            if self_collision["pairs"].shape[0] == 0:
+                self_collision = None
         try:
-            sim.native = NativeSim(models, _native_params(sim), sim.device_index)
+            sim.native = NativeSim(models, _native_params(sim), sim.device_index, self_collision=self_collision)
         except L.EmlocoError as e:
             print("***", e)
             return False

@@ -235,6 +235,82 @@ def write_mjcf(model: HumanoidModel, path):
         fh.write("\n".join(out) + "\n")
 
 
+# per-shape collision filter bitmasks of the SMPL humanoid (pacer/pacer/env/tasks/humanoid.py:926, no mesh, no master
+# foot): two shapes collide only if (filter_a & filter_b) == 0
+SMPL_SHAPE_FILTERS = [0, 0, 7, 16, 12, 0, 56, 2, 33, 128, 0, 192, 0, 64, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+
+
+def collision_capsules(model: HumanoidModel):
+    """Sphere-swept segment of every body for limb-limb contact: spheres and capsules as they are, boxes (feet) as the
+    capsule along their longest axis with the smallest half extent as radius.  Returns (a, b, r) in the body frame."""
+    a, b, r = model.geom_a.copy(), model.geom_a.copy(), model.geom_r.copy()
+    for i in range(model.num_bodies):
+        if model.geom_type[i] == GEOM_CAPSULE:
+            b[i] = model.geom_b[i]
+        elif model.geom_type[i] == GEOM_BOX:
+            h = np.abs(model.geom_b[i])
+            ax = int(np.argmax(h))
+            rad = float(np.min(h))
+            half = np.zeros(3)
+            half[ax] = max(h[ax] - rad, 0.0)
+            a[i], b[i], r[i] = model.geom_a[i] - half, model.geom_a[i] + half, rad
+    return a, b, r
+
+
+def _segment_distance(p0, p1, q0, q1):
+    d1, d2, rr = p1 - p0, q1 - q0, p0 - q0
+    aa, ee, ff = d1 @ d1, d2 @ d2, d2 @ rr
+    if aa <= 1e-12 and ee <= 1e-12:
+        s = t = 0.0
+    elif aa <= 1e-12:
+        s, t = 0.0, np.clip(ff / ee, 0, 1)
+    else:
+        cc = d1 @ rr
+        if ee <= 1e-12:
+            t, s = 0.0, np.clip(-cc / aa, 0, 1)
+        else:
+            bb = d1 @ d2
+            den = aa * ee - bb * bb
+            s = np.clip((bb * ff - cc * ee) / den, 0, 1) if den > 1e-12 else 0.0
+            t = (bb * s + ff) / ee
+            if t < 0:
+                t, s = 0.0, np.clip(-cc / aa, 0, 1)
+            elif t > 1:
+                t, s = 1.0, np.clip((bb - cc) / aa, 0, 1)
+    return float(np.linalg.norm((p0 + d1 * s) - (q0 + d2 * t)))
+
+
+def self_collision_pairs(model: HumanoidModel, filters=None, margin=0.01):
+    """Body pairs tested for self-contact (`has_self_collision`, humanoid.py:917-944): not parent / child (articulation
+    links never collide with their parent), filter bitmasks disjoint, and not already touching in the bind pose (all joint
+    angles zero) -- a penalty contact on a permanent overlap would push the limbs apart for ever, so those pairs are
+    filtered the way asset importers do.  Returns uint8 [n][2] with i < j, ascending."""
+    filters = SMPL_SHAPE_FILTERS if filters is None else filters
+    nb = model.num_bodies
+    pw = np.zeros((nb, 3))
+    for i in range(1, nb):
+        pw[i] = pw[model.parent[i]] + model.joint_off[i]
+    a, b, r = collision_capsules(model)
+    pairs = []
+    for i in range(nb):
+        for j in range(i + 1, nb):
+            if model.parent[j] == i or model.parent[i] == j or (filters[i] & filters[j]) != 0:
+                continue
+            if _segment_distance(pw[i] + a[i], pw[i] + b[i], pw[j] + a[j], pw[j] + b[j]) < r[i] + r[j] + margin:
+                continue
+            pairs.append((i, j))
+    return np.asarray(pairs, dtype=np.uint8).reshape(-1, 2)
+
+
+def pack_self_collision(models, k=1.5e4, c=60.0, max_pen=0.04, filters=None):
+    """Arrays of `EmlocoSelfCollisionDesc` (include/emloco_sim.h): the pair table of the first model (one table per
+    sim: the kernels share it across envs) and per-env collision capsules."""
+    caps = [collision_capsules(m) for m in models]
+    f32 = lambda idx: np.ascontiguousarray(np.stack([cpl[idx] for cpl in caps]).astype(np.float32))
+    return dict(pairs=np.ascontiguousarray(self_collision_pairs(models[0], filters)), cap_a=f32(0), cap_b=f32(1), cap_r=f32(2),
+                k=float(k), c=float(c), max_pen=float(max_pen))
+
+
 def pack_models(models):
     """Stack per-env models into the float32 arrays the C ABI takes (`EmlocoModelDesc`, include/emloco_sim.h)."""
     m0 = models[0]

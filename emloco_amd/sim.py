@@ -44,7 +44,9 @@ def dptr(t):
 
 
 class NativeSim:
-    def __init__(self, models, params=None, device_index=0):
+    def __init__(self, models, params=None, device_index=0, self_collision=None):
+        """`self_collision`: None / False = off; True = limb-limb contacts with the defaults of
+        `model.pack_self_collision`; a dict from `pack_self_collision(models, ...)` to choose the parameters."""
         lib = L.require_device()
         self.lib = lib
         self.device_index = int(device_index)
@@ -67,6 +69,17 @@ class NativeSim:
                            f(p["com"]), f(p["inertia"]), f(p["geom_a"]), f(p["geom_b"]), f(p["geom_r"]),
                            f(p["kp"]), f(p["kd"]), f(p["armature"]), f(p["effort"]))
         L.check(lib.emloco_sim_set_models(self._h, C.byref(desc)), "emloco_sim_set_models")
+        if self_collision:
+            if self_collision is True:
+                if isinstance(models, dict):
+                    raise L.EmlocoError("self_collision=True needs HumanoidModel objects (or pass pack_self_collision(...))")
+                from .model import pack_self_collision
+                self_collision = pack_self_collision(models)
+            sc = self._sc = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in self_collision.items()}
+            scd = L.SelfCollisionDesc(int(sc["pairs"].shape[0]), sc["pairs"].ctypes.data_as(C.POINTER(C.c_uint8)), f(sc["cap_a"]),
+                                      f(sc["cap_b"]), f(sc["cap_r"]), float(sc["k"]), float(sc["c"]), float(sc["max_pen"]))
+            lib.emloco_sim_set_self_collision.argtypes = [C.c_void_p, C.POINTER(L.SelfCollisionDesc)]
+            L.check(lib.emloco_sim_set_self_collision(self._h, C.byref(scd)), "emloco_sim_set_self_collision")
         L.check(lib.emloco_sim_prepare(self._h), "emloco_sim_prepare")
         self.root_state = self._tensor(L.T_ROOT_STATE)
         self.dof_state = self._tensor(L.T_DOF_STATE)

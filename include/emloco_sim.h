@@ -67,6 +67,24 @@ typedef struct {
     const float *kp, *kd, *armature, *effort; /* [n_env][69] (gym.set_actor_dof_properties, humanoid.py:904-914) */
 } EmlocoModelDesc;
 
+/* Limb-limb contact (`has_self_collision: True`, pacer.yaml:17; per-shape filters humanoid.py:917-944).  Penalty
+ * contacts between the bodies' collision capsules, evaluated every substep inside the step kernel: for each listed
+ * pair, closest points of the two sphere-swept segments; on overlap a force k * pen - c * v_n (>= 0, pen capped at
+ * max_pen) along the contact normal acts on both bodies at the contact point (equal and opposite).  Optional: call
+ * between emloco_sim_set_models and emloco_sim_prepare; never calling it (or n_pairs = 0) leaves self-collision off. */
+#define EMLOCO_SC_MAXPAIRS 256
+#define EMLOCO_SC_MAXHITS 32    /* simultaneous limb-limb contacts kept per env and substep (lowest pair indices first) */
+typedef struct {
+    int32_t n_pairs;
+    const uint8_t *pairs;      /* [n_pairs][2] body indices, i < j, shared by all envs */
+    const float *cap_a;        /* [n_env][24][3] capsule end 0, body frame */
+    const float *cap_b;        /* [n_env][24][3] capsule end 1 */
+    const float *cap_r;        /* [n_env][24] radius */
+    float k;                   /* stiffness [N/m] */
+    float c;                   /* normal damping [N s/m] */
+    float max_pen;             /* penetration used for the spring is capped here [m] */
+} EmlocoSelfCollisionDesc;
+
 /* state tensors a caller may alias (gym.acquire_*_tensor, humanoid.py:137-148) */
 enum {
     EMLOCO_T_ROOT_STATE = 0,    /* f32 [n_env][13]      acquire_actor_root_state_tensor */
@@ -90,6 +108,7 @@ int emloco_sim_destroy(EmlocoSim *sim);
 /* gym.load_asset + create_env/create_actor + set_actor_dof_properties for all envs -- humanoid.py:720,809,864,914 */
 int emloco_sim_set_models(EmlocoSim *sim, const EmlocoModelDesc *desc);
 /* gym.prepare_sim -- base_task.py:128: allocates the device state, uploads the models */
+int emloco_sim_set_self_collision(EmlocoSim *sim, const EmlocoSelfCollisionDesc *desc);
 int emloco_sim_prepare(EmlocoSim *sim);
 /* gym.get_sim_params / set_sim_params -- base_task.py:151 */
 int emloco_sim_get_params(EmlocoSim *sim, EmlocoSimParams *out);

@@ -62,20 +62,32 @@ class Model(C.Structure):
                 ("com", C.POINTER(C.c_float)), ("inertia", C.POINTER(C.c_float)),
                 ("geom_a", C.POINTER(C.c_float)), ("geom_b", C.POINTER(C.c_float)),
                 ("geom_r", C.POINTER(C.c_float)), ("kp", C.POINTER(C.c_float)), ("kd", C.POINTER(C.c_float)),
-                ("armature", C.POINTER(C.c_float)), ("effort", C.POINTER(C.c_float))]
+                ("armature", C.POINTER(C.c_float)), ("effort", C.POINTER(C.c_float)),
+                ("sc_n", C.c_int32), ("sc_pairs", C.POINTER(C.c_uint8)), ("sc_cap_a", C.POINTER(C.c_float)),
+                ("sc_cap_b", C.POINTER(C.c_float)), ("sc_cap_r", C.POINTER(C.c_float)), ("sc_k", C.c_float), ("sc_c", C.c_float),
+                ("sc_max_pen", C.c_float)]
 
 
 class Sim:
     """Sequential CPU simulator over the packed model arrays of emloco_amd.model.pack_models()."""
 
-    def __init__(self, packed, params=None):
+    def __init__(self, packed, params=None, self_collision=None):
+        """`self_collision`: dict from emloco_amd.model.pack_self_collision (pairs, cap_a, cap_b, cap_r, k, c, max_pen) or None."""
         self.arr = {k: np.ascontiguousarray(v) for k, v in packed.items()}
+        self.sc = None if not self_collision else {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v)
+                                                   for k, v in self_collision.items()}
         self.E = self.arr["mass"].shape[0]
         self.params = params or default_params()
         a = self.arr
         self.model = Model(_p(a["parent"], C.c_int32), _p(a["geom_type"], C.c_int32), _p(a["joint_off"]),
                            _p(a["mass"]), _p(a["com"]), _p(a["inertia"]), _p(a["geom_a"]), _p(a["geom_b"]),
                            _p(a["geom_r"]), _p(a["kp"]), _p(a["kd"]), _p(a["armature"]), _p(a["effort"]))
+        if self.sc is not None:
+            c = self.sc
+            self.model.sc_n = int(c["pairs"].shape[0])
+            self.model.sc_pairs = _p(c["pairs"], C.c_uint8)
+            self.model.sc_cap_a, self.model.sc_cap_b, self.model.sc_cap_r = _p(c["cap_a"]), _p(c["cap_b"]), _p(c["cap_r"])
+            self.model.sc_k, self.model.sc_c, self.model.sc_max_pen = float(c["k"]), float(c["c"]), float(c["max_pen"])
         E = self.E
         self.root_state = np.zeros((E, 13), np.float32)
         self.root_state[:, 6] = 1.0

@@ -134,6 +134,10 @@ static void quat2rotvec(const float *qin, float *e) {
 typedef struct {
     const int32_t *parent, *gtype;
     const float *off, *mass, *com, *inertia, *ga, *gb, *gr, *kp, *kd, *arm, *eff;
+    int sc_n;
+    const uint8_t *sc_pairs;
+    const float *sc_a, *sc_b, *sc_r;
+    float sc_k, sc_c, sc_max_pen;
 } EnvModel;
 
 static EnvModel env_model(const OrcModel *m, int e) {
@@ -144,6 +148,10 @@ static EnvModel env_model(const OrcModel *m, int e) {
     x.ga = m->geom_a + (long)e * NB * 3; x.gb = m->geom_b + (long)e * NB * 3; x.gr = m->geom_r + (long)e * NB;
     x.kp = m->kp + (long)e * ORC_NDOF; x.kd = m->kd + (long)e * ORC_NDOF;
     x.arm = m->armature + (long)e * ORC_NDOF; x.eff = m->effort + (long)e * ORC_NDOF;
+    x.sc_n = m->sc_n; x.sc_pairs = m->sc_pairs; x.sc_k = m->sc_k; x.sc_c = m->sc_c; x.sc_max_pen = m->sc_max_pen;
+    x.sc_a = m->sc_n > 0 ? m->sc_cap_a + (long)e * NB * 3 : 0;
+    x.sc_b = m->sc_n > 0 ? m->sc_cap_b + (long)e * NB * 3 : 0;
+    x.sc_r = m->sc_n > 0 ? m->sc_cap_r + (long)e * NB : 0;
     return x;
 }
 
@@ -215,6 +223,81 @@ static void mat6vec(const float *M, const float *v, float *o) {
     memcpy(o, t, 24);
 }
 
+/* ---------------------------------------------------------------- 1b. limb-limb penalty contacts (self-collision)
+ * Our own scheme (the reference's engine resolves self-contacts as PhysX constraints; parity unpinned): sphere-swept
+ * segments per body, closest points (Ericson RTCD 5.1.9), force k pen - c v_n >= 0 along the normal at the middle of the
+ * overlap, equal and opposite on the two bodies; the first ORC_SC_MAXHITS hits in pair order are kept.  Same operation
+ * order as emloco_amd/csrc/sim_kernels.hip phase 1b / dev_math.h seg_seg_closest. */
+static float sc_clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+static void seg_seg_closest(const float *p0, const float *p1, const float *q0, const float *q1, float *c1, float *c2) {
+    const float EPS = 1e-12f;
+    float d1[3], d2[3], r[3];
+    for (int k = 0; k < 3; ++k) { d1[k] = p1[k] - p0[k]; d2[k] = q1[k] - q0[k]; r[k] = p0[k] - q0[k]; }
+    const float a = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2];
+    const float e = d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2];
+    const float f = d2[0] * r[0] + d2[1] * r[1] + d2[2] * r[2];
+    float s = 0.0f, t = 0.0f;
+    if (a <= EPS && e <= EPS) { s = 0.0f; t = 0.0f; }
+    else if (a <= EPS) { s = 0.0f; t = sc_clamp01(f / e); }
+    else {
+        const float c = d1[0] * r[0] + d1[1] * r[1] + d1[2] * r[2];
+        if (e <= EPS) { t = 0.0f; s = sc_clamp01(-c / a); }
+        else {
+            const float b = d1[0] * d2[0] + d1[1] * d2[1] + d1[2] * d2[2];
+            const float den = a * e - b * b;
+            s = den > EPS ? sc_clamp01((b * f - c * e) / den) : 0.0f;
+            t = (b * s + f) / e;
+            if (t < 0.0f) { t = 0.0f; s = sc_clamp01(-c / a); }
+            else if (t > 1.0f) { t = 1.0f; s = sc_clamp01((b - c) / a); }
+        }
+    }
+    for (int k = 0; k < 3; ++k) { c1[k] = p0[k] + d1[k] * s; c2[k] = q0[k] + d2[k] * t; }
+}
+
+static void self_contacts(const Env *s, const EnvModel *m, float (*fext)[6]) {
+    float seg[NB][7];
+    memset(fext, 0, sizeof(float) * NB * 6);
+    for (int i = 0; i < NB; ++i) {
+        float pa[3], pb[3];
+        matvec3(s->R[i], m->sc_a + i * 3, pa); matvec3(s->R[i], m->sc_b + i * 3, pb);
+        for (int k = 0; k < 3; ++k) { seg[i][k] = s->r[i][k] + pa[k]; seg[i][3 + k] = s->r[i][k] + pb[k]; }
+        seg[i][6] = m->sc_r[i];
+    }
+    float hitw[ORC_SC_MAXHITS][6];
+    int hitb[ORC_SC_MAXHITS][2], nh = 0;
+    for (int q = 0; q < m->sc_n && nh < ORC_SC_MAXHITS; ++q) {
+        const int bi = m->sc_pairs[2 * q], bj = m->sc_pairs[2 * q + 1];
+        float c1[3], c2[3];
+        const float rsum = seg[bi][6] + seg[bj][6];
+        seg_seg_closest(seg[bi], seg[bi] + 3, seg[bj], seg[bj] + 3, c1, c2);
+        const float dv[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
+        const float dist2 = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+        if (!(dist2 < rsum * rsum && dist2 > 1e-12f)) continue;
+        const float dist = sqrtf(dist2);
+        float pen = rsum - dist;
+        const float n[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist};
+        const float off = seg[bj][6] - 0.5f * pen;
+        const float pt[3] = {c2[0] + n[0] * off, c2[1] + n[1] * off, c2[2] + n[2] * off};
+        float wi[3], wj[3];
+        cross3(s->V[bi], pt, wi); cross3(s->V[bj], pt, wj);
+        const float vn = ((s->V[bi][3] + wi[0]) - (s->V[bj][3] + wj[0])) * n[0] + ((s->V[bi][4] + wi[1]) - (s->V[bj][4] + wj[1])) * n[1]
+                       + ((s->V[bi][5] + wi[2]) - (s->V[bj][5] + wj[2])) * n[2];
+        if (pen > m->sc_max_pen) pen = m->sc_max_pen;
+        const float F = m->sc_k * pen - m->sc_c * vn;
+        if (!(F > 0.0f)) continue;
+        const float Fv[3] = {n[0] * F, n[1] * F, n[2] * F};
+        cross3(pt, Fv, hitw[nh]);
+        hitw[nh][3] = Fv[0]; hitw[nh][4] = Fv[1]; hitw[nh][5] = Fv[2];
+        hitb[nh][0] = bi; hitb[nh][1] = bj;
+        ++nh;
+    }
+    for (int i = 0; i < NB; ++i)
+        for (int h = 0; h < nh; ++h) {
+            if (hitb[h][0] == i) for (int k = 0; k < 6; ++k) fext[i][k] += hitw[h][k];
+            else if (hitb[h][1] == i) for (int k = 0; k < 6; ++k) fext[i][k] -= hitw[h][k];
+        }
+}
+
 /* ---------------------------------------------------------------- 2. bias forces + drive */
 static void bias_and_drive(Env *s, const EnvModel *m, const OrcSimParams *prm, const float *edof,
                            const float *tgt) {
@@ -248,6 +331,12 @@ static void bias_and_drive(Env *s, const EnvModel *m, const OrcSimParams *prm, c
         float fg[3] = {0.0f, 0.0f, m->mass[i] * prm->gravity_z}, ng[3];
         cross3(c, fg, ng);
         for (int k = 0; k < 3; ++k) { s->f[i][k] -= ng[k]; s->f[i][3 + k] -= fg[k]; }
+    }
+    if (m->sc_n > 0) {               /* limb-limb contact wrenches as external forces: f -= [p x F ; F] */
+        float fext[NB][6];
+        self_contacts(s, m, fext);
+        for (int i = 0; i < NB; ++i)
+            for (int k = 0; k < 6; ++k) s->f[i][k] -= fext[i][k];
     }
     /* implicit PD: tau~ = kp (q* - q) - (kd + h kp) qd ; diagonal d = armature + h kd + h^2 kp.
      * A drive whose explicit torque exceeds the effort limit acts as a constant torque instead. */

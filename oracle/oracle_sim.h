@@ -12,6 +12,7 @@
 #define ORC_NB 24
 #define ORC_NJ 23
 #define ORC_NDOF 69
+#define ORC_SC_MAXHITS 32
 #define ORC_MAXCAND 96
 #define ORC_MAXC 20
 
@@ -46,6 +47,11 @@ typedef struct {
     const float *geom_b;       /* [E][24][3] unused        | capsule end 1 | box half extents */
     const float *geom_r;       /* [E][24] radius (0 for boxes) */
     const float *kp, *kd, *armature, *effort; /* [E][69] */
+    /* optional limb-limb penalty contacts (sc_n = 0: off); mirrors EmlocoSelfCollisionDesc */
+    int32_t sc_n;
+    const uint8_t *sc_pairs;   /* [sc_n][2] */
+    const float *sc_cap_a, *sc_cap_b, *sc_cap_r;   /* [E][24][3|3|1] */
+    float sc_k, sc_c, sc_max_pen;
 } OrcModel;
 
 /* one call = n_sub substeps for every env */

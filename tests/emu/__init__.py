@@ -52,9 +52,21 @@ def model_desc(arr):
                      _p(arr["effort"]))
 
 
+class SelfCollisionDesc(C.Structure):
+    _fields_ = [("n_pairs", C.c_int32), ("pairs", C.POINTER(C.c_uint8)), ("cap_a", C.POINTER(C.c_float)),
+                ("cap_b", C.POINTER(C.c_float)), ("cap_r", C.POINTER(C.c_float)), ("k", C.c_float), ("c", C.c_float),
+                ("max_pen", C.c_float)]
+
+
 def sim_step(osim, n_calls=1):
     """Advance an oracle.Sim-shaped state holder with the emulated HIP kernel (same arrays, in place)."""
     desc = model_desc(osim.arr)
+    sc = getattr(osim, "sc", None)
+    scd = None
+    if sc is not None:
+        scd = SelfCollisionDesc(int(sc["pairs"].shape[0]), _p(sc["pairs"], C.c_uint8), _p(sc["cap_a"]), _p(sc["cap_b"]),
+                                _p(sc["cap_r"]), float(sc["k"]), float(sc["c"]), float(sc["max_pen"]))
+    lib().emu_sim_set_self_collision(C.byref(scd) if scd is not None else None)
     rc = lib().emu_sim_step(C.byref(osim.params), C.byref(desc), _p(osim.root_state), _p(osim.dof_state),
                             _p(osim.pd_target), _p(osim.rb_state), _p(osim.contact_force), _p(osim.dof_force),
                             _p(osim.lambda_ws), C.c_int(n_calls))

@@ -4,6 +4,9 @@
 #include "../../emloco_amd/csrc/sim_kernels.hip"
 #include "../../emloco_amd/csrc/topology.h"
 
+static const EmlocoSelfCollisionDesc *g_sc = nullptr;      // set by emu_sim_set_self_collision for the next emu_sim_step calls
+extern "C" void emu_sim_set_self_collision(const EmlocoSelfCollisionDesc *sc) { g_sc = sc; }
+
 extern "C" int emu_sim_step(const EmlocoSimParams *prm, const EmlocoModelDesc *m, float *root_state,
                             float *dof_state, const float *pd_target, float *rb_state, float *contact_force,
                             float *dof_force, float *lambda_ws, int n_calls) {
@@ -19,6 +22,10 @@ extern "C" int emu_sim_step(const EmlocoSimParams *prm, const EmlocoModelDesc *m
     d.kp = m->kp; d.kd = m->kd; d.armature = m->armature; d.effort = m->effort;
     d.root_state = root_state; d.dof_state = dof_state; d.pd_target = pd_target;
     d.rb_state = rb_state; d.contact_force = contact_force; d.dof_force = dof_force; d.lambda_ws = lambda_ws;
+    if (g_sc && g_sc->n_pairs > 0) {
+        d.sc_n = g_sc->n_pairs; d.sc_pairs = g_sc->pairs; d.sc_cap_a = g_sc->cap_a; d.sc_cap_b = g_sc->cap_b; d.sc_cap_r = g_sc->cap_r;
+        d.sc_k = g_sc->k; d.sc_c = g_sc->c; d.sc_max_pen = g_sc->max_pen;
+    }
     EmlocoSimParams p = *prm;
     p.n_sub = prm->n_sub * n_calls;
     emu::launch((unsigned)m->n_env, 64, [&] { emloco::sim_step_kernel(p, d); });

@@ -39,9 +39,12 @@ def scene_state(E, seed=1, height=0.93, perturbed_from=1):
     return root, dof, tgt
 
 
-def oracle_sim(models, root, dof, tgt, **params):
+def oracle_sim(models, root, dof, tgt, self_collision=None, **params):
     import oracle
-    s = oracle.Sim(pack_models(models), oracle.default_params(**params))
+    if self_collision is True:
+        from emloco_amd.model import pack_self_collision
+        self_collision = pack_self_collision(models)
+    s = oracle.Sim(pack_models(models), oracle.default_params(**params), self_collision=self_collision)
     s.root_state[:] = root
     s.dof_state[:] = dof
     s.pd_target[:] = tgt

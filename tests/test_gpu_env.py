@@ -60,7 +60,8 @@ def test_reset_then_step_matches_oracle_recompute():
         m.kp = e.actors[0].dof_props["stiffness"].astype(np.float64)
         m.kd = e.actors[0].dof_props["damping"].astype(np.float64)
         ms.append(m)
-    osim = oracle_sim(ms, root0, dof0, tgt, n_sub=4)
+    assert task.sim.native._sc["pairs"].shape[0] == 245          # has_self_collision: True (pacer.yaml) reached the simulator
+    osim = oracle_sim(ms, root0, dof0, tgt, self_collision=task.sim.native._sc, n_sub=4)
     osim.step(1)
     np.testing.assert_array_equal(task._rigid_body_state.view(E, 24, 13).cpu().numpy(), osim.rb_state)   # bit-exact physics
     assert (task.progress_buf == 1).all()

@@ -117,3 +117,35 @@ def test_4096_envs_stand_and_carry_their_weight():
     fz = sim.contact_force.view(E, 24, 3)[:, :, 2].sum(1)
     assert ((fz - w).abs() / w).max().item() < 0.05
     assert (rb[:, 0, 2] > 0.7).all()   # nobody fell
+
+
+def test_self_collision_step_is_bit_exact_and_changes_the_motion():
+    """has_self_collision: limb-limb penalty contacts (kernel phase 1b) over a full 168-step episode of folding, falling
+    humanoids with weak drives: the HIP step stays on the oracle's bytes, and differs from the run without it."""
+    from emloco_amd import _lib as L
+    from emloco_amd.model import pack_self_collision
+    from emloco_amd.sim import NativeSim
+    from helpers import oracle_sim, scene_state, varied_models
+    E = 8
+    models = varied_models(E, 21)
+    for m in models:
+        m.kp = m.kp * 0.05
+    root, dof, tgt = scene_state(E, 22, perturbed_from=0)
+    dof[:, :, 0] *= 3.0
+    sc = pack_self_collision(models)
+    osim = oracle_sim(models, root, dof, tgt, self_collision=sc, n_sub=4)
+    gsim = NativeSim(models, L.default_sim_params(n_sub=2), self_collision=sc)
+    gref = NativeSim(models, L.default_sim_params(n_sub=2))
+    for g in (gsim, gref):
+        g.root_state.copy_(torch.from_numpy(root))
+        g.dof_state.view(E, 69, 2).copy_(torch.from_numpy(dof))
+        g.pd_target.copy_(torch.from_numpy(tgt))
+    for k in range(168):
+        osim.step(1)
+        gsim.step(2)
+        gref.step(2)
+        if k in (0, 10, 60, 167):
+            _compare(osim, gsim, E, what=f"self-collision step {k}")
+    torch.cuda.synchronize()
+    assert not torch.equal(gsim.dof_state, gref.dof_state)
+    assert torch.isfinite(gsim.rigid_body_state).all()

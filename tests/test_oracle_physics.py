@@ -129,3 +129,58 @@ def test_same_inputs_same_bytes():
         for _ in range(25):
             s_.step()
     assert a.rb_state.tobytes() == b.rb_state.tobytes()
+
+
+def test_self_collision_keeps_limbs_apart():
+    """Limb-limb penalty contacts (has_self_collision): an arm driven into the trunk is held near the surface instead of
+    passing through (with self-collision off the same drive penetrates), and the equal-and-opposite contact wrenches do
+    not push the floating body as a whole."""
+    from emloco_amd.model import collision_capsules, pack_self_collision, self_collision_pairs
+    m = smpl_humanoid()
+    pairs = self_collision_pairs(m)
+    assert len(pairs) == 245 and all(m.parent[j] != i and m.parent[i] != j for i, j in pairs)      # no parent-child pairs
+    assert (11, 13) not in set(map(tuple, pairs.tolist()))                                          # Chest-Head: filter bits 192 & 64
+    names = m.names
+    sh = names.index("L_Shoulder")
+
+    def run(sc):
+        s = oracle.Sim(pack_models([m]), oracle.default_params(gravity_z=0.0), self_collision=pack_self_collision([m]) if sc else None)
+        s.root_state[0, :3] = [0, 0, 3.0]                       # floating, no ground contact, no gravity
+        s.pd_target[0, (sh - 1) * 3 + 0] = -2.5                 # drive the left arm (T-pose) down and into the trunk / hip
+        p0 = None
+        depth = []
+        a, b, r = collision_capsules(m)
+        for k in range(60):
+            s.step()
+            rb = s.rb_state[0]
+            def rot(q):
+                x, y, z, w = q
+                return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                                 [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                                 [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+            vc = np.stack([rb[i, 7:10] + np.cross(rb[i, 10:13], rot(rb[i, 3:7]) @ m.com[i]) for i in range(24)])
+            com_v = (m.mass[:, None] * vc).sum(0) / m.mass.sum()       # true linear momentum / mass
+            # deepest overlap between the left fore-arm / hand chain and the torso chain capsules
+            import itertools
+            worst = 0.0
+            for i, j in itertools.product([names.index(n) for n in ("L_Elbow", "L_Wrist", "L_Hand")],
+                                          [names.index(n) for n in ("Torso", "Spine", "Chest", "Pelvis", "L_Hip", "R_Hip")]):
+                from emloco_amd.model import _segment_distance
+                def world(bi, pt):
+                    q = rb[bi, 3:7]
+                    x, y, z, w = q
+                    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+                    return rb[bi, :3] + R @ pt
+                dist = _segment_distance(world(i, a[i]), world(i, b[i]), world(j, a[j]), world(j, b[j]))
+                worst = max(worst, r[i] + r[j] - dist)
+            depth.append(worst)
+        return np.array(depth), com_v, s
+
+    d_on, v_on, s_on = run(True)
+    d_off, v_off, _ = run(False)
+    assert d_off.max() > 0.04                                   # without self-collision the arm sinks into the torso
+    assert d_on.max() < 0.5 * d_off.max() and d_on[-10:].max() < 0.03      # with it the overlap stays shallow
+    assert np.abs(v_on - v_off).max() < 5e-3                    # internal forces only: no net push on the floating body
+    assert np.isfinite(s_on.rb_state).all()
