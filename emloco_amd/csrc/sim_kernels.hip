@@ -69,6 +69,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     __shared__ float sh_lam[MAXR];
     __shared__ float sh_lws[MAXCAND * 3];
     __shared__ unsigned char sh_lca[NB * NB];
+    __shared__ unsigned char sh_rowb[64];    // body of contact row r (NB for unused rows): lookup of the matrix-core Gram build
     __shared__ float sh_cf[NB][3];
     __shared__ float sh_fext[NB][6];         // limb-limb penalty wrench per body (self-collision), about O
     // body inertia / bias force handed from phase 2 to phase 3 through LDS; they alias the contact matrix, which is
@@ -546,19 +547,58 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         __syncthreads();
 
         PSTAMP(6);
-        // ============================================================ 6b. contact matrix, lower triangle (lane = column s)
-        // A[rr][s] = <y_rr, y_s> over the common-ancestor prefix; y_rr is broadcast from lane rr with v_readlane.
-        for (int rr = 0; rr < nr; ++rr) {
-            const int brr = sh_cbody[rr / 3];
-            const int kmax = 6 + 3 * sh_dep[brr];                    // y_rr is zero beyond its own chain (wave-uniform bound)
-            const int len = (lane < nr) ? 6 + 3 * (int)sh_lca[brr * NB + rbody] : 0;
-            float acc = 0.0f;
-            for (int k = 0; k < YLEN; ++k) {
-                if (k >= kmax) break;
-                const float yr = lane_bcast(ys[k], rr);
-                if (k < len) acc = fmaf(yr, ys[k], acc);
+        // ============================================================ 6b. contact matrix A = Y Y^T on the matrix cores
+        // A[r][s] = <y_r, y_s> over the common-ancestor prefix (6 root entries + 3 per shared tree level).  One
+        // v_mfma_f32_32x32x2_f32 chain runs over root block and levels for a whole 32 x 32 tile of (row, column) pairs --
+        // bit-equal to the fmaf chain in ascending k (measured: tools/exp/mfma_exact.hip) -- and after the block of level
+        // L-1 every pair whose common-ancestor depth is L takes a snapshot of its accumulator: the prefix sum it needs.
+        // Operands: lanes 0-31 feed k = 2s, lanes 32-63 k = 2s+1, so row r's y values are needed in lanes r and r + 32 (one
+        // cross-half exchange per value).  The 3-wide level blocks are padded with one 0*0 step.  Tiles: (0,0) [, (1,0), (1,1)].
+        {
+            typedef float sim_f32x16 __attribute__((vector_size(64)));
+            const int h = lane >> 5, j31 = lane & 31;
+            sh_rowb[lane] = (unsigned char)((lane < nr) ? rbody : NB);
+            int mydep = (lane < nr) ? sh_dep[rbody] : 0;
+            for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(mydep, off); mydep = o > mydep ? o : mydep; }
+            const int dmax = __builtin_amdgcn_readfirstlane(mydep);           // deepest chain among the contact bodies
+            __syncthreads();
+            const int ntile = nr > 32 ? 3 : 1;
+            for (int t = 0; t < ntile; ++t) {
+                const int tr = t > 0 ? 1 : 0, tc = t > 1 ? 1 : 0;
+                const int col = 32 * tc + j31;
+                const int bcol = sh_rowb[col];
+                int lc[16];
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * tr + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int brow = sh_rowb[row];
+                    const bool ok = brow < NB && bcol < NB;
+                    lc[r] = ok ? (int)sh_lca[(ok ? brow : 0) * NB + (ok ? bcol : 0)] : 255;
+                }
+                sim_f32x16 acc, res;
+                for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; res[r] = 0.0f; }
+#define GRAM_STEP(V0, V1)                                                                                              \
+                {                                                                                                      \
+                    const float v0_ = (V0), v1_ = (V1);                                                                \
+                    const float p0_ = __shfl_xor(v0_, 32), p1_ = __shfl_xor(v1_, 32);                                  \
+                    const float op0_ = h ? p1_ : v0_;            /* rows  0-31: lower half own k even, upper takes k odd */ \
+                    const float op1_ = h ? v1_ : p0_;            /* rows 32-63 */                                      \
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tr ? op1_ : op0_, tc ? op1_ : op0_, acc, 0, 0, 0);      \
+                }
+#define GRAM_SNAP(L) for (int r = 0; r < 16; ++r) res[r] = (lc[r] == (L)) ? acc[r] : res[r];
+                GRAM_STEP(ys[0], ys[1]) GRAM_STEP(ys[2], ys[3]) GRAM_STEP(ys[4], ys[5])
+                GRAM_SNAP(0)
+                for (int lev = 0; lev < 8; ++lev) {
+                    if (lev >= dmax) break;
+                    GRAM_STEP(ys[6 + 3 * lev], ys[7 + 3 * lev]) GRAM_STEP(ys[8 + 3 * lev], 0.0f)
+                    GRAM_SNAP(lev + 1)
+                }
+#undef GRAM_STEP
+#undef GRAM_SNAP
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * tr + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < nr && col <= row) sh_A[row * (row + 1) / 2 + col] = res[r];
+                }
             }
-            if (lane <= rr) sh_A[rr * (rr + 1) / 2 + lane] = acc;
         }
         __syncthreads();
 

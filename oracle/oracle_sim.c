@@ -594,7 +594,11 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
             for (int d1 = 0; d1 < 3; ++d1)
                 for (int d2 = 0; d2 < 3; ++d2) {
                     float acc = 0.0f;
-                    for (int k = 0; k < len; ++k) acc = fmaf(Y[3 * c1 + d1][k], Y[3 * c2 + d2][k], acc);
+                    for (int k = 0; k < len; ++k) {
+                        acc = fmaf(Y[3 * c1 + d1][k], Y[3 * c2 + d2][k], acc);
+                        /* the GPU pads every 3-wide tree-level block to two k = 2 matrix-core steps: one 0 * 0 term */
+                        if (k >= 6 && (k - 6) % 3 == 2) acc = fmaf(0.0f, 0.0f, acc);
+                    }
                     A[3 * c1 + d1][3 * c2 + d2] = acc;
                 }
         }

@@ -103,3 +103,4 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     return emu_exchange(src, (int)from);
 }
 static inline int __builtin_amdgcn_readlane(int v, int src_lane) { return emu_exchange(v, src_lane); }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return emu_exchange(v, 0); }
