@@ -44,6 +44,16 @@ __device__ __forceinline__ void cross3(const float *a, const float *b, float *o)
     o[0] = x; o[1] = y; o[2] = z;
 }
 __device__ __forceinline__ float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+// Fused sum-of-products forms for the articulated-body factorisation / solves (phases 3, 4, 7): one rounding per term,
+// ascending k.  The library is built with -ffp-contract=off, so a fused multiply-add exists only where it is written; the
+// CPU checker spells the same chains.
+__device__ __forceinline__ float fdot6(const float *a, const float *b) {
+    return fmaf(a[5], b[5], fmaf(a[4], b[4], fmaf(a[3], b[3], fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])))));
+}
+#define SOP2(a0, b0, a1, b1) fmaf((a1), (b1), (a0) * (b0))
+#define SOP3(a0, b0, a1, b1, a2, b2) fmaf((a2), (b2), fmaf((a1), (b1), (a0) * (b0)))
+#define ADD_SOP3(c, a0, b0, a1, b1, a2, b2) fmaf((a2), (b2), fmaf((a1), (b1), fmaf((a0), (b0), (c))))
+#define SUB_SOP3(c, a0, b0, a1, b1, a2, b2) fmaf(-(a2), (b2), fmaf(-(a1), (b1), fmaf(-(a0), (b0), (c))))
 __device__ __forceinline__ float dot6(const float *a, const float *b) {
     return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
 }

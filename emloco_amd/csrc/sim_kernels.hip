@@ -326,40 +326,40 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     for (int c = 0; c < 3; ++c) {
                         const float Sc[6] = {R[c], R[3 + c], R[6 + c], Sl[c][0], Sl[c][1], Sl[c][2]};
                         for (int a = 0; a < 6; ++a)
-                            U[a * 3 + c] = IA[sidx(a, 0)] * Sc[0] + IA[sidx(a, 1)] * Sc[1] + IA[sidx(a, 2)] * Sc[2] + IA[sidx(a, 3)] * Sc[3] + IA[sidx(a, 4)] * Sc[4] + IA[sidx(a, 5)] * Sc[5];
+                        { const float Ir[6] = {IA[sidx(a, 0)], IA[sidx(a, 1)], IA[sidx(a, 2)], IA[sidx(a, 3)], IA[sidx(a, 4)], IA[sidx(a, 5)]}; U[a * 3 + c] = fdot6(Ir, Sc); }
                     }
                     for (int a = 0; a < 3; ++a) {
                         const float Sa[6] = {R[a], R[3 + a], R[6 + a], Sl[a][0], Sl[a][1], Sl[a][2]};
                         for (int q = 0; q < 3; ++q) {
                             float acc = 0.0f;
-                            for (int k = 0; k < 6; ++k) acc += Sa[k] * U[k * 3 + q];
+                            for (int k = 0; k < 6; ++k) acc = fmaf(Sa[k], U[k * 3 + q], acc);
                             D[a * 3 + q] = acc + (a == q ? dd[a] : 0.0f);
                         }
                     }
                     const float l00 = sqrtf(D[0]), l10 = D[3] / l00, l20 = D[6] / l00;
-                    const float l11 = sqrtf(D[4] - l10 * l10), l21 = (D[7] - l20 * l10) / l11;
-                    const float l22 = sqrtf(D[8] - l20 * l20 - l21 * l21);
+                    const float l11 = sqrtf(fmaf(-l10, l10, D[4])), l21 = fmaf(-l20, l10, D[7]) / l11;
+                    const float l22 = sqrtf(fmaf(-l21, l21, fmaf(-l20, l20, D[8])));
                     const float k00 = 1.0f / l00, k11 = 1.0f / l11, k22 = 1.0f / l22;
-                    const float k10 = -l10 * k00 * k11, k21 = -l21 * k11 * k22, k20 = -(l20 * k00 + l21 * k10) * k22;
+                    const float k10 = -l10 * k00 * k11, k21 = -l21 * k11 * k22, k20 = -SOP2(l20, k00, l21, k10) * k22;
                     Km[0] = k00; Km[1] = k10; Km[2] = k11; Km[3] = k20; Km[4] = k21; Km[5] = k22;
                     for (int a = 0; a < 6; ++a) {
                         Wm[a * 3 + 0] = U[a * 3] * k00;
-                        Wm[a * 3 + 1] = U[a * 3] * k10 + U[a * 3 + 1] * k11;
-                        Wm[a * 3 + 2] = U[a * 3] * k20 + U[a * 3 + 1] * k21 + U[a * 3 + 2] * k22;
+                        Wm[a * 3 + 1] = SOP2(U[a * 3], k10, U[a * 3 + 1], k11);
+                        Wm[a * 3 + 2] = SOP3(U[a * 3], k20, U[a * 3 + 1], k21, U[a * 3 + 2], k22);
                     }
                     float u[3];
                     for (int c = 0; c < 3; ++c) {
                         const float Sc[6] = {R[c], R[3 + c], R[6 + c], Sl[c][0], Sl[c][1], Sl[c][2]};
-                        u[c] = tau[c] - dot6(Sc, pA);
+                        u[c] = tau[c] - fdot6(Sc, pA);
                     }
                     uh[0] = Km[0] * u[0];
-                    uh[1] = Km[1] * u[0] + Km[2] * u[1];
-                    uh[2] = Km[3] * u[0] + Km[4] * u[1] + Km[5] * u[2];
+                    uh[1] = SOP2(Km[1], u[0], Km[2], u[1]);
+                    uh[2] = SOP3(Km[3], u[0], Km[4], u[1], Km[5], u[2]);
                     for (int a = 0; a < 6; ++a)
                         for (int q = a; q < 6; ++q)
-                            sh_Ia[lane][sidx(a, q)] = IA[sidx(a, q)] - (Wm[a * 3] * Wm[q * 3] + Wm[a * 3 + 1] * Wm[q * 3 + 1] + Wm[a * 3 + 2] * Wm[q * 3 + 2]);
+                            sh_Ia[lane][sidx(a, q)] = SUB_SOP3(IA[sidx(a, q)], Wm[a * 3], Wm[q * 3], Wm[a * 3 + 1], Wm[q * 3 + 1], Wm[a * 3 + 2], Wm[q * 3 + 2]);
                     for (int k = 0; k < 6; ++k)
-                        sh_pa[lane][k] = pA[k] + (Wm[k * 3] * uh[0] + Wm[k * 3 + 1] * uh[1] + Wm[k * 3 + 2] * uh[2]);
+                        sh_pa[lane][k] = ADD_SOP3(pA[k], Wm[k * 3], uh[0], Wm[k * 3 + 1], uh[1], Wm[k * 3 + 2], uh[2]);
                     for (int k = 0; k < 18; ++k) sh_W[lane][k] = Wm[k];
                     for (int k = 0; k < 6; ++k) sh_K[lane][k] = Km[k];
                 } else {
@@ -369,18 +369,18 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     for (int a = 0; a < 6; ++a)
                         for (int q = 0; q <= a; ++q) {
                             float acc = IA[sidx(a, q)];
-                            for (int k = 0; k < q; ++k) acc -= LT(a, k) * LT(q, k);
+                            for (int k = 0; k < q; ++k) acc = fmaf(-LT(a, k), LT(q, k), acc);
                             LT(a, q) = (a == q) ? sqrtf(acc) : acc / LT(q, q);
                         }
                     float y[6], x[6];
                     for (int a = 0; a < 6; ++a) {
                         float acc = -pA[a];
-                        for (int k = 0; k < a; ++k) acc -= LT(a, k) * y[k];
+                        for (int k = 0; k < a; ++k) acc = fmaf(-LT(a, k), y[k], acc);
                         y[a] = acc / LT(a, a);
                     }
                     for (int a = 5; a >= 0; --a) {
                         float acc = y[a];
-                        for (int k = a + 1; k < 6; ++k) acc -= LT(k, a) * x[k];
+                        for (int k = a + 1; k < 6; ++k) acc = fmaf(-LT(k, a), x[k], acc);
                         x[a] = acc / LT(a, a);
                     }
                     for (int a = 0; a < 6; ++a)
@@ -406,15 +406,15 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 for (int k = 0; k < 6; ++k) ap[k] = sh_a[bc.parent][k];
                 for (int c = 0; c < 3; ++c) {
                     float acc = 0.0f;
-                    for (int k = 0; k < 6; ++k) acc += Wm[k * 3 + c] * ap[k];
+                    for (int k = 0; k < 6; ++k) acc = fmaf(Wm[k * 3 + c], ap[k], acc);
                     t[c] = uh[c] - acc;
                 }
-                qdd[0] = Km[0] * t[0] + Km[1] * t[1] + Km[3] * t[2];
-                qdd[1] = Km[2] * t[1] + Km[4] * t[2];
+                qdd[0] = SOP3(Km[0], t[0], Km[1], t[1], Km[3], t[2]);
+                qdd[1] = SOP2(Km[2], t[1], Km[4], t[2]);
                 qdd[2] = Km[5] * t[2];
                 for (int k = 0; k < 3; ++k) {
-                    a[k] = ap[k] + (R[k * 3] * qdd[0] + R[k * 3 + 1] * qdd[1] + R[k * 3 + 2] * qdd[2]);
-                    a[3 + k] = ap[3 + k] + (Sl[0][k] * qdd[0] + Sl[1][k] * qdd[1] + Sl[2][k] * qdd[2]);
+                    a[k] = ADD_SOP3(ap[k], R[k * 3], qdd[0], R[k * 3 + 1], qdd[1], R[k * 3 + 2], qdd[2]);
+                    a[3 + k] = ADD_SOP3(ap[3 + k], Sl[0][k], qdd[0], Sl[1][k], qdd[1], Sl[2][k], qdd[2]);
                 }
                 for (int k = 0; k < 6; ++k) sh_a[lane][k] = a[k];
             }
@@ -539,7 +539,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             }
             for (int a = 0; a < 6; ++a) {   // L0 y = p
                 float acc = p[a];
-                for (int k = 0; k < a; ++k) acc -= sh_L0[a * 6 + k] * ys[k];
+                for (int k = 0; k < a; ++k) acc = fmaf(-sh_L0[a * 6 + k], ys[k], acc);
                 ys[a] = acc / sh_L0[a * 6 + a];
             }
             lam = prm.warm * sh_lws[sh_ccand[myc] * 3 + myd];
@@ -687,23 +687,23 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                         for (int k = 0; k < 6; ++k) Km[k] = sh_K[lane][k];
                         for (int c = 0; c < 3; ++c) {
                             const float Sc[6] = {R[c], R[3 + c], R[6 + c], Sl[c][0], Sl[c][1], Sl[c][2]};
-                            u[c] = 0.0f - dot6(Sc, pA);
+                            u[c] = 0.0f - fdot6(Sc, pA);
                         }
                         uh[0] = Km[0] * u[0];
-                        uh[1] = Km[1] * u[0] + Km[2] * u[1];
-                        uh[2] = Km[3] * u[0] + Km[4] * u[1] + Km[5] * u[2];
+                        uh[1] = SOP2(Km[1], u[0], Km[2], u[1]);
+                        uh[2] = SOP3(Km[3], u[0], Km[4], u[1], Km[5], u[2]);
                         for (int k = 0; k < 6; ++k)
-                            sh_pa[lane][k] = pA[k] + (Wm[k * 3] * uh[0] + Wm[k * 3 + 1] * uh[1] + Wm[k * 3 + 2] * uh[2]);
+                            sh_pa[lane][k] = ADD_SOP3(pA[k], Wm[k * 3], uh[0], Wm[k * 3 + 1], uh[1], Wm[k * 3 + 2], uh[2]);
                     } else {
                         float y[6], x[6];
                         for (int a = 0; a < 6; ++a) {
                             float acc = -pA[a];
-                            for (int k = 0; k < a; ++k) acc -= sh_L0[a * 6 + k] * y[k];
+                            for (int k = 0; k < a; ++k) acc = fmaf(-sh_L0[a * 6 + k], y[k], acc);
                             y[a] = acc / sh_L0[a * 6 + a];
                         }
                         for (int a = 5; a >= 0; --a) {
                             float acc = y[a];
-                            for (int k = a + 1; k < 6; ++k) acc -= sh_L0[k * 6 + a] * x[k];
+                            for (int k = a + 1; k < 6; ++k) acc = fmaf(-sh_L0[k * 6 + a], x[k], acc);
                             x[a] = acc / sh_L0[a * 6 + a];
                         }
                         for (int k = 0; k < 6; ++k) { sh_a[0][k] = x[k]; da0[k] = x[k]; }
@@ -723,15 +723,15 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     for (int k = 0; k < 6; ++k) ap[k] = sh_a[bc.parent][k];
                     for (int c = 0; c < 3; ++c) {
                         float acc = 0.0f;
-                        for (int k = 0; k < 6; ++k) acc += Wm[k * 3 + c] * ap[k];
+                        for (int k = 0; k < 6; ++k) acc = fmaf(Wm[k * 3 + c], ap[k], acc);
                         t[c] = uh[c] - acc;
                     }
-                    dq[0] = Km[0] * t[0] + Km[1] * t[1] + Km[3] * t[2];
-                    dq[1] = Km[2] * t[1] + Km[4] * t[2];
+                    dq[0] = SOP3(Km[0], t[0], Km[1], t[1], Km[3], t[2]);
+                    dq[1] = SOP2(Km[2], t[1], Km[4], t[2]);
                     dq[2] = Km[5] * t[2];
                     for (int k = 0; k < 3; ++k) {
-                        a[k] = ap[k] + (R[k * 3] * dq[0] + R[k * 3 + 1] * dq[1] + R[k * 3 + 2] * dq[2]);
-                        a[3 + k] = ap[3 + k] + (Sl[0][k] * dq[0] + Sl[1][k] * dq[1] + Sl[2][k] * dq[2]);
+                        a[k] = ADD_SOP3(ap[k], R[k * 3], dq[0], R[k * 3 + 1], dq[1], R[k * 3 + 2], dq[2]);
+                        a[3 + k] = ADD_SOP3(ap[3 + k], Sl[0][k], dq[0], Sl[1][k], dq[1], Sl[2][k], dq[2]);
                     }
                     for (int k = 0; k < 6; ++k) sh_a[lane][k] = a[k];
                 }

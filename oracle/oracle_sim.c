@@ -53,6 +53,14 @@ static void cross3(const float *a, const float *b, float *o) {
     o[0] = x; o[1] = y; o[2] = z;
 }
 static float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+/* fused forms of the factorisation / solves, as in emloco_amd/csrc/dev_math.h */
+static float fdot6(const float *a, const float *b) {
+    return fmaf(a[5], b[5], fmaf(a[4], b[4], fmaf(a[3], b[3], fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])))));
+}
+#define SOP2(a0, b0, a1, b1) fmaf((a1), (b1), (a0) * (b0))
+#define SOP3(a0, b0, a1, b1, a2, b2) fmaf((a2), (b2), fmaf((a1), (b1), (a0) * (b0)))
+#define ADD_SOP3(c, a0, b0, a1, b1, a2, b2) fmaf((a2), (b2), fmaf((a1), (b1), fmaf((a0), (b0), (c))))
+#define SUB_SOP3(c, a0, b0, a1, b1, a2, b2) fmaf(-(a2), (b2), fmaf(-(a1), (b1), fmaf(-(a0), (b0), (c))))
 static float dot6(const float *a, const float *b) {
     return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
 }
@@ -367,33 +375,30 @@ static void factorize(Env *s, const EnvModel *m) {
         int p = m->parent[i];
         float U[18], D[9];
         for (int c = 0; c < 3; ++c) {
-            float u[6];
-            mat6vec(IAp[i], s->S[i][c], u);
-            for (int a = 0; a < 6; ++a) U[a * 3 + c] = u[a];
+            for (int a = 0; a < 6; ++a) U[a * 3 + c] = fdot6(IAp[i] + a * 6, s->S[i][c]);
         }
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) {
                 float acc = 0.0f;
-                for (int k = 0; k < 6; ++k) acc += s->S[i][a][k] * U[k * 3 + b];
+                for (int k = 0; k < 6; ++k) acc = fmaf(s->S[i][a][k], U[k * 3 + b], acc);
                 D[a * 3 + b] = acc + (a == b ? s->dd[i][a] : 0.0f);
             }
         float l00 = sqrtf(D[0]), l10 = D[3] / l00, l20 = D[6] / l00;
-        float l11 = sqrtf(D[4] - l10 * l10), l21 = (D[7] - l20 * l10) / l11;
-        float l22 = sqrtf(D[8] - l20 * l20 - l21 * l21);
+        float l11 = sqrtf(fmaf(-l10, l10, D[4])), l21 = fmaf(-l20, l10, D[7]) / l11;
+        float l22 = sqrtf(fmaf(-l21, l21, fmaf(-l20, l20, D[8])));
         float k00 = 1.0f / l00, k11 = 1.0f / l11, k22 = 1.0f / l22;
-        float k10 = -l10 * k00 * k11, k21 = -l21 * k11 * k22, k20 = -(l20 * k00 + l21 * k10) * k22;
+        float k10 = -l10 * k00 * k11, k21 = -l21 * k11 * k22, k20 = -SOP2(l20, k00, l21, k10) * k22;
         float *K = s->K[i];
         K[0] = k00; K[1] = k10; K[2] = k11; K[3] = k20; K[4] = k21; K[5] = k22;
         float *W = s->W[i];
         for (int a = 0; a < 6; ++a) {
             W[a * 3 + 0] = U[a * 3] * k00;
-            W[a * 3 + 1] = U[a * 3] * k10 + U[a * 3 + 1] * k11;
-            W[a * 3 + 2] = U[a * 3] * k20 + U[a * 3 + 1] * k21 + U[a * 3 + 2] * k22;
+            W[a * 3 + 1] = SOP2(U[a * 3], k10, U[a * 3 + 1], k11);
+            W[a * 3 + 2] = SOP3(U[a * 3], k20, U[a * 3 + 1], k21, U[a * 3 + 2], k22);
         }
         for (int a = 0; a < 6; ++a)
             for (int b = 0; b < 6; ++b)
-                IAp[p][a * 6 + b] += IAp[i][a * 6 + b] -
-                                     (W[a * 3] * W[b * 3] + W[a * 3 + 1] * W[b * 3 + 1] + W[a * 3 + 2] * W[b * 3 + 2]);
+                IAp[p][a * 6 + b] += SUB_SOP3(IAp[i][a * 6 + b], W[a * 3], W[b * 3], W[a * 3 + 1], W[b * 3 + 1], W[a * 3 + 2], W[b * 3 + 2]);
     }
     /* Cholesky of the 6x6 root articulated inertia */
     float *L = s->L0;
@@ -401,7 +406,7 @@ static void factorize(Env *s, const EnvModel *m) {
     for (int a = 0; a < 6; ++a)
         for (int b = 0; b <= a; ++b) {
             float acc = IAp[0][a * 6 + b];
-            for (int k = 0; k < b; ++k) acc -= L[a * 6 + k] * L[b * 6 + k];
+            for (int k = 0; k < b; ++k) acc = fmaf(-L[a * 6 + k], L[b * 6 + k], acc);
             L[a * 6 + b] = (a == b) ? sqrtf(acc) : acc / L[b * 6 + b];
         }
 }
@@ -409,14 +414,14 @@ static void factorize(Env *s, const EnvModel *m) {
 static void root_fwd(const float *L, const float *b, float *y) { /* L y = b */
     for (int a = 0; a < 6; ++a) {
         float acc = b[a];
-        for (int k = 0; k < a; ++k) acc -= L[a * 6 + k] * y[k];
+        for (int k = 0; k < a; ++k) acc = fmaf(-L[a * 6 + k], y[k], acc);
         y[a] = acc / L[a * 6 + a];
     }
 }
 static void root_bwd(const float *L, const float *y, float *x) { /* L^T x = y */
     for (int a = 5; a >= 0; --a) {
         float acc = y[a];
-        for (int k = a + 1; k < 6; ++k) acc -= L[k * 6 + a] * x[k];
+        for (int k = a + 1; k < 6; ++k) acc = fmaf(-L[k * 6 + a], x[k], acc);
         x[a] = acc / L[a * 6 + a];
     }
 }
@@ -429,14 +434,14 @@ static void aba_solve(const Env *s, const EnvModel *m, float (*pin)[6], float (*
     for (int i = NB - 1; i >= 1; --i) {
         int p = m->parent[i];
         float u[3];
-        for (int c = 0; c < 3; ++c) u[c] = (tau ? tau[i][c] : 0.0f) - dot6(s->S[i][c], pA[i]);
+        for (int c = 0; c < 3; ++c) u[c] = (tau ? tau[i][c] : 0.0f) - fdot6(s->S[i][c], pA[i]);
         const float *K = s->K[i];
         uh[i][0] = K[0] * u[0];
-        uh[i][1] = K[1] * u[0] + K[2] * u[1];
-        uh[i][2] = K[3] * u[0] + K[4] * u[1] + K[5] * u[2];
+        uh[i][1] = SOP2(K[1], u[0], K[2], u[1]);
+        uh[i][2] = SOP3(K[3], u[0], K[4], u[1], K[5], u[2]);
         const float *W = s->W[i];
         for (int k = 0; k < 6; ++k)
-            pA[p][k] += pA[i][k] + (W[k * 3] * uh[i][0] + W[k * 3 + 1] * uh[i][1] + W[k * 3 + 2] * uh[i][2]);
+            pA[p][k] += ADD_SOP3(pA[i][k], W[k * 3], uh[i][0], W[k * 3 + 1], uh[i][1], W[k * 3 + 2], uh[i][2]);
     }
     float y[6], nb[6];
     for (int k = 0; k < 6; ++k) nb[k] = -pA[0][k];
@@ -449,14 +454,14 @@ static void aba_solve(const Env *s, const EnvModel *m, float (*pin)[6], float (*
         float t[3];
         for (int c = 0; c < 3; ++c) {
             float acc = 0.0f;
-            for (int k = 0; k < 6; ++k) acc += W[k * 3 + c] * a[p][k];
+            for (int k = 0; k < 6; ++k) acc = fmaf(W[k * 3 + c], a[p][k], acc);
             t[c] = uh[i][c] - acc;
         }
-        qdd[i][0] = K[0] * t[0] + K[1] * t[1] + K[3] * t[2];
-        qdd[i][1] = K[2] * t[1] + K[4] * t[2];
+        qdd[i][0] = SOP3(K[0], t[0], K[1], t[1], K[3], t[2]);
+        qdd[i][1] = SOP2(K[2], t[1], K[4], t[2]);
         qdd[i][2] = K[5] * t[2];
         for (int k = 0; k < 6; ++k)
-            a[i][k] = a[p][k] + (s->S[i][0][k] * qdd[i][0] + s->S[i][1][k] * qdd[i][1] + s->S[i][2][k] * qdd[i][2]);
+            a[i][k] = ADD_SOP3(a[p][k], s->S[i][0][k], qdd[i][0], s->S[i][1][k], qdd[i][1], s->S[i][2][k], qdd[i][2]);
     }
 }
 
