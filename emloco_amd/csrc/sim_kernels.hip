@@ -607,39 +607,49 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         // Lane s owns row s: its multiplier `lam`, the running residual w_s = rhs_s + sum_r A_sr lam_r and 1/(A_ss (1+cfm)).
         // A row update happens in lane rr alone; its change is broadcast with one v_readlane and every lane folds it into
         // w with one fma through column rr of the symmetric matrix -- no wave reduction in the loop.
+        // Lane s keeps its whole row of the symmetric matrix in registers (statically unrolled over the MAXR rows, guarded by
+        // the wave-uniform row count): the sweeps then touch no LDS and do no index arithmetic.
         const int ls = lane < nr ? lane : 0;                      // idle lanes shadow lane 0 (their w is never used)
         const int tri_s = ls * (ls + 1) / 2;
         const float ainv = (lane < nr) ? 1.0f / (sh_A[tri_s + ls] * (1.0f + prm.cfm)) : 0.0f;
+        float arow[MAXR];
+#pragma unroll
+        for (int rr = 0; rr < MAXR; ++rr) arow[rr] = (rr < nr) ? sh_A[ls <= rr ? rr * (rr + 1) / 2 + ls : tri_s + rr] : 0.0f;
         float w = rhs;
-        for (int rr = 0; rr < nr; ++rr) {                         // warm start
-            const float lr = lane_bcast(lam, rr);
-            if (lr != 0.0f) w = fmaf(sh_A[ls <= rr ? rr * (rr + 1) / 2 + ls : tri_s + rr], lr, w);
+#pragma unroll
+        for (int rr = 0; rr < MAXR; ++rr) {                       // warm start
+            if (rr < nr) {
+                const float lr = lane_bcast(lam, rr);
+                if (lr != 0.0f) w = fmaf(arow[rr], lr, w);
+            }
         }
         for (int it = 0; it < prm.n_iter; ++it) {
-            for (int c = 0; c < nc; ++c) {
-                float acol[3];
-                for (int dr = 0; dr < 3; ++dr) {
-                    const int rr = 3 * c + dr;
-                    acol[dr] = sh_A[ls <= rr ? rr * (rr + 1) / 2 + ls : tri_s + rr];
-                    float delta = 0.0f;
-                    if (lane == rr) {
-                        float nl = fmaf(-w, ainv, lam);
-                        if (dr == 0 && nl < 0.0f) nl = 0.0f;
-                        delta = nl - lam;
-                        lam = nl;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                if (c < nc) {
+#pragma unroll
+                    for (int dr = 0; dr < 3; ++dr) {
+                        const int rr = 3 * c + dr;
+                        float delta = 0.0f;
+                        if (lane == rr) {
+                            float nl = fmaf(-w, ainv, lam);
+                            if (dr == 0 && nl < 0.0f) nl = 0.0f;
+                            delta = nl - lam;
+                            lam = nl;
+                        }
+                        w = fmaf(arow[rr], lane_bcast(delta, rr), w);
                     }
-                    w = fmaf(acol[dr], lane_bcast(delta, rr), w);
-                }
-                const float ln = lane_bcast(lam, 3 * c), l1 = lane_bcast(lam, 3 * c + 1), l2 = lane_bcast(lam, 3 * c + 2);
-                const float lim = prm.mu * ln;
-                const float m2 = fmaf(l1, l1, l2 * l2);
-                if (m2 > lim * lim) {                             // wave-uniform: outside the friction cone
-                    const float sc = lim / sqrtf(m2);
-                    const float n1 = l1 * sc, n2 = l2 * sc;
-                    if (lane == 3 * c + 1) lam = n1;
-                    if (lane == 3 * c + 2) lam = n2;
-                    w = fmaf(acol[1], n1 - l1, w);
-                    w = fmaf(acol[2], n2 - l2, w);
+                    const float ln = lane_bcast(lam, 3 * c), l1 = lane_bcast(lam, 3 * c + 1), l2 = lane_bcast(lam, 3 * c + 2);
+                    const float lim = prm.mu * ln;
+                    const float m2 = fmaf(l1, l1, l2 * l2);
+                    if (m2 > lim * lim) {                         // wave-uniform: outside the friction cone
+                        const float sc = lim / sqrtf(m2);
+                        const float n1 = l1 * sc, n2 = l2 * sc;
+                        if (lane == 3 * c + 1) lam = n1;
+                        if (lane == 3 * c + 2) lam = n2;
+                        w = fmaf(arow[3 * c + 1], n1 - l1, w);
+                        w = fmaf(arow[3 * c + 2], n2 - l2, w);
+                    }
                 }
             }
         }
