@@ -54,21 +54,25 @@ if len(res) == 2:
 print("\n".join(lines))
 PY
 # 3. MFMA utilisation of the predictor kernels (JTA leg): busy cycles of the matrix pipes over all SIMDs vs GPU-active cycles
-rm -rf /tmp/prof_mfma && (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_mfma -- $BENCH --steps 10 --warmup 2 --no_policy > "$OUT/pmc_mfma.log" 2>&1)
-python - "$OUT/${R}_mfma_utilisation.txt" <<'PY'
+rm -rf /tmp/prof_mfma && (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/prof_mfma -- $BENCH --steps 10 --warmup 2 --no_policy > "$OUT/pmc_mfma.log" 2>&1)
+python - "$OUT/${R}_mfma_utilisation.txt" "$OUT/${R}_bench_kernel_stats_top.csv" <<'PY'
 import csv, glob, sys, collections
-busy, act, n = collections.defaultdict(float), collections.defaultdict(float), collections.defaultdict(int)
+busy, n = collections.defaultdict(float), collections.defaultdict(int)
 for f in glob.glob("/tmp/prof_mfma/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"][:70]
         if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+            k = r["Kernel_Name"][:70]
             busy[k] += float(r["Counter_Value"]); n[k] += 1
-        elif r["Counter_Name"] == "GRBM_GUI_ACTIVE":
-            act[k] += float(r["Counter_Value"])
-lines = ["kernel | launches | MFMA busy cycles (sum over SIMDs) | GPU-active cycles | MFMA utilisation = busy / (active x 1024 SIMDs)"]
+avg_ns = {}
+for r in list(csv.reader(open(sys.argv[2])))[1:]:
+    avg_ns[r[0][:70]] = float(r[3])
+CLK = 2.4          # GHz, MI355X peak engine clock (MI355X_MICROARCH.md); 256 CUs x 4 SIMDs
+lines = ["kernel | launches | MFMA busy cycles per launch (sum over the 1024 SIMDs) | avg duration [us] (kernel-trace pass) | "
+         "MFMA utilisation = busy / (duration x 2.4 GHz x 1024)"]
 for k in sorted(busy, key=lambda k: -busy[k])[:10]:
-    if busy[k] > 0 and act[k] > 0:
-        lines.append(f"{k:70s} | {n[k]:5d} | {busy[k]:.4g} | {act[k]:.4g} | {busy[k] / (act[k] * 1024):.3f}")
+    if busy[k] > 0 and k in avg_ns:
+        per = busy[k] / n[k]
+        lines.append(f"{k:70s} | {n[k]:5d} | {per:.4g} | {avg_ns[k] / 1e3:9.1f} | {per / (avg_ns[k] * CLK * 1024):.3f}")
 open(sys.argv[1], "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
