@@ -30,7 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SIM_BYTES_PER_ENV = 8624          # state in/out + per-env model + warm-start, per launch
+SIM_BYTES_PER_ENV = 9296          # state in/out + per-env model (+ collision capsules) + warm-start, per launch
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 

@@ -54,8 +54,10 @@ if len(res) == 2:
 print("\n".join(lines))
 PY
 # 3. MFMA utilisation of the predictor kernels (JTA leg): busy cycles of the matrix pipes over all SIMDs vs GPU-active cycles
-rm -rf /tmp/prof_mfma && (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/prof_mfma -- $BENCH --steps 10 --warmup 2 --no_policy > "$OUT/pmc_mfma.log" 2>&1)
-python - "$OUT/${R}_mfma_utilisation.txt" "$OUT/${R}_bench_kernel_stats_top.csv" <<'PY'
+JTA="$BENCH --steps 10 --warmup 2 --no_policy"      # the same command for the duration pass and the counter pass
+rm -rf /tmp/prof_mfma_kt && (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mfma_kt -- $JTA > "$OUT/mfma_kt.log" 2>&1)
+rm -rf /tmp/prof_mfma && (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/prof_mfma -- $JTA > "$OUT/pmc_mfma.log" 2>&1)
+python - "$OUT/${R}_mfma_utilisation.txt" "$(find /tmp/prof_mfma_kt -name '*kernel_stats.csv' | head -1)" <<'PY'
 import csv, glob, sys, collections
 busy, n = collections.defaultdict(float), collections.defaultdict(int)
 for f in glob.glob("/tmp/prof_mfma/**/*counter_collection.csv", recursive=True):
