@@ -59,7 +59,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     __shared__ float sh_pw[NB][3], sh_qw[NB][4], sh_R[NB][9], sh_r[NB][3];
     __shared__ float sh_V[NB][6], sh_Aacc[NB][6];
     __shared__ float sh_Ia[NB][21], sh_pa[NB][6];
-    __shared__ float sh_W[NB][18], sh_K[NB][6], sh_L0[36];
+    __shared__ float sh_W[NB][18], sh_K[NB][6], sh_L0[36], sh_L0i[6];   // root Cholesky factor and 1 / its diagonal
     __shared__ float sh_a[NB][6], sh_Vf[NB][6];
     __shared__ float sh_root[13];            // p0[3] q0[4] V0[6]
     __shared__ int sh_par[NB], sh_dep[NB];
@@ -336,10 +336,10 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                             D[a * 3 + q] = acc + (a == q ? dd[a] : 0.0f);
                         }
                     }
-                    const float l00 = sqrtf(D[0]), l10 = D[3] / l00, l20 = D[6] / l00;
-                    const float l11 = sqrtf(fmaf(-l10, l10, D[4])), l21 = fmaf(-l20, l10, D[7]) / l11;
-                    const float l22 = sqrtf(fmaf(-l21, l21, fmaf(-l20, l20, D[8])));
-                    const float k00 = 1.0f / l00, k11 = 1.0f / l11, k22 = 1.0f / l22;
+                    // reciprocals of the pivots first: the off-diagonal entries multiply instead of divide
+                    const float l00 = sqrtf(D[0]), k00 = 1.0f / l00, l10 = D[3] * k00, l20 = D[6] * k00;
+                    const float l11 = sqrtf(fmaf(-l10, l10, D[4])), k11 = 1.0f / l11, l21 = fmaf(-l20, l10, D[7]) * k11;
+                    const float l22 = sqrtf(fmaf(-l21, l21, fmaf(-l20, l20, D[8]))), k22 = 1.0f / l22;
                     const float k10 = -l10 * k00 * k11, k21 = -l21 * k11 * k22, k20 = -SOP2(l20, k00, l21, k10) * k22;
                     Km[0] = k00; Km[1] = k10; Km[2] = k11; Km[3] = k20; Km[4] = k21; Km[5] = k22;
                     for (int a = 0; a < 6; ++a) {
@@ -364,27 +364,29 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     for (int k = 0; k < 6; ++k) sh_K[lane][k] = Km[k];
                 } else {
                     // root: Cholesky of the 6x6 articulated inertia, a0 = -IA0^-1 pA0
-                    float L[21];    // lower triangle, (a, q<=a) at a(a+1)/2 + q
+                    float L[21], Li[6];    // lower triangle, (a, q<=a) at a(a+1)/2 + q; reciprocal pivots
 #define LT(a, q) L[(a) * ((a) + 1) / 2 + (q)]
                     for (int a = 0; a < 6; ++a)
                         for (int q = 0; q <= a; ++q) {
                             float acc = IA[sidx(a, q)];
                             for (int k = 0; k < q; ++k) acc = fmaf(-LT(a, k), LT(q, k), acc);
-                            LT(a, q) = (a == q) ? sqrtf(acc) : acc / LT(q, q);
+                            if (a == q) { LT(a, q) = sqrtf(acc); Li[a] = 1.0f / LT(a, q); }
+                            else LT(a, q) = acc * Li[q];
                         }
                     float y[6], x[6];
                     for (int a = 0; a < 6; ++a) {
                         float acc = -pA[a];
                         for (int k = 0; k < a; ++k) acc = fmaf(-LT(a, k), y[k], acc);
-                        y[a] = acc / LT(a, a);
+                        y[a] = acc * Li[a];
                     }
                     for (int a = 5; a >= 0; --a) {
                         float acc = y[a];
                         for (int k = a + 1; k < 6; ++k) acc = fmaf(-LT(k, a), x[k], acc);
-                        x[a] = acc / LT(a, a);
+                        x[a] = acc * Li[a];
                     }
                     for (int a = 0; a < 6; ++a)
                         for (int q = 0; q <= a; ++q) sh_L0[a * 6 + q] = LT(a, q);
+                    for (int a = 0; a < 6; ++a) sh_L0i[a] = Li[a];
 #undef LT
                     for (int k = 0; k < 6; ++k) sh_a[0][k] = x[k];
                 }
@@ -540,7 +542,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             for (int a = 0; a < 6; ++a) {   // L0 y = p
                 float acc = p[a];
                 for (int k = 0; k < a; ++k) acc = fmaf(-sh_L0[a * 6 + k], ys[k], acc);
-                ys[a] = acc / sh_L0[a * 6 + a];
+                ys[a] = acc * sh_L0i[a];
             }
             lam = prm.warm * sh_lws[sh_ccand[myc] * 3 + myd];
         }
@@ -709,12 +711,12 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                         for (int a = 0; a < 6; ++a) {
                             float acc = -pA[a];
                             for (int k = 0; k < a; ++k) acc = fmaf(-sh_L0[a * 6 + k], y[k], acc);
-                            y[a] = acc / sh_L0[a * 6 + a];
+                            y[a] = acc * sh_L0i[a];
                         }
                         for (int a = 5; a >= 0; --a) {
                             float acc = y[a];
                             for (int k = a + 1; k < 6; ++k) acc = fmaf(-sh_L0[k * 6 + a], x[k], acc);
-                            x[a] = acc / sh_L0[a * 6 + a];
+                            x[a] = acc * sh_L0i[a];
                         }
                         for (int k = 0; k < 6; ++k) { sh_a[0][k] = x[k]; da0[k] = x[k]; }
                     }

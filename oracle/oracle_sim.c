@@ -44,6 +44,7 @@ typedef struct {
     float W[NB][18];  /* 6x3 row-major */
     float K[NB][6];   /* k00 k10 k11 k20 k21 k22 */
     float L0[36];     /* Cholesky factor of the root articulated inertia, lower, row-major */
+    float L0i[6];     /* reciprocals of its diagonal */
     int depth[NB];
 } Env;
 
@@ -383,10 +384,9 @@ static void factorize(Env *s, const EnvModel *m) {
                 for (int k = 0; k < 6; ++k) acc = fmaf(s->S[i][a][k], U[k * 3 + b], acc);
                 D[a * 3 + b] = acc + (a == b ? s->dd[i][a] : 0.0f);
             }
-        float l00 = sqrtf(D[0]), l10 = D[3] / l00, l20 = D[6] / l00;
-        float l11 = sqrtf(fmaf(-l10, l10, D[4])), l21 = fmaf(-l20, l10, D[7]) / l11;
-        float l22 = sqrtf(fmaf(-l21, l21, fmaf(-l20, l20, D[8])));
-        float k00 = 1.0f / l00, k11 = 1.0f / l11, k22 = 1.0f / l22;
+        float l00 = sqrtf(D[0]), k00 = 1.0f / l00, l10 = D[3] * k00, l20 = D[6] * k00;
+        float l11 = sqrtf(fmaf(-l10, l10, D[4])), k11 = 1.0f / l11, l21 = fmaf(-l20, l10, D[7]) * k11;
+        float l22 = sqrtf(fmaf(-l21, l21, fmaf(-l20, l20, D[8]))), k22 = 1.0f / l22;
         float k10 = -l10 * k00 * k11, k21 = -l21 * k11 * k22, k20 = -SOP2(l20, k00, l21, k10) * k22;
         float *K = s->K[i];
         K[0] = k00; K[1] = k10; K[2] = k11; K[3] = k20; K[4] = k21; K[5] = k22;
@@ -407,22 +407,23 @@ static void factorize(Env *s, const EnvModel *m) {
         for (int b = 0; b <= a; ++b) {
             float acc = IAp[0][a * 6 + b];
             for (int k = 0; k < b; ++k) acc = fmaf(-L[a * 6 + k], L[b * 6 + k], acc);
-            L[a * 6 + b] = (a == b) ? sqrtf(acc) : acc / L[b * 6 + b];
+            if (a == b) { L[a * 6 + b] = sqrtf(acc); s->L0i[a] = 1.0f / L[a * 6 + b]; }
+            else L[a * 6 + b] = acc * s->L0i[b];
         }
 }
 
-static void root_fwd(const float *L, const float *b, float *y) { /* L y = b */
+static void root_fwd(const float *L, const float *Li, const float *b, float *y) { /* L y = b */
     for (int a = 0; a < 6; ++a) {
         float acc = b[a];
         for (int k = 0; k < a; ++k) acc = fmaf(-L[a * 6 + k], y[k], acc);
-        y[a] = acc / L[a * 6 + a];
+        y[a] = acc * Li[a];
     }
 }
-static void root_bwd(const float *L, const float *y, float *x) { /* L^T x = y */
+static void root_bwd(const float *L, const float *Li, const float *y, float *x) { /* L^T x = y */
     for (int a = 5; a >= 0; --a) {
         float acc = y[a];
         for (int k = a + 1; k < 6; ++k) acc = fmaf(-L[k * 6 + a], x[k], acc);
-        x[a] = acc / L[a * 6 + a];
+        x[a] = acc * Li[a];
     }
 }
 
@@ -445,8 +446,8 @@ static void aba_solve(const Env *s, const EnvModel *m, float (*pin)[6], float (*
     }
     float y[6], nb[6];
     for (int k = 0; k < 6; ++k) nb[k] = -pA[0][k];
-    root_fwd(s->L0, nb, y);
-    root_bwd(s->L0, y, a0);
+    root_fwd(s->L0, s->L0i, nb, y);
+    root_bwd(s->L0, s->L0i, y, a0);
     memcpy(a[0], a0, 24);
     for (int i = 1; i < NB; ++i) {
         int p = m->parent[i];
@@ -582,7 +583,7 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
                 Y[r][slot] = uh[0]; Y[r][slot + 1] = uh[1]; Y[r][slot + 2] = uh[2];
                 for (int k = 0; k < 6; ++k) p[k] += W[k * 3] * uh[0] + W[k * 3 + 1] * uh[1] + W[k * 3 + 2] * uh[2];
             }
-            root_fwd(s->L0, p, Y[r]);
+            root_fwd(s->L0, s->L0i, p, Y[r]);
             /* warm start */
             lam[r] = prm->warm * lam_ws[con[c].cand * 3 + d];
         }
