@@ -19,6 +19,17 @@
 // bound, not bandwidth bound.
 #include <hip/hip_runtime.h>
 #include "dev_math.h"
+#include "sim_math.h"
+// the rigid-body kernels use the fused helper set (sim_math.h); undone at the end of this file
+#define cross3 fcross3
+#define dot3 fdot3
+#define dot6 fdot6
+#define qmul fqmul
+#define qnormalize fqnormalize
+#define q2mat fq2mat
+#define matvec3 fmatvec3
+#define rotvec2quat frotvec2quat
+#define quat2rotvec fquat2rotvec
 #include "emloco_types.h"
 
 namespace emloco {
@@ -276,8 +287,9 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             float Aa[6], hI[6], IAc[6], x1[3], x2[3];
             for (int k = 0; k < 6; ++k) Aa[k] = sh_Aacc[lane][k];
             for (int a = 0; a < 6; ++a) {
-                hI[a] = I6[sidx(a, 0)] * V[0] + I6[sidx(a, 1)] * V[1] + I6[sidx(a, 2)] * V[2] + I6[sidx(a, 3)] * V[3] + I6[sidx(a, 4)] * V[4] + I6[sidx(a, 5)] * V[5];
-                IAc[a] = I6[sidx(a, 0)] * Aa[0] + I6[sidx(a, 1)] * Aa[1] + I6[sidx(a, 2)] * Aa[2] + I6[sidx(a, 3)] * Aa[3] + I6[sidx(a, 4)] * Aa[4] + I6[sidx(a, 5)] * Aa[5];
+                const float Ir[6] = {I6[sidx(a, 0)], I6[sidx(a, 1)], I6[sidx(a, 2)], I6[sidx(a, 3)], I6[sidx(a, 4)], I6[sidx(a, 5)]};
+                hI[a] = fdot6(Ir, V);
+                IAc[a] = fdot6(Ir, Aa);
             }
             cross3(V, hI, x1); cross3(V + 3, hI + 3, x2);
             for (int k = 0; k < 3; ++k) f[k] = IAc[k] + x1[k] + x2[k];
@@ -875,3 +887,13 @@ sim_fk_kernel(EmlocoSimDev d, const int *env_ids, int n_ids) {
 }
 
 }  // namespace emloco
+
+#undef cross3
+#undef dot3
+#undef dot6
+#undef qmul
+#undef qnormalize
+#undef q2mat
+#undef matvec3
+#undef rotvec2quat
+#undef quat2rotvec

@@ -50,10 +50,10 @@ typedef struct {
 
 /* ---------------------------------------------------------------- small helpers */
 static void cross3(const float *a, const float *b, float *o) {
-    float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    float x = fmaf(a[1], b[2], -(a[2] * b[1])), y = fmaf(a[2], b[0], -(a[0] * b[2])), z = fmaf(a[0], b[1], -(a[1] * b[0]));   /* fused forms: emloco_amd/csrc/sim_math.h */
     o[0] = x; o[1] = y; o[2] = z;
 }
-static float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static float dot3(const float *a, const float *b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
 /* fused forms of the factorisation / solves, as in emloco_amd/csrc/dev_math.h */
 static float fdot6(const float *a, const float *b) {
     return fmaf(a[5], b[5], fmaf(a[4], b[4], fmaf(a[3], b[3], fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])))));
@@ -62,56 +62,57 @@ static float fdot6(const float *a, const float *b) {
 #define SOP3(a0, b0, a1, b1, a2, b2) fmaf((a2), (b2), fmaf((a1), (b1), (a0) * (b0)))
 #define ADD_SOP3(c, a0, b0, a1, b1, a2, b2) fmaf((a2), (b2), fmaf((a1), (b1), fmaf((a0), (b0), (c))))
 #define SUB_SOP3(c, a0, b0, a1, b1, a2, b2) fmaf(-(a2), (b2), fmaf(-(a1), (b1), fmaf(-(a0), (b0), (c))))
-static float dot6(const float *a, const float *b) {
-    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
-}
+static float dot6(const float *a, const float *b) { return fdot6(a, b); }
 static void qmul(const float *a, const float *b, float *o) { /* Hamilton product, xyzw */
-    float x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
-    float y = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
-    float z = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
-    float w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    float x = fmaf(-a[2], b[1], fmaf(a[1], b[2], fmaf(a[0], b[3], a[3] * b[0])));
+    float y = fmaf(a[2], b[0], fmaf(a[1], b[3], fmaf(-a[0], b[2], a[3] * b[1])));
+    float z = fmaf(a[2], b[3], fmaf(-a[1], b[0], fmaf(a[0], b[1], a[3] * b[2])));
+    float w = fmaf(-a[2], b[2], fmaf(-a[1], b[1], fmaf(-a[0], b[0], a[3] * b[3])));
     o[0] = x; o[1] = y; o[2] = z; o[3] = w;
 }
 static void qnormalize(float *q) {
-    float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    float n = sqrtf(fmaf(q[3], q[3], fmaf(q[2], q[2], fmaf(q[1], q[1], q[0] * q[0]))));
     float s = 1.0f / n;
     q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
 }
 static void q2mat(const float *q, float *R) { /* row-major */
     float x = q[0], y = q[1], z = q[2], w = q[3];
-    R[0] = 1.0f - 2.0f * (y * y + z * z); R[1] = 2.0f * (x * y - z * w); R[2] = 2.0f * (x * z + y * w);
-    R[3] = 2.0f * (x * y + z * w); R[4] = 1.0f - 2.0f * (x * x + z * z); R[5] = 2.0f * (y * z - x * w);
-    R[6] = 2.0f * (x * z - y * w); R[7] = 2.0f * (y * z + x * w); R[8] = 1.0f - 2.0f * (x * x + y * y);
+    R[0] = fmaf(-2.0f, fmaf(y, y, z * z), 1.0f); R[1] = 2.0f * fmaf(x, y, -(z * w)); R[2] = 2.0f * fmaf(x, z, y * w);
+    R[3] = 2.0f * fmaf(x, y, z * w); R[4] = fmaf(-2.0f, fmaf(x, x, z * z), 1.0f); R[5] = 2.0f * fmaf(y, z, -(x * w));
+    R[6] = 2.0f * fmaf(x, z, -(y * w)); R[7] = 2.0f * fmaf(y, z, x * w); R[8] = fmaf(-2.0f, fmaf(x, x, y * y), 1.0f);
 }
 static void matvec3(const float *R, const float *v, float *o) {
-    float x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
-    float y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
-    float z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+    float x = SOP3(R[0], v[0], R[1], v[1], R[2], v[2]);
+    float y = SOP3(R[3], v[0], R[4], v[1], R[5], v[2]);
+    float z = SOP3(R[6], v[0], R[7], v[1], R[8], v[2]);
     o[0] = x; o[1] = y; o[2] = z;
 }
 /* Deterministic sin/cos/atan built from +,-,*,/ and sqrt only (all correctly rounded in IEEE fp32), so the
  * GPU kernel, which uses the same operation sequence, reproduces the oracle bit for bit.  libm / ocml
  * transcendentals differ in the last ulp, and a falling humanoid amplifies that chaotically. */
 static void det_sincos(float x, float *sn, float *cs) {
-    /* reduce to [-pi/2, pi/2]: x = k*pi + y */
+    /* reduce to [-pi/2, pi/2]: x = k*pi + y; Horner steps as fused multiply-adds */
     const float inv_pi = 0.318309886f, pi_hi = 3.140625f, pi_lo = 9.67653589793e-4f;
-    float kf = floorf(x * inv_pi + 0.5f);
-    float y = (x - kf * pi_hi) - kf * pi_lo;
+    float kf = floorf(fmaf(x, inv_pi, 0.5f));
+    float y = fmaf(-kf, pi_lo, fmaf(-kf, pi_hi, x));
     float y2 = y * y;
-    float ps = 1.0f + y2 * (-1.0f / 6.0f + y2 * (1.0f / 120.0f + y2 * (-1.0f / 5040.0f + y2 * (1.0f / 362880.0f +
-               y2 * (-1.0f / 39916800.0f + y2 * (1.0f / 6227020800.0f))))));
-    float pc = 1.0f + y2 * (-0.5f + y2 * (1.0f / 24.0f + y2 * (-1.0f / 720.0f + y2 * (1.0f / 40320.0f +
-               y2 * (-1.0f / 3628800.0f + y2 * (1.0f / 479001600.0f + y2 * (-1.0f / 87178291200.0f)))))));
+    float ps = 1.0f / 6227020800.0f;
+    ps = fmaf(y2, ps, -1.0f / 39916800.0f); ps = fmaf(y2, ps, 1.0f / 362880.0f); ps = fmaf(y2, ps, -1.0f / 5040.0f);
+    ps = fmaf(y2, ps, 1.0f / 120.0f); ps = fmaf(y2, ps, -1.0f / 6.0f); ps = fmaf(y2, ps, 1.0f);
+    float pc = -1.0f / 87178291200.0f;
+    pc = fmaf(y2, pc, 1.0f / 479001600.0f); pc = fmaf(y2, pc, -1.0f / 3628800.0f); pc = fmaf(y2, pc, 1.0f / 40320.0f);
+    pc = fmaf(y2, pc, -1.0f / 720.0f); pc = fmaf(y2, pc, 1.0f / 24.0f); pc = fmaf(y2, pc, -0.5f); pc = fmaf(y2, pc, 1.0f);
     float sgn = (((long)kf) & 1) ? -1.0f : 1.0f;
     *sn = sgn * (y * ps);
     *cs = sgn * pc;
 }
 /* atan(t) for t in [0, 1] */
 static float det_atan01(float t) {
-    float u = t / (1.0f + sqrtf(1.0f + t * t)); /* half-angle: atan(t) = 2 atan(u), u <= 0.4143 */
+    float u = t / (1.0f + sqrtf(fmaf(t, t, 1.0f))); /* half-angle: atan(t) = 2 atan(u), u <= 0.4143 */
     float u2 = u * u;
-    float p = 1.0f + u2 * (-1.0f / 3.0f + u2 * (1.0f / 5.0f + u2 * (-1.0f / 7.0f + u2 * (1.0f / 9.0f + u2 * (-1.0f / 11.0f +
-              u2 * (1.0f / 13.0f + u2 * (-1.0f / 15.0f + u2 * (1.0f / 17.0f))))))));
+    float p = 1.0f / 17.0f;
+    p = fmaf(u2, p, -1.0f / 15.0f); p = fmaf(u2, p, 1.0f / 13.0f); p = fmaf(u2, p, -1.0f / 11.0f); p = fmaf(u2, p, 1.0f / 9.0f);
+    p = fmaf(u2, p, -1.0f / 7.0f); p = fmaf(u2, p, 1.0f / 5.0f); p = fmaf(u2, p, -1.0f / 3.0f); p = fmaf(u2, p, 1.0f);
     return 2.0f * (u * p);
 }
 /* atan2(s, w) for s >= 0, w >= 0 */
@@ -121,10 +122,10 @@ static float det_atan2_pos(float s, float w) {
 }
 /* rotation vector -> quaternion */
 static void rotvec2quat(const float *e, float *q) {
-    float th2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+    float th2 = dot3(e, e);
     float th = sqrtf(th2);
     float k, c;
-    if (th < 1e-4f) { k = 0.5f - th2 * (1.0f / 48.0f); c = 1.0f - th2 * 0.125f; }
+    if (th < 1e-4f) { k = fmaf(-th2, 1.0f / 48.0f, 0.5f); c = fmaf(-th2, 0.125f, 1.0f); }
     else { float sn; det_sincos(0.5f * th, &sn, &c); k = sn / th; }
     q[0] = e[0] * k; q[1] = e[1] * k; q[2] = e[2] * k; q[3] = c;
 }
@@ -132,7 +133,7 @@ static void rotvec2quat(const float *e, float *q) {
 static void quat2rotvec(const float *qin, float *e) {
     float q[4] = {qin[0], qin[1], qin[2], qin[3]};
     if (q[3] < 0.0f) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
-    float s = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    float s = sqrtf(dot3(q, q));
     float k;
     if (s < 1e-6f) k = 2.0f;
     else k = 2.0f * det_atan2_pos(s, q[3]) / s;
