@@ -161,9 +161,9 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     cross3(r, ax, Sl[c]);
                 }
                 for (int k = 0; k < 3; ++k) {
-                    wv[k] = R[k * 3] * wj[0] + R[k * 3 + 1] * wj[1] + R[k * 3 + 2] * wj[2];
+                    wv[k] = SOP3(R[k * 3], wj[0], R[k * 3 + 1], wj[1], R[k * 3 + 2], wj[2]);
                     V[k] = Vp[k] + wv[k];
-                    V[3 + k] = Vp[3 + k] + (Sl[0][k] * wj[0] + Sl[1][k] * wj[1] + Sl[2][k] * wj[2]);
+                    V[3 + k] = Vp[3 + k] + SOP3(Sl[0][k], wj[0], Sl[1][k], wj[1], Sl[2][k], wj[2]);
                 }
                 // velocity-product acceleration c = [w_p x wv ; vj x wv + r x (w_p x wv)]
                 float t[3], vj[3], cc[6], t1[3], t2[3];
@@ -268,10 +268,10 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             const float bmass = d.mass[mb0];
             const float Ib[9] = {in6[0], in6[3], in6[4], in6[3], in6[1], in6[5], in6[4], in6[5], in6[2]};
             for (int a = 0; a < 3; ++a)
-                for (int q = 0; q < 3; ++q) Rc[a * 3 + q] = R[a * 3] * Ib[q] + R[a * 3 + 1] * Ib[3 + q] + R[a * 3 + 2] * Ib[6 + q];
+                for (int q = 0; q < 3; ++q) Rc[a * 3 + q] = SOP3(R[a * 3], Ib[q], R[a * 3 + 1], Ib[3 + q], R[a * 3 + 2], Ib[6 + q]);
             for (int a = 0; a < 3; ++a)
                 for (int q = a; q < 3; ++q) {
-                    Ic[a * 3 + q] = Rc[a * 3] * R[q * 3] + Rc[a * 3 + 1] * R[q * 3 + 1] + Rc[a * 3 + 2] * R[q * 3 + 2];
+                    Ic[a * 3 + q] = SOP3(Rc[a * 3], R[q * 3], Rc[a * 3 + 1], R[q * 3 + 1], Rc[a * 3 + 2], R[q * 3 + 2]);
                     Ic[q * 3 + a] = Ic[a * 3 + q];
                 }
             matvec3(R, bcom, cw);
@@ -436,9 +436,9 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         }
         float wjf[3] = {0, 0, 0}, V0f[6];
         if (is_body) {
-            for (int k = 0; k < 6; ++k) sh_Vf[lane][k] = sh_V[lane][k] + h * sh_a[lane][k];
-            if (lane >= 1) for (int k = 0; k < 3; ++k) wjf[k] = wj[k] + h * qdd[k];
-            if (lane == 0) for (int k = 0; k < 6; ++k) V0f[k] = sh_root[7 + k] + h * sh_a[0][k];
+            for (int k = 0; k < 6; ++k) sh_Vf[lane][k] = fmaf(h, sh_a[lane][k], sh_V[lane][k]);
+            if (lane >= 1) for (int k = 0; k < 3; ++k) wjf[k] = fmaf(h, qdd[k], wj[k]);
+            if (lane == 0) for (int k = 0; k < 6; ++k) V0f[k] = fmaf(h, sh_a[0][k], sh_root[7 + k]);
         }
 
         PSTAMP(4);
@@ -545,11 +545,11 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     u[a] = -dot6(Sa, p);
                 }
                 const float *K = sh_K[i], *W = sh_W[i];
-                uhh[0] = K[0] * u[0]; uhh[1] = K[1] * u[0] + K[2] * u[1]; uhh[2] = K[3] * u[0] + K[4] * u[1] + K[5] * u[2];
+                uhh[0] = K[0] * u[0]; uhh[1] = SOP2(K[1], u[0], K[2], u[1]); uhh[2] = SOP3(K[3], u[0], K[4], u[1], K[5], u[2]);
                 const int lev = sh_dep[i] - 1;          // static register indexing: select the level's slot
                 for (int q = 0; q < 8; ++q)
                     if (q == lev) { ys[6 + 3 * q] = uhh[0]; ys[6 + 3 * q + 1] = uhh[1]; ys[6 + 3 * q + 2] = uhh[2]; }
-                for (int k = 0; k < 6; ++k) p[k] += W[k * 3] * uhh[0] + W[k * 3 + 1] * uhh[1] + W[k * 3 + 2] * uhh[2];
+                for (int k = 0; k < 6; ++k) p[k] = ADD_SOP3(p[k], W[k * 3], uhh[0], W[k * 3 + 1], uhh[1], W[k * 3 + 2], uhh[2]);
             }
             for (int a = 0; a < 6; ++a) {   // L0 y = p
                 float acc = p[a];
@@ -689,7 +689,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                             cross3(x, dir, Jr);
                             Jr[3] = dir[0]; Jr[4] = dir[1]; Jr[5] = dir[2];
                             const float l = sh_lam[3 * c + dr];
-                            for (int k = 0; k < 6; ++k) pin[k] -= Jr[k] * l;
+                            for (int k = 0; k < 6; ++k) pin[k] = fmaf(-Jr[k], l, pin[k]);
                             for (int k = 0; k < 3; ++k) cf[k] += dir[k] * l / h;
                         }
                 if (last) for (int k = 0; k < 3; ++k) sh_cf[lane][k] = cf[k];
@@ -868,8 +868,8 @@ sim_fk_kernel(EmlocoSimDev d, const int *env_ids, int n_ids) {
             float Sl[3][3];
             for (int c = 0; c < 3; ++c) { float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
             for (int k = 0; k < 3; ++k) {
-                V[k] = sh_V[parent][k] + (R[k * 3] * wj[0] + R[k * 3 + 1] * wj[1] + R[k * 3 + 2] * wj[2]);
-                V[3 + k] = sh_V[parent][3 + k] + (Sl[0][k] * wj[0] + Sl[1][k] * wj[1] + Sl[2][k] * wj[2]);
+                V[k] = sh_V[parent][k] + SOP3(R[k * 3], wj[0], R[k * 3 + 1], wj[1], R[k * 3 + 2], wj[2]);
+                V[3 + k] = sh_V[parent][3 + k] + SOP3(Sl[0][k], wj[0], Sl[1][k], wj[1], Sl[2][k], wj[2]);
             }
             for (int k = 0; k < 3; ++k) sh_pw[lane][k] = pw[k];
             for (int k = 0; k < 4; ++k) sh_qw[lane][k] = qw[k];

@@ -194,7 +194,7 @@ static void velocities(Env *s, const EnvModel *m, float (*V)[6], const float *V0
     for (int i = 1; i < NB; ++i) {
         int p = m->parent[i];
         for (int k = 0; k < 6; ++k)
-            V[i][k] = V[p][k] + (s->S[i][0][k] * wj[i][0] + s->S[i][1][k] * wj[i][1] + s->S[i][2][k] * wj[i][2]);
+            V[i][k] = V[p][k] + SOP3(s->S[i][0][k], wj[i][0], s->S[i][1][k], wj[i][1], s->S[i][2][k], wj[i][2]);
     }
 }
 
@@ -206,10 +206,10 @@ static void body_inertia(const Env *s, const EnvModel *m, int i, float *I6, floa
     const float *R = s->R[i];
     /* Ic = R Ib R^T */
     for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) Rc[a * 3 + b] = R[a * 3] * Ib[b] + R[a * 3 + 1] * Ib[3 + b] + R[a * 3 + 2] * Ib[6 + b];
+        for (int b = 0; b < 3; ++b) Rc[a * 3 + b] = SOP3(R[a * 3], Ib[b], R[a * 3 + 1], Ib[3 + b], R[a * 3 + 2], Ib[6 + b]);
     for (int a = 0; a < 3; ++a)
         for (int b = a; b < 3; ++b) { /* upper triangle, mirrored: exactly symmetric */
-            Ic[a * 3 + b] = Rc[a * 3] * R[b * 3] + Rc[a * 3 + 1] * R[b * 3 + 1] + Rc[a * 3 + 2] * R[b * 3 + 2];
+            Ic[a * 3 + b] = SOP3(Rc[a * 3], R[b * 3], Rc[a * 3 + 1], R[b * 3 + 1], Rc[a * 3 + 2], R[b * 3 + 2]);
             Ic[b * 3 + a] = Ic[a * 3 + b];
         }
     matvec3(R, m->com + i * 3, cw);
@@ -317,7 +317,7 @@ static void bias_and_drive(Env *s, const EnvModel *m, const OrcSimParams *prm, c
         int p = m->parent[i];
         float wv[3], vj[3], t[3], c[6];
         for (int k = 0; k < 3; ++k)
-            wv[k] = s->S[i][0][k] * s->wj[i][0] + s->S[i][1][k] * s->wj[i][1] + s->S[i][2][k] * s->wj[i][2];
+            wv[k] = SOP3(s->S[i][0][k], s->wj[i][0], s->S[i][1][k], s->wj[i][1], s->S[i][2][k], s->wj[i][2]);
         cross3(s->V[i], s->r[i], t); /* w_i x r_i */
         for (int k = 0; k < 3; ++k) vj[k] = s->V[i][3 + k] + t[k];
         cross3(s->V[p], wv, c);      /* w_p x wv */
@@ -546,11 +546,11 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
 
     /* 4. unconstrained velocities: generalized, and per body V + h a */
     float V0f[6], wjf[NB][3], Vf[NB][6];
-    for (int k = 0; k < 6; ++k) V0f[k] = s->V0[k] + h * a0[k];
+    for (int k = 0; k < 6; ++k) V0f[k] = fmaf(h, a0[k], s->V0[k]);
     for (int i = 1; i < NB; ++i)
-        for (int k = 0; k < 3; ++k) wjf[i][k] = s->wj[i][k] + h * qdd[i][k];
+        for (int k = 0; k < 3; ++k) wjf[i][k] = fmaf(h, qdd[i][k], s->wj[i][k]);
     for (int i = 0; i < NB; ++i)
-        for (int k = 0; k < 6; ++k) Vf[i][k] = s->V[i][k] + h * acc[i][k];
+        for (int k = 0; k < 6; ++k) Vf[i][k] = fmaf(h, acc[i][k], s->V[i][k]);
 
     /* 5./6. contacts */
     Contact con[ORC_MAXC];
@@ -579,10 +579,10 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
                 float u[3], uh[3];
                 for (int a = 0; a < 3; ++a) u[a] = -dot6(s->S[i][a], p);
                 const float *K = s->K[i], *W = s->W[i];
-                uh[0] = K[0] * u[0]; uh[1] = K[1] * u[0] + K[2] * u[1]; uh[2] = K[3] * u[0] + K[4] * u[1] + K[5] * u[2];
+                uh[0] = K[0] * u[0]; uh[1] = SOP2(K[1], u[0], K[2], u[1]); uh[2] = SOP3(K[3], u[0], K[4], u[1], K[5], u[2]);
                 int slot = 6 + 3 * (s->depth[i] - 1);
                 Y[r][slot] = uh[0]; Y[r][slot + 1] = uh[1]; Y[r][slot + 2] = uh[2];
-                for (int k = 0; k < 6; ++k) p[k] += W[k * 3] * uh[0] + W[k * 3 + 1] * uh[1] + W[k * 3 + 2] * uh[2];
+                for (int k = 0; k < 6; ++k) p[k] = ADD_SOP3(p[k], W[k * 3], uh[0], W[k * 3 + 1], uh[1], W[k * 3 + 2], uh[2]);
             }
             root_fwd(s->L0, s->L0i, p, Y[r]);
             /* warm start */
@@ -648,7 +648,7 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
     for (int c = 0; c < nc; ++c)
         for (int d = 0; d < 3; ++d) {
             int r = 3 * c + d;
-            for (int k = 0; k < 6; ++k) pin[con[c].body][k] -= J[r][k] * lam[r];
+            for (int k = 0; k < 6; ++k) pin[con[c].body][k] = fmaf(-J[r][k], lam[r], pin[con[c].body][k]);
             lam_ws[con[c].cand * 3 + d] = lam[r];
             if (last)
                 for (int k = 0; k < 3; ++k) cforce[con[c].body * 3 + k] += dirs[d][k] * lam[r] / h;
