@@ -50,10 +50,13 @@ __device__ __forceinline__ float sample_h(const EmlocoResetBufs &t, float x, flo
 
 __global__ void __launch_bounds__(64)
 reset_sample_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n, const float *rnd) {
-    if ((int)blockIdx.x >= n) return;
-    const int env = ids[blockIdx.x], lane = threadIdx.x;
-    if (env < 0) return;                     // padding entry of a device-compacted id list (emloco_task_compact_done)
-    const float *u = rnd + (long)blockIdx.x * EMLOCO_RESET_RND;
+    // grid-stride over the id list: a device-compacted list (emloco_task_compact_done) holds its valid entries first and
+    // -1 after them, so a small grid stops at the first padding entry instead of launching one workgroup per env
+    const int lane = threadIdx.x;
+    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
+    const int env = ids[bi];
+    if (env < 0) break;
+    const float *u = rnd + (long)bi * EMLOCO_RESET_RND;
     int mid = (int)(u[EMLOCO_RND_MOTION] * (float)t.n_motions);
     if (mid > t.n_motions - 1) mid = t.n_motions - 1;
     const float time = u[EMLOCO_RND_TIME] * t.motion_len[mid];
@@ -117,6 +120,8 @@ reset_sample_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
         t.motion_ids[env] = mid;
         t.motion_times[env] = time;
     }
+        __syncthreads();                              // LDS is reused by the next list entry
+    }
 }
 
 // traj_generator.py:278-296 calc_pos at one time
@@ -131,10 +136,11 @@ __device__ __forceinline__ void r_calc_pos(const float *verts, float time, float
 
 __global__ void __launch_bounds__(64)
 reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n, const float *rnd) {
-    if ((int)blockIdx.x >= n) return;
-    const int env = ids[blockIdx.x], lane = threadIdx.x;
-    if (env < 0) return;
-    const float *u = rnd + (long)blockIdx.x * EMLOCO_RESET_RND;
+    const int lane = threadIdx.x;
+    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
+    const int env = ids[bi];
+    if (env < 0) break;
+    const float *u = rnd + (long)bi * EMLOCO_RESET_RND;
     __shared__ float sh_v[RNV][3];
 
     // ---- a. lowest collision point -> vertical shift (replaces the SMPL-mesh height fix, humanoid_amp.py:321-379)
@@ -279,15 +285,18 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
         for (int k = 0; k < 3; ++k) t.init_pose[((long)env * RNB + lane) * 3 + k] = s.rb_state[((long)env * RNB + lane) * 13 + k];
     if (lane == 0) { t.init_vel[(long)env * 2] = rvx; t.init_vel[(long)env * 2 + 1] = rvy; }
 
+        __syncthreads();                              // LDS is reused by the next list entry
+    }
 }
 
 // ---- e. AMP history rows 1..14 from the motion library at t - k dt (humanoid_amp.py:486-535): one workgroup per
 // (finished env, history row) -- the rows are independent, a single wave walking all 14 was the longest serial path of a reset.
 __global__ void __launch_bounds__(64)
 reset_amp_history_kernel(EmlocoResetBufs t, const int32_t *ids, int n) {
-    if ((int)blockIdx.x >= n) return;
-    const int env = ids[blockIdx.x], lane = threadIdx.x;
-    if (env < 0) return;
+    const int lane = threadIdx.x;
+    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
+    const int env = ids[bi];
+    if (env < 0) break;
     const int k = 1 + (int)blockIdx.y;
     __shared__ float sh_root[13], sh_dp[RNDOF], sh_dv[RNDOF], sh_key[12];
     const int mid = (int)t.motion_ids[env];
@@ -318,6 +327,8 @@ reset_amp_history_kernel(EmlocoResetBufs t, const int32_t *ids, int n) {
     __syncthreads();
     amp_row(lane, sh_root, sh_root + 3, sh_root + 7, sh_root + 10, sh_dp, sh_dv, 1, sh_key, t.betas + (long)env * 17,
             t.dof_subset, t.n_dof_subset, t.amp_obs_buf + ((long)env * EMLOCO_AMP_STEPS + k) * EMLOCO_AMP_ROW);
+        __syncthreads();                              // LDS is reused by the next list entry
+    }
 }
 
 }  // namespace emloco

@@ -259,7 +259,7 @@ static int set_indexed(EmlocoSim *s, const float *dev_full, float *own, int row_
         hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)n), dim3(64), 0, st, dev_full, own, (const int *)ids, n, row_len);
         HIPCHK(hipGetLastError());
     }
-    hipLaunchKernelGGL(emloco::sim_fk_kernel, dim3((unsigned)n), dim3(64), 0, st, s->dev, (const int *)ids, n);
+    hipLaunchKernelGGL(emloco::sim_fk_kernel, dim3((unsigned)(n > 256 ? 256 : n)), dim3(64), 0, st, s->dev, (const int *)ids, n);
     HIPCHK(hipGetLastError());
     return EMLOCO_OK;
 }
@@ -283,7 +283,7 @@ int emloco_sim_refresh_bodies(EmlocoSim *s, void *stream) {
 // internal (not in the public header): forward kinematics of the listed envs, used by emloco_task_reset
 int emloco_sim_fk_indexed(EmlocoSim *s, const int32_t *ids, int n, void *stream) {
     if (!s || !s->prepared || !ids || n < 1) return fail(EMLOCO_E_ARG, "emloco_sim_fk_indexed: bad argument");
-    hipLaunchKernelGGL(emloco::sim_fk_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, s->dev, (const int *)ids, n);
+    hipLaunchKernelGGL(emloco::sim_fk_kernel, dim3((unsigned)(n > 256 ? 256 : n)), dim3(64), 0, (hipStream_t)stream, s->dev, (const int *)ids, n);
     HIPCHK(hipGetLastError());
     return EMLOCO_OK;
 }

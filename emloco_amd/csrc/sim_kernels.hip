@@ -830,9 +830,10 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
 __global__ void __launch_bounds__(64)
 sim_fk_kernel(EmlocoSimDev d, const int *env_ids, int n_ids) {
     const int lane = threadIdx.x;
-    if ((int)blockIdx.x >= n_ids) return;
-    const int env = env_ids ? env_ids[blockIdx.x] : (int)blockIdx.x;
-    if (env < 0) return;                     // padding entry of a device-compacted id list
+    // grid-stride over the id list (one pass when the grid covers it); a device-compacted list ends at its first -1
+    for (int bi = blockIdx.x; bi < n_ids; bi += gridDim.x) {
+    const int env = env_ids ? env_ids[bi] : bi;
+    if (env < 0) break;
     __shared__ float sh_pw[NB][3], sh_qw[NB][4], sh_R[NB][9], sh_V[NB][6];
     const bool is_body = lane < NB;
     const int b = is_body ? lane : 0;
@@ -883,6 +884,8 @@ sim_fk_kernel(EmlocoSimDev d, const int *env_ids, int n_ids) {
         cross3(V, r, t);
         for (int k = 0; k < 3; ++k) { o[k] = sh_pw[lane][k]; o[7 + k] = V[3 + k] + t[k]; o[10 + k] = V[k]; }
         for (int k = 0; k < 4; ++k) o[3 + k] = sh_qw[lane][k];
+    }
+        __syncthreads();
     }
 }
 

@@ -102,13 +102,14 @@ int emloco_task_reset(EmlocoSim *sim, const EmlocoResetBufs *b, const int32_t *d
         return tfail(-1, "emloco_task_reset: no valid locations");
     if ((b->flags & EMLOCO_RESET_REAL_PATH) && b->n_real > 0 && !b->real_traj) return tfail(-1, "emloco_task_reset: real_path without data");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(emloco::reset_sample_kernel, dim3((unsigned)n), dim3(64), 0, st, *b, sim->dev, dev_env_ids, n, dev_rnd);
+    const unsigned grid = (unsigned)(n < 256 ? n : 256);        // grid-stride kernels: see reset_kernels.hip
+    hipLaunchKernelGGL(emloco::reset_sample_kernel, dim3(grid), dim3(64), 0, st, *b, sim->dev, dev_env_ids, n, dev_rnd);
     THIPCHK(hipGetLastError());
     const int rc = emloco_sim_fk_indexed(sim, dev_env_ids, n, stream);
     if (rc != 0) return rc;
-    hipLaunchKernelGGL(emloco::reset_finish_kernel, dim3((unsigned)n), dim3(64), 0, st, *b, sim->dev, dev_env_ids, n, dev_rnd);
+    hipLaunchKernelGGL(emloco::reset_finish_kernel, dim3(grid), dim3(64), 0, st, *b, sim->dev, dev_env_ids, n, dev_rnd);
     THIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(emloco::reset_amp_history_kernel, dim3((unsigned)n, EMLOCO_AMP_STEPS - 1), dim3(64), 0, st, *b, dev_env_ids, n);
+    hipLaunchKernelGGL(emloco::reset_amp_history_kernel, dim3(grid, EMLOCO_AMP_STEPS - 1), dim3(64), 0, st, *b, dev_env_ids, n);
     THIPCHK(hipGetLastError());
     return 0;
 }
