@@ -292,7 +292,11 @@ class Humanoid(BaseTask):
             self._flip_obs_buf = torch.zeros((self.num_envs, self.num_obs), device=self.device, dtype=torch.float)
         else:
             raise NotImplementedError("emloco fused kernels always produce the mirrored observations (motion_sym_loss: True)")
-        self._pd_targets = torch.zeros((self.num_envs, self.num_dof), device=self.device, dtype=torch.float)
+        # the PD-target buffer IS the simulator's own target tensor when the native sim exists: set_dof_position_target_tensor
+        # then has nothing to copy (emloco_sim_set_pd_targets skips an aliasing pointer)
+        native = getattr(self.sim, "native", None)
+        self._pd_targets = native.pd_target.view(self.num_envs, self.num_dof) if native is not None else \
+            torch.zeros((self.num_envs, self.num_dof), device=self.device, dtype=torch.float)
         self._post = PostPhysics(self.device, key_bodies=self.key_bodies, contact_bodies=contact_bodies)
         self._post_bufs = None
 
