@@ -55,13 +55,31 @@ int emloco_gemm_timing_stats(int *n_launches, float *total_ms, double *total_flo
 int emloco_gemm_f32(int batch, int m, int n, int k, float alpha, const float *A, int lda, int64_t stride_a, int trans_a,
                     const float *B, int ldb, int64_t stride_b, int trans_b, float *C, int ldc, int64_t stride_c,
                     const float *bias, int flags, int ksplit, float *workspace, void *stream) {
+    if (flags & EMLOCO_GEMM_DROPOUT) return pfail(-1, "emloco_gemm_f32: the dropout epilogue needs emloco_gemm_f32_ex");
+    return emloco_gemm_f32_ex(batch, m, n, k, alpha, A, lda, stride_a, trans_a, B, ldb, stride_b, trans_b, C, ldc, stride_c, bias, flags,
+                              ksplit, workspace, 0.0f, 0u, stream);
+}
+
+int emloco_act_bwd(int64_t total, const float *dy, const float *y, int relu, float drop_p, uint32_t drop_seed, float *dz, void *stream) {
+    if (total < 1 || !dy || !dz || (relu && !y) || !(drop_p >= 0.0f && drop_p < 1.0f)) return pfail(-1, "emloco_act_bwd: bad argument");
+    hipLaunchKernelGGL(emloco::act_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (long)total, dy, y, relu, drop_p, drop_seed, dz);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha, const float *A, int lda, int64_t stride_a, int trans_a,
+                       const float *B, int ldb, int64_t stride_b, int trans_b, float *C, int ldc, int64_t stride_c,
+                       const float *bias, int flags, int ksplit, float *workspace, float drop_p, uint32_t drop_seed, void *stream) {
+    if ((flags & EMLOCO_GEMM_DROPOUT) && (!(drop_p > 0.0f && drop_p < 1.0f) || ldc != n || (batch > 1 && stride_c != (int64_t)m * n)))
+        return pfail(-1, "emloco_gemm_f32_ex: dropout needs 0 < p < 1 and a dense output (the mask is indexed by the flat element)");
     if (batch < 1 || m < 1 || n < 1 || k < 1 || !A || !B || !C) return pfail(-1, "emloco_gemm_f32: bad argument");
     if ((flags & EMLOCO_GEMM_BIAS) && !bias) return pfail(-1, "emloco_gemm_f32: bias flag without bias");
     if (ksplit < 1) ksplit = 1;
     if (ksplit > 1 && !workspace) return pfail(-1, "emloco_gemm_f32: ksplit > 1 needs a workspace");
     if ((long)batch * ksplit > 65535) return pfail(-1, "emloco_gemm_f32: batch * ksplit exceeds the grid z limit");
     emloco::GemmArgs g{batch, m, n, k, alpha, A, lda, (long)stride_a, trans_a, B, ldb, (long)stride_b, trans_b,
-                       C, ldc, (long)stride_c, bias, flags, ksplit, workspace, 0, 0};
+                       C, ldc, (long)stride_c, bias, flags, ksplit, workspace, 0, 0, drop_p, drop_seed};
     // 16-byte global loads need the base, the leading dimension and the batch stride 16 B aligned
     g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && (stride_a % 4 == 0);
     g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (stride_b % 4 == 0);

@@ -30,7 +30,16 @@ struct GemmArgs {
     float *C; int ldc; long sc;
     const float *bias; int flags; int ksplit; float *ws;
     int vec_a, vec_b;   // operand may be read with 16-byte loads (base, leading dimension and batch stride 16 B aligned)
+    float drop_p; unsigned drop_seed;   // flags & 8: inverted dropout in the epilogue (after bias / ReLU)
 };
+
+// Counter-based dropout mask: keep element `idx` of a launch with seed `seed` iff hash(seed, idx) >= p.  A stateless
+// integer hash (murmur3 finaliser over a Weyl-mixed counter), so the backward recomputes the mask instead of storing it.
+__host__ __device__ __forceinline__ bool drop_keep(unsigned seed, unsigned long long idx, float p) {
+    unsigned long long z = idx * 0x9E3779B97F4A7C15ull + ((unsigned long long)seed << 32 | 0x632BE5ABu);
+    z ^= z >> 33; z *= 0xFF51AFD7ED558CCDull; z ^= z >> 33; z *= 0xC4CEB9FE1A85EC53ull; z ^= z >> 33;
+    return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f) >= p;
+}
 
 struct __attribute__((aligned(16))) f32x4 { float x, y, z, w; };
 
@@ -184,6 +193,7 @@ gemm_f32_kernel(GemmArgs g) {
                         float *c = g.C + (long)b * g.sc + (long)row * g.ldc + col;
                         if (g.flags & 1) v += g.bias[col];
                         if (g.flags & 2) v = v > 0.0f ? v : 0.0f;
+                        if (g.flags & 8) v = drop_keep(g.drop_seed, ((unsigned long long)b * g.m + row) * g.n + col, g.drop_p) ? v * (1.0f / (1.0f - g.drop_p)) : 0.0f;
                         if (g.flags & 4) v += *c;
                         *c = v;
                     }
@@ -226,8 +236,23 @@ __global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
     float *c = g.C + (long)b * g.sc + (long)row * g.ldc + col;
     if (g.flags & 1) v += g.bias[col];
     if (g.flags & 2) v = v > 0.0f ? v : 0.0f;
+    if (g.flags & 8) v = drop_keep(g.drop_seed, (unsigned long long)i, g.drop_p) ? v * (1.0f / (1.0f - g.drop_p)) : 0.0f;
     if (g.flags & 4) v += *c;
     *c = v;
+}
+
+// Backward of the fused epilogue: dz = dy * [relu: y > 0] * [dropout: keep / (1 - p)] in one pass (y is the forward OUTPUT:
+// after ReLU + dropout a positive output means "active and kept", so the mask is only recomputed when there is no ReLU).
+__global__ void act_bwd_kernel(long total, const float *dy, const float *y, int relu, float drop_p, unsigned drop_seed, float *dz) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float v = dy[i];
+    if (relu) v = y[i] > 0.0f ? v : 0.0f;
+    if (drop_p > 0.0f) {
+        const bool keep = relu ? true : drop_keep(drop_seed, (unsigned long long)i, drop_p);
+        v = keep ? v * (1.0f / (1.0f - drop_p)) : 0.0f;
+    }
+    dz[i] = v;
 }
 
 // ------------------------------------------------------------------ softmax (one wave per row)

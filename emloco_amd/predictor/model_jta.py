@@ -46,11 +46,12 @@ class EncoderLayer(nn.Module):
         sa = self.self_attn
         qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
         att = ops.attention(qkv, key_pad, sa.num_heads)
-        a = ops.linear(att, sa.out_proj.weight, sa.out_proj.bias)
-        x = ops.layer_norm(F.dropout(a, self.p, self.training), x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        h = ops.linear(x, self.linear1.weight, self.linear1.bias, relu=True)
-        f = ops.linear(F.dropout(h, self.p, self.training), self.linear2.weight, self.linear2.bias)
-        return ops.layer_norm(F.dropout(f, self.p, self.training), x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        p = self.p if self.training else 0.0                 # the three nn.Dropout of the layer live in the GEMM epilogues
+        a = ops.linear(att, sa.out_proj.weight, sa.out_proj.bias, drop_p=p)
+        x = ops.layer_norm(a, x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        h = ops.linear(x, self.linear1.weight, self.linear1.bias, relu=True, drop_p=p)
+        f = ops.linear(h, self.linear2.weight, self.linear2.bias, drop_p=p)
+        return ops.layer_norm(f, x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
 
 
 class Encoder(nn.Module):

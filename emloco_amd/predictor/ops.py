@@ -10,7 +10,7 @@ import torch
 from .. import _lib as L
 from ..sim import current_stream_handle
 
-GEMM_BIAS, GEMM_RELU, GEMM_ACC = 1, 2, 4
+GEMM_BIAS, GEMM_RELU, GEMM_ACC, GEMM_DROPOUT = 1, 2, 4, 8
 _bound = False
 
 
@@ -20,6 +20,8 @@ def _lib():
     if not _bound:
         vp, ci, cf, cl = C.c_void_p, C.c_int, C.c_float, C.c_int64
         lib.emloco_gemm_f32.argtypes = [ci, ci, ci, ci, cf, vp, ci, cl, ci, vp, ci, cl, ci, vp, ci, cl, vp, ci, ci, vp, vp]
+        lib.emloco_gemm_f32_ex.argtypes = [ci, ci, ci, ci, cf, vp, ci, cl, ci, vp, ci, cl, ci, vp, ci, cl, vp, ci, ci, vp, cf, C.c_uint32, vp]
+        lib.emloco_act_bwd.argtypes = [cl, vp, vp, ci, cf, C.c_uint32, vp, vp]
         lib.emloco_softmax_fwd.argtypes = [ci, ci, ci, cf, vp, vp, vp, vp]
         lib.emloco_softmax_bwd.argtypes = [ci, ci, cf, vp, vp, vp, vp]
         lib.emloco_layernorm_fwd.argtypes = [ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -55,14 +57,27 @@ def _chk(rc, what):
 
 
 def gemm(batch, m, n, k, A, lda, sa, ta, B, ldb, sb, tb, Cm, ldc, sc, alpha=1.0, bias=None, flags=0, ksplit=1,
-         a_off=0, b_off=0, c_off=0):
+         a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0):
     """Raw strided batched GEMM: C_b[m][n] (+)= alpha * sum_k A_b(m,k) B_b(n,k) (see the header for the layouts)."""
     ws = None
     if ksplit > 1:
         ws = torch.empty(ksplit * batch * m * n, dtype=torch.float32, device=Cm.device)
-    rc = _lib().emloco_gemm_f32(batch, m, n, k, float(alpha), _p(A, a_off), lda, sa, ta, _p(B, b_off), ldb, sb, tb,
-                                _p(Cm, c_off), ldc, sc, _p(bias), flags, ksplit, _p(ws), _st(Cm))
-    _chk(rc, "emloco_gemm_f32")
+    if drop_p > 0.0:
+        flags |= GEMM_DROPOUT
+    rc = _lib().emloco_gemm_f32_ex(batch, m, n, k, float(alpha), _p(A, a_off), lda, sa, ta, _p(B, b_off), ldb, sb, tb,
+                                   _p(Cm, c_off), ldc, sc, _p(bias), flags, ksplit, _p(ws), float(drop_p), int(drop_seed) & 0xFFFFFFFF,
+                                   _st(Cm))
+    _chk(rc, "emloco_gemm_f32_ex")
+
+
+_drop_counter = [0]
+
+
+def next_dropout_seed():
+    """32-bit seed of the next fused-dropout launch: a host-side counter mixed with torch's seed (no device sync; runs
+    repeat under torch.manual_seed).  The mask itself is a stateless hash of (seed, element index) on the device."""
+    _drop_counter[0] += 1
+    return (torch.initial_seed() * 0x9E3779B1 + _drop_counter[0] * 0x85EBCA6B) & 0xFFFFFFFF
 
 
 def _ksplit_for(red, out_elems):
@@ -81,10 +96,11 @@ def colsum(X2d):
 
 
 class LinearFn(torch.autograd.Function):
-    """y = x W^T + b (optionally ReLU); x (..., K), W (N, K)."""
+    """y = dropout(relu?(x W^T + b)); x (..., K), W (N, K).  Bias, ReLU and inverted dropout live in the GEMM epilogue; the
+    backward applies both masks in one pass (`emloco_act_bwd`) before the two gradient GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, W, b, relu):
+    def forward(ctx, x, W, b, relu, drop_p=0.0, drop_seed=0):
         xs = x.shape
         x2 = x.contiguous().view(-1, xs[-1])
         M, K = x2.shape
@@ -92,9 +108,10 @@ class LinearFn(torch.autograd.Function):
         Wc = W.contiguous()
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         flags = (GEMM_BIAS if b is not None else 0) | (GEMM_RELU if relu else 0)
-        gemm(1, M, N, K, x2, K, 0, 0, Wc, K, 0, 0, y, N, 0, bias=b.contiguous() if b is not None else None, flags=flags)
+        gemm(1, M, N, K, x2, K, 0, 0, Wc, K, 0, 0, y, N, 0, bias=b.contiguous() if b is not None else None, flags=flags,
+             drop_p=drop_p, drop_seed=drop_seed)
         ctx.save_for_backward(x2, Wc, y if relu else None)
-        ctx.relu, ctx.has_bias, ctx.xs = relu, b is not None, xs
+        ctx.relu, ctx.has_bias, ctx.xs, ctx.drop = relu, b is not None, xs, (float(drop_p), int(drop_seed))
         return y.view(*xs[:-1], N)
 
     @staticmethod
@@ -103,8 +120,11 @@ class LinearFn(torch.autograd.Function):
         M, K = x2.shape
         N = W.shape[0]
         dy2 = dy.contiguous().view(M, N)
-        if ctx.relu:
-            dy2 = dy2 * (y > 0)
+        p, seed = ctx.drop
+        if ctx.relu or p > 0.0:
+            dz = torch.empty_like(dy2)
+            _chk(_lib().emloco_act_bwd(M * N, _p(dy2), _p(y), 1 if ctx.relu else 0, p, seed & 0xFFFFFFFF, _p(dz), _st(dy2)), "emloco_act_bwd")
+            dy2 = dz
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
@@ -115,11 +135,16 @@ class LinearFn(torch.autograd.Function):
             gemm(1, N, K, M, dy2, N, 0, 1, x2, K, 0, 1, dW, K, 0, ksplit=_ksplit_for(M, N * K))   # dW = dy^T x
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy2)
-        return dx, dW, db, None
+        return dx, dW, db, None, None, None
 
 
-def linear(x, W, b=None, relu=False):
-    return LinearFn.apply(x, W, b, relu)
+def linear(x, W, b=None, relu=False, drop_p=0.0):
+    """nn.Linear (+ReLU) (+nn.Dropout(p) in training: pass drop_p > 0) as one GEMM launch."""
+    if drop_p > 0.0:
+        return LinearFn.apply(x, W, b, relu, float(drop_p), next_dropout_seed())
+    return LinearFn.apply(x, W, b, relu, 0.0, 0)
+
+
 
 
 class FusedAttentionFn(torch.autograd.Function):

@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-enum { EMLOCO_GEMM_BIAS = 1, EMLOCO_GEMM_RELU = 2, EMLOCO_GEMM_ACCUMULATE = 4 };
+enum { EMLOCO_GEMM_BIAS = 1, EMLOCO_GEMM_RELU = 2, EMLOCO_GEMM_ACCUMULATE = 4, EMLOCO_GEMM_DROPOUT = 8 };
 
 /* Batched strided GEMM on the matrix cores, fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: exact fp32):
  *   C[b][m][n] (+)= alpha * sum_k A_b(m,k) * B_b(n,k)   [+ bias[n]] [relu]
@@ -30,6 +30,17 @@ int emloco_gemm_f32(int batch, int m, int n, int k, float alpha,
                     const float *B, int ldb, int64_t stride_b, int trans_b,
                     float *C, int ldc, int64_t stride_c,
                     const float *bias, int flags, int ksplit, float *workspace, void *stream);
+/* The same with EMLOCO_GEMM_DROPOUT: inverted dropout (nn.Dropout in training mode, model_jta.py:177-178) applied after
+ * bias / ReLU; the keep mask is a stateless hash of (drop_seed, flat output index), so nothing is stored for the backward.
+ * Needs a dense output (ldc == n, stride_c == m * n). */
+int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha,
+                       const float *A, int lda, int64_t stride_a, int trans_a,
+                       const float *B, int ldb, int64_t stride_b, int trans_b,
+                       float *C, int ldc, int64_t stride_c,
+                       const float *bias, int flags, int ksplit, float *workspace, float drop_p, uint32_t drop_seed, void *stream);
+/* Backward of that epilogue in one pass: dz = dy * [relu: y > 0] * [dropout keep / (1 - p)], y = the forward output
+ * (with ReLU + dropout a positive output is "active and kept"; without ReLU the mask is recomputed from the seed). */
+int emloco_act_bwd(int64_t total, const float *dy, const float *y, int relu, float drop_p, uint32_t drop_seed, float *dz, void *stream);
 
 /* Row softmax of attention scores with an additive per-key bias (nn.MultiheadAttention's key_padding_mask):
  *   P[r][j] = softmax_j(scale * S[r][j] + key_bias[seq(r)][j]);  a row whose keys are all -inf gives zeros.

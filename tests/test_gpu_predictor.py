@@ -240,3 +240,38 @@ def test_train_loop_over_dataset_files_and_checkpoint_round_trip(tmp_path):
     m2 = mk()
     assert load_checkpoint(m2, path, strict=True) == 3
     assert abs(evaluate_loss(m2, dl, cfg) - l1) <= 1e-5 * max(1.0, l1)
+
+
+def test_fused_dropout_epilogue_and_backward():
+    """nn.Dropout folded into the GEMM epilogue: keep fraction and 1/(1-p) scaling, determinism per seed, and the backward
+    mask (recomputed from the seed, or read off the ReLU+dropout output) against an explicit mask."""
+    from emloco_amd.predictor import ops
+    torch.manual_seed(0)
+    M, K, N, p = 4096, 64, 256, 0.1
+    x = torch.rand(M, K, device="cuda:0") + 0.1            # positive inputs / weights -> every pre-activation is > 0
+    W = (torch.rand(N, K, device="cuda:0") + 0.1).requires_grad_(True)
+    b = torch.rand(N, device="cuda:0").requires_grad_(True)
+    ref = x @ W.t() + b
+    for relu in (False, True):
+        y = ops.LinearFn.apply(x, W, b, relu, p, 1234)
+        y2 = ops.LinearFn.apply(x, W, b, relu, p, 1234)
+        y3 = ops.LinearFn.apply(x, W, b, relu, p, 1235)
+        assert torch.equal(y, y2) and not torch.equal(y, y3)
+        keep = y != 0
+        assert abs(keep.float().mean().item() - (1 - p)) < 0.01
+        _close((y[keep] * (1 - p)).detach().cpu(), ref[keep].detach().cpu(), rel=1e-5, what="kept values scaled by 1/(1-p)")
+        dy = torch.randn(M, N, device="cuda:0")
+        gW, gb = torch.autograd.grad(y, (W, b), dy)
+        dz = dy * keep / (1 - p)
+        _close(gW.cpu(), (dz.t() @ x).cpu(), rel=1e-4, what="dW through the fused mask")
+        _close(gb.cpu(), dz.sum(0).cpu(), rel=1e-4, what="db through the fused mask")
+    # training-mode encoder layer runs and differs between calls; eval mode is unchanged by the fusion
+    from emloco_amd.predictor.model_jta import EncoderLayer
+    layer = EncoderLayer(128, 4, 256, 0.1).to("cuda:0")
+    xin = torch.randn(3, 50, 128, device="cuda:0")
+    pad = torch.zeros(3, 50, device="cuda:0")
+    layer.train()
+    o1, o2 = layer(xin, pad), layer(xin, pad)
+    assert not torch.equal(o1, o2) and torch.isfinite(o1).all()
+    layer.eval()
+    assert torch.equal(layer(xin, pad), layer(xin, pad))
