@@ -197,6 +197,19 @@ int emloco_attention_bwd(int n_seq, int S, int nhead, int d_model, float scale, 
     return 0;
 }
 
+int emloco_act_bwd_colsum(int m, int n, const float *dy, const float *y, int relu, float drop_p, uint32_t drop_seed, float *dz,
+                          float *colsum, float *workspace, void *stream) {
+    if (m < 1 || n < 1 || !dy || !dz || !colsum || !workspace || (relu && !y) || !(drop_p >= 0.0f && drop_p < 1.0f))
+        return pfail(-1, "emloco_act_bwd_colsum: bad argument (workspace = emloco_colsum_workspace(m, n) floats)");
+    const int nparts = (m + CS_ROWS - 1) / CS_ROWS;
+    hipLaunchKernelGGL(emloco::act_bwd_colsum_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream,
+                       m, n, dy, y, relu, drop_p, drop_seed, dz, workspace);
+    PHIPCHK(hipGetLastError());
+    emloco::fold_rows(FoldLaunch{(hipStream_t)stream}, nparts, n, workspace, colsum, colsum, n);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
 int emloco_obs_normalize(int rows, int cols, const float *x, int ldx, const float *mean, const float *var, float eps,
                          float clip, int split, float *out0, int ld0, float *out1, int ld1, void *stream) {
     if (rows < 1 || cols < 1 || !x || !mean || !var || !out0 || split < 0 || split > cols || (split < cols && !out1) ||

@@ -429,6 +429,26 @@ __global__ void colsum_partial_kernel(int m, int n, const float *X, float *part)
     part[(long)blockIdx.y * n + j] = s;
 }
 
+// act_bwd + bias gradient in one pass: thread j walks 256 rows of column j (coalesced across j), writes dz and leaves the
+// column partial sum for the fixed-order row folding (replaces act_bwd_kernel + colsum_partial_kernel: one read of dz less).
+__global__ void act_bwd_colsum_kernel(int m, int n, const float *dy, const float *y, int relu, float drop_p, unsigned drop_seed,
+                                      float *dz, float *part) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long r0 = (long)blockIdx.y * CS_ROWS;
+    const float inv = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    float s = 0.0f;
+    for (int r = 0; r < CS_ROWS && r0 + r < m; ++r) {
+        const long i = (r0 + r) * n + j;
+        float v = dy[i];
+        if (relu) v = y[i] > 0.0f ? v : 0.0f;
+        if (drop_p > 0.0f) v = (relu || drop_keep(drop_seed, (unsigned long long)i, drop_p)) ? v * inv : 0.0f;
+        dz[i] = v;
+        s += v;
+    }
+    part[(long)blockIdx.y * n + j] = s;
+}
+
 // ------------------------------------------------------------------ observation normaliser (policy input, A19)
 // RunningMeanStd.forward in eval mode (pacer/pacer/utils/running_mean_std.py:81-83):
 //   y = clamp((x - float(mean)) / sqrt(float(var) + eps), -5, 5)

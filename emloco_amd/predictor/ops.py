@@ -22,6 +22,7 @@ def _lib():
         lib.emloco_gemm_f32.argtypes = [ci, ci, ci, ci, cf, vp, ci, cl, ci, vp, ci, cl, ci, vp, ci, cl, vp, ci, ci, vp, vp]
         lib.emloco_gemm_f32_ex.argtypes = [ci, ci, ci, ci, cf, vp, ci, cl, ci, vp, ci, cl, ci, vp, ci, cl, vp, ci, ci, vp, cf, C.c_uint32, vp]
         lib.emloco_act_bwd.argtypes = [cl, vp, vp, ci, cf, C.c_uint32, vp, vp]
+        lib.emloco_act_bwd_colsum.argtypes = [ci, ci, vp, vp, ci, cf, C.c_uint32, vp, vp, vp, vp]
         lib.emloco_softmax_fwd.argtypes = [ci, ci, ci, cf, vp, vp, vp, vp]
         lib.emloco_softmax_bwd.argtypes = [ci, ci, cf, vp, vp, vp, vp]
         lib.emloco_layernorm_fwd.argtypes = [ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -121,11 +122,18 @@ class LinearFn(torch.autograd.Function):
         N = W.shape[0]
         dy2 = dy.contiguous().view(M, N)
         p, seed = ctx.drop
+        dx = dW = db = None
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.relu or p > 0.0:
             dz = torch.empty_like(dy2)
-            _chk(_lib().emloco_act_bwd(M * N, _p(dy2), _p(y), 1 if ctx.relu else 0, p, seed & 0xFFFFFFFF, _p(dz), _st(dy2)), "emloco_act_bwd")
+            if need_db:                                  # masks and bias gradient in one pass over dy
+                db = torch.empty(N, dtype=torch.float32, device=dy.device)
+                ws = torch.empty(_lib().emloco_colsum_workspace(M, N), dtype=torch.float32, device=dy.device)
+                _chk(_lib().emloco_act_bwd_colsum(M, N, _p(dy2), _p(y), 1 if ctx.relu else 0, p, seed & 0xFFFFFFFF, _p(dz), _p(db),
+                                                  _p(ws), _st(dy2)), "emloco_act_bwd_colsum")
+            else:
+                _chk(_lib().emloco_act_bwd(M * N, _p(dy2), _p(y), 1 if ctx.relu else 0, p, seed & 0xFFFFFFFF, _p(dz), _st(dy2)), "emloco_act_bwd")
             dy2 = dz
-        dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
             gemm(1, M, K, N, dy2, N, 0, 0, W, K, 0, 1, dx, K, 0)          # dx = dy W
@@ -133,7 +141,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
             gemm(1, N, K, M, dy2, N, 0, 1, x2, K, 0, 1, dW, K, 0, ksplit=_ksplit_for(M, N * K))   # dW = dy^T x
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if need_db and db is None:
             db = colsum(dy2)
         return dx, dW, db, None, None, None
 

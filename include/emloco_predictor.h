@@ -41,6 +41,9 @@ int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha,
 /* Backward of that epilogue in one pass: dz = dy * [relu: y > 0] * [dropout keep / (1 - p)], y = the forward output
  * (with ReLU + dropout a positive output is "active and kept"; without ReLU the mask is recomputed from the seed). */
 int emloco_act_bwd(int64_t total, const float *dy, const float *y, int relu, float drop_p, uint32_t drop_seed, float *dz, void *stream);
+/* the same for a [m][n] gradient plus the bias gradient colsum[n] = sum_m dz (fixed-order folding; workspace as emloco_colsum) */
+int emloco_act_bwd_colsum(int m, int n, const float *dy, const float *y, int relu, float drop_p, uint32_t drop_seed, float *dz,
+                          float *colsum, float *workspace, void *stream);
 
 /* Row softmax of attention scores with an additive per-key bias (nn.MultiheadAttention's key_padding_mask):
  *   P[r][j] = softmax_j(scale * S[r][j] + key_bias[seq(r)][j]);  a row whose keys are all -inf gives zeros.
