@@ -202,7 +202,7 @@ int emloco_act_bwd_colsum(int m, int n, const float *dy, const float *y, int rel
     if (m < 1 || n < 1 || !dy || !dz || !colsum || !workspace || (relu && !y) || !(drop_p >= 0.0f && drop_p < 1.0f))
         return pfail(-1, "emloco_act_bwd_colsum: bad argument (workspace = emloco_colsum_workspace(m, n) floats)");
     const int nparts = (m + CS_ROWS - 1) / CS_ROWS;
-    hipLaunchKernelGGL(emloco::act_bwd_colsum_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(emloco::act_bwd_colsum_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream,
                        m, n, dy, y, relu, drop_p, drop_seed, dz, workspace);
     PHIPCHK(hipGetLastError());
     emloco::fold_rows(FoldLaunch{(hipStream_t)stream}, nparts, n, workspace, colsum, colsum, n);

@@ -431,22 +431,29 @@ __global__ void colsum_partial_kernel(int m, int n, const float *X, float *part)
 
 // act_bwd + bias gradient in one pass: thread j walks 256 rows of column j (coalesced across j), writes dz and leaves the
 // column partial sum for the fixed-order row folding (replaces act_bwd_kernel + colsum_partial_kernel: one read of dz less).
-__global__ void act_bwd_colsum_kernel(int m, int n, const float *dy, const float *y, int relu, float drop_p, unsigned drop_seed,
-                                      float *dz, float *part) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+__global__ void __launch_bounds__(256)
+act_bwd_colsum_kernel(int m, int n, const float *dy, const float *y, int relu, float drop_p, unsigned drop_seed,
+                      float *dz, float *part) {
+    // 256 threads = 64 columns x 4 row phases (a wave reads 64 consecutive floats of a row); the four phase sums of a column
+    // are added in a fixed order through LDS, so narrow matrices (n = 128) still fill the chip.
+    __shared__ float sh[4][64];
+    const int jl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jl;
     const long r0 = (long)blockIdx.y * CS_ROWS;
     const float inv = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
     float s = 0.0f;
-    for (int r = 0; r < CS_ROWS && r0 + r < m; ++r) {
-        const long i = (r0 + r) * n + j;
-        float v = dy[i];
-        if (relu) v = y[i] > 0.0f ? v : 0.0f;
-        if (drop_p > 0.0f) v = (relu || drop_keep(drop_seed, (unsigned long long)i, drop_p)) ? v * inv : 0.0f;
-        dz[i] = v;
-        s += v;
-    }
-    part[(long)blockIdx.y * n + j] = s;
+    if (j < n)
+        for (int r = ph; r < CS_ROWS && r0 + r < m; r += 4) {
+            const long i = (r0 + r) * n + j;
+            float v = dy[i];
+            if (relu) v = y[i] > 0.0f ? v : 0.0f;
+            if (drop_p > 0.0f) v = (relu || drop_keep(drop_seed, (unsigned long long)i, drop_p)) ? v * inv : 0.0f;
+            dz[i] = v;
+            s += v;
+        }
+    sh[ph][jl] = s;
+    __syncthreads();
+    if (ph == 0 && j < n) part[(long)blockIdx.y * n + j] = (sh[0][jl] + sh[1][jl]) + (sh[2][jl] + sh[3][jl]);
 }
 
 // ------------------------------------------------------------------ observation normaliser (policy input, A19)
