@@ -90,3 +90,27 @@ class LocoValRollout:
                 self.vnet_fits += 1
                 self.game_combined_rewards = torch.zeros_like(self.game_combined_rewards)
         return self.vnet_loss
+
+    # ------------------------------------------------------------------ checkpoints (common_agent.py:248-264, finetune branch)
+    def save(self, model_output_file, epoch_num=None):
+        """`<file>_valuenet.pth`, or `<file>_valuenet_<epoch:08d>.pth` for the intermediate checkpoints: a plain state_dict
+        with the reference's keys (`_network.fc{1,2,3}.{weight,bias}`), loadable by train_jta.py / evaluate_jta.py."""
+        path = model_output_file + ("_valuenet.pth" if epoch_num is None else "_valuenet_" + str(epoch_num).zfill(8) + ".pth")
+        torch.save({k: v.detach().cpu() for k, v in self.valuenet.state_dict().items()}, path)
+        return path
+
+    def restore(self, path):
+        self.valuenet.load_state_dict(torch.load(path, map_location=self.device))
+
+    def train(self, max_epochs, model_output_file=None, save_freq=200, save_intermediate=True):
+        """The finetune loop of CommonAgent.train: one epoch = one play_steps horizon."""
+        for epoch_num in range(1, max_epochs + 1):
+            self.play_steps()
+            if model_output_file and save_freq > 0 and epoch_num % save_freq == 0:
+                self.save(model_output_file)
+                if save_intermediate and epoch_num % (save_freq * 5) == 0:
+                    self.save(model_output_file, epoch_num)
+        if model_output_file:
+            self.save(model_output_file)
+        return self.vnet_loss
+

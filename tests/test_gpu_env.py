@@ -108,6 +108,17 @@ def test_locoval_rollout_fits_value_function():
     assert agent.vnet_fits > 0 and np.isfinite(agent.vnet_loss)
     assert not torch.equal(w0, agent.valuenet._network.fc1.weight)      # the optimiser really stepped
     assert agent.frames == 6 * 16 * 128
+    # checkpoint in the reference's layout and naming (common_agent.py:252,264): a plain state_dict
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        p1 = agent.save(os.path.join(d, "Humanoid"))
+        p2 = agent.save(os.path.join(d, "Humanoid"), 25000)
+        assert p1.endswith("Humanoid_valuenet.pth") and p2.endswith("Humanoid_valuenet_00025000.pth")
+        sd = torch.load(p2)
+        assert list(sd) == ["_network.fc1.weight", "_network.fc1.bias", "_network.fc2.weight", "_network.fc2.bias", "_network.fc3.weight", "_network.fc3.bias"]
+        agent2 = LocoValRollout(env, horizon_length=16)
+        agent2.restore(p2)
+        assert torch.equal(agent2.valuenet._network.fc1.weight, agent.valuenet._network.fc1.weight)
 
 
 def test_rollout_with_frozen_policy_and_disc_reward(tmp_path):
