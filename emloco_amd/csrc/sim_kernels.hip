@@ -512,8 +512,8 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         PSTAMP(5);
         // ============================================================ 6a. rows: Jacobian, rhs, chain propagation (lane = row)
         float J[6] = {0, 0, 0, 0, 0, 0}, rhs = 0.0f, lam = 0.0f;
-        float ys[YLEN];                                   // this row's chain-propagation vector, kept in registers
-        for (int k = 0; k < YLEN; ++k) ys[k] = 0.0f;
+        float ys[YLEN];                                   // this row's chain-propagation vector (level-indexed: the compiler keeps it in
+                                                          // scratch); entries beyond the row's own chain are never written NOR read
         const int myc = lane / 3, myd = lane - 3 * myc;
         int rbody = 0;
         if (lane < nr) {
@@ -572,7 +572,8 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             typedef float sim_f32x16 __attribute__((vector_size(64)));
             const int h = lane >> 5, j31 = lane & 31;
             sh_rowb[lane] = (unsigned char)((lane < nr) ? rbody : NB);
-            int mydep = (lane < nr) ? sh_dep[rbody] : 0;
+            const int own_dep = (lane < nr) ? sh_dep[rbody] : -1;          // -1: no row in this lane (all operands zero)
+            int mydep = own_dep < 0 ? 0 : own_dep;
             for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(mydep, off); mydep = o > mydep ? o : mydep; }
             const int dmax = __builtin_amdgcn_readfirstlane(mydep);           // deepest chain among the contact bodies
             __syncthreads();
@@ -599,11 +600,14 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tr ? op1_ : op0_, tc ? op1_ : op0_, acc, 0, 0, 0);      \
                 }
 #define GRAM_SNAP(L) for (int r = 0; r < 16; ++r) res[r] = (lc[r] == (L)) ? acc[r] : res[r];
-                GRAM_STEP(ys[0], ys[1]) GRAM_STEP(ys[2], ys[3]) GRAM_STEP(ys[4], ys[5])
+                const bool has_row = own_dep >= 0;
+                GRAM_STEP(has_row ? ys[0] : 0.0f, has_row ? ys[1] : 0.0f) GRAM_STEP(has_row ? ys[2] : 0.0f, has_row ? ys[3] : 0.0f)
+                GRAM_STEP(has_row ? ys[4] : 0.0f, has_row ? ys[5] : 0.0f)
                 GRAM_SNAP(0)
                 for (int lev = 0; lev < 8; ++lev) {
                     if (lev >= dmax) break;
-                    GRAM_STEP(ys[6 + 3 * lev], ys[7 + 3 * lev]) GRAM_STEP(ys[8 + 3 * lev], 0.0f)
+                    const bool on_chain = lev < own_dep;            // the row's chain has a joint at this tree level
+                    GRAM_STEP(on_chain ? ys[6 + 3 * lev] : 0.0f, on_chain ? ys[7 + 3 * lev] : 0.0f) GRAM_STEP(on_chain ? ys[8 + 3 * lev] : 0.0f, 0.0f)
                     GRAM_SNAP(lev + 1)
                 }
 #undef GRAM_STEP
