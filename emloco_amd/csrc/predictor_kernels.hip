@@ -104,11 +104,27 @@ __device__ __forceinline__ void gemm_stash(const f32x4 (&v)[(ROWS * GBK / 4 + 25
             if (!TRANS) {
                 const int r = idx / QR, q = idx - r * QR;
                 *(f32x4 *)&S[r * GLDK + 4 * q] = v[e];
-            } else {
+            } else {                                           // row-contiguous operand: LDS stage is k-major [k][ROWS + 4]
                 const int kk = idx / (ROWS / 4), rq = idx - kk * (ROWS / 4);
-                float *d = &S[(4 * rq) * GLDK + kk];
-                d[0] = v[e].x; d[GLDK] = v[e].y; d[2 * GLDK] = v[e].z; d[3 * GLDK] = v[e].w;
+                *(f32x4 *)&S[kk * (ROWS + 4) + 4 * rq] = v[e];
             }
+        }
+    }
+}
+
+// A lane's fragment values of one 32-row block for a stage: k in [half8, half8 + GBK/2).  [row][k] stages give them as
+// GBK/8 ds_read_b128 of one LDS row; k-major stages (TRANS operands, stored with one ds_write_b128 per fetched quad instead
+// of four scattered ds_write_b32) as conflict-free ds_read_b32 of 32 consecutive rows.
+template <int ROWS, int GBK, int TRANS>
+__device__ __forceinline__ void gemm_frag(const float *S, int row, int half8, f32x4 (&out)[GBK / 8]) {
+    if (!TRANS) {
+        const float *src = S + row * (GBK + 4) + half8;
+        for (int f = 0; f < GBK / 8; ++f) out[f] = *(const f32x4 *)(src + 4 * f);
+    } else {
+        const float *src = S + half8 * (ROWS + 4) + row;
+        for (int f = 0; f < GBK / 8; ++f) {
+            out[f].x = src[(4 * f) * (ROWS + 4)]; out[f].y = src[(4 * f + 1) * (ROWS + 4)];
+            out[f].z = src[(4 * f + 2) * (ROWS + 4)]; out[f].w = src[(4 * f + 3) * (ROWS + 4)];
         }
     }
 }
@@ -160,14 +176,8 @@ gemm_f32_kernel(GemmArgs g) {
         gemm_fetch<BM, GBK, TA, VEC>(ra, A, g.lda, m0, g.m, k0 + GBK, ke, tid);
         gemm_fetch<BN, GBK, TB, VEC>(rb, B, g.ldb, n0, g.n, k0 + GBK, ke, tid);
         f32x4 fa[TI][NF], fb[TJ][NF];
-        for (int i = 0; i < TI; ++i) {
-            const float *src = &As[buf][((wm * TI + i) * 32 + l31) * GLDK + half8];
-            for (int f = 0; f < NF; ++f) fa[i][f] = *(const f32x4 *)(src + 4 * f);
-        }
-        for (int j = 0; j < TJ; ++j) {
-            const float *src = &Bs[buf][((wn * TJ + j) * 32 + l31) * GLDK + half8];
-            for (int f = 0; f < NF; ++f) fb[j][f] = *(const f32x4 *)(src + 4 * f);
-        }
+        for (int i = 0; i < TI; ++i) gemm_frag<BM, GBK, TA>(As[buf], (wm * TI + i) * 32 + l31, half8, fa[i]);
+        for (int j = 0; j < TJ; ++j) gemm_frag<BN, GBK, TB>(Bs[buf], (wn * TJ + j) * 32 + l31, half8, fb[j]);
 #define GEMM_STEP(H, C)                                                                                          \
         for (int i = 0; i < TI; ++i)                                                                             \
             for (int j = 0; j < TJ; ++j)                                                                         \
