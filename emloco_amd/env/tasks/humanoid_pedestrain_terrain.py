@@ -12,7 +12,9 @@ from scipy import ndimage
 from ... import _lib as L
 from ...gym import gymapi
 from ...gym import torch_utils as tu
-from ...gym.terrain_utils import convert_heightfield_to_trimesh
+from ...gym.terrain_utils import (SubTerrain, convert_heightfield_to_trimesh, discrete_obstacles_terrain, pyramid_sloped_terrain,
+                                  pyramid_stairs_terrain, random_uniform_terrain, stepping_stones_terrain)
+from ...utils.draw_utils import draw_curve, draw_disk, draw_ellipse, draw_polygon
 from ...utils.flags import flags
 from . import humanoid_traj
 
@@ -287,11 +289,35 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         return
 
 
+def poles_terrain(terrain, difficulty=1):                           # :937-993
+    """Obstacle course of thin tall shapes: up to 10m disks always, then with probability p each a batch of 3m curves,
+    m polygons and 5m ellipses (m = width // 80), every shape kept with probability p and raised by U[200, 500)
+    vertical units; p = [0.9, 0.4, 0.5, 0.5] * (0.5 + 0.5 * difficulty).  Rasterisation: utils/draw_utils.py."""
+    img = np.zeros((terrain.width, terrain.length), dtype=int)
+    probs = np.array([0.9, 0.4, 0.5, 0.5]) * (0.5 * difficulty + 0.5)
+    low, high = 200, 500
+    m = int(terrain.width // 80)
+    batches = [(10 * m, lambda: draw_disk(img_size=terrain.width, max_r=7)),
+               (3 * m, lambda: draw_curve(img_size=terrain.width)),
+               (1 * m, lambda: draw_polygon(img_size=terrain.width, max_sides=5)),
+               (5 * m, lambda: draw_ellipse(img_size=terrain.width, max_size=5))]
+    for k, (count, draw) in enumerate(batches):
+        p = probs[k]
+        if k > 0 and not np.random.binomial(1, p):                  # the disks have no batch-level gate
+            continue
+        for _ in range(count):
+            if np.random.binomial(1, p):
+                img += draw() * int(np.random.uniform(low, high))
+    terrain.height_field_raw[0:terrain.width, 0:terrain.length] = img
+    return terrain
+
+
 class Terrain:
     """Height-field terrain (mirror of humanoid_pedestrain_terrain.py:1135-1463): int16 height samples at 0.1 m /
-    0.005 m resolution with a 50 m border, a walkable mask, and sampling helpers.  The shaped sub-terrains
-    (slopes, stairs, stepping stones, poles) are listed under 'next'; the BASELINE configs use the flat one
-    (terrainProportions [0,0,0,0,0,0,0,1], pacer.yaml:84)."""
+    0.005 m resolution with a 50 m border, one sub-terrain per (level, terrain) cell drawn from `terrainProportions`
+    ([pyramid slope, slope + noise, stairs down, stairs up, discrete obstacles, stepping stones, poles, flat]), a
+    walkable mask, and sampling helpers.  Random draws follow the reference's `np.random` call order, so a seeded map
+    equals the reference's (tests/golden/terrain_layout.npz)."""
 
     def __init__(self, cfg, num_robots, device) -> None:
         self.type = cfg["terrainType"]
@@ -304,11 +330,10 @@ class Terrain:
         self.env_length = cfg["mapLength"]
         self.env_width = cfg["mapWidth"]
         self.proportions = [np.sum(cfg["terrainProportions"][:i + 1]) for i in range(len(cfg["terrainProportions"]))]
-        if abs(cfg["terrainProportions"][-1] - 1.0) > 1e-9:
-            raise NotImplementedError("emloco round 1: flat terrain only (terrainProportions [...,1])")
         self.env_rows = cfg["numLevels"]
         self.env_cols = cfg["numTerrains"]
         self.num_maps = self.env_rows * self.env_cols
+        self.env_origins = np.zeros((self.env_rows, self.env_cols, 3))
         self.width_per_env_pixels = int(self.env_width / self.horizontal_scale)
         self.length_per_env_pixels = int(self.env_length / self.horizontal_scale)
         self.border = int(self.border_size / self.horizontal_scale)
@@ -316,13 +341,21 @@ class Terrain:
         self.tot_rows = int(self.env_rows * self.length_per_env_pixels) + 2 * self.border
         self.height_field_raw = np.zeros((self.tot_rows, self.tot_cols), dtype=np.int16)
         self.walkable_field_raw = np.zeros((self.tot_rows, self.tot_cols), dtype=np.int16)
-        self.walkable_field_raw = ndimage.binary_dilation(self.walkable_field_raw, iterations=3).astype(int)
+        if cfg["curriculum"]:
+            self.curiculum(num_robots, num_terrains=self.env_cols, num_levels=self.env_rows)
+        else:
+            self.randomized_terrain()
         self.heightsamples = torch.from_numpy(self.height_field_raw).to(self.device)
         self.walkable_field = torch.from_numpy(self.walkable_field_raw).to(self.device)
-        # collision mesh: the flat field is two triangles (a full-resolution mesh of a flat plane adds nothing)
-        ex, ey = (self.tot_rows - 1) * self.horizontal_scale, (self.tot_cols - 1) * self.horizontal_scale
-        self.vertices = np.array([[0, 0, 0], [ex, 0, 0], [0, ey, 0], [ex, ey, 0]], dtype=np.float32)
-        self.triangles = np.array([[0, 3, 1], [0, 2, 3]], dtype=np.uint32)
+        self.is_flat = not self.height_field_raw.any()
+        if self.is_flat:
+            # collision mesh of a flat field: two triangles (a full-resolution mesh of a plane adds nothing)
+            ex, ey = (self.tot_rows - 1) * self.horizontal_scale, (self.tot_cols - 1) * self.horizontal_scale
+            self.vertices = np.array([[0, 0, 0], [ex, 0, 0], [0, ey, 0], [ex, ey, 0]], dtype=np.float32)
+            self.triangles = np.array([[0, 3, 1], [0, 2, 3]], dtype=np.uint32)
+        else:
+            self.vertices, self.triangles = convert_heightfield_to_trimesh(
+                self.height_field_raw, self.horizontal_scale, self.vertical_scale, cfg["slopeTreshold"])
         self.sample_extent_x = int((self.tot_rows - self.border * 2) * self.horizontal_scale)
         self.sample_extent_y = int((self.tot_cols - self.border * 2) * self.horizontal_scale)
         coord_x, coord_y = torch.where(self.walkable_field == 0)
@@ -333,6 +366,55 @@ class Terrain:
         self.coord_x_scale = cx[sub]
         self.coord_y_scale = cy[sub]
         self.num_samples = self.coord_x_scale.shape[0]
+
+    # ------------------------------------------------------------------ sub-terrain layout (:1299-1463)
+    def _place(self, i, j, choice, difficulty):
+        """One (level i, terrain j) cell: pick the generator by `choice` against the cumulative proportions, scale it
+        by `difficulty`, write the patch and its spawn origin (highest point of the central 2 m x 2 m)."""
+        P = self.proportions
+        patch = SubTerrain("terrain", width=self.width_per_env_pixels, length=self.width_per_env_pixels,
+                           vertical_scale=self.vertical_scale, horizontal_scale=self.horizontal_scale)
+        slope = difficulty * 0.7
+        step_height = 0.05 + 0.175 * difficulty
+        x0 = self.border + i * self.length_per_env_pixels
+        y0 = self.border + j * self.width_per_env_pixels
+        x1, y1 = x0 + self.length_per_env_pixels, y0 + self.width_per_env_pixels
+        if choice < P[0]:
+            pyramid_sloped_terrain(patch, slope=-slope if choice < 0.05 else slope, platform_size=3.)
+        elif choice < P[1]:
+            pyramid_sloped_terrain(patch, slope=-slope if choice < 0.15 else slope, platform_size=3.)
+            random_uniform_terrain(patch, min_height=-0.1, max_height=0.1, step=0.025, downsampled_scale=0.2)
+        elif choice < P[3]:
+            pyramid_stairs_terrain(patch, step_width=0.31, step_height=-step_height if choice < P[2] else step_height,
+                                   platform_size=3.)
+        elif choice < P[4]:
+            discrete_obstacles_terrain(patch, 0.025 + difficulty * 0.15, 1., 2., 40, platform_size=3.)
+        elif choice < P[5]:
+            stepping_stones_terrain(patch, stone_size=2 - 1.8 * difficulty, stone_distance=0.1, max_height=0., platform_size=3.)
+        elif choice < P[6]:
+            poles_terrain(terrain=patch, difficulty=difficulty)
+            self.walkable_field_raw[x0:x1, y0:y1] = (patch.height_field_raw != 0)
+        # else (choice < P[7]): plain walking terrain
+        self.height_field_raw[x0:x1, y0:y1] = patch.height_field_raw
+        hs = self.horizontal_scale
+        cx0, cx1 = int((self.env_length / 2. - 1) / hs), int((self.env_length / 2. + 1) / hs)
+        cy0, cy1 = int((self.env_width / 2. - 1) / hs), int((self.env_width / 2. + 1) / hs)
+        self.env_origins[i, j] = [(i + 0.5) * self.env_length, (j + 0.5) * self.env_width,
+                                  np.max(patch.height_field_raw[cx0:cx1, cy0:cy1]) * self.vertical_scale]
+
+    def randomized_terrain(self):                                   # :1299-1372: type and difficulty drawn per cell
+        for k in range(self.num_maps):
+            i, j = np.unravel_index(k, (self.env_rows, self.env_cols))
+            choice = np.random.uniform(0, 1)
+            difficulty = np.random.uniform(0.1, 1)
+            self._place(i, j, choice, difficulty)
+        self.walkable_field_raw = ndimage.binary_dilation(self.walkable_field_raw, iterations=3).astype(int)
+
+    def curiculum(self, num_robots, num_terrains, num_levels):      # :1374-1461: type by column, difficulty by level
+        for j in range(num_terrains):
+            for i in range(num_levels):
+                self._place(i, j, j / num_terrains, i / num_levels)
+        self.walkable_field_raw = ndimage.binary_dilation(self.walkable_field_raw, iterations=3).astype(int)
 
     def sample_valid_locations(self, max_num_envs, env_ids, group_num_people=16, sample_groups=False):   # :1196-1210
         idxes = np.random.randint(0, self.num_samples, size=env_ids.shape[0])
