@@ -21,5 +21,10 @@ struct EmlocoSimDev {
     const unsigned char *sc_pairs;            /* [sc_n][2] */
     const float *sc_cap_a, *sc_cap_b, *sc_cap_r;   /* per-env collision capsules [E][24][3|3|1] */
     float sc_k, sc_c, sc_max_pen, sc_pad2_;
+    // height-field ground (hf = NULL: the plane z = ground_z).  hf[ix * hf_ny + iy] in units of hf_vs metres on an
+    // hf_hs-metre grid whose sample (0, 0) sits at world (hf_ox, hf_oy)
+    const short *hf;
+    int hf_nx, hf_ny;
+    float hf_hs, hf_inv_hs, hf_vs, hf_ox, hf_oy, hf_pad_;
     long long *prof;   /* optional (built with -DEMLOCO_SIM_PROFILE): per-phase cycle stamps of env 0, else NULL */
 };

@@ -129,6 +129,19 @@ int emloco_sim_set_self_collision(EmlocoSim *s, const EmlocoSelfCollisionDesc *c
     return EMLOCO_OK;
 }
 
+int emloco_sim_set_ground_heightfield(EmlocoSim *s, const int16_t *samples, int nx, int ny, float horizontal_scale,
+                                      float vertical_scale, float origin_x, float origin_y) {
+    if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_set_ground_heightfield: null sim");
+    if (s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_set_ground_heightfield: sim already prepared");
+    s->h_hf.clear();
+    if (!samples) return EMLOCO_OK;                                   // back to the plane
+    if (nx < 2 || ny < 2 || !(horizontal_scale > 0.0f) || !(vertical_scale > 0.0f))
+        return fail(EMLOCO_E_ARG, "emloco_sim_set_ground_heightfield: need a >= 2 x 2 grid and positive scales");
+    s->h_hf.assign(samples, samples + (size_t)nx * (size_t)ny);
+    s->hf_nx = nx; s->hf_ny = ny; s->hf_hs = horizontal_scale; s->hf_vs = vertical_scale; s->hf_ox = origin_x; s->hf_oy = origin_y;
+    return EMLOCO_OK;
+}
+
 int emloco_sim_prepare(EmlocoSim *s) {
     if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_prepare: null sim");
     if (!s->have_model) return fail(EMLOCO_E_STATE, "emloco_sim_prepare: no models set");
@@ -181,6 +194,12 @@ int emloco_sim_prepare(EmlocoSim *s) {
         d.sc_n = (int)(s->h_sc_pairs.size() / 2);
         d.sc_pairs = s->d_sc_pairs.p; d.sc_cap_a = s->d_sc_a.p; d.sc_cap_b = s->d_sc_b.p; d.sc_cap_r = s->d_sc_r.p;
         d.sc_k = s->sc_k; d.sc_c = s->sc_c; d.sc_max_pen = s->sc_max_pen;
+    }
+    d.hf = nullptr;
+    if (!s->h_hf.empty()) {
+        HIPCHK(s->d_hf.upload(s->h_hf.data(), s->h_hf.size()));
+        d.hf = s->d_hf.p; d.hf_nx = s->hf_nx; d.hf_ny = s->hf_ny;
+        d.hf_hs = s->hf_hs; d.hf_inv_hs = 1.0f / s->hf_hs; d.hf_vs = s->hf_vs; d.hf_ox = s->hf_ox; d.hf_oy = s->hf_oy; d.hf_pad_ = 0.0f;
     }
     HIPCHK(hipDeviceSynchronize());
     s->prepared = true;

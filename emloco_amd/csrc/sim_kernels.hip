@@ -52,6 +52,26 @@ __device__ __forceinline__ constexpr int sidx(int a, int b) {
 #define PSTAMP(i) do { } while (0)
 #endif
 
+// Height-field ground under the world point (cx, cy): height zt of the cell triangle's plane there and its unit normal.
+// Cell (i, j) holds the mesh triangles (v00, v10, v11) [u >= v] and (v00, v11, v01) [u < v] (u, v: position in the cell
+// along x, y), as terrain_utils.convert_heightfield_to_trimesh lays them out; beyond the map the border cell's plane extends.
+__device__ __forceinline__ void hf_plane(const EmlocoSimDev &d, float cx, float cy, float &zt, float n[3]) {
+    const float gx = (cx - d.hf_ox) * d.hf_inv_hs, gy = (cy - d.hf_oy) * d.hf_inv_hs;
+    int i = (int)floorf(gx), j = (int)floorf(gy);
+    i = i < 0 ? 0 : (i > d.hf_nx - 2 ? d.hf_nx - 2 : i);
+    j = j < 0 ? 0 : (j > d.hf_ny - 2 ? d.hf_ny - 2 : j);
+    const float u = gx - (float)i, v = gy - (float)j;
+    const short *c = d.hf + (long)i * d.hf_ny + j;
+    const float h00 = d.hf_vs * (float)c[0], h01 = d.hf_vs * (float)c[1];
+    const float h10 = d.hf_vs * (float)c[d.hf_ny], h11 = d.hf_vs * (float)c[d.hf_ny + 1];
+    float zx, zy;
+    if (u >= v) { zx = h10 - h00; zy = h11 - h10; } else { zy = h01 - h00; zx = h11 - h01; }
+    zt = fmaf(v, zy, fmaf(u, zx, h00));
+    const float sx = zx * d.hf_inv_hs, sy = zy * d.hf_inv_hs;
+    const float inv = 1.0f / sqrtf(fmaf(sx, sx, fmaf(sy, sy, 1.0f)));
+    n[0] = 0.0f - sx * inv; n[1] = 0.0f - sy * inv; n[2] = inv;
+}
+
 struct BodyConst {   // per-lane (lane = body) constants kept in registers for the whole launch
     int parent, depth, nchild, child[3];
     float off[3];
@@ -85,6 +105,10 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     __shared__ float sh_fext[NB][6];         // limb-limb penalty wrench per body (self-collision), about O
     // body inertia / bias force handed from phase 2 to phase 3 through LDS; they alias the contact matrix, which is
     // only live in phases 6b-6c (barriers separate the phases)
+    // contact frames [normal | tangent 1 | tangent 2] on a height-field ground: alias of the articulated inertias, which are
+    // dead between the factorisation (phase 3) and the next substep
+    float (*sh_cdir)[9] = (float (*)[9])&sh_Ia[0][0];
+    const bool hf_on = d.hf != nullptr;      // wave-uniform
     float (*sh_I6)[21] = (float (*)[21])sh_A;
     float (*sh_f)[6] = (float (*)[6])(sh_A + NB * 21);
 
@@ -301,22 +325,22 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             if (d.sc_n > 0) for (int k = 0; k < 6; ++k) f[k] -= sh_fext[lane][k];     // external wrench: f -= [p x F ; F]
             for (int k = 0; k < 21; ++k) sh_I6[lane][k] = I6[k];
             for (int k = 0; k < 6; ++k) sh_f[lane][k] = f[k];
-            // implicit PD drive (saturated drives act as a constant torque)
+            // implicit PD drive: tau~ = kp (q* - q) - (kd + h kp) qd, joint-space diagonal d = armature + h kd + h^2 kp
             for (int k = 0; k < 3; ++k) {
-                float kp[3], kd[3], arm[3], eff[3], tgt[3];
-                kp[k] = lane >= 1 ? d.kp[dof0 + k] : 0.0f; kd[k] = lane >= 1 ? d.kd[dof0 + k] : 0.0f;
-                arm[k] = lane >= 1 ? d.armature[dof0 + k] : 0.0f; eff[k] = lane >= 1 ? d.effort[dof0 + k] : 0.0f;
-                tgt[k] = lane >= 1 ? d.pd_target[dof0 + k] : 0.0f;
-                const float e = tgt[k] - edof[k];
-                const float te = kp[k] * e - kd[k] * wj[k];
-                if (fabsf(te) > eff[k]) { sat[k] = true; tau[k] = te > 0.0f ? eff[k] : -eff[k]; dd[k] = arm[k]; }
-                else { sat[k] = false; tau[k] = kp[k] * e - (kd[k] + h * kp[k]) * wj[k]; dd[k] = arm[k] + h * kd[k] + h * h * kp[k]; }
+                const float kp = lane >= 1 ? d.kp[dof0 + k] : 0.0f, kd = lane >= 1 ? d.kd[dof0 + k] : 0.0f;
+                const float arm = lane >= 1 ? d.armature[dof0 + k] : 0.0f, tgt = lane >= 1 ? d.pd_target[dof0 + k] : 0.0f;
+                const float e = tgt - edof[k];
+                sat[k] = false; tau[k] = kp * e - (kd + h * kp) * wj[k]; dd[k] = arm + h * kd + h * h * kp;
             }
         }
 
         PSTAMP(2);
-        // ============================================================ 3. articulated-body factorisation + up pass (leaves -> root)
+        // Phases 3-4 run once with every drive implicit.  The torque such a drive delivers over the substep is
+        // tau~ - (h kd + h^2 kp) qdd; where that exceeds the effort limit the drive becomes a constant torque at the limit
+        // (no implicit terms) and the env repeats the two phases once (rare: wave-uniform branch per env).
         float pA[6];
+        for (int pass = 0; pass < 2; ++pass) {
+        // ============================================================ 3. articulated-body factorisation + up pass (leaves -> root)
         for (int lev = d.max_depth; lev >= 0; --lev) {
             if (is_body && bc.depth == lev) {
                 float IA[21], Wm[18], Km[6];
@@ -434,6 +458,17 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             }
             __syncthreads();
         }
+        if (pass == 0) {
+            bool over = false;
+            if (is_body && lane >= 1)
+                for (int k = 0; k < 3; ++k) {
+                    const float kp = d.kp[dof0 + k], kd = d.kd[dof0 + k], eff = d.effort[dof0 + k];
+                    const float ti = tau[k] - (h * kd + h * h * kp) * qdd[k];
+                    if (fabsf(ti) > eff) { sat[k] = true; tau[k] = ti > 0.0f ? eff : -eff; dd[k] = d.armature[dof0 + k]; over = true; }
+                }
+            if (__ballot(over) == 0ull) break;
+        }
+        }   // pass
         float wjf[3] = {0, 0, 0}, V0f[6];
         if (is_body) {
             for (int k = 0; k < 6; ++k) sh_Vf[lane][k] = fmaf(h, sh_a[lane][k], sh_V[lane][k]);
@@ -466,7 +501,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 }
             }
         }
-        float cdist[2], cxw[2][3]; bool act[2];
+        float cdist[2], cxw[2][3], cnrm[2][3]; bool act[2];
         for (int s = 0; s < 2; ++s) {
             act[s] = false; cdist[s] = 0.0f;
             if (cb[s] >= 0) {
@@ -474,11 +509,18 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 for (int k = 0; k < 9; ++k) Rb[k] = sh_R[cb[s]][k];
                 matvec3(Rb, clp[s], wp);
                 const float z = sh_pw[cb[s]][2] + wp[2];
-                cdist[s] = (z - prm.ground_z) - crad[s];
+                if (!hf_on) {
+                    cdist[s] = (z - prm.ground_z) - crad[s];
+                    cxw[s][0] = sh_r[cb[s]][0] + wp[0];
+                    cxw[s][1] = sh_r[cb[s]][1] + wp[1];
+                    cxw[s][2] = (sh_r[cb[s]][2] + wp[2]) - crad[s];
+                } else {      // sphere of the candidate against the plane of the terrain triangle under its centre
+                    float zt;
+                    hf_plane(d, sh_pw[cb[s]][0] + wp[0], sh_pw[cb[s]][1] + wp[1], zt, cnrm[s]);
+                    cdist[s] = (z - zt) * cnrm[s][2] - crad[s];
+                    for (int k = 0; k < 3; ++k) cxw[s][k] = (sh_r[cb[s]][k] + wp[k]) - crad[s] * cnrm[s][k];
+                }
                 act[s] = cdist[s] < prm.contact_offset;
-                cxw[s][0] = sh_r[cb[s]][0] + wp[0];
-                cxw[s][1] = sh_r[cb[s]][1] + wp[1];
-                cxw[s][2] = (sh_r[cb[s]][2] + wp[2]) - crad[s];
             }
         }
         unsigned long long m0 = __ballot(act[0]), m1 = __ballot(act[1]);
@@ -504,6 +546,15 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     const int ci = s == 0 ? i0 : i1;
                     sh_cbody[ci] = cb[s]; sh_ccand[ci] = lane + 64 * s; sh_cdist[ci] = cdist[s];
                     for (int k = 0; k < 3; ++k) sh_cx[ci][k] = cxw[s][k];
+                    if (hf_on) {      // frame: normal, t1 = (y x n) / |y x n|, t2 = n x t1  (n_z > 0 on a height field)
+                        const float *n = cnrm[s];
+                        const float il = 1.0f / sqrtf(fmaf(n[2], n[2], n[0] * n[0]));
+                        const float t1x = n[2] * il, t1z = 0.0f - n[0] * il;
+                        float *D = sh_cdir[ci];
+                        D[0] = n[0]; D[1] = n[1]; D[2] = n[2];
+                        D[3] = t1x; D[4] = 0.0f; D[5] = t1z;
+                        D[6] = n[1] * t1z; D[7] = fmaf(n[2], t1x, -(n[0] * t1z)); D[8] = 0.0f - n[1] * t1x;
+                    }
                 }
         }
         __syncthreads();
@@ -519,6 +570,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         if (lane < nr) {
             rbody = sh_cbody[myc];
             float dir[3] = {myd == 1 ? 1.0f : 0.0f, myd == 2 ? 1.0f : 0.0f, myd == 0 ? 1.0f : 0.0f};
+            if (hf_on) for (int k = 0; k < 3; ++k) dir[k] = sh_cdir[myc][3 * myd + k];
             float x[3] = {sh_cx[myc][0], sh_cx[myc][1], sh_cx[myc][2]};
             cross3(x, dir, J);
             J[3] = dir[0]; J[4] = dir[1]; J[5] = dir[2];
@@ -687,7 +739,8 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 for (int c = 0; c < nc; ++c)
                     if (sh_cbody[c] == lane)
                         for (int dr = 0; dr < 3; ++dr) {
-                            const float dir[3] = {dr == 1 ? 1.0f : 0.0f, dr == 2 ? 1.0f : 0.0f, dr == 0 ? 1.0f : 0.0f};
+                            float dir[3] = {dr == 1 ? 1.0f : 0.0f, dr == 2 ? 1.0f : 0.0f, dr == 0 ? 1.0f : 0.0f};
+                            if (hf_on) for (int k = 0; k < 3; ++k) dir[k] = sh_cdir[c][3 * dr + k];
                             const float x[3] = {sh_cx[c][0], sh_cx[c][1], sh_cx[c][2]};
                             float Jr[6];
                             cross3(x, dir, Jr);

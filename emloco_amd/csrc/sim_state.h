@@ -29,6 +29,11 @@ struct EmlocoSim {
     std::vector<unsigned char> h_sc_pairs;
     std::vector<float> h_sc_a, h_sc_b, h_sc_r;
     float sc_k = 0.0f, sc_c = 0.0f, sc_max_pen = 0.0f;
+    // optional height-field ground (host copy until prepare())
+    std::vector<short> h_hf;
+    int hf_nx = 0, hf_ny = 0;
+    float hf_hs = 0.0f, hf_vs = 0.0f, hf_ox = 0.0f, hf_oy = 0.0f;
+    DevBuf<short> d_hf;
     DevBuf<unsigned char> d_sc_pairs;
     DevBuf<float> d_sc_a, d_sc_b, d_sc_r;
     // device

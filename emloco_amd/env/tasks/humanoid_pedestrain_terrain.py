@@ -106,6 +106,9 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         tm_params.static_friction = self.cfg["env"]["terrain"]["staticFriction"]
         tm_params.dynamic_friction = self.cfg["env"]["terrain"]["dynamicFriction"]
         tm_params.restitution = self.cfg["env"]["terrain"]["restitution"]
+        if not self.terrain.is_flat:      # extension: the grid behind the (slope-corrected) mesh, see gymapi.add_triangle_mesh
+            tm_params.heightfield = dict(samples=self.terrain.height_field_raw, horizontal_scale=self.terrain.horizontal_scale,
+                                         vertical_scale=self.terrain.vertical_scale)
         self.gym.add_triangle_mesh(self.sim, self.terrain.vertices.flatten(order='C'),
                                    self.terrain.triangles.flatten(order='C'), tm_params)
         self.height_samples = self.terrain.heightsamples.view(self.terrain.tot_rows, self.terrain.tot_cols).to(self.device)

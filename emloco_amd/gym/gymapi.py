@@ -213,14 +213,49 @@ class Gym:
         sim.friction = float(plane_params.static_friction)
 
     def add_triangle_mesh(self, sim, vertices, triangles, params):   # humanoid_pedestrain_terrain.py:868-880
-        """Terrain collision.  Round 1 collides with the plane z = min height of a FLAT mesh; a mesh that is not
-        flat is rejected loudly (height-field collision is listed under 'next' in DESIGN.md)."""
+        """Terrain collision.  A flat mesh collides as the plane z = its height.  Any other mesh must be a height-field
+        mesh (terrain_utils.convert_heightfield_to_trimesh: vertex i*cols + j carries sample [i][j], triangles
+        (v00, v11, v01) / (v00, v10, v11)); it collides as that height field (emloco_sim_set_ground_heightfield).  The grid
+        is taken from `params.heightfield` = dict(samples, horizontal_scale, vertical_scale) when the caller attaches it (the
+        task does: the slope-corrected mesh moves vertices sideways, so the spacing cannot be read back from it), else it
+        is recovered from an uncorrected regular-grid mesh.  General triangle soups are rejected loudly."""
         v = np.asarray(vertices, dtype=np.float32).reshape(-1, 3)
-        zmin, zmax = float(v[:, 2].min()), float(v[:, 2].max())
-        if zmax - zmin > 1e-6:
-            raise NotImplementedError("emloco round 1: only flat terrain meshes collide (terrainProportions [...,1])")
-        sim.ground_z = zmin + float(params.transform.p.z)
+        tri = np.asarray(triangles).reshape(-1, 3)
         sim.friction = float(params.static_friction)
+        zmin, zmax = float(v[:, 2].min()), float(v[:, 2].max())
+        if zmax - zmin <= 1e-6:
+            sim.ground_z = zmin + float(params.transform.p.z)
+            sim.heightfield = None
+            return
+        if float(params.transform.p.z) != 0.0:
+            raise NotImplementedError("emloco: a height-field mesh with a vertical offset is not supported")
+        hf = getattr(params, "heightfield", None)
+        if hf is None:
+            cols = int(tri[0, 1]) - 1
+            if cols < 2 or v.shape[0] % cols or not np.array_equal(tri[0], [0, cols + 1, 1]):
+                raise NotImplementedError("emloco: only height-field meshes (convert_heightfield_to_trimesh layout) collide")
+            rows = v.shape[0] // cols
+            hs = float(v[cols, 0] - v[0, 0])
+            gx, gy = np.meshgrid(np.arange(rows) * hs, np.arange(cols) * hs, indexing="ij")
+            if hs <= 0 or np.abs(v[:, 0] - gx.ravel() - v[0, 0]).max() > 1e-4 * hs or np.abs(v[:, 1] - gy.ravel() - v[0, 1]).max() > 1e-4 * hs:
+                raise NotImplementedError("emloco: irregular mesh -- attach params.heightfield (samples, horizontal_scale, vertical_scale)")
+            z = v[:, 2].astype(np.float64)
+            nz = np.abs(z[z != 0])
+            vs = float(nz.min()) if nz.size else 1.0
+            q = z / vs
+            if np.abs(q - np.rint(q)).max() > 1e-3 or np.abs(q).max() > 32767:
+                vs = float(zmax - zmin) / 30000.0
+                q = z / vs
+            hf = dict(samples=np.rint(q).astype(np.int16).reshape(rows, cols), horizontal_scale=hs, vertical_scale=vs,
+                      origin_x=float(v[0, 0]), origin_y=float(v[0, 1]))
+        hf = dict(hf)
+        hf["samples"] = np.ascontiguousarray(hf["samples"], dtype=np.int16)
+        if hf["samples"].size != v.shape[0]:
+            raise ValueError("params.heightfield does not match the mesh: %d samples vs %d vertices" % (hf["samples"].size, v.shape[0]))
+        hf["origin_x"] = float(hf.get("origin_x", 0.0)) + float(params.transform.p.x)
+        hf["origin_y"] = float(hf.get("origin_y", 0.0)) + float(params.transform.p.y)
+        sim.heightfield = hf
+        sim.ground_z = 0.0
 
     def load_asset(self, sim, rootpath, filename, options=None):    # humanoid.py:720
         path = os.path.join(rootpath, filename)
@@ -317,7 +352,8 @@ class Gym:
             if self_collision["pairs"].shape[0] == 0:
                 self_collision = None
         try:
-            sim.native = NativeSim(models, _native_params(sim), sim.device_index, self_collision=self_collision)
+            sim.native = NativeSim(models, _native_params(sim), sim.device_index, self_collision=self_collision,
+                                   heightfield=sim.heightfield)
         except L.EmlocoError as e:
             print("***", e)
             return False

@@ -44,9 +44,11 @@ def dptr(t):
 
 
 class NativeSim:
-    def __init__(self, models, params=None, device_index=0, self_collision=None):
+    def __init__(self, models, params=None, device_index=0, self_collision=None, heightfield=None):
         """`self_collision`: None / False = off; True = limb-limb contacts with the defaults of
-        `model.pack_self_collision`; a dict from `pack_self_collision(models, ...)` to choose the parameters."""
+        `model.pack_self_collision`; a dict from `pack_self_collision(models, ...)` to choose the parameters.
+        `heightfield`: None = the plane z = params.ground_z; dict(samples int16 [nx][ny], horizontal_scale, vertical_scale,
+        origin_x=0, origin_y=0) = height-field ground (emloco_sim_set_ground_heightfield)."""
         lib = L.require_device()
         self.lib = lib
         self.device_index = int(device_index)
@@ -80,6 +82,16 @@ class NativeSim:
                                       f(sc["cap_b"]), f(sc["cap_r"]), float(sc["k"]), float(sc["c"]), float(sc["max_pen"]))
             lib.emloco_sim_set_self_collision.argtypes = [C.c_void_p, C.POINTER(L.SelfCollisionDesc)]
             L.check(lib.emloco_sim_set_self_collision(self._h, C.byref(scd)), "emloco_sim_set_self_collision")
+        if heightfield is not None:
+            hf = np.ascontiguousarray(heightfield["samples"], dtype=np.int16)
+            if hf.ndim != 2:
+                raise L.EmlocoError("heightfield samples must be a 2-D int16 array [nx][ny]")
+            lib.emloco_sim_set_ground_heightfield.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                                              C.c_float, C.c_float]
+            L.check(lib.emloco_sim_set_ground_heightfield(
+                self._h, hf.ctypes.data, hf.shape[0], hf.shape[1], float(heightfield["horizontal_scale"]),
+                float(heightfield["vertical_scale"]), float(heightfield.get("origin_x", 0.0)),
+                float(heightfield.get("origin_y", 0.0))), "emloco_sim_set_ground_heightfield")
         L.check(lib.emloco_sim_prepare(self._h), "emloco_sim_prepare")
         self.root_state = self._tensor(L.T_ROOT_STATE)
         self.dof_state = self._tensor(L.T_DOF_STATE)

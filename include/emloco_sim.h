@@ -109,6 +109,14 @@ int emloco_sim_destroy(EmlocoSim *sim);
 int emloco_sim_set_models(EmlocoSim *sim, const EmlocoModelDesc *desc);
 /* gym.prepare_sim -- base_task.py:128: allocates the device state, uploads the models */
 int emloco_sim_set_self_collision(EmlocoSim *sim, const EmlocoSelfCollisionDesc *desc);
+/* gym.add_triangle_mesh for a height-field terrain -- humanoid_pedestrain_terrain.py:859-881 (mesh built by
+ * terrain_utils.convert_heightfield_to_trimesh from Terrain.height_field_raw, :1135-1194).  `samples` is the int16 field
+ * [nx][ny] (first axis = x) in units of `vertical_scale` metres on a `horizontal_scale`-metre grid; sample (0, 0) sits at
+ * world (origin_x, origin_y) (the mesh transform, zero in the reference).  Host pointer, copied.  Each cell collides as the
+ * mesh's two triangles (v00, v10, v11) / (v00, v11, v01); a body's contact sphere is tested against the plane of the
+ * triangle under its centre.  NULL samples restore the plane z = ground_z.  Call before emloco_sim_prepare. */
+int emloco_sim_set_ground_heightfield(EmlocoSim *sim, const int16_t *samples, int nx, int ny, float horizontal_scale,
+                                      float vertical_scale, float origin_x, float origin_y);
 int emloco_sim_prepare(EmlocoSim *sim);
 /* gym.get_sim_params / set_sim_params -- base_task.py:151 */
 int emloco_sim_get_params(EmlocoSim *sim, EmlocoSimParams *out);

@@ -28,8 +28,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        if os.path.exists(os.path.join(_HERE, "oracle_sim.c")):
+            build()                              # no-op unless a source is newer than the library
         _lib = C.CDLL(_SO)
     return _lib
 
@@ -65,14 +65,17 @@ class Model(C.Structure):
                 ("armature", C.POINTER(C.c_float)), ("effort", C.POINTER(C.c_float)),
                 ("sc_n", C.c_int32), ("sc_pairs", C.POINTER(C.c_uint8)), ("sc_cap_a", C.POINTER(C.c_float)),
                 ("sc_cap_b", C.POINTER(C.c_float)), ("sc_cap_r", C.POINTER(C.c_float)), ("sc_k", C.c_float), ("sc_c", C.c_float),
-                ("sc_max_pen", C.c_float)]
+                ("sc_max_pen", C.c_float),
+                ("hf", C.POINTER(C.c_int16)), ("hf_nx", C.c_int32), ("hf_ny", C.c_int32), ("hf_hs", C.c_float), ("hf_vs", C.c_float),
+                ("hf_ox", C.c_float), ("hf_oy", C.c_float)]
 
 
 class Sim:
     """Sequential CPU simulator over the packed model arrays of emloco_amd.model.pack_models()."""
 
-    def __init__(self, packed, params=None, self_collision=None):
-        """`self_collision`: dict from emloco_amd.model.pack_self_collision (pairs, cap_a, cap_b, cap_r, k, c, max_pen) or None."""
+    def __init__(self, packed, params=None, self_collision=None, heightfield=None):
+        """`self_collision`: dict from emloco_amd.model.pack_self_collision (pairs, cap_a, cap_b, cap_r, k, c, max_pen) or None.
+        `heightfield`: dict(samples int16 [nx][ny], horizontal_scale, vertical_scale, origin_x=0, origin_y=0) or None (plane)."""
         self.arr = {k: np.ascontiguousarray(v) for k, v in packed.items()}
         self.sc = None if not self_collision else {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v)
                                                    for k, v in self_collision.items()}
@@ -88,6 +91,13 @@ class Sim:
             self.model.sc_pairs = _p(c["pairs"], C.c_uint8)
             self.model.sc_cap_a, self.model.sc_cap_b, self.model.sc_cap_r = _p(c["cap_a"]), _p(c["cap_b"]), _p(c["cap_r"])
             self.model.sc_k, self.model.sc_c, self.model.sc_max_pen = float(c["k"]), float(c["c"]), float(c["max_pen"])
+        self.hf = None
+        if heightfield is not None:
+            self.hf = np.ascontiguousarray(heightfield["samples"], dtype=np.int16)
+            self.model.hf = _p(self.hf, C.c_int16)
+            self.model.hf_nx, self.model.hf_ny = self.hf.shape
+            self.model.hf_hs, self.model.hf_vs = float(heightfield["horizontal_scale"]), float(heightfield["vertical_scale"])
+            self.model.hf_ox, self.model.hf_oy = float(heightfield.get("origin_x", 0.0)), float(heightfield.get("origin_y", 0.0))
         E = self.E
         self.root_state = np.zeros((E, 13), np.float32)
         self.root_state[:, 6] = 1.0

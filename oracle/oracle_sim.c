@@ -148,6 +148,9 @@ typedef struct {
     const uint8_t *sc_pairs;
     const float *sc_a, *sc_b, *sc_r;
     float sc_k, sc_c, sc_max_pen;
+    const int16_t *hf;
+    int hf_nx, hf_ny;
+    float hf_hs, hf_inv_hs, hf_vs, hf_ox, hf_oy;
 } EnvModel;
 
 static EnvModel env_model(const OrcModel *m, int e) {
@@ -158,6 +161,8 @@ static EnvModel env_model(const OrcModel *m, int e) {
     x.ga = m->geom_a + (long)e * NB * 3; x.gb = m->geom_b + (long)e * NB * 3; x.gr = m->geom_r + (long)e * NB;
     x.kp = m->kp + (long)e * ORC_NDOF; x.kd = m->kd + (long)e * ORC_NDOF;
     x.arm = m->armature + (long)e * ORC_NDOF; x.eff = m->effort + (long)e * ORC_NDOF;
+    x.hf = m->hf; x.hf_nx = m->hf_nx; x.hf_ny = m->hf_ny; x.hf_hs = m->hf_hs; x.hf_vs = m->hf_vs; x.hf_ox = m->hf_ox; x.hf_oy = m->hf_oy;
+    x.hf_inv_hs = m->hf ? 1.0f / m->hf_hs : 0.0f;
     x.sc_n = m->sc_n; x.sc_pairs = m->sc_pairs; x.sc_k = m->sc_k; x.sc_c = m->sc_c; x.sc_max_pen = m->sc_max_pen;
     x.sc_a = m->sc_n > 0 ? m->sc_cap_a + (long)e * NB * 3 : 0;
     x.sc_b = m->sc_n > 0 ? m->sc_cap_b + (long)e * NB * 3 : 0;
@@ -348,24 +353,36 @@ static void bias_and_drive(Env *s, const EnvModel *m, const OrcSimParams *prm, c
         for (int i = 0; i < NB; ++i)
             for (int k = 0; k < 6; ++k) s->f[i][k] -= fext[i][k];
     }
-    /* implicit PD: tau~ = kp (q* - q) - (kd + h kp) qd ; diagonal d = armature + h kd + h^2 kp.
-     * A drive whose explicit torque exceeds the effort limit acts as a constant torque instead. */
+    /* implicit PD: tau~ = kp (q* - q) - (kd + h kp) qd ; diagonal d = armature + h kd + h^2 kp (effort limits: substep()) */
     float h = prm->h;
     for (int i = 1; i < NB; ++i)
         for (int k = 0; k < 3; ++k) {
             int d = (i - 1) * 3 + k;
             float e = tgt[d] - edof[d];
-            float te = m->kp[d] * e - m->kd[d] * s->wj[i][k];
-            if (fabsf(te) > m->eff[d]) {
+            s->sat[i][k] = 0;
+            s->tau[i][k] = m->kp[d] * e - (m->kd[d] + h * m->kp[d]) * s->wj[i][k];
+            s->dd[i][k] = m->arm[d] + h * m->kd[d] + h * h * m->kp[d];
+        }
+}
+
+/* Effort limits.  After a solve with every drive implicit, the torque a drive delivers over the substep is
+ * tau~ - (h kd + h^2 kp) qdd; where that exceeds the limit the drive becomes a constant torque at the limit (no implicit
+ * terms).  Returns whether any drive changed (the caller then factorises and solves once more). */
+static int saturate_drives(Env *s, const EnvModel *m, const OrcSimParams *prm, float (*qdd)[3]) {
+    float h = prm->h;
+    int any = 0;
+    for (int i = 1; i < NB; ++i)
+        for (int k = 0; k < 3; ++k) {
+            int d = (i - 1) * 3 + k;
+            float ti = s->tau[i][k] - (h * m->kd[d] + h * h * m->kp[d]) * qdd[i][k];
+            if (fabsf(ti) > m->eff[d]) {
                 s->sat[i][k] = 1;
-                s->tau[i][k] = te > 0.0f ? m->eff[d] : -m->eff[d];
+                s->tau[i][k] = ti > 0.0f ? m->eff[d] : -m->eff[d];
                 s->dd[i][k] = m->arm[d];
-            } else {
-                s->sat[i][k] = 0;
-                s->tau[i][k] = m->kp[d] * e - (m->kd[d] + h * m->kp[d]) * s->wj[i][k];
-                s->dd[i][k] = m->arm[d] + h * m->kd[d] + h * h * m->kp[d];
+                any = 1;
             }
         }
+    return any;
 }
 
 /* ---------------------------------------------------------------- 3. articulated-body factorisation */
@@ -486,7 +503,28 @@ static void cand_local(const EnvModel *m, int b, int k, float *pt) {
     }
 }
 
-typedef struct { int body, cand; float x[3], dist; } Contact;
+/* contact frame D = [normal | tangent 1 | tangent 2]; the plane ground uses z, x, y */
+typedef struct { int body, cand; float x[3], dist, D[9]; } Contact;
+
+/* height-field ground under the world point (cx, cy): height of the cell triangle's plane there and its unit normal.  Cell
+ * (i, j) holds the mesh triangles (v00, v10, v11) [u >= v] and (v00, v11, v01) [u < v] (terrain_utils.py:286-350 layout);
+ * beyond the map the border cell's plane extends. */
+static void hf_plane(const EnvModel *m, float cx, float cy, float *zt, float *n) {
+    float gx = (cx - m->hf_ox) * m->hf_inv_hs, gy = (cy - m->hf_oy) * m->hf_inv_hs;
+    int i = (int)floorf(gx), j = (int)floorf(gy);
+    i = i < 0 ? 0 : (i > m->hf_nx - 2 ? m->hf_nx - 2 : i);
+    j = j < 0 ? 0 : (j > m->hf_ny - 2 ? m->hf_ny - 2 : j);
+    float u = gx - (float)i, v = gy - (float)j;
+    const int16_t *c = m->hf + (long)i * m->hf_ny + j;
+    float h00 = m->hf_vs * (float)c[0], h01 = m->hf_vs * (float)c[1];
+    float h10 = m->hf_vs * (float)c[m->hf_ny], h11 = m->hf_vs * (float)c[m->hf_ny + 1];
+    float zx, zy;
+    if (u >= v) { zx = h10 - h00; zy = h11 - h10; } else { zy = h01 - h00; zx = h11 - h01; }
+    *zt = fmaf(v, zy, fmaf(u, zx, h00));
+    float sx = zx * m->hf_inv_hs, sy = zy * m->hf_inv_hs;
+    float inv = 1.0f / sqrtf(fmaf(sx, sx, fmaf(sy, sy, 1.0f)));
+    n[0] = 0.0f - sx * inv; n[1] = 0.0f - sy * inv; n[2] = inv;
+}
 
 static int find_contacts(const Env *s, const EnvModel *m, const OrcSimParams *prm, Contact *out) {
     Contact all[ORC_MAXCAND];
@@ -499,11 +537,27 @@ static int find_contacts(const Env *s, const EnvModel *m, const OrcSimParams *pr
             matvec3(s->R[b], lp, wp);
             float rad = m->gr[b];
             float z = s->pw[b][2] + wp[2];
-            float dist = (z - prm->ground_z) - rad;
-            if (dist < prm->contact_offset) {
-                Contact c;
-                c.body = b; c.cand = cid; c.dist = dist;
+            static const float flat[9] = {0, 0, 1, 1, 0, 0, 0, 1, 0};
+            Contact c;
+            float dist;
+            if (!m->hf) {
+                dist = (z - prm->ground_z) - rad;
                 c.x[0] = s->r[b][0] + wp[0]; c.x[1] = s->r[b][1] + wp[1]; c.x[2] = (s->r[b][2] + wp[2]) - rad;
+                memcpy(c.D, flat, sizeof(flat));
+            } else {   /* sphere of the candidate against the plane of the terrain triangle under its centre */
+                float zt, nn[3];
+                hf_plane(m, s->pw[b][0] + wp[0], s->pw[b][1] + wp[1], &zt, nn);
+                dist = (z - zt) * nn[2] - rad;
+                for (int k = 0; k < 3; ++k) c.x[k] = (s->r[b][k] + wp[k]) - rad * nn[k];
+                /* frame: normal, t1 = (y x n) / |y x n|, t2 = n x t1 */
+                float il = 1.0f / sqrtf(fmaf(nn[2], nn[2], nn[0] * nn[0]));
+                float t1x = nn[2] * il, t1z = 0.0f - nn[0] * il;
+                c.D[0] = nn[0]; c.D[1] = nn[1]; c.D[2] = nn[2];
+                c.D[3] = t1x; c.D[4] = 0.0f; c.D[5] = t1z;
+                c.D[6] = nn[1] * t1z; c.D[7] = fmaf(nn[2], t1x, -(nn[0] * t1z)); c.D[8] = 0.0f - nn[1] * t1x;
+            }
+            if (dist < prm->contact_offset) {
+                c.body = b; c.cand = cid; c.dist = dist;
                 all[n++] = c;
             }
         }
@@ -543,6 +597,10 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
     bias_and_drive(s, m, prm, edof, tgt);
     factorize(s, m);
     aba_solve(s, m, s->f, s->tau, a0, qdd, acc);
+    if (saturate_drives(s, m, prm, qdd)) {
+        factorize(s, m);
+        aba_solve(s, m, s->f, s->tau, a0, qdd, acc);
+    }
 
     /* 4. unconstrained velocities: generalized, and per body V + h a */
     float V0f[6], wjf[NB][3], Vf[NB][6];
@@ -557,12 +615,11 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
     int nc = find_contacts(s, m, prm, con);
     int nr = 3 * nc;
     float J[3 * ORC_MAXC][6], Y[3 * ORC_MAXC][YLEN], rhs[3 * ORC_MAXC], lam[3 * ORC_MAXC];
-    static const float dirs[3][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}};
     for (int c = 0; c < nc; ++c) {
         for (int d = 0; d < 3; ++d) {
             int r = 3 * c + d;
-            cross3(con[c].x, dirs[d], J[r]);
-            memcpy(J[r] + 3, dirs[d], 12);
+            cross3(con[c].x, con[c].D + 3 * d, J[r]);
+            memcpy(J[r] + 3, con[c].D + 3 * d, 12);
             float vel = dot6(J[r], Vf[con[c].body]);
             float bias = 0.0f;
             if (d == 0) {
@@ -651,7 +708,7 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
             for (int k = 0; k < 6; ++k) pin[con[c].body][k] = fmaf(-J[r][k], lam[r], pin[con[c].body][k]);
             lam_ws[con[c].cand * 3 + d] = lam[r];
             if (last)
-                for (int k = 0; k < 3; ++k) cforce[con[c].body * 3 + k] += dirs[d][k] * lam[r] / h;
+                for (int k = 0; k < 3; ++k) cforce[con[c].body * 3 + k] += con[c].D[3 * d + k] * lam[r] / h;
         }
     if (nc > 0) aba_solve(s, m, pin, 0, da0, dq, acc);
     else { memset(da0, 0, sizeof(da0)); memset(dq, 0, sizeof(dq)); }

@@ -52,6 +52,10 @@ typedef struct {
     const uint8_t *sc_pairs;   /* [sc_n][2] */
     const float *sc_cap_a, *sc_cap_b, *sc_cap_r;   /* [E][24][3|3|1] */
     float sc_k, sc_c, sc_max_pen;
+    /* optional height-field ground (hf = NULL: the plane z = ground_z); mirrors emloco_sim_set_ground_heightfield */
+    const int16_t *hf;         /* [hf_nx][hf_ny] in units of hf_vs metres on an hf_hs-metre grid, sample (0,0) at (hf_ox, hf_oy) */
+    int32_t hf_nx, hf_ny;
+    float hf_hs, hf_vs, hf_ox, hf_oy;
 } OrcModel;
 
 /* one call = n_sub substeps for every env */

@@ -67,6 +67,14 @@ def sim_step(osim, n_calls=1):
         scd = SelfCollisionDesc(int(sc["pairs"].shape[0]), _p(sc["pairs"], C.c_uint8), _p(sc["cap_a"]), _p(sc["cap_b"]),
                                 _p(sc["cap_r"]), float(sc["k"]), float(sc["c"]), float(sc["max_pen"]))
     lib().emu_sim_set_self_collision(C.byref(scd) if scd is not None else None)
+    hf = getattr(osim, "hf", None)
+    fn = lib().emu_sim_set_heightfield
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+    if hf is not None:
+        m = osim.model
+        fn(hf.ctypes.data, hf.shape[0], hf.shape[1], m.hf_hs, m.hf_vs, m.hf_ox, m.hf_oy)
+    else:
+        fn(None, 0, 0, 0.0, 0.0, 0.0, 0.0)
     rc = lib().emu_sim_step(C.byref(osim.params), C.byref(desc), _p(osim.root_state), _p(osim.dof_state),
                             _p(osim.pd_target), _p(osim.rb_state), _p(osim.contact_force), _p(osim.dof_force),
                             _p(osim.lambda_ws), C.c_int(n_calls))

@@ -54,6 +54,53 @@ def test_sim_step_kernel_with_self_collision_is_bit_exact_vs_oracle():
     assert not np.array_equal(a.dof_state, c.dof_state)        # self-collision changed the motion
 
 
+def test_sim_step_kernel_with_saturated_drives_is_bit_exact_vs_oracle():
+    """targets far enough away that drives hit their effort limit: the second factorise / solve pass runs in some envs and
+    not in others; bytes equal the oracle and the reported drive torque sits exactly on the limit somewhere"""
+    E = 4
+    models = varied_models(E, seed=11)
+    root, dof, tgt = scene_state(E, seed=12)
+    a = oracle_sim(models, root, dof, tgt, n_sub=1)
+    b = oracle_sim(models, root, dof, tgt, n_sub=1)
+    rng = np.random.default_rng(13)
+    eff = np.stack([m.effort for m in models]).astype(np.float32)
+    hit = False
+    for _ in range(6):
+        big = (rng.normal(size=(E, 69)) * 2.0).astype(np.float32)
+        big[0] = tgt[0]                              # env 0 keeps standing (single pass), the others saturate
+        a.pd_target[:] = big
+        b.pd_target[:] = big
+        a.step(1)
+        emu.sim_step(b, 1)
+        for name in ("root_state", "dof_state", "rb_state", "contact_force", "dof_force", "lambda_ws"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), name
+        hit = hit or bool((np.abs(a.dof_force[1:]) == eff[1:]).any())
+        assert not (np.abs(a.dof_force[0]) == eff[0]).any()
+    assert hit
+    assert np.isfinite(a.rb_state).all() and np.abs(a.rb_state[:, :, 7:13]).max() < 150      # 2 rad moves within a few substeps
+
+
+def test_sim_step_kernel_on_a_heightfield_is_bit_exact_vs_oracle():
+    """height-field ground (sloped + bumpy): per-contact normals and tangent frames; emulated kernel == oracle bytes, and
+    the terrain really changes the motion relative to the plane"""
+    from helpers import bumpy_heightfield
+    E = 3
+    models = varied_models(E, seed=7)
+    root, dof, tgt = scene_state(E, seed=8)
+    hf = bumpy_heightfield(seed=3, amp=0.1, slope=0.15)
+    a = oracle_sim(models, root, dof, tgt, heightfield=hf, n_sub=4)
+    b = oracle_sim(models, root, dof, tgt, heightfield=hf, n_sub=4)
+    c = oracle_sim(models, root, dof, tgt, n_sub=4)
+    for _ in range(3):
+        a.step(1)
+        emu.sim_step(b, 1)
+        c.step(1)
+    for name in ("root_state", "dof_state", "rb_state", "contact_force", "dof_force", "lambda_ws"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert np.abs(a.contact_force).max() > 50 and np.abs(a.contact_force[..., :2]).max() > 5      # tilted contact forces
+    assert not np.array_equal(a.rb_state, c.rb_state)
+
+
 def test_sim_fk_kernel_matches_oracle():
     E = 2
     models = varied_models(E, seed=5)

@@ -257,3 +257,59 @@ def test_amp_agent_train_epoch_on_the_rollout():
     assert not torch.equal(w0, agent.a2c_network.mu.weight) and not torch.equal(d0, agent.a2c_network._disc_logits.weight)
     assert agent.frame == 2 * 8 * 64 and info["fps_step"] > 0
     assert float(agent.running_mean_std.count) > 1.0            # the observation statistics were updated in train mode
+
+
+def test_rollout_on_shaped_terrain_collides_with_the_heightfield():
+    """terrainProportions with slopes / stairs / obstacles (curriculum layout; no stepping stones: like the reference, a spawn
+    next to their 10 m deep gaps averages the gap into its ground height and starts below the stones): the task builds the
+    height-field mesh, the sim collides with it, resets place the humanoids on the local ground, the 32 x 32 height
+    observations see the relief, and nobody sinks through the terrain during a rollout."""
+    from emloco_amd.run import create_rlgpu_env, fill_flags
+    from emloco_amd.utils.config import get_args, load_cfg
+    E = 64
+    args = get_args(["--num_envs", str(E), "--seed", "3"])
+    cfg, cfg_train, _ = load_cfg(args)
+    fill_flags(args)
+    from emloco_amd.utils.flags import flags
+    flags.fixed = False                                               # run.py pins every spawn to (50, 55); spread them over the map here
+    cfg["env"]["terrain"].update(terrainProportions=[0.3, 0.0, 0.25, 0.25, 0.1, 0.0, 0.0, 0.1], numLevels=2, numTerrains=6,
+                                 mapLength=8., mapWidth=8., curriculum=True)
+    np.random.seed(3)
+    try:
+        _shaped_terrain_body(create_rlgpu_env(args, cfg, cfg_train), E)
+    finally:
+        flags.fixed = True
+
+
+def _shaped_terrain_body(env, E):
+    task = env.task
+    terr = task.terrain
+    assert not terr.is_flat and task.sim.heightfield is not None
+    assert task.sim.heightfield["samples"].shape == terr.height_field_raw.shape
+    ids = torch.arange(E, device=task.device)
+    obs = env.reset(ids)
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all()
+    hobs = obs[:, 368 + 30:368 + 30 + 1024]
+    assert hobs.std(dim=1).max().item() > 0.05                       # some humanoids look at relief
+    hs = terr.heightsamples.to(task.device).float() * terr.vertical_scale
+
+    def ground_under(p):                                              # bilinear-free lookup: min of the cell's diagonal corners
+        px = (p[..., 0] / terr.horizontal_scale).long().clamp(0, hs.shape[0] - 2)
+        py = (p[..., 1] / terr.horizontal_scale).long().clamp(0, hs.shape[1] - 2)
+        return torch.minimum(hs[px, py], hs[px + 1, py + 1])
+
+    root = task._root_states
+    assert ((root[:, 2] - ground_under(root)) > 0.5).all()            # spawned standing on the local ground, not at z = 0.9
+    assert (ground_under(root).abs() > 0.05).any()                    # ... and some of them on raised / lowered ground
+    low_gap = []
+    for k in range(45):
+        obs, rew, done, info = env.step(torch.randn(E, 69, device=task.device) * 0.1)
+        rb = task._rigid_body_state.view(E, 24, 13)
+        low_gap.append((rb[..., 2] - ground_under(rb)).min().item())
+        env.reset_done()
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(task._rigid_body_state).all()
+    assert min(low_gap) > -0.25                                       # body origins stay above the terrain (step edges: one riser of slack)
+    cf = task._contact_forces.view(E, 24, 3)
+    assert cf[..., 2].sum(1).max().item() > 300                       # the terrain carries them

@@ -149,3 +149,41 @@ def test_self_collision_step_is_bit_exact_and_changes_the_motion():
     torch.cuda.synchronize()
     assert not torch.equal(gsim.dof_state, gref.dof_state)
     assert torch.isfinite(gsim.rigid_body_state).all()
+
+
+def test_heightfield_ground_is_bit_exact_and_tilts_the_contact_forces():
+    """Height-field terrain (emloco_sim_set_ground_heightfield): humanoids falling and tumbling on a sloped, bumpy field with
+    self-collision on stay on the oracle's bytes over an episode; a flat field reproduces the plane bit for bit."""
+    from emloco_amd import _lib as L
+    from emloco_amd.model import pack_self_collision
+    from emloco_amd.sim import NativeSim
+    from helpers import bumpy_heightfield, oracle_sim, scene_state, varied_models
+    E = 8
+    models = varied_models(E, 31)
+    root, dof, tgt = scene_state(E, 32, perturbed_from=0)
+    hf = bumpy_heightfield(seed=5, amp=0.12, slope=0.2)
+    root[:, 2] += 0.2 * (root[:, 0] - 50.0) + 0.1
+    sc = pack_self_collision(models)
+    osim = oracle_sim(models, root, dof, tgt, self_collision=sc, heightfield=hf, n_sub=4)
+    gsim = NativeSim(models, L.default_sim_params(n_sub=2), self_collision=sc, heightfield=hf)
+    flat = dict(samples=np.zeros((1100, 1100), np.int16), horizontal_scale=0.1, vertical_scale=0.005)
+    gflat = NativeSim(models, L.default_sim_params(n_sub=2), self_collision=sc, heightfield=flat)
+    gplane = NativeSim(models, L.default_sim_params(n_sub=2), self_collision=sc)
+    for g in (gsim, gflat, gplane):
+        g.root_state.copy_(torch.from_numpy(root))
+        g.dof_state.view(E, 69, 2).copy_(torch.from_numpy(dof))
+        g.pd_target.copy_(torch.from_numpy(tgt))
+    tilted = 0.0
+    for k in range(168):
+        osim.step(1)
+        gsim.step(2)
+        if k < 40:
+            gflat.step(2)
+            gplane.step(2)
+        if k in (0, 5, 20, 60, 167):
+            _compare(osim, gsim, E, what=f"height-field step {k}")
+        tilted = max(tilted, float(gsim.contact_force.view(E, 24, 3)[..., :2].abs().max()))
+    torch.cuda.synchronize()
+    assert tilted > 20.0                                       # contact forces have horizontal parts on the slope
+    assert torch.isfinite(gsim.rigid_body_state).all()
+    assert torch.equal(gflat.rigid_body_state, gplane.rigid_body_state) and torch.equal(gflat.contact_force, gplane.contact_force)

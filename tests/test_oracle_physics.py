@@ -5,6 +5,7 @@ outputs ("parity unpinned").  These analytic cases pin OUR documen
 is then held bit-exact to this oracle (tests/test_gpu_sim.py, tests/test_emu_kernels.py).
 """
 import numpy as np
+import pytest
 
 import oracle
 from emloco_amd.model import pack_models, smpl_humanoid
@@ -70,6 +71,46 @@ def test_pd_drive_step_response_is_stable_and_converges():
     assert abs(trace[-1] - 0.5) < 0.02 and trace.max() < 0.6 and np.isfinite(trace).all()
 
 
+def test_random_targets_every_step_stay_bounded():
+    """Exploration-sized random targets (sigma 0.3 rad, new every control step) on light, stiffly driven links: the implicit
+    drives must not pump energy in -- in free space and on the ground alike.  (A drive clamped on its explicit torque
+    estimate does: kd * qd alone exceeds the limit on a fast light link and the clamped torque then overshoots every
+    substep -- the reason the effort limit is applied to the implicit torque.)"""
+    m = smpl_humanoid()
+    for z0, g in ((50.0, 0.0), (0.95, -9.81)):
+        s = oracle.Sim(pack_models([m] * 2), oracle.default_params(gravity_z=g))
+        s.root_state[:, :3] = [52.0, 55.0, z0]
+        s.root_state[:, 7] = 1.5
+        rng = np.random.default_rng(0)
+        peak = 0.0
+        for _ in range(90):
+            s.pd_target[:] = rng.normal(size=(2, 69)) * 0.3
+            s.step()
+            peak = max(peak, float(np.abs(s.rb_state[:, :, 7:13]).max()))
+        assert np.isfinite(s.rb_state).all() and peak < 40.0, (z0, peak)
+        assert np.abs(s.dof_force).max() <= m.effort.max() * (1 + 1e-5)
+
+
+def test_effort_limit_caps_the_delivered_drive_torque():
+    """a hip commanded 2.5 rad away: kp * err = 2000 N m >> effort 500: the drive delivers exactly the limit (constant
+    torque), its neighbours stay implicit and below their limits, and the motion stays smooth"""
+    m = smpl_humanoid()
+    s = oracle.Sim(pack_models([m]), oracle.default_params(gravity_z=0.0, n_sub=1))
+    s.root_state[0, :3] = [52.0, 55.0, 50.0]
+    j = (m.names.index("L_Hip") - 1) * 3 + 1
+    s.pd_target[0, j] = 2.5
+    s.step()                                         # one substep: dof_force reports the torque applied over it
+    assert s.dof_force[0, j] == np.float32(m.effort[j])
+    others = np.delete(s.dof_force[0], j)
+    assert np.abs(others).max() < m.effort.max()
+    trace = []
+    for _ in range(240):
+        s.step()
+        trace.append(s.dof_state[0, j, 0])
+    trace = np.array(trace)
+    assert abs(trace[-1] - 2.5) < 0.05 and trace.max() < 2.7 and np.all(np.diff(trace[:10]) > 0)
+
+
 def test_friction_holds_on_flat_ground_and_tangential_push_decays():
     s = _sim()
     s.root_state[0, :3] = [0, 0, 0.92]
@@ -121,6 +162,90 @@ def test_left_right_mirror_symmetry():
             np.testing.assert_allclose(a.rb_state[0, :, :3], b.rb_state[0, l2r, :3] * flip, atol=1e-6)
     pa, pb = a.rb_state[0, :, :3], b.rb_state[0, l2r, :3] * flip
     np.testing.assert_allclose(pa, pb, atol=5e-3)
+
+
+def _slope_field(slope, n=1100):
+    """plane z = slope * (x - 50 m) on the 0.1 m / 0.005 m grid (slope * 20 must be an integer number of units per cell)"""
+    per_cell = slope * 0.1 / 0.005
+    assert abs(per_cell - round(per_cell)) < 1e-9
+    col = (np.arange(n) - 500) * int(round(per_cell))
+    return dict(samples=np.repeat(col[:, None], n, 1).astype(np.int16), horizontal_scale=0.1, vertical_scale=0.005)
+
+
+def test_flat_heightfield_equals_the_plane_bit_for_bit():
+    hf = dict(samples=np.zeros((1100, 1100), np.int16), horizontal_scale=0.1, vertical_scale=0.005)
+    a = oracle.Sim(pack_models([smpl_humanoid()]), oracle.default_params(), heightfield=hf)
+    b = _sim()
+    for s_ in (a, b):
+        s_.root_state[0, :3] = [52.3, 57.1, 0.93]
+        s_.pd_target[0, ::5] = 0.2
+        for _ in range(30):
+            s_.step()
+    assert a.rb_state.tobytes() == b.rb_state.tobytes() and a.contact_force.tobytes() == b.contact_force.tobytes()
+    assert np.abs(a.contact_force).max() > 100
+
+
+@pytest.mark.parametrize("slope", [0.05, -0.2, 0.4])
+def test_resting_on_a_slope_holds_by_friction_and_leans_its_contact_forces(slope):
+    """|slope| < mu = 1: the humanoid comes to rest and stays (the zero-target PD mannequin, soft in the ankles, cannot keep
+    its balance on an incline: it topples and lies on the slope).  In equilibrium the summed contact force is the weight
+    straight up, i.e. a normal part m g cos(a) plus an up-slope friction part m g sin(a)"""
+    m = smpl_humanoid()
+    s = oracle.Sim(pack_models([m]), oracle.default_params(), heightfield=_slope_field(slope))
+    x0 = 52.0
+    s.root_state[0, :3] = [x0, 55.0, 0.95 + slope * (x0 - 50.0)]
+    for _ in range(260):
+        s.step()
+    W = m.total_mass() * 9.81
+    f = s.contact_force[0].sum(0)
+    assert abs(f[2] - W) / W < 0.05 and abs(f[0]) / W < 0.05 and abs(f[1]) / W < 0.02     # net force = weight, straight up
+    n = np.array([-slope, 0, 1]) / np.hypot(slope, 1)
+    fn = f @ n
+    ft = np.linalg.norm(f - fn * n)
+    assert abs(fn - W * np.cos(np.arctan(slope))) / W < 0.05 and abs(ft - W * np.sin(np.arctan(abs(slope)))) / W < 0.05
+    assert np.linalg.norm(s.root_state[0, 7:10]) < 0.05                                   # at rest
+    rb = s.rb_state[0]
+    gap = rb[:, 2] - slope * (rb[:, 0] - 50.0)
+    assert gap.min() > -0.02                                                              # nothing sank into the slope
+    x1 = s.root_state[0, 0]
+    for _ in range(30):
+        s.step()
+    assert abs(s.root_state[0, 0] - x1) < 1e-3                                            # held by friction
+
+
+def test_too_steep_a_slope_slides_downhill():
+    """slope 1.5 (56 deg) > mu = 1: friction cannot hold, the body accelerates down the slope (-x)"""
+    slope = 1.5
+    s = oracle.Sim(pack_models([smpl_humanoid()]), oracle.default_params(), heightfield=_slope_field(slope))
+    x0 = 55.0
+    s.root_state[0, :3] = [x0, 55.0, 0.95 + slope * (x0 - 50.0)]
+    for _ in range(60):
+        s.step()
+    assert s.root_state[0, 0] < x0 - 1.0 and s.root_state[0, 7] < -1.0 and np.isfinite(s.rb_state).all()
+
+
+def test_dropped_on_stairs_comes_to_rest_above_the_steps():
+    """pyramid stairs (0.15 m risers): a ragdoll-ish drop ends with every body above the terrain under it (small
+    penetration slack) and the whole weight carried"""
+    from emloco_amd.gym import terrain_utils as T
+    t = T.SubTerrain("terrain", width=160, length=160, vertical_scale=0.005, horizontal_scale=0.1)
+    T.pyramid_stairs_terrain(t, step_width=0.31, step_height=0.15, platform_size=3.)
+    field = np.zeros((1100, 1100), np.int16)
+    field[470:630, 470:630] = t.height_field_raw
+    m = smpl_humanoid()
+    s = oracle.Sim(pack_models([m]), oracle.default_params(), heightfield=dict(samples=field, horizontal_scale=0.1, vertical_scale=0.005))
+    W = m.total_mass() * 9.81
+    for x, y in ((49.2, 55.0), (48.05, 55.0)):            # over the 7th / 3rd step of the pyramid's side
+        s = oracle.Sim(pack_models([m]), oracle.default_params(), heightfield=dict(samples=field, horizontal_scale=0.1, vertical_scale=0.005))
+        s.root_state[0, :3] = [x, y, field[int(x / 0.1), int(y / 0.1)] * 0.005 + 1.1]
+        for _ in range(200):                              # lands on the steps, topples, tumbles down and stops
+            s.step()
+        rb = s.rb_state[0]
+        ix = np.clip((rb[:, 0] / 0.1).astype(int), 0, 1098)
+        iy = np.clip((rb[:, 1] / 0.1).astype(int), 0, 1098)
+        ground = np.minimum(field[ix, iy], field[ix + 1, iy + 1]) * 0.005
+        assert (rb[:, 2] - ground).min() > -0.02 and np.isfinite(rb).all()
+        assert abs(s.contact_force[0, :, 2].sum() - W) / W < 0.02 and np.abs(s.root_state[0, 7:13]).max() < 0.05
 
 
 def test_same_inputs_same_bytes():
