@@ -39,6 +39,7 @@ namespace emloco {
 #define MAXC EMLOCO_MAXC
 #define MAXR (3 * EMLOCO_MAXC)
 #define MAXCAND EMLOCO_MAXCAND
+#define EMLOCO_WH_MAX 0.4f /* largest link rotation per substep [rad]: cap of the link angular speed, see phase 1 */
 #define YLEN 30 /* chain-propagation vector: 6 root + 3 per tree level (depth <= 8) */
 
 // index into a packed symmetric 6x6 (upper triangle, row-major): (a<=b)
@@ -205,6 +206,47 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             __syncthreads();
         }
         if (final_pass) break;
+
+        // Link angular-speed limit.  The reference caps link angular velocities (AssetOptions.max_angular_velocity = 100,
+        // humanoid.py:685-688); here the cap is min(that, EMLOCO_WH_MAX / h): the velocity-product terms are integrated
+        // explicitly and beyond ~0.4 rad per substep they pump energy into fast spinning links.  When the fastest link of the
+        // env exceeds the cap (rare, wave-uniform), root angular velocity and joint rates are scaled down uniformly so that
+        // link just meets it, and the root's linear velocity is shifted so the linear momentum is unchanged:
+        // V_i -> [sc w_i ; v_0' + sc (v_i - v_0)], v_0' = v_0 + (1 - sc)(v_com - v_0); the velocity-product accelerations
+        // are quadratic in the angular rates.
+        {
+            float w2 = 0.0f;
+            if (is_body) { const float *Vb = sh_V[lane]; w2 = fmaf(Vb[0], Vb[0], fmaf(Vb[1], Vb[1], Vb[2] * Vb[2])); }
+            for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(w2, off); w2 = o > w2 ? o : w2; }
+            float wlim = EMLOCO_WH_MAX / h;
+            if (prm.max_ang_vel < wlim) wlim = prm.max_ang_vel;
+            if (w2 > wlim * wlim) {
+                const float sc = wlim / sqrtf(w2), sc2 = sc * sc;
+                float lm = 0.0f, lp[3] = {0.0f, 0.0f, 0.0f};
+                if (is_body) {
+                    float Rb[9], cm[3], cw[3], rc[3], wx[3], Vb[6];
+                    for (int k = 0; k < 9; ++k) Rb[k] = sh_R[lane][k];
+                    for (int k = 0; k < 3; ++k) cm[k] = d.com[mb0 * 3 + k];
+                    for (int k = 0; k < 6; ++k) Vb[k] = sh_V[lane][k];
+                    matvec3(Rb, cm, cw);
+                    for (int k = 0; k < 3; ++k) rc[k] = sh_r[lane][k] + cw[k];
+                    cross3(Vb, rc, wx);
+                    lm = d.mass[mb0];
+                    for (int k = 0; k < 3; ++k) lp[k] = lm * (Vb[3 + k] + wx[k]);
+                }
+                const float M = wave_sum(lm);
+                float v0[3], v0n[3];
+                for (int k = 0; k < 3; ++k) { v0[k] = sh_root[10 + k]; v0n[k] = v0[k] + (1.0f - sc) * (wave_sum(lp[k]) / M - v0[k]); }
+                __syncthreads();
+                if (is_body) {
+                    for (int k = 0; k < 3; ++k) { sh_V[lane][k] *= sc; sh_V[lane][3 + k] = v0n[k] + sc * (sh_V[lane][3 + k] - v0[k]); }
+                    for (int k = 0; k < 6; ++k) sh_Aacc[lane][k] *= sc2;
+                    if (lane >= 1) for (int k = 0; k < 3; ++k) wj[k] *= sc;
+                }
+                if (lane == 0) for (int k = 0; k < 3; ++k) { sh_root[7 + k] *= sc; sh_root[10 + k] = v0n[k]; }
+                __syncthreads();
+            }
+        }
 
         // ============================================================ 1b. limb-limb contacts (self-collision, penalty)
         // lane = body: world collision capsule -> LDS; lane = pair (4 rounds of 64): closest points, spring-damper force;
@@ -829,7 +871,10 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 wn[k] = wjf[k] + dq[k];
                 if (last) {
                     const float kpk = d.kp[dof0 + k], kdk = d.kd[dof0 + k], tgk = d.pd_target[dof0 + k];
-                    const float tq = sat[k] ? tau[k] : kpk * (tgk - edof[k] - h * wn[k]) - kdk * wn[k];
+                    // torque applied over this substep (the contact impulses moved the implicit drive along; reported within the limit)
+                    const float effk = d.effort[dof0 + k];
+                    float tq = sat[k] ? tau[k] : kpk * (tgk - edof[k] - h * wn[k]) - kdk * wn[k];
+                    tq = tq > effk ? effk : (tq < -effk ? -effk : tq);
                     d.dof_force[(long)env * NDOF + (lane - 1) * 3 + k] = tq;
                 }
                 wj[k] = wn[k] * damp;

@@ -23,6 +23,9 @@
  */
 #include <math.h>
 #include <string.h>
+#ifndef ORC_WH_MAX
+#define ORC_WH_MAX 0.4f   /* largest link rotation per substep [rad], see bias_and_drive */
+#endif
 #include "oracle_sim.h"
 
 #define NB ORC_NB
@@ -313,6 +316,8 @@ static void self_contacts(const Env *s, const EnvModel *m, float (*fext)[6]) {
         }
 }
 
+static float wave_sum_order(const float *v);
+
 /* ---------------------------------------------------------------- 2. bias forces + drive */
 static void bias_and_drive(Env *s, const EnvModel *m, const OrcSimParams *prm, const float *edof,
                            const float *tgt) {
@@ -331,6 +336,46 @@ static void bias_and_drive(Env *s, const EnvModel *m, const OrcSimParams *prm, c
         cross3(s->r[i], c, t2);
         for (int k = 0; k < 3; ++k) c[3 + k] = t1[k] + t2[k];
         for (int k = 0; k < 6; ++k) s->Aacc[i][k] = s->Aacc[p][k] + c[k];
+    }
+    /* Link angular-speed limit.  The reference caps link angular velocities (AssetOptions.max_angular_velocity = 100,
+     * humanoid.py:685-688); here the cap is min(that, ORC_WH_MAX / h): the velocity-product terms (Coriolis / centrifugal
+     * accelerations, V x* I V) are integrated explicitly and beyond ~0.4 rad per substep they pump energy into fast
+     * spinning links.  When the fastest link of the env exceeds the cap, all angular generalized velocities (root angular
+     * velocity, joint rates) are scaled down uniformly by sc so that link just meets it, and the root's linear velocity is
+     * shifted so the linear momentum is unchanged.  Body twists are linear in the generalized velocities:
+     * V_i = [w_i ; v_0 + (v_i - v_0)] -> [sc w_i ; v_0' + sc (v_i - v_0)], v_0' = v_0 + (1 - sc)(v_com - v_0); the
+     * velocity-product accelerations are quadratic in the angular rates (they do not involve v_0). */
+    float w2max = 0.0f;
+    for (int i = 0; i < NB; ++i) {
+        float w2 = fmaf(s->V[i][0], s->V[i][0], fmaf(s->V[i][1], s->V[i][1], s->V[i][2] * s->V[i][2]));
+        if (w2 > w2max) w2max = w2;
+    }
+    float wlim = ORC_WH_MAX / prm->h;
+    if (prm->max_ang_vel < wlim) wlim = prm->max_ang_vel;
+    if (w2max > wlim * wlim) {
+        const float sc = wlim / sqrtf(w2max), sc2 = sc * sc;
+        float lane_m[64], lane_p[3][64];
+        for (int i = 0; i < 64; ++i) {
+            lane_m[i] = 0.0f; lane_p[0][i] = lane_p[1][i] = lane_p[2][i] = 0.0f;
+            if (i < NB) {
+                float cw[3], rc[3], wx[3];
+                matvec3(s->R[i], m->com + i * 3, cw);
+                for (int k = 0; k < 3; ++k) rc[k] = s->r[i][k] + cw[k];
+                cross3(s->V[i], rc, wx);
+                lane_m[i] = m->mass[i];
+                for (int k = 0; k < 3; ++k) lane_p[k][i] = m->mass[i] * (s->V[i][3 + k] + wx[k]);
+            }
+        }
+        const float M = wave_sum_order(lane_m);
+        const float v0[3] = {s->V0[3], s->V0[4], s->V0[5]};
+        float v0n[3];
+        for (int k = 0; k < 3; ++k) v0n[k] = v0[k] + (1.0f - sc) * (wave_sum_order(lane_p[k]) / M - v0[k]);
+        for (int i = 0; i < NB; ++i) {
+            for (int k = 0; k < 3; ++k) { s->V[i][k] *= sc; s->V[i][3 + k] = v0n[k] + sc * (s->V[i][3 + k] - v0[k]); }
+            for (int k = 0; k < 6; ++k) s->Aacc[i][k] *= sc2;
+            if (i >= 1) for (int k = 0; k < 3; ++k) s->wj[i][k] *= sc;
+        }
+        for (int k = 0; k < 3; ++k) { s->V0[k] *= sc; s->V0[3 + k] = v0n[k]; }
     }
     for (int i = 0; i < NB; ++i) {
         float c[3], hI[6], IA[6], x1[3], x2[3];
@@ -719,9 +764,11 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
         for (int k = 0; k < 3; ++k) {
             int d = (i - 1) * 3 + k;
             float wn = wjf[i][k] + dq[i][k];
-            if (last) /* drive torque actually applied over this substep */
-                dforce[d] = s->sat[i][k] ? s->tau[i][k]
-                                         : m->kp[d] * (tgt[d] - edof[d] - h * wn) - m->kd[d] * wn;
+            if (last) { /* drive torque applied over this substep (the contact impulses moved the implicit drive along;
+                         * reported within the effort limit) */
+                float tq = s->sat[i][k] ? s->tau[i][k] : m->kp[d] * (tgt[d] - edof[d] - h * wn) - m->kd[d] * wn;
+                dforce[d] = tq > m->eff[d] ? m->eff[d] : (tq < -m->eff[d] ? -m->eff[d] : tq);
+            }
             s->wj[i][k] = wn * damp;
         }
     for (int k = 0; k < 3; ++k) s->V0[k] *= damp;

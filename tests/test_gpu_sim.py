@@ -187,3 +187,39 @@ def test_heightfield_ground_is_bit_exact_and_tilts_the_contact_forces():
     assert tilted > 20.0                                       # contact forces have horizontal parts on the slope
     assert torch.isfinite(gsim.rigid_body_state).all()
     assert torch.equal(gflat.rigid_body_state, gplane.rigid_body_state) and torch.equal(gflat.contact_force, gplane.contact_force)
+
+
+def test_large_random_targets_stay_finite_and_match_the_oracle():
+    """Exploration-sized and absurd target noise (new targets every control step): the saturating drives' second pass and the
+    link-speed limiter run in many envs; the first 8 envs stay on the oracle's bytes, all 1024 stay finite and bounded."""
+    from emloco_amd import _lib as L
+    from emloco_amd.sim import NativeSim
+    from helpers import oracle_sim, scene_state, varied_models
+    E, EO = 1024, 8
+    models = varied_models(E, 41)
+    root, dof, tgt = scene_state(E, 42)
+    osim = oracle_sim(models[:EO], root[:EO], dof[:EO], tgt[:EO], n_sub=4)
+    gsim = NativeSim(models, L.default_sim_params(n_sub=2))
+    gsim.root_state.copy_(torch.from_numpy(root))
+    gsim.dof_state.view(E, 69, 2).copy_(torch.from_numpy(dof))
+    rng = np.random.default_rng(43)
+    sig = np.where(np.arange(E) % 2 == 0, 0.3, 1.2)[:, None].astype(np.float32)      # even envs: exploration, odd: absurd
+    vmax = 0.0
+    for k in range(90):
+        t = (rng.normal(size=(E, 69)).astype(np.float32) * sig)
+        gsim.pd_target.copy_(torch.from_numpy(t))
+        osim.pd_target[:] = t[:EO]
+        osim.step(1)
+        gsim.step(2)
+        if k in (0, 15, 89):
+            torch.cuda.synchronize()
+            for name, a, b in (("root_state", gsim.root_state[:EO].cpu().numpy(), osim.root_state),
+                               ("dof_state", gsim.dof_state.view(E, 69, 2)[:EO].cpu().numpy(), osim.dof_state),
+                               ("dof_force", gsim.dof_force.view(E, 69)[:EO].cpu().numpy(), osim.dof_force)):
+                assert np.array_equal(a, b), f"step {k} {name}: max abs diff {np.abs(a - b).max():.3e}"
+        vmax = max(vmax, float(gsim.root_state[:, 7:10].norm(dim=1).max()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(gsim.rigid_body_state).all() and torch.isfinite(gsim.dof_state).all()
+    assert vmax < 60.0 and float(gsim.root_state[0::2, 7:10].norm(dim=1).max()) < 15.0
+    eff = torch.from_numpy(np.stack([m.effort for m in models]).astype(np.float32)).cuda()
+    assert (gsim.dof_force.view(E, 69).abs() <= eff * (1 + 1e-6)).all()

@@ -91,6 +91,27 @@ def test_random_targets_every_step_stay_bounded():
         assert np.abs(s.dof_force).max() <= m.effort.max() * (1 + 1e-5)
 
 
+def test_absurd_targets_degrade_gracefully():
+    """targets thrown +-1 rad (sigma) around every control step, on sloped bumpy terrain with self-collision: far outside
+    anything a policy does, but the state must stay finite and bounded (link-speed cap + implicit effort limits), since one
+    non-finite env would poison a whole training batch"""
+    from helpers import bumpy_heightfield
+    from emloco_amd.model import pack_self_collision
+    m = smpl_humanoid()
+    E = 6
+    s = oracle.Sim(pack_models([m] * E), oracle.default_params(), self_collision=pack_self_collision([m] * E),
+                   heightfield=bumpy_heightfield(seed=5, amp=0.12, slope=0.2))
+    s.root_state[:, :3] = [52.0, 55.0, 1.5]
+    rng = np.random.default_rng(2)
+    vmax = 0.0
+    for _ in range(120):
+        s.pd_target[:] = rng.normal(size=(E, 69))
+        s.step()
+        vmax = max(vmax, float(np.linalg.norm(s.root_state[:, 7:10], axis=1).max()))
+    assert np.isfinite(s.rb_state).all() and np.isfinite(s.dof_state).all() and vmax < 40.0
+    assert np.abs(s.rb_state[:, :, 10:13]).max() < 200.0
+
+
 def test_effort_limit_caps_the_delivered_drive_torque():
     """a hip commanded 2.5 rad away: kp * err = 2000 N m >> effort 500: the drive delivers exactly the limit (constant
     torque), its neighbours stay implicit and below their limits, and the motion stays smooth"""
