@@ -71,7 +71,7 @@ def rank_local():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def cpu_baseline(sample_envs=512, sample_steps=400):
+def cpu_baseline(sample_envs=256, sample_steps=300):
     """The CPU oracle on a bounded sample of the same workload (physics + post-physics maths), one core."""
     import oracle
     from emloco_amd.model import pack_models, pack_self_collision
@@ -364,7 +364,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "sim_step_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l,
-                         "note": "VALU-issue bound: ~9 KB of state per env per launch, ~40 k dependent fp32 instructions per substep"},
+                         "note": "latency bound, not bandwidth bound: ~9 KB of state per env per launch against ~50 k dependent fp32 VALU "
+                                 "wave-instructions (level-synchronous tree passes, 2 waves / SIMD); VALU issue ~27 % busy, "
+                                 "35 % of wave cycles waiting (profiles/r01_sim_step_valu.txt)"},
         }
         if world == 1 and not a.no_policy:
             out["policy"] = policy_leg(env, E, dev, a.steps, a.warmup)

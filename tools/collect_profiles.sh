@@ -78,4 +78,38 @@ for k in sorted(busy, key=lambda k: -busy[k])[:10]:
 open(sys.argv[1], "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
+# 4. VALU occupancy of the rollout kernel (env leg): where the wave cycles of sim_step_kernel go.  SQ counters only (8 slots),
+#    its own pass; durations come from pass 1's kernel trace.
+rm -rf /tmp/prof_valu && (cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/prof_valu -- $BENCH --steps 20 --warmup 5 --no_jta --no_policy > "$OUT/pmc_valu.log" 2>&1)
+python - "$OUT/${R}_sim_step_valu.txt" "$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1)" <<'PY'
+import csv, glob, sys, collections
+agg = collections.defaultdict(list)
+for f in glob.glob("/tmp/prof_valu/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "sim_step_kernel" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+m = {k: sum(v) / len(v) for k, v in agg.items()}
+dur_ns = None
+for r in list(csv.reader(open(sys.argv[2])))[1:]:
+    if "sim_step_kernel" in r[0]:
+        dur_ns = float(r[3])
+lines = ["sim_step_kernel, 4096 envs (one 64-lane wave each), mean per launch over %d launches" % len(next(iter(agg.values()), []))]
+for k in sorted(m):
+    lines.append(f"  {k:22s} {m[k]:.6g}")
+if m.get("SQ_WAVE_CYCLES"):
+    wc = m["SQ_WAVE_CYCLES"]
+    lines.append("fractions of the wave cycles (SQ_WAVE_CYCLES; quad-cycle units cancel):")
+    for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+        if k in m:
+            lines.append(f"  {k:22s} {m[k] / wc:.3f}")
+if dur_ns and m.get("SQ_INSTS_VALU"):
+    CLK, SIMDS = 2.4, 1024          # GHz nominal engine clock, 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+    cyc = dur_ns * CLK
+    lines.append(f"duration (kernel-trace pass) {dur_ns / 1e3:.1f} us = {cyc:.4g} cycles at {CLK} GHz")
+    lines.append(f"VALU wave-instructions per launch {m['SQ_INSTS_VALU']:.4g} = {m['SQ_INSTS_VALU'] / 4096:.0f} per env")
+    lines.append(f"VALU issue utilisation = insts x 2 cycles (wave64 on a SIMD-32) / (cycles x {SIMDS} SIMDs) = "
+                 f"{m['SQ_INSTS_VALU'] * 2 / (cyc * SIMDS):.3f}  (lower bound: the engine clock under load is below nominal)")
+open(sys.argv[1], "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+PY
 echo "collected into $OUT"; ls -la "$OUT"
