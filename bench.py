@@ -68,6 +68,10 @@ def make_env(num_envs, rank):
 
 
 def rank_local():
+    # EMLOCO_BENCH_SHARE_GPU=1 (testing only): every rank uses cuda:0 and gloo instead of RCCL, so the multi-process path
+    # (launch, sharding, barriers, max-over-ranks timing, aggregation) can be exercised on a 1-GPU box.  The line says so.
+    if os.environ.get("EMLOCO_BENCH_SHARE_GPU") == "1":
+        return 0
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
@@ -302,7 +306,9 @@ def main():
     from emloco_amd import _lib as L
     from emloco_amd.dist import init_from_env
     L.require_device()                                  # fail loudly: no CPU fallback
-    rank, local_rank, world = init_from_env("nccl")
+    share = os.environ.get("EMLOCO_BENCH_SHARE_GPU") == "1"
+    rank, local_rank, world = init_from_env("gloo" if share else "nccl")
+    local_rank = rank_local()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local_rank)
@@ -360,7 +366,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: PACER rollout env.step, 4096 SMPL humanoids per GPU, random_heading, "
                                    "JTA+JRDB-shaped real_path (synthetic), flat terrain, self-collision on, resets included, policy excluded",
-                       "num_envs_per_gpu": E, "substeps_per_step": 4, "parallelism": f"env-sharded x{world}"},
+                       "num_envs_per_gpu": E, "substeps_per_step": 4, "parallelism": f"env-sharded x{world}" + (" (TEST MODE: all ranks share cuda:0, gloo)" if share else "")},
             "roofline": {"bound": "hbm", "kernel": "sim_step_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l,
