@@ -898,6 +898,12 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             rotvec2quat(e, dqt);
             qmul(dqt, q0, qn); qnormalize(qn);
             for (int k = 0; k < 4; ++k) sh_root[3 + k] = qn[k];
+            // the reference point O of the spatial quantities moves with the root origin: re-base the root twist from O to
+            // O + h v (velocity of the body-fixed point there: v + w x (h v)); without it the root's linear velocity would not
+            // turn with the body and linear momentum would not be conserved
+            float wxv[3];
+            cross3(V0, V0 + 3, wxv);
+            for (int k = 0; k < 3; ++k) V0[3 + k] = fmaf(h, wxv[k], V0[3 + k]);
             for (int k = 0; k < 6; ++k) sh_root[7 + k] = V0[k];
         }
         __syncthreads();

@@ -784,6 +784,14 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
     /* semi-implicit Euler: positions with the new velocities */
     float e[3], dqt[4], qn[4];
     for (int k = 0; k < 3; ++k) { s->p0[k] += h * s->V0[3 + k]; e[k] = h * s->V0[k]; }
+    /* the reference point O of the spatial quantities moves with the root origin: re-base the root twist from O to
+     * O + h v  (velocity of the body-fixed point there: v + w x (h v)); without it the root's linear velocity would not
+     * turn with the body and linear momentum would not be conserved */
+    {
+        float wxv[3];
+        cross3(s->V0, s->V0 + 3, wxv);
+        for (int k = 0; k < 3; ++k) s->V0[3 + k] = fmaf(h, wxv[k], s->V0[3 + k]);
+    }
     rotvec2quat(e, dqt);
     qmul(dqt, s->q0, qn); qnormalize(qn); memcpy(s->q0, qn, 16);   /* world-frame w: left multiply */
     for (int i = 1; i < NB; ++i) {

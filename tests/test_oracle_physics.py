@@ -132,6 +132,52 @@ def test_effort_limit_caps_the_delivered_drive_torque():
     assert abs(trace[-1] - 2.5) < 0.05 and trace.max() < 2.7 and np.all(np.diff(trace[:10]) > 0)
 
 
+def _momenta(m, rb):
+    """total linear momentum, angular momentum about the centre of mass and kinetic energy from the body states (float64)"""
+    def rot(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    rb = rb.astype(np.float64)
+    R = [rot(rb[i, 3:7]) for i in range(24)]
+    c = np.stack([rb[i, :3] + R[i] @ m.com[i] for i in range(24)])
+    v = np.stack([rb[i, 7:10] + np.cross(rb[i, 10:13], R[i] @ m.com[i]) for i in range(24)])
+    P = (m.mass[:, None] * v).sum(0)
+    com = (m.mass[:, None] * c).sum(0) / m.mass.sum()
+    L, T = np.zeros(3), 0.0
+    for i in range(24):
+        xx, yy, zz, xy, xz, yz = m.inertia[i]
+        Iw = R[i] @ np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]]) @ R[i].T
+        w = rb[i, 10:13]
+        L += m.mass[i] * np.cross(c[i] - com, v[i]) + Iw @ w
+        T += 0.5 * m.mass[i] * v[i] @ v[i] + 0.5 * w @ Iw @ w
+    return P, L, T
+
+
+def test_free_floating_ragdoll_conserves_momentum_and_energy():
+    """drives off, no gravity, no damping, tumbling and flailing at a few rad/s: over one second (120 substeps) linear and
+    angular momentum stay within 2.5 % / 4 %, kinetic energy within 5 % (first-order integrator).  Guards the re-basing of
+    the root twist to the moving root origin: without it the linear momentum turns with w x v (87 % off here)."""
+    m = smpl_humanoid().scaled(1.0, 1.0)
+    m.kp, m.kd = m.kp * 0, m.kd * 0
+    s = oracle.Sim(pack_models([m]), oracle.default_params(gravity_z=0.0, ang_damping=0.0))
+    rng = np.random.default_rng(0)
+    s.root_state[0, :3] = [52, 55, 50]
+    s.root_state[0, 7:10] = [0.5, -0.2, 0.1]
+    s.root_state[0, 10:13] = rng.normal(size=3)
+    s.dof_state[0, :, 1] = rng.normal(size=69)
+    s.step()
+    P0, L0, T0 = _momenta(m, s.rb_state[0])
+    for _ in range(30):
+        s.step()
+    P1, L1, T1 = _momenta(m, s.rb_state[0])
+    assert np.linalg.norm(P0) > 20 and np.linalg.norm(L0) > 5
+    assert np.linalg.norm(P1 - P0) < 0.025 * np.linalg.norm(P0)
+    assert np.linalg.norm(L1 - L0) < 0.04 * np.linalg.norm(L0)
+    assert abs(T1 - T0) < 0.05 * T0
+
+
 def test_friction_holds_on_flat_ground_and_tangential_push_decays():
     s = _sim()
     s.root_state[0, :3] = [0, 0, 0.92]
@@ -170,19 +216,25 @@ def test_left_right_mirror_symmetry():
             sym.inertia[b][[3, 5]] = 0
     rng = np.random.default_rng(3)
     tgt = rng.normal(size=(23, 3)) * 0.2
-    a, b = _sim([sym]), _sim([sym])
-    for s_ in (a, b):
-        s_.root_state[0, :3] = [0, 0, 0.95]
     jm = [j - 1 for j in l2r[1:]]
-    a.pd_target[0] = tgt.reshape(-1)
-    b.pd_target[0] = (tgt[jm] * np.array([-1, 1, -1.0])).reshape(-1)      # mirrored rotation vectors
-    for k in range(40):
-        a.step()
-        b.step()
-        if k == 1:      # exact up to rounding before contact switching amplifies the last-ulp differences of the mirrored run
-            np.testing.assert_allclose(a.rb_state[0, :, :3], b.rb_state[0, l2r, :3] * flip, atol=1e-6)
-    pa, pb = a.rb_state[0, :, :3], b.rb_state[0, l2r, :3] * flip
-    np.testing.assert_allclose(pa, pb, atol=5e-3)
+    # (1) floating in zero gravity (no contact switching to amplify rounding): the mirrored run stays the mirror image
+    # (2) dropped onto its feet: exact up to rounding at first, then contact switching amplifies last-ulp differences
+    for grav, z0, early, late in ((0.0, 5.0, 2e-6, 2e-4), (-9.81, 0.95, 1e-6, 4e-2)):
+        a = oracle.Sim(pack_models([sym]), oracle.default_params(gravity_z=grav))
+        b = oracle.Sim(pack_models([sym]), oracle.default_params(gravity_z=grav))
+        for s_, sgn in ((a, 1.0), (b, -1.0)):
+            s_.root_state[0, :3] = [0, 0, z0]
+            s_.root_state[0, 7:10] = [0.8, 0.3 * sgn, 0.1]                 # true vector: y flips
+            s_.root_state[0, 10:13] = [0.5 * sgn, 0.7, -0.9 * sgn]         # pseudo vector: x and z flip
+        a.pd_target[0] = tgt.reshape(-1)
+        b.pd_target[0] = (tgt[jm] * np.array([-1, 1, -1.0])).reshape(-1)   # mirrored rotation vectors
+        for k in range(40):
+            a.step()
+            b.step()
+            if k == 1:
+                np.testing.assert_allclose(a.rb_state[0, :, :3], b.rb_state[0, l2r, :3] * flip, atol=early)
+        np.testing.assert_allclose(a.rb_state[0, :, :3], b.rb_state[0, l2r, :3] * flip, atol=late)
+        np.testing.assert_allclose(a.rb_state[0, :, 7:10], b.rb_state[0, l2r, 7:10] * flip, atol=50 * late)
 
 
 def _slope_field(slope, n=1100):
