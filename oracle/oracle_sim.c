@@ -49,6 +49,9 @@ typedef struct {
     float L0[36];     /* Cholesky factor of the root articulated inertia, lower, row-major */
     float L0i[6];     /* reciprocals of its diagonal */
     int depth[NB];
+    /* linear-momentum bookkeeping across the substeps of one call (see bias_and_drive) */
+    float Pexp[3], Pcur[3], Mtot;
+    int havP;
 } Env;
 
 /* ---------------------------------------------------------------- small helpers */
@@ -318,6 +321,43 @@ static void self_contacts(const Env *s, const EnvModel *m, float (*fext)[6]) {
 
 static float wave_sum_order(const float *v);
 
+/* Linear-momentum balance.  The integrator is first order in the velocity products, so the velocity of the centre of mass
+ * of a tumbling body would drift (measured: 5 % of g t in a tumbling free fall).  The total linear momentum is therefore
+ * carried across the substeps of a call -- P_exp = P + h (M g + sum of the contact forces), all known exactly -- and the
+ * momentum the new generalized velocities actually have (known once the kinematics of the new configuration are: next
+ * substep, or the final pass that writes the body states) is shifted onto it by a uniform change dv of the linear
+ * velocities (root and, through it, every body).  The velocity-product accelerations see dv through v_i x S_i qd_i: their
+ * linear part gains dv x (w_i - w_0). */
+static void project_momentum(Env *s, const EnvModel *m) {
+    float lane_m[64], lane_p[3][64];
+    for (int i = 0; i < 64; ++i) {
+        lane_m[i] = 0.0f; lane_p[0][i] = lane_p[1][i] = lane_p[2][i] = 0.0f;
+        if (i < NB) {
+            float cw[3], rc[3], wx[3];
+            matvec3(s->R[i], m->com + i * 3, cw);
+            for (int k = 0; k < 3; ++k) rc[k] = s->r[i][k] + cw[k];
+            cross3(s->V[i], rc, wx);
+            lane_m[i] = m->mass[i];
+            for (int k = 0; k < 3; ++k) lane_p[k][i] = m->mass[i] * (s->V[i][3 + k] + wx[k]);
+        }
+    }
+    s->Mtot = wave_sum_order(lane_m);
+    float Pact[3];
+    for (int k = 0; k < 3; ++k) Pact[k] = wave_sum_order(lane_p[k]);
+    if (s->havP) {
+        float dv[3], w0[3] = {s->V[0][0], s->V[0][1], s->V[0][2]};
+        for (int k = 0; k < 3; ++k) dv[k] = (s->Pexp[k] - Pact[k]) / s->Mtot;
+        for (int i = 0; i < NB; ++i) {
+            float wr[3] = {s->V[i][0] - w0[0], s->V[i][1] - w0[1], s->V[i][2] - w0[2]}, t[3];
+            cross3(dv, wr, t);
+            for (int k = 0; k < 3; ++k) { s->Aacc[i][3 + k] += t[k]; s->V[i][3 + k] += dv[k]; }
+        }
+        for (int k = 0; k < 3; ++k) { s->V0[3 + k] += dv[k]; s->Pcur[k] = s->Pexp[k]; }
+    } else {
+        for (int k = 0; k < 3; ++k) s->Pcur[k] = Pact[k];
+    }
+}
+
 /* ---------------------------------------------------------------- 2. bias forces + drive */
 static void bias_and_drive(Env *s, const EnvModel *m, const OrcSimParams *prm, const float *edof,
                            const float *tgt) {
@@ -377,6 +417,7 @@ static void bias_and_drive(Env *s, const EnvModel *m, const OrcSimParams *prm, c
         }
         for (int k = 0; k < 3; ++k) { s->V0[k] *= sc; s->V0[3 + k] = v0n[k]; }
     }
+    project_momentum(s, m);
     for (int i = 0; i < NB; ++i) {
         float c[3], hI[6], IA[6], x1[3], x2[3];
         body_inertia(s, m, i, s->I6[i], c);
@@ -757,6 +798,15 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
         }
     if (nc > 0) aba_solve(s, m, pin, 0, da0, dq, acc);
     else { memset(da0, 0, sizeof(da0)); memset(dq, 0, sizeof(dq)); }
+    {   /* momentum the system must have after this substep: gravity and the contact impulses are the only external ones */
+        float lane_i[3][64];
+        memset(lane_i, 0, sizeof(lane_i));
+        for (int r = 0; r < nr; ++r)
+            for (int k = 0; k < 3; ++k) lane_i[k][r] = con[r / 3].D[3 * (r % 3) + k] * lam[r];
+        for (int k = 0; k < 3; ++k) s->Pexp[k] = s->Pcur[k] + (nc > 0 ? wave_sum_order(lane_i[k]) : 0.0f);
+        s->Pexp[2] = fmaf(s->Mtot * prm->gravity_z, h, s->Pexp[2]);
+        s->havP = 1;
+    }
 
     float damp = 1.0f / (1.0f + h * prm->ang_damping);
     for (int k = 0; k < 6; ++k) s->V0[k] = V0f[k] + da0[k];
@@ -803,6 +853,7 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
 }
 
 static void load_state(Env *s, const float *root, const float *dof) {
+    s->havP = 0;
     memcpy(s->p0, root, 12); memcpy(s->q0, root + 3, 16);
     qnormalize(s->q0);
     memcpy(s->V0, root + 10, 12); memcpy(s->V0 + 3, root + 7, 12);
@@ -816,6 +867,7 @@ static void load_state(Env *s, const float *root, const float *dof) {
 static void write_bodies(Env *s, const EnvModel *m, float *rb) {
     kinematics(s, m);
     velocities(s, m, s->V, s->V0, s->wj);
+    if (s->havP) project_momentum(s, m);     /* the last substep's balance, in the configuration it ended in */
     for (int i = 0; i < NB; ++i) {
         float *o = rb + i * 13, t[3];
         memcpy(o, s->pw[i], 12); memcpy(o + 3, s->qw[i], 16);
@@ -847,6 +899,7 @@ void orc_sim_step(int n_env, const OrcSimParams *prm, const OrcModel *mdl, float
         for (int k = 0; k < prm->n_sub; ++k)
             substep(&s, &m, prm, pd_target + (long)e * ORC_NDOF, edof, lambda_ws + (long)e * ORC_MAXCAND * 3,
                     contact_force + (long)e * NB * 3, dof_force + (long)e * ORC_NDOF, k == prm->n_sub - 1);
+        write_bodies(&s, &m, rb_state + (long)e * NB * 13);      /* also settles the root's linear velocity (momentum balance) */
         memcpy(root, s.p0, 12); memcpy(root + 3, s.q0, 16);
         memcpy(root + 7, s.V0 + 3, 12); memcpy(root + 10, s.V0, 12);
         for (int i = 1; i < NB; ++i)
@@ -854,7 +907,6 @@ void orc_sim_step(int n_env, const OrcSimParams *prm, const OrcModel *mdl, float
                 dof[((i - 1) * 3 + k) * 2] = edof[(i - 1) * 3 + k];
                 dof[((i - 1) * 3 + k) * 2 + 1] = s.wj[i][k];
             }
-        write_bodies(&s, &m, rb_state + (long)e * NB * 13);
     }
 }
 
