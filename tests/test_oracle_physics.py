@@ -348,6 +348,30 @@ def test_resting_on_a_slope_holds_by_friction_and_leans_its_contact_forces(slope
     assert abs(s.root_state[0, 0] - x1) < 1e-3                                            # held by friction
 
 
+@pytest.mark.parametrize("slope,mu", [(1.5, 1.0), (1.0, 0.5), (0.5, 0.2)])
+def test_sliding_down_a_slope_obeys_coulomb(slope, mu):
+    """tan(a) > mu: once the body lies on the slope and slides, its centre of mass accelerates down the slope with
+    g (sin a - mu cos a) and the ground carries m g cos a -- the friction-cone projection of the Gauss-Seidel solver,
+    the per-contact tangent frames and the momentum balance together, to 1 %"""
+    m = smpl_humanoid()
+    M = m.mass.sum()
+    s = oracle.Sim(pack_models([m]), oracle.default_params(mu=mu), heightfield=_slope_field(slope))
+    x0 = 60.0
+    s.root_state[0, :3] = [x0, 55.0, 0.95 + slope * (x0 - 50.0)]
+    v = []
+    for _ in range(81):
+        s.step()
+        v.append(_momenta(m, s.rb_state[0])[0] / M)
+    al = np.arctan(slope)
+    t = np.array([1, 0, slope]) / np.hypot(slope, 1)            # up-slope tangent
+    n = np.array([-slope, 0, 1]) / np.hypot(slope, 1)
+    acc = (v[80] - v[50]) @ t / 1.0                              # 30 control steps = 1 s
+    want = -9.81 * (np.sin(al) - mu * np.cos(al))
+    assert abs(acc - want) < 0.01 * abs(want)
+    assert abs(v[80] @ n) < 0.02                                  # stays on the surface
+    assert abs(s.contact_force[0].sum(0) @ n / (M * 9.81) - np.cos(al)) < 0.01
+
+
 def test_too_steep_a_slope_slides_downhill():
     """slope 1.5 (56 deg) > mu = 1: friction cannot hold, the body accelerates down the slope (-x)"""
     slope = 1.5
