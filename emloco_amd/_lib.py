@@ -108,7 +108,7 @@ SYMBOLS_SIM = [
 ]
 SYMBOLS_TASK = [
     "emloco_task_post_physics", "emloco_task_amp_rows", "emloco_task_pd_targets", "emloco_task_last_ms",
-    "emloco_task_enable_timing", "emloco_task_reset", "emloco_task_compact_done",
+    "emloco_task_enable_timing", "emloco_task_reset", "emloco_task_reset_seeded", "emloco_task_compact_done",
 ]
 
 _lib = None

@@ -114,6 +114,18 @@ int emloco_task_reset(EmlocoSim *sim, const EmlocoResetBufs *b, const int32_t *d
     return 0;
 }
 
+int emloco_task_reset_seeded(EmlocoSim *sim, const EmlocoResetBufs *b, const int32_t *dev_env_ids, int n, uint64_t seed,
+                             float *dev_rnd_ws, void *stream) {
+    if (!dev_env_ids || !dev_rnd_ws) return tfail(-1, "emloco_task_reset_seeded: null argument");
+    if (n < 0) return tfail(-1, "emloco_task_reset_seeded: bad env count");
+    if (n == 0) return 0;
+    const unsigned grid = (unsigned)(n < 256 ? n : 256);
+    hipLaunchKernelGGL(emloco::reset_fill_rnd_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_env_ids, n,
+                       (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), dev_rnd_ws);
+    THIPCHK(hipGetLastError());
+    return emloco_task_reset(sim, b, dev_env_ids, n, dev_rnd_ws, stream);
+}
+
 int emloco_task_compact_done(const int64_t *dev_flags, int n, int32_t *dev_ids, void *stream) {
     if (!dev_flags || !dev_ids || n < 1) return tfail(-1, "emloco_task_compact_done: bad argument (ids holds n + 1 entries)");
     hipLaunchKernelGGL(emloco::compact_flags_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dev_flags, n, dev_ids);

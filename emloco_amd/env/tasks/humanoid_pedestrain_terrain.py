@@ -154,8 +154,13 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
                 rows += [np.asarray(v["traj"], np.float32)[:101] for v in (d.values() if isinstance(d, dict) else d)]
             real = torch.from_numpy(np.stack(rows)).to(dev).contiguous()
         E = self.num_envs
-        self._reset_motion_ids = torch.zeros(E, dtype=torch.long, device=dev)
-        self._reset_motion_times = torch.zeros(E, device=dev)
+        # the reset kernels write the sampled motion id / start time of a reset env straight into the task's per-env
+        # bookkeeping (humanoid_amp.py:191-192 does the same by index assignment): alias, no merge pass afterwards
+        assert self._sampled_motion_ids.dtype == torch.long and self._motion_start_times.dtype == torch.float32
+        self._sampled_motion_ids = self._sampled_motion_ids.contiguous()
+        self._motion_start_times = self._motion_start_times.contiguous()
+        self._reset_motion_ids = self._sampled_motion_ids
+        self._reset_motion_times = self._motion_start_times
         self._reset_ground_h = torch.zeros(E, device=dev)
         self._inverted_u8 = torch.zeros(E, dtype=torch.uint8, device=dev)
         keep = dict(real=real, vx=self.terrain.coord_x_scale.float().contiguous(), vy=self.terrain.coord_y_scale.float().contiguous(),
@@ -191,8 +196,7 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         if flags.init_heading and flags.heading_inversion:
             self._traj_gen.inverted = self._inverted_u8.bool()
         self.inverted = self._traj_gen.show_inverted()
-        self._motion_start_times[env_ids] = self._reset_motion_times[env_ids]
-        self._sampled_motion_ids[env_ids] = self._reset_motion_ids[env_ids]
+        # _motion_start_times / _sampled_motion_ids: written in place by the reset kernels (aliased in _make_reset_bufs)
 
     def reset_done(self, rnd=None):
         """Reset every env whose reset_buf is set WITHOUT the host reading which ones: the reference's loop does
@@ -213,21 +217,29 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         if getattr(self, "_done_ids", None) is None:
             self._done_ids = torch.full((E + 1,), -1, dtype=torch.int32, device=self.device)
         st = current_stream_handle(torch.device(self.device))
-        done = self.reset_buf != 0                                   # mask snapshot: the reset kernels clear reset_buf
         lib = self._post.lib
         L.check(lib.emloco_task_compact_done(C.c_void_p(self.reset_buf.data_ptr()), E, C.c_void_p(self._done_ids.data_ptr()), st),
                 "emloco_task_compact_done")
         if rnd is None:
-            rnd = torch.rand((E, L.RESET_RND), device=self.device)       # row i serves the i-th finished env (ascending id)
-        L.check(lib.emloco_task_reset(self.sim.native._h, C.byref(self._reset_bufs), C.c_void_p(self._done_ids.data_ptr()), E,
-                                      C.c_void_p(rnd.data_ptr()), st), "emloco_task_reset")
+            # random rows made on the device for the finished envs only (row i serves the i-th finished env, ascending id),
+            # from a per-call seed: torch's seed (set by run.py / set_seed) + a call counter
+            if getattr(self, "_rnd_ws", None) is None:
+                self._rnd_ws = torch.empty((E, L.RESET_RND), device=self.device)
+                self._rnd_calls = 0
+                self._rnd_seed0 = int(torch.initial_seed()) & 0xFFFFFFFFFFFF
+            self._rnd_calls += 1
+            lib.emloco_task_reset_seeded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
+            L.check(lib.emloco_task_reset_seeded(self.sim.native._h, C.byref(self._reset_bufs), C.c_void_p(self._done_ids.data_ptr()), E,
+                                                 C.c_uint64((self._rnd_seed0 * 0x9E3779B97F4A7C15 + self._rnd_calls) & 0xFFFFFFFFFFFFFFFF),
+                                                 C.c_void_p(self._rnd_ws.data_ptr()), st), "emloco_task_reset_seeded")
+        else:
+            L.check(lib.emloco_task_reset(self.sim.native._h, C.byref(self._reset_bufs), C.c_void_p(self._done_ids.data_ptr()), E,
+                                          C.c_void_p(rnd.data_ptr()), st), "emloco_task_reset")
         self._post.run(self._post_bufs if self._post_bufs is not None else self._ensure_post_bufs(), L.POST_OBS | L.POST_AMP_ROW,
                        self._done_ids[:E])
         if flags.init_heading and flags.heading_inversion:
             self._traj_gen.inverted = self._inverted_u8.bool()
-        self.inverted = self._traj_gen.show_inverted()
-        self._motion_start_times = torch.where(done, self._reset_motion_times, self._motion_start_times)
-        self._sampled_motion_ids = torch.where(done, self._reset_motion_ids, self._sampled_motion_ids)
+        self.inverted = self._traj_gen.show_inverted()      # motion ids / start times: written in place by the reset kernels
 
     def _ensure_post_bufs(self):
         self._post_bufs = self._make_post_bufs()

@@ -157,6 +157,14 @@ struct EmlocoSim;
 int emloco_task_reset(struct EmlocoSim *sim, const EmlocoResetBufs *bufs, const int32_t *dev_env_ids, int n,
                       const float *dev_rnd, void *stream);
 
+/* Same, with the random rows produced on the device: row i of `dev_rnd_ws` ([n][EMLOCO_RESET_RND] floats, caller-owned
+ * workspace) is filled with uniforms in [0, 1) from a stateless hash of (seed, i, k) for the list entries that are present,
+ * then emloco_task_reset runs on it.  Pass a fresh seed per call (e.g. base seed + call counter; the reference draws from
+ * torch's global generator: humanoid_amp.py:284-379, traj_generator.py:60-237).  With a compacted done-list this avoids
+ * generating n_env rows per step when a few dozen envs finish. */
+int emloco_task_reset_seeded(struct EmlocoSim *sim, const EmlocoResetBufs *bufs, const int32_t *dev_env_ids, int n,
+                             uint64_t seed, float *dev_rnd_ws, void *stream);
+
 /* Device-side `reset_buf.nonzero()`: dev_ids[0..count) = ascending indices of the non-zero flags, the rest of the n
  * entries = -1, dev_ids[n] = count.  Every *_indexed / env-id-list entry point of this library skips negative ids, so
  *   emloco_task_compact_done(reset_buf, E, ids, s); emloco_task_reset(sim, bufs, ids, E, rnd, s);

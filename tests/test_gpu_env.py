@@ -189,6 +189,40 @@ def test_reset_done_equals_reset_of_nonzero():
     assert torch.equal(ta._traj_gen._traj_verts, tb._traj_gen._traj_verts) if hasattr(ta._traj_gen, "_traj_verts") else True
 
 
+def test_seeded_reset_done_draws_uniform_rows_on_the_device():
+    """reset_done() without explicit rows: the rows come from the stateless device generator, only for the finished envs;
+    same seed and call count -> same bytes, the values are uniform on [0, 1), and the resets it produces are as varied as
+    torch.rand's (spawn headings over the whole circle, motion ids over the library)."""
+    from emloco_amd import _lib as L
+    args = ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel"]
+    torch.manual_seed(7)
+    a = _make_env(256, args)
+    torch.manual_seed(7)
+    b = _make_env(256, args)
+    for env in (a, b):
+        env.task.reset_buf[:] = 1
+        env.task.reset_done()
+    torch.cuda.synchronize()
+    ta, tb = a.task, b.task
+    assert ta._rnd_seed0 == tb._rnd_seed0 and torch.equal(ta._rnd_ws, tb._rnd_ws)
+    assert torch.equal(ta._root_states, tb._root_states) and torch.equal(ta._sampled_motion_ids, tb._sampled_motion_ids)
+    u = ta._rnd_ws
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0
+    assert abs(float(u.mean()) - 0.5) < 0.005 and abs(float(u.var()) - 1.0 / 12.0) < 0.003
+    assert abs(float(torch.corrcoef(torch.stack([u[:, :-1].flatten(), u[:, 1:].flatten()]))[0, 1])) < 0.01     # neighbours in a row
+    assert abs(float(torch.corrcoef(torch.stack([u[:-1].flatten(), u[1:].flatten()]))[0, 1])) < 0.01           # neighbouring rows
+    yaw = 2 * torch.atan2(ta._root_states[:, 5], ta._root_states[:, 6])
+    assert float(yaw.min()) < -2.0 and float(yaw.max()) > 2.0 and ta._sampled_motion_ids.unique().numel() > 20
+    # next call: a different seed, and only the finished envs' rows are touched
+    before = ta._rnd_ws.clone()
+    ta.reset_buf[:] = 0
+    ta.reset_buf[10:20] = 1
+    ta.reset_done()
+    torch.cuda.synchronize()
+    assert not torch.equal(ta._rnd_ws[:10], before[:10]) and torch.equal(ta._rnd_ws[10:], before[10:])
+    assert (ta.progress_buf[10:20] == 0).all()
+
+
 def test_fused_reset_matches_host_mirror():
     """The three-kernel device reset against the host-side torch mirror of the reference's reset path."""
     from emloco_amd import _lib as L
