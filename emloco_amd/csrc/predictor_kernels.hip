@@ -138,7 +138,25 @@ __device__ __forceinline__ void gemm_frag(const float *S, int row, int half8, f3
 // values per 32-row block are GBK/8 ds_read_b128 of one LDS row, and step j multiplies k = j (low half) with
 // k = GBK/2 + j (high half).  GBK = 32 (one stage = 64 MFMAs per wave, ~4 k cycles) covers the global-load latency
 // of the register prefetch for long reductions; GBK = 16 keeps LDS small (more workgroups per CU) for K <= 256.
-template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC>
+// PREC = 1 (opt-in, EMLOCO_GEMM_BF16): the same tiles, loads and LDS stages, but the fp32 fragments are rounded to bf16
+// (v_cvt_pk_bf16_f32, round to nearest even) on their way into v_mfma_f32_32x32x16_bf16 -- one matrix instruction per 16 k
+// instead of eight, fp32 accumulation.  Lane (l & 31, h = l >> 5) supplies 8 consecutive k of its half, which is what
+// two adjacent fp32 fragments already hold; A and B use the same k permutation, so no layout changes.
+#ifndef EMLOCO_EMU      /* the CPU emulation header (tests/emu/hip) supplies gemm_bf16x8 / gemm_pack_bf16 / gemm_mfma_bf16 itself */
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 gemm_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ gemm_bf16x8 gemm_pack_bf16(const f32x4 &lo, const f32x4 &hi) {
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    const vf4 l = {lo.x, lo.y, lo.z, lo.w}, h = {hi.x, hi.y, hi.z, hi.w};
+    const bf16x4 a = __builtin_convertvector(l, bf16x4), b = __builtin_convertvector(h, bf16x4);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ f32x16 gemm_mfma_bf16(gemm_bf16x8 a, gemm_bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+#endif
+
+template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int PREC = 0>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = WM * TI * 32, BN = WN * TJ * 32, GLDK = GBK + 4, NF = GBK / 8;
@@ -182,7 +200,19 @@ gemm_f32_kernel(GemmArgs g) {
         for (int i = 0; i < TI; ++i)                                                                             \
             for (int j = 0; j < TJ; ++j)                                                                         \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][H].C, fb[j][H].C, acc[i][j], 0, 0, 0);
-        for (int f = 0; f < NF; ++f) { GEMM_STEP(f, x) GEMM_STEP(f, y) GEMM_STEP(f, z) GEMM_STEP(f, w) }
+        if constexpr (PREC == 0) {
+            for (int f = 0; f < NF; ++f) { GEMM_STEP(f, x) GEMM_STEP(f, y) GEMM_STEP(f, z) GEMM_STEP(f, w) }
+        } else {
+            static_assert(PREC == 0 || NF % 2 == 0, "bf16 operands take k in groups of 16");
+            for (int f = 0; f + 1 < NF; f += 2) {
+                gemm_bf16x8 pa[TI], pb[TJ];
+                for (int i = 0; i < TI; ++i) pa[i] = gemm_pack_bf16(fa[i][f], fa[i][f + 1]);
+                for (int j = 0; j < TJ; ++j) pb[j] = gemm_pack_bf16(fb[j][f], fb[j][f + 1]);
+                for (int i = 0; i < TI; ++i)
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = gemm_mfma_bf16(pa[i], pb[j], acc[i][j]);
+            }
+        }
 #undef GEMM_STEP
         gemm_stash<BM, GBK, TA>(ra, As[buf ^ 1], tid);
         gemm_stash<BN, GBK, TB>(rb, Bs[buf ^ 1], tid);
@@ -214,7 +244,13 @@ gemm_f32_kernel(GemmArgs g) {
 // kernel variant for a problem: tile shape (narrow: n <= 32), stage depth, operand layouts, 16-byte loads
 typedef void (*GemmKernel)(GemmArgs);
 template <int WM, int WN, int TI, int TJ, int GBK>
-inline GemmKernel gemm_pick_layout(int ta, int tb, int vec) {
+inline GemmKernel gemm_pick_layout(int ta, int tb, int vec, int bf16 = 0) {
+    if (vec && bf16) {       // bf16 operands: the 16-byte-load variants only (every hot shape qualifies; others stay fp32)
+        if (!ta && !tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 0, 0, 1, 1>;
+        if (!ta && tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 0, 1, 1, 1>;
+        if (ta && !tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 1, 0, 1, 1>;
+        return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 1, 1, 1, 1>;
+    }
     if (vec) {
         if (!ta && !tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 0, 0, 1>;
         if (!ta && tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 0, 1, 1>;
@@ -228,8 +264,9 @@ inline GemmKernel gemm_pick_layout(int ta, int tb, int vec) {
 }
 inline GemmKernel gemm_pick(const GemmArgs &g, bool deep) {
     const int vec = g.vec_a && g.vec_b;
+    const int bf16 = (g.flags & 16) ? 1 : 0;
     if (g.n <= 32) return deep ? gemm_pick_layout<4, 1, 1, 1, 32>(g.ta, g.tb, vec) : gemm_pick_layout<4, 1, 1, 1, 16>(g.ta, g.tb, vec);
-    return deep ? gemm_pick_layout<2, 2, 2, 2, 32>(g.ta, g.tb, vec) : gemm_pick_layout<2, 2, 2, 2, 16>(g.ta, g.tb, vec);
+    return deep ? gemm_pick_layout<2, 2, 2, 2, 32>(g.ta, g.tb, vec, bf16) : gemm_pick_layout<2, 2, 2, 2, 16>(g.ta, g.tb, vec, bf16);
 }
 
 // sum of the ksplit partial products in a fixed order, then the epilogue

@@ -57,9 +57,28 @@ def _chk(rc, what):
         raise L.EmlocoError(f"{what} failed with code {rc}")
 
 
+GEMM_BF16 = 16
+_matmul_precision = ["fp32"]
+
+
+def set_matmul_precision(mode):
+    """"fp32" (default: fp32 operands on the fp32 matrix instruction, the path the 1e-4 parity tests hold) or "bf16"
+    (operands rounded to bf16 on their way into the matrix cores, fp32 accumulation; ~1e-3 relative output error) for
+    every `linear` / projection GEMM launched afterwards.  The fused attention kernels stay fp32."""
+    if mode not in ("fp32", "bf16"):
+        raise ValueError("matmul precision must be 'fp32' or 'bf16'")
+    _matmul_precision[0] = mode
+
+
+def get_matmul_precision():
+    return _matmul_precision[0]
+
+
 def gemm(batch, m, n, k, A, lda, sa, ta, B, ldb, sb, tb, Cm, ldc, sc, alpha=1.0, bias=None, flags=0, ksplit=1,
          a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0):
     """Raw strided batched GEMM: C_b[m][n] (+)= alpha * sum_k A_b(m,k) B_b(n,k) (see the header for the layouts)."""
+    if _matmul_precision[0] == "bf16":
+        flags |= GEMM_BF16
     ws = None
     if ksplit > 1:
         ws = torch.empty(ksplit * batch * m * n, dtype=torch.float32, device=Cm.device)

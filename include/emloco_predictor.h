@@ -15,7 +15,10 @@
 extern "C" {
 #endif
 
-enum { EMLOCO_GEMM_BIAS = 1, EMLOCO_GEMM_RELU = 2, EMLOCO_GEMM_ACCUMULATE = 4, EMLOCO_GEMM_DROPOUT = 8 };
+enum { EMLOCO_GEMM_BIAS = 1, EMLOCO_GEMM_RELU = 2, EMLOCO_GEMM_ACCUMULATE = 4, EMLOCO_GEMM_DROPOUT = 8,
+       /* opt-in reduced precision: operands rounded to bf16 on their way into the matrix cores (fp32 in memory, fp32
+        * accumulation, v_mfma_f32_32x32x16_bf16); ~1e-3 relative output error instead of fp32's 1e-6.  Off by default. */
+       EMLOCO_GEMM_BF16 = 16 };
 
 /* Batched strided GEMM on the matrix cores, fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: exact fp32):
  *   C[b][m][n] (+)= alpha * sum_k A_b(m,k) * B_b(n,k)   [+ bias[n]] [relu]

@@ -89,6 +89,42 @@ static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, 
     emu::barrier();
     return d;
 }
+// v_mfma_f32_32x32x16_bf16 behind the kernel's gemm_* wrappers: lane l supplies 8 consecutive k = 8 * (l >> 5) + e of row /
+// column l & 31, operands rounded to bf16 (nearest even), products and sums in fp32 (ascending k: the hardware's internal
+// order is not specified, the test compares with a tolerance).
+#define EMLOCO_EMU 1
+struct gemm_bf16x8 { unsigned short v[8]; };
+struct f32x4;
+static inline unsigned short emu_f32_to_bf16(float f) {
+    uint32_t u; std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);     // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static inline float emu_bf16_to_f32(unsigned short h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+template <class F4> static inline gemm_bf16x8 gemm_pack_bf16(const F4 &lo, const F4 &hi) {
+    gemm_bf16x8 r;
+    const float in[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    for (int e = 0; e < 8; ++e) r.v[e] = emu_f32_to_bf16(in[e]);
+    return r;
+}
+static inline emu_f32x16 gemm_mfma_bf16(gemm_bf16x8 a, gemm_bf16x8 b, emu_f32x16 c) {
+    static gemm_bf16x8 bufa[1024], bufb[1024];
+    const unsigned tid = threadIdx.x, base = tid & ~63u, lane = tid & 63u;
+    bufa[tid] = a; bufb[tid] = b;
+    emu::barrier();
+    emu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (int)(lane >> 5), col = (int)(lane & 31);
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 8; ++e)
+                acc = std::fmaf(emu_bf16_to_f32(bufa[base + row + 32 * h].v[e]), emu_bf16_to_f32(bufb[base + col + 32 * h].v[e]), acc);
+        d[r] = acc;
+    }
+    emu::barrier();
+    return d;
+}
 using std::exp; using std::cos; using std::sin; using std::atan2;
 
 // DPP lane permutations (the gfx9 dpp_ctrl codes the kernels use) and v_readlane

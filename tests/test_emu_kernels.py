@@ -209,6 +209,36 @@ def test_mfma_gemm_kernel_all_layouts():
     np.testing.assert_allclose(_gemm(Ab, Bb, 0, 0, 40, 50, 20, batch=3), np.einsum("bmk,bnk->bmn", Ab, Bb), **tol)
 
 
+def test_mfma_gemm_kernel_bf16_operands():
+    """EMLOCO_GEMM_BF16 (opt-in): operands rounded to bf16 on their way into the matrix cores, fp32 accumulation.  Against
+    the product of the bf16-ROUNDED operands the kernel is exact to fp32 accumulation error; against the fp32 product the
+    error is the operand rounding (2^-9 relative per factor).  All four layouts, both stage depths, ragged edges."""
+    rng = np.random.default_rng(5)
+
+    def bf16(x):
+        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+        return u.astype(np.uint32).view(np.float32)
+    for m, n, k in ((148, 136, 44), (72, 132, 520)):
+        A = rng.normal(size=(1, m, k)).astype(np.float32)
+        B = rng.normal(size=(1, n, k)).astype(np.float32)
+        exact = bf16(A[0]).astype(np.float64) @ bf16(B[0]).astype(np.float64).T
+        full = A[0].astype(np.float64) @ B[0].astype(np.float64).T
+        At, Bt = np.ascontiguousarray(A.transpose(0, 2, 1)), np.ascontiguousarray(B.transpose(0, 2, 1))
+        for a_, b_, ta, tb in ((A, B, 0, 0), (At, Bt, 1, 1), (A, Bt, 0, 1), (At, B, 1, 0)):
+            got = _gemm(a_, b_, ta, tb, m, n, k, flags=16)[0]
+            np.testing.assert_allclose(got, exact, rtol=1e-5, atol=1e-4)
+            assert 1e-4 < np.abs(got - full).max() < 0.02 * np.sqrt(k)          # really reduced precision, and only that
+        bias = rng.normal(size=n).astype(np.float32)
+        np.testing.assert_allclose(_gemm(A, B, 0, 0, m, n, k, bias=bias, flags=16 | 3)[0], np.maximum(exact + bias, 0), rtol=1e-5, atol=1e-4)
+    # shapes without 16-byte alignment fall back to the fp32 operand path (flag ignored, full precision)
+    A = rng.normal(size=(1, 37, 30)).astype(np.float32)
+    B = rng.normal(size=(1, 41, 30)).astype(np.float32)
+    At = np.ascontiguousarray(A.transpose(0, 2, 1))[:, :, :]
+    np.testing.assert_allclose(_gemm(A[:, :, :29].copy(), B[:, :, :29].copy(), 0, 0, 37, 41, 29, flags=16)[0],
+                               A[0, :, :29].astype(np.float64) @ B[0, :, :29].astype(np.float64).T, rtol=1e-5, atol=2e-5)
+
+
 def test_softmax_and_layernorm_kernels():
     lib = emu.lib()
     rng = np.random.default_rng(1)

@@ -18,6 +18,9 @@ SHAPES = [
     ("policy  4096 x 512 x 1056", 1, 4096, 512, 1056, 0, 0),
     ("square  4096^3", 1, 4096, 4096, 4096, 0, 0),
 ]
+if len(sys.argv) > 1:
+    ops.set_matmul_precision(sys.argv[1])          # "bf16": operands rounded to bf16 into the matrix cores (opt-in)
+print("matmul precision:", ops.get_matmul_precision())
 for label, b, m, n, k, ta, tb in SHAPES:
     A = torch.randn((b, k, m) if ta else (b, m, k), device=dev)
     B = torch.randn((b, k, n) if tb else (b, n, k), device=dev)
