@@ -302,8 +302,31 @@ def policy_leg(env, E, dev, steps, warmup):
         pol_ms.append(ev0.elapsed_time(ev1))
     pm = float(np.median(pol_ms))
     tf = pol.flops_per_env * E / (pm * 1e-3) / 1e12
+    # the same loop with the opt-in bf16 operand mode of the GEMMs (reported beside the fp32 figure, never instead of it)
+    from emloco_amd.predictor import ops
+    bf = None
+    try:
+        ops.set_matmul_precision("bf16")
+        for _ in range(warmup):
+            one_step(False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step(False)
+        torch.cuda.synchronize()
+        el_bf = time.perf_counter() - t0
+        pol_bf = []
+        for _ in range(20):
+            one_step(True)
+            torch.cuda.synchronize()
+            pol_bf.append(ev0.elapsed_time(ev1))
+        bf = {"value": round(E * steps / el_bf, 1), "unit": "env-steps/s", "ms_per_step": round(el_bf / steps * 1e3, 4),
+              "policy_ms": round(float(np.median(pol_bf)), 4),
+              "note": "opt-in ops.set_matmul_precision('bf16'): ~2e-3 relative error per GEMM, outside the 1e-4 parity bar"}
+    finally:
+        ops.set_matmul_precision("fp32")
     return {"metric": "env-steps/sec with the frozen policy in the loop", "value": round(E * steps / elapsed, 1), "unit": "env-steps/s",
-            "ms_per_step": round(elapsed / steps * 1e3, 4), "policy_ms": round(pm, 4),
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "policy_ms": round(pm, 4), "bf16_operands": bf,
             "policy_flops_per_env": pol.flops_per_env,
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
