@@ -168,8 +168,9 @@ def jta_leg(dev, steps=4, warmup=2, B=256):
            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
                         "frac": round(tf / 157.3, 4), "traffic": None, "gemm_launches": n, "gemm_ms_per_step": round(ms / steps, 2),
                         "note": "fp32-in fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32), peak = fp32 matrix peak"}}
-    # opt-in reduced precision, reported beside the fp32 figure (never as `value`): linear-layer GEMMs with operands rounded to
-    # bf16 into v_mfma_f32_32x32x16_bf16 (fp32 in memory, fp32 accumulation); attention, softmax, LayerNorm, losses stay fp32
+    # opt-in reduced precision, reported beside the fp32 figure (never as `value`): linear-layer GEMMs and the fused attention's
+    # tile products with operands rounded to bf16 into v_mfma_f32_32x32x16_bf16 (fp32 in memory, fp32 accumulation); softmax
+    # statistics, LayerNorm, losses and the optimiser stay fp32  (BASELINE configs[3] names "bf16 MFMA attention")
     try:
         ops.set_matmul_precision("bf16")
         for _ in range(warmup):
@@ -186,7 +187,8 @@ def jta_leg(dev, steps=4, warmup=2, B=256):
         out["bf16_operands"] = {"value": round(B * steps / dt, 2), "unit": "samples/s", "ms_per_step": round(dt / steps * 1e3, 2),
                                 "gemm_tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
                                 "gemm_ms_per_step": round(ms / steps, 2),
-                                "note": "opt-in (ops.set_matmul_precision('bf16')): ~2e-3 relative error per GEMM, outside the 1e-4 parity bar"}
+                                "note": "opt-in (ops.set_matmul_precision('bf16')): bf16 MFMA operands in the linear layers and the fused "
+                                        "attention, ~2e-3 relative error per product, outside the 1e-4 parity bar"}
     finally:
         ops.set_matmul_precision("fp32")
     return out

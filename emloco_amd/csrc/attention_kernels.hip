@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "dev_math.h"
+#include "mfma_bf16.h"
 
 namespace emloco {
 
@@ -61,11 +62,19 @@ __device__ __forceinline__ void at_grow16(const float *base, long ld, int row, i
     }
 }
 // C^T tile (32 x 32) = X_tile (rows from LDS) . Yfrag^T : acc[r] of lane (j, h) = sum_dk X[kappa(r,h)][dk] Y[j][dk]
+// PREC = 1 (opt-in, EMLOCO_ATTN_BF16): the same operands rounded to bf16 into v_mfma_f32_32x32x16_bf16 -- the lane's 16
+// values dk = 16 h + 0..15 are two groups of 8 consecutive reduction entries, A and B alike: 2 instructions instead of 16.
+template <int PREC>
 __device__ __forceinline__ at_f32x16 at_xyT(const float *tile, int l31, int h, const at_f32x4 (&yf)[4]) {
     at_f32x16 acc;
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     at_f32x4 xf[4];
     at_row16(tile, l31, h, xf);
+    if constexpr (PREC == 1) {
+        acc = gemm_mfma_bf16(gemm_pack_bf16(xf[0], xf[1]), gemm_pack_bf16(yf[0], yf[1]), acc);
+        acc = gemm_mfma_bf16(gemm_pack_bf16(xf[2], xf[3]), gemm_pack_bf16(yf[2], yf[3]), acc);
+        return acc;
+    }
     for (int f = 0; f < 4; ++f) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[f].x, yf[f].x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[f].y, yf[f].y, acc, 0, 0, 0);
@@ -75,7 +84,19 @@ __device__ __forceinline__ at_f32x16 at_xyT(const float *tile, int l31, int h, c
     return acc;
 }
 // acc^T (32 d x 32 own rows) += X_tile^T . p : sum over tile rows kappa(s, h) of X[kappa][d = lane & 31] * p[s]
+// PREC = 1: reduction entries s = 8 g + e (g = 0, 1) of the lane's half form the two groups of 8.
+template <int PREC>
 __device__ __forceinline__ at_f32x16 at_xTp(const float *tile, int l31, int h, const float (&p)[16], at_f32x16 acc) {
+    if constexpr (PREC == 1) {
+        for (int g = 0; g < 2; ++g) {
+            float x[8];
+            for (int e = 0; e < 8; ++e) x[e] = tile[at_kappa(8 * g + e, h) * AT_LD + l31];
+            const at_f32x4 x0{x[0], x[1], x[2], x[3]}, x1{x[4], x[5], x[6], x[7]};
+            const at_f32x4 p0{p[8 * g], p[8 * g + 1], p[8 * g + 2], p[8 * g + 3]}, p1{p[8 * g + 4], p[8 * g + 5], p[8 * g + 6], p[8 * g + 7]};
+            acc = gemm_mfma_bf16(gemm_pack_bf16(x0, x1), gemm_pack_bf16(p0, p1), acc);
+        }
+        return acc;
+    }
     for (int s = 0; s < 16; ++s)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[at_kappa(s, h) * AT_LD + l31], p[s], acc, 0, 0, 0);
     return acc;
@@ -106,6 +127,7 @@ __device__ __forceinline__ void at_store_rowT(float *dst, int h, const at_f32x16
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+template <int PREC>
 __global__ void __launch_bounds__(256)
 attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[2][AT_T * AT_LD], Vs[2][AT_T * AT_LD], Bs[2][AT_T];
@@ -133,7 +155,7 @@ attn_fwd_kernel(AttnArgs a) {
         rk = at_fetch4(K, ld, k0n, a.S, tid); rv = at_fetch4(V, ld, k0n, a.S, tid);      // past the end: zeros, never used
         if (tid < AT_T) { const int kk = k0n + tid; const int kc = kk < a.S ? kk : a.S - 1; const float v = kb ? kb[kc] : 0.0f; rb = kk < a.S ? v : -INFINITY; }
         // scores^T tile: keys (rows) x own queries (lanes)
-        at_f32x16 st = at_xyT(Ks[buf], l31, h, qf);
+        at_f32x16 st = at_xyT<PREC>(Ks[buf], l31, h, qf);
         float bias[16], p[16];
         at_vec16(Bs[buf], h, bias);
         float tmax = AT_NEG;
@@ -147,7 +169,7 @@ attn_fwd_kernel(AttnArgs a) {
         lsum = lsum * alpha + tsum;
         m = m_new;
         for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
-        acc_o = at_xTp(Vs[buf], l31, h, p, acc_o);     // O^T += V^T P^T
+        acc_o = at_xTp<PREC>(Vs[buf], l31, h, p, acc_o);     // O^T += V^T P^T
         at_stash4(Ks[buf ^ 1], tid, rk); at_stash4(Vs[buf ^ 1], tid, rv);
         if (tid < AT_T) Bs[buf ^ 1][tid] = rb;
         __syncthreads();
@@ -160,6 +182,7 @@ attn_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward 1: dQ (and D)
+template <int PREC>
 __global__ void __launch_bounds__(256)
 attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[2][AT_T * AT_LD], Vs[2][AT_T * AT_LD], Bs[2][AT_T];
@@ -193,8 +216,8 @@ attn_bwd_dq_kernel(AttnArgs a) {
         const int buf = t & 1, k0n = (t + 1) * AT_T;
         rk = at_fetch4(K, ld, k0n, a.S, tid); rv = at_fetch4(V, ld, k0n, a.S, tid);
         if (tid < AT_T) { const int kk = k0n + tid; const int kc = kk < a.S ? kk : a.S - 1; const float v = kb ? kb[kc] : 0.0f; rb = kk < a.S ? v : -INFINITY; }
-        const at_f32x16 st = at_xyT(Ks[buf], l31, h, qf);           // S^T
-        const at_f32x16 dpt = at_xyT(Vs[buf], l31, h, dof);         // dP^T = V dO^T
+        const at_f32x16 st = at_xyT<PREC>(Ks[buf], l31, h, qf);           // S^T
+        const at_f32x16 dpt = at_xyT<PREC>(Vs[buf], l31, h, dof);         // dP^T = V dO^T
         float bias[16], ds[16];
         at_vec16(Bs[buf], h, bias);
         for (int r = 0; r < 16; ++r) {
@@ -202,7 +225,7 @@ attn_bwd_dq_kernel(AttnArgs a) {
             const float p = v > AT_NEG ? expf(v - lse) : 0.0f;
             ds[r] = a.scale * p * (dpt[r] - dsum);
         }
-        acc = at_xTp(Ks[buf], l31, h, ds, acc);                     // dQ^T += K^T dS^T
+        acc = at_xTp<PREC>(Ks[buf], l31, h, ds, acc);                     // dQ^T += K^T dS^T
         at_stash4(Ks[buf ^ 1], tid, rk); at_stash4(Vs[buf ^ 1], tid, rv);
         if (tid < AT_T) Bs[buf ^ 1][tid] = rb;
         __syncthreads();
@@ -211,6 +234,7 @@ attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward 2: dK, dV
+template <int PREC>
 __global__ void __launch_bounds__(256)
 attn_bwd_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[2][AT_T * AT_LD], Os[2][AT_T * AT_LD], Ls[2][AT_T], Ds[2][AT_T];
@@ -240,8 +264,8 @@ attn_bwd_dkv_kernel(AttnArgs a) {
         const int buf = t & 1, q0n = (t + 1) * AT_T;
         rq = at_fetch4(Q, ld, q0n, a.S, tid); ro = at_fetch4(dO, a.d_model, q0n, a.S, tid);
         if (tid < AT_T) { const int qq = q0n + tid; const int qc = qq < a.S ? qq : a.S - 1; const float l0 = lse[qc], d0 = dsm[qc]; rl = qq < a.S ? l0 : 3.0e38f; rd = qq < a.S ? d0 : 0.0f; }
-        const at_f32x16 s = at_xyT(Qs[buf], l31, h, kf);            // S: queries (rows) x own keys (lanes)
-        const at_f32x16 dp = at_xyT(Os[buf], l31, h, vf);           // dP = dO V^T
+        const at_f32x16 s = at_xyT<PREC>(Qs[buf], l31, h, kf);            // S: queries (rows) x own keys (lanes)
+        const at_f32x16 dp = at_xyT<PREC>(Os[buf], l31, h, vf);           // dP = dO V^T
         float lrow[16], drow[16], p[16], ds[16];
         at_vec16(Ls[buf], h, lrow);
         at_vec16(Ds[buf], h, drow);
@@ -250,8 +274,8 @@ attn_bwd_dkv_kernel(AttnArgs a) {
             p[r] = v > AT_NEG ? expf(v - lrow[r]) : 0.0f;           // rows past the sequence carry lse = 3e38 -> 0
             ds[r] = a.scale * p[r] * (dp[r] - drow[r]);
         }
-        acc_v = at_xTp(Os[buf], l31, h, p, acc_v);                  // dV^T += dO^T P
-        acc_k = at_xTp(Qs[buf], l31, h, ds, acc_k);                 // dK^T += Q^T dS
+        acc_v = at_xTp<PREC>(Os[buf], l31, h, p, acc_v);                  // dV^T += dO^T P
+        acc_k = at_xTp<PREC>(Qs[buf], l31, h, ds, acc_k);                 // dK^T += Q^T dS
         at_stash4(Qs[buf ^ 1], tid, rq); at_stash4(Os[buf ^ 1], tid, ro);
         if (tid < AT_T) { Ls[buf ^ 1][tid] = rl; Ds[buf ^ 1][tid] = rd; }
         __syncthreads();

@@ -173,26 +173,40 @@ int emloco_colsum(int m, int n, const float *X, float *out, float *workspace, vo
 
 int emloco_attention_fwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                          float *out, float *lse, void *stream) {
+    return emloco_attention_fwd_ex(n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, 0, stream);
+}
+
+int emloco_attention_fwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                            float *out, float *lse, int flags, void *stream) {
     if (n_seq < 1 || S < 1 || nhead < 1 || d_model != nhead * AT_DH || !qkv || !out || !lse)
         return pfail(-1, "emloco_attention_fwd: bad argument (head dim must be 32)");
     if ((long)n_seq * nhead > 65535) return pfail(-1, "emloco_attention_fwd: n_seq * nhead exceeds the grid limit");
     emloco::AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(emloco::attn_fwd_kernel, dim3((unsigned)((S + 127) / 128), (unsigned)(n_seq * nhead)), dim3(256), 0,
-                       (hipStream_t)stream, a);
+    const dim3 grid((unsigned)((S + 127) / 128), (unsigned)(n_seq * nhead));
+    if (flags & EMLOCO_ATTN_BF16) hipLaunchKernelGGL(emloco::attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(emloco::attn_fwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
     PHIPCHK(hipGetLastError());
     return 0;
 }
 
 int emloco_attention_bwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                          const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, void *stream) {
+    return emloco_attention_bwd_ex(n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, dout, dqkv, dsum, 0, stream);
+}
+
+int emloco_attention_bwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                            const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags, void *stream) {
     if (n_seq < 1 || S < 1 || nhead < 1 || d_model != nhead * AT_DH || !qkv || !out || !lse || !dout || !dqkv || !dsum)
         return pfail(-1, "emloco_attention_bwd: bad argument (head dim must be 32; dsum = n_seq * nhead * S floats)");
     if ((long)n_seq * nhead > 65535) return pfail(-1, "emloco_attention_bwd: n_seq * nhead exceeds the grid limit");
     emloco::AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, const_cast<float *>(out), const_cast<float *>(lse), dout, dqkv, dsum};
     const dim3 grid((unsigned)((S + 127) / 128), (unsigned)(n_seq * nhead));
-    hipLaunchKernelGGL(emloco::attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);      // also writes D = rowsum(dO o O)
+    const bool bf = (flags & EMLOCO_ATTN_BF16) != 0;
+    if (bf) hipLaunchKernelGGL(emloco::attn_bwd_dq_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(emloco::attn_bwd_dq_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);      // also writes D = rowsum(dO o O)
     PHIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(emloco::attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (bf) hipLaunchKernelGGL(emloco::attn_bwd_dkv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(emloco::attn_bwd_dkv_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
     PHIPCHK(hipGetLastError());
     return 0;
 }

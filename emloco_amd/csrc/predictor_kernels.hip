@@ -13,6 +13,7 @@
 // fragments as 32 consecutive floats (conflict-free ds_read_b32).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mfma_bf16.h"
 #include "dev_math.h"
 
 namespace emloco {
@@ -142,19 +143,6 @@ __device__ __forceinline__ void gemm_frag(const float *S, int row, int half8, f3
 // (v_cvt_pk_bf16_f32, round to nearest even) on their way into v_mfma_f32_32x32x16_bf16 -- one matrix instruction per 16 k
 // instead of eight, fp32 accumulation.  Lane (l & 31, h = l >> 5) supplies 8 consecutive k of its half, which is what
 // two adjacent fp32 fragments already hold; A and B use the same k permutation, so no layout changes.
-#ifndef EMLOCO_EMU      /* the CPU emulation header (tests/emu/hip) supplies gemm_bf16x8 / gemm_pack_bf16 / gemm_mfma_bf16 itself */
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 gemm_bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ gemm_bf16x8 gemm_pack_bf16(const f32x4 &lo, const f32x4 &hi) {
-    typedef float vf4 __attribute__((ext_vector_type(4)));
-    const vf4 l = {lo.x, lo.y, lo.z, lo.w}, h = {hi.x, hi.y, hi.z, hi.w};
-    const bf16x4 a = __builtin_convertvector(l, bf16x4), b = __builtin_convertvector(h, bf16x4);
-    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-__device__ __forceinline__ f32x16 gemm_mfma_bf16(gemm_bf16x8 a, gemm_bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-#endif
 
 template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int PREC = 0>
 __global__ void __launch_bounds__(256)

@@ -30,6 +30,8 @@ def _lib():
         lib.emloco_colsum.argtypes = [ci, ci, vp, vp, vp, vp]
         lib.emloco_attention_fwd.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp]
         lib.emloco_attention_bwd.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.emloco_attention_fwd_ex.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, ci, vp]
+        lib.emloco_attention_bwd_ex.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, ci, vp]
         lib.emloco_colsum_workspace.argtypes = [ci, ci]
         lib.emloco_colsum_workspace.restype = C.c_int64
         lib.emloco_layernorm_bwd_workspace.argtypes = [ci, ci]
@@ -58,13 +60,15 @@ def _chk(rc, what):
 
 
 GEMM_BF16 = 16
+ATTN_BF16 = 16
 _matmul_precision = ["fp32"]
 
 
 def set_matmul_precision(mode):
     """"fp32" (default: fp32 operands on the fp32 matrix instruction, the path the 1e-4 parity tests hold) or "bf16"
     (operands rounded to bf16 on their way into the matrix cores, fp32 accumulation; ~1e-3 relative output error) for
-    every `linear` / projection GEMM launched afterwards.  The fused attention kernels stay fp32."""
+    every `linear` / projection GEMM and every fused attention launched afterwards (softmax statistics, LayerNorm, losses
+    and the optimiser stay fp32; tensors in memory stay fp32)."""
     if mode not in ("fp32", "bf16"):
         raise ValueError("matmul precision must be 'fp32' or 'bf16'")
     _matmul_precision[0] = mode
@@ -190,11 +194,12 @@ class FusedAttentionFn(torch.autograd.Function):
         lse = torch.empty((Bn * nhead, S), dtype=torch.float32, device=qkv.device)
         scale = 1.0 / float(d // nhead) ** 0.5
         lib, st = _lib(), _st(qkv)
+        ctx.attn_flags = ATTN_BF16 if _matmul_precision[0] == "bf16" else 0      # the backward follows the forward's choice
         step = FusedAttentionFn.MAX_SEQ_HEADS // nhead
         for b0 in range(0, Bn, step):
             n = min(step, Bn - b0)
-            _chk(lib.emloco_attention_fwd(n, S, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
-                                          _p(out, b0 * S * d), _p(lse, b0 * nhead * S), st), "emloco_attention_fwd")
+            _chk(lib.emloco_attention_fwd_ex(n, S, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
+                                             _p(out, b0 * S * d), _p(lse, b0 * nhead * S), ctx.attn_flags, st), "emloco_attention_fwd_ex")
         ctx.save_for_backward(qkv, key_pad, out, lse)
         ctx.nhead, ctx.scale = nhead, scale
         return out
@@ -212,9 +217,9 @@ class FusedAttentionFn(torch.autograd.Function):
         step = FusedAttentionFn.MAX_SEQ_HEADS // nhead
         for b0 in range(0, Bn, step):
             n = min(step, Bn - b0)
-            _chk(lib.emloco_attention_bwd(n, S, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
-                                          _p(out, b0 * S * d), _p(lse, b0 * nhead * S), _p(dout, b0 * S * d), _p(dqkv, b0 * S * d3),
-                                          _p(dsum, b0 * nhead * S), st), "emloco_attention_bwd")
+            _chk(lib.emloco_attention_bwd_ex(n, S, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
+                                             _p(out, b0 * S * d), _p(lse, b0 * nhead * S), _p(dout, b0 * S * d), _p(dqkv, b0 * S * d3),
+                                             _p(dsum, b0 * nhead * S), ctx.attn_flags, st), "emloco_attention_bwd_ex")
         return dqkv, None, None
 
 

@@ -72,6 +72,15 @@ int emloco_attention_fwd(int n_seq, int S, int nhead, int d_model, float scale, 
 int emloco_attention_bwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                          const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, void *stream);
 
+/* The same with flags: EMLOCO_ATTN_BF16 = the opt-in reduced precision of EMLOCO_GEMM_BF16 for the four (forward) / eight
+ * (backward) tile products per step: operands (q, k, v, probabilities, dO, dS) rounded to bf16 into
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulation; softmax statistics, log-sum-exp and D stay fp32.  flags = 0 is the call above. */
+enum { EMLOCO_ATTN_BF16 = 16 };
+int emloco_attention_fwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                            float *out, float *lse, int flags, void *stream);
+int emloco_attention_bwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                            const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags, void *stream);
+
 /* y = LayerNorm(x + res) * gamma + beta over the last dim (post-norm encoder layer, d <= 1024);
  * res may be NULL.  Saves mean / rstd [rows] for the backward. */
 int emloco_layernorm_fwd(int rows, int d, float eps, const float *x, const float *res, const float *gamma,

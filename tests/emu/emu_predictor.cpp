@@ -81,12 +81,14 @@ extern "C" int emu_locoval_bwd(int B, const float *traj, int ts, const float *po
     return 0;
 }
 
+static int g_attn_prec = 0;     // 1: bf16 operands (EMLOCO_ATTN_BF16)
+extern "C" void emu_attention_set_precision(int p) { g_attn_prec = p; }
 extern "C" int emu_attention_fwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                                  float *out, float *lse) {
     AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr};
     for (int y = 0; y < n_seq * nhead; ++y)
         for (int x = 0; x < (S + 127) / 128; ++x)
-            emu::launch(1, 256, [&] { blockIdx.x = x; blockIdx.y = y; attn_fwd_kernel(a); });
+            emu::launch(1, 256, [&] { blockIdx.x = x; blockIdx.y = y; if (g_attn_prec) attn_fwd_kernel<1>(a); else attn_fwd_kernel<0>(a); });
     blockIdx.x = 0; blockIdx.y = 0;
     return 0;
 }
@@ -96,7 +98,11 @@ extern "C" int emu_attention_bwd(int n_seq, int S, int nhead, int d_model, float
     for (int pass = 0; pass < 2; ++pass)
         for (int y = 0; y < n_seq * nhead; ++y)
             for (int x = 0; x < (S + 127) / 128; ++x)
-                emu::launch(1, 256, [&] { blockIdx.x = x; blockIdx.y = y; if (pass == 0) attn_bwd_dq_kernel(a); else attn_bwd_dkv_kernel(a); });
+                emu::launch(1, 256, [&] {
+                    blockIdx.x = x; blockIdx.y = y;
+                    if (pass == 0) { if (g_attn_prec) attn_bwd_dq_kernel<1>(a); else attn_bwd_dq_kernel<0>(a); }
+                    else { if (g_attn_prec) attn_bwd_dkv_kernel<1>(a); else attn_bwd_dkv_kernel<0>(a); }
+                });
     blockIdx.x = 0; blockIdx.y = 0;
     return 0;
 }

@@ -301,6 +301,19 @@ def test_bf16_operand_mode_is_opt_in_and_within_its_stated_error(golden):
         assert abs(loss.item() - float(g["mse"])) < 2e-2 * abs(float(g["mse"]))
         loss.backward()
         assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+        # the fused attention follows the same switch: against torch's fp32 attention within the reduced-precision bar
+        qkv = torch.randn(6, 200, 384, device=dev, requires_grad=True)
+        kb = torch.zeros(6, 200, device=dev)
+        kb[:, 150:] = float("-inf")
+        o_bf = ops.attention(qkv, kb, 4)
+        (g_bf,) = torch.autograd.grad(o_bf.square().sum(), qkv)
+        ops.set_matmul_precision("fp32")
+        o_32 = ops.attention(qkv, kb, 4)
+        (g_32,) = torch.autograd.grad(o_32.square().sum(), qkv)
+        ops.set_matmul_precision("bf16")
+        for a_, b_ in ((o_bf, o_32), (g_bf, g_32)):
+            e = (a_ - b_).abs().max().item()
+            assert 1e-6 < e < 2e-2 * b_.abs().max().item()
         # a plain GEMM against torch: operand rounding only (2^-9 relative per factor)
         A, B = torch.randn(512, 256, device=dev), torch.randn(384, 256, device=dev)
         Cm = torch.empty(512, 384, device=dev)
