@@ -206,6 +206,14 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
     // the cost, so lane 0 only produces theta_i and the segment length, all lanes evaluate the steps, and lane 0 adds
     // them up in the original order (same floating-point result as the one-lane loop, ~8x shorter critical path).
     __shared__ float sh_th[RNV], sh_seg[RNV];
+    // the four random streams of the walk are staged in LDS by all lanes first: lane 0's loop then runs on LDS latency
+    // instead of one dependent global load per stream and step (that was most of this kernel's 30 us)
+    __shared__ float sh_ud[RNV], sh_ub[RNV], sh_us[RNV], sh_ua[RNV];
+    for (int i = lane; i < RNV - 1; i += 64) {
+        sh_ud[i] = u[EMLOCO_RND_DTHETA + i]; sh_ub[i] = u[EMLOCO_RND_BERN + i];
+        sh_us[i] = u[EMLOCO_RND_SHARP + i]; sh_ua[i] = u[EMLOCO_RND_DSPEED + i];
+    }
+    __syncthreads();
     if (lane == 0) {
         const float vdt = t.vert_dt;
         float speed = (t.speed_max - t.speed_min) * u[EMLOCO_RND_SPEED0] + t.speed_min;
@@ -215,11 +223,11 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
         }
         float theta = 0.0f;
         for (int i = 0; i < RNV - 1; ++i) {
-            float dth = (2.0f * u[EMLOCO_RND_DTHETA + i] - 1.0f) * (t.dtheta_max * vdt);
-            if (u[EMLOCO_RND_BERN + i] < t.sharp_prob) dth = 3.14159265358979f * (2.0f * u[EMLOCO_RND_SHARP + i] - 1.0f);
+            float dth = (2.0f * sh_ud[i] - 1.0f) * (t.dtheta_max * vdt);
+            if (sh_ub[i] < t.sharp_prob) dth = 3.14159265358979f * (2.0f * sh_us[i] - 1.0f);
             if (i == 0) dth = 3.14159265358979f * (2.0f * u[EMLOCO_RND_HEADING] - 1.0f);
             else {
-                const float ds = (2.0f * u[EMLOCO_RND_DSPEED + i] - 1.0f) * (t.accel_max * vdt);
+                const float ds = (2.0f * sh_ua[i] - 1.0f) * (t.accel_max * vdt);
                 speed = speed + ds;
                 speed = speed < t.speed_min ? t.speed_min : (speed > t.speed_max ? t.speed_max : speed);
             }
