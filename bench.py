@@ -62,7 +62,8 @@ def make_env(num_envs, rank):
                      "--heading_inversion", "--adjust_root_vel", "--real_path", "JTA+JRDB",
                      "--sim_device", f"cuda:{rank_local()}", "--rl_device", f"cuda:{rank_local()}"])
     cfg, cfg_train, _ = load_cfg(args)
-    cfg["env"]["traj_data"] = [synthetic_real_paths(2000, seed=1), synthetic_real_paths(2000, seed=2)]
+    n_paths = max(2000, int(num_envs))     # the host reset draws real paths without replacement (traj_generator.py:109): pool >= envs
+    cfg["env"]["traj_data"] = [synthetic_real_paths(n_paths, seed=1), synthetic_real_paths(n_paths, seed=2)]
     fill_flags(args)
     return create_rlgpu_env(args, cfg, cfg_train, rank=rank)
 
