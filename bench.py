@@ -406,6 +406,13 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        valu = None          # VALU issue utilisation of the same kernel from the committed SQ-counter pass (profiles/README.md)
+        try:
+            for line in open(os.path.join(ROOT, "profiles", "r01_sim_step_valu.txt")):
+                if line.startswith("VALU issue utilisation"):
+                    valu = float(line.split("=")[-1].split()[0])
+        except Exception:
+            valu = None
         out = {
             "metric": "env-steps/sec (SMPL humanoid, num_envs)", "value": round(E * world * a.steps / elapsed, 1),
             "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -416,7 +423,7 @@ def main():
                        "num_envs_per_gpu": E, "substeps_per_step": 4, "parallelism": f"env-sharded x{world}" + (" (TEST MODE: all ranks share cuda:0, gloo)" if share else "")},
             "roofline": {"bound": "hbm", "kernel": "sim_step_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l,
+                         "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l, "valu_issue_frac": valu,
                          "note": "latency bound, not bandwidth bound: ~9 KB of state per env per launch against ~50 k dependent fp32 VALU "
                                  "wave-instructions (level-synchronous tree passes, 2 waves / SIMD); VALU issue ~27 % busy, "
                                  "35 % of wave cycles waiting (profiles/r01_sim_step_valu.txt)"},
