@@ -337,6 +337,40 @@ def policy_leg(env, E, dev, steps, warmup):
             "weights": "random init (no checkpoint ships)"}
 
 
+def pipelined_leg(E, dev, steps, warmup):
+    """Reported beside the headline, never instead of it: the same 4096 envs as TWO independent 2048-env shards of this GPU,
+    each stepped (reset_done + env.step) on its own HIP stream.  One shard is exactly one resident round of waves (256 CUs x
+    8), so the shards run out of phase: one shard's latency-bound small kernels (post-physics, resets, PD targets) overlap
+    the other shard's rigid-body kernel.  What a double-buffered rollout loop gets; a single env.step over all envs cannot."""
+    import torch
+    shards = [make_env(E // 2, 1000 + i) for i in range(2)]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    pools = [torch.randn(64, E // 2, 69, device=dev, generator=g) * float(np.exp(-2.9)) for _ in range(2)]
+    for e in shards:
+        e.reset(torch.arange(E // 2, device=dev))
+    torch.cuda.synchronize()
+
+    def it(k):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                shards[i].reset_done()
+                shards[i].step(pools[i][k % 64])
+
+    for k in range(warmup):
+        it(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        it(k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": "env-steps/sec, two 2048-env shards on two HIP streams (same GPU, same workload)",
+            "value": round(E * steps / dt, 1), "unit": "env-steps/s", "ms_per_step": round(dt / steps * 1e3, 4),
+            "shards": 2, "envs_per_shard": E // 2}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,6 +380,7 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_policy", action="store_true", help="skip the frozen-policy leg (row A19, reported separately)")
     ap.add_argument("--no_jta", action="store_true", help="skip the train_jta samples/s leg (run on rank 0 at N=1)")
+    ap.add_argument("--no_pipelined", action="store_true", help="skip the two-shard / two-stream leg (rank 0 at N=1, reported separately)")
     a = ap.parse_args()
 
     import torch
@@ -430,6 +465,8 @@ def main():
         }
         if world == 1 and not a.no_policy:
             out["policy"] = policy_leg(env, E, dev, a.steps, a.warmup)
+        if world == 1 and not a.no_pipelined and E % 2 == 0:
+            out["pipelined"] = pipelined_leg(E, dev, a.steps, a.warmup)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if world == 1 and not a.no_jta:
