@@ -68,6 +68,26 @@ def make_env(num_envs, rank):
     return create_rlgpu_env(args, cfg, cfg_train, rank=rank)
 
 
+def stagger_episodes(env, steps=168, seed=0, sigma=float(np.exp(-2.9))):
+    """Untimed pre-roll: every env is force-reset once at a step drawn uniformly from [0, steps), while the rollout runs.
+    After `steps` = one episode length the episode ages are spread uniformly over [0, 168), i.e. the timed window sees the
+    steady reset rate (~E/168 time-outs per step plus the early terminations) from its first step, whatever --steps is.
+    (Writing progress_buf directly would not do: the target runs along the path with progress, every env would terminate
+    on the 4 m distance test of humanoid_pedestrain_terrain.py:1468-1530.)"""
+    import torch
+    task = env.task
+    dev = task.device
+    E = task.num_envs
+    g = torch.Generator(device=dev)
+    g.manual_seed(977 + seed)
+    phase = torch.randint(0, steps, (E,), device=dev, generator=g)
+    pool = torch.randn(8, E, 69, device=dev, generator=g) * sigma
+    for k in range(steps):
+        task.reset_buf[phase == k] = 1
+        env.reset_done()
+        env.step(pool[k % 8])
+
+
 def rank_local():
     # EMLOCO_BENCH_SHARE_GPU=1 (testing only): every rank uses cuda:0 and gloo instead of RCCL, so the multi-process path
     # (launch, sharding, barriers, max-over-ranks timing, aggregation) can be exercised on a 1-GPU box.  The line says so.
@@ -399,6 +419,7 @@ def main():
     env = make_env(E, rank)
     task = env.task
     env.reset(torch.arange(E, device=dev))
+    stagger_episodes(env, seed=rank)                     # untimed: episode ages uniform over [0, 168) before the warm-up
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     pool = torch.randn(64, E, 69, device=dev, generator=g) * float(np.exp(-2.9))

@@ -15,7 +15,7 @@ TASK_OBS = 2 * TRAJ_SAMPLES + HEIGHT_POINTS
 OBS = SELF_OBS + TASK_OBS
 AMP_ROW, AMP_STEPS = 206, 15
 
-T_ROOT_STATE, T_DOF_STATE, T_RIGID_BODY, T_CONTACT_FORCE, T_DOF_FORCE, T_PD_TARGET = range(6)
+T_ROOT_STATE, T_DOF_STATE, T_RIGID_BODY, T_CONTACT_FORCE, T_DOF_FORCE, T_PD_TARGET, T_WARM_START = range(7)
 POST_ADVANCE, POST_OBS, POST_REWARD, POST_RESET, POST_AMP_SHIFT, POST_AMP_ROW = 1, 2, 4, 8, 16, 32
 POST_STEP = 63
 
@@ -80,13 +80,43 @@ class ResetBufs(C.Structure):
                 ("dof_subset", C.c_void_p), ("traj_verts", C.c_void_p), ("inverted", C.c_void_p),
                 ("progress_buf", C.c_void_p), ("reset_buf", C.c_void_p), ("terminate_buf", C.c_void_p),
                 ("waypoint_traj", C.c_void_p), ("init_pose", C.c_void_p), ("init_vel", C.c_void_p),
-                ("amp_obs_buf", C.c_void_p), ("motion_ids", C.c_void_p), ("motion_times", C.c_void_p), ("ground_h", C.c_void_p)]
+                ("amp_obs_buf", C.c_void_p), ("motion_ids", C.c_void_p), ("motion_times", C.c_void_p), ("ground_h", C.c_void_p),
+                ("real_pick", C.c_void_p), ("real_pick_key", C.c_uint32)]
 
 
 RESET_RND = 512
 RESET_RANDOM_HEADING, RESET_INIT_HEADING, RESET_HEADING_INVERSION, RESET_ADJUST_ROOT_VEL, RESET_REAL_PATH, RESET_FIXED_LOCATION = 1, 2, 4, 8, 16, 32
 RND_MOTION, RND_TIME, RND_YAW, RND_SPEED, RND_LOC, RND_REAL, RND_REAL_PICK, RND_INVERSION, RND_HEADING, RND_SPEED0 = range(10)
 RND_DTHETA, RND_SHARP, RND_BERN, RND_DSPEED = 16, 116, 216, 316
+
+
+def _fmix32(x):
+    x &= 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x85EBCA6B) & 0xFFFFFFFF
+    x ^= x >> 13
+    x = (x * 0xC2B2AE35) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def real_pick_perm(i, n, key):
+    """Row of the real-path table list entry i takes (restates reset_kernels.hip: real_pick_perm, the keyed bijection of
+    [0, n) that stands where the reference calls random.sample, traj_generator.py:132)."""
+    bits = 2
+    while (1 << bits) < n:
+        bits += 2
+    half = bits >> 1
+    mask = (1 << half) - 1
+    x = i % n
+    while True:
+        l, r = x >> half, x & mask
+        for rnd in range(4):
+            f = _fmix32((r * 0x9E3779B1 + key + rnd * 0x85EBCA6B) & 0xFFFFFFFF) & mask
+            l, r = r, l ^ f
+        x = (l << half) | r
+        if x < n:
+            return x
 
 
 def default_sim_params(**kw):
@@ -109,6 +139,7 @@ SYMBOLS_SIM = [
 SYMBOLS_TASK = [
     "emloco_task_post_physics", "emloco_task_amp_rows", "emloco_task_pd_targets", "emloco_task_last_ms",
     "emloco_task_enable_timing", "emloco_task_reset", "emloco_task_reset_seeded", "emloco_task_compact_done",
+    "emloco_task_traj_reset",
 ]
 
 _lib = None
@@ -154,6 +185,8 @@ def load():
     lib.emloco_task_pd_targets.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]
     lib.emloco_task_enable_timing.argtypes = [C.c_int]
     lib.emloco_task_reset.argtypes = [C.c_void_p, C.POINTER(ResetBufs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.emloco_task_reset_seeded.argtypes = [C.c_void_p, C.POINTER(ResetBufs), C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.emloco_task_traj_reset.argtypes = [C.POINTER(ResetBufs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emloco_task_compact_done.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib

@@ -39,8 +39,8 @@ def _deps():
     out = []
     for root, _, files in os.walk(CSRC):
         out += [os.path.join(root, f) for f in files]
-    out.append(os.path.join(os.path.dirname(HERE), "include", "emloco_sim.h"))
-    out.append(os.path.join(os.path.dirname(HERE), "include", "emloco_predictor.h"))
+    for h in ("emloco_sim.h", "emloco_task.h", "emloco_predictor.h"):
+        out.append(os.path.join(os.path.dirname(HERE), "include", h))
     return [p for p in out if os.path.exists(p)]
 
 

@@ -153,55 +153,33 @@ __device__ __forceinline__ void r_calc_pos(const float *verts, float time, float
     for (int k = 0; k < 3; ++k) out[k] = (1.0f - w) * verts[i0 * 3 + k] + w * verts[i1 * 3 + k];
 }
 
-__global__ void __launch_bounds__(64)
-reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n, const float *rnd) {
-    const int lane = threadIdx.x;
-    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
-    const int env = ids[bi];
-    if (env < 0) break;
-    const float *u = rnd + (long)bi * EMLOCO_RESET_RND;
-    __shared__ float sh_v[RNV][3];
-
-    // ---- a. lowest collision point -> vertical shift (replaces the SMPL-mesh height fix, humanoid_amp.py:321-379)
-    float low = 3.0e38f;
-    for (int sl = 0; sl < 2; ++sl) {
-        const int c = lane + 64 * sl;
-        if (c < s.n_cand) {
-            const int body = s.cand_body[c], k = s.cand_k[c];
-            const long mb = (long)env * RNB + body;
-            const float *ga = s.geom_a + mb * 3, *gb = s.geom_b + mb * 3;
-            const int gt = s.geom_type[body];
-            float lp[3];
-            if (gt == EMLOCO_GEOM_SPHERE) { lp[0] = ga[0]; lp[1] = ga[1]; lp[2] = ga[2]; }
-            else if (gt == EMLOCO_GEOM_CAPSULE) { const float *src = k == 0 ? ga : gb; lp[0] = src[0]; lp[1] = src[1]; lp[2] = src[2]; }
-            else {
-                lp[0] = ga[0] + ((k & 1) ? gb[0] : -gb[0]);
-                lp[1] = ga[1] + ((k & 2) ? gb[1] : -gb[1]);
-                lp[2] = ga[2] + ((k & 4) ? gb[2] : -gb[2]);
-            }
-            const float *rb = s.rb_state + mb * 13;
-            float R[9], wp[3];
-            q2mat(rb + 3, R);
-            matvec3(R, lp, wp);
-            const float z = rb[2] + wp[2] - s.geom_r[mb];
-            low = z < low ? z : low;
+// traj_generator.py:60-237 TrajGenerator.reset for one env (one wave): random-walk polyline from the env's random row, then
+// (flags) a real-world path instead, heading alignment / inversion.  Result in sh_v (LDS), the inversion flag in t.inverted.
+//
+// Real paths (:121-160): the reference draws `random.sample(range(data_num), real_data_num)` -- distinct rows for the envs
+// of one reset call.  Here entry bi of the call's id list takes row P_key(bi mod n_real), P_key a keyed bijection of
+// [0, n_real) (4-round Feistel network over the next even power of two, cycle-walked), so the rows of one call are distinct
+// as well (for n <= n_real; the reference raises when more real rows are asked for than exist, here the list wraps).
+// t.real_pick (optional) overrides it with explicit rows: tests replay the reference's own sample through it.
+__device__ __forceinline__ unsigned real_pick_perm(unsigned x, unsigned n, unsigned key) {
+    unsigned bits = 2;
+    while ((1u << bits) < n) bits += 2;
+    const unsigned half = bits >> 1, mask = (1u << half) - 1u;
+    do {
+        unsigned l = x >> half, r = x & mask;
+        for (unsigned round = 0; round < 4; ++round) {
+            const unsigned f = fmix32(r * 0x9E3779B1u + key + round * 0x85EBCA6Bu) & mask;
+            const unsigned nl = r;
+            r = l ^ f;
+            l = nl;
         }
-    }
-    for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(low, off); low = o < low ? o : low; }
-    const float dz = low - t.ground_h[env] - t.height_tolerance;
-    float *rs = s.root_state + (long)env * 13;
-    if (lane < RNB) s.rb_state[((long)env * RNB + lane) * 13 + 2] -= dz;
-    if (lane == 0) rs[2] -= dz;
-    __syncthreads();
+        x = (l << half) | r;
+    } while (x >= n);
+    return x;
+}
 
-    // ---- b. buffers (humanoid.py:477-480) + warm-start impulses
-    if (lane == 0) { t.progress_buf[env] = 0; t.reset_buf[env] = 0; t.terminate_buf[env] = 0; }
-    for (int i = lane; i < RNB * 3; i += 64) s.contact_force[(long)env * RNB * 3 + i] = 0.0f;
-    for (int i = lane; i < EMLOCO_MAXCAND * 3; i += 64) s.lambda_ws[(long)env * EMLOCO_MAXCAND * 3 + i] = 0.0f;
-
-    // ---- c. trajectory (traj_generator.py:60-237)
-    const float ipx = rs[0], ipy = rs[1];
-    const float rvx = rs[7], rvy = rs[8];
+__device__ __forceinline__ void reset_trajectory(const EmlocoResetBufs &t, const float *u, int bi, int env, int lane,
+                                                 float ipx, float ipy, float rvx, float rvy, float rvz, float (*sh_v)[3]) {
     // The heading / speed recurrences (clamped random walks) are sequential but cheap; the 100 cos / sin evaluations are
     // the cost, so lane 0 only produces theta_i and the segment length, all lanes evaluate the steps, and lane 0 adds
     // them up in the original order (same floating-point result as the one-lane loop, ~8x shorter critical path).
@@ -260,8 +238,9 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
     __syncthreads();
     const bool real = (t.flags & EMLOCO_RESET_REAL_PATH) && t.n_real > 0 && (u[EMLOCO_RND_REAL] > t.hybrid_prob);
     if (real) {                                     // :121-160
-        int ri = (int)(u[EMLOCO_RND_REAL_PICK] * (float)t.n_real);
-        if (ri > t.n_real - 1) ri = t.n_real - 1;
+        int ri;
+        if (t.real_pick) { ri = t.real_pick[bi]; ri = ri < 0 ? 0 : (ri > t.n_real - 1 ? t.n_real - 1 : ri); }
+        else ri = (int)real_pick_perm((unsigned)bi % (unsigned)t.n_real, (unsigned)t.n_real, t.real_pick_key);
         const float *src = t.real_traj + (long)ri * RNV * 3;
         const float ox = src[0], oy = src[1];
         float sc = 1.0f;
@@ -283,7 +262,6 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
     if (t.flags & EMLOCO_RESET_INIT_HEADING) {      // :176-235
         const float ox = sh_v[0][0], oy = sh_v[0][1];
         const float dx = sh_v[1][0] - ox, dy = sh_v[1][1] - oy;
-        const float rvz = rs[9];
         const float rmag = sqrtf(rvx * rvx + rvy * rvy + rvz * rvz), dmag = sqrtf(dx * dx + dy * dy);
         const float root_rot = rmag > 0.0f ? atan2f(rvy, rvx) : 0.0f;
         const float ih = dmag > 0.0f ? atan2f(dy, dx) : 0.0f;
@@ -299,6 +277,58 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
         if (lane == 0 && (t.flags & EMLOCO_RESET_HEADING_INVERSION)) t.inverted[env] = inv ? 1 : 0;
         __syncthreads();
     }
+}
+
+__global__ void __launch_bounds__(64)
+reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n, const float *rnd) {
+    const int lane = threadIdx.x;
+    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
+    const int env = ids[bi];
+    if (env < 0) break;
+    const float *u = rnd + (long)bi * EMLOCO_RESET_RND;
+    __shared__ float sh_v[RNV][3];
+
+    // ---- a. lowest collision point -> vertical shift (replaces the SMPL-mesh height fix, humanoid_amp.py:321-379)
+    float low = 3.0e38f;
+    for (int sl = 0; sl < 2; ++sl) {
+        const int c = lane + 64 * sl;
+        if (c < s.n_cand) {
+            const int body = s.cand_body[c], k = s.cand_k[c];
+            const long mb = (long)env * RNB + body;
+            const float *ga = s.geom_a + mb * 3, *gb = s.geom_b + mb * 3;
+            const int gt = s.geom_type[body];
+            float lp[3];
+            if (gt == EMLOCO_GEOM_SPHERE) { lp[0] = ga[0]; lp[1] = ga[1]; lp[2] = ga[2]; }
+            else if (gt == EMLOCO_GEOM_CAPSULE) { const float *src = k == 0 ? ga : gb; lp[0] = src[0]; lp[1] = src[1]; lp[2] = src[2]; }
+            else {
+                lp[0] = ga[0] + ((k & 1) ? gb[0] : -gb[0]);
+                lp[1] = ga[1] + ((k & 2) ? gb[1] : -gb[1]);
+                lp[2] = ga[2] + ((k & 4) ? gb[2] : -gb[2]);
+            }
+            const float *rb = s.rb_state + mb * 13;
+            float R[9], wp[3];
+            q2mat(rb + 3, R);
+            matvec3(R, lp, wp);
+            const float z = rb[2] + wp[2] - s.geom_r[mb];
+            low = z < low ? z : low;
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(low, off); low = o < low ? o : low; }
+    const float dz = low - t.ground_h[env] - t.height_tolerance;
+    float *rs = s.root_state + (long)env * 13;
+    if (lane < RNB) s.rb_state[((long)env * RNB + lane) * 13 + 2] -= dz;
+    if (lane == 0) rs[2] -= dz;
+    __syncthreads();
+
+    // ---- b. buffers (humanoid.py:477-480) + warm-start impulses
+    if (lane == 0) { t.progress_buf[env] = 0; t.reset_buf[env] = 0; t.terminate_buf[env] = 0; }
+    for (int i = lane; i < RNB * 3; i += 64) s.contact_force[(long)env * RNB * 3 + i] = 0.0f;
+    for (int i = lane; i < EMLOCO_MAXCAND * 3; i += 64) s.lambda_ws[(long)env * EMLOCO_MAXCAND * 3 + i] = 0.0f;
+
+    // ---- c. trajectory (traj_generator.py:60-237)
+    const float ipx = rs[0], ipy = rs[1];
+    const float rvx = rs[7], rvy = rs[8];
+    reset_trajectory(t, u, bi, env, lane, ipx, ipy, rvx, rvy, rs[9], sh_v);
     float *vout = t.traj_verts + (long)env * RNV * 3;
     for (int i = lane; i < RNV * 3; i += 64) vout[i] = (&sh_v[0][0])[i];
 
@@ -312,6 +342,23 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
         for (int k = 0; k < 3; ++k) t.init_pose[((long)env * RNB + lane) * 3 + k] = s.rb_state[((long)env * RNB + lane) * 13 + k];
     if (lane == 0) { t.init_vel[(long)env * 2] = rvx; t.init_vel[(long)env * 2 + 1] = rvy; }
 
+        __syncthreads();                              // LDS is reused by the next list entry
+    }
+}
+
+// TrajGenerator.reset(env_ids, init_pos, root_vel) on its own (traj_generator.py:60-237): the trajectory part of the reset
+// for callers that place the humanoids themselves; init_pos / root_vel are [n][3], one row per list entry.
+__global__ void __launch_bounds__(64)
+traj_reset_kernel(EmlocoResetBufs t, const int32_t *ids, int n, const float *rnd, const float *init_pos, const float *root_vel) {
+    const int lane = threadIdx.x;
+    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
+        const int env = ids[bi];
+        if (env < 0) break;
+        __shared__ float sh_v[RNV][3];
+        const float *ip = init_pos + (long)bi * 3, *rv = root_vel + (long)bi * 3;
+        reset_trajectory(t, rnd + (long)bi * EMLOCO_RESET_RND, bi, env, lane, ip[0], ip[1], rv[0], rv[1], rv[2], sh_v);
+        float *vout = t.traj_verts + (long)env * RNV * 3;
+        for (int i = lane; i < RNV * 3; i += 64) vout[i] = (&sh_v[0][0])[i];
         __syncthreads();                              // LDS is reused by the next list entry
     }
 }

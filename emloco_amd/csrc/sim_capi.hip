@@ -230,6 +230,7 @@ int emloco_sim_tensor(EmlocoSim *s, int kind, void **dev_ptr, int64_t shape[2]) 
         case EMLOCO_T_CONTACT_FORCE: *dev_ptr = s->d_cf.p; shape[0] = E * EMLOCO_NB; shape[1] = 3; break;
         case EMLOCO_T_DOF_FORCE: *dev_ptr = s->d_df.p; shape[0] = E * EMLOCO_NDOF; shape[1] = 1; break;
         case EMLOCO_T_PD_TARGET: *dev_ptr = s->d_tgt.p; shape[0] = E; shape[1] = EMLOCO_NDOF; break;
+        case EMLOCO_T_WARM_START: *dev_ptr = s->d_lws.p; shape[0] = E; shape[1] = EMLOCO_MAXCAND * 3; break;
         default: return fail(EMLOCO_E_ARG, "emloco_sim_tensor: unknown tensor kind");
     }
     return EMLOCO_OK;

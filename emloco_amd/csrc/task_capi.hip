@@ -123,7 +123,25 @@ int emloco_task_reset_seeded(EmlocoSim *sim, const EmlocoResetBufs *b, const int
     hipLaunchKernelGGL(emloco::reset_fill_rnd_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_env_ids, n,
                        (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), dev_rnd_ws);
     THIPCHK(hipGetLastError());
-    return emloco_task_reset(sim, b, dev_env_ids, n, dev_rnd_ws, stream);
+    if (!b) return tfail(-1, "emloco_task_reset_seeded: null argument");
+    EmlocoResetBufs keyed = *b;                 // a fresh real-path permutation per call (reset_kernels.hip: real_pick_perm)
+    keyed.real_pick = nullptr;
+    keyed.real_pick_key = (uint32_t)((seed * 0xD6E8FEB86659FD93ull) >> 32);
+    return emloco_task_reset(sim, &keyed, dev_env_ids, n, dev_rnd_ws, stream);
+}
+
+int emloco_task_traj_reset(const EmlocoResetBufs *b, const int32_t *dev_env_ids, int n, const float *dev_rnd,
+                           const float *dev_init_pos, const float *dev_root_vel, void *stream) {
+    if (!b || !dev_env_ids || !dev_rnd || !dev_init_pos || !dev_root_vel) return tfail(-1, "emloco_task_traj_reset: null argument");
+    if (n < 0) return tfail(-1, "emloco_task_traj_reset: bad env count");
+    if (n == 0) return 0;
+    if (!b->traj_verts || !b->inverted) return tfail(-1, "emloco_task_traj_reset: missing buffers");
+    if ((b->flags & EMLOCO_RESET_REAL_PATH) && b->n_real > 0 && !b->real_traj) return tfail(-1, "emloco_task_traj_reset: real_path without data");
+    const unsigned grid = (unsigned)(n < 256 ? n : 256);
+    hipLaunchKernelGGL(emloco::traj_reset_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *b, dev_env_ids, n, dev_rnd,
+                       dev_init_pos, dev_root_vel);
+    THIPCHK(hipGetLastError());
+    return 0;
 }
 
 int emloco_task_compact_done(const int64_t *dev_flags, int n, int32_t *dev_ids, void *stream) {

@@ -149,10 +149,7 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         f |= L.RESET_FIXED_LOCATION if flags.fixed else 0
         real = None
         if flags.real_path:
-            rows = []
-            for d in tg.traj_data:
-                rows += [np.asarray(v["traj"], np.float32)[:101] for v in (d.values() if isinstance(d, dict) else d)]
-            real = torch.from_numpy(np.stack(rows)).to(dev).contiguous()
+            real = torch.from_numpy(tg.real_rows()).to(dev).contiguous()
         E = self.num_envs
         # the reset kernels write the sampled motion id / start time of a reset env straight into the task's per-env
         # bookkeeping (humanoid_amp.py:191-192 does the same by index assignment): alias, no merge pass afterwards
@@ -228,7 +225,6 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
                 self._rnd_calls = 0
                 self._rnd_seed0 = int(torch.initial_seed()) & 0xFFFFFFFFFFFF
             self._rnd_calls += 1
-            lib.emloco_task_reset_seeded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
             L.check(lib.emloco_task_reset_seeded(self.sim.native._h, C.byref(self._reset_bufs), C.c_void_p(self._done_ids.data_ptr()), E,
                                                  C.c_uint64((self._rnd_seed0 * 0x9E3779B97F4A7C15 + self._rnd_calls) & 0xFFFFFFFFFFFFFFFF),
                                                  C.c_void_p(self._rnd_ws.data_ptr()), st), "emloco_task_reset_seeded")

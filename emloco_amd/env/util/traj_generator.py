@@ -106,7 +106,11 @@ class TrajGenerator():
             real_mask = real_prob > self._hybrid_init_prob
             real_num = int(torch.sum(real_mask))
             sizes = [len(t) for t in self.traj_data]
-            rids = random.sample(range(sum(sizes)), real_num)
+            rids = d.get("real_rids", None)                 # explicit sample (tests replay the reference's / the device's)
+            if rids is None:
+                rids = random.sample(range(sum(sizes)), real_num)
+            rids = [int(r) for r in rids]
+            assert len(rids) == real_num
             traj = torch.zeros([real_num, num_verts, 3], device=self._device)
             for i, rid in enumerate(rids):
                 k = 0
@@ -150,6 +154,57 @@ class TrajGenerator():
             self._verts[env_ids] = verts
         if f.add_noise:
             self._verts[env_ids] += torch.randn_like(self._verts[env_ids]) * 0.5
+
+    def real_rows(self):
+        """The real paths as one (n_real, num_verts, 3) float32 table, datasets concatenated in order (row = the id
+        `random.sample(range(jta_num + jrdb_num), ...)` indexes, traj_generator.py:128-143)."""
+        rows = []
+        for src in self.traj_data:
+            vals = src.values() if isinstance(src, dict) else src
+            rows += [np.asarray(v["traj"], np.float32)[:self.get_num_verts()] for v in vals]
+        return np.stack(rows) if rows else np.zeros((0, self.get_num_verts(), 3), np.float32)
+
+    def reset_on_device(self, env_ids, init_pos, root_vel, rnd=None, real_pick=None, real_pick_key=0):
+        """`reset` as one kernel launch (emloco_task_traj_reset, reset_kernels.hip): random rows `rnd` [n][RESET_RND]
+        uniform in [0, 1) laid out as include/emloco_task.h describes (drawn with torch.rand when omitted), real-path rows
+        from `real_pick` (int32 [n]) or the keyed permutation.  Needs the gfx950 library and CUDA tensors."""
+        import ctypes as C
+        from ... import _lib as L
+        from ...sim import current_stream_handle
+        lib = L.require_device()
+        n = len(env_ids)
+        if n == 0:
+            return
+        f = self._flags
+        dev = self._verts.device
+        if rnd is None:
+            rnd = torch.rand((n, L.RESET_RND), device=dev)
+        if getattr(self, "_real_dev", None) is None and f.real_path:
+            self._real_dev = torch.from_numpy(self.real_rows()).to(dev).contiguous()
+        if getattr(self, "_inverted_u8", None) is None:
+            self._inverted_u8 = torch.zeros(self.get_num_envs(), dtype=torch.uint8, device=dev)
+        self._inverted_u8.copy_(self.inverted.to(torch.uint8))
+        b = L.ResetBufs()
+        fl = (L.RESET_INIT_HEADING if f.init_heading else 0) | (L.RESET_ADJUST_ROOT_VEL if f.adjust_root_vel else 0)
+        fl |= L.RESET_HEADING_INVERSION if (f.init_heading and f.heading_inversion) else 0
+        fl |= L.RESET_REAL_PATH if f.real_path else 0
+        if f.fixed_path or f.slow or f.add_noise or getattr(f, "pred_path", False):
+            raise NotImplementedError("reset_on_device: fixed_path / slow / add_noise / pred_path stay on the host path (reset)")
+        b.flags, b.n_real = fl, (int(self._real_dev.shape[0]) if f.real_path else 0)
+        b.vert_dt, b.dtheta_max, b.speed_min, b.speed_max = self._dt, self._dtheta_max, self._speed_min, self._speed_max
+        b.accel_max, b.sharp_prob, b.hybrid_prob = self._accel_max, self._sharp_turn_prob, self._hybrid_init_prob
+        b.real_traj = self._real_dev.data_ptr() if f.real_path else None
+        b.traj_verts, b.inverted = self._verts.data_ptr(), self._inverted_u8.data_ptr()
+        keep = [rnd.contiguous(), env_ids.to(dev).to(torch.int32).contiguous(), init_pos[:, :3].float().contiguous(),
+                root_vel[:, :3].float().contiguous()]
+        if real_pick is not None:
+            keep.append(real_pick.to(dev).to(torch.int32).contiguous())
+            b.real_pick = keep[-1].data_ptr()
+        b.real_pick_key = int(real_pick_key) & 0xFFFFFFFF
+        L.check(lib.emloco_task_traj_reset(C.byref(b), keep[1].data_ptr(), n, keep[0].data_ptr(), keep[2].data_ptr(),
+                                           keep[3].data_ptr(), current_stream_handle(dev)), "emloco_task_traj_reset")
+        if f.init_heading and f.heading_inversion:
+            self.inverted = self._inverted_u8.bool()
 
     def show_inverted(self):
         return self.inverted

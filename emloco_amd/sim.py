@@ -99,6 +99,7 @@ class NativeSim:
         self.contact_force = self._tensor(L.T_CONTACT_FORCE)
         self.dof_force = self._tensor(L.T_DOF_FORCE).view(-1)
         self.pd_target = self._tensor(L.T_PD_TARGET)
+        self.warm_start = self._tensor(L.T_WARM_START)
 
     def _tensor(self, kind):
         ptr = C.c_void_p()

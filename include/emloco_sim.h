@@ -93,7 +93,9 @@ enum {
     EMLOCO_T_CONTACT_FORCE = 3, /* f32 [n_env*24][3]    acquire_net_contact_force_tensor */
     EMLOCO_T_DOF_FORCE = 4,     /* f32 [n_env*69]       acquire_dof_force_tensor */
     EMLOCO_T_PD_TARGET = 5,     /* f32 [n_env][69]      internal copy of the last set_dof_position_target_tensor */
-    EMLOCO_T_COUNT = 6
+    EMLOCO_T_WARM_START = 6,    /* f32 [n_env][EMLOCO_MAXCAND*3]  contact impulses carried between steps (solver state: save /
+                                   restore it with the five state tensors to resume a rollout bit for bit) */
+    EMLOCO_T_COUNT = 7
 };
 
 typedef struct EmlocoSim EmlocoSim;

@@ -150,6 +150,11 @@ typedef struct {
     int64_t *motion_ids;            /* [E] */
     float *motion_times;            /* [E] */
     float *ground_h;                /* [E] scratch: ground height under the reset pose */
+    /* real paths (traj_generator.py:121-160): list entry i takes row P_key(i mod n_real) of real_traj, P_key a keyed
+     * bijection of [0, n_real) -- distinct rows within one call, like the reference's random.sample(range(n), k);
+     * real_pick (device, [n] rows, optional) replaces the permutation by explicit rows */
+    const int32_t *real_pick;
+    uint32_t real_pick_key;
 } EmlocoResetBufs;
 
 struct EmlocoSim;
@@ -164,6 +169,12 @@ int emloco_task_reset(struct EmlocoSim *sim, const EmlocoResetBufs *bufs, const 
  * generating n_env rows per step when a few dozen envs finish. */
 int emloco_task_reset_seeded(struct EmlocoSim *sim, const EmlocoResetBufs *bufs, const int32_t *dev_env_ids, int n,
                              uint64_t seed, float *dev_rnd_ws, void *stream);
+
+/* TrajGenerator.reset(env_ids, init_pos, root_vel) alone (traj_generator.py:60-237): writes traj_verts / inverted of the
+ * listed envs from the random rows; dev_init_pos, dev_root_vel [n][3] (one row per list entry).  Only the trajectory
+ * fields of `bufs` are read (flags, vert_dt ... hybrid_prob, n_real, real_traj, real_pick*, traj_verts, inverted). */
+int emloco_task_traj_reset(const EmlocoResetBufs *bufs, const int32_t *dev_env_ids, int n, const float *dev_rnd,
+                           const float *dev_init_pos, const float *dev_root_vel, void *stream);
 
 /* Device-side `reset_buf.nonzero()`: dev_ids[0..count) = ascending indices of the non-zero flags, the rest of the n
  * entries = -1, dev_ids[n] = count.  Every *_indexed / env-id-list entry point of this library skips negative ids, so

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _SO = os.path.join(_HERE, "_build", "libemu.so")
 _SRCS = ["emu_sim.cpp", "emu_task.cpp", "emu_predictor.cpp", "emu_runtime.cpp", "hip/hip_runtime.h"]
-_KERNELS = ["sim_kernels.hip", "task_kernels.hip", "predictor_kernels.hip", "attention_kernels.hip", "dev_math.h", "mfma_bf16.h", "emloco_types.h", "topology.h"]
+_KERNELS = ["sim_kernels.hip", "task_kernels.hip", "reset_kernels.hip", "predictor_kernels.hip", "attention_kernels.hip", "dev_math.h", "mfma_bf16.h", "emloco_types.h", "topology.h"]
 
 
 def build():

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY: runs emloco_amd/csrc/task_kernels.hip on the CPU through tests/emu/hip/.
 #include "hip/hip_runtime.h"
 #include "../../emloco_amd/csrc/task_kernels.hip"
+#include "../../emloco_amd/csrc/reset_kernels.hip"
 
 extern "C" int emu_task_post_physics(const EmlocoTaskBufs *b, int mode, const int32_t *env_ids, int n) {
     const int count = env_ids ? n : b->n_env;
@@ -27,5 +28,12 @@ extern "C" int emu_task_pd_targets(int n_env, const float *actions, const float 
 
 extern "C" int emu_compact_flags(const int64_t *flags, int n, int32_t *ids) {
     emu::launch(1, 1024, [&] { emloco::compact_flags_kernel(flags, n, ids); });
+    return 0;
+}
+
+extern "C" int emu_task_traj_reset(const EmlocoResetBufs *b, const int32_t *env_ids, int n, const float *rnd,
+                                   const float *init_pos, const float *root_vel) {
+    EmlocoResetBufs t = *b;
+    emu::launch((unsigned)n, 64, [&] { emloco::traj_reset_kernel(t, env_ids, n, rnd, init_pos, root_vel); });
     return 0;
 }

@@ -163,6 +163,58 @@ def gen_pacer():
          r_dtheta=r1, r_dtheta_sharp=r2, bern_sharp=bern, r_heading=r3, r_dspeed=r4, r_speed0=r5,
          r_inversion=r6, verts=tg2._verts.clone(), inverted=tg2.inverted.clone().long(),
          dt_vert=np.array(tg2._dt, dtype=np.float64))
+
+    # real-world paths (traj_generator.py:120-160; configs[1] runs with --real_path JTA+JRDB): the constructor loads the
+    # pickles from hard-coded relative paths, so the generator is built with the flag off and handed the tables the way
+    # its constructor stores them (:43-52).  Synthetic tables in the saved-traj format {id: {'pose', 'traj' (>=101,3) f64}}.
+    import random as pyrandom
+
+    def fake_paths(n, seed, nv):
+        r = np.random.RandomState(seed)
+        out = {}
+        for i in range(n):
+            speed = r.uniform(0.05, 2.5)
+            turn = r.uniform(-0.5, 0.5)
+            tt = np.arange(nv) * (168 * dt / 100)
+            th = r.uniform(-np.pi, np.pi) + turn * tt
+            xy = np.cumsum(np.stack([np.cos(th), np.sin(th)], -1) * speed * (168 * dt / 100), 0) + r.uniform(-30, 30, 2)
+            z = np.full((nv, 1), r.uniform(-0.05, 0.05))
+            out[i] = {"pose": None, "traj": np.concatenate([xy, z], -1)}
+        out[0]["traj"][1] = out[0]["traj"][0]                 # a standing start: first segment of zero length
+        return out
+
+    jta, jrdb = fake_paths(23, 5, 101), fake_paths(17, 6, 108)
+    for tag, use_jrdb, adj in (("real1", False, False), ("real2", True, True), ("real2_noadj", True, False)):
+        flags.real_path = False
+        flags.init_heading = True
+        flags.heading_inversion = True
+        flags.adjust_root_vel = adj
+        tg3 = TG.TrajGenerator(E, episode_len * dt, 101, "cpu", 2.0, 0.0005, 3.0, 2.0, 0.02, None,
+                               hybridInitProb=0.5, flags=flags)
+        flags.real_path, flags.jta_path, flags.jrdb_path = True, True, use_jrdb
+        tg3.traj_data_jta, tg3.traj_data = jta, [jta]
+        if use_jrdb:
+            tg3.traj_data_jrdb = jrdb
+            tg3.traj_data.append(jrdb)
+        torch.manual_seed(90)
+        pyrandom.seed(91)
+        st, pst = torch.get_rng_state(), pyrandom.getstate()
+        tg3.reset(env_ids, pos[:, 0].clone(), root_vel.clone())
+        torch.set_rng_state(st)
+        pyrandom.setstate(pst)
+        r1 = torch.rand([E, 100]); r2 = torch.rand([E, 100])
+        bern = torch.bernoulli(0.02 * torch.ones(E, 100))
+        r3 = torch.rand([E]); r4 = torch.rand([E, 100]); r5 = torch.rand([E])
+        r_real = torch.rand(E)
+        n_real = int((r_real > 0.5).sum())
+        rids = pyrandom.sample(range(len(jta) + (len(jrdb) if use_jrdb else 0)), n_real)
+        r6 = torch.rand(E)
+        table = np.stack([v["traj"][:101] for v in jta.values()] + ([v["traj"][:101] for v in jrdb.values()] if use_jrdb else []))
+        save("traj_reset_" + tag, init_pos=pos[:, 0], root_vel=root_vel, r_dtheta=r1, r_dtheta_sharp=r2, bern_sharp=bern,
+             r_heading=r3, r_dspeed=r4, r_speed0=r5, r_real=r_real, real_rids=np.array(rids, np.int64), r_inversion=r6,
+             real_table=table.astype(np.float64), n_jta=np.array(len(jta)), adjust_root_vel=np.array(adj),
+             verts=tg3._verts.clone(), inverted=tg3.inverted.clone().long(), dt_vert=np.array(tg3._dt, dtype=np.float64))
+    flags.real_path = flags.jta_path = flags.jrdb_path = False
     flags.init_heading = False
     flags.heading_inversion = False
     flags.adjust_root_vel = False

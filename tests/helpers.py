@@ -62,3 +62,55 @@ def oracle_sim(models, root, dof, tgt, self_collision=None, heightfield=None, **
     s.dof_state[:] = dof
     s.pd_target[:] = tgt
     return s
+
+
+TRAJ_CASES = {      # golden fixture -> TrajGenerator flags (tests/golden/gen_golden.py)
+    "traj_reset_plain": dict(),
+    "traj_reset_heading": dict(init_heading=True, heading_inversion=True, adjust_root_vel=True),
+    "traj_reset_real1": dict(init_heading=True, heading_inversion=True, real_path=True, jta_path=True),
+    "traj_reset_real2": dict(init_heading=True, heading_inversion=True, adjust_root_vel=True, real_path=True, jta_path=True, jrdb_path=True),
+    "traj_reset_real2_noadj": dict(init_heading=True, heading_inversion=True, real_path=True, jta_path=True, jrdb_path=True),
+}
+
+
+def traj_rnd_rows(g, E=16):
+    """The reference's draws of one TrajGenerator.reset (a golden fixture) laid out as the device's random rows
+    (include/emloco_task.h: EMLOCO_RND_*); the Bernoulli outcome becomes a uniform on the right side of sharp_prob."""
+    from emloco_amd import _lib as L
+    rnd = np.full((E, L.RESET_RND), 0.25, np.float32)
+    rnd[:, L.RND_DTHETA:L.RND_DTHETA + 100] = g["r_dtheta"]
+    rnd[:, L.RND_SHARP:L.RND_SHARP + 100] = g["r_dtheta_sharp"]
+    rnd[:, L.RND_BERN:L.RND_BERN + 100] = np.where(g["bern_sharp"] == 1.0, 0.0, 1.0)
+    rnd[:, L.RND_DSPEED:L.RND_DSPEED + 100] = g["r_dspeed"]
+    rnd[:, L.RND_HEADING] = g["r_heading"]
+    rnd[:, L.RND_SPEED0] = g["r_speed0"]
+    if "r_real" in g:
+        rnd[:, L.RND_REAL] = g["r_real"]
+    if "r_inversion" in g:
+        rnd[:, L.RND_INVERSION] = g["r_inversion"]
+    return rnd
+
+
+def traj_real_pick(g, E=16):
+    """Per-list-entry real-path rows of a fixture: the i-th env with r_real > 0.5 takes real_rids[i] (traj_generator.py:126-143)."""
+    pick = np.zeros(E, np.int32)
+    if "real_rids" in g:
+        pick[np.nonzero(g["r_real"] > 0.5)[0]] = g["real_rids"]
+    return pick
+
+
+def traj_reset_bufs(flags, g, verts, inverted, real_table=None, real_pick=None, key=0, E=16):
+    """EmlocoResetBufs with the trajectory fields only (emloco_task_traj_reset); `verts`, `inverted`, `real_table`, `real_pick`
+    are objects with a data pointer already resolved (ints) or None."""
+    from emloco_amd import _lib as L
+    b = L.ResetBufs()
+    fl = (L.RESET_INIT_HEADING if flags.get("init_heading") else 0) | (L.RESET_ADJUST_ROOT_VEL if flags.get("adjust_root_vel") else 0)
+    fl |= L.RESET_HEADING_INVERSION if flags.get("heading_inversion") else 0
+    fl |= L.RESET_REAL_PATH if flags.get("real_path") else 0
+    b.flags = fl
+    b.vert_dt, b.dtheta_max, b.speed_min, b.speed_max = float(g["dt_vert"]), 2.0, 0.0005, 3.0
+    b.accel_max, b.sharp_prob, b.hybrid_prob = 2.0, 0.02, 0.5
+    b.n_real = 0 if real_table is None else int(g["real_table"].shape[0])
+    b.real_traj, b.real_pick, b.real_pick_key = real_table, real_pick, key
+    b.traj_verts, b.inverted = verts, inverted
+    return b

@@ -440,3 +440,54 @@ def test_compact_flags_kernel_is_nonzero():
         nz = np.nonzero(flags)[0]
         assert ids[n] == len(nz)
         assert np.array_equal(ids[:len(nz)], nz) and np.all(ids[len(nz):n] == -1)
+
+
+@pytest.mark.parametrize("name", ["traj_reset_plain", "traj_reset_heading", "traj_reset_real1", "traj_reset_real2", "traj_reset_real2_noadj"])
+def test_traj_reset_kernel_matches_reference_golden(golden, name):
+    """TrajGenerator.reset as the device computes it (reset_kernels.hip: reset_trajectory, incl. the real-path branch the
+    headline bench runs) on the reference's own draws: vertices within 1e-4 m of the reference's, inversion mask bit-exact."""
+    from helpers import TRAJ_CASES, traj_real_pick, traj_reset_bufs, traj_rnd_rows
+    g = golden(name)
+    E = 16
+    verts = np.zeros((E, 101, 3), np.float32)
+    inverted = np.full(E, 7, np.uint8)
+    table = np.ascontiguousarray(g["real_table"].astype(np.float32)) if "real_table" in g else None
+    pick = traj_real_pick(g) if table is not None else None
+    b = traj_reset_bufs(TRAJ_CASES[name], g, verts.ctypes.data, inverted.ctypes.data, None if table is None else table.ctypes.data,
+                        None if pick is None else pick.ctypes.data)
+    ids = np.arange(E, dtype=np.int32)
+    rnd = traj_rnd_rows(g)
+    ip, rv = np.ascontiguousarray(g["init_pos"], np.float32), np.ascontiguousarray(g["root_vel"], np.float32)
+    emu.lib().emu_task_traj_reset(C.byref(b), P(ids), E, P(rnd), P(ip), P(rv))
+    assert np.abs(verts - g["verts"]).max() < 1e-4, np.abs(verts - g["verts"]).max()
+    if "inverted" in g:
+        np.testing.assert_array_equal(inverted, g["inverted"])
+
+
+def test_traj_reset_kernel_real_rows_are_sampled_without_replacement(golden):
+    """Without explicit rows the kernel takes P_key(list position): distinct within the call (random.sample semantics,
+    traj_generator.py:132), equal to the host restatement, different per key."""
+    from helpers import traj_reset_bufs, traj_rnd_rows
+    from emloco_amd._lib import real_pick_perm
+    g = dict(golden("traj_reset_real2_noadj"))
+    E = 32
+    n_real = 40
+    table = np.zeros((n_real, 101, 3), np.float32)
+    table[:, :, 0] = np.linspace(0, 3, 101)[None]
+    table[:, :, 2] = np.arange(n_real)[:, None]                       # the row id rides in z, which the reset copies through
+    g["real_table"] = table
+    rnd = np.full((E, 512), 0.9, np.float32)                           # every env takes a real path
+    ids = np.arange(E, dtype=np.int32)[::-1].copy()
+    ip = np.zeros((E, 3), np.float32)
+    rv = np.ones((E, 3), np.float32)
+    seen = {}
+    for key in (11, 12):
+        verts = np.zeros((E, 101, 3), np.float32)
+        inverted = np.zeros(E, np.uint8)
+        b = traj_reset_bufs(dict(real_path=True), g, verts.ctypes.data, inverted.ctypes.data, table.ctypes.data, None, key=key)
+        emu.lib().emu_task_traj_reset(C.byref(b), P(ids), E, P(rnd), P(ip), P(rv))
+        rows = verts[ids, 0, 2].astype(int)                            # rows[i] = what list entry i took
+        assert len(set(rows.tolist())) == E
+        assert rows.tolist() == [real_pick_perm(i, n_real, key) for i in range(E)]
+        seen[key] = rows
+    assert not np.array_equal(seen[11], seen[12])

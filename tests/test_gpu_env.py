@@ -347,3 +347,181 @@ def _shaped_terrain_body(env, E):
     assert min(low_gap) > -0.25                                       # body origins stay above the terrain (step edges: one riser of slack)
     cf = task._contact_forces.view(E, 24, 3)
     assert cf[..., 2].sum(1).max().item() > 300                       # the terrain carries them
+
+
+@pytest.mark.parametrize("name", ["traj_reset_plain", "traj_reset_heading", "traj_reset_real1", "traj_reset_real2", "traj_reset_real2_noadj"])
+def test_traj_reset_on_device_matches_reference_golden(golden, name):
+    """TrajGenerator.reset on the MI355X (emloco_task_traj_reset) on the reference's own draws: real-path branch, one / two
+    datasets, with / without adjust_root_vel (traj_generator.py:60-237). Vertices within 1e-4 m, inversion mask bit-exact."""
+    from helpers import TRAJ_CASES, traj_real_pick, traj_rnd_rows
+    from emloco_amd.env.util.traj_generator import TrajGenerator
+    from emloco_amd.utils.flags import Flags
+    g = golden(name)
+    base = dict(real_path=False, jta_path=False, jrdb_path=False, pred_path=False, fixed_path=False, slow=False,
+                adjust_root_vel=False, init_heading=False, heading_inversion=False, add_noise=False, vru=False)
+    base.update(TRAJ_CASES[name])
+    data = None
+    if "real_table" in g:
+        n_jta = int(g["n_jta"])
+        tables = [g["real_table"][:n_jta]] + ([g["real_table"][n_jta:]] if g["real_table"].shape[0] > n_jta else [])
+        data = [{i: {"pose": None, "traj": t[i]} for i in range(len(t))} for t in tables]
+    dev = torch.device("cuda", 0)
+    tg = TrajGenerator(16, 168 * (2 / 60.0), 101, dev, 2.0, 0.0005, 3.0, 2.0, 0.02, None, hybridInitProb=0.5, flags=Flags(base),
+                       traj_data=data)
+    tg.inverted[:] = True
+    tg.reset_on_device(torch.arange(16, device=dev), torch.from_numpy(g["init_pos"]).to(dev), torch.from_numpy(g["root_vel"]).to(dev),
+                       rnd=torch.from_numpy(traj_rnd_rows(g)).to(dev),
+                       real_pick=torch.from_numpy(traj_real_pick(g)) if data is not None else None)
+    torch.cuda.synchronize()
+    err = np.abs(tg._verts.cpu().numpy() - g["verts"]).max()
+    assert err < 1e-4, err
+    if "inverted" in g:
+        np.testing.assert_array_equal(tg.show_inverted().long().cpu().numpy(), g["inverted"])
+
+
+def _synthetic_paths(n, seed, nv=101):
+    r = np.random.RandomState(seed)
+    out = {}
+    for i in range(n):
+        th = r.uniform(-np.pi, np.pi) + r.uniform(-0.4, 0.4) * np.arange(nv) * 0.056
+        xy = np.cumsum(np.stack([np.cos(th), np.sin(th)], -1) * r.uniform(0.02, 0.14), 0) + r.uniform(-20, 20, 2)
+        out[i] = {"pose": None, "traj": np.concatenate([xy, np.full((nv, 1), 1e-3 * i)], -1)}
+    return out
+
+
+def test_fused_reset_real_path_matches_host_mirror():
+    """configs[1]'s reset: the RESET_REAL_PATH branch of the fused device reset (reset_kernels.hip: reset_trajectory) inside
+    the full three-launch reset, against the host mirror that tests/test_host_logic.py pins to the reference
+    (traj_generator.py:120-160): same rows (keyed permutation restated on the host), vertices <= 1e-4, masks bit-exact,
+    rows distinct within the call."""
+    from emloco_amd import _lib as L
+    from emloco_amd.run import create_rlgpu_env, fill_flags
+    from emloco_amd.utils.config import get_args, load_cfg
+    from emloco_amd.utils.flags import flags
+    from emloco_amd.env.util.traj_generator import TrajGenerator
+    E = 64
+    args = get_args(["--num_envs", str(E), "--seed", "3", "--random_heading", "--init_heading", "--heading_inversion",
+                     "--adjust_root_vel", "--real_path", "JTA+JRDB"])
+    cfg, cfg_train, _ = load_cfg(args)
+    data = [_synthetic_paths(50, 1), _synthetic_paths(37, 2, nv=104)]
+    cfg["env"]["traj_data"] = data
+    fill_flags(args)
+    try:
+        env = create_rlgpu_env(args, cfg, cfg_train)
+        task = env.task
+        dev = task.device
+        ids = torch.arange(E, device=dev)
+        torch.manual_seed(0)
+        rnd = torch.rand(E, L.RESET_RND, device=dev)
+        if task._reset_bufs is None:
+            task._reset_bufs = task._make_reset_bufs()
+        key = 0xC0FFEE
+        task._reset_bufs.real_pick_key = key
+        task._fused_reset_envs(ids, rnd=rnd)
+        torch.cuda.synchronize()
+        real = (rnd[:, L.RND_REAL] > 0.5).cpu().numpy()
+        assert 20 < real.sum() < 44
+        rows = [L.real_pick_perm(i, 87, key) for i in range(E)]
+        tg = TrajGenerator(E, task.max_episode_length * task.dt, 101, dev, 2.0, task._speed_min, task._speed_max, task._accel_max,
+                           task._sharp_turn_prob, None, hybridInitProb=task._hybrid_init_prob, flags=flags, traj_data=data)
+        draws = dict(r_dtheta=rnd[:, L.RND_DTHETA:L.RND_DTHETA + 100], r_dtheta_sharp=rnd[:, L.RND_SHARP:L.RND_SHARP + 100],
+                     bern_sharp=(rnd[:, L.RND_BERN:L.RND_BERN + 100] < task._sharp_turn_prob).float(), r_heading=rnd[:, L.RND_HEADING],
+                     r_dspeed=rnd[:, L.RND_DSPEED:L.RND_DSPEED + 100], r_speed0=rnd[:, L.RND_SPEED0], r_inversion=rnd[:, L.RND_INVERSION],
+                     r_real=rnd[:, L.RND_REAL])
+        draws = {k: v.clone() for k, v in draws.items()}
+        draws["real_rids"] = [rows[i] for i in range(E) if real[i]]
+        assert len(set(draws["real_rids"])) == len(draws["real_rids"])
+        root = task._humanoid_root_states
+        tg.reset(ids, root[:, 0:3].clone(), root[:, 7:10].clone(), draws=draws)
+        got, exp = task._traj_gen._verts.cpu().numpy(), tg._verts.cpu().numpy()
+        assert np.abs(got - exp).max() < 1e-4, np.abs(got - exp).max()
+        # the real envs carry their row's z signature (1e-3 * row within its dataset), the others the flat polyline
+        z = got[:, 5, 2]
+        assert (z[~real] == 0).all()
+        exp_z = np.array([1e-3 * (r if r < 50 else r - 50) for r in rows], np.float32)
+        np.testing.assert_array_equal(z[real], exp_z[real])
+        np.testing.assert_array_equal(task.inverted.cpu().numpy(), tg.inverted.cpu().numpy())
+        np.testing.assert_allclose(task.waypoint_traj.cpu().numpy(), task._fetch_traj_samples(ids).cpu().numpy(), rtol=1e-5, atol=1e-5)
+        # the seeded path (what reset_done / bench.py run): a fresh permutation per call, rows distinct within a call
+        seen = []
+        for _ in range(2):
+            task.reset_buf[:] = 1
+            task.reset_done()
+            torch.cuda.synchronize()
+            zz = task._traj_gen._verts[:, 5, 2].cpu().numpy()
+            took = zz[zz != 0]
+            assert 15 < took.size < 50
+            sig = np.sort(np.round(took * 1e3).astype(int))
+            # a dataset-local signature appears at most twice (once per dataset) when rows are distinct
+            assert np.bincount(sig).max() <= 2
+            seen.append(zz.copy())
+        assert not np.array_equal(seen[0], seen[1])
+    finally:
+        fill_flags(get_args(["--num_envs", "1"]))
+
+
+def test_bench_config_rollout_step_matches_oracle():
+    """BASELINE configs[1] exactly as bench.py builds it (4096 envs, random_heading, init_heading + inversion,
+    adjust_root_vel, JTA+JRDB real paths, self-collision): after a reset and 12 rollout steps with resets in between,
+    one env.step of a slice of envs is recomputed by the oracle from the state, warm-start impulses and targets the
+    simulator held -- body states bit-exact, reward / reset / terminate masks equal."""
+    import copy
+    import sys, os
+    import oracle
+    from helpers import oracle_sim
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from emloco_amd.utils.config import get_args
+    from emloco_amd.run import fill_flags
+    E = 4096
+    try:
+        env = bench.make_env(E, 0)
+        task = env.task
+        dev = task.device
+        env.reset(torch.arange(E, device=dev))
+        bench.stagger_episodes(env, steps=12, seed=5)
+        g = torch.Generator(device=dev)
+        g.manual_seed(3)
+        for k in range(12):
+            env.reset_done()
+            env.step(torch.randn(E, 69, device=dev, generator=g) * float(np.exp(-2.9)))
+        env.reset_done()
+        torch.cuda.synchronize()
+        assert int((task.progress_buf == 0).sum()) > 50              # some envs were just reset through the real-path branch
+        sl = np.r_[0:24, 2040:2056, 4072:4096]                       # first / middle / last waves of the launch
+        just_reset = np.nonzero((task.progress_buf == 0).cpu().numpy())[0][:8]
+        sl = np.unique(np.concatenate([sl, just_reset]))
+        root0 = task._root_states.cpu().numpy()[sl].copy()
+        dof0 = task._dof_state.view(E, 69, 2).cpu().numpy()[sl].copy()
+        lws0 = task.sim.native.warm_start.view(E, -1, 3).cpu().numpy()[sl].copy()
+        prog0 = task.progress_buf.cpu().numpy()[sl].copy()
+        act = torch.randn(E, 69, device=dev, generator=g) * float(np.exp(-2.9))
+        obs, rew, done, info = env.step(act)
+        torch.cuda.synchronize()
+        ms = []
+        for i in sl:
+            e = task.sim.envs[int(i)]
+            m = copy.copy(e.actors[0].asset.model)
+            m.kp = e.actors[0].dof_props["stiffness"].astype(np.float64)
+            m.kd = e.actors[0].dof_props["damping"].astype(np.float64)
+            ms.append(m)
+        sc = getattr(task.sim.native, "_sc", None)
+        assert sc is not None                                         # has_self_collision: True (pacer.yaml:17)
+        sc_sl = {k: (v[sl] if isinstance(v, np.ndarray) and v.shape[:1] == (E,) else v) for k, v in sc.items()}
+        osim = oracle_sim(ms, root0, dof0, task._pd_targets.cpu().numpy()[sl], self_collision=sc_sl, n_sub=4)
+        osim.lambda_ws[:] = lws0
+        osim.step(1)
+        rb = task._rigid_body_state.view(E, 24, 13).cpu().numpy()[sl]
+        assert np.array_equal(rb, osim.rb_state), "bench-config env.step is not bit-exact against the oracle"
+        assert np.array_equal(task.sim.native.warm_start.view(E, -1, 3).cpu().numpy()[sl], osim.lambda_ws)
+        betas = task.humanoid_betas.cpu().numpy()[sl]
+        o = oracle.self_obs(rb[:, :, 0:3], rb[:, :, 3:7], rb[:, :, 7:10], rb[:, :, 10:13], betas)
+        np.testing.assert_allclose(obs[:, :368].cpu().numpy()[sl], o, rtol=1e-5, atol=2e-5)
+        tar = oracle.traj_calc_pos(task._traj_gen._verts.cpu().numpy()[sl], prog0 + 1, task.dt, task._traj_gen.get_traj_duration())
+        rs, tm = oracle.reset(prog0 + 1, osim.contact_force, osim.rb_state[:, :, :3], tar)
+        np.testing.assert_array_equal(done.cpu().numpy()[sl], rs)
+        np.testing.assert_array_equal(info["terminate"].cpu().numpy()[sl], tm)
+        r, _ = oracle.reward(rb[:, 0, :3], tar, osim.dof_force, osim.dof_state[:, :, 1])
+        np.testing.assert_allclose(rew.cpu().numpy()[sl], r, rtol=1e-5, atol=1e-6)
+    finally:
+        fill_flags(get_args(["--num_envs", "1"]))

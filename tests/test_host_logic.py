@@ -52,6 +52,42 @@ def test_traj_reset_heading_inversion_matches_reference(golden):
     np.testing.assert_array_equal(tg.show_inverted().long().numpy(), g["inverted"])   # bit-exact mask
 
 
+@pytest.mark.parametrize("name", ["traj_reset_real1", "traj_reset_real2", "traj_reset_real2_noadj"])
+def test_traj_reset_real_path_matches_reference(golden, name):
+    """flags.real_path (traj_generator.py:120-160; what configs[1] runs): one and two datasets, with and without
+    adjust_root_vel, a first segment of zero length included; the reference's random.sample is replayed through `real_rids`."""
+    from helpers import TRAJ_CASES
+    from emloco_amd.env.util.traj_generator import TrajGenerator
+    g = golden(name)
+    n_jta = int(g["n_jta"])
+    tables = [g["real_table"][:n_jta]] + ([g["real_table"][n_jta:]] if g["real_table"].shape[0] > n_jta else [])
+    data = [{i: {"pose": None, "traj": t[i]} for i in range(len(t))} for t in tables]
+    dt = 2 * (1.0 / 60.0)
+    tg = TrajGenerator(16, 168 * dt, 101, "cpu", 2.0, 0.0005, 3.0, 2.0, 0.02, None, hybridInitProb=0.5,
+                       flags=_flags(**TRAJ_CASES[name]), traj_data=data)
+    d = _draws(g, "r_real", "r_inversion")
+    d["real_rids"] = g["real_rids"].tolist()
+    tg.reset(torch.arange(16), torch.from_numpy(g["init_pos"]), torch.from_numpy(g["root_vel"]), draws=d)
+    assert int((g["r_real"] > 0.5).sum()) == len(g["real_rids"]) > 3 and len(set(g["real_rids"].tolist())) == len(g["real_rids"])
+    np.testing.assert_allclose(tg._verts.numpy(), g["verts"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_array_equal(tg.show_inverted().long().numpy(), g["inverted"])
+    np.testing.assert_array_equal(tg.real_rows(), g["real_table"].astype(np.float32))
+
+
+def test_real_pick_permutation_is_a_bijection():
+    """The keyed permutation that stands where the reference calls random.sample: distinct rows within a call (sampling
+    without replacement), every row reachable, different keys give different samples."""
+    from emloco_amd._lib import real_pick_perm
+    for n in (1, 2, 3, 17, 40, 1000, 4096, 8191):
+        for key in (0, 1, 0xDEADBEEF):
+            out = [real_pick_perm(i, n, key) for i in range(n)]
+            assert sorted(out) == list(range(n))
+    a = [real_pick_perm(i, 8192, 5) for i in range(2048)]
+    b = [real_pick_perm(i, 8192, 6) for i in range(2048)]
+    assert a != b and len(set(a) & set(b)) < 800                   # ~ 2048^2 / 8192 = 512 expected in common
+    assert abs(np.mean(a) - 4096) < 300 and abs(np.corrcoef(np.arange(2048), a)[0, 1]) < 0.08
+
+
 def test_calc_pos_matches_reference(golden):
     g = golden("traj_samples")
     tg = _gen(_flags())
