@@ -139,7 +139,7 @@ SYMBOLS_SIM = [
 SYMBOLS_TASK = [
     "emloco_task_post_physics", "emloco_task_amp_rows", "emloco_task_pd_targets", "emloco_task_last_ms",
     "emloco_task_enable_timing", "emloco_task_reset", "emloco_task_reset_seeded", "emloco_task_compact_done",
-    "emloco_task_traj_reset",
+    "emloco_task_traj_reset", "emloco_task_get_heights",
 ]
 
 _lib = None
@@ -187,6 +187,8 @@ def load():
     lib.emloco_task_reset.argtypes = [C.c_void_p, C.POINTER(ResetBufs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.emloco_task_reset_seeded.argtypes = [C.c_void_p, C.POINTER(ResetBufs), C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.emloco_task_traj_reset.argtypes = [C.POINTER(ResetBufs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emloco_task_get_heights.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emloco_task_compact_done.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib

@@ -125,6 +125,16 @@ __device__ __forceinline__ void quat2rotvec(const float *qin, float *e) {
     e[0] = q[0] * k; e[1] = q[1] * k; e[2] = q[2] * k;
 }
 
+// Transcendentals of the reference task code (atan2 / sin / cos / acos of torch's CPU path): evaluated in double precision and
+// rounded once, i.e. correctly rounded fp32 results -- the same on the device, in the emulator and in the oracle
+// (the CPU restatement used by the tests does the same), and the best available stand-in for torch's own last bit (its CPU sin / cos go
+// through MKL's closed VML, ~5 % of values differ from the correctly rounded one by 1 ulp).  The heading quaternion behind
+// the terrain probes comes from these, so the map indices (p / 0.1).long() are identical across the three.
+__device__ __forceinline__ float cr_sinf(float x) { return (float)sin((double)x); }
+__device__ __forceinline__ float cr_cosf(float x) { return (float)cos((double)x); }
+__device__ __forceinline__ float cr_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
+__device__ __forceinline__ float cr_acosf(float x) { return (float)acos((double)x); }
+
 // ---- reference task-code helpers (group 2) -------------------------------------------------
 __device__ __forceinline__ void ref_quat_rotate(const float *q, const float *v, float *o) {
     float w = q[3];
@@ -164,7 +174,7 @@ __device__ __forceinline__ void ref_quat_apply(const float *a, const float *b, f
 // quat_from_angle_axis about +z: normalize(axis) = z, then the quaternion is re-normalised
 __device__ __forceinline__ void ref_quat_about_z(float angle, float *o) {
     float th = angle / 2.0f;
-    float s = sinf(th), c = cosf(th);
+    float s = cr_sinf(th), c = cr_cosf(th);
     float n = sqrtf(s * s + c * c);
     if (n < 1e-9f) n = 1e-9f;
     o[0] = 0.0f / n; o[1] = 0.0f / n; o[2] = s / n; o[3] = c / n;
@@ -173,7 +183,7 @@ __device__ __forceinline__ float ref_calc_heading(const float *q) {
     const float ex[3] = {1.0f, 0.0f, 0.0f};
     float r[3];
     ref_quat_rotate(q, ex, r);
-    return atan2f(r[1], r[0]);
+    return cr_atan2f(r[1], r[0]);
 }
 __device__ __forceinline__ void ref_quat_to_tan_norm(const float *q, float *o6) {
     const float ex[3] = {1.0f, 0.0f, 0.0f}, ez[3] = {0.0f, 0.0f, 1.0f};
@@ -183,13 +193,13 @@ __device__ __forceinline__ void ref_quat_to_tan_norm(const float *q, float *o6) 
 __device__ __forceinline__ void ref_exp_map_to_quat(const float *e, float *o) {
     float angle = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
     float ax[3] = {e[0] / angle, e[1] / angle, e[2] / angle};
-    angle = atan2f(sinf(angle), cosf(angle));
+    angle = cr_atan2f(cr_sinf(angle), cr_cosf(angle));
     if (!(fabsf(angle) > 1e-5f)) { angle = 0.0f; ax[0] = 0.0f; ax[1] = 0.0f; ax[2] = 1.0f; }
     float n = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
     if (n < 1e-9f) n = 1e-9f;
     float th = angle / 2.0f;
-    float s = sinf(th);
-    float q[4] = {ax[0] / n * s, ax[1] / n * s, ax[2] / n * s, cosf(th)};
+    float s = cr_sinf(th);
+    float q[4] = {ax[0] / n * s, ax[1] / n * s, ax[2] / n * s, cr_cosf(th)};
     float qn = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     if (qn < 1e-9f) qn = 1e-9f;
     o[0] = q[0] / qn; o[1] = q[1] / qn; o[2] = q[2] / qn; o[3] = q[3] / qn;
@@ -223,9 +233,9 @@ __device__ __forceinline__ void ref_slerp(const float *q0, const float *q1in, fl
     float c = q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2] + q0[3] * q1[3];
     if (c < 0.0f) { q1[0] = -q1[0]; q1[1] = -q1[1]; q1[2] = -q1[2]; q1[3] = -q1[3]; }
     c = fabsf(c);
-    const float half = acosf(c);
+    const float half = cr_acosf(c);
     const float s = sqrtf(1.0f - c * c);
-    const float ra = sinf((1.0f - t) * half) / s, rb = sinf(t * half) / s;
+    const float ra = cr_sinf((1.0f - t) * half) / s, rb = cr_sinf(t * half) / s;
     for (int i = 0; i < 4; ++i) {
         float v = ra * q0[i] + rb * q1[i];
         if (fabsf(s) < 0.001f) v = 0.5f * q0[i] + 0.5f * q1[i];
@@ -236,8 +246,8 @@ __device__ __forceinline__ void ref_slerp(const float *q0, const float *q1in, fl
 // pacer/pacer/utils/torch_utils.py:26-64 quat_to_exp_map
 __device__ __forceinline__ void ref_quat_to_exp_map(const float *q, float *o) {
     const float sin_theta = sqrtf(1.0f - q[3] * q[3]);
-    float angle = 2.0f * acosf(q[3]);
-    angle = atan2f(sinf(angle), cosf(angle));
+    float angle = 2.0f * cr_acosf(q[3]);
+    angle = cr_atan2f(cr_sinf(angle), cr_cosf(angle));
     if (fabsf(sin_theta) > 1e-5f) {
         o[0] = angle * (q[0] / sin_theta); o[1] = angle * (q[1] / sin_theta); o[2] = angle * (q[2] / sin_theta);
     } else { o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; }

@@ -38,16 +38,6 @@ __device__ __forceinline__ FrameBlend frame_blend(const EmlocoResetBufs &t, int 
 
 __device__ __forceinline__ float lerp1(float a, float b, float w) { return (1.0f - w) * a + w * b; }
 
-__device__ __forceinline__ float sample_h(const EmlocoResetBufs &t, float x, float y) {
-    long px = (long)(x / t.hscale), py = (long)(y / t.hscale);
-    if (px < 0) px = 0;
-    if (px > t.hf_rows - 2) px = t.hf_rows - 2;
-    if (py < 0) py = 0;
-    if (py > t.hf_cols - 2) py = t.hf_cols - 2;
-    const int16_t h1 = t.heightfield[px * t.hf_cols + py], h2 = t.heightfield[(px + 1) * t.hf_cols + (py + 1)];
-    return (float)(h1 < h2 ? h1 : h2) * t.vscale;
-}
-
 // Random rows for the entries of a (compacted, -1 padded) env list without a host-side generator: row bi of `rnd` gets
 // EMLOCO_RESET_RND uniforms in [0, 1) from a stateless hash of (seed, bi, k) (two rounds of the murmur3 finaliser), only
 // for the entries that are present -- the caller passes a fresh seed per call.  Replaces a torch.rand of the whole
@@ -117,20 +107,14 @@ reset_sample_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
             if (li > t.n_valid - 1) li = t.n_valid - 1;
             pos[0] = t.valid_x[li]; pos[1] = t.valid_y[li];
         }
-        // centre height: 3x3 yaw-only probes (humanoid_pedestrain_terrain.py:607,732-759)
-        float qy[4] = {0.0f, 0.0f, rot[2], rot[3]};
-        float nn = sqrtf(qy[2] * qy[2] + qy[3] * qy[3]);
-        if (nn < 1e-9f) nn = 1e-9f;
-        qy[2] /= nn; qy[3] /= nn;
-        float hsum = 0.0f;
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                const float pt[3] = {-0.1f + 0.1f * (float)i, -0.2f + 0.2f * (float)j, 0.0f};
-                float rr[3];
-                ref_quat_apply(qy, pt, rr);
-                hsum += sample_h(t, rr[0] + pos[0], rr[1] + pos[1]);
-            }
-        const float gh = hsum / 9.0f;
+        // centre height: 3x3 yaw-only probes (humanoid_pedestrain_terrain.py:607,732-759), same device functions as the step
+        float ch[9];
+        for (int k = 0; k < 9; ++k) {
+            float wx, wy;
+            center_probe(pos, rot, k, &wx, &wy);
+            ch[k] = sample_height(t.heightfield, t.hf_rows, t.hf_cols, wx, wy, t.hscale, t.vscale);
+        }
+        const float gh = mean9(ch);
         pos[2] += gh;
         t.ground_h[env] = gh;
         float *rs = s.root_state + (long)env * 13;

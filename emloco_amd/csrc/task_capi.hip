@@ -144,6 +144,17 @@ int emloco_task_traj_reset(const EmlocoResetBufs *b, const int32_t *dev_env_ids,
     return 0;
 }
 
+int emloco_task_get_heights(const int16_t *dev_heightfield, int rows, int cols, float hscale, float vscale, const float *dev_pose7,
+                            int n, int grid, float *dev_heights, int64_t *dev_px, int64_t *dev_py, void *stream) {
+    if (!dev_heightfield || !dev_pose7 || rows < 2 || cols < 2 || n < 0) return tfail(-1, "emloco_task_get_heights: bad argument");
+    if ((dev_px == nullptr) != (dev_py == nullptr)) return tfail(-1, "emloco_task_get_heights: px and py go together");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(emloco::get_heights_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, dev_heightfield, rows, cols,
+                       hscale, vscale, dev_pose7, n, grid, dev_heights, dev_px, dev_py);
+    THIPCHK(hipGetLastError());
+    return 0;
+}
+
 int emloco_task_compact_done(const int64_t *dev_flags, int n, int32_t *dev_ids, void *stream) {
     if (!dev_flags || !dev_ids || n < 1) return tfail(-1, "emloco_task_compact_done: bad argument (ids holds n + 1 entries)");
     hipLaunchKernelGGL(emloco::compact_flags_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dev_flags, n, dev_ids);

@@ -35,17 +35,56 @@ __device__ __forceinline__ void calc_pos(const float *verts, float time, float t
     for (int k = 0; k < 3; ++k) out[k] = (1.0f - lerp) * verts[i0 * 3 + k] + lerp * verts[i1 * 3 + k];
 }
 
-// humanoid_pedestrain_terrain.py:1212-1218,1282-1288
-__device__ __forceinline__ float sample_height(const int16_t *hf, int rows, int cols, float x, float y, float hscale, float vscale) {
+// humanoid_pedestrain_terrain.py:1212-1218 world_points_to_map: (p / horizontal_scale).long(), clipped to [0, shape - 2]
+__device__ __forceinline__ void map_index(int rows, int cols, float x, float y, float hscale, long *opx, long *opy) {
     long px = (long)(x / hscale);
     long py = (long)(y / hscale);
     if (px < 0) px = 0;
     if (px > rows - 2) px = rows - 2;
     if (py < 0) py = 0;
     if (py > cols - 2) py = cols - 2;
+    *opx = px; *opy = py;
+}
+// :1282-1288 sample_height_points: min of the cell's two diagonal corners
+__device__ __forceinline__ float sample_height_at(const int16_t *hf, int cols, long px, long py, float vscale) {
     const int16_t h1 = hf[px * cols + py], h2 = hf[(px + 1) * cols + (py + 1)];
     const int16_t hm = h1 < h2 ? h1 : h2;
     return (float)hm * vscale;
+}
+__device__ __forceinline__ float sample_height(const int16_t *hf, int rows, int cols, float x, float y, float hscale, float vscale) {
+    long px, py;
+    map_index(rows, cols, x, y, hscale, &px, &py);
+    return sample_height_at(hf, cols, px, py, vscale);
+}
+// probe idx = 32 i + j of the 32x32 grid (+-2 m, meshgrid 'ij', :650-668) rotated by the heading quaternion hq about `origin`
+// (:778-787 get_heights): world position
+__device__ __forceinline__ void grid_probe(const float *hq, const float *origin, int idx, float *wx, float *wy) {
+    const int i = idx >> 5, j = idx & 31;
+    const float pt[3] = {linspace_f(-2.0, 2.0, 32, i), linspace_f(-2.0, 2.0, 32, j), 0.0f};
+    float rr[3];
+    ref_quat_apply(hq, pt, rr);
+    *wx = rr[0] + origin[0];
+    *wy = rr[1] + origin[1];
+}
+// probe k = 3 i + j of the 3x3 centre grid (x +-0.1, y +-0.2, :633-648), yaw-only rotation of the root (:747-750, quat_apply_yaw :1533-1538)
+__device__ __forceinline__ void center_probe(const float *root_pos, const float *root_rot, int k, float *wx, float *wy) {
+    const int i = k / 3, j = k - 3 * i;
+    const float pt[3] = {linspace_f(-0.1, 0.1, 3, i), linspace_f(-0.2, 0.2, 3, j), 0.0f};
+    float qy[4] = {0.0f, 0.0f, root_rot[2], root_rot[3]}, rr[3];
+    float nn = sqrtf(qy[2] * qy[2] + qy[3] * qy[3]);
+    if (nn < 1e-9f) nn = 1e-9f;
+    qy[0] = 0.0f / nn; qy[1] = 0.0f / nn; qy[2] = qy[2] / nn; qy[3] = qy[3] / nn;
+    ref_quat_apply(qy, pt, rr);
+    *wx = rr[0] + root_pos[0];
+    *wy = rr[1] + root_pos[1];
+}
+
+// torch's .mean(dim=-1) over the 9 centre probes (:427-429): sum / 9, the sum in the order of torch's scalar row reduction
+// (8 partial sums + remainder): ((c0 + c8) + c1) + c2 + ... + c7
+__device__ __forceinline__ float mean9(const float *c) {
+    float s = c[0] + c[8];
+    for (int k = 1; k < 8; ++k) s += c[k];
+    return s / 9.0f;
 }
 
 // one body's share of compute_humanoid_observations_smpl_max (humanoid.py:1625-1687)
@@ -171,20 +210,13 @@ post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_id
         }
         // ---- centre-height probes (3x3, yaw only) around the root
         if (lane < 9) {
-            const int i = lane / 3, j = lane - 3 * i;
-            const float pt[3] = {linspace_f(-0.1, 0.1, 3, i), linspace_f(-0.2, 0.2, 3, j), 0.0f};
-            float qy[4] = {0.0f, 0.0f, root[5], root[6]}, rr[3];
-            float nn = sqrtf(qy[2] * qy[2] + qy[3] * qy[3]);
-            if (nn < 1e-9f) nn = 1e-9f;
-            qy[0] = 0.0f / nn; qy[1] = 0.0f / nn; qy[2] = qy[2] / nn; qy[3] = qy[3] / nn;
-            ref_quat_apply(qy, pt, rr);
-            sh_center[lane] = sample_height(t.heightfield, t.hf_rows, t.hf_cols, rr[0] + root[0], rr[1] + root[1], t.hscale, t.vscale);
+            float wx, wy;
+            center_probe(root, root + 3, lane, &wx, &wy);
+            sh_center[lane] = sample_height(t.heightfield, t.hf_rows, t.hf_cols, wx, wy, t.hscale, t.vscale);
         }
         __syncthreads();
         for (int i = lane; i < EMLOCO_SELF_OBS; i += 64) { obs[i] = sh_obs[i]; fobs[i] = sh_fobs[i]; }
-        float csum = 0.0f;
-        for (int k = 0; k < 9; ++k) csum += sh_center[k];
-        const float cmean = csum / 9.0f;
+        const float cmean = mean9(sh_center);
         // ---- 32x32 height grid around the head, rotated by the head's heading (16 points per lane)
         const float *head = sh_body[t.head_body];
         float hq[4];
@@ -194,10 +226,9 @@ post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_id
         for (int it = 0; it < EMLOCO_HEIGHT_POINTS / 64; ++it) {
             const int idx = lane + 64 * it;
             const int i = idx >> 5, j = idx & 31;
-            const float pt[3] = {linspace_f(-2.0, 2.0, 32, i), linspace_f(-2.0, 2.0, 32, j), 0.0f};
-            float rr[3];
-            ref_quat_apply(hq, pt, rr);
-            const float hh = sample_height(t.heightfield, t.hf_rows, t.hf_cols, rr[0] + head[0], rr[1] + head[1], t.hscale, t.vscale);
+            float wx, wy;
+            grid_probe(hq, head, idx, &wx, &wy);
+            const float hh = sample_height(t.heightfield, t.hf_rows, t.hf_cols, wx, wy, t.hscale, t.vscale);
             float v = cmean - hh;
             if (v < -3.0f) v = -3.0f;
             if (v > 3.0f) v = 3.0f;
@@ -309,6 +340,30 @@ compact_flags_kernel(const int64_t *flags, int n, int32_t *ids) {
     const int count = sh_base;
     for (int i = count + tid; i < n; i += 1024) ids[i] = -1;
     if (tid == 0) ids[n] = count;
+}
+
+// get_heights / get_center_heights (humanoid_pedestrain_terrain.py:761-815, 732-759) for arbitrary poses, with the integer map
+// indices: pose7 [n][7] (pos3, quat4 xyzw); grid = 1: 32x32 grid rotated by the pose's heading -> out [n][1024];
+// grid = 0: 3x3 yaw-only centre probes -> out [n][9].  One wave per pose.
+__global__ void __launch_bounds__(64)
+get_heights_kernel(const int16_t *hf, int rows, int cols, float hscale, float vscale, const float *pose7, int n, int grid,
+                   float *out_h, int64_t *out_px, int64_t *out_py) {
+    const int e = blockIdx.x, lane = threadIdx.x;
+    if (e >= n) return;
+    const float *p = pose7 + (long)e * 7;
+    const int np = grid ? EMLOCO_HEIGHT_POINTS : 9;
+    float hq[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+    if (grid) ref_quat_about_z(ref_calc_heading(p + 3), hq);
+    for (int idx = lane; idx < np; idx += 64) {
+        float wx, wy;
+        long px, py;
+        if (grid) grid_probe(hq, p, idx, &wx, &wy);
+        else center_probe(p, p + 3, idx, &wx, &wy);
+        map_index(rows, cols, wx, wy, hscale, &px, &py);
+        const long o = (long)e * np + idx;
+        if (out_h) out_h[o] = sample_height_at(hf, cols, px, py, vscale);
+        if (out_px) { out_px[o] = px; out_py[o] = py; }
+    }
 }
 
 }  // namespace emloco

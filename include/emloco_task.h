@@ -176,6 +176,14 @@ int emloco_task_reset_seeded(struct EmlocoSim *sim, const EmlocoResetBufs *bufs,
 int emloco_task_traj_reset(const EmlocoResetBufs *bufs, const int32_t *dev_env_ids, int n, const float *dev_rnd,
                            const float *dev_init_pos, const float *dev_root_vel, void *stream);
 
+/* HumanoidPedestrianTerrain.get_heights / get_center_heights for arbitrary poses (humanoid_pedestrain_terrain.py:761-815,
+ * 732-759; Terrain.world_points_to_map / sample_height_points :1212-1218,1282-1288): dev_pose7 [n][7] = position + xyzw
+ * rotation; grid = 1: the 32x32 sensor grid rotated by the pose's heading -> [n][1024]; grid = 0: the 3x3 yaw-only centre
+ * probes -> [n][9].  dev_heights (metres) and the int64 map indices dev_px / dev_py are each optional.  The fused
+ * post-physics kernel evaluates the same device functions. */
+int emloco_task_get_heights(const int16_t *dev_heightfield, int rows, int cols, float hscale, float vscale, const float *dev_pose7,
+                            int n, int grid, float *dev_heights, int64_t *dev_px, int64_t *dev_py, void *stream);
+
 /* Device-side `reset_buf.nonzero()`: dev_ids[0..count) = ascending indices of the non-zero flags, the rest of the n
  * entries = -1, dev_ids[n] = count.  Every *_indexed / env-id-list entry point of this library skips negative ids, so
  *   emloco_task_compact_done(reset_buf, E, ids, s); emloco_task_reset(sim, bufs, ids, E, rnd, s);

@@ -171,24 +171,28 @@ def location_obs(root_states, samples):
     return out
 
 
-def get_heights(pose7, hf, hscale=0.1, vscale=0.005):
+def get_heights(pose7, hf, hscale=0.1, vscale=0.005, heading_q=None, return_index=False):
+    """`heading_q` (E,4): use this heading quaternion instead of computing it; `return_index`: also the int64 map indices."""
     pose7 = _f32(pose7)
     hf = np.ascontiguousarray(hf, dtype=np.int16)
     E = pose7.shape[0]
     out = np.zeros((E, 1024), np.float32)
-    lib().orc_get_heights(C.c_int(E), _p(pose7), _p(hf, C.c_int16), C.c_int(hf.shape[0]), C.c_int(hf.shape[1]),
-                          C.c_float(hscale), C.c_float(vscale), _p(out))
-    return out
+    px, py = np.zeros((E, 1024), np.int64), np.zeros((E, 1024), np.int64)
+    hq = None if heading_q is None else _f32(heading_q)
+    lib().orc_get_heights_ex(C.c_int(E), _p(pose7), None if hq is None else _p(hq), _p(hf, C.c_int16), C.c_int(hf.shape[0]),
+                             C.c_int(hf.shape[1]), C.c_float(hscale), C.c_float(vscale), _p(out), _p(px, C.c_int64), _p(py, C.c_int64))
+    return (out, px, py) if return_index else out
 
 
-def get_center_heights(root_states, hf, hscale=0.1, vscale=0.005):
+def get_center_heights(root_states, hf, hscale=0.1, vscale=0.005, return_index=False):
     root_states = _f32(root_states)
     hf = np.ascontiguousarray(hf, dtype=np.int16)
     E = root_states.shape[0]
     out = np.zeros((E, 9), np.float32)
-    lib().orc_get_center_heights(C.c_int(E), _p(root_states), _p(hf, C.c_int16), C.c_int(hf.shape[0]),
-                                 C.c_int(hf.shape[1]), C.c_float(hscale), C.c_float(vscale), _p(out))
-    return out
+    px, py = np.zeros((E, 9), np.int64), np.zeros((E, 9), np.int64)
+    lib().orc_get_center_heights_ex(C.c_int(E), _p(root_states), _p(hf, C.c_int16), C.c_int(hf.shape[0]), C.c_int(hf.shape[1]),
+                                    C.c_float(hscale), C.c_float(vscale), _p(out), _p(px, C.c_int64), _p(py, C.c_int64))
+    return (out, px, py) if return_index else out
 
 
 def height_obs(center9, heights):

@@ -12,6 +12,14 @@
 #define EMLOCO_ORACLE_MATH_H
 #include <math.h>
 
+/* atan2 / sin / cos / acos of the torch CPU path: double-precision evaluation rounded once = correctly rounded fp32 (the
+ * kernels do the same, emloco_amd/csrc/dev_math.h).  torch's own last bit is library-defined (MKL VML for sin / cos, Sleef
+ * for atan2; ~5 % of values sit 1 ulp off the correctly rounded one), so this is the closest restatement there is. */
+static inline float cr_sinf(float x) { return (float)sin((double)x); }
+static inline float cr_cosf(float x) { return (float)cos((double)x); }
+static inline float cr_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
+static inline float cr_acosf(float x) { return (float)acos((double)x); }
+
 /* R1:14-24 my_quat_rotate: a = v(2w^2-1); b = 2w (q x v); c = 2 q (q.v) */
 static inline void orc_my_quat_rotate(const float *q, const float *v, float *o) {
     float w = q[3];
@@ -68,20 +76,20 @@ static inline void orc_quat_from_angle_axis(float angle, const float *axis, floa
     float th = angle / 2.0f;
     float ax[3];
     orc_normalize(axis, 3, ax);
-    float s = sinf(th);
-    float q[4] = {ax[0] * s, ax[1] * s, ax[2] * s, cosf(th)};
+    float s = cr_sinf(th);
+    float q[4] = {ax[0] * s, ax[1] * s, ax[2] * s, cr_cosf(th)};
     orc_normalize(q, 4, o);
 }
 
 /* R2:104-106 normalize_angle */
-static inline float orc_normalize_angle(float x) { return atan2f(sinf(x), cosf(x)); }
+static inline float orc_normalize_angle(float x) { return cr_atan2f(cr_sinf(x), cr_cosf(x)); }
 
 /* R1:137-149 calc_heading = atan2 of the rotated +x axis */
 static inline float orc_calc_heading(const float *q) {
     const float ex[3] = {1.0f, 0.0f, 0.0f};
     float r[3];
     orc_my_quat_rotate(q, ex, r);
-    return atan2f(r[1], r[0]);
+    return cr_atan2f(r[1], r[0]);
 }
 
 /* R1:151-162 / R1:164-175 */
@@ -116,7 +124,7 @@ static inline void orc_exp_map_to_quat(const float *e, float *o) {
 /* R1:26-56 quat_to_angle_axis + quat_to_exp_map */
 static inline void orc_quat_to_exp_map(const float *q, float *o) {
     float sin_theta = sqrtf(1.0f - q[3] * q[3]);
-    float angle = 2.0f * acosf(q[3]);
+    float angle = 2.0f * cr_acosf(q[3]);
     angle = orc_normalize_angle(angle);
     if (fabsf(sin_theta) > 1e-5f) {
         o[0] = angle * (q[0] / sin_theta);
@@ -133,10 +141,10 @@ static inline void orc_slerp(const float *q0, const float *q1in, float t, float 
     float c = q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2] + q0[3] * q1[3];
     if (c < 0.0f) { q1[0] = -q1[0]; q1[1] = -q1[1]; q1[2] = -q1[2]; q1[3] = -q1[3]; }
     c = fabsf(c);
-    float half = acosf(c);
+    float half = cr_acosf(c);
     float s = sqrtf(1.0f - c * c);
-    float ra = sinf((1.0f - t) * half) / s;
-    float rb = sinf(t * half) / s;
+    float ra = cr_sinf((1.0f - t) * half) / s;
+    float rb = cr_sinf(t * half) / s;
     for (int i = 0; i < 4; ++i) {
         float v = ra * q0[i] + rb * q1[i];
         if (fabsf(s) < 0.001f) v = 0.5f * q0[i] + 0.5f * q1[i];

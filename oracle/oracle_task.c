@@ -122,14 +122,20 @@ void orc_location_obs(int E, const float *root_states, const float *samples, flo
     }
 }
 
-/* HPT:1212-1218 world_points_to_map + HPT:1282-1288 sample_height_points (no root_points, no velocity map) */
-static float sample_height(const int16_t *hf, int rows, int cols, float x, float y, float hscale, float vscale) {
-    long px = (long)(x / hscale); /* .long() truncates toward zero */
-    long py = (long)(y / hscale);
-    if (px < 0) px = 0;
-    if (px > rows - 2) px = rows - 2;
-    if (py < 0) py = 0;
-    if (py > cols - 2) py = cols - 2;
+/* HPT:1212-1218 world_points_to_map: (points / horizontal_scale).long() (true fp32 division by fp32(0.1), truncation
+ * toward zero), clipped to [0, shape - 2] */
+static void world_point_to_map(int rows, int cols, float x, float y, float hscale, long *px, long *py) {
+    long ix = (long)(x / hscale);
+    long iy = (long)(y / hscale);
+    if (ix < 0) ix = 0;
+    if (ix > rows - 2) ix = rows - 2;
+    if (iy < 0) iy = 0;
+    if (iy > cols - 2) iy = cols - 2;
+    *px = ix; *py = iy;
+}
+
+/* HPT:1282-1288 sample_height_points (no root_points, no velocity map): min of the cell's two diagonal corners */
+static float sample_height_at(const int16_t *hf, int cols, long px, long py, float vscale) {
     int16_t h1 = hf[px * cols + py], h2 = hf[(px + 1) * cols + (py + 1)];
     int16_t h = h1 < h2 ? h1 : h2;
     return (float)h * vscale;
@@ -143,43 +149,65 @@ static float linspace_f(double lo, double hi, int n, int i) {
 }
 
 /* HPT:761-815 get_heights with terrain_obs_root == "head" (HPT:410-412): rotate the 32x32 grid by the
- * heading of `pose` (pos3, quat4), sample the map.  out (E,1024) row-major over meshgrid(x,y) 'ij'. */
-void orc_get_heights(int E, const float *pose7, const int16_t *hf, int rows, int cols, float hscale,
-                     float vscale, float *out) {
+ * heading of `pose` (pos3, quat4), sample the map.  out (E,1024) row-major over meshgrid(x,y) 'ij'.
+ * heading_q (optional, [E][4]): use this heading quaternion instead of computing it (the sine / cosine / arctangent behind it
+ * are the one step of the chain whose last bit is library-defined: torch's CPU path calls MKL's closed VML there);
+ * px / py (optional, [E][1024] int64): the map indices. */
+void orc_get_heights_ex(int E, const float *pose7, const float *heading_q, const int16_t *hf, int rows, int cols, float hscale,
+                        float vscale, float *out, int64_t *out_px, int64_t *out_py) {
     for (int e = 0; e < E; ++e) {
         const float *p = pose7 + e * 7;
         float hq[4];
-        orc_calc_heading_quat(p + 3, hq);
+        if (heading_q) { for (int k = 0; k < 4; ++k) hq[k] = heading_q[e * 4 + k]; }
+        else orc_calc_heading_quat(p + 3, hq);
         for (int i = 0; i < 32; ++i)
             for (int j = 0; j < 32; ++j) {
                 float pt[3] = {linspace_f(-2.0, 2.0, 32, i), linspace_f(-2.0, 2.0, 32, j), 0.0f}, r[3];
+                long px, py;
                 orc_quat_apply(hq, pt, r);
-                out[(long)e * NHP + i * 32 + j] =
-                    sample_height(hf, rows, cols, r[0] + p[0], r[1] + p[1], hscale, vscale);
+                world_point_to_map(rows, cols, r[0] + p[0], r[1] + p[1], hscale, &px, &py);
+                const long o = (long)e * NHP + i * 32 + j;
+                if (out) out[o] = sample_height_at(hf, cols, px, py, vscale);
+                if (out_px) { out_px[o] = px; out_py[o] = py; }
             }
     }
 }
 
+void orc_get_heights(int E, const float *pose7, const int16_t *hf, int rows, int cols, float hscale,
+                     float vscale, float *out) {
+    orc_get_heights_ex(E, pose7, 0, hf, rows, cols, hscale, vscale, out, 0, 0);
+}
+
 /* HPT:732-759 get_center_heights: 3x3 probe (x in linspace(-.1,.1,3), y in linspace(-.2,.2,3)), yaw-only */
-void orc_get_center_heights(int E, const float *root_states, const int16_t *hf, int rows, int cols,
-                            float hscale, float vscale, float *out9) {
+void orc_get_center_heights_ex(int E, const float *root_states, const int16_t *hf, int rows, int cols,
+                               float hscale, float vscale, float *out9, int64_t *out_px, int64_t *out_py) {
     for (int e = 0; e < E; ++e) {
         const float *rs = root_states + e * 13;
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) {
                 float pt[3] = {linspace_f(-0.1, 0.1, 3, i), linspace_f(-0.2, 0.2, 3, j), 0.0f}, r[3];
+                long px, py;
                 orc_quat_apply_yaw(rs + 3, pt, r);
-                out9[e * 9 + i * 3 + j] =
-                    sample_height(hf, rows, cols, r[0] + rs[0], r[1] + rs[1], hscale, vscale);
+                world_point_to_map(rows, cols, r[0] + rs[0], r[1] + rs[1], hscale, &px, &py);
+                if (out9) out9[e * 9 + i * 3 + j] = sample_height_at(hf, cols, px, py, vscale);
+                if (out_px) { out_px[e * 9 + i * 3 + j] = px; out_py[e * 9 + i * 3 + j] = py; }
             }
     }
+}
+
+void orc_get_center_heights(int E, const float *root_states, const int16_t *hf, int rows, int cols,
+                            float hscale, float vscale, float *out9) {
+    orc_get_center_heights_ex(E, root_states, hf, rows, cols, hscale, vscale, out9, 0, 0);
 }
 
 /* HPT:427-437 height obs = clip(mean(center) - h, -3, 3) * 5 (use_center_height: true) */
 void orc_height_obs(int E, const float *center9, const float *heights, float *obs) {
     for (int e = 0; e < E; ++e) {
-        float s = 0.0f;
-        for (int k = 0; k < 9; ++k) s += center9[e * 9 + k];
+        /* torch's .mean(dim=-1) over the 9 probes = sum / 9 with the sum in the order of its scalar row reduction
+         * (8 partial sums + remainder, aten SumKernel row_sum): ((c0 + c8) + c1) + c2 + ... + c7 */
+        const float *c = center9 + e * 9;
+        float s = c[0] + c[8];
+        for (int k = 1; k < 8; ++k) s += c[k];
         float m = s / 9.0f;
         for (int k = 0; k < NHP; ++k) {
             float v = m - heights[(long)e * NHP + k];

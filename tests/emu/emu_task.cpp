@@ -37,3 +37,9 @@ extern "C" int emu_task_traj_reset(const EmlocoResetBufs *b, const int32_t *env_
     emu::launch((unsigned)n, 64, [&] { emloco::traj_reset_kernel(t, env_ids, n, rnd, init_pos, root_vel); });
     return 0;
 }
+
+extern "C" int emu_task_get_heights(const int16_t *hf, int rows, int cols, float hscale, float vscale, const float *pose7, int n,
+                                    int grid, float *out_h, int64_t *out_px, int64_t *out_py) {
+    emu::launch((unsigned)n, 64, [&] { emloco::get_heights_kernel(hf, rows, cols, hscale, vscale, pose7, n, grid, out_h, out_px, out_py); });
+    return 0;
+}

@@ -62,6 +62,60 @@ def random_body_state(g, E, nb=24):
     return pos.float(), rot.float(), vel.float(), ang.float()
 
 
+
+def terrain_index_map(rows=1080, cols=1080):
+    """The int16 height map of the terrain_index fixture, from a formula (not stored): 8 x 8 plateaus of hashed height plus
+    a hashed +-3 ripple, so neighbouring cells differ almost everywhere and a one-cell index slip changes the height."""
+    i = np.arange(rows, dtype=np.int64)[:, None]
+    j = np.arange(cols, dtype=np.int64)[None, :]
+    coarse = (((i // 8) * 73856093) ^ ((j // 8) * 19349663)) % 600 - 200
+    fine = ((i * 83492791) ^ (j * 2971215073)) % 7 - 3
+    return (coarse + fine).astype(np.int16)
+
+
+def gen_terrain_index():
+    """A10 at scale (256 envs x (1024 + 9) probes on the 1080 x 1080 map of `small_terrain`): the integer map indices
+    world_points_to_map returns (humanoid_pedestrain_terrain.py:1212-1218) and the sampled heights, for array_equal tests."""
+    import env.tasks.humanoid_pedestrain_terrain as HPT
+    from utils import torch_utils as TU
+    g = torch.Generator().manual_seed(4321)
+    E = 256
+    terr = HPT.Terrain.__new__(HPT.Terrain)
+    terr.horizontal_scale, terr.vertical_scale, terr.device = 0.1, 0.005, "cpu"
+    terr.heightsamples = torch.from_numpy(terrain_index_map())
+    pos = torch.rand(E, 3, generator=g) * torch.tensor([104.0, 104.0, 0.6]) + torch.tensor([1.0, 1.0, 0.8])
+    pos[0, 0], pos[1, 1], pos[2, 0], pos[3, 1] = -1.5, -0.7, 108.9, 109.3           # off the map: index clipping
+    pos[4, :2] = torch.tensor([50.0, 55.0])                                          # flags.fixed spawn: on cell boundaries
+    rot = rand_quat(g, E)
+    yaw = (torch.rand(E, generator=g) * 2 - 1) * np.pi
+    up = torch.stack([torch.randn(E, generator=g) * 0.05, torch.randn(E, generator=g) * 0.05, torch.sin(yaw / 2), torch.cos(yaw / 2)], -1)
+    rot[E // 8:] = (up / up.norm(dim=-1, keepdim=True))[E // 8:]
+    rot[5] = torch.tensor([0.0, 0.0, 0.0, 1.0])                                      # axis-aligned grid
+    rot[6] = torch.tensor([0.0, 0.0, 1.0, 0.0])
+    rot[7] = torch.tensor([0.0, 0.0, 0.70710678, 0.70710678])
+    head_pose = torch.cat([pos, rot], 1)
+    root_states = torch.cat([pos, rot, torch.zeros(E, 6)], 1)
+    fake = SimpleNamespace(cfg={"env": {"terrain": {"terrainType": "trimesh"}}}, num_envs=E, device="cpu", sensor_extent=2,
+                           sensor_res=32, smpl_humanoid=True, _has_upright_start=True, velocity_map=False, _divide_group=False,
+                           _group_obs=False, _disable_group_obs=False, terrain=terr)
+    fake.height_points = HPT.HumanoidPedestrianTerrain.init_square_height_points(fake)
+    fake.center_height_points = HPT.HumanoidPedestrianTerrain.init_center_height_points(fake)
+    HPT.flags.divide_group = False
+    heights = HPT.HumanoidPedestrianTerrain.get_heights(fake, head_pose.clone(), None)
+    center = HPT.HumanoidPedestrianTerrain.get_center_heights(fake, root_states.clone(), None)
+    # the indices, by the reference's own expressions (get_heights :778-787, get_center_heights :747-750, world_points_to_map)
+    heading_rot = TU.calc_heading_quat(rot)
+    pts = HPT.quat_apply(heading_rot.repeat(1, 1024).reshape(-1, 4), fake.height_points) + pos.unsqueeze(1)
+    px, py = terr.world_points_to_map(pts.clone())
+    cpts = HPT.quat_apply_yaw(rot.repeat(1, 9), fake.center_height_points) + pos.unsqueeze(1)
+    cpx, cpy = terr.world_points_to_map(cpts.clone())
+    hs = terr.heightsamples
+    assert torch.equal(torch.min(hs[px, py], hs[px + 1, py + 1]) * terr.vertical_scale, heights.view(-1))
+    save("terrain_index", head_pose=head_pose, root_states=root_states, heading_rot=heading_rot,
+         px=px.view(E, 1024).short(), py=py.view(E, 1024).short(), cpx=cpx.view(E, 9).short(), cpy=cpy.view(E, 9).short(),
+         heights_raw=torch.round(heights / 0.005).short(), center_raw=torch.round(center / 0.005).short(),
+         heights_sample=heights[:4], map_checksum=np.array(int(terrain_index_map().astype(np.int64).sum())))
+
 def gen_pacer():
     _ref_shim.install_pacer()
     import env.tasks.humanoid as H
@@ -383,6 +437,10 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "pacer"
     if which == "pacer":
         gen_pacer()
+        gen_terrain_index()
+    elif which == "terrain_index":
+        _ref_shim.install_pacer()
+        gen_terrain_index()
     elif which == "predictor":
         from gen_golden_predictor import gen_predictor
         gen_predictor()

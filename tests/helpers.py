@@ -114,3 +114,12 @@ def traj_reset_bufs(flags, g, verts, inverted, real_table=None, real_pick=None, 
     b.real_traj, b.real_pick, b.real_pick_key = real_table, real_pick, key
     b.traj_verts, b.inverted = verts, inverted
     return b
+
+
+def terrain_index_map(rows=1080, cols=1080):
+    """The int16 map of tests/golden/terrain_index.npz (formula of gen_golden.py: terrain_index_map; the fixture stores its checksum)."""
+    i = np.arange(rows, dtype=np.int64)[:, None]
+    j = np.arange(cols, dtype=np.int64)[None, :]
+    coarse = (((i // 8) * 73856093) ^ ((j // 8) * 19349663)) % 600 - 200
+    fine = ((i * 83492791) ^ (j * 2971215073)) % 7 - 3
+    return (coarse + fine).astype(np.int16)

@@ -138,7 +138,7 @@ def test_post_physics_kernel_matches_reference_golden(golden):
     head = np.concatenate([g["body_pos"][:, 13], g["body_rot"][:, 13]], -1)
     hf = gt["heightfield"]
     ho = oracle.height_obs(oracle.get_center_heights(root_states, hf), oracle.get_heights(head, hf))
-    np.testing.assert_allclose(th.obs[:, 398:], ho, rtol=1e-6, atol=1e-5)
+    np.testing.assert_array_equal(th.obs[:, 398:], ho)                 # height obs: index work, bit-exact vs the oracle
     np.testing.assert_array_equal(th.flip_obs[:, 368:], oracle.flip_task_obs(th.obs[:, 368:]))
     tar = oracle.traj_calc_pos(gs["verts"], gs["progress"], th.dt, th.traj_dur)
     rew, raw = oracle.reward(g["body_pos"][:, 0], tar, th.dof_force, th.dof_state[:, :, 1])
@@ -491,3 +491,39 @@ def test_traj_reset_kernel_real_rows_are_sampled_without_replacement(golden):
         assert rows.tolist() == [real_pick_perm(i, n_real, key) for i in range(E)]
         seen[key] = rows
     assert not np.array_equal(seen[11], seen[12])
+
+
+def test_get_heights_kernel_indices_match_reference_golden(golden):
+    """The terrain probes as the kernels compute them (task_kernels.hip: grid_probe / center_probe / map_index, shared with the
+    fused post-physics kernel): int64 map indices and heights array_equal to the reference's over 256 x (1024 + 9) probes."""
+    from helpers import terrain_index_map
+    g = golden("terrain_index")
+    hf = terrain_index_map()
+    E = 256
+    fn = emu.lib().emu_task_get_heights
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    pose = np.ascontiguousarray(g["head_pose"], np.float32)
+    h, px, py = np.zeros((E, 1024), np.float32), np.zeros((E, 1024), np.int64), np.zeros((E, 1024), np.int64)
+    fn(hf.ctypes.data, 1080, 1080, 0.1, 0.005, pose.ctypes.data, E, 1, h.ctypes.data, px.ctypes.data, py.ctypes.data)
+    np.testing.assert_array_equal(px, g["px"])
+    np.testing.assert_array_equal(py, g["py"])
+    np.testing.assert_array_equal(np.round(h / 0.005).astype(np.int16), g["heights_raw"])
+    root7 = np.ascontiguousarray(g["root_states"][:, :7], np.float32)
+    c, cx, cy = np.zeros((E, 9), np.float32), np.zeros((E, 9), np.int64), np.zeros((E, 9), np.int64)
+    fn(hf.ctypes.data, 1080, 1080, 0.1, 0.005, root7.ctypes.data, E, 0, c.ctypes.data, cx.ctypes.data, cy.ctypes.data)
+    np.testing.assert_array_equal(cx, g["cpx"])
+    np.testing.assert_array_equal(cy, g["cpy"])
+    np.testing.assert_array_equal(np.round(c / 0.005).astype(np.int16), g["center_raw"])
+
+
+def test_fused_kernel_height_observations_equal_the_reference_golden(golden):
+    """The fused post-physics kernel's 1024 height observations on the terrain fixture's own poses: array_equal to the
+    observations torch produced (humanoid_pedestrain_terrain.py:427-437), no tolerated cell flips."""
+    from emloco_amd import _lib as L
+    gt = golden("terrain_heights")
+    E = 16
+    th = emu.TaskHost(E, gt["heightfield"])
+    th.rb_state[:, 0, :7] = gt["root_states"][:, :7]
+    th.rb_state[:, 13, :7] = gt["head_pose"]
+    th.post_physics(L.POST_OBS)
+    np.testing.assert_array_equal(th.obs[:, 398:], gt["height_obs"])
