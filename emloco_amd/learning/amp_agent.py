@@ -22,7 +22,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..dist import FlatGradBucket
+from ..dist import FlatGradBucket, all_reduce_mean_scalar, broadcast_parameters, sync_running_mean_std
 from ..predictor import ops
 from ..utils.running_mean_std import RunningMeanStd
 from .amp_network_sept_builder import AMPSeptBuilder
@@ -100,6 +100,12 @@ def disc_forward_with_grad_penalty(net, amp_obs_demo, input_mask=None):
     """Discriminator logits on the demo batch and mean |dD/dx|^2 (amp_continuous.py:560-583) with the input gradient
     written as an explicit network (see module docstring).  `input_mask` is the AMP dropout mask applied to the input."""
     x = amp_obs_demo if input_mask is None else amp_obs_demo * input_mask
+    acts = [m for m in net._disc_mlp if not isinstance(m, nn.Linear)]
+    if any(not isinstance(m, nn.ReLU) for m in acts):
+        # the explicit gradient network below is the ReLU one (the shipped config, amp_humanoid_smpl_sept_task.yaml: disc
+        # activation relu); another activation needs its own derivative here
+        raise NotImplementedError("disc_forward_with_grad_penalty: the discriminator activation must be relu, got "
+                                  + ", ".join(sorted({type(m).__name__ for m in acts})))
     lin = [m for m in net._disc_mlp if isinstance(m, nn.Linear)]
     hs, h = [], x
     for m in lin:
@@ -157,6 +163,8 @@ class AMPAgent:
         self.a2c_network = b.build("amp", actions_num=self.actions_num, input_shape=(obs_size,), num_seqs=self.num_actors, value_size=1,
                                    amp_input_shape=(amp_size,), self_obs_size=self_size, task_obs_size=obs_size - self_size,
                                    task_obs_size_detail=task.get_task_obs_size_detail(), mean_std=self.running_mean_std).to(self.device)
+        # hvd.setup_algo (common_agent.py:165-166): every rank starts from rank 0's networks and (initial) statistics
+        broadcast_parameters(self.a2c_network, self.running_mean_std, self.value_mean_std, self._amp_input_mean_std)
         self.optimizer = torch.optim.Adam(self.a2c_network.parameters(), float(self.last_lr), eps=1e-08, weight_decay=0.0)
         self.bucket = FlatGradBucket([p for p in self.a2c_network.parameters() if p.requires_grad])
         self._amp_obs_demo_buffer = ReplayBuffer(int(c["amp_obs_demo_buffer_size"]), self.device)
@@ -421,6 +429,10 @@ class AMPAgent:
         self.epoch_num += 1
         self.frame += self.batch_size
         out = {k: torch.stack([i[k].float() for i in infos]).mean().item() for k in infos[0]}
+        # the reference's per-epoch exchanges: hvd.average_value of the KL (amp_continuous.py:287-288) and hvd.sync_stats of
+        # the running statistics (common_agent.py:179-180); no-ops on one rank
+        out["kl"] = all_reduce_mean_scalar(out["kl"])
+        sync_running_mean_std(self.running_mean_std, self.value_mean_std, self._amp_input_mean_std)
         out.update(play_time=t1 - t0, update_time=t2 - t1, total_time=t2 - t0, fps_step=self.batch_size / (t1 - t0),
                    fps_total=self.batch_size / (t2 - t0), reward_raw=batch["reward_raw"].tolist())
         return out

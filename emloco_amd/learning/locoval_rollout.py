@@ -1,26 +1,70 @@
 """LocoVal training rollout: the bookkeeping of AMPValueAgent.play_steps without rl_games.
 
-Mirror of pacer/pacer/learning/amp_continuous_value.py:34-178 (play_steps) and common_agent.py:89-97,154-155
-(LocoVal optimiser / target normalisation): per step reset finished envs, act, step, apply the inversion penalty,
-accumulate the discounted combined reward per env up to `step_to_pred` control steps, and when episodes finish fit
-LocoVal by sum-MSE on (waypoints, initial pose, initial velocity) -> normalised return with AdamW(1e-3, wd 1e-4).
-The policy is pluggable (`policy(obs) -> actions`; default: the frozen policy's exploration noise N(0, e^-2.9)),
-so is the AMP discriminator reward (`disc_reward(amp_obs) -> (E,)`, default 0): both networks belong to
-rl_games-side code that is listed under 'next' (SURVEY.md 8f.1).  Multi-GPU: gradients are all-reduced as one
-flat 6 174-float bucket and divided by the global number of fitted episodes (sum-reduction semantics).
+Mirror of pacer/pacer/learning/amp_continuous_value.py:34-178 (play_steps) and common_agent.py:89-97,154-155,205-209
+(LocoVal optimiser, cosine schedule, target normalisation): per step reset finished envs, act, step, apply the inversion
+penalty, accumulate the discounted reward `shaped task reward + discriminator reward` per env up to `step_to_pred` control
+steps, and when episodes finish fit LocoVal by sum-MSE on (waypoints, initial pose, initial velocity) -> normalised return
+with AdamW(1e-3, wd 1e-4).  The sum is UNWEIGHTED (:96): task_reward_w / disc_reward_w belong to the PPO path
+(`_combine_rewards`), not to the LocoVal target; `reward_shaper.scale_value` is 1 (amp_humanoid_smpl_sept_task.yaml:83-84).
+The policy is pluggable (`policy(obs) -> actions`; default: the frozen policy's exploration noise N(0, e^-2.9)), so is the
+AMP discriminator reward (`disc_reward(amp_obs) -> (E,)`, default 0).
+
+Host synchronisation: the reference reads `dones.nonzero()` and `len(valid_rewards_idx[0])` on the host every step
+(:98,123-124).  Here finished envs are reset by the device-side compaction (`reset_done`), the bookkeeping is mask
+arithmetic, the fit runs as a masked sum over all envs, and AdamW commits its update through a device-side gate on the
+(all-reduced) number of finished episodes (`flat_adamw.GatedFlatAdamW`): the host reads nothing during the rollout; the loss /
+episode counters are device tensors read when someone asks for them (`vnet_loss`, `fitted_episodes`, ...).
+
+Multi-GPU: every rank issues exactly one all-reduce per rollout step, whatever its own episodes did -- the flat gradient
+bucket (6 174 floats) with the loss sum and the episode count in its tail; gradients are sum-reduced and the loss is
+divided by the global episode count (MSELoss(reduction='sum') semantics, common_agent.py:96).  All ranks step together
+when the global count is positive, so the replicas (broadcast from rank 0 at construction) stay identical.
 """
 import math
 
 import torch
 
-from ..dist import FlatGradBucket, all_reduce_sum_count
+from ..dist import FlatGradBucket, broadcast_parameters
+from .flat_adamw import GatedFlatAdamW
+from .scheduler import CosineAnnealingLR
 from .value_pose_net import ValuePoseNet
 
 
+class ReturnAccumulator:
+    """Per-env discounted return of amp_continuous_value.py:93-118, as mask arithmetic on any device.
+
+    update() takes one step's (E,) task rewards (inversion penalty already applied), discriminator rewards and done flags and
+    returns what the reference adds to `game_combined_rewards` on that step: the discounted sum of an episode at the step it
+    ends if that is within `step_to_pred` control steps, or at step `step_to_pred` if it runs longer (later rewards of the
+    episode are accumulated but never emitted), zero elsewhere."""
+
+    def __init__(self, num_envs, step_to_pred, gamma, device):
+        z = lambda: torch.zeros(num_envs, device=device)
+        self.step_to_pred, self.gamma = step_to_pred, gamma
+        self.current_rewards, self.current_lengths, self.current_combined_rewards = z(), z(), z()
+        self.discount_coefs = torch.ones(num_envs, device=device)
+
+    def update(self, rewards, amp_rewards, dones):
+        dones_b = dones.bool()
+        not_dones = 1.0 - dones_b.float()
+        self.current_rewards += rewards
+        self.current_lengths += 1
+        combined = rewards + amp_rewards                                                    # :96, unweighted
+        self.current_combined_rewards += combined * self.discount_coefs
+        done_early = torch.logical_and(self.current_lengths <= self.step_to_pred, dones_b)
+        over_pred = torch.logical_and(self.current_lengths == self.step_to_pred, ~dones_b)
+        emitted = self.current_combined_rewards * (done_early | over_pred).float()
+        self.current_combined_rewards = self.current_combined_rewards * not_dones
+        self.discount_coefs = torch.where(dones_b, torch.ones_like(self.discount_coefs), self.discount_coefs * self.gamma)
+        self.current_rewards = self.current_rewards * not_dones
+        self.current_lengths = self.current_lengths * not_dones
+        return emitted
+
+
 class LocoValRollout:
-    def __init__(self, vec_env, use_pose=True, use_vel=True, horizon_length=32, gamma=0.99, inversion_penalty_scale=1.0,
-                 task_reward_w=0.5, disc_reward_w=0.5, policy=None, disc_reward=None, min_cum_rewards=-10.0,
-                 max_cum_rewards=100.0, lr=1e-3, weight_decay=1e-4):
+    def __init__(self, vec_env, use_pose=True, use_vel=True, horizon_length=32, gamma=0.99, inversion_penalty_scale=0.3,
+                 policy=None, disc_reward=None, min_cum_rewards=-10.0, max_cum_rewards=100.0, lr=1e-3, weight_decay=1e-4,
+                 valuenet=None, warmup_epochs=20, max_epochs=20000):
         self.vec_env = vec_env
         env = vec_env.env if hasattr(vec_env, "env") else vec_env
         self.env = env
@@ -28,68 +72,101 @@ class LocoValRollout:
         self.device = torch.device(self.task.device)
         self.num_actors = self.task.num_envs
         self.horizon_length, self.gamma = horizon_length, gamma
-        self.inversion_penalty_scale = inversion_penalty_scale
-        self.task_reward_w, self.disc_reward_w = task_reward_w, disc_reward_w
+        self.inversion_penalty_scale = inversion_penalty_scale         # amp_humanoid_smpl_sept_task.yaml:128
         self.step_to_pred = self.task.step_to_pred
         self.policy = policy or (lambda obs: torch.randn(self.num_actors, self.task.num_actions, device=self.device) * math.exp(-2.9))
         self.disc_reward = disc_reward or (lambda amp_obs: torch.zeros(self.num_actors, device=self.device))
         self.min_cum_rewards, self.max_cum_rewards = min_cum_rewards, max_cum_rewards     # common_agent.py:154-155
-        self.valuenet = ValuePoseNet(use_pose=use_pose, use_vel=use_vel).to(self.device)
-        self.vnet_optimizer = torch.optim.AdamW(self.valuenet.parameters(), lr=lr, weight_decay=weight_decay)
-        self.bucket = FlatGradBucket(self.valuenet.parameters())
+        self.valuenet = (valuenet if valuenet is not None else ValuePoseNet(use_pose=use_pose, use_vel=use_vel)).to(self.device)
+        broadcast_parameters(self.valuenet)                                                # hvd.setup_algo, common_agent.py:165-166
+        self.bucket = FlatGradBucket(self.valuenet.parameters(), extra=2)                  # tail: [loss sum, episode count]
+        self.vnet_optimizer = GatedFlatAdamW(self.valuenet.parameters(), self.bucket.grads, lr=lr, weight_decay=weight_decay)
+        self.vnet_scheduler = CosineAnnealingLR(self.vnet_optimizer, warmup_epochs=warmup_epochs, max_epochs=max_epochs)
         E = self.num_actors
-        z = lambda: torch.zeros(E, device=self.device)
-        self.current_rewards, self.current_lengths, self.current_combined_rewards = z(), z(), z()
-        self.game_combined_rewards = z()
-        self.discount_coefs = torch.ones(E, device=self.device)
-        self.done_indices = torch.arange(E, device=self.device)     # first call resets everything
-        self.vnet_loss, self.vnet_fits, self.frames = 0.0, 0, 0
+        self.acc = ReturnAccumulator(E, self.step_to_pred, gamma, self.device)
+        self.game_combined_rewards = torch.zeros(E, device=self.device)
+        self.started = False
+        self.frames = 0
+        # [last fit's loss sum, last fit's episodes, total loss sum, total episodes, number of fits] -- on the device
+        self._stats = torch.zeros(5, device=self.device, dtype=torch.float64)
+
+    # counters of the fit, read from the device on demand (a host synchronisation each)
+    @property
+    def vnet_loss(self):
+        """sum-MSE of the most recent fit divided by its (global) episode count"""
+        a = self._stats.tolist()
+        return a[0] / a[1] if a[1] > 0 else 0.0
+
+    @property
+    def fitted_episodes(self):
+        return int(round(self._stats[3].item()))
+
+    @property
+    def vnet_fits(self):
+        return int(round(self._stats[4].item()))
+
+    def _reset_finished(self):
+        """env_reset(done_indices) of :46 -- every env on the first call, afterwards the envs whose reset flag is set."""
+        if not self.started:
+            self.env.reset(torch.arange(self.num_actors, device=self.device))
+            self.started = True
+        elif hasattr(self.env, "reset_done"):
+            self.env.reset_done()
+        else:
+            self.env.reset(self.task.reset_buf.nonzero(as_tuple=False).flatten())
+
+    def step_once(self):
+        """One iteration of the play_steps loop (:45-145): reset finished envs, act, step, bookkeeping, LocoVal fit."""
+        task = self.task
+        with torch.no_grad():
+            self._reset_finished()
+            actions = self.policy(task.obs_buf)
+            obs, rewards, dones, infos = self.vec_env.step(actions)
+            inverted = task.inverted
+            rewards = torch.where(inverted, rewards * (-self.inversion_penalty_scale), rewards)      # :63-64
+            amp_rewards = self.disc_reward(infos["amp_obs"])
+            self.game_combined_rewards += self.acc.update(rewards, amp_rewards, dones)
+            self.frames += self.num_actors
+        self._fit()
+
+    def end_epoch(self):
+        """common_agent.py:205-209: the cosine schedule advances once per epoch, once episodes have finished."""
+        if not getattr(self, "_sched_live", False):
+            self._sched_live = self.fitted_episodes > 0          # one read per epoch until the first episode has finished
+        if self._sched_live:
+            self.vnet_scheduler.step()
 
     def play_steps(self):
-        env, task = self.env, self.task
         for n in range(self.horizon_length):
-            with torch.no_grad():
-                if self.done_indices.numel():
-                    env.reset(self.done_indices)
-                obs = task.obs_buf
-                actions = self.policy(obs)
-                obs, rewards, dones, infos = self.vec_env.step(actions)
-                rewards = rewards.clone()
-                inverted = task.inverted
-                rewards[inverted] *= (-self.inversion_penalty_scale)                       # :63-64
-                amp_rewards = self.disc_reward(infos["amp_obs"])
-                self.current_rewards += rewards
-                self.current_lengths += 1
-                combined = self.task_reward_w * rewards + self.disc_reward_w * amp_rewards
-                self.current_combined_rewards += combined * self.discount_coefs
-                self.done_indices = dones.nonzero(as_tuple=False).flatten()
-                not_dones = 1.0 - dones.float()
-                done_early = torch.logical_and(self.current_lengths <= self.step_to_pred, dones.bool())
-                over_pred = torch.logical_and(self.current_lengths == self.step_to_pred, not_dones.bool())
-                self.game_combined_rewards += self.current_combined_rewards * (done_early | over_pred).float()
-                self.current_combined_rewards = self.current_combined_rewards * not_dones
-                self.discount_coefs = self.discount_coefs * self.gamma
-                self.discount_coefs[self.done_indices] = 1.0
-                self.current_rewards = self.current_rewards * not_dones
-                self.current_lengths = self.current_lengths * not_dones
-                self.frames += self.num_actors
-            valid = torch.nonzero(self.game_combined_rewards, as_tuple=True)[0]
-            if valid.numel() > 0:                                                              # :122-145
-                init_pose = env.get_init_pose().to(self.device)
-                waypoint_traj = env.get_waypoint_traj()[:, :13, :].contiguous().to(self.device)
-                init_vel = env.get_init_vel().to(self.device)
-                pred = self.valuenet(waypoint_traj, init_pose, init_vel).squeeze(-1)
-                target = (self.game_combined_rewards[valid] - self.min_cum_rewards) / (self.max_cum_rewards - self.min_cum_rewards)
-                self.bucket.zero()
-                loss = torch.nn.functional.mse_loss(pred[valid], target, reduction="sum")
-                loss.backward()
-                self.bucket.all_reduce(average=False)
-                gl, gc = all_reduce_sum_count(loss, valid.numel())
-                self.vnet_optimizer.step()
-                self.vnet_loss = float(gl) / max(float(gc), 1.0)
-                self.vnet_fits += 1
-                self.game_combined_rewards = torch.zeros_like(self.game_combined_rewards)
+            self.step_once()
+        self.end_epoch()
         return self.vnet_loss
+
+    def _fit(self):
+        """:122-145 as a masked sum over all envs: identical to indexing the finished episodes, without reading their ids."""
+        env = self.env
+        valid = self.game_combined_rewards != 0
+        init_pose = env.get_init_pose().to(self.device)
+        waypoint_traj = env.get_waypoint_traj()[:, :13, :].contiguous().to(self.device)
+        init_vel = env.get_init_vel().to(self.device)
+        pred = self.valuenet(waypoint_traj, init_pose, init_vel).reshape(-1)
+        target = (self.game_combined_rewards - self.min_cum_rewards) / (self.max_cum_rewards - self.min_cum_rewards)
+        w = valid.float()
+        self.bucket.zero()
+        loss = (w * (pred - target) ** 2).sum()                                             # MSELoss(reduction='sum') on the valid rows
+        loss.backward()
+        with torch.no_grad():
+            self.bucket.tail[0] = loss.detach()
+            self.bucket.tail[1] = w.sum()
+            self.bucket.all_reduce(average=False)                                           # unconditional: one collective per step
+            tail = self.bucket.tail.double()
+            gate = tail[1] > 0.5
+            self.vnet_optimizer.step(gate)                                                  # committed on the device iff an episode finished
+            g = gate.double()
+            self._stats[0:2] = torch.where(gate, tail, self._stats[0:2])
+            self._stats[2:4] += tail * g
+            self._stats[4] += g
+            self.game_combined_rewards = torch.zeros_like(self.game_combined_rewards)
 
     # ------------------------------------------------------------------ checkpoints (common_agent.py:248-264, finetune branch)
     def save(self, model_output_file, epoch_num=None):

@@ -7,7 +7,7 @@ TransMotionJTA / ValuePoseNet.  For data-parallel training `step` all-reduces on
 """
 import torch
 
-from ..dist import FlatGradBucket
+from ..dist import FlatGradBucket, all_reduce_, broadcast_parameters, world_size
 
 
 def MSE_LOSS(output, target, mask=None):
@@ -63,11 +63,13 @@ def nan_handler(pred_traj, init_pose, init_vel):
     return pred_traj, init_pose, init_vel
 
 
-def compute_loss(model, config, in_joints, out_joints, in_masks, out_masks, padding_mask, mode='val', limit_obs=False):
+def compute_loss(model, config, in_joints, out_joints, in_masks, out_masks, padding_mask, mode='val', limit_obs=False,
+                 random_masking=None):
     in_F = in_joints.shape[1]
-    random_masking = mode == 'train'
-    if torch.isnan(in_joints).any():
-        in_joints = torch.where(torch.isnan(in_joints), torch.zeros_like(in_joints), in_joints)
+    if random_masking is None:
+        random_masking = mode == 'train'
+    # train_jta.py:102-103 replaces NaN inputs by zero when there are any; done unconditionally (same result, no host read)
+    in_joints = torch.where(torch.isnan(in_joints), torch.zeros_like(in_joints), in_joints)
     pred = model(in_joints, padding_mask, random_masking, limit_obs=limit_obs, frame_masking=config.get('USE_FRAME_MASK', False))
     loss_fn = MSE_LOSS_MULTI if config.get("MULTI_MODAL", False) else MSE_LOSS
     return loss_fn(pred[:, in_F:], out_joints, out_masks), pred
@@ -94,6 +96,35 @@ def emloco_loss(config, valuenet, pred_joints, primary_init_pose, primary_init_v
     return vl * w
 
 
+def emloco_loss_masked(config, valuenet, pred_joints, primary_init_pose, primary_init_vel, in_F):
+    """The same loss as `emloco_loss` (train_jta.py:143-165,288-308) without data-dependent shapes: instead of dropping the
+    rows `nan_handler` drops (NaN trajectory / pose / velocity, all-zero pose) they get weight 0 in the mean -- identical
+    value and gradients, no host read.  Returns (sum over kept rows of the per-row loss, averaged over modes and scaled by
+    valuenet_weight; number of kept rows): the caller divides, so that data-parallel ranks can divide by the global count.
+    A batch with no kept row contributes 0, where the reference's NaN mean is skipped (:308)."""
+    dev = pred_joints.device
+    w = config["TRAIN"].get("valuenet_weight", 1.0)
+    multi = config.get("MULTI_MODAL", False)
+    pred = pred_joints[:, in_F:]                                                    # (B, 12, M, 2)
+    B, _, M, _ = pred.shape
+    pred = torch.cat([torch.zeros(B, 1, M, 2, device=dev), pred], dim=1)           # (B, 13, M, 2)
+    if not multi:
+        pred = pred[:, :, :1]
+        M = 1
+    bad = torch.isnan(pred).flatten(1).any(1) | torch.isnan(primary_init_pose).flatten(1).any(1) | torch.isnan(primary_init_vel).any(1)
+    bad = bad | (primary_init_pose == 0).flatten(1).all(1)
+    keep = (~bad).float()
+    kb = ~bad
+    pred = torch.where(kb[:, None, None, None], pred, torch.zeros_like(pred))
+    pose = torch.where(kb[:, None, None], primary_init_pose, torch.zeros_like(primary_init_pose))
+    vel = torch.where(kb[:, None], primary_init_vel, torch.zeros_like(primary_init_vel))
+    total = 0
+    for i in range(M):                # the LocoVal call rotates `pose` in place, cumulatively over the modes (value_pose_net.py:97)
+        value = valuenet(pred[:, :, i].contiguous(), pose, vel).reshape(-1)
+        total = total + (keep * (value - 1.0) ** 2).sum()
+    return total * (w / M), keep.sum()
+
+
 class EmLocoTrainer:
     """Adam(lr) + clip_grad_norm_(max_grad_norm) (train_jta.py:317-318,411) around the loss above."""
 
@@ -103,32 +134,42 @@ class EmLocoTrainer:
             valuenet.eval()
             for p in valuenet.parameters():
                 p.requires_grad_(False)          # the LocoVal weights are frozen while the predictor trains (train_jta.py:197-204)
+        if data_parallel:
+            broadcast_parameters(model, valuenet)      # replicas start from rank 0's weights (nn.DataParallel has one copy)
         self.optimizer = torch.optim.Adam(model.parameters(), lr=config["TRAIN"]["lr"])
         self.bucket = FlatGradBucket(model.parameters()) if data_parallel else None
 
-    def step(self, joints, masks, padding_mask, modality_selection='traj+all'):
+    def step(self, joints, masks, padding_mask, modality_selection='traj+all', random_masking=True):
+        """One iteration of train_jta.py:245-320 on this rank's batch.  Data parallel: the ranks' batches are the equal
+        slices of one global batch; the MSE term is a mean over the batch (each rank adds mean / world), the EmLoco term a
+        mean over the rows nan_handler keeps (each rank adds its kept rows' sum / the GLOBAL kept count, one scalar
+        all-reduce before the backward pass), the gradient bucket is sum-reduced -- the update equals the single-process
+        step on the concatenated batch.  No host synchronisation inside the step."""
         cfg = self.config
         self.model.train()
         if self.bucket is not None:
             self.bucket.zero()
         else:
             self.optimizer.zero_grad(set_to_none=True)
+        W = world_size() if self.bucket is not None else 1
         in_joints, in_masks, out_joints, out_masks, pm = batch_process_coords(joints, masks, padding_mask, cfg, modality_selection, training=True)
         pose = joints[:, 0, 8, 3:27, :3].clone().to(cfg["DEVICE"])
         pose[..., 2] *= -1
         vel = ((in_joints[:, 8, 0, :2] - in_joints[:, 7, 0, :2]) * 2.5).clone()
-        mse, pred = compute_loss(self.model, cfg, in_joints, out_joints, in_masks, out_masks, pm.to(cfg["DEVICE"]), mode='train')
-        loss = mse.clone()
+        mse, pred = compute_loss(self.model, cfg, in_joints, out_joints, in_masks, out_masks, pm.to(cfg["DEVICE"]), mode='train',
+                                 random_masking=random_masking)
+        loss = mse / W
         if self.valuenet is not None:
-            vl = emloco_loss(cfg, self.valuenet, pred, pose, vel, in_joints.shape[1])
-            if torch.is_tensor(vl) and not torch.isnan(vl.mean()):
-                loss = loss + vl[~torch.isnan(vl)].mean()
+            vsum, cnt = emloco_loss_masked(cfg, self.valuenet, pred, pose, vel, in_joints.shape[1])
+            if W > 1:
+                cnt = all_reduce_(cnt.detach().clone())
+            loss = loss + vsum / cnt.clamp(min=1.0)
         loss.backward()
         if self.bucket is not None:
-            self.bucket.all_reduce(average=True)
+            self.bucket.all_reduce(average=False)
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg["TRAIN"]["max_grad_norm"])
         self.optimizer.step()
-        return loss.detach(), mse.detach()
+        return loss.detach() * W, mse.detach()
 
 
 # ---------------------------------------------------------------------------------------------- training loop pieces

@@ -90,10 +90,25 @@ def main(argv=None):
     train_policy = "--train_policy" in argv        # configs[1]: PPO + AMP pretraining of the policy (pacer/run.py without --test)
     if train_policy:
         argv.remove("--train_policy")
+    # one process per GPU (torch.distributed.run): the reference's --horovod launch (run.py:57-66, common_agent.py:165-180).
+    # num_envs is the GLOBAL count: rank r simulates the contiguous shard [r * E / W, (r + 1) * E / W) on cuda:LOCAL_RANK with
+    # seed + rank; the learners exchange gradients / statistics through emloco_amd.dist
+    from .dist import init_from_env, shard_range
+    rank, local_rank, world = init_from_env()
+    if world > 1:
+        for flag in ("--sim_device", "--rl_device"):
+            if flag in argv:
+                i = argv.index(flag)
+                del argv[i:i + 2]
+        argv += ["--sim_device", f"cuda:{local_rank}", "--rl_device", f"cuda:{local_rank}"]
+        torch.cuda.set_device(local_rank)
     args = get_args(argv)
+    if world > 1:
+        args.num_envs = shard_range(int(args.num_envs), rank, world)[1]
     cfg, cfg_train, _ = load_cfg(args)
     fill_flags(args)
-    env = RLGPUEnv(create_rlgpu_env(args, cfg, cfg_train))
+    env = RLGPUEnv(create_rlgpu_env(args, cfg, cfg_train, rank=rank))
+    say = print if rank == 0 else (lambda *a, **k: None)
     if train_policy:
         import yaml
         from .learning.amp_agent import AMPAgent
@@ -105,7 +120,7 @@ def main(argv=None):
         while n < steps:
             info = agent.train_epoch()
             n += agent.horizon_length
-            print(f"epoch {agent.epoch_num}: fps_step {info['fps_step']:,.0f} fps_total {info['fps_total']:,.0f} "
+            say(f"epoch {agent.epoch_num}: fps_step {info['fps_step']:,.0f} fps_total {info['fps_total']:,.0f} "
                   f"a_loss {info['actor_loss']:.4f} c_loss {info['critic_loss']:.4f} disc_loss {info['disc_loss']:.4f} kl {info['kl']:.5f}")
         return
     from .learning.locoval_rollout import LocoValRollout
@@ -114,8 +129,7 @@ def main(argv=None):
         from .learning.amp_policy import AMPPolicyBundle
         bundle = AMPPolicyBundle(env.env.task, checkpoint=policy_ckpt)
         kw = dict(policy=bundle.policy, disc_reward=bundle.disc_reward,
-                  inversion_penalty_scale=float(bundle.config.get("inversion_penalty_scale", 0.3)),
-                  task_reward_w=float(bundle.config.get("task_reward_w", 0.5)), disc_reward_w=float(bundle.config.get("disc_reward_w", 0.5)))
+                  inversion_penalty_scale=float(bundle.config.get("inversion_penalty_scale", 0.3)))
     agent = LocoValRollout(env, use_pose=args.input_init_pose, use_vel=args.input_init_vel, **kw)
     t0 = time.time()
     n = 0
@@ -124,8 +138,10 @@ def main(argv=None):
         n += agent.horizon_length
     torch.cuda.synchronize()
     dt = time.time() - t0
-    print(f"fps_step: {env.env.num_envs * n / dt:,.0f} env-steps/s ({n} steps of {env.env.num_envs} envs), "
-          f"LocoVal loss {agent.vnet_loss:.4f}")
+    say(f"fps_step: {env.env.num_envs * world * n / dt:,.0f} env-steps/s ({n} steps of {env.env.num_envs} envs x {world} ranks), "
+        f"LocoVal loss {agent.vnet_loss:.4f}, {agent.fitted_episodes} episodes fitted")
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -34,6 +34,11 @@ def lib():
     return _lib
 
 
+def set_threads(n=0):
+    """OpenMP threads of the per-env loops (0 = all cores); returns the count in effect.  Results do not depend on it."""
+    return int(lib().orc_set_threads(C.c_int(int(n))))
+
+
 def _p(a, t=C.c_float):
     return a.ctypes.data_as(C.POINTER(t))
 
@@ -176,11 +181,14 @@ def get_heights(pose7, hf, hscale=0.1, vscale=0.005, heading_q=None, return_inde
     pose7 = _f32(pose7)
     hf = np.ascontiguousarray(hf, dtype=np.int16)
     E = pose7.shape[0]
-    out = np.zeros((E, 1024), np.float32)
-    px, py = np.zeros((E, 1024), np.int64), np.zeros((E, 1024), np.int64)
+    out = np.empty((E, 1024), np.float32)
+    px = py = None
+    if return_index:
+        px, py = np.empty((E, 1024), np.int64), np.empty((E, 1024), np.int64)
     hq = None if heading_q is None else _f32(heading_q)
     lib().orc_get_heights_ex(C.c_int(E), _p(pose7), None if hq is None else _p(hq), _p(hf, C.c_int16), C.c_int(hf.shape[0]),
-                             C.c_int(hf.shape[1]), C.c_float(hscale), C.c_float(vscale), _p(out), _p(px, C.c_int64), _p(py, C.c_int64))
+                             C.c_int(hf.shape[1]), C.c_float(hscale), C.c_float(vscale), _p(out),
+                             None if px is None else _p(px, C.c_int64), None if py is None else _p(py, C.c_int64))
     return (out, px, py) if return_index else out
 
 
@@ -188,8 +196,8 @@ def get_center_heights(root_states, hf, hscale=0.1, vscale=0.005, return_index=F
     root_states = _f32(root_states)
     hf = np.ascontiguousarray(hf, dtype=np.int16)
     E = root_states.shape[0]
-    out = np.zeros((E, 9), np.float32)
-    px, py = np.zeros((E, 9), np.int64), np.zeros((E, 9), np.int64)
+    out = np.empty((E, 9), np.float32)
+    px, py = np.empty((E, 9), np.int64), np.empty((E, 9), np.int64)
     lib().orc_get_center_heights_ex(C.c_int(E), _p(root_states), _p(hf, C.c_int16), C.c_int(hf.shape[0]), C.c_int(hf.shape[1]),
                                     C.c_float(hscale), C.c_float(vscale), _p(out), _p(px, C.c_int64), _p(py, C.c_int64))
     return (out, px, py) if return_index else out

@@ -473,7 +473,7 @@ static int saturate_drives(Env *s, const EnvModel *m, const OrcSimParams *prm, f
 
 /* ---------------------------------------------------------------- 3. articulated-body factorisation */
 static void factorize(Env *s, const EnvModel *m) {
-    static float IA[NB][36]; /* not re-entrant: the oracle is single threaded per process call */
+    static __thread float IA[NB][36]; /* per-thread scratch (orc_sim_step runs envs on OpenMP threads) */
     float (*IAp)[36] = IA;
     memcpy(IAp, s->I6, sizeof(float) * NB * 36);
     for (int i = NB - 1; i >= 1; --i) {
@@ -733,7 +733,7 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
         }
     }
     /* Gram-form contact matrix: common chain = prefix up to the depth of the lowest common ancestor */
-    static float A[3 * ORC_MAXC][3 * ORC_MAXC];
+    static __thread float A[3 * ORC_MAXC][3 * ORC_MAXC];
     for (int c1 = 0; c1 < nc; ++c1)
         for (int c2 = 0; c2 < nc; ++c2) {
             int a = con[c1].body, b = con[c2].body;
@@ -888,7 +888,10 @@ void orc_sim_fk(int n_env, const OrcModel *mdl, const float *root_state, const f
 void orc_sim_step(int n_env, const OrcSimParams *prm, const OrcModel *mdl, float *root_state, float *dof_state,
                   const float *pd_target, float *rb_state, float *contact_force, float *dof_force,
                   float *lambda_ws) {
-    static Env s;
+    /* envs are independent (no inter-env contacts, humanoid.py:838-841): one OpenMP thread per slice of them; every
+     * env is computed by exactly the sequential code, so the bytes do not depend on the thread count (orc_set_threads) */
+    static __thread Env s;
+#pragma omp parallel for schedule(dynamic, 4)
     for (int e = 0; e < n_env; ++e) {
         EnvModel m = env_model(mdl, e);
         float *root = root_state + (long)e * 13, *dof = dof_state + (long)e * ORC_NDOF * 2;
@@ -909,6 +912,14 @@ void orc_sim_step(int n_env, const OrcSimParams *prm, const OrcModel *mdl, float
             }
     }
 }
+
+/* number of OpenMP threads of orc_sim_step (0: the runtime's default = all cores); returns the count in effect */
+#ifdef _OPENMP
+#include <omp.h>
+int orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int orc_set_threads(int n) { (void)n; return 1; }
+#endif
 
 /* ---------------------------------------------------------------- test hooks */
 void orc_sim_free_accel(const OrcSimParams *prm, const OrcModel *mdl, int env, const float *root_state,

@@ -55,6 +55,7 @@ static void self_obs_one(const float *pos, const float *rot, const float *vel, c
 
 void orc_self_obs(int E, const float *pos, const float *rot, const float *vel, const float *ang,
                   const float *betas, float *obs) {
+#pragma omp parallel for schedule(static)
     for (int e = 0; e < E; ++e)
         self_obs_one(pos + e * NB * 3, rot + e * NB * 4, vel + e * NB * 3, ang + e * NB * 3,
                      betas + e * 17, obs + e * SELF_OBS);
@@ -63,8 +64,9 @@ void orc_self_obs(int E, const float *pos, const float *rot, const float *vel, c
 /* H:1066-1108 _compute_flip_humanoid_obs: negate y of pos/vel, x,z of quat xyz-part / ang vel, then L/R permute */
 void orc_flip_self_obs(int E, const float *pos, const float *rot, const float *vel, const float *ang,
                        const float *betas, float *obs) {
-    float fp[NB * 3], fr[NB * 4], fv[NB * 3], fa[NB * 3];
+#pragma omp parallel for schedule(static)
     for (int e = 0; e < E; ++e) {
+        float fp[NB * 3], fr[NB * 4], fv[NB * 3], fa[NB * 3];
         const float *p = pos + e * NB * 3, *r = rot + e * NB * 4, *v = vel + e * NB * 3, *a = ang + e * NB * 3;
         for (int b = 0; b < NB; ++b) {
             int s = L2R[b];
@@ -91,6 +93,7 @@ static void calc_pos_one(const float *verts, float time, float traj_dur, float *
 }
 
 void orc_traj_calc_pos(int E, const float *verts, const int64_t *progress, float dt, float traj_dur, float *out) {
+#pragma omp parallel for schedule(static)
     for (int e = 0; e < E; ++e)
         calc_pos_one(verts + (long)e * NVERT * 3, (float)progress[e] * dt, traj_dur, out + e * 3);
 }
@@ -98,6 +101,7 @@ void orc_traj_calc_pos(int E, const float *verts, const int64_t *progress, float
 /* HT:208-224 _fetch_traj_samples: 15 samples at t + k*0.4 s */
 void orc_traj_samples(int E, const float *verts, const int64_t *progress, float dt, float traj_dur,
                       float sample_dt, float *out) {
+#pragma omp parallel for schedule(static)
     for (int e = 0; e < E; ++e) {
         float beg = (float)progress[e] * dt;
         for (int k = 0; k < NSAMP; ++k)
@@ -108,6 +112,7 @@ void orc_traj_samples(int E, const float *verts, const int64_t *progress, float 
 
 /* HPT:1549-1577 compute_location_observations (upright=True) */
 void orc_location_obs(int E, const float *root_states, const float *samples, float *obs) {
+#pragma omp parallel for schedule(static)
     for (int e = 0; e < E; ++e) {
         const float *rs = root_states + e * 13;
         float hinv[4];
@@ -155,6 +160,7 @@ static float linspace_f(double lo, double hi, int n, int i) {
  * px / py (optional, [E][1024] int64): the map indices. */
 void orc_get_heights_ex(int E, const float *pose7, const float *heading_q, const int16_t *hf, int rows, int cols, float hscale,
                         float vscale, float *out, int64_t *out_px, int64_t *out_py) {
+#pragma omp parallel for schedule(static)
     for (int e = 0; e < E; ++e) {
         const float *p = pose7 + e * 7;
         float hq[4];
@@ -181,6 +187,7 @@ void orc_get_heights(int E, const float *pose7, const int16_t *hf, int rows, int
 /* HPT:732-759 get_center_heights: 3x3 probe (x in linspace(-.1,.1,3), y in linspace(-.2,.2,3)), yaw-only */
 void orc_get_center_heights_ex(int E, const float *root_states, const int16_t *hf, int rows, int cols,
                                float hscale, float vscale, float *out9, int64_t *out_px, int64_t *out_py) {
+#pragma omp parallel for schedule(static)
     for (int e = 0; e < E; ++e) {
         const float *rs = root_states + e * 13;
         for (int i = 0; i < 3; ++i)
@@ -202,6 +209,7 @@ void orc_get_center_heights(int E, const float *root_states, const int16_t *hf, 
 
 /* HPT:427-437 height obs = clip(mean(center) - h, -3, 3) * 5 (use_center_height: true) */
 void orc_height_obs(int E, const float *center9, const float *heights, float *obs) {
+#pragma omp parallel for schedule(static)
     for (int e = 0; e < E; ++e) {
         /* torch's .mean(dim=-1) over the 9 probes = sum / 9 with the sum in the order of its scalar row reduction
          * (8 partial sums + remainder, aten SumKernel row_sum): ((c0 + c8) + c1) + c2 + ... + c7 */
@@ -220,6 +228,7 @@ void orc_height_obs(int E, const float *center9, const float *heights, float *ob
 
 /* HPT:455-491 _compute_flip_task_obs: negate traj y, mirror the height grid along its 2nd axis */
 void orc_flip_task_obs(int E, const float *task_obs, float *out) {
+#pragma omp parallel for schedule(static)
     for (int e = 0; e < E; ++e) {
         const float *t = task_obs + (long)e * TASK_OBS;
         float *o = out + (long)e * TASK_OBS;
@@ -232,6 +241,7 @@ void orc_flip_task_obs(int E, const float *task_obs, float *out) {
 /* HPT:907-930 _compute_reward + HPT:1581-1592 compute_location_reward.  rew = loc + power (power_reward True) */
 void orc_reward(int E, const float *root_pos, const float *tar_pos, const float *dof_force,
                 const float *dof_vel, float power_coef, float *rew, float *reward_raw2) {
+#pragma omp parallel for schedule(static)
     for (int e = 0; e < E; ++e) {
         float dx = tar_pos[e * 3] - root_pos[e * 3], dy = tar_pos[e * 3 + 1] - root_pos[e * 3 + 1];
         float err = dx * dx + dy * dy;
@@ -251,6 +261,7 @@ void orc_reward(int E, const float *root_pos, const float *tar_pos, const float 
 void orc_reset(int E, const int64_t *progress, const float *contact, const int *contact_body_ids, int n_cb,
                const float *body_pos, const float *tar_pos, float max_episode_length, float fail_dist,
                int64_t *reset, int64_t *terminate) {
+#pragma omp parallel for schedule(static)
     for (int e = 0; e < E; ++e) {
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
         for (int b = 0; b < NB; ++b) {
@@ -281,6 +292,7 @@ void orc_reset(int E, const int64_t *progress, const float *contact, const int *
 void orc_amp_obs(int E, const float *root_pos, const float *root_rot, const float *root_vel,
                  const float *root_ang, const float *dof_pos, const float *dof_vel, const float *key_pos,
                  const float *betas, const int *dof_subset, int n_sub, float *out) {
+#pragma omp parallel for schedule(static)
     for (int e = 0; e < E; ++e) {
         float hinv[4], lq[4];
         float *o = out + (long)e * AMP_ROW;
@@ -308,6 +320,7 @@ void orc_amp_obs(int E, const float *root_pos, const float *root_rot, const floa
 /* H:1281-1283 _action_to_pd_targets + H:1190-1196 zeroing of L/R_Hand and (freeze_toe) L/R_Toe targets */
 void orc_pd_targets(int E, const float *actions, const float *offset, const float *scale,
                     const unsigned char *zero_mask, float *out) {
+#pragma omp parallel for schedule(static)
     for (int e = 0; e < E; ++e)
         for (int d = 0; d < NDOF; ++d)
             out[e * NDOF + d] = zero_mask[d] ? 0.0f : offset[d] + scale[d] * actions[e * NDOF + d];

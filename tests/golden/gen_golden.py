@@ -116,6 +116,27 @@ def gen_terrain_index():
          heights_raw=torch.round(heights / 0.005).short(), center_raw=torch.round(center / 0.005).short(),
          heights_sample=heights[:4], map_checksum=np.array(int(terrain_index_map().astype(np.int64).sum())))
 
+
+def gen_scheduler():
+    """LocoVal learning-rate schedule (pacer/pacer/learning/scheduler.py, stepped once per epoch, common_agent.py:95,209)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_scheduler", f"{_ref_shim.REF}/pacer/pacer/learning/scheduler.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    for tag, (w, T, n) in dict(short=(5, 40, 130), locoval=(20, 20000, 80)).items():
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=1e-3, weight_decay=1e-4)
+        sch = mod.CosineAnnealingLR(opt, warmup_epochs=w, max_epochs=T)
+        lrs = [opt.param_groups[0]["lr"]]
+        for _ in range(n):
+            opt.step()
+            sch.step()
+            lrs.append(opt.param_groups[0]["lr"])
+        out["lr_" + tag] = np.array(lrs, np.float64)
+        out["cfg_" + tag] = np.array([w, T, n])
+    save("locoval_lr_schedule", **out)
+
 def gen_pacer():
     _ref_shim.install_pacer()
     import env.tasks.humanoid as H
@@ -438,6 +459,9 @@ if __name__ == "__main__":
     if which == "pacer":
         gen_pacer()
         gen_terrain_index()
+        gen_scheduler()
+    elif which == "scheduler":
+        gen_scheduler()
     elif which == "terrain_index":
         _ref_shim.install_pacer()
         gen_terrain_index()

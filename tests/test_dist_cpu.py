@@ -62,3 +62,52 @@ def test_shard_range_rejects_ragged_split():
     with pytest.raises(ValueError):
         shard_range(4097, 0, 8)
     assert shard_range(4096, 7, 8) == (3584, 512)
+
+
+def _sync_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from emloco_amd.dist import all_reduce_mean_scalar, broadcast_parameters, init_from_env, sync_running_mean_std
+    from emloco_amd.utils.running_mean_std import RunningMeanStd
+    init_from_env("gloo")
+    torch.manual_seed(10 + rank)                            # run.py seeds with base + rank: replicas differ until the broadcast
+    net = torch.nn.Linear(7, 3)
+    rms = RunningMeanStd((5,))
+    rms.running_mean += rank
+    broadcast_parameters(net, rms)
+    w = net.weight.detach().numpy().copy()
+    mean_after_bcast = rms.running_mean.numpy().copy()
+    # per-rank statistics of different samples, different counts
+    g = torch.Generator().manual_seed(3)
+    data = torch.randn(300, 5, generator=g, dtype=torch.float64) * 2 + 1
+    mine = data[:100] if rank == 0 else data[100:]
+    rms.running_mean.copy_(mine.mean(0)); rms.running_var.copy_(mine.var(0, unbiased=False)); rms.count.fill_(float(len(mine)))
+    sync_running_mean_std(rms)
+    kl = all_reduce_mean_scalar(0.25 if rank == 0 else 0.75)
+    out.put((rank, w, mean_after_bcast, rms.running_mean.numpy().copy(), rms.running_var.numpy().copy(), float(rms.count), kl))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_broadcast_statistics_sync_and_kl_mean():
+    """The reference's other three exchange steps (common_agent.py:165-166,179-180; amp_continuous.py:287-288): parameter
+    broadcast at start-up, running-mean-std synchronisation per epoch (pooled mean / variance of unequal shards), KL average."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, m0, mu0, var0, c0, kl0), (_, w1, m1, mu1, var1, c1, kl1) = res
+    import numpy as np
+    assert np.array_equal(w0, w1) and np.array_equal(m0, m1) and (m1 == 0).all()        # rank 0's values everywhere
+    g = torch.Generator().manual_seed(3)
+    data = (torch.randn(300, 5, generator=g, dtype=torch.float64) * 2 + 1).numpy()
+    np.testing.assert_allclose(mu0, data.mean(0), rtol=1e-12)
+    np.testing.assert_allclose(var0, data.var(0), rtol=1e-10)
+    assert np.array_equal(mu0, mu1) and np.array_equal(var0, var1) and c0 == c1 == 150.0
+    assert kl0 == kl1 == 0.5

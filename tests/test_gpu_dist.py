@@ -1,0 +1,220 @@
+"""GPU: the data-parallel paths with the real trainers, two ranks sharing the one GPU of the test box (gloo; device tensors
+staged through the host by emloco_amd.dist), and the NaN / zero-pose row handling of the EmLoco train step (B8)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(fn, world, *args, timeout=600):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=fn, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=timeout) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from emloco_amd.dist import init_from_env
+    init_from_env("gloo")
+    torch.cuda.set_device(0)
+
+
+# ------------------------------------------------------------------------------------------------ predictor
+def _jta_cfg(dev, multi=False):
+    return {"DEVICE": dev, "MULTI_MODAL": multi, "TRAIN": {"input_track_size": 9, "output_track_size": 12, "lr": 1e-3,
+                                                          "max_grad_norm": 1.0, "valuenet_weight": 1.0}}
+
+
+def _jta_model(dev, seed, multi=False):
+    from emloco_amd.predictor.model_jta import TransMotionJTA
+    torch.manual_seed(seed)
+    return TransMotionJTA(tok_dim=453, nhid=128, nhead=4, dim_feedfwd=256, nlayers_local=1, nlayers_global=1, nmode=3, output_scale=1,
+                          obs_and_pred=21, num_tokens=49, device=dev, dropout=0.0, multi_modal=multi).to(dev)
+
+
+def _jta_batch(B, N, seed, nan_rows=True):
+    g = torch.Generator().manual_seed(seed)
+    joints = torch.randn(B, N, 21, 49, 4, generator=g) * 0.3
+    joints[:, :, :, 0, :2] = torch.cumsum(torch.rand(B, N, 21, 2, generator=g) * 0.4, dim=2)
+    if nan_rows:
+        joints[1, 0, 8, 5, 1] = float("nan")             # NaN in the primary pose -> row dropped by nan_handler
+        joints[2, 0, 8, 3:27, :3] = 0.0                  # all-zero pose -> row dropped
+        joints[5 % B, 0, 7, 0, 0] = float("nan")         # NaN trajectory sample at t = 7 -> NaN velocity -> row dropped
+    masks = torch.ones(B, N, 21, 49)
+    pad = torch.zeros(B, N, dtype=torch.bool)
+    pad[0, N - 1] = True
+    return joints, masks, pad
+
+
+def _vnet(dev, seed=11):
+    from emloco_amd.learning.value_pose_net import ValuePoseNet
+    torch.manual_seed(seed)
+    return ValuePoseNet(True, True).to(dev)
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_emloco_loss_handles_nan_and_zero_pose_rows_like_the_reference(multi):
+    """B8 (train_jta.py:143-165,288-308): rows with a NaN pose, an all-zero pose or a NaN velocity leave the EmLoco loss.  The
+    masked, synchronisation-free form used by EmLocoTrainer.step equals the row-dropping restatement of the reference's
+    nan_handler and the stock-torch LocoVal oracle on the surviving rows -- value and gradient; a batch with no surviving
+    row adds nothing."""
+    from oracle.predictor_torch import LocoValOracle
+    from emloco_amd.predictor.train_jta import batch_process_coords, compute_loss, emloco_loss, emloco_loss_masked
+    dev = "cuda:0"
+    cfg = _jta_cfg(dev, multi)
+    model = _jta_model(dev, 3, multi)
+    vnet = _vnet(dev)
+    for p in vnet.parameters():
+        p.requires_grad_(False)
+    joints, masks, pad = _jta_batch(8, 2, 0)
+    in_j, in_m, out_j, out_m, pm = batch_process_coords(joints, masks, pad, cfg, training=True)
+    pose = joints[:, 0, 8, 3:27, :3].clone().to(dev)
+    pose[..., 2] *= -1
+    vel = ((in_j[:, 8, 0, :2] - in_j[:, 7, 0, :2]) * 2.5).clone()
+    assert torch.isnan(pose[1]).any() and (pose[2] == 0).all() and torch.isnan(vel[5]).any()
+    model.eval()
+    _, pred = compute_loss(model, cfg, in_j, out_j, in_m, out_m, pm.to(dev), mode='val')
+    assert torch.isfinite(pred).all()                                   # NaN inputs were zeroed (train_jta.py:102-103)
+    pred = pred.detach().requires_grad_(True)
+    vsum, cnt = emloco_loss_masked(cfg, vnet, pred, pose.clone(), vel.clone(), 9)
+    assert int(cnt.item()) == 5
+    masked = vsum / cnt
+    masked.backward()
+    g_masked = pred.grad.clone()
+    pred.grad = None
+    dropped = emloco_loss(cfg, vnet, pred, pose.clone(), vel.clone(), 9)      # reference control flow: boolean-mask row drop
+    dropped.backward()
+    assert abs(masked.item() - dropped.item()) <= 1e-6 * max(1.0, abs(dropped.item()))
+    assert torch.allclose(g_masked, pred.grad, rtol=1e-5, atol=1e-8)
+    assert (g_masked[[1, 2, 5]] == 0).all() and (g_masked[[0, 3, 4, 6, 7]].abs().sum(dim=(1, 2, 3)) > 0).all()
+    # stock-torch oracle on the survivors
+    keep = torch.tensor([0, 3, 4, 6, 7], device=dev)
+    orc = LocoValOracle().to(dev)
+    orc.load_state_dict(vnet.state_dict())
+    M = pred.shape[2] if multi else 1
+    tot = 0.0
+    po = pose[keep].clone()
+    for i in range(M):
+        tr = torch.cat([torch.zeros(5, 1, 2, device=dev), pred.detach()[keep, 9:, i]], dim=1)
+        v = orc(tr, po, vel[keep])
+        tot = tot + ((v - 1) ** 2).mean()
+        if multi:     # the reference rotates the caller's pose in place, cumulatively over the modes (value_pose_net.py:97)
+            a = torch.atan2(tr[:, 1, 1], torch.where(tr[:, 1, 0].abs() < 1e-10, torch.full_like(tr[:, 1, 0], 1e-10), tr[:, 1, 0]))
+            R = torch.stack([torch.cos(a), -torch.sin(a), torch.sin(a), torch.cos(a)], -1).view(-1, 2, 2)
+            po = torch.cat([torch.bmm(po[..., :2], R), po[..., 2:]], -1)
+            po[:, [4, 8, 9, 10, 11]] = 0
+    assert abs(tot.item() / M - masked.item()) <= 2e-5 * max(1.0, abs(masked.item()))
+    # nothing survives -> contributes exactly 0, the step stays finite
+    zsum, zcnt = emloco_loss_masked(cfg, vnet, pred.detach(), torch.zeros_like(pose), vel.clone(), 9)
+    assert zcnt.item() == 0 and (zsum / zcnt.clamp(min=1)).item() == 0.0
+
+
+def test_train_step_with_nan_rows_stays_finite_and_moves_the_weights():
+    from emloco_amd.predictor.train_jta import EmLocoTrainer
+    dev = "cuda:0"
+    model = _jta_model(dev, 3)
+    tr = EmLocoTrainer(model, _vnet(dev), _jta_cfg(dev))
+    w0 = model.fc_out_traj.weight.detach().clone()
+    joints, masks, pad = _jta_batch(8, 2, 0)
+    for _ in range(3):
+        loss, mse = tr.step(joints, masks, pad)
+    assert torch.isfinite(loss) and torch.isfinite(mse)
+    assert all(torch.isfinite(p).all() for p in model.parameters()) and not torch.equal(w0, model.fc_out_traj.weight)
+
+
+def _trainer_worker(rank, world, port, q, steps):
+    _init(rank, world, port)
+    import torch.distributed as dist
+    from emloco_amd.predictor.train_jta import EmLocoTrainer
+    dev = "cuda:0"
+    model = _jta_model(dev, 100 + rank)                    # different initial weights: the constructor's broadcast equalises them
+    tr = EmLocoTrainer(model, _vnet(dev, 11 + rank), _jta_cfg(dev), data_parallel=True)
+    joints, masks, pad = _jta_batch(8, 2, 0)
+    sl = slice(rank * 4, (rank + 1) * 4)
+    for _ in range(steps):
+        tr.step(joints[sl], masks[sl], pad[sl], random_masking=False)
+    torch.cuda.synchronize()
+    q.put((rank, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_emloco_trainer_equals_single_rank_on_the_concatenated_batch():
+    """EmLocoTrainer(data_parallel=True) on two ranks (4 + 4 scenes, NaN / zero-pose rows spread unevenly: rank 0 keeps 2 rows,
+    rank 1 keeps 3): identical weights on both ranks after 3 Adam steps, equal to one process stepping on the 8 scenes."""
+    from emloco_amd.predictor.train_jta import EmLocoTrainer
+    res = _spawn(_trainer_worker, 2, 3)
+    sd0, sd1 = res[0][1], res[1][1]
+    for k in sd0:
+        assert np.array_equal(sd0[k], sd1[k]), k
+    dev = "cuda:0"
+    model = _jta_model(dev, 100)
+    tr = EmLocoTrainer(model, _vnet(dev, 11), _jta_cfg(dev))
+    joints, masks, pad = _jta_batch(8, 2, 0)
+    for _ in range(3):
+        tr.step(joints, masks, pad, random_masking=False)
+    for k, v in model.state_dict().items():
+        a, b = sd0[k], v.detach().cpu().numpy()
+        assert np.abs(a - b).max() <= 2e-5 + 2e-4 * np.abs(b).max(), (k, np.abs(a - b).max())
+
+
+# ------------------------------------------------------------------------------------------------ rollout
+def _rollout_worker(rank, world, port, q, E, horizon, epochs):
+    _init(rank, world, port)
+    import torch.distributed as dist
+    from emloco_amd.learning.locoval_rollout import LocoValRollout
+    from emloco_amd.run import create_rlgpu_env, fill_flags
+    from emloco_amd.utils.config import get_args, load_cfg
+    args = get_args(["--num_envs", str(E), "--seed", "3", "--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel",
+                     "--input_init_pose", "--input_init_vel"])
+    cfg, cfg_train, _ = load_cfg(args)
+    fill_flags(args)
+    env = create_rlgpu_env(args, cfg, cfg_train, rank=rank)           # seed + rank: different episodes per rank
+    agent = LocoValRollout(env, horizon_length=horizon)
+    w_start = [p.detach().cpu().numpy().copy() for p in agent.valuenet.parameters()]
+    # large exploration noise: humanoids fall at different times on the two ranks
+    agent.policy = lambda obs: torch.randn(E, 69, device=obs.device) * (0.6 if rank == 0 else 0.05)
+    for _ in range(epochs):
+        agent.play_steps()
+    torch.cuda.synchronize()
+    q.put((rank, w_start, [p.detach().cpu().numpy() for p in agent.valuenet.parameters()], agent.fitted_episodes, agent.vnet_fits,
+           float(agent.vnet_loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_locoval_rollout_on_the_real_env_keeps_replicas_identical():
+    """LocoValRollout over the real task on two ranks (64 envs each, seed + rank, very different termination rates): the
+    replicas start from rank 0's LocoVal weights, issue one collective per step each, and hold bit-identical weights after
+    48 steps in which the weights moved."""
+    res = _spawn(_rollout_worker, 2, 64, 16, 3)
+    (_, s0, w0, n0, f0, l0), (_, s1, w1, n1, f1, l1) = res
+    for a, b in zip(s0, s1):
+        assert np.array_equal(a, b)                                    # broadcast at construction
+    for a, b in zip(w0, w1):
+        assert np.array_equal(a, b)
+    assert n0 == n1 > 0 and f0 == f1 > 0 and l0 == l1 and np.isfinite(l0)
+    assert any(not np.array_equal(a, b) for a, b in zip(s0, w0))

@@ -1,0 +1,286 @@
+"""A17 on the CPU: the LocoVal rollout bookkeeping (amp_continuous_value.py:63-145, common_agent.py:154-155,205-209) against
+known answers, and its multi-rank path with rank-dependent episode ends (2 gloo ranks)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+GAMMA, STEP_TO_PRED = 0.99, 144
+
+
+class ScriptedTask:
+    def __init__(self, E, device="cpu"):
+        self.device, self.num_envs, self.num_actions, self.step_to_pred = device, E, 69, STEP_TO_PRED
+        self.obs_buf = torch.zeros(E, 8)
+        self.inverted = torch.zeros(E, dtype=torch.bool)
+        self.reset_buf = torch.ones(E, dtype=torch.long)
+
+
+class ScriptedEnv:
+    """VecEnv stand-in driven by tables: rewards[t, e], amp[t, e], done[t, e] (global env ids `ids` pick the columns), the
+    LocoVal inputs of an episode are a function of (env, episode number) so that a wrong pairing of target and input shows."""
+
+    def __init__(self, rewards, amp, done, inverted_by_episode, ids):
+        self.ids = np.asarray(ids)
+        E = len(ids)
+        self.task = ScriptedTask(E)
+        self.rewards, self.amp, self.done = rewards[:, ids], amp[:, ids], done[:, ids]
+        self.inv = inverted_by_episode
+        self.t = 0
+        self.episode = np.zeros(E, np.int64) - 1
+        self.resets = []
+
+    def _begin_episode(self, env_ids):
+        for e in env_ids.tolist():
+            self.episode[e] += 1
+            self.task.inverted[e] = bool(self.inv[self.ids[e], self.episode[e] % self.inv.shape[1]])
+        self.task.reset_buf[env_ids] = 0
+        self.resets.append((self.t, sorted(env_ids.tolist())))
+
+    def reset(self, env_ids):
+        self._begin_episode(env_ids)
+        return self.task.obs_buf
+
+    def reset_done(self):
+        self._begin_episode(self.task.reset_buf.nonzero().flatten())
+
+    def _feat(self, k):
+        g = torch.Generator().manual_seed(0)
+        base = torch.randn(256, 16, k, generator=g)
+        return base[torch.from_numpy(self.ids % 256), torch.from_numpy(self.episode % 16)]
+
+    def get_init_pose(self):
+        return self._feat(72).view(-1, 24, 3)
+
+    def get_waypoint_traj(self):
+        f = self._feat(45).view(-1, 15, 3).clone()
+        f[:, 1, 0] = f[:, 1, 0].abs() + 0.1
+        return f
+
+    def get_init_vel(self):
+        return self._feat(2)
+
+    def step(self, actions):
+        r = torch.from_numpy(self.rewards[self.t]).float()
+        d = torch.from_numpy(self.done[self.t]).long()
+        info = {"amp_obs": torch.from_numpy(self.amp[self.t]).float()}
+        self.task.reset_buf[:] = d
+        self.t += 1
+        return self.task.obs_buf, r, d, info
+
+
+def script(E, T, seed=0):
+    rng = np.random.default_rng(seed)
+    rewards = rng.uniform(-0.2, 1.0, size=(T, E)).astype(np.float32)
+    amp = rng.uniform(0.0, 2.0, size=(T, E)).astype(np.float32)
+    done = np.zeros((T, E), np.int64)
+    age = np.zeros(E, np.int64)
+    plan = rng.integers(1, 168, size=(E, 8))
+    plan[0, :] = 168                                  # env 0 always times out (> step_to_pred: emitted at step 144)
+    plan[1, :] = 144                                  # env 1 ends exactly at the cut-off (done_early AND length == 144)
+    plan[2, :] = [3, 145, 1, 143, 168, 7, 7, 7]       # env 2: very short, one past the cut-off, single-step episodes
+    ep = np.zeros(E, np.int64)
+    for t in range(T):
+        age += 1
+        for e in range(E):
+            if age[e] >= plan[e, ep[e] % 8]:
+                done[t, e] = 1
+                age[e] = 0
+                ep[e] += 1
+    inverted = rng.random((E, 16)) < 0.4
+    return rewards, amp, done, inverted
+
+
+def expected_events(rewards, amp, done, inverted, pen=0.3):
+    """Independent restatement: per env, walk the episodes; an episode's return sum_t gamma^t (r_t * (-pen if inverted) + amp_t)
+    over its first min(length, 144) steps is emitted at the step it ends (length <= 144) or at its 144th step."""
+    T, E = rewards.shape
+    out = np.zeros((T, E), np.float64)
+    for e in range(E):
+        t0, ep = 0, 0
+        while t0 < T:
+            inv = inverted[e, ep % inverted.shape[1]]
+            G, length = 0.0, 0
+            t = t0
+            while t < T:
+                r = float(rewards[t, e]) * (-pen if inv else 1.0)
+                if length < STEP_TO_PRED:
+                    G += (GAMMA ** length) * (r + float(amp[t, e]))
+                length += 1
+                if done[t, e] and length <= STEP_TO_PRED:
+                    out[t, e] = G
+                elif length == STEP_TO_PRED and not done[t, e]:
+                    out[t, e] = G
+                t += 1
+                if done[t - 1, e]:
+                    break
+            t0, ep = t, ep + 1
+    return out
+
+
+def test_return_accumulator_known_answer():
+    """3 scripted envs (time-outs, exact cut-off, 1-step episodes) + 5 random ones over 400 steps: every emitted value, at
+    the step and env where it is emitted, equals the closed form; nothing else is emitted."""
+    from emloco_amd.learning.locoval_rollout import ReturnAccumulator
+    E, T = 8, 400
+    rewards, amp, done, inverted = script(E, T)
+    exp = expected_events(rewards, amp, done, inverted)
+    acc = ReturnAccumulator(E, STEP_TO_PRED, GAMMA, "cpu")
+    ep = np.zeros(E, np.int64)
+    got = np.zeros((T, E))
+    for t in range(T):
+        inv = torch.from_numpy(inverted[np.arange(E), ep % 16])
+        r = torch.from_numpy(rewards[t])
+        r = torch.where(inv, r * (-0.3), r)
+        got[t] = acc.update(r, torch.from_numpy(amp[t]), torch.from_numpy(done[t])).numpy()
+        ep += done[t]
+    assert (exp != 0).sum() > 30
+    np.testing.assert_array_equal(got != 0, exp != 0)
+    np.testing.assert_allclose(got, exp, rtol=2e-5, atol=1e-5)
+    assert exp[143, 0] != 0 and exp[167, 0] == 0                     # env 0: emitted at its 144th step, not at the time-out
+    assert exp[143, 1] != 0                                          # env 1: done exactly at 144 -> once
+
+
+def _stand_in_valuenet(seed):
+    from oracle.predictor_torch import LocoValOracle
+    torch.manual_seed(seed)
+    return LocoValOracle()
+
+
+def _run_rollout(env, horizon, epochs, seed=5, record=None):
+    from emloco_amd.learning.locoval_rollout import LocoValRollout
+    agent = LocoValRollout(env, horizon_length=horizon, valuenet=_stand_in_valuenet(seed), disc_reward=lambda a: a,
+                           policy=lambda obs: torch.zeros(env.task.num_envs, 69))
+    if record is not None:
+        orig = agent._fit
+
+        def fit():
+            record.append((agent.game_combined_rewards.clone(), env.episode.copy()))
+            orig()
+        agent._fit = fit
+    for _ in range(epochs):
+        agent.play_steps()
+    return agent
+
+
+def test_locoval_rollout_targets_inputs_and_schedule():
+    """The whole play_steps loop on a scripted env: the targets (G + 10) / 110 reach the fit paired with the inputs of the
+    episode they belong to, the inversion penalty is 0.3 and the sum task + disc reward is unweighted, finished envs are
+    reset at the start of the next step, the learning rate follows the reference's schedule."""
+    E, H, EPOCHS = 8, 25, 12
+    rewards, amp, done, inverted = script(E, H * EPOCHS)
+    rec = []
+    env = ScriptedEnv(rewards, amp, done, inverted, np.arange(E))
+    agent = _run_rollout(env, H, EPOCHS, record=rec)
+    exp = expected_events(rewards, amp, done, inverted, pen=0.3)
+    got = np.stack([r[0].numpy() for r in rec])
+    np.testing.assert_allclose(got, exp, rtol=2e-5, atol=1e-5)
+    assert agent.fitted_episodes == int((exp != 0).sum()) and agent.frames == E * H * EPOCHS
+    # resets: everything at t = 0, then exactly the envs that were done on the previous step
+    assert env.resets[0] == (0, list(range(E)))
+    for t, ids in env.resets[1:]:
+        assert ids == np.nonzero(done[t - 1])[0].tolist()
+    # one hand-checked number: env 1's first episode (144 steps, done at the cut-off)
+    inv = inverted[1, 0]
+    G = sum(GAMMA ** k * (float(rewards[k, 1]) * (-0.3 if inv else 1.0) + float(amp[k, 1])) for k in range(144))
+    assert abs(got[143, 1] - G) < 1e-3 and abs((got[143, 1] + 10) / 110 - (G + 10) / 110) < 1e-5
+    # replay the fit sequence with plain torch: same weights at the end
+    net = _stand_in_valuenet(5)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4)
+    from emloco_amd.learning.scheduler import CosineAnnealingLR
+    sch = CosineAnnealingLR(opt, warmup_epochs=20, max_epochs=20000)
+    env2 = ScriptedEnv(rewards, amp, done, inverted, np.arange(E))
+    env2.reset(torch.arange(E))
+    for t in range(H * EPOCHS):
+        if t > 0:
+            env2.reset_done()
+        env2.step(None)
+        idx = torch.from_numpy(np.nonzero(exp[t])[0])
+        if len(idx):
+            pred = net(env2.get_waypoint_traj()[:, :13], env2.get_init_pose(), env2.get_init_vel()).squeeze(-1)
+            target = (torch.from_numpy(got[t]).float()[idx] + 10.0) / 110.0
+            opt.zero_grad()
+            torch.nn.functional.mse_loss(pred[idx], target, reduction="sum").backward()
+            opt.step()
+        if (t + 1) % H == 0:
+            sch.step()
+    for a, b in zip(agent.valuenet.parameters(), net.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert abs(agent.vnet_optimizer.param_groups[0]["lr"] - opt.param_groups[0]["lr"]) < 1e-12
+
+
+def test_cosine_schedule_matches_reference(golden):
+    from emloco_amd.learning.scheduler import CosineAnnealingLR
+    g = golden("locoval_lr_schedule")
+    for tag in ("short", "locoval"):
+        w, T, n = [int(v) for v in g["cfg_" + tag]]
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=1e-3, weight_decay=1e-4)
+        sch = CosineAnnealingLR(opt, warmup_epochs=w, max_epochs=T)
+        lrs = [opt.param_groups[0]["lr"]]
+        for _ in range(n):
+            opt.step()
+            sch.step()
+            lrs.append(opt.param_groups[0]["lr"])
+        np.testing.assert_allclose(np.array(lrs), g["lr_" + tag], rtol=1e-12, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------- two ranks
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_worker(rank, world, port, q, E_local, H, EPOCHS):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from emloco_amd.dist import init_from_env
+    init_from_env("gloo")
+    torch.set_num_threads(1)
+    rewards, amp, done, inverted = script(E_local * world, H * EPOCHS)
+    if rank == 1:
+        done[:, E_local:] = 0
+        done[7::31, E_local:] = 1                      # rank 1 finishes episodes rarely: many steps with no local episode
+    ids = np.arange(rank * E_local, (rank + 1) * E_local)
+    env = ScriptedEnv(rewards, amp, done, inverted, ids)
+    agent = _run_rollout(env, H, EPOCHS, seed=5 + rank)      # different seeds: the broadcast must make the replicas equal
+    q.put((rank, [p.detach().numpy().copy() for p in agent.valuenet.parameters()], agent.fitted_episodes, agent.vnet_fits))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_locoval_rollout_equals_single_rank_on_all_envs():
+    """LocoValRollout on 2 gloo ranks whose envs finish at different steps (steps where only one rank -- or neither -- has an
+    episode): no dead-lock (one collective per step on every rank), identical weights on both ranks, and the same weights as
+    one rank running all the envs (sum-reduced gradients, global episode count)."""
+    import torch.multiprocessing as mp
+    world, E_local, H, EPOCHS = 2, 4, 20, 6
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, q, E_local, H, EPOCHS)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, n0, f0), (_, w1, n1, f1) = res
+    assert n0 == n1 and f0 == f1 and n0 > 10
+    for a, b in zip(w0, w1):
+        assert np.array_equal(a, b)
+    rewards, amp, done, inverted = script(E_local * world, H * EPOCHS)
+    done[:, E_local:] = 0
+    done[7::31, E_local:] = 1
+    env = ScriptedEnv(rewards, amp, done, inverted, np.arange(E_local * world))
+    single = _run_rollout(env, H, EPOCHS, seed=5)
+    assert single.fitted_episodes == n0 and single.vnet_fits == f0
+    for a, b in zip(w0, single.valuenet.parameters()):
+        np.testing.assert_allclose(a, b.detach().numpy(), rtol=2e-5, atol=2e-6)
