@@ -255,9 +255,55 @@ int emloco_locoval_bwd(int B, const float *traj, int traj_stride, const float *p
         !dparams || !dtraj || !workspace)
         return pfail(-1, "emloco_locoval_bwd: bad argument");
     hipLaunchKernelGGL(emloco::locoval_bwd_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, B, traj, traj_stride, pose, vel,
-                       w1, w2, w3, value, x100, h1, h2, angle, dvalue, workspace, dtraj);
+                       w1, w2, w3, value, x100, h1, h2, angle, dvalue, workspace, dtraj, (const int32_t *)nullptr);
     PHIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(emloco::locoval_reduce_kernel, dim3((unsigned)((LV_NPARAM + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, workspace, dparams);
+    hipLaunchKernelGGL(emloco::locoval_reduce_kernel, dim3((unsigned)((LV_NPARAM + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, workspace,
+                       dparams, (const float *)nullptr);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_locoval_bwd_rows(int B, const float *traj, int traj_stride, const float *pose, const float *vel, const float *w1,
+                            const float *w2, const float *w3, const float *value, const float *x100, const float *h1, const float *h2,
+                            const float *angle, const float *dvalue, const int32_t *slot, const float *count, float *dparams, float *dtraj,
+                            float *workspace, void *stream) {
+    if (B < 1 || traj_stride < 2 || !traj || !pose || !vel || !w1 || !w2 || !w3 || !value || !x100 || !h1 || !h2 || !angle || !dvalue ||
+        !slot || !count || !dparams || !dtraj || !workspace)
+        return pfail(-1, "emloco_locoval_bwd_rows: bad argument");
+    hipLaunchKernelGGL(emloco::locoval_bwd_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, B, traj, traj_stride, pose, vel,
+                       w1, w2, w3, value, x100, h1, h2, angle, dvalue, workspace, dtraj, slot);
+    PHIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(emloco::locoval_reduce_kernel, dim3((unsigned)((LV_NPARAM + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, workspace,
+                       dparams, count);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_locoval_returns(const EmlocoLocoValStep *t, const float *rewards, const float *amp_rewards, const int64_t *dones,
+                           const uint8_t *inverted, void *stream) {
+    if (!t || !rewards || !dones || t->n_env < 1 || !t->current_rewards || !t->current_lengths || !t->current_combined_rewards ||
+        !t->discount_coefs || !t->waypoint_traj || !t->init_pose || !t->init_vel || !t->traj13 || !t->pose || !t->vel || !t->target || !t->weight)
+        return pfail(-1, "emloco_locoval_returns: bad argument");
+    hipLaunchKernelGGL(emloco::locoval_returns_kernel, dim3((unsigned)t->n_env), dim3(64), 0, (hipStream_t)stream, *t, rewards, amp_rewards,
+                       dones, inverted);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_locoval_fit_grad(int n, const float *value, const float *target, const float *weight, float *dvalue, float *tail2, int32_t *slot,
+                            void *stream) {
+    if (n < 1 || !value || !target || !weight || !dvalue || !tail2) return pfail(-1, "emloco_locoval_fit_grad: bad argument");
+    hipLaunchKernelGGL(emloco::locoval_fit_grad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, value, target, weight, dvalue, tail2, slot);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_adamw_gated(int n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, const float *steps_in, float *steps_out,
+                       const float *tail2, float lr, float beta1, float beta2, float eps, float weight_decay, double *stats, void *stream) {
+    if (n < 1 || !params || !grads || !exp_avg || !exp_avg_sq || !steps_in || !steps_out || steps_in == steps_out)
+        return pfail(-1, "emloco_adamw_gated: bad argument");
+    hipLaunchKernelGGL(emloco::adamw_gated_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, params, grads,
+                       exp_avg, exp_avg_sq, steps_in, steps_out, tail2, lr, beta1, beta2, eps, weight_decay, stats);
     PHIPCHK(hipGetLastError());
     return 0;
 }

@@ -13,6 +13,7 @@
 // fragments as 32 consecutive floats (conflict-free ds_read_b32).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/emloco_predictor.h"
 #include "mfma_bf16.h"
 #include "dev_math.h"
 
@@ -574,14 +575,17 @@ locoval_fwd_kernel(int B, const float *traj, int ts, const float *pose, const fl
 __global__ void __launch_bounds__(64)
 locoval_bwd_kernel(int B, const float *traj, int ts, const float *pose, const float *vel, const float *w1, const float *w2,
                    const float *w3, const float *value, const float *x100, const float *h1, const float *h2,
-                   const float *angle, const float *dvalue, float *ws, float *dtraj) {
+                   const float *angle, const float *dvalue, float *ws, float *dtraj, const int32_t *slot) {
     const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= B) return;
+    // sparse mode (slot != NULL): only the rows with a slot contribute, row i's parameter-gradient share goes to ws[slot[i]]
+    const int row = slot ? slot[i] : i;
+    if (row < 0) return;
     __shared__ float x[LV_IN], d1[LV_H1], d2[LV_H2], dx[LV_IN];
     for (int k = lane; k < LV_IN; k += 64) x[k] = x100[(long)i * LV_IN + k];
     const float v = value[i];
     const float dz3 = dvalue[i] * v * (1.0f - v);
-    float *g = ws + (long)i * LV_NPARAM;
+    float *g = ws + (long)row * LV_NPARAM;
     float *gw1 = g, *gb1 = g + LV_H1 * LV_IN, *gw2 = gb1 + LV_H1, *gb2 = gw2 + LV_H2 * LV_H1, *gw3 = gb2 + LV_H2, *gb3 = gw3 + LV_H2;
     if (lane < LV_H2) {
         const float hv = h2[(long)i * LV_H2 + lane];
@@ -640,12 +644,111 @@ locoval_bwd_kernel(int B, const float *traj, int ts, const float *pose, const fl
     }
 }
 
-__global__ void locoval_reduce_kernel(int B, const float *ws, float *dparams) {
+__global__ void locoval_reduce_kernel(int B, const float *ws, float *dparams, const float *count) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= LV_NPARAM) return;
+    const int rows = count ? (int)count[0] : B;         // sparse mode: the number of slots in use
     float s = 0.0f;
-    for (int i = 0; i < B; ++i) s += ws[(long)i * LV_NPARAM + p];
+    for (int i = 0; i < rows; ++i) s += ws[(long)i * LV_NPARAM + p];
     dparams[p] = s;
+}
+
+// ---- LocoVal training step around the MLP (amp_continuous_value.py:63-145, common_agent.py:89-97,154-155) ----------------
+// One wave per env: lanes copy the LocoVal inputs the task captured at reset into origin-relative form
+// (vec_task_wrappers.py:50-66; first 13 waypoints, amp_continuous_value.py:127), lane 0 advances the per-env bookkeeping of
+// the discounted return (:63-64 inversion penalty, :93-118) and emits the normalised target / weight of this step's fit.
+__global__ void __launch_bounds__(64)
+locoval_returns_kernel(EmlocoLocoValStep t, const float *rewards, const float *amp_rewards, const int64_t *dones, const uint8_t *inverted) {
+    const int e = blockIdx.x, lane = threadIdx.x;
+    if (e >= t.n_env) return;
+    const float *wp = t.waypoint_traj + (long)e * 45, *ip = t.init_pose + (long)e * 72;
+    if (lane < 39) t.traj13[(long)e * 39 + lane] = wp[lane] - wp[lane % 3];
+    for (int k = lane; k < 72; k += 64) t.pose[(long)e * 72 + k] = ip[k] - ip[k % 3];
+    if (lane < 2) t.vel[(long)e * 2 + lane] = t.init_vel[(long)e * 2 + lane];
+    if (lane == 0) {
+        float r = rewards[e];
+        if (inverted && inverted[e]) r = r * (-t.inversion_penalty);
+        const float a = amp_rewards ? amp_rewards[e] : 0.0f;
+        const bool done = dones[e] != 0;
+        const float nd = done ? 0.0f : 1.0f;
+        const float cr = t.current_rewards[e] + r;
+        const float len = t.current_lengths[e] + 1.0f;
+        const float coef = t.discount_coefs[e];
+        const float comb = t.current_combined_rewards[e] + (r + a) * coef;
+        const bool emit = done ? (len <= (float)t.step_to_pred) : (len == (float)t.step_to_pred);
+        const float G = emit ? comb : 0.0f;
+        t.target[e] = (G - t.min_cum_rewards) / (t.max_cum_rewards - t.min_cum_rewards);
+        t.weight[e] = G != 0.0f ? 1.0f : 0.0f;
+        t.current_combined_rewards[e] = comb * nd;
+        t.discount_coefs[e] = done ? 1.0f : coef * t.gamma;
+        t.current_rewards[e] = cr * nd;
+        t.current_lengths[e] = len * nd;
+    }
+}
+
+// d/dvalue of sum_e w_e (value_e - target_e)^2 (MSELoss(reduction='sum') over the valid rows, common_agent.py:96) and the two
+// scalars that travel with the gradient bucket: tail = [loss sum, number of valid rows].  Also ranks the valid rows:
+// slot[e] = number of valid rows before e (or -1), so that the backward pass touches only those rows (a few dozen of 4096
+// per step).  One workgroup, thread t owns the contiguous rows [t c, (t + 1) c): fixed order, no atomics.
+__global__ void __launch_bounds__(1024)
+locoval_fit_grad_kernel(int n, const float *value, const float *target, const float *weight, float *dvalue, float *tail, int32_t *slot) {
+    __shared__ float sl[1024];
+    __shared__ int sc[1024];
+    const int tid = threadIdx.x;
+    const int c = (n + 1023) / 1024;
+    const int lo = tid * c, hi = (lo + c < n) ? lo + c : n;
+    float l = 0.0f;
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i) {
+        const float w = weight[i], d = value[i] - target[i];
+        dvalue[i] = 2.0f * w * d;
+        l += w * d * d;
+        cnt += w != 0.0f ? 1 : 0;
+    }
+    sl[tid] = l; sc[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan of the counts (Hillis-Steele)
+        const int add = tid >= off ? sc[tid - off] : 0;
+        __syncthreads();
+        sc[tid] += add;
+        __syncthreads();
+    }
+    if (slot) {
+        int k = sc[tid] - cnt;
+        for (int i = lo; i < hi; ++i) slot[i] = weight[i] != 0.0f ? k++ : -1;
+    }
+    const int total = sc[1023];
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+        if (tid < off) sl[tid] += sl[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) { tail[0] = sl[0]; tail[1] = (float)total; }
+}
+
+// torch.optim.AdamW's update of a flat parameter buffer, committed only when the gate is open: tail[1] (the all-reduced number
+// of finished episodes) > 0.  The step count lives on the device, double-buffered so that every thread reads the old one
+// (steps_in) while thread 0 writes the new one (steps_out).  stats (optional, double[5]) accumulates
+// [last loss sum, last count, total loss sum, total count, number of fits].
+__global__ void adamw_gated_kernel(int n, float *p, const float *g, float *m, float *v, const float *steps_in, float *steps_out,
+                                   const float *tail, float lr, float b1, float b2, float eps, float wd, double *stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool open = tail ? tail[1] > 0.5f : true;
+    const float st = steps_in[0] + (open ? 1.0f : 0.0f);
+    if (i == 0) {
+        steps_out[0] = st;
+        if (stats && open && tail) { stats[0] = tail[0]; stats[1] = tail[1]; stats[2] += tail[0]; stats[3] += tail[1]; stats[4] += 1.0; }
+    }
+    if (i >= n || !open) return;
+    const float gi = g[i];
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = m[i] + (1.0f - b1) * (gi - m[i]);                    // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    const double bc1 = 1.0 - pow((double)b1, (double)st), bc2 = 1.0 - pow((double)b2, (double)st);
+    const float step_size = (float)((double)lr / bc1);
+    const float denom = sqrtf(vi) / (float)sqrt(bc2) + eps;
+    pi = pi - step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
 }
 
 }  // namespace emloco

@@ -64,7 +64,7 @@ class ReturnAccumulator:
 class LocoValRollout:
     def __init__(self, vec_env, use_pose=True, use_vel=True, horizon_length=32, gamma=0.99, inversion_penalty_scale=0.3,
                  policy=None, disc_reward=None, min_cum_rewards=-10.0, max_cum_rewards=100.0, lr=1e-3, weight_decay=1e-4,
-                 valuenet=None, warmup_epochs=20, max_epochs=20000):
+                 valuenet=None, warmup_epochs=20, max_epochs=20000, fused=None):
         self.vec_env = vec_env
         env = vec_env.env if hasattr(vec_env, "env") else vec_env
         self.env = env
@@ -75,11 +75,21 @@ class LocoValRollout:
         self.inversion_penalty_scale = inversion_penalty_scale         # amp_humanoid_smpl_sept_task.yaml:128
         self.step_to_pred = self.task.step_to_pred
         self.policy = policy or (lambda obs: torch.randn(self.num_actors, self.task.num_actions, device=self.device) * math.exp(-2.9))
+        self._no_disc = disc_reward is None
         self.disc_reward = disc_reward or (lambda amp_obs: torch.zeros(self.num_actors, device=self.device))
         self.min_cum_rewards, self.max_cum_rewards = min_cum_rewards, max_cum_rewards     # common_agent.py:154-155
         self.valuenet = (valuenet if valuenet is not None else ValuePoseNet(use_pose=use_pose, use_vel=use_vel)).to(self.device)
         broadcast_parameters(self.valuenet)                                                # hvd.setup_algo, common_agent.py:165-166
         self.bucket = FlatGradBucket(self.valuenet.parameters(), extra=2)                  # tail: [loss sum, episode count]
+        # the fused step (three small HIP launches around the LocoVal kernels, include/emloco_predictor.h) when the network
+        # is the HIP one on a GPU; the torch formulation below it is the same arithmetic (CPU tests, other networks)
+        self.fused = (isinstance(self.valuenet, ValuePoseNet) and self.device.type == "cuda") if fused is None else bool(fused)
+        if self.fused:
+            self._flat_params = torch.cat([p.detach().reshape(-1) for p in self.valuenet.parameters()]).contiguous()
+            o = 0
+            for p in self.valuenet.parameters():               # the parameters become views of one flat buffer (AdamW in one launch)
+                p.data = self._flat_params[o:o + p.numel()].view_as(p)
+                o += p.numel()
         self.vnet_optimizer = GatedFlatAdamW(self.valuenet.parameters(), self.bucket.grads, lr=lr, weight_decay=weight_decay)
         self.vnet_scheduler = CosineAnnealingLR(self.vnet_optimizer, warmup_epochs=warmup_epochs, max_epochs=max_epochs)
         E = self.num_actors
@@ -89,6 +99,56 @@ class LocoValRollout:
         self.frames = 0
         # [last fit's loss sum, last fit's episodes, total loss sum, total episodes, number of fits] -- on the device
         self._stats = torch.zeros(5, device=self.device, dtype=torch.float64)
+        if self.fused:
+            self._init_fused()
+
+    def _init_fused(self):
+        import ctypes as C
+        from ..predictor import ops
+        E, dev, task, a = self.num_actors, self.device, self.task, self.acc
+        f = lambda *s: torch.zeros(*s, device=dev)
+        self._fz = dict(traj13=f(E, 13, 3), pose=f(E, 24, 3), vel=f(E, 2), target=f(E), weight=f(E), value=f(E), dvalue=f(E),
+                        x100=f(E, 100), h1=f(E, 49), h2=f(E, 24), ang=f(E), dtraj=f(E, 13, 3), ws=f(E * 6174), zeros=f(E),
+                        steps=[f(1), f(1)], m=f(6174), v=f(6174), slot=torch.zeros(E, dtype=torch.int32, device=dev))
+        z = self._fz
+        assert task.waypoint_traj.is_contiguous() and task.init_pose.is_contiguous() and task.init_vel.is_contiguous()
+        p = lambda t: t.data_ptr()
+        self._fstep = ops.LocoValStep(E, int(self.step_to_pred), float(self.gamma), float(self.inversion_penalty_scale),
+                                      float(self.min_cum_rewards), float(self.max_cum_rewards), p(a.current_rewards), p(a.current_lengths),
+                                      p(a.current_combined_rewards), p(a.discount_coefs), p(task.waypoint_traj), p(task.init_pose),
+                                      p(task.init_vel), p(z["traj13"]), p(z["pose"]), p(z["vel"]), p(z["target"]), p(z["weight"]))
+        self._flip = 0
+
+    def _fused_step(self, rewards, amp_rewards, dones, inverted):
+        """Bookkeeping + fit of one rollout step in 6 launches (returns, LocoVal fwd, fit grad, LocoVal bwd x2, gated AdamW)."""
+        import ctypes as C
+        from ..predictor import ops
+        from ..sim import current_stream_handle
+        lib = ops._lib()
+        z, E = self._fz, self.num_actors
+        st = current_stream_handle(self.device)
+        P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        assert rewards.dtype == torch.float32 and dones.dtype == torch.int64 and inverted.dtype == torch.bool
+        s = self._fstep
+        s.inversion_penalty = float(self.inversion_penalty_scale)
+        ops._chk(lib.emloco_locoval_returns(C.byref(s), P(rewards.contiguous()), P(amp_rewards), P(dones.contiguous()), P(inverted.contiguous()), st),
+                 "emloco_locoval_returns")
+        n = self.valuenet._network
+        w = [n.fc1.weight, n.fc1.bias, n.fc2.weight, n.fc2.bias, n.fc3.weight, n.fc3.bias]
+        ops._chk(lib.emloco_locoval_fwd(E, P(z["traj13"]), 3, P(z["pose"]), P(z["vel"]), *[P(t) for t in w], P(z["value"]), P(z["x100"]),
+                                        P(z["h1"]), P(z["h2"]), P(z["ang"]), st), "emloco_locoval_fwd")
+        ops._chk(lib.emloco_locoval_fit_grad(E, P(z["value"]), P(z["target"]), P(z["weight"]), P(z["dvalue"]), P(self.bucket.tail), P(z["slot"]), st),
+                 "emloco_locoval_fit_grad")
+        ops._chk(lib.emloco_locoval_bwd_rows(E, P(z["traj13"]), 3, P(z["pose"]), P(z["vel"]), P(w[0]), P(w[2]), P(w[4]), P(z["value"]), P(z["x100"]),
+                                             P(z["h1"]), P(z["h2"]), P(z["ang"]), P(z["dvalue"]), P(z["slot"]), P(self.bucket.tail[1:]),
+                                             P(self.bucket.grads), P(z["dtraj"]), P(z["ws"]), st), "emloco_locoval_bwd_rows")
+        self.bucket.all_reduce(average=False)                                               # unconditional: one collective per step
+        g = self.vnet_optimizer.param_groups[0]
+        a, b = z["steps"][self._flip], z["steps"][self._flip ^ 1]
+        self._flip ^= 1
+        ops._chk(lib.emloco_adamw_gated(6174, P(self._flat_params), P(self.bucket.grads), P(z["m"]), P(z["v"]), P(a), P(b), P(self.bucket.tail),
+                                        float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                                        P(self._stats), st), "emloco_adamw_gated")
 
     # counters of the fit, read from the device on demand (a host synchronisation each)
     @property
@@ -123,10 +183,14 @@ class LocoValRollout:
             actions = self.policy(task.obs_buf)
             obs, rewards, dones, infos = self.vec_env.step(actions)
             inverted = task.inverted
+            self.frames += self.num_actors
+            if self.fused:
+                amp_rewards = None if self._no_disc else self.disc_reward(infos["amp_obs"]).contiguous()
+                self._fused_step(rewards, amp_rewards, dones, inverted)
+                return
             rewards = torch.where(inverted, rewards * (-self.inversion_penalty_scale), rewards)      # :63-64
             amp_rewards = self.disc_reward(infos["amp_obs"])
             self.game_combined_rewards += self.acc.update(rewards, amp_rewards, dones)
-            self.frames += self.num_actors
         self._fit()
 
     def end_epoch(self):

@@ -14,6 +14,15 @@ GEMM_BIAS, GEMM_RELU, GEMM_ACC, GEMM_DROPOUT = 1, 2, 4, 8
 _bound = False
 
 
+class LocoValStep(C.Structure):
+    """EmlocoLocoValStep (include/emloco_predictor.h)."""
+    _fields_ = [("n_env", C.c_int32), ("step_to_pred", C.c_int32), ("gamma", C.c_float), ("inversion_penalty", C.c_float),
+                ("min_cum_rewards", C.c_float), ("max_cum_rewards", C.c_float),
+                ("current_rewards", C.c_void_p), ("current_lengths", C.c_void_p), ("current_combined_rewards", C.c_void_p),
+                ("discount_coefs", C.c_void_p), ("waypoint_traj", C.c_void_p), ("init_pose", C.c_void_p), ("init_vel", C.c_void_p),
+                ("traj13", C.c_void_p), ("pose", C.c_void_p), ("vel", C.c_void_p), ("target", C.c_void_p), ("weight", C.c_void_p)]
+
+
 def _lib():
     global _bound
     lib = L.require_device()
@@ -40,6 +49,10 @@ def _lib():
         lib.emloco_locoval_bwd.argtypes = [ci, vp, ci] + [vp] * 15
         lib.emloco_locoval_bwd_workspace.argtypes = [ci]
         lib.emloco_locoval_bwd_workspace.restype = C.c_int64
+        lib.emloco_locoval_returns.argtypes = [C.POINTER(LocoValStep), vp, vp, vp, vp, vp]
+        lib.emloco_locoval_fit_grad.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp]
+        lib.emloco_locoval_bwd_rows.argtypes = [ci, vp, ci] + [vp] * 17
+        lib.emloco_adamw_gated.argtypes = [ci] + [vp] * 7 + [cf] * 5 + [vp, vp]
         lib.emloco_gemm_enable_timing.argtypes = [ci]
         lib.emloco_gemm_timing_stats.argtypes = [C.POINTER(ci), C.POINTER(cf), C.POINTER(C.c_double)]
         _bound = True

@@ -121,6 +121,48 @@ int emloco_locoval_bwd(int B, const float *traj, int traj_stride, const float *p
 /* bytes of workspace emloco_locoval_bwd needs for batch B */
 int64_t emloco_locoval_bwd_workspace(int B);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * LocoVal training step around the MLP: the per-step body of AMPValueAgent.play_steps after env.step
+ * (pacer/pacer/learning/amp_continuous_value.py:63-145; optimiser / normalisation common_agent.py:89-97,154-155), as three small
+ * launches around emloco_locoval_fwd / _bwd instead of ~90 framework launches:
+ *   emloco_locoval_returns   inversion penalty (:63-64), discounted-return bookkeeping with the step_to_pred cut-off
+ *                            (:93-118), LocoVal inputs in origin-relative form (vec_task_wrappers.py:50-66, :126-129),
+ *                            target (G - min) / (max - min) (:135) and the 0/1 weight of the rows with a finished episode
+ *   emloco_locoval_fit_grad  d/dvalue of MSELoss(reduction='sum') over those rows (:137), loss sum and row count
+ *   emloco_adamw_gated       AdamW(1e-3, wd 1e-4) step (:139) committed on the device iff the (all-reduced) row count > 0
+ * The gradient of the 6 174 parameters comes from emloco_locoval_bwd straight into the flat bucket that is all-reduced. */
+typedef struct {
+    int32_t n_env, step_to_pred;
+    float gamma, inversion_penalty, min_cum_rewards, max_cum_rewards;
+    float *current_rewards, *current_lengths, *current_combined_rewards, *discount_coefs;   /* state [n_env] */
+    const float *waypoint_traj;     /* [n_env][15][3]  task.waypoint_traj (humanoid_pedestrain_terrain.py:511-516) */
+    const float *init_pose;         /* [n_env][24][3]  task.init_pose */
+    const float *init_vel;          /* [n_env][2]      task.init_vel */
+    float *traj13;                  /* out [n_env][13][3] */
+    float *pose;                    /* out [n_env][24][3] */
+    float *vel;                     /* out [n_env][2] */
+    float *target;                  /* out [n_env] */
+    float *weight;                  /* out [n_env] */
+} EmlocoLocoValStep;
+int emloco_locoval_returns(const EmlocoLocoValStep *s, const float *rewards, const float *amp_rewards /* or NULL = 0 */,
+                           const int64_t *dones, const uint8_t *inverted /* or NULL */, void *stream);
+/* slot (optional, int32 [n]): rank of each valid row among the valid rows, -1 elsewhere -- for emloco_locoval_bwd_rows */
+int emloco_locoval_fit_grad(int n, const float *value, const float *target, const float *weight, float *dvalue, float *tail2,
+                            int32_t *slot, void *stream);
+/* emloco_locoval_bwd over the rows that have a slot only (the others have dvalue = 0 and would add zeros): the workspace
+ * holds one 6 174-float row per slot, `count` (device float, = tail2 + 1 BEFORE the all-reduce) is the number of slots.
+ * d traj of the skipped rows is left untouched. */
+int emloco_locoval_bwd_rows(int B, const float *traj, int traj_stride, const float *pose, const float *vel,
+                            const float *w1, const float *w2, const float *w3,
+                            const float *value, const float *x100, const float *h1, const float *h2, const float *angle,
+                            const float *dvalue, const int32_t *slot, const float *count, float *dparams, float *dtraj,
+                            float *workspace, void *stream);
+/* tail2 = [loss sum, row count] after the all-reduce (NULL: always step); steps_in / steps_out: device step counters (the caller
+ * swaps them after every call); stats: optional device double[5] = [last loss, last count, total loss, total count, fits] */
+int emloco_adamw_gated(int n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq, const float *steps_in,
+                       float *steps_out, const float *tail2, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       double *stats, void *stream);
+
 /* HIP-event timing of the GEMM launches (same protocol as emloco_sim_timing_stats) */
 int emloco_gemm_enable_timing(int on);
 int emloco_gemm_timing_stats(int *n_launches, float *total_ms, double *total_flops);

@@ -76,8 +76,8 @@ extern "C" int emu_locoval_fwd(int B, const float *traj, int ts, const float *po
 extern "C" int emu_locoval_bwd(int B, const float *traj, int ts, const float *pose, const float *vel, const float *w1,
                                const float *w2, const float *w3, const float *value, const float *x100, const float *h1,
                                const float *h2, const float *angle, const float *dvalue, float *dparams, float *dtraj, float *ws) {
-    emu::launch((unsigned)B, 64, [&] { locoval_bwd_kernel(B, traj, ts, pose, vel, w1, w2, w3, value, x100, h1, h2, angle, dvalue, ws, dtraj); });
-    emu::launch((unsigned)((LV_NPARAM + 255) / 256), 256, [&] { locoval_reduce_kernel(B, ws, dparams); });
+    emu::launch((unsigned)B, 64, [&] { locoval_bwd_kernel(B, traj, ts, pose, vel, w1, w2, w3, value, x100, h1, h2, angle, dvalue, ws, dtraj, (const int32_t *)nullptr); });
+    emu::launch((unsigned)((LV_NPARAM + 255) / 256), 256, [&] { locoval_reduce_kernel(B, ws, dparams, (const float *)nullptr); });
     return 0;
 }
 
@@ -104,5 +104,20 @@ extern "C" int emu_attention_bwd(int n_seq, int S, int nhead, int d_model, float
                     else { if (g_attn_prec) attn_bwd_dkv_kernel<1>(a); else attn_bwd_dkv_kernel<0>(a); }
                 });
     blockIdx.x = 0; blockIdx.y = 0;
+    return 0;
+}
+
+extern "C" int emu_locoval_returns(const EmlocoLocoValStep *t, const float *rewards, const float *amp, const int64_t *dones, const uint8_t *inv) {
+    EmlocoLocoValStep s = *t;
+    emu::launch((unsigned)s.n_env, 64, [&] { emloco::locoval_returns_kernel(s, rewards, amp, dones, inv); });
+    return 0;
+}
+extern "C" int emu_locoval_fit_grad(int n, const float *value, const float *target, const float *weight, float *dvalue, float *tail, int32_t *slot) {
+    emu::launch(1, 1024, [&] { emloco::locoval_fit_grad_kernel(n, value, target, weight, dvalue, tail, slot); });
+    return 0;
+}
+extern "C" int emu_adamw_gated(int n, float *p, const float *g, float *m, float *v, const float *si, float *so, const float *tail, float lr,
+                               float b1, float b2, float eps, float wd, double *stats) {
+    emu::launch((unsigned)((n + 255) / 256), 256, [&] { emloco::adamw_gated_kernel(n, p, g, m, v, si, so, tail, lr, b1, b2, eps, wd, stats); });
     return 0;
 }

@@ -143,6 +143,91 @@ def test_return_accumulator_known_answer():
     assert exp[143, 1] != 0                                          # env 1: done exactly at 144 -> once
 
 
+def test_fused_returns_kernel_equals_the_accumulator():
+    """locoval_returns_kernel (the fused step's bookkeeping, run through the CPU emulator) against ReturnAccumulator and the
+    closed form: emitted targets / weights element for element over 400 scripted steps, LocoVal inputs origin-relative."""
+    import ctypes as C
+    import emu
+    from emloco_amd.learning.locoval_rollout import ReturnAccumulator
+    from emloco_amd.predictor.ops import LocoValStep
+    E, T = 8, 400
+    rewards, amp, done, inverted = script(E, T)
+    exp = expected_events(rewards, amp, done, inverted)
+    acc = ReturnAccumulator(E, STEP_TO_PRED, GAMMA, "cpu")
+    f = lambda *s: np.zeros(s, np.float32)
+    st = dict(cr=f(E), cl=f(E), cc=f(E), dc=np.ones(E, np.float32), traj13=f(E, 13, 3), pose=f(E, 24, 3), vel=f(E, 2), target=f(E), weight=f(E))
+    rng = np.random.default_rng(1)
+    wp, ip, iv = rng.normal(size=(E, 15, 3)).astype(np.float32), rng.normal(size=(E, 24, 3)).astype(np.float32), rng.normal(size=(E, 2)).astype(np.float32)
+    p = lambda a: a.ctypes.data
+    s = LocoValStep(E, STEP_TO_PRED, GAMMA, 0.3, -10.0, 100.0, p(st["cr"]), p(st["cl"]), p(st["cc"]), p(st["dc"]), p(wp), p(ip), p(iv),
+                    p(st["traj13"]), p(st["pose"]), p(st["vel"]), p(st["target"]), p(st["weight"]))
+    fn = emu.lib().emu_locoval_returns
+    fn.argtypes = [C.c_void_p] * 5
+    ep = np.zeros(E, np.int64)
+    for t in range(T):
+        inv = inverted[np.arange(E), ep % 16]
+        keep = (np.ascontiguousarray(rewards[t]), np.ascontiguousarray(amp[t]), np.ascontiguousarray(done[t]), inv.astype(np.uint8))
+        fn(C.addressof(s), *[p(k) for k in keep])
+        r = torch.from_numpy(rewards[t])
+        r = torch.where(torch.from_numpy(inv), r * (-0.3), r)
+        em = acc.update(r, torch.from_numpy(amp[t]), torch.from_numpy(done[t])).numpy()
+        np.testing.assert_array_equal(st["weight"], (em != 0).astype(np.float32))
+        np.testing.assert_array_equal(st["target"], ((em - (-10.0)) / np.float32(110.0)).astype(np.float32))
+        np.testing.assert_array_equal(st["cc"], acc.current_combined_rewards.numpy())
+        np.testing.assert_array_equal(st["dc"], acc.discount_coefs.numpy())
+        np.testing.assert_array_equal(st["weight"] != 0, exp[t] != 0)
+        ep += done[t]
+    np.testing.assert_array_equal(st["traj13"], wp[:, :13] - wp[:, :1])
+    np.testing.assert_array_equal(st["pose"], ip - ip[:, :1])
+    np.testing.assert_array_equal(st["vel"], iv)
+
+
+def test_fused_fit_grad_and_gated_adamw_kernels():
+    """locoval_fit_grad_kernel (sum-MSE gradient + [loss, count]) and adamw_gated_kernel against torch: 40 steps with the gate
+    closed on some of them equal torch.optim.AdamW stepped only on the open ones; a closed gate leaves every buffer untouched."""
+    import ctypes as C
+    import emu
+    rng = np.random.default_rng(0)
+    n = 4096
+    v, tg = rng.random(n).astype(np.float32), rng.random(n).astype(np.float32)
+    w = (rng.random(n) < 0.1).astype(np.float32)
+    dv, tail = np.zeros(n, np.float32), np.zeros(2, np.float32)
+    fg = emu.lib().emu_locoval_fit_grad
+    fg.argtypes = [C.c_int] + [C.c_void_p] * 6
+    slot = np.zeros(n, np.int32)
+    fg(n, v.ctypes.data, tg.ctypes.data, w.ctypes.data, dv.ctypes.data, tail.ctypes.data, slot.ctypes.data)
+    np.testing.assert_array_equal(slot, np.where(w != 0, np.cumsum(w != 0) - 1, -1))        # rank among the valid rows, in row order
+    np.testing.assert_allclose(dv, 2 * w * (v - tg), rtol=0, atol=0)
+    assert tail[1] == w.sum() and abs(tail[0] - float((w * (v - tg) ** 2).sum())) < 1e-3
+    N = 6174
+    fa = emu.lib().emu_adamw_gated
+    fa.argtypes = [C.c_int] + [C.c_void_p] * 7 + [C.c_float] * 5 + [C.c_void_p]
+    p0 = rng.normal(size=N).astype(np.float32)
+    p, m, vv = p0.copy(), np.zeros(N, np.float32), np.zeros(N, np.float32)
+    steps = [np.zeros(1, np.float32), np.zeros(1, np.float32)]
+    stats = np.zeros(5, np.float64)
+    ref = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=1e-4)
+    flip, n_open = 0, 0
+    for it in range(40):
+        g = rng.normal(size=N).astype(np.float32)
+        gate = it % 4 != 2
+        tl = np.array([0.5 * it, 3.0 if gate else 0.0], np.float32)
+        before = (p.copy(), m.copy(), vv.copy())
+        fa(N, p.ctypes.data, g.ctypes.data, m.ctypes.data, vv.ctypes.data, steps[flip].ctypes.data, steps[flip ^ 1].ctypes.data, tl.ctypes.data,
+           1e-3, 0.9, 0.999, 1e-8, 1e-4, stats.ctypes.data)
+        flip ^= 1
+        if gate:
+            n_open += 1
+            ref.grad = torch.from_numpy(g.copy())
+            opt.step()
+        else:
+            assert np.array_equal(p, before[0]) and np.array_equal(m, before[1]) and np.array_equal(vv, before[2])
+        assert steps[flip][0] == n_open
+    np.testing.assert_allclose(p, ref.detach().numpy(), rtol=2e-6, atol=2e-7)
+    assert stats[4] == n_open and stats[3] == 3.0 * n_open and stats[1] == 3.0
+
+
 def _stand_in_valuenet(seed):
     from oracle.predictor_torch import LocoValOracle
     torch.manual_seed(seed)
