@@ -290,3 +290,50 @@ def test_fused_locoval_step_equals_the_torch_formulation():
         assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), (p - q).abs().max()
     w0 = ValuePoseNet(True, True)
     assert any(not torch.equal(p.cpu(), q) for p, q in zip(a.valuenet.parameters(), w0.parameters()))
+
+
+def _eval_setup(dev):
+    from emloco_amd.learning.value_pose_net import ValuePoseNet
+    from emloco_amd.predictor.model_jrdb import TransMotionJRDB
+    torch.manual_seed(0)
+    cfg = {"DEVICE": dev, "MULTI_MODAL": True, "NOISY_TRAJ": 0, "TRAIN": {"input_track_size": 9, "output_track_size": 12},
+           "MODEL": {"value_threshold": 0.8}, "DATA": {"train_datasets": ["jrdb_all_visual_cues"]}}
+    model = TransMotionJRDB(tok_dim=246, nhid=128, nhead=4, dim_feedfwd=256, nlayers_local=1, nlayers_global=1, nmode=4, output_scale=1,
+                            obs_and_pred=21, num_tokens=26, device=dev, multi_modal=True).to(dev)
+    vnet = ValuePoseNet(True, True).to(dev)
+    g = torch.Generator().manual_seed(5)
+    data = []
+    for _ in range(4):
+        B, N = 8, 3
+        joints = torch.randn(B, N, 21, 26, 4, generator=g) * 0.3
+        joints[:, :, :, 0, :2] = torch.cumsum(torch.randn(B, N, 21, 2, generator=g) * 0.4, dim=2)
+        pad = torch.zeros(B, N, dtype=torch.bool)
+        pad[::3, 2] = True
+        data.append((joints, torch.ones(B, N, 21, 26), pad))
+    return cfg, model, vnet, data
+
+
+def _eval_worker(rank, world, port, q):
+    _init(rank, world, port)
+    import torch.distributed as dist
+    from emloco_amd.predictor.evaluate_jta import evaluate_ade_fde
+    cfg, model, vnet, data = _eval_setup("cuda:0")
+    res = evaluate_ade_fde(model, vnet, "test", "traj+all", data, 8, cfg, dataset="jrdb", random_ids=torch.arange(32) % 4)
+    q.put((rank, {k: (np.asarray(v).tolist() if not isinstance(v, (int, float)) else v) for k, v in res.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_evaluation_equals_single_rank():
+    """configs[4]: evaluate_ade_fde deals the batches round-robin to the ranks and all-reduces only its summary (sums, counts,
+    histograms): both ranks return the numbers of the single-process evaluation of all four batches."""
+    from emloco_amd.predictor.evaluate_jta import evaluate_ade_fde
+    res = _spawn(_eval_worker, 2)
+    r0, r1 = res[0][1], res[1][1]
+    cfg, model, vnet, data = _eval_setup("cuda:0")
+    single = evaluate_ade_fde(model, vnet, "test", "traj+all", data, 8, cfg, dataset="jrdb", random_ids=torch.arange(32) % 4)
+    assert r0["samples"] == r1["samples"] == single["samples"] == 32
+    for k, v in single.items():
+        a, b, c = np.asarray(r0[k], np.float64), np.asarray(r1[k], np.float64), np.asarray(v, np.float64)
+        assert np.array_equal(a, b, equal_nan=True), k
+        np.testing.assert_allclose(a, c, rtol=1e-6, atol=1e-9, err_msg=k, equal_nan=True)
