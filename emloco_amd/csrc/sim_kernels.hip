@@ -47,6 +47,12 @@ __device__ __forceinline__ constexpr int sidx(int a, int b) {
     return a <= b ? (a * (13 - a)) / 2 + (b - a) : (b * (13 - b)) / 2 + (a - b);
 }
 
+// (a, b) of a symmetric matrix stored as its packed lower triangle, branch-free
+__device__ __forceinline__ int tri_index(int a, int b) {
+    const int hi = a > b ? a : b, lo = a > b ? b : a;
+    return ((hi * (hi + 1)) >> 1) + lo;
+}
+
 #ifdef EMLOCO_SIM_PROFILE
 #define PSTAMP(i) do { if (d.prof && env == 0 && lane == 0) d.prof[sub * 16 + (i)] = (long long)wall_clock64(); } while (0)
 #else
@@ -81,38 +87,58 @@ struct BodyConst {   // per-lane (lane = body) constants kept in registers for t
 #ifndef EMLOCO_SIM_WAVES_PER_SIMD
 #define EMLOCO_SIM_WAVES_PER_SIMD 2   /* register budget 256 per lane: two resident waves per SIMD (8 envs per CU) */
 #endif
-__global__ void __launch_bounds__(64, EMLOCO_SIM_WAVES_PER_SIMD)
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(EMLOCO_SIM_WAVES_PER_SIMD, EMLOCO_SIM_WAVES_PER_SIMD)))
 sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     const int env = blockIdx.x;
     const int lane = threadIdx.x;
     if (env >= d.n_env) return;
 
-    // ---------------------------------------------------------------- LDS
-    __shared__ float sh_pw[NB][3], sh_qw[NB][4], sh_R[NB][9], sh_r[NB][3];
-    __shared__ float sh_V[NB][6], sh_Aacc[NB][6];
-    __shared__ float sh_Ia[NB][21], sh_pa[NB][6];
-    __shared__ float sh_W[NB][18], sh_K[NB][6], sh_L0[36], sh_L0i[6];   // root Cholesky factor and 1 / its diagonal
-    __shared__ float sh_a[NB][6], sh_Vf[NB][6];
-    __shared__ float sh_root[13];            // p0[3] q0[4] V0[6]
-    __shared__ float sh_P[7];                // linear momentum: expected [0..2], of the current substep [3..5]; total mass [6]
-    __shared__ int sh_par[NB], sh_dep[NB];
-    __shared__ int sh_cbody[MAXC], sh_ccand[MAXC];
-    __shared__ float sh_cx[MAXC][3], sh_cdist[MAXC];
-    __shared__ float sh_A[MAXR * (MAXR + 1) / 2];   // contact matrix, lower triangle: (r, s<=r) at r(r+1)/2 + s
-    __shared__ float sh_lam[MAXR];
-    __shared__ float sh_lws[MAXCAND * 3];
-    __shared__ unsigned char sh_lca[NB * NB];
-    __shared__ unsigned char sh_rowb[64];    // body of contact row r (NB for unused rows): lookup of the matrix-core Gram build
-    __shared__ float sh_cf[NB][3];
-    __shared__ float sh_fext[NB][6];         // limb-limb penalty wrench per body (self-collision), about O
-    // body inertia / bias force handed from phase 2 to phase 3 through LDS; they alias the contact matrix, which is
-    // only live in phases 6b-6c (barriers separate the phases)
-    // contact frames [normal | tangent 1 | tangent 2] on a height-field ground: alias of the articulated inertias, which are
-    // dead between the factorisation (phase 3) and the next substep
-    float (*sh_cdir)[9] = (float (*)[9])&sh_Ia[0][0];
+    // ---------------------------------------------------------------- LDS: one blob, 13.3 KB per env (12 envs per CU)
+    // Persistent part first, then the region G whose members are live in different phases of a substep:
+    //   Ia (articulated inertias)   phase 3 only; its first 180 words hold the contact frames (height field) from phase 5 to 7
+    //   I6, f                       phase 2 -> 3          pa   phases 3 and 7        a    phases 3-4 and 7
+    //   V                           phase 1 -> end of 4   Vf   end of 4 -> 6a        Aacc phase 1 -> 2     fext phase 1b -> 2
+    //   pw                          phase 1 -> 5          qw   phase 1
+    // The contact matrix (1830 words, phases 6b-6c) lies over [Ia tail .. fext], the limb-limb scratch (phase 1b) over
+    // [Ia tail .. a]; pw / qw stay out of both.  Barriers separate the phases.
+    enum { O_ROOT = 0, O_P = 16, O_PD = 24, O_R = O_PD + NB, O_r = O_R + NB * 9, O_W = O_r + NB * 3, O_K = O_W + NB * 18,
+           O_L0 = O_K + NB * 6, O_CB = O_L0 + 42, O_CX = O_CB + 2 * MAXC, O_CDIST = O_CX + 3 * MAXC, O_LAM = O_CDIST + MAXC,
+           O_SLOT = O_LAM + MAXR, O_CODE = O_SLOT + 32, O_IA = O_CODE + MAXR, O_G = O_IA + 180,
+           O_I6 = O_G + NB * 21 - 180, O_F = O_I6 + NB * 21, O_PA = O_F + NB * 6, O_A_ = O_PA + NB * 6, O_V = O_A_ + NB * 6,
+           O_VF = O_V + NB * 6, O_AACC = O_VF + NB * 6, O_FEXT = O_AACC + NB * 6, O_PW = O_FEXT + NB * 6, O_QW = O_PW + NB * 3,
+           LDS_WORDS = O_QW + NB * 4 };
+    static_assert(O_FEXT + NB * 6 - O_G >= MAXR * (MAXR + 1) / 2, "contact matrix does not fit its overlay");
+    static_assert(O_V - O_G >= NB * 8 + EMLOCO_SC_MAXHITS * 8, "limb-limb scratch does not fit its overlay");
+    static_assert(LDS_WORDS * 4 <= 13648, "LDS per env above 160 KiB / 12");
+    __shared__ float lds[LDS_WORDS];
+    float *sh_root = lds + O_ROOT;                            // p0[3] q0[4] V0[6]
+    float *sh_P = lds + O_P;                                  // linear momentum: expected [0..2], of the current substep [3..5]; total mass [6]
+    int *sh_pd = (int *)(lds + O_PD);                         // per body: parent | depth << 8 | index among the bodies of its depth << 16
+    float (*sh_R)[9] = (float (*)[9])(lds + O_R);
+    float (*sh_r)[3] = (float (*)[3])(lds + O_r);
+    float (*sh_W)[18] = (float (*)[18])(lds + O_W);
+    float (*sh_K)[6] = (float (*)[6])(lds + O_K);
+    float *sh_L0 = lds + O_L0, *sh_L0i = lds + O_L0 + 36;    // root Cholesky factor and 1 / its diagonal
+    int *sh_cbody = (int *)(lds + O_CB), *sh_ccand = (int *)(lds + O_CB + MAXC);
+    float (*sh_cx)[3] = (float (*)[3])(lds + O_CX);
+    float *sh_cdist = lds + O_CDIST;
+    float *sh_lam = lds + O_LAM;                              // per contact row: warm-start multiplier (6a), solved multiplier (after 6c)
+    unsigned char *sh_slot = (unsigned char *)(lds + O_SLOT); // per candidate: its contact slot of the latest substep (255: none)
+    unsigned *sh_code = (unsigned *)(lds + O_CODE);           // per contact row: chain code of its body (see phase 6a)
+    float (*sh_Ia)[21] = (float (*)[21])(lds + O_IA);
+    float (*sh_cdir)[9] = (float (*)[9])(lds + O_IA);        // contact frames [normal | tangent 1 | tangent 2] (height-field ground)
+    float (*sh_I6)[21] = (float (*)[21])(lds + O_I6);
+    float (*sh_f)[6] = (float (*)[6])(lds + O_F);
+    float (*sh_pa)[6] = (float (*)[6])(lds + O_PA);
+    float (*sh_a)[6] = (float (*)[6])(lds + O_A_);
+    float (*sh_V)[6] = (float (*)[6])(lds + O_V);
+    float (*sh_Vf)[6] = (float (*)[6])(lds + O_VF);
+    float (*sh_Aacc)[6] = (float (*)[6])(lds + O_AACC);
+    float (*sh_fext)[6] = (float (*)[6])(lds + O_FEXT);      // limb-limb penalty wrench per body (self-collision), about O
+    float (*sh_pw)[3] = (float (*)[3])(lds + O_PW);
+    float (*sh_qw)[4] = (float (*)[4])(lds + O_QW);
+    float *sh_A = lds + O_G;                                  // contact matrix, lower triangle: (r, s<=r) at r(r+1)/2 + s
     const bool hf_on = d.hf != nullptr;      // wave-uniform
-    float (*sh_I6)[21] = (float (*)[21])sh_A;
-    float (*sh_f)[6] = (float (*)[6])(sh_A + NB * 21);
 
     // ---------------------------------------------------------------- per-lane constants
     BodyConst bc;
@@ -126,9 +152,12 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     for (int k = 0; k < 3; ++k) bc.off[k] = d.joint_off[mb0 * 3 + k];
     // drive gains / targets are re-read (L2 hits) where they are used instead of pinning 15 registers for the launch
     const long dof0 = (long)env * NDOF + (is_body && lane >= 1 ? (lane - 1) * 3 : 0);
-    if (is_body) { sh_par[lane] = bc.parent; sh_dep[lane] = bc.depth; }
-    for (int i = lane; i < NB * NB; i += 64) sh_lca[i] = d.lca_depth[i];
-    for (int i = lane; i < MAXCAND * 3; i += 64) sh_lws[i] = d.lambda_ws[(long)env * MAXCAND * 3 + i];
+    if (is_body) {
+        int lslot = 0;                                        // index of this body among the bodies of its tree level (< 8)
+        for (int j = 0; j < lane; ++j) lslot += d.depth[j] == bc.depth;
+        sh_pd[lane] = (bc.parent & 0xff) | (bc.depth << 8) | (lslot << 16);   // the root's parent field reads 255
+    }
+    sh_slot[lane] = 255; sh_slot[lane + 64] = 255;
 
     // ---------------------------------------------------------------- state -> registers
     float qj[4] = {0, 0, 0, 1}, wj[3] = {0, 0, 0}, edof[3] = {0, 0, 0};
@@ -619,14 +648,32 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             m0 = __ballot(act[0]); m1 = __ballot(act[1]);
             nc = __popcll(m0) + __popcll(m1);
         }
+        // Warm start: the multipliers a candidate carried at the end of the previous substep (from the previous launch for
+        // substep 0).  Every lane first fetches the old values of its own candidates -- old slot map and old multipliers are
+        // still in place -- then, behind a barrier, the new contact list, its slot map and the warm values are written.
+        float wl[2][3];
+        for (int s = 0; s < 2; ++s) {
+            wl[s][0] = wl[s][1] = wl[s][2] = 0.0f;
+            const int c = lane + 64 * s;
+            if (act[s]) {
+                if (sub == 0) {
+                    for (int k = 0; k < 3; ++k) wl[s][k] = d.lambda_ws[(long)env * MAXCAND * 3 + c * 3 + k];
+                } else {
+                    const int os = sh_slot[c];
+                    if (os != 255) for (int k = 0; k < 3; ++k) wl[s][k] = sh_lam[3 * os + k];
+                }
+            }
+        }
+        __syncthreads();
         {
             const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             const int i0 = __popcll(m0 & below), i1 = __popcll(m0) + __popcll(m1 & below);
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s) {
+                const int ci = s == 0 ? i0 : i1;
+                sh_slot[lane + 64 * s] = act[s] ? (unsigned char)ci : (unsigned char)255;
                 if (act[s]) {
-                    const int ci = s == 0 ? i0 : i1;
                     sh_cbody[ci] = cb[s]; sh_ccand[ci] = lane + 64 * s; sh_cdist[ci] = cdist[s];
-                    for (int k = 0; k < 3; ++k) sh_cx[ci][k] = cxw[s][k];
+                    for (int k = 0; k < 3; ++k) { sh_cx[ci][k] = cxw[s][k]; sh_lam[3 * ci + k] = wl[s][k]; }
                     if (hf_on) {      // frame: normal, t1 = (y x n) / |y x n|, t2 = n x t1  (n_z > 0 on a height field)
                         const float *n = cnrm[s];
                         const float il = 1.0f / sqrtf(fmaf(n[2], n[2], n[0] * n[0]));
@@ -637,6 +684,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                         D[6] = n[1] * t1z; D[7] = fmaf(n[2], t1x, -(n[0] * t1z)); D[8] = 0.0f - n[1] * t1x;
                     }
                 }
+            }
         }
         __syncthreads();
         const int nr = 3 * nc;
@@ -667,7 +715,8 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             rhs = vel + bias;
             float p[6];
             for (int k = 0; k < 6; ++k) p[k] = -J[k];
-            for (int i = rbody; i >= 1; i = sh_par[i]) {
+            unsigned code = 0u;                           // (level index of the chain body + 1) per tree level, 3 bits each; depth on top
+            for (int i = rbody; i >= 1; i = sh_pd[i] & 0xff) {
                 float Ri[9], ri[3], u[3], uhh[3];
                 for (int k = 0; k < 9; ++k) Ri[k] = sh_R[i][k];
                 for (int k = 0; k < 3; ++k) ri[k] = sh_r[i][k];
@@ -679,7 +728,9 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 }
                 const float *K = sh_K[i], *W = sh_W[i];
                 uhh[0] = K[0] * u[0]; uhh[1] = SOP2(K[1], u[0], K[2], u[1]); uhh[2] = SOP3(K[3], u[0], K[4], u[1], K[5], u[2]);
-                const int lev = sh_dep[i] - 1;          // static register indexing: select the level's slot
+                const int pdi = sh_pd[i];
+                const int lev = ((pdi >> 8) & 0xff) - 1;          // static register indexing: select the level's slot
+                code |= (unsigned)(((pdi >> 16) & 0xff) + 1) << (3 * lev);
                 for (int q = 0; q < 8; ++q)
                     if (q == lev) { ys[6 + 3 * q] = uhh[0]; ys[6 + 3 * q + 1] = uhh[1]; ys[6 + 3 * q + 2] = uhh[2]; }
                 for (int k = 0; k < 6; ++k) p[k] = ADD_SOP3(p[k], W[k * 3], uhh[0], W[k * 3 + 1], uhh[1], W[k * 3 + 2], uhh[2]);
@@ -689,7 +740,10 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 for (int k = 0; k < a; ++k) acc = fmaf(-sh_L0[a * 6 + k], ys[k], acc);
                 ys[a] = acc * sh_L0i[a];
             }
-            lam = prm.warm * sh_lws[sh_ccand[myc] * 3 + myd];
+            lam = prm.warm * sh_lam[lane];
+            sh_code[lane] = code | ((unsigned)((sh_pd[rbody] >> 8) & 0xff) << 27);
+        } else if (lane < MAXR) {
+            sh_code[lane] = 0xffffffffu;
         }
         __syncthreads();
 
@@ -704,23 +758,22 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         {
             typedef float sim_f32x16 __attribute__((vector_size(64)));
             const int h = lane >> 5, j31 = lane & 31;
-            sh_rowb[lane] = (unsigned char)((lane < nr) ? rbody : NB);
-            const int own_dep = (lane < nr) ? sh_dep[rbody] : -1;          // -1: no row in this lane (all operands zero)
+            const int own_dep = (lane < nr) ? ((sh_pd[rbody] >> 8) & 0xff) : -1;   // -1: no row in this lane (all operands zero)
             int mydep = own_dep < 0 ? 0 : own_dep;
             for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(mydep, off); mydep = o > mydep ? o : mydep; }
             const int dmax = __builtin_amdgcn_readfirstlane(mydep);           // deepest chain among the contact bodies
-            __syncthreads();
             const int ntile = nr > 32 ? 3 : 1;
             for (int t = 0; t < ntile; ++t) {
                 const int tr = t > 0 ? 1 : 0, tc = t > 1 ? 1 : 0;
                 const int col = 32 * tc + j31;
-                const int bcol = sh_rowb[col];
+                // depth of the lowest common ancestor of (row body, column body) = length of the common prefix of their chain
+                // codes (3 bits per tree level); equal codes: the same body, its own depth
+                const unsigned ccol = sh_code[col < MAXR ? col : MAXR - 1];
                 int lc[16];
                 for (int r = 0; r < 16; ++r) {
                     const int row = 32 * tr + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int brow = sh_rowb[row];
-                    const bool ok = brow < NB && bcol < NB;
-                    lc[r] = ok ? (int)sh_lca[(ok ? brow : 0) * NB + (ok ? bcol : 0)] : 255;
+                    const unsigned x = sh_code[row < MAXR ? row : MAXR - 1] ^ ccol;
+                    lc[r] = x ? ((__builtin_ctz(x) * 11) >> 5) : (int)(ccol >> 27);
                 }
                 sim_f32x16 acc, res;
                 for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; res[r] = 0.0f; }
@@ -758,61 +811,63 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         // Lane s owns row s: its multiplier `lam`, the running residual w_s = rhs_s + sum_r A_sr lam_r and 1/(A_ss (1+cfm)).
         // A row update happens in lane rr alone; its change is broadcast with one v_readlane and every lane folds it into
         // w with one fma through column rr of the symmetric matrix -- no wave reduction in the loop.
-        // Lane s keeps its whole row of the symmetric matrix in registers (statically unrolled over the MAXR rows, guarded by
-        // the wave-uniform row count): the sweeps then touch no LDS and do no index arithmetic.
+        // The matrix stays in LDS (packed lower triangle): lane s reads entry (s, rr) of its row for the row being updated, one
+        // contact ahead of the sweep.  (Holding each lane's row in 60 registers cost a wave per SIMD in occupancy.)
         const int ls = lane < nr ? lane : 0;                      // idle lanes shadow lane 0 (their w is never used)
         const int tri_s = ls * (ls + 1) / 2;
         const float ainv = (lane < nr) ? 1.0f / (sh_A[tri_s + ls] * (1.0f + prm.cfm)) : 0.0f;
-        float arow[MAXR];
-#pragma unroll
-        for (int rr = 0; rr < MAXR; ++rr) arow[rr] = (rr < nr) ? sh_A[ls <= rr ? rr * (rr + 1) / 2 + ls : tri_s + rr] : 0.0f;
+        // entry (ls, rr) of the symmetric matrix in the packed lower triangle; the sweeps read the three entries of the next
+        // contact while the current one is being resolved (the reads do not depend on the multipliers)
+#define A_OF(rr) sh_A[tri_index(ls, (rr))]
         float w = rhs;
-#pragma unroll
-        for (int rr = 0; rr < MAXR; ++rr) {                       // warm start
-            if (rr < nr) {
-                const float lr = lane_bcast(lam, rr);
-                if (lr != 0.0f) w = fmaf(arow[rr], lr, w);
-            }
+        for (int rr = 0; rr < nr; ++rr) {                         // warm start
+            const float lr = lane_bcast(lam, rr);
+            const float av = A_OF(rr);
+            w = (lr != 0.0f) ? fmaf(av, lr, w) : w;
         }
+        PSTAMP(11);
         for (int it = 0; it < prm.n_iter; ++it) {
+            float n0 = 0.0f, n1a = 0.0f, n2a = 0.0f;
+            if (nc > 0) { n0 = A_OF(0); n1a = A_OF(1); n2a = A_OF(2); }
+            for (int c = 0; c < nc; ++c) {
+                const int r0 = 3 * c;
+                const float a0 = n0, a1 = n1a, a2 = n2a;
+                if (c + 1 < nc) { n0 = A_OF(r0 + 3); n1a = A_OF(r0 + 4); n2a = A_OF(r0 + 5); }
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                if (c < nc) {
-#pragma unroll
-                    for (int dr = 0; dr < 3; ++dr) {
-                        const int rr = 3 * c + dr;
-                        float delta = 0.0f;
-                        if (lane == rr) {
-                            float nl = fmaf(-w, ainv, lam);
-                            if (dr == 0 && nl < 0.0f) nl = 0.0f;
-                            delta = nl - lam;
-                            lam = nl;
-                        }
-                        w = fmaf(arow[rr], lane_bcast(delta, rr), w);
+                for (int dr = 0; dr < 3; ++dr) {
+                    const int rr = r0 + dr;
+                    float delta = 0.0f;
+                    if (lane == rr) {
+                        float nl = fmaf(-w, ainv, lam);
+                        if (dr == 0 && nl < 0.0f) nl = 0.0f;
+                        delta = nl - lam;
+                        lam = nl;
                     }
-                    const float ln = lane_bcast(lam, 3 * c), l1 = lane_bcast(lam, 3 * c + 1), l2 = lane_bcast(lam, 3 * c + 2);
-                    const float lim = prm.mu * ln;
-                    const float m2 = fmaf(l1, l1, l2 * l2);
-                    if (m2 > lim * lim) {                         // wave-uniform: outside the friction cone
-                        const float sc = lim / sqrtf(m2);
-                        const float n1 = l1 * sc, n2 = l2 * sc;
-                        if (lane == 3 * c + 1) lam = n1;
-                        if (lane == 3 * c + 2) lam = n2;
-                        w = fmaf(arow[3 * c + 1], n1 - l1, w);
-                        w = fmaf(arow[3 * c + 2], n2 - l2, w);
-                    }
+                    w = fmaf(dr == 0 ? a0 : (dr == 1 ? a1 : a2), lane_bcast(delta, rr), w);
+                }
+                const float ln = lane_bcast(lam, r0), l1 = lane_bcast(lam, r0 + 1), l2 = lane_bcast(lam, r0 + 2);
+                const float lim = prm.mu * ln;
+                const float m2 = fmaf(l1, l1, l2 * l2);
+                if (m2 > lim * lim) {                             // wave-uniform: outside the friction cone
+                    const float sc = lim / sqrtf(m2);
+                    const float n1 = l1 * sc, n2 = l2 * sc;
+                    if (lane == r0 + 1) lam = n1;
+                    if (lane == r0 + 2) lam = n2;
+                    w = fmaf(a1, n1 - l1, w);
+                    w = fmaf(a2, n2 - l2, w);
                 }
             }
+            if (it == 0) PSTAMP(12);
         }
+#undef A_OF
         if (lane < MAXR) sh_lam[lane] = (lane < nr) ? lam : 0.0f;
-        for (int i = lane; i < MAXCAND * 3; i += 64) sh_lws[i] = 0.0f;
         __syncthreads();
-        if (lane < nr) sh_lws[sh_ccand[myc] * 3 + myd] = lam;
 
         PSTAMP(8);
         // ============================================================ 7. impulses -> velocity change (second solve)
         float dq[3] = {0, 0, 0}, da0[6] = {0, 0, 0, 0, 0, 0};
-        if (is_body && last) { sh_cf[lane][0] = 0.0f; sh_cf[lane][1] = 0.0f; sh_cf[lane][2] = 0.0f; }
+        if (is_body && last && nc == 0)
+            for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = 0.0f;
         if (nc > 0) {
             float pin[6] = {0, 0, 0, 0, 0, 0};
             if (is_body) {
@@ -830,7 +885,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                             for (int k = 0; k < 6; ++k) pin[k] = fmaf(-Jr[k], l, pin[k]);
                             for (int k = 0; k < 3; ++k) cf[k] += dir[k] * l / h;
                         }
-                if (last) for (int k = 0; k < 3; ++k) sh_cf[lane][k] = cf[k];
+                if (last) for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = cf[k];
             }
             for (int lev = d.max_depth; lev >= 0; --lev) {
                 if (is_body && bc.depth == lev) {
@@ -970,7 +1025,6 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         cross3(V, r, t);
         for (int k = 0; k < 3; ++k) { o[k] = sh_pw[lane][k]; o[7 + k] = V[3 + k] + t[k]; o[10 + k] = V[k]; }
         for (int k = 0; k < 4; ++k) o[3 + k] = sh_qw[lane][k];
-        for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = sh_cf[lane][k];
         if (lane >= 1) {
             float *ds = d.dof_state + ((long)env * NDOF + (lane - 1) * 3) * 2;
             for (int k = 0; k < 3; ++k) { ds[2 * k] = edof[k]; ds[2 * k + 1] = wj[k]; }
@@ -981,7 +1035,13 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         for (int k = 0; k < 3; ++k) { rs[k] = sh_root[k]; rs[7 + k] = sh_root[10 + k]; rs[10 + k] = sh_root[7 + k]; }
         for (int k = 0; k < 4; ++k) rs[3 + k] = sh_root[3 + k];
     }
-    for (int i = lane; i < MAXCAND * 3; i += 64) d.lambda_ws[(long)env * MAXCAND * 3 + i] = sh_lws[i];
+    for (int s = 0; s < 2; ++s) {      // warm-start multipliers per candidate for the next launch
+        const int c = lane + 64 * s;
+        if (c < MAXCAND) {
+            const int os = sh_slot[c];
+            for (int k = 0; k < 3; ++k) d.lambda_ws[(long)env * MAXCAND * 3 + c * 3 + k] = os != 255 ? sh_lam[3 * os + k] : 0.0f;
+        }
+    }
 }
 
 // Forward kinematics only (used after state writes through the *_indexed setters): fills rb_state of

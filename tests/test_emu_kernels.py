@@ -32,6 +32,28 @@ def test_sim_step_kernel_is_bit_exact_vs_oracle():
     assert np.abs(a.contact_force).max() > 50
 
 
+def test_sim_step_kernel_fallen_humanoids_are_bit_exact_vs_oracle():
+    """Humanoids lying on the ground, pressed into it: more candidates than contact slots (the shallowest are dropped), limb-limb
+    contacts, contact bodies at several tree depths in the Gram build.  (Pelvis contacts -- tree depth 0 -- come up in the
+    168-step episodes of tests/test_gpu_sim.py on the hardware.)"""
+    E = 3
+    models = varied_models(E, seed=5)
+    root, dof, tgt = scene_state(E, seed=6, height=0.06, perturbed_from=0)
+    for e in range(E):                                   # lying on the back / side / front
+        ax = [(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (-1.0, 0.0, 0.0)][e]
+        s = np.sin(np.pi / 4)
+        root[e, 3:7] = [ax[0] * s, ax[1] * s, ax[2] * s, np.cos(np.pi / 4)]
+    a = oracle_sim(models, root, dof, tgt, self_collision=True, n_sub=4)
+    b = oracle_sim(models, root, dof, tgt, self_collision=True, n_sub=4)
+    for _ in range(3):
+        a.step(1)
+        emu.sim_step(b, 1)
+    for name in ("root_state", "dof_state", "rb_state", "contact_force", "dof_force", "lambda_ws"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    cf = np.abs(a.contact_force).sum(-1)
+    assert ((cf > 0).sum(1) >= 1).all()
+
+
 def test_sim_step_kernel_with_self_collision_is_bit_exact_vs_oracle():
     """phase 1b (limb-limb penalty contacts): folding ragdolls (drives off, limbs thrown together) keep the emulated kernel
     and the oracle on identical bytes, and the contacts really fire"""

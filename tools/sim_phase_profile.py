@@ -23,6 +23,7 @@ buf = (C.c_longlong * 256)()
 lib.emloco_sim_profile(sim._h, buf, 256)          # first call allocates the stamp buffer
 for _ in range(40): sim.step(2)                    # settle onto the ground so contacts are active
 torch.cuda.synchronize()
+print("contacts of env 0 (bodies with |F| > 0):", int((sim.contact_force.view(E, 24, 3)[0].abs().sum(1) > 0).sum()))
 lib.emloco_sim_profile(sim._h, buf, 256)
 t = np.array(buf[:], dtype=np.int64).reshape(16, 16)
 n_sub = 4
@@ -30,4 +31,6 @@ print(f"E={E}: ticks (100 MHz) per phase, substeps 0..{n_sub-1}")
 for i, name in enumerate(PHASES):
     d = [int(t[s, i + 1] - t[s, i]) for s in range(n_sub)]
     print(f"  {name:20s} " + " ".join(f"{x:6d}" for x in d))
+print(f"  {'PGS: setup+warm start':20s} " + " ".join(f"{int(t[s, 11] - t[s, 7]):6d}" for s in range(n_sub)))
+print(f"  {'PGS: first sweep':20s} " + " ".join(f"{int(t[s, 12] - t[s, 11]):6d}" for s in range(n_sub)))
 print(f"  {'substep total':20s} " + " ".join(f"{int(t[s, 10] - t[s, 0]):6d}" for s in range(n_sub)))
