@@ -103,7 +103,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     // [Ia tail .. a]; pw / qw stay out of both.  Barriers separate the phases.
     enum { O_ROOT = 0, O_P = 16, O_PD = 24, O_R = O_PD + NB, O_r = O_R + NB * 9, O_W = O_r + NB * 3, O_K = O_W + NB * 18,
            O_L0 = O_K + NB * 6, O_CB = O_L0 + 42, O_CX = O_CB + 2 * MAXC, O_CDIST = O_CX + 3 * MAXC, O_LAM = O_CDIST + MAXC,
-           O_SLOT = O_LAM + MAXR, O_CODE = O_SLOT + 32, O_IA = O_CODE + MAXR, O_G = O_IA + 180,
+           O_SLOT = O_LAM + MAXR, O_IA = O_SLOT + 32, O_G = O_IA + 180,
            O_I6 = O_G + NB * 21 - 180, O_F = O_I6 + NB * 21, O_PA = O_F + NB * 6, O_A_ = O_PA + NB * 6, O_V = O_A_ + NB * 6,
            O_VF = O_V + NB * 6, O_AACC = O_VF + NB * 6, O_FEXT = O_AACC + NB * 6, O_PW = O_FEXT + NB * 6, O_QW = O_PW + NB * 3,
            LDS_WORDS = O_QW + NB * 4 };
@@ -124,7 +124,6 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     float *sh_cdist = lds + O_CDIST;
     float *sh_lam = lds + O_LAM;                              // per contact row: warm-start multiplier (6a), solved multiplier (after 6c)
     unsigned char *sh_slot = (unsigned char *)(lds + O_SLOT); // per candidate: its contact slot of the latest substep (255: none)
-    unsigned *sh_code = (unsigned *)(lds + O_CODE);           // per contact row: chain code of its body (see phase 6a)
     float (*sh_Ia)[21] = (float (*)[21])(lds + O_IA);
     float (*sh_cdir)[9] = (float (*)[9])(lds + O_IA);        // contact frames [normal | tangent 1 | tangent 2] (height-field ground)
     float (*sh_I6)[21] = (float (*)[21])(lds + O_I6);
@@ -695,7 +694,9 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         float ys[YLEN];                                   // this row's chain-propagation vector (level-indexed: the compiler keeps it in
                                                           // scratch); entries beyond the row's own chain are never written NOR read
         const int myc = lane / 3, myd = lane - 3 * myc;
-        int rbody = 0;
+        int rbody = 0, rdep = 0;
+        unsigned code = 0u;
+        float p[6] = {0, 0, 0, 0, 0, 0};
         if (lane < nr) {
             rbody = sh_cbody[myc];
             float dir[3] = {myd == 1 ? 1.0f : 0.0f, myd == 2 ? 1.0f : 0.0f, myd == 0 ? 1.0f : 0.0f};
@@ -713,94 +714,100 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 else { bias = prm.erp * dist / h; if (bias < -prm.max_depen_vel) bias = -prm.max_depen_vel; }
             }
             rhs = vel + bias;
-            float p[6];
             for (int k = 0; k < 6; ++k) p[k] = -J[k];
-            unsigned code = 0u;                           // (level index of the chain body + 1) per tree level, 3 bits each; depth on top
-            for (int i = rbody; i >= 1; i = sh_pd[i] & 0xff) {
-                float Ri[9], ri[3], u[3], uhh[3];
-                for (int k = 0; k < 9; ++k) Ri[k] = sh_R[i][k];
-                for (int k = 0; k < 3; ++k) ri[k] = sh_r[i][k];
-                for (int a = 0; a < 3; ++a) {
-                    float ax[3] = {Ri[a], Ri[3 + a], Ri[6 + a]}, sl[3];
-                    cross3(ri, ax, sl);
-                    const float Sa[6] = {ax[0], ax[1], ax[2], sl[0], sl[1], sl[2]};
-                    u[a] = -dot6(Sa, p);
+            rdep = (sh_pd[rbody] >> 8) & 0xff;
+        }
+        // chain propagation, one tree level per (statically unrolled) step from the deepest level up: a row takes part from the
+        // level of its own body on; `ci` is its chain body at the current level.  The level index is static, so ys[] stays in
+        // registers; levels below every contact body are skipped wave-uniformly.
+        int rdmax = rdep;
+        for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(rdmax, off); rdmax = o > rdmax ? o : rdmax; }
+        const int dmax = __builtin_amdgcn_readfirstlane(rdmax);              // deepest chain among the contact bodies
+        {
+            int ci = rbody;
+#pragma unroll
+            for (int lev = 7; lev >= 0; --lev) {
+                if (lev < dmax) {
+                    if (lane < nr && lev < rdep) {
+                        const int i = ci;
+                        float Ri[9], ri[3], u[3], uhh[3];
+                        for (int k = 0; k < 9; ++k) Ri[k] = sh_R[i][k];
+                        for (int k = 0; k < 3; ++k) ri[k] = sh_r[i][k];
+                        for (int a = 0; a < 3; ++a) {
+                            float ax[3] = {Ri[a], Ri[3 + a], Ri[6 + a]}, sl[3];
+                            cross3(ri, ax, sl);
+                            const float Sa[6] = {ax[0], ax[1], ax[2], sl[0], sl[1], sl[2]};
+                            u[a] = -dot6(Sa, p);
+                        }
+                        const float *K = sh_K[i], *W = sh_W[i];
+                        uhh[0] = K[0] * u[0]; uhh[1] = SOP2(K[1], u[0], K[2], u[1]); uhh[2] = SOP3(K[3], u[0], K[4], u[1], K[5], u[2]);
+                        const int pdi = sh_pd[i];
+                        code |= (unsigned)(((pdi >> 16) & 0xff) + 1) << (3 * lev);
+                        ys[6 + 3 * lev] = uhh[0]; ys[6 + 3 * lev + 1] = uhh[1]; ys[6 + 3 * lev + 2] = uhh[2];
+                        for (int k = 0; k < 6; ++k) p[k] = ADD_SOP3(p[k], W[k * 3], uhh[0], W[k * 3 + 1], uhh[1], W[k * 3 + 2], uhh[2]);
+                        ci = pdi & 0xff;
+                    }
                 }
-                const float *K = sh_K[i], *W = sh_W[i];
-                uhh[0] = K[0] * u[0]; uhh[1] = SOP2(K[1], u[0], K[2], u[1]); uhh[2] = SOP3(K[3], u[0], K[4], u[1], K[5], u[2]);
-                const int pdi = sh_pd[i];
-                const int lev = ((pdi >> 8) & 0xff) - 1;          // static register indexing: select the level's slot
-                code |= (unsigned)(((pdi >> 16) & 0xff) + 1) << (3 * lev);
-                for (int q = 0; q < 8; ++q)
-                    if (q == lev) { ys[6 + 3 * q] = uhh[0]; ys[6 + 3 * q + 1] = uhh[1]; ys[6 + 3 * q + 2] = uhh[2]; }
-                for (int k = 0; k < 6; ++k) p[k] = ADD_SOP3(p[k], W[k * 3], uhh[0], W[k * 3 + 1], uhh[1], W[k * 3 + 2], uhh[2]);
             }
+        }
+        if (lane < nr) {
             for (int a = 0; a < 6; ++a) {   // L0 y = p
                 float acc = p[a];
                 for (int k = 0; k < a; ++k) acc = fmaf(-sh_L0[a * 6 + k], ys[k], acc);
                 ys[a] = acc * sh_L0i[a];
             }
             lam = prm.warm * sh_lam[lane];
-            sh_code[lane] = code | ((unsigned)((sh_pd[rbody] >> 8) & 0xff) << 27);
-        } else if (lane < MAXR) {
-            sh_code[lane] = 0xffffffffu;
         }
         __syncthreads();
 
         PSTAMP(6);
         // ============================================================ 6b. contact matrix A = Y Y^T on the matrix cores
-        // A[r][s] = <y_r, y_s> over the common-ancestor prefix (6 root entries + 3 per shared tree level).  One
-        // v_mfma_f32_32x32x2_f32 chain runs over root block and levels for a whole 32 x 32 tile of (row, column) pairs --
-        // bit-equal to the fmaf chain in ascending k (measured: tools/exp/mfma_exact.hip) -- and after the block of level
-        // L-1 every pair whose common-ancestor depth is L takes a snapshot of its accumulator: the prefix sum it needs.
-        // Operands: lanes 0-31 feed k = 2s, lanes 32-63 k = 2s+1, so row r's y values are needed in lanes r and r + 32 (one
-        // cross-half exchange per value).  The 3-wide level blocks are padded with one 0*0 step.  Tiles: (0,0) [, (1,0), (1,1)].
+        // A[r][s] = <y_r, y_s> over the common-ancestor prefix (6 root entries + 3 per shared tree level): the sum, in ascending
+        // level order, of the level blocks of the chain bodies that BOTH rows have on their chains.  One v_mfma_f32_32x32x2_f32
+        // chain per 32 x 32 tile -- bit-equal to the fmaf chain in ascending k (measured: tools/exp/mfma_exact.hip): the root
+        // block for all pairs, then per tree level one masked block per chain body present at that level, with the operands of
+        // the rows that do not pass through that body set to zero.  A pair gets its non-zero terms exactly from the bodies it
+        // shares (every other term adds an exact zero), so the accumulator IS the prefix sum: no snapshots, no per-pair depth
+        // look-ups, 16 accumulator registers.  Operands: lanes 0-31 feed k = 2s, lanes 32-63 k = 2s+1; v_permlane32_swap hands
+        // both over in one instruction.  The 3-wide level blocks are padded with one 0*0 step.  Tiles: (0,0) [, (1,0), (1,1)].
         {
             typedef float sim_f32x16 __attribute__((vector_size(64)));
             const int h = lane >> 5, j31 = lane & 31;
-            const int own_dep = (lane < nr) ? ((sh_pd[rbody] >> 8) & 0xff) : -1;   // -1: no row in this lane (all operands zero)
-            int mydep = own_dep < 0 ? 0 : own_dep;
-            for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(mydep, off); mydep = o > mydep ? o : mydep; }
-            const int dmax = __builtin_amdgcn_readfirstlane(mydep);           // deepest chain among the contact bodies
+            const int own_dep = (lane < nr) ? rdep : -1;   // -1: no row in this lane (all operands zero)
+            const bool has_row = own_dep >= 0;
             const int ntile = nr > 32 ? 3 : 1;
             for (int t = 0; t < ntile; ++t) {
                 const int tr = t > 0 ? 1 : 0, tc = t > 1 ? 1 : 0;
                 const int col = 32 * tc + j31;
-                // depth of the lowest common ancestor of (row body, column body) = length of the common prefix of their chain
-                // codes (3 bits per tree level); equal codes: the same body, its own depth
-                const unsigned ccol = sh_code[col < MAXR ? col : MAXR - 1];
-                int lc[16];
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * tr + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const unsigned x = sh_code[row < MAXR ? row : MAXR - 1] ^ ccol;
-                    lc[r] = x ? ((__builtin_ctz(x) * 11) >> 5) : (int)(ccol >> 27);
-                }
-                sim_f32x16 acc, res;
-                for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; res[r] = 0.0f; }
+                sim_f32x16 acc;
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #define GRAM_STEP(V0, V1)                                                                                              \
                 {                                                                                                      \
-                    const float v0_ = (V0), v1_ = (V1);                                                                \
-                    const float p0_ = __shfl_xor(v0_, 32), p1_ = __shfl_xor(v1_, 32);                                  \
-                    const float op0_ = h ? p1_ : v0_;            /* rows  0-31: lower half own k even, upper takes k odd */ \
-                    const float op1_ = h ? v1_ : p0_;            /* rows 32-63 */                                      \
+                    const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(V0), __float_as_uint(V1), false, false); \
+                    const float op0_ = __uint_as_float(sw_[0]), op1_ = __uint_as_float(sw_[1]);                        \
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tr ? op1_ : op0_, tc ? op1_ : op0_, acc, 0, 0, 0);      \
                 }
-#define GRAM_SNAP(L) for (int r = 0; r < 16; ++r) res[r] = (lc[r] == (L)) ? acc[r] : res[r];
-                const bool has_row = own_dep >= 0;
                 GRAM_STEP(has_row ? ys[0] : 0.0f, has_row ? ys[1] : 0.0f) GRAM_STEP(has_row ? ys[2] : 0.0f, has_row ? ys[3] : 0.0f)
                 GRAM_STEP(has_row ? ys[4] : 0.0f, has_row ? ys[5] : 0.0f)
-                GRAM_SNAP(0)
+#pragma unroll
                 for (int lev = 0; lev < 8; ++lev) {
-                    if (lev >= dmax) break;
-                    const bool on_chain = lev < own_dep;            // the row's chain has a joint at this tree level
-                    GRAM_STEP(on_chain ? ys[6 + 3 * lev] : 0.0f, on_chain ? ys[7 + 3 * lev] : 0.0f) GRAM_STEP(on_chain ? ys[8 + 3 * lev] : 0.0f, 0.0f)
-                    GRAM_SNAP(lev + 1)
+                    if (lev < dmax) {                               // wave-uniform
+                        // this row's chain body at the level, as its index within the level + 1 (0: the chain ends above it)
+                        const int gid = (lev < own_dep) ? (int)((code >> (3 * lev)) & 7u) : 0;
+                        unsigned long long rem = __ballot(gid != 0);
+                        while (rem != 0ull) {
+                            const int first = __builtin_ctzll(rem);
+                            const int g = __builtin_amdgcn_readlane(gid, first);
+                            const bool in_g = gid == g;
+                            GRAM_STEP(in_g ? ys[6 + 3 * lev] : 0.0f, in_g ? ys[7 + 3 * lev] : 0.0f) GRAM_STEP(in_g ? ys[8 + 3 * lev] : 0.0f, 0.0f)
+                            rem &= ~__ballot(in_g);
+                        }
+                    }
                 }
 #undef GRAM_STEP
-#undef GRAM_SNAP
                 for (int r = 0; r < 16; ++r) {
                     const int row = 32 * tr + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < nr && col <= row) sh_A[row * (row + 1) / 2 + col] = res[r];
+                    if (row < nr && col <= row) sh_A[row * (row + 1) / 2 + col] = acc[r];
                 }
             }
         }

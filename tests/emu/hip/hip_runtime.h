@@ -139,4 +139,16 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     return emu_exchange(src, (int)from);
 }
 static inline int __builtin_amdgcn_readlane(int v, int src_lane) { return emu_exchange(v, src_lane); }
+// v_permlane32_swap_b32: lanes 32-63 of the first operand change places with lanes 0-31 of the second
+typedef unsigned emu_u32x2 __attribute__((vector_size(8)));
+static inline emu_u32x2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned pa = emu_exchange(a, (int)(lane ^ 32u)), pb = emu_exchange(b, (int)(lane ^ 32u));
+    emu_u32x2 r;
+    r[0] = lane < 32u ? a : pb;
+    r[1] = lane < 32u ? pa : b;
+    return r;
+}
+static inline unsigned __float_as_uint(float f) { unsigned x; std::memcpy(&x, &f, 4); return x; }
+static inline float __uint_as_float(unsigned x) { float f; std::memcpy(&f, &x, 4); return f; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return emu_exchange(v, 0); }
