@@ -93,49 +93,50 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     const int lane = threadIdx.x;
     if (env >= d.n_env) return;
 
-    // ---------------------------------------------------------------- LDS: one blob, 13.3 KB per env (12 envs per CU)
+    // ---------------------------------------------------------------- LDS: one blob, 16 KB per env (8 envs per CU need <= 20 KB)
+    // Every per-body row starts on a 16-byte boundary and is padded to a multiple of four words, so a lane moves its row with
+    // ds_read_b128 / ds_write_b128 (R | r share a 12-word row; 6-vectors take 8 words, 21-word inertias 24, W 20).
     // Persistent part first, then the region G whose members are live in different phases of a substep:
     //   Ia (articulated inertias)   phase 3 only; its first 180 words hold the contact frames (height field) from phase 5 to 7
     //   I6, f                       phase 2 -> 3          pa   phases 3 and 7        a    phases 3-4 and 7
     //   V                           phase 1 -> end of 4   Vf   end of 4 -> 6a        Aacc phase 1 -> 2     fext phase 1b -> 2
     //   pw                          phase 1 -> 5          qw   phase 1
-    // The contact matrix (1830 words, phases 6b-6c) lies over [Ia tail .. fext], the limb-limb scratch (phase 1b) over
+    // The contact matrix (1830 words, phases 6b-6c) lies over [Ia tail .. ], the limb-limb scratch (phase 1b) over
     // [Ia tail .. a]; pw / qw stay out of both.  Barriers separate the phases.
-    enum { O_ROOT = 0, O_P = 16, O_PD = 24, O_R = O_PD + NB, O_r = O_R + NB * 9, O_W = O_r + NB * 3, O_K = O_W + NB * 18,
-           O_L0 = O_K + NB * 6, O_CB = O_L0 + 42, O_CX = O_CB + 2 * MAXC, O_CDIST = O_CX + 3 * MAXC, O_LAM = O_CDIST + MAXC,
+    enum { O_ROOT = 0, O_P = 16, O_PD = 24, O_R = O_PD + NB, O_W = O_R + NB * 12, O_K = O_W + NB * 20,
+           O_L0 = O_K + NB * 8, O_CB = O_L0 + 44, O_CX = O_CB + 2 * MAXC, O_CDIST = O_CX + 3 * MAXC, O_LAM = O_CDIST + MAXC,
            O_SLOT = O_LAM + MAXR, O_IA = O_SLOT + 32, O_G = O_IA + 180,
-           O_I6 = O_G + NB * 21 - 180, O_F = O_I6 + NB * 21, O_PA = O_F + NB * 6, O_A_ = O_PA + NB * 6, O_V = O_A_ + NB * 6,
-           O_VF = O_V + NB * 6, O_AACC = O_VF + NB * 6, O_FEXT = O_AACC + NB * 6, O_PW = O_FEXT + NB * 6, O_QW = O_PW + NB * 3,
-           LDS_WORDS = O_QW + NB * 4 };
-    static_assert(O_FEXT + NB * 6 - O_G >= MAXR * (MAXR + 1) / 2, "contact matrix does not fit its overlay");
+           O_I6 = O_IA + NB * 24, O_F = O_I6 + NB * 24, O_PA = O_F + NB * 8, O_A_ = O_PA + NB * 8, O_V = O_A_ + NB * 8,
+           O_VF = O_V + NB * 8, O_AACC = O_VF + NB * 8, O_FEXT = O_AACC + NB * 8, O_PQ = O_FEXT + NB * 8,
+           LDS_WORDS = O_PQ + NB * 8 };
+    static_assert(O_R % 4 == 0 && O_W % 4 == 0 && O_K % 4 == 0 && O_IA % 4 == 0 && O_I6 % 4 == 0 && O_F % 4 == 0 && O_PQ % 4 == 0, "rows must be 16-byte aligned");
+    static_assert(O_PQ - O_G >= MAXR * (MAXR + 1) / 2, "contact matrix does not fit its overlay");
     static_assert(O_V - O_G >= NB * 8 + EMLOCO_SC_MAXHITS * 8, "limb-limb scratch does not fit its overlay");
-    static_assert(LDS_WORDS * 4 <= 13648, "LDS per env above 160 KiB / 12");
-    __shared__ float lds[LDS_WORDS];
+    static_assert(LDS_WORDS * 4 <= 20480, "LDS per env above 160 KiB / 8");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_WORDS];
     float *sh_root = lds + O_ROOT;                            // p0[3] q0[4] V0[6]
     float *sh_P = lds + O_P;                                  // linear momentum: expected [0..2], of the current substep [3..5]; total mass [6]
     int *sh_pd = (int *)(lds + O_PD);                         // per body: parent | depth << 8 | index among the bodies of its depth << 16
-    float (*sh_R)[9] = (float (*)[9])(lds + O_R);
-    float (*sh_r)[3] = (float (*)[3])(lds + O_r);
-    float (*sh_W)[18] = (float (*)[18])(lds + O_W);
-    float (*sh_K)[6] = (float (*)[6])(lds + O_K);
+    float (*sh_R)[12] = (float (*)[12])(lds + O_R);           // rotation matrix [0..8] | position relative to O [9..11]
+    float (*sh_W)[20] = (float (*)[20])(lds + O_W);
+    float (*sh_K)[8] = (float (*)[8])(lds + O_K);
     float *sh_L0 = lds + O_L0, *sh_L0i = lds + O_L0 + 36;    // root Cholesky factor and 1 / its diagonal
     int *sh_cbody = (int *)(lds + O_CB), *sh_ccand = (int *)(lds + O_CB + MAXC);
     float (*sh_cx)[3] = (float (*)[3])(lds + O_CX);
     float *sh_cdist = lds + O_CDIST;
     float *sh_lam = lds + O_LAM;                              // per contact row: warm-start multiplier (6a), solved multiplier (after 6c)
     unsigned char *sh_slot = (unsigned char *)(lds + O_SLOT); // per candidate: its contact slot of the latest substep (255: none)
-    float (*sh_Ia)[21] = (float (*)[21])(lds + O_IA);
+    float (*sh_Ia)[24] = (float (*)[24])(lds + O_IA);
     float (*sh_cdir)[9] = (float (*)[9])(lds + O_IA);        // contact frames [normal | tangent 1 | tangent 2] (height-field ground)
-    float (*sh_I6)[21] = (float (*)[21])(lds + O_I6);
-    float (*sh_f)[6] = (float (*)[6])(lds + O_F);
-    float (*sh_pa)[6] = (float (*)[6])(lds + O_PA);
-    float (*sh_a)[6] = (float (*)[6])(lds + O_A_);
-    float (*sh_V)[6] = (float (*)[6])(lds + O_V);
-    float (*sh_Vf)[6] = (float (*)[6])(lds + O_VF);
-    float (*sh_Aacc)[6] = (float (*)[6])(lds + O_AACC);
-    float (*sh_fext)[6] = (float (*)[6])(lds + O_FEXT);      // limb-limb penalty wrench per body (self-collision), about O
-    float (*sh_pw)[3] = (float (*)[3])(lds + O_PW);
-    float (*sh_qw)[4] = (float (*)[4])(lds + O_QW);
+    float (*sh_I6)[24] = (float (*)[24])(lds + O_I6);
+    float (*sh_f)[8] = (float (*)[8])(lds + O_F);
+    float (*sh_pa)[8] = (float (*)[8])(lds + O_PA);
+    float (*sh_a)[8] = (float (*)[8])(lds + O_A_);
+    float (*sh_V)[8] = (float (*)[8])(lds + O_V);
+    float (*sh_Vf)[8] = (float (*)[8])(lds + O_VF);
+    float (*sh_Aacc)[8] = (float (*)[8])(lds + O_AACC);
+    float (*sh_fext)[8] = (float (*)[8])(lds + O_FEXT);      // limb-limb penalty wrench per body (self-collision), about O
+    float (*sh_pq)[8] = (float (*)[8])(lds + O_PQ);          // world position [0..2] | world rotation quaternion [4..7]
     float *sh_A = lds + O_G;                                  // contact matrix, lower triangle: (r, s<=r) at r(r+1)/2 + s
     const bool hf_on = d.hf != nullptr;      // wave-uniform
 
@@ -191,8 +192,8 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         if (lane == 0) {
             float q0[4] = {sh_root[3], sh_root[4], sh_root[5], sh_root[6]}, R[9];
             q2mat(q0, R);
-            for (int k = 0; k < 3; ++k) { sh_pw[0][k] = sh_root[k]; sh_r[0][k] = 0.0f; }
-            for (int k = 0; k < 4; ++k) sh_qw[0][k] = q0[k];
+            for (int k = 0; k < 3; ++k) { sh_pq[0][k] = sh_root[k]; sh_R[0][9 + k] = 0.0f; }
+            for (int k = 0; k < 4; ++k) sh_pq[0][4 + k] = q0[k];
             for (int k = 0; k < 9; ++k) sh_R[0][k] = R[k];
             for (int k = 0; k < 6; ++k) { sh_V[0][k] = sh_root[7 + k]; sh_Aacc[0][k] = 0.0f; }
         }
@@ -202,9 +203,9 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 const int p = bc.parent;
                 float Rp[9], o[3], qp[4], qw[4], pw[3], R[9], r[3], Sl[3][3], V[6];
                 for (int k = 0; k < 9; ++k) Rp[k] = sh_R[p][k];
-                for (int k = 0; k < 4; ++k) qp[k] = sh_qw[p][k];
+                for (int k = 0; k < 4; ++k) qp[k] = sh_pq[p][4 + k];
                 matvec3(Rp, bc.off, o);
-                for (int k = 0; k < 3; ++k) { pw[k] = sh_pw[p][k] + o[k]; r[k] = pw[k] - sh_root[k]; }
+                for (int k = 0; k < 3; ++k) { pw[k] = sh_pq[p][k] + o[k]; r[k] = pw[k] - sh_root[k]; }
                 qmul(qp, qj, qw);
                 qnormalize(qw);
                 q2mat(qw, R);
@@ -227,8 +228,8 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 cross3(vj, wv, t1);
                 cross3(r, cc, t2);
                 for (int k = 0; k < 3; ++k) cc[3 + k] = t1[k] + t2[k];
-                for (int k = 0; k < 3; ++k) { sh_pw[lane][k] = pw[k]; sh_r[lane][k] = r[k]; }
-                for (int k = 0; k < 4; ++k) sh_qw[lane][k] = qw[k];
+                for (int k = 0; k < 3; ++k) { sh_pq[lane][k] = pw[k]; sh_R[lane][9 + k] = r[k]; }
+                for (int k = 0; k < 4; ++k) sh_pq[lane][4 + k] = qw[k];
                 for (int k = 0; k < 9; ++k) sh_R[lane][k] = R[k];
                 for (int k = 0; k < 6; ++k) { sh_V[lane][k] = V[k]; sh_Aacc[lane][k] = sh_Aacc[p][k] + cc[k]; }
             }
@@ -256,7 +257,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     for (int k = 0; k < 3; ++k) cm[k] = d.com[mb0 * 3 + k];
                     for (int k = 0; k < 6; ++k) Vb[k] = sh_V[lane][k];
                     matvec3(Rb, cm, cw);
-                    for (int k = 0; k < 3; ++k) rc[k] = sh_r[lane][k] + cw[k];
+                    for (int k = 0; k < 3; ++k) rc[k] = sh_R[lane][9 + k] + cw[k];
                     cross3(Vb, rc, wx);
                     lm = d.mass[mb0];
                     for (int k = 0; k < 3; ++k) lp[k] = lm * (Vb[3 + k] + wx[k]);
@@ -289,7 +290,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 for (int k = 0; k < 3; ++k) cm[k] = d.com[mb0 * 3 + k];
                 for (int k = 0; k < 6; ++k) Vb[k] = sh_V[lane][k];
                 matvec3(Rb, cm, cw);
-                for (int k = 0; k < 3; ++k) rc[k] = sh_r[lane][k] + cw[k];
+                for (int k = 0; k < 3; ++k) rc[k] = sh_R[lane][9 + k] + cw[k];
                 cross3(Vb, rc, wx);
                 lm = d.mass[mb0];
                 for (int k = 0; k < 3; ++k) lp[k] = lm * (Vb[3 + k] + wx[k]);
@@ -325,7 +326,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             if (is_body) {
                 float R[9], r[3], ca[3], cb[3], pa[3], pb[3];
                 for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                for (int k = 0; k < 3; ++k) { r[k] = sh_r[lane][k]; ca[k] = d.sc_cap_a[mb0 * 3 + k]; cb[k] = d.sc_cap_b[mb0 * 3 + k]; }
+                for (int k = 0; k < 3; ++k) { r[k] = sh_R[lane][9 + k]; ca[k] = d.sc_cap_a[mb0 * 3 + k]; cb[k] = d.sc_cap_b[mb0 * 3 + k]; }
                 matvec3(R, ca, pa); matvec3(R, cb, pb);
                 for (int k = 0; k < 3; ++k) { sh_seg[lane * 8 + k] = r[k] + pa[k]; sh_seg[lane * 8 + 3 + k] = r[k] + pb[k]; }
                 sh_seg[lane * 8 + 6] = d.sc_cap_r[mb0];
@@ -393,7 +394,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         if (is_body) {
             float I6[21], f[6], R[9], r[3], V[6];
             for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-            for (int k = 0; k < 3; ++k) r[k] = sh_r[lane][k];
+            for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
             for (int k = 0; k < 6; ++k) V[k] = sh_V[lane][k];
             float Rc[9], Ic[9], cw[3], c[3], in6[6], bcom[3];
             for (int k = 0; k < 6; ++k) in6[k] = d.inertia[mb0 * 6 + k];      // mass properties: re-read per substep (L2 hits)
@@ -455,7 +456,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 float IA[21], Wm[18], Km[6];
                 float R[9], r[3], Sl[3][3];
                 for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                for (int k = 0; k < 3; ++k) r[k] = sh_r[lane][k];
+                for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
                 for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
                 for (int k = 0; k < 21; ++k) IA[k] = sh_I6[lane][k];
                 for (int k = 0; k < 6; ++k) pA[k] = sh_f[lane][k];
@@ -546,7 +547,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 float ap[6], t[3], a[6], Wm[18], Km[6];
                 float R[9], r[3], Sl[3][3];
                 for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                for (int k = 0; k < 3; ++k) r[k] = sh_r[lane][k];
+                for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
                 for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
                 for (int k = 0; k < 18; ++k) Wm[k] = sh_W[lane][k];
                 for (int k = 0; k < 6; ++k) Km[k] = sh_K[lane][k];
@@ -617,17 +618,17 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 float Rb[9], wp[3];
                 for (int k = 0; k < 9; ++k) Rb[k] = sh_R[cb[s]][k];
                 matvec3(Rb, clp[s], wp);
-                const float z = sh_pw[cb[s]][2] + wp[2];
+                const float z = sh_pq[cb[s]][2] + wp[2];
                 if (!hf_on) {
                     cdist[s] = (z - prm.ground_z) - crad[s];
-                    cxw[s][0] = sh_r[cb[s]][0] + wp[0];
-                    cxw[s][1] = sh_r[cb[s]][1] + wp[1];
-                    cxw[s][2] = (sh_r[cb[s]][2] + wp[2]) - crad[s];
+                    cxw[s][0] = sh_R[cb[s]][9] + wp[0];
+                    cxw[s][1] = sh_R[cb[s]][10] + wp[1];
+                    cxw[s][2] = (sh_R[cb[s]][11] + wp[2]) - crad[s];
                 } else {      // sphere of the candidate against the plane of the terrain triangle under its centre
                     float zt;
-                    hf_plane(d, sh_pw[cb[s]][0] + wp[0], sh_pw[cb[s]][1] + wp[1], zt, cnrm[s]);
+                    hf_plane(d, sh_pq[cb[s]][0] + wp[0], sh_pq[cb[s]][1] + wp[1], zt, cnrm[s]);
                     cdist[s] = (z - zt) * cnrm[s][2] - crad[s];
-                    for (int k = 0; k < 3; ++k) cxw[s][k] = (sh_r[cb[s]][k] + wp[k]) - crad[s] * cnrm[s][k];
+                    for (int k = 0; k < 3; ++k) cxw[s][k] = (sh_R[cb[s]][9 + k] + wp[k]) - crad[s] * cnrm[s][k];
                 }
                 act[s] = cdist[s] < prm.contact_offset;
             }
@@ -732,7 +733,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                         const int i = ci;
                         float Ri[9], ri[3], u[3], uhh[3];
                         for (int k = 0; k < 9; ++k) Ri[k] = sh_R[i][k];
-                        for (int k = 0; k < 3; ++k) ri[k] = sh_r[i][k];
+                        for (int k = 0; k < 3; ++k) ri[k] = sh_R[i][9 + k];
                         for (int a = 0; a < 3; ++a) {
                             float ax[3] = {Ri[a], Ri[3 + a], Ri[6 + a]}, sl[3];
                             cross3(ri, ax, sl);
@@ -905,7 +906,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                         float u[3], Wm[18], Km[6];
                         float R[9], r[3], Sl[3][3];
                         for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                        for (int k = 0; k < 3; ++k) r[k] = sh_r[lane][k];
+                        for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
                         for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
                         for (int k = 0; k < 18; ++k) Wm[k] = sh_W[lane][k];
                         for (int k = 0; k < 6; ++k) Km[k] = sh_K[lane][k];
@@ -940,7 +941,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     float ap[6], t[3], a[6], Wm[18], Km[6];
                     float R[9], r[3], Sl[3][3];
                     for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                    for (int k = 0; k < 3; ++k) r[k] = sh_r[lane][k];
+                    for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
                     for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
                     for (int k = 0; k < 18; ++k) Wm[k] = sh_W[lane][k];
                     for (int k = 0; k < 6; ++k) Km[k] = sh_K[lane][k];
@@ -1028,10 +1029,10 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         float *o = d.rb_state + ((long)env * NB + lane) * 13;
         float t[3], V[6], r[3];
         for (int k = 0; k < 6; ++k) V[k] = sh_V[lane][k];
-        for (int k = 0; k < 3; ++k) r[k] = sh_r[lane][k];
+        for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
         cross3(V, r, t);
-        for (int k = 0; k < 3; ++k) { o[k] = sh_pw[lane][k]; o[7 + k] = V[3 + k] + t[k]; o[10 + k] = V[k]; }
-        for (int k = 0; k < 4; ++k) o[3 + k] = sh_qw[lane][k];
+        for (int k = 0; k < 3; ++k) { o[k] = sh_pq[lane][k]; o[7 + k] = V[3 + k] + t[k]; o[10 + k] = V[k]; }
+        for (int k = 0; k < 4; ++k) o[3 + k] = sh_pq[lane][4 + k];
         if (lane >= 1) {
             float *ds = d.dof_state + ((long)env * NDOF + (lane - 1) * 3) * 2;
             for (int k = 0; k < 3; ++k) { ds[2 * k] = edof[k]; ds[2 * k + 1] = wj[k]; }
