@@ -105,7 +105,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     // [Ia tail .. a]; pw / qw stay out of both.  Barriers separate the phases.
     enum { O_ROOT = 0, O_P = 16, O_PD = 24, O_R = O_PD + NB, O_W = O_R + NB * 12, O_K = O_W + NB * 20,
            O_L0 = O_K + NB * 8, O_CB = O_L0 + 44, O_CX = O_CB + 2 * MAXC, O_CDIST = O_CX + 3 * MAXC, O_LAM = O_CDIST + MAXC,
-           O_SLOT = O_LAM + MAXR, O_IA = O_SLOT + 32, O_G = O_IA + 180,
+           O_SLOT = O_LAM + MAXR, O_CRANGE = O_SLOT + 32, O_IA = O_CRANGE + 2 * NB, O_G = O_IA + 180,
            O_I6 = O_IA + NB * 24, O_F = O_I6 + NB * 24, O_PA = O_F + NB * 8, O_A_ = O_PA + NB * 8, O_V = O_A_ + NB * 8,
            O_VF = O_V + NB * 8, O_AACC = O_VF + NB * 8, O_FEXT = O_AACC + NB * 8, O_PQ = O_FEXT + NB * 8,
            LDS_WORDS = O_PQ + NB * 8 };
@@ -125,6 +125,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     float (*sh_cx)[3] = (float (*)[3])(lds + O_CX);
     float *sh_cdist = lds + O_CDIST;
     float *sh_lam = lds + O_LAM;                              // per contact row: warm-start multiplier (6a), solved multiplier (after 6c)
+    int *sh_crange = (int *)(lds + O_CRANGE);                 // per body: first [0..NB) and last [NB..2NB) contact of the current substep
     unsigned char *sh_slot = (unsigned char *)(lds + O_SLOT); // per candidate: its contact slot of the latest substep (255: none)
     float (*sh_Ia)[24] = (float (*)[24])(lds + O_IA);
     float (*sh_cdir)[9] = (float (*)[9])(lds + O_IA);        // contact frames [normal | tangent 1 | tangent 2] (height-field ground)
@@ -694,6 +695,14 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         float J[6] = {0, 0, 0, 0, 0, 0}, rhs = 0.0f, lam = 0.0f;
         float ys[YLEN];                                   // this row's chain-propagation vector (level-indexed: the compiler keeps it in
                                                           // scratch); entries beyond the row's own chain are never written NOR read
+        // contacts come out of the compaction sorted by body (the candidate list is body-major): first / last contact of a body
+        if (is_body) { sh_crange[lane] = 0; sh_crange[NB + lane] = -1; }
+        __syncthreads();
+        if (lane < nc) {
+            const int cb_ = sh_cbody[lane];
+            if (lane == 0 || sh_cbody[lane - 1] != cb_) sh_crange[cb_] = lane;
+            if (lane == nc - 1 || sh_cbody[lane + 1] != cb_) sh_crange[NB + cb_] = lane;
+        }
         const int myc = lane / 3, myd = lane - 3 * myc;
         int rbody = 0, rdep = 0;
         unsigned code = 0u;
@@ -880,8 +889,9 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             float pin[6] = {0, 0, 0, 0, 0, 0};
             if (is_body) {
                 float cf[3] = {0, 0, 0};
-                for (int c = 0; c < nc; ++c)
-                    if (sh_cbody[c] == lane)
+                const int c_end = sh_crange[NB + lane];
+                for (int c = sh_crange[lane]; c <= c_end; ++c)
+                    {
                         for (int dr = 0; dr < 3; ++dr) {
                             float dir[3] = {dr == 1 ? 1.0f : 0.0f, dr == 2 ? 1.0f : 0.0f, dr == 0 ? 1.0f : 0.0f};
                             if (hf_on) for (int k = 0; k < 3; ++k) dir[k] = sh_cdir[c][3 * dr + k];
@@ -893,9 +903,14 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                             for (int k = 0; k < 6; ++k) pin[k] = fmaf(-Jr[k], l, pin[k]);
                             for (int k = 0; k < 3; ++k) cf[k] += dir[k] * l / h;
                         }
+                    }
                 if (last) for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = cf[k];
             }
-            for (int lev = d.max_depth; lev >= 0; --lev) {
+            // bodies deeper than every contact body carry no impulse and have no loaded descendant: their share of the up pass
+            // is exactly zero (uh = +0, pa = +0), so the pass starts at the deepest contact level
+            if (is_body && bc.depth > dmax) { uh[0] = uh[1] = uh[2] = 0.0f; for (int k = 0; k < 6; ++k) sh_pa[lane][k] = 0.0f; }
+            __syncthreads();
+            for (int lev = (d.max_depth < dmax ? d.max_depth : dmax); lev >= 0; --lev) {
                 if (is_body && bc.depth == lev) {
                     for (int k = 0; k < 6; ++k) pA[k] = pin[k];
                     for (int ci = 0; ci < 3; ++ci) {
