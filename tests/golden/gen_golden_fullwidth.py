@@ -1,0 +1,102 @@
+"""Full-width predictor goldens: the reference's TransMotionJTA (S = 453) and TransMotionJRDB (S = 246) at the production width
+(d = 128, 4 heads of 32, ff = 1024) with 1 local + 1 global layer, B = 2 scenes x N = 2 people, run on CPU.
+
+    python tests/golden/gen_golden_fullwidth.py     ->  tests/golden/predictor_fullwidth_{jta,jrdb}.npz
+
+Head dimension 32 is the one this repo's fused attention kernels serve, so these fixtures put them (and the d = 128 GEMM
+tiles) inside a comparison with reference output (the d = 32 fixtures take the composed attention path).  The weights come from
+tests/fullwidth_weights.py (a formula evaluated on both sides); the fixtures hold inputs, logits, losses and gradients
+(small tensors whole, large ones as strided samples).
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import _ref_shim as shim  # noqa: E402
+
+shim._MOCK_ROOTS.extend(["matplotlib", "torchvision", "pyemd"])
+shim.install_predictor()
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from fullwidth_weights import make_state_dict, sample  # noqa: E402
+
+PICK_WHOLE = ["fc_in_traj.weight", "fc_in_traj.bias", "local_former.layers.0.self_attn.in_proj_bias", "local_former.layers.0.norm1.weight",
+              "local_former.layers.0.norm2.bias", "local_former.layers.0.linear2.bias", "global_former.layers.0.self_attn.out_proj.bias",
+              "global_former.layers.0.norm2.weight"]
+PICK_SAMPLE = ["local_former.layers.0.self_attn.in_proj_weight", "local_former.layers.0.self_attn.out_proj.weight",
+               "local_former.layers.0.linear1.weight", "local_former.layers.0.linear2.weight", "global_former.layers.0.self_attn.in_proj_weight",
+               "global_former.layers.0.linear1.weight", "pose3d_encoder.learned_encoding.weight", "fc_in_3dpose.weight"]
+
+
+def run(kind):
+    torch.set_num_threads(8)
+    g = torch.Generator().manual_seed(31 if kind == "jta" else 37)
+    B, N = 2, 2
+    if kind == "jta":
+        import model_jta as M
+        from dataset_jta import batch_process_coords
+        from utils.metrics import MSE_LOSS as LOSS
+        J = 49
+        model = M.TransMotionJTA(tok_dim=453, nhid=128, nhead=4, dim_feedfwd=1024, nlayers_local=1, nlayers_global=1, nmode=4, output_scale=1,
+                                 obs_and_pred=21, num_tokens=J, device="cpu", multi_modal=False).float()
+        cfg = {"DEVICE": "cpu", "TRAIN": {"input_track_size": 9, "output_track_size": 12}}
+        head = "fc_out_traj.weight"
+    else:
+        import model_jrdb as M
+        from dataset_jrdb import batch_process_coords
+        from utils.metrics import MSE_LOSS_MULTI as LOSS
+        J = 26
+        model = M.TransMotionJRDB(tok_dim=246, nhid=128, nhead=4, dim_feedfwd=1024, nlayers_local=1, nlayers_global=1, nmode=4, output_scale=1,
+                                  obs_and_pred=21, num_tokens=J, device="cpu", multi_modal=True).float()
+        cfg = {"DEVICE": "cpu", "TRAIN": {"input_track_size": 9, "output_track_size": 12}, "DATA": {"train_datasets": ["jrdb_all_visual_cues"]}}
+        head = "predict_head.0.weight"
+    joints = torch.randn(B, N, 21, J, 4, generator=g) * 0.5
+    joints[:, :, :, 0, :2] = torch.cumsum(torch.randn(B, N, 21, 2, generator=g) * 0.3, dim=2)
+    masks = torch.ones(B, N, 21, J)
+    padding_mask = torch.zeros(B, N, dtype=torch.bool)
+    padding_mask[1, 1] = True                                         # one padded person
+    in_joints, _, out_joints, _, pm = batch_process_coords(joints.clone(), masks, padding_mask, cfg, training=(kind == "jta"))   # JRDB training mode applies a random (torchvision) rotation
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = make_state_dict(shapes, seed=1234)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.eval()
+    pred = model(in_joints.clone(), pm.clone())
+    loss = LOSS(pred[:, 9:], out_joints)
+    extra = {}
+    if kind == "jta":                                                 # EmLoco loss wiring (train_jta.py:288-308)
+        from learning.value_pose_net import ValuePoseNet
+        torch.manual_seed(5)
+        vnet = ValuePoseNet(use_pose=True, use_vel=True)
+        pose = torch.randn(B, 24, 3, generator=g) * 0.3
+        vel = (in_joints[:, 8, 0, :2] - in_joints[:, 7, 0, :2]) * 2.5
+        pred_traj = torch.cat([torch.zeros(B, 1, 2), pred[:, 9:, 0, :2]], dim=1)
+        value, vloss = vnet.calc_embodied_motion_loss(pred_traj, pose.clone(), vel.clone())
+        extra = dict(pose=pose, vel=vel, value=value.detach(), mse=loss.detach().clone(),
+                     **{"vn__" + k.replace(".", "__"): v for k, v in vnet.state_dict().items()})
+        loss = loss + 1.0 * vloss
+    loss.backward()
+    grads = {n_: p.grad.clone() for n_, p in model.named_parameters() if p.grad is not None}
+    out = dict(in_joints=in_joints, pm=pm, out_joints=out_joints, pred=pred.detach(), loss=loss.detach(),
+               weight_seed=np.array(1234), n_params=np.array(sum(int(np.prod(s)) for s in shapes.values())),
+               weight_checksum=np.array(float(sum(np.abs(v).sum(dtype=np.float64) for v in sd.values()))),
+               keys=np.array("\n".join(f"{k} {' '.join(map(str, shapes[k]))}" for k in sorted(shapes))), **extra)
+    for k in PICK_WHOLE + [head]:
+        out["grad__" + k.replace(".", "__")] = grads[k]
+    for k in PICK_SAMPLE:
+        out["gsample__" + k.replace(".", "__")] = sample(grads[k].numpy())
+    res = {}
+    for k, v in out.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        res[k] = np.asarray(v)
+    res["torch_version"] = np.array(torch.__version__)
+    np.savez_compressed(os.path.join(HERE, f"predictor_fullwidth_{kind}.npz"), **res)
+    print("wrote", kind, "params", int(res["n_params"]), "pred", res["pred"].shape, "loss", float(res["loss"]))
+
+
+if __name__ == "__main__":
+    for kind in sys.argv[1:] or ["jta", "jrdb"]:
+        run(kind)

@@ -326,3 +326,63 @@ def test_bf16_operand_mode_is_opt_in_and_within_its_stated_error(golden):
     assert torch.equal(ref, again)
     with pytest.raises(ValueError):
         ops.set_matmul_precision("fp8")
+
+
+@pytest.mark.parametrize("kind", ["jta", "jrdb"])
+def test_fullwidth_model_through_fused_attention_matches_reference(golden, kind, monkeypatch):
+    """The production width (d = 128, 4 heads of 32, ff = 1024; S = 453 for JTA, 246 for JRDB; 1 local + 1 global layer) against
+    output of the reference's own model code (tests/golden/gen_golden_fullwidth.py): logits, loss (JTA: MSE + EmLoco value loss)
+    and gradients within 1e-4 / 2e-4 of the tensor scale, with the fused attention kernels and the d = 128 GEMM tiles in the path.
+    Weights come from the formula both sides evaluate (tests/fullwidth_weights.py); key list and checksum are pinned."""
+    from fullwidth_weights import make_state_dict, sample
+    from emloco_amd.predictor import ops
+    from emloco_amd.predictor.train_jta import MSE_LOSS, MSE_LOSS_MULTI
+    g = golden(f"predictor_fullwidth_{kind}")
+    dev = "cuda:0"
+    if kind == "jta":
+        from emloco_amd.predictor.model_jta import TransMotionJTA
+        model = TransMotionJTA(tok_dim=453, nhid=128, nhead=4, dim_feedfwd=1024, nlayers_local=1, nlayers_global=1, nmode=4, output_scale=1,
+                               obs_and_pred=21, num_tokens=49, device=dev, multi_modal=False).to(dev).float()
+    else:
+        from emloco_amd.predictor.model_jrdb import TransMotionJRDB
+        model = TransMotionJRDB(tok_dim=246, nhid=128, nhead=4, dim_feedfwd=1024, nlayers_local=1, nlayers_global=1, nmode=4, output_scale=1,
+                                obs_and_pred=21, num_tokens=26, device=dev, multi_modal=True).to(dev).float()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert "\n".join(f"{k} {' '.join(map(str, shapes[k]))}" for k in sorted(shapes)) == str(g["keys"])     # same keys, same shapes
+    sd = make_state_dict(shapes, seed=int(g["weight_seed"]))
+    assert abs(sum(np.abs(v).sum(dtype=np.float64) for v in sd.values()) - float(g["weight_checksum"])) < 1e-6 * float(g["weight_checksum"])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.eval()
+    calls = {"n": 0}
+    orig = ops.FusedAttentionFn.apply
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    monkeypatch.setattr(ops.FusedAttentionFn, "apply", counted)
+    in_joints, pm, out_joints = (torch.from_numpy(g[k]).to(dev) for k in ("in_joints", "pm", "out_joints"))
+    pred = model(in_joints.clone(), pm.clone())
+    assert calls["n"] == 2                                              # local + global layer, both through the fused kernels
+    _close(pred.detach().cpu().numpy(), g["pred"], what=f"{kind} full-width logits")
+    if kind == "jta":
+        mse = MSE_LOSS(pred[:, 9:], out_joints)
+        _close(mse.item(), g["mse"], what="mse")
+        vnet = _vnet(g)
+        pred_traj = torch.cat([torch.zeros(pred.shape[0], 1, 2, device=dev), pred[:, 9:, 0, :2]], dim=1).contiguous()
+        value, vloss = vnet.calc_embodied_motion_loss(pred_traj, torch.from_numpy(g["pose"]).to(dev), torch.from_numpy(g["vel"]).to(dev))
+        _close(value.detach().cpu().numpy(), g["value"], what="LocoVal value")
+        loss = mse + 1.0 * vloss
+    else:
+        loss = MSE_LOSS_MULTI(pred[:, 9:], out_joints)
+    _close(loss.item(), g["loss"], what="loss")
+    loss.backward()
+    params = dict(model.named_parameters())
+    n_checked = 0
+    for k, v in g.items():
+        if k.startswith("grad__"):
+            _close(params[k[6:].replace("__", ".")].grad.cpu().numpy(), v, rel=2e-4, abs_=1e-6, what=k)
+            n_checked += 1
+        elif k.startswith("gsample__"):
+            _close(sample(params[k[9:].replace("__", ".")].grad.cpu().numpy()), v, rel=2e-4, abs_=1e-6, what=k)
+            n_checked += 1
+    assert n_checked >= 16

@@ -9,10 +9,11 @@ R=${1:-r01}
 OUT=$PWD/gpurun_out/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 100 --warmup 10 --no_cpu_baseline"
+BENCH="python $PWD/bench.py --steps 100 --warmup 10 --no_cpu_baseline --no_pipelined"
+T="timeout 900"      # a rocprofv3 pass that hangs must not eat the GPU budget
 
 # 1. kernel trace + stats of the bench command (env leg + JTA leg)
-rm -rf /tmp/prof_kt && (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $BENCH > "$OUT/bench_under_rocprof.log" 2>&1)
+rm -rf /tmp/prof_kt && (cd /tmp && $T rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $BENCH > "$OUT/bench_under_rocprof.log" 2>&1)
 f=$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && python - "$f" "$OUT/${R}_bench_kernel_stats_top.csv" <<'PY'
 import csv, sys
@@ -26,7 +27,7 @@ PY
 
 # 2. PMC passes (env leg only), one counter per pass
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/prof_$C && (cd /tmp && rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -- $BENCH --steps 20 --warmup 5 --no_jta > "$OUT/pmc_$C.log" 2>&1)
+  rm -rf /tmp/prof_$C && (cd /tmp && $T rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -- $BENCH --steps 20 --warmup 5 --no_jta > "$OUT/pmc_$C.log" 2>&1)
 done
 python - "$OUT/${R}_pmc_summary.txt" "$OUT/${R}_sim_step_hbm_bytes.json" <<'PY'
 import csv, glob, json, sys, collections
@@ -55,8 +56,8 @@ print("\n".join(lines))
 PY
 # 3. MFMA utilisation of the predictor kernels (JTA leg): busy cycles of the matrix pipes over all SIMDs vs GPU-active cycles
 JTA="$BENCH --steps 10 --warmup 2 --no_policy"      # the same command for the duration pass and the counter pass
-rm -rf /tmp/prof_mfma_kt && (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mfma_kt -- $JTA > "$OUT/mfma_kt.log" 2>&1)
-rm -rf /tmp/prof_mfma && (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/prof_mfma -- $JTA > "$OUT/pmc_mfma.log" 2>&1)
+rm -rf /tmp/prof_mfma_kt && (cd /tmp && $T rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mfma_kt -- $JTA > "$OUT/mfma_kt.log" 2>&1)
+rm -rf /tmp/prof_mfma && (cd /tmp && $T rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/prof_mfma -- $JTA > "$OUT/pmc_mfma.log" 2>&1)
 python - "$OUT/${R}_mfma_utilisation.txt" "$(find /tmp/prof_mfma_kt -name '*kernel_stats.csv' | head -1)" <<'PY'
 import csv, glob, sys, collections
 busy, n = collections.defaultdict(float), collections.defaultdict(int)
@@ -80,7 +81,7 @@ print("\n".join(lines))
 PY
 # 4. VALU occupancy of the rollout kernel (env leg): where the wave cycles of sim_step_kernel go.  SQ counters only (8 slots),
 #    its own pass; durations come from pass 1's kernel trace.
-rm -rf /tmp/prof_valu && (cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/prof_valu -- $BENCH --steps 20 --warmup 5 --no_jta --no_policy > "$OUT/pmc_valu.log" 2>&1)
+rm -rf /tmp/prof_valu && (cd /tmp && $T rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/prof_valu -- $BENCH --steps 20 --warmup 5 --no_jta --no_policy > "$OUT/pmc_valu.log" 2>&1)
 python - "$OUT/${R}_sim_step_valu.txt" "$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1)" <<'PY'
 import csv, glob, sys, collections
 agg = collections.defaultdict(list)
