@@ -41,7 +41,17 @@ struct AttnArgs {
     const float *dout;              // backward: [n_seq][S][d_model]
     float *dqkv;                    // backward: [n_seq][S][3 d_model]
     float *dsum;                    // backward: [n_seq * nhead][S]  D = rowsum(dO o O)
+    // dropout on the attention probabilities (nn.MultiheadAttention(dropout=p) in training mode): element (head-sequence bh,
+    // query, key) is kept iff drop_keep(drop_seed, (bh S + query) S + key, drop_p); kept probabilities are scaled by 1 / (1 - p).
+    // The softmax normaliser uses the undropped probabilities; the backward recomputes the mask from the same hash.
+    float drop_p, drop_scale;
+    unsigned drop_seed;
 };
+
+// counter-based keep mask, identical to predictor_kernels.hip: drop_keep (defined there; this file is compiled after it)
+__device__ __forceinline__ float at_keep(const AttnArgs &a, int bh, int query, int key) {
+    return drop_keep(a.drop_seed, ((unsigned long long)bh * a.S + (unsigned)query) * a.S + (unsigned)key, a.drop_p) ? a.drop_scale : 0.0f;
+}
 
 __device__ __forceinline__ int at_kappa(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 
@@ -127,7 +137,7 @@ __device__ __forceinline__ void at_store_rowT(float *dst, int h, const at_f32x16
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int PREC>
+template <int PREC, int DROP>
 __global__ void __launch_bounds__(256)
 attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[2][AT_T * AT_LD], Vs[2][AT_T * AT_LD], Bs[2][AT_T];
@@ -169,6 +179,10 @@ attn_fwd_kernel(AttnArgs a) {
         lsum = lsum * alpha + tsum;
         m = m_new;
         for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
+        if constexpr (DROP == 1) {                         // the output sums the dropped probabilities, the normaliser does not
+            const int k0 = t * AT_T;
+            for (int r = 0; r < 16; ++r) p[r] *= at_keep(a, bh, query, k0 + at_kappa(r, h));
+        }
         acc_o = at_xTp<PREC>(Vs[buf], l31, h, p, acc_o);     // O^T += V^T P^T
         at_stash4(Ks[buf ^ 1], tid, rk); at_stash4(Vs[buf ^ 1], tid, rv);
         if (tid < AT_T) Bs[buf ^ 1][tid] = rb;
@@ -182,7 +196,7 @@ attn_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward 1: dQ (and D)
-template <int PREC>
+template <int PREC, int DROP>
 __global__ void __launch_bounds__(256)
 attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[2][AT_T * AT_LD], Vs[2][AT_T * AT_LD], Bs[2][AT_T];
@@ -223,7 +237,9 @@ attn_bwd_dq_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) {
             const float v = st[r] * a.scale + bias[r];
             const float p = v > AT_NEG ? expf(v - lse) : 0.0f;
-            ds[r] = a.scale * p * (dpt[r] - dsum);
+            float dpr = dpt[r];                                           // d loss / d (dropped probability)
+            if constexpr (DROP == 1) dpr *= at_keep(a, bh, query, t * AT_T + at_kappa(r, h));
+            ds[r] = a.scale * p * (dpr - dsum);
         }
         acc = at_xTp<PREC>(Ks[buf], l31, h, ds, acc);                     // dQ^T += K^T dS^T
         at_stash4(Ks[buf ^ 1], tid, rk); at_stash4(Vs[buf ^ 1], tid, rv);
@@ -234,7 +250,7 @@ attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward 2: dK, dV
-template <int PREC>
+template <int PREC, int DROP>
 __global__ void __launch_bounds__(256)
 attn_bwd_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[2][AT_T * AT_LD], Os[2][AT_T * AT_LD], Ls[2][AT_T], Ds[2][AT_T];
@@ -272,7 +288,15 @@ attn_bwd_dkv_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) {
             const float v = s[r] * a.scale + bias;
             p[r] = v > AT_NEG ? expf(v - lrow[r]) : 0.0f;           // rows past the sequence carry lse = 3e38 -> 0
-            ds[r] = a.scale * p[r] * (dp[r] - drow[r]);
+            float dpr = dp[r];
+            if constexpr (DROP == 1) {
+                const float kp = at_keep(a, bh, t * AT_T + at_kappa(r, h), key);
+                dpr *= kp;
+                ds[r] = a.scale * p[r] * (dpr - drow[r]);
+                p[r] *= kp;                                                // dV sums the dropped probabilities
+            } else {
+                ds[r] = a.scale * p[r] * (dpr - drow[r]);
+            }
         }
         acc_v = at_xTp<PREC>(Os[buf], l31, h, p, acc_v);                  // dV^T += dO^T P
         acc_k = at_xTp<PREC>(Qs[buf], l31, h, ds, acc_k);                 // dK^T += Q^T dS

@@ -178,13 +178,22 @@ int emloco_attention_fwd(int n_seq, int S, int nhead, int d_model, float scale, 
 
 int emloco_attention_fwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                             float *out, float *lse, int flags, void *stream) {
-    if (n_seq < 1 || S < 1 || nhead < 1 || d_model != nhead * AT_DH || !qkv || !out || !lse)
-        return pfail(-1, "emloco_attention_fwd: bad argument (head dim must be 32)");
+    return emloco_attention_fwd_dropout(n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, flags, 0.0f, 0u, stream);
+}
+
+int emloco_attention_fwd_dropout(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 float *out, float *lse, int flags, float drop_p, uint32_t drop_seed, void *stream) {
+    if (n_seq < 1 || S < 1 || nhead < 1 || d_model != nhead * AT_DH || !qkv || !out || !lse || !(drop_p >= 0.0f && drop_p < 1.0f))
+        return pfail(-1, "emloco_attention_fwd: bad argument (head dim must be 32, 0 <= drop_p < 1)");
     if ((long)n_seq * nhead > 65535) return pfail(-1, "emloco_attention_fwd: n_seq * nhead exceeds the grid limit");
-    emloco::AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr};
+    emloco::AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr, drop_p, 1.0f / (1.0f - drop_p), drop_seed};
     const dim3 grid((unsigned)((S + 127) / 128), (unsigned)(n_seq * nhead));
-    if (flags & EMLOCO_ATTN_BF16) hipLaunchKernelGGL(emloco::attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(emloco::attn_fwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    const bool bf = (flags & EMLOCO_ATTN_BF16) != 0, dr = drop_p > 0.0f;
+    hipStream_t st = (hipStream_t)stream;
+    if (bf && dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    else if (bf) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 0>), grid, dim3(256), 0, st, a);
+    else if (dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<0, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((emloco::attn_fwd_kernel<0, 0>), grid, dim3(256), 0, st, a);
     PHIPCHK(hipGetLastError());
     return 0;
 }
@@ -196,17 +205,31 @@ int emloco_attention_bwd(int n_seq, int S, int nhead, int d_model, float scale, 
 
 int emloco_attention_bwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                             const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags, void *stream) {
-    if (n_seq < 1 || S < 1 || nhead < 1 || d_model != nhead * AT_DH || !qkv || !out || !lse || !dout || !dqkv || !dsum)
-        return pfail(-1, "emloco_attention_bwd: bad argument (head dim must be 32; dsum = n_seq * nhead * S floats)");
+    return emloco_attention_bwd_dropout(n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, dout, dqkv, dsum, flags, 0.0f, 0u, stream);
+}
+
+int emloco_attention_bwd_dropout(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags,
+                                 float drop_p, uint32_t drop_seed, void *stream) {
+    if (n_seq < 1 || S < 1 || nhead < 1 || d_model != nhead * AT_DH || !qkv || !out || !lse || !dout || !dqkv || !dsum ||
+        !(drop_p >= 0.0f && drop_p < 1.0f))
+        return pfail(-1, "emloco_attention_bwd: bad argument (head dim must be 32; dsum = n_seq * nhead * S floats; 0 <= drop_p < 1)");
     if ((long)n_seq * nhead > 65535) return pfail(-1, "emloco_attention_bwd: n_seq * nhead exceeds the grid limit");
-    emloco::AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, const_cast<float *>(out), const_cast<float *>(lse), dout, dqkv, dsum};
+    emloco::AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, const_cast<float *>(out), const_cast<float *>(lse), dout, dqkv, dsum,
+                       drop_p, 1.0f / (1.0f - drop_p), drop_seed};
     const dim3 grid((unsigned)((S + 127) / 128), (unsigned)(n_seq * nhead));
-    const bool bf = (flags & EMLOCO_ATTN_BF16) != 0;
-    if (bf) hipLaunchKernelGGL(emloco::attn_bwd_dq_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(emloco::attn_bwd_dq_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);      // also writes D = rowsum(dO o O)
+    const bool bf = (flags & EMLOCO_ATTN_BF16) != 0, dr = drop_p > 0.0f;
+    hipStream_t st = (hipStream_t)stream;
+    // first kernel: dQ, also writes D = rowsum(dO o O); second: dK, dV
+    if (bf && dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    else if (bf) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 0>), grid, dim3(256), 0, st, a);
+    else if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<0, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<0, 0>), grid, dim3(256), 0, st, a);
     PHIPCHK(hipGetLastError());
-    if (bf) hipLaunchKernelGGL(emloco::attn_bwd_dkv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(emloco::attn_bwd_dkv_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (bf && dr) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    else if (bf) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 0>), grid, dim3(256), 0, st, a);
+    else if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<0, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<0, 0>), grid, dim3(256), 0, st, a);
     PHIPCHK(hipGetLastError());
     return 0;
 }
@@ -305,6 +328,12 @@ int emloco_adamw_gated(int n, float *params, const float *grads, float *exp_avg,
     hipLaunchKernelGGL(emloco::adamw_gated_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, params, grads,
                        exp_avg, exp_avg_sq, steps_in, steps_out, tail2, lr, beta1, beta2, eps, weight_decay, stats);
     PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_dropout_keep_mask(uint32_t seed, uint64_t first_index, int64_t n, float p, uint8_t *host_out) {
+    if (n < 0 || !host_out || !(p >= 0.0f && p < 1.0f)) return pfail(-1, "emloco_dropout_keep_mask: bad argument");
+    for (int64_t i = 0; i < n; ++i) host_out[i] = emloco::drop_keep(seed, first_index + (uint64_t)i, p) ? 1 : 0;
     return 0;
 }
 

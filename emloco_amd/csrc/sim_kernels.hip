@@ -103,7 +103,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     //   pw                          phase 1 -> 5          qw   phase 1
     // The contact matrix (1830 words, phases 6b-6c) lies over [Ia tail .. ], the limb-limb scratch (phase 1b) over
     // [Ia tail .. a]; pw / qw stay out of both.  Barriers separate the phases.
-    enum { O_ROOT = 0, O_P = 16, O_PD = 24, O_R = O_PD + NB, O_W = O_R + NB * 12, O_K = O_W + NB * 20,
+    enum { O_ROOT = 0, O_P = 16, O_V0 = 24, O_PD = 36, O_R = O_PD + NB, O_W = O_R + NB * 12, O_K = O_W + NB * 20,
            O_L0 = O_K + NB * 8, O_CB = O_L0 + 44, O_CX = O_CB + 2 * MAXC, O_CDIST = O_CX + 3 * MAXC, O_LAM = O_CDIST + MAXC,
            O_SLOT = O_LAM + MAXR, O_CRANGE = O_SLOT + 32, O_IA = O_CRANGE + 2 * NB, O_G = O_IA + 180,
            O_I6 = O_IA + NB * 24, O_F = O_I6 + NB * 24, O_PA = O_F + NB * 8, O_A_ = O_PA + NB * 8, O_V = O_A_ + NB * 8,
@@ -115,6 +115,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     static_assert(LDS_WORDS * 4 <= 20480, "LDS per env above 160 KiB / 8");
     __shared__ __attribute__((aligned(16))) float lds[LDS_WORDS];
     float *sh_root = lds + O_ROOT;                            // p0[3] q0[4] V0[6]
+    float *sh_V0 = lds + O_V0;                                // lane 0's hand-over between phases: free root twist [0..5], impulse change [6..11]
     float *sh_P = lds + O_P;                                  // linear momentum: expected [0..2], of the current substep [3..5]; total mass [6]
     int *sh_pd = (int *)(lds + O_PD);                         // per body: parent | depth << 8 | index among the bodies of its depth << 16
     float (*sh_R)[12] = (float (*)[12])(lds + O_R);           // rotation matrix [0..8] | position relative to O [9..11]
@@ -150,7 +151,6 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     bc.nchild = 0;
     for (int k = 0; k < 3; ++k) { bc.child[k] = d.children[b * 3 + k]; bc.nchild += bc.child[k] >= 0; }
     const long mb0 = (long)env * NB + b;
-    for (int k = 0; k < 3; ++k) bc.off[k] = d.joint_off[mb0 * 3 + k];
     // drive gains / targets are re-read (L2 hits) where they are used instead of pinning 15 registers for the launch
     const long dof0 = (long)env * NDOF + (is_body && lane >= 1 ? (lane - 1) * 3 : 0);
     if (is_body) {
@@ -205,7 +205,8 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 float Rp[9], o[3], qp[4], qw[4], pw[3], R[9], r[3], Sl[3][3], V[6];
                 for (int k = 0; k < 9; ++k) Rp[k] = sh_R[p][k];
                 for (int k = 0; k < 4; ++k) qp[k] = sh_pq[p][4 + k];
-                matvec3(Rp, bc.off, o);
+                const float joff[3] = {d.joint_off[mb0 * 3], d.joint_off[mb0 * 3 + 1], d.joint_off[mb0 * 3 + 2]};   // re-read per substep (L2 hit)
+                matvec3(Rp, joff, o);
                 for (int k = 0; k < 3; ++k) { pw[k] = sh_pq[p][k] + o[k]; r[k] = pw[k] - sh_root[k]; }
                 qmul(qp, qj, qw);
                 qnormalize(qw);
@@ -580,11 +581,9 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             if (__ballot(over) == 0ull) break;
         }
         }   // pass
-        float wjf[3] = {0, 0, 0}, V0f[6];
         if (is_body) {
             for (int k = 0; k < 6; ++k) sh_Vf[lane][k] = fmaf(h, sh_a[lane][k], sh_V[lane][k]);
-            if (lane >= 1) for (int k = 0; k < 3; ++k) wjf[k] = fmaf(h, qdd[k], wj[k]);
-            if (lane == 0) for (int k = 0; k < 6; ++k) V0f[k] = fmaf(h, sh_a[0][k], sh_root[7 + k]);
+            if (lane == 0) for (int k = 0; k < 6; ++k) { sh_V0[k] = fmaf(h, sh_a[0][k], sh_root[7 + k]); sh_V0[6 + k] = 0.0f; }
         }
 
         PSTAMP(4);
@@ -882,7 +881,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
 
         PSTAMP(8);
         // ============================================================ 7. impulses -> velocity change (second solve)
-        float dq[3] = {0, 0, 0}, da0[6] = {0, 0, 0, 0, 0, 0};
+        float dq[3] = {0, 0, 0};
         if (is_body && last && nc == 0)
             for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = 0.0f;
         if (nc > 0) {
@@ -946,7 +945,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                             for (int k = a + 1; k < 6; ++k) acc = fmaf(-sh_L0[k * 6 + a], x[k], acc);
                             x[a] = acc * sh_L0i[a];
                         }
-                        for (int k = 0; k < 6; ++k) { sh_a[0][k] = x[k]; da0[k] = x[k]; }
+                        for (int k = 0; k < 6; ++k) { sh_a[0][k] = x[k]; sh_V0[6 + k] = x[k]; }
                     }
                 }
                 __syncthreads();
@@ -997,7 +996,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         if (is_body && lane >= 1) {
             float wn[3];
             for (int k = 0; k < 3; ++k) {
-                wn[k] = wjf[k] + dq[k];
+                wn[k] = fmaf(h, qdd[k], wj[k]) + dq[k];      // free joint rate of phase 4 + the impulses' share
                 if (last) {
                     const float kpk = d.kp[dof0 + k], kdk = d.kd[dof0 + k], tgk = d.pd_target[dof0 + k];
                     // torque applied over this substep (the contact impulses moved the implicit drive along; reported within the limit)
@@ -1018,7 +1017,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         }
         if (lane == 0) {
             float V0[6];
-            for (int k = 0; k < 6; ++k) V0[k] = V0f[k] + da0[k];
+            for (int k = 0; k < 6; ++k) V0[k] = sh_V0[k] + sh_V0[6 + k];
             for (int k = 0; k < 3; ++k) V0[k] *= damp;
             const float n = sqrtf(dot3(V0, V0));
             if (n > prm.max_ang_vel) { const float sc = prm.max_ang_vel / n; V0[0] *= sc; V0[1] *= sc; V0[2] *= sc; }

@@ -45,8 +45,8 @@ class EncoderLayer(nn.Module):
     def forward(self, x, key_pad):
         sa = self.self_attn
         qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
-        att = ops.attention(qkv, key_pad, sa.num_heads)
-        p = self.p if self.training else 0.0                 # the three nn.Dropout of the layer live in the GEMM epilogues
+        p = self.p if self.training else 0.0                 # the three nn.Dropout of the layer live in the GEMM epilogues,
+        att = ops.attention(qkv, key_pad, sa.num_heads, drop_p=p)   # MultiheadAttention's dropout on the probabilities in the attention kernels
         a = ops.linear(att, sa.out_proj.weight, sa.out_proj.bias, drop_p=p)
         x = ops.layer_norm(a, x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         h = ops.linear(x, self.linear1.weight, self.linear1.bias, relu=True, drop_p=p)

@@ -41,6 +41,9 @@ def _lib():
         lib.emloco_attention_bwd.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_attention_fwd_ex.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, ci, vp]
         lib.emloco_attention_bwd_ex.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+        lib.emloco_dropout_keep_mask.argtypes = [C.c_uint32, C.c_uint64, C.c_int64, cf, vp]
+        lib.emloco_attention_fwd_dropout.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, ci, cf, C.c_uint32, vp]
+        lib.emloco_attention_bwd_dropout.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, ci, cf, C.c_uint32, vp]
         lib.emloco_colsum_workspace.argtypes = [ci, ci]
         lib.emloco_colsum_workspace.restype = C.c_int64
         lib.emloco_layernorm_bwd_workspace.argtypes = [ci, ci]
@@ -198,21 +201,23 @@ class FusedAttentionFn(torch.autograd.Function):
     MAX_SEQ_HEADS = 65535
 
     @staticmethod
-    def forward(ctx, qkv, key_pad, nhead):
+    def forward(ctx, qkv, key_pad, nhead, drop_p=0.0, drop_seed=0):
         Bn, S, d3 = qkv.shape
         d = d3 // 3
         qkv = qkv.contiguous()
         key_pad = key_pad.contiguous() if key_pad is not None else None
         out = torch.empty((Bn, S, d), dtype=torch.float32, device=qkv.device)
         lse = torch.empty((Bn * nhead, S), dtype=torch.float32, device=qkv.device)
+        ctx.drop_p, ctx.drop_seed = float(drop_p), int(drop_seed)
         scale = 1.0 / float(d // nhead) ** 0.5
         lib, st = _lib(), _st(qkv)
         ctx.attn_flags = ATTN_BF16 if _matmul_precision[0] == "bf16" else 0      # the backward follows the forward's choice
         step = FusedAttentionFn.MAX_SEQ_HEADS // nhead
         for b0 in range(0, Bn, step):
             n = min(step, Bn - b0)
-            _chk(lib.emloco_attention_fwd_ex(n, S, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
-                                             _p(out, b0 * S * d), _p(lse, b0 * nhead * S), ctx.attn_flags, st), "emloco_attention_fwd_ex")
+            _chk(lib.emloco_attention_fwd_dropout(n, S, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
+                                                  _p(out, b0 * S * d), _p(lse, b0 * nhead * S), ctx.attn_flags, ctx.drop_p,
+                                                  (ctx.drop_seed + b0) & 0xFFFFFFFF, st), "emloco_attention_fwd_dropout")
         ctx.save_for_backward(qkv, key_pad, out, lse)
         ctx.nhead, ctx.scale = nhead, scale
         return out
@@ -230,18 +235,22 @@ class FusedAttentionFn(torch.autograd.Function):
         step = FusedAttentionFn.MAX_SEQ_HEADS // nhead
         for b0 in range(0, Bn, step):
             n = min(step, Bn - b0)
-            _chk(lib.emloco_attention_bwd_ex(n, S, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
-                                             _p(out, b0 * S * d), _p(lse, b0 * nhead * S), _p(dout, b0 * S * d), _p(dqkv, b0 * S * d3),
-                                             _p(dsum, b0 * nhead * S), ctx.attn_flags, st), "emloco_attention_bwd_ex")
-        return dqkv, None, None
+            _chk(lib.emloco_attention_bwd_dropout(n, S, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
+                                                  _p(out, b0 * S * d), _p(lse, b0 * nhead * S), _p(dout, b0 * S * d), _p(dqkv, b0 * S * d3),
+                                                  _p(dsum, b0 * nhead * S), ctx.attn_flags, ctx.drop_p, (ctx.drop_seed + b0) & 0xFFFFFFFF, st),
+                 "emloco_attention_bwd_dropout")
+        return dqkv, None, None, None, None
 
 
-def attention(qkv, key_pad, nhead):
-    """softmax(q k^T / sqrt(dh) + key_pad) v per head: the fused kernels for head dim 32 (the shipped d = 128, 4 heads),
-    the GEMM -> softmax -> GEMM composition otherwise."""
+def attention(qkv, key_pad, nhead, drop_p=0.0):
+    """dropout(softmax(q k^T / sqrt(dh) + key_pad)) v per head (nn.MultiheadAttention; dropout on the probabilities in training
+    mode: pass drop_p > 0): the fused kernels for head dim 32 (the shipped d = 128, 4 heads), the GEMM -> softmax -> GEMM
+    composition otherwise."""
     if qkv.shape[-1] // 3 // nhead == 32:
+        if drop_p > 0.0:
+            return FusedAttentionFn.apply(qkv, key_pad, nhead, float(drop_p), next_dropout_seed())
         return FusedAttentionFn.apply(qkv, key_pad, nhead)
-    return AttentionFn.apply(qkv, key_pad, nhead)
+    return AttentionFn.apply(qkv, key_pad, nhead, float(drop_p))
 
 
 class AttentionFn(torch.autograd.Function):
@@ -252,12 +261,17 @@ class AttentionFn(torch.autograd.Function):
     offset + leading dimension, so no permute copies are made.  P is kept for the backward (HBM is 288 GB)."""
 
     @staticmethod
-    def forward(ctx, qkv, key_pad, nhead):
+    def forward(ctx, qkv, key_pad, nhead, drop_p=0.0):
         Bn, S, d3 = qkv.shape
         d = d3 // 3
         dh = d // nhead
         qkv = qkv.contiguous()
         P = torch.empty((nhead, Bn, S, S), dtype=torch.float32, device=qkv.device)
+        # dropout on the probabilities (training): the mask multiplies the materialised P; the backward needs the dropped P for dV
+        # and mask * dP before the softmax backward, which uses the undropped P
+        M = None
+        if drop_p > 0.0:
+            M = (torch.rand((nhead, Bn, S, S), device=qkv.device) >= drop_p).float() / (1.0 - drop_p)
         out = torch.empty((Bn, S, d), dtype=torch.float32, device=qkv.device)
         scale = 1.0 / float(dh) ** 0.5
         lib = _lib()
@@ -265,14 +279,15 @@ class AttentionFn(torch.autograd.Function):
             Ph = P[h]
             gemm(Bn, S, S, dh, qkv, d3, S * d3, 0, qkv, d3, S * d3, 0, Ph, S, S * S, a_off=h * dh, b_off=d + h * dh)
             _chk(lib.emloco_softmax_fwd(Bn, S, S, scale, _p(Ph), _p(key_pad), _p(Ph), _st(qkv)), "emloco_softmax_fwd")
-            gemm(Bn, S, dh, S, Ph, S, S * S, 0, qkv, d3, S * d3, 1, out, d, S * d, b_off=2 * d + h * dh, c_off=h * dh)
-        ctx.save_for_backward(qkv, P)
+            Pd = Ph if M is None else (Ph * M[h]).contiguous()
+            gemm(Bn, S, dh, S, Pd, S, S * S, 0, qkv, d3, S * d3, 1, out, d, S * d, b_off=2 * d + h * dh, c_off=h * dh)
+        ctx.save_for_backward(qkv, P, M)
         ctx.nhead, ctx.scale = nhead, scale
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, P = ctx.saved_tensors
+        qkv, P, M = ctx.saved_tensors
         nhead, scale = ctx.nhead, ctx.scale
         Bn, S, d3 = qkv.shape
         d = d3 // 3
@@ -285,12 +300,15 @@ class AttentionFn(torch.autograd.Function):
             Ph = P[h]
             # dP = dO v^T ; dV = P^T dO
             gemm(Bn, S, S, dh, dout, d, S * d, 0, qkv, d3, S * d3, 0, dP, S, S * S, a_off=h * dh, b_off=2 * d + h * dh)
-            gemm(Bn, S, dh, S, Ph, S, S * S, 1, dout, d, S * d, 1, dqkv, d3, S * d3, b_off=h * dh, c_off=2 * d + h * dh)
+            Pd = Ph if M is None else (Ph * M[h]).contiguous()
+            gemm(Bn, S, dh, S, Pd, S, S * S, 1, dout, d, S * d, 1, dqkv, d3, S * d3, b_off=h * dh, c_off=2 * d + h * dh)
+            if M is not None:
+                dP.mul_(M[h])
             _chk(lib.emloco_softmax_bwd(Bn * S, S, scale, _p(Ph), _p(dP), _p(dP), _st(qkv)), "emloco_softmax_bwd")
             # dQ = dS k ; dK = dS^T q
             gemm(Bn, S, dh, S, dP, S, S * S, 0, qkv, d3, S * d3, 1, dqkv, d3, S * d3, b_off=d + h * dh, c_off=h * dh)
             gemm(Bn, S, dh, S, dP, S, S * S, 1, qkv, d3, S * d3, 1, dqkv, d3, S * d3, b_off=h * dh, c_off=d + h * dh)
-        return dqkv, None, None
+        return dqkv, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):

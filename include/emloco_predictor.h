@@ -81,6 +81,22 @@ int emloco_attention_fwd_ex(int n_seq, int S, int nhead, int d_model, float scal
 int emloco_attention_bwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                             const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags, void *stream);
 
+/* The same with dropout on the attention probabilities -- nn.MultiheadAttention(dropout = p) inside
+ * nn.TransformerEncoderLayer in training mode (model_jta.py:177-178): softmax -> dropout(p) -> . V.  Probability (bh, query,
+ * key) of the launch is kept iff hash(drop_seed, (bh S + query) S + key) >= drop_p (the counter-based mask of the GEMM epilogue
+ * dropout) and scaled by 1 / (1 - p); the backward recomputes the mask, so pass it the forward's (drop_p, drop_seed).
+ * drop_p = 0 is the call above. */
+int emloco_attention_fwd_dropout(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 float *out, float *lse, int flags, float drop_p, uint32_t drop_seed, void *stream);
+int emloco_attention_bwd_dropout(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags,
+                                 float drop_p, uint32_t drop_seed, void *stream);
+
+/* The counter-based keep mask of every fused dropout in this library (GEMM epilogues, attention probabilities), evaluated on the
+ * HOST: host_out[i] = 1 iff element first_index + i of a launch with `seed` is kept at rate p.  For tests and for callers that
+ * need the mask a kernel used. */
+int emloco_dropout_keep_mask(uint32_t seed, uint64_t first_index, int64_t n, float p, uint8_t *host_out);
+
 /* y = LayerNorm(x + res) * gamma + beta over the last dim (post-norm encoder layer, d <= 1024);
  * res may be NULL.  Saves mean / rstd [rows] for the backward. */
 int emloco_layernorm_fwd(int rows, int d, float eps, const float *x, const float *res, const float *gamma,

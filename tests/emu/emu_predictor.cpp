@@ -82,26 +82,32 @@ extern "C" int emu_locoval_bwd(int B, const float *traj, int ts, const float *po
 }
 
 static int g_attn_prec = 0;     // 1: bf16 operands (EMLOCO_ATTN_BF16)
+static float g_attn_drop_p = 0.0f;   // > 0: dropout on the probabilities with g_attn_drop_seed
+static unsigned g_attn_drop_seed = 0;
 extern "C" void emu_attention_set_precision(int p) { g_attn_prec = p; }
+extern "C" void emu_attention_set_dropout(float p, unsigned seed) { g_attn_drop_p = p; g_attn_drop_seed = seed; }
+extern "C" int emu_drop_keep(unsigned seed, unsigned long long idx, float p) { return emloco::drop_keep(seed, idx, p) ? 1 : 0; }
+#define ATTN_DISPATCH(K) do { const bool dr_ = g_attn_drop_p > 0.0f; \
+    if (g_attn_prec && dr_) K<1, 1>(a); else if (g_attn_prec) K<1, 0>(a); else if (dr_) K<0, 1>(a); else K<0, 0>(a); } while (0)
 extern "C" int emu_attention_fwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                                  float *out, float *lse) {
-    AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr};
+    AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr, g_attn_drop_p, 1.0f / (1.0f - g_attn_drop_p), g_attn_drop_seed};
     for (int y = 0; y < n_seq * nhead; ++y)
         for (int x = 0; x < (S + 127) / 128; ++x)
-            emu::launch(1, 256, [&] { blockIdx.x = x; blockIdx.y = y; if (g_attn_prec) attn_fwd_kernel<1>(a); else attn_fwd_kernel<0>(a); });
+            emu::launch(1, 256, [&] { blockIdx.x = x; blockIdx.y = y; ATTN_DISPATCH(attn_fwd_kernel); });
     blockIdx.x = 0; blockIdx.y = 0;
     return 0;
 }
 extern "C" int emu_attention_bwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                                  float *out, float *lse, const float *dout, float *dqkv, float *dsum) {
-    AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, dout, dqkv, dsum};
+    AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, dout, dqkv, dsum, g_attn_drop_p, 1.0f / (1.0f - g_attn_drop_p), g_attn_drop_seed};
     for (int pass = 0; pass < 2; ++pass)
         for (int y = 0; y < n_seq * nhead; ++y)
             for (int x = 0; x < (S + 127) / 128; ++x)
                 emu::launch(1, 256, [&] {
                     blockIdx.x = x; blockIdx.y = y;
-                    if (pass == 0) { if (g_attn_prec) attn_bwd_dq_kernel<1>(a); else attn_bwd_dq_kernel<0>(a); }
-                    else { if (g_attn_prec) attn_bwd_dkv_kernel<1>(a); else attn_bwd_dkv_kernel<0>(a); }
+                    if (pass == 0) { ATTN_DISPATCH(attn_bwd_dq_kernel); }
+                    else { ATTN_DISPATCH(attn_bwd_dkv_kernel); }
                 });
     blockIdx.x = 0; blockIdx.y = 0;
     return 0;

@@ -413,6 +413,53 @@ def test_fused_attention_kernels_forward_and_backward():
     assert np.all(out2 == 0)
 
 
+def test_fused_attention_kernels_with_dropout_on_the_probabilities():
+    """nn.MultiheadAttention(dropout = p) in training mode: softmax -> dropout -> . V.  The fused kernels with the counter-based
+    keep mask against a float64 attention that applies the SAME mask (the hash is evaluated on the host through the emulator
+    library): forward and all three gradients; the keep rate is 1 - p; p = 0 reproduces the plain kernels."""
+    lib = emu.lib()
+    lib.emu_attention_set_dropout.argtypes = [C.c_float, C.c_uint]
+    lib.emu_drop_keep.argtypes = [C.c_uint, C.c_ulonglong, C.c_float]
+    rng = np.random.default_rng(8)
+    n_seq, S, H = 2, 70, 2
+    d = H * 32
+    pdrop, seed = 0.1, 0xABCDEF
+    qkv = (rng.normal(size=(n_seq, S, 3 * d)) * 0.7).astype(np.float32)
+    kb = np.zeros((n_seq, S), np.float32)
+    kb[1, 60:] = -np.inf
+    scale = 1.0 / np.sqrt(32.0)
+    out, lse = np.zeros((n_seq, S, d), np.float32), np.zeros((n_seq * H, S), np.float32)
+    dout = rng.normal(size=out.shape).astype(np.float32)
+    dqkv, dsum = np.zeros_like(qkv), np.zeros((n_seq * H, S), np.float32)
+    try:
+        lib.emu_attention_set_dropout(pdrop, seed)
+        lib.emu_attention_fwd(n_seq, S, H, d, C.c_float(scale), P(qkv), P(kb), P(out), P(lse))
+        lib.emu_attention_bwd(n_seq, S, H, d, C.c_float(scale), P(qkv), P(kb), P(out), P(lse), P(dout), P(dqkv), P(dsum))
+    finally:
+        lib.emu_attention_set_dropout(0.0, 0)
+    keep = np.array([[[lib.emu_drop_keep(seed, (bh * S + i) * S + j, pdrop) for j in range(S)] for i in range(S)] for bh in range(n_seq * H)],
+                    np.float64).reshape(n_seq, H, S, S)
+    assert abs(keep.mean() - (1 - pdrop)) < 0.01
+    M = keep / (1 - pdrop)
+    q = qkv[..., :d].reshape(n_seq, S, H, 32).transpose(0, 2, 1, 3).astype(np.float64)
+    k = qkv[..., d:2 * d].reshape(n_seq, S, H, 32).transpose(0, 2, 1, 3).astype(np.float64)
+    v = qkv[..., 2 * d:].reshape(n_seq, S, H, 32).transpose(0, 2, 1, 3).astype(np.float64)
+    s = np.einsum("bhqd,bhkd->bhqk", q, k) * scale + kb[:, None, None, :].astype(np.float64)
+    e = np.exp(s - s.max(-1, keepdims=True))
+    p = e / e.sum(-1, keepdims=True)
+    pm = p * M
+    back = lambda t: t.transpose(0, 2, 1, 3).reshape(n_seq, S, d)
+    np.testing.assert_allclose(out, back(np.einsum("bhqk,bhkd->bhqd", pm, v)), rtol=1e-5, atol=3e-6)
+    do = dout.reshape(n_seq, S, H, 32).transpose(0, 2, 1, 3).astype(np.float64)
+    dv = np.einsum("bhqk,bhqd->bhkd", pm, do)
+    dp = np.einsum("bhqd,bhkd->bhqk", do, v) * M                      # gradient w.r.t. the undropped probabilities
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True)) * scale
+    np.testing.assert_allclose(dqkv[..., :d], back(np.einsum("bhqk,bhkd->bhqd", ds, k)), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(dqkv[..., d:2 * d], back(np.einsum("bhqk,bhqd->bhkd", ds, q)), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(dqkv[..., 2 * d:], back(dv), rtol=1e-4, atol=5e-6)
+    assert np.abs(out - back(np.einsum("bhqk,bhkd->bhqd", p, v))).max() > 1e-2      # ... and it is not the undropped attention
+
+
 def test_fused_attention_kernels_bf16_operands():
     """EMLOCO_ATTN_BF16: the same three kernels with the tile products on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16,
     fp32 accumulation, fp32 softmax statistics): within 2e-2 of the float64 attention (the stated bar of the reduced

@@ -386,3 +386,50 @@ def test_fullwidth_model_through_fused_attention_matches_reference(golden, kind,
             _close(sample(params[k[9:].replace("__", ".")].grad.cpu().numpy()), v, rel=2e-4, abs_=1e-6, what=k)
             n_checked += 1
     assert n_checked >= 16
+
+
+def test_fused_attention_dropout_matches_torch_with_the_same_mask():
+    """nn.MultiheadAttention(dropout = 0.1) in training mode (the reference's encoder layers, model_jta.py:177-178): the fused
+    kernels' dropout on the probabilities against float64 torch attention that applies the SAME keep mask (the library's
+    counter-based hash evaluated on the host): output and the gradient w.r.t. q, k, v; S = 453 with a padded person."""
+    import ctypes as C
+    from emloco_amd.predictor import ops
+    torch.manual_seed(4)
+    dev = "cuda:0"
+    Bn, S, H, d = 3, 453, 4, 128
+    pdrop, seed = 0.1, 0x1234567
+    qkv = (torch.randn(Bn, S, 3 * d, device=dev) * 0.6).requires_grad_(True)
+    pad = torch.zeros(Bn, S, device=dev)
+    pad[1] = 1.0
+    pad[2, 400:] = float("-inf")
+    dout = torch.randn(Bn, S, d, device=dev)
+    out = ops.FusedAttentionFn.apply(qkv, pad, H, pdrop, seed)
+    out.backward(dout)
+    lib = ops._lib()
+    keep = np.zeros(Bn * H * S * S, np.uint8)
+    assert lib.emloco_dropout_keep_mask(seed, 0, keep.size, pdrop, keep.ctypes.data_as(C.c_void_p)) == 0
+    assert abs(keep.mean() - 0.9) < 2e-3
+    M = torch.from_numpy(keep.reshape(Bn, H, S, S).astype(np.float64)).to(dev) / (1 - pdrop)
+    q64 = qkv.detach().double().requires_grad_(True)
+    qh, kh, vh = (q64[..., i * d:(i + 1) * d].view(Bn, S, H, 32).transpose(1, 2) for i in range(3))
+    s = qh @ kh.transpose(-1, -2) / np.sqrt(32.0) + pad.double()[:, None, None, :]
+    ref = ((torch.softmax(s, dim=-1) * M) @ vh).transpose(1, 2).reshape(Bn, S, d)
+    ref.backward(dout.double())
+    _close(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), what="dropout attention output")
+    _close(qkv.grad.cpu().numpy(), q64.grad.cpu().numpy(), rel=2e-4, abs_=1e-6, what="dropout attention gradient")
+    out0 = ops.FusedAttentionFn.apply(qkv.detach(), pad, H)
+    assert (out0 - out.detach()).abs().max().item() > 1e-2                   # ... and it differs from the undropped attention
+
+
+def test_encoder_layer_applies_attention_dropout_only_in_training():
+    from emloco_amd.predictor.model_jta import EncoderLayer
+    torch.manual_seed(0)
+    layer = EncoderLayer(128, 4, 256, 0.1).to("cuda:0")
+    x = torch.randn(2, 60, 128, device="cuda:0")
+    pad = torch.zeros(2, 60, device="cuda:0")
+    layer.eval()
+    a, b = layer(x, pad), layer(x, pad)
+    assert torch.equal(a, b)
+    layer.train()
+    c, e = layer(x, pad), layer(x, pad)
+    assert not torch.equal(c, e) and torch.isfinite(c).all()
