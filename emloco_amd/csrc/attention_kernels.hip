@@ -33,24 +33,34 @@ struct __attribute__((aligned(16))) at_f32x4 { float x, y, z, w; };
 
 struct AttnArgs {
     int n_seq, S, nhead, d_model;   // qkv [n_seq][S][3 d_model], d_model = nhead * 32
+    int Sq;                         // live queries: the first Sq <= S rows of every sequence attend (over all S keys); out, lse, dout,
+                                    // dsum have Sq rows per sequence.  The last layer of a former only feeds its first 21 tokens on.
     float scale;
     const float *qkv;
     const float *key_bias;          // [n_seq][S] additive (-inf masks a key) or NULL
-    float *out;                     // [n_seq][S][d_model]
-    float *lse;                     // [n_seq * nhead][S] log-sum-exp of the scaled, biased scores
-    const float *dout;              // backward: [n_seq][S][d_model]
-    float *dqkv;                    // backward: [n_seq][S][3 d_model]
-    float *dsum;                    // backward: [n_seq * nhead][S]  D = rowsum(dO o O)
-    // dropout on the attention probabilities (nn.MultiheadAttention(dropout=p) in training mode): element (head-sequence bh,
-    // query, key) is kept iff drop_keep(drop_seed, (bh S + query) S + key, drop_p); kept probabilities are scaled by 1 / (1 - p).
-    // The softmax normaliser uses the undropped probabilities; the backward recomputes the mask from the same hash.
+    float *out;                     // [n_seq][Sq][d_model]
+    float *lse;                     // [n_seq * nhead][Sq] log-sum-exp of the scaled, biased scores
+    const float *dout;              // backward: [n_seq][Sq][d_model]
+    float *dqkv;                    // backward: [n_seq][S][3 d_model]  (dQ of rows >= Sq: zero-filled by the launcher)
+    float *dsum;                    // backward: [n_seq * nhead][Sq]  D = rowsum(dO o O)
+    // dropout on the attention probabilities (nn.MultiheadAttention(dropout=p) in training mode): probability (head-sequence bh,
+    // query, key) is kept iff at_keep_bit(...) below (a 32-bit counter hash: the mask costs ~9 integer operations per element)
+    // and scaled by 1 / (1 - p).  The softmax normaliser uses the undropped probabilities; the backward recomputes the mask.
     float drop_p, drop_scale;
-    unsigned drop_seed;
+    unsigned drop_seed, drop_thr;   // drop_thr = (unsigned)(p * 2^24)
 };
 
-// counter-based keep mask, identical to predictor_kernels.hip: drop_keep (defined there; this file is compiled after it)
-__device__ __forceinline__ float at_keep(const AttnArgs &a, int bh, int query, int key) {
-    return drop_keep(a.drop_seed, ((unsigned long long)bh * a.S + (unsigned)query) * a.S + (unsigned)key, a.drop_p) ? a.drop_scale : 0.0f;
+// keep mask of the attention dropout: x = fmix32((fmix32(seed ^ bh c0) + query c1) ^ (key c2)), kept iff (x >> 8) >= p 2^24
+__host__ __device__ __forceinline__ unsigned at_fmix32(unsigned x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ unsigned at_head_key(unsigned seed, unsigned bh) { return at_fmix32(seed ^ (bh * 0x9E3779B1u)); }
+__host__ __device__ __forceinline__ bool at_keep_bit(unsigned head_key, unsigned query, unsigned key, unsigned thr) {
+    return (at_fmix32((head_key + query * 0x85EBCA6Bu) ^ (key * 0xC2B2AE35u)) >> 8) >= thr;
+}
+__device__ __forceinline__ float at_keep(const AttnArgs &a, unsigned head_key, int query, int key) {
+    return at_keep_bit(head_key, (unsigned)query, (unsigned)key, a.drop_thr) ? a.drop_scale : 0.0f;
 }
 
 __device__ __forceinline__ int at_kappa(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
@@ -143,12 +153,14 @@ attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[2][AT_T * AT_LD], Vs[2][AT_T * AT_LD], Bs[2][AT_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
+    const unsigned hkey = at_head_key(a.drop_seed, (unsigned)bh);
     const long ld = 3L * a.d_model;
     const float *Q = a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
     const float *kb = a.key_bias ? a.key_bias + (long)b * a.S : nullptr;
     const int query = blockIdx.x * 128 + wave * 32 + l31;
     at_f32x4 qf[4];
-    at_grow16(Q, ld, query, a.S, h, qf);
+    at_grow16(Q, ld, query, a.Sq, h, qf);
+    const bool live = blockIdx.x * 128 + wave * 32 < a.Sq;        // wave-uniform: waves past the live queries only help staging
     at_f32x16 acc_o;
     for (int r = 0; r < 16; ++r) acc_o[r] = 0.0f;
     float m = AT_NEG, lsum = 0.0f;
@@ -164,6 +176,7 @@ attn_fwd_kernel(AttnArgs a) {
         const int buf = t & 1, k0n = (t + 1) * AT_T;
         rk = at_fetch4(K, ld, k0n, a.S, tid); rv = at_fetch4(V, ld, k0n, a.S, tid);      // past the end: zeros, never used
         if (tid < AT_T) { const int kk = k0n + tid; const int kc = kk < a.S ? kk : a.S - 1; const float v = kb ? kb[kc] : 0.0f; rb = kk < a.S ? v : -INFINITY; }
+        if (live) {
         // scores^T tile: keys (rows) x own queries (lanes)
         at_f32x16 st = at_xyT<PREC>(Ks[buf], l31, h, qf);
         float bias[16], p[16];
@@ -181,17 +194,18 @@ attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
         if constexpr (DROP == 1) {                         // the output sums the dropped probabilities, the normaliser does not
             const int k0 = t * AT_T;
-            for (int r = 0; r < 16; ++r) p[r] *= at_keep(a, bh, query, k0 + at_kappa(r, h));
+            for (int r = 0; r < 16; ++r) p[r] *= at_keep(a, hkey, query, k0 + at_kappa(r, h));
         }
         acc_o = at_xTp<PREC>(Vs[buf], l31, h, p, acc_o);     // O^T += V^T P^T
+        }
         at_stash4(Ks[buf ^ 1], tid, rk); at_stash4(Vs[buf ^ 1], tid, rv);
         if (tid < AT_T) Bs[buf ^ 1][tid] = rb;
         __syncthreads();
     }
-    if (query < a.S) {
+    if (query < a.Sq) {
         const float inv = lsum > 0.0f ? 1.0f / lsum : 0.0f;            // fully masked row -> zeros ("safe softmax")
-        at_store_rowT(a.out + ((long)b * a.S + query) * a.d_model + hd * AT_DH, h, acc_o, inv);
-        if (h == 0 && a.lse) a.lse[(long)bh * a.S + query] = lsum > 0.0f ? m + logf(lsum) : 3.0e38f;
+        at_store_rowT(a.out + ((long)b * a.Sq + query) * a.d_model + hd * AT_DH, h, acc_o, inv);
+        if (h == 0 && a.lse) a.lse[(long)bh * a.Sq + query] = lsum > 0.0f ? m + logf(lsum) : 3.0e38f;
     }
 }
 
@@ -202,20 +216,22 @@ attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[2][AT_T * AT_LD], Vs[2][AT_T * AT_LD], Bs[2][AT_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
+    const unsigned hkey = at_head_key(a.drop_seed, (unsigned)bh);
     const long ld = 3L * a.d_model;
     const float *Q = a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
-    const float *dO = a.dout + (long)b * a.S * a.d_model + hd * AT_DH, *O = a.out + (long)b * a.S * a.d_model + hd * AT_DH;
+    const float *dO = a.dout + (long)b * a.Sq * a.d_model + hd * AT_DH, *O = a.out + (long)b * a.Sq * a.d_model + hd * AT_DH;
     const float *kb = a.key_bias ? a.key_bias + (long)b * a.S : nullptr;
     const int query = blockIdx.x * 128 + wave * 32 + l31;
     at_f32x4 qf[4], dof[4], of[4];
-    at_grow16(Q, ld, query, a.S, h, qf);
-    at_grow16(dO, a.d_model, query, a.S, h, dof);
-    at_grow16(O, a.d_model, query, a.S, h, of);
+    at_grow16(Q, ld, query, a.Sq, h, qf);
+    at_grow16(dO, a.d_model, query, a.Sq, h, dof);
+    at_grow16(O, a.d_model, query, a.Sq, h, of);
+    const bool live = blockIdx.x * 128 + wave * 32 < a.Sq;
     float dsum = 0.0f;                                 // D = sum_d dO O (the lane pair holds the two halves of d)
     for (int f = 0; f < 4; ++f) dsum += (dof[f].x * of[f].x + dof[f].y * of[f].y) + (dof[f].z * of[f].z + dof[f].w * of[f].w);
     dsum += __shfl_xor(dsum, 32);
-    const float lse = query < a.S ? a.lse[(long)bh * a.S + query] : 3.0e38f;
-    if (query < a.S && h == 0) a.dsum[(long)bh * a.S + query] = dsum;
+    const float lse = query < a.Sq ? a.lse[(long)bh * a.Sq + query] : 3.0e38f;
+    if (query < a.Sq && h == 0) a.dsum[(long)bh * a.Sq + query] = dsum;
     at_f32x16 acc;
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const int ntiles = (a.S + AT_T - 1) / AT_T;
@@ -230,6 +246,7 @@ attn_bwd_dq_kernel(AttnArgs a) {
         const int buf = t & 1, k0n = (t + 1) * AT_T;
         rk = at_fetch4(K, ld, k0n, a.S, tid); rv = at_fetch4(V, ld, k0n, a.S, tid);
         if (tid < AT_T) { const int kk = k0n + tid; const int kc = kk < a.S ? kk : a.S - 1; const float v = kb ? kb[kc] : 0.0f; rb = kk < a.S ? v : -INFINITY; }
+        if (live) {
         const at_f32x16 st = at_xyT<PREC>(Ks[buf], l31, h, qf);           // S^T
         const at_f32x16 dpt = at_xyT<PREC>(Vs[buf], l31, h, dof);         // dP^T = V dO^T
         float bias[16], ds[16];
@@ -238,15 +255,16 @@ attn_bwd_dq_kernel(AttnArgs a) {
             const float v = st[r] * a.scale + bias[r];
             const float p = v > AT_NEG ? expf(v - lse) : 0.0f;
             float dpr = dpt[r];                                           // d loss / d (dropped probability)
-            if constexpr (DROP == 1) dpr *= at_keep(a, bh, query, t * AT_T + at_kappa(r, h));
+            if constexpr (DROP == 1) dpr *= at_keep(a, hkey, query, t * AT_T + at_kappa(r, h));
             ds[r] = a.scale * p * (dpr - dsum);
         }
         acc = at_xTp<PREC>(Ks[buf], l31, h, ds, acc);                     // dQ^T += K^T dS^T
+        }
         at_stash4(Ks[buf ^ 1], tid, rk); at_stash4(Vs[buf ^ 1], tid, rv);
         if (tid < AT_T) Bs[buf ^ 1][tid] = rb;
         __syncthreads();
     }
-    if (query < a.S) at_store_rowT(a.dqkv + ((long)b * a.S + query) * ld + hd * AT_DH, h, acc, 1.0f);
+    if (query < a.Sq) at_store_rowT(a.dqkv + ((long)b * a.S + query) * ld + hd * AT_DH, h, acc, 1.0f);
 }
 
 // ------------------------------------------------------------------------------------------------ backward 2: dK, dV
@@ -256,10 +274,11 @@ attn_bwd_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[2][AT_T * AT_LD], Os[2][AT_T * AT_LD], Ls[2][AT_T], Ds[2][AT_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
+    const unsigned hkey = at_head_key(a.drop_seed, (unsigned)bh);
     const long ld = 3L * a.d_model;
     const float *Q = a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
-    const float *dO = a.dout + (long)b * a.S * a.d_model + hd * AT_DH;
-    const float *lse = a.lse + (long)bh * a.S, *dsm = a.dsum + (long)bh * a.S;
+    const float *dO = a.dout + (long)b * a.Sq * a.d_model + hd * AT_DH;
+    const float *lse = a.lse + (long)bh * a.Sq, *dsm = a.dsum + (long)bh * a.Sq;
     const int key = blockIdx.x * 128 + wave * 32 + l31;
     at_f32x4 kf[4], vf[4];
     at_grow16(K, ld, key, a.S, h, kf);
@@ -268,18 +287,18 @@ attn_bwd_dkv_kernel(AttnArgs a) {
     if (key < a.S) bias = a.key_bias ? a.key_bias[(long)b * a.S + key] : 0.0f;
     at_f32x16 acc_k, acc_v;
     for (int r = 0; r < 16; ++r) { acc_k[r] = 0.0f; acc_v[r] = 0.0f; }
-    const int ntiles = (a.S + AT_T - 1) / AT_T;
+    const int ntiles = (a.Sq + AT_T - 1) / AT_T;      // walks the live queries
 
-    at_f32x4 rq = at_fetch4(Q, ld, 0, a.S, tid), ro = at_fetch4(dO, a.d_model, 0, a.S, tid);
+    at_f32x4 rq = at_fetch4(Q, ld, 0, a.Sq, tid), ro = at_fetch4(dO, a.d_model, 0, a.Sq, tid);
     float rl = 3.0e38f, rd = 0.0f;
-    if (tid < AT_T && tid < a.S) { rl = lse[tid]; rd = dsm[tid]; }
+    if (tid < AT_T && tid < a.Sq) { rl = lse[tid]; rd = dsm[tid]; }
     at_stash4(Qs[0], tid, rq); at_stash4(Os[0], tid, ro);
     if (tid < AT_T) { Ls[0][tid] = rl; Ds[0][tid] = rd; }
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1, q0n = (t + 1) * AT_T;
-        rq = at_fetch4(Q, ld, q0n, a.S, tid); ro = at_fetch4(dO, a.d_model, q0n, a.S, tid);
-        if (tid < AT_T) { const int qq = q0n + tid; const int qc = qq < a.S ? qq : a.S - 1; const float l0 = lse[qc], d0 = dsm[qc]; rl = qq < a.S ? l0 : 3.0e38f; rd = qq < a.S ? d0 : 0.0f; }
+        rq = at_fetch4(Q, ld, q0n, a.Sq, tid); ro = at_fetch4(dO, a.d_model, q0n, a.Sq, tid);
+        if (tid < AT_T) { const int qq = q0n + tid; const int qc = qq < a.Sq ? qq : a.Sq - 1; const float l0 = lse[qc], d0 = dsm[qc]; rl = qq < a.Sq ? l0 : 3.0e38f; rd = qq < a.Sq ? d0 : 0.0f; }
         const at_f32x16 s = at_xyT<PREC>(Qs[buf], l31, h, kf);            // S: queries (rows) x own keys (lanes)
         const at_f32x16 dp = at_xyT<PREC>(Os[buf], l31, h, vf);           // dP = dO V^T
         float lrow[16], drow[16], p[16], ds[16];
@@ -290,7 +309,7 @@ attn_bwd_dkv_kernel(AttnArgs a) {
             p[r] = v > AT_NEG ? expf(v - lrow[r]) : 0.0f;           // rows past the sequence carry lse = 3e38 -> 0
             float dpr = dp[r];
             if constexpr (DROP == 1) {
-                const float kp = at_keep(a, bh, t * AT_T + at_kappa(r, h), key);
+                const float kp = at_keep(a, hkey, t * AT_T + at_kappa(r, h), key);
                 dpr *= kp;
                 ds[r] = a.scale * p[r] * (dpr - drow[r]);
                 p[r] *= kp;                                                // dV sums the dropped probabilities

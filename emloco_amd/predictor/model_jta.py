@@ -42,11 +42,16 @@ class EncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d)
         self.p = dropout
 
-    def forward(self, x, key_pad):
+    def forward(self, x, key_pad, live_rows=None):
+        """live_rows: only the first `live_rows` tokens of every sequence are read downstream (the last layer of a former):
+        they attend over all keys, and the out-projection / norms / feed-forward run on those rows only -> (Bn, live_rows, d).
+        Every row of a post-norm layer depends on the other rows through K and V alone, so the kept rows are unchanged."""
         sa = self.self_attn
         qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
         p = self.p if self.training else 0.0                 # the three nn.Dropout of the layer live in the GEMM epilogues,
-        att = ops.attention(qkv, key_pad, sa.num_heads, drop_p=p)   # MultiheadAttention's dropout on the probabilities in the attention kernels
+        att = ops.attention(qkv, key_pad, sa.num_heads, drop_p=p, n_query=live_rows)   # MultiheadAttention's dropout on the probabilities in the attention kernels
+        if live_rows is not None and live_rows < x.shape[1]:
+            x = x[:, :live_rows].contiguous()
         a = ops.linear(att, sa.out_proj.weight, sa.out_proj.bias, drop_p=p)
         x = ops.layer_norm(a, x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         h = ops.linear(x, self.linear1.weight, self.linear1.bias, relu=True, drop_p=p)
@@ -59,9 +64,10 @@ class Encoder(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList([EncoderLayer(d, nhead, dim_ff, dropout) for _ in range(num_layers)])
 
-    def forward(self, x, key_pad):
-        for layer in self.layers:
-            x = layer(x, key_pad)
+    def forward(self, x, key_pad, live_rows=None):
+        last = len(self.layers) - 1
+        for i, layer in enumerate(self.layers):
+            x = layer(x, key_pad, live_rows if i == last else None)
         return x
 
 
@@ -181,12 +187,18 @@ class TransMotionJTA(nn.Module):
         x = seq.permute(0, 2, 1, 3).reshape(B * N, S, self.nhid).contiguous()                        # batch-first (B*N, S, d)
         pad = self._key_bias(padding_mask.to(dev))                                                   # (B, N) additive
         pad_local = pad.reshape(-1, 1).expand(-1, S).contiguous()
-        out_local = self.local_former(x, pad_local) * self.output_scale + x
+        # only the 21 trajectory tokens of every person leave the local former (model_jta.py:316) and only the primary agent's
+        # rows leave the global one (:321): the last layer of each computes those rows alone (prune_dead_rows = False: all rows)
+        prune = getattr(self, "prune_dead_rows", True)
+        out_local = self.local_former(x, pad_local, 21 if prune else None) * self.output_scale + (x[:, :21] if prune else x)
         # global former over the N*21 trajectory tokens of each scene: (B, N*21, d), person-major like the reference
         g = out_local[:, :21].reshape(B, N * 21, self.nhid).contiguous()
         pad_global = pad.repeat_interleave(Fr, dim=1).contiguous()                                   # (B, N*21)
-        out_global = self.global_former(g, pad_global) * self.output_scale + g
-        out_primary = out_global.view(B, N, Fr, self.nhid)[:, 0]                                     # (B,F,d) primary agent
+        if prune:
+            out_primary = self.global_former(g, pad_global, Fr) * self.output_scale + g[:, :Fr]      # (B,F,d) primary agent
+        else:
+            out_global = self.global_former(g, pad_global) * self.output_scale + g
+            out_primary = out_global.view(B, N, Fr, self.nhid)[:, 0]
         if self.multi_modal:
             outs = [ops.linear(out_primary, h.weight, h.bias) for h in self.predict_head]
             return torch.stack(outs, dim=2)                                                          # (B,F,M,2)

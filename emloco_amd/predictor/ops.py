@@ -41,6 +41,9 @@ def _lib():
         lib.emloco_attention_bwd.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_attention_fwd_ex.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, ci, vp]
         lib.emloco_attention_bwd_ex.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+        lib.emloco_attention_fwd_queries.argtypes = [ci, ci, ci, ci, ci, cf, vp, vp, vp, vp, ci, cf, C.c_uint32, vp]
+        lib.emloco_attention_bwd_queries.argtypes = [ci, ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, ci, cf, C.c_uint32, vp]
+        lib.emloco_attention_keep_mask.argtypes = [C.c_uint32, ci, ci, cf, vp]
         lib.emloco_dropout_keep_mask.argtypes = [C.c_uint32, C.c_uint64, C.c_int64, cf, vp]
         lib.emloco_attention_fwd_dropout.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, ci, cf, C.c_uint32, vp]
         lib.emloco_attention_bwd_dropout.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, ci, cf, C.c_uint32, vp]
@@ -124,7 +127,7 @@ def _ksplit_for(red, out_elems):
     """Split a long reduction so the launch has enough workgroups (>= ~512) without a huge workspace."""
     tiles = max(1, (out_elems + 128 * 128 - 1) // (128 * 128))
     want = max(1, 512 // tiles)
-    return int(max(1, min(want, red // 256, 64)))
+    return int(max(1, min(want, red // 256, 512)))
 
 
 def colsum(X2d):
@@ -201,13 +204,14 @@ class FusedAttentionFn(torch.autograd.Function):
     MAX_SEQ_HEADS = 65535
 
     @staticmethod
-    def forward(ctx, qkv, key_pad, nhead, drop_p=0.0, drop_seed=0):
+    def forward(ctx, qkv, key_pad, nhead, drop_p=0.0, drop_seed=0, n_query=None):
         Bn, S, d3 = qkv.shape
         d = d3 // 3
+        Sq = S if n_query is None else int(n_query)
         qkv = qkv.contiguous()
         key_pad = key_pad.contiguous() if key_pad is not None else None
-        out = torch.empty((Bn, S, d), dtype=torch.float32, device=qkv.device)
-        lse = torch.empty((Bn * nhead, S), dtype=torch.float32, device=qkv.device)
+        out = torch.empty((Bn, Sq, d), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((Bn * nhead, Sq), dtype=torch.float32, device=qkv.device)
         ctx.drop_p, ctx.drop_seed = float(drop_p), int(drop_seed)
         scale = 1.0 / float(d // nhead) ** 0.5
         lib, st = _lib(), _st(qkv)
@@ -215,17 +219,17 @@ class FusedAttentionFn(torch.autograd.Function):
         step = FusedAttentionFn.MAX_SEQ_HEADS // nhead
         for b0 in range(0, Bn, step):
             n = min(step, Bn - b0)
-            _chk(lib.emloco_attention_fwd_dropout(n, S, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
-                                                  _p(out, b0 * S * d), _p(lse, b0 * nhead * S), ctx.attn_flags, ctx.drop_p,
-                                                  (ctx.drop_seed + b0) & 0xFFFFFFFF, st), "emloco_attention_fwd_dropout")
+            _chk(lib.emloco_attention_fwd_queries(n, S, Sq, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
+                                                  _p(out, b0 * Sq * d), _p(lse, b0 * nhead * Sq), ctx.attn_flags, ctx.drop_p,
+                                                  (ctx.drop_seed + b0) & 0xFFFFFFFF, st), "emloco_attention_fwd_queries")
         ctx.save_for_backward(qkv, key_pad, out, lse)
-        ctx.nhead, ctx.scale = nhead, scale
+        ctx.nhead, ctx.scale, ctx.Sq = nhead, scale, Sq
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, key_pad, out, lse = ctx.saved_tensors
-        nhead, scale = ctx.nhead, ctx.scale
+        nhead, scale, Sq = ctx.nhead, ctx.scale, ctx.Sq
         Bn, S, d3 = qkv.shape
         d = d3 // 3
         dout = dout.contiguous()
@@ -235,22 +239,24 @@ class FusedAttentionFn(torch.autograd.Function):
         step = FusedAttentionFn.MAX_SEQ_HEADS // nhead
         for b0 in range(0, Bn, step):
             n = min(step, Bn - b0)
-            _chk(lib.emloco_attention_bwd_dropout(n, S, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
-                                                  _p(out, b0 * S * d), _p(lse, b0 * nhead * S), _p(dout, b0 * S * d), _p(dqkv, b0 * S * d3),
-                                                  _p(dsum, b0 * nhead * S), ctx.attn_flags, ctx.drop_p, (ctx.drop_seed + b0) & 0xFFFFFFFF, st),
-                 "emloco_attention_bwd_dropout")
-        return dqkv, None, None, None, None
+            _chk(lib.emloco_attention_bwd_queries(n, S, Sq, nhead, d, scale, _p(qkv, b0 * S * d3), _p(key_pad, b0 * S) if key_pad is not None else None,
+                                                  _p(out, b0 * Sq * d), _p(lse, b0 * nhead * Sq), _p(dout, b0 * Sq * d), _p(dqkv, b0 * S * d3),
+                                                  _p(dsum, b0 * nhead * Sq), ctx.attn_flags, ctx.drop_p, (ctx.drop_seed + b0) & 0xFFFFFFFF, st),
+                 "emloco_attention_bwd_queries")
+        return dqkv, None, None, None, None, None
 
 
-def attention(qkv, key_pad, nhead, drop_p=0.0):
+def attention(qkv, key_pad, nhead, drop_p=0.0, n_query=None):
     """dropout(softmax(q k^T / sqrt(dh) + key_pad)) v per head (nn.MultiheadAttention; dropout on the probabilities in training
     mode: pass drop_p > 0): the fused kernels for head dim 32 (the shipped d = 128, 4 heads), the GEMM -> softmax -> GEMM
-    composition otherwise."""
+    composition otherwise.  n_query: only the first n_query rows of every sequence attend -> (Bn, n_query, d)."""
+    if n_query is not None and n_query >= qkv.shape[1]:
+        n_query = None
     if qkv.shape[-1] // 3 // nhead == 32:
-        if drop_p > 0.0:
-            return FusedAttentionFn.apply(qkv, key_pad, nhead, float(drop_p), next_dropout_seed())
-        return FusedAttentionFn.apply(qkv, key_pad, nhead)
-    return AttentionFn.apply(qkv, key_pad, nhead, float(drop_p))
+        seed = next_dropout_seed() if drop_p > 0.0 else 0
+        return FusedAttentionFn.apply(qkv, key_pad, nhead, float(drop_p), seed, n_query)
+    out = AttentionFn.apply(qkv, key_pad, nhead, float(drop_p))
+    return out if n_query is None else out[:, :n_query].contiguous()
 
 
 class AttentionFn(torch.autograd.Function):

@@ -83,16 +83,27 @@ int emloco_attention_bwd_ex(int n_seq, int S, int nhead, int d_model, float scal
 
 /* The same with dropout on the attention probabilities -- nn.MultiheadAttention(dropout = p) inside
  * nn.TransformerEncoderLayer in training mode (model_jta.py:177-178): softmax -> dropout(p) -> . V.  Probability (bh, query,
- * key) of the launch is kept iff hash(drop_seed, (bh S + query) S + key) >= drop_p (the counter-based mask of the GEMM epilogue
- * dropout) and scaled by 1 / (1 - p); the backward recomputes the mask, so pass it the forward's (drop_p, drop_seed).
- * drop_p = 0 is the call above. */
+ * key) of the launch (bh = sequence * nhead + head) is kept iff a 32-bit counter hash of (drop_seed, bh, query, key) clears
+ * p 2^24 (emloco_attention_keep_mask evaluates it on the host) and scaled by 1 / (1 - p); the backward recomputes the mask, so
+ * pass it the forward's (drop_p, drop_seed).  drop_p = 0 is the call above. */
 int emloco_attention_fwd_dropout(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                                  float *out, float *lse, int flags, float drop_p, uint32_t drop_seed, void *stream);
 int emloco_attention_bwd_dropout(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                                  const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags,
                                  float drop_p, uint32_t drop_seed, void *stream);
 
-/* The counter-based keep mask of every fused dropout in this library (GEMM epilogues, attention probabilities), evaluated on the
+/* The same with only the FIRST n_query <= S rows of every sequence attending (over all S keys): out [n_seq][n_query][d_model],
+ * lse / dsum [n_seq * nhead][n_query], dout [n_seq][n_query][d_model]; dqkv stays [n_seq][S][3 d_model] with dQ = 0 on the rows
+ * that did not attend.  The last layer of a former only feeds its first 21 tokens on (model_jta.py:316 `out_local[:21]`,
+ * :321 the primary agent's rows), so the rows nothing reads are not computed; n_query = S is the call above. */
+int emloco_attention_fwd_queries(int n_seq, int S, int n_query, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 float *out, float *lse, int flags, float drop_p, uint32_t drop_seed, void *stream);
+int emloco_attention_bwd_queries(int n_seq, int S, int n_query, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags,
+                                 float drop_p, uint32_t drop_seed, void *stream);
+/* host_out [n_seq_heads][S][S] = 1 where the attention dropout above keeps the probability */
+int emloco_attention_keep_mask(uint32_t seed, int n_seq_heads, int S, float p, uint8_t *host_out);
+/* The counter-based keep mask of the GEMM-epilogue dropout, evaluated on the
  * HOST: host_out[i] = 1 iff element first_index + i of a launch with `seed` is kept at rate p.  For tests and for callers that
  * need the mask a kernel used. */
 int emloco_dropout_keep_mask(uint32_t seed, uint64_t first_index, int64_t n, float p, uint8_t *host_out);

@@ -86,24 +86,32 @@ static float g_attn_drop_p = 0.0f;   // > 0: dropout on the probabilities with g
 static unsigned g_attn_drop_seed = 0;
 extern "C" void emu_attention_set_precision(int p) { g_attn_prec = p; }
 extern "C" void emu_attention_set_dropout(float p, unsigned seed) { g_attn_drop_p = p; g_attn_drop_seed = seed; }
-extern "C" int emu_drop_keep(unsigned seed, unsigned long long idx, float p) { return emloco::drop_keep(seed, idx, p) ? 1 : 0; }
+extern "C" int emu_attn_keep(unsigned seed, unsigned bh, unsigned q, unsigned k, float p) { return emloco::at_keep_bit(emloco::at_head_key(seed, bh), q, k, (unsigned)(p * 16777216.0f)) ? 1 : 0; }
 #define ATTN_DISPATCH(K) do { const bool dr_ = g_attn_drop_p > 0.0f; \
     if (g_attn_prec && dr_) K<1, 1>(a); else if (g_attn_prec) K<1, 0>(a); else if (dr_) K<0, 1>(a); else K<0, 0>(a); } while (0)
-extern "C" int emu_attention_fwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
-                                 float *out, float *lse) {
-    AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr, g_attn_drop_p, 1.0f / (1.0f - g_attn_drop_p), g_attn_drop_seed};
+extern "C" int emu_attention_fwd_queries(int n_seq, int S, int Sq, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                         float *out, float *lse) {
+    AttnArgs a{n_seq, S, nhead, d_model, Sq, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr, g_attn_drop_p, 1.0f / (1.0f - g_attn_drop_p), g_attn_drop_seed, (unsigned)(g_attn_drop_p * 16777216.0f)};
     for (int y = 0; y < n_seq * nhead; ++y)
-        for (int x = 0; x < (S + 127) / 128; ++x)
+        for (int x = 0; x < (Sq + 127) / 128; ++x)
             emu::launch(1, 256, [&] { blockIdx.x = x; blockIdx.y = y; ATTN_DISPATCH(attn_fwd_kernel); });
     blockIdx.x = 0; blockIdx.y = 0;
     return 0;
 }
-extern "C" int emu_attention_bwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
-                                 float *out, float *lse, const float *dout, float *dqkv, float *dsum) {
-    AttnArgs a{n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, dout, dqkv, dsum, g_attn_drop_p, 1.0f / (1.0f - g_attn_drop_p), g_attn_drop_seed};
+extern "C" int emu_attention_fwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 float *out, float *lse) {
+    return emu_attention_fwd_queries(n_seq, S, S, nhead, d_model, scale, qkv, key_bias, out, lse);
+}
+// as emloco_attention_bwd_queries: the launcher zero-fills the dQ third of the rows that did not attend
+extern "C" int emu_attention_bwd_queries(int n_seq, int S, int Sq, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                         float *out, float *lse, const float *dout, float *dqkv, float *dsum) {
+    AttnArgs a{n_seq, S, nhead, d_model, Sq, scale, qkv, key_bias, out, lse, dout, dqkv, dsum, g_attn_drop_p, 1.0f / (1.0f - g_attn_drop_p), g_attn_drop_seed, (unsigned)(g_attn_drop_p * 16777216.0f)};
+    if (Sq < S)
+        for (long r = 0; r < (long)n_seq * S; ++r)
+            for (int c = 0; c < d_model; ++c) dqkv[r * 3 * d_model + c] = 0.0f;
     for (int pass = 0; pass < 2; ++pass)
         for (int y = 0; y < n_seq * nhead; ++y)
-            for (int x = 0; x < (S + 127) / 128; ++x)
+            for (int x = 0; x < ((pass == 0 ? Sq : S) + 127) / 128; ++x)
                 emu::launch(1, 256, [&] {
                     blockIdx.x = x; blockIdx.y = y;
                     if (pass == 0) { ATTN_DISPATCH(attn_bwd_dq_kernel); }
@@ -111,6 +119,10 @@ extern "C" int emu_attention_bwd(int n_seq, int S, int nhead, int d_model, float
                 });
     blockIdx.x = 0; blockIdx.y = 0;
     return 0;
+}
+extern "C" int emu_attention_bwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 float *out, float *lse, const float *dout, float *dqkv, float *dsum) {
+    return emu_attention_bwd_queries(n_seq, S, S, nhead, d_model, scale, qkv, key_bias, out, lse, dout, dqkv, dsum);
 }
 
 extern "C" int emu_locoval_returns(const EmlocoLocoValStep *t, const float *rewards, const float *amp, const int64_t *dones, const uint8_t *inv) {

@@ -3,6 +3,7 @@
 #include "hip/hip_runtime.h"
 #include <ucontext.h>
 #include <cstdlib>
+#include <cstdio>
 
 emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 
@@ -24,7 +25,12 @@ static void trampoline() {
     swapcontext(&g_ctx[g_cur], &g_sched);
 }
 
-void barrier() { swapcontext(&g_ctx[g_cur], &g_sched); }
+// A fiber parks at a workgroup barrier (2) or at a wavefront-scope exchange (1: shuffles, ballots, matrix instructions).  The
+// scheduler releases a wave when every live lane of it is parked at scope 1, and the workgroup when every live fiber is parked
+// at scope 2 -- so wave-uniform branches around wave operations (one wave skips a tile product) keep their meaning.
+static std::vector<int> g_wait;
+void barrier() { g_wait[g_cur] = 2; swapcontext(&g_ctx[g_cur], &g_sched); }
+void wave_barrier() { g_wait[g_cur] = 1; swapcontext(&g_ctx[g_cur], &g_sched); }
 
 void launch_impl(unsigned grid, unsigned block, const std::function<void()> &body) {
     g_body = &body;
@@ -44,15 +50,35 @@ void launch_impl(unsigned grid, unsigned block, const std::function<void()> &bod
             makecontext(&g_ctx[t], trampoline, 0);
             g_alive[t] = 1;
         }
+        g_wait.assign(block, 0);
         bool any = true;
         while (any) {
             any = false;
+            bool ran = false;
             for (unsigned t = 0; t < block; ++t)
-                if (g_alive[t]) {
+                if (g_alive[t] && g_wait[t] == 0) {
                     g_cur = (int)t; threadIdx.x = t;
                     swapcontext(&g_sched, &g_ctx[t]);
-                    any = any || g_alive[t];
+                    ran = true;
                 }
+            bool released = false, all_block = true;
+            for (unsigned w0 = 0; w0 < block; w0 += 64) {
+                bool some = false, all_wave = true;
+                for (unsigned t = w0; t < w0 + 64 && t < block; ++t)
+                    if (g_alive[t]) { any = true; some = true; all_wave = all_wave && g_wait[t] == 1; all_block = all_block && g_wait[t] == 2; }
+                if (some && all_wave) {
+                    for (unsigned t = w0; t < w0 + 64 && t < block; ++t) g_wait[t] = 0;
+                    released = true;
+                }
+            }
+            if (any && all_block) {
+                for (unsigned t = 0; t < block; ++t) g_wait[t] = 0;
+                released = true;
+            }
+            if (any && !ran && !released) {
+                std::fprintf(stderr, "emu: deadlock -- lanes of one wave wait at different scopes (divergent barrier)\n");
+                std::abort();
+            }
         }
     }
 }

@@ -29,6 +29,7 @@ extern emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 // lock-step-between-barriers semantics the kernels rely on, at ~0.1 us per switch.
 namespace emu {
 void barrier();
+void wave_barrier();
 void launch_impl(unsigned grid, unsigned block, const std::function<void()> &body);
 extern uint64_t g_xbuf[1024];
 template <class F> void launch(unsigned grid, unsigned block, F body) { launch_impl(grid, block, std::function<void()>(body)); }
@@ -40,9 +41,9 @@ template <class T> static inline T emu_exchange(T v, int src) {
     static_assert(sizeof(T) <= 8, "");
     uint64_t raw = 0; std::memcpy(&raw, &v, sizeof(T));
     emu::g_xbuf[threadIdx.x] = raw;
-    emu::barrier();
+    emu::wave_barrier();
     uint64_t got = emu::g_xbuf[(threadIdx.x & ~63u) | (unsigned)(src & 63)];
-    emu::barrier();
+    emu::wave_barrier();
     T out; std::memcpy(&out, &got, sizeof(T));
     return out;
 }
@@ -50,11 +51,11 @@ template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return 
 template <class T> static inline T __shfl(T v, int src, int = 64) { return emu_exchange(v, src); }
 static inline unsigned long long __ballot(int pred) {
     emu::g_xbuf[threadIdx.x] = pred ? 1 : 0;
-    emu::barrier();
+    emu::wave_barrier();
     unsigned long long m = 0;
     unsigned base = threadIdx.x & ~63u;
     for (int i = 0; i < 64; ++i) if (base + i < blockDim.x && emu::g_xbuf[base + i]) m |= 1ull << i;
-    emu::barrier();
+    emu::wave_barrier();
     return m;
 }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
@@ -73,7 +74,7 @@ static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, 
     uint64_t ra = 0, rb = 0;
     std::memcpy(&ra, &a, 4); std::memcpy(&rb, &b, 4);
     emu::g_xbuf[tid] = ra; emu::g_ybuf[tid] = rb;
-    emu::barrier();
+    emu::wave_barrier();
     emu_f32x16 d = c;
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (int)(lane >> 5), col = (int)(lane & 31);
@@ -86,7 +87,7 @@ static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, 
         }
         d[r] = acc;
     }
-    emu::barrier();
+    emu::wave_barrier();
     return d;
 }
 // v_mfma_f32_32x32x16_bf16 behind the kernel's gemm_* wrappers: lane l supplies 8 consecutive k = 8 * (l >> 5) + e of row /
@@ -112,7 +113,7 @@ static inline emu_f32x16 gemm_mfma_bf16(gemm_bf16x8 a, gemm_bf16x8 b, emu_f32x16
     static gemm_bf16x8 bufa[1024], bufb[1024];
     const unsigned tid = threadIdx.x, base = tid & ~63u, lane = tid & 63u;
     bufa[tid] = a; bufb[tid] = b;
-    emu::barrier();
+    emu::wave_barrier();
     emu_f32x16 d = c;
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (int)(lane >> 5), col = (int)(lane & 31);
@@ -122,7 +123,7 @@ static inline emu_f32x16 gemm_mfma_bf16(gemm_bf16x8 a, gemm_bf16x8 b, emu_f32x16
                 acc = std::fmaf(emu_bf16_to_f32(bufa[base + row + 32 * h].v[e]), emu_bf16_to_f32(bufb[base + col + 32 * h].v[e]), acc);
         d[r] = acc;
     }
-    emu::barrier();
+    emu::wave_barrier();
     return d;
 }
 using std::exp; using std::cos; using std::sin; using std::atan2;

@@ -419,7 +419,7 @@ def test_fused_attention_kernels_with_dropout_on_the_probabilities():
     library): forward and all three gradients; the keep rate is 1 - p; p = 0 reproduces the plain kernels."""
     lib = emu.lib()
     lib.emu_attention_set_dropout.argtypes = [C.c_float, C.c_uint]
-    lib.emu_drop_keep.argtypes = [C.c_uint, C.c_ulonglong, C.c_float]
+    lib.emu_attn_keep.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_float]
     rng = np.random.default_rng(8)
     n_seq, S, H = 2, 70, 2
     d = H * 32
@@ -437,7 +437,7 @@ def test_fused_attention_kernels_with_dropout_on_the_probabilities():
         lib.emu_attention_bwd(n_seq, S, H, d, C.c_float(scale), P(qkv), P(kb), P(out), P(lse), P(dout), P(dqkv), P(dsum))
     finally:
         lib.emu_attention_set_dropout(0.0, 0)
-    keep = np.array([[[lib.emu_drop_keep(seed, (bh * S + i) * S + j, pdrop) for j in range(S)] for i in range(S)] for bh in range(n_seq * H)],
+    keep = np.array([[[lib.emu_attn_keep(seed, bh, i, j, pdrop) for j in range(S)] for i in range(S)] for bh in range(n_seq * H)],
                     np.float64).reshape(n_seq, H, S, S)
     assert abs(keep.mean() - (1 - pdrop)) < 0.01
     M = keep / (1 - pdrop)
@@ -458,6 +458,44 @@ def test_fused_attention_kernels_with_dropout_on_the_probabilities():
     np.testing.assert_allclose(dqkv[..., d:2 * d], back(np.einsum("bhqk,bhqd->bhkd", ds, q)), rtol=1e-4, atol=5e-6)
     np.testing.assert_allclose(dqkv[..., 2 * d:], back(dv), rtol=1e-4, atol=5e-6)
     assert np.abs(out - back(np.einsum("bhqk,bhkd->bhqd", p, v))).max() > 1e-2      # ... and it is not the undropped attention
+
+
+def test_fused_attention_kernels_with_live_query_rows():
+    """emloco_attention_{fwd,bwd}_queries: only the first n_query rows attend (the last layer of a former feeds 21 tokens on,
+    model_jta.py:316).  Forward rows and log-sum-exp are BIT-equal to the first rows of the full launch (with and without
+    dropout: the mask is indexed by (head-sequence, query, key)); the gradients equal the full backward fed with zeros on the
+    dropped rows, and dQ of the rows that did not attend is exactly zero."""
+    lib = emu.lib()
+    lib.emu_attention_set_dropout.argtypes = [C.c_float, C.c_uint]
+    rng = np.random.default_rng(9)
+    n_seq, S, H = 2, 70, 2
+    d = H * 32
+    qkv = (rng.normal(size=(n_seq, S, 3 * d)) * 0.7).astype(np.float32)
+    kb = np.zeros((n_seq, S), np.float32)
+    kb[0, 3::5] = 1.0
+    kb[1, 60:] = -np.inf
+    scale = C.c_float(1.0 / np.sqrt(32.0))
+    for Sq, pdrop in ((21, 0.0), (21, 0.1), (40, 0.1)):
+        try:
+            lib.emu_attention_set_dropout(pdrop, 77)
+            out, lse = np.zeros((n_seq, S, d), np.float32), np.zeros((n_seq * H, S), np.float32)
+            lib.emu_attention_fwd(n_seq, S, H, d, scale, P(qkv), P(kb), P(out), P(lse))
+            outq, lseq = np.zeros((n_seq, Sq, d), np.float32), np.zeros((n_seq * H, Sq), np.float32)
+            lib.emu_attention_fwd_queries(n_seq, S, Sq, H, d, scale, P(qkv), P(kb), P(outq), P(lseq))
+            assert np.array_equal(outq, out[:, :Sq]) and np.array_equal(lseq, lse[:, :Sq])
+            doutq = rng.normal(size=outq.shape).astype(np.float32)
+            dout = np.zeros_like(out)
+            dout[:, :Sq] = doutq
+            dqkv, dsum = np.zeros_like(qkv), np.zeros((n_seq * H, S), np.float32)
+            lib.emu_attention_bwd(n_seq, S, H, d, scale, P(qkv), P(kb), P(out), P(lse), P(dout), P(dqkv), P(dsum))
+            dqkvq, dsumq = np.full_like(qkv, 7.0), np.zeros((n_seq * H, Sq), np.float32)
+            lib.emu_attention_bwd_queries(n_seq, S, Sq, H, d, scale, P(qkv), P(kb), P(outq), P(lseq), P(doutq), P(dqkvq), P(dsumq))
+        finally:
+            lib.emu_attention_set_dropout(0.0, 0)
+        assert np.array_equal(dqkvq[:, :Sq, :d], dqkv[:, :Sq, :d])
+        assert np.all(dqkvq[:, Sq:, :d] == 0)
+        # dK / dV sum over fewer query tiles: the same terms, zeros dropped -> equal up to the association of the tile sums
+        np.testing.assert_allclose(dqkvq[..., d:], dqkv[..., d:], rtol=1e-5, atol=1e-6)
 
 
 def test_fused_attention_kernels_bf16_operands():

@@ -407,7 +407,7 @@ def test_fused_attention_dropout_matches_torch_with_the_same_mask():
     out.backward(dout)
     lib = ops._lib()
     keep = np.zeros(Bn * H * S * S, np.uint8)
-    assert lib.emloco_dropout_keep_mask(seed, 0, keep.size, pdrop, keep.ctypes.data_as(C.c_void_p)) == 0
+    assert lib.emloco_attention_keep_mask(seed, Bn * H, S, pdrop, keep.ctypes.data_as(C.c_void_p)) == 0
     assert abs(keep.mean() - 0.9) < 2e-3
     M = torch.from_numpy(keep.reshape(Bn, H, S, S).astype(np.float64)).to(dev) / (1 - pdrop)
     q64 = qkv.detach().double().requires_grad_(True)
@@ -433,3 +433,64 @@ def test_encoder_layer_applies_attention_dropout_only_in_training():
     layer.train()
     c, e = layer(x, pad), layer(x, pad)
     assert not torch.equal(c, e) and torch.isfinite(c).all()
+
+
+def test_last_layer_live_rows_give_the_same_outputs_and_gradients():
+    """Only 21 tokens per person leave the local former and only the primary agent's rows leave the global one
+    (model_jta.py:316, :321), so the last layer of each computes those rows alone (emloco_attention_*_queries, the
+    out-projection / norms / feed-forward on the kept rows).  Same logits BIT for bit as the all-rows model, and the same
+    gradients up to the summation order of the weight gradients (fewer rows enter the split-K sums)."""
+    from emloco_amd.predictor.model_jta import TransMotionJTA
+    torch.manual_seed(3)
+    dev = "cuda:0"
+    model = TransMotionJTA(tok_dim=453, nhid=128, nhead=4, dim_feedfwd=256, nlayers_local=2, nlayers_global=2, nmode=4, dropout=0.0,
+                           output_scale=1, obs_and_pred=21, num_tokens=49, device=dev).to(dev).float()
+    B, N = 3, 4
+    tgt = torch.randn(B, 9, N * 49, 4, device=dev)
+    pad = torch.zeros(B, N, device=dev)
+    pad[1, 2:] = 1.0
+    with torch.no_grad():
+        for _ in range(3):
+            model(tgt, pad)            # nn.Embedding(max_norm) renormalises its rows in place on look-up: let that settle
+    res = {}
+    for prune in (True, False):
+        model.prune_dead_rows = prune
+        model.eval()
+        with torch.no_grad():
+            ev = model(tgt, pad)
+        model.train()
+        model.zero_grad()
+        torch.manual_seed(11)
+        out = model(tgt, pad)
+        (out * torch.linspace(-1, 1, out.numel(), device=dev).view_as(out)).sum().backward()
+        res[prune] = (ev, out.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert torch.equal(res[True][0], res[False][0]), (res[True][0] - res[False][0]).abs().max().item()
+    assert torch.equal(res[True][1], res[False][1]), (res[True][1] - res[False][1]).abs().max().item()
+    assert res[True][2].keys() == res[False][2].keys()
+    for k in res[True][2]:
+        _close(res[True][2][k].cpu().numpy(), res[False][2][k].cpu().numpy(), rel=2e-5, abs_=1e-7, what=k)
+
+
+def test_attention_queries_entry_points_against_the_full_launch():
+    """emloco_attention_fwd_queries / _bwd_queries at S = 453, n_query = 21, with dropout: rows bit-equal to the full launch,
+    dQ of the other rows zero, dK / dV equal to the full backward fed with zeros on the dropped rows."""
+    from emloco_amd.predictor import ops
+    torch.manual_seed(6)
+    dev = "cuda:0"
+    Bn, S, H, d, Sq = 5, 453, 4, 128, 21
+    qkv = (torch.randn(Bn, S, 3 * d, device=dev) * 0.6)
+    pad = torch.zeros(Bn, S, device=dev)
+    pad[1] = 1.0
+    for pdrop, seed in ((0.0, 0), (0.1, 99)):
+        a = qkv.clone().requires_grad_(True)
+        b = qkv.clone().requires_grad_(True)
+        full = ops.FusedAttentionFn.apply(a, pad, H, pdrop, seed)
+        part = ops.FusedAttentionFn.apply(b, pad, H, pdrop, seed, Sq)
+        assert part.shape == (Bn, Sq, d) and torch.equal(part, full[:, :Sq])
+        dout = torch.randn(Bn, Sq, d, device=dev)
+        dfull = torch.zeros(Bn, S, d, device=dev)
+        dfull[:, :Sq] = dout
+        full.backward(dfull)
+        part.backward(dout)
+        assert torch.equal(b.grad[:, :Sq, :d], a.grad[:, :Sq, :d]) and (b.grad[:, Sq:, :d] == 0).all()
+        _close(b.grad[..., d:].cpu().numpy(), a.grad[..., d:].cpu().numpy(), rel=1e-5, abs_=1e-7, what="dK / dV")
