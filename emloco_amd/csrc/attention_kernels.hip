@@ -167,15 +167,18 @@ attn_fwd_kernel(AttnArgs a) {
     const int ntiles = (a.S + AT_T - 1) / AT_T;
 
     at_f32x4 rk = at_fetch4(K, ld, 0, a.S, tid), rv = at_fetch4(V, ld, 0, a.S, tid);
-    float rb = 0.0f;
-    if (tid < AT_T) rb = tid < a.S ? (kb ? kb[tid] : 0.0f) : -INFINITY;
+    // key bias of the tile: every thread loads entry (tid & 31) from a clamped address and the value is only looked at by the
+    // stash (a branch around the load, or a select right behind it, makes wave 0 wait for ALL its loads before the tile's MFMAs)
+    const float *kbp = kb ? kb : a.qkv;
+    const int t31 = tid & 31;
+    float rb = kbp[t31 < a.S ? t31 : a.S - 1];
     at_stash4(Ks[0], tid, rk); at_stash4(Vs[0], tid, rv);
-    if (tid < AT_T) Bs[0][tid] = rb;
+    if (tid < AT_T) Bs[0][tid] = tid < a.S ? (kb ? rb : 0.0f) : -INFINITY;
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1, k0n = (t + 1) * AT_T;
         rk = at_fetch4(K, ld, k0n, a.S, tid); rv = at_fetch4(V, ld, k0n, a.S, tid);      // past the end: zeros, never used
-        if (tid < AT_T) { const int kk = k0n + tid; const int kc = kk < a.S ? kk : a.S - 1; const float v = kb ? kb[kc] : 0.0f; rb = kk < a.S ? v : -INFINITY; }
+        rb = kbp[k0n + t31 < a.S ? k0n + t31 : a.S - 1];
         if (live) {
         // scores^T tile: keys (rows) x own queries (lanes)
         at_f32x16 st = at_xyT<PREC>(Ks[buf], l31, h, qf);
@@ -199,7 +202,7 @@ attn_fwd_kernel(AttnArgs a) {
         acc_o = at_xTp<PREC>(Vs[buf], l31, h, p, acc_o);     // O^T += V^T P^T
         }
         at_stash4(Ks[buf ^ 1], tid, rk); at_stash4(Vs[buf ^ 1], tid, rv);
-        if (tid < AT_T) Bs[buf ^ 1][tid] = rb;
+        if (tid < AT_T) Bs[buf ^ 1][tid] = k0n + tid < a.S ? (kb ? rb : 0.0f) : -INFINITY;
         __syncthreads();
     }
     if (query < a.Sq) {
@@ -237,15 +240,18 @@ attn_bwd_dq_kernel(AttnArgs a) {
     const int ntiles = (a.S + AT_T - 1) / AT_T;
 
     at_f32x4 rk = at_fetch4(K, ld, 0, a.S, tid), rv = at_fetch4(V, ld, 0, a.S, tid);
-    float rb = 0.0f;
-    if (tid < AT_T) rb = tid < a.S ? (kb ? kb[tid] : 0.0f) : -INFINITY;
+    // key bias of the tile: every thread loads entry (tid & 31) from a clamped address and the value is only looked at by the
+    // stash (a branch around the load, or a select right behind it, makes wave 0 wait for ALL its loads before the tile's MFMAs)
+    const float *kbp = kb ? kb : a.qkv;
+    const int t31 = tid & 31;
+    float rb = kbp[t31 < a.S ? t31 : a.S - 1];
     at_stash4(Ks[0], tid, rk); at_stash4(Vs[0], tid, rv);
-    if (tid < AT_T) Bs[0][tid] = rb;
+    if (tid < AT_T) Bs[0][tid] = tid < a.S ? (kb ? rb : 0.0f) : -INFINITY;
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1, k0n = (t + 1) * AT_T;
         rk = at_fetch4(K, ld, k0n, a.S, tid); rv = at_fetch4(V, ld, k0n, a.S, tid);
-        if (tid < AT_T) { const int kk = k0n + tid; const int kc = kk < a.S ? kk : a.S - 1; const float v = kb ? kb[kc] : 0.0f; rb = kk < a.S ? v : -INFINITY; }
+        rb = kbp[k0n + t31 < a.S ? k0n + t31 : a.S - 1];
         if (live) {
         const at_f32x16 st = at_xyT<PREC>(Ks[buf], l31, h, qf);           // S^T
         const at_f32x16 dpt = at_xyT<PREC>(Vs[buf], l31, h, dof);         // dP^T = V dO^T
@@ -261,7 +267,7 @@ attn_bwd_dq_kernel(AttnArgs a) {
         acc = at_xTp<PREC>(Ks[buf], l31, h, ds, acc);                     // dQ^T += K^T dS^T
         }
         at_stash4(Ks[buf ^ 1], tid, rk); at_stash4(Vs[buf ^ 1], tid, rv);
-        if (tid < AT_T) Bs[buf ^ 1][tid] = rb;
+        if (tid < AT_T) Bs[buf ^ 1][tid] = k0n + tid < a.S ? (kb ? rb : 0.0f) : -INFINITY;
         __syncthreads();
     }
     if (query < a.Sq) at_store_rowT(a.dqkv + ((long)b * a.S + query) * ld + hd * AT_DH, h, acc, 1.0f);
@@ -283,6 +289,7 @@ attn_bwd_dkv_kernel(AttnArgs a) {
     at_f32x4 kf[4], vf[4];
     at_grow16(K, ld, key, a.S, h, kf);
     at_grow16(V, ld, key, a.S, h, vf);
+    const bool live = blockIdx.x * 128 + wave * 32 < a.S;         // wave-uniform: a wave wholly past the keys only helps staging
     float bias = -INFINITY;
     if (key < a.S) bias = a.key_bias ? a.key_bias[(long)b * a.S + key] : 0.0f;
     at_f32x16 acc_k, acc_v;
@@ -290,15 +297,16 @@ attn_bwd_dkv_kernel(AttnArgs a) {
     const int ntiles = (a.Sq + AT_T - 1) / AT_T;      // walks the live queries
 
     at_f32x4 rq = at_fetch4(Q, ld, 0, a.Sq, tid), ro = at_fetch4(dO, a.d_model, 0, a.Sq, tid);
-    float rl = 3.0e38f, rd = 0.0f;
-    if (tid < AT_T && tid < a.Sq) { rl = lse[tid]; rd = dsm[tid]; }
+    const int t31 = tid & 31;                        // per-query log-sum-exp and D: loaded branch-free, masked by the stash
+    float rl = lse[t31 < a.Sq ? t31 : a.Sq - 1], rd = dsm[t31 < a.Sq ? t31 : a.Sq - 1];
     at_stash4(Qs[0], tid, rq); at_stash4(Os[0], tid, ro);
-    if (tid < AT_T) { Ls[0][tid] = rl; Ds[0][tid] = rd; }
+    if (tid < AT_T) { Ls[0][tid] = tid < a.Sq ? rl : 3.0e38f; Ds[0][tid] = tid < a.Sq ? rd : 0.0f; }
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1, q0n = (t + 1) * AT_T;
         rq = at_fetch4(Q, ld, q0n, a.Sq, tid); ro = at_fetch4(dO, a.d_model, q0n, a.Sq, tid);
-        if (tid < AT_T) { const int qq = q0n + tid; const int qc = qq < a.Sq ? qq : a.Sq - 1; const float l0 = lse[qc], d0 = dsm[qc]; rl = qq < a.Sq ? l0 : 3.0e38f; rd = qq < a.Sq ? d0 : 0.0f; }
+        { const int qc = q0n + t31 < a.Sq ? q0n + t31 : a.Sq - 1; rl = lse[qc]; rd = dsm[qc]; }
+        if (live) {
         const at_f32x16 s = at_xyT<PREC>(Qs[buf], l31, h, kf);            // S: queries (rows) x own keys (lanes)
         const at_f32x16 dp = at_xyT<PREC>(Os[buf], l31, h, vf);           // dP = dO V^T
         float lrow[16], drow[16], p[16], ds[16];
@@ -319,8 +327,9 @@ attn_bwd_dkv_kernel(AttnArgs a) {
         }
         acc_v = at_xTp<PREC>(Os[buf], l31, h, p, acc_v);                  // dV^T += dO^T P
         acc_k = at_xTp<PREC>(Qs[buf], l31, h, ds, acc_k);                 // dK^T += Q^T dS
+        }
         at_stash4(Qs[buf ^ 1], tid, rq); at_stash4(Os[buf ^ 1], tid, ro);
-        if (tid < AT_T) { Ls[buf ^ 1][tid] = rl; Ds[buf ^ 1][tid] = rd; }
+        if (tid < AT_T) { Ls[buf ^ 1][tid] = q0n + tid < a.Sq ? rl : 3.0e38f; Ds[buf ^ 1][tid] = q0n + tid < a.Sq ? rd : 0.0f; }
         __syncthreads();
     }
     if (key < a.S) {

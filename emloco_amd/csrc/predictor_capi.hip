@@ -79,7 +79,7 @@ int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha, const float 
     if (ksplit > 1 && !workspace) return pfail(-1, "emloco_gemm_f32: ksplit > 1 needs a workspace");
     if ((long)batch * ksplit > 65535) return pfail(-1, "emloco_gemm_f32: batch * ksplit exceeds the grid z limit");
     emloco::GemmArgs g{batch, m, n, k, alpha, A, lda, (long)stride_a, trans_a, B, ldb, (long)stride_b, trans_b,
-                       C, ldc, (long)stride_c, bias, flags, ksplit, workspace, 0, 0, drop_p, drop_seed};
+                       C, ldc, (long)stride_c, bias, flags, ksplit, workspace, 0, 0, drop_p, drop_seed, nullptr, 1.0f, nullptr};
     // 16-byte global loads need the base, the leading dimension and the batch stride 16 B aligned
     g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && (stride_a % 4 == 0);
     g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (stride_b % 4 == 0);
@@ -88,9 +88,15 @@ int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha, const float 
     if (g_timing) PHIPCHK(hipEventRecord(g_e0[slot], st));
     // stage depth: 32 for long reductions (covers the prefetch latency), 16 for short ones (less LDS, more workgroups / CU)
     static const int force_bk = getenv("EMLOCO_GEMM_BK") ? atoi(getenv("EMLOCO_GEMM_BK")) : 0;
-    const bool deep = force_bk ? force_bk == 32 : (k + ksplit - 1) / ksplit > 256;
     const unsigned bn = n <= 32 ? 32 : 128;
     dim3 grid((unsigned)((n + bn - 1) / bn), (unsigned)((m + 127) / 128), (unsigned)(batch * ksplit));
+    // measured (tools/exp/probe_jta_gemm.py, tools/probe_gemm.py): the 32-deep stage only pays while the launch is at most ~2
+    // workgroups per CU (4096 x 1024 x 2048: 87 vs 85 TFLOP/s); with many waves of workgroups the 16-deep stage's third resident
+    // workgroup per CU wins (927744 x 128 x 1024: 111 vs 102), and so it does for the k-major (transposed) operands of the
+    // weight gradients (1024 x 128 x 927744 split 64: 114 vs 107)
+    const long n_wg = (long)grid.x * grid.y * grid.z;
+    const bool long_k = (k + ksplit - 1) / ksplit > 256;
+    const bool deep = force_bk ? force_bk == 32 : (long_k && (n <= 32 || (n_wg <= 1024 && !(trans_a && trans_b))));
     hipLaunchKernelGGL(emloco::gemm_pick(g, deep), grid, dim3(256), 0, st, g);
     PHIPCHK(hipGetLastError());
     if (ksplit > 1) {
@@ -167,6 +173,27 @@ int emloco_colsum(int m, int n, const float *X, float *out, float *workspace, vo
     hipLaunchKernelGGL(emloco::colsum_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream, m, n, X, workspace);
     PHIPCHK(hipGetLastError());
     emloco::fold_rows(FoldLaunch{(hipStream_t)stream}, nparts, n, workspace, out, out, n);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int64_t emloco_gemm_relu_bwd_workspace(int m, int n) { return emloco::fold_workspace(2L * ((m + 127) / 128), n); }
+
+int emloco_gemm_relu_bwd(int m, int n, int k, const float *A, int lda, const float *B, int ldb, int trans_b, float *C,
+                         const float *y, float scale, float *colsum, float *workspace, int flags, void *stream) {
+    if (m < 1 || n < 33 || k < 1 || !A || !B || !C || !y || !colsum || !workspace)
+        return pfail(-1, "emloco_gemm_relu_bwd: bad argument (n > 32; workspace = emloco_gemm_relu_bwd_workspace(m, n) floats)");
+    emloco::GemmArgs g{1, m, n, k, 1.0f, A, lda, 0, 0, B, ldb, 0, trans_b, C, n, 0, nullptr, 32 | (flags & EMLOCO_GEMM_BF16), 1, nullptr,
+                       0, 0, 0.0f, 0u, y, scale, workspace};
+    g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
+    g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
+    if (!g.vec_a || !g.vec_b) return pfail(-1, "emloco_gemm_relu_bwd: A and B must be 16-byte aligned with leading dimensions that are multiples of 4");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((n + 127) / 128), (unsigned)((m + 127) / 128), 1);
+    const bool deep = k > 256 && (long)grid.x * grid.y <= 1024;
+    hipLaunchKernelGGL(emloco::gemm_pick(g, deep), grid, dim3(256), 0, st, g);
+    PHIPCHK(hipGetLastError());
+    emloco::fold_rows(FoldLaunch{st}, 2 * (int)grid.y, n, workspace, colsum, colsum, n);
     PHIPCHK(hipGetLastError());
     return 0;
 }

@@ -33,6 +33,10 @@ struct GemmArgs {
     const float *bias; int flags; int ksplit; float *ws;
     int vec_a, vec_b;   // operand may be read with 16-byte loads (base, leading dimension and batch stride 16 B aligned)
     float drop_p; unsigned drop_seed;   // flags & 8: inverted dropout in the epilogue (after bias / ReLU)
+    // flags & 32 (backward through dropout(relu(.)) fused into the GEMM that produces the incoming gradient): the value is
+    // multiplied by mask_scale where mask[row][col] > 0 (the forward OUTPUT, laid out like C) and zeroed elsewhere, and the
+    // column sums of what was written over the 64 rows of this wave go to colpart[(tile_row * WM + wm)][col] (bias gradient)
+    const float *mask; float mask_scale; float *colpart;
 };
 
 // Counter-based dropout mask: keep element `idx` of a launch with seed `seed` iff hash(seed, idx) >= p.  A stateless
@@ -53,8 +57,8 @@ struct __attribute__((aligned(16))) f32x4 { float x, y, z, w; };
 // TRANS: 0 = X[row][k] (k contiguous), 1 = X[k][row] (row contiguous).  VEC: 16-byte loads allowed (base, leading
 // dimension and batch stride 16 B aligned; then a clamped quad never leaves its row: ld % 4 == 0 and rows, k <= ld).
 template <int ROWS, int GBK, int TRANS, int VEC>
-__device__ __forceinline__ void gemm_fetch(f32x4 (&v)[(ROWS * GBK / 4 + 255) / 256], const float *X, int ld,
-                                           int row0, int rows, int k0, int ke, int tid) {
+__device__ __forceinline__ void gemm_fetch(f32x4 (&v)[(ROWS * GBK / 4 + 255) / 256], unsigned (&mk)[(ROWS * GBK / 4 + 255) / 256],
+                                           const float *X, int ld, int row0, int rows, int k0, int ke, int tid) {
     constexpr int NQ = ROWS * GBK / 4, QR = GBK / 4;
     for (int e = 0; e < (NQ + 255) / 256; ++e) {
         int idx = tid + 256 * e;
@@ -92,23 +96,27 @@ __device__ __forceinline__ void gemm_fetch(f32x4 (&v)[(ROWS * GBK / 4 + 255) / 2
                 t.z = base[row + 2 < rl ? row + 2 : rl]; t.w = base[row + 3 < rl ? row + 3 : rl];
             }
         }
-        t.x = ok0 ? t.x : 0.0f; t.y = ok1 ? t.y : 0.0f; t.z = ok2 ? t.z : 0.0f; t.w = ok3 ? t.w : 0.0f;
+        // the loaded value is not touched here (the mask is applied by the stash): a select now would wait for the load
+        mk[e] = (ok0 ? 1u : 0u) | (ok1 ? 2u : 0u) | (ok2 ? 4u : 0u) | (ok3 ? 8u : 0u);
         v[e] = t;
     }
 }
 
 template <int ROWS, int GBK, int TRANS>
-__device__ __forceinline__ void gemm_stash(const f32x4 (&v)[(ROWS * GBK / 4 + 255) / 256], float *S, int tid) {
+__device__ __forceinline__ void gemm_stash(const f32x4 (&v)[(ROWS * GBK / 4 + 255) / 256], const unsigned (&mk)[(ROWS * GBK / 4 + 255) / 256],
+                                           float *S, int tid) {
     constexpr int NQ = ROWS * GBK / 4, QR = GBK / 4, GLDK = GBK + 4;
     for (int e = 0; e < (NQ + 255) / 256; ++e) {
         const int idx = tid + 256 * e;
         if (NQ % 256 == 0 || idx < NQ) {
+            f32x4 t = v[e];
+            t.x = (mk[e] & 1u) ? t.x : 0.0f; t.y = (mk[e] & 2u) ? t.y : 0.0f; t.z = (mk[e] & 4u) ? t.z : 0.0f; t.w = (mk[e] & 8u) ? t.w : 0.0f;
             if (!TRANS) {
                 const int r = idx / QR, q = idx - r * QR;
-                *(f32x4 *)&S[r * GLDK + 4 * q] = v[e];
+                *(f32x4 *)&S[r * GLDK + 4 * q] = t;
             } else {                                           // row-contiguous operand: LDS stage is k-major [k][ROWS + 4]
                 const int kk = idx / (ROWS / 4), rq = idx - kk * (ROWS / 4);
-                *(f32x4 *)&S[kk * (ROWS + 4) + 4 * rq] = v[e];
+                *(f32x4 *)&S[kk * (ROWS + 4) + 4 * rq] = t;
             }
         }
     }
@@ -145,17 +153,21 @@ __device__ __forceinline__ void gemm_frag(const float *S, int row, int half8, f3
 // instead of eight, fp32 accumulation.  Lane (l & 31, h = l >> 5) supplies 8 consecutive k of its half, which is what
 // two adjacent fp32 fragments already hold; A and B use the same k permutation, so no layout changes.
 
-template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int PREC = 0>
-__global__ void __launch_bounds__(256)
-gemm_f32_kernel(GemmArgs g) {
+// EPI = 1: the fused backward epilogue (flags & 32) -- its own instantiations, so that its registers (a tile of mask values in
+// flight) do not lower the occupancy of the plain variants.
+template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int PREC, int EPI>
+__device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     constexpr int BM = WM * TI * 32, BN = WN * TJ * 32, GLDK = GBK + 4, NF = GBK / 8;
     constexpr int QA = (BM * GBK / 4 + 255) / 256, QB = (BN * GBK / 4 + 255) / 256;
     __shared__ __attribute__((aligned(16))) float As[2][BM * GLDK], Bs[2][BN * GLDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
-    const int bz = blockIdx.z;
+    // (An XCD-aware tile order -- XCD c walks the column tiles of the rows = c (mod 8) back to back so that a slab of A is
+    // fetched by one L2 only -- was measured and is SLOWER here (927744 x 1024 x 128: 2.80 -> 3.13 ms): in dispatch order every
+    // XCD keeps ONE 64 KB column tile of B hot and the eight readers of a slab of A arrive together and hit the shared L3.)
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     const int b = bz / g.ksplit, split = bz - b * g.ksplit;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
     int kchunk = (g.k + g.ksplit - 1) / g.ksplit;
     kchunk = ((kchunk + GBK - 1) / GBK) * GBK;
     const int kb = split * kchunk;
@@ -169,19 +181,23 @@ gemm_f32_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     f32x4 ra[QA], rb[QB];
+    unsigned ma[QA], mb[QB];
     if (kb < ke) {
-        gemm_fetch<BM, GBK, TA, VEC>(ra, A, g.lda, m0, g.m, kb, ke, tid);
-        gemm_fetch<BN, GBK, TB, VEC>(rb, B, g.ldb, n0, g.n, kb, ke, tid);
-        gemm_stash<BM, GBK, TA>(ra, As[0], tid);
-        gemm_stash<BN, GBK, TB>(rb, Bs[0], tid);
+        gemm_fetch<BM, GBK, TA, VEC>(ra, ma, A, g.lda, m0, g.m, kb, ke, tid);
+        gemm_fetch<BN, GBK, TB, VEC>(rb, mb, B, g.ldb, n0, g.n, kb, ke, tid);
+        gemm_stash<BM, GBK, TA>(ra, ma, As[0], tid);
+        gemm_stash<BN, GBK, TB>(rb, mb, Bs[0], tid);
     }
     __syncthreads();
     int buf = 0;
     const int half8 = (GBK / 2) * (lane >> 5), l31 = lane & 31;
     for (int k0 = kb; k0 < ke; k0 += GBK) {
         // next stage's global loads are in flight during the MFMAs (past the end they fetch zeros: clamped + masked)
-        gemm_fetch<BM, GBK, TA, VEC>(ra, A, g.lda, m0, g.m, k0 + GBK, ke, tid);
-        gemm_fetch<BN, GBK, TB, VEC>(rb, B, g.ldb, n0, g.n, k0 + GBK, ke, tid);
+        gemm_fetch<BM, GBK, TA, VEC>(ra, ma, A, g.lda, m0, g.m, k0 + GBK, ke, tid);
+        gemm_fetch<BN, GBK, TB, VEC>(rb, mb, B, g.ldb, n0, g.n, k0 + GBK, ke, tid);
+        // keep the loads HERE: left free, the scheduler sinks them below most of the stage's MFMAs (they are only consumed by the
+        // stash) and the s_waitcnt in front of the stash then exposes the whole memory latency every stage
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 fa[TI][NF], fb[TJ][NF];
         for (int i = 0; i < TI; ++i) gemm_frag<BM, GBK, TA>(As[buf], (wm * TI + i) * 32 + l31, half8, fa[i]);
         for (int j = 0; j < TJ; ++j) gemm_frag<BN, GBK, TB>(Bs[buf], (wn * TJ + j) * 32 + l31, half8, fb[j]);
@@ -203,32 +219,89 @@ gemm_f32_kernel(GemmArgs g) {
             }
         }
 #undef GEMM_STEP
-        gemm_stash<BM, GBK, TA>(ra, As[buf ^ 1], tid);
-        gemm_stash<BN, GBK, TB>(rb, Bs[buf ^ 1], tid);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm_stash<BM, GBK, TA>(ra, ma, As[buf ^ 1], tid);
+        gemm_stash<BN, GBK, TB>(rb, mb, Bs[buf ^ 1], tid);
         __syncthreads();
         buf ^= 1;
     }
-    // epilogue: C/D fragment layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    for (int i = 0; i < TI; ++i)
-        for (int j = 0; j < TJ; ++j)
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * TI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int col = n0 + (wn * TJ + j) * 32 + (lane & 31);
-                if (row < g.m && col < g.n) {
-                    float v = g.alpha * acc[i][j][r];
-                    if (g.ksplit > 1) {
-                        g.ws[(((long)split * g.batch + b) * g.m + row) * g.n + col] = v;
-                    } else {
-                        float *c = g.C + (long)b * g.sc + (long)row * g.ldc + col;
-                        if (g.flags & 1) v += g.bias[col];
-                        if (g.flags & 2) v = v > 0.0f ? v : 0.0f;
-                        if (g.flags & 8) v = drop_keep(g.drop_seed, ((unsigned long long)b * g.m + row) * g.n + col, g.drop_p) ? v * (1.0f / (1.0f - g.drop_p)) : 0.0f;
-                        if (g.flags & 4) v += *c;
+    // epilogue: C/D fragment layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  A lane owns ONE column per (j): its
+    // bias is read once (left inside the row loop, every store to C makes the compiler reload it: C may alias the bias).
+    // Addresses are a workgroup-uniform tile base (scalar registers) + a 32-bit lane offset: one VGPR per access instead of a
+    // 64-bit multiply-add and a register pair each.
+    const bool has_bias = (g.flags & 1) != 0, relu = (g.flags & 2) != 0, accum = (g.flags & 4) != 0, drop = (g.flags & 8) != 0;
+    const float keep_scale = drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+    const int mrem = g.m - m0, nrem = g.n - n0;
+    if (g.ksplit > 1) {
+        float *wt = g.ws + (((long)split * g.batch + b) * g.m + m0) * g.n + n0;
+        for (int j = 0; j < TJ; ++j) {
+            const int cl = (wn * TJ + j) * 32 + (lane & 31);
+            for (int i = 0; i < TI; ++i)
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = (wm * TI + i) * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                    if (rl < mrem && cl < nrem) wt[rl * g.n + cl] = g.alpha * acc[i][j][r];
+                }
+        }
+    } else if constexpr (EPI == 0) {
+        float *ct = g.C + (long)b * g.sc + (long)m0 * g.ldc + n0;
+        for (int j = 0; j < TJ; ++j) {
+            const int cl = (wn * TJ + j) * 32 + (lane & 31);
+            if (cl >= nrem) continue;
+            const float bj = has_bias ? g.bias[n0 + cl] : 0.0f;
+            for (int i = 0; i < TI; ++i)
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = (wm * TI + i) * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                    if (rl < mrem) {
+                        float v = g.alpha * acc[i][j][r] + bj;
+                        if (relu) v = v > 0.0f ? v : 0.0f;
+                        if (drop) v = drop_keep(g.drop_seed, ((unsigned long long)b * g.m + m0 + rl) * g.n + n0 + cl, g.drop_p) ? v * keep_scale : 0.0f;
+                        float *c = ct + (rl * g.ldc + cl);
+                        if (accum) v += *c;
                         *c = v;
                     }
                 }
+        }
+    } else {
+        const float *mt = g.mask + (long)b * g.sc + (long)m0 * g.ldc + n0;
+        float *ct = g.C + (long)b * g.sc + (long)m0 * g.ldc + n0;
+        for (int j = 0; j < TJ; ++j) {
+            const int cl = (wn * TJ + j) * 32 + (lane & 31);
+            const bool colok = cl < nrem;
+            const int clc = colok ? cl : nrem - 1;
+            float csum = 0.0f;
+            for (int i = 0; i < TI; ++i) {
+                // the 16 mask values of the fragment are requested before the first is looked at (one at a time the epilogue
+                // is a chain of memory latencies)
+                float mv[16];
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = (wm * TI + i) * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                    mv[r] = mt[(rl < mrem ? rl : mrem - 1) * g.ldc + clc];
+                }
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = (wm * TI + i) * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                    if (rl < mrem && colok) {
+                        const float v = mv[r] > 0.0f ? g.alpha * acc[i][j][r] * g.mask_scale : 0.0f;
+                        ct[rl * g.ldc + cl] = v;
+                        csum += v;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);           // one fragment's mask values in flight, not the whole tile's
             }
+            csum += __shfl_xor(csum, 32);                    // the other 32 rows of the wave's 64
+            if (lane < 32 && colok) g.colpart[((long)by * WM + wm) * g.n + n0 + cl] = csum;
+        }
+    }
 }
+
+template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int PREC = 0>
+__global__ void __launch_bounds__(256)
+gemm_f32_kernel(GemmArgs g) { gemm_body<WM, WN, TI, TJ, GBK, TA, TB, VEC, PREC, 0>(g); }
+
+// the fused-backward-epilogue variants: held to 3 waves per SIMD (168 registers; left alone the compiler keeps the whole
+// tile's mask values and offsets live and falls to 2)
+template <int GBK, int TB, int PREC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+gemm_f32_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, GBK, 0, TB, 1, PREC, 1>(g); }
 
 // kernel variant for a problem: tile shape (narrow: n <= 32), stage depth, operand layouts, 16-byte loads
 typedef void (*GemmKernel)(GemmArgs);
@@ -254,6 +327,14 @@ inline GemmKernel gemm_pick_layout(int ta, int tb, int vec, int bf16 = 0) {
 inline GemmKernel gemm_pick(const GemmArgs &g, bool deep) {
     const int vec = g.vec_a && g.vec_b;
     const int bf16 = (g.flags & 16) ? 1 : 0;
+    if (g.flags & 32) {           // fused backward epilogue: A row-major, 16-byte loads (the launcher checks)
+        if (deep) {
+            if (bf16) return g.tb ? gemm_f32_relu_bwd_kernel<32, 1, 1> : gemm_f32_relu_bwd_kernel<32, 0, 1>;
+            return g.tb ? gemm_f32_relu_bwd_kernel<32, 1, 0> : gemm_f32_relu_bwd_kernel<32, 0, 0>;
+        }
+        if (bf16) return g.tb ? gemm_f32_relu_bwd_kernel<16, 1, 1> : gemm_f32_relu_bwd_kernel<16, 0, 1>;
+        return g.tb ? gemm_f32_relu_bwd_kernel<16, 1, 0> : gemm_f32_relu_bwd_kernel<16, 0, 0>;
+    }
     if (g.n <= 32) return deep ? gemm_pick_layout<4, 1, 1, 1, 32>(g.ta, g.tb, vec) : gemm_pick_layout<4, 1, 1, 1, 16>(g.ta, g.tb, vec);
     return deep ? gemm_pick_layout<2, 2, 2, 2, 32>(g.ta, g.tb, vec, bf16) : gemm_pick_layout<2, 2, 2, 2, 16>(g.ta, g.tb, vec, bf16);
 }

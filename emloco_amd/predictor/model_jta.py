@@ -54,8 +54,7 @@ class EncoderLayer(nn.Module):
             x = x[:, :live_rows].contiguous()
         a = ops.linear(att, sa.out_proj.weight, sa.out_proj.bias, drop_p=p)
         x = ops.layer_norm(a, x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        h = ops.linear(x, self.linear1.weight, self.linear1.bias, relu=True, drop_p=p)
-        f = ops.linear(h, self.linear2.weight, self.linear2.bias, drop_p=p)
+        f = ops.feed_forward(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, drop_p=p)
         return ops.layer_norm(f, x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
 
 

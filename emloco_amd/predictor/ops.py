@@ -41,6 +41,9 @@ def _lib():
         lib.emloco_attention_bwd.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_attention_fwd_ex.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, ci, vp]
         lib.emloco_attention_bwd_ex.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+        lib.emloco_gemm_relu_bwd_workspace.argtypes = [ci, ci]
+        lib.emloco_gemm_relu_bwd_workspace.restype = C.c_int64
+        lib.emloco_gemm_relu_bwd.argtypes = [ci, ci, ci, vp, ci, vp, ci, ci, vp, vp, cf, vp, vp, ci, vp]
         lib.emloco_attention_fwd_queries.argtypes = [ci, ci, ci, ci, ci, cf, vp, vp, vp, vp, ci, cf, C.c_uint32, vp]
         lib.emloco_attention_bwd_queries.argtypes = [ci, ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, ci, cf, C.c_uint32, vp]
         lib.emloco_attention_keep_mask.argtypes = [C.c_uint32, ci, ci, cf, vp]
@@ -195,6 +198,67 @@ def linear(x, W, b=None, relu=False, drop_p=0.0):
     return LinearFn.apply(x, W, b, relu, 0.0, 0)
 
 
+
+
+class FeedForwardFn(torch.autograd.Function):
+    """f = dropout(linear2(dropout(relu(linear1(x))))) -- the feed-forward block of nn.TransformerEncoderLayer
+    (model_jta.py:177) as one autograd node, so that the backward can fuse across the two layers: the gradient w.r.t. the
+    hidden activations is masked (ReLU and dropout: hidden > 0) and column-summed (bias gradient) in the epilogue of the GEMM
+    that produces it (`emloco_gemm_relu_bwd`); the unmasked M x ff gradient never exists in memory."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, drop_p, seed1, seed2):
+        xs = x.shape
+        x2 = x.contiguous().view(-1, xs[-1])
+        M, K = x2.shape
+        F, N = W1.shape[0], W2.shape[0]
+        W1c, W2c = W1.contiguous(), W2.contiguous()
+        h = torch.empty((M, F), dtype=torch.float32, device=x.device)
+        gemm(1, M, F, K, x2, K, 0, 0, W1c, K, 0, 0, h, F, 0, bias=b1.contiguous(), flags=GEMM_BIAS | GEMM_RELU, drop_p=drop_p, drop_seed=seed1)
+        f = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        gemm(1, M, N, F, h, F, 0, 0, W2c, F, 0, 0, f, N, 0, bias=b2.contiguous(), flags=GEMM_BIAS, drop_p=drop_p, drop_seed=seed2)
+        ctx.save_for_backward(x2, W1c, W2c, h)
+        ctx.xs, ctx.drop = xs, (float(drop_p), int(seed1), int(seed2))
+        return f.view(*xs[:-1], N)
+
+    @staticmethod
+    def backward(ctx, df):
+        x2, W1, W2, h = ctx.saved_tensors
+        M, K = x2.shape
+        F, N = W1.shape[0], W2.shape[0]
+        p, _, seed2 = ctx.drop
+        lib, st, dev = _lib(), _st(x2), x2.device
+        df2 = df.contiguous().view(M, N)
+        db2 = torch.empty(N, dtype=torch.float32, device=dev)
+        if p > 0.0:                                      # the output dropout's mask and linear2's bias gradient in one pass
+            dz2 = torch.empty_like(df2)
+            ws = torch.empty(lib.emloco_colsum_workspace(M, N), dtype=torch.float32, device=dev)
+            _chk(lib.emloco_act_bwd_colsum(M, N, _p(df2), None, 0, p, seed2 & 0xFFFFFFFF, _p(dz2), _p(db2), _p(ws), st), "emloco_act_bwd_colsum")
+        else:
+            dz2, db2 = df2, colsum(df2)
+        dW2 = torch.empty((N, F), dtype=torch.float32, device=dev)
+        gemm(1, N, F, M, dz2, N, 0, 1, h, F, 0, 1, dW2, F, 0, ksplit=_ksplit_for(M, N * F))          # dW2 = dz2^T h
+        dz1 = torch.empty((M, F), dtype=torch.float32, device=dev)
+        db1 = torch.empty(F, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.emloco_gemm_relu_bwd_workspace(M, F), dtype=torch.float32, device=dev)
+        _chk(lib.emloco_gemm_relu_bwd(M, F, N, _p(dz2), N, _p(W2), F, 1, _p(dz1), _p(h), 1.0 / (1.0 - p), _p(db1), _p(ws),
+                                      GEMM_BF16 if _matmul_precision[0] == "bf16" else 0, st), "emloco_gemm_relu_bwd")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+            gemm(1, M, K, F, dz1, F, 0, 0, W1, K, 0, 1, dx, K, 0)                                    # dx = dz1 W1
+            dx = dx.view(ctx.xs)
+        dW1 = torch.empty((F, K), dtype=torch.float32, device=dev)
+        gemm(1, F, K, M, dz1, F, 0, 1, x2, K, 0, 1, dW1, K, 0, ksplit=_ksplit_for(M, F * K))         # dW1 = dz1^T x
+        return dx, dW1, db1, dW2, db2, None, None, None
+
+
+def feed_forward(x, W1, b1, W2, b2, drop_p=0.0):
+    """dropout(linear2(dropout(relu(linear1(x))))) with the two nn.Dropout(p) of the block (training: pass drop_p > 0)."""
+    if drop_p > 0.0:
+        s1 = next_dropout_seed()
+        return FeedForwardFn.apply(x, W1, b1, W2, b2, float(drop_p), s1, next_dropout_seed())
+    return FeedForwardFn.apply(x, W1, b1, W2, b2, 0.0, 0, 0)
 
 
 class FusedAttentionFn(torch.autograd.Function):

@@ -44,6 +44,16 @@ int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha,
 /* Backward of that epilogue in one pass: dz = dy * [relu: y > 0] * [dropout keep / (1 - p)], y = the forward output
  * (with ReLU + dropout a positive output is "active and kept"; without ReLU the mask is recomputed from the seed). */
 int emloco_act_bwd(int64_t total, const float *dy, const float *y, int relu, float drop_p, uint32_t drop_seed, float *dz, void *stream);
+/* Backward through y = dropout(relu(x W^T + b)) fused into the GEMM that produces the incoming gradient (the feed-forward block
+ * of nn.TransformerEncoderLayer, model_jta.py:177: linear2(dropout(relu(linear1(x))))):
+ *   C[m][n] = (A[m][k] . B) o [y > 0] * scale      B = B[n][k] (trans_b = 0) or B[k][n] (trans_b = 1), y the forward output [m][n]
+ *   colsum[n] = column sums of C  (the bias gradient of the first linear layer)
+ * One launch instead of GEMM -> emloco_act_bwd_colsum: the unmasked gradient (m x n) is never written or re-read.  scale =
+ * 1 / (1 - p) of the forward's dropout (1 without).  n > 32; A and B 16-byte aligned, lda and ldb multiples of 4.  workspace: emloco_gemm_relu_bwd_workspace(m, n) floats. */
+int64_t emloco_gemm_relu_bwd_workspace(int m, int n);
+int emloco_gemm_relu_bwd(int m, int n, int k, const float *A, int lda, const float *B, int ldb, int trans_b, float *C,
+                         const float *y, float scale, float *colsum, float *workspace, int flags, void *stream);
+
 /* the same for a [m][n] gradient plus the bias gradient colsum[n] = sum_m dz (fixed-order folding; workspace as emloco_colsum) */
 int emloco_act_bwd_colsum(int m, int n, const float *dy, const float *y, int relu, float drop_p, uint32_t drop_seed, float *dz,
                           float *colsum, float *workspace, void *stream);

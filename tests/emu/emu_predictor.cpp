@@ -31,6 +31,20 @@ extern "C" int emu_gemm_f32(int batch, int m, int n, int k, float alpha, const f
     return 0;
 }
 
+// emloco_gemm_relu_bwd without the final fold: C = (A . B) o [y > 0] * scale, colpart [2 ceil(m / 128)][n] = 64-row column sums
+extern "C" int emu_gemm_relu_bwd(int m, int n, int k, const float *A, int lda, const float *B, int ldb, int tb, float *C, const float *y,
+                                 float scale, float *colpart) {
+    GemmArgs g{1, m, n, k, 1.0f, A, lda, 0, 0, B, ldb, 0, tb, C, n, 0, nullptr, 32, 1, nullptr, 0, 0, 0.0f, 0u, y, scale, colpart};
+    g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
+    g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
+    const unsigned gx = (n + 127) / 128, gy = (m + 127) / 128;
+    for (unsigned y0 = 0; y0 < gy; ++y0)
+        for (unsigned x = 0; x < gx; ++x)
+            emu::launch(1, 256, [&] { blockIdx.x = x; blockIdx.y = y0; blockIdx.z = 0; gemm_pick(g, k > 256)(g); });
+    blockIdx.y = 0;
+    return 0;
+}
+
 extern "C" int emu_obs_normalize(int rows, int cols, const float *x, int ldx, const float *mean, const float *var, float eps,
                                  float clip, int split, float *out0, int ld0, float *out1, int ld1) {
     for (int r = 0; r < rows; ++r)

@@ -36,6 +36,7 @@ template <class F> void launch(unsigned grid, unsigned block, F body) { launch_i
 }  // namespace emu
 
 static inline void __syncthreads() { emu::barrier(); }
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 
 template <class T> static inline T emu_exchange(T v, int src) {
     static_assert(sizeof(T) <= 8, "");

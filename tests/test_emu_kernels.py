@@ -231,6 +231,27 @@ def test_mfma_gemm_kernel_all_layouts():
     np.testing.assert_allclose(_gemm(Ab, Bb, 0, 0, 40, 50, 20, batch=3), np.einsum("bmk,bnk->bmn", Ab, Bb), **tol)
 
 
+def test_gemm_epilogue_fuses_relu_dropout_backward_and_bias_gradient():
+    """emloco_gemm_relu_bwd's kernel: C = (A . B) o [y > 0] * scale with the 64-row column sums of C (the partials of the bias
+    gradient), ragged m / n, both layouts of B, both stage depths: C is BIT-equal to the plain GEMM followed by the mask."""
+    lib = emu.lib()
+    rng = np.random.default_rng(12)
+    for m, n, k, tb in ((150, 70, 36, 1), (200, 136, 44, 0), (130, 260, 300, 1)):
+        A = rng.normal(size=(m, k)).astype(np.float32)
+        B = rng.normal(size=(k, n) if tb else (n, k)).astype(np.float32)
+        y = np.maximum(rng.normal(size=(m, n)), 0).astype(np.float32)
+        scale = np.float32(1 / 0.9)
+        Cm = np.full((m, n), 7.0, np.float32)
+        nparts = 2 * ((m + 127) // 128)
+        part = np.zeros((nparts, n), np.float32)
+        lib.emu_gemm_relu_bwd(m, n, k, P(A), k, P(B), n if tb else k, tb, P(Cm), P(y), C.c_float(scale), P(part))
+        plain = _gemm(A[None], B[None], 0, tb, m, n, k)[0]
+        want = np.where(y > 0, plain * scale, np.float32(0)).astype(np.float32)
+        assert np.array_equal(Cm, want)
+        sums = np.stack([want[r:r + 64].astype(np.float64).sum(0) for r in range(0, 64 * nparts, 64)])
+        np.testing.assert_allclose(part, sums, rtol=1e-5, atol=2e-4)
+
+
 def test_mfma_gemm_kernel_bf16_operands():
     """EMLOCO_GEMM_BF16 (opt-in): operands rounded to bf16 on their way into the matrix cores, fp32 accumulation.  Against
     the product of the bf16-ROUNDED operands the kernel is exact to fp32 accumulation error; against the fp32 product the

@@ -494,3 +494,37 @@ def test_attention_queries_entry_points_against_the_full_launch():
         part.backward(dout)
         assert torch.equal(b.grad[:, :Sq, :d], a.grad[:, :Sq, :d]) and (b.grad[:, Sq:, :d] == 0).all()
         _close(b.grad[..., d:].cpu().numpy(), a.grad[..., d:].cpu().numpy(), rel=1e-5, abs_=1e-7, what="dK / dV")
+
+
+def test_feed_forward_node_matches_the_two_linear_layers():
+    """ops.feed_forward (one autograd node; the hidden gradient is masked and column-summed in the epilogue of the GEMM that
+    produces it, emloco_gemm_relu_bwd) against ops.linear(relu, dropout) -> ops.linear(dropout) with the same dropout seeds:
+    output and input gradient bit-equal, weight / bias gradients equal up to summation order; with and without dropout."""
+    from emloco_amd.predictor import ops
+    dev = "cuda:0"
+    torch.manual_seed(2)
+    M, K, F = 4 * 453, 128, 1024
+    W1 = (torch.randn(F, K, device=dev) / K ** 0.5).requires_grad_(True)
+    b1 = (torch.randn(F, device=dev) * 0.1).requires_grad_(True)
+    W2 = (torch.randn(K, F, device=dev) / F ** 0.5).requires_grad_(True)
+    b2 = (torch.randn(K, device=dev) * 0.1).requires_grad_(True)
+    x0 = torch.randn(4, 453, K, device=dev)
+    dout = torch.randn(4, 453, K, device=dev)
+    for p in (0.0, 0.1):
+        res = []
+        for fused in (True, False):
+            ops._drop_counter[0] = 1000
+            x = x0.clone().requires_grad_(True)
+            for t in (W1, b1, W2, b2):
+                t.grad = None
+            if fused:
+                f = ops.feed_forward(x, W1, b1, W2, b2, drop_p=p)
+            else:
+                f = ops.linear(ops.linear(x, W1, b1, relu=True, drop_p=p), W2, b2, drop_p=p)
+            f.backward(dout)
+            res.append((f.detach(), x.grad, W1.grad.clone(), b1.grad.clone(), W2.grad.clone(), b2.grad.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        for a, b, what in zip(res[0][2:], res[1][2:], ("dW1", "db1", "dW2", "db2")):
+            _close(a.cpu().numpy(), b.cpu().numpy(), rel=1e-5, abs_=1e-6, what=what)
+        if p > 0:
+            assert (res[0][0] == 0).float().mean().item() > 0.05        # the output dropout really drops
