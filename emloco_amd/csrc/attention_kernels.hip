@@ -214,7 +214,7 @@ attn_fwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ backward 1: dQ (and D)
 template <int PREC, int DROP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[2][AT_T * AT_LD], Vs[2][AT_T * AT_LD], Bs[2][AT_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -275,7 +275,7 @@ attn_bwd_dq_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ backward 2: dK, dV
 template <int PREC, int DROP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 attn_bwd_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[2][AT_T * AT_LD], Os[2][AT_T * AT_LD], Ls[2][AT_T], Ds[2][AT_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;

@@ -131,9 +131,14 @@ int emloco_softmax_bwd(int rows, int cols, float scale, const float *P, const fl
 
 int emloco_layernorm_fwd(int rows, int d, float eps, const float *x, const float *res, const float *gamma, const float *beta,
                          float *y, float *mean, float *rstd, void *stream) {
+    return emloco_layernorm_fwd_save(rows, d, eps, x, res, gamma, beta, y, mean, rstd, nullptr, stream);
+}
+
+int emloco_layernorm_fwd_save(int rows, int d, float eps, const float *x, const float *res, const float *gamma, const float *beta,
+                              float *y, float *mean, float *rstd, float *xr, void *stream) {
     if (rows < 1 || d < 1 || d > 1024 || !x || !gamma || !beta || !y || !mean || !rstd) return pfail(-1, "emloco_layernorm_fwd: bad argument");
     hipLaunchKernelGGL(emloco::layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       rows, d, eps, x, res, gamma, beta, y, mean, rstd);
+                       rows, d, eps, x, res, gamma, beta, y, mean, rstd, xr);
     PHIPCHK(hipGetLastError());
     return 0;
 }

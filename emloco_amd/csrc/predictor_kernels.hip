@@ -452,7 +452,7 @@ softmax_bwd_kernel(int rows, int cols, float scale, const float *P, const float 
 // ------------------------------------------------------------------ layer norm (one wave per row, d <= 1024)
 __global__ void __launch_bounds__(256)
 layernorm_fwd_kernel(int rows, int d, float eps, const float *x, const float *res, const float *gamma, const float *beta,
-                     float *y, float *mean, float *rstd) {
+                     float *y, float *mean, float *rstd, float *xr_out) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -461,7 +461,10 @@ layernorm_fwd_kernel(int rows, int d, float eps, const float *x, const float *re
     for (int t = 0; t < 16; ++t) {
         const int j = lane + 64 * t;
         v[t] = 0.0f;
-        if (j < d) { v[t] = x[row * d + j] + (res ? res[row * d + j] : 0.0f); s += v[t]; }
+        if (j < d) {
+            v[t] = x[row * d + j] + (res ? res[row * d + j] : 0.0f); s += v[t];
+            if (xr_out) xr_out[row * d + j] = v[t];          // the sum the backward needs (saves a separate add pass)
+        }
     }
     const float mu = wave_sum(s) / (float)d;
     float q = 0.0f;

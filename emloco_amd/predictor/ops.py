@@ -35,6 +35,7 @@ def _lib():
         lib.emloco_softmax_fwd.argtypes = [ci, ci, ci, cf, vp, vp, vp, vp]
         lib.emloco_softmax_bwd.argtypes = [ci, ci, cf, vp, vp, vp, vp]
         lib.emloco_layernorm_fwd.argtypes = [ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.emloco_layernorm_fwd_save.argtypes = [ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_layernorm_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_colsum.argtypes = [ci, ci, vp, vp, vp, vp]
         lib.emloco_attention_fwd.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp]
@@ -394,9 +395,9 @@ class LayerNormFn(torch.autograd.Function):
         y = torch.empty_like(x2)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        _chk(_lib().emloco_layernorm_fwd(rows, d, float(eps), _p(x2), _p(r2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd),
-                                         _st(x)), "emloco_layernorm_fwd")
-        xr = x2 + r2 if r2 is not None else x2
+        xr = torch.empty_like(x2) if r2 is not None else x2
+        _chk(_lib().emloco_layernorm_fwd_save(rows, d, float(eps), _p(x2), _p(r2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd),
+                                              _p(xr) if r2 is not None else None, _st(x)), "emloco_layernorm_fwd_save")
         ctx.save_for_backward(xr, gamma, mean, rstd)
         ctx.has_res, ctx.shp = res is not None, shp
         return y.view(shp)

@@ -122,6 +122,9 @@ int emloco_dropout_keep_mask(uint32_t seed, uint64_t first_index, int64_t n, flo
  * res may be NULL.  Saves mean / rstd [rows] for the backward. */
 int emloco_layernorm_fwd(int rows, int d, float eps, const float *x, const float *res, const float *gamma,
                          const float *beta, float *y, float *mean, float *rstd, void *stream);
+/* the same, also writing xr [rows][d] = x + res (what emloco_layernorm_bwd wants) when xr is not NULL */
+int emloco_layernorm_fwd_save(int rows, int d, float eps, const float *x, const float *res, const float *gamma,
+                              const float *beta, float *y, float *mean, float *rstd, float *xr, void *stream);
 /* dxr = dL/d(x+res); dgamma/dbeta are reduced over rows in a fixed order.  xr = x + res (the fwd input sum)
  * is recomputed from y:  xhat = (y - beta) / gamma is avoided -- pass the saved sum `xr`. */
 int emloco_layernorm_bwd(int rows, int d, const float *xr, const float *gamma, const float *mean, const float *rstd,

@@ -66,7 +66,7 @@ extern "C" int emu_softmax_bwd(int rows, int cols, float scale, const float *P, 
 }
 extern "C" int emu_layernorm_fwd(int rows, int d, float eps, const float *x, const float *res, const float *g, const float *b,
                                  float *y, float *mean, float *rstd) {
-    emu::launch((unsigned)((rows + 3) / 4), 256, [&] { layernorm_fwd_kernel(rows, d, eps, x, res, g, b, y, mean, rstd); });
+    emu::launch((unsigned)((rows + 3) / 4), 256, [&] { layernorm_fwd_kernel(rows, d, eps, x, res, g, b, y, mean, rstd, nullptr); });
     return 0;
 }
 extern "C" int emu_layernorm_bwd(int rows, int d, const float *xr, const float *g, const float *mean, const float *rstd,
