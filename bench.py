@@ -367,6 +367,7 @@ def policy_leg(env, E, dev, steps, warmup):
 
     def one_step(timed):
         env.reset_done()
+        task.wait_obs()                     # the observation launch of the last step runs on a side stream (task.overlap_obs)
         if timed:
             ev0.record()
         act = pol.act(task.obs_buf, deterministic=False, generator=gen)

@@ -733,7 +733,13 @@ __global__ void locoval_reduce_kernel(int B, const float *ws, float *dparams, co
     if (p >= LV_NPARAM) return;
     const int rows = count ? (int)count[0] : B;         // sparse mode: the number of slots in use
     float s = 0.0f;
-    for (int i = 0; i < rows; ++i) s += ws[(long)i * LV_NPARAM + p];
+    int i = 0;
+    for (; i + 8 <= rows; i += 8) {             // eight rows requested at once, added in row order (one at a time the sum is a
+        float v[8];                              // chain of memory latencies: 38 us for the ~14 finished episodes of a step)
+        for (int u = 0; u < 8; ++u) v[u] = ws[(long)(i + u) * LV_NPARAM + p];
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; i < rows; ++i) s += ws[(long)i * LV_NPARAM + p];
     dparams[p] = s;
 }
 

@@ -59,6 +59,7 @@ int emloco_task_post_physics(const EmlocoTaskBufs *b, int mode, const int32_t *d
         return tfail(-1, "emloco_task_post_physics: observation buffers missing");
     if ((mode & EMLOCO_POST_REWARD) && (!b->rew_buf || !b->reward_raw || !b->dof_force || !b->dof_state))
         return tfail(-1, "emloco_task_post_physics: reward buffers missing");
+    if ((mode & EMLOCO_POST_SKIP_DONE) && !b->reset_buf) return tfail(-1, "emloco_task_post_physics: SKIP_DONE needs reset_buf");
     if ((mode & EMLOCO_POST_RESET) && (!b->reset_buf || !b->terminate_buf || !b->contact_force || !b->contact_body_mask))
         return tfail(-1, "emloco_task_post_physics: reset buffers missing");
     if ((mode & (EMLOCO_POST_AMP_ROW | EMLOCO_POST_AMP_SHIFT)) && (!b->amp_obs_buf || !b->dof_subset || !b->key_bodies || b->n_dof_subset > 64 || b->n_dof_subset % 3))

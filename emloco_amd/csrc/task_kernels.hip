@@ -148,6 +148,7 @@ post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_id
     if ((int)blockIdx.x >= n_ids) return;
     const int env = env_ids ? env_ids[blockIdx.x] : (int)blockIdx.x;
     if (env < 0) return;                     // padding entry of a device-compacted id list
+    if ((mode & EMLOCO_POST_SKIP_DONE) && t.reset_buf[env] != 0) return;      // block-uniform
 
     __shared__ float sh_body[TNB][13];
     __shared__ float sh_samp[EMLOCO_TRAJ_SAMPLES][3];

@@ -358,7 +358,9 @@ class Humanoid(BaseTask):
 
     # ------------------------------------------------------------------ step (humanoid.py:1184-1232)
     def pre_physics_step(self, actions):
-        self.actions = actions.to(self.device).clone()
+        # the reference clones (humanoid.py:1185); the copy is skipped when the caller's tensor already lives on the device:
+        # it is only read by the launch below, before control returns
+        self.actions = actions if (actions.device == torch.device(self.device) and actions.dtype == torch.float32) else actions.to(self.device).clone()
         if not self._pd_control:
             raise NotImplementedError("torque control is outside the hot path")
         # pd_tar = offset + scale * a with hands / frozen toes zeroed, one launch (humanoid.py:1188-1202,1281-1283)
@@ -382,9 +384,38 @@ class Humanoid(BaseTask):
     def _make_post_bufs(self):
         raise NotImplementedError("the fused post-physics kernel needs the trajectory / terrain task (HumanoidPedestrianTerrain)")
 
+    # Opt-in (set by a rollout loop that calls wait_obs() before anything reads the observations): the step's launch is split
+    # into progress / reward / reset flags on the caller's stream and observations (+ AMP rows) on a side stream, so the
+    # observations of the ~4000 live envs are built while the caller's stream already resets the finished ones.  The side
+    # launch leaves the finished envs alone (POST_SKIP_DONE): their rows are rebuilt by the reset path, as in the reference
+    # (humanoid.py:1140-1160 recomputes the observations of the reset envs).
+    overlap_obs = False
+
+    def wait_obs(self):
+        """Make the caller's stream wait for the observation launch of the last step (no-op without overlap_obs)."""
+        if getattr(self, "_obs_pending", False):
+            torch.cuda.current_stream(self.device).wait_event(self._ev_obs)
+            self._obs_pending = False
+
     def post_physics_step(self):
         self._refresh_sim_tensors()
-        self._launch_post(self._post_mode_step())                 # progress += 1, obs, reward, reset [, AMP] in one launch
+        mode = self._post_mode_step()
+        if self.overlap_obs and torch.device(self.device).type == "cuda":
+            if getattr(self, "_obs_stream", None) is None:
+                self._obs_stream = torch.cuda.Stream(device=self.device)
+                self._ev_flags, self._ev_obs = torch.cuda.Event(), torch.cuda.Event()
+            self.wait_obs()                                       # nobody asked for the previous step's observations
+            side_mode = mode & (L.POST_OBS | L.POST_AMP_SHIFT | L.POST_AMP_ROW)
+            self._launch_post(mode & ~side_mode)                  # progress += 1, reward, reset flags
+            main = torch.cuda.current_stream(self.device)
+            self._ev_flags.record(main)
+            self._obs_stream.wait_event(self._ev_flags)
+            with torch.cuda.stream(self._obs_stream):
+                self._launch_post(side_mode | L.POST_SKIP_DONE)
+                self._ev_obs.record(self._obs_stream)
+            self._obs_pending = True
+        else:
+            self._launch_post(mode)                               # progress += 1, obs, reward, reset [, AMP] in one launch
         self.extras["terminate"] = self._terminate_buf
         self.extras["reward_raw"] = self.reward_raw.detach()
         if self.motion_sym_loss:

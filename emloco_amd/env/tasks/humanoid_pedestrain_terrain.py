@@ -191,7 +191,7 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         L.check(rc, "emloco_task_reset")
         self._post.run(self._post_bufs if self._post_bufs is not None else self._ensure_post_bufs(), L.POST_OBS | L.POST_AMP_ROW, ids32)
         if flags.init_heading and flags.heading_inversion:
-            self._traj_gen.inverted = self._inverted_u8.bool()
+            self._traj_gen.inverted = self._inverted_u8.view(torch.bool)     # the kernels write 0 / 1 bytes: a view, no launch
         self.inverted = self._traj_gen.show_inverted()
         # _motion_start_times / _sampled_motion_ids: written in place by the reset kernels (aliased in _make_reset_bufs)
 
@@ -234,7 +234,7 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         self._post.run(self._post_bufs if self._post_bufs is not None else self._ensure_post_bufs(), L.POST_OBS | L.POST_AMP_ROW,
                        self._done_ids[:E])
         if flags.init_heading and flags.heading_inversion:
-            self._traj_gen.inverted = self._inverted_u8.bool()
+            self._traj_gen.inverted = self._inverted_u8.view(torch.bool)     # the kernels write 0 / 1 bytes: a view, no launch
         self.inverted = self._traj_gen.show_inverted()      # motion ids / start times: written in place by the reset kernels
 
     def _ensure_post_bufs(self):

@@ -64,7 +64,7 @@ class ReturnAccumulator:
 class LocoValRollout:
     def __init__(self, vec_env, use_pose=True, use_vel=True, horizon_length=32, gamma=0.99, inversion_penalty_scale=0.3,
                  policy=None, disc_reward=None, min_cum_rewards=-10.0, max_cum_rewards=100.0, lr=1e-3, weight_decay=1e-4,
-                 valuenet=None, warmup_epochs=20, max_epochs=20000, fused=None):
+                 valuenet=None, warmup_epochs=20, max_epochs=20000, fused=None, overlap_fit=True):
         self.vec_env = vec_env
         env = vec_env.env if hasattr(vec_env, "env") else vec_env
         self.env = env
@@ -83,6 +83,9 @@ class LocoValRollout:
         self.bucket = FlatGradBucket(self.valuenet.parameters(), extra=2)                  # tail: [loss sum, episode count]
         # the fused step (three small HIP launches around the LocoVal kernels, include/emloco_predictor.h) when the network
         # is the HIP one on a GPU; the torch formulation below it is the same arithmetic (CPU tests, other networks)
+        self.overlap_fit = bool(overlap_fit)
+        if self.overlap_fit and hasattr(self.task, "overlap_obs") and getattr(self.task, "_fused_reset", False):
+            self.task.overlap_obs = True           # this loop calls task.wait_obs() before the policy reads the observations
         self.fused = (isinstance(self.valuenet, ValuePoseNet) and self.device.type == "cuda") if fused is None else bool(fused)
         if self.fused:
             self._flat_params = torch.cat([p.detach().reshape(-1) for p in self.valuenet.parameters()]).contiguous()
@@ -118,6 +121,18 @@ class LocoValRollout:
                                       p(a.current_combined_rewards), p(a.discount_coefs), p(task.waypoint_traj), p(task.init_pose),
                                       p(task.init_vel), p(z["traj13"]), p(z["pose"]), p(z["vel"]), p(z["target"]), p(z["weight"]))
         self._flip = 0
+        # The fit (forward, loss gradient, backward, all-reduce, AdamW: ~75 us of small launches) only reads what the returns
+        # kernel staged (traj13 / pose / vel / target / weight), so it runs on a side stream while the main stream goes on to
+        # reset the finished envs and to launch the next physics step; the next returns kernel waits for it.
+        self._side = torch.cuda.Stream(device=dev) if (self.overlap_fit and torch.device(dev).type == "cuda") else None
+        self._ev_staged = torch.cuda.Event() if self._side is not None else None
+        self._ev_fit = torch.cuda.Event() if self._side is not None else None
+        self._fit_pending = False
+
+    def _sync_fit(self):
+        """Host-side readers of what the fit writes (statistics, LocoVal weights) wait for the side stream."""
+        if getattr(self, "_side", None) is not None:
+            self._side.synchronize()
 
     def _fused_step(self, rewards, amp_rewards, dones, inverted):
         """Bookkeeping + fit of one rollout step in 6 launches (returns, LocoVal fwd, fit grad, LocoVal bwd x2, gated AdamW)."""
@@ -131,8 +146,27 @@ class LocoValRollout:
         assert rewards.dtype == torch.float32 and dones.dtype == torch.int64 and inverted.dtype == torch.bool
         s = self._fstep
         s.inversion_penalty = float(self.inversion_penalty_scale)
+        main = torch.cuda.current_stream(self.device) if self._side is not None else None
+        if self._side is not None and self._fit_pending:
+            main.wait_event(self._ev_fit)                   # the previous fit is done with the staging buffers
         ops._chk(lib.emloco_locoval_returns(C.byref(s), P(rewards.contiguous()), P(amp_rewards), P(dones.contiguous()), P(inverted.contiguous()), st),
                  "emloco_locoval_returns")
+        if self._side is None:
+            self._fit_launches(st)
+            return
+        self._ev_staged.record(main)
+        self._side.wait_event(self._ev_staged)
+        with torch.cuda.stream(self._side):
+            self._fit_launches(current_stream_handle(self.device))
+            self._ev_fit.record(self._side)
+        self._fit_pending = True
+
+    def _fit_launches(self, st):
+        import ctypes as C
+        from ..predictor import ops
+        lib = ops._lib()
+        z, E = self._fz, self.num_actors
+        P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         n = self.valuenet._network
         w = [n.fc1.weight, n.fc1.bias, n.fc2.weight, n.fc2.bias, n.fc3.weight, n.fc3.bias]
         ops._chk(lib.emloco_locoval_fwd(E, P(z["traj13"]), 3, P(z["pose"]), P(z["vel"]), *[P(t) for t in w], P(z["value"]), P(z["x100"]),
@@ -154,15 +188,18 @@ class LocoValRollout:
     @property
     def vnet_loss(self):
         """sum-MSE of the most recent fit divided by its (global) episode count"""
+        self._sync_fit()
         a = self._stats.tolist()
         return a[0] / a[1] if a[1] > 0 else 0.0
 
     @property
     def fitted_episodes(self):
+        self._sync_fit()
         return int(round(self._stats[3].item()))
 
     @property
     def vnet_fits(self):
+        self._sync_fit()
         return int(round(self._stats[4].item()))
 
     def _reset_finished(self):
@@ -180,10 +217,14 @@ class LocoValRollout:
         task = self.task
         with torch.no_grad():
             self._reset_finished()
+            if hasattr(task, "wait_obs"):
+                task.wait_obs()                                   # the observations of the last step (built on a side stream)
             actions = self.policy(task.obs_buf)
             obs, rewards, dones, infos = self.vec_env.step(actions)
             inverted = task.inverted
             self.frames += self.num_actors
+            if not self._no_disc and hasattr(task, "wait_obs"):
+                task.wait_obs()                                   # the discriminator reads this step's AMP observations
             if self.fused:
                 amp_rewards = None if self._no_disc else self.disc_reward(infos["amp_obs"]).contiguous()
                 self._fused_step(rewards, amp_rewards, dones, inverted)
@@ -237,10 +278,12 @@ class LocoValRollout:
         """`<file>_valuenet.pth`, or `<file>_valuenet_<epoch:08d>.pth` for the intermediate checkpoints: a plain state_dict
         with the reference's keys (`_network.fc{1,2,3}.{weight,bias}`), loadable by train_jta.py / evaluate_jta.py."""
         path = model_output_file + ("_valuenet.pth" if epoch_num is None else "_valuenet_" + str(epoch_num).zfill(8) + ".pth")
+        self._sync_fit()
         torch.save({k: v.detach().cpu() for k, v in self.valuenet.state_dict().items()}, path)
         return path
 
     def restore(self, path):
+        self._sync_fit()
         self.valuenet.load_state_dict(torch.load(path, map_location=self.device))
 
     def train(self, max_epochs, model_output_file=None, save_freq=200, save_intermediate=True):

@@ -39,7 +39,9 @@ enum {
     EMLOCO_POST_RESET = 8,      /* reset_buf, terminate_buf */
     EMLOCO_POST_AMP_SHIFT = 16, /* history shift of amp_obs_buf */
     EMLOCO_POST_AMP_ROW = 32,   /* newest AMP row */
-    EMLOCO_POST_STEP = 63       /* everything post_physics_step does */
+    EMLOCO_POST_STEP = 63,      /* everything post_physics_step does */
+    EMLOCO_POST_SKIP_DONE = 64  /* leave the envs whose reset_buf is set alone (their rows are rebuilt by the reset path): lets the
+                                 * observation launch of a step run beside that step's resets on another stream */
 };
 
 typedef struct {

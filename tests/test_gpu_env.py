@@ -525,3 +525,42 @@ def test_bench_config_rollout_step_matches_oracle():
         np.testing.assert_allclose(rew.cpu().numpy()[sl], r, rtol=1e-5, atol=1e-6)
     finally:
         fill_flags(get_args(["--num_envs", "1"]))
+
+
+def test_observations_on_a_side_stream_give_the_same_rollout():
+    """task.overlap_obs: the step's launch is split -- progress / reward / reset flags on the caller's stream, observations and
+    AMP rows of the live envs on a side stream (POST_SKIP_DONE) while the caller's stream resets the finished envs -- and the
+    loop calls wait_obs() before reading.  Two identically seeded envs, one per mode, forced and natural resets: every buffer
+    bit-equal after every step."""
+    from emloco_amd import _lib as L
+    args = ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel"]
+    envs = [_make_env(96, args), _make_env(96, args)]
+    envs[1].task.overlap_obs = True
+    dev = envs[0].task.device
+    g = torch.Generator(device=dev)
+    names = ("_root_states", "_dof_state", "obs_buf", "_flip_obs_buf", "_amp_obs_buf", "progress_buf", "reset_buf", "rew_buf",
+             "reward_raw", "_terminate_buf", "waypoint_traj", "init_pose", "init_vel")
+    for k in range(30):
+        g.manual_seed(100 + k)
+        act = torch.randn(96, 69, device=dev, generator=g) * 0.3
+        g.manual_seed(500 + k)
+        rnd = torch.rand(96, L.RESET_RND, device=dev, generator=g)
+        for e in envs:
+            t = e.task
+            if k == 0:
+                t.reset_buf[:] = 1
+            if k % 7 == 3:
+                t.reset_buf[5:40:3] = 1
+            t.reset_done(rnd=rnd)
+            t.wait_obs()
+            e.step(act)
+        envs[1].task.wait_obs()
+        torch.cuda.synchronize()
+        for name in names:
+            a, b = getattr(envs[0].task, name), getattr(envs[1].task, name)
+            live = envs[0].task.reset_buf == 0               # rows of finished envs are rebuilt by the next reset_done
+            if name in ("obs_buf", "_flip_obs_buf", "_amp_obs_buf"):
+                assert torch.equal(a[live], b[live]), (k, name)
+            else:
+                assert torch.equal(a, b), (k, name)
+    assert getattr(envs[1].task, "_obs_stream", None) is not None
