@@ -572,8 +572,9 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l, "valu_issue_frac": valu,
                          "note": "latency bound, not bandwidth bound: ~9 KB of state per env per launch against ~50 k dependent fp32 VALU "
-                                 "wave-instructions (level-synchronous tree passes, 2 waves / SIMD); VALU issue ~27 % busy, "
-                                 "35 % of wave cycles waiting (profiles/r01_sim_step_valu.txt)"},
+                                 "wave-instructions (level-synchronous tree passes, 2 waves / SIMD, two resident rounds of 2048 waves for "
+                                 "4096 envs); valu_issue_frac and the wait fractions come from profiles/r02_sim_step_valu.txt, traffic "
+                                 "from profiles/r02_sim_step_hbm_bytes.json (PMC passes of this round's kernel)"},
         }
         if env_only is not None:
             out["env_step_only"] = {"value": round(E * a.steps / env_only, 1), "unit": "env-steps/s", "ms_per_step": round(env_only / a.steps * 1e3, 4),

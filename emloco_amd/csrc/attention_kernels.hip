@@ -16,6 +16,8 @@
 //     accumulator register s of lane half h holds tile row kappa(s, h) = (s & 3) + 8 (s >> 2) + 4 h, and since the
 //     reduction index order of an MFMA chain is free, step s simply pairs it with row kappa(s, h) of the LDS operand.
 // Reductions over d = 32 use dk(s, h) = 16 h + s, so a lane's 16 operand values are four ds_read_b128 of one LDS row.
+// The exponentials are `__expf` (v_exp_f32 of x log2 e, ~2 ulp): the kernels' time follows their VALU instruction count (the
+// 16 exponentials of a tile were a third of it with the range-checked expf), the 1e-4 parity bar is four orders above that error.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "dev_math.h"
@@ -29,6 +31,9 @@ struct __attribute__((aligned(16))) at_f32x4 { float x, y, z, w; };
 #define AT_DH 32                 // head dim
 #define AT_T 32                  // tile of the walked sequence
 #define AT_LD 36                 // LDS row stride (floats): 144 B keeps 16 consecutive rows' b128 reads on distinct banks
+#ifndef AT_EXP
+#define AT_EXP(x) __expf(x)
+#endif
 #define AT_NEG (-3.0e38f)        // "masked" sentinel: scores at or below it get probability 0
 
 struct AttnArgs {
@@ -188,9 +193,9 @@ attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) { p[r] = st[r] * a.scale + bias[r]; tmax = p[r] > tmax ? p[r] : tmax; }
         { const float o = __shfl_xor(tmax, 32); tmax = o > tmax ? o : tmax; }
         const float m_new = tmax > m ? tmax : m;
-        const float alpha = expf(m - m_new);            // m = AT_NEG on the first live tile -> 0 (or 1 while nothing is live)
+        const float alpha = AT_EXP(m - m_new);            // m = AT_NEG on the first live tile -> 0 (or 1 while nothing is live)
         float tsum = 0.0f;
-        for (int r = 0; r < 16; ++r) { p[r] = p[r] > AT_NEG ? expf(p[r] - m_new) : 0.0f; tsum += p[r]; }
+        for (int r = 0; r < 16; ++r) { p[r] = p[r] > AT_NEG ? AT_EXP(p[r] - m_new) : 0.0f; tsum += p[r]; }
         tsum += __shfl_xor(tsum, 32);
         lsum = lsum * alpha + tsum;
         m = m_new;
@@ -259,7 +264,7 @@ attn_bwd_dq_kernel(AttnArgs a) {
         at_vec16(Bs[buf], h, bias);
         for (int r = 0; r < 16; ++r) {
             const float v = st[r] * a.scale + bias[r];
-            const float p = v > AT_NEG ? expf(v - lse) : 0.0f;
+            const float p = v > AT_NEG ? AT_EXP(v - lse) : 0.0f;
             float dpr = dpt[r];                                           // d loss / d (dropped probability)
             if constexpr (DROP == 1) dpr *= at_keep(a, hkey, query, t * AT_T + at_kappa(r, h));
             ds[r] = a.scale * p * (dpr - dsum);
@@ -314,7 +319,7 @@ attn_bwd_dkv_kernel(AttnArgs a) {
         at_vec16(Ds[buf], h, drow);
         for (int r = 0; r < 16; ++r) {
             const float v = s[r] * a.scale + bias;
-            p[r] = v > AT_NEG ? expf(v - lrow[r]) : 0.0f;           // rows past the sequence carry lse = 3e38 -> 0
+            p[r] = v > AT_NEG ? AT_EXP(v - lrow[r]) : 0.0f;           // rows past the sequence carry lse = 3e38 -> 0
             float dpr = dp[r];
             if constexpr (DROP == 1) {
                 const float kp = at_keep(a, hkey, t * AT_T + at_kappa(r, h), key);

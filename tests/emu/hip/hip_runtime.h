@@ -63,6 +63,7 @@ static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x
 static inline float __int_as_float(int x) { float f; std::memcpy(&f, &x, 4); return f; }
 static inline int __float_as_int(float f) { int x; std::memcpy(&x, &f, 4); return x; }
 static inline float __fdividef(float a, float b) { return a / b; }
+#define AT_EXP(x) std::exp(x)   // the attention kernels use v_exp_f32 (__expf) on the device
 static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 using std::fabs; using std::sqrt; using std::floor; using std::ceil;
 
