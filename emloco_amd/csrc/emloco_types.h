@@ -20,7 +20,7 @@ struct EmlocoSimDev {
     int sc_n, sc_pad_;
     const unsigned char *sc_pairs;            /* [sc_n][2] */
     const float *sc_cap_a, *sc_cap_b, *sc_cap_r;   /* per-env collision capsules [E][24][3|3|1] */
-    float sc_k, sc_c, sc_max_pen, sc_pad2_;
+    float sc_k, sc_c, sc_max_pen, sc_mu;
     // height-field ground (hf = NULL: the plane z = ground_z).  hf[ix * hf_ny + iy] in units of hf_vs metres on an
     // hf_hs-metre grid whose sample (0, 0) sits at world (hf_ox, hf_oy)
     const short *hf;

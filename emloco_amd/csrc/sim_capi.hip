@@ -115,7 +115,7 @@ int emloco_sim_set_self_collision(EmlocoSim *s, const EmlocoSelfCollisionDesc *c
     if (c->n_pairs < 0 || c->n_pairs > EMLOCO_SC_MAXPAIRS) return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: at most 256 pairs");
     s->h_sc_pairs.clear();
     if (c->n_pairs == 0) return EMLOCO_OK;
-    if (!c->pairs || !c->cap_a || !c->cap_b || !c->cap_r || !(c->k > 0.0f) || c->c < 0.0f || !(c->max_pen > 0.0f))
+    if (!c->pairs || !c->cap_a || !c->cap_b || !c->cap_r || !(c->k > 0.0f) || c->c < 0.0f || !(c->max_pen > 0.0f) || !(c->mu >= 0.0f))
         return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: missing arrays or non-positive stiffness / penetration cap");
     for (int i = 0; i < c->n_pairs; ++i)
         if (c->pairs[2 * i] >= c->pairs[2 * i + 1] || c->pairs[2 * i + 1] >= EMLOCO_NB)
@@ -125,7 +125,7 @@ int emloco_sim_set_self_collision(EmlocoSim *s, const EmlocoSelfCollisionDesc *c
     s->h_sc_a.assign(c->cap_a, c->cap_a + E * NBs * 3);
     s->h_sc_b.assign(c->cap_b, c->cap_b + E * NBs * 3);
     s->h_sc_r.assign(c->cap_r, c->cap_r + E * NBs);
-    s->sc_k = c->k; s->sc_c = c->c; s->sc_max_pen = c->max_pen;
+    s->sc_k = c->k; s->sc_c = c->c; s->sc_max_pen = c->max_pen; s->sc_mu = c->mu;
     return EMLOCO_OK;
 }
 
@@ -193,7 +193,7 @@ int emloco_sim_prepare(EmlocoSim *s) {
         HIPCHK(s->d_sc_r.upload(s->h_sc_r.data(), s->h_sc_r.size()));
         d.sc_n = (int)(s->h_sc_pairs.size() / 2);
         d.sc_pairs = s->d_sc_pairs.p; d.sc_cap_a = s->d_sc_a.p; d.sc_cap_b = s->d_sc_b.p; d.sc_cap_r = s->d_sc_r.p;
-        d.sc_k = s->sc_k; d.sc_c = s->sc_c; d.sc_max_pen = s->sc_max_pen;
+        d.sc_k = s->sc_k; d.sc_c = s->sc_c; d.sc_max_pen = s->sc_max_pen; d.sc_mu = s->sc_mu;
     }
     d.hf = nullptr;
     if (!s->h_hf.empty()) {

@@ -362,7 +362,18 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                         if (pen > d.sc_max_pen) pen = d.sc_max_pen;
                         float F = d.sc_k * pen - d.sc_c * vn;
                         if (F > 0.0f) {
-                            const float Fv[3] = {n[0] * F, n[1] * F, n[2] * F};
+                            float Fv[3] = {n[0] * F, n[1] * F, n[2] * F};
+                            if (d.sc_mu > 0.0f) {      // Coulomb friction capped by the contact's damper: - min(mu F / |v_t|, c) v_t
+                                const float vr[3] = {(Vi[3] + wi[0]) - (Vj[3] + wjx[0]), (Vi[4] + wi[1]) - (Vj[4] + wjx[1]),
+                                                     (Vi[5] + wi[2]) - (Vj[5] + wjx[2])};
+                                const float vt[3] = {vr[0] - vn * n[0], vr[1] - vn * n[1], vr[2] - vn * n[2]};
+                                const float vt2 = vt[0] * vt[0] + vt[1] * vt[1] + vt[2] * vt[2];
+                                if (vt2 > 1e-12f) {
+                                    float g = d.sc_mu * F / sqrtf(vt2);
+                                    if (g > d.sc_c) g = d.sc_c;
+                                    for (int k = 0; k < 3; ++k) Fv[k] -= g * vt[k];
+                                }
+                            }
                             cross3(pt, Fv, w6);
                             w6[3] = Fv[0]; w6[4] = Fv[1]; w6[5] = Fv[2];
                             hit = true;

@@ -28,7 +28,7 @@ struct EmlocoSim {
     // optional self-collision description (host copies until prepare())
     std::vector<unsigned char> h_sc_pairs;
     std::vector<float> h_sc_a, h_sc_b, h_sc_r;
-    float sc_k = 0.0f, sc_c = 0.0f, sc_max_pen = 0.0f;
+    float sc_k = 0.0f, sc_c = 0.0f, sc_max_pen = 0.0f, sc_mu = 0.0f;
     // optional height-field ground (host copy until prepare())
     std::vector<short> h_hf;
     int hf_nx = 0, hf_ny = 0;

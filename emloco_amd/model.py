@@ -302,13 +302,13 @@ def self_collision_pairs(model: HumanoidModel, filters=None, margin=0.01):
     return np.asarray(pairs, dtype=np.uint8).reshape(-1, 2)
 
 
-def pack_self_collision(models, k=1.5e4, c=60.0, max_pen=0.04, filters=None):
+def pack_self_collision(models, k=1.5e4, c=60.0, max_pen=0.04, filters=None, mu=1.0):
     """Arrays of `EmlocoSelfCollisionDesc` (include/emloco_sim.h): the pair table of the first model (one table per
     sim: the kernels share it across envs) and per-env collision capsules."""
     caps = [collision_capsules(m) for m in models]
     f32 = lambda idx: np.ascontiguousarray(np.stack([cpl[idx] for cpl in caps]).astype(np.float32))
     return dict(pairs=np.ascontiguousarray(self_collision_pairs(models[0], filters)), cap_a=f32(0), cap_b=f32(1), cap_r=f32(2),
-                k=float(k), c=float(c), max_pen=float(max_pen))
+                k=float(k), c=float(c), max_pen=float(max_pen), mu=float(mu))
 
 
 def pack_models(models):

@@ -70,7 +70,8 @@ typedef struct {
 /* Limb-limb contact (`has_self_collision: True`, pacer.yaml:17; per-shape filters humanoid.py:917-944).  Penalty
  * contacts between the bodies' collision capsules, evaluated every substep inside the step kernel: for each listed
  * pair, closest points of the two sphere-swept segments; on overlap a force k * pen - c * v_n (>= 0, pen capped at
- * max_pen) along the contact normal acts on both bodies at the contact point (equal and opposite).  Optional: call
+ * max_pen) along the contact normal acts on both bodies at the contact point (equal and opposite), plus Coulomb friction
+ * regularised by the same damper: - min(mu F / |v_t|, c) v_t with v_t the tangential relative velocity there.  Optional: call
  * between emloco_sim_set_models and emloco_sim_prepare; never calling it (or n_pairs = 0) leaves self-collision off. */
 #define EMLOCO_SC_MAXPAIRS 256
 #define EMLOCO_SC_MAXHITS 32    /* simultaneous limb-limb contacts kept per env and substep (lowest pair indices first) */
@@ -83,6 +84,7 @@ typedef struct {
     float k;                   /* stiffness [N/m] */
     float c;                   /* normal damping [N s/m] */
     float max_pen;             /* penetration used for the spring is capped here [m] */
+    float mu;                  /* friction coefficient of the limb-limb contacts (0: frictionless) */
 } EmlocoSelfCollisionDesc;
 
 /* state tensors a caller may alias (gym.acquire_*_tensor, humanoid.py:137-148) */

@@ -70,7 +70,7 @@ class Model(C.Structure):
                 ("armature", C.POINTER(C.c_float)), ("effort", C.POINTER(C.c_float)),
                 ("sc_n", C.c_int32), ("sc_pairs", C.POINTER(C.c_uint8)), ("sc_cap_a", C.POINTER(C.c_float)),
                 ("sc_cap_b", C.POINTER(C.c_float)), ("sc_cap_r", C.POINTER(C.c_float)), ("sc_k", C.c_float), ("sc_c", C.c_float),
-                ("sc_max_pen", C.c_float),
+                ("sc_max_pen", C.c_float), ("sc_mu", C.c_float),
                 ("hf", C.POINTER(C.c_int16)), ("hf_nx", C.c_int32), ("hf_ny", C.c_int32), ("hf_hs", C.c_float), ("hf_vs", C.c_float),
                 ("hf_ox", C.c_float), ("hf_oy", C.c_float)]
 
@@ -96,6 +96,7 @@ class Sim:
             self.model.sc_pairs = _p(c["pairs"], C.c_uint8)
             self.model.sc_cap_a, self.model.sc_cap_b, self.model.sc_cap_r = _p(c["cap_a"]), _p(c["cap_b"]), _p(c["cap_r"])
             self.model.sc_k, self.model.sc_c, self.model.sc_max_pen = float(c["k"]), float(c["c"]), float(c["max_pen"])
+            self.model.sc_mu = float(c.get("mu", 1.0))
         self.hf = None
         if heightfield is not None:
             self.hf = np.ascontiguousarray(heightfield["samples"], dtype=np.int16)
@@ -128,6 +129,15 @@ class Sim:
         lib().orc_sim_free_accel(C.byref(self.params), C.byref(self.model), C.c_int(env), _p(self.root_state),
                                  _p(self.dof_state), _p(self.pd_target), _p(out))
         return out
+
+    def self_contacts(self, env=0):
+        """Limb-limb contacts at the current state: rows [bi, bj, point (relative to the root origin) 3, normal 3, F_normal,
+        total force on bi 3] (test hook)."""
+        info = np.zeros((32, 12), np.float32)
+        lib().orc_sim_self_contacts.restype = C.c_int
+        n = lib().orc_sim_self_contacts(C.byref(self.params), C.byref(self.model), C.c_int(env), _p(self.root_state),
+                                        _p(self.dof_state), _p(info))
+        return info[:n]
 
     def dense_dynamics(self, env=0):
         M = np.zeros((75, 75), np.float64)

@@ -153,7 +153,7 @@ typedef struct {
     int sc_n;
     const uint8_t *sc_pairs;
     const float *sc_a, *sc_b, *sc_r;
-    float sc_k, sc_c, sc_max_pen;
+    float sc_k, sc_c, sc_max_pen, sc_mu;
     const int16_t *hf;
     int hf_nx, hf_ny;
     float hf_hs, hf_inv_hs, hf_vs, hf_ox, hf_oy;
@@ -169,7 +169,7 @@ static EnvModel env_model(const OrcModel *m, int e) {
     x.arm = m->armature + (long)e * ORC_NDOF; x.eff = m->effort + (long)e * ORC_NDOF;
     x.hf = m->hf; x.hf_nx = m->hf_nx; x.hf_ny = m->hf_ny; x.hf_hs = m->hf_hs; x.hf_vs = m->hf_vs; x.hf_ox = m->hf_ox; x.hf_oy = m->hf_oy;
     x.hf_inv_hs = m->hf ? 1.0f / m->hf_hs : 0.0f;
-    x.sc_n = m->sc_n; x.sc_pairs = m->sc_pairs; x.sc_k = m->sc_k; x.sc_c = m->sc_c; x.sc_max_pen = m->sc_max_pen;
+    x.sc_n = m->sc_n; x.sc_pairs = m->sc_pairs; x.sc_k = m->sc_k; x.sc_c = m->sc_c; x.sc_max_pen = m->sc_max_pen; x.sc_mu = m->sc_mu;
     x.sc_a = m->sc_n > 0 ? m->sc_cap_a + (long)e * NB * 3 : 0;
     x.sc_b = m->sc_n > 0 ? m->sc_cap_b + (long)e * NB * 3 : 0;
     x.sc_r = m->sc_n > 0 ? m->sc_cap_r + (long)e * NB : 0;
@@ -275,6 +275,10 @@ static void seg_seg_closest(const float *p0, const float *p1, const float *q0, c
     for (int k = 0; k < 3; ++k) { c1[k] = p0[k] + d1[k] * s; c2[k] = q0[k] + d2[k] * t; }
 }
 
+/* test hook: when set, self_contacts records per hit [bi, bj, pt (about the root origin) 3, n 3, F_normal, F total 3] */
+static float (*g_sc_info)[12] = 0;
+static int g_sc_ninfo = 0;
+
 static void self_contacts(const Env *s, const EnvModel *m, float (*fext)[6]) {
     float seg[NB][7];
     memset(fext, 0, sizeof(float) * NB * 6);
@@ -306,7 +310,25 @@ static void self_contacts(const Env *s, const EnvModel *m, float (*fext)[6]) {
         if (pen > m->sc_max_pen) pen = m->sc_max_pen;
         const float F = m->sc_k * pen - m->sc_c * vn;
         if (!(F > 0.0f)) continue;
-        const float Fv[3] = {n[0] * F, n[1] * F, n[2] * F};
+        float Fv[3] = {n[0] * F, n[1] * F, n[2] * F};
+        if (m->sc_mu > 0.0f) {       /* Coulomb friction capped by the contact's damper: - min(mu F / |v_t|, c) v_t */
+            const float vr[3] = {(s->V[bi][3] + wi[0]) - (s->V[bj][3] + wj[0]), (s->V[bi][4] + wi[1]) - (s->V[bj][4] + wj[1]),
+                                 (s->V[bi][5] + wi[2]) - (s->V[bj][5] + wj[2])};
+            const float vt[3] = {vr[0] - vn * n[0], vr[1] - vn * n[1], vr[2] - vn * n[2]};
+            const float vt2 = vt[0] * vt[0] + vt[1] * vt[1] + vt[2] * vt[2];
+            if (vt2 > 1e-12f) {
+                float g = m->sc_mu * F / sqrtf(vt2);
+                if (g > m->sc_c) g = m->sc_c;
+                for (int k = 0; k < 3; ++k) Fv[k] -= g * vt[k];
+            }
+        }
+        if (g_sc_info) {
+            float *o = g_sc_info[nh];
+            o[0] = (float)bi; o[1] = (float)bj;
+            for (int k = 0; k < 3; ++k) { o[2 + k] = pt[k]; o[5 + k] = n[k]; o[9 + k] = Fv[k]; }
+            o[8] = F;
+            g_sc_ninfo = nh + 1;
+        }
         cross3(pt, Fv, hitw[nh]);
         hitw[nh][3] = Fv[0]; hitw[nh][4] = Fv[1]; hitw[nh][5] = Fv[2];
         hitb[nh][0] = bi; hitb[nh][1] = bj;
@@ -937,6 +959,23 @@ void orc_sim_free_accel(const OrcSimParams *prm, const OrcModel *mdl, int env, c
     memcpy(qdd75, a0, 24);
     for (int i = 1; i < NB; ++i)
         for (int k = 0; k < 3; ++k) qdd75[6 + (i - 1) * 3 + k] = qdd[i][k];
+}
+
+/* the limb-limb contacts of one env at the given state: info [ORC_SC_MAXHITS][12] as described at g_sc_info; returns the count */
+int orc_sim_self_contacts(const OrcSimParams *prm, const OrcModel *mdl, int env, const float *root_state, const float *dof_state,
+                          float *info) {
+    static Env s;
+    static float fext[NB][6];
+    EnvModel m = env_model(mdl, env);
+    (void)prm;
+    load_state(&s, root_state + (long)env * 13, dof_state + (long)env * ORC_NDOF * 2);
+    kinematics(&s, &m);
+    velocities(&s, &m, s.V, s.V0, s.wj);
+    if (m.sc_n <= 0) return 0;
+    g_sc_info = (float (*)[12])info; g_sc_ninfo = 0;
+    self_contacts(&s, &m, fext);
+    g_sc_info = 0;
+    return g_sc_ninfo;
 }
 
 void orc_sim_dense_dynamics(const OrcSimParams *prm, const OrcModel *mdl, int env, const float *root_state,

@@ -51,7 +51,7 @@ typedef struct {
     int32_t sc_n;
     const uint8_t *sc_pairs;   /* [sc_n][2] */
     const float *sc_cap_a, *sc_cap_b, *sc_cap_r;   /* [E][24][3|3|1] */
-    float sc_k, sc_c, sc_max_pen;
+    float sc_k, sc_c, sc_max_pen, sc_mu;
     /* optional height-field ground (hf = NULL: the plane z = ground_z); mirrors emloco_sim_set_ground_heightfield */
     const int16_t *hf;         /* [hf_nx][hf_ny] in units of hf_vs metres on an hf_hs-metre grid, sample (0,0) at (hf_ox, hf_oy) */
     int32_t hf_nx, hf_ny;
@@ -79,6 +79,8 @@ void orc_sim_dense_dynamics(const OrcSimParams *prm, const OrcModel *mdl, int en
                             const float *root_state, const float *dof_state, const float *pd_target,
                             double *M75x75, double *rhs75);
 /* unconstrained (contact-free) acceleration of one env by the ABA factorisation: qdd[75] */
+int orc_sim_self_contacts(const OrcSimParams *prm, const OrcModel *mdl, int env, const float *root_state, const float *dof_state,
+                          float *info);
 void orc_sim_free_accel(const OrcSimParams *prm, const OrcModel *mdl, int env,
                         const float *root_state, const float *dof_state, const float *pd_target, float *qdd75);
 #endif

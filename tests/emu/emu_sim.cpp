@@ -30,7 +30,7 @@ extern "C" int emu_sim_step(const EmlocoSimParams *prm, const EmlocoModelDesc *m
     d.rb_state = rb_state; d.contact_force = contact_force; d.dof_force = dof_force; d.lambda_ws = lambda_ws;
     if (g_sc && g_sc->n_pairs > 0) {
         d.sc_n = g_sc->n_pairs; d.sc_pairs = g_sc->pairs; d.sc_cap_a = g_sc->cap_a; d.sc_cap_b = g_sc->cap_b; d.sc_cap_r = g_sc->cap_r;
-        d.sc_k = g_sc->k; d.sc_c = g_sc->c; d.sc_max_pen = g_sc->max_pen;
+        d.sc_k = g_sc->k; d.sc_c = g_sc->c; d.sc_max_pen = g_sc->max_pen; d.sc_mu = g_sc->mu;
     }
     if (g_hf.samples) {
         d.hf = g_hf.samples; d.hf_nx = g_hf.nx; d.hf_ny = g_hf.ny; d.hf_hs = g_hf.hs; d.hf_inv_hs = 1.0f / g_hf.hs; d.hf_vs = g_hf.vs;

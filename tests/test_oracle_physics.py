@@ -470,3 +470,59 @@ def test_self_collision_keeps_limbs_apart():
     assert d_on.max() < 0.5 * d_off.max() and d_on[-10:].max() < 0.03      # with it the overlap stays shallow
     assert np.abs(v_on - v_off).max() < 5e-3                    # internal forces only: no net push on the floating body
     assert np.isfinite(s_on.rb_state).all()
+
+
+def test_limb_limb_friction_is_coulomb_capped_by_the_damper_and_internal():
+    """Friction in the limb-limb contacts: at every contact the force on body i is
+    n F_n - min(mu F_n / |v_t|, c) v_t with v_t the tangential relative velocity of the two bodies at the contact point
+    (recomputed here in float64 from the body states), i.e. inside the Coulomb cone, opposing the sliding, and never stiffer
+    than the contact's normal damper (what keeps the explicit force stable); mu = 0 gives the bare normal force; being equal
+    and opposite at one point it leaves the momentum of the floating body alone; its power is negative (it only dissipates)."""
+    from emloco_amd.model import pack_self_collision
+    m = smpl_humanoid()
+    sh = m.names.index("L_Shoulder")
+
+    def run(mu, steps=60, check=False):
+        sc = pack_self_collision([m], mu=mu)
+        s = oracle.Sim(pack_models([m]), oracle.default_params(gravity_z=0.0), self_collision=sc)
+        s.root_state[0, :3] = [0, 0, 3.0]
+        s.pd_target[0, (sh - 1) * 3 + 0] = -2.5                 # the left arm swings down into the trunk / hip ...
+        s.pd_target[0, (sh - 1) * 3 + 1] = 0.6                  # ... and drags along it
+        slide, checked, sliding_rows, capped_rows = [], 0, 0, 0
+        for k in range(steps):
+            s.pd_target[0, (sh - 1) * 3 + 1] = 0.6 + 0.5 * np.sin(0.5 * k)      # keep it sliding
+            s.step()
+            rows = s.self_contacts()
+            rb = s.rb_state[0].astype(np.float64)
+            for r in rows:
+                bi, bj = int(r[0]), int(r[1])
+                p = rb[0, :3] + r[2:5]
+                n, Fn, F = r[5:8].astype(np.float64), float(r[8]), r[9:12].astype(np.float64)
+                vi = rb[bi, 7:10] + np.cross(rb[bi, 10:13], p - rb[bi, :3])
+                vj = rb[bj, 7:10] + np.cross(rb[bj, 10:13], p - rb[bj, :3])
+                vr = vi - vj
+                vt = vr - vr.dot(n) * n
+                slide.append(float((F - F.dot(n) * n).dot(vt)))          # power of the tangential force [W]
+                if check:
+                    g = min(mu * Fn / max(np.linalg.norm(vt), 1e-9), sc["c"])
+                    want = n * Fn - g * vt
+                    np.testing.assert_allclose(F, want, rtol=2e-3, atol=2e-3 * max(Fn, 1.0))
+                    ft = F - F.dot(n) * n
+                    assert np.linalg.norm(ft) <= mu * Fn * (1 + 1e-3) + 1e-3 and ft.dot(vt) <= 1e-6
+                    sliding_rows += np.linalg.norm(vt) > 1e-3
+                    capped_rows += mu * Fn / max(np.linalg.norm(vt), 1e-9) > sc["c"]
+                    checked += 1
+                elif mu == 0.0:
+                    np.testing.assert_allclose(F, n * Fn, rtol=1e-6, atol=1e-6)
+        return s, np.array(slide), checked, sliding_rows, capped_rows
+
+    s1, slide1, checked, sliding_rows, capped_rows = run(1.0, check=True)
+    s0, slide0, _, _, _ = run(0.0)
+    assert checked > 40 and sliding_rows > 20, (checked, sliding_rows)
+    # at mu = 1 and these contact forces (100-300 N) the damper cap is the active bound below ~3 m/s of sliding; a slippery
+    # mu puts the same contacts on the Coulomb cone
+    _, _, checked_s, _, capped_s = run(0.01, check=True)
+    assert capped_rows > 0.5 * checked and checked_s > 40 and checked_s - capped_s >= 5, (capped_rows, checked, capped_s, checked_s)
+    P1 = _momenta(m, s1.rb_state[0])[0]
+    assert np.linalg.norm(P1) < 2e-3 * m.mass.sum()                             # internal forces: the floating body does not drift
+    assert slide1.sum() < -1.0 and np.all(slide1 <= 1e-6) and np.abs(slide0).max() < 1e-3, (slide1.sum(), np.abs(slide0).max())   # dissipative; none without mu
