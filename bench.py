@@ -368,6 +368,8 @@ def policy_leg(env, E, dev, steps, warmup):
     def one_step(timed):
         env.reset_done()
         task.wait_obs()                     # the observation launch of the last step runs on a side stream (task.overlap_obs)
+        if hasattr(task, "wait_reset"):
+            task.wait_reset()               # the policy reads the reset envs' fresh observations
         if timed:
             ev0.record()
         act = pol.act(task.obs_buf, deterministic=False, generator=gen)
@@ -496,6 +498,10 @@ def main():
     def noise_policy(obs):
         counter[0] += 1
         return pool[counter[0] % 64]
+
+    # the stand-in policy does not read the observations, so the reset chain of the finished envs (and their step) runs
+    # beside the step of the live envs on a second stream (task.overlap_reset); a policy that reads them waits (policy leg)
+    noise_policy.reads_obs = False
 
     horizon = 32
     agent = LocoValRollout(env, horizon_length=horizon, policy=noise_policy)

@@ -27,4 +27,8 @@ struct EmlocoSimDev {
     int hf_nx, hf_ny;
     float hf_hs, hf_inv_hs, hf_vs, hf_ox, hf_oy, hf_pad_;
     long long *prof;   /* optional (built with -DEMLOCO_SIM_PROFILE): per-phase cycle stamps of env 0, else NULL */
+    // subset launches (emloco_sim_step_subset), both NULL for the plain step: envs whose step_skip entry is non-zero are left
+    // untouched; with step_ids workgroup i steps env step_ids[i] of a device-compacted list (valid ids first, -1 after them)
+    const long long *step_skip;
+    const int *step_ids;
 };

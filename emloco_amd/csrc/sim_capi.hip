@@ -263,6 +263,33 @@ int emloco_sim_step(EmlocoSim *s, int n_calls, void *stream) {
     return EMLOCO_OK;
 }
 
+int emloco_sim_step_subset(EmlocoSim *s, int n_calls, const int64_t *dev_skip, const int32_t *dev_ids, int n_ids, void *stream) {
+    if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_step_subset: null sim");
+    if (!s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_step_subset: sim not prepared");
+    if (n_calls < 1) return fail(EMLOCO_E_ARG, "emloco_sim_step_subset: n_calls < 1");
+    if ((dev_skip == nullptr) == (dev_ids == nullptr)) return fail(EMLOCO_E_ARG, "emloco_sim_step_subset: exactly one of skip flags / id list");
+    if (dev_ids && (n_ids < 0 || n_ids > s->n_env)) return fail(EMLOCO_E_ARG, "emloco_sim_step_subset: bad id count");
+    if (dev_ids && n_ids == 0) return EMLOCO_OK;
+    EmlocoSimParams p = s->prm;
+    p.n_sub = s->prm.n_sub * n_calls;
+    EmlocoSimDev d = s->dev;
+    d.step_skip = (const long long *)dev_skip;
+    d.step_ids = (const int *)dev_ids;
+    hipStream_t st = (hipStream_t)stream;
+    // the launch over everything but the flagged envs is the one the timing log follows (it stands where emloco_sim_step stood)
+    const bool timed = s->timing && dev_skip;
+    const int slot = s->ev_head;
+    if (timed) HIPCHK(hipEventRecord(s->ev0[slot], st));
+    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(dev_ids ? n_ids : s->n_env)), dim3(64), 0, st, p, d);
+    HIPCHK(hipGetLastError());
+    if (timed) {
+        HIPCHK(hipEventRecord(s->ev1[slot], st));
+        s->ev_head = (slot + 1) % EmlocoSim::kRing;
+        if (s->ev_count < EmlocoSim::kRing) ++s->ev_count;
+    }
+    return EMLOCO_OK;
+}
+
 int emloco_sim_sync(EmlocoSim *s, void *stream) {
     if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_sync: null sim");
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));

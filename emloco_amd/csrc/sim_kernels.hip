@@ -40,6 +40,15 @@ namespace emloco {
 #define MAXR (3 * EMLOCO_MAXC)
 #define MAXCAND EMLOCO_MAXCAND
 #define EMLOCO_WH_MAX 0.4f /* largest link rotation per substep [rad]: cap of the link angular speed, see phase 1 */
+#ifndef EMLOCO_WS
+#define EMLOCO_WS 1
+#endif
+#ifndef EMLOCO_IMP
+#define EMLOCO_IMP 1
+#endif
+#ifndef EMLOCO_GS
+#define EMLOCO_GS 2
+#endif
 #define YLEN 30 /* chain-propagation vector: 6 root + 3 per tree level (depth <= 8) */
 
 // index into a packed symmetric 6x6 (upper triangle, row-major): (a<=b)
@@ -89,9 +98,11 @@ struct BodyConst {   // per-lane (lane = body) constants kept in registers for t
 #endif
 __global__ void __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(EMLOCO_SIM_WAVES_PER_SIMD, EMLOCO_SIM_WAVES_PER_SIMD)))
 sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
-    const int env = blockIdx.x;
+    int env = blockIdx.x;
     const int lane = threadIdx.x;
-    if (env >= d.n_env) return;
+    if (d.step_ids) env = d.step_ids[blockIdx.x];                 // subset launch over a compacted id list (padding: -1)
+    if (env < 0 || env >= d.n_env) return;
+    if (d.step_skip && d.step_skip[env] != 0) return;            // subset launch: flagged envs are stepped elsewhere
 
     // ---------------------------------------------------------------- LDS: one blob, 16 KB per env (8 envs per CU need <= 20 KB)
     // Every per-body row starts on a 16-byte boundary and is padded to a multiple of four words, so a lane moves its row with
@@ -847,12 +858,32 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         // contact while the current one is being resolved (the reads do not depend on the multipliers)
 #define A_OF(rr) sh_A[tri_index(ls, (rr))]
         float w = rhs;
+#if EMLOCO_WS == 0
         for (int rr = 0; rr < nr; ++rr) {                         // warm start
             const float lr = lane_bcast(lam, rr);
             const float av = A_OF(rr);
             w = (lr != 0.0f) ? fmaf(av, lr, w) : w;
         }
+#else
+        {                                                          // warm start (matrix entries read one contact ahead)
+            float n0 = 0.0f, n1a = 0.0f, n2a = 0.0f;
+            if (nc > 0) { n0 = A_OF(0); n1a = A_OF(1); n2a = A_OF(2); }
+            for (int c = 0; c < nc; ++c) {
+                const int r0 = 3 * c;
+                const float a0 = n0, a1 = n1a, a2 = n2a;
+                if (c + 1 < nc) { n0 = A_OF(r0 + 3); n1a = A_OF(r0 + 4); n2a = A_OF(r0 + 5); }
+                const float l0 = lane_bcast(lam, r0), l1 = lane_bcast(lam, r0 + 1), l2 = lane_bcast(lam, r0 + 2);
+                const float u0 = fmaf(a0, l0, w);
+                w = (l0 != 0.0f) ? u0 : w;
+                const float u1 = fmaf(a1, l1, w);
+                w = (l1 != 0.0f) ? u1 : w;
+                const float u2 = fmaf(a2, l2, w);
+                w = (l2 != 0.0f) ? u2 : w;
+            }
+        }
+#endif
         PSTAMP(11);
+#if EMLOCO_GS == 0
         for (int it = 0; it < prm.n_iter; ++it) {
             float n0 = 0.0f, n1a = 0.0f, n2a = 0.0f;
             if (nc > 0) { n0 = A_OF(0); n1a = A_OF(1); n2a = A_OF(2); }
@@ -889,6 +920,93 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
 #undef A_OF
         if (lane < MAXR) sh_lam[lane] = (lane < nr) ? lam : 0.0f;
         __syncthreads();
+#else
+        // The sweeps resolve a contact inside ONE lane, the lane of its normal row (the leader): it holds the three
+        // multipliers of the contact, the reciprocal diagonals and the sub-diagonal of its 3 x 3 block, fetches the residuals
+        // of its two tangent rows (two v_readlane of values that are ready since the previous contact) and walks normal ->
+        // tangent 1 -> tangent 2 -> friction cone on its own, forming the intermediate residuals exactly as the rows'
+        // own lanes will; the three changes (and the two of a cone projection) are then broadcast and every lane folds them
+        // into its w in the same order.  Same operations per value as the row-by-row sweep (the oracle's), a third of the
+        // cross-lane round trips on the dependent chain.
+        const int lr0 = ls - (lane < nr ? myd : 0);               // first row of this lane's contact
+        float gl0 = __shfl(lam, lr0), gl1 = __shfl(lam, lr0 + 1), gl2 = __shfl(lam, lr0 + 2);
+        const float gi1 = __shfl(ainv, lr0 + 1), gi2 = __shfl(ainv, lr0 + 2);
+        const float gA10 = sh_A[tri_index(lr0 + 1, lr0)], gA20 = sh_A[tri_index(lr0 + 2, lr0)], gA21 = sh_A[tri_index(lr0 + 2, lr0 + 1)];
+        const bool leader = lane < nr && myd == 0;
+        for (int it = 0; it < prm.n_iter; ++it) {
+            float n0 = 0.0f, n1a = 0.0f, n2a = 0.0f;
+            if (nc > 0) { n0 = A_OF(0); n1a = A_OF(1); n2a = A_OF(2); }
+            for (int c = 0; c < nc; ++c) {
+                const int r0 = 3 * c;
+                const float a0 = n0, a1 = n1a, a2 = n2a;
+                if (c + 1 < nc) { n0 = A_OF(r0 + 3); n1a = A_OF(r0 + 4); n2a = A_OF(r0 + 5); }
+                const float w1s = lane_bcast(w, r0 + 1), w2s = lane_bcast(w, r0 + 2);
+#if EMLOCO_GS == 1
+                float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, p1 = 0.0f, p2 = 0.0f;
+                bool proj = false;
+                if (lane == r0) {
+                    float nl0 = fmaf(-w, ainv, gl0);
+                    if (nl0 < 0.0f) nl0 = 0.0f;
+                    d0 = nl0 - gl0;
+                    const float w1 = fmaf(gA10, d0, w1s);
+                    const float nl1 = fmaf(-w1, gi1, gl1);
+                    d1 = nl1 - gl1;
+                    const float w2 = fmaf(gA21, d1, fmaf(gA20, d0, w2s));
+                    const float nl2 = fmaf(-w2, gi2, gl2);
+                    d2 = nl2 - gl2;
+                    gl0 = nl0; gl1 = nl1; gl2 = nl2;
+                    const float lim = prm.mu * nl0;
+                    const float m2 = fmaf(nl1, nl1, nl2 * nl2);
+                    if (__builtin_expect(m2 > lim * lim, 0)) {   // outside the friction cone
+                        const float sc = lim / sqrtf(m2);
+                        const float n1 = nl1 * sc, n2 = nl2 * sc;
+                        p1 = n1 - nl1; p2 = n2 - nl2;
+                        gl1 = n1; gl2 = n2;
+                        proj = true;
+                    }
+                }
+                w = fmaf(a0, lane_bcast(d0, r0), w);
+                w = fmaf(a1, lane_bcast(d1, r0), w);
+                w = fmaf(a2, lane_bcast(d2, r0), w);
+                if (__builtin_expect(__ballot(proj) != 0ull, 0)) {   // wave-uniform
+                    w = fmaf(a1, lane_bcast(p1, r0), w);
+                    w = fmaf(a2, lane_bcast(p2, r0), w);
+                }
+#else
+                // branch-free: every lane runs the leader's chain on its own contact's values, only lane r0's results are read
+                float nl0 = fmaf(-w, ainv, gl0);
+                if (nl0 < 0.0f) nl0 = 0.0f;
+                const float d0 = nl0 - gl0;
+                const float w1 = fmaf(gA10, d0, w1s);
+                const float nl1 = fmaf(-w1, gi1, gl1);
+                const float d1 = nl1 - gl1;
+                const float w2 = fmaf(gA21, d1, fmaf(gA20, d0, w2s));
+                const float nl2 = fmaf(-w2, gi2, gl2);
+                const float d2 = nl2 - gl2;
+                const bool me = lane == r0;
+                gl0 = me ? nl0 : gl0; gl1 = me ? nl1 : gl1; gl2 = me ? nl2 : gl2;
+                const float lim = prm.mu * nl0;
+                const float m2 = fmaf(nl1, nl1, nl2 * nl2);
+                w = fmaf(a0, lane_bcast(d0, r0), w);
+                w = fmaf(a1, lane_bcast(d1, r0), w);
+                w = fmaf(a2, lane_bcast(d2, r0), w);
+                if (__builtin_expect(__ballot(me && m2 > lim * lim) != 0ull, 0)) {   // wave-uniform: outside the friction cone
+                    const float sc = lim / sqrtf(m2);
+                    const float n1 = nl1 * sc, n2 = nl2 * sc;
+                    gl1 = me ? n1 : gl1; gl2 = me ? n2 : gl2;
+                    w = fmaf(a1, lane_bcast(n1 - nl1, r0), w);
+                    w = fmaf(a2, lane_bcast(n2 - nl2, r0), w);
+                }
+#endif
+            }
+            if (it == 0) PSTAMP(12);
+        }
+#undef A_OF
+        if (leader) { sh_lam[lane] = gl0; sh_lam[lane + 1] = gl1; sh_lam[lane + 2] = gl2; }
+        else if (lane >= nr && lane < MAXR) sh_lam[lane] = 0.0f;
+        __syncthreads();
+        lam = (lane < nr) ? sh_lam[lane] : 0.0f;
+#endif
 
         PSTAMP(8);
         // ============================================================ 7. impulses -> velocity change (second solve)
@@ -896,6 +1014,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         if (is_body && last && nc == 0)
             for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = 0.0f;
         if (nc > 0) {
+#if EMLOCO_IMP == 0
             float pin[6] = {0, 0, 0, 0, 0, 0};
             if (is_body) {
                 float cf[3] = {0, 0, 0};
@@ -916,6 +1035,32 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     }
                 if (last) for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = cf[k];
             }
+#else
+            // every row's lane stages its Jacobian row (and, in the last substep, its share of the reported contact force)
+            // in the matrix's LDS, which is dead by now; a body then adds up its rows in contact order with one fma chain
+            float (*sh_row)[12] = (float (*)[12])sh_A;
+            if (lane < nr) {
+                float dir[3] = {myd == 1 ? 1.0f : 0.0f, myd == 2 ? 1.0f : 0.0f, myd == 0 ? 1.0f : 0.0f};
+                if (hf_on) for (int k = 0; k < 3; ++k) dir[k] = sh_cdir[myc][3 * myd + k];
+                const float x[3] = {sh_cx[myc][0], sh_cx[myc][1], sh_cx[myc][2]};
+                float Jr[3];
+                cross3(x, dir, Jr);
+                for (int k = 0; k < 3; ++k) { sh_row[lane][k] = Jr[k]; sh_row[lane][3 + k] = dir[k]; }
+                if (last) for (int k = 0; k < 3; ++k) sh_row[lane][6 + k] = dir[k] * lam / h;
+            }
+            __syncthreads();
+            float pin[6] = {0, 0, 0, 0, 0, 0};
+            if (is_body) {
+                float cf[3] = {0, 0, 0};
+                const int r_end = 3 * sh_crange[NB + lane] + 3;
+                for (int r = 3 * sh_crange[lane]; r < r_end; ++r) {
+                    const float l = sh_lam[r];
+                    for (int k = 0; k < 6; ++k) pin[k] = fmaf(-sh_row[r][k], l, pin[k]);
+                    if (last) for (int k = 0; k < 3; ++k) cf[k] += sh_row[r][6 + k];
+                }
+                if (last) for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = cf[k];
+            }
+#endif
             // bodies deeper than every contact body carry no impulse and have no loaded descendant: their share of the up pass
             // is exactly zero (uh = +0, pa = +0), so the pass starts at the deepest contact level
             if (is_body && bc.depth > dmax) { uh[0] = uh[1] = uh[2] = 0.0f; for (int k = 0; k < 6; ++k) sh_pa[lane][k] = 0.0f; }

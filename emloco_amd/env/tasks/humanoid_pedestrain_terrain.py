@@ -201,6 +201,7 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         queue; here the id list is compacted on the device (`emloco_task_compact_done`, padding entries -1 are skipped by
         the kernels) and the per-env bookkeeping uses masks.  Same result as `reset(reset_buf.nonzero())` with the same
         random rows.  Falls back to that when the fused reset path is not active."""
+        import contextlib
         import ctypes as C
         from ...sim import current_stream_handle
         if not (getattr(self, "_fused_reset", False) and getattr(self, "_traj_gen", None) is not None):
@@ -213,29 +214,81 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         E = self.num_envs
         if getattr(self, "_done_ids", None) is None:
             self._done_ids = torch.full((E + 1,), -1, dtype=torch.int32, device=self.device)
-        st = current_stream_handle(torch.device(self.device))
+        dev = torch.device(self.device)
         lib = self._post.lib
-        L.check(lib.emloco_task_compact_done(C.c_void_p(self.reset_buf.data_ptr()), E, C.c_void_p(self._done_ids.data_ptr()), st),
-                "emloco_task_compact_done")
-        if rnd is None:
-            # random rows made on the device for the finished envs only (row i serves the i-th finished env, ascending id),
-            # from a per-call seed: torch's seed (set by run.py / set_seed) + a call counter
-            if getattr(self, "_rnd_ws", None) is None:
-                self._rnd_ws = torch.empty((E, L.RESET_RND), device=self.device)
-                self._rnd_calls = 0
-                self._rnd_seed0 = int(torch.initial_seed()) & 0xFFFFFFFFFFFF
-            self._rnd_calls += 1
-            L.check(lib.emloco_task_reset_seeded(self.sim.native._h, C.byref(self._reset_bufs), C.c_void_p(self._done_ids.data_ptr()), E,
-                                                 C.c_uint64((self._rnd_seed0 * 0x9E3779B97F4A7C15 + self._rnd_calls) & 0xFFFFFFFFFFFFFFFF),
-                                                 C.c_void_p(self._rnd_ws.data_ptr()), st), "emloco_task_reset_seeded")
-        else:
-            L.check(lib.emloco_task_reset(self.sim.native._h, C.byref(self._reset_bufs), C.c_void_p(self._done_ids.data_ptr()), E,
-                                          C.c_void_p(rnd.data_ptr()), st), "emloco_task_reset")
-        self._post.run(self._post_bufs if self._post_bufs is not None else self._ensure_post_bufs(), L.POST_OBS | L.POST_AMP_ROW,
-                       self._done_ids[:E])
+        L.check(lib.emloco_task_compact_done(C.c_void_p(self.reset_buf.data_ptr()), E, C.c_void_p(self._done_ids.data_ptr()),
+                                             current_stream_handle(dev)), "emloco_task_compact_done")
+        side = None
+        if self.overlap_reset and dev.type == "cuda":
+            # the reset chain (and, in _physics_step, the first step of the reset envs) runs on a second stream beside the step
+            # of the live envs; the flags are snapshot first because the reset kernels clear them
+            if getattr(self, "_rs_stream", None) is None:
+                self._rs_stream = torch.cuda.Stream(device=dev, priority=-1)
+                self._rs_skip = torch.zeros(E, dtype=torch.int64, device=dev)
+                self._ev_rs_fork, self._ev_rs_reset, self._ev_rs_pd, self._ev_rs_join = (torch.cuda.Event() for _ in range(4))
+            self.wait_reset()
+            main = torch.cuda.current_stream(dev)
+            self._rs_skip.copy_(self.reset_buf)
+            self._ev_rs_fork.record(main)
+            side = self._rs_stream
+            side.wait_event(self._ev_rs_fork)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            st = current_stream_handle(dev)
+            if rnd is None:
+                # random rows made on the device for the finished envs only (row i serves the i-th finished env, ascending id),
+                # from a per-call seed: torch's seed (set by run.py / set_seed) + a call counter
+                if getattr(self, "_rnd_ws", None) is None:
+                    self._rnd_ws = torch.empty((E, L.RESET_RND), device=self.device)
+                    self._rnd_calls = 0
+                    self._rnd_seed0 = int(torch.initial_seed()) & 0xFFFFFFFFFFFF
+                self._rnd_calls += 1
+                L.check(lib.emloco_task_reset_seeded(self.sim.native._h, C.byref(self._reset_bufs), C.c_void_p(self._done_ids.data_ptr()), E,
+                                                     C.c_uint64((self._rnd_seed0 * 0x9E3779B97F4A7C15 + self._rnd_calls) & 0xFFFFFFFFFFFFFFFF),
+                                                     C.c_void_p(self._rnd_ws.data_ptr()), st), "emloco_task_reset_seeded")
+            else:
+                L.check(lib.emloco_task_reset(self.sim.native._h, C.byref(self._reset_bufs), C.c_void_p(self._done_ids.data_ptr()), E,
+                                              C.c_void_p(rnd.data_ptr()), st), "emloco_task_reset")
+            self._post.run(self._post_bufs if self._post_bufs is not None else self._ensure_post_bufs(), L.POST_OBS | L.POST_AMP_ROW,
+                           self._done_ids[:E])
+            if side is not None:
+                self._ev_rs_reset.record(side)
+                self._rs_pending = self._rs_unjoined = True
         if flags.init_heading and flags.heading_inversion:
             self._traj_gen.inverted = self._inverted_u8.view(torch.bool)     # the kernels write 0 / 1 bytes: a view, no launch
         self.inverted = self._traj_gen.show_inverted()      # motion ids / start times: written in place by the reset kernels
+
+    # Opt-in (set by a rollout loop that calls wait_reset() before it reads anything reset_done() wrote -- the observations of
+    # the reset envs, init_pose / init_vel, the trajectory -- between reset_done() and step()): envs are independent
+    # (humanoid.py:838-841), so `reset_done(); step(a)` is issued as two chains on two HIP streams.  The caller's stream
+    # steps the envs that did not finish (emloco_sim_step_subset with the flag snapshot); a second, higher-priority stream
+    # resets the finished ones, builds their observations and steps them over the compacted id list; step() joins the two
+    # before its post-physics launch.  Every env sees exactly the launches it would see in the sequential order, so the
+    # results are identical; the ~25 finished envs of a step no longer hold 4 000 live ones up.
+    overlap_reset = False
+
+    def wait_reset(self):
+        """Make the caller's stream wait for the reset chain of the last reset_done() (no-op without overlap_reset)."""
+        if getattr(self, "_rs_unjoined", False):
+            torch.cuda.current_stream(self.device).wait_event(self._ev_rs_reset)
+            self._rs_unjoined = False
+
+    def _physics_step(self):
+        if not getattr(self, "_rs_pending", False):
+            return super()._physics_step()
+        self._rs_pending = False
+        if self.paused or not self.enable_viewer_sync:
+            self.wait_reset()
+            return
+        dev = torch.device(self.device)
+        main, side, E = torch.cuda.current_stream(dev), self._rs_stream, self.num_envs
+        self._ev_rs_pd.record(main)                              # the PD targets of all envs are in place
+        self.gym.simulate_n_subset(self.sim, self.control_freq_inv, skip=self._rs_skip)
+        side.wait_event(self._ev_rs_pd)
+        with torch.cuda.stream(side):
+            self.gym.simulate_n_subset(self.sim, self.control_freq_inv, ids=self._done_ids[:E], count=False)
+            self._ev_rs_join.record(side)
+        main.wait_event(self._ev_rs_join)
+        self._rs_unjoined = False
 
     def _ensure_post_bufs(self):
         self._post_bufs = self._make_post_bufs()

@@ -411,6 +411,12 @@ class Gym:
         sim.native.step(n_calls)
         sim.frame_count += n_calls
 
+    def simulate_n_subset(self, sim, n_calls, skip=None, ids=None, count=True):
+        """Extension: simulate_n for a subset of the envs (NativeSim.step_subset); the two halves of one step count once."""
+        sim.native.step_subset(n_calls, skip=skip, ids=ids)
+        if count:
+            sim.frame_count += n_calls
+
     def fetch_results(self, sim, wait=True):
         """Stream-ordered: consumers on torch's current stream need no host wait; `wait=True` keeps the reference's
         blocking semantics only when EMLOCO_BLOCKING_FETCH=1."""

@@ -86,6 +86,11 @@ class LocoValRollout:
         self.overlap_fit = bool(overlap_fit)
         if self.overlap_fit and hasattr(self.task, "overlap_obs") and getattr(self.task, "_fused_reset", False):
             self.task.overlap_obs = True           # this loop calls task.wait_obs() before the policy reads the observations
+            if hasattr(self.task, "overlap_reset"):
+                # ... and task.wait_reset() before a policy that reads the reset envs' fresh observations (a policy object
+                # may declare `reads_obs = False`: the reset chain and the reset envs' step then run wholly beside the step
+                # of the live envs)
+                self.task.overlap_reset = True
         self.fused = (isinstance(self.valuenet, ValuePoseNet) and self.device.type == "cuda") if fused is None else bool(fused)
         if self.fused:
             self._flat_params = torch.cat([p.detach().reshape(-1) for p in self.valuenet.parameters()]).contiguous()
@@ -219,6 +224,8 @@ class LocoValRollout:
             self._reset_finished()
             if hasattr(task, "wait_obs"):
                 task.wait_obs()                                   # the observations of the last step (built on a side stream)
+            if hasattr(task, "wait_reset") and getattr(self.policy, "reads_obs", True):
+                task.wait_reset()                                 # the observations of the envs that were just reset
             actions = self.policy(task.obs_buf)
             obs, rewards, dones, infos = self.vec_env.step(actions)
             inverted = task.inverted

@@ -117,6 +117,16 @@ class NativeSim:
     def step(self, n_calls=1):
         L.check(self.lib.emloco_sim_step(self._h, int(n_calls), self._stream()), "emloco_sim_step")
 
+    def step_subset(self, n_calls=1, skip=None, ids=None):
+        """The step for a subset of the envs on the current stream: `skip` (int64 per env) leaves the flagged envs alone,
+        `ids` (int32 device-compacted list, -1 padded) steps exactly the listed ones."""
+        if skip is not None:
+            assert skip.dtype == torch.int64 and skip.numel() == self.num_envs
+        if ids is not None:
+            assert ids.dtype == torch.int32
+        L.check(self.lib.emloco_sim_step_subset(self._h, int(n_calls), dptr(skip), dptr(ids), 0 if ids is None else int(ids.numel()),
+                                                self._stream()), "emloco_sim_step_subset")
+
     def sync(self):
         L.check(self.lib.emloco_sim_sync(self._h, self._stream()), "emloco_sim_sync")
 

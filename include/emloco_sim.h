@@ -131,6 +131,12 @@ int emloco_sim_tensor(EmlocoSim *sim, int kind, void **dev_ptr, int64_t shape[2]
 int emloco_sim_set_pd_targets(EmlocoSim *sim, const float *dev_targets, void *stream);
 /* gym.simulate x n_calls -- base_task.py:792-797 (n_calls = controlFrequencyInv); one fused launch */
 int emloco_sim_step(EmlocoSim *sim, int n_calls, void *stream);
+/* The same step for a subset of the envs (extension; envs are independent, humanoid.py:838-841, so a step of all envs may be
+ * issued as two launches on two streams: the envs that just finished an episode are reset and stepped beside the others,
+ * amp_continuous_value.py:46,74 env_reset(done_indices) followed by env.step).  Exactly one of the two selectors:
+ * `dev_skip` (int64 per env, the task's reset_buf layout): envs with a non-zero entry are left untouched;
+ * `dev_env_ids` (int32, n_ids entries): a device-compacted list, valid ids first and -1 after them (emloco_task_compact_done). */
+int emloco_sim_step_subset(EmlocoSim *sim, int n_calls, const int64_t *dev_skip, const int32_t *dev_env_ids, int n_ids, void *stream);
 /* gym.fetch_results(sim, True) -- base_task.py:258: host waits for the stream */
 int emloco_sim_sync(EmlocoSim *sim, void *stream);
 /* gym.set_actor_root_state_tensor_indexed / set_dof_state_tensor_indexed -- humanoid.py:470-475.

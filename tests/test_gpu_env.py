@@ -564,3 +564,54 @@ def test_observations_on_a_side_stream_give_the_same_rollout():
             else:
                 assert torch.equal(a, b), (k, name)
     assert getattr(envs[1].task, "_obs_stream", None) is not None
+
+
+@pytest.mark.gpu
+def test_reset_chain_on_a_second_stream_gives_the_same_rollout():
+    """task.overlap_reset: `reset_done(); step(a)` issued as two chains -- the caller's stream steps the envs that did not
+    finish (emloco_sim_step_subset with the flag snapshot), a second stream resets the finished ones, builds their
+    observations and steps them over the compacted id list; step() joins before the post-physics launch.  Two identically
+    seeded envs, one per mode (the second also with the observation side stream), forced and natural resets, the sim state
+    and the warm-start impulses included: every buffer bit-equal after every step, and the reset envs' rows are valid after
+    wait_reset()."""
+    from emloco_amd import _lib as L
+    args = ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel"]
+    envs = [_make_env(96, args), _make_env(96, args)]
+    envs[1].task.overlap_reset = True
+    envs[1].task.overlap_obs = True
+    dev = envs[0].task.device
+    g = torch.Generator(device=dev)
+    names = ("_root_states", "_dof_state", "_rigid_body_state", "_contact_forces", "obs_buf", "_flip_obs_buf", "_amp_obs_buf",
+             "progress_buf", "reset_buf", "rew_buf", "reward_raw", "_terminate_buf", "waypoint_traj", "init_pose", "init_vel")
+    for k in range(40):
+        g.manual_seed(100 + k)
+        act = torch.randn(96, 69, device=dev, generator=g) * 0.3
+        g.manual_seed(500 + k)
+        rnd = torch.rand(96, L.RESET_RND, device=dev, generator=g)
+        obs_after_reset = []
+        for e in envs:
+            t = e.task
+            if k == 0:
+                t.reset_buf[:] = 1
+            if k % 7 == 3:
+                t.reset_buf[5:40:3] = 1
+            t.reset_done(rnd=rnd)
+            t.wait_obs()
+            if k % 5 == 0:                                          # a consumer between reset_done() and step()
+                t.wait_reset()
+                obs_after_reset.append(t.obs_buf.clone())
+            e.step(act)
+        envs[1].task.wait_obs()
+        torch.cuda.synchronize()
+        if obs_after_reset:
+            assert torch.equal(obs_after_reset[0], obs_after_reset[1]), k
+        for name in names:
+            a, b = getattr(envs[0].task, name), getattr(envs[1].task, name)
+            live = envs[0].task.reset_buf == 0               # rows of finished envs are rebuilt by the next reset_done
+            if name in ("obs_buf", "_flip_obs_buf", "_amp_obs_buf"):
+                assert torch.equal(a[live], b[live]), (k, name)
+            else:
+                assert torch.equal(a, b), (k, name)
+        assert torch.equal(envs[0].task.sim.native.warm_start, envs[1].task.sim.native.warm_start), k
+        assert envs[0].task.sim.frame_count == envs[1].task.sim.frame_count
+    assert getattr(envs[1].task, "_rs_stream", None) is not None
