@@ -485,6 +485,8 @@ def main():
     E = a.num_envs
     env = make_env(E, rank)
     task = env.task
+    if os.environ.get("EMLOCO_COST_ORDER", "1") != "0":
+        task.sim.native.set_cost_order(True)         # longest-first dispatch of the rigid-body launch (results unchanged)
     env.reset(torch.arange(E, device=dev))
     stagger_episodes(env, seed=rank)                     # untimed: episode ages uniform over [0, 168) before the warm-up
     g = torch.Generator(device=dev)

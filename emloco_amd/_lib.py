@@ -87,6 +87,7 @@ class ResetBufs(C.Structure):
 
 RESET_RND = 512
 RESET_RANDOM_HEADING, RESET_INIT_HEADING, RESET_HEADING_INVERSION, RESET_ADJUST_ROOT_VEL, RESET_REAL_PATH, RESET_FIXED_LOCATION = 1, 2, 4, 8, 16, 32
+RESET_NO_AMP_HISTORY = 64
 RND_MOTION, RND_TIME, RND_YAW, RND_SPEED, RND_LOC, RND_REAL, RND_REAL_PICK, RND_INVERSION, RND_HEADING, RND_SPEED0 = range(10)
 RND_DTHETA, RND_SHARP, RND_BERN, RND_DSPEED = 16, 116, 216, 316
 
@@ -133,13 +134,13 @@ SYMBOLS_SIM = [
     "emloco_last_error", "emloco_device_count", "emloco_sim_create", "emloco_sim_destroy", "emloco_sim_set_models",
     "emloco_sim_set_self_collision", "emloco_sim_set_ground_heightfield",
     "emloco_sim_prepare", "emloco_sim_get_params", "emloco_sim_set_params", "emloco_sim_tensor",
-    "emloco_sim_set_pd_targets", "emloco_sim_step", "emloco_sim_step_subset", "emloco_sim_sync", "emloco_sim_set_root_state_indexed",
+    "emloco_sim_set_pd_targets", "emloco_sim_step", "emloco_sim_step_subset", "emloco_sim_set_cost_order", "emloco_sim_sync", "emloco_sim_set_root_state_indexed",
     "emloco_sim_set_dof_state_indexed", "emloco_sim_refresh_bodies", "emloco_sim_num_candidates",
     "emloco_sim_last_step_ms", "emloco_sim_enable_timing", "emloco_sim_timing_stats",
 ]
 SYMBOLS_TASK = [
     "emloco_task_post_physics", "emloco_task_amp_rows", "emloco_task_pd_targets", "emloco_task_last_ms",
-    "emloco_task_enable_timing", "emloco_task_reset", "emloco_task_reset_seeded", "emloco_task_compact_done",
+    "emloco_task_enable_timing", "emloco_task_reset", "emloco_task_reset_seeded", "emloco_task_compact_done", "emloco_task_compact_done_snapshot", "emloco_task_reset_amp_history",
     "emloco_task_traj_reset", "emloco_task_get_heights",
 ]
 
@@ -173,6 +174,7 @@ def load():
     lib.emloco_sim_tensor.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     lib.emloco_sim_set_pd_targets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emloco_sim_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.emloco_sim_set_cost_order.argtypes = [C.c_void_p, C.c_int]
     lib.emloco_sim_step_subset.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.emloco_sim_sync.argtypes = [C.c_void_p, C.c_void_p]
     lib.emloco_sim_set_root_state_indexed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -192,6 +194,8 @@ def load():
     lib.emloco_task_get_heights.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emloco_task_compact_done.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.emloco_task_compact_done_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emloco_task_reset_amp_history.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     _lib = lib
     return lib
 

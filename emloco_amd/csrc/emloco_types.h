@@ -31,4 +31,8 @@ struct EmlocoSimDev {
     // untouched; with step_ids workgroup i steps env step_ids[i] of a device-compacted list (valid ids first, -1 after them)
     const long long *step_skip;
     const int *step_ids;
+    // cost-ordered dispatch (emloco_sim_set_cost_order): workgroup i of the full launch steps env step_order[i]; every
+    // workgroup leaves its own duration (100 MHz ticks) in step_ticks[env], the key of the next launch's order
+    const int *step_order;
+    unsigned *step_ticks;
 };

@@ -1,6 +1,7 @@
 // sim_capi.hip -- C ABI (include/emloco_sim.h) over the rollout kernels: owns device state, uploads
 // the per-env models, launches the fused step.  Host code is C++; nothing here touches torch.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -77,6 +78,7 @@ int emloco_sim_destroy(EmlocoSim *s) {
     s->d_sc_pairs.release(); s->d_sc_a.release(); s->d_sc_b.release(); s->d_sc_r.release();
     s->d_root.release(); s->d_dof.release(); s->d_tgt.release(); s->d_rb.release();
     s->d_cf.release(); s->d_df.release(); s->d_lws.release();
+    s->d_ticks.release(); s->d_order.release();
     for (auto e : s->ev0) (void)hipEventDestroy(e);
     for (auto e : s->ev1) (void)hipEventDestroy(e);
     delete s;
@@ -244,6 +246,14 @@ int emloco_sim_set_pd_targets(EmlocoSim *s, const float *dev_targets, void *stre
     return EMLOCO_OK;
 }
 
+// the dispatch order of the full launch: sorted on the caller's stream right ahead of it (a stream of the simulator's own
+// for the sort was measured and lost: with torch's pool streams it ended up sharing a hardware queue with the caller's)
+static int launch_order(EmlocoSim *s, hipStream_t st) {
+    hipLaunchKernelGGL(emloco::sim_order_kernel, dim3(1), dim3(1024), 0, st, s->d_ticks.p, s->n_env, s->d_order.p);
+    HIPCHK(hipGetLastError());
+    return EMLOCO_OK;
+}
+
 int emloco_sim_step(EmlocoSim *s, int n_calls, void *stream) {
     if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_step: null sim");
     if (!s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_step: sim not prepared");
@@ -251,9 +261,16 @@ int emloco_sim_step(EmlocoSim *s, int n_calls, void *stream) {
     EmlocoSimParams p = s->prm;
     p.n_sub = s->prm.n_sub * n_calls;
     hipStream_t st = (hipStream_t)stream;
+    EmlocoSimDev d = s->dev;
+    if (s->cost_order) {                     // longest-first dispatch order from the durations of the previous launch
+        const int rc = launch_order(s, st);
+        if (rc != EMLOCO_OK) return rc;
+        d.step_order = s->d_order.p;
+        d.step_ticks = s->d_ticks.p;
+    }
     const int slot = s->ev_head;
     if (s->timing) HIPCHK(hipEventRecord(s->ev0[slot], st));
-    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)s->n_env), dim3(64), 0, st, p, s->dev);
+    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)s->n_env), dim3(64), 0, st, p, d);
     HIPCHK(hipGetLastError());
     if (s->timing) {
         HIPCHK(hipEventRecord(s->ev1[slot], st));
@@ -276,6 +293,14 @@ int emloco_sim_step_subset(EmlocoSim *s, int n_calls, const int64_t *dev_skip, c
     d.step_skip = (const long long *)dev_skip;
     d.step_ids = (const int *)dev_ids;
     hipStream_t st = (hipStream_t)stream;
+    if (s->cost_order) {
+        d.step_ticks = s->d_ticks.p;
+        if (dev_skip) {
+            const int rc = launch_order(s, st);
+            if (rc != EMLOCO_OK) return rc;
+            d.step_order = s->d_order.p;
+        }
+    }
     // the launch over everything but the flagged envs is the one the timing log follows (it stands where emloco_sim_step stood)
     const bool timed = s->timing && dev_skip;
     const int slot = s->ev_head;
@@ -287,6 +312,20 @@ int emloco_sim_step_subset(EmlocoSim *s, int n_calls, const int64_t *dev_skip, c
         s->ev_head = (slot + 1) % EmlocoSim::kRing;
         if (s->ev_count < EmlocoSim::kRing) ++s->ev_count;
     }
+    return EMLOCO_OK;
+}
+
+int emloco_sim_set_cost_order(EmlocoSim *s, int on) {
+    if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_set_cost_order: null sim");
+    if (!s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_set_cost_order: sim not prepared");
+    if (on && s->n_env > EMLOCO_ORDER_MAX_ENVS) return fail(EMLOCO_E_ARG, "emloco_sim_set_cost_order: more than 16384 envs");
+    if (on && !s->d_ticks.p) {
+        HIPCHK(hipSetDevice(s->device));
+        HIPCHK(s->d_ticks.alloc((size_t)s->n_env));
+        HIPCHK(s->d_order.alloc((size_t)s->n_env));
+        HIPCHK(hipMemset(s->d_ticks.p, 0, sizeof(unsigned) * (size_t)s->n_env));
+    }
+    s->cost_order = on != 0;
     return EMLOCO_OK;
 }
 

@@ -40,15 +40,6 @@ namespace emloco {
 #define MAXR (3 * EMLOCO_MAXC)
 #define MAXCAND EMLOCO_MAXCAND
 #define EMLOCO_WH_MAX 0.4f /* largest link rotation per substep [rad]: cap of the link angular speed, see phase 1 */
-#ifndef EMLOCO_WS
-#define EMLOCO_WS 1
-#endif
-#ifndef EMLOCO_IMP
-#define EMLOCO_IMP 1
-#endif
-#ifndef EMLOCO_GS
-#define EMLOCO_GS 2
-#endif
 #define YLEN 30 /* chain-propagation vector: 6 root + 3 per tree level (depth <= 8) */
 
 // index into a packed symmetric 6x6 (upper triangle, row-major): (a<=b)
@@ -96,13 +87,9 @@ struct BodyConst {   // per-lane (lane = body) constants kept in registers for t
 #ifndef EMLOCO_SIM_WAVES_PER_SIMD
 #define EMLOCO_SIM_WAVES_PER_SIMD 2   /* register budget 256 per lane: two resident waves per SIMD (8 envs per CU) */
 #endif
-__global__ void __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(EMLOCO_SIM_WAVES_PER_SIMD, EMLOCO_SIM_WAVES_PER_SIMD)))
-sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
-    int env = blockIdx.x;
+// one env's step: the body of both kernels below (one 64-lane wave)
+__device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const EmlocoSimDev &d, const int env) {
     const int lane = threadIdx.x;
-    if (d.step_ids) env = d.step_ids[blockIdx.x];                 // subset launch over a compacted id list (padding: -1)
-    if (env < 0 || env >= d.n_env) return;
-    if (d.step_skip && d.step_skip[env] != 0) return;            // subset launch: flagged envs are stepped elsewhere
 
     // ---------------------------------------------------------------- LDS: one blob, 16 KB per env (8 envs per CU need <= 20 KB)
     // Every per-body row starts on a 16-byte boundary and is padded to a multiple of four words, so a lane moves its row with
@@ -856,15 +843,10 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         const float ainv = (lane < nr) ? 1.0f / (sh_A[tri_s + ls] * (1.0f + prm.cfm)) : 0.0f;
         // entry (ls, rr) of the symmetric matrix in the packed lower triangle; the sweeps read the three entries of the next
         // contact while the current one is being resolved (the reads do not depend on the multipliers)
+// (tri_index is branch-free min / max arithmetic; a compare-and-select between the two triangle forms with the uniform
+// part on the scalar unit looked cheaper and measured slower: first sweep 356 -> 432 ticks)
 #define A_OF(rr) sh_A[tri_index(ls, (rr))]
         float w = rhs;
-#if EMLOCO_WS == 0
-        for (int rr = 0; rr < nr; ++rr) {                         // warm start
-            const float lr = lane_bcast(lam, rr);
-            const float av = A_OF(rr);
-            w = (lr != 0.0f) ? fmaf(av, lr, w) : w;
-        }
-#else
         {                                                          // warm start (matrix entries read one contact ahead)
             float n0 = 0.0f, n1a = 0.0f, n2a = 0.0f;
             if (nc > 0) { n0 = A_OF(0); n1a = A_OF(1); n2a = A_OF(2); }
@@ -881,53 +863,16 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 w = (l2 != 0.0f) ? u2 : w;
             }
         }
-#endif
         PSTAMP(11);
-#if EMLOCO_GS == 0
-        for (int it = 0; it < prm.n_iter; ++it) {
-            float n0 = 0.0f, n1a = 0.0f, n2a = 0.0f;
-            if (nc > 0) { n0 = A_OF(0); n1a = A_OF(1); n2a = A_OF(2); }
-            for (int c = 0; c < nc; ++c) {
-                const int r0 = 3 * c;
-                const float a0 = n0, a1 = n1a, a2 = n2a;
-                if (c + 1 < nc) { n0 = A_OF(r0 + 3); n1a = A_OF(r0 + 4); n2a = A_OF(r0 + 5); }
-#pragma unroll
-                for (int dr = 0; dr < 3; ++dr) {
-                    const int rr = r0 + dr;
-                    float delta = 0.0f;
-                    if (lane == rr) {
-                        float nl = fmaf(-w, ainv, lam);
-                        if (dr == 0 && nl < 0.0f) nl = 0.0f;
-                        delta = nl - lam;
-                        lam = nl;
-                    }
-                    w = fmaf(dr == 0 ? a0 : (dr == 1 ? a1 : a2), lane_bcast(delta, rr), w);
-                }
-                const float ln = lane_bcast(lam, r0), l1 = lane_bcast(lam, r0 + 1), l2 = lane_bcast(lam, r0 + 2);
-                const float lim = prm.mu * ln;
-                const float m2 = fmaf(l1, l1, l2 * l2);
-                if (m2 > lim * lim) {                             // wave-uniform: outside the friction cone
-                    const float sc = lim / sqrtf(m2);
-                    const float n1 = l1 * sc, n2 = l2 * sc;
-                    if (lane == r0 + 1) lam = n1;
-                    if (lane == r0 + 2) lam = n2;
-                    w = fmaf(a1, n1 - l1, w);
-                    w = fmaf(a2, n2 - l2, w);
-                }
-            }
-            if (it == 0) PSTAMP(12);
-        }
-#undef A_OF
-        if (lane < MAXR) sh_lam[lane] = (lane < nr) ? lam : 0.0f;
-        __syncthreads();
-#else
         // The sweeps resolve a contact inside ONE lane, the lane of its normal row (the leader): it holds the three
         // multipliers of the contact, the reciprocal diagonals and the sub-diagonal of its 3 x 3 block, fetches the residuals
         // of its two tangent rows (two v_readlane of values that are ready since the previous contact) and walks normal ->
         // tangent 1 -> tangent 2 -> friction cone on its own, forming the intermediate residuals exactly as the rows'
         // own lanes will; the three changes (and the two of a cone projection) are then broadcast and every lane folds them
-        // into its w in the same order.  Same operations per value as the row-by-row sweep (the oracle's), a third of the
-        // cross-lane round trips on the dependent chain.
+        // into its w in the same order.  Same operations per value as the row-by-row sweep (the oracle's) with a third of the
+        // cross-lane round trips; branch-free on purpose (an exec-masked leader block was slower than the row-by-row sweep).
+        // A wave issues in order at ~4 cycles per instruction here, so the sweep costs what its instruction count costs:
+        // first sweep of a 3-foot-contact env 380 -> 356 ticks of 10 ns.
         const int lr0 = ls - (lane < nr ? myd : 0);               // first row of this lane's contact
         float gl0 = __shfl(lam, lr0), gl1 = __shfl(lam, lr0 + 1), gl2 = __shfl(lam, lr0 + 2);
         const float gi1 = __shfl(ainv, lr0 + 1), gi2 = __shfl(ainv, lr0 + 2);
@@ -941,38 +886,6 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 const float a0 = n0, a1 = n1a, a2 = n2a;
                 if (c + 1 < nc) { n0 = A_OF(r0 + 3); n1a = A_OF(r0 + 4); n2a = A_OF(r0 + 5); }
                 const float w1s = lane_bcast(w, r0 + 1), w2s = lane_bcast(w, r0 + 2);
-#if EMLOCO_GS == 1
-                float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, p1 = 0.0f, p2 = 0.0f;
-                bool proj = false;
-                if (lane == r0) {
-                    float nl0 = fmaf(-w, ainv, gl0);
-                    if (nl0 < 0.0f) nl0 = 0.0f;
-                    d0 = nl0 - gl0;
-                    const float w1 = fmaf(gA10, d0, w1s);
-                    const float nl1 = fmaf(-w1, gi1, gl1);
-                    d1 = nl1 - gl1;
-                    const float w2 = fmaf(gA21, d1, fmaf(gA20, d0, w2s));
-                    const float nl2 = fmaf(-w2, gi2, gl2);
-                    d2 = nl2 - gl2;
-                    gl0 = nl0; gl1 = nl1; gl2 = nl2;
-                    const float lim = prm.mu * nl0;
-                    const float m2 = fmaf(nl1, nl1, nl2 * nl2);
-                    if (__builtin_expect(m2 > lim * lim, 0)) {   // outside the friction cone
-                        const float sc = lim / sqrtf(m2);
-                        const float n1 = nl1 * sc, n2 = nl2 * sc;
-                        p1 = n1 - nl1; p2 = n2 - nl2;
-                        gl1 = n1; gl2 = n2;
-                        proj = true;
-                    }
-                }
-                w = fmaf(a0, lane_bcast(d0, r0), w);
-                w = fmaf(a1, lane_bcast(d1, r0), w);
-                w = fmaf(a2, lane_bcast(d2, r0), w);
-                if (__builtin_expect(__ballot(proj) != 0ull, 0)) {   // wave-uniform
-                    w = fmaf(a1, lane_bcast(p1, r0), w);
-                    w = fmaf(a2, lane_bcast(p2, r0), w);
-                }
-#else
                 // branch-free: every lane runs the leader's chain on its own contact's values, only lane r0's results are read
                 float nl0 = fmaf(-w, ainv, gl0);
                 if (nl0 < 0.0f) nl0 = 0.0f;
@@ -997,7 +910,6 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                     w = fmaf(a1, lane_bcast(n1 - nl1, r0), w);
                     w = fmaf(a2, lane_bcast(n2 - nl2, r0), w);
                 }
-#endif
             }
             if (it == 0) PSTAMP(12);
         }
@@ -1006,7 +918,6 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         else if (lane >= nr && lane < MAXR) sh_lam[lane] = 0.0f;
         __syncthreads();
         lam = (lane < nr) ? sh_lam[lane] : 0.0f;
-#endif
 
         PSTAMP(8);
         // ============================================================ 7. impulses -> velocity change (second solve)
@@ -1014,28 +925,6 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
         if (is_body && last && nc == 0)
             for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = 0.0f;
         if (nc > 0) {
-#if EMLOCO_IMP == 0
-            float pin[6] = {0, 0, 0, 0, 0, 0};
-            if (is_body) {
-                float cf[3] = {0, 0, 0};
-                const int c_end = sh_crange[NB + lane];
-                for (int c = sh_crange[lane]; c <= c_end; ++c)
-                    {
-                        for (int dr = 0; dr < 3; ++dr) {
-                            float dir[3] = {dr == 1 ? 1.0f : 0.0f, dr == 2 ? 1.0f : 0.0f, dr == 0 ? 1.0f : 0.0f};
-                            if (hf_on) for (int k = 0; k < 3; ++k) dir[k] = sh_cdir[c][3 * dr + k];
-                            const float x[3] = {sh_cx[c][0], sh_cx[c][1], sh_cx[c][2]};
-                            float Jr[6];
-                            cross3(x, dir, Jr);
-                            Jr[3] = dir[0]; Jr[4] = dir[1]; Jr[5] = dir[2];
-                            const float l = sh_lam[3 * c + dr];
-                            for (int k = 0; k < 6; ++k) pin[k] = fmaf(-Jr[k], l, pin[k]);
-                            for (int k = 0; k < 3; ++k) cf[k] += dir[k] * l / h;
-                        }
-                    }
-                if (last) for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = cf[k];
-            }
-#else
             // every row's lane stages its Jacobian row (and, in the last substep, its share of the reported contact force)
             // in the matrix's LDS, which is dead by now; a body then adds up its rows in contact order with one fma chain
             float (*sh_row)[12] = (float (*)[12])sh_A;
@@ -1060,7 +949,6 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
                 }
                 if (last) for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = cf[k];
             }
-#endif
             // bodies deeper than every contact body carry no impulse and have no loaded descendant: their share of the up pass
             // is exactly zero (uh = +0, pa = +0), so the pass starts at the deepest contact level
             if (is_body && bc.depth > dmax) { uh[0] = uh[1] = uh[2] = 0.0f; for (int k = 0; k < 6; ++k) sh_pa[lane][k] = 0.0f; }
@@ -1220,6 +1108,51 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
             for (int k = 0; k < 3; ++k) d.lambda_ws[(long)env * MAXCAND * 3 + c * 3 + k] = os != 255 ? sh_lam[3 * os + k] : 0.0f;
         }
     }
+}
+
+// The step of every env (one workgroup = one wave per env).  Subset launches (emloco_sim_step_subset): with skip flags the
+// workgroups of the flagged envs leave at once; with a device-compacted id list (valid ids first, -1 after them) workgroup
+// i steps list entry i.  Both are THIS kernel: a second instantiation of the 49 KB body for the list launch ran beside the
+// big launch out of a different code object, the two thrashed the instruction cache the CUs share (measured: the big
+// launch 0.58 -> 0.64 ms, the 25-env list launch 0.22 -> 0.44 ms).
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(EMLOCO_SIM_WAVES_PER_SIMD, EMLOCO_SIM_WAVES_PER_SIMD)))
+sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
+    if ((int)blockIdx.x >= d.n_env) return;
+    int env = d.step_order ? d.step_order[blockIdx.x] : (int)blockIdx.x;
+    if (d.step_ids) { env = d.step_ids[blockIdx.x]; if (env < 0) return; }   // list launch: workgroup i steps list entry i (-1: padding)
+    if (d.step_skip && d.step_skip[env] != 0) return;            // flagged envs are stepped elsewhere
+    const long long t0 = d.step_ticks ? (long long)wall_clock64() : 0ll;
+    sim_step_env(prm, d, env);
+    if (d.step_ticks && threadIdx.x == 0) d.step_ticks[env] = (unsigned)((long long)wall_clock64() - t0);
+}
+
+// Dispatch order of the next full launch: env ids sorted by the duration of their last step, longest first (counting sort
+// over 5.12 us buckets; one 1024-thread workgroup).  Workgroups are handed to the CUs in index order and the launch is two
+// resident rounds of waves (4096 envs on 256 CUs x 8), so its length is set by what the LAST workgroups cost: with the
+// expensive envs (many contacts) first and the cheap ones (airborne) last, the slots that free up late receive short work.
+// The order within a bucket is whatever the LDS atomics give -- envs are independent, results do not depend on it.
+#define EMLOCO_ORDER_BUCKETS 128
+#define EMLOCO_ORDER_MAX_ENVS 16384
+__global__ void __launch_bounds__(1024)
+sim_order_kernel(const unsigned *ticks, int n, int *order) {
+    __shared__ int sh_cnt[EMLOCO_ORDER_BUCKETS];
+    __shared__ unsigned char sh_b[EMLOCO_ORDER_MAX_ENVS];        // every duration is read ONCE: a launch that still writes durations
+    const int tid = threadIdx.x;                                  // beside this one cannot make the two passes disagree
+    if (tid < EMLOCO_ORDER_BUCKETS) sh_cnt[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        unsigned b = ticks[i] >> 9;
+        b = b > EMLOCO_ORDER_BUCKETS - 1 ? EMLOCO_ORDER_BUCKETS - 1 : b;
+        sh_b[i] = (unsigned char)b;
+        atomicAdd(&sh_cnt[b], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {                                               // descending: start offset of bucket b = envs in buckets above it
+        int run = 0;
+        for (int b = EMLOCO_ORDER_BUCKETS - 1; b >= 0; --b) { const int c = sh_cnt[b]; sh_cnt[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) order[atomicAdd(&sh_cnt[sh_b[i]], 1)] = i;
 }
 
 // Forward kinematics only (used after state writes through the *_indexed setters): fills rb_state of

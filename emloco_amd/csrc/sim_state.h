@@ -42,6 +42,10 @@ struct EmlocoSim {
     DevBuf<float> d_off, d_mass, d_com, d_inertia, d_ga, d_gb, d_gr, d_kp, d_kd, d_arm, d_eff;
     DevBuf<float> d_root, d_dof, d_tgt, d_rb, d_cf, d_df, d_lws;
     EmlocoSimDev dev{};
+    // cost-ordered dispatch of the full launch (emloco_sim_set_cost_order): per-env duration of the last step, env ids sorted by it
+    bool cost_order = false;
+    DevBuf<unsigned> d_ticks;
+    DevBuf<int> d_order;
     // HIP-event timing of step launches: a ring of event pairs recorded on the launch stream
     static constexpr int kRing = 1024;
     std::vector<hipEvent_t> ev0, ev1;

@@ -110,7 +110,21 @@ int emloco_task_reset(EmlocoSim *sim, const EmlocoResetBufs *b, const int32_t *d
     if (rc != 0) return rc;
     hipLaunchKernelGGL(emloco::reset_finish_kernel, dim3(grid), dim3(64), 0, st, *b, sim->dev, dev_env_ids, n, dev_rnd);
     THIPCHK(hipGetLastError());
+    if (b->flags & EMLOCO_RESET_NO_AMP_HISTORY) return 0;
     hipLaunchKernelGGL(emloco::reset_amp_history_kernel, dim3(grid, EMLOCO_AMP_STEPS - 1), dim3(64), 0, st, *b, dev_env_ids, n);
+    THIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_task_reset_amp_history(const EmlocoResetBufs *b, const int32_t *dev_env_ids, int n, void *stream) {
+    if (!b || !dev_env_ids) return tfail(-1, "emloco_task_reset_amp_history: null argument");
+    if (n < 0) return tfail(-1, "emloco_task_reset_amp_history: bad env count");
+    if (n == 0) return 0;
+    if (!b->gts || !b->grs || !b->lrs || !b->gvs || !b->gavs || !b->dvs || !b->motion_len || !b->motion_dt || !b->motion_nframes ||
+        !b->motion_start || !b->betas || !b->key_bodies || !b->dof_subset || !b->amp_obs_buf || !b->motion_ids || !b->motion_times)
+        return tfail(-1, "emloco_task_reset_amp_history: missing buffers");
+    const unsigned grid = (unsigned)(n < 256 ? n : 256);
+    hipLaunchKernelGGL(emloco::reset_amp_history_kernel, dim3(grid, EMLOCO_AMP_STEPS - 1), dim3(64), 0, (hipStream_t)stream, *b, dev_env_ids, n);
     THIPCHK(hipGetLastError());
     return 0;
 }
@@ -156,11 +170,15 @@ int emloco_task_get_heights(const int16_t *dev_heightfield, int rows, int cols, 
     return 0;
 }
 
-int emloco_task_compact_done(const int64_t *dev_flags, int n, int32_t *dev_ids, void *stream) {
+int emloco_task_compact_done_snapshot(const int64_t *dev_flags, int n, int32_t *dev_ids, int64_t *dev_snapshot, void *stream) {
     if (!dev_flags || !dev_ids || n < 1) return tfail(-1, "emloco_task_compact_done: bad argument (ids holds n + 1 entries)");
-    hipLaunchKernelGGL(emloco::compact_flags_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dev_flags, n, dev_ids);
+    hipLaunchKernelGGL(emloco::compact_flags_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dev_flags, n, dev_ids, dev_snapshot);
     THIPCHK(hipGetLastError());
     return 0;
+}
+
+int emloco_task_compact_done(const int64_t *dev_flags, int n, int32_t *dev_ids, void *stream) {
+    return emloco_task_compact_done_snapshot(dev_flags, n, dev_ids, nullptr, stream);
 }
 
 int emloco_task_pd_targets(int n_env, const float *actions, const float *offset, const float *scale,

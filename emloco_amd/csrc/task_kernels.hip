@@ -318,7 +318,7 @@ __global__ void pd_targets_kernel(int total, const float *actions, const float *
 // launch queue every step): ids[0..count) = ascending indices of the non-zero flags, ids[count..n) = -1, ids[n] = count.
 // One 1024-thread workgroup; ballot + popcount inside a wave, LDS prefix over the 16 waves, running base over chunks.
 __global__ void __launch_bounds__(1024)
-compact_flags_kernel(const int64_t *flags, int n, int32_t *ids) {
+compact_flags_kernel(const int64_t *flags, int n, int32_t *ids, int64_t *snapshot) {
     __shared__ int sh_wave[16];
     __shared__ int sh_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -326,7 +326,9 @@ compact_flags_kernel(const int64_t *flags, int n, int32_t *ids) {
     __syncthreads();
     for (int c0 = 0; c0 < n; c0 += 1024) {
         const int i = c0 + tid;
-        const bool on = i < n && flags[i] != 0;
+        const int64_t fl = i < n ? flags[i] : 0;
+        if (snapshot && i < n) snapshot[i] = fl;
+        const bool on = fl != 0;
         const unsigned long long bal = __ballot(on);
         const int before = __popcll(bal & ((1ull << lane) - 1ull));
         if (lane == 0) sh_wave[wave] = __popcll(bal);

@@ -391,6 +391,11 @@ class Humanoid(BaseTask):
     # (humanoid.py:1140-1160 recomputes the observations of the reset envs).
     overlap_obs = False
 
+    def _make_obs_stream(self):
+        # high priority: the short launches that run beside the rigid-body kernel get the first wave slot that frees up
+        self._obs_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        self._ev_flags, self._ev_obs = torch.cuda.Event(), torch.cuda.Event()
+
     def wait_obs(self):
         """Make the caller's stream wait for the observation launch of the last step (no-op without overlap_obs)."""
         if getattr(self, "_obs_pending", False):
@@ -402,8 +407,7 @@ class Humanoid(BaseTask):
         mode = self._post_mode_step()
         if self.overlap_obs and torch.device(self.device).type == "cuda":
             if getattr(self, "_obs_stream", None) is None:
-                self._obs_stream = torch.cuda.Stream(device=self.device)
-                self._ev_flags, self._ev_obs = torch.cuda.Event(), torch.cuda.Event()
+                self._make_obs_stream()
             self.wait_obs()                                       # nobody asked for the previous step's observations
             side_mode = mode & (L.POST_OBS | L.POST_AMP_SHIFT | L.POST_AMP_ROW)
             self._launch_post(mode & ~side_mode)                  # progress += 1, reward, reset flags

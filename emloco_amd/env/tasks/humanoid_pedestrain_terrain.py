@@ -5,6 +5,7 @@ Mirror of pacer/pacer/env/tasks/humanoid_pedestrain_terrain.py (file name spelt 
 class HumanoidPedestrianTerrain :34-930, class Terrain :1135-1463.  Everything per step -- 368 self obs,
 30 trajectory obs, 32x32 height obs, mirrored obs, reward, reset masks, AMP -- is one fused HIP launch.
 """
+import os
 import numpy as np
 import torch
 from scipy import ndimage
@@ -216,22 +217,38 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
             self._done_ids = torch.full((E + 1,), -1, dtype=torch.int32, device=self.device)
         dev = torch.device(self.device)
         lib = self._post.lib
-        L.check(lib.emloco_task_compact_done(C.c_void_p(self.reset_buf.data_ptr()), E, C.c_void_p(self._done_ids.data_ptr()),
-                                             current_stream_handle(dev)), "emloco_task_compact_done")
         side = None
         if self.overlap_reset and dev.type == "cuda":
-            # the reset chain (and, in _physics_step, the first step of the reset envs) runs on a second stream beside the step
-            # of the live envs; the flags are snapshot first because the reset kernels clear them
-            if getattr(self, "_rs_stream", None) is None:
-                self._rs_stream = torch.cuda.Stream(device=dev, priority=-1)
+            # the reset chain runs beside the step of the live envs (see overlap_reset below); the flags are snapshot by the
+            # compaction because the reset kernels clear them
+            if getattr(self, "_rs_skip", None) is None:
                 self._rs_skip = torch.zeros(E, dtype=torch.int64, device=dev)
-                self._ev_rs_fork, self._ev_rs_reset, self._ev_rs_pd, self._ev_rs_join = (torch.cuda.Event() for _ in range(4))
+                self._hp_stream = torch.cuda.Stream(device=dev, priority=-1)
+                self._ev_rs_fork, self._ev_rs_reset, self._ev_rs_pd, self._ev_rs_big = (torch.cuda.Event() for _ in range(4))
+            if getattr(self, "_obs_stream", None) is None:
+                self._make_obs_stream()
             self.wait_reset()
             main = torch.cuda.current_stream(dev)
-            self._rs_skip.copy_(self.reset_buf)
+            L.check(lib.emloco_task_compact_done_snapshot(C.c_void_p(self.reset_buf.data_ptr()), E, C.c_void_p(self._done_ids.data_ptr()),
+                                                          C.c_void_p(self._rs_skip.data_ptr()), current_stream_handle(dev)),
+                    "emloco_task_compact_done_snapshot")
             self._ev_rs_fork.record(main)
-            side = self._rs_stream
+            side = self._obs_stream
             side.wait_event(self._ev_rs_fork)
+        else:
+            L.check(lib.emloco_task_compact_done(C.c_void_p(self.reset_buf.data_ptr()), E, C.c_void_p(self._done_ids.data_ptr()),
+                                                 current_stream_handle(dev)), "emloco_task_compact_done")
+        # sequential order with an observation stream: the AMP history back-fill (reads only what the reset sampled) leaves the
+        # caller's chain for that stream; wait_obs() covers it
+        amp_aside = (side is None and self.overlap_obs and dev.type == "cuda" and getattr(self, "_obs_stream", None) is not None
+                     and os.environ.get("EMLOCO_AMP_ASIDE", "1") != "0")
+        bufs = self._reset_bufs
+        if amp_aside:
+            if getattr(self, "_reset_bufs_noamp", None) is None:
+                self._reset_bufs_noamp = type(bufs).from_buffer_copy(bufs)
+                self._reset_bufs_noamp.flags |= L.RESET_NO_AMP_HISTORY
+                self._ev_rs_state = torch.cuda.Event()
+            bufs = self._reset_bufs_noamp
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             st = current_stream_handle(dev)
             if rnd is None:
@@ -242,12 +259,20 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
                     self._rnd_calls = 0
                     self._rnd_seed0 = int(torch.initial_seed()) & 0xFFFFFFFFFFFF
                 self._rnd_calls += 1
-                L.check(lib.emloco_task_reset_seeded(self.sim.native._h, C.byref(self._reset_bufs), C.c_void_p(self._done_ids.data_ptr()), E,
+                L.check(lib.emloco_task_reset_seeded(self.sim.native._h, C.byref(bufs), C.c_void_p(self._done_ids.data_ptr()), E,
                                                      C.c_uint64((self._rnd_seed0 * 0x9E3779B97F4A7C15 + self._rnd_calls) & 0xFFFFFFFFFFFFFFFF),
                                                      C.c_void_p(self._rnd_ws.data_ptr()), st), "emloco_task_reset_seeded")
             else:
-                L.check(lib.emloco_task_reset(self.sim.native._h, C.byref(self._reset_bufs), C.c_void_p(self._done_ids.data_ptr()), E,
+                L.check(lib.emloco_task_reset(self.sim.native._h, C.byref(bufs), C.c_void_p(self._done_ids.data_ptr()), E,
                                               C.c_void_p(rnd.data_ptr()), st), "emloco_task_reset")
+            if amp_aside:
+                self._ev_rs_state.record(torch.cuda.current_stream(dev))
+                self._obs_stream.wait_event(self._ev_rs_state)
+                with torch.cuda.stream(self._obs_stream):
+                    L.check(lib.emloco_task_reset_amp_history(C.byref(bufs), C.c_void_p(self._done_ids.data_ptr()), E,
+                                                              current_stream_handle(dev)), "emloco_task_reset_amp_history")
+                    self._ev_obs.record(self._obs_stream)
+                self._obs_pending = True
             self._post.run(self._post_bufs if self._post_bufs is not None else self._ensure_post_bufs(), L.POST_OBS | L.POST_AMP_ROW,
                            self._done_ids[:E])
             if side is not None:
@@ -259,11 +284,14 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
 
     # Opt-in (set by a rollout loop that calls wait_reset() before it reads anything reset_done() wrote -- the observations of
     # the reset envs, init_pose / init_vel, the trajectory -- between reset_done() and step()): envs are independent
-    # (humanoid.py:838-841), so `reset_done(); step(a)` is issued as two chains on two HIP streams.  The caller's stream
-    # steps the envs that did not finish (emloco_sim_step_subset with the flag snapshot); a second, higher-priority stream
-    # resets the finished ones, builds their observations and steps them over the compacted id list; step() joins the two
-    # before its post-physics launch.  Every env sees exactly the launches it would see in the sequential order, so the
-    # results are identical; the ~25 finished envs of a step no longer hold 4 000 live ones up.
+    # (humanoid.py:838-841), so `reset_done(); step(a)` is issued as two chains.  The rigid-body launch of the envs that did
+    # not finish (emloco_sim_step_subset with the flag snapshot) goes to a high-priority stream; the reset chain of the
+    # finished ones and their observations run beside it on the (high-priority) observation stream; their step (the same
+    # kernel over the compacted id list: one code object, the two launches share the instruction cache) follows on the
+    # caller's stream at normal priority, so its workgroups take the wave slots the big launch leaves over at the end of its
+    # first round instead of displacing workgroups of it; step() joins before its post-physics launch.  Every env sees
+    # exactly the launches it would see in the sequential order: identical results (tests/test_gpu_env.py).  Four streams in
+    # all with the LocoVal fit's: HIP serves a process with four hardware queues.
     overlap_reset = False
 
     def wait_reset(self):
@@ -280,15 +308,15 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
             self.wait_reset()
             return
         dev = torch.device(self.device)
-        main, side, E = torch.cuda.current_stream(dev), self._rs_stream, self.num_envs
+        main, hp, E = torch.cuda.current_stream(dev), self._hp_stream, self.num_envs
         self._ev_rs_pd.record(main)                              # the PD targets of all envs are in place
-        self.gym.simulate_n_subset(self.sim, self.control_freq_inv, skip=self._rs_skip)
-        side.wait_event(self._ev_rs_pd)
-        with torch.cuda.stream(side):
-            self.gym.simulate_n_subset(self.sim, self.control_freq_inv, ids=self._done_ids[:E], count=False)
-            self._ev_rs_join.record(side)
-        main.wait_event(self._ev_rs_join)
-        self._rs_unjoined = False
+        hp.wait_event(self._ev_rs_pd)
+        with torch.cuda.stream(hp):
+            self.gym.simulate_n_subset(self.sim, self.control_freq_inv, skip=self._rs_skip)
+            self._ev_rs_big.record(hp)
+        self.wait_reset()                                        # the reset envs' state and observations are in place
+        self.gym.simulate_n_subset(self.sim, self.control_freq_inv, ids=self._done_ids[:E], count=False)
+        main.wait_event(self._ev_rs_big)
 
     def _ensure_post_bufs(self):
         self._post_bufs = self._make_post_bufs()

@@ -22,6 +22,7 @@ when the global count is positive, so the replicas (broadcast from rank 0 at con
 """
 import math
 
+import os
 import torch
 
 from ..dist import FlatGradBucket, broadcast_parameters
@@ -86,10 +87,11 @@ class LocoValRollout:
         self.overlap_fit = bool(overlap_fit)
         if self.overlap_fit and hasattr(self.task, "overlap_obs") and getattr(self.task, "_fused_reset", False):
             self.task.overlap_obs = True           # this loop calls task.wait_obs() before the policy reads the observations
-            if hasattr(self.task, "overlap_reset"):
-                # ... and task.wait_reset() before a policy that reads the reset envs' fresh observations (a policy object
-                # may declare `reads_obs = False`: the reset chain and the reset envs' step then run wholly beside the step
-                # of the live envs)
+            if hasattr(self.task, "overlap_reset") and os.environ.get("EMLOCO_OVERLAP_RESET", "0") == "1":
+                # opt-in: the reset chain and the reset envs' step beside the step of the live envs.  This loop calls
+                # task.wait_reset() before a policy that reads the reset envs' fresh observations (a policy object may declare
+                # `reads_obs = False`).  Measured on MI355X: the resident rigid-body launch leaves no wave
+                # slot free for most of its run, so the gain depends on launch timing (+8 % to -4 %); off by default.
                 self.task.overlap_reset = True
         self.fused = (isinstance(self.valuenet, ValuePoseNet) and self.device.type == "cuda") if fused is None else bool(fused)
         if self.fused:

@@ -117,6 +117,10 @@ class NativeSim:
     def step(self, n_calls=1):
         L.check(self.lib.emloco_sim_step(self._h, int(n_calls), self._stream()), "emloco_sim_step")
 
+    def set_cost_order(self, on=True):
+        """Longest-first dispatch of the step launch from the per-env durations of the previous one (emloco_sim_set_cost_order)."""
+        L.check(self.lib.emloco_sim_set_cost_order(self._h, int(bool(on))), "emloco_sim_set_cost_order")
+
     def step_subset(self, n_calls=1, skip=None, ids=None):
         """The step for a subset of the envs on the current stream: `skip` (int64 per env) leaves the flagged envs alone,
         `ids` (int32 device-compacted list, -1 padded) steps exactly the listed ones."""

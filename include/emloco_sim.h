@@ -137,6 +137,11 @@ int emloco_sim_step(EmlocoSim *sim, int n_calls, void *stream);
  * `dev_skip` (int64 per env, the task's reset_buf layout): envs with a non-zero entry are left untouched;
  * `dev_env_ids` (int32, n_ids entries): a device-compacted list, valid ids first and -1 after them (emloco_task_compact_done). */
 int emloco_sim_step_subset(EmlocoSim *sim, int n_calls, const int64_t *dev_skip, const int32_t *dev_env_ids, int n_ids, void *stream);
+/* Cost-ordered dispatch of the step launch (extension, off by default; results do not depend on it: envs are independent).
+ * Every workgroup records how long its env's step took; the next launch hands the envs to the CUs longest first (a counting
+ * sort on the device, one small launch ahead of the step).  The launch is two resident rounds of waves, so its length is set
+ * by what the last workgroups cost: airborne humanoids (no contact solve) take ~60 % of the time of fallen ones. */
+int emloco_sim_set_cost_order(EmlocoSim *sim, int on);
 /* gym.fetch_results(sim, True) -- base_task.py:258: host waits for the stream */
 int emloco_sim_sync(EmlocoSim *sim, void *stream);
 /* gym.set_actor_root_state_tensor_indexed / set_dof_state_tensor_indexed -- humanoid.py:470-475.

@@ -114,7 +114,8 @@ int emloco_task_enable_timing(int on);
 #define EMLOCO_RESET_RND 512
 enum {
     EMLOCO_RESET_RANDOM_HEADING = 1, EMLOCO_RESET_INIT_HEADING = 2, EMLOCO_RESET_HEADING_INVERSION = 4,
-    EMLOCO_RESET_ADJUST_ROOT_VEL = 8, EMLOCO_RESET_REAL_PATH = 16, EMLOCO_RESET_FIXED_LOCATION = 32
+    EMLOCO_RESET_ADJUST_ROOT_VEL = 8, EMLOCO_RESET_REAL_PATH = 16, EMLOCO_RESET_FIXED_LOCATION = 32,
+    EMLOCO_RESET_NO_AMP_HISTORY = 64      /* emloco_task_reset leaves the AMP history back-fill to emloco_task_reset_amp_history */
 };
 /* layout of one env's random row */
 enum {
@@ -172,6 +173,11 @@ int emloco_task_reset(struct EmlocoSim *sim, const EmlocoResetBufs *bufs, const 
 int emloco_task_reset_seeded(struct EmlocoSim *sim, const EmlocoResetBufs *bufs, const int32_t *dev_env_ids, int n,
                              uint64_t seed, float *dev_rnd_ws, void *stream);
 
+/* The AMP history back-fill of a reset (_init_amp_obs_ref, humanoid_amp.py:486-535) alone: rows 1..14 of the listed envs'
+ * AMP observations from the motion ids / start times the reset sampled.  It reads nothing the simulator writes, so a caller
+ * that passed EMLOCO_RESET_NO_AMP_HISTORY may run it on another stream beside the rest of the reset chain. */
+int emloco_task_reset_amp_history(const EmlocoResetBufs *bufs, const int32_t *dev_env_ids, int n, void *stream);
+
 /* TrajGenerator.reset(env_ids, init_pos, root_vel) alone (traj_generator.py:60-237): writes traj_verts / inverted of the
  * listed envs from the random rows; dev_init_pos, dev_root_vel [n][3] (one row per list entry).  Only the trajectory
  * fields of `bufs` are read (flags, vert_dt ... hybrid_prob, n_real, real_traj, real_pick*, traj_verts, inverted). */
@@ -193,6 +199,9 @@ int emloco_task_get_heights(const int16_t *dev_heightfield, int rows, int cols, 
  * resets exactly the finished envs without the host ever reading the count (the reference's loop,
  * amp_continuous_value.py:46,74, synchronises on `dones.nonzero()` every step). */
 int emloco_task_compact_done(const int64_t *dev_flags, int n, int32_t *dev_ids, void *stream);
+/* Same, and a copy of the flags as they were (`dev_snapshot`, n entries): the reset kernels clear the flags of the envs they
+ * reset, a launch that runs beside them (emloco_sim_step_subset) follows the snapshot. */
+int emloco_task_compact_done_snapshot(const int64_t *dev_flags, int n, int32_t *dev_ids, int64_t *dev_snapshot, void *stream);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ extern "C" int emu_task_pd_targets(int n_env, const float *actions, const float 
 }
 
 extern "C" int emu_compact_flags(const int64_t *flags, int n, int32_t *ids) {
-    emu::launch(1, 1024, [&] { emloco::compact_flags_kernel(flags, n, ids); });
+    emu::launch(1, 1024, [&] { emloco::compact_flags_kernel(flags, n, ids, (int64_t *)nullptr); });
     return 0;
 }
 

@@ -60,6 +60,9 @@ static inline unsigned long long __ballot(int pred) {
     return m;
 }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline unsigned long long wall_clock64() { return 0ull; }
+// lock-step fibers run one at a time: a plain read-modify-write is atomic
+static inline int atomicAdd(int *p, int v) { const int o = *p; *p = o + v; return o; }
 static inline float __int_as_float(int x) { float f; std::memcpy(&f, &x, 4); return f; }
 static inline int __float_as_int(float f) { int x; std::memcpy(&x, &f, 4); return x; }
 static inline float __fdividef(float a, float b) { return a / b; }

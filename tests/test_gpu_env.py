@@ -567,27 +567,28 @@ def test_observations_on_a_side_stream_give_the_same_rollout():
 
 
 @pytest.mark.gpu
-def test_reset_chain_on_a_second_stream_gives_the_same_rollout():
+@pytest.mark.parametrize("obs_stream", [True, False])
+def test_reset_chain_on_a_second_stream_gives_the_same_rollout(obs_stream):
     """task.overlap_reset: `reset_done(); step(a)` issued as two chains -- the caller's stream steps the envs that did not
     finish (emloco_sim_step_subset with the flag snapshot), a second stream resets the finished ones, builds their
     observations and steps them over the compacted id list; step() joins before the post-physics launch.  Two identically
     seeded envs, one per mode (the second also with the observation side stream), forced and natural resets, the sim state
     and the warm-start impulses included: every buffer bit-equal after every step, and the reset envs' rows are valid after
-    wait_reset()."""
+    wait_reset().  160 envs: the id-list launch (128 workgroups) strides over the list when every env resets."""
     from emloco_amd import _lib as L
     args = ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel"]
-    envs = [_make_env(96, args), _make_env(96, args)]
+    envs = [_make_env(160, args), _make_env(160, args)]
     envs[1].task.overlap_reset = True
-    envs[1].task.overlap_obs = True
+    envs[1].task.overlap_obs = obs_stream            # the AMP history back-fill rides on the observation stream when there is one
     dev = envs[0].task.device
     g = torch.Generator(device=dev)
     names = ("_root_states", "_dof_state", "_rigid_body_state", "_contact_forces", "obs_buf", "_flip_obs_buf", "_amp_obs_buf",
              "progress_buf", "reset_buf", "rew_buf", "reward_raw", "_terminate_buf", "waypoint_traj", "init_pose", "init_vel")
     for k in range(40):
         g.manual_seed(100 + k)
-        act = torch.randn(96, 69, device=dev, generator=g) * 0.3
+        act = torch.randn(160, 69, device=dev, generator=g) * 0.3
         g.manual_seed(500 + k)
-        rnd = torch.rand(96, L.RESET_RND, device=dev, generator=g)
+        rnd = torch.rand(160, L.RESET_RND, device=dev, generator=g)
         obs_after_reset = []
         for e in envs:
             t = e.task
@@ -614,4 +615,4 @@ def test_reset_chain_on_a_second_stream_gives_the_same_rollout():
                 assert torch.equal(a, b), (k, name)
         assert torch.equal(envs[0].task.sim.native.warm_start, envs[1].task.sim.native.warm_start), k
         assert envs[0].task.sim.frame_count == envs[1].task.sim.frame_count
-    assert getattr(envs[1].task, "_rs_stream", None) is not None
+    assert getattr(envs[1].task, "_hp_stream", None) is not None

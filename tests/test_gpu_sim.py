@@ -223,3 +223,28 @@ def test_large_random_targets_stay_finite_and_match_the_oracle():
     assert vmax < 60.0 and float(gsim.root_state[0::2, 7:10].norm(dim=1).max()) < 15.0
     eff = torch.from_numpy(np.stack([m.effort for m in models]).astype(np.float32)).cuda()
     assert (gsim.dof_force.view(E, 69).abs() <= eff * (1 + 1e-6)).all()
+
+
+def test_cost_ordered_and_subset_launches_are_the_same_step():
+    """emloco_sim_set_cost_order (longest-first dispatch from the previous launch's per-env durations) and
+    emloco_sim_step_subset (skip flags + compacted id list = two launches that together step every env once) only change
+    which workgroup steps which env: every state tensor stays on the oracle's bytes over an episode with falls."""
+    E = 300
+    osim, gsim = _mk(E, seed=21)
+    gsim.set_cost_order(True)
+    dev = gsim.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    for k in range(12):
+        osim.step(1)
+        if k % 3 == 2:                                         # split launch: a random third of the envs through the id list
+            skip = (torch.rand(E, device=dev, generator=g) < 0.33).to(torch.int64)
+            ids = torch.full((E,), -1, dtype=torch.int32, device=dev)
+            nz = skip.nonzero().flatten().to(torch.int32)
+            ids[:nz.numel()] = nz
+            gsim.step_subset(2, skip=skip)
+            gsim.step_subset(2, ids=ids)
+        else:
+            gsim.step(2)
+        _compare(osim, gsim, E, what=f"step {k}")
+    assert np.abs(osim.contact_force).max() > 50.0
