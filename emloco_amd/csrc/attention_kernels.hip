@@ -49,20 +49,23 @@ struct AttnArgs {
     float *dqkv;                    // backward: [n_seq][S][3 d_model]  (dQ of rows >= Sq: zero-filled by the launcher)
     float *dsum;                    // backward: [n_seq * nhead][Sq]  D = rowsum(dO o O)
     // dropout on the attention probabilities (nn.MultiheadAttention(dropout=p) in training mode): probability (head-sequence bh,
-    // query, key) is kept iff at_keep_bit(...) below (a 32-bit counter hash: the mask costs ~9 integer operations per element)
+    // query, key) is kept iff at_keep_bit(...) below (a 32-bit counter hash shared by two adjacent keys: ~5 integer operations per element)
     // and scaled by 1 / (1 - p).  The softmax normaliser uses the undropped probabilities; the backward recomputes the mask.
     float drop_p, drop_scale;
     unsigned drop_seed, drop_thr;   // drop_thr = (unsigned)(p * 2^24)
 };
 
-// keep mask of the attention dropout: x = fmix32((fmix32(seed ^ bh c0) + query c1) ^ (key c2)), kept iff (x >> 8) >= p 2^24
+// keep mask of the attention dropout: x = fmix32((fmix32(seed ^ bh c0) + query c1) ^ ((key >> 1) c2)), key kept iff its 16-bit half of x >= p 2^16
 __host__ __device__ __forceinline__ unsigned at_fmix32(unsigned x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
 __host__ __device__ __forceinline__ unsigned at_head_key(unsigned seed, unsigned bh) { return at_fmix32(seed ^ (bh * 0x9E3779B1u)); }
+// One hash serves the two keys 2j, 2j + 1 (its low / high 16 bits against p 2^16): a lane's 16 keys of a tile come in adjacent
+// pairs, so the unrolled loops evaluate 8 hashes per 16 probabilities.
 __host__ __device__ __forceinline__ bool at_keep_bit(unsigned head_key, unsigned query, unsigned key, unsigned thr) {
-    return (at_fmix32((head_key + query * 0x85EBCA6Bu) ^ (key * 0xC2B2AE35u)) >> 8) >= thr;
+    const unsigned x = at_fmix32((head_key + query * 0x85EBCA6Bu) ^ ((key >> 1) * 0xC2B2AE35u));
+    return ((key & 1u) ? (x >> 16) : (x & 0xffffu)) >= (thr >> 8);
 }
 __device__ __forceinline__ float at_keep(const AttnArgs &a, unsigned head_key, int query, int key) {
     return at_keep_bit(head_key, (unsigned)query, (unsigned)key, a.drop_thr) ? a.drop_scale : 0.0f;

@@ -35,4 +35,5 @@ struct EmlocoSimDev {
     // workgroup leaves its own duration (100 MHz ticks) in step_ticks[env], the key of the next launch's order
     const int *step_order;
     unsigned *step_ticks;
+    unsigned long long *step_start;   /* diagnostic (emloco_sim_cost_ticks): wall clock at the start of each env's workgroup, else NULL */
 };

@@ -269,10 +269,11 @@ int emloco_sim_step(EmlocoSim *s, int n_calls, void *stream) {
         d.step_ticks = s->d_ticks.p;
     }
     const int slot = s->ev_head;
-    if (s->timing) HIPCHK(hipEventRecord(s->ev0[slot], st));
+    const bool timed = s->timing && (s->launch_no++ % s->timing_stride) == 0;
+    if (timed) HIPCHK(hipEventRecord(s->ev0[slot], st));
     hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)s->n_env), dim3(64), 0, st, p, d);
     HIPCHK(hipGetLastError());
-    if (s->timing) {
+    if (timed) {
         HIPCHK(hipEventRecord(s->ev1[slot], st));
         s->ev_head = (slot + 1) % EmlocoSim::kRing;
         if (s->ev_count < EmlocoSim::kRing) ++s->ev_count;
@@ -302,7 +303,7 @@ int emloco_sim_step_subset(EmlocoSim *s, int n_calls, const int64_t *dev_skip, c
         }
     }
     // the launch over everything but the flagged envs is the one the timing log follows (it stands where emloco_sim_step stood)
-    const bool timed = s->timing && dev_skip;
+    const bool timed = s->timing && dev_skip && (s->launch_no++ % s->timing_stride) == 0;
     const int slot = s->ev_head;
     if (timed) HIPCHK(hipEventRecord(s->ev0[slot], st));
     hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(dev_ids ? n_ids : s->n_env)), dim3(64), 0, st, p, d);
@@ -374,6 +375,25 @@ int emloco_sim_fk_indexed(EmlocoSim *s, const int32_t *ids, int n, void *stream)
     return EMLOCO_OK;
 }
 
+// internal diagnostic: the per-env durations (100 MHz ticks) the cost-ordered dispatch sorts by and, from the second call on,
+// the wall clock at which each env's workgroup started in the latest launch
+int emloco_sim_cost_ticks(EmlocoSim *s, unsigned *host_ticks, unsigned long long *host_start, int n) {
+    if (!s || !host_ticks || n < 1 || !s->d_ticks.p) return fail(EMLOCO_E_ARG, "emloco_sim_cost_ticks: bad argument / cost order off");
+    HIPCHK(hipDeviceSynchronize());
+    const size_t m = (size_t)(n < s->n_env ? n : s->n_env);
+    HIPCHK(hipMemcpy(host_ticks, s->d_ticks.p, sizeof(unsigned) * m, hipMemcpyDeviceToHost));
+    if (host_start) {
+        if (!s->dev.step_start) {
+            unsigned long long *p = nullptr;
+            HIPCHK(hipMalloc((void **)&p, sizeof(unsigned long long) * 2 * (size_t)s->n_env));
+            HIPCHK(hipMemset(p, 0, sizeof(unsigned long long) * 2 * (size_t)s->n_env));
+            s->dev.step_start = p;
+        }
+        HIPCHK(hipMemcpy(host_start, s->dev.step_start, sizeof(unsigned long long) * 2 * (size_t)s->n_env, hipMemcpyDeviceToHost));
+    }
+    return EMLOCO_OK;
+}
+
 // internal profiling hook (kernels built with -DEMLOCO_SIM_PROFILE): cycle stamps of env 0, 16 per substep
 int emloco_sim_profile(EmlocoSim *s, long long *host_out, int n) {
     if (!s || !host_out || n < 1) return fail(EMLOCO_E_ARG, "emloco_sim_profile: bad argument");
@@ -399,6 +419,8 @@ int emloco_sim_enable_timing(EmlocoSim *s, int on) {
         for (int i = 0; i < EmlocoSim::kRing; ++i) { HIPCHK(hipEventCreate(&s->ev0[i])); HIPCHK(hipEventCreate(&s->ev1[i])); }
     }
     s->timing = on != 0;
+    s->timing_stride = on > 1 ? on : 1;
+    s->launch_no = 0;
     s->ev_head = 0; s->ev_count = 0;
     return EMLOCO_OK;
 }

@@ -88,8 +88,9 @@ struct BodyConst {   // per-lane (lane = body) constants kept in registers for t
 #define EMLOCO_SIM_WAVES_PER_SIMD 2   /* register budget 256 per lane: two resident waves per SIMD (8 envs per CU) */
 #endif
 // one env's step: the body of both kernels below (one 64-lane wave)
-__device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const EmlocoSimDev &d, const int env) {
+__device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const EmlocoSimDev &d, const int env, int &work) {
     const int lane = threadIdx.x;
+    work = 0;                                                 // contact work of this step: sum over substeps of (10 + contacts) where there are any
 
     // ---------------------------------------------------------------- LDS: one blob, 16 KB per env (8 envs per CU need <= 20 KB)
     // Every per-body row starts on a 16-byte boundary and is padded to a multiple of four words, so a lane moves its row with
@@ -109,7 +110,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
            LDS_WORDS = O_PQ + NB * 8 };
     static_assert(O_R % 4 == 0 && O_W % 4 == 0 && O_K % 4 == 0 && O_IA % 4 == 0 && O_I6 % 4 == 0 && O_F % 4 == 0 && O_PQ % 4 == 0, "rows must be 16-byte aligned");
     static_assert(O_PQ - O_G >= MAXR * (MAXR + 1) / 2, "contact matrix does not fit its overlay");
-    static_assert(O_V - O_G >= NB * 8 + EMLOCO_SC_MAXHITS * 8, "limb-limb scratch does not fit its overlay");
+    static_assert(O_V - O_G >= NB * 8 + EMLOCO_SC_MAXHITS * 8 + 256, "limb-limb scratch does not fit its overlay");
     static_assert(LDS_WORDS * 4 <= 20480, "LDS per env above 160 KiB / 8");
     __shared__ __attribute__((aligned(16))) float lds[LDS_WORDS];
     float *sh_root = lds + O_ROOT;                            // p0[3] q0[4] V0[6]
@@ -196,6 +197,9 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             for (int k = 0; k < 9; ++k) sh_R[0][k] = R[k];
             for (int k = 0; k < 6; ++k) { sh_V[0][k] = sh_root[7 + k]; sh_Aacc[0][k] = 0.0f; }
         }
+        // joint offsets: re-read per substep (L2 hit) instead of held for the launch, but ahead of the level loop so that the
+        // load's latency is not paid inside every level
+        const float joff[3] = {d.joint_off[mb0 * 3], d.joint_off[mb0 * 3 + 1], d.joint_off[mb0 * 3 + 2]};
         __syncthreads();
         for (int lev = 1; lev <= d.max_depth; ++lev) {
             if (is_body && bc.depth == lev) {
@@ -203,7 +207,6 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 float Rp[9], o[3], qp[4], qw[4], pw[3], R[9], r[3], Sl[3][3], V[6];
                 for (int k = 0; k < 9; ++k) Rp[k] = sh_R[p][k];
                 for (int k = 0; k < 4; ++k) qp[k] = sh_pq[p][4 + k];
-                const float joff[3] = {d.joint_off[mb0 * 3], d.joint_off[mb0 * 3 + 1], d.joint_off[mb0 * 3 + 2]};   // re-read per substep (L2 hit)
                 matvec3(Rp, joff, o);
                 for (int k = 0; k < 3; ++k) { pw[k] = sh_pq[p][k] + o[k]; r[k] = pw[k] - sh_root[k]; }
                 qmul(qp, qj, qw);
@@ -330,11 +333,37 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 matvec3(R, ca, pa); matvec3(R, cb, pb);
                 for (int k = 0; k < 3; ++k) { sh_seg[lane * 8 + k] = r[k] + pa[k]; sh_seg[lane * 8 + 3 + k] = r[k] + pb[k]; }
                 sh_seg[lane * 8 + 6] = d.sc_cap_r[mb0];
+                const float ax[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+                sh_seg[lane * 8 + 7] = 0.5f * sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);      // half length of the capsule's segment
+            }
+            __syncthreads();
+            // broad phase: two capsules can only touch when their segment midpoints are closer than the two radii plus the two
+            // half lengths (triangle inequality; 1 mm of slack covers the rounding): the pairs that pass -- a few dozen of the
+            // 245 -- are compacted in pair order and only they run the closest-point test, in one round instead of four.
+            // A culled pair cannot hit, so the hit list (and every force) is what the full sweep gives.
+            int *sh_cand = (int *)(sh_A + NB * 8 + EMLOCO_SC_MAXHITS * 8);
+            int ncand = 0;
+            for (int q0 = 0; q0 < d.sc_n; q0 += 64) {
+                const int q = q0 + lane;
+                bool keep = false;
+                if (q < d.sc_n) {
+                    const int bi = d.sc_pairs[2 * q], bj = d.sc_pairs[2 * q + 1];
+                    float dm2 = 0.0f;
+                    for (int k = 0; k < 3; ++k) {
+                        const float dm = (sh_seg[bi * 8 + k] + sh_seg[bi * 8 + 3 + k]) - (sh_seg[bj * 8 + k] + sh_seg[bj * 8 + 3 + k]);   // 2 (m_i - m_j)
+                        dm2 += dm * dm;
+                    }
+                    const float bound = (sh_seg[bi * 8 + 6] + sh_seg[bj * 8 + 6]) + (sh_seg[bi * 8 + 7] + sh_seg[bj * 8 + 7]) + 1e-3f;
+                    keep = dm2 <= 4.0f * bound * bound;
+                }
+                const unsigned long long bal = __ballot(keep);
+                if (keep) sh_cand[ncand + __popcll(bal & ((1ull << lane) - 1ull))] = q;
+                ncand += __popcll(bal);
             }
             __syncthreads();
             int nh = 0;
-            for (int q0 = 0; q0 < d.sc_n; q0 += 64) {
-                const int q = q0 + lane;
+            for (int c0 = 0; c0 < ncand; c0 += 64) {
+                const int q = (c0 + lane < ncand) ? sh_cand[c0 + lane] : d.sc_n;
                 bool hit = false;
                 float w6[6] = {0, 0, 0, 0, 0, 0};
                 int bi = 0, bj = 0;
@@ -697,6 +726,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         }
         __syncthreads();
         const int nr = 3 * nc;
+        work += nc > 0 ? 10 + nc : 0;
 
         PSTAMP(5);
         // ============================================================ 6a. rows: Jacobian, rhs, chain propagation (lane = row)
@@ -843,8 +873,9 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         const float ainv = (lane < nr) ? 1.0f / (sh_A[tri_s + ls] * (1.0f + prm.cfm)) : 0.0f;
         // entry (ls, rr) of the symmetric matrix in the packed lower triangle; the sweeps read the three entries of the next
         // contact while the current one is being resolved (the reads do not depend on the multipliers)
-// (tri_index is branch-free min / max arithmetic; a compare-and-select between the two triangle forms with the uniform
-// part on the scalar unit looked cheaper and measured slower: first sweep 356 -> 432 ticks)
+// (tri_index is branch-free min / max / multiply arithmetic per lane.  Two cheaper-looking forms -- a compare-and-select
+// between the two triangle forms, and the larger index's offset taken from the scalar unit with a per-lane select -- have
+// fewer vector instructions and both measured slower: first sweep 340 -> 430 / 392 ticks)
 #define A_OF(rr) sh_A[tri_index(ls, (rr))]
         float w = rhs;
         {                                                          // warm start (matrix entries read one contact ahead)
@@ -1121,13 +1152,24 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     int env = d.step_order ? d.step_order[blockIdx.x] : (int)blockIdx.x;
     if (d.step_ids) { env = d.step_ids[blockIdx.x]; if (env < 0) return; }   // list launch: workgroup i steps list entry i (-1: padding)
     if (d.step_skip && d.step_skip[env] != 0) return;            // flagged envs are stepped elsewhere
-    const long long t0 = d.step_ticks ? (long long)wall_clock64() : 0ll;
-    sim_step_env(prm, d, env);
-    if (d.step_ticks && threadIdx.x == 0) d.step_ticks[env] = (unsigned)((long long)wall_clock64() - t0);
+    const long long t0 = d.step_start ? (long long)wall_clock64() : 0ll;
+    int work;
+    sim_step_env(prm, d, env, work);
+    if (d.step_ticks && threadIdx.x == 0) {
+        // the key of the next launch's order: EMLOCO_COST_KEY_TICKS (diagnostic build) = measured duration in 5.12 us units
+#ifdef EMLOCO_COST_KEY_TICKS
+        d.step_ticks[env] = (unsigned)(((long long)wall_clock64() - t0) >> 9);
+#else
+        d.step_ticks[env] = (unsigned)work;
+#endif
+        if (d.step_start) { d.step_start[env] = (unsigned long long)t0; d.step_start[d.n_env + env] = (unsigned long long)wall_clock64(); }
+    }
 }
 
-// Dispatch order of the next full launch: env ids sorted by the duration of their last step, longest first (counting sort
-// over 5.12 us buckets; one 1024-thread workgroup).  Workgroups are handed to the CUs in index order and the launch is two
+// Dispatch order of the next full launch: env ids sorted by the contact work of their last step (sum over its substeps of
+// 10 + number of contacts where there were any: the contact phases are ~45 % of a substep and grow with the contact count),
+// most first (counting sort, one 1024-thread workgroup).  The measured duration of the last step is the worse key: it is
+// dominated by what the env's wave shared its SIMD and CU with (correlation between consecutive steps 0.2).  Workgroups are handed to the CUs in index order and the launch is two
 // resident rounds of waves (4096 envs on 256 CUs x 8), so its length is set by what the LAST workgroups cost: with the
 // expensive envs (many contacts) first and the cheap ones (airborne) last, the slots that free up late receive short work.
 // The order within a bucket is whatever the LDS atomics give -- envs are independent, results do not depend on it.
@@ -1141,7 +1183,7 @@ sim_order_kernel(const unsigned *ticks, int n, int *order) {
     if (tid < EMLOCO_ORDER_BUCKETS) sh_cnt[tid] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
-        unsigned b = ticks[i] >> 9;
+        unsigned b = ticks[i];
         b = b > EMLOCO_ORDER_BUCKETS - 1 ? EMLOCO_ORDER_BUCKETS - 1 : b;
         sh_b[i] = (unsigned char)b;
         atomicAdd(&sh_cnt[b], 1);

@@ -50,6 +50,7 @@ struct EmlocoSim {
     static constexpr int kRing = 1024;
     std::vector<hipEvent_t> ev0, ev1;
     int ev_head = 0, ev_count = 0;
+    int timing_stride = 1, launch_no = 0;      // every timing_stride-th step launch is timed (the event packets cost ~5 us each)
     float last_ms = -1.0f;
 };
 

@@ -154,8 +154,9 @@ class NativeSim:
         L.check(self.lib.emloco_sim_set_params(self._h, C.byref(p)), "emloco_sim_set_params")
         self.params = p
 
-    def enable_timing(self, on=True):
-        L.check(self.lib.emloco_sim_enable_timing(self._h, int(bool(on))), "emloco_sim_enable_timing")
+    def enable_timing(self, on=True, every=1):
+        """HIP-event timing of the step launches; `every` = N times every N-th launch only."""
+        L.check(self.lib.emloco_sim_enable_timing(self._h, int(every) if on else 0), "emloco_sim_enable_timing")
 
     def timing_stats(self):
         """(number of step launches, their summed HIP-event duration in ms) since timing was enabled / last read."""

@@ -155,7 +155,8 @@ int emloco_sim_refresh_bodies(EmlocoSim *sim, void *stream);
 int emloco_sim_num_candidates(EmlocoSim *sim);
 /* wall-clock of the last emloco_sim_step launch measured with HIP events on its stream [ms]; <0 if none */
 float emloco_sim_last_step_ms(EmlocoSim *sim);
-/* enable/disable HIP-event timing of step launches (events are recorded on the launch stream; enabling resets the log) */
+/* enable/disable HIP-event timing of step launches (events are recorded on the launch stream; enabling resets the log);
+ * on = 1: every launch, on = N > 1: every N-th launch (an event record is a packet of its own in the stream, ~5 us each) */
 int emloco_sim_enable_timing(EmlocoSim *sim, int on);
 /* number and summed duration [ms] of the step launches recorded since timing was enabled / last queried (<= 1024 kept) */
 int emloco_sim_timing_stats(EmlocoSim *sim, int *n_launches, float *total_ms);
