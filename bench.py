@@ -302,7 +302,8 @@ def eval_leg(dev, B=512, batches=2, rank=0, world=1):
 
 def jta_cpu_baseline(B=32, budget_s=60.0):
     """The same EmLoco train step on the host cores with the stock-torch restatement (oracle/predictor_torch.py): batch 32,
-    thread count swept over {8, 16, all cores} (one warm-up + one timed iteration each), the best one timed again."""
+    thread count swept upwards over {8, 16, 32, all cores} while it helps (one warm-up + one timed iteration each), the best
+    one timed again."""
     import torch
     from oracle.predictor_torch import LocoValOracle, TransMotionJTAOracle, emloco_train_step
     from emloco_amd.predictor.train_jta import batch_process_coords
@@ -320,14 +321,19 @@ def jta_cpu_baseline(B=32, budget_s=60.0):
     vel = (i[:, 8, 0, :2] - i[:, 7, 0, :2]) * 2.5
     t_start = time.perf_counter()
     sweep = {}
-    for th in sorted({min(8, ncpu), min(16, ncpu), ncpu}):
+    # more threads are tried only while they help: on the 256-thread host of the GPU box the step runs 3.9 samples/s on 8
+    # threads, 3.6 on 16 and 0.23 on all 256 (profiles/r02_bench_default.log of the earlier build: two iterations at 256
+    # threads alone took 4.6 minutes of the default run)
+    prev = None
+    for th in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu), ncpu}):
         torch.set_num_threads(th)
         emloco_train_step(model, vnet, opt, i, o, pm, pose, vel)            # warm-up at this thread count
         t0 = time.perf_counter()
         emloco_train_step(model, vnet, opt, i, o, pm, pose, vel)
         sweep[th] = time.perf_counter() - t0
-        if time.perf_counter() - t_start > budget_s * 0.6:
+        if time.perf_counter() - t_start > budget_s * 0.6 or (prev is not None and sweep[th] > prev):
             break
+        prev = sweep[th]
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     iters, tot = 0, 0.0
@@ -339,7 +345,7 @@ def jta_cpu_baseline(B=32, budget_s=60.0):
     dt = min(tot / iters, sweep[best])
     return {"value": round(B / dt, 3), "unit": "samples/s", "cores": best, "kind": "port",
             "sample": f"the same train step at batch {B} x {joints.shape[1]} people, stock torch.nn fp32 restatement; thread sweep "
-                      + ", ".join(f"{k}: {B / v:.2f}/s" for k, v in sweep.items()) + f" of {ncpu} host cores; best = {best} threads, "
+                      + ", ".join(f"{k}: {B / v:.2f}/s" for k, v in sweep.items()) + f" (stopped where more threads got slower) of {ncpu} host cores; best = {best} threads, "
                       f"{iters} more timed iterations ({dt:.2f} s / iteration)"}
 
 
@@ -485,8 +491,14 @@ def main():
     E = a.num_envs
     env = make_env(E, rank)
     task = env.task
-    if os.environ.get("EMLOCO_COST_ORDER", "1") != "0":
-        task.sim.native.set_cost_order(True)         # longest-first dispatch of the rigid-body launch (results unchanged)
+    # Two schedules of the same step (identical results, tests/test_gpu_env.py / test_gpu_sim.py):
+    #   overlap (headline): the reset chain of the finished envs and their step on a second HIP stream beside the step of the
+    #     live envs (task.overlap_reset);
+    #   sequential (reported beside it): the reference's order, with the rigid-body launch dispatched most-contact-work-first
+    #     (emloco_sim_set_cost_order).  The two do not add up: cost order keeps the wave slots busy longest.
+    overlap = os.environ.get("EMLOCO_OVERLAP_RESET", "1") != "0"
+    if not overlap and os.environ.get("EMLOCO_COST_ORDER", "1") != "0":
+        task.sim.native.set_cost_order(True)
     env.reset(torch.arange(E, device=dev))
     stagger_episodes(env, seed=rank)                     # untimed: episode ages uniform over [0, 168) before the warm-up
     g = torch.Generator(device=dev)
@@ -506,7 +518,7 @@ def main():
     noise_policy.reads_obs = False
 
     horizon = 32
-    agent = LocoValRollout(env, horizon_length=horizon, policy=noise_policy)
+    agent = LocoValRollout(env, horizon_length=horizon, policy=noise_policy, overlap_reset=overlap)
     agent.started = True                                 # the envs are already reset and staggered
     agent._sched_live = True                             # (the schedule's first-episode check is a host read; not in the timed loop)
 
@@ -548,6 +560,29 @@ def main():
         torch.cuda.synchronize()
         env_only = time.perf_counter() - t1
 
+    # the sequential, cost-ordered schedule of the same env.step (and the rigid-body kernel's duration when nothing runs beside it)
+    seq = None
+    if world == 1 and overlap:
+        task.wait_reset()
+        task.overlap_reset = False
+        task.sim.native.set_cost_order(True)
+        for k in range(a.warmup):
+            env.reset_done(); env.step(pool[k % 64])
+        task.sim.native.enable_timing(True, every=4)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(a.steps):
+            env.reset_done(); env.step(pool[k % 64])
+        torch.cuda.synchronize()
+        seq_t = time.perf_counter() - t1
+        n_s, ms_s = task.sim.native.timing_stats()
+        seq = {"value": round(E * a.steps / seq_t, 1), "unit": "env-steps/s", "ms_per_step": round(seq_t / a.steps * 1e3, 4),
+               "kernel_ms": round(ms_s / max(n_s, 1), 4), "launches_timed": n_s,
+               "note": "env.step alone in the reference's order (reset chain, then one launch for all envs), rigid-body launch "
+                       "dispatched most-contact-work-first (emloco_sim_set_cost_order); kernel_ms = sim_step_kernel with nothing beside it"}
+        task.sim.native.set_cost_order(False)
+        task.overlap_reset = True
+
     if rank == 0:
         kernel_ms = ms_l / max(n_l, 1)
         achieved = SIM_BYTES_PER_ENV * E / (kernel_ms * 1e-3) / 1e9 if n_l else 0.0
@@ -573,7 +608,10 @@ def main():
             "config": {"workload": "configs[1] env: PACER rollout env.step, 4096 SMPL humanoids per GPU, random_heading, "
                                    "JTA+JRDB-shaped real_path (synthetic), flat terrain, self-collision on, steady-state resets included "
                                    "(episode ages pre-staggered), inside the LocoVal-training loop of configs[2] (returns bookkeeping + LocoVal "
-                                   "fit + gradient all-reduce every step), policy network excluded",
+                                   "fit + gradient all-reduce every step), policy network excluded"
+                                   + ("; schedule: the reset chain of the finished envs and their step run on a second HIP stream beside "
+                                      "the step of the live envs (task.overlap_reset; same results as the sequential order)" if overlap else
+                                      "; schedule: sequential, rigid-body launch dispatched most-contact-work-first"),
                        "locoval": {"episodes_fitted": fitted, "last_fit_loss": round(vloss, 5), "exchange_floats_per_step": 6176},
                        "num_envs_per_gpu": E, "substeps_per_step": 4, "parallelism": f"env-sharded x{world}" + (" (TEST MODE: all ranks share cuda:0, gloo)" if share else "")},
             "roofline": {"bound": "hbm", "kernel": "sim_step_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
@@ -582,8 +620,13 @@ def main():
                          "note": "latency bound, not bandwidth bound: ~9 KB of state per env per launch against ~50 k dependent fp32 VALU "
                                  "wave-instructions (level-synchronous tree passes, 2 waves / SIMD, two resident rounds of 2048 waves for "
                                  "4096 envs); valu_issue_frac and the wait fractions come from profiles/r02_sim_step_valu.txt, traffic "
-                                 "from profiles/r02_sim_step_hbm_bytes.json (PMC passes of this round's kernel)"},
+                                 "from profiles/r02_sim_step_hbm_bytes.json (PMC passes of this round's kernel); kernel_ms is the launch over "
+                                 "the live envs in the timed region (every 4th launch timed), where the reset chain and the reset envs' "
+                                 "launch share the device with it -- `sequential.kernel_ms` is the same kernel with nothing beside it"},
         }
+        if seq is not None:
+            seq["roofline_frac_alone"] = round(SIM_BYTES_PER_ENV * E / (seq["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if seq["launches_timed"] else None
+            out["sequential"] = seq
         if env_only is not None:
             out["env_step_only"] = {"value": round(E * a.steps / env_only, 1), "unit": "env-steps/s", "ms_per_step": round(env_only / a.steps * 1e3, 4),
                                     "note": "reset_done + env.step without the LocoVal bookkeeping / fit (round-1 definition of the step)"}

@@ -225,7 +225,7 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
                 self._rs_skip = torch.zeros(E, dtype=torch.int64, device=dev)
                 self._hp_stream = torch.cuda.Stream(device=dev, priority=-1)
                 self._ev_rs_fork, self._ev_rs_reset, self._ev_rs_pd, self._ev_rs_big = (torch.cuda.Event() for _ in range(4))
-            if getattr(self, "_obs_stream", None) is None:
+            if self.overlap_reset_mode == "hp" and getattr(self, "_obs_stream", None) is None:
                 self._make_obs_stream()
             self.wait_reset()
             main = torch.cuda.current_stream(dev)
@@ -233,7 +233,7 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
                                                           C.c_void_p(self._rs_skip.data_ptr()), current_stream_handle(dev)),
                     "emloco_task_compact_done_snapshot")
             self._ev_rs_fork.record(main)
-            side = self._obs_stream
+            side = self._obs_stream if self.overlap_reset_mode == "hp" else self._hp_stream
             side.wait_event(self._ev_rs_fork)
         else:
             L.check(lib.emloco_task_compact_done(C.c_void_p(self.reset_buf.data_ptr()), E, C.c_void_p(self._done_ids.data_ptr()),
@@ -293,6 +293,10 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
     # exactly the launches it would see in the sequential order: identical results (tests/test_gpu_env.py).  Four streams in
     # all with the LocoVal fit's: HIP serves a process with four hardware queues.
     overlap_reset = False
+    # "side": the reset chain and the reset envs' step on one high-priority stream, the big launch on the caller's (the
+    # arrangement above with the roles of the two launches swapped: the small launch competes for wave slots at the end of
+    # the big launch's first round); "hp": as described above
+    overlap_reset_mode = os.environ.get("EMLOCO_OVERLAP_MODE", "side")
 
     def wait_reset(self):
         """Make the caller's stream wait for the reset chain of the last reset_done() (no-op without overlap_reset)."""
@@ -310,12 +314,20 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         dev = torch.device(self.device)
         main, hp, E = torch.cuda.current_stream(dev), self._hp_stream, self.num_envs
         self._ev_rs_pd.record(main)                              # the PD targets of all envs are in place
-        hp.wait_event(self._ev_rs_pd)
-        with torch.cuda.stream(hp):
+        if self.overlap_reset_mode == "hp":
+            hp.wait_event(self._ev_rs_pd)
+            with torch.cuda.stream(hp):
+                self.gym.simulate_n_subset(self.sim, self.control_freq_inv, skip=self._rs_skip)
+                self._ev_rs_big.record(hp)
+            self.wait_reset()                                    # the reset envs' state and observations are in place
+            self.gym.simulate_n_subset(self.sim, self.control_freq_inv, ids=self._done_ids[:E], count=False)
+        else:
             self.gym.simulate_n_subset(self.sim, self.control_freq_inv, skip=self._rs_skip)
-            self._ev_rs_big.record(hp)
-        self.wait_reset()                                        # the reset envs' state and observations are in place
-        self.gym.simulate_n_subset(self.sim, self.control_freq_inv, ids=self._done_ids[:E], count=False)
+            hp.wait_event(self._ev_rs_pd)
+            with torch.cuda.stream(hp):                          # behind the reset chain on its stream
+                self.gym.simulate_n_subset(self.sim, self.control_freq_inv, ids=self._done_ids[:E], count=False)
+                self._ev_rs_big.record(hp)
+            self._rs_unjoined = False                            # the join below covers the reset chain
         main.wait_event(self._ev_rs_big)
 
     def _ensure_post_bufs(self):
