@@ -497,6 +497,11 @@ def main():
     #   sequential (reported beside it): the reference's order, with the rigid-body launch dispatched most-contact-work-first
     #     (emloco_sim_set_cost_order).  The two do not add up: cost order keeps the wave slots busy longest.
     overlap = os.environ.get("EMLOCO_OVERLAP_RESET", "1") != "0"
+    # the 4 substeps of a step as two dependent workgroups per env in ONE launch (emloco_sim_set_split; bit-identical results):
+    # wave slots that cheap envs free early are refilled at half-step granularity instead of idling to the launch's end
+    n_parts = int(os.environ.get("EMLOCO_SPLIT", "2"))
+    if n_parts > 1:
+        task.sim.native.set_split(n_parts)
     if not overlap and os.environ.get("EMLOCO_COST_ORDER", "1") != "0":
         task.sim.native.set_cost_order(True)
     env.reset(torch.arange(E, device=dev))
@@ -605,7 +610,7 @@ def main():
             "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1] env: PACER rollout env.step, 4096 SMPL humanoids per GPU, random_heading, "
+            "config": {"workload": f"configs[1] env: PACER rollout env.step, {E} SMPL humanoids per GPU, random_heading, "
                                    "JTA+JRDB-shaped real_path (synthetic), flat terrain, self-collision on, steady-state resets included "
                                    "(episode ages pre-staggered), inside the LocoVal-training loop of configs[2] (returns bookkeeping + LocoVal "
                                    "fit + gradient all-reduce every step), policy network excluded"
@@ -613,7 +618,7 @@ def main():
                                       "the step of the live envs (task.overlap_reset; same results as the sequential order)" if overlap else
                                       "; schedule: sequential, rigid-body launch dispatched most-contact-work-first"),
                        "locoval": {"episodes_fitted": fitted, "last_fit_loss": round(vloss, 5), "exchange_floats_per_step": 6176},
-                       "num_envs_per_gpu": E, "substeps_per_step": 4, "parallelism": f"env-sharded x{world}" + (" (TEST MODE: all ranks share cuda:0, gloo)" if share else "")},
+                       "num_envs_per_gpu": E, "substeps_per_step": 4, "workgroups_per_env": n_parts, "parallelism": f"env-sharded x{world}" + (" (TEST MODE: all ranks share cuda:0, gloo)" if share else "")},
             "roofline": {"bound": "hbm", "kernel": "sim_step_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l, "valu_issue_frac": valu,

@@ -134,7 +134,7 @@ SYMBOLS_SIM = [
     "emloco_last_error", "emloco_device_count", "emloco_sim_create", "emloco_sim_destroy", "emloco_sim_set_models",
     "emloco_sim_set_self_collision", "emloco_sim_set_ground_heightfield",
     "emloco_sim_prepare", "emloco_sim_get_params", "emloco_sim_set_params", "emloco_sim_tensor",
-    "emloco_sim_set_pd_targets", "emloco_sim_step", "emloco_sim_step_subset", "emloco_sim_set_cost_order", "emloco_sim_sync", "emloco_sim_set_root_state_indexed",
+    "emloco_sim_set_pd_targets", "emloco_sim_step", "emloco_sim_step_subset", "emloco_sim_set_cost_order", "emloco_sim_set_split", "emloco_sim_sync", "emloco_sim_set_root_state_indexed",
     "emloco_sim_set_dof_state_indexed", "emloco_sim_refresh_bodies", "emloco_sim_num_candidates",
     "emloco_sim_last_step_ms", "emloco_sim_enable_timing", "emloco_sim_timing_stats",
 ]
@@ -175,6 +175,7 @@ def load():
     lib.emloco_sim_set_pd_targets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emloco_sim_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.emloco_sim_set_cost_order.argtypes = [C.c_void_p, C.c_int]
+    lib.emloco_sim_set_split.argtypes = [C.c_void_p, C.c_int]
     lib.emloco_sim_step_subset.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.emloco_sim_sync.argtypes = [C.c_void_p, C.c_void_p]
     lib.emloco_sim_set_root_state_indexed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

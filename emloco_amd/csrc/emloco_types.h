@@ -1,5 +1,6 @@
 // emloco_types.h -- device-side argument structs shared by the kernels and the C-ABI layer.
 #pragma once
+#define EMLOCO_PART_WORDS 368   /* 24 x 10 joint registers | 16 root | 8 momentum | 64 multipliers | 32 slot map | 8 misc */
 #include "../../include/emloco_sim.h"
 
 // Device pointers handed to the rollout kernels by value (kernarg segment).
@@ -35,5 +36,10 @@ struct EmlocoSimDev {
     // workgroup leaves its own duration (100 MHz ticks) in step_ticks[env], the key of the next launch's order
     const int *step_order;
     unsigned *step_ticks;
+    // split launch (emloco_sim_set_split): the substeps of an env.step as n_parts workgroups per env, part p + 1 continuing
+    // from the registers / LDS part p left in part_state [n_env][EMLOCO_PART_WORDS] once part_flag[env] == part_seq
+    int n_parts; unsigned part_seq;
+    float *part_state;
+    unsigned *part_flag;
     unsigned long long *step_start;   /* diagnostic (emloco_sim_cost_ticks): wall clock at the start of each env's workgroup, else NULL */
 };

@@ -79,6 +79,7 @@ int emloco_sim_destroy(EmlocoSim *s) {
     s->d_root.release(); s->d_dof.release(); s->d_tgt.release(); s->d_rb.release();
     s->d_cf.release(); s->d_df.release(); s->d_lws.release();
     s->d_ticks.release(); s->d_order.release();
+    s->d_part_state.release(); s->d_part_flag.release();
     for (auto e : s->ev0) (void)hipEventDestroy(e);
     for (auto e : s->ev1) (void)hipEventDestroy(e);
     delete s;
@@ -271,7 +272,8 @@ int emloco_sim_step(EmlocoSim *s, int n_calls, void *stream) {
     const int slot = s->ev_head;
     const bool timed = s->timing && (s->launch_no++ % s->timing_stride) == 0;
     if (timed) HIPCHK(hipEventRecord(s->ev0[slot], st));
-    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)s->n_env), dim3(64), 0, st, p, d);
+    d.n_parts = s->n_parts; d.part_seq = ++s->part_seq; d.part_state = s->d_part_state.p; d.part_flag = s->d_part_flag.p;
+    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(s->n_env * s->n_parts)), dim3(64), 0, st, p, d);
     HIPCHK(hipGetLastError());
     if (timed) {
         HIPCHK(hipEventRecord(s->ev1[slot], st));
@@ -306,13 +308,29 @@ int emloco_sim_step_subset(EmlocoSim *s, int n_calls, const int64_t *dev_skip, c
     const bool timed = s->timing && dev_skip && (s->launch_no++ % s->timing_stride) == 0;
     const int slot = s->ev_head;
     if (timed) HIPCHK(hipEventRecord(s->ev0[slot], st));
-    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(dev_ids ? n_ids : s->n_env)), dim3(64), 0, st, p, d);
+    d.n_parts = dev_ids ? 1 : s->n_parts;            // the list launch (a few dozen envs) is not split
+    d.part_seq = ++s->part_seq; d.part_state = s->d_part_state.p; d.part_flag = s->d_part_flag.p;
+    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(dev_ids ? n_ids : s->n_env * s->n_parts)), dim3(64), 0, st, p, d);
     HIPCHK(hipGetLastError());
     if (timed) {
         HIPCHK(hipEventRecord(s->ev1[slot], st));
         s->ev_head = (slot + 1) % EmlocoSim::kRing;
         if (s->ev_count < EmlocoSim::kRing) ++s->ev_count;
     }
+    return EMLOCO_OK;
+}
+
+int emloco_sim_set_split(EmlocoSim *s, int n_parts) {
+    if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_set_split: null sim");
+    if (!s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_set_split: sim not prepared");
+    if (n_parts < 1 || n_parts > 4) return fail(EMLOCO_E_ARG, "emloco_sim_set_split: 1 to 4 parts");
+    if (n_parts > 1 && !s->d_part_state.p) {
+        HIPCHK(hipSetDevice(s->device));
+        HIPCHK(s->d_part_state.alloc((size_t)s->n_env * EMLOCO_PART_WORDS));
+        HIPCHK(s->d_part_flag.alloc((size_t)s->n_env));
+        HIPCHK(hipMemset(s->d_part_flag.p, 0, sizeof(unsigned) * (size_t)s->n_env));
+    }
+    s->n_parts = n_parts;
     return EMLOCO_OK;
 }
 

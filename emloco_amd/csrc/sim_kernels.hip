@@ -53,6 +53,20 @@ __device__ __forceinline__ int tri_index(int a, int b) {
     return ((hi * (hi + 1)) >> 1) + lo;
 }
 
+// Hand-over words of a split launch (emloco_sim_set_split): written and read with agent-scope relaxed atomics -- each access
+// is coherent across the XCDs' L2s by itself -- and ordered against the flag by waiting for the stores (workgroup-scope
+// fences = s_waitcnt).  Agent-scope fences instead (__threadfence / acquire-release on the flag) write back and invalidate
+// the whole L2 of the XCD per workgroup: measured, the launch went from 0.54 to 0.68 ms with two parts.
+#ifdef EMLOCO_EMU
+#define PART_ST(p, v) (*(p) = (v))
+#define PART_LD(p) (*(p))
+#define PART_FENCE() do { } while (0)
+#else
+#define PART_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define PART_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define PART_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#endif
+
 #ifdef EMLOCO_SIM_PROFILE
 #define PSTAMP(i) do { if (d.prof && env == 0 && lane == 0) d.prof[sub * 16 + (i)] = (long long)wall_clock64(); } while (0)
 #else
@@ -88,7 +102,7 @@ struct BodyConst {   // per-lane (lane = body) constants kept in registers for t
 #define EMLOCO_SIM_WAVES_PER_SIMD 2   /* register budget 256 per lane: two resident waves per SIMD (8 envs per CU) */
 #endif
 // one env's step: the body of both kernels below (one 64-lane wave)
-__device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const EmlocoSimDev &d, const int env, int &work) {
+__device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const EmlocoSimDev &d, const int env, int &work, const int part, const int n_parts) {
     const int lane = threadIdx.x;
     work = 0;                                                 // contact work of this step: sum over substeps of (10 + contacts) where there are any
 
@@ -160,20 +174,48 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     sh_slot[lane] = 255; sh_slot[lane + 64] = 255;
 
     // ---------------------------------------------------------------- state -> registers
+    // Split launch: the substeps [sub_lo, sub_hi) of this workgroup; part 0 starts from the state tensors like the whole
+    // step, a later part continues from what its predecessor left (joint quaternions / rates / rotation vectors per lane,
+    // root, momentum balance, multipliers and their slot map: plain copies, so the parts together are the fused step bit
+    // for bit).  Parts are workgroups of ONE launch, the later ones at higher indices: the wave slots that the first
+    // parts of short envs free early are taken by second parts instead of idling until the launch's last workgroup ends.
+    const int sub_lo = (prm.n_sub * part) / n_parts, sub_hi = (prm.n_sub * (part + 1)) / n_parts;
+    float *pst = d.part_state ? d.part_state + (long)env * EMLOCO_PART_WORDS : nullptr;
     float qj[4] = {0, 0, 0, 1}, wj[3] = {0, 0, 0}, edof[3] = {0, 0, 0};
-    if (is_body && lane >= 1) {
-        const float *ds = d.dof_state + ((long)env * NDOF + (lane - 1) * 3) * 2;
-        float e[3] = {ds[0], ds[2], ds[4]};
-        rotvec2quat(e, qj);
-        wj[0] = ds[1]; wj[1] = ds[3]; wj[2] = ds[5];
-        quat2rotvec(qj, edof);
-    }
-    if (lane == 0) {
-        const float *rs = d.root_state + (long)env * 13;
-        float q0[4] = {rs[3], rs[4], rs[5], rs[6]};
-        qnormalize(q0);
-        for (int k = 0; k < 3; ++k) { sh_root[k] = rs[k]; sh_root[7 + k] = rs[10 + k]; sh_root[10 + k] = rs[7 + k]; }
-        for (int k = 0; k < 4; ++k) sh_root[3 + k] = q0[k];
+    if (part == 0) {
+        if (is_body && lane >= 1) {
+            const float *ds = d.dof_state + ((long)env * NDOF + (lane - 1) * 3) * 2;
+            float e[3] = {ds[0], ds[2], ds[4]};
+            rotvec2quat(e, qj);
+            wj[0] = ds[1]; wj[1] = ds[3]; wj[2] = ds[5];
+            quat2rotvec(qj, edof);
+        }
+        if (lane == 0) {
+            const float *rs = d.root_state + (long)env * 13;
+            float q0[4] = {rs[3], rs[4], rs[5], rs[6]};
+            qnormalize(q0);
+            for (int k = 0; k < 3; ++k) { sh_root[k] = rs[k]; sh_root[7 + k] = rs[10 + k]; sh_root[10 + k] = rs[7 + k]; }
+            for (int k = 0; k < 4; ++k) sh_root[3 + k] = q0[k];
+        }
+    } else {
+        if (lane == 0) {        // the predecessor has published its state (bounded wait: a lost flag must not hang the device)
+            int spins = 0;
+            while (PART_LD(d.part_flag + env) != d.part_seq * (unsigned)n_parts + (unsigned)part - 1u && ++spins < (1 << 22))
+                __builtin_amdgcn_s_sleep(16);
+        }
+        __syncthreads();
+        PART_FENCE();
+        unsigned *pu = (unsigned *)pst;
+        if (is_body) {
+            float *ps = pst + lane * 10;
+            for (int k = 0; k < 4; ++k) qj[k] = PART_LD(ps + k);
+            for (int k = 0; k < 3; ++k) { wj[k] = PART_LD(ps + 4 + k); edof[k] = PART_LD(ps + 7 + k); }
+        }
+        if (lane < 16) sh_root[lane] = PART_LD(pst + 240 + lane);
+        if (lane < 8) sh_P[lane] = PART_LD(pst + 256 + lane);
+        if (lane < MAXR) sh_lam[lane] = PART_LD(pst + 264 + lane);
+        if (lane < 32) ((unsigned *)sh_slot)[lane] = PART_LD(pu + 328 + lane);
+        work = (int)PART_LD(pu + 360);
     }
     __syncthreads();
 
@@ -183,7 +225,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     float tau[3], dd[3]; bool sat[3];
     float uh[3], qdd[3];
 
-    for (int sub = 0; sub <= prm.n_sub; ++sub) {
+    for (int sub = sub_lo; sub < sub_hi + (part == n_parts - 1 ? 1 : 0); ++sub) {
         const bool final_pass = (sub == prm.n_sub);   // kinematics only, to write the body states
         const bool last = (sub == prm.n_sub - 1);
 
@@ -1113,6 +1155,23 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         PSTAMP(10);
     }
 
+    if (part < n_parts - 1) {         // hand over to the next part (see above) and publish
+        unsigned *pu = (unsigned *)pst;
+        if (is_body) {
+            float *ps = pst + lane * 10;
+            for (int k = 0; k < 4; ++k) PART_ST(ps + k, qj[k]);
+            for (int k = 0; k < 3; ++k) { PART_ST(ps + 4 + k, wj[k]); PART_ST(ps + 7 + k, edof[k]); }
+        }
+        if (lane < 16) PART_ST(pst + 240 + lane, sh_root[lane]);
+        if (lane < 8) PART_ST(pst + 256 + lane, sh_P[lane]);
+        if (lane < MAXR) PART_ST(pst + 264 + lane, sh_lam[lane]);
+        if (lane < 32) PART_ST(pu + 328 + lane, ((const unsigned *)sh_slot)[lane]);
+        if (lane == 0) PART_ST(pu + 360, (unsigned)work);
+        PART_FENCE();                 // the stores above have completed ...
+        __syncthreads();
+        if (lane == 0) PART_ST(d.part_flag + env, d.part_seq * (unsigned)n_parts + (unsigned)part);      // ... before the flag goes out
+        return;
+    }
     // ---------------------------------------------------------------- write back (state after the final kinematics pass)
     if (is_body) {
         float *o = d.rb_state + ((long)env * NB + lane) * 13;
@@ -1148,14 +1207,16 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
 // launch 0.58 -> 0.64 ms, the 25-env list launch 0.22 -> 0.44 ms).
 __global__ void __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(EMLOCO_SIM_WAVES_PER_SIMD, EMLOCO_SIM_WAVES_PER_SIMD)))
 sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
-    if ((int)blockIdx.x >= d.n_env) return;
-    int env = d.step_order ? d.step_order[blockIdx.x] : (int)blockIdx.x;
-    if (d.step_ids) { env = d.step_ids[blockIdx.x]; if (env < 0) return; }   // list launch: workgroup i steps list entry i (-1: padding)
+    const int n_parts = d.n_parts > 1 ? d.n_parts : 1;
+    const int part = (int)blockIdx.x / d.n_env, slot = (int)blockIdx.x - part * d.n_env;     // all first parts, then all second parts
+    if (part >= n_parts) return;
+    int env = d.step_order ? d.step_order[slot] : slot;
+    if (d.step_ids) { env = d.step_ids[slot]; if (env < 0) return; }   // list launch: workgroup i steps list entry i (-1: padding)
     if (d.step_skip && d.step_skip[env] != 0) return;            // flagged envs are stepped elsewhere
     const long long t0 = d.step_start ? (long long)wall_clock64() : 0ll;
     int work;
-    sim_step_env(prm, d, env, work);
-    if (d.step_ticks && threadIdx.x == 0) {
+    sim_step_env(prm, d, env, work, part, n_parts);
+    if (d.step_ticks && threadIdx.x == 0 && part == n_parts - 1) {
         // the key of the next launch's order: EMLOCO_COST_KEY_TICKS (diagnostic build) = measured duration in 5.12 us units
 #ifdef EMLOCO_COST_KEY_TICKS
         d.step_ticks[env] = (unsigned)(((long long)wall_clock64() - t0) >> 9);

@@ -43,6 +43,10 @@ struct EmlocoSim {
     DevBuf<float> d_root, d_dof, d_tgt, d_rb, d_cf, d_df, d_lws;
     EmlocoSimDev dev{};
     // cost-ordered dispatch of the full launch (emloco_sim_set_cost_order): per-env duration of the last step, env ids sorted by it
+    int n_parts = 1;                           // split launch (emloco_sim_set_split)
+    unsigned part_seq = 0;
+    DevBuf<float> d_part_state;
+    DevBuf<unsigned> d_part_flag;
     bool cost_order = false;
     DevBuf<unsigned> d_ticks;
     DevBuf<int> d_order;

@@ -121,6 +121,10 @@ class NativeSim:
         """Longest-first dispatch of the step launch from the per-env durations of the previous one (emloco_sim_set_cost_order)."""
         L.check(self.lib.emloco_sim_set_cost_order(self._h, int(bool(on))), "emloco_sim_set_cost_order")
 
+    def set_split(self, n_parts=2):
+        """The substeps of a step as `n_parts` dependent workgroups per env in one launch (emloco_sim_set_split)."""
+        L.check(self.lib.emloco_sim_set_split(self._h, int(n_parts)), "emloco_sim_set_split")
+
     def step_subset(self, n_calls=1, skip=None, ids=None):
         """The step for a subset of the envs on the current stream: `skip` (int64 per env) leaves the flagged envs alone,
         `ids` (int32 device-compacted list, -1 padded) steps exactly the listed ones."""

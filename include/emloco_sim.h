@@ -137,6 +137,13 @@ int emloco_sim_step(EmlocoSim *sim, int n_calls, void *stream);
  * `dev_skip` (int64 per env, the task's reset_buf layout): envs with a non-zero entry are left untouched;
  * `dev_env_ids` (int32, n_ids entries): a device-compacted list, valid ids first and -1 after them (emloco_task_compact_done). */
 int emloco_sim_step_subset(EmlocoSim *sim, int n_calls, const int64_t *dev_skip, const int32_t *dev_env_ids, int n_ids, void *stream);
+/* Split launch (extension, off = 1 part by default; results do not depend on it).  The substeps of an env.step run as
+ * `n_parts` workgroups per env in ONE launch -- all first parts, then all second parts, ... -- a later part continuing from
+ * the registers its predecessor published (plain copies: the parts together are the fused step bit for bit).  The launch is
+ * a whole number of resident rounds of waves only on paper: envs differ in cost, and with one workgroup per env the wave
+ * slots of the cheap ones idle until the last workgroup ends; with parts they are refilled at half / quarter granularity.
+ * n_sub * n_calls must be a multiple of n_parts to split evenly (otherwise the parts are uneven, still correct). */
+int emloco_sim_set_split(EmlocoSim *sim, int n_parts);
 /* Cost-ordered dispatch of the step launch (extension, off by default; results do not depend on it: envs are independent).
  * Every workgroup records how long its env's step took; the next launch hands the envs to the CUs longest first (a counting
  * sort on the device, one small launch ahead of the step).  The launch is two resident rounds of waves, so its length is set

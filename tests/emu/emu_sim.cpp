@@ -1,3 +1,5 @@
+#include <vector>
+#include <cstdlib>
 // TEST INFRASTRUCTURE ONLY: runs emloco_amd/csrc/sim_kernels.hip on the CPU through the emulation
 // header in tests/emu/hip/, so the kernel's logic can be compared with the oracle without a GPU.
 #include "hip/hip_runtime.h"
@@ -38,7 +40,13 @@ extern "C" int emu_sim_step(const EmlocoSimParams *prm, const EmlocoModelDesc *m
     }
     EmlocoSimParams p = *prm;
     p.n_sub = prm->n_sub * n_calls;
-    emu::launch((unsigned)m->n_env, 64, [&] { emloco::sim_step_kernel(p, d); });
+    // EMLOCO_EMU_PARTS=n: the split launch (emloco_sim_set_split) -- n workgroups per env, all first parts first
+    const char *pe = getenv("EMLOCO_EMU_PARTS");
+    const int n_parts = pe ? atoi(pe) : 1;
+    std::vector<float> part_state((size_t)m->n_env * EMLOCO_PART_WORDS, 0.0f);
+    std::vector<unsigned> part_flag((size_t)m->n_env, 0u);
+    d.n_parts = n_parts; d.part_seq = 1; d.part_state = part_state.data(); d.part_flag = part_flag.data();
+    emu::launch((unsigned)(m->n_env * n_parts), 64, [&] { emloco::sim_step_kernel(p, d); });
     return 0;
 }
 

@@ -61,6 +61,8 @@ static inline unsigned long long __ballot(int pred) {
 }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline unsigned long long wall_clock64() { return 0ull; }
+static inline void __threadfence() {}
+static inline void __builtin_amdgcn_s_sleep(int) {}
 // lock-step fibers run one at a time: a plain read-modify-write is atomic
 static inline int atomicAdd(int *p, int v) { const int o = *p; *p = o + v; return o; }
 static inline float __int_as_float(int x) { float f; std::memcpy(&f, &x, 4); return f; }

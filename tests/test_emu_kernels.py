@@ -32,6 +32,25 @@ def test_sim_step_kernel_is_bit_exact_vs_oracle():
     assert np.abs(a.contact_force).max() > 50
 
 
+@pytest.mark.parametrize("parts", [2, 4])
+def test_sim_step_kernel_split_launch_is_the_fused_step(parts, monkeypatch):
+    """emloco_sim_set_split: the 4 substeps as 2 (or 4) dependent workgroups per env, each continuing from the registers its
+    predecessor published -- the emulated kernel stays on the oracle's bytes (fused 4-substep step), contacts, warm start and
+    self-collision included."""
+    monkeypatch.setenv("EMLOCO_EMU_PARTS", str(parts))
+    E = 3
+    models = varied_models(E, seed=31)
+    root, dof, tgt = scene_state(E, seed=32)
+    a = oracle_sim(models, root, dof, tgt, self_collision=True, n_sub=4)
+    b = oracle_sim(models, root, dof, tgt, self_collision=True, n_sub=4)
+    for _ in range(4):
+        a.step(1)
+        emu.sim_step(b, 1)
+    for name in ("root_state", "dof_state", "rb_state", "contact_force", "dof_force", "lambda_ws"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert np.abs(a.contact_force).max() > 50
+
+
 def test_sim_step_kernel_fallen_humanoids_are_bit_exact_vs_oracle():
     """Humanoids lying on the ground, pressed into it: more candidates than contact slots (the shallowest are dropped), limb-limb
     contacts, contact bodies at several tree depths in the Gram build.  (Pelvis contacts -- tree depth 0 -- come up in the

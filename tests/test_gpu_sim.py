@@ -225,13 +225,14 @@ def test_large_random_targets_stay_finite_and_match_the_oracle():
     assert (gsim.dof_force.view(E, 69).abs() <= eff * (1 + 1e-6)).all()
 
 
-def test_cost_ordered_and_subset_launches_are_the_same_step():
-    """emloco_sim_set_cost_order (longest-first dispatch from the previous launch's per-env durations) and
+def test_cost_ordered_split_and_subset_launches_are_the_same_step():
+    """emloco_sim_set_split (the substeps of a step as two dependent workgroups per env in one launch), emloco_sim_set_cost_order (longest-first dispatch from the previous launch's per-env durations) and
     emloco_sim_step_subset (skip flags + compacted id list = two launches that together step every env once) only change
     which workgroup steps which env: every state tensor stays on the oracle's bytes over an episode with falls."""
     E = 300
     osim, gsim = _mk(E, seed=21)
     gsim.set_cost_order(True)
+    gsim.set_split(2)                                          # each env's 4 substeps as two dependent workgroups of one launch
     dev = gsim.device
     g = torch.Generator(device=dev)
     g.manual_seed(5)
