@@ -497,12 +497,10 @@ def main():
     #   sequential (reported beside it): the reference's order, with the rigid-body launch dispatched most-contact-work-first
     #     (emloco_sim_set_cost_order).  The two do not add up: cost order keeps the wave slots busy longest.
     overlap = os.environ.get("EMLOCO_OVERLAP_RESET", "1") != "0"
-    # the 4 substeps of a step as two dependent workgroups per env in ONE launch (emloco_sim_set_split; bit-identical results):
-    # wave slots that cheap envs free early are refilled at half-step granularity instead of idling to the launch's end
+    # (the task layer already runs the 4 substeps of a step as two dependent workgroups per env in ONE launch,
+    # emloco_sim_set_split via gym.prepare_sim: wave slots that cheap envs free early are refilled at half-step granularity)
     n_parts = int(os.environ.get("EMLOCO_SPLIT", "2"))
-    if n_parts > 1:
-        task.sim.native.set_split(n_parts)
-    if not overlap and os.environ.get("EMLOCO_COST_ORDER", "1") != "0":
+    if os.environ.get("EMLOCO_COST_ORDER", "0" if overlap else "1") != "0":
         task.sim.native.set_cost_order(True)
     env.reset(torch.arange(E, device=dev))
     stagger_episodes(env, seed=rank)                     # untimed: episode ages uniform over [0, 168) before the warm-up

@@ -38,6 +38,7 @@ struct EmlocoSimDev {
     unsigned *step_ticks;
     // split launch (emloco_sim_set_split): the substeps of an env.step as n_parts workgroups per env, part p + 1 continuing
     // from the registers / LDS part p left in part_state [n_env][EMLOCO_PART_WORDS] once part_flag[env] == part_seq
+    const int *pd_pack;               /* per body: parent | depth << 8 | index among the bodies of its depth << 16 (topology.h) */
     int n_parts; unsigned part_seq;
     float *part_state;
     unsigned *part_flag;

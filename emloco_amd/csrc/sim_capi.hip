@@ -70,6 +70,7 @@ int emloco_sim_create(const EmlocoSimParams *params, int device, EmlocoSim **out
 int emloco_sim_destroy(EmlocoSim *s) {
     if (!s) return EMLOCO_OK;
     (void)hipSetDevice(s->device);
+    s->d_pd_pack.release();
     s->d_parent.release(); s->d_depth.release(); s->d_children.release(); s->d_gtype.release();
     s->d_cand_body.release(); s->d_cand_k.release(); s->d_lca.release();
     s->d_off.release(); s->d_mass.release(); s->d_com.release(); s->d_inertia.release();
@@ -153,6 +154,7 @@ int emloco_sim_prepare(EmlocoSim *s) {
     const emloco::Topology &t = s->topo;
     HIPCHK(s->d_parent.upload(t.parent.data(), t.parent.size()));
     HIPCHK(s->d_depth.upload(t.depth.data(), t.depth.size()));
+    HIPCHK(s->d_pd_pack.upload(t.pd_pack.data(), t.pd_pack.size()));
     HIPCHK(s->d_children.upload(t.children.data(), t.children.size()));
     HIPCHK(s->d_gtype.upload(t.geom_type.data(), t.geom_type.size()));
     HIPCHK(s->d_cand_body.upload(t.cand_body.data(), t.cand_body.size()));
@@ -181,6 +183,7 @@ int emloco_sim_prepare(EmlocoSim *s) {
     HIPCHK(hipGetLastError());
     EmlocoSimDev &d = s->dev;
     d.n_env = s->n_env; d.n_cand = t.n_cand; d.max_depth = t.max_depth; d.pad_ = 0;
+    d.pd_pack = s->d_pd_pack.p;
     d.parent = s->d_parent.p; d.depth = s->d_depth.p; d.children = s->d_children.p; d.geom_type = s->d_gtype.p;
     d.cand_body = s->d_cand_body.p; d.cand_k = s->d_cand_k.p; d.lca_depth = s->d_lca.p;
     d.joint_off = s->d_off.p; d.mass = s->d_mass.p; d.com = s->d_com.p; d.inertia = s->d_inertia.p;

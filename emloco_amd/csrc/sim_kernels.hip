@@ -166,11 +166,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     const long mb0 = (long)env * NB + b;
     // drive gains / targets are re-read (L2 hits) where they are used instead of pinning 15 registers for the launch
     const long dof0 = (long)env * NDOF + (is_body && lane >= 1 ? (lane - 1) * 3 : 0);
-    if (is_body) {
-        int lslot = 0;                                        // index of this body among the bodies of its tree level (< 8)
-        for (int j = 0; j < lane; ++j) lslot += d.depth[j] == bc.depth;
-        sh_pd[lane] = (bc.parent & 0xff) | (bc.depth << 8) | (lslot << 16);   // the root's parent field reads 255
-    }
+    if (is_body) sh_pd[lane] = d.pd_pack[lane];               // parent (the root's reads 255) | depth << 8 | index within its tree level << 16
     sh_slot[lane] = 255; sh_slot[lane + 64] = 255;
 
     // ---------------------------------------------------------------- state -> registers

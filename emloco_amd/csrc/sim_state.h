@@ -37,7 +37,7 @@ struct EmlocoSim {
     DevBuf<unsigned char> d_sc_pairs;
     DevBuf<float> d_sc_a, d_sc_b, d_sc_r;
     // device
-    DevBuf<int> d_parent, d_depth, d_children, d_gtype, d_cand_body, d_cand_k;
+    DevBuf<int> d_parent, d_depth, d_children, d_gtype, d_cand_body, d_cand_k, d_pd_pack;
     DevBuf<unsigned char> d_lca;
     DevBuf<float> d_off, d_mass, d_com, d_inertia, d_ga, d_gb, d_gr, d_kp, d_kd, d_arm, d_eff;
     DevBuf<float> d_root, d_dof, d_tgt, d_rb, d_cf, d_df, d_lws;

@@ -11,6 +11,7 @@ namespace emloco {
 
 struct Topology {
     std::vector<int32_t> parent, depth, children, geom_type, cand_body, cand_k;
+    std::vector<int32_t> pd_pack;   // per body: parent (the root: 255) | depth << 8 | index among the bodies of its depth << 16
     std::vector<uint8_t> lca_depth;
     int max_depth = 0;
     int n_cand = 0;
@@ -36,6 +37,12 @@ struct Topology {
             while (k < 3 && c[k] >= 0) ++k;
             if (k == 3) return false;
             c[k] = i;
+        }
+        pd_pack.assign(nb, 0);
+        for (int i = 0; i < nb; ++i) {
+            int lslot = 0;
+            for (int j = 0; j < i; ++j) lslot += depth[j] == depth[i];
+            pd_pack[i] = (parent[i] & 0xff) | (depth[i] << 8) | (lslot << 16);
         }
         lca_depth.assign(nb * nb, 0);
         for (int a = 0; a < nb; ++a)

@@ -357,6 +357,11 @@ class Gym:
         except L.EmlocoError as e:
             print("***", e)
             return False
+        # the substeps of a launch as two dependent workgroups per env (emloco_sim_set_split: identical results, shorter
+        # launch); EMLOCO_SPLIT=1 keeps one workgroup per env
+        n_parts = int(os.environ.get("EMLOCO_SPLIT", "2"))
+        if n_parts > 1:
+            sim.native.set_split(n_parts)
         root = torch.zeros((len(sim.envs), 13), dtype=torch.float32)
         for i, e in enumerate(sim.envs):
             p, r = e.actors[0].pose.p, e.actors[0].pose.r

@@ -22,7 +22,7 @@ extern "C" int emu_sim_step(const EmlocoSimParams *prm, const EmlocoModelDesc *m
     if (!t.build(m->parent, m->geom_type)) return -1;
     EmlocoSimDev d{};
     d.n_env = m->n_env; d.n_cand = t.n_cand; d.max_depth = t.max_depth;
-    d.parent = t.parent.data(); d.depth = t.depth.data(); d.children = t.children.data();
+    d.parent = t.parent.data(); d.depth = t.depth.data(); d.children = t.children.data(); d.pd_pack = t.pd_pack.data();
     d.geom_type = t.geom_type.data(); d.cand_body = t.cand_body.data(); d.cand_k = t.cand_k.data();
     d.lca_depth = t.lca_depth.data();
     d.joint_off = m->joint_off; d.mass = m->mass; d.com = m->com; d.inertia = m->inertia;
