@@ -1,6 +1,6 @@
 // emloco_types.h -- device-side argument structs shared by the kernels and the C-ABI layer.
 #pragma once
-#define EMLOCO_PART_WORDS 368   /* 24 x 10 joint registers | 16 root | 8 momentum | 64 multipliers | 32 slot map | 8 misc */
+#define EMLOCO_PART_WORDS 416   /* 24 x 12 joint registers | 16 root | 8 momentum | 64 multipliers | 32 slot map | 4 misc | pad: 16-byte granules */
 #include "../../include/emloco_sim.h"
 
 // Device pointers handed to the rollout kernels by value (kernarg segment).

@@ -53,18 +53,41 @@ __device__ __forceinline__ int tri_index(int a, int b) {
     return ((hi * (hi + 1)) >> 1) + lo;
 }
 
-// Hand-over words of a split launch (emloco_sim_set_split): written and read with agent-scope relaxed atomics -- each access
-// is coherent across the XCDs' L2s by itself -- and ordered against the flag by waiting for the stores (workgroup-scope
-// fences = s_waitcnt).  Agent-scope fences instead (__threadfence / acquire-release on the flag) write back and invalidate
-// the whole L2 of the XCD per workgroup: measured, the launch went from 0.54 to 0.68 ms with two parts.
+// Hand-over of a split launch (emloco_sim_set_split): 16-byte granules written with `sc1` (write-through) stores and read
+// with `sc1` loads -- coherent across the XCDs' L2s and the CUs' L1s access by access (MI355X_MICROARCH.md, inter-workgroup
+// visibility: "sc1 stores and loads both sides") -- and a flag word (relaxed agent-scope atomic) that goes out once the
+// stores have completed (s_waitcnt vmcnt(0)).  Measured alternatives: agent-scope fences on every lane (__threadfence) write
+// back / invalidate whole caches per workgroup: launch 0.54 -> 0.68 ms; one 4-byte agent atomic per word: as fast as this,
+// but every word is a fabric write of its own (HBM counters 46 -> 124 MB per launch).
+typedef float part_f4 __attribute__((ext_vector_type(4)));
 #ifdef EMLOCO_EMU
-#define PART_ST(p, v) (*(p) = (v))
-#define PART_LD(p) (*(p))
-#define PART_FENCE() do { } while (0)
+__device__ __forceinline__ void part_st16(float *p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+__device__ __forceinline__ void part_ld16(const float *p, float *v) { for (int k = 0; k < 4; ++k) v[k] = p[k]; }
+__device__ __forceinline__ void part_ld48(const float *p, float *v) { for (int k = 0; k < 12; ++k) v[k] = p[k]; }
+__device__ __forceinline__ void part_stores_done() {}
+__device__ __forceinline__ void part_flag_set(unsigned *f, unsigned v) { *f = v; }
+__device__ __forceinline__ unsigned part_flag_get(const unsigned *f) { return *f; }
 #else
-#define PART_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define PART_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define PART_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+__device__ __forceinline__ void part_st16(float *p, float a, float b, float c, float d) {
+    const part_f4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void part_ld16(const float *p, float *v) {
+    part_f4 a;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(p) : "memory");
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+__device__ __forceinline__ void part_ld48(const float *p, float *v) {
+    part_f4 a, b, c;
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p) : "memory");
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+}
+__device__ __forceinline__ void part_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void part_flag_set(unsigned *f, unsigned v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned part_flag_get(const unsigned *f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
 #ifdef EMLOCO_SIM_PROFILE
@@ -196,22 +219,26 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     } else {
         if (lane == 0) {        // the predecessor has published its state (bounded wait: a lost flag must not hang the device)
             int spins = 0;
-            while (PART_LD(d.part_flag + env) != d.part_seq * (unsigned)n_parts + (unsigned)part - 1u && ++spins < (1 << 22))
+            while (part_flag_get(d.part_flag + env) != d.part_seq * (unsigned)n_parts + (unsigned)part - 1u && ++spins < (1 << 22))
                 __builtin_amdgcn_s_sleep(16);
         }
         __syncthreads();
-        PART_FENCE();
-        unsigned *pu = (unsigned *)pst;
-        if (is_body) {
-            float *ps = pst + lane * 10;
-            for (int k = 0; k < 4; ++k) qj[k] = PART_LD(ps + k);
-            for (int k = 0; k < 3; ++k) { wj[k] = PART_LD(ps + 4 + k); edof[k] = PART_LD(ps + 7 + k); }
+        if (is_body) {          // granules 3 lane .. 3 lane + 2: joint quaternion | rates, e_0 | e_1, e_2
+            float v[12];
+            part_ld48(pst + lane * 12, v);
+            for (int k = 0; k < 4; ++k) qj[k] = v[k];
+            for (int k = 0; k < 3; ++k) wj[k] = v[4 + k];
+            edof[0] = v[7]; edof[1] = v[8]; edof[2] = v[9];
+        } else if (lane < NB + 31) {   // one granule of LDS state per lane: root (4) | momentum (2) | multipliers (16) | slot map (8) | misc
+            const int g = lane - NB;
+            float v[4];
+            part_ld16(pst + NB * 12 + 4 * g, v);
+            float *dst = g < 4 ? sh_root + 4 * g : g < 6 ? sh_P + 4 * (g - 4) : g < 22 ? sh_lam + 4 * (g - 6) : (float *)sh_slot + 4 * (g - 22);
+            if (g < 30) for (int k = 0; k < 4; ++k) dst[k] = v[k];
+            else sh_V0[0] = v[0];                               // the work counter, picked up below
         }
-        if (lane < 16) sh_root[lane] = PART_LD(pst + 240 + lane);
-        if (lane < 8) sh_P[lane] = PART_LD(pst + 256 + lane);
-        if (lane < MAXR) sh_lam[lane] = PART_LD(pst + 264 + lane);
-        if (lane < 32) ((unsigned *)sh_slot)[lane] = PART_LD(pu + 328 + lane);
-        work = (int)PART_LD(pu + 360);
+        __syncthreads();
+        work = __float_as_int(sh_V0[0]);
     }
     __syncthreads();
 
@@ -1152,20 +1179,20 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     }
 
     if (part < n_parts - 1) {         // hand over to the next part (see above) and publish
-        unsigned *pu = (unsigned *)pst;
         if (is_body) {
-            float *ps = pst + lane * 10;
-            for (int k = 0; k < 4; ++k) PART_ST(ps + k, qj[k]);
-            for (int k = 0; k < 3; ++k) { PART_ST(ps + 4 + k, wj[k]); PART_ST(ps + 7 + k, edof[k]); }
+            float *ps = pst + lane * 12;
+            part_st16(ps, qj[0], qj[1], qj[2], qj[3]);
+            part_st16(ps + 4, wj[0], wj[1], wj[2], edof[0]);
+            part_st16(ps + 8, edof[1], edof[2], 0.0f, 0.0f);
+        } else if (lane < NB + 31) {
+            const int g = lane - NB;
+            const float *src = g < 4 ? sh_root + 4 * g : g < 6 ? sh_P + 4 * (g - 4) : g < 22 ? sh_lam + 4 * (g - 6) : (const float *)sh_slot + 4 * (g - 22);
+            if (g < 30) part_st16(pst + NB * 12 + 4 * g, src[0], src[1], src[2], src[3]);
+            else part_st16(pst + NB * 12 + 4 * g, __int_as_float(work), 0.0f, 0.0f, 0.0f);
         }
-        if (lane < 16) PART_ST(pst + 240 + lane, sh_root[lane]);
-        if (lane < 8) PART_ST(pst + 256 + lane, sh_P[lane]);
-        if (lane < MAXR) PART_ST(pst + 264 + lane, sh_lam[lane]);
-        if (lane < 32) PART_ST(pu + 328 + lane, ((const unsigned *)sh_slot)[lane]);
-        if (lane == 0) PART_ST(pu + 360, (unsigned)work);
-        PART_FENCE();                 // the stores above have completed ...
+        part_stores_done();           // the stores above have completed ...
         __syncthreads();
-        if (lane == 0) PART_ST(d.part_flag + env, d.part_seq * (unsigned)n_parts + (unsigned)part);      // ... before the flag goes out
+        if (lane == 0) part_flag_set(d.part_flag + env, d.part_seq * (unsigned)n_parts + (unsigned)part);      // ... before the flag goes out
         return;
     }
     // ---------------------------------------------------------------- write back (state after the final kinematics pass)

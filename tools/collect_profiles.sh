@@ -25,7 +25,28 @@ with open(sys.argv[2], "w", newline="") as o:
         w.writerow(r)
 PY
 
-# 2. PMC passes (env leg only), one counter per pass
+# 1b. the rigid-body launches of pass 1 by kind: the default schedule issues two per step (live envs: grid = 2 workgroups per
+#     env; the reset envs' id-list launch), the `sequential` leg one -- the stats row above averages over all of them
+f=$(find /tmp/prof_kt -name '*kernel_trace.csv' | head -1)
+[ -n "$f" ] && python - "$f" "$OUT/${R}_sim_step_launches.txt" <<'PY'
+import csv, sys, collections
+g = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    if "sim_step_kernel" in r["Kernel_Name"]:
+        wg = int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", 64)) or 64)
+        grid = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
+        g[grid // max(wg, 1)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+with open(sys.argv[2], "w") as o:
+    o.write("sim_step_kernel launches of `bench.py --steps 100 --warmup 10 --no_cpu_baseline --no_pipelined` by grid (workgroups): calls, avg / min / max us\n")
+    for k in sorted(g, reverse=True):
+        v = g[k]
+        o.write(f"  {k:6d} workgroups: {len(v):5d} calls  avg {sum(v)/len(v):8.1f}  min {min(v):8.1f}  max {max(v):8.1f}\n")
+print(open(sys.argv[2]).read())
+PY
+
+# 2. PMC passes (env leg only), one counter per pass.  EMLOCO_OVERLAP_RESET=0: the sequential schedule -- one rigid-body launch
+#    per step for all envs -- so that "per launch" below is the whole step's kernel (the counters do not depend on the schedule)
+export EMLOCO_OVERLAP_RESET=0
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_$C && (cd /tmp && $T rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -- $BENCH --steps 20 --warmup 5 --no_jta > "$OUT/pmc_$C.log" 2>&1)
 done
@@ -80,9 +101,10 @@ open(sys.argv[1], "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
 # 4. VALU occupancy of the rollout kernel (env leg): where the wave cycles of sim_step_kernel go.  SQ counters only (8 slots),
-#    its own pass; durations come from pass 1's kernel trace.
+#    its own pass; the duration comes from a kernel-trace pass of the same (sequential-schedule) command.
+rm -rf /tmp/prof_kt_seq && (cd /tmp && $T rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt_seq -- $BENCH --steps 20 --warmup 5 --no_jta --no_policy > "$OUT/kt_seq.log" 2>&1)
 rm -rf /tmp/prof_valu && (cd /tmp && $T rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/prof_valu -- $BENCH --steps 20 --warmup 5 --no_jta --no_policy > "$OUT/pmc_valu.log" 2>&1)
-python - "$OUT/${R}_sim_step_valu.txt" "$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1)" <<'PY'
+python - "$OUT/${R}_sim_step_valu.txt" "$(find /tmp/prof_kt_seq -name '*kernel_stats.csv' | head -1)" <<'PY'
 import csv, glob, sys, collections
 agg = collections.defaultdict(list)
 for f in glob.glob("/tmp/prof_valu/**/*counter_collection.csv", recursive=True):
@@ -94,7 +116,7 @@ dur_ns = None
 for r in list(csv.reader(open(sys.argv[2])))[1:]:
     if "sim_step_kernel" in r[0]:
         dur_ns = float(r[3])
-lines = ["sim_step_kernel, 4096 envs (one 64-lane wave each), mean per launch over %d launches" % len(next(iter(agg.values()), []))]
+lines = ["sim_step_kernel, 4096 envs (two 64-lane waves each: split launch), sequential schedule, mean per launch over %d launches" % len(next(iter(agg.values()), []))]
 for k in sorted(m):
     lines.append(f"  {k:22s} {m[k]:.6g}")
 if m.get("SQ_WAVE_CYCLES"):
