@@ -345,7 +345,7 @@ def jta_cpu_baseline(B=32, budget_s=60.0):
     dt = min(tot / iters, sweep[best])
     return {"value": round(B / dt, 3), "unit": "samples/s", "cores": best, "kind": "port",
             "sample": f"the same train step at batch {B} x {joints.shape[1]} people, stock torch.nn fp32 restatement; thread sweep "
-                      + ", ".join(f"{k}: {B / v:.2f}/s" for k, v in sweep.items()) + f" (stopped where more threads got slower) of {ncpu} host cores; best = {best} threads, "
+                      + ", ".join(f"{k}: {B / v:.2f}/s" for k, v in sweep.items()) + f" (more threads are tried while they help and the time budget lasts) of {ncpu} host cores; best = {best} threads, "
                       f"{iters} more timed iterations ({dt:.2f} s / iteration)"}
 
 
@@ -621,9 +621,12 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l, "valu_issue_frac": valu,
                          "note": "latency bound, not bandwidth bound: ~9 KB of state per env per launch against ~50 k dependent fp32 VALU "
-                                 "wave-instructions (level-synchronous tree passes, 2 waves / SIMD, two resident rounds of 2048 waves for "
-                                 "4096 envs); valu_issue_frac and the wait fractions come from profiles/r02_sim_step_valu.txt, traffic "
-                                 "from profiles/r02_sim_step_hbm_bytes.json (PMC passes of this round's kernel); kernel_ms is the launch over "
+                                 "wave-instructions (level-synchronous tree passes, 2 waves / SIMD; each env's 4 substeps run as two dependent "
+                                 "workgroups of the launch, i.e. four resident rounds of 2048 half-step waves for 4096 envs); valu_issue_frac "
+                                 "and the wait fractions come from profiles/r02_sim_step_valu.txt, traffic from profiles/r02_sim_step_hbm_bytes.json "
+                                 "(PMC passes of this round's kernel, sequential schedule; 78 MB = the 38 MB algorithmic + the 1.7 KB per-env "
+                                 "hand-over between the two workgroups, out and back through write-through granules, + the second workgroup's "
+                                 "re-read of the per-env model constants); kernel_ms is the launch over "
                                  "the live envs in the timed region (every 4th launch timed), where the reset chain and the reset envs' "
                                  "launch share the device with it -- `sequential.kernel_ms` is the same kernel with nothing beside it"},
         }
