@@ -497,9 +497,9 @@ def main():
     #   sequential (reported beside it): the reference's order, with the rigid-body launch dispatched most-contact-work-first
     #     (emloco_sim_set_cost_order).  The two do not add up: cost order keeps the wave slots busy longest.
     overlap = os.environ.get("EMLOCO_OVERLAP_RESET", "1") != "0"
-    # (the task layer already runs the 4 substeps of a step as two dependent workgroups per env in ONE launch,
-    # emloco_sim_set_split via gym.prepare_sim: wave slots that cheap envs free early are refilled at half-step granularity)
-    n_parts = int(os.environ.get("EMLOCO_SPLIT", "2"))
+    # (the task layer already runs the 4 substeps of a step as four dependent workgroups per env in ONE launch,
+    # emloco_sim_set_split via gym.prepare_sim: wave slots that cheap envs free early are refilled at substep granularity)
+    n_parts = int(os.environ.get("EMLOCO_SPLIT", "4"))
     if os.environ.get("EMLOCO_COST_ORDER", "0" if overlap else "1") != "0":
         task.sim.native.set_cost_order(True)
     env.reset(torch.arange(E, device=dev))
@@ -621,12 +621,12 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l, "valu_issue_frac": valu,
                          "note": "latency bound, not bandwidth bound: ~9 KB of state per env per launch against ~50 k dependent fp32 VALU "
-                                 "wave-instructions (level-synchronous tree passes, 2 waves / SIMD; each env's 4 substeps run as two dependent "
-                                 "workgroups of the launch, i.e. four resident rounds of 2048 half-step waves for 4096 envs); valu_issue_frac "
+                                 "wave-instructions (level-synchronous tree passes, 2 waves / SIMD; each env's 4 substeps run as four dependent "
+                                 "workgroups of the launch, i.e. eight resident rounds of 2048 one-substep waves for 4096 envs); valu_issue_frac "
                                  "and the wait fractions come from profiles/r02_sim_step_valu.txt, traffic from profiles/r02_sim_step_hbm_bytes.json "
-                                 "(PMC passes of this round's kernel, sequential schedule; 78 MB = the 38 MB algorithmic + the 1.7 KB per-env "
-                                 "hand-over between the two workgroups, out and back through write-through granules, + the second workgroup's "
-                                 "re-read of the per-env model constants); kernel_ms is the launch over "
+                                 "(PMC passes of this round's kernel, sequential schedule; the 38 MB algorithmic + the 1.7 KB per-env hand-over "
+                                 "between consecutive workgroups of an env, out and back through write-through granules, + the later workgroups' "
+                                 "re-reads of the per-env model constants); kernel_ms is the launch over "
                                  "the live envs in the timed region (every 4th launch timed), where the reset chain and the reset envs' "
                                  "launch share the device with it -- `sequential.kernel_ms` is the same kernel with nothing beside it"},
         }

@@ -275,8 +275,9 @@ int emloco_sim_step(EmlocoSim *s, int n_calls, void *stream) {
     const int slot = s->ev_head;
     const bool timed = s->timing && (s->launch_no++ % s->timing_stride) == 0;
     if (timed) HIPCHK(hipEventRecord(s->ev0[slot], st));
-    d.n_parts = s->n_parts; d.part_seq = ++s->part_seq; d.part_state = s->d_part_state.p; d.part_flag = s->d_part_flag.p;
-    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(s->n_env * s->n_parts)), dim3(64), 0, st, p, d);
+    d.n_parts = s->n_parts < p.n_sub ? s->n_parts : p.n_sub;       // at least one substep per part
+    d.part_seq = ++s->part_seq; d.part_state = s->d_part_state.p; d.part_flag = s->d_part_flag.p;
+    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(s->n_env * d.n_parts)), dim3(64), 0, st, p, d);
     HIPCHK(hipGetLastError());
     if (timed) {
         HIPCHK(hipEventRecord(s->ev1[slot], st));
@@ -311,9 +312,9 @@ int emloco_sim_step_subset(EmlocoSim *s, int n_calls, const int64_t *dev_skip, c
     const bool timed = s->timing && dev_skip && (s->launch_no++ % s->timing_stride) == 0;
     const int slot = s->ev_head;
     if (timed) HIPCHK(hipEventRecord(s->ev0[slot], st));
-    d.n_parts = dev_ids ? 1 : s->n_parts;            // the list launch (a few dozen envs) is not split
+    d.n_parts = dev_ids ? 1 : (s->n_parts < p.n_sub ? s->n_parts : p.n_sub);      // the list launch (a few dozen envs) is not split
     d.part_seq = ++s->part_seq; d.part_state = s->d_part_state.p; d.part_flag = s->d_part_flag.p;
-    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(dev_ids ? n_ids : s->n_env * s->n_parts)), dim3(64), 0, st, p, d);
+    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(dev_ids ? n_ids : s->n_env * d.n_parts)), dim3(64), 0, st, p, d);
     HIPCHK(hipGetLastError());
     if (timed) {
         HIPCHK(hipEventRecord(s->ev1[slot], st));

@@ -63,7 +63,7 @@ typedef float part_f4 __attribute__((ext_vector_type(4)));
 #ifdef EMLOCO_EMU
 __device__ __forceinline__ void part_st16(float *p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 __device__ __forceinline__ void part_ld16(const float *p, float *v) { for (int k = 0; k < 4; ++k) v[k] = p[k]; }
-__device__ __forceinline__ void part_ld48(const float *p, float *v) { for (int k = 0; k < 12; ++k) v[k] = p[k]; }
+__device__ __forceinline__ void part_ld48(const float *p, float *v) { for (int g = 0; g < 3; ++g) for (int k = 0; k < 4; ++k) v[4 * g + k] = p[g * 4 * EMLOCO_NB + k]; }
 __device__ __forceinline__ void part_stores_done() {}
 __device__ __forceinline__ void part_flag_set(unsigned *f, unsigned v) { *f = v; }
 __device__ __forceinline__ unsigned part_flag_get(const unsigned *f) { return *f; }
@@ -79,8 +79,9 @@ __device__ __forceinline__ void part_ld16(const float *p, float *v) {
 }
 __device__ __forceinline__ void part_ld48(const float *p, float *v) {
     part_f4 a, b, c;
-    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
-                 "global_load_dwordx4 %2, %3, off offset:32 sc1\n\ts_waitcnt vmcnt(0)"
+    static_assert(EMLOCO_NB * 16 == 384, "granule-major hand-over: a lane's three granules are 24 x 16 bytes apart");
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %3, off offset:384 sc1\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:768 sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p) : "memory");
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
@@ -223,9 +224,9 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 __builtin_amdgcn_s_sleep(16);
         }
         __syncthreads();
-        if (is_body) {          // granules 3 lane .. 3 lane + 2: joint quaternion | rates, e_0 | e_1, e_2
-            float v[12];
-            part_ld48(pst + lane * 12, v);
+        if (is_body) {          // granules lane, 24 + lane, 48 + lane (granule-major: the lanes of one store / load instruction
+            float v[12];        // touch one contiguous 384-byte run): joint quaternion | rates, e_0 | e_1, e_2
+            part_ld48(pst + lane * 4, v);
             for (int k = 0; k < 4; ++k) qj[k] = v[k];
             for (int k = 0; k < 3; ++k) wj[k] = v[4 + k];
             edof[0] = v[7]; edof[1] = v[8]; edof[2] = v[9];
@@ -1180,10 +1181,10 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
 
     if (part < n_parts - 1) {         // hand over to the next part (see above) and publish
         if (is_body) {
-            float *ps = pst + lane * 12;
+            float *ps = pst + lane * 4;
             part_st16(ps, qj[0], qj[1], qj[2], qj[3]);
-            part_st16(ps + 4, wj[0], wj[1], wj[2], edof[0]);
-            part_st16(ps + 8, edof[1], edof[2], 0.0f, 0.0f);
+            part_st16(ps + 4 * NB, wj[0], wj[1], wj[2], edof[0]);
+            part_st16(ps + 8 * NB, edof[1], edof[2], 0.0f, 0.0f);
         } else if (lane < NB + 31) {
             const int g = lane - NB;
             const float *src = g < 4 ? sh_root + 4 * g : g < 6 ? sh_P + 4 * (g - 4) : g < 22 ? sh_lam + 4 * (g - 6) : (const float *)sh_slot + 4 * (g - 22);

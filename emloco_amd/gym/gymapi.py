@@ -357,9 +357,9 @@ class Gym:
         except L.EmlocoError as e:
             print("***", e)
             return False
-        # the substeps of a launch as two dependent workgroups per env (emloco_sim_set_split: identical results, shorter
-        # launch); EMLOCO_SPLIT=1 keeps one workgroup per env
-        n_parts = int(os.environ.get("EMLOCO_SPLIT", "2"))
+        # the substeps of a launch as dependent workgroups of their own, up to four per env (emloco_sim_set_split: identical
+        # results, shorter launch); EMLOCO_SPLIT=1 keeps one workgroup per env
+        n_parts = int(os.environ.get("EMLOCO_SPLIT", "4"))
         if n_parts > 1:
             sim.native.set_split(n_parts)
         root = torch.zeros((len(sim.envs), 13), dtype=torch.float32)
