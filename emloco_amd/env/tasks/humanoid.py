@@ -360,6 +360,7 @@ class Humanoid(BaseTask):
     def pre_physics_step(self, actions):
         # the reference clones (humanoid.py:1185); the copy is skipped when the caller's tensor already lives on the device:
         # it is only read by the launch below, before control returns
+        self.wait_obs()             # the observation launch of the last step reads what this step's rigid-body launch overwrites
         self.actions = actions if (actions.device == torch.device(self.device) and actions.dtype == torch.float32) else actions.to(self.device).clone()
         if not self._pd_control:
             raise NotImplementedError("torque control is outside the hot path")

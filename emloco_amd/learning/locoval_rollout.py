@@ -96,6 +96,9 @@ class LocoValRollout:
                 # without a policy in the loop; the resident rigid-body launch leaves no wave slot free for most of its run,
                 # so the gain hangs on launch timing and the mode stays off unless asked for.
                 self.task.overlap_reset = True
+                # with the reset chain off the caller's stream the observation launch has nothing to hide behind: on a side
+                # stream it costs two cross-stream hand-overs (~13 us each, measured) around a 50 us launch the loop waits for
+                self.task.overlap_obs = os.environ.get("EMLOCO_OVERLAP_OBS", "0") == "1"
         self.fused = (isinstance(self.valuenet, ValuePoseNet) and self.device.type == "cuda") if fused is None else bool(fused)
         if self.fused:
             self._flat_params = torch.cat([p.detach().reshape(-1) for p in self.valuenet.parameters()]).contiguous()
