@@ -496,7 +496,8 @@ def main():
     #     live envs (task.overlap_reset);
     #   sequential (reported beside it): the reference's order, with the rigid-body launch dispatched most-contact-work-first
     #     (emloco_sim_set_cost_order).  The two do not add up: cost order keeps the wave slots busy longest.
-    overlap = os.environ.get("EMLOCO_OVERLAP_RESET", "1") != "0"
+    # (below ~one and a half resident rounds of waves the device is not full and the sequential schedule is faster: DESIGN.md section 5)
+    overlap = os.environ.get("EMLOCO_OVERLAP_RESET", "1" if a.num_envs >= 3072 else "0") != "0"
     # (the task layer already runs the 4 substeps of a step as four dependent workgroups per env in ONE launch,
     # emloco_sim_set_split via gym.prepare_sim: wave slots that cheap envs free early are refilled at substep granularity)
     n_parts = int(os.environ.get("EMLOCO_SPLIT", "4"))
