@@ -616,3 +616,40 @@ def test_reset_chain_on_a_second_stream_gives_the_same_rollout(obs_stream):
         assert torch.equal(envs[0].task.sim.native.warm_start, envs[1].task.sim.native.warm_start), k
         assert envs[0].task.sim.frame_count == envs[1].task.sim.frame_count
     assert getattr(envs[1].task, "_hp_stream", None) is not None
+
+
+@pytest.mark.gpu
+def test_locoval_loop_with_the_reset_chain_beside_the_step_fits_the_same_network():
+    """The headline loop of bench.py in both schedules: LocoValRollout(overlap_reset=False / True) with a policy that does not
+    read the observations, same seeds -- after 64 steps with natural resets the fitted LocoVal parameters, the episode count
+    and the simulator state are bit-equal."""
+    from emloco_amd.learning.locoval_rollout import LocoValRollout
+    from emloco_amd.run import RLGPUEnv
+    E, outs = 256, []
+    for ov in (False, True):
+        env = RLGPUEnv(_make_env(E, ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel",
+                                     "--input_init_pose", "--input_init_vel"]))
+        task = env.env.task
+        g = torch.Generator(device=task.device)
+        g.manual_seed(77)
+        pool = torch.randn(8, E, 69, device=task.device, generator=g) * 0.3
+        k = [0]
+
+        def pol(obs):
+            k[0] += 1
+            return pool[k[0] % 8]
+        pol.reads_obs = False
+        torch.manual_seed(5)
+        agent = LocoValRollout(env, horizon_length=8, policy=pol, overlap_reset=ov)
+        for _ in range(8):
+            agent.play_steps()
+        n_fit = agent.fitted_episodes                      # waits for the fit stream
+        task.wait_reset()
+        torch.cuda.synchronize()
+        assert task.overlap_reset == ov
+        outs.append((torch.cat([p.detach().reshape(-1) for p in agent.valuenet.parameters()]).clone(), n_fit,
+                     task._root_states.clone(), task._dof_state.clone(), task.progress_buf.clone(), task.rew_buf.clone()))
+    assert outs[0][1] == outs[1][1] and outs[0][1] > 20
+    for a, b in zip(outs[0], outs[1]):
+        if torch.is_tensor(a):
+            assert torch.equal(a, b)
