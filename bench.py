@@ -638,7 +638,15 @@ def main():
             out["env_step_only"] = {"value": round(E * a.steps / env_only, 1), "unit": "env-steps/s", "ms_per_step": round(env_only / a.steps * 1e3, 4),
                                     "note": "reset_done + env.step without the LocoVal bookkeeping / fit (round-1 definition of the step)"}
         if world == 1 and not a.no_policy:
+            # a policy reads the reset envs' fresh observations, so the reset chain cannot hide beside the step: the sequential
+            # schedule (observation launch of the live envs beside the reset chain, cost-ordered dispatch) is the faster one here
+            # (measured: 3.95 M against 3.78 M env-steps/s)
+            task.wait_reset()
+            task.overlap_reset = False
+            task.overlap_obs = True
+            task.sim.native.set_cost_order(True)
             out["policy"] = policy_leg(env, E, dev, a.steps, a.warmup)
+            out["policy"]["schedule"] = "sequential, cost-ordered dispatch"
         if world == 1 and not a.no_pipelined and E % 2 == 0:
             out["pipelined"] = pipelined_leg(E, dev, a.steps, a.warmup)
         if world == 1 and not a.no_cpu_baseline:
