@@ -19,6 +19,7 @@ T_ROOT_STATE, T_DOF_STATE, T_RIGID_BODY, T_CONTACT_FORCE, T_DOF_FORCE, T_PD_TARG
 POST_ADVANCE, POST_OBS, POST_REWARD, POST_RESET, POST_AMP_SHIFT, POST_AMP_ROW = 1, 2, 4, 8, 16, 32
 POST_STEP = 63
 POST_SKIP_DONE = 64
+POST_AMP_DONE_ONLY = 128
 
 
 class EmlocoError(RuntimeError):

@@ -2,6 +2,10 @@
 #pragma once
 #define EMLOCO_PART_WORDS 416   /* 24 x 12 joint registers | 16 root | 8 momentum | 64 multipliers | 32 slot map | 4 misc | pad: 16-byte granules */
 #include "../../include/emloco_sim.h"
+/* hand-over tag of part `part` of the launch numbered `seq`: unique whatever n_parts the launches before it used (list launches
+ * and unsplit launches bump the sequence number without publishing, so a stale flag can never equal an awaited tag) */
+#define EMLOCO_PART_TAG(seq, part) ((seq) * 4u + (unsigned)(part))
+#define EMLOCO_ERR_PART_TIMEOUT 1u
 
 // Device pointers handed to the rollout kernels by value (kernarg segment).
 struct EmlocoSimDev {
@@ -37,10 +41,14 @@ struct EmlocoSimDev {
     const int *step_order;
     unsigned *step_ticks;
     // split launch (emloco_sim_set_split): the substeps of an env.step as n_parts workgroups per env, part p + 1 continuing
-    // from the registers / LDS part p left in part_state [n_env][EMLOCO_PART_WORDS] once part_flag[env] == part_seq
+    // from the registers / LDS part p left in part_state [n_env][EMLOCO_PART_WORDS] once part_flag[env] holds the predecessor's tag (EMLOCO_PART_TAG)
     const int *pd_pack;               /* per body: parent | depth << 8 | index among the bodies of its depth << 16 (topology.h) */
     int n_parts; unsigned part_seq;
     float *part_state;
     unsigned *part_flag;
+    unsigned *err;                    /* device error word (sim_capi.hip: surfaced by emloco_sim_sync and by the next step): bit 0 = a part of a
+                                         split launch gave up waiting for its predecessor's hand-over; that env's step was abandoned */
+    int part_spin_max;                /* bound of a part's wait for its predecessor, in 16 x 64-clock sleeps (default 1 << 22: seconds) */
+    int part_poison;                  /* test hook (emloco_sim_debug_poison_part): the first part of this env withholds its flag; -1: none */
     unsigned long long *step_start;   /* diagnostic (emloco_sim_cost_ticks): wall clock at the start of each env's workgroup, else NULL */
 };

@@ -28,6 +28,17 @@ int fail(int code, const char *what, hipError_t e = hipSuccess) {
         if (e_ != hipSuccess) return fail(EMLOCO_E_HIP, #expr, e_);             \
     } while (0)
 
+// the device error word (EmlocoSimDev::err) lives in pinned host memory: reading it costs nothing and needs no copy
+int check_device_error(EmlocoSim *s, const char *where) {
+    if (!s->h_err) return EMLOCO_OK;
+    const unsigned e = __atomic_exchange_n(s->h_err, 0u, __ATOMIC_RELAXED);     // reported once, then cleared
+    if (e == 0u) return EMLOCO_OK;
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: device error word 0x%x%s", where, e,
+             (e & EMLOCO_ERR_PART_TIMEOUT) ? " (split launch: a part's wait for its predecessor's hand-over ran out; the step of that env was abandoned)" : "");
+    return fail(EMLOCO_E_HIP, buf);
+}
+
 __global__ void copy_rows_kernel(const float *src, float *dst, const int *ids, int n_ids, int row_len) {
     const int i = blockIdx.x;
     if (i >= n_ids) return;
@@ -79,8 +90,9 @@ int emloco_sim_destroy(EmlocoSim *s) {
     s->d_sc_pairs.release(); s->d_sc_a.release(); s->d_sc_b.release(); s->d_sc_r.release();
     s->d_root.release(); s->d_dof.release(); s->d_tgt.release(); s->d_rb.release();
     s->d_cf.release(); s->d_df.release(); s->d_lws.release();
-    s->d_ticks.release(); s->d_order.release();
+    s->d_ticks.release(); s->d_order.release(); s->d_order_ws.release();
     s->d_part_state.release(); s->d_part_flag.release();
+    if (s->h_err) (void)hipHostFree(s->h_err);
     for (auto e : s->ev0) (void)hipEventDestroy(e);
     for (auto e : s->ev1) (void)hipEventDestroy(e);
     delete s;
@@ -191,6 +203,11 @@ int emloco_sim_prepare(EmlocoSim *s) {
     d.kp = s->d_kp.p; d.kd = s->d_kd.p; d.armature = s->d_arm.p; d.effort = s->d_eff.p;
     d.root_state = s->d_root.p; d.dof_state = s->d_dof.p; d.pd_target = s->d_tgt.p;
     d.rb_state = s->d_rb.p; d.contact_force = s->d_cf.p; d.dof_force = s->d_df.p; d.lambda_ws = s->d_lws.p;
+    HIPCHK(hipHostMalloc((void **)&s->h_err, sizeof(unsigned), hipHostMallocMapped));
+    *s->h_err = 0u;
+    HIPCHK(hipHostGetDevicePointer((void **)&d.err, s->h_err, 0));
+    d.part_spin_max = s->part_spin_max; d.part_poison = -1;
+    if (const char *pad = getenv("EMLOCO_SIM_LDS_PAD")) s->lds_pad = atoi(pad);
     d.sc_n = 0;
     if (!s->h_sc_pairs.empty()) {
         HIPCHK(s->d_sc_pairs.upload(s->h_sc_pairs.data(), s->h_sc_pairs.size()));
@@ -253,7 +270,7 @@ int emloco_sim_set_pd_targets(EmlocoSim *s, const float *dev_targets, void *stre
 // the dispatch order of the full launch: sorted on the caller's stream right ahead of it (a stream of the simulator's own
 // for the sort was measured and lost: with torch's pool streams it ended up sharing a hardware queue with the caller's)
 static int launch_order(EmlocoSim *s, hipStream_t st) {
-    hipLaunchKernelGGL(emloco::sim_order_kernel, dim3(1), dim3(1024), 0, st, s->d_ticks.p, s->n_env, s->d_order.p);
+    hipLaunchKernelGGL(emloco::sim_order_kernel, dim3(1), dim3(1024), 0, st, s->d_ticks.p, s->n_env, s->d_order.p, s->d_order_ws.p);
     HIPCHK(hipGetLastError());
     return EMLOCO_OK;
 }
@@ -262,6 +279,7 @@ int emloco_sim_step(EmlocoSim *s, int n_calls, void *stream) {
     if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_step: null sim");
     if (!s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_step: sim not prepared");
     if (n_calls < 1) return fail(EMLOCO_E_ARG, "emloco_sim_step: n_calls < 1");
+    if (const int rc = check_device_error(s, "emloco_sim_step")) return rc;
     EmlocoSimParams p = s->prm;
     p.n_sub = s->prm.n_sub * n_calls;
     hipStream_t st = (hipStream_t)stream;
@@ -277,7 +295,8 @@ int emloco_sim_step(EmlocoSim *s, int n_calls, void *stream) {
     if (timed) HIPCHK(hipEventRecord(s->ev0[slot], st));
     d.n_parts = s->n_parts < p.n_sub ? s->n_parts : p.n_sub;       // at least one substep per part
     d.part_seq = ++s->part_seq; d.part_state = s->d_part_state.p; d.part_flag = s->d_part_flag.p;
-    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(s->n_env * d.n_parts)), dim3(64), 0, st, p, d);
+    d.part_spin_max = s->part_spin_max; d.part_poison = s->part_poison;
+    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(s->n_env * d.n_parts)), dim3(64), (size_t)s->lds_pad, st, p, d);
     HIPCHK(hipGetLastError());
     if (timed) {
         HIPCHK(hipEventRecord(s->ev1[slot], st));
@@ -294,6 +313,7 @@ int emloco_sim_step_subset(EmlocoSim *s, int n_calls, const int64_t *dev_skip, c
     if ((dev_skip == nullptr) == (dev_ids == nullptr)) return fail(EMLOCO_E_ARG, "emloco_sim_step_subset: exactly one of skip flags / id list");
     if (dev_ids && (n_ids < 0 || n_ids > s->n_env)) return fail(EMLOCO_E_ARG, "emloco_sim_step_subset: bad id count");
     if (dev_ids && n_ids == 0) return EMLOCO_OK;
+    if (const int rc = check_device_error(s, "emloco_sim_step_subset")) return rc;
     EmlocoSimParams p = s->prm;
     p.n_sub = s->prm.n_sub * n_calls;
     EmlocoSimDev d = s->dev;
@@ -314,7 +334,8 @@ int emloco_sim_step_subset(EmlocoSim *s, int n_calls, const int64_t *dev_skip, c
     if (timed) HIPCHK(hipEventRecord(s->ev0[slot], st));
     d.n_parts = dev_ids ? 1 : (s->n_parts < p.n_sub ? s->n_parts : p.n_sub);      // the list launch (a few dozen envs) is not split
     d.part_seq = ++s->part_seq; d.part_state = s->d_part_state.p; d.part_flag = s->d_part_flag.p;
-    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(dev_ids ? n_ids : s->n_env * d.n_parts)), dim3(64), 0, st, p, d);
+    d.part_spin_max = s->part_spin_max; d.part_poison = s->part_poison;
+    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(dev_ids ? n_ids : s->n_env * d.n_parts)), dim3(64), (size_t)s->lds_pad, st, p, d);
     HIPCHK(hipGetLastError());
     if (timed) {
         HIPCHK(hipEventRecord(s->ev1[slot], st));
@@ -341,11 +362,11 @@ int emloco_sim_set_split(EmlocoSim *s, int n_parts) {
 int emloco_sim_set_cost_order(EmlocoSim *s, int on) {
     if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_set_cost_order: null sim");
     if (!s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_set_cost_order: sim not prepared");
-    if (on && s->n_env > EMLOCO_ORDER_MAX_ENVS) return fail(EMLOCO_E_ARG, "emloco_sim_set_cost_order: more than 16384 envs");
     if (on && !s->d_ticks.p) {
         HIPCHK(hipSetDevice(s->device));
         HIPCHK(s->d_ticks.alloc((size_t)s->n_env));
         HIPCHK(s->d_order.alloc((size_t)s->n_env));
+        if (s->n_env > EMLOCO_ORDER_LDS_ENVS) HIPCHK(s->d_order_ws.alloc((size_t)s->n_env));
         HIPCHK(hipMemset(s->d_ticks.p, 0, sizeof(unsigned) * (size_t)s->n_env));
     }
     s->cost_order = on != 0;
@@ -355,6 +376,16 @@ int emloco_sim_set_cost_order(EmlocoSim *s, int on) {
 int emloco_sim_sync(EmlocoSim *s, void *stream) {
     if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_sync: null sim");
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return check_device_error(s, "emloco_sim_sync");
+}
+
+// internal test hook (not in the public header): the first part of `env` withholds its hand-over flag in the split launches
+// that follow (-1: back to normal) and a part's wait is bounded by `spin_max` sleeps (<= 0: the default) -- lets a test see
+// the timeout of a lost hand-over surface as EMLOCO_E_HIP instead of waiting seconds for it
+int emloco_sim_debug_poison_part(EmlocoSim *s, int env, int spin_max) {
+    if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_debug_poison_part: null sim");
+    s->part_poison = env;
+    s->part_spin_max = spin_max > 0 ? spin_max : (1 << 22);
     return EMLOCO_OK;
 }
 

@@ -67,6 +67,7 @@ __device__ __forceinline__ void part_ld48(const float *p, float *v) { for (int g
 __device__ __forceinline__ void part_stores_done() {}
 __device__ __forceinline__ void part_flag_set(unsigned *f, unsigned v) { *f = v; }
 __device__ __forceinline__ unsigned part_flag_get(const unsigned *f) { return *f; }
+__device__ __forceinline__ void part_err_raise(unsigned *e, unsigned bit) { if (e) *e |= bit; }
 #else
 __device__ __forceinline__ void part_st16(float *p, float a, float b, float c, float d) {
     const part_f4 v = {a, b, c, d};
@@ -89,6 +90,7 @@ __device__ __forceinline__ void part_ld48(const float *p, float *v) {
 __device__ __forceinline__ void part_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void part_flag_set(unsigned *f, unsigned v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned part_flag_get(const unsigned *f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void part_err_raise(unsigned *e, unsigned bit) { if (e) __hip_atomic_fetch_or(e, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 #endif
 
 #ifdef EMLOCO_SIM_PROFILE
@@ -218,11 +220,19 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             for (int k = 0; k < 4; ++k) sh_root[3 + k] = q0[k];
         }
     } else {
-        if (lane == 0) {        // the predecessor has published its state (bounded wait: a lost flag must not hang the device)
+        // The predecessor has published its state.  Parts are workgroups of one launch at ascending indices, so in dispatch
+        // order the flag is set long before; the wait is bounded all the same (a lost flag must not hang the device) and a
+        // wait that runs out is an ERROR, not a reason to go on from stale hand-over state: the workgroup raises the device
+        // error word (emloco_sim_sync / the next step return EMLOCO_E_HIP) and abandons this env's step.
+        if (lane == 0) {
             int spins = 0;
-            while (part_flag_get(d.part_flag + env) != d.part_seq * (unsigned)n_parts + (unsigned)part - 1u && ++spins < (1 << 22))
-                __builtin_amdgcn_s_sleep(16);
+            const unsigned want = EMLOCO_PART_TAG(d.part_seq, part - 1);
+            while (part_flag_get(d.part_flag + env) != want && ++spins < d.part_spin_max) __builtin_amdgcn_s_sleep(16);
+            sh_V0[0] = spins < d.part_spin_max ? 1.0f : 0.0f;
+            if (spins >= d.part_spin_max) part_err_raise(d.err, EMLOCO_ERR_PART_TIMEOUT);
         }
+        __syncthreads();
+        if (sh_V0[0] == 0.0f) { work = -1; return; }
         __syncthreads();
         if (is_body) {          // granules lane, 24 + lane, 48 + lane (granule-major: the lanes of one store / load instruction
             float v[12];        // touch one contiguous 384-byte run): joint quaternion | rates, e_0 | e_1, e_2
@@ -1193,7 +1203,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         }
         part_stores_done();           // the stores above have completed ...
         __syncthreads();
-        if (lane == 0) part_flag_set(d.part_flag + env, d.part_seq * (unsigned)n_parts + (unsigned)part);      // ... before the flag goes out
+        if (lane == 0 && !(part == 0 && env == d.part_poison)) part_flag_set(d.part_flag + env, EMLOCO_PART_TAG(d.part_seq, part));      // ... before the flag goes out
         return;
     }
     // ---------------------------------------------------------------- write back (state after the final kinematics pass)
@@ -1259,18 +1269,21 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
 // expensive envs (many contacts) first and the cheap ones (airborne) last, the slots that free up late receive short work.
 // The order within a bucket is whatever the LDS atomics give -- envs are independent, results do not depend on it.
 #define EMLOCO_ORDER_BUCKETS 128
-#define EMLOCO_ORDER_MAX_ENVS 16384
+#define EMLOCO_ORDER_LDS_ENVS 16384
 __global__ void __launch_bounds__(1024)
-sim_order_kernel(const unsigned *ticks, int n, int *order) {
+sim_order_kernel(const unsigned *ticks, int n, int *order, unsigned char *bucket_ws) {
     __shared__ int sh_cnt[EMLOCO_ORDER_BUCKETS];
-    __shared__ unsigned char sh_b[EMLOCO_ORDER_MAX_ENVS];        // every duration is read ONCE: a launch that still writes durations
-    const int tid = threadIdx.x;                                  // beside this one cannot make the two passes disagree
+    // every key is read ONCE (a launch that still writes keys beside this one cannot make the two passes disagree) and its
+    // bucket kept in LDS -- in the global workspace `bucket_ws` [n] beyond EMLOCO_ORDER_LDS_ENVS envs
+    __shared__ unsigned char sh_b[EMLOCO_ORDER_LDS_ENVS];
+    unsigned char *bk = n <= EMLOCO_ORDER_LDS_ENVS ? sh_b : bucket_ws;
+    const int tid = threadIdx.x;
     if (tid < EMLOCO_ORDER_BUCKETS) sh_cnt[tid] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         unsigned b = ticks[i];
         b = b > EMLOCO_ORDER_BUCKETS - 1 ? EMLOCO_ORDER_BUCKETS - 1 : b;
-        sh_b[i] = (unsigned char)b;
+        bk[i] = (unsigned char)b;
         atomicAdd(&sh_cnt[b], 1);
     }
     __syncthreads();
@@ -1279,7 +1292,7 @@ sim_order_kernel(const unsigned *ticks, int n, int *order) {
         for (int b = EMLOCO_ORDER_BUCKETS - 1; b >= 0; --b) { const int c = sh_cnt[b]; sh_cnt[b] = run; run += c; }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) order[atomicAdd(&sh_cnt[sh_b[i]], 1)] = i;
+    for (int i = tid; i < n; i += 1024) order[atomicAdd(&sh_cnt[bk[i]], 1)] = i;      // a thread re-reads only what it wrote itself
 }
 
 // Forward kinematics only (used after state writes through the *_indexed setters): fills rb_state of

@@ -47,9 +47,13 @@ struct EmlocoSim {
     unsigned part_seq = 0;
     DevBuf<float> d_part_state;
     DevBuf<unsigned> d_part_flag;
+    unsigned *h_err = nullptr;                 // device error word in pinned host memory (kernels raise bits with system-scope atomics)
+    int part_spin_max = 1 << 22, part_poison = -1;
+    int lds_pad = 0;                           // diagnostic (EMLOCO_SIM_LDS_PAD): extra dynamic LDS per workgroup of the step launch, caps the residency
     bool cost_order = false;
     DevBuf<unsigned> d_ticks;
     DevBuf<int> d_order;
+    DevBuf<unsigned char> d_order_ws;           // bucket of every env, beyond the 16384 envs the sort keeps in LDS
     // HIP-event timing of step launches: a ring of event pairs recorded on the launch stream
     static constexpr int kRing = 1024;
     std::vector<hipEvent_t> ev0, ev1;

@@ -255,6 +255,7 @@ post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_id
             t.reward_raw[(long)env * 2 + 1] = pw;
         }
     }
+    int done_now = 0;                            // this env's reset flag as this launch leaves it (lane 0; broadcast below)
     if ((mode & EMLOCO_POST_RESET) && lane == 0) {
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
         for (int bb = 0; bb < TNB; ++bb) {
@@ -271,7 +272,12 @@ post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_id
         const bool far = d2 > t.fail_dist * t.fail_dist;
         const int64_t term = (fallen || far) ? 1 : 0;
         t.terminate_buf[env] = term;
-        t.reset_buf[env] = ((float)prog >= t.max_episode_length - 1.0f) ? 1 : term;
+        done_now = ((float)prog >= t.max_episode_length - 1.0f) ? 1 : (int)term;
+        t.reset_buf[env] = done_now;
+    }
+    if (mode & EMLOCO_POST_AMP_DONE_ONLY) {      // the AMP rows of the finished envs only (block-uniform)
+        done_now = (mode & EMLOCO_POST_RESET) ? __shfl(done_now, 0) : (int)(t.reset_buf[env] != 0);
+        if (!done_now) return;
     }
 
     if (mode & (EMLOCO_POST_AMP_SHIFT | EMLOCO_POST_AMP_ROW)) {

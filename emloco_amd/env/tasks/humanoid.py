@@ -388,8 +388,9 @@ class Humanoid(BaseTask):
     # Opt-in (set by a rollout loop that calls wait_obs() before anything reads the observations): the step's launch is split
     # into progress / reward / reset flags on the caller's stream and observations (+ AMP rows) on a side stream, so the
     # observations of the ~4000 live envs are built while the caller's stream already resets the finished ones.  The side
-    # launch leaves the finished envs alone (POST_SKIP_DONE): their rows are rebuilt by the reset path, as in the reference
-    # (humanoid.py:1140-1160 recomputes the observations of the reset envs).
+    # launch leaves the finished envs alone (POST_SKIP_DONE): their observation rows are rebuilt by the reset path, as in the
+    # reference (humanoid.py:1140-1160 recomputes the observations of the reset envs); their terminal AMP rows come from the
+    # flags launch (POST_AMP_DONE_ONLY).
     overlap_obs = False
 
     def _make_obs_stream(self):
@@ -411,7 +412,11 @@ class Humanoid(BaseTask):
                 self._make_obs_stream()
             self.wait_obs()                                       # nobody asked for the previous step's observations
             side_mode = mode & (L.POST_OBS | L.POST_AMP_SHIFT | L.POST_AMP_ROW)
-            self._launch_post(mode & ~side_mode)                  # progress += 1, reward, reset flags
+            # progress += 1, reward, reset flags -- and the AMP rows of the envs that finish on this step: their terminal AMP
+            # observations are scored by the caller (amp_continuous_value.py:90-96) and must be taken from the state the reset
+            # path is about to overwrite, so they cannot ride on the side launch
+            amp = mode & (L.POST_AMP_SHIFT | L.POST_AMP_ROW)
+            self._launch_post((mode & ~side_mode) | (amp | L.POST_AMP_DONE_ONLY if amp else 0))
             main = torch.cuda.current_stream(self.device)
             self._ev_flags.record(main)
             self._obs_stream.wait_event(self._ev_flags)

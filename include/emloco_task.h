@@ -40,8 +40,12 @@ enum {
     EMLOCO_POST_AMP_SHIFT = 16, /* history shift of amp_obs_buf */
     EMLOCO_POST_AMP_ROW = 32,   /* newest AMP row */
     EMLOCO_POST_STEP = 63,      /* everything post_physics_step does */
-    EMLOCO_POST_SKIP_DONE = 64  /* leave the envs whose reset_buf is set alone (their rows are rebuilt by the reset path): lets the
-                                 * observation launch of a step run beside that step's resets on another stream */
+    EMLOCO_POST_SKIP_DONE = 64, /* leave the envs whose reset_buf is set alone (their observation rows are rebuilt by the reset
+                                 * path): lets the observation launch of a step run beside that step's resets on another stream */
+    EMLOCO_POST_AMP_DONE_ONLY = 128 /* AMP_SHIFT / AMP_ROW act on the envs whose reset flag is set after this launch only: the
+                                 * terminal AMP observations of the finished envs (amp_continuous_value.py:90-96 scores them) are
+                                 * written by the flags launch, BEFORE the reset path overwrites those envs' state; the side
+                                 * launch (SKIP_DONE) writes the live envs' rows */
 };
 
 typedef struct {

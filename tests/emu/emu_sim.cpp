@@ -46,8 +46,13 @@ extern "C" int emu_sim_step(const EmlocoSimParams *prm, const EmlocoModelDesc *m
     std::vector<float> part_state((size_t)m->n_env * EMLOCO_PART_WORDS, 0.0f);
     std::vector<unsigned> part_flag((size_t)m->n_env, 0u);
     d.n_parts = n_parts; d.part_seq = 1; d.part_state = part_state.data(); d.part_flag = part_flag.data();
+    // EMLOCO_EMU_POISON=env: the first part of that env withholds its hand-over flag (emloco_sim_debug_poison_part); the
+    // device error word is the return value (0: fine)
+    const char *po = getenv("EMLOCO_EMU_POISON");
+    unsigned err = 0u;
+    d.part_spin_max = 4; d.part_poison = po ? atoi(po) : -1; d.err = &err;
     emu::launch((unsigned)(m->n_env * n_parts), 64, [&] { emloco::sim_step_kernel(p, d); });
-    return 0;
+    return (int)err;
 }
 
 extern "C" int emu_sim_fk(const EmlocoModelDesc *m, float *root_state, float *dof_state, float *rb_state) {

@@ -51,6 +51,28 @@ def test_sim_step_kernel_split_launch_is_the_fused_step(parts, monkeypatch):
     assert np.abs(a.contact_force).max() > 50
 
 
+def test_sim_step_kernel_split_launch_lost_handover_raises_the_error_word(monkeypatch):
+    """A part whose predecessor never publishes its flag must not go on from stale hand-over state: its bounded wait runs
+    out, the device error word gets EMLOCO_ERR_PART_TIMEOUT and the env's step is abandoned (state tensors untouched); the
+    other envs are stepped as usual.  A stale flag of an earlier launch with another part count can never match a tag."""
+    monkeypatch.setenv("EMLOCO_EMU_PARTS", "4")
+    E = 3
+    models = varied_models(E, seed=31)
+    root, dof, tgt = scene_state(E, seed=32)
+    a = oracle_sim(models, root, dof, tgt, self_collision=True, n_sub=4)
+    b = oracle_sim(models, root, dof, tgt, self_collision=True, n_sub=4)
+    a.step(1)
+    emu.sim_step(b, 1)
+    before = {n: getattr(b, n).copy() for n in ("root_state", "dof_state", "rb_state")}
+    monkeypatch.setenv("EMLOCO_EMU_POISON", "1")
+    a.step(1)
+    assert emu.sim_step(b, 1, expect_error=True) == 1
+    for name in ("root_state", "dof_state", "rb_state"):
+        x, y = getattr(a, name).reshape(E, -1), getattr(b, name).reshape(E, -1)
+        assert np.array_equal(x[[0, 2]], y[[0, 2]]), name                          # the others: the oracle's bytes
+        assert np.array_equal(y[1], before[name].reshape(E, -1)[1]), name         # the poisoned env: abandoned, not corrupted
+
+
 def test_sim_step_kernel_fallen_humanoids_are_bit_exact_vs_oracle():
     """Humanoids lying on the ground, pressed into it: more candidates than contact slots (the shallowest are dropped), limb-limb
     contacts, contact bodies at several tree depths in the Gram build.  (Pelvis contacts -- tree depth 0 -- come up in the

@@ -529,8 +529,8 @@ def test_bench_config_rollout_step_matches_oracle():
 
 def test_observations_on_a_side_stream_give_the_same_rollout():
     """task.overlap_obs: the step's launch is split -- progress / reward / reset flags on the caller's stream, observations and
-    AMP rows of the live envs on a side stream (POST_SKIP_DONE) while the caller's stream resets the finished envs -- and the
-    loop calls wait_obs() before reading.  Two identically seeded envs, one per mode, forced and natural resets: every buffer
+    AMP rows of the live envs on a side stream (POST_SKIP_DONE) while the caller's stream resets the finished envs (whose
+    terminal AMP rows the flags launch writes, POST_AMP_DONE_ONLY) -- and the loop calls wait_obs() before reading.  Two identically seeded envs, one per mode, forced and natural resets: every buffer
     bit-equal after every step."""
     from emloco_amd import _lib as L
     args = ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel"]
@@ -558,8 +558,10 @@ def test_observations_on_a_side_stream_give_the_same_rollout():
         torch.cuda.synchronize()
         for name in names:
             a, b = getattr(envs[0].task, name), getattr(envs[1].task, name)
-            live = envs[0].task.reset_buf == 0               # rows of finished envs are rebuilt by the next reset_done
-            if name in ("obs_buf", "_flip_obs_buf", "_amp_obs_buf"):
+            # observation rows of finished envs are rebuilt by the next reset_done; their terminal AMP rows (what
+            # infos['amp_obs'] hands the discriminator for the last step of an episode) must be there in both schedules
+            live = envs[0].task.reset_buf == 0
+            if name in ("obs_buf", "_flip_obs_buf"):
                 assert torch.equal(a[live], b[live]), (k, name)
             else:
                 assert torch.equal(a, b), (k, name)
@@ -608,8 +610,10 @@ def test_reset_chain_on_a_second_stream_gives_the_same_rollout(obs_stream):
             assert torch.equal(obs_after_reset[0], obs_after_reset[1]), k
         for name in names:
             a, b = getattr(envs[0].task, name), getattr(envs[1].task, name)
-            live = envs[0].task.reset_buf == 0               # rows of finished envs are rebuilt by the next reset_done
-            if name in ("obs_buf", "_flip_obs_buf", "_amp_obs_buf"):
+            # observation rows of finished envs are rebuilt by the next reset_done; their terminal AMP rows (what
+            # infos['amp_obs'] hands the discriminator for the last step of an episode) must be there in both schedules
+            live = envs[0].task.reset_buf == 0
+            if name in ("obs_buf", "_flip_obs_buf"):
                 assert torch.equal(a[live], b[live]), (k, name)
             else:
                 assert torch.equal(a, b), (k, name)

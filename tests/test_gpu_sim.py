@@ -249,3 +249,58 @@ def test_cost_ordered_split_and_subset_launches_are_the_same_step():
             gsim.step(2)
         _compare(osim, gsim, E, what=f"step {k}")
     assert np.abs(osim.contact_force).max() > 50.0
+
+
+def test_split_launch_lost_handover_is_an_error_not_silent_corruption():
+    """A later part of a split launch whose predecessor never publishes its flag gives up after a bounded wait, raises the
+    device error word and abandons that env's step; emloco_sim_sync then returns EMLOCO_E_HIP (reported once) instead of the
+    step going on from stale hand-over state.  The other envs are stepped on the oracle's bytes; launches with other part
+    counts in between (unsplit, list launches) cannot make a stale flag match: the tags are unique per launch and part."""
+    from emloco_amd import _lib as L
+    E = 64
+    osim, gsim = _mk(E, seed=33)
+    gsim.set_split(4)
+    for _ in range(2):
+        osim.step(1)
+        gsim.step(2)
+    gsim.sync()
+    _compare(osim, gsim, E, what="before the poisoned launch")
+    before = gsim.rigid_body_state.view(E, 24, 13)[5].clone()
+    gsim.lib.emloco_sim_debug_poison_part.argtypes = [L.C.c_void_p, L.C.c_int, L.C.c_int]
+    L.check(gsim.lib.emloco_sim_debug_poison_part(gsim._h, 5, 1 << 14), "poison")
+    osim.step(1)
+    gsim.step(2)
+    with pytest.raises(L.EmlocoError, match="hand-over"):
+        gsim.sync()
+    gsim.sync()                                                # reported once, then cleared
+    rb = gsim.rigid_body_state.view(E, 24, 13).cpu().numpy()
+    keep = np.arange(E) != 5
+    assert np.array_equal(rb[keep], osim.rb_state[keep]), "the other envs must be on the oracle's bytes"
+    assert torch.equal(gsim.rigid_body_state.view(E, 24, 13)[5], before), "the poisoned env's step is abandoned, not corrupted"
+    L.check(gsim.lib.emloco_sim_debug_poison_part(gsim._h, -1, 0), "unpoison")
+    # a launch with another part count, then split launches again: stale flags never match a tag
+    gsim.set_split(2); gsim.step(2); gsim.set_split(1); gsim.step(2); gsim.set_split(4); gsim.step(2)
+    gsim.sync()
+
+
+def test_cost_order_above_the_lds_sort_capacity():
+    """emloco_sim_set_cost_order beyond 16384 envs (the sort keeps its buckets in a global workspace there): still every env
+    stepped exactly once -- the cost-ordered launch equals the plain one."""
+    from emloco_amd import _lib as L
+    from emloco_amd.sim import NativeSim
+    from helpers import scene_state, varied_models
+    E = 16384 + 512
+    base = varied_models(64, 3)
+    models = [base[i % 64] for i in range(E)]
+    root, dof, tgt = scene_state(E, 4)
+    sims = []
+    for order in (False, True):
+        s = NativeSim(models, L.default_sim_params(n_sub=2))
+        s.root_state.copy_(torch.from_numpy(root)); s.dof_state.view(E, 69, 2).copy_(torch.from_numpy(dof)); s.pd_target.copy_(torch.from_numpy(tgt))
+        s.set_cost_order(order)
+        for _ in range(3):
+            s.step(2)
+        s.sync()
+        sims.append(s)
+    assert torch.equal(sims[0].rigid_body_state, sims[1].rigid_body_state)
+    assert torch.equal(sims[0].dof_state, sims[1].dof_state)
