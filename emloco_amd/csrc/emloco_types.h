@@ -7,25 +7,33 @@
 #define EMLOCO_PART_TAG(seq, part) ((seq) * 4u + (unsigned)(part))
 #define EMLOCO_ERR_PART_TIMEOUT 1u
 
+// Topology block (ints, shared by all envs; built by model_pack.h): one pointer instead of eight
+#define EMLOCO_TOPO_PARENT 0      /* [24] parent body (-1: root) */
+#define EMLOCO_TOPO_DEPTH 24      /* [24] tree depth */
+#define EMLOCO_TOPO_CHILD 48      /* [24][3] children, descending body index, -1 padded */
+#define EMLOCO_TOPO_PDPACK 120    /* [24] parent (the root: 31) | depth << 5 | index among the bodies of its depth << 9 | children << 12, 17, 22 */
+#define EMLOCO_TOPO_CAND 144      /* [96] ground-contact candidate: body | k << 8 | geom type << 16 */
+#define EMLOCO_TOPO_SCPAIR 240    /* [256] limb-limb pair: body i | body j << 8 */
+#define EMLOCO_TOPO_WORDS 496
+
+// Per-env model block (floats, [n_env][EMLOCO_MODEL_WORDS]; built by model_pack.h).  16-byte records so that a lane fetches what a
+// phase needs with a few dwordx4 loads off ONE workgroup-uniform base (scalar registers) and a 32-bit lane offset:
+#define EMLOCO_MB_DYN 0           /* [24][16]  joint offset xyz, mass | com xyz, 0 | Ixx Iyy Izz Ixy | Ixz Iyz 0 0 */
+#define EMLOCO_MB_GEO 384         /* [24][8]   geom a xyz, geom radius | geom b xyz, 0 */
+#define EMLOCO_MB_CAP 576         /* [24][8]   collision capsule end a xyz, radius | end b xyz, 0  (self-collision; zeros when off) */
+#define EMLOCO_MB_DRV 768         /* [69][4]   kp, kd, armature, effort limit */
+#define EMLOCO_MODEL_WORDS 1048
+
 // Device pointers handed to the rollout kernels by value (kernarg segment).
 struct EmlocoSimDev {
-    int n_env, n_cand, max_depth, pad_;
-    // topology (shared by all envs)
-    const int *parent, *depth, *children /* [24][3], descending, -1 padded */, *geom_type;
-    const int *cand_body, *cand_k;            /* [n_cand] */
-    const unsigned char *lca_depth;           /* [24][24] depth of the lowest common ancestor */
-    // per-env model, layout [field][env][body|dof] so one wave reads contiguous segments
-    const float *joint_off, *mass, *com, *inertia, *geom_a, *geom_b, *geom_r;
-    const float *kp, *kd, *armature, *effort;
+    int n_env, n_cand, max_depth, sc_n;       /* sc_n: limb-limb pairs (0: self-collision off) */
+    const int *topo;                          /* EMLOCO_TOPO_* */
+    const float *model;                       /* EMLOCO_MB_*, one block per env */
     // state
     float *root_state, *dof_state;
     const float *pd_target;
     float *rb_state, *contact_force, *dof_force, *lambda_ws;
-    // limb-limb penalty contacts (sc_n = 0: off)
-    int sc_n, sc_pad_;
-    const unsigned char *sc_pairs;            /* [sc_n][2] */
-    const float *sc_cap_a, *sc_cap_b, *sc_cap_r;   /* per-env collision capsules [E][24][3|3|1] */
-    float sc_k, sc_c, sc_max_pen, sc_mu;
+    float sc_k, sc_c, sc_max_pen, sc_mu;      /* limb-limb penalty contacts */
     // height-field ground (hf = NULL: the plane z = ground_z).  hf[ix * hf_ny + iy] in units of hf_vs metres on an
     // hf_hs-metre grid whose sample (0, 0) sits at world (hf_ox, hf_oy)
     const short *hf;
@@ -37,12 +45,11 @@ struct EmlocoSimDev {
     const long long *step_skip;
     const int *step_ids;
     // cost-ordered dispatch (emloco_sim_set_cost_order): workgroup i of the full launch steps env step_order[i]; every
-    // workgroup leaves its own duration (100 MHz ticks) in step_ticks[env], the key of the next launch's order
+    // workgroup leaves its contact work in step_ticks[env], the key of the next launch's order
     const int *step_order;
     unsigned *step_ticks;
     // split launch (emloco_sim_set_split): the substeps of an env.step as n_parts workgroups per env, part p + 1 continuing
     // from the registers / LDS part p left in part_state [n_env][EMLOCO_PART_WORDS] once part_flag[env] holds the predecessor's tag (EMLOCO_PART_TAG)
-    const int *pd_pack;               /* per body: parent | depth << 8 | index among the bodies of its depth << 16 (topology.h) */
     int n_parts; unsigned part_seq;
     float *part_state;
     unsigned *part_flag;

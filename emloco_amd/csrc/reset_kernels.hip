@@ -277,10 +277,9 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
     for (int sl = 0; sl < 2; ++sl) {
         const int c = lane + 64 * sl;
         if (c < s.n_cand) {
-            const int body = s.cand_body[c], k = s.cand_k[c];
+            const int cp = s.topo[EMLOCO_TOPO_CAND + c], body = cp & 0xff, k = (cp >> 8) & 0xff, gt = cp >> 16;
             const long mb = (long)env * RNB + body;
-            const float *ga = s.geom_a + mb * 3, *gb = s.geom_b + mb * 3;
-            const int gt = s.geom_type[body];
+            const float *ga = s.model + (size_t)env * EMLOCO_MODEL_WORDS + EMLOCO_MB_GEO + body * 8, *gb = ga + 4;   // a xyz, radius | b xyz
             float lp[3];
             if (gt == EMLOCO_GEOM_SPHERE) { lp[0] = ga[0]; lp[1] = ga[1]; lp[2] = ga[2]; }
             else if (gt == EMLOCO_GEOM_CAPSULE) { const float *src = k == 0 ? ga : gb; lp[0] = src[0]; lp[1] = src[1]; lp[2] = src[2]; }
@@ -293,7 +292,7 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
             float R[9], wp[3];
             q2mat(rb + 3, R);
             matvec3(R, lp, wp);
-            const float z = rb[2] + wp[2] - s.geom_r[mb];
+            const float z = rb[2] + wp[2] - ga[3];
             low = z < low ? z : low;
         }
     }

@@ -8,6 +8,7 @@
 #include <vector>
 #include "sim_kernels.hip"
 #include "topology.h"
+#include "model_pack.h"
 #include "sim_state.h"
 
 namespace {
@@ -81,13 +82,7 @@ int emloco_sim_create(const EmlocoSimParams *params, int device, EmlocoSim **out
 int emloco_sim_destroy(EmlocoSim *s) {
     if (!s) return EMLOCO_OK;
     (void)hipSetDevice(s->device);
-    s->d_pd_pack.release();
-    s->d_parent.release(); s->d_depth.release(); s->d_children.release(); s->d_gtype.release();
-    s->d_cand_body.release(); s->d_cand_k.release(); s->d_lca.release();
-    s->d_off.release(); s->d_mass.release(); s->d_com.release(); s->d_inertia.release();
-    s->d_ga.release(); s->d_gb.release(); s->d_gr.release();
-    s->d_kp.release(); s->d_kd.release(); s->d_arm.release(); s->d_eff.release();
-    s->d_sc_pairs.release(); s->d_sc_a.release(); s->d_sc_b.release(); s->d_sc_r.release();
+    s->d_topo.release(); s->d_model.release();
     s->d_root.release(); s->d_dof.release(); s->d_tgt.release(); s->d_rb.release();
     s->d_cf.release(); s->d_df.release(); s->d_lws.release();
     s->d_ticks.release(); s->d_order.release(); s->d_order_ws.release();
@@ -164,25 +159,16 @@ int emloco_sim_prepare(EmlocoSim *s) {
     if (s->prepared) return EMLOCO_OK;
     HIPCHK(hipSetDevice(s->device));
     const emloco::Topology &t = s->topo;
-    HIPCHK(s->d_parent.upload(t.parent.data(), t.parent.size()));
-    HIPCHK(s->d_depth.upload(t.depth.data(), t.depth.size()));
-    HIPCHK(s->d_pd_pack.upload(t.pd_pack.data(), t.pd_pack.size()));
-    HIPCHK(s->d_children.upload(t.children.data(), t.children.size()));
-    HIPCHK(s->d_gtype.upload(t.geom_type.data(), t.geom_type.size()));
-    HIPCHK(s->d_cand_body.upload(t.cand_body.data(), t.cand_body.size()));
-    HIPCHK(s->d_cand_k.upload(t.cand_k.data(), t.cand_k.size()));
-    HIPCHK(s->d_lca.upload(t.lca_depth.data(), t.lca_depth.size()));
-    HIPCHK(s->d_off.upload(s->h_off.data(), s->h_off.size()));
-    HIPCHK(s->d_mass.upload(s->h_mass.data(), s->h_mass.size()));
-    HIPCHK(s->d_com.upload(s->h_com.data(), s->h_com.size()));
-    HIPCHK(s->d_inertia.upload(s->h_inertia.data(), s->h_inertia.size()));
-    HIPCHK(s->d_ga.upload(s->h_ga.data(), s->h_ga.size()));
-    HIPCHK(s->d_gb.upload(s->h_gb.data(), s->h_gb.size()));
-    HIPCHK(s->d_gr.upload(s->h_gr.data(), s->h_gr.size()));
-    HIPCHK(s->d_kp.upload(s->h_kp.data(), s->h_kp.size()));
-    HIPCHK(s->d_kd.upload(s->h_kd.data(), s->h_kd.size()));
-    HIPCHK(s->d_arm.upload(s->h_arm.data(), s->h_arm.size()));
-    HIPCHK(s->d_eff.upload(s->h_eff.data(), s->h_eff.size()));
+    const bool sc_on = !s->h_sc_pairs.empty();
+    {   // the two blocks the kernels read: topology tables, one model record block per env (model_pack.h)
+        const std::vector<int32_t> topo = emloco::pack_topology(t, sc_on ? s->h_sc_pairs.data() : nullptr, sc_on ? (int)(s->h_sc_pairs.size() / 2) : 0);
+        const std::vector<float> mdl = emloco::pack_models(s->n_env, s->h_off.data(), s->h_mass.data(), s->h_com.data(), s->h_inertia.data(),
+                                                           s->h_ga.data(), s->h_gb.data(), s->h_gr.data(), s->h_kp.data(), s->h_kd.data(),
+                                                           s->h_arm.data(), s->h_eff.data(), sc_on ? s->h_sc_a.data() : nullptr,
+                                                           sc_on ? s->h_sc_b.data() : nullptr, sc_on ? s->h_sc_r.data() : nullptr);
+        HIPCHK(s->d_topo.upload(topo.data(), topo.size()));
+        HIPCHK(s->d_model.upload(mdl.data(), mdl.size()));
+    }
     const size_t E = (size_t)s->n_env;
     HIPCHK(s->d_root.alloc(E * 13)); HIPCHK(hipMemset(s->d_root.p, 0, E * 13 * 4));
     HIPCHK(s->d_dof.alloc(E * EMLOCO_NDOF * 2)); HIPCHK(hipMemset(s->d_dof.p, 0, E * EMLOCO_NDOF * 2 * 4));
@@ -194,13 +180,8 @@ int emloco_sim_prepare(EmlocoSim *s) {
     hipLaunchKernelGGL(fill_quat_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, 0, s->d_root.p, s->n_env);
     HIPCHK(hipGetLastError());
     EmlocoSimDev &d = s->dev;
-    d.n_env = s->n_env; d.n_cand = t.n_cand; d.max_depth = t.max_depth; d.pad_ = 0;
-    d.pd_pack = s->d_pd_pack.p;
-    d.parent = s->d_parent.p; d.depth = s->d_depth.p; d.children = s->d_children.p; d.geom_type = s->d_gtype.p;
-    d.cand_body = s->d_cand_body.p; d.cand_k = s->d_cand_k.p; d.lca_depth = s->d_lca.p;
-    d.joint_off = s->d_off.p; d.mass = s->d_mass.p; d.com = s->d_com.p; d.inertia = s->d_inertia.p;
-    d.geom_a = s->d_ga.p; d.geom_b = s->d_gb.p; d.geom_r = s->d_gr.p;
-    d.kp = s->d_kp.p; d.kd = s->d_kd.p; d.armature = s->d_arm.p; d.effort = s->d_eff.p;
+    d.n_env = s->n_env; d.n_cand = t.n_cand; d.max_depth = t.max_depth;
+    d.topo = s->d_topo.p; d.model = s->d_model.p;
     d.root_state = s->d_root.p; d.dof_state = s->d_dof.p; d.pd_target = s->d_tgt.p;
     d.rb_state = s->d_rb.p; d.contact_force = s->d_cf.p; d.dof_force = s->d_df.p; d.lambda_ws = s->d_lws.p;
     HIPCHK(hipHostMalloc((void **)&s->h_err, sizeof(unsigned), hipHostMallocMapped));
@@ -209,13 +190,8 @@ int emloco_sim_prepare(EmlocoSim *s) {
     d.part_spin_max = s->part_spin_max; d.part_poison = -1;
     if (const char *pad = getenv("EMLOCO_SIM_LDS_PAD")) s->lds_pad = atoi(pad);
     d.sc_n = 0;
-    if (!s->h_sc_pairs.empty()) {
-        HIPCHK(s->d_sc_pairs.upload(s->h_sc_pairs.data(), s->h_sc_pairs.size()));
-        HIPCHK(s->d_sc_a.upload(s->h_sc_a.data(), s->h_sc_a.size()));
-        HIPCHK(s->d_sc_b.upload(s->h_sc_b.data(), s->h_sc_b.size()));
-        HIPCHK(s->d_sc_r.upload(s->h_sc_r.data(), s->h_sc_r.size()));
+    if (sc_on) {
         d.sc_n = (int)(s->h_sc_pairs.size() / 2);
-        d.sc_pairs = s->d_sc_pairs.p; d.sc_cap_a = s->d_sc_a.p; d.sc_cap_b = s->d_sc_b.p; d.sc_cap_r = s->d_sc_r.p;
         d.sc_k = s->sc_k; d.sc_c = s->sc_c; d.sc_max_pen = s->sc_max_pen; d.sc_mu = s->sc_mu;
     }
     d.hf = nullptr;

@@ -93,10 +93,37 @@ __device__ __forceinline__ unsigned part_flag_get(const unsigned *f) { return __
 __device__ __forceinline__ void part_err_raise(unsigned *e, unsigned bit) { if (e) __hip_atomic_fetch_or(e, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 #endif
 
-#ifdef EMLOCO_SIM_PROFILE
-#define PSTAMP(i) do { if (d.prof && env == 0 && lane == 0) d.prof[sub * 16 + (i)] = (long long)wall_clock64(); } while (0)
+// 16-byte load of a model record: base is workgroup-uniform (scalar registers), off a 32-bit lane offset in words
+#ifdef EMLOCO_EMU
+__device__ __forceinline__ void ld4(const float *base, int off, float *v) { for (int k = 0; k < 4; ++k) v[k] = base[off + k]; }
 #else
-#define PSTAMP(i) do { } while (0)
+__device__ __forceinline__ void ld4(const float *base, int off, float *v) {
+    const part_f4 a = *(const part_f4 *)(base + off);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+#endif
+
+// Register diet.  Everything a lane derives from its index alone (LDS row addresses at a dozen strides, model-record offsets,
+// tree constants, the compare masks of the level loops) is launch-invariant, and the compiler hoists all of it out of the
+// substep loop and keeps it in registers for the whole launch -- at 168 registers per lane (3 waves per SIMD) that was ~60
+// spilled dwords.  Each phase therefore starts from a lane index the compiler cannot see through (an empty asm that
+// redefines it): what a phase derives from it dies with the phase, and is recomputed (a handful of integer instructions)
+// by the next one.  The tree constants of a body come from one packed LDS word per phase.
+#ifdef EMLOCO_EMU
+#define FRESH_LANE() do { } while (0)
+#else
+#define FRESH_LANE() asm volatile("" : "+v"(lane))
+#endif
+// pd_pack word (topology.h): parent | depth << 5 | index among the bodies of its depth << 9 | children << 12, 17, 22 (31: none)
+#define PD_PARENT(w) ((w) & 31)
+#define PD_DEPTH(w) (((w) >> 5) & 15)
+#define PD_SLOT(w) (((w) >> 9) & 7)
+#define PD_CHILD(w, i) (((w) >> (12 + 5 * (i))) & 31)
+
+#ifdef EMLOCO_SIM_PROFILE
+#define PSTAMP(i) do { if (d.prof && env == 0 && lane == 0) d.prof[sub * 16 + (i)] = (long long)wall_clock64(); FRESH_LANE(); } while (0)
+#else
+#define PSTAMP(i) FRESH_LANE()
 #endif
 
 // Height-field ground under the world point (cx, cy): height zt of the cell triangle's plane there and its unit normal.
@@ -119,17 +146,12 @@ __device__ __forceinline__ void hf_plane(const EmlocoSimDev &d, float cx, float 
     n[0] = 0.0f - sx * inv; n[1] = 0.0f - sy * inv; n[2] = inv;
 }
 
-struct BodyConst {   // per-lane (lane = body) constants kept in registers for the whole launch
-    int parent, depth, nchild, child[3];
-    float off[3];
-};
-
 #ifndef EMLOCO_SIM_WAVES_PER_SIMD
 #define EMLOCO_SIM_WAVES_PER_SIMD 2   /* register budget 256 per lane: two resident waves per SIMD (8 envs per CU) */
 #endif
 // one env's step: the body of both kernels below (one 64-lane wave)
 __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const EmlocoSimDev &d, const int env, int &work, const int part, const int n_parts) {
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x;                                   // redefined at every phase boundary (FRESH_LANE)
     work = 0;                                                 // contact work of this step: sum over substeps of (10 + contacts) where there are any
 
     // ---------------------------------------------------------------- LDS: one blob, 16 KB per env (8 envs per CU need <= 20 KB)
@@ -143,12 +165,12 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     // The contact matrix (1830 words, phases 6b-6c) lies over [Ia tail .. ], the limb-limb scratch (phase 1b) over
     // [Ia tail .. a]; pw / qw stay out of both.  Barriers separate the phases.
     enum { O_ROOT = 0, O_P = 16, O_V0 = 24, O_PD = 36, O_R = O_PD + NB, O_W = O_R + NB * 12, O_K = O_W + NB * 20,
-           O_L0 = O_K + NB * 8, O_CB = O_L0 + 44, O_CX = O_CB + 2 * MAXC, O_CDIST = O_CX + 3 * MAXC, O_LAM = O_CDIST + MAXC,
+           O_SL = O_K + NB * 8, O_L0 = O_SL + NB * 12, O_CB = O_L0 + 44, O_CX = O_CB + 2 * MAXC, O_CDIST = O_CX + 3 * MAXC, O_LAM = O_CDIST + MAXC,
            O_SLOT = O_LAM + MAXR, O_CRANGE = O_SLOT + 32, O_IA = O_CRANGE + 2 * NB, O_G = O_IA + 180,
            O_I6 = O_IA + NB * 24, O_F = O_I6 + NB * 24, O_PA = O_F + NB * 8, O_A_ = O_PA + NB * 8, O_V = O_A_ + NB * 8,
            O_VF = O_V + NB * 8, O_AACC = O_VF + NB * 8, O_FEXT = O_AACC + NB * 8, O_PQ = O_FEXT + NB * 8,
            LDS_WORDS = O_PQ + NB * 8 };
-    static_assert(O_R % 4 == 0 && O_W % 4 == 0 && O_K % 4 == 0 && O_IA % 4 == 0 && O_I6 % 4 == 0 && O_F % 4 == 0 && O_PQ % 4 == 0, "rows must be 16-byte aligned");
+    static_assert(O_R % 4 == 0 && O_W % 4 == 0 && O_K % 4 == 0 && O_SL % 4 == 0 && O_IA % 4 == 0 && O_I6 % 4 == 0 && O_F % 4 == 0 && O_PQ % 4 == 0, "rows must be 16-byte aligned");
     static_assert(O_PQ - O_G >= MAXR * (MAXR + 1) / 2, "contact matrix does not fit its overlay");
     static_assert(O_V - O_G >= NB * 8 + EMLOCO_SC_MAXHITS * 8 + 256, "limb-limb scratch does not fit its overlay");
     static_assert(LDS_WORDS * 4 <= 20480, "LDS per env above 160 KiB / 8");
@@ -156,10 +178,11 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     float *sh_root = lds + O_ROOT;                            // p0[3] q0[4] V0[6]
     float *sh_V0 = lds + O_V0;                                // lane 0's hand-over between phases: free root twist [0..5], impulse change [6..11]
     float *sh_P = lds + O_P;                                  // linear momentum: expected [0..2], of the current substep [3..5]; total mass [6]
-    int *sh_pd = (int *)(lds + O_PD);                         // per body: parent | depth << 8 | index among the bodies of its depth << 16
+    int *sh_pd = (int *)(lds + O_PD);                         // per body: tree constants, packed (PD_PARENT / PD_DEPTH / PD_SLOT / PD_CHILD)
     float (*sh_R)[12] = (float (*)[12])(lds + O_R);           // rotation matrix [0..8] | position relative to O [9..11]
     float (*sh_W)[20] = (float (*)[20])(lds + O_W);
     float (*sh_K)[8] = (float (*)[8])(lds + O_K);
+    float (*sh_Sl)[12] = (float (*)[12])(lds + O_SL);         // linear part of the joint's motion subspace about O: r x (R e_c), c-major [c][k]
     float *sh_L0 = lds + O_L0, *sh_L0i = lds + O_L0 + 36;    // root Cholesky factor and 1 / its diagonal
     int *sh_cbody = (int *)(lds + O_CB), *sh_ccand = (int *)(lds + O_CB + MAXC);
     float (*sh_cx)[3] = (float (*)[3])(lds + O_CX);
@@ -182,17 +205,18 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     const bool hf_on = d.hf != nullptr;      // wave-uniform
 
     // ---------------------------------------------------------------- per-lane constants
-    BodyConst bc;
-    const bool is_body = lane < NB;
-    const int b = is_body ? lane : 0;
-    bc.parent = d.parent[b];
-    bc.depth = d.depth[b];
-    bc.nchild = 0;
-    for (int k = 0; k < 3; ++k) { bc.child[k] = d.children[b * 3 + k]; bc.nchild += bc.child[k] >= 0; }
-    const long mb0 = (long)env * NB + b;
-    // drive gains / targets are re-read (L2 hits) where they are used instead of pinning 15 registers for the launch
-    const long dof0 = (long)env * NDOF + (is_body && lane >= 1 ? (lane - 1) * 3 : 0);
-    if (is_body) sh_pd[lane] = d.pd_pack[lane];               // parent (the root's reads 255) | depth << 8 | index within its tree level << 16
+    const int *topo = d.topo;
+    // This env's model block and state rows: workgroup-uniform bases (scalar registers) + 32-bit lane offsets.  Model
+    // constants, drive gains and targets are re-read (L2 hits) where they are used instead of pinned in registers for the launch.
+    const float *mdl = d.model + (size_t)env * EMLOCO_MODEL_WORDS;
+#define o_dyn (EMLOCO_MB_DYN + (lane < NB ? lane : 0) * 16)                                     /* this body's dynamics record */
+#define jdof ((lane >= 1 && lane < NB) ? (lane - 1) * 3 : 0)                                  /* first dof of this body's joint */
+#define o_drv (EMLOCO_MB_DRV + jdof * 4)
+    const float *tgt_env = d.pd_target + (size_t)env * NDOF;
+    float *dofs_env = d.dof_state + (size_t)env * NDOF * 2;
+    float *cf_env = d.contact_force + (size_t)env * NB * 3;
+    float *lws_env = d.lambda_ws + (size_t)env * MAXCAND * 3;
+    if (lane < NB) sh_pd[lane] = topo[EMLOCO_TOPO_PDPACK + lane];
     sh_slot[lane] = 255; sh_slot[lane + 64] = 255;
 
     // ---------------------------------------------------------------- state -> registers
@@ -205,8 +229,8 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     float *pst = d.part_state ? d.part_state + (long)env * EMLOCO_PART_WORDS : nullptr;
     float qj[4] = {0, 0, 0, 1}, wj[3] = {0, 0, 0}, edof[3] = {0, 0, 0};
     if (part == 0) {
-        if (is_body && lane >= 1) {
-            const float *ds = d.dof_state + ((long)env * NDOF + (lane - 1) * 3) * 2;
+        if ((lane < NB) && lane >= 1) {
+            const float *ds = dofs_env + jdof * 2;
             float e[3] = {ds[0], ds[2], ds[4]};
             rotvec2quat(e, qj);
             wj[0] = ds[1]; wj[1] = ds[3]; wj[2] = ds[5];
@@ -234,7 +258,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         __syncthreads();
         if (sh_V0[0] == 0.0f) { work = -1; return; }
         __syncthreads();
-        if (is_body) {          // granules lane, 24 + lane, 48 + lane (granule-major: the lanes of one store / load instruction
+        if ((lane < NB)) {          // granules lane, 24 + lane, 48 + lane (granule-major: the lanes of one store / load instruction
             float v[12];        // touch one contiguous 384-byte run): joint quaternion | rates, e_0 | e_1, e_2
             part_ld48(pst + lane * 4, v);
             for (int k = 0; k < 4; ++k) qj[k] = v[k];
@@ -275,11 +299,14 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         }
         // joint offsets: re-read per substep (L2 hit) instead of held for the launch, but ahead of the level loop so that the
         // load's latency is not paid inside every level
-        const float joff[3] = {d.joint_off[mb0 * 3], d.joint_off[mb0 * 3 + 1], d.joint_off[mb0 * 3 + 2]};
+        float jm[4];                                     // joint offset xyz | body mass
+        ld4(mdl, o_dyn, jm);
+        const float joff[3] = {jm[0], jm[1], jm[2]};
         __syncthreads();
+        const int pd1 = sh_pd[lane < NB ? lane : 0];
         for (int lev = 1; lev <= d.max_depth; ++lev) {
-            if (is_body && bc.depth == lev) {
-                const int p = bc.parent;
+            if ((lane < NB) && PD_DEPTH(pd1) == lev) {
+                const int p = PD_PARENT(pd1);
                 float Rp[9], o[3], qp[4], qw[4], pw[3], R[9], r[3], Sl[3][3], V[6];
                 for (int k = 0; k < 9; ++k) Rp[k] = sh_R[p][k];
                 for (int k = 0; k < 4; ++k) qp[k] = sh_pq[p][4 + k];
@@ -310,6 +337,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 for (int k = 0; k < 3; ++k) { sh_pq[lane][k] = pw[k]; sh_R[lane][9 + k] = r[k]; }
                 for (int k = 0; k < 4; ++k) sh_pq[lane][4 + k] = qw[k];
                 for (int k = 0; k < 9; ++k) sh_R[lane][k] = R[k];
+                for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) sh_Sl[lane][c * 3 + k] = Sl[c][k];   // read by every later pass of the substep
                 for (int k = 0; k < 6; ++k) { sh_V[lane][k] = V[k]; sh_Aacc[lane][k] = sh_Aacc[p][k] + cc[k]; }
             }
             __syncthreads();
@@ -323,29 +351,29 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         // are quadratic in the angular rates.
         if (!final_pass) {
             float w2 = 0.0f;
-            if (is_body) { const float *Vb = sh_V[lane]; w2 = fmaf(Vb[0], Vb[0], fmaf(Vb[1], Vb[1], Vb[2] * Vb[2])); }
+            if ((lane < NB)) { const float *Vb = sh_V[lane]; w2 = fmaf(Vb[0], Vb[0], fmaf(Vb[1], Vb[1], Vb[2] * Vb[2])); }
             for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(w2, off); w2 = o > w2 ? o : w2; }
             float wlim = EMLOCO_WH_MAX / h;
             if (prm.max_ang_vel < wlim) wlim = prm.max_ang_vel;
             if (w2 > wlim * wlim) {
                 const float sc = wlim / sqrtf(w2), sc2 = sc * sc;
                 float lm = 0.0f, lp[3] = {0.0f, 0.0f, 0.0f};
-                if (is_body) {
-                    float Rb[9], cm[3], cw[3], rc[3], wx[3], Vb[6];
+                if ((lane < NB)) {
+                    float Rb[9], cm[4], cw[3], rc[3], wx[3], Vb[6];
                     for (int k = 0; k < 9; ++k) Rb[k] = sh_R[lane][k];
-                    for (int k = 0; k < 3; ++k) cm[k] = d.com[mb0 * 3 + k];
+                    ld4(mdl, o_dyn + 4, cm);
                     for (int k = 0; k < 6; ++k) Vb[k] = sh_V[lane][k];
                     matvec3(Rb, cm, cw);
                     for (int k = 0; k < 3; ++k) rc[k] = sh_R[lane][9 + k] + cw[k];
                     cross3(Vb, rc, wx);
-                    lm = d.mass[mb0];
+                    lm = jm[3];
                     for (int k = 0; k < 3; ++k) lp[k] = lm * (Vb[3 + k] + wx[k]);
                 }
                 const float M = wave_sum(lm);
                 float v0[3], v0n[3];
                 for (int k = 0; k < 3; ++k) { v0[k] = sh_root[10 + k]; v0n[k] = v0[k] + (1.0f - sc) * (wave_sum(lp[k]) / M - v0[k]); }
                 __syncthreads();
-                if (is_body) {
+                if ((lane < NB)) {
                     for (int k = 0; k < 3; ++k) { sh_V[lane][k] *= sc; sh_V[lane][3 + k] = v0n[k] + sc * (sh_V[lane][3 + k] - v0[k]); }
                     for (int k = 0; k < 6; ++k) sh_Aacc[lane][k] *= sc2;
                     if (lane >= 1) for (int k = 0; k < 3; ++k) wj[k] *= sc;
@@ -363,15 +391,15 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         // dv of the linear velocities.  The velocity-product accelerations see dv through v_i x S_i qd_i: + dv x (w_i - w_0).
         {
             float lm = 0.0f, lp[3] = {0.0f, 0.0f, 0.0f}, Vb[6] = {0, 0, 0, 0, 0, 0};
-            if (is_body) {
-                float Rb[9], cm[3], cw[3], rc[3], wx[3];
+            if ((lane < NB)) {
+                float Rb[9], cm[4], cw[3], rc[3], wx[3];
                 for (int k = 0; k < 9; ++k) Rb[k] = sh_R[lane][k];
-                for (int k = 0; k < 3; ++k) cm[k] = d.com[mb0 * 3 + k];
+                ld4(mdl, o_dyn + 4, cm);
                 for (int k = 0; k < 6; ++k) Vb[k] = sh_V[lane][k];
                 matvec3(Rb, cm, cw);
                 for (int k = 0; k < 3; ++k) rc[k] = sh_R[lane][9 + k] + cw[k];
                 cross3(Vb, rc, wx);
-                lm = d.mass[mb0];
+                lm = jm[3];
                 for (int k = 0; k < 3; ++k) lp[k] = lm * (Vb[3 + k] + wx[k]);
             }
             const float Mtot = wave_sum(lm);
@@ -380,7 +408,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             if (sub > 0) {                                       // wave-uniform: a balance exists from the previous substep
                 float dv[3];
                 for (int k = 0; k < 3; ++k) dv[k] = (sh_P[k] - Pact[k]) / Mtot;
-                if (is_body) {
+                if ((lane < NB)) {
                     const float wr[3] = {Vb[0] - sh_V[0][0], Vb[1] - sh_V[0][1], Vb[2] - sh_V[0][2]};
                     float t[3];
                     cross3(dv, wr, t);
@@ -402,13 +430,14 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             float *sh_seg = sh_A;                                  // [NB][8]   (sh_A is free until the contact phase)
             float *sh_hitw = sh_A + NB * 8;                        // [MAXHITS][6] wrench on body i about O (body j gets the negative)
             int *sh_hitb = (int *)(sh_A + NB * 8 + EMLOCO_SC_MAXHITS * 6);   // [MAXHITS][2]
-            if (is_body) {
-                float R[9], r[3], ca[3], cb[3], pa[3], pb[3];
+            if ((lane < NB)) {
+                float R[9], r[3], ca[4], cb[4], pa[3], pb[3];
                 for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                for (int k = 0; k < 3; ++k) { r[k] = sh_R[lane][9 + k]; ca[k] = d.sc_cap_a[mb0 * 3 + k]; cb[k] = d.sc_cap_b[mb0 * 3 + k]; }
+                for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
+                ld4(mdl, EMLOCO_MB_CAP + lane * 8, ca); ld4(mdl, EMLOCO_MB_CAP + lane * 8 + 4, cb);     // end a xyz, radius | end b xyz
                 matvec3(R, ca, pa); matvec3(R, cb, pb);
                 for (int k = 0; k < 3; ++k) { sh_seg[lane * 8 + k] = r[k] + pa[k]; sh_seg[lane * 8 + 3 + k] = r[k] + pb[k]; }
-                sh_seg[lane * 8 + 6] = d.sc_cap_r[mb0];
+                sh_seg[lane * 8 + 6] = ca[3];
                 const float ax[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
                 sh_seg[lane * 8 + 7] = 0.5f * sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);      // half length of the capsule's segment
             }
@@ -423,7 +452,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 const int q = q0 + lane;
                 bool keep = false;
                 if (q < d.sc_n) {
-                    const int bi = d.sc_pairs[2 * q], bj = d.sc_pairs[2 * q + 1];
+                    const int pr = topo[EMLOCO_TOPO_SCPAIR + q], bi = pr & 0xff, bj = pr >> 8;
                     float dm2 = 0.0f;
                     for (int k = 0; k < 3; ++k) {
                         const float dm = (sh_seg[bi * 8 + k] + sh_seg[bi * 8 + 3 + k]) - (sh_seg[bj * 8 + k] + sh_seg[bj * 8 + 3 + k]);   // 2 (m_i - m_j)
@@ -444,7 +473,8 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 float w6[6] = {0, 0, 0, 0, 0, 0};
                 int bi = 0, bj = 0;
                 if (q < d.sc_n) {
-                    bi = d.sc_pairs[2 * q]; bj = d.sc_pairs[2 * q + 1];
+                    const int pr = topo[EMLOCO_TOPO_SCPAIR + q];
+                    bi = pr & 0xff; bj = pr >> 8;
                     float p0[3], p1[3], g0[3], g1[3], c1[3], c2[3];
                     for (int k = 0; k < 3; ++k) { p0[k] = sh_seg[bi * 8 + k]; p1[k] = sh_seg[bi * 8 + 3 + k]; g0[k] = sh_seg[bj * 8 + k]; g1[k] = sh_seg[bj * 8 + 3 + k]; }
                     const float rsum = sh_seg[bi * 8 + 6] + sh_seg[bj * 8 + 6];
@@ -493,7 +523,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             }
             if (nh > EMLOCO_SC_MAXHITS) nh = EMLOCO_SC_MAXHITS;
             __syncthreads();
-            if (is_body) {
+            if ((lane < NB)) {
                 float fe[6] = {0, 0, 0, 0, 0, 0};
                 for (int hh = 0; hh < nh; ++hh) {
                     const int bi = sh_hitb[hh * 2], bj = sh_hitb[hh * 2 + 1];
@@ -507,15 +537,15 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
 
         PSTAMP(1);
         // ============================================================ 2. inertia about O, bias force, drive
-        if (is_body) {
+        if ((lane < NB)) {
             float I6[21], f[6], R[9], r[3], V[6];
             for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
             for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
             for (int k = 0; k < 6; ++k) V[k] = sh_V[lane][k];
-            float Rc[9], Ic[9], cw[3], c[3], in6[6], bcom[3];
-            for (int k = 0; k < 6; ++k) in6[k] = d.inertia[mb0 * 6 + k];      // mass properties: re-read per substep (L2 hits)
-            for (int k = 0; k < 3; ++k) bcom[k] = d.com[mb0 * 3 + k];
-            const float bmass = d.mass[mb0];
+            float Rc[9], Ic[9], cw[3], c[3], in6[8], bcom[4];
+            ld4(mdl, o_dyn + 8, in6); ld4(mdl, o_dyn + 12, in6 + 4);            // mass properties: re-read per substep (L2 hits)
+            ld4(mdl, o_dyn + 4, bcom);
+            const float bmass = jm[3];
             const float Ib[9] = {in6[0], in6[3], in6[4], in6[3], in6[1], in6[5], in6[4], in6[5], in6[2]};
             for (int a = 0; a < 3; ++a)
                 for (int q = 0; q < 3; ++q) Rc[a * 3 + q] = SOP3(R[a * 3], Ib[q], R[a * 3 + 1], Ib[3 + q], R[a * 3 + 2], Ib[6 + q]);
@@ -553,8 +583,10 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             for (int k = 0; k < 6; ++k) sh_f[lane][k] = f[k];
             // implicit PD drive: tau~ = kp (q* - q) - (kd + h kp) qd, joint-space diagonal d = armature + h kd + h^2 kp
             for (int k = 0; k < 3; ++k) {
-                const float kp = lane >= 1 ? d.kp[dof0 + k] : 0.0f, kd = lane >= 1 ? d.kd[dof0 + k] : 0.0f;
-                const float arm = lane >= 1 ? d.armature[dof0 + k] : 0.0f, tgt = lane >= 1 ? d.pd_target[dof0 + k] : 0.0f;
+                float dr[4];                                     // kp, kd, armature, effort limit of this dof
+                ld4(mdl, o_drv + 4 * k, dr);
+                const float kp = lane >= 1 ? dr[0] : 0.0f, kd = lane >= 1 ? dr[1] : 0.0f;
+                const float arm = lane >= 1 ? dr[2] : 0.0f, tgt = lane >= 1 ? tgt_env[jdof + k] : 0.0f;
                 const float e = tgt - edof[k];
                 sat[k] = false; tau[k] = kp * e - (kd + h * kp) * wj[k]; dd[k] = arm + h * kd + h * h * kp;
             }
@@ -567,18 +599,18 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         float pA[6];
         for (int pass = 0; pass < 2; ++pass) {
         // ============================================================ 3. articulated-body factorisation + up pass (leaves -> root)
+        const int pd3 = sh_pd[lane < NB ? lane : 0];
         for (int lev = d.max_depth; lev >= 0; --lev) {
-            if (is_body && bc.depth == lev) {
+            if ((lane < NB) && PD_DEPTH(pd3) == lev) {
                 float IA[21], Wm[18], Km[6];
-                float R[9], r[3], Sl[3][3];
+                float R[9], Sl[3][3];
                 for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
-                for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
+                for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) Sl[c][k] = sh_Sl[lane][c * 3 + k];
                 for (int k = 0; k < 21; ++k) IA[k] = sh_I6[lane][k];
                 for (int k = 0; k < 6; ++k) pA[k] = sh_f[lane][k];
                 for (int ci = 0; ci < 3; ++ci) {     // children in descending body index
-                    const int ch = bc.child[ci];
-                    if (ch >= 0) {
+                    const int ch = PD_CHILD(pd3, ci);
+                    if (ch != 31) {
                         for (int k = 0; k < 21; ++k) IA[k] += sh_Ia[ch][k];
                         for (int k = 0; k < 6; ++k) pA[k] += sh_pa[ch][k];
                     }
@@ -658,16 +690,16 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
 
         PSTAMP(3);
         // ============================================================ 4. down pass: joint accelerations, v_free
+        const int pd4 = sh_pd[lane < NB ? lane : 0];
         for (int lev = 1; lev <= d.max_depth; ++lev) {
-            if (is_body && bc.depth == lev) {
+            if ((lane < NB) && PD_DEPTH(pd4) == lev) {
                 float ap[6], t[3], a[6], Wm[18], Km[6];
-                float R[9], r[3], Sl[3][3];
+                float R[9], Sl[3][3];
                 for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
-                for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
+                for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) Sl[c][k] = sh_Sl[lane][c * 3 + k];
                 for (int k = 0; k < 18; ++k) Wm[k] = sh_W[lane][k];
                 for (int k = 0; k < 6; ++k) Km[k] = sh_K[lane][k];
-                for (int k = 0; k < 6; ++k) ap[k] = sh_a[bc.parent][k];
+                for (int k = 0; k < 6; ++k) ap[k] = sh_a[PD_PARENT(pd4)][k];
                 for (int c = 0; c < 3; ++c) {
                     float acc = 0.0f;
                     for (int k = 0; k < 6; ++k) acc = fmaf(Wm[k * 3 + c], ap[k], acc);
@@ -686,16 +718,18 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         }
         if (pass == 0) {
             bool over = false;
-            if (is_body && lane >= 1)
+            if ((lane < NB) && lane >= 1)
                 for (int k = 0; k < 3; ++k) {
-                    const float kp = d.kp[dof0 + k], kd = d.kd[dof0 + k], eff = d.effort[dof0 + k];
+                    float dr[4];
+                    ld4(mdl, o_drv + 4 * k, dr);
+                    const float kp = dr[0], kd = dr[1], eff = dr[3];
                     const float ti = tau[k] - (h * kd + h * h * kp) * qdd[k];
-                    if (fabsf(ti) > eff) { sat[k] = true; tau[k] = ti > 0.0f ? eff : -eff; dd[k] = d.armature[dof0 + k]; over = true; }
+                    if (fabsf(ti) > eff) { sat[k] = true; tau[k] = ti > 0.0f ? eff : -eff; dd[k] = dr[2]; over = true; }
                 }
             if (__ballot(over) == 0ull) break;
         }
         }   // pass
-        if (is_body) {
+        if ((lane < NB)) {
             for (int k = 0; k < 6; ++k) sh_Vf[lane][k] = fmaf(h, sh_a[lane][k], sh_V[lane][k]);
             if (lane == 0) for (int k = 0; k < 6; ++k) { sh_V0[k] = fmaf(h, sh_a[0][k], sh_root[7 + k]); sh_V0[6 + k] = 0.0f; }
         }
@@ -709,11 +743,10 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             const int c = lane + 64 * s;
             cb[s] = -1; crad[s] = 0.0f; clp[s][0] = clp[s][1] = clp[s][2] = 0.0f;
             if (c < d.n_cand) {
-                const int body = d.cand_body[c], k = d.cand_k[c];
-                const long mb = (long)env * NB + body;
-                const float *ga = d.geom_a + mb * 3, *gb = d.geom_b + mb * 3;
-                const int gt = d.geom_type[body];
-                cb[s] = body; crad[s] = d.geom_r[mb];
+                const int cp = topo[EMLOCO_TOPO_CAND + c], body = cp & 0xff, k = (cp >> 8) & 0xff, gt = cp >> 16;
+                float ga[4], gb[4];                              // geom a xyz, radius | geom b xyz
+                ld4(mdl, EMLOCO_MB_GEO + body * 8, ga); ld4(mdl, EMLOCO_MB_GEO + body * 8 + 4, gb);
+                cb[s] = body; crad[s] = ga[3];
                 if (gt == EMLOCO_GEOM_SPHERE) { clp[s][0] = ga[0]; clp[s][1] = ga[1]; clp[s][2] = ga[2]; }
                 else if (gt == EMLOCO_GEOM_CAPSULE) {
                     const float *src = k == 0 ? ga : gb;
@@ -771,7 +804,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             const int c = lane + 64 * s;
             if (act[s]) {
                 if (sub == 0) {
-                    for (int k = 0; k < 3; ++k) wl[s][k] = d.lambda_ws[(long)env * MAXCAND * 3 + c * 3 + k];
+                    for (int k = 0; k < 3; ++k) wl[s][k] = lws_env[c * 3 + k];
                 } else {
                     const int os = sh_slot[c];
                     if (os != 255) for (int k = 0; k < 3; ++k) wl[s][k] = sh_lam[3 * os + k];
@@ -810,7 +843,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         float ys[YLEN];                                   // this row's chain-propagation vector (level-indexed: the compiler keeps it in
                                                           // scratch); entries beyond the row's own chain are never written NOR read
         // contacts come out of the compaction sorted by body (the candidate list is body-major): first / last contact of a body
-        if (is_body) { sh_crange[lane] = 0; sh_crange[NB + lane] = -1; }
+        if ((lane < NB)) { sh_crange[lane] = 0; sh_crange[NB + lane] = -1; }
         __syncthreads();
         if (lane < nc) {
             const int cb_ = sh_cbody[lane];
@@ -839,7 +872,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             }
             rhs = vel + bias;
             for (int k = 0; k < 6; ++k) p[k] = -J[k];
-            rdep = (sh_pd[rbody] >> 8) & 0xff;
+            rdep = PD_DEPTH(sh_pd[rbody]);
         }
         // chain propagation, one tree level per (statically unrolled) step from the deepest level up: a row takes part from the
         // level of its own body on; `ci` is its chain body at the current level.  The level index is static, so ys[] stays in
@@ -854,22 +887,20 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 if (lev < dmax) {
                     if (lane < nr && lev < rdep) {
                         const int i = ci;
-                        float Ri[9], ri[3], u[3], uhh[3];
+                        float Ri[9], u[3], uhh[3];
                         for (int k = 0; k < 9; ++k) Ri[k] = sh_R[i][k];
-                        for (int k = 0; k < 3; ++k) ri[k] = sh_R[i][9 + k];
                         for (int a = 0; a < 3; ++a) {
-                            float ax[3] = {Ri[a], Ri[3 + a], Ri[6 + a]}, sl[3];
-                            cross3(ri, ax, sl);
-                            const float Sa[6] = {ax[0], ax[1], ax[2], sl[0], sl[1], sl[2]};
+                            const float *sl = sh_Sl[i] + 3 * a;
+                            const float Sa[6] = {Ri[a], Ri[3 + a], Ri[6 + a], sl[0], sl[1], sl[2]};
                             u[a] = -dot6(Sa, p);
                         }
                         const float *K = sh_K[i], *W = sh_W[i];
                         uhh[0] = K[0] * u[0]; uhh[1] = SOP2(K[1], u[0], K[2], u[1]); uhh[2] = SOP3(K[3], u[0], K[4], u[1], K[5], u[2]);
                         const int pdi = sh_pd[i];
-                        code |= (unsigned)(((pdi >> 16) & 0xff) + 1) << (3 * lev);
+                        code |= (unsigned)(PD_SLOT(pdi) + 1) << (3 * lev);
                         ys[6 + 3 * lev] = uhh[0]; ys[6 + 3 * lev + 1] = uhh[1]; ys[6 + 3 * lev + 2] = uhh[2];
                         for (int k = 0; k < 6; ++k) p[k] = ADD_SOP3(p[k], W[k * 3], uhh[0], W[k * 3 + 1], uhh[1], W[k * 3 + 2], uhh[2]);
-                        ci = pdi & 0xff;
+                        ci = PD_PARENT(pdi);
                     }
                 }
             }
@@ -1029,8 +1060,8 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         PSTAMP(8);
         // ============================================================ 7. impulses -> velocity change (second solve)
         float dq[3] = {0, 0, 0};
-        if (is_body && last && nc == 0)
-            for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = 0.0f;
+        if ((lane < NB) && last && nc == 0)
+            for (int k = 0; k < 3; ++k) cf_env[lane * 3 + k] = 0.0f;
         if (nc > 0) {
             // every row's lane stages its Jacobian row (and, in the last substep, its share of the reported contact force)
             // in the matrix's LDS, which is dead by now; a body then adds up its rows in contact order with one fma chain
@@ -1046,7 +1077,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             }
             __syncthreads();
             float pin[6] = {0, 0, 0, 0, 0, 0};
-            if (is_body) {
+            if ((lane < NB)) {
                 float cf[3] = {0, 0, 0};
                 const int r_end = 3 * sh_crange[NB + lane] + 3;
                 for (int r = 3 * sh_crange[lane]; r < r_end; ++r) {
@@ -1054,25 +1085,25 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                     for (int k = 0; k < 6; ++k) pin[k] = fmaf(-sh_row[r][k], l, pin[k]);
                     if (last) for (int k = 0; k < 3; ++k) cf[k] += sh_row[r][6 + k];
                 }
-                if (last) for (int k = 0; k < 3; ++k) d.contact_force[((long)env * NB + lane) * 3 + k] = cf[k];
+                if (last) for (int k = 0; k < 3; ++k) cf_env[lane * 3 + k] = cf[k];
             }
             // bodies deeper than every contact body carry no impulse and have no loaded descendant: their share of the up pass
             // is exactly zero (uh = +0, pa = +0), so the pass starts at the deepest contact level
-            if (is_body && bc.depth > dmax) { uh[0] = uh[1] = uh[2] = 0.0f; for (int k = 0; k < 6; ++k) sh_pa[lane][k] = 0.0f; }
+            const int pd7 = sh_pd[lane < NB ? lane : 0];
+            if ((lane < NB) && PD_DEPTH(pd7) > dmax) { uh[0] = uh[1] = uh[2] = 0.0f; for (int k = 0; k < 6; ++k) sh_pa[lane][k] = 0.0f; }
             __syncthreads();
             for (int lev = (d.max_depth < dmax ? d.max_depth : dmax); lev >= 0; --lev) {
-                if (is_body && bc.depth == lev) {
+                if ((lane < NB) && PD_DEPTH(pd7) == lev) {
                     for (int k = 0; k < 6; ++k) pA[k] = pin[k];
                     for (int ci = 0; ci < 3; ++ci) {
-                        const int ch = bc.child[ci];
-                        if (ch >= 0) for (int k = 0; k < 6; ++k) pA[k] += sh_pa[ch][k];
+                        const int ch = PD_CHILD(pd7, ci);
+                        if (ch != 31) for (int k = 0; k < 6; ++k) pA[k] += sh_pa[ch][k];
                     }
                     if (lev > 0) {
                         float u[3], Wm[18], Km[6];
-                        float R[9], r[3], Sl[3][3];
+                        float R[9], Sl[3][3];
                         for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                        for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
-                        for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
+                        for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) Sl[c][k] = sh_Sl[lane][c * 3 + k];
                         for (int k = 0; k < 18; ++k) Wm[k] = sh_W[lane][k];
                         for (int k = 0; k < 6; ++k) Km[k] = sh_K[lane][k];
                         for (int c = 0; c < 3; ++c) {
@@ -1102,15 +1133,14 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 __syncthreads();
             }
             for (int lev = 1; lev <= d.max_depth; ++lev) {
-                if (is_body && bc.depth == lev) {
+                if ((lane < NB) && PD_DEPTH(pd7) == lev) {
                     float ap[6], t[3], a[6], Wm[18], Km[6];
-                    float R[9], r[3], Sl[3][3];
+                    float R[9], Sl[3][3];
                     for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                    for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
-                    for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
+                    for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) Sl[c][k] = sh_Sl[lane][c * 3 + k];
                     for (int k = 0; k < 18; ++k) Wm[k] = sh_W[lane][k];
                     for (int k = 0; k < 6; ++k) Km[k] = sh_K[lane][k];
-                    for (int k = 0; k < 6; ++k) ap[k] = sh_a[bc.parent][k];
+                    for (int k = 0; k < 6; ++k) ap[k] = sh_a[PD_PARENT(pd7)][k];
                     for (int c = 0; c < 3; ++c) {
                         float acc = 0.0f;
                         for (int k = 0; k < 6; ++k) acc = fmaf(Wm[k * 3 + c], ap[k], acc);
@@ -1144,17 +1174,19 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         PSTAMP(9);
         // ============================================================ 8. integrate
         const float damp = 1.0f / (1.0f + h * prm.ang_damping);
-        if (is_body && lane >= 1) {
+        if ((lane < NB) && lane >= 1) {
             float wn[3];
             for (int k = 0; k < 3; ++k) {
                 wn[k] = fmaf(h, qdd[k], wj[k]) + dq[k];      // free joint rate of phase 4 + the impulses' share
                 if (last) {
-                    const float kpk = d.kp[dof0 + k], kdk = d.kd[dof0 + k], tgk = d.pd_target[dof0 + k];
+                    float dr[4];
+                    ld4(mdl, o_drv + 4 * k, dr);
+                    const float kpk = dr[0], kdk = dr[1], tgk = tgt_env[jdof + k];
                     // torque applied over this substep (the contact impulses moved the implicit drive along; reported within the limit)
-                    const float effk = d.effort[dof0 + k];
+                    const float effk = dr[3];
                     float tq = sat[k] ? tau[k] : kpk * (tgk - edof[k] - h * wn[k]) - kdk * wn[k];
                     tq = tq > effk ? effk : (tq < -effk ? -effk : tq);
-                    d.dof_force[(long)env * NDOF + (lane - 1) * 3 + k] = tq;
+                    d.dof_force[(size_t)env * NDOF + jdof + k] = tq;
                 }
                 wj[k] = wn[k] * damp;
             }
@@ -1190,7 +1222,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     }
 
     if (part < n_parts - 1) {         // hand over to the next part (see above) and publish
-        if (is_body) {
+        if ((lane < NB)) {
             float *ps = pst + lane * 4;
             part_st16(ps, qj[0], qj[1], qj[2], qj[3]);
             part_st16(ps + 4 * NB, wj[0], wj[1], wj[2], edof[0]);
@@ -1207,8 +1239,8 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         return;
     }
     // ---------------------------------------------------------------- write back (state after the final kinematics pass)
-    if (is_body) {
-        float *o = d.rb_state + ((long)env * NB + lane) * 13;
+    if ((lane < NB)) {
+        float *o = d.rb_state + (size_t)env * NB * 13 + lane * 13;
         float t[3], V[6], r[3];
         for (int k = 0; k < 6; ++k) V[k] = sh_V[lane][k];
         for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
@@ -1216,7 +1248,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         for (int k = 0; k < 3; ++k) { o[k] = sh_pq[lane][k]; o[7 + k] = V[3 + k] + t[k]; o[10 + k] = V[k]; }
         for (int k = 0; k < 4; ++k) o[3 + k] = sh_pq[lane][4 + k];
         if (lane >= 1) {
-            float *ds = d.dof_state + ((long)env * NDOF + (lane - 1) * 3) * 2;
+            float *ds = dofs_env + jdof * 2;
             for (int k = 0; k < 3; ++k) { ds[2 * k] = edof[k]; ds[2 * k + 1] = wj[k]; }
         }
     }
@@ -1229,10 +1261,13 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         const int c = lane + 64 * s;
         if (c < MAXCAND) {
             const int os = sh_slot[c];
-            for (int k = 0; k < 3; ++k) d.lambda_ws[(long)env * MAXCAND * 3 + c * 3 + k] = os != 255 ? sh_lam[3 * os + k] : 0.0f;
+            for (int k = 0; k < 3; ++k) lws_env[c * 3 + k] = os != 255 ? sh_lam[3 * os + k] : 0.0f;
         }
     }
 }
+#undef o_dyn
+#undef jdof
+#undef o_drv
 
 // The step of every env (one workgroup = one wave per env).  Subset launches (emloco_sim_step_subset): with skip flags the
 // workgroups of the flagged envs leave at once; with a device-compacted id list (valid ids first, -1 after them) workgroup
@@ -1247,6 +1282,7 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
     int env = d.step_order ? d.step_order[slot] : slot;
     if (d.step_ids) { env = d.step_ids[slot]; if (env < 0) return; }   // list launch: workgroup i steps list entry i (-1: padding)
     if (d.step_skip && d.step_skip[env] != 0) return;            // flagged envs are stepped elsewhere
+    env = __builtin_amdgcn_readfirstlane(env);                   // workgroup-uniform: the env's bases live in scalar registers
     const long long t0 = d.step_start ? (long long)wall_clock64() : 0ll;
     int work;
     sim_step_env(prm, d, env, work, part, n_parts);
@@ -1305,12 +1341,11 @@ sim_fk_kernel(EmlocoSimDev d, const int *env_ids, int n_ids) {
     const int env = env_ids ? env_ids[bi] : bi;
     if (env < 0) break;
     __shared__ float sh_pw[NB][3], sh_qw[NB][4], sh_R[NB][9], sh_V[NB][6];
-    const bool is_body = lane < NB;
-    const int b = is_body ? lane : 0;
-    const int parent = d.parent[b], depth = d.depth[b];
+    const int b = (lane < NB) ? lane : 0;
+    const int parent = d.topo[EMLOCO_TOPO_PARENT + b], depth = d.topo[EMLOCO_TOPO_DEPTH + b];
     float off[3], qj[4] = {0, 0, 0, 1}, wj[3] = {0, 0, 0}, V[6] = {0, 0, 0, 0, 0, 0}, r[3] = {0, 0, 0};
-    for (int k = 0; k < 3; ++k) off[k] = d.joint_off[((long)env * NB + b) * 3 + k];
-    if (is_body && lane >= 1) {
+    for (int k = 0; k < 3; ++k) off[k] = d.model[(size_t)env * EMLOCO_MODEL_WORDS + EMLOCO_MB_DYN + b * 16 + k];
+    if ((lane < NB) && lane >= 1) {
         const float *ds = d.dof_state + ((long)env * NDOF + (lane - 1) * 3) * 2;
         float e[3] = {ds[0], ds[2], ds[4]};
         rotvec2quat(e, qj);
@@ -1329,7 +1364,7 @@ sim_fk_kernel(EmlocoSimDev d, const int *env_ids, int n_ids) {
     }
     __syncthreads();
     for (int lev = 1; lev <= d.max_depth; ++lev) {
-        if (is_body && depth == lev) {
+        if ((lane < NB) && depth == lev) {
             float Rp[9], o[3], qp[4], qw[4], pw[3], R[9];
             for (int k = 0; k < 9; ++k) Rp[k] = sh_R[parent][k];
             for (int k = 0; k < 4; ++k) qp[k] = sh_qw[parent][k];
@@ -1349,7 +1384,7 @@ sim_fk_kernel(EmlocoSimDev d, const int *env_ids, int n_ids) {
         }
         __syncthreads();
     }
-    if (is_body) {
+    if ((lane < NB)) {
         float *o = d.rb_state + ((long)env * NB + lane) * 13, t[3];
         cross3(V, r, t);
         for (int k = 0; k < 3; ++k) { o[k] = sh_pw[lane][k]; o[7 + k] = V[3 + k] + t[k]; o[10 + k] = V[k]; }

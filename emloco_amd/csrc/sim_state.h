@@ -34,12 +34,9 @@ struct EmlocoSim {
     int hf_nx = 0, hf_ny = 0;
     float hf_hs = 0.0f, hf_vs = 0.0f, hf_ox = 0.0f, hf_oy = 0.0f;
     DevBuf<short> d_hf;
-    DevBuf<unsigned char> d_sc_pairs;
-    DevBuf<float> d_sc_a, d_sc_b, d_sc_r;
     // device
-    DevBuf<int> d_parent, d_depth, d_children, d_gtype, d_cand_body, d_cand_k, d_pd_pack;
-    DevBuf<unsigned char> d_lca;
-    DevBuf<float> d_off, d_mass, d_com, d_inertia, d_ga, d_gb, d_gr, d_kp, d_kd, d_arm, d_eff;
+    DevBuf<int> d_topo;                        // EMLOCO_TOPO_* tables
+    DevBuf<float> d_model;                     // EMLOCO_MB_* records, one block per env
     DevBuf<float> d_root, d_dof, d_tgt, d_rb, d_cf, d_df, d_lws;
     EmlocoSimDev dev{};
     // cost-ordered dispatch of the full launch (emloco_sim_set_cost_order): per-env duration of the last step, env ids sorted by it

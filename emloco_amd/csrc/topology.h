@@ -11,7 +11,7 @@ namespace emloco {
 
 struct Topology {
     std::vector<int32_t> parent, depth, children, geom_type, cand_body, cand_k;
-    std::vector<int32_t> pd_pack;   // per body: parent (the root: 255) | depth << 8 | index among the bodies of its depth << 16
+    std::vector<int32_t> pd_pack;   // per body: parent (the root: 31) | depth << 5 | index among the bodies of its depth << 9 | children << 12, 17, 22 (31: none)
     std::vector<uint8_t> lca_depth;
     int max_depth = 0;
     int n_cand = 0;
@@ -42,7 +42,9 @@ struct Topology {
         for (int i = 0; i < nb; ++i) {
             int lslot = 0;
             for (int j = 0; j < i; ++j) lslot += depth[j] == depth[i];
-            pd_pack[i] = (parent[i] & 0xff) | (depth[i] << 8) | (lslot << 16);
+            if (lslot > 6) return false;                          // the Gram build keeps slot + 1 in three bits
+            pd_pack[i] = (parent[i] < 0 ? 31 : parent[i]) | (depth[i] << 5) | (lslot << 9);
+            for (int k = 0; k < 3; ++k) pd_pack[i] |= (children[i * 3 + k] < 0 ? 31 : children[i * 3 + k]) << (12 + 5 * k);
         }
         lca_depth.assign(nb * nb, 0);
         for (int a = 0; a < nb; ++a)

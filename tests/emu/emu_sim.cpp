@@ -5,6 +5,7 @@
 #include "hip/hip_runtime.h"
 #include "../../emloco_amd/csrc/sim_kernels.hip"
 #include "../../emloco_amd/csrc/topology.h"
+#include "../../emloco_amd/csrc/model_pack.h"
 
 static const EmlocoSelfCollisionDesc *g_sc = nullptr;      // set by emu_sim_set_self_collision for the next emu_sim_step calls
 extern "C" void emu_sim_set_self_collision(const EmlocoSelfCollisionDesc *sc) { g_sc = sc; }
@@ -22,18 +23,15 @@ extern "C" int emu_sim_step(const EmlocoSimParams *prm, const EmlocoModelDesc *m
     if (!t.build(m->parent, m->geom_type)) return -1;
     EmlocoSimDev d{};
     d.n_env = m->n_env; d.n_cand = t.n_cand; d.max_depth = t.max_depth;
-    d.parent = t.parent.data(); d.depth = t.depth.data(); d.children = t.children.data(); d.pd_pack = t.pd_pack.data();
-    d.geom_type = t.geom_type.data(); d.cand_body = t.cand_body.data(); d.cand_k = t.cand_k.data();
-    d.lca_depth = t.lca_depth.data();
-    d.joint_off = m->joint_off; d.mass = m->mass; d.com = m->com; d.inertia = m->inertia;
-    d.geom_a = m->geom_a; d.geom_b = m->geom_b; d.geom_r = m->geom_r;
-    d.kp = m->kp; d.kd = m->kd; d.armature = m->armature; d.effort = m->effort;
+    const bool sc_on = g_sc && g_sc->n_pairs > 0;
+    const std::vector<int32_t> topo = emloco::pack_topology(t, sc_on ? g_sc->pairs : nullptr, sc_on ? g_sc->n_pairs : 0);
+    const std::vector<float> mdl = emloco::pack_models(m->n_env, m->joint_off, m->mass, m->com, m->inertia, m->geom_a, m->geom_b, m->geom_r,
+                                                       m->kp, m->kd, m->armature, m->effort, sc_on ? g_sc->cap_a : nullptr,
+                                                       sc_on ? g_sc->cap_b : nullptr, sc_on ? g_sc->cap_r : nullptr);
+    d.topo = topo.data(); d.model = mdl.data();
     d.root_state = root_state; d.dof_state = dof_state; d.pd_target = pd_target;
     d.rb_state = rb_state; d.contact_force = contact_force; d.dof_force = dof_force; d.lambda_ws = lambda_ws;
-    if (g_sc && g_sc->n_pairs > 0) {
-        d.sc_n = g_sc->n_pairs; d.sc_pairs = g_sc->pairs; d.sc_cap_a = g_sc->cap_a; d.sc_cap_b = g_sc->cap_b; d.sc_cap_r = g_sc->cap_r;
-        d.sc_k = g_sc->k; d.sc_c = g_sc->c; d.sc_max_pen = g_sc->max_pen; d.sc_mu = g_sc->mu;
-    }
+    if (sc_on) { d.sc_n = g_sc->n_pairs; d.sc_k = g_sc->k; d.sc_c = g_sc->c; d.sc_max_pen = g_sc->max_pen; d.sc_mu = g_sc->mu; }
     if (g_hf.samples) {
         d.hf = g_hf.samples; d.hf_nx = g_hf.nx; d.hf_ny = g_hf.ny; d.hf_hs = g_hf.hs; d.hf_inv_hs = 1.0f / g_hf.hs; d.hf_vs = g_hf.vs;
         d.hf_ox = g_hf.ox; d.hf_oy = g_hf.oy;
@@ -60,8 +58,11 @@ extern "C" int emu_sim_fk(const EmlocoModelDesc *m, float *root_state, float *do
     if (!t.build(m->parent, m->geom_type)) return -1;
     EmlocoSimDev d{};
     d.n_env = m->n_env; d.n_cand = t.n_cand; d.max_depth = t.max_depth;
-    d.parent = t.parent.data(); d.depth = t.depth.data();
-    d.joint_off = m->joint_off; d.root_state = root_state; d.dof_state = dof_state; d.rb_state = rb_state;
+    const std::vector<int32_t> topo = emloco::pack_topology(t, nullptr, 0);
+    const std::vector<float> mdl = emloco::pack_models(m->n_env, m->joint_off, m->mass, m->com, m->inertia, m->geom_a, m->geom_b, m->geom_r,
+                                                       m->kp, m->kd, m->armature, m->effort, nullptr, nullptr, nullptr);
+    d.topo = topo.data(); d.model = mdl.data();
+    d.root_state = root_state; d.dof_state = dof_state; d.rb_state = rb_state;
     emu::launch((unsigned)m->n_env, 64, [&] { emloco::sim_fk_kernel(d, nullptr, m->n_env); });
     return 0;
 }
