@@ -147,53 +147,50 @@ __device__ __forceinline__ void hf_plane(const EmlocoSimDev &d, float cx, float 
 }
 
 #ifndef EMLOCO_SIM_WAVES_PER_SIMD
-#define EMLOCO_SIM_WAVES_PER_SIMD 2   /* register budget 256 per lane: two resident waves per SIMD (8 envs per CU) */
+#define EMLOCO_SIM_WAVES_PER_SIMD 3   /* register budget 168 per lane and 12.4 KB of LDS per env: three resident waves per SIMD, 12 envs per CU */
 #endif
 // one env's step: the body of both kernels below (one 64-lane wave)
 __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const EmlocoSimDev &d, const int env, int &work, const int part, const int n_parts) {
     int lane = threadIdx.x;                                   // redefined at every phase boundary (FRESH_LANE)
     work = 0;                                                 // contact work of this step: sum over substeps of (10 + contacts) where there are any
 
-    // ---------------------------------------------------------------- LDS: one blob, 16 KB per env (8 envs per CU need <= 20 KB)
+    // ---------------------------------------------------------------- LDS: one blob, 13.0 KB per env (12 envs per CU need <= 13.3 KB)
     // Every per-body row starts on a 16-byte boundary and is padded to a multiple of four words, so a lane moves its row with
     // ds_read_b128 / ds_write_b128 (R | r share a 12-word row; 6-vectors take 8 words, 21-word inertias 24, W 20).
     // Persistent part first, then the region G whose members are live in different phases of a substep:
     //   Ia (articulated inertias)   phase 3 only; its first 180 words hold the contact frames (height field) from phase 5 to 7
-    //   I6, f                       phase 2 -> 3          pa   phases 3 and 7        a    phases 3-4 and 7
+    //   pa   phases 3 and 7         a    phases 3-4 and 7
     //   V                           phase 1 -> end of 4   Vf   end of 4 -> 6a        Aacc phase 1 -> 2     fext phase 1b -> 2
-    //   pw                          phase 1 -> 5          qw   phase 1
-    // The contact matrix (1830 words, phases 6b-6c) lies over [Ia tail .. ], the limb-limb scratch (phase 1b) over
-    // [Ia tail .. a]; pw / qw stay out of both.  Barriers separate the phases.
-    enum { O_ROOT = 0, O_P = 16, O_V0 = 24, O_PD = 36, O_R = O_PD + NB, O_W = O_R + NB * 12, O_K = O_W + NB * 20,
-           O_SL = O_K + NB * 8, O_L0 = O_SL + NB * 12, O_CB = O_L0 + 44, O_CX = O_CB + 2 * MAXC, O_CDIST = O_CX + 3 * MAXC, O_LAM = O_CDIST + MAXC,
-           O_SLOT = O_LAM + MAXR, O_CRANGE = O_SLOT + 32, O_IA = O_CRANGE + 2 * NB, O_G = O_IA + 180,
-           O_I6 = O_IA + NB * 24, O_F = O_I6 + NB * 24, O_PA = O_F + NB * 8, O_A_ = O_PA + NB * 8, O_V = O_A_ + NB * 8,
+    //   pq (world position | quaternion)   phase 1 -> 5, and the final pass
+    // (body inertias and bias forces never reach LDS: phase 2b leaves them in the lane's registers for its level of phase 3.)
+    // The contact matrix (1830 words, phases 6b-6c: everything above is dead then) lies over [Ia tail .. pq] and 90 words
+    // past it, the staged Jacobian rows of phase 7 (720 words) over [Ia tail .. a] -- dead again before pa / a are written --
+    // and the limb-limb scratch (phase 1b) over [Ia tail .. a].  Barriers separate the phases.
+    enum { O_ROOT = 0, O_P = 16, O_V0 = 24, O_PD = 36, O_R = O_PD + NB, O_W = O_R + NB * 12,
+           O_L0 = O_W + NB * 24, O_CB = O_L0 + 44, O_CX = O_CB + MAXC / 4 + 3, O_CDIST = O_CX + 3 * MAXC, O_LAM = O_CDIST + MAXC,
+           O_SLOT = O_LAM + MAXR, O_CRANGE = O_SLOT + 32, O_IA = O_CRANGE + 2 * NB / 4, O_G = O_IA + 180,
+           O_PA = O_IA + NB * 24, O_A_ = O_PA + NB * 8, O_V = O_A_ + NB * 8,
            O_VF = O_V + NB * 8, O_AACC = O_VF + NB * 8, O_FEXT = O_AACC + NB * 8, O_PQ = O_FEXT + NB * 8,
-           LDS_WORDS = O_PQ + NB * 8 };
-    static_assert(O_R % 4 == 0 && O_W % 4 == 0 && O_K % 4 == 0 && O_SL % 4 == 0 && O_IA % 4 == 0 && O_I6 % 4 == 0 && O_F % 4 == 0 && O_PQ % 4 == 0, "rows must be 16-byte aligned");
-    static_assert(O_PQ - O_G >= MAXR * (MAXR + 1) / 2, "contact matrix does not fit its overlay");
+           LDS_WORDS = (O_PQ + NB * 8 > O_G + MAXR * (MAXR + 1) / 2) ? O_PQ + NB * 8 : O_G + MAXR * (MAXR + 1) / 2 };
+    static_assert(O_R % 4 == 0 && O_W % 4 == 0 && O_IA % 4 == 0 && O_PA % 4 == 0 && O_PQ % 4 == 0, "rows must be 16-byte aligned");
     static_assert(O_V - O_G >= NB * 8 + EMLOCO_SC_MAXHITS * 8 + 256, "limb-limb scratch does not fit its overlay");
-    static_assert(LDS_WORDS * 4 <= 20480, "LDS per env above 160 KiB / 8");
+    static_assert(LDS_WORDS * 4 <= 13312, "LDS per env above 160 KiB / 12 in 512-byte granules (three waves per SIMD, 12 envs per CU)");
     __shared__ __attribute__((aligned(16))) float lds[LDS_WORDS];
     float *sh_root = lds + O_ROOT;                            // p0[3] q0[4] V0[6]
     float *sh_V0 = lds + O_V0;                                // lane 0's hand-over between phases: free root twist [0..5], impulse change [6..11]
     float *sh_P = lds + O_P;                                  // linear momentum: expected [0..2], of the current substep [3..5]; total mass [6]
     int *sh_pd = (int *)(lds + O_PD);                         // per body: tree constants, packed (PD_PARENT / PD_DEPTH / PD_SLOT / PD_CHILD)
     float (*sh_R)[12] = (float (*)[12])(lds + O_R);           // rotation matrix [0..8] | position relative to O [9..11]
-    float (*sh_W)[20] = (float (*)[20])(lds + O_W);
-    float (*sh_K)[8] = (float (*)[8])(lds + O_K);
-    float (*sh_Sl)[12] = (float (*)[12])(lds + O_SL);         // linear part of the joint's motion subspace about O: r x (R e_c), c-major [c][k]
+    float (*sh_W)[24] = (float (*)[24])(lds + O_W);           // per joint: W = U K^T (6 x 3) [0..17] | K, the inverse Cholesky factor of D (packed lower) [18..23]
     float *sh_L0 = lds + O_L0, *sh_L0i = lds + O_L0 + 36;    // root Cholesky factor and 1 / its diagonal
-    int *sh_cbody = (int *)(lds + O_CB), *sh_ccand = (int *)(lds + O_CB + MAXC);
+    unsigned char *sh_cbody = (unsigned char *)(lds + O_CB);  // body of each contact (bytes)
     float (*sh_cx)[3] = (float (*)[3])(lds + O_CX);
     float *sh_cdist = lds + O_CDIST;
     float *sh_lam = lds + O_LAM;                              // per contact row: warm-start multiplier (6a), solved multiplier (after 6c)
-    int *sh_crange = (int *)(lds + O_CRANGE);                 // per body: first [0..NB) and last [NB..2NB) contact of the current substep
+    signed char *sh_crange = (signed char *)(lds + O_CRANGE); // per body (bytes): first [0..NB) and last [NB..2NB) contact of the current substep
     unsigned char *sh_slot = (unsigned char *)(lds + O_SLOT); // per candidate: its contact slot of the latest substep (255: none)
     float (*sh_Ia)[24] = (float (*)[24])(lds + O_IA);
     float (*sh_cdir)[9] = (float (*)[9])(lds + O_IA);        // contact frames [normal | tangent 1 | tangent 2] (height-field ground)
-    float (*sh_I6)[24] = (float (*)[24])(lds + O_I6);
-    float (*sh_f)[8] = (float (*)[8])(lds + O_F);
     float (*sh_pa)[8] = (float (*)[8])(lds + O_PA);
     float (*sh_a)[8] = (float (*)[8])(lds + O_A_);
     float (*sh_V)[8] = (float (*)[8])(lds + O_V);
@@ -337,7 +334,6 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 for (int k = 0; k < 3; ++k) { sh_pq[lane][k] = pw[k]; sh_R[lane][9 + k] = r[k]; }
                 for (int k = 0; k < 4; ++k) sh_pq[lane][4 + k] = qw[k];
                 for (int k = 0; k < 9; ++k) sh_R[lane][k] = R[k];
-                for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) sh_Sl[lane][c * 3 + k] = Sl[c][k];   // read by every later pass of the substep
                 for (int k = 0; k < 6; ++k) { sh_V[lane][k] = V[k]; sh_Aacc[lane][k] = sh_Aacc[p][k] + cc[k]; }
             }
             __syncthreads();
@@ -536,9 +532,57 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         }
 
         PSTAMP(1);
-        // ============================================================ 2. inertia about O, bias force, drive
+        // ============================================================ 2. drive
         if ((lane < NB)) {
-            float I6[21], f[6], R[9], r[3], V[6];
+            // implicit PD drive: tau~ = kp (q* - q) - (kd + h kp) qd, joint-space diagonal d = armature + h kd + h^2 kp
+            for (int k = 0; k < 3; ++k) {
+                float dr[4];                                     // kp, kd, armature, effort limit of this dof
+                ld4(mdl, o_drv + 4 * k, dr);
+                const float kp = lane >= 1 ? dr[0] : 0.0f, kd = lane >= 1 ? dr[1] : 0.0f;
+                const float arm = lane >= 1 ? dr[2] : 0.0f, tgt = lane >= 1 ? tgt_env[jdof + k] : 0.0f;
+                const float e = tgt - edof[k];
+                sat[k] = false; tau[k] = kp * e - (kd + h * kp) * wj[k]; dd[k] = arm + h * kd + h * h * kp;
+            }
+        }
+
+        PSTAMP(2);
+#if defined(EMLOCO_DUMMY_VALU) || defined(EMLOCO_DUMMY_LDS) || defined(EMLOCO_DUMMY_SALU)
+        {   // sensitivity probes (diagnostic builds only): extra instructions of one kind per substep, results discarded
+#ifdef EMLOCO_DUMMY_VALU
+            float z0 = h, z1 = h + 1.0f, z2 = h + 2.0f, z3 = h + 3.0f;
+            for (int i = 0; i < EMLOCO_DUMMY_VALU / 4; ++i)
+                asm volatile("v_fma_f32 %0, %0, %0, %1\n\tv_fma_f32 %1, %1, %1, %2\n\tv_fma_f32 %2, %2, %2, %3\n\tv_fma_f32 %3, %3, %3, %0"
+                             : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3));
+            if (z0 + z1 + z2 + z3 == 12345.678f) sh_V0[11] = z0;
+#endif
+#ifdef EMLOCO_DUMMY_LDS
+            part_f4 q0, q1, q2, q3;
+            const unsigned la = (unsigned)(lane & 15) * 48u + (unsigned)(O_R * 4);
+            for (int i = 0; i < EMLOCO_DUMMY_LDS / 4; ++i)
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                             : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3) : "v"(la) : "memory");
+            if (q0.x + q1.x + q2.x + q3.x == 12345.678f) sh_V0[11] = q0.x;
+#endif
+#ifdef EMLOCO_DUMMY_SALU
+            int c0 = sub, c1 = sub + 1;
+            for (int i = 0; i < EMLOCO_DUMMY_SALU / 4; ++i)
+                asm volatile("s_add_i32 %0, %0, %1\n\ts_xor_b32 %1, %1, %0\n\ts_add_i32 %0, %0, 7\n\ts_xor_b32 %1, %1, 5" : "+s"(c0), "+s"(c1));
+            if (c0 + c1 == 123456789) sh_V0[11] = 1.0f;
+#endif
+        }
+#endif
+        // Phases 3-4 run once with every drive implicit.  The torque such a drive delivers over the substep is
+        // tau~ - (h kd + h^2 kp) qdd; where that exceeds the effort limit the drive becomes a constant torque at the limit
+        // (no implicit terms) and the env repeats the two phases once (rare: wave-uniform branch per env).
+        float pA[6];
+        for (int pass = 0; pass < 2; ++pass) {
+        // ============================================================ 2b. inertia about O and bias force of every body (lane = body)
+        // They stay in this lane's registers until its level of the up pass below takes them over in place -- no trip through
+        // LDS (768 words per env, which is what let a third wave per SIMD in); the rare second pass recomputes them.
+        float IA[21];
+        for (int k = 0; k < 21; ++k) IA[k] = 0.0f;
+        if ((lane < NB)) {
+            float R[9], r[3], V[6];
             for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
             for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
             for (int k = 0; k < 6; ++k) V[k] = sh_V[lane][k];
@@ -558,56 +602,37 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             for (int k = 0; k < 3; ++k) c[k] = r[k] + cw[k];
             const float ms = bmass, cc = dot3(c, c);
             for (int a = 0; a < 3; ++a)
-                for (int q = a; q < 3; ++q) I6[sidx(a, q)] = Ic[a * 3 + q] + ms * ((a == q ? cc : 0.0f) - c[a] * c[q]);
+                for (int q = a; q < 3; ++q) IA[sidx(a, q)] = Ic[a * 3 + q] + ms * ((a == q ? cc : 0.0f) - c[a] * c[q]);
             const float cx[9] = {0.0f, -c[2], c[1], c[2], 0.0f, -c[0], -c[1], c[0], 0.0f};
             for (int a = 0; a < 3; ++a)
-                for (int q = 0; q < 3; ++q) I6[sidx(a, 3 + q)] = ms * cx[a * 3 + q];
+                for (int q = 0; q < 3; ++q) IA[sidx(a, 3 + q)] = ms * cx[a * 3 + q];
             for (int a = 0; a < 3; ++a)
-                for (int q = a; q < 3; ++q) I6[sidx(3 + a, 3 + q)] = (a == q) ? ms : 0.0f;
+                for (int q = a; q < 3; ++q) IA[sidx(3 + a, 3 + q)] = (a == q) ? ms : 0.0f;
             float Aa[6], hI[6], IAc[6], x1[3], x2[3];
             for (int k = 0; k < 6; ++k) Aa[k] = sh_Aacc[lane][k];
             for (int a = 0; a < 6; ++a) {
-                const float Ir[6] = {I6[sidx(a, 0)], I6[sidx(a, 1)], I6[sidx(a, 2)], I6[sidx(a, 3)], I6[sidx(a, 4)], I6[sidx(a, 5)]};
+                const float Ir[6] = {IA[sidx(a, 0)], IA[sidx(a, 1)], IA[sidx(a, 2)], IA[sidx(a, 3)], IA[sidx(a, 4)], IA[sidx(a, 5)]};
                 hI[a] = fdot6(Ir, V);
                 IAc[a] = fdot6(Ir, Aa);
             }
             cross3(V, hI, x1); cross3(V + 3, hI + 3, x2);
-            for (int k = 0; k < 3; ++k) f[k] = IAc[k] + x1[k] + x2[k];
+            for (int k = 0; k < 3; ++k) pA[k] = IAc[k] + x1[k] + x2[k];
             cross3(V, hI + 3, x1);
-            for (int k = 0; k < 3; ++k) f[3 + k] = IAc[3 + k] + x1[k];
+            for (int k = 0; k < 3; ++k) pA[3 + k] = IAc[3 + k] + x1[k];
             float fg[3] = {0.0f, 0.0f, ms * prm.gravity_z}, ng[3];
             cross3(c, fg, ng);
-            for (int k = 0; k < 3; ++k) { f[k] -= ng[k]; f[3 + k] -= fg[k]; }
-            if (d.sc_n > 0) for (int k = 0; k < 6; ++k) f[k] -= sh_fext[lane][k];     // external wrench: f -= [p x F ; F]
-            for (int k = 0; k < 21; ++k) sh_I6[lane][k] = I6[k];
-            for (int k = 0; k < 6; ++k) sh_f[lane][k] = f[k];
-            // implicit PD drive: tau~ = kp (q* - q) - (kd + h kp) qd, joint-space diagonal d = armature + h kd + h^2 kp
-            for (int k = 0; k < 3; ++k) {
-                float dr[4];                                     // kp, kd, armature, effort limit of this dof
-                ld4(mdl, o_drv + 4 * k, dr);
-                const float kp = lane >= 1 ? dr[0] : 0.0f, kd = lane >= 1 ? dr[1] : 0.0f;
-                const float arm = lane >= 1 ? dr[2] : 0.0f, tgt = lane >= 1 ? tgt_env[jdof + k] : 0.0f;
-                const float e = tgt - edof[k];
-                sat[k] = false; tau[k] = kp * e - (kd + h * kp) * wj[k]; dd[k] = arm + h * kd + h * h * kp;
-            }
+            for (int k = 0; k < 3; ++k) { pA[k] -= ng[k]; pA[3 + k] -= fg[k]; }
+            if (d.sc_n > 0) for (int k = 0; k < 6; ++k) pA[k] -= sh_fext[lane][k];     // external wrench: f -= [p x F ; F]
         }
-
-        PSTAMP(2);
-        // Phases 3-4 run once with every drive implicit.  The torque such a drive delivers over the substep is
-        // tau~ - (h kd + h^2 kp) qdd; where that exceeds the effort limit the drive becomes a constant torque at the limit
-        // (no implicit terms) and the env repeats the two phases once (rare: wave-uniform branch per env).
-        float pA[6];
-        for (int pass = 0; pass < 2; ++pass) {
         // ============================================================ 3. articulated-body factorisation + up pass (leaves -> root)
         const int pd3 = sh_pd[lane < NB ? lane : 0];
         for (int lev = d.max_depth; lev >= 0; --lev) {
             if ((lane < NB) && PD_DEPTH(pd3) == lev) {
-                float IA[21], Wm[18], Km[6];
-                float R[9], Sl[3][3];
+                float Wm[18], Km[6];
+                float R[9], r[3], Sl[3][3];
                 for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) Sl[c][k] = sh_Sl[lane][c * 3 + k];
-                for (int k = 0; k < 21; ++k) IA[k] = sh_I6[lane][k];
-                for (int k = 0; k < 6; ++k) pA[k] = sh_f[lane][k];
+                for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
+                for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
                 for (int ci = 0; ci < 3; ++ci) {     // children in descending body index
                     const int ch = PD_CHILD(pd3, ci);
                     if (ch != 31) {
@@ -655,7 +680,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                     for (int k = 0; k < 6; ++k)
                         sh_pa[lane][k] = ADD_SOP3(pA[k], Wm[k * 3], uh[0], Wm[k * 3 + 1], uh[1], Wm[k * 3 + 2], uh[2]);
                     for (int k = 0; k < 18; ++k) sh_W[lane][k] = Wm[k];
-                    for (int k = 0; k < 6; ++k) sh_K[lane][k] = Km[k];
+                    for (int k = 0; k < 6; ++k) sh_W[lane][18 + k] = Km[k];
                 } else {
                     // root: Cholesky of the 6x6 articulated inertia, a0 = -IA0^-1 pA0
                     float L[21], Li[6];    // lower triangle, (a, q<=a) at a(a+1)/2 + q; reciprocal pivots
@@ -694,11 +719,12 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         for (int lev = 1; lev <= d.max_depth; ++lev) {
             if ((lane < NB) && PD_DEPTH(pd4) == lev) {
                 float ap[6], t[3], a[6], Wm[18], Km[6];
-                float R[9], Sl[3][3];
+                float R[9], r[3], Sl[3][3];
                 for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) Sl[c][k] = sh_Sl[lane][c * 3 + k];
+                for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
+                for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
                 for (int k = 0; k < 18; ++k) Wm[k] = sh_W[lane][k];
-                for (int k = 0; k < 6; ++k) Km[k] = sh_K[lane][k];
+                for (int k = 0; k < 6; ++k) Km[k] = sh_W[lane][18 + k];
                 for (int k = 0; k < 6; ++k) ap[k] = sh_a[PD_PARENT(pd4)][k];
                 for (int c = 0; c < 3; ++c) {
                     float acc = 0.0f;
@@ -819,7 +845,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 const int ci = s == 0 ? i0 : i1;
                 sh_slot[lane + 64 * s] = act[s] ? (unsigned char)ci : (unsigned char)255;
                 if (act[s]) {
-                    sh_cbody[ci] = cb[s]; sh_ccand[ci] = lane + 64 * s; sh_cdist[ci] = cdist[s];
+                    sh_cbody[ci] = (unsigned char)cb[s]; sh_cdist[ci] = cdist[s];
                     for (int k = 0; k < 3; ++k) { sh_cx[ci][k] = cxw[s][k]; sh_lam[3 * ci + k] = wl[s][k]; }
                     if (hf_on) {      // frame: normal, t1 = (y x n) / |y x n|, t2 = n x t1  (n_z > 0 on a height field)
                         const float *n = cnrm[s];
@@ -847,8 +873,8 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         __syncthreads();
         if (lane < nc) {
             const int cb_ = sh_cbody[lane];
-            if (lane == 0 || sh_cbody[lane - 1] != cb_) sh_crange[cb_] = lane;
-            if (lane == nc - 1 || sh_cbody[lane + 1] != cb_) sh_crange[NB + cb_] = lane;
+            if (lane == 0 || sh_cbody[lane - 1] != cb_) sh_crange[cb_] = (signed char)lane;
+            if (lane == nc - 1 || sh_cbody[lane + 1] != cb_) sh_crange[NB + cb_] = (signed char)lane;
         }
         const int myc = lane / 3, myd = lane - 3 * myc;
         int rbody = 0, rdep = 0;
@@ -887,14 +913,16 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 if (lev < dmax) {
                     if (lane < nr && lev < rdep) {
                         const int i = ci;
-                        float Ri[9], u[3], uhh[3];
+                        float Ri[9], ri[3], u[3], uhh[3];
                         for (int k = 0; k < 9; ++k) Ri[k] = sh_R[i][k];
+                        for (int k = 0; k < 3; ++k) ri[k] = sh_R[i][9 + k];
                         for (int a = 0; a < 3; ++a) {
-                            const float *sl = sh_Sl[i] + 3 * a;
-                            const float Sa[6] = {Ri[a], Ri[3 + a], Ri[6 + a], sl[0], sl[1], sl[2]};
+                            float ax[3] = {Ri[a], Ri[3 + a], Ri[6 + a]}, sl[3];
+                            cross3(ri, ax, sl);
+                            const float Sa[6] = {ax[0], ax[1], ax[2], sl[0], sl[1], sl[2]};
                             u[a] = -dot6(Sa, p);
                         }
-                        const float *K = sh_K[i], *W = sh_W[i];
+                        const float *W = sh_W[i], *K = W + 18;
                         uhh[0] = K[0] * u[0]; uhh[1] = SOP2(K[1], u[0], K[2], u[1]); uhh[2] = SOP3(K[3], u[0], K[4], u[1], K[5], u[2]);
                         const int pdi = sh_pd[i];
                         code |= (unsigned)(PD_SLOT(pdi) + 1) << (3 * lev);
@@ -1087,6 +1115,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 }
                 if (last) for (int k = 0; k < 3; ++k) cf_env[lane * 3 + k] = cf[k];
             }
+            __syncthreads();                                       // the staged rows lie over pa / a, which are written from here on
             // bodies deeper than every contact body carry no impulse and have no loaded descendant: their share of the up pass
             // is exactly zero (uh = +0, pa = +0), so the pass starts at the deepest contact level
             const int pd7 = sh_pd[lane < NB ? lane : 0];
@@ -1101,11 +1130,12 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                     }
                     if (lev > 0) {
                         float u[3], Wm[18], Km[6];
-                        float R[9], Sl[3][3];
+                        float R[9], r[3], Sl[3][3];
                         for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                        for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) Sl[c][k] = sh_Sl[lane][c * 3 + k];
+                        for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
+                        for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
                         for (int k = 0; k < 18; ++k) Wm[k] = sh_W[lane][k];
-                        for (int k = 0; k < 6; ++k) Km[k] = sh_K[lane][k];
+                        for (int k = 0; k < 6; ++k) Km[k] = sh_W[lane][18 + k];
                         for (int c = 0; c < 3; ++c) {
                             const float Sc[6] = {R[c], R[3 + c], R[6 + c], Sl[c][0], Sl[c][1], Sl[c][2]};
                             u[c] = 0.0f - fdot6(Sc, pA);
@@ -1135,11 +1165,12 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             for (int lev = 1; lev <= d.max_depth; ++lev) {
                 if ((lane < NB) && PD_DEPTH(pd7) == lev) {
                     float ap[6], t[3], a[6], Wm[18], Km[6];
-                    float R[9], Sl[3][3];
+                    float R[9], r[3], Sl[3][3];
                     for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                    for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) Sl[c][k] = sh_Sl[lane][c * 3 + k];
+                    for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
+                    for (int c = 0; c < 3; ++c) { const float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
                     for (int k = 0; k < 18; ++k) Wm[k] = sh_W[lane][k];
-                    for (int k = 0; k < 6; ++k) Km[k] = sh_K[lane][k];
+                    for (int k = 0; k < 6; ++k) Km[k] = sh_W[lane][18 + k];
                     for (int k = 0; k < 6; ++k) ap[k] = sh_a[PD_PARENT(pd7)][k];
                     for (int c = 0; c < 3; ++c) {
                         float acc = 0.0f;
