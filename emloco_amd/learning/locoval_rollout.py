@@ -31,35 +31,16 @@ from .scheduler import CosineAnnealingLR
 from .value_pose_net import ValuePoseNet
 
 
-class ReturnAccumulator:
-    """Per-env discounted return of amp_continuous_value.py:93-118, as mask arithmetic on any device.
-
-    update() takes one step's (E,) task rewards (inversion penalty already applied), discriminator rewards and done flags and
-    returns what the reference adds to `game_combined_rewards` on that step: the discounted sum of an episode at the step it
-    ends if that is within `step_to_pred` control steps, or at step `step_to_pred` if it runs longer (later rewards of the
-    episode are accumulated but never emitted), zero elsewhere."""
+class _ReturnState:
+    """Device buffers of the per-env discounted return (amp_continuous_value.py:93-118): updated in place by
+    `locoval_returns_kernel` (csrc/predictor_kernels.hip).  The torch restatement of that arithmetic is test infrastructure
+    (oracle/locoval_returns.py), pinned by a fixture generated from the reference's own play_steps."""
 
     def __init__(self, num_envs, step_to_pred, gamma, device):
         z = lambda: torch.zeros(num_envs, device=device)
         self.step_to_pred, self.gamma = step_to_pred, gamma
         self.current_rewards, self.current_lengths, self.current_combined_rewards = z(), z(), z()
         self.discount_coefs = torch.ones(num_envs, device=device)
-
-    def update(self, rewards, amp_rewards, dones):
-        dones_b = dones.bool()
-        not_dones = 1.0 - dones_b.float()
-        self.current_rewards += rewards
-        self.current_lengths += 1
-        combined = rewards + amp_rewards                                                    # :96, unweighted
-        self.current_combined_rewards += combined * self.discount_coefs
-        done_early = torch.logical_and(self.current_lengths <= self.step_to_pred, dones_b)
-        over_pred = torch.logical_and(self.current_lengths == self.step_to_pred, ~dones_b)
-        emitted = self.current_combined_rewards * (done_early | over_pred).float()
-        self.current_combined_rewards = self.current_combined_rewards * not_dones
-        self.discount_coefs = torch.where(dones_b, torch.ones_like(self.discount_coefs), self.discount_coefs * self.gamma)
-        self.current_rewards = self.current_rewards * not_dones
-        self.current_lengths = self.current_lengths * not_dones
-        return emitted
 
 
 class LocoValRollout:
@@ -82,8 +63,7 @@ class LocoValRollout:
         self.valuenet = (valuenet if valuenet is not None else ValuePoseNet(use_pose=use_pose, use_vel=use_vel)).to(self.device)
         broadcast_parameters(self.valuenet)                                                # hvd.setup_algo, common_agent.py:165-166
         self.bucket = FlatGradBucket(self.valuenet.parameters(), extra=2)                  # tail: [loss sum, episode count]
-        # the fused step (three small HIP launches around the LocoVal kernels, include/emloco_predictor.h) when the network
-        # is the HIP one on a GPU; the torch formulation below it is the same arithmetic (CPU tests, other networks)
+        # the fused step: three small HIP launches around the LocoVal kernels (include/emloco_predictor.h)
         self.overlap_fit = bool(overlap_fit)
         if self.overlap_fit and hasattr(self.task, "overlap_obs") and getattr(self.task, "_fused_reset", False):
             self.task.overlap_obs = True           # this loop calls task.wait_obs() before the policy reads the observations
@@ -100,6 +80,9 @@ class LocoValRollout:
                 # stream it costs two cross-stream hand-overs (~13 us each, measured) around a 50 us launch the loop waits for
                 self.task.overlap_obs = os.environ.get("EMLOCO_OVERLAP_OBS", "0") == "1"
         self.fused = (isinstance(self.valuenet, ValuePoseNet) and self.device.type == "cuda") if fused is None else bool(fused)
+        if not self.fused and type(self)._bookkeeping is LocoValRollout._bookkeeping:
+            raise RuntimeError("LocoValRollout runs its bookkeeping and fit as HIP kernels: it needs libemloco_hip.so, a gfx950 device "
+                               "and the HIP ValuePoseNet (there is no CPU path in the product)")
         if self.fused:
             self._flat_params = torch.cat([p.detach().reshape(-1) for p in self.valuenet.parameters()]).contiguous()
             o = 0
@@ -109,7 +92,7 @@ class LocoValRollout:
         self.vnet_optimizer = GatedFlatAdamW(self.valuenet.parameters(), self.bucket.grads, lr=lr, weight_decay=weight_decay)
         self.vnet_scheduler = CosineAnnealingLR(self.vnet_optimizer, warmup_epochs=warmup_epochs, max_epochs=max_epochs)
         E = self.num_actors
-        self.acc = ReturnAccumulator(E, self.step_to_pred, gamma, self.device)
+        self.acc = self._make_return_state(E, self.step_to_pred, gamma, self.device)
         self.game_combined_rewards = torch.zeros(E, device=self.device)
         self.started = False
         self.frames = 0
@@ -127,7 +110,7 @@ class LocoValRollout:
                         x100=f(E, 100), h1=f(E, 49), h2=f(E, 24), ang=f(E), dtraj=f(E, 13, 3), ws=f(E * 6174), zeros=f(E),
                         steps=[f(1), f(1)], m=f(6174), v=f(6174), slot=torch.zeros(E, dtype=torch.int32, device=dev))
         z = self._fz
-        assert task.waypoint_traj.is_contiguous() and task.init_pose.is_contiguous() and task.init_vel.is_contiguous()
+        self._check_fused_inputs()
         p = lambda t: t.data_ptr()
         self._fstep = ops.LocoValStep(E, int(self.step_to_pred), float(self.gamma), float(self.inversion_penalty_scale),
                                       float(self.min_cum_rewards), float(self.max_cum_rewards), p(a.current_rewards), p(a.current_lengths),
@@ -141,6 +124,24 @@ class LocoValRollout:
         self._ev_staged = torch.cuda.Event() if self._side is not None else None
         self._ev_fit = torch.cuda.Event() if self._side is not None else None
         self._fit_pending = False
+
+    def _check_fused_inputs(self):
+        """The fused step keeps raw device pointers of the task's LocoVal inputs (the kernel hard-codes their strides: 15 x 3
+        waypoints, 24 x 3 joints, 2 velocity components per env): shape, dtype, device and -- from the second call on -- the
+        address must be what they were when the pointers were taken (a task that re-allocates them must rebuild the rollout)."""
+        task, E = self.task, self.num_actors
+        want = {"waypoint_traj": (E, 15, 3), "init_pose": (E, 24, 3), "init_vel": (E, 2)}
+        ptrs = []
+        for name, shape in want.items():
+            t = getattr(task, name)
+            if tuple(t.shape) != shape or t.dtype != torch.float32 or t.device.type != self.device.type or not t.is_contiguous():
+                raise RuntimeError(f"LocoValRollout: task.{name} must be a contiguous float32 {shape} tensor on {self.device}, got "
+                                   f"{tuple(t.shape)} {t.dtype} {t.device}")
+            ptrs.append(t.data_ptr())
+        if getattr(self, "_fused_ptrs", None) is None:
+            self._fused_ptrs = ptrs
+        elif ptrs != self._fused_ptrs:
+            raise RuntimeError("LocoValRollout: the task re-allocated waypoint_traj / init_pose / init_vel after the fused step took their addresses")
 
     def _sync_fit(self):
         """Host-side readers of what the fit writes (statistics, LocoVal weights) wait for the side stream."""
@@ -157,6 +158,7 @@ class LocoValRollout:
         st = current_stream_handle(self.device)
         P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         assert rewards.dtype == torch.float32 and dones.dtype == torch.int64 and inverted.dtype == torch.bool
+        self._check_fused_inputs()
         s = self._fstep
         s.inversion_penalty = float(self.inversion_penalty_scale)
         main = torch.cuda.current_stream(self.device) if self._side is not None else None
@@ -240,14 +242,16 @@ class LocoValRollout:
             self.frames += self.num_actors
             if not self._no_disc and hasattr(task, "wait_obs"):
                 task.wait_obs()                                   # the discriminator reads this step's AMP observations
-            if self.fused:
-                amp_rewards = None if self._no_disc else self.disc_reward(infos["amp_obs"]).contiguous()
-                self._fused_step(rewards, amp_rewards, dones, inverted)
-                return
-            rewards = torch.where(inverted, rewards * (-self.inversion_penalty_scale), rewards)      # :63-64
-            amp_rewards = self.disc_reward(infos["amp_obs"])
-            self.game_combined_rewards += self.acc.update(rewards, amp_rewards, dones)
-        self._fit()
+            amp_rewards = None if self._no_disc else self.disc_reward(infos["amp_obs"]).contiguous()
+        self._bookkeeping(rewards, amp_rewards, dones, inverted)
+
+    def _make_return_state(self, E, step_to_pred, gamma, device):
+        return _ReturnState(E, step_to_pred, gamma, device)
+
+    def _bookkeeping(self, rewards, amp_rewards, dones, inverted):
+        """The step's return accumulation and LocoVal fit: 6 HIP launches (the torch formulation of the same arithmetic lives
+        with the tests, oracle/locoval_returns.py: TorchLocoValRollout overrides this hook)."""
+        self._fused_step(rewards, amp_rewards, dones, inverted)
 
     def end_epoch(self):
         """common_agent.py:205-209: the cosine schedule advances once per epoch, once episodes have finished."""
@@ -261,32 +265,6 @@ class LocoValRollout:
             self.step_once()
         self.end_epoch()
         return self.vnet_loss
-
-    def _fit(self):
-        """:122-145 as a masked sum over all envs: identical to indexing the finished episodes, without reading their ids."""
-        env = self.env
-        valid = self.game_combined_rewards != 0
-        init_pose = env.get_init_pose().to(self.device)
-        waypoint_traj = env.get_waypoint_traj()[:, :13, :].contiguous().to(self.device)
-        init_vel = env.get_init_vel().to(self.device)
-        pred = self.valuenet(waypoint_traj, init_pose, init_vel).reshape(-1)
-        target = (self.game_combined_rewards - self.min_cum_rewards) / (self.max_cum_rewards - self.min_cum_rewards)
-        w = valid.float()
-        self.bucket.zero()
-        loss = (w * (pred - target) ** 2).sum()                                             # MSELoss(reduction='sum') on the valid rows
-        loss.backward()
-        with torch.no_grad():
-            self.bucket.tail[0] = loss.detach()
-            self.bucket.tail[1] = w.sum()
-            self.bucket.all_reduce(average=False)                                           # unconditional: one collective per step
-            tail = self.bucket.tail.double()
-            gate = tail[1] > 0.5
-            self.vnet_optimizer.step(gate)                                                  # committed on the device iff an episode finished
-            g = gate.double()
-            self._stats[0:2] = torch.where(gate, tail, self._stats[0:2])
-            self._stats[2:4] += tail * g
-            self._stats[4] += g
-            self.game_combined_rewards = torch.zeros_like(self.game_combined_rewards)
 
     # ------------------------------------------------------------------ checkpoints (common_agent.py:248-264, finetune branch)
     def save(self, model_output_file, epoch_num=None):

@@ -222,7 +222,7 @@ def test_two_rank_locoval_rollout_on_the_real_env_keeps_replicas_identical():
 
 def test_fused_locoval_step_equals_the_torch_formulation():
     """The fused rollout step (emloco_locoval_returns / _fit_grad / _adamw_gated around the LocoVal kernels) against the torch
-    formulation of the same loop (ReturnAccumulator + masked fit + GatedFlatAdamW), both on a scripted env on the GPU: after 300
+    formulation of the same loop (oracle/locoval_returns.py: ReturnAccumulator + masked fit + GatedFlatAdamW), both on a scripted env on the GPU: after 300
     steps with ~17 fits the LocoVal weights agree to 1e-5, the counters exactly."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -274,11 +274,12 @@ def test_fused_locoval_step_equals_the_torch_formulation():
 
     rewards, amp, done, inverted = script(E, H * EPOCHS)
     agents = []
-    for fused in (True, False):
+    from oracle.locoval_returns import TorchLocoValRollout
+    for cls in (LocoValRollout, TorchLocoValRollout):
         torch.manual_seed(21)
         env = GpuScripted(rewards, amp, done, inverted, np.arange(E))
-        ag = LocoValRollout(env, horizon_length=H, valuenet=ValuePoseNet(True, True, inplace_pose=False), disc_reward=lambda a: a,
-                            policy=lambda obs: torch.zeros(E, 69, device=dev), fused=fused)
+        ag = cls(env, horizon_length=H, valuenet=ValuePoseNet(True, True, inplace_pose=False), disc_reward=lambda a: a,
+                 policy=lambda obs: torch.zeros(E, 69, device=dev))
         for _ in range(EPOCHS):
             ag.play_steps()
         agents.append(ag)
@@ -290,6 +291,36 @@ def test_fused_locoval_step_equals_the_torch_formulation():
         assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), (p - q).abs().max()
     w0 = ValuePoseNet(True, True)
     assert any(not torch.equal(p.cpu(), q) for p, q in zip(a.valuenet.parameters(), w0.parameters()))
+
+
+def test_locoval_returns_kernel_matches_the_reference_play_steps():
+    """A17 through the C ABI on the device: emloco_locoval_returns over the 400 scripted steps of the fixture that the reference's
+    own AMPValueAgent.play_steps produced (tests/golden/gen_golden_a17.py) -- rows that enter the fit, their targets
+    (G + 10) / 110, and the running sums / discounts / lengths after every step, element for element."""
+    import ctypes as C
+    from emloco_amd.predictor import ops
+    from emloco_amd.sim import current_stream_handle
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "locoval_returns.npz"))
+    dev = torch.device("cuda", 0)
+    T, E = g["rewards"].shape
+    f = lambda *s: torch.zeros(*s, device=dev)
+    st = dict(cr=f(E), cl=f(E), cc=f(E), dc=torch.ones(E, device=dev), traj13=f(E, 13, 3), pose=f(E, 24, 3), vel=f(E, 2), target=f(E), weight=f(E))
+    wp, ip, iv = f(E, 15, 3), f(E, 24, 3), f(E, 2)
+    p = lambda t: t.data_ptr()
+    s = ops.LocoValStep(E, int(g["step_to_pred"]), float(g["gamma"]), float(g["penalty"]), float(g["min_cum"]), float(g["max_cum"]), p(st["cr"]),
+                        p(st["cl"]), p(st["cc"]), p(st["dc"]), p(wp), p(ip), p(iv), p(st["traj13"]), p(st["pose"]), p(st["vel"]), p(st["target"]), p(st["weight"]))
+    lib = ops._lib()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    for t in range(T):
+        r, a = torch.from_numpy(g["rewards"][t]).to(dev), torch.from_numpy(g["amp"][t]).to(dev)
+        d, inv = torch.from_numpy(g["dones"][t]).to(dev), torch.from_numpy(g["inverted"][t]).to(dev)
+        ops._chk(lib.emloco_locoval_returns(C.byref(s), P(r), P(a), P(d), P(inv), current_stream_handle(dev)), "emloco_locoval_returns")
+        valid = g["valid"][t]
+        assert np.array_equal(st["weight"].cpu().numpy() != 0, valid), t
+        assert np.array_equal(st["target"].cpu().numpy()[valid], g["target"][t][valid]), t
+        for key, name in (("cc", "cur_combined"), ("dc", "discount"), ("cl", "lengths"), ("cr", "cur_rewards")):
+            assert np.array_equal(st[key].cpu().numpy(), g[name][t]), (t, name)
+    assert g["valid"].sum() >= 30
 
 
 def _eval_setup(dev):

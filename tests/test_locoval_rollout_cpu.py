@@ -123,7 +123,7 @@ def expected_events(rewards, amp, done, inverted, pen=0.3):
 def test_return_accumulator_known_answer():
     """3 scripted envs (time-outs, exact cut-off, 1-step episodes) + 5 random ones over 400 steps: every emitted value, at
     the step and env where it is emitted, equals the closed form; nothing else is emitted."""
-    from emloco_amd.learning.locoval_rollout import ReturnAccumulator
+    from oracle.locoval_returns import ReturnAccumulator
     E, T = 8, 400
     rewards, amp, done, inverted = script(E, T)
     exp = expected_events(rewards, amp, done, inverted)
@@ -143,12 +143,69 @@ def test_return_accumulator_known_answer():
     assert exp[143, 1] != 0                                          # env 1: done exactly at 144 -> once
 
 
+def _a17_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "locoval_returns.npz"))
+
+
+def test_return_accumulator_matches_the_reference_play_steps():
+    """The torch restatement (oracle/locoval_returns.py) against the fixture produced by the reference's own
+    AMPValueAgent.play_steps (tests/golden/gen_golden_a17.py): which rows enter the fit at which step, their targets
+    (G + 10) / 110, and the running state (discounted sum, gamma^t, episode length, undiscounted return) after every step."""
+    from oracle.locoval_returns import ReturnAccumulator
+    g = _a17_golden()
+    T, E = g["rewards"].shape
+    acc = ReturnAccumulator(E, int(g["step_to_pred"]), float(g["gamma"]), "cpu")
+    pen, lo, hi = float(g["penalty"]), float(g["min_cum"]), float(g["max_cum"])
+    for t in range(T):
+        r = torch.from_numpy(g["rewards"][t])
+        r = torch.where(torch.from_numpy(g["inverted"][t]), r * (-pen), r)
+        em = acc.update(r, torch.from_numpy(g["amp"][t]), torch.from_numpy(g["dones"][t]))
+        valid = (em != 0).numpy()
+        np.testing.assert_array_equal(valid, g["valid"][t], err_msg=f"step {t}")
+        np.testing.assert_array_equal(((em - lo) / (hi - lo)).numpy()[valid], g["target"][t][valid], err_msg=f"step {t}")
+        np.testing.assert_array_equal(acc.current_combined_rewards.numpy(), g["cur_combined"][t], err_msg=f"step {t}")
+        np.testing.assert_array_equal(acc.discount_coefs.numpy(), g["discount"][t], err_msg=f"step {t}")
+        np.testing.assert_array_equal(acc.current_lengths.numpy(), g["lengths"][t], err_msg=f"step {t}")
+        np.testing.assert_array_equal(acc.current_rewards.numpy(), g["cur_rewards"][t], err_msg=f"step {t}")
+    assert g["valid"].sum() >= 30 and g["valid"][143].any() and not g["valid"][167, 1]
+
+
+def test_fused_returns_kernel_matches_the_reference_play_steps():
+    """locoval_returns_kernel (the product's bookkeeping kernel, run through the CPU emulator) against the same fixture: the
+    emitted targets / weights and the four state arrays, element for element over the 400 scripted steps."""
+    import ctypes as C
+    import emu
+    from emloco_amd.predictor.ops import LocoValStep
+    g = _a17_golden()
+    T, E = g["rewards"].shape
+    f = lambda *s: np.zeros(s, np.float32)
+    st = dict(cr=f(E), cl=f(E), cc=f(E), dc=np.ones(E, np.float32), traj13=f(E, 13, 3), pose=f(E, 24, 3), vel=f(E, 2), target=f(E), weight=f(E))
+    wp, ip, iv = f(E, 15, 3), f(E, 24, 3), f(E, 2)
+    p = lambda a: a.ctypes.data
+    s = LocoValStep(E, int(g["step_to_pred"]), float(g["gamma"]), float(g["penalty"]), float(g["min_cum"]), float(g["max_cum"]), p(st["cr"]),
+                    p(st["cl"]), p(st["cc"]), p(st["dc"]), p(wp), p(ip), p(iv), p(st["traj13"]), p(st["pose"]), p(st["vel"]), p(st["target"]), p(st["weight"]))
+    fn = emu.lib().emu_locoval_returns
+    fn.argtypes = [C.c_void_p] * 5
+    for t in range(T):
+        keep = (np.ascontiguousarray(g["rewards"][t]), np.ascontiguousarray(g["amp"][t]), np.ascontiguousarray(g["dones"][t]),
+                g["inverted"][t].astype(np.uint8))
+        fn(C.addressof(s), *[p(k) for k in keep])
+        valid = g["valid"][t]
+        np.testing.assert_array_equal(st["weight"] != 0, valid, err_msg=f"step {t}")
+        np.testing.assert_array_equal(st["target"][valid], g["target"][t][valid], err_msg=f"step {t}")
+        np.testing.assert_array_equal(st["cc"], g["cur_combined"][t], err_msg=f"step {t}")
+        np.testing.assert_array_equal(st["dc"], g["discount"][t], err_msg=f"step {t}")
+        np.testing.assert_array_equal(st["cl"], g["lengths"][t], err_msg=f"step {t}")
+        np.testing.assert_array_equal(st["cr"], g["cur_rewards"][t], err_msg=f"step {t}")
+
+
 def test_fused_returns_kernel_equals_the_accumulator():
     """locoval_returns_kernel (the fused step's bookkeeping, run through the CPU emulator) against ReturnAccumulator and the
     closed form: emitted targets / weights element for element over 400 scripted steps, LocoVal inputs origin-relative."""
     import ctypes as C
     import emu
-    from emloco_amd.learning.locoval_rollout import ReturnAccumulator
+    from oracle.locoval_returns import ReturnAccumulator
     from emloco_amd.predictor.ops import LocoValStep
     E, T = 8, 400
     rewards, amp, done, inverted = script(E, T)
@@ -235,7 +292,7 @@ def _stand_in_valuenet(seed):
 
 
 def _run_rollout(env, horizon, epochs, seed=5, record=None):
-    from emloco_amd.learning.locoval_rollout import LocoValRollout
+    from oracle.locoval_returns import TorchLocoValRollout as LocoValRollout
     agent = LocoValRollout(env, horizon_length=horizon, valuenet=_stand_in_valuenet(seed), disc_reward=lambda a: a,
                            policy=lambda obs: torch.zeros(env.task.num_envs, 69))
     if record is not None:
