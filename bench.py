@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SIM_BYTES_PER_ENV = 9296          # state in/out + per-env model (+ collision capsules) + warm-start, per launch
+PROFILE_ROUND = "r03"             # profiles/<round>_*: the committed rocprofv3 summaries of this round's kernels
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 
@@ -99,14 +100,16 @@ def rank_local():
 
 
 def cpu_baseline(sample_envs=4096, sample_steps=100, budget_s=22.0):
-    """The CPU oracle (C restatement, OpenMP over envs) on the same workload size -- 4096 envs, physics + post-physics maths.
-    Thread count swept over {16, 32, 64, all host cores} with 2 steps each (containers often expose more cores than they may
-    use), the best one runs for `budget_s` seconds or `sample_steps` steps."""
+    """The CPU oracle (C restatement, OpenMP over envs in the physics step AND in every observation / reward / reset function) on
+    the same workload size -- 4096 envs, physics + post-physics maths.  The thread count is swept over {8, 16, 32, 64, all CPUs this
+    process may run on (os.sched_getaffinity)} with 2 steps each and the best one runs for `budget_s` seconds or `sample_steps`
+    steps: the boxes of the pool expose 256 CPUs in the affinity mask but are shared, and a team larger than the cores that are
+    actually free loses to OpenMP's barriers (the sweep is in `sample`)."""
     import oracle
     from emloco_amd.model import pack_models, pack_self_collision
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import varied_models
-    ncpu = os.cpu_count() or 1
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     models = varied_models(64, seed=0)
     models = [models[i % 64] for i in range(sample_envs)]
     s = oracle.Sim(pack_models(models), oracle.default_params(n_sub=4), self_collision=pack_self_collision(models))   # as the GPU run
@@ -142,7 +145,7 @@ def cpu_baseline(sample_envs=4096, sample_steps=100, budget_s=22.0):
         prog[prog >= 167] = 0
 
     sweep = {}
-    for th in sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu), ncpu}):
+    for th in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu), ncpu}):
         oracle.set_threads(th)
         one()
         t0 = time.perf_counter()
@@ -156,10 +159,10 @@ def cpu_baseline(sample_envs=4096, sample_steps=100, budget_s=22.0):
         one()
         done += 1
     dt = time.perf_counter() - t0
-    return {"value": round(sample_envs * done / dt, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+    return {"value": round(sample_envs * done / dt, 1), "unit": "env-steps/s", "cores": cores, "cpus_in_affinity_mask": ncpu, "kind": "port",
             "sample": f"{sample_envs} envs x {done} steps of the same env.step maths (oracle/ C restatement, OpenMP over envs; thread sweep "
                       + ", ".join(f"{k}: {sample_envs / v:,.0f}/s" for k, v in sweep.items())
-                      + f" of os.cpu_count() = {ncpu}; best = {cores} threads, {dt:.1f} s)"}
+                      + f"; {ncpu} CPUs in this process's affinity mask; best = {cores} threads, {dt:.1f} s)"}
 
 
 def synthetic_jta_batch(B, seed=0, max_people=8, nan_frac=0.02):
@@ -307,7 +310,7 @@ def jta_cpu_baseline(B=32, budget_s=60.0):
     import torch
     from oracle.predictor_torch import LocoValOracle, TransMotionJTAOracle, emloco_train_step
     from emloco_amd.predictor.train_jta import batch_process_coords
-    ncpu = os.cpu_count() or 1
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.manual_seed(0)
     model = TransMotionJTAOracle(dropout=0.0)
     vnet = LocoValOracle()
@@ -492,17 +495,14 @@ def main():
     env = make_env(E, rank)
     task = env.task
     # Two schedules of the same step (identical results, tests/test_gpu_env.py / test_gpu_sim.py):
-    #   overlap (headline): the reset chain of the finished envs and their step on a second HIP stream beside the step of the
-    #     live envs (task.overlap_reset);
-    #   sequential (reported beside it): the reference's order, with the rigid-body launch dispatched most-contact-work-first
-    #     (emloco_sim_set_cost_order).  The two do not add up: cost order keeps the wave slots busy longest.
-    # (below ~one and a half resident rounds of waves the device is not full and the sequential schedule is faster: DESIGN.md section 5)
-    overlap = os.environ.get("EMLOCO_OVERLAP_RESET", "1" if a.num_envs >= 3072 else "0") != "0"
-    # (the task layer already runs the 4 substeps of a step as four dependent workgroups per env in ONE launch,
-    # emloco_sim_set_split via gym.prepare_sim: wave slots that cheap envs free early are refilled at substep granularity)
+    #   sequential (HEADLINE): the reference's order -- reset chain of the finished envs, then one rigid-body launch for all envs,
+    #     dispatched most-contact-work-first (emloco_sim_set_cost_order).  Every consumer can use it: the observations of the
+    #     reset envs exist before the policy runs (amp_continuous_value.py:46-52);
+    #   overlapped (reported beside it as `overlapped_obs_blind`, N = 1): the reset chain and the reset envs' step on a second
+    #     HIP stream beside the step of the live envs (task.overlap_reset) -- only a policy that does not read the reset envs'
+    #     fresh observations can start the step before the reset chain has finished.
     n_parts = int(os.environ.get("EMLOCO_SPLIT", "4"))
-    if os.environ.get("EMLOCO_COST_ORDER", "0" if overlap else "1") != "0":
-        task.sim.native.set_cost_order(True)
+    task.sim.native.set_cost_order(os.environ.get("EMLOCO_COST_ORDER", "1") != "0")
     env.reset(torch.arange(E, device=dev))
     stagger_episodes(env, seed=rank)                     # untimed: episode ages uniform over [0, 168) before the warm-up
     g = torch.Generator(device=dev)
@@ -513,38 +513,37 @@ def main():
     from emloco_amd.learning.locoval_rollout import LocoValRollout
     counter = [0]
 
-    def noise_policy(obs):
-        counter[0] += 1
+    def noise_policy(obs):          # stands where the frozen policy stands (its network is the `policy` leg); like a real policy it
+        counter[0] += 1             # is handed the observations only once the reset chain has written the reset envs' rows
         return pool[counter[0] % 64]
 
-    # the stand-in policy does not read the observations, so the reset chain of the finished envs (and their step) runs
-    # beside the step of the live envs on a second stream (task.overlap_reset); a policy that reads them waits (policy leg)
-    noise_policy.reads_obs = False
-
     horizon = 32
-    agent = LocoValRollout(env, horizon_length=horizon, policy=noise_policy, overlap_reset=overlap)
+
+    def timed_loop(agent):
+        def one_step(k):
+            agent.step_once()
+            if (k + 1) % horizon == 0:
+                agent.end_epoch()
+        for k in range(a.warmup):
+            one_step(k)
+        task.sim.native.enable_timing(True, every=4)     # HIP events around every 4th launch of the timed region (an event record costs ~5 us of stream time)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            one_step(k)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_l, ms_l = task.sim.native.timing_stats()
+        return dt, n_l, ms_l
+
+    agent = LocoValRollout(env, horizon_length=horizon, policy=noise_policy, overlap_reset=False)
     agent.started = True                                 # the envs are already reset and staggered
     agent._sched_live = True                             # (the schedule's first-episode check is a host read; not in the timed loop)
-
-    def one_step(k):
-        agent.step_once()
-        if (k + 1) % horizon == 0:
-            agent.end_epoch()
-
-    for k in range(a.warmup):
-        one_step(k)
-    task.sim.native.enable_timing(True, every=4)         # HIP events around every 4th launch of the timed region (an event record costs ~5 us of stream time)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        one_step(k)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    n_l, ms_l = task.sim.native.timing_stats()
+    elapsed, n_l, ms_l = timed_loop(agent)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         from emloco_amd.dist import all_reduce_
@@ -552,24 +551,10 @@ def main():
         elapsed = float(t.item())
     fitted, vloss = agent.fitted_episodes, agent.vnet_loss
 
-    # env.step alone (no LocoVal bookkeeping / fit), reported beside the headline at N = 1
+    # env.step alone in the same (sequential) schedule, no LocoVal bookkeeping / fit: reported beside the headline at N = 1
     env_only = None
     if world == 1:
-        for k in range(a.warmup):
-            env.reset_done(); env.step(pool[k % 64])
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for k in range(a.steps):
-            env.reset_done(); env.step(pool[k % 64])
-        torch.cuda.synchronize()
-        env_only = time.perf_counter() - t1
-
-    # the sequential, cost-ordered schedule of the same env.step (and the rigid-body kernel's duration when nothing runs beside it)
-    seq = None
-    if world == 1 and overlap:
-        task.wait_reset()
-        task.overlap_reset = False
-        task.sim.native.set_cost_order(True)
+        agent._sync_fit()
         for k in range(a.warmup):
             env.reset_done(); env.step(pool[k % 64])
         task.sim.native.enable_timing(True, every=4)
@@ -578,32 +563,55 @@ def main():
         for k in range(a.steps):
             env.reset_done(); env.step(pool[k % 64])
         torch.cuda.synchronize()
-        seq_t = time.perf_counter() - t1
+        env_only = time.perf_counter() - t1
         n_s, ms_s = task.sim.native.timing_stats()
-        seq = {"value": round(E * a.steps / seq_t, 1), "unit": "env-steps/s", "ms_per_step": round(seq_t / a.steps * 1e3, 4),
-               "kernel_ms": round(ms_s / max(n_s, 1), 4), "launches_timed": n_s,
-               "note": "env.step alone in the reference's order (reset chain, then one launch for all envs), rigid-body launch "
-                       "dispatched most-contact-work-first (emloco_sim_set_cost_order); kernel_ms = sim_step_kernel with nothing beside it"}
-        task.sim.native.set_cost_order(False)
+
+    # the overlapped schedule (a consumer that does not read the reset envs' observations before it acts)
+    blind = None
+    if world == 1 and os.environ.get("EMLOCO_OVERLAP_RESET", "1") != "0":
+        task.sim.native.set_cost_order(False)             # the two do not add up: cost order keeps the wave slots busy longest
+        blind_policy = lambda obs: noise_policy(obs)
+        blind_policy.reads_obs = False
+        # the same agent (HIP serves a process with four hardware queues: a second agent's side stream would share one)
+        agent.policy = blind_policy
         task.overlap_reset = True
+        task.overlap_obs = os.environ.get("EMLOCO_OVERLAP_OBS", "0") == "1"    # see LocoValRollout.__init__: nothing to hide behind here
+        b_t, b_n, b_ms = timed_loop(agent)
+        agent._sync_fit()
+        task.wait_reset()
+        for k in range(a.warmup):
+            env.reset_done(); env.step(pool[k % 64])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(a.steps):
+            env.reset_done(); env.step(pool[k % 64])
+        torch.cuda.synchronize()
+        b_env = time.perf_counter() - t1
+        task.wait_reset()
+        task.overlap_reset = False
+        task.sim.native.set_cost_order(True)
+        blind = {"value": round(E * a.steps / b_t, 1), "unit": "env-steps/s", "ms_per_step": round(b_t / a.steps * 1e3, 4),
+                 "kernel_ms": round(b_ms / max(b_n, 1), 4), "launches_timed": b_n,
+                 "env_step_only": round(E * a.steps / b_env, 1),
+                 "note": "the same LocoVal loop with the reset chain of the finished envs and their step on a second HIP stream beside "
+                         "the step of the live envs (task.overlap_reset); usable only by a policy that does not read the reset envs' fresh "
+                         "observations before acting (the stand-in noise policy declares reads_obs = False here) -- NOT the headline; "
+                         "kernel_ms = the live envs' launch with the reset chain and the id-list launch sharing the device"}
 
     if rank == 0:
         kernel_ms = ms_l / max(n_l, 1)
         achieved = SIM_BYTES_PER_ENV * E / (kernel_ms * 1e-3) / 1e9 if n_l else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r02_sim_step_hbm_bytes.json")     # PMC pass of THIS round's kernel (tools/collect_profiles.sh)
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        valu = None          # VALU issue utilisation of the same kernel from the committed SQ-counter pass (profiles/README.md)
+        prof = {}                 # numbers of the committed counter passes of this round's kernel: pointers, not measurements of this run
         try:
-            for line in open(os.path.join(ROOT, "profiles", "r02_sim_step_valu.txt")):
-                if line.startswith("VALU issue utilisation"):
-                    valu = float(line.split("=")[-1].split()[0])
+            prof["traffic"] = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_sim_step_hbm_bytes.json"))).get("hbm_bytes_per_launch")
         except Exception:
-            valu = None
+            prof["traffic"] = None
+        try:
+            for line in open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_sim_step_valu.txt")):
+                if line.startswith("VALU busy"):
+                    prof["valu_busy_frac"] = float(line.split("=")[-1].split()[0])
+        except Exception:
+            pass
         out = {
             "metric": "env-steps/sec (SMPL humanoid, num_envs)", "value": round(E * world * a.steps / elapsed, 1),
             "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -612,39 +620,36 @@ def main():
             "config": {"workload": f"configs[1] env: PACER rollout env.step, {E} SMPL humanoids per GPU, random_heading, "
                                    "JTA+JRDB-shaped real_path (synthetic), flat terrain, self-collision on, steady-state resets included "
                                    "(episode ages pre-staggered), inside the LocoVal-training loop of configs[2] (returns bookkeeping + LocoVal "
-                                   "fit + gradient all-reduce every step), policy network excluded"
-                                   + ("; schedule: the reset chain of the finished envs and their step run on a second HIP stream beside "
-                                      "the step of the live envs (task.overlap_reset; same results as the sequential order)" if overlap else
-                                      "; schedule: sequential, rigid-body launch dispatched most-contact-work-first"),
+                                   "fit + gradient all-reduce every step), policy network excluded (its forward is the `policy` leg); "
+                                   "schedule: the reference's order (reset chain of the finished envs, observations, then ONE rigid-body launch "
+                                   "for all envs, dispatched most-contact-work-first) -- what a policy that reads the observations can use",
                        "locoval": {"episodes_fitted": fitted, "last_fit_loss": round(vloss, 5), "exchange_floats_per_step": 6176},
                        "num_envs_per_gpu": E, "substeps_per_step": 4, "workgroups_per_env": n_parts, "parallelism": f"env-sharded x{world}" + (" (TEST MODE: all ranks share cuda:0, gloo)" if share else "")},
             "roofline": {"bound": "hbm", "kernel": "sim_step_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l, "valu_issue_frac": valu,
-                         "note": "latency bound, not bandwidth bound: ~9 KB of state per env per launch against ~50 k dependent fp32 VALU "
-                                 "wave-instructions (level-synchronous tree passes, 2 waves / SIMD; each env's 4 substeps run as four dependent "
-                                 "workgroups of the launch, i.e. eight resident rounds of 2048 one-substep waves for 4096 envs); valu_issue_frac "
-                                 "and the wait fractions come from profiles/r02_sim_step_valu.txt, traffic from profiles/r02_sim_step_hbm_bytes.json "
-                                 "(PMC passes of this round's kernel, sequential schedule; the 38 MB algorithmic + the 1.7 KB per-env hand-over "
-                                 "between consecutive workgroups of an env, out and back through write-through granules, + the later workgroups' "
-                                 "re-reads of the per-env model constants); kernel_ms is the launch over "
-                                 "the live envs in the timed region (every 4th launch timed), where the reset chain and the reset envs' "
-                                 "launch share the device with it -- `sequential.kernel_ms` is the same kernel with nothing beside it"},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": prof.get("traffic"),
+                         "traffic_source": f"profiles/{PROFILE_ROUND}_sim_step_hbm_bytes.json (committed PMC passes of this kernel; NOT measured in this run)",
+                         "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l,
+                         "from_profiles": {"valu_busy_frac": prof.get("valu_busy_frac"), "source": f"profiles/{PROFILE_ROUND}_sim_step_valu.txt (committed SQ-counter pass; NOT measured in this run)"},
+                         "note": "achieved = algorithmic bytes (9 296 B per env per launch, DESIGN.md section 5) / kernel_ms, both live: HIP events on "
+                                 "every 4th launch of the timed region.  The kernel is instruction / latency bound, not bandwidth bound: ~9 KB of state "
+                                 "per env per launch against ~47 k fp32 VALU wave-instructions (level-synchronous tree passes; 3 waves per SIMD, 12 envs "
+                                 "per CU; each env's 4 substeps run as four dependent workgroups of one launch)"},
         }
-        if seq is not None:
-            seq["roofline_frac_alone"] = round(SIM_BYTES_PER_ENV * E / (seq["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if seq["launches_timed"] else None
-            out["sequential"] = seq
         if env_only is not None:
+            k_alone = ms_s / max(n_s, 1)
             out["env_step_only"] = {"value": round(E * a.steps / env_only, 1), "unit": "env-steps/s", "ms_per_step": round(env_only / a.steps * 1e3, 4),
-                                    "note": "reset_done + env.step without the LocoVal bookkeeping / fit (round-1 definition of the step)"}
+                                    "kernel_ms": round(k_alone, 4), "launches_timed": n_s,
+                                    "roofline_frac_alone": round(SIM_BYTES_PER_ENV * E / (k_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if n_s else None,
+                                    "note": "reset_done + env.step in the same sequential schedule without the LocoVal bookkeeping / fit; kernel_ms = "
+                                            "sim_step_kernel with nothing but the observation launch of the previous step beside it"}
+            out["sequential"] = dict(out["env_step_only"])         # the name earlier rounds reported this leg under
+        if blind is not None:
+            out["overlapped_obs_blind"] = blind
         if world == 1 and not a.no_policy:
             # a policy reads the reset envs' fresh observations, so the reset chain cannot hide beside the step: the sequential
             # schedule (observation launch of the live envs beside the reset chain, cost-ordered dispatch) is the faster one here
             # (measured: 3.95 M against 3.78 M env-steps/s)
-            task.wait_reset()
-            task.overlap_reset = False
             task.overlap_obs = True
-            task.sim.native.set_cost_order(True)
             out["policy"] = policy_leg(env, E, dev, a.steps, a.warmup)
             out["policy"]["schedule"] = "sequential, cost-ordered dispatch"
         if world == 1 and not a.no_pipelined and E % 2 == 0:

@@ -101,7 +101,8 @@ def emloco_loss_masked(config, valuenet, pred_joints, primary_init_pose, primary
     rows `nan_handler` drops (NaN trajectory / pose / velocity, all-zero pose) they get weight 0 in the mean -- identical
     value and gradients, no host read.  Returns (sum over kept rows of the per-row loss, averaged over modes and scaled by
     valuenet_weight; number of kept rows): the caller divides, so that data-parallel ranks can divide by the global count.
-    A batch with no kept row contributes 0, where the reference's NaN mean is skipped (:308)."""
+    A batch with no kept row contributes 0, where the reference's NaN mean is skipped (:308); so does a batch in which LocoVal
+    returns NaN for a kept row."""
     dev = pred_joints.device
     w = config["TRAIN"].get("valuenet_weight", 1.0)
     multi = config.get("MULTI_MODAL", False)
@@ -119,10 +120,16 @@ def emloco_loss_masked(config, valuenet, pred_joints, primary_init_pose, primary
     pose = torch.where(kb[:, None, None], primary_init_pose, torch.zeros_like(primary_init_pose))
     vel = torch.where(kb[:, None], primary_init_vel, torch.zeros_like(primary_init_vel))
     total = 0
+    any_nan = torch.zeros((), dtype=torch.bool, device=dev)
     for i in range(M):                # the LocoVal call rotates `pose` in place, cumulatively over the modes (value_pose_net.py:97)
         value = valuenet(pred[:, :, i].contiguous(), pose, vel).reshape(-1)
+        # a NaN value of a kept row makes the reference's (scalar) value loss NaN, and the reference then leaves the term out of
+        # the step (train_jta.py:308); here the NaN is taken out of the graph and the whole term gets weight 0 -- no host read
+        nan_row = torch.isnan(value)
+        any_nan = any_nan | (nan_row & kb).any()
+        value = torch.where(nan_row, torch.ones_like(value), value)
         total = total + (keep * (value - 1.0) ** 2).sum()
-    return total * (w / M), keep.sum()
+    return total * (~any_nan).float() * (w / M), keep.sum()
 
 
 class EmLocoTrainer:

@@ -2,6 +2,11 @@
 (d = 128, 4 heads of 32, ff = 1024) with 1 local + 1 global layer, B = 2 scenes x N = 2 people, run on CPU.
 
     python tests/golden/gen_golden_fullwidth.py     ->  tests/golden/predictor_fullwidth_{jta,jrdb}.npz
+    python tests/golden/gen_golden_fullwidth.py jta_deep jta_deep_mm
+                                                    ->  tests/golden/predictor_fulldepth_{jta,jta_mm}.npz
+
+The `_deep` kinds are the SHIPPED model (social-transmotion/configs/jta_all_visual_cues.yaml:20-33): 6 local + 3 global layers;
+`jta_deep` single-mode with the EmLoco loss (configs[3]), `jta_deep_mm` with the 20 prediction heads and MSE_LOSS_MULTI (configs[4]).
 
 Head dimension 32 is the one this repo's fused attention kernels serve, so these fixtures put them (and the d = 128 GEMM
 tiles) inside a comparison with reference output (the d = 32 fixtures take the composed attention path).  The weights come from
@@ -33,17 +38,26 @@ PICK_SAMPLE = ["local_former.layers.0.self_attn.in_proj_weight", "local_former.l
 
 def run(kind):
     torch.set_num_threads(8)
-    g = torch.Generator().manual_seed(31 if kind == "jta" else 37)
+    deep = kind.startswith("jta_deep")
+    mm = kind.endswith("_mm")
+    nl, ng, nmode = (6, 3, 20) if deep else (1, 1, 4)
+    fname = {"jta_deep": "predictor_fulldepth_jta", "jta_deep_mm": "predictor_fulldepth_jta_mm"}.get(kind, f"predictor_fullwidth_{kind}")
+    g = torch.Generator().manual_seed({"jta": 31, "jrdb": 37, "jta_deep": 41, "jta_deep_mm": 43}[kind])
     B, N = 2, 2
+    if deep:
+        kind = "jta"
     if kind == "jta":
         import model_jta as M
         from dataset_jta import batch_process_coords
-        from utils.metrics import MSE_LOSS as LOSS
+        if mm:
+            from utils.metrics import MSE_LOSS_MULTI as LOSS
+        else:
+            from utils.metrics import MSE_LOSS as LOSS
         J = 49
-        model = M.TransMotionJTA(tok_dim=453, nhid=128, nhead=4, dim_feedfwd=1024, nlayers_local=1, nlayers_global=1, nmode=4, output_scale=1,
-                                 obs_and_pred=21, num_tokens=J, device="cpu", multi_modal=False).float()
+        model = M.TransMotionJTA(tok_dim=453, nhid=128, nhead=4, dim_feedfwd=1024, nlayers_local=nl, nlayers_global=ng, nmode=nmode, output_scale=1,
+                                 obs_and_pred=21, num_tokens=J, device="cpu", multi_modal=mm).float()
         cfg = {"DEVICE": "cpu", "TRAIN": {"input_track_size": 9, "output_track_size": 12}}
-        head = "fc_out_traj.weight"
+        head = "predict_head.19.weight" if mm else "fc_out_traj.weight"
     else:
         import model_jrdb as M
         from dataset_jrdb import batch_process_coords
@@ -66,7 +80,7 @@ def run(kind):
     pred = model(in_joints.clone(), pm.clone())
     loss = LOSS(pred[:, 9:], out_joints)
     extra = {}
-    if kind == "jta":                                                 # EmLoco loss wiring (train_jta.py:288-308)
+    if kind == "jta" and not mm:                                      # EmLoco loss wiring (train_jta.py:288-308)
         from learning.value_pose_net import ValuePoseNet
         torch.manual_seed(5)
         vnet = ValuePoseNet(use_pose=True, use_vel=True)
@@ -83,9 +97,15 @@ def run(kind):
                weight_seed=np.array(1234), n_params=np.array(sum(int(np.prod(s)) for s in shapes.values())),
                weight_checksum=np.array(float(sum(np.abs(v).sum(dtype=np.float64) for v in sd.values()))),
                keys=np.array("\n".join(f"{k} {' '.join(map(str, shapes[k]))}" for k in sorted(shapes))), **extra)
-    for k in PICK_WHOLE + [head]:
+    whole, samp = list(PICK_WHOLE), list(PICK_SAMPLE)
+    if deep:                                                          # the last layers too: nine stacked post-norm layers
+        whole += ["local_former.layers.5.norm2.weight", "local_former.layers.5.linear2.bias", "global_former.layers.2.norm2.weight",
+                  "global_former.layers.2.self_attn.out_proj.bias", "local_former.layers.3.self_attn.in_proj_bias"]
+        samp += ["local_former.layers.5.linear1.weight", "local_former.layers.3.self_attn.in_proj_weight", "global_former.layers.2.linear2.weight",
+                 "local_former.layers.2.linear2.weight"]
+    for k in whole + [head]:
         out["grad__" + k.replace(".", "__")] = grads[k]
-    for k in PICK_SAMPLE:
+    for k in samp:
         out["gsample__" + k.replace(".", "__")] = sample(grads[k].numpy())
     res = {}
     for k, v in out.items():
@@ -93,7 +113,7 @@ def run(kind):
             v = v.detach().cpu().numpy()
         res[k] = np.asarray(v)
     res["torch_version"] = np.array(torch.__version__)
-    np.savez_compressed(os.path.join(HERE, f"predictor_fullwidth_{kind}.npz"), **res)
+    np.savez_compressed(os.path.join(HERE, fname + ".npz"), **res)
     print("wrote", kind, "params", int(res["n_params"]), "pred", res["pred"].shape, "loss", float(res["loss"]))
 
 

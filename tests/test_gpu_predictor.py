@@ -388,6 +388,136 @@ def test_fullwidth_model_through_fused_attention_matches_reference(golden, kind,
     assert n_checked >= 16
 
 
+@pytest.mark.parametrize("kind", ["jta", "jta_mm"])
+def test_shipped_depth_model_matches_reference(golden, kind):
+    """The SHIPPED model (social-transmotion/configs/jta_all_visual_cues.yaml:20-33: 6 local + 3 global layers, d = 128, 4 heads,
+    ff = 1024, S = 453; `jta_mm`: the 20 prediction heads of configs[4]) against the reference's own model code run at that
+    depth (tests/golden/gen_golden_fullwidth.py jta_deep / jta_deep_mm): logits, loss (single mode: MSE + EmLoco value loss;
+    multi-modal: MSE_LOSS_MULTI) and gradients from the first to the last of the nine stacked post-norm layers within 1e-4 / 2e-4
+    of the tensor scale on the fp32 path."""
+    from fullwidth_weights import make_state_dict, sample
+    from emloco_amd.predictor.model_jta import TransMotionJTA
+    from emloco_amd.predictor.train_jta import MSE_LOSS, MSE_LOSS_MULTI
+    mm = kind.endswith("_mm")
+    g = golden(f"predictor_fulldepth_{kind}")
+    dev = "cuda:0"
+    model = TransMotionJTA(tok_dim=453, nhid=128, nhead=4, dim_feedfwd=1024, nlayers_local=6, nlayers_global=3, nmode=20, output_scale=1,
+                           obs_and_pred=21, num_tokens=49, device=dev, multi_modal=mm).to(dev).float()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert "\n".join(f"{k} {' '.join(map(str, shapes[k]))}" for k in sorted(shapes)) == str(g["keys"])
+    assert int(g["n_params"]) == (3225064 if mm else 3220162)         # SURVEY section 8c: the reference's own counts
+    sd = make_state_dict(shapes, seed=int(g["weight_seed"]))
+    assert abs(sum(np.abs(v).sum(dtype=np.float64) for v in sd.values()) - float(g["weight_checksum"])) < 1e-6 * float(g["weight_checksum"])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.eval()
+    in_joints, pm, out_joints = (torch.from_numpy(g[k]).to(dev) for k in ("in_joints", "pm", "out_joints"))
+    pred = model(in_joints.clone(), pm.clone())
+    assert tuple(pred.shape) == tuple(g["pred"].shape)
+    _close(pred.detach().cpu().numpy(), g["pred"], what=f"{kind} shipped-depth logits")
+    if mm:
+        loss = MSE_LOSS_MULTI(pred[:, 9:], out_joints)
+    else:
+        mse = MSE_LOSS(pred[:, 9:], out_joints)
+        _close(mse.item(), g["mse"], what="mse")
+        vnet = _vnet(g)
+        pred_traj = torch.cat([torch.zeros(pred.shape[0], 1, 2, device=dev), pred[:, 9:, 0, :2]], dim=1).contiguous()
+        value, vloss = vnet.calc_embodied_motion_loss(pred_traj, torch.from_numpy(g["pose"]).to(dev), torch.from_numpy(g["vel"]).to(dev))
+        _close(value.detach().cpu().numpy(), g["value"], what="LocoVal value")
+        loss = mse + 1.0 * vloss
+    _close(loss.item(), g["loss"], what="loss")
+    loss.backward()
+    # Gradients: 2e-4 of the tensor scale where the path to the loss is short (the last local layer, the global former, the
+    # heads: measured 1e-6), 1e-3 below that.  A ReLU / LayerNorm stack is not smooth: a pre-activation that rounds to the other
+    # side of zero flips a mask, and two fp32 evaluations of the SAME six-layer stack (stock torch on the CPU vs float64) already
+    # differ by 1e-4 .. 7e-4 of the scale in the early layers' gradients, as this library does (tools/exp/stack_err.py,
+    # profiles/r03_fp32_depth_noise.txt); a single layer agrees with float64 to 1e-6 in every tensor (tools/exp/layer_err.py).
+    params = dict(model.named_parameters())
+    n_checked = 0
+    short = ("local_former__layers__5", "global_former", "predict_head", "fc_out_traj")
+    for k, v in g.items():
+        rel = 2e-4 if any(t in k for t in short) else 1e-3
+        if k.startswith("grad__"):
+            _close(params[k[6:].replace("__", ".")].grad.cpu().numpy(), v, rel=rel, abs_=1e-6, what=k)
+            n_checked += 1
+        elif k.startswith("gsample__"):
+            rel_k = 5e-3 if "learned_encoding" in k else rel       # max_norm renormalisation divides by a norm close to the threshold
+            _close(sample(params[k[9:].replace("__", ".")].grad.cpu().numpy()), v, rel=rel_k, abs_=1e-6, what=k)
+            n_checked += 1
+    assert n_checked >= 25
+
+
+def _shipped_trainer(dev, multi, lr=1e-4, seed=0):
+    from emloco_amd.learning.value_pose_net import ValuePoseNet
+    from emloco_amd.predictor.model_jta import TransMotionJTA
+    from emloco_amd.predictor.train_jta import EmLocoTrainer
+    torch.manual_seed(seed)
+    cfg = {"DEVICE": dev, "MULTI_MODAL": multi, "TRAIN": {"input_track_size": 9, "output_track_size": 12, "lr": lr, "max_grad_norm": 1.0,
+                                                           "valuenet_weight": 1.0}}
+    model = TransMotionJTA(tok_dim=453, nhid=128, nhead=4, dim_feedfwd=1024, nlayers_local=6, nlayers_global=3, nmode=20, output_scale=1,
+                           obs_and_pred=21, num_tokens=49, device=dev, multi_modal=multi, dropout=0.0).to(dev)
+    return EmLocoTrainer(model, ValuePoseNet(True, True).to(dev), cfg), cfg
+
+
+def _jta_shaped_batch(B, seed, max_people=4):
+    g = torch.Generator().manual_seed(seed)
+    joints = torch.randn(B, max_people, 21, 49, 4, generator=g) * 0.3
+    joints[:, :, :, 0, :2] = torch.cumsum(torch.randn(B, max_people, 21, 2, generator=g) * 0.3, dim=2)
+    n = torch.randint(1, max_people + 1, (B,), generator=g)
+    pad = torch.arange(max_people)[None, :] >= n[:, None]
+    return joints, torch.ones(B, max_people, 21, 49), pad
+
+
+def test_configs3_batch_256_shipped_depth_train_step_properties():
+    """configs[3] under -m gpu: the shipped 6 + 3-layer model, EmLoco loss (valueloss_w = 1), batch 256 (1 - 4 people per scene,
+    padded).  Properties that do not need the reference: every output finite; the loss of the batch equals the mean of the
+    losses of its four 64-scene slices (no cross-sample leakage through padding or batching; slices evaluated with the same
+    weights); three Adam steps on the same batch lower the loss."""
+    from emloco_amd.predictor.train_jta import batch_process_coords, compute_loss, emloco_loss_masked
+    dev = "cuda:0"
+    tr, cfg = _shipped_trainer(dev, multi=False, lr=1e-4)
+    joints, masks, pad = _jta_shaped_batch(256, seed=11)
+
+    def eval_loss(sl):
+        tr.model.eval()
+        with torch.no_grad():
+            in_j, in_m, out_j, out_m, pm = batch_process_coords(joints[sl], masks[sl], pad[sl], cfg, training=False)
+            mse, pred = compute_loss(tr.model, cfg, in_j, out_j, in_m, out_m, pm.to(dev), mode="val")
+            pose = joints[sl][:, 0, 8, 3:27, :3].clone().to(dev)
+            pose[..., 2] *= -1
+            vel = ((in_j[:, 8, 0, :2] - in_j[:, 7, 0, :2]) * 2.5).clone()
+            vsum, cnt = emloco_loss_masked(cfg, tr.valuenet, pred, pose, vel, in_j.shape[1])
+        assert torch.isfinite(pred).all() and tuple(pred.shape) == (joints[sl].shape[0], 21, 1, 2)
+        return mse.item(), vsum.item(), cnt.item()
+    whole = eval_loss(slice(0, 256))
+    parts = [eval_loss(slice(i, i + 64)) for i in range(0, 256, 64)]
+    assert whole[2] == sum(p[2] for p in parts) == 256
+    assert abs(whole[0] - np.mean([p[0] for p in parts])) <= 1e-4 * abs(whole[0])
+    assert abs(whole[1] - sum(p[1] for p in parts)) <= 1e-4 * abs(whole[1])
+    losses = [tr.step(joints, masks, pad, random_masking=False)[0].item() for _ in range(4)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+
+
+def test_configs4_batch_512_twenty_modes_forward_properties():
+    """configs[4] under -m gpu: the shipped depth with the 20 prediction heads at batch 512: finite logits of shape
+    (512, 21, 20, 2), equal to the logits of the same scenes evaluated in slices of 128, and the multi-modal loss is the
+    minimum over the modes."""
+    from emloco_amd.predictor.train_jta import MSE_LOSS_MULTI, batch_process_coords
+    dev = "cuda:0"
+    tr, cfg = _shipped_trainer(dev, multi=True)
+    joints, masks, pad = _jta_shaped_batch(512, seed=12)
+    tr.model.eval()
+    with torch.no_grad():
+        in_j, in_m, out_j, out_m, pm = batch_process_coords(joints, masks, pad, cfg, training=False)
+        pred = tr.model(in_j, pm.to(dev))
+        assert tuple(pred.shape) == (512, 21, 20, 2) and torch.isfinite(pred).all()
+        for i in range(0, 512, 128):
+            part = tr.model(in_j[i:i + 128], pm[i:i + 128].to(dev))
+            _close(part.cpu().numpy(), pred[i:i + 128].cpu().numpy(), rel=1e-5, abs_=1e-5, what=f"slice {i}")
+        loss = MSE_LOSS_MULTI(pred[:, 9:], out_j)
+        per_mode = (pred[:, 9:] - out_j[:, :, 0, :2].unsqueeze(2).to(dev)).norm(dim=-1).mean(1)          # (B, 20)
+        assert abs(loss.item() - per_mode.min(dim=1).values.mean().item() * 100.0) <= 1e-3 * loss.item()
+
+
 def test_fused_attention_dropout_matches_torch_with_the_same_mask():
     """nn.MultiheadAttention(dropout = 0.1) in training mode (the reference's encoder layers, model_jta.py:177-178): the fused
     kernels' dropout on the probabilities against float64 torch attention that applies the SAME keep mask (the library's
