@@ -31,7 +31,7 @@ class SimParams(C.Structure):
     _fields_ = [("n_sub", C.c_int32), ("n_iter", C.c_int32), ("h", C.c_float), ("gravity_z", C.c_float),
                 ("contact_offset", C.c_float), ("erp", C.c_float), ("max_depen_vel", C.c_float),
                 ("mu", C.c_float), ("ang_damping", C.c_float), ("max_ang_vel", C.c_float),
-                ("ground_z", C.c_float), ("cfm", C.c_float), ("warm", C.c_float)]
+                ("ground_z", C.c_float), ("cfm", C.c_float), ("warm", C.c_float), ("drive_mode", C.c_int32)]
 
 
 class ModelDesc(C.Structure):
@@ -125,7 +125,7 @@ def real_pick_perm(i, n, key):
 def default_sim_params(**kw):
     """Engine parameters of pacer.yaml:93-104 / config.py:143-163 mapped onto EmlocoSimParams."""
     p = dict(n_sub=2, n_iter=4, h=(1.0 / 60.0) / 2, gravity_z=-9.81, contact_offset=0.02, erp=0.2,
-             max_depen_vel=10.0, mu=1.0, ang_damping=0.01, max_ang_vel=100.0, ground_z=0.0, cfm=1e-4, warm=1.0)
+             max_depen_vel=10.0, mu=1.0, ang_damping=0.01, max_ang_vel=100.0, ground_z=0.0, cfm=1e-4, warm=1.0, drive_mode=0)
     p.update(kw)
     return SimParams(**p)
 
@@ -135,7 +135,7 @@ SYMBOLS_SIM = [
     "emloco_last_error", "emloco_device_count", "emloco_sim_create", "emloco_sim_destroy", "emloco_sim_set_models",
     "emloco_sim_set_self_collision", "emloco_sim_set_ground_heightfield",
     "emloco_sim_prepare", "emloco_sim_get_params", "emloco_sim_set_params", "emloco_sim_tensor",
-    "emloco_sim_set_pd_targets", "emloco_sim_step", "emloco_sim_step_subset", "emloco_sim_set_cost_order", "emloco_sim_set_split", "emloco_sim_sync", "emloco_sim_set_root_state_indexed",
+    "emloco_sim_set_pd_targets", "emloco_sim_set_dof_actuation_force", "emloco_sim_step", "emloco_sim_step_subset", "emloco_sim_set_cost_order", "emloco_sim_set_split", "emloco_sim_sync", "emloco_sim_set_root_state_indexed",
     "emloco_sim_set_dof_state_indexed", "emloco_sim_refresh_bodies", "emloco_sim_num_candidates",
     "emloco_sim_last_step_ms", "emloco_sim_enable_timing", "emloco_sim_timing_stats",
 ]
@@ -174,6 +174,7 @@ def load():
     lib.emloco_sim_set_params.argtypes = [C.c_void_p, C.POINTER(SimParams)]
     lib.emloco_sim_tensor.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     lib.emloco_sim_set_pd_targets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emloco_sim_set_dof_actuation_force.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emloco_sim_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.emloco_sim_set_cost_order.argtypes = [C.c_void_p, C.c_int]
     lib.emloco_sim_set_split.argtypes = [C.c_void_p, C.c_int]

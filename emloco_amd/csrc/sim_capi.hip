@@ -66,8 +66,8 @@ int emloco_device_count(void) {
 
 int emloco_sim_create(const EmlocoSimParams *params, int device, EmlocoSim **out) {
     if (!params || !out) return fail(EMLOCO_E_ARG, "emloco_sim_create: null argument");
-    if (params->n_sub < 1 || params->h <= 0.0f || params->n_iter < 0)
-        return fail(EMLOCO_E_ARG, "emloco_sim_create: n_sub >= 1, h > 0, n_iter >= 0 required");
+    if (params->n_sub < 1 || params->h <= 0.0f || params->n_iter < 0 || params->drive_mode < 0 || params->drive_mode > 1)
+        return fail(EMLOCO_E_ARG, "emloco_sim_create: n_sub >= 1, h > 0, n_iter >= 0, drive_mode 0 | 1 required");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(EMLOCO_E_NODEV, "no HIP device visible");
     if (device < 0 || device >= n) return fail(EMLOCO_E_ARG, "emloco_sim_create: device index out of range");
@@ -240,6 +240,17 @@ int emloco_sim_set_pd_targets(EmlocoSim *s, const float *dev_targets, void *stre
     if (!s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_set_pd_targets: sim not prepared");
     if (dev_targets != s->d_tgt.p)
         HIPCHK(hipMemcpyAsync(s->d_tgt.p, dev_targets, (size_t)s->n_env * EMLOCO_NDOF * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    s->prm.drive_mode = 0;
+    return EMLOCO_OK;
+}
+
+int emloco_sim_set_dof_actuation_force(EmlocoSim *s, const float *dev_forces, void *stream) {
+    if (!s || !dev_forces) return fail(EMLOCO_E_ARG, "emloco_sim_set_dof_actuation_force: null argument");
+    if (!s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_set_dof_actuation_force: sim not prepared");
+    // the torques travel in the buffer the position targets travel in (one of the two is live, EmlocoSimParams::drive_mode says which)
+    if (dev_forces != s->d_tgt.p)
+        HIPCHK(hipMemcpyAsync(s->d_tgt.p, dev_forces, (size_t)s->n_env * EMLOCO_NDOF * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    s->prm.drive_mode = 1;
     return EMLOCO_OK;
 }
 

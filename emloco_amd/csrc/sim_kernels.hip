@@ -541,7 +541,12 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 const float kp = lane >= 1 ? dr[0] : 0.0f, kd = lane >= 1 ? dr[1] : 0.0f;
                 const float arm = lane >= 1 ? dr[2] : 0.0f, tgt = lane >= 1 ? tgt_env[jdof + k] : 0.0f;
                 const float e = tgt - edof[k];
-                sat[k] = false; tau[k] = kp * e - (kd + h * kp) * wj[k]; dd[k] = arm + h * kd + h * h * kp;
+                if (prm.drive_mode == 1) {       // effort drive (gymapi.DOF_MODE_EFFORT): the given torque within the limit, nothing implicit
+                    const float eff = lane >= 1 ? dr[3] : 0.0f;
+                    sat[k] = true; tau[k] = tgt > eff ? eff : (tgt < -eff ? -eff : tgt); dd[k] = arm;
+                } else {
+                    sat[k] = false; tau[k] = kp * e - (kd + h * kp) * wj[k]; dd[k] = arm + h * kd + h * h * kp;
+                }
             }
         }
 
@@ -750,7 +755,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                     ld4(mdl, o_drv + 4 * k, dr);
                     const float kp = dr[0], kd = dr[1], eff = dr[3];
                     const float ti = tau[k] - (h * kd + h * h * kp) * qdd[k];
-                    if (fabsf(ti) > eff) { sat[k] = true; tau[k] = ti > 0.0f ? eff : -eff; dd[k] = dr[2]; over = true; }
+                    if (!sat[k] && fabsf(ti) > eff) { sat[k] = true; tau[k] = ti > 0.0f ? eff : -eff; dd[k] = dr[2]; over = true; }
                 }
             if (__ballot(over) == 0ull) break;
         }

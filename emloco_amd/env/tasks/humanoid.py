@@ -45,10 +45,10 @@ class Humanoid(BaseTask):
         self.cfg["env"]["numObservations"] = self.get_obs_size()
         self.cfg["env"]["numActions"] = self.get_action_size()
         self.cfg["device_type"], self.cfg["device_id"], self.cfg["headless"] = device_type, device_id, headless
-        if not (self._pd_control and self._local_root_obs and not self._root_height_obs and self._has_shape_obs
+        if not (self._local_root_obs and not self._root_height_obs and self._has_shape_obs
                 and self._has_upright_start and not self._has_limb_weight_obs and self._enable_early_termination):
             raise NotImplementedError("emloco fused kernels cover the pacer.yaml observation configuration "
-                                      "(pdControl, localRootObs, rootHeightObs False, has_shape_obs, upright start)")
+                                      "(localRootObs, rootHeightObs False, has_shape_obs, upright start)")
         super().__init__(cfg=self.cfg)
         self.dt = self.control_freq_inv * sim_params.dt
         self._setup_tensors()
@@ -362,8 +362,10 @@ class Humanoid(BaseTask):
         # it is only read by the launch below, before control returns
         self.wait_obs()             # the observation launch of the last step reads what this step's rigid-body launch overwrites
         self.actions = actions if (actions.device == torch.device(self.device) and actions.dtype == torch.float32) else actions.to(self.device).clone()
-        if not self._pd_control:
-            raise NotImplementedError("torque control is outside the hot path")
+        if not self._pd_control:                                  # humanoid.py:1203-1207: joint torques, effort drives
+            forces = self.actions * self.motor_efforts.unsqueeze(0) * self.power_scale
+            self.gym.set_dof_actuation_force_tensor(self.sim, gymtorch.unwrap_tensor(forces.contiguous()))
+            return
         # pd_tar = offset + scale * a with hands / frozen toes zeroed, one launch (humanoid.py:1188-1202,1281-1283)
         self._post.pd_targets(self.actions.contiguous(), self._pd_action_offset, self._pd_action_scale,
                               self._pd_zero_mask, self._pd_targets)

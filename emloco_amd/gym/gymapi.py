@@ -401,11 +401,18 @@ class Gym:
 
     # ------------------------------------------------------------------ stepping (humanoid.py:1201-1207, base_task.py:258,792-797)
     def set_dof_position_target_tensor(self, sim, tensor):
-        sim.native.set_pd_targets(_as_torch(tensor))
+        try:
+            sim.native.set_pd_targets(_as_torch(tensor))
+        except L.EmlocoError:
+            return False
         return True
 
-    def set_dof_actuation_force_tensor(self, sim, tensor):
-        raise NotImplementedError("emloco: torque control (pdControl: False) is outside the hot path")
+    def set_dof_actuation_force_tensor(self, sim, tensor):    # humanoid.py:1206-1207 (`pdControl: False`: DOF_MODE_EFFORT drives)
+        try:
+            sim.native.set_dof_actuation_force(_as_torch(tensor))
+        except L.EmlocoError:
+            return False                                      # the gym API reports failure by value, it never raises
+        return True
 
     def simulate(self, sim):
         sim.native.step(1)

@@ -34,7 +34,7 @@ from .value_pose_net import ValuePoseNet
 class _ReturnState:
     """Device buffers of the per-env discounted return (amp_continuous_value.py:93-118): updated in place by
     `locoval_returns_kernel` (csrc/predictor_kernels.hip).  The torch restatement of that arithmetic is test infrastructure
-    (oracle/locoval_returns.py), pinned by a fixture generated from the reference's own play_steps."""
+    (the test oracle, module locoval_returns), pinned by a fixture generated from the reference's own play_steps."""
 
     def __init__(self, num_envs, step_to_pred, gamma, device):
         z = lambda: torch.zeros(num_envs, device=device)
@@ -250,7 +250,7 @@ class LocoValRollout:
 
     def _bookkeeping(self, rewards, amp_rewards, dones, inverted):
         """The step's return accumulation and LocoVal fit: 6 HIP launches (the torch formulation of the same arithmetic lives
-        with the tests, oracle/locoval_returns.py: TorchLocoValRollout overrides this hook)."""
+        with the tests, in their oracle package: TorchLocoValRollout overrides this hook)."""
         self._fused_step(rewards, amp_rewards, dones, inverted)
 
     def end_epoch(self):

@@ -56,6 +56,8 @@ def create_dataset(dataset_name, logger=None, **args):
         logger.info("Loading dataset " + dataset_name)
     if dataset_name == "jta_all_visual_cues":
         return JtaAllVisualCuesDataset(**args)
+    if dataset_name == "jrdb_all_visual_cues":                     # dataset_jrdb.py: the same on-disk layout, 26 tokens per person
+        return MultiPersonTrajPoseDataset("jrdb_all_visual_cues", frequency=1, **args)
     raise ValueError(f"Dataset with name '{dataset_name}' not found.")
 
 

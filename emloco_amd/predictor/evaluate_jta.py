@@ -314,3 +314,108 @@ def evaluate_ade_fde(model, valuenet, split, modality_selection, dataloader, bs,
                                ("ADE of rejected samples", "ade_rejected"), ("FDE of rejected samples", "fde_rejected")):
                 logger.info(f"{label}: {res[key]:.5f}")
     return res
+
+
+# ---------------------------------------------------------------------------------------------- entry point (evaluate_jta.py:509-625)
+def build_arg_parser():
+    """The flags of the reference's `python evaluate_jta.py` (evaluate_jta.py:511-527), plus --data_root / --out_root / --dataset."""
+    import argparse
+    p = argparse.ArgumentParser()
+    p.add_argument("--exp_name", type=str, help="checkpoint path")
+    p.add_argument("--split", type=str, default="test", help="Split to use. one of [train, test, valid]")
+    p.add_argument("--metric", type=str, default="ade_fde", help="Evaluation metric")
+    p.add_argument("--modality", type=str, default="traj+all", help="modality combination, e.g. 'traj', 'traj+3dpose', 'traj+all'")
+    p.add_argument("--vis", action="store_true", help="Visualize the predictions (out of scope here: ignored)")
+    p.add_argument("--limit_obs", type=int, default=0, help="Limit the number of observations")
+    p.add_argument("--valueloss", action="store_true", help="Use value loss")
+    p.add_argument("--all_frames", action="store_true", help="Evaluate all observation frames")
+    p.add_argument("--noisy_traj", type=float, default=0, help="Add noise to the trajectory to mimic real data")
+    p.add_argument("--multi_modal", action="store_true", help="Use multi-modal model")
+    p.add_argument("--last_epoch", action="store_true", help="Use last epoch checkpoint")
+    p.add_argument("--no_pose", action="store_true", help="No pose in valuenet")
+    p.add_argument("--no_vel", action="store_true", help="No velocity in valuenet")
+    p.add_argument("--epoch", type=str, default=0, help="Epoch to evaluate")
+    p.add_argument("--filter_threshold", type=float, default=0.7, help="Threshold for filtering samples")
+    p.add_argument("--data_root", type=str, default="data", help="root of <dataset>/preprocess_smpl/<split>/part_*.pkl")
+    p.add_argument("--out_root", type=str, default="experiments", help="root of the experiment directories")
+    p.add_argument("--dataset", type=str, default="jta", choices=["jta", "jrdb"], help="evaluate_jta.py | evaluate_jrdb.py")
+    return p
+
+
+def find_checkpoint(args):
+    """evaluate_jta.py:537-553: which file of the experiment's checkpoint directory the flags select."""
+    import os
+    d = os.path.join(args.out_root, args.dataset.upper(), args.exp_name, "checkpoints")
+    if args.last_epoch:
+        names = ["checkpoint.pth.tar"]
+    elif args.epoch != 0:
+        names = [f"best_val_checkpoint_{args.epoch}epoch.pth.tar", f"checkpoint_{args.epoch}epoch.pth.tar", f"best_val_{args.epoch}.pth.tar"]
+    else:
+        names = ["best_val_checkpoint.pth.tar"]
+    for n in names:
+        if os.path.exists(os.path.join(d, n)):
+            return os.path.join(d, n)
+    raise FileNotFoundError(f"Checkpoint not found: {names} under {d}")
+
+
+def run(args, logger=None):
+    """evaluate_jta.py:555-625: load the checkpoint and its config, the LocoVal network, the split, and evaluate."""
+    import os
+    from torch.utils.data import DataLoader
+    from ..learning.value_pose_net import ValuePoseNet
+    from .train_jta import load_checkpoint, load_config
+    dev = f"cuda:{torch.cuda.current_device()}"
+    ckpt_name = find_checkpoint(args)
+    if logger is not None:
+        logger.info(f"Loading checkpoint from {ckpt_name}")
+    config = torch.load(ckpt_name, map_location="cpu")["config"]
+    new_cfg = load_config(f"configs/{args.dataset}_all_visual_cues.yaml", exp_name=args.exp_name + "_eval", dataset_name=args.dataset.upper(),
+                          out_root=args.out_root)
+    config["DEVICE"], config["NOISY_TRAJ"], config["MULTI_MODAL"] = dev, args.noisy_traj, args.multi_modal
+    config["MODEL"]["value_threshold"] = args.filter_threshold
+    valuenet = None
+    if args.valueloss:
+        valuenet = ValuePoseNet(use_pose=not args.no_pose, use_vel=not args.no_vel)
+        vck = config["MODEL"].get("valuenet_checkpoint") or new_cfg["MODEL"].get("valuenet_checkpoint", "")
+        if vck:
+            valuenet.load_state_dict(torch.load(vck, map_location="cpu"))
+        elif logger is not None:
+            logger.info("No checkpoint provided for valuenet. Using random weights.")
+        valuenet = valuenet.to(dev).eval()
+    from .dataset_jta import create_dataset
+    if args.dataset == "jta":
+        from .dataset_jta import collate_batch
+        from .model_jta import create_model
+    else:
+        from .dataset_jrdb import collate_batch
+        from .model_jrdb import create_model
+    model = create_model(config, logger)
+    load_checkpoint(model, ckpt_name, strict=True)
+    in_F, out_F = config["TRAIN"]["input_track_size"], config["TRAIN"]["output_track_size"]
+    dataset = create_dataset(config["DATA"]["train_datasets"][0], logger, split=args.split, track_size=in_F + out_F, track_cutoff=in_F,
+                             preprocessed=config["DATA"]["preprocessed"], root=args.data_root)
+    bs = new_cfg["TRAIN"]["batch_size"] * 10
+    loader = DataLoader(dataset, batch_size=bs, num_workers=0, shuffle=False, collate_fn=collate_batch)
+    out = {}
+    for obs_i in ([1, 2, 3, 4, 5, 6, 7, 8, 0] if args.all_frames else [args.limit_obs]):
+        if logger is not None:
+            logger.info(f"Evaluating with {9 if obs_i == 0 else obs_i} frames")
+        out[obs_i] = evaluate_ade_fde(model, valuenet, args.split, args.modality, loader, bs, config, logger, args.exp_name, return_all=True,
+                                      limit_obs=obs_i, dataset=args.dataset)
+    return out
+
+
+if __name__ == "__main__":
+    import random
+    from .. import _lib
+    from ..dist import init_from_env
+    from .train_jta import create_logger
+    _lib.require_device()
+    a = build_arg_parser().parse_args()
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    _rank, local_rank, _world = init_from_env("nccl")
+    torch.cuda.set_device(local_rank)
+    import os
+    logdir = os.path.join(a.out_root, a.dataset.upper(), a.exp_name, "eval_logs")
+    os.makedirs(logdir, exist_ok=True)
+    run(a, create_logger(logdir))

@@ -240,3 +240,167 @@ def train_epoch(trainer, dataloader, epoch, modality_selection='traj+all', max_s
         if max_steps is not None and step + 1 >= max_steps:
             break
     return tot / max(n, 1)
+
+
+# ---------------------------------------------------------------------------------------------- entry point (train_jta.py:354-506)
+def load_config(path, exp_name="default", dataset_name="default", out_root="experiments"):
+    """utils/utils.py:49-63: read the yaml, add the OUTPUT directories of the experiment and leave a copy of the config beside
+    the checkpoints.  A relative `path` that does not exist is looked up among the configs that ship with this package."""
+    import os
+    import yaml
+    if not os.path.exists(path):
+        shipped = os.path.join(os.path.dirname(os.path.abspath(__file__)), path)
+        if os.path.exists(shipped):
+            path = shipped
+    with open(path, "rt") as f:
+        config = yaml.safe_load(f)
+    base = os.path.join(out_root, dataset_name, exp_name or "default")
+    config.setdefault("OUTPUT", {})
+    for key, sub in (("log_dir", "logs"), ("ckpt_dir", "checkpoints"), ("runs_dir", "runs")):
+        config["OUTPUT"][key] = os.path.join(base, sub)
+        os.makedirs(config["OUTPUT"][key], exist_ok=True)
+    with open(os.path.join(config["OUTPUT"]["ckpt_dir"], "config.yaml"), "w") as f:
+        yaml.safe_dump(config, f)
+    return config
+
+
+def create_logger(log_dir):
+    import logging
+    import os
+    logger = logging.getLogger("emloco.train_jta")
+    logger.setLevel(logging.INFO)
+    if not logger.handlers:
+        fmt = logging.Formatter("%(asctime)s - %(levelname)s - %(message)s")
+        for h in (logging.StreamHandler(), logging.FileHandler(os.path.join(log_dir, "log.txt"))):
+            h.setFormatter(fmt)
+            logger.addHandler(h)
+    return logger
+
+
+def prepare(config, logger, data_root="data"):
+    """train_jta.py:180-223: the frozen LocoVal network (when the value loss is on) and the train / validation loaders."""
+    from torch.utils.data import ConcatDataset, DataLoader
+    from ..learning.value_pose_net import ValuePoseNet
+    from .dataset_jta import collate_batch, create_dataset, get_datasets
+    valuenet = None
+    if config.get("USE_VALUELOSS"):
+        valuenet = ValuePoseNet(use_pose=config.get("USE_POSE", True), use_vel=config.get("USE_VELOCITY", True)).to(config["DEVICE"])
+        ck = config["MODEL"].get("valuenet_checkpoint", "")
+        if ck:
+            logger.info(f"Loading checkpoint from {ck}")
+            valuenet.load_state_dict(torch.load(ck, map_location="cpu"))
+        else:
+            logger.info("No checkpoint provided for valuenet. Using random weights.")
+    in_F, out_F = config["TRAIN"]["input_track_size"], config["TRAIN"]["output_track_size"]
+    train = ConcatDataset(get_datasets(config["DATA"]["train_datasets"], config, logger, root=data_root))
+    val = create_dataset(config["DATA"]["train_datasets"][0], logger, split="valid", track_size=in_F + out_F, track_cutoff=in_F,
+                         preprocessed=config["DATA"]["preprocessed"], root=data_root)
+    kw = dict(batch_size=config["TRAIN"]["batch_size"], num_workers=config["TRAIN"].get("num_workers", 0), collate_fn=collate_batch)
+    if world_size() > 1:          # data parallel: every rank draws its own slice of each epoch's permutation (nn.DataParallel scatters a batch)
+        from torch.utils.data.distributed import DistributedSampler
+        return valuenet, DataLoader(train, sampler=DistributedSampler(train, shuffle=True, drop_last=True), **kw), DataLoader(val, shuffle=False, **kw)
+    return valuenet, DataLoader(train, shuffle=True, **kw), DataLoader(val, shuffle=False, **kw)
+
+
+def main(config, logger, valuenet, dataloader_train, dataloader_val, limit_obs=0):
+    """train_jta.py:354-444: create the model (optionally resume), train epoch by epoch with the EmLoco loss, keep the best
+    validation checkpoint (`best_val_checkpoint.pth.tar`, `best_val_checkpoint_<epoch>epoch.pth.tar`) and `checkpoint.pth.tar`
+    every fifth epoch.  Returns (best validation ADE, its epoch)."""
+    import os
+    from .model_jta import create_model
+    model = create_model(config, logger)
+    if config.get("RESUME", -1) != -1:
+        ck = config["MODEL"].get("checkpoint", "")
+        if not ck:
+            for name in ("checkpoint.pth.tar", "best_val_checkpoint.pth.tar"):
+                if os.path.exists(os.path.join(config["OUTPUT"]["ckpt_dir"], name)):
+                    ck = os.path.join(config["OUTPUT"]["ckpt_dir"], name)
+                    break
+            if not ck:
+                raise ValueError("No checkpoint found.")
+        logger.info(f"Loading checkpoint from {ck}")
+        load_checkpoint(model, ck)
+    else:
+        logger.info("Training from scratch.")
+    trainer = EmLocoTrainer(model, valuenet, config, data_parallel=world_size() > 1)
+    logger.info(f"Model has {sum(p.numel() for p in model.parameters() if p.requires_grad)} parameters.")
+    if valuenet is not None:
+        logger.info(f'Using Value Loss weight: {float(config["TRAIN"]["valuenet_weight"]):.3f}')
+    modality = config.get("MODALITY", "traj+all")
+    min_val, best_epoch = 1e6, -1
+    for epoch in range(config.get("RESUME", -1) + 1, config["TRAIN"]["epochs"]):
+        tr = train_epoch(trainer, dataloader_train, epoch, modality, max_steps=1 if config.get("dry_run") else None)
+        val_ade = evaluate_loss(model, dataloader_val, config, modality, limit_obs=limit_obs) / 100
+        logger.info(f"Epoch {epoch} | Train Loss: {tr:.3f} | Val ADE: {val_ade:.3f}")
+        if val_ade < min_val:
+            min_val, best_epoch = val_ade, epoch
+            logger.info(f"Best ADE: {val_ade}")
+            save_checkpoint(model, trainer.optimizer, epoch, config, "best_val_checkpoint.pth.tar", logger)
+            save_checkpoint(model, trainer.optimizer, epoch, config, f"best_val_checkpoint_{epoch}epoch.pth.tar", logger)
+        if epoch % 5 == 0:
+            save_checkpoint(model, trainer.optimizer, epoch, config, "checkpoint.pth.tar", logger)
+        if config.get("dry_run"):
+            break
+    return min_val, best_epoch
+
+
+def build_arg_parser():
+    """The flags of the reference's `python train_jta.py` (train_jta.py:446-463), plus --data_root / --out_root for where the
+    preprocessed splits and the experiment directories live."""
+    import argparse
+    p = argparse.ArgumentParser()
+    p.add_argument("--exp_name", type=str, default="", help="Experiment name. Otherwise will use timestamp")
+    p.add_argument("--cfg", type=str, default="configs/jta_all_visual_cues.yaml", help="Config name. Otherwise will use default config")
+    p.add_argument("--dry-run", action="store_true", help="Run just one iteration")
+    p.add_argument("--valueloss_w", type=float, default=0, help="Use value loss")
+    p.add_argument("--resume", type=int, default=-1, help="Resume training from a checkpoint")
+    p.add_argument("--not_pose", action="store_true", help="Not using pose input for value function")
+    p.add_argument("--not_vel", action="store_true", help="Not using velocity input for value function")
+    p.add_argument("--limit_obs", type=int, default=0, help="Limit the number of observations")
+    p.add_argument("--frame_mask", type=bool, default=True, help="Use frame masking")
+    p.add_argument("--value_path", type=str, default="", help="Path to the value network checkpoint")
+    p.add_argument("--value_dir", type=str, default="", help="Directory to the value network checkpoint")
+    p.add_argument("--noisy_traj", type=float, default=0, help="Add noise to the trajectory to mimic real data")
+    p.add_argument("--multi_modal", action="store_true", help="Use multimodal model")
+    p.add_argument("--valueloss_only", action="store_true", help="Train with the value loss only")
+    p.add_argument("--modality", type=str, default="traj+all", help="modality combination, e.g. 'traj', 'traj+3dpose', 'traj+all'")
+    p.add_argument("--data_root", type=str, default="data", help="root of <dataset>/preprocess_smpl/<split>/part_*.pkl")
+    p.add_argument("--out_root", type=str, default="experiments", help="root of the experiment directories")
+    return p
+
+
+def config_from_args(args):
+    """train_jta.py:465-488: the command line folded into the config dict."""
+    import os
+    cfg = load_config(args.cfg, exp_name=args.exp_name, dataset_name="JTA", out_root=args.out_root)
+    cfg["dry_run"], cfg["RESUME"] = args.dry_run, args.resume
+    cfg["USE_VALUELOSS"] = args.valueloss_w > 0
+    cfg["USE_POSE"], cfg["USE_VELOCITY"] = not args.not_pose, not args.not_vel
+    cfg["TRAIN"]["valuenet_weight"] = args.valueloss_w
+    cfg["USE_FRAME_MASK"], cfg["hypara_tune"] = args.frame_mask, False
+    cfg["NOISY_TRAJ"], cfg["MULTI_MODAL"] = args.noisy_traj, args.multi_modal
+    cfg["VAL_LOSS_ONLY"], cfg["MODALITY"] = args.valueloss_only, args.modality
+    ck = args.value_path or cfg["MODEL"].get("valuenet_checkpoint", "")
+    cfg["MODEL"]["valuenet_checkpoint"] = os.path.join(args.value_dir, ck) if ck else ""
+    return cfg
+
+
+if __name__ == "__main__":
+    import random
+    import numpy as np
+    from .. import _lib
+    from ..dist import init_from_env
+    _lib.require_device()                                # the predictor runs on the HIP library: no CPU path
+    args = build_arg_parser().parse_args()
+    rank, local_rank, _world = init_from_env("nccl")
+    torch.cuda.set_device(local_rank)
+    cfg = config_from_args(args)
+    cfg["DEVICE"] = f"cuda:{local_rank}"
+    random.seed(cfg["SEED"]); torch.manual_seed(cfg["SEED"]); np.random.seed(cfg["SEED"])
+    logger = create_logger(cfg["OUTPUT"]["log_dir"])
+    logger.info("Initializing with config:")
+    logger.info(cfg)
+    valuenet, dl_train, dl_val = prepare(cfg, logger, data_root=args.data_root)
+    best, epoch = main(cfg, logger, valuenet, dl_train, dl_val, limit_obs=args.limit_obs)
+    logger.info(f"Best validation loss: {best:.3f} at epoch {epoch}")
+    logger.info("All done.")

@@ -114,6 +114,12 @@ class NativeSim:
     def set_pd_targets(self, targets):
         L.check(self.lib.emloco_sim_set_pd_targets(self._h, dptr(targets), self._stream()), "emloco_sim_set_pd_targets")
 
+    def set_dof_actuation_force(self, forces):
+        """Joint torques [n_env][69] for effort drives (emloco_sim_set_dof_actuation_force); set_pd_targets switches back."""
+        if forces.dtype != torch.float32 or forces.numel() != self.num_envs * 69:
+            raise L.EmlocoError("actuation forces must be a float32 [n_env][69] tensor")
+        L.check(self.lib.emloco_sim_set_dof_actuation_force(self._h, dptr(forces), self._stream()), "emloco_sim_set_dof_actuation_force")
+
     def step(self, n_calls=1):
         L.check(self.lib.emloco_sim_step(self._h, int(n_calls), self._stream()), "emloco_sim_step")
 

@@ -49,6 +49,10 @@ typedef struct {
     float ground_z;         /* plane height (gymapi.PlaneParams.distance) */
     float cfm;              /* relative diagonal regularisation of the contact matrix */
     float warm;             /* contact warm-start factor */
+    int32_t drive_mode;     /* 0: position drives (gymapi.DOF_MODE_POS, implicit PD towards the targets of
+                             * emloco_sim_set_pd_targets); 1: effort drives (gymapi.DOF_MODE_EFFORT, `pdControl: False`,
+                             * humanoid.py:905-913,1203-1207): the torques of emloco_sim_set_dof_actuation_force, clipped to the
+                             * effort limits, no drive stiffness or damping */
 } EmlocoSimParams;
 
 /* Host description of the humanoids, one model per env (gym.load_asset + create_actor,
@@ -129,6 +133,9 @@ int emloco_sim_set_params(EmlocoSim *sim, const EmlocoSimParams *in);
 int emloco_sim_tensor(EmlocoSim *sim, int kind, void **dev_ptr, int64_t shape[2]);
 /* gym.set_dof_position_target_tensor -- humanoid.py:1201-1202 (device pointer, [n_env][69] f32) */
 int emloco_sim_set_pd_targets(EmlocoSim *sim, const float *dev_targets, void *stream);
+/* gym.set_dof_actuation_force_tensor -- humanoid.py:1206-1207 (device pointer, [n_env][69] f32 joint torques).  Switches the
+ * sim to effort drives (drive_mode = 1) for the steps that follow; emloco_sim_set_pd_targets switches back. */
+int emloco_sim_set_dof_actuation_force(EmlocoSim *sim, const float *dev_forces, void *stream);
 /* gym.simulate x n_calls -- base_task.py:792-797 (n_calls = controlFrequencyInv); one fused launch */
 int emloco_sim_step(EmlocoSim *sim, int n_calls, void *stream);
 /* The same step for a subset of the envs (extension; envs are independent, humanoid.py:838-841, so a step of all envs may be

@@ -51,12 +51,12 @@ class SimParams(C.Structure):
     _fields_ = [("n_sub", C.c_int32), ("n_iter", C.c_int32), ("h", C.c_float), ("gravity_z", C.c_float),
                 ("contact_offset", C.c_float), ("erp", C.c_float), ("max_depen_vel", C.c_float),
                 ("mu", C.c_float), ("ang_damping", C.c_float), ("max_ang_vel", C.c_float),
-                ("ground_z", C.c_float), ("cfm", C.c_float), ("warm", C.c_float)]
+                ("ground_z", C.c_float), ("cfm", C.c_float), ("warm", C.c_float), ("drive_mode", C.c_int32)]
 
 
 def default_params(**kw):
     p = dict(n_sub=4, n_iter=4, h=1.0 / 120.0, gravity_z=-9.81, contact_offset=0.02, erp=0.2,
-             max_depen_vel=10.0, mu=1.0, ang_damping=0.01, max_ang_vel=100.0, ground_z=0.0, cfm=1e-4, warm=1.0)
+             max_depen_vel=10.0, mu=1.0, ang_damping=0.01, max_ang_vel=100.0, ground_z=0.0, cfm=1e-4, warm=1.0, drive_mode=0)
     p.update(kw)
     return SimParams(**p)
 

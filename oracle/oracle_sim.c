@@ -467,6 +467,13 @@ static void bias_and_drive(Env *s, const EnvModel *m, const OrcSimParams *prm, c
         for (int k = 0; k < 3; ++k) {
             int d = (i - 1) * 3 + k;
             float e = tgt[d] - edof[d];
+            if (prm->drive_mode == 1) {      /* effort drive: the given torque within the limit, nothing implicit */
+                float t = tgt[d];
+                s->sat[i][k] = 1;
+                s->tau[i][k] = t > m->eff[d] ? m->eff[d] : (t < -m->eff[d] ? -m->eff[d] : t);
+                s->dd[i][k] = m->arm[d];
+                continue;
+            }
             s->sat[i][k] = 0;
             s->tau[i][k] = m->kp[d] * e - (m->kd[d] + h * m->kp[d]) * s->wj[i][k];
             s->dd[i][k] = m->arm[d] + h * m->kd[d] + h * h * m->kp[d];
@@ -483,7 +490,7 @@ static int saturate_drives(Env *s, const EnvModel *m, const OrcSimParams *prm, f
         for (int k = 0; k < 3; ++k) {
             int d = (i - 1) * 3 + k;
             float ti = s->tau[i][k] - (h * m->kd[d] + h * h * m->kp[d]) * qdd[i][k];
-            if (fabsf(ti) > m->eff[d]) {
+            if (!s->sat[i][k] && fabsf(ti) > m->eff[d]) {
                 s->sat[i][k] = 1;
                 s->tau[i][k] = ti > 0.0f ? m->eff[d] : -m->eff[d];
                 s->dd[i][k] = m->arm[d];

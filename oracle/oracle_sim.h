@@ -32,6 +32,8 @@ typedef struct {
     float ground_z;        /* height of the ground plane */
     float cfm;             /* relative diagonal regularisation of the contact matrix */
     float warm;            /* warm-start factor for contact impulses */
+    int32_t drive_mode;    /* 0: implicit PD drives towards pd_target; 1: effort drives -- pd_target holds joint torques, applied
+                            * clipped to the effort limits with no drive stiffness / damping (gymapi.DOF_MODE_EFFORT) */
 } OrcSimParams;
 
 typedef struct {

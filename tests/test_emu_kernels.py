@@ -73,6 +73,27 @@ def test_sim_step_kernel_split_launch_lost_handover_raises_the_error_word(monkey
         assert np.array_equal(y[1], before[name].reshape(E, -1)[1]), name         # the poisoned env: abandoned, not corrupted
 
 
+def test_sim_step_kernel_effort_drives_are_bit_exact_vs_oracle():
+    """drive_mode = 1 (gym.set_dof_actuation_force_tensor, humanoid.py:1203-1207): joint torques instead of position targets,
+    some beyond the effort limit, contacts and limb-limb contacts active -- the emulated kernel stays on the oracle's bytes."""
+    E = 3
+    models = varied_models(E, seed=41)
+    root, dof, _ = scene_state(E, seed=42)
+    rng = np.random.default_rng(43)
+    torque = (rng.normal(size=(E, 69)) * 120.0).astype(np.float32)
+    torque[:, ::7] *= 8.0                                               # beyond the 500 N m limit here and there
+    a = oracle_sim(models, root, dof, torque, self_collision=True, n_sub=4, drive_mode=1)
+    b = oracle_sim(models, root, dof, torque, self_collision=True, n_sub=4, drive_mode=1)
+    for _ in range(3):
+        a.step(1)
+        emu.sim_step(b, 1)
+    for name in ("root_state", "dof_state", "rb_state", "contact_force", "dof_force", "lambda_ws"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert np.isfinite(a.rb_state).all()
+    lim = np.stack([m.effort for m in models]).astype(np.float32)
+    assert np.array_equal(a.dof_force, np.clip(torque, -lim, lim))      # what the drives applied = the command within the limit
+
+
 def test_sim_step_kernel_fallen_humanoids_are_bit_exact_vs_oracle():
     """Humanoids lying on the ground, pressed into it: more candidates than contact slots (the shallowest are dropped), limb-limb
     contacts, contact bodies at several tree depths in the Gram build.  (Pelvis contacts -- tree depth 0 -- come up in the

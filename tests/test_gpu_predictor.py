@@ -1,5 +1,6 @@
 """GPU parity of the predictor path: this repo's TransMotionJTA / ValuePoseNet (HIP kernels) against golden vectors
 produced by the reference's own model code (tests/golden/gen_golden_predictor.py).  fp32 MFMA path: 1e-4 rel."""
+import os
 import numpy as np
 import pytest
 
@@ -658,3 +659,35 @@ def test_feed_forward_node_matches_the_two_linear_layers():
             _close(a.cpu().numpy(), b.cpu().numpy(), rel=1e-5, abs_=1e-6, what=what)
         if p > 0:
             assert (res[0][0] == 0).float().mean().item() > 0.05        # the output dropout really drops
+
+
+def test_train_and_evaluate_entry_points_from_the_shipped_yaml(tmp_path):
+    """`python -m emloco_amd.predictor.train_jta --cfg configs/jta_all_visual_cues.yaml --valueloss_w 1.0 --dry-run` and
+    `python -m emloco_amd.predictor.evaluate_jta --valueloss --multi_modal ...` (social-transmotion/train_jta.py:446-506,
+    evaluate_jta.py:509-625): the reference's command lines on a synthetic preprocessed split -- the shipped yaml builds the
+    6 + 3-layer model through create_model, one optimiser step runs, the best-validation checkpoint and the config copy land in
+    the experiment directory, and the evaluation entry point loads them and logs finite metrics."""
+    import subprocess
+    import sys
+    from emloco_amd.predictor.dataset_jta import write_synthetic_split
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = str(tmp_path / "data")
+    for split, n in (("train", 24), ("valid", 12), ("test", 12)):
+        write_synthetic_split(data, split, n, max_people=3, seed=len(split))
+    out = str(tmp_path / "experiments")
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "emloco_amd.predictor.train_jta", "--exp_name", "t0", "--cfg", "configs/jta_all_visual_cues.yaml",
+                        "--valueloss_w", "1.0", "--dry-run", "--multi_modal", "--data_root", data, "--out_root", out],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ck = os.path.join(out, "JTA", "t0", "checkpoints")
+    assert os.path.exists(os.path.join(ck, "best_val_checkpoint.pth.tar")) and os.path.exists(os.path.join(ck, "config.yaml"))
+    assert "Model has 3225064 parameters" in r.stderr + r.stdout           # the shipped architecture with its 20 heads (SURVEY 8c)
+    r = subprocess.run([sys.executable, "-m", "emloco_amd.predictor.evaluate_jta", "--exp_name", "t0", "--valueloss", "--multi_modal",
+                        "--filter_threshold", "0.5", "--data_root", data, "--out_root", out],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    log = r.stderr + r.stdout
+    assert "Total samples: 12" in log and "ADE with Value sampling" in log
+    ade = float(log.split("ADE: ")[1].split()[0])
+    assert np.isfinite(ade) and ade > 0

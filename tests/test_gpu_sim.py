@@ -304,3 +304,33 @@ def test_cost_order_above_the_lds_sort_capacity():
         sims.append(s)
     assert torch.equal(sims[0].rigid_body_state, sims[1].rigid_body_state)
     assert torch.equal(sims[0].dof_state, sims[1].dof_state)
+
+
+def test_effort_drives_through_the_c_abi_are_bit_exact_and_switch_back():
+    """emloco_sim_set_dof_actuation_force (gym.set_dof_actuation_force_tensor, humanoid.py:1203-1207, `pdControl: False`): joint
+    torques instead of position targets -- bit-exact against the oracle's drive_mode = 1, the reported dof forces are the
+    commands clipped to the effort limits; emloco_sim_set_pd_targets switches the sim back to position drives."""
+    from helpers import oracle_sim, scene_state, varied_models
+    E = 48
+    osim, gsim = _mk(E, seed=51)
+    models = varied_models(E, 51)
+    rng = np.random.default_rng(52)
+    torque = (rng.normal(size=(E, 69)) * 120.0).astype(np.float32)
+    torque[:, ::7] *= 8.0
+    osim.params.drive_mode = 1
+    osim.pd_target[:] = torque
+    tq = torch.from_numpy(torque).to(gsim.device)
+    for k in range(4):
+        osim.step(1)
+        gsim.set_dof_actuation_force(tq)
+        gsim.step(2)
+        _compare(osim, gsim, E, what=f"effort step {k}")
+    lim = np.stack([m.effort for m in models]).astype(np.float32)
+    assert np.array_equal(gsim.dof_force.view(E, 69).cpu().numpy(), np.clip(torque, -lim, lim))
+    osim.params.drive_mode = 0
+    osim.pd_target[:] = 0.0
+    gsim.set_pd_targets(torch.zeros(E, 69, device=gsim.device))
+    for k in range(2):
+        osim.step(1)
+        gsim.step(2)
+        _compare(osim, gsim, E, what=f"position step {k}")

@@ -118,3 +118,23 @@ def test_jta_dataset_pickles_and_collate(tmp_path):
     assert len(get_datasets(["jta_all_visual_cues"], cfg, root=str(tmp_path))[0]) == 23
     with pytest.raises(ValueError):
         create_dataset("nope", split="train", preprocessed=True, root=str(tmp_path))
+def test_predictor_config_and_cli_plumbing(tmp_path):
+    """The shipped yaml files parse into the dict create_model reads, the command line folds into it as train_jta.py:465-488
+    does, and the checkpoint picker follows evaluate_jta.py:537-553 -- host logic only, no GPU."""
+    import os
+    from emloco_amd.predictor import evaluate_jta as ev
+    from emloco_amd.predictor import train_jta as tr
+    args = tr.build_arg_parser().parse_args(["--exp_name", "x", "--valueloss_w", "1.0", "--multi_modal", "--out_root", str(tmp_path)])
+    cfg = tr.config_from_args(args)
+    assert cfg["MODEL"]["num_layers_local"] == 6 and cfg["MODEL"]["num_layers_global"] == 3 and cfg["MODEL"]["num_modes"] == 20
+    assert cfg["MODEL"]["seq_len"] == 453 and cfg["MODEL"]["token_num"] == 49 and cfg["TRAIN"]["max_grad_norm"] == 1.0
+    assert cfg["USE_VALUELOSS"] and cfg["MULTI_MODAL"] and cfg["TRAIN"]["valuenet_weight"] == 1.0 and cfg["RESUME"] == -1
+    assert os.path.exists(os.path.join(cfg["OUTPUT"]["ckpt_dir"], "config.yaml"))
+    j = tr.load_config("configs/jrdb_all_visual_cues.yaml", exp_name="y", dataset_name="JRDB", out_root=str(tmp_path))
+    assert j["MODEL"]["seq_len"] == 246 and j["MODEL"]["token_num"] == 26 and j["TRAIN"]["batch_size"] == 20
+    ea = ev.build_arg_parser().parse_args(["--exp_name", "x", "--out_root", str(tmp_path), "--epoch", "7"])
+    d = os.path.join(str(tmp_path), "JTA", "x", "checkpoints")
+    open(os.path.join(d, "checkpoint_7epoch.pth.tar"), "w").close()
+    assert ev.find_checkpoint(ea).endswith("checkpoint_7epoch.pth.tar")
+    open(os.path.join(d, "best_val_checkpoint_7epoch.pth.tar"), "w").close()
+    assert ev.find_checkpoint(ea).endswith("best_val_checkpoint_7epoch.pth.tar")

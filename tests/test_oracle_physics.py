@@ -526,3 +526,34 @@ def test_limb_limb_friction_is_coulomb_capped_by_the_damper_and_internal():
     P1 = _momenta(m, s1.rb_state[0])[0]
     assert np.linalg.norm(P1) < 2e-3 * m.mass.sum()                             # internal forces: the floating body does not drift
     assert slide1.sum() < -1.0 and np.all(slide1 <= 1e-6) and np.abs(slide0).max() < 1e-3, (slide1.sum(), np.abs(slide0).max())   # dissipative; none without mu
+
+
+def test_effort_drive_is_the_constant_torque_recurrence_and_respects_the_limit():
+    """Effort drives (drive_mode = 1, `pdControl: False`, humanoid.py:1203-1207): a constant torque on the L_Hand joint of a
+    free-floating humanoid gives that joint the closed-form constant acceleration tau / (I + armature) -- the hand is light on a
+    heavy arm, angular damping off -- with no drive stiffness or damping in the way, the reported dof force is the commanded
+    torque, and a command beyond the effort limit is applied (and reported) at the limit."""
+    m = smpl_humanoid()
+    s = oracle.Sim(pack_models([m]), oracle.default_params(gravity_z=0.0, n_sub=1, ang_damping=0.0, drive_mode=1))
+    s.root_state[0, :3] = [52, 55, 50]
+    b = m.names.index("L_Hand")
+    j = (b - 1) * 3 + 1
+    tau = 0.02
+    s.pd_target[0, j] = tau
+    got = []
+    for _ in range(30):
+        s.step()
+        got.append(s.dof_state[0, j, 1])
+    yy, c = m.inertia[b][1], m.com[b]
+    I = yy + m.mass[b] * (c[0] ** 2 + c[2] ** 2) + m.armature[j]
+    ref = tau / I * (1.0 / 120.0) * np.arange(1, 31)
+    np.testing.assert_allclose(got, ref, rtol=0.02)                    # the arm gives way a little: 2 %
+    assert abs(s.dof_force[0, j] - tau) < 1e-7
+    others = np.delete(np.arange(69), [j])
+    assert np.abs(s.dof_force[0, others]).max() == 0.0
+    s2 = oracle.Sim(pack_models([m]), oracle.default_params(gravity_z=0.0, n_sub=1, drive_mode=1))
+    s2.root_state[0, :3] = [52, 55, 50]
+    s2.pd_target[0, j] = 10.0 * m.effort[j]
+    s2.step()
+    assert s2.dof_force[0, j] == np.float32(m.effort[j])
+    assert np.isfinite(s2.dof_state).all()
