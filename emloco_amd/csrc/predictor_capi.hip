@@ -305,6 +305,16 @@ int emloco_obs_normalize(int rows, int cols, const float *x, int ldx, const floa
     return 0;
 }
 
+int emloco_rms_update(int rows, int cols, const float *x, int ldx, double *mean, double *var, const double *count_in, double *count_out,
+                      int first_col, void *stream) {
+    if (rows < 1 || cols < 1 || !x || !mean || !var || !count_in || !count_out || count_in == count_out || ldx < cols || first_col < 0 || first_col > cols)
+        return pfail(-1, "emloco_rms_update: bad argument");
+    hipLaunchKernelGGL(emloco::rms_update_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, (hipStream_t)stream, rows, cols, x, ldx,
+                       mean, var, count_in, count_out, first_col);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
 int emloco_locoval_fwd(int B, const float *traj, int traj_stride, const float *pose, const float *vel, const float *w1,
                        const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float *value,
                        float *x100, float *h1, float *h2, float *angle, void *stream) {

@@ -593,6 +593,57 @@ obs_normalize_kernel(int rows, int cols, const float *x, int ldx, const float *m
     }
 }
 
+// ------------------------------------------------------------------ observation normaliser: statistics update
+// RunningMeanStd.forward in training mode (pacer/pacer/utils/running_mean_std.py:85-95): the batch's per-column mean and
+// unbiased variance (torch.var) are merged into the float64 running moments with the parallel-variance rule,
+//   n = count + rows, d = mean_b - mean, mean <- mean + d rows / n, var <- (var count + var_b rows + d^2 count rows / n) / n,
+// in ONE launch with no intermediate tensors.  A workgroup owns 64 columns; its 4 waves take every fourth row each (coalesced
+// 256-byte row segments), keep a Welford pair (mean, M2) per column in float64 and are folded with the same rule in LDS.
+// Columns below first_col keep their moments (freeze_partial: only the last `diff` columns learn); the new count goes to
+// count_out (every workgroup reads count_in, so it is not updated in place).
+__global__ void __launch_bounds__(256)
+rms_update_kernel(int rows, int cols, const float *x, int ldx, double *mean, double *var, const double *count_in, double *count_out, int first_col) {
+    __shared__ double sh_m[4][64], sh_s[4][64];
+    __shared__ int sh_n[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    double m = 0.0, s2 = 0.0;
+    int n = 0;
+    if (j < cols)
+        for (int r = w; r < rows; r += 4) {
+            const double v = (double)x[(long)r * ldx + j];
+            n += 1;
+            const double d = v - m;
+            m += d / (double)n;
+            s2 += d * (v - m);
+        }
+    else
+        for (int r = w; r < rows; r += 4) n += 1;
+    sh_m[w][lane] = m; sh_s[w][lane] = s2;
+    if (lane == 0) sh_n[w] = n;
+    __syncthreads();
+    if (w == 0 && j < cols) {
+        double nb = (double)sh_n[0];
+        for (int k = 1; k < 4; ++k) {
+            const double nk = (double)sh_n[k];
+            if (nk > 0.0) {
+                const double d = sh_m[k][lane] - m, nt = nb + nk;
+                m += d * nk / nt;
+                s2 += sh_s[k][lane] + d * d * nb * nk / nt;
+                nb = nt;
+            }
+        }
+        const double cnt = count_in[0], bvar = s2 / (nb - 1.0);        // torch.var: unbiased (NaN for a one-row batch, as in torch)
+        if (j >= first_col) {
+            const double d = m - mean[j], tot = cnt + nb;
+            const double M2 = var[j] * cnt + bvar * nb + d * d * cnt * nb / tot;
+            mean[j] += d * nb / tot;
+            var[j] = M2 / tot;
+        }
+        if (j == 0) count_out[0] = cnt + nb;
+    }
+}
+
 // ------------------------------------------------------------------ LocoVal (one wave per sample)
 #define LV_IN 100
 #define LV_H1 49

@@ -1,9 +1,12 @@
-"""RunningMeanStd -- mirror of /root/reference/pacer/pacer/utils/running_mean_std.py:9-97.
+"""RunningMeanStd: the observation / AMP-observation normaliser of the policy and the learners.
 
-Same constructor, buffers (float64 `running_mean`, `running_var`, `count`), freeze switches and `forward(input,
-unnorm=False)` semantics.  The eval-mode normalisation of a 2-D batch (the policy-input hot path, SURVEY.md section 8
-row A19) runs in `emloco_obs_normalize`; the statistics update (training only) and the rarely used branches stay in
-torch on the device.
+Stands where /root/reference/pacer/pacer/utils/running_mean_std.py:9-97 stands: same constructor, the same three float64
+buffers under the same names (`running_mean`, `running_var`, `count` -- reference checkpoints load), the same freeze switches
+and `forward(input, unnorm=False)` contract.  Both halves of forward run in libemloco_hip.so for the batches the rollout
+produces (2-D float32 on the device): the normalisation in `emloco_obs_normalize` (policy hot path, SURVEY.md section 8 row
+A19), the statistics update of training mode in `emloco_rms_update` -- one launch that folds the batch's per-column mean and
+unbiased variance into the running moments with the parallel-variance rule.  The per-channel image layouts of the reference
+class are not part of this path and are rejected.
 """
 import ctypes as C
 
@@ -35,24 +38,35 @@ def obs_normalize(x, mean32, var32, eps, clip=5.0, split=None, out0=None, out1=N
     return out0, out1
 
 
+def rms_update(x, mean64, var64, count64, first_col=0, scratch=None):
+    """Fold the batch x (rows, cols) into the running moments in place (emloco_rms_update); returns nothing.  `count64` is a
+    0-dim float64 tensor; the kernel writes the new count to `scratch` and it is copied back on the same stream."""
+    lib = L.require_device()
+    rows, cols = x.shape
+    if scratch is None:
+        scratch = torch.empty((), dtype=torch.float64, device=x.device)
+    vp = C.c_void_p
+    rc = lib.emloco_rms_update(rows, cols, vp(x.data_ptr()), x.stride(0), vp(mean64.data_ptr()), vp(var64.data_ptr()), vp(count64.data_ptr()),
+                               vp(scratch.data_ptr()), int(first_col), current_stream_handle(x.device))
+    if rc != 0:
+        raise L.EmlocoError(f"emloco_rms_update failed with code {rc}")
+    count64.copy_(scratch)
+
+
 class RunningMeanStd(nn.Module):
     def __init__(self, insize, epsilon=1e-05, per_channel=False, norm_only=False):
         super().__init__()
-        self.insize = insize
-        self.epsilon = epsilon
-        self.norm_only = norm_only
-        self.per_channel = per_channel
         if per_channel:
-            self.axis = {3: [0, 2, 3], 2: [0, 2], 1: [0]}[len(self.insize)]
-            in_size = self.insize[0]
-        else:
-            self.axis = [0]
-            in_size = insize
-        self.register_buffer("running_mean", torch.zeros(in_size, dtype=torch.float64))
-        self.register_buffer("running_var", torch.ones(in_size, dtype=torch.float64))
+            raise NotImplementedError("RunningMeanStd(per_channel=True) normalises image tensors; the rollout path has flat observations only")
+        self.insize, self.epsilon, self.norm_only, self.per_channel = insize, epsilon, norm_only, False
+        self.axis = [0]
+        self.register_buffer("running_mean", torch.zeros(insize, dtype=torch.float64))
+        self.register_buffer("running_var", torch.ones(insize, dtype=torch.float64))
         self.register_buffer("count", torch.ones((), dtype=torch.float64))
-        self.forzen = False            # (sic) attribute names as in the reference
+        # the reference spells these two attributes this way; checkpoints and callers that poke them keep working
+        self.forzen = False
         self.forzen_partial = False
+        self.diff = 0
 
     def freeze(self):
         self.forzen = True
@@ -61,45 +75,26 @@ class RunningMeanStd(nn.Module):
         self.forzen = False
 
     def freeze_partial(self, diff):
-        self.forzen_partial = True
-        self.diff = diff
+        """Only the last `diff` columns keep learning (the future part of the observation); the count advances for all."""
+        self.forzen_partial, self.diff = True, int(diff)
 
-    def _update_mean_var_count_from_moments(self, mean, var, count, batch_mean, batch_var, batch_count):
-        delta = batch_mean - mean
-        tot_count = count + batch_count
-        new_mean = mean + delta * batch_count / tot_count
-        m_a = var * count
-        m_b = batch_var * batch_count
-        M2 = m_a + m_b + delta ** 2 * count * batch_count / tot_count
-        return new_mean, M2 / tot_count, tot_count
+    def _on_device_batch(self, t):
+        return t.dim() == 2 and t.is_cuda and t.dtype == torch.float32 and t.stride(1) == 1 and not t.requires_grad
 
     def forward(self, input, unnorm=False):
-        if self.per_channel:
-            shape = [1, self.insize[0]] + [1] * (len(self.insize) - 1)
-            current_mean = self.running_mean.view(shape).expand_as(input)
-            current_var = self.running_var.view(shape).expand_as(input)
-        else:
-            current_mean, current_var = self.running_mean, self.running_var
-        if unnorm:
-            y = torch.clamp(input, min=-5.0, max=5.0)
-            y = torch.sqrt(current_var.float() + self.epsilon) * y + current_mean.float()
+        mean32, var32 = self.running_mean.float(), self.running_var.float()
+        if unnorm:                                   # back from normalised values: sigma * clamp(y) + mu
+            out = torch.sqrt(var32 + self.epsilon) * input.clamp(-5.0, 5.0) + mean32
         elif self.norm_only:
-            y = input / torch.sqrt(current_var.float() + self.epsilon)
-        elif (not self.per_channel) and input.dim() == 2 and input.is_cuda and input.dtype == torch.float32 \
-                and input.stride(1) == 1 and not input.requires_grad:
-            y, _ = obs_normalize(input, current_mean.float(), current_var.float(), self.epsilon)
-        else:
-            y = (input - current_mean.float()) / torch.sqrt(current_var.float() + self.epsilon)
-            y = torch.clamp(y, min=-5.0, max=5.0)
-        # statistics are updated AFTER normalising, as in the reference (running_mean_std.py:85-95)
+            out = input / torch.sqrt(var32 + self.epsilon)
+        elif self._on_device_batch(input):
+            out, _ = obs_normalize(input, mean32, var32, self.epsilon)
+        else:                                        # gradients wanted, or a layout the kernel does not take: elementwise torch on the device
+            out = ((input - mean32) / torch.sqrt(var32 + self.epsilon)).clamp(-5.0, 5.0)
+        # the moments learn from the batch AFTER it has been normalised with the old ones (running_mean_std.py:85-95)
         if self.training and not self.forzen:
-            mean = input.mean(self.axis)
-            var = input.var(self.axis)
-            new_mean, new_var, new_count = self._update_mean_var_count_from_moments(
-                self.running_mean, self.running_var, self.count, mean, var, input.size()[0])
-            if self.forzen_partial:
-                self.running_mean[-self.diff:], self.running_var[-self.diff:], self.count = \
-                    new_mean[-self.diff:], new_var[-self.diff:], new_count
-            else:
-                self.running_mean, self.running_var, self.count = new_mean, new_var, new_count
-        return y
+            if not self._on_device_batch(input.detach()):
+                raise L.EmlocoError("RunningMeanStd statistics update needs a 2-D float32 batch on the GPU (emloco_rms_update); there is no CPU path")
+            first = input.shape[1] - self.diff if self.forzen_partial else 0
+            rms_update(input.detach(), self.running_mean, self.running_var, self.count, first_col=first)
+        return out

@@ -145,6 +145,14 @@ int64_t emloco_colsum_workspace(int m, int n);   /* floats */
 int emloco_obs_normalize(int rows, int cols, const float *x, int ldx, const float *mean, const float *var, float eps,
                          float clip, int split, float *out0, int ld0, float *out1, int ld1, void *stream);
 
+/* Statistics update of the same normaliser (RunningMeanStd.forward in training mode, running_mean_std.py:85-95, called once per
+ * rollout step by the PPO / AMP learner on the observation and AMP-observation batches): merges the per-column mean and unbiased
+ * variance of x [rows][ldx] into the float64 running moments mean / var [cols] with the parallel-variance rule (count_in [1] rows
+ * seen so far), one launch, no intermediate tensors.  Columns below first_col keep their moments (freeze_partial); the new count
+ * is written to count_out [1] (a different buffer than count_in). */
+int emloco_rms_update(int rows, int cols, const float *x, int ldx, double *mean, double *var, const double *count_in, double *count_out,
+                      int first_col, void *stream);
+
 /* LocoVal MLP (value_pose_net.py:36-159), fused: yaw normalisation (:73-103) + hidden joints zeroed (:141-144)
  * + 100->49->24->1 MLP with ReLU/ReLU/sigmoid.  traj [B][13][traj_stride>=2], pose [B][24][3], vel [B][2].
  * Outputs value [B]; x100 [B][100] (normalised MLP input) and h1 [B][49], h2 [B][24] are kept for the backward. */

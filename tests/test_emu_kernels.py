@@ -450,6 +450,27 @@ def test_obs_normalize_kernel_matches_reference_golden(golden):
     assert np.all(out1[:, cols - split:] == 0) and ref.max() == 5.0 and ref.min() == -5.0
 
 
+def test_rms_update_kernel_matches_the_reference_class(golden):
+    """rms_update_kernel (RunningMeanStd's training-mode statistics update, one launch) against the moments the reference's own
+    class reached over four batches (tests/golden/gen_golden_rms.py), freeze_partial(3) from the third batch on: float64 moments
+    to 2e-6 (the reference takes the batch mean / variance in float32 before merging; the kernel accumulates in float64), the count
+    exactly."""
+    g = golden("running_mean_std")
+    lib = emu.lib()
+    cols = g["x0"].shape[1]
+    mean, var = np.zeros(cols, np.float64), np.ones(cols, np.float64)
+    cnt, cnt2 = np.ones(1, np.float64), np.zeros(1, np.float64)
+    for i in range(int(g["n_batches"])):
+        x = np.ascontiguousarray(g[f"x{i}"], np.float32)
+        first = cols - 3 if i >= 2 else 0
+        lib.emu_rms_update(x.shape[0], cols, P(x), cols, mean.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p),
+                           cnt.ctypes.data_as(C.c_void_p), cnt2.ctypes.data_as(C.c_void_p), first)
+        cnt[0] = cnt2[0]
+        np.testing.assert_allclose(mean, g[f"mean{i}"], rtol=2e-6, atol=2e-6, err_msg=f"batch {i}")
+        np.testing.assert_allclose(var, g[f"var{i}"], rtol=2e-6, atol=2e-6, err_msg=f"batch {i}")
+        assert cnt[0] == float(g[f"count{i}"])
+
+
 def test_fused_attention_kernels_forward_and_backward():
     """attn_fwd / attn_bwd_dq / attn_bwd_dkv (head dim 32) against a float64 numpy attention, ragged S (two query blocks'
     worth of tiles would be slow in the emulator: S = 70 covers a partial last tile), additive and -inf key biases."""

@@ -215,3 +215,32 @@ def test_amp_ppo_losses_match_plain_torch_double_backward():
     for k, g in got.items():
         _close(g.cpu(), P[k].grad.cpu(), rel=3e-4, abs_=1e-6, what=f"grad {k}")
     assert abs(info["disc_grad_penalty"].item() - gx.pow(2).sum(-1).mean().item()) <= 1e-4 * gx.pow(2).sum(-1).mean().item()
+
+
+def test_running_mean_std_training_update_matches_the_reference_class():
+    """RunningMeanStd in training mode on the device (normalise with the old moments, then emloco_rms_update) against the
+    reference's own class over four batches incl. freeze_partial (tests/golden/gen_golden_rms.py): outputs and moments to 2e-6 (the reference takes
+    the batch mean / variance in float32 before merging, the kernel accumulates in float64), count exact; eval mode leaves the moments alone; a CPU batch in training mode is refused (no CPU path)."""
+    import os
+    from emloco_amd import _lib as L
+    from emloco_amd.utils.running_mean_std import RunningMeanStd
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "running_mean_std.npz"))
+    cols = g["x0"].shape[1]
+    rms = RunningMeanStd((cols,)).to(DEV)
+    rms.train()
+    for i in range(int(g["n_batches"])):
+        if i == 2:
+            rms.freeze_partial(3)
+        y = rms(torch.from_numpy(g[f"x{i}"]).to(DEV))
+        np.testing.assert_allclose(y.cpu().numpy(), g[f"y{i}"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(rms.running_mean.cpu().numpy(), g[f"mean{i}"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(rms.running_var.cpu().numpy(), g[f"var{i}"], rtol=2e-6, atol=2e-6)
+        assert float(rms.count) == float(g[f"count{i}"])
+    rms.eval()
+    before = rms.running_mean.clone()
+    rms(torch.from_numpy(g["x0"]).to(DEV))
+    assert torch.equal(before, rms.running_mean)
+    cpu = RunningMeanStd((cols,))
+    cpu.train()
+    with pytest.raises(L.EmlocoError):
+        cpu(torch.from_numpy(g["x0"]))
