@@ -79,12 +79,32 @@ __device__ __forceinline__ void at_row16(const float *tile, int row, int h, at_f
     f[0] = *(const at_f32x4 *)src; f[1] = *(const at_f32x4 *)(src + 4);
     f[2] = *(const at_f32x4 *)(src + 8); f[3] = *(const at_f32x4 *)(src + 12);
 }
+// IO = 1: the tensor behind `base` holds bf16 (the reduced-precision mode keeps q|k|v and its gradient in HBM as bf16): element
+// offsets are applied on the 2-byte type, four values arrive in one 8-byte load and are widened, results are rounded on the way out
+template <int IO>
+__device__ __forceinline__ const float *at_off(const float *base, long elems) {
+    return IO ? (const float *)((const unsigned short *)base + elems) : base + elems;
+}
+template <int IO>
+__device__ __forceinline__ at_f32x4 at_ld4(const float *base, long elems) {
+    if (IO) {
+        const uint2 u = *(const uint2 *)((const unsigned short *)base + elems);
+        return at_f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    }
+    return *(const at_f32x4 *)(base + elems);
+}
+__device__ __forceinline__ unsigned at_bf16_pair(float lo, float hi) {          // two values rounded to nearest even, packed
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7fffu + ((a >> 16) & 1u); b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
 // the same from global memory (a row of Q / K / V / dO / O of one head), zero for rows past the sequence
+template <int IO = 0>
 __device__ __forceinline__ void at_grow16(const float *base, long ld, int row, int S, int h, at_f32x4 (&f)[4]) {
     const int rc = row < S ? row : S - 1;
-    const float *src = base + (long)rc * ld + 16 * h;
+    const long src = (long)rc * ld + 16 * h;
     for (int i = 0; i < 4; ++i) {
-        at_f32x4 t = *(const at_f32x4 *)(src + 4 * i);
+        at_f32x4 t = at_ld4<IO>(base, src + 4 * i);
         if (row >= S) t = at_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         f[i] = t;
     }
@@ -131,10 +151,11 @@ __device__ __forceinline__ at_f32x16 at_xTp(const float *tile, int l31, int h, c
 }
 // one thread's share of a 32 x 32 tile fetch: rows row0.., 8 float4 per row
 struct AtFetch { at_f32x4 a, b; float c, d; };
+template <int IO = 0>
 __device__ __forceinline__ at_f32x4 at_fetch4(const float *base, long ld, int row0, int S, int tid) {
     const int r = tid >> 3, q = tid & 7;
     const int row = row0 + r, rc = row < S ? row : S - 1;
-    at_f32x4 t = *(const at_f32x4 *)(base + (long)rc * ld + 4 * q);
+    at_f32x4 t = at_ld4<IO>(base, (long)rc * ld + 4 * q);
     if (row >= S) t = at_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     return t;
 }
@@ -149,13 +170,21 @@ __device__ __forceinline__ void at_vec16(const float *vec, int h, float (&o)[16]
     }
 }
 // write the transposed accumulator (rows = d, column = own row) as 4 float4 of the row's 32 floats
+template <int IO = 0>
 __device__ __forceinline__ void at_store_rowT(float *dst, int h, const at_f32x16 &acc, float mul) {
-    for (int g = 0; g < 4; ++g)
-        *(at_f32x4 *)&dst[8 * g + 4 * h] = at_f32x4{acc[4 * g] * mul, acc[4 * g + 1] * mul, acc[4 * g + 2] * mul, acc[4 * g + 3] * mul};
+    for (int g = 0; g < 4; ++g) {
+        if (IO) {
+            uint2 u;
+            u.x = at_bf16_pair(acc[4 * g] * mul, acc[4 * g + 1] * mul); u.y = at_bf16_pair(acc[4 * g + 2] * mul, acc[4 * g + 3] * mul);
+            *(uint2 *)((unsigned short *)dst + 8 * g + 4 * h) = u;
+        } else {
+            *(at_f32x4 *)&dst[8 * g + 4 * h] = at_f32x4{acc[4 * g] * mul, acc[4 * g + 1] * mul, acc[4 * g + 2] * mul, acc[4 * g + 3] * mul};
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int PREC, int DROP>
+template <int PREC, int DROP, int IO = 0>
 __global__ void __launch_bounds__(256)
 attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[2][AT_T * AT_LD], Vs[2][AT_T * AT_LD], Bs[2][AT_T];
@@ -163,18 +192,18 @@ attn_fwd_kernel(AttnArgs a) {
     const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
     const unsigned hkey = at_head_key(a.drop_seed, (unsigned)bh);
     const long ld = 3L * a.d_model;
-    const float *Q = a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
+    const float *Q = at_off<IO>(a.qkv, (long)b * a.S * ld + hd * AT_DH), *K = at_off<IO>(Q, a.d_model), *V = at_off<IO>(Q, 2 * a.d_model);
     const float *kb = a.key_bias ? a.key_bias + (long)b * a.S : nullptr;
     const int query = blockIdx.x * 128 + wave * 32 + l31;
     at_f32x4 qf[4];
-    at_grow16(Q, ld, query, a.Sq, h, qf);
+    at_grow16<IO>(Q, ld, query, a.Sq, h, qf);
     const bool live = blockIdx.x * 128 + wave * 32 < a.Sq;        // wave-uniform: waves past the live queries only help staging
     at_f32x16 acc_o;
     for (int r = 0; r < 16; ++r) acc_o[r] = 0.0f;
     float m = AT_NEG, lsum = 0.0f;
     const int ntiles = (a.S + AT_T - 1) / AT_T;
 
-    at_f32x4 rk = at_fetch4(K, ld, 0, a.S, tid), rv = at_fetch4(V, ld, 0, a.S, tid);
+    at_f32x4 rk = at_fetch4<IO>(K, ld, 0, a.S, tid), rv = at_fetch4<IO>(V, ld, 0, a.S, tid);
     // key bias of the tile: every thread loads entry (tid & 31) from a clamped address and the value is only looked at by the
     // stash (a branch around the load, or a select right behind it, makes wave 0 wait for ALL its loads before the tile's MFMAs)
     const float *kbp = kb ? kb : a.qkv;
@@ -185,7 +214,7 @@ attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1, k0n = (t + 1) * AT_T;
-        rk = at_fetch4(K, ld, k0n, a.S, tid); rv = at_fetch4(V, ld, k0n, a.S, tid);      // past the end: zeros, never used
+        rk = at_fetch4<IO>(K, ld, k0n, a.S, tid); rv = at_fetch4<IO>(V, ld, k0n, a.S, tid);      // past the end: zeros, never used
         rb = kbp[k0n + t31 < a.S ? k0n + t31 : a.S - 1];
         if (live) {
         // scores^T tile: keys (rows) x own queries (lanes)
@@ -221,7 +250,7 @@ attn_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward 1: dQ (and D)
-template <int PREC, int DROP>
+template <int PREC, int DROP, int IO = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[2][AT_T * AT_LD], Vs[2][AT_T * AT_LD], Bs[2][AT_T];
@@ -229,12 +258,12 @@ attn_bwd_dq_kernel(AttnArgs a) {
     const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
     const unsigned hkey = at_head_key(a.drop_seed, (unsigned)bh);
     const long ld = 3L * a.d_model;
-    const float *Q = a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
+    const float *Q = at_off<IO>(a.qkv, (long)b * a.S * ld + hd * AT_DH), *K = at_off<IO>(Q, a.d_model), *V = at_off<IO>(Q, 2 * a.d_model);
     const float *dO = a.dout + (long)b * a.Sq * a.d_model + hd * AT_DH, *O = a.out + (long)b * a.Sq * a.d_model + hd * AT_DH;
     const float *kb = a.key_bias ? a.key_bias + (long)b * a.S : nullptr;
     const int query = blockIdx.x * 128 + wave * 32 + l31;
     at_f32x4 qf[4], dof[4], of[4];
-    at_grow16(Q, ld, query, a.Sq, h, qf);
+    at_grow16<IO>(Q, ld, query, a.Sq, h, qf);
     at_grow16(dO, a.d_model, query, a.Sq, h, dof);
     at_grow16(O, a.d_model, query, a.Sq, h, of);
     const bool live = blockIdx.x * 128 + wave * 32 < a.Sq;
@@ -247,7 +276,7 @@ attn_bwd_dq_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const int ntiles = (a.S + AT_T - 1) / AT_T;
 
-    at_f32x4 rk = at_fetch4(K, ld, 0, a.S, tid), rv = at_fetch4(V, ld, 0, a.S, tid);
+    at_f32x4 rk = at_fetch4<IO>(K, ld, 0, a.S, tid), rv = at_fetch4<IO>(V, ld, 0, a.S, tid);
     // key bias of the tile: every thread loads entry (tid & 31) from a clamped address and the value is only looked at by the
     // stash (a branch around the load, or a select right behind it, makes wave 0 wait for ALL its loads before the tile's MFMAs)
     const float *kbp = kb ? kb : a.qkv;
@@ -258,7 +287,7 @@ attn_bwd_dq_kernel(AttnArgs a) {
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1, k0n = (t + 1) * AT_T;
-        rk = at_fetch4(K, ld, k0n, a.S, tid); rv = at_fetch4(V, ld, k0n, a.S, tid);
+        rk = at_fetch4<IO>(K, ld, k0n, a.S, tid); rv = at_fetch4<IO>(V, ld, k0n, a.S, tid);
         rb = kbp[k0n + t31 < a.S ? k0n + t31 : a.S - 1];
         if (live) {
         const at_f32x16 st = at_xyT<PREC>(Ks[buf], l31, h, qf);           // S^T
@@ -278,11 +307,11 @@ attn_bwd_dq_kernel(AttnArgs a) {
         if (tid < AT_T) Bs[buf ^ 1][tid] = k0n + tid < a.S ? (kb ? rb : 0.0f) : -INFINITY;
         __syncthreads();
     }
-    if (query < a.Sq) at_store_rowT(a.dqkv + ((long)b * a.S + query) * ld + hd * AT_DH, h, acc, 1.0f);
+    if (query < a.Sq) at_store_rowT<IO>((float *)at_off<IO>(a.dqkv, ((long)b * a.S + query) * ld + hd * AT_DH), h, acc, 1.0f);
 }
 
 // ------------------------------------------------------------------------------------------------ backward 2: dK, dV
-template <int PREC, int DROP>
+template <int PREC, int DROP, int IO = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 attn_bwd_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[2][AT_T * AT_LD], Os[2][AT_T * AT_LD], Ls[2][AT_T], Ds[2][AT_T];
@@ -290,13 +319,13 @@ attn_bwd_dkv_kernel(AttnArgs a) {
     const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
     const unsigned hkey = at_head_key(a.drop_seed, (unsigned)bh);
     const long ld = 3L * a.d_model;
-    const float *Q = a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
+    const float *Q = at_off<IO>(a.qkv, (long)b * a.S * ld + hd * AT_DH), *K = at_off<IO>(Q, a.d_model), *V = at_off<IO>(Q, 2 * a.d_model);
     const float *dO = a.dout + (long)b * a.Sq * a.d_model + hd * AT_DH;
     const float *lse = a.lse + (long)bh * a.Sq, *dsm = a.dsum + (long)bh * a.Sq;
     const int key = blockIdx.x * 128 + wave * 32 + l31;
     at_f32x4 kf[4], vf[4];
-    at_grow16(K, ld, key, a.S, h, kf);
-    at_grow16(V, ld, key, a.S, h, vf);
+    at_grow16<IO>(K, ld, key, a.S, h, kf);
+    at_grow16<IO>(V, ld, key, a.S, h, vf);
     const bool live = blockIdx.x * 128 + wave * 32 < a.S;         // wave-uniform: a wave wholly past the keys only helps staging
     float bias = -INFINITY;
     if (key < a.S) bias = a.key_bias ? a.key_bias[(long)b * a.S + key] : 0.0f;
@@ -304,7 +333,7 @@ attn_bwd_dkv_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) { acc_k[r] = 0.0f; acc_v[r] = 0.0f; }
     const int ntiles = (a.Sq + AT_T - 1) / AT_T;      // walks the live queries
 
-    at_f32x4 rq = at_fetch4(Q, ld, 0, a.Sq, tid), ro = at_fetch4(dO, a.d_model, 0, a.Sq, tid);
+    at_f32x4 rq = at_fetch4<IO>(Q, ld, 0, a.Sq, tid), ro = at_fetch4(dO, a.d_model, 0, a.Sq, tid);
     const int t31 = tid & 31;                        // per-query log-sum-exp and D: loaded branch-free, masked by the stash
     float rl = lse[t31 < a.Sq ? t31 : a.Sq - 1], rd = dsm[t31 < a.Sq ? t31 : a.Sq - 1];
     at_stash4(Qs[0], tid, rq); at_stash4(Os[0], tid, ro);
@@ -312,7 +341,7 @@ attn_bwd_dkv_kernel(AttnArgs a) {
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1, q0n = (t + 1) * AT_T;
-        rq = at_fetch4(Q, ld, q0n, a.Sq, tid); ro = at_fetch4(dO, a.d_model, q0n, a.Sq, tid);
+        rq = at_fetch4<IO>(Q, ld, q0n, a.Sq, tid); ro = at_fetch4(dO, a.d_model, q0n, a.Sq, tid);
         { const int qc = q0n + t31 < a.Sq ? q0n + t31 : a.Sq - 1; rl = lse[qc]; rd = dsm[qc]; }
         if (live) {
         const at_f32x16 s = at_xyT<PREC>(Qs[buf], l31, h, kf);            // S: queries (rows) x own keys (lanes)
@@ -341,9 +370,9 @@ attn_bwd_dkv_kernel(AttnArgs a) {
         __syncthreads();
     }
     if (key < a.S) {
-        float *dst = a.dqkv + ((long)b * a.S + key) * ld + hd * AT_DH;
-        at_store_rowT(dst + a.d_model, h, acc_k, 1.0f);
-        at_store_rowT(dst + 2 * a.d_model, h, acc_v, 1.0f);
+        const float *dst = at_off<IO>(a.dqkv, ((long)b * a.S + key) * ld + hd * AT_DH);
+        at_store_rowT<IO>((float *)at_off<IO>(dst, a.d_model), h, acc_k, 1.0f);
+        at_store_rowT<IO>((float *)at_off<IO>(dst, 2 * a.d_model), h, acc_v, 1.0f);
     }
 }
 

@@ -83,6 +83,14 @@ int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha, const float 
     // 16-byte global loads need the base, the leading dimension and the batch stride 16 B aligned
     g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && (stride_a % 4 == 0);
     g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (stride_b % 4 == 0);
+    g.a16 = (flags & EMLOCO_GEMM_A_BF16MEM) ? 1 : 0; g.b16 = (flags & EMLOCO_GEMM_B_BF16MEM) ? 1 : 0;
+    g.c16 = (flags & EMLOCO_GEMM_C_BF16MEM) ? 1 : 0; g.m16 = 0;
+    if (g.a16 || g.b16 || g.c16) {
+        if (!(flags & EMLOCO_GEMM_BF16) || !g.vec_a || !g.vec_b || n <= 32)
+            return pfail(-1, "emloco_gemm_f32: bf16 memory operands need EMLOCO_GEMM_BF16, 16-byte-aligned operands and n > 32");
+        if (g.c16 && ksplit > 1) return pfail(-1, "emloco_gemm_f32: a bf16 output cannot be split along k (the partial sums are fp32)");
+        if ((g.b16) && !(trans_a && trans_b)) return pfail(-1, "emloco_gemm_f32: a bf16 B operand is served for the weight-gradient layout only (trans_a and trans_b)");
+    }
     hipStream_t st = (hipStream_t)stream;
     const int slot = g_head;
     if (g_timing) PHIPCHK(hipEventRecord(g_e0[slot], st));
@@ -97,7 +105,9 @@ int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha, const float 
     const long n_wg = (long)grid.x * grid.y * grid.z;
     const bool long_k = (k + ksplit - 1) / ksplit > 256;
     const bool deep = force_bk ? force_bk == 32 : (long_k && (n <= 32 || (n_wg <= 1024 && !(trans_a && trans_b))));
-    hipLaunchKernelGGL(emloco::gemm_pick(g, deep), grid, dim3(256), 0, st, g);
+    const emloco::GemmKernel kern = emloco::gemm_pick(g, deep);
+    if (!kern) return pfail(-1, "emloco_gemm_f32: this combination of bf16 memory operands and layouts is not served");
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, g);
     PHIPCHK(hipGetLastError());
     if (ksplit > 1) {
         const long total = (long)batch * m * n;
@@ -172,10 +182,15 @@ int emloco_layernorm_bwd(int rows, int d, const float *xr, const float *gamma, c
 int64_t emloco_colsum_workspace(int m, int n) { return emloco::fold_workspace((m + CS_ROWS - 1) / CS_ROWS, n); }
 
 int emloco_colsum(int m, int n, const float *X, float *out, float *workspace, void *stream) {
+    return emloco_colsum_ex(m, n, X, out, workspace, 0, stream);
+}
+
+int emloco_colsum_ex(int m, int n, const float *X, float *out, float *workspace, int flags, void *stream) {
     if (m < 1 || n < 1 || !X || !out || !workspace)
         return pfail(-1, "emloco_colsum: bad argument (workspace = emloco_colsum_workspace(m, n) floats)");
     const int nparts = (m + CS_ROWS - 1) / CS_ROWS;
-    hipLaunchKernelGGL(emloco::colsum_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream, m, n, X, workspace);
+    hipLaunchKernelGGL(emloco::colsum_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream, m, n, X, workspace,
+                       (flags & EMLOCO_GEMM_A_BF16MEM) ? 1 : 0);
     PHIPCHK(hipGetLastError());
     emloco::fold_rows(FoldLaunch{(hipStream_t)stream}, nparts, n, workspace, out, out, n);
     PHIPCHK(hipGetLastError());
@@ -192,6 +207,10 @@ int emloco_gemm_relu_bwd(int m, int n, int k, const float *A, int lda, const flo
                        0, 0, 0.0f, 0u, y, scale, workspace};
     g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
     g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
+    g.a16 = g.b16 = 0;                                        // the incoming gradient and the weight are fp32
+    g.c16 = (flags & EMLOCO_GEMM_C_BF16MEM) ? 1 : 0; g.m16 = (flags & EMLOCO_GEMM_MASK_BF16MEM) ? 1 : 0;
+    if ((g.c16 || g.m16) && (!(flags & EMLOCO_GEMM_BF16) || g.c16 != g.m16))
+        return pfail(-1, "emloco_gemm_relu_bwd: a bf16 hidden layer needs EMLOCO_GEMM_BF16 and comes with a bf16 gradient (C and MASK flags together)");
     if (!g.vec_a || !g.vec_b) return pfail(-1, "emloco_gemm_relu_bwd: A and B must be 16-byte aligned with leading dimensions that are multiples of 4");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)((n + 127) / 128), (unsigned)((m + 127) / 128), 1);
@@ -228,6 +247,13 @@ int emloco_attention_fwd_queries(int n_seq, int S, int n_query, int nhead, int d
     const dim3 grid((unsigned)((n_query + 127) / 128), (unsigned)(n_seq * nhead));
     const bool bf = (flags & EMLOCO_ATTN_BF16) != 0, dr = drop_p > 0.0f;
     hipStream_t st = (hipStream_t)stream;
+    if (flags & EMLOCO_ATTN_QKV_BF16MEM) {
+        if (!bf) return pfail(-1, "emloco_attention_fwd: a bf16 q|k|v tensor needs EMLOCO_ATTN_BF16");
+        if (dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 1, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 0, 1>), grid, dim3(256), 0, st, a);
+        PHIPCHK(hipGetLastError());
+        return 0;
+    }
     if (bf && dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 1>), grid, dim3(256), 0, st, a);
     else if (bf) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 0>), grid, dim3(256), 0, st, a);
     else if (dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<0, 1>), grid, dim3(256), 0, st, a);
@@ -265,8 +291,20 @@ int emloco_attention_bwd_queries(int n_seq, int S, int n_query, int nhead, int d
     const dim3 grid((unsigned)((S + 127) / 128), (unsigned)(n_seq * nhead)), qgrid((unsigned)((n_query + 127) / 128), (unsigned)(n_seq * nhead));
     const bool bf = (flags & EMLOCO_ATTN_BF16) != 0, dr = drop_p > 0.0f;
     hipStream_t st = (hipStream_t)stream;
+    const bool q16 = (flags & EMLOCO_ATTN_QKV_BF16MEM) != 0;
+    if (q16 && !bf) return pfail(-1, "emloco_attention_bwd: a bf16 q|k|v tensor needs EMLOCO_ATTN_BF16");
+    const size_t esz = q16 ? 2 : sizeof(float);
     // rows that do not attend get dQ = 0 (the Q third of every dqkv row; the live rows are overwritten below)
-    if (n_query < S) PHIPCHK(hipMemset2DAsync(dqkv, 3 * (size_t)d_model * sizeof(float), 0, (size_t)d_model * sizeof(float), (size_t)n_seq * S, st));
+    if (n_query < S) PHIPCHK(hipMemset2DAsync(dqkv, 3 * (size_t)d_model * esz, 0, (size_t)d_model * esz, (size_t)n_seq * S, st));
+    if (q16) {
+        if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 1, 1>), qgrid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 0, 1>), qgrid, dim3(256), 0, st, a);
+        PHIPCHK(hipGetLastError());
+        if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 1, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 0, 1>), grid, dim3(256), 0, st, a);
+        PHIPCHK(hipGetLastError());
+        return 0;
+    }
     // first kernel: dQ, also writes D = rowsum(dO o O); second: dK, dV
     if (bf && dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 1>), qgrid, dim3(256), 0, st, a);
     else if (bf) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 0>), qgrid, dim3(256), 0, st, a);

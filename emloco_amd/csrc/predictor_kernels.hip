@@ -37,7 +37,27 @@ struct GemmArgs {
     // multiplied by mask_scale where mask[row][col] > 0 (the forward OUTPUT, laid out like C) and zeroed elsewhere, and the
     // column sums of what was written over the 64 rows of this wave go to colpart[(tile_row * WM + wm)][col] (bias gradient)
     const float *mask; float mask_scale; float *colpart;
+    // memory dtypes of the reduced-precision mode (flags & 16 only): an operand / the output / the mask holds bf16 (2 bytes per
+    // element; leading dimensions and strides still count elements).  The large activations of an encoder layer -- the fused
+    // q|k|v projection and the feed-forward hidden layer -- live in HBM as bf16 there; accumulation stays fp32.
+    int a16, b16, c16, m16;
 };
+
+// bf16 <-> fp32 on the way to / from memory: widening is a shift, narrowing rounds to nearest even
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {                         // branch-free (selects): unrolled epilogues stay unrolled
+    const unsigned u = __float_as_uint(f);
+    const unsigned r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    const unsigned q = (u >> 16) | 0x40u;                                                  // NaN stays NaN
+    return (unsigned short)(((u & 0x7fffffffu) > 0x7f800000u) ? q : r);
+}
+__device__ __forceinline__ float ld_act(const float *p, long i, int is16) {
+    return is16 ? bf16_lo(((const unsigned short *)p)[i]) : p[i];
+}
+__device__ __forceinline__ void st_act(float *p, long i, float v, int is16) {
+    if (is16) ((unsigned short *)p)[i] = f32_to_bf16(v); else p[i] = v;
+}
 
 // Counter-based dropout mask: keep element `idx` of a launch with seed `seed` iff hash(seed, idx) >= p.  A stateless
 // integer hash (murmur3 finaliser over a Weyl-mixed counter), so the backward recomputes the mask instead of storing it.
@@ -56,9 +76,11 @@ struct __attribute__((aligned(16))) f32x4 { float x, y, z, w; };
 // select, so the compiler keeps every load asynchronous (a branchy version made it wait after each load).
 // TRANS: 0 = X[row][k] (k contiguous), 1 = X[k][row] (row contiguous).  VEC: 16-byte loads allowed (base, leading
 // dimension and batch stride 16 B aligned; then a clamped quad never leaves its row: ld % 4 == 0 and rows, k <= ld).
-template <int ROWS, int GBK, int TRANS, int VEC>
+// IO = 1: the operand is bf16 in memory (VEC only): a quad is one 8-byte load, widened on arrival.
+template <int ROWS, int GBK, int TRANS, int VEC, int IO = 0>
 __device__ __forceinline__ void gemm_fetch(f32x4 (&v)[(ROWS * GBK / 4 + 255) / 256], unsigned (&mk)[(ROWS * GBK / 4 + 255) / 256],
                                            const float *X, int ld, int row0, int rows, int k0, int ke, int tid) {
+    static_assert(IO == 0 || VEC == 1, "bf16 operands take the vector-load path");
     constexpr int NQ = ROWS * GBK / 4, QR = GBK / 4;
     for (int e = 0; e < (NQ + 255) / 256; ++e) {
         int idx = tid + 256 * e;
@@ -72,7 +94,11 @@ __device__ __forceinline__ void gemm_fetch(f32x4 (&v)[(ROWS * GBK / 4 + 255) / 2
             const bool rok = row < rows;
             ok0 = rok && kk < ke; ok1 = rok && kk + 1 < ke; ok2 = rok && kk + 2 < ke; ok3 = rok && kk + 3 < ke;
             const float *base = X + (long)rowc * ld;
-            if (VEC) {
+            if (IO) {
+                const int kq = (ke - 1) & ~3;
+                const uint2 u = *(const uint2 *)((const unsigned short *)X + (long)rowc * ld + (kk < kq ? kk : kq));
+                t.x = bf16_lo(u.x); t.y = bf16_hi(u.x); t.z = bf16_lo(u.y); t.w = bf16_hi(u.y);
+            } else if (VEC) {
                 const int kq = (ke - 1) & ~3;
                 t = *(const f32x4 *)(base + (kk < kq ? kk : kq));
             } else {
@@ -87,7 +113,11 @@ __device__ __forceinline__ void gemm_fetch(f32x4 (&v)[(ROWS * GBK / 4 + 255) / 2
             const bool kok = kg < ke;
             ok0 = kok && row < rows; ok1 = kok && row + 1 < rows; ok2 = kok && row + 2 < rows; ok3 = kok && row + 3 < rows;
             const float *base = X + (long)kc * ld;
-            if (VEC) {
+            if (IO) {
+                const int rq4 = (rows - 1) & ~3;
+                const uint2 u = *(const uint2 *)((const unsigned short *)X + (long)kc * ld + (row < rq4 ? row : rq4));
+                t.x = bf16_lo(u.x); t.y = bf16_hi(u.x); t.z = bf16_lo(u.y); t.w = bf16_hi(u.y);
+            } else if (VEC) {
                 const int rq4 = (rows - 1) & ~3;
                 t = *(const f32x4 *)(base + (row < rq4 ? row : rq4));
             } else {
@@ -155,7 +185,9 @@ __device__ __forceinline__ void gemm_frag(const float *S, int row, int half8, f3
 
 // EPI = 1: the fused backward epilogue (flags & 32) -- its own instantiations, so that its registers (a tile of mask values in
 // flight) do not lower the occupancy of the plain variants.
-template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int PREC, int EPI>
+// EPIO (EPI = 1 only): the mask and the output are bf16 in memory -- a template parameter, not a flag: a run-time dtype test inside
+// the mask prefetch turns sixteen loads in flight into sixteen round trips (measured: 1.7 -> 5.4 ms per launch)
+template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int PREC, int EPI, int IOA = 0, int IOB = 0, int EPIO = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     constexpr int BM = WM * TI * 32, BN = WN * TJ * 32, GLDK = GBK + 4, NF = GBK / 8;
     constexpr int QA = (BM * GBK / 4 + 255) / 256, QB = (BN * GBK / 4 + 255) / 256;
@@ -172,8 +204,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     kchunk = ((kchunk + GBK - 1) / GBK) * GBK;
     const int kb = split * kchunk;
     const int ke = (kb + kchunk < g.k) ? kb + kchunk : g.k;
-    const float *A = g.A + (long)b * g.sa;
-    const float *B = g.B + (long)b * g.sb;
+    // (a bf16 operand is addressed in 2-byte elements: the batch stride is applied on that type)
+    const float *A = IOA ? (const float *)((const unsigned short *)g.A + (long)b * g.sa) : g.A + (long)b * g.sa;
+    const float *B = IOB ? (const float *)((const unsigned short *)g.B + (long)b * g.sb) : g.B + (long)b * g.sb;
 
     f32x16 acc[TI][TJ];
     for (int i = 0; i < TI; ++i)
@@ -183,8 +216,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     f32x4 ra[QA], rb[QB];
     unsigned ma[QA], mb[QB];
     if (kb < ke) {
-        gemm_fetch<BM, GBK, TA, VEC>(ra, ma, A, g.lda, m0, g.m, kb, ke, tid);
-        gemm_fetch<BN, GBK, TB, VEC>(rb, mb, B, g.ldb, n0, g.n, kb, ke, tid);
+        gemm_fetch<BM, GBK, TA, VEC, IOA>(ra, ma, A, g.lda, m0, g.m, kb, ke, tid);
+        gemm_fetch<BN, GBK, TB, VEC, IOB>(rb, mb, B, g.ldb, n0, g.n, kb, ke, tid);
         gemm_stash<BM, GBK, TA>(ra, ma, As[0], tid);
         gemm_stash<BN, GBK, TB>(rb, mb, Bs[0], tid);
     }
@@ -193,8 +226,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     const int half8 = (GBK / 2) * (lane >> 5), l31 = lane & 31;
     for (int k0 = kb; k0 < ke; k0 += GBK) {
         // next stage's global loads are in flight during the MFMAs (past the end they fetch zeros: clamped + masked)
-        gemm_fetch<BM, GBK, TA, VEC>(ra, ma, A, g.lda, m0, g.m, k0 + GBK, ke, tid);
-        gemm_fetch<BN, GBK, TB, VEC>(rb, mb, B, g.ldb, n0, g.n, k0 + GBK, ke, tid);
+        gemm_fetch<BM, GBK, TA, VEC, IOA>(ra, ma, A, g.lda, m0, g.m, k0 + GBK, ke, tid);
+        gemm_fetch<BN, GBK, TB, VEC, IOB>(rb, mb, B, g.ldb, n0, g.n, k0 + GBK, ke, tid);
         // keep the loads HERE: left free, the scheduler sinks them below most of the stage's MFMAs (they are only consumed by the
         // stash) and the s_waitcnt in front of the stash then exposes the whole memory latency every stage
         __builtin_amdgcn_sched_barrier(0);
@@ -243,7 +276,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
                 }
         }
     } else if constexpr (EPI == 0) {
-        float *ct = g.C + (long)b * g.sc + (long)m0 * g.ldc + n0;
+        const int c16 = g.c16;
+        float *ct = c16 ? (float *)((unsigned short *)g.C + (long)b * g.sc + (long)m0 * g.ldc + n0) : g.C + (long)b * g.sc + (long)m0 * g.ldc + n0;
         for (int j = 0; j < TJ; ++j) {
             const int cl = (wn * TJ + j) * 32 + (lane & 31);
             if (cl >= nrem) continue;
@@ -255,15 +289,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
                         float v = g.alpha * acc[i][j][r] + bj;
                         if (relu) v = v > 0.0f ? v : 0.0f;
                         if (drop) v = drop_keep(g.drop_seed, ((unsigned long long)b * g.m + m0 + rl) * g.n + n0 + cl, g.drop_p) ? v * keep_scale : 0.0f;
-                        float *c = ct + (rl * g.ldc + cl);
-                        if (accum) v += *c;
-                        *c = v;
+                        const int ci = rl * g.ldc + cl;
+                        if (accum) v += ld_act(ct, ci, c16);
+                        st_act(ct, ci, v, c16);
                     }
                 }
         }
     } else {
-        const float *mt = g.mask + (long)b * g.sc + (long)m0 * g.ldc + n0;
-        float *ct = g.C + (long)b * g.sc + (long)m0 * g.ldc + n0;
+        constexpr int c16 = EPIO, m16 = EPIO;
+        const float *mt = m16 ? (const float *)((const unsigned short *)g.mask + (long)b * g.sc + (long)m0 * g.ldc + n0) : g.mask + (long)b * g.sc + (long)m0 * g.ldc + n0;
+        float *ct = c16 ? (float *)((unsigned short *)g.C + (long)b * g.sc + (long)m0 * g.ldc + n0) : g.C + (long)b * g.sc + (long)m0 * g.ldc + n0;
         for (int j = 0; j < TJ; ++j) {
             const int cl = (wn * TJ + j) * 32 + (lane & 31);
             const bool colok = cl < nrem;
@@ -275,13 +310,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
                 float mv[16];
                 for (int r = 0; r < 16; ++r) {
                     const int rl = (wm * TI + i) * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
-                    mv[r] = mt[(rl < mrem ? rl : mrem - 1) * g.ldc + clc];
+                    if constexpr (m16) mv[r] = bf16_lo(((const unsigned short *)mt)[(rl < mrem ? rl : mrem - 1) * g.ldc + clc]);
+                    else mv[r] = mt[(rl < mrem ? rl : mrem - 1) * g.ldc + clc];
                 }
                 for (int r = 0; r < 16; ++r) {
                     const int rl = (wm * TI + i) * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
                     if (rl < mrem && colok) {
-                        const float v = mv[r] > 0.0f ? g.alpha * acc[i][j][r] * g.mask_scale : 0.0f;
-                        ct[rl * g.ldc + cl] = v;
+                        float v = mv[r] > 0.0f ? g.alpha * acc[i][j][r] * g.mask_scale : 0.0f;
+                        if constexpr (c16) {                               // rounded once; the bias gradient sums what the next GEMMs will read
+                            const unsigned short hb = f32_to_bf16(v);
+                            ((unsigned short *)ct)[rl * g.ldc + cl] = hb;
+                            v = bf16_lo(hb);
+                        } else {
+                            ct[rl * g.ldc + cl] = v;
+                        }
                         csum += v;
                     }
                 }
@@ -293,20 +335,38 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     }
 }
 
-template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int PREC = 0>
+template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int PREC = 0, int IOA = 0, int IOB = 0>
 __global__ void __launch_bounds__(256)
-gemm_f32_kernel(GemmArgs g) { gemm_body<WM, WN, TI, TJ, GBK, TA, TB, VEC, PREC, 0>(g); }
+gemm_f32_kernel(GemmArgs g) { gemm_body<WM, WN, TI, TJ, GBK, TA, TB, VEC, PREC, 0, IOA, IOB>(g); }
 
 // the fused-backward-epilogue variants: held to 3 waves per SIMD (168 registers; left alone the compiler keeps the whole
 // tile's mask values and offsets live and falls to 2)
 template <int GBK, int TB, int PREC>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-gemm_f32_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, GBK, 0, TB, 1, PREC, 1>(g); }
+gemm_f32_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, GBK, 0, TB, 1, PREC, 1, 0, 0, 0>(g); }
+// bf16 hidden layer and gradient
+template <int GBK, int TB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+gemm_bf16_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, GBK, 0, TB, 1, 1, 1, 0, 0, 1>(g); }
 
 // kernel variant for a problem: tile shape (narrow: n <= 32), stage depth, operand layouts, 16-byte loads
 typedef void (*GemmKernel)(GemmArgs);
 template <int WM, int WN, int TI, int TJ, int GBK>
-inline GemmKernel gemm_pick_layout(int ta, int tb, int vec, int bf16 = 0) {
+inline GemmKernel gemm_pick_layout(int ta, int tb, int vec, int bf16 = 0, int a16 = 0, int b16 = 0) {
+    if (vec && bf16 && a16 && !b16) {       // A (an activation) is bf16 in memory
+        if (!ta && !tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 0, 0, 1, 1, 1, 0>;
+        if (!ta && tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 0, 1, 1, 1, 1, 0>;
+        if (ta && !tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 1, 0, 1, 1, 1, 0>;
+        return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 1, 1, 1, 1, 1, 0>;
+    }
+    if (vec && bf16 && !a16 && b16) {       // B is bf16 in memory (weight gradient against a bf16 activation)
+        if (ta && tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 1, 1, 1, 1, 0, 1>;
+        return nullptr;
+    }
+    if (vec && bf16 && a16 && b16) {
+        if (ta && tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 1, 1, 1, 1, 1, 1>;
+        return nullptr;
+    }
     if (vec && bf16) {       // bf16 operands: the 16-byte-load variants only (every hot shape qualifies; others stay fp32)
         if (!ta && !tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 0, 0, 1, 1>;
         if (!ta && tb) return gemm_f32_kernel<WM, WN, TI, TJ, GBK, 0, 1, 1, 1>;
@@ -328,6 +388,10 @@ inline GemmKernel gemm_pick(const GemmArgs &g, bool deep) {
     const int vec = g.vec_a && g.vec_b;
     const int bf16 = (g.flags & 16) ? 1 : 0;
     if (g.flags & 32) {           // fused backward epilogue: A row-major, 16-byte loads (the launcher checks)
+        if (g.c16 || g.m16) {     // bf16 hidden layer and gradient (both or neither: the launcher checks)
+            if (deep) return g.tb ? gemm_bf16_relu_bwd_kernel<32, 1> : gemm_bf16_relu_bwd_kernel<32, 0>;
+            return g.tb ? gemm_bf16_relu_bwd_kernel<16, 1> : gemm_bf16_relu_bwd_kernel<16, 0>;
+        }
         if (deep) {
             if (bf16) return g.tb ? gemm_f32_relu_bwd_kernel<32, 1, 1> : gemm_f32_relu_bwd_kernel<32, 0, 1>;
             return g.tb ? gemm_f32_relu_bwd_kernel<32, 1, 0> : gemm_f32_relu_bwd_kernel<32, 0, 0>;
@@ -336,7 +400,7 @@ inline GemmKernel gemm_pick(const GemmArgs &g, bool deep) {
         return g.tb ? gemm_f32_relu_bwd_kernel<16, 1, 0> : gemm_f32_relu_bwd_kernel<16, 0, 0>;
     }
     if (g.n <= 32) return deep ? gemm_pick_layout<4, 1, 1, 1, 32>(g.ta, g.tb, vec) : gemm_pick_layout<4, 1, 1, 1, 16>(g.ta, g.tb, vec);
-    return deep ? gemm_pick_layout<2, 2, 2, 2, 32>(g.ta, g.tb, vec, bf16) : gemm_pick_layout<2, 2, 2, 2, 16>(g.ta, g.tb, vec, bf16);
+    return deep ? gemm_pick_layout<2, 2, 2, 2, 32>(g.ta, g.tb, vec, bf16, g.a16, g.b16) : gemm_pick_layout<2, 2, 2, 2, 16>(g.ta, g.tb, vec, bf16, g.a16, g.b16);
 }
 
 // sum of the ksplit partial products in a fixed order, then the epilogue
@@ -540,12 +604,12 @@ inline void fold_rows(LAUNCH launch, int n, int w, float *buf, float *out0, floa
 
 // column sums: 256-row partials, then folded
 #define CS_ROWS 256
-__global__ void colsum_partial_kernel(int m, int n, const float *X, float *part) {
+__global__ void colsum_partial_kernel(int m, int n, const float *X, float *part, int x16) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const long r0 = (long)blockIdx.y * CS_ROWS;
     float s = 0.0f;
-    for (int r = 0; r < CS_ROWS && r0 + r < m; ++r) s += X[(r0 + r) * n + j];
+    for (int r = 0; r < CS_ROWS && r0 + r < m; ++r) s += ld_act(X, (r0 + r) * n + j, x16);
     part[(long)blockIdx.y * n + j] = s;
 }
 

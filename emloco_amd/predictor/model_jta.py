@@ -47,7 +47,8 @@ class EncoderLayer(nn.Module):
         they attend over all keys, and the out-projection / norms / feed-forward run on those rows only -> (Bn, live_rows, d).
         Every row of a post-norm layer depends on the other rows through K and V alone, so the kept rows are unchanged."""
         sa = self.self_attn
-        qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
+        # (reduced-precision mode: q|k|v goes to the fused attention kernels as bf16 in HBM)
+        qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias, out_bf16=(sa.embed_dim // sa.num_heads == 32))
         p = self.p if self.training else 0.0                 # the three nn.Dropout of the layer live in the GEMM epilogues,
         att = ops.attention(qkv, key_pad, sa.num_heads, drop_p=p, n_query=live_rows)   # MultiheadAttention's dropout on the probabilities in the attention kernels
         if live_rows is not None and live_rows < x.shape[1]:

@@ -38,6 +38,7 @@ def _lib():
         lib.emloco_layernorm_fwd_save.argtypes = [ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_layernorm_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_colsum.argtypes = [ci, ci, vp, vp, vp, vp]
+        lib.emloco_colsum_ex.argtypes = [ci, ci, vp, vp, vp, ci, vp]
         lib.emloco_attention_fwd.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp]
         lib.emloco_attention_bwd.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_attention_fwd_ex.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, ci, vp]
@@ -70,7 +71,8 @@ def _lib():
 
 
 def _p(t, offset=0):
-    return None if t is None else C.c_void_p(t.data_ptr() + 4 * offset)
+    """device address of element `offset` of a tensor (fp32, or bf16 in the reduced-precision mode)"""
+    return None if t is None else C.c_void_p(t.data_ptr() + t.element_size() * offset)
 
 
 def _st(t):
@@ -83,15 +85,18 @@ def _chk(rc, what):
 
 
 GEMM_BF16 = 16
+GEMM_A16, GEMM_B16, GEMM_C16, GEMM_MASK16 = 64, 128, 256, 512      # EMLOCO_GEMM_*_BF16MEM: that operand is bf16 in memory
 ATTN_BF16 = 16
+ATTN_QKV16 = 32        # EMLOCO_ATTN_QKV_BF16MEM
 _matmul_precision = ["fp32"]
 
 
 def set_matmul_precision(mode):
     """"fp32" (default: fp32 operands on the fp32 matrix instruction, the path the 1e-4 parity tests hold) or "bf16"
     (operands rounded to bf16 on their way into the matrix cores, fp32 accumulation; ~1e-3 relative output error) for
-    every `linear` / projection GEMM and every fused attention launched afterwards (softmax statistics, LayerNorm, losses
-    and the optimiser stay fp32; tensors in memory stay fp32)."""
+    every `linear` / projection GEMM and every fused attention launched afterwards; the two large activations of an encoder
+    layer -- the feed-forward hidden layer (M x 1024) and the fused q|k|v projection (M x 384) -- and their gradients are then
+    kept in HBM as bf16 (softmax statistics, LayerNorm, residual stream, weight gradients, losses and the optimiser stay fp32)."""
     if mode not in ("fp32", "bf16"):
         raise ValueError("matmul precision must be 'fp32' or 'bf16'")
     _matmul_precision[0] = mode
@@ -103,9 +108,14 @@ def get_matmul_precision():
 
 def gemm(batch, m, n, k, A, lda, sa, ta, B, ldb, sb, tb, Cm, ldc, sc, alpha=1.0, bias=None, flags=0, ksplit=1,
          a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0):
-    """Raw strided batched GEMM: C_b[m][n] (+)= alpha * sum_k A_b(m,k) B_b(n,k) (see the header for the layouts)."""
+    """Raw strided batched GEMM: C_b[m][n] (+)= alpha * sum_k A_b(m,k) B_b(n,k) (see the header for the layouts).  bf16 tensors
+    (the reduced-precision mode's large activations) are passed as they are: the dtype travels in the flags."""
     if _matmul_precision[0] == "bf16":
         flags |= GEMM_BF16
+    for t, bit in ((A, GEMM_A16), (B, GEMM_B16), (Cm, GEMM_C16)):
+        if t.dtype == torch.bfloat16:
+            assert a_off == 0 and b_off == 0 and c_off == 0
+            flags |= bit | GEMM_BF16
     ws = None
     if ksplit > 1:
         ws = torch.empty(ksplit * batch * m * n, dtype=torch.float32, device=Cm.device)
@@ -138,7 +148,7 @@ def colsum(X2d):
     m, n = X2d.shape
     out = torch.empty(n, dtype=torch.float32, device=X2d.device)
     ws = torch.empty(_lib().emloco_colsum_workspace(m, n), dtype=torch.float32, device=X2d.device)
-    _chk(_lib().emloco_colsum(m, n, _p(X2d), _p(out), _p(ws), _st(X2d)), "emloco_colsum")
+    _chk(_lib().emloco_colsum_ex(m, n, _p(X2d), _p(out), _p(ws), GEMM_A16 if X2d.dtype == torch.bfloat16 else 0, _st(X2d)), "emloco_colsum")
     return out
 
 
@@ -147,13 +157,15 @@ class LinearFn(torch.autograd.Function):
     backward applies both masks in one pass (`emloco_act_bwd`) before the two gradient GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, W, b, relu, drop_p=0.0, drop_seed=0):
+    def forward(ctx, x, W, b, relu, drop_p=0.0, drop_seed=0, out_bf16=False):
         xs = x.shape
         x2 = x.contiguous().view(-1, xs[-1])
         M, K = x2.shape
         N = W.shape[0]
         Wc = W.contiguous()
-        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        # out_bf16: the result lives in HBM as bf16 (the fused q|k|v projection in the reduced-precision mode); its gradient
+        # arrives as bf16 too and is consumed as it is by the two gradient GEMMs and the bias-gradient column sum
+        y = torch.empty((M, N), dtype=torch.bfloat16 if (out_bf16 and _matmul_precision[0] == "bf16") else torch.float32, device=x.device)
         flags = (GEMM_BIAS if b is not None else 0) | (GEMM_RELU if relu else 0)
         gemm(1, M, N, K, x2, K, 0, 0, Wc, K, 0, 0, y, N, 0, bias=b.contiguous() if b is not None else None, flags=flags,
              drop_p=drop_p, drop_seed=drop_seed)
@@ -189,14 +201,14 @@ class LinearFn(torch.autograd.Function):
             gemm(1, N, K, M, dy2, N, 0, 1, x2, K, 0, 1, dW, K, 0, ksplit=_ksplit_for(M, N * K))   # dW = dy^T x
         if need_db and db is None:
             db = colsum(dy2)
-        return dx, dW, db, None, None, None
+        return dx, dW, db, None, None, None, None
 
 
-def linear(x, W, b=None, relu=False, drop_p=0.0):
+def linear(x, W, b=None, relu=False, drop_p=0.0, out_bf16=False):
     """nn.Linear (+ReLU) (+nn.Dropout(p) in training: pass drop_p > 0) as one GEMM launch."""
     if drop_p > 0.0:
-        return LinearFn.apply(x, W, b, relu, float(drop_p), next_dropout_seed())
-    return LinearFn.apply(x, W, b, relu, 0.0, 0)
+        return LinearFn.apply(x, W, b, relu, float(drop_p), next_dropout_seed(), out_bf16)
+    return LinearFn.apply(x, W, b, relu, 0.0, 0, out_bf16)
 
 
 
@@ -214,7 +226,10 @@ class FeedForwardFn(torch.autograd.Function):
         M, K = x2.shape
         F, N = W1.shape[0], W2.shape[0]
         W1c, W2c = W1.contiguous(), W2.contiguous()
-        h = torch.empty((M, F), dtype=torch.float32, device=x.device)
+        # the hidden layer is the largest tensor of the step (M x 1024): bf16 in HBM in the reduced-precision mode
+        # (the bf16-in-memory GEMM variants serve the 128-wide tiles and 8-byte-aligned rows only: small models keep fp32)
+        h16 = _matmul_precision[0] == "bf16" and N > 32 and F > 32 and K > 32 and F % 4 == 0 and K % 4 == 0 and N % 4 == 0
+        h = torch.empty((M, F), dtype=torch.bfloat16 if h16 else torch.float32, device=x.device)
         gemm(1, M, F, K, x2, K, 0, 0, W1c, K, 0, 0, h, F, 0, bias=b1.contiguous(), flags=GEMM_BIAS | GEMM_RELU, drop_p=drop_p, drop_seed=seed1)
         f = torch.empty((M, N), dtype=torch.float32, device=x.device)
         gemm(1, M, N, F, h, F, 0, 0, W2c, F, 0, 0, f, N, 0, bias=b2.contiguous(), flags=GEMM_BIAS, drop_p=drop_p, drop_seed=seed2)
@@ -239,11 +254,13 @@ class FeedForwardFn(torch.autograd.Function):
             dz2, db2 = df2, colsum(df2)
         dW2 = torch.empty((N, F), dtype=torch.float32, device=dev)
         gemm(1, N, F, M, dz2, N, 0, 1, h, F, 0, 1, dW2, F, 0, ksplit=_ksplit_for(M, N * F))          # dW2 = dz2^T h
-        dz1 = torch.empty((M, F), dtype=torch.float32, device=dev)
+        h16 = h.dtype == torch.bfloat16
+        dz1 = torch.empty((M, F), dtype=h.dtype, device=dev)         # the hidden layer's gradient follows its dtype
         db1 = torch.empty(F, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.emloco_gemm_relu_bwd_workspace(M, F), dtype=torch.float32, device=dev)
-        _chk(lib.emloco_gemm_relu_bwd(M, F, N, _p(dz2), N, _p(W2), F, 1, _p(dz1), _p(h), 1.0 / (1.0 - p), _p(db1), _p(ws),
-                                      GEMM_BF16 if _matmul_precision[0] == "bf16" else 0, st), "emloco_gemm_relu_bwd")
+        fl = (GEMM_BF16 | GEMM_C16 | GEMM_MASK16) if h16 else (GEMM_BF16 if _matmul_precision[0] == "bf16" else 0)
+        _chk(lib.emloco_gemm_relu_bwd(M, F, N, _p(dz2), N, _p(W2), F, 1, _p(dz1), _p(h), 1.0 / (1.0 - p), _p(db1), _p(ws), fl, st),
+             "emloco_gemm_relu_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
@@ -281,6 +298,8 @@ class FusedAttentionFn(torch.autograd.Function):
         scale = 1.0 / float(d // nhead) ** 0.5
         lib, st = _lib(), _st(qkv)
         ctx.attn_flags = ATTN_BF16 if _matmul_precision[0] == "bf16" else 0      # the backward follows the forward's choice
+        if qkv.dtype == torch.bfloat16:
+            ctx.attn_flags = ATTN_BF16 | ATTN_QKV16
         step = FusedAttentionFn.MAX_SEQ_HEADS // nhead
         for b0 in range(0, Bn, step):
             n = min(step, Bn - b0)

@@ -18,7 +18,12 @@ extern "C" {
 enum { EMLOCO_GEMM_BIAS = 1, EMLOCO_GEMM_RELU = 2, EMLOCO_GEMM_ACCUMULATE = 4, EMLOCO_GEMM_DROPOUT = 8,
        /* opt-in reduced precision: operands rounded to bf16 on their way into the matrix cores (fp32 in memory, fp32
         * accumulation, v_mfma_f32_32x32x16_bf16); ~1e-3 relative output error instead of fp32's 1e-6.  Off by default. */
-       EMLOCO_GEMM_BF16 = 16 };
+       EMLOCO_GEMM_BF16 = 16,
+       /* memory dtypes of the reduced-precision mode (only together with EMLOCO_GEMM_BF16, 16-byte-aligned operands): the A operand /
+        * the B operand / the output (for emloco_gemm_relu_bwd: the forward output `y` it masks by) holds bf16 -- 2 bytes per element,
+        * leading dimensions and strides still count elements; accumulation, bias and split-K workspaces stay fp32.  This is how the
+        * two large activations of an encoder layer (the fused q|k|v projection, the feed-forward hidden layer) live in HBM there. */
+       EMLOCO_GEMM_A_BF16MEM = 64, EMLOCO_GEMM_B_BF16MEM = 128, EMLOCO_GEMM_C_BF16MEM = 256, EMLOCO_GEMM_MASK_BF16MEM = 512 };
 
 /* Batched strided GEMM on the matrix cores, fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: exact fp32):
  *   C[b][m][n] (+)= alpha * sum_k A_b(m,k) * B_b(n,k)   [+ bias[n]] [relu]
@@ -85,7 +90,9 @@ int emloco_attention_bwd(int n_seq, int S, int nhead, int d_model, float scale, 
 /* The same with flags: EMLOCO_ATTN_BF16 = the opt-in reduced precision of EMLOCO_GEMM_BF16 for the four (forward) / eight
  * (backward) tile products per step: operands (q, k, v, probabilities, dO, dS) rounded to bf16 into
  * v_mfma_f32_32x32x16_bf16, fp32 accumulation; softmax statistics, log-sum-exp and D stay fp32.  flags = 0 is the call above. */
-enum { EMLOCO_ATTN_BF16 = 16 };
+enum { EMLOCO_ATTN_BF16 = 16,
+       EMLOCO_ATTN_QKV_BF16MEM = 32   /* with EMLOCO_ATTN_BF16: qkv (and, in the backward, dqkv) hold bf16 in memory -- 2 bytes per element,
+                                       * same shapes; out / dout / lse / dsum stay fp32 */ };
 int emloco_attention_fwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                             float *out, float *lse, int flags, void *stream);
 int emloco_attention_bwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
@@ -134,6 +141,8 @@ int64_t emloco_layernorm_bwd_workspace(int rows, int d);
 
 /* column sums: out[n] = sum_m X[m][n]  (bias gradients), fixed reduction order */
 int emloco_colsum(int m, int n, const float *X, float *out, float *workspace, void *stream);
+/* The same for a bf16 matrix: flags = EMLOCO_GEMM_A_BF16MEM (the bias gradient of the bf16 q|k|v gradient); sums in fp32. */
+int emloco_colsum_ex(int m, int n, const float *X, float *out, float *workspace, int flags, void *stream);
 int64_t emloco_colsum_workspace(int m, int n);   /* floats */
 
 /* Policy-input normaliser (frozen policy forward): RunningMeanStd.forward in eval mode,

@@ -1,4 +1,4 @@
-"""The JTA EmLoco train step alone (fp32), for profiling: python tools/exp/jta_step.py [steps]"""
+"""The JTA EmLoco train step alone, for profiling: python tools/exp/jta_step.py [steps]   (JTA_PRECISION=bf16: the reduced-precision mode)"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R)
 import torch
@@ -7,6 +7,8 @@ from emloco_amd.learning.value_pose_net import ValuePoseNet
 from emloco_amd.predictor.model_jta import TransMotionJTA
 from emloco_amd.predictor.train_jta import EmLocoTrainer
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+from emloco_amd.predictor import ops
+ops.set_matmul_precision(os.environ.get("JTA_PRECISION", "fp32"))
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 cfg = {"DEVICE": str(dev), "MULTI_MODAL": False, "USE_FRAME_MASK": False,
