@@ -710,9 +710,8 @@ def test_shipped_depth_model_in_the_bf16_mode_is_within_its_bar(golden):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(shapes, seed=int(g["weight_seed"])).items()}, strict=True)
     model.eval()
     in_joints, pm, out_joints = (torch.from_numpy(g[k]).to(dev) for k in ("in_joints", "pm", "out_joints"))
-    ref = model(in_joints.clone(), pm.clone()).detach()
-    seen = []
-    orig_ff, orig_att = ops.FeedForwardFn.forward, ops.FusedAttentionFn.forward
+    for _ in range(3):       # nn.Embedding(max_norm=1) renormalises the looked-up rows in place: settles after two forwards
+        ref = model(in_joints.clone(), pm.clone()).detach()
     try:
         ops.set_matmul_precision("bf16")
         pred = model(in_joints.clone(), pm.clone())
