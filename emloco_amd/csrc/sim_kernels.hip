@@ -224,6 +224,8 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     // parts of short envs free early are taken by second parts instead of idling until the launch's last workgroup ends.
     const int sub_lo = (prm.n_sub * part) / n_parts, sub_hi = (prm.n_sub * (part + 1)) / n_parts;
     float *pst = d.part_state ? d.part_state + (long)env * EMLOCO_PART_WORDS : nullptr;
+    // (the rotation vectors edof could wait in LDS -- they are read twice per substep -- but 96 more words put the 13th KB on the
+    // env's LDS and cost the twelfth resident env per CU: measured slower than letting the compiler park them in scratch)
     float qj[4] = {0, 0, 0, 1}, wj[3] = {0, 0, 0}, edof[3] = {0, 0, 0};
     if (part == 0) {
         if ((lane < NB) && lane >= 1) {
@@ -277,7 +279,9 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     const float h = prm.h;
     // registers that persist across phases (lane = body)
     // (R, r, V of a body live in LDS; the motion-subspace columns S = [R e_c ; r x R e_c] are re-formed where needed)
-    float tau[3], dd[3]; bool sat[3];
+    float tau[3], dd[3];
+    int sat[3];            // 0: implicit drive; +1 / -1: constant torque at +/- the effort limit; 2: effort drive (the command, clipped).
+                           // With it the torque report of the last substep needs no tau: three registers fewer across the contact phases
     float uh[3], qdd[3];
 
     for (int sub = sub_lo; sub < sub_hi + (part == n_parts - 1 ? 1 : 0); ++sub) {
@@ -543,9 +547,9 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 const float e = tgt - edof[k];
                 if (prm.drive_mode == 1) {       // effort drive (gymapi.DOF_MODE_EFFORT): the given torque within the limit, nothing implicit
                     const float eff = lane >= 1 ? dr[3] : 0.0f;
-                    sat[k] = true; tau[k] = tgt > eff ? eff : (tgt < -eff ? -eff : tgt); dd[k] = arm;
+                    sat[k] = 2; tau[k] = tgt > eff ? eff : (tgt < -eff ? -eff : tgt); dd[k] = arm;
                 } else {
-                    sat[k] = false; tau[k] = kp * e - (kd + h * kp) * wj[k]; dd[k] = arm + h * kd + h * h * kp;
+                    sat[k] = 0; tau[k] = kp * e - (kd + h * kp) * wj[k]; dd[k] = arm + h * kd + h * h * kp;
                 }
             }
         }
@@ -594,7 +598,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             float Rc[9], Ic[9], cw[3], c[3], in6[8], bcom[4];
             ld4(mdl, o_dyn + 8, in6); ld4(mdl, o_dyn + 12, in6 + 4);            // mass properties: re-read per substep (L2 hits)
             ld4(mdl, o_dyn + 4, bcom);
-            const float bmass = jm[3];
+            const float bmass = mdl[o_dyn + 3];
             const float Ib[9] = {in6[0], in6[3], in6[4], in6[3], in6[1], in6[5], in6[4], in6[5], in6[2]};
             for (int a = 0; a < 3; ++a)
                 for (int q = 0; q < 3; ++q) Rc[a * 3 + q] = SOP3(R[a * 3], Ib[q], R[a * 3 + 1], Ib[3 + q], R[a * 3 + 2], Ib[6 + q]);
@@ -755,7 +759,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                     ld4(mdl, o_drv + 4 * k, dr);
                     const float kp = dr[0], kd = dr[1], eff = dr[3];
                     const float ti = tau[k] - (h * kd + h * h * kp) * qdd[k];
-                    if (!sat[k] && fabsf(ti) > eff) { sat[k] = true; tau[k] = ti > 0.0f ? eff : -eff; dd[k] = dr[2]; over = true; }
+                    if (sat[k] == 0 && fabsf(ti) > eff) { sat[k] = ti > 0.0f ? 1 : -1; tau[k] = ti > 0.0f ? eff : -eff; dd[k] = dr[2]; over = true; }
                 }
             if (__ballot(over) == 0ull) break;
         }
@@ -769,45 +773,46 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         // ============================================================ 5. ground-contact candidates (lane = candidate)
         // two candidates per lane (`lane`, `lane + 64`); their body-frame points are re-derived from the model each
         // substep (L2 hits) rather than held in registers across the launch
-        int cb[2]; float clp[2][3], crad[2];
+        // What a candidate leaves for the contact list -- its contact point and, on a height field, the ground normal there -- waits
+        // in LDS (arrays that are dead in this phase: Ia tail | pa | a | V) instead of 12 registers per lane across the ballots
+        float *sh_stage = lds + O_G;                           // [128][7]
+        static_assert(O_VF - O_G >= 128 * 7, "candidate staging does not fit the arrays that are dead in phase 5");
+        int cb[2]; float cdist[2]; bool act[2];
         for (int s = 0; s < 2; ++s) {
             const int c = lane + 64 * s;
-            cb[s] = -1; crad[s] = 0.0f; clp[s][0] = clp[s][1] = clp[s][2] = 0.0f;
+            cb[s] = -1; act[s] = false; cdist[s] = 0.0f;
             if (c < d.n_cand) {
                 const int cp = topo[EMLOCO_TOPO_CAND + c], body = cp & 0xff, k = (cp >> 8) & 0xff, gt = cp >> 16;
-                float ga[4], gb[4];                              // geom a xyz, radius | geom b xyz
+                float ga[4], gb[4], clp[3];                      // geom a xyz, radius | geom b xyz
                 ld4(mdl, EMLOCO_MB_GEO + body * 8, ga); ld4(mdl, EMLOCO_MB_GEO + body * 8 + 4, gb);
-                cb[s] = body; crad[s] = ga[3];
-                if (gt == EMLOCO_GEOM_SPHERE) { clp[s][0] = ga[0]; clp[s][1] = ga[1]; clp[s][2] = ga[2]; }
+                const float crad = ga[3];
+                cb[s] = body;
+                if (gt == EMLOCO_GEOM_SPHERE) { clp[0] = ga[0]; clp[1] = ga[1]; clp[2] = ga[2]; }
                 else if (gt == EMLOCO_GEOM_CAPSULE) {
                     const float *src = k == 0 ? ga : gb;
-                    clp[s][0] = src[0]; clp[s][1] = src[1]; clp[s][2] = src[2];
+                    clp[0] = src[0]; clp[1] = src[1]; clp[2] = src[2];
                 } else {
-                    clp[s][0] = ga[0] + ((k & 1) ? gb[0] : -gb[0]);
-                    clp[s][1] = ga[1] + ((k & 2) ? gb[1] : -gb[1]);
-                    clp[s][2] = ga[2] + ((k & 4) ? gb[2] : -gb[2]);
+                    clp[0] = ga[0] + ((k & 1) ? gb[0] : -gb[0]);
+                    clp[1] = ga[1] + ((k & 2) ? gb[1] : -gb[1]);
+                    clp[2] = ga[2] + ((k & 4) ? gb[2] : -gb[2]);
                 }
-            }
-        }
-        float cdist[2], cxw[2][3], cnrm[2][3]; bool act[2];
-        for (int s = 0; s < 2; ++s) {
-            act[s] = false; cdist[s] = 0.0f;
-            if (cb[s] >= 0) {
-                float Rb[9], wp[3];
-                for (int k = 0; k < 9; ++k) Rb[k] = sh_R[cb[s]][k];
-                matvec3(Rb, clp[s], wp);
-                const float z = sh_pq[cb[s]][2] + wp[2];
+                float Rb[9], wp[3], cxw[3];
+                for (int k2 = 0; k2 < 9; ++k2) Rb[k2] = sh_R[body][k2];
+                matvec3(Rb, clp, wp);
+                const float z = sh_pq[body][2] + wp[2];
+                float *stg = sh_stage + c * 7;
                 if (!hf_on) {
-                    cdist[s] = (z - prm.ground_z) - crad[s];
-                    cxw[s][0] = sh_R[cb[s]][9] + wp[0];
-                    cxw[s][1] = sh_R[cb[s]][10] + wp[1];
-                    cxw[s][2] = (sh_R[cb[s]][11] + wp[2]) - crad[s];
+                    cdist[s] = (z - prm.ground_z) - crad;
+                    cxw[0] = sh_R[body][9] + wp[0];
+                    cxw[1] = sh_R[body][10] + wp[1];
+                    cxw[2] = (sh_R[body][11] + wp[2]) - crad;
                 } else {      // sphere of the candidate against the plane of the terrain triangle under its centre
-                    float zt;
-                    hf_plane(d, sh_pq[cb[s]][0] + wp[0], sh_pq[cb[s]][1] + wp[1], zt, cnrm[s]);
-                    cdist[s] = (z - zt) * cnrm[s][2] - crad[s];
-                    for (int k = 0; k < 3; ++k) cxw[s][k] = (sh_R[cb[s]][9 + k] + wp[k]) - crad[s] * cnrm[s][k];
+                    float zt, cnrm[3];
+                    hf_plane(d, sh_pq[body][0] + wp[0], sh_pq[body][1] + wp[1], zt, cnrm);
+                    cdist[s] = (z - zt) * cnrm[2] - crad;
+                    for (int k2 = 0; k2 < 3; ++k2) { cxw[k2] = (sh_R[body][9 + k2] + wp[k2]) - crad * cnrm[k2]; stg[3 + k2] = cnrm[k2]; }
                 }
+                for (int k2 = 0; k2 < 3; ++k2) stg[k2] = cxw[k2];
                 act[s] = cdist[s] < prm.contact_offset;
             }
         }
@@ -850,10 +855,11 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 const int ci = s == 0 ? i0 : i1;
                 sh_slot[lane + 64 * s] = act[s] ? (unsigned char)ci : (unsigned char)255;
                 if (act[s]) {
+                    const float *stg = sh_stage + (lane + 64 * s) * 7;      // this lane's own entry: no other lane touches it
                     sh_cbody[ci] = (unsigned char)cb[s]; sh_cdist[ci] = cdist[s];
-                    for (int k = 0; k < 3; ++k) { sh_cx[ci][k] = cxw[s][k]; sh_lam[3 * ci + k] = wl[s][k]; }
+                    for (int k = 0; k < 3; ++k) { sh_cx[ci][k] = stg[k]; sh_lam[3 * ci + k] = wl[s][k]; }
                     if (hf_on) {      // frame: normal, t1 = (y x n) / |y x n|, t2 = n x t1  (n_z > 0 on a height field)
-                        const float *n = cnrm[s];
+                        const float n[3] = {stg[3], stg[4], stg[5]};
                         const float il = 1.0f / sqrtf(fmaf(n[2], n[2], n[0] * n[0]));
                         const float t1x = n[2] * il, t1z = 0.0f - n[0] * il;
                         float *D = sh_cdir[ci];
@@ -1220,7 +1226,8 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                     const float kpk = dr[0], kdk = dr[1], tgk = tgt_env[jdof + k];
                     // torque applied over this substep (the contact impulses moved the implicit drive along; reported within the limit)
                     const float effk = dr[3];
-                    float tq = sat[k] ? tau[k] : kpk * (tgk - edof[k] - h * wn[k]) - kdk * wn[k];
+                    float tq = sat[k] == 0 ? kpk * (tgk - edof[k] - h * wn[k]) - kdk * wn[k]
+                             : (sat[k] == 2 ? tgk : (sat[k] > 0 ? effk : -effk));         // (clipped to the limit just below)
                     tq = tq > effk ? effk : (tq < -effk ? -effk : tq);
                     d.dof_force[(size_t)env * NDOF + jdof + k] = tq;
                 }

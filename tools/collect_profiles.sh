@@ -116,7 +116,7 @@ dur_ns = None
 for r in list(csv.reader(open(sys.argv[2])))[1:]:
     if "sim_step_kernel" in r[0]:
         dur_ns = float(r[3])
-lines = ["sim_step_kernel, 4096 envs (two 64-lane waves each: split launch), sequential schedule, mean per launch over %d launches" % len(next(iter(agg.values()), []))]
+lines = ["sim_step_kernel, 4096 envs (one 64-lane wave per env and substep: 4 dependent workgroups per env), sequential schedule, mean per launch over %d launches" % len(next(iter(agg.values()), []))]
 for k in sorted(m):
     lines.append(f"  {k:22s} {m[k]:.6g}")
 if m.get("SQ_WAVE_CYCLES"):
@@ -132,6 +132,14 @@ if dur_ns and m.get("SQ_INSTS_VALU"):
     lines.append(f"VALU wave-instructions per launch {m['SQ_INSTS_VALU']:.4g} = {m['SQ_INSTS_VALU'] / 4096:.0f} per env")
     lines.append(f"VALU issue utilisation = insts x 2 cycles (wave64 on a SIMD-32) / (cycles x {SIMDS} SIMDs) = "
                  f"{m['SQ_INSTS_VALU'] * 2 / (cyc * SIMDS):.3f}  (lower bound: the engine clock under load is below nominal)")
+    if m.get("SQ_ACTIVE_INST_VALU"):
+        # SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave has a VALU instruction in flight: x 4 = cycles, summed over the waves
+        # of a SIMD; measured cost per instruction (active / insts) and the share of the SIMD-cycles of the launch it covers
+        per = m["SQ_ACTIVE_INST_VALU"] * 4 / m["SQ_INSTS_VALU"]
+        lines.append(f"VALU busy = SQ_ACTIVE_INST_VALU x 4 cycles / (cycles x {SIMDS} SIMDs) = {m['SQ_ACTIVE_INST_VALU'] * 4 / (cyc * SIMDS):.3f}"
+                     f"  ({per:.2f} cycles of VALU-active time per instruction)")
+    if m.get("SQ_WAVE_CYCLES"):
+        lines.append(f"resident waves per SIMD (time average) = SQ_WAVE_CYCLES x 4 / (cycles x {SIMDS}) = {m['SQ_WAVE_CYCLES'] * 4 / (cyc * SIMDS):.2f}")
 open(sys.argv[1], "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
