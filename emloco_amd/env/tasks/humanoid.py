@@ -358,10 +358,13 @@ class Humanoid(BaseTask):
 
     # ------------------------------------------------------------------ step (humanoid.py:1184-1232)
     def pre_physics_step(self, actions):
-        # the reference clones (humanoid.py:1185); the copy is skipped when the caller's tensor already lives on the device:
-        # it is only read by the launch below, before control returns
+        # the reference clones (humanoid.py:1185): `self.actions` must not alias a buffer the caller goes on writing into (a policy
+        # that reuses its output tensor).  Copied into a persistent buffer of the task: same semantics, no allocation per step
         self.wait_obs()             # the observation launch of the last step reads what this step's rigid-body launch overwrites
-        self.actions = actions if (actions.device == torch.device(self.device) and actions.dtype == torch.float32) else actions.to(self.device).clone()
+        if getattr(self, "_actions_buf", None) is None or self._actions_buf.shape != actions.shape:
+            self._actions_buf = torch.empty(actions.shape, dtype=torch.float32, device=self.device)
+        self._actions_buf.copy_(actions)
+        self.actions = self._actions_buf
         if not self._pd_control:                                  # humanoid.py:1203-1207: joint torques, effort drives
             forces = self.actions * self.motor_efforts.unsqueeze(0) * self.power_scale
             self.gym.set_dof_actuation_force_tensor(self.sim, gymtorch.unwrap_tensor(forces.contiguous()))
