@@ -20,6 +20,18 @@ __device__ __forceinline__ gemm_bf16x8 gemm_pack_bf16(const F4 &lo, const F4 &hi
 __device__ __forceinline__ mfma_f32x16 gemm_mfma_bf16(gemm_bf16x8 a, gemm_bf16x8 b, mfma_f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// The split mode (fp32 products rebuilt from bf16 pieces, predictor_kernels.hip) keeps operands as packed words: two bf16 per
+// 32-bit word (low half = the first element), four words = the 8 reduction entries a lane feeds one matrix instruction.
+struct __attribute__((aligned(16))) bf16w4 { unsigned x, y, z, w; };
+__device__ __forceinline__ unsigned gemm_pack2_bf16(float a, float b) {                    // v_cvt_pk_bf16_f32: round to nearest even
+    typedef float vf2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const vf2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ mfma_f32x16 gemm_mfma_bf16_w(const bf16w4 &a, const bf16w4 &b, mfma_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gemm_bf16x8, a), __builtin_bit_cast(gemm_bf16x8, b), c, 0, 0, 0);
+}
 }  // namespace emloco
 #endif
 #endif

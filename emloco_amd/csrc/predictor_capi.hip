@@ -104,7 +104,9 @@ int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha, const float 
     // weight gradients (1024 x 128 x 927744 split 64: 114 vs 107)
     const long n_wg = (long)grid.x * grid.y * grid.z;
     const bool long_k = (k + ksplit - 1) / ksplit > 256;
-    const bool deep = force_bk ? force_bk == 32 : (long_k && (n <= 32 || (n_wg <= 1024 && !(trans_a && trans_b))));
+    bool deep = force_bk ? force_bk == 32 : (long_k && (n <= 32 || (n_wg <= 1024 && !(trans_a && trans_b))));
+    if ((flags & EMLOCO_GEMM_SPLIT) && !(flags & EMLOCO_GEMM_BF16) && g.vec_a && g.vec_b && n > 32) deep = false;   // split stages are 16 deep
+    else g.flags &= ~EMLOCO_GEMM_SPLIT;
     const emloco::GemmKernel kern = emloco::gemm_pick(g, deep);
     if (!kern) return pfail(-1, "emloco_gemm_f32: this combination of bf16 memory operands and layouts is not served");
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, g);
@@ -203,7 +205,8 @@ int emloco_gemm_relu_bwd(int m, int n, int k, const float *A, int lda, const flo
                          const float *y, float scale, float *colsum, float *workspace, int flags, void *stream) {
     if (m < 1 || n < 33 || k < 1 || !A || !B || !C || !y || !colsum || !workspace)
         return pfail(-1, "emloco_gemm_relu_bwd: bad argument (n > 32; workspace = emloco_gemm_relu_bwd_workspace(m, n) floats)");
-    emloco::GemmArgs g{1, m, n, k, 1.0f, A, lda, 0, 0, B, ldb, 0, trans_b, C, n, 0, nullptr, 32 | (flags & EMLOCO_GEMM_BF16), 1, nullptr,
+    emloco::GemmArgs g{1, m, n, k, 1.0f, A, lda, 0, 0, B, ldb, 0, trans_b, C, n, 0, nullptr,
+                       32 | (flags & EMLOCO_GEMM_BF16) | ((flags & EMLOCO_GEMM_BF16) ? 0 : (flags & EMLOCO_GEMM_SPLIT)), 1, nullptr,
                        0, 0, 0.0f, 0u, y, scale, workspace};
     g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
     g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);

@@ -169,6 +169,102 @@ __device__ __forceinline__ void gemm_frag(const float *S, int row, int half8, f3
     }
 }
 
+// ---- PREC = 2, the split mode: fp32 products rebuilt from bf16 pieces -------------------------------------------------------
+// gfx950 runs v_mfma_f32_32x32x2_f32 at 1/16 of the bf16 rate (157 vs 2500 TFLOP/s) and has no xf32.  An fp32 value is the exact
+// sum of three bf16 pieces a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2); each remainder is exact in
+// fp32 and round-to-nearest leaves it at most half an ulp of the piece above, so three 8-bit significands cover the 24), and
+//   a b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1) + O(2^-24 a b)
+// -- six v_mfma_f32_32x32x16_bf16 per 16 k (192 matrix-pipe cycles) where the fp32 instruction needs eight x 64 = 512.  Every
+// bf16 x bf16 product is exact in fp32 and the accumulation is fp32, so the result is in fp32's error class: measured against
+// float64 (tools/exp/bf16split_err.hip, K = 128 .. 4096, signed / all-positive / wide-range data) max 1.2e-7 .. 2.4e-6 of
+// sum |a b| for the six-term form vs 1.2e-7 .. 2.8e-6 for the fp32 instruction; nine terms change nothing, three terms give
+// 2e-6 (not fp32 class).  It is NOT bit-equal to the fmaf chain.  Inf operands come out NaN (inf - inf in the remainder).
+//
+// The pieces are made ONCE per element, when a stage goes to LDS (not per consuming wave).  LDS image of one operand stage
+// (16 k): three planes, each [2 halves][ROWS + 4 slots], a slot = the 8 bf16 (16 B) of one row and one half of the stage -- what
+// a lane feeds one matrix instruction, read with a single ds_read_b128; 16 consecutive rows = 256 consecutive bytes = all 64
+// banks.  The +4 slots put the two halves on different banks for the 8-byte stores of a [row][k] operand (thread = 4 k of a row).
+// A row-contiguous (TRANS) operand arrives as 4 rows at one k per thread; a thread takes TWO adjacent k there and stores one
+// packed word per row and plane, the rows of a 16-row group bit-permuted (and crossed with the next row bit) so that the 32
+// lanes of a store group hit 16 banks (2-way: free on a 4-byte store) instead of 2; reads stay conflict-free because the
+// permutation keeps every aligned 16-row group inside its 16 slots.
+constexpr int split_half_words(int rows) { return (rows + 4) * 4; }
+constexpr int split_plane_words(int rows) { return 2 * split_half_words(rows); }
+constexpr int split_stage_words(int rows) { return 3 * split_plane_words(rows); }
+template <int TRANS>
+__device__ __forceinline__ int split_slot(int row) {
+    if (!TRANS) return row;
+    const int b0 = row & 1, b1 = (row >> 1) & 1, b2 = (row >> 2) & 1, b3 = (row >> 3) & 1, b4 = (row >> 4) & 1;
+    return (row & ~15) | (b0 << 3) | ((b1 ^ b4) << 2) | (b3 << 1) | b2;
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned &p1, unsigned &p2, unsigned &p3) {
+    p1 = gemm_pack2_bf16(a, b);
+    float ra = a - bf16_lo(p1), rb = b - bf16_hi(p1);
+    p2 = gemm_pack2_bf16(ra, rb);
+    ra -= bf16_lo(p2); rb -= bf16_hi(p2);
+    p3 = gemm_pack2_bf16(ra, rb);
+}
+// thread -> (row quad, k pair) of a TRANS operand stage: 16-lane runs of row quads (256 contiguous bytes per run and k), the
+// two runs of a 32-lane store group on adjacent k pairs
+__device__ __forceinline__ void split_trans_map(int tid, int &rq, int &kp) {
+    rq = (tid & 15) + 16 * ((tid >> 5) & 1);
+    kp = ((tid >> 4) & 1) + 2 * (tid >> 6);
+}
+// TRANS operand, 128 rows x 16 k, 256 threads: the quads (4 rows) at k = 2 kp and 2 kp + 1
+__device__ __forceinline__ void split_fetch_trans(f32x4 (&v)[2], unsigned (&mk)[2], const float *X, int ld, int row0, int rows, int k0, int ke, int tid) {
+    int rq, kp;
+    split_trans_map(tid, rq, kp);
+    const int row = row0 + 4 * rq, rq4 = (rows - 1) & ~3;
+    const int rowc = row < rq4 ? row : rq4;
+    const unsigned rm = (row < rows ? 1u : 0u) | (row + 1 < rows ? 2u : 0u) | (row + 2 < rows ? 4u : 0u) | (row + 3 < rows ? 8u : 0u);
+    for (int e = 0; e < 2; ++e) {
+        const int kg = k0 + 2 * kp + e;
+        const int kc = kg < ke ? kg : ke - 1;
+        v[e] = *(const f32x4 *)(X + (long)kc * ld + rowc);
+        mk[e] = kg < ke ? rm : 0u;
+    }
+}
+template <int ROWS, int TRANS>
+__device__ __forceinline__ void split_stash(const f32x4 (&v)[2], const unsigned (&mk)[2], unsigned *S, int tid) {
+    static_assert(ROWS == 128, "split stages are 128 rows x 16 k on 256 threads");
+    constexpr int HW = split_half_words(ROWS), PW = split_plane_words(ROWS);
+    f32x4 t[2];
+    for (int e = 0; e < 2; ++e) {
+        t[e] = v[e];
+        t[e].x = (mk[e] & 1u) ? t[e].x : 0.0f; t[e].y = (mk[e] & 2u) ? t[e].y : 0.0f;
+        t[e].z = (mk[e] & 4u) ? t[e].z : 0.0f; t[e].w = (mk[e] & 8u) ? t[e].w : 0.0f;
+    }
+    if (!TRANS) {
+        for (int e = 0; e < 2; ++e) {                          // quad = 4 consecutive k of one row: 8 bytes per plane
+            const int idx = tid + 256 * e, r = idx >> 2, q = idx & 3;
+            unsigned a1, a2, a3, b1, b2, b3;
+            split_pair(t[e].x, t[e].y, a1, a2, a3);
+            split_pair(t[e].z, t[e].w, b1, b2, b3);
+            unsigned *dst = S + (q >> 1) * HW + r * 4 + (q & 1) * 2;
+            *(uint2 *)(dst) = uint2{a1, b1};
+            *(uint2 *)(dst + PW) = uint2{a2, b2};
+            *(uint2 *)(dst + 2 * PW) = uint2{a3, b3};
+        }
+    } else {                                                   // 4 rows x 2 adjacent k: one word per row and plane
+        int rq, kp;
+        split_trans_map(tid, rq, kp);
+        const float lo[4] = {t[0].x, t[0].y, t[0].z, t[0].w}, hi[4] = {t[1].x, t[1].y, t[1].z, t[1].w};
+        unsigned *base = S + (kp >> 2) * HW + (kp & 3);
+        for (int j = 0; j < 4; ++j) {
+            unsigned p1, p2, p3;
+            split_pair(lo[j], hi[j], p1, p2, p3);
+            unsigned *dst = base + split_slot<1>(4 * rq + j) * 4;
+            dst[0] = p1; dst[PW] = p2; dst[2 * PW] = p3;
+        }
+    }
+}
+// the three pieces of a lane's 8 reduction entries (its half of the stage) of one row
+template <int ROWS, int TRANS>
+__device__ __forceinline__ void split_frag(const unsigned *S, int row, int half, bf16w4 (&out)[3]) {
+    const unsigned *src = S + half * split_half_words(ROWS) + split_slot<TRANS>(row) * 4;
+    for (int p = 0; p < 3; ++p) out[p] = *(const bf16w4 *)(src + p * split_plane_words(ROWS));
+}
+
 // Tile shapes: <2,2,2,2> = 128x128 (4 waves as 2x2, each 2x2 MFMA tiles) for the projections / FFN / score products;
 // <4,1,1,1> = 128x32 (4 waves stacked in M, one MFMA tile each) for the products whose N is the head dim (32):
 // P.V, dQ, dK, dV -- a 128-wide tile would waste 3/4 of its MFMAs there.
@@ -191,7 +287,10 @@ template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int 
 __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     constexpr int BM = WM * TI * 32, BN = WN * TJ * 32, GLDK = GBK + 4, NF = GBK / 8;
     constexpr int QA = (BM * GBK / 4 + 255) / 256, QB = (BN * GBK / 4 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * GLDK], Bs[2][BN * GLDK];
+    static_assert(PREC != 2 || (GBK == 16 && BM == 128 && BN == 128 && VEC == 1 && IOA == 0 && IOB == 0),
+                  "split mode: 128 x 128 x 16 stages, fp32 operands, 16-byte loads");
+    constexpr int SA = PREC == 2 ? split_stage_words(BM) : BM * GLDK, SB = PREC == 2 ? split_stage_words(BN) : BN * GLDK;
+    __shared__ __attribute__((aligned(16))) float As[2][SA], Bs[2][SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
     // (An XCD-aware tile order -- XCD c walks the column tiles of the rows = c (mod 8) back to back so that a slab of A is
@@ -215,22 +314,44 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
 
     f32x4 ra[QA], rb[QB];
     unsigned ma[QA], mb[QB];
+    // fetch / stash of one stage in the mode's own LDS image
+#define GEMM_FETCH(K0)                                                                                          \
+    if constexpr (PREC == 2 && TA) split_fetch_trans(ra, ma, A, g.lda, m0, g.m, (K0), ke, tid);                 \
+    else gemm_fetch<BM, GBK, TA, VEC, IOA>(ra, ma, A, g.lda, m0, g.m, (K0), ke, tid);                           \
+    if constexpr (PREC == 2 && TB) split_fetch_trans(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);                 \
+    else gemm_fetch<BN, GBK, TB, VEC, IOB>(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);
+#define GEMM_STASH(BUF)                                                                                         \
+    if constexpr (PREC == 2) {                                                                                  \
+        split_stash<BM, TA>(ra, ma, (unsigned *)As[BUF], tid);                                                  \
+        split_stash<BN, TB>(rb, mb, (unsigned *)Bs[BUF], tid);                                                  \
+    } else {                                                                                                    \
+        gemm_stash<BM, GBK, TA>(ra, ma, As[BUF], tid);                                                          \
+        gemm_stash<BN, GBK, TB>(rb, mb, Bs[BUF], tid);                                                          \
+    }
     if (kb < ke) {
-        gemm_fetch<BM, GBK, TA, VEC, IOA>(ra, ma, A, g.lda, m0, g.m, kb, ke, tid);
-        gemm_fetch<BN, GBK, TB, VEC, IOB>(rb, mb, B, g.ldb, n0, g.n, kb, ke, tid);
-        gemm_stash<BM, GBK, TA>(ra, ma, As[0], tid);
-        gemm_stash<BN, GBK, TB>(rb, mb, Bs[0], tid);
+        GEMM_FETCH(kb)
+        GEMM_STASH(0)
     }
     __syncthreads();
     int buf = 0;
     const int half8 = (GBK / 2) * (lane >> 5), l31 = lane & 31;
     for (int k0 = kb; k0 < ke; k0 += GBK) {
         // next stage's global loads are in flight during the MFMAs (past the end they fetch zeros: clamped + masked)
-        gemm_fetch<BM, GBK, TA, VEC, IOA>(ra, ma, A, g.lda, m0, g.m, k0 + GBK, ke, tid);
-        gemm_fetch<BN, GBK, TB, VEC, IOB>(rb, mb, B, g.ldb, n0, g.n, k0 + GBK, ke, tid);
+        GEMM_FETCH(k0 + GBK)
         // keep the loads HERE: left free, the scheduler sinks them below most of the stage's MFMAs (they are only consumed by the
         // stash) and the s_waitcnt in front of the stash then exposes the whole memory latency every stage
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PREC == 2) {
+            bf16w4 sa[TI][3], sb[TJ][3];
+            for (int i = 0; i < TI; ++i) split_frag<BM, TA>((const unsigned *)As[buf], (wm * TI + i) * 32 + l31, lane >> 5, sa[i]);
+            for (int j = 0; j < TJ; ++j) split_frag<BN, TB>((const unsigned *)Bs[buf], (wn * TJ + j) * 32 + l31, lane >> 5, sb[j]);
+            // the six products, smallest first; term-outer so that consecutive matrix instructions go to different accumulators
+#define SPLIT_TERM(PA, PB)                                                                                      \
+            for (int i = 0; i < TI; ++i)                                                                        \
+                for (int j = 0; j < TJ; ++j) acc[i][j] = gemm_mfma_bf16_w(sa[i][PA], sb[j][PB], acc[i][j]);
+            SPLIT_TERM(2, 0) SPLIT_TERM(0, 2) SPLIT_TERM(1, 1) SPLIT_TERM(1, 0) SPLIT_TERM(0, 1) SPLIT_TERM(0, 0)
+#undef SPLIT_TERM
+        } else {
         f32x4 fa[TI][NF], fb[TJ][NF];
         for (int i = 0; i < TI; ++i) gemm_frag<BM, GBK, TA>(As[buf], (wm * TI + i) * 32 + l31, half8, fa[i]);
         for (int j = 0; j < TJ; ++j) gemm_frag<BN, GBK, TB>(Bs[buf], (wn * TJ + j) * 32 + l31, half8, fb[j]);
@@ -241,7 +362,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
         if constexpr (PREC == 0) {
             for (int f = 0; f < NF; ++f) { GEMM_STEP(f, x) GEMM_STEP(f, y) GEMM_STEP(f, z) GEMM_STEP(f, w) }
         } else {
-            static_assert(PREC == 0 || NF % 2 == 0, "bf16 operands take k in groups of 16");
+            static_assert(PREC != 1 || NF % 2 == 0, "bf16 operands take k in groups of 16");
             for (int f = 0; f + 1 < NF; f += 2) {
                 gemm_bf16x8 pa[TI], pb[TJ];
                 for (int i = 0; i < TI; ++i) pa[i] = gemm_pack_bf16(fa[i][f], fa[i][f + 1]);
@@ -252,12 +373,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
             }
         }
 #undef GEMM_STEP
+        }
         __builtin_amdgcn_sched_barrier(0);
-        gemm_stash<BM, GBK, TA>(ra, ma, As[buf ^ 1], tid);
-        gemm_stash<BN, GBK, TB>(rb, mb, Bs[buf ^ 1], tid);
+        GEMM_STASH(buf ^ 1)
         __syncthreads();
         buf ^= 1;
     }
+#undef GEMM_FETCH
+#undef GEMM_STASH
     // epilogue: C/D fragment layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  A lane owns ONE column per (j): its
     // bias is read once (left inside the row loop, every store to C makes the compiler reload it: C may alias the bias).
     // Addresses are a workgroup-uniform tile base (scalar registers) + a 32-bit lane offset: one VGPR per access instead of a
@@ -349,6 +472,14 @@ template <int GBK, int TB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 gemm_bf16_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, GBK, 0, TB, 1, 1, 1, 0, 0, 1>(g); }
 
+// split mode: three workgroups per CU (50.7 KB of LDS each)
+template <int TA, int TB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+gemm_split_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, TA, TB, 1, 2, 0>(g); }
+template <int TB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+gemm_split_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, 0, TB, 1, 2, 1, 0, 0, 0>(g); }
+
 // kernel variant for a problem: tile shape (narrow: n <= 32), stage depth, operand layouts, 16-byte loads
 typedef void (*GemmKernel)(GemmArgs);
 template <int WM, int WN, int TI, int TJ, int GBK>
@@ -387,6 +518,7 @@ inline GemmKernel gemm_pick_layout(int ta, int tb, int vec, int bf16 = 0, int a1
 inline GemmKernel gemm_pick(const GemmArgs &g, bool deep) {
     const int vec = g.vec_a && g.vec_b;
     const int bf16 = (g.flags & 16) ? 1 : 0;
+    if ((g.flags & 32) && (g.flags & 1024) && !bf16 && !g.c16 && !g.m16) return g.tb ? gemm_split_relu_bwd_kernel<1> : gemm_split_relu_bwd_kernel<0>;
     if (g.flags & 32) {           // fused backward epilogue: A row-major, 16-byte loads (the launcher checks)
         if (g.c16 || g.m16) {     // bf16 hidden layer and gradient (both or neither: the launcher checks)
             if (deep) return g.tb ? gemm_bf16_relu_bwd_kernel<32, 1> : gemm_bf16_relu_bwd_kernel<32, 0>;
@@ -400,6 +532,12 @@ inline GemmKernel gemm_pick(const GemmArgs &g, bool deep) {
         return g.tb ? gemm_f32_relu_bwd_kernel<16, 1, 0> : gemm_f32_relu_bwd_kernel<16, 0, 0>;
     }
     if (g.n <= 32) return deep ? gemm_pick_layout<4, 1, 1, 1, 32>(g.ta, g.tb, vec) : gemm_pick_layout<4, 1, 1, 1, 16>(g.ta, g.tb, vec);
+    if ((g.flags & 1024) && vec && !bf16) {        // split mode (fp32 class on the bf16 matrix rate): 16-byte-aligned operands, 128-wide tiles
+        if (!g.ta && !g.tb) return gemm_split_kernel<0, 0>;
+        if (!g.ta && g.tb) return gemm_split_kernel<0, 1>;
+        if (g.ta && !g.tb) return gemm_split_kernel<1, 0>;
+        return gemm_split_kernel<1, 1>;
+    }
     return deep ? gemm_pick_layout<2, 2, 2, 2, 32>(g.ta, g.tb, vec, bf16, g.a16, g.b16) : gemm_pick_layout<2, 2, 2, 2, 16>(g.ta, g.tb, vec, bf16, g.a16, g.b16);
 }
 

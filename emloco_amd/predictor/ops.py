@@ -85,6 +85,7 @@ def _chk(rc, what):
 
 
 GEMM_BF16 = 16
+GEMM_SPLIT = 1024      # EMLOCO_GEMM_SPLIT: fp32-class products from bf16 pieces (six bf16 matrix instructions per 16 k)
 GEMM_A16, GEMM_B16, GEMM_C16, GEMM_MASK16 = 64, 128, 256, 512      # EMLOCO_GEMM_*_BF16MEM: that operand is bf16 in memory
 ATTN_BF16 = 16
 ATTN_QKV16 = 32        # EMLOCO_ATTN_QKV_BF16MEM
@@ -97,8 +98,8 @@ def set_matmul_precision(mode):
     every `linear` / projection GEMM and every fused attention launched afterwards; the two large activations of an encoder
     layer -- the feed-forward hidden layer (M x 1024) and the fused q|k|v projection (M x 384) -- and their gradients are then
     kept in HBM as bf16 (softmax statistics, LayerNorm, residual stream, weight gradients, losses and the optimiser stay fp32)."""
-    if mode not in ("fp32", "bf16"):
-        raise ValueError("matmul precision must be 'fp32' or 'bf16'")
+    if mode not in ("fp32", "fp32_split", "bf16"):
+        raise ValueError("matmul precision must be 'fp32', 'fp32_split' or 'bf16'")
     _matmul_precision[0] = mode
 
 
@@ -112,6 +113,8 @@ def gemm(batch, m, n, k, A, lda, sa, ta, B, ldb, sb, tb, Cm, ldc, sc, alpha=1.0,
     (the reduced-precision mode's large activations) are passed as they are: the dtype travels in the flags."""
     if _matmul_precision[0] == "bf16":
         flags |= GEMM_BF16
+    elif _matmul_precision[0] == "fp32_split":
+        flags |= GEMM_SPLIT
     for t, bit in ((A, GEMM_A16), (B, GEMM_B16), (Cm, GEMM_C16)):
         if t.dtype == torch.bfloat16:
             assert a_off == 0 and b_off == 0 and c_off == 0
@@ -258,7 +261,7 @@ class FeedForwardFn(torch.autograd.Function):
         dz1 = torch.empty((M, F), dtype=h.dtype, device=dev)         # the hidden layer's gradient follows its dtype
         db1 = torch.empty(F, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.emloco_gemm_relu_bwd_workspace(M, F), dtype=torch.float32, device=dev)
-        fl = (GEMM_BF16 | GEMM_C16 | GEMM_MASK16) if h16 else (GEMM_BF16 if _matmul_precision[0] == "bf16" else 0)
+        fl = (GEMM_BF16 | GEMM_C16 | GEMM_MASK16) if h16 else {"bf16": GEMM_BF16, "fp32_split": GEMM_SPLIT}.get(_matmul_precision[0], 0)
         _chk(lib.emloco_gemm_relu_bwd(M, F, N, _p(dz2), N, _p(W2), F, 1, _p(dz1), _p(h), 1.0 / (1.0 - p), _p(db1), _p(ws), fl, st),
              "emloco_gemm_relu_bwd")
         dx = None

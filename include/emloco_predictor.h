@@ -23,7 +23,14 @@ enum { EMLOCO_GEMM_BIAS = 1, EMLOCO_GEMM_RELU = 2, EMLOCO_GEMM_ACCUMULATE = 4, E
         * the B operand / the output (for emloco_gemm_relu_bwd: the forward output `y` it masks by) holds bf16 -- 2 bytes per element,
         * leading dimensions and strides still count elements; accumulation, bias and split-K workspaces stay fp32.  This is how the
         * two large activations of an encoder layer (the fused q|k|v projection, the feed-forward hidden layer) live in HBM there. */
-       EMLOCO_GEMM_A_BF16MEM = 64, EMLOCO_GEMM_B_BF16MEM = 128, EMLOCO_GEMM_C_BF16MEM = 256, EMLOCO_GEMM_MASK_BF16MEM = 512 };
+       EMLOCO_GEMM_A_BF16MEM = 64, EMLOCO_GEMM_B_BF16MEM = 128, EMLOCO_GEMM_C_BF16MEM = 256, EMLOCO_GEMM_MASK_BF16MEM = 512,
+       /* fp32 results on the bf16 matrix rate ("split" mode): every fp32 operand is the exact sum of three bf16 pieces, and the six
+        * largest piece products (six v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulation) stand where eight
+        * v_mfma_f32_32x32x2_f32 stood -- 2.7x less matrix-pipe time (gfx950's fp32 MFMA runs at 1/16 of the bf16 rate, no xf32).
+        * Error against float64 is fp32's own class (measured 1e-7 .. 2e-6 of sum |a b|, the same as the fp32 instruction's);
+        * results are NOT bit-equal to the fmaf chain of the plain mode.  Served for 16-byte-aligned fp32 operands and n > 32 (others
+        * silently take the plain fp32 path); ignored together with EMLOCO_GEMM_BF16. */
+       EMLOCO_GEMM_SPLIT = 1024 };
 
 /* Batched strided GEMM on the matrix cores, fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: exact fp32):
  *   C[b][m][n] (+)= alpha * sum_k A_b(m,k) * B_b(n,k)   [+ bias[n]] [relu]

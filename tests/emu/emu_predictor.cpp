@@ -20,7 +20,9 @@ extern "C" int emu_gemm_f32(int batch, int m, int n, int k, float alpha, const f
                 emu::launch(1, 256, [&] {
                     blockIdx.x = x; blockIdx.y = y; blockIdx.z = z;
                     const bool deep = (k + ksplit - 1) / ksplit > 256;     // as emloco_gemm_f32 picks the stage depth
-                    gemm_pick(g, deep)(g);
+                    GemmArgs gl = g;
+                    if (!((flags & 1024) && !(flags & 16) && g.vec_a && g.vec_b && n > 32)) gl.flags &= ~1024;   // as emloco_gemm_f32_ex serves the split mode
+                    gemm_pick(gl, deep)(gl);
                 });
             }
     blockIdx.y = 0; blockIdx.z = 0;
@@ -32,9 +34,15 @@ extern "C" int emu_gemm_f32(int batch, int m, int n, int k, float alpha, const f
 }
 
 // emloco_gemm_relu_bwd without the final fold: C = (A . B) o [y > 0] * scale, colpart [2 ceil(m / 128)][n] = 64-row column sums
+extern "C" int emu_gemm_relu_bwd_ex(int m, int n, int k, const float *A, int lda, const float *B, int ldb, int tb, float *C, const float *y,
+                                    float scale, float *colpart, int flags);
 extern "C" int emu_gemm_relu_bwd(int m, int n, int k, const float *A, int lda, const float *B, int ldb, int tb, float *C, const float *y,
                                  float scale, float *colpart) {
-    GemmArgs g{1, m, n, k, 1.0f, A, lda, 0, 0, B, ldb, 0, tb, C, n, 0, nullptr, 32, 1, nullptr, 0, 0, 0.0f, 0u, y, scale, colpart};
+    return emu_gemm_relu_bwd_ex(m, n, k, A, lda, B, ldb, tb, C, y, scale, colpart, 0);
+}
+extern "C" int emu_gemm_relu_bwd_ex(int m, int n, int k, const float *A, int lda, const float *B, int ldb, int tb, float *C, const float *y,
+                                    float scale, float *colpart, int flags) {
+    GemmArgs g{1, m, n, k, 1.0f, A, lda, 0, 0, B, ldb, 0, tb, C, n, 0, nullptr, 32 | flags, 1, nullptr, 0, 0, 0.0f, 0u, y, scale, colpart};
     g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
     g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
     const unsigned gx = (n + 127) / 128, gy = (m + 127) / 128;

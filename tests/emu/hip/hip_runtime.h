@@ -134,6 +134,13 @@ static inline emu_f32x16 gemm_mfma_bf16(gemm_bf16x8 a, gemm_bf16x8 b, emu_f32x16
     emu::wave_barrier();
     return d;
 }
+struct alignas(16) bf16w4 { unsigned x, y, z, w; };
+static inline unsigned gemm_pack2_bf16(float a, float b) { return (unsigned)emu_f32_to_bf16(a) | ((unsigned)emu_f32_to_bf16(b) << 16); }
+static inline emu_f32x16 gemm_mfma_bf16_w(const bf16w4 &a, const bf16w4 &b, emu_f32x16 c) {
+    gemm_bf16x8 pa, pb;
+    std::memcpy(pa.v, &a, 16); std::memcpy(pb.v, &b, 16);
+    return gemm_mfma_bf16(pa, pb, c);
+}
 using std::exp; using std::cos; using std::sin; using std::atan2;
 
 // DPP lane permutations (the gfx9 dpp_ctrl codes the kernels use) and v_readlane

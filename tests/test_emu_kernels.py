@@ -314,6 +314,51 @@ def test_gemm_epilogue_fuses_relu_dropout_backward_and_bias_gradient():
         np.testing.assert_allclose(part, sums, rtol=1e-5, atol=2e-4)
 
 
+def test_mfma_gemm_kernel_split_mode_is_fp32_class():
+    """EMLOCO_GEMM_SPLIT: fp32 operands as three bf16 pieces each, six piece products on v_mfma_f32_32x32x16_bf16.  The emulated
+    kernel (same source, same LDS image, same thread maps) against float64: all four layouts with ragged rows / columns / k, split
+    k, bias + ReLU, a long reduction, values over a wide range of magnitudes -- inside the plain fp32 kernel's own tolerance, and
+    the pieces must rebuild every operand exactly (a wrong slot, plane or k pairing shows as an error of 2^-8, not 2^-24)."""
+    rng = np.random.default_rng(21)
+    SPLIT = 1024
+    for m, n, k in ((148, 136, 44), (72, 260, 520), (256, 128, 16)):
+        A = (rng.normal(size=(1, m, k)) * np.exp(rng.uniform(-3, 3, size=(1, m, k)))).astype(np.float32)
+        B = (rng.normal(size=(1, n, k)) * np.exp(rng.uniform(-3, 3, size=(1, n, k)))).astype(np.float32)
+        ref = A[0].astype(np.float64) @ B[0].astype(np.float64).T
+        mag = np.abs(A[0]).astype(np.float64) @ np.abs(B[0]).astype(np.float64).T
+        At, Bt = np.ascontiguousarray(A.transpose(0, 2, 1)), np.ascontiguousarray(B.transpose(0, 2, 1))
+        plain_err = np.max(np.abs(_gemm(A, B, 0, 0, m, n, k)[0] - ref) / mag)
+        for (a, b, ta, tb) in ((A, B, 0, 0), (At, Bt, 1, 1), (A, Bt, 0, 1), (At, B, 1, 0)):
+            got = _gemm(a, b, ta, tb, m, n, k, flags=SPLIT)[0]
+            err = np.max(np.abs(got - ref) / mag)
+            assert err < 4 * plain_err + 2e-7, (m, n, k, ta, tb, err, plain_err)     # (a misplaced piece would show as 2^-8 = 4e-3)
+        got = _gemm(A, Bt, 0, 1, m, n, k, flags=SPLIT, ksplit=2)[0]
+        assert np.max(np.abs(got - ref) / mag) < 4 * plain_err + 2e-7
+        bias = rng.normal(size=n).astype(np.float32)
+        got = _gemm(A, B, 0, 0, m, n, k, bias=bias, flags=SPLIT | 3, alpha=0.5)[0]
+        np.testing.assert_allclose(got, np.maximum(0.5 * ref + bias, 0), rtol=0, atol=2e-6 * float(mag.max()))
+    # operands the split mode does not serve (unaligned, narrow n) fall back to the plain kernel: bit-equal to it
+    A = rng.normal(size=(1, 70, 37)).astype(np.float32)
+    B = rng.normal(size=(1, 50, 37)).astype(np.float32)
+    assert np.array_equal(_gemm(A, B, 0, 0, 70, 50, 37, flags=SPLIT), _gemm(A, B, 0, 0, 70, 50, 37))
+    # the fused backward epilogue in split mode: mask, scale and the bias-gradient partials of what was written
+    lib = emu.lib()
+    for m, n, k, tb in ((150, 72, 36, 1), (200, 136, 44, 0)):
+        A = rng.normal(size=(m, k)).astype(np.float32)
+        B = rng.normal(size=(k, n) if tb else (n, k)).astype(np.float32)
+        y = np.maximum(rng.normal(size=(m, n)), 0).astype(np.float32)
+        scale = np.float32(1 / 0.9)
+        Cm = np.full((m, n), 7.0, np.float32)
+        nparts = 2 * ((m + 127) // 128)
+        part = np.zeros((nparts, n), np.float32)
+        lib.emu_gemm_relu_bwd_ex(m, n, k, P(A), k, P(B), n if tb else k, tb, P(Cm), P(y), C.c_float(scale), P(part), SPLIT)
+        plain = _gemm(A[None], B[None], 0, tb, m, n, k, flags=SPLIT)[0]
+        want = np.where(y > 0, plain * scale, np.float32(0)).astype(np.float32)
+        assert np.array_equal(Cm, want)
+        sums = np.stack([want[r:r + 64].astype(np.float64).sum(0) for r in range(0, 64 * nparts, 64)])
+        np.testing.assert_allclose(part, sums, rtol=1e-5, atol=2e-4)
+
+
 def test_mfma_gemm_kernel_bf16_operands():
     """EMLOCO_GEMM_BF16 (opt-in): operands rounded to bf16 on their way into the matrix cores, fp32 accumulation.  Against
     the product of the bf16-ROUNDED operands the kernel is exact to fp32 accumulation error; against the fp32 product the
