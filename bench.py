@@ -596,6 +596,7 @@ def main():
         blind_policy.reads_obs = False
         # the same agent (HIP serves a process with four hardware queues: a second agent's side stream would share one)
         agent.policy = blind_policy
+        fused_chain, task.fused_chain = task.fused_chain, False
         task.overlap_reset = True
         task.overlap_obs = os.environ.get("EMLOCO_OVERLAP_OBS", "0") == "1"    # see LocoValRollout.__init__: nothing to hide behind here
         b_t, b_n, b_ms = timed_loop(agent)
@@ -611,6 +612,7 @@ def main():
         b_env = time.perf_counter() - t1
         task.wait_reset()
         task.overlap_reset = False
+        task.fused_chain = fused_chain
         task.sim.native.set_cost_order(True)
         blind = {"value": round(E * a.steps / b_t, 1), "unit": "env-steps/s", "ms_per_step": round(b_t / a.steps * 1e3, 4),
                  "kernel_ms": round(b_ms / max(b_n, 1), 4), "launches_timed": b_n,

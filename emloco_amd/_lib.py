@@ -142,7 +142,7 @@ SYMBOLS_SIM = [
 SYMBOLS_TASK = [
     "emloco_task_post_physics", "emloco_task_amp_rows", "emloco_task_pd_targets", "emloco_task_last_ms",
     "emloco_task_enable_timing", "emloco_task_reset", "emloco_task_reset_seeded", "emloco_task_compact_done", "emloco_task_compact_done_snapshot", "emloco_task_reset_amp_history",
-    "emloco_task_traj_reset", "emloco_task_get_heights",
+    "emloco_task_traj_reset", "emloco_task_get_heights", "emloco_task_pd_targets_copy", "emloco_task_compact_done_order", "emloco_task_reset_obs",
 ]
 
 _lib = None
@@ -199,6 +199,10 @@ def load():
     lib.emloco_task_compact_done.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.emloco_task_compact_done_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emloco_task_reset_amp_history.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.emloco_task_pd_targets_copy.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_void_p, C.c_void_p]
+    lib.emloco_task_compact_done_order.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emloco_task_reset_obs.argtypes = [C.c_void_p, C.POINTER(ResetBufs), C.POINTER(TaskBufs), C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 

@@ -1009,6 +1009,11 @@ locoval_returns_kernel(EmlocoLocoValStep t, const float *rewards, const float *a
     for (int k = lane; k < 72; k += 64) t.pose[(long)e * 72 + k] = ip[k] - ip[k % 3];
     if (lane < 2) t.vel[(long)e * 2 + lane] = t.init_vel[(long)e * 2 + lane];
     if (lane == 0) {
+        // the bookkeeping follows the reference's torch expressions operation by operation (fixture locoval_returns.npz is matched
+        // bit for bit): no multiply-add contraction here, whatever the translation unit's default is
+#ifndef EMLOCO_EMU
+#pragma clang fp contract(off)
+#endif
         float r = rewards[e];
         if (inverted && inverted[e]) r = r * (-t.inversion_penalty);
         const float a = amp_rewards ? amp_rewards[e] : 0.0f;

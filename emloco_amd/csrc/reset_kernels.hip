@@ -46,29 +46,34 @@ __device__ __forceinline__ unsigned fmix32(unsigned x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
+__device__ __forceinline__ float reset_rnd_value(unsigned seed_lo, unsigned seed_hi, int bi, int k) {     // entry k of list entry bi's row
+    const unsigned row = fmix32(seed_lo ^ ((unsigned)bi * 0x9E3779B1u)) + seed_hi;
+    const unsigned x = fmix32(fmix32(row ^ ((unsigned)k * 0x27D4EB2Fu)) + 0x165667B1u);
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ void reset_fill_row(unsigned seed_lo, unsigned seed_hi, int bi, float *rnd, int lane, int nlanes) {
+    for (int k = lane; k < EMLOCO_RESET_RND; k += nlanes) rnd[(long)bi * EMLOCO_RESET_RND + k] = reset_rnd_value(seed_lo, seed_hi, bi, k);
+}
 __global__ void reset_fill_rnd_kernel(const int32_t *ids, int n, unsigned seed_lo, unsigned seed_hi, float *rnd) {
     for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
         if (ids[bi] < 0) break;
-        const unsigned row = fmix32(seed_lo ^ ((unsigned)bi * 0x9E3779B1u)) + seed_hi;
-        for (int k = threadIdx.x; k < EMLOCO_RESET_RND; k += blockDim.x) {
-            const unsigned x = fmix32(fmix32(row ^ ((unsigned)k * 0x27D4EB2Fu)) + 0x165667B1u);
-            rnd[(long)bi * EMLOCO_RESET_RND + k] = (float)(x >> 8) * (1.0f / 16777216.0f);
-        }
+        reset_fill_row(seed_lo, seed_hi, bi, rnd, threadIdx.x, blockDim.x);
     }
 }
 
-__global__ void __launch_bounds__(64)
-reset_sample_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n, const float *rnd) {
-    // grid-stride over the id list: a device-compacted list (emloco_task_compact_done) holds its valid entries first and
-    // -1 after them, so a small grid stops at the first padding entry instead of launching one workgroup per env
-    const int lane = threadIdx.x;
-    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
-    const int env = ids[bi];
-    if (env < 0) break;
-    const float *u = rnd + (long)bi * EMLOCO_RESET_RND;
-    int mid = (int)(u[EMLOCO_RND_MOTION] * (float)t.n_motions);
+// the motion clip and start time a reset draws from its random row (one definition: the sample and the AMP history back-fill of
+// a fused launch each evaluate it)
+__device__ __forceinline__ void reset_pick_motion(const EmlocoResetBufs &t, float u_motion, float u_time, int *mid_out, float *time_out) {
+    int mid = (int)(u_motion * (float)t.n_motions);
     if (mid > t.n_motions - 1) mid = t.n_motions - 1;
-    const float time = u[EMLOCO_RND_TIME] * t.motion_len[mid];
+    *mid_out = mid;
+    *time_out = u_time * t.motion_len[mid];
+}
+
+// reset_sample of ONE list entry by one wave (u = its random row)
+__device__ __forceinline__ void reset_sample_env(const EmlocoResetBufs &t, const EmlocoSimDev &s, int env, const float *u, int lane) {
+    int mid; float time;
+    reset_pick_motion(t, u[EMLOCO_RND_MOTION], u[EMLOCO_RND_TIME], &mid, &time);
     const FrameBlend fb = frame_blend(t, mid, time);
     if (lane >= 1 && lane < RNB) {          // joint lane-1: local rotation -> rotation vector; dof velocity
         float q[4], e[3];
@@ -123,6 +128,17 @@ reset_sample_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
         t.motion_ids[env] = mid;
         t.motion_times[env] = time;
     }
+}
+
+__global__ void __launch_bounds__(64)
+reset_sample_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n, const float *rnd) {
+    // grid-stride over the id list: a device-compacted list (emloco_task_compact_done) holds its valid entries first and
+    // -1 after them, so a small grid stops at the first padding entry instead of launching one workgroup per env
+    const int lane = threadIdx.x;
+    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
+        const int env = ids[bi];
+        if (env < 0) break;
+        reset_sample_env(t, s, env, rnd + (long)bi * EMLOCO_RESET_RND, lane);
         __syncthreads();                              // LDS is reused by the next list entry
     }
 }
@@ -263,13 +279,8 @@ __device__ __forceinline__ void reset_trajectory(const EmlocoResetBufs &t, const
     }
 }
 
-__global__ void __launch_bounds__(64)
-reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n, const float *rnd) {
-    const int lane = threadIdx.x;
-    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
-    const int env = ids[bi];
-    if (env < 0) break;
-    const float *u = rnd + (long)bi * EMLOCO_RESET_RND;
+// reset_finish of ONE list entry by one wave
+__device__ __forceinline__ void reset_finish_env(const EmlocoResetBufs &t, const EmlocoSimDev &s, int bi, int env, const float *u, int lane) {
     __shared__ float sh_v[RNV][3];
 
     // ---- a. lowest collision point -> vertical shift (replaces the SMPL-mesh height fix, humanoid_amp.py:321-379)
@@ -324,7 +335,15 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
     if (lane < RNB)
         for (int k = 0; k < 3; ++k) t.init_pose[((long)env * RNB + lane) * 3 + k] = s.rb_state[((long)env * RNB + lane) * 13 + k];
     if (lane == 0) { t.init_vel[(long)env * 2] = rvx; t.init_vel[(long)env * 2 + 1] = rvy; }
+}
 
+__global__ void __launch_bounds__(64)
+reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n, const float *rnd) {
+    const int lane = threadIdx.x;
+    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
+        const int env = ids[bi];
+        if (env < 0) break;
+        reset_finish_env(t, s, bi, env, rnd + (long)bi * EMLOCO_RESET_RND, lane);
         __syncthreads();                              // LDS is reused by the next list entry
     }
 }
@@ -348,16 +367,8 @@ traj_reset_kernel(EmlocoResetBufs t, const int32_t *ids, int n, const float *rnd
 
 // ---- e. AMP history rows 1..14 from the motion library at t - k dt (humanoid_amp.py:486-535): one workgroup per
 // (finished env, history row) -- the rows are independent, a single wave walking all 14 was the longest serial path of a reset.
-__global__ void __launch_bounds__(64)
-reset_amp_history_kernel(EmlocoResetBufs t, const int32_t *ids, int n) {
-    const int lane = threadIdx.x;
-    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
-    const int env = ids[bi];
-    if (env < 0) break;
-    const int k = 1 + (int)blockIdx.y;
+__device__ __forceinline__ void reset_amp_history_row(const EmlocoResetBufs &t, int env, int k, int mid, float mt, int lane) {
     __shared__ float sh_root[13], sh_dp[RNDOF], sh_dv[RNDOF], sh_key[12];
-    const int mid = (int)t.motion_ids[env];
-    const float mt = t.motion_times[env];
     const FrameBlend fb = frame_blend(t, mid, mt - t.dt * (float)k);
     if (lane >= 1 && lane < RNB) {
         float q[4], e[3];
@@ -384,6 +395,15 @@ reset_amp_history_kernel(EmlocoResetBufs t, const int32_t *ids, int n) {
     __syncthreads();
     amp_row(lane, sh_root, sh_root + 3, sh_root + 7, sh_root + 10, sh_dp, sh_dv, 1, sh_key, t.betas + (long)env * 17,
             t.dof_subset, t.n_dof_subset, t.amp_obs_buf + ((long)env * EMLOCO_AMP_STEPS + k) * EMLOCO_AMP_ROW);
+}
+
+__global__ void __launch_bounds__(64)
+reset_amp_history_kernel(EmlocoResetBufs t, const int32_t *ids, int n) {
+    const int lane = threadIdx.x;
+    for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
+        const int env = ids[bi];
+        if (env < 0) break;
+        reset_amp_history_row(t, env, 1 + (int)blockIdx.y, (int)t.motion_ids[env], t.motion_times[env], lane);
         __syncthreads();                              // LDS is reused by the next list entry
     }
 }

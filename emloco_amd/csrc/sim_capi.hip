@@ -257,6 +257,7 @@ int emloco_sim_set_dof_actuation_force(EmlocoSim *s, const float *dev_forces, vo
 // the dispatch order of the full launch: sorted on the caller's stream right ahead of it (a stream of the simulator's own
 // for the sort was measured and lost: with torch's pool streams it ended up sharing a hardware queue with the caller's)
 static int launch_order(EmlocoSim *s, hipStream_t st) {
+    if (s->order_ready) { s->order_ready = false; return EMLOCO_OK; }       // sorted earlier in the chain, behind the previous step
     hipLaunchKernelGGL(emloco::sim_order_kernel, dim3(1), dim3(1024), 0, st, s->d_ticks.p, s->n_env, s->d_order.p, s->d_order_ws.p);
     HIPCHK(hipGetLastError());
     return EMLOCO_OK;

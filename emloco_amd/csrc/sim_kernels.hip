@@ -31,6 +31,8 @@
 #define rotvec2quat frotvec2quat
 #define quat2rotvec fquat2rotvec
 #include "emloco_types.h"
+#include "fk_device.h"
+#include "order_device.h"
 
 namespace emloco {
 
@@ -1347,93 +1349,22 @@ sim_step_kernel(EmlocoSimParams prm, EmlocoSimDev d) {
 // resident rounds of waves (4096 envs on 256 CUs x 8), so its length is set by what the LAST workgroups cost: with the
 // expensive envs (many contacts) first and the cheap ones (airborne) last, the slots that free up late receive short work.
 // The order within a bucket is whatever the LDS atomics give -- envs are independent, results do not depend on it.
-#define EMLOCO_ORDER_BUCKETS 128
-#define EMLOCO_ORDER_LDS_ENVS 16384
 __global__ void __launch_bounds__(1024)
 sim_order_kernel(const unsigned *ticks, int n, int *order, unsigned char *bucket_ws) {
-    __shared__ int sh_cnt[EMLOCO_ORDER_BUCKETS];
-    // every key is read ONCE (a launch that still writes keys beside this one cannot make the two passes disagree) and its
-    // bucket kept in LDS -- in the global workspace `bucket_ws` [n] beyond EMLOCO_ORDER_LDS_ENVS envs
-    __shared__ unsigned char sh_b[EMLOCO_ORDER_LDS_ENVS];
-    unsigned char *bk = n <= EMLOCO_ORDER_LDS_ENVS ? sh_b : bucket_ws;
-    const int tid = threadIdx.x;
-    if (tid < EMLOCO_ORDER_BUCKETS) sh_cnt[tid] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        unsigned b = ticks[i];
-        b = b > EMLOCO_ORDER_BUCKETS - 1 ? EMLOCO_ORDER_BUCKETS - 1 : b;
-        bk[i] = (unsigned char)b;
-        atomicAdd(&sh_cnt[b], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {                                               // descending: start offset of bucket b = envs in buckets above it
-        int run = 0;
-        for (int b = EMLOCO_ORDER_BUCKETS - 1; b >= 0; --b) { const int c = sh_cnt[b]; sh_cnt[b] = run; run += c; }
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) order[atomicAdd(&sh_cnt[bk[i]], 1)] = i;      // a thread re-reads only what it wrote itself
+    order_sort(ticks, n, order, bucket_ws);             // order_device.h
 }
 
 // Forward kinematics only (used after state writes through the *_indexed setters): fills rb_state of
-// the listed envs from root_state / dof_state.  One wave per env; lanes walk the tree level by level.
+// the listed envs from root_state / dof_state.  One wave per env; lanes walk the tree level by level (fk_device.h).
 __global__ void __launch_bounds__(64)
 sim_fk_kernel(EmlocoSimDev d, const int *env_ids, int n_ids) {
     const int lane = threadIdx.x;
     // grid-stride over the id list (one pass when the grid covers it); a device-compacted list ends at its first -1
     for (int bi = blockIdx.x; bi < n_ids; bi += gridDim.x) {
-    const int env = env_ids ? env_ids[bi] : bi;
-    if (env < 0) break;
-    __shared__ float sh_pw[NB][3], sh_qw[NB][4], sh_R[NB][9], sh_V[NB][6];
-    const int b = (lane < NB) ? lane : 0;
-    const int parent = d.topo[EMLOCO_TOPO_PARENT + b], depth = d.topo[EMLOCO_TOPO_DEPTH + b];
-    float off[3], qj[4] = {0, 0, 0, 1}, wj[3] = {0, 0, 0}, V[6] = {0, 0, 0, 0, 0, 0}, r[3] = {0, 0, 0};
-    for (int k = 0; k < 3; ++k) off[k] = d.model[(size_t)env * EMLOCO_MODEL_WORDS + EMLOCO_MB_DYN + b * 16 + k];
-    if ((lane < NB) && lane >= 1) {
-        const float *ds = d.dof_state + ((long)env * NDOF + (lane - 1) * 3) * 2;
-        float e[3] = {ds[0], ds[2], ds[4]};
-        rotvec2quat(e, qj);
-        wj[0] = ds[1]; wj[1] = ds[3]; wj[2] = ds[5];
-    }
-    const float *rs = d.root_state + (long)env * 13;
-    const float p0[3] = {rs[0], rs[1], rs[2]};
-    if (lane == 0) {
-        float q0[4] = {rs[3], rs[4], rs[5], rs[6]}, R[9];
-        qnormalize(q0);
-        q2mat(q0, R);
-        for (int k = 0; k < 3; ++k) { sh_pw[0][k] = p0[k]; V[k] = rs[10 + k]; V[3 + k] = rs[7 + k]; }
-        for (int k = 0; k < 4; ++k) sh_qw[0][k] = q0[k];
-        for (int k = 0; k < 9; ++k) sh_R[0][k] = R[k];
-        for (int k = 0; k < 6; ++k) sh_V[0][k] = V[k];
-    }
-    __syncthreads();
-    for (int lev = 1; lev <= d.max_depth; ++lev) {
-        if ((lane < NB) && depth == lev) {
-            float Rp[9], o[3], qp[4], qw[4], pw[3], R[9];
-            for (int k = 0; k < 9; ++k) Rp[k] = sh_R[parent][k];
-            for (int k = 0; k < 4; ++k) qp[k] = sh_qw[parent][k];
-            matvec3(Rp, off, o);
-            for (int k = 0; k < 3; ++k) { pw[k] = sh_pw[parent][k] + o[k]; r[k] = pw[k] - p0[k]; }
-            qmul(qp, qj, qw); qnormalize(qw); q2mat(qw, R);
-            float Sl[3][3];
-            for (int c = 0; c < 3; ++c) { float ax[3] = {R[c], R[3 + c], R[6 + c]}; cross3(r, ax, Sl[c]); }
-            for (int k = 0; k < 3; ++k) {
-                V[k] = sh_V[parent][k] + SOP3(R[k * 3], wj[0], R[k * 3 + 1], wj[1], R[k * 3 + 2], wj[2]);
-                V[3 + k] = sh_V[parent][3 + k] + SOP3(Sl[0][k], wj[0], Sl[1][k], wj[1], Sl[2][k], wj[2]);
-            }
-            for (int k = 0; k < 3; ++k) sh_pw[lane][k] = pw[k];
-            for (int k = 0; k < 4; ++k) sh_qw[lane][k] = qw[k];
-            for (int k = 0; k < 9; ++k) sh_R[lane][k] = R[k];
-            for (int k = 0; k < 6; ++k) sh_V[lane][k] = V[k];
-        }
-        __syncthreads();
-    }
-    if ((lane < NB)) {
-        float *o = d.rb_state + ((long)env * NB + lane) * 13, t[3];
-        cross3(V, r, t);
-        for (int k = 0; k < 3; ++k) { o[k] = sh_pw[lane][k]; o[7 + k] = V[3 + k] + t[k]; o[10 + k] = V[k]; }
-        for (int k = 0; k < 4; ++k) o[3 + k] = sh_qw[lane][k];
-    }
-        __syncthreads();
+        const int env = env_ids ? env_ids[bi] : bi;
+        if (env < 0) break;
+        fk_env(d, env, lane);
+        __syncthreads();                              // LDS is reused by the next list entry
     }
 }
 

@@ -48,6 +48,7 @@ struct EmlocoSim {
     int part_spin_max = 1 << 22, part_poison = -1;
     int lds_pad = 0;                           // diagnostic (EMLOCO_SIM_LDS_PAD): extra dynamic LDS per workgroup of the step launch, caps the residency
     bool cost_order = false;
+    bool order_ready = false;                   // d_order already holds the next full launch's order (emloco_task_compact_done_order sorted it)
     DevBuf<unsigned> d_ticks;
     DevBuf<int> d_order;
     DevBuf<unsigned char> d_order_ws;           // bucket of every env, beyond the 16384 envs the sort keeps in LDS

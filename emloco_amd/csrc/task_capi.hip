@@ -4,6 +4,7 @@
 #include <string>
 #include "task_kernels.hip"
 #include "reset_kernels.hip"
+#include "chain_kernels.hip"
 #include "sim_state.h"
 
 extern "C" int emloco_sim_fk_indexed(EmlocoSim *s, const int32_t *ids, int n, void *stream);
@@ -13,6 +14,7 @@ hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 bool g_timing = false, g_pending = false;
 float g_last_ms = -1.0f;
 thread_local std::string g_terr;
+long long *g_chain_prof = nullptr;
 int tfail(int code, const char *what, hipError_t e = hipSuccess) {
     char buf[512];
     if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
@@ -181,12 +183,82 @@ int emloco_task_compact_done(const int64_t *dev_flags, int n, int32_t *dev_ids, 
     return emloco_task_compact_done_snapshot(dev_flags, n, dev_ids, nullptr, stream);
 }
 
-int emloco_task_pd_targets(int n_env, const float *actions, const float *offset, const float *scale,
-                           const uint8_t *zero_mask, float *pd_targets, void *stream) {
+int emloco_task_pd_targets_copy(int n_env, const float *actions, const float *offset, const float *scale,
+                                const uint8_t *zero_mask, float *pd_targets, float *actions_copy, void *stream) {
     if (n_env < 1 || !actions || !offset || !scale || !zero_mask || !pd_targets) return tfail(-1, "emloco_task_pd_targets: bad argument");
+    if (actions_copy == actions) actions_copy = nullptr;
     const int total = n_env * 69;
     hipLaunchKernelGGL(emloco::pd_targets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       total, actions, offset, scale, zero_mask, pd_targets);
+                       total, actions, offset, scale, zero_mask, pd_targets, actions_copy);
+    THIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_task_pd_targets(int n_env, const float *actions, const float *offset, const float *scale,
+                           const uint8_t *zero_mask, float *pd_targets, void *stream) {
+    return emloco_task_pd_targets_copy(n_env, actions, offset, scale, zero_mask, pd_targets, nullptr, stream);
+}
+
+int emloco_task_compact_done_order(EmlocoSim *sim, const int64_t *dev_flags, int n, int32_t *dev_ids, int64_t *dev_snapshot, void *stream) {
+    if (!dev_flags || !dev_ids || n < 1) return tfail(-1, "emloco_task_compact_done_order: bad argument (ids holds n + 1 entries)");
+    const bool sort = sim && sim->prepared && sim->cost_order && sim->d_ticks.p && sim->d_order.p;
+    hipLaunchKernelGGL(emloco::compact_order_kernel, dim3(sort ? 2 : 1), dim3(1024), 0, (hipStream_t)stream, dev_flags, n, dev_ids, dev_snapshot,
+                       sort ? sim->d_ticks.p : nullptr, sort ? sim->n_env : 0, sort ? sim->d_order.p : nullptr, sort ? sim->d_order_ws.p : nullptr);
+    THIPCHK(hipGetLastError());
+    if (sort) sim->order_ready = true;
+    return 0;
+}
+
+// internal diagnostic (not in the header): the first call allocates 16 wall-clock stamps (100 MHz) that every later
+// emloco_task_reset_obs launch overwrites -- [0..5] reset slot 0: start, random row, sample, kinematics, finish, observations;
+// [6, 7] last AMP history row of entry 0; [8, 9] / [10, 11] the observation workgroups of env 0 / the last env -- and copies them out
+int emloco_task_chain_profile(long long *host16) {
+    if (!g_chain_prof) { THIPCHK(hipMalloc((void **)&g_chain_prof, 16 * sizeof(long long))); THIPCHK(hipMemset(g_chain_prof, 0, 16 * sizeof(long long))); }
+    THIPCHK(hipDeviceSynchronize());
+    if (host16) THIPCHK(hipMemcpy(host16, g_chain_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int emloco_task_reset_obs(EmlocoSim *sim, const EmlocoResetBufs *rb, const EmlocoTaskBufs *pb, int live_mode, const int64_t *dev_skip,
+                          const int32_t *dev_env_ids, int n, uint64_t seed, float *dev_rnd_ws, const float *dev_rnd, void *stream) {
+    if (!sim || !rb || !pb || !dev_env_ids) return tfail(-1, "emloco_task_reset_obs: null argument");
+    if (!sim->prepared) return tfail(-3, "emloco_task_reset_obs: sim not prepared");
+    if (n < 0 || n > sim->n_env) return tfail(-1, "emloco_task_reset_obs: bad env count");
+    if (!dev_rnd && !dev_rnd_ws) return tfail(-1, "emloco_task_reset_obs: neither random rows nor a workspace for them");
+    if (live_mode && !dev_skip) return tfail(-1, "emloco_task_reset_obs: the live envs' role needs the flag snapshot");
+    if (live_mode & ~(EMLOCO_POST_OBS | EMLOCO_POST_AMP_SHIFT | EMLOCO_POST_AMP_ROW | EMLOCO_POST_SKIP_DONE))
+        return tfail(-1, "emloco_task_reset_obs: the live envs' role builds observations / AMP rows only (progress, reward and flags belong to the flags launch)");
+    if (pb->n_env != sim->n_env) return tfail(-1, "emloco_task_reset_obs: task buffers and simulator disagree on the env count");
+    const EmlocoResetBufs *b = rb;
+    if (!b->gts || !b->grs || !b->lrs || !b->gvs || !b->gavs || !b->dvs || !b->motion_len || !b->motion_dt || !b->motion_nframes ||
+        !b->motion_start || b->n_motions < 1 || !b->heightfield || !b->betas || !b->key_bodies || !b->dof_subset || !b->traj_verts ||
+        !b->inverted || !b->progress_buf || !b->reset_buf || !b->terminate_buf || !b->waypoint_traj || !b->init_pose || !b->init_vel ||
+        !b->amp_obs_buf || !b->motion_ids || !b->motion_times || !b->ground_h)
+        return tfail(-1, "emloco_task_reset_obs: missing reset buffers");
+    if (!(b->flags & EMLOCO_RESET_FIXED_LOCATION) && (!b->valid_x || !b->valid_y || b->n_valid < 1))
+        return tfail(-1, "emloco_task_reset_obs: no valid locations");
+    if ((b->flags & EMLOCO_RESET_REAL_PATH) && b->n_real > 0 && !b->real_traj) return tfail(-1, "emloco_task_reset_obs: real_path without data");
+    if (!pb->rb_state || !pb->progress_buf || !pb->traj_verts || !pb->obs_buf || !pb->flip_obs_buf || !pb->heightfield || !pb->betas ||
+        !pb->left_to_right || !pb->amp_obs_buf || !pb->dof_subset || !pb->key_bodies || !pb->dof_state || pb->n_dof_subset > 64 || pb->n_dof_subset % 3)
+        return tfail(-1, "emloco_task_reset_obs: missing observation buffers");
+    emloco::ChainArgs a;
+    a.n = n;
+    a.n_slots = n < 256 ? (n > 0 ? n : 1) : 256;
+    a.n_hist = (b->flags & EMLOCO_RESET_NO_AMP_HISTORY) ? 0 : EMLOCO_AMP_STEPS - 1;
+    a.live_mode = live_mode & ~EMLOCO_POST_SKIP_DONE;
+    a.reset_mode = EMLOCO_POST_OBS | EMLOCO_POST_AMP_ROW;
+    a.seeded = dev_rnd ? 0 : 1;
+    a.seed_lo = (unsigned)(seed & 0xffffffffu); a.seed_hi = (unsigned)(seed >> 32);
+    a.ids = dev_env_ids; a.skip = dev_skip; a.rnd_in = dev_rnd; a.rnd_ws = dev_rnd_ws;
+    a.prof = g_chain_prof;
+    EmlocoResetBufs keyed = *rb;
+    if (a.seeded) {                              // a fresh real-path permutation per call, as emloco_task_reset_seeded
+        keyed.real_pick = nullptr;
+        keyed.real_pick_key = (uint32_t)((seed * 0xD6E8FEB86659FD93ull) >> 32);
+    }
+    const unsigned grid = (unsigned)(a.n_slots * (1 + a.n_hist) + (a.live_mode ? pb->n_env : 0));
+    if (n == 0 && !a.live_mode) return 0;
+    hipLaunchKernelGGL(emloco::reset_obs_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *pb, keyed, sim->dev, a);
     THIPCHK(hipGetLastError());
     return 0;
 }

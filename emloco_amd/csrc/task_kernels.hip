@@ -142,14 +142,9 @@ __device__ __forceinline__ void amp_row(int lane, const float *root_pos, const f
     if (lane < 11) out[12 + nj * 6 + n_sub + 12 + lane] = betas[lane];
 }
 
-__global__ void __launch_bounds__(64)
-post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_ids) {
-    const int lane = threadIdx.x;
-    if ((int)blockIdx.x >= n_ids) return;
-    const int env = env_ids ? env_ids[blockIdx.x] : (int)blockIdx.x;
-    if (env < 0) return;                     // padding entry of a device-compacted id list
-    if ((mode & EMLOCO_POST_SKIP_DONE) && t.reset_buf[env] != 0) return;      // block-uniform
-
+// The post-physics work of ONE env by one wave (every early return is wave-uniform): post_physics_kernel below and the
+// observation roles of reset_obs_kernel (chain_kernels.hip) run this body.
+__device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mode, int env, int lane) {
     __shared__ float sh_body[TNB][13];
     __shared__ float sh_samp[EMLOCO_TRAJ_SAMPLES][3];
     __shared__ float sh_center[9];
@@ -301,6 +296,16 @@ post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_id
 }
 
 __global__ void __launch_bounds__(64)
+post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_ids) {
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= n_ids) return;
+    const int env = env_ids ? env_ids[blockIdx.x] : (int)blockIdx.x;
+    if (env < 0) return;                     // padding entry of a device-compacted id list
+    if ((mode & EMLOCO_POST_SKIP_DONE) && t.reset_buf[env] != 0) return;      // block-uniform
+    post_physics_env(t, mode, env, lane);
+}
+
+__global__ void __launch_bounds__(64)
 amp_rows_kernel(int n, const float *root_pos, const float *root_rot, const float *root_vel, const float *root_ang,
                 const float *dof_pos, const float *dof_vel, const float *key_pos, const float *betas,
                 const int32_t *subset, int n_sub, float *out) {
@@ -312,19 +317,21 @@ amp_rows_kernel(int n, const float *root_pos, const float *root_rot, const float
 }
 
 // pre_physics_step: pd_tar = offset + scale * a, zero where masked (humanoid.py:1184-1202,1281-1283)
+// actions_copy (optional): the task's own copy of the actions (the reference clones them, humanoid.py:1185) written by the same launch
 __global__ void pd_targets_kernel(int total, const float *actions, const float *offset, const float *scale,
-                                  const uint8_t *zero_mask, float *out) {
+                                  const uint8_t *zero_mask, float *out, float *actions_copy) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int dd = i % TNDOF;
-    out[i] = zero_mask[dd] ? 0.0f : offset[dd] + scale[dd] * actions[i];
+    const float a = actions[i];
+    if (actions_copy) actions_copy[i] = a;
+    out[i] = zero_mask[dd] ? 0.0f : offset[dd] + scale[dd] * a;
 }
 
 // Device-side replacement of `reset_buf.nonzero()` (amp_continuous_value.py:46,74 does it on the host, which stalls the
 // launch queue every step): ids[0..count) = ascending indices of the non-zero flags, ids[count..n) = -1, ids[n] = count.
 // One 1024-thread workgroup; ballot + popcount inside a wave, LDS prefix over the 16 waves, running base over chunks.
-__global__ void __launch_bounds__(1024)
-compact_flags_kernel(const int64_t *flags, int n, int32_t *ids, int64_t *snapshot) {
+__device__ __forceinline__ void compact_flags(const int64_t *flags, int n, int32_t *ids, int64_t *snapshot) {
     __shared__ int sh_wave[16];
     __shared__ int sh_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -350,6 +357,8 @@ compact_flags_kernel(const int64_t *flags, int n, int32_t *ids, int64_t *snapsho
     for (int i = count + tid; i < n; i += 1024) ids[i] = -1;
     if (tid == 0) ids[n] = count;
 }
+__global__ void __launch_bounds__(1024)
+compact_flags_kernel(const int64_t *flags, int n, int32_t *ids, int64_t *snapshot) { compact_flags(flags, n, ids, snapshot); }
 
 // get_heights / get_center_heights (humanoid_pedestrain_terrain.py:761-815, 732-759) for arbitrary poses, with the integer map
 // indices: pose7 [n][7] (pos3, quat4 xyzw); grid = 1: 32x32 grid rotated by the pose's heading -> out [n][1024];

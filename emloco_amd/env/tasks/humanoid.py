@@ -315,6 +315,7 @@ class Humanoid(BaseTask):
 
     # ------------------------------------------------------------------ reset (humanoid.py:439-481)
     def reset(self, env_ids=None):
+        self.wait_obs()             # a deferred observation pass (fused_chain) goes first: it must see the pre-reset flags and state
         if (env_ids is None):
             env_ids = to_torch(np.arange(self.num_envs), device=self.device, dtype=torch.long)
         self._reset_envs(env_ids)
@@ -363,15 +364,18 @@ class Humanoid(BaseTask):
         self.wait_obs()             # the observation launch of the last step reads what this step's rigid-body launch overwrites
         if getattr(self, "_actions_buf", None) is None or self._actions_buf.shape != actions.shape:
             self._actions_buf = torch.empty(actions.shape, dtype=torch.float32, device=self.device)
-        self._actions_buf.copy_(actions)
-        self.actions = self._actions_buf
         if not self._pd_control:                                  # humanoid.py:1203-1207: joint torques, effort drives
+            self._actions_buf.copy_(actions)
+            self.actions = self._actions_buf
             forces = self.actions * self.motor_efforts.unsqueeze(0) * self.power_scale
             self.gym.set_dof_actuation_force_tensor(self.sim, gymtorch.unwrap_tensor(forces.contiguous()))
             return
-        # pd_tar = offset + scale * a with hands / frozen toes zeroed, one launch (humanoid.py:1188-1202,1281-1283)
-        self._post.pd_targets(self.actions.contiguous(), self._pd_action_offset, self._pd_action_scale,
-                              self._pd_zero_mask, self._pd_targets)
+        # pd_tar = offset + scale * a with hands / frozen toes zeroed (humanoid.py:1188-1202,1281-1283) and the task's copy of the
+        # actions, one launch
+        src = actions if (actions.dtype == torch.float32 and actions.is_contiguous()) else actions.to(torch.float32).contiguous()
+        self._post.pd_targets(src, self._pd_action_offset, self._pd_action_scale, self._pd_zero_mask, self._pd_targets,
+                              actions_copy=self._actions_buf)
+        self.actions = self._actions_buf
         self.gym.set_dof_position_target_tensor(self.sim, gymtorch.unwrap_tensor(self._pd_targets))
         return
 
@@ -397,6 +401,14 @@ class Humanoid(BaseTask):
     # reference (humanoid.py:1140-1160 recomputes the observations of the reset envs); their terminal AMP rows come from the
     # flags launch (POST_AMP_DONE_ONLY).
     overlap_obs = False
+    # Opt-in (set by a rollout loop that calls reset_done() -- or wait_obs() -- before anything reads the observations of a step):
+    # post_physics_step launches only progress / reward / reset flags (+ the terminal AMP rows of the envs that finish); the
+    # observations and AMP rows of the live envs are DEFERRED into the next reset_done(), where they ride in the same launch as the
+    # reset chain of the finished envs (emloco_task_reset_obs: one launch, no side stream, no event packets).  wait_obs() -- which
+    # pre_physics_step calls too -- launches a deferred observation pass on the spot when no reset_done() took it, so a caller that
+    # never resets still gets its observations before the state moves on.  Takes precedence over overlap_obs.
+    fused_chain = False
+    _obs_deferred = 0
 
     def _make_obs_stream(self):
         # high priority: the short launches that run beside the rigid-body kernel get the first wave slot that frees up
@@ -404,7 +416,11 @@ class Humanoid(BaseTask):
         self._ev_flags, self._ev_obs = torch.cuda.Event(), torch.cuda.Event()
 
     def wait_obs(self):
-        """Make the caller's stream wait for the observation launch of the last step (no-op without overlap_obs)."""
+        """Make the caller's stream wait for the observation launch of the last step (no-op without overlap_obs); a deferred
+        observation pass (fused_chain) that no reset_done() has taken is launched here."""
+        if self._obs_deferred:
+            mode, self._obs_deferred = self._obs_deferred, 0
+            self._launch_post(mode | L.POST_SKIP_DONE)
         if getattr(self, "_obs_pending", False):
             torch.cuda.current_stream(self.device).wait_event(self._ev_obs)
             self._obs_pending = False
@@ -412,7 +428,13 @@ class Humanoid(BaseTask):
     def post_physics_step(self):
         self._refresh_sim_tensors()
         mode = self._post_mode_step()
-        if self.overlap_obs and torch.device(self.device).type == "cuda":
+        if self.fused_chain and torch.device(self.device).type == "cuda" and getattr(self, "_fused_reset", False):
+            self.wait_obs()
+            side_mode = mode & (L.POST_OBS | L.POST_AMP_SHIFT | L.POST_AMP_ROW)
+            amp = mode & (L.POST_AMP_SHIFT | L.POST_AMP_ROW)
+            self._launch_post((mode & ~side_mode) | (amp | L.POST_AMP_DONE_ONLY if amp else 0))
+            self._obs_deferred = side_mode
+        elif self.overlap_obs and torch.device(self.device).type == "cuda":
             if getattr(self, "_obs_stream", None) is None:
                 self._make_obs_stream()
             self.wait_obs()                                       # nobody asked for the previous step's observations

@@ -218,11 +218,41 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         dev = torch.device(self.device)
         lib = self._post.lib
         side = None
+        if self.fused_chain and dev.type == "cuda":
+            # the whole chain in two launches on the caller's stream: compaction (+ flag snapshot + the next step's dispatch order),
+            # then ONE launch for the reset chain of the finished envs, their AMP history, their observations AND the observation /
+            # AMP pass post_physics_step deferred for the envs that did not finish (humanoid.py: fused_chain)
+            if getattr(self, "_rs_skip", None) is None:
+                self._rs_skip = torch.zeros(E, dtype=torch.int64, device=dev)
+            st = current_stream_handle(dev)
+            L.check(lib.emloco_task_compact_done_order(self.sim.native._h, C.c_void_p(self.reset_buf.data_ptr()), E,
+                                                       C.c_void_p(self._done_ids.data_ptr()), C.c_void_p(self._rs_skip.data_ptr()), st),
+                    "emloco_task_compact_done_order")
+            live_mode, self._obs_deferred = self._obs_deferred, 0
+            if rnd is None:
+                if getattr(self, "_rnd_ws", None) is None:
+                    self._rnd_ws = torch.empty((E, L.RESET_RND), device=self.device)
+                    self._rnd_calls = 0
+                    self._rnd_seed0 = int(torch.initial_seed()) & 0xFFFFFFFFFFFF
+                self._rnd_calls += 1
+                seed = (self._rnd_seed0 * 0x9E3779B97F4A7C15 + self._rnd_calls) & 0xFFFFFFFFFFFFFFFF
+            else:
+                seed = 0
+            post_bufs = self._post_bufs if self._post_bufs is not None else self._ensure_post_bufs()
+            L.check(lib.emloco_task_reset_obs(self.sim.native._h, C.byref(self._reset_bufs), C.byref(post_bufs), int(live_mode),
+                                              C.c_void_p(self._rs_skip.data_ptr()), C.c_void_p(self._done_ids.data_ptr()), E, C.c_uint64(seed),
+                                              None if rnd is not None else C.c_void_p(self._rnd_ws.data_ptr()),
+                                              None if rnd is None else C.c_void_p(rnd.data_ptr()), st), "emloco_task_reset_obs")
+            if flags.init_heading and flags.heading_inversion:
+                self._traj_gen.inverted = self._inverted_u8.view(torch.bool)
+            self.inverted = self._traj_gen.show_inverted()
+            return
         if self.overlap_reset and dev.type == "cuda":
             # the reset chain runs beside the step of the live envs (see overlap_reset below); the flags are snapshot by the
             # compaction because the reset kernels clear them
-            if getattr(self, "_rs_skip", None) is None:
-                self._rs_skip = torch.zeros(E, dtype=torch.int64, device=dev)
+            if getattr(self, "_hp_stream", None) is None:
+                if getattr(self, "_rs_skip", None) is None:
+                    self._rs_skip = torch.zeros(E, dtype=torch.int64, device=dev)
                 self._hp_stream = torch.cuda.Stream(device=dev, priority=-1)
                 self._ev_rs_fork, self._ev_rs_reset, self._ev_rs_pd, self._ev_rs_big = (torch.cuda.Event() for _ in range(4))
             if self.overlap_reset_mode == "hp" and getattr(self, "_obs_stream", None) is None:

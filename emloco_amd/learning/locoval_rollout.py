@@ -67,6 +67,12 @@ class LocoValRollout:
         self.overlap_fit = bool(overlap_fit)
         if self.overlap_fit and hasattr(self.task, "overlap_obs") and getattr(self.task, "_fused_reset", False):
             self.task.overlap_obs = True           # this loop calls task.wait_obs() before the policy reads the observations
+            # the chain between two rigid-body steps in three launches on ONE stream (flags | compaction + dispatch order | reset
+            # chain + every observation): this loop calls reset_done() before the policy reads the observations, which is all that
+            # mode asks for.  With a discriminator the AMP observations of a step are scored right after it, before the resets:
+            # the deferred observation pass would be flushed on its own there, so the side-stream arrangement stays.
+            if hasattr(self.task, "fused_chain") and self._no_disc and os.environ.get("EMLOCO_FUSED_CHAIN", "1") != "0":
+                self.task.fused_chain = True
             if overlap_reset is None:
                 overlap_reset = os.environ.get("EMLOCO_OVERLAP_RESET", "0") == "1"
             if hasattr(self.task, "overlap_reset") and overlap_reset:
@@ -76,6 +82,7 @@ class LocoValRollout:
                 # without a policy in the loop; the resident rigid-body launch leaves no wave slot free for most of its run,
                 # so the gain hangs on launch timing and the mode stays off unless asked for.
                 self.task.overlap_reset = True
+                self.task.fused_chain = False          # the two-chain schedule has its own arrangement of these launches
                 # with the reset chain off the caller's stream the observation launch has nothing to hide behind: on a side
                 # stream it costs two cross-stream hand-overs (~13 us each, measured) around a 50 us launch the loop waits for
                 self.task.overlap_obs = os.environ.get("EMLOCO_OVERLAP_OBS", "0") == "1"

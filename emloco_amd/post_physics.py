@@ -73,8 +73,8 @@ class PostPhysics:
         L.check(rc, "emloco_task_amp_rows")
         return out
 
-    def pd_targets(self, actions, offset, scale, zero_mask, out):
-        rc = self.lib.emloco_task_pd_targets(int(actions.shape[0]), dptr(actions), dptr(offset), dptr(scale),
-                                             dptr(zero_mask), dptr(out), current_stream_handle(self.device))
-        L.check(rc, "emloco_task_pd_targets")
+    def pd_targets(self, actions, offset, scale, zero_mask, out, actions_copy=None):
+        rc = self.lib.emloco_task_pd_targets_copy(int(actions.shape[0]), dptr(actions), dptr(offset), dptr(scale),
+                                                  dptr(zero_mask), dptr(out), dptr(actions_copy), current_stream_handle(self.device))
+        L.check(rc, "emloco_task_pd_targets_copy")
         return out

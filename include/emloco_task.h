@@ -99,6 +99,11 @@ int emloco_task_amp_rows(int n, const float *root_pos, const float *root_rot, co
 int emloco_task_pd_targets(int n_env, const float *actions, const float *offset, const float *scale,
                            const uint8_t *zero_mask, float *pd_targets, void *stream);
 
+/* Same, and a copy of the actions as they were read into `actions_copy` ([n_env][69], optional, ignored when it aliases
+ * `actions`): the reference keeps `self.actions = actions.clone()` (humanoid.py:1185); one launch instead of a copy and a launch. */
+int emloco_task_pd_targets_copy(int n_env, const float *actions, const float *offset, const float *scale,
+                                const uint8_t *zero_mask, float *pd_targets, float *actions_copy, void *stream);
+
 /* wall-clock of the last emloco_task_post_physics launch measured with HIP events [ms]; <0 if none */
 float emloco_task_last_ms(void);
 int emloco_task_enable_timing(int on);
@@ -206,6 +211,32 @@ int emloco_task_compact_done(const int64_t *dev_flags, int n, int32_t *dev_ids, 
 /* Same, and a copy of the flags as they were (`dev_snapshot`, n entries): the reset kernels clear the flags of the envs they
  * reset, a launch that runs beside them (emloco_sim_step_subset) follows the snapshot. */
 int emloco_task_compact_done_snapshot(const int64_t *dev_flags, int n, int32_t *dev_ids, int64_t *dev_snapshot, void *stream);
+
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The chain between two rigid-body steps in three launches ("around the kernel").  In the reference's
+ * loop (amp_continuous_value.py:45-75: env_reset(done_indices) -> obs -> policy -> env.step) everything between two
+ * gym.simulate calls is one dependent chain; as separate launches it was 11 kernels and two stream hand-overs.
+ *
+ * emloco_task_compact_done_order: emloco_task_compact_done_snapshot and -- when `sim` has the cost-ordered dispatch on
+ * (emloco_sim_set_cost_order) -- the sort of the NEXT rigid-body launch's dispatch order, as two workgroups of one launch;
+ * the next emloco_sim_step / emloco_sim_step_subset then uses that order instead of sorting again.  `sim` may be NULL. */
+int emloco_task_compact_done_order(struct EmlocoSim *sim, const int64_t *dev_flags, int n, int32_t *dev_ids,
+                                   int64_t *dev_snapshot, void *stream);
+
+/* emloco_task_reset_obs: ONE launch for
+ *   (a) the reset of the listed envs: emloco_task_reset[_seeded] (random rows, sample, kinematics, height fix, trajectory,
+ *       LocoVal inputs, AMP history unless EMLOCO_RESET_NO_AMP_HISTORY) followed by
+ *       emloco_task_post_physics(EMLOCO_POST_OBS | EMLOCO_POST_AMP_ROW) of the same envs (humanoid.py:459-465), and
+ *   (b) with live_mode != 0: emloco_task_post_physics(live_mode) of every env whose `dev_skip` entry (the flag snapshot
+ *       of emloco_task_compact_done_order) is zero -- the observation / AMP part of post_physics_step (humanoid.py:1214,
+ *       humanoid_amp.py:150-155) for the envs that did not finish, which the caller left out of its flags launch.
+ * live_mode may hold EMLOCO_POST_OBS, _AMP_SHIFT, _AMP_ROW.  Random rows: `dev_rnd` [n][EMLOCO_RESET_RND] as for
+ * emloco_task_reset, or NULL: made on the device from `seed` into `dev_rnd_ws` as for emloco_task_reset_seeded.
+ * Results are those of the separate calls, byte for byte (the same device functions run). */
+int emloco_task_reset_obs(struct EmlocoSim *sim, const EmlocoResetBufs *reset_bufs, const EmlocoTaskBufs *task_bufs, int live_mode,
+                          const int64_t *dev_skip, const int32_t *dev_env_ids, int n, uint64_t seed, float *dev_rnd_ws,
+                          const float *dev_rnd, void *stream);
 
 #ifdef __cplusplus
 }

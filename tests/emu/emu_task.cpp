@@ -22,7 +22,7 @@ extern "C" int emu_task_amp_rows(int n, const float *root_pos, const float *root
 extern "C" int emu_task_pd_targets(int n_env, const float *actions, const float *offset, const float *scale,
                                    const uint8_t *zero_mask, float *out) {
     const int total = n_env * 69;
-    emu::launch((unsigned)((total + 255) / 256), 256, [&] { emloco::pd_targets_kernel(total, actions, offset, scale, zero_mask, out); });
+    emu::launch((unsigned)((total + 255) / 256), 256, [&] { emloco::pd_targets_kernel(total, actions, offset, scale, zero_mask, out, (float *)nullptr); });
     return 0;
 }
 

@@ -569,6 +569,62 @@ def test_observations_on_a_side_stream_give_the_same_rollout():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seeded", [False, True])
+def test_fused_chain_gives_the_same_rollout(seeded):
+    """task.fused_chain: post_physics_step launches only progress / reward / flags (+ the terminal AMP rows of the finished envs),
+    reset_done() is two launches -- emloco_task_compact_done_order (compaction + flag snapshot + the next step's dispatch order) and
+    emloco_task_reset_obs (reset chain of the finished envs, their AMP history, their observations AND the deferred observation /
+    AMP pass of the envs that did not finish).  Two identically seeded envs, one per schedule, forced and natural resets, random
+    rows supplied or drawn on the device from the same seeds: every buffer bit-equal after every reset_done, the terminal AMP rows
+    after every step."""
+    from emloco_amd import _lib as L
+    args = ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel"]
+    torch.manual_seed(11)
+    envs = [_make_env(96, args), _make_env(96, args)]
+    envs[1].task.fused_chain = True
+    for e in envs:
+        e.task.sim.native.set_cost_order(True)
+    dev = envs[0].task.device
+    g = torch.Generator(device=dev)
+    names = ("_root_states", "_dof_state", "_rigid_body_state", "obs_buf", "_flip_obs_buf", "_amp_obs_buf", "progress_buf", "reset_buf",
+             "rew_buf", "reward_raw", "_terminate_buf", "waypoint_traj", "init_pose", "init_vel", "inverted")
+    for k in range(30):
+        g.manual_seed(100 + k)
+        act = torch.randn(96, 69, device=dev, generator=g) * 0.3
+        g.manual_seed(500 + k)
+        rnd = None if seeded else torch.rand(96, L.RESET_RND, device=dev, generator=g)
+        for e in envs:
+            t = e.task
+            if k == 0:
+                t.reset_buf[:] = 1
+            if k % 7 == 3:
+                t.reset_buf[5:40:3] = 1
+            t.reset_done(rnd=rnd)
+        assert envs[1].task._obs_deferred == 0
+        torch.cuda.synchronize()
+        for name in names:
+            a, b = getattr(envs[0].task, name), getattr(envs[1].task, name)
+            assert torch.equal(a, b), (k, name, "after reset_done")
+        for e in envs:
+            e.step(act)
+        assert (envs[1].task._obs_deferred != 0) and envs[0].task._obs_deferred == 0
+        torch.cuda.synchronize()
+        done = envs[0].task.reset_buf != 0
+        assert torch.equal(envs[0].task.reset_buf, envs[1].task.reset_buf), k
+        assert torch.equal(envs[0].task._amp_obs_buf[done], envs[1].task._amp_obs_buf[done]), (k, "terminal AMP rows")
+        for name in ("_rigid_body_state", "rew_buf", "progress_buf", "_terminate_buf"):
+            assert torch.equal(getattr(envs[0].task, name), getattr(envs[1].task, name)), (k, name, "after step")
+    assert int((envs[0].task.progress_buf == 0).sum()) < 96            # natural / forced resets happened, not only the first
+    # a caller that never calls reset_done still gets its observations: wait_obs() launches the deferred pass
+    for e in envs:
+        e.task.wait_obs()
+    torch.cuda.synchronize()
+    live = envs[0].task.reset_buf == 0
+    for name in ("obs_buf", "_flip_obs_buf", "_amp_obs_buf"):
+        assert torch.equal(getattr(envs[0].task, name)[live], getattr(envs[1].task, name)[live]), name
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("obs_stream", [True, False])
 def test_reset_chain_on_a_second_stream_gives_the_same_rollout(obs_stream):
     """task.overlap_reset: `reset_done(); step(a)` issued as two chains -- the caller's stream steps the envs that did not

@@ -13,7 +13,7 @@ def wgs(r):
     return int(r.get('Grid_Size', r.get('Grid_Size_X', 0)) or 0) // max(int(r.get('Workgroup_Size', r.get('Workgroup_Size_X', 64)) or 64), 1)
 big = [i for i, r in enumerate(rows) if 'sim_step_kernel' in r['Kernel_Name'] and wgs(r) > 4096]
 with open(sys.argv[1], 'w') as o:
-    for label, k in (("LocoVal loop (headline)", len(big) * 30 // 100), ("env.step alone (overlapped)", len(big) * 55 // 100)):
+    for label, k in [(f"at {pc} % of the run's rigid-body launches", len(big) * pc // 100) for pc in (10, 35, 60, 85)]:
         a, b = big[k], big[k + 1]
         t0 = int(rows[a]['Start_Timestamp'])
         o.write(f"\n{label}: one step in launch order (start us, duration us, queue, workgroups, kernel)\n")
