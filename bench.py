@@ -214,6 +214,15 @@ def _timed(fn, steps, warmup, world, dev):
     return dt
 
 
+def gemm_peak(ops):
+    """(peak TFLOP/s, note) of the matrix path the fp32-class GEMMs run on in the current precision mode."""
+    if ops.get_matmul_precision() == "fp32_split":
+        return round(MFMA_BF16_PEAK_TFLOPS / 6.0, 1), ("fp32-class products from three bf16 pieces per operand: six v_mfma_f32_32x32x16_bf16 per 16 k, fp32 "
+                                                       "accumulation, error against float64 at or below the fp32 matrix instruction's (profiles/r03_gemm_split.txt); "
+                                                       "peak = dense bf16 matrix peak / 6 piece products; the fp32 matrix instruction's own peak is 157.3")
+    return 157.3, "fp32-in fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32), peak = fp32 matrix peak"
+
+
 def jta_leg(dev, steps=4, warmup=2, B=256, rank=0, world=1):
     """train_jta.py EmLoco step (configs[3]): fwd + MSE + LocoVal loss + bwd + clip + Adam, batch 256 per GPU, fp32 MFMA.
     world > 1: data parallel (EmLocoTrainer(data_parallel=True): one flat 3.2 M-float gradient all-reduce per step)."""
@@ -235,15 +244,17 @@ def jta_leg(dev, steps=4, warmup=2, B=256, rank=0, world=1):
     n, ms, fl = ops.gemm_timing()
     ops.gemm_timing(False)
     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    peak, peak_note = gemm_peak(ops)
     out = {"metric": "JTA samples/sec (train_jta EmLoco step)", "value": round(B * world * steps / dt, 2), "unit": "samples/s", "n_gpus": world,
            "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "warmup": warmup, "dtype": "f32",
            "config": {"workload": "configs[3]: Social-Transmotion train_jta.py with EmLoco loss (valueloss_w=1.0), batch 256, "
                                   "9-in/12-out frames, people/scene U{1..8} padded, 2 % NaN rows, d=128 h=4 ff=1024, 6+3 layers"
                                   + (f", data-parallel x{world} (256 per GPU)" if world > 1 else ""),
                       "batch": B, "people_padded": int(joints.shape[1]), "tokens_per_person": 453},
-           "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
-                        "frac": round(tf / 157.3, 4), "traffic": None, "gemm_launches": n, "gemm_ms_per_step": round(ms / steps, 2),
-                        "note": "fp32-in fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32), peak = fp32 matrix peak"}}
+           "precision": ops.get_matmul_precision(),
+           "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(tf / peak, 4), "frac_of_fp32_instruction_peak": round(tf / 157.3, 4), "traffic": None, "gemm_launches": n,
+                        "gemm_ms_per_step": round(ms / steps, 2), "note": peak_note}}
     # The reduced-precision mode of BASELINE configs[3] ("bf16 MFMA attention"), reported beside the fp32 figure under its own
     # parity bar (2e-2 on activations against the fp32 fixtures, tests/test_gpu_predictor.py): every linear-layer GEMM and
     # the fused attention's tile products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the two large activations of a layer
@@ -270,7 +281,7 @@ def jta_leg(dev, steps=4, warmup=2, B=256, rank=0, world=1):
                                "hidden layer and q|k|v as bf16 in HBM; parity bar 2e-2 (SURVEY 8c), NOT the 1e-4 of the fp32 path that `value` reports"}
         out["bf16_operands"] = out["bf16"]                      # the name earlier rounds reported this leg under
     finally:
-        ops.set_matmul_precision("fp32")
+        ops.set_matmul_precision(ops.DEFAULT_PRECISION)
     return out
 
 
@@ -414,6 +425,8 @@ def policy_leg(env, E, dev, steps, warmup):
     tf = pol.flops_per_env * E / (pm * 1e-3) / 1e12
     # the same loop with the opt-in bf16 operand mode of the GEMMs (reported beside the fp32 figure, never instead of it)
     from emloco_amd.predictor import ops
+    peak, peak_note = gemm_peak(ops)
+    precision = ops.get_matmul_precision()
     bf = None
     try:
         ops.set_matmul_precision("bf16")
@@ -434,13 +447,14 @@ def policy_leg(env, E, dev, steps, warmup):
               "policy_ms": round(float(np.median(pol_bf)), 4),
               "note": "opt-in ops.set_matmul_precision('bf16'): ~2e-3 relative error per GEMM, outside the 1e-4 parity bar"}
     finally:
-        ops.set_matmul_precision("fp32")
+        ops.set_matmul_precision(ops.DEFAULT_PRECISION)
     return {"metric": "env-steps/sec with the frozen policy in the loop", "value": round(E * steps / elapsed, 1), "unit": "env-steps/s",
             "ms_per_step": round(elapsed / steps * 1e3, 4), "policy_ms": round(pm, 4), "bf16_operands": bf,
             "policy_flops_per_env": pol.flops_per_env,
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                         "note": "normalise + 5 GEMM launches (bias/ReLU fused, fp32 MFMA), median of 20 HIP-event timings"},
+            "precision": precision,
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(tf, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(tf / peak, 4), "frac_of_fp32_instruction_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                         "note": "normalise + 5 GEMM launches (bias / ReLU fused), median of 20 HIP-event timings; " + peak_note},
             "weights": "random init (no checkpoint ships)"}
 
 

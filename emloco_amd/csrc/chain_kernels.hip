@@ -65,6 +65,9 @@ reset_obs_kernel(EmlocoTaskBufs pt, EmlocoResetBufs rt, EmlocoSimDev s, ChainArg
     const int lane = threadIdx.x;
     const int b = (int)blockIdx.x, S = a.n_slots;
     if (b < S) {                                                    // ---- reset chain of the list entries b, b + S, ...
+#ifndef EMLOCO_EMU
+        __builtin_amdgcn_s_setprio(3);                              // the launch's longest serial path: ahead of the observation waves
+#endif
         for (int bi = b; bi < a.n; bi += S) {
             const int env = a.ids[bi];
             if (env < 0) break;

@@ -85,8 +85,10 @@ __device__ __forceinline__ void reset_sample_env(const EmlocoResetBufs &t, const
             ds[2 * k + 1] = lerp1(t.dvs[fb.f0 * RNDOF + (lane - 1) * 3 + k], t.dvs[fb.f1 * RNDOF + (lane - 1) * 3 + k], fb.blend);
         }
     }
+    // root state: lane 0 blends / turns it, then the nine centre-height probes run on nine lanes (as a serial loop in lane 0 they were
+    // nine dependent chains of map loads, most of this phase's latency), lane 0 averages them in the order the step uses (mean9)
+    float pos[3] = {0.0f, 0.0f, 0.0f}, rot[4] = {0.0f, 0.0f, 0.0f, 1.0f}, vel[3] = {0.0f, 0.0f, 0.0f}, ang[3] = {0.0f, 0.0f, 0.0f};
     if (lane == 0) {
-        float pos[3], rot[4], vel[3], ang[3];
         for (int k = 0; k < 3; ++k) {
             pos[k] = lerp1(t.gts[(fb.f0 * RNB) * 3 + k], t.gts[(fb.f1 * RNB) * 3 + k], fb.blend);
             vel[k] = lerp1(t.gvs[(fb.f0 * RNB) * 3 + k], t.gvs[(fb.f1 * RNB) * 3 + k], fb.blend);
@@ -112,13 +114,20 @@ __device__ __forceinline__ void reset_sample_env(const EmlocoResetBufs &t, const
             if (li > t.n_valid - 1) li = t.n_valid - 1;
             pos[0] = t.valid_x[li]; pos[1] = t.valid_y[li];
         }
-        // centre height: 3x3 yaw-only probes (humanoid_pedestrain_terrain.py:607,732-759), same device functions as the step
-        float ch[9];
-        for (int k = 0; k < 9; ++k) {
-            float wx, wy;
-            center_probe(pos, rot, k, &wx, &wy);
-            ch[k] = sample_height(t.heightfield, t.hf_rows, t.hf_cols, wx, wy, t.hscale, t.vscale);
-        }
+    }
+    // centre height: 3x3 yaw-only probes (humanoid_pedestrain_terrain.py:607,732-759), same device functions as the step
+    float ppos[3], prot[4];
+    for (int k = 0; k < 3; ++k) ppos[k] = __shfl(pos[k], 0);
+    for (int k = 0; k < 4; ++k) prot[k] = __shfl(rot[k], 0);
+    float hk = 0.0f;
+    if (lane < 9) {
+        float wx, wy;
+        center_probe(ppos, prot, lane, &wx, &wy);
+        hk = sample_height(t.heightfield, t.hf_rows, t.hf_cols, wx, wy, t.hscale, t.vscale);
+    }
+    float ch[9];
+    for (int k = 0; k < 9; ++k) ch[k] = __shfl(hk, k);
+    if (lane == 0) {
         const float gh = mean9(ch);
         pos[2] += gh;
         t.ground_h[env] = gh;

@@ -4,6 +4,7 @@ PyTorch carries the autograd graph, device memory and the current stream; every 
 layer norm below runs in libemloco_hip.so.  There is no fallback: without the library / a GPU these raise.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -89,11 +90,19 @@ GEMM_SPLIT = 1024      # EMLOCO_GEMM_SPLIT: fp32-class products from bf16 pieces
 GEMM_A16, GEMM_B16, GEMM_C16, GEMM_MASK16 = 64, 128, 256, 512      # EMLOCO_GEMM_*_BF16MEM: that operand is bf16 in memory
 ATTN_BF16 = 16
 ATTN_QKV16 = 32        # EMLOCO_ATTN_QKV_BF16MEM
-_matmul_precision = ["fp32"]
+# The default is the split mode: every fp32 operand is cut into three bf16 pieces (8 + 8 + 8 mantissa bits, exact) and the six
+# piece products that carry more than 2^-24 of the result run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Against float64
+# its error is at or below the fp32 matrix instruction's on every shape of the train step and the policy (1.7e-7 vs 2.6e-7 of
+# sum |a||b| on the q|k|v projection, profiles/r03_gemm_split.txt), the 1e-4 parity tests hold in it, and it is 1.25-1.37x faster
+# (the bf16 pipe is 16x the fp32 one; the split costs 6 instructions where fp32 needs 8).  EMLOCO_MATMUL_PRECISION=fp32 puts
+# every GEMM back on v_mfma_f32_32x32x2_f32.
+DEFAULT_PRECISION = os.environ.get("EMLOCO_MATMUL_PRECISION", "fp32_split")       # "fp32" | "fp32_split" | "bf16"
+_matmul_precision = [DEFAULT_PRECISION]
 
 
 def set_matmul_precision(mode):
-    """"fp32" (default: fp32 operands on the fp32 matrix instruction, the path the 1e-4 parity tests hold) or "bf16"
+    """"fp32_split" (default: fp32-class products rebuilt from bf16 pieces, see DEFAULT_PRECISION), "fp32" (fp32 operands on the
+    fp32 matrix instruction) -- the 1e-4 parity tests hold in both -- or "bf16"
     (operands rounded to bf16 on their way into the matrix cores, fp32 accumulation; ~1e-3 relative output error) for
     every `linear` / projection GEMM and every fused attention launched afterwards; the two large activations of an encoder
     layer -- the feed-forward hidden layer (M x 1024) and the fused q|k|v projection (M x 384) -- and their gradients are then

@@ -289,7 +289,7 @@ def test_bf16_operand_mode_is_opt_in_and_within_its_stated_error(golden):
     model.eval()
     dev = "cuda:0"
     in_joints, pm, out_joints = (torch.from_numpy(g[k]).to(dev) for k in ("in_joints", "pm", "out_joints"))
-    assert ops.get_matmul_precision() == "fp32"
+    assert ops.get_matmul_precision() == ops.DEFAULT_PRECISION and ops.DEFAULT_PRECISION in ("fp32", "fp32_split")
     for _ in range(3):       # nn.Embedding(max_norm=1) renormalises the looked-up rows in place: settles after two forwards
         ref = model(in_joints.clone(), pm.clone()).detach()
     try:
@@ -322,7 +322,7 @@ def test_bf16_operand_mode_is_opt_in_and_within_its_stated_error(golden):
         want = A.bfloat16().float() @ B.bfloat16().float().T
         assert (Cm - want).abs().max().item() < 1e-3 and (Cm - A @ B.T).abs().max().item() > 1e-3
     finally:
-        ops.set_matmul_precision("fp32")
+        ops.set_matmul_precision(ops.DEFAULT_PRECISION)
     again = model(in_joints.clone(), pm.clone()).detach()
     assert torch.equal(ref, again)
     with pytest.raises(ValueError):
@@ -747,6 +747,6 @@ def test_shipped_depth_model_in_the_bf16_mode_is_within_its_bar(golden):
         rel = ((gb - gf).norm() / gf.norm()).item()
         assert 1e-6 < rel < 8e-2, ("input gradient, relative L2", rel)
     finally:
-        ops.set_matmul_precision("fp32")
+        ops.set_matmul_precision(ops.DEFAULT_PRECISION)
     again = model(in_joints.clone(), pm.clone()).detach()
     assert torch.equal(ref, again)
