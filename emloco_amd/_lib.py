@@ -122,6 +122,14 @@ def real_pick_perm(i, n, key):
             return x
 
 
+POOL_FLOATS = 512              # EMLOCO_POOL_FLOATS
+
+
+class ResetPool(C.Structure):   # EmlocoResetPool
+    _fields_ = [("k", C.c_int32), ("cur", C.c_void_p), ("cur_tag", C.c_void_p), ("next", C.c_void_p), ("next_tag", C.c_void_p),
+                ("next_seed", C.c_uint64)]
+
+
 def default_sim_params(**kw):
     """Engine parameters of pacer.yaml:93-104 / config.py:143-163 mapped onto EmlocoSimParams."""
     p = dict(n_sub=2, n_iter=4, h=(1.0 / 60.0) / 2, gravity_z=-9.81, contact_offset=0.02, erp=0.2,
@@ -142,7 +150,7 @@ SYMBOLS_SIM = [
 SYMBOLS_TASK = [
     "emloco_task_post_physics", "emloco_task_amp_rows", "emloco_task_pd_targets", "emloco_task_last_ms",
     "emloco_task_enable_timing", "emloco_task_reset", "emloco_task_reset_seeded", "emloco_task_compact_done", "emloco_task_compact_done_snapshot", "emloco_task_reset_amp_history",
-    "emloco_task_traj_reset", "emloco_task_get_heights", "emloco_task_pd_targets_copy", "emloco_task_compact_done_order", "emloco_task_reset_obs",
+    "emloco_task_traj_reset", "emloco_task_get_heights", "emloco_task_pd_targets_copy", "emloco_task_compact_done_order", "emloco_task_reset_obs", "emloco_task_reset_obs_pooled",
 ]
 
 _lib = None
@@ -201,6 +209,8 @@ def load():
     lib.emloco_task_reset_amp_history.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.emloco_task_pd_targets_copy.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_void_p, C.c_void_p]
     lib.emloco_task_compact_done_order.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emloco_task_reset_obs_pooled.argtypes = [C.c_void_p, C.POINTER(ResetBufs), C.POINTER(TaskBufs), C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                 C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(ResetPool), C.c_void_p]
     lib.emloco_task_reset_obs.argtypes = [C.c_void_p, C.POINTER(ResetBufs), C.POINTER(TaskBufs), C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib

@@ -12,9 +12,10 @@
 //                            [0, S)             reset chain of list entry bi (bi = slot, slot + S, ...): random row, sample,
 //                                               kinematics, finish, observations + newest AMP row -- one wave walks the
 //                                               phases with workgroup barriers between them (the separate kernels' bodies)
-//                            [S, S + 14 S)      AMP history row k of list entry bi (independent of the chain: the clip and its
+//                            then 14 Sh         AMP history row k of list entry bi (independent of the chain: the clip and its
 //                                               start time are functions of the random row alone)
-//                            [S + 14 S, .. + E) post-physics observations (+ AMP shift / row) of the envs that did NOT finish
+//                            then 16 K          the pool of pre-drawn episodes for the NEXT call (below)
+//                            then E             post-physics observations (+ AMP shift / row) of the envs that did NOT finish
 //                                               (flag snapshot), i.e. the launch that ran on the observation stream
 // The reset workgroups come first in dispatch order: the longest serial path of the launch starts first, the 4096 short
 // observation workgroups fill the device beside it.  Same device functions as the separate kernels -> same bytes
@@ -35,9 +36,31 @@ compact_order_kernel(const int64_t *flags, int n, int32_t *ids, int64_t *snapsho
     else order_sort(ticks, n_order, order, bucket_ws);
 }
 
+// Pool of pre-drawn episodes.  What a reset draws -- clip and start time, joint state, root state on the terrain, trajectory,
+// LocoVal waypoints -- is a function of (call seed, position in the finished-env list) alone; only the kinematics on the env's
+// own skeleton, the height fix and the observations need to know WHICH env finished.  So every launch also draws the leading
+// entries of the NEXT call (whose seed the host knows: base + call counter) into a pool -- two workgroups per entry, sample and
+// trajectory side by side -- and the reset chain of an entry whose pool slot carries this call's seed copies it instead of walking
+// sample -> trajectory itself: the launch's longest serial path loses its two longest phases (82 -> 38 us for one entry).  How many
+// entries are drawn follows the number of envs that finished THIS step (+ 25 % + 32, at most pool_k).  Entries beyond the pool and
+// slots drawn for another seed (first call, caller-supplied random rows) take the direct path; the same device functions fill
+// both, so the bytes are the same (tests/test_gpu_env.py: pooled launches against the separate kernels).
+// Entry layout in floats (16-byte aligned blocks; EMLOCO_POOL_FLOATS per entry):
+#define POOL_ROOT 0        /* [13] root state (z includes the ground height) */
+#define POOL_GH 13         /* ground height under the pose */
+#define POOL_TIME 14       /* clip start time */
+#define POOL_INV 15        /* heading-inversion flag: first byte */
+#define POOL_MID 16        /* int64 clip id (2 floats) */
+#define POOL_DOF 20        /* [69][2] */
+#define POOL_VERTS 160     /* [101][3] */
+#define POOL_WAY 464       /* [15][3] */
+static_assert(POOL_WAY + EMLOCO_TRAJ_SAMPLES * 3 <= EMLOCO_POOL_FLOATS, "pool entry size (include/emloco_task.h)");
+static_assert(POOL_DOF + EMLOCO_NDOF * 2 <= POOL_VERTS && POOL_VERTS + EMLOCO_TRAJ_VERTS * 3 <= POOL_WAY, "pool layout");
+
 struct ChainArgs {
     int n;                      // capacity of the id list (entries beyond the finished envs are -1)
     int n_slots;                // S: workgroups of the reset role (grid-stride over the list)
+    int h_slots;                // workgroups per AMP history row (grid-stride over the list)
     int n_hist;                 // AMP history rows back-filled per reset env (14, or 0: EMLOCO_RESET_NO_AMP_HISTORY)
     int live_mode;              // post-physics mode of the envs that did not finish (0: that role is absent)
     int reset_mode;             // post-physics mode of the reset envs (OBS | AMP_ROW)
@@ -47,20 +70,32 @@ struct ChainArgs {
     const int64_t *skip;        // flag snapshot [n_env]: the live role leaves envs with a non-zero entry alone
     const float *rnd_in;
     float *rnd_ws;
+    // pool of pre-drawn episodes (all NULL / 0: every entry takes the direct path, nothing is drawn ahead)
+    int pool_k;
+    const float *pool_cur;                   // [pool_k][EMLOCO_POOL_FLOATS] drawn by the previous launch ...
+    const unsigned long long *tag_cur;       // ... for the seed in its tag [pool_k]
+    float *pool_next;                        // filled by this launch for the next call's seed
+    unsigned long long *tag_next;
+    unsigned nseed_lo, nseed_hi, next_key;   // next call: seed halves, real-path permutation key
     long long *prof;            // diagnostic (emloco_task_chain_profile): wall-clock stamps of reset slot 0's phases and of the last
                                 // observation workgroup, else NULL
 };
 
-// Between the phases of the reset role the lane index, the env and the random-row pointer are redefined through an empty asm:
-// what a phase derived from them (addresses, masks) dies with the phase instead of being held in registers for the whole chain
-// (the kernel must fit the register budget of the 4096 observation workgroups that share the launch).
+// Between the phases of the reset role the lane index and the env are redefined through an empty asm: what a phase derived from
+// them (addresses, masks) dies with the phase instead of being held in registers for the whole chain (the kernel must fit the
+// register budget of the 4096 observation workgroups that share the launch).
 #ifdef EMLOCO_EMU
-#define PHASE_FENCE(ln, ev, u) do { } while (0)
+#define PHASE_FENCE(ln, ev) do { } while (0)
 #else
-#define PHASE_FENCE(ln, ev, u) asm volatile("" : "+v"(ln), "+s"(ev))
+#define PHASE_FENCE(ln, ev) do { int e_ = (ev); asm volatile("" : "+v"(ln), "+v"(e_)); (ev) = __builtin_amdgcn_readfirstlane(e_); } while (0)
 #endif
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__device__ __forceinline__ bool pool_hit(const ChainArgs &a, int bi) {
+    return a.seeded && a.pool_cur && bi < a.pool_k && a.tag_cur[bi] == (((unsigned long long)a.seed_hi << 32) | a.seed_lo);
+}
+
+// three waves per SIMD: what the launch's 13 KB of LDS per workgroup allow anyway (12 workgroups per CU)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8)))
 reset_obs_kernel(EmlocoTaskBufs pt, EmlocoResetBufs rt, EmlocoSimDev s, ChainArgs a) {
     const int lane = threadIdx.x;
     const int b = (int)blockIdx.x, S = a.n_slots;
@@ -71,59 +106,120 @@ reset_obs_kernel(EmlocoTaskBufs pt, EmlocoResetBufs rt, EmlocoSimDev s, ChainArg
         for (int bi = b; bi < a.n; bi += S) {
             const int env = a.ids[bi];
             if (env < 0) break;
-            const float *u = a.rnd_in + (long)bi * EMLOCO_RESET_RND;
-            if (a.seeded) {
-                reset_fill_row(a.seed_lo, a.seed_hi, bi, a.rnd_ws, lane, 64);
-                u = a.rnd_ws + (long)bi * EMLOCO_RESET_RND;
-                __syncthreads();                                    // workgroup barrier + fence: the row is read by other lanes
-            }
-            #ifdef EMLOCO_EMU
+#ifdef EMLOCO_EMU
             int ln = lane, ev = env;
 #else
             int ln = lane, ev = __builtin_amdgcn_readfirstlane(env);
 #endif
             const bool stamp = a.prof && b == 0 && bi == 0 && lane == 0;
             if (stamp) a.prof[0] = wall_clock64();
-            PHASE_FENCE(ln, ev, u);
-            if (stamp) a.prof[1] = wall_clock64();
-            reset_sample_env(rt, s, ev, u, ln);
+            const bool pooled = pool_hit(a, bi);                    // wave-uniform
+            const float *u = a.rnd_in + (long)bi * EMLOCO_RESET_RND;
+            const float *pe = a.pool_cur + (long)bi * EMLOCO_POOL_FLOATS;
+            if (pooled) {                                           // the episode drawn ahead: joint state, root state, clip
+                float *dst = s.dof_state + (long)ev * EMLOCO_NDOF * 2;
+                for (int i = ln; i < EMLOCO_NDOF * 2; i += 64) dst[i] = pe[POOL_DOF + i];
+                if (ln < 13) s.root_state[(long)ev * 13 + ln] = pe[POOL_ROOT + ln];
+                if (ln == 0) {
+                    rt.ground_h[ev] = pe[POOL_GH];
+                    rt.motion_times[ev] = pe[POOL_TIME];
+                    rt.motion_ids[ev] = *(const int64_t *)(pe + POOL_MID);
+                }
+                if (stamp) a.prof[1] = wall_clock64();
+            } else {
+                if (a.seeded) {
+                    reset_fill_row(a.seed_lo, a.seed_hi, bi, a.rnd_ws, lane, 64);
+                    u = a.rnd_ws + (long)bi * EMLOCO_RESET_RND;
+                    __syncthreads();                                // workgroup barrier + fence: the row is read by other lanes
+                }
+                if (stamp) a.prof[1] = wall_clock64();
+                PHASE_FENCE(ln, ev);
+                reset_sample_env(rt, s, ev, u, ln);
+            }
             __syncthreads();
             if (stamp) a.prof[2] = wall_clock64();
-            PHASE_FENCE(ln, ev, u);
+            PHASE_FENCE(ln, ev);
             fk_env(s, ev, ln);
             __syncthreads();
             if (stamp) a.prof[3] = wall_clock64();
-            PHASE_FENCE(ln, ev, u);
-            reset_finish_env(rt, s, bi, ev, u, ln);
+            PHASE_FENCE(ln, ev);
+            if (pooled) {
+                reset_fix_height(rt, s, ev, ln);
+                float *vo = rt.traj_verts + (long)ev * EMLOCO_TRAJ_VERTS * 3;
+                for (int i = ln; i < EMLOCO_TRAJ_VERTS * 3; i += 64) vo[i] = pe[POOL_VERTS + i];
+                if (ln < EMLOCO_TRAJ_SAMPLES * 3) rt.waypoint_traj[(long)ev * EMLOCO_TRAJ_SAMPLES * 3 + ln] = pe[POOL_WAY + ln];
+                if (ln == 0 && (rt.flags & EMLOCO_RESET_INIT_HEADING) && (rt.flags & EMLOCO_RESET_HEADING_INVERSION)) rt.inverted[ev] = *(const uint8_t *)(pe + POOL_INV);
+                reset_capture_pose(rt, s, ev, ln, pe[POOL_ROOT + 7], pe[POOL_ROOT + 8]);
+            } else {
+                reset_finish_env(rt, s, bi, ev, u, ln);
+            }
             __syncthreads();
             if (stamp) a.prof[4] = wall_clock64();
-            PHASE_FENCE(ln, ev, u);
+            PHASE_FENCE(ln, ev);
             post_physics_env(pt, a.reset_mode, ev, ln);
             __syncthreads();                                        // LDS is reused by the next list entry
             if (stamp) a.prof[5] = wall_clock64();
         }
         return;
     }
-    const int hb = b - S;
-    if (hb < S * a.n_hist) {                                        // ---- AMP history row k of the list entries slot, slot + S, ...
-        const int slot = hb % S, k = 1 + hb / S;
-        for (int bi = slot; bi < a.n; bi += S) {
+    int hb = b - S;
+    const int Sh = a.h_slots;
+    if (hb < Sh * a.n_hist) {                                       // ---- AMP history row k of the list entries slot, slot + Sh, ...
+        const int slot = hb % Sh, k = 1 + hb / Sh;
+        for (int bi = slot; bi < a.n; bi += Sh) {
             const int env = a.ids[bi];
             if (env < 0) break;
+            const bool stamp = a.prof && hb == Sh * a.n_hist - Sh && bi == 0 && lane == 0;    // last history row of entry 0
+            if (stamp) a.prof[6] = wall_clock64();
             const float um = a.seeded ? reset_rnd_value(a.seed_lo, a.seed_hi, bi, EMLOCO_RND_MOTION) : a.rnd_in[(long)bi * EMLOCO_RESET_RND + EMLOCO_RND_MOTION];
             const float ut = a.seeded ? reset_rnd_value(a.seed_lo, a.seed_hi, bi, EMLOCO_RND_TIME) : a.rnd_in[(long)bi * EMLOCO_RESET_RND + EMLOCO_RND_TIME];
             int mid; float mt;
             reset_pick_motion(rt, um, ut, &mid, &mt);
-            const bool stamp = a.prof && hb == S * a.n_hist - S && bi == 0 && lane == 0;      // last history row of entry 0
-            if (stamp) a.prof[6] = wall_clock64();
             reset_amp_history_row(rt, env, k, mid, mt, lane);
             __syncthreads();
             if (stamp) a.prof[7] = wall_clock64();
         }
         return;
     }
+    hb -= Sh * a.n_hist;
+    const int n_draw = a.pool_next ? a.pool_k * 2 : 0;
+    if (hb < n_draw) {                                              // ---- draw entry e of the NEXT call into the pool
+        const int e = hb % a.pool_k, kind = hb / a.pool_k;         // kind 0: sample, 1: trajectory
+        const int now = a.ids[a.n];                                 // envs that finished this step (emloco_task_compact_done*: ids[n] = count)
+        if (e >= now + (now >> 2) + 32) return;                     // the next step will not need more (if it does: direct path)
+        float *pe = a.pool_next + (long)e * EMLOCO_POOL_FLOATS;
+        __shared__ float sh_u[EMLOCO_RESET_RND];
+        for (int k = lane; k < EMLOCO_RESET_RND; k += 64) sh_u[k] = reset_rnd_value(a.nseed_lo, a.nseed_hi, e, k);
+        __syncthreads();
+        const bool stamp = a.prof && e == 0 && lane == 0;                               // the first entry's sample / trajectory workgroups
+        if (stamp) a.prof[12 + 2 * kind] = wall_clock64();
+        if (kind == 0) {
+            reset_sample_to(rt, sh_u, lane, pe + POOL_DOF, pe + POOL_ROOT, pe + POOL_GH, (int64_t *)(pe + POOL_MID), pe + POOL_TIME);
+            if (lane == 0) a.tag_next[e] = ((unsigned long long)a.nseed_hi << 32) | a.nseed_lo;
+            __syncthreads();
+            if (stamp) a.prof[13] = wall_clock64();
+        } else if (kind == 1) {
+            // the trajectory starts at the root's place and follows its velocity: lane 0 repeats the root part of the sample
+            int mid; float time;
+            reset_pick_motion(rt, sh_u[EMLOCO_RND_MOTION], sh_u[EMLOCO_RND_TIME], &mid, &time);
+            const FrameBlend fb = frame_blend(rt, mid, time);
+            float pos[3] = {0.0f, 0.0f, 0.0f}, rot[4] = {0.0f, 0.0f, 0.0f, 1.0f}, vel[3] = {0.0f, 0.0f, 0.0f}, ang[3] = {0.0f, 0.0f, 0.0f};
+            if (lane == 0) reset_sample_root(rt, fb, sh_u, pos, rot, vel, ang);
+            const float ipx = __shfl(pos[0], 0), ipy = __shfl(pos[1], 0);
+            const float rvx = __shfl(vel[0], 0), rvy = __shfl(vel[1], 0), rvz = __shfl(vel[2], 0);
+            EmlocoResetBufs nx = rt;
+            nx.real_pick = nullptr;
+            nx.real_pick_key = a.next_key;
+            if (lane == 0) *(uint8_t *)(pe + POOL_INV) = 0;
+            reset_traj_to(nx, sh_u, e, lane, ipx, ipy, rvx, rvy, rvz, pe + POOL_VERTS, (uint8_t *)(pe + POOL_INV), pe + POOL_WAY);
+            __syncthreads();
+            if (stamp) a.prof[15] = wall_clock64();
+        }
+        return;
+    }
+    hb -= n_draw;
     if (!a.live_mode) return;
-    const int env = hb - S * a.n_hist;                              // ---- observations of an env that did not finish
+    const int env = hb;                                             // ---- observations of an env that did not finish
     if (env >= pt.n_env) return;
     if (a.skip[env] != 0) return;
     const bool stamp = a.prof && lane == 0 && (env == 0 || env == pt.n_env - 1);

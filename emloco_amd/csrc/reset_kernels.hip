@@ -70,8 +70,41 @@ __device__ __forceinline__ void reset_pick_motion(const EmlocoResetBufs &t, floa
     *time_out = u_time * t.motion_len[mid];
 }
 
-// reset_sample of ONE list entry by one wave (u = its random row)
-__device__ __forceinline__ void reset_sample_env(const EmlocoResetBufs &t, const EmlocoSimDev &s, int env, const float *u, int lane) {
+// root state of a reset before the terrain height is added -- lane 0's serial part: blended motion frame, random heading and
+// forward speed, placement (humanoid_pedestrain_terrain.py:526-573)
+__device__ __forceinline__ void reset_sample_root(const EmlocoResetBufs &t, const FrameBlend &fb, const float *u, float *pos, float *rot, float *vel, float *ang) {
+    for (int k = 0; k < 3; ++k) {
+        pos[k] = lerp1(t.gts[(fb.f0 * RNB) * 3 + k], t.gts[(fb.f1 * RNB) * 3 + k], fb.blend);
+        vel[k] = lerp1(t.gvs[(fb.f0 * RNB) * 3 + k], t.gvs[(fb.f1 * RNB) * 3 + k], fb.blend);
+        ang[k] = lerp1(t.gavs[(fb.f0 * RNB) * 3 + k], t.gavs[(fb.f1 * RNB) * 3 + k], fb.blend);
+    }
+    ref_slerp(t.grs + (fb.f0 * RNB) * 4, t.grs + (fb.f1 * RNB) * 4, fb.blend, rot);
+    if (t.flags & EMLOCO_RESET_RANDOM_HEADING) {        // humanoid_pedestrain_terrain.py:556-569
+        const float yaw = 3.14159265358979f * (2.0f * u[EMLOCO_RND_YAW] - 1.0f);
+        const float hq[4] = {0.0f, 0.0f, sinf(0.5f * yaw), cosf(0.5f * yaw)};
+        float r2[4], a2[3], hh[4], v2[3];
+        ref_quat_mul(hq, rot, r2);
+        ref_quat_apply(hq, ang, a2);
+        for (int k = 0; k < 4; ++k) rot[k] = r2[k];
+        for (int k = 0; k < 3; ++k) ang[k] = a2[k];
+        ref_quat_about_z(ref_calc_heading(rot), hh);
+        vel[0] = u[EMLOCO_RND_SPEED] * 0.5f + 1.0f;
+        ref_quat_apply(hh, vel, v2);
+        for (int k = 0; k < 3; ++k) vel[k] = v2[k];
+    }
+    if (t.flags & EMLOCO_RESET_FIXED_LOCATION) { pos[0] = t.fixed_x; pos[1] = t.fixed_y; }
+    else {
+        int li = (int)(u[EMLOCO_RND_LOC] * (float)t.n_valid);
+        if (li > t.n_valid - 1) li = t.n_valid - 1;
+        pos[0] = t.valid_x[li]; pos[1] = t.valid_y[li];
+    }
+}
+
+// reset_sample of ONE list entry by one wave (u = its random row).  Nothing here depends on WHICH env is reset: the destinations are
+// that env's simulator rows, or an entry of the pool of pre-drawn episodes (chain_kernels.hip).  dof_out [69][2] (position, velocity),
+// root_out [13], *gh_out ground height under the pose, *mid_out / *time_out the clip and its start time.
+__device__ __forceinline__ void reset_sample_to(const EmlocoResetBufs &t, const float *u, int lane, float *dof_out, float *root_out,
+                                                float *gh_out, int64_t *mid_out, float *time_out) {
     int mid; float time;
     reset_pick_motion(t, u[EMLOCO_RND_MOTION], u[EMLOCO_RND_TIME], &mid, &time);
     const FrameBlend fb = frame_blend(t, mid, time);
@@ -79,7 +112,7 @@ __device__ __forceinline__ void reset_sample_env(const EmlocoResetBufs &t, const
         float q[4], e[3];
         ref_slerp(t.lrs + (fb.f0 * RNB + lane) * 4, t.lrs + (fb.f1 * RNB + lane) * 4, fb.blend, q);
         ref_quat_to_exp_map(q, e);
-        float *ds = s.dof_state + ((long)env * RNDOF + (lane - 1) * 3) * 2;
+        float *ds = dof_out + (lane - 1) * 3 * 2;
         for (int k = 0; k < 3; ++k) {
             ds[2 * k] = e[k];
             ds[2 * k + 1] = lerp1(t.dvs[fb.f0 * RNDOF + (lane - 1) * 3 + k], t.dvs[fb.f1 * RNDOF + (lane - 1) * 3 + k], fb.blend);
@@ -88,33 +121,7 @@ __device__ __forceinline__ void reset_sample_env(const EmlocoResetBufs &t, const
     // root state: lane 0 blends / turns it, then the nine centre-height probes run on nine lanes (as a serial loop in lane 0 they were
     // nine dependent chains of map loads, most of this phase's latency), lane 0 averages them in the order the step uses (mean9)
     float pos[3] = {0.0f, 0.0f, 0.0f}, rot[4] = {0.0f, 0.0f, 0.0f, 1.0f}, vel[3] = {0.0f, 0.0f, 0.0f}, ang[3] = {0.0f, 0.0f, 0.0f};
-    if (lane == 0) {
-        for (int k = 0; k < 3; ++k) {
-            pos[k] = lerp1(t.gts[(fb.f0 * RNB) * 3 + k], t.gts[(fb.f1 * RNB) * 3 + k], fb.blend);
-            vel[k] = lerp1(t.gvs[(fb.f0 * RNB) * 3 + k], t.gvs[(fb.f1 * RNB) * 3 + k], fb.blend);
-            ang[k] = lerp1(t.gavs[(fb.f0 * RNB) * 3 + k], t.gavs[(fb.f1 * RNB) * 3 + k], fb.blend);
-        }
-        ref_slerp(t.grs + (fb.f0 * RNB) * 4, t.grs + (fb.f1 * RNB) * 4, fb.blend, rot);
-        if (t.flags & EMLOCO_RESET_RANDOM_HEADING) {        // humanoid_pedestrain_terrain.py:556-569
-            const float yaw = 3.14159265358979f * (2.0f * u[EMLOCO_RND_YAW] - 1.0f);
-            const float hq[4] = {0.0f, 0.0f, sinf(0.5f * yaw), cosf(0.5f * yaw)};
-            float r2[4], a2[3], hh[4], v2[3];
-            ref_quat_mul(hq, rot, r2);
-            ref_quat_apply(hq, ang, a2);
-            for (int k = 0; k < 4; ++k) rot[k] = r2[k];
-            for (int k = 0; k < 3; ++k) ang[k] = a2[k];
-            ref_quat_about_z(ref_calc_heading(rot), hh);
-            vel[0] = u[EMLOCO_RND_SPEED] * 0.5f + 1.0f;
-            ref_quat_apply(hh, vel, v2);
-            for (int k = 0; k < 3; ++k) vel[k] = v2[k];
-        }
-        if (t.flags & EMLOCO_RESET_FIXED_LOCATION) { pos[0] = t.fixed_x; pos[1] = t.fixed_y; }
-        else {
-            int li = (int)(u[EMLOCO_RND_LOC] * (float)t.n_valid);
-            if (li > t.n_valid - 1) li = t.n_valid - 1;
-            pos[0] = t.valid_x[li]; pos[1] = t.valid_y[li];
-        }
-    }
+    if (lane == 0) reset_sample_root(t, fb, u, pos, rot, vel, ang);
     // centre height: 3x3 yaw-only probes (humanoid_pedestrain_terrain.py:607,732-759), same device functions as the step
     float ppos[3], prot[4];
     for (int k = 0; k < 3; ++k) ppos[k] = __shfl(pos[k], 0);
@@ -130,13 +137,16 @@ __device__ __forceinline__ void reset_sample_env(const EmlocoResetBufs &t, const
     if (lane == 0) {
         const float gh = mean9(ch);
         pos[2] += gh;
-        t.ground_h[env] = gh;
-        float *rs = s.root_state + (long)env * 13;
-        for (int k = 0; k < 3; ++k) { rs[k] = pos[k]; rs[7 + k] = vel[k]; rs[10 + k] = ang[k]; }
-        for (int k = 0; k < 4; ++k) rs[3 + k] = rot[k];
-        t.motion_ids[env] = mid;
-        t.motion_times[env] = time;
+        *gh_out = gh;
+        for (int k = 0; k < 3; ++k) { root_out[k] = pos[k]; root_out[7 + k] = vel[k]; root_out[10 + k] = ang[k]; }
+        for (int k = 0; k < 4; ++k) root_out[3 + k] = rot[k];
+        *mid_out = mid;
+        *time_out = time;
     }
+}
+__device__ __forceinline__ void reset_sample_env(const EmlocoResetBufs &t, const EmlocoSimDev &s, int env, const float *u, int lane) {
+    reset_sample_to(t, u, lane, s.dof_state + (long)env * RNDOF * 2, s.root_state + (long)env * 13, t.ground_h + env, t.motion_ids + env,
+                    t.motion_times + env);
 }
 
 __global__ void __launch_bounds__(64)
@@ -187,7 +197,7 @@ __device__ __forceinline__ unsigned real_pick_perm(unsigned x, unsigned n, unsig
     return x;
 }
 
-__device__ __forceinline__ void reset_trajectory(const EmlocoResetBufs &t, const float *u, int bi, int env, int lane,
+__device__ __forceinline__ void reset_trajectory(const EmlocoResetBufs &t, const float *u, int bi, uint8_t *inv_out, int lane,
                                                  float ipx, float ipy, float rvx, float rvy, float rvz, float (*sh_v)[3]) {
     // The heading / speed recurrences (clamped random walks) are sequential but cheap; the 100 cos / sin evaluations are
     // the cost, so lane 0 only produces theta_i and the segment length, all lanes evaluate the steps, and lane 0 adds
@@ -283,15 +293,17 @@ __device__ __forceinline__ void reset_trajectory(const EmlocoResetBufs &t, const
             sh_v[i][0] = (x * c + y * sn) + ox;
             sh_v[i][1] = (-x * sn + y * c) + oy;
         }
-        if (lane == 0 && (t.flags & EMLOCO_RESET_HEADING_INVERSION)) t.inverted[env] = inv ? 1 : 0;
+        if (lane == 0 && (t.flags & EMLOCO_RESET_HEADING_INVERSION)) *inv_out = inv ? 1 : 0;
         __syncthreads();
     }
 }
 
-// reset_finish of ONE list entry by one wave
-__device__ __forceinline__ void reset_finish_env(const EmlocoResetBufs &t, const EmlocoSimDev &s, int bi, int env, const float *u, int lane) {
-    __shared__ float sh_v[RNV][3];
-
+// reset_finish of ONE list entry by one wave, in three pieces (the pooled reset of chain_kernels.hip runs the first and the last
+// and copies what the middle one produced ahead of time):
+//   reset_fix_height     a. lowest collision point -> vertical shift, b. buffers + warm-start impulses        (needs the env)
+//   reset_traj_to        c. trajectory, d1. the LocoVal waypoints sampled from it                            (env-independent)
+//   reset_capture_pose   d2. LocoVal pose / velocity inputs                                                    (needs the env)
+__device__ __forceinline__ void reset_fix_height(const EmlocoResetBufs &t, const EmlocoSimDev &s, int env, int lane) {
     // ---- a. lowest collision point -> vertical shift (replaces the SMPL-mesh height fix, humanoid_amp.py:321-379)
     float low = 3.0e38f;
     for (int sl = 0; sl < 2; ++sl) {
@@ -327,23 +339,37 @@ __device__ __forceinline__ void reset_finish_env(const EmlocoResetBufs &t, const
     if (lane == 0) { t.progress_buf[env] = 0; t.reset_buf[env] = 0; t.terminate_buf[env] = 0; }
     for (int i = lane; i < RNB * 3; i += 64) s.contact_force[(long)env * RNB * 3 + i] = 0.0f;
     for (int i = lane; i < EMLOCO_MAXCAND * 3; i += 64) s.lambda_ws[(long)env * EMLOCO_MAXCAND * 3 + i] = 0.0f;
+}
 
+__device__ __forceinline__ void reset_traj_to(const EmlocoResetBufs &t, const float *u, int bi, int lane, float ipx, float ipy, float rvx,
+                                              float rvy, float rvz, float *verts_out, uint8_t *inv_out, float *way_out) {
+    __shared__ float sh_v[RNV][3];
     // ---- c. trajectory (traj_generator.py:60-237)
-    const float ipx = rs[0], ipy = rs[1];
-    const float rvx = rs[7], rvy = rs[8];
-    reset_trajectory(t, u, bi, env, lane, ipx, ipy, rvx, rvy, rs[9], sh_v);
-    float *vout = t.traj_verts + (long)env * RNV * 3;
-    for (int i = lane; i < RNV * 3; i += 64) vout[i] = (&sh_v[0][0])[i];
-
-    // ---- d. LocoVal inputs captured at reset (humanoid_pedestrain_terrain.py:511-516)
+    reset_trajectory(t, u, bi, inv_out, lane, ipx, ipy, rvx, rvy, rvz, sh_v);
+    for (int i = lane; i < RNV * 3; i += 64) verts_out[i] = (&sh_v[0][0])[i];
+    // ---- d1. LocoVal waypoints captured at reset (humanoid_pedestrain_terrain.py:511-516)
     if (lane < EMLOCO_TRAJ_SAMPLES) {
         float p[3];
         r_calc_pos(&sh_v[0][0], (float)lane * t.sample_dt, t.traj_dur, p);
-        for (int k = 0; k < 3; ++k) t.waypoint_traj[((long)env * EMLOCO_TRAJ_SAMPLES + lane) * 3 + k] = p[k];
+        for (int k = 0; k < 3; ++k) way_out[lane * 3 + k] = p[k];
     }
+}
+
+__device__ __forceinline__ void reset_capture_pose(const EmlocoResetBufs &t, const EmlocoSimDev &s, int env, int lane, float rvx, float rvy) {
+    // ---- d2. LocoVal pose / velocity inputs captured at reset (humanoid_pedestrain_terrain.py:511-516)
     if (lane < RNB)
         for (int k = 0; k < 3; ++k) t.init_pose[((long)env * RNB + lane) * 3 + k] = s.rb_state[((long)env * RNB + lane) * 13 + k];
     if (lane == 0) { t.init_vel[(long)env * 2] = rvx; t.init_vel[(long)env * 2 + 1] = rvy; }
+}
+
+__device__ __forceinline__ void reset_finish_env(const EmlocoResetBufs &t, const EmlocoSimDev &s, int bi, int env, const float *u, int lane) {
+    reset_fix_height(t, s, env, lane);
+    const float *rs = s.root_state + (long)env * 13;
+    const float ipx = rs[0], ipy = rs[1];
+    const float rvx = rs[7], rvy = rs[8];
+    reset_traj_to(t, u, bi, lane, ipx, ipy, rvx, rvy, rs[9], t.traj_verts + (long)env * RNV * 3, t.inverted + env,
+                  t.waypoint_traj + (long)env * EMLOCO_TRAJ_SAMPLES * 3);
+    reset_capture_pose(t, s, env, lane, rvx, rvy);
 }
 
 __global__ void __launch_bounds__(64)
@@ -367,7 +393,7 @@ traj_reset_kernel(EmlocoResetBufs t, const int32_t *ids, int n, const float *rnd
         if (env < 0) break;
         __shared__ float sh_v[RNV][3];
         const float *ip = init_pos + (long)bi * 3, *rv = root_vel + (long)bi * 3;
-        reset_trajectory(t, rnd + (long)bi * EMLOCO_RESET_RND, bi, env, lane, ip[0], ip[1], rv[0], rv[1], rv[2], sh_v);
+        reset_trajectory(t, rnd + (long)bi * EMLOCO_RESET_RND, bi, t.inverted + env, lane, ip[0], ip[1], rv[0], rv[1], rv[2], sh_v);
         float *vout = t.traj_verts + (long)env * RNV * 3;
         for (int i = lane; i < RNV * 3; i += 64) vout[i] = (&sh_v[0][0])[i];
         __syncthreads();                              // LDS is reused by the next list entry
@@ -376,7 +402,7 @@ traj_reset_kernel(EmlocoResetBufs t, const int32_t *ids, int n, const float *rnd
 
 // ---- e. AMP history rows 1..14 from the motion library at t - k dt (humanoid_amp.py:486-535): one workgroup per
 // (finished env, history row) -- the rows are independent, a single wave walking all 14 was the longest serial path of a reset.
-__device__ __forceinline__ void reset_amp_history_row(const EmlocoResetBufs &t, int env, int k, int mid, float mt, int lane) {
+__device__ __forceinline__ void reset_amp_history_row_to(const EmlocoResetBufs &t, const float *betas, float *out, int k, int mid, float mt, int lane) {
     __shared__ float sh_root[13], sh_dp[RNDOF], sh_dv[RNDOF], sh_key[12];
     const FrameBlend fb = frame_blend(t, mid, mt - t.dt * (float)k);
     if (lane >= 1 && lane < RNB) {
@@ -402,8 +428,10 @@ __device__ __forceinline__ void reset_amp_history_row(const EmlocoResetBufs &t, 
             sh_key[lane * 3 + c] = lerp1(t.gts[(fb.f0 * RNB + kb) * 3 + c], t.gts[(fb.f1 * RNB + kb) * 3 + c], fb.blend);
     }
     __syncthreads();
-    amp_row(lane, sh_root, sh_root + 3, sh_root + 7, sh_root + 10, sh_dp, sh_dv, 1, sh_key, t.betas + (long)env * 17,
-            t.dof_subset, t.n_dof_subset, t.amp_obs_buf + ((long)env * EMLOCO_AMP_STEPS + k) * EMLOCO_AMP_ROW);
+    amp_row(lane, sh_root, sh_root + 3, sh_root + 7, sh_root + 10, sh_dp, sh_dv, 1, sh_key, betas, t.dof_subset, t.n_dof_subset, out);
+}
+__device__ __forceinline__ void reset_amp_history_row(const EmlocoResetBufs &t, int env, int k, int mid, float mt, int lane) {
+    reset_amp_history_row_to(t, t.betas + (long)env * 17, t.amp_obs_buf + ((long)env * EMLOCO_AMP_STEPS + k) * EMLOCO_AMP_ROW, k, mid, mt, lane);
 }
 
 __global__ void __launch_bounds__(64)

@@ -209,6 +209,10 @@ int emloco_task_compact_done_order(EmlocoSim *sim, const int64_t *dev_flags, int
     return 0;
 }
 
+int emloco_task_reset_obs_pooled(EmlocoSim *sim, const EmlocoResetBufs *rb, const EmlocoTaskBufs *pb, int live_mode, const int64_t *dev_skip,
+                                 const int32_t *dev_env_ids, int n, uint64_t seed, float *dev_rnd_ws, const float *dev_rnd,
+                                 const EmlocoResetPool *pool, void *stream);
+
 // internal diagnostic (not in the header): the first call allocates 16 wall-clock stamps (100 MHz) that every later
 // emloco_task_reset_obs launch overwrites -- [0..5] reset slot 0: start, random row, sample, kinematics, finish, observations;
 // [6, 7] last AMP history row of entry 0; [8, 9] / [10, 11] the observation workgroups of env 0 / the last env -- and copies them out
@@ -221,7 +225,15 @@ int emloco_task_chain_profile(long long *host16) {
 
 int emloco_task_reset_obs(EmlocoSim *sim, const EmlocoResetBufs *rb, const EmlocoTaskBufs *pb, int live_mode, const int64_t *dev_skip,
                           const int32_t *dev_env_ids, int n, uint64_t seed, float *dev_rnd_ws, const float *dev_rnd, void *stream) {
+    return emloco_task_reset_obs_pooled(sim, rb, pb, live_mode, dev_skip, dev_env_ids, n, seed, dev_rnd_ws, dev_rnd, nullptr, stream);
+}
+
+int emloco_task_reset_obs_pooled(EmlocoSim *sim, const EmlocoResetBufs *rb, const EmlocoTaskBufs *pb, int live_mode, const int64_t *dev_skip,
+                                 const int32_t *dev_env_ids, int n, uint64_t seed, float *dev_rnd_ws, const float *dev_rnd,
+                                 const EmlocoResetPool *pool, void *stream) {
     if (!sim || !rb || !pb || !dev_env_ids) return tfail(-1, "emloco_task_reset_obs: null argument");
+    if (pool && (pool->k < 0 || pool->k > 4096 || (pool->k > 0 && ((pool->cur && !pool->cur_tag) || (pool->next && !pool->next_tag)))))
+        return tfail(-1, "emloco_task_reset_obs: bad pool (k in [0, 4096], every pool buffer with its tag array)");
     if (!sim->prepared) return tfail(-3, "emloco_task_reset_obs: sim not prepared");
     if (n < 0 || n > sim->n_env) return tfail(-1, "emloco_task_reset_obs: bad env count");
     if (!dev_rnd && !dev_rnd_ws) return tfail(-1, "emloco_task_reset_obs: neither random rows nor a workspace for them");
@@ -244,6 +256,7 @@ int emloco_task_reset_obs(EmlocoSim *sim, const EmlocoResetBufs *rb, const Emloc
     emloco::ChainArgs a;
     a.n = n;
     a.n_slots = n < 256 ? (n > 0 ? n : 1) : 256;
+    a.h_slots = n < 256 ? (n > 0 ? n : 1) : 256;
     a.n_hist = (b->flags & EMLOCO_RESET_NO_AMP_HISTORY) ? 0 : EMLOCO_AMP_STEPS - 1;
     a.live_mode = live_mode & ~EMLOCO_POST_SKIP_DONE;
     a.reset_mode = EMLOCO_POST_OBS | EMLOCO_POST_AMP_ROW;
@@ -251,13 +264,20 @@ int emloco_task_reset_obs(EmlocoSim *sim, const EmlocoResetBufs *rb, const Emloc
     a.seed_lo = (unsigned)(seed & 0xffffffffu); a.seed_hi = (unsigned)(seed >> 32);
     a.ids = dev_env_ids; a.skip = dev_skip; a.rnd_in = dev_rnd; a.rnd_ws = dev_rnd_ws;
     a.prof = g_chain_prof;
+    const bool pooled = pool && pool->k > 0 && a.seeded;
+    a.pool_k = pooled ? pool->k : 0;
+    a.pool_cur = pooled ? pool->cur : nullptr; a.tag_cur = pooled ? (const unsigned long long *)pool->cur_tag : nullptr;
+    a.pool_next = pooled ? pool->next : nullptr; a.tag_next = pooled ? (unsigned long long *)pool->next_tag : nullptr;
+    const uint64_t nseed = pooled ? pool->next_seed : 0;
+    a.nseed_lo = (unsigned)(nseed & 0xffffffffu); a.nseed_hi = (unsigned)(nseed >> 32);
+    a.next_key = (uint32_t)((nseed * 0xD6E8FEB86659FD93ull) >> 32);
     EmlocoResetBufs keyed = *rb;
     if (a.seeded) {                              // a fresh real-path permutation per call, as emloco_task_reset_seeded
         keyed.real_pick = nullptr;
         keyed.real_pick_key = (uint32_t)((seed * 0xD6E8FEB86659FD93ull) >> 32);
     }
-    const unsigned grid = (unsigned)(a.n_slots * (1 + a.n_hist) + (a.live_mode ? pb->n_env : 0));
-    if (n == 0 && !a.live_mode) return 0;
+    const unsigned grid = (unsigned)(a.n_slots + a.h_slots * a.n_hist + (a.pool_next ? a.pool_k * 2 : 0) + (a.live_mode ? pb->n_env : 0));
+    if (n == 0 && !a.live_mode && !a.pool_next) return 0;
     hipLaunchKernelGGL(emloco::reset_obs_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *pb, keyed, sim->dev, a);
     THIPCHK(hipGetLastError());
     return 0;

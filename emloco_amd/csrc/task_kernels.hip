@@ -219,12 +219,25 @@ __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mo
         ref_quat_about_z(ref_calc_heading(head + 3), hq);
         float *hobs = obs + EMLOCO_SELF_OBS + 2 * EMLOCO_TRAJ_SAMPLES;
         float *fhobs = fobs + EMLOCO_SELF_OBS + 2 * EMLOCO_TRAJ_SAMPLES;
+        // two passes: all sixteen probes of a lane first fetch their two map cells (the loads of one probe do not wait for the stores of
+        // the one before it: sixteen dependent round trips to the map were most of this kernel's latency), then the rows are written
+        const int16_t *__restrict__ hf = t.heightfield;
+        int16_t c1[EMLOCO_HEIGHT_POINTS / 64], c2[EMLOCO_HEIGHT_POINTS / 64];
+#pragma unroll
+        for (int it = 0; it < EMLOCO_HEIGHT_POINTS / 64; ++it) {
+            float wx, wy;
+            long px, py;
+            grid_probe(hq, head, lane + 64 * it, &wx, &wy);
+            map_index(t.hf_rows, t.hf_cols, wx, wy, t.hscale, &px, &py);
+            c1[it] = hf[px * t.hf_cols + py];
+            c2[it] = hf[(px + 1) * t.hf_cols + (py + 1)];
+        }
+#pragma unroll
         for (int it = 0; it < EMLOCO_HEIGHT_POINTS / 64; ++it) {
             const int idx = lane + 64 * it;
             const int i = idx >> 5, j = idx & 31;
-            float wx, wy;
-            grid_probe(hq, head, idx, &wx, &wy);
-            const float hh = sample_height(t.heightfield, t.hf_rows, t.hf_cols, wx, wy, t.hscale, t.vscale);
+            const int16_t hm = c1[it] < c2[it] ? c1[it] : c2[it];           // sample_height_at
+            const float hh = (float)hm * t.vscale;
             float v = cmean - hh;
             if (v < -3.0f) v = -3.0f;
             if (v > 3.0f) v = 3.0f;

@@ -236,13 +236,28 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
                     self._rnd_seed0 = int(torch.initial_seed()) & 0xFFFFFFFFFFFF
                 self._rnd_calls += 1
                 seed = (self._rnd_seed0 * 0x9E3779B97F4A7C15 + self._rnd_calls) & 0xFFFFFFFFFFFFFFFF
+                # the pool of pre-drawn episodes (include/emloco_task.h: EmlocoResetPool): this launch draws the first K entries of the
+                # NEXT call beside its other work, and copies the ones the previous launch drew for THIS call's seed
+                K = min(int(os.environ.get("EMLOCO_RESET_POOL", "256")), E)
+                pool = None
+                if K > 0:
+                    if getattr(self, "_pool", None) is None or self._pool[0].shape[0] != K:
+                        self._pool = [torch.zeros((K, L.POOL_FLOATS), device=dev) for _ in range(2)]
+                        self._pool_tag = [torch.zeros(K, dtype=torch.int64, device=dev) for _ in range(2)]
+                        self._pool_flip = 0
+                    c, nx = self._pool_flip, self._pool_flip ^ 1
+                    self._pool_flip = nx
+                    next_seed = (self._rnd_seed0 * 0x9E3779B97F4A7C15 + self._rnd_calls + 1) & 0xFFFFFFFFFFFFFFFF
+                    pool = L.ResetPool(K, self._pool[c].data_ptr(), self._pool_tag[c].data_ptr(), self._pool[nx].data_ptr(),
+                                       self._pool_tag[nx].data_ptr(), next_seed)
             else:
-                seed = 0
+                seed, pool = 0, None
             post_bufs = self._post_bufs if self._post_bufs is not None else self._ensure_post_bufs()
-            L.check(lib.emloco_task_reset_obs(self.sim.native._h, C.byref(self._reset_bufs), C.byref(post_bufs), int(live_mode),
-                                              C.c_void_p(self._rs_skip.data_ptr()), C.c_void_p(self._done_ids.data_ptr()), E, C.c_uint64(seed),
-                                              None if rnd is not None else C.c_void_p(self._rnd_ws.data_ptr()),
-                                              None if rnd is None else C.c_void_p(rnd.data_ptr()), st), "emloco_task_reset_obs")
+            L.check(lib.emloco_task_reset_obs_pooled(self.sim.native._h, C.byref(self._reset_bufs), C.byref(post_bufs), int(live_mode),
+                                                     C.c_void_p(self._rs_skip.data_ptr()), C.c_void_p(self._done_ids.data_ptr()), E, C.c_uint64(seed),
+                                                     None if rnd is not None else C.c_void_p(self._rnd_ws.data_ptr()),
+                                                     None if rnd is None else C.c_void_p(rnd.data_ptr()),
+                                                     None if pool is None else C.byref(pool), st), "emloco_task_reset_obs_pooled")
             if flags.init_heading and flags.heading_inversion:
                 self._traj_gen.inverted = self._inverted_u8.view(torch.bool)
             self.inverted = self._traj_gen.show_inverted()

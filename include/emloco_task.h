@@ -238,6 +238,27 @@ int emloco_task_reset_obs(struct EmlocoSim *sim, const EmlocoResetBufs *reset_bu
                           const int64_t *dev_skip, const int32_t *dev_env_ids, int n, uint64_t seed, float *dev_rnd_ws,
                           const float *dev_rnd, void *stream);
 
+/* The same launch with a pool of pre-drawn episodes.  What a reset draws (clip, joint and root state on the terrain, trajectory,
+ * LocoVal waypoints) depends on (seed, position in the list) only -- not on which env finished -- so the launch also draws the
+ * leading entries (as many as finished this step + 25 % + 32, at most k) of the NEXT call (seed `next_seed`) into `next` in
+ * workgroups of its own, and the reset chain of an entry whose slot in `cur` carries THIS call's seed copies it instead of
+ * computing it: the longest serial path of the launch loses its two longest phases.  Entries beyond the pool and slots tagged
+ * with another seed take the direct path; same bytes either way.
+ * The caller alternates two buffers: this call's `next` is the following call's `cur`.  Ignored (direct path, nothing drawn)
+ * when dev_rnd is given. */
+#define EMLOCO_POOL_FLOATS 512      /* per entry: root 13 | misc | dof 138 | trajectory 303 | waypoints 45 */
+typedef struct {
+    int32_t k;                      /* entries per pool buffer (0: no pool) */
+    const float *cur;               /* [k][EMLOCO_POOL_FLOATS] or NULL */
+    const uint64_t *cur_tag;        /* [k] seed each entry of `cur` was drawn for */
+    float *next;                    /* filled by this launch, or NULL */
+    uint64_t *next_tag;
+    uint64_t next_seed;             /* the seed the caller will pass to its next call */
+} EmlocoResetPool;
+int emloco_task_reset_obs_pooled(struct EmlocoSim *sim, const EmlocoResetBufs *reset_bufs, const EmlocoTaskBufs *task_bufs, int live_mode,
+                                 const int64_t *dev_skip, const int32_t *dev_env_ids, int n, uint64_t seed, float *dev_rnd_ws,
+                                 const float *dev_rnd, const EmlocoResetPool *pool, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

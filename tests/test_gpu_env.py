@@ -569,15 +569,18 @@ def test_observations_on_a_side_stream_give_the_same_rollout():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seeded", [False, True])
-def test_fused_chain_gives_the_same_rollout(seeded):
+@pytest.mark.parametrize("seeded,pool", [(False, 64), (True, 64), (True, 8), (True, 0)])
+def test_fused_chain_gives_the_same_rollout(seeded, pool, monkeypatch):
     """task.fused_chain: post_physics_step launches only progress / reward / flags (+ the terminal AMP rows of the finished envs),
     reset_done() is two launches -- emloco_task_compact_done_order (compaction + flag snapshot + the next step's dispatch order) and
     emloco_task_reset_obs (reset chain of the finished envs, their AMP history, their observations AND the deferred observation /
     AMP pass of the envs that did not finish).  Two identically seeded envs, one per schedule, forced and natural resets, random
     rows supplied or drawn on the device from the same seeds: every buffer bit-equal after every reset_done, the terminal AMP rows
-    after every step."""
+    after every step.  With device-drawn rows the fused launch also keeps a pool of pre-drawn episodes (EmlocoResetPool: `pool`
+    entries drawn one call ahead, copied by the reset chain; 8 < the 12 forced resets: entries beyond the pool take the direct path;
+    0: no pool) -- the separate kernels of the other env know nothing of it, the bytes must not differ."""
     from emloco_amd import _lib as L
+    monkeypatch.setenv("EMLOCO_RESET_POOL", str(pool))
     args = ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel"]
     torch.manual_seed(11)
     envs = [_make_env(96, args), _make_env(96, args)]
@@ -615,6 +618,9 @@ def test_fused_chain_gives_the_same_rollout(seeded):
         for name in ("_rigid_body_state", "rew_buf", "progress_buf", "_terminate_buf"):
             assert torch.equal(getattr(envs[0].task, name), getattr(envs[1].task, name)), (k, name, "after step")
     assert int((envs[0].task.progress_buf == 0).sum()) < 96            # natural / forced resets happened, not only the first
+    if seeded and pool > 0:                                            # the pool was in use: the last launch tagged its draw
+        t = envs[1].task
+        assert int((t._pool_tag[t._pool_flip] != 0).sum()) >= min(pool, 32)
     # a caller that never calls reset_done still gets its observations: wait_obs() launches the deferred pass
     for e in envs:
         e.task.wait_obs()

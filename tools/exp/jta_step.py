@@ -8,7 +8,7 @@ from emloco_amd.predictor.model_jta import TransMotionJTA
 from emloco_amd.predictor.train_jta import EmLocoTrainer
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 from emloco_amd.predictor import ops
-ops.set_matmul_precision(os.environ.get("JTA_PRECISION", "fp32"))
+ops.set_matmul_precision(os.environ.get("JTA_PRECISION", ops.DEFAULT_PRECISION))
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 cfg = {"DEVICE": str(dev), "MULTI_MODAL": False, "USE_FRAME_MASK": False,
