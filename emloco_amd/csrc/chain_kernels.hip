@@ -12,11 +12,11 @@
 //                            [0, S)             reset chain of list entry bi (bi = slot, slot + S, ...): random row, sample,
 //                                               kinematics, finish, observations + newest AMP row -- one wave walks the
 //                                               phases with workgroup barriers between them (the separate kernels' bodies)
-//                            then 14 Sh         AMP history row k of list entry bi (independent of the chain: the clip and its
-//                                               start time are functions of the random row alone)
-//                            then 16 K          the pool of pre-drawn episodes for the NEXT call (below)
+//                            then 2 K           the pool of pre-drawn episodes for the NEXT call (below)
 //                            then E             post-physics observations (+ AMP shift / row) of the envs that did NOT finish
 //                                               (flag snapshot), i.e. the launch that ran on the observation stream
+//                            then 14 S          AMP history row k of list entry bi (independent of the chain: the clip and its
+//                                               start time are functions of the random row alone)
 // The reset workgroups come first in dispatch order: the longest serial path of the launch starts first, the 4096 short
 // observation workgroups fill the device beside it.  Same device functions as the separate kernels -> same bytes
 // (tests/test_emu_kernels.py, tests/test_gpu_env.py).
@@ -162,9 +162,16 @@ reset_obs_kernel(EmlocoTaskBufs pt, EmlocoResetBufs rt, EmlocoSimDev s, ChainArg
         }
         return;
     }
-    int hb = b - S;
+    // dispatch order behind the chain: pool draw (long, few), the observation workgroups (4096, ~20 us each, most of the launch's
+    // work), the AMP history rows last -- ~2000 short workgroups that are not on anybody's path and fill the second round; ahead of
+    // the observation workgroups they took the first round's slots and the last observation workgroup started 34 us into the launch
     const int Sh = a.h_slots;
-    if (hb < Sh * a.n_hist) {                                       // ---- AMP history row k of the list entries slot, slot + Sh, ...
+    const int n_draw = a.pool_next ? a.pool_k * 2 : 0;
+    const int n_live = a.live_mode ? pt.n_env : 0;
+    const int rb = b - S;
+    int hb = rb - n_draw - n_live;                                  // index among the history workgroups (< 0: another role)
+    if (hb >= 0) {
+      if (hb < Sh * a.n_hist) {                                       // ---- AMP history row k of the list entries slot, slot + Sh, ...
         const int slot = hb % Sh, k = 1 + hb / Sh;
         for (int bi = slot; bi < a.n; bi += Sh) {
             const int env = a.ids[bi];
@@ -179,10 +186,10 @@ reset_obs_kernel(EmlocoTaskBufs pt, EmlocoResetBufs rt, EmlocoSimDev s, ChainArg
             __syncthreads();
             if (stamp) a.prof[7] = wall_clock64();
         }
-        return;
+      }
+      return;
     }
-    hb -= Sh * a.n_hist;
-    const int n_draw = a.pool_next ? a.pool_k * 2 : 0;
+    hb = rb;
     if (hb < n_draw) {                                              // ---- draw entry e of the NEXT call into the pool
         const int e = hb % a.pool_k, kind = hb / a.pool_k;         // kind 0: sample, 1: trajectory
         const int now = a.ids[a.n];                                 // envs that finished this step (emloco_task_compact_done*: ids[n] = count)
@@ -218,7 +225,7 @@ reset_obs_kernel(EmlocoTaskBufs pt, EmlocoResetBufs rt, EmlocoSimDev s, ChainArg
         return;
     }
     hb -= n_draw;
-    if (!a.live_mode) return;
+    if (!a.live_mode || hb >= n_live) return;
     const int env = hb;                                             // ---- observations of an env that did not finish
     if (env >= pt.n_env) return;
     if (a.skip[env] != 0) return;
