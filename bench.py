@@ -562,7 +562,7 @@ def main():
                 agent.end_epoch()
         for k in range(a.warmup):
             one_step(k)
-        task.sim.native.enable_timing(True, every=4)     # HIP events around every 4th launch of the timed region (an event record costs ~5 us of stream time)
+        task.sim.native.enable_timing(True, every=8)     # HIP events around every 8th launch of the timed region (an event record costs ~6 us of stream time)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -593,7 +593,7 @@ def main():
         agent._sync_fit()
         for k in range(a.warmup):
             env.reset_done(); env.step(pool[k % 64])
-        task.sim.native.enable_timing(True, every=4)
+        task.sim.native.enable_timing(True, every=8)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for k in range(a.steps):
@@ -669,7 +669,7 @@ def main():
                          "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l,
                          "from_profiles": {"valu_busy_frac": prof.get("valu_busy_frac"), "source": f"profiles/{PROFILE_ROUND}_sim_step_valu.txt (committed SQ-counter pass; NOT measured in this run)"},
                          "note": "achieved = algorithmic bytes (9 296 B per env per launch, DESIGN.md section 5) / kernel_ms, both live: HIP events on "
-                                 "every 4th launch of the timed region.  The kernel is instruction / latency bound, not bandwidth bound: ~9 KB of state "
+                                 "every 8th launch of the timed region.  The kernel is instruction / latency bound, not bandwidth bound: ~9 KB of state "
                                  "per env per launch against ~47 k fp32 VALU wave-instructions (level-synchronous tree passes; 3 waves per SIMD, 12 envs "
                                  "per CU; each env's 4 substeps run as four dependent workgroups of one launch)"},
         }

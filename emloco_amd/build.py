@@ -17,13 +17,19 @@ LIB = os.path.join(LIBDIR, "libemloco_hip.so")
 
 # translation units: (source, extra flags).  The rollout kernels are built without fused-multiply-add
 # contraction so that fp32 body states track the CPU oracle's plain C arithmetic (tests/test_gpu_sim.py).
+# -fno-slp-vectorize on the rigid-body unit: the SLP vectoriser pairs the kernel's scalar fp32 arithmetic into v_pk_fma / v_pk_mul /
+# v_pk_add_f32, and the register-pair shuffling that feeds them costs more than the pairs save in this kernel (static count: 943 -> 417
+# v_mov_b32, 48 -> 0 bytes of scratch at the 168-register cap) -- measured 0.392 -> 0.351 ms per launch at 4096 envs, same bytes
+# (tests/test_gpu_sim.py); eleven further scheduler / vectoriser switches were within +-1 % or worse (tools/exp/run_flag_variants.sh).
 UNITS = [
-    ("sim_capi.hip", ["-ffp-contract=off"]),
+    ("sim_capi.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
     ("task_capi.hip", ["-ffp-contract=off"]),
-    ("predictor_capi.hip", []),
+    ("predictor_capi.hip", ["-fno-slp-vectorize"]),      # split-mode GEMMs: 183.6 -> 176.5 ms per fp32-class train step, policy 0.341 -> 0.311 ms
+    ("attention_capi.hip", []),                          # the fused attention keeps the SLP vectoriser (bf16 kernels 8-18 % slower without)
 ]
-# EMLOCO_HIPCC_EXTRA="-DFOO=1 ..." appends flags to every unit (A/B experiments)
+# EMLOCO_HIPCC_EXTRA="-DFOO=1 ..." appends flags to every unit, EMLOCO_HIPCC_EXTRA_SIM / _TASK / _PREDICTOR to one (A/B experiments)
 EXTRA = os.environ.get("EMLOCO_HIPCC_EXTRA", "").split()
+UNIT_EXTRA = {u: os.environ.get("EMLOCO_HIPCC_EXTRA_" + u.split("_")[0].upper(), "").split() for u in ("sim_capi.hip", "task_capi.hip", "predictor_capi.hip", "attention_capi.hip")}
 COMMON = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
@@ -62,7 +68,7 @@ def build(force=False, verbose=False):
         if not os.path.exists(path):
             continue
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc()] + COMMON + extra + ["-I", CSRC, "-c", path, "-o", obj]
+        cmd = [hipcc()] + COMMON + extra + UNIT_EXTRA.get(src, []) + ["-I", CSRC, "-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

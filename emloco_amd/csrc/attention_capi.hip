@@ -1,0 +1,135 @@
+// attention_capi.hip -- C ABI of the fused attention kernels (include/emloco_predictor.h), a translation unit of its own: the
+// GEMM / LayerNorm unit (predictor_capi.hip) is built with -fno-slp-vectorize (the split-mode GEMMs lose 4 % to the packed-fp32
+// pairing of their piece arithmetic), the attention kernels keep the SLP vectoriser (without it the bf16 kernels are 8-18 % slower:
+// their softmax / dropout arithmetic pairs well) -- emloco_amd/build.py.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <stdlib.h>
+#include "attention_kernels.hip"
+#include "../../include/emloco_predictor.h"
+
+namespace {
+int pfail(int code, const char *what, hipError_t e = hipSuccess) {
+    if (e != hipSuccess) fprintf(stderr, "[emloco] %s: %s\n", what, hipGetErrorString(e));
+    else fprintf(stderr, "[emloco] %s\n", what);
+    return code;
+}
+}  // namespace
+
+#define PHIPCHK(expr)                                                  \
+    do {                                                               \
+        hipError_t e_ = (expr);                                        \
+        if (e_ != hipSuccess) return pfail(-2, #expr, e_);             \
+    } while (0)
+
+extern "C" {
+
+int emloco_attention_fwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                         float *out, float *lse, void *stream) {
+    return emloco_attention_fwd_ex(n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, 0, stream);
+}
+
+int emloco_attention_fwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                            float *out, float *lse, int flags, void *stream) {
+    return emloco_attention_fwd_dropout(n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, flags, 0.0f, 0u, stream);
+}
+
+int emloco_attention_fwd_dropout(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 float *out, float *lse, int flags, float drop_p, uint32_t drop_seed, void *stream) {
+    return emloco_attention_fwd_queries(n_seq, S, S, nhead, d_model, scale, qkv, key_bias, out, lse, flags, drop_p, drop_seed, stream);
+}
+
+int emloco_attention_fwd_queries(int n_seq, int S, int n_query, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 float *out, float *lse, int flags, float drop_p, uint32_t drop_seed, void *stream) {
+    if (n_query < 1 || n_query > S) return pfail(-1, "emloco_attention_fwd: n_query must be in [1, S]");
+    if (n_seq < 1 || S < 1 || nhead < 1 || d_model != nhead * AT_DH || !qkv || !out || !lse || !(drop_p >= 0.0f && drop_p < 1.0f))
+        return pfail(-1, "emloco_attention_fwd: bad argument (head dim must be 32, 0 <= drop_p < 1)");
+    if ((long)n_seq * nhead > 65535) return pfail(-1, "emloco_attention_fwd: n_seq * nhead exceeds the grid limit");
+    emloco::AttnArgs a{n_seq, S, nhead, d_model, n_query, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr, drop_p, 1.0f / (1.0f - drop_p), drop_seed, (unsigned)(drop_p * 16777216.0f)};
+    const dim3 grid((unsigned)((n_query + 127) / 128), (unsigned)(n_seq * nhead));
+    const bool bf = (flags & EMLOCO_ATTN_BF16) != 0, dr = drop_p > 0.0f;
+    hipStream_t st = (hipStream_t)stream;
+    if (flags & EMLOCO_ATTN_QKV_BF16MEM) {
+        if (!bf) return pfail(-1, "emloco_attention_fwd: a bf16 q|k|v tensor needs EMLOCO_ATTN_BF16");
+        if (dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 1, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 0, 1>), grid, dim3(256), 0, st, a);
+        PHIPCHK(hipGetLastError());
+        return 0;
+    }
+    if (bf && dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    else if (bf) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 0>), grid, dim3(256), 0, st, a);
+    else if (dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<0, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((emloco::attn_fwd_kernel<0, 0>), grid, dim3(256), 0, st, a);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_attention_bwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                         const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, void *stream) {
+    return emloco_attention_bwd_ex(n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, dout, dqkv, dsum, 0, stream);
+}
+
+int emloco_attention_bwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                            const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags, void *stream) {
+    return emloco_attention_bwd_dropout(n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, dout, dqkv, dsum, flags, 0.0f, 0u, stream);
+}
+
+int emloco_attention_bwd_dropout(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags,
+                                 float drop_p, uint32_t drop_seed, void *stream) {
+    return emloco_attention_bwd_queries(n_seq, S, S, nhead, d_model, scale, qkv, key_bias, out, lse, dout, dqkv, dsum, flags, drop_p, drop_seed, stream);
+}
+
+int emloco_attention_bwd_queries(int n_seq, int S, int n_query, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
+                                 const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags,
+                                 float drop_p, uint32_t drop_seed, void *stream) {
+    if (n_query < 1 || n_query > S) return pfail(-1, "emloco_attention_bwd: n_query must be in [1, S]");
+    if (n_seq < 1 || S < 1 || nhead < 1 || d_model != nhead * AT_DH || !qkv || !out || !lse || !dout || !dqkv || !dsum ||
+        !(drop_p >= 0.0f && drop_p < 1.0f))
+        return pfail(-1, "emloco_attention_bwd: bad argument (head dim must be 32; dsum = n_seq * nhead * S floats; 0 <= drop_p < 1)");
+    if ((long)n_seq * nhead > 65535) return pfail(-1, "emloco_attention_bwd: n_seq * nhead exceeds the grid limit");
+    emloco::AttnArgs a{n_seq, S, nhead, d_model, n_query, scale, qkv, key_bias, const_cast<float *>(out), const_cast<float *>(lse), dout, dqkv, dsum,
+                       drop_p, 1.0f / (1.0f - drop_p), drop_seed, (unsigned)(drop_p * 16777216.0f)};
+    const dim3 grid((unsigned)((S + 127) / 128), (unsigned)(n_seq * nhead)), qgrid((unsigned)((n_query + 127) / 128), (unsigned)(n_seq * nhead));
+    const bool bf = (flags & EMLOCO_ATTN_BF16) != 0, dr = drop_p > 0.0f;
+    hipStream_t st = (hipStream_t)stream;
+    const bool q16 = (flags & EMLOCO_ATTN_QKV_BF16MEM) != 0;
+    if (q16 && !bf) return pfail(-1, "emloco_attention_bwd: a bf16 q|k|v tensor needs EMLOCO_ATTN_BF16");
+    const size_t esz = q16 ? 2 : sizeof(float);
+    // rows that do not attend get dQ = 0 (the Q third of every dqkv row; the live rows are overwritten below)
+    if (n_query < S) PHIPCHK(hipMemset2DAsync(dqkv, 3 * (size_t)d_model * esz, 0, (size_t)d_model * esz, (size_t)n_seq * S, st));
+    if (q16) {
+        if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 1, 1>), qgrid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 0, 1>), qgrid, dim3(256), 0, st, a);
+        PHIPCHK(hipGetLastError());
+        if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 1, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 0, 1>), grid, dim3(256), 0, st, a);
+        PHIPCHK(hipGetLastError());
+        return 0;
+    }
+    // first kernel: dQ, also writes D = rowsum(dO o O); second: dK, dV
+    if (bf && dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 1>), qgrid, dim3(256), 0, st, a);
+    else if (bf) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 0>), qgrid, dim3(256), 0, st, a);
+    else if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<0, 1>), qgrid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<0, 0>), qgrid, dim3(256), 0, st, a);
+    PHIPCHK(hipGetLastError());
+    if (bf && dr) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    else if (bf) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 0>), grid, dim3(256), 0, st, a);
+    else if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<0, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<0, 0>), grid, dim3(256), 0, st, a);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_attention_keep_mask(uint32_t seed, int n_seq_heads, int S, float p, uint8_t *host_out) {
+    if (n_seq_heads < 1 || S < 1 || !host_out || !(p >= 0.0f && p < 1.0f)) return pfail(-1, "emloco_attention_keep_mask: bad argument");
+    const unsigned thr = (unsigned)(p * 16777216.0f);
+    for (int bh = 0; bh < n_seq_heads; ++bh) {
+        const unsigned hk = emloco::at_head_key(seed, (unsigned)bh);
+        for (int q = 0; q < S; ++q)
+            for (int k = 0; k < S; ++k) host_out[((size_t)bh * S + q) * S + k] = emloco::at_keep_bit(hk, (unsigned)q, (unsigned)k, thr) ? 1 : 0;
+    }
+    return 0;
+}
+
+}  // extern "C"

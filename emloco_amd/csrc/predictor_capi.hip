@@ -5,7 +5,6 @@
 #include <stdlib.h>
 #include <vector>
 #include "predictor_kernels.hip"
-#include "attention_kernels.hip"
 #include "../../include/emloco_predictor.h"
 
 namespace {
@@ -225,103 +224,6 @@ int emloco_gemm_relu_bwd(int m, int n, int k, const float *A, int lda, const flo
     return 0;
 }
 
-int emloco_attention_fwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
-                         float *out, float *lse, void *stream) {
-    return emloco_attention_fwd_ex(n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, 0, stream);
-}
-
-int emloco_attention_fwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
-                            float *out, float *lse, int flags, void *stream) {
-    return emloco_attention_fwd_dropout(n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, flags, 0.0f, 0u, stream);
-}
-
-int emloco_attention_fwd_dropout(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
-                                 float *out, float *lse, int flags, float drop_p, uint32_t drop_seed, void *stream) {
-    return emloco_attention_fwd_queries(n_seq, S, S, nhead, d_model, scale, qkv, key_bias, out, lse, flags, drop_p, drop_seed, stream);
-}
-
-int emloco_attention_fwd_queries(int n_seq, int S, int n_query, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
-                                 float *out, float *lse, int flags, float drop_p, uint32_t drop_seed, void *stream) {
-    if (n_query < 1 || n_query > S) return pfail(-1, "emloco_attention_fwd: n_query must be in [1, S]");
-    if (n_seq < 1 || S < 1 || nhead < 1 || d_model != nhead * AT_DH || !qkv || !out || !lse || !(drop_p >= 0.0f && drop_p < 1.0f))
-        return pfail(-1, "emloco_attention_fwd: bad argument (head dim must be 32, 0 <= drop_p < 1)");
-    if ((long)n_seq * nhead > 65535) return pfail(-1, "emloco_attention_fwd: n_seq * nhead exceeds the grid limit");
-    emloco::AttnArgs a{n_seq, S, nhead, d_model, n_query, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr, drop_p, 1.0f / (1.0f - drop_p), drop_seed, (unsigned)(drop_p * 16777216.0f)};
-    const dim3 grid((unsigned)((n_query + 127) / 128), (unsigned)(n_seq * nhead));
-    const bool bf = (flags & EMLOCO_ATTN_BF16) != 0, dr = drop_p > 0.0f;
-    hipStream_t st = (hipStream_t)stream;
-    if (flags & EMLOCO_ATTN_QKV_BF16MEM) {
-        if (!bf) return pfail(-1, "emloco_attention_fwd: a bf16 q|k|v tensor needs EMLOCO_ATTN_BF16");
-        if (dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 1, 1>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 0, 1>), grid, dim3(256), 0, st, a);
-        PHIPCHK(hipGetLastError());
-        return 0;
-    }
-    if (bf && dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 1>), grid, dim3(256), 0, st, a);
-    else if (bf) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 0>), grid, dim3(256), 0, st, a);
-    else if (dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<0, 1>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((emloco::attn_fwd_kernel<0, 0>), grid, dim3(256), 0, st, a);
-    PHIPCHK(hipGetLastError());
-    return 0;
-}
-
-int emloco_attention_bwd(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
-                         const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, void *stream) {
-    return emloco_attention_bwd_ex(n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, dout, dqkv, dsum, 0, stream);
-}
-
-int emloco_attention_bwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
-                            const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags, void *stream) {
-    return emloco_attention_bwd_dropout(n_seq, S, nhead, d_model, scale, qkv, key_bias, out, lse, dout, dqkv, dsum, flags, 0.0f, 0u, stream);
-}
-
-int emloco_attention_bwd_dropout(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
-                                 const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags,
-                                 float drop_p, uint32_t drop_seed, void *stream) {
-    return emloco_attention_bwd_queries(n_seq, S, S, nhead, d_model, scale, qkv, key_bias, out, lse, dout, dqkv, dsum, flags, drop_p, drop_seed, stream);
-}
-
-int emloco_attention_bwd_queries(int n_seq, int S, int n_query, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
-                                 const float *out, const float *lse, const float *dout, float *dqkv, float *dsum, int flags,
-                                 float drop_p, uint32_t drop_seed, void *stream) {
-    if (n_query < 1 || n_query > S) return pfail(-1, "emloco_attention_bwd: n_query must be in [1, S]");
-    if (n_seq < 1 || S < 1 || nhead < 1 || d_model != nhead * AT_DH || !qkv || !out || !lse || !dout || !dqkv || !dsum ||
-        !(drop_p >= 0.0f && drop_p < 1.0f))
-        return pfail(-1, "emloco_attention_bwd: bad argument (head dim must be 32; dsum = n_seq * nhead * S floats; 0 <= drop_p < 1)");
-    if ((long)n_seq * nhead > 65535) return pfail(-1, "emloco_attention_bwd: n_seq * nhead exceeds the grid limit");
-    emloco::AttnArgs a{n_seq, S, nhead, d_model, n_query, scale, qkv, key_bias, const_cast<float *>(out), const_cast<float *>(lse), dout, dqkv, dsum,
-                       drop_p, 1.0f / (1.0f - drop_p), drop_seed, (unsigned)(drop_p * 16777216.0f)};
-    const dim3 grid((unsigned)((S + 127) / 128), (unsigned)(n_seq * nhead)), qgrid((unsigned)((n_query + 127) / 128), (unsigned)(n_seq * nhead));
-    const bool bf = (flags & EMLOCO_ATTN_BF16) != 0, dr = drop_p > 0.0f;
-    hipStream_t st = (hipStream_t)stream;
-    const bool q16 = (flags & EMLOCO_ATTN_QKV_BF16MEM) != 0;
-    if (q16 && !bf) return pfail(-1, "emloco_attention_bwd: a bf16 q|k|v tensor needs EMLOCO_ATTN_BF16");
-    const size_t esz = q16 ? 2 : sizeof(float);
-    // rows that do not attend get dQ = 0 (the Q third of every dqkv row; the live rows are overwritten below)
-    if (n_query < S) PHIPCHK(hipMemset2DAsync(dqkv, 3 * (size_t)d_model * esz, 0, (size_t)d_model * esz, (size_t)n_seq * S, st));
-    if (q16) {
-        if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 1, 1>), qgrid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 0, 1>), qgrid, dim3(256), 0, st, a);
-        PHIPCHK(hipGetLastError());
-        if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 1, 1>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 0, 1>), grid, dim3(256), 0, st, a);
-        PHIPCHK(hipGetLastError());
-        return 0;
-    }
-    // first kernel: dQ, also writes D = rowsum(dO o O); second: dK, dV
-    if (bf && dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 1>), qgrid, dim3(256), 0, st, a);
-    else if (bf) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 0>), qgrid, dim3(256), 0, st, a);
-    else if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<0, 1>), qgrid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<0, 0>), qgrid, dim3(256), 0, st, a);
-    PHIPCHK(hipGetLastError());
-    if (bf && dr) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 1>), grid, dim3(256), 0, st, a);
-    else if (bf) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 0>), grid, dim3(256), 0, st, a);
-    else if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<0, 1>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<0, 0>), grid, dim3(256), 0, st, a);
-    PHIPCHK(hipGetLastError());
-    return 0;
-}
-
 int emloco_act_bwd_colsum(int m, int n, const float *dy, const float *y, int relu, float drop_p, uint32_t drop_seed, float *dz,
                           float *colsum, float *workspace, void *stream) {
     if (m < 1 || n < 1 || !dy || !dz || !colsum || !workspace || (relu && !y) || !(drop_p >= 0.0f && drop_p < 1.0f))
@@ -426,17 +328,6 @@ int emloco_adamw_gated(int n, float *params, const float *grads, float *exp_avg,
     hipLaunchKernelGGL(emloco::adamw_gated_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, params, grads,
                        exp_avg, exp_avg_sq, steps_in, steps_out, tail2, lr, beta1, beta2, eps, weight_decay, stats);
     PHIPCHK(hipGetLastError());
-    return 0;
-}
-
-int emloco_attention_keep_mask(uint32_t seed, int n_seq_heads, int S, float p, uint8_t *host_out) {
-    if (n_seq_heads < 1 || S < 1 || !host_out || !(p >= 0.0f && p < 1.0f)) return pfail(-1, "emloco_attention_keep_mask: bad argument");
-    const unsigned thr = (unsigned)(p * 16777216.0f);
-    for (int bh = 0; bh < n_seq_heads; ++bh) {
-        const unsigned hk = emloco::at_head_key(seed, (unsigned)bh);
-        for (int q = 0; q < S; ++q)
-            for (int k = 0; k < S; ++k) host_out[((size_t)bh * S + q) * S + k] = emloco::at_keep_bit(hk, (unsigned)q, (unsigned)k, thr) ? 1 : 0;
-    }
     return 0;
 }
 
