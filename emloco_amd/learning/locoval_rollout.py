@@ -127,7 +127,7 @@ class LocoValRollout:
         # The fit (forward, loss gradient, backward, all-reduce, AdamW: ~75 us of small launches) only reads what the returns
         # kernel staged (traj13 / pose / vel / target / weight), so it runs on a side stream while the main stream goes on to
         # reset the finished envs and to launch the next physics step; the next returns kernel waits for it.
-        self._side = torch.cuda.Stream(device=dev) if (self.overlap_fit and torch.device(dev).type == "cuda") else None
+        self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("EMLOCO_FIT_PRIORITY", "0"))) if (self.overlap_fit and torch.device(dev).type == "cuda") else None
         self._ev_staged = torch.cuda.Event() if self._side is not None else None
         self._ev_fit = torch.cuda.Event() if self._side is not None else None
         self._fit_pending = False
