@@ -660,7 +660,8 @@ def main():
                                    "(episode ages pre-staggered), inside the LocoVal-training loop of configs[2] (returns bookkeeping + LocoVal "
                                    "fit + gradient all-reduce every step), policy network excluded (its forward is the `policy` leg); "
                                    "schedule: the reference's order (reset chain of the finished envs, observations, then ONE rigid-body launch "
-                                   "for all envs, dispatched most-contact-work-first) -- what a policy that reads the observations can use",
+                                   "for all envs, dispatched most-contact-work-first) -- what a policy that reads the observations can use; "
+                                   "the launches between two rigid-body steps folded into four on one stream (task.fused_chain)",
                        "locoval": {"episodes_fitted": fitted, "last_fit_loss": round(vloss, 5), "exchange_floats_per_step": 6176},
                        "num_envs_per_gpu": E, "substeps_per_step": 4, "workgroups_per_env": n_parts, "parallelism": f"env-sharded x{world}" + (" (TEST MODE: all ranks share cuda:0, gloo)" if share else "")},
             "roofline": {"bound": "hbm", "kernel": "sim_step_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
@@ -671,7 +672,7 @@ def main():
                          "note": "achieved = algorithmic bytes (9 296 B per env per launch, DESIGN.md section 5) / kernel_ms, both live: HIP events on "
                                  "every 8th launch of the timed region.  The kernel is instruction / latency bound, not bandwidth bound: ~9 KB of state "
                                  "per env per launch against ~47 k fp32 VALU wave-instructions (level-synchronous tree passes; 3 waves per SIMD, 12 envs "
-                                 "per CU; each env's 4 substeps run as four dependent workgroups of one launch)"},
+                                 "per CU; each env's 4 substeps run as four dependent workgroups of one launch); VALU busy 93 % of the SIMD-cycles"},
         }
         if env_only is not None:
             k_alone = ms_s / max(n_s, 1)
