@@ -132,6 +132,12 @@ __device__ __forceinline__ void quat2rotvec(const float *qin, float *e) {
 // the terrain probes comes from these, so the map indices (p / 0.1).long() are identical across the three.
 __device__ __forceinline__ float cr_sinf(float x) { return (float)sin((double)x); }
 __device__ __forceinline__ float cr_cosf(float x) { return (float)cos((double)x); }
+// both at once (one argument reduction): the double results are the ones sin() / cos() give, rounded the same way
+__device__ __forceinline__ void cr_sincosf(float x, float *s, float *c) {
+    double ds, dc;
+    sincos((double)x, &ds, &dc);
+    *s = (float)ds; *c = (float)dc;
+}
 __device__ __forceinline__ float cr_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
 __device__ __forceinline__ float cr_acosf(float x) { return (float)acos((double)x); }
 
@@ -174,7 +180,8 @@ __device__ __forceinline__ void ref_quat_apply(const float *a, const float *b, f
 // quat_from_angle_axis about +z: normalize(axis) = z, then the quaternion is re-normalised
 __device__ __forceinline__ void ref_quat_about_z(float angle, float *o) {
     float th = angle / 2.0f;
-    float s = cr_sinf(th), c = cr_cosf(th);
+    float s, c;
+    cr_sincosf(th, &s, &c);
     float n = sqrtf(s * s + c * c);
     if (n < 1e-9f) n = 1e-9f;
     o[0] = 0.0f / n; o[1] = 0.0f / n; o[2] = s / n; o[3] = c / n;
@@ -193,7 +200,7 @@ __device__ __forceinline__ void ref_quat_to_tan_norm(const float *q, float *o6) 
 __device__ __forceinline__ void ref_exp_map_to_quat(const float *e, float *o) {
     float angle = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
     float ax[3] = {e[0] / angle, e[1] / angle, e[2] / angle};
-    angle = cr_atan2f(cr_sinf(angle), cr_cosf(angle));
+    { float sa, ca; cr_sincosf(angle, &sa, &ca); angle = cr_atan2f(sa, ca); }
     if (!(fabsf(angle) > 1e-5f)) { angle = 0.0f; ax[0] = 0.0f; ax[1] = 0.0f; ax[2] = 1.0f; }
     float n = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
     if (n < 1e-9f) n = 1e-9f;
@@ -247,7 +254,7 @@ __device__ __forceinline__ void ref_slerp(const float *q0, const float *q1in, fl
 __device__ __forceinline__ void ref_quat_to_exp_map(const float *q, float *o) {
     const float sin_theta = sqrtf(1.0f - q[3] * q[3]);
     float angle = 2.0f * cr_acosf(q[3]);
-    angle = cr_atan2f(cr_sinf(angle), cr_cosf(angle));
+    { float sa, ca; cr_sincosf(angle, &sa, &ca); angle = cr_atan2f(sa, ca); }
     if (fabsf(sin_theta) > 1e-5f) {
         o[0] = angle * (q[0] / sin_theta); o[1] = angle * (q[1] / sin_theta); o[2] = angle * (q[2] / sin_theta);
     } else { o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; }

@@ -36,23 +36,30 @@ __device__ __forceinline__ void calc_pos(const float *verts, float time, float t
 }
 
 // humanoid_pedestrain_terrain.py:1212-1218 world_points_to_map: (p / horizontal_scale).long(), clipped to [0, shape - 2]
-__device__ __forceinline__ void map_index(int rows, int cols, float x, float y, float hscale, long *opx, long *opy) {
-    long px = (long)(x / hscale);
-    long py = (long)(y / hscale);
-    if (px < 0) px = 0;
-    if (px > rows - 2) px = rows - 2;
-    if (py < 0) py = 0;
-    if (py > cols - 2) py = cols - 2;
-    *opx = px; *opy = py;
+// (32-bit: a float -> int64 conversion is ~15 instructions with double-precision steps on this target, 41 of them per env.  The
+// quotient is clamped to [-1, shape] as a float first, so the truncation never leaves the int range and the result equals the
+// 64-bit form's for every input: below -1 -> 0, above shape -> shape - 2, NaN -> 0.)
+__device__ __forceinline__ int map_index1(float x, float hscale, int n) {
+    float v = x / hscale;
+    v = v > -1.0f ? v : -1.0f;                     // NaN -> -1
+    v = v < (float)n ? v : (float)n;
+    int p = (int)v;
+    if (p < 0) p = 0;
+    if (p > n - 2) p = n - 2;
+    return p;
+}
+__device__ __forceinline__ void map_index(int rows, int cols, float x, float y, float hscale, int *opx, int *opy) {
+    *opx = map_index1(x, hscale, rows);
+    *opy = map_index1(y, hscale, cols);
 }
 // :1282-1288 sample_height_points: min of the cell's two diagonal corners
-__device__ __forceinline__ float sample_height_at(const int16_t *hf, int cols, long px, long py, float vscale) {
+__device__ __forceinline__ float sample_height_at(const int16_t *hf, int cols, int px, int py, float vscale) {
     const int16_t h1 = hf[px * cols + py], h2 = hf[(px + 1) * cols + (py + 1)];
     const int16_t hm = h1 < h2 ? h1 : h2;
     return (float)hm * vscale;
 }
 __device__ __forceinline__ float sample_height(const int16_t *hf, int rows, int cols, float x, float y, float hscale, float vscale) {
-    long px, py;
+    int px, py;
     map_index(rows, cols, x, y, hscale, &px, &py);
     return sample_height_at(hf, cols, px, py, vscale);
 }
@@ -226,7 +233,7 @@ __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mo
 #pragma unroll
         for (int it = 0; it < EMLOCO_HEIGHT_POINTS / 64; ++it) {
             float wx, wy;
-            long px, py;
+            int px, py;
             grid_probe(hq, head, lane + 64 * it, &wx, &wy);
             map_index(t.hf_rows, t.hf_cols, wx, wy, t.hscale, &px, &py);
             c1[it] = hf[px * t.hf_cols + py];
@@ -387,7 +394,7 @@ get_heights_kernel(const int16_t *hf, int rows, int cols, float hscale, float vs
     if (grid) ref_quat_about_z(ref_calc_heading(p + 3), hq);
     for (int idx = lane; idx < np; idx += 64) {
         float wx, wy;
-        long px, py;
+        int px, py;
         if (grid) grid_probe(hq, p, idx, &wx, &wy);
         else center_probe(p, p + 3, idx, &wx, &wy);
         map_index(rows, cols, wx, wy, hscale, &px, &py);
