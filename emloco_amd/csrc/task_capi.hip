@@ -223,6 +223,21 @@ int emloco_task_chain_profile(long long *host16) {
     return 0;
 }
 
+#ifdef EMLOCO_POST_PROFILE
+// internal diagnostic (builds with -DEMLOCO_POST_PROFILE only): 8 wall-clock stamps of the last env's post-physics workgroup
+int emloco_task_post_profile(long long *host8) {
+    static long long *buf = nullptr;
+    if (!buf) {
+        THIPCHK(hipMalloc((void **)&buf, 8 * sizeof(long long)));
+        THIPCHK(hipMemset(buf, 0, 8 * sizeof(long long)));
+        THIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(emloco::g_post_prof), &buf, sizeof(buf)));
+    }
+    THIPCHK(hipDeviceSynchronize());
+    if (host8) THIPCHK(hipMemcpy(host8, buf, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+
 int emloco_task_reset_obs(EmlocoSim *sim, const EmlocoResetBufs *rb, const EmlocoTaskBufs *pb, int live_mode, const int64_t *dev_skip,
                           const int32_t *dev_env_ids, int n, uint64_t seed, float *dev_rnd_ws, const float *dev_rnd, void *stream) {
     return emloco_task_reset_obs_pooled(sim, rb, pb, live_mode, dev_skip, dev_env_ids, n, seed, dev_rnd_ws, dev_rnd, nullptr, stream);

@@ -151,7 +151,14 @@ __device__ __forceinline__ void amp_row(int lane, const float *root_pos, const f
 
 // The post-physics work of ONE env by one wave (every early return is wave-uniform): post_physics_kernel below and the
 // observation roles of reset_obs_kernel (chain_kernels.hip) run this body.
+#ifdef EMLOCO_POST_PROFILE
+__device__ long long *g_post_prof = nullptr;
+#define PPSTAMP(i) do { if (g_post_prof && lane == 0 && env == t.n_env - 1) g_post_prof[i] = wall_clock64(); } while (0)
+#else
+#define PPSTAMP(i) do { } while (0)
+#endif
 __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mode, int env, int lane) {
+    PPSTAMP(0);
     __shared__ float sh_body[TNB][13];
     __shared__ float sh_samp[EMLOCO_TRAJ_SAMPLES][3];
     __shared__ float sh_center[9];
@@ -175,6 +182,7 @@ __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mo
         for (int k = 0; k < 3; ++k) sh_samp[lane][k] = s[k];
     }
     __syncthreads();
+    PPSTAMP(1);
     if ((mode & EMLOCO_POST_ADVANCE) && lane == 0) t.progress_buf[env] = prog;
     const float *root = sh_body[0];
 
@@ -185,6 +193,7 @@ __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mo
         ref_quat_about_z(-ref_calc_heading(root + 3), hinv);
         const float froot_rot[4] = {-root[3], root[4], -root[5], root[6]};
         ref_quat_about_z(-ref_calc_heading(froot_rot), hinv_f);
+        PPSTAMP(2);
         // ---- self obs + mirrored self obs (lane = body); staged in LDS so the row is written coalesced
         if (lane < TNB) {
             const float *bd = sh_body[lane];
@@ -218,12 +227,14 @@ __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mo
             sh_center[lane] = sample_height(t.heightfield, t.hf_rows, t.hf_cols, wx, wy, t.hscale, t.vscale);
         }
         __syncthreads();
+        PPSTAMP(3);
         for (int i = lane; i < EMLOCO_SELF_OBS; i += 64) { obs[i] = sh_obs[i]; fobs[i] = sh_fobs[i]; }
         const float cmean = mean9(sh_center);
         // ---- 32x32 height grid around the head, rotated by the head's heading (16 points per lane)
         const float *head = sh_body[t.head_body];
         float hq[4];
         ref_quat_about_z(ref_calc_heading(head + 3), hq);
+        PPSTAMP(4);
         float *hobs = obs + EMLOCO_SELF_OBS + 2 * EMLOCO_TRAJ_SAMPLES;
         float *fhobs = fobs + EMLOCO_SELF_OBS + 2 * EMLOCO_TRAJ_SAMPLES;
         // two passes: all sixteen probes of a lane first fetch their two map cells (the loads of one probe do not wait for the stores of
@@ -254,6 +265,7 @@ __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mo
         }
     }
 
+    PPSTAMP(5);
     const float *tar = sh_samp[0];
     if (mode & EMLOCO_POST_REWARD) {
         float part = 0.0f;
@@ -306,6 +318,7 @@ __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mo
             __syncthreads();
             for (int j = 0; j < PER; ++j) { const int e = lane + 64 * j; if (e < NEL) amp[EMLOCO_AMP_ROW + e] = keep[j]; }
         }
+        PPSTAMP(6);
         if (mode & EMLOCO_POST_AMP_ROW) {
             if (lane < 4) for (int k = 0; k < 3; ++k) sh_key[lane][k] = sh_body[t.key_bodies[lane]][k];
             __syncthreads();
@@ -313,6 +326,7 @@ __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mo
             amp_row(lane, root, root + 3, root + 7, root + 10, ds, ds + 1, 2, &sh_key[0][0], t.betas + (long)env * 17, t.dof_subset, t.n_dof_subset, amp);
         }
     }
+    PPSTAMP(7);
 }
 
 __global__ void __launch_bounds__(64)
