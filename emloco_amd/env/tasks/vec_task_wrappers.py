@@ -34,7 +34,12 @@ class VecTaskPython():
 
     def _obs(self):
         # clip_observations is read from the wrong dict level in the reference => inf => no clipping (parse_task.py:45)
-        o = self.task.obs_buf if np.isinf(self.clip_obs) else torch.clamp(self.task.obs_buf, -self.clip_obs, self.clip_obs)
+        if np.isinf(self.clip_obs):
+            o = self.task.obs_buf         # the live buffer: a deferred / side-stream observation pass (task.fused_chain, overlap_obs) fills it later
+        else:
+            if hasattr(self.task, "wait_obs"):
+                self.task.wait_obs()      # a clipped COPY must see the finished rows
+            o = torch.clamp(self.task.obs_buf, -self.clip_obs, self.clip_obs)
         return o.to(self.rl_device)
 
     def step(self, actions):

@@ -236,6 +236,41 @@ def test_post_physics_kernel_matches_reference_golden(golden):
     np.testing.assert_array_equal(th.amp[:, 1:], amp_before[:, :-1])
 
 
+def test_fused_launch_observation_role_equals_the_post_physics_launch(golden):
+    """reset_obs_kernel with an empty finished-env list: the workgroups behind the reset / history roles run the deferred observation /
+    AMP pass of every env whose flag-snapshot entry is zero -- the same bytes as post_physics_kernel(OBS | AMP_SHIFT | AMP_ROW |
+    SKIP_DONE) on the same state, skipped envs untouched (the split `task.fused_chain` relies on; the reset roles need a simulator
+    and are compared on the GPU: tests/test_gpu_env.py)."""
+    from emloco_amd import _lib as L
+    g, gt, gs = golden("self_obs"), golden("terrain_heights"), golden("traj_samples")
+    E = 16
+    rng = np.random.default_rng(3)
+    hosts = []
+    for _ in range(2):
+        th = emu.TaskHost(E, gt["heightfield"])
+        th.rb_state[:] = np.concatenate([g["body_pos"], g["body_rot"], g["body_vel"], g["body_ang_vel"]], -1)
+        th.betas[:] = g["betas"]
+        th.traj_verts[:] = gs["verts"]
+        th.progress[:] = gs["progress"]
+        hosts.append(th)
+    dof, amp0 = rng.normal(size=(E, 69, 2)), rng.normal(size=hosts[0].amp.shape)
+    skip = np.zeros(E, np.int64); skip[[2, 7, 8]] = 1
+    for th in hosts:
+        th.dof_state[:] = dof; th.amp[:] = amp0
+        th.obs[:] = -5.0; th.flip_obs[:] = -6.0
+        th.reset[:] = skip
+    mode = L.POST_OBS | L.POST_AMP_SHIFT | L.POST_AMP_ROW
+    hosts[0].post_physics(mode | L.POST_SKIP_DONE)
+    b = hosts[1].bufs()
+    ids = np.full(E + 1, -1, np.int32); ids[E] = 0
+    fn = emu.lib().emu_reset_obs_live
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 4
+    assert fn(C.byref(b), mode, P(skip), P(ids), E, 5, 3, 14) == 0       # 5 reset slots, 3 x 14 history workgroups ahead of / behind the role
+    for name in ("obs", "flip_obs", "amp", "progress", "reset", "rew"):
+        np.testing.assert_array_equal(getattr(hosts[0], name), getattr(hosts[1], name), err_msg=name)
+    assert np.all(hosts[1].obs[[2, 7, 8]] == -5.0) and np.all(hosts[1].obs[0] != -5.0)
+
+
 def test_pd_targets_kernel_matches_reference_golden(golden):
     g = golden("pd_targets")
     zero = np.zeros(69, np.uint8)
@@ -696,6 +731,33 @@ def test_compact_flags_kernel_is_nonzero():
         nz = np.nonzero(flags)[0]
         assert ids[n] == len(nz)
         assert np.array_equal(ids[:len(nz)], nz) and np.all(ids[len(nz):n] == -1)
+
+
+def test_compact_order_kernel_compacts_and_sorts_in_one_launch():
+    """compact_order_kernel (the fused chain's second launch): workgroup 0 = `reset_buf.nonzero()` + a snapshot of the flags, workgroup
+    1 = the next rigid-body launch's dispatch order -- env ids by descending contact work (bucket = min(key, 127); the order inside a
+    bucket is free).  Sizes around the 1024-thread chunk and beyond the 16 384 keys the sort keeps in LDS."""
+    lib = emu.lib()
+    rng = np.random.default_rng(5)
+    for n, prob in ((4096, 0.04), (1500, 0.5), (77, 0.0), (20000, 0.01)):
+        flags = (rng.random(n) < prob).astype(np.int64) * rng.integers(1, 5, n)
+        ids = np.full(n + 1, 12345, np.int32)
+        snap = np.full(n, -7, np.int64)
+        ticks = rng.integers(0, 300, n).astype(np.uint32)
+        order = np.full(n, -1, np.int32)
+        ws = np.zeros(n, np.uint8)
+        lib.emu_compact_order(P(flags), n, P(ids), P(snap), P(ticks), n, P(order), P(ws))
+        nz = np.nonzero(flags)[0]
+        assert ids[n] == len(nz) and np.array_equal(ids[:len(nz)], nz) and np.all(ids[len(nz):n] == -1)
+        assert np.array_equal(snap, flags)
+        assert np.array_equal(np.sort(order), np.arange(n))                       # a permutation of the envs
+        b = np.minimum(ticks[order], 127)
+        assert np.all(np.diff(b.astype(np.int64)) <= 0)                           # most work first
+    # without keys (cost order off) the launch is the compaction alone
+    flags = (rng.random(300) < 0.2).astype(np.int64)
+    ids = np.zeros(301, np.int32)
+    lib.emu_compact_order(P(flags), 300, P(ids), None, None, 0, None, None)
+    assert ids[300] == flags.sum()
 
 
 @pytest.mark.parametrize("name", ["traj_reset_plain", "traj_reset_heading", "traj_reset_real1", "traj_reset_real2", "traj_reset_real2_noadj"])
