@@ -94,11 +94,17 @@ __device__ __forceinline__ bool pool_hit(const ChainArgs &a, int bi) {
     return a.seeded && a.pool_cur && bi < a.pool_k && a.tag_cur[bi] == (((unsigned long long)a.seed_hi << 32) | a.seed_lo);
 }
 
-// three waves per SIMD: what the launch's 13 KB of LDS per workgroup allow anyway (12 workgroups per CU)
+// three waves per SIMD (168 registers): with the roles' LDS overlaid (5.7 KB) four (128 registers) or five (96) would fit, and were
+// measured slower -- 9.07 / 8.85 / 8.46 M env-steps/s: what the observation workgroups gain in residency the reset roles lose to spills
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8)))
 reset_obs_kernel(EmlocoTaskBufs pt, EmlocoResetBufs rt, EmlocoSimDev s, ChainArgs a) {
     const int lane = threadIdx.x;
     const int b = (int)blockIdx.x, S = a.n_slots;
+    // ONE block of LDS for whatever role this workgroup plays (a role's phases follow each other behind barriers and reuse it):
+    // post-physics pass 4.8 KB | kinematics 2.1 KB | trajectory 3.6 KB | history row 0.7 KB | pool draw: random row 2 KB + trajectory
+    constexpr int SM_FLOATS = EMLOCO_RESET_RND + TRAJ_SM_FLOATS > POST_SM_FLOATS ? EMLOCO_RESET_RND + TRAJ_SM_FLOATS : POST_SM_FLOATS;
+    static_assert(SM_FLOATS >= FK_SM_FLOATS && SM_FLOATS >= HIST_SM_FLOATS && SM_FLOATS >= TRAJ_SM_FLOATS, "role workspace");
+    __shared__ float sm[SM_FLOATS];
     if (b < S) {                                                    // ---- reset chain of the list entries b, b + S, ...
 #ifndef EMLOCO_EMU
         __builtin_amdgcn_s_setprio(3);                              // the launch's longest serial path: ahead of the observation waves
@@ -139,7 +145,7 @@ reset_obs_kernel(EmlocoTaskBufs pt, EmlocoResetBufs rt, EmlocoSimDev s, ChainArg
             __syncthreads();
             if (stamp) a.prof[2] = wall_clock64();
             PHASE_FENCE(ln, ev);
-            fk_env(s, ev, ln);
+            fk_env(s, ev, ln, sm);
             __syncthreads();
             if (stamp) a.prof[3] = wall_clock64();
             PHASE_FENCE(ln, ev);
@@ -151,12 +157,12 @@ reset_obs_kernel(EmlocoTaskBufs pt, EmlocoResetBufs rt, EmlocoSimDev s, ChainArg
                 if (ln == 0 && (rt.flags & EMLOCO_RESET_INIT_HEADING) && (rt.flags & EMLOCO_RESET_HEADING_INVERSION)) rt.inverted[ev] = *(const uint8_t *)(pe + POOL_INV);
                 reset_capture_pose(rt, s, ev, ln, pe[POOL_ROOT + 7], pe[POOL_ROOT + 8]);
             } else {
-                reset_finish_env(rt, s, bi, ev, u, ln);
+                reset_finish_env(rt, s, bi, ev, u, ln, sm);
             }
             __syncthreads();
             if (stamp) a.prof[4] = wall_clock64();
             PHASE_FENCE(ln, ev);
-            post_physics_env(pt, a.reset_mode, ev, ln);
+            post_physics_env(pt, a.reset_mode, ev, ln, sm);
             __syncthreads();                                        // LDS is reused by the next list entry
             if (stamp) a.prof[5] = wall_clock64();
         }
@@ -182,7 +188,7 @@ reset_obs_kernel(EmlocoTaskBufs pt, EmlocoResetBufs rt, EmlocoSimDev s, ChainArg
             const float ut = a.seeded ? reset_rnd_value(a.seed_lo, a.seed_hi, bi, EMLOCO_RND_TIME) : a.rnd_in[(long)bi * EMLOCO_RESET_RND + EMLOCO_RND_TIME];
             int mid; float mt;
             reset_pick_motion(rt, um, ut, &mid, &mt);
-            reset_amp_history_row(rt, env, k, mid, mt, lane);
+            reset_amp_history_row(rt, env, k, mid, mt, lane, sm);
             __syncthreads();
             if (stamp) a.prof[7] = wall_clock64();
         }
@@ -195,7 +201,7 @@ reset_obs_kernel(EmlocoTaskBufs pt, EmlocoResetBufs rt, EmlocoSimDev s, ChainArg
         const int now = a.ids[a.n];                                 // envs that finished this step (emloco_task_compact_done*: ids[n] = count)
         if (e >= now + (now >> 2) + 32) return;                     // the next step will not need more (if it does: direct path)
         float *pe = a.pool_next + (long)e * EMLOCO_POOL_FLOATS;
-        __shared__ float sh_u[EMLOCO_RESET_RND];
+        float *sh_u = sm;                                           // the random row, then the trajectory workspace behind it
         for (int k = lane; k < EMLOCO_RESET_RND; k += 64) sh_u[k] = reset_rnd_value(a.nseed_lo, a.nseed_hi, e, k);
         __syncthreads();
         const bool stamp = a.prof && e == 0 && lane == 0;                               // the first entry's sample / trajectory workgroups
@@ -218,7 +224,7 @@ reset_obs_kernel(EmlocoTaskBufs pt, EmlocoResetBufs rt, EmlocoSimDev s, ChainArg
             nx.real_pick = nullptr;
             nx.real_pick_key = a.next_key;
             if (lane == 0) *(uint8_t *)(pe + POOL_INV) = 0;
-            reset_traj_to(nx, sh_u, e, lane, ipx, ipy, rvx, rvy, rvz, pe + POOL_VERTS, (uint8_t *)(pe + POOL_INV), pe + POOL_WAY);
+            reset_traj_to(nx, sh_u, e, lane, ipx, ipy, rvx, rvy, rvz, pe + POOL_VERTS, (uint8_t *)(pe + POOL_INV), pe + POOL_WAY, sm + EMLOCO_RESET_RND);
             __syncthreads();
             if (stamp) a.prof[15] = wall_clock64();
         }
@@ -231,7 +237,7 @@ reset_obs_kernel(EmlocoTaskBufs pt, EmlocoResetBufs rt, EmlocoSimDev s, ChainArg
     if (a.skip[env] != 0) return;
     const bool stamp = a.prof && lane == 0 && (env == 0 || env == pt.n_env - 1);
     if (stamp) a.prof[env == 0 ? 8 : 10] = wall_clock64();
-    post_physics_env(pt, a.live_mode, env, lane);
+    post_physics_env(pt, a.live_mode, env, lane, sm);
     if (stamp) a.prof[env == 0 ? 9 : 11] = wall_clock64();
 }
 

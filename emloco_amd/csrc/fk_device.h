@@ -11,8 +11,12 @@ namespace emloco {
 
 // rb_state of env from its root_state / dof_state.  All 64 lanes of the wave call it (barriers inside); the caller puts a barrier
 // behind it before the LDS arrays are reused.
-__device__ __forceinline__ void fk_env(const EmlocoSimDev &d, int env, int lane) {
-    __shared__ float sh_pw[EMLOCO_NB][3], sh_qw[EMLOCO_NB][4], sh_R[EMLOCO_NB][9], sh_V[EMLOCO_NB][6];
+#define FK_SM_FLOATS (EMLOCO_NB * 22)      /* LDS workspace of the calling workgroup */
+__device__ __forceinline__ void fk_env(const EmlocoSimDev &d, int env, int lane, float *sm) {
+    float (*sh_pw)[3] = (float (*)[3])sm;
+    float (*sh_qw)[4] = (float (*)[4])(sm + EMLOCO_NB * 3);
+    float (*sh_R)[9] = (float (*)[9])(sm + EMLOCO_NB * 7);
+    float (*sh_V)[6] = (float (*)[6])(sm + EMLOCO_NB * 16);
     const int b = (lane < EMLOCO_NB) ? lane : 0;
     const int parent = d.topo[EMLOCO_TOPO_PARENT + b], depth = d.topo[EMLOCO_TOPO_DEPTH + b];
     float off[3], qj[4] = {0, 0, 0, 1}, wj[3] = {0, 0, 0}, V[6] = {0, 0, 0, 0, 0, 0}, r[3] = {0, 0, 0};

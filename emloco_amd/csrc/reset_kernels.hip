@@ -198,14 +198,14 @@ __device__ __forceinline__ unsigned real_pick_perm(unsigned x, unsigned n, unsig
 }
 
 __device__ __forceinline__ void reset_trajectory(const EmlocoResetBufs &t, const float *u, int bi, uint8_t *inv_out, int lane,
-                                                 float ipx, float ipy, float rvx, float rvy, float rvz, float (*sh_v)[3]) {
+                                                 float ipx, float ipy, float rvx, float rvy, float rvz, float (*sh_v)[3], float *sm6) {
     // The heading / speed recurrences (clamped random walks) are sequential but cheap; the 100 cos / sin evaluations are
     // the cost, so lane 0 only produces theta_i and the segment length, all lanes evaluate the steps, and lane 0 adds
     // them up in the original order (same floating-point result as the one-lane loop, ~8x shorter critical path).
-    __shared__ float sh_th[RNV], sh_seg[RNV];
+    float *sh_th = sm6, *sh_seg = sm6 + RNV;          // sm6: 6 x RNV floats of the workgroup's LDS
     // the four random streams of the walk are staged in LDS by all lanes first: lane 0's loop then runs on LDS latency
     // instead of one dependent global load per stream and step (that was most of this kernel's 30 us)
-    __shared__ float sh_ud[RNV], sh_ub[RNV], sh_us[RNV], sh_ua[RNV];
+    float *sh_ud = sm6 + 2 * RNV, *sh_ub = sm6 + 3 * RNV, *sh_us = sm6 + 4 * RNV, *sh_ua = sm6 + 5 * RNV;
     for (int i = lane; i < RNV - 1; i += 64) {
         sh_ud[i] = u[EMLOCO_RND_DTHETA + i]; sh_ub[i] = u[EMLOCO_RND_BERN + i];
         sh_us[i] = u[EMLOCO_RND_SHARP + i]; sh_ua[i] = u[EMLOCO_RND_DSPEED + i];
@@ -341,11 +341,12 @@ __device__ __forceinline__ void reset_fix_height(const EmlocoResetBufs &t, const
     for (int i = lane; i < EMLOCO_MAXCAND * 3; i += 64) s.lambda_ws[(long)env * EMLOCO_MAXCAND * 3 + i] = 0.0f;
 }
 
+#define TRAJ_SM_FLOATS (RNV * 9)            /* LDS workspace: the vertices [RNV][3] + six RNV-float scratch rows */
 __device__ __forceinline__ void reset_traj_to(const EmlocoResetBufs &t, const float *u, int bi, int lane, float ipx, float ipy, float rvx,
-                                              float rvy, float rvz, float *verts_out, uint8_t *inv_out, float *way_out) {
-    __shared__ float sh_v[RNV][3];
+                                              float rvy, float rvz, float *verts_out, uint8_t *inv_out, float *way_out, float *sm) {
+    float (*sh_v)[3] = (float (*)[3])sm;
     // ---- c. trajectory (traj_generator.py:60-237)
-    reset_trajectory(t, u, bi, inv_out, lane, ipx, ipy, rvx, rvy, rvz, sh_v);
+    reset_trajectory(t, u, bi, inv_out, lane, ipx, ipy, rvx, rvy, rvz, sh_v, sm + RNV * 3);
     for (int i = lane; i < RNV * 3; i += 64) verts_out[i] = (&sh_v[0][0])[i];
     // ---- d1. LocoVal waypoints captured at reset (humanoid_pedestrain_terrain.py:511-516)
     if (lane < EMLOCO_TRAJ_SAMPLES) {
@@ -362,13 +363,13 @@ __device__ __forceinline__ void reset_capture_pose(const EmlocoResetBufs &t, con
     if (lane == 0) { t.init_vel[(long)env * 2] = rvx; t.init_vel[(long)env * 2 + 1] = rvy; }
 }
 
-__device__ __forceinline__ void reset_finish_env(const EmlocoResetBufs &t, const EmlocoSimDev &s, int bi, int env, const float *u, int lane) {
+__device__ __forceinline__ void reset_finish_env(const EmlocoResetBufs &t, const EmlocoSimDev &s, int bi, int env, const float *u, int lane, float *sm) {
     reset_fix_height(t, s, env, lane);
     const float *rs = s.root_state + (long)env * 13;
     const float ipx = rs[0], ipy = rs[1];
     const float rvx = rs[7], rvy = rs[8];
     reset_traj_to(t, u, bi, lane, ipx, ipy, rvx, rvy, rs[9], t.traj_verts + (long)env * RNV * 3, t.inverted + env,
-                  t.waypoint_traj + (long)env * EMLOCO_TRAJ_SAMPLES * 3);
+                  t.waypoint_traj + (long)env * EMLOCO_TRAJ_SAMPLES * 3, sm);
     reset_capture_pose(t, s, env, lane, rvx, rvy);
 }
 
@@ -378,7 +379,8 @@ reset_finish_kernel(EmlocoResetBufs t, EmlocoSimDev s, const int32_t *ids, int n
     for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
         const int env = ids[bi];
         if (env < 0) break;
-        reset_finish_env(t, s, bi, env, rnd + (long)bi * EMLOCO_RESET_RND, lane);
+        __shared__ float sm[TRAJ_SM_FLOATS];
+        reset_finish_env(t, s, bi, env, rnd + (long)bi * EMLOCO_RESET_RND, lane, sm);
         __syncthreads();                              // LDS is reused by the next list entry
     }
 }
@@ -391,9 +393,10 @@ traj_reset_kernel(EmlocoResetBufs t, const int32_t *ids, int n, const float *rnd
     for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
         const int env = ids[bi];
         if (env < 0) break;
-        __shared__ float sh_v[RNV][3];
+        __shared__ float sm[TRAJ_SM_FLOATS];
+        float (*sh_v)[3] = (float (*)[3])sm;
         const float *ip = init_pos + (long)bi * 3, *rv = root_vel + (long)bi * 3;
-        reset_trajectory(t, rnd + (long)bi * EMLOCO_RESET_RND, bi, t.inverted + env, lane, ip[0], ip[1], rv[0], rv[1], rv[2], sh_v);
+        reset_trajectory(t, rnd + (long)bi * EMLOCO_RESET_RND, bi, t.inverted + env, lane, ip[0], ip[1], rv[0], rv[1], rv[2], sh_v, sm + RNV * 3);
         float *vout = t.traj_verts + (long)env * RNV * 3;
         for (int i = lane; i < RNV * 3; i += 64) vout[i] = (&sh_v[0][0])[i];
         __syncthreads();                              // LDS is reused by the next list entry
@@ -402,8 +405,9 @@ traj_reset_kernel(EmlocoResetBufs t, const int32_t *ids, int n, const float *rnd
 
 // ---- e. AMP history rows 1..14 from the motion library at t - k dt (humanoid_amp.py:486-535): one workgroup per
 // (finished env, history row) -- the rows are independent, a single wave walking all 14 was the longest serial path of a reset.
-__device__ __forceinline__ void reset_amp_history_row_to(const EmlocoResetBufs &t, const float *betas, float *out, int k, int mid, float mt, int lane) {
-    __shared__ float sh_root[13], sh_dp[RNDOF], sh_dv[RNDOF], sh_key[12];
+#define HIST_SM_FLOATS (16 + 2 * RNDOF + 12)
+__device__ __forceinline__ void reset_amp_history_row_to(const EmlocoResetBufs &t, const float *betas, float *out, int k, int mid, float mt, int lane, float *sm) {
+    float *sh_root = sm, *sh_dp = sm + 16, *sh_dv = sh_dp + RNDOF, *sh_key = sh_dv + RNDOF;
     const FrameBlend fb = frame_blend(t, mid, mt - t.dt * (float)k);
     if (lane >= 1 && lane < RNB) {
         float q[4], e[3];
@@ -430,8 +434,8 @@ __device__ __forceinline__ void reset_amp_history_row_to(const EmlocoResetBufs &
     __syncthreads();
     amp_row(lane, sh_root, sh_root + 3, sh_root + 7, sh_root + 10, sh_dp, sh_dv, 1, sh_key, betas, t.dof_subset, t.n_dof_subset, out);
 }
-__device__ __forceinline__ void reset_amp_history_row(const EmlocoResetBufs &t, int env, int k, int mid, float mt, int lane) {
-    reset_amp_history_row_to(t, t.betas + (long)env * 17, t.amp_obs_buf + ((long)env * EMLOCO_AMP_STEPS + k) * EMLOCO_AMP_ROW, k, mid, mt, lane);
+__device__ __forceinline__ void reset_amp_history_row(const EmlocoResetBufs &t, int env, int k, int mid, float mt, int lane, float *sm) {
+    reset_amp_history_row_to(t, t.betas + (long)env * 17, t.amp_obs_buf + ((long)env * EMLOCO_AMP_STEPS + k) * EMLOCO_AMP_ROW, k, mid, mt, lane, sm);
 }
 
 __global__ void __launch_bounds__(64)
@@ -440,7 +444,8 @@ reset_amp_history_kernel(EmlocoResetBufs t, const int32_t *ids, int n) {
     for (int bi = blockIdx.x; bi < n; bi += gridDim.x) {
         const int env = ids[bi];
         if (env < 0) break;
-        reset_amp_history_row(t, env, 1 + (int)blockIdx.y, (int)t.motion_ids[env], t.motion_times[env], lane);
+        __shared__ float sm[HIST_SM_FLOATS];
+        reset_amp_history_row(t, env, 1 + (int)blockIdx.y, (int)t.motion_ids[env], t.motion_times[env], lane, sm);
         __syncthreads();                              // LDS is reused by the next list entry
     }
 }

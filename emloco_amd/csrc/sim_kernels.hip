@@ -1363,7 +1363,8 @@ sim_fk_kernel(EmlocoSimDev d, const int *env_ids, int n_ids) {
     for (int bi = blockIdx.x; bi < n_ids; bi += gridDim.x) {
         const int env = env_ids ? env_ids[bi] : bi;
         if (env < 0) break;
-        fk_env(d, env, lane);
+        __shared__ float sm[FK_SM_FLOATS];
+        fk_env(d, env, lane, sm);
         __syncthreads();                              // LDS is reused by the next list entry
     }
 }

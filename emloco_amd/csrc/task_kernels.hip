@@ -157,14 +157,17 @@ __device__ long long *g_post_prof = nullptr;
 #else
 #define PPSTAMP(i) do { } while (0)
 #endif
-__device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mode, int env, int lane) {
+// `sm`: POST_SM_FLOATS floats of LDS owned by the calling workgroup (the caller decides what else lives there before and after:
+// the fused launches overlay it with their other roles' arrays)
+#define POST_SM_FLOATS (TNB * 13 + EMLOCO_TRAJ_SAMPLES * 3 + 12 + TNB * 3 + 2 * EMLOCO_SELF_OBS + 12)
+__device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mode, int env, int lane, float *sm) {
     PPSTAMP(0);
-    __shared__ float sh_body[TNB][13];
-    __shared__ float sh_samp[EMLOCO_TRAJ_SAMPLES][3];
-    __shared__ float sh_center[9];
-    __shared__ float sh_cf[TNB][3];
-    __shared__ float sh_obs[EMLOCO_SELF_OBS], sh_fobs[EMLOCO_SELF_OBS];
-    __shared__ float sh_key[4][3];
+    float (*sh_body)[13] = (float (*)[13])sm;
+    float (*sh_samp)[3] = (float (*)[3])(sm + TNB * 13);
+    float *sh_center = sm + TNB * 13 + EMLOCO_TRAJ_SAMPLES * 3;
+    float (*sh_cf)[3] = (float (*)[3])(sh_center + 12);
+    float *sh_obs = sh_center + 12 + TNB * 3, *sh_fobs = sh_obs + EMLOCO_SELF_OBS;
+    float (*sh_key)[3] = (float (*)[3])(sh_fobs + EMLOCO_SELF_OBS);
 
     int64_t prog = t.progress_buf[env];
     if (mode & EMLOCO_POST_ADVANCE) prog += 1;      // stored after the barrier below, once every lane has read it
@@ -336,7 +339,8 @@ post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_id
     const int env = env_ids ? env_ids[blockIdx.x] : (int)blockIdx.x;
     if (env < 0) return;                     // padding entry of a device-compacted id list
     if ((mode & EMLOCO_POST_SKIP_DONE) && t.reset_buf[env] != 0) return;      // block-uniform
-    post_physics_env(t, mode, env, lane);
+    __shared__ float sm[POST_SM_FLOATS];
+    post_physics_env(t, mode, env, lane, sm);
 }
 
 __global__ void __launch_bounds__(64)
