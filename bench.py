@@ -458,6 +458,37 @@ def policy_leg(env, E, dev, steps, warmup):
             "weights": "random init (no checkpoint ships)"}
 
 
+def locoval_policy_leg(env, E, dev, steps, warmup):
+    """configs[2] as the reference runs it on one GPU (amp_continuous_value.py:45-145): the frozen policy acts on the observations,
+    the AMP discriminator scores each step's AMP observations (the style half of the LocoVal return), LocoVal is fitted on the
+    finished episodes -- `python -m emloco_amd.run --policy_random_init`'s loop.  Random-init weights of the shipped architectures."""
+    import torch
+    from emloco_amd.learning.amp_policy import AMPPolicyBundle
+    from emloco_amd.learning.locoval_rollout import LocoValRollout
+    task = env.task
+    bundle = AMPPolicyBundle(task, seed=0)
+    agent = LocoValRollout(env, horizon_length=32, policy=bundle.policy, disc_reward=bundle.disc_reward, overlap_reset=False)
+    agent.started = True
+    agent._sched_live = True
+    for k in range(warmup):
+        agent.step_once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        agent.step_once()
+        if (k + 1) % 32 == 0:
+            agent.end_epoch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    agent._sync_fit()
+    return {"metric": "env-steps/sec, frozen policy + AMP discriminator reward + LocoVal fit in the loop (configs[2] on one GPU)",
+            "value": round(E * steps / dt, 1), "unit": "env-steps/s", "ms_per_step": round(dt / steps * 1e3, 4),
+            "episodes_fitted": agent.fitted_episodes,
+            "note": "policy forward (5 GEMMs) and discriminator forward (3 GEMMs, 3090 -> 1024 -> 512 -> 1) on the split-mode matrix path every step; "
+                    "the discriminator reads the step's AMP observations before the resets, so the AMP rows of every env stay in the flags launch "
+                    "(task.fused_amp_early) and only the observation rows ride in the fused reset / observation launch"}
+
+
 def pipelined_leg(E, dev, steps, warmup):
     """Reported beside the headline, never instead of it: the same 4096 envs as TWO independent 2048-env shards of this GPU,
     each stepped (reset_done + env.step) on its own HIP stream.  One shard is exactly one resident round of waves (256 CUs x
@@ -691,6 +722,7 @@ def main():
             task.overlap_obs = True
             out["policy"] = policy_leg(env, E, dev, a.steps, a.warmup)
             out["policy"]["schedule"] = "sequential, cost-ordered dispatch"
+            out["policy"]["with_discriminator_and_locoval_fit"] = locoval_policy_leg(env, E, dev, a.steps, a.warmup)
         if world == 1 and not a.no_pipelined and E % 2 == 0:
             out["pipelined"] = pipelined_leg(E, dev, a.steps, a.warmup)
         if world == 1 and not a.no_cpu_baseline:

@@ -408,6 +408,9 @@ class Humanoid(BaseTask):
     # pre_physics_step calls too -- launches a deferred observation pass on the spot when no reset_done() took it, so a caller that
     # never resets still gets its observations before the state moves on.  Takes precedence over overlap_obs.
     fused_chain = False
+    # with fused_chain: keep the AMP history shift / newest AMP row of EVERY env in the flags launch and defer only the observation
+    # rows -- for a loop that scores this step's AMP observations (discriminator reward, amp_continuous_value.py:90-96) before it resets
+    fused_amp_early = False
     _obs_deferred = 0
 
     def _make_obs_stream(self):
@@ -430,9 +433,13 @@ class Humanoid(BaseTask):
         mode = self._post_mode_step()
         if self.fused_chain and torch.device(self.device).type == "cuda" and getattr(self, "_fused_reset", False):
             self.wait_obs()
-            side_mode = mode & (L.POST_OBS | L.POST_AMP_SHIFT | L.POST_AMP_ROW)
-            amp = mode & (L.POST_AMP_SHIFT | L.POST_AMP_ROW)
-            self._launch_post((mode & ~side_mode) | (amp | L.POST_AMP_DONE_ONLY if amp else 0))
+            if self.fused_amp_early:
+                side_mode = mode & L.POST_OBS
+                self._launch_post(mode & ~side_mode)
+            else:
+                side_mode = mode & (L.POST_OBS | L.POST_AMP_SHIFT | L.POST_AMP_ROW)
+                amp = mode & (L.POST_AMP_SHIFT | L.POST_AMP_ROW)
+                self._launch_post((mode & ~side_mode) | (amp | L.POST_AMP_DONE_ONLY if amp else 0))
             self._obs_deferred = side_mode
         elif self.overlap_obs and torch.device(self.device).type == "cuda":
             if getattr(self, "_obs_stream", None) is None:

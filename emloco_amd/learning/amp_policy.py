@@ -15,7 +15,7 @@ import yaml
 
 from ..utils.running_mean_std import RunningMeanStd
 from .amp_network_sept_builder import AMPSeptBuilder
-from .policy_runner import FrozenPolicy
+from .policy_runner import FrozenDisc, FrozenPolicy
 
 DEFAULT_CFG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "cfg", "train", "rlg",
                            "amp_humanoid_smpl_sept_task.yaml")
@@ -53,6 +53,8 @@ class AMPPolicyBundle:
                                    clip_actions=float(self.config.get("clip_actions", 1.0)))
         self.deterministic = deterministic
         self.disc_reward_scale = float(self.config.get("disc_reward_scale", 2.0))
+        self.frozen_disc = FrozenDisc(self.a2c_network, self.amp_input_mean_std, self.num_envs, self.device,
+                                      disc_reward_scale=self.disc_reward_scale, normalize=bool(self.config.get("normalize_amp_input", True)))
         self.generator = torch.Generator(device=self.device)
         self.generator.manual_seed(seed)
 
@@ -60,6 +62,12 @@ class AMPPolicyBundle:
         return self.frozen.act(obs, deterministic=self.deterministic, generator=self.generator)
 
     def disc_reward(self, amp_obs):
+        """The style reward of a step (amp_continuous.py:675-692) through the packed runner; `disc_reward_modules` is the same through
+        the network's modules (what the tests compare it with)."""
+        with torch.no_grad():
+            return self.frozen_disc.reward(amp_obs)
+
+    def disc_reward_modules(self, amp_obs):
         with torch.no_grad():
             x = amp_obs.reshape(amp_obs.shape[0], -1)
             if self.config.get("normalize_amp_input", True):

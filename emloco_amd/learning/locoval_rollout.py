@@ -70,9 +70,10 @@ class LocoValRollout:
             # the chain between two rigid-body steps in three launches on ONE stream (flags | compaction + dispatch order | reset
             # chain + every observation): this loop calls reset_done() before the policy reads the observations, which is all that
             # mode asks for.  With a discriminator the AMP observations of a step are scored right after it, before the resets:
-            # the deferred observation pass would be flushed on its own there, so the side-stream arrangement stays.
-            if hasattr(self.task, "fused_chain") and self._no_disc and os.environ.get("EMLOCO_FUSED_CHAIN", "1") != "0":
+            # the AMP rows of every env then stay in the flags launch (task.fused_amp_early), only the observation rows are deferred.
+            if hasattr(self.task, "fused_chain") and os.environ.get("EMLOCO_FUSED_CHAIN", "1") != "0":
                 self.task.fused_chain = True
+                self.task.fused_amp_early = not self._no_disc      # the discriminator scores a step's AMP observations before the resets
             if overlap_reset is None:
                 overlap_reset = os.environ.get("EMLOCO_OVERLAP_RESET", "0") == "1"
             if hasattr(self.task, "overlap_reset") and overlap_reset:
@@ -247,7 +248,7 @@ class LocoValRollout:
             obs, rewards, dones, infos = self.vec_env.step(actions)
             inverted = task.inverted
             self.frames += self.num_actors
-            if not self._no_disc and hasattr(task, "wait_obs"):
+            if not self._no_disc and hasattr(task, "wait_obs") and not (getattr(task, "fused_chain", False) and getattr(task, "fused_amp_early", False)):
                 task.wait_obs()                                   # the discriminator reads this step's AMP observations
             amp_rewards = None if self._no_disc else self.disc_reward(infos["amp_obs"]).contiguous()
         self._bookkeeping(rewards, amp_rewards, dones, inverted)

@@ -97,3 +97,61 @@ class FrozenPolicy:
             return torch.clamp(mu, -self.clip, self.clip)
         noise = torch.randn(mu.shape, dtype=mu.dtype, device=mu.device, generator=generator)
         return torch.clamp(mu + torch.exp(self.sigma) * noise, -self.clip, self.clip)
+
+
+class FrozenDisc:
+    """The AMP discriminator's style reward for the LocoVal rollout (config 2), as the frozen policy above: what the reference
+    computes per step with `_amp_input_mean_std(amp_obs)`, `a2c_network.eval_disc` (amp_network_builder.py:81-84: MLP 3090 -> 1024
+    -> 512, logits -> 1) and `-log(max(1 - sigmoid(logit), 1e-4)) * disc_reward_scale` (amp_continuous.py:675-692), here as one
+    normalise launch into a 16-byte-aligned operand, three GEMM launches with the bias / ReLU epilogue on pre-packed weights and
+    preallocated buffers, and the scalar transform on the (E,) logits -- no module dispatch, no per-step allocation."""
+
+    def __init__(self, network, amp_mean_std, num_envs, device, disc_reward_scale=2.0, normalize=True):
+        self.E, self.device, self.scale, self.normalize = num_envs, torch.device(device), float(disc_reward_scale), bool(normalize)
+        sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in network.state_dict().items()}
+        idx = sorted({int(k.split(".")[1]) for k in sd if k.startswith("_disc_mlp.") and k.endswith(".weight")})
+        self.layers = [(sd[f"_disc_mlp.{i}.weight"], sd[f"_disc_mlp.{i}.bias"]) for i in idx]
+        self.logit_w, self.logit_b = sd["_disc_logits.weight"], sd["_disc_logits.bias"]
+        w0, b0 = self.layers[0]
+        self.in_size = w0.shape[1]
+        self.in_k = (self.in_size + _PAD - 1) // _PAD * _PAD
+        w0p = torch.zeros((w0.shape[0], self.in_k), dtype=torch.float32, device=self.device)
+        w0p[:, :self.in_size] = w0
+        self.layers[0] = (w0p, b0)
+        self.mean32 = amp_mean_std.running_mean.to(self.device).float().contiguous()
+        self.var32 = amp_mean_std.running_var.to(self.device).float().contiguous()
+        self.eps = float(amp_mean_std.epsilon)
+        f = dict(dtype=torch.float32, device=self.device)
+        self.x = torch.zeros((num_envs, self.in_k), **f)              # pad columns stay zero
+        self.h = [torch.empty((num_envs, w.shape[0]), **f) for w, _ in self.layers]
+        self.logits = torch.empty((num_envs, 1), **f)
+        self.floor = torch.tensor(0.0001, device=self.device)
+
+    def _linear(self, x, k, w, b, out, relu):
+        m, n = x.shape[0], w.shape[0]
+        ops.gemm(1, m, n, k, x, x.stride(0), 0, 0, w, w.stride(0), 0, 0, out, out.stride(0), 0, bias=b,
+                 flags=ops.GEMM_BIAS | (ops.GEMM_RELU if relu else 0), ksplit=_ksplit(m, n, k))
+
+    def logits_of(self, amp_obs):
+        x = amp_obs.reshape(amp_obs.shape[0], -1)
+        assert x.shape == (self.E, self.in_size) and x.dtype == torch.float32
+        if self.normalize:
+            self._normalize_padded(x.contiguous())
+        else:
+            self.x[:, :self.in_size].copy_(x)
+        cur, k = self.x, self.in_k
+        for (w, b), out in zip(self.layers, self.h):
+            self._linear(cur, k, w, b, out, True)
+            cur, k = out, w.shape[0]
+        self._linear(cur, k, self.logit_w, self.logit_b, self.logits, False)
+        return self.logits
+
+    def _normalize_padded(self, x):
+        # emloco_obs_normalize writes `split` columns to out0 with its own leading dimension: the padded operand takes them all
+        obs_normalize(x, self.mean32, self.var32, self.eps, 5.0, split=self.in_size, out0=self.x)
+
+    def reward(self, amp_obs):
+        logits = self.logits_of(amp_obs)
+        prob = 1 / (1 + torch.exp(-logits))
+        disc_r = -torch.log(torch.maximum(1 - prob, self.floor))
+        return (disc_r * self.scale).squeeze(-1)

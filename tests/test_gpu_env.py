@@ -145,6 +145,8 @@ def test_rollout_with_frozen_policy_and_disc_reward(tmp_path):
     assert a.shape == (128, 69) and float(a.abs().max()) <= 1.0
     r = bundle.disc_reward(task._amp_obs_buf)
     assert r.shape == (128,) and torch.isfinite(r).all() and float(r.min()) >= 0.0
+    # the packed runner (FrozenDisc: one normalise launch + three GEMMs on preallocated buffers) against the network's modules
+    assert torch.allclose(r, bundle.disc_reward_modules(task._amp_obs_buf), rtol=1e-5, atol=1e-6)
     assert bundle.eval_critic(obs).shape == (128, 1)
     agent = LocoValRollout(env, horizon_length=16, policy=bundle.policy, disc_reward=bundle.disc_reward,
                            inversion_penalty_scale=0.3)
@@ -569,8 +571,8 @@ def test_observations_on_a_side_stream_give_the_same_rollout():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seeded,pool", [(False, 64), (True, 64), (True, 8), (True, 0)])
-def test_fused_chain_gives_the_same_rollout(seeded, pool, monkeypatch):
+@pytest.mark.parametrize("seeded,pool,amp_early", [(False, 64, False), (True, 64, False), (True, 8, False), (True, 0, False), (True, 64, True)])
+def test_fused_chain_gives_the_same_rollout(seeded, pool, amp_early, monkeypatch):
     """task.fused_chain: post_physics_step launches only progress / reward / flags (+ the terminal AMP rows of the finished envs),
     reset_done() is two launches -- emloco_task_compact_done_order (compaction + flag snapshot + the next step's dispatch order) and
     emloco_task_reset_obs (reset chain of the finished envs, their AMP history, their observations AND the deferred observation /
@@ -585,6 +587,7 @@ def test_fused_chain_gives_the_same_rollout(seeded, pool, monkeypatch):
     torch.manual_seed(11)
     envs = [_make_env(96, args), _make_env(96, args)]
     envs[1].task.fused_chain = True
+    envs[1].task.fused_amp_early = amp_early        # AMP rows of every env in the flags launch (a discriminator reads them before the resets)
     for e in envs:
         e.task.sim.native.set_cost_order(True)
     dev = envs[0].task.device
@@ -615,6 +618,8 @@ def test_fused_chain_gives_the_same_rollout(seeded, pool, monkeypatch):
         done = envs[0].task.reset_buf != 0
         assert torch.equal(envs[0].task.reset_buf, envs[1].task.reset_buf), k
         assert torch.equal(envs[0].task._amp_obs_buf[done], envs[1].task._amp_obs_buf[done]), (k, "terminal AMP rows")
+        if amp_early:
+            assert torch.equal(envs[0].task._amp_obs_buf, envs[1].task._amp_obs_buf), (k, "AMP observations of every env right after the step")
         for name in ("_rigid_body_state", "rew_buf", "progress_buf", "_terminate_buf"):
             assert torch.equal(getattr(envs[0].task, name), getattr(envs[1].task, name)), (k, name, "after step")
     assert int((envs[0].task.progress_buf == 0).sum()) < 96            # natural / forced resets happened, not only the first
