@@ -715,6 +715,8 @@ def main():
             out["sequential"] = dict(out["env_step_only"])         # the name earlier rounds reported this leg under
         if blind is not None:
             out["overlapped_obs_blind"] = blind
+        if world == 1 and not a.no_pipelined and E % 2 == 0:        # ahead of the policy legs: their agents' streams would share its hardware queues
+            out["pipelined"] = pipelined_leg(E, dev, a.steps, a.warmup)
         if world == 1 and not a.no_policy:
             # a policy reads the reset envs' fresh observations, so the reset chain cannot hide beside the step: the sequential
             # schedule (observation launch of the live envs beside the reset chain, cost-ordered dispatch) is the faster one here
@@ -723,8 +725,6 @@ def main():
             out["policy"] = policy_leg(env, E, dev, a.steps, a.warmup)
             out["policy"]["schedule"] = "sequential, cost-ordered dispatch"
             out["policy"]["with_discriminator_and_locoval_fit"] = locoval_policy_leg(env, E, dev, a.steps, a.warmup)
-        if world == 1 and not a.no_pipelined and E % 2 == 0:
-            out["pipelined"] = pipelined_leg(E, dev, a.steps, a.warmup)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     # the JTA train-step and evaluation legs run on every rank (data parallel at N > 1); rank 0 reports
