@@ -258,15 +258,21 @@ int emloco_rms_update(int rows, int cols, const float *x, int ldx, double *mean,
     return 0;
 }
 
-int emloco_locoval_fwd(int B, const float *traj, int traj_stride, const float *pose, const float *vel, const float *w1,
-                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float *value,
-                       float *x100, float *h1, float *h2, float *angle, void *stream) {
+int emloco_locoval_fwd_rows(int B, const float *traj, int traj_stride, const float *pose, const float *vel, const float *w1,
+                            const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float *value,
+                            float *x100, float *h1, float *h2, float *angle, const float *row_weight, void *stream) {
     if (B < 1 || traj_stride < 2 || !traj || !pose || !vel || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !value || !x100 || !h1 || !h2)
         return pfail(-1, "emloco_locoval_fwd: bad argument");
     hipLaunchKernelGGL(emloco::locoval_fwd_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, B, traj, traj_stride, pose, vel,
-                       w1, b1, w2, b2, w3, b3, value, x100, h1, h2, angle);
+                       w1, b1, w2, b2, w3, b3, value, x100, h1, h2, angle, row_weight);
     PHIPCHK(hipGetLastError());
     return 0;
+}
+
+int emloco_locoval_fwd(int B, const float *traj, int traj_stride, const float *pose, const float *vel, const float *w1,
+                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float *value,
+                       float *x100, float *h1, float *h2, float *angle, void *stream) {
+    return emloco_locoval_fwd_rows(B, traj, traj_stride, pose, vel, w1, b1, w2, b2, w3, b3, value, x100, h1, h2, angle, nullptr, stream);
 }
 
 int64_t emloco_locoval_bwd_workspace(int B) { return (int64_t)B * LV_NPARAM * (int64_t)sizeof(float); }

@@ -881,9 +881,12 @@ __device__ __forceinline__ void locoval_input(int lane, const float *traj, int t
 __global__ void __launch_bounds__(64)
 locoval_fwd_kernel(int B, const float *traj, int ts, const float *pose, const float *vel, const float *w1, const float *b1,
                    const float *w2, const float *b2, const float *w3, const float *b3, float *value, float *x100,
-                   float *h1o, float *h2o, float *angle) {
+                   float *h1o, float *h2o, float *angle, const float *row_weight) {
     const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= B) return;
+    // fit of a rollout step: only the rows that carry a target are evaluated (a few hundred of 4096); the others leave at once and
+    // keep whatever value / activations they held -- their weight is 0 in the loss and its gradient
+    if (row_weight && row_weight[i] == 0.0f) return;
     __shared__ float x[LV_IN], h1[LV_H1], h2[LV_H2];
     locoval_input(lane, traj + (long)i * 13 * ts, ts, pose + (long)i * 72, vel + (long)i * 2, x, angle ? angle + i : nullptr);
     __syncthreads();

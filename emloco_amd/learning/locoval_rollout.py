@@ -192,8 +192,8 @@ class LocoValRollout:
         P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         n = self.valuenet._network
         w = [n.fc1.weight, n.fc1.bias, n.fc2.weight, n.fc2.bias, n.fc3.weight, n.fc3.bias]
-        ops._chk(lib.emloco_locoval_fwd(E, P(z["traj13"]), 3, P(z["pose"]), P(z["vel"]), *[P(t) for t in w], P(z["value"]), P(z["x100"]),
-                                        P(z["h1"]), P(z["h2"]), P(z["ang"]), st), "emloco_locoval_fwd")
+        ops._chk(lib.emloco_locoval_fwd_rows(E, P(z["traj13"]), 3, P(z["pose"]), P(z["vel"]), *[P(t) for t in w], P(z["value"]), P(z["x100"]),
+                                             P(z["h1"]), P(z["h2"]), P(z["ang"]), P(z["weight"]), st), "emloco_locoval_fwd_rows")
         ops._chk(lib.emloco_locoval_fit_grad(E, P(z["value"]), P(z["target"]), P(z["weight"]), P(z["dvalue"]), P(self.bucket.tail), P(z["slot"]), st),
                  "emloco_locoval_fit_grad")
         ops._chk(lib.emloco_locoval_bwd_rows(E, P(z["traj13"]), 3, P(z["pose"]), P(z["vel"]), P(w[0]), P(w[2]), P(w[4]), P(z["value"]), P(z["x100"]),

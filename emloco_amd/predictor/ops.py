@@ -58,6 +58,7 @@ def _lib():
         lib.emloco_layernorm_bwd_workspace.argtypes = [ci, ci]
         lib.emloco_layernorm_bwd_workspace.restype = C.c_int64
         lib.emloco_locoval_fwd.argtypes = [ci, vp, ci] + [vp] * 14
+        lib.emloco_locoval_fwd_rows.argtypes = [ci, vp, ci] + [vp] * 15
         lib.emloco_locoval_bwd.argtypes = [ci, vp, ci] + [vp] * 15
         lib.emloco_locoval_bwd_workspace.argtypes = [ci]
         lib.emloco_locoval_bwd_workspace.restype = C.c_int64

@@ -175,6 +175,12 @@ int emloco_rms_update(int rows, int cols, const float *x, int ldx, double *mean,
 int emloco_locoval_fwd(int B, const float *traj, int traj_stride, const float *pose, const float *vel,
                        const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
                        float *value, float *x100, float *h1, float *h2, float *angle, void *stream);
+/* Same, evaluating only the rows whose `row_weight` entry is non-zero (NULL: all): the fit of a rollout step needs the value of the
+ * episodes that emit a target (amp_continuous_value.py:112-145), a few hundred of the 4096 envs; the other rows of value / x100 / h1 /
+ * h2 are left as they are. */
+int emloco_locoval_fwd_rows(int B, const float *traj, int traj_stride, const float *pose, const float *vel, const float *w1,
+                            const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float *value,
+                            float *x100, float *h1, float *h2, float *angle, const float *row_weight, void *stream);
 /* Backward: given dvalue [B] -> gradients of the 6 parameter tensors (summed over the batch, fixed order, written
  * to dparams = [dw1 4900 | db1 49 | dw2 1176 | db2 24 | dw3 24 | db3 1]) and d traj [B][13][traj_stride]
  * (the gradient that reaches the predicted trajectory in the EmLoco loss, train_jta.py:288-308). */

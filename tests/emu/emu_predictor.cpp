@@ -97,7 +97,7 @@ extern "C" long emu_layernorm_bwd_workspace(int rows, int d) { return fold_works
 extern "C" int emu_locoval_fwd(int B, const float *traj, int ts, const float *pose, const float *vel, const float *w1,
                                const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
                                float *value, float *x100, float *h1, float *h2, float *angle) {
-    emu::launch((unsigned)B, 64, [&] { locoval_fwd_kernel(B, traj, ts, pose, vel, w1, b1, w2, b2, w3, b3, value, x100, h1, h2, angle); });
+    emu::launch((unsigned)B, 64, [&] { locoval_fwd_kernel(B, traj, ts, pose, vel, w1, b1, w2, b2, w3, b3, value, x100, h1, h2, angle, (const float *)nullptr); });
     return 0;
 }
 extern "C" int emu_locoval_bwd(int B, const float *traj, int ts, const float *pose, const float *vel, const float *w1,
