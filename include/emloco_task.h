@@ -245,7 +245,8 @@ int emloco_task_reset_obs(struct EmlocoSim *sim, const EmlocoResetBufs *reset_bu
  * computing it: the longest serial path of the launch loses its two longest phases.  Entries beyond the pool and slots tagged
  * with another seed take the direct path; same bytes either way.
  * The caller alternates two buffers: this call's `next` is the following call's `cur`.  Ignored (direct path, nothing drawn)
- * when dev_rnd is given. */
+ * when dev_rnd is given.  With a pool, dev_env_ids must be a list of emloco_task_compact_done* (n + 1 entries: the draw count
+ * follows dev_env_ids[n], the number of finished envs). */
 #define EMLOCO_POOL_FLOATS 512      /* per entry: root 13 | misc | dof 138 | trajectory 303 | waypoints 45 */
 typedef struct {
     int32_t k;                      /* entries per pool buffer (0: no pool) */
