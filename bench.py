@@ -622,6 +622,7 @@ def main():
     env_only = None
     if world == 1:
         agent._sync_fit()
+        agent.detach()                                   # the LocoVal return bookkeeping leaves the task's flags launch
         for k in range(a.warmup):
             env.reset_done(); env.step(pool[k % 64])
         task.sim.native.enable_timing(True, every=8)
@@ -641,11 +642,13 @@ def main():
         blind_policy.reads_obs = False
         # the same agent (HIP serves a process with four hardware queues: a second agent's side stream would share one)
         agent.policy = blind_policy
+        agent.attach()
         fused_chain, task.fused_chain = task.fused_chain, False
         task.overlap_reset = True
         task.overlap_obs = os.environ.get("EMLOCO_OVERLAP_OBS", "0") == "1"    # see LocoValRollout.__init__: nothing to hide behind here
         b_t, b_n, b_ms = timed_loop(agent)
         agent._sync_fit()
+        agent.detach()
         task.wait_reset()
         for k in range(a.warmup):
             env.reset_done(); env.step(pool[k % 64])

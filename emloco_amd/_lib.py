@@ -150,7 +150,7 @@ SYMBOLS_SIM = [
 SYMBOLS_TASK = [
     "emloco_task_post_physics", "emloco_task_amp_rows", "emloco_task_pd_targets", "emloco_task_last_ms",
     "emloco_task_enable_timing", "emloco_task_reset", "emloco_task_reset_seeded", "emloco_task_compact_done", "emloco_task_compact_done_snapshot", "emloco_task_reset_amp_history",
-    "emloco_task_traj_reset", "emloco_task_get_heights", "emloco_task_pd_targets_copy", "emloco_task_compact_done_order", "emloco_task_reset_obs", "emloco_task_reset_obs_pooled",
+    "emloco_task_traj_reset", "emloco_task_get_heights", "emloco_task_pd_targets_copy", "emloco_task_compact_done_order", "emloco_task_reset_obs", "emloco_task_reset_obs_pooled", "emloco_task_post_physics_returns",
 ]
 
 _lib = None
@@ -196,6 +196,7 @@ def load():
     lib.emloco_sim_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.emloco_sim_timing_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]
     lib.emloco_task_post_physics.argtypes = [C.POINTER(TaskBufs), C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.emloco_task_post_physics_returns.argtypes = [C.POINTER(TaskBufs), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emloco_task_amp_rows.argtypes = [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p, C.c_void_p]
     lib.emloco_task_pd_targets.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]
     lib.emloco_task_enable_timing.argtypes = [C.c_int]

@@ -16,6 +16,7 @@
 #include "../../include/emloco_predictor.h"
 #include "mfma_bf16.h"
 #include "dev_math.h"
+#include "locoval_returns_device.h"
 
 namespace emloco {
 
@@ -1000,41 +1001,12 @@ __global__ void locoval_reduce_kernel(int B, const float *ws, float *dparams, co
 }
 
 // ---- LocoVal training step around the MLP (amp_continuous_value.py:63-145, common_agent.py:89-97,154-155) ----------------
-// One wave per env: lanes copy the LocoVal inputs the task captured at reset into origin-relative form
-// (vec_task_wrappers.py:50-66; first 13 waypoints, amp_continuous_value.py:127), lane 0 advances the per-env bookkeeping of
-// the discounted return (:63-64 inversion penalty, :93-118) and emits the normalised target / weight of this step's fit.
+// the return bookkeeping of one env: locoval_returns_device.h (shared with the task's flags launch)
 __global__ void __launch_bounds__(64)
 locoval_returns_kernel(EmlocoLocoValStep t, const float *rewards, const float *amp_rewards, const int64_t *dones, const uint8_t *inverted) {
     const int e = blockIdx.x, lane = threadIdx.x;
     if (e >= t.n_env) return;
-    const float *wp = t.waypoint_traj + (long)e * 45, *ip = t.init_pose + (long)e * 72;
-    if (lane < 39) t.traj13[(long)e * 39 + lane] = wp[lane] - wp[lane % 3];
-    for (int k = lane; k < 72; k += 64) t.pose[(long)e * 72 + k] = ip[k] - ip[k % 3];
-    if (lane < 2) t.vel[(long)e * 2 + lane] = t.init_vel[(long)e * 2 + lane];
-    if (lane == 0) {
-        // the bookkeeping follows the reference's torch expressions operation by operation (fixture locoval_returns.npz is matched
-        // bit for bit): no multiply-add contraction here, whatever the translation unit's default is
-#ifndef EMLOCO_EMU
-#pragma clang fp contract(off)
-#endif
-        float r = rewards[e];
-        if (inverted && inverted[e]) r = r * (-t.inversion_penalty);
-        const float a = amp_rewards ? amp_rewards[e] : 0.0f;
-        const bool done = dones[e] != 0;
-        const float nd = done ? 0.0f : 1.0f;
-        const float cr = t.current_rewards[e] + r;
-        const float len = t.current_lengths[e] + 1.0f;
-        const float coef = t.discount_coefs[e];
-        const float comb = t.current_combined_rewards[e] + (r + a) * coef;
-        const bool emit = done ? (len <= (float)t.step_to_pred) : (len == (float)t.step_to_pred);
-        const float G = emit ? comb : 0.0f;
-        t.target[e] = (G - t.min_cum_rewards) / (t.max_cum_rewards - t.min_cum_rewards);
-        t.weight[e] = G != 0.0f ? 1.0f : 0.0f;
-        t.current_combined_rewards[e] = comb * nd;
-        t.discount_coefs[e] = done ? 1.0f : coef * t.gamma;
-        t.current_rewards[e] = cr * nd;
-        t.current_lengths[e] = len * nd;
-    }
+    locoval_returns_env(t, e, lane, rewards[e], amp_rewards ? amp_rewards[e] : 0.0f, dones[e] != 0, inverted && inverted[e]);
 }
 
 // d/dvalue of sum_e w_e (value_e - target_e)^2 (MSELoss(reduction='sum') over the valid rows, common_agent.py:96) and the two

@@ -6,6 +6,7 @@
 #include "reset_kernels.hip"
 #include "chain_kernels.hip"
 #include "sim_state.h"
+#include "../../include/emloco_predictor.h"
 
 extern "C" int emloco_sim_fk_indexed(EmlocoSim *s, const int32_t *ids, int n, void *stream);
 
@@ -72,6 +73,29 @@ int emloco_task_post_physics(const EmlocoTaskBufs *b, int mode, const int32_t *d
     hipStream_t st = (hipStream_t)stream;
     if (g_timing) THIPCHK(hipEventRecord(g_ev0, st));
     hipLaunchKernelGGL(emloco::post_physics_kernel, dim3((unsigned)count), dim3(64), 0, st, *b, mode, dev_env_ids, count);
+    THIPCHK(hipGetLastError());
+    if (g_timing) { THIPCHK(hipEventRecord(g_ev1, st)); g_pending = true; }
+    return 0;
+}
+
+int emloco_task_post_physics_returns(const EmlocoTaskBufs *b, int mode, const void *step_, const uint8_t *dev_inverted, void *stream) {
+    const EmlocoLocoValStep *step = (const EmlocoLocoValStep *)step_;
+    if (!b || !step) return tfail(-1, "emloco_task_post_physics_returns: null argument");
+    if (!(mode & EMLOCO_POST_REWARD) || !(mode & EMLOCO_POST_RESET) || (mode & EMLOCO_POST_SKIP_DONE))
+        return tfail(-1, "emloco_task_post_physics_returns: the return bookkeeping follows the reward and the reset flag of the same launch, for every env");
+    if (step->n_env != b->n_env || !step->current_rewards || !step->current_lengths || !step->current_combined_rewards || !step->discount_coefs ||
+        !step->waypoint_traj || !step->init_pose || !step->init_vel || !step->traj13 || !step->pose || !step->vel || !step->target || !step->weight)
+        return tfail(-1, "emloco_task_post_physics_returns: LocoVal step buffers missing or for another env count");
+    if (b->n_env < 1 || b->hf_rows < 2 || b->hf_cols < 2 || !b->rb_state || !b->progress_buf || !b->traj_verts || !b->rew_buf || !b->reward_raw ||
+        !b->dof_force || !b->dof_state || !b->reset_buf || !b->terminate_buf || !b->contact_force || !b->contact_body_mask)
+        return tfail(-1, "emloco_task_post_physics_returns: task buffers missing");
+    if ((mode & EMLOCO_POST_OBS) && (!b->obs_buf || !b->flip_obs_buf || !b->heightfield || !b->betas || !b->left_to_right))
+        return tfail(-1, "emloco_task_post_physics_returns: observation buffers missing");
+    if ((mode & (EMLOCO_POST_AMP_ROW | EMLOCO_POST_AMP_SHIFT)) && (!b->amp_obs_buf || !b->dof_subset || !b->key_bodies || !b->betas || b->n_dof_subset > 64 || b->n_dof_subset % 3))
+        return tfail(-1, "emloco_task_post_physics_returns: AMP buffers missing");
+    hipStream_t st = (hipStream_t)stream;
+    if (g_timing) THIPCHK(hipEventRecord(g_ev0, st));
+    hipLaunchKernelGGL(emloco::post_physics_returns_kernel, dim3((unsigned)b->n_env), dim3(64), 0, st, *b, mode, *step, dev_inverted);
     THIPCHK(hipGetLastError());
     if (g_timing) { THIPCHK(hipEventRecord(g_ev1, st)); g_pending = true; }
     return 0;

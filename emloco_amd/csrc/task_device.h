@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include "dev_math.h"
 #include "../../include/emloco_task.h"
+#include "locoval_returns_device.h"
 
 namespace emloco {
 
@@ -155,7 +156,10 @@ __device__ long long *g_post_prof = nullptr;
 // `sm`: POST_SM_FLOATS floats of LDS owned by the calling workgroup (the caller decides what else lives there before and after:
 // the fused launches overlay it with their other roles' arrays)
 #define POST_SM_FLOATS (TNB * 13 + EMLOCO_TRAJ_SAMPLES * 3 + 12 + TNB * 3 + 2 * EMLOCO_SELF_OBS + 12)
-__device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mode, int env, int lane, float *sm) {
+// `lv` (optional): the LocoVal return bookkeeping of this env (locoval_returns_device.h) runs right behind its reward and reset flag
+// -- needs EMLOCO_POST_REWARD and EMLOCO_POST_RESET in `mode`; `lv_inverted` [n_env] bytes (or NULL) are the heading-inversion flags.
+__device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mode, int env, int lane, float *sm,
+                                                 const EmlocoLocoValStep *lv = nullptr, const uint8_t *lv_inverted = nullptr) {
     PPSTAMP(0);
     float (*sh_body)[13] = (float (*)[13])sm;
     float (*sh_samp)[3] = (float (*)[3])(sm + TNB * 13);
@@ -265,6 +269,7 @@ __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mo
 
     PPSTAMP(5);
     const float *tar = sh_samp[0];
+    float rew_now = 0.0f;                        // lane 0: this step's reward (the returns hook below reads it)
     if (mode & EMLOCO_POST_REWARD) {
         float part = 0.0f;
         for (int dd = lane; dd < TNDOF; dd += 64)
@@ -275,7 +280,8 @@ __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mo
             const float err = dx * dx + dy * dy;
             const float loc = expf(-2.0f * err);
             const float pw = -t.power_coef * power;
-            t.rew_buf[env] = loc + pw;
+            rew_now = loc + pw;
+            t.rew_buf[env] = rew_now;
             t.reward_raw[(long)env * 2] = loc;
             t.reward_raw[(long)env * 2 + 1] = pw;
         }
@@ -300,6 +306,8 @@ __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mo
         done_now = ((float)prog >= t.max_episode_length - 1.0f) ? 1 : (int)term;
         t.reset_buf[env] = done_now;
     }
+    if (lv && (mode & EMLOCO_POST_REWARD) && (mode & EMLOCO_POST_RESET))
+        locoval_returns_env(*lv, env, lane, rew_now, 0.0f, done_now != 0, lv_inverted && lv_inverted[env]);
     if (mode & EMLOCO_POST_AMP_DONE_ONLY) {      // the AMP rows of the finished envs only (block-uniform)
         done_now = (mode & EMLOCO_POST_RESET) ? __shfl(done_now, 0) : (int)(t.reset_buf[env] != 0);
         if (!done_now) return;

@@ -26,6 +26,15 @@ post_physics_kernel(EmlocoTaskBufs t, int mode, const int32_t *env_ids, int n_id
     post_physics_env(t, mode, env, lane, sm);
 }
 
+// the same launch with the LocoVal return bookkeeping of every env behind its flags (emloco_task_post_physics_returns)
+__global__ void __launch_bounds__(64)
+post_physics_returns_kernel(EmlocoTaskBufs t, int mode, EmlocoLocoValStep lv, const uint8_t *lv_inverted) {
+    const int lane = threadIdx.x, env = (int)blockIdx.x;
+    if (env >= t.n_env) return;
+    __shared__ float sm[POST_SM_FLOATS];
+    post_physics_env(t, mode, env, lane, sm, &lv, lv_inverted);
+}
+
 __global__ void __launch_bounds__(64)
 amp_rows_kernel(int n, const float *root_pos, const float *root_rot, const float *root_vel, const float *root_ang,
                 const float *dof_pos, const float *dof_vel, const float *key_pos, const float *betas,

@@ -385,9 +385,31 @@ class Humanoid(BaseTask):
     def _post_mode_step(self):
         return L.POST_ADVANCE | L.POST_OBS | L.POST_REWARD | L.POST_RESET
 
+    # A rollout loop may hand the task its LocoVal return bookkeeping (LocoValRollout.attach: an EmlocoLocoValStep): the launch that
+    # computes a step's rewards and reset flags for all envs then also advances the returns (emloco_task_post_physics_returns) and
+    # raises `_returns_in_flags` for the loop to see that its own launch is not needed this step.
+    _returns_hook = None
+    _returns_in_flags = False
+
+    def attach_returns(self, step_struct, before=None):
+        """`before` (optional callable) runs right ahead of the launch -- the loop's "staging buffers are free" wait belongs there, behind
+        the rigid-body launch, where it never blocks."""
+        self._returns_hook = step_struct
+        self._returns_before = before if step_struct is not None else None
+
     def _launch_post(self, mode, env_ids=None):
         if self._post_bufs is None:
             self._post_bufs = self._make_post_bufs()
+        if (self._returns_hook is not None and env_ids is None and (mode & L.POST_REWARD) and (mode & L.POST_RESET)
+                and not (mode & L.POST_SKIP_DONE)):
+            if getattr(self, "_returns_before", None) is not None:
+                self._returns_before()
+            inv = self.inverted if isinstance(getattr(self, "inverted", None), torch.Tensor) else None
+            if inv is not None and inv.dtype == torch.bool:
+                inv = inv.view(torch.uint8)
+            self._post.run(self._post_bufs, mode, None, returns=(self._returns_hook, inv.contiguous() if inv is not None else None))
+            self._returns_in_flags = True
+            return
         ids = None if env_ids is None else self._humanoid_actor_ids[env_ids.to(self.device)].contiguous()
         self._post.run(self._post_bufs, mode, ids)
 

@@ -106,6 +106,8 @@ class LocoValRollout:
         self.frames = 0
         # [last fit's loss sum, last fit's episodes, total loss sum, total episodes, number of fits] -- on the device
         self._stats = torch.zeros(5, device=self.device, dtype=torch.float64)
+        if hasattr(self.task, "attach_returns"):
+            self.task.attach_returns(None)
         if self.fused:
             self._init_fused()
 
@@ -128,6 +130,11 @@ class LocoValRollout:
         # The fit (forward, loss gradient, backward, all-reduce, AdamW: ~75 us of small launches) only reads what the returns
         # kernel staged (traj13 / pose / vel / target / weight), so it runs on a side stream while the main stream goes on to
         # reset the finished envs and to launch the next physics step; the next returns kernel waits for it.
+        # the return bookkeeping rides in the task's flags launch when there is no AMP reward to wait for (one launch less on the chain)
+        self._returns_in_flags = (self._no_disc and hasattr(task, "attach_returns") and torch.device(dev).type == "cuda"
+                                  and os.environ.get("EMLOCO_RETURNS_IN_FLAGS", "1") != "0")
+        if hasattr(task, "attach_returns"):
+            task.attach_returns(self._fstep if self._returns_in_flags else None, before=self._before_flags)      # (None: a hook an earlier loop left behind goes)
         self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("EMLOCO_FIT_PRIORITY", "0"))) if (self.overlap_fit and torch.device(dev).type == "cuda") else None
         self._ev_staged = torch.cuda.Event() if self._side is not None else None
         self._ev_fit = torch.cuda.Event() if self._side is not None else None
@@ -170,10 +177,13 @@ class LocoValRollout:
         s = self._fstep
         s.inversion_penalty = float(self.inversion_penalty_scale)
         main = torch.cuda.current_stream(self.device) if self._side is not None else None
-        if self._side is not None and self._fit_pending:
-            main.wait_event(self._ev_fit)                   # the previous fit is done with the staging buffers
-        ops._chk(lib.emloco_locoval_returns(C.byref(s), P(rewards.contiguous()), P(amp_rewards), P(dones.contiguous()), P(inverted.contiguous()), st),
-                 "emloco_locoval_returns")
+        if getattr(self.task, "_returns_in_flags", False) and amp_rewards is None:
+            self.task._returns_in_flags = False             # this step's flags launch has advanced the returns (_before_step waited for the fit)
+        else:
+            if self._side is not None and self._fit_pending:
+                main.wait_event(self._ev_fit)               # the previous fit is done with the staging buffers
+            ops._chk(lib.emloco_locoval_returns(C.byref(s), P(rewards.contiguous()), P(amp_rewards), P(dones.contiguous()), P(inverted.contiguous()), st),
+                     "emloco_locoval_returns")
         if self._side is None:
             self._fit_launches(st)
             return
@@ -245,6 +255,7 @@ class LocoValRollout:
             if hasattr(task, "wait_reset") and getattr(self.policy, "reads_obs", True):
                 task.wait_reset()                                 # the observations of the envs that were just reset
             actions = self.policy(task.obs_buf)
+            self._before_step()
             obs, rewards, dones, infos = self.vec_env.step(actions)
             inverted = task.inverted
             self.frames += self.num_actors
@@ -252,6 +263,29 @@ class LocoValRollout:
                 task.wait_obs()                                   # the discriminator reads this step's AMP observations
             amp_rewards = None if self._no_disc else self.disc_reward(infos["amp_obs"]).contiguous()
         self._bookkeeping(rewards, amp_rewards, dones, inverted)
+
+    def detach(self):
+        """Take this loop's return bookkeeping out of the task's flags launch (a caller that steps the env on its own in between)."""
+        if getattr(self, "_returns_in_flags", False) and hasattr(self.task, "attach_returns"):
+            self.task.attach_returns(None)
+
+    def attach(self):
+        if getattr(self, "_returns_in_flags", False) and hasattr(self.task, "attach_returns"):
+            self.task.attach_returns(self._fstep, before=self._before_flags)
+
+    def _before_flags(self):
+        """Runs right ahead of the task's flags launch when that launch carries the return bookkeeping: the previous fit must have read
+        the staging buffers the launch is about to overwrite (a wait that sits behind the rigid-body launch never blocks)."""
+        if self._side is not None and self._fit_pending:
+            torch.cuda.current_stream(self.device).wait_event(self._ev_fit)
+
+    def _before_step(self):
+        """With the return bookkeeping inside the task's flags launch: what _fused_step does ahead of its own returns launch -- the
+        staging buffers must be free (the previous fit has read them), the penalty scale current."""
+        if not getattr(self, "_returns_in_flags", False) or not self.fused:
+            return
+        self._check_fused_inputs()
+        self._fstep.inversion_penalty = float(self.inversion_penalty_scale)
 
     def _make_return_state(self, E, step_to_pred, gamma, device):
         return _ReturnState(E, step_to_pred, gamma, device)

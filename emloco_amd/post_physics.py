@@ -56,7 +56,14 @@ class PostPhysics:
                           p(self.dof_subset), p(progress_buf), p(reset_buf), p(terminate_buf), p(obs_buf),
                           p(flip_obs_buf), p(rew_buf), p(reward_raw), p(amp_obs_buf))
 
-    def run(self, bufs, mode=L.POST_STEP, env_ids_i32=None):
+    def run(self, bufs, mode=L.POST_STEP, env_ids_i32=None, returns=None):
+        """`returns` = (EmlocoLocoValStep ctypes struct, inverted bool / uint8 tensor or None): the LocoVal return bookkeeping of every
+        env in the same launch (emloco_task_post_physics_returns; all envs, mode with REWARD and RESET)."""
+        if returns is not None:
+            step, inv = returns
+            rc = self.lib.emloco_task_post_physics_returns(C.byref(bufs), int(mode), C.byref(step), dptr(inv), current_stream_handle(self.device))
+            L.check(rc, "emloco_task_post_physics_returns")
+            return
         n = 0 if env_ids_i32 is None else int(env_ids_i32.numel())
         if env_ids_i32 is not None and n == 0:
             return

@@ -88,6 +88,13 @@ typedef struct {
  * (_compute_observations(env_ids) on reset, humanoid.py:459-465). */
 int emloco_task_post_physics(const EmlocoTaskBufs *bufs, int mode, const int32_t *dev_env_ids, int n, void *stream);
 
+/* emloco_task_post_physics for all envs with the LocoVal return bookkeeping of amp_continuous_value.py:63-64,93-129 behind it in the
+ * SAME launch: what emloco_locoval_returns (include/emloco_predictor.h) does with rewards = rew_buf, dones = reset_buf and no AMP
+ * reward, for each env right after its reward and reset flag exist.  `mode` must hold EMLOCO_POST_REWARD | EMLOCO_POST_RESET.
+ * `step` is an EmlocoLocoValStep (emloco_predictor.h), dev_inverted the heading-inversion flags [n_env] (bytes) or NULL. */
+int emloco_task_post_physics_returns(const EmlocoTaskBufs *bufs, int mode, const void *step /* const EmlocoLocoValStep * */,
+                                     const uint8_t *dev_inverted, void *stream);
+
 /* AMP rows from explicit states (history back-fill from the motion library, humanoid_amp.py:486-535):
  * n rows; inputs [n][3|4|3|3|69|69|4*3|17]; out [n][206]. */
 int emloco_task_amp_rows(int n, const float *root_pos, const float *root_rot, const float *root_vel,

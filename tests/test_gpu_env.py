@@ -724,3 +724,43 @@ def test_locoval_loop_with_the_reset_chain_beside_the_step_fits_the_same_network
     for a, b in zip(outs[0], outs[1]):
         if torch.is_tensor(a):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_return_bookkeeping_inside_the_flags_launch_fits_the_same_network(monkeypatch):
+    """The LocoVal return bookkeeping as part of the task's flags launch (emloco_task_post_physics_returns; LocoValRollout without a
+    discriminator attaches its EmlocoLocoValStep to the task) against the launch of its own (EMLOCO_RETURNS_IN_FLAGS=0): same seeds,
+    64 steps with natural resets -- fitted LocoVal parameters, episode count, return accumulators and simulator state bit-equal."""
+    from emloco_amd.learning.locoval_rollout import LocoValRollout
+    from emloco_amd.run import RLGPUEnv
+    E, outs = 256, []
+    for in_flags in ("0", "1"):
+        monkeypatch.setenv("EMLOCO_RETURNS_IN_FLAGS", in_flags)
+        env = RLGPUEnv(_make_env(E, ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel",
+                                     "--input_init_pose", "--input_init_vel"]))
+        task = env.env.task
+        g = torch.Generator(device=task.device)
+        g.manual_seed(77)
+        pool = torch.randn(8, E, 69, device=task.device, generator=g) * 0.3
+        k = [0]
+
+        def pol(obs):
+            k[0] += 1
+            return pool[k[0] % 8]
+        torch.manual_seed(5)
+        agent = LocoValRollout(env, horizon_length=8, policy=pol, overlap_reset=False)
+        assert agent._returns_in_flags == (in_flags == "1") and (task._returns_hook is not None) == (in_flags == "1")
+        for _ in range(8):
+            agent.play_steps()
+        n_fit = agent.fitted_episodes                      # waits for the fit stream
+        torch.cuda.synchronize()
+        a = agent.acc
+        outs.append((torch.cat([p.detach().reshape(-1) for p in agent.valuenet.parameters()]).clone(), n_fit,
+                     a.current_rewards.clone(), a.current_lengths.clone(), a.current_combined_rewards.clone(), a.discount_coefs.clone(),
+                     task._root_states.clone(), task.progress_buf.clone(), task.rew_buf.clone()))
+        agent.detach()
+        assert task._returns_hook is None
+    assert outs[0][1] == outs[1][1] and outs[0][1] > 20
+    for a, b in zip(outs[0], outs[1]):
+        if torch.is_tensor(a):
+            assert torch.equal(a, b)
