@@ -65,3 +65,10 @@ extern "C" int emu_reset_obs_live(const EmlocoTaskBufs *pb, int live_mode, const
     emu::launch(grid, 64, [&] { emloco::reset_obs_kernel(*pb, rb, sd, a); });
     return 0;
 }
+
+// the flags launch with the LocoVal return bookkeeping of every env behind its reward and reset flag
+extern "C" int emu_task_post_physics_returns(const EmlocoTaskBufs *b, int mode, const EmlocoLocoValStep *step, const uint8_t *inverted) {
+    EmlocoLocoValStep lv = *step;
+    emu::launch((unsigned)b->n_env, 64, [&] { emloco::post_physics_returns_kernel(*b, mode, lv, inverted); });
+    return 0;
+}

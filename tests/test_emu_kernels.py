@@ -271,6 +271,57 @@ def test_fused_launch_observation_role_equals_the_post_physics_launch(golden):
     assert np.all(hosts[1].obs[[2, 7, 8]] == -5.0) and np.all(hosts[1].obs[0] != -5.0)
 
 
+def test_flags_launch_with_the_return_bookkeeping_equals_the_two_launches(golden):
+    """post_physics_returns_kernel (emloco_task_post_physics_returns: the LocoVal return bookkeeping of an env right behind its reward
+    and reset flag, one launch) against post_physics_kernel followed by locoval_returns_kernel on its outputs: task buffers, return
+    accumulators, staged LocoVal inputs, targets and weights byte for byte, over several steps with episodes ending."""
+    from emloco_amd import _lib as L
+    from emloco_amd.predictor.ops import LocoValStep
+    g, gt, gs = golden("self_obs"), golden("terrain_heights"), golden("traj_samples")
+    E = 16
+    rng = np.random.default_rng(9)
+    mode = L.POST_ADVANCE | L.POST_REWARD | L.POST_RESET | L.POST_AMP_SHIFT | L.POST_AMP_ROW | L.POST_AMP_DONE_ONLY
+    f = lambda *s: np.zeros(s, np.float32)
+    sides = []
+    for _ in range(2):
+        th = emu.TaskHost(E, gt["heightfield"], episode_len=6)
+        th.rb_state[:] = np.concatenate([g["body_pos"], g["body_rot"], g["body_vel"], g["body_ang_vel"]], -1)
+        th.betas[:] = g["betas"]
+        th.traj_verts[:] = gs["verts"]
+        th.progress[:] = 0; th.reset[:] = 0; th.terminate[:] = 0
+        st = dict(cr=f(E), cl=f(E), cc=f(E), dc=np.ones(E, np.float32), traj13=f(E, 13, 3), pose=f(E, 24, 3), vel=f(E, 2), target=f(E), weight=f(E),
+                  wp=rng.normal(size=(E, 15, 3)).astype(np.float32), ip=rng.normal(size=(E, 24, 3)).astype(np.float32), iv=rng.normal(size=(E, 2)).astype(np.float32))
+        sides.append((th, st))
+    for k in ("wp", "ip", "iv"):
+        sides[1][1][k][:] = sides[0][1][k]
+    p = lambda a: a.ctypes.data
+    steps = [LocoValStep(E, 4, 0.99, 0.3, -10.0, 100.0, p(st["cr"]), p(st["cl"]), p(st["cc"]), p(st["dc"]), p(st["wp"]), p(st["ip"]), p(st["iv"]),
+                         p(st["traj13"]), p(st["pose"]), p(st["vel"]), p(st["target"]), p(st["weight"])) for _, st in sides]
+    lib = emu.lib()
+    lib.emu_locoval_returns.argtypes = [C.c_void_p] * 5
+    lib.emu_task_post_physics_returns.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    inv = (rng.random(E) < 0.4).astype(np.uint8)
+    emitted = 0
+    for t in range(9):
+        dof, frc = rng.normal(size=(E, 69, 2)).astype(np.float32), (rng.normal(size=(E, 69)) * 30).astype(np.float32)
+        cf = np.zeros((E, 24, 3), np.float32); cf[rng.random(E) < 0.2, 11] = 80.0          # some envs fall
+        for th, _ in sides:
+            th.dof_state[:] = dof; th.dof_force[:] = frc; th.contact_force[:] = cf
+            th.progress[th.reset != 0] = 0                                                   # a finished env starts over
+        (tha, sta), (thb, stb) = sides
+        tha.post_physics(mode)
+        rew, dones = np.ascontiguousarray(tha.rew), np.ascontiguousarray(tha.reset)
+        lib.emu_locoval_returns(C.addressof(steps[0]), p(rew), None, p(dones), p(inv))
+        bb = thb.bufs()
+        assert lib.emu_task_post_physics_returns(C.byref(bb), mode, C.addressof(steps[1]), p(inv)) == 0
+        for name in ("progress", "reset", "terminate", "rew", "reward_raw", "amp"):
+            np.testing.assert_array_equal(getattr(tha, name), getattr(thb, name), err_msg=f"{name} step {t}")
+        for k in sta:
+            np.testing.assert_array_equal(sta[k], stb[k], err_msg=f"{k} step {t}")
+        emitted += int((sta["weight"] != 0).sum())
+    assert emitted > 0 and int((sides[0][0].reset != 0).sum()) >= 0
+
+
 def test_pd_targets_kernel_matches_reference_golden(golden):
     g = golden("pd_targets")
     zero = np.zeros(69, np.uint8)
