@@ -9,17 +9,27 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _SO = os.path.join(_HERE, "_build", "libemu.so")
 _SRCS = ["emu_sim.cpp", "emu_task.cpp", "emu_predictor.cpp", "emu_runtime.cpp", "hip/hip_runtime.h"]
-_KERNELS = ["sim_kernels.hip", "task_kernels.hip", "reset_kernels.hip", "predictor_kernels.hip", "attention_kernels.hip", "dev_math.h", "mfma_bf16.h", "emloco_types.h", "topology.h"]
-
-
 def build():
-    deps = [os.path.join(_HERE, s) for s in _SRCS] + [os.path.join(_ROOT, "emloco_amd", "csrc", k) for k in _KERNELS]
-    deps = [d for d in deps if os.path.exists(d)]
-    if not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
+    """g++ over the kernel sources; every file under emloco_amd/csrc and include/ is a dependency.  Built under a file lock into a
+    temporary name and renamed, so that the workers of a parallel test run neither build twice at once nor load a half-written file."""
+    import fcntl
+    csrc, inc = os.path.join(_ROOT, "emloco_amd", "csrc"), os.path.join(_ROOT, "include")
+    deps = [os.path.join(_HERE, s) for s in _SRCS] + [os.path.join(d, f) for d in (csrc, inc) for f in os.listdir(d)]
+    deps = [d for d in deps if os.path.isfile(d)]
+
+    def stale():
+        return not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps)
+
+    if stale():
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
-        cpps = [os.path.join(_HERE, s) for s in _SRCS if s.endswith(".cpp") and os.path.exists(os.path.join(_HERE, s))]
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-ffp-contract=off", "-Wno-psabi",
-                               "-I", _HERE, "-o", _SO] + cpps + ["-lpthread"])
+        with open(_SO + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if stale():
+                cpps = [os.path.join(_HERE, s) for s in _SRCS if s.endswith(".cpp") and os.path.exists(os.path.join(_HERE, s))]
+                tmp = _SO + f".{os.getpid()}.tmp"
+                subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-ffp-contract=off", "-Wno-psabi",
+                                       "-I", _HERE, "-o", tmp] + cpps + ["-lpthread"])
+                os.replace(tmp, _SO)
     return _SO
 
 
