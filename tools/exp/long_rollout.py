@@ -8,6 +8,8 @@ E = 4096
 SIG = float(sys.argv[1]) if len(sys.argv) > 1 else 0.055
 BURST = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
 env = bench.make_env(E, 0); dev = torch.device("cuda", 0); task = env.task
+task.fused_chain = os.environ.get("EMLOCO_FUSED_CHAIN", "1") != "0"      # the fused chain between two steps (pooled resets, deferred observations)
+task.sim.native.set_cost_order(True)
 env.reset(torch.arange(E, device=dev))
 g = torch.Generator(device=dev); g.manual_seed(0)
 n_done = torch.zeros((), device=dev); ep_len_sum = torch.zeros((), device=dev); term = torch.zeros((), device=dev)
