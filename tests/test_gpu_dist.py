@@ -323,6 +323,37 @@ def test_locoval_returns_kernel_matches_the_reference_play_steps():
     assert g["valid"].sum() >= 30
 
 
+def test_locoval_forward_on_the_rows_that_carry_a_target():
+    """emloco_locoval_fwd_rows (the fit of a rollout step): rows whose weight is non-zero get exactly what emloco_locoval_fwd gives
+    them -- value and the activations the backward reads -- the other rows are left untouched."""
+    import ctypes as C
+    from emloco_amd.learning.value_pose_net import ValuePoseNet
+    from emloco_amd.predictor import ops
+    from emloco_amd.sim import current_stream_handle
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    B = 300
+    net = ValuePoseNet(True, True).to(dev)._network
+    w = [t.detach().contiguous() for t in (net.fc1.weight, net.fc1.bias, net.fc2.weight, net.fc2.bias, net.fc3.weight, net.fc3.bias)]
+    traj, pose, vel = torch.randn(B, 13, 3, device=dev), torch.randn(B, 24, 3, device=dev), torch.randn(B, 2, device=dev)
+    weight = (torch.rand(B, device=dev) < 0.1).float()
+    lib = ops._lib()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = current_stream_handle(dev)
+
+    def bufs(fill):
+        return [torch.full(s, fill, device=dev) for s in ((B,), (B, 100), (B, 49), (B, 24), (B,))]
+    full, rows = bufs(0.0), bufs(-7.0)
+    ops._chk(lib.emloco_locoval_fwd(B, P(traj), 3, P(pose), P(vel), *[P(t) for t in w], *[P(t) for t in full], st), "emloco_locoval_fwd")
+    ops._chk(lib.emloco_locoval_fwd_rows(B, P(traj), 3, P(pose), P(vel), *[P(t) for t in w], *[P(t) for t in rows], P(weight), st), "emloco_locoval_fwd_rows")
+    torch.cuda.synchronize()
+    on = weight != 0
+    assert 5 < int(on.sum()) < B
+    for a, b in zip(full, rows):
+        assert torch.equal(a[on], b[on])
+        assert bool((b[~on] == -7.0).all())
+
+
 def _eval_setup(dev):
     from emloco_amd.learning.value_pose_net import ValuePoseNet
     from emloco_amd.predictor.model_jrdb import TransMotionJRDB
