@@ -284,7 +284,8 @@ int emloco_sim_step(EmlocoSim *s, int n_calls, void *stream) {
     d.n_parts = s->n_parts < p.n_sub ? s->n_parts : p.n_sub;       // at least one substep per part
     d.part_seq = ++s->part_seq; d.part_state = s->d_part_state.p; d.part_flag = s->d_part_flag.p;
     d.part_spin_max = s->part_spin_max; d.part_poison = s->part_poison;
-    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(s->n_env * d.n_parts)), dim3(64), (size_t)s->lds_pad, st, p, d);
+    if (d.hf) hipLaunchKernelGGL(emloco::sim_step_kernel<1>, dim3((unsigned)(s->n_env * d.n_parts)), dim3(64), (size_t)s->lds_pad, st, p, d);
+    else hipLaunchKernelGGL(emloco::sim_step_kernel<0>, dim3((unsigned)(s->n_env * d.n_parts)), dim3(64), (size_t)s->lds_pad, st, p, d);
     HIPCHK(hipGetLastError());
     if (timed) {
         HIPCHK(hipEventRecord(s->ev1[slot], st));
@@ -323,7 +324,8 @@ int emloco_sim_step_subset(EmlocoSim *s, int n_calls, const int64_t *dev_skip, c
     d.n_parts = dev_ids ? 1 : (s->n_parts < p.n_sub ? s->n_parts : p.n_sub);      // the list launch (a few dozen envs) is not split
     d.part_seq = ++s->part_seq; d.part_state = s->d_part_state.p; d.part_flag = s->d_part_flag.p;
     d.part_spin_max = s->part_spin_max; d.part_poison = s->part_poison;
-    hipLaunchKernelGGL(emloco::sim_step_kernel, dim3((unsigned)(dev_ids ? n_ids : s->n_env * d.n_parts)), dim3(64), (size_t)s->lds_pad, st, p, d);
+    if (d.hf) hipLaunchKernelGGL(emloco::sim_step_kernel<1>, dim3((unsigned)(dev_ids ? n_ids : s->n_env * d.n_parts)), dim3(64), (size_t)s->lds_pad, st, p, d);
+    else hipLaunchKernelGGL(emloco::sim_step_kernel<0>, dim3((unsigned)(dev_ids ? n_ids : s->n_env * d.n_parts)), dim3(64), (size_t)s->lds_pad, st, p, d);
     HIPCHK(hipGetLastError());
     if (timed) {
         HIPCHK(hipEventRecord(s->ev1[slot], st));

@@ -49,7 +49,7 @@ extern "C" int emu_sim_step(const EmlocoSimParams *prm, const EmlocoModelDesc *m
     const char *po = getenv("EMLOCO_EMU_POISON");
     unsigned err = 0u;
     d.part_spin_max = 4; d.part_poison = po ? atoi(po) : -1; d.err = &err;
-    emu::launch((unsigned)(m->n_env * n_parts), 64, [&] { emloco::sim_step_kernel(p, d); });
+    emu::launch((unsigned)(m->n_env * n_parts), 64, [&] { if (d.hf) emloco::sim_step_kernel<1>(p, d); else emloco::sim_step_kernel<0>(p, d); });
     return (int)err;
 }
 
