@@ -282,6 +282,25 @@ def jta_leg(dev, steps=4, warmup=2, B=256, rank=0, world=1):
         out["bf16_operands"] = out["bf16"]                      # the name earlier rounds reported this leg under
     finally:
         ops.set_matmul_precision(ops.DEFAULT_PRECISION)
+    # NOT the reference's model function: the same step with collate_batch's BOOL padding mask (cfg MASK_PADDED_PERSONS) -- padded
+    # persons masked with -inf instead of biased by +1 (the reference's loops pass the float copy, dataset_jta.py:84), which lets the
+    # local former skip them (model_jta.py `_transform`; pinned to the reference run with a bool mask, predictor_boolmask_jta.npz)
+    try:
+        cfg["MASK_PADDED_PERSONS"] = True
+        live = int((~pad).sum())
+        masked = {"live_person_sequences": live, "padded_person_sequences": int(pad.numel()),
+                  "note": "extension, off by default: bool padding mask = padded persons masked (-inf) rather than biased (+1) as in the "
+                          "reference's training loop; the local former then runs on the live person-sequences only.  A different "
+                          "model function from `value` -- reported beside it, never as it"}
+        for mode in (ops.DEFAULT_PRECISION, "bf16"):
+            ops.set_matmul_precision(mode)
+            _timed(lambda: trainer.step(joints, masks, pad), 0, warmup, world, dev)
+            dt = _timed(lambda: trainer.step(joints, masks, pad), steps, 0, world, dev)
+            masked[mode] = {"value": round(B * world * steps / dt, 2), "unit": "samples/s", "ms_per_step": round(dt / steps * 1e3, 2)}
+        out["masked_padded_persons"] = masked
+    finally:
+        cfg["MASK_PADDED_PERSONS"] = False
+        ops.set_matmul_precision(ops.DEFAULT_PRECISION)
     return out
 
 

@@ -1023,7 +1023,10 @@ locoval_fit_grad_kernel(int n, const float *value, const float *target, const fl
     float l = 0.0f;
     int cnt = 0;
     for (int i = lo; i < hi; ++i) {
-        const float w = weight[i], d = value[i] - target[i];
+        // rows without a target (w == 0) are not evaluated by the rows-only forward: whatever value[] still holds for them (a NaN
+        // of a diverged episode included, 0 * NaN = NaN) must not reach the loss sum or the gradient
+        const float w = weight[i];
+        const float d = w != 0.0f ? value[i] - target[i] : 0.0f;
         dvalue[i] = 2.0f * w * d;
         l += w * d * d;
         cnt += w != 0.0f ? 1 : 0;

@@ -214,7 +214,12 @@ int emloco_sim_get_params(EmlocoSim *s, EmlocoSimParams *out) {
 int emloco_sim_set_params(EmlocoSim *s, const EmlocoSimParams *in) {
     if (!s || !in) return fail(EMLOCO_E_ARG, "emloco_sim_set_params: null argument");
     if (in->n_sub < 1 || in->h <= 0.0f || in->n_iter < 0) return fail(EMLOCO_E_ARG, "emloco_sim_set_params: invalid parameters");
+    if (in->drive_mode < 0 || in->drive_mode > 1) return fail(EMLOCO_E_ARG, "emloco_sim_set_params: drive_mode 0 | 1 required");
+    // the drive mode is a property of what was uploaded last (emloco_sim_set_pd_targets / emloco_sim_set_dof_actuation_force:
+    // both travel in one buffer), not of the solver parameters: a parameter update keeps the live mode
+    const int live_mode = s->prm.drive_mode;
     s->prm = *in;
+    if (s->prepared) s->prm.drive_mode = live_mode;
     return EMLOCO_OK;
 }
 
@@ -369,9 +374,9 @@ int emloco_sim_sync(EmlocoSim *s, void *stream) {
     return check_device_error(s, "emloco_sim_sync");
 }
 
-// internal test hook (not in the public header): the first part of `env` withholds its hand-over flag in the split launches
-// that follow (-1: back to normal) and a part's wait is bounded by `spin_max` sleeps (<= 0: the default) -- lets a test see
-// the timeout of a lost hand-over surface as EMLOCO_E_HIP instead of waiting seconds for it
+// fault injection (include/emloco_sim.h): the first part of `env` withholds its hand-over flag in the split launches that
+// follow (-1: back to normal) and a part's wait is bounded by `spin_max` sleeps (<= 0: the default) -- lets a test see the
+// timeout of a lost hand-over surface as EMLOCO_E_HIP instead of waiting seconds for it
 int emloco_sim_debug_poison_part(EmlocoSim *s, int env, int spin_max) {
     if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_debug_poison_part: null sim");
     s->part_poison = env;

@@ -45,6 +45,15 @@ def get_rank():
     return dist.get_rank() if is_distributed() else 0
 
 
+rank = get_rank
+
+
+def barrier():
+    """All ranks arrive before any leaves; no-op on one rank."""
+    if is_distributed():
+        dist.barrier()
+
+
 def shard_range(num_envs_global, rank, world):
     """Contiguous env shard of this rank; global ids stay rank*E_local + i for bit-exact mask comparison."""
     per = num_envs_global // world

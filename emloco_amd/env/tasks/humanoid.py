@@ -368,15 +368,19 @@ class Humanoid(BaseTask):
             self._actions_buf.copy_(actions)
             self.actions = self._actions_buf
             forces = self.actions * self.motor_efforts.unsqueeze(0) * self.power_scale
-            self.gym.set_dof_actuation_force_tensor(self.sim, gymtorch.unwrap_tensor(forces.contiguous()))
+            if not self.gym.set_dof_actuation_force_tensor(self.sim, gymtorch.unwrap_tensor(forces.contiguous())):
+                raise RuntimeError("set_dof_actuation_force_tensor failed (simulator not prepared, or a tensor of the wrong shape / dtype)")
             return
         # pd_tar = offset + scale * a with hands / frozen toes zeroed (humanoid.py:1188-1202,1281-1283) and the task's copy of the
         # actions, one launch
-        src = actions if (actions.dtype == torch.float32 and actions.is_contiguous()) else actions.to(torch.float32).contiguous()
+        # (a no-op for a float32 contiguous tensor on the sim device; an rl_device='cpu' / other-GPU tensor is moved first as the
+        # reference's `actions.to(self.device).clone()` does: the kernel takes a raw pointer)
+        src = actions.to(device=self.device, dtype=torch.float32).contiguous()
         self._post.pd_targets(src, self._pd_action_offset, self._pd_action_scale, self._pd_zero_mask, self._pd_targets,
                               actions_copy=self._actions_buf)
         self.actions = self._actions_buf
-        self.gym.set_dof_position_target_tensor(self.sim, gymtorch.unwrap_tensor(self._pd_targets))
+        if not self.gym.set_dof_position_target_tensor(self.sim, gymtorch.unwrap_tensor(self._pd_targets)):
+            raise RuntimeError("set_dof_position_target_tensor failed (simulator not prepared, or a tensor of the wrong shape / dtype)")
         return
 
     def _action_to_pd_targets(self, action):

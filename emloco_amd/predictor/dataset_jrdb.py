@@ -65,3 +65,74 @@ def batch_process_coords(coords, masks, padding_mask, config, modality_selection
     out_F = config["TRAIN"]["output_track_size"]
     return (joints[:, :in_F].float(), masks[:, :in_F].float(), joints[:, in_F:in_F + out_F].float(),
             masks[:, in_F:in_F + out_F].float(), padding_mask.float())
+
+
+# ---------------------------------------------------------------------------------------------- datasets (dataset_jrdb.py:129-260)
+PREPROCESSED_DIR = "preprocess_smpl_filtered_v4"       # dataset_jrdb.py:146: the split directory the reference reads
+
+
+class MultiPersonTrajPoseDataset(torch.utils.data.Dataset):
+    """`<root>/<name>/preprocess_smpl_filtered_v4/<split>/*.pkl`, each a pickled list of scenes; a scene is a list of people; a
+    person is a tuple (joints (21, 26, 4), mask (21, 26)[, ids]).  Items carry the scene index (dataset_jrdb.py:203-210: the
+    evaluation looks up scene names through it).  The raw-data branch (`preprocessed: false`) is out of scope."""
+
+    def __init__(self, name, split="train", track_size=21, track_cutoff=9, segmented=True, add_flips=False, frequency=1,
+                 preprocessed=False, root="data"):
+        import os
+        import pickle
+        self.name, self.split, self.track_size, self.track_cutoff, self.frequency = name, split, track_size, track_cutoff, frequency
+        if not preprocessed:
+            raise NotImplementedError("only preprocessed splits are supported (DATA.preprocessed: true, as the shipped configs set)")
+        self.datalist = []
+        d = os.path.join(root, self.name, PREPROCESSED_DIR, self.split)
+        for file in sorted(os.listdir(d)):
+            with open(os.path.join(d, file), "rb") as f:
+                self.datalist += pickle.load(f)
+
+    def __len__(self):
+        return len(self.datalist)
+
+    def show_meta_info(self, idx):
+        return [s[2] for s in self.datalist[idx]]
+
+    def __getitem__(self, idx):
+        scene = self.datalist[idx]
+        return torch.stack([torch.as_tensor(s[0]) for s in scene]), torch.stack([torch.as_tensor(s[1]) for s in scene]), idx
+
+
+def create_dataset(dataset_name, logger=None, **args):
+    if logger is not None:
+        logger.info("Loading dataset " + dataset_name)
+    if dataset_name == "jta_all_visual_cues":
+        raise NotImplementedError("This is a code for JRDB dataset, not JTA dataset.")
+    if dataset_name in ("jrdb_2dbox", "jrdb_all_visual_cues"):
+        return MultiPersonTrajPoseDataset(dataset_name, frequency=1, **args)
+    raise ValueError(f"Dataset with name '{dataset_name}' not found.")
+
+
+def get_datasets(datasets_list, config, logger=None, root="data"):
+    in_F, out_F = config["TRAIN"]["input_track_size"], config["TRAIN"]["output_track_size"]
+    return [create_dataset(n, logger, split="train", track_size=in_F + out_F, track_cutoff=in_F,
+                           preprocessed=config["DATA"]["preprocessed"], root=root) for n in datasets_list]
+
+
+def write_synthetic_split(root, split, n_scenes, max_people=8, seed=0, name="jrdb_all_visual_cues"):
+    """Scenes in the on-disk format above with SURVEY 8d's statistics (26 tokens per person: trajectory, 2-D box, 24 joints)."""
+    import os
+    import pickle
+    import tempfile
+    from .dataset_jta import write_synthetic_split as write_jta
+    with tempfile.TemporaryDirectory() as tmp:
+        src = write_jta(tmp, split, n_scenes, max_people=max_people, seed=seed, name=name, tokens=26)
+        d = os.path.join(root, name, PREPROCESSED_DIR, split)
+        os.makedirs(d, exist_ok=True)
+        for f in sorted(os.listdir(src)):
+            with open(os.path.join(src, f), "rb") as fi:
+                scenes = pickle.load(fi)
+            for si, people in enumerate(scenes):            # pose joints around the pelvis in tokens 2:26, ids as the reference stores them
+                for pi, (j, m) in enumerate(people):
+                    j[:, 2:26, :3] = j[:, 0:1, :3] + torch.randn(21, 24, 3, generator=torch.Generator().manual_seed(seed * 7919 + si * 31 + pi)) * 0.3
+                    people[pi] = (j, m, (f"scene_{si}", list(range(21))))
+            with open(os.path.join(d, f), "wb") as fo:
+                pickle.dump(scenes, fo)
+    return d

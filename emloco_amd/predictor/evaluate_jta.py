@@ -382,12 +382,11 @@ def run(args, logger=None):
         elif logger is not None:
             logger.info("No checkpoint provided for valuenet. Using random weights.")
         valuenet = valuenet.to(dev).eval()
-    from .dataset_jta import create_dataset
     if args.dataset == "jta":
-        from .dataset_jta import collate_batch
+        from .dataset_jta import collate_batch, create_dataset
         from .model_jta import create_model
     else:
-        from .dataset_jrdb import collate_batch
+        from .dataset_jrdb import collate_batch, create_dataset
         from .model_jrdb import create_model
     model = create_model(config, logger)
     load_checkpoint(model, ckpt_name, strict=True)

@@ -181,16 +181,37 @@ class TransMotionJTA(nn.Module):
 
     def _transform(self, seq, padding_mask, B, N, Fr):
         """local former over every person's S tokens -> global former over the N*21 trajectory tokens -> heads
-        (model_jta.py:299-335; shared with TransMotionJRDB, model_jrdb.py:110-143)."""
+        (model_jta.py:299-335; shared with TransMotionJRDB, model_jrdb.py:110-143).
+
+        Padded persons.  What the mask means is torch's: the reference's training and evaluation loops hand over the FLOAT copy
+        (dataset_jta.py:84 `padding_mask.float()`), which nn.MultiheadAttention ADDS to the scores -- padded persons' keys get
+        a +1 bias, they are not removed, and their local-former outputs do reach the primary agent's rows through the global
+        former; every person-sequence is computed then, as in the reference.  A BOOL mask (what collate_batch produces,
+        dataset_jta.py:23) masks with -inf: a padded person's 21 tokens are never attended to in any global layer and only the
+        primary agent's rows are read (:321), so nothing computed for a padded person reaches the output or any gradient.  With
+        a bool mask the local former therefore runs on the live person-sequences only (`skip_padded_persons`, default on:
+        gather the live rows, six layers, scatter the 21 trajectory tokens back, zeros for padded persons) -- outputs and
+        gradients are those of the full computation (tests/golden/predictor_boolmask_jta.npz: the reference run with a bool mask)."""
         dev = self.device
         S = seq.shape[1]
-        x = seq.permute(0, 2, 1, 3).reshape(B * N, S, self.nhid).contiguous()                        # batch-first (B*N, S, d)
-        pad = self._key_bias(padding_mask.to(dev))                                                   # (B, N) additive
-        pad_local = pad.reshape(-1, 1).expand(-1, S).contiguous()
-        # only the 21 trajectory tokens of every person leave the local former (model_jta.py:316) and only the primary agent's
-        # rows leave the global one (:321): the last layer of each computes those rows alone (prune_dead_rows = False: all rows)
         prune = getattr(self, "prune_dead_rows", True)
-        out_local = self.local_former(x, pad_local, 21 if prune else None) * self.output_scale + (x[:, :21] if prune else x)
+        live = None
+        if padding_mask.dtype == torch.bool and prune and getattr(self, "skip_padded_persons", True):
+            # the list of live persons is taken on the host: collate_batch builds the mask there, so a caller that passes it as it
+            # is pays no device read-back; a device mask costs one synchronisation
+            live = (~padding_mask.cpu().reshape(-1)).nonzero().squeeze(1)
+            live = None if live.numel() == B * N else live.to(dev)
+        pad = self._key_bias(padding_mask.to(dev))                                                   # (B, N) additive
+        if live is not None:
+            x = seq.permute(0, 2, 1, 3)[live // N, live % N].contiguous()                              # (L, S, d): live person-sequences
+            out_live = self.local_former(x, None, 21) * self.output_scale + x[:, :21]                # no key bias: every key is live
+            out_local = torch.zeros(B * N, 21, self.nhid, device=dev, dtype=out_live.dtype).index_copy(0, live, out_live)
+        else:
+            x = seq.permute(0, 2, 1, 3).reshape(B * N, S, self.nhid).contiguous()                    # batch-first (B*N, S, d)
+            pad_local = pad.reshape(-1, 1).expand(-1, S).contiguous()
+            # only the 21 trajectory tokens of every person leave the local former (model_jta.py:316) and only the primary agent's
+            # rows leave the global one (:321): the last layer of each computes those rows alone (prune_dead_rows = False: all rows)
+            out_local = self.local_former(x, pad_local, 21 if prune else None) * self.output_scale + (x[:, :21] if prune else x)
         # global former over the N*21 trajectory tokens of each scene: (B, N*21, d), person-major like the reference
         g = out_local[:, :21].reshape(B, N * 21, self.nhid).contiguous()
         pad_global = pad.repeat_interleave(Fr, dim=1).contiguous()                                   # (B, N*21)
@@ -200,8 +221,10 @@ class TransMotionJTA(nn.Module):
             out_global = self.global_former(g, pad_global) * self.output_scale + g
             out_primary = out_global.view(B, N, Fr, self.nhid)[:, 0]
         if self.multi_modal:
-            outs = [ops.linear(out_primary, h.weight, h.bias) for h in self.predict_head]
-            return torch.stack(outs, dim=2)                                                          # (B,F,M,2)
+            # the M prediction heads (model_jta.py:323-335: M separate nn.Linear(d, 2)) as ONE d -> 2M GEMM on the stacked weights
+            W = torch.cat([h.weight for h in self.predict_head], dim=0)                              # (2M, d)
+            bvec = torch.cat([h.bias for h in self.predict_head], dim=0)
+            return ops.linear(out_primary, W, bvec).reshape(B, Fr, len(self.predict_head), 2)        # (B,F,M,2)
         return ops.linear(out_primary, self.fc_out_traj.weight, self.fc_out_traj.bias).reshape(B, Fr, 1, 2)
 
 

@@ -7,7 +7,7 @@ TransMotionJTA / ValuePoseNet.  For data-parallel training `step` all-reduces on
 """
 import torch
 
-from ..dist import FlatGradBucket, all_reduce_, broadcast_parameters, world_size
+from ..dist import FlatGradBucket, all_reduce_, barrier, broadcast_parameters, rank, world_size
 
 
 def MSE_LOSS(output, target, mask=None):
@@ -70,6 +70,9 @@ def compute_loss(model, config, in_joints, out_joints, in_masks, out_masks, padd
         random_masking = mode == 'train'
     # train_jta.py:102-103 replaces NaN inputs by zero when there are any; done unconditionally (same result, no host read)
     in_joints = torch.where(torch.isnan(in_joints), torch.zeros_like(in_joints), in_joints)
+    if config.get("NOISY_TRAJ"):      # train_jta.py:115-117: gaussian noise on the primary track, inputs and targets (in place, as there)
+        in_joints[:, :, 0, :2] = in_joints[:, :, 0, :2] + torch.randn_like(in_joints[:, :, 0, :2]) * config["NOISY_TRAJ"] ** 2
+        out_joints[:, :, 0, :2] = out_joints[:, :, 0, :2] + torch.randn_like(out_joints[:, :, 0, :2]) * config["NOISY_TRAJ"] ** 2
     pred = model(in_joints, padding_mask, random_masking, limit_obs=limit_obs, frame_masking=config.get('USE_FRAME_MASK', False))
     loss_fn = MSE_LOSS_MULTI if config.get("MULTI_MODAL", False) else MSE_LOSS
     return loss_fn(pred[:, in_F:], out_joints, out_masks), pred
@@ -146,6 +149,18 @@ class EmLocoTrainer:
         self.optimizer = torch.optim.Adam(model.parameters(), lr=config["TRAIN"]["lr"])
         self.bucket = FlatGradBucket(model.parameters()) if data_parallel else None
 
+    # what differs between train_jta.py and train_jrdb.py inside the loop body
+    process_coords = staticmethod(batch_process_coords)
+    value_loss_with_multi_modal = True        # train_jta.py:308 adds the value term in both branches
+
+    def primary_state(self, joints, in_joints):
+        """LocoVal's pose / velocity input of the primary agent (train_jta.py:264-274): raw SMPL joints at the last observed
+        frame with z flipped, velocity from the last two observed positions at 2.5 fps."""
+        pose = joints[:, 0, 8, 3:27, :3].clone().to(self.config["DEVICE"])
+        pose[..., 2] *= -1
+        vel = ((in_joints[:, 8, 0, :2] - in_joints[:, 7, 0, :2]) * 2.5).clone()
+        return pose, vel
+
     def step(self, joints, masks, padding_mask, modality_selection='traj+all', random_masking=True):
         """One iteration of train_jta.py:245-320 on this rank's batch.  Data parallel: the ranks' batches are the equal
         slices of one global batch; the MSE term is a mean over the batch (each rank adds mean / world), the EmLoco term a
@@ -159,14 +174,18 @@ class EmLocoTrainer:
         else:
             self.optimizer.zero_grad(set_to_none=True)
         W = world_size() if self.bucket is not None else 1
-        in_joints, in_masks, out_joints, out_masks, pm = batch_process_coords(joints, masks, padding_mask, cfg, modality_selection, training=True)
-        pose = joints[:, 0, 8, 3:27, :3].clone().to(cfg["DEVICE"])
-        pose[..., 2] *= -1
-        vel = ((in_joints[:, 8, 0, :2] - in_joints[:, 7, 0, :2]) * 2.5).clone()
-        mse, pred = compute_loss(self.model, cfg, in_joints, out_joints, in_masks, out_masks, pm.to(cfg["DEVICE"]), mode='train',
+        in_joints, in_masks, out_joints, out_masks, pm = self.process_coords(joints, masks, padding_mask, cfg, modality_selection, training=True)
+        pose, vel = self.primary_state(joints, in_joints)
+        # MASK_PADDED_PERSONS (extension, off = the reference): hand the model collate_batch's BOOL mask instead of the float copy
+        # batch_process_coords returns -- padded persons are then masked (-inf) instead of biased (+1), and the model skips them
+        # in the local former (model_jta.py `_transform`); a different model function from the reference's training loop
+        pm_model = padding_mask.bool() if cfg.get("MASK_PADDED_PERSONS") else pm.to(cfg["DEVICE"])
+        mse, pred = compute_loss(self.model, cfg, in_joints, out_joints, in_masks, out_masks, pm_model, mode='train',
                                  random_masking=random_masking)
+        if cfg.get("VAL_LOSS_ONLY"):
+            mse = mse * 0                     # train_jta.py:282-283: the value term alone drives the step
         loss = mse / W
-        if self.valuenet is not None:
+        if self.valuenet is not None and (self.value_loss_with_multi_modal or not cfg.get("MULTI_MODAL", False)):
             vsum, cnt = emloco_loss_masked(cfg, self.valuenet, pred, pose, vel, in_joints.shape[1])
             if W > 1:
                 cnt = all_reduce_(cnt.detach().clone())
@@ -199,9 +218,11 @@ def save_checkpoint(model, optimizer, epoch, config, filename, logger=None):
     if not any(k.startswith("module.") for k in sd):
         sd = {"module." + k: v for k, v in sd.items()}
     path = os.path.join(config['OUTPUT']['ckpt_dir'], filename)
-    if logger is not None:
-        logger.info(f'Saving checkpoint to {path}.')
-    torch.save({'model': sd, 'optimizer': optimizer.state_dict(), 'epoch': epoch, 'config': config}, path)
+    if rank() == 0:               # data parallel: the replicas are identical, one writer (concurrent torch.save to one path corrupts it)
+        if logger is not None:
+            logger.info(f'Saving checkpoint to {path}.')
+        torch.save({'model': sd, 'optimizer': optimizer.state_dict(), 'epoch': epoch, 'config': config}, path)
+    barrier()                     # nobody resumes from / evaluates a file that is still being written
     return path
 
 
@@ -232,6 +253,9 @@ def evaluate_loss(model, dataloader, config, modality_selection='traj+all', limi
 def train_epoch(trainer, dataloader, epoch, modality_selection='traj+all', max_steps=None):
     """One epoch of train_jta.py:225-352 over a DataLoader with the EmLoco loss (EmLocoTrainer.step per batch)."""
     adjust_learning_rate(trainer.optimizer, epoch, trainer.config)
+    sampler = getattr(dataloader, "sampler", None)
+    if hasattr(sampler, "set_epoch"):          # DistributedSampler: a new permutation (and per-rank shard) every epoch, as shuffle=True gives
+        sampler.set_epoch(epoch)
     tot, n = 0.0, 0
     for step, (joints, masks, padding_mask) in enumerate(dataloader):
         loss, _mse = trainer.step(joints, masks, padding_mask, modality_selection)
@@ -259,8 +283,9 @@ def load_config(path, exp_name="default", dataset_name="default", out_root="expe
     for key, sub in (("log_dir", "logs"), ("ckpt_dir", "checkpoints"), ("runs_dir", "runs")):
         config["OUTPUT"][key] = os.path.join(base, sub)
         os.makedirs(config["OUTPUT"][key], exist_ok=True)
-    with open(os.path.join(config["OUTPUT"]["ckpt_dir"], "config.yaml"), "w") as f:
-        yaml.safe_dump(config, f)
+    if rank() == 0:               # one writer per experiment directory
+        with open(os.path.join(config["OUTPUT"]["ckpt_dir"], "config.yaml"), "w") as f:
+            yaml.safe_dump(config, f)
     return config
 
 
@@ -392,7 +417,7 @@ if __name__ == "__main__":
     from ..dist import init_from_env
     _lib.require_device()                                # the predictor runs on the HIP library: no CPU path
     args = build_arg_parser().parse_args()
-    rank, local_rank, _world = init_from_env("nccl")
+    _rank, local_rank, _world = init_from_env("nccl")
     torch.cuda.set_device(local_rank)
     cfg = config_from_args(args)
     cfg["DEVICE"] = f"cuda:{local_rank}"

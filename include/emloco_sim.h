@@ -128,6 +128,8 @@ int emloco_sim_set_ground_heightfield(EmlocoSim *sim, const int16_t *samples, in
 int emloco_sim_prepare(EmlocoSim *sim);
 /* gym.get_sim_params / set_sim_params -- base_task.py:151 */
 int emloco_sim_get_params(EmlocoSim *sim, EmlocoSimParams *out);
+/* (set_params validates like emloco_sim_create; once the sim is prepared `drive_mode` is ignored: the live mode belongs to the
+ * last emloco_sim_set_pd_targets / emloco_sim_set_dof_actuation_force upload) */
 int emloco_sim_set_params(EmlocoSim *sim, const EmlocoSimParams *in);
 /* gym.acquire_*_tensor -- humanoid.py:137-148: device pointer + shape of a state tensor the sim owns */
 int emloco_sim_tensor(EmlocoSim *sim, int kind, void **dev_ptr, int64_t shape[2]);
@@ -158,6 +160,12 @@ int emloco_sim_set_split(EmlocoSim *sim, int n_parts);
 int emloco_sim_set_cost_order(EmlocoSim *sim, int on);
 /* gym.fetch_results(sim, True) -- base_task.py:258: host waits for the stream */
 int emloco_sim_sync(EmlocoSim *sim, void *stream);
+/* Fault injection for the split launch's hand-over (no counterpart in the gym API; the product never calls it).  The first
+ * part of `env` withholds its hand-over flag in the split launches that follow (env = -1: back to normal), and a later part's
+ * wait is bounded by `spin_max` sleeps (<= 0: the default, 1 << 22).  A wait that runs out raises the device error word that
+ * emloco_sim_sync / the next emloco_sim_step return as EMLOCO_E_HIP: this call lets a test see that path in milliseconds
+ * instead of seconds (tests/test_gpu_sim.py).  Costs the kernel one scalar compare per part. */
+int emloco_sim_debug_poison_part(EmlocoSim *sim, int env, int spin_max);
 /* gym.set_actor_root_state_tensor_indexed / set_dof_state_tensor_indexed -- humanoid.py:470-475.
  * `dev_full` is the full tensor (may be the sim's own alias); rows of the listed envs are applied and the
  * rigid-body state of those envs is recomputed.  `dev_env_ids` int32 device pointer, n entries. */

@@ -4,6 +4,13 @@
     python tests/golden/gen_golden_fullwidth.py     ->  tests/golden/predictor_fullwidth_{jta,jrdb}.npz
     python tests/golden/gen_golden_fullwidth.py jta_deep jta_deep_mm
                                                     ->  tests/golden/predictor_fulldepth_{jta,jta_mm}.npz
+    python tests/golden/gen_golden_fullwidth.py jta_bool
+                                                    ->  tests/golden/predictor_boolmask_jta.npz
+
+`jta_bool` hands the model the BOOL padding mask `collate_batch` produces (dataset_jta.py:23) instead of the float copy
+`batch_process_coords` returns (:84): torch then masks padded persons' keys with -inf instead of biasing them by +1.  B = 3 scenes
+x N = 3 people (four padded), 2 local + 2 global layers.  Pins the masked semantics, under which this repo may skip padded
+persons in the local former altogether.
 
 The `_deep` kinds are the SHIPPED model (social-transmotion/configs/jta_all_visual_cues.yaml:20-33): 6 local + 3 global layers;
 `jta_deep` single-mode with the EmLoco loss (configs[3]), `jta_deep_mm` with the 20 prediction heads and MSE_LOSS_MULTI (configs[4]).
@@ -41,10 +48,14 @@ def run(kind):
     deep = kind.startswith("jta_deep")
     mm = kind.endswith("_mm")
     nl, ng, nmode = (6, 3, 20) if deep else (1, 1, 4)
-    fname = {"jta_deep": "predictor_fulldepth_jta", "jta_deep_mm": "predictor_fulldepth_jta_mm"}.get(kind, f"predictor_fullwidth_{kind}")
-    g = torch.Generator().manual_seed({"jta": 31, "jrdb": 37, "jta_deep": 41, "jta_deep_mm": 43}[kind])
-    B, N = 2, 2
-    if deep:
+    boolmask = kind == "jta_bool"
+    if boolmask:
+        nl, ng = 2, 2
+    fname = {"jta_deep": "predictor_fulldepth_jta", "jta_deep_mm": "predictor_fulldepth_jta_mm",
+             "jta_bool": "predictor_boolmask_jta"}.get(kind, f"predictor_fullwidth_{kind}")
+    g = torch.Generator().manual_seed({"jta": 31, "jrdb": 37, "jta_deep": 41, "jta_deep_mm": 43, "jta_bool": 47}[kind])
+    B, N = (3, 3) if boolmask else (2, 2)
+    if deep or boolmask:
         kind = "jta"
     if kind == "jta":
         import model_jta as M
@@ -72,11 +83,17 @@ def run(kind):
     masks = torch.ones(B, N, 21, J)
     padding_mask = torch.zeros(B, N, dtype=torch.bool)
     padding_mask[1, 1] = True                                         # one padded person
+    if boolmask:
+        padding_mask[1, 2] = True
+        padding_mask[2, 1:] = True
+        joints[padding_mask] = 0                                      # pad_sequence fills padded persons with zeros (dataset_jta.py:20)
     in_joints, _, out_joints, _, pm = batch_process_coords(joints.clone(), masks, padding_mask, cfg, training=(kind == "jta"))   # JRDB training mode applies a random (torchvision) rotation
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = make_state_dict(shapes, seed=1234)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model.eval()
+    if boolmask:
+        pm = padding_mask
     pred = model(in_joints.clone(), pm.clone())
     loss = LOSS(pred[:, 9:], out_joints)
     extra = {}
@@ -98,6 +115,9 @@ def run(kind):
                weight_checksum=np.array(float(sum(np.abs(v).sum(dtype=np.float64) for v in sd.values()))),
                keys=np.array("\n".join(f"{k} {' '.join(map(str, shapes[k]))}" for k in sorted(shapes))), **extra)
     whole, samp = list(PICK_WHOLE), list(PICK_SAMPLE)
+    if boolmask:
+        whole += ["local_former.layers.1.norm2.weight", "global_former.layers.1.self_attn.out_proj.bias", "double_id_encoder.person_encoding.weight"]
+        samp += ["local_former.layers.1.linear1.weight", "global_former.layers.1.linear2.weight"]
     if deep:                                                          # the last layers too: nine stacked post-norm layers
         whole += ["local_former.layers.5.norm2.weight", "local_former.layers.5.linear2.bias", "global_former.layers.2.norm2.weight",
                   "global_former.layers.2.self_attn.out_proj.bias", "local_former.layers.3.self_attn.in_proj_bias"]

@@ -389,6 +389,79 @@ def test_fullwidth_model_through_fused_attention_matches_reference(golden, kind,
     assert n_checked >= 16
 
 
+@pytest.mark.parametrize("skip", [True, False])
+def test_bool_padding_mask_matches_reference_with_and_without_skipping_padded_persons(golden, skip):
+    """The reference's own model run with collate_batch's BOOL padding mask (tests/golden/gen_golden_fullwidth.py jta_bool: 3 scenes
+    x 3 people, four of them padded, 2 local + 2 global layers, d = 128): torch masks padded persons' keys with -inf.  Here the
+    local former then runs on the five live person-sequences only (`skip_padded_persons`); logits, loss and gradients -- of the
+    person encoding too, whose padded slots must get exactly what the reference gives them -- within 1e-4 / 2e-4 of the tensor scale
+    of the reference, with the skipping on and off."""
+    from fullwidth_weights import make_state_dict, sample
+    from emloco_amd.predictor.model_jta import TransMotionJTA
+    from emloco_amd.predictor.train_jta import MSE_LOSS
+    g = golden("predictor_boolmask_jta")
+    dev = "cuda:0"
+    model = TransMotionJTA(tok_dim=453, nhid=128, nhead=4, dim_feedfwd=1024, nlayers_local=2, nlayers_global=2, nmode=4, output_scale=1,
+                           obs_and_pred=21, num_tokens=49, device=dev, multi_modal=False).to(dev).float()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert "\n".join(f"{k} {' '.join(map(str, shapes[k]))}" for k in sorted(shapes)) == str(g["keys"])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(shapes, seed=int(g["weight_seed"])).items()}, strict=True)
+    model.eval()
+    model.skip_padded_persons = skip
+    pm = torch.from_numpy(g["pm"])
+    assert pm.dtype == torch.bool and int(pm.sum()) == 4
+    seen = []
+    orig = model.local_former.forward
+    model.local_former.forward = lambda x, *a, **k: (seen.append(x.shape[0]), orig(x, *a, **k))[1]
+    in_joints, out_joints = torch.from_numpy(g["in_joints"]).to(dev), torch.from_numpy(g["out_joints"]).to(dev)
+    pred = model(in_joints.clone(), pm.clone())                       # the host mask, as collate_batch hands it over
+    assert seen == [5 if skip else 9]                                 # person-sequences that went through the local former
+    _close(pred.detach().cpu().numpy(), g["pred"], what="bool-mask logits")
+    mse = MSE_LOSS(pred[:, 9:], out_joints)
+    _close(mse.item(), g["mse"], what="mse")
+    vnet = _vnet(g)
+    pred_traj = torch.cat([torch.zeros(pred.shape[0], 1, 2, device=dev), pred[:, 9:, 0, :2]], dim=1).contiguous()
+    _value, vloss = vnet.calc_embodied_motion_loss(pred_traj, torch.from_numpy(g["pose"]).to(dev), torch.from_numpy(g["vel"]).to(dev))
+    loss = mse + 1.0 * vloss
+    _close(loss.item(), g["loss"], what="loss")
+    loss.backward()
+    params = dict(model.named_parameters())
+    n_checked = 0
+    for k, v in g.items():
+        if k.startswith("grad__"):
+            _close(params[k[6:].replace("__", ".")].grad.cpu().numpy(), v, rel=2e-4, abs_=1e-6, what=k)
+            n_checked += 1
+        elif k.startswith("gsample__"):
+            _close(sample(params[k[9:].replace("__", ".")].grad.cpu().numpy()), v, rel=2e-4, abs_=1e-6, what=k)
+            n_checked += 1
+    assert n_checked >= 21
+    # a device mask gives the same result (one read-back)
+    again = model(in_joints.clone(), pm.to(dev))
+    assert torch.equal(again, pred)
+
+
+def test_float_padding_mask_keeps_padded_persons_in_play():
+    """Why the skipping is tied to the mask's dtype: with the FLOAT mask the reference's loops pass (dataset_jta.py:84) a padded
+    person's keys are biased by +1, not masked -- changing a padded person's input changes the primary agent's prediction -- while
+    with the bool mask it cannot."""
+    from emloco_amd.predictor.model_jta import TransMotionJTA
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    model = TransMotionJTA(tok_dim=453, nhid=128, nhead=4, dim_feedfwd=256, nlayers_local=1, nlayers_global=1, nmode=4, output_scale=1,
+                           obs_and_pred=21, num_tokens=49, device=dev, multi_modal=False).to(dev).float().eval()
+    x = torch.randn(2, 9, 2 * 49, 4, device=dev)
+    pm = torch.tensor([[False, True], [False, False]])
+    x2 = x.clone()
+    x2[0, :, 49:] += 1.0                                              # scene 0's padded person
+    for _ in range(2):
+        model(x, pm)                                                   # Embedding(max_norm) settles
+    assert torch.equal(model(x, pm), model(x2, pm))
+    a, b = model(x, pm.float().to(dev)), model(x2, pm.float().to(dev))
+    assert (a[0] - b[0]).abs().max().item() > 1e-4 and torch.equal(a[1], b[1])
+    model.skip_padded_persons = False
+    assert torch.equal(model(x, pm), model(x2, pm))
+
+
 @pytest.mark.parametrize("kind", ["jta", "jta_mm"])
 def test_shipped_depth_model_matches_reference(golden, kind):
     """The SHIPPED model (social-transmotion/configs/jta_all_visual_cues.yaml:20-33: 6 local + 3 global layers, d = 128, 4 heads,
@@ -689,6 +762,38 @@ def test_train_and_evaluate_entry_points_from_the_shipped_yaml(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     log = r.stderr + r.stdout
     assert "Total samples: 12" in log and "ADE with Value sampling" in log
+    ade = float(log.split("ADE: ")[1].split()[0])
+    assert np.isfinite(ade) and ade > 0
+
+
+def test_train_jrdb_entry_point_from_the_shipped_yaml(tmp_path):
+    """`python -m emloco_amd.predictor.train_jrdb --cfg configs/jrdb_all_visual_cues.yaml --valueloss_w 1.0 --dry-run`
+    (social-transmotion/train_jrdb.py:353-421) on a synthetic preprocessed split: the shipped yaml builds TransMotionJRDB
+    (S = 246) through create_model, the initial validation pass and one optimiser step run with the random-yaw augmentation and
+    the EmLoco loss, the checkpoints land where `evaluate_jta --dataset jrdb` looks for them, and that entry point loads them."""
+    import subprocess
+    import sys
+    from emloco_amd.predictor.dataset_jrdb import write_synthetic_split
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = str(tmp_path / "data")
+    for split, n in (("train", 24), ("val", 12), ("test", 12)):
+        write_synthetic_split(data, split, n, max_people=3, seed=len(split))
+    out = str(tmp_path / "experiments")
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "emloco_amd.predictor.train_jrdb", "--exp_name", "j0", "--valueloss_w", "1.0", "--dry-run",
+                        "--data_root", data, "--out_root", out], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    log = r.stderr + r.stdout
+    ck = os.path.join(out, "JRDB", "j0", "checkpoints")
+    assert "Initial validation loss" in log and "Model has 3220162 parameters" in log
+    assert os.path.exists(os.path.join(ck, "checkpoint_0epoch.pth.tar")) and os.path.exists(os.path.join(ck, "config.yaml"))
+    if not os.path.exists(os.path.join(ck, "best_val_checkpoint.pth.tar")):      # (one step need not beat the initial validation loss)
+        os.rename(os.path.join(ck, "checkpoint_0epoch.pth.tar"), os.path.join(ck, "best_val_checkpoint.pth.tar"))
+    r = subprocess.run([sys.executable, "-m", "emloco_amd.predictor.evaluate_jta", "--dataset", "jrdb", "--exp_name", "j0", "--valueloss",
+                        "--data_root", data, "--out_root", out], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    log = r.stderr + r.stdout
+    assert "Total samples: 12" in log
     ade = float(log.split("ADE: ")[1].split()[0])
     assert np.isfinite(ade) and ade > 0
 

@@ -138,3 +138,38 @@ def test_predictor_config_and_cli_plumbing(tmp_path):
     assert ev.find_checkpoint(ea).endswith("checkpoint_7epoch.pth.tar")
     open(os.path.join(d, "best_val_checkpoint_7epoch.pth.tar"), "w").close()
     assert ev.find_checkpoint(ea).endswith("best_val_checkpoint_7epoch.pth.tar")
+
+
+def test_jrdb_dataset_pickles_collate_and_cli(tmp_path):
+    """On-disk JRDB format (dataset_jrdb.py:129-210): `preprocess_smpl_filtered_v4/<split>` pickles of scenes -> people ->
+    (joints (21,26,4), mask, ids); items carry the scene index, collate returns the index list as a fourth entry; the JRDB
+    command line (train_jrdb.py:353-397) folds into the config -- host logic only, no GPU."""
+    import torch
+    from torch.utils.data import DataLoader
+    from emloco_amd.predictor import train_jrdb as tj
+    from emloco_amd.predictor.dataset_jrdb import collate_batch, create_dataset, get_datasets, write_synthetic_split
+    write_synthetic_split(str(tmp_path), "train", 11, max_people=4, seed=2)
+    ds = create_dataset("jrdb_all_visual_cues", split="train", track_size=21, track_cutoff=9, preprocessed=True, root=str(tmp_path))
+    assert len(ds) == 11 and os.path.isdir(tmp_path / "jrdb_all_visual_cues" / "preprocess_smpl_filtered_v4" / "train")
+    j, m, idx = ds[3]
+    assert j.shape[1:] == (21, 26, 4) and m.shape[1:] == (21, 26) and idx == 3 and len(ds.show_meta_info(3)) == j.shape[0]
+    joints, masks, pad, idxs = next(iter(DataLoader(ds, batch_size=4, collate_fn=collate_batch, shuffle=False)))
+    assert joints.shape[0] == 4 and joints.shape[2:] == (21, 26, 4) and pad.dtype == torch.bool and idxs == [0, 1, 2, 3]
+    cfg = {"TRAIN": {"input_track_size": 9, "output_track_size": 12}, "DATA": {"preprocessed": True}}
+    assert len(get_datasets(["jrdb_all_visual_cues"], cfg, root=str(tmp_path))[0]) == 11
+    with pytest.raises(NotImplementedError):
+        create_dataset("jta_all_visual_cues", split="train", preprocessed=True, root=str(tmp_path))
+    a = tj.build_arg_parser().parse_args(["--exp_name", "j", "--valueloss_w", "0.5", "--valueloss_only", "--noisy_traj", "--out_root", str(tmp_path)])
+    c = tj.config_from_args(a)
+    assert c["MODEL"]["seq_len"] == 246 and c["USE_VALUELOSS"] and c["VAL_LOSS_ONLY"] and c["NOISY_TRAJ"] is True
+    assert c["TRAIN"]["valuenet_weight"] == 0.5 and os.path.exists(os.path.join(c["OUTPUT"]["ckpt_dir"], "config.yaml"))
+    assert c["OUTPUT"]["ckpt_dir"].endswith(os.path.join("JRDB", "j", "checkpoints"))
+    with pytest.raises(NotImplementedError):
+        tj.config_from_args(tj.build_arg_parser().parse_args(["--use_hypara_best", "--out_root", str(tmp_path)]))
+    # the JRDB loop's LocoVal inputs: normalised tokens 2:26 of the last observed frame, no z flip (train_jrdb.py:186)
+    tr = tj.JrdbTrainer.__new__(tj.JrdbTrainer)
+    tr.config = {"DEVICE": "cpu"}
+    inj = torch.randn(3, 9, 2 * 26, 4)
+    pose, vel = tr.primary_state(None, inj)
+    assert torch.equal(pose, inj[:, 8, 2:26, :3]) and torch.allclose(vel, (inj[:, 8, 0, :2] - inj[:, 7, 0, :2]) * 2.5)
+    assert tj.JrdbTrainer.value_loss_with_multi_modal is False
