@@ -503,43 +503,12 @@ def locoval_policy_leg(env, E, dev, steps, warmup):
     return {"metric": "env-steps/sec, frozen policy + AMP discriminator reward + LocoVal fit in the loop (configs[2] on one GPU)",
             "value": round(E * steps / dt, 1), "unit": "env-steps/s", "ms_per_step": round(dt / steps * 1e3, 4),
             "episodes_fitted": agent.fitted_episodes,
-            "note": "policy forward (5 GEMMs) and discriminator forward (3 GEMMs, 3090 -> 1024 -> 512 -> 1) on the split-mode matrix path every step; "
-                    "the discriminator reads the step's AMP observations before the resets, so the AMP rows of every env stay in the flags launch "
-                    "(task.fused_amp_early) and only the observation rows ride in the fused reset / observation launch"}
-
-
-def pipelined_leg(E, dev, steps, warmup):
-    """Reported beside the headline, never instead of it: the same 4096 envs as TWO independent 2048-env shards of this GPU,
-    each stepped (reset_done + env.step) on its own HIP stream.  One shard is exactly one resident round of waves (256 CUs x
-    8), so the shards run out of phase: one shard's latency-bound small kernels (post-physics, resets, PD targets) overlap
-    the other shard's rigid-body kernel.  What a double-buffered rollout loop gets; a single env.step over all envs cannot."""
-    import torch
-    shards = [make_env(E // 2, 1000 + i) for i in range(2)]
-    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-    g = torch.Generator(device=dev)
-    g.manual_seed(4321)
-    pools = [torch.randn(64, E // 2, 69, device=dev, generator=g) * float(np.exp(-2.9)) for _ in range(2)]
-    for e in shards:
-        e.reset(torch.arange(E // 2, device=dev))
-    torch.cuda.synchronize()
-
-    def it(k):
-        for i in range(2):
-            with torch.cuda.stream(streams[i]):
-                shards[i].reset_done()
-                shards[i].step(pools[i][k % 64])
-
-    for k in range(warmup):
-        it(k)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        it(k)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"metric": "env-steps/sec, two 2048-env shards on two HIP streams (same GPU, same workload)",
-            "value": round(E * steps / dt, 1), "unit": "env-steps/s", "ms_per_step": round(dt / steps * 1e3, 4),
-            "shards": 2, "envs_per_shard": E // 2}
+            "discriminator_deferred": agent._disc_halves is not None,
+            "note": "policy forward (5 GEMMs) on the chain; the discriminator (3 GEMMs, 3090 -> 1024 -> 512 -> 1, split-mode matrix path) OFF it: "
+                    "its style reward feeds the return bookkeeping only, so the flags launch stages the step (LocoVal inputs, penalised reward, done "
+                    "flag), one launch takes the normalised GEMM operand out of the AMP observations before the resets, and a side stream runs the "
+                    "GEMMs, emloco_locoval_returns_finish and the fit beside the resets / policy / next rigid-body launch; results bit-equal to "
+                    "the sequential order (tests/test_gpu_env.py); EMLOCO_DEFER_DISC=0 puts the discriminator back between env.step and the reset"}
 
 
 def main():
@@ -551,7 +520,7 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_policy", action="store_true", help="skip the frozen-policy leg (row A19, reported separately)")
     ap.add_argument("--no_jta", action="store_true", help="skip the train_jta samples/s leg (run on rank 0 at N=1)")
-    ap.add_argument("--no_pipelined", action="store_true", help="skip the two-shard / two-stream leg (rank 0 at N=1, reported separately)")
+    ap.add_argument("--no_pipelined", action="store_true", help="(accepted, ignored: the two-shard and two-chain legs of rounds 2-3 lost to the headline schedule and are gone)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher -- one process per GPU, as the driver's
@@ -580,13 +549,10 @@ def main():
     E = a.num_envs
     env = make_env(E, rank)
     task = env.task
-    # Two schedules of the same step (identical results, tests/test_gpu_env.py / test_gpu_sim.py):
-    #   sequential (HEADLINE): the reference's order -- reset chain of the finished envs, then one rigid-body launch for all envs,
-    #     dispatched most-contact-work-first (emloco_sim_set_cost_order).  Every consumer can use it: the observations of the
-    #     reset envs exist before the policy runs (amp_continuous_value.py:46-52);
-    #   overlapped (reported beside it as `overlapped_obs_blind`, N = 1): the reset chain and the reset envs' step on a second
-    #     HIP stream beside the step of the live envs (task.overlap_reset) -- only a policy that does not read the reset envs'
-    #     fresh observations can start the step before the reset chain has finished.
+    # The schedule: the reference's order -- reset chain of the finished envs, then one rigid-body launch for all envs, dispatched
+    # most-contact-work-first (emloco_sim_set_cost_order).  Every consumer can use it: the observations of the reset envs exist
+    # before the policy runs (amp_continuous_value.py:46-52).  (Rounds 2-3 also reported a two-chain schedule for observation-blind
+    # consumers and a two-shard pipeline: both lost to this one once the chain between two steps was fused, and are gone.)
     n_parts = int(os.environ.get("EMLOCO_SPLIT", "4"))
     task.sim.native.set_cost_order(os.environ.get("EMLOCO_COST_ORDER", "1") != "0")
     env.reset(torch.arange(E, device=dev))
@@ -653,42 +619,6 @@ def main():
         env_only = time.perf_counter() - t1
         n_s, ms_s = task.sim.native.timing_stats()
 
-    # the overlapped schedule (a consumer that does not read the reset envs' observations before it acts)
-    blind = None
-    if world == 1 and os.environ.get("EMLOCO_OVERLAP_RESET", "1") != "0":
-        task.sim.native.set_cost_order(False)             # the two do not add up: cost order keeps the wave slots busy longest
-        blind_policy = lambda obs: noise_policy(obs)
-        blind_policy.reads_obs = False
-        # the same agent (HIP serves a process with four hardware queues: a second agent's side stream would share one)
-        agent.policy = blind_policy
-        agent.attach()
-        fused_chain, task.fused_chain = task.fused_chain, False
-        task.overlap_reset = True
-        task.overlap_obs = os.environ.get("EMLOCO_OVERLAP_OBS", "0") == "1"    # see LocoValRollout.__init__: nothing to hide behind here
-        b_t, b_n, b_ms = timed_loop(agent)
-        agent._sync_fit()
-        agent.detach()
-        task.wait_reset()
-        for k in range(a.warmup):
-            env.reset_done(); env.step(pool[k % 64])
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for k in range(a.steps):
-            env.reset_done(); env.step(pool[k % 64])
-        torch.cuda.synchronize()
-        b_env = time.perf_counter() - t1
-        task.wait_reset()
-        task.overlap_reset = False
-        task.fused_chain = fused_chain
-        task.sim.native.set_cost_order(True)
-        blind = {"value": round(E * a.steps / b_t, 1), "unit": "env-steps/s", "ms_per_step": round(b_t / a.steps * 1e3, 4),
-                 "kernel_ms": round(b_ms / max(b_n, 1), 4), "launches_timed": b_n,
-                 "env_step_only": round(E * a.steps / b_env, 1),
-                 "note": "the same LocoVal loop with the reset chain of the finished envs and their step on a second HIP stream beside "
-                         "the step of the live envs (task.overlap_reset); usable only by a policy that does not read the reset envs' fresh "
-                         "observations before acting (the stand-in noise policy declares reads_obs = False here) -- NOT the headline; "
-                         "kernel_ms = the live envs' launch with the reset chain and the id-list launch sharing the device"}
-
     if rank == 0:
         kernel_ms = ms_l / max(n_l, 1)
         achieved = SIM_BYTES_PER_ENV * E / (kernel_ms * 1e-3) / 1e9 if n_l else 0.0
@@ -735,10 +665,6 @@ def main():
                                     "note": "reset_done + env.step in the same sequential schedule without the LocoVal bookkeeping / fit; kernel_ms = "
                                             "sim_step_kernel with nothing but the observation launch of the previous step beside it"}
             out["sequential"] = dict(out["env_step_only"])         # the name earlier rounds reported this leg under
-        if blind is not None:
-            out["overlapped_obs_blind"] = blind
-        if world == 1 and not a.no_pipelined and E % 2 == 0:        # ahead of the policy legs: their agents' streams would share its hardware queues
-            out["pipelined"] = pipelined_leg(E, dev, a.steps, a.warmup)
         if world == 1 and not a.no_policy:
             # a policy reads the reset envs' fresh observations, so the reset chain cannot hide beside the step: the sequential
             # schedule (observation launch of the live envs beside the reset chain, cost-ordered dispatch) is the faster one here

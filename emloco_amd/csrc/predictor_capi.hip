@@ -313,8 +313,21 @@ int emloco_locoval_returns(const EmlocoLocoValStep *t, const float *rewards, con
     if (!t || !rewards || !dones || t->n_env < 1 || !t->current_rewards || !t->current_lengths || !t->current_combined_rewards ||
         !t->discount_coefs || !t->waypoint_traj || !t->init_pose || !t->init_vel || !t->traj13 || !t->pose || !t->vel || !t->target || !t->weight)
         return pfail(-1, "emloco_locoval_returns: bad argument");
+    if ((t->staged_reward == nullptr) != (t->staged_done == nullptr))
+        return pfail(-1, "emloco_locoval_returns: staged_reward and staged_done go together");
     hipLaunchKernelGGL(emloco::locoval_returns_kernel, dim3((unsigned)t->n_env), dim3(64), 0, (hipStream_t)stream, *t, rewards, amp_rewards,
                        dones, inverted);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
+int emloco_locoval_returns_finish(const EmlocoLocoValStep *t, const float *amp_rewards, void *stream) {
+    if (!t || t->n_env < 1 || !t->current_rewards || !t->current_lengths || !t->current_combined_rewards || !t->discount_coefs ||
+        !t->target || !t->weight)
+        return pfail(-1, "emloco_locoval_returns_finish: bad argument");
+    if (!t->staged_reward || !t->staged_done) return pfail(-1, "emloco_locoval_returns_finish: the step has no staging arrays (nothing was staged)");
+    hipLaunchKernelGGL(emloco::locoval_returns_finish_kernel, dim3((unsigned)((t->n_env + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *t,
+                       amp_rewards);
     PHIPCHK(hipGetLastError());
     return 0;
 }

@@ -1009,6 +1009,14 @@ locoval_returns_kernel(EmlocoLocoValStep t, const float *rewards, const float *a
     locoval_returns_env(t, e, lane, rewards[e], amp_rewards ? amp_rewards[e] : 0.0f, dones[e] != 0, inverted && inverted[e]);
 }
 
+// second half of a staged step (locoval_returns_device.h): one thread per env
+__global__ void __launch_bounds__(256)
+locoval_returns_finish_kernel(EmlocoLocoValStep t, const float *amp_rewards) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= t.n_env) return;
+    locoval_advance_env(t, e, t.staged_reward[e], amp_rewards ? amp_rewards[e] : 0.0f, t.staged_done[e] != 0);
+}
+
 // d/dvalue of sum_e w_e (value_e - target_e)^2 (MSELoss(reduction='sum') over the valid rows, common_agent.py:96) and the two
 // scalars that travel with the gradient bucket: tail = [loss sum, number of valid rows].  Also ranks the valid rows:
 // slot[e] = number of valid rows before e (or -1), so that the backward pass touches only those rows (a few dozen of 4096

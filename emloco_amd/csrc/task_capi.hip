@@ -86,6 +86,8 @@ int emloco_task_post_physics_returns(const EmlocoTaskBufs *b, int mode, const vo
     if (step->n_env != b->n_env || !step->current_rewards || !step->current_lengths || !step->current_combined_rewards || !step->discount_coefs ||
         !step->waypoint_traj || !step->init_pose || !step->init_vel || !step->traj13 || !step->pose || !step->vel || !step->target || !step->weight)
         return tfail(-1, "emloco_task_post_physics_returns: LocoVal step buffers missing or for another env count");
+    if ((step->staged_reward == nullptr) != (step->staged_done == nullptr))
+        return tfail(-1, "emloco_task_post_physics_returns: staged_reward and staged_done go together");
     if (b->n_env < 1 || b->hf_rows < 2 || b->hf_cols < 2 || !b->rb_state || !b->progress_buf || !b->traj_verts || !b->rew_buf || !b->reward_raw ||
         !b->dof_force || !b->dof_state || !b->reset_buf || !b->terminate_buf || !b->contact_force || !b->contact_body_mask)
         return tfail(-1, "emloco_task_post_physics_returns: task buffers missing");

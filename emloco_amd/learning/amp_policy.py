@@ -67,6 +67,16 @@ class AMPPolicyBundle:
         with torch.no_grad():
             return self.frozen_disc.reward(amp_obs)
 
+    def disc_stage(self, amp_obs):
+        """First half of `disc_reward` (FrozenDisc.stage): one launch that reads the step's AMP observations."""
+        with torch.no_grad():
+            self.frozen_disc.stage(amp_obs)
+
+    def disc_reward_staged(self):
+        """Second half (FrozenDisc.reward_staged): the GEMMs and the scalar transform, nothing of the task's is read."""
+        with torch.no_grad():
+            return self.frozen_disc.reward_staged()
+
     def disc_reward_modules(self, amp_obs):
         with torch.no_grad():
             x = amp_obs.reshape(amp_obs.shape[0], -1)

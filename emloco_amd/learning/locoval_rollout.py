@@ -139,6 +139,26 @@ class LocoValRollout:
         self._ev_staged = torch.cuda.Event() if self._side is not None else None
         self._ev_fit = torch.cuda.Event() if self._side is not None else None
         self._fit_pending = False
+        # The discriminator off the chain between two rigid-body steps.  Its style reward (amp_continuous_value.py:90-96) feeds the
+        # return bookkeeping only -- not the action, not the resets -- but in the reference's order it sits between env.step and the
+        # next env_reset: 3 GEMMs (30 GFLOP at 4096 envs, ~0.26 ms) every step.  Deferred mode: the task's flags launch STAGES the
+        # step (LocoVal inputs, penalised reward, done flag: emloco_task_post_physics_returns with staging arrays), one launch on the
+        # main stream takes the normalised GEMM operand out of the AMP observations (`disc_stage`), and the side stream runs the
+        # GEMMs, the scalar transform, emloco_locoval_returns_finish and the fit while the main stream goes on to the resets, the
+        # policy and the next rigid-body launch.  Same kernels on the same values: returns, targets and the fitted network are the
+        # sequential loop's bit for bit (tests/test_gpu_env.py).  Needs a discriminator that comes in two halves (`disc_stage` /
+        # `disc_reward_staged` on the object `disc_reward` is bound to: AMPPolicyBundle) and the task's returns hook.
+        owner = getattr(self.disc_reward, "__self__", None)
+        self._disc_halves = None
+        if (not self._no_disc and self._side is not None and hasattr(task, "attach_returns") and hasattr(owner, "disc_stage")
+                and hasattr(owner, "disc_reward_staged") and getattr(task, "fused_chain", False)
+                and os.environ.get("EMLOCO_DEFER_DISC", "1") != "0"):
+            self._disc_halves = (owner.disc_stage, owner.disc_reward_staged)
+            z["staged_reward"] = f(E)
+            z["staged_done"] = torch.zeros(E, dtype=torch.uint8, device=dev)
+            self._fstep.staged_reward, self._fstep.staged_done = p(z["staged_reward"]), p(z["staged_done"])
+            task.attach_returns(self._fstep, before=self._before_flags)
+            self._returns_in_flags = True
 
     def _check_fused_inputs(self):
         """The fused step keeps raw device pointers of the task's LocoVal inputs (the kernel hard-codes their strides: 15 x 3
@@ -184,6 +204,8 @@ class LocoValRollout:
                 main.wait_event(self._ev_fit)               # the previous fit is done with the staging buffers
             ops._chk(lib.emloco_locoval_returns(C.byref(s), P(rewards.contiguous()), P(amp_rewards), P(dones.contiguous()), P(inverted.contiguous()), st),
                      "emloco_locoval_returns")
+            if s.staged_reward:                             # a step that carries staging arrays was only staged by that call
+                ops._chk(lib.emloco_locoval_returns_finish(C.byref(s), P(amp_rewards), st), "emloco_locoval_returns_finish")
         if self._side is None:
             self._fit_launches(st)
             return
@@ -259,10 +281,35 @@ class LocoValRollout:
             obs, rewards, dones, infos = self.vec_env.step(actions)
             inverted = task.inverted
             self.frames += self.num_actors
+            if self._disc_halves is not None and getattr(task, "_returns_in_flags", False):
+                self._deferred_disc_step(infos["amp_obs"])
+                return
             if not self._no_disc and hasattr(task, "wait_obs") and not (getattr(task, "fused_chain", False) and getattr(task, "fused_amp_early", False)):
                 task.wait_obs()                                   # the discriminator reads this step's AMP observations
             amp_rewards = None if self._no_disc else self.disc_reward(infos["amp_obs"]).contiguous()
         self._bookkeeping(rewards, amp_rewards, dones, inverted)
+
+    def _deferred_disc_step(self, amp_obs):
+        """The step's flags launch has staged the return bookkeeping (after waiting for the previous fit: `_before_flags`).  Main stream:
+        one launch that reads the AMP observations; side stream: discriminator GEMMs, reward transform, the bookkeeping's second half,
+        the fit.  Nothing the side stream reads is written by the main stream before the next flags launch, which waits for `_ev_fit`."""
+        import ctypes as C
+        from ..predictor import ops
+        from ..sim import current_stream_handle
+        stage, finish = self._disc_halves
+        self.task._returns_in_flags = False
+        main = torch.cuda.current_stream(self.device)
+        stage(amp_obs)
+        self._ev_staged.record(main)
+        self._side.wait_event(self._ev_staged)
+        with torch.cuda.stream(self._side):
+            amp_rewards = finish().contiguous()
+            st = current_stream_handle(self.device)
+            ops._chk(ops._lib().emloco_locoval_returns_finish(C.byref(self._fstep), C.c_void_p(amp_rewards.data_ptr()), st),
+                     "emloco_locoval_returns_finish")
+            self._fit_launches(st)
+            self._ev_fit.record(self._side)
+        self._fit_pending = True
 
     def detach(self):
         """Take this loop's return bookkeeping out of the task's flags launch (a caller that steps the env on its own in between)."""

@@ -151,7 +151,29 @@ class FrozenDisc:
         obs_normalize(x, self.mean32, self.var32, self.eps, 5.0, split=self.in_size, out0=self.x)
 
     def reward(self, amp_obs):
-        logits = self.logits_of(amp_obs)
+        return self._reward_of(self.logits_of(amp_obs))
+
+    def _reward_of(self, logits):
         prob = 1 / (1 + torch.exp(-logits))
         disc_r = -torch.log(torch.maximum(1 - prob, self.floor))
         return (disc_r * self.scale).squeeze(-1)
+
+    # The same reward in two halves, for a rollout that keeps the discriminator off the chain between two rigid-body steps: `stage`
+    # (one launch on the caller's stream) takes what it needs out of the step's AMP observations -- the normalised, padded GEMM
+    # operand -- before the resets overwrite them; `reward_staged` (three GEMMs + the scalar transform, any stream ordered behind the
+    # stage) reads nothing of the task's.  Same launches on the same values as `reward`.
+    def stage(self, amp_obs):
+        x = amp_obs.reshape(amp_obs.shape[0], -1)
+        assert x.shape == (self.E, self.in_size) and x.dtype == torch.float32
+        if self.normalize:
+            self._normalize_padded(x.contiguous())
+        else:
+            self.x[:, :self.in_size].copy_(x)
+
+    def reward_staged(self):
+        cur, k = self.x, self.in_k
+        for (w, b), out in zip(self.layers, self.h):
+            self._linear(cur, k, w, b, out, True)
+            cur, k = out, w.shape[0]
+        self._linear(cur, k, self.logit_w, self.logit_b, self.logits, False)
+        return self._reward_of(self.logits)

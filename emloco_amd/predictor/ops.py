@@ -21,7 +21,8 @@ class LocoValStep(C.Structure):
                 ("min_cum_rewards", C.c_float), ("max_cum_rewards", C.c_float),
                 ("current_rewards", C.c_void_p), ("current_lengths", C.c_void_p), ("current_combined_rewards", C.c_void_p),
                 ("discount_coefs", C.c_void_p), ("waypoint_traj", C.c_void_p), ("init_pose", C.c_void_p), ("init_vel", C.c_void_p),
-                ("traj13", C.c_void_p), ("pose", C.c_void_p), ("vel", C.c_void_p), ("target", C.c_void_p), ("weight", C.c_void_p)]
+                ("traj13", C.c_void_p), ("pose", C.c_void_p), ("vel", C.c_void_p), ("target", C.c_void_p), ("weight", C.c_void_p),
+                ("staged_reward", C.c_void_p), ("staged_done", C.c_void_p)]          # staged mode (both NULL: off)
 
 
 def _lib():
@@ -63,6 +64,7 @@ def _lib():
         lib.emloco_locoval_bwd_workspace.argtypes = [ci]
         lib.emloco_locoval_bwd_workspace.restype = C.c_int64
         lib.emloco_locoval_returns.argtypes = [C.POINTER(LocoValStep), vp, vp, vp, vp, vp]
+        lib.emloco_locoval_returns_finish.argtypes = [C.POINTER(LocoValStep), vp, vp]
         lib.emloco_locoval_fit_grad.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_locoval_bwd_rows.argtypes = [ci, vp, ci] + [vp] * 17
         lib.emloco_adamw_gated.argtypes = [ci] + [vp] * 7 + [cf] * 5 + [vp, vp]

@@ -213,9 +213,19 @@ typedef struct {
     float *vel;                     /* out [n_env][2] */
     float *target;                  /* out [n_env] */
     float *weight;                  /* out [n_env] */
+    /* Staged mode (both NULL: off).  With an AMP discriminator in the loop the style reward of a step (:90-96) exists three GEMMs
+     * after the step, while everything else the bookkeeping reads is overwritten by the resets that follow it.  A step with these two
+     * arrays set is STAGED by emloco_locoval_returns / emloco_task_post_physics_returns -- LocoVal inputs copied, the reward after the
+     * inversion penalty and the done flag parked here, state untouched -- and finished by emloco_locoval_returns_finish when the
+     * discriminator's reward is there: the same operations on the same values, so state / target / weight are the one-call
+     * results bit for bit.  The discriminator then runs beside the next step instead of between two steps. */
+    float *staged_reward;           /* [n_env] or NULL */
+    uint8_t *staged_done;           /* [n_env] or NULL */
 } EmlocoLocoValStep;
 int emloco_locoval_returns(const EmlocoLocoValStep *s, const float *rewards, const float *amp_rewards /* or NULL = 0 */,
                            const int64_t *dones, const uint8_t *inverted /* or NULL */, void *stream);
+/* second half of a staged step: the bookkeeping from s->staged_reward / s->staged_done and the AMP reward (NULL = 0) */
+int emloco_locoval_returns_finish(const EmlocoLocoValStep *s, const float *amp_rewards, void *stream);
 /* slot (optional, int32 [n]): rank of each valid row among the valid rows, -1 elsewhere -- for emloco_locoval_bwd_rows */
 int emloco_locoval_fit_grad(int n, const float *value, const float *target, const float *weight, float *dvalue, float *tail2,
                             int32_t *slot, void *stream);

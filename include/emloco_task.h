@@ -91,7 +91,9 @@ int emloco_task_post_physics(const EmlocoTaskBufs *bufs, int mode, const int32_t
 /* emloco_task_post_physics for all envs with the LocoVal return bookkeeping of amp_continuous_value.py:63-64,93-129 behind it in the
  * SAME launch: what emloco_locoval_returns (include/emloco_predictor.h) does with rewards = rew_buf, dones = reset_buf and no AMP
  * reward, for each env right after its reward and reset flag exist.  `mode` must hold EMLOCO_POST_REWARD | EMLOCO_POST_RESET.
- * `step` is an EmlocoLocoValStep (emloco_predictor.h), dev_inverted the heading-inversion flags [n_env] (bytes) or NULL. */
+ * `step` is an EmlocoLocoValStep (emloco_predictor.h), dev_inverted the heading-inversion flags [n_env] (bytes) or NULL.  A step
+ * with staging arrays (staged_reward / staged_done) is only STAGED here; emloco_locoval_returns_finish completes it once the AMP
+ * discriminator's reward of the step exists. */
 int emloco_task_post_physics_returns(const EmlocoTaskBufs *bufs, int mode, const void *step /* const EmlocoLocoValStep * */,
                                      const uint8_t *dev_inverted, void *stream);
 

@@ -157,6 +157,11 @@ extern "C" int emu_locoval_returns(const EmlocoLocoValStep *t, const float *rewa
     emu::launch((unsigned)s.n_env, 64, [&] { emloco::locoval_returns_kernel(s, rewards, amp, dones, inv); });
     return 0;
 }
+extern "C" int emu_locoval_returns_finish(const EmlocoLocoValStep *t, const float *amp) {
+    EmlocoLocoValStep s = *t;
+    emu::launch((unsigned)((s.n_env + 255) / 256), 256, [&] { emloco::locoval_returns_finish_kernel(s, amp); });
+    return 0;
+}
 extern "C" int emu_locoval_fit_grad(int n, const float *value, const float *target, const float *weight, float *dvalue, float *tail, int32_t *slot) {
     emu::launch(1, 1024, [&] { emloco::locoval_fit_grad_kernel(n, value, target, weight, dvalue, tail, slot); });
     return 0;

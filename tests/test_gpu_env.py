@@ -764,3 +764,43 @@ def test_return_bookkeeping_inside_the_flags_launch_fits_the_same_network(monkey
     for a, b in zip(outs[0], outs[1]):
         if torch.is_tensor(a):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_discriminator_beside_the_next_step_fits_the_same_network(monkeypatch):
+    """configs[2] with the AMP discriminator OFF the chain between two rigid-body steps (LocoValRollout's deferred mode: the flags
+    launch stages the step's return bookkeeping, one launch takes the GEMM operand out of the AMP observations, the side stream runs
+    the discriminator, emloco_locoval_returns_finish and the fit beside the resets / policy / next step) against the sequential order
+    (EMLOCO_DEFER_DISC=0: discriminator and bookkeeping between env.step and the next reset, as amp_continuous_value.py:63-145
+    has them): same seeds, frozen policy reading the observations, 64 steps with natural resets -- fitted LocoVal parameters,
+    episode count, return accumulators, last style rewards and simulator state bit-equal."""
+    from emloco_amd.learning.amp_policy import AMPPolicyBundle
+    from emloco_amd.learning.locoval_rollout import LocoValRollout
+    from emloco_amd.run import RLGPUEnv
+    E, outs = 256, []
+    for defer in ("0", "1"):
+        monkeypatch.setenv("EMLOCO_DEFER_DISC", defer)
+        env = RLGPUEnv(_make_env(E, ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel",
+                                     "--input_init_pose", "--input_init_vel"]))
+        task = env.env.task
+        torch.manual_seed(11)
+        bundle = AMPPolicyBundle(task, seed=3, deterministic=False)
+        with torch.no_grad():                              # livelier actions than a fresh network's: episodes end by falling too
+            bundle.frozen.mu_b.add_(torch.randn_like(bundle.frozen.mu_b) * 0.3)
+        torch.manual_seed(5)
+        agent = LocoValRollout(env, horizon_length=8, policy=bundle.policy, disc_reward=bundle.disc_reward, overlap_reset=False)
+        assert (agent._disc_halves is not None) == (defer == "1")
+        assert (task._returns_hook is not None) == (defer == "1") and task.fused_chain and task.fused_amp_early
+        for _ in range(8):
+            agent.play_steps()
+        n_fit = agent.fitted_episodes                      # waits for the fit stream
+        torch.cuda.synchronize()
+        a = agent.acc
+        outs.append((torch.cat([p.detach().reshape(-1) for p in agent.valuenet.parameters()]).clone(), n_fit,
+                     a.current_rewards.clone(), a.current_lengths.clone(), a.current_combined_rewards.clone(), a.discount_coefs.clone(),
+                     bundle.frozen_disc.logits.clone(), task._root_states.clone(), task.progress_buf.clone(), task.rew_buf.clone()))
+        agent.detach()
+    assert outs[0][1] == outs[1][1] and outs[0][1] > 20
+    for a, b in zip(outs[0], outs[1]):
+        if torch.is_tensor(a):
+            assert torch.equal(a, b)

@@ -435,9 +435,10 @@ def test_bool_padding_mask_matches_reference_with_and_without_skipping_padded_pe
             _close(sample(params[k[9:].replace("__", ".")].grad.cpu().numpy()), v, rel=2e-4, abs_=1e-6, what=k)
             n_checked += 1
     assert n_checked >= 21
-    # a device mask gives the same result (one read-back)
-    again = model(in_joints.clone(), pm.to(dev))
-    assert torch.equal(again, pred)
+    # a device mask gives the same result (one read-back); nn.Embedding(max_norm=1) has renormalised the looked-up rows in place
+    # by now, so compare two settled forwards
+    settled = model(in_joints.clone(), pm.clone())
+    assert torch.equal(model(in_joints.clone(), pm.to(dev)), settled)
 
 
 def test_float_padding_mask_keeps_padded_persons_in_play():

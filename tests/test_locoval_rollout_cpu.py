@@ -171,9 +171,13 @@ def test_return_accumulator_matches_the_reference_play_steps():
     assert g["valid"].sum() >= 30 and g["valid"][143].any() and not g["valid"][167, 1]
 
 
-def test_fused_returns_kernel_matches_the_reference_play_steps():
+@pytest.mark.parametrize("staged", [False, True])
+def test_fused_returns_kernel_matches_the_reference_play_steps(staged):
     """locoval_returns_kernel (the product's bookkeeping kernel, run through the CPU emulator) against the same fixture: the
-    emitted targets / weights and the four state arrays, element for element over the 400 scripted steps."""
+    emitted targets / weights and the four state arrays, element for element over the 400 scripted steps.  `staged`: the two-phase
+    form a rollout with an AMP discriminator uses -- the step is staged WITHOUT the style reward (which exists three GEMMs later,
+    while the resets that follow overwrite what the task knows), state untouched, and locoval_returns_finish_kernel completes it
+    with the reward: the reference's bytes again."""
     import ctypes as C
     import emu
     from emloco_amd.predictor.ops import LocoValStep
@@ -187,10 +191,23 @@ def test_fused_returns_kernel_matches_the_reference_play_steps():
                     p(st["cl"]), p(st["cc"]), p(st["dc"]), p(wp), p(ip), p(iv), p(st["traj13"]), p(st["pose"]), p(st["vel"]), p(st["target"]), p(st["weight"]))
     fn = emu.lib().emu_locoval_returns
     fn.argtypes = [C.c_void_p] * 5
+    fin = emu.lib().emu_locoval_returns_finish
+    fin.argtypes = [C.c_void_p] * 2
+    sr, sd = f(E), np.zeros(E, np.uint8)
+    if staged:
+        s.staged_reward, s.staged_done = p(sr), p(sd)
     for t in range(T):
         keep = (np.ascontiguousarray(g["rewards"][t]), np.ascontiguousarray(g["amp"][t]), np.ascontiguousarray(g["dones"][t]),
                 g["inverted"][t].astype(np.uint8))
-        fn(C.addressof(s), *[p(k) for k in keep])
+        if staged:
+            before = {k: st[k].copy() for k in ("cr", "cl", "cc", "dc")}
+            fn(C.addressof(s), p(keep[0]), None, p(keep[2]), p(keep[3]))
+            assert all(np.array_equal(before[k], st[k]) for k in before)          # staging leaves the state alone
+            np.testing.assert_array_equal(sd != 0, keep[2] != 0)
+            keep[0][:] = np.nan; keep[2][:] = 0; keep[3][:] = 0                    # the resets that follow may overwrite the task's buffers
+            fin(C.addressof(s), p(keep[1]))
+        else:
+            fn(C.addressof(s), *[p(k) for k in keep])
         valid = g["valid"][t]
         np.testing.assert_array_equal(st["weight"] != 0, valid, err_msg=f"step {t}")
         np.testing.assert_array_equal(st["target"][valid], g["target"][t][valid], err_msg=f"step {t}")
