@@ -108,6 +108,7 @@ class LocoValRollout:
         self._stats = torch.zeros(5, device=self.device, dtype=torch.float64)
         if hasattr(self.task, "attach_returns"):
             self.task.attach_returns(None)
+        self._disc_halves = None
         if self.fused:
             self._init_fused()
 
