@@ -477,6 +477,60 @@ def policy_leg(env, E, dev, steps, warmup):
             "weights": "random init (no checkpoint ships)"}
 
 
+def ppo_leg(env, E, dev, epochs=2, warmup=1):
+    """configs[1] END TO END as the reference reports it: one `train_epoch` = a 32-step rollout of all envs with the policy / critic
+    acting (amp_continuous.py:98-321 play_steps) + the PPO / AMP update over the collected batch (6 mini-epochs of minibatches of
+    2 560, amp_humanoid_smpl_sept_task.yaml:102-115; amp_continuous.py:335-479), and the two rates common_agent.py:183-194 logs:
+    fps_step = frames / play_time, fps_total = frames / (play_time + update_time).  Random-init networks of the shipped architecture
+    (11.2 M parameters: actor, critic, discriminator, task MLP), synthetic motion library for the AMP demonstrations."""
+    import torch
+    import yaml
+    from emloco_amd.learning.amp_agent import AMPAgent
+    from emloco_amd.predictor import ops
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "emloco_amd", "data", "cfg", "train", "rlg", "amp_humanoid_smpl_sept_task.yaml")))
+    task = env.task
+    for attr in ("fused_chain", "overlap_reset"):           # the learner's loop resets through env.reset(ids): the plain launches
+        if hasattr(task, attr):
+            setattr(task, attr, False)
+    if hasattr(task, "attach_returns"):
+        task.attach_returns(None)
+    c = cfg["params"]["config"]
+    batch = int(c["horizon_length"]) * E
+    mb_cfg = int(c["minibatch_size"])
+    if batch % mb_cfg:        # the shipped 2 560 divides the reference's 1 600 x 32 (pacer.yaml:10); rl_games asserts divisibility: largest divisor below it
+        c["minibatch_size"] = max(d for d in range(1, mb_cfg + 1) if batch % d == 0)
+    agent = AMPAgent(env, cfg)
+    n_params = sum(p.numel() for p in agent.a2c_network.parameters())
+    for _ in range(warmup):
+        agent.train_epoch()
+    infos = []
+    ops.gemm_timing(True)
+    for _ in range(epochs):
+        infos.append(agent.train_epoch())
+    n, ms, fl = ops.gemm_timing()
+    ops.gemm_timing(False)
+    play = sum(i["play_time"] for i in infos)
+    total = sum(i["total_time"] for i in infos)
+    frames = agent.batch_size * epochs
+    tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    peak, peak_note = gemm_peak(ops)
+    steps_per_epoch = agent.mini_epochs_num * (agent.batch_size // agent.minibatch_size)
+    last = infos[-1]
+    return {"metric": "env-steps/sec of PPO + AMP policy pretraining (configs[1] end to end: rollout + update)",
+            "fps_step": round(frames / play, 1), "fps_total": round(frames / total, 1), "unit": "env-steps/s",
+            "play_ms_per_epoch": round(play / epochs * 1e3, 1), "update_ms_per_epoch": round((total - play) / epochs * 1e3, 1),
+            "epochs_timed": epochs, "horizon_length": agent.horizon_length, "batch_size": agent.batch_size, "minibatch_size": agent.minibatch_size,
+            "minibatch_size_configured": mb_cfg, "mini_epochs": agent.mini_epochs_num, "optimizer_steps_per_epoch": steps_per_epoch, "parameters": n_params,
+            "update_ms_per_optimizer_step": round((total - play) / epochs / steps_per_epoch * 1e3, 3),
+            "losses": {k: round(float(last[k]), 5) for k in ("actor_loss", "critic_loss", "disc_loss", "kl") if k in last},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (rollout + update GEMMs of the timed epochs)", "achieved": round(tf, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(tf / peak, 4), "gemm_launches": n, "gemm_ms_per_epoch": round(ms / epochs, 1),
+                         "traffic": None, "note": peak_note},
+            "note": "fps_step / fps_total as common_agent.py:183-194 defines them (frames / play_time, frames / total_time), the host "
+                    "synchronisations of the reference's loop included (dones.nonzero() every step, the epoch's statistics); the learner steps the "
+                    "env through env.reset(ids) + env.step, not through the fused chain of the LocoVal loop"}
+
+
 def locoval_policy_leg(env, E, dev, steps, warmup):
     """configs[2] as the reference runs it on one GPU (amp_continuous_value.py:45-145): the frozen policy acts on the observations,
     the AMP discriminator scores each step's AMP observations (the style half of the LocoVal return), LocoVal is fitted on the
@@ -520,6 +574,7 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_policy", action="store_true", help="skip the frozen-policy leg (row A19, reported separately)")
     ap.add_argument("--no_jta", action="store_true", help="skip the train_jta samples/s leg (run on rank 0 at N=1)")
+    ap.add_argument("--no_ppo", action="store_true", help="skip the PPO + AMP train_epoch leg (configs[1] end to end; rank 0 at N=1, under `policy`)")
     ap.add_argument("--no_pipelined", action="store_true", help="(accepted, ignored: the two-shard and two-chain legs of rounds 2-3 lost to the headline schedule and are gone)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -673,6 +728,8 @@ def main():
             out["policy"] = policy_leg(env, E, dev, a.steps, a.warmup)
             out["policy"]["schedule"] = "sequential, cost-ordered dispatch"
             out["policy"]["with_discriminator_and_locoval_fit"] = locoval_policy_leg(env, E, dev, a.steps, a.warmup)
+            if not a.no_ppo:
+                out["policy"]["ppo"] = ppo_leg(env, E, dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     # the JTA train-step and evaluation legs run on every rank (data parallel at N > 1); rank 0 reports

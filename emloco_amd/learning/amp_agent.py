@@ -84,16 +84,20 @@ def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma):
 
 
 def amp_dropout_mask(B, steps, feat, num_masks=3, dropout_rate=0.3, device="cpu"):
-    """amp_models.py:62-90 for the 206-wide AMP row: whole joints (6 rotation + 3 velocity values) are dropped together."""
+    """amp_models.py:62-90 for the 206-wide AMP row: whole joints (6 rotation + 3 velocity values) are dropped together.
+    The draws are the reference's (19 x torch.rand(B, num_masks) from the CPU generator, in its order); the (B, steps * 206,
+    num_masks) mask itself is expanded ON THE DEVICE from the B x 19 x num_masks keep bits -- the reference assembles the 76 MB
+    tensor of a 2 048-row minibatch on the host and uploads it every optimiser step (measured here: 60 - 200 ms of an 80 ms step)."""
     assert feat == 206
     dof_off, num_joints = 12, 19
     vel_off = dof_off + num_joints * 6
-    mask = torch.ones([B, feat, num_masks])
+    keep = torch.stack([(torch.rand(B, num_masks) > dropout_rate) for _ in range(num_joints)], dim=1)      # (B, 19, M)
+    keep = torch.cat([keep, torch.ones(B, 1, num_masks, dtype=torch.bool)], dim=1).to(device).float()     # slot 19: always kept
+    col = torch.full((feat,), num_joints, dtype=torch.long)
     for j in range(num_joints):
-        keep = (torch.rand(B, num_masks) > dropout_rate).float()
-        mask[:, dof_off + j * 6:dof_off + j * 6 + 6, :] = keep[:, None]
-        mask[:, vel_off + j * 3:vel_off + j * 3 + 3, :] = keep[:, None]
-    return mask.repeat(1, steps, 1).to(device)
+        col[dof_off + j * 6:dof_off + j * 6 + 6] = j
+        col[vel_off + j * 3:vel_off + j * 3 + 3] = j
+    return keep[:, col.to(device), :].repeat(1, steps, 1)
 
 
 def disc_forward_with_grad_penalty(net, amp_obs_demo, input_mask=None):

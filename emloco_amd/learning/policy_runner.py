@@ -21,9 +21,12 @@ from ..utils.running_mean_std import obs_normalize
 _PAD = 4
 
 
+_KSPLIT_TARGET = int(__import__("os").environ.get("EMLOCO_KSPLIT_TARGET", "512"))       # workgroups a launch should reach (256 CUs)
+
+
 def _ksplit(m, n, k):
     tiles = ((m + 127) // 128) * ((n + 31) // 32 if n <= 32 else (n + 127) // 128)
-    return int(max(1, min(512 // max(tiles, 1), k // 128, 16)))
+    return int(max(1, min(_KSPLIT_TARGET // max(tiles, 1), k // 128, 16)))
 
 
 class FrozenPolicy:

@@ -111,3 +111,84 @@ def test_two_rank_broadcast_statistics_sync_and_kl_mean():
     np.testing.assert_allclose(var0, data.var(0), rtol=1e-10)
     assert np.array_equal(mu0, mu1) and np.array_equal(var0, var1) and c0 == c1 == 150.0
     assert kl0 == kl1 == 0.5
+
+
+def _eight_rank_worker(rank, world, port, out, steps):
+    """One rank of the LocoVal exchange pattern: every step every rank joins ONE all-reduce of the flat bucket
+    [gradient | loss sum | episode count], whatever its own episodes did, and the AdamW commit is gated by the GLOBAL count."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from emloco_amd.dist import FlatGradBucket, broadcast_parameters, init_from_env, sync_running_mean_std
+    from emloco_amd.learning.flat_adamw import GatedFlatAdamW
+    from emloco_amd.utils.running_mean_std import RunningMeanStd
+    init_from_env("gloo")
+    torch.manual_seed(50 + rank)                            # replicas differ until the broadcast (run.py:65 seeds with base + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(100, 49), torch.nn.ReLU(), torch.nn.Linear(49, 24), torch.nn.ReLU(), torch.nn.Linear(24, 1))
+    broadcast_parameters(net)
+    bucket = FlatGradBucket(net.parameters(), extra=2)
+    opt = GatedFlatAdamW(net.parameters(), bucket.grads, lr=1e-3, weight_decay=1e-4)
+    rms = RunningMeanStd((6,))
+    g = torch.Generator().manual_seed(900 + rank)
+    seen = []
+    commits = 0
+    for t in range(steps):
+        bucket.zero()
+        # rank r finishes episodes only on steps t with t % world == r (disjoint steps), rank 0 never on its own; steps with
+        # t % (world + 3) >= world have no finished episode anywhere: the collective still runs, nothing is committed
+        slot = t % (world + 3)
+        n = (2 + rank) if (slot == rank and rank > 0) else 0
+        if n:
+            x, y = torch.randn(n, 100, generator=g), torch.rand(n, 1, generator=g)
+            loss = torch.nn.functional.mse_loss(net(x), y, reduction="sum")
+            loss.backward()
+            bucket.tail[0], bucket.tail[1] = loss.detach(), float(n)
+        bucket.all_reduce(average=False)                    # unconditional: one collective per step on every rank
+        cnt = bucket.tail[1].clone()
+        bucket.grads.div_(cnt.clamp(min=1.0))               # MSELoss(reduction='sum') / global count (common_agent.py:96)
+        opt.step(gate=cnt > 0)
+        commits += int(cnt.item() > 0)
+        seen.append(torch.randn(4 + rank, 6, generator=g, dtype=torch.float64) * (1 + rank) + rank)   # this rank's observations
+    # per-rank observation statistics (the training-mode update itself is a HIP launch, emloco_rms_update: set here directly)
+    data = torch.cat(seen)
+    rms.running_mean.copy_(data.mean(0)); rms.running_var.copy_(data.var(0, unbiased=False)); rms.count.fill_(float(len(data)))
+    mine = (rms.running_mean.clone(), rms.running_var.clone(), float(rms.count))
+    sync_running_mean_std(rms)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    out.put((rank, flat, commits, float(opt.steps), mine, rms.running_mean.clone(), rms.running_var.clone(), float(rms.count)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gated_fit_with_episodes_on_disjoint_steps():
+    """DESIGN section 6's no-deadlock claim at the driver's rank count: 8 gloo ranks, each finishing episodes on its own steps only
+    (rank 0 never, some steps nobody): every rank issues the same number of collectives, the device-side gate commits AdamW on
+    exactly the steps where the GLOBAL episode count is positive, the replicas stay bit-identical and moved, and the epoch's
+    running-mean-std synchronisation pools eight unequal shards by the law of total variance."""
+    world, steps = 8, 33
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eight_rank_worker, args=(r, world, port, q, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    expect = sum(1 for t in range(steps) if 1 <= t % (world + 3) < world)       # slots 1..7 have a finishing rank; 0, 8, 9, 10 none
+    torch.manual_seed(50)
+    ref = torch.nn.Sequential(torch.nn.Linear(100, 49), torch.nn.ReLU(), torch.nn.Linear(49, 24), torch.nn.ReLU(), torch.nn.Linear(24, 1))
+    start = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+    for r, flat, commits, nstep, _mine, _mu, _var, _c in res:
+        assert torch.equal(flat, res[0][1]), r                                  # replicas identical after 33 steps
+        assert commits == expect and nstep == float(expect), (r, commits, nstep)
+    assert not torch.equal(res[0][1], start)                                    # ... and they moved away from rank 0's initial weights
+    # pooled statistics: weights count_r / sum(count)
+    cs = torch.tensor([m[4][2] for m in res], dtype=torch.float64)
+    mus = torch.stack([m[4][0].double() for m in res])
+    vs = torch.stack([m[4][1].double() for m in res])
+    w = (cs / cs.sum()).unsqueeze(1)
+    mu = (w * mus).sum(0)
+    var = (w * (vs + (mus - mu) ** 2)).sum(0)
+    for m in res:
+        assert torch.allclose(m[5].double(), mu, rtol=1e-6, atol=1e-7) and torch.allclose(m[6].double(), var, rtol=1e-6, atol=1e-7)
+        assert abs(m[7] - float(cs.mean())) < 1e-3
