@@ -258,6 +258,26 @@ int emloco_rms_update(int rows, int cols, const float *x, int ldx, double *mean,
     return 0;
 }
 
+int64_t emloco_rms_update_workspace(int rows, int cols) {
+    const int64_t chunks = (rows + RMS_CHUNK - 1) / RMS_CHUNK;
+    return chunks * 3 * (int64_t)cols * (int64_t)sizeof(double);
+}
+
+int emloco_rms_update_chunked(int rows, int cols, const float *x, int ldx, double *mean, double *var, const double *count_in, double *count_out,
+                              int first_col, void *workspace, void *stream) {
+    if (rows < 1 || cols < 1 || !x || !mean || !var || !count_in || !count_out || count_in == count_out || ldx < cols || first_col < 0 ||
+        first_col > cols || !workspace)
+        return pfail(-1, "emloco_rms_update_chunked: bad argument");
+    const int chunks = (rows + RMS_CHUNK - 1) / RMS_CHUNK;
+    hipLaunchKernelGGL(emloco::rms_partial_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, rows,
+                       cols, x, ldx, (double *)workspace);
+    PHIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(emloco::rms_merge_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, chunks, cols,
+                       (const double *)workspace, mean, var, count_in, count_out, first_col);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
 int emloco_locoval_fwd_rows(int B, const float *traj, int traj_stride, const float *pose, const float *vel, const float *w1,
                             const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, float *value,
                             float *x100, float *h1, float *h2, float *angle, const float *row_weight, void *stream) {

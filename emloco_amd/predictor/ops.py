@@ -221,6 +221,15 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, W, b=None, relu=False, drop_p=0.0, out_bf16=False):
     """nn.Linear (+ReLU) (+nn.Dropout(p) in training: pass drop_p > 0) as one GEMM launch."""
+    K = x.shape[-1]
+    if K % 4 and K >= 256:
+        # a long reduction whose rows are not 16-byte aligned (the AMP discriminator's 3 090 inputs) falls off the 16-byte-load /
+        # split-mode kernels onto the scalar-load fp32 ones (measured: 59 TFLOP/s).  Zero-padding both operands to a multiple of 4
+        # costs two small copies and puts the three GEMMs of the layer (forward, input gradient, weight gradient) on the fast path;
+        # autograd slices the gradients back.
+        pad = 4 - K % 4
+        x = torch.nn.functional.pad(x, (0, pad))
+        W = torch.nn.functional.pad(W, (0, pad))
     if drop_p > 0.0:
         return LinearFn.apply(x, W, b, relu, float(drop_p), next_dropout_seed(), out_bf16)
     return LinearFn.apply(x, W, b, relu, 0.0, 0, out_bf16)

@@ -46,8 +46,15 @@ def rms_update(x, mean64, var64, count64, first_col=0, scratch=None):
     if scratch is None:
         scratch = torch.empty((), dtype=torch.float64, device=x.device)
     vp = C.c_void_p
-    rc = lib.emloco_rms_update(rows, cols, vp(x.data_ptr()), x.stride(0), vp(mean64.data_ptr()), vp(var64.data_ptr()), vp(count64.data_ptr()),
-                               vp(scratch.data_ptr()), int(first_col), current_stream_handle(x.device))
+    if rows >= 512:                   # tall batch (the learner's minibatches): chunked partial moments + in-order fold, two launches
+        lib.emloco_rms_update_workspace.restype = C.c_int64
+        ws = torch.empty(int(lib.emloco_rms_update_workspace(rows, cols)) // 8, dtype=torch.float64, device=x.device)
+        rc = lib.emloco_rms_update_chunked(rows, cols, vp(x.data_ptr()), x.stride(0), vp(mean64.data_ptr()), vp(var64.data_ptr()),
+                                           vp(count64.data_ptr()), vp(scratch.data_ptr()), int(first_col), vp(ws.data_ptr()),
+                                           current_stream_handle(x.device))
+    else:
+        rc = lib.emloco_rms_update(rows, cols, vp(x.data_ptr()), x.stride(0), vp(mean64.data_ptr()), vp(var64.data_ptr()), vp(count64.data_ptr()),
+                                   vp(scratch.data_ptr()), int(first_col), current_stream_handle(x.device))
     if rc != 0:
         raise L.EmlocoError(f"emloco_rms_update failed with code {rc}")
     count64.copy_(scratch)

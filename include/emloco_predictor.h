@@ -168,6 +168,13 @@ int emloco_obs_normalize(int rows, int cols, const float *x, int ldx, const floa
  * is written to count_out [1] (a different buffer than count_in). */
 int emloco_rms_update(int rows, int cols, const float *x, int ldx, double *mean, double *var, const double *count_in, double *count_out,
                       int first_col, void *stream);
+/* The same update for tall batches (the learner's 2 048 .. 25 600-row minibatches, amp_continuous.py:335-346 in training mode): two
+ * launches -- per (256-row chunk, column) partial moments taken from registers, then an in-order fold of the chunks -- instead of one
+ * serial chain per column; same arithmetic rule, results equal to the single launch to float64 rounding.  `workspace`:
+ * emloco_rms_update_workspace(rows, cols) bytes of device memory. */
+int64_t emloco_rms_update_workspace(int rows, int cols);
+int emloco_rms_update_chunked(int rows, int cols, const float *x, int ldx, double *mean, double *var, const double *count_in, double *count_out,
+                              int first_col, void *workspace, void *stream);
 
 /* LocoVal MLP (value_pose_net.py:36-159), fused: yaw normalisation (:73-103) + hidden joints zeroed (:141-144)
  * + 100->49->24->1 MLP with ReLU/ReLU/sigmoid.  traj [B][13][traj_stride>=2], pose [B][24][3], vel [B][2].

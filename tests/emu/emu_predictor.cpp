@@ -68,6 +68,15 @@ extern "C" int emu_rms_update(int rows, int cols, const float *x, int ldx, doubl
     emu::launch((unsigned)((cols + 63) / 64), 256, [&] { rms_update_kernel(rows, cols, x, ldx, mean, var, count_in, count_out, first_col); });
     return 0;
 }
+extern "C" int emu_rms_update_chunked(int rows, int cols, const float *x, int ldx, double *mean, double *var, const double *count_in,
+                                      double *count_out, int first_col, double *ws) {
+    const int chunks = (rows + RMS_CHUNK - 1) / RMS_CHUNK;
+    for (int c = 0; c < chunks; ++c)
+        emu::launch((unsigned)((cols + 63) / 64), 256, [&] { blockIdx.y = c; rms_partial_kernel(rows, cols, x, ldx, ws); });
+    blockIdx.y = 0;
+    emu::launch((unsigned)((cols + 255) / 256), 256, [&] { rms_merge_kernel(chunks, cols, ws, mean, var, count_in, count_out, first_col); });
+    return 0;
+}
 extern "C" int emu_softmax_fwd(int n_seq, int rps, int cols, float scale, const float *S, const float *kp, float *P) {
     const long rows = (long)n_seq * rps;
     emu::launch((unsigned)((rows + 3) / 4), 256, [&] { softmax_fwd_kernel((int)rows, rps, cols, scale, S, kp, P); });

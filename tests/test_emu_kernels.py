@@ -602,6 +602,39 @@ def test_rms_update_kernel_matches_the_reference_class(golden):
         assert cnt[0] == float(g[f"count{i}"])
 
 
+def test_chunked_rms_update_equals_the_single_launch():
+    """rms_partial_kernel + rms_merge_kernel (the learner's tall minibatches: per-chunk moments from registers, in-order fold) against
+    rms_update_kernel and numpy float64 on a ragged tall batch (1 100 rows: four full 256-row chunks and a 76-row one whose last
+    wave is empty; 70 columns: a partial column group), with freeze_partial columns: moments to 1e-12, count exact."""
+    lib = emu.lib()
+    rng = np.random.default_rng(4)
+    rows, cols = 1100, 70
+    x = (rng.normal(size=(rows, cols)) * rng.uniform(0.1, 30, size=cols) + rng.uniform(-50, 50, size=cols)).astype(np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    res = []
+    for chunked in (False, True):
+        mean, var = rng.normal(size=cols) * 0 + np.linspace(-1, 1, cols), np.linspace(0.5, 2, cols)
+        cnt, cnt2 = np.array([37.0]), np.zeros(1)
+        if chunked:
+            ws = np.zeros(((rows + 255) // 256) * 3 * cols, np.float64)
+            lib.emu_rms_update_chunked(rows, cols, P(x), cols, vp(mean), vp(var), vp(cnt), vp(cnt2), 5, vp(ws))
+        else:
+            lib.emu_rms_update(rows, cols, P(x), cols, vp(mean), vp(var), vp(cnt), vp(cnt2), 5)
+        res.append((mean.copy(), var.copy(), cnt2[0]))
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(res[1][1], res[0][1], rtol=1e-12, atol=1e-12)
+    assert res[0][2] == res[1][2] == 37.0 + rows
+    x64 = x.astype(np.float64)
+    m0, v0 = np.linspace(-1, 1, cols), np.linspace(0.5, 2, cols)
+    bm, bv = x64.mean(0), x64.var(0, ddof=1)
+    d, tot = bm - m0, 37.0 + rows
+    em = m0 + d * rows / tot
+    ev = (v0 * 37.0 + bv * rows + d * d * 37.0 * rows / tot) / tot
+    np.testing.assert_allclose(res[1][0][5:], em[5:], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(res[1][1][5:], ev[5:], rtol=1e-11, atol=1e-11)
+    np.testing.assert_array_equal(res[1][0][:5], m0[:5])                  # frozen columns keep their moments
+
+
 def test_fused_attention_kernels_forward_and_backward():
     """attn_fwd / attn_bwd_dq / attn_bwd_dkv (head dim 32) against a float64 numpy attention, ragged S (two query blocks'
     worth of tiles would be slow in the emulator: S = 70 covers a partial last tile), additive and -inf key biases."""
