@@ -95,8 +95,11 @@ int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha, const float 
     if (g_timing) PHIPCHK(hipEventRecord(g_e0[slot], st));
     // stage depth: 32 for long reductions (covers the prefetch latency), 16 for short ones (less LDS, more workgroups / CU)
     static const int force_bk = getenv("EMLOCO_GEMM_BK") ? atoi(getenv("EMLOCO_GEMM_BK")) : 0;
-    const unsigned bn = n <= 32 ? 32 : 128;
-    dim3 grid((unsigned)((n + bn - 1) / bn), (unsigned)((m + 127) / 128), (unsigned)(batch * ksplit));
+    const bool split_ok = (flags & EMLOCO_GEMM_SPLIT) && !(flags & EMLOCO_GEMM_BF16) && g.vec_a && g.vec_b && n > 32;
+    static const int force_small = getenv("EMLOCO_GEMM_SMALL") ? atoi(getenv("EMLOCO_GEMM_SMALL")) : -1;      // 0 / 1: never / always (A/B runs)
+    g.small = split_ok && (force_small >= 0 ? force_small == 1 : emloco::gemm_use_small_tile(batch, m, n, ksplit)) ? 1 : 0;
+    const unsigned bn = n <= 32 ? 32 : (g.small ? 64 : 128), bm = g.small ? 64 : 128;
+    dim3 grid((unsigned)((n + bn - 1) / bn), (unsigned)((m + bm - 1) / bm), (unsigned)(batch * ksplit));
     // measured (tools/exp/probe_jta_gemm.py, tools/probe_gemm.py): the 32-deep stage only pays while the launch is at most ~2
     // workgroups per CU (4096 x 1024 x 2048: 87 vs 85 TFLOP/s); with many waves of workgroups the 16-deep stage's third resident
     // workgroup per CU wins (927744 x 128 x 1024: 111 vs 102), and so it does for the k-major (transposed) operands of the
@@ -180,7 +183,7 @@ int emloco_layernorm_bwd(int rows, int d, const float *xr, const float *gamma, c
     return 0;
 }
 
-int64_t emloco_colsum_workspace(int m, int n) { return emloco::fold_workspace((m + CS_ROWS - 1) / CS_ROWS, n); }
+int64_t emloco_colsum_workspace(int m, int n) { const int cs = emloco::cs_rows_for(m); return emloco::fold_workspace((m + cs - 1) / cs, n); }
 
 int emloco_colsum(int m, int n, const float *X, float *out, float *workspace, void *stream) {
     return emloco_colsum_ex(m, n, X, out, workspace, 0, stream);
@@ -189,9 +192,9 @@ int emloco_colsum(int m, int n, const float *X, float *out, float *workspace, vo
 int emloco_colsum_ex(int m, int n, const float *X, float *out, float *workspace, int flags, void *stream) {
     if (m < 1 || n < 1 || !X || !out || !workspace)
         return pfail(-1, "emloco_colsum: bad argument (workspace = emloco_colsum_workspace(m, n) floats)");
-    const int nparts = (m + CS_ROWS - 1) / CS_ROWS;
+    const int cs = emloco::cs_rows_for(m), nparts = (m + cs - 1) / cs;
     hipLaunchKernelGGL(emloco::colsum_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream, m, n, X, workspace,
-                       (flags & EMLOCO_GEMM_A_BF16MEM) ? 1 : 0);
+                       (flags & EMLOCO_GEMM_A_BF16MEM) ? 1 : 0, cs);
     PHIPCHK(hipGetLastError());
     emloco::fold_rows(FoldLaunch{(hipStream_t)stream}, nparts, n, workspace, out, out, n);
     PHIPCHK(hipGetLastError());
@@ -228,9 +231,9 @@ int emloco_act_bwd_colsum(int m, int n, const float *dy, const float *y, int rel
                           float *colsum, float *workspace, void *stream) {
     if (m < 1 || n < 1 || !dy || !dz || !colsum || !workspace || (relu && !y) || !(drop_p >= 0.0f && drop_p < 1.0f))
         return pfail(-1, "emloco_act_bwd_colsum: bad argument (workspace = emloco_colsum_workspace(m, n) floats)");
-    const int nparts = (m + CS_ROWS - 1) / CS_ROWS;
+    const int cs = emloco::cs_rows_for(m), nparts = (m + cs - 1) / cs;
     hipLaunchKernelGGL(emloco::act_bwd_colsum_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream,
-                       m, n, dy, y, relu, drop_p, drop_seed, dz, workspace);
+                       m, n, dy, y, relu, drop_p, drop_seed, dz, workspace, cs);
     PHIPCHK(hipGetLastError());
     emloco::fold_rows(FoldLaunch{(hipStream_t)stream}, nparts, n, workspace, colsum, colsum, n);
     PHIPCHK(hipGetLastError());

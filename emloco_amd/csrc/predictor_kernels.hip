@@ -42,7 +42,14 @@ struct GemmArgs {
     // element; leading dimensions and strides still count elements).  The large activations of an encoder layer -- the fused
     // q|k|v projection and the feed-forward hidden layer -- live in HBM as bf16 there; accumulation stays fp32.
     int a16, b16, c16, m16;
+    int small;          // split mode on the 64 x 64 tile (gemm_split_small_kernel): the launcher sets it and sizes the grid for it
 };
+
+// the 64 x 64 split tile serves a launch whose 128 x 128 grid would be at most this many workgroups (3 per CU)
+constexpr long GEMM_SMALL_MAX_WG = 768;
+inline bool gemm_use_small_tile(int batch, int m, int n, int ksplit) {
+    return (long)((m + 127) / 128) * ((n + 127) / 128) * batch * ksplit <= GEMM_SMALL_MAX_WG;
+}
 
 // bf16 <-> fp32 on the way to / from memory: widening is a shift, narrowing rounds to nearest even
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
@@ -206,15 +213,25 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned &p1, unsig
     p3 = gemm_pack2_bf16(ra, rb);
 }
 // thread -> (row quad, k pair) of a TRANS operand stage: 16-lane runs of row quads (256 contiguous bytes per run and k), the
-// two runs of a 32-lane store group on adjacent k pairs
-__device__ __forceinline__ void split_trans_map(int tid, int &rq, int &kp) {
-    rq = (tid & 15) + 16 * ((tid >> 5) & 1);
-    kp = ((tid >> 4) & 1) + 2 * (tid >> 6);
+// two runs of a 32-lane store group on adjacent k pairs.  A 64-row stage (the small tile) has 16 row quads x 8 k pairs: the first
+// two waves carry it (returns false for the idle threads, which fetch a valid duplicate and stash nothing).
+template <int ROWS>
+__device__ __forceinline__ bool split_trans_map(int tid, int &rq, int &kp) {
+    static_assert(ROWS == 128 || ROWS == 64, "split stages are 128 or 64 rows x 16 k on 256 threads");
+    if (ROWS == 128) {
+        rq = (tid & 15) + 16 * ((tid >> 5) & 1);
+        kp = ((tid >> 4) & 1) + 2 * (tid >> 6);
+        return true;
+    }
+    rq = tid & 15;
+    kp = (tid >> 4) & 7;
+    return tid < 128;
 }
-// TRANS operand, 128 rows x 16 k, 256 threads: the quads (4 rows) at k = 2 kp and 2 kp + 1
+// TRANS operand, ROWS rows x 16 k, 256 threads: the quads (4 rows) at k = 2 kp and 2 kp + 1
+template <int ROWS>
 __device__ __forceinline__ void split_fetch_trans(f32x4 (&v)[2], unsigned (&mk)[2], const float *X, int ld, int row0, int rows, int k0, int ke, int tid) {
     int rq, kp;
-    split_trans_map(tid, rq, kp);
+    split_trans_map<ROWS>(tid, rq, kp);
     const int row = row0 + 4 * rq, rq4 = (rows - 1) & ~3;
     const int rowc = row < rq4 ? row : rq4;
     const unsigned rm = (row < rows ? 1u : 0u) | (row + 1 < rows ? 2u : 0u) | (row + 2 < rows ? 4u : 0u) | (row + 3 < rows ? 8u : 0u);
@@ -225,18 +242,20 @@ __device__ __forceinline__ void split_fetch_trans(f32x4 (&v)[2], unsigned (&mk)[
         mk[e] = kg < ke ? rm : 0u;
     }
 }
+// quads a thread holds of one operand stage: 2 adjacent k of a row quad (TRANS), or ROWS / 64 quads of 4 consecutive k
+constexpr int split_nv(int rows, int trans) { return trans ? 2 : rows / 64; }
 template <int ROWS, int TRANS>
-__device__ __forceinline__ void split_stash(const f32x4 (&v)[2], const unsigned (&mk)[2], unsigned *S, int tid) {
-    static_assert(ROWS == 128, "split stages are 128 rows x 16 k on 256 threads");
-    constexpr int HW = split_half_words(ROWS), PW = split_plane_words(ROWS);
-    f32x4 t[2];
-    for (int e = 0; e < 2; ++e) {
+__device__ __forceinline__ void split_stash(const f32x4 (&v)[split_nv(ROWS, TRANS)], const unsigned (&mk)[split_nv(ROWS, TRANS)], unsigned *S, int tid) {
+    static_assert(ROWS == 128 || ROWS == 64, "split stages are 128 or 64 rows x 16 k on 256 threads");
+    constexpr int HW = split_half_words(ROWS), PW = split_plane_words(ROWS), NV = split_nv(ROWS, TRANS);
+    f32x4 t[NV];
+    for (int e = 0; e < NV; ++e) {
         t[e] = v[e];
         t[e].x = (mk[e] & 1u) ? t[e].x : 0.0f; t[e].y = (mk[e] & 2u) ? t[e].y : 0.0f;
         t[e].z = (mk[e] & 4u) ? t[e].z : 0.0f; t[e].w = (mk[e] & 8u) ? t[e].w : 0.0f;
     }
-    if (!TRANS) {
-        for (int e = 0; e < 2; ++e) {                          // quad = 4 consecutive k of one row: 8 bytes per plane
+    if constexpr (!TRANS) {
+        for (int e = 0; e < NV; ++e) {                         // quad = 4 consecutive k of one row: 8 bytes per plane
             const int idx = tid + 256 * e, r = idx >> 2, q = idx & 3;
             unsigned a1, a2, a3, b1, b2, b3;
             split_pair(t[e].x, t[e].y, a1, a2, a3);
@@ -248,7 +267,7 @@ __device__ __forceinline__ void split_stash(const f32x4 (&v)[2], const unsigned 
         }
     } else {                                                   // 4 rows x 2 adjacent k: one word per row and plane
         int rq, kp;
-        split_trans_map(tid, rq, kp);
+        if (!split_trans_map<ROWS>(tid, rq, kp)) return;
         const float lo[4] = {t[0].x, t[0].y, t[0].z, t[0].w}, hi[4] = {t[1].x, t[1].y, t[1].z, t[1].w};
         unsigned *base = S + (kp >> 2) * HW + (kp & 3);
         for (int j = 0; j < 4; ++j) {
@@ -287,9 +306,9 @@ __device__ __forceinline__ void split_frag(const unsigned *S, int row, int half,
 template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int PREC, int EPI, int IOA = 0, int IOB = 0, int EPIO = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     constexpr int BM = WM * TI * 32, BN = WN * TJ * 32, GLDK = GBK + 4, NF = GBK / 8;
-    constexpr int QA = (BM * GBK / 4 + 255) / 256, QB = (BN * GBK / 4 + 255) / 256;
-    static_assert(PREC != 2 || (GBK == 16 && BM == 128 && BN == 128 && VEC == 1 && IOA == 0 && IOB == 0),
-                  "split mode: 128 x 128 x 16 stages, fp32 operands, 16-byte loads");
+    constexpr int QA = (PREC == 2 && TA) ? 2 : (BM * GBK / 4 + 255) / 256, QB = (PREC == 2 && TB) ? 2 : (BN * GBK / 4 + 255) / 256;
+    static_assert(PREC != 2 || (GBK == 16 && (BM == 128 || BM == 64) && (BN == 128 || BN == 64) && VEC == 1 && IOA == 0 && IOB == 0),
+                  "split mode: 128 / 64-row x 16 stages, fp32 operands, 16-byte loads");
     constexpr int SA = PREC == 2 ? split_stage_words(BM) : BM * GLDK, SB = PREC == 2 ? split_stage_words(BN) : BN * GLDK;
     __shared__ __attribute__((aligned(16))) float As[2][SA], Bs[2][SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -317,9 +336,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     unsigned ma[QA], mb[QB];
     // fetch / stash of one stage in the mode's own LDS image
 #define GEMM_FETCH(K0)                                                                                          \
-    if constexpr (PREC == 2 && TA) split_fetch_trans(ra, ma, A, g.lda, m0, g.m, (K0), ke, tid);                 \
+    if constexpr (PREC == 2 && TA) split_fetch_trans<BM>(ra, ma, A, g.lda, m0, g.m, (K0), ke, tid);             \
     else gemm_fetch<BM, GBK, TA, VEC, IOA>(ra, ma, A, g.lda, m0, g.m, (K0), ke, tid);                           \
-    if constexpr (PREC == 2 && TB) split_fetch_trans(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);                 \
+    if constexpr (PREC == 2 && TB) split_fetch_trans<BN>(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);             \
     else gemm_fetch<BN, GBK, TB, VEC, IOB>(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);
 #define GEMM_STASH(BUF)                                                                                         \
     if constexpr (PREC == 2) {                                                                                  \
@@ -481,6 +500,13 @@ template <int TB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 gemm_split_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, 0, TB, 1, 2, 1, 0, 0, 0>(g); }
 
+// split mode on a 64 x 64 tile (four waves, one matrix tile each; 26 KB of LDS: up to six workgroups per CU) for launches that
+// are too small to fill the chip with 128 x 128 tiles -- the learners' and the policy's M = 2 048 .. 4 096 layers: 128 .. 512
+// workgroups on 256 CUs leave every SIMD with one wave and nothing to hide a load, a barrier or a matrix chain behind.
+template <int TA, int TB>
+__global__ void __launch_bounds__(256)
+gemm_split_small_kernel(GemmArgs g) { gemm_body<2, 2, 1, 1, 16, TA, TB, 1, 2, 0>(g); }
+
 // kernel variant for a problem: tile shape (narrow: n <= 32), stage depth, operand layouts, 16-byte loads
 typedef void (*GemmKernel)(GemmArgs);
 template <int WM, int WN, int TI, int TJ, int GBK>
@@ -533,6 +559,12 @@ inline GemmKernel gemm_pick(const GemmArgs &g, bool deep) {
         return g.tb ? gemm_f32_relu_bwd_kernel<16, 1, 0> : gemm_f32_relu_bwd_kernel<16, 0, 0>;
     }
     if (g.n <= 32) return deep ? gemm_pick_layout<4, 1, 1, 1, 32>(g.ta, g.tb, vec) : gemm_pick_layout<4, 1, 1, 1, 16>(g.ta, g.tb, vec);
+    if ((g.flags & 1024) && vec && !bf16 && g.small) {
+        if (!g.ta && !g.tb) return gemm_split_small_kernel<0, 0>;
+        if (!g.ta && g.tb) return gemm_split_small_kernel<0, 1>;
+        if (g.ta && !g.tb) return gemm_split_small_kernel<1, 0>;
+        return gemm_split_small_kernel<1, 1>;
+    }
     if ((g.flags & 1024) && vec && !bf16) {        // split mode (fp32 class on the bf16 matrix rate): 16-byte-aligned operands, 128-wide tiles
         if (!g.ta && !g.tb) return gemm_split_kernel<0, 0>;
         if (!g.ta && g.tb) return gemm_split_kernel<0, 1>;
@@ -741,14 +773,17 @@ inline void fold_rows(LAUNCH launch, int n, int w, float *buf, float *out0, floa
     }
 }
 
-// column sums: 256-row partials, then folded
+// column sums: cs_rows-row partials, then folded.  256 rows per partial for the predictor's tall activations (M ~ 10^6); 32 for the
+// learners' minibatches (M = 2 048 .. 25 600), where a 256-row walk is a chain of 64 dependent load latencies per thread and 8
+// workgroup rows leave most of the chip idle (measured: 27.6 us for a 16 MB pass).
 #define CS_ROWS 256
-__global__ void colsum_partial_kernel(int m, int n, const float *X, float *part, int x16) {
+__host__ __device__ inline int cs_rows_for(int m) { return m >= 32768 ? CS_ROWS : 32; }
+__global__ void colsum_partial_kernel(int m, int n, const float *X, float *part, int x16, int cs_rows) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const long r0 = (long)blockIdx.y * CS_ROWS;
+    const long r0 = (long)blockIdx.y * cs_rows;
     float s = 0.0f;
-    for (int r = 0; r < CS_ROWS && r0 + r < m; ++r) s += ld_act(X, (r0 + r) * n + j, x16);
+    for (int r = 0; r < cs_rows && r0 + r < m; ++r) s += ld_act(X, (r0 + r) * n + j, x16);
     part[(long)blockIdx.y * n + j] = s;
 }
 
@@ -756,17 +791,17 @@ __global__ void colsum_partial_kernel(int m, int n, const float *X, float *part,
 // column partial sum for the fixed-order row folding (replaces act_bwd_kernel + colsum_partial_kernel: one read of dz less).
 __global__ void __launch_bounds__(256)
 act_bwd_colsum_kernel(int m, int n, const float *dy, const float *y, int relu, float drop_p, unsigned drop_seed,
-                      float *dz, float *part) {
+                      float *dz, float *part, int cs_rows) {
     // 256 threads = 64 columns x 4 row phases (a wave reads 64 consecutive floats of a row); the four phase sums of a column
     // are added in a fixed order through LDS, so narrow matrices (n = 128) still fill the chip.
     __shared__ float sh[4][64];
     const int jl = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + jl;
-    const long r0 = (long)blockIdx.y * CS_ROWS;
+    const long r0 = (long)blockIdx.y * cs_rows;
     const float inv = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
     float s = 0.0f;
     if (j < n)
-        for (int r = ph; r < CS_ROWS && r0 + r < m; r += 4) {
+        for (int r = ph; r < cs_rows && r0 + r < m; r += 4) {
             const long i = (r0 + r) * n + j;
             float v = dy[i];
             if (relu) v = y[i] > 0.0f ? v : 0.0f;

@@ -230,6 +230,14 @@ def linear(x, W, b=None, relu=False, drop_p=0.0, out_bf16=False):
         pad = 4 - K % 4
         x = torch.nn.functional.pad(x, (0, pad))
         W = torch.nn.functional.pad(W, (0, pad))
+    N = W.shape[0]
+    if N % 4 and N >= 32 and x.numel() // x.shape[-1] >= 1024:
+        # the same for an output width that is not a multiple of 4 (the policy's 69 actions, the 3 090-wide input gradient of the
+        # discriminator's gradient penalty): the incoming gradient is then a 16-byte-aligned operand of the two backward GEMMs
+        padn = 4 - N % 4
+        W = torch.nn.functional.pad(W, (0, 0, 0, padn))
+        b = torch.nn.functional.pad(b, (0, padn)) if b is not None else None
+        return linear(x, W, b, relu, drop_p, out_bf16)[..., :N]
     if drop_p > 0.0:
         return LinearFn.apply(x, W, b, relu, float(drop_p), next_dropout_seed(), out_bf16)
     return LinearFn.apply(x, W, b, relu, 0.0, 0, out_bf16)

@@ -13,7 +13,11 @@ extern "C" int emu_gemm_f32(int batch, int m, int n, int k, float alpha, const f
     g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && (sa % 4 == 0);     // as emloco_gemm_f32 decides it
     g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (sb % 4 == 0);
     const bool narrow = n <= 32;
-    const unsigned gx = narrow ? (n + 31) / 32 : (n + 127) / 128, gy = (m + 127) / 128, gz = batch * ksplit;
+    // flags & (1 << 20): test-only request for the 64 x 64 split tile (the launcher picks it by launch size, gemm_use_small_tile)
+    g.small = ((flags & (1 << 20)) && (flags & 1024) && !(flags & 16) && g.vec_a && g.vec_b && n > 32) ? 1 : 0;
+    g.flags &= ~(1 << 20);
+    const unsigned bt = g.small ? 64 : 128;
+    const unsigned gx = narrow ? (n + 31) / 32 : (n + bt - 1) / bt, gy = (m + bt - 1) / bt, gz = batch * ksplit;
     for (unsigned z = 0; z < gz; ++z)
         for (unsigned y = 0; y < gy; ++y)
             for (unsigned x = 0; x < gx; ++x) {
@@ -21,7 +25,7 @@ extern "C" int emu_gemm_f32(int batch, int m, int n, int k, float alpha, const f
                     blockIdx.x = x; blockIdx.y = y; blockIdx.z = z;
                     const bool deep = (k + ksplit - 1) / ksplit > 256;     // as emloco_gemm_f32 picks the stage depth
                     GemmArgs gl = g;
-                    if (!((flags & 1024) && !(flags & 16) && g.vec_a && g.vec_b && n > 32)) gl.flags &= ~1024;   // as emloco_gemm_f32_ex serves the split mode
+                    if (!((g.flags & 1024) && !(g.flags & 16) && g.vec_a && g.vec_b && n > 32)) gl.flags &= ~1024;   // as emloco_gemm_f32_ex serves the split mode
                     gemm_pick(gl, deep)(gl);
                 });
             }

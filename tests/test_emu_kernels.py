@@ -420,6 +420,16 @@ def test_mfma_gemm_kernel_split_mode_is_fp32_class():
             assert err < 4 * plain_err + 2e-7, (m, n, k, ta, tb, err, plain_err)     # (a misplaced piece would show as 2^-8 = 4e-3)
         got = _gemm(A, Bt, 0, 1, m, n, k, flags=SPLIT, ksplit=2)[0]
         assert np.max(np.abs(got - ref) / mag) < 4 * plain_err + 2e-7
+        # the 64 x 64 tile the launcher picks for launches too small to fill the chip with 128 x 128 tiles (gemm_split_small_kernel):
+        # same pieces, same six products per 16 k -- the same bar, and the SAME BITS as the 128 x 128 tile (the reduction order of an
+        # output element does not depend on the tile it sits in)
+        SMALL = 1 << 20
+        for (a, b, ta, tb) in ((A, B, 0, 0), (At, Bt, 1, 1), (A, Bt, 0, 1), (At, B, 1, 0)):
+            got = _gemm(a, b, ta, tb, m, n, k, flags=SPLIT | SMALL)[0]
+            assert np.max(np.abs(got - ref) / mag) < 4 * plain_err + 2e-7, ("small tile", m, n, k, ta, tb)
+            assert np.array_equal(got, _gemm(a, b, ta, tb, m, n, k, flags=SPLIT)[0]), ("small tile bits", m, n, k, ta, tb)
+        got = _gemm(At, Bt, 1, 1, m, n, k, flags=SPLIT | SMALL, ksplit=3)[0]
+        assert np.max(np.abs(got - ref) / mag) < 4 * plain_err + 2e-7
         bias = rng.normal(size=n).astype(np.float32)
         got = _gemm(A, B, 0, 0, m, n, k, bias=bias, flags=SPLIT | 3, alpha=0.5)[0]
         np.testing.assert_allclose(got, np.maximum(0.5 * ref + bias, 0), rtol=0, atol=2e-6 * float(mag.max()))
