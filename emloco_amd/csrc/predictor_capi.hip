@@ -67,6 +67,14 @@ int emloco_act_bwd(int64_t total, const float *dy, const float *y, int relu, flo
     return 0;
 }
 
+// tile choice of the split mode: -1 = by launch size (gemm_use_small_tile), 0 / 1 = never / always the 64 x 64 tile
+static int g_force_small = getenv("EMLOCO_GEMM_SMALL") ? atoi(getenv("EMLOCO_GEMM_SMALL")) : -1;
+int emloco_gemm_set_small_tile(int mode) {
+    if (mode < -1 || mode > 1) return pfail(-1, "emloco_gemm_set_small_tile: mode -1 (by launch size), 0 (never) or 1 (always)");
+    g_force_small = mode;
+    return 0;
+}
+
 int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha, const float *A, int lda, int64_t stride_a, int trans_a,
                        const float *B, int ldb, int64_t stride_b, int trans_b, float *C, int ldc, int64_t stride_c,
                        const float *bias, int flags, int ksplit, float *workspace, float drop_p, uint32_t drop_seed, void *stream) {
@@ -96,8 +104,7 @@ int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha, const float 
     // stage depth: 32 for long reductions (covers the prefetch latency), 16 for short ones (less LDS, more workgroups / CU)
     static const int force_bk = getenv("EMLOCO_GEMM_BK") ? atoi(getenv("EMLOCO_GEMM_BK")) : 0;
     const bool split_ok = (flags & EMLOCO_GEMM_SPLIT) && !(flags & EMLOCO_GEMM_BF16) && g.vec_a && g.vec_b && n > 32;
-    static const int force_small = getenv("EMLOCO_GEMM_SMALL") ? atoi(getenv("EMLOCO_GEMM_SMALL")) : -1;      // 0 / 1: never / always (A/B runs)
-    g.small = split_ok && (force_small >= 0 ? force_small == 1 : emloco::gemm_use_small_tile(batch, m, n, ksplit)) ? 1 : 0;
+    g.small = split_ok && (g_force_small >= 0 ? g_force_small == 1 : emloco::gemm_use_small_tile(batch, m, n, ksplit)) ? 1 : 0;
     const unsigned bn = n <= 32 ? 32 : (g.small ? 64 : 128), bm = g.small ? 64 : 128;
     dim3 grid((unsigned)((n + bn - 1) / bn), (unsigned)((m + bm - 1) / bm), (unsigned)(batch * ksplit));
     // measured (tools/exp/probe_jta_gemm.py, tools/probe_gemm.py): the 32-deep stage only pays while the launch is at most ~2

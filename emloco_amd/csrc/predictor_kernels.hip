@@ -45,8 +45,12 @@ struct GemmArgs {
     int small;          // split mode on the 64 x 64 tile (gemm_split_small_kernel): the launcher sets it and sizes the grid for it
 };
 
-// the 64 x 64 split tile serves a launch whose 128 x 128 grid would be at most this many workgroups (3 per CU)
-constexpr long GEMM_SMALL_MAX_WG = 768;
+// the 64 x 64 split tile serves a launch whose 128 x 128 grid (split-K included) would be at most this many workgroups.  Measured on
+// MI355X (tools/exp/probe_small_gemm.py, M = 2 048 / 4 096 layers of the policy, the discriminator and the PPO update): with the
+// split-K factor chosen for ~512 workgroups the 128 x 128 tile wins everywhere except the narrowest layers (4096 x 256 x 512: 19.8
+// vs 22.5 us, the 69-wide action head: 18.2 vs 20.3 us) -- the small tile halves the matrix work per split piece; it is kept for
+// launches that stay under half a workgroup per CU even after splitting k.
+constexpr long GEMM_SMALL_MAX_WG = 128;
 inline bool gemm_use_small_tile(int batch, int m, int n, int ksplit) {
     return (long)((m + 127) / 128) * ((n + 127) / 128) * batch * ksplit <= GEMM_SMALL_MAX_WG;
 }

@@ -182,8 +182,10 @@ class LinearFn(torch.autograd.Function):
         # arrives as bf16 too and is consumed as it is by the two gradient GEMMs and the bias-gradient column sum
         y = torch.empty((M, N), dtype=torch.bfloat16 if (out_bf16 and _matmul_precision[0] == "bf16") else torch.float32, device=x.device)
         flags = (GEMM_BIAS if b is not None else 0) | (GEMM_RELU if relu else 0)
+        # (split-K for the learners' small batches: a 2 048 x 1 024 x 2 048 layer is 128 tiles on 256 CUs -- 124 us whole, 62 us in
+        # four k-slices, tools/exp/probe_small_gemm.py; the predictor's tall activations have thousands of tiles and stay whole)
         gemm(1, M, N, K, x2, K, 0, 0, Wc, K, 0, 0, y, N, 0, bias=b.contiguous() if b is not None else None, flags=flags,
-             drop_p=drop_p, drop_seed=drop_seed)
+             drop_p=drop_p, drop_seed=drop_seed, ksplit=1 if y.dtype == torch.bfloat16 else _ksplit_for(K, M * N))
         ctx.save_for_backward(x2, Wc, y if relu else None)
         ctx.relu, ctx.has_bias, ctx.xs, ctx.drop = relu, b is not None, xs, (float(drop_p), int(drop_seed))
         return y.view(*xs[:-1], N)
@@ -209,7 +211,7 @@ class LinearFn(torch.autograd.Function):
             dy2 = dz
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            gemm(1, M, K, N, dy2, N, 0, 0, W, K, 0, 1, dx, K, 0)          # dx = dy W
+            gemm(1, M, K, N, dy2, N, 0, 0, W, K, 0, 1, dx, K, 0, ksplit=1 if dy2.dtype == torch.bfloat16 else _ksplit_for(N, M * K))   # dx = dy W
             dx = dx.view(ctx.xs)
         if ctx.needs_input_grad[1]:
             dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)

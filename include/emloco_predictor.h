@@ -250,6 +250,11 @@ int emloco_adamw_gated(int n, float *params, const float *grads, float *exp_avg,
                        float *steps_out, const float *tail2, float lr, float beta1, float beta2, float eps, float weight_decay,
                        double *stats, void *stream);
 
+/* Tile choice of the split mode (EMLOCO_GEMM_SPLIT): -1 (default) picks the 64 x 64 tile for launches whose 128 x 128 grid would
+ * leave CUs idle, 0 / 1 force never / always.  Results do not depend on it (an output element's reduction order is the same in both
+ * tiles: bit-equal, tests/test_emu_kernels.py); a tuning / A-B knob, also settable through EMLOCO_GEMM_SMALL. */
+int emloco_gemm_set_small_tile(int mode);
+
 /* HIP-event timing of the GEMM launches (same protocol as emloco_sim_timing_stats) */
 int emloco_gemm_enable_timing(int on);
 int emloco_gemm_timing_stats(int *n_launches, float *total_ms, double *total_flops);

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the configs[2] loop's schedule knobs on one box (run through gpurun): prints the `with_discriminator_and_locoval_fit` line per variant
+mkdir -p gpurun_out/r04
 OUT=gpurun_out/r04/ab_disc.txt
 : > $OUT
 run() {

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the 64 x 64 split tile and the split-K target on the policy / discriminator / PPO legs (one box; run through gpurun)
+mkdir -p gpurun_out/r04
 OUT=gpurun_out/r04/ab_small_tile.txt
 : > $OUT
 run() {
