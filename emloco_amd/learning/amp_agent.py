@@ -91,13 +91,23 @@ def amp_dropout_mask(B, steps, feat, num_masks=3, dropout_rate=0.3, device="cpu"
     assert feat == 206
     dof_off, num_joints = 12, 19
     vel_off = dof_off + num_joints * 6
-    keep = torch.stack([(torch.rand(B, num_masks) > dropout_rate) for _ in range(num_joints)], dim=1)      # (B, 19, M)
-    keep = torch.cat([keep, torch.ones(B, 1, num_masks, dtype=torch.bool)], dim=1).to(device).float()     # slot 19: always kept
-    col = torch.full((feat,), num_joints, dtype=torch.long)
-    for j in range(num_joints):
-        col[dof_off + j * 6:dof_off + j * 6 + 6] = j
-        col[vel_off + j * 3:vel_off + j * 3 + 3] = j
-    return keep[:, col.to(device), :].repeat(1, steps, 1)
+    if (B * num_masks) % 16 == 0:      # one call draws the same stream as the 19 (checked for these sizes in tests/test_amp_agent_cpu.py)
+        u = torch.rand(num_joints, B, num_masks)
+    else:
+        u = torch.stack([torch.rand(B, num_masks) for _ in range(num_joints)])
+    keep = (u.to(device) > dropout_rate).permute(1, 0, 2).float()                                          # (B, 19, M), on the device
+    keep = torch.cat([keep, torch.ones(B, 1, num_masks, device=device)], dim=1)                            # slot 19: always kept
+    key = str(device)
+    if key not in _AMP_COL:
+        col = torch.full((feat,), num_joints, dtype=torch.long)
+        for j in range(num_joints):
+            col[dof_off + j * 6:dof_off + j * 6 + 6] = j
+            col[vel_off + j * 3:vel_off + j * 3 + 3] = j
+        _AMP_COL[key] = col.to(device)
+    return keep[:, _AMP_COL[key], :].repeat(1, steps, 1)
+
+
+_AMP_COL = {}
 
 
 def disc_forward_with_grad_penalty(net, amp_obs_demo, input_mask=None):

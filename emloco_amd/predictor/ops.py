@@ -266,7 +266,8 @@ class FeedForwardFn(torch.autograd.Function):
         h = torch.empty((M, F), dtype=torch.bfloat16 if h16 else torch.float32, device=x.device)
         gemm(1, M, F, K, x2, K, 0, 0, W1c, K, 0, 0, h, F, 0, bias=b1.contiguous(), flags=GEMM_BIAS | GEMM_RELU, drop_p=drop_p, drop_seed=seed1)
         f = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        gemm(1, M, N, F, h, F, 0, 0, W2c, F, 0, 0, f, N, 0, bias=b2.contiguous(), flags=GEMM_BIAS, drop_p=drop_p, drop_seed=seed2)
+        gemm(1, M, N, F, h, F, 0, 0, W2c, F, 0, 0, f, N, 0, bias=b2.contiguous(), flags=GEMM_BIAS, drop_p=drop_p, drop_seed=seed2,
+             ksplit=_ksplit_for(F, M * N))                     # (whole for the predictor's tall batches; as LinearFn splits a small one)
         ctx.save_for_backward(x2, W1c, W2c, h)
         ctx.xs, ctx.drop = xs, (float(drop_p), int(seed1), int(seed2))
         return f.view(*xs[:-1], N)
@@ -298,7 +299,7 @@ class FeedForwardFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-            gemm(1, M, K, F, dz1, F, 0, 0, W1, K, 0, 1, dx, K, 0)                                    # dx = dz1 W1
+            gemm(1, M, K, F, dz1, F, 0, 0, W1, K, 0, 1, dx, K, 0, ksplit=1 if h16 else _ksplit_for(F, M * K))   # dx = dz1 W1
             dx = dx.view(ctx.xs)
         dW1 = torch.empty((F, K), dtype=torch.float32, device=dev)
         gemm(1, F, K, M, dz1, F, 0, 1, x2, K, 0, 1, dW1, K, 0, ksplit=_ksplit_for(M, F * K))         # dW1 = dz1^T x

@@ -66,3 +66,18 @@ def test_amp_dropout_mask_drops_whole_joints_consistently_over_steps():
     vel = row[:, 0, 12 + 19 * 6:12 + 19 * 9].reshape(64, 19, 3, 3)
     assert (rot == rot[:, :, :1]).all() and (vel == rot[:, :, :3]).all()              # a joint's 6 rotation + 3 velocity values share one draw
     assert 0.6 < rot.mean().item() < 0.8                                              # keep probability 0.7
+
+
+def test_amp_dropout_mask_draws_the_reference_stream():
+    """The mask is assembled on the device from ONE host draw; that draw must be the stream of the reference's 19 successive
+    `torch.rand(B, num_masks)` calls (amp_models.py:85-89), whatever the batch size."""
+    for B in (2048, 2560, 64, 37):
+        torch.manual_seed(5)
+        m = amp_dropout_mask(B, 3, 206)
+        torch.manual_seed(5)
+        ref = torch.ones(B, 206, 3)
+        for j in range(19):
+            keep = (torch.rand(B, 3) > 0.3).float()
+            ref[:, 12 + j * 6:12 + j * 6 + 6, :] = keep[:, None]
+            ref[:, 126 + j * 3:126 + j * 3 + 3, :] = keep[:, None]
+        assert torch.equal(m, ref.repeat(1, 3, 1)), B

@@ -153,7 +153,9 @@ def _eight_rank_worker(rank, world, port, out, steps):
     mine = (rms.running_mean.clone(), rms.running_var.clone(), float(rms.count))
     sync_running_mean_std(rms)
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
-    out.put((rank, flat, commits, float(opt.steps), mine, rms.running_mean.clone(), rms.running_var.clone(), float(rms.count)))
+    # (numpy, not tensors: a tensor travels through the queue as a shared-memory handle that must outlive the sender)
+    out.put((rank, flat.numpy().copy(), commits, float(opt.steps), (mine[0].numpy().copy(), mine[1].numpy().copy(), mine[2]),
+             rms.running_mean.numpy().copy(), rms.running_var.numpy().copy(), float(rms.count)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -178,17 +180,19 @@ def test_eight_rank_gated_fit_with_episodes_on_disjoint_steps():
     torch.manual_seed(50)
     ref = torch.nn.Sequential(torch.nn.Linear(100, 49), torch.nn.ReLU(), torch.nn.Linear(49, 24), torch.nn.ReLU(), torch.nn.Linear(24, 1))
     start = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+    import numpy as np
     for r, flat, commits, nstep, _mine, _mu, _var, _c in res:
-        assert torch.equal(flat, res[0][1]), r                                  # replicas identical after 33 steps
+        assert np.array_equal(flat, res[0][1]), r                               # replicas identical after 33 steps
         assert commits == expect and nstep == float(expect), (r, commits, nstep)
-    assert not torch.equal(res[0][1], start)                                    # ... and they moved away from rank 0's initial weights
+    assert not np.array_equal(res[0][1], start.numpy())                         # ... and they moved away from rank 0's initial weights
     # pooled statistics: weights count_r / sum(count)
-    cs = torch.tensor([m[4][2] for m in res], dtype=torch.float64)
-    mus = torch.stack([m[4][0].double() for m in res])
-    vs = torch.stack([m[4][1].double() for m in res])
-    w = (cs / cs.sum()).unsqueeze(1)
+    cs = np.array([m[4][2] for m in res], np.float64)
+    mus = np.stack([m[4][0].astype(np.float64) for m in res])
+    vs = np.stack([m[4][1].astype(np.float64) for m in res])
+    w = (cs / cs.sum())[:, None]
     mu = (w * mus).sum(0)
     var = (w * (vs + (mus - mu) ** 2)).sum(0)
     for m in res:
-        assert torch.allclose(m[5].double(), mu, rtol=1e-6, atol=1e-7) and torch.allclose(m[6].double(), var, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(m[5], mu, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(m[6], var, rtol=1e-6, atol=1e-7)
         assert abs(m[7] - float(cs.mean())) < 1e-3
