@@ -41,7 +41,8 @@ namespace emloco {
 #define MAXC EMLOCO_MAXC
 #define MAXR (3 * EMLOCO_MAXC)
 #define MAXCAND EMLOCO_MAXCAND
-#define EMLOCO_WH_MAX 0.4f /* largest link rotation per substep [rad]: cap of the link angular speed, see phase 1 */
+#define EMLOCO_WH_MAX 1.0f /* largest link rotation per substep [rad]: 120 rad/s at h = 1/120 -- above the asset's max_angular_velocity = 100
+                            * (humanoid.py:685-688), which is therefore the cap that binds (phase 1; 0.4 = 48 rad/s before the angular-momentum balance) */
 #define YLEN 30 /* chain-propagation vector: 6 root + 3 per tree level (depth <= 8) */
 
 // index into a packed symmetric 6x6 (upper triangle, row-major): (a<=b)
@@ -169,7 +170,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     // The contact matrix (1830 words, phases 6b-6c: everything above is dead then) lies over [Ia tail .. pq] and 90 words
     // past it, the staged Jacobian rows of phase 7 (720 words) over [Ia tail .. a] -- dead again before pa / a are written --
     // and the limb-limb scratch (phase 1b) over [Ia tail .. a].  Barriers separate the phases.
-    enum { O_ROOT = 0, O_P = 16, O_V0 = 24, O_PD = 36, O_R = O_PD + NB, O_W = O_R + NB * 12,
+    enum { O_ROOT = 0, O_P = 16, O_V0 = 24, O_L = 36, O_PD = 48, O_R = O_PD + NB, O_W = O_R + NB * 12,
            O_L0 = O_W + NB * 24, O_CB = O_L0 + 44, O_CX = O_CB + MAXC / 4 + 3, O_CDIST = O_CX + 3 * MAXC, O_LAM = O_CDIST + MAXC,
            O_SLOT = O_LAM + MAXR, O_CRANGE = O_SLOT + 32, O_IA = O_CRANGE + 2 * NB / 4, O_G = O_IA + 180,
            O_PA = O_IA + NB * 24, O_A_ = O_PA + NB * 8, O_V = O_A_ + NB * 8,
@@ -182,6 +183,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
     float *sh_root = lds + O_ROOT;                            // p0[3] q0[4] V0[6]
     float *sh_V0 = lds + O_V0;                                // lane 0's hand-over between phases: free root twist [0..5], impulse change [6..11]
     float *sh_P = lds + O_P;                                  // linear momentum: expected [0..2], of the current substep [3..5]; total mass [6]
+    float *sh_L = lds + O_L;                                  // angular momentum about the centre of mass: expected [0..2], "a balance exists" [3] (1 / 0), of the current substep [4..6]; centre of mass relative to O [8..10]
     int *sh_pd = (int *)(lds + O_PD);                         // per body: tree constants, packed (PD_PARENT / PD_DEPTH / PD_SLOT / PD_CHILD)
     float (*sh_R)[12] = (float (*)[12])(lds + O_R);           // rotation matrix [0..8] | position relative to O [9..11]
     float (*sh_W)[24] = (float (*)[24])(lds + O_W);           // per joint: W = U K^T (6 x 3) [0..17] | K, the inverse Cholesky factor of D (packed lower) [18..23]
@@ -266,12 +268,12 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             for (int k = 0; k < 4; ++k) qj[k] = v[k];
             for (int k = 0; k < 3; ++k) wj[k] = v[4 + k];
             edof[0] = v[7]; edof[1] = v[8]; edof[2] = v[9];
-        } else if (lane < NB + 31) {   // one granule of LDS state per lane: root (4) | momentum (2) | multipliers (16) | slot map (8) | misc
+        } else if (lane < NB + 32) {   // one granule of LDS state per lane: root (4) | momentum (2) | multipliers (16) | slot map (8) | misc | angular momentum
             const int g = lane - NB;
             float v[4];
             part_ld16(pst + NB * 12 + 4 * g, v);
-            float *dst = g < 4 ? sh_root + 4 * g : g < 6 ? sh_P + 4 * (g - 4) : g < 22 ? sh_lam + 4 * (g - 6) : (float *)sh_slot + 4 * (g - 22);
-            if (g < 30) for (int k = 0; k < 4; ++k) dst[k] = v[k];
+            float *dst = g < 4 ? sh_root + 4 * g : g < 6 ? sh_P + 4 * (g - 4) : g < 22 ? sh_lam + 4 * (g - 6) : g < 30 ? (float *)sh_slot + 4 * (g - 22) : sh_L;
+            if (g != 30) for (int k = 0; k < 4; ++k) dst[k] = v[k];
             else sh_V0[0] = v[0];                               // the work counter, picked up below
         }
         __syncthreads();
@@ -381,7 +383,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                     for (int k = 0; k < 6; ++k) sh_Aacc[lane][k] *= sc2;
                     if (lane >= 1) for (int k = 0; k < 3; ++k) wj[k] *= sc;
                 }
-                if (lane == 0) for (int k = 0; k < 3; ++k) { sh_root[7 + k] *= sc; sh_root[10 + k] = v0n[k]; }
+                if (lane == 0) for (int k = 0; k < 3; ++k) { sh_root[7 + k] *= sc; sh_root[10 + k] = v0n[k]; sh_L[k] *= sc; }   // (every angular rate scaled: so is L about c)
                 __syncthreads();
             }
         }
@@ -423,6 +425,78 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             }
             if (lane == 0) sh_P[6] = Mtot;
             __syncthreads();
+            // Angular-momentum balance (oracle_sim.c: project_angular_momentum).  The velocity products are integrated explicitly: a
+            // free body tumbling at 13 rad/s gained 50 % kinetic energy a second, which is why links used to be capped at 48 rad/s.
+            // Like the linear momentum, the angular momentum about the centre of mass c is carried across the substeps of a launch --
+            // L_exp = damp (L + sum of (x - c) x contact impulse) -- and what the new generalized velocities have in the new
+            // configuration is moved onto it by a rigid rotation rate dw of the whole body about c: J dw = L_exp - L (J: composite
+            // inertia about c, joints locked), every body twist gains [dw ; c x dw] about O -- the linear momentum is untouched.
+            {
+                float lc[3] = {0.0f, 0.0f, 0.0f}, rcb[3] = {0.0f, 0.0f, 0.0f}, vcb[3] = {0.0f, 0.0f, 0.0f}, Vn[6] = {0, 0, 0, 0, 0, 0}, Rb[9];
+                if ((lane < NB)) {
+                    float cm[4], cw[3], wx[3];
+                    for (int k = 0; k < 9; ++k) Rb[k] = sh_R[lane][k];
+                    ld4(mdl, o_dyn + 4, cm);
+                    for (int k = 0; k < 6; ++k) Vn[k] = sh_V[lane][k];
+                    matvec3(Rb, cm, cw);
+                    for (int k = 0; k < 3; ++k) rcb[k] = sh_R[lane][9 + k] + cw[k];
+                    cross3(Vn, rcb, wx);
+                    for (int k = 0; k < 3; ++k) { vcb[k] = Vn[3 + k] + wx[k]; lc[k] = lm * rcb[k]; }
+                }
+                float Cc[3], vc[3];
+                for (int k = 0; k < 3; ++k) { Cc[k] = wave_sum(lc[k]) / Mtot; vc[k] = sh_P[3 + k] / Mtot; }
+                float ll[3] = {0.0f, 0.0f, 0.0f}, lj[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                if ((lane < NB)) {
+                    float in6[8], Rc[9], Ic[6], dC[3], u[3], du[3], Iw[3];
+                    ld4(mdl, o_dyn + 8, in6); ld4(mdl, o_dyn + 12, in6 + 4);
+                    const float Ib[9] = {in6[0], in6[3], in6[4], in6[3], in6[1], in6[5], in6[4], in6[5], in6[2]};
+                    for (int a = 0; a < 3; ++a)
+                        for (int q = 0; q < 3; ++q) Rc[a * 3 + q] = SOP3(Rb[a * 3], Ib[q], Rb[a * 3 + 1], Ib[3 + q], Rb[a * 3 + 2], Ib[6 + q]);
+                    const int ja[6] = {0, 1, 2, 0, 0, 1}, jb[6] = {0, 1, 2, 1, 2, 2};          // upper triangle: 00 11 22 01 02 12
+                    for (int e = 0; e < 6; ++e) {
+                        const int a = ja[e], q = jb[e];
+                        Ic[e] = SOP3(Rc[a * 3], Rb[q * 3], Rc[a * 3 + 1], Rb[q * 3 + 1], Rc[a * 3 + 2], Rb[q * 3 + 2]);
+                    }
+                    for (int k = 0; k < 3; ++k) { dC[k] = rcb[k] - Cc[k]; u[k] = vcb[k] - vc[k]; }
+                    cross3(dC, u, du);
+                    Iw[0] = SOP3(Ic[0], Vn[0], Ic[3], Vn[1], Ic[4], Vn[2]);
+                    Iw[1] = SOP3(Ic[3], Vn[0], Ic[1], Vn[1], Ic[5], Vn[2]);
+                    Iw[2] = SOP3(Ic[4], Vn[0], Ic[5], Vn[1], Ic[2], Vn[2]);
+                    const float dd2 = dot3(dC, dC);
+                    for (int k = 0; k < 3; ++k) ll[k] = Iw[k] + lm * du[k];
+                    for (int e = 0; e < 6; ++e) {
+                        const int a = ja[e], q = jb[e];
+                        lj[e] = Ic[e] + lm * ((a == q ? dd2 : 0.0f) - dC[a] * dC[q]);
+                    }
+                }
+                float Lact[3], Jc[6];
+                for (int k = 0; k < 3; ++k) Lact[k] = wave_sum(ll[k]);
+                for (int e = 0; e < 6; ++e) Jc[e] = wave_sum(lj[e]);
+                const bool havL = sub > 0 && sh_L[3] != 0.0f;        // wave-uniform
+                float dw[3] = {0.0f, 0.0f, 0.0f}, dvO[3] = {0.0f, 0.0f, 0.0f};
+                bool moved = false;
+                if (havL) {
+                    const float b0 = sh_L[0] - Lact[0], b1 = sh_L[1] - Lact[1], b2 = sh_L[2] - Lact[2];
+                    const float c00 = Jc[1] * Jc[2] - Jc[5] * Jc[5], c01 = Jc[4] * Jc[5] - Jc[3] * Jc[2], c02 = Jc[3] * Jc[5] - Jc[4] * Jc[1];
+                    const float c11 = Jc[0] * Jc[2] - Jc[4] * Jc[4], c12 = Jc[3] * Jc[4] - Jc[0] * Jc[5], c22 = Jc[0] * Jc[1] - Jc[3] * Jc[3];
+                    const float det = SOP3(Jc[0], c00, Jc[3], c01, Jc[4], c02);
+                    if (det > 1e-12f) {
+                        dw[0] = SOP3(c00, b0, c01, b1, c02, b2) / det;
+                        dw[1] = SOP3(c01, b0, c11, b1, c12, b2) / det;
+                        dw[2] = SOP3(c02, b0, c12, b1, c22, b2) / det;
+                        cross3(Cc, dw, dvO);
+                        moved = true;
+                    }
+                }
+                __syncthreads();                                      // every lane has read sh_L / sh_P / sh_V
+                if (moved && (lane < NB))
+                    for (int k = 0; k < 3; ++k) { sh_V[lane][k] = Vn[k] + dw[k]; sh_V[lane][3 + k] = Vn[3 + k] + dvO[k]; }
+                if (lane == 0) {
+                    if (moved) for (int k = 0; k < 3; ++k) { sh_root[7 + k] += dw[k]; sh_root[10 + k] += dvO[k]; }
+                    for (int k = 0; k < 3; ++k) { sh_L[4 + k] = moved ? sh_L[k] : Lact[k]; sh_L[8 + k] = Cc[k]; }
+                }
+                __syncthreads();
+            }
         }
         if (final_pass) break;
 
@@ -1216,9 +1290,25 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 sh_P[2] = fmaf(sh_P[6] * prm.gravity_z, h, sh_P[2]);
             }
         }
+        const float damp = 1.0f / (1.0f + h * prm.ang_damping);
+        {   // angular momentum about the centre of mass after this substep: the moments of the contact impulses, then the damping
+            float tq[3] = {0.0f, 0.0f, 0.0f};
+            if (nc > 0) {
+                float dir[3] = {myd == 1 ? 1.0f : 0.0f, myd == 2 ? 1.0f : 0.0f, myd == 0 ? 1.0f : 0.0f};
+                if (hf_on && lane < nr) for (int k = 0; k < 3; ++k) dir[k] = sh_cdir[myc][3 * myd + k];
+                float t[3] = {0.0f, 0.0f, 0.0f};
+                if (lane < nr) {
+                    float arm[3], ip[3];
+                    for (int k = 0; k < 3; ++k) { arm[k] = sh_cx[myc][k] - sh_L[8 + k]; ip[k] = dir[k] * lam; }
+                    cross3(arm, ip, t);
+                }
+                for (int k = 0; k < 3; ++k) tq[k] = wave_sum(t[k]);
+            }
+            if (lane == 0) for (int k = 0; k < 3; ++k) sh_L[k] = (sh_L[4 + k] + tq[k]) * damp;
+        }
         PSTAMP(9);
         // ============================================================ 8. integrate
-        const float damp = 1.0f / (1.0f + h * prm.ang_damping);
+        bool clamped = false;       // a rate clamped to max_ang_vel changes the angular momentum in a way the balance does not predict: it is skipped once
         if ((lane < NB) && lane >= 1) {
             float wn[3];
             for (int k = 0; k < 3; ++k) {
@@ -1237,7 +1327,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 wj[k] = wn[k] * damp;
             }
             const float nj = sqrtf(dot3(wj, wj));
-            if (nj > prm.max_ang_vel) { const float sc = prm.max_ang_vel / nj; wj[0] *= sc; wj[1] *= sc; wj[2] *= sc; }
+            if (nj > prm.max_ang_vel) { const float sc = prm.max_ang_vel / nj; wj[0] *= sc; wj[1] *= sc; wj[2] *= sc; clamped = true; }
             float e[3] = {h * wj[0], h * wj[1], h * wj[2]}, dqt[4], qn[4];
             rotvec2quat(e, dqt);
             qmul(qj, dqt, qn); qnormalize(qn);
@@ -1249,7 +1339,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             for (int k = 0; k < 6; ++k) V0[k] = sh_V0[k] + sh_V0[6 + k];
             for (int k = 0; k < 3; ++k) V0[k] *= damp;
             const float n = sqrtf(dot3(V0, V0));
-            if (n > prm.max_ang_vel) { const float sc = prm.max_ang_vel / n; V0[0] *= sc; V0[1] *= sc; V0[2] *= sc; }
+            if (n > prm.max_ang_vel) { const float sc = prm.max_ang_vel / n; V0[0] *= sc; V0[1] *= sc; V0[2] *= sc; clamped = true; }
             float e[3], dqt[4], qn[4], q0[4] = {sh_root[3], sh_root[4], sh_root[5], sh_root[6]};
             for (int k = 0; k < 3; ++k) { sh_root[k] += h * V0[3 + k]; e[k] = h * V0[k]; }
             rotvec2quat(e, dqt);
@@ -1263,6 +1353,10 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             for (int k = 0; k < 3; ++k) V0[3 + k] = fmaf(h, wxv[k], V0[3 + k]);
             for (int k = 0; k < 6; ++k) sh_root[7 + k] = V0[k];
         }
+        {
+            const bool any_clamped = __ballot(clamped) != 0ull;
+            if (lane == 0) sh_L[3] = any_clamped ? 0.0f : 1.0f;
+        }
         __syncthreads();
         PSTAMP(10);
     }
@@ -1273,10 +1367,10 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             part_st16(ps, qj[0], qj[1], qj[2], qj[3]);
             part_st16(ps + 4 * NB, wj[0], wj[1], wj[2], edof[0]);
             part_st16(ps + 8 * NB, edof[1], edof[2], 0.0f, 0.0f);
-        } else if (lane < NB + 31) {
+        } else if (lane < NB + 32) {
             const int g = lane - NB;
-            const float *src = g < 4 ? sh_root + 4 * g : g < 6 ? sh_P + 4 * (g - 4) : g < 22 ? sh_lam + 4 * (g - 6) : (const float *)sh_slot + 4 * (g - 22);
-            if (g < 30) part_st16(pst + NB * 12 + 4 * g, src[0], src[1], src[2], src[3]);
+            const float *src = g < 4 ? sh_root + 4 * g : g < 6 ? sh_P + 4 * (g - 4) : g < 22 ? sh_lam + 4 * (g - 6) : g < 30 ? (const float *)sh_slot + 4 * (g - 22) : sh_L;
+            if (g != 30) part_st16(pst + NB * 12 + 4 * g, src[0], src[1], src[2], src[3]);
             else part_st16(pst + NB * 12 + 4 * g, __int_as_float(work), 0.0f, 0.0f, 0.0f);
         }
         part_stores_done();           // the stores above have completed ...

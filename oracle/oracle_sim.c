@@ -24,7 +24,8 @@
 #include <math.h>
 #include <string.h>
 #ifndef ORC_WH_MAX
-#define ORC_WH_MAX 0.4f   /* largest link rotation per substep [rad], see bias_and_drive */
+#define ORC_WH_MAX 1.0f   /* largest link rotation per substep [rad], see bias_and_drive: 120 rad/s at h = 1/120 -- above the asset's
+                           * max_angular_velocity = 100 (humanoid.py:685-688), which is therefore the cap that binds */
 #endif
 #include "oracle_sim.h"
 
@@ -52,6 +53,9 @@ typedef struct {
     /* linear-momentum bookkeeping across the substeps of one call (see bias_and_drive) */
     float Pexp[3], Pcur[3], Mtot;
     int havP;
+    /* angular-momentum bookkeeping about the centre of mass (see project_angular_momentum) */
+    float Lexp[3], Lcur[3], com[3];
+    int havL;
 } Env;
 
 /* ---------------------------------------------------------------- small helpers */
@@ -380,6 +384,80 @@ static void project_momentum(Env *s, const EnvModel *m) {
     }
 }
 
+/* Angular-momentum balance.  The velocity products are integrated explicitly (first order): a free body tumbling at 13 rad/s gained
+ * 50 % kinetic energy and lost 30 % of its angular momentum within a second, which is why the link speed used to be capped at
+ * 48 rad/s.  The remedy is the one the linear momentum got: the angular momentum about the centre of mass is carried across the
+ * substeps of a call -- L_exp = damp (L + sum over the contact impulses of (x - c) x impulse): gravity has no moment about c, drive
+ * and limb-limb forces are internal, the angular damping scales every angular rate and with it L -- and the momentum the new
+ * generalized velocities actually have in the new configuration is moved onto it by a RIGID rotation rate dw of the whole body
+ * about c: J dw = L_exp - L with J the composite inertia about c (joints locked), every body twist gains [dw ; c x dw] (about O),
+ * which leaves the linear momentum alone.  With L exact the kinetic energy of a free rigid motion stays between L^2 / 2 I_max and
+ * L^2 / 2 I_min.  The velocity-product accelerations of this substep are left as computed (dw is itself second order in h).
+ * Called right after project_momentum (V and Pcur current). */
+static void project_angular_momentum(Env *s, const EnvModel *m) {
+    float lane_c[3][64], lane_l[3][64], lane_j[6][64];
+    float rc[NB][3], vcb[NB][3];
+    for (int i = 0; i < 64; ++i) {
+        for (int k = 0; k < 3; ++k) lane_c[k][i] = 0.0f;
+        if (i < NB) {
+            float cw[3], wx[3];
+            matvec3(s->R[i], m->com + i * 3, cw);
+            for (int k = 0; k < 3; ++k) rc[i][k] = s->r[i][k] + cw[k];
+            cross3(s->V[i], rc[i], wx);
+            for (int k = 0; k < 3; ++k) { vcb[i][k] = s->V[i][3 + k] + wx[k]; lane_c[k][i] = m->mass[i] * rc[i][k]; }
+        }
+    }
+    float C[3], vc[3];
+    for (int k = 0; k < 3; ++k) { C[k] = wave_sum_order(lane_c[k]) / s->Mtot; vc[k] = s->Pcur[k] / s->Mtot; s->com[k] = C[k]; }
+    for (int i = 0; i < 64; ++i) {
+        for (int k = 0; k < 3; ++k) lane_l[k][i] = 0.0f;
+        for (int k = 0; k < 6; ++k) lane_j[k][i] = 0.0f;
+        if (i < NB) {
+            const float *in = m->inertia + i * 6, *R = s->R[i];
+            const float Ib[9] = {in[0], in[3], in[4], in[3], in[1], in[5], in[4], in[5], in[2]};
+            float Rc[9], Ic[6], d[3], u[3], du[3], Iw[3];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) Rc[a * 3 + b] = SOP3(R[a * 3], Ib[b], R[a * 3 + 1], Ib[3 + b], R[a * 3 + 2], Ib[6 + b]);
+            /* Ic = R Ib R^T, upper triangle: 00 11 22 01 02 12 */
+            static const int ja[6] = {0, 1, 2, 0, 0, 1}, jb[6] = {0, 1, 2, 1, 2, 2};
+            for (int e = 0; e < 6; ++e) {
+                int a = ja[e], b = jb[e];
+                Ic[e] = SOP3(Rc[a * 3], R[b * 3], Rc[a * 3 + 1], R[b * 3 + 1], Rc[a * 3 + 2], R[b * 3 + 2]);
+            }
+            for (int k = 0; k < 3; ++k) { d[k] = rc[i][k] - C[k]; u[k] = vcb[i][k] - vc[k]; }
+            cross3(d, u, du);
+            const float *w = s->V[i];
+            Iw[0] = SOP3(Ic[0], w[0], Ic[3], w[1], Ic[4], w[2]);
+            Iw[1] = SOP3(Ic[3], w[0], Ic[1], w[1], Ic[5], w[2]);
+            Iw[2] = SOP3(Ic[4], w[0], Ic[5], w[1], Ic[2], w[2]);
+            const float ms = m->mass[i], dd = dot3(d, d);
+            for (int k = 0; k < 3; ++k) lane_l[k][i] = Iw[k] + ms * du[k];
+            for (int e = 0; e < 6; ++e) {
+                int a = ja[e], b = jb[e];
+                lane_j[e][i] = Ic[e] + ms * ((a == b ? dd : 0.0f) - d[a] * d[b]);
+            }
+        }
+    }
+    float L[3], J[6];
+    for (int k = 0; k < 3; ++k) L[k] = wave_sum_order(lane_l[k]);
+    for (int e = 0; e < 6; ++e) J[e] = wave_sum_order(lane_j[e]);
+    if (!s->havL) { memcpy(s->Lcur, L, 12); return; }
+    /* J dw = L_exp - L by cofactors (J symmetric positive definite: 00 11 22 01 02 12) */
+    const float b0 = s->Lexp[0] - L[0], b1 = s->Lexp[1] - L[1], b2 = s->Lexp[2] - L[2];
+    const float c00 = J[1] * J[2] - J[5] * J[5], c01 = J[4] * J[5] - J[3] * J[2], c02 = J[3] * J[5] - J[4] * J[1];
+    const float c11 = J[0] * J[2] - J[4] * J[4], c12 = J[3] * J[4] - J[0] * J[5], c22 = J[0] * J[1] - J[3] * J[3];
+    const float det = SOP3(J[0], c00, J[3], c01, J[4], c02);
+    if (!(det > 1e-12f)) { memcpy(s->Lcur, L, 12); return; }
+    float dw[3], dvO[3];
+    dw[0] = SOP3(c00, b0, c01, b1, c02, b2) / det;
+    dw[1] = SOP3(c01, b0, c11, b1, c12, b2) / det;
+    dw[2] = SOP3(c02, b0, c12, b1, c22, b2) / det;
+    cross3(C, dw, dvO);
+    for (int i = 0; i < NB; ++i)
+        for (int k = 0; k < 3; ++k) { s->V[i][k] += dw[k]; s->V[i][3 + k] += dvO[k]; }
+    for (int k = 0; k < 3; ++k) { s->V0[k] += dw[k]; s->V0[3 + k] += dvO[k]; s->Lcur[k] = s->Lexp[k]; }
+}
+
 /* ---------------------------------------------------------------- 2. bias forces + drive */
 static void bias_and_drive(Env *s, const EnvModel *m, const OrcSimParams *prm, const float *edof,
                            const float *tgt) {
@@ -438,8 +516,10 @@ static void bias_and_drive(Env *s, const EnvModel *m, const OrcSimParams *prm, c
             if (i >= 1) for (int k = 0; k < 3; ++k) s->wj[i][k] *= sc;
         }
         for (int k = 0; k < 3; ++k) { s->V0[k] *= sc; s->V0[3 + k] = v0n[k]; }
+        for (int k = 0; k < 3; ++k) s->Lexp[k] *= sc;      /* every angular rate was scaled by sc: so was the angular momentum about c */
     }
     project_momentum(s, m);
+    project_angular_momentum(s, m);
     for (int i = 0; i < NB; ++i) {
         float c[3], hI[6], IA[6], x1[3], x2[3];
         body_inertia(s, m, i, s->I6[i], c);
@@ -836,8 +916,21 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
         s->Pexp[2] = fmaf(s->Mtot * prm->gravity_z, h, s->Pexp[2]);
         s->havP = 1;
     }
-
     float damp = 1.0f / (1.0f + h * prm->ang_damping);
+    {   /* angular momentum about the centre of mass after this substep: the moments of the contact impulses, then the damping */
+        float lane_t[3][64];
+        memset(lane_t, 0, sizeof(lane_t));
+        for (int r = 0; r < nr; ++r) {
+            const Contact *cc = &con[r / 3];
+            float arm[3], imp[3], t[3];
+            for (int k = 0; k < 3; ++k) { arm[k] = cc->x[k] - s->com[k]; imp[k] = cc->D[3 * (r % 3) + k] * lam[r]; }
+            cross3(arm, imp, t);
+            for (int k = 0; k < 3; ++k) lane_t[k][r] = t[k];
+        }
+        for (int k = 0; k < 3; ++k) s->Lexp[k] = (s->Lcur[k] + (nc > 0 ? wave_sum_order(lane_t[k]) : 0.0f)) * damp;
+        s->havL = 1;
+    }
+
     for (int k = 0; k < 6; ++k) s->V0[k] = V0f[k] + da0[k];
     for (int i = 1; i < NB; ++i)
         for (int k = 0; k < 3; ++k) {
@@ -853,11 +946,12 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
     for (int k = 0; k < 3; ++k) s->V0[k] *= damp;
     /* clamp angular speeds */
     {
+        /* (a clamped rate changes the angular momentum in a way the balance does not predict: it is skipped once) */
         float n = sqrtf(dot3(s->V0, s->V0));
-        if (n > prm->max_ang_vel) { float sc = prm->max_ang_vel / n; s->V0[0] *= sc; s->V0[1] *= sc; s->V0[2] *= sc; }
+        if (n > prm->max_ang_vel) { float sc = prm->max_ang_vel / n; s->V0[0] *= sc; s->V0[1] *= sc; s->V0[2] *= sc; s->havL = 0; }
         for (int i = 1; i < NB; ++i) {
             float nj = sqrtf(dot3(s->wj[i], s->wj[i]));
-            if (nj > prm->max_ang_vel) { float sc = prm->max_ang_vel / nj; s->wj[i][0] *= sc; s->wj[i][1] *= sc; s->wj[i][2] *= sc; }
+            if (nj > prm->max_ang_vel) { float sc = prm->max_ang_vel / nj; s->wj[i][0] *= sc; s->wj[i][1] *= sc; s->wj[i][2] *= sc; s->havL = 0; }
         }
     }
     /* semi-implicit Euler: positions with the new velocities */
@@ -882,7 +976,7 @@ static void substep(Env *s, const EnvModel *m, const OrcSimParams *prm, const fl
 }
 
 static void load_state(Env *s, const float *root, const float *dof) {
-    s->havP = 0;
+    s->havP = 0; s->havL = 0;
     memcpy(s->p0, root, 12); memcpy(s->q0, root + 3, 16);
     qnormalize(s->q0);
     memcpy(s->V0, root + 10, 12); memcpy(s->V0 + 3, root + 7, 12);
@@ -896,7 +990,7 @@ static void load_state(Env *s, const float *root, const float *dof) {
 static void write_bodies(Env *s, const EnvModel *m, float *rb) {
     kinematics(s, m);
     velocities(s, m, s->V, s->V0, s->wj);
-    if (s->havP) project_momentum(s, m);     /* the last substep's balance, in the configuration it ended in */
+    if (s->havP) { project_momentum(s, m); project_angular_momentum(s, m); }   /* the last substep's balances, in the configuration it ended in */
     for (int i = 0; i < NB; ++i) {
         float *o = rb + i * 13, t[3];
         memcpy(o, s->pw[i], 12); memcpy(o + 3, s->qw[i], 16);
