@@ -70,7 +70,14 @@ class HumanoidAMP(Humanoid):
     def _load_motion(self, motion_file):
         assert (self._dof_offsets[-1] == self.num_dof)
         if motion_file not in (None, "", "synthetic"):
-            raise NotImplementedError("AMASS pickles do not ship; motion_file must be 'synthetic'")
+            # an AMASS pickle in the reference's format (convert_amass_isaac.py:309-317): one clip per env on that env's skeleton
+            # (humanoid_amp.py:256-271); the height fix through the SMPL mesh is replaced by the lowest-collision-point fix at reset
+            from ...utils.motion_lib_smpl import MotionLib
+            self._motion_lib = MotionLib(motion_file=motion_file, key_body_ids=self._key_body_ids.cpu().numpy(), device=self.device,
+                                         fix_height=False, masterfoot_conifg=None, min_length=self._min_motion_len if hasattr(self, "_min_motion_len") else -1)
+            self._motion_lib.load_motions(skeleton_trees=[a.model for a in self.humanoid_assets], gender_betas=self.humanoid_betas.cpu(),
+                                          limb_weights=None, random_sample=True)
+            return
         self._motion_lib = MotionLibSynthetic(self.humanoid_assets[0].model, self._key_body_ids.cpu().numpy(),
                                               self.device, num_motions=int(self.cfg["env"].get("num_motions", 64)),
                                               seed=int(self.cfg["env"].get("motion_seed", 0)))

@@ -41,64 +41,13 @@ def _gait_pose_aa(t, speed, phase0):
     return aa
 
 
-class MotionLibSynthetic:
-    def __init__(self, model, key_body_ids, device, num_motions=64, fps=30, seed=0):
-        self._device = torch.device(device)
-        self._key_body_ids = torch.as_tensor(key_body_ids, dtype=torch.long, device=self._device)
-        self.num_bodies = model.num_bodies
-        rng = np.random.default_rng(seed)
-        parent = model.parent
-        off = torch.tensor(model.joint_off, dtype=torch.float32)
-        gts, grs, lrs, gvs, gavs, dvs, lens, nfr, starts = [], [], [], [], [], [], [], [], []
-        self._motion_aa = []
-        dt = 1.0 / fps
-        total = 0
-        for m in range(num_motions):
-            T = int(rng.integers(150, 301))
-            speed = rng.uniform(0.5, 2.5)
-            t = np.arange(T, dtype=np.float32) * dt
-            aa = torch.from_numpy(_gait_pose_aa(t, speed, rng.uniform(0, 2 * np.pi)))
-            lq = torch.cat([torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(T, 1, 4), tu.exp_map_to_quat(aa.reshape(-1, 3)).view(T, 23, 4)], 1)
-            root_pos = torch.zeros(T, 3)
-            root_pos[:, 0] = torch.from_numpy(speed * t)
-            root_pos[:, 2] = 0.92 + 0.01 * torch.sin(torch.from_numpy(4 * np.pi * (0.7 + 0.45 * speed) * t))
-            gq = torch.zeros(T, self.num_bodies, 4)
-            gp = torch.zeros(T, self.num_bodies, 3)
-            gq[:, 0], gp[:, 0] = lq[:, 0], root_pos
-            for b in range(1, self.num_bodies):
-                p = int(parent[b])
-                gp[:, b] = gp[:, p] + tu.quat_apply(gq[:, p], off[b].expand(T, 3))
-                gq[:, b] = tu.normalize(tu.quat_mul(gq[:, p], lq[:, b]))
-            vel = torch.zeros_like(gp)
-            vel[:-1] = (gp[1:] - gp[:-1]) / dt
-            vel[-1] = vel[-2]
-            dq = tu.quat_mul(gq[1:], tu.quat_conjugate(gq[:-1]))
-            ang = torch.zeros_like(gp)
-            ang[:-1] = tu.quat_to_exp_map(tu.normalize(dq).reshape(-1, 4)).view(T - 1, self.num_bodies, 3) / dt
-            ang[-1] = ang[-2]
-            dl = tu.quat_mul(tu.quat_conjugate(lq[:-1, 1:]), lq[1:, 1:])            # motion_lib_smpl.py:44-50
-            dv = torch.zeros(T, 69)
-            dv[:-1] = (tu.quat_to_exp_map(tu.normalize(dl).reshape(-1, 4)).view(T - 1, 23, 3) / dt).reshape(T - 1, 69)
-            dv[-1] = dv[-2]
-            gts.append(gp); grs.append(gq); lrs.append(lq); gvs.append(vel); gavs.append(ang); dvs.append(dv)
-            self._motion_aa.append(torch.cat([torch.zeros(T, 3), aa.reshape(T, 69)], 1))
-            lens.append(dt * (T - 1)); nfr.append(T); starts.append(total)
-            total += T
-        dev = self._device
-        self.gts, self.grs, self.lrs = torch.cat(gts).to(dev), torch.cat(grs).to(dev), torch.cat(lrs).to(dev)
-        self.gvs, self.gavs, self.dvs = torch.cat(gvs).to(dev), torch.cat(gavs).to(dev), torch.cat(dvs).to(dev)
-        self._motion_aa = torch.cat(self._motion_aa).to(dev)
-        self._motion_lengths = torch.tensor(lens, dtype=torch.float32, device=dev)
-        self._motion_num_frames = torch.tensor(nfr, dtype=torch.long, device=dev)
-        self._motion_dt = torch.full((num_motions,), dt, dtype=torch.float32, device=dev)
-        self._motion_fps = torch.full((num_motions,), float(fps), device=dev)
-        self.length_starts = torch.tensor(starts, dtype=torch.long, device=dev)
-        self._motion_weights = torch.full((num_motions,), 1.0 / num_motions, device=dev)
-        self._motion_bodies = torch.zeros(num_motions, 17, device=dev)
-        self._motion_limb_weights = torch.zeros(num_motions, 10, device=dev)
+class MotionLibBase:
+    """The query side of the reference's MotionLib (sampling, frame blending, `get_motion_state_smpl`) over the per-frame cache a
+    subclass fills: gts / grs / lrs / gvs / gavs / dvs (frames of all clips concatenated), length_starts, _motion_lengths,
+    _motion_num_frames, _motion_dt, _motion_fps, _motion_weights, _motion_bodies, _motion_limb_weights, _motion_aa."""
 
     def load_motions(self, **kwargs):
-        return None     # the synthetic cache is built once; kept for interface parity (humanoid_amp.py:269-271)
+        return None     # caches that are built once; kept for interface parity (humanoid_amp.py:269-271)
 
     def num_motions(self):
         return int(self._motion_lengths.shape[0])
@@ -154,3 +103,60 @@ class MotionLibSynthetic:
             "body_ang_vel": body_ang_vel, "motion_bodies": self._motion_bodies[motion_ids],
             "motion_limb_weights": self._motion_limb_weights[motion_ids],
         }
+
+
+class MotionLibSynthetic(MotionLibBase):
+    def __init__(self, model, key_body_ids, device, num_motions=64, fps=30, seed=0):
+        self._device = torch.device(device)
+        self._key_body_ids = torch.as_tensor(key_body_ids, dtype=torch.long, device=self._device)
+        self.num_bodies = model.num_bodies
+        rng = np.random.default_rng(seed)
+        parent = model.parent
+        off = torch.tensor(model.joint_off, dtype=torch.float32)
+        gts, grs, lrs, gvs, gavs, dvs, lens, nfr, starts = [], [], [], [], [], [], [], [], []
+        self._motion_aa = []
+        dt = 1.0 / fps
+        total = 0
+        for m in range(num_motions):
+            T = int(rng.integers(150, 301))
+            speed = rng.uniform(0.5, 2.5)
+            t = np.arange(T, dtype=np.float32) * dt
+            aa = torch.from_numpy(_gait_pose_aa(t, speed, rng.uniform(0, 2 * np.pi)))
+            lq = torch.cat([torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(T, 1, 4), tu.exp_map_to_quat(aa.reshape(-1, 3)).view(T, 23, 4)], 1)
+            root_pos = torch.zeros(T, 3)
+            root_pos[:, 0] = torch.from_numpy(speed * t)
+            root_pos[:, 2] = 0.92 + 0.01 * torch.sin(torch.from_numpy(4 * np.pi * (0.7 + 0.45 * speed) * t))
+            gq = torch.zeros(T, self.num_bodies, 4)
+            gp = torch.zeros(T, self.num_bodies, 3)
+            gq[:, 0], gp[:, 0] = lq[:, 0], root_pos
+            for b in range(1, self.num_bodies):
+                p = int(parent[b])
+                gp[:, b] = gp[:, p] + tu.quat_apply(gq[:, p], off[b].expand(T, 3))
+                gq[:, b] = tu.normalize(tu.quat_mul(gq[:, p], lq[:, b]))
+            vel = torch.zeros_like(gp)
+            vel[:-1] = (gp[1:] - gp[:-1]) / dt
+            vel[-1] = vel[-2]
+            dq = tu.quat_mul(gq[1:], tu.quat_conjugate(gq[:-1]))
+            ang = torch.zeros_like(gp)
+            ang[:-1] = tu.quat_to_exp_map(tu.normalize(dq).reshape(-1, 4)).view(T - 1, self.num_bodies, 3) / dt
+            ang[-1] = ang[-2]
+            dl = tu.quat_mul(tu.quat_conjugate(lq[:-1, 1:]), lq[1:, 1:])            # motion_lib_smpl.py:44-50
+            dv = torch.zeros(T, 69)
+            dv[:-1] = (tu.quat_to_exp_map(tu.normalize(dl).reshape(-1, 4)).view(T - 1, 23, 3) / dt).reshape(T - 1, 69)
+            dv[-1] = dv[-2]
+            gts.append(gp); grs.append(gq); lrs.append(lq); gvs.append(vel); gavs.append(ang); dvs.append(dv)
+            self._motion_aa.append(torch.cat([torch.zeros(T, 3), aa.reshape(T, 69)], 1))
+            lens.append(dt * (T - 1)); nfr.append(T); starts.append(total)
+            total += T
+        dev = self._device
+        self.gts, self.grs, self.lrs = torch.cat(gts).to(dev), torch.cat(grs).to(dev), torch.cat(lrs).to(dev)
+        self.gvs, self.gavs, self.dvs = torch.cat(gvs).to(dev), torch.cat(gavs).to(dev), torch.cat(dvs).to(dev)
+        self._motion_aa = torch.cat(self._motion_aa).to(dev)
+        self._motion_lengths = torch.tensor(lens, dtype=torch.float32, device=dev)
+        self._motion_num_frames = torch.tensor(nfr, dtype=torch.long, device=dev)
+        self._motion_dt = torch.full((num_motions,), dt, dtype=torch.float32, device=dev)
+        self._motion_fps = torch.full((num_motions,), float(fps), device=dev)
+        self.length_starts = torch.tensor(starts, dtype=torch.long, device=dev)
+        self._motion_weights = torch.full((num_motions,), 1.0 / num_motions, device=dev)
+        self._motion_bodies = torch.zeros(num_motions, 17, device=dev)
+        self._motion_limb_weights = torch.zeros(num_motions, 10, device=dev)

@@ -804,3 +804,37 @@ def test_discriminator_beside_the_next_step_fits_the_same_network(monkeypatch):
     for a, b in zip(outs[0], outs[1]):
         if torch.is_tensor(a):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_rollout_from_an_amass_pickle(tmp_path):
+    """`--motion_file <pkl>` in the reference's AMASS format (utils/motion_lib_smpl.py; the clips of tests/golden/motion_amass.npz):
+    the task builds one clip per env on that env's skeleton, resets sample reference states from it (host path and the fused device
+    reset chain), the reset poses stand on the ground, the AMP demonstration batch comes from the clips, and the rollout runs."""
+    import joblib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "motion_amass.npz"))
+    clips = {f"clip{i}": {"pose_quat_global": g[f"c{i}_pose_quat_global"], "root_trans_offset": torch.from_numpy(g[f"c{i}_root_trans_offset"]),
+                          "pose_aa": g[f"c{i}_pose_aa"], "beta": g[f"c{i}_beta"], "gender": "neutral", "fps": int(g[f"c{i}_fps"])} for i in range(2)}
+    path = str(tmp_path / "amass_isaac_synthetic.pkl")
+    joblib.dump(clips, path)
+    from emloco_amd.utils.motion_lib_smpl import MotionLib
+    E = 48
+    env = _make_env(E, ["--random_heading", "--init_heading", "--adjust_root_vel", "--motion_file", path])
+    task = env.task
+    lib = task._motion_lib
+    assert isinstance(lib, MotionLib) and lib.num_motions() == E and set(lib._curr_motion_ids.tolist()) <= {0, 1}
+    assert lib.gts.is_cuda and lib.gts.shape[1:] == (24, 3)
+    obs = env.reset(torch.arange(E, device=task.device))
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all()
+    low = task._lowest_point(torch.arange(E, device=task.device))
+    assert float(low.abs().max()) < 0.03                                 # grounded by the lowest collision point
+    demo = task.fetch_amp_obs_demo(32)
+    assert demo.shape == (32, task.get_num_amp_obs()) and torch.isfinite(demo).all() and float(demo.abs().max()) > 0.1
+    for k in range(40):                                                  # natural resets through the fused device chain
+        if hasattr(env, "reset_done"):
+            env.reset_done()
+        obs, rew, done, info = env.step(torch.randn(E, 69, device=task.device) * 0.3)
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(task._amp_obs_buf).all() and torch.isfinite(rew).all()
+    assert int(task._sampled_motion_ids.max()) < E
