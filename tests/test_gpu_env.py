@@ -1,4 +1,6 @@
 """GPU: the task / VecEnv mirror end to end (create -> reset -> step), checked against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
