@@ -22,7 +22,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("EMLOCO_FORCE_COLLECTIVES") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -34,7 +34,12 @@ def init_from_env(backend=None):
 
 
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """More than one rank -- or EMLOCO_FORCE_COLLECTIVES=1 with an initialised group of ONE: every collective of the product then runs
+    (an all-reduce over one rank is the identity) so that the RCCL path -- stream-ordered launches on the stream the caller is on --
+    can be exercised on a one-GPU box (tests/test_gpu_dist.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("EMLOCO_FORCE_COLLECTIVES") == "1"
 
 
 def world_size():

@@ -29,7 +29,13 @@ enum { EMLOCO_GEMM_BIAS = 1, EMLOCO_GEMM_RELU = 2, EMLOCO_GEMM_ACCUMULATE = 4, E
         * v_mfma_f32_32x32x2_f32 stood -- 2.7x less matrix-pipe time (gfx950's fp32 MFMA runs at 1/16 of the bf16 rate, no xf32).
         * Error against float64 is fp32's own class (measured 1e-7 .. 2e-6 of sum |a b|, the same as the fp32 instruction's);
         * results are NOT bit-equal to the fmaf chain of the plain mode.  Served for 16-byte-aligned fp32 operands and n > 32 (others
-        * silently take the plain fp32 path); ignored together with EMLOCO_GEMM_BF16. */
+        * silently take the plain fp32 path); ignored together with EMLOCO_GEMM_BF16.
+        * NON-FINITE AND HUGE OPERANDS (defined behaviour, tests/test_emu_kernels.py, tests/test_gpu_predictor.py): a NaN, an Inf, or a
+        * finite value whose bf16 rounding overflows (|a| > 3.3895e38 = bf16's largest finite; fp32 reaches 3.4028e38) makes every
+        * output element whose reduction it enters NaN -- the remainder a - bf16(a) is inf - inf.  The plain fp32 mode (and torch) give
+        * +-Inf for a lone Inf operand; both are non-finite, which is all a caller may rely on (the trainers' NaN handling,
+        * train_jta.py:143-165 / :308, treats them alike).  Output elements whose reductions see only finite operands below that
+        * bound are unaffected, whatever else is in the matrices. */
        EMLOCO_GEMM_SPLIT = 1024 };
 
 /* Batched strided GEMM on the matrix cores, fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: exact fp32):

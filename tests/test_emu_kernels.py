@@ -612,6 +612,29 @@ def test_rms_update_kernel_matches_the_reference_class(golden):
         assert cnt[0] == float(g[f"count{i}"])
 
 
+def test_split_mode_gemm_with_non_finite_and_huge_operands():
+    """The documented behaviour of EMLOCO_GEMM_SPLIT for operands it cannot cut into bf16 pieces (include/emloco_predictor.h): an
+    Inf, a NaN or a finite value above bf16's largest finite makes exactly the output elements whose reduction it enters NaN (the
+    plain fp32 mode gives +-Inf for the lone Inf); every other element equals the clean product bit for bit."""
+    rng = np.random.default_rng(8)
+    SPLIT = 1024
+    m, n, k = 72, 136, 48
+    A = rng.normal(size=(1, m, k)).astype(np.float32)
+    B = rng.normal(size=(1, n, k)).astype(np.float32)
+    clean = _gemm(A, B, 0, 0, m, n, k, flags=SPLIT)[0]
+    Ab, Bb = A.copy(), B.copy()
+    Ab[0, 5, 7] = np.inf                      # row 5 of the output
+    Ab[0, 40, 0] = np.float32(3.40e38)        # finite in fp32, overflows bf16: row 40
+    Bb[0, 100, 3] = np.nan                    # column 100
+    got = _gemm(Ab, Bb, 0, 0, m, n, k, flags=SPLIT)[0]
+    bad = np.zeros((m, n), bool)
+    bad[5, :] = bad[40, :] = bad[:, 100] = True
+    assert np.isnan(got[bad]).all()
+    assert np.array_equal(got[~bad], clean[~bad])
+    plain = _gemm(Ab, Bb, 0, 0, m, n, k)[0]
+    assert np.isinf(plain[5, :100]).all() and not np.isnan(plain[40, :100]).any() and np.isnan(plain[:, 100]).all()
+
+
 def test_chunked_rms_update_equals_the_single_launch():
     """rms_partial_kernel + rms_merge_kernel (the learner's tall minibatches: per-chunk moments from registers, in-order fold) against
     rms_update_kernel and numpy float64 on a ragged tall batch (1 100 rows: four full 256-row chunks and a 76-row one whose last

@@ -593,6 +593,69 @@ def test_configs4_batch_512_twenty_modes_forward_properties():
         assert abs(loss.item() - per_mode.min(dim=1).values.mean().item() * 100.0) <= 1e-3 * loss.item()
 
 
+def test_configs4_full_size_jrdb_model_with_locoval_filter_batch_512():
+    """configs[4] AT ITS REAL SIZE under -m gpu: TransMotionJRDB (d = 128, 6 + 3 layers, 20 modes, 26 tokens / person, S = 246) at
+    batch 512 WITH the LocoVal filter (evaluate_jrdb.py:84-221, threshold 0.8) -- what bench.py's `jta.eval` leg times.  Size-independent
+    properties: the metrics of the 512-scene batch equal the sample-weighted metrics of the same scenes evaluated in four batches of
+    128 (the evaluation has no cross-sample state: the reference's in-place pose rotation acts within a sample), min-ADE <= ADE <=
+    worst-ADE, the filtered ADE lies between min and worst, the LocoVal values are probabilities, one LocoVal launch serves all
+    512 x 20 x 2 trajectories."""
+    from emloco_amd.learning.value_pose_net import ValuePoseNet
+    from emloco_amd.predictor.evaluate_jta import evaluate_ade_fde
+    from emloco_amd.predictor.model_jrdb import TransMotionJRDB
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    cfg = {"DEVICE": dev, "MULTI_MODAL": True, "NOISY_TRAJ": 0, "TRAIN": {"input_track_size": 9, "output_track_size": 12},
+           "MODEL": {"value_threshold": 0.8}, "DATA": {"train_datasets": ["jrdb_all_visual_cues"]}}
+    model = TransMotionJRDB(tok_dim=246, nhid=128, nhead=4, dim_feedfwd=1024, nlayers_local=6, nlayers_global=3, nmode=20, output_scale=1,
+                            obs_and_pred=21, num_tokens=26, device=dev, multi_modal=True).to(dev).eval()
+    vnet = ValuePoseNet(True, True).to(dev).eval()
+    with torch.no_grad():                                   # a filter that really separates: push the value head around 0.8
+        vnet._network.fc3.bias.fill_(1.2)
+    g = torch.Generator().manual_seed(5)
+    B, N = 512, 8
+    joints = torch.randn(B, N, 21, 26, 4, generator=g) * 0.3
+    joints[:, :, :, 0, :2] = torch.cumsum(torch.randn(B, N, 21, 2, generator=g) * 0.4, dim=2)
+    pad = torch.arange(N)[None, :] >= torch.randint(1, N + 1, (B,), generator=g)[:, None]
+    masks = torch.ones(B, N, 21, 26)
+    kw = dict(dataset="jrdb")
+    whole = evaluate_ade_fde(model, vnet, "test", "traj+all", [(joints, masks, pad)], B, cfg, **kw)
+    parts = evaluate_ade_fde(model, vnet, "test", "traj+all", [(joints[i:i + 128], masks[i:i + 128], pad[i:i + 128]) for i in range(0, B, 128)],
+                             128, cfg, **kw)
+    assert whole["samples"] == parts["samples"] == B
+    for k in ("ade", "fde", "min_ade", "min_fde", "worst_ade", "value_mean"):
+        assert np.isfinite(whole[k]) and abs(whole[k] - parts[k]) <= 2e-4 * abs(whole[k]) + 1e-6, (k, whole[k], parts[k])
+    assert whole["min_ade"] <= whole["ade"] <= whole["worst_ade"]
+    assert 0.0 < whole["value_mean"] < 1.0
+    if "ade_value" in whole:
+        assert whole["min_ade"] - 1e-6 <= whole["ade_value"] <= whole["worst_ade"] + 1e-6
+
+
+def test_split_mode_gemm_non_finite_operands_on_the_device():
+    """include/emloco_predictor.h, EMLOCO_GEMM_SPLIT: an Inf, a NaN or a finite operand above bf16's range makes exactly the output
+    elements whose reduction it enters NaN; all other elements equal the clean product bit for bit (the emulator test's twin)."""
+    from emloco_amd.predictor import ops
+    dev = "cuda:0"
+    torch.manual_seed(1)
+    assert ops.get_matmul_precision() == "fp32_split"
+    m, n, k = 300, 264, 512
+    A, Bm = torch.randn(m, k, device=dev), torch.randn(n, k, device=dev)
+
+    def mm(a, b):
+        c = torch.empty(m, n, device=dev)
+        ops.gemm(1, m, n, k, a, k, 0, 0, b, k, 0, 0, c, n, 0)
+        return c
+    clean = mm(A, Bm)
+    Ab, Bb = A.clone(), Bm.clone()
+    Ab[5, 7] = float("inf")
+    Ab[140, 300] = 3.40e38
+    Bb[200, 3] = float("nan")
+    got = mm(Ab, Bb)
+    bad = torch.zeros(m, n, dtype=torch.bool, device=dev)
+    bad[5, :] = True; bad[140, :] = True; bad[:, 200] = True
+    assert torch.isnan(got[bad]).all() and torch.equal(got[~bad], clean[~bad])
+
+
 def test_fused_attention_dropout_matches_torch_with_the_same_mask():
     """nn.MultiheadAttention(dropout = 0.1) in training mode (the reference's encoder layers, model_jta.py:177-178): the fused
     kernels' dropout on the probabilities against float64 torch attention that applies the SAME keep mask (the library's
