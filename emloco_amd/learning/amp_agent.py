@@ -83,20 +83,21 @@ def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma):
     return (c1 + c2 - 0.5).sum(dim=-1).mean()
 
 
-def amp_dropout_mask(B, steps, feat, num_masks=3, dropout_rate=0.3, device="cpu"):
-    """amp_models.py:62-90 for the 206-wide AMP row: whole joints (6 rotation + 3 velocity values) are dropped together.
-    The draws are the reference's (19 x torch.rand(B, num_masks) from the CPU generator, in its order); the (B, steps * 206,
-    num_masks) mask itself is expanded ON THE DEVICE from the B x 19 x num_masks keep bits -- the reference assembles the 76 MB
-    tensor of a 2 048-row minibatch on the host and uploads it every optimiser step (measured here: 60 - 200 ms of an 80 ms step)."""
+def amp_dropout_draw(B, num_masks=3, num_joints=19):
+    """The host draw of amp_dropout_mask: (19, B, num_masks) uniforms in the reference's stream order (amp_models.py:85-89)."""
+    if (B * num_masks) % 16 == 0:
+        return torch.rand(num_joints, B, num_masks)
+    return torch.stack([torch.rand(B, num_masks) for _ in range(num_joints)])
+
+
+def amp_dropout_expand(u, steps, feat=206, dropout_rate=0.3):
+    """(19, B, M) uniforms ON THE DEVICE -> the (B, steps * 206, M) keep mask (device ops only: capturable in a HIP graph)."""
     assert feat == 206
     dof_off, num_joints = 12, 19
     vel_off = dof_off + num_joints * 6
-    if (B * num_masks) % 16 == 0:      # one call draws the same stream as the 19 (checked for these sizes in tests/test_amp_agent_cpu.py)
-        u = torch.rand(num_joints, B, num_masks)
-    else:
-        u = torch.stack([torch.rand(B, num_masks) for _ in range(num_joints)])
-    keep = (u.to(device) > dropout_rate).permute(1, 0, 2).float()                                          # (B, 19, M), on the device
-    keep = torch.cat([keep, torch.ones(B, 1, num_masks, device=device)], dim=1)                            # slot 19: always kept
+    B, M, device = u.shape[1], u.shape[2], u.device
+    keep = (u > dropout_rate).permute(1, 0, 2).float()
+    keep = torch.cat([keep, torch.ones(B, 1, M, device=device)], dim=1)
     key = str(device)
     if key not in _AMP_COL:
         col = torch.full((feat,), num_joints, dtype=torch.long)
@@ -105,6 +106,14 @@ def amp_dropout_mask(B, steps, feat, num_masks=3, dropout_rate=0.3, device="cpu"
             col[vel_off + j * 3:vel_off + j * 3 + 3] = j
         _AMP_COL[key] = col.to(device)
     return keep[:, _AMP_COL[key], :].repeat(1, steps, 1)
+
+
+def amp_dropout_mask(B, steps, feat, num_masks=3, dropout_rate=0.3, device="cpu"):
+    """amp_models.py:62-90 for the 206-wide AMP row: whole joints (6 rotation + 3 velocity values) are dropped together.
+    The draws are the reference's (19 x torch.rand(B, num_masks) from the CPU generator, in its order); the (B, steps * 206,
+    num_masks) mask itself is expanded ON THE DEVICE from the B x 19 x num_masks keep bits -- the reference assembles the 76 MB
+    tensor of a 2 048-row minibatch on the host and uploads it every optimiser step (measured here: 60 - 200 ms of an 80 ms step)."""
+    return amp_dropout_expand(amp_dropout_draw(B, num_masks).to(device), steps, feat, dropout_rate)
 
 
 _AMP_COL = {}
@@ -179,7 +188,15 @@ class AMPAgent:
                                    task_obs_size_detail=task.get_task_obs_size_detail(), mean_std=self.running_mean_std).to(self.device)
         # hvd.setup_algo (common_agent.py:165-166): every rank starts from rank 0's networks and (initial) statistics
         broadcast_parameters(self.a2c_network, self.running_mean_std, self.value_mean_std, self._amp_input_mean_std)
-        self.optimizer = torch.optim.Adam(self.a2c_network.parameters(), float(self.last_lr), eps=1e-08, weight_decay=0.0)
+        # The optimiser step as ONE HIP graph (use_graph): an update step is ~650 launches of 4 - 80 us each -- 8 ms of kernel time that
+        # the host needs 40 ms to issue through autograd, torch ops and ctypes.  Captured once (static minibatch buffers, the dropout
+        # draw and the shuffled indices filled from the host outside the graph, Adam with device-side step counters) and replayed
+        # for the epoch's remaining minibatches and every later epoch.  Single rank only: a gloo all-reduce cannot be captured.
+        import os
+        self.use_graph = (self.device.type == "cuda" and os.environ.get("EMLOCO_PPO_GRAPH", "1") != "0")
+        self._graph, self._g_in, self._g_u, self._g_acc, self._g_keys = None, None, None, None, None
+        self.optimizer = torch.optim.Adam(self.a2c_network.parameters(), float(self.last_lr), eps=1e-08, weight_decay=0.0,
+                                          capturable=self.use_graph)
         self.bucket = FlatGradBucket([p for p in self.a2c_network.parameters() if p.requires_grad])
         self._amp_obs_demo_buffer = ReplayBuffer(int(c["amp_obs_demo_buffer_size"]), self.device)
         self._amp_replay_buffer = ReplayBuffer(int(c["amp_replay_buffer_size"]), self.device)
@@ -325,7 +342,9 @@ class AMPAgent:
         idx = self.task.left_to_right_index_action
         flip_a, _ = self.a2c_network.eval_actor(flip_obs)
         orig_a, _ = self.a2c_network.eval_actor(orig_obs)
-        orig_a = orig_a.view(B, -1, 3) * torch.tensor([-1.0, 1.0, -1.0], device=orig_a.device)
+        if getattr(self, "_sym_sign", None) is None or self._sym_sign.device != orig_a.device:
+            self._sym_sign = torch.tensor([-1.0, 1.0, -1.0], device=orig_a.device)      # (made once: no host-to-device copy in the step)
+        orig_a = orig_a.view(B, -1, 3) * self._sym_sign
         orig_a = orig_a[..., idx, :]
         return {"sym_loss": (orig_a.reshape(B, -1) - flip_a).pow(2).mean(dim=-1) * 50}
 
@@ -390,6 +409,66 @@ class AMPAgent:
         self.train_result = info
         return info
 
+    # ------------------------------------------------------------------ the optimiser step as a HIP graph
+    def _graph_body(self):
+        """calc_gradients on the static minibatch buffers; every value the epoch averages is added to a static accumulator."""
+        d = self._g_in
+        masks = None
+        if self._amp_dropout:
+            masks = amp_dropout_expand(self._g_u, self.task._num_amp_obs_steps)
+        loss, info, mu, sigma = self.compute_loss(d, dropout_masks=masks)
+        self.bucket.zero()
+        loss.backward()
+        if self.truncate_grads:
+            nn.utils.clip_grad_norm_(self.a2c_network.parameters(), self.grad_norm)
+        self.optimizer.step()
+        with torch.no_grad():
+            info["kl"] = policy_kl(mu, sigma, d["mu"], d["sigma"])
+            info["loss"] = loss.detach()
+            if self._g_acc is None:
+                self._g_keys = sorted(info)
+                self._g_acc = torch.zeros(len(self._g_keys), dtype=torch.float32, device=self.device)
+            self._g_acc += torch.stack([info[k].float().reshape(()) for k in self._g_keys])
+        return info
+
+    def _graph_fill(self, i):
+        """Host side of a graphed step: gather minibatch i into the static buffers, draw the AMP dropout uniforms."""
+        start, end = i * self.minibatch_size, (i + 1) * self.minibatch_size
+        idx = self._idx_buf[start:end].to(self.device)
+        if self._g_in is None:
+            self._g_in = {k: torch.empty((self.minibatch_size,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device)
+                          for k, v in self.dataset.items() if v is not None}
+            self._g_u = torch.empty(19, self._amp_minibatch_size, 3, device=self.device)
+        for k, buf in self._g_in.items():
+            torch.index_select(self.dataset[k], 0, idx, out=buf)
+        if self._amp_dropout:
+            self._g_u.copy_(amp_dropout_draw(self._amp_minibatch_size), non_blocking=True)
+        if end >= self.batch_size:
+            self._idx_buf[:] = torch.randperm(self.batch_size)
+
+    def _graph_step(self, i):
+        """One optimiser step: eager (on a side stream) for the first three calls, then captured, then replayed."""
+        self.set_train()
+        self._graph_fill(i)
+        if self._graph is not None:
+            self._graph.replay()
+            return
+        self._g_warm = getattr(self, "_g_warm", 0) + 1
+        if self._g_warm <= 3:                               # warm-up off the default stream, as graph capture asks
+            side = getattr(self, "_g_side", None) or torch.cuda.Stream(device=self.device)
+            self._g_side = side
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                self._graph_body()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            return
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.graph(g):
+            self._graph_body()
+        self._graph = g                                     # (capture does not execute: run the step that was just captured)
+        g.replay()
+
     # ------------------------------------------------------------------ epoch
     def prepare_dataset(self, batch):
         advantages = torch.sum(batch["returns"] - batch["values"], axis=1)
@@ -434,15 +513,28 @@ class AMPAgent:
         self.set_train()
         self.prepare_dataset(batch)
         infos = []
+        from ..dist import world_size
+        graphed = self.use_graph and world_size() == 1
+        n_steps = self.mini_epochs_num * (self.batch_size // self.minibatch_size)
+        if graphed and self._g_acc is not None:
+            self._g_acc.zero_()
         for _ in range(self.mini_epochs_num):
             for i in range(self.batch_size // self.minibatch_size):
-                infos.append(self.calc_gradients(self._minibatch(i)))
+                if graphed:
+                    self._graph_step(i)
+                else:
+                    infos.append(self.calc_gradients(self._minibatch(i)))
         self._store_replay_amp_obs(batch["amp_obs"])
         torch.cuda.synchronize(self.device)
         t2 = time.time()
         self.epoch_num += 1
         self.frame += self.batch_size
-        out = {k: torch.stack([i[k].float() for i in infos]).mean().item() for k in infos[0]}
+        if graphed:
+            vals = (self._g_acc / n_steps).tolist()
+            out = dict(zip(self._g_keys, vals))
+            self.train_result = out
+        else:
+            out = {k: torch.stack([i[k].float() for i in infos]).mean().item() for k in infos[0]}
         # the reference's per-epoch exchanges: hvd.average_value of the KL (amp_continuous.py:287-288) and hvd.sync_stats of
         # the running statistics (common_agent.py:179-180); no-ops on one rank
         out["kl"] = all_reduce_mean_scalar(out["kl"])

@@ -840,3 +840,38 @@ def test_rollout_from_an_amass_pickle(tmp_path):
     torch.cuda.synchronize()
     assert torch.isfinite(obs).all() and torch.isfinite(task._amp_obs_buf).all() and torch.isfinite(rew).all()
     assert int(task._sampled_motion_ids.max()) < E
+
+
+@pytest.mark.gpu
+def test_amp_agent_optimiser_step_as_a_hip_graph_equals_the_eager_step(monkeypatch):
+    """AMPAgent's update step captured once as a HIP graph (static minibatch buffers, dropout draw and shuffled indices filled from the
+    host, Adam with device-side step counters) and replayed, against the same agent issuing every launch eagerly: same seeds, two
+    epochs of 2 x 4 minibatches -- network weights, observation statistics and the epoch's averaged losses agree to float rounding
+    (the capturable Adam kernel differs from the default one in the last bit), and the graph really replays."""
+    import yaml
+    from emloco_amd.learning.amp_agent import AMPAgent
+    from emloco_amd.learning.amp_policy import DEFAULT_CFG
+    from emloco_amd.run import RLGPUEnv
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EMLOCO_PPO_GRAPH", mode)
+        torch.manual_seed(21)
+        np.random.seed(21)
+        env = RLGPUEnv(_make_env(64, ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel"]))
+        cfg = yaml.safe_load(open(DEFAULT_CFG))
+        cfg["params"]["network"]["mlp"]["units"] = [256, 128]
+        cfg["params"]["network"]["disc"]["units"] = [128, 64]
+        cfg["params"]["config"].update(horizon_length=8, minibatch_size=128, amp_minibatch_size=128, amp_batch_size=64,
+                                       amp_obs_demo_buffer_size=512, amp_replay_buffer_size=512, mini_epochs=2)
+        agent = AMPAgent(env, cfg, seed=4)
+        assert agent.use_graph == (mode == "1")
+        torch.manual_seed(33)
+        infos = [agent.train_epoch() for _ in range(2)]
+        assert (agent._graph is not None) == (mode == "1")
+        outs.append((torch.cat([p.detach().reshape(-1) for p in agent.a2c_network.parameters()]).clone(), agent.running_mean_std.running_mean.clone(),
+                     agent._amp_input_mean_std.running_var.clone(), infos[-1]))
+    (w0, m0, v0, i0), (w1, m1, v1, i1) = outs
+    assert torch.isfinite(w1).all() and (w0 - w1).abs().max().item() <= 2e-5 * w0.abs().max().item() + 1e-6
+    assert torch.allclose(m0, m1, rtol=1e-9, atol=1e-9) and torch.allclose(v0, v1, rtol=1e-9, atol=1e-9)
+    for k in ("actor_loss", "critic_loss", "disc_loss", "kl", "b_loss"):
+        assert abs(i0[k] - i1[k]) <= 2e-3 * abs(i0[k]) + 1e-5, (k, i0[k], i1[k])
