@@ -339,7 +339,9 @@ class AMPAgent:
 
     def _sym_loss(self, flip_obs, orig_obs):
         B = flip_obs.shape[0]
-        idx = self.task.left_to_right_index_action
+        if getattr(self, "_sym_idx", None) is None or self._sym_idx.device != flip_obs.device:
+            self._sym_idx = torch.as_tensor(self.task.left_to_right_index_action, dtype=torch.long, device=flip_obs.device)   # (an index list would be uploaded every step)
+        idx = self._sym_idx
         flip_a, _ = self.a2c_network.eval_actor(flip_obs)
         orig_a, _ = self.a2c_network.eval_actor(orig_obs)
         if getattr(self, "_sym_sign", None) is None or self._sym_sign.device != orig_a.device:
