@@ -443,10 +443,10 @@ class AMPAgent:
             self._g_u = torch.empty(19, self._amp_minibatch_size, 3, device=self.device)
         for k, buf in self._g_in.items():
             torch.index_select(self.dataset[k], 0, idx, out=buf)
+        if end >= self.batch_size:                           # (host draws in the eager step's order: reshuffle, then the dropout uniforms)
+            self._idx_buf[:] = torch.randperm(self.batch_size)
         if self._amp_dropout:
             self._g_u.copy_(amp_dropout_draw(self._amp_minibatch_size), non_blocking=True)
-        if end >= self.batch_size:
-            self._idx_buf[:] = torch.randperm(self.batch_size)
 
     def _graph_step(self, i):
         """One optimiser step: eager (on a side stream) for the first three calls, then captured, then replayed."""
