@@ -432,23 +432,19 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             // configuration is moved onto it by a rigid rotation rate dw of the whole body about c: J dw = L_exp - L (J: composite
             // inertia about c, joints locked), every body twist gains [dw ; c x dw] about O -- the linear momentum is untouched.
             {
-                float lc[3] = {0.0f, 0.0f, 0.0f}, rcb[3] = {0.0f, 0.0f, 0.0f}, vcb[3] = {0.0f, 0.0f, 0.0f}, Vn[6] = {0, 0, 0, 0, 0, 0}, Rb[9];
+                // the twelve wave sums are taken about O (none waits for another) and moved to c afterwards:
+                // L_c = L_O - c x P,  J_c = J_O - M ((c.c) E - c c^T)
+                float lc[3] = {0.0f, 0.0f, 0.0f}, ll[3] = {0.0f, 0.0f, 0.0f}, lj[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, Vn[6] = {0, 0, 0, 0, 0, 0};
                 if ((lane < NB)) {
-                    float cm[4], cw[3], wx[3];
+                    float Rb[9], cm[4], cw[3], rcb[3], wx[3], vcb[3], in6[8], Rc[9], Ic[6], ru[3], Iw[3];
                     for (int k = 0; k < 9; ++k) Rb[k] = sh_R[lane][k];
                     ld4(mdl, o_dyn + 4, cm);
+                    ld4(mdl, o_dyn + 8, in6); ld4(mdl, o_dyn + 12, in6 + 4);
                     for (int k = 0; k < 6; ++k) Vn[k] = sh_V[lane][k];
                     matvec3(Rb, cm, cw);
                     for (int k = 0; k < 3; ++k) rcb[k] = sh_R[lane][9 + k] + cw[k];
                     cross3(Vn, rcb, wx);
-                    for (int k = 0; k < 3; ++k) { vcb[k] = Vn[3 + k] + wx[k]; lc[k] = lm * rcb[k]; }
-                }
-                float Cc[3], vc[3];
-                for (int k = 0; k < 3; ++k) { Cc[k] = wave_sum(lc[k]) / Mtot; vc[k] = sh_P[3 + k] / Mtot; }
-                float ll[3] = {0.0f, 0.0f, 0.0f}, lj[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                if ((lane < NB)) {
-                    float in6[8], Rc[9], Ic[6], dC[3], u[3], du[3], Iw[3];
-                    ld4(mdl, o_dyn + 8, in6); ld4(mdl, o_dyn + 12, in6 + 4);
+                    for (int k = 0; k < 3; ++k) vcb[k] = Vn[3 + k] + wx[k];
                     const float Ib[9] = {in6[0], in6[3], in6[4], in6[3], in6[1], in6[5], in6[4], in6[5], in6[2]};
                     for (int a = 0; a < 3; ++a)
                         for (int q = 0; q < 3; ++q) Rc[a * 3 + q] = SOP3(Rb[a * 3], Ib[q], Rb[a * 3 + 1], Ib[3 + q], Rb[a * 3 + 2], Ib[6 + q]);
@@ -457,21 +453,29 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                         const int a = ja[e], q = jb[e];
                         Ic[e] = SOP3(Rc[a * 3], Rb[q * 3], Rc[a * 3 + 1], Rb[q * 3 + 1], Rc[a * 3 + 2], Rb[q * 3 + 2]);
                     }
-                    for (int k = 0; k < 3; ++k) { dC[k] = rcb[k] - Cc[k]; u[k] = vcb[k] - vc[k]; }
-                    cross3(dC, u, du);
+                    cross3(rcb, vcb, ru);
                     Iw[0] = SOP3(Ic[0], Vn[0], Ic[3], Vn[1], Ic[4], Vn[2]);
                     Iw[1] = SOP3(Ic[3], Vn[0], Ic[1], Vn[1], Ic[5], Vn[2]);
                     Iw[2] = SOP3(Ic[4], Vn[0], Ic[5], Vn[1], Ic[2], Vn[2]);
-                    const float dd2 = dot3(dC, dC);
-                    for (int k = 0; k < 3; ++k) ll[k] = Iw[k] + lm * du[k];
+                    const float rr = dot3(rcb, rcb);
+                    for (int k = 0; k < 3; ++k) { lc[k] = lm * rcb[k]; ll[k] = Iw[k] + lm * ru[k]; }
                     for (int e = 0; e < 6; ++e) {
                         const int a = ja[e], q = jb[e];
-                        lj[e] = Ic[e] + lm * ((a == q ? dd2 : 0.0f) - dC[a] * dC[q]);
+                        lj[e] = Ic[e] + lm * ((a == q ? rr : 0.0f) - rcb[a] * rcb[q]);
                     }
                 }
-                float Lact[3], Jc[6];
-                for (int k = 0; k < 3; ++k) Lact[k] = wave_sum(ll[k]);
-                for (int e = 0; e < 6; ++e) Jc[e] = wave_sum(lj[e]);
+                float Cc[3], LO[3], JO[6], Lact[3], Jc[6], cP[3];
+                for (int k = 0; k < 3; ++k) Cc[k] = wave_sum(lc[k]) / Mtot;
+                for (int k = 0; k < 3; ++k) LO[k] = wave_sum(ll[k]);
+                for (int e = 0; e < 6; ++e) JO[e] = wave_sum(lj[e]);
+                {
+                    const float Pc[3] = {sh_P[3], sh_P[4], sh_P[5]};
+                    cross3(Cc, Pc, cP);
+                    for (int k = 0; k < 3; ++k) Lact[k] = LO[k] - cP[k];
+                    const int ja[6] = {0, 1, 2, 0, 0, 1}, jb[6] = {0, 1, 2, 1, 2, 2};
+                    const float cc = dot3(Cc, Cc);
+                    for (int e = 0; e < 6; ++e) Jc[e] = JO[e] - Mtot * ((ja[e] == jb[e] ? cc : 0.0f) - Cc[ja[e]] * Cc[jb[e]]);
+                }
                 const bool havL = sub > 0 && sh_L[3] != 0.0f;        // wave-uniform
                 float dw[3] = {0.0f, 0.0f, 0.0f}, dvO[3] = {0.0f, 0.0f, 0.0f};
                 bool moved = false;

@@ -395,27 +395,20 @@ static void project_momentum(Env *s, const EnvModel *m) {
  * L^2 / 2 I_min.  The velocity-product accelerations of this substep are left as computed (dw is itself second order in h).
  * Called right after project_momentum (V and Pcur current). */
 static void project_angular_momentum(Env *s, const EnvModel *m) {
+    /* The twelve wave sums are taken about O (none waits for another: the centre of mass is one of them) and moved to the centre of
+     * mass c afterwards: L_c = L_O - c x P,  J_c = J_O - M ((c.c) E - c c^T). */
     float lane_c[3][64], lane_l[3][64], lane_j[6][64];
-    float rc[NB][3], vcb[NB][3];
     for (int i = 0; i < 64; ++i) {
-        for (int k = 0; k < 3; ++k) lane_c[k][i] = 0.0f;
-        if (i < NB) {
-            float cw[3], wx[3];
-            matvec3(s->R[i], m->com + i * 3, cw);
-            for (int k = 0; k < 3; ++k) rc[i][k] = s->r[i][k] + cw[k];
-            cross3(s->V[i], rc[i], wx);
-            for (int k = 0; k < 3; ++k) { vcb[i][k] = s->V[i][3 + k] + wx[k]; lane_c[k][i] = m->mass[i] * rc[i][k]; }
-        }
-    }
-    float C[3], vc[3];
-    for (int k = 0; k < 3; ++k) { C[k] = wave_sum_order(lane_c[k]) / s->Mtot; vc[k] = s->Pcur[k] / s->Mtot; s->com[k] = C[k]; }
-    for (int i = 0; i < 64; ++i) {
-        for (int k = 0; k < 3; ++k) lane_l[k][i] = 0.0f;
+        for (int k = 0; k < 3; ++k) { lane_c[k][i] = 0.0f; lane_l[k][i] = 0.0f; }
         for (int k = 0; k < 6; ++k) lane_j[k][i] = 0.0f;
         if (i < NB) {
             const float *in = m->inertia + i * 6, *R = s->R[i];
             const float Ib[9] = {in[0], in[3], in[4], in[3], in[1], in[5], in[4], in[5], in[2]};
-            float Rc[9], Ic[6], d[3], u[3], du[3], Iw[3];
+            float cw[3], rc[3], wx[3], vcb[3], Rc[9], Ic[6], ru[3], Iw[3];
+            matvec3(R, m->com + i * 3, cw);
+            for (int k = 0; k < 3; ++k) rc[k] = s->r[i][k] + cw[k];
+            cross3(s->V[i], rc, wx);
+            for (int k = 0; k < 3; ++k) vcb[k] = s->V[i][3 + k] + wx[k];
             for (int a = 0; a < 3; ++a)
                 for (int b = 0; b < 3; ++b) Rc[a * 3 + b] = SOP3(R[a * 3], Ib[b], R[a * 3 + 1], Ib[3 + b], R[a * 3 + 2], Ib[6 + b]);
             /* Ic = R Ib R^T, upper triangle: 00 11 22 01 02 12 */
@@ -424,23 +417,31 @@ static void project_angular_momentum(Env *s, const EnvModel *m) {
                 int a = ja[e], b = jb[e];
                 Ic[e] = SOP3(Rc[a * 3], R[b * 3], Rc[a * 3 + 1], R[b * 3 + 1], Rc[a * 3 + 2], R[b * 3 + 2]);
             }
-            for (int k = 0; k < 3; ++k) { d[k] = rc[i][k] - C[k]; u[k] = vcb[i][k] - vc[k]; }
-            cross3(d, u, du);
+            cross3(rc, vcb, ru);
             const float *w = s->V[i];
             Iw[0] = SOP3(Ic[0], w[0], Ic[3], w[1], Ic[4], w[2]);
             Iw[1] = SOP3(Ic[3], w[0], Ic[1], w[1], Ic[5], w[2]);
             Iw[2] = SOP3(Ic[4], w[0], Ic[5], w[1], Ic[2], w[2]);
-            const float ms = m->mass[i], dd = dot3(d, d);
-            for (int k = 0; k < 3; ++k) lane_l[k][i] = Iw[k] + ms * du[k];
+            const float ms = m->mass[i], rr = dot3(rc, rc);
+            for (int k = 0; k < 3; ++k) { lane_c[k][i] = ms * rc[k]; lane_l[k][i] = Iw[k] + ms * ru[k]; }
             for (int e = 0; e < 6; ++e) {
                 int a = ja[e], b = jb[e];
-                lane_j[e][i] = Ic[e] + ms * ((a == b ? dd : 0.0f) - d[a] * d[b]);
+                lane_j[e][i] = Ic[e] + ms * ((a == b ? rr : 0.0f) - rc[a] * rc[b]);
             }
         }
     }
-    float L[3], J[6];
-    for (int k = 0; k < 3; ++k) L[k] = wave_sum_order(lane_l[k]);
-    for (int e = 0; e < 6; ++e) J[e] = wave_sum_order(lane_j[e]);
+    float C[3], LO[3], JO[6];
+    for (int k = 0; k < 3; ++k) { C[k] = wave_sum_order(lane_c[k]) / s->Mtot; s->com[k] = C[k]; }
+    for (int k = 0; k < 3; ++k) LO[k] = wave_sum_order(lane_l[k]);
+    for (int e = 0; e < 6; ++e) JO[e] = wave_sum_order(lane_j[e]);
+    float L[3], J[6], cP[3];
+    cross3(C, s->Pcur, cP);
+    for (int k = 0; k < 3; ++k) L[k] = LO[k] - cP[k];
+    {
+        static const int ja[6] = {0, 1, 2, 0, 0, 1}, jb[6] = {0, 1, 2, 1, 2, 2};
+        const float cc = dot3(C, C);
+        for (int e = 0; e < 6; ++e) J[e] = JO[e] - s->Mtot * ((ja[e] == jb[e] ? cc : 0.0f) - C[ja[e]] * C[jb[e]]);
+    }
     if (!s->havL) { memcpy(s->Lcur, L, 12); return; }
     /* J dw = L_exp - L by cofactors (J symmetric positive definite: 00 11 22 01 02 12) */
     const float b0 = s->Lexp[0] - L[0], b1 = s->Lexp[1] - L[1], b2 = s->Lexp[2] - L[2];
