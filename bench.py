@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SIM_BYTES_PER_ENV = 9296          # state in/out + per-env model (+ collision capsules) + warm-start, per launch
-PROFILE_ROUND = "r03"             # profiles/<round>_*: the committed rocprofv3 summaries of this round's kernels
+PROFILE_ROUND = "r04"             # profiles/<round>_*: the committed rocprofv3 summaries of this round's kernels
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16), no sparsity
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
@@ -690,8 +690,8 @@ def main():
             prof["traffic"] = None
         try:
             for line in open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_sim_step_valu.txt")):
-                if line.startswith("VALU busy"):
-                    prof["valu_busy_frac"] = float(line.split("=")[-1].split()[0])
+                if line.startswith("VALU issue utilisation"):
+                    prof["valu_issue_utilisation"] = float(line.split("=")[-1].split()[0])
         except Exception:
             pass
         out = {
@@ -712,11 +712,12 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": prof.get("traffic"),
                          "traffic_source": f"profiles/{PROFILE_ROUND}_sim_step_hbm_bytes.json (committed PMC passes of this kernel; NOT measured in this run)",
                          "kernel_ms": round(kernel_ms, 4), "launches_timed": n_l,
-                         "from_profiles": {"valu_busy_frac": prof.get("valu_busy_frac"), "source": f"profiles/{PROFILE_ROUND}_sim_step_valu.txt (committed SQ-counter pass; NOT measured in this run)"},
+                         "from_profiles": {"valu_issue_utilisation": prof.get("valu_issue_utilisation"), "source": f"profiles/{PROFILE_ROUND}_sim_step_valu.txt (committed SQ-counter pass; NOT measured in this run)"},
                          "note": "achieved = algorithmic bytes (9 296 B per env per launch, DESIGN.md section 5) / kernel_ms, both live: HIP events on "
                                  "every 8th launch of the timed region.  The kernel is instruction / latency bound, not bandwidth bound: ~9 KB of state "
                                  "per env per launch against ~47 k fp32 VALU wave-instructions (level-synchronous tree passes; 3 waves per SIMD, 12 envs "
-                                 "per CU; each env's 4 substeps run as four dependent workgroups of one launch); VALU busy 93 % of the SIMD-cycles"},
+                                 "per CU; each env's 4 substeps run as four dependent workgroups of one launch); VALU issue utilisation (wave64 = 2 issue cycles on a "
+                                 "SIMD-32) in `from_profiles`: about half the issue slots, the rest is dependent-instruction latency and LDS"},
         }
         if env_only is not None:
             k_alone = ms_s / max(n_s, 1)
