@@ -247,6 +247,13 @@ int emloco_act_bwd_colsum(int m, int n, const float *dy, const float *y, int rel
     return 0;
 }
 
+int emloco_disc_reward(int n, const float *logits, float scale, float *reward, void *stream) {
+    if (n < 1 || !logits || !reward) return pfail(-1, "emloco_disc_reward: bad argument");
+    hipLaunchKernelGGL(emloco::disc_reward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, logits, scale, reward);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
+
 int emloco_obs_normalize(int rows, int cols, const float *x, int ldx, const float *mean, const float *var, float eps,
                          float clip, int split, float *out0, int ld0, float *out1, int ld1, void *stream) {
     if (rows < 1 || cols < 1 || !x || !mean || !var || !out0 || split < 0 || split > cols || (split < cols && !out1) ||

@@ -835,6 +835,18 @@ obs_normalize_kernel(int rows, int cols, const float *x, int ldx, const float *m
     }
 }
 
+// The AMP style reward of a step from the discriminator's logits (amp_continuous.py:675-692):
+//   prob = 1 / (1 + exp(-logit)),  r = -log(max(1 - prob, 1e-4)) * disc_reward_scale
+// one launch for the scalar chain the reference writes as seven tensor operations (the rollout issues it every step).
+__global__ void __launch_bounds__(256)
+disc_reward_kernel(int n, const float *logits, float scale, float *reward) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float prob = 1.0f / (1.0f + expf(-logits[i]));
+    const float om = 1.0f - prob;
+    reward[i] = -logf(om > 0.0001f ? om : 0.0001f) * scale;
+}
+
 // ------------------------------------------------------------------ observation normaliser: statistics update
 // RunningMeanStd.forward in training mode (pacer/pacer/utils/running_mean_std.py:85-95): the batch's per-column mean and
 // unbiased variance (torch.var) are merged into the float64 running moments with the parallel-variance rule,

@@ -69,6 +69,7 @@ def _lib():
         lib.emloco_locoval_bwd_rows.argtypes = [ci, vp, ci] + [vp] * 17
         lib.emloco_adamw_gated.argtypes = [ci] + [vp] * 7 + [cf] * 5 + [vp, vp]
         lib.emloco_gemm_enable_timing.argtypes = [ci]
+        lib.emloco_disc_reward.argtypes = [ci, vp, cf, vp, vp]
         lib.emloco_gemm_timing_stats.argtypes = [C.POINTER(ci), C.POINTER(cf), C.POINTER(C.c_double)]
         _bound = True
     return lib

@@ -164,6 +164,10 @@ int64_t emloco_colsum_workspace(int m, int n);   /* floats */
  * out0 (leading dimension ld0), columns [split, cols) to out1 (ld1); split == cols writes everything to out0.
  * The MLPs themselves (amp_network_sept_builder.py:50-110: task MLP 1054->512->256, actor MLP 624->2048->1024->69)
  * run on emloco_gemm_f32 with the bias + ReLU epilogue. */
+/* AMP style reward from the discriminator's logits [n] (pacer/pacer/learning/amp_continuous.py:675-692 `_calc_disc_rewards`):
+ * reward = -log(max(1 - sigmoid(logit), 1e-4)) * scale, one launch */
+int emloco_disc_reward(int n, const float *logits, float scale, float *reward, void *stream);
+
 int emloco_obs_normalize(int rows, int cols, const float *x, int ldx, const float *mean, const float *var, float eps,
                          float clip, int split, float *out0, int ld0, float *out1, int ld1, void *stream);
 

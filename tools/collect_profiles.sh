@@ -9,7 +9,7 @@ R=${1:-r01}
 OUT=$PWD/gpurun_out/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 100 --warmup 10 --no_cpu_baseline --no_pipelined"
+BENCH="python $PWD/bench.py --steps 100 --warmup 10 --no_cpu_baseline --no_pipelined --no_ppo"
 T="timeout 900"      # a rocprofv3 pass that hangs must not eat the GPU budget
 
 # 1. kernel trace + stats of the bench command (env leg + JTA leg)
@@ -48,7 +48,7 @@ PY
 #    per step for all envs -- so that "per launch" below is the whole step's kernel (the counters do not depend on the schedule)
 export EMLOCO_OVERLAP_RESET=0
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/prof_$C && (cd /tmp && $T rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -- $BENCH --steps 20 --warmup 5 --no_jta > "$OUT/pmc_$C.log" 2>&1)
+  rm -rf /tmp/prof_$C && (cd /tmp && $T rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -- $BENCH --steps 20 --warmup 5 --no_jta --no_policy > "$OUT/pmc_$C.log" 2>&1)
 done
 python - "$OUT/${R}_pmc_summary.txt" "$OUT/${R}_sim_step_hbm_bytes.json" <<'PY'
 import csv, glob, json, sys, collections
