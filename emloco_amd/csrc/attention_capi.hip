@@ -56,7 +56,10 @@ int emloco_attention_fwd_queries(int n_seq, int S, int n_query, int nhead, int d
         PHIPCHK(hipGetLastError());
         return 0;
     }
-    if (bf && dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    const bool sp = !bf && (flags & EMLOCO_ATTN_SPLIT) != 0;
+    if (sp && dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<2, 1>), grid, dim3(256), 0, st, a);
+    else if (sp) hipLaunchKernelGGL((emloco::attn_fwd_kernel<2, 0>), grid, dim3(256), 0, st, a);
+    else if (bf && dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 1>), grid, dim3(256), 0, st, a);
     else if (bf) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 0>), grid, dim3(256), 0, st, a);
     else if (dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<0, 1>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((emloco::attn_fwd_kernel<0, 0>), grid, dim3(256), 0, st, a);
@@ -108,12 +111,17 @@ int emloco_attention_bwd_queries(int n_seq, int S, int n_query, int nhead, int d
         return 0;
     }
     // first kernel: dQ, also writes D = rowsum(dO o O); second: dK, dV
-    if (bf && dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 1>), qgrid, dim3(256), 0, st, a);
+    const bool sp = !bf && (flags & EMLOCO_ATTN_SPLIT) != 0;
+    if (sp && dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<2, 1>), qgrid, dim3(256), 0, st, a);
+    else if (sp) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<2, 0>), qgrid, dim3(256), 0, st, a);
+    else if (bf && dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 1>), qgrid, dim3(256), 0, st, a);
     else if (bf) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 0>), qgrid, dim3(256), 0, st, a);
     else if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<0, 1>), qgrid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<0, 0>), qgrid, dim3(256), 0, st, a);
     PHIPCHK(hipGetLastError());
-    if (bf && dr) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    if (sp && dr) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<2, 1>), grid, dim3(256), 0, st, a);
+    else if (sp) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<2, 0>), grid, dim3(256), 0, st, a);
+    else if (bf && dr) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 1>), grid, dim3(256), 0, st, a);
     else if (bf) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<1, 0>), grid, dim3(256), 0, st, a);
     else if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<0, 1>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((emloco::attn_bwd_dkv_kernel<0, 0>), grid, dim3(256), 0, st, a);

@@ -109,15 +109,58 @@ __device__ __forceinline__ void at_grow16(const float *base, long ld, int row, i
         f[i] = t;
     }
 }
+// ---- PREC = 2, the split mode (the default precision class of the product, ops.DEFAULT_PRECISION): fp32 products rebuilt from bf16
+// pieces, as in the GEMMs (predictor_kernels.hip).  v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate; an fp32 value is the exact
+// sum of three bf16 pieces and the six piece products above 2^-24 of the result on v_mfma_f32_32x32x16_bf16 (fp32 accumulation) give
+// fp32-class products: 12 matrix instructions (384 matrix cycles) per 32 x 32 x 32 tile product where the fp32 instruction needs 16
+// (1 024).  The price is vector work: ~7 instructions per pair of values cut into pieces -- the loop-invariant operand of a kernel
+// (its own q / k / v / dO rows) is cut once, the walked tile's rows and the probabilities per tile.
+struct AtPieces { bf16w4 g[2][3]; };          // 16 reduction entries of a lane: two groups of 8, three pieces each
+__device__ __forceinline__ void at_split8(const float (&v)[8], bf16w4 (&pc)[3]) {
+    unsigned w[3][4];
+    for (int i = 0; i < 4; ++i) {
+        float a = v[2 * i], b = v[2 * i + 1];
+        const unsigned p1 = gemm_pack2_bf16(a, b);
+        a -= __uint_as_float(p1 << 16); b -= __uint_as_float(p1 & 0xffff0000u);
+        const unsigned p2 = gemm_pack2_bf16(a, b);
+        a -= __uint_as_float(p2 << 16); b -= __uint_as_float(p2 & 0xffff0000u);
+        w[0][i] = p1; w[1][i] = p2; w[2][i] = gemm_pack2_bf16(a, b);
+    }
+    for (int q = 0; q < 3; ++q) pc[q] = bf16w4{w[q][0], w[q][1], w[q][2], w[q][3]};
+}
+__device__ __forceinline__ void at_split16(const at_f32x4 (&f)[4], AtPieces &o) {
+    const float v0[8] = {f[0].x, f[0].y, f[0].z, f[0].w, f[1].x, f[1].y, f[1].z, f[1].w};
+    const float v1[8] = {f[2].x, f[2].y, f[2].z, f[2].w, f[3].x, f[3].y, f[3].z, f[3].w};
+    at_split8(v0, o.g[0]); at_split8(v1, o.g[1]);
+}
+// the six products of two cut operands, smallest first
+__device__ __forceinline__ at_f32x16 at_mfma_split(const bf16w4 (&x)[3], const bf16w4 (&y)[3], at_f32x16 acc) {
+    acc = gemm_mfma_bf16_w(x[2], y[0], acc); acc = gemm_mfma_bf16_w(x[0], y[2], acc); acc = gemm_mfma_bf16_w(x[1], y[1], acc);
+    acc = gemm_mfma_bf16_w(x[1], y[0], acc); acc = gemm_mfma_bf16_w(x[0], y[1], acc); acc = gemm_mfma_bf16_w(x[0], y[0], acc);
+    return acc;
+}
+// a kernel's own row operand (16 values of q / k / v / dO per lane): fp32 fragments, and in the split mode their pieces (cut once)
+template <int PREC> struct AtRow { at_f32x4 f[4]; };
+template <> struct AtRow<2> { at_f32x4 f[4]; AtPieces s; };
+template <int PREC> __device__ __forceinline__ void at_row_prep(AtRow<PREC> &r) { if constexpr (PREC == 2) at_split16(r.f, r.s); }
+
 // C^T tile (32 x 32) = X_tile (rows from LDS) . Yfrag^T : acc[r] of lane (j, h) = sum_dk X[kappa(r,h)][dk] Y[j][dk]
 // PREC = 1 (opt-in, EMLOCO_ATTN_BF16): the same operands rounded to bf16 into v_mfma_f32_32x32x16_bf16 -- the lane's 16
 // values dk = 16 h + 0..15 are two groups of 8 consecutive reduction entries, A and B alike: 2 instructions instead of 16.
 template <int PREC>
-__device__ __forceinline__ at_f32x16 at_xyT(const float *tile, int l31, int h, const at_f32x4 (&yf)[4]) {
+__device__ __forceinline__ at_f32x16 at_xyT(const float *tile, int l31, int h, const AtRow<PREC> &y) {
+    const at_f32x4 (&yf)[4] = y.f;
     at_f32x16 acc;
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     at_f32x4 xf[4];
     at_row16(tile, l31, h, xf);
+    if constexpr (PREC == 2) {
+        AtPieces xs;
+        at_split16(xf, xs);
+        acc = at_mfma_split(xs.g[0], y.s.g[0], acc);
+        acc = at_mfma_split(xs.g[1], y.s.g[1], acc);
+        return acc;
+    }
     if constexpr (PREC == 1) {
         acc = gemm_mfma_bf16(gemm_pack_bf16(xf[0], xf[1]), gemm_pack_bf16(yf[0], yf[1]), acc);
         acc = gemm_mfma_bf16(gemm_pack_bf16(xf[2], xf[3]), gemm_pack_bf16(yf[2], yf[3]), acc);
@@ -135,6 +178,16 @@ __device__ __forceinline__ at_f32x16 at_xyT(const float *tile, int l31, int h, c
 // PREC = 1: reduction entries s = 8 g + e (g = 0, 1) of the lane's half form the two groups of 8.
 template <int PREC>
 __device__ __forceinline__ at_f32x16 at_xTp(const float *tile, int l31, int h, const float (&p)[16], at_f32x16 acc) {
+    if constexpr (PREC == 2) {
+        for (int g = 0; g < 2; ++g) {
+            float x[8], pv[8];
+            for (int e = 0; e < 8; ++e) { x[e] = tile[at_kappa(8 * g + e, h) * AT_LD + l31]; pv[e] = p[8 * g + e]; }
+            bf16w4 xs[3], ps[3];
+            at_split8(x, xs); at_split8(pv, ps);
+            acc = at_mfma_split(xs, ps, acc);
+        }
+        return acc;
+    }
     if constexpr (PREC == 1) {
         for (int g = 0; g < 2; ++g) {
             float x[8];
@@ -195,8 +248,9 @@ attn_fwd_kernel(AttnArgs a) {
     const float *Q = at_off<IO>(a.qkv, (long)b * a.S * ld + hd * AT_DH), *K = at_off<IO>(Q, a.d_model), *V = at_off<IO>(Q, 2 * a.d_model);
     const float *kb = a.key_bias ? a.key_bias + (long)b * a.S : nullptr;
     const int query = blockIdx.x * 128 + wave * 32 + l31;
-    at_f32x4 qf[4];
-    at_grow16<IO>(Q, ld, query, a.Sq, h, qf);
+    AtRow<PREC> qf;
+    at_grow16<IO>(Q, ld, query, a.Sq, h, qf.f);
+    at_row_prep(qf);
     const bool live = blockIdx.x * 128 + wave * 32 < a.Sq;        // wave-uniform: waves past the live queries only help staging
     at_f32x16 acc_o;
     for (int r = 0; r < 16; ++r) acc_o[r] = 0.0f;
@@ -262,13 +316,15 @@ attn_bwd_dq_kernel(AttnArgs a) {
     const float *dO = a.dout + (long)b * a.Sq * a.d_model + hd * AT_DH, *O = a.out + (long)b * a.Sq * a.d_model + hd * AT_DH;
     const float *kb = a.key_bias ? a.key_bias + (long)b * a.S : nullptr;
     const int query = blockIdx.x * 128 + wave * 32 + l31;
-    at_f32x4 qf[4], dof[4], of[4];
-    at_grow16<IO>(Q, ld, query, a.Sq, h, qf);
-    at_grow16(dO, a.d_model, query, a.Sq, h, dof);
+    AtRow<PREC> qf, dof;
+    at_f32x4 of[4];
+    at_grow16<IO>(Q, ld, query, a.Sq, h, qf.f);
+    at_grow16(dO, a.d_model, query, a.Sq, h, dof.f);
     at_grow16(O, a.d_model, query, a.Sq, h, of);
     const bool live = blockIdx.x * 128 + wave * 32 < a.Sq;
     float dsum = 0.0f;                                 // D = sum_d dO O (the lane pair holds the two halves of d)
-    for (int f = 0; f < 4; ++f) dsum += (dof[f].x * of[f].x + dof[f].y * of[f].y) + (dof[f].z * of[f].z + dof[f].w * of[f].w);
+    for (int f = 0; f < 4; ++f) dsum += (dof.f[f].x * of[f].x + dof.f[f].y * of[f].y) + (dof.f[f].z * of[f].z + dof.f[f].w * of[f].w);
+    at_row_prep(qf); at_row_prep(dof);
     dsum += __shfl_xor(dsum, 32);
     const float lse = query < a.Sq ? a.lse[(long)bh * a.Sq + query] : 3.0e38f;
     if (query < a.Sq && h == 0) a.dsum[(long)bh * a.Sq + query] = dsum;
@@ -323,9 +379,10 @@ attn_bwd_dkv_kernel(AttnArgs a) {
     const float *dO = a.dout + (long)b * a.Sq * a.d_model + hd * AT_DH;
     const float *lse = a.lse + (long)bh * a.Sq, *dsm = a.dsum + (long)bh * a.Sq;
     const int key = blockIdx.x * 128 + wave * 32 + l31;
-    at_f32x4 kf[4], vf[4];
-    at_grow16<IO>(K, ld, key, a.S, h, kf);
-    at_grow16<IO>(V, ld, key, a.S, h, vf);
+    AtRow<PREC> kf, vf;
+    at_grow16<IO>(K, ld, key, a.S, h, kf.f);
+    at_grow16<IO>(V, ld, key, a.S, h, vf.f);
+    at_row_prep(kf); at_row_prep(vf);
     const bool live = blockIdx.x * 128 + wave * 32 < a.S;         // wave-uniform: a wave wholly past the keys only helps staging
     float bias = -INFINITY;
     if (key < a.S) bias = a.key_bias ? a.key_bias[(long)b * a.S + key] : 0.0f;

@@ -93,6 +93,7 @@ GEMM_BF16 = 16
 GEMM_SPLIT = 1024      # EMLOCO_GEMM_SPLIT: fp32-class products from bf16 pieces (six bf16 matrix instructions per 16 k)
 GEMM_A16, GEMM_B16, GEMM_C16, GEMM_MASK16 = 64, 128, 256, 512      # EMLOCO_GEMM_*_BF16MEM: that operand is bf16 in memory
 ATTN_BF16 = 16
+ATTN_SPLIT = 64        # EMLOCO_ATTN_SPLIT: the fused attention's tile products as fp32-class sums of bf16 piece products
 ATTN_QKV16 = 32        # EMLOCO_ATTN_QKV_BF16MEM
 # The default is the split mode: every fp32 operand is cut into three bf16 pieces (8 + 8 + 8 mantissa bits, exact) and the six
 # piece products that carry more than 2^-24 of the result run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Against float64
@@ -101,6 +102,7 @@ ATTN_QKV16 = 32        # EMLOCO_ATTN_QKV_BF16MEM
 # (the bf16 pipe is 16x the fp32 one; the split costs 6 instructions where fp32 needs 8).  EMLOCO_MATMUL_PRECISION=fp32 puts
 # every GEMM back on v_mfma_f32_32x32x2_f32.
 DEFAULT_PRECISION = os.environ.get("EMLOCO_MATMUL_PRECISION", "fp32_split")       # "fp32" | "fp32_split" | "bf16"
+_ATTN_SPLIT = os.environ.get("EMLOCO_ATTN_SPLIT", "1") != "0"        # (A/B knob: the fused attention of the split mode on the fp32 matrix instruction)
 _matmul_precision = [DEFAULT_PRECISION]
 
 
@@ -333,7 +335,7 @@ class FusedAttentionFn(torch.autograd.Function):
         ctx.drop_p, ctx.drop_seed = float(drop_p), int(drop_seed)
         scale = 1.0 / float(d // nhead) ** 0.5
         lib, st = _lib(), _st(qkv)
-        ctx.attn_flags = ATTN_BF16 if _matmul_precision[0] == "bf16" else 0      # the backward follows the forward's choice
+        ctx.attn_flags = {"bf16": ATTN_BF16, "fp32_split": ATTN_SPLIT if _ATTN_SPLIT else 0}.get(_matmul_precision[0], 0)   # the backward follows the forward's choice
         if qkv.dtype == torch.bfloat16:
             ctx.attn_flags = ATTN_BF16 | ATTN_QKV16
         step = FusedAttentionFn.MAX_SEQ_HEADS // nhead

@@ -103,7 +103,9 @@ int emloco_attention_bwd(int n_seq, int S, int nhead, int d_model, float scale, 
 /* The same with flags: EMLOCO_ATTN_BF16 = the opt-in reduced precision of EMLOCO_GEMM_BF16 for the four (forward) / eight
  * (backward) tile products per step: operands (q, k, v, probabilities, dO, dS) rounded to bf16 into
  * v_mfma_f32_32x32x16_bf16, fp32 accumulation; softmax statistics, log-sum-exp and D stay fp32.  flags = 0 is the call above. */
-enum { EMLOCO_ATTN_BF16 = 16,
+enum { EMLOCO_ATTN_SPLIT = 64,        /* fp32-class tile products from bf16 pieces (the attention's EMLOCO_GEMM_SPLIT: six v_mfma_f32_32x32x16_bf16
+                                       * per 16 reduction entries, fp32 accumulation; error class of the fp32 instruction; ignored with EMLOCO_ATTN_BF16) */
+       EMLOCO_ATTN_BF16 = 16,
        EMLOCO_ATTN_QKV_BF16MEM = 32   /* with EMLOCO_ATTN_BF16: qkv (and, in the backward, dqkv) hold bf16 in memory -- 2 bytes per element,
                                        * same shapes; out / dout / lse / dsum stay fp32 */ };
 int emloco_attention_fwd_ex(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,

@@ -128,6 +128,7 @@ extern "C" void emu_attention_set_precision(int p) { g_attn_prec = p; }
 extern "C" void emu_attention_set_dropout(float p, unsigned seed) { g_attn_drop_p = p; g_attn_drop_seed = seed; }
 extern "C" int emu_attn_keep(unsigned seed, unsigned bh, unsigned q, unsigned k, float p) { return emloco::at_keep_bit(emloco::at_head_key(seed, bh), q, k, (unsigned)(p * 16777216.0f)) ? 1 : 0; }
 #define ATTN_DISPATCH(K) do { const bool dr_ = g_attn_drop_p > 0.0f; \
+    if (g_attn_prec == 2 && dr_) K<2, 1>(a); else if (g_attn_prec == 2) K<2, 0>(a); else \
     if (g_attn_prec && dr_) K<1, 1>(a); else if (g_attn_prec) K<1, 0>(a); else if (dr_) K<0, 1>(a); else K<0, 0>(a); } while (0)
 extern "C" int emu_attention_fwd_queries(int n_seq, int S, int Sq, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                                          float *out, float *lse) {

@@ -668,7 +668,17 @@ def test_chunked_rms_update_equals_the_single_launch():
     np.testing.assert_array_equal(res[1][0][:5], m0[:5])                  # frozen columns keep their moments
 
 
-def test_fused_attention_kernels_forward_and_backward():
+@pytest.fixture(params=[0, 2], ids=["fp32", "split"])
+def attn_precision(request):
+    """the fused attention on the fp32 matrix instruction (0) and with fp32-class tile products from bf16 pieces (2, EMLOCO_ATTN_SPLIT:
+    the product's default) -- the same tolerances against float64 in both"""
+    lib = emu.lib()
+    lib.emu_attention_set_precision(request.param)
+    yield request.param
+    lib.emu_attention_set_precision(0)
+
+
+def test_fused_attention_kernels_forward_and_backward(attn_precision):
     """attn_fwd / attn_bwd_dq / attn_bwd_dkv (head dim 32) against a float64 numpy attention, ragged S (two query blocks'
     worth of tiles would be slow in the emulator: S = 70 covers a partial last tile), additive and -inf key biases."""
     lib = emu.lib()
@@ -714,7 +724,7 @@ def test_fused_attention_kernels_forward_and_backward():
     assert np.all(out2 == 0)
 
 
-def test_fused_attention_kernels_with_dropout_on_the_probabilities():
+def test_fused_attention_kernels_with_dropout_on_the_probabilities(attn_precision):
     """nn.MultiheadAttention(dropout = p) in training mode: softmax -> dropout -> . V.  The fused kernels with the counter-based
     keep mask against a float64 attention that applies the SAME mask (the hash is evaluated on the host through the emulator
     library): forward and all three gradients; the keep rate is 1 - p; p = 0 reproduces the plain kernels."""
