@@ -47,7 +47,7 @@ class SelfCollisionDesc(C.Structure):
     """EmlocoSelfCollisionDesc (include/emloco_sim.h)."""
     _fields_ = [("n_pairs", C.c_int32), ("pairs", C.POINTER(C.c_uint8)), ("cap_a", C.POINTER(C.c_float)),
                 ("cap_b", C.POINTER(C.c_float)), ("cap_r", C.POINTER(C.c_float)), ("k", C.c_float), ("c", C.c_float),
-                ("max_pen", C.c_float), ("mu", C.c_float)]
+                ("max_pen", C.c_float), ("mu", C.c_float), ("n_seg", C.c_int32), ("seg_body", C.POINTER(C.c_uint8))]
 
 
 class TaskBufs(C.Structure):

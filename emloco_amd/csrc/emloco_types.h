@@ -13,20 +13,21 @@
 #define EMLOCO_TOPO_CHILD 48      /* [24][3] children, descending body index, -1 padded */
 #define EMLOCO_TOPO_PDPACK 120    /* [24] parent (the root: 31) | depth << 5 | index among the bodies of its depth << 9 | children << 12, 17, 22 */
 #define EMLOCO_TOPO_CAND 144      /* [96] ground-contact candidate: body | k << 8 | geom type << 16 */
-#define EMLOCO_TOPO_SCPAIR 240    /* [256] limb-limb pair: body i | body j << 8 */
-#define EMLOCO_TOPO_WORDS 496
+#define EMLOCO_TOPO_SCPAIR 240    /* [320] limb-limb pair: segment i | segment j << 8 | body of i << 16 | body of j << 24 */
+#define EMLOCO_TOPO_WORDS 560
 
 // Per-env model block (floats, [n_env][EMLOCO_MODEL_WORDS]; built by model_pack.h).  16-byte records so that a lane fetches what a
 // phase needs with a few dwordx4 loads off ONE workgroup-uniform base (scalar registers) and a 32-bit lane offset:
 #define EMLOCO_MB_DYN 0           /* [24][16]  joint offset xyz, mass | com xyz, 0 | Ixx Iyy Izz Ixy | Ixz Iyz 0 0 */
 #define EMLOCO_MB_GEO 384         /* [24][8]   geom a xyz, geom radius | geom b xyz, 0 */
-#define EMLOCO_MB_CAP 576         /* [24][8]   collision capsule end a xyz, radius | end b xyz, 0  (self-collision; zeros when off) */
-#define EMLOCO_MB_DRV 768         /* [69][4]   kp, kd, armature, effort limit */
-#define EMLOCO_MODEL_WORDS 1048
+#define EMLOCO_MB_CAP 576         /* [32][8]   collision segment: capsule end a xyz, radius | end b xyz, its body  (self-collision; zeros when off) */
+#define EMLOCO_MB_DRV 832         /* [69][4]   kp, kd, armature, effort limit */
+#define EMLOCO_MODEL_WORDS 1112
 
 // Device pointers handed to the rollout kernels by value (kernarg segment).
 struct EmlocoSimDev {
     int n_env, n_cand, max_depth, sc_n;       /* sc_n: limb-limb pairs (0: self-collision off) */
+    int sc_nseg;                              /* collision segments per env (24 .. EMLOCO_SC_MAXSEG) */
     const int *topo;                          /* EMLOCO_TOPO_* */
     const float *model;                       /* EMLOCO_MB_*, one block per env */
     // state

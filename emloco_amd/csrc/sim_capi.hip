@@ -123,15 +123,26 @@ int emloco_sim_set_self_collision(EmlocoSim *s, const EmlocoSelfCollisionDesc *c
     if (!s || !c) return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: null argument");
     if (!s->have_model) return fail(EMLOCO_E_STATE, "emloco_sim_set_self_collision: set the models first");
     if (s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_set_self_collision: sim already prepared");
-    if (c->n_pairs < 0 || c->n_pairs > EMLOCO_SC_MAXPAIRS) return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: at most 256 pairs");
+    if (c->n_pairs < 0 || c->n_pairs > EMLOCO_SC_MAXPAIRS) return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: at most EMLOCO_SC_MAXPAIRS pairs");
     s->h_sc_pairs.clear();
     if (c->n_pairs == 0) return EMLOCO_OK;
     if (!c->pairs || !c->cap_a || !c->cap_b || !c->cap_r || !(c->k > 0.0f) || c->c < 0.0f || !(c->max_pen > 0.0f) || !(c->mu >= 0.0f))
         return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: missing arrays or non-positive stiffness / penetration cap");
-    for (int i = 0; i < c->n_pairs; ++i)
-        if (c->pairs[2 * i] >= c->pairs[2 * i + 1] || c->pairs[2 * i + 1] >= EMLOCO_NB)
-            return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: pairs must be (i < j < 24)");
-    const size_t E = (size_t)s->n_env, NBs = EMLOCO_NB;
+    const int n_seg = (c->n_seg > 0 && c->seg_body) ? c->n_seg : EMLOCO_NB;
+    if (n_seg < EMLOCO_NB || n_seg > EMLOCO_SC_MAXSEG) return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: 24 <= n_seg <= EMLOCO_SC_MAXSEG");
+    s->h_sc_segbody.resize((size_t)n_seg);
+    for (int i = 0; i < n_seg; ++i) {
+        const int b = (c->n_seg > 0 && c->seg_body) ? c->seg_body[i] : i;
+        if (b >= EMLOCO_NB || (i < EMLOCO_NB && b != i)) return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: seg_body[i] = i for i < 24, a body index beyond");
+        s->h_sc_segbody[(size_t)i] = (unsigned char)b;
+    }
+    for (int i = 0; i < c->n_pairs; ++i) {
+        const int si = c->pairs[2 * i], sj = c->pairs[2 * i + 1];
+        if (si >= sj || sj >= n_seg || s->h_sc_segbody[(size_t)si] == s->h_sc_segbody[(size_t)sj])
+            return fail(EMLOCO_E_ARG, "emloco_sim_set_self_collision: pairs must be segments (i < j < n_seg) of two different bodies");
+    }
+    s->sc_nseg = n_seg;
+    const size_t E = (size_t)s->n_env, NBs = (size_t)n_seg;
     s->h_sc_pairs.assign(c->pairs, c->pairs + 2 * (size_t)c->n_pairs);
     s->h_sc_a.assign(c->cap_a, c->cap_a + E * NBs * 3);
     s->h_sc_b.assign(c->cap_b, c->cap_b + E * NBs * 3);
@@ -161,11 +172,13 @@ int emloco_sim_prepare(EmlocoSim *s) {
     const emloco::Topology &t = s->topo;
     const bool sc_on = !s->h_sc_pairs.empty();
     {   // the two blocks the kernels read: topology tables, one model record block per env (model_pack.h)
-        const std::vector<int32_t> topo = emloco::pack_topology(t, sc_on ? s->h_sc_pairs.data() : nullptr, sc_on ? (int)(s->h_sc_pairs.size() / 2) : 0);
+        const std::vector<int32_t> topo = emloco::pack_topology(t, sc_on ? s->h_sc_pairs.data() : nullptr, sc_on ? (int)(s->h_sc_pairs.size() / 2) : 0,
+                                                                sc_on ? s->h_sc_segbody.data() : nullptr);
         const std::vector<float> mdl = emloco::pack_models(s->n_env, s->h_off.data(), s->h_mass.data(), s->h_com.data(), s->h_inertia.data(),
                                                            s->h_ga.data(), s->h_gb.data(), s->h_gr.data(), s->h_kp.data(), s->h_kd.data(),
                                                            s->h_arm.data(), s->h_eff.data(), sc_on ? s->h_sc_a.data() : nullptr,
-                                                           sc_on ? s->h_sc_b.data() : nullptr, sc_on ? s->h_sc_r.data() : nullptr);
+                                                           sc_on ? s->h_sc_b.data() : nullptr, sc_on ? s->h_sc_r.data() : nullptr,
+                                                           sc_on ? s->sc_nseg : EMLOCO_NB, sc_on ? s->h_sc_segbody.data() : nullptr);
         HIPCHK(s->d_topo.upload(topo.data(), topo.size()));
         HIPCHK(s->d_model.upload(mdl.data(), mdl.size()));
     }
@@ -192,6 +205,7 @@ int emloco_sim_prepare(EmlocoSim *s) {
     d.sc_n = 0;
     if (sc_on) {
         d.sc_n = (int)(s->h_sc_pairs.size() / 2);
+        d.sc_nseg = s->sc_nseg;
         d.sc_k = s->sc_k; d.sc_c = s->sc_c; d.sc_max_pen = s->sc_max_pen; d.sc_mu = s->sc_mu;
     }
     d.hf = nullptr;

@@ -177,7 +177,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
            O_VF = O_V + NB * 8, O_AACC = O_VF + NB * 8, O_FEXT = O_AACC + NB * 8, O_PQ = O_FEXT + NB * 8,
            LDS_WORDS = (O_PQ + NB * 8 > O_G + MAXR * (MAXR + 1) / 2) ? O_PQ + NB * 8 : O_G + MAXR * (MAXR + 1) / 2 };
     static_assert(O_R % 4 == 0 && O_W % 4 == 0 && O_IA % 4 == 0 && O_PA % 4 == 0 && O_PQ % 4 == 0, "rows must be 16-byte aligned");
-    static_assert(O_V - O_G >= NB * 8 + EMLOCO_SC_MAXHITS * 8 + 256, "limb-limb scratch does not fit its overlay");
+    static_assert(O_V - O_G >= EMLOCO_SC_MAXSEG * 8 + EMLOCO_SC_MAXHITS * 8 + 256, "limb-limb scratch does not fit its overlay");
     static_assert(LDS_WORDS * 4 <= 13312, "LDS per env above 160 KiB / 12 in 512-byte granules (three waves per SIMD, 12 envs per CU)");
     __shared__ __attribute__((aligned(16))) float lds[LDS_WORDS];
     float *sh_root = lds + O_ROOT;                            // p0[3] q0[4] V0[6]
@@ -508,14 +508,17 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         // lane = body: world collision capsule -> LDS; lane = pair (4 rounds of 64): closest points, spring-damper force;
         // hits are compacted in pair order (ballot) and every body adds the wrenches that act on it in that order.
         if (d.sc_n > 0) {
-            float *sh_seg = sh_A;                                  // [NB][8]   (sh_A is free until the contact phase)
-            float *sh_hitw = sh_A + NB * 8;                        // [MAXHITS][6] wrench on body i about O (body j gets the negative)
-            int *sh_hitb = (int *)(sh_A + NB * 8 + EMLOCO_SC_MAXHITS * 6);   // [MAXHITS][2]
-            if ((lane < NB)) {
+            // lane = collision segment: one sphere-swept segment per body, and a second one for a box much wider than thick (the
+            // ankle boxes: two capsules along the long edges); the segment's record names its body
+            float *sh_seg = sh_A;                                  // [MAXSEG][8]   (sh_A is free until the contact phase)
+            float *sh_hitw = sh_A + EMLOCO_SC_MAXSEG * 8;          // [MAXHITS][6] wrench on body i about O (body j gets the negative)
+            int *sh_hitb = (int *)(sh_A + EMLOCO_SC_MAXSEG * 8 + EMLOCO_SC_MAXHITS * 6);   // [MAXHITS][2]
+            if (lane < d.sc_nseg) {
                 float R[9], r[3], ca[4], cb[4], pa[3], pb[3];
-                for (int k = 0; k < 9; ++k) R[k] = sh_R[lane][k];
-                for (int k = 0; k < 3; ++k) r[k] = sh_R[lane][9 + k];
-                ld4(mdl, EMLOCO_MB_CAP + lane * 8, ca); ld4(mdl, EMLOCO_MB_CAP + lane * 8 + 4, cb);     // end a xyz, radius | end b xyz
+                ld4(mdl, EMLOCO_MB_CAP + lane * 8, ca); ld4(mdl, EMLOCO_MB_CAP + lane * 8 + 4, cb);     // end a xyz, radius | end b xyz, body
+                const int sb = (int)cb[3];
+                for (int k = 0; k < 9; ++k) R[k] = sh_R[sb][k];
+                for (int k = 0; k < 3; ++k) r[k] = sh_R[sb][9 + k];
                 matvec3(R, ca, pa); matvec3(R, cb, pb);
                 for (int k = 0; k < 3; ++k) { sh_seg[lane * 8 + k] = r[k] + pa[k]; sh_seg[lane * 8 + 3 + k] = r[k] + pb[k]; }
                 sh_seg[lane * 8 + 6] = ca[3];
@@ -527,13 +530,13 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
             // half lengths (triangle inequality; 1 mm of slack covers the rounding): the pairs that pass -- a few dozen of the
             // 245 -- are compacted in pair order and only they run the closest-point test, in one round instead of four.
             // A culled pair cannot hit, so the hit list (and every force) is what the full sweep gives.
-            int *sh_cand = (int *)(sh_A + NB * 8 + EMLOCO_SC_MAXHITS * 8);
+            int *sh_cand = (int *)(sh_A + EMLOCO_SC_MAXSEG * 8 + EMLOCO_SC_MAXHITS * 8);
             int ncand = 0;
             for (int q0 = 0; q0 < d.sc_n; q0 += 64) {
                 const int q = q0 + lane;
                 bool keep = false;
                 if (q < d.sc_n) {
-                    const int pr = topo[EMLOCO_TOPO_SCPAIR + q], bi = pr & 0xff, bj = pr >> 8;
+                    const int pr = topo[EMLOCO_TOPO_SCPAIR + q], bi = pr & 0xff, bj = (pr >> 8) & 0xff;      // segments
                     float dm2 = 0.0f;
                     for (int k = 0; k < 3; ++k) {
                         const float dm = (sh_seg[bi * 8 + k] + sh_seg[bi * 8 + 3 + k]) - (sh_seg[bj * 8 + k] + sh_seg[bj * 8 + 3 + k]);   // 2 (m_i - m_j)
@@ -555,10 +558,11 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                 int bi = 0, bj = 0;
                 if (q < d.sc_n) {
                     const int pr = topo[EMLOCO_TOPO_SCPAIR + q];
-                    bi = pr & 0xff; bj = pr >> 8;
+                    const int si = pr & 0xff, sj = (pr >> 8) & 0xff;                 // the two segments ...
+                    bi = (pr >> 16) & 0xff; bj = (pr >> 24) & 0xff;                  // ... and the bodies they belong to
                     float p0[3], p1[3], g0[3], g1[3], c1[3], c2[3];
-                    for (int k = 0; k < 3; ++k) { p0[k] = sh_seg[bi * 8 + k]; p1[k] = sh_seg[bi * 8 + 3 + k]; g0[k] = sh_seg[bj * 8 + k]; g1[k] = sh_seg[bj * 8 + 3 + k]; }
-                    const float rsum = sh_seg[bi * 8 + 6] + sh_seg[bj * 8 + 6];
+                    for (int k = 0; k < 3; ++k) { p0[k] = sh_seg[si * 8 + k]; p1[k] = sh_seg[si * 8 + 3 + k]; g0[k] = sh_seg[sj * 8 + k]; g1[k] = sh_seg[sj * 8 + 3 + k]; }
+                    const float rsum = sh_seg[si * 8 + 6] + sh_seg[sj * 8 + 6];
                     seg_seg_closest(p0, p1, g0, g1, c1, c2);
                     const float dv[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
                     const float dist2 = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
@@ -566,7 +570,7 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                         const float dist = sqrtf(dist2);
                         float pen = rsum - dist;
                         const float n[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist};
-                        const float off = sh_seg[bj * 8 + 6] - 0.5f * pen;     // contact point: middle of the overlap
+                        const float off = sh_seg[sj * 8 + 6] - 0.5f * pen;     // contact point: middle of the overlap
                         const float pt[3] = {c2[0] + n[0] * off, c2[1] + n[1] * off, c2[2] + n[2] * off};
                         float Vi[6], Vj[6], wi[3], wjx[3];
                         for (int k = 0; k < 6; ++k) { Vi[k] = sh_V[bi][k]; Vj[k] = sh_V[bj][k]; }

@@ -26,7 +26,8 @@ struct EmlocoSim {
     // host copies of the model until prepare()
     std::vector<float> h_off, h_mass, h_com, h_inertia, h_ga, h_gb, h_gr, h_kp, h_kd, h_arm, h_eff;
     // optional self-collision description (host copies until prepare())
-    std::vector<unsigned char> h_sc_pairs;
+    std::vector<unsigned char> h_sc_pairs, h_sc_segbody;
+    int sc_nseg = EMLOCO_NB;
     std::vector<float> h_sc_a, h_sc_b, h_sc_r;
     float sc_k = 0.0f, sc_c = 0.0f, sc_max_pen = 0.0f, sc_mu = 0.0f;
     // optional height-field ground (host copy until prepare())

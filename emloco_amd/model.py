@@ -240,21 +240,38 @@ def write_mjcf(model: HumanoidModel, path):
 SMPL_SHAPE_FILTERS = [0, 0, 7, 16, 12, 0, 56, 2, 33, 128, 0, 192, 0, 64, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
 
 
+SC_MAXSEG = 32          # EMLOCO_SC_MAXSEG
+
+
 def collision_capsules(model: HumanoidModel):
-    """Sphere-swept segment of every body for limb-limb contact: spheres and capsules as they are, boxes (feet) as the
-    capsule along their longest axis with the smallest half extent as radius.  Returns (a, b, r) in the body frame."""
-    a, b, r = model.geom_a.copy(), model.geom_a.copy(), model.geom_r.copy()
-    for i in range(model.num_bodies):
+    """Sphere-swept segments of the bodies for limb-limb contact, in the body frame: spheres and capsules as they are; a box as
+    the capsule along its longest axis with the smallest half extent as radius -- and, where the box is much WIDER than that
+    capsule (middle half extent > 1.5 x the smallest: the SMPL ankle boxes, 17 x 9.7 x 4.2 cm; the toe boxes are as thick as wide
+    and keep one capsule), as TWO such capsules along its two long edges, so that the foot collides with its real width.
+    Returns (a, b, r, seg_body): n_seg = 24 + number of second capsules rows each; seg_body[i] = i for i < 24."""
+    nb = model.num_bodies
+    a, b, r = [model.geom_a[i].copy() for i in range(nb)], [model.geom_a[i].copy() for i in range(nb)], [float(model.geom_r[i]) for i in range(nb)]
+    seg_body = list(range(nb))
+    for i in range(nb):
         if model.geom_type[i] == GEOM_CAPSULE:
-            b[i] = model.geom_b[i]
+            b[i] = model.geom_b[i].copy()
         elif model.geom_type[i] == GEOM_BOX:
             h = np.abs(model.geom_b[i])
-            ax = int(np.argmax(h))
-            rad = float(np.min(h))
+            order = np.argsort(h)                              # thinnest, middle, longest axis
+            rad = float(h[order[0]])
             half = np.zeros(3)
-            half[ax] = max(h[ax] - rad, 0.0)
-            a[i], b[i], r[i] = model.geom_a[i] - half, model.geom_a[i] + half, rad
-    return a, b, r
+            half[order[2]] = max(h[order[2]] - rad, 0.0)
+            if h[order[1]] > 1.5 * rad:
+                side = np.zeros(3)
+                side[order[1]] = h[order[1]] - rad                 # the two capsules touch the box's long faces from inside
+                a[i], b[i], r[i] = model.geom_a[i] - half - side, model.geom_a[i] + half - side, rad
+                a.append(model.geom_a[i] - half + side); b.append(model.geom_a[i] + half + side); r.append(rad)
+                seg_body.append(i)
+            else:
+                a[i], b[i], r[i] = model.geom_a[i] - half, model.geom_a[i] + half, rad
+    if len(seg_body) > SC_MAXSEG:
+        raise ValueError(f"{len(seg_body)} collision segments; the kernels hold {SC_MAXSEG}")
+    return np.asarray(a, np.float64), np.asarray(b, np.float64), np.asarray(r, np.float64), np.asarray(seg_body, np.uint8)
 
 
 def _segment_distance(p0, p1, q0, q1):
@@ -281,34 +298,38 @@ def _segment_distance(p0, p1, q0, q1):
 
 
 def self_collision_pairs(model: HumanoidModel, filters=None, margin=0.01):
-    """Body pairs tested for self-contact (`has_self_collision`, humanoid.py:917-944): not parent / child (articulation
-    links never collide with their parent), filter bitmasks disjoint, and not already touching in the bind pose (all joint
-    angles zero) -- a penalty contact on a permanent overlap would push the limbs apart for ever, so those pairs are
-    filtered the way asset importers do.  Returns uint8 [n][2] with i < j, ascending."""
+    """SEGMENT pairs tested for self-contact (`has_self_collision`, humanoid.py:917-944): segments of two different bodies that are
+    not parent / child (articulation links never collide with their parent), whose filter bitmasks are disjoint, and that do not
+    already touch in the bind pose (all joint angles zero) -- a penalty contact on a permanent overlap would push the limbs apart
+    for ever, so those pairs are filtered the way asset importers do.  Returns uint8 [n][2] with i < j, ascending."""
     filters = SMPL_SHAPE_FILTERS if filters is None else filters
     nb = model.num_bodies
     pw = np.zeros((nb, 3))
     for i in range(1, nb):
         pw[i] = pw[model.parent[i]] + model.joint_off[i]
-    a, b, r = collision_capsules(model)
+    a, b, r, sb = collision_capsules(model)
     pairs = []
-    for i in range(nb):
-        for j in range(i + 1, nb):
-            if model.parent[j] == i or model.parent[i] == j or (filters[i] & filters[j]) != 0:
+    for i in range(len(sb)):
+        for j in range(i + 1, len(sb)):
+            bi, bj = int(sb[i]), int(sb[j])
+            if bi == bj or model.parent[bj] == bi or model.parent[bi] == bj or (filters[bi] & filters[bj]) != 0:
                 continue
-            if _segment_distance(pw[i] + a[i], pw[i] + b[i], pw[j] + a[j], pw[j] + b[j]) < r[i] + r[j] + margin:
+            if _segment_distance(pw[bi] + a[i], pw[bi] + b[i], pw[bj] + a[j], pw[bj] + b[j]) < r[i] + r[j] + margin:
                 continue
             pairs.append((i, j))
     return np.asarray(pairs, dtype=np.uint8).reshape(-1, 2)
 
 
 def pack_self_collision(models, k=1.5e4, c=60.0, max_pen=0.04, filters=None, mu=1.0):
-    """Arrays of `EmlocoSelfCollisionDesc` (include/emloco_sim.h): the pair table of the first model (one table per
-    sim: the kernels share it across envs) and per-env collision capsules."""
+    """Arrays of `EmlocoSelfCollisionDesc` (include/emloco_sim.h): the segment-pair table and segment -> body map of the first model
+    (one table per sim: the kernels share it across envs) and per-env collision segments."""
     caps = [collision_capsules(m) for m in models]
+    seg_body = caps[0][3]
+    if any(len(cpl[3]) != len(seg_body) or (cpl[3] != seg_body).any() for cpl in caps):
+        raise ValueError("the envs' humanoids must have the same collision segments (same boxes split in two)")
     f32 = lambda idx: np.ascontiguousarray(np.stack([cpl[idx] for cpl in caps]).astype(np.float32))
     return dict(pairs=np.ascontiguousarray(self_collision_pairs(models[0], filters)), cap_a=f32(0), cap_b=f32(1), cap_r=f32(2),
-                k=float(k), c=float(c), max_pen=float(max_pen), mu=float(mu))
+                k=float(k), c=float(c), max_pen=float(max_pen), mu=float(mu), seg_body=np.ascontiguousarray(seg_body))
 
 
 def pack_models(models):

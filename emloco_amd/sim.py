@@ -79,7 +79,9 @@ class NativeSim:
                 self_collision = pack_self_collision(models)
             sc = self._sc = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in self_collision.items()}
             scd = L.SelfCollisionDesc(int(sc["pairs"].shape[0]), sc["pairs"].ctypes.data_as(C.POINTER(C.c_uint8)), f(sc["cap_a"]),
-                                      f(sc["cap_b"]), f(sc["cap_r"]), float(sc["k"]), float(sc["c"]), float(sc["max_pen"]), float(sc.get("mu", 1.0)))
+                                      f(sc["cap_b"]), f(sc["cap_r"]), float(sc["k"]), float(sc["c"]), float(sc["max_pen"]), float(sc.get("mu", 1.0)),
+                                      int(sc["seg_body"].shape[0]) if sc.get("seg_body") is not None else 0,
+                                      sc["seg_body"].ctypes.data_as(C.POINTER(C.c_uint8)) if sc.get("seg_body") is not None else None)
             lib.emloco_sim_set_self_collision.argtypes = [C.c_void_p, C.POINTER(L.SelfCollisionDesc)]
             L.check(lib.emloco_sim_set_self_collision(self._h, C.byref(scd)), "emloco_sim_set_self_collision")
         if heightfield is not None:

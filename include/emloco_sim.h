@@ -77,18 +77,25 @@ typedef struct {
  * max_pen) along the contact normal acts on both bodies at the contact point (equal and opposite), plus Coulomb friction
  * regularised by the same damper: - min(mu F / |v_t|, c) v_t with v_t the tangential relative velocity there.  Optional: call
  * between emloco_sim_set_models and emloco_sim_prepare; never calling it (or n_pairs = 0) leaves self-collision off. */
-#define EMLOCO_SC_MAXPAIRS 256
+#define EMLOCO_SC_MAXPAIRS 320
+#define EMLOCO_SC_MAXSEG 32     /* collision segments per humanoid: one per body + up to 8 second ones (wide boxes: the feet) */
 #define EMLOCO_SC_MAXHITS 32    /* simultaneous limb-limb contacts kept per env and substep (lowest pair indices first) */
 typedef struct {
     int32_t n_pairs;
-    const uint8_t *pairs;      /* [n_pairs][2] body indices, i < j, shared by all envs */
-    const float *cap_a;        /* [n_env][24][3] capsule end 0, body frame */
-    const float *cap_b;        /* [n_env][24][3] capsule end 1 */
-    const float *cap_r;        /* [n_env][24] radius */
+    const uint8_t *pairs;      /* [n_pairs][2] SEGMENT indices, i < j, shared by all envs (segment = body while n_seg = 0) */
+    const float *cap_a;        /* [n_env][n_seg or 24][3] capsule end 0, frame of the segment's body */
+    const float *cap_b;        /* [n_env][n_seg or 24][3] capsule end 1 */
+    const float *cap_r;        /* [n_env][n_seg or 24] radius */
     float k;                   /* stiffness [N/m] */
     float c;                   /* normal damping [N s/m] */
     float max_pen;             /* penetration used for the spring is capped here [m] */
     float mu;                  /* friction coefficient of the limb-limb contacts (0: frictionless) */
+    /* Round 4: a body may carry more than one sphere-swept segment -- a box much wider than thick (the SMPL humanoid's ankle boxes,
+     * 17 x 9.7 x 4.2 cm, smpl_humanoid.xml) is two parallel capsules along its long edges, not one down its middle.  n_seg = 0 (or
+     * seg_body NULL): 24 segments, segment i on body i.  Else 24 <= n_seg <= EMLOCO_SC_MAXSEG, seg_body[i] = i for i < 24 and the
+     * body of every further segment; pairs never join two segments of one body. */
+    int32_t n_seg;
+    const uint8_t *seg_body;   /* [n_seg] */
 } EmlocoSelfCollisionDesc;
 
 /* state tensors a caller may alias (gym.acquire_*_tensor, humanoid.py:137-148) */

@@ -70,7 +70,7 @@ class Model(C.Structure):
                 ("armature", C.POINTER(C.c_float)), ("effort", C.POINTER(C.c_float)),
                 ("sc_n", C.c_int32), ("sc_pairs", C.POINTER(C.c_uint8)), ("sc_cap_a", C.POINTER(C.c_float)),
                 ("sc_cap_b", C.POINTER(C.c_float)), ("sc_cap_r", C.POINTER(C.c_float)), ("sc_k", C.c_float), ("sc_c", C.c_float),
-                ("sc_max_pen", C.c_float), ("sc_mu", C.c_float),
+                ("sc_max_pen", C.c_float), ("sc_mu", C.c_float), ("sc_nseg", C.c_int32), ("sc_segbody", C.POINTER(C.c_uint8)),
                 ("hf", C.POINTER(C.c_int16)), ("hf_nx", C.c_int32), ("hf_ny", C.c_int32), ("hf_hs", C.c_float), ("hf_vs", C.c_float),
                 ("hf_ox", C.c_float), ("hf_oy", C.c_float)]
 
@@ -97,6 +97,10 @@ class Sim:
             self.model.sc_cap_a, self.model.sc_cap_b, self.model.sc_cap_r = _p(c["cap_a"]), _p(c["cap_b"]), _p(c["cap_r"])
             self.model.sc_k, self.model.sc_c, self.model.sc_max_pen = float(c["k"]), float(c["c"]), float(c["max_pen"])
             self.model.sc_mu = float(c.get("mu", 1.0))
+            if c.get("seg_body") is not None:
+                self._seg_body = np.ascontiguousarray(c["seg_body"], np.uint8)
+                self.model.sc_nseg = int(self._seg_body.shape[0])
+                self.model.sc_segbody = _p(self._seg_body, C.c_uint8)
         self.hf = None
         if heightfield is not None:
             self.hf = np.ascontiguousarray(heightfield["samples"], dtype=np.int16)

@@ -158,6 +158,8 @@ typedef struct {
     const uint8_t *sc_pairs;
     const float *sc_a, *sc_b, *sc_r;
     float sc_k, sc_c, sc_max_pen, sc_mu;
+    int sc_nseg;
+    const uint8_t *sc_segbody;
     const int16_t *hf;
     int hf_nx, hf_ny;
     float hf_hs, hf_inv_hs, hf_vs, hf_ox, hf_oy;
@@ -174,9 +176,11 @@ static EnvModel env_model(const OrcModel *m, int e) {
     x.hf = m->hf; x.hf_nx = m->hf_nx; x.hf_ny = m->hf_ny; x.hf_hs = m->hf_hs; x.hf_vs = m->hf_vs; x.hf_ox = m->hf_ox; x.hf_oy = m->hf_oy;
     x.hf_inv_hs = m->hf ? 1.0f / m->hf_hs : 0.0f;
     x.sc_n = m->sc_n; x.sc_pairs = m->sc_pairs; x.sc_k = m->sc_k; x.sc_c = m->sc_c; x.sc_max_pen = m->sc_max_pen; x.sc_mu = m->sc_mu;
-    x.sc_a = m->sc_n > 0 ? m->sc_cap_a + (long)e * NB * 3 : 0;
-    x.sc_b = m->sc_n > 0 ? m->sc_cap_b + (long)e * NB * 3 : 0;
-    x.sc_r = m->sc_n > 0 ? m->sc_cap_r + (long)e * NB : 0;
+    x.sc_nseg = (m->sc_nseg > 0 && m->sc_segbody) ? m->sc_nseg : NB;
+    x.sc_segbody = (m->sc_nseg > 0) ? m->sc_segbody : 0;
+    x.sc_a = m->sc_n > 0 ? m->sc_cap_a + (long)e * x.sc_nseg * 3 : 0;
+    x.sc_b = m->sc_n > 0 ? m->sc_cap_b + (long)e * x.sc_nseg * 3 : 0;
+    x.sc_r = m->sc_n > 0 ? m->sc_cap_r + (long)e * x.sc_nseg : 0;
     return x;
 }
 
@@ -284,28 +288,31 @@ static float (*g_sc_info)[12] = 0;
 static int g_sc_ninfo = 0;
 
 static void self_contacts(const Env *s, const EnvModel *m, float (*fext)[6]) {
-    float seg[NB][7];
+    /* collision segments: one per body, and a second one for a box much wider than thick (the ankle boxes) */
+    float seg[ORC_SC_MAXSEG][7];
     memset(fext, 0, sizeof(float) * NB * 6);
-    for (int i = 0; i < NB; ++i) {
+    for (int i = 0; i < m->sc_nseg; ++i) {
         float pa[3], pb[3];
-        matvec3(s->R[i], m->sc_a + i * 3, pa); matvec3(s->R[i], m->sc_b + i * 3, pb);
-        for (int k = 0; k < 3; ++k) { seg[i][k] = s->r[i][k] + pa[k]; seg[i][3 + k] = s->r[i][k] + pb[k]; }
+        const int sb = m->sc_segbody ? m->sc_segbody[i] : i;
+        matvec3(s->R[sb], m->sc_a + i * 3, pa); matvec3(s->R[sb], m->sc_b + i * 3, pb);
+        for (int k = 0; k < 3; ++k) { seg[i][k] = s->r[sb][k] + pa[k]; seg[i][3 + k] = s->r[sb][k] + pb[k]; }
         seg[i][6] = m->sc_r[i];
     }
     float hitw[ORC_SC_MAXHITS][6];
     int hitb[ORC_SC_MAXHITS][2], nh = 0;
     for (int q = 0; q < m->sc_n && nh < ORC_SC_MAXHITS; ++q) {
-        const int bi = m->sc_pairs[2 * q], bj = m->sc_pairs[2 * q + 1];
+        const int si = m->sc_pairs[2 * q], sj = m->sc_pairs[2 * q + 1];          /* segments ... */
+        const int bi = m->sc_segbody ? m->sc_segbody[si] : si, bj = m->sc_segbody ? m->sc_segbody[sj] : sj;   /* ... and their bodies */
         float c1[3], c2[3];
-        const float rsum = seg[bi][6] + seg[bj][6];
-        seg_seg_closest(seg[bi], seg[bi] + 3, seg[bj], seg[bj] + 3, c1, c2);
+        const float rsum = seg[si][6] + seg[sj][6];
+        seg_seg_closest(seg[si], seg[si] + 3, seg[sj], seg[sj] + 3, c1, c2);
         const float dv[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
         const float dist2 = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
         if (!(dist2 < rsum * rsum && dist2 > 1e-12f)) continue;
         const float dist = sqrtf(dist2);
         float pen = rsum - dist;
         const float n[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist};
-        const float off = seg[bj][6] - 0.5f * pen;
+        const float off = seg[sj][6] - 0.5f * pen;
         const float pt[3] = {c2[0] + n[0] * off, c2[1] + n[1] * off, c2[2] + n[2] * off};
         float wi[3], wj[3];
         cross3(s->V[bi], pt, wi); cross3(s->V[bj], pt, wj);

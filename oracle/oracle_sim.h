@@ -13,6 +13,7 @@
 #define ORC_NJ 23
 #define ORC_NDOF 69
 #define ORC_SC_MAXHITS 32
+#define ORC_SC_MAXSEG 32
 #define ORC_MAXCAND 96
 #define ORC_MAXC 20
 
@@ -52,8 +53,10 @@ typedef struct {
     /* optional limb-limb penalty contacts (sc_n = 0: off); mirrors EmlocoSelfCollisionDesc */
     int32_t sc_n;
     const uint8_t *sc_pairs;   /* [sc_n][2] */
-    const float *sc_cap_a, *sc_cap_b, *sc_cap_r;   /* [E][24][3|3|1] */
+    const float *sc_cap_a, *sc_cap_b, *sc_cap_r;   /* [E][sc_nseg or 24][3|3|1] */
     float sc_k, sc_c, sc_max_pen, sc_mu;
+    int32_t sc_nseg;           /* collision segments per env (0: 24, segment i on body i); sc_pairs index segments */
+    const uint8_t *sc_segbody; /* [sc_nseg] body of each segment */
     /* optional height-field ground (hf = NULL: the plane z = ground_z); mirrors emloco_sim_set_ground_heightfield */
     const int16_t *hf;         /* [hf_nx][hf_ny] in units of hf_vs metres on an hf_hs-metre grid, sample (0,0) at (hf_ox, hf_oy) */
     int32_t hf_nx, hf_ny;

@@ -65,7 +65,7 @@ def model_desc(arr):
 class SelfCollisionDesc(C.Structure):
     _fields_ = [("n_pairs", C.c_int32), ("pairs", C.POINTER(C.c_uint8)), ("cap_a", C.POINTER(C.c_float)),
                 ("cap_b", C.POINTER(C.c_float)), ("cap_r", C.POINTER(C.c_float)), ("k", C.c_float), ("c", C.c_float),
-                ("max_pen", C.c_float), ("mu", C.c_float)]
+                ("max_pen", C.c_float), ("mu", C.c_float), ("n_seg", C.c_int32), ("seg_body", C.POINTER(C.c_uint8))]
 
 
 def sim_step(osim, n_calls=1, expect_error=None):
@@ -75,7 +75,9 @@ def sim_step(osim, n_calls=1, expect_error=None):
     scd = None
     if sc is not None:
         scd = SelfCollisionDesc(int(sc["pairs"].shape[0]), _p(sc["pairs"], C.c_uint8), _p(sc["cap_a"]), _p(sc["cap_b"]),
-                                _p(sc["cap_r"]), float(sc["k"]), float(sc["c"]), float(sc["max_pen"]), float(sc.get("mu", 1.0)))
+                                _p(sc["cap_r"]), float(sc["k"]), float(sc["c"]), float(sc["max_pen"]), float(sc.get("mu", 1.0)),
+                                int(sc["seg_body"].shape[0]) if sc.get("seg_body") is not None else 0,
+                                _p(sc["seg_body"], C.c_uint8) if sc.get("seg_body") is not None else None)
     lib().emu_sim_set_self_collision(C.byref(scd) if scd is not None else None)
     hf = getattr(osim, "hf", None)
     fn = lib().emu_sim_set_heightfield

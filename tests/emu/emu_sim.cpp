@@ -24,14 +24,16 @@ extern "C" int emu_sim_step(const EmlocoSimParams *prm, const EmlocoModelDesc *m
     EmlocoSimDev d{};
     d.n_env = m->n_env; d.n_cand = t.n_cand; d.max_depth = t.max_depth;
     const bool sc_on = g_sc && g_sc->n_pairs > 0;
-    const std::vector<int32_t> topo = emloco::pack_topology(t, sc_on ? g_sc->pairs : nullptr, sc_on ? g_sc->n_pairs : 0);
+    const int n_seg = (sc_on && g_sc->n_seg > 0 && g_sc->seg_body) ? g_sc->n_seg : EMLOCO_NB;
+    const unsigned char *seg_body = (sc_on && g_sc->n_seg > 0) ? g_sc->seg_body : nullptr;
+    const std::vector<int32_t> topo = emloco::pack_topology(t, sc_on ? g_sc->pairs : nullptr, sc_on ? g_sc->n_pairs : 0, seg_body);
     const std::vector<float> mdl = emloco::pack_models(m->n_env, m->joint_off, m->mass, m->com, m->inertia, m->geom_a, m->geom_b, m->geom_r,
                                                        m->kp, m->kd, m->armature, m->effort, sc_on ? g_sc->cap_a : nullptr,
-                                                       sc_on ? g_sc->cap_b : nullptr, sc_on ? g_sc->cap_r : nullptr);
+                                                       sc_on ? g_sc->cap_b : nullptr, sc_on ? g_sc->cap_r : nullptr, n_seg, seg_body);
     d.topo = topo.data(); d.model = mdl.data();
     d.root_state = root_state; d.dof_state = dof_state; d.pd_target = pd_target;
     d.rb_state = rb_state; d.contact_force = contact_force; d.dof_force = dof_force; d.lambda_ws = lambda_ws;
-    if (sc_on) { d.sc_n = g_sc->n_pairs; d.sc_k = g_sc->k; d.sc_c = g_sc->c; d.sc_max_pen = g_sc->max_pen; d.sc_mu = g_sc->mu; }
+    if (sc_on) { d.sc_nseg = n_seg; d.sc_n = g_sc->n_pairs; d.sc_k = g_sc->k; d.sc_c = g_sc->c; d.sc_max_pen = g_sc->max_pen; d.sc_mu = g_sc->mu; }
     if (g_hf.samples) {
         d.hf = g_hf.samples; d.hf_nx = g_hf.nx; d.hf_ny = g_hf.ny; d.hf_hs = g_hf.hs; d.hf_inv_hs = 1.0f / g_hf.hs; d.hf_vs = g_hf.vs;
         d.hf_ox = g_hf.ox; d.hf_oy = g_hf.oy;

@@ -417,6 +417,43 @@ def test_same_inputs_same_bytes():
     assert a.rb_state.tobytes() == b.rb_state.tobytes()
 
 
+def names_index(m, name):
+    return m.names.index(name)
+
+
+def test_ankle_boxes_collide_with_their_width():
+    """The SMPL ankle boxes are 17 x 9.7 x 4.2 cm: one capsule down the middle (rounds 1-3) leaves 2.8 cm of each side uncovered.
+    Two capsules along the long edges: with the legs adducted so that the two ankle boxes overlap sideways by ~1 cm while their
+    centre lines are still 8.7 cm apart (far more than two 2.1 cm radii), a limb-limb contact between L_Ankle and R_Ankle exists and
+    pushes them apart along y; with the feet a box width + 2 cm apart there is none."""
+    from emloco_amd.model import pack_self_collision
+    m = smpl_humanoid()
+    la, ra = names_index(m, "L_Ankle"), names_index(m, "R_Ankle")
+
+    def foot_contacts(adduct):
+        s = oracle.Sim(pack_models([m]), oracle.default_params(gravity_z=0.0), self_collision=pack_self_collision([m]))
+        s.root_state[0, :3] = [0, 0, 3.0]
+        hl, hr = names_index(m, "L_Hip"), names_index(m, "R_Hip")
+        s.dof_state[0, (hl - 1) * 3 + 0, 0] = -adduct          # hip rotation about x swings the leg sideways
+        s.dof_state[0, (hr - 1) * 3 + 0, 0] = adduct
+        s.fk()
+        rb = s.rb_state[0]
+        gap = abs((rb[la, 1] + m.geom_a[la][1]) - (rb[ra, 1] + m.geom_a[ra][1]))       # centre-line distance of the two boxes (y)
+        return gap, [c for c in s.self_contacts() if {int(c[0]), int(c[1])} == {la, ra}]
+    # find the adduction that brings the box centre lines to ~8.7 cm (boxes are 9.66 cm wide: ~1 cm of overlap)
+    lo, hi = 0.0, 0.3
+    for _ in range(30):
+        mid = 0.5 * (lo + hi)
+        gap, _c = foot_contacts(mid)
+        lo, hi = (mid, hi) if gap > 0.087 else (lo, mid)
+    gap, cont = foot_contacts(hi)
+    assert 0.080 < gap < 0.0875 and len(cont) >= 1
+    n = cont[0][5:8]
+    assert abs(n[1]) > 0.9 and cont[0][8] > 0                  # pushed apart sideways
+    gap0, none = foot_contacts(0.0)
+    assert gap0 > 0.0966 + 0.02 and none == []
+
+
 def test_self_collision_keeps_limbs_apart():
     """Limb-limb penalty contacts (has_self_collision): an arm driven into the trunk is held near the surface instead of
     passing through (with self-collision off the same drive penetrates), and the equal-and-opposite contact wrenches do
@@ -424,7 +461,9 @@ def test_self_collision_keeps_limbs_apart():
     from emloco_amd.model import collision_capsules, pack_self_collision, self_collision_pairs
     m = smpl_humanoid()
     pairs = self_collision_pairs(m)
-    assert len(pairs) == 245 and all(m.parent[j] != i and m.parent[i] != j for i, j in pairs)      # no parent-child pairs
+    sb = collision_capsules(m)[3]                               # 26 segments: one per body + the second capsule of each ankle box
+    assert len(sb) == 26 and list(sb[24:]) == [names_index(m, "L_Ankle"), names_index(m, "R_Ankle")]
+    assert len(pairs) == 286 and all(sb[i] != sb[j] and m.parent[sb[j]] != sb[i] and m.parent[sb[i]] != sb[j] for i, j in pairs)   # no same-body / parent-child pairs
     assert (11, 13) not in set(map(tuple, pairs.tolist()))                                          # Chest-Head: filter bits 192 & 64
     names = m.names
     sh = names.index("L_Shoulder")
@@ -435,7 +474,7 @@ def test_self_collision_keeps_limbs_apart():
         s.pd_target[0, (sh - 1) * 3 + 0] = -2.5                 # drive the left arm (T-pose) down and into the trunk / hip
         p0 = None
         depth = []
-        a, b, r = collision_capsules(m)
+        a, b, r, _sb = collision_capsules(m)
         for k in range(60):
             s.step()
             rb = s.rb_state[0]
