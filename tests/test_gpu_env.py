@@ -62,7 +62,7 @@ def test_reset_then_step_matches_oracle_recompute():
         m.kp = e.actors[0].dof_props["stiffness"].astype(np.float64)
         m.kd = e.actors[0].dof_props["damping"].astype(np.float64)
         ms.append(m)
-    assert task.sim.native._sc["pairs"].shape[0] == 245          # has_self_collision: True (pacer.yaml) reached the simulator
+    assert task.sim.native._sc["pairs"].shape[0] == 286 and task.sim.native._sc["seg_body"].shape[0] == 26    # has_self_collision: True (pacer.yaml) reached the simulator: 26 segments (ankle boxes as two capsules)
     osim = oracle_sim(ms, root0, dof0, tgt, self_collision=task.sim.native._sc, n_sub=4)
     osim.step(1)
     np.testing.assert_array_equal(task._rigid_body_state.view(E, 24, 13).cpu().numpy(), osim.rb_state)   # bit-exact physics
