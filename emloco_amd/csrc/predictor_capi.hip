@@ -158,8 +158,13 @@ int emloco_layernorm_fwd(int rows, int d, float eps, const float *x, const float
 int emloco_layernorm_fwd_save(int rows, int d, float eps, const float *x, const float *res, const float *gamma, const float *beta,
                               float *y, float *mean, float *rstd, float *xr, void *stream) {
     if (rows < 1 || d < 1 || d > 1024 || !x || !gamma || !beta || !y || !mean || !rstd) return pfail(-1, "emloco_layernorm_fwd: bad argument");
-    hipLaunchKernelGGL(emloco::layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       rows, d, eps, x, res, gamma, beta, y, mean, rstd, xr);
+    const bool al16 = (((uintptr_t)x | (uintptr_t)res | (uintptr_t)y | (uintptr_t)xr | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
+    if (d == 128 && al16)            // the predictor's width: two rows per wave, 16-byte accesses (predictor_kernels.hip)
+        hipLaunchKernelGGL(emloco::layernorm_fwd128_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
+                           rows, eps, x, res, gamma, beta, y, mean, rstd, xr);
+    else
+        hipLaunchKernelGGL(emloco::layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           rows, d, eps, x, res, gamma, beta, y, mean, rstd, xr);
     PHIPCHK(hipGetLastError());
     return 0;
 }
@@ -182,8 +187,13 @@ int emloco_layernorm_bwd(int rows, int d, const float *xr, const float *gamma, c
     if (rows < 1 || d < 1 || d > 1024 || !xr || !gamma || !mean || !rstd || !dy || !dxr || !dgamma || !dbeta || !workspace)
         return pfail(-1, "emloco_layernorm_bwd: bad argument (workspace = emloco_layernorm_bwd_workspace(rows, d) floats)");
     const int nblocks = (rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(emloco::layernorm_bwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
-                       rows, d, xr, gamma, mean, rstd, dy, dxr, workspace);
+    const bool al16 = (((uintptr_t)xr | (uintptr_t)dy | (uintptr_t)dxr | (uintptr_t)gamma) & 15) == 0;
+    if (d == 128 && al16)
+        hipLaunchKernelGGL(emloco::layernorm_bwd128_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
+                           rows, xr, gamma, mean, rstd, dy, dxr, workspace);
+    else
+        hipLaunchKernelGGL(emloco::layernorm_bwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
+                           rows, d, xr, gamma, mean, rstd, dy, dxr, workspace);
     PHIPCHK(hipGetLastError());
     emloco::fold_rows(FoldLaunch{(hipStream_t)stream}, nblocks, 2 * d, workspace, dgamma, dbeta, d);
     PHIPCHK(hipGetLastError());
@@ -200,8 +210,11 @@ int emloco_colsum_ex(int m, int n, const float *X, float *out, float *workspace,
     if (m < 1 || n < 1 || !X || !out || !workspace)
         return pfail(-1, "emloco_colsum: bad argument (workspace = emloco_colsum_workspace(m, n) floats)");
     const int cs = emloco::cs_rows_for(m), nparts = (m + cs - 1) / cs;
-    hipLaunchKernelGGL(emloco::colsum_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream, m, n, X, workspace,
-                       (flags & EMLOCO_GEMM_A_BF16MEM) ? 1 : 0, cs);
+    if (!(flags & EMLOCO_GEMM_A_BF16MEM) && n % 4 == 0 && (((uintptr_t)X | (uintptr_t)workspace) & 15) == 0)
+        hipLaunchKernelGGL(emloco::colsum4_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream, m, n, X, workspace, cs);
+    else
+        hipLaunchKernelGGL(emloco::colsum_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream, m, n, X, workspace,
+                           (flags & EMLOCO_GEMM_A_BF16MEM) ? 1 : 0, cs);
     PHIPCHK(hipGetLastError());
     emloco::fold_rows(FoldLaunch{(hipStream_t)stream}, nparts, n, workspace, out, out, n);
     PHIPCHK(hipGetLastError());

@@ -749,6 +749,69 @@ layernorm_bwd_kernel(int rows, int d, const float *xr, const float *gamma, const
     }
 }
 
+// The predictor's width (d = 128): a row is 32 lanes x 16 bytes, so a wave takes TWO rows at a time (one per 32-lane half) with one
+// dwordx4 load per operand, the row sums stay inside a half, and the dgamma / dbeta partials are carried in registers over the wave's
+// rows (the generic kernel above walks a row with 4-byte loads and keeps the partials in LDS: 2 read-modify-writes per element;
+// measured on MI355X at 470 k rows: 263 -> see profiles/r04_jta_step_kernels.txt).  Same partial layout, same fold.
+__device__ __forceinline__ float half_sum(float v) {          // sum over the lane's 32-lane half, in every lane of it
+    v += dpp_mov<0x140>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v);      // the 16-lane row (as wave_sum)
+    return v + __shfl_xor(v, 16);
+}
+__global__ void __launch_bounds__(256)
+layernorm_fwd128_kernel(int rows, float eps, const float *x, const float *res, const float *gamma, const float *beta,
+                        float *y, float *mean, float *rstd, float *xr_out) {
+    const int lane = threadIdx.x & 63, l = lane & 31;
+    const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool on = row < rows;
+    const long rowc = on ? row : (long)rows - 1;
+    f32x4 v = *(const f32x4 *)(x + rowc * 128 + 4 * l);
+    if (res) { const f32x4 r = *(const f32x4 *)(res + rowc * 128 + 4 * l); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    if (xr_out && on) *(f32x4 *)(xr_out + row * 128 + 4 * l) = v;
+    const float mu = half_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 128.0f);
+    const float cx = v.x - mu, cy = v.y - mu, cz = v.z - mu, cw = v.w - mu;
+    const float rs = 1.0f / sqrtf(half_sum((cx * cx + cy * cy) + (cz * cz + cw * cw)) * (1.0f / 128.0f) + eps);
+    if (!on) return;
+    const f32x4 g = *(const f32x4 *)(gamma + 4 * l), b = *(const f32x4 *)(beta + 4 * l);
+    *(f32x4 *)(y + row * 128 + 4 * l) = f32x4{cx * rs * g.x + b.x, cy * rs * g.y + b.y, cz * rs * g.z + b.z, cw * rs * g.w + b.w};
+    if (l == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+__global__ void __launch_bounds__(256)
+layernorm_bwd128_kernel(int rows, const float *xr, const float *gamma, const float *mean, const float *rstd,
+                        const float *dy, float *dxr, float *part /* [nblocks][2][128] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, l = lane & 31;
+    __shared__ float sh_g[8][128], sh_b[8][128];
+    const f32x4 gm = *(const f32x4 *)(gamma + 4 * l);
+    float ag[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ab[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const long r0 = (long)blockIdx.x * LN_ROWS_PER_BLOCK;
+    for (int rr = 2 * w + half; rr < LN_ROWS_PER_BLOCK; rr += 8) {
+        const long row = r0 + rr;
+        const bool on = row < rows;                           // (both halves run the exchanges; a half past the end carries zeros)
+        const long rowc = on ? row : (long)rows - 1;
+        const float mu = mean[rowc], rs = rstd[rowc];
+        const f32x4 dv4 = *(const f32x4 *)(dy + rowc * 128 + 4 * l), xv4 = *(const f32x4 *)(xr + rowc * 128 + 4 * l);
+        const float dv[4] = {dv4.x, dv4.y, dv4.z, dv4.w}, xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, g4[4] = {gm.x, gm.y, gm.z, gm.w};
+        float xh[4], gg[4], s1 = 0.0f, s2 = 0.0f;
+        for (int c = 0; c < 4; ++c) {
+            xh[c] = (xv[c] - mu) * rs;
+            gg[c] = dv[c] * g4[c];
+            s1 += gg[c]; s2 += gg[c] * xh[c];
+            if (on) { ag[c] += dv[c] * xh[c]; ab[c] += dv[c]; }
+        }
+        const float m1 = half_sum(s1) * (1.0f / 128.0f), m2 = half_sum(s2) * (1.0f / 128.0f);
+        if (on) *(f32x4 *)(dxr + row * 128 + 4 * l) = f32x4{rs * (gg[0] - m1 - xh[0] * m2), rs * (gg[1] - m1 - xh[1] * m2),
+                                                               rs * (gg[2] - m1 - xh[2] * m2), rs * (gg[3] - m1 - xh[3] * m2)};
+    }
+    for (int c = 0; c < 4; ++c) { sh_g[2 * w + half][4 * l + c] = ag[c]; sh_b[2 * w + half][4 * l + c] = ab[c]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int j = threadIdx.x;
+        float sg = 0.0f, sb = 0.0f;
+        for (int k = 0; k < 8; ++k) { sg += sh_g[k][j]; sb += sh_b[k][j]; }
+        part[((long)blockIdx.x * 2 + 0) * 128 + j] = sg;
+        part[((long)blockIdx.x * 2 + 1) * 128 + j] = sb;
+    }
+}
+
 // Row folding: out[r][j] = sum of rows [32 r, 32 r + 32) of in[n][w] in ascending order.  Applied level by level
 // (n -> n/32 -> ... -> 1) it reduces per-block partials with a fixed association order and full-chip parallelism
 // (the earlier single-pass reduce walked 14 k partial rows with 128 threads: 3.5 ms).  The last level can split its
@@ -789,6 +852,29 @@ __global__ void colsum_partial_kernel(int m, int n, const float *X, float *part,
     float s = 0.0f;
     for (int r = 0; r < cs_rows && r0 + r < m; ++r) s += ld_act(X, (r0 + r) * n + j, x16);
     part[(long)blockIdx.y * n + j] = s;
+}
+
+// the same for fp32 rows of a multiple of 4 columns (16-byte aligned): 256 threads = 64 column quads x 4 row phases, one dwordx4 load per
+// thread and row; the four phase sums are added in a fixed order through LDS (the q|k|v gradient of the predictor, 470 k x 384: 200 us ->
+// profiles/r04_jta_step_kernels.txt)
+__global__ void __launch_bounds__(256)
+colsum4_partial_kernel(int m, int n, const float *X, float *part, int cs_rows) {
+    __shared__ f32x4 sh[4][64];
+    const int ql = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int j = (blockIdx.x * 64 + ql) * 4;
+    const long r0 = (long)blockIdx.y * cs_rows;
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (j < n)
+        for (int r = ph; r < cs_rows && r0 + r < m; r += 4) {
+            const f32x4 v = *(const f32x4 *)(X + (r0 + r) * n + j);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    sh[ph][ql] = s;
+    __syncthreads();
+    if (ph == 0 && j < n) {
+        const f32x4 a = sh[0][ql], b = sh[1][ql], c = sh[2][ql], d = sh[3][ql];
+        *(f32x4 *)(part + (long)blockIdx.y * n + j) = f32x4{(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
+    }
 }
 
 // act_bwd + bias gradient in one pass: thread j walks 256 rows of column j (coalesced across j), writes dz and leaves the

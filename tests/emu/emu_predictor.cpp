@@ -92,18 +92,36 @@ extern "C" int emu_softmax_bwd(int rows, int cols, float scale, const float *P, 
 }
 extern "C" int emu_layernorm_fwd(int rows, int d, float eps, const float *x, const float *res, const float *g, const float *b,
                                  float *y, float *mean, float *rstd) {
-    emu::launch((unsigned)((rows + 3) / 4), 256, [&] { layernorm_fwd_kernel(rows, d, eps, x, res, g, b, y, mean, rstd, nullptr); });
+    if (d == 128) emu::launch((unsigned)((rows + 7) / 8), 256, [&] { layernorm_fwd128_kernel(rows, eps, x, res, g, b, y, mean, rstd, nullptr); });
+    else emu::launch((unsigned)((rows + 3) / 4), 256, [&] { layernorm_fwd_kernel(rows, d, eps, x, res, g, b, y, mean, rstd, nullptr); });
     return 0;
 }
 extern "C" int emu_layernorm_bwd(int rows, int d, const float *xr, const float *g, const float *mean, const float *rstd,
                                  const float *dy, float *dxr, float *dg, float *db, float *ws) {
     const int nb = (rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
-    emu::launch((unsigned)nb, 256, [&] { layernorm_bwd_kernel(rows, d, xr, g, mean, rstd, dy, dxr, ws); });
+    if (d == 128) emu::launch((unsigned)nb, 256, [&] { layernorm_bwd128_kernel(rows, xr, g, mean, rstd, dy, dxr, ws); });       // (the capi's dispatch)
+    else emu::launch((unsigned)nb, 256, [&] { layernorm_bwd_kernel(rows, d, xr, g, mean, rstd, dy, dxr, ws); });
     fold_rows([&](unsigned gx, unsigned gy, int n, int w, const float *in, float *o0, float *o1, int split) {
         for (unsigned y = 0; y < gy; ++y)
             emu::launch(gx, 256, [&] { blockIdx.y = y; rows_fold_kernel(n, w, in, o0, o1, split); });
         blockIdx.y = 0;
     }, nb, 2 * d, ws, dg, db, d);
+    return 0;
+}
+// column sums as emloco_colsum_ex dispatches them: 16-byte rows of fp32 through the quad kernel, anything else through the scalar one
+extern "C" long emu_colsum_workspace(int m, int n) { const int cs = cs_rows_for(m); return fold_workspace((m + cs - 1) / cs, n); }
+extern "C" int emu_colsum(int m, int n, const float *X, float *out, float *ws, int force_scalar) {
+    const int cs = cs_rows_for(m), np_ = (m + cs - 1) / cs;
+    for (unsigned y = 0; y < (unsigned)np_; ++y) {
+        if (n % 4 == 0 && !force_scalar) emu::launch((unsigned)((n + 255) / 256), 256, [&] { blockIdx.y = y; colsum4_partial_kernel(m, n, X, ws, cs); });
+        else emu::launch((unsigned)((n + 255) / 256), 256, [&] { blockIdx.y = y; colsum_partial_kernel(m, n, X, ws, 0, cs); });
+    }
+    blockIdx.y = 0;
+    fold_rows([&](unsigned gx, unsigned gy, int nn, int w, const float *in, float *o0, float *o1, int split) {
+        for (unsigned y = 0; y < gy; ++y)
+            emu::launch(gx, 256, [&] { blockIdx.y = y; rows_fold_kernel(nn, w, in, o0, o1, split); });
+        blockIdx.y = 0;
+    }, np_, n, ws, out, out, n);
     return 0;
 }
 extern "C" long emu_layernorm_bwd_workspace(int rows, int d) { return fold_workspace((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK, 2L * d); }

@@ -519,28 +519,43 @@ def test_softmax_and_layernorm_kernels():
     lib.emu_softmax_bwd(2, 1100, C.c_float(0.5), P(Pl), P(dPl), P(dSl))
     np.testing.assert_allclose(dSl, 0.5 * Pl * (dPl - (dPl * Pl).sum(1, keepdims=True)), rtol=1e-4, atol=1e-7)
 
-    rows, d = 2130, 128          # 34 row blocks: two fold levels
-    x = rng.normal(size=(rows, d)).astype(np.float32)
-    res = rng.normal(size=(rows, d)).astype(np.float32)
-    gam = rng.normal(size=d).astype(np.float32)
-    bet = rng.normal(size=d).astype(np.float32)
-    y, mean, rstd = np.zeros_like(x), np.zeros(rows, np.float32), np.zeros(rows, np.float32)
-    lib.emu_layernorm_fwd(rows, d, C.c_float(1e-5), P(x), P(res), P(gam), P(bet), P(y), P(mean), P(rstd))
-    xr = (x + res).astype(np.float64)
-    mu, var = xr.mean(1, keepdims=True), xr.var(1, keepdims=True)
-    xh = (xr - mu) / np.sqrt(var + 1e-5)
-    np.testing.assert_allclose(y, xh * gam + bet, rtol=1e-4, atol=1e-5)
-    dy = rng.normal(size=(rows, d)).astype(np.float32)
-    dxr, dg, db = np.zeros_like(x), np.zeros(d, np.float32), np.zeros(d, np.float32)
-    lib.emu_layernorm_bwd_workspace.restype = C.c_long
-    ws = np.zeros(lib.emu_layernorm_bwd_workspace(rows, d), np.float32)
-    xrf = (x + res).astype(np.float32)
-    lib.emu_layernorm_bwd(rows, d, P(xrf), P(gam), P(mean), P(rstd), P(dy), P(dxr), P(dg), P(db), P(ws))
-    gg = dy * gam
-    ref_dx = (gg - gg.mean(1, keepdims=True) - xh * (gg * xh).mean(1, keepdims=True)) / np.sqrt(var + 1e-5)
-    np.testing.assert_allclose(dxr, ref_dx, rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(dg, (dy * xh).sum(0), rtol=1e-4, atol=5e-4)
-    np.testing.assert_allclose(db, dy.sum(0), rtol=1e-4, atol=5e-4)
+    for rows, d in ((2130, 128), (2129, 128), (700, 200)):     # 34 row blocks: two fold levels; d = 128 has its own backward (two rows per wave: odd tail)
+        x = rng.normal  (size=(rows, d)).astype(np.float32)
+        res = rng.normal(size=(rows, d)).astype(np.float32)
+        gam = rng.normal(size=d).astype(np.float32)
+        bet = rng.normal(size=d).astype(np.float32)
+        y, mean, rstd = np.zeros_like(x), np.zeros(rows, np.float32), np.zeros(rows, np.float32)
+        lib.emu_layernorm_fwd(rows, d, C.c_float(1e-5), P(x), P(res), P(gam), P(bet), P(y), P(mean), P(rstd))
+        xr = (x + res).astype(np.float64)
+        mu, var = xr.mean(1, keepdims=True), xr.var(1, keepdims=True)
+        xh = (xr - mu) / np.sqrt(var + 1e-5)
+        np.testing.assert_allclose(y, xh * gam + bet, rtol=1e-4, atol=1e-5)
+        dy = rng.normal(size=(rows, d)).astype(np.float32)
+        dxr, dg, db = np.zeros_like(x), np.zeros(d, np.float32), np.zeros(d, np.float32)
+        lib.emu_layernorm_bwd_workspace.restype = C.c_long
+        ws = np.zeros(lib.emu_layernorm_bwd_workspace(rows, d), np.float32)
+        xrf = (x + res).astype(np.float32)
+        lib.emu_layernorm_bwd(rows, d, P(xrf), P(gam), P(mean), P(rstd), P(dy), P(dxr), P(dg), P(db), P(ws))
+        gg = dy * gam
+        ref_dx = (gg - gg.mean(1, keepdims=True) - xh * (gg * xh).mean(1, keepdims=True)) / np.sqrt(var + 1e-5)
+        np.testing.assert_allclose(dxr, ref_dx, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(dg, (dy * xh).sum(0), rtol=1e-4, atol=5e-4)
+        np.testing.assert_allclose(db, dy.sum(0), rtol=1e-4, atol=5e-4)
+
+
+def test_column_sum_kernels():
+    """Bias gradients: the 16-byte-row kernel (n % 4 == 0) and the scalar one, short (32-row partials) and tall (256-row partials) inputs
+    with ragged tails, against a float64 sum."""
+    lib = emu.lib()
+    lib.emu_colsum_workspace.restype = C.c_long
+    rng = np.random.default_rng(4)
+    for m, n, scalar in ((1000, 384, 0), (1000, 384, 1), (33000, 128, 0), (517, 100, 0), (517, 69, 0), (40, 260, 0)):
+        X = rng.normal(size=(m, n)).astype(np.float32)
+        out = np.zeros(n, np.float32)
+        ws = np.zeros(lib.emu_colsum_workspace(m, n) + 4, np.float32)
+        off = (-ws.ctypes.data // 4) % 4                        # a 16-byte aligned workspace, as torch hands one out
+        lib.emu_colsum(m, n, P(X), P(out), C.c_void_p(ws.ctypes.data + 4 * off), scalar)
+        np.testing.assert_allclose(out, X.astype(np.float64).sum(0), rtol=1e-5, atol=2e-5 * np.sqrt(m), err_msg=f"{m}x{n}")
 
 
 def test_locoval_kernels_match_reference_golden(golden):
