@@ -210,9 +210,11 @@ int emloco_colsum_ex(int m, int n, const float *X, float *out, float *workspace,
     if (m < 1 || n < 1 || !X || !out || !workspace)
         return pfail(-1, "emloco_colsum: bad argument (workspace = emloco_colsum_workspace(m, n) floats)");
     const int cs = emloco::cs_rows_for(m), nparts = (m + cs - 1) / cs;
-    if (!(flags & EMLOCO_GEMM_A_BF16MEM) && n % 4 == 0 && (((uintptr_t)X | (uintptr_t)workspace) & 15) == 0)
-        hipLaunchKernelGGL(emloco::colsum4_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream, m, n, X, workspace, cs);
-    else
+    const bool x16 = (flags & EMLOCO_GEMM_A_BF16MEM) != 0;
+    if (n % 4 == 0 && (((uintptr_t)X | (uintptr_t)workspace) & 15) == 0) {
+        if (x16) hipLaunchKernelGGL(emloco::colsum4_partial_kernel<1>, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream, m, n, X, workspace, cs);
+        else hipLaunchKernelGGL(emloco::colsum4_partial_kernel<0>, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream, m, n, X, workspace, cs);
+    } else
         hipLaunchKernelGGL(emloco::colsum_partial_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nparts), dim3(256), 0, (hipStream_t)stream, m, n, X, workspace,
                            (flags & EMLOCO_GEMM_A_BF16MEM) ? 1 : 0, cs);
     PHIPCHK(hipGetLastError());

@@ -857,6 +857,7 @@ __global__ void colsum_partial_kernel(int m, int n, const float *X, float *part,
 // the same for fp32 rows of a multiple of 4 columns (16-byte aligned): 256 threads = 64 column quads x 4 row phases, one dwordx4 load per
 // thread and row; the four phase sums are added in a fixed order through LDS (the q|k|v gradient of the predictor, 470 k x 384: 200 us ->
 // profiles/r04_jta_step_kernels.txt)
+template <int X16>      // X16: the rows are bf16 in memory (8-byte quads)
 __global__ void __launch_bounds__(256)
 colsum4_partial_kernel(int m, int n, const float *X, float *part, int cs_rows) {
     __shared__ f32x4 sh[4][64];
@@ -866,7 +867,11 @@ colsum4_partial_kernel(int m, int n, const float *X, float *part, int cs_rows) {
     f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
     if (j < n)
         for (int r = ph; r < cs_rows && r0 + r < m; r += 4) {
-            const f32x4 v = *(const f32x4 *)(X + (r0 + r) * n + j);
+            f32x4 v;
+            if constexpr (X16) {
+                const uint2 u = *(const uint2 *)((const unsigned short *)X + (r0 + r) * n + j);
+                v = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+            } else v = *(const f32x4 *)(X + (r0 + r) * n + j);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     sh[ph][ql] = s;

@@ -110,11 +110,13 @@ extern "C" int emu_layernorm_bwd(int rows, int d, const float *xr, const float *
 }
 // column sums as emloco_colsum_ex dispatches them: 16-byte rows of fp32 through the quad kernel, anything else through the scalar one
 extern "C" long emu_colsum_workspace(int m, int n) { const int cs = cs_rows_for(m); return fold_workspace((m + cs - 1) / cs, n); }
-extern "C" int emu_colsum(int m, int n, const float *X, float *out, float *ws, int force_scalar) {
+extern "C" int emu_colsum(int m, int n, const float *X, float *out, float *ws, int force_scalar, int x16) {
     const int cs = cs_rows_for(m), np_ = (m + cs - 1) / cs;
     for (unsigned y = 0; y < (unsigned)np_; ++y) {
-        if (n % 4 == 0 && !force_scalar) emu::launch((unsigned)((n + 255) / 256), 256, [&] { blockIdx.y = y; colsum4_partial_kernel(m, n, X, ws, cs); });
-        else emu::launch((unsigned)((n + 255) / 256), 256, [&] { blockIdx.y = y; colsum_partial_kernel(m, n, X, ws, 0, cs); });
+        if (n % 4 == 0 && !force_scalar) {
+            if (x16) emu::launch((unsigned)((n + 255) / 256), 256, [&] { blockIdx.y = y; colsum4_partial_kernel<1>(m, n, X, ws, cs); });
+            else emu::launch((unsigned)((n + 255) / 256), 256, [&] { blockIdx.y = y; colsum4_partial_kernel<0>(m, n, X, ws, cs); });
+        } else emu::launch((unsigned)((n + 255) / 256), 256, [&] { blockIdx.y = y; colsum_partial_kernel(m, n, X, ws, x16, cs); });
     }
     blockIdx.y = 0;
     fold_rows([&](unsigned gx, unsigned gy, int nn, int w, const float *in, float *o0, float *o1, int split) {

@@ -549,13 +549,19 @@ def test_column_sum_kernels():
     lib = emu.lib()
     lib.emu_colsum_workspace.restype = C.c_long
     rng = np.random.default_rng(4)
-    for m, n, scalar in ((1000, 384, 0), (1000, 384, 1), (33000, 128, 0), (517, 100, 0), (517, 69, 0), (40, 260, 0)):
+    for m, n, scalar, x16 in ((1000, 384, 0, 0), (1000, 384, 1, 0), (33000, 128, 0, 0), (517, 100, 0, 0), (517, 69, 0, 0), (40, 260, 0, 0),
+                              (1000, 384, 0, 1), (517, 384, 1, 1)):
         X = rng.normal(size=(m, n)).astype(np.float32)
+        Xin = X
+        if x16:                                                 # rows of bf16 in memory (the reduced-precision mode's q|k|v gradient)
+            bits = (X.view(np.uint32) >> 16).astype(np.uint16)
+            X = (bits.astype(np.uint32) << 16).view(np.float32)
+            Xin = bits
         out = np.zeros(n, np.float32)
         ws = np.zeros(lib.emu_colsum_workspace(m, n) + 4, np.float32)
         off = (-ws.ctypes.data // 4) % 4                        # a 16-byte aligned workspace, as torch hands one out
-        lib.emu_colsum(m, n, P(X), P(out), C.c_void_p(ws.ctypes.data + 4 * off), scalar)
-        np.testing.assert_allclose(out, X.astype(np.float64).sum(0), rtol=1e-5, atol=2e-5 * np.sqrt(m), err_msg=f"{m}x{n}")
+        lib.emu_colsum(m, n, C.c_void_p(Xin.ctypes.data), P(out), C.c_void_p(ws.ctypes.data + 4 * off), scalar, x16)
+        np.testing.assert_allclose(out, X.astype(np.float64).sum(0), rtol=1e-5, atol=2e-5 * np.sqrt(m), err_msg=f"{m}x{n} x16={x16}")
 
 
 def test_locoval_kernels_match_reference_golden(golden):
