@@ -816,7 +816,7 @@ layernorm_bwd128_kernel(int rows, const float *xr, const float *gamma, const flo
 // (n -> n/32 -> ... -> 1) it reduces per-block partials with a fixed association order and full-chip parallelism
 // (the earlier single-pass reduce walked 14 k partial rows with 128 threads: 3.5 ms).  The last level can split its
 // row into two outputs (dgamma | dbeta).
-#define FOLD 32
+#define FOLD 32      // (64 -- one level less on most reductions -- measured the same: tools/exp/ab_fold.sh)
 __global__ void rows_fold_kernel(int n, int w, const float *in, float *out0, float *out1, int split) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= w) return;
