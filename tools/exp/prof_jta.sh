@@ -1,14 +1,22 @@
 #!/bin/bash
-# per-kernel times of the JTA train step (fp32-class + bf16), top 14 kernels
-mkdir -p gpurun_out/r04
-R=$PWD
-cd /tmp; export TMPDIR=/tmp
-rm -rf /tmp/pj
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pj -- python $R/tools/exp/jta_time.py > /tmp/pj.log 2>&1
-F=$(find /tmp/pj -name '*kernel_stats.csv' | head -1)
-python - "$F" > $R/gpurun_out/r04/jta_kernels_${1:-x}.txt <<PY
-import csv,sys
-for i,r in enumerate(csv.DictReader(open(sys.argv[1]))):
-    if i<60: print(f'{r["Name"][:90]:90s} {r["Calls"]:>6s} {float(r["AverageNs"])/1e3:10.1f} us {r["Percentage"]:>6s} %')
+# per-kernel time of the JTA train step: bash tools/exp/prof_jta.sh <out.txt> [steps]   (run on the GPU box)
+out=${1:-gpurun_out/r02/jta_kernels.txt}; steps=${2:-4}
+R=$(pwd); mkdir -p $(dirname $out)
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_jta
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_jta -- python $R/tools/exp/jta_step.py $steps > /tmp/prof_jta.log 2>&1
+cd $R
+python - "$out" "$steps" <<'PY'
+import csv, glob, sys, re
+out, steps = sys.argv[1], int(sys.argv[2]) + 2
+f = glob.glob('/tmp/prof_jta/**/*kernel_stats.csv', recursive=True)
+rows = list(csv.DictReader(open(f[0])))
+tot = 0.0
+with open(out, 'w') as o:
+    o.write(open('/tmp/prof_jta.log').read()[-300:] + "\n")
+    for r in rows[:40]:
+        ms = float(r['TotalDurationNs']) / 1e6 / steps
+        tot += ms
+        name = re.sub(r'\(.*', '', r['Name'])[:110]
+        o.write(f"{ms:8.2f} ms/step  {int(r['Calls'])//steps:5d} calls  avg {float(r['AverageNs'])/1e3:9.1f} us  {name}\n")
+    o.write(f"total (top 40) {tot:.1f} ms/step\n")
 PY
-cat $R/gpurun_out/r04/jta_kernels_${1:-x}.txt; tail -5 /tmp/pj.log
