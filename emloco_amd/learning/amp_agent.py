@@ -15,6 +15,8 @@ result is identical):  dD/dx = W1^T (m1 o (W2^T (m2 o w3)))  -- three more GEMMs
 Multi-GPU: one flat gradient bucket all-reduced (averaged) per minibatch over RCCL, KL averaged, as the reference does
 with Horovod (amp_continuous.py:436-444, common_agent.py:179-180).
 """
+import contextlib
+import os
 import math
 import time
 
@@ -192,7 +194,6 @@ class AMPAgent:
         # the host needs 40 ms to issue through autograd, torch ops and ctypes.  Captured once (static minibatch buffers, the dropout
         # draw and the shuffled indices filled from the host outside the graph, Adam with device-side step counters) and replayed
         # for the epoch's remaining minibatches and every later epoch.  Single rank only: a gloo all-reduce cannot be captured.
-        import os
         self.use_graph = (self.device.type == "cuda" and os.environ.get("EMLOCO_PPO_GRAPH", "1") != "0")
         self._graph, self._g_in, self._g_u, self._g_acc, self._g_keys = None, None, None, None, None
         self.optimizer = torch.optim.Adam(self.a2c_network.parameters(), float(self.last_lr), eps=1e-08, weight_decay=0.0,
@@ -342,8 +343,9 @@ class AMPAgent:
         if getattr(self, "_sym_idx", None) is None or self._sym_idx.device != flip_obs.device:
             self._sym_idx = torch.as_tensor(self.task.left_to_right_index_action, dtype=torch.long, device=flip_obs.device)   # (an index list would be uploaded every step)
         idx = self._sym_idx
-        flip_a, _ = self.a2c_network.eval_actor(flip_obs)
-        orig_a, _ = self.a2c_network.eval_actor(orig_obs)
+        # (one evaluation of the 2 B stacked rows: the network is row-wise, the GEMMs twice as tall -- amp_continuous.py evaluates twice)
+        both, _ = self.a2c_network.eval_actor(torch.cat([flip_obs, orig_obs], dim=0))
+        flip_a, orig_a = both[:B], both[B:]
         if getattr(self, "_sym_sign", None) is None or self._sym_sign.device != orig_a.device:
             self._sym_sign = torch.tensor([-1.0, 1.0, -1.0], device=orig_a.device)      # (made once: no host-to-device copy in the step)
         orig_a = orig_a.view(B, -1, 3) * self._sym_sign
@@ -360,38 +362,69 @@ class AMPAgent:
         return {"disc_loss": disc_loss, "disc_grad_penalty": grad_penalty.detach(), "disc_logit_loss": logit_loss.detach(),
                 "disc_agent_acc": (disc_agent_logit < 0).float().mean().detach(), "disc_demo_acc": (disc_demo_logit > 0).float().mean().detach()}
 
-    def compute_loss(self, d, dropout_masks=None):
-        """The scalar of calc_gradients (amp_continuous.py:335-425) for one minibatch dict `d`."""
+    def compute_loss(self, d, dropout_masks=None, branch_streams=None):
+        """The scalar of calc_gradients (amp_continuous.py:335-425) for one minibatch dict `d`.
+
+        branch_streams = (critic, discriminator, symmetry-loss stream): the networks are independent until their losses are added -- the
+        critic, the discriminator (three evaluations + the gradient penalty) and the symmetry loss (two more actor evaluations) are
+        issued on streams of their own, forked from and joined to the caller's, and only their scalar losses cross.  Autograd runs a node's backward on the stream of its forward, so
+        the backward passes fork the same way.  A 2 048-row minibatch is 128-256 tiles per GEMM on 256 CUs: one chain leaves half the
+        chip idle, three fill it (inside the captured optimiser step the branches are parallel arms of the graph)."""
         net = self.a2c_network
+        main = torch.cuda.current_stream(self.device) if branch_streams is not None else None
+        s_c, s_d, s_s = branch_streams if branch_streams is not None else (None, None, None)
+
+        def on(stream):
+            if stream is None:
+                return contextlib.nullcontext()
+            stream.wait_stream(main)
+            return torch.cuda.stream(stream)
+
+        if self._amp_dropout and dropout_masks is None:
+            steps = self.task._num_amp_obs_steps
+            dropout_masks = amp_dropout_mask(self._amp_minibatch_size, steps, d["amp_obs"].shape[1] // steps, device=d["amp_obs"].device)
+        if s_d is not None and dropout_masks is not None:
+            dropout_masks.record_stream(s_d)
+        with on(s_d):
+            n_amp = self._amp_minibatch_size
+            amp_obs = self._preproc_amp_obs(d["amp_obs"][0:n_amp])
+            amp_replay = self._preproc_amp_obs(d["amp_obs_replay"][0:n_amp])
+            amp_demo = self._preproc_amp_obs(d["amp_obs_demo"][0:n_amp])
+            m = (lambda i: dropout_masks[..., i]) if dropout_masks is not None else (lambda i: None)
+            mul = lambda x, k: x if k is None else x * k
+            # (agent and replay rows through the discriminator as ONE stacked batch: row-wise network, the loss wants them stacked anyway)
+            disc_agent_replay_logit = net.eval_disc(torch.cat([mul(amp_obs, m(0)), mul(amp_replay, m(1))], dim=0))
+            disc_demo_logit, grad_pen = disc_forward_with_grad_penalty(net, amp_demo, m(2))
+            disc_info = self._disc_loss(disc_agent_replay_logit, disc_demo_logit, grad_pen)
+        s_loss = None
+        if self.motion_sym_loss:                             # (two more actor evaluations)
+            with on(s_s):
+                s_loss = torch.mean(self._sym_loss(self._preproc_obs(d["flip_obs"]), self._preproc_obs(d["next_obses"]))["sym_loss"])
         obs = self._preproc_obs(d["obs"])
-        n_amp = self._amp_minibatch_size
-        amp_obs = self._preproc_amp_obs(d["amp_obs"][0:n_amp])
-        amp_replay = self._preproc_amp_obs(d["amp_obs_replay"][0:n_amp])
-        amp_demo = self._preproc_amp_obs(d["amp_obs_demo"][0:n_amp])
+        if s_c is not None:
+            obs.record_stream(s_c)
+        with on(s_c):
+            values = net.eval_critic(obs)
+            c_info = self._critic_loss(d["old_values"], values, self.e_clip, d["returns"], self.clip_value)
+            c_loss = torch.mean(c_info["critic_loss"])
         mu, logstd = net.eval_actor(obs)
-        values = net.eval_critic(obs)
         sigma = torch.exp(logstd)
         action_log_probs = neglogp(d["actions"], mu, sigma, logstd)
         entropy = (0.5 + 0.5 * math.log(2 * math.pi) + logstd).sum(dim=-1)
-        if self._amp_dropout and dropout_masks is None:
-            steps = self.task._num_amp_obs_steps
-            dropout_masks = amp_dropout_mask(amp_obs.shape[0], steps, amp_obs.shape[1] // steps, device=amp_obs.device)
-        m = (lambda i: dropout_masks[..., i]) if dropout_masks is not None else (lambda i: None)
-        mul = lambda x, k: x if k is None else x * k
-        disc_agent_logit = net.eval_disc(mul(amp_obs, m(0)))
-        disc_replay_logit = net.eval_disc(mul(amp_replay, m(1)))
-        disc_demo_logit, grad_pen = disc_forward_with_grad_penalty(net, amp_demo, m(2))
         a_info = self._actor_loss(d["old_logp_actions"], action_log_probs, d["advantages"], self.e_clip)
-        c_info = self._critic_loss(d["old_values"], values, self.e_clip, d["returns"], self.clip_value)
-        a_loss, c_loss = torch.mean(a_info["actor_loss"]), torch.mean(c_info["critic_loss"])
+        a_loss = torch.mean(a_info["actor_loss"])
         b_loss, entropy = torch.mean(self.bound_loss(mu)), torch.mean(entropy)
-        disc_info = self._disc_loss(torch.cat([disc_agent_logit, disc_replay_logit], dim=0), disc_demo_logit, grad_pen)
+        if branch_streams is not None:
+            # join: what crosses is a handful of scalars (allocated on the branch streams: tell the allocator who else reads them)
+            for st, ts in ((s_c, [c_loss]), (s_d, list(disc_info.values())), (s_s, [s_loss] if s_loss is not None else [])):
+                main.wait_stream(st)
+                for t in ts:
+                    t.record_stream(main)
         loss = a_loss + self.critic_coef * c_loss - self.entropy_coef * entropy + self.bounds_loss_coef * b_loss \
             + self._disc_coef * disc_info["disc_loss"]
         info = {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "entropy": entropy.detach(),
                 "actor_clip_frac": a_info["actor_clipped"].float().mean(), **{k: v.detach() for k, v in disc_info.items()}}
-        if self.motion_sym_loss:
-            s_loss = torch.mean(self._sym_loss(self._preproc_obs(d["flip_obs"]), self._preproc_obs(d["next_obses"]))["sym_loss"])
+        if s_loss is not None:
             loss = loss + s_loss * self.sym_loss_coef
             info["sym_loss"] = s_loss.detach()
         return loss, info, mu.detach(), sigma.detach()
@@ -418,8 +451,8 @@ class AMPAgent:
         masks = None
         if self._amp_dropout:
             masks = amp_dropout_expand(self._g_u, self.task._num_amp_obs_steps)
-        loss, info, mu, sigma = self.compute_loss(d, dropout_masks=masks)
-        self.bucket.zero()
+        self.bucket.zero()                                   # (ahead of the fork: the branches' backward passes write into it)
+        loss, info, mu, sigma = self.compute_loss(d, dropout_masks=masks, branch_streams=self._branch_streams())
         loss.backward()
         if self.truncate_grads:
             nn.utils.clip_grad_norm_(self.a2c_network.parameters(), self.grad_norm)
@@ -432,6 +465,14 @@ class AMPAgent:
                 self._g_acc = torch.zeros(len(self._g_keys), dtype=torch.float32, device=self.device)
             self._g_acc += torch.stack([info[k].float().reshape(()) for k in self._g_keys])
         return info
+
+    def _branch_streams(self):
+        """Streams of the critic / discriminator / symmetry-loss arms of the optimiser step (EMLOCO_PPO_BRANCHES=0: one chain)."""
+        if os.environ.get("EMLOCO_PPO_BRANCHES", "1") == "0":
+            return None
+        if getattr(self, "_g_branch", None) is None:
+            self._g_branch = tuple(torch.cuda.Stream(device=self.device) for _ in range(3))
+        return self._g_branch
 
     def _graph_fill(self, i):
         """Host side of a graphed step: gather minibatch i into the static buffers, draw the AMP dropout uniforms."""
