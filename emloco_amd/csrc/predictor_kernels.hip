@@ -1294,4 +1294,57 @@ __global__ void adamw_gated_kernel(int n, float *p, const float *g, float *m, fl
     p[i] = pi; m[i] = mi; v[i] = vi;
 }
 
+// clip_grad_norm_ + torch.optim.Adam on ONE flat parameter / gradient buffer in three launches (the foreach implementations issue ~25
+// over the predictor's 118 tensors): sum of squares per 4096-element block, the clip coefficient from the partials in a fixed order, the
+// update.  Adam as torch writes it (adam.py, _single_tensor_adam): g += wd * p; m.lerp_(g, 1 - b1); v = b2 v + (1 - b2) g^2;
+// p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps); the clipped gradient is written back as clip_grad_norm_ leaves it.
+#define ADAM_BLOCK 4096
+__global__ void __launch_bounds__(256)
+sumsq_partial_kernel(long n, const float *g, float *part) {
+    __shared__ float sh[4];
+    const long b0 = (long)blockIdx.x * ADAM_BLOCK;
+    float s = 0.0f;
+    for (int k = 0; k < ADAM_BLOCK / 256; ++k) {
+        const long i = b0 + k * 256 + threadIdx.x;
+        const float x = i < n ? g[i] : 0.0f;
+        s += x * x;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+// out[0] = total norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)) (clip_grad_norm_'s); one workgroup, fixed order
+__global__ void __launch_bounds__(256)
+clip_coef_kernel(int nparts, const float *part, float max_norm, float *out) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += (double)part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(sh[0]);
+        const float c = max_norm / (norm + 1e-6f);
+        out[0] = norm; out[1] = c < 1.0f ? c : 1.0f;
+    }
+}
+__global__ void adam_flat_kernel(long n, float *p, float *g, float *m, float *v, const float *coef, float lr, float omb1, float b2, float omb2,
+                                 float eps, float wd, float bc1, float bc2_sqrt) {      // omb = 1 - beta, rounded from the double (as torch passes it)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i];
+    if (coef) { gi *= coef[1]; g[i] = gi; }
+    float pi = p[i];
+    if (wd != 0.0f) gi += wd * pi;
+    const float mi = m[i] + omb1 * (gi - m[i]);
+    const float vi = v[i] * b2 + omb2 * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+    m[i] = mi; v[i] = vi;
+}
+
 }  // namespace emloco

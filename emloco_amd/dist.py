@@ -126,17 +126,24 @@ class FlatGradBucket:
     """One flat fp32 buffer aliased by the .grad of every parameter: a single all-reduce per step.  `extra` appends that many
     scalars behind the gradients (`tail`): loss sums / sample counts that travel in the same collective."""
 
-    def __init__(self, params, extra=0):
+    def __init__(self, params, extra=0, align=1):
+        """align: every parameter's slice starts at a multiple of `align` elements (zeros in between) -- 64 (256 bytes) keeps the
+        16-byte-load kernels usable on views of a flat PARAMETER buffer laid out the same way (predictor/fused_adam.py)."""
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        self.align = int(align)
+        self.offsets = []
+        o = 0
+        for p in self.params:
+            o = -(-o // self.align) * self.align
+            self.offsets.append(o)
+            o += p.numel()
+        n = -(-o // self.align) * self.align
         dev = self.params[0].device
         self.flat = torch.zeros(n + extra, dtype=torch.float32, device=dev)
         self.grads = self.flat[:n]
         self.tail = self.flat[n:]
-        o = 0
-        for p in self.params:
+        for p, o in zip(self.params, self.offsets):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
-            o += p.numel()
 
     def zero(self):
         self.flat.zero_()

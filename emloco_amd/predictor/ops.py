@@ -68,6 +68,9 @@ def _lib():
         lib.emloco_locoval_fit_grad.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_locoval_bwd_rows.argtypes = [ci, vp, ci] + [vp] * 17
         lib.emloco_adamw_gated.argtypes = [ci] + [vp] * 7 + [cf] * 5 + [vp, vp]
+        lib.emloco_adam_clip_flat.argtypes = [C.c_int64] + [vp] * 4 + [cf, C.c_double, C.c_double] + [cf] * 5 + [vp, vp]
+        lib.emloco_adam_clip_flat_workspace.argtypes = [C.c_int64]
+        lib.emloco_adam_clip_flat_workspace.restype = C.c_int64
         lib.emloco_gemm_enable_timing.argtypes = [ci]
         lib.emloco_disc_reward.argtypes = [ci, vp, cf, vp, vp]
         lib.emloco_gemm_timing_stats.argtypes = [C.POINTER(ci), C.POINTER(cf), C.POINTER(C.c_double)]

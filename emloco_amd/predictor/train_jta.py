@@ -5,6 +5,8 @@ dataset_jta.py (batch_process_coords :27-86) and utils/metrics.py (MSE_LOSS / MS
 flow is the reference's; the arithmetic of the model and of the LocoVal loss runs in the HIP kernels behind
 TransMotionJTA / ValuePoseNet.  For data-parallel training `step` all-reduces one flat gradient bucket (RCCL).
 """
+import os
+
 import torch
 
 from ..dist import FlatGradBucket, all_reduce_, barrier, broadcast_parameters, rank, world_size
@@ -146,8 +148,18 @@ class EmLocoTrainer:
                 p.requires_grad_(False)          # the LocoVal weights are frozen while the predictor trains (train_jta.py:197-204)
         if data_parallel:
             broadcast_parameters(model, valuenet)      # replicas start from rank 0's weights (nn.DataParallel has one copy)
-        self.optimizer = torch.optim.Adam(model.parameters(), lr=config["TRAIN"]["lr"])
-        self.bucket = FlatGradBucket(model.parameters()) if data_parallel else None
+        # clip_grad_norm_ + Adam as three launches on flat buffers (fused_adam.py; a torch.optim.Adam in every other respect: same
+        # state dict, same param_groups).  EMLOCO_FLAT_ADAM=0, or parameters that are not on a GPU: torch's own.
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.flat_adam = bool(params) and params[0].device.type == "cuda" and os.environ.get("EMLOCO_FLAT_ADAM", "1") != "0"
+        if self.flat_adam:
+            from .fused_adam import FlatClipAdam
+            self.optimizer = FlatClipAdam(params, lr=config["TRAIN"]["lr"])
+            self.bucket = self.optimizer.bucket                # (also what the data-parallel all-reduce travels in)
+        else:
+            self.bucket = FlatGradBucket(model.parameters()) if data_parallel else None
+            self.optimizer = torch.optim.Adam(model.parameters(), lr=config["TRAIN"]["lr"])
+        self.data_parallel = bool(data_parallel)
 
     # what differs between train_jta.py and train_jrdb.py inside the loop body
     process_coords = staticmethod(batch_process_coords)
@@ -173,7 +185,7 @@ class EmLocoTrainer:
             self.bucket.zero()
         else:
             self.optimizer.zero_grad(set_to_none=True)
-        W = world_size() if self.bucket is not None else 1
+        W = world_size() if self.data_parallel else 1
         in_joints, in_masks, out_joints, out_masks, pm = self.process_coords(joints, masks, padding_mask, cfg, modality_selection, training=True)
         pose, vel = self.primary_state(joints, in_joints)
         # MASK_PADDED_PERSONS (extension, off = the reference): hand the model collate_batch's BOOL mask instead of the float copy
@@ -191,10 +203,13 @@ class EmLocoTrainer:
                 cnt = all_reduce_(cnt.detach().clone())
             loss = loss + vsum / cnt.clamp(min=1.0)
         loss.backward()
-        if self.bucket is not None:
+        if self.data_parallel:
             self.bucket.all_reduce(average=False)
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg["TRAIN"]["max_grad_norm"])
-        self.optimizer.step()
+        if self.flat_adam:
+            self.optimizer.step(max_grad_norm=cfg["TRAIN"]["max_grad_norm"])
+        else:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg["TRAIN"]["max_grad_norm"])
+            self.optimizer.step()
         return loss.detach() * W, mse.detach()
 
 

@@ -262,6 +262,16 @@ int emloco_adamw_gated(int n, float *params, const float *grads, float *exp_avg,
                        float *steps_out, const float *tail2, float lr, float beta1, float beta2, float eps, float weight_decay,
                        double *stats, void *stream);
 
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() (train_jta.py:317-318,411; train_jrdb.py likewise) on ONE
+ * flat fp32 buffer of n parameters with their gradients, first and second moments laid out alike -- three launches (block sums of
+ * squares, the clip coefficient from them in a fixed order, the update) where the foreach implementations issue ~25.  The gradient is
+ * left clipped, as clip_grad_norm_ leaves it; workspace[0] holds the total norm it returns, workspace[1] the coefficient.
+ * bias_correction1 = 1 - beta1^t, bias_correction2_sqrt = sqrt(1 - beta2^t) for the step count t AFTER this step (host arithmetic, as
+ * torch's non-capturable Adam does it); the betas are doubles because torch rounds 1 - beta from the double.  max_norm <= 0: no clipping (workspace may be NULL).  weight_decay is Adam's L2 term. */
+int64_t emloco_adam_clip_flat_workspace(int64_t n);
+int emloco_adam_clip_flat(int64_t n, float *params, float *grads, float *exp_avg, float *exp_avg_sq, float lr, double beta1, double beta2, float eps,
+                          float weight_decay, float bias_correction1, float bias_correction2_sqrt, float max_norm, float *workspace, void *stream);
+
 /* Tile choice of the split mode (EMLOCO_GEMM_SPLIT): -1 (default) picks the 64 x 64 tile for launches whose 128 x 128 grid would
  * leave CUs idle, 0 / 1 force never / always.  Results do not depend on it (an output element's reduction order is the same in both
  * tiles: bit-equal, tests/test_emu_kernels.py); a tuning / A-B knob, also settable through EMLOCO_GEMM_SMALL. */

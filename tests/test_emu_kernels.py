@@ -564,6 +564,35 @@ def test_column_sum_kernels():
         np.testing.assert_allclose(out, X.astype(np.float64).sum(0), rtol=1e-5, atol=2e-5 * np.sqrt(m), err_msg=f"{m}x{n} x16={x16}")
 
 
+def test_flat_clip_adam_kernels_follow_torch():
+    """emloco_adam_clip_flat's three kernels against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam (CPU, single-tensor path) over
+    three steps of a flat vector whose length is not a multiple of the block: parameters, moments, the clipped gradient, the norm."""
+    import torch
+    lib = emu.lib()
+    rng = np.random.default_rng(8)
+    n, lr, b1, b2, eps, wd, max_norm = 9001, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0.7
+    p0 = rng.normal(size=n).astype(np.float32)
+    p, m, v = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    ws = np.zeros(n // 4096 + 4, np.float32)
+    tp = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([tp], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, foreach=False)
+    for t in range(1, 4):
+        g = (rng.normal(size=n) * (3.0 if t != 2 else 1e-3)).astype(np.float32)        # step 2: under the bound, coefficient 1
+        tp.grad = torch.from_numpy(g.copy())
+        norm = torch.nn.utils.clip_grad_norm_([tp], max_norm)
+        opt.step()
+        gk = g.copy()
+        lib.emu_adam_clip_flat(C.c_long(n), P(p), P(gk), P(m), P(v), C.c_float(lr), C.c_double(b1), C.c_double(b2), C.c_float(eps), C.c_float(wd),
+                               C.c_float(1 - b1 ** t), C.c_float(np.sqrt(1 - b2 ** t)), C.c_float(max_norm), P(ws))
+        np.testing.assert_allclose(ws[0], float(norm), rtol=2e-6)
+        np.testing.assert_allclose(gk, tp.grad.numpy(), rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(p, tp.detach().numpy(), rtol=1e-6, atol=2e-7)
+        st = opt.state[tp]
+        np.testing.assert_allclose(m, st["exp_avg"].numpy(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(v, st["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-12)
+    assert np.abs(p - p0).max() > 1e-3
+
+
 def test_locoval_kernels_match_reference_golden(golden):
     """Forward value, EmLoco loss gradient w.r.t. the predicted trajectory and all six parameter gradients."""
     g = golden("locoval")

@@ -919,3 +919,58 @@ def test_shipped_depth_model_in_the_bf16_mode_is_within_its_bar(golden):
         ops.set_matmul_precision(ops.DEFAULT_PRECISION)
     again = model(in_joints.clone(), pm.clone()).detach()
     assert torch.equal(ref, again)
+
+
+@pytest.mark.gpu
+def test_flat_clip_adam_is_torch_adam_with_clip_grad_norm_and_trades_state_dicts():
+    """FlatClipAdam (three launches on flat buffers) against clip_grad_norm_ + torch.optim.Adam on a copy of the predictor: parameters
+    after four steps, the reported norm; then its state dict loaded into a fresh torch Adam and back -- both continue identically."""
+    import copy
+    from emloco_amd.predictor.fused_adam import FlatClipAdam
+    from emloco_amd.predictor.model_jta import TransMotionJTA
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    ma = TransMotionJTA(tok_dim=453, nhid=32, nhead=4, dim_feedfwd=64, nlayers_local=2, nlayers_global=1, output_scale=1,
+                        obs_and_pred=21, num_tokens=49, device=dev, dropout=0.0).to(dev)
+    mb = copy.deepcopy(ma)
+    oa = FlatClipAdam(ma.parameters(), lr=3e-3)
+    ob = torch.optim.Adam(mb.parameters(), lr=3e-3)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+
+    def fake_grads(scale):
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            g = torch.randn(pa.shape, device=dev, generator=gen) * scale
+            pa.grad.copy_(g)
+            pb.grad = g.clone()
+
+    def both_step(scale, oa, ob):
+        fake_grads(scale)
+        norm = torch.nn.utils.clip_grad_norm_(mb.parameters(), 1.0)
+        ob.step()
+        oa.step(max_grad_norm=1.0)
+        assert abs(float(oa.last_norm) - float(norm)) <= 2e-6 * float(norm)
+
+    def same():
+        for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+            d = (pa - pb).abs().max().item()
+            assert d <= 2e-6 * max(pb.abs().max().item(), 1e-3) + 1e-7, f"{k}: {d:.3e}"
+
+    for s in (1.0, 1e-4, 0.3, 1.0):
+        both_step(s, oa, ob)
+    same()
+    # torch's Adam continues from the flat optimiser's state dict, the flat optimiser from torch's
+    ob2 = torch.optim.Adam(mb.parameters(), lr=3e-3)
+    ob2.load_state_dict(copy.deepcopy(oa.state_dict()))
+    oa2 = FlatClipAdam(ma.parameters(), lr=3e-3)
+    oa2.load_state_dict(copy.deepcopy(ob.state_dict()))
+    for s in (0.5, 1.0):
+        both_step(s, oa2, ob2)
+    same()
+    sd = oa2.state_dict()
+    assert sorted(sd) == ["param_groups", "state"] and sorted(sd["state"][0]) == ["exp_avg", "exp_avg_sq", "step"]
+    # a dropped alias is an error, not a silently skipped parameter
+    oa2.zero_grad()
+    next(ma.parameters()).grad = torch.zeros_like(next(ma.parameters()))
+    with pytest.raises(RuntimeError, match="no longer aliases"):
+        oa2.step()
