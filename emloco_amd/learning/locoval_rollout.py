@@ -138,8 +138,19 @@ class LocoValRollout:
             task.attach_returns(self._fstep if self._returns_in_flags else None, before=self._before_flags)      # (None: a hook an earlier loop left behind goes)
         self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("EMLOCO_FIT_PRIORITY", "0"))) if (self.overlap_fit and torch.device(dev).type == "cuda") else None
         self._ev_staged = torch.cuda.Event() if self._side is not None else None
-        self._ev_fit = torch.cuda.Event() if self._side is not None else None
-        self._fit_pending = False
+        # The staging buffers the returns launch writes and the fit reads are a RING of `EMLOCO_FIT_BUFFERS` sets (default 4): step t
+        # writes set t mod 4, which the fit of step t - 4 has long read.  That a set is free is then checked by the HOST (a wait on the
+        # event of a fit issued four steps ago: it has completed, the call returns at once; it only ever blocks a host that has run four
+        # steps ahead of the GPU) instead of by a wait packet on the main stream behind the rigid-body launch: the gap between that
+        # launch and the flags launch shrinks from 11 to 6 us (profiles/r04_env_step_trace.txt), 0.4580 -> 0.4545 ms per step, same bytes.
+        # 1 = one set and the stream-side wait.  (The other packet of the hand-shake -- the event the fit's stream waits for -- stays:
+        # replacing it by a counter the flags launch publishes + hipStreamWaitValue64 on the fit's stream works and is 80 us SLOWER.)
+        self._nbuf = max(1, int(os.environ.get("EMLOCO_FIT_BUFFERS", "4"))) if self._side is not None else 1
+        stage_keys = ("traj13", "pose", "vel", "target", "weight")
+        self._stage = [{k: (z[k] if i == 0 else torch.zeros_like(z[k])) for k in stage_keys} for i in range(self._nbuf)]
+        self._ev_fits = [torch.cuda.Event() for _ in range(self._nbuf)] if self._side is not None else []
+        self._buf_busy = [False] * self._nbuf             # a fit that reads the set has been issued (its event recorded)
+        self._buf = 0                                      # the set the next returns launch writes
         # The discriminator off the chain between two rigid-body steps.  Its style reward (amp_continuous_value.py:90-96) feeds the
         # return bookkeeping only -- not the action, not the resets -- but in the reference's order it sits between env.step and the
         # next env_reset: 3 GEMMs (30 GFLOP at 4096 envs, ~0.26 ms) every step.  Deferred mode: the task's flags launch STAGES the
@@ -160,8 +171,10 @@ class LocoValRollout:
             # a GEMM workgroup beside it takes residency away from it, the pipes do not overlap for free; off by default)
             self._disc_under_physics = os.environ.get("EMLOCO_DISC_UNDER_PHYSICS", "0") == "1"
             self._disc_pending = False
-            z["staged_reward"] = f(E)
-            z["staged_done"] = torch.zeros(E, dtype=torch.uint8, device=dev)
+            for i, st_ in enumerate(self._stage):          # the staged reward / done flag travel with the set
+                st_["staged_reward"] = f(E)
+                st_["staged_done"] = torch.zeros(E, dtype=torch.uint8, device=dev)
+            z["staged_reward"], z["staged_done"] = self._stage[0]["staged_reward"], self._stage[0]["staged_done"]
             self._fstep.staged_reward, self._fstep.staged_done = p(z["staged_reward"]), p(z["staged_done"])
             task.attach_returns(self._fstep, before=self._before_flags)
             self._returns_in_flags = True
@@ -183,6 +196,30 @@ class LocoValRollout:
             self._fused_ptrs = ptrs
         elif ptrs != self._fused_ptrs:
             raise RuntimeError("LocoValRollout: the task re-allocated waypoint_traj / init_pose / init_vel after the fused step took their addresses")
+
+    def _acquire_stage(self):
+        """Make the staging set of the coming returns launch current (struct pointers + the arrays the fit launches read) once the
+        fit that last read it is done: the host waits on that fit's event (ring of sets), or the main stream does (one set)."""
+        if self._side is None:
+            return
+        k = self._buf
+        if self._buf_busy[k]:
+            if self._nbuf > 1:
+                self._ev_fits[k].synchronize()
+            else:
+                self._ev_fits[k].wait(torch.cuda.current_stream(self.device))
+        if self._nbuf > 1:
+            st_, s, z = self._stage[k], self._fstep, self._fz
+            for name, t in st_.items():
+                z[name] = t
+                setattr(s, name, t.data_ptr())
+
+    def _fit_issued(self):
+        """The fit that reads the current staging set has been issued on the side stream: record its event, move to the next set."""
+        k = self._buf
+        self._ev_fits[k].record(self._side)
+        self._buf_busy[k] = True
+        self._buf = (k + 1) % self._nbuf
 
     def _sync_fit(self):
         """Host-side readers of what the fit writes (statistics, LocoVal weights) wait for the side stream."""
@@ -208,8 +245,7 @@ class LocoValRollout:
         if getattr(self.task, "_returns_in_flags", False) and amp_rewards is None:
             self.task._returns_in_flags = False             # this step's flags launch has advanced the returns (_before_step waited for the fit)
         else:
-            if self._side is not None and self._fit_pending:
-                main.wait_event(self._ev_fit)               # the previous fit is done with the staging buffers
+            self._acquire_stage()                           # the fit that last read this staging set is done with it
             ops._chk(lib.emloco_locoval_returns(C.byref(s), P(rewards.contiguous()), P(amp_rewards), P(dones.contiguous()), P(inverted.contiguous()), st),
                      "emloco_locoval_returns")
             if s.staged_reward:                             # a step that carries staging arrays was only staged by that call
@@ -221,8 +257,7 @@ class LocoValRollout:
         self._side.wait_event(self._ev_staged)
         with torch.cuda.stream(self._side):
             self._fit_launches(current_stream_handle(self.device))
-            self._ev_fit.record(self._side)
-        self._fit_pending = True
+            self._fit_issued()
 
     def _fit_launches(self, st):
         import ctypes as C
@@ -300,7 +335,7 @@ class LocoValRollout:
     def _deferred_disc_step(self, amp_obs):
         """The step's flags launch has staged the return bookkeeping (after waiting for the previous fit: `_before_flags`).  Main stream:
         one launch that reads the AMP observations; side stream: discriminator GEMMs, reward transform, the bookkeeping's second half,
-        the fit.  Nothing the side stream reads is written by the main stream before the next flags launch, which waits for `_ev_fit`.
+        the fit.  Nothing the side stream reads is written by the main stream before the next flags launch, whose staging set is free (`_acquire_stage`).
         WHEN the side stream's work is issued decides what it runs beside: issued here it competes with the next step's policy GEMMs for
         the matrix pipes (the resets' small launches aside); issued right ahead of the next rigid-body launch (`_disc_under_physics`,
         from `_before_step`) it runs beside a kernel that is bound by the vector pipe."""
@@ -328,8 +363,7 @@ class LocoValRollout:
             ops._chk(ops._lib().emloco_locoval_returns_finish(C.byref(self._fstep), C.c_void_p(amp_rewards.data_ptr()), st),
                      "emloco_locoval_returns_finish")
             self._fit_launches(st)
-            self._ev_fit.record(self._side)
-        self._fit_pending = True
+            self._fit_issued()
 
     def detach(self):
         """Take this loop's return bookkeeping out of the task's flags launch (a caller that steps the env on its own in between)."""
@@ -343,10 +377,9 @@ class LocoValRollout:
             self.task.attach_returns(self._fstep, before=self._before_flags)
 
     def _before_flags(self):
-        """Runs right ahead of the task's flags launch when that launch carries the return bookkeeping: the previous fit must have read
-        the staging buffers the launch is about to overwrite (a wait that sits behind the rigid-body launch never blocks)."""
-        if self._side is not None and self._fit_pending:
-            torch.cuda.current_stream(self.device).wait_event(self._ev_fit)
+        """Runs right ahead of the task's flags launch when that launch carries the return bookkeeping: the fit that last read the
+        staging set the launch is about to overwrite must be done (`_acquire_stage`)."""
+        self._acquire_stage()
 
     def _before_step(self):
         """With the return bookkeeping inside the task's flags launch: what _fused_step does ahead of its own returns launch -- the
