@@ -64,7 +64,7 @@ class TaskBufs(C.Structure):
                 ("dof_subset", C.c_void_p),
                 ("progress_buf", C.c_void_p), ("reset_buf", C.c_void_p), ("terminate_buf", C.c_void_p),
                 ("obs_buf", C.c_void_p), ("flip_obs_buf", C.c_void_p), ("rew_buf", C.c_void_p),
-                ("reward_raw", C.c_void_p), ("amp_obs_buf", C.c_void_p)]
+                ("reward_raw", C.c_void_p), ("amp_obs_buf", C.c_void_p), ("amp_ring", C.c_int32)]
 
 
 class ResetBufs(C.Structure):
@@ -83,7 +83,7 @@ class ResetBufs(C.Structure):
                 ("progress_buf", C.c_void_p), ("reset_buf", C.c_void_p), ("terminate_buf", C.c_void_p),
                 ("waypoint_traj", C.c_void_p), ("init_pose", C.c_void_p), ("init_vel", C.c_void_p),
                 ("amp_obs_buf", C.c_void_p), ("motion_ids", C.c_void_p), ("motion_times", C.c_void_p), ("ground_h", C.c_void_p),
-                ("real_pick", C.c_void_p), ("real_pick_key", C.c_uint32)]
+                ("real_pick", C.c_void_p), ("real_pick_key", C.c_uint32), ("amp_ring", C.c_int32)]
 
 
 RESET_RND = 512

@@ -435,7 +435,8 @@ __device__ __forceinline__ void reset_amp_history_row_to(const EmlocoResetBufs &
     amp_row(lane, sh_root, sh_root + 3, sh_root + 7, sh_root + 10, sh_dp, sh_dv, 1, sh_key, betas, t.dof_subset, t.n_dof_subset, out);
 }
 __device__ __forceinline__ void reset_amp_history_row(const EmlocoResetBufs &t, int env, int k, int mid, float mt, int lane, float *sm) {
-    reset_amp_history_row_to(t, t.betas + (long)env * 17, t.amp_obs_buf + ((long)env * EMLOCO_AMP_STEPS + k) * EMLOCO_AMP_ROW, k, mid, mt, lane, sm);
+    reset_amp_history_row_to(t, t.betas + (long)env * 17, t.amp_obs_buf + ((long)env * EMLOCO_AMP_STEPS + EMLOCO_AMP_PHYS_ROW(t.amp_ring, k)) * EMLOCO_AMP_ROW,
+                             k, mid, mt, lane, sm);
 }
 
 __global__ void __launch_bounds__(64)

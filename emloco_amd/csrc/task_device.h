@@ -315,7 +315,7 @@ __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mo
 
     if (mode & (EMLOCO_POST_AMP_SHIFT | EMLOCO_POST_AMP_ROW)) {
         float *amp = t.amp_obs_buf + (long)env * EMLOCO_AMP_STEPS * EMLOCO_AMP_ROW;
-        if (mode & EMLOCO_POST_AMP_SHIFT) {
+        if ((mode & EMLOCO_POST_AMP_SHIFT) && !t.amp_ring) {         // (ring: the caller moved the head, nothing is copied)
             // rows 0..13 -> rows 1..14; every lane first loads all of its elements, then stores
             constexpr int NEL = (EMLOCO_AMP_STEPS - 1) * EMLOCO_AMP_ROW;
             constexpr int PER = (NEL + 63) / 64;
@@ -329,7 +329,8 @@ __device__ __forceinline__ void post_physics_env(const EmlocoTaskBufs &t, int mo
             if (lane < 4) for (int k = 0; k < 3; ++k) sh_key[lane][k] = sh_body[t.key_bodies[lane]][k];
             __syncthreads();
             const float *ds = t.dof_state + (long)env * TNDOF * 2;
-            amp_row(lane, root, root + 3, root + 7, root + 10, ds, ds + 1, 2, &sh_key[0][0], t.betas + (long)env * 17, t.dof_subset, t.n_dof_subset, amp);
+            amp_row(lane, root, root + 3, root + 7, root + 10, ds, ds + 1, 2, &sh_key[0][0], t.betas + (long)env * 17, t.dof_subset, t.n_dof_subset,
+                    amp + EMLOCO_AMP_PHYS_ROW(t.amp_ring, 0) * EMLOCO_AMP_ROW);
         }
     }
     PPSTAMP(7);

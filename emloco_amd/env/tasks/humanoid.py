@@ -404,6 +404,8 @@ class Humanoid(BaseTask):
     def _launch_post(self, mode, env_ids=None):
         if self._post_bufs is None:
             self._post_bufs = self._make_post_bufs()
+            if hasattr(self, "_amp_ring_to_bufs"):
+                self._amp_ring_to_bufs()
         if (self._returns_hook is not None and env_ids is None and (mode & L.POST_REWARD) and (mode & L.POST_RESET)
                 and not (mode & L.POST_SKIP_DONE)):
             if getattr(self, "_returns_before", None) is not None:

@@ -119,9 +119,51 @@ class HumanoidAMP(Humanoid):
         return super()._post_mode_step() | L.POST_AMP_SHIFT | L.POST_AMP_ROW
 
     def post_physics_step(self):                                  # humanoid_amp.py:139-157
+        if self.amp_ring:
+            self._amp_head = (self._amp_head + self._num_amp_obs_steps - 1) % self._num_amp_obs_steps      # the step's "shift"
+            self._amp_ring_to_bufs()
         super().post_physics_step()
-        self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.get_num_amp_obs())
+        # (ring: the physical buffer is not the reference's layout -- who reads the AMP observations asks amp_obs_logical())
+        self.extras["amp_obs"] = None if self.amp_ring else self._amp_obs_buf.view(-1, self.get_num_amp_obs())
         return
+
+    # The AMP history as a RING (opt-in, for a loop that does not read every step's AMP observations as one tensor): the reference
+    # shifts rows 0..13 of every env to 1..14 each step (humanoid_amp.py:585-594) -- 23 KB of the ~38 KB an env-step moves.  With the
+    # ring the row the reference calls k lives in physical row (head + k) % 15 of `_amp_obs_buf`, a step moves `head` back by one and
+    # writes only the newest row (EmlocoTaskBufs.amp_ring); `amp_obs_logical()` is the reference's tensor, built on demand.
+    amp_ring = False
+    _amp_head = 0
+
+    def enable_amp_ring(self, on=True):
+        on = bool(on)
+        if on == self.amp_ring:
+            return
+        if on and (torch.device(self.device).type != "cuda" or not getattr(self, "_fused_reset", False)):
+            raise RuntimeError("amp ring: needs the fused device step / reset kernels (a CUDA device, fused_reset)")
+        if not on:                                   # back to the reference's layout, in place
+            self._amp_obs_buf.copy_(self.amp_obs_logical().view_as(self._amp_obs_buf))
+        self._amp_head = 0                           # (switching on: physical = logical at head 0, nothing moves)
+        self.amp_ring = on
+        self._amp_ring_to_bufs()
+        if not on:
+            self.extras["amp_obs"] = self._amp_obs_buf.view(-1, self.get_num_amp_obs())
+
+    def _amp_ring_to_bufs(self):
+        v = (1 + self._amp_head) if self.amp_ring else 0
+        for name in ("_post_bufs", "_reset_bufs", "_reset_bufs_noamp"):
+            b = getattr(self, name, None)
+            if b is not None:
+                b.amp_ring = v
+
+    def amp_obs_logical(self):
+        """(num_envs, 15 * 206) AMP observations in the reference's order (newest first), whatever the physical layout."""
+        if not self.amp_ring or self._amp_head == 0:
+            return self._amp_obs_buf.view(-1, self.get_num_amp_obs())
+        return torch.roll(self._amp_obs_buf, shifts=-self._amp_head, dims=1).reshape(-1, self.get_num_amp_obs())
+
+    def _amp_rows_phys(self, first, count):
+        """physical rows of the logical rows first .. first + count - 1 (a LongTensor for index assignment)"""
+        return (torch.arange(first, first + count, device=self.device) + (self._amp_head if self.amp_ring else 0)) % self._num_amp_obs_steps
 
     def get_num_amp_obs(self):
         return self._num_amp_obs_steps * self._num_amp_obs_per_step
@@ -240,6 +282,11 @@ class HumanoidAMP(Humanoid):
         return
 
     def _init_amp_obs_default(self, env_ids):
+        if self.amp_ring:
+            ids = torch.as_tensor(env_ids, device=self.device).long()
+            cur = self._amp_obs_buf[ids, self._amp_rows_phys(0, 1)[0]]
+            self._amp_obs_buf[ids.unsqueeze(1), self._amp_rows_phys(1, self._num_amp_obs_steps - 1).unsqueeze(0)] = cur.unsqueeze(1)
+            return
         self._hist_amp_obs_buf[env_ids] = self._curr_amp_obs_buf[env_ids].unsqueeze(-2)
         return
 
@@ -251,6 +298,10 @@ class HumanoidAMP(Humanoid):
         mtimes = (motion_times.unsqueeze(-1) + steps).view(-1)
         betas = self.humanoid_betas[env_ids].unsqueeze(1).expand(-1, n, -1).reshape(-1, 17)
         rows = self._amp_rows_from_motion(mids, mtimes, betas)
+        if self.amp_ring:
+            ids = torch.as_tensor(env_ids, device=self.device).long()
+            self._amp_obs_buf[ids.unsqueeze(1), self._amp_rows_phys(1, n).unsqueeze(0)] = rows.view(len(env_ids), n, self._num_amp_obs_per_step)
+            return
         self._hist_amp_obs_buf[env_ids] = rows.view(len(env_ids), n, self._num_amp_obs_per_step)
         return
 

@@ -183,6 +183,8 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
         from ...sim import current_stream_handle
         if self._reset_bufs is None:
             self._reset_bufs = self._make_reset_bufs()
+            if hasattr(self, "_amp_ring_to_bufs"):
+                self._amp_ring_to_bufs()
         n = int(env_ids.numel())
         ids32 = self._humanoid_actor_ids[env_ids.to(self.device)].contiguous()
         if rnd is None:
@@ -212,6 +214,8 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
             return
         if self._reset_bufs is None:
             self._reset_bufs = self._make_reset_bufs()
+            if hasattr(self, "_amp_ring_to_bufs"):
+                self._amp_ring_to_bufs()
         E = self.num_envs
         if getattr(self, "_done_ids", None) is None:
             self._done_ids = torch.full((E + 1,), -1, dtype=torch.int32, device=self.device)
@@ -293,6 +297,7 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
                 self._reset_bufs_noamp = type(bufs).from_buffer_copy(bufs)
                 self._reset_bufs_noamp.flags |= L.RESET_NO_AMP_HISTORY
                 self._ev_rs_state = torch.cuda.Event()
+            self._reset_bufs_noamp.amp_ring = bufs.amp_ring
             bufs = self._reset_bufs_noamp
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             st = current_stream_handle(dev)
@@ -377,6 +382,8 @@ class HumanoidPedestrianTerrain(humanoid_traj.HumanoidTraj):
 
     def _ensure_post_bufs(self):
         self._post_bufs = self._make_post_bufs()
+        if hasattr(self, "_amp_ring_to_bufs"):
+            self._amp_ring_to_bufs()
         return self._post_bufs
 
     def _reset_envs(self, env_ids):

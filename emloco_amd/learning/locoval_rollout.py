@@ -87,6 +87,13 @@ class LocoValRollout:
                 # with the reset chain off the caller's stream the observation launch has nothing to hide behind: on a side
                 # stream it costs two cross-stream hand-overs (~13 us each, measured) around a 50 us launch the loop waits for
                 self.task.overlap_obs = os.environ.get("EMLOCO_OVERLAP_OBS", "0") == "1"
+        # Nobody in this loop reads the AMP observations when there is no discriminator: the task keeps their history as a ring
+        # (HumanoidAMP.enable_amp_ring: no 23 KB / env shift per step; `task.amp_obs_logical()` still gives the reference's tensor;
+        # detach() hands the task back in the reference's layout).  EMLOCO_AMP_RING=0: the shifted layout.
+        self._amp_ring = (self._no_disc and getattr(self.task, "fused_chain", False) and hasattr(self.task, "enable_amp_ring")
+                          and self.device.type == "cuda" and os.environ.get("EMLOCO_AMP_RING", "1") != "0")
+        if self._amp_ring:
+            self.task.enable_amp_ring(True)
         self.fused = (isinstance(self.valuenet, ValuePoseNet) and self.device.type == "cuda") if fused is None else bool(fused)
         if not self.fused and type(self)._bookkeeping is LocoValRollout._bookkeeping:
             raise RuntimeError("LocoValRollout runs its bookkeeping and fit as HIP kernels: it needs libemloco_hip.so, a gfx950 device "
@@ -371,10 +378,14 @@ class LocoValRollout:
             self._issue_deferred_disc()
         if getattr(self, "_returns_in_flags", False) and hasattr(self.task, "attach_returns"):
             self.task.attach_returns(None)
+        if getattr(self, "_amp_ring", False):
+            self.task.enable_amp_ring(False)
 
     def attach(self):
         if getattr(self, "_returns_in_flags", False) and hasattr(self.task, "attach_returns"):
             self.task.attach_returns(self._fstep, before=self._before_flags)
+        if getattr(self, "_amp_ring", False):
+            self.task.enable_amp_ring(True)
 
     def _before_flags(self):
         """Runs right ahead of the task's flags launch when that launch carries the return bookkeeping: the fit that last read the

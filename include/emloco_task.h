@@ -82,7 +82,13 @@ typedef struct {
     float *rew_buf;                 /* [E] */
     float *reward_raw;              /* [E][2] */
     float *amp_obs_buf;             /* [E][15][206], index 0 = newest */
+    /* 0: amp_obs_buf is the reference's layout (humanoid_amp.py:585-594): EMLOCO_POST_AMP_SHIFT moves rows 0..13 to 1..14 every step
+     * -- 23 KB of the ~38 KB an env-step moves.  1 + h: amp_obs_buf is a RING: the row the reference calls k lives in physical row
+     * (h + k) % 15, EMLOCO_POST_AMP_SHIFT is a no-op and EMLOCO_POST_AMP_ROW writes physical row h.  The caller moves h back by one
+     * (h <- (h + 14) % 15) once per step, ahead of that step's launches, and hands the same value to EmlocoResetBufs.amp_ring. */
+    int32_t amp_ring;
 } EmlocoTaskBufs;
+#define EMLOCO_AMP_PHYS_ROW(amp_ring, k) ((amp_ring) ? ((amp_ring) - 1 + (k)) % EMLOCO_AMP_STEPS : (k))
 
 /* post_physics_step for all envs (dev_env_ids == NULL) or for the listed envs
  * (_compute_observations(env_ids) on reset, humanoid.py:459-465). */
@@ -176,6 +182,7 @@ typedef struct {
      * real_pick (device, [n] rows, optional) replaces the permutation by explicit rows */
     const int32_t *real_pick;
     uint32_t real_pick_key;
+    int32_t amp_ring;               /* as EmlocoTaskBufs.amp_ring: where the back-filled history rows 1..14 go */
 } EmlocoResetBufs;
 
 struct EmlocoSim;

@@ -875,3 +875,46 @@ def test_amp_agent_optimiser_step_as_a_hip_graph_equals_the_eager_step(monkeypat
     assert torch.allclose(m0, m1, rtol=1e-9, atol=1e-9) and torch.allclose(v0, v1, rtol=1e-9, atol=1e-9)
     for k in ("actor_loss", "critic_loss", "disc_loss", "kl", "b_loss"):
         assert abs(i0[k] - i1[k]) <= 2e-3 * abs(i0[k]) + 1e-5, (k, i0[k], i1[k])
+
+
+@pytest.mark.gpu
+def test_amp_history_as_a_ring_holds_the_reference_layout_on_demand(monkeypatch):
+    """The AMP history as a ring (HumanoidAMP.enable_amp_ring: the step moves a head instead of 14 rows per env; LocoValRollout without
+    a discriminator switches it on) against the shifted layout (EMLOCO_AMP_RING=0): same seeds, 40 steps with natural resets -- the
+    reference's (E, 15 x 206) tensor rebuilt from the ring equals the shifted buffer after every step, resets' back-filled history
+    included; detach() leaves the task in the reference's layout; simulator state and fit are untouched by the choice."""
+    from emloco_amd.learning.locoval_rollout import LocoValRollout
+    from emloco_amd.run import RLGPUEnv
+    E, runs = 192, []
+    for ring in ("0", "1"):
+        monkeypatch.setenv("EMLOCO_AMP_RING", ring)
+        env = RLGPUEnv(_make_env(E, ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel",
+                                     "--input_init_pose", "--input_init_vel"]))
+        task = env.env.task
+        g = torch.Generator(device=task.device)
+        g.manual_seed(41)
+        pool = torch.randn(8, E, 69, device=task.device, generator=g) * 0.4
+        k = [0]
+
+        def pol(obs):
+            k[0] += 1
+            return pool[k[0] % 8]
+        torch.manual_seed(9)
+        agent = LocoValRollout(env, horizon_length=8, policy=pol, overlap_reset=False)
+        assert task.amp_ring == (ring == "1")
+        snaps, resets = [], 0
+        for _ in range(40):
+            agent.step_once()
+            task.wait_obs()                                # the live envs' observation / AMP pass is deferred into the next reset: take it now
+            resets += int((task.reset_buf != 0).sum().item())
+            snaps.append(task.amp_obs_logical().clone())
+        assert (task.extras["amp_obs"] is None) == (ring == "1")
+        n_fit = agent.fitted_episodes
+        agent.detach()
+        assert not task.amp_ring and task.extras["amp_obs"] is not None
+        runs.append((snaps, task._amp_obs_buf.clone().view(E, -1), task._root_states.clone(), n_fit, resets, task._amp_head))
+    assert runs[0][4] == runs[1][4] and runs[0][4] > 10 and runs[0][3] == runs[1][3]
+    for t, (a, b) in enumerate(zip(runs[0][0], runs[1][0])):
+        assert torch.equal(a, b), f"step {t}"
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][1], runs[0][0][-1])      # after detach: the reference's layout
+    assert torch.equal(runs[0][2], runs[1][2])
