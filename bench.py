@@ -31,6 +31,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import emloco_amd  # noqa: E402,F401  (ahead of the first GPU call: the package raises GPU_MAX_HW_QUEUES, emloco_amd/__init__.py)
 
 SIM_BYTES_PER_ENV = 9296          # state in/out + per-env model (+ collision capsules) + warm-start, per launch
 PROFILE_ROUND = "r04"             # profiles/<round>_*: the committed rocprofv3 summaries of this round's kernels
@@ -528,7 +529,7 @@ def ppo_leg(env, E, dev, epochs=2, warmup=1):
             "update_ms_per_optimizer_step": round((total - play) / epochs / steps_per_epoch * 1e3, 3),
             "optimizer_step_as_hip_graph": bool(graphed and agent._graph is not None),
             "graph_arms": ("actor | critic | discriminator | symmetry loss on streams of their own (parallel arms of the graph)"
-                           if (graphed and os.environ.get("EMLOCO_PPO_BRANCHES", "1") != "0") else "one chain"),
+                           if (graphed and getattr(agent, "_g_branch", None) is not None) else "one chain"),
             "eager_update_ms_per_optimizer_step": round(eager["update_time"] / steps_per_epoch * 1e3, 3),
             "losses": {k: round(float(last[k]), 5) for k in ("actor_loss", "critic_loss", "disc_loss", "kl") if k in last},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (rollout + update GEMMs of one eagerly issued epoch)", "achieved": round(tf, 2), "peak": peak,
