@@ -529,7 +529,8 @@ def ppo_leg(env, E, dev, epochs=2, warmup=1):
             "update_ms_per_optimizer_step": round((total - play) / epochs / steps_per_epoch * 1e3, 3),
             "optimizer_step_as_hip_graph": bool(graphed and agent._graph is not None),
             "graph_arms": ("actor | critic | discriminator | symmetry loss on streams of their own (parallel arms of the graph)"
-                           if (graphed and getattr(agent, "_g_branch", None) is not None) else "one chain"),
+                           if (graphed and getattr(agent, "_g_arms", False)) else "one chain"),
+            "graph_trial_ms": getattr(agent, "_g_trial_ms", None),
             "eager_update_ms_per_optimizer_step": round(eager["update_time"] / steps_per_epoch * 1e3, 3),
             "losses": {k: round(float(last[k]), 5) for k in ("actor_loss", "critic_loss", "disc_loss", "kl") if k in last},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (rollout + update GEMMs of one eagerly issued epoch)", "achieved": round(tf, 2), "peak": peak,

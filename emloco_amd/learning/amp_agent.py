@@ -467,13 +467,8 @@ class AMPAgent:
         return info
 
     def _branch_streams(self):
-        """Streams of the critic / discriminator / symmetry-loss arms of the optimiser step (EMLOCO_PPO_BRANCHES=0: one chain)."""
-        mode = os.environ.get("EMLOCO_PPO_BRANCHES", "auto")
-        if mode == "0":
-            return None
-        # the arms of the graph need hardware queues of their own: on the runtime's default of 4 they alias and the step is SLOWER
-        # than one chain (9.4 vs 6.0 ms; the package raises GPU_MAX_HW_QUEUES to 16 when it is imported ahead of the first GPU call)
-        if mode == "auto" and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
+        """Streams of the critic / discriminator / symmetry-loss arms of the optimiser step, or None for one chain (`_g_arms`)."""
+        if not getattr(self, "_g_arms", False):
             return None
         if getattr(self, "_g_branch", None) is None:
             self._g_branch = tuple(torch.cuda.Stream(device=self.device) for _ in range(3))
@@ -494,8 +489,32 @@ class AMPAgent:
         if self._amp_dropout:
             self._g_u.copy_(amp_dropout_draw(self._amp_minibatch_size), non_blocking=True)
 
+    # Whether the arms of the step run side by side or get in each other's way is decided by how the HIP runtime happens to map the
+    # graph's internal streams onto its hardware queues (GPU_MAX_HW_QUEUES, the streams the process created earlier): measured 4.75 ms
+    # with arms against 5.7 as one chain in one process, 9.4 against 6.0 in another (profiles/r04_ppo_hw_queues.txt).  So the step is
+    # captured BOTH ways and each graph is timed on its first `_G_TRIALS` steps -- real optimiser steps, the two graphs compute the same
+    # update -- and the faster one replays from then on.  EMLOCO_PPO_BRANCHES=0 / 1 pins one chain / the arms.
+    _G_TRIALS = 4
+
+    def _capture(self, arms):
+        self._g_arms = bool(arms)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.graph(g):
+            self._graph_body()
+        return g
+
+    def _timed_replay(self, g):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
     def _graph_step(self, i):
-        """One optimiser step: eager (on a side stream) for the first three calls, then captured, then replayed."""
+        """One optimiser step: eager (on a side stream) for the first three calls, then captured (one chain and with arms), the two
+        graphs timed on the next steps, then the faster one replayed."""
         self.set_train()
         self._graph_fill(i)
         if self._graph is not None:
@@ -510,12 +529,22 @@ class AMPAgent:
                 self._graph_body()
             torch.cuda.current_stream(self.device).wait_stream(side)
             return
-        g = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize(self.device)
-        with torch.cuda.graph(g):
-            self._graph_body()
-        self._graph = g                                     # (capture does not execute: run the step that was just captured)
-        g.replay()
+        mode = os.environ.get("EMLOCO_PPO_BRANCHES", "auto")
+        if mode in ("0", "1"):
+            self._graph = self._capture(mode == "1")        # (capture does not execute: run the step that was just captured)
+            self._graph.replay()
+            return
+        if getattr(self, "_g_cand", None) is None:
+            self._g_cand = [[self._capture(False), [], False], [self._capture(True), [], True]]
+        for cand in self._g_cand:                           # each candidate takes its share of real steps, timed
+            if len(cand[1]) < self._G_TRIALS:
+                cand[1].append(self._timed_replay(cand[0]))
+                break
+        if all(len(c[1]) >= self._G_TRIALS for c in self._g_cand):
+            best = min(self._g_cand, key=lambda c: sorted(c[1])[len(c[1]) // 2])
+            self._graph, self._g_arms = best[0], best[2]
+            self._g_trial_ms = {("arms" if c[2] else "one chain"): round(sorted(c[1])[len(c[1]) // 2], 3) for c in self._g_cand}
+            self._g_cand = None
 
     # ------------------------------------------------------------------ epoch
     def prepare_dataset(self, batch):
