@@ -140,6 +140,8 @@ class HumanoidAMP(Humanoid):
             return
         if on and (torch.device(self.device).type != "cuda" or not getattr(self, "_fused_reset", False)):
             raise RuntimeError("amp ring: needs the fused device step / reset kernels (a CUDA device, fused_reset)")
+        if hasattr(self, "wait_obs"):
+            self.wait_obs()                          # a deferred observation / AMP pass of the last step runs in the layout it was deferred in
         if not on:                                   # back to the reference's layout, in place
             self._amp_obs_buf.copy_(self.amp_obs_logical().view_as(self._amp_obs_buf))
         self._amp_head = 0                           # (switching on: physical = logical at head 0, nothing moves)
