@@ -94,6 +94,8 @@ class LocoValRollout:
                           and self.device.type == "cuda" and os.environ.get("EMLOCO_AMP_RING", "1") != "0")
         if self._amp_ring:
             self.task.enable_amp_ring(True)
+        elif getattr(self.task, "amp_ring", False):
+            self.task.enable_amp_ring(False)               # a task an earlier loop left in the ring layout: this loop reads the plain tensor
         self.fused = (isinstance(self.valuenet, ValuePoseNet) and self.device.type == "cuda") if fused is None else bool(fused)
         if not self.fused and type(self)._bookkeeping is LocoValRollout._bookkeeping:
             raise RuntimeError("LocoValRollout runs its bookkeeping and fit as HIP kernels: it needs libemloco_hip.so, a gfx950 device "
