@@ -151,6 +151,8 @@ class AMPAgent:
         self.vec_env = vec_env
         env = vec_env.env if hasattr(vec_env, "env") else vec_env
         self.env, self.task = env, env.task
+        if getattr(self.task, "amp_ring", False):
+            self.task.enable_amp_ring(False)     # this learner reads infos["amp_obs"] every step: the reference's layout (a rollout loop may have left the ring on)
         task = self.task
         self.device = torch.device(task.device)
         params = cfg_train["params"]
