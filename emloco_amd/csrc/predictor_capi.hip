@@ -184,16 +184,21 @@ int64_t emloco_layernorm_bwd_workspace(int rows, int d) {
 
 int emloco_layernorm_bwd(int rows, int d, const float *xr, const float *gamma, const float *mean, const float *rstd,
                          const float *dy, float *dxr, float *dgamma, float *dbeta, float *workspace, void *stream) {
+    return emloco_layernorm_bwd2(rows, d, xr, gamma, mean, rstd, dy, nullptr, dxr, dgamma, dbeta, workspace, stream);
+}
+
+int emloco_layernorm_bwd2(int rows, int d, const float *xr, const float *gamma, const float *mean, const float *rstd,
+                          const float *dy, const float *dy2, float *dxr, float *dgamma, float *dbeta, float *workspace, void *stream) {
     if (rows < 1 || d < 1 || d > 1024 || !xr || !gamma || !mean || !rstd || !dy || !dxr || !dgamma || !dbeta || !workspace)
         return pfail(-1, "emloco_layernorm_bwd: bad argument (workspace = emloco_layernorm_bwd_workspace(rows, d) floats)");
     const int nblocks = (rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
-    const bool al16 = (((uintptr_t)xr | (uintptr_t)dy | (uintptr_t)dxr | (uintptr_t)gamma) & 15) == 0;
+    const bool al16 = (((uintptr_t)xr | (uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)dxr | (uintptr_t)gamma) & 15) == 0;
     if (d == 128 && al16)
         hipLaunchKernelGGL(emloco::layernorm_bwd128_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
-                           rows, xr, gamma, mean, rstd, dy, dxr, workspace);
+                           rows, xr, gamma, mean, rstd, dy, dy2, dxr, workspace);
     else
         hipLaunchKernelGGL(emloco::layernorm_bwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
-                           rows, d, xr, gamma, mean, rstd, dy, dxr, workspace);
+                           rows, d, xr, gamma, mean, rstd, dy, dy2, dxr, workspace);
     PHIPCHK(hipGetLastError());
     emloco::fold_rows(FoldLaunch{(hipStream_t)stream}, nblocks, 2 * d, workspace, dgamma, dbeta, d);
     PHIPCHK(hipGetLastError());

@@ -717,7 +717,8 @@ layernorm_fwd_kernel(int rows, int d, float eps, const float *x, const float *re
 #define LN_ROWS_PER_BLOCK 64
 __global__ void __launch_bounds__(256)
 layernorm_bwd_kernel(int rows, int d, const float *xr, const float *gamma, const float *mean, const float *rstd,
-                     const float *dy, float *dxr, float *part /* [nblocks][2][d] */) {
+                     const float *dy, const float *dy2 /* optional: a second incoming gradient, added on load */, float *dxr,
+                     float *part /* [nblocks][2][d] */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __shared__ float sh_g[4][1024], sh_b[4][1024];
     for (int j = lane; j < d; j += 64) { sh_g[w][j] = 0.0f; sh_b[w][j] = 0.0f; }
@@ -731,7 +732,7 @@ layernorm_bwd_kernel(int rows, int d, const float *xr, const float *gamma, const
             const int j = lane + 64 * t;
             xh[t] = 0.0f; gg[t] = 0.0f;
             if (j < d) {
-                const float dyv = dy[row * d + j];
+                const float dyv = dy2 ? dy[row * d + j] + dy2[row * d + j] : dy[row * d + j];
                 xh[t] = (xr[row * d + j] - mu) * rs;
                 gg[t] = dyv * gamma[j];
                 s1 += gg[t]; s2 += gg[t] * xh[t];
@@ -777,7 +778,7 @@ layernorm_fwd128_kernel(int rows, float eps, const float *x, const float *res, c
 }
 __global__ void __launch_bounds__(256)
 layernorm_bwd128_kernel(int rows, const float *xr, const float *gamma, const float *mean, const float *rstd,
-                        const float *dy, float *dxr, float *part /* [nblocks][2][128] */) {
+                        const float *dy, const float *dy2 /* optional: added on load */, float *dxr, float *part /* [nblocks][2][128] */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, l = lane & 31;
     __shared__ float sh_g[8][128], sh_b[8][128];
     const f32x4 gm = *(const f32x4 *)(gamma + 4 * l);
@@ -788,7 +789,9 @@ layernorm_bwd128_kernel(int rows, const float *xr, const float *gamma, const flo
         const bool on = row < rows;                           // (both halves run the exchanges; a half past the end carries zeros)
         const long rowc = on ? row : (long)rows - 1;
         const float mu = mean[rowc], rs = rstd[rowc];
-        const f32x4 dv4 = *(const f32x4 *)(dy + rowc * 128 + 4 * l), xv4 = *(const f32x4 *)(xr + rowc * 128 + 4 * l);
+        f32x4 dv4 = *(const f32x4 *)(dy + rowc * 128 + 4 * l);
+        const f32x4 xv4 = *(const f32x4 *)(xr + rowc * 128 + 4 * l);
+        if (dy2) { const f32x4 e = *(const f32x4 *)(dy2 + rowc * 128 + 4 * l); dv4.x += e.x; dv4.y += e.y; dv4.z += e.z; dv4.w += e.w; }
         const float dv[4] = {dv4.x, dv4.y, dv4.z, dv4.w}, xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, g4[4] = {gm.x, gm.y, gm.z, gm.w};
         float xh[4], gg[4], s1 = 0.0f, s2 = 0.0f;
         for (int c = 0; c < 4; ++c) {

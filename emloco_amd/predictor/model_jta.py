@@ -42,21 +42,25 @@ class EncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d)
         self.p = dropout
 
-    def forward(self, x, key_pad, live_rows=None):
+    def forward(self, x, key_pad, live_rows=None, x_res=None, fork_out=False):
         """live_rows: only the first `live_rows` tokens of every sequence are read downstream (the last layer of a former):
         they attend over all keys, and the out-projection / norms / feed-forward run on those rows only -> (Bn, live_rows, d).
-        Every row of a post-norm layer depends on the other rows through K and V alone, so the kept rows are unchanged."""
+        Every row of a post-norm layer depends on the other rows through K and V alone, so the kept rows are unchanged.
+        x_res: the same values as `x` as a second autograd edge (the previous layer's forked LayerNorm output) for the residual branch;
+        fork_out: return (y, y') likewise for the next layer.  Two edges instead of one used twice: the LayerNorm backward adds the
+        two gradients on load instead of autograd in a pass of its own."""
         sa = self.self_attn
+        xr = x if x_res is None else x_res
         # (reduced-precision mode: q|k|v goes to the fused attention kernels as bf16 in HBM)
         qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias, out_bf16=(sa.embed_dim // sa.num_heads == 32))
         p = self.p if self.training else 0.0                 # the three nn.Dropout of the layer live in the GEMM epilogues,
         att = ops.attention(qkv, key_pad, sa.num_heads, drop_p=p, n_query=live_rows)   # MultiheadAttention's dropout on the probabilities in the attention kernels
         if live_rows is not None and live_rows < x.shape[1]:
-            x = x[:, :live_rows].contiguous()
+            xr = xr[:, :live_rows].contiguous()
         a = ops.linear(att, sa.out_proj.weight, sa.out_proj.bias, drop_p=p)
-        x = ops.layer_norm(a, x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        f = ops.feed_forward(x, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, drop_p=p)
-        return ops.layer_norm(f, x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x1, x1r = ops.layer_norm(a, xr, self.norm1.weight, self.norm1.bias, self.norm1.eps, fork=True)
+        f = ops.feed_forward(x1, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, drop_p=p)
+        return ops.layer_norm(f, x1r, self.norm2.weight, self.norm2.bias, self.norm2.eps, fork=fork_out)
 
 
 class Encoder(nn.Module):
@@ -66,8 +70,12 @@ class Encoder(nn.Module):
 
     def forward(self, x, key_pad, live_rows=None):
         last = len(self.layers) - 1
+        xr = None
         for i, layer in enumerate(self.layers):
-            x = layer(x, key_pad, live_rows if i == last else None)
+            if i == last:
+                x = layer(x, key_pad, live_rows, x_res=xr)
+            else:
+                x, xr = layer(x, key_pad, None, x_res=xr, fork_out=True)
         return x
 
 

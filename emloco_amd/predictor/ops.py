@@ -39,6 +39,7 @@ def _lib():
         lib.emloco_layernorm_fwd.argtypes = [ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_layernorm_fwd_save.argtypes = [ci, ci, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_layernorm_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.emloco_layernorm_bwd2.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.emloco_colsum.argtypes = [ci, ci, vp, vp, vp, vp]
         lib.emloco_colsum_ex.argtypes = [ci, ci, vp, vp, vp, ci, vp]
         lib.emloco_attention_fwd.argtypes = [ci, ci, ci, ci, cf, vp, vp, vp, vp, vp]
@@ -446,7 +447,10 @@ class LayerNormFn(torch.autograd.Function):
     """y = LayerNorm(x + res) * gamma + beta (post-norm encoder layer)."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps):
+    def forward(ctx, x, res, gamma, beta, eps, fork=False):
+        # fork: the output is returned TWICE (y, y').  A post-norm layer's output feeds the next sublayer and its residual branch: with
+        # one output autograd adds the two gradients in a pass of its own (read 2, write 1 over M x d) before this node's backward
+        # reads the sum; with two outputs the backward gets both and adds them on load (emloco_layernorm_bwd2).
         shp = x.shape
         d = shp[-1]
         x2 = x.contiguous().view(-1, d)
@@ -460,25 +464,34 @@ class LayerNormFn(torch.autograd.Function):
                                               _p(xr) if r2 is not None else None, _st(x)), "emloco_layernorm_fwd_save")
         ctx.save_for_backward(xr, gamma, mean, rstd)
         ctx.has_res, ctx.shp = res is not None, shp
+        if fork:
+            return y.view(shp), y.view(shp).detach()
         return y.view(shp)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy_b=None):
         xr, gamma, mean, rstd = ctx.saved_tensors
         rows, d = xr.shape
+        if dy is None:
+            dy, dy_b = dy_b, None
         dy2 = dy.contiguous().view(rows, d)
+        dyb = dy_b.contiguous().view(rows, d) if dy_b is not None else None
         dxr = torch.empty_like(xr)
         dg = torch.empty(d, dtype=torch.float32, device=dy.device)
         db = torch.empty(d, dtype=torch.float32, device=dy.device)
         ws = torch.empty(_lib().emloco_layernorm_bwd_workspace(rows, d), dtype=torch.float32, device=dy.device)
-        _chk(_lib().emloco_layernorm_bwd(rows, d, _p(xr), _p(gamma), _p(mean), _p(rstd), _p(dy2), _p(dxr), _p(dg), _p(db), _p(ws),
-                                         _st(dy)), "emloco_layernorm_bwd")
+        _chk(_lib().emloco_layernorm_bwd2(rows, d, _p(xr), _p(gamma), _p(mean), _p(rstd), _p(dy2), _p(dyb), _p(dxr), _p(dg), _p(db), _p(ws),
+                                          _st(dy)), "emloco_layernorm_bwd")
         dxr = dxr.view(ctx.shp)
-        return dxr, (dxr if ctx.has_res else None), dg, db, None
+        return dxr, (dxr if ctx.has_res else None), dg, db, None, None
 
 
-def layer_norm(x, res, gamma, beta, eps=1e-5):
-    return LayerNormFn.apply(x, res, gamma, beta, eps)
+def layer_norm(x, res, gamma, beta, eps=1e-5, fork=False):
+    """fork=True returns (y, y'): hand y to the next sublayer and y' to its residual branch (see LayerNormFn.forward)."""
+    if fork and not (torch.is_grad_enabled() and (x.requires_grad or (res is not None and res.requires_grad))):
+        y = LayerNormFn.apply(x, res, gamma, beta, eps)
+        return y, y
+    return LayerNormFn.apply(x, res, gamma, beta, eps, bool(fork))
 
 
 class LocoValFn(torch.autograd.Function):

@@ -151,6 +151,10 @@ int emloco_layernorm_fwd_save(int rows, int d, float eps, const float *x, const 
  * is recomputed from y:  xhat = (y - beta) / gamma is avoided -- pass the saved sum `xr`. */
 int emloco_layernorm_bwd(int rows, int d, const float *xr, const float *gamma, const float *mean, const float *rstd,
                          const float *dy, float *dxr, float *dgamma, float *dbeta, float *workspace, void *stream);
+/* the same with TWO incoming gradients, added on load (dy2 may be NULL): a post-norm layer's output feeds the next sublayer AND its
+ * residual branch; handing both gradients to the backward saves the add pass autograd would run over two [rows][d] tensors first */
+int emloco_layernorm_bwd2(int rows, int d, const float *xr, const float *gamma, const float *mean, const float *rstd,
+                          const float *dy, const float *dy2, float *dxr, float *dgamma, float *dbeta, float *workspace, void *stream);
 /* floats of device workspace emloco_layernorm_bwd needs (per-block partials + their fold levels) */
 int64_t emloco_layernorm_bwd_workspace(int rows, int d);
 

@@ -96,11 +96,17 @@ extern "C" int emu_layernorm_fwd(int rows, int d, float eps, const float *x, con
     else emu::launch((unsigned)((rows + 3) / 4), 256, [&] { layernorm_fwd_kernel(rows, d, eps, x, res, g, b, y, mean, rstd, nullptr); });
     return 0;
 }
+extern "C" int emu_layernorm_bwd2(int rows, int d, const float *xr, const float *g, const float *mean, const float *rstd,
+                                  const float *dy, const float *dy2, float *dxr, float *dg, float *db, float *ws);
 extern "C" int emu_layernorm_bwd(int rows, int d, const float *xr, const float *g, const float *mean, const float *rstd,
                                  const float *dy, float *dxr, float *dg, float *db, float *ws) {
+    return emu_layernorm_bwd2(rows, d, xr, g, mean, rstd, dy, nullptr, dxr, dg, db, ws);
+}
+extern "C" int emu_layernorm_bwd2(int rows, int d, const float *xr, const float *g, const float *mean, const float *rstd,
+                                  const float *dy, const float *dy2, float *dxr, float *dg, float *db, float *ws) {
     const int nb = (rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
-    if (d == 128) emu::launch((unsigned)nb, 256, [&] { layernorm_bwd128_kernel(rows, xr, g, mean, rstd, dy, dxr, ws); });       // (the capi's dispatch)
-    else emu::launch((unsigned)nb, 256, [&] { layernorm_bwd_kernel(rows, d, xr, g, mean, rstd, dy, dxr, ws); });
+    if (d == 128) emu::launch((unsigned)nb, 256, [&] { layernorm_bwd128_kernel(rows, xr, g, mean, rstd, dy, dy2, dxr, ws); });       // (the capi's dispatch)
+    else emu::launch((unsigned)nb, 256, [&] { layernorm_bwd_kernel(rows, d, xr, g, mean, rstd, dy, dy2, dxr, ws); });
     fold_rows([&](unsigned gx, unsigned gy, int n, int w, const float *in, float *o0, float *o1, int split) {
         for (unsigned y = 0; y < gy; ++y)
             emu::launch(gx, 256, [&] { blockIdx.y = y; rows_fold_kernel(n, w, in, o0, o1, split); });

@@ -541,6 +541,15 @@ def test_softmax_and_layernorm_kernels():
         np.testing.assert_allclose(dxr, ref_dx, rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(dg, (dy * xh).sum(0), rtol=1e-4, atol=5e-4)
         np.testing.assert_allclose(db, dy.sum(0), rtol=1e-4, atol=5e-4)
+        # two incoming gradients added on load (emloco_layernorm_bwd2) = the one launch on their fp32 sum, bit for bit
+        dya = rng.normal(size=(rows, d)).astype(np.float32)
+        dyb = (dy - dya).astype(np.float32)
+        one = [np.zeros_like(x), np.zeros(d, np.float32), np.zeros(d, np.float32)]
+        two = [np.zeros_like(x), np.zeros(d, np.float32), np.zeros(d, np.float32)]
+        lib.emu_layernorm_bwd(rows, d, P(xrf), P(gam), P(mean), P(rstd), P((dya + dyb).astype(np.float32)), P(one[0]), P(one[1]), P(one[2]), P(ws))
+        lib.emu_layernorm_bwd2(rows, d, P(xrf), P(gam), P(mean), P(rstd), P(dya), P(dyb), P(two[0]), P(two[1]), P(two[2]), P(ws))
+        for a_, b_ in zip(one, two):
+            assert np.array_equal(a_, b_)
 
 
 def test_column_sum_kernels():
