@@ -132,12 +132,14 @@ __device__ __forceinline__ void ld4(const float *base, int off, float *v) {
 // Height-field ground under the world point (cx, cy): height zt of the cell triangle's plane there and its unit normal.
 // Cell (i, j) holds the mesh triangles (v00, v10, v11) [u >= v] and (v00, v11, v01) [u < v] (u, v: position in the cell
 // along x, y), as terrain_utils.convert_heightfield_to_trimesh lays them out; beyond the map the border cell's plane extends.
-__device__ __forceinline__ void hf_plane(const EmlocoSimDev &d, float cx, float cy, float &zt, float n[3]) {
+// `id` names the triangle that was used: (cell i, cell j, which half)
+__device__ __forceinline__ void hf_plane(const EmlocoSimDev &d, float cx, float cy, float &zt, float n[3], int &id) {
     const float gx = (cx - d.hf_ox) * d.hf_inv_hs, gy = (cy - d.hf_oy) * d.hf_inv_hs;
     int i = (int)floorf(gx), j = (int)floorf(gy);
     i = i < 0 ? 0 : (i > d.hf_nx - 2 ? d.hf_nx - 2 : i);
     j = j < 0 ? 0 : (j > d.hf_ny - 2 ? d.hf_ny - 2 : j);
     const float u = gx - (float)i, v = gy - (float)j;
+    id = ((i << 15) + j) * 2 + (u >= v ? 1 : 0);
     const short *c = d.hf + (long)i * d.hf_ny + j;
     const float h00 = d.hf_vs * (float)c[0], h01 = d.hf_vs * (float)c[1];
     const float h10 = d.hf_vs * (float)c[d.hf_ny], h11 = d.hf_vs * (float)c[d.hf_ny + 1];
@@ -147,6 +149,15 @@ __device__ __forceinline__ void hf_plane(const EmlocoSimDev &d, float cx, float 
     const float sx = zx * d.hf_inv_hs, sy = zy * d.hf_inv_hs;
     const float inv = 1.0f / sqrtf(fmaf(sx, sx, fmaf(sy, sy, 1.0f)));
     n[0] = 0.0f - sx * inv; n[1] = 0.0f - sy * inv; n[2] = inv;
+}
+// the triangle under a point, without its plane
+__device__ __forceinline__ int hf_triangle(const EmlocoSimDev &d, float cx, float cy) {
+    const float gx = (cx - d.hf_ox) * d.hf_inv_hs, gy = (cy - d.hf_oy) * d.hf_inv_hs;
+    int i = (int)floorf(gx), j = (int)floorf(gy);
+    i = i < 0 ? 0 : (i > d.hf_nx - 2 ? d.hf_nx - 2 : i);
+    j = j < 0 ? 0 : (j > d.hf_ny - 2 ? d.hf_ny - 2 : j);
+    const float u = gx - (float)i, v = gy - (float)j;
+    return ((i << 15) + j) * 2 + (u >= v ? 1 : 0);
 }
 
 #ifndef EMLOCO_SIM_WAVES_PER_SIMD
@@ -891,10 +902,28 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                     cxw[0] = sh_R[body][9] + wp[0];
                     cxw[1] = sh_R[body][10] + wp[1];
                     cxw[2] = (sh_R[body][11] + wp[2]) - crad;
-                } else {      // sphere of the candidate against the plane of the terrain triangle under its centre
+                } else {
+                    // sphere of the candidate against the plane of the terrain triangle under its centre -- and, for a sphere with a
+                    // radius, against the triangles under four probes one radius out along +-x / +-y: a neighbouring face (the ramp
+                    // of a stair riser) is met when the sphere's SURFACE reaches it, not when its centre has crossed into the face's
+                    // cell.  A probed triangle counts when the foot of the centre's perpendicular lies in it (its plane is not the
+                    // terrain elsewhere) and its plane is nearer than what has been found; one contact per candidate, the nearest.
                     float zt, cnrm[3];
-                    hf_plane(d, sh_pq[body][0] + wp[0], sh_pq[body][1] + wp[1], zt, cnrm);
-                    cdist[s] = (z - zt) * cnrm[2] - crad;
+                    int tid0;
+                    const float pcx = sh_pq[body][0] + wp[0], pcy = sh_pq[body][1] + wp[1];
+                    hf_plane(d, pcx, pcy, zt, cnrm, tid0);
+                    float dperp = (z - zt) * cnrm[2];
+                    if (crad > 0.0f)
+                        for (int q = 0; q < 4; ++q) {
+                            const float ex = q == 0 ? crad : (q == 1 ? 0.0f - crad : 0.0f), ey = q == 2 ? crad : (q == 3 ? 0.0f - crad : 0.0f);
+                            float ztq, nq[3];
+                            int tidq;
+                            hf_plane(d, pcx + ex, pcy + ey, ztq, nq, tidq);
+                            const float dq = fmaf(z - ztq, nq[2], 0.0f - fmaf(ex, nq[0], ey * nq[1]));
+                            const int tidf = hf_triangle(d, pcx - dq * nq[0], pcy - dq * nq[1]);
+                            if (tidq != tid0 && tidf == tidq && dq < dperp) { dperp = dq; cnrm[0] = nq[0]; cnrm[1] = nq[1]; cnrm[2] = nq[2]; }
+                        }
+                    cdist[s] = dperp - crad;
                     for (int k2 = 0; k2 < 3; ++k2) { cxw[k2] = (sh_R[body][9 + k2] + wp[k2]) - crad * cnrm[k2]; stg[3 + k2] = cnrm[k2]; }
                 }
                 for (int k2 = 0; k2 < 3; ++k2) stg[k2] = cxw[k2];

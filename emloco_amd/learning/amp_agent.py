@@ -385,13 +385,22 @@ class AMPAgent:
         if self._amp_dropout and dropout_masks is None:
             steps = self.task._num_amp_obs_steps
             dropout_masks = amp_dropout_mask(self._amp_minibatch_size, steps, d["amp_obs"].shape[1] // steps, device=d["amp_obs"].device)
-        if s_d is not None and dropout_masks is not None:
-            dropout_masks.record_stream(s_d)
+        # Every normaliser call on the caller's stream, in the reference's order (obs, the three AMP batches, flipped, next:
+        # amp_continuous.py:345-352,405): in training mode a RunningMeanStd UPDATES its statistics with the batch it is handed, so the
+        # order is part of the arithmetic -- and two arms updating one normaliser at once would be a race.  The arms get the results.
+        n_amp = self._amp_minibatch_size
+        obs = self._preproc_obs(d["obs"])
+        amp_obs = self._preproc_amp_obs(d["amp_obs"][0:n_amp])
+        amp_replay = self._preproc_amp_obs(d["amp_obs_replay"][0:n_amp])
+        amp_demo = self._preproc_amp_obs(d["amp_obs_demo"][0:n_amp])
+        flip_n = next_n = None
+        if self.motion_sym_loss:
+            flip_n, next_n = self._preproc_obs(d["flip_obs"]), self._preproc_obs(d["next_obses"])
+        if branch_streams is not None:                       # (allocated on the caller's stream, read on an arm's)
+            for t, st in ((obs, s_c), (amp_obs, s_d), (amp_replay, s_d), (amp_demo, s_d), (flip_n, s_s), (next_n, s_s), (dropout_masks, s_d)):
+                if t is not None:
+                    t.record_stream(st)
         with on(s_d):
-            n_amp = self._amp_minibatch_size
-            amp_obs = self._preproc_amp_obs(d["amp_obs"][0:n_amp])
-            amp_replay = self._preproc_amp_obs(d["amp_obs_replay"][0:n_amp])
-            amp_demo = self._preproc_amp_obs(d["amp_obs_demo"][0:n_amp])
             m = (lambda i: dropout_masks[..., i]) if dropout_masks is not None else (lambda i: None)
             mul = lambda x, k: x if k is None else x * k
             # (agent and replay rows through the discriminator as ONE stacked batch: row-wise network, the loss wants them stacked anyway)
@@ -401,10 +410,7 @@ class AMPAgent:
         s_loss = None
         if self.motion_sym_loss:                             # (two more actor evaluations)
             with on(s_s):
-                s_loss = torch.mean(self._sym_loss(self._preproc_obs(d["flip_obs"]), self._preproc_obs(d["next_obses"]))["sym_loss"])
-        obs = self._preproc_obs(d["obs"])
-        if s_c is not None:
-            obs.record_stream(s_c)
+                s_loss = torch.mean(self._sym_loss(flip_n, next_n)["sym_loss"])
         with on(s_c):
             values = net.eval_critic(obs)
             c_info = self._critic_loss(d["old_values"], values, self.e_clip, d["returns"], self.clip_value)

@@ -129,7 +129,8 @@ int emloco_sim_set_self_collision(EmlocoSim *sim, const EmlocoSelfCollisionDesc 
  * [nx][ny] (first axis = x) in units of `vertical_scale` metres on a `horizontal_scale`-metre grid; sample (0, 0) sits at
  * world (origin_x, origin_y) (the mesh transform, zero in the reference).  Host pointer, copied.  Each cell collides as the
  * mesh's two triangles (v00, v10, v11) / (v00, v11, v01); a body's contact sphere is tested against the plane of the
- * triangle under its centre.  NULL samples restore the plane z = ground_z.  Call before emloco_sim_prepare. */
+ * triangle under its centre and, when it has a radius, of the triangles under four probes one radius out along +-x / +-y (the nearest
+ * plane whose perpendicular foot lies in its own triangle wins: a neighbouring face is met when the sphere's surface reaches it).  NULL samples restore the plane z = ground_z.  Call before emloco_sim_prepare. */
 int emloco_sim_set_ground_heightfield(EmlocoSim *sim, const int16_t *samples, int nx, int ny, float horizontal_scale,
                                       float vertical_scale, float origin_x, float origin_y);
 int emloco_sim_prepare(EmlocoSim *sim);

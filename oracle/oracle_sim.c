@@ -712,12 +712,13 @@ typedef struct { int body, cand; float x[3], dist, D[9]; } Contact;
 /* height-field ground under the world point (cx, cy): height of the cell triangle's plane there and its unit normal.  Cell
  * (i, j) holds the mesh triangles (v00, v10, v11) [u >= v] and (v00, v11, v01) [u < v] (terrain_utils.py:286-350 layout);
  * beyond the map the border cell's plane extends. */
-static void hf_plane(const EnvModel *m, float cx, float cy, float *zt, float *n) {
+static void hf_plane(const EnvModel *m, float cx, float cy, float *zt, float *n, int *id) {
     float gx = (cx - m->hf_ox) * m->hf_inv_hs, gy = (cy - m->hf_oy) * m->hf_inv_hs;
     int i = (int)floorf(gx), j = (int)floorf(gy);
     i = i < 0 ? 0 : (i > m->hf_nx - 2 ? m->hf_nx - 2 : i);
     j = j < 0 ? 0 : (j > m->hf_ny - 2 ? m->hf_ny - 2 : j);
     float u = gx - (float)i, v = gy - (float)j;
+    *id = ((i << 15) + j) * 2 + (u >= v ? 1 : 0);               /* the triangle that was used: (cell i, cell j, which half) */
     const int16_t *c = m->hf + (long)i * m->hf_ny + j;
     float h00 = m->hf_vs * (float)c[0], h01 = m->hf_vs * (float)c[1];
     float h10 = m->hf_vs * (float)c[m->hf_ny], h11 = m->hf_vs * (float)c[m->hf_ny + 1];
@@ -727,6 +728,16 @@ static void hf_plane(const EnvModel *m, float cx, float cy, float *zt, float *n)
     float sx = zx * m->hf_inv_hs, sy = zy * m->hf_inv_hs;
     float inv = 1.0f / sqrtf(fmaf(sx, sx, fmaf(sy, sy, 1.0f)));
     n[0] = 0.0f - sx * inv; n[1] = 0.0f - sy * inv; n[2] = inv;
+}
+
+/* the triangle under a point, without its plane */
+static int hf_triangle(const EnvModel *m, float cx, float cy) {
+    float gx = (cx - m->hf_ox) * m->hf_inv_hs, gy = (cy - m->hf_oy) * m->hf_inv_hs;
+    int i = (int)floorf(gx), j = (int)floorf(gy);
+    i = i < 0 ? 0 : (i > m->hf_nx - 2 ? m->hf_nx - 2 : i);
+    j = j < 0 ? 0 : (j > m->hf_ny - 2 ? m->hf_ny - 2 : j);
+    float u = gx - (float)i, v = gy - (float)j;
+    return ((i << 15) + j) * 2 + (u >= v ? 1 : 0);
 }
 
 static int find_contacts(const Env *s, const EnvModel *m, const OrcSimParams *prm, Contact *out) {
@@ -747,10 +758,27 @@ static int find_contacts(const Env *s, const EnvModel *m, const OrcSimParams *pr
                 dist = (z - prm->ground_z) - rad;
                 c.x[0] = s->r[b][0] + wp[0]; c.x[1] = s->r[b][1] + wp[1]; c.x[2] = (s->r[b][2] + wp[2]) - rad;
                 memcpy(c.D, flat, sizeof(flat));
-            } else {   /* sphere of the candidate against the plane of the terrain triangle under its centre */
+            } else {
+                /* sphere of the candidate against the plane of the terrain triangle under its centre -- and, for a sphere with a
+                 * radius, against the triangles under four probes one radius out along +-x / +-y: a probed
+                 * triangle counts when the foot of the centre's perpendicular lies in it and its plane is nearer than what has been
+                 * found; one contact per candidate, the nearest */
                 float zt, nn[3];
-                hf_plane(m, s->pw[b][0] + wp[0], s->pw[b][1] + wp[1], &zt, nn);
-                dist = (z - zt) * nn[2] - rad;
+                int tid0;
+                float pcx = s->pw[b][0] + wp[0], pcy = s->pw[b][1] + wp[1];
+                hf_plane(m, pcx, pcy, &zt, nn, &tid0);
+                float dperp = (z - zt) * nn[2];
+                if (rad > 0.0f)
+                    for (int q = 0; q < 4; ++q) {
+                        float ex = q == 0 ? rad : (q == 1 ? 0.0f - rad : 0.0f), ey = q == 2 ? rad : (q == 3 ? 0.0f - rad : 0.0f);
+                        float ztq, nq[3];
+                        int tidq;
+                        hf_plane(m, pcx + ex, pcy + ey, &ztq, nq, &tidq);
+                        float dq = fmaf(z - ztq, nq[2], 0.0f - fmaf(ex, nq[0], ey * nq[1]));
+                        int tidf = hf_triangle(m, pcx - dq * nq[0], pcy - dq * nq[1]);
+                        if (tidq != tid0 && tidf == tidq && dq < dperp) { dperp = dq; nn[0] = nq[0]; nn[1] = nq[1]; nn[2] = nq[2]; }
+                    }
+                dist = dperp - rad;
                 for (int k = 0; k < 3; ++k) c.x[k] = (s->r[b][k] + wp[k]) - rad * nn[k];
                 /* frame: normal, t1 = (y x n) / |y x n|, t2 = n x t1 */
                 float il = 1.0f / sqrtf(fmaf(nn[2], nn[2], nn[0] * nn[0]));

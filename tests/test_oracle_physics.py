@@ -718,3 +718,55 @@ def test_free_ragdoll_at_moderate_spin_keeps_momentum_exactly_and_energy_within_
         Ts.append(T1 / T0)
     assert np.linalg.norm(L1 - L0) < 1e-5 * np.linalg.norm(L0) and np.linalg.norm(P1 - P0) < 1e-4 * np.linalg.norm(P0)
     assert 0.95 < min(Ts) and max(Ts) < 1.45
+
+
+def test_sphere_sliding_into_a_step_stops_at_the_face():
+    """Terrain contacts of a sphere with a radius look one radius ahead (four probes along +-x / +-y): the head
+    (r = 0.101 m) of a humanoid sliding on its back, head first, over low-friction ground into a 20 cm riser (one 10 cm cell wide: a
+    63-degree ramp in the height field) is stopped when its SURFACE reaches the ramp -- centre 0.618 r before the ramp's foot, the point
+    where a sphere resting on the floor touches a plane of slope 2 -- not when its centre has crossed into the ramp's cell (measured
+    without the probes: the centre reaches x = 52.001, 57 mm inside the ramp).  No sphere or capsule end of the body is ever deeper
+    than a few millimetres in the terrain solid."""
+    m = smpl_humanoid()
+    field = np.zeros((1100, 1100), np.int16)
+    field[521:, :] = 40                                           # 40 x 0.005 = 0.2 m from x = 52.1 on; the cell [52.0, 52.1) is the ramp
+    s = oracle.Sim(pack_models([m]), oracle.default_params(mu=0.05), heightfield=dict(samples=field, horizontal_scale=0.1, vertical_scale=0.005))
+    s.root_state[0, :3] = [50.6, 55.0, 0.16]
+    s.root_state[0, 3:7] = [0.0, np.sin(np.pi / 4), 0.0, np.cos(np.pi / 4)]      # on its back, head towards +x
+    s.root_state[0, 7] = 2.0
+
+    def rot(q, v):
+        x, y, z, w = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        return R @ v
+
+    def seg(p, a, b):
+        ab = b - a
+        return np.linalg.norm(p - (a + np.clip((p - a) @ ab / (ab @ ab), 0, 1) * ab))
+
+    F0, A, B, T = np.array([0.0, 0.0]), np.array([52.0, 0.0]), np.array([52.1, 0.2]), np.array([70.0, 0.2])   # the profile in (x, z)
+    head = m.names.index("Head")
+    r_head = float(m.geom_r[head])
+    worst, head_x, first_touch = 0.0, [], None
+    for _ in range(60):
+        s.step()
+        rb = s.rb_state[0]
+        for b in range(24):
+            gt, r = int(m.geom_type[b]), float(m.geom_r[b])
+            ends = [m.geom_a[b]] if gt == 0 else ([m.geom_a[b], m.geom_b[b]] if gt == 1 else [])
+            for lp in ends:
+                c = rb[b, :3] + rot(rb[b, 3:7], np.asarray(lp, float))
+                p = np.array([c[0], c[2]])
+                ground = 0.0 if p[0] < 52.0 else (2.0 * (p[0] - 52.0) if p[0] < 52.1 else 0.2)
+                dist = min(seg(p, F0, A), seg(p, A, B), seg(p, B, T)) * (-1.0 if p[1] < ground else 1.0)
+                worst = max(worst, r - dist)
+        hc = rb[head, :3] + rot(rb[head, 3:7], np.asarray(m.geom_a[head], float))
+        head_x.append(float(hc[0]))
+        if first_touch is None and seg(np.array([hc[0], hc[2]]), A, B) - r_head < 0.004:
+            first_touch = (float(hc[0]), float(hc[2]))
+    touch = 52.0 - r_head * (np.sqrt(5.0) - 1.0) / 2.0             # a sphere on the floor touches a plane of slope 2 at 0.618 r before its foot
+    assert worst < 0.008, worst
+    assert first_touch is not None and abs(first_touch[0] - touch) < 0.012 and abs(first_touch[1] - r_head) < 0.01, (first_touch, touch)
+    assert np.isfinite(s.rb_state).all()
