@@ -495,6 +495,13 @@ gemm_f32_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, GBK, 0, TB, 1, PREC
 template <int GBK, int TB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 gemm_bf16_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, GBK, 0, TB, 1, 1, 1, 0, 0, 1>(g); }
+// the 32-deep stages of the two (long reductions on small grids): their LDS stages hold them to 2 waves per SIMD whatever is asked for
+template <int TB, int PREC>
+__global__ void __launch_bounds__(256)
+gemm_f32_relu_bwd_deep_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 32, 0, TB, 1, PREC, 1, 0, 0, 0>(g); }
+template <int TB>
+__global__ void __launch_bounds__(256)
+gemm_bf16_relu_bwd_deep_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 32, 0, TB, 1, 1, 1, 0, 0, 1>(g); }
 
 // split mode: three workgroups per CU (50.7 KB of LDS each)
 template <int TA, int TB>
@@ -552,12 +559,12 @@ inline GemmKernel gemm_pick(const GemmArgs &g, bool deep) {
     if ((g.flags & 32) && (g.flags & 1024) && !bf16 && !g.c16 && !g.m16) return g.tb ? gemm_split_relu_bwd_kernel<1> : gemm_split_relu_bwd_kernel<0>;
     if (g.flags & 32) {           // fused backward epilogue: A row-major, 16-byte loads (the launcher checks)
         if (g.c16 || g.m16) {     // bf16 hidden layer and gradient (both or neither: the launcher checks)
-            if (deep) return g.tb ? gemm_bf16_relu_bwd_kernel<32, 1> : gemm_bf16_relu_bwd_kernel<32, 0>;
+            if (deep) return g.tb ? gemm_bf16_relu_bwd_deep_kernel<1> : gemm_bf16_relu_bwd_deep_kernel<0>;
             return g.tb ? gemm_bf16_relu_bwd_kernel<16, 1> : gemm_bf16_relu_bwd_kernel<16, 0>;
         }
         if (deep) {
-            if (bf16) return g.tb ? gemm_f32_relu_bwd_kernel<32, 1, 1> : gemm_f32_relu_bwd_kernel<32, 0, 1>;
-            return g.tb ? gemm_f32_relu_bwd_kernel<32, 1, 0> : gemm_f32_relu_bwd_kernel<32, 0, 0>;
+            if (bf16) return g.tb ? gemm_f32_relu_bwd_deep_kernel<1, 1> : gemm_f32_relu_bwd_deep_kernel<0, 1>;
+            return g.tb ? gemm_f32_relu_bwd_deep_kernel<1, 0> : gemm_f32_relu_bwd_deep_kernel<0, 0>;
         }
         if (bf16) return g.tb ? gemm_f32_relu_bwd_kernel<16, 1, 1> : gemm_f32_relu_bwd_kernel<16, 0, 1>;
         return g.tb ? gemm_f32_relu_bwd_kernel<16, 1, 0> : gemm_f32_relu_bwd_kernel<16, 0, 0>;
