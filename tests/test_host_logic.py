@@ -173,3 +173,17 @@ def test_jrdb_dataset_pickles_collate_and_cli(tmp_path):
     pose, vel = tr.primary_state(None, inj)
     assert torch.equal(pose, inj[:, 8, 2:26, :3]) and torch.allclose(vel, (inj[:, 8, 0, :2] - inj[:, 7, 0, :2]) * 2.5)
     assert tj.JrdbTrainer.value_loss_with_multi_modal is False
+
+
+def test_package_import_raises_the_hardware_queue_count_only_when_the_caller_has_not_chosen():
+    """emloco_amd/__init__.py: GPU_MAX_HW_QUEUES = 16 unless the environment already holds a value (the HIP runtime reads it when it
+    initialises; the package's side streams and the PPO step's graph arms need queues of their own)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, emloco_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    env["PYTHONPATH"] = root
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "16"
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "4"
