@@ -178,7 +178,11 @@ class LocoValRollout:
             # (measured on MI355X, 4096 envs: issued at once 0.93 ms / step, issued ahead of the rigid-body launch 1.06 ms, the
             # sequential order 1.01 ms -- the rigid-body launch holds 3 waves x 168 registers per SIMD and 12 x 12.4 KB of LDS per CU:
             # a GEMM workgroup beside it takes residency away from it, the pipes do not overlap for free; off by default)
-            self._disc_under_physics = os.environ.get("EMLOCO_DISC_UNDER_PHYSICS", "0") == "1"
+            # ... on the runtime's default of 4 hardware queues.  With 16 (what the package sets at import, emloco_amd/__init__.py) the
+            # discriminator's stream has a queue of its own and issuing it ahead of the rigid-body launch WINS: 0.961 -> 0.915 ms per step,
+            # 4.26 -> 4.48 M env-steps/s on one box (profiles/r04_ab_disc_schedule.txt); default: on from 16 queues up.
+            dup = os.environ.get("EMLOCO_DISC_UNDER_PHYSICS", "auto")
+            self._disc_under_physics = dup == "1" or (dup == "auto" and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 16)
             self._disc_pending = False
             for i, st_ in enumerate(self._stage):          # the staged reward / done flag travel with the set
                 st_["staged_reward"] = f(E)
