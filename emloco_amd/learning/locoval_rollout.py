@@ -158,6 +158,12 @@ class LocoValRollout:
         stage_keys = ("traj13", "pose", "vel", "target", "weight")
         self._stage = [{k: (z[k] if i == 0 else torch.zeros_like(z[k])) for k in stage_keys} for i in range(self._nbuf)]
         self._ev_fits = [torch.cuda.Event() for _ in range(self._nbuf)] if self._side is not None else []
+        # WHEN the fit's five small launches are issued: at once (beside the resets' launches, which are on the chain between two
+        # rigid-body launches) or right ahead of the next rigid-body launch (beside a kernel nothing waits for).  Measured on 16 hardware
+        # queues: at once 0.4478 ms per step, ahead of the launch 0.4510 -- the fit's workgroups then sit in the rigid-body launch's wave
+        # slots for its first ~300 us (its kernel time goes 0.364 -> 0.373 ms).  Off unless EMLOCO_FIT_UNDER_PHYSICS=1.
+        self._fit_under_physics = (self._side is not None and os.environ.get("EMLOCO_FIT_UNDER_PHYSICS", "0") == "1")
+        self._fit_waiting = False
         self._buf_busy = [False] * self._nbuf             # a fit that reads the set has been issued (its event recorded)
         self._buf = 0                                      # the set the next returns launch writes
         # The discriminator off the chain between two rigid-body steps.  Its style reward (amp_continuous_value.py:90-96) feeds the
@@ -238,6 +244,8 @@ class LocoValRollout:
         """Host-side readers of what the fit writes (statistics, LocoVal weights) wait for the side stream."""
         if getattr(self, "_disc_halves", None) is not None:
             self._issue_deferred_disc()                     # a step whose discriminator half was still waiting for the next step
+        if getattr(self, "_fit_waiting", False):
+            self._issue_fit()
         if getattr(self, "_side", None) is not None:
             self._side.synchronize()
 
@@ -266,7 +274,16 @@ class LocoValRollout:
         if self._side is None:
             self._fit_launches(st)
             return
-        self._ev_staged.record(main)
+        if self._fit_under_physics:                         # issued from _before_step, right ahead of the next rigid-body launch
+            self._fit_waiting = True
+            return
+        self._issue_fit()
+
+    def _issue_fit(self):
+        """The fit of the step whose returns are staged, on the side stream behind an event of the main stream."""
+        from ..sim import current_stream_handle
+        self._fit_waiting = False
+        self._ev_staged.record(torch.cuda.current_stream(self.device))
         self._side.wait_event(self._ev_staged)
         with torch.cuda.stream(self._side):
             self._fit_launches(current_stream_handle(self.device))
@@ -382,6 +399,8 @@ class LocoValRollout:
         """Take this loop's return bookkeeping out of the task's flags launch (a caller that steps the env on its own in between)."""
         if getattr(self, "_disc_halves", None) is not None:
             self._issue_deferred_disc()
+        if getattr(self, "_fit_waiting", False):
+            self._issue_fit()
         if getattr(self, "_returns_in_flags", False) and hasattr(self.task, "attach_returns"):
             self.task.attach_returns(None)
         if getattr(self, "_amp_ring", False):
@@ -401,6 +420,8 @@ class LocoValRollout:
     def _before_step(self):
         """With the return bookkeeping inside the task's flags launch: what _fused_step does ahead of its own returns launch -- the
         staging buffers must be free (the previous fit has read them), the penalty scale current."""
+        if getattr(self, "_fit_waiting", False):
+            self._issue_fit()                               # the previous step's fit, beside this step's rigid-body launch
         if not getattr(self, "_returns_in_flags", False) or not self.fused:
             return
         if self._disc_halves is not None:
@@ -420,6 +441,8 @@ class LocoValRollout:
         """common_agent.py:205-209: the cosine schedule advances once per epoch, once episodes have finished."""
         if getattr(self, "_disc_halves", None) is not None:
             self._issue_deferred_disc()                          # the epoch's last fit is issued with the epoch's learning rate
+        if getattr(self, "_fit_waiting", False):
+            self._issue_fit()
         if not getattr(self, "_sched_live", False):
             self._sched_live = self.fitted_episodes > 0          # one read per epoch until the first episode has finished
         if self._sched_live:

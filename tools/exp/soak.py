@@ -28,7 +28,7 @@ if __name__ == "__main__":
     def pol(obs):
         k[0] += 1
         return pool[k[0] % 64]
-    agent = LocoValRollout(env, horizon_length=32, policy=pol, overlap_reset=False)
+    agent = LocoValRollout(env, horizon_length=32, policy=pol, overlap_reset=os.environ.get("EMLOCO_SOAK_OVERLAP_RESET", "0") == "1")
     resets, rates = 0, []
     t0 = time.perf_counter()
     for i in range(N):
