@@ -1031,3 +1031,26 @@ def test_fused_kernel_height_observations_equal_the_reference_golden(golden):
     th.rb_state[:, 13, :7] = gt["head_pose"]
     th.post_physics(L.POST_OBS)
     np.testing.assert_array_equal(th.obs[:, 398:], gt["height_obs"])
+
+
+def test_sim_step_kernel_at_the_edge_of_the_heightfield_and_on_stairs_is_bit_exact_vs_oracle():
+    """The terrain probes one radius out (four per sphere) where they leave the map (the border cell's plane extends: clamped cell
+    indices) and where neighbouring triangles differ most (a staircase of one-cell risers): emulated kernel == oracle bytes."""
+    E = 3
+    models = varied_models(E, seed=17)
+    root, dof, tgt = scene_state(E, seed=18)
+    n = 200
+    steps = ((np.arange(n)[:, None] // 3) % 4 * 30 + 0 * np.arange(n)[None, :]).astype(np.int16)      # 15 cm risers every 30 cm, 4 high, repeating
+    hf = dict(samples=steps, horizontal_scale=0.1, vertical_scale=0.005)
+    root = root.copy()
+    root[:, 0] = [0.04, 9.93, 19.88]                      # over the first cell, mid map, over the last cell (the map is 19.9 m wide)
+    root[:, 1] = [0.03, 10.0, 19.86]
+    root[:, 2] = 1.05 + steps[np.clip((root[:, 0] / 0.1).astype(int), 0, n - 1), 0] * 0.005
+    a = oracle_sim(models, root, dof, tgt, heightfield=hf, n_sub=4)
+    b = oracle_sim(models, root, dof, tgt, heightfield=hf, n_sub=4)
+    for _ in range(6):
+        a.step(1)
+        emu.sim_step(b, 1)
+        for name in ("root_state", "dof_state", "rb_state", "contact_force", "dof_force", "lambda_ws"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert np.isfinite(a.rb_state).all() and np.abs(a.contact_force).max() > 50

@@ -334,3 +334,31 @@ def test_effort_drives_through_the_c_abi_are_bit_exact_and_switch_back():
         osim.step(1)
         gsim.step(2)
         _compare(osim, gsim, E, what=f"position step {k}")
+
+
+def test_stairs_and_map_border_stay_on_the_oracles_bytes():
+    """The terrain probes one radius out (four per sphere) on a staircase of one-cell risers and where they leave the map (clamped border
+    cells): humanoids standing over the first cell, mid map and the last cell, falling and tumbling over the steps for an episode."""
+    from emloco_amd import _lib as L
+    from emloco_amd.sim import NativeSim
+    from helpers import oracle_sim, scene_state, varied_models
+    E = 6
+    models = varied_models(E, 41)
+    root, dof, tgt = scene_state(E, 42, perturbed_from=0)
+    n = 200
+    steps = ((np.arange(n)[:, None] // 3) % 4 * 30 + 0 * np.arange(n)[None, :]).astype(np.int16)      # 15 cm risers every 30 cm
+    hf = dict(samples=steps, horizontal_scale=0.1, vertical_scale=0.005)
+    root[:, 0] = [0.04, 9.93, 19.88, 5.0, 5.15, 12.31]
+    root[:, 1] = [0.03, 10.0, 19.86, 0.02, 8.0, 19.89]
+    root[:, 2] = 1.05 + steps[np.clip((root[:, 0] / 0.1).astype(int), 0, n - 1), 0] * 0.005
+    osim = oracle_sim(models, root, dof, tgt, heightfield=hf, n_sub=4)
+    gsim = NativeSim(models, L.default_sim_params(n_sub=2), heightfield=hf)
+    gsim.root_state.copy_(torch.from_numpy(root))
+    gsim.dof_state.view(E, 69, 2).copy_(torch.from_numpy(dof))
+    gsim.pd_target.copy_(torch.from_numpy(tgt))
+    for k in range(120):
+        osim.step(1)
+        gsim.step(2)
+        if k in (0, 3, 15, 50, 119):
+            _compare(osim, gsim, E, what=f"stairs step {k}")
+    assert torch.isfinite(gsim.rigid_body_state).all() and float(gsim.contact_force.abs().max()) > 50.0
