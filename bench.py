@@ -585,7 +585,6 @@ def main():
     ap.add_argument("--no_policy", action="store_true", help="skip the frozen-policy leg (row A19, reported separately)")
     ap.add_argument("--no_jta", action="store_true", help="skip the train_jta samples/s leg (run on rank 0 at N=1)")
     ap.add_argument("--no_ppo", action="store_true", help="skip the PPO + AMP train_epoch leg (configs[1] end to end; rank 0 at N=1, under `policy`)")
-    ap.add_argument("--no_pipelined", action="store_true", help="(accepted, ignored: the two-shard and two-chain legs of rounds 2-3 lost to the headline schedule and are gone)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher -- one process per GPU, as the driver's

@@ -1339,7 +1339,9 @@ clip_coef_kernel(int nparts, const float *part, float max_norm, float *out) {
     if (threadIdx.x == 0) {
         const float norm = (float)sqrt(sh[0]);
         const float c = max_norm / (norm + 1e-6f);
-        out[0] = norm; out[1] = c < 1.0f ? c : 1.0f;
+        // torch.clamp(c, max=1): a NaN norm gives a NaN coefficient and with it NaN in EVERY gradient -- loud, like clip_grad_norm_
+        // (c < 1 ? c : 1 alone would turn it into 1 and let the finite slices train on a corrupt step)
+        out[0] = norm; out[1] = (c < 1.0f || c != c) ? c : 1.0f;
     }
 }
 __global__ void adam_flat_kernel(long n, float *p, float *g, float *m, float *v, const float *coef, float lr, float omb1, float b2, float omb2,

@@ -8,7 +8,6 @@
 #include "sim_state.h"
 #include "../../include/emloco_predictor.h"
 
-extern "C" int emloco_sim_fk_indexed(EmlocoSim *s, const int32_t *ids, int n, void *stream);
 
 namespace {
 hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;

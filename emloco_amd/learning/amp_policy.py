@@ -72,6 +72,11 @@ class AMPPolicyBundle:
         with torch.no_grad():
             self.frozen_disc.stage(amp_obs)
 
+    def disc_stage_ring(self, n):
+        """Size the staged operand's ring: the number of `disc_stage` calls that may be issued before the oldest `disc_reward_staged`
+        has run (FrozenDisc.set_stage_ring)."""
+        self.frozen_disc.set_stage_ring(n)
+
     def disc_reward_staged(self):
         """Second half (FrozenDisc.reward_staged): the GEMMs and the scalar transform, nothing of the task's is read."""
         with torch.no_grad():

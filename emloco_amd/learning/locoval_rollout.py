@@ -181,6 +181,14 @@ class LocoValRollout:
                 and hasattr(owner, "disc_reward_staged") and getattr(task, "fused_chain", False)
                 and os.environ.get("EMLOCO_DEFER_DISC", "1") != "0"):
             self._disc_halves = (owner.disc_stage, owner.disc_reward_staged)
+            # the staged GEMM operand travels with the ring of staging sets: stage(t) on the main stream must not overwrite what the
+            # discriminator of an earlier step still reads on the side stream (the host-side hand-back of a set, `_acquire_stage`, runs
+            # ahead of every flags launch and so ahead of every stage; it waits for the fit BEHIND that discriminator)
+            if hasattr(owner, "disc_stage_ring"):
+                owner.disc_stage_ring(self._nbuf)
+            elif self._nbuf > 1:
+                raise RuntimeError("LocoValRollout: a two-half discriminator must provide disc_stage_ring(n) to run beside a ring of "
+                                   "staging sets (set EMLOCO_FIT_BUFFERS=1 for a single set and the stream-side wait)")
             # (measured on MI355X, 4096 envs: issued at once 0.93 ms / step, issued ahead of the rigid-body launch 1.06 ms, the
             # sequential order 1.01 ms -- the rigid-body launch holds 3 waves x 168 registers per SIMD and 12 x 12.4 KB of LDS per CU:
             # a GEMM workgroup beside it takes residency away from it, the pipes do not overlap for free; off by default)
@@ -188,7 +196,8 @@ class LocoValRollout:
             # discriminator's stream has a queue of its own and issuing it ahead of the rigid-body launch WINS: 0.961 -> 0.915 ms per step,
             # 4.26 -> 4.48 M env-steps/s on one box (profiles/r04_ab_disc_schedule.txt); default: on from 16 queues up.
             dup = os.environ.get("EMLOCO_DISC_UNDER_PHYSICS", "auto")
-            self._disc_under_physics = dup == "1" or (dup == "auto" and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 16)
+            from .. import hw_queues                       # what the runtime was initialised with (None: unknown -> the 4-queue order)
+            self._disc_under_physics = dup == "1" or (dup == "auto" and (hw_queues() or 4) >= 16)
             self._disc_pending = False
             for i, st_ in enumerate(self._stage):          # the staged reward / done flag travel with the set
                 st_["staged_reward"] = f(E)
@@ -446,6 +455,10 @@ class LocoValRollout:
         if not getattr(self, "_sched_live", False):
             self._sched_live = self.fitted_episodes > 0          # one read per epoch until the first episode has finished
         if self._sched_live:
+            # (the fit's AdamW is a HIP kernel, `emloco_adamw_gated`: torch never sees an optimizer.step() and would warn on every
+            # epoch that the schedule is stepped first -- the counter it looks at is bumped here instead; the schedule itself is pinned
+            # to the reference's class, tests/golden/locoval_lr_schedule.npz)
+            self.vnet_optimizer._opt_called = True
             self.vnet_scheduler.step()
 
     def play_steps(self):

@@ -127,6 +127,9 @@ class FrozenDisc:
         self.eps = float(amp_mean_std.epsilon)
         f = dict(dtype=torch.float32, device=self.device)
         self.x = torch.zeros((num_envs, self.in_k), **f)              # pad columns stay zero
+        # the staged halves below hand the operand from `stage` (caller's stream) to `reward_staged` (possibly another stream, later):
+        # a ring of operands, written and read in FIFO order, so that a stage never overwrites what a lagging reward_staged still reads
+        self._xs, self._xw, self._xr = [self.x], 0, 0
         self.h = [torch.empty((num_envs, w.shape[0]), **f) for w, _ in self.layers]
         self.logits = torch.empty((num_envs, 1), **f)
         self.floor = torch.tensor(0.0001, device=self.device)
@@ -140,19 +143,22 @@ class FrozenDisc:
         x = amp_obs.reshape(amp_obs.shape[0], -1)
         assert x.shape == (self.E, self.in_size) and x.dtype == torch.float32
         if self.normalize:
-            self._normalize_padded(x.contiguous())
+            self._normalize_padded(x.contiguous(), self.x)
         else:
             self.x[:, :self.in_size].copy_(x)
-        cur, k = self.x, self.in_k
+        return self._logits_from(self.x)
+
+    def _logits_from(self, operand):
+        cur, k = operand, self.in_k
         for (w, b), out in zip(self.layers, self.h):
             self._linear(cur, k, w, b, out, True)
             cur, k = out, w.shape[0]
         self._linear(cur, k, self.logit_w, self.logit_b, self.logits, False)
         return self.logits
 
-    def _normalize_padded(self, x):
+    def _normalize_padded(self, x, out):
         # emloco_obs_normalize writes `split` columns to out0 with its own leading dimension: the padded operand takes them all
-        obs_normalize(x, self.mean32, self.var32, self.eps, 5.0, split=self.in_size, out0=self.x)
+        obs_normalize(x, self.mean32, self.var32, self.eps, 5.0, split=self.in_size, out0=out)
 
     def reward(self, amp_obs):
         return self._reward_of(self.logits_of(amp_obs))
@@ -170,18 +176,30 @@ class FrozenDisc:
     # (one launch on the caller's stream) takes what it needs out of the step's AMP observations -- the normalised, padded GEMM
     # operand -- before the resets overwrite them; `reward_staged` (three GEMMs + the scalar transform, any stream ordered behind the
     # stage) reads nothing of the task's.  Same launches on the same values as `reward`.
+    # The operand is a ring (`set_stage_ring(n)`; one buffer by default): stage number t writes buffer t mod n, the t-th reward_staged
+    # reads it.  A caller that runs reward_staged on another stream sizes the ring to the number of stages it lets run ahead of the
+    # rewards (LocoValRollout: its ring of staging sets, whose hand-back -- the host waits for the fit of n steps ago before the flags
+    # launch -- then covers this operand as well; with ONE buffer, stage(t + 1) on the main stream raced the first GEMM of
+    # reward_staged(t) on the side stream whenever the side stream lagged: round-4 review).
+    def set_stage_ring(self, n):
+        n = max(1, int(n))
+        while len(self._xs) < n:
+            self._xs.append(torch.zeros_like(self.x))              # pad columns stay zero
+        del self._xs[n:]
+        self._xw = self._xr = 0
+
     def stage(self, amp_obs):
         x = amp_obs.reshape(amp_obs.shape[0], -1)
         assert x.shape == (self.E, self.in_size) and x.dtype == torch.float32
+        dst = self._xs[self._xw % len(self._xs)]
+        self._xw += 1
         if self.normalize:
-            self._normalize_padded(x.contiguous())
+            self._normalize_padded(x.contiguous(), dst)
         else:
-            self.x[:, :self.in_size].copy_(x)
+            dst[:, :self.in_size].copy_(x)
 
     def reward_staged(self):
-        cur, k = self.x, self.in_k
-        for (w, b), out in zip(self.layers, self.h):
-            self._linear(cur, k, w, b, out, True)
-            cur, k = out, w.shape[0]
-        self._linear(cur, k, self.logit_w, self.logit_b, self.logits, False)
-        return self._reward_of(self.logits)
+        assert self._xr < self._xw, "reward_staged without a stage"
+        src = self._xs[self._xr % len(self._xs)]
+        self._xr += 1
+        return self._reward_of(self._logits_from(src))

@@ -243,13 +243,30 @@ SMPL_SHAPE_FILTERS = [0, 0, 7, 16, 12, 0, 56, 2, 33, 128, 0, 192, 0, 64, 0, 0, 0
 SC_MAXSEG = 32          # EMLOCO_SC_MAXSEG
 
 
-def collision_capsules(model: HumanoidModel):
+def collision_topology(model: HumanoidModel):
+    """The SHAPE of a humanoid's collision segments, decided once per simulator from a canonical model (the first env's): per box
+    body the axis order (thinnest, middle, longest) and whether the box is split into two capsules.  Every env of the sim then uses
+    this topology with its own dimensions (`collision_capsules(m, topology)`): a population of body shapes in which one foot box
+    crosses the split threshold, or swaps two nearly equal axes, still shares one segment list and one pair table."""
+    topo = {}
+    for i in range(model.num_bodies):
+        if model.geom_type[i] == GEOM_BOX:
+            h = np.abs(model.geom_b[i])
+            order = np.argsort(h)                              # thinnest, middle, longest axis
+            topo[i] = (tuple(int(x) for x in order), bool(h[order[1]] > 1.5 * float(h[order[0]])))
+    return topo
+
+
+def collision_capsules(model: HumanoidModel, topology=None):
     """Sphere-swept segments of the bodies for limb-limb contact, in the body frame: spheres and capsules as they are; a box as
     the capsule along its longest axis with the smallest half extent as radius -- and, where the box is much WIDER than that
     capsule (middle half extent > 1.5 x the smallest: the SMPL ankle boxes, 17 x 9.7 x 4.2 cm; the toe boxes are as thick as wide
     and keep one capsule), as TWO such capsules along its two long edges, so that the foot collides with its real width.
+    `topology` (collision_topology of a canonical model; default: this model's own) fixes which boxes are split and along which
+    axes; only end points and radii follow this model's dimensions.
     Returns (a, b, r, seg_body): n_seg = 24 + number of second capsules rows each; seg_body[i] = i for i < 24."""
     nb = model.num_bodies
+    topology = collision_topology(model) if topology is None else topology
     a, b, r = [model.geom_a[i].copy() for i in range(nb)], [model.geom_a[i].copy() for i in range(nb)], [float(model.geom_r[i]) for i in range(nb)]
     seg_body = list(range(nb))
     for i in range(nb):
@@ -257,13 +274,13 @@ def collision_capsules(model: HumanoidModel):
             b[i] = model.geom_b[i].copy()
         elif model.geom_type[i] == GEOM_BOX:
             h = np.abs(model.geom_b[i])
-            order = np.argsort(h)                              # thinnest, middle, longest axis
+            order, split = topology[i]
             rad = float(h[order[0]])
             half = np.zeros(3)
             half[order[2]] = max(h[order[2]] - rad, 0.0)
-            if h[order[1]] > 1.5 * rad:
+            if split:
                 side = np.zeros(3)
-                side[order[1]] = h[order[1]] - rad                 # the two capsules touch the box's long faces from inside
+                side[order[1]] = max(h[order[1]] - rad, 0.0)       # the two capsules touch the box's long faces from inside
                 a[i], b[i], r[i] = model.geom_a[i] - half - side, model.geom_a[i] + half - side, rad
                 a.append(model.geom_a[i] - half + side); b.append(model.geom_a[i] + half + side); r.append(rad)
                 seg_body.append(i)
@@ -323,10 +340,11 @@ def self_collision_pairs(model: HumanoidModel, filters=None, margin=0.01):
 def pack_self_collision(models, k=1.5e4, c=60.0, max_pen=0.04, filters=None, mu=1.0):
     """Arrays of `EmlocoSelfCollisionDesc` (include/emloco_sim.h): the segment-pair table and segment -> body map of the first model
     (one table per sim: the kernels share it across envs) and per-env collision segments."""
-    caps = [collision_capsules(m) for m in models]
+    if any((m.geom_type != models[0].geom_type).any() for m in models):
+        raise ValueError("the envs' humanoids must have the same geom types per body (one segment topology per sim)")
+    topo = collision_topology(models[0])              # which boxes are split, along which axes: decided ONCE, dimensions per env
+    caps = [collision_capsules(m, topo) for m in models]
     seg_body = caps[0][3]
-    if any(len(cpl[3]) != len(seg_body) or (cpl[3] != seg_body).any() for cpl in caps):
-        raise ValueError("the envs' humanoids must have the same collision segments (same boxes split in two)")
     f32 = lambda idx: np.ascontiguousarray(np.stack([cpl[idx] for cpl in caps]).astype(np.float32))
     return dict(pairs=np.ascontiguousarray(self_collision_pairs(models[0], filters)), cap_a=f32(0), cap_b=f32(1), cap_r=f32(2),
                 k=float(k), c=float(c), max_pen=float(max_pen), mu=float(mu), seg_body=np.ascontiguousarray(seg_body))

@@ -13,6 +13,11 @@ moments are views into four flat fp32 buffers:
   (`last_norm`).
 
 One param group, no amsgrad / maximize (what the reference uses); anything else raises.
+
+Two deliberate differences from torch.optim.Adam, both outside what the reference's loops do: (1) a parameter whose gradient was never
+written is treated as having a ZERO gradient (its slice of the bucket is zero: step count and moment decay advance), where torch skips
+parameters whose `.grad` is None -- every parameter of the predictor receives a gradient every step; (2) a NaN / Inf gradient norm
+makes the clip coefficient NaN and with it every gradient, parameter and moment (as `clip_grad_norm_` does: loud, not partial).
 """
 import ctypes as C
 import math

@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from ..dist import world_size
+from ..dist import all_reduce_mean_scalar, world_size
 from .dataset_jrdb import batch_process_coords, collate_batch, create_dataset, get_datasets
 from .train_jta import (MSE_LOSS, MSE_LOSS_MULTI, EmLocoTrainer, adjust_learning_rate, create_logger, load_checkpoint,  # noqa: F401
                         load_config, save_checkpoint)
@@ -110,14 +110,15 @@ def main(config, logger, valuenet, dataloader_train, dataloader_val, limit_obs=0
     trainer = JrdbTrainer(model, valuenet, config, data_parallel=world_size() > 1)
     logger.info(f"Model has {sum(p.numel() for p in model.parameters() if p.requires_grad)} parameters.")
     modality = config.get("MODALITY", "traj+all")
-    min_val = 1e6 if not config.get("RESUME", -1) else evaluate_loss(model, dataloader_val, valuenet, config) / 100
+    min_val = 1e6 if not config.get("RESUME", -1) else all_reduce_mean_scalar(evaluate_loss(model, dataloader_val, valuenet, config) / 100)
     logger.info(f"Initial validation loss: {min_val:.3f}")
     if valuenet is not None:
         logger.info(f'Using Value Loss weight: {float(config["TRAIN"]["valuenet_weight"]):.3f}')
     best_epoch = -1
     for epoch in range(config.get("RESUME", -1) + 1, config["TRAIN"]["epochs"]):
         tr = train_epoch(trainer, dataloader_train, epoch, modality, max_steps=1 if config.get("dry_run") else None)
-        val_ade = evaluate_loss(model, dataloader_val, valuenet, config, limit_obs=False, modality_selection=modality) / 100
+        # (the ranks' mean: the comparison below leads into save_checkpoint's barrier and must come out the same on every rank)
+        val_ade = all_reduce_mean_scalar(evaluate_loss(model, dataloader_val, valuenet, config, limit_obs=False, modality_selection=modality) / 100)
         logger.info(f"Epoch {epoch} | Train Loss: {tr:.3f} | Val ADE: {val_ade:.3f}")
         if val_ade < min_val:
             min_val, best_epoch = val_ade, epoch

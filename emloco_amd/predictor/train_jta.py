@@ -9,7 +9,7 @@ import os
 
 import torch
 
-from ..dist import FlatGradBucket, all_reduce_, barrier, broadcast_parameters, rank, world_size
+from ..dist import FlatGradBucket, all_reduce_, all_reduce_mean_scalar, barrier, broadcast_parameters, rank, world_size
 
 
 def MSE_LOSS(output, target, mask=None):
@@ -370,7 +370,9 @@ def main(config, logger, valuenet, dataloader_train, dataloader_val, limit_obs=0
     min_val, best_epoch = 1e6, -1
     for epoch in range(config.get("RESUME", -1) + 1, config["TRAIN"]["epochs"]):
         tr = train_epoch(trainer, dataloader_train, epoch, modality, max_steps=1 if config.get("dry_run") else None)
-        val_ade = evaluate_loss(model, dataloader_val, config, modality, limit_obs=limit_obs) / 100
+        # data parallel: every rank evaluates its own shuffled pass and the ranks' numbers differ in the last digits; the decision
+        # below leads into a collective (save_checkpoint's barrier), so it is taken on the ranks' MEAN, which is the same everywhere
+        val_ade = all_reduce_mean_scalar(evaluate_loss(model, dataloader_val, config, modality, limit_obs=limit_obs) / 100)
         logger.info(f"Epoch {epoch} | Train Loss: {tr:.3f} | Val ADE: {val_ade:.3f}")
         if val_ade < min_val:
             min_val, best_epoch = val_ade, epoch

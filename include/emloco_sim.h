@@ -174,6 +174,18 @@ int emloco_sim_sync(EmlocoSim *sim, void *stream);
  * emloco_sim_sync / the next emloco_sim_step return as EMLOCO_E_HIP: this call lets a test see that path in milliseconds
  * instead of seconds (tests/test_gpu_sim.py).  Costs the kernel one scalar compare per part. */
 int emloco_sim_debug_poison_part(EmlocoSim *sim, int env, int spin_max);
+/* Diagnostics and one cross-unit helper (no counterpart in the gym API; the product's Python never calls the three diagnostic
+ * ones -- tools/sim_phase_profile.py, tools/exp/cost_hist.py do).  They synchronise the device and copy to HOST buffers.
+ *   emloco_sim_fk_indexed   forward kinematics of the listed envs (device int32 ids); the reset chain of emloco_task.h calls it
+ *                           (the two translation units link through this symbol)
+ *   emloco_sim_cost_ticks   per-env durations (100 MHz ticks) of the latest step, the key of the cost-ordered dispatch
+ *                           (emloco_sim_set_cost_order must be on) and, from the second call on, each workgroup's start stamps
+ *                           (host_start: 2 n_envs entries, or NULL)
+ *   emloco_sim_profile      wall-clock stamps of env 0, 16 per substep (kernels built with -DEMLOCO_SIM_PROFILE; without it the
+ *                           buffer stays zero).  The first call allocates the stamp buffer and returns. */
+int emloco_sim_fk_indexed(EmlocoSim *sim, const int32_t *dev_env_ids, int n, void *stream);
+int emloco_sim_cost_ticks(EmlocoSim *sim, unsigned *host_ticks, unsigned long long *host_start, int n);
+int emloco_sim_profile(EmlocoSim *sim, long long *host_out, int n);
 /* gym.set_actor_root_state_tensor_indexed / set_dof_state_tensor_indexed -- humanoid.py:470-475.
  * `dev_full` is the full tensor (may be the sim's own alias); rows of the listed envs are applied and the
  * rigid-body state of those envs is recomputed.  `dev_env_ids` int32 device pointer, n entries. */

@@ -276,6 +276,12 @@ int emloco_task_reset_obs_pooled(struct EmlocoSim *sim, const EmlocoResetBufs *r
                                  const int64_t *dev_skip, const int32_t *dev_env_ids, int n, uint64_t seed, float *dev_rnd_ws,
                                  const float *dev_rnd, const EmlocoResetPool *pool, void *stream);
 
+/* Diagnostic (tools/exp/chain_prof.py; the product never calls it): the first call allocates 16 wall-clock stamps (100 MHz) that
+ * every later emloco_task_reset_obs* launch overwrites -- [0..5] reset entry 0: start, random row, sample, kinematics, finish,
+ * observations; [6, 7] last AMP history row of entry 0; [8, 9] / [10, 11] the observation workgroups of env 0 / the last env -- and
+ * copies them to host16 (may be NULL).  Synchronises the device. */
+int emloco_task_chain_profile(long long *host16);
+
 #ifdef __cplusplus
 }
 #endif

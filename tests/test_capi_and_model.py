@@ -27,6 +27,12 @@ def test_library_exports_every_declared_symbol():
             assert hasattr(lib, n), f"{n} declared in include/{header} but not exported"
     assert set(_lib.SYMBOLS_SIM) <= set(_declared("emloco_sim.h"))
     assert set(_lib.SYMBOLS_TASK) <= set(_declared("emloco_task.h"))
+    # ... and the other way round: nothing is exported behind the headers' back (round-4 review: four diagnostic exports were)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("emloco_")}
+    declared = set(_declared("emloco_sim.h")) | set(_declared("emloco_task.h")) | set(_declared("emloco_predictor.h"))
+    assert exported <= declared, f"exported but not declared in include/*.h: {sorted(exported - declared)}"
 
 
 def test_product_path_fails_loudly_without_a_gpu():
@@ -101,3 +107,30 @@ def test_host_torch_utils_match_reference(golden):
     np.testing.assert_allclose(tu.quat_to_exp_map(q).numpy(), g["quat_to_exp_map"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(tu.slerp(q, q2, torch.from_numpy(g["t"])).numpy(), g["slerp"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(tu.quat_apply_yaw(q.clone(), v).numpy(), g["quat_apply_yaw"], **tol)
+
+
+def test_collision_topology_is_decided_once_for_all_envs():
+    """model.pack_self_collision: which boxes are split in two capsules, and along which axes, comes from the FIRST env's model; an
+    env whose foot box falls on the other side of the split threshold (or whose two smaller half extents swap order) shares that
+    topology with its own dimensions -- before round 5 such a population made sim creation raise."""
+    import copy
+    from emloco_amd.model import GEOM_BOX, collision_capsules, collision_topology, pack_self_collision, smpl_humanoid
+    base = smpl_humanoid()
+    ankle = [i for i in range(base.num_bodies) if base.geom_type[i] == GEOM_BOX and "Ankle" in base.names[i]][0]
+    odd = copy.deepcopy(base)
+    h = np.abs(odd.geom_b[ankle]).copy()
+    order = np.argsort(h)
+    h[order[1]] = 1.2 * h[order[0]]                      # middle half extent below 1.5 x the thinnest: on its own this box is ONE capsule
+    odd.geom_b[ankle] = h * np.sign(np.where(odd.geom_b[ankle] == 0, 1.0, odd.geom_b[ankle]))
+    assert len(collision_capsules(odd)[3]) == len(collision_capsules(base)[3]) - 1
+    sc = pack_self_collision([base, odd, base])
+    n_seg = len(sc["seg_body"])
+    assert sc["cap_a"].shape == (3, n_seg, 3) and n_seg == len(collision_capsules(base)[3])
+    topo = collision_topology(base)
+    a, b, r, sb = collision_capsules(odd, topo)
+    assert list(sb) == list(sc["seg_body"])
+    second = [i for i in range(24, n_seg) if sb[i] == ankle][0]
+    # the two capsules of the narrow box still straddle its centre line along the canonical middle axis, by its OWN half width
+    mid = topo[ankle][0][1]
+    assert abs((a[second][mid] - a[ankle][mid]) - 2 * (h[order[1]] - h[order[0]])) < 1e-12
+    assert np.allclose(sc["cap_a"][0], sc["cap_a"][2]) and not np.allclose(sc["cap_a"][0], sc["cap_a"][1])

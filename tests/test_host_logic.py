@@ -187,3 +187,12 @@ def test_package_import_raises_the_hardware_queue_count_only_when_the_caller_has
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "16"
     env["GPU_MAX_HW_QUEUES"] = "4"
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "4"
+    # opt-out: a host application that does not want the library to touch the process environment
+    env2 = {k: v for k, v in env.items() if k != "GPU_MAX_HW_QUEUES"}
+    env2["EMLOCO_KEEP_HW_QUEUES"] = "1"
+    code2 = "import os, emloco_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'), emloco_amd.hw_queues())"
+    assert subprocess.run([sys.executable, "-c", code2], env=env2, capture_output=True, text=True).stdout.split() == ["None", "4"]
+    # the package records what the runtime will be initialised with: schedules key off that, not off the environment of the moment
+    code3 = "import os, emloco_amd; os.environ['GPU_MAX_HW_QUEUES'] = '2'; print(emloco_amd.hw_queues())"
+    env3 = {k: v for k, v in env.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code3], env=env3, capture_output=True, text=True).stdout.strip() == "16"

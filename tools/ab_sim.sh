@@ -8,7 +8,7 @@ for rep in 1 2 3; do
   for v in A B; do
     f=$A; [ $v = B ] && f=$B
     cp $f $LIB
-    python bench.py --no_cpu_baseline --no_jta --no_policy --no_pipelined --steps 200 --warmup 20 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], 'kernel_ms', d['roofline']['kernel_ms'], 'env_only', d['env_step_only']['value'])"
+    python bench.py --no_cpu_baseline --no_jta --no_policy --steps 200 --warmup 20 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], 'kernel_ms', d['roofline']['kernel_ms'], 'env_only', d['env_step_only']['value'])"
   done
 done
 cp /tmp/orig.so $LIB

@@ -9,7 +9,7 @@ R=${1:-r01}
 OUT=$PWD/gpurun_out/$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 100 --warmup 10 --no_cpu_baseline --no_pipelined --no_ppo"
+BENCH="python $PWD/bench.py --steps 100 --warmup 10 --no_cpu_baseline --no_ppo"
 T="timeout 900"      # a rocprofv3 pass that hangs must not eat the GPU budget
 
 # 1. kernel trace + stats of the bench command (env leg + JTA leg)
@@ -37,7 +37,7 @@ for r in csv.DictReader(open(sys.argv[1])):
         grid = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
         g[grid // max(wg, 1)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 with open(sys.argv[2], "w") as o:
-    o.write("sim_step_kernel launches of `bench.py --steps 100 --warmup 10 --no_cpu_baseline --no_pipelined` by grid (workgroups): calls, avg / min / max us\n")
+    o.write("sim_step_kernel launches of `bench.py --steps 100 --warmup 10 --no_cpu_baseline` by grid (workgroups): calls, avg / min / max us\n")
     for k in sorted(g, reverse=True):
         v = g[k]
         o.write(f"  {k:6d} workgroups: {len(v):5d} calls  avg {sum(v)/len(v):8.1f}  min {min(v):8.1f}  max {max(v):8.1f}\n")

@@ -8,7 +8,7 @@ for rep in 1 2; do
     f=$A; [ $v = B ] && f=$B
     cp $f $LIB
     echo "$v fp32-class: $(python tools/exp/jta_step.py 4 2>/dev/null | tail -1)   bf16: $(JTA_PRECISION=bf16 python tools/exp/jta_step.py 4 2>/dev/null | tail -1)"
-    python bench.py --no_cpu_baseline --no_jta --no_pipelined --steps 200 --warmup 20 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], 'env_only', d['env_step_only']['value'], 'policy', d['policy']['value'], d['policy']['policy_ms'])"
+    python bench.py --no_cpu_baseline --no_jta --steps 200 --warmup 20 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], 'env_only', d['env_step_only']['value'], 'policy', d['policy']['value'], d['policy']['policy_ms'])"
   done
 done
 cp /tmp/orig.so $LIB

@@ -3,7 +3,7 @@
 out=${1:-gpurun_out/r02/env_kernels.txt}
 R=$(pwd); mkdir -p $(dirname $out)
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_env
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_env -- python $R/bench.py --steps 200 --warmup 20 --no_cpu_baseline --no_policy --no_jta --no_pipelined > /tmp/prof_env.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_env -- python $R/bench.py --steps 200 --warmup 20 --no_cpu_baseline --no_policy --no_jta > /tmp/prof_env.log 2>&1
 cd $R
 python - "$out" <<'PY'
 import csv, glob, sys, re

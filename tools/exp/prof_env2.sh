@@ -3,7 +3,7 @@
 out=${1:-gpurun_out/env_trace2.txt}
 R=$(pwd); mkdir -p $(dirname $out)
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_env2
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_env2 -- python $R/bench.py --steps 120 --warmup 20 --no_cpu_baseline --no_policy --no_jta --no_pipelined > /tmp/prof_env2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_env2 -- python $R/bench.py --steps 120 --warmup 20 --no_cpu_baseline --no_policy --no_jta > /tmp/prof_env2.log 2>&1
 cd $R
 python - "$out" <<'PY'
 import csv, glob, sys, re

@@ -7,7 +7,7 @@ R=$(pwd); mkdir -p $(dirname $out)
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_2r
 EMLOCO_BENCH_SHARE_GPU=1 timeout 900 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/prof_2r -- \
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 $R/bench.py --gpus 2 --steps 60 --warmup 20 \
-  --num_envs 2048 --no_jta --no_policy --no_pipelined --no_cpu_baseline > /tmp/prof_2r.log 2>&1
+  --num_envs 2048 --no_jta --no_policy --no_cpu_baseline > /tmp/prof_2r.log 2>&1
 cd $R
 python - "$out" <<'PY'
 import csv, glob, sys, re, collections

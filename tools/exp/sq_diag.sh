@@ -3,7 +3,7 @@
 # (counters only; separate passes).  Usage: bash tools/exp/sq_diag.sh OUTFILE
 export TMPDIR=/tmp
 OUT=${1:-gpurun_out/sq_diag.txt}
-CMD="python $PWD/bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_pipelined --no_jta --no_policy"
+CMD="python $PWD/bench.py --steps 20 --warmup 5 --no_cpu_baseline --no_jta --no_policy"
 export EMLOCO_OVERLAP_RESET=0
 SETS=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_MFMA"
       "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU"

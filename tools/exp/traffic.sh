@@ -4,7 +4,7 @@ R=$(pwd); export TMPDIR=/tmp EMLOCO_OVERLAP_RESET=0
 for SP in "$@"; do
   export EMLOCO_SPLIT=$SP
   for C in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/tr_$C && (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/tr_$C -- python $R/bench.py --steps 20 --warmup 5 --no_jta --no_policy --no_pipelined --no_cpu_baseline > /tmp/tr_$C.log 2>&1)
+    rm -rf /tmp/tr_$C && (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/tr_$C -- python $R/bench.py --steps 20 --warmup 5 --no_jta --no_policy --no_cpu_baseline > /tmp/tr_$C.log 2>&1)
   done
   python - $SP <<'PY'
 import csv, glob, sys
