@@ -1,0 +1,56 @@
+// ffn_capi.hip -- C ABI of the chained feed-forward kernels (include/emloco_predictor.h), a translation unit of its own so that its
+// compiler switches can be chosen apart from the GEMM unit's (emloco_amd/build.py).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <stdlib.h>
+#include "ffn_kernels.hip"
+#include "../../include/emloco_predictor.h"
+
+namespace {
+int ffail(int code, const char *what, hipError_t e = hipSuccess) {
+    if (e != hipSuccess) fprintf(stderr, "[emloco] %s: %s\n", what, hipGetErrorString(e));
+    else fprintf(stderr, "[emloco] %s\n", what);
+    return code;
+}
+bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+}  // namespace
+
+extern "C" {
+
+int emloco_ffn_fwd(int M, int F, const float *x, const uint16_t *w1_bf16, const uint16_t *w2_bf16, const float *b1, const float *b2,
+                   uint16_t *hidden, float *out, float drop_p, uint32_t seed_hidden, uint32_t seed_out, void *stream) {
+    if (M < 1 || F < FFN_CH || F % FFN_CH || !x || !w1_bf16 || !w2_bf16 || !b1 || !b2 || !hidden || !out || !(drop_p >= 0.0f && drop_p < 1.0f))
+        return ffail(-1, "emloco_ffn_fwd: bad argument (hidden width must be a multiple of 64, 0 <= drop_p < 1)");
+    if (!aligned16(x) || !aligned16(w1_bf16) || !aligned16(w2_bf16) || !aligned16(b1) || !aligned16(b2) || !aligned16(hidden) || !aligned16(out))
+        return ffail(-1, "emloco_ffn_fwd: operands must be 16-byte aligned");
+    emloco::FfnArgs a{M, F, x, w1_bf16, w2_bf16, b1, b2, hidden, nullptr, out, drop_p, 1.0f / (1.0f - drop_p), seed_hidden,
+                      (unsigned)(drop_p * 65536.0f), seed_out};
+    const dim3 grid((unsigned)((M + FFN_ROWS - 1) / FFN_ROWS));
+    if (drop_p > 0.0f) hipLaunchKernelGGL((emloco::ffn_chain_kernel<0, 1>), grid, dim3(FFN_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((emloco::ffn_chain_kernel<0, 0>), grid, dim3(FFN_THREADS), 0, (hipStream_t)stream, a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : ffail(-2, "emloco_ffn_fwd launch", e);
+}
+
+int emloco_ffn_bwd_input(int M, int F, const float *dz2, const uint16_t *w2t_bf16, const uint16_t *w1t_bf16, const uint16_t *hidden,
+                         uint16_t *dz1, float *dx, float drop_p, void *stream) {
+    if (M < 1 || F < FFN_CH || F % FFN_CH || !dz2 || !w2t_bf16 || !w1t_bf16 || !hidden || !dz1 || !dx || !(drop_p >= 0.0f && drop_p < 1.0f))
+        return ffail(-1, "emloco_ffn_bwd_input: bad argument (hidden width must be a multiple of 64, 0 <= drop_p < 1)");
+    if (!aligned16(dz2) || !aligned16(w2t_bf16) || !aligned16(w1t_bf16) || !aligned16(hidden) || !aligned16(dz1) || !aligned16(dx))
+        return ffail(-1, "emloco_ffn_bwd_input: operands must be 16-byte aligned");
+    emloco::FfnArgs a{M, F, dz2, w2t_bf16, w1t_bf16, nullptr, nullptr, const_cast<uint16_t *>(hidden), dz1, dx, drop_p, 1.0f / (1.0f - drop_p), 0u, 0u, 0u};
+    const dim3 grid((unsigned)((M + FFN_ROWS - 1) / FFN_ROWS));
+    hipLaunchKernelGGL((emloco::ffn_chain_kernel<1, 0>), grid, dim3(FFN_THREADS), 0, (hipStream_t)stream, a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : ffail(-2, "emloco_ffn_bwd_input launch", e);
+}
+
+int emloco_ffn_keep_mask(uint32_t seed_hidden, int64_t first_row, int64_t rows, int F, float p, uint8_t *host_out) {
+    if (rows < 0 || F < 1 || !host_out || !(p >= 0.0f && p < 1.0f)) return ffail(-1, "emloco_ffn_keep_mask: bad argument");
+    const unsigned thr = (unsigned)(p * 65536.0f);
+    for (int64_t r = 0; r < rows; ++r)
+        for (int f = 0; f < F; ++f) host_out[r * F + f] = emloco::ffn_keep16(seed_hidden, (unsigned)(first_row + r), (unsigned)f, thr) ? 1 : 0;
+    return 0;
+}
+
+}  // extern "C"

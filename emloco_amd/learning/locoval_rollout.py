@@ -155,6 +155,20 @@ class LocoValRollout:
         # 1 = one set and the stream-side wait.  (The other packet of the hand-shake -- the event the fit's stream waits for -- stays:
         # replacing it by a counter the flags launch publishes + hipStreamWaitValue64 on the fit's stream works and is 80 us SLOWER.)
         self._nbuf = max(1, int(os.environ.get("EMLOCO_FIT_BUFFERS", "4"))) if self._side is not None else 1
+        # The fit in GROUPS of `EMLOCO_FIT_EVERY` steps (round 5; default 4, 1 = every step as before).  What is left of the hand-shake
+        # after the ring above is the event the fit's stream waits for: a record packet on the main stream behind every flags launch and
+        # five small launches on the side stream beside every chain (~15 us of a 0.458 ms step, profiles/r04_env_step_trace.txt).  The
+        # return bookkeeping already stages a step's rows in a set of its own, so the fits of k steps can be issued together, in step
+        # order, behind ONE event after the k-th step: the same launches on the same staged values with the same learning rate (a group
+        # never straddles an epoch: end_epoch flushes), so the network after every group -- and after every epoch -- is the per-step
+        # loop's bit for bit (tests/test_gpu_env.py).  The ring then holds two groups (one being written, one being fitted).  Not with a
+        # deferred discriminator (its GEMMs want to start under the NEXT rigid-body launch) nor with EMLOCO_FIT_UNDER_PHYSICS.
+        self._fit_every = max(1, int(os.environ.get("EMLOCO_FIT_EVERY", "4"))) if self._side is not None else 1
+        if os.environ.get("EMLOCO_FIT_UNDER_PHYSICS", "0") == "1" or not self._no_disc:
+            self._fit_every = 1
+        if self._fit_every > 1:
+            self._nbuf = max(self._nbuf, 2 * self._fit_every)
+        self._pending = []                                 # staging sets whose fits have not been issued yet, in step order
         stage_keys = ("traj13", "pose", "vel", "target", "weight")
         self._stage = [{k: (z[k] if i == 0 else torch.zeros_like(z[k])) for k in stage_keys} for i in range(self._nbuf)]
         self._ev_fits = [torch.cuda.Event() for _ in range(self._nbuf)] if self._side is not None else []
@@ -165,6 +179,7 @@ class LocoValRollout:
         self._fit_under_physics = (self._side is not None and os.environ.get("EMLOCO_FIT_UNDER_PHYSICS", "0") == "1")
         self._fit_waiting = False
         self._buf_busy = [False] * self._nbuf             # a fit that reads the set has been issued (its event recorded)
+        self._buf_event = list(range(self._nbuf))          # which set's event covers that fit (the last set of its group)
         self._buf = 0                                      # the set the next returns launch writes
         # The discriminator off the chain between two rigid-body steps.  Its style reward (amp_continuous_value.py:90-96) feeds the
         # return bookkeeping only -- not the action, not the resets -- but in the reference's order it sits between env.step and the
@@ -231,11 +246,14 @@ class LocoValRollout:
         if self._side is None:
             return
         k = self._buf
+        if k in self._pending:                              # (a ring shorter than the fits in flight: cannot happen with 2 groups of sets)
+            self._flush_fits()
         if self._buf_busy[k]:
+            ev = self._ev_fits[self._buf_event[k]]          # the event behind the LAST fit of the group this set belonged to
             if self._nbuf > 1:
-                self._ev_fits[k].synchronize()
+                ev.synchronize()
             else:
-                self._ev_fits[k].wait(torch.cuda.current_stream(self.device))
+                ev.wait(torch.cuda.current_stream(self.device))
         if self._nbuf > 1:
             st_, s, z = self._stage[k], self._fstep, self._fz
             for name, t in st_.items():
@@ -247,6 +265,7 @@ class LocoValRollout:
         k = self._buf
         self._ev_fits[k].record(self._side)
         self._buf_busy[k] = True
+        self._buf_event[k] = k
         self._buf = (k + 1) % self._nbuf
 
     def _sync_fit(self):
@@ -255,6 +274,8 @@ class LocoValRollout:
             self._issue_deferred_disc()                     # a step whose discriminator half was still waiting for the next step
         if getattr(self, "_fit_waiting", False):
             self._issue_fit()
+        if getattr(self, "_pending", None):
+            self._flush_fits()
         if getattr(self, "_side", None) is not None:
             self._side.synchronize()
 
@@ -289,20 +310,42 @@ class LocoValRollout:
         self._issue_fit()
 
     def _issue_fit(self):
-        """The fit of the step whose returns are staged, on the side stream behind an event of the main stream."""
-        from ..sim import current_stream_handle
+        """The step whose returns are staged in the current set joins the pending group; the group's fits are issued once it is full."""
         self._fit_waiting = False
+        self._pending.append(self._buf)
+        self._buf = (self._buf + 1) % self._nbuf
+        if len(self._pending) >= self._fit_every:
+            self._flush_fits()
+
+    def _flush_fits(self):
+        """The fits of the pending steps, in step order, on the side stream behind ONE event of the main stream; one event behind the
+        last of them hands all their staging sets back."""
+        from ..sim import current_stream_handle
+        if not self._pending:
+            return
         self._ev_staged.record(torch.cuda.current_stream(self.device))
         self._side.wait_event(self._ev_staged)
+        last = self._pending[-1]
         with torch.cuda.stream(self._side):
-            self._fit_launches(current_stream_handle(self.device))
-            self._fit_issued()
+            st = current_stream_handle(self.device)
+            for k in self._pending:
+                self._fit_launches(st, self._stage[k] if self._nbuf > 1 else None)
+            self._ev_fits[last].record(self._side)
+        for k in self._pending:
+            self._buf_busy[k] = True
+            self._buf_event[k] = last
+        self._pending = []
 
-    def _fit_launches(self, st):
+    def _fit_launches(self, st, stage=None):
+        """The five launches of one step's fit on stream `st`; `stage`: the staging set that holds the step's rows (default: the
+        current one, whose arrays `self._fz` points at)."""
         import ctypes as C
         from ..predictor import ops
         lib = ops._lib()
         z, E = self._fz, self.num_actors
+        if stage is not None:
+            z = dict(z)
+            z.update(stage)
         P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         n = self.valuenet._network
         w = [n.fc1.weight, n.fc1.bias, n.fc2.weight, n.fc2.bias, n.fc3.weight, n.fc3.bias]
@@ -410,6 +453,8 @@ class LocoValRollout:
             self._issue_deferred_disc()
         if getattr(self, "_fit_waiting", False):
             self._issue_fit()
+        if getattr(self, "_pending", None):
+            self._flush_fits()
         if getattr(self, "_returns_in_flags", False) and hasattr(self.task, "attach_returns"):
             self.task.attach_returns(None)
         if getattr(self, "_amp_ring", False):
@@ -452,6 +497,8 @@ class LocoValRollout:
             self._issue_deferred_disc()                          # the epoch's last fit is issued with the epoch's learning rate
         if getattr(self, "_fit_waiting", False):
             self._issue_fit()
+        if getattr(self, "_pending", None):
+            self._flush_fits()                                   # a group never straddles an epoch: its fits run at this epoch's rate
         if not getattr(self, "_sched_live", False):
             self._sched_live = self.fitted_episodes > 0          # one read per epoch until the first episode has finished
         if self._sched_live:

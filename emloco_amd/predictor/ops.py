@@ -73,6 +73,9 @@ def _lib():
         lib.emloco_adam_clip_flat_workspace.argtypes = [C.c_int64]
         lib.emloco_adam_clip_flat_workspace.restype = C.c_int64
         lib.emloco_gemm_enable_timing.argtypes = [ci]
+        lib.emloco_ffn_fwd.argtypes = [ci, ci] + [vp] * 7 + [cf, C.c_uint32, C.c_uint32, vp]
+        lib.emloco_ffn_bwd_input.argtypes = [ci, ci] + [vp] * 6 + [cf, vp]
+        lib.emloco_ffn_keep_mask.argtypes = [C.c_uint32, cl, cl, ci, cf, vp]
         lib.emloco_disc_reward.argtypes = [ci, vp, cf, vp, vp]
         lib.emloco_gemm_timing_stats.argtypes = [C.POINTER(ci), C.POINTER(cf), C.POINTER(C.c_double)]
         _bound = True
@@ -254,11 +257,25 @@ def linear(x, W, b=None, relu=False, drop_p=0.0, out_bf16=False):
 
 
 
+# The chained feed-forward kernels (csrc/ffn_kernels.hip) serve the reduced-precision mode at the model's width; EMLOCO_FFN_CHAIN=0
+# puts the block back on the separate GEMMs (A/B knob)
+_FFN_CHAIN = os.environ.get("EMLOCO_FFN_CHAIN", "1") != "0"
+
+
+def _ffn_chain_ok(M, K, F, N):
+    return _FFN_CHAIN and _matmul_precision[0] == "bf16" and K == 128 and N == 128 and F >= 64 and F % 64 == 0
+
+
 class FeedForwardFn(torch.autograd.Function):
     """f = dropout(linear2(dropout(relu(linear1(x))))) -- the feed-forward block of nn.TransformerEncoderLayer
     (model_jta.py:177) as one autograd node, so that the backward can fuse across the two layers: the gradient w.r.t. the
     hidden activations is masked (ReLU and dropout: hidden > 0) and column-summed (bias gradient) in the epilogue of the GEMM
-    that produces it (`emloco_gemm_relu_bwd`); the unmasked M x ff gradient never exists in memory."""
+    that produces it (`emloco_gemm_relu_bwd`); the unmasked M x ff gradient never exists in memory.
+
+    Reduced-precision mode at the model's width (d = 128, ff a multiple of 64): the two products of the forward -- and the two of the
+    input-gradient pass -- are CHAINED in one launch each (`emloco_ffn_fwd`, `emloco_ffn_bwd_input`, csrc/ffn_kernels.hip): the hidden
+    tile goes from one product to the next in registers, the hidden layer and its gradient cross HBM four times per layer (as bf16)
+    instead of seven."""
 
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, drop_p, seed1, seed2):
@@ -267,6 +284,16 @@ class FeedForwardFn(torch.autograd.Function):
         M, K = x2.shape
         F, N = W1.shape[0], W2.shape[0]
         W1c, W2c = W1.contiguous(), W2.contiguous()
+        ctx.xs, ctx.drop = xs, (float(drop_p), int(seed1), int(seed2))
+        ctx.chain = _ffn_chain_ok(M, K, F, N) and x2.dtype == torch.float32
+        if ctx.chain:
+            W1b, W2b = W1c.to(torch.bfloat16), W2c.to(torch.bfloat16)
+            h = torch.empty((M, F), dtype=torch.bfloat16, device=x.device)
+            f = torch.empty((M, N), dtype=torch.float32, device=x.device)
+            _chk(_lib().emloco_ffn_fwd(M, F, _p(x2), _p(W1b), _p(W2b), _p(b1.contiguous()), _p(b2.contiguous()), _p(h), _p(f), float(drop_p),
+                                       int(seed1) & 0xFFFFFFFF, int(seed2) & 0xFFFFFFFF, _st(x2)), "emloco_ffn_fwd")
+            ctx.save_for_backward(x2, W1b, W2b, h)
+            return f.view(*xs[:-1], N)
         # the hidden layer is the largest tensor of the step (M x 1024): bf16 in HBM in the reduced-precision mode
         # (the bf16-in-memory GEMM variants serve the 128-wide tiles and 8-byte-aligned rows only: small models keep fp32)
         h16 = _matmul_precision[0] == "bf16" and N > 32 and F > 32 and K > 32 and F % 4 == 0 and K % 4 == 0 and N % 4 == 0
@@ -276,7 +303,6 @@ class FeedForwardFn(torch.autograd.Function):
         gemm(1, M, N, F, h, F, 0, 0, W2c, F, 0, 0, f, N, 0, bias=b2.contiguous(), flags=GEMM_BIAS, drop_p=drop_p, drop_seed=seed2,
              ksplit=_ksplit_for(F, M * N))                     # (whole for the predictor's tall batches; as LinearFn splits a small one)
         ctx.save_for_backward(x2, W1c, W2c, h)
-        ctx.xs, ctx.drop = xs, (float(drop_p), int(seed1), int(seed2))
         return f.view(*xs[:-1], N)
 
     @staticmethod
@@ -294,6 +320,17 @@ class FeedForwardFn(torch.autograd.Function):
             _chk(lib.emloco_act_bwd_colsum(M, N, _p(df2), None, 0, p, seed2 & 0xFFFFFFFF, _p(dz2), _p(db2), _p(ws), st), "emloco_act_bwd_colsum")
         else:
             dz2, db2 = df2, colsum(df2)
+        if ctx.chain:
+            # (W1, W2 are the forward's bf16 copies: the weight-gradient products below never read them)
+            dz1 = torch.empty((M, F), dtype=torch.bfloat16, device=dev)
+            dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+            _chk(lib.emloco_ffn_bwd_input(M, F, _p(dz2), _p(W2.t().contiguous()), _p(W1.t().contiguous()), _p(h), _p(dz1), _p(dx), float(p), st),
+                 "emloco_ffn_bwd_input")
+            dW2 = torch.empty((N, F), dtype=torch.float32, device=dev)
+            gemm(1, N, F, M, dz2, N, 0, 1, h, F, 0, 1, dW2, F, 0, ksplit=_ksplit_for(M, N * F))          # dW2 = dz2^T h
+            dW1 = torch.empty((F, K), dtype=torch.float32, device=dev)
+            gemm(1, F, K, M, dz1, F, 0, 1, x2, K, 0, 1, dW1, K, 0, ksplit=_ksplit_for(M, F * K))         # dW1 = dz1^T x
+            return (dx.view(ctx.xs) if ctx.needs_input_grad[0] else None), dW1, colsum(dz1), dW2, db2, None, None, None
         dW2 = torch.empty((N, F), dtype=torch.float32, device=dev)
         gemm(1, N, F, M, dz2, N, 0, 1, h, F, 0, 1, dW2, F, 0, ksplit=_ksplit_for(M, N * F))          # dW2 = dz2^T h
         h16 = h.dtype == torch.bfloat16

@@ -1054,3 +1054,68 @@ def test_sim_step_kernel_at_the_edge_of_the_heightfield_and_on_stairs_is_bit_exa
         for name in ("root_state", "dof_state", "rb_state", "contact_force", "dof_force", "lambda_ws"):
             assert np.array_equal(getattr(a, name), getattr(b, name)), name
     assert np.isfinite(a.rb_state).all() and np.abs(a.contact_force).max() > 50
+
+
+def _bf16_bits(x):
+    """fp32 -> bf16 bit patterns (uint16), round to nearest even"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7fff + ((u >> 16) & 1)) >> 16) & 0xffff).astype(np.uint16)
+
+
+def _bf16_val(bits):
+    return (bits.astype(np.uint32) << 16).view(np.float32)
+
+
+def test_chained_feed_forward_kernels():
+    """csrc/ffn_kernels.hip (round 5): the feed-forward block as two matrix products chained through registers -- the forward
+    (hidden = dropout(relu(x W1^T + b1)) stored as bf16, out = dropout(hidden W2^T + b2)) and the input-gradient pass (dz1 = (dz2 W2) o
+    [hidden > 0] / (1 - p) stored as bf16, dx = dz1 W1) -- emulated lane for lane against numpy on the bf16-rounded operands.  The first
+    product is checked through the stored tile (one bf16 rounding apart at most, exact zeros where the mask says so), the second against
+    the product of the tile the KERNEL stored (fp32 accumulation error only).  Ragged row count (the last workgroup is partial), both
+    dropout settings; the hidden mask is the documented pair hash, the output mask the GEMM epilogue's counter hash."""
+    lib = emu.lib()
+    lib.emu_ffn_keep.restype = C.c_int
+    lib.emu_drop_keep.restype = C.c_int
+    rng = np.random.default_rng(11)
+    M, F, D = 300, 128, 128
+    x = rng.normal(size=(M, D)).astype(np.float32)
+    W1 = (rng.normal(size=(F, D)) / np.sqrt(D)).astype(np.float32)
+    W2 = (rng.normal(size=(D, F)) / np.sqrt(F)).astype(np.float32)
+    b1 = (rng.normal(size=F) * 0.3).astype(np.float32)
+    b2 = (rng.normal(size=D) * 0.3).astype(np.float32)
+    W1b, W2b = _bf16_bits(W1), _bf16_bits(W2)
+    xb = _bf16_val(_bf16_bits(x)).astype(np.float64)
+    pre = xb @ _bf16_val(W1b).astype(np.float64).T + b1
+    U16 = lambda a: a.ctypes.data_as(C.POINTER(C.c_ushort))
+    for p, s1, s2 in ((0.0, 0, 0), (0.1, 12345, 777)):
+        h = np.full((M, F), 0x7fc0, np.uint16)                    # NaN patterns: every element must be written
+        out = np.full((M, D), np.nan, np.float32)
+        lib.emu_ffn_chain(0, M, F, P(x), U16(W1b), U16(W2b), P(b1), P(b2), U16(h), None, P(out), C.c_float(p), C.c_uint(s1), C.c_uint(s2))
+        keep = np.ones((M, F), bool)
+        if p > 0:
+            keep = np.array([[lib.emu_ffn_keep(C.c_uint(s1), r, f, C.c_float(p)) for f in range(F)] for r in range(M)], bool)
+            assert 0.85 < keep.mean() < 0.95
+        want = np.where(keep, np.maximum(pre, 0.0) / (1.0 - p), 0.0)
+        got = _bf16_val(h).astype(np.float64)
+        assert not np.isnan(got).any()
+        assert ((got == 0) == (want <= 0)).mean() > 0.999            # (a pre-activation within rounding of zero may fall either side)
+        np.testing.assert_allclose(got, want, rtol=2.0 ** -7, atol=2e-5)
+        assert np.mean(got == _bf16_val(_bf16_bits(want.astype(np.float32)))) > 0.98      # the same bf16 value almost everywhere
+        f = got @ _bf16_val(W2b).astype(np.float64).T + b2
+        if p > 0:
+            k2 = np.array([[lib.emu_drop_keep(C.c_uint(s2), C.c_ulonglong(r * D + c), C.c_float(p)) for c in range(D)] for r in range(M)], bool)
+            f = np.where(k2, f / (1.0 - p), 0.0)
+            assert 0.85 < k2.mean() < 0.95
+        np.testing.assert_allclose(out, f, rtol=1e-5, atol=2e-5)
+        # input gradient: dz2 stands for the gradient w.r.t. linear2's output; P = W2^T [F][128], Q = W1^T [128][F]
+        dz2 = rng.normal(size=(M, D)).astype(np.float32)
+        W2T, W1T = np.ascontiguousarray(W2b.T), np.ascontiguousarray(W1b.T)
+        dz1 = np.full((M, F), 0x7fc0, np.uint16)
+        dx = np.full((M, D), np.nan, np.float32)
+        lib.emu_ffn_chain(1, M, F, P(dz2), U16(W2T), U16(W1T), None, None, U16(h), U16(dz1), P(dx), C.c_float(p), C.c_uint(0), C.c_uint(0))
+        t = _bf16_val(_bf16_bits(dz2)).astype(np.float64) @ _bf16_val(W2b).astype(np.float64)
+        want1 = np.where(got > 0, t / (1.0 - p), 0.0)
+        got1 = _bf16_val(dz1).astype(np.float64)
+        assert np.array_equal(got1 == 0, (got <= 0) | (want1 == 0))
+        np.testing.assert_allclose(got1, want1, rtol=2.0 ** -7, atol=2e-5)
+        np.testing.assert_allclose(dx, got1 @ _bf16_val(W1b).astype(np.float64), rtol=1e-5, atol=2e-5)

@@ -729,6 +729,51 @@ def test_locoval_loop_with_the_reset_chain_beside_the_step_fits_the_same_network
 
 
 @pytest.mark.gpu
+def test_locoval_fit_in_groups_of_steps_gives_the_per_step_network_after_every_epoch(monkeypatch):
+    """EMLOCO_FIT_EVERY (round 5): the fits of k rollout steps issued together behind one event, in step order, from a ring of 2 k
+    staging sets -- against the per-step loop (k = 1), same seeds: after EVERY epoch (horizon 8, not a multiple of k = 3: the epoch's
+    end flushes a short group, k = 4 and k = 8: whole groups) the LocoVal parameters, the fit counters and the loss are bit-equal, and
+    so are the return accumulators and the simulator state at the end.  The learning rate moves every epoch (warm-up of 2 epochs)."""
+    from emloco_amd.learning.locoval_rollout import LocoValRollout
+    from emloco_amd.run import RLGPUEnv
+    E, outs = 256, []
+    for every in ("1", "3", "4", "8"):
+        monkeypatch.setenv("EMLOCO_FIT_EVERY", every)
+        env = RLGPUEnv(_make_env(E, ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel",
+                                     "--input_init_pose", "--input_init_vel"]))
+        task = env.env.task
+        g = torch.Generator(device=task.device)
+        g.manual_seed(77)
+        pool = torch.randn(8, E, 69, device=task.device, generator=g) * 0.3
+        k = [0]
+
+        def pol(obs):
+            k[0] += 1
+            return pool[k[0] % 8]
+        torch.manual_seed(5)
+        agent = LocoValRollout(env, horizon_length=8, policy=pol, overlap_reset=False, warmup_epochs=3, max_epochs=40)
+        assert agent._fit_every == int(every) and agent._nbuf >= 2 * int(every) or every == "1"
+        per_epoch = []
+        for _ in range(8):
+            loss = agent.play_steps()                      # (reads the loss: flushes and waits for the fit stream)
+            per_epoch.append((torch.cat([p.detach().reshape(-1) for p in agent.valuenet.parameters()]).clone(), agent.vnet_fits,
+                              agent.fitted_episodes, float(loss), float(agent.vnet_optimizer.param_groups[0]["lr"])))
+        assert not agent._pending
+        torch.cuda.synchronize()
+        a = agent.acc
+        outs.append((per_epoch, a.current_rewards.clone(), a.current_lengths.clone(), a.current_combined_rewards.clone(),
+                     a.discount_coefs.clone(), task._root_states.clone(), task.progress_buf.clone()))
+        agent.detach()
+    ref = outs[0]
+    assert ref[0][-1][2] > 20 and len({e[4] for e in ref[0]}) > 2              # episodes were fitted, the rate moved
+    for o in outs[1:]:
+        for (w0, f0, n0, l0, r0), (w1, f1, n1, l1, r1) in zip(ref[0], o[0]):
+            assert torch.equal(w0, w1) and (f0, n0, l0, r0) == (f1, n1, l1, r1)
+        for x, y in zip(ref[1:], o[1:]):
+            assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
 def test_return_bookkeeping_inside_the_flags_launch_fits_the_same_network(monkeypatch):
     """The LocoVal return bookkeeping as part of the task's flags launch (emloco_task_post_physics_returns; LocoValRollout without a
     discriminator attaches its EmlocoLocoValStep to the task) against the launch of its own (EMLOCO_RETURNS_IN_FLAGS=0): same seeds,

@@ -798,6 +798,72 @@ def test_feed_forward_node_matches_the_two_linear_layers():
             assert (res[0][0] == 0).float().mean().item() > 0.05        # the output dropout really drops
 
 
+def test_chained_feed_forward_matches_float64_on_the_rounded_operands_and_the_separate_gemms():
+    """Round 5, reduced-precision mode: ops.feed_forward at the model's width runs its two forward products -- and the two of the
+    input-gradient pass -- as ONE launch each (csrc/ffn_kernels.hip: the hidden tile stays in registers between them).  With dropout
+    0.1: against float64 on the bf16-rounded operands with the kernels' own masks (emloco_ffn_keep_mask for the hidden layer,
+    emloco_dropout_keep_mask for the output): output, input gradient, weight and bias gradients within the bf16 operand class (the
+    hidden layer and its gradient are rounded to bf16 once).  Without dropout: against the separate bf16 GEMMs of the same mode
+    (EMLOCO_FFN_CHAIN=0's path) -- the same roundings, only the summation order differs.  Ragged row count."""
+    import ctypes as C
+    from emloco_amd.predictor import ops
+    dev = "cuda:0"
+    torch.manual_seed(4)
+    M0, K, F = 3 * 453 + 7, 128, 1024
+    W1 = (torch.randn(F, K, device=dev) / K ** 0.5).requires_grad_(True)
+    b1 = (torch.randn(F, device=dev) * 0.1).requires_grad_(True)
+    W2 = (torch.randn(K, F, device=dev) / F ** 0.5).requires_grad_(True)
+    b2 = (torch.randn(K, device=dev) * 0.1).requires_grad_(True)
+    x0 = torch.randn(M0, K, device=dev)
+    dout = torch.randn(M0, K, device=dev)
+    bf = lambda t: t.detach().to(torch.bfloat16).double()
+    ops.set_matmul_precision("bf16")
+    try:
+        # ---- without dropout: chained launches vs the separate GEMMs
+        res = []
+        for chain in (True, False):
+            ops._FFN_CHAIN = chain
+            x = x0.clone().requires_grad_(True)
+            for t in (W1, b1, W2, b2):
+                t.grad = None
+            f = ops.feed_forward(x, W1, b1, W2, b2, drop_p=0.0)
+            f.backward(dout)
+            res.append([t.detach().double().cpu().numpy() for t in (f, x.grad, W1.grad, b1.grad, W2.grad, b2.grad)])
+        for a, b, what in zip(res[0], res[1], ("f", "dx", "dW1", "db1", "dW2", "db2")):
+            _close(a, b, rel=4e-3, abs_=1e-6, what=f"chained vs separate, {what}")
+        # ---- with dropout: against float64 with the kernels' masks
+        ops._FFN_CHAIN = True
+        p = 0.1
+        ops._drop_counter[0] = 500
+        s1 = (torch.initial_seed() * 0x9E3779B1 + 501 * 0x85EBCA6B) & 0xFFFFFFFF
+        s2 = (torch.initial_seed() * 0x9E3779B1 + 502 * 0x85EBCA6B) & 0xFFFFFFFF
+        x = x0.clone().requires_grad_(True)
+        for t in (W1, b1, W2, b2):
+            t.grad = None
+        f = ops.feed_forward(x, W1, b1, W2, b2, drop_p=p)
+        f.backward(dout)
+        lib = ops._lib()
+        k1 = np.zeros((M0, F), np.uint8)
+        k2 = np.zeros((M0 * K,), np.uint8)
+        assert lib.emloco_ffn_keep_mask(s1, 0, M0, F, p, k1.ctypes.data_as(C.c_void_p)) == 0
+        assert lib.emloco_dropout_keep_mask(s2, 0, M0 * K, p, k2.ctypes.data_as(C.c_void_p)) == 0
+        k1 = torch.from_numpy(k1).to(dev).double() / (1 - p)
+        k2 = torch.from_numpy(k2.reshape(M0, K)).to(dev).double() / (1 - p)
+        assert 0.88 < (k1 > 0).double().mean().item() < 0.92 and 0.88 < (k2 > 0).double().mean().item() < 0.92
+        h = bf(torch.relu(bf(x0) @ bf(W1).T + b1.detach().double()) * k1)          # the hidden layer as stored: rounded once
+        fr = (h @ bf(W2).T + b2.detach().double()) * k2
+        dz2 = dout.double() * k2
+        dz1 = bf((bf(dz2) @ bf(W2)) * (h > 0).double() / (1 - p))
+        refs = (fr, dz1 @ bf(W1), bf(dz1).T @ bf(x0), dz1.sum(0), bf(dz2).T @ h, dz2.sum(0))
+        gots = (f, x.grad, W1.grad, b1.grad, W2.grad, b2.grad)
+        for a, b, what in zip(gots, refs, ("f", "dx", "dW1", "db1", "dW2", "db2")):
+            _close(a.detach().double().cpu().numpy(), b.cpu().numpy(), rel=4e-3, abs_=1e-6, what=f"chained vs float64, {what}")
+        assert (f == 0).float().mean().item() > 0.05
+    finally:
+        ops._FFN_CHAIN = True
+        ops.set_matmul_precision(ops.DEFAULT_PRECISION)
+
+
 def test_train_and_evaluate_entry_points_from_the_shipped_yaml(tmp_path):
     """`python -m emloco_amd.predictor.train_jta --cfg configs/jta_all_visual_cues.yaml --valueloss_w 1.0 --dry-run` and
     `python -m emloco_amd.predictor.evaluate_jta --valueloss --multi_modal ...` (social-transmotion/train_jta.py:446-506,
