@@ -92,6 +92,7 @@ __device__ __forceinline__ void ffn_fetch(const FfnArgs &a, int chunk, int tid, 
     const int nch = a.F / FFN_CH;
     const int c = chunk < nch ? chunk : nch - 1;                       // past the end: a valid duplicate, never consumed
     const unsigned short *pp = a.P + (long)c * FFN_CH * FFN_D;
+    #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int idx = tid + FFN_THREADS * e;
         s.p[e] = *(const ffn_u32x4 *)(pp + (long)idx * 8);
@@ -100,6 +101,7 @@ __device__ __forceinline__ void ffn_fetch(const FfnArgs &a, int chunk, int tid, 
     }
 }
 __device__ __forceinline__ void ffn_stash(char *lp, char *lq, int tid, const FfnStage &s) {
+    #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int idx = tid + FFN_THREADS * e;
         *(ffn_u32x4 *)(lp + ffn_p_off(idx >> 4, idx & 15)) = s.p[e];
@@ -117,22 +119,27 @@ __global__ void __launch_bounds__(FFN_THREADS)
 ffn_chain_kernel(FfnArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2][FFN_P_BYTES + FFN_Q_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int row = blockIdx.x * FFN_ROWS + wave * 32 + l31;
-    const bool rok = row < a.M;
-    const long rowc = rok ? row : a.M - 1;
+    // rows past the end compute -- and store -- the LAST row again (identical values to the same addresses): no lane-dependent branch
+    // splits the chunk loop into basic blocks, the matrix instructions schedule across the stores
+    const int row_raw = blockIdx.x * FFN_ROWS + wave * 32 + l31;
+    const long rowc = row_raw < a.M ? row_raw : a.M - 1;
+    const int row = (int)rowc;
     const int nch = a.F / FFN_CH;
 
     // this lane's row of X as the B operand of the first product: step s covers k = 16 s + 8 hi + 0..7
     bf16w4 xb[8];
     {
         const float *xr = a.x + rowc * FFN_D + 8 * hi;
+        #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const ffn_f32x4 v0 = *(const ffn_f32x4 *)(xr + 16 * s), v1 = *(const ffn_f32x4 *)(xr + 16 * s + 4);
             xb[s] = bf16w4{gemm_pack2_bf16(v0.x, v0.y), gemm_pack2_bf16(v0.z, v0.w), gemm_pack2_bf16(v1.x, v1.y), gemm_pack2_bf16(v1.z, v1.w)};
         }
     }
     ffn_f32x16 acc[4];
+    #pragma unroll
     for (int n = 0; n < 4; ++n)
+        #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
     const unsigned rkey = DROP ? ffn_row_key(a.seed1, (unsigned)row) : 0u;
 
@@ -147,8 +154,11 @@ ffn_chain_kernel(FfnArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         // ---- first product: T^T[t] (32 hidden x 32 rows) = P[t] . X^T, reduction over the 128 model columns
         ffn_f32x16 T[2];
+        #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            #pragma unroll
             for (int r = 0; r < 16; ++r) T[t][r] = 0.0f;
+            #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const bf16w4 pa = *(const bf16w4 *)(lp + ffn_p_off(t * 32 + l31, 2 * s + hi));
                 T[t] = gemm_mfma_bf16_w(pa, xb[s], T[t]);
@@ -156,14 +166,17 @@ ffn_chain_kernel(FfnArgs a) {
         }
         // ---- between the products: register r of tile t is hidden unit c 64 + t 32 + (r & 3) + 8 (r >> 2) + 4 hi of this lane's row
         bf16w4 tb[2][2];
+        #pragma unroll
         for (int t = 0; t < 2; ++t) {
             unsigned w[8];
+            #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int hid = c * FFN_CH + t * 32 + 8 * q + 4 * hi;      // four consecutive hidden units
                 float v[4] = {T[t][4 * q], T[t][4 * q + 1], T[t][4 * q + 2], T[t][4 * q + 3]};
                 if (MODE == 0) {
                     const ffn_f32x4 b = *(const ffn_f32x4 *)(a.b1 + hid);
                     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
                     if (DROP) {
                         const unsigned h0 = ffn_pair_hash(rkey, (unsigned)(hid >> 1)), h1 = ffn_pair_hash(rkey, (unsigned)(hid >> 1) + 1u);
@@ -173,7 +186,11 @@ ffn_chain_kernel(FfnArgs a) {
                         v[3] = (h1 >> 16) >= a.thr16 ? v[3] * a.keep_scale : 0.0f;
                     }
                 } else {
+#ifdef FFN_EXP_NO_HLOAD
+                    const ffn_u32x2 hm{0x3f803f80u, 0x3f803f80u};
+#else
                     const ffn_u32x2 hm = *(const ffn_u32x2 *)(a.h + rowc * a.F + hid);       // the stored hidden layer: > 0 = active and kept
+#endif
                     v[0] = ffn_bf16_lo(hm.x) > 0.0f ? v[0] * a.keep_scale : 0.0f;
                     v[1] = ffn_bf16_hi(hm.x) > 0.0f ? v[1] * a.keep_scale : 0.0f;
                     v[2] = ffn_bf16_lo(hm.y) > 0.0f ? v[2] * a.keep_scale : 0.0f;
@@ -181,14 +198,19 @@ ffn_chain_kernel(FfnArgs a) {
                 }
                 const unsigned w0 = gemm_pack2_bf16(v[0], v[1]), w1 = gemm_pack2_bf16(v[2], v[3]);
                 w[2 * q] = w0; w[2 * q + 1] = w1;
-                if (rok) *(ffn_u32x2 *)((MODE == 0 ? a.h : a.dz1) + (long)row * a.F + hid) = ffn_u32x2{w0, w1};     // what the second product consumes, rounded once
+#ifndef FFN_EXP_NO_HSTORE
+                *(ffn_u32x2 *)((MODE == 0 ? a.h : a.dz1) + rowc * a.F + hid) = ffn_u32x2{w0, w1};     // what the second product consumes, rounded once
+#endif
             }
             tb[t][0] = bf16w4{w[0], w[1], w[2], w[3]};                  // hidden 16-block 0 of the tile: units 4 hi + 0..3, 8 + 4 hi + 0..3
             tb[t][1] = bf16w4{w[4], w[5], w[6], w[7]};
         }
         // ---- second product: out^T[n] (32 model columns x 32 rows) += Q[n] . T^T, reduction over the chunk's 64 hidden units
+        #pragma unroll
         for (int n = 0; n < 4; ++n)
+            #pragma unroll
             for (int t = 0; t < 2; ++t)
+                #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     const bf16w4 qa = *(const bf16w4 *)(lq + ffn_q_off(n * 32 + l31, 2 * (2 * t + g) + hi));
                     acc[n] = gemm_mfma_bf16_w(qa, tb[t][g], acc[n]);
@@ -198,9 +220,11 @@ ffn_chain_kernel(FfnArgs a) {
         __syncthreads();
     }
     // ---- epilogue: register r of acc[n] is model column n 32 + (r & 3) + 8 (r >> 2) + 4 hi of this lane's row
-    if (rok) {
-        float *o = a.out + (long)row * FFN_D;
+    {
+        float *o = a.out + rowc * FFN_D;
+        #pragma unroll
         for (int n = 0; n < 4; ++n)
+            #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int col = n * 32 + 8 * q + 4 * hi;
                 float v[4] = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
@@ -208,6 +232,7 @@ ffn_chain_kernel(FfnArgs a) {
                     const ffn_f32x4 b = *(const ffn_f32x4 *)(a.b2 + col);
                     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     if (DROP)
+                        #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             v[e] = ffn_out_keep(a.seed2, (unsigned long long)row * FFN_D + col + e, a.drop_p) ? v[e] * a.keep_scale : 0.0f;
                 }

@@ -453,15 +453,26 @@ class AMPAgent:
         return info
 
     # ------------------------------------------------------------------ the optimiser step as a HIP graph
-    def _graph_body(self):
-        """calc_gradients on the static minibatch buffers; every value the epoch averages is added to a static accumulator."""
+    def _graph_body(self, part=None):
+        """calc_gradients on the static minibatch buffers; every value the epoch averages is added to a static accumulator.
+        part None: the whole step (one rank).  Data parallel the step is captured as TWO graphs around the gradient exchange
+        (amp_continuous.py:440 `optimizer.synchronize()`): part "grad" = zero the bucket, losses, backward; part "apply" = clip, Adam,
+        the epoch's accumulators -- between their replays `bucket.all_reduce` is issued on the same stream (RCCL: stream-ordered)."""
         d = self._g_in
-        masks = None
-        if self._amp_dropout:
-            masks = amp_dropout_expand(self._g_u, self.task._num_amp_obs_steps)
-        self.bucket.zero()                                   # (ahead of the fork: the branches' backward passes write into it)
-        loss, info, mu, sigma = self.compute_loss(d, dropout_masks=masks, branch_streams=self._branch_streams())
-        loss.backward()
+        if part in (None, "grad"):
+            masks = None
+            if self._amp_dropout:
+                masks = amp_dropout_expand(self._g_u, self.task._num_amp_obs_steps)
+            self.bucket.zero()                                   # (ahead of the fork: the branches' backward passes write into it)
+            loss, info, mu, sigma = self.compute_loss(d, dropout_masks=masks, branch_streams=self._branch_streams())
+            loss.backward()
+            if part == "grad":
+                self._g_mid = (loss.detach(), {k: v.detach() for k, v in info.items()}, mu.detach(), sigma.detach())   # static tensors of the graphs' pool
+                return None
+            loss = loss.detach()
+        else:
+            loss, info, mu, sigma = self._g_mid
+            info = dict(info)
         if self.truncate_grads:
             nn.utils.clip_grad_norm_(self.a2c_network.parameters(), self.grad_norm)
         self.optimizer.step()
@@ -505,17 +516,35 @@ class AMPAgent:
     _G_TRIALS = 4
 
     def _capture(self, arms):
+        """The step as a replayable object: one graph on one rank; data parallel a pair (gradient graph, apply graph) sharing one
+        memory pool, replayed around the bucket's all-reduce (`_replay`)."""
+        from ..dist import world_size
         self._g_arms = bool(arms)
-        g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(self.device)
-        with torch.cuda.graph(g):
-            self._graph_body()
-        return g
+        if world_size() == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._graph_body()
+            return g
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self._graph_body("grad")
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            self._graph_body("apply")
+        return (ga, gb)
+
+    def _replay(self, g):
+        if isinstance(g, tuple):
+            g[0].replay()
+            self.bucket.all_reduce(average=True)            # on the replays' stream: behind the gradient graph, ahead of the apply graph
+            g[1].replay()
+        else:
+            g.replay()
 
     def _timed_replay(self, g):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        g.replay()
+        self._replay(g)
         e1.record()
         e1.synchronize()
         return e0.elapsed_time(e1)
@@ -525,8 +554,9 @@ class AMPAgent:
         graphs timed on the next steps, then the faster one replayed."""
         self.set_train()
         self._graph_fill(i)
+        from ..dist import world_size
         if self._graph is not None:
-            self._graph.replay()
+            self._replay(self._graph)
             return
         self._g_warm = getattr(self, "_g_warm", 0) + 1
         if self._g_warm <= 3:                               # warm-up off the default stream, as graph capture asks
@@ -534,13 +564,22 @@ class AMPAgent:
             self._g_side = side
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
-                self._graph_body()
+                if world_size() == 1:
+                    self._graph_body()
+                else:                                       # the data-parallel step, eagerly: gradients | exchange | apply
+                    self._graph_body("grad")
+                    self.bucket.all_reduce(average=True)
+                    self._graph_body("apply")
             torch.cuda.current_stream(self.device).wait_stream(side)
             return
         mode = os.environ.get("EMLOCO_PPO_BRANCHES", "auto")
+        if world_size() > 1 and mode == "auto":
+            # every rank must replay the SAME number of collectives per step and the timing trial below is rank-local: data parallel the
+            # choice is made by the environment (default: the arms, what wins on 16 hardware queues) and is the same on every rank
+            mode = "1"
         if mode in ("0", "1"):
             self._graph = self._capture(mode == "1")        # (capture does not execute: run the step that was just captured)
-            self._graph.replay()
+            self._replay(self._graph)
             return
         if getattr(self, "_g_cand", None) is None:
             self._g_cand = [[self._capture(False), [], False], [self._capture(True), [], True]]
@@ -599,7 +638,8 @@ class AMPAgent:
         self.prepare_dataset(batch)
         infos = []
         from ..dist import world_size
-        graphed = self.use_graph and world_size() == 1
+        # (round 5: the graphed step also runs data parallel -- two captured segments around the bucket's all-reduce, `_capture`)
+        graphed = self.use_graph
         n_steps = self.mini_epochs_num * (self.batch_size // self.minibatch_size)
         if graphed and self._g_acc is not None:
             self._g_acc.zero_()

@@ -324,8 +324,8 @@ class FeedForwardFn(torch.autograd.Function):
             # (W1, W2 are the forward's bf16 copies: the weight-gradient products below never read them)
             dz1 = torch.empty((M, F), dtype=torch.bfloat16, device=dev)
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-            _chk(lib.emloco_ffn_bwd_input(M, F, _p(dz2), _p(W2.t().contiguous()), _p(W1.t().contiguous()), _p(h), _p(dz1), _p(dx), float(p), st),
-                 "emloco_ffn_bwd_input")
+            w2t, w1t = W2.t().contiguous(), W1.t().contiguous()       # (named: a temporary's block would be handed to the next allocation)
+            _chk(lib.emloco_ffn_bwd_input(M, F, _p(dz2), _p(w2t), _p(w1t), _p(h), _p(dz1), _p(dx), float(p), st), "emloco_ffn_bwd_input")
             dW2 = torch.empty((N, F), dtype=torch.float32, device=dev)
             gemm(1, N, F, M, dz2, N, 0, 1, h, F, 0, 1, dW2, F, 0, ksplit=_ksplit_for(M, N * F))          # dW2 = dz2^T h
             dW1 = torch.empty((F, K), dtype=torch.float32, device=dev)

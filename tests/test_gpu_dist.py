@@ -472,3 +472,72 @@ def test_rccl_all_reduce_runs_stream_ordered_inside_the_rollout():
     the RCCL path itself has executed."""
     (_, ident, n, side, n_fit, same, finite), = _spawn(_rccl_worker, 1)
     assert ident and n >= 48 and side >= 48 and n_fit > 0 and not same and finite
+
+
+def _ppo_graph_worker(rank, world, port, q, backend):
+    """One AMPAgent epoch pair twice in one process -- eagerly, then with the graphed step -- under an initialised process group."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", EMLOCO_PPO_GRAPH="1")
+    if world == 1:
+        os.environ["EMLOCO_FORCE_COLLECTIVES"] = "1"
+    import yaml
+    import torch.distributed as dist
+    from emloco_amd import dist as D
+    from emloco_amd.learning.amp_agent import AMPAgent
+    from emloco_amd.learning.amp_policy import DEFAULT_CFG
+    from emloco_amd.run import create_rlgpu_env, fill_flags
+    from emloco_amd.utils.config import get_args, load_cfg
+    D.init_from_env(backend)
+    torch.cuda.set_device(0)
+    assert D.is_distributed() and dist.get_backend() == backend
+    calls = {"n": 0}
+    orig = dist.all_reduce
+
+    def counted(tensor, *a, **k):
+        calls["n"] += 1
+        return orig(tensor, *a, **k)
+    dist.all_reduce = counted
+    outs = []
+    for graph in (False, True):
+        torch.manual_seed(21)
+        np.random.seed(21)
+        args = get_args(["--num_envs", "64", "--seed", "3", "--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel"])
+        cfg, _cfg_train, _ = load_cfg(args)
+        fill_flags(args)
+        env = create_rlgpu_env(args, cfg, _cfg_train, rank=0)       # the SAME shard on every rank: the mean gradient is each rank's own
+        cfgt = yaml.safe_load(open(DEFAULT_CFG))
+        cfgt["params"]["network"]["mlp"]["units"] = [256, 128]
+        cfgt["params"]["network"]["disc"]["units"] = [128, 64]
+        cfgt["params"]["config"].update(horizon_length=8, minibatch_size=128, amp_minibatch_size=128, amp_batch_size=64,
+                                        amp_obs_demo_buffer_size=512, amp_replay_buffer_size=512, mini_epochs=2)
+        agent = AMPAgent(env, cfgt, seed=4)
+        agent.use_graph = graph
+        torch.manual_seed(33)
+        n0 = calls["n"]
+        infos = [agent.train_epoch() for _ in range(2)]
+        torch.cuda.synchronize()
+        steps = 2 * agent.mini_epochs_num * (agent.batch_size // agent.minibatch_size)
+        outs.append((torch.cat([p.detach().reshape(-1) for p in agent.a2c_network.parameters()]).cpu(), infos[-1]["actor_loss"], infos[-1]["disc_loss"],
+                     calls["n"] - n0, steps, isinstance(agent._graph, tuple)))
+    q.put((rank, outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend,world", [("nccl", 1), ("gloo", 2)])
+def test_graphed_ppo_step_runs_data_parallel_around_the_gradient_exchange(backend, world):
+    """Round 5: AMPAgent's captured optimiser step at world_size > 1 -- two HIP graphs (losses + backward | clip + Adam + the epoch's
+    accumulators) replayed around `bucket.all_reduce` on the same stream (amp_continuous.py:440 `optimizer.synchronize()`).  RCCL with
+    one rank (EMLOCO_FORCE_COLLECTIVES=1: every collective is issued; all a one-GPU box allows) and gloo with two ranks sharing the
+    GPU on identical shards: the graphed step equals the eagerly issued data-parallel step (weights to float rounding, the epoch's
+    losses), it really is the two-graph form, every optimiser step issues its gradient all-reduce, and the two gloo ranks end
+    identical."""
+    res = _spawn(_ppo_graph_worker, world, backend)
+    for _, outs in res:
+        (w0, a0, d0, n0, steps, g0), (w1, a1, d1, n1, _, g1) = outs
+        assert not g0 and g1
+        assert n0 >= steps and n1 >= steps                         # one gradient exchange per optimiser step, graphed or not
+        assert torch.isfinite(w1).all() and (w0 - w1).abs().max().item() <= 2e-5 * w0.abs().max().item() + 1e-6
+        assert abs(a0 - a1) <= 5e-3 * abs(a0) + 1e-5 and abs(d0 - d1) <= 5e-3 * abs(d0) + 1e-5
+    if world > 1:
+        assert torch.equal(res[0][1][1][0], res[1][1][1][0])
