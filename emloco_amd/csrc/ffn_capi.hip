@@ -18,12 +18,12 @@ bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 extern "C" {
 
 int emloco_ffn_fwd(int M, int F, const float *x, const uint16_t *w1_bf16, const uint16_t *w2_bf16, const float *b1, const float *b2,
-                   uint16_t *hidden, float *out, float drop_p, uint32_t seed_hidden, uint32_t seed_out, void *stream) {
-    if (M < 1 || F < FFN_CH || F % FFN_CH || !x || !w1_bf16 || !w2_bf16 || !b1 || !b2 || !hidden || !out || !(drop_p >= 0.0f && drop_p < 1.0f))
+                   uint16_t *hidden, uint32_t *mask, float *out, float drop_p, uint32_t seed_hidden, uint32_t seed_out, void *stream) {
+    if (M < 1 || F < FFN_CH || F % FFN_CH || !x || !w1_bf16 || !w2_bf16 || !b1 || !b2 || !hidden || !mask || !out || !(drop_p >= 0.0f && drop_p < 1.0f))
         return ffail(-1, "emloco_ffn_fwd: bad argument (hidden width must be a multiple of 64, 0 <= drop_p < 1)");
-    if (!aligned16(x) || !aligned16(w1_bf16) || !aligned16(w2_bf16) || !aligned16(b1) || !aligned16(b2) || !aligned16(hidden) || !aligned16(out))
+    if (!aligned16(x) || !aligned16(w1_bf16) || !aligned16(w2_bf16) || !aligned16(b1) || !aligned16(b2) || !aligned16(hidden) || !aligned16(mask) || !aligned16(out))
         return ffail(-1, "emloco_ffn_fwd: operands must be 16-byte aligned");
-    emloco::FfnArgs a{M, F, x, w1_bf16, w2_bf16, b1, b2, hidden, nullptr, out, drop_p, 1.0f / (1.0f - drop_p), seed_hidden,
+    emloco::FfnArgs a{M, F, x, w1_bf16, w2_bf16, b1, b2, hidden, nullptr, mask, out, drop_p, 1.0f / (1.0f - drop_p), seed_hidden,
                       (unsigned)(drop_p * 65536.0f), seed_out};
     const dim3 grid((unsigned)((M + FFN_ROWS - 1) / FFN_ROWS));
     if (drop_p > 0.0f) hipLaunchKernelGGL((emloco::ffn_chain_kernel<0, 1>), grid, dim3(FFN_THREADS), 0, (hipStream_t)stream, a);
@@ -32,13 +32,13 @@ int emloco_ffn_fwd(int M, int F, const float *x, const uint16_t *w1_bf16, const 
     return e == hipSuccess ? 0 : ffail(-2, "emloco_ffn_fwd launch", e);
 }
 
-int emloco_ffn_bwd_input(int M, int F, const float *dz2, const uint16_t *w2t_bf16, const uint16_t *w1t_bf16, const uint16_t *hidden,
+int emloco_ffn_bwd_input(int M, int F, const float *dz2, const uint16_t *w2t_bf16, const uint16_t *w1t_bf16, const uint32_t *mask,
                          uint16_t *dz1, float *dx, float drop_p, void *stream) {
-    if (M < 1 || F < FFN_CH || F % FFN_CH || !dz2 || !w2t_bf16 || !w1t_bf16 || !hidden || !dz1 || !dx || !(drop_p >= 0.0f && drop_p < 1.0f))
+    if (M < 1 || F < FFN_CH || F % FFN_CH || !dz2 || !w2t_bf16 || !w1t_bf16 || !mask || !dz1 || !dx || !(drop_p >= 0.0f && drop_p < 1.0f))
         return ffail(-1, "emloco_ffn_bwd_input: bad argument (hidden width must be a multiple of 64, 0 <= drop_p < 1)");
-    if (!aligned16(dz2) || !aligned16(w2t_bf16) || !aligned16(w1t_bf16) || !aligned16(hidden) || !aligned16(dz1) || !aligned16(dx))
+    if (!aligned16(dz2) || !aligned16(w2t_bf16) || !aligned16(w1t_bf16) || !aligned16(mask) || !aligned16(dz1) || !aligned16(dx))
         return ffail(-1, "emloco_ffn_bwd_input: operands must be 16-byte aligned");
-    emloco::FfnArgs a{M, F, dz2, w2t_bf16, w1t_bf16, nullptr, nullptr, const_cast<uint16_t *>(hidden), dz1, dx, drop_p, 1.0f / (1.0f - drop_p), 0u, 0u, 0u};
+    emloco::FfnArgs a{M, F, dz2, w2t_bf16, w1t_bf16, nullptr, nullptr, nullptr, dz1, const_cast<uint32_t *>(mask), dx, drop_p, 1.0f / (1.0f - drop_p), 0u, 0u, 0u};
     const dim3 grid((unsigned)((M + FFN_ROWS - 1) / FFN_ROWS));
     hipLaunchKernelGGL((emloco::ffn_chain_kernel<1, 0>), grid, dim3(FFN_THREADS), 0, (hipStream_t)stream, a);
     const hipError_t e = hipGetLastError();

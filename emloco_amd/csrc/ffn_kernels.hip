@@ -22,6 +22,13 @@
 // so Q's LDS image simply stores each 16-hidden block in the order [0..3, 8..11 | 4..7, 12..15] the two lane halves supply.  A
 // lane's row of X (128 values) stays in registers as bf16 for the whole launch; the hidden width is walked in chunks of 64 whose
 // weight tiles (16 KB + 16 KB) are staged through LDS, double buffered, fetched one chunk ahead into registers.
+//
+// Memory access (measured on MI355X, tools/exp/ffn_probe.py, one launch at M = 927 744): with lane = row a lane's eight 8-byte pieces of
+// the stored tile lie 2 KB apart from its neighbours' -- written straight from the registers the stores touched 32 lines per
+// instruction and cost 0.31 ms (forward) / 0.72 ms (backward) of a launch, and the backward's mask read straight off the stored hidden
+// layer another 0.77 ms.  So (a) a wave passes its 32 x 64 tile through 4 KB of LDS of its own and stores it as whole 128-byte lines
+// (four 16-byte stores per lane and chunk), and (b) the forward leaves the mask as BITS (one word per lane and chunk), which is all
+// the backward reads.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mfma_bf16.h"
@@ -45,8 +52,10 @@ struct FfnArgs {
     const unsigned short *Q;        // [128][F] bf16: second product's                 (forward W2; backward W1^T)
     const float *b1;                // forward: [F] bias of linear1
     const float *b2;                // forward: [128] bias of linear2
-    unsigned short *h;              // [M][F] bf16: forward OUT (hidden layer after ReLU + dropout); backward IN (its sign is the mask)
+    unsigned short *h;              // forward OUT [M][F] bf16: hidden layer after ReLU + dropout (operand of the weight gradient dW2)
     unsigned short *dz1;            // backward OUT [M][F] bf16: gradient w.r.t. linear1's output
+    unsigned *mask;                 // [M][F / 32] words: bit = "hidden unit active and kept" (forward OUT, backward IN); word (row, chunk c, lane half hi)
+                                    // at [row][2 c + hi], bit 16 t + 4 q + e = unit c 64 + t 32 + 8 q + 4 hi + e -- what one lane holds of a chunk
     float *out;                     // [M][128] fp32: forward f / backward dx
     float drop_p, keep_scale;       // dropout of the block (both nn.Dropout(p)): keep_scale = 1 / (1 - p)
     unsigned seed1, thr16;          // hidden-layer mask: ffn_keep16 below, thr16 = (unsigned)(p 65536)
@@ -82,8 +91,15 @@ __device__ __forceinline__ float ffn_bf16_hi(unsigned u) { return __uint_as_floa
 // rows of eight 16-byte slots s = 2 (16-hidden block) + lane half, slot s of row r at s ^ ((r >> 1) & 7) (two rows fill a bank row).
 #define FFN_P_BYTES (FFN_CH * FFN_D * 2)
 #define FFN_Q_BYTES (FFN_D * FFN_CH * 2)
+#define FFN_T_BYTES (32 * FFN_CH * 2)       /* a wave's 32 x 64 bf16 tile on its way out: 128-byte rows, 16-byte slot s of row r at s ^ (r & 7) */
 __device__ __forceinline__ int ffn_p_off(int r, int c) { return r * 256 + ((c ^ (r & 15)) << 4); }
 __device__ __forceinline__ int ffn_q_off(int r, int s) { return r * 128 + ((s ^ ((r >> 1) & 7)) << 4); }
+__device__ __forceinline__ int ffn_t_off(int r, int s) { return r * 128 + ((s ^ (r & 7)) << 4); }
+#ifdef EMLOCO_EMU
+__device__ __forceinline__ void ffn_wave_sync() { emu::wave_barrier(); }        // lock-step fibers: the wave's lanes meet between the tile's write and read
+#else
+__device__ __forceinline__ void ffn_wave_sync() { __builtin_amdgcn_wave_barrier(); }   // DS instructions of one wave complete in issue order: a scheduling fence only
+#endif
 
 // one thread's share of a chunk's weight tiles: two 16-byte pieces of P (the chunk's 64 rows are one contiguous 16 KB run) and two of Q
 // (rows 2 F bytes apart, 128 bytes each)
@@ -118,6 +134,7 @@ template <int MODE, int DROP>
 __global__ void __launch_bounds__(FFN_THREADS)
 ffn_chain_kernel(FfnArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2][FFN_P_BYTES + FFN_Q_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds_t[FFN_THREADS / 64][FFN_T_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     // rows past the end compute -- and store -- the LAST row again (identical values to the same addresses): no lane-dependent branch
     // splits the chunk loop into basic blocks, the matrix instructions schedule across the stores
@@ -151,6 +168,8 @@ ffn_chain_kernel(FfnArgs a) {
         const int buf = c & 1;
         const char *lp = lds[buf], *lq = lds[buf] + FFN_P_BYTES;
         ffn_fetch(a, c + 1, tid, st);                                  // the next chunk's weights fly during this chunk's products
+        unsigned mword = 0u;
+        if (MODE == 1) mword = a.mask[rowc * (a.F / 32) + 2 * c + hi];  // this lane's 32 units of the chunk: requested ahead of the first product
         __builtin_amdgcn_sched_barrier(0);
         // ---- first product: T^T[t] (32 hidden x 32 rows) = P[t] . X^T, reduction over the 128 model columns
         ffn_f32x16 T[2];
@@ -185,26 +204,35 @@ ffn_chain_kernel(FfnArgs a) {
                         v[2] = (h1 & 0xffffu) >= a.thr16 ? v[2] * a.keep_scale : 0.0f;
                         v[3] = (h1 >> 16) >= a.thr16 ? v[3] * a.keep_scale : 0.0f;
                     }
+                    #pragma unroll
+                    for (int e = 0; e < 4; ++e) mword |= (v[e] > 0.0f ? 1u : 0u) << (16 * t + 4 * q + e);
                 } else {
-#ifdef FFN_EXP_NO_HLOAD
-                    const ffn_u32x2 hm{0x3f803f80u, 0x3f803f80u};
-#else
-                    const ffn_u32x2 hm = *(const ffn_u32x2 *)(a.h + rowc * a.F + hid);       // the stored hidden layer: > 0 = active and kept
-#endif
-                    v[0] = ffn_bf16_lo(hm.x) > 0.0f ? v[0] * a.keep_scale : 0.0f;
-                    v[1] = ffn_bf16_hi(hm.x) > 0.0f ? v[1] * a.keep_scale : 0.0f;
-                    v[2] = ffn_bf16_lo(hm.y) > 0.0f ? v[2] * a.keep_scale : 0.0f;
-                    v[3] = ffn_bf16_hi(hm.y) > 0.0f ? v[3] * a.keep_scale : 0.0f;
+                    #pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ((mword >> (16 * t + 4 * q + e)) & 1u) ? v[e] * a.keep_scale : 0.0f;
                 }
-                const unsigned w0 = gemm_pack2_bf16(v[0], v[1]), w1 = gemm_pack2_bf16(v[2], v[3]);
+                const unsigned w0 = gemm_pack2_bf16(v[0], v[1]), w1 = gemm_pack2_bf16(v[2], v[3]);      // what the second product consumes, rounded once
                 w[2 * q] = w0; w[2 * q + 1] = w1;
-#ifndef FFN_EXP_NO_HSTORE
-                *(ffn_u32x2 *)((MODE == 0 ? a.h : a.dz1) + rowc * a.F + hid) = ffn_u32x2{w0, w1};     // what the second product consumes, rounded once
-#endif
+                *(ffn_u32x2 *)(lds_t[wave] + ffn_t_off(l31, 4 * t + q) + 8 * hi) = ffn_u32x2{w0, w1};
             }
             tb[t][0] = bf16w4{w[0], w[1], w[2], w[3]};                  // hidden 16-block 0 of the tile: units 4 hi + 0..3, 8 + 4 hi + 0..3
             tb[t][1] = bf16w4{w[4], w[5], w[6], w[7]};
         }
+        // the tile leaves as whole lines: 8 lanes x 16 bytes = the 128 bytes a row holds of this chunk, 8 rows per store instruction
+        // (rows past the end store the last row's values again, as everywhere in this kernel)
+        if (MODE == 0) a.mask[rowc * (a.F / 32) + 2 * c + hi] = mword;
+        ffn_wave_sync();
+        {
+            unsigned short *dst = (MODE == 0 ? a.h : a.dz1) + (long)c * FFN_CH + 8 * (lane & 7);
+            const int r0w = blockIdx.x * FFN_ROWS + wave * 32;
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rl = 8 * i + (lane >> 3);
+                const long rg = r0w + rl < a.M ? r0w + rl : a.M - 1;
+                const ffn_u32x4 piece = *(const ffn_u32x4 *)(lds_t[wave] + ffn_t_off(rl, lane & 7));
+                *(ffn_u32x4 *)(dst + rg * a.F) = piece;
+            }
+        }
+        ffn_wave_sync();
         // ---- second product: out^T[n] (32 model columns x 32 rows) += Q[n] . T^T, reduction over the chunk's 64 hidden units
         #pragma unroll
         for (int n = 0; n < 4; ++n)

@@ -518,10 +518,10 @@ class AMPAgent:
     def _capture(self, arms):
         """The step as a replayable object: one graph on one rank; data parallel a pair (gradient graph, apply graph) sharing one
         memory pool, replayed around the bucket's all-reduce (`_replay`)."""
-        from ..dist import world_size
+        from ..dist import is_distributed
         self._g_arms = bool(arms)
         torch.cuda.synchronize(self.device)
-        if world_size() == 1:
+        if not is_distributed():                            # (true for one rank with EMLOCO_FORCE_COLLECTIVES=1 as well: the exchange is issued)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._graph_body()
@@ -554,7 +554,7 @@ class AMPAgent:
         graphs timed on the next steps, then the faster one replayed."""
         self.set_train()
         self._graph_fill(i)
-        from ..dist import world_size
+        from ..dist import is_distributed
         if self._graph is not None:
             self._replay(self._graph)
             return
@@ -564,7 +564,7 @@ class AMPAgent:
             self._g_side = side
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
-                if world_size() == 1:
+                if not is_distributed():
                     self._graph_body()
                 else:                                       # the data-parallel step, eagerly: gradients | exchange | apply
                     self._graph_body("grad")
@@ -573,7 +573,7 @@ class AMPAgent:
             torch.cuda.current_stream(self.device).wait_stream(side)
             return
         mode = os.environ.get("EMLOCO_PPO_BRANCHES", "auto")
-        if world_size() > 1 and mode == "auto":
+        if is_distributed() and mode == "auto":
             # every rank must replay the SAME number of collectives per step and the timing trial below is rank-local: data parallel the
             # choice is made by the environment (default: the arms, what wins on 16 hardware queues) and is the same on every rank
             mode = "1"

@@ -73,7 +73,7 @@ def _lib():
         lib.emloco_adam_clip_flat_workspace.argtypes = [C.c_int64]
         lib.emloco_adam_clip_flat_workspace.restype = C.c_int64
         lib.emloco_gemm_enable_timing.argtypes = [ci]
-        lib.emloco_ffn_fwd.argtypes = [ci, ci] + [vp] * 7 + [cf, C.c_uint32, C.c_uint32, vp]
+        lib.emloco_ffn_fwd.argtypes = [ci, ci] + [vp] * 8 + [cf, C.c_uint32, C.c_uint32, vp]
         lib.emloco_ffn_bwd_input.argtypes = [ci, ci] + [vp] * 6 + [cf, vp]
         lib.emloco_ffn_keep_mask.argtypes = [C.c_uint32, cl, cl, ci, cf, vp]
         lib.emloco_disc_reward.argtypes = [ci, vp, cf, vp, vp]
@@ -290,9 +290,11 @@ class FeedForwardFn(torch.autograd.Function):
             W1b, W2b = W1c.to(torch.bfloat16), W2c.to(torch.bfloat16)
             h = torch.empty((M, F), dtype=torch.bfloat16, device=x.device)
             f = torch.empty((M, N), dtype=torch.float32, device=x.device)
-            _chk(_lib().emloco_ffn_fwd(M, F, _p(x2), _p(W1b), _p(W2b), _p(b1.contiguous()), _p(b2.contiguous()), _p(h), _p(f), float(drop_p),
+            mbits = torch.empty((M, F // 32), dtype=torch.int32, device=x.device)      # "active and kept", one bit per hidden unit
+            _chk(_lib().emloco_ffn_fwd(M, F, _p(x2), _p(W1b), _p(W2b), _p(b1.contiguous()), _p(b2.contiguous()), _p(h), _p(mbits), _p(f), float(drop_p),
                                        int(seed1) & 0xFFFFFFFF, int(seed2) & 0xFFFFFFFF, _st(x2)), "emloco_ffn_fwd")
             ctx.save_for_backward(x2, W1b, W2b, h)
+            ctx.mbits = mbits
             return f.view(*xs[:-1], N)
         # the hidden layer is the largest tensor of the step (M x 1024): bf16 in HBM in the reduced-precision mode
         # (the bf16-in-memory GEMM variants serve the 128-wide tiles and 8-byte-aligned rows only: small models keep fp32)
@@ -325,7 +327,7 @@ class FeedForwardFn(torch.autograd.Function):
             dz1 = torch.empty((M, F), dtype=torch.bfloat16, device=dev)
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
             w2t, w1t = W2.t().contiguous(), W1.t().contiguous()       # (named: a temporary's block would be handed to the next allocation)
-            _chk(lib.emloco_ffn_bwd_input(M, F, _p(dz2), _p(w2t), _p(w1t), _p(h), _p(dz1), _p(dx), float(p), st), "emloco_ffn_bwd_input")
+            _chk(lib.emloco_ffn_bwd_input(M, F, _p(dz2), _p(w2t), _p(w1t), _p(ctx.mbits), _p(dz1), _p(dx), float(p), st), "emloco_ffn_bwd_input")
             dW2 = torch.empty((N, F), dtype=torch.float32, device=dev)
             gemm(1, N, F, M, dz2, N, 0, 1, h, F, 0, 1, dW2, F, 0, ksplit=_ksplit_for(M, N * F))          # dW2 = dz2^T h
             dW1 = torch.empty((F, K), dtype=torch.float32, device=dev)

@@ -77,19 +77,22 @@ int emloco_gemm_relu_bwd(int m, int n, int k, const float *A, int lda, const flo
  * v_mfma_f32_32x32x16_bf16, fp32 accumulation): the hidden tile goes from the product that makes it to the product that consumes it in
  * registers; it is also stored, as bf16, for the two weight-gradient products (ordinary GEMMs with a bf16 operand).  Model width 128,
  * F a multiple of 64; every pointer 16-byte aligned; weights are bf16 copies the caller makes per call (2 x 256 KB at F = 1024).
- *   emloco_ffn_fwd        hidden[M][F] = dropout(relu(x w1^T + b1)) (bf16), out[M][128] = dropout(hidden w2^T + b2) (fp32);
- *                         w1_bf16 [F][128], w2_bf16 [128][F].  Hidden mask: emloco_ffn_keep_mask(seed_hidden, ...); output mask: the GEMM
- *                         epilogue's counter hash, emloco_dropout_keep_mask(seed_out, row * 128 + col, ...) -- so emloco_act_bwd_colsum(M,
- *                         128, dout, NULL, 0, p, seed_out, ...) is the backward of the output dropout.  drop_p = 0: no dropout (eval).
- *   emloco_ffn_bwd_input  dz1[M][F] = (dz2 w2) o [hidden > 0] / (1 - p) (bf16), dx[M][128] = dz1 w1 (fp32); dz2 [M][128] fp32 is the
- *                         gradient w.r.t. linear2's output (output dropout already applied), w2t_bf16 = w2^T [F][128], w1t_bf16 = w1^T
- *                         [128][F].  The weight and bias gradients follow from hidden / dz1: dW2 = dz2^T hidden, dW1 = dz1^T x,
- *                         db1 = column sums of dz1 (emloco_gemm_f32_ex with a bf16 operand, emloco_colsum_ex).
+ *   emloco_ffn_fwd        hidden[M][F] = dropout(relu(x w1^T + b1)) (bf16), out[M][128] = dropout(hidden w2^T + b2) (fp32), mask[M][F / 32]:
+ *                         one BIT per hidden unit, "active and kept" (word (row, 64-unit chunk c, h) at [row][2 c + h], bit 16 t + 4 q + e =
+ *                         unit 64 c + 32 t + 8 q + 4 h + e: the units one lane of the kernel holds) -- all the input-gradient pass reads of the
+ *                         hidden layer; w1_bf16 [F][128], w2_bf16 [128][F].  Hidden dropout mask: emloco_ffn_keep_mask(seed_hidden, ...);
+ *                         output mask: the GEMM epilogue's counter hash, emloco_dropout_keep_mask(seed_out, row * 128 + col, ...) -- so
+ *                         emloco_act_bwd_colsum(M, 128, dout, NULL, 0, p, seed_out, ...) is the backward of the output dropout.  drop_p = 0:
+ *                         no dropout (eval).
+ *   emloco_ffn_bwd_input  dz1[M][F] = (dz2 w2) o [mask] / (1 - p) (bf16), dx[M][128] = dz1 w1 (fp32); dz2 [M][128] fp32 is the gradient
+ *                         w.r.t. linear2's output (output dropout already applied), w2t_bf16 = w2^T [F][128], w1t_bf16 = w1^T [128][F].
+ *                         The weight and bias gradients follow from hidden / dz1: dW2 = dz2^T hidden, dW1 = dz1^T x, db1 = column sums of
+ *                         dz1 (emloco_gemm_f32_ex with a bf16 operand, emloco_colsum_ex).
  *   emloco_ffn_keep_mask  the hidden layer's keep mask on the HOST (host_out[r][f] = 1 iff unit f of row first_row + r is kept): one 32-bit
  *                         hash per pair of adjacent units, 16 bits each against p 2^16.  For tests. */
 int emloco_ffn_fwd(int M, int F, const float *x, const uint16_t *w1_bf16, const uint16_t *w2_bf16, const float *b1, const float *b2,
-                   uint16_t *hidden, float *out, float drop_p, uint32_t seed_hidden, uint32_t seed_out, void *stream);
-int emloco_ffn_bwd_input(int M, int F, const float *dz2, const uint16_t *w2t_bf16, const uint16_t *w1t_bf16, const uint16_t *hidden,
+                   uint16_t *hidden, uint32_t *mask, float *out, float drop_p, uint32_t seed_hidden, uint32_t seed_out, void *stream);
+int emloco_ffn_bwd_input(int M, int F, const float *dz2, const uint16_t *w2t_bf16, const uint16_t *w1t_bf16, const uint32_t *mask,
                          uint16_t *dz1, float *dx, float drop_p, void *stream);
 int emloco_ffn_keep_mask(uint32_t seed_hidden, int64_t first_row, int64_t rows, int F, float p, uint8_t *host_out);
 

@@ -1090,7 +1090,9 @@ def test_chained_feed_forward_kernels():
     for p, s1, s2 in ((0.0, 0, 0), (0.1, 12345, 777)):
         h = np.full((M, F), 0x7fc0, np.uint16)                    # NaN patterns: every element must be written
         out = np.full((M, D), np.nan, np.float32)
-        lib.emu_ffn_chain(0, M, F, P(x), U16(W1b), U16(W2b), P(b1), P(b2), U16(h), None, P(out), C.c_float(p), C.c_uint(s1), C.c_uint(s2))
+        mbits = np.full((M, F // 32), 0xdeadbeef, np.uint32)
+        lib.emu_ffn_chain(0, M, F, P(x), U16(W1b), U16(W2b), P(b1), P(b2), U16(h), None, mbits.ctypes.data_as(C.POINTER(C.c_uint)), P(out),
+                          C.c_float(p), C.c_uint(s1), C.c_uint(s2))
         keep = np.ones((M, F), bool)
         if p > 0:
             keep = np.array([[lib.emu_ffn_keep(C.c_uint(s1), r, f, C.c_float(p)) for f in range(F)] for r in range(M)], bool)
@@ -1098,6 +1100,11 @@ def test_chained_feed_forward_kernels():
         want = np.where(keep, np.maximum(pre, 0.0) / (1.0 - p), 0.0)
         got = _bf16_val(h).astype(np.float64)
         assert not np.isnan(got).any()
+        # the mask bits the input-gradient pass reads: word [row][2 c + hi], bit 16 t + 4 q + e = unit 64 c + 32 t + 8 q + 4 hi + e
+        unit = np.arange(F)
+        cc, tt, qq, hh, ee = unit // 64, (unit % 64) // 32, (unit % 32) // 8, (unit % 8) // 4, unit % 4
+        bits = (mbits[:, 2 * cc + hh] >> (16 * tt + 4 * qq + ee).astype(np.uint32)) & 1
+        assert np.array_equal(bits.astype(bool), got > 0)
         assert ((got == 0) == (want <= 0)).mean() > 0.999            # (a pre-activation within rounding of zero may fall either side)
         np.testing.assert_allclose(got, want, rtol=2.0 ** -7, atol=2e-5)
         assert np.mean(got == _bf16_val(_bf16_bits(want.astype(np.float32)))) > 0.98      # the same bf16 value almost everywhere
@@ -1112,7 +1119,8 @@ def test_chained_feed_forward_kernels():
         W2T, W1T = np.ascontiguousarray(W2b.T), np.ascontiguousarray(W1b.T)
         dz1 = np.full((M, F), 0x7fc0, np.uint16)
         dx = np.full((M, D), np.nan, np.float32)
-        lib.emu_ffn_chain(1, M, F, P(dz2), U16(W2T), U16(W1T), None, None, U16(h), U16(dz1), P(dx), C.c_float(p), C.c_uint(0), C.c_uint(0))
+        lib.emu_ffn_chain(1, M, F, P(dz2), U16(W2T), U16(W1T), None, None, None, U16(dz1), mbits.ctypes.data_as(C.POINTER(C.c_uint)), P(dx),
+                          C.c_float(p), C.c_uint(0), C.c_uint(0))
         t = _bf16_val(_bf16_bits(dz2)).astype(np.float64) @ _bf16_val(W2b).astype(np.float64)
         want1 = np.where(got > 0, t / (1.0 - p), 0.0)
         got1 = _bf16_val(dz1).astype(np.float64)

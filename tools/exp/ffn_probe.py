@@ -18,11 +18,12 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 handles = []
 for path in libs:
     L = C.CDLL(path)
-    L.emloco_ffn_fwd.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.emloco_ffn_fwd.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]
     L.emloco_ffn_bwd_input.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p]
     handles.append((os.path.basename(path), L))
-def fwd(L, p): assert L.emloco_ffn_fwd(M, F, P(x), P(W1), P(W2), P(b1), P(b2), P(h), P(out), p, 11, 22, st) == 0
-def bwd(L, p): assert L.emloco_ffn_bwd_input(M, F, P(dz2), P(W2T), P(W1T), P(h), P(dz1), P(dx), p, st) == 0
+mb = torch.empty(M, F // 32, dtype=torch.int32, device=dev)
+def fwd(L, p): assert L.emloco_ffn_fwd(M, F, P(x), P(W1), P(W2), P(b1), P(b2), P(h), P(mb), P(out), p, 11, 22, st) == 0
+def bwd(L, p): assert L.emloco_ffn_bwd_input(M, F, P(dz2), P(W2T), P(W1T), P(mb), P(dz1), P(dx), p, st) == 0
 res = {}
 for rep in range(3):
     for name, L in handles:
