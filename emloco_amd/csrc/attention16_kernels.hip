@@ -1,0 +1,400 @@
+// attention16_kernels.hip -- the fused attention of the reduced-precision mode (q|k|v held in HBM as bf16, ops.set_matmul_precision("bf16"):
+// BASELINE configs[3] "bf16 MFMA attention"), head dim 32, gfx950 (MI355X).  Round 5.
+//
+// Reference: nn.MultiheadAttention inside nn.TransformerEncoderLayer, /root/reference/social-transmotion/model_jta.py:177-178,311-321.
+// Same mathematics, arguments, dropout mask (at_keep_bit) and memory formats as attn_fwd / attn_bwd_dq / attn_bwd_dkv<1, DROP, 1>
+// (attention_kernels.hip), which these kernels replace for that mode.  What changed, and why (profiles/r04_mfma_utilisation.txt: the
+// matrix pipe of those kernels was 8.5-10.9 % busy; their time was their vector-instruction count and the latency of one dependent
+// chain per wave):
+//   * a wave owns TWO blocks of 32 rows (64 queries, or keys in the dK/dV kernel): every operand fragment read from LDS feeds two matrix
+//     instructions, a workgroup covers 256 rows (half the barriers and tile fetches per row), and the two blocks' softmax chains are
+//     independent instruction streams the scheduler interleaves with the other block's matrix instructions;
+//   * the walked tiles live in LDS as bf16 in the layout the matrix instruction consumes -- a [32][32] row image whose 16-byte slots
+//     are the 8 consecutive reduction entries a lane feeds (one ds_read_b128 per instruction operand, no widening to fp32 on the way in
+//     and no per-wave re-packing on the way out), and for the products that reduce over the tile's rows a TRANSPOSED image whose slots
+//     hold the rows in the order the accumulator registers of the producing instruction have them (kappa order);
+//   * softmax in base 2 (one v_exp_f32 per probability, scale and bias folded into one fma), no select around the exponential (a masked
+//     key carries -inf), the dropout scale folded into the final normalisation.
+#include "attention_kernels.hip"
+
+namespace emloco {
+
+#define A16_LOG2E 1.4426950408889634f
+#define A16_LN2 0.6931471805599453f
+#define A16_TILE_BYTES 2048                 // 32 x 32 bf16
+struct __attribute__((aligned(8))) a16_u32x2 { unsigned x, y; };
+
+// row image: row r (64 bytes), 16-byte slot s (8 consecutive columns) at s ^ ((r >> 2) & 3): the 16 rows of a ds_read_b128 lane group
+// cover all 64 banks.  Transposed image: row = column c of the tile, slot s = 2 (16-row block of the tile) + lane half, holding the
+// block's rows [4 h .. 4 h + 3, 8 + 4 h .. 8 + 4 h + 3] -- what registers 8 g .. 8 g + 7 of lane half h hold of an accumulator.
+__device__ __forceinline__ int a16_slot_off(int r, int s) { return r * 64 + ((s ^ ((r >> 2) & 3)) << 4); }
+__device__ __forceinline__ bf16w4 a16_frag(const char *tile, int row, int slot) { return *(const bf16w4 *)(tile + a16_slot_off(row, slot)); }
+// one thread's 4 consecutive columns (c0 = 4 piece) of tile row `r`, as two packed words
+__device__ __forceinline__ void a16_stash_rows(char *tile, int r, int piece, a16_u32x2 v) {
+    *(a16_u32x2 *)(tile + a16_slot_off(r, piece >> 1) + (piece & 1) * 8) = v;
+}
+__device__ __forceinline__ void a16_stash_cols(char *tile, int r, int piece, a16_u32x2 v) {
+    const int slot = 2 * (r >> 4) + ((r >> 2) & 1), idx = (r & 3) + 4 * ((r >> 3) & 1);
+    unsigned short *t = (unsigned short *)tile;
+    const unsigned short e[4] = {(unsigned short)(v.x & 0xffffu), (unsigned short)(v.x >> 16), (unsigned short)(v.y & 0xffffu), (unsigned short)(v.y >> 16)};
+    #pragma unroll
+    for (int k = 0; k < 4; ++k) t[(a16_slot_off(4 * piece + k, slot) >> 1) + idx] = e[k];
+}
+__device__ __forceinline__ a16_u32x2 a16_ld_bf16x4(const unsigned short *base, long elems, bool ok) {
+    a16_u32x2 v = *(const a16_u32x2 *)(base + elems);
+    if (!ok) v = a16_u32x2{0u, 0u};
+    return v;
+}
+__device__ __forceinline__ a16_u32x2 a16_ld_f32x4(const float *base, long elems, bool ok) {
+    const at_f32x4 t = *(const at_f32x4 *)(base + elems);
+    a16_u32x2 v{gemm_pack2_bf16(t.x, t.y), gemm_pack2_bf16(t.z, t.w)};
+    if (!ok) v = a16_u32x2{0u, 0u};
+    return v;
+}
+// a lane's own row as the B operand of a product that reduces over the head dim: step ks covers d = 16 ks + 8 hi + 0..7
+__device__ __forceinline__ void a16_own_row_bf16(const unsigned short *base, long ld, int row, int rows, int hi, bf16w4 (&f)[2]) {
+    const long rc = row < rows ? row : rows - 1;
+    #pragma unroll
+    for (int ks = 0; ks < 2; ++ks) f[ks] = *(const bf16w4 *)(base + rc * ld + 16 * ks + 8 * hi);
+}
+__device__ __forceinline__ void a16_own_row_f32(const float *base, long ld, int row, int rows, int hi, bf16w4 (&f)[2], float (&raw)[16]) {
+    const long rc = row < rows ? row : rows - 1;
+    #pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const at_f32x4 v0 = *(const at_f32x4 *)(base + rc * ld + 16 * ks + 8 * hi), v1 = *(const at_f32x4 *)(base + rc * ld + 16 * ks + 8 * hi + 4);
+        f[ks] = bf16w4{gemm_pack2_bf16(v0.x, v0.y), gemm_pack2_bf16(v0.z, v0.w), gemm_pack2_bf16(v1.x, v1.y), gemm_pack2_bf16(v1.z, v1.w)};
+        raw[8 * ks] = v0.x; raw[8 * ks + 1] = v0.y; raw[8 * ks + 2] = v0.z; raw[8 * ks + 3] = v0.w;
+        raw[8 * ks + 4] = v1.x; raw[8 * ks + 5] = v1.y; raw[8 * ks + 6] = v1.z; raw[8 * ks + 7] = v1.w;
+    }
+}
+// 16 accumulator values -> the two B operands (reduction over the tile's rows, kappa order) of the next product
+__device__ __forceinline__ void a16_pack16(const float (&p)[16], bf16w4 (&o)[2]) {
+    #pragma unroll
+    for (int g = 0; g < 2; ++g)
+        o[g] = bf16w4{gemm_pack2_bf16(p[8 * g], p[8 * g + 1]), gemm_pack2_bf16(p[8 * g + 2], p[8 * g + 3]),
+                      gemm_pack2_bf16(p[8 * g + 4], p[8 * g + 5]), gemm_pack2_bf16(p[8 * g + 6], p[8 * g + 7])};
+}
+// keep factors (1 / 0) of a lane's 16 entries of a tile: entry r = (tile row kappa(r, hi), own row) -- `rows_are_keys`: the tile's rows
+// are keys and the lane's own row is the query (forward, dQ), else the tile's rows are queries and the own row is a key (dK / dV).
+// One hash serves two adjacent KEYS (at_keep_bit): with keys along the registers that is registers (2 j, 2 j + 1); with queries along
+// the registers every register has its own hash.
+template <bool ROWS_ARE_KEYS>
+__device__ __forceinline__ void a16_keep16(const AttnArgs &a, unsigned hkey, int own, int t0, int hi, bool (&keep)[16]) {
+    const unsigned thr = a.drop_thr >> 8;
+    if (ROWS_ARE_KEYS) {
+        const unsigned qk = hkey + (unsigned)own * 0x85EBCA6Bu;
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned key = (unsigned)(t0 + at_kappa(2 * j, hi));
+            const unsigned x = at_fmix32(qk ^ ((key >> 1) * 0xC2B2AE35u));
+            keep[2 * j] = (x & 0xffffu) >= thr; keep[2 * j + 1] = (x >> 16) >= thr;
+        }
+    } else {
+        const unsigned kk = ((unsigned)own >> 1) * 0xC2B2AE35u;
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned x = at_fmix32((hkey + (unsigned)(t0 + at_kappa(r, hi)) * 0x85EBCA6Bu) ^ kk);
+            keep[r] = ((own & 1) ? (x >> 16) : (x & 0xffffu)) >= thr;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int DROP>
+__global__ void __launch_bounds__(256)
+attn16_fwd_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char Kt[2][A16_TILE_BYTES], Vt[2][A16_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) float Bs[2][AT_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
+    const unsigned hkey = at_head_key(a.drop_seed, (unsigned)bh);
+    const long ld = 3L * a.d_model;
+    const unsigned short *Q = (const unsigned short *)a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
+    const float *kb = a.key_bias ? a.key_bias + (long)b * a.S : nullptr;
+    const int q0 = blockIdx.x * 256 + wave * 64;
+    int query[2];
+    bf16w4 qf[2][2];
+    bool live[2];
+    at_f32x16 acc_o[2];
+    float m[2], lsum[2];
+    #pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        query[g] = q0 + 32 * g + l31;
+        a16_own_row_bf16(Q, ld, query[g], a.Sq, hi, qf[g]);
+        live[g] = q0 + 32 * g < a.Sq;                        // wave-uniform: a block wholly past the live queries only helps staging
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[g][r] = 0.0f;
+        m[g] = AT_NEG; lsum[g] = 0.0f;
+    }
+    const float scale2 = a.scale * A16_LOG2E;
+    const int ntiles = (a.S + AT_T - 1) / AT_T;
+    // staging: thread = (tile row tid >> 3, 4 columns 4 (tid & 7)) of K and of V; thread tid < 32 the key bias of tile row tid
+    const int sr = tid >> 3, sp = tid & 7, t31 = tid & 31;
+    const float *kbp = kb ? kb : (const float *)a.qkv;
+    a16_u32x2 rk = a16_ld_bf16x4(K, (long)(sr < a.S ? sr : a.S - 1) * ld + 4 * sp, sr < a.S);
+    a16_u32x2 rv = a16_ld_bf16x4(V, (long)(sr < a.S ? sr : a.S - 1) * ld + 4 * sp, sr < a.S);
+    float rb = kbp[t31 < a.S ? t31 : a.S - 1];
+    a16_stash_rows(Kt[0], sr, sp, rk); a16_stash_cols(Vt[0], sr, sp, rv);
+    if (tid < AT_T) Bs[0][tid] = tid < a.S ? (kb ? rb * A16_LOG2E : 0.0f) : -INFINITY;
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, k0 = t * AT_T, k0n = k0 + AT_T;
+        {
+            const int kr = k0n + sr;
+            const long kc = kr < a.S ? kr : a.S - 1;
+            rk = a16_ld_bf16x4(K, kc * ld + 4 * sp, kr < a.S); rv = a16_ld_bf16x4(V, kc * ld + 4 * sp, kr < a.S);
+            rb = kbp[k0n + t31 < a.S ? k0n + t31 : a.S - 1];
+        }
+        if (live[0]) {                                        // (block 1 is never live without block 0)
+            const bf16w4 kf0 = a16_frag(Kt[buf], l31, hi), kf1 = a16_frag(Kt[buf], l31, 2 + hi);
+            const bf16w4 vf0 = a16_frag(Vt[buf], l31, hi), vf1 = a16_frag(Vt[buf], l31, 2 + hi);
+            float bias[16];
+            at_vec16(Bs[buf], hi, bias);
+            #pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 1 && !live[1]) break;
+                at_f32x16 st;
+                #pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+                st = gemm_mfma_bf16_w(kf0, qf[g][0], st);       // scores^T: keys (rows) x own queries (lanes)
+                st = gemm_mfma_bf16_w(kf1, qf[g][1], st);
+                float p[16], tmax = AT_NEG;
+                #pragma unroll
+                for (int r = 0; r < 16; ++r) { p[r] = fmaf(st[r], scale2, bias[r]); tmax = p[r] > tmax ? p[r] : tmax; }
+                { const float o = __shfl_xor(tmax, 32); tmax = o > tmax ? o : tmax; }
+                const float m_new = tmax > m[g] ? tmax : m[g];
+                const float alpha = exp2f(m[g] - m_new);          // m = AT_NEG before the first live key: 0
+                float tsum = 0.0f;
+                #pragma unroll
+                for (int r = 0; r < 16; ++r) { p[r] = exp2f(p[r] - m_new); tsum += p[r]; }     // a masked key carries -inf: 0
+                tsum += __shfl_xor(tsum, 32);
+                lsum[g] = lsum[g] * alpha + tsum;
+                m[g] = m_new;
+                #pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[g][r] *= alpha;
+                if (DROP) {                                       // the output sums the kept probabilities (scaled at the end), the normaliser all of them
+                    bool keep[16];
+                    a16_keep16<true>(a, hkey, query[g], k0, hi, keep);
+                    #pragma unroll
+                    for (int r = 0; r < 16; ++r) p[r] = keep[r] ? p[r] : 0.0f;
+                }
+                bf16w4 pb[2];
+                a16_pack16(p, pb);
+                acc_o[g] = gemm_mfma_bf16_w(vf0, pb[0], acc_o[g]);  // O^T += V^T P^T
+                acc_o[g] = gemm_mfma_bf16_w(vf1, pb[1], acc_o[g]);
+            }
+        }
+        a16_stash_rows(Kt[buf ^ 1], sr, sp, rk); a16_stash_cols(Vt[buf ^ 1], sr, sp, rv);
+        if (tid < AT_T) Bs[buf ^ 1][tid] = k0n + tid < a.S ? (kb ? rb * A16_LOG2E : 0.0f) : -INFINITY;
+        __syncthreads();
+    }
+    #pragma unroll
+    for (int g = 0; g < 2; ++g)
+        if (query[g] < a.Sq) {
+            const float inv = lsum[g] > 0.0f ? (DROP ? a.drop_scale : 1.0f) / lsum[g] : 0.0f;       // fully masked row -> zeros ("safe softmax")
+            at_store_rowT(a.out + ((long)b * a.Sq + query[g]) * a.d_model + hd * AT_DH, hi, acc_o[g], inv);
+            if (hi == 0 && a.lse) a.lse[(long)bh * a.Sq + query[g]] = lsum[g] > 0.0f ? m[g] * A16_LN2 + logf(lsum[g]) : 3.0e38f;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ backward 1: dQ (and D)
+template <int DROP>
+__global__ void __launch_bounds__(256)
+attn16_bwd_dq_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char Kt[2][A16_TILE_BYTES], Vr[2][A16_TILE_BYTES], Kc[2][A16_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) float Bs[2][AT_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
+    const unsigned hkey = at_head_key(a.drop_seed, (unsigned)bh);
+    const long ld = 3L * a.d_model;
+    const unsigned short *Q = (const unsigned short *)a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
+    const float *dO = a.dout + (long)b * a.Sq * a.d_model + hd * AT_DH, *O = a.out + (long)b * a.Sq * a.d_model + hd * AT_DH;
+    const float *kb = a.key_bias ? a.key_bias + (long)b * a.S : nullptr;
+    const int q0 = blockIdx.x * 256 + wave * 64;
+    int query[2];
+    bf16w4 qf[2][2], dof[2][2];
+    bool live[2];
+    at_f32x16 acc[2];
+    float lse2[2], dsum[2];
+    #pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        query[g] = q0 + 32 * g + l31;
+        live[g] = q0 + 32 * g < a.Sq;
+        a16_own_row_bf16(Q, ld, query[g], a.Sq, hi, qf[g]);
+        float dor[16], orow[16];
+        bf16w4 unused[2];
+        a16_own_row_f32(dO, a.d_model, query[g], a.Sq, hi, dof[g], dor);
+        a16_own_row_f32(O, a.d_model, query[g], a.Sq, hi, unused, orow);
+        float ds = 0.0f;                                      // D = sum_d dO O (the lane pair holds the two halves of d)
+        #pragma unroll
+        for (int e = 0; e < 16; ++e) ds = fmaf(dor[e], orow[e], ds);
+        ds += __shfl_xor(ds, 32);
+        dsum[g] = ds;
+        const bool qok = query[g] < a.Sq;
+        lse2[g] = qok ? a.lse[(long)bh * a.Sq + query[g]] * A16_LOG2E : 3.0e38f;
+        if (qok && hi == 0) a.dsum[(long)bh * a.Sq + query[g]] = ds;
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
+    }
+    const float scale2 = a.scale * A16_LOG2E;
+    const float dscale = DROP ? a.drop_scale : 1.0f;
+    const int ntiles = (a.S + AT_T - 1) / AT_T;
+    const int sr = tid >> 3, sp = tid & 7, t31 = tid & 31;
+    const float *kbp = kb ? kb : (const float *)a.qkv;
+    a16_u32x2 rk = a16_ld_bf16x4(K, (long)(sr < a.S ? sr : a.S - 1) * ld + 4 * sp, sr < a.S);
+    a16_u32x2 rv = a16_ld_bf16x4(V, (long)(sr < a.S ? sr : a.S - 1) * ld + 4 * sp, sr < a.S);
+    float rb = kbp[t31 < a.S ? t31 : a.S - 1];
+    a16_stash_rows(Kt[0], sr, sp, rk); a16_stash_cols(Kc[0], sr, sp, rk); a16_stash_rows(Vr[0], sr, sp, rv);
+    if (tid < AT_T) Bs[0][tid] = tid < a.S ? (kb ? rb * A16_LOG2E : 0.0f) : -INFINITY;
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, k0 = t * AT_T, k0n = k0 + AT_T;
+        {
+            const int kr = k0n + sr;
+            const long kc = kr < a.S ? kr : a.S - 1;
+            rk = a16_ld_bf16x4(K, kc * ld + 4 * sp, kr < a.S); rv = a16_ld_bf16x4(V, kc * ld + 4 * sp, kr < a.S);
+            rb = kbp[k0n + t31 < a.S ? k0n + t31 : a.S - 1];
+        }
+        if (live[0]) {
+            const bf16w4 kf0 = a16_frag(Kt[buf], l31, hi), kf1 = a16_frag(Kt[buf], l31, 2 + hi);
+            const bf16w4 vf0 = a16_frag(Vr[buf], l31, hi), vf1 = a16_frag(Vr[buf], l31, 2 + hi);
+            const bf16w4 kc0 = a16_frag(Kc[buf], l31, hi), kc1 = a16_frag(Kc[buf], l31, 2 + hi);
+            float bias[16];
+            at_vec16(Bs[buf], hi, bias);
+            #pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 1 && !live[1]) break;
+                at_f32x16 st, dpt;
+                #pragma unroll
+                for (int r = 0; r < 16; ++r) { st[r] = 0.0f; dpt[r] = 0.0f; }
+                st = gemm_mfma_bf16_w(kf0, qf[g][0], st);       // S^T
+                st = gemm_mfma_bf16_w(kf1, qf[g][1], st);
+                dpt = gemm_mfma_bf16_w(vf0, dof[g][0], dpt);    // dP^T = V dO^T
+                dpt = gemm_mfma_bf16_w(vf1, dof[g][1], dpt);
+                float ds[16];
+                bool keep[16];
+                if (DROP) a16_keep16<true>(a, hkey, query[g], k0, hi, keep);
+                #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = exp2f(fmaf(st[r], scale2, bias[r]) - lse2[g]);       // masked key: -inf -> 0; row past the end: lse = 3e38 -> 0
+                    float dpr = dpt[r] * dscale;                                      // d loss / d (dropped probability)
+                    if (DROP) dpr = keep[r] ? dpr : 0.0f;
+                    ds[r] = a.scale * p * (dpr - dsum[g]);
+                }
+                bf16w4 db[2];
+                a16_pack16(ds, db);
+                acc[g] = gemm_mfma_bf16_w(kc0, db[0], acc[g]);  // dQ^T += K^T dS^T
+                acc[g] = gemm_mfma_bf16_w(kc1, db[1], acc[g]);
+            }
+        }
+        a16_stash_rows(Kt[buf ^ 1], sr, sp, rk); a16_stash_cols(Kc[buf ^ 1], sr, sp, rk); a16_stash_rows(Vr[buf ^ 1], sr, sp, rv);
+        if (tid < AT_T) Bs[buf ^ 1][tid] = k0n + tid < a.S ? (kb ? rb * A16_LOG2E : 0.0f) : -INFINITY;
+        __syncthreads();
+    }
+    #pragma unroll
+    for (int g = 0; g < 2; ++g)
+        if (query[g] < a.Sq)
+            at_store_rowT<1>((float *)((unsigned short *)a.dqkv + ((long)b * a.S + query[g]) * ld + hd * AT_DH), hi, acc[g], 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------ backward 2: dK, dV
+template <int DROP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))       // (left alone: 247 + 64 accumulator registers, one wave per SIMD)
+attn16_bwd_dkv_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char Qr[2][A16_TILE_BYTES], Or[2][A16_TILE_BYTES], Qc[2][A16_TILE_BYTES], Oc[2][A16_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) float Ls[2][AT_T], Ds[2][AT_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
+    const unsigned hkey = at_head_key(a.drop_seed, (unsigned)bh);
+    const long ld = 3L * a.d_model;
+    const unsigned short *Q = (const unsigned short *)a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
+    const float *dO = a.dout + (long)b * a.Sq * a.d_model + hd * AT_DH;
+    const float *lse = a.lse + (long)bh * a.Sq, *dsm = a.dsum + (long)bh * a.Sq;
+    const int k0w = blockIdx.x * 256 + wave * 64;
+    int key[2];
+    bf16w4 kf[2][2], vf[2][2];
+    bool live[2];
+    float bias2[2];
+    at_f32x16 acc_k[2], acc_v[2];
+    #pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        key[g] = k0w + 32 * g + l31;
+        live[g] = k0w + 32 * g < a.S;                         // wave-uniform
+        a16_own_row_bf16(K, ld, key[g], a.S, hi, kf[g]);
+        a16_own_row_bf16(V, ld, key[g], a.S, hi, vf[g]);
+        bias2[g] = -INFINITY;
+        if (key[g] < a.S) bias2[g] = a.key_bias ? a.key_bias[(long)b * a.S + key[g]] * A16_LOG2E : 0.0f;
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_k[g][r] = 0.0f; acc_v[g][r] = 0.0f; }
+    }
+    const float scale2 = a.scale * A16_LOG2E;
+    const float dscale = DROP ? a.drop_scale : 1.0f;
+    const int ntiles = (a.Sq + AT_T - 1) / AT_T;               // walks the live queries
+    const int sr = tid >> 3, sp = tid & 7, t31 = tid & 31;
+    a16_u32x2 rq = a16_ld_bf16x4(Q, (long)(sr < a.Sq ? sr : a.Sq - 1) * ld + 4 * sp, sr < a.Sq);
+    a16_u32x2 ro = a16_ld_f32x4(dO, (long)(sr < a.Sq ? sr : a.Sq - 1) * a.d_model + 4 * sp, sr < a.Sq);
+    float rl = lse[t31 < a.Sq ? t31 : a.Sq - 1], rd = dsm[t31 < a.Sq ? t31 : a.Sq - 1];
+    a16_stash_rows(Qr[0], sr, sp, rq); a16_stash_cols(Qc[0], sr, sp, rq); a16_stash_rows(Or[0], sr, sp, ro); a16_stash_cols(Oc[0], sr, sp, ro);
+    if (tid < AT_T) { Ls[0][tid] = tid < a.Sq ? rl * A16_LOG2E : 3.0e38f; Ds[0][tid] = tid < a.Sq ? rd : 0.0f; }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, q0 = t * AT_T, q0n = q0 + AT_T;
+        {
+            const int qr = q0n + sr;
+            const long qc = qr < a.Sq ? qr : a.Sq - 1;
+            rq = a16_ld_bf16x4(Q, qc * ld + 4 * sp, qr < a.Sq); ro = a16_ld_f32x4(dO, qc * a.d_model + 4 * sp, qr < a.Sq);
+            const int qs = q0n + t31 < a.Sq ? q0n + t31 : a.Sq - 1;
+            rl = lse[qs]; rd = dsm[qs];
+        }
+        if (live[0]) {
+            const bf16w4 qr0 = a16_frag(Qr[buf], l31, hi), qr1 = a16_frag(Qr[buf], l31, 2 + hi);
+            const bf16w4 or0 = a16_frag(Or[buf], l31, hi), or1 = a16_frag(Or[buf], l31, 2 + hi);
+            const bf16w4 qc0 = a16_frag(Qc[buf], l31, hi), qc1 = a16_frag(Qc[buf], l31, 2 + hi);
+            const bf16w4 oc0 = a16_frag(Oc[buf], l31, hi), oc1 = a16_frag(Oc[buf], l31, 2 + hi);
+            float lrow[16], drow[16];
+            at_vec16(Ls[buf], hi, lrow);
+            at_vec16(Ds[buf], hi, drow);
+            #pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 1 && !live[1]) break;
+                at_f32x16 s, dp;
+                #pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+                s = gemm_mfma_bf16_w(qr0, kf[g][0], s);          // S: queries (rows) x own keys (lanes)
+                s = gemm_mfma_bf16_w(qr1, kf[g][1], s);
+                dp = gemm_mfma_bf16_w(or0, vf[g][0], dp);        // dP = dO V^T
+                dp = gemm_mfma_bf16_w(or1, vf[g][1], dp);
+                float p[16], ds[16];
+                bool keep[16];
+                if (DROP) a16_keep16<false>(a, hkey, key[g], q0, hi, keep);
+                #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pr = exp2f(fmaf(s[r], scale2, bias2[g]) - lrow[r]);     // rows past the sequence carry lse = 3e38 -> 0
+                    float dpr = dp[r] * dscale;
+                    if (DROP) dpr = keep[r] ? dpr : 0.0f;
+                    ds[r] = a.scale * pr * (dpr - drow[r]);
+                    p[r] = DROP ? (keep[r] ? pr * dscale : 0.0f) : pr;                     // dV sums the dropped probabilities
+                }
+                bf16w4 pb[2], db[2];
+                a16_pack16(p, pb);
+                a16_pack16(ds, db);
+                acc_v[g] = gemm_mfma_bf16_w(oc0, pb[0], acc_v[g]);   // dV^T += dO^T P
+                acc_v[g] = gemm_mfma_bf16_w(oc1, pb[1], acc_v[g]);
+                acc_k[g] = gemm_mfma_bf16_w(qc0, db[0], acc_k[g]);   // dK^T += Q^T dS
+                acc_k[g] = gemm_mfma_bf16_w(qc1, db[1], acc_k[g]);
+            }
+        }
+        a16_stash_rows(Qr[buf ^ 1], sr, sp, rq); a16_stash_cols(Qc[buf ^ 1], sr, sp, rq); a16_stash_rows(Or[buf ^ 1], sr, sp, ro); a16_stash_cols(Oc[buf ^ 1], sr, sp, ro);
+        if (tid < AT_T) { Ls[buf ^ 1][tid] = q0n + tid < a.Sq ? rl * A16_LOG2E : 3.0e38f; Ds[buf ^ 1][tid] = q0n + tid < a.Sq ? rd : 0.0f; }
+        __syncthreads();
+    }
+    #pragma unroll
+    for (int g = 0; g < 2; ++g)
+        if (key[g] < a.S) {
+            unsigned short *dst = (unsigned short *)a.dqkv + ((long)b * a.S + key[g]) * ld + hd * AT_DH;
+            at_store_rowT<1>((float *)(dst + a.d_model), hi, acc_k[g], 1.0f);
+            at_store_rowT<1>((float *)(dst + 2 * a.d_model), hi, acc_v[g], 1.0f);
+        }
+}
+
+}  // namespace emloco

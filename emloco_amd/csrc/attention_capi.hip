@@ -5,10 +5,12 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <stdlib.h>
-#include "attention_kernels.hip"
+#include "attention16_kernels.hip"      // (includes attention_kernels.hip)
 #include "../../include/emloco_predictor.h"
 
 namespace {
+// EMLOCO_ATTN16_OLD=1: the bf16-in-memory mode on round 4's kernels (one block of 32 rows per wave, fp32 LDS tiles) -- A/B knob
+bool attn16_old() { static const bool v = [] { const char *e = getenv("EMLOCO_ATTN16_OLD"); return e && e[0] == '1'; }(); return v; }
 int pfail(int code, const char *what, hipError_t e = hipSuccess) {
     if (e != hipSuccess) fprintf(stderr, "[emloco] %s: %s\n", what, hipGetErrorString(e));
     else fprintf(stderr, "[emloco] %s\n", what);
@@ -51,6 +53,13 @@ int emloco_attention_fwd_queries(int n_seq, int S, int n_query, int nhead, int d
     hipStream_t st = (hipStream_t)stream;
     if (flags & EMLOCO_ATTN_QKV_BF16MEM) {
         if (!bf) return pfail(-1, "emloco_attention_fwd: a bf16 q|k|v tensor needs EMLOCO_ATTN_BF16");
+        if (!attn16_old()) {                                 // round 5: two blocks of 32 queries per wave, bf16 tile images (attention16_kernels.hip)
+            const dim3 grid16((unsigned)((n_query + 255) / 256), (unsigned)(n_seq * nhead));
+            if (dr) hipLaunchKernelGGL((emloco::attn16_fwd_kernel<1>), grid16, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((emloco::attn16_fwd_kernel<0>), grid16, dim3(256), 0, st, a);
+            PHIPCHK(hipGetLastError());
+            return 0;
+        }
         if (dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 1, 1>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 0, 1>), grid, dim3(256), 0, st, a);
         PHIPCHK(hipGetLastError());
@@ -101,6 +110,16 @@ int emloco_attention_bwd_queries(int n_seq, int S, int n_query, int nhead, int d
     const size_t esz = q16 ? 2 : sizeof(float);
     // rows that do not attend get dQ = 0 (the Q third of every dqkv row; the live rows are overwritten below)
     if (n_query < S) PHIPCHK(hipMemset2DAsync(dqkv, 3 * (size_t)d_model * esz, 0, (size_t)d_model * esz, (size_t)n_seq * S, st));
+    if (q16 && !attn16_old()) {
+        const dim3 grid16((unsigned)((S + 255) / 256), (unsigned)(n_seq * nhead)), qgrid16((unsigned)((n_query + 255) / 256), (unsigned)(n_seq * nhead));
+        if (dr) hipLaunchKernelGGL((emloco::attn16_bwd_dq_kernel<1>), qgrid16, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emloco::attn16_bwd_dq_kernel<0>), qgrid16, dim3(256), 0, st, a);
+        PHIPCHK(hipGetLastError());
+        if (dr) hipLaunchKernelGGL((emloco::attn16_bwd_dkv_kernel<1>), grid16, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emloco::attn16_bwd_dkv_kernel<0>), grid16, dim3(256), 0, st, a);
+        PHIPCHK(hipGetLastError());
+        return 0;
+    }
     if (q16) {
         if (dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 1, 1>), qgrid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 0, 1>), qgrid, dim3(256), 0, st, a);

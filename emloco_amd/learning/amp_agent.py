@@ -526,10 +526,12 @@ class AMPAgent:
             with torch.cuda.graph(g):
                 self._graph_body()
             return g
+        # (capture_error_mode "thread_local": the process group's watchdog thread polls the events of earlier collectives while this
+        # thread captures -- under the default global mode its hipEventQuery fails the capture with "operation not permitted")
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
+        with torch.cuda.graph(ga, capture_error_mode="thread_local"):
             self._graph_body("grad")
-        with torch.cuda.graph(gb, pool=ga.pool()):
+        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
             self._graph_body("apply")
         return (ga, gb)
 

@@ -1127,3 +1127,77 @@ def test_chained_feed_forward_kernels():
         assert np.array_equal(got1 == 0, (got <= 0) | (want1 == 0))
         np.testing.assert_allclose(got1, want1, rtol=2.0 ** -7, atol=2e-5)
         np.testing.assert_allclose(dx, got1 @ _bf16_val(W1b).astype(np.float64), rtol=1e-5, atol=2e-5)
+
+
+def test_bf16_attention_kernels_two_blocks_per_wave():
+    """csrc/attention16_kernels.hip (round 5): the reduced-precision mode's fused attention with q|k|v in memory as bf16 -- a wave owns two
+    blocks of 32 rows, the walked tiles live in LDS as bf16 in the matrix instruction's operand layout, base-2 softmax.  Emulated against
+    (a) float64 attention on the bf16-rounded q|k|v with the kernels' own dropout mask (at_keep_bit) -- forward output, log-sum-exp and
+    all three gradients within the bf16 operand class -- and (b) round 4's kernels for the same mode (attn_*<1, DROP, 1>): the same
+    mathematics and the same mask, so they agree to accumulation order.  S = 300 (two workgroups of 256 rows, ragged last tile, a wave
+    whose second block is idle, a wave that is idle altogether), key bias with +1 entries and -inf keys, a fully masked sequence, and the
+    live-query form (Sq < S)."""
+    lib = emu.lib()
+    lib.emu_attn_keep.restype = C.c_int
+    rng = np.random.default_rng(9)
+    U16 = lambda a: a.ctypes.data_as(C.POINTER(C.c_ushort))
+    scale = 1.0 / np.sqrt(32.0)
+    for (n_seq, S, Sq, H, p, seed) in ((2, 300, 300, 1, 0.0, 0), (1, 70, 70, 2, 0.1, 4242), (1, 300, 21, 1, 0.1, 77)):
+        d = H * 32
+        qkv32 = (rng.normal(size=(n_seq, S, 3 * d)) * 0.7).astype(np.float32)
+        qkvb = _bf16_bits(qkv32)
+        qkv = _bf16_val(qkvb).astype(np.float64)
+        kb = np.zeros((n_seq, S), np.float32)
+        kb[0, 5::7] = 1.0
+        kb[-1, S - 20:] = -np.inf
+        dout = rng.normal(size=(n_seq, Sq, d)).astype(np.float32)
+        res = {}
+        for which in (0, 1):
+            out = np.full((n_seq, Sq, d), np.nan, np.float32)
+            lse = np.full((n_seq * H, Sq), np.nan, np.float32)
+            lib.emu_attention16(which, n_seq, S, Sq, H, d, C.c_float(scale), U16(qkvb), P(kb), P(out), P(lse), None, None, None, C.c_float(p), C.c_uint(seed))
+            dqkv = np.zeros((n_seq, S, 3 * d), np.uint16)            # (rows that do not attend keep dQ = 0: the launcher's memset)
+            dsum = np.full((n_seq * H, Sq), np.nan, np.float32)
+            lib.emu_attention16(which, n_seq, S, Sq, H, d, C.c_float(scale), U16(qkvb), P(kb), P(out), P(lse), P(dout), U16(dqkv), P(dsum), C.c_float(p), C.c_uint(seed))
+            res[which] = (out, lse, _bf16_val(dqkv), dsum)
+        # float64 reference with the kernels' mask
+        ref_out = np.zeros((n_seq, Sq, d)); ref_lse = np.zeros((n_seq * H, Sq)); ref_dqkv = np.zeros((n_seq, S, 3 * d))
+        for b in range(n_seq):
+            for h in range(H):
+                q, k, v = (qkv[b, :, i * d + h * 32:i * d + (h + 1) * 32] for i in range(3))
+                s = q[:Sq] @ k.T * scale + kb[b].astype(np.float64)
+                mx = s.max(1, keepdims=True)
+                e = np.exp(s - mx)
+                l = e.sum(1, keepdims=True)
+                P_ = e / l
+                keep = np.ones((Sq, S))
+                if p > 0:
+                    keep = np.array([[lib.emu_attn_keep(C.c_uint(seed), b * H + h, qi, ki, C.c_float(p)) for ki in range(S)] for qi in range(Sq)], np.float64) / (1 - p)
+                Pd = P_ * keep
+                ref_out[b, :, h * 32:(h + 1) * 32] = Pd @ v
+                ref_lse[b * H + h] = (mx + np.log(l))[:, 0]
+                do = dout[b, :, h * 32:(h + 1) * 32].astype(np.float64)
+                dPd = do @ v.T
+                dP = dPd * keep
+                dS = P_ * (dP - (dP * P_).sum(1, keepdims=True))
+                ref_dqkv[b, :Sq, h * 32:(h + 1) * 32] = dS @ k * scale
+                ref_dqkv[b, :, d + h * 32:d + (h + 1) * 32] = dS.T @ q[:Sq] * scale
+                ref_dqkv[b, :, 2 * d + h * 32:2 * d + (h + 1) * 32] = Pd.T @ do
+        new, old = res[1], res[0]
+        assert np.isfinite(new[0]).all() and np.isfinite(new[2]).all()
+        for got, want, what, rel in ((new[0], ref_out, "out", 2e-2), (new[1], ref_lse, "lse", 2e-3), (new[2], ref_dqkv, "dqkv", 3e-2)):
+            err = np.abs(got - want).max()
+            assert err <= rel * np.abs(want).max() + 1e-6, (S, Sq, p, what, err, np.abs(want).max())
+        # round 4's kernels of the same mode: same operands, same mask -- accumulation order (and the base of the exponential) apart
+        # (a probability on a bf16 rounding boundary may fall either side: 2^-9 of one term of a row's sum)
+        for a_, b_, what, tol in ((new[0], old[0], "out", 5e-3), (new[1], old[1], "lse", 2e-5), (new[3], old[3], "dsum", 5e-3), (new[2], old[2], "dqkv", 1.2e-2)):
+            err = np.abs(a_ - b_).max()
+            assert err <= tol * np.abs(b_).max() + 1e-7, (S, Sq, p, what, "vs round 4", err, np.abs(b_).max())
+        assert np.all(new[2][-1, S - 20:, d:] == 0)                  # masked keys receive no gradient
+    # a fully masked sequence: zeros, not NaN ("safe softmax"), and the sentinel log-sum-exp
+    S, H, d = 40, 1, 32
+    qkvb = _bf16_bits(rng.normal(size=(1, S, 3 * d)).astype(np.float32))
+    kb2 = np.full((1, S), -np.inf, np.float32)
+    out2 = np.ones((1, S, d), np.float32); lse2 = np.zeros((H, S), np.float32)
+    lib.emu_attention16(1, 1, S, S, H, d, C.c_float(scale), U16(qkvb), P(kb2), P(out2), P(lse2), None, None, None, C.c_float(0.0), C.c_uint(0))
+    assert np.all(out2 == 0) and np.all(lse2 > 1e38)

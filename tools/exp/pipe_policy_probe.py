@@ -19,7 +19,8 @@ rms = RunningMeanStd((1422,)).to(dev); rms.eval()
 b = AMPSeptBuilder(); b.load(cfg["params"]["network"])
 net = b.build("amp", actions_num=69, input_shape=(1422,), num_seqs=1, value_size=1, amp_input_shape=(3090,), self_obs_size=368,
               task_obs_size=1054, task_obs_size_detail={"traj": 30, "heightmap": 1024}, mean_std=rms).to(dev)
-for S, prio in ((1, 0), (2, 0), (2, -1), (4, 0)):
+CONFIGS = [tuple(int(x) for x in c.split(":")) for c in os.environ.get("PIPE_CONFIGS", "1:0,2:0,2:-1,4:0").split(",")]
+for S, prio in CONFIGS:
     n = E // S
     shards = [bench.make_env(n, 3000 + i) for i in range(S)]
     streams = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(S)]
