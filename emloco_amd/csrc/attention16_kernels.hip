@@ -74,6 +74,44 @@ __device__ __forceinline__ void a16_pack16(const float (&p)[16], bf16w4 (&o)[2])
         o[g] = bf16w4{gemm_pack2_bf16(p[8 * g], p[8 * g + 1]), gemm_pack2_bf16(p[8 * g + 2], p[8 * g + 3]),
                       gemm_pack2_bf16(p[8 * g + 4], p[8 * g + 5]), gemm_pack2_bf16(p[8 * g + 6], p[8 * g + 7])};
 }
+
+#ifndef A16_TREE
+#define A16_TREE 1
+#endif
+// max / sum of a lane's 16 tile entries: pairwise trees (depth 4) instead of 16-deep dependent chains
+__device__ __forceinline__ float a16_max16(const float (&p)[16]) {
+#if A16_TREE
+    float a[8];
+    #pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = fmaxf(p[2 * i], p[2 * i + 1]);
+    #pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = fmaxf(a[2 * i], a[2 * i + 1]);
+    return fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+#else
+    float m = p[0];
+    #pragma unroll
+    for (int i = 1; i < 16; ++i) m = p[i] > m ? p[i] : m;
+    return m;
+#endif
+}
+__device__ __forceinline__ float a16_sum16(const float (&p)[16]) {
+#if A16_TREE
+    float a[8];
+    #pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = p[2 * i] + p[2 * i + 1];
+    #pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = a[2 * i] + a[2 * i + 1];
+    return (a[0] + a[1]) + (a[2] + a[3]);
+#else
+    float s = 0.0f;
+    #pragma unroll
+    for (int i = 0; i < 16; ++i) s += p[i];
+    return s;
+#endif
+}
+#ifndef A16_WPE
+#define A16_WPE 2
+#endif
 // keep factors (1 / 0) of a lane's 16 entries of a tile: entry r = (tile row kappa(r, hi), own row) -- `rows_are_keys`: the tile's rows
 // are keys and the lane's own row is the query (forward, dQ), else the tile's rows are queries and the own row is a key (dK / dV).
 // One hash serves two adjacent KEYS (at_keep_bit): with keys along the registers that is registers (2 j, 2 j + 1); with queries along
@@ -86,14 +124,15 @@ __device__ __forceinline__ void a16_keep16(const AttnArgs &a, unsigned hkey, int
         #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const unsigned key = (unsigned)(t0 + at_kappa(2 * j, hi));
-            const unsigned x = at_fmix32(qk ^ ((key >> 1) * 0xC2B2AE35u));
+            const unsigned x = drop_hash(qk, key >> 1);
             keep[2 * j] = (x & 0xffffu) >= thr; keep[2 * j + 1] = (x >> 16) >= thr;
         }
     } else {
-        const unsigned kk = ((unsigned)own >> 1) * 0xC2B2AE35u;
+        const unsigned kk = drop_mul24((unsigned)own >> 1, 0xC2B2AFu);            // (drop_hash's column term: the lane's own key)
+        const unsigned q0k = hkey + (unsigned)(t0 + 4 * hi) * 0x85EBCA6Bu;        // one slow multiply per tile; the registers' queries add constants
         #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const unsigned x = at_fmix32((hkey + (unsigned)(t0 + at_kappa(r, hi)) * 0x85EBCA6Bu) ^ kk);
+            const unsigned x = drop_mix24((q0k + (unsigned)((r & 3) + 8 * (r >> 2)) * 0x85EBCA6Bu) ^ kk);
             keep[r] = ((own & 1) ? (x >> 16) : (x & 0xffffu)) >= thr;
         }
     }
@@ -101,7 +140,7 @@ __device__ __forceinline__ void a16_keep16(const AttnArgs &a, unsigned hkey, int
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int DROP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(A16_WPE, A16_WPE)))
 attn16_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char Kt[2][A16_TILE_BYTES], Vt[2][A16_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) float Bs[2][AT_T];
@@ -152,21 +191,21 @@ attn16_fwd_kernel(AttnArgs a) {
             at_vec16(Bs[buf], hi, bias);
             #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                if (g == 1 && !live[1]) break;
                 at_f32x16 st;
                 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[r] = 0.0f;
                 st = gemm_mfma_bf16_w(kf0, qf[g][0], st);       // scores^T: keys (rows) x own queries (lanes)
                 st = gemm_mfma_bf16_w(kf1, qf[g][1], st);
-                float p[16], tmax = AT_NEG;
+                float p[16];
                 #pragma unroll
-                for (int r = 0; r < 16; ++r) { p[r] = fmaf(st[r], scale2, bias[r]); tmax = p[r] > tmax ? p[r] : tmax; }
+                for (int r = 0; r < 16; ++r) p[r] = fmaf(st[r], scale2, bias[r]);
+                float tmax = fmaxf(a16_max16(p), AT_NEG);
                 { const float o = __shfl_xor(tmax, 32); tmax = o > tmax ? o : tmax; }
                 const float m_new = tmax > m[g] ? tmax : m[g];
                 const float alpha = exp2f(m[g] - m_new);          // m = AT_NEG before the first live key: 0
-                float tsum = 0.0f;
                 #pragma unroll
-                for (int r = 0; r < 16; ++r) { p[r] = exp2f(p[r] - m_new); tsum += p[r]; }     // a masked key carries -inf: 0
+                for (int r = 0; r < 16; ++r) p[r] = exp2f(p[r] - m_new);                        // a masked key carries -inf: 0
+                float tsum = a16_sum16(p);
                 tsum += __shfl_xor(tsum, 32);
                 lsum[g] = lsum[g] * alpha + tsum;
                 m[g] = m_new;
@@ -199,7 +238,7 @@ attn16_fwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ backward 1: dQ (and D)
 template <int DROP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(A16_WPE, A16_WPE)))
 attn16_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char Kt[2][A16_TILE_BYTES], Vr[2][A16_TILE_BYTES], Kc[2][A16_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) float Bs[2][AT_T];
@@ -263,7 +302,6 @@ attn16_bwd_dq_kernel(AttnArgs a) {
             at_vec16(Bs[buf], hi, bias);
             #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                if (g == 1 && !live[1]) break;
                 at_f32x16 st, dpt;
                 #pragma unroll
                 for (int r = 0; r < 16; ++r) { st[r] = 0.0f; dpt[r] = 0.0f; }
@@ -356,7 +394,6 @@ attn16_bwd_dkv_kernel(AttnArgs a) {
             at_vec16(Ds[buf], hi, drow);
             #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                if (g == 1 && !live[1]) break;
                 at_f32x16 s, dp;
                 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }

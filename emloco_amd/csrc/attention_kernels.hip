@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include "dev_math.h"
 #include "mfma_bf16.h"
+#include "drop_hash.h"
 
 namespace emloco {
 
@@ -55,7 +56,7 @@ struct AttnArgs {
     unsigned drop_seed, drop_thr;   // drop_thr = (unsigned)(p * 2^24)
 };
 
-// keep mask of the attention dropout: x = fmix32((fmix32(seed ^ bh c0) + query c1) ^ ((key >> 1) c2)), key kept iff its 16-bit half of x >= p 2^16
+// keep mask of the attention dropout: x = drop_hash(fmix32(seed ^ bh c0) + query c1, key >> 1), key kept iff its 16-bit half of x >= p 2^16
 __host__ __device__ __forceinline__ unsigned at_fmix32(unsigned x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
@@ -63,8 +64,9 @@ __host__ __device__ __forceinline__ unsigned at_fmix32(unsigned x) {
 __host__ __device__ __forceinline__ unsigned at_head_key(unsigned seed, unsigned bh) { return at_fmix32(seed ^ (bh * 0x9E3779B1u)); }
 // One hash serves the two keys 2j, 2j + 1 (its low / high 16 bits against p 2^16): a lane's 16 keys of a tile come in adjacent
 // pairs, so the unrolled loops evaluate 8 hashes per 16 probabilities.
+// (round 5: the per-probability mixer is drop_hash -- full-rate 24-bit multiplies, drop_hash.h; the head key stays murmur-mixed)
 __host__ __device__ __forceinline__ bool at_keep_bit(unsigned head_key, unsigned query, unsigned key, unsigned thr) {
-    const unsigned x = at_fmix32((head_key + query * 0x85EBCA6Bu) ^ ((key >> 1) * 0xC2B2AE35u));
+    const unsigned x = drop_hash(head_key + query * 0x85EBCA6Bu, key >> 1);
     return ((key & 1u) ? (x >> 16) : (x & 0xffffu)) >= (thr >> 8);
 }
 __device__ __forceinline__ float at_keep(const AttnArgs &a, unsigned head_key, int query, int key) {

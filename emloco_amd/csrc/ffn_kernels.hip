@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mfma_bf16.h"
+#include "drop_hash.h"
 
 namespace emloco {
 
@@ -63,14 +64,14 @@ struct FfnArgs {
 };
 
 // Keep mask of the hidden layer's dropout: one 32-bit hash per PAIR of adjacent hidden units (its low / high 16 bits against p 2^16),
-// keyed by (seed, row): x = fmix32(fmix32(seed ^ row c0) ^ (pair c2)).  Stateless, so nothing is stored: the backward reads the mask
+// keyed by (seed, row): x = drop_hash(fmix32(seed ^ row c0), pair).  Stateless, so nothing is stored: the backward reads the mask
 // off the stored hidden layer (after ReLU + dropout a positive value means "active and kept").
 __host__ __device__ __forceinline__ unsigned ffn_fmix32(unsigned x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
 __host__ __device__ __forceinline__ unsigned ffn_row_key(unsigned seed, unsigned row) { return ffn_fmix32(seed ^ (row * 0x9E3779B1u)); }
-__host__ __device__ __forceinline__ unsigned ffn_pair_hash(unsigned row_key, unsigned pair) { return ffn_fmix32(row_key ^ (pair * 0xC2B2AE35u)); }
+__host__ __device__ __forceinline__ unsigned ffn_pair_hash(unsigned row_key, unsigned pair) { return drop_hash(row_key, pair); }   // full-rate 24-bit multiplies (drop_hash.h)
 __host__ __device__ __forceinline__ bool ffn_keep16(unsigned seed, unsigned row, unsigned hidden, unsigned thr16) {
     const unsigned x = ffn_pair_hash(ffn_row_key(seed, row), hidden >> 1);
     return ((hidden & 1u) ? (x >> 16) : (x & 0xffffu)) >= thr16;

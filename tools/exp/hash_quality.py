@@ -1,0 +1,54 @@
+"""Statistical check of the dropout-mask mixers (emloco_amd/csrc/drop_hash.h): keep rate, correlations between the two halves of a hash,
+adjacent keys / queries / heads, chi-square of the 16-bit halves, variance of the kept count per row and column -- the murmur finaliser of
+rounds 3-4 (`old`) beside the full-rate candidates; `mixA` is the one shipped.   python tools/exp/hash_quality.py"""
+import numpy as np
+M32 = np.uint64(0xffffffff)
+def u(x): return x & M32
+def fmix32(x):
+    x = u(x); x ^= x >> np.uint64(16); x = u(x * np.uint64(0x85EBCA6B)); x ^= x >> np.uint64(13); x = u(x * np.uint64(0xC2B2AE35)); x ^= x >> np.uint64(16); return x
+def mul24(a, c): return u((a & np.uint64(0xffffff)) * np.uint64(c & 0xffffff))
+def mixA(x, c1=0x9E3779, c2=0x85EBCB):
+    x = u(x); x ^= x >> np.uint64(16); x = mul24(x, c1); x ^= x >> np.uint64(13); x = mul24(x, c2); x ^= x >> np.uint64(16); return x
+def mixB(x, c1=0xB5297B, c2=0x68E31D):   # fold 15, mul, fold 12, mul, fold 15
+    x = u(x); x ^= x >> np.uint64(15); x = mul24(x, c1); x ^= x >> np.uint64(12); x = mul24(x, c2); x ^= x >> np.uint64(15); return x
+def mixC(x):   # one mul24 only
+    x = u(x); x ^= x >> np.uint64(16); x = mul24(x, 0x9E3779); x ^= x >> np.uint64(15); return x
+def old(qk, kp): return fmix32(qk ^ u(kp * np.uint64(0xC2B2AE35)))
+def newh(mix):
+    return lambda qk, kp: mix(qk ^ mul24(kp, 0xC2B2AF))
+def stats(name, h):
+    seed = 12345
+    nq, nk = 453, 227   # queries, key pairs
+    res = []
+    for bh in range(16):
+        hk = fmix32(np.uint64(seed) ^ u(np.uint64(bh) * np.uint64(0x9E3779B1)))
+        q = np.arange(nq, dtype=np.uint64)[:, None]
+        kp = np.arange(nk, dtype=np.uint64)[None, :]
+        qk = u(hk + q * np.uint64(0x85EBCA6B))
+        x = h(qk, kp)
+        res.append(x)
+    x = np.stack(res)            # [bh][q][kp]
+    lo, hi = (x & np.uint64(0xffff)).astype(np.float64), (x >> np.uint64(16)).astype(np.float64)
+    thr = 6553
+    klo, khi = lo >= thr, hi >= thr
+    keep = np.stack([klo, khi], -1).reshape(16, nq, 2 * nk).astype(np.float64)
+    m = keep.mean()
+    def corr(a, b): a = a - a.mean(); b = b - b.mean(); return (a * b).mean() / np.sqrt((a * a).mean() * (b * b).mean())
+    c_pair = corr(klo.astype(float), khi.astype(float))
+    c_key = corr(keep[:, :, :-1], keep[:, :, 1:])
+    c_key2 = corr(keep[:, :, :-2], keep[:, :, 2:])
+    c_q = corr(keep[:, :-1], keep[:, 1:])
+    c_bh = corr(keep[:-1], keep[1:])
+    # uniformity of the 16-bit values: chi-square over 256 buckets
+    hist = np.bincount((lo.ravel() / 256).astype(int), minlength=256); e = lo.size / 256
+    chi_lo = ((hist - e) ** 2 / e).sum()
+    hist = np.bincount((hi.ravel() / 256).astype(int), minlength=256)
+    chi_hi = ((hist - e) ** 2 / e).sum()
+    # row sums (per query kept count) variance vs binomial
+    rs = keep.sum(-1); var_ratio = rs.var() / (2 * nk * m * (1 - m))
+    cs = keep.sum(1); var_ratio_c = cs.var() / (nq * m * (1 - m))
+    print(f"{name:8s} keep {m:.5f}  corr pair {c_pair:+.4f} adj-key {c_key:+.4f} key+2 {c_key2:+.4f} adj-query {c_q:+.4f} adj-head {c_bh:+.4f}  chi2/255 lo {chi_lo/255:.2f} hi {chi_hi/255:.2f}  row-var ratio {var_ratio:.3f} col-var ratio {var_ratio_c:.3f}")
+stats("old", old)
+stats("mixA", newh(mixA))
+stats("mixB", newh(mixB))
+stats("mixC", newh(mixC))

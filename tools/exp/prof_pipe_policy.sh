@@ -21,11 +21,12 @@ with open(sys.argv[1], 'w') as o:
     o.write(open('/tmp/prof_pp.log').read()[-300:] + "\n")
     qa = rows[big[len(big) // 2]].get('Queue_Id', '?')
     mine = [i for i in big if rows[i].get('Queue_Id', '?') == qa]
-    for label, k in [(f"at {pc} % of the run", len(mine) * pc // 100) for pc in (40, 70)]:
+    for label, k in [(f"at {pc} % of the run (the timed loop: the pre-roll without a policy is the first ~70 %)", len(mine) * pc // 100) for pc in (90, 96)]:
         a, b = mine[k], mine[k + 1]
         t0 = int(rows[a]['Start_Timestamp'])
         o.write(f"\n{label} (half on queue {qa}):\n")
         for r in rows[a:b + 1]:
+            if int(r['End_Timestamp']) < t0: continue
             o.write(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f}  q{r.get('Queue_Id', '?'):>3} {wgs(r):6d}  {re.sub(r'[(<].*', '', r['Kernel_Name'])[:60]}\n")
 print(open(sys.argv[1]).read()[-5000:])
 PY
