@@ -22,6 +22,13 @@ namespace emloco {
 #define A16_LOG2E 1.4426950408889634f
 #define A16_LN2 0.6931471805599453f
 #define A16_TILE_BYTES 2048                 // 32 x 32 bf16
+// 2^x as ONE v_exp_f32: exp2f() wraps the instruction in a range-scaling sequence (compare, select, add, v_ldexp: five instructions per
+// probability) so that results below 2^-126 come out as denormals -- here they may flush to zero, like the probabilities of masked keys
+#ifdef EMLOCO_EMU
+#define A16_EXP2(x) exp2f(x)
+#else
+#define A16_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
 struct __attribute__((aligned(8))) a16_u32x2 { unsigned x, y; };
 
 // row image: row r (64 bytes), 16-byte slot s (8 consecutive columns) at s ^ ((r >> 2) & 3): the 16 rows of a ds_read_b128 lane group
@@ -109,8 +116,19 @@ __device__ __forceinline__ float a16_sum16(const float (&p)[16]) {
     return s;
 #endif
 }
-#ifndef A16_WPE
-#define A16_WPE 2
+// a value of this lane and of its partner in the other 32-lane half (which of the two is which differs between the halves: use them
+// symmetrically), by v_permlane32_swap -- a vector instruction -- instead of a round trip through the LDS crossbar (__shfl_xor)
+__device__ __forceinline__ void a16_halves(float x, float &u, float &v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    u = __uint_as_float(r[0]); v = __uint_as_float(r[1]);
+}
+// resident waves per SIMD the register allocation aims at (measured on MI355X, tools/exp/attn_probe.py, one launch at the train step's
+// size: forward 0.866 ms at 2, 0.824 at 3; dQ + dK/dV 2.447 at 2 / 2, 2.631 with dQ at 3 -- it spills there)
+#ifndef A16_WPE_FWD
+#define A16_WPE_FWD 3
+#endif
+#ifndef A16_WPE_DQ
+#define A16_WPE_DQ 2
 #endif
 // keep factors (1 / 0) of a lane's 16 entries of a tile: entry r = (tile row kappa(r, hi), own row) -- `rows_are_keys`: the tile's rows
 // are keys and the lane's own row is the query (forward, dQ), else the tile's rows are queries and the own row is a key (dK / dV).
@@ -140,7 +158,7 @@ __device__ __forceinline__ void a16_keep16(const AttnArgs &a, unsigned hkey, int
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int DROP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(A16_WPE, A16_WPE)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(A16_WPE_FWD, A16_WPE_FWD)))
 attn16_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char Kt[2][A16_TILE_BYTES], Vt[2][A16_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) float Bs[2][AT_T];
@@ -200,13 +218,13 @@ attn16_fwd_kernel(AttnArgs a) {
                 #pragma unroll
                 for (int r = 0; r < 16; ++r) p[r] = fmaf(st[r], scale2, bias[r]);
                 float tmax = fmaxf(a16_max16(p), AT_NEG);
-                { const float o = __shfl_xor(tmax, 32); tmax = o > tmax ? o : tmax; }
+                { float u, v; a16_halves(tmax, u, v); tmax = fmaxf(u, v); }
                 const float m_new = tmax > m[g] ? tmax : m[g];
-                const float alpha = exp2f(m[g] - m_new);          // m = AT_NEG before the first live key: 0
+                const float alpha = A16_EXP2(m[g] - m_new);          // m = AT_NEG before the first live key: 0
                 #pragma unroll
-                for (int r = 0; r < 16; ++r) p[r] = exp2f(p[r] - m_new);                        // a masked key carries -inf: 0
+                for (int r = 0; r < 16; ++r) p[r] = A16_EXP2(p[r] - m_new);                        // a masked key carries -inf: 0
                 float tsum = a16_sum16(p);
-                tsum += __shfl_xor(tsum, 32);
+                { float u, v; a16_halves(tsum, u, v); tsum = u + v; }
                 lsum[g] = lsum[g] * alpha + tsum;
                 m[g] = m_new;
                 #pragma unroll
@@ -238,7 +256,7 @@ attn16_fwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ backward 1: dQ (and D)
 template <int DROP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(A16_WPE, A16_WPE)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(A16_WPE_DQ, A16_WPE_DQ)))
 attn16_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char Kt[2][A16_TILE_BYTES], Vr[2][A16_TILE_BYTES], Kc[2][A16_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) float Bs[2][AT_T];
@@ -314,7 +332,7 @@ attn16_bwd_dq_kernel(AttnArgs a) {
                 if (DROP) a16_keep16<true>(a, hkey, query[g], k0, hi, keep);
                 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = exp2f(fmaf(st[r], scale2, bias[r]) - lse2[g]);       // masked key: -inf -> 0; row past the end: lse = 3e38 -> 0
+                    const float p = A16_EXP2(fmaf(st[r], scale2, bias[r]) - lse2[g]);       // masked key: -inf -> 0; row past the end: lse = 3e38 -> 0
                     float dpr = dpt[r] * dscale;                                      // d loss / d (dropped probability)
                     if (DROP) dpr = keep[r] ? dpr : 0.0f;
                     ds[r] = a.scale * p * (dpr - dsum[g]);
@@ -406,7 +424,7 @@ attn16_bwd_dkv_kernel(AttnArgs a) {
                 if (DROP) a16_keep16<false>(a, hkey, key[g], q0, hi, keep);
                 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pr = exp2f(fmaf(s[r], scale2, bias2[g]) - lrow[r]);     // rows past the sequence carry lse = 3e38 -> 0
+                    const float pr = A16_EXP2(fmaf(s[r], scale2, bias2[g]) - lrow[r]);     // rows past the sequence carry lse = 3e38 -> 0
                     float dpr = dp[r] * dscale;
                     if (DROP) dpr = keep[r] ? dpr : 0.0f;
                     ds[r] = a.scale * pr * (dpr - drow[r]);

@@ -19,9 +19,9 @@ with open(sys.argv[1], 'w') as o:
             "PIPE_CONFIGS=2:0), rocprofv3 --kernel-trace: the kernels between two rigid-body launches of ONE half, in START order;\n"
             "columns: start us (from that half's rigid-body launch), duration us, queue, workgroups, kernel.  Queues of the rigid-body launches: " + ", ".join(qs) + "\n")
     o.write(open('/tmp/prof_pp.log').read()[-300:] + "\n")
-    qa = rows[big[len(big) // 2]].get('Queue_Id', '?')
+    qa = rows[big[-3]].get('Queue_Id', '?')            # a stream of the timed loop (the pre-roll ran on the default stream's queue)
     mine = [i for i in big if rows[i].get('Queue_Id', '?') == qa]
-    for label, k in [(f"at {pc} % of the run (the timed loop: the pre-roll without a policy is the first ~70 %)", len(mine) * pc // 100) for pc in (90, 96)]:
+    for label, k in [(f"at {pc} % of the run (the timed loop: the pre-roll without a policy is the first ~70 %)", len(mine) * pc // 100) for pc in (80, 92)]:
         a, b = mine[k], mine[k + 1]
         t0 = int(rows[a]['Start_Timestamp'])
         o.write(f"\n{label} (half on queue {qa}):\n")
