@@ -28,5 +28,19 @@ __host__ __device__ __forceinline__ unsigned drop_mix24(unsigned x) {
 }
 // hash of (row key, column index < 2^24): its low / high 16 bits are two independent uniform samples
 __host__ __device__ __forceinline__ unsigned drop_hash(unsigned row_key, unsigned column) { return drop_mix24(row_key ^ drop_mul24(column, 0xC2B2AFu)); }
+// Keep decision of element `idx` (flat index into the output of a launch with seed `seed`) at drop probability p -- the mask of the
+// GEMM epilogues' inverted dropout, of emloco_act_bwd* (which recompute it) and of emloco_dropout_keep_mask (the host's copy).  Rounds
+// 2-4 ran murmur3's 64-bit finaliser per element: three 64-bit multiplies = a dozen quarter-rate 32-bit ones, ~150 cycles per element,
+// which made the mask 40 % of the time of the feed-forward's first GEMM (64 output elements per lane and tile, K = 128).  Now: one
+// drop_hash per PAIR of adjacent elements (the pair index split 24 | rest: both 24-bit multiplies are full rate), 16 bits each
+// against p 2^16 -- the resolution of p is 1.5e-5, as in the attention mask.
+__host__ __device__ __forceinline__ bool drop_keep(unsigned seed, unsigned long long idx, float p) {
+    const unsigned long long pair = idx >> 1;
+    unsigned lo = (unsigned)pair & 0xffffffu;
+    lo ^= (lo >> 9) ^ (lo << 11);                // (rows of a matrix are a power of two apart in the index: bring the bits that differ into the multiply's low end
+                                                 //  -- without it the kept count per COLUMN of a 4096 x 1024 output had 1.15x the binomial variance)
+    const unsigned x = drop_hash(seed + drop_mul24((unsigned)(pair >> 24), 0x7FEB35u), lo);
+    return ((idx & 1ull) ? (x >> 16) : (x & 0xffffu)) >= (unsigned)(p * 65536.0f);
+}
 }  // namespace emloco
 #endif

@@ -76,13 +76,9 @@ __host__ __device__ __forceinline__ bool ffn_keep16(unsigned seed, unsigned row,
     const unsigned x = ffn_pair_hash(ffn_row_key(seed, row), hidden >> 1);
     return ((hidden & 1u) ? (x >> 16) : (x & 0xffffu)) >= thr16;
 }
-// the GEMM epilogue's 64-bit counter hash (predictor_kernels.hip: drop_keep) restated for the output dropout, so that the existing
-// backward pass over the output gradient (emloco_act_bwd_colsum) recomputes the same mask
-__host__ __device__ __forceinline__ bool ffn_out_keep(unsigned seed, unsigned long long idx, float p) {
-    unsigned long long z = idx * 0x9E3779B97F4A7C15ull + ((unsigned long long)seed << 32 | 0x632BE5ABu);
-    z ^= z >> 33; z *= 0xFF51AFD7ED558CCDull; z ^= z >> 33; z *= 0xC4CEB9FE1A85EC53ull; z ^= z >> 33;
-    return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f) >= p;
-}
+// the output dropout is the GEMM epilogue's mask (drop_hash.h: drop_keep over the flat element index row * 128 + col), so that the
+// existing backward pass over the output gradient (emloco_act_bwd_colsum) recomputes it
+__host__ __device__ __forceinline__ bool ffn_out_keep(unsigned seed, unsigned long long idx, float p) { return drop_keep(seed, idx, p); }
 
 __device__ __forceinline__ float ffn_bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float ffn_bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }

@@ -92,6 +92,9 @@ int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha, const float 
     g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (stride_b % 4 == 0);
     g.a16 = (flags & EMLOCO_GEMM_A_BF16MEM) ? 1 : 0; g.b16 = (flags & EMLOCO_GEMM_B_BF16MEM) ? 1 : 0;
     g.c16 = (flags & EMLOCO_GEMM_C_BF16MEM) ? 1 : 0; g.m16 = 0;
+    // 16-byte stores of whole output lines (the LDS-transposed epilogue): EMLOCO_GEMM_WIDE_STORES=0 keeps the per-register stores (A/B knob)
+    static const bool wide = !(getenv("EMLOCO_GEMM_WIDE_STORES") && getenv("EMLOCO_GEMM_WIDE_STORES")[0] == '0');
+    g.vec_c = (wide && (uintptr_t)C % 16 == 0 && ldc % (g.c16 ? 8 : 4) == 0 && stride_c % (g.c16 ? 8 : 4) == 0) ? 1 : 0;
     if (g.a16 || g.b16 || g.c16) {
         if (!(flags & EMLOCO_GEMM_BF16) || !g.vec_a || !g.vec_b || n <= 32)
             return pfail(-1, "emloco_gemm_f32: bf16 memory operands need EMLOCO_GEMM_BF16, 16-byte-aligned operands and n > 32");
@@ -244,6 +247,10 @@ int emloco_gemm_relu_bwd(int m, int n, int k, const float *A, int lda, const flo
     if ((g.c16 || g.m16) && (!(flags & EMLOCO_GEMM_BF16) || g.c16 != g.m16))
         return pfail(-1, "emloco_gemm_relu_bwd: a bf16 hidden layer needs EMLOCO_GEMM_BF16 and comes with a bf16 gradient (C and MASK flags together)");
     if (!g.vec_a || !g.vec_b) return pfail(-1, "emloco_gemm_relu_bwd: A and B must be 16-byte aligned with leading dimensions that are multiples of 4");
+    {   // wide accesses of the fp32 epilogue (mask in, gradient out as whole lines); EMLOCO_GEMM_WIDE_STORES=0: per-register accesses
+        static const bool wide = !(getenv("EMLOCO_GEMM_WIDE_STORES") && getenv("EMLOCO_GEMM_WIDE_STORES")[0] == '0');
+        g.vec_c = (wide && !g.c16 && (uintptr_t)C % 16 == 0 && (uintptr_t)y % 16 == 0 && n % 4 == 0) ? 1 : 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)((n + 127) / 128), (unsigned)((m + 127) / 128), 1);
     const bool deep = k > 256 && (long)grid.x * grid.y <= 1024;

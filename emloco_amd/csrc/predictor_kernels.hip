@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include "../../include/emloco_predictor.h"
 #include "mfma_bf16.h"
+#include "drop_hash.h"
 #include "dev_math.h"
 #include "locoval_returns_device.h"
 
@@ -43,6 +44,8 @@ struct GemmArgs {
     // q|k|v projection and the feed-forward hidden layer -- live in HBM as bf16 there; accumulation stays fp32.
     int a16, b16, c16, m16;
     int small;          // split mode on the 64 x 64 tile (gemm_split_small_kernel): the launcher sets it and sizes the grid for it
+    int vec_c;          // the output may be written with 16-byte stores (base, leading dimension and batch stride 16 B aligned): the
+                        // epilogue then passes each 32 x 32 accumulator tile through LDS and stores whole lines (round 5)
 };
 
 // the 64 x 64 split tile serves a launch whose 128 x 128 grid (split-K included) would be at most this many workgroups.  Measured on
@@ -71,15 +74,14 @@ __device__ __forceinline__ void st_act(float *p, long i, float v, int is16) {
     if (is16) ((unsigned short *)p)[i] = f32_to_bf16(v); else p[i] = v;
 }
 
-// Counter-based dropout mask: keep element `idx` of a launch with seed `seed` iff hash(seed, idx) >= p.  A stateless
-// integer hash (murmur3 finaliser over a Weyl-mixed counter), so the backward recomputes the mask instead of storing it.
-__host__ __device__ __forceinline__ bool drop_keep(unsigned seed, unsigned long long idx, float p) {
-    unsigned long long z = idx * 0x9E3779B97F4A7C15ull + ((unsigned long long)seed << 32 | 0x632BE5ABu);
-    z ^= z >> 33; z *= 0xFF51AFD7ED558CCDull; z ^= z >> 33; z *= 0xC4CEB9FE1A85EC53ull; z ^= z >> 33;
-    return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f) >= p;
-}
-
+// Counter-based dropout mask of the GEMM epilogues: keep element `idx` of a launch with seed `seed` iff drop_keep(seed, idx, p)
+// (drop_hash.h: a stateless hash of the element's flat index, so the backward recomputes the mask instead of storing it).
 struct __attribute__((aligned(16))) f32x4 { float x, y, z, w; };
+#ifdef EMLOCO_EMU
+__device__ __forceinline__ void gemm_wave_sync() { emu::wave_barrier(); }           // lock-step fibers: the wave's lanes meet between a scratch write and its read
+#else
+__device__ __forceinline__ void gemm_wave_sync() { __builtin_amdgcn_wave_barrier(); }  // DS instructions of one wave complete in issue order: a scheduling fence only
+#endif
 
 // One operand stage: a ROWS x GBK slab of X (rows = output rows for A, output columns for B) fetched with 16-byte
 // global loads into registers (`gemm_fetch`), later stored to LDS as [row][k] (`gemm_stash`).  Splitting fetch
@@ -422,6 +424,57 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
                     if (rl < mrem && cl < nrem) wt[rl * g.n + cl] = g.alpha * acc[i][j][r];
                 }
         }
+    } else if (EPI == 0 && g.vec_c && 2 * SA >= 4 * 1024 && mrem >= BM && nrem >= BN) {
+        // Wide stores (round 5).  A lane of the accumulator layout owns ONE column and 16 scattered rows of a 32 x 32 tile: written
+        // straight from the registers a tile costs 16 four-byte store instructions per lane (two 128-byte row segments each) -- 64 per
+        // lane for the workgroup's 128 x 128 tile, and with K = 128 (eight stages) that store tail was most of a tile's life: the
+        // feed-forward's first layer (927 744 x 1024 x 128) ran at 82 TFLOP/s, 1.3 TB/s of output (profiles/r05_jta_launches_*).  Here
+        // the epilogue's arithmetic stays on the accumulator registers (bias per lane = per column), the tile then crosses 4 KB of the
+        // wave's own LDS (the operand stages are dead) and leaves as four 16-byte stores per lane (two for a bf16 output), whole lines.
+        __syncthreads();                                     // (every wave is past its last fragment read of the stages)
+        const int c16 = g.c16;
+        float *scr = &As[0][0] + wave * 1024;
+        for (int j = 0; j < TJ; ++j) {
+            const int cl = (wn * TJ + j) * 32 + (lane & 31);
+            const float bj = has_bias ? g.bias[n0 + cl] : 0.0f;
+            for (int i = 0; i < TI; ++i) {
+                const int r0 = (wm * TI + i) * 32;
+                for (int r = 0; r < 16; ++r) {
+                    const int rt = 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                    float v = g.alpha * acc[i][j][r] + bj;
+                    if (relu) v = v > 0.0f ? v : 0.0f;
+                    if (drop) v = drop_keep(g.drop_seed, ((unsigned long long)b * g.m + m0 + r0 + rt) * g.n + n0 + cl, g.drop_p) ? v * keep_scale : 0.0f;
+                    scr[rt * 32 + (lane & 31)] = v;
+                }
+                gemm_wave_sync();
+                const int c0 = (wn * TJ + j) * 32;
+                if (c16) {                                       // 32 bf16 = 64 bytes per row: 4 lanes x 16 bytes, 16 rows per instruction
+                    unsigned short *cb = (unsigned short *)g.C + (long)b * g.sc + (long)(m0 + r0) * g.ldc + n0 + c0;
+                    for (int p = 0; p < 2; ++p) {
+                        const int rt = 16 * p + (lane >> 2), q = lane & 3;
+                        const f32x4 t0 = *(const f32x4 *)(scr + rt * 32 + 8 * q), t1 = *(const f32x4 *)(scr + rt * 32 + 8 * q + 4);
+                        unsigned short *dst = cb + (long)rt * g.ldc + 8 * q;
+                        float e[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                        if (accum) { const uint4 o = *(const uint4 *)dst; e[0] += bf16_lo(o.x); e[1] += bf16_hi(o.x); e[2] += bf16_lo(o.y); e[3] += bf16_hi(o.y);
+                                     e[4] += bf16_lo(o.z); e[5] += bf16_hi(o.z); e[6] += bf16_lo(o.w); e[7] += bf16_hi(o.w); }
+                        uint4 w;
+                        w.x = (unsigned)f32_to_bf16(e[0]) | ((unsigned)f32_to_bf16(e[1]) << 16); w.y = (unsigned)f32_to_bf16(e[2]) | ((unsigned)f32_to_bf16(e[3]) << 16);
+                        w.z = (unsigned)f32_to_bf16(e[4]) | ((unsigned)f32_to_bf16(e[5]) << 16); w.w = (unsigned)f32_to_bf16(e[6]) | ((unsigned)f32_to_bf16(e[7]) << 16);
+                        *(uint4 *)dst = w;
+                    }
+                } else {                                         // 32 floats = 128 bytes per row: 8 lanes x 16 bytes, 8 rows per instruction
+                    float *cf = g.C + (long)b * g.sc + (long)(m0 + r0) * g.ldc + n0 + c0;
+                    for (int p = 0; p < 4; ++p) {
+                        const int rt = 8 * p + (lane >> 3), q = lane & 7;
+                        f32x4 t = *(const f32x4 *)(scr + rt * 32 + 4 * q);
+                        float *dst = cf + (long)rt * g.ldc + 4 * q;
+                        if (accum) { const f32x4 o = *(const f32x4 *)dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+                        *(f32x4 *)dst = t;
+                    }
+                }
+                gemm_wave_sync();
+            }
+        }
     } else if constexpr (EPI == 0) {
         const int c16 = g.c16;
         float *ct = c16 ? (float *)((unsigned short *)g.C + (long)b * g.sc + (long)m0 * g.ldc + n0) : g.C + (long)b * g.sc + (long)m0 * g.ldc + n0;
@@ -441,6 +494,39 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
                         st_act(ct, ci, v, c16);
                     }
                 }
+        }
+    } else if (EPIO == 0 && g.vec_c && 2 * SA >= 8 * 1024 && mrem >= BM && nrem >= BN) {
+        // the fused backward epilogue with wide accesses (round 5, fp32 mask and output): the forward output's 32 x 32 tile comes in as
+        // whole lines (four 16-byte loads per lane), crosses the wave's LDS into the accumulator layout (where the column sums are a
+        // lane's own registers), and the masked gradient leaves like the plain epilogue's tile, as whole lines
+        __syncthreads();
+        float *scr = &As[0][0] + wave * 2048, *msk = scr + 1024;
+        for (int j = 0; j < TJ; ++j) {
+            const int c0 = (wn * TJ + j) * 32;
+            float csum = 0.0f;
+            for (int i = 0; i < TI; ++i) {
+                const int r0 = (wm * TI + i) * 32;
+                const long tile = (long)b * g.sc + (long)(m0 + r0) * g.ldc + n0 + c0;
+                for (int p = 0; p < 4; ++p) {
+                    const int rt = 8 * p + (lane >> 3), q = lane & 7;
+                    *(f32x4 *)(msk + rt * 32 + 4 * q) = *(const f32x4 *)(g.mask + tile + (long)rt * g.ldc + 4 * q);
+                }
+                gemm_wave_sync();
+                for (int r = 0; r < 16; ++r) {
+                    const int rt = 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                    const float v = msk[rt * 32 + (lane & 31)] > 0.0f ? g.alpha * acc[i][j][r] * g.mask_scale : 0.0f;
+                    scr[rt * 32 + (lane & 31)] = v;
+                    csum += v;
+                }
+                gemm_wave_sync();
+                for (int p = 0; p < 4; ++p) {
+                    const int rt = 8 * p + (lane >> 3), q = lane & 7;
+                    *(f32x4 *)(g.C + tile + (long)rt * g.ldc + 4 * q) = *(const f32x4 *)(scr + rt * 32 + 4 * q);
+                }
+                gemm_wave_sync();
+            }
+            csum += __shfl_xor(csum, 32);                    // the other 32 rows of the wave's 64
+            if (lane < 32) g.colpart[((long)by * WM + wm) * g.n + n0 + c0 + lane] = csum;
         }
     } else {
         constexpr int c16 = EPIO, m16 = EPIO;

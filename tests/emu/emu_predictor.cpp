@@ -12,6 +12,7 @@ extern "C" int emu_gemm_f32(int batch, int m, int n, int k, float alpha, const f
     GemmArgs g{batch, m, n, k, alpha, A, lda, sa, ta, B, ldb, sb, tb, C, ldc, sc, bias, flags, ksplit, ws, 0, 0};
     g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0) && (sa % 4 == 0);     // as emloco_gemm_f32 decides it
     g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (sb % 4 == 0);
+    g.vec_c = ((uintptr_t)C % 16 == 0) && (ldc % 4 == 0) && (sc % 4 == 0);     // the wide-store epilogue, as the launcher decides it
     const bool narrow = n <= 32;
     // flags & (1 << 20): test-only request for the 64 x 64 split tile (the launcher picks it by launch size, gemm_use_small_tile)
     g.small = ((flags & (1 << 20)) && (flags & 1024) && !(flags & 16) && g.vec_a && g.vec_b && n > 32) ? 1 : 0;
@@ -49,6 +50,7 @@ extern "C" int emu_gemm_relu_bwd_ex(int m, int n, int k, const float *A, int lda
     GemmArgs g{1, m, n, k, 1.0f, A, lda, 0, 0, B, ldb, 0, tb, C, n, 0, nullptr, 32 | flags, 1, nullptr, 0, 0, 0.0f, 0u, y, scale, colpart};
     g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
     g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
+    g.vec_c = ((uintptr_t)C % 16 == 0) && ((uintptr_t)y % 16 == 0) && (n % 4 == 0) && !(flags & 256);     // wide epilogue accesses, as the launcher decides them
     const unsigned gx = (n + 127) / 128, gy = (m + 127) / 128;
     for (unsigned y0 = 0; y0 < gy; ++y0)
         for (unsigned x = 0; x < gx; ++x)

@@ -23,6 +23,7 @@
 
 struct emu_dim3 { unsigned x = 1, y = 1, z = 1; };
 struct uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
 extern emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 // One workgroup = blockDim.x fibers (ucontext) run round-robin by a scheduler: a fiber runs until its
