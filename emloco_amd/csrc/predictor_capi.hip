@@ -15,7 +15,8 @@ int pfail(int code, const char *what, hipError_t e = hipSuccess) {
 }
 constexpr int kRing = 4096;
 std::vector<hipEvent_t> g_e0, g_e1;
-std::vector<double> g_fl;
+std::vector<double> g_fl, g_by;
+double g_last_bytes = 0.0;        // algorithmic bytes of the launches the last emloco_gemm_timing_stats call summed
 int g_head = 0, g_count = 0;
 bool g_timing = false;
 }  // namespace
@@ -30,7 +31,7 @@ extern "C" {
 
 int emloco_gemm_enable_timing(int on) {
     if (on && g_e0.empty()) {
-        g_e0.resize(kRing); g_e1.resize(kRing); g_fl.resize(kRing);
+        g_e0.resize(kRing); g_e1.resize(kRing); g_fl.resize(kRing); g_by.resize(kRing);
         for (int i = 0; i < kRing; ++i) { PHIPCHK(hipEventCreate(&g_e0[i])); PHIPCHK(hipEventCreate(&g_e1[i])); }
     }
     g_timing = on != 0; g_head = 0; g_count = 0;
@@ -39,15 +40,21 @@ int emloco_gemm_enable_timing(int on) {
 
 int emloco_gemm_timing_stats(int *n_launches, float *total_ms, double *total_flops) {
     if (!n_launches || !total_ms || !total_flops) return pfail(-1, "emloco_gemm_timing_stats: null argument");
-    *n_launches = 0; *total_ms = 0.0f; *total_flops = 0.0;
+    *n_launches = 0; *total_ms = 0.0f; *total_flops = 0.0; g_last_bytes = 0.0;
     for (int k = 0; k < g_count; ++k) {
         const int slot = (g_head - 1 - k + 2 * kRing) % kRing;
         PHIPCHK(hipEventSynchronize(g_e1[slot]));
         float ms = 0.0f;
         PHIPCHK(hipEventElapsedTime(&ms, g_e0[slot], g_e1[slot]));
-        *total_ms += ms; *total_flops += g_fl[slot]; ++*n_launches;
+        *total_ms += ms; *total_flops += g_fl[slot]; g_last_bytes += g_by[slot]; ++*n_launches;
     }
     g_count = 0;
+    return 0;
+}
+
+int emloco_gemm_timing_bytes(double *total_bytes) {
+    if (!total_bytes) return pfail(-1, "emloco_gemm_timing_bytes: null argument");
+    *total_bytes = g_last_bytes;
     return 0;
 }
 
@@ -131,6 +138,8 @@ int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha, const float 
     if (g_timing) {
         PHIPCHK(hipEventRecord(g_e1[slot], st));
         g_fl[slot] = 2.0 * batch * (double)m * n * k;
+        // algorithmic bytes: each operand once, the output once (split-K partial slabs and re-reads through the caches are not algorithmic)
+        g_by[slot] = (double)batch * ((double)m * k * (g.a16 ? 2 : 4) + (double)n * k * (g.b16 ? 2 : 4) + (double)m * n * (g.c16 ? 2 : 4));
         g_head = (slot + 1) % kRing;
         if (g_count < kRing) ++g_count;
     }

@@ -78,6 +78,7 @@ def _lib():
         lib.emloco_ffn_keep_mask.argtypes = [C.c_uint32, cl, cl, ci, cf, vp]
         lib.emloco_disc_reward.argtypes = [ci, vp, cf, vp, vp]
         lib.emloco_gemm_timing_stats.argtypes = [C.POINTER(ci), C.POINTER(cf), C.POINTER(C.c_double)]
+        lib.emloco_gemm_timing_bytes.argtypes = [C.POINTER(C.c_double)]
         _bound = True
     return lib
 
@@ -575,3 +576,10 @@ def gemm_timing(enable=None):
     n, ms, fl = C.c_int(), C.c_float(), C.c_double()
     _chk(lib.emloco_gemm_timing_stats(C.byref(n), C.byref(ms), C.byref(fl)), "emloco_gemm_timing_stats")
     return n.value, ms.value, fl.value
+
+
+def gemm_timing_bytes():
+    """Algorithmic bytes (operands + output once, in their memory dtypes) of the launches the last `gemm_timing()` read summed."""
+    b = C.c_double()
+    _chk(_lib().emloco_gemm_timing_bytes(C.byref(b)), "emloco_gemm_timing_bytes")
+    return b.value

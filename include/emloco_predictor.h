@@ -308,6 +308,9 @@ int emloco_gemm_set_small_tile(int mode);
 /* HIP-event timing of the GEMM launches (same protocol as emloco_sim_timing_stats) */
 int emloco_gemm_enable_timing(int on);
 int emloco_gemm_timing_stats(int *n_launches, float *total_ms, double *total_flops);
+/* algorithmic bytes (each operand and the output once, in their memory dtypes) of the launches the LAST emloco_gemm_timing_stats call
+ * summed -- bytes / total_ms is the rate the GEMMs of that window moved their data at (the HBM view of launches whose reduction is short) */
+int emloco_gemm_timing_bytes(double *total_bytes);
 
 #ifdef __cplusplus
 }
