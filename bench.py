@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 import emloco_amd  # noqa: E402,F401  (ahead of the first GPU call: the package raises GPU_MAX_HW_QUEUES, emloco_amd/__init__.py)
 
 SIM_BYTES_PER_ENV = 9296          # state in/out + per-env model (+ collision capsules) + warm-start, per launch
-PROFILE_ROUND = "r04"             # profiles/<round>_*: the committed rocprofv3 summaries of this round's kernels
+PROFILE_ROUND = "r05"             # profiles/<round>_*: the committed rocprofv3 summaries of this round's kernels
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16), no sparsity
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
@@ -243,9 +243,16 @@ def jta_leg(dev, steps=4, warmup=2, B=256, rank=0, world=1):
     ops.gemm_timing(True)
     dt = _timed(lambda: trainer.step(joints, masks, pad), steps, 0, world, dev)
     n, ms, fl = ops.gemm_timing()
+    gemm_bytes = ops.gemm_timing_bytes()
     ops.gemm_timing(False)
     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    gbs = gemm_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     peak, peak_note = gemm_peak(ops)
+    traffic = None            # HBM-side bytes of the step's GEMM launches from the committed PMC passes (pointer, not a measurement of this run)
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_jta_gemm_hbm_bytes.json"))).get("gemm_bytes_per_step")
+    except Exception:
+        pass
     out = {"metric": "JTA samples/sec (train_jta EmLoco step)", "value": round(B * world * steps / dt, 2), "unit": "samples/s", "n_gpus": world,
            "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "warmup": warmup, "dtype": "f32",
            "config": {"workload": "configs[3]: Social-Transmotion train_jta.py with EmLoco loss (valueloss_w=1.0), batch 256, "
@@ -253,9 +260,17 @@ def jta_leg(dev, steps=4, warmup=2, B=256, rank=0, world=1):
                                   + (f", data-parallel x{world} (256 per GPU)" if world > 1 else ""),
                       "batch": B, "people_padded": int(joints.shape[1]), "tokens_per_person": 453},
            "precision": ops.get_matmul_precision(),
-           "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(tf / peak, 4), "frac_of_fp32_instruction_peak": round(tf / 157.3, 4), "traffic": None, "gemm_launches": n,
-                        "gemm_ms_per_step": round(ms / steps, 2), "note": peak_note}}
+           # The step's GEMM launches as a class (45 % of its kernel time; the fused attention, VALU / matrix bound, is the other half and
+           # is reported under `attention`).  Their reductions are short (K = 128 for five of the seven products of a layer) and their
+           # outputs large: what bounds them is data movement, not the matrix pipe (round-4 review) -- hence `bound: hbm`.
+           "roofline": {"bound": "hbm", "kernel": "gemm_split_kernel / gemm_f32_kernel (all GEMM launches of the step)",
+                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "traffic": traffic, "traffic_source": f"profiles/{PROFILE_ROUND}_jta_gemm_hbm_bytes.json (committed --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per step; NOT measured in this run)",
+                        "algorithmic_bytes_per_step": round(gemm_bytes / steps), "gemm_launches": n, "gemm_ms_per_step": round(ms / steps, 2),
+                        "mfma_view": {"achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                                      "frac_of_fp32_instruction_peak": round(tf / 157.3, 4), "note": peak_note},
+                        "note": "achieved = algorithmic bytes (every operand and the output once, in their memory dtypes) of the timed GEMM launches / "
+                                "their HIP-event time; per-kernel TB/s from the counters: profiles/" + PROFILE_ROUND + "_jta_hbm_fp32_split.txt"}}
     # The reduced-precision mode of BASELINE configs[3] ("bf16 MFMA attention"), reported beside the fp32 figure under its own
     # parity bar (2e-2 on activations against the fp32 fixtures, tests/test_gpu_predictor.py): every linear-layer GEMM and
     # the fused attention's tile products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the two large activations of a layer
@@ -267,6 +282,7 @@ def jta_leg(dev, steps=4, warmup=2, B=256, rank=0, world=1):
         ops.gemm_timing(True)
         dt = _timed(lambda: trainer.step(joints, masks, pad), steps, 0, world, dev)
         n, ms, fl = ops.gemm_timing()
+        gemm_bytes16 = ops.gemm_timing_bytes()
         ops.gemm_timing(False)
         # algorithmic flops of the step = padded person-sequences x 7.4 GFLOP (forward + backward of the 6 + 3 layers)
         seqs = B * int(joints.shape[1])
@@ -275,10 +291,14 @@ def jta_leg(dev, steps=4, warmup=2, B=256, rank=0, world=1):
                        "roofline": {"bound": "mfma", "kernel": "whole step (GEMMs + fused attention)", "achieved": round(step_tf * world, 2),
                                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(step_tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                                     "gemm_tflops": round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None, "gemm_ms_per_step": round(ms / steps, 2),
+                                    "gemm_gbs": round(gemm_bytes16 / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                                     "note": "achieved = padded person-sequences x 7.4 GFLOP (SURVEY 8d) / step time, against the dense bf16 MFMA "
-                                            "peak; the step is far from it: the attention kernels are VALU bound (softmax + dropout hash per "
-                                            "probability), LayerNorm / bias-gradient / residual passes are separate launches"},
-                       "note": "ops.set_matmul_precision('bf16'): bf16 MFMA operands in the linear layers and the fused attention, the feed-forward "
+                                            "peak; the step is far from it: at head dim 32 the attention kernels are bound by the vector work per "
+                                            "probability (a quarter-rate exponential, the dropout hash, the softmax arithmetic: ~12 vector cycles against 2 "
+                                            "matrix cycles), the GEMMs (feed-forward chained in registers, ffn_chain_kernel) by their data movement, "
+                                            "LayerNorm / bias-gradient / residual passes are separate launches"},
+                       "note": "ops.set_matmul_precision('bf16'): bf16 MFMA operands in the linear layers and the fused attention (round 5: two blocks of 32 "
+                               "rows per wave, bf16 tile images), the feed-forward block as two chained launches (hidden tile in registers), the "
                                "hidden layer and q|k|v as bf16 in HBM; parity bar 2e-2 (SURVEY 8c), NOT the 1e-4 of the fp32 path that `value` reports"}
         out["bf16_operands"] = out["bf16"]                      # the name earlier rounds reported this leg under
     finally:

@@ -58,30 +58,112 @@ __device__ __forceinline__ a16_u32x2 a16_ld_f32x4(const float *base, long elems,
     if (!ok) v = a16_u32x2{0u, 0u};
     return v;
 }
-// a lane's own row as the B operand of a product that reduces over the head dim: step ks covers d = 16 ks + 8 hi + 0..7
-__device__ __forceinline__ void a16_own_row_bf16(const unsigned short *base, long ld, int row, int rows, int hi, bf16w4 (&f)[2]) {
-    const long rc = row < rows ? row : rows - 1;
-    #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) f[ks] = *(const bf16w4 *)(base + rc * ld + 16 * ks + 8 * hi);
+// ---- operands in NP pieces.  NP = 1: bf16 operands (the reduced-precision mode).  NP = 3: the split mode -- every fp32 value is the exact
+// sum of three bf16 pieces and a product is the six piece products above 2^-24 of it (attention_kernels.hip: at_mfma_split); a tile image
+// is then three planes (one per piece), a fragment three 16-byte reads, a tile product six matrix instructions per 16 reduction entries.
+// The pieces of a WALKED tile are cut ONCE, by the thread that stages the element (round 4 cut them per consuming wave: 630 vector
+// instructions per wave and 32 x 32 tile in the forward, profiles/r05_attn_counters_fp32_split.txt).
+template <int NP> struct A16Frag { bf16w4 p[NP]; };
+__device__ __forceinline__ void a16_split_pair(float a, float b, unsigned &p1, unsigned &p2, unsigned &p3) {
+    p1 = gemm_pack2_bf16(a, b);
+    a -= __uint_as_float(p1 << 16); b -= __uint_as_float(p1 & 0xffff0000u);
+    p2 = gemm_pack2_bf16(a, b);
+    a -= __uint_as_float(p2 << 16); b -= __uint_as_float(p2 & 0xffff0000u);
+    p3 = gemm_pack2_bf16(a, b);
 }
-__device__ __forceinline__ void a16_own_row_f32(const float *base, long ld, int row, int rows, int hi, bf16w4 (&f)[2], float (&raw)[16]) {
+// four consecutive values -> NP packed pairs of words
+template <int NP>
+__device__ __forceinline__ void a16_cut4(float v0, float v1, float v2, float v3, a16_u32x2 (&o)[NP]) {
+    if constexpr (NP == 1) {
+        o[0] = a16_u32x2{gemm_pack2_bf16(v0, v1), gemm_pack2_bf16(v2, v3)};
+    } else {
+        unsigned a[3], b[3];
+        a16_split_pair(v0, v1, a[0], a[1], a[2]);
+        a16_split_pair(v2, v3, b[0], b[1], b[2]);
+        #pragma unroll
+        for (int q = 0; q < 3; ++q) o[q] = a16_u32x2{a[q], b[q]};
+    }
+}
+// eight consecutive values (the reduction entries a lane feeds one matrix instruction) -> a fragment
+template <int NP>
+__device__ __forceinline__ A16Frag<NP> a16_cut8(const float (&v)[8]) {
+    a16_u32x2 lo[NP], hi[NP];
+    a16_cut4<NP>(v[0], v[1], v[2], v[3], lo);
+    a16_cut4<NP>(v[4], v[5], v[6], v[7], hi);
+    A16Frag<NP> f;
+    #pragma unroll
+    for (int q = 0; q < NP; ++q) f.p[q] = bf16w4{lo[q].x, lo[q].y, hi[q].x, hi[q].y};
+    return f;
+}
+template <int NP>
+__device__ __forceinline__ at_f32x16 a16_mma(const A16Frag<NP> &x, const A16Frag<NP> &y, at_f32x16 acc) {
+    if constexpr (NP == 1) {
+        return gemm_mfma_bf16_w(x.p[0], y.p[0], acc);
+    } else {                                                  // the six products, smallest first
+        acc = gemm_mfma_bf16_w(x.p[2], y.p[0], acc); acc = gemm_mfma_bf16_w(x.p[0], y.p[2], acc); acc = gemm_mfma_bf16_w(x.p[1], y.p[1], acc);
+        acc = gemm_mfma_bf16_w(x.p[1], y.p[0], acc); acc = gemm_mfma_bf16_w(x.p[0], y.p[1], acc); acc = gemm_mfma_bf16_w(x.p[0], y.p[0], acc);
+        return acc;
+    }
+}
+template <int NP>
+__device__ __forceinline__ A16Frag<NP> a16_frag_n(const char *tile, int row, int slot) {
+    A16Frag<NP> f;
+    #pragma unroll
+    for (int q = 0; q < NP; ++q) f.p[q] = a16_frag(tile + q * A16_TILE_BYTES, row, slot);
+    return f;
+}
+// one thread's 4 consecutive columns of a tile row, from memory (MEM16: bf16, else fp32), cut and stored into the row and / or the
+// transposed image (NP planes each)
+template <int NP, int MEM16>
+__device__ __forceinline__ void a16_fetch4(const void *base, long elems, bool ok, a16_u32x2 (&o)[NP]) {
+    if constexpr (MEM16) {
+        static_assert(NP == 1 || !MEM16, "bf16 memory holds one piece");
+        o[0] = a16_ld_bf16x4((const unsigned short *)base, elems, ok);
+    } else {
+        at_f32x4 t = *(const at_f32x4 *)((const float *)base + elems);
+        if (!ok) t = at_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        a16_cut4<NP>(t.x, t.y, t.z, t.w, o);
+    }
+}
+template <int NP>
+__device__ __forceinline__ void a16_put_rows(char *tile, int r, int piece, const a16_u32x2 (&o)[NP]) {
+    #pragma unroll
+    for (int q = 0; q < NP; ++q) a16_stash_rows(tile + q * A16_TILE_BYTES, r, piece, o[q]);
+}
+template <int NP>
+__device__ __forceinline__ void a16_put_cols(char *tile, int r, int piece, const a16_u32x2 (&o)[NP]) {
+    #pragma unroll
+    for (int q = 0; q < NP; ++q) a16_stash_cols(tile + q * A16_TILE_BYTES, r, piece, o[q]);
+}
+// a lane's own row as the B operand of a product that reduces over the head dim: step ks covers d = 16 ks + 8 hi + 0..7
+template <int NP, int MEM16>
+__device__ __forceinline__ void a16_own_row(const void *base, long ld, int row, int rows, int hi, A16Frag<NP> (&f)[2], float *raw /* 16 values or NULL */) {
     const long rc = row < rows ? row : rows - 1;
     #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        const at_f32x4 v0 = *(const at_f32x4 *)(base + rc * ld + 16 * ks + 8 * hi), v1 = *(const at_f32x4 *)(base + rc * ld + 16 * ks + 8 * hi + 4);
-        f[ks] = bf16w4{gemm_pack2_bf16(v0.x, v0.y), gemm_pack2_bf16(v0.z, v0.w), gemm_pack2_bf16(v1.x, v1.y), gemm_pack2_bf16(v1.z, v1.w)};
-        raw[8 * ks] = v0.x; raw[8 * ks + 1] = v0.y; raw[8 * ks + 2] = v0.z; raw[8 * ks + 3] = v0.w;
-        raw[8 * ks + 4] = v1.x; raw[8 * ks + 5] = v1.y; raw[8 * ks + 6] = v1.z; raw[8 * ks + 7] = v1.w;
+        if constexpr (MEM16) {
+            f[ks].p[0] = *(const bf16w4 *)((const unsigned short *)base + rc * ld + 16 * ks + 8 * hi);
+        } else {
+            const float *src = (const float *)base + rc * ld + 16 * ks + 8 * hi;
+            const at_f32x4 v0 = *(const at_f32x4 *)src, v1 = *(const at_f32x4 *)(src + 4);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            f[ks] = a16_cut8<NP>(v);
+            if (raw) {
+                #pragma unroll
+                for (int e = 0; e < 8; ++e) raw[8 * ks + e] = v[e];
+            }
+        }
     }
 }
-// 16 accumulator values -> the two B operands (reduction over the tile's rows, kappa order) of the next product
-__device__ __forceinline__ void a16_pack16(const float (&p)[16], bf16w4 (&o)[2]) {
+// 16 accumulator-layout values -> the two B operands (reduction over the tile's rows, kappa order) of the next product
+template <int NP>
+__device__ __forceinline__ void a16_pack16(const float (&p)[16], A16Frag<NP> (&o)[2]) {
     #pragma unroll
-    for (int g = 0; g < 2; ++g)
-        o[g] = bf16w4{gemm_pack2_bf16(p[8 * g], p[8 * g + 1]), gemm_pack2_bf16(p[8 * g + 2], p[8 * g + 3]),
-                      gemm_pack2_bf16(p[8 * g + 4], p[8 * g + 5]), gemm_pack2_bf16(p[8 * g + 6], p[8 * g + 7])};
+    for (int g = 0; g < 2; ++g) {
+        const float v[8] = {p[8 * g], p[8 * g + 1], p[8 * g + 2], p[8 * g + 3], p[8 * g + 4], p[8 * g + 5], p[8 * g + 6], p[8 * g + 7]};
+        o[g] = a16_cut8<NP>(v);
+    }
 }
-
 #ifndef A16_TREE
 #define A16_TREE 1
 #endif
@@ -124,6 +206,11 @@ __device__ __forceinline__ void a16_halves(float x, float &u, float &v) {
 }
 // resident waves per SIMD the register allocation aims at (measured on MI355X, tools/exp/attn_probe.py, one launch at the train step's
 // size: forward 0.866 ms at 2, 0.824 at 3; dQ + dK/dV 2.447 at 2 / 2, 2.631 with dQ at 3 -- it spills there)
+#ifdef EMLOCO_EMU
+#define A16_WAVES(n)
+#else
+#define A16_WAVES(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
 #ifndef A16_WPE_FWD
 #define A16_WPE_FWD 3
 #endif
@@ -157,27 +244,30 @@ __device__ __forceinline__ void a16_keep16(const AttnArgs &a, unsigned hkey, int
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int DROP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(A16_WPE_FWD, A16_WPE_FWD)))
+// NP: pieces per operand (1 = bf16 operands, 3 = split mode); G: blocks of 32 queries per wave; MEM16: q|k|v in memory as bf16
+template <int NP, int G, int DROP, int MEM16>
+__global__ void __launch_bounds__(256) A16_WAVES(NP == 1 ? A16_WPE_FWD : 2)
 attn16_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char Kt[2][A16_TILE_BYTES], Vt[2][A16_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char Kt[2][NP * A16_TILE_BYTES], Vt[2][NP * A16_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) float Bs[2][AT_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
     const unsigned hkey = at_head_key(a.drop_seed, (unsigned)bh);
     const long ld = 3L * a.d_model;
-    const unsigned short *Q = (const unsigned short *)a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
+    const void *Q = MEM16 ? (const void *)((const unsigned short *)a.qkv + (long)b * a.S * ld + hd * AT_DH) : (const void *)(a.qkv + (long)b * a.S * ld + hd * AT_DH);
+    const void *K = MEM16 ? (const void *)((const unsigned short *)Q + a.d_model) : (const void *)((const float *)Q + a.d_model);
+    const void *V = MEM16 ? (const void *)((const unsigned short *)Q + 2 * a.d_model) : (const void *)((const float *)Q + 2 * a.d_model);
     const float *kb = a.key_bias ? a.key_bias + (long)b * a.S : nullptr;
-    const int q0 = blockIdx.x * 256 + wave * 64;
-    int query[2];
-    bf16w4 qf[2][2];
-    bool live[2];
-    at_f32x16 acc_o[2];
-    float m[2], lsum[2];
+    const int q0 = blockIdx.x * (128 * G) + wave * (32 * G);
+    int query[G];
+    A16Frag<NP> qf[G][2];
+    bool live[G];
+    at_f32x16 acc_o[G];
+    float m[G], lsum[G];
     #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < G; ++g) {
         query[g] = q0 + 32 * g + l31;
-        a16_own_row_bf16(Q, ld, query[g], a.Sq, hi, qf[g]);
+        a16_own_row<NP, MEM16>(Q, ld, query[g], a.Sq, hi, qf[g], nullptr);
         live[g] = q0 + 32 * g < a.Sq;                        // wave-uniform: a block wholly past the live queries only helps staging
         #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[g][r] = 0.0f;
@@ -187,11 +277,12 @@ attn16_fwd_kernel(AttnArgs a) {
     const int ntiles = (a.S + AT_T - 1) / AT_T;
     // staging: thread = (tile row tid >> 3, 4 columns 4 (tid & 7)) of K and of V; thread tid < 32 the key bias of tile row tid
     const int sr = tid >> 3, sp = tid & 7, t31 = tid & 31;
-    const float *kbp = kb ? kb : (const float *)a.qkv;
-    a16_u32x2 rk = a16_ld_bf16x4(K, (long)(sr < a.S ? sr : a.S - 1) * ld + 4 * sp, sr < a.S);
-    a16_u32x2 rv = a16_ld_bf16x4(V, (long)(sr < a.S ? sr : a.S - 1) * ld + 4 * sp, sr < a.S);
+    const float *kbp = kb ? kb : a.qkv;
+    a16_u32x2 rk[NP], rv[NP];
+    a16_fetch4<NP, MEM16>(K, (long)(sr < a.S ? sr : a.S - 1) * ld + 4 * sp, sr < a.S, rk);
+    a16_fetch4<NP, MEM16>(V, (long)(sr < a.S ? sr : a.S - 1) * ld + 4 * sp, sr < a.S, rv);
     float rb = kbp[t31 < a.S ? t31 : a.S - 1];
-    a16_stash_rows(Kt[0], sr, sp, rk); a16_stash_cols(Vt[0], sr, sp, rv);
+    a16_put_rows<NP>(Kt[0], sr, sp, rk); a16_put_cols<NP>(Vt[0], sr, sp, rv);
     if (tid < AT_T) Bs[0][tid] = tid < a.S ? (kb ? rb * A16_LOG2E : 0.0f) : -INFINITY;
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
@@ -199,21 +290,21 @@ attn16_fwd_kernel(AttnArgs a) {
         {
             const int kr = k0n + sr;
             const long kc = kr < a.S ? kr : a.S - 1;
-            rk = a16_ld_bf16x4(K, kc * ld + 4 * sp, kr < a.S); rv = a16_ld_bf16x4(V, kc * ld + 4 * sp, kr < a.S);
+            a16_fetch4<NP, MEM16>(K, kc * ld + 4 * sp, kr < a.S, rk); a16_fetch4<NP, MEM16>(V, kc * ld + 4 * sp, kr < a.S, rv);
             rb = kbp[k0n + t31 < a.S ? k0n + t31 : a.S - 1];
         }
-        if (live[0]) {                                        // (block 1 is never live without block 0)
-            const bf16w4 kf0 = a16_frag(Kt[buf], l31, hi), kf1 = a16_frag(Kt[buf], l31, 2 + hi);
-            const bf16w4 vf0 = a16_frag(Vt[buf], l31, hi), vf1 = a16_frag(Vt[buf], l31, 2 + hi);
+        if (live[0]) {                                        // (a later block is never live without block 0)
+            const A16Frag<NP> kf0 = a16_frag_n<NP>(Kt[buf], l31, hi), kf1 = a16_frag_n<NP>(Kt[buf], l31, 2 + hi);
+            const A16Frag<NP> vf0 = a16_frag_n<NP>(Vt[buf], l31, hi), vf1 = a16_frag_n<NP>(Vt[buf], l31, 2 + hi);
             float bias[16];
             at_vec16(Bs[buf], hi, bias);
             #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < G; ++g) {
                 at_f32x16 st;
                 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[r] = 0.0f;
-                st = gemm_mfma_bf16_w(kf0, qf[g][0], st);       // scores^T: keys (rows) x own queries (lanes)
-                st = gemm_mfma_bf16_w(kf1, qf[g][1], st);
+                st = a16_mma<NP>(kf0, qf[g][0], st);              // scores^T: keys (rows) x own queries (lanes)
+                st = a16_mma<NP>(kf1, qf[g][1], st);
                 float p[16];
                 #pragma unroll
                 for (int r = 0; r < 16; ++r) p[r] = fmaf(st[r], scale2, bias[r]);
@@ -235,18 +326,18 @@ attn16_fwd_kernel(AttnArgs a) {
                     #pragma unroll
                     for (int r = 0; r < 16; ++r) p[r] = keep[r] ? p[r] : 0.0f;
                 }
-                bf16w4 pb[2];
-                a16_pack16(p, pb);
-                acc_o[g] = gemm_mfma_bf16_w(vf0, pb[0], acc_o[g]);  // O^T += V^T P^T
-                acc_o[g] = gemm_mfma_bf16_w(vf1, pb[1], acc_o[g]);
+                A16Frag<NP> pb[2];
+                a16_pack16<NP>(p, pb);
+                acc_o[g] = a16_mma<NP>(vf0, pb[0], acc_o[g]);     // O^T += V^T P^T
+                acc_o[g] = a16_mma<NP>(vf1, pb[1], acc_o[g]);
             }
         }
-        a16_stash_rows(Kt[buf ^ 1], sr, sp, rk); a16_stash_cols(Vt[buf ^ 1], sr, sp, rv);
+        a16_put_rows<NP>(Kt[buf ^ 1], sr, sp, rk); a16_put_cols<NP>(Vt[buf ^ 1], sr, sp, rv);
         if (tid < AT_T) Bs[buf ^ 1][tid] = k0n + tid < a.S ? (kb ? rb * A16_LOG2E : 0.0f) : -INFINITY;
         __syncthreads();
     }
     #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < G; ++g)
         if (query[g] < a.Sq) {
             const float inv = lsum[g] > 0.0f ? (DROP ? a.drop_scale : 1.0f) / lsum[g] : 0.0f;       // fully masked row -> zeros ("safe softmax")
             at_store_rowT(a.out + ((long)b * a.Sq + query[g]) * a.d_model + hd * AT_DH, hi, acc_o[g], inv);
@@ -255,37 +346,39 @@ attn16_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward 1: dQ (and D)
-template <int DROP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(A16_WPE_DQ, A16_WPE_DQ)))
+template <int NP, int G, int DROP, int MEM16>
+__global__ void __launch_bounds__(256) A16_WAVES(A16_WPE_DQ)
 attn16_bwd_dq_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char Kt[2][A16_TILE_BYTES], Vr[2][A16_TILE_BYTES], Kc[2][A16_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char Kt[2][NP * A16_TILE_BYTES], Vr[2][NP * A16_TILE_BYTES], Kc[2][NP * A16_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) float Bs[2][AT_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
     const unsigned hkey = at_head_key(a.drop_seed, (unsigned)bh);
     const long ld = 3L * a.d_model;
-    const unsigned short *Q = (const unsigned short *)a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
+    const void *Q = MEM16 ? (const void *)((const unsigned short *)a.qkv + (long)b * a.S * ld + hd * AT_DH) : (const void *)(a.qkv + (long)b * a.S * ld + hd * AT_DH);
+    const void *K = MEM16 ? (const void *)((const unsigned short *)Q + a.d_model) : (const void *)((const float *)Q + a.d_model);
+    const void *V = MEM16 ? (const void *)((const unsigned short *)Q + 2 * a.d_model) : (const void *)((const float *)Q + 2 * a.d_model);
     const float *dO = a.dout + (long)b * a.Sq * a.d_model + hd * AT_DH, *O = a.out + (long)b * a.Sq * a.d_model + hd * AT_DH;
     const float *kb = a.key_bias ? a.key_bias + (long)b * a.S : nullptr;
-    const int q0 = blockIdx.x * 256 + wave * 64;
-    int query[2];
-    bf16w4 qf[2][2], dof[2][2];
-    bool live[2];
-    at_f32x16 acc[2];
-    float lse2[2], dsum[2];
+    const int q0 = blockIdx.x * (128 * G) + wave * (32 * G);
+    int query[G];
+    A16Frag<NP> qf[G][2], dof[G][2];
+    bool live[G];
+    at_f32x16 acc[G];
+    float lse2[G], dsum[G];
     #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < G; ++g) {
         query[g] = q0 + 32 * g + l31;
         live[g] = q0 + 32 * g < a.Sq;
-        a16_own_row_bf16(Q, ld, query[g], a.Sq, hi, qf[g]);
+        a16_own_row<NP, MEM16>(Q, ld, query[g], a.Sq, hi, qf[g], nullptr);
         float dor[16], orow[16];
-        bf16w4 unused[2];
-        a16_own_row_f32(dO, a.d_model, query[g], a.Sq, hi, dof[g], dor);
-        a16_own_row_f32(O, a.d_model, query[g], a.Sq, hi, unused, orow);
+        A16Frag<1> unused[2];
+        a16_own_row<NP, 0>(dO, a.d_model, query[g], a.Sq, hi, dof[g], dor);
+        a16_own_row<1, 0>(O, a.d_model, query[g], a.Sq, hi, unused, orow);
         float ds = 0.0f;                                      // D = sum_d dO O (the lane pair holds the two halves of d)
         #pragma unroll
         for (int e = 0; e < 16; ++e) ds = fmaf(dor[e], orow[e], ds);
-        ds += __shfl_xor(ds, 32);
+        { float u, v; a16_halves(ds, u, v); ds = u + v; }
         dsum[g] = ds;
         const bool qok = query[g] < a.Sq;
         lse2[g] = qok ? a.lse[(long)bh * a.Sq + query[g]] * A16_LOG2E : 3.0e38f;
@@ -297,11 +390,12 @@ attn16_bwd_dq_kernel(AttnArgs a) {
     const float dscale = DROP ? a.drop_scale : 1.0f;
     const int ntiles = (a.S + AT_T - 1) / AT_T;
     const int sr = tid >> 3, sp = tid & 7, t31 = tid & 31;
-    const float *kbp = kb ? kb : (const float *)a.qkv;
-    a16_u32x2 rk = a16_ld_bf16x4(K, (long)(sr < a.S ? sr : a.S - 1) * ld + 4 * sp, sr < a.S);
-    a16_u32x2 rv = a16_ld_bf16x4(V, (long)(sr < a.S ? sr : a.S - 1) * ld + 4 * sp, sr < a.S);
+    const float *kbp = kb ? kb : a.qkv;
+    a16_u32x2 rk[NP], rv[NP];
+    a16_fetch4<NP, MEM16>(K, (long)(sr < a.S ? sr : a.S - 1) * ld + 4 * sp, sr < a.S, rk);
+    a16_fetch4<NP, MEM16>(V, (long)(sr < a.S ? sr : a.S - 1) * ld + 4 * sp, sr < a.S, rv);
     float rb = kbp[t31 < a.S ? t31 : a.S - 1];
-    a16_stash_rows(Kt[0], sr, sp, rk); a16_stash_cols(Kc[0], sr, sp, rk); a16_stash_rows(Vr[0], sr, sp, rv);
+    a16_put_rows<NP>(Kt[0], sr, sp, rk); a16_put_cols<NP>(Kc[0], sr, sp, rk); a16_put_rows<NP>(Vr[0], sr, sp, rv);
     if (tid < AT_T) Bs[0][tid] = tid < a.S ? (kb ? rb * A16_LOG2E : 0.0f) : -INFINITY;
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
@@ -309,24 +403,21 @@ attn16_bwd_dq_kernel(AttnArgs a) {
         {
             const int kr = k0n + sr;
             const long kc = kr < a.S ? kr : a.S - 1;
-            rk = a16_ld_bf16x4(K, kc * ld + 4 * sp, kr < a.S); rv = a16_ld_bf16x4(V, kc * ld + 4 * sp, kr < a.S);
+            a16_fetch4<NP, MEM16>(K, kc * ld + 4 * sp, kr < a.S, rk); a16_fetch4<NP, MEM16>(V, kc * ld + 4 * sp, kr < a.S, rv);
             rb = kbp[k0n + t31 < a.S ? k0n + t31 : a.S - 1];
         }
         if (live[0]) {
-            const bf16w4 kf0 = a16_frag(Kt[buf], l31, hi), kf1 = a16_frag(Kt[buf], l31, 2 + hi);
-            const bf16w4 vf0 = a16_frag(Vr[buf], l31, hi), vf1 = a16_frag(Vr[buf], l31, 2 + hi);
-            const bf16w4 kc0 = a16_frag(Kc[buf], l31, hi), kc1 = a16_frag(Kc[buf], l31, 2 + hi);
             float bias[16];
             at_vec16(Bs[buf], hi, bias);
             #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < G; ++g) {
                 at_f32x16 st, dpt;
                 #pragma unroll
                 for (int r = 0; r < 16; ++r) { st[r] = 0.0f; dpt[r] = 0.0f; }
-                st = gemm_mfma_bf16_w(kf0, qf[g][0], st);       // S^T
-                st = gemm_mfma_bf16_w(kf1, qf[g][1], st);
-                dpt = gemm_mfma_bf16_w(vf0, dof[g][0], dpt);    // dP^T = V dO^T
-                dpt = gemm_mfma_bf16_w(vf1, dof[g][1], dpt);
+                st = a16_mma<NP>(a16_frag_n<NP>(Kt[buf], l31, hi), qf[g][0], st);       // S^T
+                st = a16_mma<NP>(a16_frag_n<NP>(Kt[buf], l31, 2 + hi), qf[g][1], st);
+                dpt = a16_mma<NP>(a16_frag_n<NP>(Vr[buf], l31, hi), dof[g][0], dpt);    // dP^T = V dO^T
+                dpt = a16_mma<NP>(a16_frag_n<NP>(Vr[buf], l31, 2 + hi), dof[g][1], dpt);
                 float ds[16];
                 bool keep[16];
                 if (DROP) a16_keep16<true>(a, hkey, query[g], k0, hi, keep);
@@ -337,47 +428,51 @@ attn16_bwd_dq_kernel(AttnArgs a) {
                     if (DROP) dpr = keep[r] ? dpr : 0.0f;
                     ds[r] = a.scale * p * (dpr - dsum[g]);
                 }
-                bf16w4 db[2];
-                a16_pack16(ds, db);
-                acc[g] = gemm_mfma_bf16_w(kc0, db[0], acc[g]);  // dQ^T += K^T dS^T
-                acc[g] = gemm_mfma_bf16_w(kc1, db[1], acc[g]);
+                A16Frag<NP> db[2];
+                a16_pack16<NP>(ds, db);
+                acc[g] = a16_mma<NP>(a16_frag_n<NP>(Kc[buf], l31, hi), db[0], acc[g]);  // dQ^T += K^T dS^T
+                acc[g] = a16_mma<NP>(a16_frag_n<NP>(Kc[buf], l31, 2 + hi), db[1], acc[g]);
             }
         }
-        a16_stash_rows(Kt[buf ^ 1], sr, sp, rk); a16_stash_cols(Kc[buf ^ 1], sr, sp, rk); a16_stash_rows(Vr[buf ^ 1], sr, sp, rv);
+        a16_put_rows<NP>(Kt[buf ^ 1], sr, sp, rk); a16_put_cols<NP>(Kc[buf ^ 1], sr, sp, rk); a16_put_rows<NP>(Vr[buf ^ 1], sr, sp, rv);
         if (tid < AT_T) Bs[buf ^ 1][tid] = k0n + tid < a.S ? (kb ? rb * A16_LOG2E : 0.0f) : -INFINITY;
         __syncthreads();
     }
     #pragma unroll
-    for (int g = 0; g < 2; ++g)
-        if (query[g] < a.Sq)
-            at_store_rowT<1>((float *)((unsigned short *)a.dqkv + ((long)b * a.S + query[g]) * ld + hd * AT_DH), hi, acc[g], 1.0f);
+    for (int g = 0; g < G; ++g)
+        if (query[g] < a.Sq) {
+            if (MEM16) at_store_rowT<1>((float *)((unsigned short *)a.dqkv + ((long)b * a.S + query[g]) * ld + hd * AT_DH), hi, acc[g], 1.0f);
+            else at_store_rowT<0>(a.dqkv + ((long)b * a.S + query[g]) * ld + hd * AT_DH, hi, acc[g], 1.0f);
+        }
 }
 
 // ------------------------------------------------------------------------------------------------ backward 2: dK, dV
-template <int DROP>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))       // (left alone: 247 + 64 accumulator registers, one wave per SIMD)
+template <int NP, int G, int DROP, int MEM16>
+__global__ void __launch_bounds__(256) A16_WAVES(2)       // (left alone: 247 + 64 accumulator registers at NP = 1, G = 2: one wave per SIMD)
 attn16_bwd_dkv_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char Qr[2][A16_TILE_BYTES], Or[2][A16_TILE_BYTES], Qc[2][A16_TILE_BYTES], Oc[2][A16_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char Qr[2][NP * A16_TILE_BYTES], Or[2][NP * A16_TILE_BYTES], Qc[2][NP * A16_TILE_BYTES], Oc[2][NP * A16_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) float Ls[2][AT_T], Ds[2][AT_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.nhead, hd = bh - b * a.nhead;
     const unsigned hkey = at_head_key(a.drop_seed, (unsigned)bh);
     const long ld = 3L * a.d_model;
-    const unsigned short *Q = (const unsigned short *)a.qkv + (long)b * a.S * ld + hd * AT_DH, *K = Q + a.d_model, *V = Q + 2 * a.d_model;
+    const void *Q = MEM16 ? (const void *)((const unsigned short *)a.qkv + (long)b * a.S * ld + hd * AT_DH) : (const void *)(a.qkv + (long)b * a.S * ld + hd * AT_DH);
+    const void *K = MEM16 ? (const void *)((const unsigned short *)Q + a.d_model) : (const void *)((const float *)Q + a.d_model);
+    const void *V = MEM16 ? (const void *)((const unsigned short *)Q + 2 * a.d_model) : (const void *)((const float *)Q + 2 * a.d_model);
     const float *dO = a.dout + (long)b * a.Sq * a.d_model + hd * AT_DH;
     const float *lse = a.lse + (long)bh * a.Sq, *dsm = a.dsum + (long)bh * a.Sq;
-    const int k0w = blockIdx.x * 256 + wave * 64;
-    int key[2];
-    bf16w4 kf[2][2], vf[2][2];
-    bool live[2];
-    float bias2[2];
-    at_f32x16 acc_k[2], acc_v[2];
+    const int k0w = blockIdx.x * (128 * G) + wave * (32 * G);
+    int key[G];
+    A16Frag<NP> kf[G][2], vf[G][2];
+    bool live[G];
+    float bias2[G];
+    at_f32x16 acc_k[G], acc_v[G];
     #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < G; ++g) {
         key[g] = k0w + 32 * g + l31;
         live[g] = k0w + 32 * g < a.S;                         // wave-uniform
-        a16_own_row_bf16(K, ld, key[g], a.S, hi, kf[g]);
-        a16_own_row_bf16(V, ld, key[g], a.S, hi, vf[g]);
+        a16_own_row<NP, MEM16>(K, ld, key[g], a.S, hi, kf[g], nullptr);
+        a16_own_row<NP, MEM16>(V, ld, key[g], a.S, hi, vf[g], nullptr);
         bias2[g] = -INFINITY;
         if (key[g] < a.S) bias2[g] = a.key_bias ? a.key_bias[(long)b * a.S + key[g]] * A16_LOG2E : 0.0f;
         #pragma unroll
@@ -387,10 +482,11 @@ attn16_bwd_dkv_kernel(AttnArgs a) {
     const float dscale = DROP ? a.drop_scale : 1.0f;
     const int ntiles = (a.Sq + AT_T - 1) / AT_T;               // walks the live queries
     const int sr = tid >> 3, sp = tid & 7, t31 = tid & 31;
-    a16_u32x2 rq = a16_ld_bf16x4(Q, (long)(sr < a.Sq ? sr : a.Sq - 1) * ld + 4 * sp, sr < a.Sq);
-    a16_u32x2 ro = a16_ld_f32x4(dO, (long)(sr < a.Sq ? sr : a.Sq - 1) * a.d_model + 4 * sp, sr < a.Sq);
+    a16_u32x2 rq[NP], ro[NP];
+    a16_fetch4<NP, MEM16>(Q, (long)(sr < a.Sq ? sr : a.Sq - 1) * ld + 4 * sp, sr < a.Sq, rq);
+    a16_fetch4<NP, 0>(dO, (long)(sr < a.Sq ? sr : a.Sq - 1) * a.d_model + 4 * sp, sr < a.Sq, ro);
     float rl = lse[t31 < a.Sq ? t31 : a.Sq - 1], rd = dsm[t31 < a.Sq ? t31 : a.Sq - 1];
-    a16_stash_rows(Qr[0], sr, sp, rq); a16_stash_cols(Qc[0], sr, sp, rq); a16_stash_rows(Or[0], sr, sp, ro); a16_stash_cols(Oc[0], sr, sp, ro);
+    a16_put_rows<NP>(Qr[0], sr, sp, rq); a16_put_cols<NP>(Qc[0], sr, sp, rq); a16_put_rows<NP>(Or[0], sr, sp, ro); a16_put_cols<NP>(Oc[0], sr, sp, ro);
     if (tid < AT_T) { Ls[0][tid] = tid < a.Sq ? rl * A16_LOG2E : 3.0e38f; Ds[0][tid] = tid < a.Sq ? rd : 0.0f; }
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
@@ -398,27 +494,23 @@ attn16_bwd_dkv_kernel(AttnArgs a) {
         {
             const int qr = q0n + sr;
             const long qc = qr < a.Sq ? qr : a.Sq - 1;
-            rq = a16_ld_bf16x4(Q, qc * ld + 4 * sp, qr < a.Sq); ro = a16_ld_f32x4(dO, qc * a.d_model + 4 * sp, qr < a.Sq);
+            a16_fetch4<NP, MEM16>(Q, qc * ld + 4 * sp, qr < a.Sq, rq); a16_fetch4<NP, 0>(dO, qc * a.d_model + 4 * sp, qr < a.Sq, ro);
             const int qs = q0n + t31 < a.Sq ? q0n + t31 : a.Sq - 1;
             rl = lse[qs]; rd = dsm[qs];
         }
         if (live[0]) {
-            const bf16w4 qr0 = a16_frag(Qr[buf], l31, hi), qr1 = a16_frag(Qr[buf], l31, 2 + hi);
-            const bf16w4 or0 = a16_frag(Or[buf], l31, hi), or1 = a16_frag(Or[buf], l31, 2 + hi);
-            const bf16w4 qc0 = a16_frag(Qc[buf], l31, hi), qc1 = a16_frag(Qc[buf], l31, 2 + hi);
-            const bf16w4 oc0 = a16_frag(Oc[buf], l31, hi), oc1 = a16_frag(Oc[buf], l31, 2 + hi);
             float lrow[16], drow[16];
             at_vec16(Ls[buf], hi, lrow);
             at_vec16(Ds[buf], hi, drow);
             #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < G; ++g) {
                 at_f32x16 s, dp;
                 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
-                s = gemm_mfma_bf16_w(qr0, kf[g][0], s);          // S: queries (rows) x own keys (lanes)
-                s = gemm_mfma_bf16_w(qr1, kf[g][1], s);
-                dp = gemm_mfma_bf16_w(or0, vf[g][0], dp);        // dP = dO V^T
-                dp = gemm_mfma_bf16_w(or1, vf[g][1], dp);
+                s = a16_mma<NP>(a16_frag_n<NP>(Qr[buf], l31, hi), kf[g][0], s);          // S: queries (rows) x own keys (lanes)
+                s = a16_mma<NP>(a16_frag_n<NP>(Qr[buf], l31, 2 + hi), kf[g][1], s);
+                dp = a16_mma<NP>(a16_frag_n<NP>(Or[buf], l31, hi), vf[g][0], dp);        // dP = dO V^T
+                dp = a16_mma<NP>(a16_frag_n<NP>(Or[buf], l31, 2 + hi), vf[g][1], dp);
                 float p[16], ds[16];
                 bool keep[16];
                 if (DROP) a16_keep16<false>(a, hkey, key[g], q0, hi, keep);
@@ -430,25 +522,36 @@ attn16_bwd_dkv_kernel(AttnArgs a) {
                     ds[r] = a.scale * pr * (dpr - drow[r]);
                     p[r] = DROP ? (keep[r] ? pr * dscale : 0.0f) : pr;                     // dV sums the dropped probabilities
                 }
-                bf16w4 pb[2], db[2];
-                a16_pack16(p, pb);
-                a16_pack16(ds, db);
-                acc_v[g] = gemm_mfma_bf16_w(oc0, pb[0], acc_v[g]);   // dV^T += dO^T P
-                acc_v[g] = gemm_mfma_bf16_w(oc1, pb[1], acc_v[g]);
-                acc_k[g] = gemm_mfma_bf16_w(qc0, db[0], acc_k[g]);   // dK^T += Q^T dS
-                acc_k[g] = gemm_mfma_bf16_w(qc1, db[1], acc_k[g]);
+                {
+                    A16Frag<NP> pb[2];
+                    a16_pack16<NP>(p, pb);
+                    acc_v[g] = a16_mma<NP>(a16_frag_n<NP>(Oc[buf], l31, hi), pb[0], acc_v[g]);   // dV^T += dO^T P
+                    acc_v[g] = a16_mma<NP>(a16_frag_n<NP>(Oc[buf], l31, 2 + hi), pb[1], acc_v[g]);
+                }
+                {
+                    A16Frag<NP> db[2];
+                    a16_pack16<NP>(ds, db);
+                    acc_k[g] = a16_mma<NP>(a16_frag_n<NP>(Qc[buf], l31, hi), db[0], acc_k[g]);   // dK^T += Q^T dS
+                    acc_k[g] = a16_mma<NP>(a16_frag_n<NP>(Qc[buf], l31, 2 + hi), db[1], acc_k[g]);
+                }
             }
         }
-        a16_stash_rows(Qr[buf ^ 1], sr, sp, rq); a16_stash_cols(Qc[buf ^ 1], sr, sp, rq); a16_stash_rows(Or[buf ^ 1], sr, sp, ro); a16_stash_cols(Oc[buf ^ 1], sr, sp, ro);
+        a16_put_rows<NP>(Qr[buf ^ 1], sr, sp, rq); a16_put_cols<NP>(Qc[buf ^ 1], sr, sp, rq); a16_put_rows<NP>(Or[buf ^ 1], sr, sp, ro); a16_put_cols<NP>(Oc[buf ^ 1], sr, sp, ro);
         if (tid < AT_T) { Ls[buf ^ 1][tid] = q0n + tid < a.Sq ? rl * A16_LOG2E : 3.0e38f; Ds[buf ^ 1][tid] = q0n + tid < a.Sq ? rd : 0.0f; }
         __syncthreads();
     }
     #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < G; ++g)
         if (key[g] < a.S) {
-            unsigned short *dst = (unsigned short *)a.dqkv + ((long)b * a.S + key[g]) * ld + hd * AT_DH;
-            at_store_rowT<1>((float *)(dst + a.d_model), hi, acc_k[g], 1.0f);
-            at_store_rowT<1>((float *)(dst + 2 * a.d_model), hi, acc_v[g], 1.0f);
+            if (MEM16) {
+                unsigned short *dst = (unsigned short *)a.dqkv + ((long)b * a.S + key[g]) * ld + hd * AT_DH;
+                at_store_rowT<1>((float *)(dst + a.d_model), hi, acc_k[g], 1.0f);
+                at_store_rowT<1>((float *)(dst + 2 * a.d_model), hi, acc_v[g], 1.0f);
+            } else {
+                float *dst = a.dqkv + ((long)b * a.S + key[g]) * ld + hd * AT_DH;
+                at_store_rowT<0>(dst + a.d_model, hi, acc_k[g], 1.0f);
+                at_store_rowT<0>(dst + 2 * a.d_model, hi, acc_v[g], 1.0f);
+            }
         }
 }
 

@@ -55,8 +55,8 @@ int emloco_attention_fwd_queries(int n_seq, int S, int n_query, int nhead, int d
         if (!bf) return pfail(-1, "emloco_attention_fwd: a bf16 q|k|v tensor needs EMLOCO_ATTN_BF16");
         if (!attn16_old()) {                                 // round 5: two blocks of 32 queries per wave, bf16 tile images (attention16_kernels.hip)
             const dim3 grid16((unsigned)((n_query + 255) / 256), (unsigned)(n_seq * nhead));
-            if (dr) hipLaunchKernelGGL((emloco::attn16_fwd_kernel<1>), grid16, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((emloco::attn16_fwd_kernel<0>), grid16, dim3(256), 0, st, a);
+            if (dr) hipLaunchKernelGGL((emloco::attn16_fwd_kernel<1, 2, 1, 1>), grid16, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((emloco::attn16_fwd_kernel<1, 2, 0, 1>), grid16, dim3(256), 0, st, a);
             PHIPCHK(hipGetLastError());
             return 0;
         }
@@ -66,6 +66,16 @@ int emloco_attention_fwd_queries(int n_seq, int S, int n_query, int nhead, int d
         return 0;
     }
     const bool sp = !bf && (flags & EMLOCO_ATTN_SPLIT) != 0;
+    if (sp && !attn16_old()) {                               // round 5: the split mode on the piece-plane tile images (attention16_kernels.hip, NP = 3)
+#ifndef A16_SPLIT_G_FWD
+#define A16_SPLIT_G_FWD 1                                    /* blocks of 32 queries per wave of the split-mode forward */
+#endif
+        const dim3 gridf((unsigned)((n_query + 128 * A16_SPLIT_G_FWD - 1) / (128 * A16_SPLIT_G_FWD)), (unsigned)(n_seq * nhead));
+        if (dr) hipLaunchKernelGGL((emloco::attn16_fwd_kernel<3, A16_SPLIT_G_FWD, 1, 0>), gridf, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emloco::attn16_fwd_kernel<3, A16_SPLIT_G_FWD, 0, 0>), gridf, dim3(256), 0, st, a);
+        PHIPCHK(hipGetLastError());
+        return 0;
+    }
     if (sp && dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<2, 1>), grid, dim3(256), 0, st, a);
     else if (sp) hipLaunchKernelGGL((emloco::attn_fwd_kernel<2, 0>), grid, dim3(256), 0, st, a);
     else if (bf && dr) hipLaunchKernelGGL((emloco::attn_fwd_kernel<1, 1>), grid, dim3(256), 0, st, a);
@@ -112,11 +122,11 @@ int emloco_attention_bwd_queries(int n_seq, int S, int n_query, int nhead, int d
     if (n_query < S) PHIPCHK(hipMemset2DAsync(dqkv, 3 * (size_t)d_model * esz, 0, (size_t)d_model * esz, (size_t)n_seq * S, st));
     if (q16 && !attn16_old()) {
         const dim3 grid16((unsigned)((S + 255) / 256), (unsigned)(n_seq * nhead)), qgrid16((unsigned)((n_query + 255) / 256), (unsigned)(n_seq * nhead));
-        if (dr) hipLaunchKernelGGL((emloco::attn16_bwd_dq_kernel<1>), qgrid16, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((emloco::attn16_bwd_dq_kernel<0>), qgrid16, dim3(256), 0, st, a);
+        if (dr) hipLaunchKernelGGL((emloco::attn16_bwd_dq_kernel<1, 2, 1, 1>), qgrid16, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emloco::attn16_bwd_dq_kernel<1, 2, 0, 1>), qgrid16, dim3(256), 0, st, a);
         PHIPCHK(hipGetLastError());
-        if (dr) hipLaunchKernelGGL((emloco::attn16_bwd_dkv_kernel<1>), grid16, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((emloco::attn16_bwd_dkv_kernel<0>), grid16, dim3(256), 0, st, a);
+        if (dr) hipLaunchKernelGGL((emloco::attn16_bwd_dkv_kernel<1, 2, 1, 1>), grid16, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emloco::attn16_bwd_dkv_kernel<1, 2, 0, 1>), grid16, dim3(256), 0, st, a);
         PHIPCHK(hipGetLastError());
         return 0;
     }
@@ -131,6 +141,15 @@ int emloco_attention_bwd_queries(int n_seq, int S, int n_query, int nhead, int d
     }
     // first kernel: dQ, also writes D = rowsum(dO o O); second: dK, dV
     const bool sp = !bf && (flags & EMLOCO_ATTN_SPLIT) != 0;
+    if (sp && !attn16_old()) {
+        if (dr) hipLaunchKernelGGL((emloco::attn16_bwd_dq_kernel<3, 1, 1, 0>), qgrid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emloco::attn16_bwd_dq_kernel<3, 1, 0, 0>), qgrid, dim3(256), 0, st, a);
+        PHIPCHK(hipGetLastError());
+        if (dr) hipLaunchKernelGGL((emloco::attn16_bwd_dkv_kernel<3, 1, 1, 0>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((emloco::attn16_bwd_dkv_kernel<3, 1, 0, 0>), grid, dim3(256), 0, st, a);
+        PHIPCHK(hipGetLastError());
+        return 0;
+    }
     if (sp && dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<2, 1>), qgrid, dim3(256), 0, st, a);
     else if (sp) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<2, 0>), qgrid, dim3(256), 0, st, a);
     else if (bf && dr) hipLaunchKernelGGL((emloco::attn_bwd_dq_kernel<1, 1>), qgrid, dim3(256), 0, st, a);

@@ -19,8 +19,8 @@ extern "C" {
 
 int emloco_ffn_fwd(int M, int F, const float *x, const uint16_t *w1_bf16, const uint16_t *w2_bf16, const float *b1, const float *b2,
                    uint16_t *hidden, uint32_t *mask, float *out, float drop_p, uint32_t seed_hidden, uint32_t seed_out, void *stream) {
-    if (M < 1 || F < FFN_CH || F % FFN_CH || !x || !w1_bf16 || !w2_bf16 || !b1 || !b2 || !hidden || !mask || !out || !(drop_p >= 0.0f && drop_p < 1.0f))
-        return ffail(-1, "emloco_ffn_fwd: bad argument (hidden width must be a multiple of 64, 0 <= drop_p < 1)");
+    if (M < 1 || F < FFN_CH || F % FFN_CH || F > 2048 || !x || !w1_bf16 || !w2_bf16 || !b1 || !b2 || !hidden || !mask || !out || !(drop_p >= 0.0f && drop_p < 1.0f))
+        return ffail(-1, "emloco_ffn_fwd: bad argument (hidden width must be a multiple of 64, at most 2048; 0 <= drop_p < 1)");
     if (!aligned16(x) || !aligned16(w1_bf16) || !aligned16(w2_bf16) || !aligned16(b1) || !aligned16(b2) || !aligned16(hidden) || !aligned16(mask) || !aligned16(out))
         return ffail(-1, "emloco_ffn_fwd: operands must be 16-byte aligned");
     emloco::FfnArgs a{M, F, x, w1_bf16, w2_bf16, b1, b2, hidden, nullptr, mask, out, drop_p, 1.0f / (1.0f - drop_p), seed_hidden,

@@ -132,6 +132,10 @@ __global__ void __launch_bounds__(FFN_THREADS)
 ffn_chain_kernel(FfnArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2][FFN_P_BYTES + FFN_Q_BYTES];
     __shared__ __attribute__((aligned(16))) char lds_t[FFN_THREADS / 64][FFN_T_BYTES];
+    // linear1's bias in LDS (forward): read from memory inside the chunk loop its loads queue behind the previous chunk's tile stores
+    // (the vector-memory counter retires in order) and every chunk waited for those stores to land -- 56 % of the forward's wave
+    // cycles were such waits (profiles/r05_attn_counters_bf16.txt)
+    __shared__ __attribute__((aligned(16))) float lds_b1[MODE == 0 ? 2048 : 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     // rows past the end compute -- and store -- the LAST row again (identical values to the same addresses): no lane-dependent branch
     // splits the chunk loop into basic blocks, the matrix instructions schedule across the stores
@@ -157,6 +161,8 @@ ffn_chain_kernel(FfnArgs a) {
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
     const unsigned rkey = DROP ? ffn_row_key(a.seed1, (unsigned)row) : 0u;
 
+    if (MODE == 0)
+        for (int i = tid; i < a.F && i < 2048; i += FFN_THREADS) lds_b1[i] = a.b1[i];
     FfnStage st;
     ffn_fetch(a, 0, tid, st);
     ffn_stash(lds[0], lds[0] + FFN_P_BYTES, tid, st);
@@ -190,7 +196,7 @@ ffn_chain_kernel(FfnArgs a) {
                 const int hid = c * FFN_CH + t * 32 + 8 * q + 4 * hi;      // four consecutive hidden units
                 float v[4] = {T[t][4 * q], T[t][4 * q + 1], T[t][4 * q + 2], T[t][4 * q + 3]};
                 if (MODE == 0) {
-                    const ffn_f32x4 b = *(const ffn_f32x4 *)(a.b1 + hid);
+                    const ffn_f32x4 b = *(const ffn_f32x4 *)(lds_b1 + hid);
                     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;

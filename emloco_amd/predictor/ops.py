@@ -264,7 +264,7 @@ _FFN_CHAIN = os.environ.get("EMLOCO_FFN_CHAIN", "1") != "0"
 
 
 def _ffn_chain_ok(M, K, F, N):
-    return _FFN_CHAIN and _matmul_precision[0] == "bf16" and K == 128 and N == 128 and F >= 64 and F % 64 == 0
+    return _FFN_CHAIN and _matmul_precision[0] == "bf16" and K == 128 and N == 128 and 64 <= F <= 2048 and F % 64 == 0
 
 
 class FeedForwardFn(torch.autograd.Function):

@@ -1201,3 +1201,63 @@ def test_bf16_attention_kernels_two_blocks_per_wave():
     out2 = np.ones((1, S, d), np.float32); lse2 = np.zeros((H, S), np.float32)
     lib.emu_attention16(1, 1, S, S, H, d, C.c_float(scale), U16(qkvb), P(kb2), P(out2), P(lse2), None, None, None, C.c_float(0.0), C.c_uint(0))
     assert np.all(out2 == 0) and np.all(lse2 > 1e38)
+
+
+def test_split_mode_attention_on_piece_plane_tile_images():
+    """csrc/attention16_kernels.hip with NP = 3 (round 5): the DEFAULT precision class of the fused attention -- fp32 q|k|v, every tile
+    product rebuilt from bf16 pieces (six matrix instructions per 16 reduction entries) -- on the tile images of the bf16 kernels, one
+    plane per piece: the walked tile's pieces are cut once, by the staging thread, not by every consuming wave.  Against float64 attention
+    with the kernels' own dropout mask: fp32 class (1e-5 of the tensor scale; the bf16 kernels hold 2e-2), forward, log-sum-exp and all
+    three gradients; and against round 4's split-mode kernels (attn_*<2, DROP, 0>): same pieces, same products, same mask -- summation
+    order and the base of the exponential apart.  Ragged S, +1 and -inf key bias, dropout, the live-query form."""
+    lib = emu.lib()
+    lib.emu_attn_keep.restype = C.c_int
+    rng = np.random.default_rng(10)
+    scale = 1.0 / np.sqrt(32.0)
+    VP = lambda a: a.ctypes.data_as(C.c_void_p)
+    for (n_seq, S, Sq, H, p, seed) in ((2, 150, 150, 1, 0.0, 0), (1, 70, 70, 2, 0.1, 4242), (1, 150, 21, 1, 0.1, 77)):
+        d = H * 32
+        qkv = (rng.normal(size=(n_seq, S, 3 * d)) * 0.7).astype(np.float32)
+        kb = np.zeros((n_seq, S), np.float32)
+        kb[0, 5::7] = 1.0
+        kb[-1, S - 20:] = -np.inf
+        dout = rng.normal(size=(n_seq, Sq, d)).astype(np.float32)
+        res = {}
+        for which in (2, 3):
+            out = np.full((n_seq, Sq, d), np.nan, np.float32)
+            lse = np.full((n_seq * H, Sq), np.nan, np.float32)
+            lib.emu_attention16(which, n_seq, S, Sq, H, d, C.c_float(scale), VP(qkv), P(kb), P(out), P(lse), None, None, None, C.c_float(p), C.c_uint(seed))
+            dqkv = np.zeros_like(qkv)
+            dsum = np.full((n_seq * H, Sq), np.nan, np.float32)
+            lib.emu_attention16(which, n_seq, S, Sq, H, d, C.c_float(scale), VP(qkv), P(kb), P(out), P(lse), P(dout), VP(dqkv), P(dsum), C.c_float(p), C.c_uint(seed))
+            res[which] = (out, lse, dqkv, dsum)
+        q64 = qkv.astype(np.float64)
+        ref_out = np.zeros((n_seq, Sq, d)); ref_lse = np.zeros((n_seq * H, Sq)); ref_dqkv = np.zeros((n_seq, S, 3 * d))
+        for b in range(n_seq):
+            for h in range(H):
+                q, k, v = (q64[b, :, i * d + h * 32:i * d + (h + 1) * 32] for i in range(3))
+                s_ = q[:Sq] @ k.T * scale + kb[b].astype(np.float64)
+                mx = s_.max(1, keepdims=True)
+                e = np.exp(s_ - mx)
+                l = e.sum(1, keepdims=True)
+                P_ = e / l
+                keep = np.ones((Sq, S))
+                if p > 0:
+                    keep = np.array([[lib.emu_attn_keep(C.c_uint(seed), b * H + h, qi, ki, C.c_float(p)) for ki in range(S)] for qi in range(Sq)], np.float64) / (1 - p)
+                Pd = P_ * keep
+                ref_out[b, :, h * 32:(h + 1) * 32] = Pd @ v
+                ref_lse[b * H + h] = (mx + np.log(l))[:, 0]
+                do = dout[b, :, h * 32:(h + 1) * 32].astype(np.float64)
+                dP = (do @ v.T) * keep
+                dS = P_ * (dP - (dP * P_).sum(1, keepdims=True))
+                ref_dqkv[b, :Sq, h * 32:(h + 1) * 32] = dS @ k * scale
+                ref_dqkv[b, :, d + h * 32:d + (h + 1) * 32] = dS.T @ q[:Sq] * scale
+                ref_dqkv[b, :, 2 * d + h * 32:2 * d + (h + 1) * 32] = Pd.T @ do
+        new, old = res[3], res[2]
+        for got, want, what in ((new[0], ref_out, "out"), (new[1], ref_lse, "lse"), (new[2], ref_dqkv, "dqkv")):
+            err = np.abs(got - want).max()
+            assert np.isfinite(got).all() and err <= 1e-5 * np.abs(want).max() + 1e-7, (S, Sq, p, what, err, np.abs(want).max())
+        for a_, b_, what in ((new[0], old[0], "out"), (new[1], old[1], "lse"), (new[3], old[3], "dsum"), (new[2], old[2], "dqkv")):
+            err = np.abs(a_ - b_).max()
+            assert err <= 1e-5 * np.abs(b_).max() + 1e-7, (S, Sq, p, what, "vs round 4", err)
+        assert np.all(new[2][-1, S - 20:, d:] == 0)

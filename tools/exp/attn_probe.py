@@ -8,13 +8,15 @@ libs = sys.argv[1:] or [os.path.join(R, "emloco_amd", "lib", "libemloco_hip.so")
 n_seq, S, H, d = int(os.environ.get("ATTN_NSEQ", 2048)), 453, 4, 128
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
-qkv = (torch.randn(n_seq, S, 3 * d, device=dev) * 0.7).to(torch.bfloat16)
+SPLIT = os.environ.get("ATTN_MODE", "bf16") == "split"       # the default precision class: fp32 q|k|v, tile products from bf16 pieces
+qkv = (torch.randn(n_seq, S, 3 * d, device=dev) * 0.7)
+if not SPLIT: qkv = qkv.to(torch.bfloat16)
 kb = torch.zeros(n_seq, S, device=dev); kb[:, 400:] = 1.0
 out = torch.empty(n_seq, S, d, device=dev); lse = torch.empty(n_seq * H, S, device=dev); dsum = torch.empty_like(lse)
 dout = torch.randn(n_seq, S, d, device=dev); dqkv = torch.empty_like(qkv)
 P = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-FL = 16 | 32       # EMLOCO_ATTN_BF16 | EMLOCO_ATTN_QKV_BF16MEM
+FL = 64 if SPLIT else (16 | 32)       # EMLOCO_ATTN_SPLIT, or EMLOCO_ATTN_BF16 | EMLOCO_ATTN_QKV_BF16MEM
 handles = []
 for path in libs:
     L = C.CDLL(path)

@@ -5,7 +5,7 @@
 # Output: per kernel -- launches per step, average duration, read / written bytes per launch, effective TB/s.
 L=${1:-x}; P=${2:-fp32_split}
 R=$PWD; OUT=$R/gpurun_out/r05; mkdir -p $OUT
-cd /tmp; export TMPDIR=/tmp JTA_PRECISION=$P
+cd /tmp; export TMPDIR=/tmp JTA_PRECISION=$P JH_OUT=$OUT
 STEPS=3
 rm -rf /tmp/jh_kt /tmp/jh_F /tmp/jh_W
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/jh_kt -- python $R/tools/exp/jta_step.py $STEPS > /tmp/jh_kt.log 2>&1
@@ -41,5 +41,13 @@ for t, k, n, ns, rd, wr in sorted(rows, reverse=True)[:28]:
     print(f"{k:80s} {n / calls:10.1f} {ns / 1e3:9.1f} {rd / 1e6:9.1f} {wr / 1e6:9.1f} {tbs:6.2f} {t / calls / 1e6:8.2f} {(rd + wr) * n / calls / 1e9:8.2f}")
     tot_ms += t / calls / 1e6; tot_gb += (rd + wr) * n / calls / 1e9
 print(f"top rows: {tot_ms:.1f} ms and {tot_gb:.1f} GB per step -> {tot_gb / tot_ms:.2f} TB/s on average while a kernel runs")
+import json, os
+gem = [(n, ns, rd, wr) for t, k, n, ns, rd, wr in rows if "gemm" in k]
+gb = sum((rd + wr) * n for n, ns, rd, wr in gem) / calls
+gms = sum(n * ns for n, ns, rd, wr in gem) / calls / 1e6
+json.dump({"precision": prec, "gemm_bytes_per_step": gb, "gemm_ms_per_step": gms, "gemm_tb_per_s": gb / gms / 1e9 if gms else None,
+           "note": "all kernels whose name contains 'gemm' (split-K reductions included): FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 per launch x launches per step; "
+                   "separate --pmc passes of tools/exp/jta_step.py; FETCH counts fabric requests (Infinity-Cache hits included)"},
+          open(os.path.join(os.environ.get("JH_OUT", "/tmp"), f"jta_gemm_hbm_bytes_{prec}.json"), "w"), indent=1)
 PY
 cat $OUT/jta_hbm_${L}_${P}.txt; tail -2 /tmp/jh_kt.log
