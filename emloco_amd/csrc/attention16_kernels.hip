@@ -540,6 +540,11 @@ attn16_bwd_dkv_kernel(AttnArgs a) {
         if (tid < AT_T) { Ls[buf ^ 1][tid] = q0n + tid < a.Sq ? rl * A16_LOG2E : 3.0e38f; Ds[buf ^ 1][tid] = q0n + tid < a.Sq ? rd : 0.0f; }
         __syncthreads();
     }
+    // rows that do not attend (the live-query form, Sq < S) get dQ = 0 here -- every row of the sequence is a key of this kernel; the
+    // launcher's 2-D memset of the Q third of ALL rows (475 MB per layer at the train step's size) is gone with it
+    at_f32x16 zero;
+    #pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
     #pragma unroll
     for (int g = 0; g < G; ++g)
         if (key[g] < a.S) {
@@ -547,10 +552,12 @@ attn16_bwd_dkv_kernel(AttnArgs a) {
                 unsigned short *dst = (unsigned short *)a.dqkv + ((long)b * a.S + key[g]) * ld + hd * AT_DH;
                 at_store_rowT<1>((float *)(dst + a.d_model), hi, acc_k[g], 1.0f);
                 at_store_rowT<1>((float *)(dst + 2 * a.d_model), hi, acc_v[g], 1.0f);
+                if (key[g] >= a.Sq) at_store_rowT<1>((float *)dst, hi, zero, 1.0f);
             } else {
                 float *dst = a.dqkv + ((long)b * a.S + key[g]) * ld + hd * AT_DH;
                 at_store_rowT<0>(dst + a.d_model, hi, acc_k[g], 1.0f);
                 at_store_rowT<0>(dst + 2 * a.d_model, hi, acc_v[g], 1.0f);
+                if (key[g] >= a.Sq) at_store_rowT<0>(dst, hi, zero, 1.0f);
             }
         }
 }

@@ -255,11 +255,13 @@ extern "C" int emu_attention16(int which, int n_seq, int S, int Sq, int nhead, i
         else if (which == 3) { if (dr) KNEW<3, 1, 1, 0>(a); else KNEW<3, 1, 0, 0>(a); } \
         else if (which == 0) { if (dr) KOLD_BF<1, 1, 1>(a); else KOLD_BF<1, 0, 1>(a); } \
         else { if (dr) KOLD_SP<2, 1, 0>(a); else KOLD_SP<2, 0, 0>(a); } } while (0)
+    const unsigned rows_fwd = (which == 3 && !dout) ? 256 : rows_per_wg;      // the split-mode forward runs two blocks per wave (attention_capi.hip: A16_SPLIT_G_FWD)
     for (unsigned y = 0; y < (unsigned)(n_seq * nhead); ++y)
-        for (unsigned x = 0; x < (Sq + rows_per_wg - 1) / rows_per_wg; ++x)
+        for (unsigned x = 0; x < (Sq + rows_fwd - 1) / rows_fwd; ++x)
             emu::launch(1, 256, [&] {
                 blockIdx.x = x; blockIdx.y = y;
-                if (!dout) A16_RUN(attn_fwd_kernel, attn_fwd_kernel, attn16_fwd_kernel);
+                if (!dout && which == 3) { if (dr) attn16_fwd_kernel<3, 2, 1, 0>(a); else attn16_fwd_kernel<3, 2, 0, 0>(a); }
+                else if (!dout) A16_RUN(attn_fwd_kernel, attn_fwd_kernel, attn16_fwd_kernel);
                 else A16_RUN(attn_bwd_dq_kernel, attn_bwd_dq_kernel, attn16_bwd_dq_kernel);
             });
     if (dout)

@@ -1156,7 +1156,8 @@ def test_bf16_attention_kernels_two_blocks_per_wave():
             out = np.full((n_seq, Sq, d), np.nan, np.float32)
             lse = np.full((n_seq * H, Sq), np.nan, np.float32)
             lib.emu_attention16(which, n_seq, S, Sq, H, d, C.c_float(scale), U16(qkvb), P(kb), P(out), P(lse), None, None, None, C.c_float(p), C.c_uint(seed))
-            dqkv = np.zeros((n_seq, S, 3 * d), np.uint16)            # (rows that do not attend keep dQ = 0: the launcher's memset)
+            # rows that do not attend get dQ = 0: from the launcher's memset for round 4's kernels, from the dK / dV kernel itself in round 5's
+            dqkv = np.zeros((n_seq, S, 3 * d), np.uint16) if which == 0 else np.full((n_seq, S, 3 * d), 0x7fc0, np.uint16)
             dsum = np.full((n_seq * H, Sq), np.nan, np.float32)
             lib.emu_attention16(which, n_seq, S, Sq, H, d, C.c_float(scale), U16(qkvb), P(kb), P(out), P(lse), P(dout), U16(dqkv), P(dsum), C.c_float(p), C.c_uint(seed))
             res[which] = (out, lse, _bf16_val(dqkv), dsum)
@@ -1227,7 +1228,7 @@ def test_split_mode_attention_on_piece_plane_tile_images():
             out = np.full((n_seq, Sq, d), np.nan, np.float32)
             lse = np.full((n_seq * H, Sq), np.nan, np.float32)
             lib.emu_attention16(which, n_seq, S, Sq, H, d, C.c_float(scale), VP(qkv), P(kb), P(out), P(lse), None, None, None, C.c_float(p), C.c_uint(seed))
-            dqkv = np.zeros_like(qkv)
+            dqkv = np.zeros_like(qkv) if which == 2 else np.full_like(qkv, np.nan)
             dsum = np.full((n_seq * H, Sq), np.nan, np.float32)
             lib.emu_attention16(which, n_seq, S, Sq, H, d, C.c_float(scale), VP(qkv), P(kb), P(out), P(lse), P(dout), VP(dqkv), P(dsum), C.c_float(p), C.c_uint(seed))
             res[which] = (out, lse, dqkv, dsum)
