@@ -93,7 +93,7 @@ for r in list(csv.reader(open(sys.argv[2])))[1:]:
 CLK = 2.4          # GHz, MI355X peak engine clock (MI355X_MICROARCH.md); 256 CUs x 4 SIMDs
 lines = ["kernel | launches | MFMA busy cycles per launch (sum over the 1024 SIMDs) | avg duration [us] (kernel-trace pass) | "
          "MFMA utilisation = busy / (duration x 2.4 GHz x 1024)"]
-for k in sorted(busy, key=lambda k: -busy[k])[:10]:
+for k in sorted(busy, key=lambda k: -busy[k])[:20]:
     if busy[k] > 0 and k in avg_ns:
         per = busy[k] / n[k]
         lines.append(f"{k:70s} | {n[k]:5d} | {per:.4g} | {avg_ns[k] / 1e3:9.1f} | {per / (avg_ns[k] * CLK * 1024):.3f}")
