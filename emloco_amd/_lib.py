@@ -141,7 +141,7 @@ def default_sim_params(**kw):
 # every symbol the headers declare; checked at load time
 SYMBOLS_SIM = [
     "emloco_last_error", "emloco_device_count", "emloco_sim_create", "emloco_sim_destroy", "emloco_sim_set_models",
-    "emloco_sim_set_self_collision", "emloco_sim_set_ground_heightfield",
+    "emloco_sim_set_self_collision", "emloco_sim_set_ground_heightfield", "emloco_sim_set_ground_mesh_moves",
     "emloco_sim_prepare", "emloco_sim_get_params", "emloco_sim_set_params", "emloco_sim_tensor",
     "emloco_sim_set_pd_targets", "emloco_sim_set_dof_actuation_force", "emloco_sim_step", "emloco_sim_step_subset", "emloco_sim_set_cost_order", "emloco_sim_set_split", "emloco_sim_sync", "emloco_sim_set_root_state_indexed",
     "emloco_sim_set_dof_state_indexed", "emloco_sim_refresh_bodies", "emloco_sim_num_candidates",

@@ -40,6 +40,9 @@ struct EmlocoSimDev {
     const short *hf;
     int hf_nx, hf_ny;
     float hf_hs, hf_inv_hs, hf_vs, hf_ox, hf_oy, hf_pad_;
+    // vertex moves of the slope-corrected mesh (emloco_sim_set_ground_mesh_moves), NULL: none.  One byte per sample: bits 0-1 move
+    // along x + 1, bits 2-3 move along y + 1, bit 4 = some vertex of the 4 x 4 block around cell (i, j) moved
+    const unsigned char *hf_mv;
     long long *prof;   /* optional (built with -DEMLOCO_SIM_PROFILE): per-phase cycle stamps of env 0, else NULL */
     // subset launches (emloco_sim_step_subset), both NULL for the plain step: envs whose step_skip entry is non-zero are left
     // untouched; with step_ids workgroup i steps env step_ids[i] of a device-compacted list (valid ids first, -1 after them)

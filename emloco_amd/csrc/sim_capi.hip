@@ -155,12 +155,42 @@ int emloco_sim_set_ground_heightfield(EmlocoSim *s, const int16_t *samples, int 
                                       float vertical_scale, float origin_x, float origin_y) {
     if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_set_ground_heightfield: null sim");
     if (s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_set_ground_heightfield: sim already prepared");
-    s->h_hf.clear();
+    s->h_hf.clear(); s->h_hf_mv.clear();
     if (!samples) return EMLOCO_OK;                                   // back to the plane
     if (nx < 2 || ny < 2 || !(horizontal_scale > 0.0f) || !(vertical_scale > 0.0f))
         return fail(EMLOCO_E_ARG, "emloco_sim_set_ground_heightfield: need a >= 2 x 2 grid and positive scales");
     s->h_hf.assign(samples, samples + (size_t)nx * (size_t)ny);
     s->hf_nx = nx; s->hf_ny = ny; s->hf_hs = horizontal_scale; s->hf_vs = vertical_scale; s->hf_ox = origin_x; s->hf_oy = origin_y;
+    return EMLOCO_OK;
+}
+
+int emloco_sim_set_ground_mesh_moves(EmlocoSim *s, const int8_t *move_x, const int8_t *move_y) {
+    if (!s) return fail(EMLOCO_E_ARG, "emloco_sim_set_ground_mesh_moves: null sim");
+    if (s->prepared) return fail(EMLOCO_E_STATE, "emloco_sim_set_ground_mesh_moves: sim already prepared");
+    s->h_hf_mv.clear();
+    if (!move_x && !move_y) return EMLOCO_OK;
+    if (!move_x || !move_y) return fail(EMLOCO_E_ARG, "emloco_sim_set_ground_mesh_moves: need both move arrays (or neither)");
+    if (s->h_hf.empty()) return fail(EMLOCO_E_STATE, "emloco_sim_set_ground_mesh_moves: set the height field first");
+    const int nx = s->hf_nx, ny = s->hf_ny;
+    std::vector<uint8_t> mv((size_t)nx * ny);
+    bool any = false;
+    for (size_t k = 0; k < mv.size(); ++k) {
+        const int mx = move_x[k], my = move_y[k];
+        if (mx < -1 || mx > 1 || my < -1 || my > 1) return fail(EMLOCO_E_ARG, "emloco_sim_set_ground_mesh_moves: a move must be -1, 0 or +1 cells");
+        any = any || mx != 0 || my != 0;
+        mv[k] = (uint8_t)((mx + 1) | ((my + 1) << 2));
+    }
+    if (!any) return EMLOCO_OK;                                      // an uncorrected mesh: the regular-grid path
+    // bit 4 of sample (i, j): some vertex of the block (i - 1 .. i + 2) x (j - 1 .. j + 2) moved -- lookups from cell (i, j) take the mesh path
+    for (int i = 0; i < nx; ++i)
+        for (int j = 0; j < ny; ++j) {
+            bool f = false;
+            for (int a = i - 1; a <= i + 2 && !f; ++a)
+                for (int b = j - 1; b <= j + 2 && !f; ++b)
+                    if (a >= 0 && a < nx && b >= 0 && b < ny && (mv[(size_t)a * ny + b] & 15) != 5) f = true;
+            if (f) mv[(size_t)i * ny + j] |= 16;
+        }
+    s->h_hf_mv.swap(mv);
     return EMLOCO_OK;
 }
 
@@ -208,11 +238,16 @@ int emloco_sim_prepare(EmlocoSim *s) {
         d.sc_nseg = s->sc_nseg;
         d.sc_k = s->sc_k; d.sc_c = s->sc_c; d.sc_max_pen = s->sc_max_pen; d.sc_mu = s->sc_mu;
     }
-    d.hf = nullptr;
+    d.hf = nullptr; d.hf_mv = nullptr;
     if (!s->h_hf.empty()) {
         HIPCHK(s->d_hf.upload(s->h_hf.data(), s->h_hf.size()));
         d.hf = s->d_hf.p; d.hf_nx = s->hf_nx; d.hf_ny = s->hf_ny;
         d.hf_hs = s->hf_hs; d.hf_inv_hs = 1.0f / s->hf_hs; d.hf_vs = s->hf_vs; d.hf_ox = s->hf_ox; d.hf_oy = s->hf_oy; d.hf_pad_ = 0.0f;
+        d.hf_mv = nullptr;
+        if (s->h_hf_mv.size() == s->h_hf.size()) {
+            HIPCHK(s->d_hf_mv.upload(s->h_hf_mv.data(), s->h_hf_mv.size()));
+            d.hf_mv = s->d_hf_mv.p;
+        }
     }
     HIPCHK(hipDeviceSynchronize());
     s->prepared = true;

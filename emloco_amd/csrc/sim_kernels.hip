@@ -160,6 +160,135 @@ __device__ __forceinline__ int hf_triangle(const EmlocoSimDev &d, float cx, floa
     return ((i << 15) + j) * 2 + (u >= v ? 1 : 0);
 }
 
+// ---- the slope-corrected mesh (terrain_utils.convert_heightfield_to_trimesh with a slope threshold, built by the task at
+// humanoid_pedestrain_terrain.py:859-881): where the step between two neighbouring samples exceeds the threshold the LOWER vertex
+// sits one cell sideways, under the upper one -- the cell between them is a vertical face (a stair riser), the cell on the low
+// side is stretched.  d.hf_mv carries the moves; xy in grid units (integers as floats), z in metres.
+struct MeshV { float x, y, z; };
+__device__ __forceinline__ MeshV mesh_vert(const EmlocoSimDev &d, int ci, int cj) {
+    const long k = (long)ci * d.hf_ny + cj;
+    const int b = d.hf_mv[k];
+    MeshV v;
+    v.x = (float)(ci + (b & 3) - 1); v.y = (float)(cj + ((b >> 2) & 3) - 1); v.z = d.hf_vs * (float)d.hf[k];
+    return v;
+}
+// cell (ci, cj), triangle t: t = 0 (v00, v10, v11) [id half 1], t = 1 (v00, v11, v01) [id half 0]: the mesh's winding, normals out of the solid
+__device__ __forceinline__ void mesh_tri(const EmlocoSimDev &d, int ci, int cj, int t, MeshV &A, MeshV &B, MeshV &Cc) {
+    A = mesh_vert(d, ci, cj);
+    if (t == 0) { B = mesh_vert(d, ci + 1, cj); Cc = mesh_vert(d, ci + 1, cj + 1); }
+    else { B = mesh_vert(d, ci + 1, cj + 1); Cc = mesh_vert(d, ci, cj + 1); }
+}
+// The mesh surface under the world point (cx, cy): the highest of the (at most 18) triangles of the 3 x 3 cells around the point's
+// regular cell that cover it.  Cells whose 4 x 4 vertex block carries no move take the regular-grid formula (bit-equal to the
+// uncorrected height field), and so do points no triangle covers (beyond the map).
+__device__ __noinline__ void mesh_plane(const EmlocoSimDev &d, float cx, float cy, float &zt, float n[3], int &id) {
+    if (!d.hf_mv) { hf_plane(d, cx, cy, zt, n, id); return; }
+    const float gx = (cx - d.hf_ox) * d.hf_inv_hs, gy = (cy - d.hf_oy) * d.hf_inv_hs;
+    int i = (int)floorf(gx), j = (int)floorf(gy);
+    i = i < 0 ? 0 : (i > d.hf_nx - 2 ? d.hf_nx - 2 : i);
+    j = j < 0 ? 0 : (j > d.hf_ny - 2 ? d.hf_ny - 2 : j);
+    if (!(d.hf_mv[(long)i * d.hf_ny + j] & 16)) { hf_plane(d, cx, cy, zt, n, id); return; }
+    bool found = false;
+    int bid = 0;
+    float bz = 0.0f, bsx = 0.0f, bsy = 0.0f;
+    for (int a = -1; a <= 1; ++a) {
+        const int ci = i + a;
+        if (ci < 0 || ci > d.hf_nx - 2) continue;
+        for (int b = -1; b <= 1; ++b) {
+            const int cj = j + b;
+            if (cj < 0 || cj > d.hf_ny - 2) continue;
+            for (int t = 0; t < 2; ++t) {
+                MeshV A, B, Cc;
+                mesh_tri(d, ci, cj, t, A, B, Cc);
+                const float bx = B.x - A.x, by = B.y - A.y, qx = Cc.x - A.x, qy = Cc.y - A.y;
+                const float ar = bx * qy - by * qx;
+                if (ar == 0.0f) continue;                                   // collapsed: a vertical face, see mesh_walls
+                const float px = gx - A.x, py = gy - A.y;
+                const float eb = px * qy - py * qx, ec = bx * py - by * px;
+                const bool in = ar > 0.0f ? (eb >= 0.0f && ec >= 0.0f && eb + ec <= ar) : (eb <= 0.0f && ec <= 0.0f && eb + ec >= ar);
+                if (!in) continue;
+                const float zb = B.z - A.z, zc = Cc.z - A.z;
+                const float sx = (zb * qy - zc * by) / ar, sy = (zc * bx - zb * qx) / ar;
+                const float z = fmaf(py, sy, fmaf(px, sx, A.z));
+                if (!found || z > bz) { found = true; bz = z; bsx = sx; bsy = sy; bid = ((ci << 15) + cj) * 2 + (t == 0 ? 1 : 0); }
+            }
+        }
+    }
+    if (!found) { hf_plane(d, cx, cy, zt, n, id); return; }
+    zt = bz; id = bid;
+    const float sx = bsx * d.hf_inv_hs, sy = bsy * d.hf_inv_hs;
+    const float inv = 1.0f / sqrtf(fmaf(sx, sx, fmaf(sy, sy, 1.0f)));
+    n[0] = 0.0f - sx * inv; n[1] = 0.0f - sy * inv; n[2] = inv;
+}
+__device__ __forceinline__ float dot3f(const float *a, const float *b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+// The vertical faces of the mesh near the world point P (centre of a contact sphere): every collapsed triangle of the 3 x 3 cells
+// around P's regular cell, closest point by regions (vertex, edge, face).  dsel / nsel hold the signed distance of P to the nearest
+// surface found so far and its normal (>= 0: P is outside the terrain solid).  Outside: a face P is in front of wins when it is
+// nearer, normal from its closest point to P.  Inside: a face P is behind wins when the foot of P's perpendicular lies in it and
+// it is nearer than the surface above, normal = the face's.
+__device__ __noinline__ void mesh_walls(const EmlocoSimDev &d, const float P[3], float &dsel, float nsel[3]) {
+    const float gx = (P[0] - d.hf_ox) * d.hf_inv_hs, gy = (P[1] - d.hf_oy) * d.hf_inv_hs;
+    int i = (int)floorf(gx), j = (int)floorf(gy);
+    i = i < 0 ? 0 : (i > d.hf_nx - 2 ? d.hf_nx - 2 : i);
+    j = j < 0 ? 0 : (j > d.hf_ny - 2 ? d.hf_ny - 2 : j);
+    if (!(d.hf_mv[(long)i * d.hf_ny + j] & 16)) return;
+    for (int a = -1; a <= 1; ++a) {
+        const int ci = i + a;
+        if (ci < 0 || ci > d.hf_nx - 2) continue;
+        for (int b = -1; b <= 1; ++b) {
+            const int cj = j + b;
+            if (cj < 0 || cj > d.hf_ny - 2) continue;
+            for (int t = 0; t < 2; ++t) {
+                MeshV A, B, Cc;
+                mesh_tri(d, ci, cj, t, A, B, Cc);
+                if ((B.x - A.x) * (Cc.y - A.y) - (B.y - A.y) * (Cc.x - A.x) != 0.0f) continue;
+                // corners relative to P, metres
+                const float va[3] = {fmaf(A.x, d.hf_hs, d.hf_ox) - P[0], fmaf(A.y, d.hf_hs, d.hf_oy) - P[1], A.z - P[2]};
+                const float vb[3] = {fmaf(B.x, d.hf_hs, d.hf_ox) - P[0], fmaf(B.y, d.hf_hs, d.hf_oy) - P[1], B.z - P[2]};
+                const float vc[3] = {fmaf(Cc.x, d.hf_hs, d.hf_ox) - P[0], fmaf(Cc.y, d.hf_hs, d.hf_oy) - P[1], Cc.z - P[2]};
+                const float ab[3] = {vb[0] - va[0], vb[1] - va[1], vb[2] - va[2]}, ac[3] = {vc[0] - va[0], vc[1] - va[1], vc[2] - va[2]};
+                const float fn[3] = {ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0]};
+                const float fn2 = dot3f(fn, fn);
+                if (fn2 == 0.0f) continue;                                  // no area in space either
+                // closest point q of the triangle to the origin (= P), by regions
+                const float ap[3] = {0.0f - va[0], 0.0f - va[1], 0.0f - va[2]}, bp[3] = {0.0f - vb[0], 0.0f - vb[1], 0.0f - vb[2]};
+                const float cp[3] = {0.0f - vc[0], 0.0f - vc[1], 0.0f - vc[2]};
+                const float d1 = dot3f(ab, ap), d2 = dot3f(ac, ap), d3 = dot3f(ab, bp), d4 = dot3f(ac, bp), d5 = dot3f(ab, cp), d6 = dot3f(ac, cp);
+                float q[3];
+                bool face = false;
+                const float vcc = d1 * d4 - d3 * d2, vbb = d5 * d2 - d1 * d6, vaa = d3 * d6 - d5 * d4;
+                if (d1 <= 0.0f && d2 <= 0.0f) { q[0] = va[0]; q[1] = va[1]; q[2] = va[2]; }
+                else if (d3 >= 0.0f && d4 <= d3) { q[0] = vb[0]; q[1] = vb[1]; q[2] = vb[2]; }
+                else if (vcc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) { const float w = d1 / (d1 - d3); for (int k = 0; k < 3; ++k) q[k] = fmaf(w, ab[k], va[k]); }
+                else if (d6 >= 0.0f && d5 <= d6) { q[0] = vc[0]; q[1] = vc[1]; q[2] = vc[2]; }
+                else if (vbb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) { const float w = d2 / (d2 - d6); for (int k = 0; k < 3; ++k) q[k] = fmaf(w, ac[k], va[k]); }
+                else if (vaa <= 0.0f && d4 - d3 >= 0.0f && d5 - d6 >= 0.0f) {
+                    const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+                    for (int k = 0; k < 3; ++k) q[k] = fmaf(w, vc[k] - vb[k], vb[k]);
+                } else {
+                    const float den = 1.0f / (vaa + vbb + vcc), v = vbb * den, w = vcc * den;
+                    for (int k = 0; k < 3; ++k) q[k] = fmaf(w, ac[k], fmaf(v, ab[k], va[k]));
+                    face = true;
+                }
+                const float dv[3] = {0.0f - q[0], 0.0f - q[1], 0.0f - q[2]};
+                const float side = dot3f(dv, fn);
+                const float ifn = 1.0f / sqrtf(fn2);
+                if (dsel >= 0.0f) {
+                    const float dist = sqrtf(dot3f(dv, dv));
+                    if (side >= 0.0f && dist < dsel) {
+                        dsel = dist;
+                        if (dist > 1.0e-6f) { const float id_ = 1.0f / dist; for (int k = 0; k < 3; ++k) nsel[k] = dv[k] * id_; }
+                        else for (int k = 0; k < 3; ++k) nsel[k] = fn[k] * ifn;
+                    }
+                } else if (side < 0.0f && face) {
+                    const float dw = side * ifn;
+                    if (dw > dsel) { dsel = dw; for (int k = 0; k < 3; ++k) nsel[k] = fn[k] * ifn; }
+                }
+            }
+        }
+    }
+}
+
 #ifndef EMLOCO_SIM_WAVES_PER_SIMD
 #define EMLOCO_SIM_WAVES_PER_SIMD 3   /* register budget 168 per lane and 12.4 KB of LDS per env: three resident waves per SIMD, 12 envs per CU */
 #endif
@@ -911,18 +1040,24 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                     float zt, cnrm[3];
                     int tid0;
                     const float pcx = sh_pq[body][0] + wp[0], pcy = sh_pq[body][1] + wp[1];
-                    hf_plane(d, pcx, pcy, zt, cnrm, tid0);
+                    mesh_plane(d, pcx, pcy, zt, cnrm, tid0);
                     float dperp = (z - zt) * cnrm[2];
                     if (crad > 0.0f)
                         for (int q = 0; q < 4; ++q) {
                             const float ex = q == 0 ? crad : (q == 1 ? 0.0f - crad : 0.0f), ey = q == 2 ? crad : (q == 3 ? 0.0f - crad : 0.0f);
                             float ztq, nq[3];
                             int tidq;
-                            hf_plane(d, pcx + ex, pcy + ey, ztq, nq, tidq);
+                            mesh_plane(d, pcx + ex, pcy + ey, ztq, nq, tidq);
                             const float dq = fmaf(z - ztq, nq[2], 0.0f - fmaf(ex, nq[0], ey * nq[1]));
-                            const int tidf = hf_triangle(d, pcx - dq * nq[0], pcy - dq * nq[1]);
+                            int tidf;
+                            if (d.hf_mv) { float zf, nf[3]; mesh_plane(d, pcx - dq * nq[0], pcy - dq * nq[1], zf, nf, tidf); }
+                            else tidf = hf_triangle(d, pcx - dq * nq[0], pcy - dq * nq[1]);
                             if (tidq != tid0 && tidf == tidq && dq < dperp) { dperp = dq; cnrm[0] = nq[0]; cnrm[1] = nq[1]; cnrm[2] = nq[2]; }
                         }
+                    if (d.hf_mv) {                                   // the corrected mesh's vertical faces
+                        const float P[3] = {pcx, pcy, z};
+                        mesh_walls(d, P, dperp, cnrm);
+                    }
                     cdist[s] = dperp - crad;
                     for (int k2 = 0; k2 < 3; ++k2) { cxw[k2] = (sh_R[body][9 + k2] + wp[k2]) - crad * cnrm[k2]; stg[3 + k2] = cnrm[k2]; }
                 }
@@ -972,14 +1107,22 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
                     const float *stg = sh_stage + (lane + 64 * s) * 7;      // this lane's own entry: no other lane touches it
                     sh_cbody[ci] = (unsigned char)cb[s]; sh_cdist[ci] = cdist[s];
                     for (int k = 0; k < 3; ++k) { sh_cx[ci][k] = stg[k]; sh_lam[3 * ci + k] = wl[s][k]; }
-                    if (hf_on) {      // frame: normal, t1 = (y x n) / |y x n|, t2 = n x t1  (n_z > 0 on a height field)
+                    if (hf_on) {      // frame: normal, t1 = (y x n) / |y x n|, t2 = n x t1
                         const float n[3] = {stg[3], stg[4], stg[5]};
-                        const float il = 1.0f / sqrtf(fmaf(n[2], n[2], n[0] * n[0]));
-                        const float t1x = n[2] * il, t1z = 0.0f - n[0] * il;
+                        const float l2 = fmaf(n[2], n[2], n[0] * n[0]);
                         float *D = sh_cdir[ci];
                         D[0] = n[0]; D[1] = n[1]; D[2] = n[2];
-                        D[3] = t1x; D[4] = 0.0f; D[5] = t1z;
-                        D[6] = n[1] * t1z; D[7] = fmaf(n[2], t1x, -(n[0] * t1z)); D[8] = 0.0f - n[1] * t1x;
+                        if (l2 >= 0.1f) {
+                            const float il = 1.0f / sqrtf(l2);
+                            const float t1x = n[2] * il, t1z = 0.0f - n[0] * il;
+                            D[3] = t1x; D[4] = 0.0f; D[5] = t1z;
+                            D[6] = n[1] * t1z; D[7] = fmaf(n[2], t1x, -(n[0] * t1z)); D[8] = 0.0f - n[1] * t1x;
+                        } else {      // a face looking along y (a riser across the y axis): t1 = (n x x) / |n x x|, t2 = n x t1
+                            const float il = 1.0f / sqrtf(fmaf(n[2], n[2], n[1] * n[1]));
+                            const float t1y = n[2] * il, t1z = 0.0f - n[1] * il;
+                            D[3] = 0.0f; D[4] = t1y; D[5] = t1z;
+                            D[6] = fmaf(n[1], t1z, -(n[2] * t1y)); D[7] = 0.0f - n[0] * t1z; D[8] = n[0] * t1y;
+                        }
                     }
                 }
             }

@@ -32,9 +32,11 @@ struct EmlocoSim {
     float sc_k = 0.0f, sc_c = 0.0f, sc_max_pen = 0.0f, sc_mu = 0.0f;
     // optional height-field ground (host copy until prepare())
     std::vector<short> h_hf;
+    std::vector<uint8_t> h_hf_mv;      // packed vertex moves of the slope-corrected mesh (emloco_types.h: hf_mv), empty: none
     int hf_nx = 0, hf_ny = 0;
     float hf_hs = 0.0f, hf_vs = 0.0f, hf_ox = 0.0f, hf_oy = 0.0f;
     DevBuf<short> d_hf;
+    DevBuf<unsigned char> d_hf_mv;
     // device
     DevBuf<int> d_topo;                        // EMLOCO_TOPO_* tables
     DevBuf<float> d_model;                     // EMLOCO_MB_* records, one block per env

@@ -252,6 +252,17 @@ class Gym:
         hf["samples"] = np.ascontiguousarray(hf["samples"], dtype=np.int16)
         if hf["samples"].size != v.shape[0]:
             raise ValueError("params.heightfield does not match the mesh: %d samples vs %d vertices" % (hf["samples"].size, v.shape[0]))
+        if hf.get("move_x") is None and os.environ.get("EMLOCO_TERRAIN_RISERS", "1") != "0":
+            # the slope-corrected mesh (convert_heightfield_to_trimesh(slope_threshold)): read the whole-cell vertex moves back from
+            # the vertices so that the simulator collides with THIS mesh -- vertical risers -- not with the raw grid's one-cell ramps
+            from .terrain_utils import mesh_vertex_moves
+            try:
+                mx, my = mesh_vertex_moves(v, hf["samples"].shape, hf["horizontal_scale"],
+                                           (float(hf.get("origin_x", 0.0)), float(hf.get("origin_y", 0.0))))
+            except ValueError as e:
+                raise NotImplementedError("emloco: the mesh is not the height field's (regular or slope-corrected) mesh: %s" % e)
+            if mx.any() or my.any():
+                hf["move_x"], hf["move_y"] = mx, my
         hf["origin_x"] = float(hf.get("origin_x", 0.0)) + float(params.transform.p.x)
         hf["origin_y"] = float(hf.get("origin_y", 0.0)) + float(params.transform.p.y)
         sim.heightfield = hf

@@ -193,3 +193,19 @@ def convert_heightfield_to_trimesh(height_field_raw, horizontal_scale, vertical_
     triangles[0::2] = np.stack([a, d, b], 1)
     triangles[1::2] = np.stack([a, c, d], 1)
     return vertices, triangles
+
+
+def mesh_vertex_moves(vertices, shape, horizontal_scale, origin=(0.0, 0.0)):
+    """The slope correction of `convert_heightfield_to_trimesh` read back from a mesh: how many cells (-1, 0, +1) vertex (i, j)
+    sits away from its grid position (i, j) * horizontal_scale + origin along x and y.  Returns (move_x, move_y) int8 [rows][cols];
+    raises when the mesh is not a height-field mesh whose vertices moved by whole cells (`add_triangle_mesh` hands these to the
+    simulator, which collides with the corrected mesh: `emloco_sim_set_ground_mesh_moves`)."""
+    rows, cols = shape
+    v = np.asarray(vertices, dtype=np.float64).reshape(rows, cols, 3)
+    gx, gy = np.meshgrid(np.arange(rows) * float(horizontal_scale), np.arange(cols) * float(horizontal_scale), indexing="ij")
+    fx = (v[:, :, 0] - origin[0] - gx) / float(horizontal_scale)
+    fy = (v[:, :, 1] - origin[1] - gy) / float(horizontal_scale)
+    mx, my = np.rint(fx), np.rint(fy)
+    if np.abs(fx - mx).max() > 1e-3 or np.abs(fy - my).max() > 1e-3 or np.abs(mx).max() > 1 or np.abs(my).max() > 1:
+        raise ValueError("not a height-field mesh with whole-cell vertex moves")
+    return mx.astype(np.int8), my.astype(np.int8)

@@ -48,7 +48,8 @@ class NativeSim:
         """`self_collision`: None / False = off; True = limb-limb contacts with the defaults of
         `model.pack_self_collision`; a dict from `pack_self_collision(models, ...)` to choose the parameters.
         `heightfield`: None = the plane z = params.ground_z; dict(samples int16 [nx][ny], horizontal_scale, vertical_scale,
-        origin_x=0, origin_y=0) = height-field ground (emloco_sim_set_ground_heightfield)."""
+        origin_x=0, origin_y=0[, move_x, move_y int8 [nx][ny]]) = height-field ground (emloco_sim_set_ground_heightfield); with the
+        vertex moves of the slope-corrected mesh (terrain_utils.mesh_vertex_moves) its vertical faces collide too."""
         lib = L.require_device()
         self.lib = lib
         self.device_index = int(device_index)
@@ -94,6 +95,13 @@ class NativeSim:
                 self._h, hf.ctypes.data, hf.shape[0], hf.shape[1], float(heightfield["horizontal_scale"]),
                 float(heightfield["vertical_scale"]), float(heightfield.get("origin_x", 0.0)),
                 float(heightfield.get("origin_y", 0.0))), "emloco_sim_set_ground_heightfield")
+            if heightfield.get("move_x") is not None:          # the slope-corrected mesh: its vertical faces collide
+                mx = np.ascontiguousarray(heightfield["move_x"], dtype=np.int8)
+                my = np.ascontiguousarray(heightfield["move_y"], dtype=np.int8)
+                if mx.shape != hf.shape or my.shape != hf.shape:
+                    raise L.EmlocoError("heightfield move_x / move_y must have the samples' shape")
+                lib.emloco_sim_set_ground_mesh_moves.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+                L.check(lib.emloco_sim_set_ground_mesh_moves(self._h, mx.ctypes.data, my.ctypes.data), "emloco_sim_set_ground_mesh_moves")
         L.check(lib.emloco_sim_prepare(self._h), "emloco_sim_prepare")
         self.root_state = self._tensor(L.T_ROOT_STATE)
         self.dof_state = self._tensor(L.T_DOF_STATE)

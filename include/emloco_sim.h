@@ -133,6 +133,16 @@ int emloco_sim_set_self_collision(EmlocoSim *sim, const EmlocoSelfCollisionDesc 
  * plane whose perpendicular foot lies in its own triangle wins: a neighbouring face is met when the sphere's surface reaches it).  NULL samples restore the plane z = ground_z.  Call before emloco_sim_prepare. */
 int emloco_sim_set_ground_heightfield(EmlocoSim *sim, const int16_t *samples, int nx, int ny, float horizontal_scale,
                                       float vertical_scale, float origin_x, float origin_y);
+/* The SLOPE-CORRECTED terrain mesh -- terrain_utils.py:313-325 (convert_heightfield_to_trimesh with slope_threshold, the mesh
+ * humanoid_pedestrain_terrain.py:859-881 hands to gym.add_triangle_mesh): where the step between two neighbouring samples exceeds the
+ * threshold the lower vertex sits one cell sideways, under the upper one, so a stair riser is a vertical face.  `move_x`, `move_y`
+ * [nx][ny]: how many cells (-1, 0, +1) vertex (i, j) of the mesh sits away from its grid position along x / y (host pointers, copied;
+ * both NULL: none).  Call after emloco_sim_set_ground_heightfield and before emloco_sim_prepare.  With moves set a contact sphere is
+ * tested against the mesh triangle that covers its centre (highest of the 3 x 3 cells' triangles; cells without a moved vertex nearby
+ * keep the regular-grid formula bit for bit), the four probed triangles, and the mesh's vertical faces (closest point by vertex / edge /
+ * face regions); still ONE contact per candidate: the nearest surface on the centre's side -- outside the solid the nearest face in
+ * front of the centre, inside it (a box corner that crossed a riser) the nearest face behind it. */
+int emloco_sim_set_ground_mesh_moves(EmlocoSim *sim, const int8_t *move_x, const int8_t *move_y);
 int emloco_sim_prepare(EmlocoSim *sim);
 /* gym.get_sim_params / set_sim_params -- base_task.py:151 */
 int emloco_sim_get_params(EmlocoSim *sim, EmlocoSimParams *out);

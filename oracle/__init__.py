@@ -72,7 +72,24 @@ class Model(C.Structure):
                 ("sc_cap_b", C.POINTER(C.c_float)), ("sc_cap_r", C.POINTER(C.c_float)), ("sc_k", C.c_float), ("sc_c", C.c_float),
                 ("sc_max_pen", C.c_float), ("sc_mu", C.c_float), ("sc_nseg", C.c_int32), ("sc_segbody", C.POINTER(C.c_uint8)),
                 ("hf", C.POINTER(C.c_int16)), ("hf_nx", C.c_int32), ("hf_ny", C.c_int32), ("hf_hs", C.c_float), ("hf_vs", C.c_float),
-                ("hf_ox", C.c_float), ("hf_oy", C.c_float)]
+                ("hf_ox", C.c_float), ("hf_oy", C.c_float), ("hf_mv", C.POINTER(C.c_uint8))]
+
+
+def pack_mesh_moves(move_x, move_y):
+    """Vertex moves of the slope-corrected terrain mesh (terrain_utils.py:313-325), each -1 / 0 / +1 cells, as the byte per
+    sample oracle_sim.h: hf_mv describes: bits 0-1 move_x + 1, bits 2-3 move_y + 1, bit 4 = some vertex of the 4 x 4 block
+    (i - 1 .. i + 2, j - 1 .. j + 2) around cell (i, j) moved."""
+    mx, my = np.asarray(move_x).astype(np.int64), np.asarray(move_y).astype(np.int64)
+    assert mx.shape == my.shape and mx.ndim == 2 and np.abs(mx).max() <= 1 and np.abs(my).max() <= 1
+    moved = ((mx != 0) | (my != 0))
+    nx, ny = mx.shape
+    pad = np.zeros((nx + 3, ny + 3), bool)
+    pad[1:nx + 1, 1:ny + 1] = moved
+    flag = np.zeros((nx, ny), bool)
+    for a in range(4):
+        for b in range(4):
+            flag |= pad[a:a + nx, b:b + ny]
+    return np.ascontiguousarray((mx + 1) | ((my + 1) << 2) | (flag.astype(np.int64) << 4), dtype=np.uint8)
 
 
 class Sim:
@@ -108,6 +125,10 @@ class Sim:
             self.model.hf_nx, self.model.hf_ny = self.hf.shape
             self.model.hf_hs, self.model.hf_vs = float(heightfield["horizontal_scale"]), float(heightfield["vertical_scale"])
             self.model.hf_ox, self.model.hf_oy = float(heightfield.get("origin_x", 0.0)), float(heightfield.get("origin_y", 0.0))
+            if heightfield.get("move_x") is not None:
+                self.hf_mv = pack_mesh_moves(heightfield["move_x"], heightfield["move_y"])
+                assert self.hf_mv.shape == self.hf.shape
+                self.model.hf_mv = _p(self.hf_mv, C.c_uint8)
         E = self.E
         self.root_state = np.zeros((E, 13), np.float32)
         self.root_state[:, 6] = 1.0

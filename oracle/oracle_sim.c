@@ -163,6 +163,7 @@ typedef struct {
     const int16_t *hf;
     int hf_nx, hf_ny;
     float hf_hs, hf_inv_hs, hf_vs, hf_ox, hf_oy;
+    const uint8_t *hf_mv;
 } EnvModel;
 
 static EnvModel env_model(const OrcModel *m, int e) {
@@ -175,6 +176,7 @@ static EnvModel env_model(const OrcModel *m, int e) {
     x.arm = m->armature + (long)e * ORC_NDOF; x.eff = m->effort + (long)e * ORC_NDOF;
     x.hf = m->hf; x.hf_nx = m->hf_nx; x.hf_ny = m->hf_ny; x.hf_hs = m->hf_hs; x.hf_vs = m->hf_vs; x.hf_ox = m->hf_ox; x.hf_oy = m->hf_oy;
     x.hf_inv_hs = m->hf ? 1.0f / m->hf_hs : 0.0f;
+    x.hf_mv = m->hf ? m->hf_mv : 0;
     x.sc_n = m->sc_n; x.sc_pairs = m->sc_pairs; x.sc_k = m->sc_k; x.sc_c = m->sc_c; x.sc_max_pen = m->sc_max_pen; x.sc_mu = m->sc_mu;
     x.sc_nseg = (m->sc_nseg > 0 && m->sc_segbody) ? m->sc_nseg : NB;
     x.sc_segbody = (m->sc_nseg > 0) ? m->sc_segbody : 0;
@@ -740,6 +742,139 @@ static int hf_triangle(const EnvModel *m, float cx, float cy) {
     return ((i << 15) + j) * 2 + (u >= v ? 1 : 0);
 }
 
+
+/* ---- the slope-corrected mesh (terrain_utils.py:313-325; built by the task at humanoid_pedestrain_terrain.py:859-881) ----
+ * Where the height step between two neighbouring samples exceeds the slope threshold the LOWER vertex is moved one cell
+ * sideways, under the upper one: the cell between them collapses to a vertical face (a stair riser), the cell on the low
+ * side stretches.  hf_mv carries the moves; xy below are in grid units (integers as floats), z in metres. */
+typedef struct { float x, y, z; } MeshV;
+static MeshV mesh_vert(const EnvModel *m, int ci, int cj) {
+    long k = (long)ci * m->hf_ny + cj;
+    int b = m->hf_mv[k];
+    MeshV v;
+    v.x = (float)(ci + (b & 3) - 1); v.y = (float)(cj + ((b >> 2) & 3) - 1); v.z = m->hf_vs * (float)m->hf[k];
+    return v;
+}
+/* cell (ci, cj), triangle t: t = 0 (v00, v10, v11) [id half 1], t = 1 (v00, v11, v01) [id half 0] -- the mesh's winding, normals out
+ * of the solid */
+static void mesh_tri(const EnvModel *m, int ci, int cj, int t, MeshV *A, MeshV *B, MeshV *Cc) {
+    *A = mesh_vert(m, ci, cj);
+    if (t == 0) { *B = mesh_vert(m, ci + 1, cj); *Cc = mesh_vert(m, ci + 1, cj + 1); }
+    else { *B = mesh_vert(m, ci + 1, cj + 1); *Cc = mesh_vert(m, ci, cj + 1); }
+}
+
+/* the mesh surface under the world point (cx, cy): the highest of the (at most 18) triangles of the 3 x 3 cells around the point's
+ * regular cell that cover it; cells whose 4 x 4 vertex block carries no move take the regular-grid formula (bit-equal to the
+ * uncorrected height field), and so do points no triangle covers (beyond the map) */
+static void mesh_plane(const EnvModel *m, float cx, float cy, float *zt, float *n, int *id) {
+    if (!m->hf_mv) { hf_plane(m, cx, cy, zt, n, id); return; }
+    float gx = (cx - m->hf_ox) * m->hf_inv_hs, gy = (cy - m->hf_oy) * m->hf_inv_hs;
+    int i = (int)floorf(gx), j = (int)floorf(gy);
+    i = i < 0 ? 0 : (i > m->hf_nx - 2 ? m->hf_nx - 2 : i);
+    j = j < 0 ? 0 : (j > m->hf_ny - 2 ? m->hf_ny - 2 : j);
+    if (!(m->hf_mv[(long)i * m->hf_ny + j] & 16)) { hf_plane(m, cx, cy, zt, n, id); return; }
+    int found = 0, bid = 0;
+    float bz = 0.0f, bsx = 0.0f, bsy = 0.0f;
+    for (int a = -1; a <= 1; ++a) {
+        int ci = i + a;
+        if (ci < 0 || ci > m->hf_nx - 2) continue;
+        for (int b = -1; b <= 1; ++b) {
+            int cj = j + b;
+            if (cj < 0 || cj > m->hf_ny - 2) continue;
+            for (int t = 0; t < 2; ++t) {
+                MeshV A, B, Cc;
+                mesh_tri(m, ci, cj, t, &A, &B, &Cc);
+                float bx = B.x - A.x, by = B.y - A.y, qx = Cc.x - A.x, qy = Cc.y - A.y;
+                float ar = bx * qy - by * qx;
+                if (ar == 0.0f) continue;                                   /* collapsed: a vertical face, see mesh_walls */
+                float px = gx - A.x, py = gy - A.y;
+                float eb = px * qy - py * qx, ec = bx * py - by * px;
+                int in = ar > 0.0f ? (eb >= 0.0f && ec >= 0.0f && eb + ec <= ar) : (eb <= 0.0f && ec <= 0.0f && eb + ec >= ar);
+                if (!in) continue;
+                float zb = B.z - A.z, zc = Cc.z - A.z;
+                float sx = (zb * qy - zc * by) / ar, sy = (zc * bx - zb * qx) / ar;
+                float z = fmaf(py, sy, fmaf(px, sx, A.z));
+                if (!found || z > bz) { found = 1; bz = z; bsx = sx; bsy = sy; bid = ((ci << 15) + cj) * 2 + (t == 0 ? 1 : 0); }
+            }
+        }
+    }
+    if (!found) { hf_plane(m, cx, cy, zt, n, id); return; }
+    *zt = bz; *id = bid;
+    float sx = bsx * m->hf_inv_hs, sy = bsy * m->hf_inv_hs;
+    float inv = 1.0f / sqrtf(fmaf(sx, sx, fmaf(sy, sy, 1.0f)));
+    n[0] = 0.0f - sx * inv; n[1] = 0.0f - sy * inv; n[2] = inv;
+}
+
+static float dot3f(const float *a, const float *b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+
+/* the vertical faces of the mesh near the world point P (centre of a contact sphere): every collapsed triangle of the 3 x 3 cells
+ * around P's regular cell, closest point by regions (vertex, edge, face).  *dsel / nsel hold the signed distance of P to the
+ * nearest surface found so far and its normal (>= 0: P is outside the terrain solid).  Outside: a face P is in front of wins when
+ * it is nearer, normal from its closest point to P.  Inside: a face P is behind wins when the foot of P's perpendicular lies
+ * in it and it is nearer than the surface above, normal = the face's. */
+static void mesh_walls(const EnvModel *m, const float *P, float *dsel, float *nsel) {
+    float gx = (P[0] - m->hf_ox) * m->hf_inv_hs, gy = (P[1] - m->hf_oy) * m->hf_inv_hs;
+    int i = (int)floorf(gx), j = (int)floorf(gy);
+    i = i < 0 ? 0 : (i > m->hf_nx - 2 ? m->hf_nx - 2 : i);
+    j = j < 0 ? 0 : (j > m->hf_ny - 2 ? m->hf_ny - 2 : j);
+    if (!(m->hf_mv[(long)i * m->hf_ny + j] & 16)) return;
+    for (int a = -1; a <= 1; ++a) {
+        int ci = i + a;
+        if (ci < 0 || ci > m->hf_nx - 2) continue;
+        for (int b = -1; b <= 1; ++b) {
+            int cj = j + b;
+            if (cj < 0 || cj > m->hf_ny - 2) continue;
+            for (int t = 0; t < 2; ++t) {
+                MeshV A, B, Cc;
+                mesh_tri(m, ci, cj, t, &A, &B, &Cc);
+                if ((B.x - A.x) * (Cc.y - A.y) - (B.y - A.y) * (Cc.x - A.x) != 0.0f) continue;
+                /* corners relative to P, metres */
+                float va[3] = {fmaf(A.x, m->hf_hs, m->hf_ox) - P[0], fmaf(A.y, m->hf_hs, m->hf_oy) - P[1], A.z - P[2]};
+                float vb[3] = {fmaf(B.x, m->hf_hs, m->hf_ox) - P[0], fmaf(B.y, m->hf_hs, m->hf_oy) - P[1], B.z - P[2]};
+                float vc[3] = {fmaf(Cc.x, m->hf_hs, m->hf_ox) - P[0], fmaf(Cc.y, m->hf_hs, m->hf_oy) - P[1], Cc.z - P[2]};
+                float ab[3] = {vb[0] - va[0], vb[1] - va[1], vb[2] - va[2]}, ac[3] = {vc[0] - va[0], vc[1] - va[1], vc[2] - va[2]};
+                float fn[3] = {ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0]};
+                float fn2 = dot3f(fn, fn);
+                if (fn2 == 0.0f) continue;                                  /* no area in space either */
+                /* closest point q of the triangle to the origin (= P), by regions */
+                float ap[3] = {0.0f - va[0], 0.0f - va[1], 0.0f - va[2]}, bp[3] = {0.0f - vb[0], 0.0f - vb[1], 0.0f - vb[2]};
+                float cp[3] = {0.0f - vc[0], 0.0f - vc[1], 0.0f - vc[2]};
+                float d1 = dot3f(ab, ap), d2 = dot3f(ac, ap), d3 = dot3f(ab, bp), d4 = dot3f(ac, bp), d5 = dot3f(ab, cp), d6 = dot3f(ac, cp);
+                float q[3];
+                int face = 0;
+                float vcc = d1 * d4 - d3 * d2, vbb = d5 * d2 - d1 * d6, vaa = d3 * d6 - d5 * d4;
+                if (d1 <= 0.0f && d2 <= 0.0f) { q[0] = va[0]; q[1] = va[1]; q[2] = va[2]; }
+                else if (d3 >= 0.0f && d4 <= d3) { q[0] = vb[0]; q[1] = vb[1]; q[2] = vb[2]; }
+                else if (vcc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) { float w = d1 / (d1 - d3); for (int k = 0; k < 3; ++k) q[k] = fmaf(w, ab[k], va[k]); }
+                else if (d6 >= 0.0f && d5 <= d6) { q[0] = vc[0]; q[1] = vc[1]; q[2] = vc[2]; }
+                else if (vbb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) { float w = d2 / (d2 - d6); for (int k = 0; k < 3; ++k) q[k] = fmaf(w, ac[k], va[k]); }
+                else if (vaa <= 0.0f && d4 - d3 >= 0.0f && d5 - d6 >= 0.0f) {
+                    float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+                    for (int k = 0; k < 3; ++k) q[k] = fmaf(w, vc[k] - vb[k], vb[k]);
+                } else {
+                    float den = 1.0f / (vaa + vbb + vcc), v = vbb * den, w = vcc * den;
+                    for (int k = 0; k < 3; ++k) q[k] = fmaf(w, ac[k], fmaf(v, ab[k], va[k]));
+                    face = 1;
+                }
+                float dv[3] = {0.0f - q[0], 0.0f - q[1], 0.0f - q[2]};
+                float side = dot3f(dv, fn);
+                float ifn = 1.0f / sqrtf(fn2);
+                if (*dsel >= 0.0f) {
+                    float dist = sqrtf(dot3f(dv, dv));
+                    if (side >= 0.0f && dist < *dsel) {
+                        *dsel = dist;
+                        if (dist > 1.0e-6f) { float id_ = 1.0f / dist; for (int k = 0; k < 3; ++k) nsel[k] = dv[k] * id_; }
+                        else for (int k = 0; k < 3; ++k) nsel[k] = fn[k] * ifn;
+                    }
+                } else if (side < 0.0f && face) {
+                    float dw = side * ifn;
+                    if (dw > *dsel) { *dsel = dw; for (int k = 0; k < 3; ++k) nsel[k] = fn[k] * ifn; }
+                }
+            }
+        }
+    }
+}
+
 static int find_contacts(const Env *s, const EnvModel *m, const OrcSimParams *prm, Contact *out) {
     Contact all[ORC_MAXCAND];
     int n = 0, cid = 0;
@@ -766,26 +901,40 @@ static int find_contacts(const Env *s, const EnvModel *m, const OrcSimParams *pr
                 float zt, nn[3];
                 int tid0;
                 float pcx = s->pw[b][0] + wp[0], pcy = s->pw[b][1] + wp[1];
-                hf_plane(m, pcx, pcy, &zt, nn, &tid0);
+                mesh_plane(m, pcx, pcy, &zt, nn, &tid0);
                 float dperp = (z - zt) * nn[2];
                 if (rad > 0.0f)
                     for (int q = 0; q < 4; ++q) {
                         float ex = q == 0 ? rad : (q == 1 ? 0.0f - rad : 0.0f), ey = q == 2 ? rad : (q == 3 ? 0.0f - rad : 0.0f);
                         float ztq, nq[3];
                         int tidq;
-                        hf_plane(m, pcx + ex, pcy + ey, &ztq, nq, &tidq);
+                        mesh_plane(m, pcx + ex, pcy + ey, &ztq, nq, &tidq);
                         float dq = fmaf(z - ztq, nq[2], 0.0f - fmaf(ex, nq[0], ey * nq[1]));
-                        int tidf = hf_triangle(m, pcx - dq * nq[0], pcy - dq * nq[1]);
+                        int tidf;
+                        if (m->hf_mv) { float zf, nf[3]; mesh_plane(m, pcx - dq * nq[0], pcy - dq * nq[1], &zf, nf, &tidf); }
+                        else tidf = hf_triangle(m, pcx - dq * nq[0], pcy - dq * nq[1]);
                         if (tidq != tid0 && tidf == tidq && dq < dperp) { dperp = dq; nn[0] = nq[0]; nn[1] = nq[1]; nn[2] = nq[2]; }
                     }
+                if (m->hf_mv) {                                  /* the corrected mesh's vertical faces */
+                    float P[3] = {pcx, pcy, z};
+                    mesh_walls(m, P, &dperp, nn);
+                }
                 dist = dperp - rad;
                 for (int k = 0; k < 3; ++k) c.x[k] = (s->r[b][k] + wp[k]) - rad * nn[k];
                 /* frame: normal, t1 = (y x n) / |y x n|, t2 = n x t1 */
-                float il = 1.0f / sqrtf(fmaf(nn[2], nn[2], nn[0] * nn[0]));
-                float t1x = nn[2] * il, t1z = 0.0f - nn[0] * il;
+                float l2 = fmaf(nn[2], nn[2], nn[0] * nn[0]);
                 c.D[0] = nn[0]; c.D[1] = nn[1]; c.D[2] = nn[2];
-                c.D[3] = t1x; c.D[4] = 0.0f; c.D[5] = t1z;
-                c.D[6] = nn[1] * t1z; c.D[7] = fmaf(nn[2], t1x, -(nn[0] * t1z)); c.D[8] = 0.0f - nn[1] * t1x;
+                if (l2 >= 0.1f) {
+                    float il = 1.0f / sqrtf(l2);
+                    float t1x = nn[2] * il, t1z = 0.0f - nn[0] * il;
+                    c.D[3] = t1x; c.D[4] = 0.0f; c.D[5] = t1z;
+                    c.D[6] = nn[1] * t1z; c.D[7] = fmaf(nn[2], t1x, -(nn[0] * t1z)); c.D[8] = 0.0f - nn[1] * t1x;
+                } else {              /* a face looking along y (a riser across the y axis): t1 = (n x x) / |n x x|, t2 = n x t1 */
+                    float il = 1.0f / sqrtf(fmaf(nn[2], nn[2], nn[1] * nn[1]));
+                    float t1y = nn[2] * il, t1z = 0.0f - nn[1] * il;
+                    c.D[3] = 0.0f; c.D[4] = t1y; c.D[5] = t1z;
+                    c.D[6] = fmaf(nn[1], t1z, -(nn[2] * t1y)); c.D[7] = 0.0f - nn[0] * t1z; c.D[8] = nn[0] * t1y;
+                }
             }
             if (dist < prm->contact_offset) {
                 c.body = b; c.cand = cid; c.dist = dist;

@@ -61,6 +61,10 @@ typedef struct {
     const int16_t *hf;         /* [hf_nx][hf_ny] in units of hf_vs metres on an hf_hs-metre grid, sample (0,0) at (hf_ox, hf_oy) */
     int32_t hf_nx, hf_ny;
     float hf_hs, hf_vs, hf_ox, hf_oy;
+    /* optional vertex moves of the slope-corrected mesh (terrain_utils.py:313-325), NULL: none.  One byte per sample: bits 0-1 =
+     * move along x + 1, bits 2-3 = move along y + 1 (each move -1, 0 or +1 cells), bit 4 = some vertex of the 4 x 4 block around
+     * cell (i, j) moved (the cell's lookups take the mesh path); mirrors emloco_sim_set_ground_mesh_moves */
+    const uint8_t *hf_mv;
 } OrcModel;
 
 /* one call = n_sub substeps for every env */

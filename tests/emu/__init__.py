@@ -81,12 +81,13 @@ def sim_step(osim, n_calls=1, expect_error=None):
     lib().emu_sim_set_self_collision(C.byref(scd) if scd is not None else None)
     hf = getattr(osim, "hf", None)
     fn = lib().emu_sim_set_heightfield
-    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
     if hf is not None:
         m = osim.model
-        fn(hf.ctypes.data, hf.shape[0], hf.shape[1], m.hf_hs, m.hf_vs, m.hf_ox, m.hf_oy)
+        mv = getattr(osim, "hf_mv", None)
+        fn(hf.ctypes.data, hf.shape[0], hf.shape[1], m.hf_hs, m.hf_vs, m.hf_ox, m.hf_oy, mv.ctypes.data if mv is not None else None)
     else:
-        fn(None, 0, 0, 0.0, 0.0, 0.0, 0.0)
+        fn(None, 0, 0, 0.0, 0.0, 0.0, 0.0, None)
     rc = lib().emu_sim_step(C.byref(osim.params), C.byref(desc), _p(osim.root_state), _p(osim.dof_state),
                             _p(osim.pd_target), _p(osim.rb_state), _p(osim.contact_force), _p(osim.dof_force),
                             _p(osim.lambda_ws), C.c_int(n_calls))

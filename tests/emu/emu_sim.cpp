@@ -10,10 +10,10 @@
 static const EmlocoSelfCollisionDesc *g_sc = nullptr;      // set by emu_sim_set_self_collision for the next emu_sim_step calls
 extern "C" void emu_sim_set_self_collision(const EmlocoSelfCollisionDesc *sc) { g_sc = sc; }
 
-struct EmuHeightfield { const short *samples; int nx, ny; float hs, vs, ox, oy; };
-static EmuHeightfield g_hf = {nullptr, 0, 0, 0, 0, 0, 0};   // set by emu_sim_set_heightfield for the next emu_sim_step calls
-extern "C" void emu_sim_set_heightfield(const short *samples, int nx, int ny, float hs, float vs, float ox, float oy) {
-    g_hf = {samples, nx, ny, hs, vs, ox, oy};
+struct EmuHeightfield { const short *samples; int nx, ny; float hs, vs, ox, oy; const unsigned char *mv; };
+static EmuHeightfield g_hf = {nullptr, 0, 0, 0, 0, 0, 0, nullptr};   // set by emu_sim_set_heightfield for the next emu_sim_step calls
+extern "C" void emu_sim_set_heightfield(const short *samples, int nx, int ny, float hs, float vs, float ox, float oy, const unsigned char *mv) {
+    g_hf = {samples, nx, ny, hs, vs, ox, oy, mv};       // mv: packed vertex moves of the slope-corrected mesh (emloco_types.h: hf_mv) or NULL
 }
 
 extern "C" int emu_sim_step(const EmlocoSimParams *prm, const EmlocoModelDesc *m, float *root_state,
@@ -36,7 +36,7 @@ extern "C" int emu_sim_step(const EmlocoSimParams *prm, const EmlocoModelDesc *m
     if (sc_on) { d.sc_nseg = n_seg; d.sc_n = g_sc->n_pairs; d.sc_k = g_sc->k; d.sc_c = g_sc->c; d.sc_max_pen = g_sc->max_pen; d.sc_mu = g_sc->mu; }
     if (g_hf.samples) {
         d.hf = g_hf.samples; d.hf_nx = g_hf.nx; d.hf_ny = g_hf.ny; d.hf_hs = g_hf.hs; d.hf_inv_hs = 1.0f / g_hf.hs; d.hf_vs = g_hf.vs;
-        d.hf_ox = g_hf.ox; d.hf_oy = g_hf.oy;
+        d.hf_ox = g_hf.ox; d.hf_oy = g_hf.oy; d.hf_mv = g_hf.mv;
     }
     EmlocoSimParams p = *prm;
     p.n_sub = prm->n_sub * n_calls;

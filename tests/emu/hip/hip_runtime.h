@@ -17,6 +17,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
+#define __noinline__
 #define __shared__ static
 #define __launch_bounds__(...)
 #define __restrict__

@@ -123,3 +123,15 @@ def terrain_index_map(rows=1080, cols=1080):
     coarse = (((i // 8) * 73856093) ^ ((j // 8) * 19349663)) % 600 - 200
     fine = ((i * 83492791) ^ (j * 2971215073)) % 7 - 3
     return (coarse + fine).astype(np.int16)
+
+
+def corrected_stairs(n=200):
+    """A staircase along x (15 cm risers every 30 cm, 4 high, repeating) crossed by a 20 cm trench along y, as the height field and as
+    the vertex moves of its slope-corrected mesh (terrain_utils.convert_heightfield_to_trimesh, threshold 0.9)."""
+    from emloco_amd.gym import terrain_utils as T
+    steps = ((np.arange(n)[:, None] // 3) % 4 * 30 + 0 * np.arange(n)[None, :]).astype(np.int16)
+    steps[:, 96:104] -= 40
+    verts, _ = T.convert_heightfield_to_trimesh(steps, 0.1, 0.005, 0.9)
+    mx, my = T.mesh_vertex_moves(verts, steps.shape, 0.1)
+    assert (mx != 0).any() and (my != 0).any()
+    return steps, dict(samples=steps, horizontal_scale=0.1, vertical_scale=0.005, move_x=mx, move_y=my)

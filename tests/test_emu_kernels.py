@@ -1056,6 +1056,36 @@ def test_sim_step_kernel_at_the_edge_of_the_heightfield_and_on_stairs_is_bit_exa
     assert np.isfinite(a.rb_state).all() and np.abs(a.contact_force).max() > 50
 
 
+def test_sim_step_kernel_on_the_slope_corrected_mesh_is_bit_exact_vs_oracle():
+    """Round 5: collision with the slope-corrected terrain mesh (vertical risers: emloco_sim_set_ground_mesh_moves) -- the mesh
+    triangle covering a point among the 3 x 3 cells' moved triangles, the probes on it, the closest-point test against the collapsed
+    cells' vertical faces (faces looking along x AND along y: both tangent-frame branches).  Humanoids dropped across risers, into the
+    trench and over the map's border: emulated kernel == oracle bytes, and the result differs from the uncorrected field's."""
+    E = 4
+    models = varied_models(E, seed=27)
+    root, dof, tgt = scene_state(E, seed=28)
+    from helpers import corrected_stairs
+    steps, hf = corrected_stairs()
+    root = root.copy()
+    root[:, 0] = [0.04, 9.93, 10.21, 19.88]
+    root[:, 1] = [0.03, 10.0, 9.62, 19.86]
+    root[:, 2] = 0.98 + steps[np.clip((root[:, 0] / 0.1).astype(int), 0, 199), np.clip((root[:, 1] / 0.1).astype(int), 0, 199)] * 0.005
+    root[:, 7] = [0.5, 1.5, -1.0, 0.0]
+    root[:, 8] = [0.0, -1.0, 1.5, 0.0]
+    a = oracle_sim(models, root, dof, tgt, heightfield=hf, n_sub=4)
+    b = oracle_sim(models, root, dof, tgt, heightfield=hf, n_sub=4)
+    plain = oracle_sim(models, root, dof, tgt, heightfield={k: v for k, v in hf.items() if not k.startswith("move")}, n_sub=4)
+    for _ in range(10):
+        a.step(1)
+        emu.sim_step(b, 1)
+        plain.step(1)
+        for name in ("root_state", "dof_state", "rb_state", "contact_force", "dof_force", "lambda_ws"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert np.isfinite(a.rb_state).all() and np.abs(a.contact_force).max() > 50
+    assert np.abs(a.contact_force[:, :, :2]).max() > 20                      # something pushed sideways: a riser or an edge
+    assert not np.array_equal(a.rb_state, plain.rb_state)
+
+
 def _bf16_bits(x):
     """fp32 -> bf16 bit patterns (uint16), round to nearest even"""
     u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)

@@ -324,6 +324,11 @@ def _shaped_terrain_body(env, E):
     terr = task.terrain
     assert not terr.is_flat and task.sim.heightfield is not None
     assert task.sim.heightfield["samples"].shape == terr.height_field_raw.shape
+    # round 5: the sim collides with the slope-corrected mesh the task built (vertical risers), its vertex moves read back from the mesh
+    mv = task.sim.heightfield
+    assert mv.get("move_x") is not None and (mv["move_x"] != 0).any() and (mv["move_y"] != 0).any()
+    vx = terr.vertices.reshape(terr.tot_rows, terr.tot_cols, 3)[:, :, 0]
+    np.testing.assert_allclose(vx, (np.arange(terr.tot_rows)[:, None] + mv["move_x"]) * terr.horizontal_scale, atol=1e-4)
     ids = torch.arange(E, device=task.device)
     obs = env.reset(ids)
     torch.cuda.synchronize()

@@ -362,3 +362,38 @@ def test_stairs_and_map_border_stay_on_the_oracles_bytes():
         if k in (0, 3, 15, 50, 119):
             _compare(osim, gsim, E, what=f"stairs step {k}")
     assert torch.isfinite(gsim.rigid_body_state).all() and float(gsim.contact_force.abs().max()) > 50.0
+
+
+def test_slope_corrected_mesh_stays_on_the_oracles_bytes():
+    """Round 5: collision with the slope-corrected terrain mesh (emloco_sim_set_ground_mesh_moves: vertical risers along x, a trench
+    with faces looking along y) -- humanoids dropped across risers, into the trench, over the map's border and walking speed into a
+    face, for an episode: bytes of the oracle at every compared step, and a different trajectory from the raw height field's."""
+    from emloco_amd import _lib as L
+    from emloco_amd.sim import NativeSim
+    from helpers import corrected_stairs, oracle_sim, scene_state, varied_models
+    E = 6
+    models = varied_models(E, 51)
+    root, dof, tgt = scene_state(E, 52, perturbed_from=0)
+    steps, hf = corrected_stairs()
+    root[:, 0] = [0.04, 9.93, 10.21, 19.88, 5.15, 12.31]
+    root[:, 1] = [0.03, 10.0, 9.62, 19.86, 8.0, 19.89]
+    root[:, 2] = 1.0 + steps[np.clip((root[:, 0] / 0.1).astype(int), 0, 199), np.clip((root[:, 1] / 0.1).astype(int), 0, 199)] * 0.005
+    root[:, 7] = [0.5, 1.5, -1.0, 0.0, 1.2, -0.8]
+    root[:, 8] = [0.0, -1.0, 1.5, 0.0, 0.0, 0.3]
+    osim = oracle_sim(models, root, dof, tgt, heightfield=hf, n_sub=4)
+    gsim = NativeSim(models, L.default_sim_params(n_sub=2), heightfield=hf)
+    raw = NativeSim(models, L.default_sim_params(n_sub=2), heightfield={k: v for k, v in hf.items() if not k.startswith("move")})
+    for g in (gsim, raw):
+        g.root_state.copy_(torch.from_numpy(root))
+        g.dof_state.view(E, 69, 2).copy_(torch.from_numpy(dof))
+        g.pd_target.copy_(torch.from_numpy(tgt))
+    side = 0.0
+    for k in range(120):
+        osim.step(1)
+        gsim.step(2)
+        raw.step(2)
+        side = max(side, float(gsim.contact_force[:, :2].abs().max()))
+        if k in (0, 3, 15, 50, 119):
+            _compare(osim, gsim, E, what=f"corrected mesh step {k}")
+    assert torch.isfinite(gsim.rigid_body_state).all() and float(gsim.contact_force.abs().max()) > 50.0 and side > 20.0
+    assert not torch.equal(gsim.rigid_body_state, raw.rigid_body_state)

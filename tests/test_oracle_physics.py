@@ -770,3 +770,100 @@ def test_sphere_sliding_into_a_step_stops_at_the_face():
     assert worst < 0.008, worst
     assert first_touch is not None and abs(first_touch[0] - touch) < 0.012 and abs(first_touch[1] - r_head) < 0.01, (first_touch, touch)
     assert np.isfinite(s.rb_state).all()
+
+
+# ------------------------------------------------------------------ the slope-corrected terrain mesh (round 5)
+def _riser_field(up):
+    """A 20 cm step across x on a 110 m map, as the raw field and with the vertex moves of its slope-corrected mesh
+    (terrain_utils.convert_heightfield_to_trimesh, threshold 0.9).  up: low ground for x < 52.1, the riser's face at x = 52.1
+    (the raw field has a ramp over [52.0, 52.1] instead); not up: a 0.2 m tread up to x = 51.9, the face there, low ground beyond."""
+    from emloco_amd.gym import terrain_utils as T
+    field = np.zeros((1100, 1100), np.int16)
+    if up:
+        field[521:, :] = 40
+    else:
+        field[:520, :] = 40
+    verts, _ = T.convert_heightfield_to_trimesh(field, 0.1, 0.005, 0.9)
+    mx, my = T.mesh_vertex_moves(verts, field.shape, 0.1)
+    face_x = np.unique(verts.reshape(1100, 1100, 3)[519:522, 0, 0])
+    assert (mx != 0).sum() == 1100 and np.allclose(face_x, [51.9, 52.1])       # (the corner rule moves the same vertices one cell along y too)
+    return dict(samples=field, horizontal_scale=0.1, vertical_scale=0.005, move_x=mx, move_y=my)
+
+
+def _qrot(q, v):
+    x, y, z, w = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return R @ v
+
+
+def _box_corners(m, rb):
+    out = []
+    for b in range(24):
+        if int(m.geom_type[b]) == 2:
+            for k in range(8):
+                sgn = np.array([1 if k & 1 else -1, 1 if k & 2 else -1, 1 if k & 4 else -1])
+                out.append(rb[b, :3] + _qrot(rb[b, 3:7], np.asarray(m.geom_a[b], float) + np.asarray(m.geom_b[b], float) * sgn))
+    return np.array(out)
+
+
+def test_sphere_sliding_into_a_riser_of_the_corrected_mesh_stops_with_its_surface_at_the_face():
+    """Collision with the slope-corrected mesh (emloco_sim_set_ground_mesh_moves / oracle hf_mv): the scene of
+    test_sphere_sliding_into_a_step_stops_at_the_face, but the riser is the mesh's VERTICAL face at x = 52.1 -- the head (r = 0.101 m)
+    sliding in at 2 m/s is stopped with its surface at the face (not 0.62 r early on a ramp, not late), never deeper than 4 mm in it,
+    and stays at the height it slid at: there is no ramp to climb."""
+    m = smpl_humanoid()
+    s = oracle.Sim(pack_models([m]), oracle.default_params(mu=0.05), heightfield=_riser_field(True))
+    s.root_state[0, :3] = [50.6, 55.0, 0.16]
+    s.root_state[0, 3:7] = [0.0, np.sin(np.pi / 4), 0.0, np.cos(np.pi / 4)]      # on its back, head towards +x
+    s.root_state[0, 7] = 2.0
+    head = m.names.index("Head")
+    r = float(m.geom_r[head])
+    surf, zc = [], []
+    for _ in range(60):
+        s.step()
+        rb = s.rb_state[0]
+        hc = rb[head, :3] + _qrot(rb[head, 3:7], np.asarray(m.geom_a[head], float))
+        surf.append(float(hc[0]) + r)
+        zc.append(float(hc[2]))
+    assert max(surf) < 52.1 + 0.004, max(surf)                           # never more than 4 mm into the face
+    assert abs(surf[-1] - 52.1) < 0.003 and abs(surf[-1] - surf[-10]) < 1e-3, surf[-10:]     # at rest AT the face
+    assert max(np.abs(np.array(zc[15:]) - r)) < 0.004                    # on the floor throughout
+    assert np.abs(s.root_state[0, 7:13]).max() < 0.02 and np.isfinite(s.rb_state).all()
+
+
+def test_foot_box_one_centimetre_from_a_tread_edge_stays():
+    """A humanoid standing on a 0.2 m tread with the front corners of its toe boxes 1 cm from the edge (the corrected mesh's face at
+    x = 51.9): the corners rest a hair inside the tread AND 1 cm behind the riser's face -- the contact stays with the tread (the
+    nearest surface), the feet are not pushed off sideways: nothing moves, the whole weight is carried, no horizontal force."""
+    m = smpl_humanoid()
+    s = oracle.Sim(pack_models([m]), oracle.default_params(), heightfield=_riser_field(False))
+    s.root_state[0, :3] = [51.9 - 0.01 - 0.1500, 55.0, 0.95 + 0.2]        # a standing humanoid's front corners sit 0.1500 m ahead of its start
+    xs = []
+    for k in range(240):
+        s.step()
+        xs.append(_box_corners(m, s.rb_state[0])[:, 0].max())
+    c = _box_corners(m, s.rb_state[0])
+    W = m.total_mass() * 9.81
+    assert abs(xs[-1] - 51.89) < 0.002 and max(xs) < 51.893 and min(xs[20:]) > 51.887, (xs[-1], max(xs), min(xs[20:]))
+    assert abs(c[:, 2].min() - 0.2) < 0.002
+    assert abs(s.contact_force[0, :, 2].sum() - W) / W < 0.01 and np.abs(s.contact_force[0, :, :2].sum(0)).max() < 2.0
+    assert np.abs(s.root_state[0, 7:13]).max() < 0.01
+
+
+def test_box_corner_inside_a_riser_is_pushed_back_out_through_the_face():
+    """A standing humanoid whose toe boxes start 8 mm INSIDE the riser (face at x = 52.1, the tread's top 0.2 m above the corners): the
+    corners are 0.2 m below the tread's plane and 8 mm behind the face -- the face is the nearest surface, the contact normal is the
+    face's and the feet are pushed back out horizontally (front corners end just before the face, the humanoid keeps standing on the
+    low ground).  Picking the DEEPEST penetration instead would fire them up through the tread."""
+    m = smpl_humanoid()
+    s = oracle.Sim(pack_models([m]), oracle.default_params(), heightfield=_riser_field(True))
+    s.root_state[0, :3] = [52.1 + 0.008 - 0.1500, 55.0, 0.95]
+    for k in range(120):
+        s.step()
+        c = _box_corners(m, s.rb_state[0])
+        assert c[:, 2].min() > -0.005 and c[:, 2].max() < 0.08, (k, c[:, 2].min(), c[:, 2].max())    # the feet never leave the low ground
+    assert 52.09 < c[:, 0].max() < 52.1005, c[:, 0].max()
+    W = m.total_mass() * 9.81
+    assert abs(s.contact_force[0, :, 2].sum() - W) / W < 0.01 and 0.85 < s.root_state[0, 2] < 0.95

@@ -98,3 +98,54 @@ def test_unpinned_generators_have_the_documented_shape():
     g = p.height_field_raw
     assert g.min() == 0 and g.max() >= 200                                   # poles are 1.0 - 2.5 m tall (200-500 units; overlaps add)
     assert 0.002 < (g != 0).mean() < 0.35                                    # sparse obstacles
+
+
+def test_vertex_moves_read_back_from_the_corrected_mesh_follow_the_reference_rule():
+    """`gym.add_triangle_mesh` hands the simulator the whole-cell vertex moves of the slope-corrected mesh (terrain_utils.py:313-325,
+    `emloco_sim_set_ground_mesh_moves`); they are read back from the mesh's vertices (`mesh_vertex_moves`).  On the reference-pinned
+    mesh (golden vertices) they equal the rule stated on the samples: a vertex moves +1 along x under a neighbour more than the
+    threshold higher at i + 1, -1 under one at i - 1, the diagonal rule where the axis rule is silent."""
+    g = np.load(os.path.join(G, "terrain_generators.npz"))
+    hf = g["trimesh_field"]
+    mx, my = T.mesh_vertex_moves(g["trimesh_thr_vertices"], hf.shape, 0.1)
+    thr = 0.9 * 0.1 / 0.005
+    h = hf.astype(np.int64)
+    ex, ey, ec = (np.zeros(hf.shape, np.int64) for _ in range(3))
+    ex[:-1] += (h[1:] - h[:-1]) > thr
+    ex[1:] -= (h[:-1] - h[1:]) > thr
+    ey[:, :-1] += (h[:, 1:] - h[:, :-1]) > thr
+    ey[:, 1:] -= (h[:, :-1] - h[:, 1:]) > thr
+    ec[:-1, :-1] += (h[1:, 1:] - h[:-1, :-1]) > thr
+    ec[1:, 1:] -= (h[:-1, :-1] - h[1:, 1:]) > thr
+    np.testing.assert_array_equal(mx, ex + ec * (ex == 0))
+    np.testing.assert_array_equal(my, ey + ec * (ey == 0))
+    assert (mx != 0).any() and (my != 0).any()
+    zx, zy = T.mesh_vertex_moves(g["trimesh_plain_vertices"], hf.shape, 0.1)
+    assert not zx.any() and not zy.any()
+    with pytest.raises(ValueError):
+        bad = g["trimesh_thr_vertices"].copy()
+        bad[5, 0] += 0.04
+        T.mesh_vertex_moves(bad, hf.shape, 0.1)
+
+
+def test_add_triangle_mesh_attaches_the_moves_of_a_corrected_mesh():
+    from emloco_amd.gym import gymapi
+    t = _sub((40, 40))
+    T.pyramid_stairs_terrain(t, step_width=0.31, step_height=0.15, platform_size=1.)
+    v, tri = T.convert_heightfield_to_trimesh(t.height_field_raw, 0.1, 0.005, 0.9)
+    gym = gymapi.acquire_gym()
+
+    class _Sim:
+        pass
+    sim = _Sim()
+    prm = gymapi.TriangleMeshParams()
+    prm.heightfield = dict(samples=t.height_field_raw, horizontal_scale=0.1, vertical_scale=0.005)
+    gym.add_triangle_mesh(sim, v.flatten(), tri.flatten(), prm)
+    mx, my = T.mesh_vertex_moves(v, t.height_field_raw.shape, 0.1)
+    np.testing.assert_array_equal(sim.heightfield["move_x"], mx)
+    np.testing.assert_array_equal(sim.heightfield["move_y"], my)
+    assert (mx != 0).any()
+    v0, tri0 = T.convert_heightfield_to_trimesh(t.height_field_raw, 0.1, 0.005, None)      # an uncorrected mesh carries no moves
+    sim2 = _Sim()
+    gym.add_triangle_mesh(sim2, v0.flatten(), tri0.flatten(), gymapi.TriangleMeshParams())
+    assert sim2.heightfield.get("move_x") is None
