@@ -27,10 +27,11 @@ UNITS = [
     ("predictor_capi.hip", ["-fno-slp-vectorize"]),      # split-mode GEMMs: 183.6 -> 176.5 ms per fp32-class train step, policy 0.341 -> 0.311 ms
     ("attention_capi.hip", []),                          # the fused attention keeps the SLP vectoriser (bf16 kernels 8-18 % slower without)
     ("ffn_capi.hip", []),                                # the chained feed-forward kernels (round 5)
+    ("ppo_capi.hip", []),                                # the PPO learner's loss heads (round 5)
 ]
 # EMLOCO_HIPCC_EXTRA="-DFOO=1 ..." appends flags to every unit, EMLOCO_HIPCC_EXTRA_SIM / _TASK / _PREDICTOR to one (A/B experiments)
 EXTRA = os.environ.get("EMLOCO_HIPCC_EXTRA", "").split()
-UNIT_EXTRA = {u: os.environ.get("EMLOCO_HIPCC_EXTRA_" + u.split("_")[0].upper(), "").split() for u in ("sim_capi.hip", "task_capi.hip", "predictor_capi.hip", "attention_capi.hip", "ffn_capi.hip")}
+UNIT_EXTRA = {u: os.environ.get("EMLOCO_HIPCC_EXTRA_" + u.split("_")[0].upper(), "").split() for u in ("sim_capi.hip", "task_capi.hip", "predictor_capi.hip", "attention_capi.hip", "ffn_capi.hip", "ppo_capi.hip")}
 COMMON = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 

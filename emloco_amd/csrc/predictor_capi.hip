@@ -423,25 +423,41 @@ int emloco_adamw_gated(int n, float *params, const float *grads, float *exp_avg,
     return 0;
 }
 
-int64_t emloco_adam_clip_flat_workspace(int64_t n) { return (n + ADAM_BLOCK - 1) / ADAM_BLOCK + 2; }
+int64_t emloco_adam_clip_flat_workspace(int64_t n) { return (n + ADAM_BLOCK - 1) / ADAM_BLOCK + 4; }
+
+// workspace: [0] norm, [1] clip coefficient, [2] 1 - beta1^t, [3] sqrt(1 - beta2^t) (counted variant), [4..] block partials
+static int adam_clip_flat(int64_t n, float *params, float *grads, float *exp_avg, float *exp_avg_sq, float lr, double beta1, double beta2, float eps,
+                          float weight_decay, float bc1, float bc2_sqrt, float max_norm, float *workspace, float *step_count, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const float *coef = nullptr;
+    if (max_norm > 0.0f) {
+        const int nparts = (int)((n + ADAM_BLOCK - 1) / ADAM_BLOCK);
+        hipLaunchKernelGGL(emloco::sumsq_partial_kernel, dim3((unsigned)nparts), dim3(256), 0, st, (long)n, grads, workspace + 4);
+        hipLaunchKernelGGL(emloco::clip_coef_kernel, dim3(1), dim3(256), 0, st, nparts, workspace + 4, max_norm, workspace);
+        coef = workspace;
+    }
+    if (step_count) hipLaunchKernelGGL(emloco::adam_step_count_kernel, dim3(1), dim3(64), 0, st, step_count, beta1, beta2, workspace + 2);
+    hipLaunchKernelGGL(emloco::adam_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (long)n, params, grads, exp_avg, exp_avg_sq,
+                       coef, lr, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, bc1, bc2_sqrt,
+                       step_count ? (const float *)(workspace + 2) : (const float *)nullptr);
+    PHIPCHK(hipGetLastError());
+    return 0;
+}
 
 int emloco_adam_clip_flat(int64_t n, float *params, float *grads, float *exp_avg, float *exp_avg_sq, float lr, double beta1, double beta2, float eps,
                           float weight_decay, float bias_correction1, float bias_correction2_sqrt, float max_norm, float *workspace, void *stream) {
     if (n < 1 || !params || !grads || !exp_avg || !exp_avg_sq || !(bias_correction1 > 0.0f) || !(bias_correction2_sqrt > 0.0f)
         || (max_norm > 0.0f && !workspace))
         return pfail(-1, "emloco_adam_clip_flat: bad argument (workspace = emloco_adam_clip_flat_workspace(n) floats when max_norm > 0)");
-    hipStream_t st = (hipStream_t)stream;
-    const float *coef = nullptr;
-    if (max_norm > 0.0f) {                       // workspace: [0] norm, [1] coefficient, [2..] block partials
-        const int nparts = (int)((n + ADAM_BLOCK - 1) / ADAM_BLOCK);
-        hipLaunchKernelGGL(emloco::sumsq_partial_kernel, dim3((unsigned)nparts), dim3(256), 0, st, (long)n, grads, workspace + 2);
-        hipLaunchKernelGGL(emloco::clip_coef_kernel, dim3(1), dim3(256), 0, st, nparts, workspace + 2, max_norm, workspace);
-        coef = workspace;
-    }
-    hipLaunchKernelGGL(emloco::adam_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (long)n, params, grads, exp_avg, exp_avg_sq,
-                       coef, lr, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, bias_correction1, bias_correction2_sqrt);
-    PHIPCHK(hipGetLastError());
-    return 0;
+    return adam_clip_flat(n, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2_sqrt,
+                          max_norm, workspace, nullptr, stream);
+}
+
+int emloco_adam_clip_flat_counted(int64_t n, float *params, float *grads, float *exp_avg, float *exp_avg_sq, float lr, double beta1, double beta2,
+                                  float eps, float weight_decay, float max_norm, float *workspace, float *step_count, void *stream) {
+    if (n < 1 || !params || !grads || !exp_avg || !exp_avg_sq || !workspace || !step_count)
+        return pfail(-1, "emloco_adam_clip_flat_counted: bad argument (workspace = emloco_adam_clip_flat_workspace(n) floats, step_count = 1 device float)");
+    return adam_clip_flat(n, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, 1.0f, 1.0f, max_norm, workspace, step_count, stream);
 }
 
 int emloco_dropout_keep_mask(uint32_t seed, uint64_t first_index, int64_t n, float p, uint8_t *host_out) {

@@ -1430,10 +1430,20 @@ clip_coef_kernel(int nparts, const float *part, float max_norm, float *out) {
         out[0] = norm; out[1] = (c < 1.0f || c != c) ? c : 1.0f;
     }
 }
+// The step counter on the device (a captured optimiser step replays with the same kernel arguments): count[0] += 1, then
+// bc[0] = 1 - beta1^t, bc[1] = sqrt(1 - beta2^t) for the update launch behind it.  One thread.
+__global__ void adam_step_count_kernel(float *count, double beta1, double beta2, float *bc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float t = count[0] + 1.0f;
+    count[0] = t;
+    bc[0] = (float)(1.0 - pow(beta1, (double)t));
+    bc[1] = (float)sqrt(1.0 - pow(beta2, (double)t));
+}
 __global__ void adam_flat_kernel(long n, float *p, float *g, float *m, float *v, const float *coef, float lr, float omb1, float b2, float omb2,
-                                 float eps, float wd, float bc1, float bc2_sqrt) {      // omb = 1 - beta, rounded from the double (as torch passes it)
+                                 float eps, float wd, float bc1, float bc2_sqrt, const float *bc_dev) {      // omb = 1 - beta, rounded from the double (as torch passes it)
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (bc_dev) { bc1 = bc_dev[0]; bc2_sqrt = bc_dev[1]; }          // (uniform: two scalar loads)
     float gi = g[i];
     if (coef) { gi *= coef[1]; g[i] = gi; }
     float pi = p[i];

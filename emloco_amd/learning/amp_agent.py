@@ -27,6 +27,7 @@ import torch.nn as nn
 from ..dist import FlatGradBucket, all_reduce_mean_scalar, broadcast_parameters, sync_running_mean_std
 from ..predictor import ops
 from ..utils.running_mean_std import RunningMeanStd
+from . import ppo_heads
 from .amp_network_sept_builder import AMPSeptBuilder
 
 
@@ -198,9 +199,22 @@ class AMPAgent:
         # for the epoch's remaining minibatches and every later epoch.  Single rank only: a gloo all-reduce cannot be captured.
         self.use_graph = (self.device.type == "cuda" and os.environ.get("EMLOCO_PPO_GRAPH", "1") != "0")
         self._graph, self._g_in, self._g_u, self._g_acc, self._g_keys = None, None, None, None, None
-        self.optimizer = torch.optim.Adam(self.a2c_network.parameters(), float(self.last_lr), eps=1e-08, weight_decay=0.0,
-                                          capturable=self.use_graph)
-        self.bucket = FlatGradBucket([p for p in self.a2c_network.parameters() if p.requires_grad])
+        # clip_grad_norm_ + Adam (common_agent.py:573-603 through amp_continuous.py:440-445) on flat buffers: 4 launches
+        # (`emloco_adam_clip_flat_counted`: the step count lives on the device, so the captured step replays as the next one) where
+        # torch's foreach implementations issue ~30 passes over the 11 M parameters.  EMLOCO_PPO_FLAT_ADAM=0 / a CPU device: torch's own.
+        self._flat_adam = self.device.type == "cuda" and os.environ.get("EMLOCO_PPO_FLAT_ADAM", "1") != "0"
+        # the loss heads as fused launches (learning/ppo_heads.py); EMLOCO_PPO_HEADS=0 / CPU tensors: the torch expressions
+        self._fused_heads = self.device.type == "cuda" and os.environ.get("EMLOCO_PPO_HEADS", "1") != "0"
+        self._head_kl = None
+        if self._flat_adam:
+            from ..predictor.fused_adam import FlatClipAdam
+            trainable = [p for p in self.a2c_network.parameters() if p.requires_grad]
+            self.bucket = FlatGradBucket(trainable, align=FlatClipAdam.ALIGN)
+            self.optimizer = FlatClipAdam(trainable, float(self.last_lr), eps=1e-08, weight_decay=0.0, bucket=self.bucket, counted=True)
+        else:
+            self.optimizer = torch.optim.Adam(self.a2c_network.parameters(), float(self.last_lr), eps=1e-08, weight_decay=0.0,
+                                              capturable=self.use_graph)
+            self.bucket = FlatGradBucket([p for p in self.a2c_network.parameters() if p.requires_grad])
         self._amp_obs_demo_buffer = ReplayBuffer(int(c["amp_obs_demo_buffer_size"]), self.device)
         self._amp_replay_buffer = ReplayBuffer(int(c["amp_replay_buffer_size"]), self.device)
         self._amp_replay_keep_prob = c["amp_replay_keep_prob"]
@@ -355,14 +369,21 @@ class AMPAgent:
         return {"sym_loss": (orig_a.reshape(B, -1) - flip_a).pow(2).mean(dim=-1) * 50}
 
     def _disc_loss(self, disc_agent_logit, disc_demo_logit, grad_penalty):
-        bce = torch.nn.BCEWithLogitsLoss()
-        disc_loss = 0.5 * (bce(disc_agent_logit, torch.zeros_like(disc_agent_logit)) + bce(disc_demo_logit, torch.ones_like(disc_demo_logit)))
+        if self._fused_heads and disc_agent_logit.is_cuda:
+            bce_agent, agent_acc, bce_demo, demo_acc = ppo_heads.disc_head(disc_agent_logit, disc_demo_logit)
+            disc_loss = 0.5 * (bce_agent + bce_demo)
+        else:
+            bce = torch.nn.BCEWithLogitsLoss()
+            disc_loss = 0.5 * (bce(disc_agent_logit, torch.zeros_like(disc_agent_logit)) + bce(disc_demo_logit, torch.ones_like(disc_demo_logit)))
+            agent_acc, demo_acc = (disc_agent_logit < 0).float().mean(), (disc_demo_logit > 0).float().mean()
         logit_loss = torch.sum(torch.square(self.a2c_network.get_disc_logit_weights()))
         disc_loss = disc_loss + self._disc_logit_reg * logit_loss + self._disc_grad_penalty * grad_penalty
         if self._disc_weight_decay != 0:
-            disc_loss = disc_loss + self._disc_weight_decay * torch.sum(torch.square(torch.cat(self.a2c_network.get_disc_weights(), dim=-1)))
+            # (the sum of the per-matrix sums: the reference concatenates the flattened weights first -- 3.7 M floats copied every step)
+            wd = sum(torch.sum(torch.square(w)) for w in self.a2c_network.get_disc_weights())
+            disc_loss = disc_loss + self._disc_weight_decay * wd
         return {"disc_loss": disc_loss, "disc_grad_penalty": grad_penalty.detach(), "disc_logit_loss": logit_loss.detach(),
-                "disc_agent_acc": (disc_agent_logit < 0).float().mean().detach(), "disc_demo_acc": (disc_demo_logit > 0).float().mean().detach()}
+                "disc_agent_acc": agent_acc.detach(), "disc_demo_acc": demo_acc.detach()}
 
     def compute_loss(self, d, dropout_masks=None, branch_streams=None):
         """The scalar of calc_gradients (amp_continuous.py:335-425) for one minibatch dict `d`.
@@ -411,17 +432,28 @@ class AMPAgent:
         if self.motion_sym_loss:                             # (two more actor evaluations)
             with on(s_s):
                 s_loss = torch.mean(self._sym_loss(flip_n, next_n)["sym_loss"])
+        heads = self._fused_heads and obs.is_cuda
         with on(s_c):
             values = net.eval_critic(obs)
-            c_info = self._critic_loss(d["old_values"], values, self.e_clip, d["returns"], self.clip_value)
-            c_loss = torch.mean(c_info["critic_loss"])
+            if heads:
+                c_loss = ppo_heads.critic_head(values, d["old_values"], d["returns"], self.e_clip, self.clip_value)
+            else:
+                c_info = self._critic_loss(d["old_values"], values, self.e_clip, d["returns"], self.clip_value)
+                c_loss = torch.mean(c_info["critic_loss"])
         mu, logstd = net.eval_actor(obs)
         sigma = torch.exp(logstd)
-        action_log_probs = neglogp(d["actions"], mu, sigma, logstd)
-        entropy = (0.5 + 0.5 * math.log(2 * math.pi) + logstd).sum(dim=-1)
-        a_info = self._actor_loss(d["old_logp_actions"], action_log_probs, d["advantages"], self.e_clip)
-        a_loss = torch.mean(a_info["actor_loss"])
-        b_loss, entropy = torch.mean(self.bound_loss(mu)), torch.mean(entropy)
+        self._head_kl = None
+        if heads and self.bounds_loss_coef is not None:
+            # neglogp, surrogate, entropy, bound loss, clip fraction and the step's KL in one forward launch (learning/ppo_heads.py)
+            a_loss, entropy, b_loss, clip_frac, self._head_kl = ppo_heads.actor_head(
+                mu, logstd, d["actions"], d["old_logp_actions"], d["advantages"], self.e_clip, d.get("mu"), d.get("sigma"))
+        else:
+            action_log_probs = neglogp(d["actions"], mu, sigma, logstd)
+            entropy = (0.5 + 0.5 * math.log(2 * math.pi) + logstd).sum(dim=-1)
+            a_info = self._actor_loss(d["old_logp_actions"], action_log_probs, d["advantages"], self.e_clip)
+            a_loss = torch.mean(a_info["actor_loss"])
+            b_loss, entropy = torch.mean(self.bound_loss(mu)), torch.mean(entropy)
+            clip_frac = a_info["actor_clipped"].float().mean()
         if branch_streams is not None:
             # join: what crosses is a handful of scalars (allocated on the branch streams: tell the allocator who else reads them)
             for st, ts in ((s_c, [c_loss]), (s_d, list(disc_info.values())), (s_s, [s_loss] if s_loss is not None else [])):
@@ -431,7 +463,7 @@ class AMPAgent:
         loss = a_loss + self.critic_coef * c_loss - self.entropy_coef * entropy + self.bounds_loss_coef * b_loss \
             + self._disc_coef * disc_info["disc_loss"]
         info = {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "entropy": entropy.detach(),
-                "actor_clip_frac": a_info["actor_clipped"].float().mean(), **{k: v.detach() for k, v in disc_info.items()}}
+                "actor_clip_frac": clip_frac.detach(), **{k: v.detach() for k, v in disc_info.items()}}
         if s_loss is not None:
             loss = loss + s_loss * self.sym_loss_coef
             info["sym_loss"] = s_loss.detach()
@@ -443,14 +475,20 @@ class AMPAgent:
         self.bucket.zero()                                         # the .grad of every parameter aliases the flat bucket
         loss.backward()
         self.bucket.all_reduce(average=True)                       # no-op on one rank
-        if self.truncate_grads:
-            nn.utils.clip_grad_norm_(self.a2c_network.parameters(), self.grad_norm)
-        self.optimizer.step()
+        self._clip_and_step()
         with torch.no_grad():
-            info["kl"] = policy_kl(mu, sigma, d["mu"], d["sigma"])
+            info["kl"] = self._head_kl if self._head_kl is not None else policy_kl(mu, sigma, d["mu"], d["sigma"])
         info["loss"] = loss.detach()
         self.train_result = info
         return info
+
+    def _clip_and_step(self):
+        if self._flat_adam:
+            self.optimizer.step(max_grad_norm=self.grad_norm if self.truncate_grads else 0.0)
+            return
+        if self.truncate_grads:
+            nn.utils.clip_grad_norm_(self.a2c_network.parameters(), self.grad_norm)
+        self.optimizer.step()
 
     # ------------------------------------------------------------------ the optimiser step as a HIP graph
     def _graph_body(self, part=None):
@@ -473,11 +511,9 @@ class AMPAgent:
         else:
             loss, info, mu, sigma = self._g_mid
             info = dict(info)
-        if self.truncate_grads:
-            nn.utils.clip_grad_norm_(self.a2c_network.parameters(), self.grad_norm)
-        self.optimizer.step()
+        self._clip_and_step()
         with torch.no_grad():
-            info["kl"] = policy_kl(mu, sigma, d["mu"], d["sigma"])
+            info["kl"] = self._head_kl if self._head_kl is not None else policy_kl(mu, sigma, d["mu"], d["sigma"])
             info["loss"] = loss.detach()
             if self._g_acc is None:
                 self._g_keys = sorted(info)

@@ -31,9 +31,13 @@ from . import ops
 class FlatClipAdam(torch.optim.Adam):
     ALIGN = 64
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucket=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucket=None, counted=False):
+        """counted: the step count lives on the device (`emloco_adam_clip_flat_counted`) so that a step captured in a HIP graph replays
+        as the NEXT step (the PPO learner's graphed optimiser step); the per-parameter `step` entries of the state are then views of
+        that one device scalar, as torch's capturable Adam keeps them."""
         params = [p for p in params if p.requires_grad]
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, capturable=False)
+        self._counted = bool(counted)
         if len(self.param_groups) != 1:
             raise NotImplementedError("FlatClipAdam: one parameter group")
         dev = params[0].device
@@ -51,13 +55,14 @@ class FlatClipAdam(torch.optim.Adam):
         self._flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
         self._flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
         self._flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._count = torch.zeros(1, dtype=torch.float32, device=dev) if self._counted else None
         with torch.no_grad():
             for p, o in zip(params, self._offsets):
                 k = p.numel()
                 self._flat_p[o:o + k].copy_(p.detach().reshape(-1))
                 p.data = self._flat_p[o:o + k].view_as(p)
-                self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self._flat_m[o:o + k].view_as(p),
-                                 "exp_avg_sq": self._flat_v[o:o + k].view_as(p)}
+                self.state[p] = {"step": self._count[0] if self._counted else torch.tensor(0.0),
+                                 "exp_avg": self._flat_m[o:o + k].view_as(p), "exp_avg_sq": self._flat_v[o:o + k].view_as(p)}
         self._ws = torch.zeros(ops._lib().emloco_adam_clip_flat_workspace(n), dtype=torch.float32, device=dev)
         self._t = 0
 
@@ -84,6 +89,14 @@ class FlatClipAdam(torch.optim.Adam):
         if g.get("amsgrad") or g.get("maximize"):
             raise NotImplementedError("FlatClipAdam: amsgrad / maximize")
         self._check_aliasing()
+        if self._counted:
+            P = lambda t: C.c_void_p(t.data_ptr())
+            b1, b2 = g["betas"]
+            ops._chk(ops._lib().emloco_adam_clip_flat_counted(self._n, P(self._flat_p), P(self.bucket.grads), P(self._flat_m), P(self._flat_v),
+                                                              float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
+                                                              float(max_grad_norm or 0.0), P(self._ws), P(self._count), ops._st(self._flat_p)),
+                     "emloco_adam_clip_flat_counted")
+            return
         self._t += 1
         b1, b2 = g["betas"]
         bc1, bc2s = 1.0 - b1 ** self._t, math.sqrt(1.0 - b2 ** self._t)
@@ -109,7 +122,10 @@ class FlatClipAdam(torch.optim.Adam):
                 else:
                     m.zero_(); v.zero_()
                     steps.add(0)
-                self.state[p] = {"step": torch.tensor(float(max(steps) if steps else 0)), "exp_avg": m, "exp_avg_sq": v}
+                self.state[p] = {"step": self._count[0] if self._counted else torch.tensor(float(max(steps) if steps else 0)),
+                                 "exp_avg": m, "exp_avg_sq": v}
         if len(steps) > 1:
             raise NotImplementedError("FlatClipAdam: parameters with different step counts")
         self._t = steps.pop() if steps else 0
+        if self._counted:
+            self._count.fill_(float(self._t))

@@ -70,6 +70,7 @@ def _lib():
         lib.emloco_locoval_bwd_rows.argtypes = [ci, vp, ci] + [vp] * 17
         lib.emloco_adamw_gated.argtypes = [ci] + [vp] * 7 + [cf] * 5 + [vp, vp]
         lib.emloco_adam_clip_flat.argtypes = [C.c_int64] + [vp] * 4 + [cf, C.c_double, C.c_double] + [cf] * 5 + [vp, vp]
+        lib.emloco_adam_clip_flat_counted.argtypes = [C.c_int64] + [vp] * 4 + [cf, C.c_double, C.c_double] + [cf] * 3 + [vp, vp, vp]
         lib.emloco_adam_clip_flat_workspace.argtypes = [C.c_int64]
         lib.emloco_adam_clip_flat_workspace.restype = C.c_int64
         lib.emloco_gemm_enable_timing.argtypes = [ci]

@@ -297,8 +297,42 @@ int emloco_adamw_gated(int n, float *params, const float *grads, float *exp_avg,
  * bias_correction1 = 1 - beta1^t, bias_correction2_sqrt = sqrt(1 - beta2^t) for the step count t AFTER this step (host arithmetic, as
  * torch's non-capturable Adam does it); the betas are doubles because torch rounds 1 - beta from the double.  max_norm <= 0: no clipping (workspace may be NULL).  weight_decay is Adam's L2 term. */
 int64_t emloco_adam_clip_flat_workspace(int64_t n);
+/* (workspace: [0] norm, [1] clip coefficient, [2] 1 - beta1^t, [3] sqrt(1 - beta2^t) (counted variant), [4 ..] block partials) */
 int emloco_adam_clip_flat(int64_t n, float *params, float *grads, float *exp_avg, float *exp_avg_sq, float lr, double beta1, double beta2, float eps,
                           float weight_decay, float bias_correction1, float bias_correction2_sqrt, float max_norm, float *workspace, void *stream);
+
+/* The same with the step count on the DEVICE: step_count[0] (one float, the number of steps taken so far) is incremented and the bias
+ * corrections are computed from it by a one-thread launch ahead of the update -- a step captured in a HIP graph (the PPO learner's
+ * optimiser step, amp_continuous.py:335-479 through common_agent.py:573-603) replays as the next step.  Four launches with clipping. */
+int emloco_adam_clip_flat_counted(int64_t n, float *params, float *grads, float *exp_avg, float *exp_avg_sq, float lr, double beta1, double beta2,
+                                  float eps, float weight_decay, float max_norm, float *workspace, float *step_count, void *stream);
+
+/* ---- PPO loss heads (round 5): the tail between the networks' outputs and the scalar loss of the PPO + AMP update
+ * (amp_continuous.py:335-425, common_agent.py:426-468; neglogp / entropy / policy_kl of rl_games 1.1.4 as restated in
+ * learning/amp_agent.py) -- ~140 elementwise / reduction launches per optimiser step in torch -- as one launch over the rows, one
+ * fixed-order mean and one backward launch per head.  All pointers are device pointers, rows contiguous.
+ *
+ * Actor head.  mu, logstd, actions, old_mu, old_sigma: [B][A]; old_neglogp, advantages: [B].  out5 = means over the rows of
+ * [clipped surrogate max(-adv r, -adv clamp(r, 1 - e, 1 + e)) with r = exp(old_neglogp - neglogp), entropy, bound loss (soft bound 1),
+ * fraction of rows with |r - 1| > e, KL(new || old) (old_mu / old_sigma NULL: 0)].  rows: B x 5 floats of workspace.
+ * Backward: grad3 = device [d loss / d out5[0], d / d out5[1], d / d out5[2]]; dmu, dlogstd [B][A] (dlogstd may be NULL). */
+int emloco_ppo_actor_head_fwd(int B, int A, const float *mu, const float *logstd, const float *actions, const float *old_neglogp,
+                              const float *advantages, const float *old_mu, const float *old_sigma, float e_clip, float *rows,
+                              float *out5, void *stream);
+int emloco_ppo_actor_head_bwd(int B, int A, const float *mu, const float *logstd, const float *actions, const float *old_neglogp,
+                              const float *advantages, float e_clip, const float *grad3, float *dmu, float *dlogstd, void *stream);
+/* Critic head: out1 = mean(max((v - R)^2, (v_old + clamp(v - v_old, -e, e) - R)^2)), or mean((R - v)^2) with clip_value = 0.
+ * rows: B floats of workspace.  Backward: grad1 = device [d loss / d out1]; torch's tie rule (half each) and closed clamp interval. */
+int emloco_ppo_critic_head_fwd(int B, const float *values, const float *old_values, const float *returns, float e_clip, int clip_value,
+                               float *rows, float *out1, void *stream);
+int emloco_ppo_critic_head_bwd(int B, const float *values, const float *old_values, const float *returns, float e_clip, int clip_value,
+                               const float *grad1, float *dvalues, void *stream);
+/* Discriminator head (amp_continuous.py:515-558): out4 = [mean BCEWithLogits(agent logits, 0), fraction of agent logits < 0,
+ * mean BCEWithLogits(demo logits, 1), fraction of demo logits > 0].  rows: (n_agent + n_demo) x 2 floats of workspace.
+ * Backward: grad2 = device [d loss / d out4[0], d loss / d out4[2]]. */
+int emloco_ppo_disc_head_fwd(int n_agent, int n_demo, const float *agent_logits, const float *demo_logits, float *rows, float *out4, void *stream);
+int emloco_ppo_disc_head_bwd(int n_agent, int n_demo, const float *agent_logits, const float *demo_logits, const float *grad2,
+                             float *d_agent, float *d_demo, void *stream);
 
 /* Tile choice of the split mode (EMLOCO_GEMM_SPLIT): -1 (default) picks the 64 x 64 tile for launches whose 128 x 128 grid would
  * leave CUs idle, 0 / 1 force never / always.  Results do not depend on it (an output element's reduction order is the same in both

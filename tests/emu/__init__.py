@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _SO = os.path.join(_HERE, "_build", "libemu.so")
-_SRCS = ["emu_sim.cpp", "emu_task.cpp", "emu_predictor.cpp", "emu_runtime.cpp", "hip/hip_runtime.h"]
+_SRCS = ["emu_sim.cpp", "emu_task.cpp", "emu_predictor.cpp", "emu_ppo.cpp", "emu_runtime.cpp", "hip/hip_runtime.h"]
 def build():
     """g++ over the kernel sources; every file under emloco_amd/csrc and include/ is a dependency.  Built under a file lock into a
     temporary name and renamed, so that the workers of a parallel test run neither build twice at once nor load a half-written file."""

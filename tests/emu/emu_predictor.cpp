@@ -134,16 +134,19 @@ extern "C" int emu_colsum(int m, int n, const float *X, float *out, float *ws, i
     }, np_, n, ws, out, out, n);
     return 0;
 }
+// step_count non-NULL: the counted variant (emloco_adam_clip_flat_counted) -- the bias corrections come from the device-side counter
 extern "C" int emu_adam_clip_flat(long n, float *p, float *g, float *m, float *v, float lr, double b1, double b2, float eps, float wd,
-                                  float bc1, float bc2s, float max_norm, float *ws) {
+                                  float bc1, float bc2s, float max_norm, float *ws, float *step_count) {
     const float *coef = nullptr;
     if (max_norm > 0.0f) {
         const int np_ = (int)((n + ADAM_BLOCK - 1) / ADAM_BLOCK);
-        emu::launch((unsigned)np_, 256, [&] { sumsq_partial_kernel(n, g, ws + 2); });
-        emu::launch(1, 256, [&] { clip_coef_kernel(np_, ws + 2, max_norm, ws); });
+        emu::launch((unsigned)np_, 256, [&] { sumsq_partial_kernel(n, g, ws + 4); });
+        emu::launch(1, 256, [&] { clip_coef_kernel(np_, ws + 4, max_norm, ws); });
         coef = ws;
     }
-    emu::launch((unsigned)((n + 255) / 256), 256, [&] { adam_flat_kernel(n, p, g, m, v, coef, lr, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), eps, wd, bc1, bc2s); });
+    if (step_count) emu::launch(1, 64, [&] { adam_step_count_kernel(step_count, b1, b2, ws + 2); });
+    const float *bc = step_count ? ws + 2 : nullptr;
+    emu::launch((unsigned)((n + 255) / 256), 256, [&] { adam_flat_kernel(n, p, g, m, v, coef, lr, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), eps, wd, bc1, bc2s, bc); });
     return 0;
 }
 extern "C" long emu_layernorm_bwd_workspace(int rows, int d) { return fold_workspace((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK, 2L * d); }

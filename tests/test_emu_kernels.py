@@ -582,7 +582,9 @@ def test_flat_clip_adam_kernels_follow_torch():
     n, lr, b1, b2, eps, wd, max_norm = 9001, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0.7
     p0 = rng.normal(size=n).astype(np.float32)
     p, m, v = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
-    ws = np.zeros(n // 4096 + 4, np.float32)
+    ws = np.zeros(n // 4096 + 6, np.float32)
+    # the counted variant (emloco_adam_clip_flat_counted: the step count lives on the device, a captured step replays unchanged) beside it
+    pc, mc, vc, wsc, count = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n // 4096 + 6, np.float32), np.zeros(1, np.float32)
     tp = torch.nn.Parameter(torch.from_numpy(p0.copy()))
     opt = torch.optim.Adam([tp], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, foreach=False)
     for t in range(1, 4):
@@ -590,15 +592,20 @@ def test_flat_clip_adam_kernels_follow_torch():
         tp.grad = torch.from_numpy(g.copy())
         norm = torch.nn.utils.clip_grad_norm_([tp], max_norm)
         opt.step()
-        gk = g.copy()
+        gk, gc = g.copy(), g.copy()
         lib.emu_adam_clip_flat(C.c_long(n), P(p), P(gk), P(m), P(v), C.c_float(lr), C.c_double(b1), C.c_double(b2), C.c_float(eps), C.c_float(wd),
-                               C.c_float(1 - b1 ** t), C.c_float(np.sqrt(1 - b2 ** t)), C.c_float(max_norm), P(ws))
+                               C.c_float(1 - b1 ** t), C.c_float(np.sqrt(1 - b2 ** t)), C.c_float(max_norm), P(ws), None)
+        lib.emu_adam_clip_flat(C.c_long(n), P(pc), P(gc), P(mc), P(vc), C.c_float(lr), C.c_double(b1), C.c_double(b2), C.c_float(eps), C.c_float(wd),
+                               C.c_float(1.0), C.c_float(1.0), C.c_float(max_norm), P(wsc), P(count))
         np.testing.assert_allclose(ws[0], float(norm), rtol=2e-6)
         np.testing.assert_allclose(gk, tp.grad.numpy(), rtol=2e-6, atol=1e-9)
         np.testing.assert_allclose(p, tp.detach().numpy(), rtol=1e-6, atol=2e-7)
         st = opt.state[tp]
         np.testing.assert_allclose(m, st["exp_avg"].numpy(), rtol=1e-5, atol=1e-9)
         np.testing.assert_allclose(v, st["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-12)
+        assert count[0] == t and np.array_equal(gc, gk) and np.array_equal(mc, m) and np.array_equal(vc, v)
+        np.testing.assert_allclose(wsc[2:4], [1 - b1 ** t, np.sqrt(1 - b2 ** t)], rtol=1e-6)
+        np.testing.assert_allclose(pc, p, rtol=0, atol=3e-7)
     assert np.abs(p - p0).max() > 1e-3
 
 
@@ -1292,3 +1299,74 @@ def test_split_mode_attention_on_piece_plane_tile_images():
             err = np.abs(a_ - b_).max()
             assert err <= 1e-5 * np.abs(b_).max() + 1e-7, (S, Sq, p, what, "vs round 4", err)
         assert np.all(new[2][-1, S - 20:, d:] == 0)
+
+
+def test_ppo_loss_heads_follow_the_torch_expressions():
+    """csrc/ppo_kernels.hip (round 5): the PPO + AMP learner's loss heads -- actor (neglogp, clipped surrogate, entropy, bound loss, clip
+    fraction, policy KL), critic (clipped value loss), discriminator (two binary cross entropies, accuracies) -- emulated against the
+    torch expressions of learning/amp_agent.py (the restatement of amp_continuous.py:335-425 / rl_games 1.1.4), values AND gradients
+    (torch autograd on the CPU): ratios inside and outside the clip range, both signs of the advantage, actions beyond the soft
+    bound, value moves inside and outside the value clip."""
+    import math
+    import torch
+    from emloco_amd.learning.amp_agent import neglogp, policy_kl
+    lib = emu.lib()
+    rng = np.random.default_rng(12)
+    B, A, e = 203, 69, 0.2
+    f = lambda *s: rng.normal(size=s).astype(np.float32)
+    mu = (f(B, A) * 0.8).astype(np.float32)
+    logstd = (f(B, A) * 0.05 - 1.0).astype(np.float32)
+    sig = np.exp(logstd)
+    actions = (mu + sig * f(B, A)).astype(np.float32)
+    adv = f(B)
+    old_mu, old_sigma = (mu + 0.05 * f(B, A)).astype(np.float32), (sig * np.exp(0.05 * f(B, A))).astype(np.float32)
+    tmu, tls = torch.tensor(mu, requires_grad=True), torch.tensor(logstd, requires_grad=True)
+    tsig = torch.exp(tls)
+    nlp = neglogp(torch.tensor(actions), tmu, tsig, tls)
+    old_nlp = (nlp.detach().numpy() + 0.25 * f(B)).astype(np.float32)                 # ratios on both sides of the clip range
+    ratio = torch.exp(torch.tensor(old_nlp) - nlp)
+    tadv = torch.tensor(adv)
+    a_loss = torch.max(-tadv * ratio, -tadv * torch.clamp(ratio, 1.0 - e, 1.0 + e)).mean()
+    ent = (0.5 + 0.5 * math.log(2 * math.pi) + tls).sum(-1).mean()
+    bnd = (torch.clamp_max(tmu + 1.0, 0.0) ** 2 + torch.clamp_min(tmu - 1.0, 0.0) ** 2).sum(-1).mean()
+    clipf = (torch.abs(ratio - 1.0) > e).float().mean()
+    kl = policy_kl(tmu.detach(), tsig.detach(), torch.tensor(old_mu), torch.tensor(old_sigma))
+    g3 = np.array([1.0, -0.003, 10.0], np.float32)
+    (g3[0] * a_loss + g3[1] * ent + g3[2] * bnd).backward()
+    rows, out5 = np.zeros((B, 5), np.float32), np.zeros(5, np.float32)
+    dmu, dls = np.zeros((B, A), np.float32), np.zeros((B, A), np.float32)
+    lib.emu_ppo_actor_head(B, A, P(mu), P(logstd), P(actions), P(old_nlp), P(adv), P(old_mu), P(old_sigma), C.c_float(e), P(rows), P(out5),
+                           P(g3), P(dmu), P(dls))
+    want = np.array([t.item() for t in (a_loss.detach(), ent.detach(), bnd.detach(), clipf, kl)])
+    assert 0.2 < want[3] < 0.8 and want[2] > 0                                        # both clip states and the bound are exercised
+    np.testing.assert_allclose(out5, want, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(dmu, tmu.grad.numpy(), rtol=2e-4, atol=2e-7)
+    np.testing.assert_allclose(dls, tls.grad.numpy(), rtol=2e-4, atol=2e-7)
+
+    v, v_old, ret = f(B), f(B), f(B)
+    v = (v_old + 0.3 * f(B)).astype(np.float32)
+    for clip_value in (1, 0):
+        tv = torch.tensor(v, requires_grad=True)
+        tvo, tr = torch.tensor(v_old), torch.tensor(ret)
+        if clip_value:
+            cl = torch.max((tv - tr) ** 2, (tvo + (tv - tvo).clamp(-e, e) - tr) ** 2).mean()
+        else:
+            cl = ((tr - tv) ** 2).mean()
+        (0.5 * cl).backward()
+        rows1, out1, dv = np.zeros(B, np.float32), np.zeros(1, np.float32), np.zeros(B, np.float32)
+        lib.emu_ppo_critic_head(B, P(v), P(v_old), P(ret), C.c_float(e), clip_value, P(rows1), P(out1), P(np.array([0.5], np.float32)), P(dv))
+        np.testing.assert_allclose(out1[0], cl.item(), rtol=2e-6)
+        np.testing.assert_allclose(dv, tv.grad.numpy(), rtol=2e-5, atol=1e-8)
+
+    na, nd = 301, 150
+    la, ld = (2.0 * f(na)).astype(np.float32), (2.0 * f(nd)).astype(np.float32)
+    ta, td = torch.tensor(la, requires_grad=True), torch.tensor(ld, requires_grad=True)
+    bce = torch.nn.BCEWithLogitsLoss()
+    la_loss, ld_loss = bce(ta, torch.zeros_like(ta)), bce(td, torch.ones_like(td))
+    (0.5 * la_loss + 0.25 * ld_loss).backward()
+    rows2, out4 = np.zeros((na + nd, 2), np.float32), np.zeros(4, np.float32)
+    da, dd = np.zeros(na, np.float32), np.zeros(nd, np.float32)
+    lib.emu_ppo_disc_head(na, nd, P(la), P(ld), P(rows2), P(out4), P(np.array([0.5, 0.25], np.float32)), P(da), P(dd))
+    np.testing.assert_allclose(out4, [la_loss.item(), (ta < 0).float().mean().item(), ld_loss.item(), (td > 0).float().mean().item()], rtol=3e-6)
+    np.testing.assert_allclose(da, ta.grad.numpy(), rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(dd, td.grad.numpy(), rtol=2e-5, atol=1e-9)

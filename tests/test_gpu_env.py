@@ -297,6 +297,56 @@ def test_amp_agent_train_epoch_on_the_rollout():
     assert float(agent.running_mean_std.count) > 1.0            # the observation statistics were updated in train mode
 
 
+def test_ppo_loss_heads_give_the_torch_losses_and_gradients_inside_the_agent():
+    """The PPO learner's fused loss heads (learning/ppo_heads.py, csrc/ppo_kernels.hip) against the torch expressions they replace, INSIDE
+    the agent: `compute_loss` on one real minibatch of a rollout with the heads on and off -- every reported scalar, the total loss and the
+    gradient of every parameter (through the actor, critic and discriminator networks) agree to the GEMMs' tolerance; the KL the
+    heads report equals policy_kl."""
+    import yaml
+    from emloco_amd.learning.amp_agent import AMPAgent, policy_kl
+    from emloco_amd.learning.amp_policy import DEFAULT_CFG
+    from emloco_amd.run import RLGPUEnv
+    env = RLGPUEnv(_make_env(64, ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel"]))
+    cfg = yaml.safe_load(open(DEFAULT_CFG))
+    cfg["params"]["network"]["mlp"]["units"] = [256, 128]
+    cfg["params"]["network"]["disc"]["units"] = [128, 64]
+    cfg["params"]["config"].update(horizon_length=8, minibatch_size=128, amp_minibatch_size=128, amp_batch_size=64,
+                                   amp_obs_demo_buffer_size=512, amp_replay_buffer_size=512, mini_epochs=1)
+    os.environ["EMLOCO_PPO_GRAPH"] = "0"
+    try:
+        agent = AMPAgent(env, cfg)
+    finally:
+        os.environ.pop("EMLOCO_PPO_GRAPH")
+    assert agent._fused_heads and agent._flat_adam
+    agent.train_epoch()                                              # fills the dataset, moves the policy off its initial point
+    agent.set_eval()                                                 # (frozen normalisers: two evaluations of one minibatch must see the same inputs)
+    d = {k: (v[:128] if v is not None else None) for k, v in agent.dataset.items()}
+    d["advantages"] = d["advantages"] * 3.0                          # (spread the ratios' effect; clipping happens on both sides)
+    from emloco_amd.learning.amp_agent import amp_dropout_mask
+    masks = None
+    if agent._amp_dropout:
+        torch.manual_seed(0)
+        masks = amp_dropout_mask(agent._amp_minibatch_size, agent.task._num_amp_obs_steps, d["amp_obs"].shape[1] // agent.task._num_amp_obs_steps,
+                                 device=d["amp_obs"].device)
+    res = {}
+    for heads in (True, False):
+        agent._fused_heads = heads
+        agent.bucket.zero()
+        loss, info, mu, sigma = agent.compute_loss(d, dropout_masks=masks)
+        loss.backward()
+        kl = agent._head_kl if heads else policy_kl(mu, sigma, d["mu"], d["sigma"])
+        assert (agent._head_kl is not None) == heads
+        res[heads] = (loss.detach().clone(), {k: v.detach().clone() for k, v in info.items()}, agent.bucket.grads.clone(), kl.detach().clone())
+    agent._fused_heads = True
+    (l1, i1, g1, k1), (l0, i0, g0, k0) = res[True], res[False]
+    assert torch.isfinite(g1).all() and g1.abs().max() > 0
+    assert abs(float(l1) - float(l0)) <= 2e-5 * abs(float(l0)) + 1e-6, (float(l1), float(l0))
+    for k in i0:
+        assert abs(float(i1[k]) - float(i0[k])) <= 1e-4 * abs(float(i0[k])) + 1e-6, (k, float(i1[k]), float(i0[k]))
+    assert abs(float(k1) - float(k0)) <= 1e-4 * abs(float(k0)) + 1e-7
+    assert (g1 - g0).abs().max().item() <= 2e-4 * g0.abs().max().item(), ((g1 - g0).abs().max().item(), g0.abs().max().item())
+
+
 def test_rollout_on_shaped_terrain_collides_with_the_heightfield():
     """terrainProportions with slopes / stairs / obstacles (curriculum layout; no stepping stones: like the reference, a spawn
     next to their 10 m deep gaps averages the gap into its ground height and starts below the stones): the task builds the

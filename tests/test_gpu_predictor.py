@@ -988,6 +988,62 @@ def test_shipped_depth_model_in_the_bf16_mode_is_within_its_bar(golden):
 
 
 @pytest.mark.gpu
+def test_counted_flat_clip_adam_replays_in_a_graph_as_successive_steps():
+    """FlatClipAdam(counted=True) -- the step count on the device (`emloco_adam_clip_flat_counted`), what the PPO learner's graphed
+    optimiser step runs: ONE captured step replayed five times on fresh gradients equals five steps of clip_grad_norm_ + torch.optim.Adam
+    (the bias corrections advance with the device counter), the counter reads 6 after the capture's own step, and the state dict
+    (device `step` entries) loads into a plain torch Adam."""
+    import copy
+    from emloco_amd.predictor.fused_adam import FlatClipAdam
+    dev = "cuda:0"
+    torch.manual_seed(5)
+    ma = torch.nn.Sequential(torch.nn.Linear(70, 130), torch.nn.ReLU(), torch.nn.Linear(130, 9)).to(dev)
+    mb = copy.deepcopy(ma)
+    oa = FlatClipAdam(ma.parameters(), lr=2e-3, counted=True)
+    ob = torch.optim.Adam(mb.parameters(), lr=2e-3)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2)
+    static_g = [torch.zeros_like(p) for p in ma.parameters()]
+
+    def fake_grads(scale):
+        for sg, pb in zip(static_g, mb.parameters()):
+            sg.copy_(torch.randn(sg.shape, device=dev, generator=gen) * scale)
+            pb.grad = sg.clone()
+
+    def body():
+        for pa, sg in zip(ma.parameters(), static_g):
+            pa.grad.copy_(sg)
+        oa.step(max_grad_norm=0.5)
+
+    side = torch.cuda.Stream()
+    fake_grads(1.0)
+    with torch.cuda.stream(side):
+        body()                                                    # step 1, eagerly (warm-up of the capture)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.nn.utils.clip_grad_norm_(mb.parameters(), 0.5)
+    ob.step()
+    g = torch.cuda.CUDAGraph()
+    fake_grads(0.2)
+    with torch.cuda.graph(g):
+        body()                                                    # (capture only: nothing runs)
+    for scale in (0.2, 3.0, 1e-3, 1.0, 0.7):
+        if scale != 0.2:
+            fake_grads(scale)
+        g.replay()
+        torch.nn.utils.clip_grad_norm_(mb.parameters(), 0.5)
+        ob.step()
+    torch.cuda.synchronize()
+    assert float(oa._count) == 6.0
+    for pa, pb in zip(ma.parameters(), mb.parameters()):
+        assert (pa - pb).abs().max().item() <= 3e-6 * max(pb.abs().max().item(), 1e-3) + 1e-7
+    ob2 = torch.optim.Adam(mb.parameters(), lr=2e-3)
+    ob2.load_state_dict(copy.deepcopy(oa.state_dict()))
+    assert all(float(st["step"]) == 6.0 for st in ob2.state.values())
+    oa2 = FlatClipAdam(ma.parameters(), lr=2e-3, counted=True)
+    oa2.load_state_dict(copy.deepcopy(ob.state_dict()))
+    assert float(oa2._count) == 6.0
+
+
 def test_flat_clip_adam_is_torch_adam_with_clip_grad_norm_and_trades_state_dicts():
     """FlatClipAdam (three launches on flat buffers) against clip_grad_norm_ + torch.optim.Adam on a copy of the predictor: parameters
     after four steps, the reported norm; then its state dict loaded into a fresh torch Adam and back -- both continue identically."""
