@@ -91,15 +91,42 @@ __device__ __forceinline__ void gemm_wave_sync() { __builtin_amdgcn_wave_barrier
 // TRANS: 0 = X[row][k] (k contiguous), 1 = X[k][row] (row contiguous).  VEC: 16-byte loads allowed (base, leading
 // dimension and batch stride 16 B aligned; then a clamped quad never leaves its row: ld % 4 == 0 and rows, k <= ld).
 // IO = 1: the operand is bf16 in memory (VEC only): a quad is one 8-byte load, widened on arrival.
-template <int ROWS, int GBK, int TRANS, int VEC, int IO = 0>
+// MASKED = 0 (round 5): the tile lies inside the operand and its k range is whole stages -- no row clamps, no masks (mk = 15 is a
+// compile-time constant: the selects of the stash fold away); only k is still clamped, for the one stage fetched past the end.
+template <int ROWS, int GBK, int TRANS, int VEC, int IO = 0, int MASKED = 1>
 __device__ __forceinline__ void gemm_fetch(f32x4 (&v)[(ROWS * GBK / 4 + 255) / 256], unsigned (&mk)[(ROWS * GBK / 4 + 255) / 256],
                                            const float *X, int ld, int row0, int rows, int k0, int ke, int tid) {
     static_assert(IO == 0 || VEC == 1, "bf16 operands take the vector-load path");
+    static_assert(MASKED == 1 || VEC == 1, "the unmasked fetch is the vector-load path's");
     constexpr int NQ = ROWS * GBK / 4, QR = GBK / 4;
     for (int e = 0; e < (NQ + 255) / 256; ++e) {
         int idx = tid + 256 * e;
         if (NQ % 256 != 0 && idx >= NQ) idx = NQ - 1;          // surplus threads re-read the last quad (never stashed)
         f32x4 t;
+        if constexpr (!MASKED) {
+            // the stage's k origin is workgroup-uniform (a scalar), and so is its clamp for the stage past the end: the per-thread part of
+            // the address does not depend on the stage
+            const int kbase = k0 < ke ? k0 : ke - GBK;
+            if (!TRANS) {
+                const int r = idx / QR, q = idx - r * QR;
+                const long off = (long)(row0 + r) * ld + 4 * q;
+                if (IO) {
+                    const uint2 u = *(const uint2 *)((const unsigned short *)X + kbase + off);
+                    t.x = bf16_lo(u.x); t.y = bf16_hi(u.x); t.z = bf16_lo(u.y); t.w = bf16_hi(u.y);
+                } else t = *(const f32x4 *)(X + kbase + off);
+            } else {
+                const int kk = idx / (ROWS / 4), rq = idx - kk * (ROWS / 4);
+                const long off = (long)kk * ld + row0 + 4 * rq;
+                const long kb_off = (long)kbase * ld;
+                if (IO) {
+                    const uint2 u = *(const uint2 *)((const unsigned short *)X + kb_off + off);
+                    t.x = bf16_lo(u.x); t.y = bf16_hi(u.x); t.z = bf16_lo(u.y); t.w = bf16_hi(u.y);
+                } else t = *(const f32x4 *)(X + kb_off + off);
+            }
+            mk[e] = 15u;
+            v[e] = t;
+            continue;
+        }
         bool ok0, ok1, ok2, ok3;
         if (!TRANS) {                                          // 4 consecutive k of one row
             const int r = idx / QR, q = idx - r * QR;
@@ -234,10 +261,19 @@ __device__ __forceinline__ bool split_trans_map(int tid, int &rq, int &kp) {
     return tid < 128;
 }
 // TRANS operand, ROWS rows x 16 k, 256 threads: the quads (4 rows) at k = 2 kp and 2 kp + 1
-template <int ROWS>
+template <int ROWS, int MASKED = 1>
 __device__ __forceinline__ void split_fetch_trans(f32x4 (&v)[2], unsigned (&mk)[2], const float *X, int ld, int row0, int rows, int k0, int ke, int tid) {
     int rq, kp;
     split_trans_map<ROWS>(tid, rq, kp);
+    if constexpr (!MASKED) {
+        const long kb_off = (long)(k0 < ke ? k0 : ke - 16) * ld;          // workgroup-uniform (scalar): the stage, clamped past the end
+        for (int e = 0; e < 2; ++e) {
+            const long off = (long)(2 * kp + e) * ld + row0 + 4 * rq;     // per thread, the same for every stage
+            v[e] = *(const f32x4 *)(X + kb_off + off);
+            mk[e] = 15u;
+        }
+        return;
+    }
     const int row = row0 + 4 * rq, rq4 = (rows - 1) & ~3;
     const int rowc = row < rq4 ? row : rq4;
     const unsigned rm = (row < rows ? 1u : 0u) | (row + 1 < rows ? 2u : 0u) | (row + 2 < rows ? 4u : 0u) | (row + 3 < rows ? 8u : 0u);
@@ -309,6 +345,10 @@ __device__ __forceinline__ void split_frag(const unsigned *S, int row, int half,
 // flight) do not lower the occupancy of the plain variants.
 // EPIO (EPI = 1 only): the mask and the output are bf16 in memory -- a template parameter, not a flag: a run-time dtype test inside
 // the mask prefetch turns sixteen loads in flight into sixteen round trips (measured: 1.7 -> 5.4 ms per launch)
+// (Measured and dropped in round 5, profiles/r05_ab_gemm_pf2.txt: the split mode with the global loads TWO stages ahead of the matrix
+// instructions -- two register sets, the stash woven between the matrix instructions with sched_group_barrier -- costs 70 registers, i.e.
+// two workgroups per CU instead of three, and is 5 % slower on the tall GEMMs, 15 % on the M = 2 048 ones.)
+template <int V> struct gemm_int_c { static constexpr int value = V; };
 template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int PREC, int EPI, int IOA = 0, int IOB = 0, int EPIO = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     constexpr int BM = WM * TI * 32, BN = WN * TJ * 32, GLDK = GBK + 4, NF = GBK / 8;
@@ -338,14 +378,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
         for (int j = 0; j < TJ; ++j)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // The main loop twice (round 5): MK = 0 for a tile that lies inside both operands with a k range of whole stages (every tile of
+    // the predictor's tall GEMMs but the last row of tiles) -- no clamps, no masks, no selects: 107 instead of 132 vector instructions
+    // per stage of the split mode beside its 24 matrix instructions (the two pipes take turns on a SIMD: profiles/r05_gemm_split_counters.txt).
+    const bool inside = VEC && m0 + BM <= g.m && n0 + BN <= g.n && ke > kb && (ke - kb) % GBK == 0;
+    auto main_loop = [&](auto mk_c) {
+    constexpr int MK = decltype(mk_c)::value;
     f32x4 ra[QA], rb[QB];
     unsigned ma[QA], mb[QB];
     // fetch / stash of one stage in the mode's own LDS image
 #define GEMM_FETCH(K0)                                                                                          \
-    if constexpr (PREC == 2 && TA) split_fetch_trans<BM>(ra, ma, A, g.lda, m0, g.m, (K0), ke, tid);             \
-    else gemm_fetch<BM, GBK, TA, VEC, IOA>(ra, ma, A, g.lda, m0, g.m, (K0), ke, tid);                           \
-    if constexpr (PREC == 2 && TB) split_fetch_trans<BN>(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);             \
-    else gemm_fetch<BN, GBK, TB, VEC, IOB>(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);
+    if constexpr (PREC == 2 && TA) split_fetch_trans<BM, MK>(ra, ma, A, g.lda, m0, g.m, (K0), ke, tid);         \
+    else gemm_fetch<BM, GBK, TA, VEC, IOA, MK>(ra, ma, A, g.lda, m0, g.m, (K0), ke, tid);                       \
+    if constexpr (PREC == 2 && TB) split_fetch_trans<BN, MK>(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);         \
+    else gemm_fetch<BN, GBK, TB, VEC, IOB, MK>(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);
 #define GEMM_STASH(BUF)                                                                                         \
     if constexpr (PREC == 2) {                                                                                  \
         split_stash<BM, TA>(ra, ma, (unsigned *)As[BUF], tid);                                                  \
@@ -354,13 +400,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
         gemm_stash<BM, GBK, TA>(ra, ma, As[BUF], tid);                                                          \
         gemm_stash<BN, GBK, TB>(rb, mb, Bs[BUF], tid);                                                          \
     }
+    const int half8 = (GBK / 2) * (lane >> 5), l31 = lane & 31;
     if (kb < ke) {
         GEMM_FETCH(kb)
         GEMM_STASH(0)
     }
     __syncthreads();
     int buf = 0;
-    const int half8 = (GBK / 2) * (lane >> 5), l31 = lane & 31;
     for (int k0 = kb; k0 < ke; k0 += GBK) {
         // next stage's global loads are in flight during the MFMAs (past the end they fetch zeros: clamped + masked)
         GEMM_FETCH(k0 + GBK)
@@ -407,6 +453,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     }
 #undef GEMM_FETCH
 #undef GEMM_STASH
+    };
+    if constexpr (VEC) {
+        if (inside) main_loop(gemm_int_c<0>{});
+        else main_loop(gemm_int_c<1>{});
+    } else main_loop(gemm_int_c<1>{});
     // epilogue: C/D fragment layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  A lane owns ONE column per (j): its
     // bias is read once (left inside the row loop, every store to C makes the compiler reload it: C may alias the bias).
     // Addresses are a workgroup-uniform tile base (scalar registers) + a 32-bit lane offset: one VGPR per access instead of a
@@ -596,7 +647,6 @@ gemm_split_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, TA, TB, 1, 2, 0>(g); }
 template <int TB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 gemm_split_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, 0, TB, 1, 2, 1, 0, 0, 0>(g); }
-
 // split mode on a 64 x 64 tile (four waves, one matrix tile each; 26 KB of LDS: up to six workgroups per CU) for launches that
 // are too small to fill the chip with 128 x 128 tiles -- the learners' and the policy's M = 2 048 .. 4 096 layers: 128 .. 512
 // workgroups on 256 CUs leave every SIMD with one wave and nothing to hide a load, a barrier or a matrix chain behind.

@@ -407,7 +407,8 @@ def test_mfma_gemm_kernel_split_mode_is_fp32_class():
     the pieces must rebuild every operand exactly (a wrong slot, plane or k pairing shows as an error of 2^-8, not 2^-24)."""
     rng = np.random.default_rng(21)
     SPLIT = 1024
-    for m, n, k in ((148, 136, 44), (72, 260, 520), (256, 128, 16)):
+    # (256 x 256 x 80 and 256 x 128 x 16: every tile inside both operands, whole stages -- the main loop without clamps and masks, round 5)
+    for m, n, k in ((148, 136, 44), (72, 260, 520), (256, 128, 16), (256, 256, 80)):
         A = (rng.normal(size=(1, m, k)) * np.exp(rng.uniform(-3, 3, size=(1, m, k)))).astype(np.float32)
         B = (rng.normal(size=(1, n, k)) * np.exp(rng.uniform(-3, 3, size=(1, n, k)))).astype(np.float32)
         ref = A[0].astype(np.float64) @ B[0].astype(np.float64).T

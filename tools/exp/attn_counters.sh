@@ -7,13 +7,13 @@ rm -rf /tmp/ac1 /tmp/ac2
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/ac1 -- python $R/tools/exp/jta_step.py 2 > /tmp/ac1.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_MISC --output-format csv -d /tmp/ac2 -- python $R/tools/exp/jta_step.py 2 > /tmp/ac2.log 2>&1
 python - $P > $OUT/attn_counters_${L}_${P}.txt <<'PY'
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("/tmp/ac1", "/tmp/ac2"):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"][:60]
-            if "attn" in k or "ffn_chain" in k:
+            if any(t in k for t in (os.environ.get("KFILTER") or "attn,ffn_chain").split(",")):
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print(f"SQ counters of the attention kernels, JTA train step ({sys.argv[1]}), rocprofv3 --pmc (two passes), the LARGEST launches of each kernel (the five full local layers), mean per launch")
 for k, c in agg.items():
