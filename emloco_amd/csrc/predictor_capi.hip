@@ -99,6 +99,12 @@ int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha, const float 
     g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (stride_b % 4 == 0);
     g.a16 = (flags & EMLOCO_GEMM_A_BF16MEM) ? 1 : 0; g.b16 = (flags & EMLOCO_GEMM_B_BF16MEM) ? 1 : 0;
     g.c16 = (flags & EMLOCO_GEMM_C_BF16MEM) ? 1 : 0; g.m16 = 0;
+    if (flags & EMLOCO_GEMM_B_SPLITIMG) {                     // B = the piece image of a weight (emloco_gemm_split_pack), A row-major fp32
+        if (!(flags & EMLOCO_GEMM_SPLIT) || (flags & EMLOCO_GEMM_BF16) || batch != 1 || trans_a || !g.vec_a || n <= 32 || (uintptr_t)B % 16)
+            return pfail(-1, "emloco_gemm_f32: a piece image serves the split mode with a row-major, 16-byte-aligned A, batch 1, n > 32");
+        g.bimg = 1; g.vec_b = 1; g.tb = 0;
+        g.flags &= ~EMLOCO_GEMM_B_SPLITIMG;
+    }
     // 16-byte stores of whole output lines (the LDS-transposed epilogue): EMLOCO_GEMM_WIDE_STORES=0 keeps the per-register stores (A/B knob)
     static const bool wide = !(getenv("EMLOCO_GEMM_WIDE_STORES") && getenv("EMLOCO_GEMM_WIDE_STORES")[0] == '0');
     g.vec_c = (wide && (uintptr_t)C % 16 == 0 && ldc % (g.c16 ? 8 : 4) == 0 && stride_c % (g.c16 ? 8 : 4) == 0) ? 1 : 0;
@@ -143,6 +149,20 @@ int emloco_gemm_f32_ex(int batch, int m, int n, int k, float alpha, const float 
         g_head = (slot + 1) % kRing;
         if (g_count < kRing) ++g_count;
     }
+    return 0;
+}
+
+int64_t emloco_gemm_split_image_words(int n, int k) {
+    if (n < 1 || k < 1) return 0;
+    return (int64_t)((n + 127) / 128) * ((k + 15) / 16) * SPLIT_IMG_SLOTS * 4;
+}
+
+int emloco_gemm_split_pack(const float *W, int n, int k, int ld, int trans, uint32_t *image, void *stream) {
+    if (!W || !image || n < 1 || k < 1 || ld < (trans ? n : k) || (uintptr_t)image % 16)
+        return pfail(-1, "emloco_gemm_split_pack: bad argument (image = emloco_gemm_split_image_words(n, k) 32-bit words, 16-byte aligned)");
+    hipLaunchKernelGGL(emloco::gemm_split_pack_kernel, dim3((unsigned)((k + 15) / 16), (unsigned)((n + 127) / 128)), dim3(256), 0, (hipStream_t)stream,
+                       W, n, k, ld, trans, (emloco::gemm_u32x4 *)image);
+    PHIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -251,6 +271,10 @@ int emloco_gemm_relu_bwd(int m, int n, int k, const float *A, int lda, const flo
                        0, 0, 0.0f, 0u, y, scale, workspace};
     g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
     g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
+    if (flags & EMLOCO_GEMM_B_SPLITIMG) {                     // B = the weight's piece image (emloco_gemm_split_pack)
+        if (!(g.flags & EMLOCO_GEMM_SPLIT) || (uintptr_t)B % 16) return pfail(-1, "emloco_gemm_relu_bwd: a piece image needs EMLOCO_GEMM_SPLIT (without EMLOCO_GEMM_BF16) and 16-byte alignment");
+        g.bimg = 1; g.vec_b = 1; g.tb = 0;
+    }
     g.a16 = g.b16 = 0;                                        // the incoming gradient and the weight are fp32
     g.c16 = (flags & EMLOCO_GEMM_C_BF16MEM) ? 1 : 0; g.m16 = (flags & EMLOCO_GEMM_MASK_BF16MEM) ? 1 : 0;
     if ((g.c16 || g.m16) && (!(flags & EMLOCO_GEMM_BF16) || g.c16 != g.m16))

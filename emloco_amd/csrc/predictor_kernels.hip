@@ -43,6 +43,7 @@ struct GemmArgs {
     // element; leading dimensions and strides still count elements).  The large activations of an encoder layer -- the fused
     // q|k|v projection and the feed-forward hidden layer -- live in HBM as bf16 there; accumulation stays fp32.
     int a16, b16, c16, m16;
+    int bimg;           // split mode: B points at the piece image of a weight (gemm_split_pack_kernel), not at the matrix
     int small;          // split mode on the 64 x 64 tile (gemm_split_small_kernel): the launcher sets it and sizes the grid for it
     int vec_c;          // the output may be written with 16-byte stores (base, leading dimension and batch stride 16 B aligned): the
                         // epilogue then passes each 32 x 32 accumulator tile through LDS and stores whole lines (round 5)
@@ -327,6 +328,62 @@ __device__ __forceinline__ void split_frag(const unsigned *S, int row, int half,
     for (int p = 0; p < 3; ++p) out[p] = *(const bf16w4 *)(src + p * split_plane_words(ROWS));
 }
 
+// ---- a B operand that was cut ONCE (round 5): the piece image of a weight matrix -------------------------------------------
+// In y = x W^T and dx = dy W the B operand is a WEIGHT: every one of the thousands of workgroups of a tall GEMM cuts the same 128 x 16
+// stage of it into pieces again (44 of a stage's ~105 vector instructions, beside 24 matrix instructions whose pipe takes turns with
+// the vector pipe).  gemm_split_pack_kernel cuts it once into the stages' own LDS image -- per (128-column tile, 16-k stage) three
+// planes x two halves x 128 slots of 16 bytes = 768 slots, zeros beyond the matrix -- and the GEMM (IOB = 2) copies a stage with three
+// 16-byte loads and three 16-byte LDS stores per thread, no vector arithmetic, no masks.  Same pieces, same products: the same bits.
+#define SPLIT_IMG_SLOTS 768            /* 16-byte slots per (tile, stage) */
+typedef unsigned gemm_u32x4 __attribute__((vector_size(16)));
+__global__ void __launch_bounds__(256)
+gemm_split_pack_kernel(const float *W, int n, int k, int ld, int trans, gemm_u32x4 *image) {
+    const int st = blockIdx.x, jt = blockIdx.y, nst = gridDim.x;
+    const int h = threadIdx.x >> 7, slot = threadIdx.x & 127;
+    const int row = jt * 128 + slot, k8 = st * 16 + 8 * h;
+    float v[8];
+    for (int i = 0; i < 8; ++i) {
+        const int kk = k8 + i;
+        const bool ok = row < n && kk < k;
+        const long idx = trans ? (long)(ok ? kk : 0) * ld + (ok ? row : 0) : (long)(ok ? row : 0) * ld + (ok ? kk : 0);
+        const float x = W[idx];
+        v[i] = ok ? x : 0.0f;
+    }
+    unsigned p1[4], p2[4], p3[4];
+    for (int w = 0; w < 4; ++w) split_pair(v[2 * w], v[2 * w + 1], p1[w], p2[w], p3[w]);
+    gemm_u32x4 *dst = image + ((long)jt * nst + st) * SPLIT_IMG_SLOTS + h * 128 + slot;
+    dst[0] = gemm_u32x4{p1[0], p1[1], p1[2], p1[3]};
+    dst[256] = gemm_u32x4{p2[0], p2[1], p2[2], p2[3]};
+    dst[512] = gemm_u32x4{p3[0], p3[1], p3[2], p3[3]};
+}
+// a stage of the image for a ROWS-wide tile (ROWS = 64: one half of the 128 slots): slots per thread
+constexpr int split_img_nv(int rows) { return (6 * rows + 255) / 256; }
+template <int ROWS>
+__device__ __forceinline__ void split_img_fetch(gemm_u32x4 (&v)[split_img_nv(ROWS)], const gemm_u32x4 *image, int n0, int nst, int k0, int tid) {
+    int st = k0 >> 4;
+    st = st < nst ? st : nst - 1;                              // (the stage fetched past the end: any valid one, it is never multiplied)
+    const gemm_u32x4 *src = image + ((long)(n0 >> 7) * nst + st) * SPLIT_IMG_SLOTS + (ROWS == 64 ? (n0 & 64) : 0);
+#pragma unroll
+    for (int e = 0; e < split_img_nv(ROWS); ++e) {
+        int q = tid + 256 * e;
+        if (6 * ROWS % 256 != 0 && q >= 6 * ROWS) q = 6 * ROWS - 1;
+        const int ph = q / ROWS, sl = q - ph * ROWS;           // ph = plane * 2 + half
+        v[e] = src[ph * 128 + sl];
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void split_img_stash(const gemm_u32x4 (&v)[split_img_nv(ROWS)], unsigned *S, int tid) {
+    constexpr int HW = split_half_words(ROWS), PW = split_plane_words(ROWS);
+#pragma unroll
+    for (int e = 0; e < split_img_nv(ROWS); ++e) {
+        const int q = tid + 256 * e;
+        if (6 * ROWS % 256 == 0 || q < 6 * ROWS) {
+            const int ph = q / ROWS, sl = q - ph * ROWS;
+            *(gemm_u32x4 *)(S + (ph >> 1) * PW + (ph & 1) * HW + sl * 4) = v[e];
+        }
+    }
+}
+
 // Tile shapes: <2,2,2,2> = 128x128 (4 waves as 2x2, each 2x2 MFMA tiles) for the projections / FFN / score products;
 // <4,1,1,1> = 128x32 (4 waves stacked in M, one MFMA tile each) for the products whose N is the head dim (32):
 // P.V, dQ, dK, dV -- a 128-wide tile would waste 3/4 of its MFMAs there.
@@ -353,8 +410,9 @@ template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int 
 __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     constexpr int BM = WM * TI * 32, BN = WN * TJ * 32, GLDK = GBK + 4, NF = GBK / 8;
     constexpr int QA = (PREC == 2 && TA) ? 2 : (BM * GBK / 4 + 255) / 256, QB = (PREC == 2 && TB) ? 2 : (BN * GBK / 4 + 255) / 256;
-    static_assert(PREC != 2 || (GBK == 16 && (BM == 128 || BM == 64) && (BN == 128 || BN == 64) && VEC == 1 && IOA == 0 && IOB == 0),
-                  "split mode: 128 / 64-row x 16 stages, fp32 operands, 16-byte loads");
+    static_assert(PREC != 2 || (GBK == 16 && (BM == 128 || BM == 64) && (BN == 128 || BN == 64) && VEC == 1 && IOA == 0 && (IOB == 0 || IOB == 2)),
+                  "split mode: 128 / 64-row x 16 stages, fp32 operands (or B as its piece image), 16-byte loads");
+    static_assert(IOB != 2 || PREC == 2, "the piece image is the split mode's");
     constexpr int SA = PREC == 2 ? split_stage_words(BM) : BM * GLDK, SB = PREC == 2 ? split_stage_words(BN) : BN * GLDK;
     __shared__ __attribute__((aligned(16))) float As[2][SA], Bs[2][SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -371,7 +429,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     const int ke = (kb + kchunk < g.k) ? kb + kchunk : g.k;
     // (a bf16 operand is addressed in 2-byte elements: the batch stride is applied on that type)
     const float *A = IOA ? (const float *)((const unsigned short *)g.A + (long)b * g.sa) : g.A + (long)b * g.sa;
-    const float *B = IOB ? (const float *)((const unsigned short *)g.B + (long)b * g.sb) : g.B + (long)b * g.sb;
+    const float *B = IOB == 2 ? g.B : (IOB ? (const float *)((const unsigned short *)g.B + (long)b * g.sb) : g.B + (long)b * g.sb);
+    const int img_nst = (g.k + 15) >> 4;                       // stages of the piece image (IOB = 2)
 
     f32x16 acc[TI][TJ];
     for (int i = 0; i < TI; ++i)
@@ -381,21 +440,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     // The main loop twice (round 5): MK = 0 for a tile that lies inside both operands with a k range of whole stages (every tile of
     // the predictor's tall GEMMs but the last row of tiles) -- no clamps, no masks, no selects: 107 instead of 132 vector instructions
     // per stage of the split mode beside its 24 matrix instructions (the two pipes take turns on a SIMD: profiles/r05_gemm_split_counters.txt).
-    const bool inside = VEC && m0 + BM <= g.m && n0 + BN <= g.n && ke > kb && (ke - kb) % GBK == 0;
+    const bool inside = VEC && m0 + BM <= g.m && (IOB == 2 || n0 + BN <= g.n) && ke > kb && (ke - kb) % GBK == 0;
     auto main_loop = [&](auto mk_c) {
     constexpr int MK = decltype(mk_c)::value;
     f32x4 ra[QA], rb[QB];
     unsigned ma[QA], mb[QB];
+    gemm_u32x4 rbi[split_img_nv(BN)];                              // (IOB = 2: a stage of B's piece image)
     // fetch / stash of one stage in the mode's own LDS image
 #define GEMM_FETCH(K0)                                                                                          \
     if constexpr (PREC == 2 && TA) split_fetch_trans<BM, MK>(ra, ma, A, g.lda, m0, g.m, (K0), ke, tid);         \
     else gemm_fetch<BM, GBK, TA, VEC, IOA, MK>(ra, ma, A, g.lda, m0, g.m, (K0), ke, tid);                       \
-    if constexpr (PREC == 2 && TB) split_fetch_trans<BN, MK>(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);         \
-    else gemm_fetch<BN, GBK, TB, VEC, IOB, MK>(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);
+    if constexpr (IOB == 2) split_img_fetch<BN>(rbi, (const gemm_u32x4 *)B, n0, img_nst, (K0), tid);                 \
+    else if constexpr (PREC == 2 && TB) split_fetch_trans<BN, MK>(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);    \
+    else gemm_fetch<BN, GBK, TB, VEC, (IOB == 2 ? 0 : IOB), MK>(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);
 #define GEMM_STASH(BUF)                                                                                         \
     if constexpr (PREC == 2) {                                                                                  \
         split_stash<BM, TA>(ra, ma, (unsigned *)As[BUF], tid);                                                  \
-        split_stash<BN, TB>(rb, mb, (unsigned *)Bs[BUF], tid);                                                  \
+        if constexpr (IOB == 2) split_img_stash<BN>(rbi, (unsigned *)Bs[BUF], tid);                             \
+        else split_stash<BN, TB>(rb, mb, (unsigned *)Bs[BUF], tid);                                             \
     } else {                                                                                                    \
         gemm_stash<BM, GBK, TA>(ra, ma, As[BUF], tid);                                                          \
         gemm_stash<BN, GBK, TB>(rb, mb, Bs[BUF], tid);                                                          \
@@ -416,7 +478,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
         if constexpr (PREC == 2) {
             bf16w4 sa[TI][3], sb[TJ][3];
             for (int i = 0; i < TI; ++i) split_frag<BM, TA>((const unsigned *)As[buf], (wm * TI + i) * 32 + l31, lane >> 5, sa[i]);
-            for (int j = 0; j < TJ; ++j) split_frag<BN, TB>((const unsigned *)Bs[buf], (wn * TJ + j) * 32 + l31, lane >> 5, sb[j]);
+            for (int j = 0; j < TJ; ++j) split_frag<BN, (IOB == 2 ? 0 : TB)>((const unsigned *)Bs[buf], (wn * TJ + j) * 32 + l31, lane >> 5, sb[j]);
             // the six products, smallest first; term-outer so that consecutive matrix instructions go to different accumulators
 #define SPLIT_TERM(PA, PB)                                                                                      \
             for (int i = 0; i < TI; ++i)                                                                        \
@@ -647,6 +709,14 @@ gemm_split_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, TA, TB, 1, 2, 0>(g); }
 template <int TB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 gemm_split_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, 0, TB, 1, 2, 1, 0, 0, 0>(g); }
+// B as the piece image of a weight (IOB = 2; A row-major): the forward and input-gradient GEMMs of the linear layers
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+gemm_split_img_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, 0, 0, 1, 2, 0, 0, 2>(g); }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+gemm_split_relu_bwd_img_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, 0, 0, 1, 2, 1, 0, 2, 0>(g); }
+__global__ void __launch_bounds__(256)
+gemm_split_small_img_kernel(GemmArgs g) { gemm_body<2, 2, 1, 1, 16, 0, 0, 1, 2, 0, 0, 2>(g); }
+
 // split mode on a 64 x 64 tile (four waves, one matrix tile each; 26 KB of LDS: up to six workgroups per CU) for launches that
 // are too small to fill the chip with 128 x 128 tiles -- the learners' and the policy's M = 2 048 .. 4 096 layers: 128 .. 512
 // workgroups on 256 CUs leave every SIMD with one wave and nothing to hide a load, a barrier or a matrix chain behind.
@@ -692,6 +762,7 @@ inline GemmKernel gemm_pick_layout(int ta, int tb, int vec, int bf16 = 0, int a1
 inline GemmKernel gemm_pick(const GemmArgs &g, bool deep) {
     const int vec = g.vec_a && g.vec_b;
     const int bf16 = (g.flags & 16) ? 1 : 0;
+    if ((g.flags & 32) && (g.flags & 1024) && !bf16 && !g.c16 && !g.m16 && g.bimg) return gemm_split_relu_bwd_img_kernel;
     if ((g.flags & 32) && (g.flags & 1024) && !bf16 && !g.c16 && !g.m16) return g.tb ? gemm_split_relu_bwd_kernel<1> : gemm_split_relu_bwd_kernel<0>;
     if (g.flags & 32) {           // fused backward epilogue: A row-major, 16-byte loads (the launcher checks)
         if (g.c16 || g.m16) {     // bf16 hidden layer and gradient (both or neither: the launcher checks)
@@ -706,6 +777,7 @@ inline GemmKernel gemm_pick(const GemmArgs &g, bool deep) {
         return g.tb ? gemm_f32_relu_bwd_kernel<16, 1, 0> : gemm_f32_relu_bwd_kernel<16, 0, 0>;
     }
     if (g.n <= 32) return deep ? gemm_pick_layout<4, 1, 1, 1, 32>(g.ta, g.tb, vec) : gemm_pick_layout<4, 1, 1, 1, 16>(g.ta, g.tb, vec);
+    if ((g.flags & 1024) && !bf16 && g.bimg) return g.small ? gemm_split_small_img_kernel : gemm_split_img_kernel;
     if ((g.flags & 1024) && vec && !bf16 && g.small) {
         if (!g.ta && !g.tb) return gemm_split_small_kernel<0, 0>;
         if (!g.ta && g.tb) return gemm_split_small_kernel<0, 1>;

@@ -29,6 +29,19 @@ def _ksplit(m, n, k):
     return int(max(1, min(_KSPLIT_TARGET // max(tiles, 1), k // 128, 16)))
 
 
+def _frozen_image(owner, w, n, k):
+    """The piece image of a FROZEN weight (ops.split_image: the matrix cut into the split mode's bf16 pieces once, when first used,
+    instead of by every workgroup of every launch of the rollout); None where the image does not apply (narrow heads).  The weights
+    of these runners are private copies made at construction and never written again."""
+    if n <= 32 or not ops._IMAGE_FROZEN or ops._matmul_precision[0] != "fp32_split":
+        return None
+    cache = owner.__dict__.setdefault("_images", {})
+    key = (w.data_ptr(), n, k)
+    if key not in cache:
+        cache[key] = ops.split_image(w, n, k, w.stride(0), 0)
+    return cache[key]
+
+
 class FrozenPolicy:
     def __init__(self, network, mean_std, num_envs, device, clip_actions=1.0):
         self.E, self.device, self.clip = num_envs, torch.device(device), float(clip_actions)
@@ -75,7 +88,8 @@ class FrozenPolicy:
     def _linear(self, x, k, w, b, out, ldc=None, c_off=0, relu=True):
         m, n = x.shape[0], w.shape[0]
         ops.gemm(1, m, n, k, x, x.stride(0), 0, 0, w, w.stride(0), 0, 0, out, ldc if ldc is not None else out.stride(0), 0,
-                 bias=b, flags=ops.GEMM_BIAS | (ops.GEMM_RELU if relu else 0), ksplit=_ksplit(m, n, k), c_off=c_off)
+                 bias=b, flags=ops.GEMM_BIAS | (ops.GEMM_RELU if relu else 0), ksplit=_ksplit(m, n, k), c_off=c_off,
+                 b_image=_frozen_image(self, w, n, k))
 
     def act_mean(self, obs):
         """obs (E, self+task) fp32 on the device -> mu (E, actions); the returned tensor is reused by the next call."""
@@ -137,7 +151,7 @@ class FrozenDisc:
     def _linear(self, x, k, w, b, out, relu):
         m, n = x.shape[0], w.shape[0]
         ops.gemm(1, m, n, k, x, x.stride(0), 0, 0, w, w.stride(0), 0, 0, out, out.stride(0), 0, bias=b,
-                 flags=ops.GEMM_BIAS | (ops.GEMM_RELU if relu else 0), ksplit=_ksplit(m, n, k))
+                 flags=ops.GEMM_BIAS | (ops.GEMM_RELU if relu else 0), ksplit=_ksplit(m, n, k), b_image=_frozen_image(self, w, n, k))
 
     def logits_of(self, amp_obs):
         x = amp_obs.reshape(amp_obs.shape[0], -1)

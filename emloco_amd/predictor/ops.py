@@ -72,6 +72,9 @@ def _lib():
         lib.emloco_adam_clip_flat.argtypes = [C.c_int64] + [vp] * 4 + [cf, C.c_double, C.c_double] + [cf] * 5 + [vp, vp]
         lib.emloco_adam_clip_flat_counted.argtypes = [C.c_int64] + [vp] * 4 + [cf, C.c_double, C.c_double] + [cf] * 3 + [vp, vp, vp]
         lib.emloco_adam_clip_flat_workspace.argtypes = [C.c_int64]
+        lib.emloco_gemm_split_image_words.argtypes = [C.c_int, C.c_int]
+        lib.emloco_gemm_split_image_words.restype = C.c_int64
+        lib.emloco_gemm_split_pack.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         lib.emloco_adam_clip_flat_workspace.restype = C.c_int64
         lib.emloco_gemm_enable_timing.argtypes = [ci]
         lib.emloco_ffn_fwd.argtypes = [ci, ci] + [vp] * 8 + [cf, C.c_uint32, C.c_uint32, vp]
@@ -101,6 +104,30 @@ def _chk(rc, what):
 GEMM_BF16 = 16
 GEMM_SPLIT = 1024      # EMLOCO_GEMM_SPLIT: fp32-class products from bf16 pieces (six bf16 matrix instructions per 16 k)
 GEMM_A16, GEMM_B16, GEMM_C16, GEMM_MASK16 = 64, 128, 256, 512      # EMLOCO_GEMM_*_BF16MEM: that operand is bf16 in memory
+GEMM_B_SPLITIMG = 2048  # EMLOCO_GEMM_B_SPLITIMG: B is the piece image of a weight (split_image)
+# Frozen weights (the rollout's policy and discriminator) are cut into their bf16 pieces ONCE, when first used (learning/policy_runner.py:
+# +1.4 % on the policy forward, +1.8 % on the configs[2] loop, profiles/r05_ab_weight_image.txt); EMLOCO_GEMM_WEIGHT_IMAGE=0: never.
+# A trained weight would have to be cut once per launch (one small extra launch): measured on the predictor's tall GEMMs that buys
+# nothing (40 % fewer vector instructions in the main loop, the same 132 ms step: those launches are bound by their epilogues and by
+# HBM, not by the cut), so it is off unless EMLOCO_GEMM_WEIGHT_IMAGE_ROWS names a row count from which to do it (the bit-equality
+# test does).
+_IMAGE_FROZEN = os.environ.get("EMLOCO_GEMM_WEIGHT_IMAGE", "1") != "0"
+_IMAGE_MIN_ROWS = int(os.environ.get("EMLOCO_GEMM_WEIGHT_IMAGE_ROWS", "0")) or (1 << 62)
+
+
+def split_image(W, n, k, ld, trans):
+    """Piece image (emloco_gemm_split_pack) of the B operand B(n, k) = W[n * ld + k] (trans = 0) / W[k * ld + n] (trans = 1)."""
+    lib = _lib()
+    img = torch.empty(lib.emloco_gemm_split_image_words(int(n), int(k)), dtype=torch.int32, device=W.device)
+    _chk(lib.emloco_gemm_split_pack(_p(W), int(n), int(k), int(ld), int(trans), _p(img), _st(W)), "emloco_gemm_split_pack")
+    return img
+
+
+def _weight_image(W, rows, n, k, ld, trans):
+    """The image for a launch of `rows` output rows, or None where it does not pay / does not apply."""
+    if rows < _IMAGE_MIN_ROWS or _matmul_precision[0] != "fp32_split" or W.dtype != torch.float32 or n <= 32:
+        return None
+    return split_image(W, n, k, ld, trans)
 ATTN_BF16 = 16
 ATTN_SPLIT = 64        # EMLOCO_ATTN_SPLIT: the fused attention's tile products as fp32-class sums of bf16 piece products
 ATTN_QKV16 = 32        # EMLOCO_ATTN_QKV_BF16MEM
@@ -132,13 +159,16 @@ def get_matmul_precision():
 
 
 def gemm(batch, m, n, k, A, lda, sa, ta, B, ldb, sb, tb, Cm, ldc, sc, alpha=1.0, bias=None, flags=0, ksplit=1,
-         a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0):
+         a_off=0, b_off=0, c_off=0, drop_p=0.0, drop_seed=0, b_image=None):
     """Raw strided batched GEMM: C_b[m][n] (+)= alpha * sum_k A_b(m,k) B_b(n,k) (see the header for the layouts).  bf16 tensors
-    (the reduced-precision mode's large activations) are passed as they are: the dtype travels in the flags."""
+    (the reduced-precision mode's large activations) are passed as they are: the dtype travels in the flags.
+    b_image: the piece image of B (`split_image`) -- the split mode then reads it instead of B (same bits)."""
     if _matmul_precision[0] == "bf16":
         flags |= GEMM_BF16
     elif _matmul_precision[0] == "fp32_split":
         flags |= GEMM_SPLIT
+        if b_image is not None and batch == 1 and not ta and A.dtype == torch.float32 and n > 32 and lda % 4 == 0 and (A.data_ptr() + 4 * a_off) % 16 == 0:
+            B, b_off, flags = b_image, 0, flags | GEMM_B_SPLITIMG
     for t, bit in ((A, GEMM_A16), (B, GEMM_B16), (Cm, GEMM_C16)):
         if t.dtype == torch.bfloat16:
             assert a_off == 0 and b_off == 0 and c_off == 0
@@ -197,7 +227,8 @@ class LinearFn(torch.autograd.Function):
         # (split-K for the learners' small batches: a 2 048 x 1 024 x 2 048 layer is 128 tiles on 256 CUs -- 124 us whole, 62 us in
         # four k-slices, tools/exp/probe_small_gemm.py; the predictor's tall activations have thousands of tiles and stay whole)
         gemm(1, M, N, K, x2, K, 0, 0, Wc, K, 0, 0, y, N, 0, bias=b.contiguous() if b is not None else None, flags=flags,
-             drop_p=drop_p, drop_seed=drop_seed, ksplit=1 if y.dtype == torch.bfloat16 else _ksplit_for(K, M * N))
+             drop_p=drop_p, drop_seed=drop_seed, ksplit=1 if y.dtype == torch.bfloat16 else _ksplit_for(K, M * N),
+             b_image=_weight_image(Wc, M, N, K, K, 0) if x2.dtype == torch.float32 and y.dtype == torch.float32 else None)
         ctx.save_for_backward(x2, Wc, y if relu else None)
         ctx.relu, ctx.has_bias, ctx.xs, ctx.drop = relu, b is not None, xs, (float(drop_p), int(drop_seed))
         return y.view(*xs[:-1], N)
@@ -223,7 +254,8 @@ class LinearFn(torch.autograd.Function):
             dy2 = dz
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            gemm(1, M, K, N, dy2, N, 0, 0, W, K, 0, 1, dx, K, 0, ksplit=1 if dy2.dtype == torch.bfloat16 else _ksplit_for(N, M * K))   # dx = dy W
+            gemm(1, M, K, N, dy2, N, 0, 0, W, K, 0, 1, dx, K, 0, ksplit=1 if dy2.dtype == torch.bfloat16 else _ksplit_for(N, M * K),
+                 b_image=_weight_image(W, M, K, N, K, 1) if dy2.dtype == torch.float32 else None)                                       # dx = dy W
             dx = dx.view(ctx.xs)
         if ctx.needs_input_grad[1]:
             dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
@@ -302,10 +334,13 @@ class FeedForwardFn(torch.autograd.Function):
         # (the bf16-in-memory GEMM variants serve the 128-wide tiles and 8-byte-aligned rows only: small models keep fp32)
         h16 = _matmul_precision[0] == "bf16" and N > 32 and F > 32 and K > 32 and F % 4 == 0 and K % 4 == 0 and N % 4 == 0
         h = torch.empty((M, F), dtype=torch.bfloat16 if h16 else torch.float32, device=x.device)
-        gemm(1, M, F, K, x2, K, 0, 0, W1c, K, 0, 0, h, F, 0, bias=b1.contiguous(), flags=GEMM_BIAS | GEMM_RELU, drop_p=drop_p, drop_seed=seed1)
+        f32 = x2.dtype == torch.float32 and not h16
+        gemm(1, M, F, K, x2, K, 0, 0, W1c, K, 0, 0, h, F, 0, bias=b1.contiguous(), flags=GEMM_BIAS | GEMM_RELU, drop_p=drop_p, drop_seed=seed1,
+             b_image=_weight_image(W1c, M, F, K, K, 0) if f32 else None)
         f = torch.empty((M, N), dtype=torch.float32, device=x.device)
         gemm(1, M, N, F, h, F, 0, 0, W2c, F, 0, 0, f, N, 0, bias=b2.contiguous(), flags=GEMM_BIAS, drop_p=drop_p, drop_seed=seed2,
-             ksplit=_ksplit_for(F, M * N))                     # (whole for the predictor's tall batches; as LinearFn splits a small one)
+             ksplit=_ksplit_for(F, M * N),                     # (whole for the predictor's tall batches; as LinearFn splits a small one)
+             b_image=_weight_image(W2c, M, N, F, F, 0) if f32 else None)
         ctx.save_for_backward(x2, W1c, W2c, h)
         return f.view(*xs[:-1], N)
 
@@ -342,12 +377,14 @@ class FeedForwardFn(torch.autograd.Function):
         db1 = torch.empty(F, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.emloco_gemm_relu_bwd_workspace(M, F), dtype=torch.float32, device=dev)
         fl = (GEMM_BF16 | GEMM_C16 | GEMM_MASK16) if h16 else {"bf16": GEMM_BF16, "fp32_split": GEMM_SPLIT}.get(_matmul_precision[0], 0)
-        _chk(lib.emloco_gemm_relu_bwd(M, F, N, _p(dz2), N, _p(W2), F, 1, _p(dz1), _p(h), 1.0 / (1.0 - p), _p(db1), _p(ws), fl, st),
-             "emloco_gemm_relu_bwd")
+        img2 = _weight_image(W2, M, F, N, F, 1) if (not h16 and dz2.dtype == torch.float32) else None     # B(n = hidden unit, k = output) = W2[k][n]
+        _chk(lib.emloco_gemm_relu_bwd(M, F, N, _p(dz2), N, _p(img2 if img2 is not None else W2), F, 1, _p(dz1), _p(h), 1.0 / (1.0 - p), _p(db1), _p(ws),
+                                      fl | (GEMM_B_SPLITIMG if img2 is not None else 0), st), "emloco_gemm_relu_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-            gemm(1, M, K, F, dz1, F, 0, 0, W1, K, 0, 1, dx, K, 0, ksplit=1 if h16 else _ksplit_for(F, M * K))   # dx = dz1 W1
+            gemm(1, M, K, F, dz1, F, 0, 0, W1, K, 0, 1, dx, K, 0, ksplit=1 if h16 else _ksplit_for(F, M * K),   # dx = dz1 W1
+                 b_image=_weight_image(W1, M, K, F, K, 1) if not h16 else None)
             dx = dx.view(ctx.xs)
         dW1 = torch.empty((F, K), dtype=torch.float32, device=dev)
         gemm(1, F, K, M, dz1, F, 0, 1, x2, K, 0, 1, dW1, K, 0, ksplit=_ksplit_for(M, F * K))         # dW1 = dz1^T x

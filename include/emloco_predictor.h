@@ -36,7 +36,12 @@ enum { EMLOCO_GEMM_BIAS = 1, EMLOCO_GEMM_RELU = 2, EMLOCO_GEMM_ACCUMULATE = 4, E
         * +-Inf for a lone Inf operand; both are non-finite, which is all a caller may rely on (the trainers' NaN handling,
         * train_jta.py:143-165 / :308, treats them alike).  Output elements whose reductions see only finite operands below that
         * bound are unaffected, whatever else is in the matrices. */
-       EMLOCO_GEMM_SPLIT = 1024 };
+       EMLOCO_GEMM_SPLIT = 1024,
+       /* (round 5) with EMLOCO_GEMM_SPLIT: B is not the matrix but its PIECE IMAGE made by emloco_gemm_split_pack -- the operand cut into
+        * bf16 pieces once, in the order the kernel's LDS stages hold them -- for the products whose B is a weight (y = x W^T: pack with
+        * trans = 0; dx = dy W: trans = 1).  A must be row-major fp32, batch 1; ldb / stride_b / trans_b are ignored.  Same pieces, same
+        * products, the same bits as the matrix itself; the thousands of workgroups of a tall GEMM no longer cut the same weight tile. */
+       EMLOCO_GEMM_B_SPLITIMG = 2048 };
 
 /* Batched strided GEMM on the matrix cores, fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: exact fp32):
  *   C[b][m][n] (+)= alpha * sum_k A_b(m,k) * B_b(n,k)   [+ bias[n]] [relu]
@@ -333,6 +338,12 @@ int emloco_ppo_critic_head_bwd(int B, const float *values, const float *old_valu
 int emloco_ppo_disc_head_fwd(int n_agent, int n_demo, const float *agent_logits, const float *demo_logits, float *rows, float *out4, void *stream);
 int emloco_ppo_disc_head_bwd(int n_agent, int n_demo, const float *agent_logits, const float *demo_logits, const float *grad2,
                              float *d_agent, float *d_demo, void *stream);
+
+/* The piece image of a B operand for EMLOCO_GEMM_B_SPLITIMG: B(n, k) = W[n * ld + k] (trans = 0) or W[k * ld + n] (trans = 1), n x k;
+ * image: emloco_gemm_split_image_words(n, k) 32-bit words of device memory, 16-byte aligned (1.5 x the matrix, zero-padded to whole
+ * 128 x 16 stages).  One small launch; valid until W changes.  Also accepted by emloco_gemm_relu_bwd (flags). */
+int64_t emloco_gemm_split_image_words(int n, int k);
+int emloco_gemm_split_pack(const float *W, int n, int k, int ld, int trans, uint32_t *image, void *stream);
 
 /* Tile choice of the split mode (EMLOCO_GEMM_SPLIT): -1 (default) picks the 64 x 64 tile for launches whose 128 x 128 grid would
  * leave CUs idle, 0 / 1 force never / always.  Results do not depend on it (an output element's reduction order is the same in both

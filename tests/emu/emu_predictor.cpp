@@ -17,6 +17,10 @@ extern "C" int emu_gemm_f32(int batch, int m, int n, int k, float alpha, const f
     // flags & (1 << 20): test-only request for the 64 x 64 split tile (the launcher picks it by launch size, gemm_use_small_tile)
     g.small = ((flags & (1 << 20)) && (flags & 1024) && !(flags & 16) && g.vec_a && g.vec_b && n > 32) ? 1 : 0;
     g.flags &= ~(1 << 20);
+    if (flags & 2048) {                     // EMLOCO_GEMM_B_SPLITIMG: B is the weight's piece image (emu_gemm_split_pack), as emloco_gemm_f32_ex serves it
+        g.bimg = 1; g.vec_b = 1; g.tb = 0;
+        g.flags &= ~2048;
+    }
     const unsigned bt = g.small ? 64 : 128;
     const unsigned gx = narrow ? (n + 31) / 32 : (n + bt - 1) / bt, gy = (m + bt - 1) / bt, gz = batch * ksplit;
     for (unsigned z = 0; z < gz; ++z)
@@ -38,6 +42,18 @@ extern "C" int emu_gemm_f32(int batch, int m, int n, int k, float alpha, const f
     return 0;
 }
 
+extern "C" long emu_gemm_split_image_words(int n, int k) { return (long)((n + 127) / 128) * ((k + 15) / 16) * SPLIT_IMG_SLOTS * 4; }
+extern "C" int emu_gemm_split_pack(const float *W, int n, int k, int ld, int trans, unsigned *image) {
+    const unsigned nst = (k + 15) / 16, nt = (n + 127) / 128;
+    for (unsigned y = 0; y < nt; ++y)
+        for (unsigned x = 0; x < nst; ++x) {
+            gridDim.x = nst;
+            emu::launch(1, 256, [&] { blockIdx.x = x; blockIdx.y = y; gridDim.x = nst; gemm_split_pack_kernel(W, n, k, ld, trans, (gemm_u32x4 *)image); });
+        }
+    blockIdx.y = 0;
+    return 0;
+}
+
 // emloco_gemm_relu_bwd without the final fold: C = (A . B) o [y > 0] * scale, colpart [2 ceil(m / 128)][n] = 64-row column sums
 extern "C" int emu_gemm_relu_bwd_ex(int m, int n, int k, const float *A, int lda, const float *B, int ldb, int tb, float *C, const float *y,
                                     float scale, float *colpart, int flags);
@@ -47,9 +63,10 @@ extern "C" int emu_gemm_relu_bwd(int m, int n, int k, const float *A, int lda, c
 }
 extern "C" int emu_gemm_relu_bwd_ex(int m, int n, int k, const float *A, int lda, const float *B, int ldb, int tb, float *C, const float *y,
                                     float scale, float *colpart, int flags) {
-    GemmArgs g{1, m, n, k, 1.0f, A, lda, 0, 0, B, ldb, 0, tb, C, n, 0, nullptr, 32 | flags, 1, nullptr, 0, 0, 0.0f, 0u, y, scale, colpart};
+    GemmArgs g{1, m, n, k, 1.0f, A, lda, 0, 0, B, ldb, 0, tb, C, n, 0, nullptr, 32 | (flags & ~2048), 1, nullptr, 0, 0, 0.0f, 0u, y, scale, colpart};
+    if (flags & 2048) { g.bimg = 1; g.tb = 0; }
     g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
-    g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
+    g.vec_b = g.bimg ? 1 : ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
     g.vec_c = ((uintptr_t)C % 16 == 0) && ((uintptr_t)y % 16 == 0) && (n % 4 == 0) && !(flags & 256);     // wide epilogue accesses, as the launcher decides them
     const unsigned gx = (n + 127) / 128, gy = (m + 127) / 128;
     for (unsigned y0 = 0; y0 < gy; ++y0)

@@ -398,6 +398,11 @@ def test_gemm_epilogue_fuses_relu_dropout_backward_and_bias_gradient():
         assert np.array_equal(Cm, want)
         sums = np.stack([want[r:r + 64].astype(np.float64).sum(0) for r in range(0, 64 * nparts, 64)])
         np.testing.assert_allclose(part, sums, rtol=1e-5, atol=2e-4)
+        img = np.zeros(lib.emu_gemm_split_image_words(n, k), np.uint32)          # the weight as its piece image: same bits
+        lib.emu_gemm_split_pack(P(B), n, k, n if tb else k, tb, C.c_void_p(img.ctypes.data))
+        Cm2, part2 = np.full((m, n), 7.0, np.float32), np.zeros((nparts, n), np.float32)
+        lib.emu_gemm_relu_bwd_ex(m, n, k, P(A), k, C.c_void_p(img.ctypes.data), 0, 0, P(Cm2), P(y), C.c_float(scale), P(part2), SPLIT | 2048)
+        assert np.array_equal(Cm2, Cm) and np.array_equal(part2, part)
 
 
 def test_mfma_gemm_kernel_split_mode_is_fp32_class():
@@ -407,6 +412,8 @@ def test_mfma_gemm_kernel_split_mode_is_fp32_class():
     the pieces must rebuild every operand exactly (a wrong slot, plane or k pairing shows as an error of 2^-8, not 2^-24)."""
     rng = np.random.default_rng(21)
     SPLIT = 1024
+    lib_ = emu.lib()
+    lib_.emu_gemm_split_image_words.restype = C.c_long
     # (256 x 256 x 80 and 256 x 128 x 16: every tile inside both operands, whole stages -- the main loop without clamps and masks, round 5)
     for m, n, k in ((148, 136, 44), (72, 260, 520), (256, 128, 16), (256, 256, 80)):
         A = (rng.normal(size=(1, m, k)) * np.exp(rng.uniform(-3, 3, size=(1, m, k)))).astype(np.float32)
@@ -431,6 +438,18 @@ def test_mfma_gemm_kernel_split_mode_is_fp32_class():
             assert np.array_equal(got, _gemm(a, b, ta, tb, m, n, k, flags=SPLIT)[0]), ("small tile bits", m, n, k, ta, tb)
         got = _gemm(At, Bt, 1, 1, m, n, k, flags=SPLIT | SMALL, ksplit=3)[0]
         assert np.max(np.abs(got - ref) / mag) < 4 * plain_err + 2e-7
+        # B as its PIECE IMAGE (EMLOCO_GEMM_B_SPLITIMG, round 5: a weight cut once by gemm_split_pack_kernel instead of by every
+        # workgroup): from either layout of the matrix, on both tiles, with split k -- the SAME BITS as the matrix itself
+        IMG = 2048
+        words = lib_.emu_gemm_split_image_words(n, k)
+        for Bsrc, trans, ld in ((B, 0, k), (Bt, 1, n)):
+            img = np.zeros((1, words), np.uint32)
+            lib_.emu_gemm_split_pack(P(Bsrc), n, k, ld, trans, C.c_void_p(img.ctypes.data))
+            want = _gemm(A, B, 0, 0, m, n, k, flags=SPLIT)[0]
+            assert np.array_equal(_gemm(A, img.view(np.float32), 0, 0, m, n, k, flags=SPLIT | IMG)[0], want), ("image", m, n, k, trans)
+            assert np.array_equal(_gemm(A, img.view(np.float32), 0, 0, m, n, k, flags=SPLIT | IMG | SMALL)[0], want), ("image, small tile", m, n, k, trans)
+            assert np.array_equal(_gemm(A, img.view(np.float32), 0, 0, m, n, k, flags=SPLIT | IMG, ksplit=2)[0],
+                                  _gemm(A, B, 0, 0, m, n, k, flags=SPLIT, ksplit=2)[0]), ("image, split k", m, n, k, trans)
         bias = rng.normal(size=n).astype(np.float32)
         got = _gemm(A, B, 0, 0, m, n, k, bias=bias, flags=SPLIT | 3, alpha=0.5)[0]
         np.testing.assert_allclose(got, np.maximum(0.5 * ref + bias, 0), rtol=0, atol=2e-6 * float(mag.max()))

@@ -109,6 +109,16 @@ def test_frozen_policy_full_width_vs_torch_fp32():
         ref = F.linear(h, sd["mu.weight"], sd["mu.bias"])
     _close(mu.cpu(), ref.cpu(), what="full-width mu")
     assert pol.flops_per_env == 2 * (1056 * 512 + 512 * 256 + 624 * 2048 + 2048 * 1024 + 1024 * 69)
+    # round 5: the frozen weights are read as piece images (cut once at first use: policy_runner._frozen_image) -- the same bits as the matrices
+    from emloco_amd.predictor import ops
+    if ops._matmul_precision[0] == "fp32_split":
+        assert len(pol._images) == 5
+        with_images = mu.clone()
+        ops._IMAGE_FROZEN = False
+        try:
+            assert torch.equal(FrozenPolicy(net, rms, E, DEV).act_mean(obs), with_images)
+        finally:
+            ops._IMAGE_FROZEN = True
 
 
 class _FakeTask:

@@ -1096,3 +1096,40 @@ def test_flat_clip_adam_is_torch_adam_with_clip_grad_norm_and_trades_state_dicts
     next(ma.parameters()).grad = torch.zeros_like(next(ma.parameters()))
     with pytest.raises(RuntimeError, match="no longer aliases"):
         oa2.step()
+
+
+def test_weight_piece_images_give_the_same_bits_as_the_matrices():
+    """Round 5: in the split mode a linear layer can read its weight as a piece image (`ops.split_image`, EMLOCO_GEMM_B_SPLITIMG: the
+    matrix cut into bf16 pieces once, not by each of the launch's workgroups; what the frozen policy's layers do, and the trained layers
+    from EMLOCO_GEMM_WEIGHT_IMAGE_ROWS rows on) -- forward, input gradient, the feed-forward block's fused backward: outputs and all
+    gradients BIT-EQUAL to the same calls on the matrices (ragged row count, dropout on)."""
+    from emloco_amd.predictor import ops
+    dev = "cuda:0"
+    prev = ops._matmul_precision[0]
+    ops.set_matmul_precision("fp32_split")
+    try:
+        torch.manual_seed(4)
+        M, K, F = 20011, 128, 256
+        x = torch.randn(M, K, device=dev)
+        W1, b1 = torch.randn(F, K, device=dev) * 0.1, torch.randn(F, device=dev) * 0.1
+        W2, b2 = torch.randn(K, F, device=dev) * 0.1, torch.randn(K, device=dev) * 0.1
+        Wq, bq = torch.randn(3 * K, K, device=dev) * 0.1, torch.randn(3 * K, device=dev) * 0.1
+        gy = torch.randn(M, K, device=dev)
+        gq = torch.randn(M, 3 * K, device=dev)
+        res = {}
+        for use in (True, False):
+            ops._IMAGE_MIN_ROWS = 16384 if use else (1 << 62)
+            leaves = [t.clone().requires_grad_(True) for t in (x, W1, b1, W2, b2, Wq, bq)]
+            xx, w1, bb1, w2, bb2, wq, bbq = leaves
+            ops._drop_counter[0] = 77
+            y = ops.feed_forward(xx, w1, bb1, w2, bb2, drop_p=0.1)
+            q = ops.linear(xx, wq, bbq)
+            (y * gy).sum().backward(retain_graph=True)
+            (q * gq).sum().backward()
+            res[use] = [y.detach().clone(), q.detach().clone()] + [t.grad.clone() for t in leaves]
+        for a, b in zip(res[True], res[False]):
+            assert torch.equal(a, b)
+        assert res[True][2].abs().max() > 0
+    finally:
+        ops._IMAGE_MIN_ROWS = 1 << 62
+        ops.set_matmul_precision(prev)
