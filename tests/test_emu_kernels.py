@@ -398,11 +398,6 @@ def test_gemm_epilogue_fuses_relu_dropout_backward_and_bias_gradient():
         assert np.array_equal(Cm, want)
         sums = np.stack([want[r:r + 64].astype(np.float64).sum(0) for r in range(0, 64 * nparts, 64)])
         np.testing.assert_allclose(part, sums, rtol=1e-5, atol=2e-4)
-        img = np.zeros(lib.emu_gemm_split_image_words(n, k), np.uint32)          # the weight as its piece image: same bits
-        lib.emu_gemm_split_pack(P(B), n, k, n if tb else k, tb, C.c_void_p(img.ctypes.data))
-        Cm2, part2 = np.full((m, n), 7.0, np.float32), np.zeros((nparts, n), np.float32)
-        lib.emu_gemm_relu_bwd_ex(m, n, k, P(A), k, C.c_void_p(img.ctypes.data), 0, 0, P(Cm2), P(y), C.c_float(scale), P(part2), SPLIT | 2048)
-        assert np.array_equal(Cm2, Cm) and np.array_equal(part2, part)
 
 
 def test_mfma_gemm_kernel_split_mode_is_fp32_class():
@@ -473,6 +468,11 @@ def test_mfma_gemm_kernel_split_mode_is_fp32_class():
         assert np.array_equal(Cm, want)
         sums = np.stack([want[r:r + 64].astype(np.float64).sum(0) for r in range(0, 64 * nparts, 64)])
         np.testing.assert_allclose(part, sums, rtol=1e-5, atol=2e-4)
+        img = np.zeros(lib.emu_gemm_split_image_words(n, k), np.uint32)          # the weight as its piece image: same bits
+        lib.emu_gemm_split_pack(P(B), n, k, n if tb else k, tb, C.c_void_p(img.ctypes.data))
+        Cm2, part2 = np.full((m, n), 7.0, np.float32), np.zeros((nparts, n), np.float32)
+        lib.emu_gemm_relu_bwd_ex(m, n, k, P(A), k, C.c_void_p(img.ctypes.data), 0, 0, P(Cm2), P(y), C.c_float(scale), P(part2), SPLIT | 2048)
+        assert np.array_equal(Cm2, Cm) and np.array_equal(part2, part)
 
 
 def test_mfma_gemm_kernel_bf16_operands():
