@@ -494,7 +494,8 @@ def policy_leg(env, E, dev, steps, warmup):
             "precision": precision,
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(tf, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(tf / peak, 4), "frac_of_fp32_instruction_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                         "note": "normalise + 5 GEMM launches (bias / ReLU fused), median of 20 HIP-event timings; " + peak_note},
+                         "note": "normalise + 5 GEMM launches (bias / ReLU fused; round 5: the frozen weights read as piece images cut once), "
+                                 "median of 20 HIP-event timings; " + peak_note},
             "weights": "random init (no checkpoint ships)"}
 
 
@@ -558,7 +559,9 @@ def ppo_leg(env, E, dev, epochs=2, warmup=1):
                          "traffic": None, "note": peak_note},
             "note": "fps_step / fps_total as common_agent.py:183-194 defines them (frames / play_time, frames / total_time), the host "
                     "synchronisations of the reference's loop included (dones.nonzero() every step, the epoch's statistics); the learner steps the "
-                    "env through env.reset(ids) + env.step, not through the fused chain of the LocoVal loop"}
+                    "env through env.reset(ids) + env.step, not through the fused chain of the LocoVal loop.  Round 5: clip + Adam as four "
+                    "launches on flat buffers with a device-side step count, the actor / critic / discriminator loss heads as fused launches "
+                    "(profiles/r05_ab_ppo_update.txt, r05_ppo_step_trace.txt)"}
 
 
 def locoval_policy_leg(env, E, dev, steps, warmup):

@@ -78,4 +78,18 @@ int emloco_ppo_disc_head_bwd(int n_agent, int n_demo, const float *agent_logits,
     return launched("emloco_ppo_disc_head_bwd launch");
 }
 
+int emloco_ppo_gather_rows(int n_tables, int n_rows, const int64_t *idx, const float *const *src, float *const *dst, const int *cols, void *stream) {
+    if (n_tables < 1 || n_tables > PPO_GATHER_MAX || n_rows < 1 || !idx || !src || !dst || !cols)
+        return lfail(-1, "emloco_ppo_gather_rows: bad argument (1 .. 16 tables; src / dst / cols are HOST arrays of device pointers / row widths)");
+    emloco::PpoGatherArgs a{};
+    a.n_tables = n_tables; a.n_rows = n_rows; a.idx = (const long long *)idx;
+    for (int t = 0; t < n_tables; ++t) {
+        if (!src[t] || !dst[t] || cols[t] < 1) return lfail(-1, "emloco_ppo_gather_rows: null table or empty rows");
+        a.src[t] = src[t]; a.dst[t] = dst[t]; a.cols[t] = cols[t];
+    }
+    const unsigned gx = (unsigned)((n_rows + 3) / 4 < 1024 ? (n_rows + 3) / 4 : 1024);
+    hipLaunchKernelGGL(emloco::ppo_gather_rows_kernel, dim3(gx, (unsigned)n_tables), dim3(256), 0, (hipStream_t)stream, a);
+    return launched("emloco_ppo_gather_rows launch");
+}
+
 }  // extern "C"

@@ -163,4 +163,34 @@ __global__ void ppo_disc_head_bwd_kernel(int n_agent, int n_demo, const float *a
     else d_agent[r] = g[0] * sg / (float)n_agent;
 }
 
+// Minibatch gather (AMPDataset._get_item, amp_datasets.py:16-33: every tensor of the dataset indexed with the same shuffled row ids):
+// all tables in ONE launch -- dst_t[r][:] = src_t[idx[r]][:] for up to PPO_GATHER_MAX fp32 tables; blockIdx.y = table, a wave per row,
+// 16-byte copies where a table's rows are 16-byte aligned.  torch issues one index_select per tensor (13 launches of 5-25 us).
+#define PPO_GATHER_MAX 16
+struct PpoGatherArgs {
+    int n_tables, n_rows;
+    const long long *idx;
+    const float *src[PPO_GATHER_MAX];
+    float *dst[PPO_GATHER_MAX];
+    int cols[PPO_GATHER_MAX];
+};
+__global__ void __launch_bounds__(256)
+ppo_gather_rows_kernel(PpoGatherArgs a) {
+    const int t = blockIdx.y, lane = threadIdx.x & 63;
+    const int cols = a.cols[t];
+    const float *src = a.src[t];
+    float *dst = a.dst[t];
+    const bool vec = (cols & 3) == 0 && (((unsigned long long)src | (unsigned long long)dst) & 15ull) == 0;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < a.n_rows; r += gridDim.x * 4) {
+        const float *s = src + a.idx[r] * (long)cols;
+        float *d = dst + (long)r * cols;
+        if (vec) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            for (int c = lane; c < cols / 4; c += 64) ((f4 *)d)[c] = ((const f4 *)s)[c];
+        } else {
+            for (int c = lane; c < cols; c += 64) d[c] = s[c];
+        }
+    }
+}
+
 }  // namespace emloco

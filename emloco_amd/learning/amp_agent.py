@@ -79,6 +79,18 @@ def neglogp(x, mean, std, logstd):
     return 0.5 * (((x - mean) / std) ** 2).sum(dim=-1) + 0.5 * math.log(2.0 * math.pi) * x.size()[-1] + logstd.sum(dim=-1)
 
 
+_COEF_CACHE = {}
+
+
+def _weighted_sum(terms, coef):
+    """sum_i coef_i * terms_i of 0-dim tensors as one stack and one dot; the coefficient vector is made once per (values, device)."""
+    key = (tuple(float(c) for c in coef), str(terms[0].device))
+    c = _COEF_CACHE.get(key)
+    if c is None:
+        c = _COEF_CACHE[key] = torch.tensor(key[0], dtype=torch.float32, device=terms[0].device)
+    return torch.dot(torch.stack([t.float().reshape(()) for t in terms]), c)
+
+
 def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma):
     """torch_ext.policy_kl (rl_games 1.1.4), reduced."""
     c1 = torch.log(p1_sigma / p0_sigma + 1e-5)
@@ -371,7 +383,13 @@ class AMPAgent:
     def _disc_loss(self, disc_agent_logit, disc_demo_logit, grad_penalty):
         if self._fused_heads and disc_agent_logit.is_cuda:
             bce_agent, agent_acc, bce_demo, demo_acc = ppo_heads.disc_head(disc_agent_logit, disc_demo_logit)
-            disc_loss = 0.5 * (bce_agent + bce_demo)
+            logit_loss = torch.sum(torch.square(self.a2c_network.get_disc_logit_weights()))
+            terms, coef = [bce_agent, bce_demo, logit_loss, grad_penalty], [0.5, 0.5, self._disc_logit_reg, self._disc_grad_penalty]
+            if self._disc_weight_decay != 0:
+                terms += [torch.sum(torch.square(w)) for w in self.a2c_network.get_disc_weights()]
+                coef += [self._disc_weight_decay] * (len(terms) - 4)
+            return {"disc_loss": _weighted_sum(terms, coef), "disc_grad_penalty": grad_penalty.detach(), "disc_logit_loss": logit_loss.detach(),
+                    "disc_agent_acc": agent_acc.detach(), "disc_demo_acc": demo_acc.detach()}
         else:
             bce = torch.nn.BCEWithLogitsLoss()
             disc_loss = 0.5 * (bce(disc_agent_logit, torch.zeros_like(disc_agent_logit)) + bce(disc_demo_logit, torch.ones_like(disc_demo_logit)))
@@ -460,12 +478,20 @@ class AMPAgent:
                 main.wait_stream(st)
                 for t in ts:
                     t.record_stream(main)
-        loss = a_loss + self.critic_coef * c_loss - self.entropy_coef * entropy + self.bounds_loss_coef * b_loss \
-            + self._disc_coef * disc_info["disc_loss"]
         info = {"actor_loss": a_loss.detach(), "critic_loss": c_loss.detach(), "b_loss": b_loss.detach(), "entropy": entropy.detach(),
                 "actor_clip_frac": clip_frac.detach(), **{k: v.detach() for k, v in disc_info.items()}}
+        if heads:
+            # the weighted sum as ONE stack + dot (two launches forward, two backward) instead of a multiply and an add per term, each a
+            # launch of its own in both directions
+            terms = [a_loss, c_loss, entropy, b_loss, disc_info["disc_loss"]] + ([s_loss] if s_loss is not None else [])
+            coef = [1.0, self.critic_coef, -self.entropy_coef, self.bounds_loss_coef, self._disc_coef] + ([self.sym_loss_coef] if s_loss is not None else [])
+            loss = _weighted_sum(terms, coef)
+        else:
+            loss = a_loss + self.critic_coef * c_loss - self.entropy_coef * entropy + self.bounds_loss_coef * b_loss \
+                + self._disc_coef * disc_info["disc_loss"]
+            if s_loss is not None:
+                loss = loss + s_loss * self.sym_loss_coef
         if s_loss is not None:
-            loss = loss + s_loss * self.sym_loss_coef
             info["sym_loss"] = s_loss.detach()
         return loss, info, mu.detach(), sigma.detach()
 
@@ -532,15 +558,26 @@ class AMPAgent:
     def _graph_fill(self, i):
         """Host side of a graphed step: gather minibatch i into the static buffers, draw the AMP dropout uniforms."""
         start, end = i * self.minibatch_size, (i + 1) * self.minibatch_size
-        idx = self._idx_buf[start:end].to(self.device)
+        # the shuffled row ids live on the device for a whole pass (one upload per reshuffle): a per-step upload from pageable host
+        # memory makes the host wait for the stream -- i.e. for the previous optimiser step -- before it can issue this one
+        if getattr(self, "_idx_dev", None) is None:
+            self._idx_dev = self._idx_buf.to(self.device)
+        idx = self._idx_dev[start:end]
         if self._g_in is None:
             self._g_in = {k: torch.empty((self.minibatch_size,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device)
                           for k, v in self.dataset.items() if v is not None}
             self._g_u = torch.empty(19, self._amp_minibatch_size, 3, device=self.device)
-        for k, buf in self._g_in.items():
-            torch.index_select(self.dataset[k], 0, idx, out=buf)
+        if self._fused_heads:                                # every fp32 table of the dataset in one gather launch (13 index_select launches otherwise)
+            f32 = [k for k, buf in self._g_in.items() if buf.dtype == torch.float32 and self.dataset[k].is_contiguous()]
+            ppo_heads.gather_rows(idx, [self.dataset[k] for k in f32], [self._g_in[k] for k in f32])
+            rest = [k for k in self._g_in if k not in f32]
+        else:
+            rest = list(self._g_in)
+        for k in rest:
+            torch.index_select(self.dataset[k], 0, idx, out=self._g_in[k])
         if end >= self.batch_size:                           # (host draws in the eager step's order: reshuffle, then the dropout uniforms)
             self._idx_buf[:] = torch.randperm(self.batch_size)
+            self._idx_dev = None
         if self._amp_dropout:
             self._g_u.copy_(amp_dropout_draw(self._amp_minibatch_size), non_blocking=True)
 
@@ -653,6 +690,7 @@ class AMPAgent:
         d = {k: v[idx] for k, v in self.dataset.items() if v is not None}
         if end >= self.batch_size:
             self._idx_buf[:] = torch.randperm(self.batch_size)
+            self._idx_dev = None
         return d
 
     def _store_replay_amp_obs(self, amp_obs):

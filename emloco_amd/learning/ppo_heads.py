@@ -26,8 +26,25 @@ def _lib():
         lib.emloco_ppo_critic_head_bwd.argtypes = [ci, vp, vp, vp, cf, ci, vp, vp, vp]
         lib.emloco_ppo_disc_head_fwd.argtypes = [ci, ci, vp, vp, vp, vp, vp]
         lib.emloco_ppo_disc_head_bwd.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp]
+        lib.emloco_ppo_gather_rows.argtypes = [ci, ci, vp, vp, vp, vp, vp]
         _BOUND = True
     return lib
+
+
+def gather_rows(idx, srcs, dsts):
+    """dst[r] = src[idx[r]] for every (src, dst) pair of 2-D-viewable contiguous fp32 CUDA tensors, in one launch (<= 16 pairs per launch)."""
+    assert idx.dtype == torch.int64 and idx.is_cuda and idx.is_contiguous()
+    n = idx.shape[0]
+    pairs = list(zip(srcs, dsts))
+    for o in range(0, len(pairs), 16):
+        part = pairs[o:o + 16]
+        for s_, d_ in part:
+            assert s_.dtype == torch.float32 and d_.dtype == torch.float32 and s_.is_contiguous() and d_.is_contiguous() and d_.shape[0] == n
+        k = len(part)
+        src = (C.c_void_p * k)(*[t[0].data_ptr() for t in part])
+        dst = (C.c_void_p * k)(*[t[1].data_ptr() for t in part])
+        cols = (C.c_int * k)(*[max(t[0].numel() // max(t[0].shape[0], 1), 1) for t in part])
+        ops._chk(_lib().emloco_ppo_gather_rows(k, n, _p(idx), src, dst, cols, ops._st(idx)), "emloco_ppo_gather_rows")
 
 
 def _c(t):

@@ -339,6 +339,11 @@ int emloco_ppo_disc_head_fwd(int n_agent, int n_demo, const float *agent_logits,
 int emloco_ppo_disc_head_bwd(int n_agent, int n_demo, const float *agent_logits, const float *demo_logits, const float *grad2,
                              float *d_agent, float *d_demo, void *stream);
 
+/* The minibatch gather of the learner (AMPDataset._get_item, amp_datasets.py:16-33): dst_t[r][:] = src_t[idx[r]][:] for n_tables
+ * (<= 16) fp32 tables in one launch.  idx: n_rows int64 row ids on the device; src / dst / cols: HOST arrays of n_tables device
+ * pointers / row widths (copied into the launch's arguments). */
+int emloco_ppo_gather_rows(int n_tables, int n_rows, const int64_t *idx, const float *const *src, float *const *dst, const int *cols, void *stream);
+
 /* The piece image of a B operand for EMLOCO_GEMM_B_SPLITIMG: B(n, k) = W[n * ld + k] (trans = 0) or W[k * ld + n] (trans = 1), n x k;
  * image: emloco_gemm_split_image_words(n, k) 32-bit words of device memory, 16-byte aligned (1.5 x the matrix, zero-padded to whole
  * 128 x 16 stages).  One small launch; valid until W changes.  Also accepted by emloco_gemm_relu_bwd (flags). */

@@ -254,3 +254,21 @@ def test_running_mean_std_training_update_matches_the_reference_class():
     cpu.train()
     with pytest.raises(L.EmlocoError):
         cpu(torch.from_numpy(g["x0"]))
+
+
+def test_minibatch_gather_of_all_tables_in_one_launch():
+    """`ppo_heads.gather_rows` (emloco_ppo_gather_rows): the learner's minibatch gather -- every fp32 tensor of the dataset indexed with
+    the same shuffled row ids (amp_datasets.py:16-33) -- as one launch: equal to torch.index_select per tensor, for row widths with and
+    without 16-byte alignment, 1-D tables, more than 16 tables (two launches) and repeated ids."""
+    from emloco_amd.learning import ppo_heads
+    torch.manual_seed(9)
+    N, n = 5000, 777
+    widths = [1422, 69, 1, 3090, 7, 412] + [5] * 13
+    srcs = [torch.randn(N, w, device=DEV) if w != 1 else torch.randn(N, device=DEV) for w in widths]
+    idx = torch.randint(0, N, (n,), device=DEV)
+    idx[10] = idx[11]
+    dsts = [torch.full((n,) + tuple(s.shape[1:]), float("nan"), device=DEV) for s in srcs]
+    ppo_heads.gather_rows(idx, srcs, dsts)
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(d, torch.index_select(s, 0, idx))
