@@ -46,7 +46,7 @@ class FrozenPolicy:
     def __init__(self, network, mean_std, num_envs, device, clip_actions=1.0):
         self.E, self.device, self.clip = num_envs, torch.device(device), float(clip_actions)
         self.self_size, self.task_size = network.self_obs_size, network.task_obs_size
-        sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in network.state_dict().items()}
+        sd = {k: v.detach().to(self.device, torch.float32).clone().contiguous() for k, v in network.state_dict().items()}      # private copies: frozen for good (the piece images below are cut from them once)
 
         def layers(prefix):
             idx = sorted({int(k.split(".")[1]) for k in sd if k.startswith(prefix + ".") and k.endswith(".weight")})
@@ -126,7 +126,7 @@ class FrozenDisc:
 
     def __init__(self, network, amp_mean_std, num_envs, device, disc_reward_scale=2.0, normalize=True):
         self.E, self.device, self.scale, self.normalize = num_envs, torch.device(device), float(disc_reward_scale), bool(normalize)
-        sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in network.state_dict().items()}
+        sd = {k: v.detach().to(self.device, torch.float32).clone().contiguous() for k, v in network.state_dict().items()}      # private copies: frozen for good (the piece images below are cut from them once)
         idx = sorted({int(k.split(".")[1]) for k in sd if k.startswith("_disc_mlp.") and k.endswith(".weight")})
         self.layers = [(sd[f"_disc_mlp.{i}.weight"], sd[f"_disc_mlp.{i}.bias"]) for i in idx]
         self.logit_w, self.logit_b = sd["_disc_logits.weight"], sd["_disc_logits.bias"]
