@@ -62,28 +62,35 @@ __global__ void pd_targets_kernel(int total, const float *actions, const float *
 // launch queue every step): ids[0..count) = ascending indices of the non-zero flags, ids[count..n) = -1, ids[n] = count.
 // One 1024-thread workgroup; ballot + popcount inside a wave, LDS prefix over the 16 waves, running base over chunks.
 __device__ __forceinline__ void compact_flags(const int64_t *flags, int n, int32_t *ids, int64_t *snapshot) {
+    // ONE pass (round 5; was a loop of 1024-flag chunks with three barriers each): thread t owns the run of `per` consecutive flags
+    // [t per, (t + 1) per), counts its non-zero ones, the counts are scanned inside each wave (six shuffle steps) and across the 16
+    // waves (LDS), and the thread writes its ids behind its offset -- ascending, as the chunked loop left them.
     __shared__ int sh_wave[16];
-    __shared__ int sh_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) sh_base = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += 1024) {
-        const int i = c0 + tid;
-        const int64_t fl = i < n ? flags[i] : 0;
-        if (snapshot && i < n) snapshot[i] = fl;
-        const bool on = fl != 0;
-        const unsigned long long bal = __ballot(on);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) sh_wave[wave] = __popcll(bal);
-        __syncthreads();
-        int off = sh_base;
-        for (int w = 0; w < wave; ++w) off += sh_wave[w];
-        if (on) ids[off + before] = i;
-        __syncthreads();
-        if (tid == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += sh_wave[w]; sh_base += tot; }
-        __syncthreads();
+    const int per = (n + 1023) / 1024;
+    const int i0 = tid * per;
+    int cnt = 0;
+    for (int k = 0; k < per; ++k) {
+        const int i = i0 + k;
+        if (i < n) {
+            const int64_t fl = flags[i];
+            if (snapshot) snapshot[i] = fl;
+            cnt += fl != 0 ? 1 : 0;
+        }
     }
-    const int count = sh_base;
+    int inc = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl(inc, lane - d < 0 ? 0 : lane - d);
+        if (lane >= d) inc += up;
+    }
+    if (lane == 63) sh_wave[wave] = inc;
+    __syncthreads();
+    int off = inc - cnt, count = 0;
+    for (int w = 0; w < 16; ++w) { const int c = sh_wave[w]; off += w < wave ? c : 0; count += c; }
+    for (int k = 0; k < per; ++k) {
+        const int i = i0 + k;
+        if (i < n && flags[i] != 0) ids[off++] = i;
+    }
     for (int i = count + tid; i < n; i += 1024) ids[i] = -1;
     if (tid == 0) ids[n] = count;
 }
