@@ -24,7 +24,7 @@ def timeit(f, n=5):
     return ts[len(ts) // 2]
 
 
-for N, K in ((1024, 128), (384, 128), (128, 128), (128, 1024), (1024, 256), (1024, 512)):
+for N, K in ((1024, 128), (1024, 128), (384, 128), (128, 128), (128, 1024), (1024, 256), (1024, 512)):
     x = torch.randn(M, K, device=dev)
     W = torch.randn(N, K, device=dev) * 0.05
     b = torch.randn(N, device=dev)
@@ -32,7 +32,8 @@ for N, K in ((1024, 128), (384, 128), (128, 128), (128, 1024), (1024, 256), (102
     img = ops.split_image(W, N, K, K, 0)
     for name, kw in (("plain", dict()), ("bias+relu", dict(bias=b, flags=ops.GEMM_BIAS | ops.GEMM_RELU)),
                      ("bias+relu+dropout", dict(bias=b, flags=ops.GEMM_BIAS | ops.GEMM_RELU, drop_p=0.1, drop_seed=5)),
-                     ("plain, weight image", dict(b_image=img))):
+                     ("plain, weight image", dict(b_image=img)), ("plain again", dict()),
+                     ("bias+relu+dropout, image", dict(bias=b, flags=ops.GEMM_BIAS | ops.GEMM_RELU, drop_p=0.1, drop_seed=5, b_image=img))):
         t = timeit(lambda: ops.gemm(1, M, N, K, x, K, 0, 0, W, K, 0, 0, y, N, 0, **kw))
         fl = 2.0 * M * N * K
         by = 4.0 * (M * K + N * K + M * N)
