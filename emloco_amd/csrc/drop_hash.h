@@ -34,12 +34,15 @@ __host__ __device__ __forceinline__ unsigned drop_hash(unsigned row_key, unsigne
 // which made the mask 40 % of the time of the feed-forward's first GEMM (64 output elements per lane and tile, K = 128).  Now: one
 // drop_hash per PAIR of adjacent elements (the pair index split 24 | rest: both 24-bit multiplies are full rate), 16 bits each
 // against p 2^16 -- the resolution of p is 1.5e-5, as in the attention mask.
-__host__ __device__ __forceinline__ bool drop_keep(unsigned seed, unsigned long long idx, float p) {
-    const unsigned long long pair = idx >> 1;
+// the hash of a PAIR of adjacent elements (pair = idx >> 1): low 16 bits decide the even element, high 16 bits the odd one
+__host__ __device__ __forceinline__ unsigned drop_pair_hash(unsigned seed, unsigned long long pair) {
     unsigned lo = (unsigned)pair & 0xffffffu;
     lo ^= (lo >> 9) ^ (lo << 11);                // (rows of a matrix are a power of two apart in the index: bring the bits that differ into the multiply's low end
                                                  //  -- without it the kept count per COLUMN of a 4096 x 1024 output had 1.15x the binomial variance)
-    const unsigned x = drop_hash(seed + drop_mul24((unsigned)(pair >> 24), 0x7FEB35u), lo);
+    return drop_hash(seed + drop_mul24((unsigned)(pair >> 24), 0x7FEB35u), lo);
+}
+__host__ __device__ __forceinline__ bool drop_keep(unsigned seed, unsigned long long idx, float p) {
+    const unsigned x = drop_pair_hash(seed, idx >> 1);
     return ((idx & 1ull) ? (x >> 16) : (x & 0xffffu)) >= (unsigned)(p * 65536.0f);
 }
 }  // namespace emloco

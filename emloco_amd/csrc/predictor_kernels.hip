@@ -547,27 +547,44 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
         __syncthreads();                                     // (every wave is past its last fragment read of the stages)
         const int c16 = g.c16;
         float *scr = &As[0][0] + wave * 1024;
+#pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int cl = (wn * TJ + j) * 32 + (lane & 31);
             const float bj = has_bias ? g.bias[n0 + cl] : 0.0f;
+#pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int r0 = (wm * TI + i) * 32;
+#pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rt = 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
                     float v = g.alpha * acc[i][j][r] + bj;
                     if (relu) v = v > 0.0f ? v : 0.0f;
-                    if (drop) v = drop_keep(g.drop_seed, ((unsigned long long)b * g.m + m0 + r0 + rt) * g.n + n0 + cl, g.drop_p) ? v * keep_scale : 0.0f;
                     scr[rt * 32 + (lane & 31)] = v;
                 }
                 gemm_wave_sync();
                 const int c0 = (wn * TJ + j) * 32;
+                // The dropout mask is applied BEHIND the transposition, where a lane holds 4 (8) consecutive elements of a row: one hash
+                // per PAIR of elements, as the mask is defined, and one index per lane and store -- in the accumulator layout the two
+                // elements of a pair sit in neighbouring lanes and each lane evaluated the pair's hash for its own half (measured:
+                // the mask was 0.37 of the 2.11 ms of the feed-forward's first layer, profiles/r05_gemm_k128_probe.txt).  Same mask.
+                const unsigned dthr = (unsigned)(g.drop_p * 65536.0f);
                 if (c16) {                                       // 32 bf16 = 64 bytes per row: 4 lanes x 16 bytes, 16 rows per instruction
                     unsigned short *cb = (unsigned short *)g.C + (long)b * g.sc + (long)(m0 + r0) * g.ldc + n0 + c0;
+#pragma unroll
                     for (int p = 0; p < 2; ++p) {
                         const int rt = 16 * p + (lane >> 2), q = lane & 3;
                         const f32x4 t0 = *(const f32x4 *)(scr + rt * 32 + 8 * q), t1 = *(const f32x4 *)(scr + rt * 32 + 8 * q + 4);
                         unsigned short *dst = cb + (long)rt * g.ldc + 8 * q;
                         float e[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                        if (drop) {
+                            const unsigned long long pr = ((((unsigned long long)b * g.m + m0 + r0 + rt) * g.n + n0 + c0) >> 1) + 4 * q;
+#pragma unroll
+                            for (int h2 = 0; h2 < 4; ++h2) {
+                                const unsigned x = drop_pair_hash(g.drop_seed, pr + h2);
+                                e[2 * h2] = (x & 0xffffu) >= dthr ? e[2 * h2] * keep_scale : 0.0f;
+                                e[2 * h2 + 1] = (x >> 16) >= dthr ? e[2 * h2 + 1] * keep_scale : 0.0f;
+                            }
+                        }
                         if (accum) { const uint4 o = *(const uint4 *)dst; e[0] += bf16_lo(o.x); e[1] += bf16_hi(o.x); e[2] += bf16_lo(o.y); e[3] += bf16_hi(o.y);
                                      e[4] += bf16_lo(o.z); e[5] += bf16_hi(o.z); e[6] += bf16_lo(o.w); e[7] += bf16_hi(o.w); }
                         uint4 w;
@@ -577,10 +594,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
                     }
                 } else {                                         // 32 floats = 128 bytes per row: 8 lanes x 16 bytes, 8 rows per instruction
                     float *cf = g.C + (long)b * g.sc + (long)(m0 + r0) * g.ldc + n0 + c0;
+#pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         const int rt = 8 * p + (lane >> 3), q = lane & 7;
                         f32x4 t = *(const f32x4 *)(scr + rt * 32 + 4 * q);
                         float *dst = cf + (long)rt * g.ldc + 4 * q;
+                        if (drop) {
+                            const unsigned long long pr = ((((unsigned long long)b * g.m + m0 + r0 + rt) * g.n + n0 + c0) >> 1) + 2 * q;
+                            const unsigned x0 = drop_pair_hash(g.drop_seed, pr), x1 = drop_pair_hash(g.drop_seed, pr + 1);
+                            t.x = (x0 & 0xffffu) >= dthr ? t.x * keep_scale : 0.0f;
+                            t.y = (x0 >> 16) >= dthr ? t.y * keep_scale : 0.0f;
+                            t.z = (x1 & 0xffffu) >= dthr ? t.z * keep_scale : 0.0f;
+                            t.w = (x1 >> 16) >= dthr ? t.w * keep_scale : 0.0f;
+                        }
                         if (accum) { const f32x4 o = *(const f32x4 *)dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
                         *(f32x4 *)dst = t;
                     }
