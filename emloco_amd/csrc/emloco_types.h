@@ -48,6 +48,7 @@ struct EmlocoSimDev {
     // untouched; with step_ids workgroup i steps env step_ids[i] of a device-compacted list (valid ids first, -1 after them)
     const long long *step_skip;
     const int *step_ids;
+    int n_slots;                      /* env slots of this launch (n_env, or the length of the id list): workgroup i steps slots 2 i and 2 i + 1 */
     // cost-ordered dispatch (emloco_sim_set_cost_order): workgroup i of the full launch steps env step_order[i]; every
     // workgroup leaves its contact work in step_ticks[env], the key of the next launch's order
     const int *step_order;

@@ -6,7 +6,15 @@
 #include <cstring>
 #include <string>
 #include <vector>
+// EMLOCO_SIM_PAIR=1 (round 6, experimental: python -m emloco_amd.build with EMLOCO_HIPCC_EXTRA_SIM="-DEMLOCO_SIM_PAIR=1"): the rigid-body
+// step with TWO envs per 64-lane wave (sim_pair_kernels.hip) instead of one (sim_kernels.hip).  Same entry points, same bytes.
+#ifdef EMLOCO_SIM_PAIR
+#include "sim_pair_kernels.hip"
+#define EMLOCO_SIM_ENVS_PER_WG 2
+#else
 #include "sim_kernels.hip"
+#define EMLOCO_SIM_ENVS_PER_WG 1
+#endif
 #include "topology.h"
 #include "model_pack.h"
 #include "sim_state.h"
@@ -338,8 +346,10 @@ int emloco_sim_step(EmlocoSim *s, int n_calls, void *stream) {
     d.n_parts = s->n_parts < p.n_sub ? s->n_parts : p.n_sub;       // at least one substep per part
     d.part_seq = ++s->part_seq; d.part_state = s->d_part_state.p; d.part_flag = s->d_part_flag.p;
     d.part_spin_max = s->part_spin_max; d.part_poison = s->part_poison;
-    if (d.hf) hipLaunchKernelGGL(emloco::sim_step_kernel<1>, dim3((unsigned)(s->n_env * d.n_parts)), dim3(64), (size_t)s->lds_pad, st, p, d);
-    else hipLaunchKernelGGL(emloco::sim_step_kernel<0>, dim3((unsigned)(s->n_env * d.n_parts)), dim3(64), (size_t)s->lds_pad, st, p, d);
+    d.n_slots = s->n_env;
+    const unsigned grid = (unsigned)(((s->n_env + EMLOCO_SIM_ENVS_PER_WG - 1) / EMLOCO_SIM_ENVS_PER_WG) * d.n_parts);       // one 64-lane workgroup per env (pair) and part
+    if (d.hf) hipLaunchKernelGGL(emloco::sim_step_kernel<1>, dim3(grid), dim3(64), (size_t)s->lds_pad, st, p, d);
+    else hipLaunchKernelGGL(emloco::sim_step_kernel<0>, dim3(grid), dim3(64), (size_t)s->lds_pad, st, p, d);
     HIPCHK(hipGetLastError());
     if (timed) {
         HIPCHK(hipEventRecord(s->ev1[slot], st));
@@ -378,8 +388,10 @@ int emloco_sim_step_subset(EmlocoSim *s, int n_calls, const int64_t *dev_skip, c
     d.n_parts = dev_ids ? 1 : (s->n_parts < p.n_sub ? s->n_parts : p.n_sub);      // the list launch (a few dozen envs) is not split
     d.part_seq = ++s->part_seq; d.part_state = s->d_part_state.p; d.part_flag = s->d_part_flag.p;
     d.part_spin_max = s->part_spin_max; d.part_poison = s->part_poison;
-    if (d.hf) hipLaunchKernelGGL(emloco::sim_step_kernel<1>, dim3((unsigned)(dev_ids ? n_ids : s->n_env * d.n_parts)), dim3(64), (size_t)s->lds_pad, st, p, d);
-    else hipLaunchKernelGGL(emloco::sim_step_kernel<0>, dim3((unsigned)(dev_ids ? n_ids : s->n_env * d.n_parts)), dim3(64), (size_t)s->lds_pad, st, p, d);
+    d.n_slots = dev_ids ? n_ids : s->n_env;
+    const unsigned grid = (unsigned)(((d.n_slots + EMLOCO_SIM_ENVS_PER_WG - 1) / EMLOCO_SIM_ENVS_PER_WG) * d.n_parts);      // one 64-lane workgroup per slot (pair) and part
+    if (d.hf) hipLaunchKernelGGL(emloco::sim_step_kernel<1>, dim3(grid), dim3(64), (size_t)s->lds_pad, st, p, d);
+    else hipLaunchKernelGGL(emloco::sim_step_kernel<0>, dim3(grid), dim3(64), (size_t)s->lds_pad, st, p, d);
     HIPCHK(hipGetLastError());
     if (timed) {
         HIPCHK(hipEventRecord(s->ev1[slot], st));

@@ -7,7 +7,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
-_SO = os.path.join(_HERE, "_build", "libemu.so")
+_EXTRA = os.environ.get("EMLOCO_EMU_EXTRA", "").split()          # e.g. -DEMLOCO_SIM_PAIR=1: the experimental two-envs-per-wave rigid-body kernel
+_SO = os.path.join(_HERE, "_build", "libemu" + ("_" + "".join(c for c in "".join(_EXTRA) if c.isalnum()) if _EXTRA else "") + ".so")
 _SRCS = ["emu_sim.cpp", "emu_task.cpp", "emu_predictor.cpp", "emu_ppo.cpp", "emu_runtime.cpp", "hip/hip_runtime.h"]
 def build():
     """g++ over the kernel sources; every file under emloco_amd/csrc and include/ is a dependency.  Built under a file lock into a
@@ -28,7 +29,7 @@ def build():
                 cpps = [os.path.join(_HERE, s) for s in _SRCS if s.endswith(".cpp") and os.path.exists(os.path.join(_HERE, s))]
                 tmp = _SO + f".{os.getpid()}.tmp"
                 subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-ffp-contract=off", "-Wno-psabi",
-                                       "-I", _HERE, "-o", tmp] + cpps + ["-lpthread"])
+                                       "-I", _HERE, "-o", tmp] + _EXTRA + cpps + ["-lpthread"])
                 os.replace(tmp, _SO)
     return _SO
 

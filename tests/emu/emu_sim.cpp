@@ -3,7 +3,13 @@
 // TEST INFRASTRUCTURE ONLY: runs emloco_amd/csrc/sim_kernels.hip on the CPU through the emulation
 // header in tests/emu/hip/, so the kernel's logic can be compared with the oracle without a GPU.
 #include "hip/hip_runtime.h"
+#ifdef EMLOCO_SIM_PAIR      /* EMLOCO_EMU_EXTRA="-DEMLOCO_SIM_PAIR=1": the two-envs-per-wave kernel (round 6, experimental) */
+#include "../../emloco_amd/csrc/sim_pair_kernels.hip"
+#define EMU_ENVS_PER_WG 2
+#else
 #include "../../emloco_amd/csrc/sim_kernels.hip"
+#define EMU_ENVS_PER_WG 1
+#endif
 #include "../../emloco_amd/csrc/topology.h"
 #include "../../emloco_amd/csrc/model_pack.h"
 
@@ -51,7 +57,8 @@ extern "C" int emu_sim_step(const EmlocoSimParams *prm, const EmlocoModelDesc *m
     const char *po = getenv("EMLOCO_EMU_POISON");
     unsigned err = 0u;
     d.part_spin_max = 4; d.part_poison = po ? atoi(po) : -1; d.err = &err;
-    emu::launch((unsigned)(m->n_env * n_parts), 64, [&] { if (d.hf) emloco::sim_step_kernel<1>(p, d); else emloco::sim_step_kernel<0>(p, d); });
+    d.n_slots = m->n_env;
+    emu::launch((unsigned)(((m->n_env + EMU_ENVS_PER_WG - 1) / EMU_ENVS_PER_WG) * n_parts), 64, [&] { if (d.hf) emloco::sim_step_kernel<1>(p, d); else emloco::sim_step_kernel<0>(p, d); });
     return (int)err;
 }
 

@@ -28,9 +28,22 @@ lib.emloco_sim_profile(sim._h, buf, 256)
 t = np.array(buf[:], dtype=np.int64).reshape(16, 16)
 n_sub = 4
 print(f"E={E}: ticks (100 MHz) per phase, substeps 0..{n_sub-1}")
-for i, name in enumerate(PHASES):
-    d = [int(t[s, i + 1] - t[s, i]) for s in range(n_sub)]
-    print(f"  {name:20s} " + " ".join(f"{x:6d}" for x in d))
-print(f"  {'PGS: setup+warm start':20s} " + " ".join(f"{int(t[s, 11] - t[s, 7]):6d}" for s in range(n_sub)))
-print(f"  {'PGS: first sweep':20s} " + " ".join(f"{int(t[s, 12] - t[s, 11]):6d}" for s in range(n_sub)))
-print(f"  {'substep total':20s} " + " ".join(f"{int(t[s, 10] - t[s, 0]):6d}" for s in range(n_sub)))
+def row(name, a, b):
+    print(f"  {name:34s} " + " ".join(f"{int(t[s, b] - t[s, a]):6d}" for s in range(n_sub)))
+# round 6 (two envs per wave): stamps of the pair that holds env 0; joint = both envs in one instruction stream
+row("1 kinematics + 1b limb-limb (joint|x2)", 0, 1)
+row("2 drive (joint)", 1, 2)
+row("2b-3 inertia, factorise (joint)", 2, 3)
+row("4 down pass (joint)", 3, 4)
+row("5 candidates, env 0", 4, 5)
+row("6a rows / chain y, env 0", 5, 6)
+row("6b matrix -> registers, env 0", 6, 13)
+row("5 candidates, env 1", 13, 14)
+row("6a rows / chain y, env 1", 14, 15)
+row("6b matrix -> registers, env 1", 15, 7)
+row("6c Gauss-Seidel, both envs", 7, 8)
+row("   setup + warm start", 7, 11)
+row("   first sweep", 11, 12)
+row("7a+7 impulses, tree passes", 8, 9)
+row("8 integrate (joint)", 9, 10)
+row("substep total (pair)", 0, 10)
