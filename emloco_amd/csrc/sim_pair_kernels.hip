@@ -298,14 +298,13 @@ __device__ __forceinline__ float half_sum(float v, int half) {
 }
 
 
-// ---- projected Gauss-Seidel on matrix rows held in registers (phase 6c).  One PgsRow per env of the pair.  The row lives in two
-// 32-register tuples that the contact loop indexes with its (wave-uniform) counter -- v_movrels-style indirect register reads, three
-// per contact -- so the loops stay rolled: unrolled over the 20 contact slots the sweeps were 45 KB of straight-line code that the
-// waves of a CU streamed through the instruction cache four times per substep.  `lo` holds the columns of contacts 0-9 (0..29), `hi`
-// those of contacts 10-19 (30..59): no contact straddles the two.
-typedef float sim_f32x32 __attribute__((vector_size(128)));
+// ---- projected Gauss-Seidel on matrix rows held in registers (phase 6c).  One PgsRow per env of the pair; every function is
+// inlined into the unrolled contact loop, so A[] is indexed statically.
+// (Measured alternatives, all slower -- profiles/r06_sim_pair_experiment.txt: the rows as two 32-register tuples indexed by the loop
+// counter with rolled loops; env 1's matrix in LDS; every lane forming the contact's multipliers redundantly from three
+// broadcast residuals with the contacts' constants in LDS.)
 struct PgsRow {
-    sim_f32x32 lo, hi;             // this lane's row of the contact matrix (row = lane)
+    float A[MAXR];                 // this lane's row of the contact matrix (row = lane)
     float w, lam;                  // running residual, warm-start multiplier of this lane's row
     float ainv, diag;              // 1 / (A_ss (1 + cfm)), A_ss
     float gl0, gl1, gl2;           // leader lane (normal row of a contact): the contact's three multipliers ...
@@ -314,20 +313,14 @@ struct PgsRow {
 };
 struct PgsTmp { float nl1, nl2, lim, m2, a1, a2; bool me; unsigned long long cone; };
 __device__ __forceinline__ void pgs_clear(PgsRow &G) {
-    for (int k = 0; k < 32; ++k) { G.lo[k] = 0.0f; G.hi[k] = 0.0f; }
+    for (int k = 0; k < MAXR; ++k) G.A[k] = 0.0f;
     G.w = G.lam = G.ainv = G.gl0 = G.gl1 = G.gl2 = G.gi1 = G.gi2 = G.gA10 = G.gA20 = G.gA21 = 0.0f;
     G.diag = 1.0f; G.nc = 0;
 }
 __device__ __forceinline__ void pgs_take(PgsRow &G, const float (&Arow)[64], float rhs, float lam, int nc) {
-    static_assert(MAXR == 60, "two tuples of 30 columns");
-    for (int k = 0; k < 30; ++k) { G.lo[k] = Arow[k]; G.hi[k] = Arow[30 + k]; }
-    G.lo[30] = G.lo[31] = G.hi[30] = G.hi[31] = 0.0f;
+    for (int k = 0; k < MAXR; ++k) G.A[k] = Arow[k];
     G.w = rhs; G.lam = lam; G.nc = nc;
-}
-// entries (row = lane, columns 3 c .. 3 c + 2): c is wave-uniform
-__device__ __forceinline__ void pgs_entries(const PgsRow &G, int c, float &a0, float &a1, float &a2) {
-    if (c < 10) { const int p = 3 * c; a0 = G.lo[p]; a1 = G.lo[p + 1]; a2 = G.lo[p + 2]; }
-    else { const int p = 3 * c - 30; a0 = G.hi[p]; a1 = G.hi[p + 1]; a2 = G.hi[p + 2]; }
+    G.ainv = G.gi1 = G.gi2 = G.gA10 = G.gA20 = G.gA21 = 0.0f; G.diag = 1.0f;
 }
 // first row of this lane's contact (idle lanes shadow lane 0: their values are never used)
 __device__ __forceinline__ int pgs_lr0(const PgsRow &G, int lane, int myd) { return lane < 3 * G.nc ? lane - myd : 0; }
@@ -337,8 +330,9 @@ __device__ __forceinline__ void pgs_begin(PgsRow &G, int lane, int myd) {
 }
 // warm start through contact c (w += A[., r] lam_r for its three rows, skipping zero multipliers as the oracle does); on the way
 // the lanes of contact c pick their diagonal entry, its leader the sub-diagonal of the 3 x 3 block
-__device__ __forceinline__ void pgs_warm(PgsRow &G, const int c, int lane, float a0, float a1, float a2) {
+__device__ __forceinline__ void pgs_warm(PgsRow &G, const int c, int lane) {
     const int r0 = 3 * c;
+    const float a0 = G.A[r0], a1 = G.A[r0 + 1], a2 = G.A[r0 + 2];
     const float l0 = lane_bcast(G.lam, r0), l1 = lane_bcast(G.lam, r0 + 1), l2 = lane_bcast(G.lam, r0 + 2);
     const float u0 = fmaf(a0, l0, G.w);
     G.w = (l0 != 0.0f) ? u0 : G.w;
@@ -346,10 +340,6 @@ __device__ __forceinline__ void pgs_warm(PgsRow &G, const int c, int lane, float
     G.w = (l1 != 0.0f) ? u1 : G.w;
     const float u2 = fmaf(a2, l2, G.w);
     G.w = (l2 != 0.0f) ? u2 : G.w;
-}
-// (rows in registers) the lanes of contact c pick their diagonal entry, its leader the sub-diagonal of the 3 x 3 block
-__device__ __forceinline__ void pgs_capture(PgsRow &G, const int c, int lane, float a0, float a1, float a2) {
-    const int r0 = 3 * c;
     G.diag = lane == r0 ? a0 : (lane == r0 + 1 ? a1 : (lane == r0 + 2 ? a2 : G.diag));
     const float t21 = lane_bcast(a2, r0 + 1);                  // A[r0 + 1][r0 + 2]
     if (lane == r0) { G.gA10 = a1; G.gA20 = a2; G.gA21 = t21; }
@@ -360,9 +350,10 @@ __device__ __forceinline__ void pgs_ready(PgsRow &G, int lane, int myd, float cf
     G.gi1 = __shfl(G.ainv, lr0 + 1); G.gi2 = __shfl(G.ainv, lr0 + 2);
 }
 // contact c of one sweep: branch-free -- every lane runs the leader's chain on its own values, only lane r0's results are read
-__device__ __forceinline__ void pgs_step(PgsRow &G, PgsTmp &T, const int c, int lane, float mu, float a0, float a1, float a2) {
+__device__ __forceinline__ void pgs_step(PgsRow &G, PgsTmp &T, const int c, int lane, float mu) {
     const int r0 = 3 * c;
     const bool act = c < G.nc;                                 // wave-uniform: the partner env may have more contacts
+    const float a0 = G.A[r0], a1 = G.A[r0 + 1], a2 = G.A[r0 + 2];
     const float w1s = lane_bcast(G.w, r0 + 1), w2s = lane_bcast(G.w, r0 + 2);
     float nl0 = fmaf(-G.w, G.ainv, G.gl0);
     if (nl0 < 0.0f) nl0 = 0.0f;
@@ -412,23 +403,20 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
     // phase 4), pq (8), [a | Aacc] (12; the `a` half carries the limb-limb wrench from phase 1b to 2b, the `Aacc` half the body's bias
     // force from 2b on, for the rare second factorisation pass), Ia (24, phase 3 only).
     // Shared region of the pair, in this order:  B1 = [V|pa]_1 pq_1 | B0 = [V|pa]_0 pq_0 | [a|Aacc]_0 | Ia_0 | Ia_1 | [a|Aacc]_1
-    // Env 0's contact matrix is NOT here (round 6: every lane holds its row in registers, phase 6b); env 1's (packed lower triangle,
-    // 1 830 words) lies over B1 .. Ia_0, which are dead once env 1's rows are formed.  What the contact phases stage lies over rows
-    // that are dead then: the candidate staging of phase 5 and both envs' contact frames (height field) in
+    // The contact matrices are NOT here (every lane holds its row of each env's matrix in registers, phase 6b).  What the contact
+    // phases stage lies over rows that are dead then: the candidate staging of phase 5 and both envs' contact frames (height field) in
     // [a|Aacc]_0 .. Ia_1, the staged Jacobian rows of phase 7a in the B blocks, the limb-limb scratch of phase 1b in Ia_0 | Ia_1.
     enum { O_ROOT = 0, O_P = 16, O_V0 = 24, O_L = 36, O_PD = 48, O_R = O_PD + NB, O_W = O_R + NB * 12,
            O_L0 = O_W + NB * 24, O_CB = O_L0 + 44, O_CX = O_CB + MAXC / 4 + 3, O_CDIST = O_CX + 3 * MAXC, O_LAM = O_CDIST + MAXC,
            O_SLOT = O_LAM + MAXR, O_CRANGE = O_SLOT + 32, PW = O_CRANGE + 2 * NB / 4,
            SR = 2 * PW, BW = NB * 12 + NB * 8, O_B1 = SR, O_B0 = SR + BW,
            O_AA0 = SR + 2 * BW, O_IA0 = O_AA0 + NB * 12, O_IA1 = O_IA0 + NB * 24, O_AA1 = O_IA1 + NB * 24, LDS_WORDS = O_AA1 + NB * 12,
-           AMAT = MAXR * (MAXR + 1) / 2,
-           O_A1 = O_B1,                                        // env 1's contact matrix (packed lower triangle), phases 6b-6c: over B1 B0 [a|Aacc]_0 Ia_0
            O_STAGE = O_AA0,                                    // candidate staging of phase 5 [MAXCAND][7]
            O_CDIR = LDS_WORDS - 2 * 9 * MAXC,                  // contact frames [2 envs][MAXC][9] (height-field ground)
            O_ROWS = O_B1,                                      // staged Jacobian rows of phase 7a [MAXR][12]
            O_SCR = O_IA0 };                                    // limb-limb scratch of phase 1b
     static_assert(PW % 4 == 0 && O_R % 4 == 0 && O_W % 4 == 0 && SR % 4 == 0 && BW % 4 == 0, "rows must be 16-byte aligned");
-    static_assert(O_A1 + AMAT <= O_CDIR && O_STAGE + MAXCAND * 7 <= O_CDIR, "env 1's contact matrix / the candidate staging reach the contact frames");
+    static_assert(O_STAGE + MAXCAND * 7 <= O_CDIR, "the candidate staging reaches the contact frames");
     static_assert(MAXR * 12 <= 2 * BW, "staged Jacobian rows do not fit the B blocks");
     static_assert(O_SCR + EMLOCO_SC_MAXSEG * 8 + EMLOCO_SC_MAXHITS * 8 + EMLOCO_SC_MAXPAIRS <= O_AA1, "limb-limb scratch does not fit Ia_0 | Ia_1");
     static_assert(LDS_WORDS * 4 <= 20480, "LDS per env pair above 160 KiB / 8 (two waves per SIMD, 16 envs per CU)");
@@ -1349,13 +1337,11 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
             // shares (every other term adds an exact zero), so the accumulator IS the prefix sum.  Operands: lanes 0-31 feed
             // k = 2s, lanes 32-63 k = 2s+1; v_permlane32_swap hands both over in one instruction.  The 3-wide level blocks are padded
             // with one 0*0 step.
-            // Round 6: all tiles advance in ONE pass over the steps -- independent accumulator chains behind one operand swap and one
-            // ballot / readlane group walk (three passes of one chain each before).  Env 0's matrix goes into REGISTERS: four tiles
-            // (0,0) (1,0) (0,1) (1,1); a lane of the accumulator layout holds 16 rows of ONE column per tile, the matrix is symmetric,
-            // so after 32 v_permlane32_swap (lane i <-> lane i + 32) every lane s holds row s complete -- columns 0-31 from tiles
-            // (0,0) | (0,1), columns 32-63 from (1,0) | (1,1).  Env 1's goes to LDS as the packed lower triangle (three tiles): two
-            // rows of 60 in registers next to everything else that is live here did not fit 256 registers (140 spilled), and with
-            // env 1's entries prefetched a contact ahead the joint sweeps hide the LDS reads under env 0's chain.
+            // Round 6: ALL FOUR tiles (0,0) (1,0) (0,1) (1,1) advance in one pass over the steps -- four independent accumulator
+            // chains behind one operand swap and one ballot / readlane group walk -- and the matrix never reaches LDS: a lane of the
+            // accumulator layout holds 16 rows of ONE column per tile, the matrix is symmetric, so after 32 v_permlane32_swap
+            // (lane i <-> lane i + 32) every lane s holds row s complete -- columns 0-31 from tiles (0,0) | (0,1), columns 32-63
+            // from (1,0) | (1,1) -- in registers the (unrolled) sweeps index statically.
             {
                 typedef float sim_f32x16 __attribute__((vector_size(64)));
                 const int own_dep = (lane < nr) ? rdep : -1;   // -1: no row in this lane (all operands zero)
@@ -1370,7 +1356,7 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
                     acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(op0_, op0_, acc00, 0, 0, 0);                          \
                     if (big) {                                                                                         \
                         acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(op1_, op0_, acc10, 0, 0, 0);                      \
-                        if (e == 0) acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(op0_, op1_, acc01, 0, 0, 0);          \
+                        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(op0_, op1_, acc01, 0, 0, 0);                      \
                         acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(op1_, op1_, acc11, 0, 0, 0);                      \
                     }                                                                                                  \
                 }
@@ -1392,33 +1378,18 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
                     }
                 }
 #undef GRAM_STEP
-                if (e == 0) {
-                    // lane (j, hh) holds column 32 tc + j, rows 32 tr + (r & 3) + 8 (r >> 2) + 4 hh of tile (tr, tc); after the swaps lane s
-                    // holds of ITS row s the columns (r & 3) + 8 (r >> 2) [first result] and + 4 [second result]
-                    float Arow[64];
+                // lane (j, hh) holds column 32 tc + j, rows 32 tr + (r & 3) + 8 (r >> 2) + 4 hh of tile (tr, tc); after the swaps lane s
+                // holds of ITS row s the columns (r & 3) + 8 (r >> 2) [first result] and + 4 [second result]
+                float Arow[64];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int c0 = (r & 3) + 8 * (r >> 2);
-                        const auto lo = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc00[r]), __float_as_uint(acc01[r]), false, false);
-                        Arow[c0] = __uint_as_float(lo[0]); Arow[c0 + 4] = __uint_as_float(lo[1]);
-                        const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc10[r]), __float_as_uint(acc11[r]), false, false);
-                        Arow[32 + c0] = __uint_as_float(hi[0]); Arow[32 + c0 + 4] = __uint_as_float(hi[1]);
-                    }
-                    pgs_take(G, Arow, rhs, lam, nc);
-                } else {
-                    float *const sh_A = lds + O_A1;                    // packed lower triangle: (r, s<=r) at r(r+1)/2 + s
-                    const int hh = lane >> 5, j31 = lane & 31;
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        if (row < nr && j31 <= row) sh_A[row * (row + 1) / 2 + j31] = acc00[r];
-                        if (big) {
-                            const int row1 = 32 + row;
-                            if (row1 < nr) sh_A[row1 * (row1 + 1) / 2 + j31] = acc10[r];
-                            if (row1 < nr && 32 + j31 <= row1) sh_A[row1 * (row1 + 1) / 2 + 32 + j31] = acc11[r];
-                        }
-                    }
-                    G.w = rhs; G.lam = lam; G.nc = nc;
+                for (int r = 0; r < 16; ++r) {
+                    const int c0 = (r & 3) + 8 * (r >> 2);
+                    const auto lo = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc00[r]), __float_as_uint(acc01[r]), false, false);
+                    Arow[c0] = __uint_as_float(lo[0]); Arow[c0 + 4] = __uint_as_float(lo[1]);
+                    const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc10[r]), __float_as_uint(acc11[r]), false, false);
+                    Arow[32 + c0] = __uint_as_float(hi[0]); Arow[32 + c0 + 4] = __uint_as_float(hi[1]);
                 }
+                pgs_take(G, Arow, rhs, lam, nc);
             }
             if (mine) { my_nc = nc; my_dmax = dmax; }
             __syncthreads();                                       // the candidate staging is reused by the partner env
@@ -1444,52 +1415,25 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
             const int ncmax = G0.nc > G1.nc ? G0.nc : G1.nc;
             const int myd = lane - 3 * (lane / 3);
             pgs_begin(G0, lane, myd); pgs_begin(G1, lane, myd);
-            // env 1: the matrix stays in LDS (packed lower triangle); lane s reads entry (s, rr) of its row for the row being updated,
-            // one contact ahead of the sweep (the reads do not depend on the multipliers)
-            const float *const sh_A1 = lds + O_A1;
-            const int nc1 = G1.nc, nr1 = 3 * nc1;
-            const int ls1 = lane < nr1 ? lane : 0;                  // idle lanes shadow lane 0 (their w is never used)
-#define A1_OF(rr) sh_A1[tri_index(ls1, (rr))]
-            {
-                G1.ainv = (lane < nr1) ? 1.0f / (sh_A1[ls1 * (ls1 + 1) / 2 + ls1] * (1.0f + prm.cfm)) : 0.0f;
-                const int lr0 = pgs_lr0(G1, lane, myd);
-                G1.gi1 = __shfl(G1.ainv, lr0 + 1); G1.gi2 = __shfl(G1.ainv, lr0 + 2);
-                G1.gA10 = sh_A1[tri_index(lr0 + 1, lr0)]; G1.gA20 = sh_A1[tri_index(lr0 + 2, lr0)]; G1.gA21 = sh_A1[tri_index(lr0 + 2, lr0 + 1)];
-            }
-            const int clast1 = nc1 > 0 ? nc1 - 1 : 0;
-            float n0 = A1_OF(0), n1 = A1_OF(1), n2 = A1_OF(2);
-#pragma nounroll
-            for (int c = 0; c < ncmax; ++c) {
-                float a0, a1, a2;
-                pgs_entries(G0, c, a0, a1, a2);
-                const float b0 = n0, b1 = n1, b2 = n2;
-                const int cn = c + 1 < nc1 ? c + 1 : clast1;
-                n0 = A1_OF(3 * cn); n1 = A1_OF(3 * cn + 1); n2 = A1_OF(3 * cn + 2);
-                pgs_warm(G0, c, lane, a0, a1, a2); pgs_capture(G0, c, lane, a0, a1, a2);
-                pgs_warm(G1, c, lane, b0, b1, b2);
-            }
-            pgs_ready(G0, lane, myd, prm.cfm);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < ncmax) { pgs_warm(G0, c, lane); pgs_warm(G1, c, lane); }
+            pgs_ready(G0, lane, myd, prm.cfm); pgs_ready(G1, lane, myd, prm.cfm);
             PSTAMP(11);
             for (int it = 0; it < prm.n_iter; ++it) {
-                n0 = A1_OF(0); n1 = A1_OF(1); n2 = A1_OF(2);
-#pragma nounroll
-                for (int c = 0; c < ncmax; ++c) {
-                    float a0, a1, a2;
-                    pgs_entries(G0, c, a0, a1, a2);
-                    const float b0 = n0, b1 = n1, b2 = n2;
-                    const int cn = c + 1 < nc1 ? c + 1 : clast1;
-                    n0 = A1_OF(3 * cn); n1 = A1_OF(3 * cn + 1); n2 = A1_OF(3 * cn + 2);
-                    PgsTmp T0, T1;
-                    pgs_step(G0, T0, c, lane, prm.mu, a0, a1, a2);
-                    pgs_step(G1, T1, c, lane, prm.mu, b0, b1, b2);
-                    if (__builtin_expect((T0.cone | T1.cone) != 0ull, 0)) {       // wave-uniform: a contact outside its friction cone
-                        if (T0.cone != 0ull) pgs_cone(G0, T0, c, lane);
-                        if (T1.cone != 0ull) pgs_cone(G1, T1, c, lane);
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < ncmax) {
+                        PgsTmp T0, T1;
+                        pgs_step(G0, T0, c, lane, prm.mu);
+                        pgs_step(G1, T1, c, lane, prm.mu);
+                        if (__builtin_expect((T0.cone | T1.cone) != 0ull, 0)) {       // wave-uniform: a contact outside its friction cone
+                            if (T0.cone != 0ull) pgs_cone(G0, T0, c, lane);
+                            if (T1.cone != 0ull) pgs_cone(G1, T1, c, lane);
+                        }
                     }
-                }
                 if (it == 0) PSTAMP(12);
             }
-#undef A1_OF
         }
 
         PSTAMP(8);

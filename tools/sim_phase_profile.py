@@ -1,6 +1,7 @@
 """Per-phase cycle profile of sim_step_kernel (env 0, lane 0; wall_clock64 ticks at 100 MHz).
 
-Run on a GPU box:   EMLOCO_HIPCC_EXTRA="-DEMLOCO_SIM_PROFILE=1" python -m emloco_amd.build && python tools/sim_phase_profile.py
+Run on a GPU box:   EMLOCO_HIPCC_EXTRA="-DEMLOCO_SIM_PROFILE=1" python -m emloco_amd.build && python tools/sim_phase_profile.py [4096] [--pair]
+(--pair: the library was built with EMLOCO_HIPCC_EXTRA_SIM="-DEMLOCO_SIM_PAIR=1 -DEMLOCO_SIM_PROFILE=1")
 The stamps exist only in a library built with -DEMLOCO_SIM_PROFILE=1 (the product build carries none).
 """
 import ctypes as C, os, sys
@@ -13,7 +14,7 @@ from helpers import varied_models
 
 PHASES = ["kinematics", "inertia+bias", "factorise", "down pass", "contact candidates", "rows/chain y", "A build",
           "PGS", "impulse solve", "integrate"]
-E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+E = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4096
 models = varied_models(64, seed=11); models = [models[i % 64] for i in range(E)]
 sim = NativeSim(models, L.default_sim_params())
 sim.root_state[:, 2] = 0.93
@@ -30,7 +31,15 @@ n_sub = 4
 print(f"E={E}: ticks (100 MHz) per phase, substeps 0..{n_sub-1}")
 def row(name, a, b):
     print(f"  {name:34s} " + " ".join(f"{int(t[s, b] - t[s, a]):6d}" for s in range(n_sub)))
-# round 6 (two envs per wave): stamps of the pair that holds env 0; joint = both envs in one instruction stream
+if "--pair" not in sys.argv:        # sim_kernels.hip (one env per wave)
+    for i, name in enumerate(PHASES):
+        row(name, i, i + 1)
+    row("PGS: setup+warm start", 7, 11)
+    row("PGS: first sweep", 11, 12)
+    row("substep total", 0, 10)
+    sys.exit(0)
+# --pair: sim_pair_kernels.hip (-DEMLOCO_SIM_PAIR=1, two envs per wave): stamps of the pair that holds env 0; joint = both envs in one
+# instruction stream
 row("1 kinematics + 1b limb-limb (joint|x2)", 0, 1)
 row("2 drive (joint)", 1, 2)
 row("2b-3 inertia, factorise (joint)", 2, 3)
