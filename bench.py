@@ -31,7 +31,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import emloco_amd  # noqa: E402,F401  (ahead of the first GPU call: the package raises GPU_MAX_HW_QUEUES, emloco_amd/__init__.py)
+import emloco_amd  # noqa: E402
+emloco_amd.configure_runtime()   # ahead of the first GPU call: 16 hardware queues for the side streams / graph arms (emloco_amd/__init__.py)
 
 SIM_BYTES_PER_ENV = 9296          # state in/out + per-env model (+ collision capsules) + warm-start, per launch
 PROFILE_ROUND = "r05"             # profiles/<round>_*: the committed rocprofv3 summaries of this round's kernels
@@ -224,7 +225,7 @@ def gemm_peak(ops):
     return 157.3, "fp32-in fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32), peak = fp32 matrix peak"
 
 
-def jta_leg(dev, steps=4, warmup=2, B=256, rank=0, world=1):
+def jta_leg(dev, steps=10, warmup=2, B=256, rank=0, world=1):
     """train_jta.py EmLoco step (configs[3]): fwd + MSE + LocoVal loss + bwd + clip + Adam, batch 256 per GPU, fp32 MFMA.
     world > 1: data parallel (EmLocoTrainer(data_parallel=True): one flat 3.2 M-float gradient all-reduce per step)."""
     import torch
@@ -598,6 +599,34 @@ def locoval_policy_leg(env, E, dev, steps, warmup):
                     "the sequential order (tests/test_gpu_env.py); EMLOCO_DEFER_DISC=0 puts the discriminator back between env.step and the reset"}
 
 
+def summary_of(out):
+    """Compact digest of the line (numbers only, no notes), printed as its last key so that a reader of the TAIL of stdout sees every leg:
+    headline, the rigid-body kernel, env_step_only, policy, configs[2] (frozen policy + discriminator reward + LocoVal fit), the PPO
+    learner, the JTA train step in both precision classes, evaluation, the CPU baselines."""
+    def g(d, *ks):
+        for k in ks:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    s = {"headline_env_steps_per_s": out.get("value"), "ms_per_step": out.get("ms_per_step"), "n_gpus": out.get("n_gpus"),
+         "sim_kernel_ms": g(out, "roofline", "kernel_ms"), "roofline_frac": g(out, "roofline", "frac"),
+         "env_step_only": g(out, "env_step_only", "value"),
+         "policy": g(out, "policy", "value"), "policy_ms": g(out, "policy", "policy_ms"),
+         "configs2_policy_disc_locoval_fit": g(out, "policy", "with_discriminator_and_locoval_fit", "value"),
+         "configs2_ms_per_step": g(out, "policy", "with_discriminator_and_locoval_fit", "ms_per_step"),
+         "ppo_fps_total": g(out, "policy", "ppo", "fps_total"), "ppo_fps_step": g(out, "policy", "ppo", "fps_step"),
+         "ppo_update_ms_per_optimizer_step": g(out, "policy", "ppo", "update_ms_per_optimizer_step"),
+         "cpu_baseline_env_steps_per_s": g(out, "cpu_baseline", "value"), "cpu_baseline_cores": g(out, "cpu_baseline", "cores"),
+         "jta_samples_per_s": g(out, "jta", "value"), "jta_ms_per_step": g(out, "jta", "ms_per_step"), "jta_steps_timed": g(out, "jta", "steps"),
+         "jta_roofline_frac": g(out, "jta", "roofline", "frac"),
+         "jta_bf16_samples_per_s": g(out, "jta", "bf16", "value"), "jta_bf16_ms_per_step": g(out, "jta", "bf16", "ms_per_step"),
+         "jta_bf16_roofline_frac": g(out, "jta", "bf16", "roofline", "frac"),
+         "eval_samples_per_s": g(out, "jta", "eval", "value"),
+         "jta_cpu_baseline_samples_per_s": g(out, "jta", "cpu_baseline", "value")}
+    return {k: v for k, v in s.items() if v is not None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -782,6 +811,7 @@ def main():
             if world == 1 and not a.no_cpu_baseline:
                 out["jta"]["cpu_baseline"] = jta_cpu_baseline()
     if rank == 0:
+        out["summary"] = summary_of(out)              # LAST key of the line: the numbers of every leg inside the final kilobyte of stdout
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -10,10 +10,12 @@ import sys as _sys
 # `hw_queues()` is what the package believes the runtime runs with (None: unknown -- the runtime was up before the package could see
 # or set the variable); schedules that depend on the queue count key off it, not off the environment of the moment.
 #
-# Who sets it: the package's ENTRY POINTS (bench.py, emloco_amd.run, the train / evaluate mains) call `configure_runtime()` ahead of
-# their first GPU call.  A plain `import emloco_amd` inside a host application does the same unless EMLOCO_KEEP_HW_QUEUES=1 is set
-# (opt-out: the library then leaves the process environment alone and runs on whatever the host chose), and never touches a value the
-# caller has exported.
+# Who sets it (round 6: opt-IN): the ENTRY POINTS -- bench.py, emloco_amd.run, the train / evaluate mains, __graft_entry__ -- call
+# `configure_runtime()` ahead of their first GPU call.  A plain `import emloco_amd` inside a host application changes nothing in the
+# process environment: it records what the runtime will be (or was) initialised with -- the caller's GPU_MAX_HW_QUEUES, else the
+# runtime's default of 4 -- and the schedules that depend on the queue count (learning/amp_agent.py, learning/locoval_rollout.py) fall
+# back to their 4-queue forms.  A host that wants the 16-queue schedules calls `emloco_amd.configure_runtime()` itself before its
+# first GPU call, or exports the variable.
 _HW_QUEUES = None
 
 
@@ -42,12 +44,8 @@ def hw_queues():
     return _HW_QUEUES
 
 
-if _runtime_up():
-    pass                                                         # the host initialised the GPU first: nothing is changed, nothing assumed
-elif _os.environ.get("EMLOCO_KEEP_HW_QUEUES", "0") == "1":
-    try:                                                         # opt-out: record the host's choice (the runtime default is 4)
+if not _runtime_up():
+    try:                                                         # record, never set: the caller's value, else the runtime's default
         _HW_QUEUES = int(_os.environ.get("GPU_MAX_HW_QUEUES", "4"))
     except ValueError:
         _HW_QUEUES = None
-else:
-    configure_runtime()

@@ -23,7 +23,12 @@ __host__ __device__ __forceinline__ unsigned drop_mul24(unsigned a, unsigned b) 
 #endif
 }
 __host__ __device__ __forceinline__ unsigned drop_mix24(unsigned x) {
-    x ^= x >> 16; x = drop_mul24(x, 0x9E3779u); x ^= x >> 13; x = drop_mul24(x, 0x85EBCBu); x ^= x >> 16;
+    // (round 6: the first 24-bit multiply sees x only through the fold x ^ (x >> 16), in which the top byte meets bits 8..15: keys that
+    // differ by (d << 24) | (d << 8) gave the SAME hash for every column -- two rows with one mask, ~25 000 row pairs per layer at
+    // 927 744 token rows.  The key's upper 24 bits now also enter behind the first multiply, unmultiplied: a collision needs the
+    // product to differ by exactly that pattern.  tools/exp/hash_quality.py: row-key collision test.)
+    const unsigned hi = x >> 8;
+    x ^= x >> 16; x = drop_mul24(x, 0x9E3779u); x ^= hi; x ^= x >> 13; x = drop_mul24(x, 0x85EBCBu); x ^= x >> 16;
     return x;
 }
 // hash of (row key, column index < 2^24): its low / high 16 bits are two independent uniform samples

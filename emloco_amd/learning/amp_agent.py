@@ -650,8 +650,11 @@ class AMPAgent:
         mode = os.environ.get("EMLOCO_PPO_BRANCHES", "auto")
         if is_distributed() and mode == "auto":
             # every rank must replay the SAME number of collectives per step and the timing trial below is rank-local: data parallel the
-            # choice is made by the environment (default: the arms, what wins on 16 hardware queues) and is the same on every rank
-            mode = "1"
+            # choice is made by what the runtime was initialised with -- the arms when it has 16 hardware queues (what wins there), one
+            # chain otherwise (4 queues: the arms serialise, 9.4 against 4.7 ms, profiles/r04_ppo_hw_queues.txt) -- which comes from the
+            # environment / the entry point and is the same on every rank
+            from .. import hw_queues
+            mode = "1" if (hw_queues() or 4) >= 16 else "0"
         if mode in ("0", "1"):
             self._graph = self._capture(mode == "1")        # (capture does not execute: run the step that was just captured)
             self._replay(self._graph)

@@ -406,8 +406,9 @@ def run(args, logger=None):
 
 if __name__ == "__main__":
     import random
-    from .. import _lib
+    from .. import _lib, configure_runtime
     from ..dist import init_from_env
+    configure_runtime()                                  # entry point: 16 hardware queues, ahead of the first GPU call
     from .train_jta import create_logger
     _lib.require_device()
     a = build_arg_parser().parse_args()

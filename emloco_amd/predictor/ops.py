@@ -319,7 +319,9 @@ class FeedForwardFn(torch.autograd.Function):
         F, N = W1.shape[0], W2.shape[0]
         W1c, W2c = W1.contiguous(), W2.contiguous()
         ctx.xs, ctx.drop = xs, (float(drop_p), int(seed1), int(seed2))
-        ctx.chain = _ffn_chain_ok(M, K, F, N) and x2.dtype == torch.float32
+        # (the chained kernels read whole 16-byte groups of x: a view whose storage offset is not a multiple of four floats goes to the
+        # separate GEMMs instead of failing in emloco_ffn_fwd)
+        ctx.chain = _ffn_chain_ok(M, K, F, N) and x2.dtype == torch.float32 and x2.data_ptr() % 16 == 0
         if ctx.chain:
             W1b, W2b = W1c.to(torch.bfloat16), W2c.to(torch.bfloat16)
             h = torch.empty((M, F), dtype=torch.bfloat16, device=x.device)
@@ -327,8 +329,7 @@ class FeedForwardFn(torch.autograd.Function):
             mbits = torch.empty((M, F // 32), dtype=torch.int32, device=x.device)      # "active and kept", one bit per hidden unit
             _chk(_lib().emloco_ffn_fwd(M, F, _p(x2), _p(W1b), _p(W2b), _p(b1.contiguous()), _p(b2.contiguous()), _p(h), _p(mbits), _p(f), float(drop_p),
                                        int(seed1) & 0xFFFFFFFF, int(seed2) & 0xFFFFFFFF, _st(x2)), "emloco_ffn_fwd")
-            ctx.save_for_backward(x2, W1b, W2b, h)
-            ctx.mbits = mbits
+            ctx.save_for_backward(x2, W1b, W2b, h, mbits)
             return f.view(*xs[:-1], N)
         # the hidden layer is the largest tensor of the step (M x 1024): bf16 in HBM in the reduced-precision mode
         # (the bf16-in-memory GEMM variants serve the 128-wide tiles and 8-byte-aligned rows only: small models keep fp32)
@@ -346,7 +347,8 @@ class FeedForwardFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, df):
-        x2, W1, W2, h = ctx.saved_tensors
+        x2, W1, W2, h = ctx.saved_tensors[:4]
+        mbits = ctx.saved_tensors[4] if ctx.chain else None
         M, K = x2.shape
         F, N = W1.shape[0], W2.shape[0]
         p, _, seed2 = ctx.drop
@@ -364,11 +366,13 @@ class FeedForwardFn(torch.autograd.Function):
             dz1 = torch.empty((M, F), dtype=torch.bfloat16, device=dev)
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
             w2t, w1t = W2.t().contiguous(), W1.t().contiguous()       # (named: a temporary's block would be handed to the next allocation)
-            _chk(lib.emloco_ffn_bwd_input(M, F, _p(dz2), _p(w2t), _p(w1t), _p(ctx.mbits), _p(dz1), _p(dx), float(p), st), "emloco_ffn_bwd_input")
+            _chk(lib.emloco_ffn_bwd_input(M, F, _p(dz2), _p(w2t), _p(w1t), _p(mbits), _p(dz1), _p(dx), float(p), st), "emloco_ffn_bwd_input")
             dW2 = torch.empty((N, F), dtype=torch.float32, device=dev)
             gemm(1, N, F, M, dz2, N, 0, 1, h, F, 0, 1, dW2, F, 0, ksplit=_ksplit_for(M, N * F))          # dW2 = dz2^T h
             dW1 = torch.empty((F, K), dtype=torch.float32, device=dev)
             gemm(1, F, K, M, dz1, F, 0, 1, x2, K, 0, 1, dW1, K, 0, ksplit=_ksplit_for(M, F * K))         # dW1 = dz1^T x
+            # (linear1's bias gradient is the column sum of dz1 as STORED -- bf16-rounded -- where the unchained bf16 path sums the fp32
+            # values before rounding them: a difference of one bf16 rounding per element, inside the reduced-precision mode's 2e-2 bar)
             return (dx.view(ctx.xs) if ctx.needs_input_grad[0] else None), dW1, colsum(dz1), dW2, db2, None, None, None
         dW2 = torch.empty((N, F), dtype=torch.float32, device=dev)
         gemm(1, N, F, M, dz2, N, 0, 1, h, F, 0, 1, dW2, F, 0, ksplit=_ksplit_for(M, N * F))          # dW2 = dz2^T h

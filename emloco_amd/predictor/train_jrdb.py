@@ -177,8 +177,9 @@ def config_from_args(args):
 if __name__ == "__main__":
     import random
     import numpy as np
-    from .. import _lib
+    from .. import _lib, configure_runtime
     from ..dist import init_from_env
+    configure_runtime()                                  # entry point: 16 hardware queues, ahead of the first GPU call
     _lib.require_device()                                # the predictor runs on the HIP library: no CPU path
     args = build_arg_parser().parse_args()
     _rank, local_rank, _world = init_from_env("nccl")

@@ -73,6 +73,8 @@ class RLGPUEnv:
 
 
 def main(argv=None):
+    from . import configure_runtime
+    configure_runtime()                                  # entry point: 16 hardware queues, ahead of the first GPU call (emloco_amd/__init__.py)
     argv = list(sys.argv[1:] if argv is None else argv)
     steps = 100
     if "--steps" in argv:

@@ -426,6 +426,26 @@ def test_bench_launcher_four_ranks_sharing_the_gpu_prints_one_json_line():
     assert d["config"]["locoval"]["exchange_floats_per_step"] == 6176
 
 
+def test_bench_launcher_eight_ranks_sharing_the_gpu_runs_the_drivers_rank_count():
+    """The driver's `--gpus 8` contract at its REAL rank count, once, before an 8-GPU node appears: eight processes (gloo, one device),
+    128 envs each, the rollout legs only (the predictor legs are covered at four ranks above and would put eight models on one GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EMLOCO_BENCH_SHARE_GPU="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--num_envs", "128", "--steps", "12", "--warmup", "4",
+                        "--no_cpu_baseline", "--no_jta"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 12 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["num_envs_per_gpu"] == 128 and "x8" in d["config"]["parallelism"] and "TEST MODE" in d["config"]["parallelism"]
+    assert abs(d["value"] - 8 * 128 * 12 / (d["ms_per_step"] * 12 / 1e3)) < 0.02 * d["value"]      # whole-job aggregate over the eight shards
+    assert d["summary"]["headline_env_steps_per_s"] == d["value"] and list(d)[-1] == "summary"      # the digest closes the line
+
+
 def _rccl_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                       HSA_ENABLE_IPC_MODE_LEGACY="0", EMLOCO_FORCE_COLLECTIVES="1")

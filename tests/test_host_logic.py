@@ -175,24 +175,25 @@ def test_jrdb_dataset_pickles_collate_and_cli(tmp_path):
     assert tj.JrdbTrainer.value_loss_with_multi_modal is False
 
 
-def test_package_import_raises_the_hardware_queue_count_only_when_the_caller_has_not_chosen():
-    """emloco_amd/__init__.py: GPU_MAX_HW_QUEUES = 16 unless the environment already holds a value (the HIP runtime reads it when it
-    initialises; the package's side streams and the PPO step's graph arms need queues of their own)."""
+def test_package_import_leaves_the_environment_alone_and_entry_points_opt_in():
+    """emloco_amd/__init__.py (round 6): importing the package never touches GPU_MAX_HW_QUEUES -- it records the caller's value (else the
+    runtime default, 4) -- and `configure_runtime()`, which the entry points call ahead of their first GPU call, raises it to 16 unless the
+    caller has chosen a value (the HIP runtime reads the variable once, when it initialises)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = "import os, emloco_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
-    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "EMLOCO_KEEP_HW_QUEUES")}
     env["PYTHONPATH"] = root
-    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "16"
-    env["GPU_MAX_HW_QUEUES"] = "4"
-    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "4"
-    # opt-out: a host application that does not want the library to touch the process environment
-    env2 = {k: v for k, v in env.items() if k != "GPU_MAX_HW_QUEUES"}
-    env2["EMLOCO_KEEP_HW_QUEUES"] = "1"
-    code2 = "import os, emloco_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'), emloco_amd.hw_queues())"
-    assert subprocess.run([sys.executable, "-c", code2], env=env2, capture_output=True, text=True).stdout.split() == ["None", "4"]
+    run = lambda code, e: subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True).stdout.split()
+    code = "import os, emloco_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'), emloco_amd.hw_queues())"
+    assert run(code, env) == ["None", "4"]                                   # plain import: nothing set, the default recorded
+    assert run(code, dict(env, GPU_MAX_HW_QUEUES="8")) == ["8", "8"]          # the caller's choice is recorded
+    code2 = "import os, emloco_amd; print(emloco_amd.configure_runtime(), os.environ.get('GPU_MAX_HW_QUEUES'), emloco_amd.hw_queues())"
+    assert run(code2, env) == ["16", "16", "16"]                             # an entry point opts in
+    assert run(code2, dict(env, GPU_MAX_HW_QUEUES="4")) == ["4", "4", "4"]   # ... and never overrides an exported value
     # the package records what the runtime will be initialised with: schedules key off that, not off the environment of the moment
-    code3 = "import os, emloco_amd; os.environ['GPU_MAX_HW_QUEUES'] = '2'; print(emloco_amd.hw_queues())"
-    env3 = {k: v for k, v in env.items() if k != "GPU_MAX_HW_QUEUES"}
-    assert subprocess.run([sys.executable, "-c", code3], env=env3, capture_output=True, text=True).stdout.strip() == "16"
+    code3 = "import os, emloco_amd; emloco_amd.configure_runtime(); os.environ['GPU_MAX_HW_QUEUES'] = '2'; print(emloco_amd.hw_queues())"
+    assert run(code3, env) == ["16"]
+    # the benchmark and the smoke entry opt in
+    for f in ("bench.py", "__graft_entry__.py", os.path.join("emloco_amd", "run.py")):
+        assert "configure_runtime()" in open(os.path.join(root, f)).read(), f

@@ -7,8 +7,10 @@ def u(x): return x & M32
 def fmix32(x):
     x = u(x); x ^= x >> np.uint64(16); x = u(x * np.uint64(0x85EBCA6B)); x ^= x >> np.uint64(13); x = u(x * np.uint64(0xC2B2AE35)); x ^= x >> np.uint64(16); return x
 def mul24(a, c): return u((a & np.uint64(0xffffff)) * np.uint64(c & 0xffffff))
-def mixA(x, c1=0x9E3779, c2=0x85EBCB):
+def mixA5(x, c1=0x9E3779, c2=0x85EBCB):        # round 5's mixer: the key's top byte reaches the first multiply only through bits 8..15
     x = u(x); x ^= x >> np.uint64(16); x = mul24(x, c1); x ^= x >> np.uint64(13); x = mul24(x, c2); x ^= x >> np.uint64(16); return x
+def mixA(x, c1=0x9E3779, c2=0x85EBCB):         # shipped (round 6): the key's upper 24 bits also enter behind the first multiply
+    x = u(x); hi = x >> np.uint64(8); x ^= x >> np.uint64(16); x = mul24(x, c1); x ^= hi; x ^= x >> np.uint64(13); x = mul24(x, c2); x ^= x >> np.uint64(16); return x
 def mixB(x, c1=0xB5297B, c2=0x68E31D):   # fold 15, mul, fold 12, mul, fold 15
     x = u(x); x ^= x >> np.uint64(15); x = mul24(x, c1); x ^= x >> np.uint64(12); x = mul24(x, c2); x ^= x >> np.uint64(15); return x
 def mixC(x):   # one mul24 only
@@ -50,6 +52,7 @@ def stats(name, h):
     print(f"{name:8s} keep {m:.5f}  corr pair {c_pair:+.4f} adj-key {c_key:+.4f} key+2 {c_key2:+.4f} adj-query {c_q:+.4f} adj-head {c_bh:+.4f}  chi2/255 lo {chi_lo/255:.2f} hi {chi_hi/255:.2f}  row-var ratio {var_ratio:.3f} col-var ratio {var_ratio_c:.3f}")
 stats("old", old)
 stats("mixA", newh(mixA))
+stats("mixA r05", newh(mixA5))
 stats("mixB", newh(mixB))
 stats("mixC", newh(mixC))
 
@@ -78,3 +81,24 @@ def drop_keep_stats():
 
 
 drop_keep_stats()
+
+
+def row_key_collisions():
+    """Two row keys must not share their whole mask.  Round 5's mixer did for keys that differ by (d << 24) | (d << 8): identical hashes
+    for EVERY column.  Counted here: over 512 columns, pairs (key, key ^ pattern) whose hashes agree in every column, for the structured
+    patterns of the finding and for random key pairs."""
+    rng = np.random.default_rng(0)
+    cols = np.arange(512, dtype=np.uint64)[None, :]
+    keys = rng.integers(0, 1 << 32, size=4096, dtype=np.uint64)[:, None]
+    for name, mix in (("mixA (shipped)", mixA), ("mixA r05", mixA5)):
+        h = newh(mix)
+        same = 0
+        for d in (1, 0x5a, 0xff, 0x80, 0x33):
+            pat = np.uint64((d << 24) | (d << 8))
+            same += int((h(keys, cols) == h(keys ^ pat, cols)).all(axis=1).sum())
+        rnd = int((h(keys, cols) == h(np.roll(keys, 1, axis=0), cols)).all(axis=1).sum())
+        part = float((h(keys, cols) == h(keys ^ np.uint64((0x5a << 24) | (0x5a << 8)), cols)).mean())
+        print(f"{name:16s} structured pairs with identical masks over 512 columns: {same} of {5 * 4096}; random pairs: {rnd}; share of equal hashes, d = 0x5a: {part:.5f}")
+
+
+row_key_collisions()
