@@ -211,6 +211,9 @@ class AMPAgent:
         # for the epoch's remaining minibatches and every later epoch.  Single rank only: a gloo all-reduce cannot be captured.
         self.use_graph = (self.device.type == "cuda" and os.environ.get("EMLOCO_PPO_GRAPH", "1") != "0")
         self._graph, self._g_in, self._g_u, self._g_acc, self._g_keys = None, None, None, None, None
+        # the arms' streams exist from construction on (round 6): which hardware queue a stream lands on depends on how many streams
+        # the process created before it, so they are made here, in a fixed order, not at the first captured step
+        self._g_branch = tuple(torch.cuda.Stream(device=self.device) for _ in range(3)) if self.use_graph else None
         # clip_grad_norm_ + Adam (common_agent.py:573-603 through amp_continuous.py:440-445) on flat buffers: 4 launches
         # (`emloco_adam_clip_flat_counted`: the step count lives on the device, so the captured step replays as the next one) where
         # torch's foreach implementations issue ~30 passes over the 11 M parameters.  EMLOCO_PPO_FLAT_ADAM=0 / a CPU device: torch's own.
@@ -227,6 +230,17 @@ class AMPAgent:
             self.optimizer = torch.optim.Adam(self.a2c_network.parameters(), float(self.last_lr), eps=1e-08, weight_decay=0.0,
                                               capturable=self.use_graph)
             self.bucket = FlatGradBucket([p for p in self.a2c_network.parameters() if p.requires_grad])
+        # Round 6: one stacked actor evaluation per step (EMLOCO_PPO_STACK_ACTOR=0: three, as the reference), and the weight gradients of
+        # the layers that are used on ONE stream and by nothing but their GEMMs -- actor and critic trunks, the value head -- accumulate
+        # straight into the flat bucket (ops.mark_direct_grad; EMLOCO_PPO_DIRECT_GRAD=0: through autograd).  Not the task MLP (evaluated
+        # on the actor's and on the critic's stream) and not the discriminator (weight decay, logit regulariser and the gradient-penalty
+        # network reach its weights through autograd's accumulation, which runs on a stream of its own choosing).
+        self._stack_actor = os.environ.get("EMLOCO_PPO_STACK_ACTOR", "1") != "0"
+        if self.device.type == "cuda" and os.environ.get("EMLOCO_PPO_DIRECT_GRAD", "1") != "0" and (self._stack_actor or not self.motion_sym_loss):
+            from ..predictor import ops as _ops
+            net_ = self.a2c_network
+            direct = [m.weight for m in list(net_.actor_mlp.modules()) + list(net_.critic_mlp.modules()) if isinstance(m, nn.Linear)]
+            _ops.mark_direct_grad(direct + [net_.value.weight])
         self._amp_obs_demo_buffer = ReplayBuffer(int(c["amp_obs_demo_buffer_size"]), self.device)
         self._amp_replay_buffer = ReplayBuffer(int(c["amp_replay_buffer_size"]), self.device)
         self._amp_replay_keep_prob = c["amp_replay_keep_prob"]
@@ -373,7 +387,14 @@ class AMPAgent:
         idx = self._sym_idx
         # (one evaluation of the 2 B stacked rows: the network is row-wise, the GEMMs twice as tall -- amp_continuous.py evaluates twice)
         both, _ = self.a2c_network.eval_actor(torch.cat([flip_obs, orig_obs], dim=0))
-        flip_a, orig_a = both[:B], both[B:]
+        return self._sym_from_actions(both[:B], both[B:])
+
+    def _sym_from_actions(self, flip_a, orig_a):
+        """The symmetry loss (amp_continuous.py:405-418) from the actor's means on the flipped and on the next observations."""
+        B = flip_a.shape[0]
+        if getattr(self, "_sym_idx", None) is None or self._sym_idx.device != flip_a.device:
+            self._sym_idx = torch.as_tensor(self.task.left_to_right_index_action, dtype=torch.long, device=flip_a.device)
+        idx = self._sym_idx
         if getattr(self, "_sym_sign", None) is None or self._sym_sign.device != orig_a.device:
             self._sym_sign = torch.tensor([-1.0, 1.0, -1.0], device=orig_a.device)      # (made once: no host-to-device copy in the step)
         orig_a = orig_a.view(B, -1, 3) * self._sym_sign
@@ -424,32 +445,31 @@ class AMPAgent:
         if self._amp_dropout and dropout_masks is None:
             steps = self.task._num_amp_obs_steps
             dropout_masks = amp_dropout_mask(self._amp_minibatch_size, steps, d["amp_obs"].shape[1] // steps, device=d["amp_obs"].device)
-        # Every normaliser call on the caller's stream, in the reference's order (obs, the three AMP batches, flipped, next:
-        # amp_continuous.py:345-352,405): in training mode a RunningMeanStd UPDATES its statistics with the batch it is handed, so the
-        # order is part of the arithmetic -- and two arms updating one normaliser at once would be a race.  The arms get the results.
+        # In training mode a RunningMeanStd UPDATES its statistics with the batch it is handed, so the order of the calls on ONE normaliser
+        # is part of the arithmetic (the reference's: obs, the three AMP batches, flipped, next: amp_continuous.py:345-352,405) -- and two
+        # streams updating one normaliser at once would be a race: each normaliser is called from one stream only, in that order.
+        # Round 6 -- order of issue.  The two normalisers are independent objects: the AMP one sees its three batches in the reference's
+        # order on the DISCRIMINATOR's arm (the only reader of its results), the observation one sees obs, flipped, next in the
+        # reference's order on the caller's stream.  Each arm forks as soon as its inputs exist: the discriminator before anything
+        # else, the critic behind the normalised observations and ahead of the flipped / next ones (before: all six normaliser chains --
+        # 36 launches -- on the stream every arm forks from, ahead of every fork).
         n_amp = self._amp_minibatch_size
-        obs = self._preproc_obs(d["obs"])
-        amp_obs = self._preproc_amp_obs(d["amp_obs"][0:n_amp])
-        amp_replay = self._preproc_amp_obs(d["amp_obs_replay"][0:n_amp])
-        amp_demo = self._preproc_amp_obs(d["amp_obs_demo"][0:n_amp])
-        flip_n = next_n = None
-        if self.motion_sym_loss:
-            flip_n, next_n = self._preproc_obs(d["flip_obs"]), self._preproc_obs(d["next_obses"])
-        if branch_streams is not None:                       # (allocated on the caller's stream, read on an arm's)
-            for t, st in ((obs, s_c), (amp_obs, s_d), (amp_replay, s_d), (amp_demo, s_d), (flip_n, s_s), (next_n, s_s), (dropout_masks, s_d)):
-                if t is not None:
-                    t.record_stream(st)
+        stack_actor = self.motion_sym_loss and self._stack_actor and d["obs"].is_cuda
+        if branch_streams is not None and dropout_masks is not None:      # (allocated on the caller's stream, read on an arm's)
+            dropout_masks.record_stream(s_d)
         with on(s_d):
+            amp_obs = self._preproc_amp_obs(d["amp_obs"][0:n_amp])
+            amp_replay = self._preproc_amp_obs(d["amp_obs_replay"][0:n_amp])
+            amp_demo = self._preproc_amp_obs(d["amp_obs_demo"][0:n_amp])
             m = (lambda i: dropout_masks[..., i]) if dropout_masks is not None else (lambda i: None)
             mul = lambda x, k: x if k is None else x * k
             # (agent and replay rows through the discriminator as ONE stacked batch: row-wise network, the loss wants them stacked anyway)
             disc_agent_replay_logit = net.eval_disc(torch.cat([mul(amp_obs, m(0)), mul(amp_replay, m(1))], dim=0))
             disc_demo_logit, grad_pen = disc_forward_with_grad_penalty(net, amp_demo, m(2))
             disc_info = self._disc_loss(disc_agent_replay_logit, disc_demo_logit, grad_pen)
-        s_loss = None
-        if self.motion_sym_loss:                             # (two more actor evaluations)
-            with on(s_s):
-                s_loss = torch.mean(self._sym_loss(flip_n, next_n)["sym_loss"])
+        obs = self._preproc_obs(d["obs"])
+        if branch_streams is not None:
+            obs.record_stream(s_c)
         heads = self._fused_heads and obs.is_cuda
         with on(s_c):
             values = net.eval_critic(obs)
@@ -458,7 +478,24 @@ class AMPAgent:
             else:
                 c_info = self._critic_loss(d["old_values"], values, self.e_clip, d["returns"], self.clip_value)
                 c_loss = torch.mean(c_info["critic_loss"])
-        mu, logstd = net.eval_actor(obs)
+        flip_n = next_n = None
+        if self.motion_sym_loss:
+            flip_n, next_n = self._preproc_obs(d["flip_obs"]), self._preproc_obs(d["next_obses"])
+        s_loss = None
+        if self.motion_sym_loss and not stack_actor:         # (two more actor evaluations, on an arm of their own)
+            if branch_streams is not None:
+                flip_n.record_stream(s_s); next_n.record_stream(s_s)
+            with on(s_s):
+                s_loss = torch.mean(self._sym_loss(flip_n, next_n)["sym_loss"])
+        # one evaluation of the actor on the stacked rows [policy | flipped | next] (the network is row-wise; amp_continuous.py evaluates
+        # it three times): a third of the actor's launches, one weight-gradient product per layer instead of three and their sums
+        if stack_actor:
+            B = obs.shape[0]
+            mu_all, logstd_all = net.eval_actor(torch.cat([obs, flip_n, next_n], dim=0))
+            mu, logstd = mu_all[:B], logstd_all[:B]
+            s_loss = torch.mean(self._sym_from_actions(mu_all[B:2 * B], mu_all[2 * B:])["sym_loss"])
+        else:
+            mu, logstd = net.eval_actor(obs)
         sigma = torch.exp(logstd)
         self._head_kl = None
         if heads and self.bounds_loss_coef is not None:
@@ -474,7 +511,7 @@ class AMPAgent:
             clip_frac = a_info["actor_clipped"].float().mean()
         if branch_streams is not None:
             # join: what crosses is a handful of scalars (allocated on the branch streams: tell the allocator who else reads them)
-            for st, ts in ((s_c, [c_loss]), (s_d, list(disc_info.values())), (s_s, [s_loss] if s_loss is not None else [])):
+            for st, ts in ((s_c, [c_loss]), (s_d, list(disc_info.values())), (s_s, [s_loss] if (s_loss is not None and not stack_actor) else [])):
                 main.wait_stream(st)
                 for t in ts:
                     t.record_stream(main)

@@ -231,6 +231,7 @@ class LinearFn(torch.autograd.Function):
              b_image=_weight_image(Wc, M, N, K, K, 0) if x2.dtype == torch.float32 and y.dtype == torch.float32 else None)
         ctx.save_for_backward(x2, Wc, y if relu else None)
         ctx.relu, ctx.has_bias, ctx.xs, ctx.drop = relu, b is not None, xs, (float(drop_p), int(drop_seed))
+        ctx.w_param = W if getattr(W, "_emloco_direct_grad", False) else None     # (see `mark_direct_grad`)
         return y.view(*xs[:-1], N)
 
     @staticmethod
@@ -258,11 +259,26 @@ class LinearFn(torch.autograd.Function):
                  b_image=_weight_image(W, M, K, N, K, 1) if dy2.dtype == torch.float32 else None)                                       # dx = dy W
             dx = dx.view(ctx.xs)
         if ctx.needs_input_grad[1]:
-            dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            gemm(1, N, K, M, dy2, N, 0, 1, x2, K, 0, 1, dW, K, 0, ksplit=_ksplit_for(M, N * K))   # dW = dy^T x
+            g = ctx.w_param.grad if ctx.w_param is not None else None
+            if g is not None and g.dtype == torch.float32 and g.shape == (N, K) and g.is_contiguous() and g.data_ptr() % 16 == 0 and dy2.dtype == torch.float32:
+                # the weight gradient goes straight INTO the parameter's .grad (a view of the learner's flat bucket): C += dy^T x in the
+                # GEMM's epilogue instead of a fresh N x K tensor and autograd's accumulation launch behind it
+                gemm(1, N, K, M, dy2, N, 0, 1, x2, K, 0, 1, g, K, 0, ksplit=_ksplit_for(M, N * K), flags=GEMM_ACC)
+            else:
+                dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+                gemm(1, N, K, M, dy2, N, 0, 1, x2, K, 0, 1, dW, K, 0, ksplit=_ksplit_for(M, N * K))   # dW = dy^T x
         if need_db and db is None:
             db = colsum(dy2)
         return dx, dW, db, None, None, None, None
+
+
+def mark_direct_grad(params, on=True):
+    """Weights whose gradient `LinearFn.backward` may accumulate directly into `.grad` (GEMM epilogue, C += ...) instead of returning it
+    to autograd.  The caller vouches that (1) `.grad` exists and is zeroed before every backward (FlatGradBucket) and (2) every use of
+    the weight in one backward pass runs on ONE stream (the accumulations are then stream-ordered; autograd's own accumulation node
+    is what orders gradients that arrive from several streams)."""
+    for p_ in params:
+        p_._emloco_direct_grad = bool(on)
 
 
 def linear(x, W, b=None, relu=False, drop_p=0.0, out_bf16=False):
