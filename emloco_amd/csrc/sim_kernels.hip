@@ -1067,6 +1067,14 @@ __device__ __forceinline__ void sim_step_env(const EmlocoSimParams &prm, const E
         }
         unsigned long long m0 = __ballot(act[0]), m1 = __ballot(act[1]);
         int nc = __popcll(m0) + __popcll(m1);
+#ifdef EMLOCO_SIM_NCHIST
+        // diagnostic build (tools/exp/contact_hist.py): histogram over env-substeps of the candidates inside the contact offset
+        // [0..63] and of the contacts kept [64 + 0..MAXC], in the buffer the phase stamps use (emloco_sim_profile)
+        if (d.prof && lane == 0) {
+            atomicAdd((unsigned long long *)&d.prof[nc < 63 ? nc : 63], 1ull);
+            atomicAdd((unsigned long long *)&d.prof[64 + (nc < MAXC ? nc : MAXC)], 1ull);
+        }
+#endif
         while (nc > MAXC) {   // rare: drop the shallowest candidate (largest dist; ties -> highest candidate id)
             float best = -3.0e38f; int bid = -1;
             for (int s = 0; s < 2; ++s)

@@ -115,8 +115,20 @@ __device__ __forceinline__ void ld4(const float *base, int off, float *v) {
 
 #ifdef EMLOCO_SIM_PROFILE
 #define PSTAMP(i) do { if (d.prof && env0 == 0 && lane == 0) d.prof[sub * 16 + (i)] = (long long)wall_clock64(); } while (0)
+#endif
+#ifdef EMLOCO_SIM_PACC
+// segment times summed over ALL pairs of the launches since the buffer was cleared (tools/sim_phase_profile.py --pair-all): slot 128 + i
+// collects the ticks since the previous PACC of this wave, slot 160 + i how often
+#define PACC(i) do { if (d.prof && lane == 0) { const long long t_ = (long long)wall_clock64(); atomicAdd((unsigned long long *)&d.prof[128 + (i)], (unsigned long long)(t_ - pacc_t)); \
+                                                atomicAdd((unsigned long long *)&d.prof[160 + (i)], 1ull); pacc_t = t_; } } while (0)
 #else
+#define PACC(i) do { } while (0)
+#endif
+#ifndef EMLOCO_SIM_PROFILE
 #define PSTAMP(i) do { } while (0)
+#endif
+#ifndef PAIR_FAST_MAXC
+#define PAIR_FAST_MAXC 10   /* contacts per env up to which the row phases of both envs of a pair share the wave (3 x 10 rows <= 32 lanes) */
 #endif
 
 // Height-field ground under the world point (cx, cy): height zt of the cell triangle's plane there and its unit normal.
@@ -298,91 +310,8 @@ __device__ __forceinline__ float half_sum(float v, int half) {
 }
 
 
-// ---- projected Gauss-Seidel on matrix rows held in registers (phase 6c).  One PgsRow per env of the pair; every function is
-// inlined into the unrolled contact loop, so A[] is indexed statically.
-// (Measured alternatives, all slower -- profiles/r06_sim_pair_experiment.txt: the rows as two 32-register tuples indexed by the loop
-// counter with rolled loops; env 1's matrix in LDS; every lane forming the contact's multipliers redundantly from three
-// broadcast residuals with the contacts' constants in LDS.)
-struct PgsRow {
-    float A[MAXR];                 // this lane's row of the contact matrix (row = lane)
-    float w, lam;                  // running residual, warm-start multiplier of this lane's row
-    float ainv, diag;              // 1 / (A_ss (1 + cfm)), A_ss
-    float gl0, gl1, gl2;           // leader lane (normal row of a contact): the contact's three multipliers ...
-    float gi1, gi2, gA10, gA20, gA21;   // ... the reciprocal diagonals of its tangent rows and the sub-diagonal of its 3 x 3 block
-    int nc;                        // contacts of the env (wave-uniform)
-};
-struct PgsTmp { float nl1, nl2, lim, m2, a1, a2; bool me; unsigned long long cone; };
-__device__ __forceinline__ void pgs_clear(PgsRow &G) {
-    for (int k = 0; k < MAXR; ++k) G.A[k] = 0.0f;
-    G.w = G.lam = G.ainv = G.gl0 = G.gl1 = G.gl2 = G.gi1 = G.gi2 = G.gA10 = G.gA20 = G.gA21 = 0.0f;
-    G.diag = 1.0f; G.nc = 0;
-}
-__device__ __forceinline__ void pgs_take(PgsRow &G, const float (&Arow)[64], float rhs, float lam, int nc) {
-    for (int k = 0; k < MAXR; ++k) G.A[k] = Arow[k];
-    G.w = rhs; G.lam = lam; G.nc = nc;
-    G.ainv = G.gi1 = G.gi2 = G.gA10 = G.gA20 = G.gA21 = 0.0f; G.diag = 1.0f;
-}
-// first row of this lane's contact (idle lanes shadow lane 0: their values are never used)
-__device__ __forceinline__ int pgs_lr0(const PgsRow &G, int lane, int myd) { return lane < 3 * G.nc ? lane - myd : 0; }
-__device__ __forceinline__ void pgs_begin(PgsRow &G, int lane, int myd) {
-    const int lr0 = pgs_lr0(G, lane, myd);
-    G.gl0 = __shfl(G.lam, lr0); G.gl1 = __shfl(G.lam, lr0 + 1); G.gl2 = __shfl(G.lam, lr0 + 2);
-}
-// warm start through contact c (w += A[., r] lam_r for its three rows, skipping zero multipliers as the oracle does); on the way
-// the lanes of contact c pick their diagonal entry, its leader the sub-diagonal of the 3 x 3 block
-__device__ __forceinline__ void pgs_warm(PgsRow &G, const int c, int lane) {
-    const int r0 = 3 * c;
-    const float a0 = G.A[r0], a1 = G.A[r0 + 1], a2 = G.A[r0 + 2];
-    const float l0 = lane_bcast(G.lam, r0), l1 = lane_bcast(G.lam, r0 + 1), l2 = lane_bcast(G.lam, r0 + 2);
-    const float u0 = fmaf(a0, l0, G.w);
-    G.w = (l0 != 0.0f) ? u0 : G.w;
-    const float u1 = fmaf(a1, l1, G.w);
-    G.w = (l1 != 0.0f) ? u1 : G.w;
-    const float u2 = fmaf(a2, l2, G.w);
-    G.w = (l2 != 0.0f) ? u2 : G.w;
-    G.diag = lane == r0 ? a0 : (lane == r0 + 1 ? a1 : (lane == r0 + 2 ? a2 : G.diag));
-    const float t21 = lane_bcast(a2, r0 + 1);                  // A[r0 + 1][r0 + 2]
-    if (lane == r0) { G.gA10 = a1; G.gA20 = a2; G.gA21 = t21; }
-}
-__device__ __forceinline__ void pgs_ready(PgsRow &G, int lane, int myd, float cfm) {
-    G.ainv = (lane < 3 * G.nc) ? 1.0f / (G.diag * (1.0f + cfm)) : 0.0f;
-    const int lr0 = pgs_lr0(G, lane, myd);
-    G.gi1 = __shfl(G.ainv, lr0 + 1); G.gi2 = __shfl(G.ainv, lr0 + 2);
-}
-// contact c of one sweep: branch-free -- every lane runs the leader's chain on its own values, only lane r0's results are read
-__device__ __forceinline__ void pgs_step(PgsRow &G, PgsTmp &T, const int c, int lane, float mu) {
-    const int r0 = 3 * c;
-    const bool act = c < G.nc;                                 // wave-uniform: the partner env may have more contacts
-    const float a0 = G.A[r0], a1 = G.A[r0 + 1], a2 = G.A[r0 + 2];
-    const float w1s = lane_bcast(G.w, r0 + 1), w2s = lane_bcast(G.w, r0 + 2);
-    float nl0 = fmaf(-G.w, G.ainv, G.gl0);
-    if (nl0 < 0.0f) nl0 = 0.0f;
-    const float d0 = nl0 - G.gl0;
-    const float w1 = fmaf(G.gA10, d0, w1s);
-    const float nl1 = fmaf(-w1, G.gi1, G.gl1);
-    const float d1 = nl1 - G.gl1;
-    const float w2 = fmaf(G.gA21, d1, fmaf(G.gA20, d0, w2s));
-    const float nl2 = fmaf(-w2, G.gi2, G.gl2);
-    const float d2 = nl2 - G.gl2;
-    const bool me = act && lane == r0;
-    G.gl0 = me ? nl0 : G.gl0; G.gl1 = me ? nl1 : G.gl1; G.gl2 = me ? nl2 : G.gl2;
-    const float lim = mu * nl0;
-    const float m2 = fmaf(nl1, nl1, nl2 * nl2);
-    float wn = fmaf(a0, lane_bcast(d0, r0), G.w);
-    wn = fmaf(a1, lane_bcast(d1, r0), wn);
-    wn = fmaf(a2, lane_bcast(d2, r0), wn);
-    G.w = act ? wn : G.w;
-    T.cone = __ballot(me && m2 > lim * lim);                   // outside the friction cone
-    T.nl1 = nl1; T.nl2 = nl2; T.lim = lim; T.m2 = m2; T.a1 = a1; T.a2 = a2; T.me = me;
-}
-__device__ __forceinline__ void pgs_cone(PgsRow &G, const PgsTmp &T, const int c, int lane) {
-    const int r0 = 3 * c;
-    const float sc = T.lim / sqrtf(T.m2);
-    const float n1 = T.nl1 * sc, n2 = T.nl2 * sc;
-    G.gl1 = T.me ? n1 : G.gl1; G.gl2 = T.me ? n2 : G.gl2;
-    G.w = fmaf(T.a1, lane_bcast(n1 - T.nl1, r0), G.w);
-    G.w = fmaf(T.a2, lane_bcast(n2 - T.nl2, r0), G.w);
-}
+// the 32 bits of a wave ballot that belong to one half of the wave
+__device__ __forceinline__ unsigned half_bits(unsigned long long m, int half) { return (unsigned)(half ? (m >> 32) : m); }
 
 // One step of an env PAIR: the body of the kernel below (one 64-lane wave, two envs; env1 or env0 may be -1: that half idles).
 //
@@ -403,21 +332,24 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
     // phase 4), pq (8), [a | Aacc] (12; the `a` half carries the limb-limb wrench from phase 1b to 2b, the `Aacc` half the body's bias
     // force from 2b on, for the rare second factorisation pass), Ia (24, phase 3 only).
     // Shared region of the pair, in this order:  B1 = [V|pa]_1 pq_1 | B0 = [V|pa]_0 pq_0 | [a|Aacc]_0 | Ia_0 | Ia_1 | [a|Aacc]_1
-    // The contact matrices are NOT here (every lane holds its row of each env's matrix in registers, phase 6b).  What the contact
-    // phases stage lies over rows that are dead then: the candidate staging of phase 5 and both envs' contact frames (height field) in
+    // Contact matrices: on the fast path (both envs <= 10 contacts) every lane holds its row in registers; on the full-size path the
+    // packed lower triangle (1 830 words) of the env being solved lies over its B block .. Ia (env 0: from B0, env 1: from B1 -- B1 is
+    // still live while env 0 solves).  What the contact phases stage lies over rows that are dead then: the candidate staging of phase 5 and both envs' contact frames (height field) in
     // [a|Aacc]_0 .. Ia_1, the staged Jacobian rows of phase 7a in the B blocks, the limb-limb scratch of phase 1b in Ia_0 | Ia_1.
     enum { O_ROOT = 0, O_P = 16, O_V0 = 24, O_L = 36, O_PD = 48, O_R = O_PD + NB, O_W = O_R + NB * 12,
            O_L0 = O_W + NB * 24, O_CB = O_L0 + 44, O_CX = O_CB + MAXC / 4 + 3, O_CDIST = O_CX + 3 * MAXC, O_LAM = O_CDIST + MAXC,
            O_SLOT = O_LAM + MAXR, O_CRANGE = O_SLOT + 32, PW = O_CRANGE + 2 * NB / 4,
            SR = 2 * PW, BW = NB * 12 + NB * 8, O_B1 = SR, O_B0 = SR + BW,
            O_AA0 = SR + 2 * BW, O_IA0 = O_AA0 + NB * 12, O_IA1 = O_IA0 + NB * 24, O_AA1 = O_IA1 + NB * 24, LDS_WORDS = O_AA1 + NB * 12,
-           O_STAGE = O_AA0,                                    // candidate staging of phase 5 [MAXCAND][7]
+           AMAT = MAXR * (MAXR + 1) / 2,
+           O_STAGE = O_AA0,                                    // candidate staging of phase 5 [2 envs][MAXCAND][7]
            O_CDIR = LDS_WORDS - 2 * 9 * MAXC,                  // contact frames [2 envs][MAXC][9] (height-field ground)
-           O_ROWS = O_B1,                                      // staged Jacobian rows of phase 7a [MAXR][12]
+           O_ROWS = O_B1,                                      // fast path: staged Jacobian rows of phase 7a [2 envs][32][12]
            O_SCR = O_IA0 };                                    // limb-limb scratch of phase 1b
     static_assert(PW % 4 == 0 && O_R % 4 == 0 && O_W % 4 == 0 && SR % 4 == 0 && BW % 4 == 0, "rows must be 16-byte aligned");
-    static_assert(O_STAGE + MAXCAND * 7 <= O_CDIR, "the candidate staging reaches the contact frames");
-    static_assert(MAXR * 12 <= 2 * BW, "staged Jacobian rows do not fit the B blocks");
+    static_assert(O_STAGE + 2 * MAXCAND * 7 <= O_CDIR, "the candidate staging reaches the contact frames");
+    static_assert(O_B0 + AMAT <= O_CDIR, "the full-size path's contact matrix (env 0: from B0 on; env 1: from B1 on) reaches the contact frames");
+    static_assert(2 * 32 * 12 <= 2 * BW && 3 * PAIR_FAST_MAXC <= 32, "the fast path's staged rows do not fit the B blocks");
     static_assert(O_SCR + EMLOCO_SC_MAXSEG * 8 + EMLOCO_SC_MAXHITS * 8 + EMLOCO_SC_MAXPAIRS <= O_AA1, "limb-limb scratch does not fit Ia_0 | Ia_1");
     static_assert(LDS_WORDS * 4 <= 20480, "LDS per env pair above 160 KiB / 8 (two waves per SIMD, 16 envs per CU)");
     __shared__ __attribute__((aligned(16))) float lds[LDS_WORDS];
@@ -544,6 +476,9 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
         const bool last = (sub == prm.n_sub - 1);
 
         PSTAMP(0);
+#ifdef EMLOCO_SIM_PACC
+        long long pacc_t = (long long)wall_clock64();
+#endif
         // ============================================================ 1. kinematics + velocities (root -> leaves), both envs
         if (on && b == 0) {
             float q0[4] = {sh_root[3], sh_root[4], sh_root[5], sh_root[6]}, R[9];
@@ -877,7 +812,7 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
             }
         }
 
-        PSTAMP(1);
+        PSTAMP(1); PACC(0);
         // ============================================================ 2. drive (both envs)
         if (on) {
             // implicit PD drive: tau~ = kp (q* - q) - (kd + h kp) qd, joint-space diagonal d = armature + h kd + h^2 kp
@@ -896,7 +831,7 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
             }
         }
 
-        PSTAMP(2);
+        PSTAMP(2); PACC(1);
         // Phases 3-4 run once with every drive implicit.  The torque such a drive delivers over the substep is
         // tau~ - (h kd + h^2 kp) qdd; where that exceeds the effort limit the drive becomes a constant torque at the limit
         // (no implicit terms) and the phases run once more (rare; when either env of the pair needs it -- the partner repeats
@@ -1046,7 +981,7 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
             __syncthreads();
         }
 
-        PSTAMP(3);
+        PSTAMP(3); PACC(2);
         // ============================================================ 4. down pass: joint accelerations, v_free
         const int pd4 = sh_pd[bb];
         for (int lev = 1; lev <= d.max_depth; ++lev) {
@@ -1094,35 +1029,27 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
         }
         __syncthreads();
 
-        PSTAMP(4);
-        // ============================================================ 5 - 6b: one env at a time, one env wide
-        // What the joint tree passes of phase 7 need from the contact phases stays in the lanes of the env's half: the impulse each
-        // body collects from its contact rows (pin, phase 7a), the env's contact count and deepest contact level.
+        PSTAMP(4); PACC(3);
+        // ============================================================ 5 - 7a: the contact phases
+        // What the joint tree passes of phase 7 need from here stays in the lanes of the env's half: the impulse each body collects
+        // from its contact rows (pin, phase 7a), the env's contact count and deepest contact level.
         float pin[6] = {0, 0, 0, 0, 0, 0};
         int my_nc = 0, my_dmax = 0;
-        // what phases 5-6b of an env leave for the joint sweeps: its matrix row, residual start, multiplier, contact count
-        PgsRow G0, G1;
-        // (two inlined copies, not a loop of two: a loop would carry both envs' rows -- 144 registers -- through every phase of its body)
-        auto contact_front = [&](const int e, PgsRow &G) __attribute__((always_inline)) {
-            const int env = e ? env1 : env0;
-            if (env < 0) { pgs_clear(G); return; }
-            ENV_VIEW(lds + e * PW, lds + (e ? O_B1 : O_B0), lds + (e ? O_AA1 : O_AA0), lds + (e ? O_IA1 : O_IA0))
-            const float *mdl = d.model + (size_t)env * EMLOCO_MODEL_WORDS;
-            const float *lws_env = d.lambda_ws + (size_t)env * MAXCAND * 3;
-            float (*const sh_cdir)[9] = (float (*)[9])(lds + O_CDIR + e * 9 * MAXC);   // contact frames [normal | tangent 1 | tangent 2] (height-field ground)
-            const bool mine = half == e;                          // this lane's half carries env e's bodies in the joint phases
-
-            // ======================================================== 5. ground-contact candidates (lane = candidate)
-            // two candidates per lane (`lane`, `lane + 64`); their body-frame points are re-derived from the model each
-            // substep (L2 hits) rather than held in registers across the launch.  What a candidate leaves for the contact list --
-            // its contact point and, on a height field, the ground normal there -- waits in LDS instead of 12 registers per lane
-            // across the ballots
-            float *sh_stage = lds + O_STAGE;                       // [MAXCAND][7]
-            int cb[2]; float cdist[2]; bool act[2];
-            for (int s = 0; s < 2; ++s) {
-                const int c = lane + 64 * s;
+        const bool live = my_env >= 0;
+        // ============================================================ 5. ground-contact candidates of BOTH envs (lane = 32 env + candidate mod 32)
+        // three candidates per lane (`b`, `b + 32`, `b + 64`); their body-frame points are re-derived from the model each substep
+        // (L2 hits).  What a candidate leaves for the contact list -- its contact point and, on a height field, the ground normal there --
+        // waits in LDS instead of registers across the ballots.
+        float *const sh_stage = lds + O_STAGE + half * (MAXCAND * 7);                               // [MAXCAND][7] per env
+        float (*const sh_cdir)[9] = (float (*)[9])(lds + O_CDIR + half * 9 * MAXC);               // contact frames (height-field ground)
+        int nc = 0;
+        {
+            const float *lws_m = d.lambda_ws + (size_t)senv * MAXCAND * 3;
+            int cb[3]; float cdist[3]; bool act[3];
+            for (int s = 0; s < 3; ++s) {
+                const int c = b + 32 * s;
                 cb[s] = -1; act[s] = false; cdist[s] = 0.0f;
-                if (c < d.n_cand) {
+                if (live && c < d.n_cand) {
                     const int cp = topo[EMLOCO_TOPO_CAND + c], body = cp & 0xff, k = (cp >> 8) & 0xff, gt = cp >> 16;
                     float ga[4], gb[4], clp[3];                      // geom a xyz, radius | geom b xyz
                     ld4(mdl, EMLOCO_MB_GEO + body * 8, ga); ld4(mdl, EMLOCO_MB_GEO + body * 8 + 4, gb);
@@ -1181,31 +1108,32 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
                     act[s] = cdist[s] < prm.contact_offset;
                 }
             }
-            unsigned long long m0 = __ballot(act[0]), m1 = __ballot(act[1]);
-            int nc = __popcll(m0) + __popcll(m1);
-            while (nc > MAXC) {   // rare: drop the shallowest candidate (largest dist; ties -> highest candidate id)
+            unsigned mh[3];                                           // the half's candidate masks
+            for (int s = 0; s < 3; ++s) mh[s] = half_bits(__ballot(act[s]), half);
+            nc = (int)(__popc(mh[0]) + __popc(mh[1]) + __popc(mh[2]));
+            while (__ballot(nc > MAXC) != 0ull) {   // rare: drop the shallowest candidate (largest dist; ties -> highest candidate id) of the env(s) over the limit
                 float best = -3.0e38f; int bid = -1;
-                for (int s = 0; s < 2; ++s)
-                    if (act[s] && (cdist[s] > best || (cdist[s] == best && lane + 64 * s > bid))) { best = cdist[s]; bid = lane + 64 * s; }
-                for (int off = 32; off >= 1; off >>= 1) {
+                if (nc > MAXC)
+                    for (int s = 0; s < 3; ++s)
+                        if (act[s] && (cdist[s] > best || (cdist[s] == best && b + 32 * s > bid))) { best = cdist[s]; bid = b + 32 * s; }
+                for (int off = 16; off >= 1; off >>= 1) {            // within the half
                     const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bid, off);
                     if (ob > best || (ob == best && oi > bid)) { best = ob; bid = oi; }
                 }
-                if (bid == lane) act[0] = false;
-                if (bid == lane + 64) act[1] = false;
-                m0 = __ballot(act[0]); m1 = __ballot(act[1]);
-                nc = __popcll(m0) + __popcll(m1);
+                if (nc > MAXC) for (int s = 0; s < 3; ++s) if (bid == b + 32 * s) act[s] = false;
+                for (int s = 0; s < 3; ++s) mh[s] = half_bits(__ballot(act[s]), half);
+                nc = (int)(__popc(mh[0]) + __popc(mh[1]) + __popc(mh[2]));
             }
             // Warm start: the multipliers a candidate carried at the end of the previous substep (from the previous launch for
             // substep 0).  Every lane first fetches the old values of its own candidates -- old slot map and old multipliers are
             // still in place -- then, behind a barrier, the new contact list, its slot map and the warm values are written.
-            float wl[2][3];
-            for (int s = 0; s < 2; ++s) {
+            float wl[3][3];
+            for (int s = 0; s < 3; ++s) {
                 wl[s][0] = wl[s][1] = wl[s][2] = 0.0f;
-                const int c = lane + 64 * s;
+                const int c = b + 32 * s;
                 if (act[s]) {
                     if (sub == 0) {
-                        for (int k = 0; k < 3; ++k) wl[s][k] = lws_env[c * 3 + k];
+                        for (int k = 0; k < 3; ++k) wl[s][k] = lws_m[c * 3 + k];
                     } else {
                         const int os = sh_slot[c];
                         if (os != 255) for (int k = 0; k < 3; ++k) wl[s][k] = sh_lam[3 * os + k];
@@ -1213,14 +1141,14 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
                 }
             }
             __syncthreads();
-            {
-                const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-                const int i0 = __popcll(m0 & below), i1 = __popcll(m0) + __popcll(m1 & below);
-                for (int s = 0; s < 2; ++s) {
-                    const int ci = s == 0 ? i0 : i1;
-                    sh_slot[lane + 64 * s] = act[s] ? (unsigned char)ci : (unsigned char)255;
+            if (live) {
+                const unsigned below = (1u << b) - 1u;
+                const int base[3] = {0, (int)__popc(mh[0]), (int)(__popc(mh[0]) + __popc(mh[1]))};
+                for (int s = 0; s < 3; ++s) {
+                    const int c = b + 32 * s, ci = base[s] + (int)__popc(mh[s] & below);
+                    sh_slot[c] = act[s] ? (unsigned char)ci : (unsigned char)255;
                     if (act[s]) {
-                        const float *stg = sh_stage + (lane + 64 * s) * 7;      // this lane's own entry: no other lane touches it
+                        const float *stg = sh_stage + c * 7;              // this lane's own entry: no other lane touches it
                         sh_cbody[ci] = (unsigned char)cb[s]; sh_cdist[ci] = cdist[s];
                         for (int k = 0; k < 3; ++k) { sh_cx[ci][k] = stg[k]; sh_lam[3 * ci + k] = wl[s][k]; }
                         if (hf_on) {      // frame: normal, t1 = (y x n) / |y x n|, t2 = n x t1
@@ -1244,29 +1172,35 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
                 }
             }
             __syncthreads();
-            const int nr = 3 * nc;
-            if (mine) work += nc > 0 ? 10 + nc : 0;
+        }
+        if (live) work += nc > 0 ? 10 + nc : 0;
+        my_nc = nc;
+        const int nc0 = __builtin_amdgcn_readlane(nc, 0), nc1 = __builtin_amdgcn_readlane(nc, 32);      // wave-uniform
+        PSTAMP(5); PACC(4);
 
-            PSTAMP(e ? 14 : 5);
-            // ======================================================== 6a. rows: Jacobian, rhs, chain propagation (lane = row)
+        if (nc0 <= PAIR_FAST_MAXC && nc1 <= PAIR_FAST_MAXC) {
+            // ======================================================== FAST PATH (86 % of the env-substeps of the bench workload have <= 10
+            // contacts, profiles/r06_contact_histogram.txt): an env's <= 30 rows fit the 32 lanes of its half, so the row phases run
+            // for BOTH envs at once too -- lane = 32 env + row -- and a pair's substep costs about what one env's did.
+            constexpr int FR = 3 * PAIR_FAST_MAXC;                   // rows per env on this path
+            const int nr = 3 * nc;                                    // (uniform within a half)
+            // ---------------------------------------------------- 6a. rows: Jacobian, rhs, chain propagation
             float J[6] = {0, 0, 0, 0, 0, 0}, rhs = 0.0f, lam = 0.0f;
-            float ys[YLEN];                                   // this row's chain-propagation vector (level-indexed); entries beyond the
-                                                              // row's own chain are never written NOR read
-            // contacts come out of the compaction sorted by body (the candidate list is body-major): first / last contact of a body
-            if (lane < NB) { sh_crange[lane] = 0; sh_crange[NB + lane] = -1; }
+            float ys[YLEN];
+            if (b < NB) { sh_crange[b] = 0; sh_crange[NB + b] = -1; }
             __syncthreads();
-            if (lane < nc) {
-                const int cb_ = sh_cbody[lane];
-                if (lane == 0 || sh_cbody[lane - 1] != cb_) sh_crange[cb_] = (signed char)lane;
-                if (lane == nc - 1 || sh_cbody[lane + 1] != cb_) sh_crange[NB + cb_] = (signed char)lane;
+            if (b < nc) {
+                const int cb_ = sh_cbody[b];
+                if (b == 0 || sh_cbody[b - 1] != cb_) sh_crange[cb_] = (signed char)b;
+                if (b == nc - 1 || sh_cbody[b + 1] != cb_) sh_crange[NB + cb_] = (signed char)b;
             }
-            const int myc = lane / 3, myd = lane - 3 * myc;
+            const int myc = b / 3, myd = b - 3 * myc;
             int rbody = 0, rdep = 0;
             unsigned code = 0u;
             float p[6] = {0, 0, 0, 0, 0, 0};
-            if (lane < nr) {
+            float dir[3] = {myd == 1 ? 1.0f : 0.0f, myd == 2 ? 1.0f : 0.0f, myd == 0 ? 1.0f : 0.0f};
+            if (b < nr) {
                 rbody = sh_cbody[myc];
-                float dir[3] = {myd == 1 ? 1.0f : 0.0f, myd == 2 ? 1.0f : 0.0f, myd == 0 ? 1.0f : 0.0f};
                 if (hf_on) for (int k = 0; k < 3; ++k) dir[k] = sh_cdir[myc][3 * myd + k];
                 float x[3] = {sh_cx[myc][0], sh_cx[myc][1], sh_cx[myc][2]};
                 cross3(x, dir, J);
@@ -1284,18 +1218,17 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
                 for (int k = 0; k < 6; ++k) p[k] = -J[k];
                 rdep = PD_DEPTH(sh_pd[rbody]);
             }
-            // chain propagation, one tree level per (statically unrolled) step from the deepest level up: a row takes part from the
-            // level of its own body on; `ci` is its chain body at the current level.  The level index is static, so ys[] stays in
-            // registers; levels below every contact body are skipped wave-uniformly.
             int rdmax = rdep;
-            for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(rdmax, off); rdmax = o > rdmax ? o : rdmax; }
-            const int dmax = __builtin_amdgcn_readfirstlane(rdmax);              // deepest chain among the contact bodies
+            for (int off = 16; off >= 1; off >>= 1) { const int o = __shfl_xor(rdmax, off); rdmax = o > rdmax ? o : rdmax; }   // within the half
+            my_dmax = rdmax;                                         // deepest chain among the env's contact bodies
+            const int dm0 = __builtin_amdgcn_readlane(rdmax, 0), dm1 = __builtin_amdgcn_readlane(rdmax, 32);
+            const int dmax = dm0 > dm1 ? dm0 : dm1;                  // wave-uniform bound of the level loops
             {
                 int ci = rbody;
 #pragma unroll
                 for (int lev = 7; lev >= 0; --lev) {
                     if (lev < dmax) {
-                        if (lane < nr && lev < rdep) {
+                        if (b < nr && lev < rdep) {
                             const int i = ci;
                             float Ri[9], ri[3], u[3], uhh[3];
                             for (int k = 0; k < 9; ++k) Ri[k] = sh_R[i][k];
@@ -1317,48 +1250,33 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
                     }
                 }
             }
-            if (lane < nr) {
+            if (b < nr) {
                 for (int a = 0; a < 6; ++a) {   // L0 y = p
                     float acc = p[a];
                     for (int k = 0; k < a; ++k) acc = fmaf(-sh_L0[a * 6 + k], ys[k], acc);
                     ys[a] = acc * sh_L0i[a];
                 }
-                lam = prm.warm * sh_lam[lane];
+                lam = prm.warm * sh_lam[b];
             }
             __syncthreads();
-
-            PSTAMP(e ? 15 : 6);
-            // ======================================================== 6b. contact matrix A = Y Y^T on the matrix cores
-            // A[r][s] = <y_r, y_s> over the common-ancestor prefix (6 root entries + 3 per shared tree level): the sum, in ascending
-            // level order, of the level blocks of the chain bodies that BOTH rows have on their chains.  One v_mfma_f32_32x32x2_f32
-            // chain per 32 x 32 tile -- bit-equal to the fmaf chain in ascending k (measured: tools/exp/mfma_exact.hip): the root
-            // block for all pairs, then per tree level one masked block per chain body present at that level, with the operands of
-            // the rows that do not pass through that body set to zero.  A pair gets its non-zero terms exactly from the bodies it
-            // shares (every other term adds an exact zero), so the accumulator IS the prefix sum.  Operands: lanes 0-31 feed
-            // k = 2s, lanes 32-63 k = 2s+1; v_permlane32_swap hands both over in one instruction.  The 3-wide level blocks are padded
-            // with one 0*0 step.
-            // Round 6: ALL FOUR tiles (0,0) (1,0) (0,1) (1,1) advance in one pass over the steps -- four independent accumulator
-            // chains behind one operand swap and one ballot / readlane group walk -- and the matrix never reaches LDS: a lane of the
-            // accumulator layout holds 16 rows of ONE column per tile, the matrix is symmetric, so after 32 v_permlane32_swap
-            // (lane i <-> lane i + 32) every lane s holds row s complete -- columns 0-31 from tiles (0,0) | (0,1), columns 32-63
-            // from (1,0) | (1,1) -- in registers the (unrolled) sweeps index statically.
+            PSTAMP(6); PACC(5);
+            // ---------------------------------------------------- 6b. both contact matrices in one pass: env 0 = tile (0,0), env 1 = tile (1,1)
+            // The operand swap hands lanes 0-31 env 0's rows (k even | odd) and lanes 32-63 env 1's: acc0 += Y0 Y0^T, acc1 += Y1 Y1^T.
+            // The masked level blocks walk the chain bodies of BOTH envs together (one group of each per step; an env that has
+            // run out of groups at a level adds exact zeros).  Rows to registers as in the full-size path: 16 swaps.
+            float A[32];
             {
                 typedef float sim_f32x16 __attribute__((vector_size(64)));
-                const int own_dep = (lane < nr) ? rdep : -1;   // -1: no row in this lane (all operands zero)
+                const int own_dep = (b < nr) ? rdep : -1;        // -1: no row in this lane (all operands zero)
                 const bool has_row = own_dep >= 0;
-                const bool big = nr > 32;                      // wave-uniform: rows beyond the first tile
-                sim_f32x16 acc00, acc10, acc01, acc11;
-                for (int r = 0; r < 16; ++r) { acc00[r] = 0.0f; acc10[r] = 0.0f; acc01[r] = 0.0f; acc11[r] = 0.0f; }
+                sim_f32x16 acc0, acc1;
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
 #define GRAM_STEP(V0, V1)                                                                                              \
                 {                                                                                                      \
                     const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(V0), __float_as_uint(V1), false, false); \
                     const float op0_ = __uint_as_float(sw_[0]), op1_ = __uint_as_float(sw_[1]);                        \
-                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(op0_, op0_, acc00, 0, 0, 0);                          \
-                    if (big) {                                                                                         \
-                        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(op1_, op0_, acc10, 0, 0, 0);                      \
-                        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(op0_, op1_, acc01, 0, 0, 0);                      \
-                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(op1_, op1_, acc11, 0, 0, 0);                      \
-                    }                                                                                                  \
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(op0_, op0_, acc0, 0, 0, 0);                            \
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(op1_, op1_, acc1, 0, 0, 0);                            \
                 }
                 GRAM_STEP(has_row ? ys[0] : 0.0f, has_row ? ys[1] : 0.0f) GRAM_STEP(has_row ? ys[2] : 0.0f, has_row ? ys[3] : 0.0f)
                 GRAM_STEP(has_row ? ys[4] : 0.0f, has_row ? ys[5] : 0.0f)
@@ -1369,142 +1287,391 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
                         const int gid = (lev < own_dep) ? (int)((code >> (3 * lev)) & 7u) : 0;
                         unsigned long long rem = __ballot(gid != 0);
                         while (rem != 0ull) {
-                            const int first = __builtin_ctzll(rem);
-                            const int g = __builtin_amdgcn_readlane(gid, first);
-                            const bool in_g = gid == g;
+                            const unsigned lo = (unsigned)rem, hi = (unsigned)(rem >> 32);
+                            const int g0 = lo ? __builtin_amdgcn_readlane(gid, __builtin_ctz(lo)) : 0;
+                            const int g1 = hi ? __builtin_amdgcn_readlane(gid, 32 + __builtin_ctz(hi)) : 0;
+                            const bool in_g = gid != 0 && gid == (half ? g1 : g0);
                             GRAM_STEP(in_g ? ys[6 + 3 * lev] : 0.0f, in_g ? ys[7 + 3 * lev] : 0.0f) GRAM_STEP(in_g ? ys[8 + 3 * lev] : 0.0f, 0.0f)
                             rem &= ~__ballot(in_g);
                         }
                     }
                 }
 #undef GRAM_STEP
-                // lane (j, hh) holds column 32 tc + j, rows 32 tr + (r & 3) + 8 (r >> 2) + 4 hh of tile (tr, tc); after the swaps lane s
-                // holds of ITS row s the columns (r & 3) + 8 (r >> 2) [first result] and + 4 [second result]
-                float Arow[64];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int c0 = (r & 3) + 8 * (r >> 2);
-                    const auto lo = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc00[r]), __float_as_uint(acc01[r]), false, false);
-                    Arow[c0] = __uint_as_float(lo[0]); Arow[c0 + 4] = __uint_as_float(lo[1]);
-                    const auto hi = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc10[r]), __float_as_uint(acc11[r]), false, false);
-                    Arow[32 + c0] = __uint_as_float(hi[0]); Arow[32 + c0 + 4] = __uint_as_float(hi[1]);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[r]), __float_as_uint(acc1[r]), false, false);
+                    A[c0] = __uint_as_float(sw[0]); A[c0 + 4] = __uint_as_float(sw[1]);
                 }
-                pgs_take(G, Arow, rhs, lam, nc);
             }
-            if (mine) { my_nc = nc; my_dmax = dmax; }
-            __syncthreads();                                       // the candidate staging is reused by the partner env
-            if (e == 0) PSTAMP(13);
-        };
-        contact_front(0, G0);
-        contact_front(1, G1);
-
-        PSTAMP(7);
-        // ============================================================ 6c. projected Gauss-Seidel, BOTH envs in one instruction stream
-        // Lane s owns row s of each env: its multiplier, the running residual w_s = rhs_s + sum_r A_sr lam_r, 1/(A_ss (1+cfm)) and
-        // (round 6) the row itself in registers.  A row update happens in lane rr alone; its change is broadcast with one v_readlane
-        // and every lane folds it into w with one fma through column rr of the symmetric matrix -- no wave reduction in the loop.
-        // The sweeps resolve a contact inside ONE lane, the lane of its normal row (the leader): it holds the three multipliers of
-        // the contact, the reciprocal diagonals and the sub-diagonal of its 3 x 3 block, fetches the residuals of its two tangent
-        // rows and walks normal -> tangent 1 -> tangent 2 -> friction cone on its own, forming the intermediate residuals exactly
-        // as the rows' own lanes will; the three changes (and the two of a cone projection) are then broadcast and every lane
-        // folds them into its w in the same order.  Same operations per value as the row-by-row sweep (the oracle's).
-        // A sweep is a chain of dependent instructions (~25 per contact) that one wave issues at a fraction of the SIMD's rate;
-        // contact c of env 0 and contact c of env 1 are two INDEPENDENT chains in one basic block, which the scheduler interleaves:
-        // the pair's sweeps cost about what one env's did.
-        {
-            const int ncmax = G0.nc > G1.nc ? G0.nc : G1.nc;
-            const int myd = lane - 3 * (lane / 3);
-            pgs_begin(G0, lane, myd); pgs_begin(G1, lane, myd);
+            PSTAMP(7); PACC(6);
+            // ---------------------------------------------------- 6c. projected Gauss-Seidel, both envs in lock step (lane 32 e + s holds row s of env e)
+            // The leader-lane sweep of the full-size path; a broadcast from row r is one v_readlane per half and a select.
+            const int lb = 32 * half;
+#define HB(x, r) (half ? lane_bcast((x), 32 + (r)) : lane_bcast((x), (r)))
+            const int ncmax = nc0 > nc1 ? nc0 : nc1;
+            const int lr0 = (b < nr) ? b - myd : 0;                  // first row of this lane's contact (idle lanes shadow row 0)
+            float w = rhs;
+            float gl0 = __shfl(lam, lb + lr0), gl1 = __shfl(lam, lb + lr0 + 1), gl2 = __shfl(lam, lb + lr0 + 2);
+            float diag = 1.0f, gA10 = 0.0f, gA20 = 0.0f, gA21 = 0.0f;
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c)
-                if (c < ncmax) { pgs_warm(G0, c, lane); pgs_warm(G1, c, lane); }
-            pgs_ready(G0, lane, myd, prm.cfm); pgs_ready(G1, lane, myd, prm.cfm);
-            PSTAMP(11);
+            for (int c = 0; c < PAIR_FAST_MAXC; ++c)
+                if (c < ncmax) {                                     // warm start (rows beyond an env's own carry zero multipliers: skipped)
+                    const int r0 = 3 * c;
+                    const float a0 = A[r0], a1 = A[r0 + 1], a2 = A[r0 + 2];
+                    const float l0 = HB(lam, r0), l1 = HB(lam, r0 + 1), l2 = HB(lam, r0 + 2);
+                    const float u0 = fmaf(a0, l0, w);
+                    w = (l0 != 0.0f) ? u0 : w;
+                    const float u1 = fmaf(a1, l1, w);
+                    w = (l1 != 0.0f) ? u1 : w;
+                    const float u2 = fmaf(a2, l2, w);
+                    w = (l2 != 0.0f) ? u2 : w;
+                    diag = b == r0 ? a0 : (b == r0 + 1 ? a1 : (b == r0 + 2 ? a2 : diag));
+                    const float t21 = HB(a2, r0 + 1);                // A[r0 + 1][r0 + 2]
+                    if (b == r0) { gA10 = a1; gA20 = a2; gA21 = t21; }
+                }
+            const float ainv = (b < nr) ? 1.0f / (diag * (1.0f + prm.cfm)) : 0.0f;
+            const float gi1 = __shfl(ainv, lb + lr0 + 1), gi2 = __shfl(ainv, lb + lr0 + 2);
+            PSTAMP(11); PACC(7);
             for (int it = 0; it < prm.n_iter; ++it) {
 #pragma unroll
-                for (int c = 0; c < MAXC; ++c)
+                for (int c = 0; c < PAIR_FAST_MAXC; ++c)
                     if (c < ncmax) {
-                        PgsTmp T0, T1;
-                        pgs_step(G0, T0, c, lane, prm.mu);
-                        pgs_step(G1, T1, c, lane, prm.mu);
-                        if (__builtin_expect((T0.cone | T1.cone) != 0ull, 0)) {       // wave-uniform: a contact outside its friction cone
-                            if (T0.cone != 0ull) pgs_cone(G0, T0, c, lane);
-                            if (T1.cone != 0ull) pgs_cone(G1, T1, c, lane);
+                        const int r0 = 3 * c;
+                        const bool act = c < nc;                     // (uniform within a half)
+                        const float a0 = A[r0], a1 = A[r0 + 1], a2 = A[r0 + 2];
+                        const float w1s = HB(w, r0 + 1), w2s = HB(w, r0 + 2);
+                        // branch-free: every lane runs the leader's chain on its own contact's values, only row r0's results are read
+                        float nl0 = fmaf(-w, ainv, gl0);
+                        if (nl0 < 0.0f) nl0 = 0.0f;
+                        const float d0 = nl0 - gl0;
+                        const float w1 = fmaf(gA10, d0, w1s);
+                        const float nl1 = fmaf(-w1, gi1, gl1);
+                        const float d1 = nl1 - gl1;
+                        const float w2 = fmaf(gA21, d1, fmaf(gA20, d0, w2s));
+                        const float nl2 = fmaf(-w2, gi2, gl2);
+                        const float d2 = nl2 - gl2;
+                        const bool me = act && b == r0;
+                        gl0 = me ? nl0 : gl0; gl1 = me ? nl1 : gl1; gl2 = me ? nl2 : gl2;
+                        const float lim = prm.mu * nl0;
+                        const float m2 = fmaf(nl1, nl1, nl2 * nl2);
+                        float wn = fmaf(a0, HB(d0, r0), w);
+                        wn = fmaf(a1, HB(d1, r0), wn);
+                        wn = fmaf(a2, HB(d2, r0), wn);
+                        w = act ? wn : w;
+                        const bool out = me && m2 > lim * lim;
+                        const unsigned long long cone = __ballot(out);
+                        if (__builtin_expect(cone != 0ull, 0)) {     // wave-uniform: a contact outside its friction cone (in either env)
+                            const bool mine_out = half_bits(cone, half) != 0u;
+                            const float sc = lim / sqrtf(m2);
+                            const float n1 = nl1 * sc, n2 = nl2 * sc;
+                            gl1 = out ? n1 : gl1; gl2 = out ? n2 : gl2;
+                            const float e1 = HB(n1 - nl1, r0), e2 = HB(n2 - nl2, r0);
+                            const float wc = fmaf(a2, e2, fmaf(a1, e1, w));
+                            w = mine_out ? wc : w;
                         }
                     }
                 if (it == 0) PSTAMP(12);
             }
-        }
-
-        PSTAMP(8);
-        // ============================================================ 7a. impulses: what each body collects from its contact rows (one env at a time)
-#pragma nounroll
-        for (int e = 0; e < 2; ++e) {
-            const int env = e ? env1 : env0;
-            if (env < 0) continue;
-            ENV_VIEW(lds + e * PW, lds + (e ? O_B1 : O_B0), lds + (e ? O_AA1 : O_AA0), lds + (e ? O_IA1 : O_IA0))
-            float *cf_env = d.contact_force + (size_t)env * NB * 3;
-            float (*const sh_cdir)[9] = (float (*)[9])(lds + O_CDIR + e * 9 * MAXC);
-            const bool mine = half == e;
-            const int nc = e ? G1.nc : G0.nc, nr = 3 * nc;
-            const int myc = lane / 3, myd = lane - 3 * myc;
-            const bool leader = lane < nr && myd == 0;
-            const float g0 = e ? G1.gl0 : G0.gl0, g1 = e ? G1.gl1 : G0.gl1, g2 = e ? G1.gl2 : G0.gl2;
-            if (leader) { sh_lam[lane] = g0; sh_lam[lane + 1] = g1; sh_lam[lane + 2] = g2; }
-            else if (lane >= nr && lane < MAXR) sh_lam[lane] = 0.0f;
+#undef HB
+            if (b < nr && myd == 0) { sh_lam[b] = gl0; sh_lam[b + 1] = gl1; sh_lam[b + 2] = gl2; }
+            else if (b >= nr) sh_lam[b] = 0.0f;
+            if (b + 32 < MAXR) sh_lam[b + 32] = 0.0f;                 // (nr <= 30: the rows beyond the half hold no contact)
             __syncthreads();
-            const float lam = (lane < nr) ? sh_lam[lane] : 0.0f;
-            if ((lane < NB) && last && nc == 0)
-                for (int k = 0; k < 3; ++k) cf_env[lane * 3 + k] = 0.0f;
-            float dir[3] = {myd == 1 ? 1.0f : 0.0f, myd == 2 ? 1.0f : 0.0f, myd == 0 ? 1.0f : 0.0f};
-            if (hf_on && lane < nr) for (int k = 0; k < 3; ++k) dir[k] = sh_cdir[myc][3 * myd + k];
-            if (nc > 0) {
-                // every row's lane stages its Jacobian row (and, in the last substep, its share of the reported contact force)
-                // in LDS (the B blocks: dead by now); a body then adds up its rows in contact order with one fma chain -- in the
-                // lane that carries the body in the joint phases (lanes 32 e + body)
-                float (*sh_row)[12] = (float (*)[12])(lds + O_ROWS);
-                if (lane < nr) {
-                    const float x[3] = {sh_cx[myc][0], sh_cx[myc][1], sh_cx[myc][2]};
-                    float Jr[3];
-                    cross3(x, dir, Jr);
-                    for (int k = 0; k < 3; ++k) { sh_row[lane][k] = Jr[k]; sh_row[lane][3 + k] = dir[k]; }
-                    if (last) for (int k = 0; k < 3; ++k) sh_row[lane][6 + k] = dir[k] * lam / h;
+            lam = (b < nr) ? sh_lam[b] : 0.0f;
+            PSTAMP(8); PACC(8);
+            // ---------------------------------------------------- 7a. impulses: what each body collects from its contact rows
+            float *cf_m = d.contact_force + (size_t)senv * NB * 3;
+            if (live && b < NB && last && nc == 0)
+                for (int k = 0; k < 3; ++k) cf_m[b * 3 + k] = 0.0f;
+            float (*sh_row)[12] = (float (*)[12])(lds + O_ROWS + half * (32 * 12));
+            if (b < nr) {
+                const float x[3] = {sh_cx[myc][0], sh_cx[myc][1], sh_cx[myc][2]};
+                float Jr[3];
+                cross3(x, dir, Jr);
+                for (int k = 0; k < 3; ++k) { sh_row[b][k] = Jr[k]; sh_row[b][3 + k] = dir[k]; }
+                if (last) for (int k = 0; k < 3; ++k) sh_row[b][6 + k] = dir[k] * lam / h;
+            }
+            __syncthreads();
+            if (live && b < NB && nc > 0) {
+                float cf[3] = {0, 0, 0};
+                const int r_end = 3 * sh_crange[NB + b] + 3;
+                for (int r = 3 * sh_crange[b]; r < r_end; ++r) {
+                    const float l = sh_lam[r];
+                    for (int k = 0; k < 6; ++k) pin[k] = fmaf(-sh_row[r][k], l, pin[k]);
+                    if (last) for (int k = 0; k < 3; ++k) cf[k] += sh_row[r][6 + k];
                 }
-                __syncthreads();
-                if (mine && b < NB) {
-                    float cf[3] = {0, 0, 0};
-                    const int r_end = 3 * sh_crange[NB + b] + 3;
-                    for (int r = 3 * sh_crange[b]; r < r_end; ++r) {
-                        const float l = sh_lam[r];
-                        for (int k = 0; k < 6; ++k) pin[k] = fmaf(-sh_row[r][k], l, pin[k]);
-                        if (last) for (int k = 0; k < 3; ++k) cf[k] += sh_row[r][6 + k];
-                    }
-                    if (last) for (int k = 0; k < 3; ++k) cf_env[b * 3 + k] = cf[k];
-                }
+                if (last) for (int k = 0; k < 3; ++k) cf_m[b * 3 + k] = cf[k];
             }
             {   // momentum the system must have after this substep: gravity and the contact impulses are the only external ones
-                float imp[3] = {0.0f, 0.0f, 0.0f};
-                if (nc > 0) for (int k = 0; k < 3; ++k) imp[k] = wave_sum(lane < nr ? dir[k] * lam : 0.0f);
-                if (lane == 0) {
-                    for (int k = 0; k < 3; ++k) sh_P[k] = sh_P[3 + k] + imp[k];
+                float imp[3];
+                for (int k = 0; k < 3; ++k) imp[k] = half_sum(b < nr ? dir[k] * lam : 0.0f, half);
+                if (live && b == 0) {
+                    for (int k = 0; k < 3; ++k) sh_P[k] = sh_P[3 + k] + (nc > 0 ? imp[k] : 0.0f);
                     sh_P[2] = fmaf(sh_P[6] * prm.gravity_z, h, sh_P[2]);
                 }
             }
             {   // angular momentum about the centre of mass after this substep: the moments of the contact impulses, then the damping
-                const float damp = 1.0f / (1.0f + h * prm.ang_damping);
-                float tq[3] = {0.0f, 0.0f, 0.0f};
-                if (nc > 0) {
-                    float t[3] = {0.0f, 0.0f, 0.0f};
-                    if (lane < nr) {
-                        float arm[3], ip[3];
-                        for (int k = 0; k < 3; ++k) { arm[k] = sh_cx[myc][k] - sh_L[8 + k]; ip[k] = dir[k] * lam; }
-                        cross3(arm, ip, t);
-                    }
-                    for (int k = 0; k < 3; ++k) tq[k] = wave_sum(t[k]);
+                const float damp_ = 1.0f / (1.0f + h * prm.ang_damping);
+                float t[3] = {0.0f, 0.0f, 0.0f}, tq[3];
+                if (b < nr) {
+                    float arm[3], ip[3];
+                    for (int k = 0; k < 3; ++k) { arm[k] = sh_cx[myc][k] - sh_L[8 + k]; ip[k] = dir[k] * lam; }
+                    cross3(arm, ip, t);
                 }
-                if (lane == 0) for (int k = 0; k < 3; ++k) sh_L[k] = (sh_L[4 + k] + tq[k]) * damp;
+                for (int k = 0; k < 3; ++k) tq[k] = half_sum(t[k], half);
+                if (live && b == 0) for (int k = 0; k < 3; ++k) sh_L[k] = (sh_L[4 + k] + (nc > 0 ? tq[k] : 0.0f)) * damp_;
             }
-            __syncthreads();                                       // the staged rows are reused by the partner env / phase 7
+            __syncthreads();
+            PACC(9);
+        } else {
+            // ======================================================== FULL-SIZE PATH: an env with more than 10 contacts needs the whole wave for
+            // its rows; the two envs go one after the other (a loop of two, not unrolled), the matrix in LDS as the packed lower triangle
+#pragma nounroll
+            for (int e = 0; e < 2; ++e) {
+                const int env = e ? env1 : env0;
+                if (env < 0) continue;
+                ENV_VIEW(lds + e * PW, lds + (e ? O_B1 : O_B0), lds + (e ? O_AA1 : O_AA0), lds + (e ? O_IA1 : O_IA0))
+                float *cf_env = d.contact_force + (size_t)env * NB * 3;
+                float *const sh_A = lds + (e ? O_B1 : O_B0);           // contact matrix, lower triangle: (r, s<=r) at r(r+1)/2 + s
+                float (*const sh_cdir)[9] = (float (*)[9])(lds + O_CDIR + e * 9 * MAXC);
+                const bool mine = half == e;                          // this lane's half carries env e's bodies in the joint phases
+                const int nc = e ? nc1 : nc0, nr = 3 * nc;
+                // ------------------------------------------------ 6a. rows: Jacobian, rhs, chain propagation (lane = row)
+                float J[6] = {0, 0, 0, 0, 0, 0}, rhs = 0.0f, lam = 0.0f;
+                float ys[YLEN];
+                if (lane < NB) { sh_crange[lane] = 0; sh_crange[NB + lane] = -1; }
+                __syncthreads();
+                if (lane < nc) {
+                    const int cb_ = sh_cbody[lane];
+                    if (lane == 0 || sh_cbody[lane - 1] != cb_) sh_crange[cb_] = (signed char)lane;
+                    if (lane == nc - 1 || sh_cbody[lane + 1] != cb_) sh_crange[NB + cb_] = (signed char)lane;
+                }
+                const int myc = lane / 3, myd = lane - 3 * myc;
+                int rbody = 0, rdep = 0;
+                unsigned code = 0u;
+                float p[6] = {0, 0, 0, 0, 0, 0};
+                float dir[3] = {myd == 1 ? 1.0f : 0.0f, myd == 2 ? 1.0f : 0.0f, myd == 0 ? 1.0f : 0.0f};
+                if (lane < nr) {
+                    rbody = sh_cbody[myc];
+                    if (hf_on) for (int k = 0; k < 3; ++k) dir[k] = sh_cdir[myc][3 * myd + k];
+                    float x[3] = {sh_cx[myc][0], sh_cx[myc][1], sh_cx[myc][2]};
+                    cross3(x, dir, J);
+                    J[3] = dir[0]; J[4] = dir[1]; J[5] = dir[2];
+                    float Vb[6];
+                    for (int k = 0; k < 6; ++k) Vb[k] = sh_V[rbody][k];                  // v_free (end of phase 4)
+                    const float vel = dot6(J, Vb);
+                    float bias = 0.0f;
+                    if (myd == 0) {
+                        const float dist = sh_cdist[myc];
+                        if (dist > 0.0f) bias = dist / h;
+                        else { bias = prm.erp * dist / h; if (bias < -prm.max_depen_vel) bias = -prm.max_depen_vel; }
+                    }
+                    rhs = vel + bias;
+                    for (int k = 0; k < 6; ++k) p[k] = -J[k];
+                    rdep = PD_DEPTH(sh_pd[rbody]);
+                }
+                int rdmax = rdep;
+                for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(rdmax, off); rdmax = o > rdmax ? o : rdmax; }
+                const int dmax = __builtin_amdgcn_readfirstlane(rdmax);              // deepest chain among the contact bodies
+                if (mine) my_dmax = dmax;
+                {
+                    int ci = rbody;
+#pragma unroll
+                    for (int lev = 7; lev >= 0; --lev) {
+                        if (lev < dmax) {
+                            if (lane < nr && lev < rdep) {
+                                const int i = ci;
+                                float Ri[9], ri[3], u[3], uhh[3];
+                                for (int k = 0; k < 9; ++k) Ri[k] = sh_R[i][k];
+                                for (int k = 0; k < 3; ++k) ri[k] = sh_R[i][9 + k];
+                                for (int a = 0; a < 3; ++a) {
+                                    float ax[3] = {Ri[a], Ri[3 + a], Ri[6 + a]}, sl[3];
+                                    cross3(ri, ax, sl);
+                                    const float Sa[6] = {ax[0], ax[1], ax[2], sl[0], sl[1], sl[2]};
+                                    u[a] = -dot6(Sa, p);
+                                }
+                                const float *W = sh_W[i], *K = W + 18;
+                                uhh[0] = K[0] * u[0]; uhh[1] = SOP2(K[1], u[0], K[2], u[1]); uhh[2] = SOP3(K[3], u[0], K[4], u[1], K[5], u[2]);
+                                const int pdi = sh_pd[i];
+                                code |= (unsigned)(PD_SLOT(pdi) + 1) << (3 * lev);
+                                ys[6 + 3 * lev] = uhh[0]; ys[6 + 3 * lev + 1] = uhh[1]; ys[6 + 3 * lev + 2] = uhh[2];
+                                for (int k = 0; k < 6; ++k) p[k] = ADD_SOP3(p[k], W[k * 3], uhh[0], W[k * 3 + 1], uhh[1], W[k * 3 + 2], uhh[2]);
+                                ci = PD_PARENT(pdi);
+                            }
+                        }
+                    }
+                }
+                if (lane < nr) {
+                    for (int a = 0; a < 6; ++a) {   // L0 y = p
+                        float acc = p[a];
+                        for (int k = 0; k < a; ++k) acc = fmaf(-sh_L0[a * 6 + k], ys[k], acc);
+                        ys[a] = acc * sh_L0i[a];
+                    }
+                    lam = prm.warm * sh_lam[lane];
+                }
+                __syncthreads();
+                // ------------------------------------------------ 6b. contact matrix: the three tiles in one pass, to LDS
+                {
+                    typedef float sim_f32x16 __attribute__((vector_size(64)));
+                    const int hh = lane >> 5, j31 = lane & 31;
+                    const int own_dep = (lane < nr) ? rdep : -1;   // -1: no row in this lane (all operands zero)
+                    const bool has_row = own_dep >= 0;
+                    const bool big = nr > 32;                      // wave-uniform: rows beyond the first tile
+                    sim_f32x16 acc00, acc10, acc11;
+                    for (int r = 0; r < 16; ++r) { acc00[r] = 0.0f; acc10[r] = 0.0f; acc11[r] = 0.0f; }
+#define GRAM_STEP(V0, V1)                                                                                              \
+                    {                                                                                                      \
+                        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(V0), __float_as_uint(V1), false, false); \
+                        const float op0_ = __uint_as_float(sw_[0]), op1_ = __uint_as_float(sw_[1]);                        \
+                        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(op0_, op0_, acc00, 0, 0, 0);                          \
+                        if (big) {                                                                                         \
+                            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(op1_, op0_, acc10, 0, 0, 0);                      \
+                            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(op1_, op1_, acc11, 0, 0, 0);                      \
+                        }                                                                                                  \
+                    }
+                    GRAM_STEP(has_row ? ys[0] : 0.0f, has_row ? ys[1] : 0.0f) GRAM_STEP(has_row ? ys[2] : 0.0f, has_row ? ys[3] : 0.0f)
+                    GRAM_STEP(has_row ? ys[4] : 0.0f, has_row ? ys[5] : 0.0f)
+#pragma unroll
+                    for (int lev = 0; lev < 8; ++lev) {
+                        if (lev < dmax) {                               // wave-uniform
+                            const int gid = (lev < own_dep) ? (int)((code >> (3 * lev)) & 7u) : 0;
+                            unsigned long long rem = __ballot(gid != 0);
+                            while (rem != 0ull) {
+                                const int first = __builtin_ctzll(rem);
+                                const int g = __builtin_amdgcn_readlane(gid, first);
+                                const bool in_g = gid == g;
+                                GRAM_STEP(in_g ? ys[6 + 3 * lev] : 0.0f, in_g ? ys[7 + 3 * lev] : 0.0f) GRAM_STEP(in_g ? ys[8 + 3 * lev] : 0.0f, 0.0f)
+                                rem &= ~__ballot(in_g);
+                            }
+                        }
+                    }
+#undef GRAM_STEP
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        if (row < nr && j31 <= row) sh_A[row * (row + 1) / 2 + j31] = acc00[r];
+                        if (big) {
+                            const int row1 = 32 + row;
+                            if (row1 < nr) sh_A[row1 * (row1 + 1) / 2 + j31] = acc10[r];
+                            if (row1 < nr && 32 + j31 <= row1) sh_A[row1 * (row1 + 1) / 2 + 32 + j31] = acc11[r];
+                        }
+                    }
+                }
+                __syncthreads();
+                // ------------------------------------------------ 6c. projected Gauss-Seidel (lane s holds lambda_s), leader-lane sweep
+                const int ls = lane < nr ? lane : 0;                      // idle lanes shadow lane 0 (their w is never used)
+                const int tri_s = ls * (ls + 1) / 2;
+                const float ainv = (lane < nr) ? 1.0f / (sh_A[tri_s + ls] * (1.0f + prm.cfm)) : 0.0f;
+#define A_OF(rr) sh_A[tri_index(ls, (rr))]
+                float w = rhs;
+                {                                                          // warm start (matrix entries read one contact ahead)
+                    float n0 = 0.0f, n1a = 0.0f, n2a = 0.0f;
+                    if (nc > 0) { n0 = A_OF(0); n1a = A_OF(1); n2a = A_OF(2); }
+                    for (int c = 0; c < nc; ++c) {
+                        const int r0 = 3 * c;
+                        const float a0 = n0, a1 = n1a, a2 = n2a;
+                        if (c + 1 < nc) { n0 = A_OF(r0 + 3); n1a = A_OF(r0 + 4); n2a = A_OF(r0 + 5); }
+                        const float l0 = lane_bcast(lam, r0), l1 = lane_bcast(lam, r0 + 1), l2 = lane_bcast(lam, r0 + 2);
+                        const float u0 = fmaf(a0, l0, w);
+                        w = (l0 != 0.0f) ? u0 : w;
+                        const float u1 = fmaf(a1, l1, w);
+                        w = (l1 != 0.0f) ? u1 : w;
+                        const float u2 = fmaf(a2, l2, w);
+                        w = (l2 != 0.0f) ? u2 : w;
+                    }
+                }
+                const int lr0 = ls - (lane < nr ? myd : 0);               // first row of this lane's contact
+                float gl0 = __shfl(lam, lr0), gl1 = __shfl(lam, lr0 + 1), gl2 = __shfl(lam, lr0 + 2);
+                const float gi1 = __shfl(ainv, lr0 + 1), gi2 = __shfl(ainv, lr0 + 2);
+                const float gA10 = sh_A[tri_index(lr0 + 1, lr0)], gA20 = sh_A[tri_index(lr0 + 2, lr0)], gA21 = sh_A[tri_index(lr0 + 2, lr0 + 1)];
+                const bool leader = lane < nr && myd == 0;
+                for (int it = 0; it < prm.n_iter; ++it) {
+                    float n0 = 0.0f, n1a = 0.0f, n2a = 0.0f;
+                    if (nc > 0) { n0 = A_OF(0); n1a = A_OF(1); n2a = A_OF(2); }
+                    for (int c = 0; c < nc; ++c) {
+                        const int r0 = 3 * c;
+                        const float a0 = n0, a1 = n1a, a2 = n2a;
+                        if (c + 1 < nc) { n0 = A_OF(r0 + 3); n1a = A_OF(r0 + 4); n2a = A_OF(r0 + 5); }
+                        const float w1s = lane_bcast(w, r0 + 1), w2s = lane_bcast(w, r0 + 2);
+                        float nl0 = fmaf(-w, ainv, gl0);
+                        if (nl0 < 0.0f) nl0 = 0.0f;
+                        const float d0 = nl0 - gl0;
+                        const float w1 = fmaf(gA10, d0, w1s);
+                        const float nl1 = fmaf(-w1, gi1, gl1);
+                        const float d1 = nl1 - gl1;
+                        const float w2 = fmaf(gA21, d1, fmaf(gA20, d0, w2s));
+                        const float nl2 = fmaf(-w2, gi2, gl2);
+                        const float d2 = nl2 - gl2;
+                        const bool me = lane == r0;
+                        gl0 = me ? nl0 : gl0; gl1 = me ? nl1 : gl1; gl2 = me ? nl2 : gl2;
+                        const float lim = prm.mu * nl0;
+                        const float m2 = fmaf(nl1, nl1, nl2 * nl2);
+                        w = fmaf(a0, lane_bcast(d0, r0), w);
+                        w = fmaf(a1, lane_bcast(d1, r0), w);
+                        w = fmaf(a2, lane_bcast(d2, r0), w);
+                        if (__builtin_expect(__ballot(me && m2 > lim * lim) != 0ull, 0)) {   // wave-uniform: outside the friction cone
+                            const float sc = lim / sqrtf(m2);
+                            const float n1 = nl1 * sc, n2 = nl2 * sc;
+                            gl1 = me ? n1 : gl1; gl2 = me ? n2 : gl2;
+                            w = fmaf(a1, lane_bcast(n1 - nl1, r0), w);
+                            w = fmaf(a2, lane_bcast(n2 - nl2, r0), w);
+                        }
+                    }
+                }
+#undef A_OF
+                if (leader) { sh_lam[lane] = gl0; sh_lam[lane + 1] = gl1; sh_lam[lane + 2] = gl2; }
+                else if (lane >= nr && lane < MAXR) sh_lam[lane] = 0.0f;
+                __syncthreads();
+                lam = (lane < nr) ? sh_lam[lane] : 0.0f;
+                // ------------------------------------------------ 7a. impulses: what each body collects from its contact rows
+                if ((lane < NB) && last && nc == 0)
+                    for (int k = 0; k < 3; ++k) cf_env[lane * 3 + k] = 0.0f;
+                if (nc > 0) {
+                    float (*sh_row)[12] = (float (*)[12])sh_A;        // (the matrix's place: dead by now)
+                    if (lane < nr) {
+                        const float x[3] = {sh_cx[myc][0], sh_cx[myc][1], sh_cx[myc][2]};
+                        float Jr[3];
+                        cross3(x, dir, Jr);
+                        for (int k = 0; k < 3; ++k) { sh_row[lane][k] = Jr[k]; sh_row[lane][3 + k] = dir[k]; }
+                        if (last) for (int k = 0; k < 3; ++k) sh_row[lane][6 + k] = dir[k] * lam / h;
+                    }
+                    __syncthreads();
+                    if (mine && b < NB) {
+                        float cf[3] = {0, 0, 0};
+                        const int r_end = 3 * sh_crange[NB + b] + 3;
+                        for (int r = 3 * sh_crange[b]; r < r_end; ++r) {
+                            const float l = sh_lam[r];
+                            for (int k = 0; k < 6; ++k) pin[k] = fmaf(-sh_row[r][k], l, pin[k]);
+                            if (last) for (int k = 0; k < 3; ++k) cf[k] += sh_row[r][6 + k];
+                        }
+                        if (last) for (int k = 0; k < 3; ++k) cf_env[b * 3 + k] = cf[k];
+                    }
+                }
+                {   // momentum the system must have after this substep
+                    float imp[3] = {0.0f, 0.0f, 0.0f};
+                    if (nc > 0) for (int k = 0; k < 3; ++k) imp[k] = wave_sum(lane < nr ? dir[k] * lam : 0.0f);
+                    if (lane == 0) {
+                        for (int k = 0; k < 3; ++k) sh_P[k] = sh_P[3 + k] + imp[k];
+                        sh_P[2] = fmaf(sh_P[6] * prm.gravity_z, h, sh_P[2]);
+                    }
+                }
+                {   // angular momentum about the centre of mass after this substep
+                    const float damp_ = 1.0f / (1.0f + h * prm.ang_damping);
+                    float tq[3] = {0.0f, 0.0f, 0.0f};
+                    if (nc > 0) {
+                        float t[3] = {0.0f, 0.0f, 0.0f};
+                        if (lane < nr) {
+                            float arm[3], ip[3];
+                            for (int k = 0; k < 3; ++k) { arm[k] = sh_cx[myc][k] - sh_L[8 + k]; ip[k] = dir[k] * lam; }
+                            cross3(arm, ip, t);
+                        }
+                        for (int k = 0; k < 3; ++k) tq[k] = wave_sum(t[k]);
+                    }
+                    if (lane == 0) for (int k = 0; k < 3; ++k) sh_L[k] = (sh_L[4 + k] + tq[k]) * damp_;
+                }
+                __syncthreads();                                       // the matrix's place is reused by the partner env / phase 7
+            }
+            PACC(10);
         }
 
         // ============================================================ 7. impulses -> velocity change (second solve): tree passes, both envs
@@ -1590,7 +1757,7 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
             }
         }
         const float damp = 1.0f / (1.0f + h * prm.ang_damping);
-        PSTAMP(9);
+        PSTAMP(9); PACC(11);
         // ============================================================ 8. integrate (both envs)
         bool clamped = false;       // a rate clamped to max_ang_vel changes the angular momentum in a way the balance does not predict: it is skipped once
         if (on && b >= 1) {
@@ -1643,7 +1810,7 @@ __device__ __forceinline__ void sim_step_pair(const EmlocoSimParams &prm, const 
             if (on && b == 0) sh_L[3] = any_clamped ? 0.0f : 1.0f;
         }
         __syncthreads();
-        PSTAMP(10);
+        PSTAMP(10); PACC(12);
     }
 
     if (part < n_parts - 1) {         // hand over to the next part (see above) and publish

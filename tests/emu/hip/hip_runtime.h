@@ -63,6 +63,7 @@ static inline unsigned long long __ballot(int pred) {
     return m;
 }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline unsigned long long wall_clock64() { return 0ull; }
 static inline void __threadfence() {}
 static inline void __builtin_amdgcn_s_sleep(int) {}

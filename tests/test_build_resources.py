@@ -53,6 +53,10 @@ def test_hot_kernels_stay_inside_their_register_and_scratch_budgets():
     # the rigid-body kernel on plane ground (the headline's): 3 waves per SIMD, nothing in scratch
     for k, r in pick("sim_step_kernelILi0").items():
         assert r["ScratchSize"] == 0 and r["Occupancy"] >= 3 and r["VGPRs"] <= 168, (k, r)
+    # the height-field instantiation (terrain configs; mesh_plane / mesh_walls are __noinline__ calls with their own frames): three waves per
+    # SIMD as well, and its scratch stays where round 5 left it (480 B per lane then, 496 with round 6's one-pass contact-matrix tiles)
+    for k, r in pick("sim_step_kernelILi1").items():
+        assert r["Occupancy"] >= 3 and r["VGPRs"] <= 168 and r["ScratchSize"] <= 512, (k, r)
     # split-mode GEMMs: three workgroups per CU (168 registers, 50.7 KB of LDS), accumulators in registers
     for sub in ("gemm_split_kernel", "gemm_split_img_kernel", "gemm_split_relu_bwd_kernel", "gemm_split_relu_bwd_img_kernel"):
         for k, r in pick(sub).items():

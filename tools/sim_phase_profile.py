@@ -29,6 +29,19 @@ lib.emloco_sim_profile(sim._h, buf, 256)
 t = np.array(buf[:], dtype=np.int64).reshape(16, 16)
 n_sub = 4
 print(f"E={E}: ticks (100 MHz) per phase, substeps 0..{n_sub-1}")
+if "--pair-all" in sys.argv:      # segment times summed over ALL pairs since the buffer was cleared (PACC in sim_pair_kernels.hip)
+    names = ["1 kinematics + 1b (joint)", "2 drive (joint)", "2b-3 inertia, factorise (joint)", "4 down pass (joint)", "5 candidates (joint)",
+             "fast: 6a rows / chain y", "fast: 6b matrices -> registers", "fast: 6c setup + warm start", "fast: 6c sweeps", "fast: 7a impulses",
+             "full-size path: 6a-7a, both envs", "7 tree passes (joint)", "8 integrate (joint)"]
+    tt, cnt = np.array(buf[128:128 + 13], dtype=np.float64), np.array(buf[160:160 + 13], dtype=np.float64)
+    n_pairsub = cnt[0]
+    print(f"pair-substeps profiled: {int(n_pairsub)}; fast path {int(cnt[9])} ({cnt[9] / max(n_pairsub, 1):.3f}), full-size path {int(cnt[10])}")
+    print("segment: mean ticks (10 ns) when it runs | share of all pair-substep time")
+    for i, nm in enumerate(names):
+        if cnt[i] > 0:
+            print(f"  {nm:36s} {tt[i] / cnt[i]:8.1f}   {tt[i] / tt.sum():6.3f}")
+    print(f"  mean pair-substep: {tt.sum() / max(n_pairsub, 1):.1f} ticks")
+    sys.exit(0)
 def row(name, a, b):
     print(f"  {name:34s} " + " ".join(f"{int(t[s, b] - t[s, a]):6d}" for s in range(n_sub)))
 if "--pair" not in sys.argv:        # sim_kernels.hip (one env per wave)
