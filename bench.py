@@ -35,7 +35,7 @@ import emloco_amd  # noqa: E402
 emloco_amd.configure_runtime()   # ahead of the first GPU call: 16 hardware queues for the side streams / graph arms (emloco_amd/__init__.py)
 
 SIM_BYTES_PER_ENV = 9296          # state in/out + per-env model (+ collision capsules) + warm-start, per launch
-PROFILE_ROUND = "r05"             # profiles/<round>_*: the committed rocprofv3 summaries of this round's kernels
+PROFILE_ROUND = "r06"             # profiles/<round>_*: the committed rocprofv3 summaries of this round's kernels
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16), no sparsity
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)

@@ -608,6 +608,9 @@ class AMPAgent:
             f32 = [k for k, buf in self._g_in.items() if buf.dtype == torch.float32 and self.dataset[k].is_contiguous()]
             ppo_heads.gather_rows(idx, [self.dataset[k] for k in f32], [self._g_in[k] for k in f32])
             rest = [k for k in self._g_in if k not in f32]
+            if os.environ.get("EMLOCO_PPO_DEBUG") and not getattr(self, "_dbg_fill", False):
+                self._dbg_fill = True
+                print("graph_fill: fused gather", f32, "| index_select", rest, "|", {k: (tuple(v.shape), v.dtype, v.is_contiguous()) for k, v in self.dataset.items() if v is not None}, flush=True)
         else:
             rest = list(self._g_in)
         for k in rest:
