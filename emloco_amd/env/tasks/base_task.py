@@ -57,6 +57,9 @@ class BaseTask():
     def step(self, actions):                                   # base_task.py:245-265
         self.pre_physics_step(actions)
         self._physics_step()
+        cb = getattr(self, "after_physics_launch", None)       # (a rollout loop's hook: host work to issue WHILE the rigid-body launch
+        if cb is not None:                                      # runs -- side-stream launches that want to start under it)
+            cb()
         self.gym.fetch_results(self.sim, True)
         self.post_physics_step()
 

@@ -192,6 +192,7 @@ class LocoValRollout:
         # `disc_reward_staged` on the object `disc_reward` is bound to: AMPPolicyBundle) and the task's returns hook.
         owner = getattr(self.disc_reward, "__self__", None)
         self._disc_halves = None
+        self._disc_after_launch = False
         if (not self._no_disc and self._side is not None and hasattr(task, "attach_returns") and hasattr(owner, "disc_stage")
                 and hasattr(owner, "disc_reward_staged") and getattr(task, "fused_chain", False)
                 and os.environ.get("EMLOCO_DEFER_DISC", "1") != "0"):
@@ -214,6 +215,14 @@ class LocoValRollout:
             from .. import hw_queues                       # what the runtime was initialised with (None: unknown -> the 4-queue order)
             self._disc_under_physics = dup == "1" or (dup == "auto" and (hw_queues() or 4) >= 16)
             self._disc_pending = False
+            # Round 6 experiment: WHERE in the host's sequence the side stream's ~15 launches are issued.  Ahead of the rigid-body launch
+            # (round 4; default) there is a 64 us hole on the main stream between the policy's last launch and the PD-target launch
+            # (profiles/r06_env_step_trace_disc.txt); issued right BEHIND the rigid-body launch (EMLOCO_DISC_AFTER_LAUNCH=1: the task's
+            # `after_physics_launch` hook; the event they wait for is still recorded ahead of it) the step is no faster: 0.873-0.878
+            # against 0.865-0.876 ms, three interleaved runs each (tools/exp/c2_after_launch.py) -- the hole is not the host's issue time.
+            self._disc_after_launch = (self._disc_under_physics and os.environ.get("EMLOCO_DISC_AFTER_LAUNCH", "0") == "1")
+            if self._disc_after_launch:
+                task.after_physics_launch = self._issue_deferred_disc
             for i, st_ in enumerate(self._stage):          # the staged reward / done flag travel with the set
                 st_["staged_reward"] = f(E)
                 st_["staged_done"] = torch.zeros(E, dtype=torch.uint8, device=dev)
@@ -436,8 +445,9 @@ class LocoValRollout:
             return
         self._disc_pending = False
         _stage, finish = self._disc_halves
-        main = torch.cuda.current_stream(self.device)
-        self._ev_staged.record(main)
+        if not getattr(self, "_disc_event_recorded", False):   # (issued behind the rigid-body launch: `_before_step` recorded it AHEAD of the launch)
+            self._ev_staged.record(torch.cuda.current_stream(self.device))
+        self._disc_event_recorded = False
         self._side.wait_event(self._ev_staged)
         with torch.cuda.stream(self._side):
             amp_rewards = finish().contiguous()
@@ -457,12 +467,16 @@ class LocoValRollout:
             self._flush_fits()
         if getattr(self, "_returns_in_flags", False) and hasattr(self.task, "attach_returns"):
             self.task.attach_returns(None)
+        if getattr(self, "_disc_after_launch", False):
+            self.task.after_physics_launch = None
         if getattr(self, "_amp_ring", False):
             self.task.enable_amp_ring(False)
 
     def attach(self):
         if getattr(self, "_returns_in_flags", False) and hasattr(self.task, "attach_returns"):
             self.task.attach_returns(self._fstep, before=self._before_flags)
+        if getattr(self, "_disc_after_launch", False):
+            self.task.after_physics_launch = self._issue_deferred_disc
         if getattr(self, "_amp_ring", False):
             self.task.enable_amp_ring(True)
 
@@ -479,7 +493,13 @@ class LocoValRollout:
         if not getattr(self, "_returns_in_flags", False) or not self.fused:
             return
         if self._disc_halves is not None:
-            self._issue_deferred_disc()                     # the previous step's discriminator half, beside this step's rigid-body launch
+            if not self._disc_after_launch:
+                self._issue_deferred_disc()                 # the previous step's discriminator half, beside this step's rigid-body launch
+            elif getattr(self, "_disc_pending", False):
+                # its launches follow BEHIND the rigid-body launch (`after_physics_launch`); what they wait for -- the staged operand -- is
+                # marked here, ahead of the launch: an event behind it would make the side stream wait for the rigid-body kernel
+                self._ev_staged.record(torch.cuda.current_stream(self.device))
+                self._disc_event_recorded = True
         self._check_fused_inputs()
         self._fstep.inversion_penalty = float(self.inversion_penalty_scale)
 
