@@ -134,10 +134,31 @@ def amp_dropout_mask(B, steps, feat, num_masks=3, dropout_rate=0.3, device="cpu"
 _AMP_COL = {}
 
 
-def disc_forward_with_grad_penalty(net, amp_obs_demo, input_mask=None):
+def disc_first_layer(net):
+    """The discriminator's first Linear and its weight with the input width padded to a multiple of four (the AMP observation is 3 090
+    wide; the 16-byte-load GEMM kernels want 3 092): ONE pad per optimiser step, shared by every evaluation of the step (ops.linear pads x
+    and W per call otherwise -- two fill + copy pairs per evaluation)."""
+    lin0 = next(m for m in net._disc_mlp if isinstance(m, nn.Linear))
+    pad = (-lin0.in_features) % 4
+    Wp = torch.nn.functional.pad(lin0.weight, (0, pad)) if pad else lin0.weight
+    return lin0, Wp
+
+
+def disc_eval_padded(net, xp, first):
+    """net.eval_disc on an input that is already padded to the first layer's padded width (pad columns zero)."""
+    lin0, Wp = first
+    lin = [m for m in net._disc_mlp if isinstance(m, nn.Linear)]
+    h = ops.linear(xp, Wp, lin0.bias, relu=True)
+    for m in lin[1:]:
+        h = ops.linear(h, m.weight, m.bias, relu=True)
+    return ops.linear(h, net._disc_logits.weight, net._disc_logits.bias)
+
+
+def disc_forward_with_grad_penalty(net, amp_obs_demo, input_mask=None, padded=None):
     """Discriminator logits on the demo batch and mean |dD/dx|^2 (amp_continuous.py:560-583) with the input gradient
-    written as an explicit network (see module docstring).  `input_mask` is the AMP dropout mask applied to the input."""
-    x = amp_obs_demo if input_mask is None else amp_obs_demo * input_mask
+    written as an explicit network (see module docstring).  `input_mask` is the AMP dropout mask applied to the input.
+    padded = (first, xp): the step's padded first-layer weight (`disc_first_layer`) and a zero-padded buffer xp (B, K + pad) the masked
+    input is written into -- no per-call padding of the operands."""
     acts = [m for m in net._disc_mlp if not isinstance(m, nn.Linear)]
     if any(not isinstance(m, nn.ReLU) for m in acts):
         # the explicit gradient network below is the ReLU one (the shipped config, amp_humanoid_smpl_sept_task.yaml: disc
@@ -145,15 +166,28 @@ def disc_forward_with_grad_penalty(net, amp_obs_demo, input_mask=None):
         raise NotImplementedError("disc_forward_with_grad_penalty: the discriminator activation must be relu, got "
                                   + ", ".join(sorted({type(m).__name__ for m in acts})))
     lin = [m for m in net._disc_mlp if isinstance(m, nn.Linear)]
+    K = lin[0].in_features
+    if padded is not None:
+        (lin0, Wp), xp = padded
+        if input_mask is None:
+            xp[:, :K].copy_(amp_obs_demo)
+        else:
+            torch.mul(amp_obs_demo, input_mask, out=xp[:, :K])
+        x, W0 = xp, Wp
+    else:
+        x = amp_obs_demo if input_mask is None else amp_obs_demo * input_mask
+        W0 = lin[0].weight
     hs, h = [], x
-    for m in lin:
-        h = ops.linear(h, m.weight, m.bias, relu=True)
+    for i, m in enumerate(lin):
+        h = ops.linear(h, W0 if i == 0 else m.weight, m.bias, relu=True)
         hs.append(h)
     logits = ops.linear(h, net._disc_logits.weight, net._disc_logits.bias)
-    g = (hs[-1] > 0).float() * net._disc_logits.weight                       # (B, units[-1])
+    g = ops.relu_mask(net._disc_logits.weight.expand_as(hs[-1]), hs[-1])     # (B, units[-1])
     for i in range(len(lin) - 1, 0, -1):
-        g = (hs[i - 1] > 0).float() * ops.linear(g, lin[i].weight.t())
-    gx = ops.linear(g, lin[0].weight.t())
+        g = ops.relu_mask(ops.linear(g, lin[i].weight.t()), hs[i - 1])
+    gx = ops.linear(g, W0.t())
+    if padded is not None:
+        gx = gx[:, :K]                                       # (the pad columns are exact zeros: W0's pad columns are)
     if input_mask is not None:
         gx = gx * input_mask
     return logits, torch.mean(torch.sum(torch.square(gx), dim=-1))
@@ -236,6 +270,10 @@ class AMPAgent:
         # on the actor's and on the critic's stream) and not the discriminator (weight decay, logit regulariser and the gradient-penalty
         # network reach its weights through autograd's accumulation, which runs on a stream of its own choosing).
         self._stack_actor = os.environ.get("EMLOCO_PPO_STACK_ACTOR", "1") != "0"
+        # (the discriminator's operands born padded -- persistent zero-padded input buffers, one weight pad per step: measured, no gain
+        # with the arms graph (3.46-3.53 against 3.40-3.48 ms; the one-chain graph 4.43 -> 4.37): the discriminator's arm is not the
+        # critical one.  Off unless EMLOCO_PPO_DISC_PADDED=1)
+        self._disc_padded = os.environ.get("EMLOCO_PPO_DISC_PADDED", "0") == "1"
         if self.device.type == "cuda" and os.environ.get("EMLOCO_PPO_DIRECT_GRAD", "1") != "0" and (self._stack_actor or not self.motion_sym_loss):
             from ..predictor import ops as _ops
             net_ = self.a2c_network
@@ -463,9 +501,27 @@ class AMPAgent:
             amp_demo = self._preproc_amp_obs(d["amp_obs_demo"][0:n_amp])
             m = (lambda i: dropout_masks[..., i]) if dropout_masks is not None else (lambda i: None)
             mul = lambda x, k: x if k is None else x * k
-            # (agent and replay rows through the discriminator as ONE stacked batch: row-wise network, the loss wants them stacked anyway)
-            disc_agent_replay_logit = net.eval_disc(torch.cat([mul(amp_obs, m(0)), mul(amp_replay, m(1))], dim=0))
-            disc_demo_logit, grad_pen = disc_forward_with_grad_penalty(net, amp_demo, m(2))
+            K_amp = amp_obs.shape[1]
+            if amp_obs.is_cuda and K_amp % 4 and self._disc_padded:
+                # (round 6) the discriminator's operands are BORN padded: persistent zero-padded buffers the masked rows are written into
+                # (agent | replay stacked, demo), the first layer's weight padded once per step -- was: F.pad of x and of W inside every
+                # ops.linear call on the 3 090-wide input, and a torch.cat for the stacking
+                Kp = K_amp + (-K_amp) % 4
+                if getattr(self, "_disc_xs", None) is None or self._disc_xs.shape != (2 * n_amp, Kp) or self._disc_xs.device != amp_obs.device:
+                    self._disc_xs = torch.zeros(2 * n_amp, Kp, device=amp_obs.device)
+                    self._disc_xd = torch.zeros(n_amp, Kp, device=amp_obs.device)
+                xs, first = self._disc_xs, disc_first_layer(net)
+                for rows, src, k in ((xs[:n_amp, :K_amp], amp_obs, m(0)), (xs[n_amp:, :K_amp], amp_replay, m(1))):
+                    if k is None:
+                        rows.copy_(src)
+                    else:
+                        torch.mul(src, k, out=rows)
+                disc_agent_replay_logit = disc_eval_padded(net, xs, first)
+                disc_demo_logit, grad_pen = disc_forward_with_grad_penalty(net, amp_demo, m(2), padded=(first, self._disc_xd))
+            else:
+                # (agent and replay rows through the discriminator as ONE stacked batch: row-wise network, the loss wants them stacked anyway)
+                disc_agent_replay_logit = net.eval_disc(torch.cat([mul(amp_obs, m(0)), mul(amp_replay, m(1))], dim=0))
+                disc_demo_logit, grad_pen = disc_forward_with_grad_penalty(net, amp_demo, m(2))
             disc_info = self._disc_loss(disc_agent_replay_logit, disc_demo_logit, grad_pen)
         obs = self._preproc_obs(d["obs"])
         if branch_streams is not None:

@@ -272,6 +272,35 @@ class LinearFn(torch.autograd.Function):
         return dx, dW, db, None, None, None, None
 
 
+class ReluMaskFn(torch.autograd.Function):
+    """t * [h > 0] in ONE launch each way (`emloco_act_bwd` used as a forward op): the ReLU derivative of the explicit gradient network of
+    the discriminator's gradient penalty (learning/amp_agent.py), which torch writes as compare + cast + multiply.  No gradient reaches h
+    (the mask is piecewise constant), as with the torch expression."""
+
+    @staticmethod
+    def forward(ctx, t, h):
+        t2, h2 = t.contiguous(), h.contiguous()
+        out = torch.empty_like(t2)
+        _chk(_lib().emloco_act_bwd(t2.numel(), _p(t2), _p(h2), 1, 0.0, 0, _p(out), _st(t2)), "emloco_act_bwd")
+        ctx.save_for_backward(h2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h2,) = ctx.saved_tensors
+        d2 = dy.contiguous()
+        out = torch.empty_like(d2)
+        _chk(_lib().emloco_act_bwd(d2.numel(), _p(d2), _p(h2), 1, 0.0, 0, _p(out), _st(d2)), "emloco_act_bwd")
+        return out, None
+
+
+def relu_mask(t, h):
+    """t where h > 0, else 0 (same shapes, fp32, CUDA: one launch; otherwise the torch expression)."""
+    if t.is_cuda and t.dtype == torch.float32 and h.dtype == torch.float32 and t.shape == h.shape:
+        return ReluMaskFn.apply(t, h)
+    return (h > 0).to(t.dtype) * t
+
+
 def mark_direct_grad(params, on=True):
     """Weights whose gradient `LinearFn.backward` may accumulate directly into `.grad` (GEMM epilogue, C += ...) instead of returning it
     to autograd.  The caller vouches that (1) `.grad` exists and is zeroed before every backward (FlatGradBucket) and (2) every use of
