@@ -227,6 +227,66 @@ def test_amp_ppo_losses_match_plain_torch_double_backward():
     assert abs(info["disc_grad_penalty"].item() - gx.pow(2).sum(-1).mean().item()) <= 1e-4 * gx.pow(2).sum(-1).mean().item()
 
 
+def test_round6_step_variants_agree(monkeypatch):
+    """Round 6's forms of the optimiser step's loss -- one stacked actor evaluation, weight gradients written straight into the flat bucket,
+    the discriminator's operands born padded (an AMP width that is NOT a multiple of four, like the shipped 3 090), the one-launch
+    ReLU-mask op of the gradient-penalty network -- give the loss and every gradient of the reference-shaped step (three actor evaluations,
+    autograd's accumulation, F.pad per call) on the same weights and minibatch."""
+    import math
+    from emloco_amd.learning import amp_agent as A
+    from emloco_amd.predictor import ops
+
+    class Task(_FakeTask):
+        def get_num_amp_obs(self): return 2 * 207                           # 414: not a multiple of four (two steps of a 207-wide row)
+        def fetch_amp_obs_demo(self, n): return torch.randn(n, 414, device=self.device)
+
+    def make(stack, direct, padded):
+        import yaml
+        from emloco_amd.learning.amp_policy import DEFAULT_CFG
+        monkeypatch.setenv("EMLOCO_PPO_STACK_ACTOR", stack); monkeypatch.setenv("EMLOCO_PPO_DIRECT_GRAD", direct); monkeypatch.setenv("EMLOCO_PPO_DISC_PADDED", padded)
+        cfg = yaml.safe_load(open(DEFAULT_CFG))
+        cfg["params"]["network"]["mlp"]["units"] = [96, 48]
+        cfg["params"]["network"]["task_mlp"]["units"] = [64, 32]
+        cfg["params"]["network"]["disc"]["units"] = [80, 40]
+        cfg["params"]["config"].update(horizon_length=4, minibatch_size=16, amp_minibatch_size=16, amp_batch_size=32, amp_obs_demo_buffer_size=64,
+                                       amp_replay_buffer_size=64, mini_epochs=1)
+        return A.AMPAgent(Task(8), cfg)
+
+    ref_agent = make("0", "0", "0")
+    new_agent = make("1", "1", "1")
+    new_agent.a2c_network.load_state_dict(ref_agent.a2c_network.state_dict())
+    assert any(getattr(p_, "_emloco_direct_grad", False) for p_ in new_agent.a2c_network.parameters())
+    assert not any(getattr(p_, "_emloco_direct_grad", False) for p_ in ref_agent.a2c_network.parameters())
+    torch.manual_seed(3)
+    B = 16
+    d = {"obs": torch.randn(B, 1422, device=DEV), "flip_obs": torch.randn(B, 1422, device=DEV), "next_obses": torch.randn(B, 1422, device=DEV),
+         "actions": torch.randn(B, 69, device=DEV) * 0.3, "old_logp_actions": torch.randn(B, device=DEV) * 0.1 + 30,
+         "advantages": torch.randn(B, device=DEV), "old_values": torch.randn(B, 1, device=DEV), "returns": torch.randn(B, 1, device=DEV),
+         "mu": torch.randn(B, 69, device=DEV) * 0.1, "sigma": torch.full((B, 69), math.exp(-2.9), device=DEV),
+         "amp_obs": torch.randn(B, 414, device=DEV), "amp_obs_replay": torch.randn(B, 414, device=DEV), "amp_obs_demo": torch.randn(B, 414, device=DEV)}
+    masks = (torch.rand(B, 414, 3, device=DEV) > 0.3).float()
+    out = []
+    for ag in (ref_agent, new_agent):
+        ag.set_eval()
+        loss, info, mu, sigma = ag.compute_loss(d, dropout_masks=masks)
+        ag.bucket.zero()
+        loss.backward()
+        out.append((loss.item(), {k: v.item() for k, v in info.items()}, {k: p_.grad.clone() for k, p_ in ag.a2c_network.named_parameters() if p_.requires_grad}))
+    (l0, i0, g0), (l1, i1, g1) = out
+    assert abs(l0 - l1) <= 2e-5 * abs(l0), (l0, l1)
+    for k in i0:
+        assert abs(i0[k] - i1[k]) <= 1e-4 * max(abs(i0[k]), 1e-3), (k, i0[k], i1[k])
+    for k in g0:
+        _close(g1[k].cpu(), g0[k].cpu(), rel=2e-4, abs_=1e-6, what=f"grad {k}")
+    # the ReLU-mask op against its torch expression, value and gradient
+    t = torch.randn(33, 40, device=DEV, requires_grad=True)
+    hh = torch.randn(33, 40, device=DEV)
+    y = ops.relu_mask(t, hh)
+    assert torch.equal(y, (hh > 0).float() * t)
+    (gt,) = torch.autograd.grad(y.sum() * 2.0, t)
+    assert torch.equal(gt, (hh > 0).float() * 2.0)
+
+
 def test_running_mean_std_training_update_matches_the_reference_class():
     """RunningMeanStd in training mode on the device (normalise with the old moments, then emloco_rms_update) against the
     reference's own class over four batches incl. freeze_partial (tests/golden/gen_golden_rms.py): outputs and moments to 2e-6 (the reference takes

@@ -197,3 +197,26 @@ def test_package_import_leaves_the_environment_alone_and_entry_points_opt_in():
     # the benchmark and the smoke entry opt in
     for f in ("bench.py", "__graft_entry__.py", os.path.join("emloco_amd", "run.py")):
         assert "configure_runtime()" in open(os.path.join(root, f)).read(), f
+
+
+def test_bench_summary_is_a_compact_digest_of_every_leg():
+    """bench.summary_of: the numbers of every leg, no notes -- printed as the LAST key of the line (configs[2] was outside
+    the tail of stdout the driver keeps)."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    src = open(os.path.join(root, "bench.py")).read()
+    assert src.index('out["summary"] = summary_of(out)') < src.index("print(json.dumps(out))")
+    ns = {}
+    start = src.index("def summary_of(out):")
+    exec(src[start:src.index("def main():")], ns)
+    out = {"value": 9.3e6, "ms_per_step": 0.44, "n_gpus": 1, "roofline": {"kernel_ms": 0.359, "frac": 0.0133, "note": "x" * 900},
+           "env_step_only": {"value": 9.35e6}, "policy": {"value": 5.9e6, "policy_ms": 0.27, "with_discriminator_and_locoval_fit": {"value": 4.78e6, "ms_per_step": 0.856},
+                                                          "ppo": {"fps_total": 96e3, "fps_step": 2e6, "update_ms_per_optimizer_step": 3.4}},
+           "jta": {"value": 1971.0, "ms_per_step": 129.9, "steps": 10, "roofline": {"frac": 0.37}, "bf16": {"value": 3396.0, "ms_per_step": 75.4, "roofline": {"frac": 0.08}},
+                   "eval": {"value": 10735.0}}}
+    sm = ns["summary_of"](out)
+    assert sm["configs2_policy_disc_locoval_fit"] == 4.78e6 and sm["ppo_update_ms_per_optimizer_step"] == 3.4 and sm["jta_steps_timed"] == 10
+    assert sm["headline_env_steps_per_s"] == 9.3e6 and "cpu_baseline_env_steps_per_s" not in sm          # absent legs are left out
+    assert len(json.dumps(sm)) < 1000
