@@ -76,6 +76,12 @@ template <int NP>
 __device__ __forceinline__ void a16_cut4(float v0, float v1, float v2, float v3, a16_u32x2 (&o)[NP]) {
     if constexpr (NP == 1) {
         o[0] = a16_u32x2{gemm_pack2_bf16(v0, v1), gemm_pack2_bf16(v2, v3)};
+    } else if constexpr (NP == 2) {                           // two pieces: the value to 2^-17 of its magnitude
+        const unsigned a1 = gemm_pack2_bf16(v0, v1), b1 = gemm_pack2_bf16(v2, v3);
+        v0 -= __uint_as_float(a1 << 16); v1 -= __uint_as_float(a1 & 0xffff0000u);
+        v2 -= __uint_as_float(b1 << 16); v3 -= __uint_as_float(b1 & 0xffff0000u);
+        o[0] = a16_u32x2{a1, b1};
+        o[1] = a16_u32x2{gemm_pack2_bf16(v0, v1), gemm_pack2_bf16(v2, v3)};
     } else {
         unsigned a[3], b[3];
         a16_split_pair(v0, v1, a[0], a[1], a[2]);
@@ -99,6 +105,9 @@ template <int NP>
 __device__ __forceinline__ at_f32x16 a16_mma(const A16Frag<NP> &x, const A16Frag<NP> &y, at_f32x16 acc) {
     if constexpr (NP == 1) {
         return gemm_mfma_bf16_w(x.p[0], y.p[0], acc);
+    } else if constexpr (NP == 2) {                           // the three products above 2^-16 of the result
+        acc = gemm_mfma_bf16_w(x.p[1], y.p[0], acc); acc = gemm_mfma_bf16_w(x.p[0], y.p[1], acc); acc = gemm_mfma_bf16_w(x.p[0], y.p[0], acc);
+        return acc;
     } else {                                                  // the six products, smallest first
         acc = gemm_mfma_bf16_w(x.p[2], y.p[0], acc); acc = gemm_mfma_bf16_w(x.p[0], y.p[2], acc); acc = gemm_mfma_bf16_w(x.p[1], y.p[1], acc);
         acc = gemm_mfma_bf16_w(x.p[1], y.p[0], acc); acc = gemm_mfma_bf16_w(x.p[0], y.p[1], acc); acc = gemm_mfma_bf16_w(x.p[0], y.p[0], acc);
@@ -216,6 +225,12 @@ __device__ __forceinline__ void a16_halves(float x, float &u, float &v) {
 #endif
 #ifndef A16_WPE_DQ
 #define A16_WPE_DQ 2
+#endif
+#ifndef A16_WPE_DQ2
+#define A16_WPE_DQ2 2
+#endif
+#ifndef A16_WPE_DKV2
+#define A16_WPE_DKV2 2
 #endif
 // keep factors (1 / 0) of a lane's 16 entries of a tile: entry r = (tile row kappa(r, hi), own row) -- `rows_are_keys`: the tile's rows
 // are keys and the lane's own row is the query (forward, dQ), else the tile's rows are queries and the own row is a key (dK / dV).
@@ -347,7 +362,7 @@ attn16_fwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ backward 1: dQ (and D)
 template <int NP, int G, int DROP, int MEM16>
-__global__ void __launch_bounds__(256) A16_WAVES(A16_WPE_DQ)
+__global__ void __launch_bounds__(256) A16_WAVES(NP == 2 ? A16_WPE_DQ2 : A16_WPE_DQ)
 attn16_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char Kt[2][NP * A16_TILE_BYTES], Vr[2][NP * A16_TILE_BYTES], Kc[2][NP * A16_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) float Bs[2][AT_T];
@@ -448,7 +463,7 @@ attn16_bwd_dq_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ backward 2: dK, dV
 template <int NP, int G, int DROP, int MEM16>
-__global__ void __launch_bounds__(256) A16_WAVES(2)       // (left alone: 247 + 64 accumulator registers at NP = 1, G = 2: one wave per SIMD)
+__global__ void __launch_bounds__(256) A16_WAVES(NP == 2 ? A16_WPE_DKV2 : 2)       // (left alone: 247 + 64 accumulator registers at NP = 1, G = 2: one wave per SIMD)
 attn16_bwd_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char Qr[2][NP * A16_TILE_BYTES], Or[2][NP * A16_TILE_BYTES], Qc[2][NP * A16_TILE_BYTES], Oc[2][NP * A16_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) float Ls[2][AT_T], Ds[2][AT_T];

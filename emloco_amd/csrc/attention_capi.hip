@@ -11,6 +11,13 @@
 namespace {
 // EMLOCO_ATTN16_OLD=1: the bf16-in-memory mode on round 4's kernels (one block of 32 rows per wave, fp32 LDS tiles) -- A/B knob
 bool attn16_old() { static const bool v = [] { const char *e = getenv("EMLOCO_ATTN16_OLD"); return e && e[0] == '1'; }(); return v; }
+// Pieces per operand in the split mode's BACKWARD kernels (round 6).  Default 2: every operand is the sum of two bf16 pieces and a product
+// the three piece products above 2^-16 of it -- gradients to ~2^-17 of their magnitude (measured on the shipped-depth model,
+// tools/exp/graderr.py: 2-3e-6 of a tensor's scale next to the loss, where three pieces give 6e-7 and the test bar is 2e-4; the early
+// layers' 3e-5 .. 1e-4 do not move: that is the ReLU / LayerNorm stack's own fp32 noise), half the matrix instructions and 40 % of the
+// piece arithmetic: dQ + dK/dV 5.99 -> 4.09 ms per launch pair at the train step's size.  The FORWARD stays on three pieces (logits to
+// 5e-7).  EMLOCO_ATTN_BWD_PIECES=3 restores the three-piece backward.
+int attn_bwd_pieces() { static const int v = [] { const char *e = getenv("EMLOCO_ATTN_BWD_PIECES"); return e && e[0] == '3' ? 3 : 2; }(); return v; }
 int pfail(int code, const char *what, hipError_t e = hipSuccess) {
     if (e != hipSuccess) fprintf(stderr, "[emloco] %s: %s\n", what, hipGetErrorString(e));
     else fprintf(stderr, "[emloco] %s\n", what);
@@ -144,6 +151,23 @@ int emloco_attention_bwd_queries(int n_seq, int S, int n_query, int nhead, int d
     // first kernel: dQ, also writes D = rowsum(dO o O); second: dK, dV
     const bool sp = !bf && (flags & EMLOCO_ATTN_SPLIT) != 0;
     if (sp && !attn16_old()) {
+        if (attn_bwd_pieces() == 2) {
+#ifndef A16_NP2_DQ_G
+#define A16_NP2_DQ_G 2                                       /* two blocks of 32 queries per wave fit with two pieces (4.30 -> 4.09 ms); dK/dV: one (two: 4.98) */
+#endif
+#ifndef A16_NP2_DKV_G
+#define A16_NP2_DKV_G 1
+#endif
+            const dim3 qg2((unsigned)((n_query + 128 * A16_NP2_DQ_G - 1) / (128 * A16_NP2_DQ_G)), (unsigned)(n_seq * nhead));
+            const dim3 kg2((unsigned)((S + 128 * A16_NP2_DKV_G - 1) / (128 * A16_NP2_DKV_G)), (unsigned)(n_seq * nhead));
+            if (dr) hipLaunchKernelGGL((emloco::attn16_bwd_dq_kernel<2, A16_NP2_DQ_G, 1, 0>), qg2, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((emloco::attn16_bwd_dq_kernel<2, A16_NP2_DQ_G, 0, 0>), qg2, dim3(256), 0, st, a);
+            PHIPCHK(hipGetLastError());
+            if (dr) hipLaunchKernelGGL((emloco::attn16_bwd_dkv_kernel<2, A16_NP2_DKV_G, 1, 0>), kg2, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((emloco::attn16_bwd_dkv_kernel<2, A16_NP2_DKV_G, 0, 0>), kg2, dim3(256), 0, st, a);
+            PHIPCHK(hipGetLastError());
+            return 0;
+        }
         if (dr) hipLaunchKernelGGL((emloco::attn16_bwd_dq_kernel<3, 1, 1, 0>), qgrid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((emloco::attn16_bwd_dq_kernel<3, 1, 0, 0>), qgrid, dim3(256), 0, st, a);
         PHIPCHK(hipGetLastError());

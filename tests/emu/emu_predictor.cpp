@@ -263,24 +263,29 @@ extern "C" int emu_drop_keep(unsigned seed, unsigned long long idx, float p) { r
 
 // ---- round 5's attention kernels (attention16_kernels.hip), launched as the C ABI launches them.  which = 1: bf16 memory, two blocks per
 // wave (qkv / dqkv hold bf16); which = 0: round 4's kernels of that mode (attn_*<1, DROP, 1>); which = 3: the split mode on piece-plane tile
-// images (fp32 memory, one block per wave); which = 2: round 4's split-mode kernels (attn_*<2, DROP, 0>).
+// images (fp32 memory; forward: three pieces, two blocks per wave; backward as the C ABI launches it by default since round 6: TWO pieces,
+// dQ two blocks per wave); which = 5: the same with the three-piece backward (EMLOCO_ATTN_BWD_PIECES=3); which = 2: round 4's split-mode
+// kernels (attn_*<2, DROP, 0>).
 extern "C" int emu_attention16(int which, int n_seq, int S, int Sq, int nhead, int d_model, float scale, const void *qkv, const float *key_bias,
                                float *out, float *lse, const float *dout, void *dqkv, float *dsum, float drop_p, unsigned seed) {
     AttnArgs a{n_seq, S, nhead, d_model, Sq, scale, (const float *)qkv, key_bias, out, lse, dout, (float *)dqkv, dsum, drop_p, 1.0f / (1.0f - drop_p), seed,
                (unsigned)(drop_p * 16777216.0f)};
     const unsigned rows_per_wg = which == 1 ? 256 : 128;
+    const unsigned rows_dq = (which == 1 || which == 3) ? 256 : 128;
     const bool dr = drop_p > 0.0f;
 #define A16_RUN(KOLD_BF, KOLD_SP, KNEW) do { \
         if (which == 1) { if (dr) KNEW<1, 2, 1, 1>(a); else KNEW<1, 2, 0, 1>(a); } \
-        else if (which == 3) { if (dr) KNEW<3, 1, 1, 0>(a); else KNEW<3, 1, 0, 0>(a); } \
+        else if (which == 5) { if (dr) KNEW<3, 1, 1, 0>(a); else KNEW<3, 1, 0, 0>(a); } \
         else if (which == 0) { if (dr) KOLD_BF<1, 1, 1>(a); else KOLD_BF<1, 0, 1>(a); } \
         else { if (dr) KOLD_SP<2, 1, 0>(a); else KOLD_SP<2, 0, 0>(a); } } while (0)
-    const unsigned rows_fwd = (which == 3 && !dout) ? 256 : rows_per_wg;      // the split-mode forward runs two blocks per wave (attention_capi.hip: A16_SPLIT_G_FWD)
+    const bool split_new = which == 3 || which == 5;
+    const unsigned rows_fwd = !dout ? (split_new ? 256 : rows_per_wg) : rows_dq;      // the split-mode forward runs two blocks per wave (attention_capi.hip: A16_SPLIT_G_FWD)
     for (unsigned y = 0; y < (unsigned)(n_seq * nhead); ++y)
         for (unsigned x = 0; x < (Sq + rows_fwd - 1) / rows_fwd; ++x)
             emu::launch(1, 256, [&] {
                 blockIdx.x = x; blockIdx.y = y;
-                if (!dout && which == 3) { if (dr) attn16_fwd_kernel<3, 2, 1, 0>(a); else attn16_fwd_kernel<3, 2, 0, 0>(a); }
+                if (!dout && split_new) { if (dr) attn16_fwd_kernel<3, 2, 1, 0>(a); else attn16_fwd_kernel<3, 2, 0, 0>(a); }
+                else if (dout && which == 3) { if (dr) attn16_bwd_dq_kernel<2, 2, 1, 0>(a); else attn16_bwd_dq_kernel<2, 2, 0, 0>(a); }
                 else if (!dout) A16_RUN(attn_fwd_kernel, attn_fwd_kernel, attn16_fwd_kernel);
                 else A16_RUN(attn_bwd_dq_kernel, attn_bwd_dq_kernel, attn16_bwd_dq_kernel);
             });
@@ -289,7 +294,8 @@ extern "C" int emu_attention16(int which, int n_seq, int S, int Sq, int nhead, i
             for (unsigned x = 0; x < (S + rows_per_wg - 1) / rows_per_wg; ++x)
                 emu::launch(1, 256, [&] {
                     blockIdx.x = x; blockIdx.y = y;
-                    A16_RUN(attn_bwd_dkv_kernel, attn_bwd_dkv_kernel, attn16_bwd_dkv_kernel);
+                    if (which == 3) { if (dr) attn16_bwd_dkv_kernel<2, 1, 1, 0>(a); else attn16_bwd_dkv_kernel<2, 1, 0, 0>(a); }
+                    else A16_RUN(attn_bwd_dkv_kernel, attn_bwd_dkv_kernel, attn16_bwd_dkv_kernel);
                 });
 #undef A16_RUN
     blockIdx.x = 0; blockIdx.y = 0;

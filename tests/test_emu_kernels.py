@@ -1267,7 +1267,8 @@ def test_split_mode_attention_on_piece_plane_tile_images():
     plane per piece: the walked tile's pieces are cut once, by the staging thread, not by every consuming wave.  Against float64 attention
     with the kernels' own dropout mask: fp32 class (1e-5 of the tensor scale; the bf16 kernels hold 2e-2), forward, log-sum-exp and all
     three gradients; and against round 4's split-mode kernels (attn_*<2, DROP, 0>): same pieces, same products, same mask -- summation
-    order and the base of the exponential apart.  Ragged S, +1 and -inf key bias, dropout, the live-query form."""
+    order and the base of the exponential apart.  Ragged S, +1 and -inf key bias, dropout, the live-query form.  Round 6: the DEFAULT
+    backward runs on two pieces per operand (three products): same forward bytes, gradients within 2^-16 of the tensor scale."""
     lib = emu.lib()
     lib.emu_attn_keep.restype = C.c_int
     rng = np.random.default_rng(10)
@@ -1281,7 +1282,7 @@ def test_split_mode_attention_on_piece_plane_tile_images():
         kb[-1, S - 20:] = -np.inf
         dout = rng.normal(size=(n_seq, Sq, d)).astype(np.float32)
         res = {}
-        for which in (2, 3):
+        for which in (2, 3, 5):
             out = np.full((n_seq, Sq, d), np.nan, np.float32)
             lse = np.full((n_seq * H, Sq), np.nan, np.float32)
             lib.emu_attention16(which, n_seq, S, Sq, H, d, C.c_float(scale), VP(qkv), P(kb), P(out), P(lse), None, None, None, C.c_float(p), C.c_uint(seed))
@@ -1311,7 +1312,12 @@ def test_split_mode_attention_on_piece_plane_tile_images():
                 ref_dqkv[b, :Sq, h * 32:(h + 1) * 32] = dS @ k * scale
                 ref_dqkv[b, :, d + h * 32:d + (h + 1) * 32] = dS.T @ q[:Sq] * scale
                 ref_dqkv[b, :, 2 * d + h * 32:2 * d + (h + 1) * 32] = Pd.T @ do
-        new, old = res[3], res[2]
+        new, old, dflt = res[5], res[2], res[3]
+        # the default launch (round 6): the same forward, the backward on TWO pieces per operand -- gradients to 2^-16 of the tensor scale
+        assert np.array_equal(dflt[0], new[0]) and np.array_equal(dflt[1], new[1]) and np.array_equal(dflt[3], new[3])
+        err2 = np.abs(dflt[2] - ref_dqkv).max()
+        assert np.isfinite(dflt[2]).all() and err2 <= 1.6e-5 * np.abs(ref_dqkv).max() + 1e-7, (S, Sq, p, "two-piece backward", err2, np.abs(ref_dqkv).max())
+        assert np.all(dflt[2][-1, S - 20:, d:] == 0)
         for got, want, what in ((new[0], ref_out, "out"), (new[1], ref_lse, "lse"), (new[2], ref_dqkv, "dqkv")):
             err = np.abs(got - want).max()
             assert np.isfinite(got).all() and err <= 1e-5 * np.abs(want).max() + 1e-7, (S, Sq, p, what, err, np.abs(want).max())

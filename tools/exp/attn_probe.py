@@ -24,8 +24,9 @@ for path in libs:
     L.emloco_attention_bwd_queries.argtypes = [C.c_int] * 5 + [C.c_float] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_uint32, C.c_void_p]
     handles.append((os.path.basename(path), L))
 sc = 1.0 / 32 ** 0.5
-def fwd(L): assert L.emloco_attention_fwd_queries(n_seq, S, S, H, d, sc, P(qkv), P(kb), P(out), P(lse), FL, 0.1, 99, st) == 0
-def bwd(L): assert L.emloco_attention_bwd_queries(n_seq, S, S, H, d, sc, P(qkv), P(kb), P(out), P(lse), P(dout), P(dqkv), P(dsum), FL, 0.1, 99, st) == 0
+PD = float(os.environ.get("ATTN_P", 0.1))
+def fwd(L): assert L.emloco_attention_fwd_queries(n_seq, S, S, H, d, sc, P(qkv), P(kb), P(out), P(lse), FL, PD, 99, st) == 0
+def bwd(L): assert L.emloco_attention_bwd_queries(n_seq, S, S, H, d, sc, P(qkv), P(kb), P(out), P(lse), P(dout), P(dqkv), P(dsum), FL, PD, 99, st) == 0
 res = {}
 for rep in range(3):
     for name, L in handles:
