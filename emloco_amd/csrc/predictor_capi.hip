@@ -267,7 +267,7 @@ int emloco_gemm_relu_bwd(int m, int n, int k, const float *A, int lda, const flo
     if (m < 1 || n < 33 || k < 1 || !A || !B || !C || !y || !colsum || !workspace)
         return pfail(-1, "emloco_gemm_relu_bwd: bad argument (n > 32; workspace = emloco_gemm_relu_bwd_workspace(m, n) floats)");
     emloco::GemmArgs g{1, m, n, k, 1.0f, A, lda, 0, 0, B, ldb, 0, trans_b, C, n, 0, nullptr,
-                       32 | (flags & EMLOCO_GEMM_BF16) | ((flags & EMLOCO_GEMM_BF16) ? 0 : (flags & EMLOCO_GEMM_SPLIT)), 1, nullptr,
+                       32 | (flags & EMLOCO_GEMM_BF16) | ((flags & EMLOCO_GEMM_BF16) ? 0 : (flags & (EMLOCO_GEMM_SPLIT | EMLOCO_GEMM_SPLIT2))), 1, nullptr,
                        0, 0, 0.0f, 0u, y, scale, workspace};
     g.vec_a = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
     g.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);

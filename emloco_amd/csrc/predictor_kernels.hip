@@ -287,7 +287,7 @@ __device__ __forceinline__ void split_fetch_trans(f32x4 (&v)[2], unsigned (&mk)[
 }
 // quads a thread holds of one operand stage: 2 adjacent k of a row quad (TRANS), or ROWS / 64 quads of 4 consecutive k
 constexpr int split_nv(int rows, int trans) { return trans ? 2 : rows / 64; }
-template <int ROWS, int TRANS>
+template <int ROWS, int TRANS, int NPC = 3>      // NPC = 2: the third plane is neither cut nor written (two-piece products, round 6)
 __device__ __forceinline__ void split_stash(const f32x4 (&v)[split_nv(ROWS, TRANS)], const unsigned (&mk)[split_nv(ROWS, TRANS)], unsigned *S, int tid) {
     static_assert(ROWS == 128 || ROWS == 64, "split stages are 128 or 64 rows x 16 k on 256 threads");
     constexpr int HW = split_half_words(ROWS), PW = split_plane_words(ROWS), NV = split_nv(ROWS, TRANS);
@@ -306,7 +306,7 @@ __device__ __forceinline__ void split_stash(const f32x4 (&v)[split_nv(ROWS, TRAN
             unsigned *dst = S + (q >> 1) * HW + r * 4 + (q & 1) * 2;
             *(uint2 *)(dst) = uint2{a1, b1};
             *(uint2 *)(dst + PW) = uint2{a2, b2};
-            *(uint2 *)(dst + 2 * PW) = uint2{a3, b3};
+            if constexpr (NPC == 3) *(uint2 *)(dst + 2 * PW) = uint2{a3, b3};
         }
     } else {                                                   // 4 rows x 2 adjacent k: one word per row and plane
         int rq, kp;
@@ -317,15 +317,16 @@ __device__ __forceinline__ void split_stash(const f32x4 (&v)[split_nv(ROWS, TRAN
             unsigned p1, p2, p3;
             split_pair(lo[j], hi[j], p1, p2, p3);
             unsigned *dst = base + split_slot<1>(4 * rq + j) * 4;
-            dst[0] = p1; dst[PW] = p2; dst[2 * PW] = p3;
+            dst[0] = p1; dst[PW] = p2;
+            if constexpr (NPC == 3) dst[2 * PW] = p3;
         }
     }
 }
 // the three pieces of a lane's 8 reduction entries (its half of the stage) of one row
-template <int ROWS, int TRANS>
+template <int ROWS, int TRANS, int NPC = 3>
 __device__ __forceinline__ void split_frag(const unsigned *S, int row, int half, bf16w4 (&out)[3]) {
     const unsigned *src = S + half * split_half_words(ROWS) + split_slot<TRANS>(row) * 4;
-    for (int p = 0; p < 3; ++p) out[p] = *(const bf16w4 *)(src + p * split_plane_words(ROWS));
+    for (int p = 0; p < NPC; ++p) out[p] = *(const bf16w4 *)(src + p * split_plane_words(ROWS));
 }
 
 // ---- a B operand that was cut ONCE (round 5): the piece image of a weight matrix -------------------------------------------
@@ -406,7 +407,9 @@ __device__ __forceinline__ void split_img_stash(const gemm_u32x4 (&v)[split_img_
 // instructions -- two register sets, the stash woven between the matrix instructions with sched_group_barrier -- costs 70 registers, i.e.
 // two workgroups per CU instead of three, and is 5 % slower on the tall GEMMs, 15 % on the M = 2 048 ones.)
 template <int V> struct gemm_int_c { static constexpr int value = V; };
-template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int PREC, int EPI, int IOA = 0, int IOB = 0, int EPIO = 0>
+// NPC (split mode, round 6): pieces per operand.  3: the six piece products above 2^-24 of a product (fp32 class).  2: the three above
+// 2^-16 -- for the GRADIENT products of the backward pass (EMLOCO_GEMM_SPLIT2): half the matrix instructions, a shorter cut.
+template <int WM, int WN, int TI, int TJ, int GBK, int TA, int TB, int VEC, int PREC, int EPI, int IOA = 0, int IOB = 0, int EPIO = 0, int NPC = 3>
 __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     constexpr int BM = WM * TI * 32, BN = WN * TJ * 32, GLDK = GBK + 4, NF = GBK / 8;
     constexpr int QA = (PREC == 2 && TA) ? 2 : (BM * GBK / 4 + 255) / 256, QB = (PREC == 2 && TB) ? 2 : (BN * GBK / 4 + 255) / 256;
@@ -455,9 +458,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     else gemm_fetch<BN, GBK, TB, VEC, (IOB == 2 ? 0 : IOB), MK>(rb, mb, B, g.ldb, n0, g.n, (K0), ke, tid);
 #define GEMM_STASH(BUF)                                                                                         \
     if constexpr (PREC == 2) {                                                                                  \
-        split_stash<BM, TA>(ra, ma, (unsigned *)As[BUF], tid);                                                  \
+        split_stash<BM, TA, NPC>(ra, ma, (unsigned *)As[BUF], tid);                                             \
         if constexpr (IOB == 2) split_img_stash<BN>(rbi, (unsigned *)Bs[BUF], tid);                             \
-        else split_stash<BN, TB>(rb, mb, (unsigned *)Bs[BUF], tid);                                             \
+        else split_stash<BN, TB, NPC>(rb, mb, (unsigned *)Bs[BUF], tid);                                        \
     } else {                                                                                                    \
         gemm_stash<BM, GBK, TA>(ra, ma, As[BUF], tid);                                                          \
         gemm_stash<BN, GBK, TB>(rb, mb, Bs[BUF], tid);                                                          \
@@ -477,13 +480,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PREC == 2) {
             bf16w4 sa[TI][3], sb[TJ][3];
-            for (int i = 0; i < TI; ++i) split_frag<BM, TA>((const unsigned *)As[buf], (wm * TI + i) * 32 + l31, lane >> 5, sa[i]);
-            for (int j = 0; j < TJ; ++j) split_frag<BN, (IOB == 2 ? 0 : TB)>((const unsigned *)Bs[buf], (wn * TJ + j) * 32 + l31, lane >> 5, sb[j]);
+            static_assert(NPC == 3 || IOB != 2, "the piece image serves the three-piece products");
+            for (int i = 0; i < TI; ++i) split_frag<BM, TA, NPC>((const unsigned *)As[buf], (wm * TI + i) * 32 + l31, lane >> 5, sa[i]);
+            for (int j = 0; j < TJ; ++j) split_frag<BN, (IOB == 2 ? 0 : TB), NPC>((const unsigned *)Bs[buf], (wn * TJ + j) * 32 + l31, lane >> 5, sb[j]);
             // the six products, smallest first; term-outer so that consecutive matrix instructions go to different accumulators
 #define SPLIT_TERM(PA, PB)                                                                                      \
             for (int i = 0; i < TI; ++i)                                                                        \
                 for (int j = 0; j < TJ; ++j) acc[i][j] = gemm_mfma_bf16_w(sa[i][PA], sb[j][PB], acc[i][j]);
-            SPLIT_TERM(2, 0) SPLIT_TERM(0, 2) SPLIT_TERM(1, 1) SPLIT_TERM(1, 0) SPLIT_TERM(0, 1) SPLIT_TERM(0, 0)
+            if constexpr (NPC == 3) { SPLIT_TERM(2, 0) SPLIT_TERM(0, 2) SPLIT_TERM(1, 1) }
+            SPLIT_TERM(1, 0) SPLIT_TERM(0, 1) SPLIT_TERM(0, 0)
 #undef SPLIT_TERM
         } else {
         f32x4 fa[TI][NF], fb[TJ][NF];
@@ -735,6 +740,16 @@ gemm_split_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, TA, TB, 1, 2, 0>(g); }
 template <int TB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 gemm_split_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, 0, TB, 1, 2, 1, 0, 0, 0>(g); }
+// two pieces per operand (EMLOCO_GEMM_SPLIT2, round 6): the gradient products of the backward pass
+template <int TA, int TB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+gemm_split2_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, TA, TB, 1, 2, 0, 0, 0, 0, 2>(g); }
+template <int TB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+gemm_split2_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, 0, TB, 1, 2, 1, 0, 0, 0, 2>(g); }
+template <int TA, int TB>
+__global__ void __launch_bounds__(256)
+gemm_split2_small_kernel(GemmArgs g) { gemm_body<2, 2, 1, 1, 16, TA, TB, 1, 2, 0, 0, 0, 0, 2>(g); }
 // B as the piece image of a weight (IOB = 2; A row-major): the forward and input-gradient GEMMs of the linear layers
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 gemm_split_img_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, 0, 0, 1, 2, 0, 0, 2>(g); }
@@ -788,6 +803,8 @@ inline GemmKernel gemm_pick_layout(int ta, int tb, int vec, int bf16 = 0, int a1
 inline GemmKernel gemm_pick(const GemmArgs &g, bool deep) {
     const int vec = g.vec_a && g.vec_b;
     const int bf16 = (g.flags & 16) ? 1 : 0;
+    const bool two = (g.flags & 4096) && !g.bimg;              // EMLOCO_GEMM_SPLIT2 (a piece image holds three pieces: it wins)
+    if ((g.flags & 32) && (g.flags & 1024) && !bf16 && !g.c16 && !g.m16 && two) return g.tb ? gemm_split2_relu_bwd_kernel<1> : gemm_split2_relu_bwd_kernel<0>;
     if ((g.flags & 32) && (g.flags & 1024) && !bf16 && !g.c16 && !g.m16 && g.bimg) return gemm_split_relu_bwd_img_kernel;
     if ((g.flags & 32) && (g.flags & 1024) && !bf16 && !g.c16 && !g.m16) return g.tb ? gemm_split_relu_bwd_kernel<1> : gemm_split_relu_bwd_kernel<0>;
     if (g.flags & 32) {           // fused backward epilogue: A row-major, 16-byte loads (the launcher checks)
@@ -804,6 +821,18 @@ inline GemmKernel gemm_pick(const GemmArgs &g, bool deep) {
     }
     if (g.n <= 32) return deep ? gemm_pick_layout<4, 1, 1, 1, 32>(g.ta, g.tb, vec) : gemm_pick_layout<4, 1, 1, 1, 16>(g.ta, g.tb, vec);
     if ((g.flags & 1024) && !bf16 && g.bimg) return g.small ? gemm_split_small_img_kernel : gemm_split_img_kernel;
+    if ((g.flags & 1024) && vec && !bf16 && two) {
+        if (g.small) {
+            if (!g.ta && !g.tb) return gemm_split2_small_kernel<0, 0>;
+            if (!g.ta && g.tb) return gemm_split2_small_kernel<0, 1>;
+            if (g.ta && !g.tb) return gemm_split2_small_kernel<1, 0>;
+            return gemm_split2_small_kernel<1, 1>;
+        }
+        if (!g.ta && !g.tb) return gemm_split2_kernel<0, 0>;
+        if (!g.ta && g.tb) return gemm_split2_kernel<0, 1>;
+        if (g.ta && !g.tb) return gemm_split2_kernel<1, 0>;
+        return gemm_split2_kernel<1, 1>;
+    }
     if ((g.flags & 1024) && vec && !bf16 && g.small) {
         if (!g.ta && !g.tb) return gemm_split_small_kernel<0, 0>;
         if (!g.ta && g.tb) return gemm_split_small_kernel<0, 1>;

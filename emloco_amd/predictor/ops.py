@@ -105,6 +105,22 @@ GEMM_BF16 = 16
 GEMM_SPLIT = 1024      # EMLOCO_GEMM_SPLIT: fp32-class products from bf16 pieces (six bf16 matrix instructions per 16 k)
 GEMM_A16, GEMM_B16, GEMM_C16, GEMM_MASK16 = 64, 128, 256, 512      # EMLOCO_GEMM_*_BF16MEM: that operand is bf16 in memory
 GEMM_B_SPLITIMG = 2048  # EMLOCO_GEMM_B_SPLITIMG: B is the piece image of a weight (split_image)
+GEMM_SPLIT2 = 4096      # EMLOCO_GEMM_SPLIT2: with GEMM_SPLIT, two pieces per operand (three piece products): the backward's gradient products
+# Pieces per operand of the split mode's BACKWARD products (round 6; the forward always runs on three: logits to 5e-7 of the reference).
+# Two pieces = the three piece products above 2^-16 of a product instead of the six above 2^-24: half the matrix instructions and a shorter
+# cut, on a SIMD whose matrix and vector pipes take turns (profiles/r06_attn_dq_ablation.txt).  "dx": the input-gradient GEMMs (dx = dy W,
+# the fused ReLU backward; compute-bound at K = 1024: 170 TFLOP/s); "dw": the weight gradients (dW = dy^T x).  The fused attention's
+# backward has its own switch inside the library (EMLOCO_ATTN_BWD_PIECES).  Measured on one box (profiles/r06_ab_bwd_pieces.txt): fp32-class
+# JTA train step 138 ms (all three) -> 127.5 (attention) -> 123 (+ dx) -> 119 (+ dw); gradients of the shipped-depth model against the
+# reference's: 4-9e-6 of a tensor's scale next to the loss (6e-7 with three pieces; the tests' bar is 2e-4), unchanged in the early
+# layers (3e-5 .. 1.3e-4: the ReLU / LayerNorm stack's own fp32 noise, bar 1e-3).  EMLOCO_BWD_PIECES=3 (and EMLOCO_ATTN_BWD_PIECES=3)
+# restore round 5's backward.
+_BWD_PIECES = {"dx": int(os.environ.get("EMLOCO_BWD_PIECES_DX", os.environ.get("EMLOCO_BWD_PIECES", "2"))),
+               "dw": int(os.environ.get("EMLOCO_BWD_PIECES_DW", os.environ.get("EMLOCO_BWD_PIECES", "2")))}
+
+
+def _bwd_flags(kind):
+    return GEMM_SPLIT2 if _BWD_PIECES[kind] == 2 else 0
 # Frozen weights (the rollout's policy and discriminator) are cut into their bf16 pieces ONCE, when first used (learning/policy_runner.py:
 # +1.4 % on the policy forward, +1.8 % on the configs[2] loop, profiles/r05_ab_weight_image.txt); EMLOCO_GEMM_WEIGHT_IMAGE=0: never.
 # A trained weight would have to be cut once per launch (one small extra launch): measured on the predictor's tall GEMMs that buys
@@ -256,17 +272,18 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
             gemm(1, M, K, N, dy2, N, 0, 0, W, K, 0, 1, dx, K, 0, ksplit=1 if dy2.dtype == torch.bfloat16 else _ksplit_for(N, M * K),
-                 b_image=_weight_image(W, M, K, N, K, 1) if dy2.dtype == torch.float32 else None)                                       # dx = dy W
+                 b_image=_weight_image(W, M, K, N, K, 1) if (dy2.dtype == torch.float32 and _BWD_PIECES["dx"] == 3) else None,
+                 flags=_bwd_flags("dx"))                                                                                                # dx = dy W
             dx = dx.view(ctx.xs)
         if ctx.needs_input_grad[1]:
             g = ctx.w_param.grad if ctx.w_param is not None else None
             if g is not None and g.dtype == torch.float32 and g.shape == (N, K) and g.is_contiguous() and g.data_ptr() % 16 == 0 and dy2.dtype == torch.float32:
                 # the weight gradient goes straight INTO the parameter's .grad (a view of the learner's flat bucket): C += dy^T x in the
                 # GEMM's epilogue instead of a fresh N x K tensor and autograd's accumulation launch behind it
-                gemm(1, N, K, M, dy2, N, 0, 1, x2, K, 0, 1, g, K, 0, ksplit=_ksplit_for(M, N * K), flags=GEMM_ACC)
+                gemm(1, N, K, M, dy2, N, 0, 1, x2, K, 0, 1, g, K, 0, ksplit=_ksplit_for(M, N * K), flags=GEMM_ACC | _bwd_flags("dw"))
             else:
                 dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-                gemm(1, N, K, M, dy2, N, 0, 1, x2, K, 0, 1, dW, K, 0, ksplit=_ksplit_for(M, N * K))   # dW = dy^T x
+                gemm(1, N, K, M, dy2, N, 0, 1, x2, K, 0, 1, dW, K, 0, ksplit=_ksplit_for(M, N * K), flags=_bwd_flags("dw"))   # dW = dy^T x
         if need_db and db is None:
             db = colsum(dy2)
         return dx, dW, db, None, None, None, None
@@ -420,23 +437,24 @@ class FeedForwardFn(torch.autograd.Function):
             # values before rounding them: a difference of one bf16 rounding per element, inside the reduced-precision mode's 2e-2 bar)
             return (dx.view(ctx.xs) if ctx.needs_input_grad[0] else None), dW1, colsum(dz1), dW2, db2, None, None, None
         dW2 = torch.empty((N, F), dtype=torch.float32, device=dev)
-        gemm(1, N, F, M, dz2, N, 0, 1, h, F, 0, 1, dW2, F, 0, ksplit=_ksplit_for(M, N * F))          # dW2 = dz2^T h
+        gemm(1, N, F, M, dz2, N, 0, 1, h, F, 0, 1, dW2, F, 0, ksplit=_ksplit_for(M, N * F), flags=_bwd_flags("dw"))          # dW2 = dz2^T h
         h16 = h.dtype == torch.bfloat16
         dz1 = torch.empty((M, F), dtype=h.dtype, device=dev)         # the hidden layer's gradient follows its dtype
         db1 = torch.empty(F, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.emloco_gemm_relu_bwd_workspace(M, F), dtype=torch.float32, device=dev)
-        fl = (GEMM_BF16 | GEMM_C16 | GEMM_MASK16) if h16 else {"bf16": GEMM_BF16, "fp32_split": GEMM_SPLIT}.get(_matmul_precision[0], 0)
-        img2 = _weight_image(W2, M, F, N, F, 1) if (not h16 and dz2.dtype == torch.float32) else None     # B(n = hidden unit, k = output) = W2[k][n]
+        fl = (GEMM_BF16 | GEMM_C16 | GEMM_MASK16) if h16 else {"bf16": GEMM_BF16, "fp32_split": GEMM_SPLIT | _bwd_flags("dx")}.get(_matmul_precision[0], 0)
+        # (a piece image holds three pieces: with the two-piece backward the matrix itself is the faster operand)
+        img2 = _weight_image(W2, M, F, N, F, 1) if (not h16 and dz2.dtype == torch.float32 and _BWD_PIECES["dx"] == 3) else None     # B(n = hidden unit, k = output) = W2[k][n]
         _chk(lib.emloco_gemm_relu_bwd(M, F, N, _p(dz2), N, _p(img2 if img2 is not None else W2), F, 1, _p(dz1), _p(h), 1.0 / (1.0 - p), _p(db1), _p(ws),
                                       fl | (GEMM_B_SPLITIMG if img2 is not None else 0), st), "emloco_gemm_relu_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
             gemm(1, M, K, F, dz1, F, 0, 0, W1, K, 0, 1, dx, K, 0, ksplit=1 if h16 else _ksplit_for(F, M * K),   # dx = dz1 W1
-                 b_image=_weight_image(W1, M, K, F, K, 1) if not h16 else None)
+                 b_image=_weight_image(W1, M, K, F, K, 1) if (not h16 and _BWD_PIECES["dx"] == 3) else None, flags=_bwd_flags("dx"))
             dx = dx.view(ctx.xs)
         dW1 = torch.empty((F, K), dtype=torch.float32, device=dev)
-        gemm(1, F, K, M, dz1, F, 0, 1, x2, K, 0, 1, dW1, K, 0, ksplit=_ksplit_for(M, F * K))         # dW1 = dz1^T x
+        gemm(1, F, K, M, dz1, F, 0, 1, x2, K, 0, 1, dW1, K, 0, ksplit=_ksplit_for(M, F * K), flags=_bwd_flags("dw"))         # dW1 = dz1^T x
         return dx, dW1, db1, dW2, db2, None, None, None
 
 

@@ -41,7 +41,12 @@ enum { EMLOCO_GEMM_BIAS = 1, EMLOCO_GEMM_RELU = 2, EMLOCO_GEMM_ACCUMULATE = 4, E
         * bf16 pieces once, in the order the kernel's LDS stages hold them -- for the products whose B is a weight (y = x W^T: pack with
         * trans = 0; dx = dy W: trans = 1).  A must be row-major fp32, batch 1; ldb / stride_b / trans_b are ignored.  Same pieces, same
         * products, the same bits as the matrix itself; the thousands of workgroups of a tall GEMM no longer cut the same weight tile. */
-       EMLOCO_GEMM_B_SPLITIMG = 2048 };
+       EMLOCO_GEMM_B_SPLITIMG = 2048,
+       /* (round 6) with EMLOCO_GEMM_SPLIT: TWO bf16 pieces per operand -- the three piece products above 2^-16 of a product instead of the
+        * six above 2^-24: half the matrix instructions, a shorter cut.  Meant for the GRADIENT products of the backward pass (dx = dy W,
+        * the fused ReLU backward): the trainers' gradient bars (2e-4 of a tensor's scale next to the loss) are met with a margin of
+        * ~50 (profiles/r06_ab_bwd_pieces.txt); forward products stay on three pieces.  Ignored with a piece image (three pieces). */
+       EMLOCO_GEMM_SPLIT2 = 4096 };
 
 /* Batched strided GEMM on the matrix cores, fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: exact fp32):
  *   C[b][m][n] (+)= alpha * sum_k A_b(m,k) * B_b(n,k)   [+ bias[n]] [relu]

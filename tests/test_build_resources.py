@@ -58,7 +58,8 @@ def test_hot_kernels_stay_inside_their_register_and_scratch_budgets():
     for k, r in pick("sim_step_kernelILi1").items():
         assert r["Occupancy"] >= 3 and r["VGPRs"] <= 168 and r["ScratchSize"] <= 512, (k, r)
     # split-mode GEMMs: three workgroups per CU (168 registers, 50.7 KB of LDS), accumulators in registers
-    for sub in ("gemm_split_kernel", "gemm_split_img_kernel", "gemm_split_relu_bwd_kernel", "gemm_split_relu_bwd_img_kernel"):
+    for sub in ("gemm_split_kernel", "gemm_split_img_kernel", "gemm_split_relu_bwd_kernel", "gemm_split_relu_bwd_img_kernel",
+                "gemm_split2_kernel", "gemm_split2_relu_bwd_kernel"):      # (split2: round 6's two-piece gradient products)
         for k, r in pick(sub).items():
             assert r["ScratchSize"] == 0 and r["Occupancy"] >= 3, (k, r)
     for k, r in pick("gemm_split_small").items():

@@ -398,6 +398,12 @@ def test_gemm_epilogue_fuses_relu_dropout_backward_and_bias_gradient():
         assert np.array_equal(Cm, want)
         sums = np.stack([want[r:r + 64].astype(np.float64).sum(0) for r in range(0, 64 * nparts, 64)])
         np.testing.assert_allclose(part, sums, rtol=1e-5, atol=2e-4)
+        # ... and on two pieces (EMLOCO_GEMM_SPLIT2): the same epilogue around the two-piece product
+        Cm2 = np.full((m, n), 7.0, np.float32)
+        part_two = np.zeros_like(part)
+        lib.emu_gemm_relu_bwd_ex(m, n, k, P(A), k, P(B), n if tb else k, tb, P(Cm2), P(y), C.c_float(scale), P(part_two), SPLIT | 4096)
+        plain2 = _gemm(A[None], B[None], 0, tb, m, n, k, flags=SPLIT | 4096)[0]
+        assert np.array_equal(Cm2, np.where(y > 0, plain2 * scale, np.float32(0)).astype(np.float32)) and not np.array_equal(Cm2, Cm)
 
 
 def test_mfma_gemm_kernel_split_mode_is_fp32_class():
@@ -448,6 +454,17 @@ def test_mfma_gemm_kernel_split_mode_is_fp32_class():
         bias = rng.normal(size=n).astype(np.float32)
         got = _gemm(A, B, 0, 0, m, n, k, bias=bias, flags=SPLIT | 3, alpha=0.5)[0]
         np.testing.assert_allclose(got, np.maximum(0.5 * ref + bias, 0), rtol=0, atol=2e-6 * float(mag.max()))
+        # EMLOCO_GEMM_SPLIT2 (round 6: the backward's gradient products): TWO pieces per operand, the three piece products above 2^-16 --
+        # the dropped ones (a2 b2, a1 b3, a3 b1) are each at most 2^-16 of |a| |b|: error under 3 x 2^-16 of the magnitude sum, on every
+        # layout, both tiles (same bits), with split k; and well above the three-piece error (the kernel really runs on two)
+        SPLIT2 = 4096
+        for (a, b, ta, tb) in ((A, B, 0, 0), (At, Bt, 1, 1), (A, Bt, 0, 1), (At, B, 1, 0)):
+            got = _gemm(a, b, ta, tb, m, n, k, flags=SPLIT | SPLIT2)[0]
+            err = np.max(np.abs(got - ref) / mag)
+            assert 4 * plain_err + 2e-7 < err < 3 * 2.0 ** -16, ("two pieces", m, n, k, ta, tb, err)
+            assert np.array_equal(got, _gemm(a, b, ta, tb, m, n, k, flags=SPLIT | SPLIT2 | SMALL)[0]), ("two pieces, small tile bits", m, n, k, ta, tb)
+        got = _gemm(At, Bt, 1, 1, m, n, k, flags=SPLIT | SPLIT2, ksplit=3)[0]
+        assert np.max(np.abs(got - ref) / mag) < 3 * 2.0 ** -16
     # operands the split mode does not serve (unaligned, narrow n) fall back to the plain kernel: bit-equal to it
     A = rng.normal(size=(1, 70, 37)).astype(np.float32)
     B = rng.normal(size=(1, 50, 37)).astype(np.float32)
@@ -468,6 +485,12 @@ def test_mfma_gemm_kernel_split_mode_is_fp32_class():
         assert np.array_equal(Cm, want)
         sums = np.stack([want[r:r + 64].astype(np.float64).sum(0) for r in range(0, 64 * nparts, 64)])
         np.testing.assert_allclose(part, sums, rtol=1e-5, atol=2e-4)
+        # ... and on two pieces (EMLOCO_GEMM_SPLIT2): the same epilogue around the two-piece product
+        Cm2 = np.full((m, n), 7.0, np.float32)
+        part_two = np.zeros_like(part)
+        lib.emu_gemm_relu_bwd_ex(m, n, k, P(A), k, P(B), n if tb else k, tb, P(Cm2), P(y), C.c_float(scale), P(part_two), SPLIT | 4096)
+        plain2 = _gemm(A[None], B[None], 0, tb, m, n, k, flags=SPLIT | 4096)[0]
+        assert np.array_equal(Cm2, np.where(y > 0, plain2 * scale, np.float32(0)).astype(np.float32)) and not np.array_equal(Cm2, Cm)
         img = np.zeros(lib.emu_gemm_split_image_words(n, k), np.uint32)          # the weight as its piece image: same bits
         lib.emu_gemm_split_pack(P(B), n, k, n if tb else k, tb, C.c_void_p(img.ctypes.data))
         Cm2, part2 = np.full((m, n), 7.0, np.float32), np.zeros((nparts, n), np.float32)

@@ -178,6 +178,14 @@ def test_two_rank_emloco_trainer_equals_single_rank_on_the_concatenated_batch():
         tr.step(joints, masks, pad, random_masking=False)
     for k, v in model.state_dict().items():
         a, b = sd0[k], v.detach().cpu().numpy()
+        if k.endswith("self_attn.in_proj_bias"):
+            # the KEY third of the bias has no gradient at all (a constant added to every key shifts a query's scores by one number, which
+            # the softmax drops): what arrives is the rounding noise of the backward products, and Adam turns noise above its eps
+            # (1e-8) into steps of +-lr whatever its size -- two ranks and one process see different noise (round 6's two-piece backward:
+            # ~1e-7 where three pieces left ~1e-9).  Bound: 3 steps x lr; the query and value thirds compare like every other tensor.
+            d = a.shape[0] // 3
+            assert np.abs(a[d:2 * d] - b[d:2 * d]).max() <= 3 * _jta_cfg(dev)["TRAIN"]["lr"] * 1.01, (k, "key third")
+            a, b = np.concatenate([a[:d], a[2 * d:]]), np.concatenate([b[:d], b[2 * d:]])
         assert np.abs(a - b).max() <= 2e-5 + 2e-4 * np.abs(b).max(), (k, np.abs(a - b).max())
 
 

@@ -1098,13 +1098,17 @@ def test_flat_clip_adam_is_torch_adam_with_clip_grad_norm_and_trades_state_dicts
         oa2.step()
 
 
-def test_weight_piece_images_give_the_same_bits_as_the_matrices():
+@pytest.mark.parametrize("bwd_pieces", [3, 2])
+def test_weight_piece_images_give_the_same_bits_as_the_matrices(bwd_pieces, monkeypatch):
     """Round 5: in the split mode a linear layer can read its weight as a piece image (`ops.split_image`, EMLOCO_GEMM_B_SPLITIMG: the
     matrix cut into bf16 pieces once, not by each of the launch's workgroups; what the frozen policy's layers do, and the trained layers
     from EMLOCO_GEMM_WEIGHT_IMAGE_ROWS rows on) -- forward, input gradient, the feed-forward block's fused backward: outputs and all
-    gradients BIT-EQUAL to the same calls on the matrices (ragged row count, dropout on)."""
+    gradients BIT-EQUAL to the same calls on the matrices (ragged row count, dropout on).  Round 6: with the default two-piece backward
+    (`ops._BWD_PIECES`) the input-gradient products read the matrix (an image holds three pieces) -- the forward still reads the image;
+    with the three-piece backward every product of the block does."""
     from emloco_amd.predictor import ops
     dev = "cuda:0"
+    monkeypatch.setattr(ops, "_BWD_PIECES", {"dx": bwd_pieces, "dw": bwd_pieces})
     prev = ops._matmul_precision[0]
     ops.set_matmul_precision("fp32_split")
     try:
