@@ -853,8 +853,18 @@ __global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
     const long total = (long)g.batch * g.m * g.n;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
+    // (round 6: eight partials in flight per thread -- one load per iteration made a launch a chain of ksplit memory latencies, 41 us for
+    // the 25 MB of a weight gradient's 48 partial slabs; the additions keep their order, the bits are the same)
     float v = 0.0f;
-    for (int s = 0; s < g.ksplit; ++s) v += g.ws[(long)s * total + i];
+    int s = 0;
+    for (; s + 8 <= g.ksplit; s += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = g.ws[(long)(s + u) * total + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; s < g.ksplit; ++s) v += g.ws[(long)s * total + i];
     const int col = (int)(i % g.n);
     const long rowb = i / g.n;
     const int row = (int)(rowb % g.m);
@@ -1094,8 +1104,17 @@ __global__ void rows_fold_kernel(int n, int w, const float *in, float *out0, flo
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= w) return;
     const long r = blockIdx.y, i0 = r * FOLD;
+    // (round 6: all FOLD loads in flight, rows past the end read the last row and are not added -- the loop with its early exit was a chain of
+    // 32 dependent latencies; same order of additions)
+    float t[FOLD];
+#pragma unroll
+    for (int i = 0; i < FOLD; ++i) {
+        const long row = i0 + i < n ? i0 + i : (long)n - 1;
+        t[i] = in[row * w + j];
+    }
     float s = 0.0f;
-    for (int i = 0; i < FOLD && i0 + i < n; ++i) s += in[(i0 + i) * w + j];
+#pragma unroll
+    for (int i = 0; i < FOLD; ++i) s = (i0 + i < n) ? s + t[i] : s;
     if (j < split) out0[r * split + j] = s; else out1[r * (w - split) + (j - split)] = s;
 }
 inline long fold_workspace(long n, long w) { return (n + (n + FOLD - 1) / FOLD) * w; }
