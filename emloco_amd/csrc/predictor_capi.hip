@@ -307,6 +307,26 @@ int emloco_act_bwd_colsum(int m, int n, const float *dy, const float *y, int rel
     return 0;
 }
 
+int emloco_gather_flat(int n, const float *const *src, const int64_t *numel, const int64_t *dst_offset, float *flat, void *stream) {
+    if (n < 0 || (n > 0 && (!src || !numel || !dst_offset || !flat))) return pfail(-1, "emloco_gather_flat: bad argument");
+    for (int i0 = 0; i0 < n; i0 += GATHER_MAX) {
+        emloco::GatherArgs a;
+        const int m = n - i0 < GATHER_MAX ? n - i0 : GATHER_MAX;
+        long big = 0;
+        for (int i = 0; i < m; ++i) {
+            if (!src[i0 + i] || numel[i0 + i] < 0 || dst_offset[i0 + i] < 0) return pfail(-1, "emloco_gather_flat: null source or negative size / offset");
+            a.src[i] = src[i0 + i]; a.numel[i] = (long)numel[i0 + i]; a.off[i] = (long)dst_offset[i0 + i];
+            if (a.numel[i] > big) big = a.numel[i];
+        }
+        a.flat = flat;
+        long gx = (big / 4 + 255) / 256;                       // workgroups along the largest tensor: one 16-byte copy per thread, at most 64
+        gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+        hipLaunchKernelGGL(emloco::gather_flat_kernel, dim3((unsigned)gx, (unsigned)m), dim3(256), 0, (hipStream_t)stream, a);
+        PHIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
 int emloco_disc_reward(int n, const float *logits, float scale, float *reward, void *stream) {
     if (n < 1 || !logits || !reward) return pfail(-1, "emloco_disc_reward: bad argument");
     hipLaunchKernelGGL(emloco::disc_reward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, logits, scale, reward);

@@ -1201,6 +1201,23 @@ act_bwd_colsum_kernel(int m, int n, const float *dy, const float *y, int relu, f
     if (ph == 0 && j < n) part[(long)blockIdx.y * n + j] = (sh[0][jl] + sh[1][jl]) + (sh[2][jl] + sh[3][jl]);
 }
 
+// ------------------------------------------------------------------ gradients into the flat bucket (round 6)
+// flat[off[t] ..] = src[t][..] for the tensors of one table (blockIdx.y = tensor); 16-byte copies where both ends are aligned
+#define GATHER_MAX 96
+struct GatherArgs { const float *src[GATHER_MAX]; long numel[GATHER_MAX]; long off[GATHER_MAX]; float *flat; };
+__global__ void __launch_bounds__(256)
+gather_flat_kernel(GatherArgs a) {
+    const int t = blockIdx.y;
+    const long n = a.numel[t];
+    const float *s = a.src[t];
+    float *d = a.flat + a.off[t];
+    const bool v4 = ((((unsigned long long)s) | ((unsigned long long)d)) & 15ull) == 0ull;
+    const long n4 = v4 ? (n >> 2) : 0;
+    const long step = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) ((f32x4 *)d)[i] = ((const f32x4 *)s)[i];
+    for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += step) d[i] = s[i];
+}
+
 // ------------------------------------------------------------------ observation normaliser (policy input, A19)
 // RunningMeanStd.forward in eval mode (pacer/pacer/utils/running_mean_std.py:81-83):
 //   y = clamp((x - float(mean)) / sqrt(float(var) + eps), -5, 5)

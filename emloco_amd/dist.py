@@ -148,6 +148,32 @@ class FlatGradBucket:
     def zero(self):
         self.flat.zero_()
 
+    def release(self):
+        """Ahead of a backward pass: detach every parameter's .grad from the bucket.  With .grad aliasing its slice autograd's accumulation
+        node ADDS each incoming gradient into it -- one elementwise launch per parameter and step; with .grad = None it keeps the
+        incoming tensor and `gather` copies them all into their slices in one launch per 96 tensors (`emloco_gather_flat`)."""
+        for p in self.params:
+            p.grad = None
+
+    def gather(self):
+        """Behind the backward pass that followed `release`: the gradients autograd left on the parameters -> their slices of the flat
+        buffer (a parameter that received none keeps the zeros of `zero()`), and every .grad aliases its slice again."""
+        got = [(p.grad, o) for p, o in zip(self.params, self.offsets) if p.grad is not None]
+        if got and self.flat.is_cuda:
+            import ctypes as C
+            from .predictor import ops
+            src = [g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous() for g, _ in got]
+            n = len(src)
+            ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in src])
+            numel = (C.c_int64 * n)(*[t.numel() for t in src])
+            offs = (C.c_int64 * n)(*[o for _, o in got])
+            ops._chk(ops._lib().emloco_gather_flat(n, ptrs, numel, offs, C.c_void_p(self.flat.data_ptr()), ops._st(self.flat)), "emloco_gather_flat")
+        else:                                                 # host tensors (the multi-process CPU tests)
+            for g, o in got:
+                self.flat[o:o + g.numel()].copy_(g.reshape(-1))
+        for p, o in zip(self.params, self.offsets):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+
     def all_reduce(self, average=True):
         if is_distributed():
             all_reduce_(self.flat)

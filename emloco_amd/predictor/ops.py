@@ -71,6 +71,7 @@ def _lib():
         lib.emloco_adamw_gated.argtypes = [ci] + [vp] * 7 + [cf] * 5 + [vp, vp]
         lib.emloco_adam_clip_flat.argtypes = [C.c_int64] + [vp] * 4 + [cf, C.c_double, C.c_double] + [cf] * 5 + [vp, vp]
         lib.emloco_adam_clip_flat_counted.argtypes = [C.c_int64] + [vp] * 4 + [cf, C.c_double, C.c_double] + [cf] * 3 + [vp, vp, vp]
+        lib.emloco_gather_flat.argtypes = [ci, vp, vp, vp, vp, vp]
         lib.emloco_adam_clip_flat_workspace.argtypes = [C.c_int64]
         lib.emloco_gemm_split_image_words.argtypes = [C.c_int, C.c_int]
         lib.emloco_gemm_split_image_words.restype = C.c_int64

@@ -160,6 +160,9 @@ class EmLocoTrainer:
             self.bucket = FlatGradBucket(model.parameters()) if data_parallel else None
             self.optimizer = torch.optim.Adam(model.parameters(), lr=config["TRAIN"]["lr"])
         self.data_parallel = bool(data_parallel)
+        # the backward pass leaves its gradients on the parameters and ONE launch gathers them into the bucket (dist.FlatGradBucket.release /
+        # gather) instead of one accumulation launch per parameter (132 per step); EMLOCO_GATHER_GRADS=0: autograd's accumulation
+        self._gather_grads = os.environ.get("EMLOCO_GATHER_GRADS", "1") != "0"
 
     # what differs between train_jta.py and train_jrdb.py inside the loop body
     process_coords = staticmethod(batch_process_coords)
@@ -183,6 +186,8 @@ class EmLocoTrainer:
         self.model.train()
         if self.bucket is not None:
             self.bucket.zero()
+            if self._gather_grads:
+                self.bucket.release()
         else:
             self.optimizer.zero_grad(set_to_none=True)
         W = world_size() if self.data_parallel else 1
@@ -203,6 +208,8 @@ class EmLocoTrainer:
                 cnt = all_reduce_(cnt.detach().clone())
             loss = loss + vsum / cnt.clamp(min=1.0)
         loss.backward()
+        if self.bucket is not None and self._gather_grads:
+            self.bucket.gather()
         if self.data_parallel:
             self.bucket.all_reduce(average=False)
         if self.flat_adam:

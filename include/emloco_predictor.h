@@ -317,6 +317,13 @@ int emloco_adam_clip_flat(int64_t n, float *params, float *grads, float *exp_avg
 int emloco_adam_clip_flat_counted(int64_t n, float *params, float *grads, float *exp_avg, float *exp_avg_sq, float lr, double beta1, double beta2,
                                   float eps, float weight_decay, float max_norm, float *workspace, float *step_count, void *stream);
 
+/* (round 6) Gradient tensors into their slices of ONE flat buffer: flat[dst_offset[i] .. + numel[i]) = src[i][0 .. numel[i]) for i < n, in
+ * one launch per 96 tensors (the table travels in the kernel arguments).  src / numel / dst_offset are HOST arrays of DEVICE pointers /
+ * element counts / element offsets.  What it replaces: with every parameter's .grad aliasing the optimiser's flat bucket, autograd's
+ * accumulation node ADDS each incoming gradient into its slice -- one launch per parameter and step (132 in the JTA train step,
+ * train_jta.py:311-318); with .grad released ahead of the backward pass autograd only keeps the tensors, and this gathers them. */
+int emloco_gather_flat(int n, const float *const *src, const int64_t *numel, const int64_t *dst_offset, float *flat, void *stream);
+
 /* ---- PPO loss heads (round 5): the tail between the networks' outputs and the scalar loss of the PPO + AMP update
  * (amp_continuous.py:335-425, common_agent.py:426-468; neglogp / entropy / policy_kl of rl_games 1.1.4 as restated in
  * learning/amp_agent.py) -- ~140 elementwise / reduction launches per optimiser step in torch -- as one launch over the rows, one

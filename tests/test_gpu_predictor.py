@@ -542,6 +542,43 @@ def _jta_shaped_batch(B, seed, max_people=4):
     return joints, torch.ones(B, max_people, 21, 49), pad
 
 
+def test_gradients_gathered_into_the_flat_bucket_equal_autograds_accumulation():
+    """Round 6: the train step releases every parameter's .grad ahead of the backward pass and gathers the gradients autograd leaves on
+    the parameters into the optimiser's flat bucket with one launch per 96 tensors (`emloco_gather_flat`, dist.FlatGradBucket.release /
+    gather) instead of one accumulation launch per parameter.  `emloco_gather_flat` alone (ragged sizes, unaligned slices, more tensors
+    than one table holds), then the shipped-depth trainer: three steps with and without it leave the SAME weights (0 + g = g)."""
+    import ctypes as C
+    from emloco_amd.predictor import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(5)
+    sizes = [int(v) for v in torch.randint(1, 700, (230,), generator=g)] + [131072, 4, 3]
+    srcs = [torch.randn(n, generator=g).to(dev) for n in sizes]
+    offs, o = [], 5
+    for n in sizes:
+        offs.append(o)
+        o += n + int(torch.randint(0, 3, (1,), generator=g))
+    flat = torch.full((o + 7,), 7.0, device=dev)
+    n = len(srcs)
+    rc = ops._lib().emloco_gather_flat(n, (C.c_void_p * n)(*[t.data_ptr() for t in srcs]), (C.c_int64 * n)(*sizes), (C.c_int64 * n)(*offs),
+                                       C.c_void_p(flat.data_ptr()), ops._st(flat))
+    assert rc == 0
+    want = torch.full_like(flat, 7.0)
+    for t, off in zip(srcs, offs):
+        want[off:off + t.numel()] = t
+    assert torch.equal(flat, want)
+    joints, masks, pad = _jta_shaped_batch(8, 3)
+    sds = []
+    for gather in (True, False):
+        tr, _ = _shipped_trainer(dev, multi=False, lr=1e-3, seed=11)
+        assert tr._gather_grads
+        tr._gather_grads = gather
+        for _ in range(3):
+            tr.step(joints, masks, pad, random_masking=False)
+        tr.optimizer._check_aliasing()
+        sds.append({k: v.detach().clone() for k, v in tr.model.state_dict().items()})
+    assert all(torch.equal(sds[0][k], sds[1][k]) for k in sds[0])
+
+
 def test_configs3_batch_256_shipped_depth_train_step_properties():
     """configs[3] under -m gpu: the shipped 6 + 3-layer model, EmLoco loss (valueloss_w = 1), batch 256 (1 - 4 people per scene,
     padded).  Properties that do not need the reference: every output finite; the loss of the batch equals the mean of the
