@@ -255,6 +255,12 @@ class AMPAgent:
         # the loss heads as fused launches (learning/ppo_heads.py); EMLOCO_PPO_HEADS=0 / CPU tensors: the torch expressions
         self._fused_heads = self.device.type == "cuda" and os.environ.get("EMLOCO_PPO_HEADS", "1") != "0"
         self._head_kl = None
+        # EMLOCO_PPO_GATHER_GRADS=1: autograd keeps the step's gradients and one launch per 96 tensors gathers them into the flat bucket
+        # (dist.FlatGradBucket.release / gather, `emloco_gather_flat`: what the predictor's train step does) instead of one accumulation
+        # launch per parameter.  Off here: the large weights already accumulate in their GEMMs' epilogues (mark_direct_grad below) and the
+        # captured step pays nothing per launch -- measured 3.14-3.17 ms per optimiser step without, 3.23-3.24 with
+        # (profiles/r06_ab_ppo_gather.txt)
+        self._gather_grads = self.device.type == "cuda" and os.environ.get("EMLOCO_PPO_GATHER_GRADS", "0") == "1"
         if self._flat_adam:
             from ..predictor.fused_adam import FlatClipAdam
             trainable = [p for p in self.a2c_network.parameters() if p.requires_grad]
@@ -592,7 +598,11 @@ class AMPAgent:
         self.set_train()
         loss, info, mu, sigma = self.compute_loss(d)
         self.bucket.zero()                                         # the .grad of every parameter aliases the flat bucket
+        if self._gather_grads:
+            self.bucket.release()                                  # (autograd keeps the gradients; one launch gathers them: dist.FlatGradBucket)
         loss.backward()
+        if self._gather_grads:
+            self.bucket.gather()
         self.bucket.all_reduce(average=True)                       # no-op on one rank
         self._clip_and_step()
         with torch.no_grad():
@@ -621,8 +631,12 @@ class AMPAgent:
             if self._amp_dropout:
                 masks = amp_dropout_expand(self._g_u, self.task._num_amp_obs_steps)
             self.bucket.zero()                                   # (ahead of the fork: the branches' backward passes write into it)
+            if self._gather_grads:
+                self.bucket.release()
             loss, info, mu, sigma = self.compute_loss(d, dropout_masks=masks, branch_streams=self._branch_streams())
             loss.backward()
+            if self._gather_grads:
+                self.bucket.gather()                             # (the engine has joined the arms' streams into this one by now)
             if part == "grad":
                 self._g_mid = (loss.detach(), {k: v.detach() for k, v in info.items()}, mu.detach(), sigma.detach())   # static tensors of the graphs' pool
                 return None
