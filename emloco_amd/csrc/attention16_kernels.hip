@@ -248,12 +248,18 @@ __device__ __forceinline__ void a16_keep16(const AttnArgs &a, unsigned hkey, int
             keep[2 * j] = (x & 0xffffu) >= thr; keep[2 * j + 1] = (x >> 16) >= thr;
         }
     } else {
+        // (round 6) The lanes of a pair (own, own ^ 1: an even key and the odd one behind it -- adjacent lanes) share the key pair and
+        // the tile's 16 queries, i.e. all 16 hashes: each is computed ONCE per pair -- the even lane takes registers 0 .. 7, the odd
+        // lane 8 .. 15 (the same queries 16 rows further on) -- and read by both through DPP (quad_perm [0,0,2,2] / [1,1,3,3]).
         const unsigned kk = drop_mul24((unsigned)own >> 1, 0xC2B2AFu);            // (drop_hash's column term: the lane's own key)
-        const unsigned q0k = hkey + (unsigned)(t0 + 4 * hi) * 0x85EBCA6Bu;        // one slow multiply per tile; the registers' queries add constants
+        const unsigned q0k = hkey + (unsigned)(t0 + 4 * hi + 16 * (own & 1)) * 0x85EBCA6Bu;   // one slow multiply per tile; the registers' queries add constants
         #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned x = drop_mix24((q0k + (unsigned)((r & 3) + 8 * (r >> 2)) * 0x85EBCA6Bu) ^ kk);
-            keep[r] = ((own & 1) ? (x >> 16) : (x & 0xffffu)) >= thr;
+        for (int j = 0; j < 8; ++j) {
+            const unsigned xc = drop_mix24((q0k + (unsigned)((j & 3) + 8 * (j >> 2)) * 0x85EBCA6Bu) ^ kk);
+            const unsigned xa = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xc, 0xA0, 0xF, 0xF, false);   // the even lane's: register j
+            const unsigned xb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xc, 0xF5, 0xF, 0xF, false);   // the odd lane's: register 8 + j
+            keep[j] = ((own & 1) ? (xa >> 16) : (xa & 0xffffu)) >= thr;
+            keep[8 + j] = ((own & 1) ? (xb >> 16) : (xb & 0xffffu)) >= thr;
         }
     }
 }
