@@ -221,7 +221,11 @@ def gemm_peak(ops):
     if ops.get_matmul_precision() == "fp32_split":
         return round(MFMA_BF16_PEAK_TFLOPS / 6.0, 1), ("fp32-class products from three bf16 pieces per operand: six v_mfma_f32_32x32x16_bf16 per 16 k, fp32 "
                                                        "accumulation, error against float64 at or below the fp32 matrix instruction's (profiles/r03_gemm_split.txt); "
-                                                       "peak = dense bf16 matrix peak / 6 piece products; the fp32 matrix instruction's own peak is 157.3")
+                                                       "peak = dense bf16 matrix peak / 6 piece products; the fp32 matrix instruction's own peak is 157.3.  Round 6: "
+                                                       "the FORWARD runs on three pieces (logits 5e-7 of the reference's); the backward's gradient products (attention "
+                                                       "dQ / dK / dV, dx, dW) on TWO pieces = three piece products (gradients 4-9e-6 of a tensor's scale next to the loss, "
+                                                       "bar 2e-4: profiles/r06_ab_bwd_pieces.txt; EMLOCO_BWD_PIECES=3 EMLOCO_ATTN_BWD_PIECES=3 restore three) -- the "
+                                                       "peak quoted here stays the six-product one, so the backward launches count against a ceiling they do not have")
     return 157.3, "fp32-in fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32), peak = fp32 matrix peak"
 
 
@@ -261,6 +265,7 @@ def jta_leg(dev, steps=10, warmup=2, B=256, rank=0, world=1):
                                   + (f", data-parallel x{world} (256 per GPU)" if world > 1 else ""),
                       "batch": B, "people_padded": int(joints.shape[1]), "tokens_per_person": 453},
            "precision": ops.get_matmul_precision(),
+           "backward_pieces": {"attention": int(os.environ.get("EMLOCO_ATTN_BWD_PIECES", "2")), **ops.backward_pieces()},
            # The step's GEMM launches as a class (45 % of its kernel time; the fused attention, VALU / matrix bound, is the other half and
            # is reported under `attention`).  Their reductions are short (K = 128 for five of the seven products of a layer) and their
            # outputs large: what bounds them is data movement, not the matrix pipe (round-4 review) -- hence `bound: hbm`.

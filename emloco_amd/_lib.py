@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libemloco_hip.so")
+LIB_PATH = os.environ.get("EMLOCO_LIB") or os.path.join(HERE, "lib", "libemloco_hip.so")     # (EMLOCO_LIB: another build of the library, for A/B runs)
 
 NB, NDOF, MAXC, MAXCAND = 24, 69, 20, 96
 SELF_OBS, TRAJ_SAMPLES, TRAJ_VERTS, HEIGHT_POINTS = 368, 15, 101, 1024

@@ -409,6 +409,10 @@ attn16_bwd_dq_kernel(AttnArgs a) {
     }
     const float scale2 = a.scale * A16_LOG2E;
     const float dscale = DROP ? a.drop_scale : 1.0f;
+    const float sds = a.scale * dscale;
+    float nsd[G];
+    #pragma unroll
+    for (int g = 0; g < G; ++g) nsd[g] = 0.0f - a.scale * dsum[g];
     const int ntiles = (a.S + AT_T - 1) / AT_T;
     const int sr = tid >> 3, sp = tid & 7, t31 = tid & 31;
     const float *kbp = kb ? kb : a.qkv;
@@ -442,12 +446,14 @@ attn16_bwd_dq_kernel(AttnArgs a) {
                 float ds[16];
                 bool keep[16];
                 if (DROP) a16_keep16<true>(a, hkey, query[g], k0, hi, keep);
+                // dS = scale p (keep dP / (1 - p_drop) - D) as p * fma(keep dP, scale / (1 - p_drop), -scale D): the two constants are
+                // formed once per launch / block (round 6: three multiplies and a subtraction per entry were five of its eight instructions)
                 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float p = A16_EXP2(fmaf(st[r], scale2, bias[r]) - lse2[g]);       // masked key: -inf -> 0; row past the end: lse = 3e38 -> 0
-                    float dpr = dpt[r] * dscale;                                      // d loss / d (dropped probability)
+                    float dpr = dpt[r];                                               // d loss / d (dropped probability), before its scale
                     if (DROP) dpr = keep[r] ? dpr : 0.0f;
-                    ds[r] = a.scale * p * (dpr - dsum[g]);
+                    ds[r] = p * fmaf(dpr, sds, nsd[g]);
                 }
                 A16Frag<NP> db[2];
                 a16_pack16<NP>(ds, db);
@@ -483,6 +489,9 @@ attn16_bwd_dkv_kernel(AttnArgs a) {
     const float *dO = a.dout + (long)b * a.Sq * a.d_model + hd * AT_DH;
     const float *lse = a.lse + (long)bh * a.Sq, *dsm = a.dsum + (long)bh * a.Sq;
     const int k0w = blockIdx.x * (128 * G) + wave * (32 * G);
+    const float dscale = DROP ? a.drop_scale : 1.0f;
+    const float ldsc = DROP ? log2f(a.drop_scale) : 0.0f;      // log2 of the dropout scale: rides in the key's bias
+    const float dfac = 0.0f - a.scale / dscale;                 // staged D -> -D scale (1 - p_drop)
     int key[G];
     A16Frag<NP> kf[G][2], vf[G][2];
     bool live[G];
@@ -495,12 +504,11 @@ attn16_bwd_dkv_kernel(AttnArgs a) {
         a16_own_row<NP, MEM16>(K, ld, key[g], a.S, hi, kf[g], nullptr);
         a16_own_row<NP, MEM16>(V, ld, key[g], a.S, hi, vf[g], nullptr);
         bias2[g] = -INFINITY;
-        if (key[g] < a.S) bias2[g] = a.key_bias ? a.key_bias[(long)b * a.S + key[g]] * A16_LOG2E : 0.0f;
+        if (key[g] < a.S) bias2[g] = (a.key_bias ? a.key_bias[(long)b * a.S + key[g]] * A16_LOG2E : 0.0f) + ldsc;
         #pragma unroll
         for (int r = 0; r < 16; ++r) { acc_k[g][r] = 0.0f; acc_v[g][r] = 0.0f; }
     }
     const float scale2 = a.scale * A16_LOG2E;
-    const float dscale = DROP ? a.drop_scale : 1.0f;
     const int ntiles = (a.Sq + AT_T - 1) / AT_T;               // walks the live queries
     const int sr = tid >> 3, sp = tid & 7, t31 = tid & 31;
     a16_u32x2 rq[NP], ro[NP];
@@ -508,7 +516,7 @@ attn16_bwd_dkv_kernel(AttnArgs a) {
     a16_fetch4<NP, 0>(dO, (long)(sr < a.Sq ? sr : a.Sq - 1) * a.d_model + 4 * sp, sr < a.Sq, ro);
     float rl = lse[t31 < a.Sq ? t31 : a.Sq - 1], rd = dsm[t31 < a.Sq ? t31 : a.Sq - 1];
     a16_put_rows<NP>(Qr[0], sr, sp, rq); a16_put_cols<NP>(Qc[0], sr, sp, rq); a16_put_rows<NP>(Or[0], sr, sp, ro); a16_put_cols<NP>(Oc[0], sr, sp, ro);
-    if (tid < AT_T) { Ls[0][tid] = tid < a.Sq ? rl * A16_LOG2E : 3.0e38f; Ds[0][tid] = tid < a.Sq ? rd : 0.0f; }
+    if (tid < AT_T) { Ls[0][tid] = tid < a.Sq ? rl * A16_LOG2E : 3.0e38f; Ds[0][tid] = tid < a.Sq ? rd * dfac : 0.0f; }
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1, q0 = t * AT_T, q0n = q0 + AT_T;
@@ -535,13 +543,16 @@ attn16_bwd_dkv_kernel(AttnArgs a) {
                 float p[16], ds[16];
                 bool keep[16];
                 if (DROP) a16_keep16<false>(a, hkey, key[g], q0, hi, keep);
+                // (round 6) the probability arrives scaled by 1 / (1 - p_drop) -- its logarithm rides in the key's bias -- as dV wants
+                // it; dS = scale p (keep dP / (1 - p_drop) - D) is then p' * fma(keep dP, scale, -D scale (1 - p_drop)), the second
+                // constant folded into the staged D: four multiplies and a subtraction per entry become one fma and one multiply
                 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pr = A16_EXP2(fmaf(s[r], scale2, bias2[g]) - lrow[r]);     // rows past the sequence carry lse = 3e38 -> 0
-                    float dpr = dp[r] * dscale;
+                    const float pr = A16_EXP2(fmaf(s[r], scale2, bias2[g]) - lrow[r]);     // p / (1 - p_drop); rows past the sequence carry lse = 3e38 -> 0
+                    float dpr = dp[r];
                     if (DROP) dpr = keep[r] ? dpr : 0.0f;
-                    ds[r] = a.scale * pr * (dpr - drow[r]);
-                    p[r] = DROP ? (keep[r] ? pr * dscale : 0.0f) : pr;                     // dV sums the dropped probabilities
+                    ds[r] = pr * fmaf(dpr, a.scale, drow[r]);
+                    p[r] = DROP ? (keep[r] ? pr : 0.0f) : pr;                             // dV sums the dropped probabilities
                 }
                 {
                     A16Frag<NP> pb[2];
@@ -558,7 +569,7 @@ attn16_bwd_dkv_kernel(AttnArgs a) {
             }
         }
         a16_put_rows<NP>(Qr[buf ^ 1], sr, sp, rq); a16_put_cols<NP>(Qc[buf ^ 1], sr, sp, rq); a16_put_rows<NP>(Or[buf ^ 1], sr, sp, ro); a16_put_cols<NP>(Oc[buf ^ 1], sr, sp, ro);
-        if (tid < AT_T) { Ls[buf ^ 1][tid] = q0n + tid < a.Sq ? rl * A16_LOG2E : 3.0e38f; Ds[buf ^ 1][tid] = q0n + tid < a.Sq ? rd : 0.0f; }
+        if (tid < AT_T) { Ls[buf ^ 1][tid] = q0n + tid < a.Sq ? rl * A16_LOG2E : 3.0e38f; Ds[buf ^ 1][tid] = q0n + tid < a.Sq ? rd * dfac : 0.0f; }
         __syncthreads();
     }
     // rows that do not attend (the live-query form, Sq < S) get dQ = 0 here -- every row of the sequence is a key of this kernel; the

@@ -416,7 +416,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
     static_assert(PREC != 2 || (GBK == 16 && (BM == 128 || BM == 64) && (BN == 128 || BN == 64) && VEC == 1 && IOA == 0 && (IOB == 0 || IOB == 2)),
                   "split mode: 128 / 64-row x 16 stages, fp32 operands (or B as its piece image), 16-byte loads");
     static_assert(IOB != 2 || PREC == 2, "the piece image is the split mode's");
-    constexpr int SA = PREC == 2 ? split_stage_words(BM) : BM * GLDK, SB = PREC == 2 ? split_stage_words(BN) : BN * GLDK;
+#ifndef GEMM_SPLIT2_PLANES
+#define GEMM_SPLIT2_PLANES 3                                  /* LDS planes allocated per stage by the two-piece kernels (2: a fourth workgroup per CU fits) */
+#endif
+    constexpr int NPL = NPC == 2 ? GEMM_SPLIT2_PLANES : 3;
+    constexpr int SA = PREC == 2 ? NPL * split_plane_words(BM) : BM * GLDK, SB = PREC == 2 ? NPL * split_plane_words(BN) : BN * GLDK;
     __shared__ __attribute__((aligned(16))) float As[2][SA], Bs[2][SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -741,11 +745,14 @@ template <int TB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 gemm_split_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, 0, TB, 1, 2, 1, 0, 0, 0>(g); }
 // two pieces per operand (EMLOCO_GEMM_SPLIT2, round 6): the gradient products of the backward pass
+#ifndef GEMM_SPLIT2_WAVES
+#define GEMM_SPLIT2_WAVES 3
+#endif
 template <int TA, int TB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GEMM_SPLIT2_WAVES, GEMM_SPLIT2_WAVES)))
 gemm_split2_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, TA, TB, 1, 2, 0, 0, 0, 0, 2>(g); }
 template <int TB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GEMM_SPLIT2_WAVES, GEMM_SPLIT2_WAVES)))
 gemm_split2_relu_bwd_kernel(GemmArgs g) { gemm_body<2, 2, 2, 2, 16, 0, TB, 1, 2, 1, 0, 0, 0, 2>(g); }
 template <int TA, int TB>
 __global__ void __launch_bounds__(256)

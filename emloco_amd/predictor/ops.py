@@ -120,6 +120,11 @@ _BWD_PIECES = {"dx": int(os.environ.get("EMLOCO_BWD_PIECES_DX", os.environ.get("
                "dw": int(os.environ.get("EMLOCO_BWD_PIECES_DW", os.environ.get("EMLOCO_BWD_PIECES", "2")))}
 
 
+def backward_pieces():
+    """{"dx": 2 | 3, "dw": 2 | 3}: pieces per operand of the split mode's gradient GEMMs (see above)."""
+    return dict(_BWD_PIECES)
+
+
 def _bwd_flags(kind):
     return GEMM_SPLIT2 if _BWD_PIECES[kind] == 2 else 0
 # Frozen weights (the rollout's policy and discriminator) are cut into their bf16 pieces ONCE, when first used (learning/policy_runner.py:
