@@ -220,3 +220,33 @@ def test_bench_summary_is_a_compact_digest_of_every_leg():
     assert sm["configs2_policy_disc_locoval_fit"] == 4.78e6 and sm["ppo_update_ms_per_optimizer_step"] == 3.4 and sm["jta_steps_timed"] == 10
     assert sm["headline_env_steps_per_s"] == 9.3e6 and "cpu_baseline_env_steps_per_s" not in sm          # absent legs are left out
     assert len(json.dumps(sm)) < 1000
+
+
+def test_flat_grad_bucket_release_and_gather_on_host_tensors():
+    """Round 6: `FlatGradBucket.release()` detaches every .grad ahead of a backward pass (autograd then KEEPS the incoming gradients
+    instead of adding each into its slice) and `gather()` copies them into the bucket and re-aliases every .grad -- same bucket contents
+    as the accumulate-into-views way, a parameter without a gradient keeps its zeros.  (Host tensors: the path of the multi-process CPU
+    tests; on the GPU one `emloco_gather_flat` launch per 96 tensors does the copies, tests/test_gpu_predictor.py.)"""
+    import torch
+    from emloco_amd.dist import FlatGradBucket
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2))]
+    x = torch.randn(5)
+
+    def loss_of():
+        return (ps[0].t() @ x).sum() * 2.0 + (ps[1] ** 2).sum()          # ps[2] gets no gradient
+
+    b = FlatGradBucket(ps, align=4)
+    b.zero()
+    loss_of().backward()
+    want = b.flat.clone()
+    b.zero()
+    b.release()
+    assert all(p.grad is None for p in ps)
+    loss_of().backward()
+    assert ps[2].grad is None and ps[0].grad.data_ptr() != b.flat.data_ptr()
+    b.gather()
+    assert torch.equal(b.flat, want) and want.abs().sum() > 0
+    for p, o in zip(b.params, b.offsets):
+        assert p.grad.data_ptr() == b.flat.data_ptr() + 4 * o and p.grad.shape == p.shape
+    assert torch.equal(ps[2].grad, torch.zeros(2, 2))
