@@ -169,6 +169,17 @@ class LocoValRollout:
         if self._fit_every > 1:
             self._nbuf = max(self._nbuf, 2 * self._fit_every)
         self._pending = []                                 # staging sets whose fits have not been issued yet, in step order
+        # Host-side readers of the LocoVal network that do not go through this loop (a checkpoint save mid-epoch, `state_dict()` of the
+        # value net) would see a network up to `_fit_every` - 1 fits behind: its state_dict waits for the pending fits first.
+        if self._fit_every > 1 and hasattr(self.valuenet, "register_state_dict_pre_hook"):
+            import weakref
+            me = weakref.ref(self)
+
+            def _flush_before_state_dict(*_a, **_k):
+                loop = me()
+                if loop is not None and getattr(loop, "_pending", None):
+                    loop._sync_fit()
+            self.valuenet.register_state_dict_pre_hook(_flush_before_state_dict)
         stage_keys = ("traj13", "pose", "vel", "target", "weight")
         self._stage = [{k: (z[k] if i == 0 else torch.zeros_like(z[k])) for k in stage_keys} for i in range(self._nbuf)]
         self._ev_fits = [torch.cuda.Event() for _ in range(self._nbuf)] if self._side is not None else []

@@ -829,6 +829,41 @@ def test_locoval_fit_in_groups_of_steps_gives_the_per_step_network_after_every_e
 
 
 @pytest.mark.gpu
+def test_state_dict_of_the_value_net_mid_epoch_waits_for_the_pending_fits(monkeypatch):
+    """With the fits issued in groups (EMLOCO_FIT_EVERY = 4) up to three steps' fits are not issued yet between two steps: a host-side
+    reader that does not go through the loop -- `valuenet.state_dict()` for a checkpoint -- flushes them first (round 6: a state_dict
+    pre-hook) and sees the per-step loop's network of that step."""
+    from emloco_amd.learning.locoval_rollout import LocoValRollout
+    from emloco_amd.run import RLGPUEnv
+    E, snaps = 256, []
+    for every in ("1", "4"):
+        monkeypatch.setenv("EMLOCO_FIT_EVERY", every)
+        env = RLGPUEnv(_make_env(E, ["--random_heading", "--init_heading", "--heading_inversion", "--adjust_root_vel",
+                                     "--input_init_pose", "--input_init_vel"]))
+        task = env.env.task
+        g = torch.Generator(device=task.device)
+        g.manual_seed(78)
+        pool = torch.randn(8, E, 69, device=task.device, generator=g) * 0.3
+        k, holder, got = [0], [], []
+
+        def pol(obs):
+            k[0] += 1
+            if k[0] in (11, 22):                            # mid-epoch (horizon 8): behind 2 resp. 5 steps of the epoch
+                got.append((len(holder[0]._pending), {n: v.clone() for n, v in holder[0].valuenet.state_dict().items()}, len(holder[0]._pending)))
+            return pool[k[0] % 8]
+        torch.manual_seed(6)
+        agent = LocoValRollout(env, horizon_length=8, policy=pol, overlap_reset=False, warmup_epochs=3, max_epochs=40)
+        holder.append(agent)
+        for _ in range(3):
+            agent.play_steps()
+        snaps.append(got)
+        agent.detach()
+    assert any(before > 0 for before, _, _ in snaps[1]) and all(after == 0 for _, _, after in snaps[1])     # fits WERE pending, and were flushed
+    for (_, a, _), (_, b, _) in zip(snaps[0], snaps[1]):
+        assert a.keys() == b.keys() and all(torch.equal(a[n], b[n]) for n in a)
+
+
+@pytest.mark.gpu
 def test_return_bookkeeping_inside_the_flags_launch_fits_the_same_network(monkeypatch):
     """The LocoVal return bookkeeping as part of the task's flags launch (emloco_task_post_physics_returns; LocoValRollout without a
     discriminator attaches its EmlocoLocoValStep to the task) against the launch of its own (EMLOCO_RETURNS_IN_FLAGS=0): same seeds,
