@@ -234,32 +234,37 @@ __device__ __forceinline__ void a16_halves(float x, float &u, float &v) {
 #endif
 // keep factors (1 / 0) of a lane's 16 entries of a tile: entry r = (tile row kappa(r, hi), own row) -- `rows_are_keys`: the tile's rows
 // are keys and the lane's own row is the query (forward, dQ), else the tile's rows are queries and the own row is a key (dK / dV).
-// One hash serves two adjacent KEYS (at_keep_bit): with keys along the registers that is registers (2 j, 2 j + 1); with queries along
-// the registers every register has its own hash.
+// One hash serves four adjacent KEYS, a byte each (at_keep_bit): with keys along the registers that is registers 4 q .. 4 q + 3 (keys
+// 8 q + 4 hi + 0 .. 3 of the tile); with queries along the registers every register has its own hash -- which the four lanes of a
+// quad (keys own & ~3 .. + 3) share: each computes four of them and all read them through DPP.
 template <bool ROWS_ARE_KEYS>
 __device__ __forceinline__ void a16_keep16(const AttnArgs &a, unsigned hkey, int own, int t0, int hi, bool (&keep)[16]) {
-    const unsigned thr = a.drop_thr >> 8;
+    const unsigned thr = a.drop_thr;
     if (ROWS_ARE_KEYS) {
         const unsigned qk = hkey + (unsigned)own * 0x85EBCA6Bu;
         #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned key = (unsigned)(t0 + at_kappa(2 * j, hi));
-            const unsigned x = drop_hash(qk, key >> 1);
-            keep[2 * j] = (x & 0xffffu) >= thr; keep[2 * j + 1] = (x >> 16) >= thr;
+        for (int q = 0; q < 4; ++q) {
+            const unsigned x = drop_hash(qk, (unsigned)((t0 >> 2) + 2 * q + hi));
+            #pragma unroll
+            for (int e = 0; e < 4; ++e) keep[4 * q + e] = ((x >> (8 * e)) & 0xffu) >= thr;
         }
     } else {
-        // (round 6) The lanes of a pair (own, own ^ 1: an even key and the odd one behind it -- adjacent lanes) share the key pair and
-        // the tile's 16 queries, i.e. all 16 hashes: each is computed ONCE per pair -- the even lane takes registers 0 .. 7, the odd
-        // lane 8 .. 15 (the same queries 16 rows further on) -- and read by both through DPP (quad_perm [0,0,2,2] / [1,1,3,3]).
-        const unsigned kk = drop_mul24((unsigned)own >> 1, 0xC2B2AFu);            // (drop_hash's column term: the lane's own key)
-        const unsigned q0k = hkey + (unsigned)(t0 + 4 * hi + 16 * (own & 1)) * 0x85EBCA6Bu;   // one slow multiply per tile; the registers' queries add constants
+        const unsigned kk = drop_mul24((unsigned)own >> 2, 0xC2B2AFu);            // (drop_hash's column term: the lane's own key quad)
+        const int e = own & 3;                                                     // = lane & 3: which of the quad's lanes this is, and its byte
+        const unsigned q0k = hkey + (unsigned)(t0 + 4 * hi + 8 * e) * 0x85EBCA6Bu; // one slow multiply per tile; the registers' queries add constants
+        unsigned xc[4];
         #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned xc = drop_mix24((q0k + (unsigned)((j & 3) + 8 * (j >> 2)) * 0x85EBCA6Bu) ^ kk);
-            const unsigned xa = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xc, 0xA0, 0xF, 0xF, false);   // the even lane's: register j
-            const unsigned xb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xc, 0xF5, 0xF, 0xF, false);   // the odd lane's: register 8 + j
-            keep[j] = ((own & 1) ? (xa >> 16) : (xa & 0xffffu)) >= thr;
-            keep[8 + j] = ((own & 1) ? (xb >> 16) : (xb & 0xffffu)) >= thr;
+        for (int j = 0; j < 4; ++j) xc[j] = drop_mix24((q0k + (unsigned)j * 0x85EBCA6Bu) ^ kk);     // registers 4 e + j: queries t0 + 4 hi + 8 e + j
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned x0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xc[j], 0x00, 0xF, 0xF, false);   // quad lane 0's: register j
+            const unsigned x1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xc[j], 0x55, 0xF, 0xF, false);   // lane 1's: register 4 + j
+            const unsigned x2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xc[j], 0xAA, 0xF, 0xF, false);   // lane 2's: register 8 + j
+            const unsigned x3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xc[j], 0xFF, 0xF, 0xF, false);   // lane 3's: register 12 + j
+            keep[j] = ((x0 >> (8 * e)) & 0xffu) >= thr;
+            keep[4 + j] = ((x1 >> (8 * e)) & 0xffu) >= thr;
+            keep[8 + j] = ((x2 >> (8 * e)) & 0xffu) >= thr;
+            keep[12 + j] = ((x3 >> (8 * e)) & 0xffu) >= thr;
         }
     }
 }

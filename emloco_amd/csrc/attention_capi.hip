@@ -54,7 +54,7 @@ int emloco_attention_fwd_queries(int n_seq, int S, int n_query, int nhead, int d
     if (n_seq < 1 || S < 1 || nhead < 1 || d_model != nhead * AT_DH || !qkv || !out || !lse || !(drop_p >= 0.0f && drop_p < 1.0f))
         return pfail(-1, "emloco_attention_fwd: bad argument (head dim must be 32, 0 <= drop_p < 1)");
     if ((long)n_seq * nhead > 65535) return pfail(-1, "emloco_attention_fwd: n_seq * nhead exceeds the grid limit");
-    emloco::AttnArgs a{n_seq, S, nhead, d_model, n_query, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr, drop_p, 1.0f / (1.0f - drop_p), drop_seed, (unsigned)(drop_p * 16777216.0f)};
+    emloco::AttnArgs a{n_seq, S, nhead, d_model, n_query, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr, drop_p, emloco::at_drop_scale(drop_p), drop_seed, emloco::at_drop_thr8(drop_p)};
     const dim3 grid((unsigned)((n_query + 127) / 128), (unsigned)(n_seq * nhead));
     const bool bf = (flags & EMLOCO_ATTN_BF16) != 0, dr = drop_p > 0.0f;
     hipStream_t st = (hipStream_t)stream;
@@ -118,7 +118,7 @@ int emloco_attention_bwd_queries(int n_seq, int S, int n_query, int nhead, int d
         return pfail(-1, "emloco_attention_bwd: bad argument (head dim must be 32; dsum = n_seq * nhead * S floats; 0 <= drop_p < 1)");
     if ((long)n_seq * nhead > 65535) return pfail(-1, "emloco_attention_bwd: n_seq * nhead exceeds the grid limit");
     emloco::AttnArgs a{n_seq, S, nhead, d_model, n_query, scale, qkv, key_bias, const_cast<float *>(out), const_cast<float *>(lse), dout, dqkv, dsum,
-                       drop_p, 1.0f / (1.0f - drop_p), drop_seed, (unsigned)(drop_p * 16777216.0f)};
+                       drop_p, emloco::at_drop_scale(drop_p), drop_seed, emloco::at_drop_thr8(drop_p)};
     const dim3 grid((unsigned)((S + 127) / 128), (unsigned)(n_seq * nhead)), qgrid((unsigned)((n_query + 127) / 128), (unsigned)(n_seq * nhead));
     const bool bf = (flags & EMLOCO_ATTN_BF16) != 0, dr = drop_p > 0.0f;
     hipStream_t st = (hipStream_t)stream;
@@ -195,7 +195,7 @@ int emloco_attention_bwd_queries(int n_seq, int S, int n_query, int nhead, int d
 
 int emloco_attention_keep_mask(uint32_t seed, int n_seq_heads, int S, float p, uint8_t *host_out) {
     if (n_seq_heads < 1 || S < 1 || !host_out || !(p >= 0.0f && p < 1.0f)) return pfail(-1, "emloco_attention_keep_mask: bad argument");
-    const unsigned thr = (unsigned)(p * 16777216.0f);
+    const unsigned thr = emloco::at_drop_thr8(p);
     for (int bh = 0; bh < n_seq_heads; ++bh) {
         const unsigned hk = emloco::at_head_key(seed, (unsigned)bh);
         for (int q = 0; q < S; ++q)

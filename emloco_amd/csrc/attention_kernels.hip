@@ -52,22 +52,31 @@ struct AttnArgs {
     // dropout on the attention probabilities (nn.MultiheadAttention(dropout=p) in training mode): probability (head-sequence bh,
     // query, key) is kept iff at_keep_bit(...) below (a 32-bit counter hash shared by two adjacent keys: ~5 integer operations per element)
     // and scaled by 1 / (1 - p).  The softmax normaliser uses the undropped probabilities; the backward recomputes the mask.
-    float drop_p, drop_scale;
-    unsigned drop_seed, drop_thr;   // drop_thr = (unsigned)(p * 2^24)
+    float drop_p, drop_scale;       // drop_scale = 256 / (256 - drop_thr): the scale of the probability the mask REALISES (at_drop_thr8)
+    unsigned drop_seed, drop_thr;   // drop_thr = at_drop_thr8(p): p in 1/256ths
 };
+// (round 6) A keep decision is one BYTE of a hash against p 2^8 -- one hash serves FOUR adjacent keys -- so the drop probability is
+// realised in 1/256ths: p = 0.1 -> 26/256 = 0.1016, and the kept probabilities are scaled by 256 / (256 - 26), the inverse keep rate of
+// the mask that is actually drawn (unbiased; nn.MultiheadAttention(dropout=0.1) with p off by 1.6 % of itself).  Half the hashes of the
+// 16-bit decisions: the hash was 31 % of the bf16 attention kernels' time (profiles/r06_attn_dq_ablation.txt).  0 < thr8 < 256.
+__host__ __device__ __forceinline__ unsigned at_drop_thr8(float p) {
+    const unsigned t = (unsigned)(p * 256.0f + 0.5f);
+    return t < 1u ? (p > 0.0f ? 1u : 0u) : (t > 255u ? 255u : t);
+}
+__host__ __device__ __forceinline__ float at_drop_scale(float p) { return 256.0f / (256.0f - (float)at_drop_thr8(p)); }
 
-// keep mask of the attention dropout: x = drop_hash(fmix32(seed ^ bh c0) + query c1, key >> 1), key kept iff its 16-bit half of x >= p 2^16
+// keep mask of the attention dropout: x = drop_hash(fmix32(seed ^ bh c0) + query c1, key >> 2), key kept iff its byte of x >= p 2^8
 __host__ __device__ __forceinline__ unsigned at_fmix32(unsigned x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
 __host__ __device__ __forceinline__ unsigned at_head_key(unsigned seed, unsigned bh) { return at_fmix32(seed ^ (bh * 0x9E3779B1u)); }
-// One hash serves the two keys 2j, 2j + 1 (its low / high 16 bits against p 2^16): a lane's 16 keys of a tile come in adjacent
-// pairs, so the unrolled loops evaluate 8 hashes per 16 probabilities.
+// One hash serves the four keys 4j .. 4j + 3 (its bytes against p 2^8): a lane's 16 keys of a tile come in aligned quads, so the
+// unrolled loops evaluate 4 hashes per 16 probabilities.  thr8 = at_drop_thr8(p).
 // (round 5: the per-probability mixer is drop_hash -- full-rate 24-bit multiplies, drop_hash.h; the head key stays murmur-mixed)
-__host__ __device__ __forceinline__ bool at_keep_bit(unsigned head_key, unsigned query, unsigned key, unsigned thr) {
-    const unsigned x = drop_hash(head_key + query * 0x85EBCA6Bu, key >> 1);
-    return ((key & 1u) ? (x >> 16) : (x & 0xffffu)) >= (thr >> 8);
+__host__ __device__ __forceinline__ bool at_keep_bit(unsigned head_key, unsigned query, unsigned key, unsigned thr8) {
+    const unsigned x = drop_hash(head_key + query * 0x85EBCA6Bu, key >> 2);
+    return ((x >> (8u * (key & 3u))) & 0xffu) >= thr8;
 }
 __device__ __forceinline__ float at_keep(const AttnArgs &a, unsigned head_key, int query, int key) {
     return at_keep_bit(head_key, (unsigned)query, (unsigned)key, a.drop_thr) ? a.drop_scale : 0.0f;

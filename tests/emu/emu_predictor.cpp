@@ -186,13 +186,13 @@ static float g_attn_drop_p = 0.0f;   // > 0: dropout on the probabilities with g
 static unsigned g_attn_drop_seed = 0;
 extern "C" void emu_attention_set_precision(int p) { g_attn_prec = p; }
 extern "C" void emu_attention_set_dropout(float p, unsigned seed) { g_attn_drop_p = p; g_attn_drop_seed = seed; }
-extern "C" int emu_attn_keep(unsigned seed, unsigned bh, unsigned q, unsigned k, float p) { return emloco::at_keep_bit(emloco::at_head_key(seed, bh), q, k, (unsigned)(p * 16777216.0f)) ? 1 : 0; }
+extern "C" int emu_attn_keep(unsigned seed, unsigned bh, unsigned q, unsigned k, float p) { return emloco::at_keep_bit(emloco::at_head_key(seed, bh), q, k, emloco::at_drop_thr8(p)) ? 1 : 0; }
 #define ATTN_DISPATCH(K) do { const bool dr_ = g_attn_drop_p > 0.0f; \
     if (g_attn_prec == 2 && dr_) K<2, 1>(a); else if (g_attn_prec == 2) K<2, 0>(a); else \
     if (g_attn_prec && dr_) K<1, 1>(a); else if (g_attn_prec) K<1, 0>(a); else if (dr_) K<0, 1>(a); else K<0, 0>(a); } while (0)
 extern "C" int emu_attention_fwd_queries(int n_seq, int S, int Sq, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                                          float *out, float *lse) {
-    AttnArgs a{n_seq, S, nhead, d_model, Sq, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr, g_attn_drop_p, 1.0f / (1.0f - g_attn_drop_p), g_attn_drop_seed, (unsigned)(g_attn_drop_p * 16777216.0f)};
+    AttnArgs a{n_seq, S, nhead, d_model, Sq, scale, qkv, key_bias, out, lse, nullptr, nullptr, nullptr, g_attn_drop_p, emloco::at_drop_scale(g_attn_drop_p), g_attn_drop_seed, emloco::at_drop_thr8(g_attn_drop_p)};
     for (int y = 0; y < n_seq * nhead; ++y)
         for (int x = 0; x < (Sq + 127) / 128; ++x)
             emu::launch(1, 256, [&] { blockIdx.x = x; blockIdx.y = y; ATTN_DISPATCH(attn_fwd_kernel); });
@@ -206,7 +206,7 @@ extern "C" int emu_attention_fwd(int n_seq, int S, int nhead, int d_model, float
 // as emloco_attention_bwd_queries: the launcher zero-fills the dQ third of the rows that did not attend
 extern "C" int emu_attention_bwd_queries(int n_seq, int S, int Sq, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                                          float *out, float *lse, const float *dout, float *dqkv, float *dsum) {
-    AttnArgs a{n_seq, S, nhead, d_model, Sq, scale, qkv, key_bias, out, lse, dout, dqkv, dsum, g_attn_drop_p, 1.0f / (1.0f - g_attn_drop_p), g_attn_drop_seed, (unsigned)(g_attn_drop_p * 16777216.0f)};
+    AttnArgs a{n_seq, S, nhead, d_model, Sq, scale, qkv, key_bias, out, lse, dout, dqkv, dsum, g_attn_drop_p, emloco::at_drop_scale(g_attn_drop_p), g_attn_drop_seed, emloco::at_drop_thr8(g_attn_drop_p)};
     if (Sq < S)
         for (long r = 0; r < (long)n_seq * S; ++r)
             for (int c = 0; c < d_model; ++c) dqkv[r * 3 * d_model + c] = 0.0f;
@@ -268,8 +268,8 @@ extern "C" int emu_drop_keep(unsigned seed, unsigned long long idx, float p) { r
 // kernels (attn_*<2, DROP, 0>).
 extern "C" int emu_attention16(int which, int n_seq, int S, int Sq, int nhead, int d_model, float scale, const void *qkv, const float *key_bias,
                                float *out, float *lse, const float *dout, void *dqkv, float *dsum, float drop_p, unsigned seed) {
-    AttnArgs a{n_seq, S, nhead, d_model, Sq, scale, (const float *)qkv, key_bias, out, lse, dout, (float *)dqkv, dsum, drop_p, 1.0f / (1.0f - drop_p), seed,
-               (unsigned)(drop_p * 16777216.0f)};
+    AttnArgs a{n_seq, S, nhead, d_model, Sq, scale, (const float *)qkv, key_bias, out, lse, dout, (float *)dqkv, dsum, drop_p, emloco::at_drop_scale(drop_p), seed,
+               emloco::at_drop_thr8(drop_p)};
     const unsigned rows_per_wg = which == 1 ? 256 : 128;
     const unsigned rows_dq = (which == 1 || which == 3) ? 256 : 128;
     const bool dr = drop_p > 0.0f;

@@ -14,6 +14,11 @@ import oracle
 from helpers import oracle_sim, scene_state, varied_models
 
 
+def ATTN_P8(p):
+    """The drop probability the fused attention's mask realises: p in 1/256ths (csrc/attention_kernels.hip: at_drop_thr8)."""
+    return min(max(int(p * 256.0 + 0.5), 1 if p > 0 else 0), 255) / 256.0
+
+
 def P(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
@@ -853,8 +858,8 @@ def test_fused_attention_kernels_with_dropout_on_the_probabilities(attn_precisio
         lib.emu_attention_set_dropout(0.0, 0)
     keep = np.array([[[lib.emu_attn_keep(seed, bh, i, j, pdrop) for j in range(S)] for i in range(S)] for bh in range(n_seq * H)],
                     np.float64).reshape(n_seq, H, S, S)
-    assert abs(keep.mean() - (1 - pdrop)) < 0.01
-    M = keep / (1 - pdrop)
+    assert abs(keep.mean() - (1 - ATTN_P8(pdrop))) < 0.01
+    M = keep / (1 - ATTN_P8(pdrop))                        # (the mask realises p in 1/256ths: at_drop_thr8)
     q = qkv[..., :d].reshape(n_seq, S, H, 32).transpose(0, 2, 1, 3).astype(np.float64)
     k = qkv[..., d:2 * d].reshape(n_seq, S, H, 32).transpose(0, 2, 1, 3).astype(np.float64)
     v = qkv[..., 2 * d:].reshape(n_seq, S, H, 32).transpose(0, 2, 1, 3).astype(np.float64)
@@ -1247,7 +1252,7 @@ def test_bf16_attention_kernels_two_blocks_per_wave():
                 P_ = e / l
                 keep = np.ones((Sq, S))
                 if p > 0:
-                    keep = np.array([[lib.emu_attn_keep(C.c_uint(seed), b * H + h, qi, ki, C.c_float(p)) for ki in range(S)] for qi in range(Sq)], np.float64) / (1 - p)
+                    keep = np.array([[lib.emu_attn_keep(C.c_uint(seed), b * H + h, qi, ki, C.c_float(p)) for ki in range(S)] for qi in range(Sq)], np.float64) / (1 - ATTN_P8(p))      # (the mask realises p in 1/256ths: at_drop_thr8)
                 Pd = P_ * keep
                 ref_out[b, :, h * 32:(h + 1) * 32] = Pd @ v
                 ref_lse[b * H + h] = (mx + np.log(l))[:, 0]
@@ -1319,7 +1324,7 @@ def test_split_mode_attention_on_piece_plane_tile_images():
                 P_ = e / l
                 keep = np.ones((Sq, S))
                 if p > 0:
-                    keep = np.array([[lib.emu_attn_keep(C.c_uint(seed), b * H + h, qi, ki, C.c_float(p)) for ki in range(S)] for qi in range(Sq)], np.float64) / (1 - p)
+                    keep = np.array([[lib.emu_attn_keep(C.c_uint(seed), b * H + h, qi, ki, C.c_float(p)) for ki in range(S)] for qi in range(Sq)], np.float64) / (1 - ATTN_P8(p))      # (the mask realises p in 1/256ths: at_drop_thr8)
                 Pd = P_ * keep
                 ref_out[b, :, h * 32:(h + 1) * 32] = Pd @ v
                 ref_lse[b * H + h] = (mx + np.log(l))[:, 0]

@@ -102,3 +102,28 @@ def row_key_collisions():
 
 
 row_key_collisions()
+
+
+def byte_stats(name, h, thr8=26):
+    """Round 6: the fused attention's keep decisions are the four BYTES of one hash per four adjacent keys (at_keep_bit), against p 2^8."""
+    seed, nq, nk4 = 12345, 453, 114
+    res = []
+    for bh in range(16):
+        hk = fmix32(np.uint64(seed) ^ u(np.uint64(bh) * np.uint64(0x9E3779B1)))
+        q = np.arange(nq, dtype=np.uint64)[:, None]
+        k4 = np.arange(nk4, dtype=np.uint64)[None, :]
+        res.append(h(u(hk + q * np.uint64(0x85EBCA6B)), k4))
+    x = np.stack(res)                                             # [bh][q][key quad]
+    by = np.stack([(x >> np.uint64(8 * e)) & np.uint64(0xff) for e in range(4)], -1).reshape(16, nq, 4 * nk4)[:, :, :453]
+    keep = (by >= thr8).astype(np.float64)
+    m = keep.mean()
+    def corr(a, b): a = a - a.mean(); b = b - b.mean(); return (a * b).mean() / np.sqrt((a * a).mean() * (b * b).mean())
+    chi = [((np.bincount(((x >> np.uint64(8 * e)) & np.uint64(0xff)).ravel().astype(int), minlength=256) - x.size / 256) ** 2 / (x.size / 256)).sum() / 255 for e in range(4)]
+    rs = keep.sum(-1); cs = keep.sum(1)
+    print(f"{name:8s} bytes, thr {thr8}/256: keep {m:.5f} (nominal {1 - thr8 / 256:.5f}; p = 0.1 asks 0.90000)  corr key+1 {corr(keep[:, :, :-1], keep[:, :, 1:]):+.4f} key+2 {corr(keep[:, :, :-2], keep[:, :, 2:]):+.4f} "
+          f"key+4 {corr(keep[:, :, :-4], keep[:, :, 4:]):+.4f} adj-query {corr(keep[:, :-1], keep[:, 1:]):+.4f} adj-head {corr(keep[:-1], keep[1:]):+.4f}  chi2/255 per byte {' '.join(f'{c:.2f}' for c in chi)}  "
+          f"var(kept per query) / binomial {rs.var() / (453 * m * (1 - m)):.3f}  per key {cs.var() / (nq * m * (1 - m)):.3f}")
+
+
+byte_stats("mixA", newh(mixA))
+byte_stats("old", old)
