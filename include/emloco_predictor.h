@@ -149,9 +149,12 @@ int emloco_attention_bwd_ex(int n_seq, int S, int nhead, int d_model, float scal
 
 /* The same with dropout on the attention probabilities -- nn.MultiheadAttention(dropout = p) inside
  * nn.TransformerEncoderLayer in training mode (model_jta.py:177-178): softmax -> dropout(p) -> . V.  Probability (bh, query,
- * key) of the launch (bh = sequence * nhead + head) is kept iff a 32-bit counter hash of (drop_seed, bh, query, key) clears
- * p 2^24 (emloco_attention_keep_mask evaluates it on the host) and scaled by 1 / (1 - p); the backward recomputes the mask, so
- * pass it the forward's (drop_p, drop_seed).  drop_p = 0 is the call above. */
+ * key) of the launch (bh = sequence * nhead + head) is kept iff its BYTE of a 32-bit counter hash of (drop_seed, bh, query, key / 4)
+ * clears p 2^8 (emloco_attention_keep_mask evaluates it on the host); the backward recomputes the mask, so pass it the forward's
+ * (drop_p, drop_seed).  drop_p = 0 is the call above.  (Round 6) one hash serves four adjacent keys, so the drop probability is REALISED
+ * in 1/256ths -- p8 = round(256 p) / 256, 26 / 256 = 0.1016 for the model's 0.1 -- and the kept probabilities are scaled by
+ * 1 / (1 - p8), the inverse keep rate of the mask that is drawn (unbiased; rounds 2-5 compared 16 bits per decision: twice the hashes,
+ * which were 31 % of the bf16 attention kernels' time). */
 int emloco_attention_fwd_dropout(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
                                  float *out, float *lse, int flags, float drop_p, uint32_t drop_seed, void *stream);
 int emloco_attention_bwd_dropout(int n_seq, int S, int nhead, int d_model, float scale, const float *qkv, const float *key_bias,
