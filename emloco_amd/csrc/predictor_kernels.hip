@@ -417,7 +417,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g) {
                   "split mode: 128 / 64-row x 16 stages, fp32 operands (or B as its piece image), 16-byte loads");
     static_assert(IOB != 2 || PREC == 2, "the piece image is the split mode's");
 #ifndef GEMM_SPLIT2_PLANES
-#define GEMM_SPLIT2_PLANES 3                                  /* LDS planes allocated per stage by the two-piece kernels (2: a fourth workgroup per CU fits) */
+#define GEMM_SPLIT2_PLANES 3                                  /* LDS planes allocated per stage by the two-piece kernels (2: a fourth workgroup per CU fits --
+                                                                 measured with GEMM_SPLIT2_WAVES = 4, 128 registers: JTA step 117 ms against 110, HISTORY.md) */
 #endif
     constexpr int NPL = NPC == 2 ? GEMM_SPLIT2_PLANES : 3;
     constexpr int SA = PREC == 2 ? NPL * split_plane_words(BM) : BM * GLDK, SB = PREC == 2 ? NPL * split_plane_words(BN) : BN * GLDK;
