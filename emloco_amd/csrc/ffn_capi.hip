@@ -24,7 +24,7 @@ int emloco_ffn_fwd(int M, int F, const float *x, const uint16_t *w1_bf16, const 
     if (!aligned16(x) || !aligned16(w1_bf16) || !aligned16(w2_bf16) || !aligned16(b1) || !aligned16(b2) || !aligned16(hidden) || !aligned16(mask) || !aligned16(out))
         return ffail(-1, "emloco_ffn_fwd: operands must be 16-byte aligned");
     emloco::FfnArgs a{M, F, x, w1_bf16, w2_bf16, b1, b2, hidden, nullptr, mask, out, drop_p, 1.0f / (1.0f - drop_p), seed_hidden,
-                      (unsigned)(drop_p * 65536.0f), seed_out};
+                      (unsigned)(drop_p * 65536.0f), seed_out, nullptr};
     const dim3 grid((unsigned)((M + FFN_ROWS - 1) / FFN_ROWS));
     if (drop_p > 0.0f) hipLaunchKernelGGL((emloco::ffn_chain_kernel<0, 1>), grid, dim3(FFN_THREADS), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((emloco::ffn_chain_kernel<0, 0>), grid, dim3(FFN_THREADS), 0, (hipStream_t)stream, a);
@@ -34,11 +34,25 @@ int emloco_ffn_fwd(int M, int F, const float *x, const uint16_t *w1_bf16, const 
 
 int emloco_ffn_bwd_input(int M, int F, const float *dz2, const uint16_t *w2t_bf16, const uint16_t *w1t_bf16, const uint32_t *mask,
                          uint16_t *dz1, float *dx, float drop_p, void *stream) {
+    return emloco_ffn_bwd_input_colsum(M, F, dz2, w2t_bf16, w1t_bf16, mask, dz1, dx, drop_p, nullptr, stream);
+}
+
+int64_t emloco_ffn_bwd_colsum_rows(int M) { return ((int64_t)M + FFN_ROWS - 1) / FFN_ROWS * (FFN_THREADS / 64); }
+
+int emloco_ffn_bwd_input_colsum(int M, int F, const float *dz2, const uint16_t *w2t_bf16, const uint16_t *w1t_bf16, const uint32_t *mask,
+                                uint16_t *dz1, float *dx, float drop_p, float *colpart, void *stream) {
     if (M < 1 || F < FFN_CH || F % FFN_CH || !dz2 || !w2t_bf16 || !w1t_bf16 || !mask || !dz1 || !dx || !(drop_p >= 0.0f && drop_p < 1.0f))
         return ffail(-1, "emloco_ffn_bwd_input: bad argument (hidden width must be a multiple of 64, 0 <= drop_p < 1)");
     if (!aligned16(dz2) || !aligned16(w2t_bf16) || !aligned16(w1t_bf16) || !aligned16(mask) || !aligned16(dz1) || !aligned16(dx))
         return ffail(-1, "emloco_ffn_bwd_input: operands must be 16-byte aligned");
-    emloco::FfnArgs a{M, F, dz2, w2t_bf16, w1t_bf16, nullptr, nullptr, nullptr, dz1, const_cast<uint32_t *>(mask), dx, drop_p, 1.0f / (1.0f - drop_p), 0u, 0u, 0u};
+    emloco::FfnArgs a{M, F, dz2, w2t_bf16, w1t_bf16, nullptr, nullptr, nullptr, dz1, const_cast<uint32_t *>(mask), dx, drop_p, 1.0f / (1.0f - drop_p), 0u, 0u, 0u, colpart};
+    if (colpart && !aligned16(colpart)) return ffail(-1, "emloco_ffn_bwd_input_colsum: colpart must be 16-byte aligned");
+    // (waves wholly past the last row write nothing: their rows of colpart must read as zero)
+    if (colpart && M % FFN_ROWS) {
+        const int64_t rows = emloco_ffn_bwd_colsum_rows(M), live = ((int64_t)M + 31) / 32;
+        if (rows > live && hipMemsetAsync(colpart + live * F, 0, (size_t)(rows - live) * F * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return ffail(-2, "emloco_ffn_bwd_input_colsum: memset");
+    }
     const dim3 grid((unsigned)((M + FFN_ROWS - 1) / FFN_ROWS));
     hipLaunchKernelGGL((emloco::ffn_chain_kernel<1, 0>), grid, dim3(FFN_THREADS), 0, (hipStream_t)stream, a);
     const hipError_t e = hipGetLastError();

@@ -61,6 +61,8 @@ struct FfnArgs {
     float drop_p, keep_scale;       // dropout of the block (both nn.Dropout(p)): keep_scale = 1 / (1 - p)
     unsigned seed1, thr16;          // hidden-layer mask: ffn_keep16 below, thr16 = (unsigned)(p 65536)
     unsigned seed2;                 // output mask: the GEMM epilogue's drop_keep(seed2, row * 128 + col, p) (predictor_kernels.hip)
+    float *colpart;                 // backward, optional OUT [ceil(M / 32)][F]: column sums of dz1 AS STORED (bf16-rounded) over each wave's 32 rows --
+                                    // linear1's bias gradient after a fixed-order fold (round 6: was a pass of its own over the M x F gradient)
 };
 
 // Keep mask of the hidden layer's dropout: one 32-bit hash per PAIR of adjacent hidden units (its low / high 16 bits against p 2^16),
@@ -82,6 +84,13 @@ __host__ __device__ __forceinline__ bool ffn_out_keep(unsigned seed, unsigned lo
 
 __device__ __forceinline__ float ffn_bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float ffn_bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+struct __attribute__((aligned(8))) ffn_f32x2 { float x, y; };
+// the lane's value plus its partner's in the other 32-lane half (v_permlane32_swap: a vector instruction; which of the two results is the
+// lane's own differs between the halves, the sum does not)
+__device__ __forceinline__ float ffn_both_halves(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 // LDS images of one chunk (bytes).  P tile [64 hidden][128 k] bf16: 256-byte rows, the 16-byte slot c of row r at slot c ^ (r & 15)
 // (a lane group of a ds_read_b128 -- 16 rows at one column -- then covers all 64 banks).  Q tile [128 rows][64 hidden] bf16: 128-byte
@@ -224,6 +233,23 @@ ffn_chain_kernel(FfnArgs a) {
         // (rows past the end store the last row's values again, as everywhere in this kernel)
         if (MODE == 0) a.mask[rowc * (a.F / 32) + 2 * c + hi] = mword;
         ffn_wave_sync();
+        if (MODE == 1 && a.colpart) {
+            // column sums of the wave's tile, read back as it was rounded: lane half h takes rows h, h + 2, ... (128 bytes apart: the two
+            // halves hit different banks), lane (h, j) columns 2 j, 2 j + 1 -- sixteen 4-byte reads; rows past the end (duplicates of the
+            // last row) are left out; the halves meet through v_permlane32_swap and lanes 0 .. 31 store the 64 sums as one 256-byte line
+            const int r0w = blockIdx.x * FFN_ROWS + wave * 32;
+            float s0 = 0.0f, s1 = 0.0f;
+            #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = 2 * r + hi;
+                const unsigned w = *(const unsigned *)(lds_t[wave] + ffn_t_off(rl, l31 >> 2) + 4 * (l31 & 3));
+                const bool ok = r0w + rl < a.M;
+                s0 += ok ? ffn_bf16_lo(w) : 0.0f;
+                s1 += ok ? ffn_bf16_hi(w) : 0.0f;
+            }
+            s0 = ffn_both_halves(s0); s1 = ffn_both_halves(s1);
+            if (hi == 0 && r0w < a.M) *(ffn_f32x2 *)(a.colpart + ((long)blockIdx.x * (FFN_THREADS / 64) + wave) * a.F + (long)c * FFN_CH + 2 * l31) = ffn_f32x2{s0, s1};
+        }
         {
             unsigned short *dst = (MODE == 0 ? a.h : a.dz1) + (long)c * FFN_CH + 8 * (lane & 7);
             const int r0w = blockIdx.x * FFN_ROWS + wave * 32;

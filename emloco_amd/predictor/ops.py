@@ -80,6 +80,9 @@ def _lib():
         lib.emloco_gemm_enable_timing.argtypes = [ci]
         lib.emloco_ffn_fwd.argtypes = [ci, ci] + [vp] * 8 + [cf, C.c_uint32, C.c_uint32, vp]
         lib.emloco_ffn_bwd_input.argtypes = [ci, ci] + [vp] * 6 + [cf, vp]
+        lib.emloco_ffn_bwd_input_colsum.argtypes = [ci, ci] + [vp] * 6 + [cf, vp, vp]
+        lib.emloco_ffn_bwd_colsum_rows.argtypes = [ci]
+        lib.emloco_ffn_bwd_colsum_rows.restype = C.c_int64
         lib.emloco_ffn_keep_mask.argtypes = [C.c_uint32, cl, cl, ci, cf, vp]
         lib.emloco_disc_reward.argtypes = [ci, vp, cf, vp, vp]
         lib.emloco_gemm_timing_stats.argtypes = [C.POINTER(ci), C.POINTER(cf), C.POINTER(C.c_double)]
@@ -118,6 +121,9 @@ GEMM_SPLIT2 = 4096      # EMLOCO_GEMM_SPLIT2: with GEMM_SPLIT, two pieces per op
 # restore round 5's backward.
 _BWD_PIECES = {"dx": int(os.environ.get("EMLOCO_BWD_PIECES_DX", os.environ.get("EMLOCO_BWD_PIECES", "2"))),
                "dw": int(os.environ.get("EMLOCO_BWD_PIECES_DW", os.environ.get("EMLOCO_BWD_PIECES", "2")))}
+
+
+_FFN_COLSUM = os.environ.get("EMLOCO_FFN_COLSUM", "1") != "0"      # the chained feed-forward's backward sums dz1's columns itself (round 6)
 
 
 def backward_pieces():
@@ -434,14 +440,18 @@ class FeedForwardFn(torch.autograd.Function):
             dz1 = torch.empty((M, F), dtype=torch.bfloat16, device=dev)
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
             w2t, w1t = W2.t().contiguous(), W1.t().contiguous()       # (named: a temporary's block would be handed to the next allocation)
-            _chk(lib.emloco_ffn_bwd_input(M, F, _p(dz2), _p(w2t), _p(w1t), _p(mbits), _p(dz1), _p(dx), float(p), st), "emloco_ffn_bwd_input")
+            # (round 6) the kernel leaves the column sums of dz1 per wave (M / 32 rows x F): linear1's bias gradient without a pass over dz1
+            # (EMLOCO_FFN_COLSUM=0: the separate pass, A/B knob)
+            cpart = torch.empty((lib.emloco_ffn_bwd_colsum_rows(M), F), dtype=torch.float32, device=dev) if _FFN_COLSUM else None
+            _chk(lib.emloco_ffn_bwd_input_colsum(M, F, _p(dz2), _p(w2t), _p(w1t), _p(mbits), _p(dz1), _p(dx), float(p), _p(cpart), st), "emloco_ffn_bwd_input_colsum")
             dW2 = torch.empty((N, F), dtype=torch.float32, device=dev)
             gemm(1, N, F, M, dz2, N, 0, 1, h, F, 0, 1, dW2, F, 0, ksplit=_ksplit_for(M, N * F))          # dW2 = dz2^T h
             dW1 = torch.empty((F, K), dtype=torch.float32, device=dev)
             gemm(1, F, K, M, dz1, F, 0, 1, x2, K, 0, 1, dW1, K, 0, ksplit=_ksplit_for(M, F * K))         # dW1 = dz1^T x
             # (linear1's bias gradient is the column sum of dz1 as STORED -- bf16-rounded -- where the unchained bf16 path sums the fp32
-            # values before rounding them: a difference of one bf16 rounding per element, inside the reduced-precision mode's 2e-2 bar)
-            return (dx.view(ctx.xs) if ctx.needs_input_grad[0] else None), dW1, colsum(dz1), dW2, db2, None, None, None
+            # values before rounding them: a difference of one bf16 rounding per element, inside the reduced-precision mode's 2e-2 bar;
+            # summed inside the backward kernel per wave, folded here)
+            return (dx.view(ctx.xs) if ctx.needs_input_grad[0] else None), dW1, colsum(cpart if cpart is not None else dz1), dW2, db2, None, None, None
         dW2 = torch.empty((N, F), dtype=torch.float32, device=dev)
         gemm(1, N, F, M, dz2, N, 0, 1, h, F, 0, 1, dW2, F, 0, ksplit=_ksplit_for(M, N * F), flags=_bwd_flags("dw"))          # dW2 = dz2^T h
         h16 = h.dtype == torch.bfloat16

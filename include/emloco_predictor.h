@@ -104,6 +104,12 @@ int emloco_ffn_fwd(int M, int F, const float *x, const uint16_t *w1_bf16, const 
                    uint16_t *hidden, uint32_t *mask, float *out, float drop_p, uint32_t seed_hidden, uint32_t seed_out, void *stream);
 int emloco_ffn_bwd_input(int M, int F, const float *dz2, const uint16_t *w2t_bf16, const uint16_t *w1t_bf16, const uint32_t *mask,
                          uint16_t *dz1, float *dx, float drop_p, void *stream);
+/* (round 6) The same, also leaving the column sums of dz1 AS STORED (bf16-rounded) over each wave's 32 rows in colpart
+ * [emloco_ffn_bwd_colsum_rows(M)][F] floats (16-byte aligned; rows of waves past the last row are zeroed): linear1's bias gradient is
+ * their column sum (emloco_colsum over that matrix) -- a read of M / 32 x F floats where the separate pass read the M x F gradient. */
+int emloco_ffn_bwd_input_colsum(int M, int F, const float *dz2, const uint16_t *w2t_bf16, const uint16_t *w1t_bf16, const uint32_t *mask,
+                                uint16_t *dz1, float *dx, float drop_p, float *colpart, void *stream);
+int64_t emloco_ffn_bwd_colsum_rows(int M);
 int emloco_ffn_keep_mask(uint32_t seed_hidden, int64_t first_row, int64_t rows, int F, float p, uint8_t *host_out);
 
 /* the same for a [m][n] gradient plus the bias gradient colsum[n] = sum_m dz (fixed-order folding; workspace as emloco_colsum) */

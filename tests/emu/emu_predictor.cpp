@@ -248,9 +248,11 @@ extern "C" int emu_adamw_gated(int n, float *p, const float *g, float *m, float 
 
 // ---- the chained feed-forward kernels (emloco_amd/csrc/ffn_kernels.hip), launched as emloco_ffn_fwd / emloco_ffn_bwd_input launch them
 #include "../../emloco_amd/csrc/ffn_kernels.hip"
+static float *g_ffn_colpart = nullptr;       // optional [ceil(M / 32)][F] column partials of the next backward launch (emu_ffn_set_colpart)
+extern "C" void emu_ffn_set_colpart(float *p) { g_ffn_colpart = p; }
 extern "C" int emu_ffn_chain(int mode, int M, int F, const float *x, const unsigned short *P, const unsigned short *Q, const float *b1,
                              const float *b2, unsigned short *h, unsigned short *dz1, unsigned *mask, float *out, float drop_p, unsigned seed1, unsigned seed2) {
-    FfnArgs a{M, F, x, P, Q, b1, b2, h, dz1, mask, out, drop_p, 1.0f / (1.0f - drop_p), seed1, (unsigned)(drop_p * 65536.0f), seed2};
+    FfnArgs a{M, F, x, P, Q, b1, b2, h, dz1, mask, out, drop_p, 1.0f / (1.0f - drop_p), seed1, (unsigned)(drop_p * 65536.0f), seed2, g_ffn_colpart};
     const unsigned grid = (unsigned)((M + FFN_ROWS - 1) / FFN_ROWS);
     if (mode == 0 && drop_p > 0.0f) emu::launch(grid, FFN_THREADS, [&] { ffn_chain_kernel<0, 1>(a); });
     else if (mode == 0) emu::launch(grid, FFN_THREADS, [&] { ffn_chain_kernel<0, 0>(a); });

@@ -1198,14 +1198,24 @@ def test_chained_feed_forward_kernels():
         W2T, W1T = np.ascontiguousarray(W2b.T), np.ascontiguousarray(W1b.T)
         dz1 = np.full((M, F), 0x7fc0, np.uint16)
         dx = np.full((M, D), np.nan, np.float32)
+        # (round 6) the launch also leaves the column sums of dz1 per wave of 32 rows: linear1's bias gradient without a pass over dz1
+        n_part = ((M + 255) // 256) * 8
+        colpart = np.full((n_part, F), np.nan, np.float32)
+        colpart[(M + 31) // 32:] = 0.0                           # (rows of waves wholly past the end: the launcher zeroes them)
+        lib.emu_ffn_set_colpart(P(colpart))
         lib.emu_ffn_chain(1, M, F, P(dz2), U16(W2T), U16(W1T), None, None, None, U16(dz1), mbits.ctypes.data_as(C.POINTER(C.c_uint)), P(dx),
                           C.c_float(p), C.c_uint(0), C.c_uint(0))
+        lib.emu_ffn_set_colpart(None)
         t = _bf16_val(_bf16_bits(dz2)).astype(np.float64) @ _bf16_val(W2b).astype(np.float64)
         want1 = np.where(got > 0, t / (1.0 - p), 0.0)
         got1 = _bf16_val(dz1).astype(np.float64)
         assert np.array_equal(got1 == 0, (got <= 0) | (want1 == 0))
         np.testing.assert_allclose(got1, want1, rtol=2.0 ** -7, atol=2e-5)
         np.testing.assert_allclose(dx, got1 @ _bf16_val(W1b).astype(np.float64), rtol=1e-5, atol=2e-5)
+        assert np.isfinite(colpart).all()
+        for w in range((M + 31) // 32):                          # every wave's partial = the sum of ITS rows of the stored gradient
+            np.testing.assert_allclose(colpart[w], got1[32 * w:32 * w + 32].sum(0), rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(colpart.sum(0), got1.sum(0), rtol=1e-5, atol=1e-4)
 
 
 def test_bf16_attention_kernels_two_blocks_per_wave():
