@@ -32,6 +32,24 @@ int emloco_ffn_fwd(int M, int F, const float *x, const uint16_t *w1_bf16, const 
     return e == hipSuccess ? 0 : ffail(-2, "emloco_ffn_fwd launch", e);
 }
 
+int emloco_ffn_fwd_norm(int M, int F, const float *x, const uint16_t *w1_bf16, const uint16_t *w2_bf16, const float *b1, const float *b2,
+                        uint16_t *hidden, uint32_t *mask, const float *res, const float *gamma, const float *beta, float eps,
+                        float *y, float *xr, float *mean, float *rstd, float drop_p, uint32_t seed_hidden, uint32_t seed_out, void *stream) {
+    if (M < 1 || F < FFN_CH || F % FFN_CH || F > 2048 || !x || !w1_bf16 || !w2_bf16 || !b1 || !b2 || !hidden || !mask || !res || !gamma || !beta ||
+        !y || !xr || !mean || !rstd || !(drop_p >= 0.0f && drop_p < 1.0f) || !(eps >= 0.0f))
+        return ffail(-1, "emloco_ffn_fwd_norm: bad argument (hidden width must be a multiple of 64, at most 2048; 0 <= drop_p < 1)");
+    if (!aligned16(x) || !aligned16(w1_bf16) || !aligned16(w2_bf16) || !aligned16(b1) || !aligned16(b2) || !aligned16(hidden) || !aligned16(mask) ||
+        !aligned16(res) || !aligned16(gamma) || !aligned16(beta) || !aligned16(y) || !aligned16(xr))
+        return ffail(-1, "emloco_ffn_fwd_norm: operands must be 16-byte aligned");
+    emloco::FfnArgs a{M, F, x, w1_bf16, w2_bf16, b1, b2, hidden, nullptr, mask, y, drop_p, 1.0f / (1.0f - drop_p), seed_hidden,
+                      (unsigned)(drop_p * 65536.0f), seed_out, nullptr, res, gamma, beta, xr, mean, rstd, eps};
+    const dim3 grid((unsigned)((M + FFN_ROWS - 1) / FFN_ROWS));
+    if (drop_p > 0.0f) hipLaunchKernelGGL((emloco::ffn_chain_kernel<0, 1>), grid, dim3(FFN_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((emloco::ffn_chain_kernel<0, 0>), grid, dim3(FFN_THREADS), 0, (hipStream_t)stream, a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : ffail(-2, "emloco_ffn_fwd_norm launch", e);
+}
+
 int emloco_ffn_bwd_input(int M, int F, const float *dz2, const uint16_t *w2t_bf16, const uint16_t *w1t_bf16, const uint32_t *mask,
                          uint16_t *dz1, float *dx, float drop_p, void *stream) {
     return emloco_ffn_bwd_input_colsum(M, F, dz2, w2t_bf16, w1t_bf16, mask, dz1, dx, drop_p, nullptr, stream);

@@ -63,6 +63,11 @@ struct FfnArgs {
     unsigned seed2;                 // output mask: the GEMM epilogue's drop_keep(seed2, row * 128 + col, p) (predictor_kernels.hip)
     float *colpart;                 // backward, optional OUT [ceil(M / 32)][F]: column sums of dz1 AS STORED (bf16-rounded) over each wave's 32 rows --
                                     // linear1's bias gradient after a fixed-order fold (round 6: was a pass of its own over the M x F gradient)
+    // forward, optional (round 6): the post-norm layer's residual add + LayerNorm in the epilogue -- a lane holds half a row, its partner
+    // half the other: xr = f + res, y = (xr - mean) rstd gamma + beta.  With xr set, `out` receives y and f itself is never written.
+    const float *res, *gamma, *beta;
+    float *xr, *mean, *rstd;
+    float eps;
 };
 
 // Keep mask of the hidden layer's dropout: one 32-bit hash per PAIR of adjacent hidden units (its low / high 16 bits against p 2^16),
@@ -277,6 +282,56 @@ ffn_chain_kernel(FfnArgs a) {
         __syncthreads();
     }
     // ---- epilogue: register r of acc[n] is model column n 32 + (r & 3) + 8 (r >> 2) + 4 hi of this lane's row
+    if (MODE == 0 && a.xr) {
+        // residual add + LayerNorm of the row (model_jta.py:177: norm2(x + dropout(ff(x)))): the 128 values of a row sit in this lane and
+        // its partner of the other half -- sums in a fixed order, the halves meet through v_permlane32_swap (biased variance, as nn.LayerNorm)
+        const float *rr = a.res + rowc * FFN_D;
+        float *xo = a.xr + rowc * FFN_D;
+        float s1 = 0.0f;
+        #pragma unroll
+        for (int n = 0; n < 4; ++n)
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = n * 32 + 8 * q + 4 * hi;
+                float v[4] = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
+                const ffn_f32x4 b = *(const ffn_f32x4 *)(a.b2 + col);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                if (DROP)
+                    #pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = ffn_out_keep(a.seed2, (unsigned long long)row * FFN_D + col + e, a.drop_p) ? v[e] * a.keep_scale : 0.0f;
+                const ffn_f32x4 r4 = *(const ffn_f32x4 *)(rr + col);
+                v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                *(ffn_f32x4 *)(xo + col) = ffn_f32x4{v[0], v[1], v[2], v[3]};
+                #pragma unroll
+                for (int e = 0; e < 4; ++e) acc[n][4 * q + e] = v[e];
+                s1 += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        const float mu = ffn_both_halves(s1) * (1.0f / 128.0f);
+        float s2 = 0.0f;
+        #pragma unroll
+        for (int n = 0; n < 4; ++n)
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float c[4];
+                #pragma unroll
+                for (int e = 0; e < 4; ++e) { c[e] = acc[n][4 * q + e] - mu; acc[n][4 * q + e] = c[e]; }
+                s2 += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+            }
+        const float rs = 1.0f / sqrtf(ffn_both_halves(s2) * (1.0f / 128.0f) + a.eps);
+        float *o = a.out + rowc * FFN_D;
+        #pragma unroll
+        for (int n = 0; n < 4; ++n)
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = n * 32 + 8 * q + 4 * hi;
+                const ffn_f32x4 g = *(const ffn_f32x4 *)(a.gamma + col), be = *(const ffn_f32x4 *)(a.beta + col);
+                *(ffn_f32x4 *)(o + col) = ffn_f32x4{acc[n][4 * q] * rs * g.x + be.x, acc[n][4 * q + 1] * rs * g.y + be.y,
+                                                    acc[n][4 * q + 2] * rs * g.z + be.z, acc[n][4 * q + 3] * rs * g.w + be.w};
+            }
+        if (hi == 0) { a.mean[rowc] = mu; a.rstd[rowc] = rs; }
+        return;
+    }
     {
         float *o = a.out + rowc * FFN_D;
         #pragma unroll

@@ -59,8 +59,9 @@ class EncoderLayer(nn.Module):
             xr = xr[:, :live_rows].contiguous()
         a = ops.linear(att, sa.out_proj.weight, sa.out_proj.bias, drop_p=p)
         x1, x1r = ops.layer_norm(a, xr, self.norm1.weight, self.norm1.bias, self.norm1.eps, fork=True)
-        f = ops.feed_forward(x1, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, drop_p=p)
-        return ops.layer_norm(f, x1r, self.norm2.weight, self.norm2.bias, self.norm2.eps, fork=fork_out)
+        # feed-forward, residual, norm2 (one forward launch in the reduced-precision mode, else feed_forward + layer_norm)
+        return ops.feed_forward_norm(x1, x1r, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                                     self.norm2.weight, self.norm2.bias, self.norm2.eps, drop_p=p, fork=fork_out)
 
 
 class Encoder(nn.Module):

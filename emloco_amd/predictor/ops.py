@@ -81,6 +81,7 @@ def _lib():
         lib.emloco_ffn_fwd.argtypes = [ci, ci] + [vp] * 8 + [cf, C.c_uint32, C.c_uint32, vp]
         lib.emloco_ffn_bwd_input.argtypes = [ci, ci] + [vp] * 6 + [cf, vp]
         lib.emloco_ffn_bwd_input_colsum.argtypes = [ci, ci] + [vp] * 6 + [cf, vp, vp]
+        lib.emloco_ffn_fwd_norm.argtypes = [ci, ci] + [vp] * 10 + [cf] + [vp] * 4 + [cf, C.c_uint32, C.c_uint32, vp]
         lib.emloco_ffn_bwd_colsum_rows.argtypes = [ci]
         lib.emloco_ffn_bwd_colsum_rows.restype = C.c_int64
         lib.emloco_ffn_keep_mask.argtypes = [C.c_uint32, cl, cl, ci, cf, vp]
@@ -421,11 +422,18 @@ class FeedForwardFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, df):
-        x2, W1, W2, h = ctx.saved_tensors[:4]
-        mbits = ctx.saved_tensors[4] if ctx.chain else None
+        dx, dW1, db1, dW2, db2 = _ffn_backward(ctx.saved_tensors[:5] if ctx.chain else tuple(ctx.saved_tensors[:4]) + (None,), ctx.chain, ctx.drop, ctx.xs,
+                                               ctx.needs_input_grad[0], df)
+        return dx, dW1, db1, dW2, db2, None, None, None
+
+
+def _ffn_backward(saved, chain, drop, xs, need_dx, df):
+    """The feed-forward block's backward pass (FeedForwardFn / FeedForwardNormFn): (dx, dW1, db1, dW2, db2) from the gradient w.r.t. its output."""
+    if True:
+        x2, W1, W2, h, mbits = saved
         M, K = x2.shape
         F, N = W1.shape[0], W2.shape[0]
-        p, _, seed2 = ctx.drop
+        p, _, seed2 = drop
         lib, st, dev = _lib(), _st(x2), x2.device
         df2 = df.contiguous().view(M, N)
         db2 = torch.empty(N, dtype=torch.float32, device=dev)
@@ -435,7 +443,7 @@ class FeedForwardFn(torch.autograd.Function):
             _chk(lib.emloco_act_bwd_colsum(M, N, _p(df2), None, 0, p, seed2 & 0xFFFFFFFF, _p(dz2), _p(db2), _p(ws), st), "emloco_act_bwd_colsum")
         else:
             dz2, db2 = df2, colsum(df2)
-        if ctx.chain:
+        if chain:
             # (W1, W2 are the forward's bf16 copies: the weight-gradient products below never read them)
             dz1 = torch.empty((M, F), dtype=torch.bfloat16, device=dev)
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
@@ -451,7 +459,7 @@ class FeedForwardFn(torch.autograd.Function):
             # (linear1's bias gradient is the column sum of dz1 as STORED -- bf16-rounded -- where the unchained bf16 path sums the fp32
             # values before rounding them: a difference of one bf16 rounding per element, inside the reduced-precision mode's 2e-2 bar;
             # summed inside the backward kernel per wave, folded here)
-            return (dx.view(ctx.xs) if ctx.needs_input_grad[0] else None), dW1, colsum(cpart if cpart is not None else dz1), dW2, db2, None, None, None
+            return (dx.view(xs) if need_dx else None), dW1, colsum(cpart if cpart is not None else dz1), dW2, db2
         dW2 = torch.empty((N, F), dtype=torch.float32, device=dev)
         gemm(1, N, F, M, dz2, N, 0, 1, h, F, 0, 1, dW2, F, 0, ksplit=_ksplit_for(M, N * F), flags=_bwd_flags("dw"))          # dW2 = dz2^T h
         h16 = h.dtype == torch.bfloat16
@@ -464,14 +472,79 @@ class FeedForwardFn(torch.autograd.Function):
         _chk(lib.emloco_gemm_relu_bwd(M, F, N, _p(dz2), N, _p(img2 if img2 is not None else W2), F, 1, _p(dz1), _p(h), 1.0 / (1.0 - p), _p(db1), _p(ws),
                                       fl | (GEMM_B_SPLITIMG if img2 is not None else 0), st), "emloco_gemm_relu_bwd")
         dx = None
-        if ctx.needs_input_grad[0]:
+        if need_dx:
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
             gemm(1, M, K, F, dz1, F, 0, 0, W1, K, 0, 1, dx, K, 0, ksplit=1 if h16 else _ksplit_for(F, M * K),   # dx = dz1 W1
                  b_image=_weight_image(W1, M, K, F, K, 1) if (not h16 and _BWD_PIECES["dx"] == 3) else None, flags=_bwd_flags("dx"))
-            dx = dx.view(ctx.xs)
+            dx = dx.view(xs)
         dW1 = torch.empty((F, K), dtype=torch.float32, device=dev)
         gemm(1, F, K, M, dz1, F, 0, 1, x2, K, 0, 1, dW1, K, 0, ksplit=_ksplit_for(M, F * K), flags=_bwd_flags("dw"))         # dW1 = dz1^T x
-        return dx, dW1, db1, dW2, db2, None, None, None
+        return dx, dW1, db1, dW2, db2
+
+
+_FFN_NORM = os.environ.get("EMLOCO_FFN_NORM", "1") != "0"      # the chained feed-forward also adds the residual and normalises (round 6)
+
+
+class FeedForwardNormFn(torch.autograd.Function):
+    """y = LayerNorm(res + dropout(linear2(dropout(relu(linear1(x)))))) gamma + beta -- the second half of the post-norm encoder layer
+    (model_jta.py:177) as ONE forward launch in the reduced-precision mode (`emloco_ffn_fwd_norm`, round 6): the chained feed-forward
+    kernel holds a row in a lane pair, so the residual add and the row's statistics cost one v_permlane32_swap; the block's own output is
+    never written (a write and a read of M x 128 less than FeedForwardFn + LayerNormFn).  The backward is theirs: LayerNorm backward on
+    the saved sum, then the feed-forward's.  x and res are two autograd edges (as `layer_norm(..., fork=True)` hands them out)."""
+
+    @staticmethod
+    def forward(ctx, x, res, W1, b1, W2, b2, gamma, beta, eps, drop_p, seed1, seed2, fork):
+        xs = x.shape
+        x2 = x.contiguous().view(-1, xs[-1])
+        r2 = res.contiguous().view(-1, xs[-1])
+        M, K = x2.shape
+        F = W1.shape[0]
+        dev = x.device
+        W1b, W2b = W1.contiguous().to(torch.bfloat16), W2.contiguous().to(torch.bfloat16)
+        h = torch.empty((M, F), dtype=torch.bfloat16, device=dev)
+        mbits = torch.empty((M, F // 32), dtype=torch.int32, device=dev)
+        y, xr = torch.empty((M, K), dtype=torch.float32, device=dev), torch.empty((M, K), dtype=torch.float32, device=dev)
+        mean, rstd = torch.empty(M, dtype=torch.float32, device=dev), torch.empty(M, dtype=torch.float32, device=dev)
+        _chk(_lib().emloco_ffn_fwd_norm(M, F, _p(x2), _p(W1b), _p(W2b), _p(b1.contiguous()), _p(b2.contiguous()), _p(h), _p(mbits), _p(r2),
+                                        _p(gamma), _p(beta), float(eps), _p(y), _p(xr), _p(mean), _p(rstd), float(drop_p),
+                                        int(seed1) & 0xFFFFFFFF, int(seed2) & 0xFFFFFFFF, _st(x2)), "emloco_ffn_fwd_norm")
+        ctx.save_for_backward(x2, W1b, W2b, h, mbits, xr, gamma, mean, rstd)
+        ctx.xs, ctx.drop = xs, (float(drop_p), int(seed1), int(seed2))
+        if fork:
+            return y.view(xs), y.view(xs).detach()
+        return y.view(xs)
+
+    @staticmethod
+    def backward(ctx, dy, dy_b=None):
+        x2, W1b, W2b, h, mbits, xr, gamma, mean, rstd = ctx.saved_tensors
+        rows, d = xr.shape
+        if dy is None:
+            dy, dy_b = dy_b, None
+        dy2 = dy.contiguous().view(rows, d)
+        dyb = dy_b.contiguous().view(rows, d) if dy_b is not None else None
+        dxr = torch.empty_like(xr)
+        dg = torch.empty(d, dtype=torch.float32, device=dy.device)
+        db = torch.empty(d, dtype=torch.float32, device=dy.device)
+        ws = torch.empty(_lib().emloco_layernorm_bwd_workspace(rows, d), dtype=torch.float32, device=dy.device)
+        _chk(_lib().emloco_layernorm_bwd2(rows, d, _p(xr), _p(gamma), _p(mean), _p(rstd), _p(dy2), _p(dyb), _p(dxr), _p(dg), _p(db), _p(ws),
+                                          _st(dy)), "emloco_layernorm_bwd")
+        dx, dW1, db1, dW2, db2 = _ffn_backward((x2, W1b, W2b, h, mbits), True, ctx.drop, ctx.xs, ctx.needs_input_grad[0], dxr)
+        return dx, dxr.view(ctx.xs), dW1, db1, dW2, db2, dg, db, None, None, None, None, None
+
+
+def feed_forward_norm(x, res, W1, b1, W2, b2, gamma, beta, eps=1e-5, drop_p=0.0, fork=False):
+    """layer_norm(feed_forward(x, ...), res, gamma, beta, eps, fork) -- as one forward launch where the chained kernel serves the shapes
+    (reduced-precision mode, d = 128; EMLOCO_FFN_NORM=0: always the two ops)."""
+    K = x.shape[-1]
+    M = x.numel() // K
+    if (_FFN_NORM and x.is_cuda and x.dtype == torch.float32 and res.dtype == torch.float32 and res.shape == x.shape and _ffn_chain_ok(M, K, W1.shape[0], W2.shape[0])
+            and x.contiguous().data_ptr() % 16 == 0 and res.contiguous().data_ptr() % 16 == 0 and gamma.data_ptr() % 16 == 0 and beta.data_ptr() % 16 == 0):
+        s1, s2 = (next_dropout_seed(), next_dropout_seed()) if drop_p > 0.0 else (0, 0)
+        if fork and not (torch.is_grad_enabled() and (x.requires_grad or res.requires_grad)):
+            y = FeedForwardNormFn.apply(x, res, W1, b1, W2, b2, gamma, beta, float(eps), float(drop_p), s1, s2, False)
+            return y, y
+        return FeedForwardNormFn.apply(x, res, W1, b1, W2, b2, gamma, beta, float(eps), float(drop_p), s1, s2, bool(fork))
+    return layer_norm(feed_forward(x, W1, b1, W2, b2, drop_p=drop_p), res, gamma, beta, eps, fork=fork)
 
 
 def feed_forward(x, W1, b1, W2, b2, drop_p=0.0):

@@ -104,6 +104,13 @@ int emloco_ffn_fwd(int M, int F, const float *x, const uint16_t *w1_bf16, const 
                    uint16_t *hidden, uint32_t *mask, float *out, float drop_p, uint32_t seed_hidden, uint32_t seed_out, void *stream);
 int emloco_ffn_bwd_input(int M, int F, const float *dz2, const uint16_t *w2t_bf16, const uint16_t *w1t_bf16, const uint32_t *mask,
                          uint16_t *dz1, float *dx, float drop_p, void *stream);
+/* (round 6) emloco_ffn_fwd with the post-norm layer's tail in its epilogue (model_jta.py:177: norm2(x1 + dropout(ff(x1)))):
+ * xr[M][128] = ff(x) + res, y = LayerNorm(xr) gamma + beta (biased variance, eps as nn.LayerNorm), mean / rstd [M] as
+ * emloco_layernorm_fwd_save leaves them (the backward is emloco_layernorm_bwd2 on xr, then emloco_ffn_bwd_input* on its dxr); the
+ * feed-forward's own output is never written.  A lane of the kernel holds half a row, its partner the other half. */
+int emloco_ffn_fwd_norm(int M, int F, const float *x, const uint16_t *w1_bf16, const uint16_t *w2_bf16, const float *b1, const float *b2,
+                        uint16_t *hidden, uint32_t *mask, const float *res, const float *gamma, const float *beta, float eps,
+                        float *y, float *xr, float *mean, float *rstd, float drop_p, uint32_t seed_hidden, uint32_t seed_out, void *stream);
 /* (round 6) The same, also leaving the column sums of dz1 AS STORED (bf16-rounded) over each wave's 32 rows in colpart
  * [emloco_ffn_bwd_colsum_rows(M)][F] floats (16-byte aligned; rows of waves past the last row are zeroed): linear1's bias gradient is
  * their column sum (emloco_colsum over that matrix) -- a read of M / 32 x F floats where the separate pass read the M x F gradient. */

@@ -250,9 +250,16 @@ extern "C" int emu_adamw_gated(int n, float *p, const float *g, float *m, float 
 #include "../../emloco_amd/csrc/ffn_kernels.hip"
 static float *g_ffn_colpart = nullptr;       // optional [ceil(M / 32)][F] column partials of the next backward launch (emu_ffn_set_colpart)
 extern "C" void emu_ffn_set_colpart(float *p) { g_ffn_colpart = p; }
+// the forward's optional residual + LayerNorm epilogue (emloco_ffn_fwd_norm): all NULL = off
+static const float *g_ffn_res = nullptr, *g_ffn_gamma = nullptr, *g_ffn_beta = nullptr;
+static float *g_ffn_xr = nullptr, *g_ffn_mean = nullptr, *g_ffn_rstd = nullptr, g_ffn_eps = 0.0f;
+extern "C" void emu_ffn_set_norm(const float *res, const float *gamma, const float *beta, float eps, float *xr, float *mean, float *rstd) {
+    g_ffn_res = res; g_ffn_gamma = gamma; g_ffn_beta = beta; g_ffn_eps = eps; g_ffn_xr = xr; g_ffn_mean = mean; g_ffn_rstd = rstd;
+}
 extern "C" int emu_ffn_chain(int mode, int M, int F, const float *x, const unsigned short *P, const unsigned short *Q, const float *b1,
                              const float *b2, unsigned short *h, unsigned short *dz1, unsigned *mask, float *out, float drop_p, unsigned seed1, unsigned seed2) {
-    FfnArgs a{M, F, x, P, Q, b1, b2, h, dz1, mask, out, drop_p, 1.0f / (1.0f - drop_p), seed1, (unsigned)(drop_p * 65536.0f), seed2, g_ffn_colpart};
+    FfnArgs a{M, F, x, P, Q, b1, b2, h, dz1, mask, out, drop_p, 1.0f / (1.0f - drop_p), seed1, (unsigned)(drop_p * 65536.0f), seed2, g_ffn_colpart,
+              g_ffn_res, g_ffn_gamma, g_ffn_beta, g_ffn_xr, g_ffn_mean, g_ffn_rstd, g_ffn_eps};
     const unsigned grid = (unsigned)((M + FFN_ROWS - 1) / FFN_ROWS);
     if (mode == 0 && drop_p > 0.0f) emu::launch(grid, FFN_THREADS, [&] { ffn_chain_kernel<0, 1>(a); });
     else if (mode == 0) emu::launch(grid, FFN_THREADS, [&] { ffn_chain_kernel<0, 0>(a); });

@@ -1193,6 +1193,25 @@ def test_chained_feed_forward_kernels():
             f = np.where(k2, f / (1.0 - p), 0.0)
             assert 0.85 < k2.mean() < 0.95
         np.testing.assert_allclose(out, f, rtol=1e-5, atol=2e-5)
+        # (round 6) the same launch with the post-norm layer's tail in its epilogue (emloco_ffn_fwd_norm): xr = f + res, y = LayerNorm(xr)
+        res_ = rng.normal(size=(M, D)).astype(np.float32)
+        gam, bet = (1.0 + 0.1 * rng.normal(size=D)).astype(np.float32), (0.1 * rng.normal(size=D)).astype(np.float32)
+        y_n, xr_n = np.full((M, D), np.nan, np.float32), np.full((M, D), np.nan, np.float32)
+        mean_n, rstd_n = np.full(M, np.nan, np.float32), np.full(M, np.nan, np.float32)
+        h_n, mb_n = np.full((M, F), 0x7fc0, np.uint16), np.full((M, F // 32), 0xdeadbeef, np.uint32)
+        lib.emu_ffn_set_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.emu_ffn_set_norm(P(res_), P(gam), P(bet), C.c_float(1e-5), P(xr_n), P(mean_n), P(rstd_n))
+        lib.emu_ffn_chain(0, M, F, P(x), U16(W1b), U16(W2b), P(b1), P(b2), U16(h_n), None, mb_n.ctypes.data_as(C.POINTER(C.c_uint)), P(y_n),
+                          C.c_float(p), C.c_uint(s1), C.c_uint(s2))
+        lib.emu_ffn_set_norm(None, None, None, C.c_float(0.0), None, None, None)
+        assert np.array_equal(h_n, h) and np.array_equal(mb_n, mbits)                       # the block itself is untouched
+        xr_w = out.astype(np.float64) + res_                                                # `out`: the unfused launch's f
+        np.testing.assert_allclose(xr_n, xr_w, rtol=1e-6, atol=1e-6)
+        mu_w = xr_n.astype(np.float64).mean(1)
+        rs_w = 1.0 / np.sqrt(xr_n.astype(np.float64).var(1) + 1e-5)
+        np.testing.assert_allclose(mean_n, mu_w, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rstd_n, rs_w, rtol=1e-5)
+        np.testing.assert_allclose(y_n, (xr_n - mu_w[:, None]) * rs_w[:, None] * gam + bet, rtol=1e-5, atol=1e-5)
         # input gradient: dz2 stands for the gradient w.r.t. linear2's output; P = W2^T [F][128], Q = W1^T [128][F]
         dz2 = rng.normal(size=(M, D)).astype(np.float32)
         W2T, W1T = np.ascontiguousarray(W2b.T), np.ascontiguousarray(W1b.T)

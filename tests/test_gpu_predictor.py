@@ -542,6 +542,39 @@ def _jta_shaped_batch(B, seed, max_people=4):
     return joints, torch.ones(B, max_people, 21, 49), pad
 
 
+def test_feed_forward_with_residual_and_norm_in_one_launch_equals_the_two_ops(monkeypatch):
+    """Round 6, reduced-precision mode: `ops.feed_forward_norm` (chained feed-forward kernel with the residual add and LayerNorm in its
+    epilogue, `emloco_ffn_fwd_norm`) against `layer_norm(feed_forward(x), res)` -- same seeds, same masks: output and every gradient
+    (both input edges, the block's four parameters, gamma, beta) agree to float rounding of the row statistics (the two paths sum a row
+    in different orders) where no bf16 rounding lies on the way, to 2e-3 of the tensor scale where one does; ragged row count; with and without dropout; forked outputs."""
+    from emloco_amd.predictor import ops
+    dev = "cuda:0"
+    prev = ops._matmul_precision[0]
+    ops.set_matmul_precision("bf16")
+    try:
+        torch.manual_seed(8)
+        M, K, F = 1000 + 37, 128, 256
+        base = [torch.randn(M, K, device=dev), torch.randn(M, K, device=dev), torch.randn(F, K, device=dev) * 0.1, torch.randn(F, device=dev) * 0.1,
+                torch.randn(K, F, device=dev) * 0.1, torch.randn(K, device=dev) * 0.1, 1.0 + 0.1 * torch.randn(K, device=dev), 0.1 * torch.randn(K, device=dev)]
+        gy, gy2 = torch.randn(M, K, device=dev), torch.randn(M, K, device=dev)
+        for p_drop in (0.0, 0.1):
+            res = {}
+            for fused in (True, False):
+                monkeypatch.setattr(ops, "_FFN_NORM", fused)
+                leaves = [t.clone().requires_grad_(True) for t in base]
+                ops._drop_counter[0] = 123
+                y, y2 = ops.feed_forward_norm(*leaves, 1e-5, drop_p=p_drop, fork=True)
+                ((y * gy).sum() + (y2 * gy2).sum()).backward()
+                res[fused] = [y.detach().clone()] + [t.grad.clone() for t in leaves]
+            # (what passes through a bf16 rounding on its way -- dz1 and the operands of the bf16 products -- can flip a rounding on a
+            # last-bit difference of its input: 2^-8 of single elements; the fp32-only quantities agree to float rounding)
+            for a, b, name in zip(res[True], res[False], ["y", "dx", "dres", "dW1", "db1", "dW2", "db2", "dgamma", "dbeta"]):
+                tol = 2e-5 if name in ("y", "dres", "db2", "dgamma", "dbeta") else 2e-3
+                assert torch.isfinite(a).all() and (a - b).abs().max().item() <= tol * b.abs().max().item() + 1e-6, (p_drop, name, (a - b).abs().max().item())
+    finally:
+        ops.set_matmul_precision(prev)
+
+
 def test_gradients_gathered_into_the_flat_bucket_equal_autograds_accumulation():
     """Round 6: the train step releases every parameter's .grad ahead of the backward pass and gathers the gradients autograd leaves on
     the parameters into the optimiser's flat bucket with one launch per 96 tensors (`emloco_gather_flat`, dist.FlatGradBucket.release /
